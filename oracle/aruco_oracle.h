@@ -1,0 +1,130 @@
+/*
+ * aruco_oracle.h -- CPU restatement of the reference's aruco hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * This is the parity oracle for fiducials_amd.  Only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg may load it; the product library (fiducials_amd/lib/libfid_amd.so)
+ * never links, loads or calls it.
+ *
+ * What it restates: the arithmetic behind
+ *     aruco::detectMarkers(...)       /root/reference/aruco_detect/src/aruco_detect.cpp:350
+ *     cv::solvePnP(...)               aruco_detect.cpp:247   (SOLVEPNP_ITERATIVE, the default)
+ *     cv::projectPoints(...)          aruco_detect.cpp:210
+ * with the node's effective parameters (aruco_detect.cpp:690-727).  That arithmetic lives in
+ * OpenCV 4.2.0 + opencv_contrib aruco (the version the reference's CI builds against,
+ * .github/workflows/.ros-noetic.yml:19-27), which is NOT vendored in the reference and is not
+ * installed here; the algorithm is therefore restated from the published 4.2.0 sources
+ * (modules/aruco/src/{aruco,dictionary}.cpp, modules/imgproc/src/{thresh,box_filter,contours,
+ * approx,convhull,imgwarp,cornersubpix,samplers,geometry}.cpp, modules/calib3d/src/
+ * {solvepnp,calibration,fundam,undistort,compat_ptsetreg}.cpp) and pinned against the reference's
+ * own golden vectors (aruco_detect/test/aruco_images_test.cpp:96-147,
+ * fiducial_slam/test/auto_init_403_test.cpp:129-137, aruco_transforms.bag) -- see
+ * tests/test_oracle_golden.py for how close it lands.
+ */
+#ifndef ARUCO_ORACLE_H
+#define ARUCO_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* aruco::DetectorParameters fields the node sets (aruco_detect.cpp:690-727) */
+typedef struct ora_params {
+    double adaptiveThreshConstant;            /* 7    :690 */
+    int    adaptiveThreshWinSizeMin;          /* 3    :692 */
+    int    adaptiveThreshWinSizeMax;          /* 53   :691 */
+    int    adaptiveThreshWinSizeStep;         /* 4    :693 */
+    int    cornerRefinementMethod;            /* 1 = SUBPIX (:700-714), 0 = NONE */
+    int    cornerRefinementWinSize;           /* 5    :696 */
+    int    cornerRefinementMaxIterations;     /* 30   :694 */
+    double cornerRefinementMinAccuracy;       /* 0.01 :695 */
+    double errorCorrectionRate;               /* 0.6  :716 */
+    double minCornerDistanceRate;             /* 0.05 :717 */
+    int    markerBorderBits;                  /* 1    :718 */
+    double maxErroneousBitsInBorderRate;      /* 0.04 :719 */
+    int    minDistanceToBorder;               /* 3    :720 */
+    double minMarkerDistanceRate;             /* 0.05 :721 */
+    double minMarkerPerimeterRate;            /* 0.1  :722 */
+    double maxMarkerPerimeterRate;            /* 4.0  :723 */
+    double minOtsuStdDev;                     /* 5.0  :724 */
+    double perspectiveRemoveIgnoredMarginPerCell; /* 0.13 :725 */
+    int    perspectiveRemovePixelPerCell;     /* 8    :726 */
+    double polygonalApproxAccuracyRate;       /* 0.01 :727 */
+} ora_params;
+
+/* aruco::Dictionary: bytesList is nMarkers x (4 rotations x nbytes), rotation-major (OpenCV 4.x) */
+typedef struct ora_dict {
+    int marker_size;
+    int max_correction_bits;
+    int n_markers;
+    const uint8_t *bytes;
+} ora_dict;
+
+typedef struct ora_marker {
+    int32_t id;
+    float   corners[8];   /* x0,y0 .. x3,y3 : TL,TR,BR,BL of the canonical marker */
+} ora_marker;
+
+/* one quad candidate as it leaves _findMarkerContours (before reorder / too-close filter) */
+typedef struct ora_candidate {
+    int32_t scale;        /* index of the threshold window */
+    int32_t contour_size; /* contours[i].size() */
+    int32_t start_x, start_y; /* first point of the contour (Suzuki start pixel) */
+    int32_t is_hole;
+    float   corners[8];
+} ora_candidate;
+
+/* optional stage trace (any pointer may be NULL) */
+typedef struct ora_trace {
+    ora_candidate *initial;  int cap_initial;  int n_initial;   /* all scales, detection order */
+    ora_candidate *filtered; int cap_filtered; int n_filtered;  /* after reorder + too-close    */
+    uint8_t *bits;           /* n_filtered x (ms+2)^2 bytes (0/1); caller sizes it cap_filtered*81 */
+    int32_t *ident;          /* n_filtered x 2: id (-1 rejected), rotation                        */
+    ora_marker *presubpix;   int cap_pre; int n_pre;            /* after _filterDetectedMarkers  */
+} ora_trace;
+
+void ora_default_params(ora_params *p);
+
+/* a2: cv_bridge toCvCopy(BGR8) + cvtColor(BGR2GRAY).  enc: 0 mono8, 1 bgr8, 2 rgb8 */
+int ora_to_gray(const uint8_t *img, int w, int h, int stride, int enc, uint8_t *gray /* w*h */);
+
+/* a3: adaptiveThreshold(MEAN_C, BINARY_INV, win, C) -> 0/255 */
+int ora_adaptive_threshold(const uint8_t *gray, int w, int h, int win, double C, uint8_t *out);
+
+/* a4 first half: findContours(RETR_LIST, CHAIN_APPROX_NONE).  Contours are returned in OpenCV's
+ * output order (reverse discovery).  pts: x,y pairs.  offsets[n+1].  Returns 0, or -1 on overflow. */
+int ora_find_contours(const uint8_t *mask, int w, int h, int32_t *pts, int64_t cap_pts,
+                      int64_t *offsets, int32_t *is_hole, int cap_contours, int *n_contours);
+
+/* approxPolyDP(closed) on integer points; returns number of output points (<= cap) or -1 */
+int ora_approx_poly_dp(const int32_t *pts, int n, double eps, int32_t *out, int cap);
+
+/* full a3..a9 */
+int ora_detect(const uint8_t *gray, int w, int h, const ora_params *p, const ora_dict *d,
+               ora_marker *out, int cap, int *n, ora_trace *trace);
+
+/* a9 alone: cornerSubPix on n points */
+int ora_corner_subpix(const uint8_t *gray, int w, int h, float *pts, int n, int win, int max_iter,
+                      double eps);
+
+/* a6/a7 alone on one candidate: returns id or -1; bits (ms+2)^2; rotation */
+int ora_identify(const uint8_t *gray, int w, int h, const ora_params *p, const ora_dict *d,
+                 const float corners[8], uint8_t *bits, int *rotation);
+
+/* a11/a12: solvePnP(ITERATIVE) for one square marker + reprojection error (mean squared, px^2) */
+int ora_solve_pnp_square(const double K[9], const double D[5], const float corners[8],
+                         double marker_len, double rvec[3], double tvec[3], double *reproj_err);
+/* generic n-point planar/non-planar ITERATIVE PnP (used for the 5-point STag pose, s10) */
+int ora_solve_pnp(const double K[9], const double D[5], const float *obj3 /* n*3 */,
+                  const float *img2 /* n*2 */, int n, double rvec[3], double tvec[3]);
+int ora_project_points(const double K[9], const double D[5], const double rvec[3],
+                       const double tvec[3], const float *obj3, int n, double *img2);
+
+/* a13 */
+double ora_fiducial_area(const float corners[8]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

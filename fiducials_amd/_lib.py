@@ -1,0 +1,124 @@
+"""ctypes binding of the C-ABI (include/fid_abi.h).  Loading fails loudly if the HIP library is missing:
+there is no CPU fallback in this package."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from . import build as _build
+
+
+class FidParams(C.Structure):
+    _fields_ = [
+        ("adaptiveThreshConstant", C.c_double),
+        ("adaptiveThreshWinSizeMin", C.c_int32),
+        ("adaptiveThreshWinSizeMax", C.c_int32),
+        ("adaptiveThreshWinSizeStep", C.c_int32),
+        ("cornerRefinementMethod", C.c_int32),
+        ("cornerRefinementWinSize", C.c_int32),
+        ("cornerRefinementMaxIterations", C.c_int32),
+        ("cornerRefinementMinAccuracy", C.c_double),
+        ("errorCorrectionRate", C.c_double),
+        ("minCornerDistanceRate", C.c_double),
+        ("markerBorderBits", C.c_int32),
+        ("minDistanceToBorder", C.c_int32),
+        ("maxErroneousBitsInBorderRate", C.c_double),
+        ("minMarkerDistanceRate", C.c_double),
+        ("minMarkerPerimeterRate", C.c_double),
+        ("maxMarkerPerimeterRate", C.c_double),
+        ("minOtsuStdDev", C.c_double),
+        ("perspectiveRemoveIgnoredMarginPerCell", C.c_double),
+        ("perspectiveRemovePixelPerCell", C.c_int32),
+        ("reserved0", C.c_int32),
+        ("polygonalApproxAccuracyRate", C.c_double),
+    ]
+
+
+class FidDict(C.Structure):
+    _fields_ = [("marker_size", C.c_int32), ("max_correction_bits", C.c_int32), ("n_markers", C.c_int32),
+                ("reserved0", C.c_int32), ("bytes", C.c_void_p)]
+
+
+class FidMarker(C.Structure):
+    _fields_ = [("id", C.c_int32), ("corners", C.c_float * 8)]
+
+
+class FidPoseOut(C.Structure):
+    _fields_ = [("rvec", C.c_double * 3), ("tvec", C.c_double * 3), ("image_error", C.c_double),
+                ("object_error", C.c_double), ("fiducial_area", C.c_double)]
+
+
+class FidLimits(C.Structure):
+    _fields_ = [("max_width", C.c_int32), ("max_height", C.c_int32), ("max_batch", C.c_int32),
+                ("max_starts_per_frame", C.c_int32), ("max_contours_per_frame", C.c_int32),
+                ("max_candidates_per_frame", C.c_int32), ("max_markers_per_frame", C.c_int32),
+                ("reserved0", C.c_int32)]
+
+
+class FidCandidate(C.Structure):
+    _fields_ = [("scale", C.c_int32), ("contour_size", C.c_int32), ("start_x", C.c_int32), ("start_y", C.c_int32),
+                ("is_hole", C.c_int32), ("corners", C.c_float * 8)]
+
+
+FID_OK = 0
+FID_E_INVALID_ARG, FID_E_NO_DEVICE, FID_E_HIP, FID_E_CAPACITY, FID_E_OUT_OF_MEMORY, FID_E_UNSUPPORTED = 1, 2, 3, 4, 5, 6
+ENC = {"mono8": 0, "bgr8": 1, "rgb8": 2}
+TAP_MASKS, TAP_CANDIDATES, TAP_FILTERED, TAP_BITS, TAP_IDENT, TAP_PRESUBPIX, TAP_COUNTS, TAP_GRAY = range(8)
+
+# every symbol include/fid_abi.h declares
+SYMBOLS = [
+    "fid_default_params", "fid_default_limits", "fid_create", "fid_destroy", "fid_set_params", "fid_detect",
+    "fid_detect_batch", "fid_detect_device", "fid_pose", "fid_pose_last", "fid_tap_bytes", "fid_tap_read",
+    "fid_last_stage_ms", "fid_stream", "fid_strerror", "fid_last_error", "fid_abi_version",
+]
+
+_LIB = None
+
+
+class FidError(RuntimeError):
+    def __init__(self, status: int, msg: str):
+        super().__init__(f"fid status {status}: {msg}")
+        self.status = status
+
+
+def lib_path() -> str:
+    return _build.LIB
+
+
+def load():
+    """Load libfid_amd.so.  Raises if it has not been built (run `python -m fiducials_amd.build` or
+    __graft_entry__.build()); never substitutes another implementation."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not os.path.exists(path):
+        raise FidError(FID_E_NO_DEVICE, f"{path} is missing: build the HIP library first (fiducials_amd.build.build())")
+    L = C.CDLL(path)
+    vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
+    L.fid_default_params.argtypes = [C.POINTER(FidParams)]
+    L.fid_default_limits.argtypes = [C.POINTER(FidLimits)]
+    L.fid_create.argtypes = [C.POINTER(FidParams), C.POINTER(FidDict), C.POINTER(FidLimits), C.c_int, C.POINTER(vp)]
+    L.fid_destroy.argtypes = [vp]
+    L.fid_destroy.restype = None
+    L.fid_set_params.argtypes = [vp, C.POINTER(FidParams)]
+    L.fid_detect.argtypes = [vp, vp, i32, i32, i32, C.c_int, C.POINTER(FidMarker), i32, C.POINTER(i32)]
+    L.fid_detect_batch.argtypes = [vp, vp, i32, i32, i32, i32, i64, C.c_int, C.POINTER(FidMarker), i32, C.POINTER(i32)]
+    L.fid_detect_device.argtypes = [vp, vp, i32, i32, i32, i32, i64, C.c_int, C.POINTER(FidMarker), i32, C.POINTER(i32)]
+    L.fid_pose.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(FidMarker), C.POINTER(C.c_double),
+                           i32, C.c_double, C.POINTER(FidPoseOut)]
+    L.fid_pose_last.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double, C.POINTER(FidPoseOut), i32]
+    L.fid_tap_bytes.argtypes = [vp, C.c_int]
+    L.fid_tap_bytes.restype = i64
+    L.fid_tap_read.argtypes = [vp, C.c_int, vp, i64]
+    L.fid_last_stage_ms.argtypes = [vp, C.POINTER(C.c_float), i32, C.POINTER(C.POINTER(C.c_char_p))]
+    L.fid_last_stage_ms.restype = i32
+    L.fid_stream.argtypes = [vp]
+    L.fid_stream.restype = vp
+    L.fid_strerror.argtypes = [C.c_int]
+    L.fid_strerror.restype = C.c_char_p
+    L.fid_last_error.argtypes = [vp]
+    L.fid_last_error.restype = C.c_char_p
+    L.fid_abi_version.restype = i32
+    _LIB = L
+    return L

@@ -1,0 +1,746 @@
+// fid_api.hip -- the C-ABI of libfid_amd.so (include/fid_abi.h): context, buffers in HBM, the launch
+// sequence of the detection pipeline on one HIP stream, result hand-back.  No CPU fallback: without a
+// HIP device fid_create fails with FID_E_NO_DEVICE.
+#include "fid_kernels.hip"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <new>
+#include <string>
+#include <vector>
+
+namespace {
+
+enum { ST_GRAY = 0, ST_THRESH, ST_STARTS, ST_WALK, ST_APPROX, ST_SORT, ST_NEAR, ST_RESOLVE, ST_IDENT, ST_FILTER, ST_SUBPIX, ST_POSE, ST_COUNT };
+const char *const kStageNames[ST_COUNT] = {"to_gray", "threshold", "find_starts", "walk_count", "approx", "sort_cands",
+                                           "near", "resolve", "identify", "filter_markers", "subpix", "pose"};
+
+constexpr int TX = 128, TY = 32, NT = 256;
+
+}  // namespace
+
+struct fid_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    fid_params params;
+    fid_limits lim;
+    DevParams P;
+    std::vector<uint8_t> dict_host;
+    int dict_ms = 0, dict_maxc = 0, dict_n = 0;
+    // device buffers
+    uint8_t *d_in = nullptr;
+    size_t d_in_bytes = 0;
+    uint8_t *d_gray = nullptr;
+    uint32_t *d_masks = nullptr;
+    size_t masks_bytes = 0;
+    int masks_W = 0, masks_H = 0, masks_S = 0;
+    uint2 *d_starts = nullptr;
+    uint4 *d_contours = nullptr;
+    DevCand *d_cands = nullptr, *d_sorted = nullptr, *d_filtered = nullptr;
+    uint32_t *d_near = nullptr;
+    DevIdent *d_ident = nullptr;
+    fid_marker *d_pre = nullptr, *d_markers = nullptr;
+    fid_pose_out *d_poses = nullptr;
+    DevCounts *d_counts = nullptr;
+    DevGlobal *d_global = nullptr;
+    unsigned *d_worklist = nullptr, *d_nwork = nullptr;
+    uint8_t *d_dict = nullptr;
+    float *d_subpix_mask = nullptr;
+    double *d_lens = nullptr;
+    fid_marker *d_pose_in = nullptr;
+    int *d_pose_n = nullptr;
+    int pose_cap = 0;
+    // pinned host staging
+    fid_marker *h_markers = nullptr;
+    DevCounts *h_counts = nullptr;
+    DevGlobal *h_global = nullptr;
+    fid_pose_out *h_poses = nullptr;
+    // last call
+    int last_frames = 0, last_W = 0, last_H = 0;
+    const uint8_t *last_gray = nullptr;
+    long long last_gfstride = 0;
+    bool profile = false;
+    hipEvent_t ev[ST_COUNT + 1] = {};
+    bool ev_valid[ST_COUNT + 1] = {};
+    float stage_ms[ST_COUNT] = {};
+    std::string last_error;
+};
+
+namespace {
+
+#define HIPCHK(ctx, expr)                                                                         \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess) {                                                                   \
+            (ctx)->last_error = std::string(#expr) + ": " + hipGetErrorString(e_);                \
+            return e_ == hipErrorOutOfMemory ? FID_E_OUT_OF_MEMORY : FID_E_HIP;                   \
+        }                                                                                         \
+    } while (0)
+
+template <typename T>
+fid_status dalloc(fid_ctx *c, T **p, size_t count)
+{
+    HIPCHK(c, hipMalloc((void **)p, count * sizeof(T)));
+    return FID_OK;
+}
+
+int roundup(int v, int m) { return (v + m - 1) / m * m; }
+
+fid_status apply_params(fid_ctx *c, const fid_params *p)
+{
+    if (p->adaptiveThreshWinSizeMin < 3 || p->adaptiveThreshWinSizeMax < p->adaptiveThreshWinSizeMin ||
+        p->adaptiveThreshWinSizeStep <= 0)
+        return FID_E_INVALID_ARG;
+    if (!(p->minMarkerPerimeterRate > 0 && p->maxMarkerPerimeterRate > 0 && p->polygonalApproxAccuracyRate > 0 &&
+          p->minCornerDistanceRate >= 0 && p->minDistanceToBorder >= 0 && p->minMarkerDistanceRate >= 0))
+        return FID_E_INVALID_ARG;  // the CV_Assert set of _findMarkerContours / _filterTooCloseCandidates
+    if (p->markerBorderBits <= 0) return FID_E_INVALID_ARG;
+    int nsc = (p->adaptiveThreshWinSizeMax - p->adaptiveThreshWinSizeMin) / p->adaptiveThreshWinSizeStep + 1;
+    if (nsc > FID_MAX_SCALES) return FID_E_UNSUPPORTED;
+    DevParams &P = c->P;
+    P.nscales = nsc;
+    P.rmax = 0;
+    for (int i = 0; i < nsc; i++) {
+        int w = p->adaptiveThreshWinSizeMin + i * p->adaptiveThreshWinSizeStep;
+        if (w % 2 == 0) w++;
+        P.win[i] = w;
+        if (w / 2 > P.rmax) P.rmax = w / 2;
+    }
+    if (P.rmax > 40) return FID_E_UNSUPPORTED;  // LDS tile budget of k_threshold
+    {
+        double cdelta = p->adaptiveThreshConstant;
+        int i = (int)cdelta;
+        P.idelta = i + (i < cdelta);  // cvCeil
+    }
+    P.polyAcc = p->polygonalApproxAccuracyRate;
+    P.minCornerDistRate = p->minCornerDistanceRate;
+    P.minMarkerDistRate = p->minMarkerDistanceRate;
+    P.minDistToBorder = p->minDistanceToBorder;
+    P.markerSize = c->dict_ms;
+    P.borderBits = p->markerBorderBits;
+    P.cellSize = p->perspectiveRemovePixelPerCell;
+    P.cellMargin = (int)(p->perspectiveRemoveIgnoredMarginPerCell * p->perspectiveRemovePixelPerCell);
+    if (P.markerSize + 2 * P.borderBits > FID_MAX_CELLS) return FID_E_UNSUPPORTED;
+    if (P.cellSize < 1 || P.cellSize - 2 * P.cellMargin < 1 || (P.markerSize + 2 * P.borderBits) * P.cellSize > 160) return FID_E_UNSUPPORTED;
+    P.minOtsuStdDev = p->minOtsuStdDev;
+    P.maxBorderErr = (int)(c->dict_ms * c->dict_ms * p->maxErroneousBitsInBorderRate);
+    P.maxCorr = (int)((double)c->dict_maxc * p->errorCorrectionRate);
+    P.nMarkers = c->dict_n;
+    P.nbytes = (c->dict_ms * c->dict_ms + 7) / 8;
+    P.refine = p->cornerRefinementMethod == 1;
+    if (p->cornerRefinementMethod != 0 && p->cornerRefinementMethod != 1) return FID_E_UNSUPPORTED;
+    P.subpixWin = p->cornerRefinementWinSize;
+    if (P.refine && (P.subpixWin < 1 || P.subpixWin > SP_MAXWIN || p->cornerRefinementMaxIterations < 1 ||
+                     !(p->cornerRefinementMinAccuracy > 0)))
+        return FID_E_INVALID_ARG;
+    {
+        int mi = p->cornerRefinementMaxIterations;
+        P.subpixMaxIter = mi < 1 ? 1 : (mi > 100 ? 100 : mi);
+        double e = p->cornerRefinementMinAccuracy > 0 ? p->cornerRefinementMinAccuracy : 0.;
+        P.subpixEps = e * e;
+    }
+    c->params = *p;
+    // cornerSubPix weight mask, computed once on the host exactly as cornersubpix.cpp does (float expf)
+    if (P.refine) {
+        int win = P.subpixWin, ww = 2 * win + 1;
+        std::vector<float> mask((size_t)ww * ww);
+        for (int i = 0; i < ww; i++) {
+            float y = (float)(i - win) / win;
+            float vy = expf(-y * y);
+            for (int j = 0; j < ww; j++) {
+                float x = (float)(j - win) / win;
+                mask[(size_t)i * ww + j] = (float)(vy * expf(-x * x));
+            }
+        }
+        HIPCHK(c, hipMemcpy(c->d_subpix_mask, mask.data(), mask.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+    return FID_OK;
+}
+
+void set_geometry(fid_ctx *c, int W, int H, int gstride, int F)
+{
+    DevParams &P = c->P;
+    P.W = W;
+    P.H = H;
+    P.gstride = gstride;
+    P.WW = (W + 31) / 32;
+    P.WWP = MASK_PADW + roundup(roundup(W, TX) / 32, 4) + 4;
+    P.nframes = F;
+    int maxdim = W > H ? W : H;
+    P.minPerim = (int)(unsigned int)(c->params.minMarkerPerimeterRate * maxdim);
+    P.maxPerim = (int)(unsigned int)(c->params.maxMarkerPerimeterRate * maxdim);
+    P.maxStarts = c->lim.max_starts_per_frame;
+    P.maxContours = c->lim.max_contours_per_frame;
+    P.maxCands = c->lim.max_candidates_per_frame;
+    P.maxMarkers = c->lim.max_markers_per_frame;
+}
+
+size_t masks_elems(const fid_ctx *c, int W, int H, int F)
+{
+    int WWP = MASK_PADW + roundup(roundup(W, TX) / 32, 4) + 4;
+    return (size_t)F * c->P.nscales * (H + 2) * WWP;
+}
+
+void mark(fid_ctx *c, int idx)
+{
+    if (c->profile) {
+        (void)hipEventRecord(c->ev[idx], c->stream);
+        c->ev_valid[idx] = true;
+    }
+}
+
+// the whole detection pipeline for F frames whose gray images are resident at d_gray
+fid_status run_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H, int stride, long long fstride, fid_encoding enc,
+                      fid_marker *out, int cap_per_frame, int *n_per_frame)
+{
+    if (!out || !n_per_frame || cap_per_frame < 0) return FID_E_INVALID_ARG;
+    if (F < 1 || F > c->lim.max_batch || W < 8 || H < 8 || W > c->lim.max_width || H > c->lim.max_height || W > 65535 || H > 65535)
+        return FID_E_INVALID_ARG;
+    if (enc != FID_ENC_MONO8 && enc != FID_ENC_BGR8 && enc != FID_ENC_RGB8) return FID_E_INVALID_ARG;
+    int bpp = enc == FID_ENC_MONO8 ? 1 : 3;
+    if (stride < W * bpp) return FID_E_INVALID_ARG;
+    if ((unsigned)(c->params.maxMarkerPerimeterRate * (W > H ? W : H)) > 60000u) return FID_E_UNSUPPORTED;  // contour points live in LDS
+    hipStream_t st = c->stream;
+    for (int i = 0; i <= ST_COUNT; i++) c->ev_valid[i] = false;
+    mark(c, 0);
+    // ---- K0: gray
+    const uint8_t *gray;
+    long long gfstride;
+    int gstride;
+    if (enc == FID_ENC_MONO8 && true) {
+        // use the caller's buffer in place (any stride)
+        gray = d_src;
+        gstride = stride;
+        gfstride = fstride;
+    } else {
+        int blocks = 2048;
+        hipLaunchKernelGGL(k_to_gray, dim3(blocks), dim3(256), 0, st, d_src, stride, fstride, (int)enc, c->d_gray, W, H, F);
+        gray = c->d_gray;
+        gstride = W;
+        gfstride = (long long)W * H;
+    }
+    set_geometry(c, W, H, gstride, F);
+    const DevParams &P = c->P;
+    mark(c, ST_GRAY + 1);
+    // masks pad words must be zero; re-zero when the layout changes
+    if (c->masks_W != W || c->masks_H != H || c->masks_S != P.nscales) {
+        HIPCHK(c, hipMemsetAsync(c->d_masks, 0, c->masks_bytes, st));
+        c->masks_W = W;
+        c->masks_H = H;
+        c->masks_S = P.nscales;
+    }
+    HIPCHK(c, hipMemsetAsync(c->d_counts, 0, sizeof(DevCounts) * F, st));
+    HIPCHK(c, hipMemsetAsync(c->d_global, 0, sizeof(DevGlobal), st));
+    HIPCHK(c, hipMemsetAsync(c->d_nwork, 0, sizeof(unsigned), st));
+    // ---- K1
+    {
+        int R = P.rmax, RW = TX + 2 * R, RH = TY + 2 * R, PT = (RW + 1) | 1;
+        size_t lds = (size_t)(RH + 1) * PT * sizeof(uint32_t);
+        dim3 grid((W + TX - 1) / TX, (H + TY - 1) / TY, F);
+        hipLaunchKernelGGL((k_threshold<TX, TY, NT>), grid, dim3(NT), lds, st, gray, gfstride, c->d_masks, P);
+    }
+    mark(c, ST_THRESH + 1);
+    // ---- K2
+    {
+        long long words = (long long)F * P.nscales * H * P.WW;
+        long long blocks = (words + 255) / 256;
+        if (blocks > 256 * 16) blocks = 256 * 16;
+        hipLaunchKernelGGL(k_find_starts, dim3((unsigned)blocks), dim3(256), 0, st, c->d_masks, c->d_starts, c->d_global, P);
+    }
+    mark(c, ST_STARTS + 1);
+    // ---- K3
+    hipLaunchKernelGGL(k_walk_count, dim3(256 * 8), dim3(256), 0, st, c->d_masks, c->d_starts, c->d_contours, c->d_global, P);
+    mark(c, ST_WALK + 1);
+    // ---- K4
+    {
+        size_t lds = (size_t)(P.maxPerim + 1) * sizeof(uint32_t);
+        hipLaunchKernelGGL(k_approx, dim3(256 * 8), dim3(64), lds, st, c->d_masks, c->d_contours, c->d_cands, c->d_counts,
+                           c->d_global, P);
+    }
+    mark(c, ST_APPROX + 1);
+    // ---- K5
+    hipLaunchKernelGGL(k_sort_cands, dim3(F), dim3(256), (size_t)P.maxCands * 8, st, c->d_cands, c->d_sorted, c->d_counts, P);
+    mark(c, ST_SORT + 1);
+    hipLaunchKernelGGL(k_near, dim3(32, F), dim3(256), 0, st, c->d_sorted, c->d_near, c->d_counts, P);
+    mark(c, ST_NEAR + 1);
+    hipLaunchKernelGGL(k_resolve, dim3(F), dim3(64), (size_t)P.maxCands * 4, st, c->d_sorted, c->d_near, c->d_filtered,
+                       c->d_counts, c->d_worklist, c->d_nwork, P);
+    mark(c, ST_RESOLVE + 1);
+    // ---- K6
+    {
+        int SZ = (P.markerSize + 2 * P.borderBits) * P.cellSize;
+        hipLaunchKernelGGL(k_identify, dim3(256 * 4), dim3(64), (size_t)SZ * SZ, st, gray, gfstride, c->d_filtered,
+                           c->d_worklist, c->d_nwork, c->d_dict, c->d_ident, P);
+    }
+    mark(c, ST_IDENT + 1);
+    // ---- K7
+    hipLaunchKernelGGL(k_filter_markers, dim3(F), dim3(64), (size_t)P.maxCands * sizeof(fid_marker), st, c->d_filtered,
+                       c->d_ident, c->d_pre, c->d_counts, P);
+    mark(c, ST_FILTER + 1);
+    {
+        long long items = (long long)F * P.maxMarkers * 4;
+        int blocks = (int)(items < 256 * 16 ? items : 256 * 16);
+        hipLaunchKernelGGL(k_subpix, dim3(blocks), dim3(64), 0, st, gray, gfstride, c->d_pre, c->d_markers, c->d_counts,
+                           c->d_subpix_mask, P);
+    }
+    mark(c, ST_SUBPIX + 1);
+    HIPCHK(c, hipGetLastError());
+    // ---- results
+    HIPCHK(c, hipMemcpyAsync(c->h_counts, c->d_counts, sizeof(DevCounts) * F, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(c->h_global, c->d_global, sizeof(DevGlobal), hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(c->h_markers, c->d_markers, sizeof(fid_marker) * (size_t)F * P.maxMarkers, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    c->last_frames = F;
+    c->last_W = W;
+    c->last_H = H;
+    c->last_gray = gray;
+    c->last_gfstride = gfstride;
+    if (c->profile) {
+        for (int i = 0; i < ST_COUNT; i++) {
+            c->stage_ms[i] = 0.f;
+            // elapsed from the previous valid event
+            int prev = i;
+            while (prev > 0 && !c->ev_valid[prev]) prev--;
+            if (c->ev_valid[i + 1] && c->ev_valid[prev]) (void)hipEventElapsedTime(&c->stage_ms[i], c->ev[prev], c->ev[i + 1]);
+        }
+    }
+    fid_status rc = FID_OK;
+    if (c->h_global->overflow) {
+        c->last_error = "internal capacity exceeded (starts/contours/stack): raise fid_limits";
+        rc = FID_E_CAPACITY;
+    }
+    for (int f = 0; f < F; f++) {
+        int n = c->h_counts[f].nmark;
+        if (c->h_counts[f].overflow) {
+            c->last_error = "per-frame candidate/marker capacity exceeded: raise fid_limits";
+            rc = FID_E_CAPACITY;
+        }
+        if (n > cap_per_frame) {
+            n = cap_per_frame;
+            c->last_error = "caller marker capacity too small";
+            rc = FID_E_CAPACITY;
+        }
+        n_per_frame[f] = n;
+        memcpy(out + (size_t)f * cap_per_frame, c->h_markers + (size_t)f * P.maxMarkers, sizeof(fid_marker) * n);
+    }
+    return rc;
+}
+
+}  // namespace
+
+extern "C" {
+
+void fid_default_params(fid_params *p)
+{
+    if (!p) return;
+    memset(p, 0, sizeof(*p));
+    // node defaults: aruco_detect.cpp:690-727
+    p->adaptiveThreshConstant = 7;
+    p->adaptiveThreshWinSizeMin = 3;
+    p->adaptiveThreshWinSizeMax = 53;
+    p->adaptiveThreshWinSizeStep = 4;
+    p->cornerRefinementMethod = 1;
+    p->cornerRefinementWinSize = 5;
+    p->cornerRefinementMaxIterations = 30;
+    p->cornerRefinementMinAccuracy = 0.01;
+    p->errorCorrectionRate = 0.6;
+    p->minCornerDistanceRate = 0.05;
+    p->markerBorderBits = 1;
+    p->minDistanceToBorder = 3;
+    p->maxErroneousBitsInBorderRate = 0.04;
+    p->minMarkerDistanceRate = 0.05;
+    p->minMarkerPerimeterRate = 0.1;
+    p->maxMarkerPerimeterRate = 4.0;
+    p->minOtsuStdDev = 5.0;
+    p->perspectiveRemoveIgnoredMarginPerCell = 0.13;
+    p->perspectiveRemovePixelPerCell = 8;
+    p->polygonalApproxAccuracyRate = 0.01;
+}
+
+void fid_default_limits(fid_limits *l)
+{
+    if (!l) return;
+    memset(l, 0, sizeof(*l));
+    l->max_width = 1920;
+    l->max_height = 1080;
+    l->max_batch = 1;
+    l->max_starts_per_frame = 262144;
+    l->max_contours_per_frame = 16384;
+    l->max_candidates_per_frame = 2048;
+    l->max_markers_per_frame = 256;
+}
+
+fid_status fid_create(const fid_params *params, const fid_dict *dict, const fid_limits *limits, int device, fid_ctx **out)
+{
+    if (!params || !dict || !out || !dict->bytes || dict->n_markers <= 0 || dict->marker_size < 3 || dict->marker_size > 7)
+        return FID_E_INVALID_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return FID_E_NO_DEVICE;
+    if (device < 0 || device >= ndev) return FID_E_INVALID_ARG;
+    fid_ctx *c = new (std::nothrow) fid_ctx();
+    if (!c) return FID_E_OUT_OF_MEMORY;
+    c->device = device;
+    fid_limits L;
+    fid_default_limits(&L);
+    if (limits) {
+        if (limits->max_width > 0) L.max_width = limits->max_width;
+        if (limits->max_height > 0) L.max_height = limits->max_height;
+        if (limits->max_batch > 0) L.max_batch = limits->max_batch;
+        if (limits->max_starts_per_frame > 0) L.max_starts_per_frame = limits->max_starts_per_frame;
+        if (limits->max_contours_per_frame > 0) L.max_contours_per_frame = limits->max_contours_per_frame;
+        if (limits->max_candidates_per_frame > 0) L.max_candidates_per_frame = limits->max_candidates_per_frame;
+        if (limits->max_markers_per_frame > 0) L.max_markers_per_frame = limits->max_markers_per_frame;
+    }
+    L.max_candidates_per_frame = roundup(L.max_candidates_per_frame, 32);
+    if (L.max_candidates_per_frame > 4096 || L.max_batch > 65535 || L.max_markers_per_frame > L.max_candidates_per_frame) {
+        delete c;
+        return FID_E_INVALID_ARG;
+    }
+    c->lim = L;
+    c->dict_ms = dict->marker_size;
+    c->dict_maxc = dict->max_correction_bits;
+    c->dict_n = dict->n_markers;
+    size_t dbytes = (size_t)dict->n_markers * 4 * ((dict->marker_size * dict->marker_size + 7) / 8);
+    c->dict_host.assign(dict->bytes, dict->bytes + dbytes);
+    c->profile = getenv("FID_PROFILE") && atoi(getenv("FID_PROFILE")) != 0;
+    memset(&c->P, 0, sizeof(c->P));
+
+    fid_status rc = FID_OK;
+    auto fail = [&](fid_status s) {
+        fid_destroy(c);
+        return s;
+    };
+#define TRY(expr)                         \
+    do {                                  \
+        rc = (expr);                      \
+        if (rc != FID_OK) return fail(rc); \
+    } while (0)
+#define TRYHIP(expr)                                   \
+    do {                                               \
+        hipError_t e_ = (expr);                        \
+        if (e_ != hipSuccess) {                        \
+            fprintf(stderr, "fid_create: %s: %s\n", #expr, hipGetErrorString(e_)); \
+            return fail(e_ == hipErrorOutOfMemory ? FID_E_OUT_OF_MEMORY : FID_E_HIP); \
+        }                                              \
+    } while (0)
+    TRYHIP(hipSetDevice(device));
+    TRYHIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    for (int i = 0; i <= ST_COUNT; i++) TRYHIP(hipEventCreate(&c->ev[i]));
+    const size_t F = L.max_batch, MC = L.max_candidates_per_frame, MM = L.max_markers_per_frame;
+    TRY(dalloc(c, &c->d_subpix_mask, (size_t)(2 * SP_MAXWIN + 1) * (2 * SP_MAXWIN + 1)));
+    TRY(dalloc(c, &c->d_dict, dbytes));
+    TRYHIP(hipMemcpy(c->d_dict, c->dict_host.data(), dbytes, hipMemcpyHostToDevice));
+    rc = apply_params(c, params);
+    if (rc != FID_OK) return fail(rc);
+    TRY(dalloc(c, &c->d_gray, F * L.max_width * L.max_height));
+    c->masks_bytes = masks_elems(c, L.max_width, L.max_height, (int)F) * sizeof(uint32_t);
+    // a narrower image can need a larger padded pitch only through rounding; keep a margin
+    c->masks_bytes += (size_t)F * c->P.nscales * (L.max_height + 2) * 16 * sizeof(uint32_t);
+    TRYHIP(hipMalloc((void **)&c->d_masks, c->masks_bytes));
+    TRY(dalloc(c, &c->d_starts, F * L.max_starts_per_frame));
+    TRY(dalloc(c, &c->d_contours, F * L.max_contours_per_frame));
+    TRY(dalloc(c, &c->d_cands, F * MC));
+    TRY(dalloc(c, &c->d_sorted, F * MC));
+    TRY(dalloc(c, &c->d_filtered, F * MC));
+    TRY(dalloc(c, &c->d_near, F * MC * (MC / 32)));
+    TRY(dalloc(c, &c->d_ident, F * MC));
+    TRY(dalloc(c, &c->d_pre, F * MM));
+    TRY(dalloc(c, &c->d_markers, F * MM));
+    TRY(dalloc(c, &c->d_poses, F * MM));
+    TRY(dalloc(c, &c->d_counts, F));
+    TRY(dalloc(c, &c->d_global, 1));
+    TRY(dalloc(c, &c->d_worklist, F * MC));
+    TRY(dalloc(c, &c->d_nwork, 1));
+    TRY(dalloc(c, &c->d_pose_n, 1));
+    TRYHIP(hipHostMalloc((void **)&c->h_markers, sizeof(fid_marker) * F * MM, hipHostMallocDefault));
+    TRYHIP(hipHostMalloc((void **)&c->h_counts, sizeof(DevCounts) * F, hipHostMallocDefault));
+    TRYHIP(hipHostMalloc((void **)&c->h_global, sizeof(DevGlobal), hipHostMallocDefault));
+    TRYHIP(hipHostMalloc((void **)&c->h_poses, sizeof(fid_pose_out) * F * MM, hipHostMallocDefault));
+    TRYHIP(hipMemset(c->d_masks, 0, c->masks_bytes));
+    // opt in to large dynamic LDS where needed
+    TRYHIP(hipFuncSetAttribute((const void *)k_threshold<TX, TY, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+    TRYHIP(hipFuncSetAttribute((const void *)k_approx, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    TRYHIP(hipFuncSetAttribute((const void *)k_filter_markers, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+#undef TRY
+#undef TRYHIP
+    *out = c;
+    return FID_OK;
+}
+
+void fid_destroy(fid_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    void *dev[] = {c->d_in, c->d_gray, c->d_masks, c->d_starts, c->d_contours, c->d_cands, c->d_sorted, c->d_filtered, c->d_near,
+                   c->d_ident, c->d_pre, c->d_markers, c->d_poses, c->d_counts, c->d_global, c->d_worklist, c->d_nwork, c->d_dict,
+                   c->d_subpix_mask, c->d_lens, c->d_pose_in, c->d_pose_n};
+    for (void *p : dev)
+        if (p) (void)hipFree(p);
+    void *host[] = {c->h_markers, c->h_counts, c->h_global, c->h_poses};
+    for (void *p : host)
+        if (p) (void)hipHostFree(p);
+    for (int i = 0; i <= ST_COUNT; i++)
+        if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+fid_status fid_set_params(fid_ctx *c, const fid_params *p)
+{
+    if (!c || !p) return FID_E_INVALID_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    int old_scales = c->P.nscales;
+    fid_params keep = c->params;
+    fid_status rc = apply_params(c, p);
+    if (rc == FID_OK && c->P.nscales > old_scales) {
+        // the masks buffer was sized for the scale count at creation
+        size_t need = masks_elems(c, c->lim.max_width, c->lim.max_height, c->lim.max_batch) * sizeof(uint32_t);
+        if (need > c->masks_bytes) {
+            (void)apply_params(c, &keep);
+            return FID_E_UNSUPPORTED;
+        }
+    }
+    if (rc != FID_OK) (void)apply_params(c, &keep);
+    c->masks_W = 0;  // force re-zero
+    return rc;
+}
+
+fid_status fid_detect_device(fid_ctx *c, const void *d_imgs, int32_t nframes, int32_t width, int32_t height, int32_t stride,
+                             int64_t frame_stride, fid_encoding enc, fid_marker *out, int32_t cap_per_frame, int32_t *n_per_frame)
+{
+    if (!c || !d_imgs) return FID_E_INVALID_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    return run_detect(c, (const uint8_t *)d_imgs, nframes, width, height, stride, frame_stride, enc, out, cap_per_frame, n_per_frame);
+}
+
+fid_status fid_detect_batch(fid_ctx *c, const uint8_t *imgs, int32_t nframes, int32_t width, int32_t height, int32_t stride,
+                            int64_t frame_stride, fid_encoding enc, fid_marker *out, int32_t cap_per_frame, int32_t *n_per_frame)
+{
+    if (!c || !imgs || nframes < 1 || height < 1 || stride < 1) return FID_E_INVALID_ARG;
+    if (nframes > c->lim.max_batch) return FID_E_INVALID_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (frame_stride < (int64_t)stride * height) return FID_E_INVALID_ARG;
+    size_t need = (size_t)frame_stride * (nframes - 1) + (size_t)stride * height;
+    if (need > c->d_in_bytes) {
+        if (c->d_in) (void)hipFree(c->d_in);
+        c->d_in = nullptr;
+        c->d_in_bytes = 0;
+        HIPCHK(c, hipMalloc((void **)&c->d_in, need));
+        c->d_in_bytes = need;
+    }
+    // pageable or pinned host memory: one async copy on the context stream (H2D of the frame)
+    HIPCHK(c, hipMemcpyAsync(c->d_in, imgs, need, hipMemcpyHostToDevice, c->stream));
+    return run_detect(c, c->d_in, nframes, width, height, stride, frame_stride, enc, out, cap_per_frame, n_per_frame);
+}
+
+fid_status fid_detect(fid_ctx *c, const uint8_t *img, int32_t width, int32_t height, int32_t stride, fid_encoding enc,
+                      fid_marker *out, int32_t cap, int32_t *n)
+{
+    return fid_detect_batch(c, img, 1, width, height, stride, (int64_t)stride * height, enc, out, cap, n);
+}
+
+static fid_status run_pose(fid_ctx *c, const fid_marker *d_markers, const int *d_n, int n_stride_ints, const double *d_lens,
+                           int F, int per_frame, const double K[9], const double D[5], double fiducial_len, fid_pose_out *d_out)
+{
+    PoseCam cam;
+    for (int i = 0; i < 9; i++) cam.K[i] = K[i];
+    for (int i = 0; i < 5; i++) cam.D[i] = D ? D[i] : 0.;
+    cam.fiducial_len = fiducial_len;
+    int total = F * per_frame;
+    int blocks = (total + 63) / 64;
+    if (blocks < 1) blocks = 1;
+    if (c->profile) (void)hipEventRecord(c->ev[ST_POSE], c->stream);
+    hipLaunchKernelGGL(k_pose, dim3(blocks), dim3(64), 0, c->stream, d_markers, d_n, n_stride_ints, d_lens, F, per_frame, cam, d_out);
+    if (c->profile) (void)hipEventRecord(c->ev[ST_POSE + 1], c->stream);
+    HIPCHK(c, hipGetLastError());
+    return FID_OK;
+}
+
+fid_status fid_pose_last(fid_ctx *c, const double K[9], const double D[5], double fiducial_len, fid_pose_out *out,
+                         int32_t cap_per_frame)
+{
+    if (!c || !K || !out || c->last_frames <= 0 || !(fiducial_len > 0)) return FID_E_INVALID_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    const int F = c->last_frames, MM = c->P.maxMarkers;
+    fid_status rc = run_pose(c, c->d_markers, &c->d_counts[0].nmark, (int)(sizeof(DevCounts) / sizeof(int)), nullptr, F, MM, K, D,
+                             fiducial_len, c->d_poses);
+    if (rc != FID_OK) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->h_poses, c->d_poses, sizeof(fid_pose_out) * (size_t)F * MM, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->profile) (void)hipEventElapsedTime(&c->stage_ms[ST_POSE], c->ev[ST_POSE], c->ev[ST_POSE + 1]);
+    for (int f = 0; f < F; f++) {
+        int n = c->h_counts[f].nmark;
+        if (n > cap_per_frame) {
+            n = cap_per_frame;
+            rc = FID_E_CAPACITY;
+        }
+        memcpy(out + (size_t)f * cap_per_frame, c->h_poses + (size_t)f * MM, sizeof(fid_pose_out) * n);
+    }
+    return rc;
+}
+
+fid_status fid_pose(fid_ctx *c, const double K[9], const double D[5], const fid_marker *markers, const double *len_per_marker,
+                    int32_t n, double fiducial_len, fid_pose_out *out)
+{
+    if (!c || !K || (n > 0 && (!markers || !out)) || n < 0 || !(fiducial_len > 0)) return FID_E_INVALID_ARG;
+    if (n == 0) return FID_OK;
+    if (len_per_marker)
+        for (int i = 0; i < n; i++)
+            if (!(len_per_marker[i] > 0)) return FID_E_INVALID_ARG;  // CV_Assert(markerLength > 0), aruco_detect.cpp:229
+    HIPCHK(c, hipSetDevice(c->device));
+    if (n > c->pose_cap) {
+        if (c->d_pose_in) (void)hipFree(c->d_pose_in);
+        if (c->d_lens) (void)hipFree(c->d_lens);
+        c->d_pose_in = nullptr;
+        c->d_lens = nullptr;
+        c->pose_cap = 0;
+        int cap = roundup(n, 256);
+        HIPCHK(c, hipMalloc((void **)&c->d_pose_in, sizeof(fid_marker) * cap + sizeof(fid_pose_out) * cap));
+        HIPCHK(c, hipMalloc((void **)&c->d_lens, sizeof(double) * cap));
+        c->pose_cap = cap;
+    }
+    fid_pose_out *d_out = (fid_pose_out *)((char *)c->d_pose_in + sizeof(fid_marker) * c->pose_cap);
+    HIPCHK(c, hipMemcpyAsync(c->d_pose_in, markers, sizeof(fid_marker) * n, hipMemcpyHostToDevice, c->stream));
+    std::vector<double> lens(n);
+    for (int i = 0; i < n; i++) lens[i] = len_per_marker ? len_per_marker[i] : fiducial_len;
+    HIPCHK(c, hipMemcpyAsync(c->d_lens, lens.data(), sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+    int nn = n;
+    HIPCHK(c, hipMemcpyAsync(c->d_pose_n, &nn, sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));  // lens/nn are stack/heap temporaries
+    fid_status rc = run_pose(c, c->d_pose_in, c->d_pose_n, 0, c->d_lens, 1, n, K, D, fiducial_len, d_out);
+    if (rc != FID_OK) return rc;
+    HIPCHK(c, hipMemcpyAsync(out, d_out, sizeof(fid_pose_out) * n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return FID_OK;
+}
+
+int64_t fid_tap_bytes(fid_ctx *c, fid_tap which)
+{
+    if (!c || c->last_frames <= 0) return 0;
+    const DevParams &P = c->P;
+    const int64_t F = c->last_frames;
+    const int msb = P.markerSize + 2 * P.borderBits;
+    switch (which) {
+    case FID_TAP_MASKS: return F * P.nscales * P.H * P.WW * 4;
+    case FID_TAP_CANDIDATES:
+    case FID_TAP_FILTERED: return F * P.maxCands * (int64_t)sizeof(fid_candidate);
+    case FID_TAP_BITS: return F * P.maxCands * msb * msb;
+    case FID_TAP_IDENT: return F * P.maxCands * 8;
+    case FID_TAP_PRESUBPIX: return F * P.maxMarkers * (int64_t)sizeof(fid_marker);
+    case FID_TAP_COUNTS: return F * 8 * 4;
+    case FID_TAP_GRAY: return F * (int64_t)P.W * P.H;
+    }
+    return 0;
+}
+
+fid_status fid_tap_read(fid_ctx *c, fid_tap which, void *dst, int64_t dst_bytes)
+{
+    if (!c || !dst || c->last_frames <= 0) return FID_E_INVALID_ARG;
+    int64_t need = fid_tap_bytes(c, which);
+    if (need <= 0 || dst_bytes < need) return FID_E_CAPACITY;
+    HIPCHK(c, hipSetDevice(c->device));
+    const DevParams &P = c->P;
+    const int F = c->last_frames;
+    const int msb = P.markerSize + 2 * P.borderBits;
+    switch (which) {
+    case FID_TAP_MASKS: {
+        // strip the padding: 2-D copy per (frame, scale)
+        for (int fs = 0; fs < F * P.nscales; fs++) {
+            const uint32_t *src = c->d_masks + ((size_t)fs * (P.H + 2) + 1) * P.WWP + MASK_PADW;
+            HIPCHK(c, hipMemcpy2D((char *)dst + (size_t)fs * P.H * P.WW * 4, (size_t)P.WW * 4, src, (size_t)P.WWP * 4,
+                                  (size_t)P.WW * 4, P.H, hipMemcpyDeviceToHost));
+        }
+        return FID_OK;
+    }
+    case FID_TAP_CANDIDATES:
+    case FID_TAP_FILTERED: {
+        std::vector<DevCand> tmp((size_t)F * P.maxCands);
+        HIPCHK(c, hipMemcpy(tmp.data(), which == FID_TAP_CANDIDATES ? c->d_sorted : c->d_filtered, tmp.size() * sizeof(DevCand),
+                            hipMemcpyDeviceToHost));
+        fid_candidate *o = (fid_candidate *)dst;
+        for (size_t i = 0; i < tmp.size(); i++) {
+            o[i].scale = tmp[i].scale;
+            o[i].contour_size = tmp[i].size;
+            o[i].start_x = tmp[i].sx;
+            o[i].start_y = tmp[i].sy;
+            o[i].is_hole = tmp[i].hole;
+            memcpy(o[i].corners, tmp[i].c, sizeof(float) * 8);
+        }
+        return FID_OK;
+    }
+    case FID_TAP_BITS:
+    case FID_TAP_IDENT: {
+        std::vector<DevIdent> tmp((size_t)F * P.maxCands);
+        HIPCHK(c, hipMemcpy(tmp.data(), c->d_ident, tmp.size() * sizeof(DevIdent), hipMemcpyDeviceToHost));
+        if (which == FID_TAP_BITS) {
+            uint8_t *o = (uint8_t *)dst;
+            for (size_t i = 0; i < tmp.size(); i++) memcpy(o + i * msb * msb, tmp[i].bits, (size_t)msb * msb);
+        } else {
+            int32_t *o = (int32_t *)dst;
+            for (size_t i = 0; i < tmp.size(); i++) {
+                o[2 * i] = tmp[i].id;
+                o[2 * i + 1] = tmp[i].rot;
+            }
+        }
+        return FID_OK;
+    }
+    case FID_TAP_PRESUBPIX:
+        HIPCHK(c, hipMemcpy(dst, c->d_pre, (size_t)need, hipMemcpyDeviceToHost));
+        return FID_OK;
+    case FID_TAP_COUNTS: {
+        int32_t *o = (int32_t *)dst;
+        for (int f = 0; f < F; f++) {
+            o[8 * f + 0] = (int32_t)c->h_global->nstarts;
+            o[8 * f + 1] = (int32_t)c->h_global->ncontours;
+            o[8 * f + 2] = c->h_counts[f].ncand;
+            o[8 * f + 3] = c->h_counts[f].nfilt;
+            o[8 * f + 4] = c->h_counts[f].nacc;
+            o[8 * f + 5] = c->h_counts[f].nmark;
+            o[8 * f + 6] = c->h_counts[f].overflow | ((int32_t)c->h_global->overflow << 8);
+            o[8 * f + 7] = 0;
+        }
+        return FID_OK;
+    }
+    case FID_TAP_GRAY:
+        for (int f = 0; f < F; f++)
+            HIPCHK(c, hipMemcpy2D((char *)dst + (size_t)f * P.W * P.H, (size_t)P.W, c->last_gray + (size_t)f * c->last_gfstride,
+                                  (size_t)P.gstride, (size_t)P.W, P.H, hipMemcpyDeviceToHost));
+        return FID_OK;
+    }
+    return FID_E_INVALID_ARG;
+}
+
+int32_t fid_last_stage_ms(fid_ctx *c, float *ms, int32_t cap, const char *const **names)
+{
+    if (names) *names = kStageNames;
+    if (!c || !ms) return ST_COUNT;
+    for (int i = 0; i < ST_COUNT && i < cap; i++) ms[i] = c->profile ? c->stage_ms[i] : -1.f;
+    return ST_COUNT;
+}
+
+void *fid_stream(fid_ctx *c) { return c ? (void *)c->stream : nullptr; }
+
+const char *fid_strerror(fid_status s)
+{
+    switch (s) {
+    case FID_OK: return "ok";
+    case FID_E_INVALID_ARG: return "invalid argument";
+    case FID_E_NO_DEVICE: return "no HIP device (this library has no CPU fallback)";
+    case FID_E_HIP: return "HIP runtime error";
+    case FID_E_CAPACITY: return "capacity exceeded";
+    case FID_E_OUT_OF_MEMORY: return "out of memory";
+    case FID_E_UNSUPPORTED: return "unsupported parameter combination";
+    }
+    return "unknown status";
+}
+
+const char *fid_last_error(fid_ctx *c) { return c ? c->last_error.c_str() : ""; }
+
+int32_t fid_abi_version(void) { return FID_ABI_VERSION; }
+
+}  // extern "C"

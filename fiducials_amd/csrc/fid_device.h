@@ -1,0 +1,71 @@
+// fid_device.h -- device-side data layout shared by the kernels and the C-ABI host code.
+//
+// HBM layout (all per context, sized at fid_create for max_batch frames F of W x H):
+//   gray      u8   [F][H][W]                  the image the detector sees (aliases the caller's
+//                                              buffer for mono8 device input with stride == W)
+//   masks     u32  [F][S][H+2][WWP]           13 bit-packed adaptive-threshold masks; pixel x of row y
+//                                              is bit (x & 31) of word MASK_PADW + (x >> 5) in padded
+//                                              row y+1; pad rows/words are zero so border following
+//                                              never bounds-checks
+//   starts    uint2 [F * max_starts]          border-following start points (all frames, all scales)
+//   contours  uint4 [F * max_contours]        contours that passed the perimeter gate
+//   cands     DevCand [F][max_cands]          quads leaving _findMarkerContours
+//   sorted / filtered DevCand [F][max_cands]  OpenCV order; after reorder + too-close filter
+//   near      u32  [F][max_cands][max_cands/32]
+//   ident     DevIdent [F][max_cands]
+//   markers   fid_marker [F][max_markers]     (pre- and post-subpix)
+//   poses     fid_pose_out [F][max_markers]
+#pragma once
+#include <stdint.h>
+
+#define MASK_PADW 4  // zero words in front of every mask row (keeps 16-B store alignment)
+#define FID_MAX_SCALES 32
+#define FID_MAX_CELLS 9  // marker_size + 2*border <= 9 (7x7 dictionaries)
+
+struct DevParams {
+    int W, H, gstride, WW, WWP, nscales, nframes;
+    int win[FID_MAX_SCALES];       // odd window sizes
+    int idelta;                    // cvCeil(adaptiveThreshConstant)
+    int rmax;                      // max window radius
+    int minPerim, maxPerim;        // (unsigned)(rate * max(W,H))
+    double polyAcc, minCornerDistRate, minMarkerDistRate;
+    int minDistToBorder;
+    int markerSize, borderBits, cellSize, cellMargin;  // dictionary n, markerBorderBits, px per cell, margin px
+    double minOtsuStdDev;
+    int maxBorderErr, maxCorr, nMarkers, nbytes;
+    int subpixWin, subpixMaxIter;
+    double subpixEps;  // squared
+    int refine;
+    int maxStarts, maxContours, maxCands, maxMarkers;  // per-frame capacities (starts/contours: x F global)
+};
+
+struct DevCand {
+    int scale;
+    int size;       // contour.size()
+    int sx, sy;     // first contour point
+    int hole;
+    unsigned key;   // discovery position in the padded raster (outer: start pixel, hole: pixel right of it)
+    float c[8];
+};
+
+struct DevIdent {
+    int id, rot;
+    unsigned char bits[FID_MAX_CELLS * FID_MAX_CELLS + 3];
+};
+
+// per-frame counters
+struct DevCounts {
+    int ncand;      // candidates emitted by k_approx
+    int nfilt;      // after too-close filter
+    int nacc;       // identified
+    int nmark;      // after _filterDetectedMarkers
+    int overflow;   // bit0 cands, bit1 markers
+    int pad[3];
+};
+
+// global counters
+struct DevGlobal {
+    unsigned nstarts, ncontours;
+    unsigned overflow;  // bit0 starts, bit1 contours
+    unsigned pad;
+};

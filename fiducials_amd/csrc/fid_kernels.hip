@@ -1,0 +1,1853 @@
+// fid_kernels.hip -- hand-written gfx950 kernels for the aruco detection hot path
+// (reference boundary: aruco::detectMarkers / cv::solvePnP as called from
+//  /root/reference/aruco_detect/src/aruco_detect.cpp:350 and :247; stage map in SURVEY.md §8a).
+//
+//   K0 k_to_gray        a2  bgr8/rgb8 -> gray (15-bit fixed point), or stride compaction
+//   K1 k_threshold      a3  13-scale adaptive threshold from one LDS tile integral, bit-packed output
+//   K2 k_find_starts    a4  border-following start points by bit-parallel 3x3 tests + wave compaction
+//   K3 k_walk_count     a4  one lane per start: Suzuki-Abe border following, canonical-start + length gate
+//   K4 k_approx         a4  one wave per contour: re-walk into LDS, approxPolyDP, quad gates
+//   K5 k_sort_cands / k_near / k_resolve   a5  OpenCV order, corner reorder, too-close filter
+//   K6 k_identify       a6/a7 one wave per candidate: homography (LU on 64 lanes), unwarp, Otsu, bits, Hamming
+//   K7 k_filter_markers / k_subpix        a8/a9
+//   K8 k_pose           a11-a13 one lane per marker: planar init + Levenberg-Marquardt
+//
+// Wavefront = 64 everywhere.  Integer stages are bit-exact by construction; floating-point stages
+// replay the reference's operation order (this TU is built with -ffp-contract=off).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <float.h>
+#include <limits.h>
+
+#include "fid_device.h"
+#include "../../include/fid_abi.h"
+
+#define WAVE 64
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & (WAVE - 1); }
+
+__device__ __forceinline__ unsigned long long ballot64(int pred) { return __ballot(pred); }
+
+// inclusive wave scan (all 64 lanes must be active)
+__device__ __forceinline__ int wave_iscan(int v)
+{
+    int lane = lane_id();
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) {
+        int t = __shfl_up(v, d, WAVE);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+
+// wave max of a 64-bit key (hi, lo)
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long k)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        unsigned lo = __shfl_xor((unsigned)k, d, WAVE);
+        unsigned hi = __shfl_xor((unsigned)(k >> 32), d, WAVE);
+        unsigned long long o = ((unsigned long long)hi << 32) | lo;
+        k = o > k ? o : k;
+    }
+    return k;
+}
+
+__device__ __forceinline__ int wave_min_i32(int v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        int o = __shfl_xor(v, d, WAVE);
+        v = o < v ? o : v;
+    }
+    return v;
+}
+
+__device__ __forceinline__ int wave_sum_i32(int v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, WAVE);
+    return v;
+}
+
+__device__ __forceinline__ long long wave_sum_i64(long long v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        unsigned lo = __shfl_xor((unsigned)v, d, WAVE);
+        unsigned hi = __shfl_xor((unsigned)((unsigned long long)v >> 32), d, WAVE);
+        v += (long long)(((unsigned long long)hi << 32) | lo);
+    }
+    return v;
+}
+
+__device__ __forceinline__ double shfl_f64(double v, int src)
+{
+    unsigned long long u = __double_as_longlong(v);
+    unsigned lo = __shfl((unsigned)u, src, WAVE);
+    unsigned hi = __shfl((unsigned)(u >> 32), src, WAVE);
+    return __longlong_as_double(((unsigned long long)hi << 32) | lo);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K0: cv_bridge::toCvCopy(BGR8) + cvtColor(BGR2GRAY)  (aruco_detect.cpp:348; OpenCV 4.x RGB2Gray<uchar>:
+//     (B*3735 + G*19235 + R*9798 + 2^14) >> 15).  Also used to compact a strided mono8 frame.
+__global__ __launch_bounds__(256) void k_to_gray(const uint8_t *__restrict__ src, int stride, long long fstride,
+                                                  int enc, uint8_t *__restrict__ dst, int W, int H, int F)
+{
+    long long total = (long long)W * H * F;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        int x = (int)(i % W);
+        long long t = i / W;
+        int y = (int)(t % H);
+        int f = (int)(t / H);
+        const uint8_t *s = src + f * fstride + (long long)y * stride;
+        uint8_t v;
+        if (enc == FID_ENC_MONO8) {
+            v = s[x];
+        } else {
+            int c0 = s[3 * x], c1 = s[3 * x + 1], c2 = s[3 * x + 2];
+            int b = enc == FID_ENC_BGR8 ? c0 : c2, r = enc == FID_ENC_BGR8 ? c2 : c0;
+            v = (uint8_t)((b * 3735 + c1 * 19235 + r * 9798 + (1 << 14)) >> 15);
+        }
+        dst[i] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1: multi-scale adaptive threshold.
+//   adaptiveThreshold(MEAN_C, BINARY_INV, win, C): mean = round(boxsum / win^2) with BORDER_REPLICATE,
+//   foreground iff src - mean <= -ceil(C)   <=>   2*boxsum >= (2*(src + idelta) - 1) * win^2
+//   (exact: boxsum/win^2 never sits on a half for odd win).
+// One workgroup = one TX x TY output tile: the tile plus a rmax halo is loaded once (clamped =
+// replicate border), turned into a 2-D integral image in LDS, and all scales read their four corners
+// from it.  A wave covers 64 consecutive x so one ballot yields two packed mask words per (row, scale).
+template <int TX, int TY, int NT>
+__global__ __launch_bounds__(NT) void k_threshold(const uint8_t *__restrict__ gray, long long gfstride,
+                                                   uint32_t *__restrict__ masks, const DevParams P)
+{
+    extern __shared__ uint32_t I[];
+    const int R = P.rmax;
+    const int RW = TX + 2 * R, RH = TY + 2 * R;
+    const int PT = (RW + 1) | 1;  // odd pitch: column walks are bank-conflict free
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    constexpr int NWAVES = NT / 64;
+    const int x0 = blockIdx.x * TX, y0 = blockIdx.y * TY, f = blockIdx.z;
+    const uint8_t *g = gray + (long long)f * gfstride;
+    const int W = P.W, H = P.H, gs = P.gstride;
+
+    for (int i = tid; i < PT; i += NT) I[i] = 0;
+    for (int i = tid; i <= RH; i += NT) I[i * PT] = 0;
+    // phase 1+2: load rows (clamped) and row-prefix them with a wave scan
+    for (int ry = wid; ry < RH; ry += NWAVES) {
+        int gy = y0 - R + ry;
+        gy = gy < 0 ? 0 : (gy >= H ? H - 1 : gy);
+        const uint8_t *grow = g + (long long)gy * gs;
+        int carry = 0;
+        for (int c = 0; c < RW; c += 64) {
+            int rx = c + lane;
+            int gx = x0 - R + rx;
+            gx = gx < 0 ? 0 : (gx >= W ? W - 1 : gx);
+            int v = rx < RW ? (int)grow[gx] : 0;
+            v = wave_iscan(v) + carry;
+            if (rx < RW) I[(ry + 1) * PT + rx + 1] = (uint32_t)v;
+            carry = __shfl(v, 63, WAVE);
+        }
+    }
+    __syncthreads();
+    // phase 3: column prefix, one thread per column
+    for (int cx = 1 + tid; cx <= RW; cx += NT) {
+        uint32_t acc = 0;
+#pragma unroll 4
+        for (int ry = 1; ry <= RH; ry++) {
+            acc += I[ry * PT + cx];
+            I[ry * PT + cx] = acc;
+        }
+    }
+    __syncthreads();
+    // phase 4: evaluate all scales
+    constexpr int SEGS = TX / 64;
+    const int S = P.nscales, WWP = P.WWP;
+    for (int item = wid; item < TY * SEGS; item += NWAVES) {
+        int ty = item / SEGS, seg = item % SEGS;
+        int x = seg * 64 + lane;
+        int gx = x0 + x, gy = y0 + ty;
+        if (gy >= H) continue;  // wave-uniform
+        int valid = gx < W;
+        int gv = valid ? (int)g[(long long)gy * gs + gx] : 0;
+        int t2 = 2 * (gv + P.idelta) - 1;
+        int rc = ty + R, cc = x + R;
+        uint32_t *mrow = masks + (((long long)f * S) * (H + 2) + (gy + 1)) * WWP + MASK_PADW + ((x0 + seg * 64) >> 5);
+        for (int s = 0; s < S; s++) {
+            int win = P.win[s], r = win >> 1;
+            const uint32_t *top = I + (rc - r) * PT, *bot = I + (rc + r + 1) * PT;
+            int sum = (int)(bot[cc + r + 1] - top[cc + r + 1] - bot[cc - r] + top[cc - r]);
+            int fg = valid && (2 * sum >= t2 * win * win);
+            unsigned long long b = ballot64(fg);
+            if (lane == 0) {
+                uint2 wv;
+                wv.x = (uint32_t)b;
+                wv.y = (uint32_t)(b >> 32);
+                *reinterpret_cast<uint2 *>(mrow + (long long)s * (H + 2) * WWP) = wv;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2: start points of Suzuki-Abe border following, found without the sequential raster scan:
+//   outer border start  = foreground pixel whose W, NW, N, NE neighbours are background
+//                         (necessary for being the raster-first pixel of its 8-connected component)
+//   hole border start   = foreground pixel p with background E and foreground NE
+//                         (necessary for E being the raster-first pixel of a 4-connected hole)
+// K3 decides which of them are the canonical start of their border.  32 pixels per lane-op.
+__global__ __launch_bounds__(256) void k_find_starts(const uint32_t *__restrict__ masks, uint2 *__restrict__ starts,
+                                                      DevGlobal *__restrict__ G, const DevParams P)
+{
+    const int lane = lane_id();
+    const int WW = P.WW, WWP = P.WWP, H = P.H, S = P.nscales;
+    const long long total = (long long)P.nframes * S * H * WW;
+    const long long totalr = (total + 63) & ~63LL;
+    const unsigned cap = (unsigned)P.maxStarts * (unsigned)P.nframes;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < totalr; i += (long long)gridDim.x * blockDim.x) {
+        uint32_t outer = 0, hole = 0;
+        int w = 0, y = 0, s = 0, f = 0;
+        if (i < total) {
+            w = (int)(i % WW);
+            long long t = i / WW;
+            y = (int)(t % H);
+            t /= H;
+            s = (int)(t % S);
+            f = (int)(t / S);
+            const uint32_t *row = masks + (((long long)f * S + s) * (H + 2) + (y + 1)) * WWP + MASK_PADW + w;
+            uint32_t cur = row[0];
+            if (cur) {
+                const uint32_t *up = row - WWP;
+                uint32_t curL = row[-1], curR = row[1], u = up[0], uL = up[-1], uR = up[1];
+                uint32_t Wst = (cur << 1) | (curL >> 31);
+                uint32_t Est = (cur >> 1) | (curR << 31);
+                uint32_t NW = (u << 1) | (uL >> 31);
+                uint32_t NE = (u >> 1) | (uR << 31);
+                outer = cur & ~Wst & ~NW & ~u & ~NE;
+                hole = cur & ~Est & NE;
+            }
+        }
+        int cnt = __popc(outer) + __popc(hole);
+        int incl = wave_iscan(cnt);
+        int tot = __shfl(incl, 63, WAVE);
+        if (tot == 0) continue;  // wave-uniform
+        unsigned base = 0;
+        if (lane == 63) base = atomicAdd(&G->nstarts, (unsigned)tot);
+        base = __shfl(base, 63, WAVE);
+        unsigned off = base + (unsigned)(incl - cnt);
+        uint32_t meta = (uint32_t)f | ((uint32_t)s << 16);
+        while (outer) {
+            int b = __ffs(outer) - 1;
+            outer &= outer - 1;
+            if (off < cap) starts[off] = make_uint2((uint32_t)(w * 32 + b) | ((uint32_t)y << 16), meta);
+            off++;
+        }
+        while (hole) {
+            int b = __ffs(hole) - 1;
+            hole &= hole - 1;
+            if (off < cap) starts[off] = make_uint2((uint32_t)(w * 32 + b) | ((uint32_t)y << 16), meta | (1u << 24));
+            off++;
+        }
+        if (lane == 63 && base + (unsigned)tot > cap) atomicOr(&G->overflow, 1u);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Border following on the bit-packed padded mask.
+// Directions (contours.cpp icvCodeDeltas): 0 E, 1 NE, 2 N, 3 NW, 4 W, 5 SW, 6 S, 7 SE.
+__device__ __constant__ int c_dx8[8] = {1, 1, 0, -1, -1, -1, 0, 1};
+__device__ __constant__ int c_dy8[8] = {0, -1, -1, -1, 0, 1, 1, 1};
+
+struct MaskView {
+    const uint32_t *base;  // padded row 0 (image row -1), word 0
+    int WWP;
+};
+
+// 8-neighbourhood occupancy of pixel (x, y): bit d = neighbour in direction d is foreground
+__device__ __forceinline__ unsigned nb8(const MaskView &m, int x, int y)
+{
+    // bits x-1, x, x+1 of rows y-1, y, y+1; pixel x lives at bit (x & 31) of word MASK_PADW + (x >> 5)
+    int xb = x - 1 + MASK_PADW * 32;
+    int wi = xb >> 5, sh = xb & 31;
+    const uint32_t *r0 = m.base + (long long)y * m.WWP + wi;  // padded row y = image row y-1
+    const uint32_t *r1 = r0 + m.WWP, *r2 = r1 + m.WWP;
+    unsigned tu = __builtin_amdgcn_alignbit(r0[1], r0[0], sh) & 7u;
+    unsigned tm = __builtin_amdgcn_alignbit(r1[1], r1[0], sh) & 7u;
+    unsigned td = __builtin_amdgcn_alignbit(r2[1], r2[0], sh) & 7u;
+    return ((tm >> 2) & 1u) | (((tu >> 2) & 1u) << 1) | (((tu >> 1) & 1u) << 2) | ((tu & 1u) << 3) | ((tm & 1u) << 4) |
+           ((td & 1u) << 5) | (((td >> 1) & 1u) << 6) | (((td >> 2) & 1u) << 7);
+}
+
+// padded raster index used to order discovery events like cvFindNextContour's scan
+__device__ __forceinline__ int pidx(int x, int y, int W) { return (y + 1) * (W + 2) + (x + 1); }
+
+// K3: one lane per start.  Walks the border exactly as icvFetchContour does (contours.cpp), counting points;
+// stops early when the start turns out not to be the canonical one (so each border is reported once, from
+// the pixel where cvFindNextContour would have started it) or when the contour exceeds maxPerimeterPixels.
+__global__ __launch_bounds__(256) void k_walk_count(const uint32_t *__restrict__ masks, const uint2 *__restrict__ starts,
+                                                     uint4 *__restrict__ contours, DevGlobal *__restrict__ G,
+                                                     const DevParams P)
+{
+    const unsigned cap = (unsigned)P.maxStarts * (unsigned)P.nframes;
+    unsigned n = G->nstarts;
+    n = n < cap ? n : cap;
+    const unsigned ccap = (unsigned)P.maxContours * (unsigned)P.nframes;
+    const int W = P.W, H = P.H, S = P.nscales;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        uint2 st = starts[i];
+        int x0 = st.x & 0xffff, y0 = st.x >> 16;
+        int f = st.y & 0xffff, s = (st.y >> 16) & 0xff, hole = (st.y >> 24) & 1;
+        MaskView m;
+        m.base = masks + (((long long)f * S + s) * (H + 2)) * P.WWP;
+        m.WWP = P.WWP;
+        // canonical key: outer = own index, hole = index of the background pixel to the right
+        const int key = hole ? pidx(x0 + 1, y0, W) : pidx(x0, y0, W);
+        unsigned nb = nb8(m, x0, y0);
+        int sdir, s_end;
+        s_end = sdir = hole ? 0 : 4;
+        int found = 0;
+        // do { s = (s - 1) & 7; } while (*i1 == 0 && s != s_end)   -- clockwise search for the last neighbour
+        for (int k = 0; k < 8; k++) {
+            sdir = (sdir - 1) & 7;
+            if ((nb >> sdir) & 1u) {
+                found = 1;
+                break;
+            }
+            if (sdir == s_end) break;
+        }
+        int count = 0, ok = 1;
+        if (!found || sdir == s_end) {
+            if (!((nb >> sdir) & 1u)) {
+                count = 1;  // single pixel domain
+                found = 0;
+            }
+        }
+        if (found) {
+            const int i1x = x0 + c_dx8[sdir], i1y = y0 + c_dy8[sdir];
+            int cx = x0, cy = y0;
+            for (;;) {
+                // search counter-clockwise from sdir+1 for the next foreground neighbour
+                unsigned nb2 = nb | (nb << 8);
+                int start = (sdir + 1) & 7;
+                unsigned rot = (nb2 >> start) & 0xffu;
+                int t = __ffs(rot) - 1;  // rot != 0: the neighbour we came from is foreground
+                if (hole) {
+                    // background pixels examined in the 4-directions belong to this border's hole region
+                    for (int q = 0; q < t; q++) {
+                        int d = (start + q) & 7;
+                        if (!(d & 1) && pidx(cx + c_dx8[d], cy + c_dy8[d], W) < key) ok = 0;
+                    }
+                }
+                int sn = (start + t) & 7;
+                count++;
+                int nx = cx + c_dx8[sn], ny = cy + c_dy8[sn];
+                if (!ok || count > P.maxPerim) {
+                    ok = 0;
+                    break;
+                }
+                if (nx == x0 && ny == y0 && cx == i1x && cy == i1y) break;
+                cx = nx;
+                cy = ny;
+                if (!hole && pidx(cx, cy, W) < key) {
+                    ok = 0;
+                    break;
+                }
+                sdir = (sn + 4) & 7;
+                nb = nb8(m, cx, cy);
+            }
+        }
+        if (ok && count >= P.minPerim && count <= P.maxPerim) {
+            unsigned o = atomicAdd(&G->ncontours, 1u);
+            if (o < ccap)
+                contours[o] = make_uint4(st.x, st.y, (unsigned)count, (unsigned)key);
+            else
+                atomicOr(&G->overflow, 2u);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K4: one wave per surviving contour: replay the walk into LDS (points packed x | y << 16), then
+// approxPolyDP(closed, eps = size * polygonalApproxAccuracyRate) exactly as approx.cpp approxPolyDP_<int>
+// orders its work (the slice stack is sequential, each slice's farthest-point search is a wave reduction
+// with first-maximum tie-break), then _findMarkerContours' gates (aruco.cpp): 4 points, convex, min side,
+// distance to the image border.
+#define DP_STACK 1024
+__global__ __launch_bounds__(64) void k_approx(const uint32_t *__restrict__ masks, const uint4 *__restrict__ contours,
+                                                DevCand *__restrict__ cands, DevCounts *__restrict__ counts,
+                                                DevGlobal *__restrict__ G, const DevParams P)
+{
+    extern __shared__ uint32_t pts[];  // maxPerim points
+    __shared__ int2 stack[DP_STACK];
+    __shared__ int dst[2 * 16];
+    const int lane = lane_id();
+    const unsigned ccap = (unsigned)P.maxContours * (unsigned)P.nframes;
+    unsigned n = G->ncontours;
+    n = n < ccap ? n : ccap;
+    const int W = P.W, H = P.H, S = P.nscales;
+    for (unsigned ci = blockIdx.x; ci < n; ci += gridDim.x) {
+        uint4 c = contours[ci];
+        const int x0 = c.x & 0xffff, y0 = c.x >> 16;
+        const int f = c.y & 0xffff, s = (c.y >> 16) & 0xff, hole = (c.y >> 24) & 1;
+        const int count = (int)c.z;
+        MaskView m;
+        m.base = masks + (((long long)f * S + s) * (H + 2)) * P.WWP;
+        m.WWP = P.WWP;
+        __syncthreads();
+        // ---- replay the border (wave-uniform; lane 0 stores)
+        {
+            unsigned nb = nb8(m, x0, y0);
+            int sdir = hole ? 0 : 4;
+            for (int k = 0; k < 8; k++) {
+                sdir = (sdir - 1) & 7;
+                if ((nb >> sdir) & 1u) break;
+            }
+            int cx = x0, cy = y0;
+            for (int k = 0; k < count; k++) {
+                if (lane == 0) pts[k] = (uint32_t)cx | ((uint32_t)cy << 16);
+                unsigned nb2 = nb | (nb << 8);
+                int start = (sdir + 1) & 7;
+                int t = __ffs((nb2 >> start) & 0xffu) - 1;
+                int sn = (start + t) & 7;
+                cx += c_dx8[sn];
+                cy += c_dy8[sn];
+                sdir = (sn + 4) & 7;
+                if (k + 1 < count) nb = nb8(m, cx, cy);
+            }
+        }
+        __syncthreads();
+        // ---- approxPolyDP
+        double eps = (double)count * P.polyAcc;
+        eps *= eps;
+        int new_count = 0, reject = 0, top = 0;
+        int rs_start = 0, pos = 0, le_eps = 0;
+        int sx = 0, sy = 0;
+        // 1. find approximately two farthest points
+        for (int it = 0; it < 3; it++) {
+            pos = (pos + rs_start) % count;
+            uint32_t sp = pts[pos];
+            sx = sp & 0xffff;
+            sy = sp >> 16;
+            // points j = 1 .. count-1 at index (pos + j) % count; READ_PT leaves pos back at its start
+            unsigned long long best = 0;
+            for (int j = 1 + lane; j < count; j += 64) {
+                int idx = pos + j;
+                idx = idx >= count ? idx - count : idx;
+                uint32_t p = pts[idx];
+                int dx = (int)(p & 0xffff) - sx, dy = (int)(p >> 16) - sy;
+                unsigned d = (unsigned)(dx * dx + dy * dy);
+                unsigned long long k = ((unsigned long long)d << 32) | (0xffffffffu - (unsigned)j);
+                best = k > best ? k : best;
+            }
+            best = wave_max_u64(best);
+            unsigned md = (unsigned)(best >> 32);
+            if (md > 0) rs_start = (int)(0xffffffffu - (unsigned)best);
+            le_eps = (double)md <= eps;
+            // after the loop READ_PT has advanced pos by count (mod count): pos unchanged
+        }
+        if (!le_eps) {
+            int2 rs, sl;
+            rs.y = sl.x = pos % count;
+            sl.y = rs.x = (rs_start + sl.x) % count;
+            if (lane == 0) {
+                stack[0] = rs;
+                stack[1] = sl;
+            }
+            top = 2;
+        } else {
+            if (lane == 0) {
+                dst[0] = sx;
+                dst[1] = sy;
+            }
+            new_count = 1;
+        }
+        __syncthreads();
+        // 3. recursive process
+        while (top > 0 && !reject) {
+            int2 sl = stack[--top];
+            uint32_t ep = pts[sl.y];
+            int ex = ep & 0xffff, ey = ep >> 16;
+            uint32_t sp = pts[sl.x];
+            sx = sp & 0xffff;
+            sy = sp >> 16;
+            int mcount = sl.y - sl.x;
+            if (mcount < 0) mcount += count;
+            mcount -= 1;  // interior points
+            int split = 0;
+            if (mcount > 0) {
+                int dx = ex - sx, dy = ey - sy;
+                unsigned long long best = 0;
+                for (int t = lane; t < mcount; t += 64) {
+                    int idx = sl.x + 1 + t;
+                    idx = idx >= count ? idx - count : idx;
+                    uint32_t p = pts[idx];
+                    int px = p & 0xffff, py = p >> 16;
+                    int cr = (py - sy) * dx - (px - sx) * dy;
+                    unsigned d = (unsigned)(cr < 0 ? -cr : cr);
+                    unsigned long long k = ((unsigned long long)d << 32) | (0xffffffffu - (unsigned)t);
+                    best = k > best ? k : best;
+                }
+                best = wave_max_u64(best);
+                double max_dist = (double)(unsigned)(best >> 32);
+                int bt = (int)(0xffffffffu - (unsigned)best);
+                le_eps = max_dist * max_dist <= eps * ((double)dx * dx + (double)dy * dy);
+                if (!le_eps) {
+                    split = sl.x + 1 + bt;
+                    split = split >= count ? split - count : split;
+                }
+            } else {
+                le_eps = 1;
+            }
+            __syncthreads();
+            if (le_eps) {
+                if (new_count >= 9) {
+                    reject = 1;  // the clean-up pass removes at most half: more than 8 can never end as 4
+                } else {
+                    if (lane == 0) {
+                        dst[2 * new_count] = sx;
+                        dst[2 * new_count + 1] = sy;
+                    }
+                    new_count++;
+                }
+            } else {
+                if (top + 2 > DP_STACK) {
+                    reject = 1;
+                    if (lane == 0) atomicOr(&G->overflow, 4u);
+                } else {
+                    if (lane == 0) {
+                        stack[top] = make_int2(split, sl.y);   // right_slice
+                        stack[top + 1] = make_int2(sl.x, split);  // slice
+                    }
+                    top += 2;
+                }
+            }
+            __syncthreads();
+        }
+        if (reject || new_count < 4) continue;
+        // last stage: remove extra points on the [almost] straight lines (wave-uniform scalar code)
+        {
+            const int cnt = new_count;
+            int posd = cnt - 1, wpos, i;
+            int spx, spy, ptx, pty, epx, epy;
+#define RD(X, Y)                  \
+    do {                          \
+        X = dst[2 * posd];        \
+        Y = dst[2 * posd + 1];    \
+        if (++posd >= cnt) posd = 0; \
+    } while (0)
+            RD(spx, spy);
+            wpos = posd;
+            RD(ptx, pty);
+            for (i = 0; i < cnt && new_count > 2; i++) {
+                RD(epx, epy);
+                double dx = epx - spx, dy = epy - spy;
+                double dist = fabs((double)(ptx - spx) * dy - (double)(pty - spy) * dx);
+                double sip = (double)(ptx - spx) * (epx - ptx) + (double)(pty - spy) * (epy - pty);
+                __syncthreads();
+                if (dist * dist <= 0.5 * eps * (dx * dx + dy * dy) && dx != 0 && dy != 0 && sip >= 0) {
+                    new_count--;
+                    spx = epx;
+                    spy = epy;
+                    if (lane == 0) {
+                        dst[2 * wpos] = spx;
+                        dst[2 * wpos + 1] = spy;
+                    }
+                    if (++wpos >= cnt) wpos = 0;
+                    __syncthreads();
+                    RD(ptx, pty);
+                    i++;
+                    continue;
+                }
+                spx = ptx;
+                spy = pty;
+                if (lane == 0) {
+                    dst[2 * wpos] = spx;
+                    dst[2 * wpos + 1] = spy;
+                }
+                if (++wpos >= cnt) wpos = 0;
+                ptx = epx;
+                pty = epy;
+                __syncthreads();
+            }
+#undef RD
+        }
+        __syncthreads();
+        if (new_count != 4) continue;
+        int ax[4], ay[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            ax[k] = dst[2 * k];
+            ay[k] = dst[2 * k + 1];
+        }
+        // isContourConvex_<int> (convhull.cpp)
+        {
+            int prevx = ax[2], prevy = ay[2], curx = ax[3], cury = ay[3];
+            int dx0 = curx - prevx, dy0 = cury - prevy, orientation = 0, convex = 1;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                prevx = curx;
+                prevy = cury;
+                curx = ax[k];
+                cury = ay[k];
+                int dx = curx - prevx, dy = cury - prevy;
+                int dxdy0 = dx * dy0, dydx0 = dy * dx0;
+                orientation |= (dydx0 > dxdy0) ? 1 : ((dydx0 < dxdy0) ? 2 : 3);
+                if (orientation == 3) convex = 0;
+                dx0 = dx;
+                dy0 = dy;
+            }
+            if (!convex) continue;
+        }
+        {
+            int maxdim = W > H ? W : H;
+            double minDistSq = (double)maxdim * maxdim;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                int k1 = (k + 1) & 3;
+                double d = (double)(ax[k] - ax[k1]) * (double)(ax[k] - ax[k1]) + (double)(ay[k] - ay[k1]) * (double)(ay[k] - ay[k1]);
+                minDistSq = minDistSq < d ? minDistSq : d;
+            }
+            double mcd = (double)count * P.minCornerDistRate;
+            if (minDistSq < mcd * mcd) continue;
+            int tooNear = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (ax[k] < P.minDistToBorder || ay[k] < P.minDistToBorder || ax[k] > W - 1 - P.minDistToBorder ||
+                    ay[k] > H - 1 - P.minDistToBorder)
+                    tooNear = 1;
+            if (tooNear) continue;
+        }
+        if (lane == 0) {
+            int o = atomicAdd(&counts[f].ncand, 1);
+            if (o < P.maxCands) {
+                DevCand cd;
+                cd.scale = s;
+                cd.size = count;
+                cd.sx = x0;
+                cd.sy = y0;
+                cd.hole = hole;
+                cd.key = c.w;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    cd.c[2 * k] = (float)ax[k];
+                    cd.c[2 * k + 1] = (float)ay[k];
+                }
+                cands[(long long)f * P.maxCands + o] = cd;
+            } else {
+                atomicOr(&counts[f].overflow, 1);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K5a: restore OpenCV's candidate order (scale ascending; inside a scale cv::findContours returns the
+// RETR_LIST contours newest-first = discovery position descending) by rank sort, and apply
+// _reorderCandidatesCorners (aruco.cpp).  One workgroup per frame.
+__global__ __launch_bounds__(256) void k_sort_cands(const DevCand *__restrict__ cands, DevCand *__restrict__ sorted,
+                                                     DevCounts *__restrict__ counts, const DevParams P)
+{
+    extern __shared__ unsigned long long keys[];
+    const int f = blockIdx.x;
+    int n = counts[f].ncand;
+    n = n < P.maxCands ? n : P.maxCands;
+    const DevCand *src = cands + (long long)f * P.maxCands;
+    DevCand *dstc = sorted + (long long)f * P.maxCands;
+    for (int i = threadIdx.x; i < n; i += blockDim.x)
+        keys[i] = ((unsigned long long)(unsigned)src[i].scale << 32) | (0xffffffffu - src[i].key);
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        unsigned long long k = keys[i];
+        int rank = 0;
+        for (int j = 0; j < n; j++) rank += keys[j] < k;
+        DevCand c = src[i];
+        double dx1 = c.c[2] - c.c[0], dy1 = c.c[3] - c.c[1];
+        double dx2 = c.c[4] - c.c[0], dy2 = c.c[5] - c.c[1];
+        double cross = (dx1 * dy2) - (dy1 * dx2);
+        if (cross < 0.0) {
+            float tx = c.c[2], ty = c.c[3];
+            c.c[2] = c.c[6];
+            c.c[3] = c.c[7];
+            c.c[6] = tx;
+            c.c[7] = ty;
+        }
+        dstc[rank] = c;
+    }
+}
+
+// K5b: _filterTooCloseCandidates pair test (aruco.cpp): bit j of near[f][i][j>>5] for j > i.
+__global__ __launch_bounds__(256) void k_near(const DevCand *__restrict__ sorted, uint32_t *__restrict__ nearb,
+                                               const DevCounts *__restrict__ counts, const DevParams P)
+{
+    const int f = blockIdx.y;
+    int n = counts[f].ncand;
+    n = n < P.maxCands ? n : P.maxCands;
+    const int NW = P.maxCands >> 5;
+    const int nw = (n + 31) >> 5;
+    const DevCand *cs = sorted + (long long)f * P.maxCands;
+    uint32_t *nb = nearb + (long long)f * P.maxCands * NW;
+    for (int item = blockIdx.x * blockDim.x + threadIdx.x; item < n * nw; item += gridDim.x * blockDim.x) {
+        int i = item / nw, w = item % nw;
+        uint32_t bits = 0;
+        if (w * 32 + 31 > i) {
+            DevCand a = cs[i];
+            for (int b = 0; b < 32; b++) {
+                int j = w * 32 + b;
+                if (j <= i || j >= n) continue;
+                const DevCand &o = cs[j];
+                int minimumPerimeter = a.size < o.size ? a.size : o.size;
+                double mmd = (double)minimumPerimeter * P.minMarkerDistRate;
+                mmd = mmd * mmd;
+                for (int fc = 0; fc < 4; fc++) {
+                    double distSq = 0;
+                    for (int c = 0; c < 4; c++) {
+                        int modC = (c + fc) & 3;
+                        float ax = a.c[2 * modC] - o.c[2 * c];
+                        float ay = a.c[2 * modC + 1] - o.c[2 * c + 1];
+                        distSq += ax * ax + ay * ay;
+                    }
+                    distSq /= 4.;
+                    if (distSq < mmd) {
+                        bits |= 1u << b;
+                        break;
+                    }
+                }
+            }
+        }
+        nb[(long long)i * NW + w] = bits;
+    }
+}
+
+// K5c: the sequential part of _filterTooCloseCandidates: near pairs are visited in (i, j) order, a pair
+// whose members are both still alive removes the one with the smaller contour (ties: the first).
+// For a live i this means: scan its live near j > i in order; every j with size_j < size_i dies, the
+// first j with size_j >= size_i kills i and ends the row.  One wave per frame, lanes own 32-bit words.
+__global__ __launch_bounds__(64) void k_resolve(const DevCand *__restrict__ sorted, const uint32_t *__restrict__ nearb,
+                                                 DevCand *__restrict__ filtered, DevCounts *__restrict__ counts,
+                                                 unsigned *__restrict__ worklist, unsigned *__restrict__ nwork,
+                                                 const DevParams P)
+{
+    extern __shared__ int sizes[];  // maxCands
+    const int f = blockIdx.x, lane = lane_id();
+    int n = counts[f].ncand;
+    n = n < P.maxCands ? n : P.maxCands;
+    const int NW = P.maxCands >> 5;
+    const DevCand *cs = sorted + (long long)f * P.maxCands;
+    const uint32_t *nb = nearb + (long long)f * P.maxCands * NW;
+    for (int i = lane; i < n; i += 64) sizes[i] = cs[i].size;
+    __syncthreads();
+    // removed bits: lane l owns words l, l+64, ... (maxCands <= 4096 -> at most 2 words per lane)
+    uint32_t rem0 = 0, rem1 = 0;
+    const int nw = (n + 31) >> 5;
+    for (int i = 0; i < n; i++) {
+        int wi = i >> 5;
+        uint32_t rw = __shfl(wi < 64 ? rem0 : rem1, wi & 63, WAVE);
+        if ((rw >> (i & 31)) & 1u) continue;  // wave-uniform
+        int szi = sizes[i];
+        int firstKill = INT_MAX;
+        uint32_t live0 = 0, live1 = 0;
+        // each lane scans its words
+        for (int k = 0; k < 2; k++) {
+            int w = lane + 64 * k;
+            if (w < nw && w >= wi) {
+                uint32_t bits = nb[(long long)i * NW + w] & ~(k == 0 ? rem0 : rem1);
+                if (k == 0) live0 = bits; else live1 = bits;
+                uint32_t t = bits;
+                while (t) {
+                    int b = __ffs(t) - 1;
+                    t &= t - 1;
+                    int j = w * 32 + b;
+                    if (sizes[j] >= szi) {
+                        firstKill = firstKill < j ? firstKill : j;
+                        break;
+                    }
+                }
+            }
+        }
+        int jk = wave_min_i32(firstKill);
+        // every live near j < jk has size_j < size_i and is removed
+        for (int k = 0; k < 2; k++) {
+            int w = lane + 64 * k;
+            uint32_t bits = k == 0 ? live0 : live1;
+            if (bits) {
+                uint32_t m;
+                if (jk == INT_MAX || (jk >> 5) > w) m = 0xffffffffu;
+                else if ((jk >> 5) < w) m = 0;
+                else m = (1u << (jk & 31)) - 1u;
+                if (k == 0) rem0 |= bits & m; else rem1 |= bits & m;
+            }
+        }
+        if (jk != INT_MAX) {
+            if ((wi & 63) == lane) {
+                if (wi < 64) rem0 |= 1u << (i & 31); else rem1 |= 1u << (i & 31);
+            }
+        }
+    }
+    // compaction in order
+    int base = 0;
+    for (int w0 = 0; w0 < nw; w0 += 64) {
+        int w = w0 + lane;
+        uint32_t alive = 0;
+        if (w < nw) {
+            alive = ~(w0 == 0 ? rem0 : rem1);
+            int hi = n - w * 32;
+            if (hi < 32) alive &= (1u << hi) - 1u;
+        }
+        int cnt = __popc(alive);
+        int incl = wave_iscan(cnt);
+        int off = base + incl - cnt;
+        while (alive) {
+            int b = __ffs(alive) - 1;
+            alive &= alive - 1;
+            filtered[(long long)f * P.maxCands + off] = cs[w * 32 + b];
+            off++;
+        }
+        base += __shfl(incl, 63, WAVE);
+    }
+    if (lane == 0) {
+        counts[f].nfilt = base;
+        unsigned o = atomicAdd(nwork, (unsigned)base);
+        for (int k = 0; k < base; k++) worklist[o + k] = ((unsigned)f << 16) | (unsigned)k;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K6: _identifyOneCandidate (aruco.cpp): one wave per candidate.
+//   getPerspectiveTransform = 8x8 LU with partial pivoting (hal LU64f order), one matrix element per lane;
+//   warpPerspective(INTER_NEAREST) into an LDS patch; meanStdDev; Otsu (sequential, as
+//   getThreshVal_Otsu_8u); cell majority; border test; Dictionary::identify by XOR+popcount.
+__device__ __forceinline__ int sat_round_int(double v)
+{
+    // saturate_cast<int>(double) after the std::max/min clamp of WarpPerspectiveInvoker
+    v = fmax((double)INT_MIN, fmin((double)INT_MAX, v));
+    return (int)rint(v);
+}
+
+__global__ __launch_bounds__(64) void k_identify(const uint8_t *__restrict__ gray, long long gfstride,
+                                                  const DevCand *__restrict__ filtered, const unsigned *__restrict__ worklist,
+                                                  const unsigned *__restrict__ nwork, const uint8_t *__restrict__ dict,
+                                                  DevIdent *__restrict__ ident, const DevParams P)
+{
+    extern __shared__ uint8_t patch[];  // S*S bytes
+    __shared__ int hist[256];
+    __shared__ uint8_t cellbits[FID_MAX_CELLS * FID_MAX_CELLS];
+    __shared__ int s_thr;
+    const int lane = lane_id();
+    const unsigned n = *nwork;
+    const int ms = P.markerSize, bb = P.borderBits, msb = ms + 2 * bb, cellSize = P.cellSize;
+    const int SZ = msb * cellSize;
+    const int W = P.W, H = P.H;
+    for (unsigned wi = blockIdx.x; wi < n; wi += gridDim.x) {
+        const unsigned item = worklist[wi];
+        const int f = item >> 16, k = item & 0xffff;
+        const DevCand cd = filtered[(long long)f * P.maxCands + k];
+        const uint8_t *g = gray + (long long)f * gfstride;
+        DevIdent *out = ident + (long long)f * P.maxCands + k;
+        __syncthreads();
+        for (int i = lane; i < 256; i += 64) hist[i] = 0;
+        // ---- getPerspectiveTransform(src = candidate corners, dst = patch corners), lane = row*8 + col
+        const int row = lane >> 3, col = lane & 7;
+        double a, b;
+        {
+            const float fs1 = (float)SZ - 1.f;
+            const int pi = row & 3;
+            float sxp = cd.c[2 * pi], syp = cd.c[2 * pi + 1];
+            float dxp = (pi == 1 || pi == 2) ? fs1 : 0.f;
+            float dyp = (pi >= 2) ? fs1 : 0.f;
+            float dsel = row < 4 ? dxp : dyp;
+            // rows 0-3: [x y 1 0 0 0 -x*X -y*X], rows 4-7: [0 0 0 x y 1 -x*Y -y*Y]
+            double v = 0.;
+            int c3 = row < 4 ? col : col - 3;
+            if (col < 6) {
+                if (c3 == 0) v = sxp;
+                else if (c3 == 1) v = syp;
+                else if (c3 == 2) v = 1.;
+                else v = 0.;
+                if (row >= 4 && col < 3) v = 0.;
+                if (row < 4 && col >= 3) v = 0.;
+            } else if (col == 6) {
+                v = (double)(-sxp * dsel);
+            } else {
+                v = (double)(-syp * dsel);
+            }
+            a = v;
+            b = dsel;
+        }
+        int singular = 0;
+        for (int i = 0; i < 8; i++) {
+            // pivot search down column i
+            int kp = i;
+            double best = fabs(shfl_f64(a, i * 8 + i));
+            for (int j = i + 1; j < 8; j++) {
+                double v = fabs(shfl_f64(a, j * 8 + i));
+                if (v > best) {
+                    best = v;
+                    kp = j;
+                }
+            }
+            if (best < DBL_EPSILON * 100) {
+                singular = 1;
+                break;
+            }
+            if (kp != i) {
+                double ai = shfl_f64(a, i * 8 + col), ak = shfl_f64(a, kp * 8 + col);
+                double bi = shfl_f64(b, i * 8), bk = shfl_f64(b, kp * 8);
+                if (row == i) { a = ak; b = bk; }
+                else if (row == kp) { a = ai; b = bi; }
+            }
+            double d = -1 / shfl_f64(a, i * 8 + i);
+            double alpha = shfl_f64(a, row * 8 + i) * d;
+            double piv = shfl_f64(a, i * 8 + col);
+            double pb = shfl_f64(b, i * 8);
+            if (row > i) {
+                if (col > i) a += alpha * piv;
+                b += alpha * pb;
+            }
+        }
+        double M[9];
+        if (!singular) {
+            double x[8];
+#pragma unroll
+            for (int i = 7; i >= 0; i--) {
+                double s = shfl_f64(b, i * 8);
+#pragma unroll
+                for (int kk = i + 1; kk < 8; kk++) s -= shfl_f64(a, i * 8 + kk) * x[kk];
+                x[i] = s / shfl_f64(a, i * 8 + i);
+            }
+#pragma unroll
+            for (int i = 0; i < 8; i++) M[i] = x[i];
+            M[8] = 1.;
+        }
+        // ---- invert (cv::invert 3x3 fast path) and warp
+        double Mi[9];
+        int okinv = 0;
+        if (!singular) {
+#define Sd(r, c) M[(r)*3 + (c)]
+            double d = Sd(0, 0) * (Sd(1, 1) * Sd(2, 2) - Sd(1, 2) * Sd(2, 1)) - Sd(0, 1) * (Sd(1, 0) * Sd(2, 2) - Sd(1, 2) * Sd(2, 0)) +
+                       Sd(0, 2) * (Sd(1, 0) * Sd(2, 1) - Sd(1, 1) * Sd(2, 0));
+            if (d != 0.) {
+                okinv = 1;
+                d = 1. / d;
+                Mi[0] = (Sd(1, 1) * Sd(2, 2) - Sd(1, 2) * Sd(2, 1)) * d;
+                Mi[1] = (Sd(0, 2) * Sd(2, 1) - Sd(0, 1) * Sd(2, 2)) * d;
+                Mi[2] = (Sd(0, 1) * Sd(1, 2) - Sd(0, 2) * Sd(1, 1)) * d;
+                Mi[3] = (Sd(1, 2) * Sd(2, 0) - Sd(1, 0) * Sd(2, 2)) * d;
+                Mi[4] = (Sd(0, 0) * Sd(2, 2) - Sd(0, 2) * Sd(2, 0)) * d;
+                Mi[5] = (Sd(0, 2) * Sd(1, 0) - Sd(0, 0) * Sd(1, 2)) * d;
+                Mi[6] = (Sd(1, 0) * Sd(2, 1) - Sd(1, 1) * Sd(2, 0)) * d;
+                Mi[7] = (Sd(0, 1) * Sd(2, 0) - Sd(0, 0) * Sd(2, 1)) * d;
+                Mi[8] = (Sd(0, 0) * Sd(1, 1) - Sd(0, 1) * Sd(1, 0)) * d;
+            }
+#undef Sd
+        }
+        __syncthreads();
+        long long ssum = 0, ssq = 0;
+        const int in0 = cellSize / 2, in1 = SZ - cellSize / 2;
+        for (int p = lane; p < SZ * SZ; p += 64) {
+            int y = p / SZ, x1 = p - y * SZ;
+            uint8_t v = 0;
+            if (okinv) {
+                double X0 = Mi[0] * 0 + Mi[1] * y + Mi[2];
+                double Y0 = Mi[3] * 0 + Mi[4] * y + Mi[5];
+                double W0 = Mi[6] * 0 + Mi[7] * y + Mi[8];
+                double Wd = W0 + Mi[6] * x1;
+                Wd = Wd ? 1. / Wd : 0;
+                int X = sat_round_int((X0 + Mi[0] * x1) * Wd);
+                int Y = sat_round_int((Y0 + Mi[3] * x1) * Wd);
+                X = X < SHRT_MIN ? SHRT_MIN : (X > SHRT_MAX ? SHRT_MAX : X);
+                Y = Y < SHRT_MIN ? SHRT_MIN : (Y > SHRT_MAX ? SHRT_MAX : Y);
+                if ((unsigned)X < (unsigned)W && (unsigned)Y < (unsigned)H) v = g[(long long)Y * P.gstride + X];
+            }
+            patch[p] = v;
+            atomicAdd(&hist[v], 1);
+            if (y >= in0 && y < in1 && x1 >= in0 && x1 < in1) {
+                ssum += v;
+                ssq += (int)v * (int)v;
+            }
+        }
+        ssum = wave_sum_i64(ssum);
+        ssq = wave_sum_i64(ssq);
+        __syncthreads();
+        // ---- meanStdDev on the inner region
+        const int nin = (in1 - in0) * (in1 - in0);
+        double scale = nin ? 1. / nin : 0.;
+        double mean = ssum * scale;
+        double var = ssq * scale - mean * mean;
+        double stddev = sqrt(var > 0. ? var : 0.);
+        int uniform_bits = -1;
+        if (stddev < P.minOtsuStdDev) uniform_bits = mean > 127 ? 1 : 0;
+        if (uniform_bits < 0) {
+            // getThreshVal_Otsu_8u, sequential over the 256 bins (lane 0)
+            if (lane == 0) {
+                const int N = 256;
+                double mu = 0, sc = 1. / (SZ * SZ);
+                for (int i = 0; i < N; i++) mu += i * (double)hist[i];
+                mu *= sc;
+                double mu1 = 0, q1 = 0, max_sigma = 0, max_val = 0;
+                for (int i = 0; i < N; i++) {
+                    double p_i = hist[i] * sc;
+                    mu1 *= q1;
+                    q1 += p_i;
+                    double q2 = 1. - q1;
+                    if (fmin(q1, q2) < FLT_EPSILON || fmax(q1, q2) > 1. - FLT_EPSILON) continue;
+                    mu1 = (mu1 + i * p_i) / q1;
+                    double mu2 = (mu - q1 * mu1) / q2;
+                    double sigma = q1 * q2 * (mu1 - mu2) * (mu1 - mu2);
+                    if (sigma > max_sigma) {
+                        max_sigma = sigma;
+                        max_val = i;
+                    }
+                }
+                s_thr = (int)floor(max_val);
+            }
+            __syncthreads();
+            const int thr = s_thr;
+            const int cs = cellSize - 2 * P.cellMargin;
+            for (int c = lane; c < msb * msb; c += 64) {
+                int cy = c / msb, cx = c - cy * msb;
+                int Xs = cx * cellSize + P.cellMargin, Ys = cy * cellSize + P.cellMargin;
+                int nz = 0;
+                for (int yy = 0; yy < cs; yy++)
+                    for (int xx = 0; xx < cs; xx++) nz += patch[(Ys + yy) * SZ + Xs + xx] > thr;
+                cellbits[c] = (unsigned)nz > (unsigned)(cs * cs) / 2 ? 1 : 0;
+            }
+        } else {
+            for (int c = lane; c < msb * msb; c += 64) cellbits[c] = (uint8_t)uniform_bits;
+        }
+        __syncthreads();
+        for (int c = lane; c < msb * msb; c += 64) out->bits[c] = cellbits[c];
+        // ---- _getBorderErrors (every lane computes the same scalar answer from LDS)
+        int borderErrors = 0;
+        for (int y = 0; y < msb; y++)
+            for (int kk = 0; kk < bb; kk++) {
+                borderErrors += cellbits[y * msb + kk] != 0;
+                borderErrors += cellbits[y * msb + msb - 1 - kk] != 0;
+            }
+        for (int x = bb; x < msb - bb; x++)
+            for (int kk = 0; kk < bb; kk++) {
+                borderErrors += cellbits[kk * msb + x] != 0;
+                borderErrors += cellbits[(msb - 1 - kk) * msb + x] != 0;
+            }
+        int id = -1, rot = -1;
+        if (borderErrors <= P.maxBorderErr) {
+            // candidate bytes (Dictionary::getByteListFromBits, rotation 0), nbytes <= 8
+            unsigned long long cw = 0;
+            {
+                const int nb2 = ms * ms;
+                for (int t = 0; t < nb2; t++) {
+                    int r = t / ms, c = t - r * ms;
+                    int byte = t >> 3, q = t & 7;
+                    int inbyte = nb2 - 8 * byte;
+                    inbyte = inbyte > 8 ? 8 : inbyte;  // the last partial byte is right-aligned
+                    unsigned long long bit = cellbits[(r + bb) * msb + c + bb];
+                    cw |= bit << (8 * byte + (inbyte - 1 - q));
+                }
+            }
+            const int nbytes = P.nbytes;
+            int bestm = INT_MAX, bestr = 0;
+            for (int m0 = 0; m0 < P.nMarkers; m0 += 64) {
+                int mi = m0 + lane;
+                int myr = -1;
+                if (mi < P.nMarkers) {
+                    int cmin = ms * ms + 1;
+                    for (int r = 0; r < 4; r++) {
+                        const uint8_t *t = dict + ((long long)mi * 4 + r) * nbytes;
+                        unsigned long long tw = 0;
+                        for (int q = 0; q < nbytes; q++) tw |= (unsigned long long)t[q] << (8 * q);
+                        int ham = __popcll(tw ^ cw);
+                        if (ham < cmin) {
+                            cmin = ham;
+                            myr = r;
+                        }
+                    }
+                    if (cmin > P.maxCorr) myr = -1;
+                }
+                unsigned long long hit = ballot64(myr >= 0);
+                if (hit) {
+                    int src = __ffsll((long long)hit) - 1;
+                    bestm = m0 + src;
+                    bestr = __shfl(myr, src, WAVE);
+                    break;
+                }
+            }
+            if (bestm != INT_MAX) {
+                id = bestm;
+                rot = bestr;
+            }
+        }
+        if (lane == 0) {
+            out->id = id;
+            out->rot = rot;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K7a: collect identified candidates in order, rotate corners (std::rotate by 4 - rotation) and apply
+// _filterDetectedMarkers (aruco.cpp; pointPolygonTest from geometry.cpp).  One wave per frame.
+__device__ __forceinline__ double point_polygon_test4(const float *cnt, float ptx, float pty)
+{
+    int counter = 0;
+    float vx = cnt[6], vy = cnt[7], v0x, v0y;
+    for (int i = 0; i < 4; i++) {
+        v0x = vx;
+        v0y = vy;
+        vx = cnt[2 * i];
+        vy = cnt[2 * i + 1];
+        if ((v0y <= pty && vy <= pty) || (v0y > pty && vy > pty) || (v0x < ptx && vx < ptx)) {
+            if (pty == vy && (ptx == vx || (pty == v0y && ((v0x <= ptx && ptx <= vx) || (vx <= ptx && ptx <= v0x))))) return 0;
+            continue;
+        }
+        double dist = (double)(pty - v0y) * (vx - v0x) - (double)(ptx - v0x) * (vy - v0y);
+        if (dist == 0) return 0;
+        if (vy < v0y) dist = -dist;
+        counter += dist > 0;
+    }
+    return counter % 2 == 0 ? -1 : 1;
+}
+
+__global__ __launch_bounds__(64) void k_filter_markers(const DevCand *__restrict__ filtered, const DevIdent *__restrict__ ident,
+                                                        fid_marker *__restrict__ pre, DevCounts *__restrict__ counts,
+                                                        const DevParams P)
+{
+    extern __shared__ fid_marker acc[];  // maxCands
+    const int f = blockIdx.x, lane = lane_id();
+    int nf = counts[f].nfilt;
+    const DevCand *cs = filtered + (long long)f * P.maxCands;
+    const DevIdent *idn = ident + (long long)f * P.maxCands;
+    int base = 0;
+    for (int k0 = 0; k0 < nf; k0 += 64) {
+        int k = k0 + lane;
+        int id = -1, rot = 0;
+        if (k < nf) {
+            id = idn[k].id;
+            rot = idn[k].rot;
+        }
+        unsigned long long hit = ballot64(id >= 0);
+        int off = base + __popcll(hit & ((1ull << lane) - 1ull));
+        if (id >= 0) {
+            fid_marker m;
+            m.id = id;
+            for (int c = 0; c < 4; c++) {
+                int sc = (c + 4 - rot) & 3;
+                m.corners[2 * c] = cs[k].c[2 * sc];
+                m.corners[2 * c + 1] = cs[k].c[2 * sc + 1];
+            }
+            acc[off] = m;
+        }
+        base += __popcll(hit);
+    }
+    const int nacc = base;
+    __syncthreads();
+    // toRemove flags: pure function of the pairs (the loops never test toRemove before comparing)
+    int outbase = 0;
+    for (int j0 = 0; j0 < nacc; j0 += 64) {
+        int j = j0 + lane;
+        int removed = 0;
+        if (j < nacc) {
+            for (int i = 0; i < nacc; i++) {
+                if (i == j || acc[i].id != acc[j].id) continue;
+                int a = i < j ? i : j, bq = i < j ? j : i;  // pair (a, b), a < b
+                // first: is b inside a?  then: is a inside b?
+                int b_in_a = 1;
+                for (int q = 0; q < 4; q++)
+                    if (point_polygon_test4(acc[a].corners, acc[bq].corners[2 * q], acc[bq].corners[2 * q + 1]) < 0) {
+                        b_in_a = 0;
+                        break;
+                    }
+                if (b_in_a) {
+                    if (j == bq) removed = 1;
+                    continue;
+                }
+                int a_in_b = 1;
+                for (int q = 0; q < 4; q++)
+                    if (point_polygon_test4(acc[bq].corners, acc[a].corners[2 * q], acc[a].corners[2 * q + 1]) < 0) {
+                        a_in_b = 0;
+                        break;
+                    }
+                if (a_in_b && j == a) removed = 1;
+            }
+        }
+        int keep = j < nacc && !removed;
+        unsigned long long hit = ballot64(keep);
+        int off = outbase + __popcll(hit & ((1ull << lane) - 1ull));
+        if (keep) {
+            if (off < P.maxMarkers) pre[(long long)f * P.maxMarkers + off] = acc[j];
+        }
+        outbase += __popcll(hit);
+    }
+    if (lane == 0) {
+        counts[f].nacc = nacc;
+        if (outbase > P.maxMarkers) {
+            atomicOr(&counts[f].overflow, 2);
+            outbase = P.maxMarkers;
+        }
+        counts[f].nmark = outbase;
+    }
+}
+
+// K7b: cornerSubPix (cornersubpix.cpp) with getRectSubPix 8u->32f (samplers.cpp), one wave per corner.
+// The (2w+3)^2 patch and the per-tap products are computed in parallel; the five accumulators are summed
+// by lane 0 in the reference's (i, j) order so the float corner equals the sequential result bit for bit.
+#define SP_MAXWIN 7
+__global__ __launch_bounds__(64) void k_subpix(const uint8_t *__restrict__ gray, long long gfstride,
+                                                const fid_marker *__restrict__ pre, fid_marker *__restrict__ out,
+                                                const DevCounts *__restrict__ counts, const float *__restrict__ maskw,
+                                                const DevParams P)
+{
+    __shared__ float sp[(2 * SP_MAXWIN + 3) * (2 * SP_MAXWIN + 3)];
+    __shared__ double prod[5][(2 * SP_MAXWIN + 1) * (2 * SP_MAXWIN + 1)];
+    __shared__ float s_c[2];
+    __shared__ int s_flag;
+    const int lane = lane_id();
+    const int win = P.subpixWin, ww = 2 * win + 1, pw = ww + 2;
+    const int W = P.W, H = P.H, gs = P.gstride;
+    const int total = P.nframes * P.maxMarkers * 4;
+    for (int item = blockIdx.x; item < total; item += gridDim.x) {
+        int f = item / (P.maxMarkers * 4), r = item % (P.maxMarkers * 4);
+        int mk = r >> 2, cn = r & 3;
+        if (mk >= counts[f].nmark) continue;
+        const fid_marker *src = pre + (long long)f * P.maxMarkers + mk;
+        fid_marker *dstm = out + (long long)f * P.maxMarkers + mk;
+        const uint8_t *g = gray + (long long)f * gfstride;
+        if (cn == 0 && lane == 0) dstm->id = src->id;
+        const float cTx = src->corners[2 * cn], cTy = src->corners[2 * cn + 1];
+        float cIx = cTx, cIy = cTy;
+        if (!P.refine) {
+            if (lane == 0) {
+                dstm->corners[2 * cn] = cTx;
+                dstm->corners[2 * cn + 1] = cTy;
+            }
+            continue;
+        }
+        int iter = 0;
+        for (;;) {
+            // getRectSubPix(src, (pw, pw), cI) -> sp
+            float cx = cIx - (pw - 1) * 0.5f, cy = cIy - (pw - 1) * 0.5f;
+            int ipx = (int)floorf(cx), ipy = (int)floorf(cy);
+            __syncthreads();
+            if (0 <= ipx && ipx + pw < W && 0 <= ipy && ipy + pw < H) {
+                // getRectSubPix_8u32f fast path: dst[j] = prev_j + t_j, prev_0 = (1-a)(b1 s[0] + b2 s[step]),
+                // prev_j = (float)(t_{j-1} * s), t_j = a12 s[j+1] + a22 s[j+1+step]
+                float a = cx - ipx, b = cy - ipy;
+                a = a > 0.0001f ? a : 0.0001f;
+                float a12 = a * (1.f - b), a22 = a * b, b1 = 1.f - b, b2 = b;
+                double s = (1. - a) / a;
+                const uint8_t *s0 = g + (long long)ipy * gs + ipx;
+                for (int p = lane; p < pw * pw; p += 64) {
+                    int i = p / pw, j = p - i * pw;
+                    const uint8_t *sr = s0 + (long long)i * gs;
+                    float t = a12 * sr[j + 1] + a22 * sr[j + 1 + gs];
+                    float prev;
+                    if (j == 0) {
+                        prev = (1 - a) * (b1 * sr[0] + b2 * sr[gs]);
+                    } else {
+                        float tp = a12 * sr[j] + a22 * sr[j + gs];
+                        prev = (float)(tp * s);
+                    }
+                    sp[p] = prev + t;
+                }
+            } else {
+                // getRectSubPix_Cn_ with replicated border (adjustRect semantics == clamped coordinates)
+                float a = cx - ipx, b = cy - ipy;
+                float a11 = (1.f - a) * (1.f - b), a12 = a * (1.f - b), a21 = (1.f - a) * b, a22 = a * b;
+                float b1 = 1.f - b, b2 = b;
+                int inside = 0 <= ipx && ipx < W - pw && 0 <= ipy && ipy < H - pw;
+                // emulate adjustRect: r = [rx, rw) x [ry, rh) are the columns/rows that interpolate normally
+                int rx, ry, rw, rh;
+                long long basey, basex;
+                {
+                    int x = ipx, y = ipy;
+                    basey = 0; basex = 0;
+                    if (y >= 0) { basey += y; ry = 0; } else ry = -y < pw ? -y : pw;
+                    if (y + pw < H) rh = pw; else { rh = H - y - 1; if (rh < 0) { basey += rh; rh = 0; } }
+                    if (x >= 0) { basex += x; rx = 0; } else rx = -x < pw ? -x : pw;
+                    if (x + pw < W) rw = pw; else { rw = W - x - 1; if (rw < 0) { basex += rw; rw = 0; } }
+                    basex -= rx;
+                }
+                for (int p = lane; p < pw * pw; p += 64) {
+                    int i = p / pw, j = p - i * pw;
+                    float v;
+                    if (inside) {
+                        const uint8_t *sr = g + (long long)(ipy + i) * gs + ipx;
+                        v = sr[j] * a11 + sr[j + 1] * a12 + sr[j + gs] * a21 + sr[j + gs + 1] * a22;
+                    } else {
+                        // row pointer after i iterations of the reference loop: src advances only while
+                        // ry <= row < rh
+                        int adv = 0;
+                        {
+                            int lo = ry, hi = rh < i ? rh : i;  // rows r in [0, i) with r >= ry && r < rh advance
+                            adv = hi > lo ? hi - lo : 0;
+                        }
+                        long long y0r = basey + adv;
+                        long long y1r = (i < ry || i >= rh) ? y0r : y0r + 1;
+                        const uint8_t *sr = g + y0r * gs + basex;
+                        const uint8_t *sr2 = g + y1r * gs + basex;
+                        if (j < rx) v = sr[rx] * b1 + sr2[rx] * b2;
+                        else if (j < rw) v = sr[j] * a11 + sr[j + 1] * a12 + sr2[j] * a21 + sr2[j + 1] * a22;
+                        else v = sr[rw] * b1 + sr2[rw] * b2;
+                    }
+                    sp[p] = v;
+                }
+            }
+            __syncthreads();
+            for (int t = lane; t < ww * ww; t += 64) {
+                int i = t / ww, j = t - i * ww;
+                const float *q = sp + (i + 1) * pw + (j + 1);
+                double m = maskw[t];
+                double tgx = q[1] - q[-1];
+                double tgy = q[pw] - q[-pw];
+                double gxx = tgx * tgx * m, gxy = tgx * tgy * m, gyy = tgy * tgy * m;
+                double px = j - win, py = i - win;
+                prod[0][t] = gxx;
+                prod[1][t] = gxy;
+                prod[2][t] = gyy;
+                prod[3][t] = gxx * px + gxy * py;
+                prod[4][t] = gxy * px + gyy * py;
+            }
+            __syncthreads();
+            if (lane == 0) {
+                double a = 0, b = 0, c = 0, bb1 = 0, bb2 = 0;
+                for (int t = 0; t < ww * ww; t++) {
+                    a += prod[0][t];
+                    b += prod[1][t];
+                    c += prod[2][t];
+                    bb1 += prod[3][t];
+                    bb2 += prod[4][t];
+                }
+                int flag = 0;  // 0 continue, 1 stop
+                double det = a * c - b * b;
+                if (fabs(det) <= DBL_EPSILON * DBL_EPSILON) {
+                    flag = 1;
+                } else {
+                    double scale = 1.0 / det;
+                    float nx = (float)(cIx + c * scale * bb1 - b * scale * bb2);
+                    float ny = (float)(cIy - b * scale * bb1 + a * scale * bb2);
+                    double err = (nx - cIx) * (nx - cIx) + (ny - cIy) * (ny - cIy);
+                    s_c[0] = nx;
+                    s_c[1] = ny;
+                    if (nx < 0 || nx >= W || ny < 0 || ny >= H) flag = 1;
+                    else if (!(iter + 1 < P.subpixMaxIter && err > P.subpixEps)) flag = 1;
+                    flag |= 2;  // moved
+                }
+                s_flag = flag;
+            }
+            __syncthreads();
+            int flag = s_flag;
+            if (flag & 2) {
+                cIx = s_c[0];
+                cIy = s_c[1];
+            }
+            iter++;
+            if (flag & 1) break;
+        }
+        if (fabsf(cIx - cTx) > win || fabsf(cIy - cTy) > win) {
+            cIx = cTx;
+            cIy = cTy;
+        }
+        if (lane == 0) {
+            dstm->corners[2 * cn] = cIx;
+            dstm->corners[2 * cn + 1] = cIy;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K8: per-marker pose = cv::solvePnP(SOLVEPNP_ITERATIVE) for 4 coplanar points as
+// calibration.cpp cvFindExtrinsicCameraParams2 does it (undistort -> normalised-DLT homography ->
+// R,t -> Levenberg-Marquardt on the distorted reprojection error, CvLevMarq state machine), followed by
+// getReprojectionError / calcFiducialArea / object_error of aruco_detect.cpp:203-221,179-200,493-495.
+// One lane per marker; double precision; the symmetric eigenproblems use cyclic Jacobi.
+template <int N>
+__device__ void jacobi_eigen(double *A, double *w, double *V)
+{
+    for (int i = 0; i < N; i++)
+        for (int j = 0; j < N; j++) V[i * N + j] = i == j ? 1. : 0.;
+    for (int sweep = 0; sweep < 60; sweep++) {
+        double off = 0;
+        for (int p = 0; p < N; p++)
+            for (int q = p + 1; q < N; q++) off += A[p * N + q] * A[p * N + q];
+        if (off < 1e-300) break;
+        for (int p = 0; p < N; p++)
+            for (int q = p + 1; q < N; q++) {
+                double apq = A[p * N + q];
+                if (fabs(apq) < 1e-300) continue;
+                double app = A[p * N + p], aqq = A[q * N + q];
+                double theta = (aqq - app) / (2. * apq);
+                double t = (theta >= 0 ? 1. : -1.) / (fabs(theta) + sqrt(theta * theta + 1.));
+                double c = 1. / sqrt(t * t + 1.), s = t * c;
+                for (int k = 0; k < N; k++) {
+                    double akp = A[k * N + p], akq = A[k * N + q];
+                    A[k * N + p] = c * akp - s * akq;
+                    A[k * N + q] = s * akp + c * akq;
+                }
+                for (int k = 0; k < N; k++) {
+                    double apk = A[p * N + k], aqk = A[q * N + k];
+                    A[p * N + k] = c * apk - s * aqk;
+                    A[q * N + k] = s * apk + c * aqk;
+                }
+                for (int k = 0; k < N; k++) {
+                    double vpk = V[p * N + k], vqk = V[q * N + k];
+                    V[p * N + k] = c * vpk - s * vqk;
+                    V[q * N + k] = s * vpk + c * vqk;
+                }
+            }
+    }
+    for (int i = 0; i < N; i++) w[i] = A[i * N + i];
+    for (int i = 0; i < N - 1; i++) {
+        int m = i;
+        for (int j = i + 1; j < N; j++)
+            if (w[j] > w[m]) m = j;
+        if (m != i) {
+            double t = w[i];
+            w[i] = w[m];
+            w[m] = t;
+            for (int k = 0; k < N; k++) {
+                t = V[i * N + k];
+                V[i * N + k] = V[m * N + k];
+                V[m * N + k] = t;
+            }
+        }
+    }
+}
+
+__device__ void mat3_mul(const double *A, const double *B, double *C)
+{
+    double T[9];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) T[i * 3 + j] = A[i * 3] * B[j] + A[i * 3 + 1] * B[3 + j] + A[i * 3 + 2] * B[6 + j];
+    for (int i = 0; i < 9; i++) C[i] = T[i];
+}
+
+__device__ void orthonormalize3(double *R)
+{
+    double RtR[9], w[3], V[9];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) RtR[i * 3 + j] = R[i] * R[j] + R[3 + i] * R[3 + j] + R[6 + i] * R[6 + j];
+    jacobi_eigen<3>(RtR, w, V);
+    double Pm[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int k = 0; k < 3; k++) {
+        double is = w[k] > 1e-300 ? 1. / sqrt(w[k]) : 0.;
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) Pm[i * 3 + j] += V[k * 3 + i] * V[k * 3 + j] * is;
+    }
+    mat3_mul(R, Pm, R);
+}
+
+__device__ void rodrigues_v2m(const double *r_in, double *R, double *J)
+{
+    double rx = r_in[0], ry = r_in[1], rz = r_in[2];
+    double theta = sqrt(rx * rx + ry * ry + rz * rz);
+    if (theta < DBL_EPSILON) {
+        for (int i = 0; i < 9; i++) R[i] = (i % 4 == 0) ? 1. : 0.;
+        if (J) {
+            for (int i = 0; i < 27; i++) J[i] = 0;
+            J[5] = J[15] = J[19] = -1;
+            J[7] = J[11] = J[21] = 1;
+        }
+        return;
+    }
+    double c = cos(theta), s = sin(theta), c1 = 1. - c, itheta = theta ? 1. / theta : 0.;
+    rx *= itheta;
+    ry *= itheta;
+    rz *= itheta;
+    double rrt[9] = {rx * rx, rx * ry, rx * rz, rx * ry, ry * ry, ry * rz, rx * rz, ry * rz, rz * rz};
+    double r_x[9] = {0, -rz, ry, rz, 0, -rx, -ry, rx, 0};
+    for (int k = 0; k < 9; k++) R[k] = c * ((k % 4 == 0) ? 1. : 0.) + c1 * rrt[k] + s * r_x[k];
+    if (J) {
+        const double I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+        double drrt[27] = {rx + rx, ry, rz, ry, 0,       0,  rz, 0,  0,       0, rx, 0, rx, ry + ry,
+                           rz,      0,  rz, 0,  0,       0,  rx, 0,  0,       ry, rx, ry, rz + rz};
+        const double d_r_x_[27] = {0, 0, 0, 0, 0, -1, 0, 1, 0, 0, 0, 1, 0, 0, 0, -1, 0, 0, 0, -1, 0, 1, 0, 0, 0, 0, 0};
+        for (int i = 0; i < 3; i++) {
+            double ri = i == 0 ? rx : i == 1 ? ry : rz;
+            double a0 = -s * ri, a1 = (s - 2 * c1 * itheta) * ri, a2 = c1 * itheta;
+            double a3 = (c - s * itheta) * ri, a4 = s * itheta;
+            for (int k = 0; k < 9; k++)
+                J[i * 9 + k] = a0 * I[k] + a1 * rrt[k] + a2 * drrt[i * 9 + k] + a3 * r_x[k] + a4 * d_r_x_[i * 9 + k];
+        }
+    }
+}
+
+__device__ void rodrigues_m2v(const double *Rin, double *r)
+{
+    double R[9];
+    for (int i = 0; i < 9; i++) R[i] = Rin[i];
+    orthonormalize3(R);
+    double rx = R[7] - R[5], ry = R[2] - R[6], rz = R[3] - R[1];
+    double s = sqrt((rx * rx + ry * ry + rz * rz) * 0.25);
+    double c = (R[0] + R[4] + R[8] - 1) * 0.5;
+    c = c > 1. ? 1. : c < -1. ? -1. : c;
+    double theta = acos(c);
+    if (s < 1e-5) {
+        double t;
+        if (c > 0)
+            rx = ry = rz = 0;
+        else {
+            t = (R[0] + 1) * 0.5;
+            rx = sqrt(t > 0. ? t : 0.);
+            t = (R[4] + 1) * 0.5;
+            ry = sqrt(t > 0. ? t : 0.) * (R[1] < 0 ? -1. : 1.);
+            t = (R[8] + 1) * 0.5;
+            rz = sqrt(t > 0. ? t : 0.) * (R[2] < 0 ? -1. : 1.);
+            if (fabs(rx) < fabs(ry) && fabs(rx) < fabs(rz) && (R[5] > 0) != (ry * rz > 0)) rz = -rz;
+            theta /= sqrt(rx * rx + ry * ry + rz * rz);
+            rx *= theta;
+            ry *= theta;
+            rz *= theta;
+        }
+    } else {
+        double vth = 1 / (2 * s);
+        vth *= theta;
+        rx *= vth;
+        ry *= vth;
+        rz *= vth;
+    }
+    r[0] = rx;
+    r[1] = ry;
+    r[2] = rz;
+}
+
+// cvProjectPoints2Internal for 4 points, plumb-bob k1 k2 p1 p2 k3
+__device__ void project4(const double *M, const double *rv, const double *tv, const double *K, const double *k,
+                         double *m, double *dpdr, double *dpdt)
+{
+    double R[9], dRdr[27];
+    rodrigues_v2m(rv, R, dpdr ? dRdr : nullptr);
+    double fx = K[0], fy = K[4], cx = K[2], cy = K[5];
+    for (int i = 0; i < 4; i++) {
+        double X = M[i * 3], Y = M[i * 3 + 1], Z = M[i * 3 + 2];
+        double x = R[0] * X + R[1] * Y + R[2] * Z + tv[0];
+        double y = R[3] * X + R[4] * Y + R[5] * Z + tv[1];
+        double z = R[6] * X + R[7] * Y + R[8] * Z + tv[2];
+        z = z ? 1. / z : 1;
+        x *= z;
+        y *= z;
+        double r2 = x * x + y * y, r4 = r2 * r2, r6 = r4 * r2;
+        double a1 = 2 * x * y, a2 = r2 + 2 * x * x, a3 = r2 + 2 * y * y;
+        double cdist = 1 + k[0] * r2 + k[1] * r4 + k[4] * r6;
+        double icdist2 = 1.;
+        double xd = x * cdist * icdist2 + k[2] * a1 + k[3] * a2;
+        double yd = y * cdist * icdist2 + k[2] * a3 + k[3] * a1;
+        m[i * 2] = xd * fx + cx;
+        m[i * 2 + 1] = yd * fy + cy;
+        if (dpdt) {
+            double dxdt[3] = {z, 0, -x * z}, dydt[3] = {0, z, -y * z};
+            for (int j = 0; j < 3; j++) {
+                double dr2dt = 2 * x * dxdt[j] + 2 * y * dydt[j];
+                double dcdist_dt = k[0] * dr2dt + 2 * k[1] * r2 * dr2dt + 3 * k[4] * r4 * dr2dt;
+                double da1dt = 2 * (x * dydt[j] + y * dxdt[j]);
+                double dmxdt = (dxdt[j] * cdist * icdist2 + x * dcdist_dt * icdist2 + k[2] * da1dt + k[3] * (dr2dt + 4 * x * dxdt[j]));
+                double dmydt = (dydt[j] * cdist * icdist2 + y * dcdist_dt * icdist2 + k[2] * (dr2dt + 4 * y * dydt[j]) + k[3] * da1dt);
+                dpdt[(2 * i) * 3 + j] = fx * dmxdt;
+                dpdt[(2 * i + 1) * 3 + j] = fy * dmydt;
+            }
+        }
+        if (dpdr) {
+            double dx0dr[3] = {X * dRdr[0] + Y * dRdr[1] + Z * dRdr[2], X * dRdr[9] + Y * dRdr[10] + Z * dRdr[11],
+                               X * dRdr[18] + Y * dRdr[19] + Z * dRdr[20]};
+            double dy0dr[3] = {X * dRdr[3] + Y * dRdr[4] + Z * dRdr[5], X * dRdr[12] + Y * dRdr[13] + Z * dRdr[14],
+                               X * dRdr[21] + Y * dRdr[22] + Z * dRdr[23]};
+            double dz0dr[3] = {X * dRdr[6] + Y * dRdr[7] + Z * dRdr[8], X * dRdr[15] + Y * dRdr[16] + Z * dRdr[17],
+                               X * dRdr[24] + Y * dRdr[25] + Z * dRdr[26]};
+            for (int j = 0; j < 3; j++) {
+                double dxdr = z * (dx0dr[j] - x * dz0dr[j]);
+                double dydr = z * (dy0dr[j] - y * dz0dr[j]);
+                double dr2dr = 2 * x * dxdr + 2 * y * dydr;
+                double dcdist_dr = (k[0] + 2 * k[1] * r2 + 3 * k[4] * r4) * dr2dr;
+                double da1dr = 2 * (x * dydr + y * dxdr);
+                double dmxdr = (dxdr * cdist * icdist2 + x * dcdist_dr * icdist2 + k[2] * da1dr + k[3] * (dr2dr + 4 * x * dxdr));
+                double dmydr = (dydr * cdist * icdist2 + y * dcdist_dr * icdist2 + k[2] * (dr2dr + 4 * y * dydr) + k[3] * da1dr);
+                dpdr[(2 * i) * 3 + j] = fx * dmxdr;
+                dpdr[(2 * i + 1) * 3 + j] = fy * dmydr;
+            }
+        }
+    }
+}
+
+// fundam.cpp HomographyEstimatorCallback::runKernel on 4 correspondences (float inputs)
+__device__ int homography4(const double *Mxy, const double *mn, double *H)
+{
+    const int count = 4;
+    float Mf[8], mf[8];
+    for (int i = 0; i < 8; i++) {
+        Mf[i] = (float)Mxy[i];
+        mf[i] = (float)mn[i];
+    }
+    double LtL[81], Wv[9], V[81];
+    double cMx = 0, cMy = 0, cmx = 0, cmy = 0, sMx = 0, sMy = 0, smx = 0, smy = 0;
+    for (int i = 0; i < count; i++) {
+        cmx += mf[2 * i];
+        cmy += mf[2 * i + 1];
+        cMx += Mf[2 * i];
+        cMy += Mf[2 * i + 1];
+    }
+    cmx /= count;
+    cmy /= count;
+    cMx /= count;
+    cMy /= count;
+    for (int i = 0; i < count; i++) {
+        smx += fabs(mf[2 * i] - cmx);
+        smy += fabs(mf[2 * i + 1] - cmy);
+        sMx += fabs(Mf[2 * i] - cMx);
+        sMy += fabs(Mf[2 * i + 1] - cMy);
+    }
+    if (fabs(smx) < DBL_EPSILON || fabs(smy) < DBL_EPSILON || fabs(sMx) < DBL_EPSILON || fabs(sMy) < DBL_EPSILON) return 0;
+    smx = count / smx;
+    smy = count / smy;
+    sMx = count / sMx;
+    sMy = count / sMy;
+    double invHnorm[9] = {1. / smx, 0, cmx, 0, 1. / smy, cmy, 0, 0, 1};
+    double Hnorm2[9] = {sMx, 0, -cMx * sMx, 0, sMy, -cMy * sMy, 0, 0, 1};
+    for (int i = 0; i < 81; i++) LtL[i] = 0;
+    for (int i = 0; i < count; i++) {
+        double x = (mf[2 * i] - cmx) * smx, y = (mf[2 * i + 1] - cmy) * smy;
+        double X = (Mf[2 * i] - cMx) * sMx, Y = (Mf[2 * i + 1] - cMy) * sMy;
+        double Lx[9] = {X, Y, 1, 0, 0, 0, -x * X, -x * Y, -x};
+        double Ly[9] = {0, 0, 0, X, Y, 1, -y * X, -y * Y, -y};
+        for (int j = 0; j < 9; j++)
+            for (int k = j; k < 9; k++) LtL[j * 9 + k] += Lx[j] * Lx[k] + Ly[j] * Ly[k];
+    }
+    for (int j = 0; j < 9; j++)
+        for (int k = 0; k < j; k++) LtL[j * 9 + k] = LtL[k * 9 + j];
+    jacobi_eigen<9>(LtL, Wv, V);
+    double H0[9], T[9];
+    for (int i = 0; i < 9; i++) H0[i] = V[8 * 9 + i];
+    mat3_mul(invHnorm, H0, T);
+    mat3_mul(T, Hnorm2, H0);
+    if (H0[8] == 0) return 0;
+    double sc = 1. / H0[8];
+    for (int i = 0; i < 9; i++) H[i] = H0[i] * sc;
+    return 1;
+}
+
+__device__ double dist2f_d(float x1f, float y1f, float x2f, float y2f)
+{
+    double x1 = x1f, y1 = y1f, x2 = x2f, y2 = y2f;
+    double dx = x1 - x2, dy = y1 - y2;
+    return sqrt(dx * dx + dy * dy);
+}
+
+struct PoseCam {
+    double K[9];
+    double D[5];
+    double fiducial_len;
+};
+
+__device__ void lm_step(const double *JtJ, const double *JtErr, const double *prevParam, double *param, int lambdaLg10)
+{
+    const double LOG10 = log(10.);
+    double lambda = exp(lambdaLg10 * LOG10);
+    double A[36], w[6], V[36];
+    for (int i = 0; i < 36; i++) A[i] = JtJ[i];
+    for (int i = 0; i < 6; i++) A[i * 6 + i] *= 1. + lambda;
+    jacobi_eigen<6>(A, w, V);
+    double thr = 0;
+    for (int i = 0; i < 6; i++) thr += fabs(w[i]);
+    thr *= DBL_EPSILON * 2;
+    double x[6] = {0, 0, 0, 0, 0, 0};
+    for (int k = 0; k < 6; k++) {
+        if (fabs(w[k]) <= thr) continue;
+        double d = 0;
+        for (int i = 0; i < 6; i++) d += V[k * 6 + i] * JtErr[i];
+        d /= w[k];
+        for (int i = 0; i < 6; i++) x[i] += V[k * 6 + i] * d;
+    }
+    for (int i = 0; i < 6; i++) param[i] = prevParam[i] - x[i];
+}
+
+__device__ int solve_pnp_square(const PoseCam &cam, const float *corners, double marker_len, double *rvec, double *tvec,
+                                double *reproj)
+{
+    const int count = 4, max_iter = 20;
+    float ml = (float)marker_len;
+    float objf[12] = {-ml / 2.f, ml / 2.f, 0, ml / 2.f, ml / 2.f, 0, ml / 2.f, -ml / 2.f, 0, -ml / 2.f, -ml / 2.f, 0};
+    double M[12], m[8], mn[8], Mxy[8];
+    for (int i = 0; i < 12; i++) M[i] = objf[i];
+    for (int i = 0; i < 8; i++) m[i] = corners[i];
+    const double *K = cam.K, *k = cam.D;
+    // cvUndistortPoints, 5 fixed iterations
+    {
+        double fx = K[0], fy = K[4], ifx = 1. / fx, ify = 1. / fy, cx = K[2], cy = K[5];
+        for (int i = 0; i < count; i++) {
+            double x = m[2 * i], y = m[2 * i + 1], x0, y0, u = x, v = y;
+            x = (x - cx) * ifx;
+            y = (y - cy) * ify;
+            x0 = x;
+            y0 = y;
+            for (int j = 0; j < 5; j++) {
+                double r2 = x * x + y * y;
+                double icdist = (1) / (1 + ((k[4] * r2 + k[1]) * r2 + k[0]) * r2);
+                if (icdist < 0) {
+                    x = (u - cx) * ifx;
+                    y = (v - cy) * ify;
+                    break;
+                }
+                double deltaX = 2 * k[2] * x * y + k[3] * (r2 + 2 * x * x);
+                double deltaY = k[2] * (r2 + 2 * y * y) + 2 * k[3] * x * y;
+                x = (x0 - deltaX) * icdist;
+                y = (y0 - deltaY) * icdist;
+            }
+            mn[2 * i] = x;
+            mn[2 * i + 1] = y;
+        }
+    }
+    double param[6] = {0, 0, 0, 0, 0, 0};
+    {
+        // planar branch with R_transform = I (marker points lie in z = 0, centred): Mxy = (X, Y)
+        double Mc[3] = {0, 0, 0};
+        for (int i = 0; i < count; i++)
+            for (int j = 0; j < 3; j++) Mc[j] += M[i * 3 + j];
+        for (int j = 0; j < 3; j++) Mc[j] /= count;
+        double tt[3] = {-Mc[0], -Mc[1], -Mc[2]};
+        for (int i = 0; i < count; i++) {
+            Mxy[2 * i] = M[i * 3] + tt[0];
+            Mxy[2 * i + 1] = M[i * 3 + 1] + tt[1];
+        }
+        double h[9], R[9];
+        if (homography4(Mxy, mn, h)) {
+            double h1_norm = sqrt(h[0] * h[0] + h[3] * h[3] + h[6] * h[6]);
+            double h2_norm = sqrt(h[1] * h[1] + h[4] * h[4] + h[7] * h[7]);
+            double s1 = 1. / fmax(h1_norm, DBL_EPSILON), s2 = 1. / fmax(h2_norm, DBL_EPSILON);
+            double st = 2. / fmax(h1_norm + h2_norm, DBL_EPSILON);
+            double t3[3] = {h[2] * st, h[5] * st, h[8] * st};
+            h[0] *= s1;
+            h[3] *= s1;
+            h[6] *= s1;
+            h[1] *= s2;
+            h[4] *= s2;
+            h[7] *= s2;
+            h[2] = h[3] * h[7] - h[6] * h[4];
+            h[5] = h[6] * h[1] - h[0] * h[7];
+            h[8] = h[0] * h[4] - h[3] * h[1];
+            double rtmp[3];
+            rodrigues_m2v(h, rtmp);
+            rodrigues_v2m(rtmp, h, nullptr);
+            for (int i = 0; i < 3; i++) param[3 + i] = h[i * 3] * tt[0] + h[i * 3 + 1] * tt[1] + h[i * 3 + 2] * tt[2] + t3[i];
+            for (int i = 0; i < 9; i++) R[i] = h[i];
+        } else {
+            for (int i = 0; i < 9; i++) R[i] = (i % 4 == 0) ? 1. : 0.;
+        }
+        rodrigues_m2v(R, param);
+    }
+    // CvLevMarq
+    double prevParam[6], JtJ[36], JtErr[6], J[48], err[8], dpdr[24], dpdt[24], proj[8];
+    double prevErrNorm = 0, errNorm = 0;
+    int lambdaLg10 = -3, iters = 0, state = 1;
+    const int nerr = 8;
+    for (;;) {
+        int needJ = 0, needErr = 0;
+        if (state == 1) {
+            needJ = needErr = 1;
+            state = 2;
+        } else if (state == 2) {
+            for (int a = 0; a < 6; a++) {
+                for (int b = 0; b < 6; b++) {
+                    double acc = 0;
+                    for (int kk = 0; kk < nerr; kk++) acc += J[kk * 6 + a] * J[kk * 6 + b];
+                    JtJ[a * 6 + b] = acc;
+                }
+                double acc = 0;
+                for (int kk = 0; kk < nerr; kk++) acc += J[kk * 6 + a] * err[kk];
+                JtErr[a] = acc;
+            }
+            for (int i = 0; i < 6; i++) prevParam[i] = param[i];
+            lm_step(JtJ, JtErr, prevParam, param, lambdaLg10);
+            if (iters == 0) {
+                double s = 0;
+                for (int i = 0; i < nerr; i++) s += err[i] * err[i];
+                prevErrNorm = sqrt(s);
+            }
+            needErr = 1;
+            state = 3;
+        } else {
+            double s = 0;
+            for (int i = 0; i < nerr; i++) s += err[i] * err[i];
+            errNorm = sqrt(s);
+            int retry = 0;
+            if (errNorm > prevErrNorm) {
+                if (++lambdaLg10 <= 16) {
+                    lm_step(JtJ, JtErr, prevParam, param, lambdaLg10);
+                    needErr = 1;
+                    state = 3;
+                    retry = 1;
+                }
+            }
+            if (!retry) {
+                lambdaLg10 = lambdaLg10 - 1 > -16 ? lambdaLg10 - 1 : -16;
+                double dn = 0, pn = 0;
+                for (int i = 0; i < 6; i++) {
+                    dn += (param[i] - prevParam[i]) * (param[i] - prevParam[i]);
+                    pn += prevParam[i] * prevParam[i];
+                }
+                double rel = sqrt(dn) / (sqrt(pn) + DBL_EPSILON);
+                if (++iters >= max_iter || rel < FLT_EPSILON) break;
+                prevErrNorm = errNorm;
+                needJ = needErr = 1;
+                state = 2;
+            }
+        }
+        if (!needErr) break;
+        project4(M, param, param + 3, K, k, proj, needJ ? dpdr : nullptr, needJ ? dpdt : nullptr);
+        for (int kk = 0; kk < nerr; kk++) err[kk] = proj[kk] - m[kk];
+        if (needJ)
+            for (int kk = 0; kk < nerr; kk++)
+                for (int j = 0; j < 3; j++) {
+                    J[kk * 6 + j] = dpdr[kk * 3 + j];
+                    J[kk * 6 + 3 + j] = dpdt[kk * 3 + j];
+                }
+    }
+    for (int i = 0; i < 3; i++) {
+        rvec[i] = param[i];
+        tvec[i] = param[3 + i];
+    }
+    // getReprojectionError: projections rounded to float (vector<Point2f>)
+    project4(M, rvec, tvec, K, k, proj, nullptr, nullptr);
+    double total = 0;
+    for (int i = 0; i < 4; i++) {
+        double x1 = corners[2 * i], y1 = corners[2 * i + 1];
+        double x2 = (float)proj[2 * i], y2 = (float)proj[2 * i + 1];
+        double dx = x1 - x2, dy = y1 - y2;
+        double e = sqrt(dx * dx + dy * dy);
+        total += e * e;
+    }
+    *reproj = total / 4.0;
+    return 0;
+}
+
+__global__ __launch_bounds__(64) void k_pose(const fid_marker *__restrict__ markers, const int *__restrict__ nmark_per_frame,
+                                              int nmark_stride_ints, const double *__restrict__ lens, int nframes,
+                                              int per_frame, PoseCam cam, fid_pose_out *__restrict__ out)
+{
+    int total = nframes * per_frame;
+    for (int item = blockIdx.x * blockDim.x + threadIdx.x; item < total; item += gridDim.x * blockDim.x) {
+        int f = item / per_frame, k = item - f * per_frame;
+        if (k >= nmark_per_frame[(long long)f * nmark_stride_ints]) continue;
+        const fid_marker mk = markers[item];
+        double len = lens ? lens[item] : cam.fiducial_len;
+        fid_pose_out o;
+        double err = 0;
+        solve_pnp_square(cam, mk.corners, len, o.rvec, o.tvec, &err);
+        o.image_error = err;
+        const float *c = mk.corners;
+        // calcFiducialArea (Heron on two triangles)
+        double a1 = dist2f_d(c[0], c[1], c[2], c[3]);
+        double b1 = dist2f_d(c[0], c[1], c[6], c[7]);
+        double c1 = dist2f_d(c[2], c[3], c[6], c[7]);
+        double a2 = dist2f_d(c[2], c[3], c[4], c[5]);
+        double b2 = dist2f_d(c[4], c[5], c[6], c[7]);
+        double c2 = c1;
+        double s1 = (a1 + b1 + c1) / 2.0, s2 = (a2 + b2 + c2) / 2.0;
+        a1 = sqrt(s1 * (s1 - a1) * (s1 - b1) * (s1 - c1));
+        a2 = sqrt(s2 * (s2 - a2) * (s2 - b2) * (s2 - c2));
+        o.fiducial_area = a1 + a2;
+        double nt = sqrt(o.tvec[0] * o.tvec[0] + o.tvec[1] * o.tvec[1] + o.tvec[2] * o.tvec[2]);
+        o.object_error = (err / dist2f_d(c[0], c[1], c[4], c[5])) * (nt / cam.fiducial_len);
+        out[item] = o;
+    }
+}

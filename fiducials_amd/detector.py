@@ -1,0 +1,226 @@
+"""Host-side mirror of the reference's detector interface, on top of the C-ABI.
+
+`ArucoDetector.detect_markers(image)` has the argument meaning and result shape of
+`aruco::detectMarkers(image, dictionary, corners, ids, detectorParams)` as aruco_detect calls it
+(aruco_detect/src/aruco_detect.cpp:350): corners are (n, 4, 2) float32 in TL,TR,BR,BL order of the
+canonical marker, ids (n,) int32, in OpenCV's output order.  `estimate_pose_single_markers` mirrors
+`FiducialsNode::estimatePoseSingleMarkers` (:223-255) plus the per-marker error/area values that
+poseEstimateCallback publishes (:480-497).
+
+Everything here runs on the MI355X through libfid_amd.so; there is no CPU path in this package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _lib
+from ._lib import FidCandidate, FidDict, FidError, FidLimits, FidMarker, FidParams, FidPoseOut
+from .dictionary import Dictionary, get_predefined_dictionary
+
+
+def default_params() -> FidParams:
+    p = FidParams()
+    _lib.load().fid_default_params(C.byref(p))
+    return p
+
+
+@dataclass
+class PoseResult:
+    rvecs: np.ndarray  # (n, 3)
+    tvecs: np.ndarray  # (n, 3)
+    image_error: np.ndarray  # (n,)
+    object_error: np.ndarray
+    fiducial_area: np.ndarray
+
+
+def _poses_to_result(arr, n) -> PoseResult:
+    return PoseResult(
+        rvecs=np.array([list(arr[i].rvec) for i in range(n)], dtype=np.float64).reshape(n, 3),
+        tvecs=np.array([list(arr[i].tvec) for i in range(n)], dtype=np.float64).reshape(n, 3),
+        image_error=np.array([arr[i].image_error for i in range(n)]),
+        object_error=np.array([arr[i].object_error for i in range(n)]),
+        fiducial_area=np.array([arr[i].fiducial_area for i in range(n)]),
+    )
+
+
+class ArucoDetector:
+    def __init__(self, dictionary: Dictionary | int | str = 7, params: FidParams | None = None, device: int = 0,
+                 max_width: int = 1920, max_height: int = 1080, max_batch: int = 1, max_markers: int = 256,
+                 max_candidates: int = 2048, max_starts: int = 0, max_contours: int = 0):
+        self._L = _lib.load()
+        self.dictionary = dictionary if isinstance(dictionary, Dictionary) else get_predefined_dictionary(dictionary)
+        self.params = params or default_params()
+        d = self.dictionary
+        self._dict_bytes = np.ascontiguousarray(d.bytes_list, dtype=np.uint8)
+        fd = FidDict(d.marker_size, d.max_correction_bits, d.n_markers, 0, self._dict_bytes.ctypes.data)
+        lim = FidLimits()
+        self._L.fid_default_limits(C.byref(lim))
+        lim.max_width, lim.max_height, lim.max_batch = max_width, max_height, max_batch
+        lim.max_markers_per_frame, lim.max_candidates_per_frame = max_markers, max_candidates
+        if max_starts:
+            lim.max_starts_per_frame = max_starts
+        if max_contours:
+            lim.max_contours_per_frame = max_contours
+        self.limits = lim
+        self._ctx = C.c_void_p()
+        rc = self._L.fid_create(C.byref(self.params), C.byref(fd), C.byref(lim), device, C.byref(self._ctx))
+        if rc != _lib.FID_OK:
+            raise FidError(rc, self._L.fid_strerror(rc).decode())
+        self.device = device
+        self.max_markers = max_markers
+        self.max_batch = max_batch
+        self._out = (FidMarker * (max_batch * max_markers))()
+        self._n = (C.c_int32 * max_batch)()
+        self._poses = (FidPoseOut * (max_batch * max_markers))()
+        self._last_frames = 0
+
+    # -- lifetime ------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_ctx", None) is not None and self._ctx.value:
+            self._L.fid_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != _lib.FID_OK:
+            raise FidError(rc, (self._L.fid_last_error(self._ctx) or b"").decode() or self._L.fid_strerror(rc).decode())
+
+    def set_params(self, params: FidParams):
+        """dynamic_reconfigure path (aruco_detect.cpp:257-298)."""
+        self._check(self._L.fid_set_params(self._ctx, C.byref(params)))
+        self.params = params
+
+    # -- detection ----------------------------------------------------------------------------
+    def _unpack(self, nframes):
+        res = []
+        mm = self.max_markers
+        for f in range(nframes):
+            n = self._n[f]
+            ids = np.array([self._out[f * mm + i].id for i in range(n)], dtype=np.int32)
+            cor = np.array([list(self._out[f * mm + i].corners) for i in range(n)], dtype=np.float32).reshape(n, 4, 2)
+            res.append((cor, ids))
+        self._last_frames = nframes
+        return res
+
+    def detect_markers(self, image: np.ndarray, encoding: str | None = None):
+        """One frame from host memory.  image: (H, W) uint8 mono8 or (H, W, 3) bgr8/rgb8 (default bgr8, the
+        encoding imageCallback requests from cv_bridge, :348).  Returns (corners, ids)."""
+        img = np.asarray(image)
+        if img.dtype != np.uint8 or img.ndim not in (2, 3):
+            raise FidError(_lib.FID_E_INVALID_ARG, "image must be uint8 HxW or HxWx3")
+        if encoding is None:
+            encoding = "mono8" if img.ndim == 2 else "bgr8"
+        if img.strides[-1] != 1 or (img.ndim == 3 and img.strides[1] != 3):
+            img = np.ascontiguousarray(img)
+        h, w = img.shape[:2]
+        rc = self._L.fid_detect(self._ctx, img.ctypes.data, w, h, img.strides[0], _lib.ENC[encoding], self._out,
+                                self.max_markers, self._n)
+        self._check(rc)
+        return self._unpack(1)[0]
+
+    def detect_markers_batch(self, images: np.ndarray, encoding: str | None = None):
+        imgs = np.ascontiguousarray(images, dtype=np.uint8)
+        if encoding is None:
+            encoding = "mono8" if imgs.ndim == 3 else "bgr8"
+        f, h, w = imgs.shape[:3]
+        rc = self._L.fid_detect_batch(self._ctx, imgs.ctypes.data, f, w, h, imgs.strides[1], imgs.strides[0],
+                                      _lib.ENC[encoding], self._out, self.max_markers, self._n)
+        self._check(rc)
+        return self._unpack(f)
+
+    def detect_markers_device(self, data_ptr: int, nframes: int, width: int, height: int, stride: int | None = None,
+                              frame_stride: int | None = None, encoding: str = "mono8", unpack: bool = True):
+        """Frames already resident in HBM (e.g. a torch uint8 tensor's data_ptr() on this device)."""
+        bpp = 1 if encoding == "mono8" else 3
+        stride = stride or width * bpp
+        frame_stride = frame_stride or stride * height
+        rc = self._L.fid_detect_device(self._ctx, C.c_void_p(data_ptr), nframes, width, height, stride, frame_stride,
+                                       _lib.ENC[encoding], self._out, self.max_markers, self._n)
+        self._check(rc)
+        self._last_frames = nframes
+        if not unpack:
+            return [int(self._n[f]) for f in range(nframes)]
+        return self._unpack(nframes)
+
+    # -- pose ---------------------------------------------------------------------------------
+    def estimate_pose_single_markers(self, corners: np.ndarray, ids: np.ndarray, fiducial_len: float, K, D,
+                                     fiducial_len_override: dict | None = None) -> PoseResult:
+        corners = np.ascontiguousarray(corners, dtype=np.float32).reshape(-1, 8)
+        n = corners.shape[0]
+        mk = (FidMarker * max(n, 1))()
+        lens = (C.c_double * max(n, 1))()
+        for i in range(n):
+            mk[i].id = int(ids[i])
+            for j in range(8):
+                mk[i].corners[j] = float(corners[i, j])
+            lens[i] = float((fiducial_len_override or {}).get(int(ids[i]), fiducial_len))  # :241-244
+        Kc = (C.c_double * 9)(*np.asarray(K, dtype=np.float64).reshape(9))
+        Dc = (C.c_double * 5)(*np.asarray(D, dtype=np.float64).reshape(-1)[:5])
+        out = (FidPoseOut * max(n, 1))()
+        self._check(self._L.fid_pose(self._ctx, Kc, Dc, mk, lens, n, float(fiducial_len), out))
+        return _poses_to_result(out, n)
+
+    def pose_last(self, fiducial_len: float, K, D, unpack: bool = True):
+        """Poses of the markers found by the last detect_* call, computed without the corners leaving HBM."""
+        Kc = (C.c_double * 9)(*np.asarray(K, dtype=np.float64).reshape(9))
+        Dc = (C.c_double * 5)(*np.asarray(D, dtype=np.float64).reshape(-1)[:5])
+        self._check(self._L.fid_pose_last(self._ctx, Kc, Dc, float(fiducial_len), self._poses, self.max_markers))
+        if not unpack:
+            return None
+        res = []
+        for f in range(self._last_frames):
+            n = self._n[f]
+            sub = [self._poses[f * self.max_markers + i] for i in range(n)]
+            res.append(_poses_to_result(sub, n))
+        return res
+
+    # -- stage taps for parity tests ------------------------------------------------------------
+    def tap(self, which: int) -> np.ndarray:
+        nbytes = self._L.fid_tap_bytes(self._ctx, which)
+        buf = np.zeros(nbytes, dtype=np.uint8)
+        self._check(self._L.fid_tap_read(self._ctx, which, buf.ctypes.data, nbytes))
+        return buf
+
+    def tap_counts(self):
+        return self.tap(_lib.TAP_COUNTS).view(np.int32).reshape(-1, 8)
+
+    def tap_masks(self, nframes, nscales, h, w):
+        ww = (w + 31) // 32
+        m = self.tap(_lib.TAP_MASKS).view(np.uint32).reshape(nframes, nscales, h, ww)
+        bits = np.unpackbits(m.view(np.uint8).reshape(nframes, nscales, h, ww * 4), axis=-1, bitorder="little")
+        return bits[..., :w]
+
+    def tap_candidates(self, filtered: bool = False):
+        raw = self.tap(_lib.TAP_FILTERED if filtered else _lib.TAP_CANDIDATES)
+        dt = np.dtype([("scale", "<i4"), ("contour_size", "<i4"), ("start_x", "<i4"), ("start_y", "<i4"),
+                       ("is_hole", "<i4"), ("corners", "<f4", (8,))])
+        return raw.view(dt).reshape(-1, self.limits.max_candidates_per_frame)
+
+    def tap_bits(self):
+        msb = self.dictionary.marker_size + 2 * self.params.markerBorderBits
+        return self.tap(_lib.TAP_BITS).reshape(-1, self.limits.max_candidates_per_frame, msb, msb)
+
+    def tap_ident(self):
+        return self.tap(_lib.TAP_IDENT).view(np.int32).reshape(-1, self.limits.max_candidates_per_frame, 2)
+
+    def tap_presubpix(self):
+        dt = np.dtype([("id", "<i4"), ("corners", "<f4", (8,))])
+        return self.tap(_lib.TAP_PRESUBPIX).view(dt).reshape(-1, self.max_markers)
+
+    def stage_ms(self) -> dict:
+        ms = (C.c_float * 32)()
+        names = C.POINTER(C.c_char_p)()
+        n = self._L.fid_last_stage_ms(self._ctx, ms, 32, C.byref(names))
+        return {names[i].decode(): float(ms[i]) for i in range(n)}
+
+    @property
+    def stream(self) -> int:
+        return int(self._L.fid_stream(self._ctx) or 0)

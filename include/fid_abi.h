@@ -1,0 +1,186 @@
+/*
+ * fid_abi.h -- C-ABI of the MI355X-native fiducial detection front-end (libfid_amd.so).
+ *
+ * This is the seam a maintainer of UbiquityRobotics/fiducials binds to in order to replace the
+ * OpenCV calls on aruco_detect's hot path (reference paths relative to /root/reference):
+ *
+ *   fid_detect / fid_detect_batch / fid_detect_device
+ *        replaces  cv_bridge::toCvCopy(msg, BGR8)  +  aruco::detectMarkers(image, dictionary,
+ *        corners, ids, detectorParams)            aruco_detect/src/aruco_detect.cpp:348,350
+ *   fid_pose
+ *        replaces  FiducialsNode::estimatePoseSingleMarkers (cv::solvePnP per marker, :223-255,
+ *        call :247), getReprojectionError (cv::projectPoints, :203-221), calcFiducialArea
+ *        (:179-200) and the object_error formula (:455-457,:493-495)
+ *   fid_params   mirrors aruco::DetectorParameters as the node fills it      (:690-727)
+ *   fid_dict     mirrors aruco::Dictionary{bytesList, markerSize, maxCorrectionBits} as returned
+ *                by aruco::getPredefinedDictionary(dicno)                     (:671)
+ *
+ * Rules: plain C, caller-allocated outputs with capacity + count, integer status codes, nothing
+ * throws across the boundary.  A context is single-threaded (the node runs under ros::spin(),
+ * aruco_detect.cpp:737); several contexts (one per GPU / stream) may be used concurrently.
+ * Host image memory may be pageable.  Device pointers (fid_detect_device) must be on ctx's device.
+ *
+ * The reference-side bindings are shown in INTEGRATION.md.
+ */
+#ifndef FID_ABI_H
+#define FID_ABI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FID_ABI_VERSION 1
+
+typedef enum fid_status {
+    FID_OK = 0,
+    FID_E_INVALID_ARG = 1,   /* null pointer, bad size, unsupported encoding */
+    FID_E_NO_DEVICE = 2,     /* no HIP device / kernels unavailable: the library never falls back to CPU */
+    FID_E_HIP = 3,           /* a HIP runtime call failed (fid_last_error gives the text) */
+    FID_E_CAPACITY = 4,      /* an internal or caller buffer was too small; outputs truncated */
+    FID_E_OUT_OF_MEMORY = 5,
+    FID_E_UNSUPPORTED = 6    /* parameter combination outside what the kernels implement */
+} fid_status;
+
+typedef enum fid_encoding {  /* sensor_msgs/Image encodings the node accepts via toCvCopy(BGR8) */
+    FID_ENC_MONO8 = 0,
+    FID_ENC_BGR8 = 1,
+    FID_ENC_RGB8 = 2
+} fid_encoding;
+
+/* aruco::DetectorParameters, fields and defaults as set by the node (aruco_detect.cpp:690-727) */
+typedef struct fid_params {
+    double adaptiveThreshConstant;                 /* 7    */
+    int32_t adaptiveThreshWinSizeMin;              /* 3    */
+    int32_t adaptiveThreshWinSizeMax;              /* 53   */
+    int32_t adaptiveThreshWinSizeStep;             /* 4    */
+    int32_t cornerRefinementMethod;                /* 1 = CORNER_REFINE_SUBPIX (node default), 0 = NONE */
+    int32_t cornerRefinementWinSize;               /* 5    */
+    int32_t cornerRefinementMaxIterations;         /* 30   */
+    double cornerRefinementMinAccuracy;            /* 0.01 */
+    double errorCorrectionRate;                    /* 0.6  */
+    double minCornerDistanceRate;                  /* 0.05 */
+    int32_t markerBorderBits;                      /* 1    */
+    int32_t minDistanceToBorder;                   /* 3    */
+    double maxErroneousBitsInBorderRate;           /* 0.04 */
+    double minMarkerDistanceRate;                  /* 0.05 */
+    double minMarkerPerimeterRate;                 /* 0.1  */
+    double maxMarkerPerimeterRate;                 /* 4.0  */
+    double minOtsuStdDev;                          /* 5.0  */
+    double perspectiveRemoveIgnoredMarginPerCell;  /* 0.13 */
+    int32_t perspectiveRemovePixelPerCell;         /* 8    */
+    int32_t reserved0;
+    double polygonalApproxAccuracyRate;            /* 0.01 */
+} fid_params;
+
+/* aruco::Dictionary.  bytes = bytesList data: n_markers x 4 rotations x nbytes, nbytes =
+ * (marker_size^2 + 7) / 8, rotation-major per marker (OpenCV >= 4.0 layout). Copied at fid_create. */
+typedef struct fid_dict {
+    int32_t marker_size;
+    int32_t max_correction_bits;
+    int32_t n_markers;
+    int32_t reserved0;
+    const uint8_t *bytes;
+} fid_dict;
+
+/* one detected marker: what imageCallback copies into fiducial_msgs/Fiducial (aruco_detect.cpp:366-377) */
+typedef struct fid_marker {
+    int32_t id;
+    float corners[8]; /* x0,y0,x1,y1,x2,y2,x3,y3 */
+} fid_marker;
+
+/* per-marker pose record: what poseEstimateCallback puts into fiducial_msgs/FiducialTransform
+ * (aruco_detect.cpp:480-497) before the axis-angle -> quaternion step */
+typedef struct fid_pose_out {
+    double rvec[3];
+    double tvec[3];
+    double image_error;   /* getReprojectionError: mean squared reprojection error, px^2 (:214-220) */
+    double object_error;  /* (image_error / dist(c0,c2)) * (norm(tvec) / fiducial_len)  (:493-495) */
+    double fiducial_area; /* calcFiducialArea (:179-200) */
+} fid_pose_out;
+
+typedef struct fid_ctx fid_ctx;
+
+/* sizes fixed at creation; 0 selects the default in brackets */
+typedef struct fid_limits {
+    int32_t max_width;              /* [1920] */
+    int32_t max_height;             /* [1080] */
+    int32_t max_batch;              /* [1]   frames per fid_detect_batch call */
+    int32_t max_starts_per_frame;   /* [262144] border-following start points, all scales */
+    int32_t max_contours_per_frame; /* [16384]  contours passing the perimeter gate, all scales */
+    int32_t max_candidates_per_frame; /* [2048] quads leaving _findMarkerContours, all scales */
+    int32_t max_markers_per_frame;  /* [256] */
+    int32_t reserved0;
+} fid_limits;
+
+void fid_default_params(fid_params *p);
+void fid_default_limits(fid_limits *l);
+
+fid_status fid_create(const fid_params *params, const fid_dict *dict, const fid_limits *limits /* may be NULL */,
+                      int device, fid_ctx **out);
+void fid_destroy(fid_ctx *ctx);
+/* dynamic_reconfigure path (aruco_detect.cpp:257-298) */
+fid_status fid_set_params(fid_ctx *ctx, const fid_params *params);
+
+/* one frame from host memory (the imageCallback path). */
+fid_status fid_detect(fid_ctx *ctx, const uint8_t *img, int32_t width, int32_t height, int32_t stride_bytes,
+                      fid_encoding enc, fid_marker *out, int32_t cap, int32_t *n);
+/* nframes contiguous frames (frame_stride_bytes apart) from host memory; out is nframes x cap_per_frame */
+fid_status fid_detect_batch(fid_ctx *ctx, const uint8_t *imgs, int32_t nframes, int32_t width, int32_t height,
+                            int32_t stride_bytes, int64_t frame_stride_bytes, fid_encoding enc, fid_marker *out,
+                            int32_t cap_per_frame, int32_t *n_per_frame);
+/* same, frames already resident in device memory (throughput mode, BASELINE cfg 3) */
+fid_status fid_detect_device(fid_ctx *ctx, const void *d_imgs, int32_t nframes, int32_t width, int32_t height,
+                             int32_t stride_bytes, int64_t frame_stride_bytes, fid_encoding enc, fid_marker *out,
+                             int32_t cap_per_frame, int32_t *n_per_frame);
+
+/* poseEstimateCallback arithmetic for n markers.  K row-major 3x3, D = plumb-bob k1,k2,p1,p2,k3
+ * (CameraInfo.K / .D[0..4], aruco_detect.cpp:315-323).  len_per_marker[i] is fiducial_len or its per-id
+ * override (:241-244).  fiducial_len is the node's ~fiducial_len used in object_error. */
+fid_status fid_pose(fid_ctx *ctx, const double K[9], const double D[5], const fid_marker *markers,
+                    const double *len_per_marker, int32_t n, double fiducial_len, fid_pose_out *out);
+
+/* Detection and pose of the LAST fid_detect* call fused on the device (no round trip of the corners):
+ * poses for frame f start at out[f * cap_per_frame]. */
+fid_status fid_pose_last(fid_ctx *ctx, const double K[9], const double D[5], double fiducial_len,
+                         fid_pose_out *out, int32_t cap_per_frame);
+
+/* stage taps for parity tests (device -> host copies of intermediate buffers of the last call) */
+typedef enum fid_tap {
+    FID_TAP_MASKS = 0,       /* uint32 [nframes][nscales][height][words_per_row], bit x&31 of word x>>5 */
+    FID_TAP_CANDIDATES = 1,  /* fid_candidate [nframes][max_candidates_per_frame], OpenCV order */
+    FID_TAP_FILTERED = 2,    /* fid_candidate after reorder + too-close filter */
+    FID_TAP_BITS = 3,        /* uint8 [nframes][max_candidates_per_frame][(ms+2)^2] for FILTERED entries */
+    FID_TAP_IDENT = 4,       /* int32 [nframes][max_candidates_per_frame][2] id, rotation */
+    FID_TAP_PRESUBPIX = 5,   /* fid_marker [nframes][max_markers_per_frame] */
+    FID_TAP_COUNTS = 6,      /* int32 [nframes][8]: starts, contours, candidates, filtered, accepted, markers, overflow flags, 0 */
+    FID_TAP_GRAY = 7         /* uint8 [nframes][height][width] the gray image the detector saw */
+} fid_tap;
+
+typedef struct fid_candidate {
+    int32_t scale;
+    int32_t contour_size;
+    int32_t start_x, start_y;
+    int32_t is_hole;
+    float corners[8];
+} fid_candidate;
+
+int64_t fid_tap_bytes(fid_ctx *ctx, fid_tap which);
+fid_status fid_tap_read(fid_ctx *ctx, fid_tap which, void *dst, int64_t dst_bytes);
+
+/* timing of the last call's kernels on the context stream, measured with hipEvents (ms); names is a
+ * static table of nstages strings.  Returns the number of stages. */
+int32_t fid_last_stage_ms(fid_ctx *ctx, float *ms, int32_t cap, const char *const **names);
+
+/* the HIP stream the context launches on (hipStream_t as void*), for callers that bracket it with events */
+void *fid_stream(fid_ctx *ctx);
+
+const char *fid_strerror(fid_status s);
+const char *fid_last_error(fid_ctx *ctx);
+int32_t fid_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FID_ABI_H */

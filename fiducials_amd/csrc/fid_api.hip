@@ -39,6 +39,8 @@ struct fid_ctx {
     int masks_W = 0, masks_H = 0, masks_S = 0;
     uint2 *d_starts = nullptr;
     uint4 *d_contours = nullptr;
+    uint32_t *d_ckpts = nullptr;
+    size_t ckpts_elems = 0;
     DevCand *d_cands = nullptr, *d_sorted = nullptr, *d_filtered = nullptr;
     uint32_t *d_near = nullptr;
     DevIdent *d_ident = nullptr;
@@ -197,7 +199,7 @@ fid_status run_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H, int
                       fid_marker *out, int cap_per_frame, int *n_per_frame)
 {
     if (!out || !n_per_frame || cap_per_frame < 0) return FID_E_INVALID_ARG;
-    if (F < 1 || F > c->lim.max_batch || W < 8 || H < 8 || W > c->lim.max_width || H > c->lim.max_height || W > 65535 || H > 65535)
+    if (F < 1 || F > c->lim.max_batch || W < 8 || H < 8 || W > c->lim.max_width || H > c->lim.max_height || W > 8191 || H > 8191)  // 13-bit checkpoint packing
         return FID_E_INVALID_ARG;
     if (enc != FID_ENC_MONO8 && enc != FID_ENC_BGR8 && enc != FID_ENC_RGB8) return FID_E_INVALID_ARG;
     int bpp = enc == FID_ENC_MONO8 ? 1 : 3;
@@ -245,20 +247,26 @@ fid_status run_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H, int
     mark(c, ST_THRESH + 1);
     // ---- K2
     {
-        long long words = (long long)F * P.nscales * H * P.WW;
-        long long blocks = (words + 255) / 256;
-        if (blocks > 256 * 16) blocks = 256 * 16;
-        hipLaunchKernelGGL(k_find_starts, dim3((unsigned)blocks), dim3(256), 0, st, c->d_masks, c->d_starts, c->d_global, P);
+        long long groups = (long long)P.nscales * H * ((P.WW + 3) / 4);
+        long long blocks = (groups + 255) / 256;
+        if (blocks > 64) blocks = 64;
+        hipLaunchKernelGGL(k_find_starts, dim3((unsigned)blocks, F), dim3(256), 0, st, c->d_masks, c->d_starts, c->d_counts,
+                           c->d_global, P);
     }
     mark(c, ST_STARTS + 1);
     // ---- K3
-    hipLaunchKernelGGL(k_walk_count, dim3(256 * 8), dim3(256), 0, st, c->d_masks, c->d_starts, c->d_contours, c->d_global, P);
+    if ((size_t)F * P.maxContours * (P.maxPerim / 64 + 1) > c->ckpts_elems) {
+        c->last_error = "checkpoint buffer too small for this image size / maxMarkerPerimeterRate";
+        return FID_E_UNSUPPORTED;
+    }
+    hipLaunchKernelGGL(k_walk_count, dim3(32, F), dim3(256), 0, st, c->d_masks, c->d_starts, c->d_contours, c->d_ckpts,
+                       c->d_counts, c->d_global, P);
     mark(c, ST_WALK + 1);
     // ---- K4
     {
         size_t lds = (size_t)(P.maxPerim + 1) * sizeof(uint32_t);
-        hipLaunchKernelGGL(k_approx, dim3(256 * 8), dim3(64), lds, st, c->d_masks, c->d_contours, c->d_cands, c->d_counts,
-                           c->d_global, P);
+        hipLaunchKernelGGL(k_approx, dim3(64, F), dim3(64), lds, st, c->d_masks, c->d_contours, c->d_ckpts, c->d_cands,
+                           c->d_counts, c->d_global, P);
     }
     mark(c, ST_APPROX + 1);
     // ---- K5
@@ -443,6 +451,12 @@ fid_status fid_create(const fid_params *params, const fid_dict *dict, const fid_
     TRYHIP(hipMalloc((void **)&c->d_masks, c->masks_bytes));
     TRY(dalloc(c, &c->d_starts, F * L.max_starts_per_frame));
     TRY(dalloc(c, &c->d_contours, F * L.max_contours_per_frame));
+    {
+        int maxdim = L.max_width > L.max_height ? L.max_width : L.max_height;
+        size_t nck = (size_t)(params->maxMarkerPerimeterRate * maxdim) / 64 + 2;
+        c->ckpts_elems = F * L.max_contours_per_frame * nck;
+        TRY(dalloc(c, &c->d_ckpts, c->ckpts_elems));
+    }
     TRY(dalloc(c, &c->d_cands, F * MC));
     TRY(dalloc(c, &c->d_sorted, F * MC));
     TRY(dalloc(c, &c->d_filtered, F * MC));
@@ -476,7 +490,7 @@ void fid_destroy(fid_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    void *dev[] = {c->d_in, c->d_gray, c->d_masks, c->d_starts, c->d_contours, c->d_cands, c->d_sorted, c->d_filtered, c->d_near,
+    void *dev[] = {c->d_in, c->d_gray, c->d_masks, c->d_starts, c->d_contours, c->d_ckpts, c->d_cands, c->d_sorted, c->d_filtered, c->d_near,
                    c->d_ident, c->d_pre, c->d_markers, c->d_poses, c->d_counts, c->d_global, c->d_worklist, c->d_nwork, c->d_dict,
                    c->d_subpix_mask, c->d_lens, c->d_pose_in, c->d_pose_n};
     for (void *p : dev)
@@ -552,8 +566,9 @@ static fid_status run_pose(fid_ctx *c, const fid_marker *d_markers, const int *d
     for (int i = 0; i < 5; i++) cam.D[i] = D ? D[i] : 0.;
     cam.fiducial_len = fiducial_len;
     int total = F * per_frame;
-    int blocks = (total + 63) / 64;
+    int blocks = (total + 7) / 8;  // eight lanes per marker, eight markers per wave
     if (blocks < 1) blocks = 1;
+    if (blocks > 256 * 16) blocks = 256 * 16;
     if (c->profile) (void)hipEventRecord(c->ev[ST_POSE], c->stream);
     hipLaunchKernelGGL(k_pose, dim3(blocks), dim3(64), 0, c->stream, d_markers, d_n, n_stride_ints, d_lens, F, per_frame, cam, d_out);
     if (c->profile) (void)hipEventRecord(c->ev[ST_POSE + 1], c->stream);
@@ -695,8 +710,8 @@ fid_status fid_tap_read(fid_ctx *c, fid_tap which, void *dst, int64_t dst_bytes)
     case FID_TAP_COUNTS: {
         int32_t *o = (int32_t *)dst;
         for (int f = 0; f < F; f++) {
-            o[8 * f + 0] = (int32_t)c->h_global->nstarts;
-            o[8 * f + 1] = (int32_t)c->h_global->ncontours;
+            o[8 * f + 0] = c->h_counts[f].nstarts;
+            o[8 * f + 1] = c->h_counts[f].ncontours;
             o[8 * f + 2] = c->h_counts[f].ncand;
             o[8 * f + 3] = c->h_counts[f].nfilt;
             o[8 * f + 4] = c->h_counts[f].nacc;

@@ -7,8 +7,9 @@
 //                                              is bit (x & 31) of word MASK_PADW + (x >> 5) in padded
 //                                              row y+1; pad rows/words are zero so border following
 //                                              never bounds-checks
-//   starts    uint2 [F * max_starts]          border-following start points (all frames, all scales)
-//   contours  uint4 [F * max_contours]        contours that passed the perimeter gate
+//   starts    uint2 [F][max_starts]           border-following start candidates (all scales)
+//   contours  uint4 [F][max_contours]         contour slots: start, meta, length (0 = dropped), discovery key
+//   ckpts     u32  [F][max_contours][maxPerim/64+1]  walk state every 64 points (parallel replay in k_approx)
 //   cands     DevCand [F][max_cands]          quads leaving _findMarkerContours
 //   sorted / filtered DevCand [F][max_cands]  OpenCV order; after reorder + too-close filter
 //   near      u32  [F][max_cands][max_cands/32]
@@ -60,12 +61,13 @@ struct DevCounts {
     int nacc;       // identified
     int nmark;      // after _filterDetectedMarkers
     int overflow;   // bit0 cands, bit1 markers
-    int pad[3];
+    int nstarts;    // border-following start candidates found by k_find_starts
+    int ncontours;  // contour slots handed out by k_walk_count (dropped walks leave count == 0)
+    int pad;
 };
 
 // global counters
 struct DevGlobal {
-    unsigned nstarts, ncontours;
-    unsigned overflow;  // bit0 starts, bit1 contours
-    unsigned pad;
+    unsigned overflow;  // bit0 starts, bit1 contours, bit2 approxPolyDP stack
+    unsigned pad[3];
 };

@@ -195,66 +195,135 @@ __global__ __launch_bounds__(NT) void k_threshold(const uint8_t *__restrict__ gr
 }
 
 // ------------------------------------------------------------------------------------------------
-// K2: start points of Suzuki-Abe border following, found without the sequential raster scan:
-//   outer border start  = foreground pixel whose W, NW, N, NE neighbours are background
-//                         (necessary for being the raster-first pixel of its 8-connected component)
-//   hole border start   = foreground pixel p with background E and foreground NE
-//                         (necessary for E being the raster-first pixel of a 4-connected hole)
-// K3 decides which of them are the canonical start of their border.  32 pixels per lane-op.
-__global__ __launch_bounds__(256) void k_find_starts(const uint32_t *__restrict__ masks, uint2 *__restrict__ starts,
-                                                      DevGlobal *__restrict__ G, const DevParams P)
+// K2: start points of Suzuki-Abe border following, found without the sequential raster scan.
+//   outer border start: the first pixel of a horizontal foreground run whose W neighbour is background
+//     and none of whose pixels has a foreground N / NW / NE neighbour (a run that touches nothing above
+//     it; necessary for holding the raster-first pixel of its 8-connected component)
+//   hole border start: the pixel left of the first pixel of a horizontal background run whose every
+//     pixel has foreground above it (necessary for the run to hold the raster-first pixel of a
+//     4-connected hole); the run start itself has foreground N by the same test
+// Runs are tested inside one 32-bit word with a Kogge-Stone fill; a run that crosses a word border is
+// kept as a candidate (K3 makes the exact decision by walking).  32 pixels per lane-op, one atomic per
+// workgroup iteration on a per-frame counter.
+__device__ __forceinline__ uint32_t fill_toward_lsb(uint32_t seed, uint32_t runs)
 {
-    const int lane = lane_id();
-    const int WW = P.WW, WWP = P.WWP, H = P.H, S = P.nscales;
-    const long long total = (long long)P.nframes * S * H * WW;
-    const long long totalr = (total + 63) & ~63LL;
-    const unsigned cap = (unsigned)P.maxStarts * (unsigned)P.nframes;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < totalr; i += (long long)gridDim.x * blockDim.x) {
-        uint32_t outer = 0, hole = 0;
-        int w = 0, y = 0, s = 0, f = 0;
+    // spread every seed bit to all lower bits of its run of ones in `runs`
+    uint32_t f = seed & runs, m = runs;
+    f |= (f >> 1) & m;
+    m &= m >> 1;
+    f |= (f >> 2) & m;
+    m &= m >> 2;
+    f |= (f >> 4) & m;
+    m &= m >> 4;
+    f |= (f >> 8) & m;
+    m &= m >> 8;
+    f |= (f >> 16) & m;
+    return f;
+}
+
+#define K2_WPT 4  // words per thread per iteration
+__global__ __launch_bounds__(256) void k_find_starts(const uint32_t *__restrict__ masks, uint2 *__restrict__ starts,
+                                                      DevCounts *__restrict__ counts, DevGlobal *__restrict__ G,
+                                                      const DevParams P)
+{
+    __shared__ int s_wsum[4];
+    __shared__ unsigned s_base;
+    const int lane = lane_id(), wid = threadIdx.x >> 6;
+    const int f = blockIdx.y;
+    const int WW = P.WW, WWP = P.WWP, H = P.H, S = P.nscales, W = P.W;
+    const int WQ = (WW + K2_WPT - 1) / K2_WPT;  // word groups per row
+    const long long total = (long long)S * H * WQ;
+    const long long totalr = (total + 255) & ~255LL;
+    const unsigned cap = (unsigned)P.maxStarts;
+    uint2 *fst = starts + (long long)f * P.maxStarts;
+    for (long long i0 = (long long)blockIdx.x * 256; i0 < totalr; i0 += (long long)gridDim.x * 256) {
+        long long i = i0 + threadIdx.x;
+        uint32_t outer[K2_WPT], hole[K2_WPT], ebits[K2_WPT];
+        int w0 = 0, y = 0, s = 0, cnt = 0, extra = 0;
+#pragma unroll
+        for (int k = 0; k < K2_WPT; k++) outer[k] = hole[k] = ebits[k] = 0;
         if (i < total) {
-            w = (int)(i % WW);
-            long long t = i / WW;
+            int wq = (int)(i % WQ);
+            long long t = i / WQ;
             y = (int)(t % H);
-            t /= H;
-            s = (int)(t % S);
-            f = (int)(t / S);
-            const uint32_t *row = masks + (((long long)f * S + s) * (H + 2) + (y + 1)) * WWP + MASK_PADW + w;
-            uint32_t cur = row[0];
-            if (cur) {
-                const uint32_t *up = row - WWP;
-                uint32_t curL = row[-1], curR = row[1], u = up[0], uL = up[-1], uR = up[1];
-                uint32_t Wst = (cur << 1) | (curL >> 31);
-                uint32_t Est = (cur >> 1) | (curR << 31);
-                uint32_t NW = (u << 1) | (uL >> 31);
-                uint32_t NE = (u >> 1) | (uR << 31);
-                outer = cur & ~Wst & ~NW & ~u & ~NE;
-                hole = cur & ~Est & NE;
+            s = (int)(t / H);
+            w0 = wq * K2_WPT;
+            const uint32_t *row = masks + (((long long)f * S + s) * (H + 2) + (y + 1)) * WWP + MASK_PADW + w0;
+            const uint32_t *up = row - WWP;
+            uint32_t prevc = row[-1], prevu = up[-1];
+            uint32_t cur = row[0], u = up[0];
+#pragma unroll
+            for (int k = 0; k < K2_WPT; k++) {
+                uint32_t nextc = row[k + 1], nextu = up[k + 1];
+                if (w0 + k < WW) {
+                    uint32_t Wst = (cur << 1) | (prevc >> 31);
+                    uint32_t NW = (u << 1) | (prevu >> 31);
+                    uint32_t NE = (u >> 1) | (nextu << 31);
+                    // outer: starts of foreground runs that have no foreground above (N / NW / NE) anywhere
+                    uint32_t touch = cur & (NW | u | NE);
+                    outer[k] = cur & ~Wst & ~fill_toward_lsb(touch, cur);
+                    // hole: first pixel e of a background run (W neighbour foreground) that is closed above
+                    uint32_t bg = ~cur;
+                    uint32_t open = bg & ~u;  // background with background above: joins an earlier pixel
+                    ebits[k] = bg & Wst & ~fill_toward_lsb(open, bg);
+                }
+                prevc = cur;
+                prevu = u;
+                cur = nextc;
+                u = nextu;
             }
+            // the border-following start is the foreground pixel LEFT of e
+#pragma unroll
+            for (int k = 0; k < K2_WPT; k++) {
+                hole[k] = ebits[k] >> 1;
+                if (k + 1 < K2_WPT) hole[k] |= (ebits[k + 1] & 1u) << 31;
+            }
+            extra = (int)(ebits[0] & 1u);  // start pixel = last pixel of the previous word group (w0 > 0 when set)
+            cnt = extra;
+#pragma unroll
+            for (int k = 0; k < K2_WPT; k++) cnt += __popc(outer[k]) + __popc(hole[k]);
         }
-        int cnt = __popc(outer) + __popc(hole);
         int incl = wave_iscan(cnt);
-        int tot = __shfl(incl, 63, WAVE);
-        if (tot == 0) continue;  // wave-uniform
-        unsigned base = 0;
-        if (lane == 63) base = atomicAdd(&G->nstarts, (unsigned)tot);
-        base = __shfl(base, 63, WAVE);
-        unsigned off = base + (unsigned)(incl - cnt);
-        uint32_t meta = (uint32_t)f | ((uint32_t)s << 16);
-        while (outer) {
-            int b = __ffs(outer) - 1;
-            outer &= outer - 1;
-            if (off < cap) starts[off] = make_uint2((uint32_t)(w * 32 + b) | ((uint32_t)y << 16), meta);
-            off++;
+        if (lane == 63) s_wsum[wid] = incl;
+        __syncthreads();
+        int wbase = 0, tot = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            int v = s_wsum[k];
+            if (k < wid) wbase += v;
+            tot += v;
         }
-        while (hole) {
-            int b = __ffs(hole) - 1;
-            hole &= hole - 1;
-            if (off < cap) starts[off] = make_uint2((uint32_t)(w * 32 + b) | ((uint32_t)y << 16), meta | (1u << 24));
-            off++;
+        if (threadIdx.x == 0 && tot) s_base = atomicAdd((unsigned *)&counts[f].nstarts, (unsigned)tot);
+        __syncthreads();
+        if (tot) {
+            unsigned off = s_base + (unsigned)(wbase + incl - cnt);
+            uint32_t meta = (uint32_t)f | ((uint32_t)s << 16);
+            if (extra) {
+                if (off < cap) fst[off] = make_uint2((uint32_t)(w0 * 32 - 1) | ((uint32_t)y << 16), meta | (1u << 24));
+                off++;
+            }
+#pragma unroll
+            for (int k = 0; k < K2_WPT; k++) {
+                uint32_t o = outer[k], hh = hole[k];
+                int xb = (w0 + k) * 32;
+                while (o) {
+                    int b = __ffs(o) - 1;
+                    o &= o - 1;
+                    if (off < cap) fst[off] = make_uint2((uint32_t)(xb + b) | ((uint32_t)y << 16), meta);
+                    off++;
+                }
+                while (hh) {
+                    int b = __ffs(hh) - 1;
+                    hh &= hh - 1;
+                    if (off < cap) fst[off] = make_uint2((uint32_t)(xb + b) | ((uint32_t)y << 16), meta | (1u << 24));
+                    off++;
+                }
+            }
+            if (threadIdx.x == 0 && s_base + (unsigned)tot > cap) atomicOr(&G->overflow, 1u);
         }
-        if (lane == 63 && base + (unsigned)tot > cap) atomicOr(&G->overflow, 1u);
+        __syncthreads();
     }
+    (void)W;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -286,52 +355,64 @@ __device__ __forceinline__ unsigned nb8(const MaskView &m, int x, int y)
 // padded raster index used to order discovery events like cvFindNextContour's scan
 __device__ __forceinline__ int pidx(int x, int y, int W) { return (y + 1) * (W + 2) + (x + 1); }
 
-// K3: one lane per start.  Walks the border exactly as icvFetchContour does (contours.cpp), counting points;
-// stops early when the start turns out not to be the canonical one (so each border is reported once, from
-// the pixel where cvFindNextContour would have started it) or when the contour exceeds maxPerimeterPixels.
+// checkpoints of a walk: state before emitting point CK*k, packed x | y << 13 | backdir << 26
+#define CK 64
+__device__ __forceinline__ uint32_t ck_pack(int x, int y, int sdir) { return (uint32_t)x | ((uint32_t)y << 13) | ((uint32_t)sdir << 26); }
+
+// K3: one lane per start.  Walks the border exactly as icvFetchContour does (contours.cpp), counting points.
+// A start is reported only if it is the canonical one of its border (the pixel where cvFindNextContour's
+// raster scan would have started it): outer borders start at their raster-first pixel, hole borders left of
+// the raster-first background pixel of the hole.  A walker gives up as soon as it meets an earlier pixel;
+// to make that happen fast on staircase edges a second cursor walks the border BACKWARDS for the first
+// BACK_BUDGET steps.  Walks longer than maxPerimeterPixels are dropped.  Every CK steps the state is
+// checkpointed so that K4 can replay the border with 64 lanes in parallel.
+#define BACK_BUDGET 48
 __global__ __launch_bounds__(256) void k_walk_count(const uint32_t *__restrict__ masks, const uint2 *__restrict__ starts,
-                                                     uint4 *__restrict__ contours, DevGlobal *__restrict__ G,
+                                                     uint4 *__restrict__ contours, uint32_t *__restrict__ ckpts,
+                                                     DevCounts *__restrict__ counts, DevGlobal *__restrict__ G,
                                                      const DevParams P)
 {
-    const unsigned cap = (unsigned)P.maxStarts * (unsigned)P.nframes;
-    unsigned n = G->nstarts;
-    n = n < cap ? n : cap;
-    const unsigned ccap = (unsigned)P.maxContours * (unsigned)P.nframes;
+    const int f = blockIdx.y;
+    unsigned n = (unsigned)counts[f].nstarts;
+    n = n < (unsigned)P.maxStarts ? n : (unsigned)P.maxStarts;
+    const unsigned ccap = (unsigned)P.maxContours;
     const int W = P.W, H = P.H, S = P.nscales;
+    const int nck = P.maxPerim / CK + 1;
+    const uint2 *fst = starts + (long long)f * P.maxStarts;
+    uint4 *fco = contours + (long long)f * P.maxContours;
+    uint32_t *fck = ckpts + (long long)f * P.maxContours * nck;
     for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        uint2 st = starts[i];
+        uint2 st = fst[i];
         int x0 = st.x & 0xffff, y0 = st.x >> 16;
-        int f = st.y & 0xffff, s = (st.y >> 16) & 0xff, hole = (st.y >> 24) & 1;
+        int s = (st.y >> 16) & 0xff, hole = (st.y >> 24) & 1;
         MaskView m;
         m.base = masks + (((long long)f * S + s) * (H + 2)) * P.WWP;
         m.WWP = P.WWP;
         // canonical key: outer = own index, hole = index of the background pixel to the right
         const int key = hole ? pidx(x0 + 1, y0, W) : pidx(x0, y0, W);
         unsigned nb = nb8(m, x0, y0);
-        int sdir, s_end;
-        s_end = sdir = hole ? 0 : 4;
-        int found = 0;
-        // do { s = (s - 1) & 7; } while (*i1 == 0 && s != s_end)   -- clockwise search for the last neighbour
-        for (int k = 0; k < 8; k++) {
-            sdir = (sdir - 1) & 7;
-            if ((nb >> sdir) & 1u) {
-                found = 1;
-                break;
-            }
-            if (sdir == s_end) break;
-        }
+        const int s_end = hole ? 0 : 4;
+        // do { s = (s - 1) & 7; } while (*i1 == 0 && s != s_end)  == first foreground clockwise from s_end - 1
         int count = 0, ok = 1;
-        if (!found || sdir == s_end) {
-            if (!((nb >> sdir) & 1u)) {
-                count = 1;  // single pixel domain
-                found = 0;
+        int slot = -1;
+        if (nb == 0) {
+            count = 1;  // single pixel domain
+        } else {
+            int sdir;
+            {
+                unsigned nb2 = nb | (nb << 8);
+                int c0 = (s_end - 1) & 7;
+                unsigned win = (nb2 >> (c0 + 1)) & 0xffu;
+                int t = 7 - (31 - __clz((int)win));
+                sdir = (c0 - t) & 7;
             }
-        }
-        if (found) {
             const int i1x = x0 + c_dx8[sdir], i1y = y0 + c_dy8[sdir];
+            // backward cursor starts on i1 with forward direction pointing at the start pixel
+            int bx = i1x, by = i1y, bf = (sdir + 4) & 7, bleft = BACK_BUDGET;
+            if (!hole && pidx(bx, by, W) < key) ok = 0;
             int cx = x0, cy = y0;
-            for (;;) {
-                // search counter-clockwise from sdir+1 for the next foreground neighbour
+            while (ok) {
+                // ---- forward step: first foreground counter-clockwise from sdir + 1
                 unsigned nb2 = nb | (nb << 8);
                 int start = (sdir + 1) & 7;
                 unsigned rot = (nb2 >> start) & 0xffu;
@@ -344,6 +425,19 @@ __global__ __launch_bounds__(256) void k_walk_count(const uint32_t *__restrict__
                     }
                 }
                 int sn = (start + t) & 7;
+                if ((count & (CK - 1)) == 0 && count) {
+                    if (slot < 0) {
+                        unsigned o = atomicAdd((unsigned *)&counts[f].ncontours, 1u);
+                        if (o < ccap) {
+                            slot = (int)o;
+                            fco[slot] = make_uint4(st.x, st.y, 0u, (unsigned)key);  // count 0 = not (yet) accepted
+                        } else {
+                            atomicOr(&G->overflow, 2u);
+                            ok = 0;
+                        }
+                    }
+                    if (slot >= 0) fck[(long long)slot * nck + count / CK] = ck_pack(cx, cy, sdir);
+                }
                 count++;
                 int nx = cx + c_dx8[sn], ny = cy + c_dy8[sn];
                 if (!ok || count > P.maxPerim) {
@@ -359,57 +453,94 @@ __global__ __launch_bounds__(256) void k_walk_count(const uint32_t *__restrict__
                 }
                 sdir = (sn + 4) & 7;
                 nb = nb8(m, cx, cy);
+                // ---- backward step (bounded): predecessor = first foreground clockwise from bf - 1
+                if (bleft > 0) {
+                    bleft--;
+                    unsigned bn = nb8(m, bx, by);
+                    unsigned bn2 = bn | (bn << 8);
+                    int c0 = (bf - 1) & 7;
+                    unsigned win = (bn2 >> (c0 + 1)) & 0xffu;
+                    int tz = 7 - (31 - __clz((int)win));
+                    if (hole) {
+                        for (int q = 0; q < tz; q++) {
+                            int d = (c0 - q) & 7;
+                            if (!(d & 1) && pidx(bx + c_dx8[d], by + c_dy8[d], W) < key) ok = 0;
+                        }
+                    }
+                    int bd = (c0 - tz) & 7;
+                    bx += c_dx8[bd];
+                    by += c_dy8[bd];
+                    bf = (bd + 4) & 7;
+                    if (!hole && pidx(bx, by, W) < key) ok = 0;
+                }
             }
         }
         if (ok && count >= P.minPerim && count <= P.maxPerim) {
-            unsigned o = atomicAdd(&G->ncontours, 1u);
-            if (o < ccap)
-                contours[o] = make_uint4(st.x, st.y, (unsigned)count, (unsigned)key);
-            else
-                atomicOr(&G->overflow, 2u);
+            if (slot < 0) {
+                unsigned o = atomicAdd((unsigned *)&counts[f].ncontours, 1u);
+                if (o < ccap) slot = (int)o;
+                else atomicOr(&G->overflow, 2u);
+            }
+            if (slot >= 0) fco[slot] = make_uint4(st.x, st.y, (unsigned)count, (unsigned)key);
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------------
-// K4: one wave per surviving contour: replay the walk into LDS (points packed x | y << 16), then
-// approxPolyDP(closed, eps = size * polygonalApproxAccuracyRate) exactly as approx.cpp approxPolyDP_<int>
-// orders its work (the slice stack is sequential, each slice's farthest-point search is a wave reduction
-// with first-maximum tie-break), then _findMarkerContours' gates (aruco.cpp): 4 points, convex, min side,
-// distance to the image border.
+// K4: one wave per surviving contour: replay the walk into LDS (points packed x | y << 16) -- lane l replays
+// points [CK*l, CK*l + CK) from checkpoint l -- then approxPolyDP(closed, eps = size *
+// polygonalApproxAccuracyRate) exactly as approx.cpp approxPolyDP_<int> orders its work (the slice stack is
+// sequential, each slice's farthest-point search is a wave reduction with first-maximum tie-break), then
+// _findMarkerContours' gates (aruco.cpp): 4 points, convex, min side, distance to the image border.
 #define DP_STACK 1024
 __global__ __launch_bounds__(64) void k_approx(const uint32_t *__restrict__ masks, const uint4 *__restrict__ contours,
-                                                DevCand *__restrict__ cands, DevCounts *__restrict__ counts,
-                                                DevGlobal *__restrict__ G, const DevParams P)
+                                                const uint32_t *__restrict__ ckpts, DevCand *__restrict__ cands,
+                                                DevCounts *__restrict__ counts, DevGlobal *__restrict__ G, const DevParams P)
 {
     extern __shared__ uint32_t pts[];  // maxPerim points
     __shared__ int2 stack[DP_STACK];
     __shared__ int dst[2 * 16];
     const int lane = lane_id();
-    const unsigned ccap = (unsigned)P.maxContours * (unsigned)P.nframes;
-    unsigned n = G->ncontours;
-    n = n < ccap ? n : ccap;
+    const int f = blockIdx.y;
+    unsigned n = (unsigned)counts[f].ncontours;
+    n = n < (unsigned)P.maxContours ? n : (unsigned)P.maxContours;
     const int W = P.W, H = P.H, S = P.nscales;
+    const int nck = P.maxPerim / CK + 1;
+    const uint4 *fco = contours + (long long)f * P.maxContours;
+    const uint32_t *fck = ckpts + (long long)f * P.maxContours * nck;
     for (unsigned ci = blockIdx.x; ci < n; ci += gridDim.x) {
-        uint4 c = contours[ci];
-        const int x0 = c.x & 0xffff, y0 = c.x >> 16;
-        const int f = c.y & 0xffff, s = (c.y >> 16) & 0xff, hole = (c.y >> 24) & 1;
+        uint4 c = fco[ci];
         const int count = (int)c.z;
+        if (count == 0) continue;  // slot of a walk that was dropped
+        const int x0 = c.x & 0xffff, y0 = c.x >> 16;
+        const int s = (c.y >> 16) & 0xff, hole = (c.y >> 24) & 1;
         MaskView m;
         m.base = masks + (((long long)f * S + s) * (H + 2)) * P.WWP;
         m.WWP = P.WWP;
         __syncthreads();
-        // ---- replay the border (wave-uniform; lane 0 stores)
-        {
-            unsigned nb = nb8(m, x0, y0);
-            int sdir = hole ? 0 : 4;
-            for (int k = 0; k < 8; k++) {
-                sdir = (sdir - 1) & 7;
-                if ((nb >> sdir) & 1u) break;
+        // ---- replay the border, CK points per lane
+        for (int seg = lane; seg * CK < count; seg += 64) {
+            int cx, cy, sdir;
+            if (seg == 0) {
+                cx = x0;
+                cy = y0;
+                unsigned nb0 = nb8(m, x0, y0);
+                unsigned nb2 = nb0 | (nb0 << 8);
+                int c0 = ((hole ? 0 : 4) - 1) & 7;
+                unsigned win = (nb2 >> (c0 + 1)) & 0xffu;
+                int t = 7 - (31 - __clz((int)win));
+                sdir = (c0 - t) & 7;
+            } else {
+                uint32_t ck = fck[(long long)ci * nck + seg];
+                cx = ck & 0x1fff;
+                cy = (ck >> 13) & 0x1fff;
+                sdir = ck >> 26;
             }
-            int cx = x0, cy = y0;
-            for (int k = 0; k < count; k++) {
-                if (lane == 0) pts[k] = (uint32_t)cx | ((uint32_t)cy << 16);
+            int kend = seg * CK + CK;
+            kend = kend < count ? kend : count;
+            for (int k = seg * CK; k < kend; k++) {
+                pts[k] = (uint32_t)cx | ((uint32_t)cy << 16);
+                unsigned nb = nb8(m, cx, cy);
                 unsigned nb2 = nb | (nb << 8);
                 int start = (sdir + 1) & 7;
                 int t = __ffs((nb2 >> start) & 0xffu) - 1;
@@ -417,7 +548,6 @@ __global__ __launch_bounds__(64) void k_approx(const uint32_t *__restrict__ mask
                 cx += c_dx8[sn];
                 cy += c_dy8[sn];
                 sdir = (sn + 4) & 7;
-                if (k + 1 < count) nb = nb8(m, cx, cy);
             }
         }
         __syncthreads();
@@ -1358,125 +1488,115 @@ __global__ __launch_bounds__(64) void k_subpix(const uint8_t *__restrict__ gray,
 }
 
 // ------------------------------------------------------------------------------------------------
-// K8: per-marker pose = cv::solvePnP(SOLVEPNP_ITERATIVE) for 4 coplanar points as
-// calibration.cpp cvFindExtrinsicCameraParams2 does it (undistort -> normalised-DLT homography ->
-// R,t -> Levenberg-Marquardt on the distorted reprojection error, CvLevMarq state machine), followed by
-// getReprojectionError / calcFiducialArea / object_error of aruco_detect.cpp:203-221,179-200,493-495.
-// One lane per marker; double precision; the symmetric eigenproblems use cyclic Jacobi.
-template <int N>
-__device__ void jacobi_eigen(double *A, double *w, double *V)
+// K8: per-marker pose = cv::solvePnP(SOLVEPNP_ITERATIVE) for the 4 coplanar marker corners as
+// calibration.cpp cvFindExtrinsicCameraParams2 does it: undistort (5 fixed-point iterations) -> homography
+// between the marker square and the normalised image points -> R,t -> Levenberg-Marquardt on the distorted
+// reprojection error with CvLevMarq's state machine (lambda 1e-3, x10 / /10, 20 iterations, eps FLT_EPSILON,
+// analytic Jacobians of cvProjectPoints2 / cvRodrigues2), followed by getReprojectionError /
+// calcFiducialArea / object_error of aruco_detect.cpp:203-221,179-200,493-495.
+// Eight lanes per marker: lane g owns residual g (corner g>>1, x or y); J^T J is reduced with xor-shuffles.
+// What is only an initial guess or a damped linear solve is computed in closed form (square-to-quad
+// homography instead of the 9x9 DLT eigenproblem, LDL^T instead of SVD back-substitution): the converged
+// minimum is what is compared (tolerance in tests/, measured ~1e-12).
+__device__ __forceinline__ double shfl_xor_f64(double v, int mask)
 {
-    for (int i = 0; i < N; i++)
-        for (int j = 0; j < N; j++) V[i * N + j] = i == j ? 1. : 0.;
-    for (int sweep = 0; sweep < 60; sweep++) {
-        double off = 0;
-        for (int p = 0; p < N; p++)
-            for (int q = p + 1; q < N; q++) off += A[p * N + q] * A[p * N + q];
-        if (off < 1e-300) break;
-        for (int p = 0; p < N; p++)
-            for (int q = p + 1; q < N; q++) {
-                double apq = A[p * N + q];
+    unsigned long long u = __double_as_longlong(v);
+    unsigned lo = __shfl_xor((unsigned)u, mask, WAVE);
+    unsigned hi = __shfl_xor((unsigned)(u >> 32), mask, WAVE);
+    return __longlong_as_double(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ double grp_sum8(double v)
+{
+    v += shfl_xor_f64(v, 1);
+    v += shfl_xor_f64(v, 2);
+    v += shfl_xor_f64(v, 4);
+    return v;
+}
+
+struct PoseCam {
+    double K[9];
+    double D[5];
+    double fiducial_len;
+};
+
+// symmetric 3x3 eigen-decomposition by cyclic Jacobi, fully unrolled (static register indexing)
+__device__ __forceinline__ void jacobi3(double A[3][3], double V[3][3])
+{
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) V[i][j] = i == j ? 1. : 0.;
+    for (int sweep = 0; sweep < 30; sweep++) {
+        double off = A[0][1] * A[0][1] + A[0][2] * A[0][2] + A[1][2] * A[1][2];
+        double dg = A[0][0] * A[0][0] + A[1][1] * A[1][1] + A[2][2] * A[2][2];
+        if (off <= 1e-60 * dg || off < 1e-300) break;
+#pragma unroll
+        for (int p = 0; p < 3; p++)
+#pragma unroll
+            for (int q = p + 1; q < 3; q++) {
+                double apq = A[p][q];
                 if (fabs(apq) < 1e-300) continue;
-                double app = A[p * N + p], aqq = A[q * N + q];
-                double theta = (aqq - app) / (2. * apq);
+                double theta = (A[q][q] - A[p][p]) / (2. * apq);
                 double t = (theta >= 0 ? 1. : -1.) / (fabs(theta) + sqrt(theta * theta + 1.));
                 double c = 1. / sqrt(t * t + 1.), s = t * c;
-                for (int k = 0; k < N; k++) {
-                    double akp = A[k * N + p], akq = A[k * N + q];
-                    A[k * N + p] = c * akp - s * akq;
-                    A[k * N + q] = s * akp + c * akq;
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    double akp = A[k][p], akq = A[k][q];
+                    A[k][p] = c * akp - s * akq;
+                    A[k][q] = s * akp + c * akq;
                 }
-                for (int k = 0; k < N; k++) {
-                    double apk = A[p * N + k], aqk = A[q * N + k];
-                    A[p * N + k] = c * apk - s * aqk;
-                    A[q * N + k] = s * apk + c * aqk;
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    double apk = A[p][k], aqk = A[q][k];
+                    A[p][k] = c * apk - s * aqk;
+                    A[q][k] = s * apk + c * aqk;
                 }
-                for (int k = 0; k < N; k++) {
-                    double vpk = V[p * N + k], vqk = V[q * N + k];
-                    V[p * N + k] = c * vpk - s * vqk;
-                    V[q * N + k] = s * vpk + c * vqk;
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    double vpk = V[p][k], vqk = V[q][k];
+                    V[p][k] = c * vpk - s * vqk;
+                    V[q][k] = s * vpk + c * vqk;
                 }
             }
     }
-    for (int i = 0; i < N; i++) w[i] = A[i * N + i];
-    for (int i = 0; i < N - 1; i++) {
-        int m = i;
-        for (int j = i + 1; j < N; j++)
-            if (w[j] > w[m]) m = j;
-        if (m != i) {
-            double t = w[i];
-            w[i] = w[m];
-            w[m] = t;
-            for (int k = 0; k < N; k++) {
-                t = V[i * N + k];
-                V[i * N + k] = V[m * N + k];
-                V[m * N + k] = t;
-            }
-        }
-    }
 }
 
-__device__ void mat3_mul(const double *A, const double *B, double *C)
+// R <- U * Vt of its SVD  ( = R * (RtR)^(-1/2) ), as cvRodrigues2 does before reading the axis
+__device__ __forceinline__ void orthonormalize3(double R[9])
 {
-    double T[9];
+    double A[3][3], V[3][3];
+#pragma unroll
     for (int i = 0; i < 3; i++)
-        for (int j = 0; j < 3; j++) T[i * 3 + j] = A[i * 3] * B[j] + A[i * 3 + 1] * B[3 + j] + A[i * 3 + 2] * B[6 + j];
-    for (int i = 0; i < 9; i++) C[i] = T[i];
-}
-
-__device__ void orthonormalize3(double *R)
-{
-    double RtR[9], w[3], V[9];
+#pragma unroll
+        for (int j = 0; j < 3; j++) A[i][j] = R[i] * R[j] + R[3 + i] * R[3 + j] + R[6 + i] * R[6 + j];
+    jacobi3(A, V);
+    double Pm[3][3];
+#pragma unroll
     for (int i = 0; i < 3; i++)
-        for (int j = 0; j < 3; j++) RtR[i * 3 + j] = R[i] * R[j] + R[3 + i] * R[3 + j] + R[6 + i] * R[6 + j];
-    jacobi_eigen<3>(RtR, w, V);
-    double Pm[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < 3; j++) Pm[i][j] = 0;
+#pragma unroll
     for (int k = 0; k < 3; k++) {
-        double is = w[k] > 1e-300 ? 1. / sqrt(w[k]) : 0.;
+        double w = A[k][k];
+        double is = w > 1e-300 ? 1. / sqrt(w) : 0.;
+#pragma unroll
         for (int i = 0; i < 3; i++)
-            for (int j = 0; j < 3; j++) Pm[i * 3 + j] += V[k * 3 + i] * V[k * 3 + j] * is;
+#pragma unroll
+            for (int j = 0; j < 3; j++) Pm[i][j] += V[k][i] * V[k][j] * is;
     }
-    mat3_mul(R, Pm, R);
+    double T[9];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) T[i * 3 + j] = R[i * 3] * Pm[0][j] + R[i * 3 + 1] * Pm[1][j] + R[i * 3 + 2] * Pm[2][j];
+#pragma unroll
+    for (int i = 0; i < 9; i++) R[i] = T[i];
 }
 
-__device__ void rodrigues_v2m(const double *r_in, double *R, double *J)
-{
-    double rx = r_in[0], ry = r_in[1], rz = r_in[2];
-    double theta = sqrt(rx * rx + ry * ry + rz * rz);
-    if (theta < DBL_EPSILON) {
-        for (int i = 0; i < 9; i++) R[i] = (i % 4 == 0) ? 1. : 0.;
-        if (J) {
-            for (int i = 0; i < 27; i++) J[i] = 0;
-            J[5] = J[15] = J[19] = -1;
-            J[7] = J[11] = J[21] = 1;
-        }
-        return;
-    }
-    double c = cos(theta), s = sin(theta), c1 = 1. - c, itheta = theta ? 1. / theta : 0.;
-    rx *= itheta;
-    ry *= itheta;
-    rz *= itheta;
-    double rrt[9] = {rx * rx, rx * ry, rx * rz, rx * ry, ry * ry, ry * rz, rx * rz, ry * rz, rz * rz};
-    double r_x[9] = {0, -rz, ry, rz, 0, -rx, -ry, rx, 0};
-    for (int k = 0; k < 9; k++) R[k] = c * ((k % 4 == 0) ? 1. : 0.) + c1 * rrt[k] + s * r_x[k];
-    if (J) {
-        const double I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-        double drrt[27] = {rx + rx, ry, rz, ry, 0,       0,  rz, 0,  0,       0, rx, 0, rx, ry + ry,
-                           rz,      0,  rz, 0,  0,       0,  rx, 0,  0,       ry, rx, ry, rz + rz};
-        const double d_r_x_[27] = {0, 0, 0, 0, 0, -1, 0, 1, 0, 0, 0, 1, 0, 0, 0, -1, 0, 0, 0, -1, 0, 1, 0, 0, 0, 0, 0};
-        for (int i = 0; i < 3; i++) {
-            double ri = i == 0 ? rx : i == 1 ? ry : rz;
-            double a0 = -s * ri, a1 = (s - 2 * c1 * itheta) * ri, a2 = c1 * itheta;
-            double a3 = (c - s * itheta) * ri, a4 = s * itheta;
-            for (int k = 0; k < 9; k++)
-                J[i * 9 + k] = a0 * I[k] + a1 * rrt[k] + a2 * drrt[i * 9 + k] + a3 * r_x[k] + a4 * d_r_x_[i * 9 + k];
-        }
-    }
-}
-
-__device__ void rodrigues_m2v(const double *Rin, double *r)
+__device__ __forceinline__ void rodrigues_m2v(const double Rin[9], double r[3])
 {
     double R[9];
+#pragma unroll
     for (int i = 0; i < 9; i++) R[i] = Rin[i];
     orthonormalize3(R);
     double rx = R[7] - R[5], ry = R[2] - R[6], rz = R[3] - R[1];
@@ -1513,117 +1633,150 @@ __device__ void rodrigues_m2v(const double *Rin, double *r)
     r[2] = rz;
 }
 
-// cvProjectPoints2Internal for 4 points, plumb-bob k1 k2 p1 p2 k3
-__device__ void project4(const double *M, const double *rv, const double *tv, const double *K, const double *k,
-                         double *m, double *dpdr, double *dpdt)
+// cvRodrigues2 vector -> matrix with dR/dr (J[i*9+k] = dR_k / dr_i)
+__device__ __forceinline__ void rodrigues_v2m(const double r_in[3], double R[9], double J[27], bool wantJ)
 {
-    double R[9], dRdr[27];
-    rodrigues_v2m(rv, R, dpdr ? dRdr : nullptr);
-    double fx = K[0], fy = K[4], cx = K[2], cy = K[5];
-    for (int i = 0; i < 4; i++) {
-        double X = M[i * 3], Y = M[i * 3 + 1], Z = M[i * 3 + 2];
-        double x = R[0] * X + R[1] * Y + R[2] * Z + tv[0];
-        double y = R[3] * X + R[4] * Y + R[5] * Z + tv[1];
-        double z = R[6] * X + R[7] * Y + R[8] * Z + tv[2];
-        z = z ? 1. / z : 1;
-        x *= z;
-        y *= z;
-        double r2 = x * x + y * y, r4 = r2 * r2, r6 = r4 * r2;
-        double a1 = 2 * x * y, a2 = r2 + 2 * x * x, a3 = r2 + 2 * y * y;
-        double cdist = 1 + k[0] * r2 + k[1] * r4 + k[4] * r6;
-        double icdist2 = 1.;
-        double xd = x * cdist * icdist2 + k[2] * a1 + k[3] * a2;
-        double yd = y * cdist * icdist2 + k[2] * a3 + k[3] * a1;
-        m[i * 2] = xd * fx + cx;
-        m[i * 2 + 1] = yd * fy + cy;
-        if (dpdt) {
-            double dxdt[3] = {z, 0, -x * z}, dydt[3] = {0, z, -y * z};
-            for (int j = 0; j < 3; j++) {
-                double dr2dt = 2 * x * dxdt[j] + 2 * y * dydt[j];
-                double dcdist_dt = k[0] * dr2dt + 2 * k[1] * r2 * dr2dt + 3 * k[4] * r4 * dr2dt;
-                double da1dt = 2 * (x * dydt[j] + y * dxdt[j]);
-                double dmxdt = (dxdt[j] * cdist * icdist2 + x * dcdist_dt * icdist2 + k[2] * da1dt + k[3] * (dr2dt + 4 * x * dxdt[j]));
-                double dmydt = (dydt[j] * cdist * icdist2 + y * dcdist_dt * icdist2 + k[2] * (dr2dt + 4 * y * dydt[j]) + k[3] * da1dt);
-                dpdt[(2 * i) * 3 + j] = fx * dmxdt;
-                dpdt[(2 * i + 1) * 3 + j] = fy * dmydt;
-            }
+    double rx = r_in[0], ry = r_in[1], rz = r_in[2];
+    double theta = sqrt(rx * rx + ry * ry + rz * rz);
+    if (theta < DBL_EPSILON) {
+#pragma unroll
+        for (int i = 0; i < 9; i++) R[i] = (i % 4 == 0) ? 1. : 0.;
+        if (wantJ) {
+#pragma unroll
+            for (int i = 0; i < 27; i++) J[i] = 0;
+            J[5] = J[15] = J[19] = -1;
+            J[7] = J[11] = J[21] = 1;
         }
-        if (dpdr) {
-            double dx0dr[3] = {X * dRdr[0] + Y * dRdr[1] + Z * dRdr[2], X * dRdr[9] + Y * dRdr[10] + Z * dRdr[11],
-                               X * dRdr[18] + Y * dRdr[19] + Z * dRdr[20]};
-            double dy0dr[3] = {X * dRdr[3] + Y * dRdr[4] + Z * dRdr[5], X * dRdr[12] + Y * dRdr[13] + Z * dRdr[14],
-                               X * dRdr[21] + Y * dRdr[22] + Z * dRdr[23]};
-            double dz0dr[3] = {X * dRdr[6] + Y * dRdr[7] + Z * dRdr[8], X * dRdr[15] + Y * dRdr[16] + Z * dRdr[17],
-                               X * dRdr[24] + Y * dRdr[25] + Z * dRdr[26]};
-            for (int j = 0; j < 3; j++) {
-                double dxdr = z * (dx0dr[j] - x * dz0dr[j]);
-                double dydr = z * (dy0dr[j] - y * dz0dr[j]);
-                double dr2dr = 2 * x * dxdr + 2 * y * dydr;
-                double dcdist_dr = (k[0] + 2 * k[1] * r2 + 3 * k[4] * r4) * dr2dr;
-                double da1dr = 2 * (x * dydr + y * dxdr);
-                double dmxdr = (dxdr * cdist * icdist2 + x * dcdist_dr * icdist2 + k[2] * da1dr + k[3] * (dr2dr + 4 * x * dxdr));
-                double dmydr = (dydr * cdist * icdist2 + y * dcdist_dr * icdist2 + k[2] * (dr2dr + 4 * y * dydr) + k[3] * da1dr);
-                dpdr[(2 * i) * 3 + j] = fx * dmxdr;
-                dpdr[(2 * i + 1) * 3 + j] = fy * dmydr;
-            }
+        return;
+    }
+    double c = cos(theta), s = sin(theta), c1 = 1. - c, itheta = theta ? 1. / theta : 0.;
+    rx *= itheta;
+    ry *= itheta;
+    rz *= itheta;
+    const double rrt[9] = {rx * rx, rx * ry, rx * rz, rx * ry, ry * ry, ry * rz, rx * rz, ry * rz, rz * rz};
+    const double r_x[9] = {0, -rz, ry, rz, 0, -rx, -ry, rx, 0};
+#pragma unroll
+    for (int k = 0; k < 9; k++) R[k] = c * ((k % 4 == 0) ? 1. : 0.) + c1 * rrt[k] + s * r_x[k];
+    if (wantJ) {
+        const double I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+        const double drrt[27] = {rx + rx, ry, rz, ry, 0,       0,  rz, 0,  0,       0, rx, 0, rx, ry + ry,
+                                 rz,      0,  rz, 0,  0,       0,  rx, 0,  0,       ry, rx, ry, rz + rz};
+        const double d_r_x_[27] = {0, 0, 0, 0, 0, -1, 0, 1, 0, 0, 0, 1, 0, 0, 0, -1, 0, 0, 0, -1, 0, 1, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            double ri = i == 0 ? rx : i == 1 ? ry : rz;
+            double a0 = -s * ri, a1 = (s - 2 * c1 * itheta) * ri, a2 = c1 * itheta;
+            double a3 = (c - s * itheta) * ri, a4 = s * itheta;
+#pragma unroll
+            for (int k = 0; k < 9; k++)
+                J[i * 9 + k] = a0 * I[k] + a1 * rrt[k] + a2 * drrt[i * 9 + k] + a3 * r_x[k] + a4 * d_r_x_[i * 9 + k];
         }
     }
 }
 
-// fundam.cpp HomographyEstimatorCallback::runKernel on 4 correspondences (float inputs)
-__device__ int homography4(const double *Mxy, const double *mn, double *H)
+// cvProjectPoints2Internal for ONE object point and ONE image coordinate (sel = 0: x, 1: y);
+// Jrow[0..2] = d/d rvec, Jrow[3..5] = d/d tvec
+__device__ __forceinline__ double project_one(const double M[3], const double param[6], const double K[9], const double k[5],
+                                               int sel, double Jrow[6], bool wantJ)
 {
-    const int count = 4;
-    float Mf[8], mf[8];
-    for (int i = 0; i < 8; i++) {
-        Mf[i] = (float)Mxy[i];
-        mf[i] = (float)mn[i];
+    double R[9], dRdr[27];
+    rodrigues_v2m(param, R, dRdr, wantJ);
+    const double fx = K[0], fy = K[4], cx = K[2], cy = K[5];
+    const double X = M[0], Y = M[1], Z = M[2];
+    double x = R[0] * X + R[1] * Y + R[2] * Z + param[3];
+    double y = R[3] * X + R[4] * Y + R[5] * Z + param[4];
+    double z = R[6] * X + R[7] * Y + R[8] * Z + param[5];
+    z = z ? 1. / z : 1;
+    x *= z;
+    y *= z;
+    double r2 = x * x + y * y, r4 = r2 * r2, r6 = r4 * r2;
+    double a1 = 2 * x * y, a2 = r2 + 2 * x * x, a3 = r2 + 2 * y * y;
+    double cdist = 1 + k[0] * r2 + k[1] * r4 + k[4] * r6;
+    const double icdist2 = 1.;
+    double xd = x * cdist * icdist2 + k[2] * a1 + k[3] * a2;
+    double yd = y * cdist * icdist2 + k[2] * a3 + k[3] * a1;
+    double out = sel == 0 ? xd * fx + cx : yd * fy + cy;
+    if (wantJ) {
+        const double dxdt[3] = {z, 0, -x * z}, dydt[3] = {0, z, -y * z};
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            double dr2dt = 2 * x * dxdt[j] + 2 * y * dydt[j];
+            double dcdist_dt = k[0] * dr2dt + 2 * k[1] * r2 * dr2dt + 3 * k[4] * r4 * dr2dt;
+            double da1dt = 2 * (x * dydt[j] + y * dxdt[j]);
+            double dmxdt = (dxdt[j] * cdist * icdist2 + x * dcdist_dt * icdist2 + k[2] * da1dt + k[3] * (dr2dt + 4 * x * dxdt[j]));
+            double dmydt = (dydt[j] * cdist * icdist2 + y * dcdist_dt * icdist2 + k[2] * (dr2dt + 4 * y * dydt[j]) + k[3] * da1dt);
+            Jrow[3 + j] = sel == 0 ? fx * dmxdt : fy * dmydt;
+        }
+        const double dx0dr[3] = {X * dRdr[0] + Y * dRdr[1] + Z * dRdr[2], X * dRdr[9] + Y * dRdr[10] + Z * dRdr[11],
+                                 X * dRdr[18] + Y * dRdr[19] + Z * dRdr[20]};
+        const double dy0dr[3] = {X * dRdr[3] + Y * dRdr[4] + Z * dRdr[5], X * dRdr[12] + Y * dRdr[13] + Z * dRdr[14],
+                                 X * dRdr[21] + Y * dRdr[22] + Z * dRdr[23]};
+        const double dz0dr[3] = {X * dRdr[6] + Y * dRdr[7] + Z * dRdr[8], X * dRdr[15] + Y * dRdr[16] + Z * dRdr[17],
+                                 X * dRdr[24] + Y * dRdr[25] + Z * dRdr[26]};
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            double dxdr = z * (dx0dr[j] - x * dz0dr[j]);
+            double dydr = z * (dy0dr[j] - y * dz0dr[j]);
+            double dr2dr = 2 * x * dxdr + 2 * y * dydr;
+            double dcdist_dr = (k[0] + 2 * k[1] * r2 + 3 * k[4] * r4) * dr2dr;
+            double da1dr = 2 * (x * dydr + y * dxdr);
+            double dmxdr = (dxdr * cdist * icdist2 + x * dcdist_dr * icdist2 + k[2] * da1dr + k[3] * (dr2dr + 4 * x * dxdr));
+            double dmydr = (dydr * cdist * icdist2 + y * dcdist_dr * icdist2 + k[2] * (dr2dr + 4 * y * dydr) + k[3] * da1dr);
+            Jrow[j] = sel == 0 ? fx * dmxdr : fy * dmydr;
+        }
     }
-    double LtL[81], Wv[9], V[81];
-    double cMx = 0, cMy = 0, cmx = 0, cmy = 0, sMx = 0, sMy = 0, smx = 0, smy = 0;
-    for (int i = 0; i < count; i++) {
-        cmx += mf[2 * i];
-        cmy += mf[2 * i + 1];
-        cMx += Mf[2 * i];
-        cMy += Mf[2 * i + 1];
+    return out;
+}
+
+// solve (JtJ with its diagonal scaled by 1 + lambda) x = JtErr, JtJ symmetric positive definite (packed upper
+// triangle, row-major: index of (a, b), a <= b, is a*6 - a*(a-1)/2 + (b - a)); LDL^T, unrolled
+__device__ __forceinline__ void solve6_spd(const double S[21], const double g[6], double lambda, double x[6])
+{
+    double A[6][6];
+    {
+        int idx = 0;
+#pragma unroll
+        for (int a = 0; a < 6; a++)
+#pragma unroll
+            for (int b = a; b < 6; b++) {
+                A[a][b] = S[idx];
+                A[b][a] = S[idx];
+                idx++;
+            }
     }
-    cmx /= count;
-    cmy /= count;
-    cMx /= count;
-    cMy /= count;
-    for (int i = 0; i < count; i++) {
-        smx += fabs(mf[2 * i] - cmx);
-        smy += fabs(mf[2 * i + 1] - cmy);
-        sMx += fabs(Mf[2 * i] - cMx);
-        sMy += fabs(Mf[2 * i + 1] - cMy);
+#pragma unroll
+    for (int i = 0; i < 6; i++) A[i][i] *= 1. + lambda;
+    double L[6][6], Dg[6];
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+        double d = A[j][j];
+#pragma unroll
+        for (int k = 0; k < j; k++) d -= L[j][k] * L[j][k] * Dg[k];
+        Dg[j] = d;
+        double id = d != 0. ? 1. / d : 0.;
+#pragma unroll
+        for (int i = j + 1; i < 6; i++) {
+            double v = A[i][j];
+#pragma unroll
+            for (int k = 0; k < j; k++) v -= L[i][k] * L[j][k] * Dg[k];
+            L[i][j] = v * id;
+        }
     }
-    if (fabs(smx) < DBL_EPSILON || fabs(smy) < DBL_EPSILON || fabs(sMx) < DBL_EPSILON || fabs(sMy) < DBL_EPSILON) return 0;
-    smx = count / smx;
-    smy = count / smy;
-    sMx = count / sMx;
-    sMy = count / sMy;
-    double invHnorm[9] = {1. / smx, 0, cmx, 0, 1. / smy, cmy, 0, 0, 1};
-    double Hnorm2[9] = {sMx, 0, -cMx * sMx, 0, sMy, -cMy * sMy, 0, 0, 1};
-    for (int i = 0; i < 81; i++) LtL[i] = 0;
-    for (int i = 0; i < count; i++) {
-        double x = (mf[2 * i] - cmx) * smx, y = (mf[2 * i + 1] - cmy) * smy;
-        double X = (Mf[2 * i] - cMx) * sMx, Y = (Mf[2 * i + 1] - cMy) * sMy;
-        double Lx[9] = {X, Y, 1, 0, 0, 0, -x * X, -x * Y, -x};
-        double Ly[9] = {0, 0, 0, X, Y, 1, -y * X, -y * Y, -y};
-        for (int j = 0; j < 9; j++)
-            for (int k = j; k < 9; k++) LtL[j * 9 + k] += Lx[j] * Lx[k] + Ly[j] * Ly[k];
+    double yv[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        double v = g[i];
+#pragma unroll
+        for (int k = 0; k < i; k++) v -= L[i][k] * yv[k];
+        yv[i] = v;
     }
-    for (int j = 0; j < 9; j++)
-        for (int k = 0; k < j; k++) LtL[j * 9 + k] = LtL[k * 9 + j];
-    jacobi_eigen<9>(LtL, Wv, V);
-    double H0[9], T[9];
-    for (int i = 0; i < 9; i++) H0[i] = V[8 * 9 + i];
-    mat3_mul(invHnorm, H0, T);
-    mat3_mul(T, Hnorm2, H0);
-    if (H0[8] == 0) return 0;
-    double sc = 1. / H0[8];
-    for (int i = 0; i < 9; i++) H[i] = H0[i] * sc;
-    return 1;
+#pragma unroll
+    for (int i = 5; i >= 0; i--) {
+        double v = Dg[i] != 0. ? yv[i] / Dg[i] : 0.;
+#pragma unroll
+        for (int k = i + 1; k < 6; k++) v -= L[k][i] * x[k];
+        x[i] = v;
+    }
 }
 
 __device__ double dist2f_d(float x1f, float y1f, float x2f, float y2f)
@@ -1633,221 +1786,207 @@ __device__ double dist2f_d(float x1f, float y1f, float x2f, float y2f)
     return sqrt(dx * dx + dy * dy);
 }
 
-struct PoseCam {
-    double K[9];
-    double D[5];
-    double fiducial_len;
-};
-
-__device__ void lm_step(const double *JtJ, const double *JtErr, const double *prevParam, double *param, int lambdaLg10)
-{
-    const double LOG10 = log(10.);
-    double lambda = exp(lambdaLg10 * LOG10);
-    double A[36], w[6], V[36];
-    for (int i = 0; i < 36; i++) A[i] = JtJ[i];
-    for (int i = 0; i < 6; i++) A[i * 6 + i] *= 1. + lambda;
-    jacobi_eigen<6>(A, w, V);
-    double thr = 0;
-    for (int i = 0; i < 6; i++) thr += fabs(w[i]);
-    thr *= DBL_EPSILON * 2;
-    double x[6] = {0, 0, 0, 0, 0, 0};
-    for (int k = 0; k < 6; k++) {
-        if (fabs(w[k]) <= thr) continue;
-        double d = 0;
-        for (int i = 0; i < 6; i++) d += V[k * 6 + i] * JtErr[i];
-        d /= w[k];
-        for (int i = 0; i < 6; i++) x[i] += V[k * 6 + i] * d;
-    }
-    for (int i = 0; i < 6; i++) param[i] = prevParam[i] - x[i];
-}
-
-__device__ int solve_pnp_square(const PoseCam &cam, const float *corners, double marker_len, double *rvec, double *tvec,
-                                double *reproj)
-{
-    const int count = 4, max_iter = 20;
-    float ml = (float)marker_len;
-    float objf[12] = {-ml / 2.f, ml / 2.f, 0, ml / 2.f, ml / 2.f, 0, ml / 2.f, -ml / 2.f, 0, -ml / 2.f, -ml / 2.f, 0};
-    double M[12], m[8], mn[8], Mxy[8];
-    for (int i = 0; i < 12; i++) M[i] = objf[i];
-    for (int i = 0; i < 8; i++) m[i] = corners[i];
-    const double *K = cam.K, *k = cam.D;
-    // cvUndistortPoints, 5 fixed iterations
-    {
-        double fx = K[0], fy = K[4], ifx = 1. / fx, ify = 1. / fy, cx = K[2], cy = K[5];
-        for (int i = 0; i < count; i++) {
-            double x = m[2 * i], y = m[2 * i + 1], x0, y0, u = x, v = y;
-            x = (x - cx) * ifx;
-            y = (y - cy) * ify;
-            x0 = x;
-            y0 = y;
-            for (int j = 0; j < 5; j++) {
-                double r2 = x * x + y * y;
-                double icdist = (1) / (1 + ((k[4] * r2 + k[1]) * r2 + k[0]) * r2);
-                if (icdist < 0) {
-                    x = (u - cx) * ifx;
-                    y = (v - cy) * ify;
-                    break;
-                }
-                double deltaX = 2 * k[2] * x * y + k[3] * (r2 + 2 * x * x);
-                double deltaY = k[2] * (r2 + 2 * y * y) + 2 * k[3] * x * y;
-                x = (x0 - deltaX) * icdist;
-                y = (y0 - deltaY) * icdist;
-            }
-            mn[2 * i] = x;
-            mn[2 * i + 1] = y;
-        }
-    }
-    double param[6] = {0, 0, 0, 0, 0, 0};
-    {
-        // planar branch with R_transform = I (marker points lie in z = 0, centred): Mxy = (X, Y)
-        double Mc[3] = {0, 0, 0};
-        for (int i = 0; i < count; i++)
-            for (int j = 0; j < 3; j++) Mc[j] += M[i * 3 + j];
-        for (int j = 0; j < 3; j++) Mc[j] /= count;
-        double tt[3] = {-Mc[0], -Mc[1], -Mc[2]};
-        for (int i = 0; i < count; i++) {
-            Mxy[2 * i] = M[i * 3] + tt[0];
-            Mxy[2 * i + 1] = M[i * 3 + 1] + tt[1];
-        }
-        double h[9], R[9];
-        if (homography4(Mxy, mn, h)) {
-            double h1_norm = sqrt(h[0] * h[0] + h[3] * h[3] + h[6] * h[6]);
-            double h2_norm = sqrt(h[1] * h[1] + h[4] * h[4] + h[7] * h[7]);
-            double s1 = 1. / fmax(h1_norm, DBL_EPSILON), s2 = 1. / fmax(h2_norm, DBL_EPSILON);
-            double st = 2. / fmax(h1_norm + h2_norm, DBL_EPSILON);
-            double t3[3] = {h[2] * st, h[5] * st, h[8] * st};
-            h[0] *= s1;
-            h[3] *= s1;
-            h[6] *= s1;
-            h[1] *= s2;
-            h[4] *= s2;
-            h[7] *= s2;
-            h[2] = h[3] * h[7] - h[6] * h[4];
-            h[5] = h[6] * h[1] - h[0] * h[7];
-            h[8] = h[0] * h[4] - h[3] * h[1];
-            double rtmp[3];
-            rodrigues_m2v(h, rtmp);
-            rodrigues_v2m(rtmp, h, nullptr);
-            for (int i = 0; i < 3; i++) param[3 + i] = h[i * 3] * tt[0] + h[i * 3 + 1] * tt[1] + h[i * 3 + 2] * tt[2] + t3[i];
-            for (int i = 0; i < 9; i++) R[i] = h[i];
-        } else {
-            for (int i = 0; i < 9; i++) R[i] = (i % 4 == 0) ? 1. : 0.;
-        }
-        rodrigues_m2v(R, param);
-    }
-    // CvLevMarq
-    double prevParam[6], JtJ[36], JtErr[6], J[48], err[8], dpdr[24], dpdt[24], proj[8];
-    double prevErrNorm = 0, errNorm = 0;
-    int lambdaLg10 = -3, iters = 0, state = 1;
-    const int nerr = 8;
-    for (;;) {
-        int needJ = 0, needErr = 0;
-        if (state == 1) {
-            needJ = needErr = 1;
-            state = 2;
-        } else if (state == 2) {
-            for (int a = 0; a < 6; a++) {
-                for (int b = 0; b < 6; b++) {
-                    double acc = 0;
-                    for (int kk = 0; kk < nerr; kk++) acc += J[kk * 6 + a] * J[kk * 6 + b];
-                    JtJ[a * 6 + b] = acc;
-                }
-                double acc = 0;
-                for (int kk = 0; kk < nerr; kk++) acc += J[kk * 6 + a] * err[kk];
-                JtErr[a] = acc;
-            }
-            for (int i = 0; i < 6; i++) prevParam[i] = param[i];
-            lm_step(JtJ, JtErr, prevParam, param, lambdaLg10);
-            if (iters == 0) {
-                double s = 0;
-                for (int i = 0; i < nerr; i++) s += err[i] * err[i];
-                prevErrNorm = sqrt(s);
-            }
-            needErr = 1;
-            state = 3;
-        } else {
-            double s = 0;
-            for (int i = 0; i < nerr; i++) s += err[i] * err[i];
-            errNorm = sqrt(s);
-            int retry = 0;
-            if (errNorm > prevErrNorm) {
-                if (++lambdaLg10 <= 16) {
-                    lm_step(JtJ, JtErr, prevParam, param, lambdaLg10);
-                    needErr = 1;
-                    state = 3;
-                    retry = 1;
-                }
-            }
-            if (!retry) {
-                lambdaLg10 = lambdaLg10 - 1 > -16 ? lambdaLg10 - 1 : -16;
-                double dn = 0, pn = 0;
-                for (int i = 0; i < 6; i++) {
-                    dn += (param[i] - prevParam[i]) * (param[i] - prevParam[i]);
-                    pn += prevParam[i] * prevParam[i];
-                }
-                double rel = sqrt(dn) / (sqrt(pn) + DBL_EPSILON);
-                if (++iters >= max_iter || rel < FLT_EPSILON) break;
-                prevErrNorm = errNorm;
-                needJ = needErr = 1;
-                state = 2;
-            }
-        }
-        if (!needErr) break;
-        project4(M, param, param + 3, K, k, proj, needJ ? dpdr : nullptr, needJ ? dpdt : nullptr);
-        for (int kk = 0; kk < nerr; kk++) err[kk] = proj[kk] - m[kk];
-        if (needJ)
-            for (int kk = 0; kk < nerr; kk++)
-                for (int j = 0; j < 3; j++) {
-                    J[kk * 6 + j] = dpdr[kk * 3 + j];
-                    J[kk * 6 + 3 + j] = dpdt[kk * 3 + j];
-                }
-    }
-    for (int i = 0; i < 3; i++) {
-        rvec[i] = param[i];
-        tvec[i] = param[3 + i];
-    }
-    // getReprojectionError: projections rounded to float (vector<Point2f>)
-    project4(M, rvec, tvec, K, k, proj, nullptr, nullptr);
-    double total = 0;
-    for (int i = 0; i < 4; i++) {
-        double x1 = corners[2 * i], y1 = corners[2 * i + 1];
-        double x2 = (float)proj[2 * i], y2 = (float)proj[2 * i + 1];
-        double dx = x1 - x2, dy = y1 - y2;
-        double e = sqrt(dx * dx + dy * dy);
-        total += e * e;
-    }
-    *reproj = total / 4.0;
-    return 0;
-}
-
 __global__ __launch_bounds__(64) void k_pose(const fid_marker *__restrict__ markers, const int *__restrict__ nmark_per_frame,
                                               int nmark_stride_ints, const double *__restrict__ lens, int nframes,
                                               int per_frame, PoseCam cam, fid_pose_out *__restrict__ out)
 {
-    int total = nframes * per_frame;
-    for (int item = blockIdx.x * blockDim.x + threadIdx.x; item < total; item += gridDim.x * blockDim.x) {
-        int f = item / per_frame, k = item - f * per_frame;
-        if (k >= nmark_per_frame[(long long)f * nmark_stride_ints]) continue;
+    const int total = nframes * per_frame;
+    const int g = threadIdx.x & 7;       // residual index inside the marker's lane group
+    const int pi = g >> 1, sel = g & 1;  // corner, coordinate
+    const int groups_per_block = blockDim.x >> 3;
+    for (int item0 = blockIdx.x * groups_per_block; item0 < total; item0 += gridDim.x * groups_per_block) {
+        const int item = item0 + (threadIdx.x >> 3);
+        bool live = item < total;
+        int f = 0, kk = 0;
+        if (live) {
+            f = item / per_frame;
+            kk = item - f * per_frame;
+            live = kk < nmark_per_frame[(long long)f * nmark_stride_ints];
+        }
+        if (!live) continue;  // group-uniform
         const fid_marker mk = markers[item];
-        double len = lens ? lens[item] : cam.fiducial_len;
-        fid_pose_out o;
-        double err = 0;
-        solve_pnp_square(cam, mk.corners, len, o.rvec, o.tvec, &err);
-        o.image_error = err;
-        const float *c = mk.corners;
-        // calcFiducialArea (Heron on two triangles)
-        double a1 = dist2f_d(c[0], c[1], c[2], c[3]);
-        double b1 = dist2f_d(c[0], c[1], c[6], c[7]);
-        double c1 = dist2f_d(c[2], c[3], c[6], c[7]);
-        double a2 = dist2f_d(c[2], c[3], c[4], c[5]);
-        double b2 = dist2f_d(c[4], c[5], c[6], c[7]);
-        double c2 = c1;
-        double s1 = (a1 + b1 + c1) / 2.0, s2 = (a2 + b2 + c2) / 2.0;
-        a1 = sqrt(s1 * (s1 - a1) * (s1 - b1) * (s1 - c1));
-        a2 = sqrt(s2 * (s2 - a2) * (s2 - b2) * (s2 - c2));
-        o.fiducial_area = a1 + a2;
-        double nt = sqrt(o.tvec[0] * o.tvec[0] + o.tvec[1] * o.tvec[1] + o.tvec[2] * o.tvec[2]);
-        o.object_error = (err / dist2f_d(c[0], c[1], c[4], c[5])) * (nt / cam.fiducial_len);
-        out[item] = o;
+        const double len = lens ? lens[item] : cam.fiducial_len;
+        const double *K = cam.K, *kd = cam.D;
+        const float ml = (float)len;
+        const float hx = ml / 2.f;
+        // object point of this lane: (-h, h), (h, h), (h, -h), (-h, -h)   aruco_detect.cpp:151-161
+        const double M[3] = {(double)((pi == 1 || pi == 2) ? hx : -hx), (double)((pi < 2) ? hx : -hx), 0.};
+        const double mobs = (double)mk.corners[g];
+        // ---- cvUndistortPoints (5 iterations) on every corner (each lane needs all four for the homography)
+        double mnx[4], mny[4];
+        {
+            const double fx = K[0], fy = K[4], ifx = 1. / fx, ify = 1. / fy, cx = K[2], cy = K[5];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                double x = mk.corners[2 * i], y = mk.corners[2 * i + 1], u = x, v = y;
+                x = (x - cx) * ifx;
+                y = (y - cy) * ify;
+                const double x0 = x, y0 = y;
+                for (int j = 0; j < 5; j++) {
+                    double r2 = x * x + y * y;
+                    double icdist = (1) / (1 + ((kd[4] * r2 + kd[1]) * r2 + kd[0]) * r2);
+                    if (icdist < 0) {
+                        x = (u - cx) * ifx;
+                        y = (v - cy) * ify;
+                        break;
+                    }
+                    double deltaX = 2 * kd[2] * x * y + kd[3] * (r2 + 2 * x * x);
+                    double deltaY = kd[2] * (r2 + 2 * y * y) + 2 * kd[3] * x * y;
+                    x = (x0 - deltaX) * icdist;
+                    y = (y0 - deltaY) * icdist;
+                }
+                // findHomography converts its inputs to float
+                mnx[i] = (double)(float)x;
+                mny[i] = (double)(float)y;
+            }
+        }
+        double param[6];
+        {
+            // homography marker plane -> normalised image: unit square (0,0),(1,0),(1,1),(0,1) -> quad (Heckbert),
+            // composed with (X, Y) -> ((X + h) / 2h, (h - Y) / 2h)
+            const double x0 = mnx[0], y0 = mny[0], x1 = mnx[1], y1 = mny[1], x2 = mnx[2], y2 = mny[2], x3 = mnx[3], y3 = mny[3];
+            const double dx1 = x1 - x2, dx2 = x3 - x2, sx = x0 - x1 + x2 - x3;
+            const double dy1 = y1 - y2, dy2 = y3 - y2, sy = y0 - y1 + y2 - y3;
+            const double den = dx1 * dy2 - dy1 * dx2;
+            double h[9];
+            bool okh = den != 0.;
+            if (okh) {
+                const double gg = (sx * dy2 - sy * dx2) / den, hh = (dx1 * sy - dy1 * sx) / den;
+                const double a = x1 - x0 + gg * x1, b = x3 - x0 + hh * x3, c = x0;
+                const double d = y1 - y0 + gg * y1, e = y3 - y0 + hh * y3, ff = y0;
+                const double hq = (double)hx;
+                const double s = 1. / (2. * hq);
+                // H = Hunit * [[s, 0, .5], [0, -s, .5], [0, 0, 1]]
+                h[0] = a * s;  h[1] = -b * s;  h[2] = 0.5 * a + 0.5 * b + c;
+                h[3] = d * s;  h[4] = -e * s;  h[5] = 0.5 * d + 0.5 * e + ff;
+                h[6] = gg * s; h[7] = -hh * s; h[8] = 0.5 * gg + 0.5 * hh + 1.;
+                okh = h[8] != 0.;
+                if (okh) {
+                    const double sc = 1. / h[8];
+#pragma unroll
+                    for (int i = 0; i < 9; i++) h[i] *= sc;
+                }
+            }
+            double R[9];
+            param[3] = param[4] = param[5] = 0.;
+            if (okh) {
+                const double h1_norm = sqrt(h[0] * h[0] + h[3] * h[3] + h[6] * h[6]);
+                const double h2_norm = sqrt(h[1] * h[1] + h[4] * h[4] + h[7] * h[7]);
+                const double s1 = 1. / fmax(h1_norm, DBL_EPSILON), s2 = 1. / fmax(h2_norm, DBL_EPSILON);
+                const double stt = 2. / fmax(h1_norm + h2_norm, DBL_EPSILON);
+                param[3] = h[2] * stt;
+                param[4] = h[5] * stt;
+                param[5] = h[8] * stt;
+                h[0] *= s1; h[3] *= s1; h[6] *= s1;
+                h[1] *= s2; h[4] *= s2; h[7] *= s2;
+                h[2] = h[3] * h[7] - h[6] * h[4];
+                h[5] = h[6] * h[1] - h[0] * h[7];
+                h[8] = h[0] * h[4] - h[3] * h[1];
+                double rtmp[3], dummy[27];
+                rodrigues_m2v(h, rtmp);
+                rodrigues_v2m(rtmp, R, dummy, false);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 9; i++) R[i] = (i % 4 == 0) ? 1. : 0.;
+            }
+            rodrigues_m2v(R, param);
+        }
+        // ---- CvLevMarq
+        double prevParam[6], S[21], gJ[6], Jrow[6];
+        double err = 0, prevErrNorm = 0, errNorm = 0;
+        int lambdaLg10 = -3, iters = 0, state = 1;
+        const double LOG10 = log(10.);
+#pragma unroll
+        for (int i = 0; i < 6; i++) prevParam[i] = param[i];
+        for (;;) {
+            bool needJ = false, needErr = false;
+            if (state == 1) {
+                needJ = needErr = true;
+                state = 2;
+            } else if (state == 2) {
+                {
+                    int idx = 0;
+#pragma unroll
+                    for (int a = 0; a < 6; a++) {
+#pragma unroll
+                        for (int b = a; b < 6; b++) S[idx++] = grp_sum8(Jrow[a] * Jrow[b]);
+                        gJ[a] = grp_sum8(Jrow[a] * err);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 6; i++) prevParam[i] = param[i];
+                double xs[6];
+                solve6_spd(S, gJ, exp(lambdaLg10 * LOG10), xs);
+#pragma unroll
+                for (int i = 0; i < 6; i++) param[i] = prevParam[i] - xs[i];
+                if (iters == 0) prevErrNorm = sqrt(grp_sum8(err * err));
+                needErr = true;
+                state = 3;
+            } else {
+                errNorm = sqrt(grp_sum8(err * err));
+                bool retry = false;
+                if (errNorm > prevErrNorm) {
+                    if (++lambdaLg10 <= 16) {
+                        double xs[6];
+                        solve6_spd(S, gJ, exp(lambdaLg10 * LOG10), xs);
+#pragma unroll
+                        for (int i = 0; i < 6; i++) param[i] = prevParam[i] - xs[i];
+                        needErr = true;
+                        state = 3;
+                        retry = true;
+                    }
+                }
+                if (!retry) {
+                    lambdaLg10 = lambdaLg10 - 1 > -16 ? lambdaLg10 - 1 : -16;
+                    double dn = 0, pn = 0;
+#pragma unroll
+                    for (int i = 0; i < 6; i++) {
+                        dn += (param[i] - prevParam[i]) * (param[i] - prevParam[i]);
+                        pn += prevParam[i] * prevParam[i];
+                    }
+                    double rel = sqrt(dn) / (sqrt(pn) + DBL_EPSILON);
+                    if (++iters >= 20 || rel < FLT_EPSILON) break;
+                    prevErrNorm = errNorm;
+                    needJ = needErr = true;
+                    state = 2;
+                }
+            }
+            if (!needErr) break;
+            double pr = project_one(M, param, K, kd, sel, Jrow, needJ);
+            err = pr - mobs;
+        }
+        // ---- getReprojectionError: projections rounded to float (vector<Point2f>), error = sum |d|^2 / 4
+        double prj = project_one(M, param, K, kd, sel, Jrow, false);
+        double dcoord = mobs - (double)(float)prj;
+        double d2 = dcoord * dcoord;
+        double pt2 = d2 + shfl_xor_f64(d2, 1);  // dx^2 + dy^2 of this corner
+        double e = sqrt(pt2);
+        double contrib = sel == 0 ? e * e : 0.;
+        double totalErr = grp_sum8(contrib);
+        if (g == 0) {
+            fid_pose_out o;
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                o.rvec[i] = param[i];
+                o.tvec[i] = param[3 + i];
+            }
+            const double rerr = totalErr / 4.0;
+            o.image_error = rerr;
+            const float *c = mk.corners;
+            // calcFiducialArea (Heron on two triangles)
+            double a1 = dist2f_d(c[0], c[1], c[2], c[3]);
+            double b1 = dist2f_d(c[0], c[1], c[6], c[7]);
+            double c1 = dist2f_d(c[2], c[3], c[6], c[7]);
+            double a2 = dist2f_d(c[2], c[3], c[4], c[5]);
+            double b2 = dist2f_d(c[4], c[5], c[6], c[7]);
+            double c2 = c1;
+            double s1 = (a1 + b1 + c1) / 2.0, s2 = (a2 + b2 + c2) / 2.0;
+            a1 = sqrt(s1 * (s1 - a1) * (s1 - b1) * (s1 - c1));
+            a2 = sqrt(s2 * (s2 - a2) * (s2 - b2) * (s2 - c2));
+            o.fiducial_area = a1 + a2;
+            double nt = sqrt(o.tvec[0] * o.tvec[0] + o.tvec[1] * o.tvec[1] + o.tvec[2] * o.tvec[2]);
+            o.object_error = (rerr / dist2f_d(c[0], c[1], c[4], c[5])) * (nt / cam.fiducial_len);
+            out[item] = o;
+        }
     }
 }

@@ -53,7 +53,12 @@ def check_stages(det, gray, d):
     assert np.array_equal(gc["contour_size"], tr["initial"]["contour_size"])
     assert np.array_equal(gc["is_hole"], tr["initial"]["is_hole"])
     assert np.array_equal(np.stack([gc["start_x"], gc["start_y"]], 1).reshape(-1, 2), tr["initial"]["start"])
-    assert np.array_equal(gc["corners"].reshape(-1, 4, 2), tr["initial"]["corners"])
+    # the CANDIDATES tap is taken after _reorderCandidatesCorners; the oracle's "initial" trace before it
+    oc = tr["initial"]["corners"].astype(np.float64)
+    cross = (oc[:, 1, 0] - oc[:, 0, 0]) * (oc[:, 2, 1] - oc[:, 0, 1]) - (oc[:, 1, 1] - oc[:, 0, 1]) * (oc[:, 2, 0] - oc[:, 0, 0])
+    ocr = tr["initial"]["corners"].copy()
+    ocr[cross < 0] = ocr[cross < 0][:, [0, 3, 2, 1]]
+    assert np.array_equal(gc["corners"].reshape(-1, 4, 2), ocr)
     gf = det.tap_candidates(True)[0][:cnt[3]]
     assert cnt[3] == len(tr["filtered"]["scale"])
     assert np.array_equal(gf["corners"].reshape(-1, 4, 2), tr["filtered"]["corners"])

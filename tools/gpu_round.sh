@@ -1,0 +1,19 @@
+#!/bin/bash
+# One GPU-box session: parity tests, bench, rocprofv3 kernel stats.  Outputs under gpurun_out/.
+set -u
+export TMPDIR=/tmp
+OUT=gpurun_out
+mkdir -p $OUT
+( time timeout 900 python -m pytest tests -m gpu -x -q ) > $OUT/pytest_gpu.log 2>&1
+echo "pytest rc=$?" >> $OUT/pytest_gpu.log
+tail -5 $OUT/pytest_gpu.log
+( time timeout 600 python bench.py ) > $OUT/bench.log 2>&1
+tail -3 $OUT/bench.log
+rm -rf $OUT/prof
+( timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof -o r -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline ) > $OUT/prof.log 2>&1
+ls -R $OUT/prof | head -20
+f=$(find $OUT/prof -name '*kernel_stats.csv' | head -1)
+[ -n "$f" ] && cp "$f" $OUT/kernel_stats.csv && head -30 $OUT/kernel_stats.csv
+# drop the big traces, keep the stats
+find $OUT/prof -name '*kernel_trace.csv' -size +8M -delete
+nproc; rocm-smi --showmeminfo vram 2>/dev/null | head -5

@@ -239,10 +239,18 @@ fid_status run_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H, int
     HIPCHK(c, hipMemsetAsync(c->d_nwork, 0, sizeof(unsigned), st));
     // ---- K1
     {
-        int R = P.rmax, RW = TX + 2 * R, RH = TY + 2 * R, PT = (RW + 1) | 1;
-        size_t lds = (size_t)(RH + 1) * PT * sizeof(uint32_t);
-        dim3 grid((W + TX - 1) / TX, (H + TY - 1) / TY, F);
-        hipLaunchKernelGGL((k_threshold<TX, TY, NT>), grid, dim3(NT), lds, st, gray, gfstride, c->d_masks, P);
+        bool node_table = P.nscales == 13;  // 3, 7, ..., 51: the node defaults (aruco_detect.cpp:690-693)
+        for (int i = 0; i < P.nscales && node_table; i++) node_table = P.win[i] == 3 + 4 * i;
+        if (node_table) {
+            using C = ThrCfg<3, 4, 13>;
+            dim3 grid((W + C::TX - 1) / C::TX, (H + C::TY - 1) / C::TY, F);
+            hipLaunchKernelGGL((k_threshold_fixed<3, 4, 13>), grid, dim3(C::NT), C::LDS_BYTES, st, gray, gfstride, c->d_masks, P);
+        } else {
+            int R = P.rmax, RW = TX + 2 * R, RH = TY + 2 * R, PT = (RW + 1) | 1;
+            size_t lds = (size_t)(RH + 1) * PT * sizeof(uint32_t);
+            dim3 grid((W + TX - 1) / TX, (H + TY - 1) / TY, F);
+            hipLaunchKernelGGL((k_threshold<TX, TY, NT>), grid, dim3(NT), lds, st, gray, gfstride, c->d_masks, P);
+        }
     }
     mark(c, ST_THRESH + 1);
     // ---- K2
@@ -477,6 +485,8 @@ fid_status fid_create(const fid_params *params, const fid_dict *dict, const fid_
     TRYHIP(hipMemset(c->d_masks, 0, c->masks_bytes));
     // opt in to large dynamic LDS where needed
     TRYHIP(hipFuncSetAttribute((const void *)k_threshold<TX, TY, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+    TRYHIP(hipFuncSetAttribute((const void *)k_threshold_fixed<3, 4, 13>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)ThrCfg<3, 4, 13>::LDS_BYTES));
     TRYHIP(hipFuncSetAttribute((const void *)k_approx, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     TRYHIP(hipFuncSetAttribute((const void *)k_filter_markers, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
 #undef TRY

@@ -19,6 +19,9 @@
 #include <float.h>
 #include <limits.h>
 
+#include <type_traits>
+#include <utility>
+
 #include "fid_device.h"
 #include "../../include/fid_abi.h"
 
@@ -190,6 +193,198 @@ __global__ __launch_bounds__(NT) void k_threshold(const uint8_t *__restrict__ gr
                 wv.y = (uint32_t)(b >> 32);
                 *reinterpret_cast<uint2 *>(mrow + (long long)s * (H + 2) * WWP) = wv;
             }
+        }
+    }
+}
+
+// v_writelane_b32: park a wave-uniform value in lane K of a VGPR (one VALU op, no exec juggling)
+template <int K>
+__device__ __forceinline__ uint32_t write_lane(uint32_t val, uint32_t old)
+{
+    asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(old) : "s"(val), "n"(K));
+    return old;
+}
+
+template <int... Ks, typename F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, Ks...>, F &&f)
+{
+    (f(std::integral_constant<int, Ks>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F &&f)
+{
+    static_for_impl(std::make_integer_sequence<int, N>{}, static_cast<F &&>(f));
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1 (fast path): the same arithmetic for the window table WMIN, WMIN + WSTEP, ... (NS windows) fixed at
+// compile time -- the node-default table 3, 7, ..., 51 (aruco_detect.cpp:690-693) -- so that every integral
+// corner is one ds_read_b32 with an immediate offset.
+//   tile          TX x TY = 128 x 120 output pixels per 1024-thread workgroup (16 waves, one workgroup per CU:
+//                 the (TY + 2R + 1) x PT u32 integral takes 128.6 KB of the 160 KB LDS); halo re-read 1.97x
+//   phase 1       wave per raw row: one dword (4 px) per lane, 4-px local prefix + wave scan -> row prefix in LDS
+//   phase 2       column prefix in two levels (5 row chunks x 184 columns, 34 values in registers per thread)
+//   phase 3       wave per (row, 64-px segment): per scale 4 LDS reads, 2*sum >= t2*win^2, v_cmp = the mask
+//                 word pair; ballots are parked in lane k of the accumulators and leave as ONE 16-byte store
+//                 per (row, scale)
+template <int WMIN, int WSTEP, int NS>
+struct ThrCfg {
+    static constexpr int TX = 128, TY = 120, NT = 1024, NW = NT / 64;
+    static constexpr int R = (WMIN + (NS - 1) * WSTEP) / 2;  // largest radius
+    static constexpr int HL = (R + 3) & ~3;                  // left halo, dword aligned
+    static constexpr int RAWW = (HL + TX + R + 3) & ~3;      // raw columns loaded per row
+    static constexpr int NDW = RAWW / 4;                     // dwords per raw row (<= 64)
+    static constexpr int RAWH = TY + 2 * R;                  // raw rows
+    static constexpr int PT = RAWW + 4;                      // integral pitch (column 0 = zero column)
+    static constexpr int NCH = 5;                            // row chunks of the column prefix
+    static constexpr int CH = (RAWH + NCH - 1) / NCH;
+    static constexpr int ROWS_PER_WAVE = (RAWH + NW - 1) / NW;
+    static constexpr int ITEMS = (TY + NW - 1) / NW;         // output rows per wave
+    static constexpr size_t LDS_BYTES = (size_t)((RAWH + 1) * PT + NCH * RAWW) * sizeof(uint32_t);
+    static_assert(NDW <= 64, "one dword per lane");
+    static_assert(NCH * RAWW <= NT, "column-prefix threads");
+};
+
+template <int WMIN, int WSTEP, int NS>
+__global__ __launch_bounds__(1024) void k_threshold_fixed(const uint8_t *__restrict__ gray, long long gfstride,
+                                                           uint32_t *__restrict__ masks, const DevParams P)
+{
+    using C = ThrCfg<WMIN, WSTEP, NS>;
+    constexpr int TX = C::TX, TY = C::TY, NW = C::NW, R = C::R, HL = C::HL, RAWW = C::RAWW, NDW = C::NDW, RAWH = C::RAWH,
+                  PT = C::PT, NCH = C::NCH, CH = C::CH;
+    extern __shared__ uint32_t I[];       // (RAWH + 1) x PT, I[j][i] = sum of raw rows < j, raw cols < i
+    uint32_t *tot = I + (RAWH + 1) * PT;  // NCH x RAWW chunk totals
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int x0 = blockIdx.x * TX, y0 = blockIdx.y * TY, f = blockIdx.z;
+    const uint8_t *g = gray + (long long)f * gfstride;
+    const int W = P.W, H = P.H, gs = P.gstride;
+
+    // this wave's output rows: ty = wid + NW * k; their centre pixels are fetched now, used in phase 3
+    uint32_t gpix[C::ITEMS][2];
+#pragma unroll
+    for (int k = 0; k < C::ITEMS; k++) {
+        int gy = y0 + wid + NW * k;
+        gy = gy < H ? gy : H - 1;
+#pragma unroll
+        for (int sg = 0; sg < 2; sg++) {
+            int gx = x0 + sg * 64 + lane;
+            gx = gx < W ? gx : W - 1;
+            gpix[k][sg] = g[(long long)gy * gs + gx];
+        }
+    }
+    // zero row / zero column
+    for (int i = tid; i < PT; i += C::NT) I[i] = 0;
+    for (int i = tid; i <= RAWH; i += C::NT) I[i * PT] = 0;
+    // ---- phase 1: row prefix
+    {
+        const bool fast = ((((uintptr_t)g) | (unsigned)gs) & 3) == 0 && x0 - HL >= 0 && x0 - HL + RAWW <= W;
+        uint32_t raw[C::ROWS_PER_WAVE];
+#pragma unroll
+        for (int k = 0; k < C::ROWS_PER_WAVE; k++) {
+            int ry = wid + NW * k;
+            int gy = y0 - R + ry;
+            gy = gy < 0 ? 0 : (gy >= H ? H - 1 : gy);
+            const uint8_t *grow = g + (long long)gy * gs;
+            uint32_t v = 0;
+            if (ry < RAWH && lane < NDW) {
+                int gx = x0 - HL + 4 * lane;
+                if (fast) {
+                    v = *reinterpret_cast<const uint32_t *>(grow + gx);
+                } else {
+#pragma unroll
+                    for (int b = 0; b < 4; b++) {
+                        int xx = gx + b;
+                        xx = xx < 0 ? 0 : (xx >= W ? W - 1 : xx);
+                        v |= (uint32_t)grow[xx] << (8 * b);
+                    }
+                }
+            }
+            raw[k] = v;
+        }
+#pragma unroll
+        for (int k = 0; k < C::ROWS_PER_WAVE; k++) {
+            int ry = wid + NW * k;
+            if (ry >= RAWH) break;  // wave-uniform
+            uint32_t v = raw[k];
+            int p0 = v & 0xff, p1 = p0 + ((v >> 8) & 0xff), p2 = p1 + ((v >> 16) & 0xff), p3 = p2 + (v >> 24);
+            int e = wave_iscan(p3) - p3;
+            if (lane < NDW) {
+                uint32_t *dst = I + (ry + 1) * PT + 1 + 4 * lane;
+                dst[0] = (uint32_t)(e + p0);
+                dst[1] = (uint32_t)(e + p1);
+                dst[2] = (uint32_t)(e + p2);
+                dst[3] = (uint32_t)(e + p3);
+            }
+        }
+    }
+    __syncthreads();
+    // ---- phase 2: column prefix, chunk j of CH rows x column c per thread
+    {
+        const int c = tid % RAWW, j = tid / RAWW;
+        const bool act = tid < NCH * RAWW;
+        uint32_t v[CH];
+        uint32_t *col = I + (1 + j * CH) * PT + 1 + c;
+        if (act) {
+#pragma unroll
+            for (int k = 0; k < CH; k++) v[k] = (j * CH + k < RAWH) ? col[k * PT] : 0u;
+#pragma unroll
+            for (int k = 1; k < CH; k++) v[k] += v[k - 1];
+            tot[j * RAWW + c] = v[CH - 1];
+        }
+        __syncthreads();
+        if (act) {
+            uint32_t off = 0;
+#pragma unroll
+            for (int q = 0; q < NCH - 1; q++) off += q < j ? tot[q * RAWW + c] : 0u;
+#pragma unroll
+            for (int k = 0; k < CH; k++)
+                if (j * CH + k < RAWH) col[k * PT] = v[k] + off;
+        }
+    }
+    __syncthreads();
+    // ---- phase 3: all scales for this wave's rows
+    uint4 acc[NS];
+#pragma unroll
+    for (int s = 0; s < NS; s++) acc[s] = make_uint4(0u, 0u, 0u, 0u);
+    static_for<C::ITEMS>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        const int ty = wid + NW * k;
+        if (ty < TY) {  // wave-uniform
+#pragma unroll
+            for (int sg = 0; sg < 2; sg++) {
+                const int x = sg * 64 + lane;
+                const int t2 = 2 * ((int)gpix[k][sg] + P.idelta) - 1;
+                const unsigned long long vmask = ballot64(x0 + x < W);
+                // base = I[ry - R][cx - R] with ry = ty + R, cx = x + HL (raw coordinates of the pixel)
+                const uint32_t *base = I + ty * PT + (x + HL - R);
+#pragma unroll
+                for (int s = 0; s < NS; s++) {
+                    const int win = WMIN + s * WSTEP, r = win >> 1;
+                    const int o_tl = (R - r) * PT + (R - r), o_tr = (R - r) * PT + (R + r + 1);
+                    const int o_bl = (R + r + 1) * PT + (R - r), o_br = (R + r + 1) * PT + (R + r + 1);
+                    int sum = (int)(base[o_br] - base[o_tr] - base[o_bl] + base[o_tl]);
+                    unsigned long long b = ballot64(2 * sum >= __mul24(t2, win * win)) & vmask;
+                    uint32_t lo = (uint32_t)b, hi = (uint32_t)(b >> 32);
+                    if (sg == 0) {
+                        acc[s].x = write_lane<k>(lo, acc[s].x);
+                        acc[s].y = write_lane<k>(hi, acc[s].y);
+                    } else {
+                        acc[s].z = write_lane<k>(lo, acc[s].z);
+                        acc[s].w = write_lane<k>(hi, acc[s].w);
+                    }
+                }
+            }
+        }
+    });
+    // lane k holds row wid + NW * k: one 16-byte store per (row, scale)
+    {
+        const int ty = wid + NW * lane;
+        const int gy = y0 + ty;
+        if (lane < C::ITEMS && ty < TY && gy < H) {
+            const int WWP = P.WWP;
+            uint32_t *mrow = masks + (((long long)f * NS) * (H + 2) + (gy + 1)) * WWP + MASK_PADW + (x0 >> 5);
+#pragma unroll
+            for (int s = 0; s < NS; s++) *reinterpret_cast<uint4 *>(mrow + (long long)s * (H + 2) * WWP) = acc[s];
         }
     }
 }

@@ -52,7 +52,7 @@ class FidLimits(C.Structure):
     _fields_ = [("max_width", C.c_int32), ("max_height", C.c_int32), ("max_batch", C.c_int32),
                 ("max_starts_per_frame", C.c_int32), ("max_contours_per_frame", C.c_int32),
                 ("max_candidates_per_frame", C.c_int32), ("max_markers_per_frame", C.c_int32),
-                ("reserved0", C.c_int32)]
+                ("max_points_per_frame", C.c_int32)]
 
 
 class FidCandidate(C.Structure):

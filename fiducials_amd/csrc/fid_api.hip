@@ -14,8 +14,8 @@
 
 namespace {
 
-enum { ST_GRAY = 0, ST_THRESH, ST_STARTS, ST_WALK, ST_APPROX, ST_SORT, ST_NEAR, ST_RESOLVE, ST_IDENT, ST_FILTER, ST_SUBPIX, ST_POSE, ST_COUNT };
-const char *const kStageNames[ST_COUNT] = {"to_gray", "threshold", "find_starts", "walk_count", "approx", "sort_cands",
+enum { ST_GRAY = 0, ST_THRESH, ST_STARTS, ST_PROBE, ST_WALK, ST_APPROX, ST_SORT, ST_NEAR, ST_RESOLVE, ST_IDENT, ST_FILTER, ST_SUBPIX, ST_POSE, ST_COUNT };
+const char *const kStageNames[ST_COUNT] = {"to_gray", "threshold", "find_starts", "walk_probe", "walk_full", "approx", "sort_cands",
                                            "near", "resolve", "identify", "filter_markers", "subpix", "pose"};
 
 constexpr int TX = 128, TY = 32, NT = 256;
@@ -37,7 +37,9 @@ struct fid_ctx {
     uint32_t *d_masks = nullptr;
     size_t masks_bytes = 0;
     int masks_W = 0, masks_H = 0, masks_S = 0;
-    uint2 *d_starts = nullptr;
+    uint2 *d_starts = nullptr, *d_surv = nullptr;
+    uint32_t *d_pool = nullptr;
+    int max_chunks = 0;
     uint4 *d_contours = nullptr;
     uint32_t *d_ckpts = nullptr;
     size_t ckpts_elems = 0;
@@ -178,6 +180,7 @@ void set_geometry(fid_ctx *c, int W, int H, int gstride, int F)
     P.maxContours = c->lim.max_contours_per_frame;
     P.maxCands = c->lim.max_candidates_per_frame;
     P.maxMarkers = c->lim.max_markers_per_frame;
+    P.maxChunks = c->max_chunks;
 }
 
 size_t masks_elems(const fid_ctx *c, int W, int H, int F)
@@ -204,7 +207,7 @@ fid_status run_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H, int
     if (enc != FID_ENC_MONO8 && enc != FID_ENC_BGR8 && enc != FID_ENC_RGB8) return FID_E_INVALID_ARG;
     int bpp = enc == FID_ENC_MONO8 ? 1 : 3;
     if (stride < W * bpp) return FID_E_INVALID_ARG;
-    if ((unsigned)(c->params.maxMarkerPerimeterRate * (W > H ? W : H)) > 60000u) return FID_E_UNSUPPORTED;  // contour points live in LDS
+    if ((unsigned)(c->params.maxMarkerPerimeterRate * (W > H ? W : H)) > 36000u) return FID_E_UNSUPPORTED;  // contour points live in LDS
     hipStream_t st = c->stream;
     for (int i = 0; i <= ST_COUNT; i++) c->ev_valid[i] = false;
     mark(c, 0);
@@ -262,19 +265,26 @@ fid_status run_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H, int
                            c->d_global, P);
     }
     mark(c, ST_STARTS + 1);
-    // ---- K3
-    if ((size_t)F * P.maxContours * (P.maxPerim / 64 + 1) > c->ckpts_elems) {
-        c->last_error = "checkpoint buffer too small for this image size / maxMarkerPerimeterRate";
+    // ---- K3: probe every start, then walk the survivors to the end
+    if ((size_t)F * P.maxContours * (P.maxPerim / CK + 1) > c->ckpts_elems) {
+        c->last_error = "chunk table too small for this image size / maxMarkerPerimeterRate";
         return FID_E_UNSUPPORTED;
     }
-    hipLaunchKernelGGL(k_walk_count, dim3(32, F), dim3(256), 0, st, c->d_masks, c->d_starts, c->d_contours, c->d_ckpts,
-                       c->d_counts, c->d_global, P);
+    hipLaunchKernelGGL(k_walk<true>, dim3(64, F), dim3(256), 0, st, c->d_masks, c->d_starts, c->d_surv, c->d_contours, c->d_ckpts,
+                       c->d_pool, c->d_counts, c->d_global, P);
+    mark(c, ST_PROBE + 1);
+    hipLaunchKernelGGL(k_walk<false>, dim3(16, F), dim3(256), 0, st, c->d_masks, c->d_surv, c->d_surv, c->d_contours, c->d_ckpts,
+                       c->d_pool, c->d_counts, c->d_global, P);
     mark(c, ST_WALK + 1);
-    // ---- K4
+    // ---- K4: short contours with a small LDS footprint first, then the long / flagged ones
     {
-        size_t lds = (size_t)(P.maxPerim + 1) * sizeof(uint32_t);
-        hipLaunchKernelGGL(k_approx, dim3(64, F), dim3(64), lds, st, c->d_masks, c->d_contours, c->d_ckpts, c->d_cands,
-                           c->d_counts, c->d_global, P);
+        int cap1 = pts_cap_first(P);
+        size_t lds1 = (size_t)cap1 * sizeof(uint32_t) + (size_t)K4_SHORT_STACK * sizeof(int2);
+        hipLaunchKernelGGL(k_approx, dim3(128, F), dim3(64), lds1, st, c->d_contours, c->d_ckpts, c->d_pool, c->d_cands, c->d_counts,
+                           c->d_global, P, cap1, K4_SHORT_STACK, 0);
+        size_t lds2 = (size_t)(P.maxPerim + 1) * sizeof(uint32_t) + (size_t)K4_LONG_STACK * sizeof(int2);
+        hipLaunchKernelGGL(k_approx, dim3(16, F), dim3(64), lds2, st, c->d_contours, c->d_ckpts, c->d_pool, c->d_cands, c->d_counts,
+                           c->d_global, P, P.maxPerim + 1, K4_LONG_STACK, 1);
     }
     mark(c, ST_APPROX + 1);
     // ---- K5
@@ -325,7 +335,7 @@ fid_status run_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H, int
     }
     fid_status rc = FID_OK;
     if (c->h_global->overflow) {
-        c->last_error = "internal capacity exceeded (starts/contours/stack): raise fid_limits";
+        c->last_error = "internal capacity exceeded (starts/contours/stack/points): raise fid_limits";
         rc = FID_E_CAPACITY;
     }
     for (int f = 0; f < F; f++) {
@@ -387,6 +397,7 @@ void fid_default_limits(fid_limits *l)
     l->max_contours_per_frame = 16384;
     l->max_candidates_per_frame = 2048;
     l->max_markers_per_frame = 256;
+    l->max_points_per_frame = 4 * 1024 * 1024;
 }
 
 fid_status fid_create(const fid_params *params, const fid_dict *dict, const fid_limits *limits, int device, fid_ctx **out)
@@ -410,6 +421,7 @@ fid_status fid_create(const fid_params *params, const fid_dict *dict, const fid_
         if (limits->max_contours_per_frame > 0) L.max_contours_per_frame = limits->max_contours_per_frame;
         if (limits->max_candidates_per_frame > 0) L.max_candidates_per_frame = limits->max_candidates_per_frame;
         if (limits->max_markers_per_frame > 0) L.max_markers_per_frame = limits->max_markers_per_frame;
+        if (limits->max_points_per_frame > 0) L.max_points_per_frame = limits->max_points_per_frame;
     }
     L.max_candidates_per_frame = roundup(L.max_candidates_per_frame, 32);
     if (L.max_candidates_per_frame > 4096 || L.max_batch > 65535 || L.max_markers_per_frame > L.max_candidates_per_frame) {
@@ -458,6 +470,9 @@ fid_status fid_create(const fid_params *params, const fid_dict *dict, const fid_
     c->masks_bytes += (size_t)F * c->P.nscales * (L.max_height + 2) * 16 * sizeof(uint32_t);
     TRYHIP(hipMalloc((void **)&c->d_masks, c->masks_bytes));
     TRY(dalloc(c, &c->d_starts, F * L.max_starts_per_frame));
+    TRY(dalloc(c, &c->d_surv, F * L.max_starts_per_frame));
+    c->max_chunks = (L.max_points_per_frame + CK - 1) / CK;
+    TRY(dalloc(c, &c->d_pool, F * (size_t)c->max_chunks * CK));
     TRY(dalloc(c, &c->d_contours, F * L.max_contours_per_frame));
     {
         int maxdim = L.max_width > L.max_height ? L.max_width : L.max_height;
@@ -487,7 +502,7 @@ fid_status fid_create(const fid_params *params, const fid_dict *dict, const fid_
     TRYHIP(hipFuncSetAttribute((const void *)k_threshold<TX, TY, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
     TRYHIP(hipFuncSetAttribute((const void *)k_threshold_fixed<3, 4, 13>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)ThrCfg<3, 4, 13>::LDS_BYTES));
-    TRYHIP(hipFuncSetAttribute((const void *)k_approx, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    TRYHIP(hipFuncSetAttribute((const void *)k_approx, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
     TRYHIP(hipFuncSetAttribute((const void *)k_filter_markers, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
 #undef TRY
 #undef TRYHIP
@@ -500,7 +515,7 @@ void fid_destroy(fid_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    void *dev[] = {c->d_in, c->d_gray, c->d_masks, c->d_starts, c->d_contours, c->d_ckpts, c->d_cands, c->d_sorted, c->d_filtered, c->d_near,
+    void *dev[] = {c->d_in, c->d_gray, c->d_masks, c->d_starts, c->d_surv, c->d_pool, c->d_contours, c->d_ckpts, c->d_cands, c->d_sorted, c->d_filtered, c->d_near,
                    c->d_ident, c->d_pre, c->d_markers, c->d_poses, c->d_counts, c->d_global, c->d_worklist, c->d_nwork, c->d_dict,
                    c->d_subpix_mask, c->d_lens, c->d_pose_in, c->d_pose_n};
     for (void *p : dev)
@@ -727,7 +742,7 @@ fid_status fid_tap_read(fid_ctx *c, fid_tap which, void *dst, int64_t dst_bytes)
             o[8 * f + 4] = c->h_counts[f].nacc;
             o[8 * f + 5] = c->h_counts[f].nmark;
             o[8 * f + 6] = c->h_counts[f].overflow | ((int32_t)c->h_global->overflow << 8);
-            o[8 * f + 7] = 0;
+            o[8 * f + 7] = c->h_counts[f].nsurv;
         }
         return FID_OK;
     }

@@ -8,8 +8,10 @@
 //                                              row y+1; pad rows/words are zero so border following
 //                                              never bounds-checks
 //   starts    uint2 [F][max_starts]           border-following start candidates (all scales)
+//   surv      uint2 [F][max_starts]           the starts that survive the probe pass, compacted
 //   contours  uint4 [F][max_contours]         contour slots: start, meta, length (0 = dropped), discovery key
-//   ckpts     u32  [F][max_contours][maxPerim/64+1]  walk state every 64 points (parallel replay in k_approx)
+//   chunk_tab u32  [F][max_contours][maxPerim/64+1]  pool chunk of every 64 points of a contour
+//   pool      u32  [F][max_chunks][64]        contour points x | y << 16, written while the border is followed
 //   cands     DevCand [F][max_cands]          quads leaving _findMarkerContours
 //   sorted / filtered DevCand [F][max_cands]  OpenCV order; after reorder + too-close filter
 //   near      u32  [F][max_cands][max_cands/32]
@@ -37,7 +39,8 @@ struct DevParams {
     int subpixWin, subpixMaxIter;
     double subpixEps;  // squared
     int refine;
-    int maxStarts, maxContours, maxCands, maxMarkers;  // per-frame capacities (starts/contours: x F global)
+    int maxStarts, maxContours, maxCands, maxMarkers;  // per-frame capacities
+    int maxChunks;                                     // per-frame pool of CK-point contour chunks
 };
 
 struct DevCand {
@@ -62,12 +65,14 @@ struct DevCounts {
     int nmark;      // after _filterDetectedMarkers
     int overflow;   // bit0 cands, bit1 markers
     int nstarts;    // border-following start candidates found by k_find_starts
-    int ncontours;  // contour slots handed out by k_walk_count (dropped walks leave count == 0)
-    int pad;
+    int ncontours;  // contour slots handed out by the full walk pass (dropped walks leave count == 0)
+    int nsurv;      // starts that survived the probe pass
+    int npool;      // point chunks handed out by the full walk pass
+    int pad[3];
 };
 
 // global counters
 struct DevGlobal {
-    unsigned overflow;  // bit0 starts, bit1 contours, bit2 approxPolyDP stack
+    unsigned overflow;  // bit0 starts/survivors, bit1 contours, bit2 approxPolyDP stack, bit3 point pool
     unsigned pad[3];
 };

@@ -550,34 +550,48 @@ __device__ __forceinline__ unsigned nb8(const MaskView &m, int x, int y)
 // padded raster index used to order discovery events like cvFindNextContour's scan
 __device__ __forceinline__ int pidx(int x, int y, int W) { return (y + 1) * (W + 2) + (x + 1); }
 
-// checkpoints of a walk: state before emitting point CK*k, packed x | y << 13 | backdir << 26
+// Contour points are stored in chunks of CK points (x | y << 16) taken from a per-frame pool while the
+// border is followed; chunk_tab[slot][k] names the chunk that holds points [CK*k, CK*k + CK) of a contour.
 #define CK 64
-__device__ __forceinline__ uint32_t ck_pack(int x, int y, int sdir) { return (uint32_t)x | ((uint32_t)y << 13) | ((uint32_t)sdir << 26); }
 
 // K3: one lane per start.  Walks the border exactly as icvFetchContour does (contours.cpp), counting points.
 // A start is reported only if it is the canonical one of its border (the pixel where cvFindNextContour's
 // raster scan would have started it): outer borders start at their raster-first pixel, hole borders left of
 // the raster-first background pixel of the hole.  A walker gives up as soon as it meets an earlier pixel;
 // to make that happen fast on staircase edges a second cursor walks the border BACKWARDS for the first
-// BACK_BUDGET steps.  Walks longer than maxPerimeterPixels are dropped.  Every CK steps the state is
-// checkpointed so that K4 can replay the border with 64 lanes in parallel.
+// BACK_BUDGET steps.  Walks longer than maxPerimeterPixels are dropped.
+//
+// Two passes, because ~98 % of the starts die within a few steps while ~2 % run for hundreds to thousands
+// (a wave lasts as long as its longest lane):
+//   PROBE = true   every start, at most PROBE_STEPS steps; what is still undecided (or closed with an
+//                  acceptable length) is appended to the survivor list with one atomic per wave
+//   PROBE = false  dense waves of survivors walk to the end and write their points into the chunk pool,
+//                  so that K4 gathers a contour with coalesced loads instead of walking it again
 #define BACK_BUDGET 48
-__global__ __launch_bounds__(256) void k_walk_count(const uint32_t *__restrict__ masks, const uint2 *__restrict__ starts,
-                                                     uint4 *__restrict__ contours, uint32_t *__restrict__ ckpts,
-                                                     DevCounts *__restrict__ counts, DevGlobal *__restrict__ G,
-                                                     const DevParams P)
+#define PROBE_STEPS 32
+template <bool PROBE>
+__global__ __launch_bounds__(256) void k_walk(const uint32_t *__restrict__ masks, const uint2 *__restrict__ in_list,
+                                               uint2 *__restrict__ surv, uint4 *__restrict__ contours,
+                                               uint32_t *__restrict__ chunk_tab, uint32_t *__restrict__ pool,
+                                               DevCounts *__restrict__ counts, DevGlobal *__restrict__ G,
+                                               const DevParams P)
 {
     const int f = blockIdx.y;
-    unsigned n = (unsigned)counts[f].nstarts;
+    const int lane = lane_id();
+    unsigned n = (unsigned)(PROBE ? counts[f].nstarts : counts[f].nsurv);
     n = n < (unsigned)P.maxStarts ? n : (unsigned)P.maxStarts;
-    const unsigned ccap = (unsigned)P.maxContours;
+    const unsigned ccap = (unsigned)P.maxContours, pcap = (unsigned)P.maxChunks;
     const int W = P.W, H = P.H, S = P.nscales;
     const int nck = P.maxPerim / CK + 1;
-    const uint2 *fst = starts + (long long)f * P.maxStarts;
+    const uint2 *fin = in_list + (long long)f * P.maxStarts;
+    uint2 *fsv = surv + (long long)f * P.maxStarts;
     uint4 *fco = contours + (long long)f * P.maxContours;
-    uint32_t *fck = ckpts + (long long)f * P.maxContours * nck;
-    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        uint2 st = fst[i];
+    uint32_t *ftab = chunk_tab + (long long)f * P.maxContours * nck;
+    uint32_t *fpool = pool + (long long)f * P.maxChunks * CK;
+    for (unsigned i0 = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); i0 < n; i0 += gridDim.x * blockDim.x) {
+        const unsigned i = i0 + lane;
+        const bool active = i < n;
+        uint2 st = active ? fin[i] : make_uint2(0u, 0u);
         int x0 = st.x & 0xffff, y0 = st.x >> 16;
         int s = (st.y >> 16) & 0xff, hole = (st.y >> 24) & 1;
         MaskView m;
@@ -585,14 +599,44 @@ __global__ __launch_bounds__(256) void k_walk_count(const uint32_t *__restrict__
         m.WWP = P.WWP;
         // canonical key: outer = own index, hole = index of the background pixel to the right
         const int key = hole ? pidx(x0 + 1, y0, W) : pidx(x0, y0, W);
-        unsigned nb = nb8(m, x0, y0);
         const int s_end = hole ? 0 : 4;
-        // do { s = (s - 1) & 7; } while (*i1 == 0 && s != s_end)  == first foreground clockwise from s_end - 1
-        int count = 0, ok = 1;
+        int count = 0, ok = active, closed = 0;
         int slot = -1;
-        if (nb == 0) {
-            count = 1;  // single pixel domain
+        uint32_t *chunk = nullptr;
+        if (!PROBE && active) {
+            unsigned o = atomicAdd((unsigned *)&counts[f].ncontours, 1u);
+            if (o < ccap) {
+                slot = (int)o;
+                fco[slot] = make_uint4(st.x, st.y, 0u, (unsigned)key);  // count 0 = not accepted
+            } else {
+                atomicOr(&G->overflow, 2u);
+                ok = 0;
+            }
+        }
+        // emit point `count` of this contour into the chunk pool (full pass only)
+        auto emit = [&](int px, int py) {
+            if (PROBE) return;
+            if ((count & (CK - 1)) == 0) {
+                unsigned c = atomicAdd((unsigned *)&counts[f].npool, 1u);
+                if (c < pcap) {
+                    chunk = fpool + (long long)c * CK;
+                    ftab[(long long)slot * nck + count / CK] = c;
+                } else {
+                    atomicOr(&G->overflow, 8u);
+                    ok = 0;
+                    return;
+                }
+            }
+            chunk[count & (CK - 1)] = (uint32_t)px | ((uint32_t)py << 16);
+        };
+        unsigned nb = ok ? nb8(m, x0, y0) : 0u;
+        if (!ok) {
+        } else if (nb == 0) {
+            emit(x0, y0);  // single pixel domain
+            count = 1;
+            closed = 1;
         } else {
+            // do { s = (s - 1) & 7; } while (*i1 == 0 && s != s_end)  == first foreground clockwise from s_end - 1
             int sdir;
             {
                 unsigned nb2 = nb | (nb << 8);
@@ -603,7 +647,7 @@ __global__ __launch_bounds__(256) void k_walk_count(const uint32_t *__restrict__
             }
             const int i1x = x0 + c_dx8[sdir], i1y = y0 + c_dy8[sdir];
             // backward cursor starts on i1 with forward direction pointing at the start pixel
-            int bx = i1x, by = i1y, bf = (sdir + 4) & 7, bleft = BACK_BUDGET;
+            int bx = i1x, by = i1y, bf = (sdir + 4) & 7, bleft = PROBE ? PROBE_STEPS : BACK_BUDGET;
             if (!hole && pidx(bx, by, W) < key) ok = 0;
             int cx = x0, cy = y0;
             while (ok) {
@@ -620,26 +664,18 @@ __global__ __launch_bounds__(256) void k_walk_count(const uint32_t *__restrict__
                     }
                 }
                 int sn = (start + t) & 7;
-                if ((count & (CK - 1)) == 0 && count) {
-                    if (slot < 0) {
-                        unsigned o = atomicAdd((unsigned *)&counts[f].ncontours, 1u);
-                        if (o < ccap) {
-                            slot = (int)o;
-                            fco[slot] = make_uint4(st.x, st.y, 0u, (unsigned)key);  // count 0 = not (yet) accepted
-                        } else {
-                            atomicOr(&G->overflow, 2u);
-                            ok = 0;
-                        }
-                    }
-                    if (slot >= 0) fck[(long long)slot * nck + count / CK] = ck_pack(cx, cy, sdir);
-                }
+                if (ok) emit(cx, cy);
                 count++;
                 int nx = cx + c_dx8[sn], ny = cy + c_dy8[sn];
                 if (!ok || count > P.maxPerim) {
                     ok = 0;
                     break;
                 }
-                if (nx == x0 && ny == y0 && cx == i1x && cy == i1y) break;
+                if (nx == x0 && ny == y0 && cx == i1x && cy == i1y) {
+                    closed = 1;
+                    break;
+                }
+                if (PROBE && count >= PROBE_STEPS) break;
                 cx = nx;
                 cy = ny;
                 if (!hole && pidx(cx, cy, W) < key) {
@@ -670,79 +706,84 @@ __global__ __launch_bounds__(256) void k_walk_count(const uint32_t *__restrict__
                 }
             }
         }
-        if (ok && count >= P.minPerim && count <= P.maxPerim) {
-            if (slot < 0) {
-                unsigned o = atomicAdd((unsigned *)&counts[f].ncontours, 1u);
-                if (o < ccap) slot = (int)o;
-                else atomicOr(&G->overflow, 2u);
+        if (PROBE) {
+            // still undecided, or closed with a length that passes the perimeter gate
+            const int keep = ok && (!closed || (count >= P.minPerim && count <= P.maxPerim));
+            const unsigned long long mk = ballot64(keep);
+            if (mk) {
+                const int leader = __ffsll((long long)mk) - 1;
+                unsigned base = 0;
+                if (lane == leader) base = atomicAdd((unsigned *)&counts[f].nsurv, (unsigned)__popcll(mk));
+                base = __shfl(base, leader, WAVE);
+                const unsigned idx = base + (unsigned)__popcll(mk & ((1ull << lane) - 1ull));
+                if (keep) {
+                    if (idx < (unsigned)P.maxStarts) fsv[idx] = st;
+                    else atomicOr(&G->overflow, 1u);
+                }
             }
-            if (slot >= 0) fco[slot] = make_uint4(st.x, st.y, (unsigned)count, (unsigned)key);
+        } else if (ok && closed && count >= P.minPerim && count <= P.maxPerim && slot >= 0) {
+            fco[slot].z = (unsigned)count;
         }
     }
 }
 
+// points per contour the first (short-LDS) launch of k_approx accepts
+#define K4_SHORT_PTS 2048
+#define K4_SHORT_STACK 256
+#define K4_LONG_STACK 1024
+__device__ __host__ inline int pts_cap_first(const DevParams &P) { return P.maxPerim < K4_SHORT_PTS ? P.maxPerim : K4_SHORT_PTS; }
+
 // ------------------------------------------------------------------------------------------------
-// K4: one wave per surviving contour: replay the walk into LDS (points packed x | y << 16) -- lane l replays
-// points [CK*l, CK*l + CK) from checkpoint l -- then approxPolyDP(closed, eps = size *
-// polygonalApproxAccuracyRate) exactly as approx.cpp approxPolyDP_<int> orders its work (the slice stack is
-// sequential, each slice's farthest-point search is a wave reduction with first-maximum tie-break), then
-// _findMarkerContours' gates (aruco.cpp): 4 points, convex, min side, distance to the image border.
-#define DP_STACK 1024
-__global__ __launch_bounds__(64) void k_approx(const uint32_t *__restrict__ masks, const uint4 *__restrict__ contours,
-                                                const uint32_t *__restrict__ ckpts, DevCand *__restrict__ cands,
-                                                DevCounts *__restrict__ counts, DevGlobal *__restrict__ G, const DevParams P)
+// K4: one wave per accepted contour: gather its points from the chunk pool into LDS (one coalesced 256-byte
+// load per chunk), then approxPolyDP(closed, eps = size * polygonalApproxAccuracyRate) exactly as approx.cpp
+// approxPolyDP_<int> orders its work (the slice stack is sequential, each slice's farthest-point search is a
+// wave reduction with first-maximum tie-break), then _findMarkerContours' gates (aruco.cpp): 4 points,
+// convex, min side, distance to the image border.
+// LDS (points + slice stack) is what limits residency, so the launch is bucketed by contour length: the
+// first launch takes contours of at most pts_cap points with a short stack and flags the rare contour whose
+// slice stack overflows (bit 25 of the slot's meta word); the second launch, sized for maxPerimeterPixels,
+// takes the longer and the flagged ones.
+#define K4_RETRY_BIT (1u << 25)
+__global__ __launch_bounds__(64) void k_approx(uint4 *__restrict__ contours, const uint32_t *__restrict__ chunk_tab,
+                                                const uint32_t *__restrict__ pool, DevCand *__restrict__ cands,
+                                                DevCounts *__restrict__ counts, DevGlobal *__restrict__ G, const DevParams P,
+                                                int pts_cap, int stack_cap, int second_pass)
 {
-    extern __shared__ uint32_t pts[];  // maxPerim points
-    __shared__ int2 stack[DP_STACK];
+    extern __shared__ uint32_t pts[];  // pts_cap points, then stack_cap slices
+    int2 *stack = reinterpret_cast<int2 *>(pts + pts_cap);
     __shared__ int dst[2 * 16];
     const int lane = lane_id();
     const int f = blockIdx.y;
     unsigned n = (unsigned)counts[f].ncontours;
     n = n < (unsigned)P.maxContours ? n : (unsigned)P.maxContours;
-    const int W = P.W, H = P.H, S = P.nscales;
+    const int W = P.W, H = P.H;
     const int nck = P.maxPerim / CK + 1;
-    const uint4 *fco = contours + (long long)f * P.maxContours;
-    const uint32_t *fck = ckpts + (long long)f * P.maxContours * nck;
+    uint4 *fco = contours + (long long)f * P.maxContours;
+    const uint32_t *ftab = chunk_tab + (long long)f * P.maxContours * nck;
+    const uint32_t *fpool = pool + (long long)f * P.maxChunks * CK;
     for (unsigned ci = blockIdx.x; ci < n; ci += gridDim.x) {
         uint4 c = fco[ci];
         const int count = (int)c.z;
         if (count == 0) continue;  // slot of a walk that was dropped
+        if (second_pass) {
+            if (count <= pts_cap_first(P) && !(c.y & K4_RETRY_BIT)) continue;
+        } else if (count > pts_cap) {
+            continue;
+        }
         const int x0 = c.x & 0xffff, y0 = c.x >> 16;
         const int s = (c.y >> 16) & 0xff, hole = (c.y >> 24) & 1;
-        MaskView m;
-        m.base = masks + (((long long)f * S + s) * (H + 2)) * P.WWP;
-        m.WWP = P.WWP;
         __syncthreads();
-        // ---- replay the border, CK points per lane
-        for (int seg = lane; seg * CK < count; seg += 64) {
-            int cx, cy, sdir;
-            if (seg == 0) {
-                cx = x0;
-                cy = y0;
-                unsigned nb0 = nb8(m, x0, y0);
-                unsigned nb2 = nb0 | (nb0 << 8);
-                int c0 = ((hole ? 0 : 4) - 1) & 7;
-                unsigned win = (nb2 >> (c0 + 1)) & 0xffu;
-                int t = 7 - (31 - __clz((int)win));
-                sdir = (c0 - t) & 7;
-            } else {
-                uint32_t ck = fck[(long long)ci * nck + seg];
-                cx = ck & 0x1fff;
-                cy = (ck >> 13) & 0x1fff;
-                sdir = ck >> 26;
-            }
-            int kend = seg * CK + CK;
-            kend = kend < count ? kend : count;
-            for (int k = seg * CK; k < kend; k++) {
-                pts[k] = (uint32_t)cx | ((uint32_t)cy << 16);
-                unsigned nb = nb8(m, cx, cy);
-                unsigned nb2 = nb | (nb << 8);
-                int start = (sdir + 1) & 7;
-                int t = __ffs((nb2 >> start) & 0xffu) - 1;
-                int sn = (start + t) & 7;
-                cx += c_dx8[sn];
-                cy += c_dy8[sn];
-                sdir = (sn + 4) & 7;
+        // ---- gather the border
+        {
+            const int nchunks = (count + CK - 1) / CK;
+            for (int cb = 0; cb < nchunks; cb += 64) {
+                const uint32_t myc = cb + lane < nchunks ? ftab[(long long)ci * nck + cb + lane] : 0u;
+                const int m = nchunks - cb < 64 ? nchunks - cb : 64;
+                for (int q = 0; q < m; q++) {
+                    const uint32_t id = __shfl(myc, q, WAVE);
+                    const int k = (cb + q) * CK + lane;
+                    if (k < count) pts[k] = fpool[(long long)id * CK + lane];
+                }
             }
         }
         __syncthreads();
@@ -840,9 +881,12 @@ __global__ __launch_bounds__(64) void k_approx(const uint32_t *__restrict__ mask
                     new_count++;
                 }
             } else {
-                if (top + 2 > DP_STACK) {
+                if (top + 2 > stack_cap) {
                     reject = 1;
-                    if (lane == 0) atomicOr(&G->overflow, 4u);
+                    if (lane == 0) {
+                        if (second_pass) atomicOr(&G->overflow, 4u);
+                        else fco[ci].y = c.y | K4_RETRY_BIT;  // the second launch has the long stack
+                    }
                 } else {
                     if (lane == 0) {
                         stack[top] = make_int2(split, sl.y);   // right_slice

@@ -49,7 +49,7 @@ def _poses_to_result(arr, n) -> PoseResult:
 class ArucoDetector:
     def __init__(self, dictionary: Dictionary | int | str = 7, params: FidParams | None = None, device: int = 0,
                  max_width: int = 1920, max_height: int = 1080, max_batch: int = 1, max_markers: int = 256,
-                 max_candidates: int = 2048, max_starts: int = 0, max_contours: int = 0):
+                 max_candidates: int = 2048, max_starts: int = 0, max_contours: int = 0, max_points: int = 0):
         self._L = _lib.load()
         self.dictionary = dictionary if isinstance(dictionary, Dictionary) else get_predefined_dictionary(dictionary)
         self.params = params or default_params()
@@ -64,6 +64,8 @@ class ArucoDetector:
             lim.max_starts_per_frame = max_starts
         if max_contours:
             lim.max_contours_per_frame = max_contours
+        if max_points:
+            lim.max_points_per_frame = max_points
         self.limits = lim
         self._ctx = C.c_void_p()
         rc = self._L.fid_create(C.byref(self.params), C.byref(fd), C.byref(lim), device, C.byref(self._ctx))

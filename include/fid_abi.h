@@ -111,7 +111,7 @@ typedef struct fid_limits {
     int32_t max_contours_per_frame; /* [16384]  contours passing the perimeter gate, all scales */
     int32_t max_candidates_per_frame; /* [2048] quads leaving _findMarkerContours, all scales */
     int32_t max_markers_per_frame;  /* [256] */
-    int32_t reserved0;
+    int32_t max_points_per_frame;   /* [4194304] contour points kept while borders are followed, all scales */
 } fid_limits;
 
 void fid_default_params(fid_params *p);
@@ -154,7 +154,7 @@ typedef enum fid_tap {
     FID_TAP_BITS = 3,        /* uint8 [nframes][max_candidates_per_frame][(ms+2)^2] for FILTERED entries */
     FID_TAP_IDENT = 4,       /* int32 [nframes][max_candidates_per_frame][2] id, rotation */
     FID_TAP_PRESUBPIX = 5,   /* fid_marker [nframes][max_markers_per_frame] */
-    FID_TAP_COUNTS = 6,      /* int32 [nframes][8]: starts, contours, candidates, filtered, accepted, markers, overflow flags, 0 */
+    FID_TAP_COUNTS = 6,      /* int32 [nframes][8]: starts, contour slots, candidates, filtered, accepted, markers, overflow flags, probe survivors */
     FID_TAP_GRAY = 7         /* uint8 [nframes][height][width] the gray image the detector saw */
 } fid_tap;
 

@@ -171,7 +171,8 @@ void set_geometry(fid_ctx *c, int W, int H, int gstride, int F)
     P.H = H;
     P.gstride = gstride;
     P.WW = (W + 31) / 32;
-    P.WWP = MASK_PADW + roundup(roundup(W, TX) / 32, 4) + 4;
+    P.TC = MASK_PADW + roundup(W, 128) / 32 + 1;  // one zero tile column left and right (threshold tiles are 128 px wide)
+    P.TR = (H + 2 + MT_ROWS - 1) / MT_ROWS;
     P.nframes = F;
     int maxdim = W > H ? W : H;
     P.minPerim = (int)(unsigned int)(c->params.minMarkerPerimeterRate * maxdim);
@@ -185,8 +186,8 @@ void set_geometry(fid_ctx *c, int W, int H, int gstride, int F)
 
 size_t masks_elems(const fid_ctx *c, int W, int H, int F)
 {
-    int WWP = MASK_PADW + roundup(roundup(W, TX) / 32, 4) + 4;
-    return (size_t)F * c->P.nscales * (H + 2) * WWP;
+    int TC = MASK_PADW + roundup(W, 128) / 32 + 1, TR = (H + 2 + MT_ROWS - 1) / MT_ROWS;
+    return (size_t)F * c->P.nscales * TR * TC * MT_ROWS;
 }
 
 void mark(fid_ctx *c, int idx)
@@ -258,9 +259,9 @@ fid_status run_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H, int
     mark(c, ST_THRESH + 1);
     // ---- K2
     {
-        long long groups = (long long)P.nscales * H * ((P.WW + 3) / 4);
-        long long blocks = (groups + 255) / 256;
-        if (blocks > 64) blocks = 64;
+        long long groups = (long long)P.nscales * P.TR * ((P.WW + 3) / 4);  // one wave per group
+        long long blocks = (groups + 3) / 4;
+        if (blocks > 256) blocks = 256;
         hipLaunchKernelGGL(k_find_starts, dim3((unsigned)blocks, F), dim3(256), 0, st, c->d_masks, c->d_starts, c->d_counts,
                            c->d_global, P);
     }
@@ -672,7 +673,7 @@ int64_t fid_tap_bytes(fid_ctx *c, fid_tap which)
     case FID_TAP_BITS: return F * P.maxCands * msb * msb;
     case FID_TAP_IDENT: return F * P.maxCands * 8;
     case FID_TAP_PRESUBPIX: return F * P.maxMarkers * (int64_t)sizeof(fid_marker);
-    case FID_TAP_COUNTS: return F * 8 * 4;
+    case FID_TAP_COUNTS: return F * 12 * 4;
     case FID_TAP_GRAY: return F * (int64_t)P.W * P.H;
     }
     return 0;
@@ -689,11 +690,14 @@ fid_status fid_tap_read(fid_ctx *c, fid_tap which, void *dst, int64_t dst_bytes)
     const int msb = P.markerSize + 2 * P.borderBits;
     switch (which) {
     case FID_TAP_MASKS: {
-        // strip the padding: 2-D copy per (frame, scale)
+        // un-tile on the host
+        const size_t plane = (size_t)P.TR * P.TC * MT_ROWS;
+        std::vector<uint32_t> tmp(plane);
         for (int fs = 0; fs < F * P.nscales; fs++) {
-            const uint32_t *src = c->d_masks + ((size_t)fs * (P.H + 2) + 1) * P.WWP + MASK_PADW;
-            HIPCHK(c, hipMemcpy2D((char *)dst + (size_t)fs * P.H * P.WW * 4, (size_t)P.WW * 4, src, (size_t)P.WWP * 4,
-                                  (size_t)P.WW * 4, P.H, hipMemcpyDeviceToHost));
+            HIPCHK(c, hipMemcpy(tmp.data(), c->d_masks + (size_t)fs * plane, plane * 4, hipMemcpyDeviceToHost));
+            uint32_t *o = (uint32_t *)dst + (size_t)fs * P.H * P.WW;
+            for (int y = 0; y < P.H; y++)
+                for (int w = 0; w < P.WW; w++) o[(size_t)y * P.WW + w] = tmp[(size_t)mask_word(P.TC, y + 1, MASK_PADW + w)];
         }
         return FID_OK;
     }
@@ -735,14 +739,16 @@ fid_status fid_tap_read(fid_ctx *c, fid_tap which, void *dst, int64_t dst_bytes)
     case FID_TAP_COUNTS: {
         int32_t *o = (int32_t *)dst;
         for (int f = 0; f < F; f++) {
-            o[8 * f + 0] = c->h_counts[f].nstarts;
-            o[8 * f + 1] = c->h_counts[f].ncontours;
-            o[8 * f + 2] = c->h_counts[f].ncand;
-            o[8 * f + 3] = c->h_counts[f].nfilt;
-            o[8 * f + 4] = c->h_counts[f].nacc;
-            o[8 * f + 5] = c->h_counts[f].nmark;
-            o[8 * f + 6] = c->h_counts[f].overflow | ((int32_t)c->h_global->overflow << 8);
-            o[8 * f + 7] = c->h_counts[f].nsurv;
+            o[12 * f + 0] = c->h_counts[f].nstarts;
+            o[12 * f + 1] = c->h_counts[f].ncontours;
+            o[12 * f + 2] = c->h_counts[f].ncand;
+            o[12 * f + 3] = c->h_counts[f].nfilt;
+            o[12 * f + 4] = c->h_counts[f].nacc;
+            o[12 * f + 5] = c->h_counts[f].nmark;
+            o[12 * f + 6] = c->h_counts[f].overflow | ((int32_t)c->h_global->overflow << 8);
+            o[12 * f + 7] = c->h_counts[f].nsurv;
+            o[12 * f + 8] = c->h_counts[f].npool;
+            o[12 * f + 9] = o[12 * f + 10] = o[12 * f + 11] = 0;
         }
         return FID_OK;
     }

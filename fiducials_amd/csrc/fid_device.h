@@ -3,10 +3,13 @@
 // HBM layout (all per context, sized at fid_create for max_batch frames F of W x H):
 //   gray      u8   [F][H][W]                  the image the detector sees (aliases the caller's
 //                                              buffer for mono8 device input with stride == W)
-//   masks     u32  [F][S][H+2][WWP]           13 bit-packed adaptive-threshold masks; pixel x of row y
-//                                              is bit (x & 31) of word MASK_PADW + (x >> 5) in padded
-//                                              row y+1; pad rows/words are zero so border following
-//                                              never bounds-checks
+//   masks     u32  [F][S][TR][TC][16]         13 bit-packed adaptive-threshold masks, TILED: one tile =
+//                                              32 px x 16 rows = one 64-byte line, so that the 3x3
+//                                              neighbourhoods border following reads stay inside one or
+//                                              two lines.  Pixel x of row y is bit (x & 31) of word
+//                                              (yy & 15) of tile (yy >> 4, MASK_PADW + (x >> 5)), yy = y + 1;
+//                                              pad rows / tile columns are zero so border following never
+//                                              bounds-checks
 //   starts    uint2 [F][max_starts]           border-following start candidates (all scales)
 //   surv      uint2 [F][max_starts]           the starts that survive the probe pass, compacted
 //   contours  uint4 [F][max_contours]         contour slots: start, meta, length (0 = dropped), discovery key
@@ -21,12 +24,13 @@
 #pragma once
 #include <stdint.h>
 
-#define MASK_PADW 4  // zero words in front of every mask row (keeps 16-B store alignment)
+#define MASK_PADW 1  // zero tile columns in front of every tile row
+#define MT_ROWS 16   // rows per mask tile
 #define FID_MAX_SCALES 32
 #define FID_MAX_CELLS 9  // marker_size + 2*border <= 9 (7x7 dictionaries)
 
 struct DevParams {
-    int W, H, gstride, WW, WWP, nscales, nframes;
+    int W, H, gstride, WW, TC, TR, nscales, nframes;  // WW mask words per image row; TC x TR mask tiles per plane
     int win[FID_MAX_SCALES];       // odd window sizes
     int idelta;                    // cvCeil(adaptiveThreshConstant)
     int rmax;                      // max window radius
@@ -42,6 +46,12 @@ struct DevParams {
     int maxStarts, maxContours, maxCands, maxMarkers;  // per-frame capacities
     int maxChunks;                                     // per-frame pool of CK-point contour chunks
 };
+
+// word index of padded row yy, word column wi inside one (frame, scale) mask plane of TC tile columns
+__host__ __device__ inline long long mask_word(int TC, int yy, int wi)
+{
+    return ((long long)(yy >> 4) * TC + wi) * MT_ROWS + (yy & (MT_ROWS - 1));
+}
 
 struct DevCand {
     int scale;

@@ -170,7 +170,8 @@ __global__ __launch_bounds__(NT) void k_threshold(const uint8_t *__restrict__ gr
     __syncthreads();
     // phase 4: evaluate all scales
     constexpr int SEGS = TX / 64;
-    const int S = P.nscales, WWP = P.WWP;
+    const int S = P.nscales, TC = P.TC;
+    const long long plane = (long long)P.TR * TC * MT_ROWS;
     for (int item = wid; item < TY * SEGS; item += NWAVES) {
         int ty = item / SEGS, seg = item % SEGS;
         int x = seg * 64 + lane;
@@ -180,7 +181,7 @@ __global__ __launch_bounds__(NT) void k_threshold(const uint8_t *__restrict__ gr
         int gv = valid ? (int)g[(long long)gy * gs + gx] : 0;
         int t2 = 2 * (gv + P.idelta) - 1;
         int rc = ty + R, cc = x + R;
-        uint32_t *mrow = masks + (((long long)f * S) * (H + 2) + (gy + 1)) * WWP + MASK_PADW + ((x0 + seg * 64) >> 5);
+        uint32_t *mrow = masks + (long long)f * S * plane + mask_word(TC, gy + 1, MASK_PADW + ((x0 + seg * 64) >> 5));
         for (int s = 0; s < S; s++) {
             int win = P.win[s], r = win >> 1;
             const uint32_t *top = I + (rc - r) * PT, *bot = I + (rc + r + 1) * PT;
@@ -188,10 +189,8 @@ __global__ __launch_bounds__(NT) void k_threshold(const uint8_t *__restrict__ gr
             int fg = valid && (2 * sum >= t2 * win * win);
             unsigned long long b = ballot64(fg);
             if (lane == 0) {
-                uint2 wv;
-                wv.x = (uint32_t)b;
-                wv.y = (uint32_t)(b >> 32);
-                *reinterpret_cast<uint2 *>(mrow + (long long)s * (H + 2) * WWP) = wv;
+                mrow[(long long)s * plane] = (uint32_t)b;
+                mrow[(long long)s * plane + MT_ROWS] = (uint32_t)(b >> 32);  // next tile column
             }
         }
     }
@@ -225,8 +224,8 @@ __device__ __forceinline__ void static_for(F &&f)
 //   phase 1       wave per raw row: one dword (4 px) per lane, 4-px local prefix + wave scan -> row prefix in LDS
 //   phase 2       column prefix in two levels (5 row chunks x 184 columns, 34 values in registers per thread)
 //   phase 3       wave per (row, 64-px segment): per scale 4 LDS reads, 2*sum >= t2*win^2, v_cmp = the mask
-//                 word pair; ballots are parked in lane k of the accumulators and leave as ONE 16-byte store
-//                 per (row, scale)
+//                 word pair; ballots are parked in lane k of the accumulators; each lane then stores its row's
+//                 four words per scale into the tiled mask layout
 template <int WMIN, int WSTEP, int NS>
 struct ThrCfg {
     static constexpr int TX = 128, TY = 120, NT = 1024, NW = NT / 64;
@@ -381,10 +380,16 @@ __global__ __launch_bounds__(1024) void k_threshold_fixed(const uint8_t *__restr
         const int ty = wid + NW * lane;
         const int gy = y0 + ty;
         if (lane < C::ITEMS && ty < TY && gy < H) {
-            const int WWP = P.WWP;
-            uint32_t *mrow = masks + (((long long)f * NS) * (H + 2) + (gy + 1)) * WWP + MASK_PADW + (x0 >> 5);
+            const long long plane = (long long)P.TR * P.TC * MT_ROWS;
+            uint32_t *mrow = masks + (long long)f * NS * plane + mask_word(P.TC, gy + 1, MASK_PADW + (x0 >> 5));
 #pragma unroll
-            for (int s = 0; s < NS; s++) *reinterpret_cast<uint4 *>(mrow + (long long)s * (H + 2) * WWP) = acc[s];
+            for (int s = 0; s < NS; s++) {
+                uint32_t *q = mrow + (long long)s * plane;  // the four words sit in four neighbouring tiles
+                q[0] = acc[s].x;
+                q[MT_ROWS] = acc[s].y;
+                q[2 * MT_ROWS] = acc[s].z;
+                q[3 * MT_ROWS] = acc[s].w;
+            }
         }
     }
 }
@@ -416,7 +421,8 @@ __device__ __forceinline__ uint32_t fill_toward_lsb(uint32_t seed, uint32_t runs
     return f;
 }
 
-#define K2_WPT 4  // words per thread per iteration
+// One thread per mask word; a wave covers 16 rows x 4 word columns = four whole mask tiles (256 contiguous
+// bytes).  The neighbour words (left / right, this row and the row above) come through the L1.
 __global__ __launch_bounds__(256) void k_find_starts(const uint32_t *__restrict__ masks, uint2 *__restrict__ starts,
                                                       DevCounts *__restrict__ counts, DevGlobal *__restrict__ G,
                                                       const DevParams P)
@@ -425,58 +431,48 @@ __global__ __launch_bounds__(256) void k_find_starts(const uint32_t *__restrict_
     __shared__ unsigned s_base;
     const int lane = lane_id(), wid = threadIdx.x >> 6;
     const int f = blockIdx.y;
-    const int WW = P.WW, WWP = P.WWP, H = P.H, S = P.nscales, W = P.W;
-    const int WQ = (WW + K2_WPT - 1) / K2_WPT;  // word groups per row
-    const long long total = (long long)S * H * WQ;
-    const long long totalr = (total + 255) & ~255LL;
+    const int WW = P.WW, TC = P.TC, TR = P.TR, H = P.H, S = P.nscales;
+    const int CG = (WW + 3) / 4;               // groups of 4 word columns
+    const long long ngroups = (long long)S * TR * CG;  // one wave per group
+    const long long ngr4 = (ngroups + 3) & ~3LL;
+    const long long plane = (long long)TR * TC * MT_ROWS;
     const unsigned cap = (unsigned)P.maxStarts;
     uint2 *fst = starts + (long long)f * P.maxStarts;
-    for (long long i0 = (long long)blockIdx.x * 256; i0 < totalr; i0 += (long long)gridDim.x * 256) {
-        long long i = i0 + threadIdx.x;
-        uint32_t outer[K2_WPT], hole[K2_WPT], ebits[K2_WPT];
-        int w0 = 0, y = 0, s = 0, cnt = 0, extra = 0;
-#pragma unroll
-        for (int k = 0; k < K2_WPT; k++) outer[k] = hole[k] = ebits[k] = 0;
-        if (i < total) {
-            int wq = (int)(i % WQ);
-            long long t = i / WQ;
-            y = (int)(t % H);
-            s = (int)(t / H);
-            w0 = wq * K2_WPT;
-            const uint32_t *row = masks + (((long long)f * S + s) * (H + 2) + (y + 1)) * WWP + MASK_PADW + w0;
-            const uint32_t *up = row - WWP;
-            uint32_t prevc = row[-1], prevu = up[-1];
-            uint32_t cur = row[0], u = up[0];
-#pragma unroll
-            for (int k = 0; k < K2_WPT; k++) {
-                uint32_t nextc = row[k + 1], nextu = up[k + 1];
-                if (w0 + k < WW) {
-                    uint32_t Wst = (cur << 1) | (prevc >> 31);
-                    uint32_t NW = (u << 1) | (prevu >> 31);
-                    uint32_t NE = (u >> 1) | (nextu << 31);
-                    // outer: starts of foreground runs that have no foreground above (N / NW / NE) anywhere
-                    uint32_t touch = cur & (NW | u | NE);
-                    outer[k] = cur & ~Wst & ~fill_toward_lsb(touch, cur);
-                    // hole: first pixel e of a background run (W neighbour foreground) that is closed above
-                    uint32_t bg = ~cur;
-                    uint32_t open = bg & ~u;  // background with background above: joins an earlier pixel
-                    ebits[k] = bg & Wst & ~fill_toward_lsb(open, bg);
-                }
-                prevc = cur;
-                prevu = u;
-                cur = nextc;
-                u = nextu;
+    for (long long g0 = (long long)blockIdx.x * 4; g0 < ngr4; g0 += (long long)gridDim.x * 4) {
+        const long long g = g0 + wid;
+        uint32_t outer = 0, hole = 0;
+        int x_base = 0, y = 0, s = 0, cnt = 0;
+        if (g < ngroups) {
+            const int cg = (int)(g % CG);
+            const long long t = g / CG;
+            const int tr = (int)(t % TR);
+            s = (int)(t / TR);
+            const int w = cg * 4 + (lane >> 4);
+            const int yy = tr * MT_ROWS + (lane & 15);
+            y = yy - 1;
+            x_base = w * 32;
+            if (y >= 0 && y < H && w < WW) {
+                const uint32_t *pl = masks + ((long long)f * S + s) * plane;
+                const uint32_t *row = pl + mask_word(TC, yy, MASK_PADW + w);
+                const uint32_t *up = pl + mask_word(TC, yy - 1, MASK_PADW + w);
+                const uint32_t cur = row[0], prevc = row[-MT_ROWS], nextc = row[MT_ROWS];
+                const uint32_t u = up[0], prevu = up[-MT_ROWS], nextu = up[MT_ROWS];
+                const uint32_t Wst = (cur << 1) | (prevc >> 31);
+                const uint32_t NW = (u << 1) | (prevu >> 31);
+                const uint32_t NE = (u >> 1) | (nextu << 31);
+                // outer: starts of foreground runs that have no foreground above (N / NW / NE) anywhere
+                const uint32_t touch = cur & (NW | u | NE);
+                outer = cur & ~Wst & ~fill_toward_lsb(touch, cur);
+                // hole: first pixel e of a background run (W neighbour foreground) that is closed above;
+                // the border-following start is the foreground pixel LEFT of e
+                const uint32_t bg = ~cur;
+                const uint32_t open = bg & ~u;  // background with background above: joins an earlier pixel
+                const uint32_t e = bg & Wst & ~fill_toward_lsb(open, bg);
+                const uint32_t bgn = ~nextc;
+                const uint32_t en0 = bgn & (cur >> 31) & ~fill_toward_lsb(bgn & ~nextu, bgn) & 1u;
+                hole = (e >> 1) | (en0 << 31);
+                cnt = __popc(outer) + __popc(hole);
             }
-            // the border-following start is the foreground pixel LEFT of e
-#pragma unroll
-            for (int k = 0; k < K2_WPT; k++) {
-                hole[k] = ebits[k] >> 1;
-                if (k + 1 < K2_WPT) hole[k] |= (ebits[k + 1] & 1u) << 31;
-            }
-            extra = (int)(ebits[0] & 1u);  // start pixel = last pixel of the previous word group (w0 > 0 when set)
-            cnt = extra;
-#pragma unroll
-            for (int k = 0; k < K2_WPT; k++) cnt += __popc(outer[k]) + __popc(hole[k]);
         }
         int incl = wave_iscan(cnt);
         if (lane == 63) s_wsum[wid] = incl;
@@ -492,33 +488,23 @@ __global__ __launch_bounds__(256) void k_find_starts(const uint32_t *__restrict_
         __syncthreads();
         if (tot) {
             unsigned off = s_base + (unsigned)(wbase + incl - cnt);
-            uint32_t meta = (uint32_t)f | ((uint32_t)s << 16);
-            if (extra) {
-                if (off < cap) fst[off] = make_uint2((uint32_t)(w0 * 32 - 1) | ((uint32_t)y << 16), meta | (1u << 24));
+            const uint32_t meta = (uint32_t)f | ((uint32_t)s << 16);
+            while (outer) {
+                int b = __ffs(outer) - 1;
+                outer &= outer - 1;
+                if (off < cap) fst[off] = make_uint2((uint32_t)(x_base + b) | ((uint32_t)y << 16), meta);
                 off++;
             }
-#pragma unroll
-            for (int k = 0; k < K2_WPT; k++) {
-                uint32_t o = outer[k], hh = hole[k];
-                int xb = (w0 + k) * 32;
-                while (o) {
-                    int b = __ffs(o) - 1;
-                    o &= o - 1;
-                    if (off < cap) fst[off] = make_uint2((uint32_t)(xb + b) | ((uint32_t)y << 16), meta);
-                    off++;
-                }
-                while (hh) {
-                    int b = __ffs(hh) - 1;
-                    hh &= hh - 1;
-                    if (off < cap) fst[off] = make_uint2((uint32_t)(xb + b) | ((uint32_t)y << 16), meta | (1u << 24));
-                    off++;
-                }
+            while (hole) {
+                int b = __ffs(hole) - 1;
+                hole &= hole - 1;
+                if (off < cap) fst[off] = make_uint2((uint32_t)(x_base + b) | ((uint32_t)y << 16), meta | (1u << 24));
+                off++;
             }
             if (threadIdx.x == 0 && s_base + (unsigned)tot > cap) atomicOr(&G->overflow, 1u);
         }
         __syncthreads();
     }
-    (void)W;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -528,21 +514,31 @@ __device__ __constant__ int c_dx8[8] = {1, 1, 0, -1, -1, -1, 0, 1};
 __device__ __constant__ int c_dy8[8] = {0, -1, -1, -1, 0, 1, 1, 1};
 
 struct MaskView {
-    const uint32_t *base;  // padded row 0 (image row -1), word 0
-    int WWP;
+    const uint32_t *base;  // (frame, scale) mask plane, tiled
+    int TC;
 };
 
 // 8-neighbourhood occupancy of pixel (x, y): bit d = neighbour in direction d is foreground
 __device__ __forceinline__ unsigned nb8(const MaskView &m, int x, int y)
 {
-    // bits x-1, x, x+1 of rows y-1, y, y+1; pixel x lives at bit (x & 31) of word MASK_PADW + (x >> 5)
-    int xb = x - 1 + MASK_PADW * 32;
-    int wi = xb >> 5, sh = xb & 31;
-    const uint32_t *r0 = m.base + (long long)y * m.WWP + wi;  // padded row y = image row y-1
-    const uint32_t *r1 = r0 + m.WWP, *r2 = r1 + m.WWP;
-    unsigned tu = __builtin_amdgcn_alignbit(r0[1], r0[0], sh) & 7u;
-    unsigned tm = __builtin_amdgcn_alignbit(r1[1], r1[0], sh) & 7u;
-    unsigned td = __builtin_amdgcn_alignbit(r2[1], r2[0], sh) & 7u;
+    // bits x-1, x, x+1 of rows y-1, y, y+1 (padded rows y, y+1, y+2); the second word column is only
+    // touched when the three bits straddle a word
+    const int xb = x - 1 + MASK_PADW * 32;
+    const int wi = xb >> 5, sh = xb & 31;
+    const bool two = sh > 29;
+    const uint32_t *p0 = m.base + mask_word(m.TC, y, wi);
+    const uint32_t *p1 = m.base + mask_word(m.TC, y + 1, wi);
+    const uint32_t *p2 = m.base + mask_word(m.TC, y + 2, wi);
+    const uint32_t a0 = p0[0], a1 = p1[0], a2 = p2[0];
+    uint32_t b0 = 0, b1 = 0, b2 = 0;
+    if (two) {
+        b0 = p0[MT_ROWS];
+        b1 = p1[MT_ROWS];
+        b2 = p2[MT_ROWS];
+    }
+    unsigned tu = __builtin_amdgcn_alignbit(b0, a0, sh) & 7u;
+    unsigned tm = __builtin_amdgcn_alignbit(b1, a1, sh) & 7u;
+    unsigned td = __builtin_amdgcn_alignbit(b2, a2, sh) & 7u;
     return ((tm >> 2) & 1u) | (((tu >> 2) & 1u) << 1) | (((tu >> 1) & 1u) << 2) | ((tu & 1u) << 3) | ((tm & 1u) << 4) |
            ((td & 1u) << 5) | (((td >> 1) & 1u) << 6) | (((td >> 2) & 1u) << 7);
 }
@@ -595,8 +591,8 @@ __global__ __launch_bounds__(256) void k_walk(const uint32_t *__restrict__ masks
         int x0 = st.x & 0xffff, y0 = st.x >> 16;
         int s = (st.y >> 16) & 0xff, hole = (st.y >> 24) & 1;
         MaskView m;
-        m.base = masks + (((long long)f * S + s) * (H + 2)) * P.WWP;
-        m.WWP = P.WWP;
+        m.base = masks + ((long long)f * S + s) * ((long long)P.TR * P.TC * MT_ROWS);
+        m.TC = P.TC;
         // canonical key: outer = own index, hole = index of the background pixel to the right
         const int key = hole ? pidx(x0 + 1, y0, W) : pidx(x0, y0, W);
         const int s_end = hole ? 0 : 4;

@@ -192,7 +192,7 @@ class ArucoDetector:
         return buf
 
     def tap_counts(self):
-        return self.tap(_lib.TAP_COUNTS).view(np.int32).reshape(-1, 8)
+        return self.tap(_lib.TAP_COUNTS).view(np.int32).reshape(-1, 12)
 
     def tap_masks(self, nframes, nscales, h, w):
         ww = (w + 31) // 32

@@ -40,6 +40,7 @@ struct fid_ctx {
     uint2 *d_starts = nullptr, *d_surv = nullptr;
     uint32_t *d_pool = nullptr;
     int max_chunks = 0;
+    int walk_blocks = 24;  // one-wave workgroups per frame in the full walk pass
     uint4 *d_contours = nullptr;
     uint32_t *d_ckpts = nullptr;
     size_t ckpts_elems = 0;
@@ -172,7 +173,7 @@ void set_geometry(fid_ctx *c, int W, int H, int gstride, int F)
     P.gstride = gstride;
     P.WW = (W + 31) / 32;
     P.TC = MASK_PADW + roundup(W, 128) / 32 + 1;  // one zero tile column left and right (threshold tiles are 128 px wide)
-    P.TR = (H + 2 + MT_ROWS - 1) / MT_ROWS;
+    P.TR = (H + 2 + MT_ROWS - 1) / MT_ROWS + 1;  // + one zero tile row: a 2 x 2 tile window always exists
     P.nframes = F;
     int maxdim = W > H ? W : H;
     P.minPerim = (int)(unsigned int)(c->params.minMarkerPerimeterRate * maxdim);
@@ -186,7 +187,7 @@ void set_geometry(fid_ctx *c, int W, int H, int gstride, int F)
 
 size_t masks_elems(const fid_ctx *c, int W, int H, int F)
 {
-    int TC = MASK_PADW + roundup(W, 128) / 32 + 1, TR = (H + 2 + MT_ROWS - 1) / MT_ROWS;
+    int TC = MASK_PADW + roundup(W, 128) / 32 + 1, TR = (H + 2 + MT_ROWS - 1) / MT_ROWS + 1;
     return (size_t)F * c->P.nscales * TR * TC * MT_ROWS;
 }
 
@@ -274,7 +275,7 @@ fid_status run_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H, int
     hipLaunchKernelGGL(k_walk<true>, dim3(64, F), dim3(256), 0, st, c->d_masks, c->d_starts, c->d_surv, c->d_contours, c->d_ckpts,
                        c->d_pool, c->d_counts, c->d_global, P);
     mark(c, ST_PROBE + 1);
-    hipLaunchKernelGGL(k_walk<false>, dim3(16, F), dim3(256), 0, st, c->d_masks, c->d_surv, c->d_surv, c->d_contours, c->d_ckpts,
+    hipLaunchKernelGGL(k_walk_full, dim3(c->walk_blocks, F), dim3(64), 0, st, c->d_masks, c->d_surv, c->d_contours, c->d_ckpts,
                        c->d_pool, c->d_counts, c->d_global, P);
     mark(c, ST_WALK + 1);
     // ---- K4: short contours with a small LDS footprint first, then the long / flagged ones
@@ -436,6 +437,7 @@ fid_status fid_create(const fid_params *params, const fid_dict *dict, const fid_
     size_t dbytes = (size_t)dict->n_markers * 4 * ((dict->marker_size * dict->marker_size + 7) / 8);
     c->dict_host.assign(dict->bytes, dict->bytes + dbytes);
     c->profile = getenv("FID_PROFILE") && atoi(getenv("FID_PROFILE")) != 0;
+    if (getenv("FID_WALK_BLOCKS")) c->walk_blocks = atoi(getenv("FID_WALK_BLOCKS")) > 0 ? atoi(getenv("FID_WALK_BLOCKS")) : c->walk_blocks;
     memset(&c->P, 0, sizeof(c->P));
 
     fid_status rc = FID_OK;

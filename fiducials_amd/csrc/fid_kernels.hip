@@ -723,6 +723,305 @@ __global__ __launch_bounds__(256) void k_walk(const uint32_t *__restrict__ masks
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// K3 full pass, windowed.  A border-following step is one dependent memory round trip (the 3x3
+// neighbourhood of the new pixel); with 64 independent walkers per wave the round trip of the slowest lane
+// is paid on every step.  Here each lane keeps a private WINDOW of the mask in LDS -- 2 x 2 mask tiles =
+// 64 px x 32 rows = 256 bytes, placed ahead of the direction of travel -- and steps inside it at LDS
+// latency.  A lane that leaves its window parks; every WALK_CKPT iterations (or as soon as nobody can step)
+// the wave reaches a CHECKPOINT where everything that touches memory is batched and asynchronous:
+//   * s_waitcnt vmcnt(0): window refills (LDS-DMA, global_load_lds_dwordx4, 16 per lane, no VGPRs in
+//     flight) and the survivor prefetch issued at the PREVIOUS checkpoint have landed -> those lanes resume
+//   * finished walkers retire (contour slot written), idle lanes take the next survivors of the wave's range
+//   * every walker without a spare pool chunk gets one from the wave's ARENA (a run of WALK_ARENA chunks
+//     taken from the frame pool with one atomic, then handed out by ballot + popcount), parked lanes issue
+//     their refill
+// so the memory latency of one lane overlaps the steps of the others and a checkpoint waits on a round trip
+// of its own only when the arena runs dry.  Points go straight to the contour's pool chunk (fire-and-forget
+// stores).
+// One step = 6 LDS words -> 8 neighbour bits -> one LDS table look-up that yields the next direction and
+// which background 4-neighbours the step examined (the hole-border canonical test).
+// The backward cursor of the probe pass is not needed here: it only ever rejects, and the forward cursor
+// visits every pixel of the border.
+#define WALK_CKPT 8
+#define WALK_RANGE 256  // survivors per wave work range
+#define WALK_ARENA 256  // pool chunks a wave takes per atomic
+
+__device__ __forceinline__ void wait_vmcnt0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ int dir_dx(int d) { return (int)((0x901Au >> (2 * d)) & 3u) - 1; }
+__device__ __forceinline__ int dir_dy(int d) { return (int)((0xA901u >> (2 * d)) & 3u) - 1; }
+
+// raw neighbourhood byte (bits 0-2 row above x-1..x+1, bit 3 W, bit 4 E, bits 5-7 row below) -> direction order
+__device__ __forceinline__ unsigned raw_to_nb(unsigned raw)
+{
+    return ((raw >> 4) & 1u) | (((raw >> 2) & 1u) << 1) | (((raw >> 1) & 1u) << 2) | ((raw & 1u) << 3) | (((raw >> 3) & 1u) << 4) |
+           (raw & 0xe0u);
+}
+
+__global__ __launch_bounds__(64) void k_walk_full(const uint32_t *__restrict__ masks, const uint2 *__restrict__ surv,
+                                                   uint4 *__restrict__ contours, uint32_t *__restrict__ chunk_tab,
+                                                   uint32_t *__restrict__ pool, DevCounts *__restrict__ counts,
+                                                   DevGlobal *__restrict__ G, const DevParams P)
+{
+    // window chunk j (16 bytes = rows 4q..4q+3 of tile (t, c), j = (c * 2 + t) * 4 + q) of lane l: s_win[j * 64 + l]
+    __shared__ uint4 s_win[16 * 64];
+    // step table: index raw | backdir << 8 -> next direction | code << 3, code = the smallest-offset background
+    // 4-neighbour the search passed over (0 none, 1 N, 2 W, 3 E, 4 S)
+    __shared__ uint8_t s_lut[2048];
+    const uint32_t *s_winw = reinterpret_cast<const uint32_t *>(s_win);
+    const int f = blockIdx.y;
+    const int lane = lane_id();
+    for (int e = lane; e < 2048; e += 64) {
+        const unsigned nb = raw_to_nb((unsigned)e & 0xffu);
+        const int sd = e >> 8;
+        const int start = (sd + 1) & 7;
+        const unsigned rot = ((nb | (nb << 8)) >> start) & 0xffu;
+        const int t = rot ? __ffs(rot) - 1 : 0;
+        unsigned seen = 0;
+        for (int q = 0; q < t; q++) seen |= 1u << ((start + q) & 7);
+        const int code = (seen & 4u) ? 1 : (seen & 16u) ? 2 : (seen & 1u) ? 3 : (seen & 64u) ? 4 : 0;
+        s_lut[e] = (uint8_t)(((start + t) & 7) | (code << 3));
+    }
+    __syncthreads();
+    unsigned n = (unsigned)counts[f].nsurv;
+    n = n < (unsigned)P.maxStarts ? n : (unsigned)P.maxStarts;
+    const unsigned ccap = (unsigned)P.maxContours, pcap = (unsigned)P.maxChunks;
+    if (blockIdx.x == 0 && lane == 0) counts[f].ncontours = (int)(n < ccap ? n : ccap);  // contour slot = survivor index
+    const int W = P.W, S = P.nscales, TC = P.TC, TR = P.TR;
+    const int W2 = W + 2;
+    const int nck = P.maxPerim / CK + 1;
+    const long long plane = (long long)TR * TC * MT_ROWS;
+    const uint2 *fin = surv + (long long)f * P.maxStarts;
+    uint4 *fco = contours + (long long)f * P.maxContours;
+    uint32_t *ftab = chunk_tab + (long long)f * P.maxContours * nck;
+    uint32_t *fpool = pool + (long long)f * P.maxChunks * CK;
+    enum { ST_IDLE = 0, ST_ACTIVE, ST_NEED, ST_LOADING, ST_FINAL };
+
+    for (unsigned r0 = blockIdx.x * WALK_RANGE; r0 < n; r0 += gridDim.x * WALK_RANGE) {
+        unsigned next = r0;                                               // wave-uniform: next survivor to hand out
+        const unsigned rend = r0 + WALK_RANGE < n ? r0 + WALK_RANGE : n;  // end of this wave's range
+        uint2 pre = next + lane < rend ? fin[next + lane] : make_uint2(0u, 0u);  // survivors next .. next + 63
+        // per-lane walker
+        int state = ST_IDLE;
+        uint2 st = make_uint2(0u, 0u);
+        const uint32_t *pl = masks;  // mask plane of the walker's scale
+        int x0 = 0, y0 = 0, hole = 0, key = 0;
+        unsigned slot = 0;
+        int cx = 0, cy = 0, pc = 0, sdir = 0, i1x = 0, i1y = 0, first = 0;
+        int count = 0, ok = 0, closed = 0;
+        int wtx = 0, wty = 0;  // window origin: tile column / tile row
+        int ndx = 1, ndy = 1;  // direction of travel used to place the next window
+        unsigned chunk = 0, spare = 0;
+        int spare_valid = 0;
+        unsigned arena_next = 0, arena_end = 0;  // wave-uniform
+        int iter = 0;
+        for (;;) {
+            const unsigned long long act = ballot64(state == ST_ACTIVE);
+            if (act == 0 || (iter & (WALK_CKPT - 1)) == 0) {
+                // ================= checkpoint =================
+                wait_vmcnt0();
+                if (state == ST_LOADING) state = ST_ACTIVE;
+                // ---- retire finished walkers
+                if (state == ST_FINAL) {
+                    const int accept = ok && closed && count >= P.minPerim && count <= P.maxPerim;
+                    if (slot < ccap) fco[slot] = make_uint4(st.x, st.y, accept ? (unsigned)count : 0u, (unsigned)key);
+                    state = ST_IDLE;
+                }
+                // ---- hand out new work to idle lanes (their records were prefetched at the last checkpoint)
+                int fresh = 0;
+                {
+                    const unsigned long long idle = ballot64(state == ST_IDLE);
+                    const int rank = __popcll(idle & ((1ull << lane) - 1ull));
+                    const unsigned gx = __shfl(pre.x, rank, WAVE), gy = __shfl(pre.y, rank, WAVE);
+                    if (state == ST_IDLE && next + (unsigned)rank < rend) {
+                        st = make_uint2(gx, gy);
+                        x0 = st.x & 0xffff;
+                        y0 = st.x >> 16;
+                        const int s = (st.y >> 16) & 0xff;
+                        hole = (st.y >> 24) & 1;
+                        pl = masks + ((long long)f * S + s) * plane;
+                        key = hole ? pidx(x0 + 1, y0, W) : pidx(x0, y0, W);
+                        count = 0;
+                        closed = 0;
+                        ok = 1;
+                        first = 1;
+                        cx = x0;
+                        cy = y0;
+                        pc = pidx(x0, y0, W);
+                        ndx = 1;
+                        ndy = 1;
+                        slot = next + (unsigned)rank;  // the contour slot is the survivor's index
+                        fresh = 1;
+                        state = ST_NEED;
+                    }
+                    const unsigned nidle = (unsigned)__popcll(idle);
+                    const unsigned nn = next + nidle < rend ? next + nidle : rend;
+                    if (nn != next) {
+                        next = nn;
+                        pre = next + lane < rend ? fin[next + lane] : make_uint2(0u, 0u);
+                    }
+                }
+                // ---- pool chunks from the wave's arena: two for a fresh walker (first + spare), one for every
+                //      walker that used up its spare
+                {
+                    const int want1 = state != ST_IDLE && !fresh && !spare_valid;
+                    const unsigned long long b1 = ballot64(want1), b2 = ballot64(fresh);
+                    const unsigned total = (unsigned)__popcll(b1) + 2u * (unsigned)__popcll(b2);
+                    if (total) {
+                        if (arena_next + total > arena_end) {
+                            unsigned base = 0;
+                            if (lane == 0) base = atomicAdd((unsigned *)&counts[f].npool, (unsigned)WALK_ARENA);
+                            arena_next = __builtin_amdgcn_readfirstlane(base);
+                            arena_end = arena_next + WALK_ARENA;
+                        }
+                        const unsigned long long lt = (1ull << lane) - 1ull;
+                        const unsigned mine = arena_next + (unsigned)__popcll(b1 & lt) + 2u * (unsigned)__popcll(b2 & lt);
+                        if (fresh) {
+                            chunk = mine;
+                            spare = mine + 1;
+                            spare_valid = 1;
+                        } else if (want1) {
+                            spare = mine;
+                            spare_valid = 1;
+                        }
+                        arena_next += total;
+                    }
+                }
+                // ---- window refills
+                if (state == ST_NEED) {
+                    // padded coordinates of the 3x3 neighbourhood: bits xb .. xb+2, rows cy .. cy+2
+                    const int xb = cx - 1 + MASK_PADW * 32;
+                    int tx = ndx >= 0 ? (xb >> 5) : ((xb + 2) >> 5) - 1;
+                    int ty = ndy >= 0 ? (cy >> 4) : ((cy + 2) >> 4) - 1;
+                    tx = tx < 0 ? 0 : (tx > TC - 2 ? TC - 2 : tx);
+                    ty = ty < 0 ? 0 : (ty > TR - 2 ? TR - 2 : ty);
+                    wtx = tx;
+                    wty = ty;
+                    const uint32_t *g00 = pl + ((long long)ty * TC + tx) * MT_ROWS;
+#pragma unroll
+                    for (int j = 0; j < 16; j++) {
+                        const int c = j >> 3, t = (j >> 2) & 1, q = j & 3;
+                        const uint32_t *src = g00 + ((long long)t * TC + c) * MT_ROWS + q * 4;
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                                         (__attribute__((address_space(3))) void *)(s_win + j * 64), 16, 0, 0);
+                    }
+                    state = ST_LOADING;
+                }
+                if (ballot64(state != ST_IDLE) == 0) break;  // range exhausted, everybody retired
+                iter = 1;
+                continue;
+            }
+            iter++;
+            if (state != ST_ACTIVE) continue;
+            // ================= one border-following step inside the window =================
+            unsigned raw;
+            {
+                const int xr = cx - 1 + MASK_PADW * 32 - wtx * 32;  // bit of x-1 in the 64-bit window row
+                const int rr = cy - wty * MT_ROWS;                  // window row of image row y-1
+                unsigned t3[3];
+#pragma unroll
+                for (int d = 0; d < 3; d++) {
+                    const int r = rr + d;
+                    const int idx = ((((r >> 4) & 1) * 4 + ((r >> 2) & 3)) * 64 + lane) * 4 + (r & 3);
+                    const uint32_t w0 = s_winw[idx], w1 = s_winw[idx + 8 * 64 * 4];
+                    const unsigned long long v = ((unsigned long long)w1 << 32) | w0;
+                    t3[d] = (unsigned)(v >> xr);
+                }
+                raw = (t3[0] & 7u) | ((t3[1] & 1u) << 3) | ((t3[1] & 4u) << 2) | ((t3[2] & 7u) << 5);
+            }
+            if (first) {
+                first = 0;
+                if (slot >= ccap) {
+                    atomicOr(&G->overflow, 2u);
+                    ok = 0;
+                    state = ST_FINAL;
+                    continue;
+                }
+                if (raw == 0) {
+                    // single pixel domain
+                    if (chunk < pcap) {
+                        ftab[(long long)slot * nck] = chunk;
+                        fpool[(long long)chunk * CK] = (uint32_t)x0 | ((uint32_t)y0 << 16);
+                    } else {
+                        atomicOr(&G->overflow, 8u);
+                        ok = 0;
+                    }
+                    count = 1;
+                    closed = 1;
+                    state = ST_FINAL;
+                    continue;
+                }
+                const unsigned nb = raw_to_nb(raw);
+                const int s_end = hole ? 0 : 4;
+                const unsigned nb2 = nb | (nb << 8);
+                const int c0 = (s_end - 1) & 7;
+                const unsigned win = (nb2 >> (c0 + 1)) & 0xffu;
+                const int t = 7 - (31 - __clz((int)win));
+                sdir = (c0 - t) & 7;
+                i1x = x0 + dir_dx(sdir);
+                i1y = y0 + dir_dy(sdir);
+                if (!hole && pidx(i1x, i1y, W) < key) {
+                    ok = 0;
+                    state = ST_FINAL;
+                    continue;
+                }
+            }
+            {
+                const unsigned e = s_lut[raw | ((unsigned)sdir << 8)];
+                const int sn = e & 7, code = e >> 3;
+                if (hole && code) {
+                    // background pixels examined in the 4-directions belong to this border's hole region
+                    const int off = code == 1 ? -W2 : code == 2 ? -1 : code == 3 ? 1 : W2;
+                    if (pc + off < key) ok = 0;
+                }
+                if (ok) {
+                    const int off = count & (CK - 1);
+                    if (off == 0) {
+                        if (count) {
+                            chunk = spare;  // handed out at a checkpoint since the last chunk started
+                            spare_valid = 0;
+                        }
+                        if (chunk < pcap) {
+                            ftab[(long long)slot * nck + (count >> 6)] = chunk;
+                        } else {
+                            atomicOr(&G->overflow, 8u);
+                            ok = 0;
+                        }
+                    }
+                    if (ok) fpool[(long long)chunk * CK + off] = (uint32_t)cx | ((uint32_t)cy << 16);
+                }
+                count++;
+                const int dx = dir_dx(sn), dy = dir_dy(sn);
+                const int nx = cx + dx, ny = cy + dy;
+                if (!ok || count > P.maxPerim) {
+                    ok = 0;
+                    state = ST_FINAL;
+                    continue;
+                }
+                if (nx == x0 && ny == y0 && cx == i1x && cy == i1y) {
+                    closed = 1;
+                    state = ST_FINAL;
+                    continue;
+                }
+                ndx = dx;
+                ndy = dy;
+                cx = nx;
+                cy = ny;
+                pc += dy * W2 + dx;
+                if (!hole && pc < key) {
+                    ok = 0;
+                    state = ST_FINAL;
+                    continue;
+                }
+                sdir = (sn + 4) & 7;
+                // still inside the window?  bits xb..xb+2 in [wtx*32, wtx*32+64), padded rows cy..cy+2 in [wty*16, wty*16+32)
+                const int xr = cx - 1 + MASK_PADW * 32 - wtx * 32, rr = cy - wty * MT_ROWS;
+                if ((unsigned)xr > 61u || (unsigned)rr > 29u) state = ST_NEED;
+            }
+        }
+    }
+}
+
 // points per contour the first (short-LDS) launch of k_approx accepts
 #define K4_SHORT_PTS 2048
 #define K4_SHORT_STACK 256

@@ -82,7 +82,8 @@ class FidError(RuntimeError):
 
 
 def lib_path() -> str:
-    return _build.LIB
+    # FID_LIB lets a developer point at an instrumented build (e.g. -DFID_DEBUG_STATS); it is still libfid_amd
+    return os.environ.get("FID_LIB") or _build.LIB
 
 
 def load():

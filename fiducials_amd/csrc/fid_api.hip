@@ -268,7 +268,7 @@ fid_status run_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H, int
     }
     mark(c, ST_STARTS + 1);
     // ---- K3: probe every start, then walk the survivors to the end
-    if ((size_t)F * P.maxContours * (P.maxPerim / CK + 1) > c->ckpts_elems) {
+    if ((size_t)F * P.maxContours * chunk_tab_pitch(P) > c->ckpts_elems) {
         c->last_error = "chunk table too small for this image size / maxMarkerPerimeterRate";
         return FID_E_UNSUPPORTED;
     }
@@ -335,6 +335,14 @@ fid_status run_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H, int
             if (c->ev_valid[i + 1] && c->ev_valid[prev]) (void)hipEventElapsedTime(&c->stage_ms[i], c->ev[prev], c->ev[i + 1]);
         }
     }
+#ifdef FID_DEBUG_STATS
+    {
+        const unsigned long long *d = c->h_global->dbg;
+        fprintf(stderr, "walk stats: ranges %llu iters %llu ckpts %llu (forced %llu) active-lanes/iter %.1f cyc/range %.0f ckpt-cyc/range %.0f wait-cyc/range %.0f\n",
+                d[7], d[0], d[1], d[5], d[0] ? (double)d[2] / d[0] : 0., d[7] ? (double)d[6] / d[7] : 0., d[7] ? (double)d[3] / d[7] : 0.,
+                d[7] ? (double)d[4] / d[7] : 0.);
+    }
+#endif
     fid_status rc = FID_OK;
     if (c->h_global->overflow) {
         c->last_error = "internal capacity exceeded (starts/contours/stack/points): raise fid_limits";
@@ -479,7 +487,7 @@ fid_status fid_create(const fid_params *params, const fid_dict *dict, const fid_
     TRY(dalloc(c, &c->d_contours, F * L.max_contours_per_frame));
     {
         int maxdim = L.max_width > L.max_height ? L.max_width : L.max_height;
-        size_t nck = (size_t)(params->maxMarkerPerimeterRate * maxdim) / 64 + 2;
+        size_t nck = (size_t)(params->maxMarkerPerimeterRate * maxdim) / 64 + 4;
         c->ckpts_elems = F * L.max_contours_per_frame * nck;
         TRY(dalloc(c, &c->d_ckpts, c->ckpts_elems));
     }

@@ -549,6 +549,8 @@ __device__ __forceinline__ int pidx(int x, int y, int W) { return (y + 1) * (W +
 // Contour points are stored in chunks of CK points (x | y << 16) taken from a per-frame pool while the
 // border is followed; chunk_tab[slot][k] names the chunk that holds points [CK*k, CK*k + CK) of a contour.
 #define CK 64
+// entries per contour in chunk_tab: the windowed walk may run WALK_CKPT points past maxPerimeterPixels before it notices
+__device__ __host__ inline int chunk_tab_pitch(const DevParams &P) { return P.maxPerim / CK + 3; }
 
 // K3: one lane per start.  Walks the border exactly as icvFetchContour does (contours.cpp), counting points.
 // A start is reported only if it is the canonical one of its border (the pixel where cvFindNextContour's
@@ -578,7 +580,7 @@ __global__ __launch_bounds__(256) void k_walk(const uint32_t *__restrict__ masks
     n = n < (unsigned)P.maxStarts ? n : (unsigned)P.maxStarts;
     const unsigned ccap = (unsigned)P.maxContours, pcap = (unsigned)P.maxChunks;
     const int W = P.W, H = P.H, S = P.nscales;
-    const int nck = P.maxPerim / CK + 1;
+    const int nck = chunk_tab_pitch(P);
     const uint2 *fin = in_list + (long long)f * P.maxStarts;
     uint2 *fsv = surv + (long long)f * P.maxStarts;
     uint4 *fco = contours + (long long)f * P.maxContours;
@@ -758,6 +760,24 @@ __device__ __forceinline__ unsigned raw_to_nb(unsigned raw)
            (raw & 0xe0u);
 }
 
+// raw 3x3 neighbourhood byte of pixel (cx, cy) read from lane `lane`'s window (origin: pixel column wx0 of
+// bit 0, padded row wy0 of window row 0)
+__device__ __forceinline__ unsigned win_raw(const uint32_t *s_winw, int lane4, int cx, int cy, int wx0, int wy0)
+{
+    const int xr = cx + (MASK_PADW * 32 - 1) - wx0;  // bit of x-1 in the 64-bit window row
+    const int rr = cy - wy0;                         // window row of image row y-1
+    unsigned t3[3];
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+        const int r = rr + d;
+        const int idx = ((r & ~3) << 6) + (r & 3) + lane4;  // chunk (r >> 2), lane, element (r & 3)
+        const uint32_t w0 = s_winw[idx], w1 = s_winw[idx + 8 * 64 * 4];
+        const unsigned long long v = ((unsigned long long)w1 << 32) | w0;
+        t3[d] = (unsigned)(v >> xr);
+    }
+    return (t3[0] & 7u) | ((t3[1] & 1u) << 3) | ((t3[1] & 4u) << 2) | ((t3[2] & 7u) << 5);
+}
+
 __global__ __launch_bounds__(64) void k_walk_full(const uint32_t *__restrict__ masks, const uint2 *__restrict__ surv,
                                                    uint4 *__restrict__ contours, uint32_t *__restrict__ chunk_tab,
                                                    uint32_t *__restrict__ pool, DevCounts *__restrict__ counts,
@@ -766,11 +786,12 @@ __global__ __launch_bounds__(64) void k_walk_full(const uint32_t *__restrict__ m
     // window chunk j (16 bytes = rows 4q..4q+3 of tile (t, c), j = (c * 2 + t) * 4 + q) of lane l: s_win[j * 64 + l]
     __shared__ uint4 s_win[16 * 64];
     // step table: index raw | backdir << 8 -> next direction | code << 3, code = the smallest-offset background
-    // 4-neighbour the search passed over (0 none, 1 N, 2 W, 3 E, 4 S)
+    // 4-neighbour the search passed over (0 none, else 4 | positive << 1 | whole-row)
     __shared__ uint8_t s_lut[2048];
     const uint32_t *s_winw = reinterpret_cast<const uint32_t *>(s_win);
     const int f = blockIdx.y;
     const int lane = lane_id();
+    const int lane4 = lane * 4;
     for (int e = lane; e < 2048; e += 64) {
         const unsigned nb = raw_to_nb((unsigned)e & 0xffu);
         const int sd = e >> 8;
@@ -779,7 +800,9 @@ __global__ __launch_bounds__(64) void k_walk_full(const uint32_t *__restrict__ m
         const int t = rot ? __ffs(rot) - 1 : 0;
         unsigned seen = 0;
         for (int q = 0; q < t; q++) seen |= 1u << ((start + q) & 7);
-        const int code = (seen & 4u) ? 1 : (seen & 16u) ? 2 : (seen & 1u) ? 3 : (seen & 64u) ? 4 : 0;
+        // code: bit 2 = some background 4-neighbour was examined, bit 1 = its raster offset is positive,
+        // bit 0 = the offset is a whole row (N / S) rather than one pixel (W / E); the smallest offset wins
+        const int code = (seen & 4u) ? 5 : (seen & 16u) ? 4 : (seen & 1u) ? 6 : (seen & 64u) ? 7 : 0;
         s_lut[e] = (uint8_t)(((start + t) & 7) | (code << 3));
     }
     __syncthreads();
@@ -789,7 +812,7 @@ __global__ __launch_bounds__(64) void k_walk_full(const uint32_t *__restrict__ m
     if (blockIdx.x == 0 && lane == 0) counts[f].ncontours = (int)(n < ccap ? n : ccap);  // contour slot = survivor index
     const int W = P.W, S = P.nscales, TC = P.TC, TR = P.TR;
     const int W2 = W + 2;
-    const int nck = P.maxPerim / CK + 1;
+    const int nck = chunk_tab_pitch(P);
     const long long plane = (long long)TR * TC * MT_ROWS;
     const uint2 *fin = surv + (long long)f * P.maxStarts;
     uint4 *fco = contours + (long long)f * P.maxContours;
@@ -809,31 +832,76 @@ __global__ __launch_bounds__(64) void k_walk_full(const uint32_t *__restrict__ m
         unsigned slot = 0;
         int cx = 0, cy = 0, pc = 0, sdir = 0, i1x = 0, i1y = 0, first = 0;
         int count = 0, ok = 0, closed = 0;
-        int wtx = 0, wty = 0;  // window origin: tile column / tile row
+        int wx0 = 0, wy0 = 0;  // window origin: pixel column of bit 0 / padded row of window row 0
         int ndx = 1, ndy = 1;  // direction of travel used to place the next window
-        unsigned chunk = 0, spare = 0;
-        int spare_valid = 0;
+        unsigned chunkA = 0, chunkB = 0;  // pool chunks of the even / odd 64-point blocks around `count`
+        int kreg = 0;                     // highest block index that has a chunk
+        unsigned ovf = 0;
         unsigned arena_next = 0, arena_end = 0;  // wave-uniform
-        int iter = 0;
+#ifdef FID_DEBUG_STATS
+        unsigned long long d_iters = 0, d_ckpts = 0, d_active = 0, d_ckcyc = 0, d_waitcyc = 0, d_forced = 0;
+        const unsigned long long d_t0 = __builtin_readcyclecounter();
+#endif
         for (;;) {
-            const unsigned long long act = ballot64(state == ST_ACTIVE);
-            if (act == 0 || (iter & (WALK_CKPT - 1)) == 0) {
-                // ================= checkpoint =================
-                wait_vmcnt0();
-                if (state == ST_LOADING) state = ST_ACTIVE;
-                // ---- retire finished walkers
-                if (state == ST_FINAL) {
-                    const int accept = ok && closed && count >= P.minPerim && count <= P.maxPerim;
-                    if (slot < ccap) fco[slot] = make_uint4(st.x, st.y, accept ? (unsigned)count : 0u, (unsigned)key);
-                    state = ST_IDLE;
+            // ================= checkpoint =================
+#ifdef FID_DEBUG_STATS
+            const unsigned long long d_c0 = __builtin_readcyclecounter();
+            d_ckpts++;
+#endif
+            wait_vmcnt0();
+#ifdef FID_DEBUG_STATS
+            d_waitcyc += __builtin_readcyclecounter() - d_c0;
+#endif
+            if (state == ST_LOADING) {
+                state = ST_ACTIVE;
+                if (first) {
+                    // the walker's first look at its start pixel: single-pixel domain, initial direction
+                    //   do { s = (s - 1) & 7; } while (*i1 == 0 && s != s_end)  == first foreground clockwise from s_end - 1
+                    first = 0;
+                    const unsigned raw = win_raw(s_winw, lane4, cx, cy, wx0, wy0);
+                    if (raw == 0) {
+                        fpool[chunkA * CK] = (uint32_t)x0 | ((uint32_t)y0 << 16);
+                        count = 1;
+                        closed = 1;
+                        state = ST_FINAL;
+                    } else {
+                        const unsigned nb = raw_to_nb(raw);
+                        const int s_end = hole ? 0 : 4;
+                        const unsigned nb2 = nb | (nb << 8);
+                        const int c0 = (s_end - 1) & 7;
+                        const unsigned win = (nb2 >> (c0 + 1)) & 0xffu;
+                        const int t = 7 - (31 - __clz((int)win));
+                        sdir = (c0 - t) & 7;
+                        i1x = x0 + dir_dx(sdir);
+                        i1y = y0 + dir_dy(sdir);
+                        if (!hole && pidx(i1x, i1y, W) < key) {
+                            ok = 0;
+                            state = ST_FINAL;
+                        }
+                    }
                 }
-                // ---- hand out new work to idle lanes (their records were prefetched at the last checkpoint)
-                int fresh = 0;
-                {
-                    const unsigned long long idle = ballot64(state == ST_IDLE);
-                    const int rank = __popcll(idle & ((1ull << lane) - 1ull));
-                    const unsigned gx = __shfl(pre.x, rank, WAVE), gy = __shfl(pre.y, rank, WAVE);
-                    if (state == ST_IDLE && next + (unsigned)rank < rend) {
+            }
+            if (state == ST_ACTIVE || state == ST_NEED) {
+                if (count > P.maxPerim) {  // checked here, not per step: a walk overshoots by at most WALK_CKPT points
+                    ok = 0;
+                    state = ST_FINAL;
+                }
+            }
+            // ---- retire finished walkers
+            if (state == ST_FINAL) {
+                const int accept = ok && closed && count >= P.minPerim && count <= P.maxPerim;
+                fco[slot] = make_uint4(st.x, st.y, accept ? (unsigned)count : 0u, (unsigned)key);
+                state = ST_IDLE;
+            }
+            // ---- hand out new work to idle lanes (their records were prefetched at the last checkpoint)
+            int fresh = 0;
+            {
+                const unsigned long long idle = ballot64(state == ST_IDLE);
+                const int rank = __popcll(idle & ((1ull << lane) - 1ull));
+                const unsigned gx = __shfl(pre.x, rank, WAVE), gy = __shfl(pre.y, rank, WAVE);
+                if (state == ST_IDLE && next + (unsigned)rank < rend) {
+                    slot = next + (unsigned)rank;  // the contour slot is the survivor's index
+                    if (slot < ccap) {
                         st = make_uint2(gx, gy);
                         x0 = st.x & 0xffff;
                         y0 = st.x >> 16;
@@ -850,175 +918,135 @@ __global__ __launch_bounds__(64) void k_walk_full(const uint32_t *__restrict__ m
                         pc = pidx(x0, y0, W);
                         ndx = 1;
                         ndy = 1;
-                        slot = next + (unsigned)rank;  // the contour slot is the survivor's index
+                        kreg = 1;
                         fresh = 1;
                         state = ST_NEED;
-                    }
-                    const unsigned nidle = (unsigned)__popcll(idle);
-                    const unsigned nn = next + nidle < rend ? next + nidle : rend;
-                    if (nn != next) {
-                        next = nn;
-                        pre = next + lane < rend ? fin[next + lane] : make_uint2(0u, 0u);
-                    }
-                }
-                // ---- pool chunks from the wave's arena: two for a fresh walker (first + spare), one for every
-                //      walker that used up its spare
-                {
-                    const int want1 = state != ST_IDLE && !fresh && !spare_valid;
-                    const unsigned long long b1 = ballot64(want1), b2 = ballot64(fresh);
-                    const unsigned total = (unsigned)__popcll(b1) + 2u * (unsigned)__popcll(b2);
-                    if (total) {
-                        if (arena_next + total > arena_end) {
-                            unsigned base = 0;
-                            if (lane == 0) base = atomicAdd((unsigned *)&counts[f].npool, (unsigned)WALK_ARENA);
-                            arena_next = __builtin_amdgcn_readfirstlane(base);
-                            arena_end = arena_next + WALK_ARENA;
-                        }
-                        const unsigned long long lt = (1ull << lane) - 1ull;
-                        const unsigned mine = arena_next + (unsigned)__popcll(b1 & lt) + 2u * (unsigned)__popcll(b2 & lt);
-                        if (fresh) {
-                            chunk = mine;
-                            spare = mine + 1;
-                            spare_valid = 1;
-                        } else if (want1) {
-                            spare = mine;
-                            spare_valid = 1;
-                        }
-                        arena_next += total;
-                    }
-                }
-                // ---- window refills
-                if (state == ST_NEED) {
-                    // padded coordinates of the 3x3 neighbourhood: bits xb .. xb+2, rows cy .. cy+2
-                    const int xb = cx - 1 + MASK_PADW * 32;
-                    int tx = ndx >= 0 ? (xb >> 5) : ((xb + 2) >> 5) - 1;
-                    int ty = ndy >= 0 ? (cy >> 4) : ((cy + 2) >> 4) - 1;
-                    tx = tx < 0 ? 0 : (tx > TC - 2 ? TC - 2 : tx);
-                    ty = ty < 0 ? 0 : (ty > TR - 2 ? TR - 2 : ty);
-                    wtx = tx;
-                    wty = ty;
-                    const uint32_t *g00 = pl + ((long long)ty * TC + tx) * MT_ROWS;
-#pragma unroll
-                    for (int j = 0; j < 16; j++) {
-                        const int c = j >> 3, t = (j >> 2) & 1, q = j & 3;
-                        const uint32_t *src = g00 + ((long long)t * TC + c) * MT_ROWS + q * 4;
-                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                                         (__attribute__((address_space(3))) void *)(s_win + j * 64), 16, 0, 0);
-                    }
-                    state = ST_LOADING;
-                }
-                if (ballot64(state != ST_IDLE) == 0) break;  // range exhausted, everybody retired
-                iter = 1;
-                continue;
-            }
-            iter++;
-            if (state != ST_ACTIVE) continue;
-            // ================= one border-following step inside the window =================
-            unsigned raw;
-            {
-                const int xr = cx - 1 + MASK_PADW * 32 - wtx * 32;  // bit of x-1 in the 64-bit window row
-                const int rr = cy - wty * MT_ROWS;                  // window row of image row y-1
-                unsigned t3[3];
-#pragma unroll
-                for (int d = 0; d < 3; d++) {
-                    const int r = rr + d;
-                    const int idx = ((((r >> 4) & 1) * 4 + ((r >> 2) & 3)) * 64 + lane) * 4 + (r & 3);
-                    const uint32_t w0 = s_winw[idx], w1 = s_winw[idx + 8 * 64 * 4];
-                    const unsigned long long v = ((unsigned long long)w1 << 32) | w0;
-                    t3[d] = (unsigned)(v >> xr);
-                }
-                raw = (t3[0] & 7u) | ((t3[1] & 1u) << 3) | ((t3[1] & 4u) << 2) | ((t3[2] & 7u) << 5);
-            }
-            if (first) {
-                first = 0;
-                if (slot >= ccap) {
-                    atomicOr(&G->overflow, 2u);
-                    ok = 0;
-                    state = ST_FINAL;
-                    continue;
-                }
-                if (raw == 0) {
-                    // single pixel domain
-                    if (chunk < pcap) {
-                        ftab[(long long)slot * nck] = chunk;
-                        fpool[(long long)chunk * CK] = (uint32_t)x0 | ((uint32_t)y0 << 16);
                     } else {
-                        atomicOr(&G->overflow, 8u);
-                        ok = 0;
+                        ovf |= 2u;
                     }
-                    count = 1;
-                    closed = 1;
-                    state = ST_FINAL;
-                    continue;
                 }
-                const unsigned nb = raw_to_nb(raw);
-                const int s_end = hole ? 0 : 4;
-                const unsigned nb2 = nb | (nb << 8);
-                const int c0 = (s_end - 1) & 7;
-                const unsigned win = (nb2 >> (c0 + 1)) & 0xffu;
-                const int t = 7 - (31 - __clz((int)win));
-                sdir = (c0 - t) & 7;
-                i1x = x0 + dir_dx(sdir);
-                i1y = y0 + dir_dy(sdir);
-                if (!hole && pidx(i1x, i1y, W) < key) {
-                    ok = 0;
-                    state = ST_FINAL;
-                    continue;
+                const unsigned nidle = (unsigned)__popcll(idle);
+                const unsigned nn = next + nidle < rend ? next + nidle : rend;
+                if (nn != next) {
+                    next = nn;
+                    pre = next + lane < rend ? fin[next + lane] : make_uint2(0u, 0u);
                 }
             }
+            // ---- pool chunks from the wave's arena: two for a fresh walker (blocks 0 and 1), one for every walker
+            //      that has entered its last chunked block (count >> 6 == kreg)
             {
-                const unsigned e = s_lut[raw | ((unsigned)sdir << 8)];
-                const int sn = e & 7, code = e >> 3;
-                if (hole && code) {
-                    // background pixels examined in the 4-directions belong to this border's hole region
-                    const int off = code == 1 ? -W2 : code == 2 ? -1 : code == 3 ? 1 : W2;
-                    if (pc + off < key) ok = 0;
-                }
-                if (ok) {
-                    const int off = count & (CK - 1);
-                    if (off == 0) {
-                        if (count) {
-                            chunk = spare;  // handed out at a checkpoint since the last chunk started
-                            spare_valid = 0;
-                        }
-                        if (chunk < pcap) {
-                            ftab[(long long)slot * nck + (count >> 6)] = chunk;
-                        } else {
-                            atomicOr(&G->overflow, 8u);
+                const int want1 = !fresh && (state == ST_ACTIVE || state == ST_NEED) && (count >> 6) == kreg;
+                const unsigned long long b1 = ballot64(want1), b2 = ballot64(fresh);
+                const unsigned total = (unsigned)__popcll(b1) + 2u * (unsigned)__popcll(b2);
+                if (total) {
+                    if (arena_next + total > arena_end) {
+                        unsigned base = 0;
+                        if (lane == 0) base = atomicAdd((unsigned *)&counts[f].npool, (unsigned)WALK_ARENA);
+                        arena_next = __builtin_amdgcn_readfirstlane(base);
+                        arena_end = arena_next + WALK_ARENA;
+                    }
+                    const unsigned long long lt = (1ull << lane) - 1ull;
+                    const unsigned mine = arena_next + (unsigned)__popcll(b1 & lt) + 2u * (unsigned)__popcll(b2 & lt);
+                    arena_next += total;
+                    if (fresh || want1) {
+                        if (mine + 1 >= pcap) {
+                            ovf |= 8u;
                             ok = 0;
+                            fco[slot] = make_uint4(st.x, st.y, 0u, (unsigned)key);
+                            state = ST_IDLE;
+                        } else if (fresh) {
+                            chunkA = mine;
+                            chunkB = mine + 1;
+                            ftab[(long long)slot * nck] = chunkA;
+                            ftab[(long long)slot * nck + 1] = chunkB;
+                        } else {
+                            kreg++;
+                            if (kreg & 1) chunkB = mine;
+                            else chunkA = mine;
+                            ftab[(long long)slot * nck + kreg] = mine;
                         }
                     }
-                    if (ok) fpool[(long long)chunk * CK + off] = (uint32_t)cx | ((uint32_t)cy << 16);
                 }
-                count++;
-                const int dx = dir_dx(sn), dy = dir_dy(sn);
-                const int nx = cx + dx, ny = cy + dy;
-                if (!ok || count > P.maxPerim) {
-                    ok = 0;
-                    state = ST_FINAL;
-                    continue;
+            }
+            // ---- window refills
+            if (state == ST_NEED) {
+                // padded coordinates of the 3x3 neighbourhood: bits xb .. xb+2, rows cy .. cy+2
+                const int xb = cx - 1 + MASK_PADW * 32;
+                int tx = ndx >= 0 ? (xb >> 5) : ((xb + 2) >> 5) - 1;
+                int ty = ndy >= 0 ? (cy >> 4) : ((cy + 2) >> 4) - 1;
+                tx = tx < 0 ? 0 : (tx > TC - 2 ? TC - 2 : tx);
+                ty = ty < 0 ? 0 : (ty > TR - 2 ? TR - 2 : ty);
+                wx0 = tx * 32;
+                wy0 = ty * MT_ROWS;
+                const uint32_t *g00 = pl + ((long long)ty * TC + tx) * MT_ROWS;
+#pragma unroll
+                for (int j = 0; j < 16; j++) {
+                    const int c = j >> 3, t = (j >> 2) & 1, q = j & 3;
+                    const uint32_t *src = g00 + ((long long)t * TC + c) * MT_ROWS + q * 4;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                                     (__attribute__((address_space(3))) void *)(s_win + j * 64), 16, 0, 0);
                 }
-                if (nx == x0 && ny == y0 && cx == i1x && cy == i1y) {
-                    closed = 1;
-                    state = ST_FINAL;
-                    continue;
+                state = ST_LOADING;
+            }
+#ifdef FID_DEBUG_STATS
+            d_ckcyc += __builtin_readcyclecounter() - d_c0;
+#endif
+            if (ballot64(state != ST_IDLE) == 0) break;  // range exhausted, everybody retired
+            // ================= up to WALK_CKPT border-following steps inside the windows =================
+            for (int it = 0; it < WALK_CKPT; it++) {
+                const unsigned long long act = ballot64(state == ST_ACTIVE);
+                if (act == 0) {
+#ifdef FID_DEBUG_STATS
+                    d_forced += it == 0;
+#endif
+                    break;
                 }
-                ndx = dx;
-                ndy = dy;
-                cx = nx;
-                cy = ny;
-                pc += dy * W2 + dx;
-                if (!hole && pc < key) {
-                    ok = 0;
-                    state = ST_FINAL;
-                    continue;
+#ifdef FID_DEBUG_STATS
+                d_iters++;
+                d_active += __popcll(act);
+#endif
+                if (state == ST_ACTIVE) {
+                    const unsigned raw = win_raw(s_winw, lane4, cx, cy, wx0, wy0);
+                    const unsigned e = s_lut[raw | ((unsigned)sdir << 8)];
+                    const int sn = e & 7, code = e >> 3;
+                    // background pixels examined in the 4-directions belong to this border's hole region
+                    const int hmag = (code & 1) ? W2 : 1;
+                    const int hoff = (code & 2) ? hmag : -hmag;
+                    int bad = hole && code && (pc + hoff < key);
+                    if (!bad) fpool[((count & CK ? chunkB : chunkA) << 6) + (unsigned)(count & (CK - 1))] = (uint32_t)cx | ((uint32_t)cy << 16);
+                    count++;
+                    const int dx = dir_dx(sn), dy = dir_dy(sn);
+                    const int nx = cx + dx, ny = cy + dy;
+                    const int cl = !bad && nx == x0 && ny == y0 && cx == i1x && cy == i1y;
+                    cx = nx;
+                    cy = ny;
+                    pc += __mul24(dy, W2) + dx;
+                    bad |= !cl && !hole && pc < key;
+                    sdir = (sn + 4) & 7;
+                    ndx = dx;
+                    ndy = dy;
+                    // still inside the window?  bits of x-1..x+1 in [0, 64), padded rows cy..cy+2 in [0, 32)
+                    const unsigned xr = (unsigned)(cx + (MASK_PADW * 32 - 1) - wx0), rr = (unsigned)(cy - wy0);
+                    const int outside = xr > 61u || rr > 29u;
+                    closed = cl;
+                    ok = !bad;
+                    state = (bad || cl) ? ST_FINAL : outside ? ST_NEED : ST_ACTIVE;
                 }
-                sdir = (sn + 4) & 7;
-                // still inside the window?  bits xb..xb+2 in [wtx*32, wtx*32+64), padded rows cy..cy+2 in [wty*16, wty*16+32)
-                const int xr = cx - 1 + MASK_PADW * 32 - wtx * 32, rr = cy - wty * MT_ROWS;
-                if ((unsigned)xr > 61u || (unsigned)rr > 29u) state = ST_NEED;
             }
         }
+        if (ovf) atomicOr(&G->overflow, ovf);
+#ifdef FID_DEBUG_STATS
+        if (lane == 0) {
+            atomicAdd(&G->dbg[0], d_iters);
+            atomicAdd(&G->dbg[1], d_ckpts);
+            atomicAdd(&G->dbg[2], d_active);
+            atomicAdd(&G->dbg[3], d_ckcyc);
+            atomicAdd(&G->dbg[4], d_waitcyc);
+            atomicAdd(&G->dbg[5], d_forced);
+            atomicAdd(&G->dbg[6], (unsigned long long)(__builtin_readcyclecounter() - d_t0));
+            atomicAdd(&G->dbg[7], 1ull);
+        }
+#endif
     }
 }
 
@@ -1052,7 +1080,7 @@ __global__ __launch_bounds__(64) void k_approx(uint4 *__restrict__ contours, con
     unsigned n = (unsigned)counts[f].ncontours;
     n = n < (unsigned)P.maxContours ? n : (unsigned)P.maxContours;
     const int W = P.W, H = P.H;
-    const int nck = P.maxPerim / CK + 1;
+    const int nck = chunk_tab_pitch(P);
     uint4 *fco = contours + (long long)f * P.maxContours;
     const uint32_t *ftab = chunk_tab + (long long)f * P.maxContours * nck;
     const uint32_t *fpool = pool + (long long)f * P.maxChunks * CK;

@@ -40,7 +40,7 @@ struct fid_ctx {
     uint2 *d_starts = nullptr, *d_surv = nullptr;
     uint32_t *d_pool = nullptr;
     int max_chunks = 0;
-    int walk_blocks = 24;  // one-wave workgroups per frame in the full walk pass
+    int walk_blocks = 0;  // one-wave workgroups per frame in the full walk pass (0 = automatic)
     uint4 *d_contours = nullptr;
     uint32_t *d_ckpts = nullptr;
     size_t ckpts_elems = 0;
@@ -275,7 +275,10 @@ fid_status run_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H, int
     hipLaunchKernelGGL(k_walk<true>, dim3(64, F), dim3(256), 0, st, c->d_masks, c->d_starts, c->d_surv, c->d_contours, c->d_ckpts,
                        c->d_pool, c->d_counts, c->d_global, P);
     mark(c, ST_PROBE + 1);
-    hipLaunchKernelGGL(k_walk_full, dim3(c->walk_blocks, F), dim3(64), 0, st, c->d_masks, c->d_surv, c->d_contours, c->d_ckpts,
+    // persistent one-wave workgroups pulling survivors from a per-frame queue: about one full residency of the chip
+    int wb = c->walk_blocks > 0 ? c->walk_blocks : (2048 + F - 1) / F;
+    wb = wb < 8 ? 8 : (wb > 64 ? 64 : wb);
+    hipLaunchKernelGGL(k_walk_full, dim3(wb, F), dim3(64), 0, st, c->d_masks, c->d_surv, c->d_contours, c->d_ckpts,
                        c->d_pool, c->d_counts, c->d_global, P);
     mark(c, ST_WALK + 1);
     // ---- K4: short contours with a small LDS footprint first, then the long / flagged ones

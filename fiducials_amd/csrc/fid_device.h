@@ -78,7 +78,8 @@ struct DevCounts {
     int ncontours;  // contour slots handed out by the full walk pass (dropped walks leave count == 0)
     int nsurv;      // starts that survived the probe pass
     int npool;      // point chunks handed out by the full walk pass
-    int pad[3];
+    int nwalk;      // survivors handed to walker waves so far (work queue head of the full pass)
+    int pad[2];
 };
 
 // global counters

@@ -745,8 +745,8 @@ __global__ __launch_bounds__(256) void k_walk(const uint32_t *__restrict__ masks
 // which background 4-neighbours the step examined (the hole-border canonical test).
 // The backward cursor of the probe pass is not needed here: it only ever rejects, and the forward cursor
 // visits every pixel of the border.
-#define WALK_CKPT 8
-#define WALK_RANGE 256  // survivors per wave work range
+#define WALK_CKPT 4
+#define WALK_GRAB 64    // survivors a wave takes from the frame's work queue per atomic
 #define WALK_ARENA 256  // pool chunks a wave takes per atomic
 
 __device__ __forceinline__ void wait_vmcnt0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
@@ -820,10 +820,11 @@ __global__ __launch_bounds__(64) void k_walk_full(const uint32_t *__restrict__ m
     uint32_t *fpool = pool + (long long)f * P.maxChunks * CK;
     enum { ST_IDLE = 0, ST_ACTIVE, ST_NEED, ST_LOADING, ST_FINAL };
 
-    for (unsigned r0 = blockIdx.x * WALK_RANGE; r0 < n; r0 += gridDim.x * WALK_RANGE) {
-        unsigned next = r0;                                               // wave-uniform: next survivor to hand out
-        const unsigned rend = r0 + WALK_RANGE < n ? r0 + WALK_RANGE : n;  // end of this wave's range
-        uint2 pre = next + lane < rend ? fin[next + lane] : make_uint2(0u, 0u);  // survivors next .. next + 63
+    {
+        // the wave's current batch of the frame's survivor queue: [next, rend), records of batch base .. base + 63 in `pre`
+        unsigned next = 0, rend = 0, pre_base = 0;  // wave-uniform
+        int exhausted = 0, pre_ready = 0;           // wave-uniform
+        uint2 pre = make_uint2(0u, 0u);
         // per-lane walker
         int state = ST_IDLE;
         uint2 st = make_uint2(0u, 0u);
@@ -852,6 +853,7 @@ __global__ __launch_bounds__(64) void k_walk_full(const uint32_t *__restrict__ m
 #ifdef FID_DEBUG_STATS
             d_waitcyc += __builtin_readcyclecounter() - d_c0;
 #endif
+            if (next < rend) pre_ready = 1;  // the batch's records were requested at the previous checkpoint
             if (state == ST_LOADING) {
                 state = ST_ACTIVE;
                 if (first) {
@@ -881,11 +883,10 @@ __global__ __launch_bounds__(64) void k_walk_full(const uint32_t *__restrict__ m
                     }
                 }
             }
-            if (state == ST_ACTIVE || state == ST_NEED) {
-                if (count > P.maxPerim) {  // checked here, not per step: a walk overshoots by at most WALK_CKPT points
-                    ok = 0;
-                    state = ST_FINAL;
-                }
+            if ((state == ST_ACTIVE || state == ST_NEED) && count > P.maxPerim) {
+                // checked here, not per step: a walk overshoots by at most WALK_CKPT points
+                ok = 0;
+                state = ST_FINAL;
             }
             // ---- retire finished walkers
             if (state == ST_FINAL) {
@@ -893,43 +894,55 @@ __global__ __launch_bounds__(64) void k_walk_full(const uint32_t *__restrict__ m
                 fco[slot] = make_uint4(st.x, st.y, accept ? (unsigned)count : 0u, (unsigned)key);
                 state = ST_IDLE;
             }
-            // ---- hand out new work to idle lanes (their records were prefetched at the last checkpoint)
+            // ---- hand out new work to idle lanes
             int fresh = 0;
-            {
-                const unsigned long long idle = ballot64(state == ST_IDLE);
-                const int rank = __popcll(idle & ((1ull << lane) - 1ull));
-                const unsigned gx = __shfl(pre.x, rank, WAVE), gy = __shfl(pre.y, rank, WAVE);
-                if (state == ST_IDLE && next + (unsigned)rank < rend) {
-                    slot = next + (unsigned)rank;  // the contour slot is the survivor's index
-                    if (slot < ccap) {
-                        st = make_uint2(gx, gy);
-                        x0 = st.x & 0xffff;
-                        y0 = st.x >> 16;
-                        const int s = (st.y >> 16) & 0xff;
-                        hole = (st.y >> 24) & 1;
-                        pl = masks + ((long long)f * S + s) * plane;
-                        key = hole ? pidx(x0 + 1, y0, W) : pidx(x0, y0, W);
-                        count = 0;
-                        closed = 0;
-                        ok = 1;
-                        first = 1;
-                        cx = x0;
-                        cy = y0;
-                        pc = pidx(x0, y0, W);
-                        ndx = 1;
-                        ndy = 1;
-                        kreg = 1;
-                        fresh = 1;
-                        state = ST_NEED;
+            const unsigned long long idle = ballot64(state == ST_IDLE);
+            if (idle) {
+                if (next == rend && !exhausted) {
+                    // take the next batch of the frame's survivors; its records arrive by the next checkpoint
+                    unsigned base = 0;
+                    if (lane == 0) base = atomicAdd((unsigned *)&counts[f].nwalk, (unsigned)WALK_GRAB);
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    if (base >= n) {
+                        exhausted = 1;
                     } else {
-                        ovf |= 2u;
+                        next = pre_base = base;
+                        rend = base + WALK_GRAB < n ? base + WALK_GRAB : n;
+                        pre_ready = 0;
+                        if (base + lane < rend) pre = fin[base + lane];
                     }
-                }
-                const unsigned nidle = (unsigned)__popcll(idle);
-                const unsigned nn = next + nidle < rend ? next + nidle : rend;
-                if (nn != next) {
-                    next = nn;
-                    pre = next + lane < rend ? fin[next + lane] : make_uint2(0u, 0u);
+                } else if (next < rend && pre_ready) {
+                    const int rank = __popcll(idle & ((1ull << lane) - 1ull));
+                    const int src = (int)(next - pre_base) + rank;
+                    const unsigned gx = __shfl(pre.x, src & 63, WAVE), gy = __shfl(pre.y, src & 63, WAVE);
+                    if (state == ST_IDLE && next + (unsigned)rank < rend) {
+                        slot = next + (unsigned)rank;  // the contour slot is the survivor's index
+                        if (slot < ccap) {
+                            st = make_uint2(gx, gy);
+                            x0 = st.x & 0xffff;
+                            y0 = st.x >> 16;
+                            const int s = (st.y >> 16) & 0xff;
+                            hole = (st.y >> 24) & 1;
+                            pl = masks + ((long long)f * S + s) * plane;
+                            key = hole ? pidx(x0 + 1, y0, W) : pidx(x0, y0, W);
+                            count = 0;
+                            closed = 0;
+                            ok = 1;
+                            first = 1;
+                            cx = x0;
+                            cy = y0;
+                            pc = pidx(x0, y0, W);
+                            ndx = 1;
+                            ndy = 1;
+                            kreg = 1;
+                            fresh = 1;
+                            state = ST_NEED;
+                        } else {
+                            ovf |= 2u;
+                        }
+                    }
+                    const unsigned nidle = (unsigned)__popcll(idle);
+                    next = next + nidle < rend ? next + nidle : rend;
                 }
             }
             // ---- pool chunks from the wave's arena: two for a fresh walker (blocks 0 and 1), one for every walker
@@ -991,7 +1004,7 @@ __global__ __launch_bounds__(64) void k_walk_full(const uint32_t *__restrict__ m
 #ifdef FID_DEBUG_STATS
             d_ckcyc += __builtin_readcyclecounter() - d_c0;
 #endif
-            if (ballot64(state != ST_IDLE) == 0) break;  // range exhausted, everybody retired
+            if (exhausted && next == rend && ballot64(state != ST_IDLE) == 0) break;  // queue empty, everybody retired
             // ================= up to WALK_CKPT border-following steps inside the windows =================
             for (int it = 0; it < WALK_CKPT; it++) {
                 const unsigned long long act = ballot64(state == ST_ACTIVE);

@@ -37,7 +37,7 @@ struct fid_ctx {
     uint32_t *d_masks = nullptr;
     size_t masks_bytes = 0;
     int masks_W = 0, masks_H = 0, masks_S = 0;
-    uint2 *d_starts = nullptr, *d_surv = nullptr;
+    uint2 *d_starts = nullptr, *d_surv1 = nullptr, *d_surv = nullptr;
     uint32_t *d_pool = nullptr;
     int max_chunks = 0;
     int walk_blocks = 0;  // one-wave workgroups per frame in the full walk pass (0 = automatic)
@@ -272,8 +272,10 @@ fid_status run_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H, int
         c->last_error = "chunk table too small for this image size / maxMarkerPerimeterRate";
         return FID_E_UNSUPPORTED;
     }
-    hipLaunchKernelGGL(k_walk<true>, dim3(64, F), dim3(256), 0, st, c->d_masks, c->d_starts, c->d_surv, c->d_contours, c->d_ckpts,
-                       c->d_pool, c->d_counts, c->d_global, P);
+    hipLaunchKernelGGL((k_probe<PROBE0_STEPS, 0>), dim3(64, F), dim3(256), 0, st, c->d_masks, c->d_starts, c->d_surv1, c->d_counts,
+                       c->d_global, P);
+    hipLaunchKernelGGL((k_probe<PROBE1_STEPS, 1>), dim3(16, F), dim3(256), 0, st, c->d_masks, c->d_surv1, c->d_surv, c->d_counts,
+                       c->d_global, P);
     mark(c, ST_PROBE + 1);
     // persistent one-wave workgroups pulling survivors from a per-frame queue: about one full residency of the chip
     int wb = c->walk_blocks > 0 ? c->walk_blocks : (2048 + F - 1) / F;
@@ -484,6 +486,7 @@ fid_status fid_create(const fid_params *params, const fid_dict *dict, const fid_
     c->masks_bytes += (size_t)F * c->P.nscales * (L.max_height + 2) * 16 * sizeof(uint32_t);
     TRYHIP(hipMalloc((void **)&c->d_masks, c->masks_bytes));
     TRY(dalloc(c, &c->d_starts, F * L.max_starts_per_frame));
+    TRY(dalloc(c, &c->d_surv1, F * L.max_starts_per_frame));
     TRY(dalloc(c, &c->d_surv, F * L.max_starts_per_frame));
     c->max_chunks = (L.max_points_per_frame + CK - 1) / CK;
     TRY(dalloc(c, &c->d_pool, F * (size_t)c->max_chunks * CK));
@@ -529,7 +532,7 @@ void fid_destroy(fid_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    void *dev[] = {c->d_in, c->d_gray, c->d_masks, c->d_starts, c->d_surv, c->d_pool, c->d_contours, c->d_ckpts, c->d_cands, c->d_sorted, c->d_filtered, c->d_near,
+    void *dev[] = {c->d_in, c->d_gray, c->d_masks, c->d_starts, c->d_surv1, c->d_surv, c->d_pool, c->d_contours, c->d_ckpts, c->d_cands, c->d_sorted, c->d_filtered, c->d_near,
                    c->d_ident, c->d_pre, c->d_markers, c->d_poses, c->d_counts, c->d_global, c->d_worklist, c->d_nwork, c->d_dict,
                    c->d_subpix_mask, c->d_lens, c->d_pose_in, c->d_pose_n};
     for (void *p : dev)
@@ -761,7 +764,8 @@ fid_status fid_tap_read(fid_ctx *c, fid_tap which, void *dst, int64_t dst_bytes)
             o[12 * f + 6] = c->h_counts[f].overflow | ((int32_t)c->h_global->overflow << 8);
             o[12 * f + 7] = c->h_counts[f].nsurv;
             o[12 * f + 8] = c->h_counts[f].npool;
-            o[12 * f + 9] = o[12 * f + 10] = o[12 * f + 11] = 0;
+            o[12 * f + 9] = c->h_counts[f].nsurv1;
+            o[12 * f + 10] = o[12 * f + 11] = 0;
         }
         return FID_OK;
     }

@@ -11,7 +11,7 @@
 //                                              pad rows / tile columns are zero so border following never
 //                                              bounds-checks
 //   starts    uint2 [F][max_starts]           border-following start candidates (all scales)
-//   surv      uint2 [F][max_starts]           the starts that survive the probe pass, compacted
+//   surv1/surv uint2 [F][max_starts]          the starts that survive the short / the long probe pass, compacted
 //   contours  uint4 [F][max_contours]         contour slots: start, meta, length (0 = dropped), discovery key
 //   chunk_tab u32  [F][max_contours][maxPerim/64+1]  pool chunk of every 64 points of a contour
 //   pool      u32  [F][max_chunks][64]        contour points x | y << 16, written while the border is followed
@@ -79,7 +79,8 @@ struct DevCounts {
     int nsurv;      // starts that survived the probe pass
     int npool;      // point chunks handed out by the full walk pass
     int nwalk;      // survivors handed to walker waves so far (work queue head of the full pass)
-    int pad[2];
+    int nsurv1;     // starts that survived the first (short) probe pass
+    int pad;
 };
 
 // global counters

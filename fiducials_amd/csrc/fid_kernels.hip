@@ -510,8 +510,10 @@ __global__ __launch_bounds__(256) void k_find_starts(const uint32_t *__restrict_
 // ------------------------------------------------------------------------------------------------
 // Border following on the bit-packed padded mask.
 // Directions (contours.cpp icvCodeDeltas): 0 E, 1 NE, 2 N, 3 NW, 4 W, 5 SW, 6 S, 7 SE.
-__device__ __constant__ int c_dx8[8] = {1, 1, 0, -1, -1, -1, 0, 1};
-__device__ __constant__ int c_dy8[8] = {0, -1, -1, -1, 0, 1, 1, 1};
+
+// direction d -> step (packed 2-bit tables of dx + 1, dy + 1)
+__device__ __forceinline__ int dir_dx(int d) { return (int)((0x901Au >> (2 * d)) & 3u) - 1; }
+__device__ __forceinline__ int dir_dy(int d) { return (int)((0xA901u >> (2 * d)) & 3u) - 1; }
 
 struct MaskView {
     const uint32_t *base;  // (frame, scale) mask plane, tiled
@@ -552,40 +554,34 @@ __device__ __forceinline__ int pidx(int x, int y, int W) { return (y + 1) * (W +
 // entries per contour in chunk_tab: the windowed walk may run WALK_CKPT points past maxPerimeterPixels before it notices
 __device__ __host__ inline int chunk_tab_pitch(const DevParams &P) { return P.maxPerim / CK + 3; }
 
-// K3: one lane per start.  Walks the border exactly as icvFetchContour does (contours.cpp), counting points.
-// A start is reported only if it is the canonical one of its border (the pixel where cvFindNextContour's
+// K3 probe passes: one lane per start.  Walks the border exactly as icvFetchContour does (contours.cpp).
+// A start is kept only if it can be the canonical one of its border (the pixel where cvFindNextContour's
 // raster scan would have started it): outer borders start at their raster-first pixel, hole borders left of
 // the raster-first background pixel of the hole.  A walker gives up as soon as it meets an earlier pixel;
-// to make that happen fast on staircase edges a second cursor walks the border BACKWARDS for the first
-// BACK_BUDGET steps.  Walks longer than maxPerimeterPixels are dropped.
-//
-// Two passes, because ~98 % of the starts die within a few steps while ~2 % run for hundreds to thousands
-// (a wave lasts as long as its longest lane):
-//   PROBE = true   every start, at most PROBE_STEPS steps; what is still undecided (or closed with an
-//                  acceptable length) is appended to the survivor list with one atomic per wave
-//   PROBE = false  dense waves of survivors walk to the end and write their points into the chunk pool,
-//                  so that K4 gathers a contour with coalesced loads instead of walking it again
-#define BACK_BUDGET 48
-#define PROBE_STEPS 32
-template <bool PROBE>
-__global__ __launch_bounds__(256) void k_walk(const uint32_t *__restrict__ masks, const uint2 *__restrict__ in_list,
-                                               uint2 *__restrict__ surv, uint4 *__restrict__ contours,
-                                               uint32_t *__restrict__ chunk_tab, uint32_t *__restrict__ pool,
-                                               DevCounts *__restrict__ counts, DevGlobal *__restrict__ G,
-                                               const DevParams P)
+// to make that happen fast on staircase edges a second cursor walks the border BACKWARDS.
+// ~98 % of the starts die within a few steps while ~2 % run for hundreds to thousands, and a wave lasts as
+// long as its longest lane, so the starts are sieved twice before the full walk:
+//   LEVEL 0   every start, at most PROBE0_STEPS steps in each direction -> surv1   (kills ~90 %)
+//   LEVEL 1   surv1, at most PROBE1_STEPS steps                         -> surv
+// What is still undecided (or closed with a length that passes the perimeter gate) is appended to the next
+// list with one atomic per wave.  Contours shorter than a probe are rejected here for good when they fail
+// minMarkerPerimeterRate.
+#define PROBE0_STEPS 6
+#define PROBE1_STEPS 32
+template <int STEPS, int LEVEL>
+__global__ __launch_bounds__(256) void k_probe(const uint32_t *__restrict__ masks, const uint2 *__restrict__ in_list,
+                                                uint2 *__restrict__ out_list, DevCounts *__restrict__ counts,
+                                                DevGlobal *__restrict__ G, const DevParams P)
 {
     const int f = blockIdx.y;
     const int lane = lane_id();
-    unsigned n = (unsigned)(PROBE ? counts[f].nstarts : counts[f].nsurv);
+    unsigned n = (unsigned)(LEVEL == 0 ? counts[f].nstarts : counts[f].nsurv1);
     n = n < (unsigned)P.maxStarts ? n : (unsigned)P.maxStarts;
-    const unsigned ccap = (unsigned)P.maxContours, pcap = (unsigned)P.maxChunks;
-    const int W = P.W, H = P.H, S = P.nscales;
-    const int nck = chunk_tab_pitch(P);
+    int *out_count = LEVEL == 0 ? &counts[f].nsurv1 : &counts[f].nsurv;
+    const int W = P.W, S = P.nscales;
+    const long long plane = (long long)P.TR * P.TC * MT_ROWS;
     const uint2 *fin = in_list + (long long)f * P.maxStarts;
-    uint2 *fsv = surv + (long long)f * P.maxStarts;
-    uint4 *fco = contours + (long long)f * P.maxContours;
-    uint32_t *ftab = chunk_tab + (long long)f * P.maxContours * nck;
-    uint32_t *fpool = pool + (long long)f * P.maxChunks * CK;
+    uint2 *fout = out_list + (long long)f * P.maxStarts;
     for (unsigned i0 = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); i0 < n; i0 += gridDim.x * blockDim.x) {
         const unsigned i = i0 + lane;
         const bool active = i < n;
@@ -593,45 +589,16 @@ __global__ __launch_bounds__(256) void k_walk(const uint32_t *__restrict__ masks
         int x0 = st.x & 0xffff, y0 = st.x >> 16;
         int s = (st.y >> 16) & 0xff, hole = (st.y >> 24) & 1;
         MaskView m;
-        m.base = masks + ((long long)f * S + s) * ((long long)P.TR * P.TC * MT_ROWS);
+        m.base = masks + ((long long)f * S + s) * plane;
         m.TC = P.TC;
         // canonical key: outer = own index, hole = index of the background pixel to the right
         const int key = hole ? pidx(x0 + 1, y0, W) : pidx(x0, y0, W);
         const int s_end = hole ? 0 : 4;
         int count = 0, ok = active, closed = 0;
-        int slot = -1;
-        uint32_t *chunk = nullptr;
-        if (!PROBE && active) {
-            unsigned o = atomicAdd((unsigned *)&counts[f].ncontours, 1u);
-            if (o < ccap) {
-                slot = (int)o;
-                fco[slot] = make_uint4(st.x, st.y, 0u, (unsigned)key);  // count 0 = not accepted
-            } else {
-                atomicOr(&G->overflow, 2u);
-                ok = 0;
-            }
-        }
-        // emit point `count` of this contour into the chunk pool (full pass only)
-        auto emit = [&](int px, int py) {
-            if (PROBE) return;
-            if ((count & (CK - 1)) == 0) {
-                unsigned c = atomicAdd((unsigned *)&counts[f].npool, 1u);
-                if (c < pcap) {
-                    chunk = fpool + (long long)c * CK;
-                    ftab[(long long)slot * nck + count / CK] = c;
-                } else {
-                    atomicOr(&G->overflow, 8u);
-                    ok = 0;
-                    return;
-                }
-            }
-            chunk[count & (CK - 1)] = (uint32_t)px | ((uint32_t)py << 16);
-        };
         unsigned nb = ok ? nb8(m, x0, y0) : 0u;
         if (!ok) {
         } else if (nb == 0) {
-            emit(x0, y0);  // single pixel domain
-            count = 1;
+            count = 1;  // single pixel domain
             closed = 1;
         } else {
             // do { s = (s - 1) & 7; } while (*i1 == 0 && s != s_end)  == first foreground clockwise from s_end - 1
@@ -643,9 +610,9 @@ __global__ __launch_bounds__(256) void k_walk(const uint32_t *__restrict__ masks
                 int t = 7 - (31 - __clz((int)win));
                 sdir = (c0 - t) & 7;
             }
-            const int i1x = x0 + c_dx8[sdir], i1y = y0 + c_dy8[sdir];
+            const int i1x = x0 + dir_dx(sdir), i1y = y0 + dir_dy(sdir);
             // backward cursor starts on i1 with forward direction pointing at the start pixel
-            int bx = i1x, by = i1y, bf = (sdir + 4) & 7, bleft = PROBE ? PROBE_STEPS : BACK_BUDGET;
+            int bx = i1x, by = i1y, bf = (sdir + 4) & 7;
             if (!hole && pidx(bx, by, W) < key) ok = 0;
             int cx = x0, cy = y0;
             while (ok) {
@@ -658,13 +625,12 @@ __global__ __launch_bounds__(256) void k_walk(const uint32_t *__restrict__ masks
                     // background pixels examined in the 4-directions belong to this border's hole region
                     for (int q = 0; q < t; q++) {
                         int d = (start + q) & 7;
-                        if (!(d & 1) && pidx(cx + c_dx8[d], cy + c_dy8[d], W) < key) ok = 0;
+                        if (!(d & 1) && pidx(cx + dir_dx(d), cy + dir_dy(d), W) < key) ok = 0;
                     }
                 }
                 int sn = (start + t) & 7;
-                if (ok) emit(cx, cy);
                 count++;
-                int nx = cx + c_dx8[sn], ny = cy + c_dy8[sn];
+                int nx = cx + dir_dx(sn), ny = cy + dir_dy(sn);
                 if (!ok || count > P.maxPerim) {
                     ok = 0;
                     break;
@@ -673,7 +639,7 @@ __global__ __launch_bounds__(256) void k_walk(const uint32_t *__restrict__ masks
                     closed = 1;
                     break;
                 }
-                if (PROBE && count >= PROBE_STEPS) break;
+                if (count >= STEPS) break;
                 cx = nx;
                 cy = ny;
                 if (!hole && pidx(cx, cy, W) < key) {
@@ -682,9 +648,8 @@ __global__ __launch_bounds__(256) void k_walk(const uint32_t *__restrict__ masks
                 }
                 sdir = (sn + 4) & 7;
                 nb = nb8(m, cx, cy);
-                // ---- backward step (bounded): predecessor = first foreground clockwise from bf - 1
-                if (bleft > 0) {
-                    bleft--;
+                // ---- backward step: predecessor = first foreground clockwise from bf - 1
+                {
                     unsigned bn = nb8(m, bx, by);
                     unsigned bn2 = bn | (bn << 8);
                     int c0 = (bf - 1) & 7;
@@ -693,34 +658,30 @@ __global__ __launch_bounds__(256) void k_walk(const uint32_t *__restrict__ masks
                     if (hole) {
                         for (int q = 0; q < tz; q++) {
                             int d = (c0 - q) & 7;
-                            if (!(d & 1) && pidx(bx + c_dx8[d], by + c_dy8[d], W) < key) ok = 0;
+                            if (!(d & 1) && pidx(bx + dir_dx(d), by + dir_dy(d), W) < key) ok = 0;
                         }
                     }
                     int bd = (c0 - tz) & 7;
-                    bx += c_dx8[bd];
-                    by += c_dy8[bd];
+                    bx += dir_dx(bd);
+                    by += dir_dy(bd);
                     bf = (bd + 4) & 7;
                     if (!hole && pidx(bx, by, W) < key) ok = 0;
                 }
             }
         }
-        if (PROBE) {
-            // still undecided, or closed with a length that passes the perimeter gate
-            const int keep = ok && (!closed || (count >= P.minPerim && count <= P.maxPerim));
-            const unsigned long long mk = ballot64(keep);
-            if (mk) {
-                const int leader = __ffsll((long long)mk) - 1;
-                unsigned base = 0;
-                if (lane == leader) base = atomicAdd((unsigned *)&counts[f].nsurv, (unsigned)__popcll(mk));
-                base = __shfl(base, leader, WAVE);
-                const unsigned idx = base + (unsigned)__popcll(mk & ((1ull << lane) - 1ull));
-                if (keep) {
-                    if (idx < (unsigned)P.maxStarts) fsv[idx] = st;
-                    else atomicOr(&G->overflow, 1u);
-                }
+        // still undecided, or closed with a length that passes the perimeter gate
+        const int keep = ok && (!closed || (count >= P.minPerim && count <= P.maxPerim));
+        const unsigned long long mk = ballot64(keep);
+        if (mk) {
+            const int leader = __ffsll((long long)mk) - 1;
+            unsigned base = 0;
+            if (lane == leader) base = atomicAdd((unsigned *)out_count, (unsigned)__popcll(mk));
+            base = __shfl(base, leader, WAVE);
+            const unsigned idx = base + (unsigned)__popcll(mk & ((1ull << lane) - 1ull));
+            if (keep) {
+                if (idx < (unsigned)P.maxStarts) fout[idx] = st;
+                else atomicOr(&G->overflow, 1u);
             }
-        } else if (ok && closed && count >= P.minPerim && count <= P.maxPerim && slot >= 0) {
-            fco[slot].z = (unsigned)count;
         }
     }
 }
@@ -750,8 +711,6 @@ __global__ __launch_bounds__(256) void k_walk(const uint32_t *__restrict__ masks
 #define WALK_ARENA 256  // pool chunks a wave takes per atomic
 
 __device__ __forceinline__ void wait_vmcnt0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-__device__ __forceinline__ int dir_dx(int d) { return (int)((0x901Au >> (2 * d)) & 3u) - 1; }
-__device__ __forceinline__ int dir_dy(int d) { return (int)((0xA901u >> (2 * d)) & 3u) - 1; }
 
 // raw neighbourhood byte (bits 0-2 row above x-1..x+1, bit 3 W, bit 4 E, bits 5-7 row below) -> direction order
 __device__ __forceinline__ unsigned raw_to_nb(unsigned raw)

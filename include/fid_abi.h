@@ -155,7 +155,7 @@ typedef enum fid_tap {
     FID_TAP_IDENT = 4,       /* int32 [nframes][max_candidates_per_frame][2] id, rotation */
     FID_TAP_PRESUBPIX = 5,   /* fid_marker [nframes][max_markers_per_frame] */
     FID_TAP_COUNTS = 6,      /* int32 [nframes][12]: starts, contour slots, candidates, filtered, accepted, markers, overflow flags,
-                                probe survivors, point chunks (64 points each), 0, 0, 0 */
+                                survivors of the long probe, point chunks (64 points each), survivors of the short probe, 0, 0 */
     FID_TAP_GRAY = 7         /* uint8 [nframes][height][width] the gray image the detector saw */
 } fid_tap;
 

@@ -260,7 +260,7 @@ fid_status run_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H, int
     mark(c, ST_THRESH + 1);
     // ---- K2
     {
-        long long groups = (long long)P.nscales * P.TR * ((P.WW + 3) / 4);  // one wave per group
+        long long groups = (long long)P.nscales * P.TR * ((P.WW + 15) / 16);  // one wave per group
         long long blocks = (groups + 3) / 4;
         if (blocks > 256) blocks = 256;
         hipLaunchKernelGGL(k_find_starts, dim3((unsigned)blocks, F), dim3(256), 0, st, c->d_masks, c->d_starts, c->d_counts,

@@ -421,8 +421,12 @@ __device__ __forceinline__ uint32_t fill_toward_lsb(uint32_t seed, uint32_t runs
     return f;
 }
 
-// One thread per mask word; a wave covers 16 rows x 4 word columns = four whole mask tiles (256 contiguous
-// bytes).  The neighbour words (left / right, this row and the row above) come through the L1.
+// One thread per mask word column x 4 rows (one 16-byte load per word column: its own, the left and the right
+// one, plus single words for the row above and the row below the group); a wave covers one tile row of
+// 16 word columns = 16 whole mask tiles (1 KB contiguous).
+// Two kinds of starts are dropped on the spot because their border is shorter than any perimeter gate
+// (when minPerimeterPixels allows it): isolated foreground pixels (a 1-point outer border) and isolated
+// background pixels (a hole border of at most 8 points).
 __global__ __launch_bounds__(256) void k_find_starts(const uint32_t *__restrict__ masks, uint2 *__restrict__ starts,
                                                       DevCounts *__restrict__ counts, DevGlobal *__restrict__ G,
                                                       const DevParams P)
@@ -432,46 +436,84 @@ __global__ __launch_bounds__(256) void k_find_starts(const uint32_t *__restrict_
     const int lane = lane_id(), wid = threadIdx.x >> 6;
     const int f = blockIdx.y;
     const int WW = P.WW, TC = P.TC, TR = P.TR, H = P.H, S = P.nscales;
-    const int CG = (WW + 3) / 4;               // groups of 4 word columns
+    const int CG = (WW + 15) / 16;                     // groups of 16 word columns
     const long long ngroups = (long long)S * TR * CG;  // one wave per group
     const long long ngr4 = (ngroups + 3) & ~3LL;
     const long long plane = (long long)TR * TC * MT_ROWS;
     const unsigned cap = (unsigned)P.maxStarts;
+    const bool drop1 = P.minPerim > 1, drop8 = P.minPerim > 8;
     uint2 *fst = starts + (long long)f * P.maxStarts;
     for (long long g0 = (long long)blockIdx.x * 4; g0 < ngr4; g0 += (long long)gridDim.x * 4) {
         const long long g = g0 + wid;
-        uint32_t outer = 0, hole = 0;
-        int x_base = 0, y = 0, s = 0, cnt = 0;
+        uint32_t outer[4], hole[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) outer[k] = hole[k] = 0;
+        int x_base = 0, yy0 = 0, s = 0, cnt = 0;
         if (g < ngroups) {
             const int cg = (int)(g % CG);
             const long long t = g / CG;
             const int tr = (int)(t % TR);
             s = (int)(t / TR);
-            const int w = cg * 4 + (lane >> 4);
-            const int yy = tr * MT_ROWS + (lane & 15);
-            y = yy - 1;
+            const int w = cg * 16 + (lane >> 2);
+            const int r4 = (lane & 3) * 4;
+            yy0 = tr * MT_ROWS + r4;  // padded row of this thread's first row; image row = yy - 1
             x_base = w * 32;
-            if (y >= 0 && y < H && w < WW) {
+            if (w < WW && yy0 <= H && yy0 + 3 >= 1) {
                 const uint32_t *pl = masks + ((long long)f * S + s) * plane;
-                const uint32_t *row = pl + mask_word(TC, yy, MASK_PADW + w);
-                const uint32_t *up = pl + mask_word(TC, yy - 1, MASK_PADW + w);
-                const uint32_t cur = row[0], prevc = row[-MT_ROWS], nextc = row[MT_ROWS];
-                const uint32_t u = up[0], prevu = up[-MT_ROWS], nextu = up[MT_ROWS];
-                const uint32_t Wst = (cur << 1) | (prevc >> 31);
-                const uint32_t NW = (u << 1) | (prevu >> 31);
-                const uint32_t NE = (u >> 1) | (nextu << 31);
-                // outer: starts of foreground runs that have no foreground above (N / NW / NE) anywhere
-                const uint32_t touch = cur & (NW | u | NE);
-                outer = cur & ~Wst & ~fill_toward_lsb(touch, cur);
-                // hole: first pixel e of a background run (W neighbour foreground) that is closed above;
-                // the border-following start is the foreground pixel LEFT of e
-                const uint32_t bg = ~cur;
-                const uint32_t open = bg & ~u;  // background with background above: joins an earlier pixel
-                const uint32_t e = bg & Wst & ~fill_toward_lsb(open, bg);
-                const uint32_t bgn = ~nextc;
-                const uint32_t en0 = bgn & (cur >> 31) & ~fill_toward_lsb(bgn & ~nextu, bgn) & 1u;
-                hole = (e >> 1) | (en0 << 31);
-                cnt = __popc(outer) + __popc(hole);
+                const uint32_t *tile = pl + ((long long)tr * TC + MASK_PADW + w) * MT_ROWS + r4;
+                const uint4 c4 = *reinterpret_cast<const uint4 *>(tile);
+                const uint4 p4 = *reinterpret_cast<const uint4 *>(tile - MT_ROWS);
+                const uint4 n4 = *reinterpret_cast<const uint4 *>(tile + MT_ROWS);
+                uint32_t upc = 0, upp = 0, upn = 0, dnc = 0, dnp = 0, dnn = 0;
+                if (yy0 > 0) {
+                    const uint32_t *q = pl + mask_word(TC, yy0 - 1, MASK_PADW + w);
+                    upc = q[0];
+                    upp = q[-MT_ROWS];
+                    upn = q[MT_ROWS];
+                }
+                {
+                    const uint32_t *q = pl + mask_word(TC, yy0 + 4, MASK_PADW + w);  // exists: TR has a spare tile row
+                    dnc = q[0];
+                    dnp = q[-MT_ROWS];
+                    dnn = q[MT_ROWS];
+                }
+                const uint32_t cc[6] = {upc, c4.x, c4.y, c4.z, c4.w, dnc};
+                const uint32_t pp[6] = {upp, p4.x, p4.y, p4.z, p4.w, dnp};
+                const uint32_t nn[6] = {upn, n4.x, n4.y, n4.z, n4.w, dnn};
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int y = yy0 + k - 1;
+                    if (y < 0 || y >= H) continue;
+                    const uint32_t cur = cc[k + 1], prevc = pp[k + 1], nextc = nn[k + 1];
+                    const uint32_t u = cc[k], prevu = pp[k], nextu = nn[k];
+                    const uint32_t d = cc[k + 2], prevd = pp[k + 2], nextd = nn[k + 2];
+                    const uint32_t Wst = (cur << 1) | (prevc >> 31);
+                    const uint32_t Est = (cur >> 1) | (nextc << 31);
+                    const uint32_t NW = (u << 1) | (prevu >> 31);
+                    const uint32_t NE = (u >> 1) | (nextu << 31);
+                    // outer: starts of foreground runs that have no foreground above (N / NW / NE) anywhere
+                    const uint32_t touch = cur & (NW | u | NE);
+                    uint32_t o = cur & ~Wst & ~fill_toward_lsb(touch, cur);
+                    if (drop1) {
+                        const uint32_t below = d | (d << 1) | (prevd >> 31) | (d >> 1) | (nextd << 31);
+                        o &= Est | below;  // an isolated pixel is a complete 1-point contour
+                    }
+                    // hole: first pixel e of a background run (W neighbour foreground) that is closed above;
+                    // the border-following start is the foreground pixel LEFT of e
+                    const uint32_t bg = ~cur;
+                    const uint32_t open = bg & ~u;  // background with background above: joins an earlier pixel
+                    uint32_t e = bg & Wst & ~fill_toward_lsb(open, bg);
+                    const uint32_t bgn = ~nextc;
+                    uint32_t en0 = bgn & (cur >> 31) & ~fill_toward_lsb(bgn & ~nextu, bgn) & 1u;
+                    if (drop8) {
+                        // a background pixel whose four 4-neighbours are foreground is a whole hole of its own
+                        e &= ~(u & d & Est);  // W is foreground by construction
+                        en0 &= ~(nextu & nextd & (nextc >> 1));  // N, S, E of the next word's pixel 0
+                    }
+                    outer[k] = o;
+                    hole[k] = (e >> 1) | (en0 << 31);
+                    cnt += __popc(outer[k]) + __popc(hole[k]);
+                }
             }
         }
         int incl = wave_iscan(cnt);
@@ -489,17 +531,22 @@ __global__ __launch_bounds__(256) void k_find_starts(const uint32_t *__restrict_
         if (tot) {
             unsigned off = s_base + (unsigned)(wbase + incl - cnt);
             const uint32_t meta = (uint32_t)f | ((uint32_t)s << 16);
-            while (outer) {
-                int b = __ffs(outer) - 1;
-                outer &= outer - 1;
-                if (off < cap) fst[off] = make_uint2((uint32_t)(x_base + b) | ((uint32_t)y << 16), meta);
-                off++;
-            }
-            while (hole) {
-                int b = __ffs(hole) - 1;
-                hole &= hole - 1;
-                if (off < cap) fst[off] = make_uint2((uint32_t)(x_base + b) | ((uint32_t)y << 16), meta | (1u << 24));
-                off++;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t y = (uint32_t)(yy0 + k - 1);
+                uint32_t o = outer[k], hh = hole[k];
+                while (o) {
+                    int b = __ffs(o) - 1;
+                    o &= o - 1;
+                    if (off < cap) fst[off] = make_uint2((uint32_t)(x_base + b) | (y << 16), meta);
+                    off++;
+                }
+                while (hh) {
+                    int b = __ffs(hh) - 1;
+                    hh &= hh - 1;
+                    if (off < cap) fst[off] = make_uint2((uint32_t)(x_base + b) | (y << 16), meta | (1u << 24));
+                    off++;
+                }
             }
             if (threadIdx.x == 0 && s_base + (unsigned)tot > cap) atomicOr(&G->overflow, 1u);
         }

@@ -41,8 +41,9 @@ MASK_BYTES = N_SCALES * W * H // 8
 ALGO_BYTES = {
     "threshold": W * H + MASK_BYTES,  # K1: gray in, masks out
     "find_starts": MASK_BYTES,        # K2: masks in
-    "walk_count": MASK_BYTES,         # K3: masks in (border pixels only; priced as one full read)
-    "approx": MASK_BYTES,             # K4: masks in (contours that passed the gate)
+    "walk_probe": MASK_BYTES,         # K3 probes: masks in (border pixels only; priced as one full read)
+    "walk_full": MASK_BYTES,          # K3 full walk: masks in (border pixels only; priced as one full read)
+    "approx": MASK_BYTES,             # K4: contour points of the accepted borders (priced as the masks they came from)
 }
 PIPELINE_BYTES = W * H + 2 * MASK_BYTES  # 8 812 800 B/frame
 

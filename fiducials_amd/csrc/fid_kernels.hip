@@ -1103,15 +1103,26 @@ __global__ __launch_bounds__(64) void k_approx(uint4 *__restrict__ contours, con
     uint4 *fco = contours + (long long)f * P.maxContours;
     const uint32_t *ftab = chunk_tab + (long long)f * P.maxContours * nck;
     const uint32_t *fpool = pool + (long long)f * P.maxChunks * CK;
-    for (unsigned ci = blockIdx.x; ci < n; ci += gridDim.x) {
-        uint4 c = fco[ci];
+    // this workgroup's slots are blockIdx.x, blockIdx.x + gridDim.x, ...: 64 of them are looked at with one
+    // load (a lane each); only the accepted ones of the right length class are then processed in turn
+    for (unsigned cb = blockIdx.x; cb < n; cb += gridDim.x * 64) {
+      const unsigned myci = cb + (unsigned)lane * gridDim.x;
+      uint4 mine = make_uint4(0u, 0u, 0u, 0u);
+      if (myci < n) mine = fco[myci];
+      int take = mine.z != 0;  // count 0 = slot of a walk that was dropped
+      if (second_pass) take = take && ((int)mine.z > pts_cap_first(P) || (mine.y & K4_RETRY_BIT));
+      else take = take && (int)mine.z <= pts_cap;
+      unsigned long long todo = ballot64(take);
+      while (todo) {
+        const int src = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const unsigned ci = cb + (unsigned)src * gridDim.x;
+        uint4 c;
+        c.x = __shfl(mine.x, src, WAVE);
+        c.y = __shfl(mine.y, src, WAVE);
+        c.z = __shfl(mine.z, src, WAVE);
+        c.w = __shfl(mine.w, src, WAVE);
         const int count = (int)c.z;
-        if (count == 0) continue;  // slot of a walk that was dropped
-        if (second_pass) {
-            if (count <= pts_cap_first(P) && !(c.y & K4_RETRY_BIT)) continue;
-        } else if (count > pts_cap) {
-            continue;
-        }
         const int x0 = c.x & 0xffff, y0 = c.x >> 16;
         const int s = (c.y >> 16) & 0xff, hole = (c.y >> 24) & 1;
         __syncthreads();
@@ -1353,6 +1364,7 @@ __global__ __launch_bounds__(64) void k_approx(uint4 *__restrict__ contours, con
                 atomicOr(&counts[f].overflow, 1);
             }
         }
+      }
     }
 }
 
@@ -1903,8 +1915,9 @@ __global__ __launch_bounds__(64) void k_filter_markers(const DevCand *__restrict
 }
 
 // K7b: cornerSubPix (cornersubpix.cpp) with getRectSubPix 8u->32f (samplers.cpp), one wave per corner.
-// The (2w+3)^2 patch and the per-tap products are computed in parallel; the five accumulators are summed
-// by lane 0 in the reference's (i, j) order so the float corner equals the sequential result bit for bit.
+// The (2w+3)^2 patch and the per-tap products are computed in parallel; each of the five accumulators is
+// summed by its own lane in the reference's (i, j) order so the float corner equals the sequential result
+// bit for bit.
 #define SP_MAXWIN 7
 __global__ __launch_bounds__(64) void k_subpix(const uint8_t *__restrict__ gray, long long gfstride,
                                                 const fid_marker *__restrict__ pre, fid_marker *__restrict__ out,
@@ -2022,15 +2035,15 @@ __global__ __launch_bounds__(64) void k_subpix(const uint8_t *__restrict__ gray,
                 prod[4][t] = gxy * px + gyy * py;
             }
             __syncthreads();
+            // the five accumulators are summed in the reference's tap order, one accumulator per lane (0..4)
+            double accv = 0;
+            if (lane < 5) {
+                const double *pr = prod[lane];
+                for (int t = 0; t < ww * ww; t++) accv += pr[t];
+            }
+            const double a = shfl_f64(accv, 0), b = shfl_f64(accv, 1), c = shfl_f64(accv, 2);
+            const double bb1 = shfl_f64(accv, 3), bb2 = shfl_f64(accv, 4);
             if (lane == 0) {
-                double a = 0, b = 0, c = 0, bb1 = 0, bb2 = 0;
-                for (int t = 0; t < ww * ww; t++) {
-                    a += prod[0][t];
-                    b += prod[1][t];
-                    c += prod[2][t];
-                    bb1 += prod[3][t];
-                    bb2 += prod[4][t];
-                }
                 int flag = 0;  // 0 continue, 1 stop
                 double det = a * c - b * b;
                 if (fabs(det) <= DBL_EPSILON * DBL_EPSILON) {

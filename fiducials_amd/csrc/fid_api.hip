@@ -346,6 +346,9 @@ fid_status run_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H, int
         fprintf(stderr, "walk stats: ranges %llu iters %llu ckpts %llu (forced %llu) active-lanes/iter %.1f cyc/range %.0f ckpt-cyc/range %.0f wait-cyc/range %.0f\n",
                 d[7], d[0], d[1], d[5], d[0] ? (double)d[2] / d[0] : 0., d[7] ? (double)d[6] / d[7] : 0., d[7] ? (double)d[3] / d[7] : 0.,
                 d[7] ? (double)d[4] / d[7] : 0.);
+        fprintf(stderr, "walk waves %llu: total cyc avg %.0f max %llu; own queue dry at avg %.0f max %llu\n", d[12],
+                d[12] ? (double)d[8] / d[12] : 0., d[9], d[12] ? (double)d[10] / d[12] : 0., d[11]);
+        fprintf(stderr, "walk longest %llu steps, total steps %llu\n", d[13], d[14]);
     }
 #endif
     fid_status rc = FID_OK;
@@ -756,7 +759,7 @@ fid_status fid_tap_read(fid_ctx *c, fid_tap which, void *dst, int64_t dst_bytes)
         int32_t *o = (int32_t *)dst;
         for (int f = 0; f < F; f++) {
             o[12 * f + 0] = c->h_counts[f].nstarts;
-            o[12 * f + 1] = c->h_counts[f].ncontours;
+            o[12 * f + 1] = c->h_counts[f].nsurv < c->P.maxContours ? c->h_counts[f].nsurv : c->P.maxContours;
             o[12 * f + 2] = c->h_counts[f].ncand;
             o[12 * f + 3] = c->h_counts[f].nfilt;
             o[12 * f + 4] = c->h_counts[f].nacc;

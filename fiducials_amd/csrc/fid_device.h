@@ -87,5 +87,5 @@ struct DevCounts {
 struct DevGlobal {
     unsigned overflow;  // bit0 starts/survivors, bit1 contours, bit2 approxPolyDP stack, bit3 point pool
     unsigned pad[3];
-    unsigned long long dbg[8];  // FID_DEBUG_STATS builds: walk-loop statistics
+    unsigned long long dbg[16];  // FID_DEBUG_STATS builds: walk-loop statistics
 };

@@ -598,7 +598,7 @@ __device__ __forceinline__ int pidx(int x, int y, int W) { return (y + 1) * (W +
 // Contour points are stored in chunks of CK points (x | y << 16) taken from a per-frame pool while the
 // border is followed; chunk_tab[slot][k] names the chunk that holds points [CK*k, CK*k + CK) of a contour.
 #define CK 64
-// entries per contour in chunk_tab: the windowed walk may run WALK_CKPT points past maxPerimeterPixels before it notices
+// entries per contour in chunk_tab: the windowed walk may run WALK_RUN (< 64) points past maxPerimeterPixels before it notices
 __device__ __host__ inline int chunk_tab_pitch(const DevParams &P) { return P.maxPerim / CK + 3; }
 
 // K3 probe passes: one lane per start.  Walks the border exactly as icvFetchContour does (contours.cpp).
@@ -753,7 +753,10 @@ __global__ __launch_bounds__(256) void k_probe(const uint32_t *__restrict__ mask
 // which background 4-neighbours the step examined (the hole-border canonical test).
 // The backward cursor of the probe pass is not needed here: it only ever rejects, and the forward cursor
 // visits every pixel of the border.
+#ifndef WALK_CKPT
 #define WALK_CKPT 4
+#endif
+#define WALK_RUN 32     // most steps between two checkpoints
 #define WALK_GRAB 64    // survivors a wave takes from the frame's work queue per atomic
 #define WALK_ARENA 256  // pool chunks a wave takes per atomic
 
@@ -795,7 +798,11 @@ __global__ __launch_bounds__(64) void k_walk_full(const uint32_t *__restrict__ m
     // 4-neighbour the search passed over (0 none, else 4 | positive << 1 | whole-row)
     __shared__ uint8_t s_lut[2048];
     const uint32_t *s_winw = reinterpret_cast<const uint32_t *>(s_win);
-    const int f = blockIdx.y;
+    int f = blockIdx.y;  // the frame whose queue this wave is serving; it moves on when that queue runs dry
+#ifdef FID_DEBUG_STATS
+    const unsigned long long d_k0 = __builtin_readcyclecounter();
+    unsigned long long d_kexh = 0;
+#endif
     const int lane = lane_id();
     const int lane4 = lane * 4;
     for (int e = lane; e < 2048; e += 64) {
@@ -812,21 +819,20 @@ __global__ __launch_bounds__(64) void k_walk_full(const uint32_t *__restrict__ m
         s_lut[e] = (uint8_t)(((start + t) & 7) | (code << 3));
     }
     __syncthreads();
-    unsigned n = (unsigned)counts[f].nsurv;
-    n = n < (unsigned)P.maxStarts ? n : (unsigned)P.maxStarts;
     const unsigned ccap = (unsigned)P.maxContours, pcap = (unsigned)P.maxChunks;
-    if (blockIdx.x == 0 && lane == 0) counts[f].ncontours = (int)(n < ccap ? n : ccap);  // contour slot = survivor index
-    const int W = P.W, S = P.nscales, TC = P.TC, TR = P.TR;
+    const int W = P.W, S = P.nscales, TC = P.TC, TR = P.TR, F = P.nframes;
     const int W2 = W + 2;
     const int nck = chunk_tab_pitch(P);
     const long long plane = (long long)TR * TC * MT_ROWS;
-    const uint2 *fin = surv + (long long)f * P.maxStarts;
-    uint4 *fco = contours + (long long)f * P.maxContours;
-    uint32_t *ftab = chunk_tab + (long long)f * P.maxContours * nck;
-    uint32_t *fpool = pool + (long long)f * P.maxChunks * CK;
     enum { ST_IDLE = 0, ST_ACTIVE, ST_NEED, ST_LOADING, ST_FINAL };
 
-    {
+    for (;;) {
+        unsigned n = (unsigned)counts[f].nsurv;
+        n = n < (unsigned)P.maxStarts ? n : (unsigned)P.maxStarts;
+        const uint2 *fin = surv + (long long)f * P.maxStarts;
+        uint4 *fco = contours + (long long)f * P.maxContours;
+        uint32_t *ftab = chunk_tab + (long long)f * P.maxContours * nck;
+        uint32_t *fpool = pool + (long long)f * P.maxChunks * CK;
         // the wave's current batch of the frame's survivor queue: [next, rend), records of batch base .. base + 63 in `pre`
         unsigned next = 0, rend = 0, pre_base = 0;  // wave-uniform
         int exhausted = 0, pre_ready = 0;           // wave-uniform
@@ -890,7 +896,7 @@ __global__ __launch_bounds__(64) void k_walk_full(const uint32_t *__restrict__ m
                 }
             }
             if ((state == ST_ACTIVE || state == ST_NEED) && count > P.maxPerim) {
-                // checked here, not per step: a walk overshoots by at most WALK_CKPT points
+                // checked here, not per step: a walk overshoots by at most WALK_RUN points
                 ok = 0;
                 state = ST_FINAL;
             }
@@ -899,6 +905,10 @@ __global__ __launch_bounds__(64) void k_walk_full(const uint32_t *__restrict__ m
                 const int accept = ok && closed && count >= P.minPerim && count <= P.maxPerim;
                 fco[slot] = make_uint4(st.x, st.y, accept ? (unsigned)count : 0u, (unsigned)key);
                 state = ST_IDLE;
+#ifdef FID_DEBUG_STATS
+                atomicMax(&G->dbg[13], (unsigned long long)count);
+                atomicAdd(&G->dbg[14], (unsigned long long)count);
+#endif
             }
             // ---- hand out new work to idle lanes
             int fresh = 0;
@@ -911,11 +921,16 @@ __global__ __launch_bounds__(64) void k_walk_full(const uint32_t *__restrict__ m
                     base = __builtin_amdgcn_readfirstlane(base);
                     if (base >= n) {
                         exhausted = 1;
+#ifdef FID_DEBUG_STATS
+                        if (!d_kexh) d_kexh = __builtin_readcyclecounter() - d_k0;
+#endif
                     } else {
                         next = pre_base = base;
                         rend = base + WALK_GRAB < n ? base + WALK_GRAB : n;
                         pre_ready = 0;
-                        if (base + lane < rend) pre = fin[base + lane];
+                        // the survivor list is roughly ordered by threshold scale, and the largest windows hold the
+                        // longest borders: hand the list out back to front so that those do not end up in the tail
+                        if (base + lane < rend) pre = fin[n - 1 - (base + lane)];
                     }
                 } else if (next < rend && pre_ready) {
                     const int rank = __popcll(idle & ((1ull << lane) - 1ull));
@@ -997,14 +1012,18 @@ __global__ __launch_bounds__(64) void k_walk_full(const uint32_t *__restrict__ m
                 ty = ty < 0 ? 0 : (ty > TR - 2 ? TR - 2 : ty);
                 wx0 = tx * 32;
                 wy0 = ty * MT_ROWS;
-                const uint32_t *g00 = pl + ((long long)ty * TC + tx) * MT_ROWS;
-#pragma unroll
-                for (int j = 0; j < 16; j++) {
-                    const int c = j >> 3, t = (j >> 2) & 1, q = j & 3;
-                    const uint32_t *src = g00 + ((long long)t * TC + c) * MT_ROWS + q * 4;
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                                     (__attribute__((address_space(3))) void *)(s_win + j * 64), 16, 0, 0);
-                }
+                // two addresses (tile rows ty, ty + 1); tile column and row quarter go into the instruction offset
+                const uint32_t *g0 = pl + ((long long)ty * TC + tx) * MT_ROWS;
+                const uint32_t *g1 = g0 + (long long)TC * MT_ROWS;
+                static_for<16>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value;
+                    constexpr int c = j >> 3, t = (j >> 2) & 1, q = j & 3;
+                    // the instruction offset moves the LDS destination as well as the source: compensate in the base
+                    constexpr int off = (c * MT_ROWS + q * 4) * 4;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(t ? g1 : g0),
+                                                     (__attribute__((address_space(3))) void *)((char *)s_win + j * 1024 - off), 16,
+                                                     off, 0);
+                });
                 state = ST_LOADING;
             }
 #ifdef FID_DEBUG_STATS
@@ -1012,8 +1031,13 @@ __global__ __launch_bounds__(64) void k_walk_full(const uint32_t *__restrict__ m
 #endif
             if (exhausted && next == rend && ballot64(state != ST_IDLE) == 0) break;  // queue empty, everybody retired
             // ================= up to WALK_CKPT border-following steps inside the windows =================
-            for (int it = 0; it < WALK_CKPT; it++) {
+            // (the next checkpoint comes after WALK_CKPT steps if some lane is waiting for one -- parked, loading, finished,
+            //  or idle with survivors still queued -- and after WALK_RUN steps at the latest: chunk hand-out and the
+            //  perimeter cap rely on that bound)
+            const int work_left = !(exhausted && next == rend);
+            for (int it = 0; it < WALK_RUN; it++) {
                 const unsigned long long act = ballot64(state == ST_ACTIVE);
+                if (it >= WALK_CKPT && ballot64(state != ST_ACTIVE && (state != ST_IDLE || work_left))) break;
                 if (act == 0) {
 #ifdef FID_DEBUG_STATS
                     d_forced += it == 0;
@@ -1054,6 +1078,23 @@ __global__ __launch_bounds__(64) void k_walk_full(const uint32_t *__restrict__ m
             }
         }
         if (ovf) atomicOr(&G->overflow, ovf);
+        // ---- this frame's queue is empty and all of this wave's walkers have retired: serve the next frame (in cyclic
+        //      order) that still has survivors waiting; 64 frames are examined per load
+        int nextf = -1;
+        for (int k0 = 1; k0 < F && nextf < 0; k0 += 64) {
+            const int k = k0 + lane;
+            int has = 0;
+            int fr = f + k;
+            fr = fr >= F ? fr - F : fr;
+            if (k < F) {
+                const unsigned done = __hip_atomic_load((unsigned *)&counts[fr].nwalk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                unsigned m = (unsigned)counts[fr].nsurv;
+                m = m < (unsigned)P.maxStarts ? m : (unsigned)P.maxStarts;
+                has = done < m;
+            }
+            const unsigned long long hb = ballot64(has);
+            if (hb) nextf = __shfl(fr, __ffsll((long long)hb) - 1, WAVE);
+        }
 #ifdef FID_DEBUG_STATS
         if (lane == 0) {
             atomicAdd(&G->dbg[0], d_iters);
@@ -1066,7 +1107,19 @@ __global__ __launch_bounds__(64) void k_walk_full(const uint32_t *__restrict__ m
             atomicAdd(&G->dbg[7], 1ull);
         }
 #endif
+        if (nextf < 0) break;
+        f = nextf;
     }
+#ifdef FID_DEBUG_STATS
+    if (lane == 0) {
+        const unsigned long long d_kt = __builtin_readcyclecounter() - d_k0;
+        atomicAdd(&G->dbg[8], d_kt);
+        atomicMax(&G->dbg[9], d_kt);
+        atomicAdd(&G->dbg[10], d_kexh);
+        atomicMax(&G->dbg[11], d_kexh);
+        atomicAdd(&G->dbg[12], 1ull);
+    }
+#endif
 }
 
 // points per contour the first (short-LDS) launch of k_approx accepts
@@ -1096,7 +1149,8 @@ __global__ __launch_bounds__(64) void k_approx(uint4 *__restrict__ contours, con
     __shared__ int dst[2 * 16];
     const int lane = lane_id();
     const int f = blockIdx.y;
-    unsigned n = (unsigned)counts[f].ncontours;
+    unsigned n = (unsigned)counts[f].nsurv;  // contour slot = survivor index
+    n = n < (unsigned)P.maxStarts ? n : (unsigned)P.maxStarts;
     n = n < (unsigned)P.maxContours ? n : (unsigned)P.maxContours;
     const int W = P.W, H = P.H;
     const int nck = chunk_tab_pitch(P);

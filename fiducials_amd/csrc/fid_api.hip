@@ -25,6 +25,11 @@ constexpr int TX = 128, TY = 32, NT = 256;
 struct fid_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    enum { MAX_SUB = 8 };
+    hipStream_t sub_stream[MAX_SUB] = {};  // sub-batches of one call run on these, overlapping each other's tails
+    hipEvent_t sub_done[MAX_SUB] = {}, fork_ev = nullptr;
+    hipEvent_t sub_ev[MAX_SUB][16] = {};   // per sub-batch stage boundaries (FID_PROFILE)
+    int sub_frames = 0;                    // frames per sub-batch (0 = automatic)
     fid_params params;
     fid_limits lim;
     DevParams P;
@@ -64,7 +69,7 @@ struct fid_ctx {
     DevGlobal *h_global = nullptr;
     fid_pose_out *h_poses = nullptr;
     // last call
-    int last_frames = 0, last_W = 0, last_H = 0;
+    int last_frames = 0, last_W = 0, last_H = 0, last_nsub = 1;
     const uint8_t *last_gray = nullptr;
     long long last_gfstride = 0;
     bool profile = false;
@@ -210,116 +215,143 @@ fid_status run_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H, int
     int bpp = enc == FID_ENC_MONO8 ? 1 : 3;
     if (stride < W * bpp) return FID_E_INVALID_ARG;
     if ((unsigned)(c->params.maxMarkerPerimeterRate * (W > H ? W : H)) > 36000u) return FID_E_UNSUPPORTED;  // contour points live in LDS
-    hipStream_t st = c->stream;
-    for (int i = 0; i <= ST_COUNT; i++) c->ev_valid[i] = false;
-    mark(c, 0);
-    // ---- K0: gray
-    const uint8_t *gray;
-    long long gfstride;
-    int gstride;
-    if (enc == FID_ENC_MONO8 && true) {
-        // use the caller's buffer in place (any stride)
-        gray = d_src;
-        gstride = stride;
-        gfstride = fstride;
-    } else {
-        int blocks = 2048;
-        hipLaunchKernelGGL(k_to_gray, dim3(blocks), dim3(256), 0, st, d_src, stride, fstride, (int)enc, c->d_gray, W, H, F);
-        gray = c->d_gray;
-        gstride = W;
-        gfstride = (long long)W * H;
-    }
+    hipStream_t st0 = c->stream;
+    // ---- K0 geometry: mono8 device input is used in place (any stride); colour goes through k_to_gray
+    const bool to_gray = enc != FID_ENC_MONO8;
+    const int gstride = to_gray ? W : stride;
+    const long long gfstride = to_gray ? (long long)W * H : fstride;
+    const uint8_t *gray = to_gray ? c->d_gray : d_src;
     set_geometry(c, W, H, gstride, F);
-    const DevParams &P = c->P;
-    mark(c, ST_GRAY + 1);
     // masks pad words must be zero; re-zero when the layout changes
-    if (c->masks_W != W || c->masks_H != H || c->masks_S != P.nscales) {
-        HIPCHK(c, hipMemsetAsync(c->d_masks, 0, c->masks_bytes, st));
+    if (c->masks_W != W || c->masks_H != H || c->masks_S != c->P.nscales) {
+        HIPCHK(c, hipMemsetAsync(c->d_masks, 0, c->masks_bytes, st0));
         c->masks_W = W;
         c->masks_H = H;
-        c->masks_S = P.nscales;
+        c->masks_S = c->P.nscales;
     }
-    HIPCHK(c, hipMemsetAsync(c->d_counts, 0, sizeof(DevCounts) * F, st));
-    HIPCHK(c, hipMemsetAsync(c->d_global, 0, sizeof(DevGlobal), st));
-    HIPCHK(c, hipMemsetAsync(c->d_nwork, 0, sizeof(unsigned), st));
-    // ---- K1
-    {
-        bool node_table = P.nscales == 13;  // 3, 7, ..., 51: the node defaults (aruco_detect.cpp:690-693)
-        for (int i = 0; i < P.nscales && node_table; i++) node_table = P.win[i] == 3 + 4 * i;
-        if (node_table) {
-            using C = ThrCfg<3, 4, 13>;
-            dim3 grid((W + C::TX - 1) / C::TX, (H + C::TY - 1) / C::TY, F);
-            hipLaunchKernelGGL((k_threshold_fixed<3, 4, 13>), grid, dim3(C::NT), C::LDS_BYTES, st, gray, gfstride, c->d_masks, P);
-        } else {
-            int R = P.rmax, RW = TX + 2 * R, RH = TY + 2 * R, PT = (RW + 1) | 1;
-            size_t lds = (size_t)(RH + 1) * PT * sizeof(uint32_t);
-            dim3 grid((W + TX - 1) / TX, (H + TY - 1) / TY, F);
-            hipLaunchKernelGGL((k_threshold<TX, TY, NT>), grid, dim3(NT), lds, st, gray, gfstride, c->d_masks, P);
-        }
-    }
-    mark(c, ST_THRESH + 1);
-    // ---- K2
-    {
-        long long groups = (long long)P.nscales * P.TR * ((P.WW + 15) / 16);  // one wave per group
-        long long blocks = (groups + 3) / 4;
-        if (blocks > 256) blocks = 256;
-        hipLaunchKernelGGL(k_find_starts, dim3((unsigned)blocks, F), dim3(256), 0, st, c->d_masks, c->d_starts, c->d_counts,
-                           c->d_global, P);
-    }
-    mark(c, ST_STARTS + 1);
-    // ---- K3: probe every start, then walk the survivors to the end
-    if ((size_t)F * P.maxContours * chunk_tab_pitch(P) > c->ckpts_elems) {
+    HIPCHK(c, hipMemsetAsync(c->d_counts, 0, sizeof(DevCounts) * F, st0));
+    HIPCHK(c, hipMemsetAsync(c->d_global, 0, sizeof(DevGlobal), st0));
+    HIPCHK(c, hipMemsetAsync(c->d_nwork, 0, sizeof(unsigned) * fid_ctx::MAX_SUB, st0));
+    if ((size_t)F * c->P.maxContours * chunk_tab_pitch(c->P) > c->ckpts_elems) {
         c->last_error = "chunk table too small for this image size / maxMarkerPerimeterRate";
         return FID_E_UNSUPPORTED;
     }
-    hipLaunchKernelGGL((k_probe<PROBE0_STEPS, 0>), dim3(64, F), dim3(256), 0, st, c->d_masks, c->d_starts, c->d_surv1, c->d_counts,
-                       c->d_global, P);
-    hipLaunchKernelGGL((k_probe<PROBE1_STEPS, 1>), dim3(16, F), dim3(256), 0, st, c->d_masks, c->d_surv1, c->d_surv, c->d_counts,
-                       c->d_global, P);
-    mark(c, ST_PROBE + 1);
-    // persistent one-wave workgroups pulling survivors from a per-frame queue: about one full residency of the chip
-    int wb = c->walk_blocks > 0 ? c->walk_blocks : (2048 + F - 1) / F;
-    wb = wb < 8 ? 8 : (wb > 64 ? 64 : wb);
-    hipLaunchKernelGGL(k_walk_full, dim3(wb, F), dim3(64), 0, st, c->d_masks, c->d_surv, c->d_contours, c->d_ckpts,
-                       c->d_pool, c->d_counts, c->d_global, P);
-    mark(c, ST_WALK + 1);
-    // ---- K4: short contours with a small LDS footprint first, then the long / flagged ones
-    {
-        int cap1 = pts_cap_first(P);
-        size_t lds1 = (size_t)cap1 * sizeof(uint32_t) + (size_t)K4_SHORT_STACK * sizeof(int2);
-        hipLaunchKernelGGL(k_approx, dim3(128, F), dim3(64), lds1, st, c->d_contours, c->d_ckpts, c->d_pool, c->d_cands, c->d_counts,
-                           c->d_global, P, cap1, K4_SHORT_STACK, 0);
-        size_t lds2 = (size_t)(P.maxPerim + 1) * sizeof(uint32_t) + (size_t)K4_LONG_STACK * sizeof(int2);
-        hipLaunchKernelGGL(k_approx, dim3(16, F), dim3(64), lds2, st, c->d_contours, c->d_ckpts, c->d_pool, c->d_cands, c->d_counts,
-                           c->d_global, P, P.maxPerim + 1, K4_LONG_STACK, 1);
+    // ---- the batch is cut into sub-batches that run the whole pipeline on their own streams: the latency-bound
+    //      tail of one sub-batch's kernels (the longest border, the last candidates) overlaps the next one's bulk
+    int per = c->sub_frames > 0 ? c->sub_frames : (F >= 32 ? (F + 1) / 2 : F);  // two halves measured best (more streams fight for CUs)
+    int nsub = (F + per - 1) / per;
+    if (nsub > fid_ctx::MAX_SUB) {
+        nsub = fid_ctx::MAX_SUB;
+        per = (F + nsub - 1) / nsub;
+        nsub = (F + per - 1) / per;
     }
-    mark(c, ST_APPROX + 1);
-    // ---- K5
-    hipLaunchKernelGGL(k_sort_cands, dim3(F), dim3(256), (size_t)P.maxCands * 8, st, c->d_cands, c->d_sorted, c->d_counts, P);
-    mark(c, ST_SORT + 1);
-    hipLaunchKernelGGL(k_near, dim3(32, F), dim3(256), 0, st, c->d_sorted, c->d_near, c->d_counts, P);
-    mark(c, ST_NEAR + 1);
-    hipLaunchKernelGGL(k_resolve, dim3(F), dim3(64), (size_t)P.maxCands * 4, st, c->d_sorted, c->d_near, c->d_filtered,
-                       c->d_counts, c->d_worklist, c->d_nwork, P);
-    mark(c, ST_RESOLVE + 1);
-    // ---- K6
-    {
-        int SZ = (P.markerSize + 2 * P.borderBits) * P.cellSize;
-        hipLaunchKernelGGL(k_identify, dim3(256 * 4), dim3(64), (size_t)SZ * SZ, st, gray, gfstride, c->d_filtered,
-                           c->d_worklist, c->d_nwork, c->d_dict, c->d_ident, P);
+    c->last_nsub = nsub;
+    if (nsub > 1) HIPCHK(c, hipEventRecord(c->fork_ev, st0));
+    for (int sb = 0; sb < nsub; sb++) {
+        const int f0 = sb * per, Fs = (f0 + per <= F ? per : F - f0);
+        hipStream_t st = nsub > 1 ? c->sub_stream[sb] : st0;
+        if (nsub > 1) HIPCHK(c, hipStreamWaitEvent(st, c->fork_ev, 0));
+        DevParams P = c->P;
+        P.nframes = Fs;
+        const size_t MC = (size_t)P.maxCands, MM = (size_t)P.maxMarkers;
+        const uint8_t *g = gray + (long long)f0 * gfstride;
+        uint32_t *masks = c->d_masks + (size_t)f0 * P.nscales * P.TR * P.TC * MT_ROWS;
+        uint2 *starts = c->d_starts + (size_t)f0 * P.maxStarts, *surv1 = c->d_surv1 + (size_t)f0 * P.maxStarts,
+              *surv = c->d_surv + (size_t)f0 * P.maxStarts;
+        uint4 *contours = c->d_contours + (size_t)f0 * P.maxContours;
+        uint32_t *tab = c->d_ckpts + (size_t)f0 * P.maxContours * chunk_tab_pitch(P);
+        uint32_t *pool = c->d_pool + (size_t)f0 * P.maxChunks * CK;
+        DevCounts *counts = c->d_counts + f0;
+        DevCand *cands = c->d_cands + f0 * MC, *sorted = c->d_sorted + f0 * MC, *filtered = c->d_filtered + f0 * MC;
+        uint32_t *nearb = c->d_near + f0 * MC * (MC / 32);
+        DevIdent *ident = c->d_ident + f0 * MC;
+        fid_marker *pre = c->d_pre + f0 * MM, *markers = c->d_markers + f0 * MM;
+        unsigned *worklist = c->d_worklist + f0 * MC, *nwork = c->d_nwork + sb;
+        hipEvent_t *ev = c->sub_ev[sb];
+        auto mark = [&](int idx) {
+            if (c->profile) (void)hipEventRecord(ev[idx], st);
+        };
+        mark(0);
+        if (to_gray)
+            hipLaunchKernelGGL(k_to_gray, dim3(2048), dim3(256), 0, st, d_src + (long long)f0 * fstride, stride, fstride, (int)enc,
+                               c->d_gray + (size_t)f0 * W * H, W, H, Fs);
+        mark(ST_GRAY + 1);
+        // ---- K1
+        {
+            bool node_table = P.nscales == 13;  // 3, 7, ..., 51: the node defaults (aruco_detect.cpp:690-693)
+            for (int i = 0; i < P.nscales && node_table; i++) node_table = P.win[i] == 3 + 4 * i;
+            if (node_table) {
+                using C = ThrCfg<3, 4, 13>;
+                dim3 grid((W + C::TX - 1) / C::TX, (H + C::TY - 1) / C::TY, Fs);
+                hipLaunchKernelGGL((k_threshold_fixed<3, 4, 13>), grid, dim3(C::NT), C::LDS_BYTES, st, g, gfstride, masks, P);
+            } else {
+                int R = P.rmax, RW = TX + 2 * R, RH = TY + 2 * R, PT = (RW + 1) | 1;
+                size_t lds = (size_t)(RH + 1) * PT * sizeof(uint32_t);
+                dim3 grid((W + TX - 1) / TX, (H + TY - 1) / TY, Fs);
+                hipLaunchKernelGGL((k_threshold<TX, TY, NT>), grid, dim3(NT), lds, st, g, gfstride, masks, P);
+            }
+        }
+        mark(ST_THRESH + 1);
+        // ---- K2
+        {
+            long long groups = (long long)P.nscales * P.TR * ((P.WW + 15) / 16);  // one wave per group
+            long long blocks = (groups + 3) / 4;
+            if (blocks > 256) blocks = 256;
+            hipLaunchKernelGGL(k_find_starts, dim3((unsigned)blocks, Fs), dim3(256), 0, st, masks, starts, counts, c->d_global, P);
+        }
+        mark(ST_STARTS + 1);
+        // ---- K3: sieve the starts twice, then walk the survivors to the end
+        hipLaunchKernelGGL((k_probe<PROBE0_STEPS, 0>), dim3(64, Fs), dim3(256), 0, st, masks, starts, surv1, counts, c->d_global, P);
+        hipLaunchKernelGGL((k_probe<PROBE1_STEPS, 1>), dim3(16, Fs), dim3(256), 0, st, masks, surv1, surv, counts, c->d_global, P);
+        mark(ST_PROBE + 1);
+        {
+            // persistent one-wave workgroups pulling survivors from per-frame queues: about one full residency of the chip
+            int wb = c->walk_blocks > 0 ? c->walk_blocks : (2048 + Fs - 1) / Fs;
+            wb = wb < 8 ? 8 : (wb > 64 ? 64 : wb);
+            hipLaunchKernelGGL(k_walk_full, dim3(wb, Fs), dim3(64), 0, st, masks, surv, contours, tab, pool, counts, c->d_global, P);
+        }
+        mark(ST_WALK + 1);
+        // ---- K4: short contours with a small LDS footprint first, then the long / flagged ones
+        {
+            int cap1 = pts_cap_first(P);
+            size_t lds1 = (size_t)cap1 * sizeof(uint32_t) + (size_t)K4_SHORT_STACK * sizeof(int2);
+            hipLaunchKernelGGL(k_approx, dim3(128, Fs), dim3(64), lds1, st, contours, tab, pool, cands, counts, c->d_global, P, cap1,
+                               K4_SHORT_STACK, 0);
+            size_t lds2 = (size_t)(P.maxPerim + 1) * sizeof(uint32_t) + (size_t)K4_LONG_STACK * sizeof(int2);
+            hipLaunchKernelGGL(k_approx, dim3(16, Fs), dim3(64), lds2, st, contours, tab, pool, cands, counts, c->d_global, P,
+                               P.maxPerim + 1, K4_LONG_STACK, 1);
+        }
+        mark(ST_APPROX + 1);
+        // ---- K5
+        hipLaunchKernelGGL(k_sort_cands, dim3(Fs), dim3(256), MC * 8, st, cands, sorted, counts, P);
+        mark(ST_SORT + 1);
+        hipLaunchKernelGGL(k_near, dim3(32, Fs), dim3(256), 0, st, sorted, nearb, counts, P);
+        mark(ST_NEAR + 1);
+        hipLaunchKernelGGL(k_resolve, dim3(Fs), dim3(64), MC * 4, st, sorted, nearb, filtered, counts, worklist, nwork, P);
+        mark(ST_RESOLVE + 1);
+        // ---- K6
+        {
+            int SZ = (P.markerSize + 2 * P.borderBits) * P.cellSize;
+            hipLaunchKernelGGL(k_identify, dim3(256 * 4), dim3(64), (size_t)SZ * SZ, st, g, gfstride, filtered, worklist, nwork,
+                               c->d_dict, ident, P);
+        }
+        mark(ST_IDENT + 1);
+        // ---- K7
+        hipLaunchKernelGGL(k_filter_markers, dim3(Fs), dim3(64), MC * sizeof(fid_marker), st, filtered, ident, pre, counts, P);
+        mark(ST_FILTER + 1);
+        {
+            long long items = (long long)Fs * P.maxMarkers * 4;
+            int blocks = (int)(items < 256 * 16 ? items : 256 * 16);
+            hipLaunchKernelGGL(k_subpix, dim3(blocks), dim3(64), 0, st, g, gfstride, pre, markers, counts, c->d_subpix_mask, P);
+        }
+        mark(ST_SUBPIX + 1);
+        if (nsub > 1) {
+            HIPCHK(c, hipEventRecord(c->sub_done[sb], st));
+            HIPCHK(c, hipStreamWaitEvent(st0, c->sub_done[sb], 0));
+        }
     }
-    mark(c, ST_IDENT + 1);
-    // ---- K7
-    hipLaunchKernelGGL(k_filter_markers, dim3(F), dim3(64), (size_t)P.maxCands * sizeof(fid_marker), st, c->d_filtered,
-                       c->d_ident, c->d_pre, c->d_counts, P);
-    mark(c, ST_FILTER + 1);
-    {
-        long long items = (long long)F * P.maxMarkers * 4;
-        int blocks = (int)(items < 256 * 16 ? items : 256 * 16);
-        hipLaunchKernelGGL(k_subpix, dim3(blocks), dim3(64), 0, st, gray, gfstride, c->d_pre, c->d_markers, c->d_counts,
-                           c->d_subpix_mask, P);
-    }
-    mark(c, ST_SUBPIX + 1);
+    hipStream_t st = st0;
+    const DevParams &P = c->P;
     HIPCHK(c, hipGetLastError());
     // ---- results
     HIPCHK(c, hipMemcpyAsync(c->h_counts, c->d_counts, sizeof(DevCounts) * F, hipMemcpyDeviceToHost, st));
@@ -332,13 +364,14 @@ fid_status run_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H, int
     c->last_gray = gray;
     c->last_gfstride = gfstride;
     if (c->profile) {
-        for (int i = 0; i < ST_COUNT; i++) {
-            c->stage_ms[i] = 0.f;
-            // elapsed from the previous valid event
-            int prev = i;
-            while (prev > 0 && !c->ev_valid[prev]) prev--;
-            if (c->ev_valid[i + 1] && c->ev_valid[prev]) (void)hipEventElapsedTime(&c->stage_ms[i], c->ev[prev], c->ev[i + 1]);
-        }
+        // a stage's time = its event-bracketed time on its own stream, summed over the sub-batches (with more than
+        // one sub-batch the brackets of different streams overlap in wall time)
+        for (int i = 0; i < ST_COUNT; i++) c->stage_ms[i] = 0.f;
+        for (int sb = 0; sb < c->last_nsub; sb++)
+            for (int i = 0; i <= ST_SUBPIX; i++) {
+                float ms = 0.f;
+                if (hipEventElapsedTime(&ms, c->sub_ev[sb][i], c->sub_ev[sb][i + 1]) == hipSuccess) c->stage_ms[i] += ms;
+            }
     }
 #ifdef FID_DEBUG_STATS
     {
@@ -453,6 +486,7 @@ fid_status fid_create(const fid_params *params, const fid_dict *dict, const fid_
     size_t dbytes = (size_t)dict->n_markers * 4 * ((dict->marker_size * dict->marker_size + 7) / 8);
     c->dict_host.assign(dict->bytes, dict->bytes + dbytes);
     c->profile = getenv("FID_PROFILE") && atoi(getenv("FID_PROFILE")) != 0;
+    if (getenv("FID_SUB_FRAMES")) c->sub_frames = atoi(getenv("FID_SUB_FRAMES"));
     if (getenv("FID_WALK_BLOCKS")) c->walk_blocks = atoi(getenv("FID_WALK_BLOCKS")) > 0 ? atoi(getenv("FID_WALK_BLOCKS")) : c->walk_blocks;
     memset(&c->P, 0, sizeof(c->P));
 
@@ -477,6 +511,12 @@ fid_status fid_create(const fid_params *params, const fid_dict *dict, const fid_
     TRYHIP(hipSetDevice(device));
     TRYHIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     for (int i = 0; i <= ST_COUNT; i++) TRYHIP(hipEventCreate(&c->ev[i]));
+    TRYHIP(hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming));
+    for (int sb = 0; sb < fid_ctx::MAX_SUB; sb++) {
+        TRYHIP(hipStreamCreateWithFlags(&c->sub_stream[sb], hipStreamNonBlocking));
+        TRYHIP(hipEventCreateWithFlags(&c->sub_done[sb], hipEventDisableTiming));
+        for (int i = 0; i < 16; i++) TRYHIP(hipEventCreate(&c->sub_ev[sb][i]));
+    }
     const size_t F = L.max_batch, MC = L.max_candidates_per_frame, MM = L.max_markers_per_frame;
     TRY(dalloc(c, &c->d_subpix_mask, (size_t)(2 * SP_MAXWIN + 1) * (2 * SP_MAXWIN + 1)));
     TRY(dalloc(c, &c->d_dict, dbytes));
@@ -511,7 +551,7 @@ fid_status fid_create(const fid_params *params, const fid_dict *dict, const fid_
     TRY(dalloc(c, &c->d_counts, F));
     TRY(dalloc(c, &c->d_global, 1));
     TRY(dalloc(c, &c->d_worklist, F * MC));
-    TRY(dalloc(c, &c->d_nwork, 1));
+    TRY(dalloc(c, &c->d_nwork, fid_ctx::MAX_SUB));
     TRY(dalloc(c, &c->d_pose_n, 1));
     TRYHIP(hipHostMalloc((void **)&c->h_markers, sizeof(fid_marker) * F * MM, hipHostMallocDefault));
     TRYHIP(hipHostMalloc((void **)&c->h_counts, sizeof(DevCounts) * F, hipHostMallocDefault));
@@ -545,6 +585,14 @@ void fid_destroy(fid_ctx *c)
         if (p) (void)hipHostFree(p);
     for (int i = 0; i <= ST_COUNT; i++)
         if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    if (c->fork_ev) (void)hipEventDestroy(c->fork_ev);
+    for (int sb = 0; sb < fid_ctx::MAX_SUB; sb++) {
+        if (c->sub_stream[sb]) (void)hipStreamSynchronize(c->sub_stream[sb]);
+        if (c->sub_done[sb]) (void)hipEventDestroy(c->sub_done[sb]);
+        for (int i = 0; i < 16; i++)
+            if (c->sub_ev[sb][i]) (void)hipEventDestroy(c->sub_ev[sb][i]);
+        if (c->sub_stream[sb]) (void)hipStreamDestroy(c->sub_stream[sb]);
+    }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }

@@ -46,6 +46,22 @@ ALGO_BYTES = {
     "approx": MASK_BYTES,             # K4: contour points of the accepted borders (priced as the masks they came from)
 }
 PIPELINE_BYTES = W * H + 2 * MASK_BYTES  # 8 812 800 B/frame
+KERNEL_OF = {"threshold": "k_threshold_fixed", "find_starts": "k_find_starts", "walk_probe": "k_probe",
+             "walk_full": "k_walk_full", "approx": "k_approx"}
+
+
+def pmc_traffic(stage, frames_per_launch):
+    """HBM bytes per launch of a stage's kernel from the committed rocprofv3 PMC passes (profiles/*pmc_traffic.json:
+    FETCH_SIZE / WRITE_SIZE per frame, collected in their own --pmc runs as MI355X_MICROARCH.md prescribes; the file
+    records the corrections applied).  None when no PMC pass has been recorded for that kernel."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as fh:
+            t = json.load(fh)["per_frame_bytes"].get(stage)
+        return None if t is None else int(t * frames_per_launch)
+    except Exception:
+        return None
+
 
 
 def _gen_one(args):
@@ -207,9 +223,11 @@ def main():
 
     if rank == 0:
         stage_ms = {k: v / max(args.steps, 1) for k, v in stage_acc.items()}
+        launches = max(det.last_launches(), 1)  # sub-batches on separate streams: every kernel is launched this often per step
+        frames_per_launch = B / launches
         dom = max((k for k in stage_ms if k in ALGO_BYTES), key=lambda k: stage_ms[k])
-        dom_ms = stage_ms[dom]
-        achieved = ALGO_BYTES[dom] * B / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        dom_ms = stage_ms[dom] / launches  # average launch duration (hipEvents on the launching stream)
+        achieved = ALGO_BYTES[dom] * frames_per_launch / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         out = {
             "metric": "frames/sec @1920x1080 20-marker (aruco detect + pose hot path)",
             "value": round(fps, 2),
@@ -233,14 +251,15 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "k_" + dom,
+                "kernel": KERNEL_OF.get(dom, "k_" + dom),
                 "achieved": round(achieved, 2),
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5),
-                "traffic": None,
-                "algo_bytes_per_launch": ALGO_BYTES[dom] * B,
+                "traffic": pmc_traffic(dom, frames_per_launch),
+                "algo_bytes_per_launch": int(ALGO_BYTES[dom] * frames_per_launch),
                 "kernel_ms_per_launch": round(dom_ms, 4),
+                "launches_per_step": launches,
                 "pipeline": {
                     "algo_bytes_per_frame": PIPELINE_BYTES,
                     "achieved": round(fps / n_gpus * PIPELINE_BYTES / 1e9, 2),

@@ -69,7 +69,7 @@ TAP_MASKS, TAP_CANDIDATES, TAP_FILTERED, TAP_BITS, TAP_IDENT, TAP_PRESUBPIX, TAP
 SYMBOLS = [
     "fid_default_params", "fid_default_limits", "fid_create", "fid_destroy", "fid_set_params", "fid_detect",
     "fid_detect_batch", "fid_detect_device", "fid_pose", "fid_pose_last", "fid_tap_bytes", "fid_tap_read",
-    "fid_last_stage_ms", "fid_stream", "fid_strerror", "fid_last_error", "fid_abi_version",
+    "fid_last_stage_ms", "fid_last_launches", "fid_stream", "fid_strerror", "fid_last_error", "fid_abi_version",
 ]
 
 _LIB = None
@@ -114,6 +114,8 @@ def load():
     L.fid_tap_read.argtypes = [vp, C.c_int, vp, i64]
     L.fid_last_stage_ms.argtypes = [vp, C.POINTER(C.c_float), i32, C.POINTER(C.POINTER(C.c_char_p))]
     L.fid_last_stage_ms.restype = i32
+    L.fid_last_launches.argtypes = [vp]
+    L.fid_last_launches.restype = i32
     L.fid_stream.argtypes = [vp]
     L.fid_stream.restype = vp
     L.fid_strerror.argtypes = [C.c_int]

@@ -837,6 +837,8 @@ int32_t fid_last_stage_ms(fid_ctx *c, float *ms, int32_t cap, const char *const 
     return ST_COUNT;
 }
 
+int32_t fid_last_launches(fid_ctx *c) { return c ? c->last_nsub : 0; }
+
 void *fid_stream(fid_ctx *c) { return c ? (void *)c->stream : nullptr; }
 
 const char *fid_strerror(fid_status s)

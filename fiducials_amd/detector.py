@@ -223,6 +223,10 @@ class ArucoDetector:
         n = self._L.fid_last_stage_ms(self._ctx, ms, 32, C.byref(names))
         return {names[i].decode(): float(ms[i]) for i in range(n)}
 
+    def last_launches(self) -> int:
+        """Launches per kernel in the last detect call (sub-batches on separate streams)."""
+        return int(self._L.fid_last_launches(self._ctx))
+
     @property
     def stream(self) -> int:
         return int(self._L.fid_stream(self._ctx) or 0)

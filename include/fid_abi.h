@@ -170,9 +170,14 @@ typedef struct fid_candidate {
 int64_t fid_tap_bytes(fid_ctx *ctx, fid_tap which);
 fid_status fid_tap_read(fid_ctx *ctx, fid_tap which, void *dst, int64_t dst_bytes);
 
-/* timing of the last call's kernels on the context stream, measured with hipEvents (ms); names is a
- * static table of nstages strings.  Returns the number of stages. */
+/* timing of the last call's kernels, measured with hipEvents on the streams they were launched on (ms, needs
+ * FID_PROFILE=1 in the environment at fid_create); names is a static table of nstages strings.  Returns the
+ * number of stages. */
 int32_t fid_last_stage_ms(fid_ctx *ctx, float *ms, int32_t cap, const char *const **names);
+/* how many launches of each kernel the last fid_detect* call made: a large batch is cut into sub-batches that run
+ * on separate streams so that the latency-bound tail of one overlaps the bulk of the next (stage times above are
+ * summed over these launches) */
+int32_t fid_last_launches(fid_ctx *ctx);
 
 /* the HIP stream the context launches on (hipStream_t as void*), for callers that bracket it with events */
 void *fid_stream(fid_ctx *ctx);

@@ -44,6 +44,12 @@ struct fid_ctx {
     int masks_W = 0, masks_H = 0, masks_S = 0;
     uint2 *d_starts = nullptr, *d_surv1 = nullptr, *d_surv = nullptr;
     uint32_t *d_pool = nullptr;
+    // segment tracing
+    DevSeg *d_segs = nullptr;
+    uint2 *d_hash = nullptr;
+    uint32_t *d_cseed = nullptr, *d_cbase = nullptr, *d_dense = nullptr;
+    int hash_size = 0;
+    bool legacy_trace = false;  // FID_TRACE=legacy: probe passes + whole-border walk instead of segment tracing
     int max_chunks = 0;
     int walk_blocks = 0;  // one-wave workgroups per frame in the full walk pass (0 = automatic)
     uint4 *d_contours = nullptr;
@@ -188,6 +194,7 @@ void set_geometry(fid_ctx *c, int W, int H, int gstride, int F)
     P.maxCands = c->lim.max_candidates_per_frame;
     P.maxMarkers = c->lim.max_markers_per_frame;
     P.maxChunks = c->max_chunks;
+    P.hashSize = c->hash_size;
 }
 
 size_t masks_elems(const fid_ctx *c, int W, int H, int F)
@@ -293,35 +300,58 @@ fid_status run_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H, int
         }
         mark(ST_THRESH + 1);
         // ---- K2
+        long long k2blocks;
         {
             long long groups = (long long)P.nscales * P.TR * ((P.WW + 15) / 16);  // one wave per group
-            long long blocks = (groups + 3) / 4;
-            if (blocks > 256) blocks = 256;
-            hipLaunchKernelGGL(k_find_starts, dim3((unsigned)blocks, Fs), dim3(256), 0, st, masks, starts, counts, c->d_global, P);
+            k2blocks = (groups + 3) / 4;
+            if (k2blocks > 256) k2blocks = 256;
         }
-        mark(ST_STARTS + 1);
-        // ---- K3: sieve the starts twice, then walk the survivors to the end
-        hipLaunchKernelGGL((k_probe<PROBE0_STEPS, 0>), dim3(64, Fs), dim3(256), 0, st, masks, starts, surv1, counts, c->d_global, P);
-        hipLaunchKernelGGL((k_probe<PROBE1_STEPS, 1>), dim3(16, Fs), dim3(256), 0, st, masks, surv1, surv, counts, c->d_global, P);
-        mark(ST_PROBE + 1);
-        {
-            // persistent one-wave workgroups pulling survivors from per-frame queues: about one full residency of the chip
-            int wb = c->walk_blocks > 0 ? c->walk_blocks : (2048 + Fs - 1) / Fs;
-            wb = wb < 8 ? 8 : (wb > 64 ? 64 : wb);
-            hipLaunchKernelGGL(k_walk_full, dim3(wb, Fs), dim3(64), 0, st, masks, surv, contours, tab, pool, counts, c->d_global, P);
-        }
-        mark(ST_WALK + 1);
-        // ---- K4: short contours with a small LDS footprint first, then the long / flagged ones
-        {
-            int cap1 = pts_cap_first(P);
-            size_t lds1 = (size_t)cap1 * sizeof(uint32_t) + (size_t)K4_SHORT_STACK * sizeof(int2);
+        int wb = c->walk_blocks > 0 ? c->walk_blocks : (2048 + Fs - 1) / Fs;  // persistent walker waves per frame
+        wb = wb < 8 ? 8 : (wb > 64 ? 64 : wb);
+        const int cap1 = pts_cap_first(P);
+        const size_t lds1 = (size_t)cap1 * sizeof(uint32_t) + (size_t)K4_SHORT_STACK * sizeof(int2);
+        const size_t lds2 = (size_t)(P.maxPerim + 1) * sizeof(uint32_t) + (size_t)K4_LONG_STACK * sizeof(int2);
+        if (c->legacy_trace) {
+            hipLaunchKernelGGL(k_find_starts<false>, dim3((unsigned)k2blocks, Fs), dim3(256), 0, st, masks, starts, counts, c->d_global,
+                               (uint2 *)nullptr, P);
+            mark(ST_STARTS + 1);
+            // ---- K3: sieve the starts twice, then walk the survivors to the end
+            hipLaunchKernelGGL((k_probe<PROBE0_STEPS, 0>), dim3(64, Fs), dim3(256), 0, st, masks, starts, surv1, counts, c->d_global, P);
+            hipLaunchKernelGGL((k_probe<PROBE1_STEPS, 1>), dim3(16, Fs), dim3(256), 0, st, masks, surv1, surv, counts, c->d_global, P);
+            mark(ST_PROBE + 1);
+            hipLaunchKernelGGL(k_walk_full<false>, dim3(wb, Fs), dim3(64), 0, st, masks, surv, contours, tab, pool, (DevSeg *)nullptr,
+                               counts, c->d_global, P);
+            mark(ST_WALK + 1);
+            // ---- K4: short contours with a small LDS footprint first, then the long / flagged ones
             hipLaunchKernelGGL(k_approx, dim3(128, Fs), dim3(64), lds1, st, contours, tab, pool, cands, counts, c->d_global, P, cap1,
-                               K4_SHORT_STACK, 0);
-            size_t lds2 = (size_t)(P.maxPerim + 1) * sizeof(uint32_t) + (size_t)K4_LONG_STACK * sizeof(int2);
+                               K4_SHORT_STACK, 0, (const uint32_t *)nullptr, (const uint32_t *)nullptr);
             hipLaunchKernelGGL(k_approx, dim3(16, Fs), dim3(64), lds2, st, contours, tab, pool, cands, counts, c->d_global, P,
-                               P.maxPerim + 1, K4_LONG_STACK, 1);
+                               P.maxPerim + 1, K4_LONG_STACK, 1, (const uint32_t *)nullptr, (const uint32_t *)nullptr);
+            mark(ST_APPROX + 1);
+        } else {
+            // ---- segment tracing: seeds -> short segments -> long segments (windowed) -> link -> chain -> flatten
+            DevSeg *segs = c->d_segs + (size_t)f0 * P.maxStarts;
+            uint2 *hash = c->d_hash + (size_t)f0 * P.hashSize;
+            uint32_t *cseed = c->d_cseed + (size_t)f0 * P.maxContours, *cbase = c->d_cbase + (size_t)f0 * P.maxContours;
+            uint32_t *dense = c->d_dense + (size_t)f0 * P.maxChunks * CK;
+            HIPCHK(c, hipMemsetAsync(hash, 0, sizeof(uint2) * (size_t)Fs * P.hashSize, st));
+            hipLaunchKernelGGL(k_find_starts<true>, dim3((unsigned)k2blocks, Fs), dim3(256), 0, st, masks, starts, counts, c->d_global, hash, P);
+            mark(ST_STARTS + 1);
+            hipLaunchKernelGGL(k_seg_short, dim3(64, Fs), dim3(256), 0, st, masks, starts, surv, segs, counts, c->d_global, P);
+            mark(ST_PROBE + 1);
+            hipLaunchKernelGGL(k_walk_full<true>, dim3(wb, Fs), dim3(64), 0, st, masks, surv, contours, tab, pool, segs, counts,
+                               c->d_global, P);
+            hipLaunchKernelGGL(k_seg_link, dim3(32, Fs), dim3(256), 0, st, starts, segs, hash, counts, c->d_global, P);
+            hipLaunchKernelGGL(k_seg_chain, dim3(32, Fs), dim3(256), 0, st, starts, segs, contours, cseed, counts, c->d_global, P);
+            hipLaunchKernelGGL(k_seg_flatten, dim3(64, Fs), dim3(64), 0, st, segs, contours, cseed, cbase, tab, pool, dense, counts,
+                               c->d_global, P);
+            mark(ST_WALK + 1);
+            hipLaunchKernelGGL(k_approx, dim3(128, Fs), dim3(64), lds1, st, contours, tab, pool, cands, counts, c->d_global, P, cap1,
+                               K4_SHORT_STACK, 0, dense, cbase);
+            hipLaunchKernelGGL(k_approx, dim3(16, Fs), dim3(64), lds2, st, contours, tab, pool, cands, counts, c->d_global, P,
+                               P.maxPerim + 1, K4_LONG_STACK, 1, dense, cbase);
+            mark(ST_APPROX + 1);
         }
-        mark(ST_APPROX + 1);
         // ---- K5
         hipLaunchKernelGGL(k_sort_cands, dim3(Fs), dim3(256), MC * 8, st, cands, sorted, counts, P);
         mark(ST_SORT + 1);
@@ -386,7 +416,7 @@ fid_status run_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H, int
 #endif
     fid_status rc = FID_OK;
     if (c->h_global->overflow) {
-        c->last_error = "internal capacity exceeded (starts/contours/stack/points): raise fid_limits";
+        c->last_error = c->h_global->overflow & 16u ? "internal error: broken segment chain" : "internal capacity exceeded (starts/contours/stack/points): raise fid_limits";
         rc = FID_E_CAPACITY;
     }
     for (int f = 0; f < F; f++) {
@@ -533,6 +563,16 @@ fid_status fid_create(const fid_params *params, const fid_dict *dict, const fid_
     TRY(dalloc(c, &c->d_surv, F * L.max_starts_per_frame));
     c->max_chunks = (L.max_points_per_frame + CK - 1) / CK;
     TRY(dalloc(c, &c->d_pool, F * (size_t)c->max_chunks * CK));
+    c->legacy_trace = getenv("FID_TRACE") && !strcmp(getenv("FID_TRACE"), "legacy");
+    if (!c->legacy_trace) {
+        c->hash_size = 1;
+        while (c->hash_size < 2 * L.max_starts_per_frame) c->hash_size *= 2;
+        TRY(dalloc(c, &c->d_segs, F * L.max_starts_per_frame));
+        TRY(dalloc(c, &c->d_hash, F * (size_t)c->hash_size));
+        TRY(dalloc(c, &c->d_cseed, F * L.max_contours_per_frame));
+        TRY(dalloc(c, &c->d_cbase, F * L.max_contours_per_frame));
+        TRY(dalloc(c, &c->d_dense, F * (size_t)c->max_chunks * CK));
+    }
     TRY(dalloc(c, &c->d_contours, F * L.max_contours_per_frame));
     {
         int maxdim = L.max_width > L.max_height ? L.max_width : L.max_height;
@@ -575,7 +615,7 @@ void fid_destroy(fid_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    void *dev[] = {c->d_in, c->d_gray, c->d_masks, c->d_starts, c->d_surv1, c->d_surv, c->d_pool, c->d_contours, c->d_ckpts, c->d_cands, c->d_sorted, c->d_filtered, c->d_near,
+    void *dev[] = {c->d_in, c->d_gray, c->d_masks, c->d_starts, c->d_surv1, c->d_surv, c->d_pool, c->d_segs, c->d_hash, c->d_cseed, c->d_cbase, c->d_dense, c->d_contours, c->d_ckpts, c->d_cands, c->d_sorted, c->d_filtered, c->d_near,
                    c->d_ident, c->d_pre, c->d_markers, c->d_poses, c->d_counts, c->d_global, c->d_worklist, c->d_nwork, c->d_dict,
                    c->d_subpix_mask, c->d_lens, c->d_pose_in, c->d_pose_n};
     for (void *p : dev)
@@ -807,7 +847,7 @@ fid_status fid_tap_read(fid_ctx *c, fid_tap which, void *dst, int64_t dst_bytes)
         int32_t *o = (int32_t *)dst;
         for (int f = 0; f < F; f++) {
             o[12 * f + 0] = c->h_counts[f].nstarts;
-            o[12 * f + 1] = c->h_counts[f].nsurv < c->P.maxContours ? c->h_counts[f].nsurv : c->P.maxContours;
+            o[12 * f + 1] = c->legacy_trace ? (c->h_counts[f].nsurv < c->P.maxContours ? c->h_counts[f].nsurv : c->P.maxContours) : c->h_counts[f].ncontours;
             o[12 * f + 2] = c->h_counts[f].ncand;
             o[12 * f + 3] = c->h_counts[f].nfilt;
             o[12 * f + 4] = c->h_counts[f].nacc;

@@ -45,6 +45,7 @@ struct DevParams {
     int refine;
     int maxStarts, maxContours, maxCands, maxMarkers;  // per-frame capacities
     int maxChunks;                                     // per-frame pool of CK-point contour chunks
+    int hashSize;                                      // per-frame slots of the seed hash table (power of two)
 };
 
 // word index of padded row yy, word column wi inside one (frame, scale) mask plane of TC tile columns
@@ -67,6 +68,20 @@ struct DevIdent {
     unsigned char bits[FID_MAX_CELLS * FID_MAX_CELLS + 3];
 };
 
+// ---- segment tracing (the default contour path): every start candidate ("seed") follows its border only to the next
+// seed; a chain pass links the segments into whole borders.
+#define SEG_INLINE 10          // points a segment record holds itself; longer segments use pool chunks
+#define SEG_INVALID 0xffffffffu
+struct DevSeg {                // one per seed, 64 bytes
+    uint32_t next_key;         // pixel of the seed state the segment ran into: x | y << 13 (same scale)
+    uint32_t next_idx;         // ... and that seed's index (filled in by k_seg_link)
+    uint32_t n;                // states in the segment (SEG_INVALID: longer than maxPerimeterPixels)
+    uint32_t mout;             // min raster index (pidx) over the segment's pixels
+    uint32_t mhole;            // min raster index over the background 4-neighbours its searches passed over
+    int32_t slot;              // >= 0: long segment, points in the chunks of chunk_tab[slot]; < 0: points inline
+    uint32_t pts[SEG_INLINE];
+};
+
 // per-frame counters
 struct DevCounts {
     int ncand;      // candidates emitted by k_approx
@@ -80,7 +95,7 @@ struct DevCounts {
     int npool;      // point chunks handed out by the full walk pass
     int nwalk;      // survivors handed to walker waves so far (work queue head of the full pass)
     int nsurv1;     // starts that survived the first (short) probe pass
-    int pad;
+    int ndense;     // segment tracing: contour points copied to the dense point array so far
 };
 
 // global counters

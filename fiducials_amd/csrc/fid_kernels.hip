@@ -427,9 +427,16 @@ __device__ __forceinline__ uint32_t fill_toward_lsb(uint32_t seed, uint32_t runs
 // Two kinds of starts are dropped on the spot because their border is shorter than any perimeter gate
 // (when minPerimeterPixels allows it): isolated foreground pixels (a 1-point outer border) and isolated
 // background pixels (a hole border of at most 8 points).
+// SEG = true (segment tracing): the candidates are the pixels a border follower can recognise from the 3x3
+// neighbourhood alone -- outer: foreground with W, NW, N, NE background; hole: foreground with E background and NE
+// foreground -- a superset of the run-level candidates above (the extra ones are never canonical); every
+// candidate is also entered into the frame's pixel -> seed-index hash table.
+__device__ __forceinline__ unsigned seg_hash(unsigned key) { return (key * 2654435761u) >> 7; }
+
+template <bool SEG>
 __global__ __launch_bounds__(256) void k_find_starts(const uint32_t *__restrict__ masks, uint2 *__restrict__ starts,
                                                       DevCounts *__restrict__ counts, DevGlobal *__restrict__ G,
-                                                      const DevParams P)
+                                                      uint2 *__restrict__ hash, const DevParams P)
 {
     __shared__ int s_wsum[4];
     __shared__ unsigned s_base;
@@ -512,6 +519,16 @@ __global__ __launch_bounds__(256) void k_find_starts(const uint32_t *__restrict_
                     }
                     outer[k] = o;
                     hole[k] = (e >> 1) | (en0 << 31);
+                    if (SEG) {
+                        uint32_t so = cur & ~Wst & ~NW & ~u & ~NE;
+                        if (drop1) {
+                            // nobody can walk INTO an isolated pixel, so it may be dropped as a seed too
+                            const uint32_t below = d | (d << 1) | (prevd >> 31) | (d >> 1) | (nextd << 31);
+                            so &= Est | below;
+                        }
+                        outer[k] = so;
+                        hole[k] = cur & ~Est & NE;
+                    }
                     cnt += __popc(outer[k]) + __popc(hole[k]);
                 }
             }
@@ -535,16 +552,28 @@ __global__ __launch_bounds__(256) void k_find_starts(const uint32_t *__restrict_
             for (int k = 0; k < 4; k++) {
                 const uint32_t y = (uint32_t)(yy0 + k - 1);
                 uint32_t o = outer[k], hh = hole[k];
-                while (o) {
-                    int b = __ffs(o) - 1;
-                    o &= o - 1;
-                    if (off < cap) fst[off] = make_uint2((uint32_t)(x_base + b) | (y << 16), meta);
-                    off++;
-                }
-                while (hh) {
-                    int b = __ffs(hh) - 1;
-                    hh &= hh - 1;
-                    if (off < cap) fst[off] = make_uint2((uint32_t)(x_base + b) | (y << 16), meta | (1u << 24));
+                uint32_t both = o | hh;  // (never both at one pixel: outer wants NE background, hole NE foreground)
+                while (both) {
+                    int b = __ffs(both) - 1;
+                    both &= both - 1;
+                    const uint32_t isHole = (hh >> b) & 1u;
+                    if (off < cap) {
+                        fst[off] = make_uint2((uint32_t)(x_base + b) | (y << 16), meta | (isHole << 24));
+                        if (SEG) {
+                            // open addressing, key + 1 so that 0 means empty
+                            const unsigned key = ((uint32_t)(x_base + b) | (y << 13) | ((uint32_t)s << 26)) + 1u;
+                            uint2 *tab = hash + (long long)f * P.hashSize;
+                            unsigned h = seg_hash(key) & (unsigned)(P.hashSize - 1);
+                            for (;;) {
+                                const unsigned prev = atomicCAS(&tab[h].x, 0u, key);
+                                if (prev == 0u) {
+                                    tab[h].y = off;
+                                    break;
+                                }
+                                h = (h + 1) & (unsigned)(P.hashSize - 1);
+                            }
+                        }
+                    }
                     off++;
                 }
             }
@@ -769,6 +798,39 @@ __device__ __forceinline__ unsigned raw_to_nb(unsigned raw)
            (raw & 0xe0u);
 }
 
+__device__ __forceinline__ int first_dir(unsigned nb, int s_end)
+{
+    // do { s = (s - 1) & 7; } while (*i1 == 0 && s != s_end)  == first foreground clockwise from s_end - 1
+    const unsigned nb2 = nb | (nb << 8);
+    const int c0 = (s_end - 1) & 7;
+    const unsigned win = (nb2 >> (c0 + 1)) & 0xffu;
+    const int t = 7 - (31 - __clz((int)win));
+    return (c0 - t) & 7;
+}
+
+// step table: index raw | backdir << 8 -> next direction | code << 3 | seed-state flag << 6; code = the smallest-offset
+// background 4-neighbour the search passed over (0 none, else 4 | positive << 1 | whole-row)
+__device__ __forceinline__ void build_step_lut(uint8_t *lut, int tid, int nthreads)
+{
+    for (int e = tid; e < 2048; e += nthreads) {
+        const unsigned raw = (unsigned)e & 0xffu;
+        const unsigned nb = raw_to_nb(raw);
+        const int sd = e >> 8;
+        const int start = (sd + 1) & 7;
+        const unsigned rot = ((nb | (nb << 8)) >> start) & 0xffu;
+        const int t = rot ? __ffs(rot) - 1 : 0;
+        unsigned seen = 0;
+        for (int q = 0; q < t; q++) seen |= 1u << ((start + q) & 7);
+        const int code = (seen & 4u) ? 5 : (seen & 16u) ? 4 : (seen & 1u) ? 6 : (seen & 64u) ? 7 : 0;
+        int seed = 0;
+        if (nb) {
+            if ((raw & 0x0fu) == 0u) seed = sd == first_dir(nb, 4);                    // outer: W, NW, N, NE background
+            else if (!(raw & 0x10u) && (raw & 0x04u)) seed = sd == first_dir(nb, 0);  // hole: E background, NE foreground
+        }
+        lut[e] = (uint8_t)(((start + t) & 7) | (code << 3) | (seed << 6));
+    }
+}
+
 // raw 3x3 neighbourhood byte of pixel (cx, cy) read from lane `lane`'s window (origin: pixel column wx0 of
 // bit 0, padded row wy0 of window row 0)
 __device__ __forceinline__ unsigned win_raw(const uint32_t *s_winw, int lane4, int cx, int cy, int wx0, int wy0)
@@ -787,10 +849,13 @@ __device__ __forceinline__ unsigned win_raw(const uint32_t *s_winw, int lane4, i
     return (t3[0] & 7u) | ((t3[1] & 1u) << 3) | ((t3[1] & 4u) << 2) | ((t3[2] & 7u) << 5);
 }
 
+// SEG = false: a walker follows a whole border from a probe survivor and applies the canonical-start test as it goes.
+// SEG = true:  a walker follows one SEGMENT, from its seed state to the next seed state, and records length and minima.
+template <bool SEG>
 __global__ __launch_bounds__(64) void k_walk_full(const uint32_t *__restrict__ masks, const uint2 *__restrict__ surv,
                                                    uint4 *__restrict__ contours, uint32_t *__restrict__ chunk_tab,
-                                                   uint32_t *__restrict__ pool, DevCounts *__restrict__ counts,
-                                                   DevGlobal *__restrict__ G, const DevParams P)
+                                                   uint32_t *__restrict__ pool, DevSeg *__restrict__ segs,
+                                                   DevCounts *__restrict__ counts, DevGlobal *__restrict__ G, const DevParams P)
 {
     // window chunk j (16 bytes = rows 4q..4q+3 of tile (t, c), j = (c * 2 + t) * 4 + q) of lane l: s_win[j * 64 + l]
     __shared__ uint4 s_win[16 * 64];
@@ -805,19 +870,7 @@ __global__ __launch_bounds__(64) void k_walk_full(const uint32_t *__restrict__ m
 #endif
     const int lane = lane_id();
     const int lane4 = lane * 4;
-    for (int e = lane; e < 2048; e += 64) {
-        const unsigned nb = raw_to_nb((unsigned)e & 0xffu);
-        const int sd = e >> 8;
-        const int start = (sd + 1) & 7;
-        const unsigned rot = ((nb | (nb << 8)) >> start) & 0xffu;
-        const int t = rot ? __ffs(rot) - 1 : 0;
-        unsigned seen = 0;
-        for (int q = 0; q < t; q++) seen |= 1u << ((start + q) & 7);
-        // code: bit 2 = some background 4-neighbour was examined, bit 1 = its raster offset is positive,
-        // bit 0 = the offset is a whole row (N / S) rather than one pixel (W / E); the smallest offset wins
-        const int code = (seen & 4u) ? 5 : (seen & 16u) ? 4 : (seen & 1u) ? 6 : (seen & 64u) ? 7 : 0;
-        s_lut[e] = (uint8_t)(((start + t) & 7) | (code << 3));
-    }
+    build_step_lut(s_lut, lane, 64);
     __syncthreads();
     const unsigned ccap = (unsigned)P.maxContours, pcap = (unsigned)P.maxChunks;
     const int W = P.W, S = P.nscales, TC = P.TC, TR = P.TR, F = P.nframes;
@@ -850,6 +903,8 @@ __global__ __launch_bounds__(64) void k_walk_full(const uint32_t *__restrict__ m
         unsigned chunkA = 0, chunkB = 0;  // pool chunks of the even / odd 64-point blocks around `count`
         int kreg = 0;                     // highest block index that has a chunk
         unsigned ovf = 0;
+        unsigned seed_idx = 0, mout = 0xffffffffu, mhole = 0xffffffffu;  // SEG: the walker's seed and its running minima
+        int too_long = 0;
         unsigned arena_next = 0, arena_end = 0;  // wave-uniform
 #ifdef FID_DEBUG_STATS
         unsigned long long d_iters = 0, d_ckpts = 0, d_active = 0, d_ckcyc = 0, d_waitcyc = 0, d_forced = 0;
@@ -877,18 +932,13 @@ __global__ __launch_bounds__(64) void k_walk_full(const uint32_t *__restrict__ m
                         fpool[chunkA * CK] = (uint32_t)x0 | ((uint32_t)y0 << 16);
                         count = 1;
                         closed = 1;
+                        mout = (unsigned)pc;
                         state = ST_FINAL;
                     } else {
-                        const unsigned nb = raw_to_nb(raw);
-                        const int s_end = hole ? 0 : 4;
-                        const unsigned nb2 = nb | (nb << 8);
-                        const int c0 = (s_end - 1) & 7;
-                        const unsigned win = (nb2 >> (c0 + 1)) & 0xffu;
-                        const int t = 7 - (31 - __clz((int)win));
-                        sdir = (c0 - t) & 7;
+                        sdir = first_dir(raw_to_nb(raw), hole ? 0 : 4);
                         i1x = x0 + dir_dx(sdir);
                         i1y = y0 + dir_dy(sdir);
-                        if (!hole && pidx(i1x, i1y, W) < key) {
+                        if (!SEG && !hole && pidx(i1x, i1y, W) < key) {
                             ok = 0;
                             state = ST_FINAL;
                         }
@@ -898,12 +948,22 @@ __global__ __launch_bounds__(64) void k_walk_full(const uint32_t *__restrict__ m
             if ((state == ST_ACTIVE || state == ST_NEED) && count > P.maxPerim) {
                 // checked here, not per step: a walk overshoots by at most WALK_RUN points
                 ok = 0;
+                too_long = 1;
                 state = ST_FINAL;
             }
             // ---- retire finished walkers
             if (state == ST_FINAL) {
-                const int accept = ok && closed && count >= P.minPerim && count <= P.maxPerim;
-                fco[slot] = make_uint4(st.x, st.y, accept ? (unsigned)count : 0u, (unsigned)key);
+                if (SEG) {
+                    DevSeg *r = segs + (long long)f * P.maxStarts + seed_idx;
+                    r->next_key = (uint32_t)cx | ((uint32_t)cy << 13);  // the seed state the walk stopped in front of
+                    r->n = too_long || !ok ? SEG_INVALID : (unsigned)count;
+                    r->mout = mout;
+                    r->mhole = mhole;
+                    r->slot = (int)slot;
+                } else {
+                    const int accept = ok && closed && count >= P.minPerim && count <= P.maxPerim;
+                    fco[slot] = make_uint4(st.x, st.y, accept ? (unsigned)count : 0u, (unsigned)key);
+                }
                 state = ST_IDLE;
 #ifdef FID_DEBUG_STATS
                 atomicMax(&G->dbg[13], (unsigned long long)count);
@@ -940,10 +1000,21 @@ __global__ __launch_bounds__(64) void k_walk_full(const uint32_t *__restrict__ m
                         slot = next + (unsigned)rank;  // the contour slot is the survivor's index
                         if (slot < ccap) {
                             st = make_uint2(gx, gy);
-                            x0 = st.x & 0xffff;
-                            y0 = st.x >> 16;
-                            const int s = (st.y >> 16) & 0xff;
-                            hole = (st.y >> 24) & 1;
+                            int s;
+                            if (SEG) {  // x | y << 13 | hole << 26 | scale << 27, seed index
+                                x0 = gx & 0x1fff;
+                                y0 = (gx >> 13) & 0x1fff;
+                                hole = (gx >> 26) & 1;
+                                s = gx >> 27;
+                                seed_idx = gy;
+                                mout = mhole = 0xffffffffu;
+                                too_long = 0;
+                            } else {
+                                x0 = st.x & 0xffff;
+                                y0 = st.x >> 16;
+                                s = (st.y >> 16) & 0xff;
+                                hole = (st.y >> 24) & 1;
+                            }
                             pl = masks + ((long long)f * S + s) * plane;
                             key = hole ? pidx(x0 + 1, y0, W) : pidx(x0, y0, W);
                             count = 0;
@@ -986,7 +1057,8 @@ __global__ __launch_bounds__(64) void k_walk_full(const uint32_t *__restrict__ m
                         if (mine + 1 >= pcap) {
                             ovf |= 8u;
                             ok = 0;
-                            fco[slot] = make_uint4(st.x, st.y, 0u, (unsigned)key);
+                            if (SEG) segs[(long long)f * P.maxStarts + seed_idx].n = SEG_INVALID;
+                            else fco[slot] = make_uint4(st.x, st.y, 0u, (unsigned)key);
                             state = ST_IDLE;
                         } else if (fresh) {
                             chunkA = mine;
@@ -1051,29 +1123,51 @@ __global__ __launch_bounds__(64) void k_walk_full(const uint32_t *__restrict__ m
                 if (state == ST_ACTIVE) {
                     const unsigned raw = win_raw(s_winw, lane4, cx, cy, wx0, wy0);
                     const unsigned e = s_lut[raw | ((unsigned)sdir << 8)];
-                    const int sn = e & 7, code = e >> 3;
-                    // background pixels examined in the 4-directions belong to this border's hole region
+                    const int sn = e & 7, code = (e >> 3) & 7;
                     const int hmag = (code & 1) ? W2 : 1;
                     const int hoff = (code & 2) ? hmag : -hmag;
-                    int bad = hole && code && (pc + hoff < key);
-                    if (!bad) fpool[((count & CK ? chunkB : chunkA) << 6) + (unsigned)(count & (CK - 1))] = (uint32_t)cx | ((uint32_t)cy << 16);
-                    count++;
-                    const int dx = dir_dx(sn), dy = dir_dy(sn);
-                    const int nx = cx + dx, ny = cy + dy;
-                    const int cl = !bad && nx == x0 && ny == y0 && cx == i1x && cy == i1y;
-                    cx = nx;
-                    cy = ny;
-                    pc += __mul24(dy, W2) + dx;
-                    bad |= !cl && !hole && pc < key;
-                    sdir = (sn + 4) & 7;
-                    ndx = dx;
-                    ndy = dy;
-                    // still inside the window?  bits of x-1..x+1 in [0, 64), padded rows cy..cy+2 in [0, 32)
-                    const unsigned xr = (unsigned)(cx + (MASK_PADW * 32 - 1) - wx0), rr = (unsigned)(cy - wy0);
-                    const int outside = xr > 61u || rr > 29u;
-                    closed = cl;
-                    ok = !bad;
-                    state = (bad || cl) ? ST_FINAL : outside ? ST_NEED : ST_ACTIVE;
+                    if (SEG) {
+                        if (count > 0 && (e & 0x40u)) {
+                            closed = 1;  // the next seed state: the segment ends in front of it
+                            state = ST_FINAL;
+                        } else {
+                            const unsigned hv = code ? (unsigned)(pc + hoff) : 0xffffffffu;
+                            mhole = hv < mhole ? hv : mhole;
+                            mout = (unsigned)pc < mout ? (unsigned)pc : mout;
+                            fpool[((count & CK ? chunkB : chunkA) << 6) + (unsigned)(count & (CK - 1))] = (uint32_t)cx | ((uint32_t)cy << 16);
+                            count++;
+                            const int dx = dir_dx(sn), dy = dir_dy(sn);
+                            cx += dx;
+                            cy += dy;
+                            pc += __mul24(dy, W2) + dx;
+                            sdir = (sn + 4) & 7;
+                            ndx = dx;
+                            ndy = dy;
+                            const unsigned xr = (unsigned)(cx + (MASK_PADW * 32 - 1) - wx0), rr = (unsigned)(cy - wy0);
+                            state = (xr > 61u || rr > 29u) ? ST_NEED : ST_ACTIVE;
+                        }
+                    } else {
+                        // background pixels examined in the 4-directions belong to this border's hole region
+                        int bad = hole && code && (pc + hoff < key);
+                        if (!bad) fpool[((count & CK ? chunkB : chunkA) << 6) + (unsigned)(count & (CK - 1))] = (uint32_t)cx | ((uint32_t)cy << 16);
+                        count++;
+                        const int dx = dir_dx(sn), dy = dir_dy(sn);
+                        const int nx = cx + dx, ny = cy + dy;
+                        const int cl = !bad && nx == x0 && ny == y0 && cx == i1x && cy == i1y;
+                        cx = nx;
+                        cy = ny;
+                        pc += __mul24(dy, W2) + dx;
+                        bad |= !cl && !hole && pc < key;
+                        sdir = (sn + 4) & 7;
+                        ndx = dx;
+                        ndy = dy;
+                        // still inside the window?  bits of x-1..x+1 in [0, 64), padded rows cy..cy+2 in [0, 32)
+                        const unsigned xr = (unsigned)(cx + (MASK_PADW * 32 - 1) - wx0), rr = (unsigned)(cy - wy0);
+                        const int outside = xr > 61u || rr > 29u;
+                        closed = cl;
+                        ok = !bad;
+                        state = (bad || cl) ? ST_FINAL : outside ? ST_NEED : ST_ACTIVE;
+                    }
                 }
             }
         }
@@ -1122,6 +1216,280 @@ __global__ __launch_bounds__(64) void k_walk_full(const uint32_t *__restrict__ m
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------
+// Segment tracing.  A border-following state is (pixel, direction back to the previous pixel); one step maps a state to the
+// next one and does not depend on how the walk was started, so a border is a cycle of states.  Every seed (k_find_starts<true>)
+// owns the states from its own start state up to, but not including, the next seed state on the cycle.  Whether a state is
+// a seed state is a function of the 3x3 neighbourhood and the back direction alone (bit 6 of the step table): the pixel
+// satisfies a seed predicate and the back direction equals the one icvFetchContour would start that seed with.
+//   k_seg_short   every seed, at most SEG_INLINE steps (plain loads); finished segments keep their points in the record,
+//                 the others go to the survivor list
+//   k_walk_full<true>   survivors, windowed, points in pool chunks
+//   k_seg_link    next seed pixel -> seed index (hash look-up)
+//   k_seg_chain   every seed as a candidate start of its type: follow the segment chain, accumulate length and the two
+//                 running minima; stop as soon as the start cannot be canonical (a smaller key on the border) or the border
+//                 is too long; a closed chain that passes the perimeter gate is an accepted contour
+//   k_seg_flatten one wave per accepted contour: copy the points of its segments, in order, into a dense array
+// The acceptance test is the one k_probe / k_walk_full<false> apply while walking (no pixel -- outer -- or examined
+// background 4-neighbour -- hole -- with a raster index below the start's key), evaluated on per-segment minima.
+// raw neighbourhood byte of (x, y) straight from the tiled mask (see win_raw for the bit order)
+__device__ __forceinline__ unsigned raw8(const MaskView &m, int x, int y)
+{
+    const int xb = x - 1 + MASK_PADW * 32;
+    const int wi = xb >> 5, sh = xb & 31;
+    const bool two = sh > 29;
+    const uint32_t *p0 = m.base + mask_word(m.TC, y, wi);
+    const uint32_t *p1 = m.base + mask_word(m.TC, y + 1, wi);
+    const uint32_t *p2 = m.base + mask_word(m.TC, y + 2, wi);
+    const uint32_t a0 = p0[0], a1 = p1[0], a2 = p2[0];
+    uint32_t b0 = 0, b1 = 0, b2 = 0;
+    if (two) {
+        b0 = p0[MT_ROWS];
+        b1 = p1[MT_ROWS];
+        b2 = p2[MT_ROWS];
+    }
+    const unsigned tu = __builtin_amdgcn_alignbit(b0, a0, sh), tm = __builtin_amdgcn_alignbit(b1, a1, sh),
+                   td = __builtin_amdgcn_alignbit(b2, a2, sh);
+    return (tu & 7u) | ((tm & 1u) << 3) | ((tm & 4u) << 2) | ((td & 7u) << 5);
+}
+
+__global__ __launch_bounds__(256) void k_seg_short(const uint32_t *__restrict__ masks, const uint2 *__restrict__ starts,
+                                                    uint2 *__restrict__ surv, DevSeg *__restrict__ segs,
+                                                    DevCounts *__restrict__ counts, DevGlobal *__restrict__ G, const DevParams P)
+{
+    __shared__ uint8_t s_lut[2048];
+    build_step_lut(s_lut, threadIdx.x, 256);
+    __syncthreads();
+    const int f = blockIdx.y;
+    const int lane = lane_id();
+    unsigned n = (unsigned)counts[f].nstarts;
+    n = n < (unsigned)P.maxStarts ? n : (unsigned)P.maxStarts;
+    const int W = P.W, S = P.nscales, W2 = P.W + 2;
+    const long long plane = (long long)P.TR * P.TC * MT_ROWS;
+    const uint2 *fin = starts + (long long)f * P.maxStarts;
+    uint2 *fsv = surv + (long long)f * P.maxStarts;
+    DevSeg *fsg = segs + (long long)f * P.maxStarts;
+    for (unsigned i0 = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); i0 < n; i0 += gridDim.x * blockDim.x) {
+        const unsigned i = i0 + lane;
+        const bool active = i < n;
+        const uint2 st = active ? fin[i] : make_uint2(0u, 0u);
+        const int x0 = st.x & 0xffff, y0 = st.x >> 16;
+        const int s = (st.y >> 16) & 0xff, hole = (st.y >> 24) & 1;
+        MaskView m;
+        m.base = masks + ((long long)f * S + s) * plane;
+        m.TC = P.TC;
+        DevSeg rec;
+        rec.next_idx = 0;
+        rec.slot = -1;
+        rec.mout = 0xffffffffu;
+        rec.mhole = 0xffffffffu;
+        int cnt = 0, done = 0;
+        int cx = x0, cy = y0, pc = pidx(x0, y0, W);
+        unsigned raw = active ? raw8(m, x0, y0) : 0u;
+        if (active) {
+            if (raw == 0) {
+                // single pixel domain: a one-state cycle
+                rec.pts[0] = (uint32_t)x0 | ((uint32_t)y0 << 16);
+                rec.mout = (uint32_t)pc;
+                cnt = 1;
+                done = 1;
+            } else {
+                int sdir = first_dir(raw_to_nb(raw), hole ? 0 : 4);
+#pragma unroll
+                for (int k = 0; k <= SEG_INLINE; k++) {
+                    if (!done) {
+                        const unsigned e = s_lut[raw | ((unsigned)sdir << 8)];
+                        if (k > 0 && (e & 0x40u)) {
+                            done = 1;  // ran into the next seed state (possibly its own)
+                        } else if (k < SEG_INLINE) {
+                            const int sn = e & 7, code = (e >> 3) & 7;
+                            if (code) {
+                                const int hmag = (code & 1) ? W2 : 1;
+                                const unsigned hv = (unsigned)(pc + ((code & 2) ? hmag : -hmag));
+                                rec.mhole = hv < rec.mhole ? hv : rec.mhole;
+                            }
+                            rec.mout = (unsigned)pc < rec.mout ? (unsigned)pc : rec.mout;
+                            rec.pts[k] = (uint32_t)cx | ((uint32_t)cy << 16);
+                            cnt = k + 1;
+                            const int dx = dir_dx(sn), dy = dir_dy(sn);
+                            cx += dx;
+                            cy += dy;
+                            pc += __mul24(dy, W2) + dx;
+                            sdir = (sn + 4) & 7;
+                            raw = raw8(m, cx, cy);
+                        }
+                    }
+                }
+            }
+        }
+        if (active && done) {
+            rec.n = (uint32_t)cnt;
+            rec.next_key = (uint32_t)cx | ((uint32_t)cy << 13);  // the seed state it stopped in front of (itself when closed)
+            fsg[i] = rec;
+        }
+        // longer segments: to the windowed walker (record: x | y << 13 | hole << 26 | scale << 27, seed index)
+        const int keep = active && !done;
+        const unsigned long long mk = ballot64(keep);
+        if (mk) {
+            const int leader = __ffsll((long long)mk) - 1;
+            unsigned base = 0;
+            if (lane == leader) base = atomicAdd((unsigned *)&counts[f].nsurv, (unsigned)__popcll(mk));
+            base = __shfl(base, leader, WAVE);
+            const unsigned idx = base + (unsigned)__popcll(mk & ((1ull << lane) - 1ull));
+            if (keep) {
+                if (idx < (unsigned)P.maxStarts && idx < (unsigned)P.maxContours)
+                    fsv[idx] = make_uint2((uint32_t)x0 | ((uint32_t)y0 << 13) | ((uint32_t)hole << 26) | ((uint32_t)s << 27), i);
+                else
+                    atomicOr(&G->overflow, 2u);
+            }
+        }
+    }
+}
+
+// next seed pixel -> seed index
+__global__ __launch_bounds__(256) void k_seg_link(const uint2 *__restrict__ starts, DevSeg *__restrict__ segs,
+                                                   const uint2 *__restrict__ hash, DevCounts *__restrict__ counts,
+                                                   DevGlobal *__restrict__ G, const DevParams P)
+{
+    const int f = blockIdx.y;
+    unsigned n = (unsigned)counts[f].nstarts;
+    n = n < (unsigned)P.maxStarts ? n : (unsigned)P.maxStarts;
+    const uint2 *fst = starts + (long long)f * P.maxStarts;
+    DevSeg *fsg = segs + (long long)f * P.maxStarts;
+    const uint2 *tab = hash + (long long)f * P.hashSize;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const unsigned s = (fst[i].y >> 16) & 0xffu;
+        const unsigned key = (fsg[i].next_key | (s << 26)) + 1u;
+        unsigned h = seg_hash(key) & (unsigned)(P.hashSize - 1);
+        unsigned idx = SEG_INVALID;
+        for (int probe = 0; probe < P.hashSize; probe++) {
+            const uint2 e = tab[h];
+            if (e.x == key) {
+                idx = e.y;
+                break;
+            }
+            if (e.x == 0u) break;
+            h = (h + 1) & (unsigned)(P.hashSize - 1);
+        }
+        fsg[i].next_idx = idx;
+    }
+}
+
+// every seed as a candidate start: accepted contours are appended to `contours` (start, meta, length, key) with the seed
+// index in cseed[]
+__global__ __launch_bounds__(256) void k_seg_chain(const uint2 *__restrict__ starts, const DevSeg *__restrict__ segs,
+                                                    uint4 *__restrict__ contours, uint32_t *__restrict__ cseed,
+                                                    DevCounts *__restrict__ counts, DevGlobal *__restrict__ G, const DevParams P)
+{
+    const int f = blockIdx.y;
+    const int lane = lane_id();
+    unsigned n = (unsigned)counts[f].nstarts;
+    n = n < (unsigned)P.maxStarts ? n : (unsigned)P.maxStarts;
+    const uint2 *fst = starts + (long long)f * P.maxStarts;
+    const DevSeg *fsg = segs + (long long)f * P.maxStarts;
+    uint4 *fco = contours + (long long)f * P.maxContours;
+    uint32_t *fcs = cseed + (long long)f * P.maxContours;
+    const int W = P.W;
+    for (unsigned i0 = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); i0 < n; i0 += gridDim.x * blockDim.x) {
+        const unsigned i = i0 + lane;
+        int accept = 0;
+        unsigned L = 0;
+        uint2 st = make_uint2(0u, 0u);
+        unsigned key = 0;
+        if (i < n) {
+            st = fst[i];
+            const int x0 = st.x & 0xffff, y0 = st.x >> 16;
+            const int hole = (st.y >> 24) & 1;
+            key = (unsigned)(hole ? pidx(x0 + 1, y0, W) : pidx(x0, y0, W));
+            unsigned cur = i;
+            for (int hops = 0; hops <= P.maxPerim; hops++) {  // (every segment has at least one state)
+                const DevSeg *r = fsg + cur;
+                const unsigned sn = r->n;
+                if (sn == SEG_INVALID || sn == 0u) break;
+                const unsigned mv = hole ? r->mhole : r->mout;
+                if (mv < key) break;  // a smaller key on the border: this start is not the canonical one
+                L += sn;
+                if (L > (unsigned)P.maxPerim) break;
+                const unsigned nx = r->next_idx;
+                if (nx == i) {
+                    accept = L >= (unsigned)P.minPerim;
+                    break;
+                }
+                if (nx == SEG_INVALID) {
+                    atomicOr(&G->overflow, 16u);  // broken chain: a seed state without a seed (must not happen)
+                    break;
+                }
+                cur = nx;
+            }
+        }
+        const unsigned long long mk = ballot64(accept);
+        if (mk) {
+            const int leader = __ffsll((long long)mk) - 1;
+            unsigned base = 0;
+            if (lane == leader) base = atomicAdd((unsigned *)&counts[f].ncontours, (unsigned)__popcll(mk));
+            base = __shfl(base, leader, WAVE);
+            const unsigned idx = base + (unsigned)__popcll(mk & ((1ull << lane) - 1ull));
+            if (accept) {
+                if (idx < (unsigned)P.maxContours) {
+                    fco[idx] = make_uint4(st.x, st.y, L, key);
+                    fcs[idx] = i;
+                } else {
+                    atomicOr(&G->overflow, 2u);
+                }
+            }
+        }
+    }
+}
+
+// one wave per accepted contour: its points, segment by segment, into dense[cbase[ci] ...]
+__global__ __launch_bounds__(64) void k_seg_flatten(const DevSeg *__restrict__ segs, const uint4 *__restrict__ contours,
+                                                     const uint32_t *__restrict__ cseed, uint32_t *__restrict__ cbase,
+                                                     const uint32_t *__restrict__ chunk_tab, const uint32_t *__restrict__ pool,
+                                                     uint32_t *__restrict__ dense, DevCounts *__restrict__ counts,
+                                                     DevGlobal *__restrict__ G, const DevParams P)
+{
+    const int f = blockIdx.y;
+    const int lane = lane_id();
+    unsigned nc = (unsigned)counts[f].ncontours;
+    nc = nc < (unsigned)P.maxContours ? nc : (unsigned)P.maxContours;
+    const DevSeg *fsg = segs + (long long)f * P.maxStarts;
+    const uint4 *fco = contours + (long long)f * P.maxContours;
+    const uint32_t *fcs = cseed + (long long)f * P.maxContours;
+    uint32_t *fcb = cbase + (long long)f * P.maxContours;
+    const int nck = chunk_tab_pitch(P);
+    const uint32_t *ftab = chunk_tab + (long long)f * P.maxContours * nck;
+    const uint32_t *fpool = pool + (long long)f * P.maxChunks * CK;
+    const unsigned dcap = (unsigned)P.maxChunks * CK;
+    uint32_t *fd = dense + (long long)f * dcap;
+    for (unsigned ci = blockIdx.x; ci < nc; ci += gridDim.x) {
+        const unsigned L = fco[ci].z, seed = fcs[ci];
+        unsigned base = 0;
+        if (lane == 0) base = atomicAdd((unsigned *)&counts[f].ndense, L);
+        base = __shfl(base, 0, WAVE);
+        if (base + L > dcap) {
+            if (lane == 0) {
+                atomicOr(&G->overflow, 8u);
+                fcb[ci] = SEG_INVALID;
+            }
+            continue;
+        }
+        if (lane == 0) fcb[ci] = base;
+        unsigned cur = seed, off = 0;
+        do {
+            const DevSeg *r = fsg + cur;
+            const unsigned sn = r->n;
+            const int slot = r->slot;
+            if (slot < 0) {
+                if ((unsigned)lane < sn) fd[base + off + lane] = r->pts[lane];
+            } else {
+                for (unsigned k = lane; k < sn; k += 64) fd[base + off + k] = fpool[(long long)ftab[(long long)slot * nck + (k >> 6)] * CK + (k & 63)];
+            }
+            off += sn;
+            cur = r->next_idx;
+        } while (cur != seed && off < L);
+    }
+}
+
 // points per contour the first (short-LDS) launch of k_approx accepts
 #define K4_SHORT_PTS 2048
 #define K4_SHORT_STACK 256
@@ -1142,14 +1510,16 @@ __device__ __host__ inline int pts_cap_first(const DevParams &P) { return P.maxP
 __global__ __launch_bounds__(64) void k_approx(uint4 *__restrict__ contours, const uint32_t *__restrict__ chunk_tab,
                                                 const uint32_t *__restrict__ pool, DevCand *__restrict__ cands,
                                                 DevCounts *__restrict__ counts, DevGlobal *__restrict__ G, const DevParams P,
-                                                int pts_cap, int stack_cap, int second_pass)
+                                                int pts_cap, int stack_cap, int second_pass, const uint32_t *__restrict__ dense,
+                                                const uint32_t *__restrict__ cbase)
 {
     extern __shared__ uint32_t pts[];  // pts_cap points, then stack_cap slices
     int2 *stack = reinterpret_cast<int2 *>(pts + pts_cap);
     __shared__ int dst[2 * 16];
     const int lane = lane_id();
     const int f = blockIdx.y;
-    unsigned n = (unsigned)counts[f].nsurv;  // contour slot = survivor index
+    // legacy path: contour slot = survivor index; segment tracing (dense != nullptr): the accepted contours, compact
+    unsigned n = (unsigned)(dense ? counts[f].ncontours : counts[f].nsurv);
     n = n < (unsigned)P.maxStarts ? n : (unsigned)P.maxStarts;
     n = n < (unsigned)P.maxContours ? n : (unsigned)P.maxContours;
     const int W = P.W, H = P.H;
@@ -1181,7 +1551,12 @@ __global__ __launch_bounds__(64) void k_approx(uint4 *__restrict__ contours, con
         const int s = (c.y >> 16) & 0xff, hole = (c.y >> 24) & 1;
         __syncthreads();
         // ---- gather the border
-        {
+        if (dense) {
+            const uint32_t cb0 = cbase[(long long)f * P.maxContours + ci];
+            if (cb0 == SEG_INVALID) continue;
+            const uint32_t *src = dense + (long long)f * P.maxChunks * CK + cb0;
+            for (int k = lane; k < count; k += 64) pts[k] = src[k];
+        } else {
             const int nchunks = (count + CK - 1) / CK;
             for (int cb = 0; cb < nchunks; cb += 64) {
                 const uint32_t myc = cb + lane < nchunks ? ftab[(long long)ci * nck + cb + lane] : 0u;

@@ -49,7 +49,7 @@ struct fid_ctx {
     uint2 *d_hash = nullptr;
     uint32_t *d_cseed = nullptr, *d_cbase = nullptr, *d_dense = nullptr;
     int hash_size = 0;
-    bool legacy_trace = false;  // FID_TRACE=legacy: probe passes + whole-border walk instead of segment tracing
+    bool legacy_trace = true;  // probe passes + whole-border walk; FID_TRACE=segments: segment tracing
     int max_chunks = 0;
     int walk_blocks = 0;  // one-wave workgroups per frame in the full walk pass (0 = automatic)
     uint4 *d_contours = nullptr;
@@ -563,7 +563,8 @@ fid_status fid_create(const fid_params *params, const fid_dict *dict, const fid_
     TRY(dalloc(c, &c->d_surv, F * L.max_starts_per_frame));
     c->max_chunks = (L.max_points_per_frame + CK - 1) / CK;
     TRY(dalloc(c, &c->d_pool, F * (size_t)c->max_chunks * CK));
-    c->legacy_trace = getenv("FID_TRACE") && !strcmp(getenv("FID_TRACE"), "legacy");
+    // FID_TRACE=segments selects segment tracing (parity-green, not yet faster than the probe + whole-border walk)
+    c->legacy_trace = !(getenv("FID_TRACE") && !strcmp(getenv("FID_TRACE"), "segments"));
     if (!c->legacy_trace) {
         c->hash_size = 1;
         while (c->hash_size < 2 * L.max_starts_per_frame) c->hash_size *= 2;

@@ -44,12 +44,13 @@ struct fid_ctx {
     int masks_W = 0, masks_H = 0, masks_S = 0;
     uint2 *d_starts = nullptr, *d_surv1 = nullptr, *d_surv = nullptr;
     uint32_t *d_pool = nullptr;
-    // segment tracing
+    // seed-accelerated tracing
     DevSeg *d_segs = nullptr;
-    uint2 *d_hash = nullptr;
-    uint32_t *d_cseed = nullptr, *d_cbase = nullptr, *d_dense = nullptr;
-    int hash_size = 0;
-    bool legacy_trace = true;  // probe passes + whole-border walk; FID_TRACE=segments: segment tracing
+    DevPend *d_pend = nullptr;
+    uint2 *d_seedq = nullptr, *d_seedplane = nullptr;
+    uint4 *d_wres = nullptr, *d_cinfo = nullptr;
+    uint32_t *d_cbase = nullptr, *d_dense = nullptr;
+    int trace_mode = 0;  // 0: probe passes + whole-border walk; 1 (FID_TRACE=seeds): seed-accelerated
     int max_chunks = 0;
     int walk_blocks = 0;  // one-wave workgroups per frame in the full walk pass (0 = automatic)
     uint4 *d_contours = nullptr;
@@ -194,7 +195,6 @@ void set_geometry(fid_ctx *c, int W, int H, int gstride, int F)
     P.maxCands = c->lim.max_candidates_per_frame;
     P.maxMarkers = c->lim.max_markers_per_frame;
     P.maxChunks = c->max_chunks;
-    P.hashSize = c->hash_size;
 }
 
 size_t masks_elems(const fid_ctx *c, int W, int H, int F)
@@ -239,7 +239,7 @@ fid_status run_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H, int
     HIPCHK(c, hipMemsetAsync(c->d_counts, 0, sizeof(DevCounts) * F, st0));
     HIPCHK(c, hipMemsetAsync(c->d_global, 0, sizeof(DevGlobal), st0));
     HIPCHK(c, hipMemsetAsync(c->d_nwork, 0, sizeof(unsigned) * fid_ctx::MAX_SUB, st0));
-    if ((size_t)F * c->P.maxContours * chunk_tab_pitch(c->P) > c->ckpts_elems) {
+    if ((size_t)F * 2 * c->P.maxContours * chunk_tab_pitch(c->P) > c->ckpts_elems) {
         c->last_error = "chunk table too small for this image size / maxMarkerPerimeterRate";
         return FID_E_UNSUPPORTED;
     }
@@ -266,7 +266,7 @@ fid_status run_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H, int
         uint2 *starts = c->d_starts + (size_t)f0 * P.maxStarts, *surv1 = c->d_surv1 + (size_t)f0 * P.maxStarts,
               *surv = c->d_surv + (size_t)f0 * P.maxStarts;
         uint4 *contours = c->d_contours + (size_t)f0 * P.maxContours;
-        uint32_t *tab = c->d_ckpts + (size_t)f0 * P.maxContours * chunk_tab_pitch(P);
+        uint32_t *tab = c->d_ckpts + (size_t)f0 * 2 * P.maxContours * chunk_tab_pitch(P);
         uint32_t *pool = c->d_pool + (size_t)f0 * P.maxChunks * CK;
         DevCounts *counts = c->d_counts + f0;
         DevCand *cands = c->d_cands + f0 * MC, *sorted = c->d_sorted + f0 * MC, *filtered = c->d_filtered + f0 * MC;
@@ -311,16 +311,16 @@ fid_status run_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H, int
         const int cap1 = pts_cap_first(P);
         const size_t lds1 = (size_t)cap1 * sizeof(uint32_t) + (size_t)K4_SHORT_STACK * sizeof(int2);
         const size_t lds2 = (size_t)(P.maxPerim + 1) * sizeof(uint32_t) + (size_t)K4_LONG_STACK * sizeof(int2);
-        if (c->legacy_trace) {
+        if (c->trace_mode == 0) {
             hipLaunchKernelGGL(k_find_starts<false>, dim3((unsigned)k2blocks, Fs), dim3(256), 0, st, masks, starts, counts, c->d_global,
-                               (uint2 *)nullptr, P);
+                               (uint2 *)nullptr, (uint2 *)nullptr, P);
             mark(ST_STARTS + 1);
             // ---- K3: sieve the starts twice, then walk the survivors to the end
             hipLaunchKernelGGL((k_probe<PROBE0_STEPS, 0>), dim3(64, Fs), dim3(256), 0, st, masks, starts, surv1, counts, c->d_global, P);
             hipLaunchKernelGGL((k_probe<PROBE1_STEPS, 1>), dim3(16, Fs), dim3(256), 0, st, masks, surv1, surv, counts, c->d_global, P);
             mark(ST_PROBE + 1);
-            hipLaunchKernelGGL(k_walk_full<false>, dim3(wb, Fs), dim3(64), 0, st, masks, surv, contours, tab, pool, (DevSeg *)nullptr,
-                               counts, c->d_global, P);
+            hipLaunchKernelGGL(k_walk_full<0>, dim3(wb, Fs), dim3(64), 0, st, masks, surv, contours, tab, pool, (DevSeg *)nullptr,
+                               (DevPend *)nullptr, counts, c->d_global, P);
             mark(ST_WALK + 1);
             // ---- K4: short contours with a small LDS footprint first, then the long / flagged ones
             hipLaunchKernelGGL(k_approx, dim3(128, Fs), dim3(64), lds1, st, contours, tab, pool, cands, counts, c->d_global, P, cap1,
@@ -329,21 +329,29 @@ fid_status run_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H, int
                                P.maxPerim + 1, K4_LONG_STACK, 1, (const uint32_t *)nullptr, (const uint32_t *)nullptr);
             mark(ST_APPROX + 1);
         } else {
-            // ---- segment tracing: seeds -> short segments -> long segments (windowed) -> link -> chain -> flatten
-            DevSeg *segs = c->d_segs + (size_t)f0 * P.maxStarts;
-            uint2 *hash = c->d_hash + (size_t)f0 * P.hashSize;
-            uint32_t *cseed = c->d_cseed + (size_t)f0 * P.maxContours, *cbase = c->d_cbase + (size_t)f0 * P.maxContours;
+            // ---- seed-accelerated tracing: seeds walk their segments while the starts are sieved; survivors walk to the
+            //      first seed; link -> chain -> flatten
+            const size_t MCn = (size_t)P.maxContours;
+            DevSeg *segs = c->d_segs + f0 * MCn;
+            DevPend *pend = c->d_pend + f0 * MCn;
+            uint2 *seedq = c->d_seedq + f0 * MCn;
+            uint2 *seedplane = c->d_seedplane + (size_t)f0 * P.nscales * P.TR * P.TC * MT_ROWS;
+            uint4 *wres = c->d_wres + f0 * MCn, *cinfo = c->d_cinfo + f0 * MCn;
+            uint32_t *cbase = c->d_cbase + f0 * MCn;
             uint32_t *dense = c->d_dense + (size_t)f0 * P.maxChunks * CK;
-            HIPCHK(c, hipMemsetAsync(hash, 0, sizeof(uint2) * (size_t)Fs * P.hashSize, st));
-            hipLaunchKernelGGL(k_find_starts<true>, dim3((unsigned)k2blocks, Fs), dim3(256), 0, st, masks, starts, counts, c->d_global, hash, P);
+            hipLaunchKernelGGL(k_find_starts<true>, dim3((unsigned)k2blocks, Fs), dim3(256), 0, st, masks, starts, counts, c->d_global,
+                               seedq, seedplane, P);
             mark(ST_STARTS + 1);
-            hipLaunchKernelGGL(k_seg_short, dim3(64, Fs), dim3(256), 0, st, masks, starts, surv, segs, counts, c->d_global, P);
+            hipLaunchKernelGGL((k_probe<PROBE0_STEPS, 0>), dim3(64, Fs), dim3(256), 0, st, masks, starts, surv1, counts, c->d_global, P);
+            hipLaunchKernelGGL((k_probe<PROBE1_STEPS, 1>), dim3(16, Fs), dim3(256), 0, st, masks, surv1, surv, counts, c->d_global, P);
             mark(ST_PROBE + 1);
-            hipLaunchKernelGGL(k_walk_full<true>, dim3(wb, Fs), dim3(64), 0, st, masks, surv, contours, tab, pool, segs, counts,
+            hipLaunchKernelGGL(k_walk_full<1>, dim3(wb, Fs), dim3(64), 0, st, masks, seedq, wres, tab, pool, segs, pend, counts,
                                c->d_global, P);
-            hipLaunchKernelGGL(k_seg_link, dim3(32, Fs), dim3(256), 0, st, starts, segs, hash, counts, c->d_global, P);
-            hipLaunchKernelGGL(k_seg_chain, dim3(32, Fs), dim3(256), 0, st, starts, segs, contours, cseed, counts, c->d_global, P);
-            hipLaunchKernelGGL(k_seg_flatten, dim3(64, Fs), dim3(64), 0, st, segs, contours, cseed, cbase, tab, pool, dense, counts,
+            hipLaunchKernelGGL(k_walk_full<2>, dim3(wb, Fs), dim3(64), 0, st, masks, surv, wres, tab, pool, segs, pend, counts,
+                               c->d_global, P);
+            hipLaunchKernelGGL(k_seg_link, dim3(16, Fs), dim3(256), 0, st, seedq, segs, surv, pend, seedplane, counts, c->d_global, P);
+            hipLaunchKernelGGL(k_seg_chain, dim3(16, Fs), dim3(64), 0, st, surv, pend, wres, segs, contours, cinfo, counts, c->d_global, P);
+            hipLaunchKernelGGL(k_seg_flatten, dim3(64, Fs), dim3(64), 0, st, segs, contours, cinfo, cbase, tab, pool, dense, counts,
                                c->d_global, P);
             mark(ST_WALK + 1);
             hipLaunchKernelGGL(k_approx, dim3(128, Fs), dim3(64), lds1, st, contours, tab, pool, cands, counts, c->d_global, P, cap1,
@@ -563,14 +571,15 @@ fid_status fid_create(const fid_params *params, const fid_dict *dict, const fid_
     TRY(dalloc(c, &c->d_surv, F * L.max_starts_per_frame));
     c->max_chunks = (L.max_points_per_frame + CK - 1) / CK;
     TRY(dalloc(c, &c->d_pool, F * (size_t)c->max_chunks * CK));
-    // FID_TRACE=segments selects segment tracing (parity-green, not yet faster than the probe + whole-border walk)
-    c->legacy_trace = !(getenv("FID_TRACE") && !strcmp(getenv("FID_TRACE"), "segments"));
-    if (!c->legacy_trace) {
-        c->hash_size = 1;
-        while (c->hash_size < 2 * L.max_starts_per_frame) c->hash_size *= 2;
-        TRY(dalloc(c, &c->d_segs, F * L.max_starts_per_frame));
-        TRY(dalloc(c, &c->d_hash, F * (size_t)c->hash_size));
-        TRY(dalloc(c, &c->d_cseed, F * L.max_contours_per_frame));
+    c->trace_mode = getenv("FID_TRACE") && !strcmp(getenv("FID_TRACE"), "seeds") ? 1 : 0;
+    if (c->trace_mode == 1) {
+        const size_t plane_words = masks_elems(c, L.max_width, L.max_height, (int)F);
+        TRY(dalloc(c, &c->d_segs, F * L.max_contours_per_frame));
+        TRY(dalloc(c, &c->d_pend, F * L.max_contours_per_frame));
+        TRY(dalloc(c, &c->d_seedq, F * L.max_contours_per_frame));
+        TRY(dalloc(c, &c->d_seedplane, plane_words));
+        TRY(dalloc(c, &c->d_wres, F * L.max_contours_per_frame));
+        TRY(dalloc(c, &c->d_cinfo, F * L.max_contours_per_frame));
         TRY(dalloc(c, &c->d_cbase, F * L.max_contours_per_frame));
         TRY(dalloc(c, &c->d_dense, F * (size_t)c->max_chunks * CK));
     }
@@ -578,7 +587,7 @@ fid_status fid_create(const fid_params *params, const fid_dict *dict, const fid_
     {
         int maxdim = L.max_width > L.max_height ? L.max_width : L.max_height;
         size_t nck = (size_t)(params->maxMarkerPerimeterRate * maxdim) / 64 + 4;
-        c->ckpts_elems = F * L.max_contours_per_frame * nck;
+        c->ckpts_elems = F * 2 * L.max_contours_per_frame * nck;  // rows: seeds, then survivors
         TRY(dalloc(c, &c->d_ckpts, c->ckpts_elems));
     }
     TRY(dalloc(c, &c->d_cands, F * MC));
@@ -616,7 +625,7 @@ void fid_destroy(fid_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    void *dev[] = {c->d_in, c->d_gray, c->d_masks, c->d_starts, c->d_surv1, c->d_surv, c->d_pool, c->d_segs, c->d_hash, c->d_cseed, c->d_cbase, c->d_dense, c->d_contours, c->d_ckpts, c->d_cands, c->d_sorted, c->d_filtered, c->d_near,
+    void *dev[] = {c->d_in, c->d_gray, c->d_masks, c->d_starts, c->d_surv1, c->d_surv, c->d_pool, c->d_segs, c->d_pend, c->d_seedq, c->d_seedplane, c->d_wres, c->d_cinfo, c->d_cbase, c->d_dense, c->d_contours, c->d_ckpts, c->d_cands, c->d_sorted, c->d_filtered, c->d_near,
                    c->d_ident, c->d_pre, c->d_markers, c->d_poses, c->d_counts, c->d_global, c->d_worklist, c->d_nwork, c->d_dict,
                    c->d_subpix_mask, c->d_lens, c->d_pose_in, c->d_pose_n};
     for (void *p : dev)
@@ -848,7 +857,8 @@ fid_status fid_tap_read(fid_ctx *c, fid_tap which, void *dst, int64_t dst_bytes)
         int32_t *o = (int32_t *)dst;
         for (int f = 0; f < F; f++) {
             o[12 * f + 0] = c->h_counts[f].nstarts;
-            o[12 * f + 1] = c->legacy_trace ? (c->h_counts[f].nsurv < c->P.maxContours ? c->h_counts[f].nsurv : c->P.maxContours) : c->h_counts[f].ncontours;
+            o[12 * f + 1] = c->trace_mode == 0 ? (c->h_counts[f].nsurv < c->P.maxContours ? c->h_counts[f].nsurv : c->P.maxContours) : c->h_counts[f].ncontours;
+            o[12 * f + 10] = c->h_counts[f].nseeds;
             o[12 * f + 2] = c->h_counts[f].ncand;
             o[12 * f + 3] = c->h_counts[f].nfilt;
             o[12 * f + 4] = c->h_counts[f].nacc;
@@ -857,7 +867,7 @@ fid_status fid_tap_read(fid_ctx *c, fid_tap which, void *dst, int64_t dst_bytes)
             o[12 * f + 7] = c->h_counts[f].nsurv;
             o[12 * f + 8] = c->h_counts[f].npool;
             o[12 * f + 9] = c->h_counts[f].nsurv1;
-            o[12 * f + 10] = o[12 * f + 11] = 0;
+            o[12 * f + 11] = 0;
         }
         return FID_OK;
     }

@@ -45,7 +45,6 @@ struct DevParams {
     int refine;
     int maxStarts, maxContours, maxCands, maxMarkers;  // per-frame capacities
     int maxChunks;                                     // per-frame pool of CK-point contour chunks
-    int hashSize;                                      // per-frame slots of the seed hash table (power of two)
 };
 
 // word index of padded row yy, word column wi inside one (frame, scale) mask plane of TC tile columns
@@ -68,19 +67,28 @@ struct DevIdent {
     unsigned char bits[FID_MAX_CELLS * FID_MAX_CELLS + 3];
 };
 
-// ---- segment tracing (the default contour path): every start candidate ("seed") follows its border only to the next
-// seed; a chain pass links the segments into whole borders.
-#define SEG_INLINE 10          // points a segment record holds itself; longer segments use pool chunks
+// ---- seed-accelerated contour tracing.  SEEDS are border-following states a walker can recognise from what it holds
+// anyway (3x3 neighbourhood, back direction, position): the pixel satisfies a local start predicate, sits on the thinning
+// lattice (seed_pos) and the back direction is the one icvFetchContour would start there with.  Every seed follows its
+// border only to the next seed (a SEGMENT); a probe survivor follows its border only to the first seed and the rest of
+// the border is read off the segment chain.
 #define SEG_INVALID 0xffffffffu
-struct DevSeg {                // one per seed, 64 bytes
-    uint32_t next_key;         // pixel of the seed state the segment ran into: x | y << 13 (same scale)
-    uint32_t next_idx;         // ... and that seed's index (filled in by k_seg_link)
-    uint32_t n;                // states in the segment (SEG_INVALID: longer than maxPerimeterPixels)
-    uint32_t mout;             // min raster index (pidx) over the segment's pixels
-    uint32_t mhole;            // min raster index over the background 4-neighbours its searches passed over
-    int32_t slot;              // >= 0: long segment, points in the chunks of chunk_tab[slot]; < 0: points inline
-    uint32_t pts[SEG_INLINE];
+struct DevSeg {           // one per seed
+    uint32_t next_key;    // pixel of the seed state the segment ran into: x | y << 13 (same scale)
+    uint32_t next_idx;    // ... and that seed's index (filled in by k_seg_link)
+    uint32_t n;           // states in the segment (SEG_INVALID: longer than maxPerimeterPixels / pool exhausted)
+    uint32_t mout;        // min raster index (pidx) over the segment's pixels
+    uint32_t mhole;       // min raster index over the background 4-neighbours its searches passed over
+    uint32_t pad[3];
 };
+struct DevPend {          // one per probe survivor that stopped in front of a seed state
+    uint32_t p;           // states it walked itself (0 = not stopped: the survivor closed or died on its own)
+    uint32_t next_key;    // pixel of that seed state
+    uint32_t next_idx;    // its seed index (k_seg_link)
+    uint32_t pad;
+};
+// thinning lattice: 1 in 16 pixels, position along x shifts with the row
+__host__ __device__ inline bool seed_pos(int x, int y) { return ((x - 5 * y) & 15) == 0; }
 
 // per-frame counters
 struct DevCounts {
@@ -95,7 +103,10 @@ struct DevCounts {
     int npool;      // point chunks handed out by the full walk pass
     int nwalk;      // survivors handed to walker waves so far (work queue head of the full pass)
     int nsurv1;     // starts that survived the first (short) probe pass
-    int ndense;     // segment tracing: contour points copied to the dense point array so far
+    int ndense;     // contour points copied to the dense point array so far
+    int nseeds;     // seeds found by k_find_starts<true>
+    int nwalk2;     // work queue head of the seed walker
+    int pad[2];
 };
 
 // global counters

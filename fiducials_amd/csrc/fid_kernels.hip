@@ -427,19 +427,18 @@ __device__ __forceinline__ uint32_t fill_toward_lsb(uint32_t seed, uint32_t runs
 // Two kinds of starts are dropped on the spot because their border is shorter than any perimeter gate
 // (when minPerimeterPixels allows it): isolated foreground pixels (a 1-point outer border) and isolated
 // background pixels (a hole border of at most 8 points).
-// SEG = true (segment tracing): the candidates are the pixels a border follower can recognise from the 3x3
-// neighbourhood alone -- outer: foreground with W, NW, N, NE background; hole: foreground with E background and NE
-// foreground -- a superset of the run-level candidates above (the extra ones are never canonical); every
-// candidate is also entered into the frame's pixel -> seed-index hash table.
-__device__ __forceinline__ unsigned seg_hash(unsigned key) { return (key * 2654435761u) >> 7; }
-
-template <bool SEG>
+// HYB = true additionally emits the SEEDS of seed-accelerated tracing: pixels that satisfy a local start predicate
+// -- outer: foreground with W, NW, N, NE background; hole: foreground with E background and NE foreground (a
+// 3x3-decidable superset of the run-level candidates) -- and sit on the thinning lattice seed_pos().  Seeds go to their
+// own list (x | y << 13 | hole << 26 | scale << 27, seed index) and, per mask word, {index of the word's first seed,
+// seed bit mask} goes to the seed-index plane so that a pixel is mapped to its seed index without any hashing.
+template <bool HYB>
 __global__ __launch_bounds__(256) void k_find_starts(const uint32_t *__restrict__ masks, uint2 *__restrict__ starts,
                                                       DevCounts *__restrict__ counts, DevGlobal *__restrict__ G,
-                                                      uint2 *__restrict__ hash, const DevParams P)
+                                                      uint2 *__restrict__ seedq, uint2 *__restrict__ seedplane, const DevParams P)
 {
-    __shared__ int s_wsum[4];
-    __shared__ unsigned s_base;
+    __shared__ int s_wsum[2][4];
+    __shared__ unsigned s_base[2];
     const int lane = lane_id(), wid = threadIdx.x >> 6;
     const int f = blockIdx.y;
     const int WW = P.WW, TC = P.TC, TR = P.TR, H = P.H, S = P.nscales;
@@ -447,15 +446,17 @@ __global__ __launch_bounds__(256) void k_find_starts(const uint32_t *__restrict_
     const long long ngroups = (long long)S * TR * CG;  // one wave per group
     const long long ngr4 = (ngroups + 3) & ~3LL;
     const long long plane = (long long)TR * TC * MT_ROWS;
-    const unsigned cap = (unsigned)P.maxStarts;
+    const unsigned cap = (unsigned)P.maxStarts, scap = (unsigned)P.maxContours;
     const bool drop1 = P.minPerim > 1, drop8 = P.minPerim > 8;
     uint2 *fst = starts + (long long)f * P.maxStarts;
+    uint2 *fsq = HYB ? seedq + (long long)f * P.maxContours : nullptr;
     for (long long g0 = (long long)blockIdx.x * 4; g0 < ngr4; g0 += (long long)gridDim.x * 4) {
         const long long g = g0 + wid;
-        uint32_t outer[4], hole[4];
+        uint32_t outer[4], hole[4], seedo[4], seedh[4];
 #pragma unroll
-        for (int k = 0; k < 4; k++) outer[k] = hole[k] = 0;
-        int x_base = 0, yy0 = 0, s = 0, cnt = 0;
+        for (int k = 0; k < 4; k++) outer[k] = hole[k] = seedo[k] = seedh[k] = 0;
+        int x_base = 0, yy0 = 0, s = 0, cnt = 0, scnt = 0;
+        long long word0 = 0;  // index of this thread's first word inside the (frame, scale) plane
         if (g < ngroups) {
             const int cg = (int)(g % CG);
             const long long t = g / CG;
@@ -467,7 +468,8 @@ __global__ __launch_bounds__(256) void k_find_starts(const uint32_t *__restrict_
             x_base = w * 32;
             if (w < WW && yy0 <= H && yy0 + 3 >= 1) {
                 const uint32_t *pl = masks + ((long long)f * S + s) * plane;
-                const uint32_t *tile = pl + ((long long)tr * TC + MASK_PADW + w) * MT_ROWS + r4;
+                word0 = ((long long)tr * TC + MASK_PADW + w) * MT_ROWS + r4;
+                const uint32_t *tile = pl + word0;
                 const uint4 c4 = *reinterpret_cast<const uint4 *>(tile);
                 const uint4 p4 = *reinterpret_cast<const uint4 *>(tile - MT_ROWS);
                 const uint4 n4 = *reinterpret_cast<const uint4 *>(tile + MT_ROWS);
@@ -498,13 +500,11 @@ __global__ __launch_bounds__(256) void k_find_starts(const uint32_t *__restrict_
                     const uint32_t Est = (cur >> 1) | (nextc << 31);
                     const uint32_t NW = (u << 1) | (prevu >> 31);
                     const uint32_t NE = (u >> 1) | (nextu << 31);
+                    const uint32_t below = d | (d << 1) | (prevd >> 31) | (d >> 1) | (nextd << 31);
                     // outer: starts of foreground runs that have no foreground above (N / NW / NE) anywhere
                     const uint32_t touch = cur & (NW | u | NE);
                     uint32_t o = cur & ~Wst & ~fill_toward_lsb(touch, cur);
-                    if (drop1) {
-                        const uint32_t below = d | (d << 1) | (prevd >> 31) | (d >> 1) | (nextd << 31);
-                        o &= Est | below;  // an isolated pixel is a complete 1-point contour
-                    }
+                    if (drop1) o &= Est | below;  // an isolated pixel is a complete 1-point contour
                     // hole: first pixel e of a background run (W neighbour foreground) that is closed above;
                     // the border-following start is the foreground pixel LEFT of e
                     const uint32_t bg = ~cur;
@@ -519,65 +519,80 @@ __global__ __launch_bounds__(256) void k_find_starts(const uint32_t *__restrict_
                     }
                     outer[k] = o;
                     hole[k] = (e >> 1) | (en0 << 31);
-                    if (SEG) {
-                        uint32_t so = cur & ~Wst & ~NW & ~u & ~NE;
-                        if (drop1) {
-                            // nobody can walk INTO an isolated pixel, so it may be dropped as a seed too
-                            const uint32_t below = d | (d << 1) | (prevd >> 31) | (d >> 1) | (nextd << 31);
-                            so &= Est | below;
-                        }
-                        outer[k] = so;
-                        hole[k] = cur & ~Est & NE;
-                    }
                     cnt += __popc(outer[k]) + __popc(hole[k]);
+                    if (HYB) {
+                        // thinning lattice of seed_pos(): x == 5 * y (mod 16)
+                        const uint32_t lattice = 0x00010001u << ((5 * y) & 15);
+                        // (an isolated pixel cannot be walked INTO, so it needs no seed either)
+                        seedo[k] = cur & ~Wst & ~NW & ~u & ~NE & (Est | below) & lattice;
+                        seedh[k] = cur & ~Est & NE & lattice;  // never both: outer wants NE background, hole NE foreground
+                        scnt += __popc(seedo[k] | seedh[k]);
+                    }
                 }
             }
         }
-        int incl = wave_iscan(cnt);
-        if (lane == 63) s_wsum[wid] = incl;
+        const int incl = wave_iscan(cnt);
+        const int sincl = HYB ? wave_iscan(scnt) : 0;
+        if (lane == 63) {
+            s_wsum[0][wid] = incl;
+            s_wsum[1][wid] = sincl;
+        }
         __syncthreads();
-        int wbase = 0, tot = 0;
+        int wbase = 0, tot = 0, swbase = 0, stot = 0;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            int v = s_wsum[k];
-            if (k < wid) wbase += v;
+            const int v = s_wsum[0][k], sv = s_wsum[1][k];
+            if (k < wid) {
+                wbase += v;
+                swbase += sv;
+            }
             tot += v;
+            stot += sv;
         }
-        if (threadIdx.x == 0 && tot) s_base = atomicAdd((unsigned *)&counts[f].nstarts, (unsigned)tot);
+        if (threadIdx.x == 0) {
+            if (tot) s_base[0] = atomicAdd((unsigned *)&counts[f].nstarts, (unsigned)tot);
+            if (HYB && stot) s_base[1] = atomicAdd((unsigned *)&counts[f].nseeds, (unsigned)stot);
+        }
         __syncthreads();
         if (tot) {
-            unsigned off = s_base + (unsigned)(wbase + incl - cnt);
+            unsigned off = s_base[0] + (unsigned)(wbase + incl - cnt);
             const uint32_t meta = (uint32_t)f | ((uint32_t)s << 16);
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const uint32_t y = (uint32_t)(yy0 + k - 1);
                 uint32_t o = outer[k], hh = hole[k];
-                uint32_t both = o | hh;  // (never both at one pixel: outer wants NE background, hole NE foreground)
-                while (both) {
-                    int b = __ffs(both) - 1;
-                    both &= both - 1;
-                    const uint32_t isHole = (hh >> b) & 1u;
-                    if (off < cap) {
-                        fst[off] = make_uint2((uint32_t)(x_base + b) | (y << 16), meta | (isHole << 24));
-                        if (SEG) {
-                            // open addressing, key + 1 so that 0 means empty
-                            const unsigned key = ((uint32_t)(x_base + b) | (y << 13) | ((uint32_t)s << 26)) + 1u;
-                            uint2 *tab = hash + (long long)f * P.hashSize;
-                            unsigned h = seg_hash(key) & (unsigned)(P.hashSize - 1);
-                            for (;;) {
-                                const unsigned prev = atomicCAS(&tab[h].x, 0u, key);
-                                if (prev == 0u) {
-                                    tab[h].y = off;
-                                    break;
-                                }
-                                h = (h + 1) & (unsigned)(P.hashSize - 1);
-                            }
-                        }
-                    }
+                while (o) {
+                    int b = __ffs(o) - 1;
+                    o &= o - 1;
+                    if (off < cap) fst[off] = make_uint2((uint32_t)(x_base + b) | (y << 16), meta);
+                    off++;
+                }
+                while (hh) {
+                    int b = __ffs(hh) - 1;
+                    hh &= hh - 1;
+                    if (off < cap) fst[off] = make_uint2((uint32_t)(x_base + b) | (y << 16), meta | (1u << 24));
                     off++;
                 }
             }
-            if (threadIdx.x == 0 && s_base + (unsigned)tot > cap) atomicOr(&G->overflow, 1u);
+            if (threadIdx.x == 0 && s_base[0] + (unsigned)tot > cap) atomicOr(&G->overflow, 1u);
+        }
+        if (HYB && stot) {
+            unsigned off = s_base[1] + (unsigned)(swbase + sincl - scnt);
+            uint2 *spl = seedplane + ((long long)f * S + s) * plane + word0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t y = (uint32_t)(yy0 + k - 1);
+                uint32_t both = seedo[k] | seedh[k];
+                if (both) spl[k] = make_uint2(off, both);
+                while (both) {
+                    int b = __ffs(both) - 1;
+                    both &= both - 1;
+                    if (off < scap)
+                        fsq[off] = make_uint2((uint32_t)(x_base + b) | (y << 13) | (((seedh[k] >> b) & 1u) << 26) | ((uint32_t)s << 27), off);
+                    off++;
+                }
+            }
+            if (threadIdx.x == 0 && s_base[1] + (unsigned)stot > scap) atomicOr(&G->overflow, 2u);
         }
         __syncthreads();
     }
@@ -849,14 +864,16 @@ __device__ __forceinline__ unsigned win_raw(const uint32_t *s_winw, int lane4, i
     return (t3[0] & 7u) | ((t3[1] & 1u) << 3) | ((t3[1] & 4u) << 2) | ((t3[2] & 7u) << 5);
 }
 
-// SEG = false: a walker follows a whole border from a probe survivor and applies the canonical-start test as it goes.
-// SEG = true:  a walker follows one SEGMENT, from its seed state to the next seed state, and records length and minima.
-template <bool SEG>
+// MODE 0: a walker follows a whole border from a probe survivor and applies the canonical-start test as it goes.
+// MODE 1: a walker follows one SEGMENT, from its seed state to the next seed state, and records length and minima.
+// MODE 2: as MODE 0, but the walker stops in front of the first seed state it meets (k_seg_chain takes over from there).
+template <int MODE>
 __global__ __launch_bounds__(64) void k_walk_full(const uint32_t *__restrict__ masks, const uint2 *__restrict__ surv,
                                                    uint4 *__restrict__ contours, uint32_t *__restrict__ chunk_tab,
-                                                   uint32_t *__restrict__ pool, DevSeg *__restrict__ segs,
+                                                   uint32_t *__restrict__ pool, DevSeg *__restrict__ segs, DevPend *__restrict__ pend,
                                                    DevCounts *__restrict__ counts, DevGlobal *__restrict__ G, const DevParams P)
 {
+    constexpr bool SEG = MODE == 1;
     // window chunk j (16 bytes = rows 4q..4q+3 of tile (t, c), j = (c * 2 + t) * 4 + q) of lane l: s_win[j * 64 + l]
     __shared__ uint4 s_win[16 * 64];
     // step table: index raw | backdir << 8 -> next direction | code << 3, code = the smallest-offset background
@@ -880,11 +897,14 @@ __global__ __launch_bounds__(64) void k_walk_full(const uint32_t *__restrict__ m
     enum { ST_IDLE = 0, ST_ACTIVE, ST_NEED, ST_LOADING, ST_FINAL };
 
     for (;;) {
-        unsigned n = (unsigned)counts[f].nsurv;
+        unsigned n = (unsigned)(SEG ? counts[f].nseeds : counts[f].nsurv);
         n = n < (unsigned)P.maxStarts ? n : (unsigned)P.maxStarts;
-        const uint2 *fin = surv + (long long)f * P.maxStarts;
+        n = n < ccap ? n : ccap;  // (walkers beyond the contour capacity were flagged by their producers)
+        const uint2 *fin = surv + (long long)f * (SEG ? P.maxContours : P.maxStarts);
+        unsigned *qhead = (unsigned *)(SEG ? &counts[f].nwalk2 : &counts[f].nwalk);
         uint4 *fco = contours + (long long)f * P.maxContours;
-        uint32_t *ftab = chunk_tab + (long long)f * P.maxContours * nck;
+        // chunk rows: seeds 0 .. maxContours-1, survivors maxContours .. 2 maxContours-1
+        uint32_t *ftab = chunk_tab + ((long long)f * 2 + (SEG ? 0 : 1)) * P.maxContours * nck;
         uint32_t *fpool = pool + (long long)f * P.maxChunks * CK;
         // the wave's current batch of the frame's survivor queue: [next, rend), records of batch base .. base + 63 in `pre`
         unsigned next = 0, rend = 0, pre_base = 0;  // wave-uniform
@@ -903,8 +923,8 @@ __global__ __launch_bounds__(64) void k_walk_full(const uint32_t *__restrict__ m
         unsigned chunkA = 0, chunkB = 0;  // pool chunks of the even / odd 64-point blocks around `count`
         int kreg = 0;                     // highest block index that has a chunk
         unsigned ovf = 0;
-        unsigned seed_idx = 0, mout = 0xffffffffu, mhole = 0xffffffffu;  // SEG: the walker's seed and its running minima
-        int too_long = 0;
+        unsigned mout = 0xffffffffu, mhole = 0xffffffffu;  // MODE 1: running minima of the segment
+        int too_long = 0, stopped = 0;
         unsigned arena_next = 0, arena_end = 0;  // wave-uniform
 #ifdef FID_DEBUG_STATS
         unsigned long long d_iters = 0, d_ckpts = 0, d_active = 0, d_ckcyc = 0, d_waitcyc = 0, d_forced = 0;
@@ -954,15 +974,20 @@ __global__ __launch_bounds__(64) void k_walk_full(const uint32_t *__restrict__ m
             // ---- retire finished walkers
             if (state == ST_FINAL) {
                 if (SEG) {
-                    DevSeg *r = segs + (long long)f * P.maxStarts + seed_idx;
+                    DevSeg *r = segs + (long long)f * P.maxContours + slot;
                     r->next_key = (uint32_t)cx | ((uint32_t)cy << 13);  // the seed state the walk stopped in front of
                     r->n = too_long || !ok ? SEG_INVALID : (unsigned)count;
                     r->mout = mout;
                     r->mhole = mhole;
-                    r->slot = (int)slot;
                 } else {
-                    const int accept = ok && closed && count >= P.minPerim && count <= P.maxPerim;
+                    // stopped in front of a seed state (MODE 2): k_seg_chain decides; else decided here
+                    const int accept = ok && closed && !stopped && count >= P.minPerim && count <= P.maxPerim;
                     fco[slot] = make_uint4(st.x, st.y, accept ? (unsigned)count : 0u, (unsigned)key);
+                    if (MODE == 2) {
+                        DevPend *pd = pend + (long long)f * P.maxContours + slot;
+                        pd->p = ok && stopped ? (unsigned)count : 0u;
+                        pd->next_key = (uint32_t)cx | ((uint32_t)cy << 13);
+                    }
                 }
                 state = ST_IDLE;
 #ifdef FID_DEBUG_STATS
@@ -977,7 +1002,7 @@ __global__ __launch_bounds__(64) void k_walk_full(const uint32_t *__restrict__ m
                 if (next == rend && !exhausted) {
                     // take the next batch of the frame's survivors; its records arrive by the next checkpoint
                     unsigned base = 0;
-                    if (lane == 0) base = atomicAdd((unsigned *)&counts[f].nwalk, (unsigned)WALK_GRAB);
+                    if (lane == 0) base = atomicAdd(qhead, (unsigned)WALK_GRAB);
                     base = __builtin_amdgcn_readfirstlane(base);
                     if (base >= n) {
                         exhausted = 1;
@@ -997,7 +1022,7 @@ __global__ __launch_bounds__(64) void k_walk_full(const uint32_t *__restrict__ m
                     const int src = (int)(next - pre_base) + rank;
                     const unsigned gx = __shfl(pre.x, src & 63, WAVE), gy = __shfl(pre.y, src & 63, WAVE);
                     if (state == ST_IDLE && next + (unsigned)rank < rend) {
-                        slot = next + (unsigned)rank;  // the contour slot is the survivor's index
+                        slot = n - 1 - (next + (unsigned)rank);  // the walker's index in its list (handed out back to front)
                         if (slot < ccap) {
                             st = make_uint2(gx, gy);
                             int s;
@@ -1006,7 +1031,6 @@ __global__ __launch_bounds__(64) void k_walk_full(const uint32_t *__restrict__ m
                                 y0 = (gx >> 13) & 0x1fff;
                                 hole = (gx >> 26) & 1;
                                 s = gx >> 27;
-                                seed_idx = gy;
                                 mout = mhole = 0xffffffffu;
                                 too_long = 0;
                             } else {
@@ -1019,6 +1043,7 @@ __global__ __launch_bounds__(64) void k_walk_full(const uint32_t *__restrict__ m
                             key = hole ? pidx(x0 + 1, y0, W) : pidx(x0, y0, W);
                             count = 0;
                             closed = 0;
+                            stopped = 0;
                             ok = 1;
                             first = 1;
                             cx = x0;
@@ -1057,8 +1082,12 @@ __global__ __launch_bounds__(64) void k_walk_full(const uint32_t *__restrict__ m
                         if (mine + 1 >= pcap) {
                             ovf |= 8u;
                             ok = 0;
-                            if (SEG) segs[(long long)f * P.maxStarts + seed_idx].n = SEG_INVALID;
-                            else fco[slot] = make_uint4(st.x, st.y, 0u, (unsigned)key);
+                            if (SEG) {
+                                segs[(long long)f * P.maxContours + slot].n = SEG_INVALID;
+                            } else {
+                                fco[slot] = make_uint4(st.x, st.y, 0u, (unsigned)key);
+                                if (MODE == 2) pend[(long long)f * P.maxContours + slot].p = 0u;
+                            }
                             state = ST_IDLE;
                         } else if (fresh) {
                             chunkA = mine;
@@ -1127,7 +1156,7 @@ __global__ __launch_bounds__(64) void k_walk_full(const uint32_t *__restrict__ m
                     const int hmag = (code & 1) ? W2 : 1;
                     const int hoff = (code & 2) ? hmag : -hmag;
                     if (SEG) {
-                        if (count > 0 && (e & 0x40u)) {
+                        if (count > 0 && (e & 0x40u) && seed_pos(cx, cy)) {
                             closed = 1;  // the next seed state: the segment ends in front of it
                             state = ST_FINAL;
                         } else {
@@ -1146,6 +1175,9 @@ __global__ __launch_bounds__(64) void k_walk_full(const uint32_t *__restrict__ m
                             const unsigned xr = (unsigned)(cx + (MASK_PADW * 32 - 1) - wx0), rr = (unsigned)(cy - wy0);
                             state = (xr > 61u || rr > 29u) ? ST_NEED : ST_ACTIVE;
                         }
+                    } else if (MODE == 2 && count > 0 && (e & 0x40u) && seed_pos(cx, cy)) {
+                        stopped = 1;  // the first seed state on this border: the segment chain continues from here
+                        state = ST_FINAL;
                     } else {
                         // background pixels examined in the 4-directions belong to this border's hole region
                         int bad = hole && code && (pc + hoff < key);
@@ -1181,9 +1213,11 @@ __global__ __launch_bounds__(64) void k_walk_full(const uint32_t *__restrict__ m
             int fr = f + k;
             fr = fr >= F ? fr - F : fr;
             if (k < F) {
-                const unsigned done = __hip_atomic_load((unsigned *)&counts[fr].nwalk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                unsigned m = (unsigned)counts[fr].nsurv;
+                const unsigned done = __hip_atomic_load((unsigned *)(SEG ? &counts[fr].nwalk2 : &counts[fr].nwalk), __ATOMIC_RELAXED,
+                                                        __HIP_MEMORY_SCOPE_AGENT);
+                unsigned m = (unsigned)(SEG ? counts[fr].nseeds : counts[fr].nsurv);
                 m = m < (unsigned)P.maxStarts ? m : (unsigned)P.maxStarts;
+                m = m < ccap ? m : ccap;
                 has = done < m;
             }
             const unsigned long long hb = ballot64(has);
@@ -1217,209 +1251,112 @@ __global__ __launch_bounds__(64) void k_walk_full(const uint32_t *__restrict__ m
 }
 
 // ------------------------------------------------------------------------------------------------
-// Segment tracing.  A border-following state is (pixel, direction back to the previous pixel); one step maps a state to the
-// next one and does not depend on how the walk was started, so a border is a cycle of states.  Every seed (k_find_starts<true>)
-// owns the states from its own start state up to, but not including, the next seed state on the cycle.  Whether a state is
-// a seed state is a function of the 3x3 neighbourhood and the back direction alone (bit 6 of the step table): the pixel
-// satisfies a seed predicate and the back direction equals the one icvFetchContour would start that seed with.
-//   k_seg_short   every seed, at most SEG_INLINE steps (plain loads); finished segments keep their points in the record,
-//                 the others go to the survivor list
-//   k_walk_full<true>   survivors, windowed, points in pool chunks
-//   k_seg_link    next seed pixel -> seed index (hash look-up)
-//   k_seg_chain   every seed as a candidate start of its type: follow the segment chain, accumulate length and the two
-//                 running minima; stop as soon as the start cannot be canonical (a smaller key on the border) or the border
-//                 is too long; a closed chain that passes the perimeter gate is an accepted contour
-//   k_seg_flatten one wave per accepted contour: copy the points of its segments, in order, into a dense array
-// The acceptance test is the one k_probe / k_walk_full<false> apply while walking (no pixel -- outer -- or examined
-// background 4-neighbour -- hole -- with a raster index below the start's key), evaluated on per-segment minima.
-// raw neighbourhood byte of (x, y) straight from the tiled mask (see win_raw for the bit order)
-__device__ __forceinline__ unsigned raw8(const MaskView &m, int x, int y)
+// Seed-accelerated tracing (k_find_starts<true> + k_walk_full<1>, <2> + the three passes below).
+// A border-following state is (pixel, direction back to the previous pixel); one step maps a state to the next one and does
+// not depend on how the walk was started, so a border is a cycle of states.  SEED states cut every cycle that contains some
+// into segments: seed i owns the states from its start state up to, not including, the next seed state.  The whole-border
+// walk of a probe survivor then only has to reach the first seed state on its border (it keeps applying the canonical
+// test on the way and closes by itself on a border without seeds); the rest comes from the segment records:
+//   k_seg_link     next seed pixel -> seed index (seed-index plane) for every segment and every stopped survivor
+//   k_seg_chain    every stopped survivor: once around the seed cycle, summing lengths and taking the two running minima;
+//                  the acceptance test is the one the whole-border walk applies (no pixel -- outer -- or examined
+//                  background 4-neighbour -- hole -- with a raster index below the start's key; perimeter gate)
+//   k_seg_flatten  one wave per accepted contour: the survivor's own points, then the segments in cycle order (the last
+//                  one cut where the survivor started), into a dense array for k_approx
+// The longest sequential piece is the longest seed-free stretch of a border, not the longest border.
+
+// seed index of pixel (x, y) from the seed-index plane of its scale
+__device__ __forceinline__ unsigned seed_lookup(const uint2 *__restrict__ spl, int TC, unsigned key)
 {
-    const int xb = x - 1 + MASK_PADW * 32;
-    const int wi = xb >> 5, sh = xb & 31;
-    const bool two = sh > 29;
-    const uint32_t *p0 = m.base + mask_word(m.TC, y, wi);
-    const uint32_t *p1 = m.base + mask_word(m.TC, y + 1, wi);
-    const uint32_t *p2 = m.base + mask_word(m.TC, y + 2, wi);
-    const uint32_t a0 = p0[0], a1 = p1[0], a2 = p2[0];
-    uint32_t b0 = 0, b1 = 0, b2 = 0;
-    if (two) {
-        b0 = p0[MT_ROWS];
-        b1 = p1[MT_ROWS];
-        b2 = p2[MT_ROWS];
-    }
-    const unsigned tu = __builtin_amdgcn_alignbit(b0, a0, sh), tm = __builtin_amdgcn_alignbit(b1, a1, sh),
-                   td = __builtin_amdgcn_alignbit(b2, a2, sh);
-    return (tu & 7u) | ((tm & 1u) << 3) | ((tm & 4u) << 2) | ((td & 7u) << 5);
+    const int x = key & 0x1fff, y = (key >> 13) & 0x1fff;
+    const uint2 e = spl[mask_word(TC, y + 1, MASK_PADW + (x >> 5))];
+    const unsigned bit = 1u << (x & 31);
+    return (e.y & bit) ? e.x + (unsigned)__popc(e.y & (bit - 1u)) : SEG_INVALID;
 }
 
-__global__ __launch_bounds__(256) void k_seg_short(const uint32_t *__restrict__ masks, const uint2 *__restrict__ starts,
-                                                    uint2 *__restrict__ surv, DevSeg *__restrict__ segs,
-                                                    DevCounts *__restrict__ counts, DevGlobal *__restrict__ G, const DevParams P)
-{
-    __shared__ uint8_t s_lut[2048];
-    build_step_lut(s_lut, threadIdx.x, 256);
-    __syncthreads();
-    const int f = blockIdx.y;
-    const int lane = lane_id();
-    unsigned n = (unsigned)counts[f].nstarts;
-    n = n < (unsigned)P.maxStarts ? n : (unsigned)P.maxStarts;
-    const int W = P.W, S = P.nscales, W2 = P.W + 2;
-    const long long plane = (long long)P.TR * P.TC * MT_ROWS;
-    const uint2 *fin = starts + (long long)f * P.maxStarts;
-    uint2 *fsv = surv + (long long)f * P.maxStarts;
-    DevSeg *fsg = segs + (long long)f * P.maxStarts;
-    for (unsigned i0 = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); i0 < n; i0 += gridDim.x * blockDim.x) {
-        const unsigned i = i0 + lane;
-        const bool active = i < n;
-        const uint2 st = active ? fin[i] : make_uint2(0u, 0u);
-        const int x0 = st.x & 0xffff, y0 = st.x >> 16;
-        const int s = (st.y >> 16) & 0xff, hole = (st.y >> 24) & 1;
-        MaskView m;
-        m.base = masks + ((long long)f * S + s) * plane;
-        m.TC = P.TC;
-        DevSeg rec;
-        rec.next_idx = 0;
-        rec.slot = -1;
-        rec.mout = 0xffffffffu;
-        rec.mhole = 0xffffffffu;
-        int cnt = 0, done = 0;
-        int cx = x0, cy = y0, pc = pidx(x0, y0, W);
-        unsigned raw = active ? raw8(m, x0, y0) : 0u;
-        if (active) {
-            if (raw == 0) {
-                // single pixel domain: a one-state cycle
-                rec.pts[0] = (uint32_t)x0 | ((uint32_t)y0 << 16);
-                rec.mout = (uint32_t)pc;
-                cnt = 1;
-                done = 1;
-            } else {
-                int sdir = first_dir(raw_to_nb(raw), hole ? 0 : 4);
-#pragma unroll
-                for (int k = 0; k <= SEG_INLINE; k++) {
-                    if (!done) {
-                        const unsigned e = s_lut[raw | ((unsigned)sdir << 8)];
-                        if (k > 0 && (e & 0x40u)) {
-                            done = 1;  // ran into the next seed state (possibly its own)
-                        } else if (k < SEG_INLINE) {
-                            const int sn = e & 7, code = (e >> 3) & 7;
-                            if (code) {
-                                const int hmag = (code & 1) ? W2 : 1;
-                                const unsigned hv = (unsigned)(pc + ((code & 2) ? hmag : -hmag));
-                                rec.mhole = hv < rec.mhole ? hv : rec.mhole;
-                            }
-                            rec.mout = (unsigned)pc < rec.mout ? (unsigned)pc : rec.mout;
-                            rec.pts[k] = (uint32_t)cx | ((uint32_t)cy << 16);
-                            cnt = k + 1;
-                            const int dx = dir_dx(sn), dy = dir_dy(sn);
-                            cx += dx;
-                            cy += dy;
-                            pc += __mul24(dy, W2) + dx;
-                            sdir = (sn + 4) & 7;
-                            raw = raw8(m, cx, cy);
-                        }
-                    }
-                }
-            }
-        }
-        if (active && done) {
-            rec.n = (uint32_t)cnt;
-            rec.next_key = (uint32_t)cx | ((uint32_t)cy << 13);  // the seed state it stopped in front of (itself when closed)
-            fsg[i] = rec;
-        }
-        // longer segments: to the windowed walker (record: x | y << 13 | hole << 26 | scale << 27, seed index)
-        const int keep = active && !done;
-        const unsigned long long mk = ballot64(keep);
-        if (mk) {
-            const int leader = __ffsll((long long)mk) - 1;
-            unsigned base = 0;
-            if (lane == leader) base = atomicAdd((unsigned *)&counts[f].nsurv, (unsigned)__popcll(mk));
-            base = __shfl(base, leader, WAVE);
-            const unsigned idx = base + (unsigned)__popcll(mk & ((1ull << lane) - 1ull));
-            if (keep) {
-                if (idx < (unsigned)P.maxStarts && idx < (unsigned)P.maxContours)
-                    fsv[idx] = make_uint2((uint32_t)x0 | ((uint32_t)y0 << 13) | ((uint32_t)hole << 26) | ((uint32_t)s << 27), i);
-                else
-                    atomicOr(&G->overflow, 2u);
-            }
-        }
-    }
-}
-
-// next seed pixel -> seed index
-__global__ __launch_bounds__(256) void k_seg_link(const uint2 *__restrict__ starts, DevSeg *__restrict__ segs,
-                                                   const uint2 *__restrict__ hash, DevCounts *__restrict__ counts,
+__global__ __launch_bounds__(256) void k_seg_link(const uint2 *__restrict__ seedq, DevSeg *__restrict__ segs,
+                                                   const uint2 *__restrict__ surv, DevPend *__restrict__ pend,
+                                                   const uint2 *__restrict__ seedplane, DevCounts *__restrict__ counts,
                                                    DevGlobal *__restrict__ G, const DevParams P)
 {
     const int f = blockIdx.y;
-    unsigned n = (unsigned)counts[f].nstarts;
-    n = n < (unsigned)P.maxStarts ? n : (unsigned)P.maxStarts;
-    const uint2 *fst = starts + (long long)f * P.maxStarts;
-    DevSeg *fsg = segs + (long long)f * P.maxStarts;
-    const uint2 *tab = hash + (long long)f * P.hashSize;
-    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const unsigned s = (fst[i].y >> 16) & 0xffu;
-        const unsigned key = (fsg[i].next_key | (s << 26)) + 1u;
-        unsigned h = seg_hash(key) & (unsigned)(P.hashSize - 1);
-        unsigned idx = SEG_INVALID;
-        for (int probe = 0; probe < P.hashSize; probe++) {
-            const uint2 e = tab[h];
-            if (e.x == key) {
-                idx = e.y;
-                break;
+    unsigned ns = (unsigned)counts[f].nseeds, nv = (unsigned)counts[f].nsurv;
+    ns = ns < (unsigned)P.maxContours ? ns : (unsigned)P.maxContours;
+    nv = nv < (unsigned)P.maxContours ? nv : (unsigned)P.maxContours;
+    const long long plane = (long long)P.TR * P.TC * MT_ROWS;
+    const uint2 *fsq = seedq + (long long)f * P.maxContours;
+    DevSeg *fsg = segs + (long long)f * P.maxContours;
+    const uint2 *fsv = surv + (long long)f * P.maxStarts;
+    DevPend *fpd = pend + (long long)f * P.maxContours;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < ns + nv; i += gridDim.x * blockDim.x) {
+        if (i < ns) {
+            const unsigned sc = fsq[i].x >> 27;
+            fsg[i].next_idx = seed_lookup(seedplane + ((long long)f * P.nscales + sc) * plane, P.TC, fsg[i].next_key);
+        } else {
+            const unsigned j = i - ns;
+            if (fpd[j].p) {
+                const unsigned sc = (fsv[j].y >> 16) & 0xffu;
+                fpd[j].next_idx = seed_lookup(seedplane + ((long long)f * P.nscales + sc) * plane, P.TC, fpd[j].next_key);
             }
-            if (e.x == 0u) break;
-            h = (h + 1) & (unsigned)(P.hashSize - 1);
         }
-        fsg[i].next_idx = idx;
     }
 }
 
-// every seed as a candidate start: accepted contours are appended to `contours` (start, meta, length, key) with the seed
-// index in cseed[]
-__global__ __launch_bounds__(256) void k_seg_chain(const uint2 *__restrict__ starts, const DevSeg *__restrict__ segs,
-                                                    uint4 *__restrict__ contours, uint32_t *__restrict__ cseed,
-                                                    DevCounts *__restrict__ counts, DevGlobal *__restrict__ G, const DevParams P)
+// stopped survivors: once around the seed cycle.  Accepted contours (also the ones k_walk_full<2> closed by itself, which
+// it appended already) end up in `contours` (start, meta, length, key) with {survivor index, own points, first seed}.
+__global__ __launch_bounds__(64) void k_seg_chain(const uint2 *__restrict__ surv, const DevPend *__restrict__ pend,
+                                                   const uint4 *__restrict__ wres, const DevSeg *__restrict__ segs,
+                                                   uint4 *__restrict__ contours,
+                                                   uint4 *__restrict__ cinfo, DevCounts *__restrict__ counts,
+                                                   DevGlobal *__restrict__ G, const DevParams P)
 {
     const int f = blockIdx.y;
     const int lane = lane_id();
-    unsigned n = (unsigned)counts[f].nstarts;
-    n = n < (unsigned)P.maxStarts ? n : (unsigned)P.maxStarts;
-    const uint2 *fst = starts + (long long)f * P.maxStarts;
-    const DevSeg *fsg = segs + (long long)f * P.maxStarts;
+    unsigned nv = (unsigned)counts[f].nsurv;
+    nv = nv < (unsigned)P.maxContours ? nv : (unsigned)P.maxContours;
+    const uint2 *fsv = surv + (long long)f * P.maxStarts;
+    const DevPend *fpd = pend + (long long)f * P.maxContours;
+    const DevSeg *fsg = segs + (long long)f * P.maxContours;
     uint4 *fco = contours + (long long)f * P.maxContours;
-    uint32_t *fcs = cseed + (long long)f * P.maxContours;
+    uint4 *fci = cinfo + (long long)f * P.maxContours;
     const int W = P.W;
-    for (unsigned i0 = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); i0 < n; i0 += gridDim.x * blockDim.x) {
+    for (unsigned i0 = blockIdx.x * 64; i0 < nv; i0 += gridDim.x * 64) {
         const unsigned i = i0 + lane;
         int accept = 0;
-        unsigned L = 0;
+        unsigned L = 0, key = 0, first = SEG_INVALID, own = 0;
         uint2 st = make_uint2(0u, 0u);
-        unsigned key = 0;
-        if (i < n) {
-            st = fst[i];
-            const int x0 = st.x & 0xffff, y0 = st.x >> 16;
-            const int hole = (st.y >> 24) & 1;
-            key = (unsigned)(hole ? pidx(x0 + 1, y0, W) : pidx(x0, y0, W));
-            unsigned cur = i;
-            for (int hops = 0; hops <= P.maxPerim; hops++) {  // (every segment has at least one state)
-                const DevSeg *r = fsg + cur;
-                const unsigned sn = r->n;
-                if (sn == SEG_INVALID || sn == 0u) break;
-                const unsigned mv = hole ? r->mhole : r->mout;
-                if (mv < key) break;  // a smaller key on the border: this start is not the canonical one
-                L += sn;
-                if (L > (unsigned)P.maxPerim) break;
-                const unsigned nx = r->next_idx;
-                if (nx == i) {
-                    accept = L >= (unsigned)P.minPerim;
-                    break;
+        if (i < nv) {
+            const DevPend pd = fpd[i];
+            if (!pd.p) {
+                // decided by the walker itself (a border without seeds): accepted iff it left a length
+                const uint4 w = wres[(long long)f * P.maxContours + i];
+                if (w.z) {
+                    st = make_uint2(w.x, w.y);
+                    L = own = w.z;
+                    key = w.w;
+                    accept = 1;
                 }
-                if (nx == SEG_INVALID) {
-                    atomicOr(&G->overflow, 16u);  // broken chain: a seed state without a seed (must not happen)
-                    break;
+            } else {
+                st = fsv[i];
+                const int x0 = st.x & 0xffff, y0 = st.x >> 16;
+                const int hole = (st.y >> 24) & 1;
+                key = (unsigned)(hole ? pidx(x0 + 1, y0, W) : pidx(x0, y0, W));
+                first = pd.next_idx;
+                own = pd.p;
+                unsigned cur = first;
+                for (int hops = 0; hops <= P.maxPerim && cur != SEG_INVALID; hops++) {  // (every segment has >= 1 state)
+                    const DevSeg r = fsg[cur];
+                    if (r.n == SEG_INVALID || r.n == 0u) break;
+                    if ((hole ? r.mhole : r.mout) < key) break;  // a smaller key on the border: not the canonical start
+                    L += r.n;
+                    if (L > (unsigned)P.maxPerim) break;
+                    if (r.next_idx == first) {
+                        accept = L >= (unsigned)P.minPerim;
+                        break;
+                    }
+                    cur = r.next_idx;
                 }
-                cur = nx;
+                if (first == SEG_INVALID) atomicOr(&G->overflow, 16u);  // a seed state without a seed: must not happen
             }
         }
         const unsigned long long mk = ballot64(accept);
@@ -1432,7 +1369,7 @@ __global__ __launch_bounds__(256) void k_seg_chain(const uint2 *__restrict__ sta
             if (accept) {
                 if (idx < (unsigned)P.maxContours) {
                     fco[idx] = make_uint4(st.x, st.y, L, key);
-                    fcs[idx] = i;
+                    fci[idx] = make_uint4(i, own, first, 0u);
                 } else {
                     atomicOr(&G->overflow, 2u);
                 }
@@ -1441,9 +1378,10 @@ __global__ __launch_bounds__(256) void k_seg_chain(const uint2 *__restrict__ sta
     }
 }
 
-// one wave per accepted contour: its points, segment by segment, into dense[cbase[ci] ...]
+// one wave per accepted contour: own points of the survivor (chunk rows maxContours + survivor), then the segments
+// (chunk rows = seed index) in cycle order, cut at the contour's length, into dense[cbase[ci] ...]
 __global__ __launch_bounds__(64) void k_seg_flatten(const DevSeg *__restrict__ segs, const uint4 *__restrict__ contours,
-                                                     const uint32_t *__restrict__ cseed, uint32_t *__restrict__ cbase,
+                                                     const uint4 *__restrict__ cinfo, uint32_t *__restrict__ cbase,
                                                      const uint32_t *__restrict__ chunk_tab, const uint32_t *__restrict__ pool,
                                                      uint32_t *__restrict__ dense, DevCounts *__restrict__ counts,
                                                      DevGlobal *__restrict__ G, const DevParams P)
@@ -1452,17 +1390,18 @@ __global__ __launch_bounds__(64) void k_seg_flatten(const DevSeg *__restrict__ s
     const int lane = lane_id();
     unsigned nc = (unsigned)counts[f].ncontours;
     nc = nc < (unsigned)P.maxContours ? nc : (unsigned)P.maxContours;
-    const DevSeg *fsg = segs + (long long)f * P.maxStarts;
+    const DevSeg *fsg = segs + (long long)f * P.maxContours;
     const uint4 *fco = contours + (long long)f * P.maxContours;
-    const uint32_t *fcs = cseed + (long long)f * P.maxContours;
+    const uint4 *fci = cinfo + (long long)f * P.maxContours;
     uint32_t *fcb = cbase + (long long)f * P.maxContours;
     const int nck = chunk_tab_pitch(P);
-    const uint32_t *ftab = chunk_tab + (long long)f * P.maxContours * nck;
+    const uint32_t *ftab = chunk_tab + (long long)f * 2 * P.maxContours * nck;
     const uint32_t *fpool = pool + (long long)f * P.maxChunks * CK;
     const unsigned dcap = (unsigned)P.maxChunks * CK;
     uint32_t *fd = dense + (long long)f * dcap;
     for (unsigned ci = blockIdx.x; ci < nc; ci += gridDim.x) {
-        const unsigned L = fco[ci].z, seed = fcs[ci];
+        const unsigned L = fco[ci].z;
+        const uint4 info = fci[ci];
         unsigned base = 0;
         if (lane == 0) base = atomicAdd((unsigned *)&counts[f].ndense, L);
         base = __shfl(base, 0, WAVE);
@@ -1474,19 +1413,21 @@ __global__ __launch_bounds__(64) void k_seg_flatten(const DevSeg *__restrict__ s
             continue;
         }
         if (lane == 0) fcb[ci] = base;
-        unsigned cur = seed, off = 0;
-        do {
-            const DevSeg *r = fsg + cur;
-            const unsigned sn = r->n;
-            const int slot = r->slot;
-            if (slot < 0) {
-                if ((unsigned)lane < sn) fd[base + off + lane] = r->pts[lane];
-            } else {
-                for (unsigned k = lane; k < sn; k += 64) fd[base + off + k] = fpool[(long long)ftab[(long long)slot * nck + (k >> 6)] * CK + (k & 63)];
-            }
-            off += sn;
-            cur = r->next_idx;
-        } while (cur != seed && off < L);
+        // the survivor's own points
+        {
+            const uint32_t *row = ftab + ((long long)P.maxContours + info.x) * nck;
+            for (unsigned k = lane; k < info.y; k += 64) fd[base + k] = fpool[(long long)row[k >> 6] * CK + (k & 63)];
+        }
+        unsigned off = info.y, cur = info.z;
+        while (off < L && cur != SEG_INVALID) {
+            const unsigned sn = fsg[cur].n;
+            if (sn == 0u) break;  // (never for a walked segment)
+            const unsigned take = sn < L - off ? sn : L - off;
+            const uint32_t *row = ftab + (long long)cur * nck;
+            for (unsigned k = lane; k < take; k += 64) fd[base + off + k] = fpool[(long long)row[k >> 6] * CK + (k & 63)];
+            off += take;
+            cur = fsg[cur].next_idx;
+        }
     }
 }
 
@@ -1525,7 +1466,7 @@ __global__ __launch_bounds__(64) void k_approx(uint4 *__restrict__ contours, con
     const int W = P.W, H = P.H;
     const int nck = chunk_tab_pitch(P);
     uint4 *fco = contours + (long long)f * P.maxContours;
-    const uint32_t *ftab = chunk_tab + (long long)f * P.maxContours * nck;
+    const uint32_t *ftab = chunk_tab + ((long long)f * 2 + 1) * P.maxContours * nck;  // survivors' chunk rows
     const uint32_t *fpool = pool + (long long)f * P.maxChunks * CK;
     // this workgroup's slots are blockIdx.x, blockIdx.x + gridDim.x, ...: 64 of them are looked at with one
     // load (a lane each); only the accepted ones of the right length class are then processed in turn

@@ -15,5 +15,5 @@ for seed in (1000, 1001, 1002):
     fr = make_frame(d, seed, width=1920, height=1080, n_markers=20)
     cor, ids = det.detect_markers(fr.image)
     c = det.tap_counts()[0]
-    print(f"seed {seed}: starts {c[0]} surv1 {c[9]} survivors {c[7]} slots {c[1]} chunks {c[8]} (= {c[8]*64} pts max) cands {c[2]} filt {c[3]} markers {c[5]} ovf {c[6]}")
+    print(f"seed {seed}: starts {c[0]} seeds {c[10]} surv1 {c[9]} survivors {c[7]} slots {c[1]} chunks {c[8]} (= {c[8]*64} pts max) cands {c[2]} filt {c[3]} markers {c[5]} ovf {c[6]}")
     print("   stage ms:", {k: round(v, 3) for k, v in det.stage_ms().items()})

@@ -4,7 +4,7 @@ set -u
 export TMPDIR=/tmp
 OUT=gpurun_out
 mkdir -p $OUT
-( time timeout 900 python -m pytest tests -m gpu -x -q ) > $OUT/pytest_gpu.log 2>&1
+( time timeout 300 python -m pytest tests -m gpu -x -q --timeout 120 ) > $OUT/pytest_gpu.log 2>&1
 echo "pytest rc=$?" >> $OUT/pytest_gpu.log
 tail -5 $OUT/pytest_gpu.log
 ( time timeout 600 python bench.py ) > $OUT/bench.log 2>&1

@@ -50,7 +50,7 @@ struct fid_ctx {
     uint2 *d_seedq = nullptr, *d_seedplane = nullptr;
     uint4 *d_wres = nullptr, *d_cinfo = nullptr;
     uint32_t *d_cbase = nullptr, *d_dense = nullptr;
-    int trace_mode = 0;  // 0: probe passes + whole-border walk; 1 (FID_TRACE=seeds): seed-accelerated
+    int trace_mode = 1;  // 1: seed-accelerated tracing; 0 (FID_TRACE=legacy): probe passes + whole-border walk only
     int max_chunks = 0;
     int walk_blocks = 0;  // one-wave workgroups per frame in the full walk pass (0 = automatic)
     uint4 *d_contours = nullptr;
@@ -571,7 +571,7 @@ fid_status fid_create(const fid_params *params, const fid_dict *dict, const fid_
     TRY(dalloc(c, &c->d_surv, F * L.max_starts_per_frame));
     c->max_chunks = (L.max_points_per_frame + CK - 1) / CK;
     TRY(dalloc(c, &c->d_pool, F * (size_t)c->max_chunks * CK));
-    c->trace_mode = getenv("FID_TRACE") && !strcmp(getenv("FID_TRACE"), "seeds") ? 1 : 0;
+    c->trace_mode = getenv("FID_TRACE") && !strcmp(getenv("FID_TRACE"), "legacy") ? 0 : 1;
     if (c->trace_mode == 1) {
         const size_t plane_words = masks_elems(c, L.max_width, L.max_height, (int)F);
         TRY(dalloc(c, &c->d_segs, F * L.max_contours_per_frame));

@@ -249,3 +249,32 @@ def test_corner_refine_none_and_param_change():
     oids, ocorners = oracle.detect(fr.image, d, params=op)
     assert ids.tolist() == oids.tolist() and np.array_equal(corners, ocorners)
     det.close()
+
+
+def test_whole_border_walk_and_seed_tracing_agree(monkeypatch):
+    """The two contour-tracing paths of the library (FID_TRACE=legacy: probe passes + whole-border walk;
+    default: seed-accelerated tracing) must both reproduce the oracle stage by stage, on adversarial blobs
+    (rings, 1-px lines, large blobs longer than maxMarkerPerimeterRate), on a noisy frame and in a batch."""
+    rng = np.random.default_rng(5)
+    blobs = np.full((720, 1280), 190, np.uint8)
+    for _ in range(150):
+        x, y = rng.integers(0, 1200), rng.integers(0, 660)
+        w, h = rng.integers(1, 300), rng.integers(1, 200)
+        blobs[y:y + h, x:x + w] = rng.choice([25, 190])
+    blobs = np.clip(blobs.astype(np.int32) + rng.integers(-6, 7, blobs.shape), 0, 255).astype(np.uint8)
+    d = get_predefined_dictionary(6)
+    fr = make_frame(d, 77, width=1280, height=720, n_markers=8)
+    for mode in ("legacy", "seeds"):
+        monkeypatch.setenv("FID_TRACE", mode)
+        det = ArucoDetector(6, max_width=1280, max_height=720, max_batch=3)
+        try:
+            check_stages(det, blobs, d)
+            check_stages(det, fr.image, d)
+            res = det.detect_markers_batch(np.stack([fr.image, blobs, fr.image]))
+            oids, ocorners = oracle.detect(fr.image, d)
+            assert res[0][1].tolist() == oids.tolist() == res[2][1].tolist()
+            assert np.array_equal(res[0][0], ocorners) and np.array_equal(res[2][0], ocorners)
+            bids, _ = oracle.detect(blobs, d)
+            assert res[1][1].tolist() == bids.tolist()
+        finally:
+            det.close()

@@ -57,6 +57,7 @@ struct fid_ctx {
     uint32_t *d_ckpts = nullptr;
     size_t ckpts_elems = 0;
     DevCand *d_cands = nullptr, *d_sorted = nullptr, *d_filtered = nullptr;
+    float4 *d_cmeta = nullptr;
     uint32_t *d_near = nullptr;
     DevIdent *d_ident = nullptr;
     fid_marker *d_pre = nullptr, *d_markers = nullptr;
@@ -361,9 +362,10 @@ fid_status run_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H, int
             mark(ST_APPROX + 1);
         }
         // ---- K5
-        hipLaunchKernelGGL(k_sort_cands, dim3(Fs), dim3(256), MC * 8, st, cands, sorted, counts, P);
+        float4 *cmeta = c->d_cmeta + f0 * MC;
+        hipLaunchKernelGGL(k_sort_cands, dim3(Fs), dim3(256), MC * 8, st, cands, sorted, cmeta, counts, P);
         mark(ST_SORT + 1);
-        hipLaunchKernelGGL(k_near, dim3(32, Fs), dim3(256), 0, st, sorted, nearb, counts, P);
+        hipLaunchKernelGGL(k_near, dim3(32, Fs), dim3(256), 0, st, sorted, cmeta, nearb, counts, P);
         mark(ST_NEAR + 1);
         hipLaunchKernelGGL(k_resolve, dim3(Fs), dim3(64), MC * 4, st, sorted, nearb, filtered, counts, worklist, nwork, P);
         mark(ST_RESOLVE + 1);
@@ -592,6 +594,7 @@ fid_status fid_create(const fid_params *params, const fid_dict *dict, const fid_
     }
     TRY(dalloc(c, &c->d_cands, F * MC));
     TRY(dalloc(c, &c->d_sorted, F * MC));
+    TRY(dalloc(c, &c->d_cmeta, F * MC));
     TRY(dalloc(c, &c->d_filtered, F * MC));
     TRY(dalloc(c, &c->d_near, F * MC * (MC / 32)));
     TRY(dalloc(c, &c->d_ident, F * MC));
@@ -625,7 +628,7 @@ void fid_destroy(fid_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    void *dev[] = {c->d_in, c->d_gray, c->d_masks, c->d_starts, c->d_surv1, c->d_surv, c->d_pool, c->d_segs, c->d_pend, c->d_seedq, c->d_seedplane, c->d_wres, c->d_cinfo, c->d_cbase, c->d_dense, c->d_contours, c->d_ckpts, c->d_cands, c->d_sorted, c->d_filtered, c->d_near,
+    void *dev[] = {c->d_in, c->d_gray, c->d_masks, c->d_starts, c->d_surv1, c->d_surv, c->d_pool, c->d_segs, c->d_pend, c->d_seedq, c->d_seedplane, c->d_wres, c->d_cinfo, c->d_cbase, c->d_dense, c->d_contours, c->d_ckpts, c->d_cands, c->d_sorted, c->d_cmeta, c->d_filtered, c->d_near,
                    c->d_ident, c->d_pre, c->d_markers, c->d_poses, c->d_counts, c->d_global, c->d_worklist, c->d_nwork, c->d_dict,
                    c->d_subpix_mask, c->d_lens, c->d_pose_in, c->d_pose_n};
     for (void *p : dev)

@@ -1743,7 +1743,7 @@ __global__ __launch_bounds__(64) void k_approx(uint4 *__restrict__ contours, con
 // RETR_LIST contours newest-first = discovery position descending) by rank sort, and apply
 // _reorderCandidatesCorners (aruco.cpp).  One workgroup per frame.
 __global__ __launch_bounds__(256) void k_sort_cands(const DevCand *__restrict__ cands, DevCand *__restrict__ sorted,
-                                                     DevCounts *__restrict__ counts, const DevParams P)
+                                                     float4 *__restrict__ cmeta, DevCounts *__restrict__ counts, const DevParams P)
 {
     extern __shared__ unsigned long long keys[];
     const int f = blockIdx.x;
@@ -1770,12 +1770,20 @@ __global__ __launch_bounds__(256) void k_sort_cands(const DevCand *__restrict__ 
             c.c[7] = ty;
         }
         dstc[rank] = c;
+        // corner sums (exact: integer coordinates) and contour size for k_near's centroid test
+        cmeta[(long long)f * P.maxCands + rank] =
+            make_float4(c.c[0] + c.c[2] + c.c[4] + c.c[6], c.c[1] + c.c[3] + c.c[5] + c.c[7], (float)c.size, 0.f);
     }
 }
 
 // K5b: _filterTooCloseCandidates pair test (aruco.cpp): bit j of near[f][i][j>>5] for j > i.
-__global__ __launch_bounds__(256) void k_near(const DevCand *__restrict__ sorted, uint32_t *__restrict__ nearb,
-                                               const DevCounts *__restrict__ counts, const DevParams P)
+// For any cyclic shift the mean squared corner distance is at least the squared distance of the corner means
+// (Jensen), so a pair whose centroids are far enough apart cannot be near: that test runs on a compact
+// {corner sums, size} record and skips the 52-byte candidate loads for almost every pair.  The margin covers the
+// float rounding of the reference's ax * ax + ay * ay.
+__global__ __launch_bounds__(256) void k_near(const DevCand *__restrict__ sorted, const float4 *__restrict__ cmeta,
+                                               uint32_t *__restrict__ nearb, const DevCounts *__restrict__ counts,
+                                               const DevParams P)
 {
     const int f = blockIdx.y;
     int n = counts[f].ncand;
@@ -1783,15 +1791,30 @@ __global__ __launch_bounds__(256) void k_near(const DevCand *__restrict__ sorted
     const int NW = P.maxCands >> 5;
     const int nw = (n + 31) >> 5;
     const DevCand *cs = sorted + (long long)f * P.maxCands;
+    const float4 *cm = cmeta + (long long)f * P.maxCands;
     uint32_t *nb = nearb + (long long)f * P.maxCands * NW;
     for (int item = blockIdx.x * blockDim.x + threadIdx.x; item < n * nw; item += gridDim.x * blockDim.x) {
         int i = item / nw, w = item % nw;
         uint32_t bits = 0;
         if (w * 32 + 31 > i) {
-            DevCand a = cs[i];
+            const float4 ma = cm[i];
+            DevCand a;
+            bool have_a = false;
             for (int b = 0; b < 32; b++) {
                 int j = w * 32 + b;
                 if (j <= i || j >= n) continue;
+                const float4 mo = cm[j];
+                {
+                    const double sz = ma.z < mo.z ? ma.z : mo.z;
+                    double lim = sz * P.minMarkerDistRate;
+                    lim = 16. * (lim * lim * (1. + 1e-5) + 1.);
+                    const double dx = (double)ma.x - (double)mo.x, dy = (double)ma.y - (double)mo.y;
+                    if (dx * dx + dy * dy >= lim) continue;  // centroids too far apart for any shift
+                }
+                if (!have_a) {
+                    a = cs[i];
+                    have_a = true;
+                }
                 const DevCand &o = cs[j];
                 int minimumPerimeter = a.size < o.size ? a.size : o.size;
                 double mmd = (double)minimumPerimeter * P.minMarkerDistRate;

@@ -307,7 +307,7 @@ fid_status run_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H, int
             k2blocks = (groups + 3) / 4;
             if (k2blocks > 256) k2blocks = 256;
         }
-        int wb = c->walk_blocks > 0 ? c->walk_blocks : (2048 + Fs - 1) / Fs;  // persistent walker waves per frame
+        int wb = c->walk_blocks > 0 ? c->walk_blocks : (4096 + Fs - 1) / Fs;  // persistent walker waves per frame (16 per CU)
         wb = wb < 8 ? 8 : (wb > 64 ? 64 : wb);
         const int cap1 = pts_cap_first(P);
         const size_t lds1 = (size_t)cap1 * sizeof(uint32_t) + (size_t)K4_SHORT_STACK * sizeof(int2);

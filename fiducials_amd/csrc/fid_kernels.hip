@@ -666,7 +666,8 @@ __global__ __launch_bounds__(256) void k_probe(const uint32_t *__restrict__ mask
 {
     const int f = blockIdx.y;
     const int lane = lane_id();
-    unsigned n = (unsigned)(LEVEL == 0 ? counts[f].nstarts : counts[f].nsurv1);
+    // LEVEL 0: starts -> surv1, LEVEL 1: surv1 -> surv, LEVEL 2: starts -> surv (single sieve)
+    unsigned n = (unsigned)(LEVEL != 1 ? counts[f].nstarts : counts[f].nsurv1);
     n = n < (unsigned)P.maxStarts ? n : (unsigned)P.maxStarts;
     int *out_count = LEVEL == 0 ? &counts[f].nsurv1 : &counts[f].nsurv;
     const int W = P.W, S = P.nscales;
@@ -780,11 +781,11 @@ __global__ __launch_bounds__(256) void k_probe(const uint32_t *__restrict__ mask
 // ------------------------------------------------------------------------------------------------
 // K3 full pass, windowed.  A border-following step is one dependent memory round trip (the 3x3
 // neighbourhood of the new pixel); with 64 independent walkers per wave the round trip of the slowest lane
-// is paid on every step.  Here each lane keeps a private WINDOW of the mask in LDS -- 2 x 2 mask tiles =
-// 64 px x 32 rows = 256 bytes, placed ahead of the direction of travel -- and steps inside it at LDS
+// is paid on every step.  Here each lane keeps a private WINDOW of the mask in LDS -- 64 px x 16 rows = 128 bytes
+// (2 word columns x four 4-row quarters of mask tiles), placed ahead of the direction of travel -- and steps inside it at LDS
 // latency.  A lane that leaves its window parks; every WALK_CKPT iterations (or as soon as nobody can step)
 // the wave reaches a CHECKPOINT where everything that touches memory is batched and asynchronous:
-//   * s_waitcnt vmcnt(0): window refills (LDS-DMA, global_load_lds_dwordx4, 16 per lane, no VGPRs in
+//   * s_waitcnt vmcnt(0): window refills (LDS-DMA, global_load_lds_dwordx4, 8 per lane, no VGPRs in
 //     flight) and the survivor prefetch issued at the PREVIOUS checkpoint have landed -> those lanes resume
 //   * finished walkers retire (contour slot written), idle lanes take the next survivors of the wave's range
 //   * every walker without a spare pool chunk gets one from the wave's ARENA (a run of WALK_ARENA chunks
@@ -798,7 +799,7 @@ __global__ __launch_bounds__(256) void k_probe(const uint32_t *__restrict__ mask
 // The backward cursor of the probe pass is not needed here: it only ever rejects, and the forward cursor
 // visits every pixel of the border.
 #ifndef WALK_CKPT
-#define WALK_CKPT 4
+#define WALK_CKPT 8
 #endif
 #define WALK_RUN 32     // most steps between two checkpoints
 #define WALK_GRAB 64    // survivors a wave takes from the frame's work queue per atomic
@@ -857,7 +858,7 @@ __device__ __forceinline__ unsigned win_raw(const uint32_t *s_winw, int lane4, i
     for (int d = 0; d < 3; d++) {
         const int r = rr + d;
         const int idx = ((r & ~3) << 6) + (r & 3) + lane4;  // chunk (r >> 2), lane, element (r & 3)
-        const uint32_t w0 = s_winw[idx], w1 = s_winw[idx + 8 * 64 * 4];
+        const uint32_t w0 = s_winw[idx], w1 = s_winw[idx + 4 * 64 * 4];
         const unsigned long long v = ((unsigned long long)w1 << 32) | w0;
         t3[d] = (unsigned)(v >> xr);
     }
@@ -874,8 +875,9 @@ __global__ __launch_bounds__(64) void k_walk_full(const uint32_t *__restrict__ m
                                                    DevCounts *__restrict__ counts, DevGlobal *__restrict__ G, const DevParams P)
 {
     constexpr bool SEG = MODE == 1;
-    // window chunk j (16 bytes = rows 4q..4q+3 of tile (t, c), j = (c * 2 + t) * 4 + q) of lane l: s_win[j * 64 + l]
-    __shared__ uint4 s_win[16 * 64];
+    // window: 64 px x 16 rows per lane = 2 word columns x 4 row quarters; chunk j = c * 4 + q (16 bytes = rows
+    // 4q..4q+3 of word column c) of lane l lives at s_win[j * 64 + l].  8 KB per wave -> 16 waves per CU.
+    __shared__ uint4 s_win[8 * 64];
     // step table: index raw | backdir << 8 -> next direction | code << 3, code = the smallest-offset background
     // 4-neighbour the search passed over (0 none, else 4 | positive << 1 | whole-row)
     __shared__ uint8_t s_lut[2048];
@@ -1105,25 +1107,25 @@ __global__ __launch_bounds__(64) void k_walk_full(const uint32_t *__restrict__ m
             }
             // ---- window refills
             if (state == ST_NEED) {
-                // padded coordinates of the 3x3 neighbourhood: bits xb .. xb+2, rows cy .. cy+2
+                // padded coordinates of the 3x3 neighbourhood: bits xb .. xb+2, rows cy .. cy+2; the window starts on a
+                // multiple of 4 rows (a 16-byte quarter of a mask tile) and lies ahead of the direction of travel
                 const int xb = cx - 1 + MASK_PADW * 32;
                 int tx = ndx >= 0 ? (xb >> 5) : ((xb + 2) >> 5) - 1;
-                int ty = ndy >= 0 ? (cy >> 4) : ((cy + 2) >> 4) - 1;
+                int wy = ndy >= 0 ? (cy & ~3) : ((cy + 2) & ~3) - 12;
                 tx = tx < 0 ? 0 : (tx > TC - 2 ? TC - 2 : tx);
-                ty = ty < 0 ? 0 : (ty > TR - 2 ? TR - 2 : ty);
+                wy = wy < 0 ? 0 : (wy > TR * MT_ROWS - 16 ? TR * MT_ROWS - 16 : wy);
                 wx0 = tx * 32;
-                wy0 = ty * MT_ROWS;
-                // two addresses (tile rows ty, ty + 1); tile column and row quarter go into the instruction offset
-                const uint32_t *g0 = pl + ((long long)ty * TC + tx) * MT_ROWS;
-                const uint32_t *g1 = g0 + (long long)TC * MT_ROWS;
-                static_for<16>([&](auto jc) {
-                    constexpr int j = decltype(jc)::value;
-                    constexpr int c = j >> 3, t = (j >> 2) & 1, q = j & 3;
-                    // the instruction offset moves the LDS destination as well as the source: compensate in the base
-                    constexpr int off = (c * MT_ROWS + q * 4) * 4;
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(t ? g1 : g0),
-                                                     (__attribute__((address_space(3))) void *)((char *)s_win + j * 1024 - off), 16,
-                                                     off, 0);
+                wy0 = wy;
+                static_for<4>([&](auto qc) {
+                    constexpr int q = decltype(qc)::value;
+                    const int row = wy + 4 * q;
+                    const uint32_t *g = pl + ((long long)(row >> 4) * TC + tx) * MT_ROWS + (row & 15);
+                    // (the instruction offset moves the LDS destination as well as the source: compensate in the base)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                                     (__attribute__((address_space(3))) void *)((char *)s_win + q * 1024), 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                                     (__attribute__((address_space(3))) void *)((char *)s_win + (4 + q) * 1024 - MT_ROWS * 4),
+                                                     16, MT_ROWS * 4, 0);
                 });
                 state = ST_LOADING;
             }
@@ -1173,7 +1175,7 @@ __global__ __launch_bounds__(64) void k_walk_full(const uint32_t *__restrict__ m
                             ndx = dx;
                             ndy = dy;
                             const unsigned xr = (unsigned)(cx + (MASK_PADW * 32 - 1) - wx0), rr = (unsigned)(cy - wy0);
-                            state = (xr > 61u || rr > 29u) ? ST_NEED : ST_ACTIVE;
+                            state = (xr > 61u || rr > 13u) ? ST_NEED : ST_ACTIVE;
                         }
                     } else if (MODE == 2 && count > 0 && (e & 0x40u) && seed_pos(cx, cy)) {
                         stopped = 1;  // the first seed state on this border: the segment chain continues from here
@@ -1193,9 +1195,9 @@ __global__ __launch_bounds__(64) void k_walk_full(const uint32_t *__restrict__ m
                         sdir = (sn + 4) & 7;
                         ndx = dx;
                         ndy = dy;
-                        // still inside the window?  bits of x-1..x+1 in [0, 64), padded rows cy..cy+2 in [0, 32)
+                        // still inside the window?  bits of x-1..x+1 in [0, 64), padded rows cy..cy+2 in [0, 16)
                         const unsigned xr = (unsigned)(cx + (MASK_PADW * 32 - 1) - wx0), rr = (unsigned)(cy - wy0);
-                        const int outside = xr > 61u || rr > 29u;
+                        const int outside = xr > 61u || rr > 13u;
                         closed = cl;
                         ok = !bad;
                         state = (bad || cl) ? ST_FINAL : outside ? ST_NEED : ST_ACTIVE;

@@ -67,11 +67,21 @@ struct DevIdent {
     unsigned char bits[FID_MAX_CELLS * FID_MAX_CELLS + 3];
 };
 
-// ---- seed-accelerated contour tracing.  SEEDS are border-following states a walker can recognise from what it holds
-// anyway (3x3 neighbourhood, back direction, position): the pixel satisfies a local start predicate, sits on the thinning
-// lattice (seed_pos) and the back direction is the one icvFetchContour would start there with.  Every seed follows its
-// border only to the next seed (a SEGMENT); a probe survivor follows its border only to the first seed and the rest of
-// the border is read off the segment chain.
+// ---- seed-accelerated contour tracing.  A border-following state is (pixel, direction d back to the previous pixel).
+// SEED states are the states a walker can recognise from what it holds anyway: the pixel sits on the class-d position of
+// the thinning lattice (seed_class) and the neighbour X(d) that border following must have found empty on the way in
+// (the one "to the right of travel": direction d+2 for an axis move, d+1 for a diagonal one) is background.  Every seed
+// follows its border only to the next seed state (a SEGMENT); a probe survivor follows its border only to the first seed
+// state and the rest of the border is read off the segment chain.
+// lattice: k = (x - 5 y) mod 128; a pixel carries class d = k / 16 when k is a multiple of 16, no class otherwise
+#define SEED_PERIOD 128
+__host__ __device__ inline int seed_class(int x, int y)
+{
+    const int k = (x - 5 * y) & (SEED_PERIOD - 1);
+    return (k & 15) ? -1 : (k >> 4);
+}
+// the neighbour direction that is empty when a state with back direction d was entered
+__host__ __device__ inline int seed_empty_dir(int d) { return (d + ((d & 1) ? 1 : 2)) & 7; }
 #define SEG_INVALID 0xffffffffu
 struct DevSeg {           // one per seed
     uint32_t next_key;    // pixel of the seed state the segment ran into: x | y << 13 (same scale)
@@ -87,8 +97,6 @@ struct DevPend {          // one per probe survivor that stopped in front of a s
     uint32_t next_idx;    // its seed index (k_seg_link)
     uint32_t pad;
 };
-// thinning lattice: 1 in 16 pixels, position along x shifts with the row
-__host__ __device__ inline bool seed_pos(int x, int y) { return ((x - 5 * y) & 15) == 0; }
 
 // per-frame counters
 struct DevCounts {

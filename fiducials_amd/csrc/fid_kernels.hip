@@ -427,11 +427,12 @@ __device__ __forceinline__ uint32_t fill_toward_lsb(uint32_t seed, uint32_t runs
 // Two kinds of starts are dropped on the spot because their border is shorter than any perimeter gate
 // (when minPerimeterPixels allows it): isolated foreground pixels (a 1-point outer border) and isolated
 // background pixels (a hole border of at most 8 points).
-// HYB = true additionally emits the SEEDS of seed-accelerated tracing: pixels that satisfy a local start predicate
-// -- outer: foreground with W, NW, N, NE background; hole: foreground with E background and NE foreground (a
-// 3x3-decidable superset of the run-level candidates) -- and sit on the thinning lattice seed_pos().  Seeds go to their
-// own list (x | y << 13 | hole << 26 | scale << 27, seed index) and, per mask word, {index of the word's first seed,
-// seed bit mask} goes to the seed-index plane so that a pixel is mapped to its seed index without any hashing.
+// HYB = true additionally emits the SEEDS of seed-accelerated tracing (fid_device.h): foreground pixels on the class-d
+// position of the thinning lattice whose neighbour in direction d is foreground and whose neighbour in direction
+// seed_empty_dir(d) is background.  Seeds go to their own list (x | y << 13 | scale << 27, seed index) and, per mask
+// word, {index of the word's first seed, seed bit mask} goes to the seed-index plane so that a pixel is mapped to its
+// seed index without any hashing.  (A seed need not lie on a real border state: such a seed walks into a real border
+// and nobody ever links to it.)
 template <bool HYB>
 __global__ __launch_bounds__(256) void k_find_starts(const uint32_t *__restrict__ masks, uint2 *__restrict__ starts,
                                                       DevCounts *__restrict__ counts, DevGlobal *__restrict__ G,
@@ -521,12 +522,19 @@ __global__ __launch_bounds__(256) void k_find_starts(const uint32_t *__restrict_
                     hole[k] = (e >> 1) | (en0 << 31);
                     cnt += __popc(outer[k]) + __popc(hole[k]);
                     if (HYB) {
-                        // thinning lattice of seed_pos(): x == 5 * y (mod 16)
-                        const uint32_t lattice = 0x00010001u << ((5 * y) & 15);
-                        // (an isolated pixel cannot be walked INTO, so it needs no seed either)
-                        seedo[k] = cur & ~Wst & ~NW & ~u & ~NE & (Est | below) & lattice;
-                        seedh[k] = cur & ~Est & NE & lattice;  // never both: outer wants NE background, hole NE foreground
-                        scnt += __popc(seedo[k] | seedh[k]);
+                        // seed states: class d of the lattice owns at most one pixel of this word; the pixel is a seed when
+                        // its neighbour in direction d (the previous pixel) is foreground and the one in direction
+                        // seed_empty_dir(d) is background
+                        const uint32_t SEst = (d >> 1) | (nextd << 31), SWst = (d << 1) | (prevd >> 31);
+                        const uint32_t nbp[8] = {Est, NE, u, NW, Wst, SWst, d, SEst};  // neighbour planes by direction
+                        uint32_t sm = 0;
+#pragma unroll
+                        for (int dd = 0; dd < 8; dd++) {
+                            const unsigned b = (unsigned)(5 * y + 16 * dd - x_base) & (SEED_PERIOD - 1);
+                            if (b < 32u) sm |= cur & nbp[dd] & ~nbp[seed_empty_dir(dd)] & (1u << b);
+                        }
+                        seedo[k] = sm;
+                        scnt += __popc(sm);
                     }
                 }
             }
@@ -582,13 +590,13 @@ __global__ __launch_bounds__(256) void k_find_starts(const uint32_t *__restrict_
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const uint32_t y = (uint32_t)(yy0 + k - 1);
-                uint32_t both = seedo[k] | seedh[k];
+                uint32_t both = seedo[k];
                 if (both) spl[k] = make_uint2(off, both);
                 while (both) {
                     int b = __ffs(both) - 1;
                     both &= both - 1;
                     if (off < scap)
-                        fsq[off] = make_uint2((uint32_t)(x_base + b) | (y << 13) | (((seedh[k] >> b) & 1u) << 26) | ((uint32_t)s << 27), off);
+                        fsq[off] = make_uint2((uint32_t)(x_base + b) | (y << 13) | ((uint32_t)s << 27), off);
                     off++;
                 }
             }
@@ -838,11 +846,8 @@ __device__ __forceinline__ void build_step_lut(uint8_t *lut, int tid, int nthrea
         unsigned seen = 0;
         for (int q = 0; q < t; q++) seen |= 1u << ((start + q) & 7);
         const int code = (seen & 4u) ? 5 : (seen & 16u) ? 4 : (seen & 1u) ? 6 : (seen & 64u) ? 7 : 0;
-        int seed = 0;
-        if (nb) {
-            if ((raw & 0x0fu) == 0u) seed = sd == first_dir(nb, 4);                    // outer: W, NW, N, NE background
-            else if (!(raw & 0x10u) && (raw & 0x04u)) seed = sd == first_dir(nb, 0);  // hole: E background, NE foreground
-        }
+        // seed-state flag (to be combined with the lattice test seed_class(x, y) == sd by the walker)
+        const int seed = ((nb >> sd) & 1u) && !((nb >> seed_empty_dir(sd)) & 1u);
         lut[e] = (uint8_t)(((start + t) & 7) | (code << 3) | (seed << 6));
     }
 }
@@ -869,7 +874,10 @@ __device__ __forceinline__ unsigned win_raw(const uint32_t *s_winw, int lane4, i
 // MODE 1: a walker follows one SEGMENT, from its seed state to the next seed state, and records length and minima.
 // MODE 2: as MODE 0, but the walker stops in front of the first seed state it meets (k_seg_chain takes over from there).
 template <int MODE>
-__global__ __launch_bounds__(64) void k_walk_full(const uint32_t *__restrict__ masks, const uint2 *__restrict__ surv,
+// Four independent walker waves per workgroup (one per SIMD: one-wave workgroups were all placed on the same SIMD of a
+// CU, which capped a CU at one SIMD's issue rate); they share nothing but the step table.
+#define WALK_WAVES 4
+__global__ __launch_bounds__(64 * WALK_WAVES) void k_walk_full(const uint32_t *__restrict__ masks, const uint2 *__restrict__ surv,
                                                    uint4 *__restrict__ contours, uint32_t *__restrict__ chunk_tab,
                                                    uint32_t *__restrict__ pool, DevSeg *__restrict__ segs, DevPend *__restrict__ pend,
                                                    DevCounts *__restrict__ counts, DevGlobal *__restrict__ G, const DevParams P)
@@ -877,7 +885,8 @@ __global__ __launch_bounds__(64) void k_walk_full(const uint32_t *__restrict__ m
     constexpr bool SEG = MODE == 1;
     // window: 64 px x 16 rows per lane = 2 word columns x 4 row quarters; chunk j = c * 4 + q (16 bytes = rows
     // 4q..4q+3 of word column c) of lane l lives at s_win[j * 64 + l].  8 KB per wave -> 16 waves per CU.
-    __shared__ uint4 s_win[8 * 64];
+    __shared__ uint4 s_win_all[WALK_WAVES][8 * 64];
+    uint4 *s_win = s_win_all[threadIdx.x >> 6];
     // step table: index raw | backdir << 8 -> next direction | code << 3, code = the smallest-offset background
     // 4-neighbour the search passed over (0 none, else 4 | positive << 1 | whole-row)
     __shared__ uint8_t s_lut[2048];
@@ -889,7 +898,7 @@ __global__ __launch_bounds__(64) void k_walk_full(const uint32_t *__restrict__ m
 #endif
     const int lane = lane_id();
     const int lane4 = lane * 4;
-    build_step_lut(s_lut, lane, 64);
+    build_step_lut(s_lut, threadIdx.x, 64 * WALK_WAVES);
     __syncthreads();
     const unsigned ccap = (unsigned)P.maxContours, pcap = (unsigned)P.maxChunks;
     const int W = P.W, S = P.nscales, TC = P.TC, TR = P.TR, F = P.nframes;
@@ -927,6 +936,8 @@ __global__ __launch_bounds__(64) void k_walk_full(const uint32_t *__restrict__ m
         unsigned ovf = 0;
         unsigned mout = 0xffffffffu, mhole = 0xffffffffu;  // MODE 1: running minima of the segment
         int too_long = 0, stopped = 0;
+        int brx = -1, bry = -1, brd = -1;  // MODE 1: state remembered for the cycle test
+        uint4 quad = make_uint4(0u, 0u, 0u, 0u);  // the last four points; every fourth step they leave as ONE 16-byte store
         unsigned arena_next = 0, arena_end = 0;  // wave-uniform
 #ifdef FID_DEBUG_STATS
         unsigned long long d_iters = 0, d_ckpts = 0, d_active = 0, d_ckcyc = 0, d_waitcyc = 0, d_forced = 0;
@@ -951,13 +962,14 @@ __global__ __launch_bounds__(64) void k_walk_full(const uint32_t *__restrict__ m
                     first = 0;
                     const unsigned raw = win_raw(s_winw, lane4, cx, cy, wx0, wy0);
                     if (raw == 0) {
-                        fpool[chunkA * CK] = (uint32_t)x0 | ((uint32_t)y0 << 16);
+                        quad.w = (uint32_t)x0 | ((uint32_t)y0 << 16);  // (written when the walker retires)
                         count = 1;
                         closed = 1;
                         mout = (unsigned)pc;
                         state = ST_FINAL;
                     } else {
-                        sdir = first_dir(raw_to_nb(raw), hole ? 0 : 4);
+                        // a seed starts in its seed state; a survivor as icvFetchContour starts a border
+                        sdir = SEG ? seed_class(x0, y0) : first_dir(raw_to_nb(raw), hole ? 0 : 4);
                         i1x = x0 + dir_dx(sdir);
                         i1y = y0 + dir_dy(sdir);
                         if (!SEG && !hole && pidx(i1x, i1y, W) < key) {
@@ -975,6 +987,21 @@ __global__ __launch_bounds__(64) void k_walk_full(const uint32_t *__restrict__ m
             }
             // ---- retire finished walkers
             if (state == ST_FINAL) {
+                {
+                    // the last count % 4 points are still in the shift register (newest in .w)
+                    const int rem = count & 3;
+                    uint32_t *dst = fpool + (((count - rem) & CK ? chunkB : chunkA) << 6) + (unsigned)((count - rem) & (CK - 1));
+                    if (rem == 1) {
+                        dst[0] = quad.w;
+                    } else if (rem == 2) {
+                        dst[0] = quad.z;
+                        dst[1] = quad.w;
+                    } else if (rem == 3) {
+                        dst[0] = quad.y;
+                        dst[1] = quad.z;
+                        dst[2] = quad.w;
+                    }
+                }
                 if (SEG) {
                     DevSeg *r = segs + (long long)f * P.maxContours + slot;
                     r->next_key = (uint32_t)cx | ((uint32_t)cy << 13);  // the seed state the walk stopped in front of
@@ -1035,6 +1062,7 @@ __global__ __launch_bounds__(64) void k_walk_full(const uint32_t *__restrict__ m
                                 s = gx >> 27;
                                 mout = mhole = 0xffffffffu;
                                 too_long = 0;
+                                brx = bry = brd = -1;
                             } else {
                                 x0 = st.x & 0xffff;
                                 y0 = st.x >> 16;
@@ -1158,14 +1186,32 @@ __global__ __launch_bounds__(64) void k_walk_full(const uint32_t *__restrict__ m
                     const int hmag = (code & 1) ? W2 : 1;
                     const int hoff = (code & 2) ? hmag : -hmag;
                     if (SEG) {
-                        if (count > 0 && (e & 0x40u) && seed_pos(cx, cy)) {
+                        if (count > 0 && (e & 0x40u) && seed_class(cx, cy) == sdir) {
                             closed = 1;  // the next seed state: the segment ends in front of it
                             state = ST_FINAL;
+                        } else if (count > 0 && cx == brx && cy == bry && sdir == brd) {
+                            // Brent's cycle test: a seed that is not a real border state has walked into a border without
+                            // seeds and is going round it; nobody links to such a seed
+                            ok = 0;
+                            state = ST_FINAL;
                         } else {
+                            if ((count & (count - 1)) == 0) {  // remember the state at every power of two
+                                brx = cx;
+                                bry = cy;
+                                brd = sdir;
+                            }
                             const unsigned hv = code ? (unsigned)(pc + hoff) : 0xffffffffu;
                             mhole = hv < mhole ? hv : mhole;
                             mout = (unsigned)pc < mout ? (unsigned)pc : mout;
-                            fpool[((count & CK ? chunkB : chunkA) << 6) + (unsigned)(count & (CK - 1))] = (uint32_t)cx | ((uint32_t)cy << 16);
+                            {
+                                const uint32_t pt = (uint32_t)cx | ((uint32_t)cy << 16);
+                                quad.x = quad.y;
+                                quad.y = quad.z;
+                                quad.z = quad.w;
+                                quad.w = pt;
+                                if ((count & 3) == 3)
+                                    *reinterpret_cast<uint4 *>(fpool + ((count & CK ? chunkB : chunkA) << 6) + (unsigned)(count & (CK - 4))) = quad;
+                            }
                             count++;
                             const int dx = dir_dx(sn), dy = dir_dy(sn);
                             cx += dx;
@@ -1177,13 +1223,21 @@ __global__ __launch_bounds__(64) void k_walk_full(const uint32_t *__restrict__ m
                             const unsigned xr = (unsigned)(cx + (MASK_PADW * 32 - 1) - wx0), rr = (unsigned)(cy - wy0);
                             state = (xr > 61u || rr > 13u) ? ST_NEED : ST_ACTIVE;
                         }
-                    } else if (MODE == 2 && count > 0 && (e & 0x40u) && seed_pos(cx, cy)) {
+                    } else if (MODE == 2 && count > 0 && (e & 0x40u) && seed_class(cx, cy) == sdir) {
                         stopped = 1;  // the first seed state on this border: the segment chain continues from here
                         state = ST_FINAL;
                     } else {
                         // background pixels examined in the 4-directions belong to this border's hole region
                         int bad = hole && code && (pc + hoff < key);
-                        if (!bad) fpool[((count & CK ? chunkB : chunkA) << 6) + (unsigned)(count & (CK - 1))] = (uint32_t)cx | ((uint32_t)cy << 16);
+                        {
+                            const uint32_t pt = (uint32_t)cx | ((uint32_t)cy << 16);
+                            quad.x = quad.y;
+                            quad.y = quad.z;
+                            quad.z = quad.w;
+                            quad.w = pt;
+                            if ((count & 3) == 3)
+                                *reinterpret_cast<uint4 *>(fpool + ((count & CK ? chunkB : chunkA) << 6) + (unsigned)(count & (CK - 4))) = quad;
+                        }
                         count++;
                         const int dx = dir_dx(sn), dy = dir_dy(sn);
                         const int nx = cx + dx, ny = cy + dy;

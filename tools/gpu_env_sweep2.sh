@@ -3,7 +3,7 @@
 export TMPDIR=/tmp
 for e in "$@"; do
   echo "== $e"
-  env $e timeout 200 python bench.py --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | python -c "
+  env $e timeout 200 python bench.py --steps ${STEPS:-3} --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):

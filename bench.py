@@ -189,7 +189,7 @@ def main():
     d_frames = torch.from_numpy(host).to(f"cuda:{local_rank}")
     torch.cuda.synchronize()
     det = ArucoDetector("DICT_5X5_250", device=local_rank, max_width=W, max_height=H, max_batch=B, max_markers=64,
-                        max_candidates=2048)
+                        max_candidates=2048, max_contours=int(os.environ.get("FID_BENCH_MAX_CONTOURS", "0")))
 
     def step():
         n = det.detect_markers_device(d_frames.data_ptr(), B, W, H, unpack=False)

@@ -73,12 +73,16 @@ struct DevIdent {
 // (the one "to the right of travel": direction d+2 for an axis move, d+1 for a diagonal one) is background.  Every seed
 // follows its border only to the next seed state (a SEGMENT); a probe survivor follows its border only to the first seed
 // state and the rest of the border is read off the segment chain.
-// lattice: k = (x - 5 y) mod 128; a pixel carries class d = k / 16 when k is a multiple of 16, no class otherwise
-#define SEED_PERIOD 128
+// lattice: k = (x - 5 y) mod SEED_PERIOD; a pixel carries class d = k >> SEED_SHIFT when k is a multiple of the class
+// spacing, no class otherwise
+#ifndef SEED_SHIFT
+#define SEED_SHIFT 4  // class spacing 2^SEED_SHIFT pixels
+#endif
+#define SEED_PERIOD (8 << SEED_SHIFT)
 __host__ __device__ inline int seed_class(int x, int y)
 {
     const int k = (x - 5 * y) & (SEED_PERIOD - 1);
-    return (k & 15) ? -1 : (k >> 4);
+    return (k & ((1 << SEED_SHIFT) - 1)) ? -1 : (k >> SEED_SHIFT);
 }
 // the neighbour direction that is empty when a state with back direction d was entered
 __host__ __device__ inline int seed_empty_dir(int d) { return (d + ((d & 1) ? 1 : 2)) & 7; }

@@ -530,7 +530,7 @@ __global__ __launch_bounds__(256) void k_find_starts(const uint32_t *__restrict_
                         uint32_t sm = 0;
 #pragma unroll
                         for (int dd = 0; dd < 8; dd++) {
-                            const unsigned b = (unsigned)(5 * y + 16 * dd - x_base) & (SEED_PERIOD - 1);
+                            const unsigned b = (unsigned)(5 * y + (dd << SEED_SHIFT) - x_base) & (SEED_PERIOD - 1);
                             if (b < 32u) sm |= cur & nbp[dd] & ~nbp[seed_empty_dir(dd)] & (1u << b);
                         }
                         seedo[k] = sm;

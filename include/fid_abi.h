@@ -108,7 +108,7 @@ typedef struct fid_limits {
     int32_t max_height;             /* [1080] */
     int32_t max_batch;              /* [1]   frames per fid_detect_batch call */
     int32_t max_starts_per_frame;   /* [262144] border-following start points, all scales */
-    int32_t max_contours_per_frame; /* [16384]  contours passing the perimeter gate, all scales */
+    int32_t max_contours_per_frame; /* [16384]  probe survivors / tracing seeds / accepted contours, all scales (each) */
     int32_t max_candidates_per_frame; /* [2048] quads leaving _findMarkerContours, all scales */
     int32_t max_markers_per_frame;  /* [256] */
     int32_t max_points_per_frame;   /* [4194304] contour points kept while borders are followed, all scales */

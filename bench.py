@@ -42,12 +42,13 @@ ALGO_BYTES = {
     "threshold": W * H + MASK_BYTES,  # K1: gray in, masks out
     "find_starts": MASK_BYTES,        # K2: masks in
     "walk_probe": MASK_BYTES,         # K3 probes: masks in (border pixels only; priced as one full read)
-    "walk_full": MASK_BYTES,          # K3 full walk: masks in (border pixels only; priced as one full read)
+    "walk_full": MASK_BYTES,          # K3 survivor walk + link / chain / flatten: masks in (priced as one full read)
+    "seed_walk": MASK_BYTES,          # K3 seed walk (own stream): masks in (border pixels only; priced as one full read)
     "approx": MASK_BYTES,             # K4: contour points of the accepted borders (priced as the masks they came from)
 }
 PIPELINE_BYTES = W * H + 2 * MASK_BYTES  # 8 812 800 B/frame
 KERNEL_OF = {"threshold": "k_threshold_fixed", "find_starts": "k_find_starts", "walk_probe": "k_probe",
-             "walk_full": "k_walk_full", "approx": "k_approx"}
+             "walk_full": "k_walk_full<2>", "seed_walk": "k_walk_full<1>", "approx": "k_approx"}
 
 
 def pmc_traffic(stage, frames_per_launch):

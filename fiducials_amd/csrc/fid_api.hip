@@ -14,9 +14,9 @@
 
 namespace {
 
-enum { ST_GRAY = 0, ST_THRESH, ST_STARTS, ST_PROBE, ST_WALK, ST_APPROX, ST_SORT, ST_NEAR, ST_RESOLVE, ST_IDENT, ST_FILTER, ST_SUBPIX, ST_POSE, ST_COUNT };
+enum { ST_GRAY = 0, ST_THRESH, ST_STARTS, ST_PROBE, ST_WALK, ST_APPROX, ST_SORT, ST_NEAR, ST_RESOLVE, ST_IDENT, ST_FILTER, ST_SUBPIX, ST_POSE, ST_SEEDWALK, ST_COUNT };
 const char *const kStageNames[ST_COUNT] = {"to_gray", "threshold", "find_starts", "walk_probe", "walk_full", "approx", "sort_cands",
-                                           "near", "resolve", "identify", "filter_markers", "subpix", "pose"};
+                                           "near", "resolve", "identify", "filter_markers", "subpix", "pose", "seed_walk"};
 
 constexpr int TX = 128, TY = 32, NT = 256;
 
@@ -352,8 +352,10 @@ fid_status run_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H, int
             HIPCHK(c, hipEventRecord(c->aux_fork[sb], st));
             HIPCHK(c, hipStreamWaitEvent(sa, c->aux_fork[sb], 0));
             const int wb2 = wb > 1 ? wb / 2 : 1;  // the two walks share the CUs' LDS
+            if (c->profile) (void)hipEventRecord(ev[14], sa);
             hipLaunchKernelGGL(k_walk_full<1>, dim3(wb2, Fs), dim3(64 * WALK_WAVES), 0, sa, masks, seedq, wres, tab, pool, segs, pend, counts,
                                c->d_global, P);
+            if (c->profile) (void)hipEventRecord(ev[15], sa);
             HIPCHK(c, hipEventRecord(c->aux_join[sb], sa));
             hipLaunchKernelGGL((k_probe<PROBE0_STEPS, 0>), dim3(64, Fs), dim3(256), 0, st, masks, starts, surv1, counts, c->d_global, P);
             hipLaunchKernelGGL((k_probe<PROBE1_STEPS, 1>), dim3(16, Fs), dim3(256), 0, st, masks, surv1, surv, counts, c->d_global, P);
@@ -422,6 +424,11 @@ fid_status run_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H, int
             for (int i = 0; i <= ST_SUBPIX; i++) {
                 float ms = 0.f;
                 if (hipEventElapsedTime(&ms, c->sub_ev[sb][i], c->sub_ev[sb][i + 1]) == hipSuccess) c->stage_ms[i] += ms;
+            }
+        if (c->trace_mode == 1)  // the seed walk runs on the auxiliary streams, beside walk_probe and part of walk_full
+            for (int sb = 0; sb < c->last_nsub; sb++) {
+                float ms = 0.f;
+                if (hipEventElapsedTime(&ms, c->sub_ev[sb][14], c->sub_ev[sb][15]) == hipSuccess) c->stage_ms[ST_SEEDWALK] += ms;
             }
     }
 #ifdef FID_DEBUG_STATS

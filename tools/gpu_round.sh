@@ -17,3 +17,4 @@ f=$(find $OUT/prof -name '*kernel_stats.csv' | head -1)
 # drop the big traces, keep the stats
 find $OUT/prof -name '*kernel_trace.csv' -size +8M -delete
 nproc; rocm-smi --showmeminfo vram 2>/dev/null | head -5
+( timeout 120 python __graft_entry__.py smoke ) > $OUT/smoke.log 2>&1; tail -2 $OUT/smoke.log

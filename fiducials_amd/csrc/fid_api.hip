@@ -444,7 +444,7 @@ fid_status run_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H, int
 #endif
     fid_status rc = FID_OK;
     if (c->h_global->overflow) {
-        c->last_error = c->h_global->overflow & 16u ? "internal error: broken segment chain" : "internal capacity exceeded (starts/contours/stack/points): raise fid_limits";
+        c->last_error = c->h_global->overflow == 16u ? "internal error: broken segment chain" : "internal capacity exceeded (starts/contours/stack/points): raise fid_limits";
         rc = FID_E_CAPACITY;
     }
     for (int f = 0; f < F; f++) {

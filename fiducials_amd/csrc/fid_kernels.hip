@@ -910,7 +910,10 @@ __global__ __launch_bounds__(64 * WALK_WAVES) void k_walk_full(const uint32_t *_
     for (;;) {
         unsigned n = (unsigned)(SEG ? counts[f].nseeds : counts[f].nsurv);
         n = n < (unsigned)P.maxStarts ? n : (unsigned)P.maxStarts;
-        n = n < ccap ? n : ccap;  // (walkers beyond the contour capacity were flagged by their producers)
+        if (n > ccap) {  // more walkers than contour rows: reported, never silently dropped
+            if (lane == 0) atomicOr(&G->overflow, 2u);
+            n = ccap;
+        }
         const uint2 *fin = surv + (long long)f * (SEG ? P.maxContours : P.maxStarts);
         unsigned *qhead = (unsigned *)(SEG ? &counts[f].nwalk2 : &counts[f].nwalk);
         uint4 *fco = contours + (long long)f * P.maxContours;
@@ -1347,12 +1350,14 @@ __global__ __launch_bounds__(256) void k_seg_link(const uint2 *__restrict__ seed
     for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < ns + nv; i += gridDim.x * blockDim.x) {
         if (i < ns) {
             const unsigned sc = fsq[i].x >> 27;
-            fsg[i].next_idx = seed_lookup(seedplane + ((long long)f * P.nscales + sc) * plane, P.TC, fsg[i].next_key);
+            const unsigned nx = seed_lookup(seedplane + ((long long)f * P.nscales + sc) * plane, P.TC, fsg[i].next_key);
+            fsg[i].next_idx = nx < ns ? nx : SEG_INVALID;  // (a seed beyond the table's capacity was reported by k_find_starts)
         } else {
             const unsigned j = i - ns;
             if (fpd[j].p) {
                 const unsigned sc = (fsv[j].y >> 16) & 0xffu;
-                fpd[j].next_idx = seed_lookup(seedplane + ((long long)f * P.nscales + sc) * plane, P.TC, fpd[j].next_key);
+                const unsigned nx = seed_lookup(seedplane + ((long long)f * P.nscales + sc) * plane, P.TC, fpd[j].next_key);
+                fpd[j].next_idx = nx < ns ? nx : SEG_INVALID;
             }
         }
     }

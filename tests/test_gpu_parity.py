@@ -278,3 +278,35 @@ def test_whole_border_walk_and_seed_tracing_agree(monkeypatch):
             assert res[1][1].tolist() == bids.tolist()
         finally:
             det.close()
+
+
+def test_internal_capacity_is_reported_not_silent(monkeypatch):
+    """Too small internal tables (seeds / survivors / points) must surface as FID_E_CAPACITY in both tracing modes --
+    never as a silently different detection list."""
+    from fiducials_amd._lib import FidError
+    d = get_predefined_dictionary(6)
+    fr = make_frame(d, 3, width=1280, height=720, n_markers=8)
+    for mode in ("legacy", "seeds"):
+        monkeypatch.setenv("FID_TRACE", mode)
+        det = ArucoDetector(6, max_width=1280, max_height=720, max_contours=96)
+        try:
+            with pytest.raises(FidError) as e:
+                det.detect_markers(fr.image)
+            assert e.value.status == _lib.FID_E_CAPACITY
+        finally:
+            det.close()
+        det = ArucoDetector(6, max_width=1280, max_height=720, max_points=4096)
+        try:
+            with pytest.raises(FidError) as e:
+                det.detect_markers(fr.image)
+            assert e.value.status == _lib.FID_E_CAPACITY
+        finally:
+            det.close()
+        # and with room to spare the same frame is fine
+        det = ArucoDetector(6, max_width=1280, max_height=720)
+        try:
+            corners, ids = det.detect_markers(fr.image)
+            oids, ocorners = oracle.detect(fr.image, d)
+            assert ids.tolist() == oids.tolist() and np.array_equal(corners, ocorners)
+        finally:
+            det.close()

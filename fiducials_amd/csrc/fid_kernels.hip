@@ -1325,9 +1325,10 @@ __global__ __launch_bounds__(64 * WALK_WAVES) void k_walk_full(const uint32_t *_
 // The longest sequential piece is the longest seed-free stretch of a border, not the longest border.
 
 // seed index of pixel (x, y) from the seed-index plane of its scale
-__device__ __forceinline__ unsigned seed_lookup(const uint2 *__restrict__ spl, int TC, unsigned key)
+__device__ __forceinline__ unsigned seed_lookup(const uint2 *__restrict__ spl, int TC, unsigned key, int W, int H)
 {
     const int x = key & 0x1fff, y = (key >> 13) & 0x1fff;
+    if (x >= W || y >= H) return SEG_INVALID;  // (never for a key a walker wrote)
     const uint2 e = spl[mask_word(TC, y + 1, MASK_PADW + (x >> 5))];
     const unsigned bit = 1u << (x & 31);
     return (e.y & bit) ? e.x + (unsigned)__popc(e.y & (bit - 1u)) : SEG_INVALID;
@@ -1350,13 +1351,15 @@ __global__ __launch_bounds__(256) void k_seg_link(const uint2 *__restrict__ seed
     for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < ns + nv; i += gridDim.x * blockDim.x) {
         if (i < ns) {
             const unsigned sc = fsq[i].x >> 27;
-            const unsigned nx = seed_lookup(seedplane + ((long long)f * P.nscales + sc) * plane, P.TC, fsg[i].next_key);
+            // (a segment that was abandoned -- too long, pool exhausted -- has no next seed)
+            const unsigned nx = fsg[i].n == SEG_INVALID ? SEG_INVALID
+                                                        : seed_lookup(seedplane + ((long long)f * P.nscales + sc) * plane, P.TC, fsg[i].next_key, P.W, P.H);
             fsg[i].next_idx = nx < ns ? nx : SEG_INVALID;  // (a seed beyond the table's capacity was reported by k_find_starts)
         } else {
             const unsigned j = i - ns;
             if (fpd[j].p) {
                 const unsigned sc = (fsv[j].y >> 16) & 0xffu;
-                const unsigned nx = seed_lookup(seedplane + ((long long)f * P.nscales + sc) * plane, P.TC, fpd[j].next_key);
+                const unsigned nx = seed_lookup(seedplane + ((long long)f * P.nscales + sc) * plane, P.TC, fpd[j].next_key, P.W, P.H);
                 fpd[j].next_idx = nx < ns ? nx : SEG_INVALID;
             }
         }

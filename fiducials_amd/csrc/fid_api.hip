@@ -53,6 +53,7 @@ struct fid_ctx {
     uint4 *d_wres = nullptr, *d_cinfo = nullptr;
     uint32_t *d_cbase = nullptr, *d_dense = nullptr;
     int trace_mode = 1;  // 1: seed-accelerated tracing; 0 (FID_TRACE=legacy): probe passes + whole-border walk only
+    long long fallbacks = 0;  // calls that fell back to the whole-border walk because the seed table was too small
     int max_chunks = 0;
     int walk_blocks = 0;  // one-wave workgroups per frame in the full walk pass (0 = automatic)
     uint4 *d_contours = nullptr;
@@ -442,6 +443,16 @@ fid_status run_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H, int
         fprintf(stderr, "walk longest %llu steps, total steps %llu\n", d[13], d[14]);
     }
 #endif
+    if (c->trace_mode == 1 && (c->h_global->overflow & (2u | 8u))) {
+        // the tracing seeds and their points scale with the total border length of the frame, texture included: when they
+        // do not fit max_contours_per_frame / max_points_per_frame, trace this call with the whole-border walk, which only
+        // needs room for the probe survivors
+        c->trace_mode = 0;
+        c->fallbacks++;
+        const fid_status rc2 = run_detect(c, d_src, F, W, H, stride, fstride, enc, out, cap_per_frame, n_per_frame);
+        c->trace_mode = 1;
+        return rc2;
+    }
     fid_status rc = FID_OK;
     if (c->h_global->overflow) {
         c->last_error = c->h_global->overflow == 16u ? "internal error: broken segment chain" : "internal capacity exceeded (starts/contours/stack/points): raise fid_limits";

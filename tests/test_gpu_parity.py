@@ -310,3 +310,38 @@ def test_internal_capacity_is_reported_not_silent(monkeypatch):
             assert ids.tolist() == oids.tolist() and np.array_equal(corners, ocorners)
         finally:
             det.close()
+
+
+def test_odd_sizes_and_textures_all_stages():
+    """Widths / heights that are not multiples of the mask word, the mask tile or the threshold tile; thin lines, checker
+    texture, salt noise, foreground touching every image border: every stage tap against the oracle."""
+    # once with room for every tracing seed of the textured frames, once with the default tables (the dense textures then
+    # overflow the seed table and the call falls back to the whole-border walk): same answers either way
+    for max_contours in (131072, 0):
+        _odd_sizes(max_contours)
+
+
+def _odd_sizes(max_contours):
+    det = ArucoDetector(7, max_width=1024, max_height=768, max_contours=max_contours)
+    d = det.dictionary
+    rng = np.random.default_rng(2024)
+    try:
+        for (w, h) in ((97, 61), (129, 121), (640, 480), (1000, 37), (33, 700), (1024, 768)):
+            img = np.full((h, w), 170, np.uint8)
+            yy, xx = np.mgrid[0:h, 0:w]
+            img[((xx // 7 + yy // 5) % 2) == 0] = 60                      # checker texture
+            for _ in range(12):                                           # thin lines
+                x0, y0 = rng.integers(0, w), rng.integers(0, h)
+                if rng.random() < 0.5:
+                    img[y0, x0:min(w, x0 + rng.integers(3, 200))] = 15
+                else:
+                    img[y0:min(h, y0 + rng.integers(3, 200)), x0] = 15
+            img[0, :] = 20                                                # foreground on every border
+            img[-1, :] = 20
+            img[:, 0] = 20
+            img[:, -1] = 20
+            salt = rng.random((h, w)) < 0.02
+            img[salt] = rng.integers(0, 256, int(salt.sum()))
+            check_stages(det, img, d)
+    finally:
+        det.close()

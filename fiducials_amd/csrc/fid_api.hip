@@ -958,3 +958,5 @@ const char *fid_last_error(fid_ctx *c) { return c ? c->last_error.c_str() : ""; 
 int32_t fid_abi_version(void) { return FID_ABI_VERSION; }
 
 }  // extern "C"
+
+#include "fid_stag.hip"

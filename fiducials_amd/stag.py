@@ -1,0 +1,63 @@
+"""Host-side mirror of the reference's STag detector interface (stag_detect/include/stag/Stag.h:41-45), on top of the
+C-ABI.  Under construction: `StagDetector(libraryHD, errorCorrection)` mirrors `Stag::Stag`; what exists on the MI355X so
+far is the EDPF edge-detection front end of `Stag::detectMarkers` (smoothing, Prewitt gradient map, anchors, anchor
+sort); the stages behind it are next.  No CPU path in this package."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import FidError
+
+TAP_SMOOTH, TAP_GRAD, TAP_DIR, TAP_ANCHORS, TAP_SORTED = range(5)
+
+
+class StagDetector:
+    def __init__(self, libraryHD: int = 21, errorCorrection: int = 7, max_width: int = 1920, max_height: int = 1080,
+                 device: int = 0):
+        self._L = _lib.load()
+        self._ctx = C.c_void_p()
+        rc = self._L.fid_stag_create(libraryHD, errorCorrection, max_width, max_height, device, C.byref(self._ctx))
+        if rc != _lib.FID_OK:
+            raise FidError(rc, self._L.fid_strerror(rc).decode())
+        self.shape = None
+
+    def close(self):
+        if getattr(self, "_ctx", None) is not None and self._ctx.value:
+            self._L.fid_stag_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def edge_frontend(self, gray: np.ndarray):
+        """Runs the EDPF front end on a mono8 image; results stay on the device (read them with tap())."""
+        img = np.asarray(gray)
+        if img.dtype != np.uint8 or img.ndim != 2:
+            raise FidError(_lib.FID_E_INVALID_ARG, "image must be uint8 HxW")
+        if img.strides[1] != 1:
+            img = np.ascontiguousarray(img)
+        h, w = img.shape
+        rc = self._L.fid_stag_edge_frontend(self._ctx, img.ctypes.data, w, h, img.strides[0])
+        if rc != _lib.FID_OK:
+            raise FidError(rc, self._L.fid_strerror(rc).decode())
+        self.shape = (h, w)
+
+    def tap(self, which: int) -> np.ndarray:
+        n = self._L.fid_stag_tap_bytes(self._ctx, which)
+        buf = np.zeros(max(n, 0), np.uint8)
+        if n:
+            rc = self._L.fid_stag_tap_read(self._ctx, which, buf.ctypes.data, n)
+            if rc != _lib.FID_OK:
+                raise FidError(rc, self._L.fid_strerror(rc).decode())
+        h, w = self.shape
+        if which in (TAP_SMOOTH, TAP_DIR, TAP_ANCHORS):
+            return buf.reshape(h, w)
+        if which == TAP_GRAD:
+            return buf.view(np.int16).reshape(h, w)
+        return buf.view(np.int32)

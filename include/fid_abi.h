@@ -182,6 +182,33 @@ int32_t fid_last_launches(fid_ctx *ctx);
 /* the HIP stream the context launches on (hipStream_t as void*), for callers that bracket it with events */
 void *fid_stream(fid_ctx *ctx);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * STag (stag_detect).  Under construction: this release covers the EDPF edge-detection FRONT END that
+ * Stag::detectMarkers (stag_detect/src/stag/Stag.cpp:24-51) reaches through QuadDetector::detectQuads ->
+ * EDInterface::runEDPFandEDLines -> DetectEdgesByEDPF (stag_detect/src/stag/ED/ED.cpp:144-187):
+ *   SmoothImage(sigma 1.0)            ED/ImageSmooth.cpp:43-55     (cv::GaussianBlur 5x5)
+ *   ComputeGradientMapByPrewitt       ED/GradientOperators.cpp:77-136
+ *   ComputeAnchorPoints               ED/EDInternals.cpp:50-86
+ *   SortAnchorsByGradValue            ED/EDInternals.cpp:146-186
+ * i.e. everything in front of the sequential edge routing.  The results stay on the device for the stages that follow
+ * (routing, EDLines, quads, decoding, pose refinement: next) and can be read back through the taps.  The constructor
+ * mirrors Stag::Stag(int libraryHD, int errorCorrection, bool keepLogs) (include/stag/Stag.h:41). */
+typedef struct fid_stag_ctx fid_stag_ctx;
+fid_status fid_stag_create(int32_t libraryHD, int32_t errorCorrection, int32_t max_width, int32_t max_height, int32_t device,
+                           fid_stag_ctx **out);
+void fid_stag_destroy(fid_stag_ctx *ctx);
+/* gray: host memory, mono8 (what StagNode::imageCallback hands to detectMarkers, stag_detect.cpp:110-131) */
+fid_status fid_stag_edge_frontend(fid_stag_ctx *ctx, const uint8_t *gray, int32_t width, int32_t height, int32_t stride_bytes);
+typedef enum fid_stag_tap {
+    FID_STAG_TAP_SMOOTH = 0,  /* uint8 [h][w] smoothed image */
+    FID_STAG_TAP_GRAD = 1,    /* int16 [h][w] |gx| + |gy| (border: GRADIENT_THRESH - 1) */
+    FID_STAG_TAP_DIR = 2,     /* uint8 [h][w] 1 = EDGE_VERTICAL, 2 = EDGE_HORIZONTAL, 0 = below GRADIENT_THRESH */
+    FID_STAG_TAP_ANCHORS = 3, /* uint8 [h][w] 254 = ANCHOR_PIXEL */
+    FID_STAG_TAP_SORTED = 4   /* int32 [n_anchors] anchor offsets, ascending gradient (the routing consumes them from the end) */
+} fid_stag_tap;
+int64_t fid_stag_tap_bytes(fid_stag_ctx *ctx, fid_stag_tap which);
+fid_status fid_stag_tap_read(fid_stag_ctx *ctx, fid_stag_tap which, void *dst, int64_t dst_bytes);
+
 const char *fid_strerror(fid_status s);
 const char *fid_last_error(fid_ctx *ctx);
 int32_t fid_abi_version(void);

@@ -1,0 +1,81 @@
+// stag_ref.cpp -- TEST INFRASTRUCTURE ONLY (parity oracle for the STag front-end).
+//
+// Builds the REFERENCE's own EDPF code where it lies under /root/reference (nothing is copied into this
+// repository): the two reference translation units below are #included in place so that their file-static
+// functions are reachable, and thin extern "C" entry points are put around them.  Output: oracle/_ref/
+// libstag_ref.so (git-ignored; it travels to the GPU box like any built library).
+//
+//   ref_stag_gradient   = ComputeGradientMapByPrewitt      stag_detect/src/stag/ED/GradientOperators.cpp:77-136
+//   ref_stag_anchors    = ComputeAnchorPoints              stag_detect/src/stag/ED/EDInternals.cpp:50-86
+//                       + SortAnchorsByGradValue           stag_detect/src/stag/ED/EDInternals.cpp:146-186
+//   ref_stag_smooth5    = what SmoothImage(..., sigma = 1.0) asks OpenCV for (ImageSmooth.cpp:43-55:
+//                         cv::GaussianBlur(src, dst, Size(5, 5), 0, 0)) -- OpenCV is not installed here, so this one
+//                         function is a RESTATEMENT ("parity unpinned"): for CV_8U and ksize 5 / sigma 0 OpenCV uses the
+//                         fixed kernel [1 4 6 4 1] / 16 in 8.8 fixed point, BORDER_REFLECT_101, i.e.
+//                         dst = (sum_ij k_i k_j src(y + i, x + j) + 128) >> 8.
+#include <stdint.h>
+#include <string.h>
+
+#include "src/stag/ED/GradientOperators.cpp"
+#include "src/stag/ED/EDInternals.cpp"
+
+static inline int reflect101(int p, int n)
+{
+    if (n == 1) return 0;
+    while (p < 0 || p >= n) p = p < 0 ? -p : 2 * n - 2 - p;
+    return p;
+}
+
+extern "C" {
+
+int ref_stag_smooth5(const uint8_t *src, uint8_t *dst, int w, int h)
+{
+    static const int k[5] = {1, 4, 6, 4, 1};
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            int acc = 0;
+            for (int i = -2; i <= 2; i++) {
+                const uint8_t *row = src + (size_t)reflect101(y + i, h) * w;
+                int racc = 0;
+                for (int j = -2; j <= 2; j++) racc += k[j + 2] * row[reflect101(x + j, w)];
+                acc += k[i + 2] * racc;
+            }
+            dst[(size_t)y * w + x] = (uint8_t)((acc + 128) >> 8);
+        }
+    return 0;
+}
+
+// grad: int16 [h][w]; dir: uint8 [h][w] (written only where grad >= thresh, as in the reference: the caller zero-fills)
+int ref_stag_gradient(const uint8_t *smooth, int16_t *grad, uint8_t *dir, int w, int h, int grad_thresh)
+{
+    ComputeGradientMapByPrewitt(const_cast<unsigned char *>(smooth), grad, dir, w, h, grad_thresh);
+    return 0;
+}
+
+// edge: uint8 [h][w] anchor map (ANCHOR_PIXEL where an anchor is); sorted: int32 [cap] anchor offsets in the order
+// JoinAnchorPointsUsingSortedAnchors consumes them from the END (ascending gradient; EDInternals.cpp:857)
+int ref_stag_anchors(const int16_t *grad, const uint8_t *dir, int w, int h, int grad_thresh, int anchor_thresh,
+                     int scan_interval, uint8_t *edge, int32_t *sorted, int cap, int *n_out)
+{
+    EdgeMap *map = new EdgeMap(w, h);
+    ComputeAnchorPoints(const_cast<short *>(grad), const_cast<unsigned char *>(dir), map, grad_thresh, anchor_thresh,
+                        scan_interval);
+    memcpy(edge, map->edgeImg, (size_t)w * h);
+    int n = 0;
+    int *A = SortAnchorsByGradValue(const_cast<short *>(grad), map, &n);
+    for (int i = 0; i < n && i < cap; i++) sorted[i] = A[i];
+    *n_out = n;
+    delete[] A;
+    delete map;
+    return n <= cap ? 0 : 1;
+}
+
+int ref_stag_constants(int *edge_vertical, int *edge_horizontal, int *anchor_pixel)
+{
+    *edge_vertical = EDGE_VERTICAL;
+    *edge_horizontal = EDGE_HORIZONTAL;
+    *anchor_pixel = ANCHOR_PIXEL;
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,76 @@
+"""ctypes wrapper of oracle/_ref/libstag_ref.so: the REFERENCE's own EDPF front-end code (gradient map, anchors, anchor
+sort) compiled in place from /root/reference/stag_detect, plus a restatement of the one OpenCV call in front of it
+(5x5 Gaussian).  TEST INFRASTRUCTURE ONLY -- imported by tests/, never by fiducials_amd."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO = os.path.join(_HERE, "_ref", "libstag_ref.so")
+REF_ROOT = "/root/reference/stag_detect"
+_LIB = None
+
+
+def build(force: bool = False) -> str | None:
+    """Compile the reference sources where they lie (only where /root/reference is mounted).  Returns the .so path, or None
+    when neither the reference tree nor a prebuilt library is available."""
+    src = os.path.join(_HERE, "stag_ref.cpp")
+    if os.path.isdir(REF_ROOT) and (force or not os.path.exists(SO) or os.path.getmtime(src) > os.path.getmtime(SO)):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "ref"])
+    return SO if os.path.exists(SO) else None
+
+
+def available() -> bool:
+    return build() is not None
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if build() is None:
+            raise RuntimeError("oracle/_ref/libstag_ref.so is missing and /root/reference is not mounted")
+        _LIB = C.CDLL(SO)
+    return _LIB
+
+
+def constants():
+    a, b, c = C.c_int(), C.c_int(), C.c_int()
+    lib().ref_stag_constants(C.byref(a), C.byref(b), C.byref(c))
+    return dict(EDGE_VERTICAL=a.value, EDGE_HORIZONTAL=b.value, ANCHOR_PIXEL=c.value)
+
+
+def smooth5(gray: np.ndarray) -> np.ndarray:
+    g = np.ascontiguousarray(gray, dtype=np.uint8)
+    out = np.empty_like(g)
+    h, w = g.shape
+    assert lib().ref_stag_smooth5(g.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), w, h) == 0
+    return out
+
+
+def gradient(smooth: np.ndarray, grad_thresh: int = 16):
+    s = np.ascontiguousarray(smooth, dtype=np.uint8)
+    h, w = s.shape
+    grad = np.zeros((h, w), np.int16)
+    dirs = np.zeros((h, w), np.uint8)  # the reference leaves pixels below the threshold unwritten: zero-filled here
+    assert lib().ref_stag_gradient(s.ctypes.data_as(C.c_void_p), grad.ctypes.data_as(C.c_void_p),
+                                   dirs.ctypes.data_as(C.c_void_p), w, h, grad_thresh) == 0
+    return grad, dirs
+
+
+def anchors(grad: np.ndarray, dirs: np.ndarray, grad_thresh: int = 16, anchor_thresh: int = 0, scan_interval: int = 1):
+    g = np.ascontiguousarray(grad, dtype=np.int16)
+    d = np.ascontiguousarray(dirs, dtype=np.uint8)
+    h, w = g.shape
+    edge = np.zeros((h, w), np.uint8)
+    cap = w * h
+    sorted_ = np.zeros(cap, np.int32)
+    n = C.c_int(0)
+    rc = lib().ref_stag_anchors(g.ctypes.data_as(C.c_void_p), d.ctypes.data_as(C.c_void_p), w, h, grad_thresh, anchor_thresh,
+                                scan_interval, edge.ctypes.data_as(C.c_void_p), sorted_.ctypes.data_as(C.c_void_p), cap,
+                                C.byref(n))
+    assert rc == 0
+    return edge, sorted_[:n.value].copy()

@@ -1,0 +1,73 @@
+"""STag EDPF front end on the MI355X, through the C-ABI, against the REFERENCE's own code
+compiled in place (oracle/_ref/libstag_ref.so: ComputeGradientMapByPrewitt, ComputeAnchorPoints,
+SortAnchorsByGradValue) -- integer work, bit-exact.  The 5x5 Gaussian in front is OpenCV's (not in this image): checked
+against the restatement in oracle/stag_ref.cpp ("parity unpinned" for that one function)."""
+import numpy as np
+import pytest
+
+from fiducials_amd import stag as fstag
+from oracle import stag_ref
+
+pytestmark = pytest.mark.gpu
+
+
+def _stag_like_frame(w, h, seed):
+    """Dark squares with a white disc and dark code dots on a noisy gradient background (Appendix C geometry, roughly)."""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w]
+    img = 140 + 40 * np.sin(xx / 97.0) * np.cos(yy / 61.0) + rng.normal(0, 3, (h, w))
+    for _ in range(6):
+        lo = max(4, min(40, min(w, h) // 4))
+        s = int(rng.integers(lo, max(lo + 1, min(w, h) // 2)))
+        x0, y0 = int(rng.integers(0, w - s)), int(rng.integers(0, h - s))
+        img[y0:y0 + s, x0:x0 + s] = 25
+        cy, cx, r = y0 + s / 2, x0 + s / 2, 0.4 * s
+        disc = (yy - cy) ** 2 + (xx - cx) ** 2 < r * r
+        img[disc] = 230
+        for _ in range(12):
+            a, rr = rng.random() * 2 * np.pi, rng.random() * 0.7 * r
+            dot = (yy - (cy + rr * np.sin(a))) ** 2 + (xx - (cx + rr * np.cos(a))) ** 2 < (0.09 * s) ** 2
+            img[dot] = 30
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+@pytest.mark.parametrize("size", [(640, 480), (1920, 1080), (333, 127), (64, 17)])
+def test_edge_frontend_matches_reference_code(size):
+    if not stag_ref.available():
+        pytest.skip("oracle/_ref/libstag_ref.so not built (needs /root/reference at build time)")
+    w, h = size
+    img = _stag_like_frame(w, h, seed=w * 31 + h)
+    det = fstag.StagDetector(21, 7, max_width=1920, max_height=1080)
+    try:
+        det.edge_frontend(img)
+        sm = det.tap(fstag.TAP_SMOOTH)
+        assert np.array_equal(sm, stag_ref.smooth5(img)), "5x5 Gaussian (restated OpenCV fixed-point kernel)"
+        # from here on the checker is the reference's own compiled code, fed with the same smoothed image
+        grad, dirs = stag_ref.gradient(sm, 16)
+        assert np.array_equal(det.tap(fstag.TAP_GRAD), grad)
+        assert np.array_equal(det.tap(fstag.TAP_DIR), dirs)
+        edge, order = stag_ref.anchors(grad, dirs, 16, 0, 1)
+        assert np.array_equal(det.tap(fstag.TAP_ANCHORS), edge)
+        got = det.tap(fstag.TAP_SORTED)
+        assert len(got) == len(order) and len(order) > 0
+        assert np.array_equal(got, order), "anchor order (ascending gradient, descending offset inside a gradient value)"
+    finally:
+        det.close()
+
+
+def test_stag_status_codes():
+    from fiducials_amd import _lib
+    from fiducials_amd._lib import FidError
+    with pytest.raises(FidError):
+        fstag.StagDetector(12, 2)  # even library
+    with pytest.raises(FidError):
+        fstag.StagDetector(21, 11)  # errorCorrection > (HD - 1) / 2
+    det = fstag.StagDetector(21, 7, max_width=320, max_height=240)
+    try:
+        with pytest.raises(FidError) as e:
+            det.edge_frontend(np.zeros((241, 320), np.uint8))
+        assert e.value.status == _lib.FID_E_INVALID_ARG
+        det.edge_frontend(np.full((240, 320), 77, np.uint8))  # flat image: no anchors
+        assert len(det.tap(fstag.TAP_SORTED)) == 0 and not det.tap(fstag.TAP_ANCHORS).any()
+    finally:
+        det.close()

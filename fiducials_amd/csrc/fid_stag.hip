@@ -5,9 +5,10 @@
 //   K9a k_stag_smooth_grad   SmoothImage(sigma = 1.0) = cv::GaussianBlur 5x5, sigma 0 (ImageSmooth.cpp:43-55) fused with
 //                            ComputeGradientMapByPrewitt (GradientOperators.cpp:77-136): one LDS tile, 3-px halo
 //   K9b k_stag_anchors       ComputeAnchorPoints (EDInternals.cpp:50-86) + the histogram of SortAnchorsByGradValue
-//   K9c k_stag_scan, k_stag_scatter, k_stag_order
+//   K9c k_stag_bandsum, k_stag_bandscan, k_stag_scan, k_stag_place
 //                            SortAnchorsByGradValue (EDInternals.cpp:146-186): counting sort by gradient value; inside a
-//                            gradient value the reference's --C[grad] placement leaves the offsets in DESCENDING order
+//                            gradient value the reference's --C[grad] placement leaves the offsets in DESCENDING order.
+//                            Counted per (row, value); slots handed out in that exact order, O(n), no sort
 //
 // Integer work throughout: results are bit-exact with the reference's own code (oracle/_ref, tests/test_gpu_stag.py).
 #include <hip/hip_runtime.h>
@@ -18,7 +19,6 @@
 #define STAG_EDGE_VERTICAL 1
 #define STAG_EDGE_HORIZONTAL 2
 #define STAG_ANCHOR_PIXEL 254
-#define STAG_GRAD_BINS 32768  // SIZE = 128 * 256 in SortAnchorsByGradValue
 
 __device__ __forceinline__ int stag_reflect101(int p, int n)
 {
@@ -89,11 +89,16 @@ __global__ __launch_bounds__(256) void k_stag_smooth_grad(const uint8_t *__restr
     }
 }
 
-// Anchor points: local gradient maxima across the edge normal (ANCHOR_THRESH, SCAN_INTERVAL as in the reference), and the
-// per-gradient-value histogram of the anchors (LDS would not hold 32768 bins: global atomics, the anchors are sparse).
+// The smoothed image is 8-bit, so |gx|, |gy| <= 3 * 255 and the gradient value never exceeds 1530: the reference's
+// 128 * 256 counting-sort bins (SIZE in SortAnchorsByGradValue) are used only below STAG_BINS.
+#define STAG_BINS 1536
+#define STAG_BAND_ROWS 8  // rows per band of k_stag_place = waves per workgroup
+
+// Anchor points: local gradient maxima across the edge normal (ANCHOR_THRESH, SCAN_INTERVAL as in the reference), counted
+// per (row, gradient value) for the counting sort (global atomics: the anchors are sparse).
 __global__ __launch_bounds__(256) void k_stag_anchors(const int16_t *__restrict__ grad, const uint8_t *__restrict__ dir, int W, int H,
                                                        int grad_thresh, int anchor_thresh, int scan_interval,
-                                                       uint8_t *__restrict__ edge, unsigned *__restrict__ hist)
+                                                       uint8_t *__restrict__ edge, unsigned *__restrict__ rowhist)
 {
     const long long total = (long long)W * H;
     for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
@@ -115,7 +120,7 @@ __global__ __launch_bounds__(256) void k_stag_anchors(const int16_t *__restrict_
                 if (d1 >= anchor_thresh && d2 >= anchor_thresh) {
                     e = STAG_ANCHOR_PIXEL;
                     // SortAnchorsByGradValue only counts anchors with 1 <= i < H-1, 1 <= j < W-1: all of these qualify
-                    atomicAdd(&hist[g], 1u);
+                    atomicAdd(&rowhist[(size_t)i * STAG_BINS + g], 1u);
                 }
             }
         }
@@ -123,67 +128,123 @@ __global__ __launch_bounds__(256) void k_stag_anchors(const int16_t *__restrict_
     }
 }
 
-// inclusive prefix sums of the histogram (one workgroup; C[g] = number of anchors with gradient <= g)
-__global__ __launch_bounds__(1024) void k_stag_scan(const unsigned *__restrict__ hist, unsigned *__restrict__ cum, unsigned *__restrict__ cursor,
-                                                     unsigned *__restrict__ n_anchors)
+// anchors per (band of STAG_BAND_ROWS rows, gradient value)
+__global__ __launch_bounds__(256) void k_stag_bandsum(const unsigned *__restrict__ rowhist, int H, unsigned *__restrict__ bandhist)
 {
-    __shared__ unsigned s_part[1024];
+    const int g = blockIdx.x * 256 + threadIdx.x, band = blockIdx.y;
+    unsigned acc = 0;
+#pragma unroll
+    for (int r = 0; r < STAG_BAND_ROWS; r++) {
+        const int row = band * STAG_BAND_ROWS + r;
+        if (row < H) acc += rowhist[(size_t)row * STAG_BINS + g];
+    }
+    bandhist[(size_t)band * STAG_BINS + g] = acc;
+}
+
+// per gradient value: bands from the LAST to the first (the reference's --C[grad] placement leaves the offsets of one
+// gradient value in descending order) -> start of each band inside the value's bucket; tot[g] = size of the bucket
+__global__ __launch_bounds__(256) void k_stag_bandscan(unsigned *__restrict__ bandhist, int nbands, unsigned *__restrict__ tot)
+{
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    unsigned acc = 0;
+    int b = nbands - 1;
+    for (; b >= 3; b -= 4) {  // four independent loads in flight
+        unsigned n[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) n[k] = bandhist[(size_t)(b - k) * STAG_BINS + g];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            bandhist[(size_t)(b - k) * STAG_BINS + g] = acc;
+            acc += n[k];
+        }
+    }
+    for (; b >= 0; b--) {
+        const unsigned n = bandhist[(size_t)b * STAG_BINS + g];
+        bandhist[(size_t)b * STAG_BINS + g] = acc;
+        acc += n;
+    }
+    tot[g] = acc;
+}
+
+// exclusive prefix sums over the gradient values (one workgroup): bstart[g] = number of anchors with a smaller gradient
+__global__ __launch_bounds__(512) void k_stag_scan(const unsigned *__restrict__ tot, unsigned *__restrict__ bstart, unsigned *__restrict__ n_anchors)
+{
+    __shared__ unsigned s_part[512];
     const int tid = threadIdx.x;
-    constexpr int PER = STAG_GRAD_BINS / 1024;  // 32 consecutive bins per thread
+    constexpr int PER = STAG_BINS / 512;
     unsigned loc[PER];
     unsigned acc = 0;
     for (int k = 0; k < PER; k++) {
-        acc += hist[tid * PER + k];
         loc[k] = acc;
+        acc += tot[tid * PER + k];
     }
     s_part[tid] = acc;
     __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) {
+    for (int d = 1; d < 512; d <<= 1) {
         unsigned v = tid >= d ? s_part[tid - d] : 0u;
         __syncthreads();
         s_part[tid] += v;
         __syncthreads();
     }
     const unsigned base = tid ? s_part[tid - 1] : 0u;
-    for (int k = 0; k < PER; k++) {
-        cum[tid * PER + k] = base + loc[k];
-        cursor[tid * PER + k] = 0u;
-    }
-    if (tid == 1023) *n_anchors = s_part[1023];
+    for (int k = 0; k < PER; k++) bstart[tid * PER + k] = base + loc[k];
+    if (tid == 511) *n_anchors = s_part[511];
 }
 
-// scatter the anchors into their gradient bucket (any order inside the bucket; k_stag_order fixes it)
-__global__ __launch_bounds__(256) void k_stag_scatter(const int16_t *__restrict__ grad, const uint8_t *__restrict__ edge, int W, int H,
-                                                       const unsigned *__restrict__ hist, const unsigned *__restrict__ cum,
-                                                       unsigned *__restrict__ cursor, int32_t *__restrict__ sorted)
+// Placement: one workgroup per band, one wave per row.  LDS holds, per (row of the band, gradient value), the next free
+// slot: bucket start + band start + anchors of that value in the LATER rows of the band.  Every wave then goes through
+// its row from the last column to the first, 64 columns at a time; lanes with the same gradient value take consecutive
+// slots in descending column order.  No sort, no atomics: the order is exactly the reference's.
+__global__ __launch_bounds__(64 * STAG_BAND_ROWS) void k_stag_place(const int16_t *__restrict__ grad, const uint8_t *__restrict__ edge, int W, int H,
+                                                                    const unsigned *__restrict__ rowhist, const unsigned *__restrict__ bandstart,
+                                                                    const unsigned *__restrict__ bstart, int32_t *__restrict__ sorted)
 {
-    const long long total = (long long)W * H;
-    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
-        if (edge[idx] != STAG_ANCHOR_PIXEL) continue;
-        const int g = grad[idx];
-        const unsigned start = cum[g] - hist[g];
-        sorted[start + atomicAdd(&cursor[g], 1u)] = (int32_t)idx;
-    }
-}
-
-// one wave per gradient value: its bucket into DESCENDING offset order (rank sort; buckets are short)
-__global__ __launch_bounds__(64) void k_stag_order(const unsigned *__restrict__ hist, const unsigned *__restrict__ cum, int32_t *__restrict__ sorted,
-                                                    int32_t *__restrict__ scratch)
-{
-    const int lane = threadIdx.x;
-    for (int g = blockIdx.x; g < STAG_GRAD_BINS; g += gridDim.x) {
-        const unsigned n = hist[g];
-        if (n < 2) continue;
-        const unsigned start = cum[g] - n;
-        for (unsigned i = lane; i < n; i += 64) scratch[start + i] = sorted[start + i];
-        __syncthreads();
-        for (unsigned i = lane; i < n; i += 64) {
-            const int32_t v = scratch[start + i];
-            unsigned rank = 0;
-            for (unsigned j = 0; j < n; j++) rank += scratch[start + j] > v;  // offsets are distinct
-            sorted[start + rank] = v;
+    __shared__ unsigned s_slot[STAG_BAND_ROWS][STAG_BINS];
+    const int band = blockIdx.x, tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    for (int g = tid; g < STAG_BINS; g += 64 * STAG_BAND_ROWS) {
+        unsigned n[STAG_BAND_ROWS];
+#pragma unroll
+        for (int r = 0; r < STAG_BAND_ROWS; r++) {
+            const int row = band * STAG_BAND_ROWS + r;
+            n[r] = row < H ? rowhist[(size_t)row * STAG_BINS + g] : 0u;
         }
-        __syncthreads();
+        unsigned acc = bstart[g] + bandstart[(size_t)band * STAG_BINS + g];
+#pragma unroll
+        for (int r = STAG_BAND_ROWS - 1; r >= 0; r--) {
+            s_slot[r][g] = acc;
+            acc += n[r];
+        }
+    }
+    __syncthreads();
+    const int row = band * STAG_BAND_ROWS + w;
+    if (row >= H) return;
+    const long long rbase = (long long)row * W;
+    const unsigned long long above = lane == 63 ? 0ull : ~0ull << (lane + 1);
+    unsigned *slot = s_slot[w];
+    for (int c4 = ((W - 1) >> 8) << 8; c4 >= 0; c4 -= 256) {
+        uint8_t e[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int col = c4 + k * 64 + lane;
+            e[k] = col < W ? edge[rbase + col] : (uint8_t)0;
+        }
+#pragma unroll
+        for (int k = 3; k >= 0; k--) {
+            const int col = c4 + k * 64 + lane;
+            const bool is_anchor = e[k] == STAG_ANCHOR_PIXEL;
+            unsigned long long pending = __ballot(is_anchor);
+            if (!pending) continue;
+            const int gv = is_anchor ? (int)grad[rbase + col] : -1;
+            while (pending) {
+                const int src = __builtin_ctzll(pending);
+                const int g0 = __builtin_amdgcn_readlane(gv, src);
+                const unsigned long long m = __ballot(gv == g0);
+                const unsigned base = slot[g0];
+                if (gv == g0) sorted[base + __builtin_popcountll(m & above)] = (int32_t)(rbase + col);
+                if (lane == src) slot[g0] = base + (unsigned)__builtin_popcountll(m);
+                pending &= ~m;
+            }
+        }
     }
 }
 
@@ -193,8 +254,8 @@ struct fid_stag_ctx {
     hipStream_t stream = nullptr;
     uint8_t *d_src = nullptr, *d_smooth = nullptr, *d_dir = nullptr, *d_edge = nullptr;
     int16_t *d_grad = nullptr;
-    unsigned *d_hist = nullptr, *d_cum = nullptr, *d_cursor = nullptr, *d_n = nullptr;
-    int32_t *d_sorted = nullptr, *d_scratch = nullptr;
+    unsigned *d_rowhist = nullptr, *d_bandhist = nullptr, *d_tot = nullptr, *d_bstart = nullptr, *d_n = nullptr;
+    int32_t *d_sorted = nullptr;
     int W = 0, H = 0;
     unsigned n_anchors = 0;
 };
@@ -223,8 +284,9 @@ fid_status fid_stag_create(int libraryHD, int errorCorrection, int max_width, in
     ok = ok && hipMalloc((void **)&c->d_src, n) == hipSuccess && hipMalloc((void **)&c->d_smooth, n) == hipSuccess &&
          hipMalloc((void **)&c->d_dir, n) == hipSuccess && hipMalloc((void **)&c->d_edge, n) == hipSuccess &&
          hipMalloc((void **)&c->d_grad, n * 2) == hipSuccess && hipMalloc((void **)&c->d_sorted, n * 4) == hipSuccess &&
-         hipMalloc((void **)&c->d_scratch, n * 4) == hipSuccess && hipMalloc((void **)&c->d_hist, STAG_GRAD_BINS * 4) == hipSuccess &&
-         hipMalloc((void **)&c->d_cum, STAG_GRAD_BINS * 4) == hipSuccess && hipMalloc((void **)&c->d_cursor, STAG_GRAD_BINS * 4) == hipSuccess &&
+         hipMalloc((void **)&c->d_rowhist, (size_t)max_height * STAG_BINS * 4) == hipSuccess &&
+         hipMalloc((void **)&c->d_bandhist, (size_t)((max_height + STAG_BAND_ROWS - 1) / STAG_BAND_ROWS) * STAG_BINS * 4) == hipSuccess &&
+         hipMalloc((void **)&c->d_tot, STAG_BINS * 4) == hipSuccess && hipMalloc((void **)&c->d_bstart, STAG_BINS * 4) == hipSuccess &&
          hipMalloc((void **)&c->d_n, 4) == hipSuccess;
     if (!ok) {
         fid_stag_destroy(c);
@@ -239,7 +301,7 @@ void fid_stag_destroy(fid_stag_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    void *dev[] = {c->d_src, c->d_smooth, c->d_dir, c->d_edge, c->d_grad, c->d_sorted, c->d_scratch, c->d_hist, c->d_cum, c->d_cursor, c->d_n};
+    void *dev[] = {c->d_src, c->d_smooth, c->d_dir, c->d_edge, c->d_grad, c->d_sorted, c->d_rowhist, c->d_bandhist, c->d_tot, c->d_bstart, c->d_n};
     for (void *p : dev)
         if (p) (void)hipFree(p);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -253,16 +315,18 @@ fid_status fid_stag_edge_frontend(fid_stag_ctx *c, const uint8_t *gray, int32_t 
     hipStream_t st = c->stream;
     const int W = width, H = height;
     if (hipMemcpy2DAsync(c->d_src, (size_t)W, gray, (size_t)stride, (size_t)W, (size_t)H, hipMemcpyHostToDevice, st) != hipSuccess) return FID_E_HIP;
-    if (hipMemsetAsync(c->d_hist, 0, STAG_GRAD_BINS * 4, st) != hipSuccess) return FID_E_HIP;
+    if (hipMemsetAsync(c->d_rowhist, 0, (size_t)H * STAG_BINS * 4, st) != hipSuccess) return FID_E_HIP;
     const int GRADIENT_THRESH = 16, ANCHOR_THRESH = 0, SCAN_INTERVAL = 1;  // DetectEdgesByEDPF, ED.cpp:155-169
     hipLaunchKernelGGL(k_stag_smooth_grad, dim3((W + SX - 1) / SX, (H + SY - 1) / SY), dim3(256), 0, st, c->d_src, W, W, H, GRADIENT_THRESH,
                        c->d_smooth, c->d_grad, c->d_dir);
-    const int blocks = 2048;
+    const int blocks = 2048, nbands = (H + STAG_BAND_ROWS - 1) / STAG_BAND_ROWS;
     hipLaunchKernelGGL(k_stag_anchors, dim3(blocks), dim3(256), 0, st, c->d_grad, c->d_dir, W, H, GRADIENT_THRESH, ANCHOR_THRESH, SCAN_INTERVAL,
-                       c->d_edge, c->d_hist);
-    hipLaunchKernelGGL(k_stag_scan, dim3(1), dim3(1024), 0, st, c->d_hist, c->d_cum, c->d_cursor, c->d_n);
-    hipLaunchKernelGGL(k_stag_scatter, dim3(blocks), dim3(256), 0, st, c->d_grad, c->d_edge, W, H, c->d_hist, c->d_cum, c->d_cursor, c->d_sorted);
-    hipLaunchKernelGGL(k_stag_order, dim3(1024), dim3(64), 0, st, c->d_hist, c->d_cum, c->d_sorted, c->d_scratch);
+                       c->d_edge, c->d_rowhist);
+    hipLaunchKernelGGL(k_stag_bandsum, dim3(STAG_BINS / 256, nbands), dim3(256), 0, st, c->d_rowhist, H, c->d_bandhist);
+    hipLaunchKernelGGL(k_stag_bandscan, dim3(STAG_BINS / 256), dim3(256), 0, st, c->d_bandhist, nbands, c->d_tot);
+    hipLaunchKernelGGL(k_stag_scan, dim3(1), dim3(512), 0, st, c->d_tot, c->d_bstart, c->d_n);
+    hipLaunchKernelGGL(k_stag_place, dim3(nbands), dim3(64 * STAG_BAND_ROWS), 0, st, c->d_grad, c->d_edge, W, H, c->d_rowhist, c->d_bandhist,
+                       c->d_bstart, c->d_sorted);
     if (hipGetLastError() != hipSuccess) return FID_E_HIP;
     if (hipMemcpyAsync(&c->n_anchors, c->d_n, 4, hipMemcpyDeviceToHost, st) != hipSuccess) return FID_E_HIP;
     if (hipStreamSynchronize(st) != hipSuccess) return FID_E_HIP;

@@ -55,6 +55,48 @@ def test_edge_frontend_matches_reference_code(size):
         det.close()
 
 
+def _compare_all(img, max_w=1920, max_h=1080):
+    det = fstag.StagDetector(21, 7, max_width=max_w, max_height=max_h)
+    try:
+        det.edge_frontend(img)
+        sm = det.tap(fstag.TAP_SMOOTH)
+        assert np.array_equal(sm, stag_ref.smooth5(img))
+        grad, dirs = stag_ref.gradient(sm, 16)
+        assert np.array_equal(det.tap(fstag.TAP_GRAD), grad)
+        assert np.array_equal(det.tap(fstag.TAP_DIR), dirs)
+        edge, order = stag_ref.anchors(grad, dirs, 16, 0, 1)
+        assert np.array_equal(det.tap(fstag.TAP_ANCHORS), edge)
+        got = det.tap(fstag.TAP_SORTED)
+        assert len(got) == len(order)
+        assert np.array_equal(got, order)
+        return len(order)
+    finally:
+        det.close()
+
+
+@pytest.mark.parametrize("kind", ["hstripes", "vstripes", "checker", "noise", "saturated"])
+def test_anchor_order_worst_cases(kind):
+    """Noise-free patterns put thousands of anchors with ONE gradient value into a row (the placement's worst case:
+    every lane of a wave in the same bucket), noise gives 64 different values per wave, black/white steps reach the
+    largest gradient value (1530)."""
+    if not stag_ref.available():
+        pytest.skip("oracle/_ref/libstag_ref.so not built (needs /root/reference at build time)")
+    w, h = 1283, 517
+    yy, xx = np.mgrid[0:h, 0:w]
+    if kind == "hstripes":
+        img = np.where((yy // 9) % 2 == 0, 40, 200)
+    elif kind == "vstripes":
+        img = np.where((xx // 7) % 2 == 0, 60, 180)
+    elif kind == "checker":
+        img = np.where(((xx // 11) + (yy // 13)) % 2 == 0, 0, 255)
+    elif kind == "noise":
+        img = np.random.default_rng(5).integers(0, 256, (h, w))
+    else:
+        img = np.where(((xx // 3) + (yy // 3)) % 2 == 0, 0, 255)
+    n = _compare_all(img.astype(np.uint8))
+    assert n > 1000
+
+
 def test_stag_status_codes():
     from fiducials_amd import _lib
     from fiducials_amd._lib import FidError

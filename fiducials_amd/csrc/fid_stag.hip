@@ -248,6 +248,303 @@ __global__ __launch_bounds__(64 * STAG_BAND_ROWS) void k_stag_place(const int16_
     }
 }
 
+// ------------------------------------------------------------------------------------------------ K10: edge routing
+// JoinAnchorPointsUsingSortedAnchors (EDInternals.cpp:842-1448): from every anchor that is still an anchor, strongest
+// first, draw the edge through the gradient ridge in both directions; where the edge orientation flips, branch; keep the
+// chain tree, emit its longest path as one segment and every remaining path of >= 10 pixels as further segments.  Every
+// decision reads what earlier walks left in the edge image, so the order is part of the result: this first version keeps
+// the reference's order by running ONE lane per frame (exact, slow); the walks of different connected components of
+// {grad >= GRADIENT_THRESH} never meet, which is the parallelism the next version uses.
+// The restatement is table-driven (one body for LEFT / RIGHT / UP / DOWN) and keeps the reference's array semantics where
+// they are visible in the result: 16-bit chain fields, the scratch pixel array shared by all chains of one anchor, the
+// contiguous output pixel array (a segment may look at the last pixel of the segment before it).
+#define STAG_EDGE_PIXEL 255
+#define STAG_MIN_PATH_LEN 10  // DoDetectEdgesByED, EDInternals.cpp:2604
+enum { SR_LEFT = 0, SR_RIGHT = 1, SR_UP = 2, SR_DOWN = 3 };
+
+struct StagChain {
+    int16_t dir;
+    uint16_t len;
+    int16_t parent;
+    int16_t child[2];
+    int32_t pix;  // first pixel of the chain in the scratch pixel array
+};
+
+struct StagRoute {
+    const int16_t *grad;
+    const uint8_t *dir;
+    uint8_t *edge;
+    int W, H;
+    int2 *pix;        // scratch: pixels of the chains of the current anchor (x = row, y = column)
+    int4 *stack;      // scratch: pending branches (r, c, dir, parent); reused by the tree walk of longest()
+    StagChain *chains;
+    int *chainNos;
+    int capPix, capStack, capChains, capNos;
+    int2 *outpix;     // map->pixels
+    int2 *segs;       // (first pixel, number of pixels) per segment
+    int capOut, capSegs;
+    int *counters;    // [0] segments [1] pixels used in outpix [2] overflow flags
+};
+
+__device__ __forceinline__ bool sr_near(int2 a, int2 b)
+{
+    int dr = a.x - b.x, dc = a.y - b.y;
+    dr = dr < 0 ? -dr : dr;
+    dc = dc < 0 ? -dc : dc;
+    return dr <= 1 && dc <= 1;
+}
+
+struct StagRouter {
+    StagRoute R;
+    int noSegments, totalPixels, overflow;
+    int segbase, nsp;  // the segment being assembled: first pixel in outpix, pixels so far
+
+    __device__ int2 cpx(int ch, int i) const
+    {
+        const int k = R.chains[ch].pix + i;
+        return k >= 0 ? R.pix[k] : make_int2(-1000, -1000);  // (the reference reads in front of its array there)
+    }
+    __device__ int2 seg(int i) const
+    {
+        const int k = segbase + i;
+        return k >= 0 ? R.outpix[k] : make_int2(-1000, -1000);
+    }
+    __device__ void seg_put(int2 v)
+    {
+        const int k = segbase + nsp;
+        if (k < R.capOut) R.outpix[k] = v;
+        else overflow |= 1;
+        nsp++;
+    }
+    // LongestChain (EDInternals.cpp:191-214): length of the longest root-to-leaf path; prunes the shorter child of every
+    // chain it visits.  Chains of length 0 end the descent.
+    __device__ int longest(int root)
+    {
+        StagChain *ch = R.chains;
+        if (root == -1 || ch[root].len == 0) return 0;
+        int sp = 0, ret = 0;
+        R.stack[sp++] = make_int4(root, 0, 0, 0);
+        while (sp > 0) {
+            int4 e = R.stack[sp - 1];
+            const int node = e.x;
+            if (e.y == 0) {
+                e.y = 1;
+                R.stack[sp - 1] = e;
+                const int c = ch[node].child[0];
+                if (c != -1 && ch[c].len != 0) {
+                    if (sp < R.capStack) R.stack[sp++] = make_int4(c, 0, 0, 0);
+                    else { overflow |= 2; ret = 0; }
+                    if (!(overflow & 2)) continue;
+                }
+                ret = 0;
+            }
+            if (e.y == 1) {
+                e.z = ret;
+                e.y = 2;
+                R.stack[sp - 1] = e;
+                const int c = ch[node].child[1];
+                if (c != -1 && ch[c].len != 0) {
+                    if (sp < R.capStack) { R.stack[sp++] = make_int4(c, 0, 0, 0); continue; }
+                    overflow |= 2;
+                }
+                ret = 0;
+            }
+            const int len0 = e.z, len1 = ret;
+            int mx;
+            if (len0 >= len1) {
+                mx = len0;
+                ch[node].child[1] = -1;
+            } else {
+                mx = len1;
+                ch[node].child[0] = -1;
+            }
+            ret = ch[node].len + mx;
+            sp--;
+        }
+        return ret;
+    }
+    // RetrieveChainNos (EDInternals.cpp:219-234)
+    __device__ int retrieve(int root)
+    {
+        int count = 0;
+        while (root != -1) {
+            if (count < R.capNos) R.chainNos[count] = root;
+            else { overflow |= 4; break; }
+            count++;
+            root = R.chains[root].child[0] != -1 ? R.chains[root].child[0] : R.chains[root].child[1];
+        }
+        return count;
+    }
+    // drop pixels at the end of the segment that touch the pixel the next chain starts with
+    __device__ void trim_tail(int2 f)
+    {
+        int index = nsp - 2;
+        while (index >= 0) {
+            if (!sr_near(f, seg(index))) break;
+            nsp--;
+            index--;
+        }
+    }
+    __device__ void append_forward(int count)
+    {
+        StagChain *ch = R.chains;
+        for (int k = 0; k < count; k++) {
+            const int cn = R.chainNos[k];
+            trim_tail(cpx(cn, 0));
+            int start = 0;
+            const int L = ch[cn].len;
+            if (L > 1 && sr_near(cpx(cn, 1), seg(nsp - 1))) start = 1;
+            for (int l = start; l < L; l++) seg_put(cpx(cn, l));
+            ch[cn].len = 0;  // copied
+        }
+    }
+    __device__ void close_segment(bool clean_first)
+    {
+        int first = segbase, n = nsp;
+        totalPixels += nsp;
+        if (clean_first && sr_near(seg(1), seg(nsp - 1))) {
+            first++;
+            n--;
+        }
+        if (noSegments < R.capSegs) R.segs[noSegments] = make_int2(first, n);
+        else overflow |= 8;
+        noSegments++;
+    }
+
+    __device__ void route_anchor(int r0, int c0, int grad_thresh)
+    {
+        const int W = R.W;
+        StagChain *ch = R.chains;
+        ch[0].dir = 0; ch[0].len = 0; ch[0].parent = -1; ch[0].child[0] = ch[0].child[1] = -1; ch[0].pix = -1;
+        int noChains = 1, len = 0, dup = 0, top = -1;
+        if (R.dir[r0 * W + c0] == STAG_EDGE_VERTICAL) {
+            R.stack[++top] = make_int4(r0, c0, SR_DOWN, 0);
+            R.stack[++top] = make_int4(r0, c0, SR_UP, 0);
+        } else {
+            R.stack[++top] = make_int4(r0, c0, SR_RIGHT, 0);
+            R.stack[++top] = make_int4(r0, c0, SR_LEFT, 0);
+        }
+        while (top >= 0) {
+            const int4 e = R.stack[top--];
+            int r = e.x, c = e.y;
+            const int d = e.z, parent = e.w;
+            if (noChains >= R.capChains || len + 2 >= R.capPix || top + 3 >= R.capStack) {
+                overflow |= 16;
+                break;
+            }
+            if (R.edge[r * W + c] != STAG_EDGE_PIXEL) dup++;
+            const int cur = noChains;
+            ch[cur].dir = (int16_t)d; ch[cur].parent = (int16_t)parent; ch[cur].child[0] = ch[cur].child[1] = -1; ch[cur].pix = len;
+            int chainLen = 0;
+            R.pix[len++] = make_int2(r, c);
+            chainLen++;
+            const bool horiz = d == SR_LEFT || d == SR_RIGHT;
+            const int need = horiz ? STAG_EDGE_HORIZONTAL : STAG_EDGE_VERTICAL;
+            const int ar = d == SR_UP ? -1 : d == SR_DOWN ? 1 : 0, ac = d == SR_LEFT ? -1 : d == SR_RIGHT ? 1 : 0;
+            const int pr = horiz ? 1 : 0, pc = horiz ? 0 : 1;            // across the walking direction
+            const int fs = (d == SR_LEFT || d == SR_UP) ? -1 : 1;         // which diagonal is looked at first
+            const int slot = (d == SR_LEFT || d == SR_UP) ? 0 : 1;
+            bool stopped = false;
+            while (R.dir[r * W + c] == need) {
+                R.edge[r * W + c] = STAG_EDGE_PIXEL;
+                uint8_t *s1 = R.edge + (r + pr) * W + (c + pc), *s2 = R.edge + (r - pr) * W + (c - pc);
+                if (*s1 == STAG_ANCHOR_PIXEL) *s1 = 0;
+                if (*s2 == STAG_ANCHOR_PIXEL) *s2 = 0;
+                const int nr = r + ar, nc = c + ac;
+                if (R.edge[nr * W + nc] >= STAG_ANCHOR_PIXEL) {
+                    r = nr; c = nc;
+                } else if (R.edge[(nr + fs * pr) * W + nc + fs * pc] >= STAG_ANCHOR_PIXEL) {
+                    r = nr + fs * pr; c = nc + fs * pc;
+                } else if (R.edge[(nr - fs * pr) * W + nc - fs * pc] >= STAG_ANCHOR_PIXEL) {
+                    r = nr - fs * pr; c = nc - fs * pc;
+                } else {
+                    const int A = R.grad[(nr - pr) * W + nc - pc], B = R.grad[nr * W + nc], Cg = R.grad[(nr + pr) * W + nc + pc];
+                    int side = 0;
+                    if (A > B) side = A > Cg ? -1 : 1;
+                    else if (Cg > B) side = 1;
+                    r = nr + side * pr; c = nc + side * pc;
+                }
+                if (R.edge[r * W + c] == STAG_EDGE_PIXEL || R.grad[r * W + c] < grad_thresh) {
+                    ch[cur].len = (uint16_t)chainLen;
+                    ch[parent].child[slot] = (int16_t)cur;
+                    noChains++;
+                    stopped = true;
+                    break;
+                }
+                if (len + 2 >= R.capPix) { overflow |= 16; stopped = true; break; }
+                R.pix[len++] = make_int2(r, c);
+                chainLen++;
+            }
+            if (stopped) continue;
+            // the edge turns here: branch both ways across, this chain ends in front of the turning pixel
+            R.stack[++top] = make_int4(r, c, horiz ? SR_DOWN : SR_RIGHT, cur);
+            R.stack[++top] = make_int4(r, c, horiz ? SR_UP : SR_LEFT, cur);
+            len--;
+            chainLen--;
+            ch[cur].len = (uint16_t)chainLen;
+            ch[parent].child[slot] = (int16_t)cur;
+            noChains++;
+        }
+        if (len - dup < STAG_MIN_PATH_LEN) {
+            for (int k = 0; k < len; k++) R.edge[R.pix[k].x * W + R.pix[k].y] = 0;
+            return;
+        }
+        // ---- the chain tree -> segments
+        segbase = totalPixels;
+        nsp = 0;
+        int totalLen = longest(ch[0].child[1]);
+        if (totalLen > 0) {  // the path behind the anchor, copied backwards so that the segment runs through the anchor
+            const int count = retrieve(ch[0].child[1]);
+            for (int k = count - 1; k >= 0; k--) {
+                const int cn = R.chainNos[k];
+                trim_tail(cpx(cn, ch[cn].len - 1));
+                if (ch[cn].len > 1 && sr_near(cpx(cn, ch[cn].len - 2), seg(nsp - 1))) ch[cn].len--;
+                for (int l = ch[cn].len - 1; l >= 0; l--) seg_put(cpx(cn, l));
+                ch[cn].len = 0;
+            }
+        }
+        totalLen = longest(ch[0].child[0]);
+        if (totalLen > 1) {
+            const int count = retrieve(ch[0].child[0]);
+            const int first = R.chainNos[0];  // its first pixel is the anchor again
+            ch[first].pix++;
+            ch[first].len--;
+            append_forward(count);
+        }
+        close_segment(true);
+        for (int k = 2; k < noChains; k++) {  // what is left of the tree
+            if (ch[k].len < 2) continue;
+            totalLen = longest(k);
+            if (totalLen >= 10) {
+                segbase = totalPixels;
+                nsp = 0;
+                append_forward(retrieve(k));
+                close_segment(false);
+            }
+        }
+    }
+};
+
+__global__ __launch_bounds__(64) void k_stag_route_seq(StagRoute R, const int32_t *__restrict__ sorted, const unsigned *__restrict__ n_anchors,
+                                                       int grad_thresh)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    StagRouter S;
+    S.R = R;
+    S.noSegments = S.totalPixels = S.overflow = 0;
+    S.segbase = S.nsp = 0;
+    const int n = (int)*n_anchors;
+    for (int k = n - 1; k >= 0; k--) {
+        const int off = sorted[k];
+        if (R.edge[off] != STAG_ANCHOR_PIXEL) continue;
+        S.route_anchor(off / R.W, off % R.W, grad_thresh);
+        if (S.overflow) break;
+    }
+    R.counters[0] = S.noSegments;
+    R.counters[1] = S.totalPixels;
+    R.counters[2] = S.overflow;
+}
+
 // ------------------------------------------------------------------------------------------------ C-ABI
 struct fid_stag_ctx {
     int device = 0, maxW = 0, maxH = 0, libraryHD = 0, errorCorrection = 0;
@@ -256,6 +553,13 @@ struct fid_stag_ctx {
     int16_t *d_grad = nullptr;
     unsigned *d_rowhist = nullptr, *d_bandhist = nullptr, *d_tot = nullptr, *d_bstart = nullptr, *d_n = nullptr;
     int32_t *d_sorted = nullptr;
+    uint8_t *d_edgeimg = nullptr;  // edge image of the routing (starts as a copy of the anchor map)
+    int2 *d_rpix = nullptr, *d_outpix = nullptr, *d_segs = nullptr;
+    int4 *d_rstack = nullptr;
+    StagChain *d_chains = nullptr;
+    int *d_chainnos = nullptr, *d_rcount = nullptr;
+    int rcount[3] = {0, 0, 0};
+    bool routed = false;
     int W = 0, H = 0;
     unsigned n_anchors = 0;
 };
@@ -288,6 +592,12 @@ fid_status fid_stag_create(int libraryHD, int errorCorrection, int max_width, in
          hipMalloc((void **)&c->d_bandhist, (size_t)((max_height + STAG_BAND_ROWS - 1) / STAG_BAND_ROWS) * STAG_BINS * 4) == hipSuccess &&
          hipMalloc((void **)&c->d_tot, STAG_BINS * 4) == hipSuccess && hipMalloc((void **)&c->d_bstart, STAG_BINS * 4) == hipSuccess &&
          hipMalloc((void **)&c->d_n, 4) == hipSuccess;
+    // routing: the reference sizes its scratch arrays for the worst case (width * height entries each, EDInternals.cpp:848-853)
+    ok = ok && hipMalloc((void **)&c->d_edgeimg, n) == hipSuccess && hipMalloc((void **)&c->d_rpix, n * sizeof(int2)) == hipSuccess &&
+         hipMalloc((void **)&c->d_outpix, n * sizeof(int2)) == hipSuccess && hipMalloc((void **)&c->d_segs, (n / 8 + 16) * sizeof(int2)) == hipSuccess &&
+         hipMalloc((void **)&c->d_rstack, n * sizeof(int4)) == hipSuccess && hipMalloc((void **)&c->d_chains, 32767 * sizeof(StagChain)) == hipSuccess &&
+         hipMalloc((void **)&c->d_chainnos, (size_t)(max_width + max_height) * 8 * sizeof(int)) == hipSuccess &&
+         hipMalloc((void **)&c->d_rcount, 16) == hipSuccess;
     if (!ok) {
         fid_stag_destroy(c);
         return FID_E_OUT_OF_MEMORY;
@@ -301,7 +611,8 @@ void fid_stag_destroy(fid_stag_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    void *dev[] = {c->d_src, c->d_smooth, c->d_dir, c->d_edge, c->d_grad, c->d_sorted, c->d_rowhist, c->d_bandhist, c->d_tot, c->d_bstart, c->d_n};
+    void *dev[] = {c->d_src, c->d_smooth, c->d_dir, c->d_edge, c->d_grad, c->d_sorted, c->d_rowhist, c->d_bandhist, c->d_tot, c->d_bstart, c->d_n,
+                   c->d_edgeimg, c->d_rpix, c->d_outpix, c->d_segs, c->d_rstack, c->d_chains, c->d_chainnos, c->d_rcount};
     for (void *p : dev)
         if (p) (void)hipFree(p);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -332,6 +643,32 @@ fid_status fid_stag_edge_frontend(fid_stag_ctx *c, const uint8_t *gray, int32_t 
     if (hipStreamSynchronize(st) != hipSuccess) return FID_E_HIP;
     c->W = W;
     c->H = H;
+    c->routed = false;
+    return FID_OK;
+}
+
+fid_status fid_stag_detect_edges(fid_stag_ctx *c, const uint8_t *gray, int32_t width, int32_t height, int32_t stride)
+{
+    fid_status rc = fid_stag_edge_frontend(c, gray, width, height, stride);
+    if (rc != FID_OK) return rc;
+    hipStream_t st = c->stream;
+    const int W = c->W, H = c->H;
+    const size_t n = (size_t)W * H;
+    if (hipMemcpyAsync(c->d_edgeimg, c->d_edge, n, hipMemcpyDeviceToDevice, st) != hipSuccess) return FID_E_HIP;
+    // pixels the routing has not written read as (-1, -1) (the reference reads uninitialised memory there)
+    if (hipMemsetAsync(c->d_outpix, 0xff, n * sizeof(int2), st) != hipSuccess) return FID_E_HIP;
+    StagRoute R;
+    R.grad = c->d_grad; R.dir = c->d_dir; R.edge = c->d_edgeimg; R.W = W; R.H = H;
+    R.pix = c->d_rpix; R.stack = c->d_rstack; R.chains = c->d_chains; R.chainNos = c->d_chainnos;
+    R.capPix = (int)((size_t)c->maxW * c->maxH); R.capStack = R.capPix; R.capChains = 32767; R.capNos = (c->maxW + c->maxH) * 8;
+    R.outpix = c->d_outpix; R.segs = c->d_segs; R.capOut = R.capPix; R.capSegs = R.capPix / 8 + 16;
+    R.counters = c->d_rcount;
+    hipLaunchKernelGGL(k_stag_route_seq, dim3(1), dim3(64), 0, st, R, c->d_sorted, c->d_n, 16);
+    if (hipGetLastError() != hipSuccess) return FID_E_HIP;
+    if (hipMemcpyAsync(c->rcount, c->d_rcount, 12, hipMemcpyDeviceToHost, st) != hipSuccess) return FID_E_HIP;
+    if (hipStreamSynchronize(st) != hipSuccess) return FID_E_HIP;
+    if (c->rcount[2]) return FID_E_CAPACITY;
+    c->routed = true;
     return FID_OK;
 }
 
@@ -345,6 +682,9 @@ int64_t fid_stag_tap_bytes(fid_stag_ctx *c, fid_stag_tap which)
     case FID_STAG_TAP_ANCHORS: return n;
     case FID_STAG_TAP_GRAD: return n * 2;
     case FID_STAG_TAP_SORTED: return (int64_t)c->n_anchors * 4;
+    case FID_STAG_TAP_EDGEIMG: return c->routed ? n : 0;
+    case FID_STAG_TAP_SEGMENTS: return c->routed ? (int64_t)c->rcount[0] * 8 : 0;
+    case FID_STAG_TAP_SEGPIX: return c->routed ? (int64_t)c->rcount[1] * 8 : 0;
     }
     return 0;
 }
@@ -362,6 +702,9 @@ fid_status fid_stag_tap_read(fid_stag_ctx *c, fid_stag_tap which, void *dst, int
     case FID_STAG_TAP_DIR: src = c->d_dir; break;
     case FID_STAG_TAP_ANCHORS: src = c->d_edge; break;
     case FID_STAG_TAP_SORTED: src = c->d_sorted; break;
+    case FID_STAG_TAP_EDGEIMG: src = c->d_edgeimg; break;
+    case FID_STAG_TAP_SEGMENTS: src = c->d_segs; break;
+    case FID_STAG_TAP_SEGPIX: src = c->d_outpix; break;
     }
     if (!src) return FID_E_INVALID_ARG;
     if (hipSetDevice(c->device) != hipSuccess) return FID_E_HIP;

@@ -11,7 +11,7 @@ import numpy as np
 from . import _lib
 from ._lib import FidError
 
-TAP_SMOOTH, TAP_GRAD, TAP_DIR, TAP_ANCHORS, TAP_SORTED = range(5)
+TAP_SMOOTH, TAP_GRAD, TAP_DIR, TAP_ANCHORS, TAP_SORTED, TAP_EDGEIMG, TAP_SEGMENTS, TAP_SEGPIX = range(8)
 
 
 class StagDetector:
@@ -37,13 +37,26 @@ class StagDetector:
 
     def edge_frontend(self, gray: np.ndarray):
         """Runs the EDPF front end on a mono8 image; results stay on the device (read them with tap())."""
+        self._run(self._L.fid_stag_edge_frontend, gray)
+
+    def detect_edges(self, gray: np.ndarray):
+        """Front end + edge routing (DoDetectEdgesByED): the EdgeMap stays on the device; edge_segments() reads it."""
+        self._run(self._L.fid_stag_detect_edges, gray)
+
+    def edge_segments(self):
+        """List of (n_i, 2) int32 arrays of (r, c): EdgeMap::segments after detect_edges()."""
+        segs = self.tap(TAP_SEGMENTS).reshape(-1, 2)
+        pix = self.tap(TAP_SEGPIX).reshape(-1, 2)
+        return [pix[a:a + n] for a, n in segs]
+
+    def _run(self, fn, gray):
         img = np.asarray(gray)
         if img.dtype != np.uint8 or img.ndim != 2:
             raise FidError(_lib.FID_E_INVALID_ARG, "image must be uint8 HxW")
         if img.strides[1] != 1:
             img = np.ascontiguousarray(img)
         h, w = img.shape
-        rc = self._L.fid_stag_edge_frontend(self._ctx, img.ctypes.data, w, h, img.strides[0])
+        rc = fn(self._ctx, img.ctypes.data, w, h, img.strides[0])
         if rc != _lib.FID_OK:
             raise FidError(rc, self._L.fid_strerror(rc).decode())
         self.shape = (h, w)
@@ -56,7 +69,7 @@ class StagDetector:
             if rc != _lib.FID_OK:
                 raise FidError(rc, self._L.fid_strerror(rc).decode())
         h, w = self.shape
-        if which in (TAP_SMOOTH, TAP_DIR, TAP_ANCHORS):
+        if which in (TAP_SMOOTH, TAP_DIR, TAP_ANCHORS, TAP_EDGEIMG):
             return buf.reshape(h, w)
         if which == TAP_GRAD:
             return buf.view(np.int16).reshape(h, w)

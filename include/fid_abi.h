@@ -199,12 +199,19 @@ fid_status fid_stag_create(int32_t libraryHD, int32_t errorCorrection, int32_t m
 void fid_stag_destroy(fid_stag_ctx *ctx);
 /* gray: host memory, mono8 (what StagNode::imageCallback hands to detectMarkers, stag_detect.cpp:110-131) */
 fid_status fid_stag_edge_frontend(fid_stag_ctx *ctx, const uint8_t *gray, int32_t width, int32_t height, int32_t stride_bytes);
+/* the front end + the edge routing JoinAnchorPointsUsingSortedAnchors (ED/EDInternals.cpp:842-1448): DoDetectEdgesByED
+ * (ED/EDInternals.cpp:2598-2619) complete; the EdgeMap stays on the device.  FID_E_CAPACITY if a scratch array is too small. */
+fid_status fid_stag_detect_edges(fid_stag_ctx *ctx, const uint8_t *gray, int32_t width, int32_t height, int32_t stride_bytes);
 typedef enum fid_stag_tap {
     FID_STAG_TAP_SMOOTH = 0,  /* uint8 [h][w] smoothed image */
     FID_STAG_TAP_GRAD = 1,    /* int16 [h][w] |gx| + |gy| (border: GRADIENT_THRESH - 1) */
     FID_STAG_TAP_DIR = 2,     /* uint8 [h][w] 1 = EDGE_VERTICAL, 2 = EDGE_HORIZONTAL, 0 = below GRADIENT_THRESH */
     FID_STAG_TAP_ANCHORS = 3, /* uint8 [h][w] 254 = ANCHOR_PIXEL */
-    FID_STAG_TAP_SORTED = 4   /* int32 [n_anchors] anchor offsets, ascending gradient (the routing consumes them from the end) */
+    FID_STAG_TAP_SORTED = 4,  /* int32 [n_anchors] anchor offsets, ascending gradient (the routing consumes them from the end) */
+    /* after fid_stag_detect_edges: */
+    FID_STAG_TAP_EDGEIMG = 5,  /* uint8 [h][w] EdgeMap::edgeImg after the routing (255 = EDGE_PIXEL, 254 = anchor never reached) */
+    FID_STAG_TAP_SEGMENTS = 6, /* int32 [noSegments][2]: index of the first pixel in SEGPIX, number of pixels (EdgeSegment) */
+    FID_STAG_TAP_SEGPIX = 7    /* int32 [][2]: (r, c) of EdgeMap::pixels, the segments one after the other */
 } fid_stag_tap;
 int64_t fid_stag_tap_bytes(fid_stag_ctx *ctx, fid_stag_tap which);
 fid_status fid_stag_tap_read(fid_stag_ctx *ctx, fid_stag_tap which, void *dst, int64_t dst_bytes);

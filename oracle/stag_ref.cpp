@@ -8,6 +8,7 @@
 //   ref_stag_gradient   = ComputeGradientMapByPrewitt      stag_detect/src/stag/ED/GradientOperators.cpp:77-136
 //   ref_stag_anchors    = ComputeAnchorPoints              stag_detect/src/stag/ED/EDInternals.cpp:50-86
 //                       + SortAnchorsByGradValue           stag_detect/src/stag/ED/EDInternals.cpp:146-186
+//   ref_stag_route      = JoinAnchorPointsUsingSortedAnchors stag_detect/src/stag/ED/EDInternals.cpp:842-1448
 //   ref_stag_smooth5    = what SmoothImage(..., sigma = 1.0) asks OpenCV for (ImageSmooth.cpp:43-55:
 //                         cv::GaussianBlur(src, dst, Size(5, 5), 0, 0)) -- OpenCV is not installed here, so this one
 //                         function is a RESTATEMENT ("parity unpinned"): for CV_8U and ksize 5 / sigma 0 OpenCV uses the
@@ -68,6 +69,38 @@ int ref_stag_anchors(const int16_t *grad, const uint8_t *dir, int w, int h, int 
     delete[] A;
     delete map;
     return n <= cap ? 0 : 1;
+}
+
+// JoinAnchorPointsUsingSortedAnchors (EDInternals.cpp:842-1448) on a given anchor map.  edge: in = anchor map, out = the
+// edge image after the routing.  segpix: int32 [cap_pix][2] = map->pixels as (r, c); seg: int32 [cap_seg][2] = (offset of
+// segments[i].pixels inside map->pixels, noPixels).
+int ref_stag_route(const int16_t *grad, const uint8_t *dir, int w, int h, int grad_thresh, int min_path_len, uint8_t *edge,
+                   int32_t *segpix, int cap_pix, int32_t *seg, int cap_seg, int *n_seg, int *n_pix)
+{
+    EdgeMap *map = new EdgeMap(w, h);
+    memcpy(map->edgeImg, edge, (size_t)w * h);
+    memset(map->pixels, 0xff, sizeof(Pixel) * (size_t)w * h);  // (r, c) = (-1, -1) where the reference would read uninitialised memory
+    JoinAnchorPointsUsingSortedAnchors(const_cast<short *>(grad), const_cast<unsigned char *>(dir), map, grad_thresh, min_path_len);
+    memcpy(edge, map->edgeImg, (size_t)w * h);
+    int total = 0, rc = 0;
+    for (int i = 0; i < map->noSegments; i++) {
+        const int off = (int)(map->segments[i].pixels - map->pixels), n = map->segments[i].noPixels;
+        if (i < cap_seg) {
+            seg[2 * i] = off;
+            seg[2 * i + 1] = n;
+        } else
+            rc = 1;
+        if (off + n > total) total = off + n;
+    }
+    if (total > cap_pix) rc = 1;
+    for (int i = 0; i < total && i < cap_pix; i++) {
+        segpix[2 * i] = map->pixels[i].r;
+        segpix[2 * i + 1] = map->pixels[i].c;
+    }
+    *n_seg = map->noSegments;
+    *n_pix = total;
+    delete map;
+    return rc;
 }
 
 int ref_stag_constants(int *edge_vertical, int *edge_horizontal, int *anchor_pixel)

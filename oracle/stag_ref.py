@@ -74,3 +74,20 @@ def anchors(grad: np.ndarray, dirs: np.ndarray, grad_thresh: int = 16, anchor_th
                                 C.byref(n))
     assert rc == 0
     return edge, sorted_[:n.value].copy()
+
+
+def route(grad: np.ndarray, dirs: np.ndarray, anchor_map: np.ndarray, grad_thresh: int = 16, min_path_len: int = 10):
+    """The reference's JoinAnchorPointsUsingSortedAnchors.  Returns (edge image, [(n_i, 2) int32 (r, c) per segment])."""
+    g = np.ascontiguousarray(grad, dtype=np.int16)
+    d = np.ascontiguousarray(dirs, dtype=np.uint8)
+    e = np.ascontiguousarray(anchor_map, dtype=np.uint8).copy()
+    h, w = g.shape
+    cap = w * h
+    pix = np.zeros((cap, 2), np.int32)
+    seg = np.zeros((cap // 4 + 16, 2), np.int32)
+    ns, npx = C.c_int(0), C.c_int(0)
+    rc = lib().ref_stag_route(g.ctypes.data_as(C.c_void_p), d.ctypes.data_as(C.c_void_p), w, h, grad_thresh, min_path_len,
+                              e.ctypes.data_as(C.c_void_p), pix.ctypes.data_as(C.c_void_p), cap,
+                              seg.ctypes.data_as(C.c_void_p), len(seg), C.byref(ns), C.byref(npx))
+    assert rc == 0
+    return e, [pix[a:a + n].copy() for a, n in seg[:ns.value]]

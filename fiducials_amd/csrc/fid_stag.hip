@@ -545,6 +545,258 @@ __global__ __launch_bounds__(64) void k_stag_route_seq(StagRoute R, const int32_
     R.counters[2] = S.overflow;
 }
 
+// ------------------------------------------------------------------------------------------------ K11: segment validation
+// ValidateEdgeSegments (ValidateEdgeSegments.cpp:365-413) after the second smoothing of DetectEdgesByEDPF
+// (ED.cpp:176-178: SmoothImage(sigma = 1 / 2.5) = cv::GaussianBlur(Size(0, 0), 0.4): OpenCV picks ksize 3 and the 8.8
+// fixed-point kernel [10 236 10] / 256, one rounding at the end -- restated, "parity unpinned").
+//   k_stag_smooth3_prewitt   the 3x3 blur fused with ComputePrewitt3x3 (:63-115): gradient map + histogram
+//   k_stag_valid_prob        H[g] = P(gradient >= g) (:107-111), np = sum len (len - 1) / 2 (:381-385)
+//   k_stag_test_segments     TestSegment (:134-199), one wave per segment, the recursion on an explicit stack that lives
+//                            in the scratch slots of the segment's own pixels
+//   k_stag_extract           ExtractNewSegments (:319-360): runs of still-marked pixels of >= 10 (count pass, scan, write pass)
+__global__ __launch_bounds__(256) void k_stag_smooth3_prewitt(const uint8_t *__restrict__ src, int stride, int W, int H,
+                                                              uint8_t *__restrict__ smooth, int16_t *__restrict__ grad,
+                                                              unsigned *__restrict__ hist)
+{
+    __shared__ uint8_t s_src[SY + 4][SX + 4 + 4];
+    __shared__ uint16_t s_h[SY + 4][SX + 2];
+    __shared__ uint8_t s_sm[SY + 2][SX + 2 + 2];
+    __shared__ unsigned s_hist[STAG_BINS];
+    const int x0 = blockIdx.x * SX, y0 = blockIdx.y * SY;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < STAG_BINS; i += 256) s_hist[i] = 0;
+    for (int i = tid; i < (SY + 4) * (SX + 4); i += 256) {
+        const int r = i / (SX + 4), c = i - r * (SX + 4);
+        const int gy = stag_reflect101(y0 - 2 + r, H), gx = stag_reflect101(x0 - 2 + c, W);
+        s_src[r][c] = src[(long long)gy * stride + gx];
+    }
+    __syncthreads();
+    for (int i = tid; i < (SY + 4) * (SX + 2); i += 256) {
+        const int r = i / (SX + 2), c = i - r * (SX + 2);
+        const uint8_t *p = &s_src[r][c];
+        s_h[r][c] = (uint16_t)(10 * p[0] + 236 * p[1] + 10 * p[2]);
+    }
+    __syncthreads();
+    for (int i = tid; i < (SY + 2) * (SX + 2); i += 256) {
+        const int r = i / (SX + 2), c = i - r * (SX + 2);
+        const unsigned acc = 10u * s_h[r][c] + 236u * s_h[r + 1][c] + 10u * s_h[r + 2][c];
+        s_sm[r][c] = (uint8_t)((acc + 32768u) >> 16);
+    }
+    __syncthreads();
+    for (int i = tid; i < SY * SX; i += 256) {
+        const int r = i / SX, c = i - r * SX;
+        const int gy = y0 + r, gx = x0 + c;
+        if (gy >= H || gx >= W) continue;
+        const long long idx = (long long)gy * W + gx;
+        smooth[idx] = s_sm[r + 1][c + 1];
+        int g = 0;
+        if (gy >= 1 && gy < H - 1 && gx >= 1 && gx < W - 1) {
+            const int A = s_sm[r][c], B = s_sm[r][c + 1], C = s_sm[r][c + 2];
+            const int D = s_sm[r + 1][c], E = s_sm[r + 1][c + 2];
+            const int F = s_sm[r + 2][c], G = s_sm[r + 2][c + 1], Hh = s_sm[r + 2][c + 2];
+            const int com1 = Hh - A, com2 = C - F;
+            int gxv = com1 + com2 + (E - D), gyv = com1 - com2 + (G - B);
+            gxv = gxv < 0 ? -gxv : gxv;
+            gyv = gyv < 0 ? -gyv : gyv;
+            g = gxv + gyv;
+            atomicAdd(&s_hist[g], 1u);
+        }
+        grad[idx] = (int16_t)g;
+    }
+    __syncthreads();
+    for (int i = tid; i < STAG_BINS; i += 256)
+        if (s_hist[i]) atomicAdd(&hist[i], s_hist[i]);
+}
+
+// one workgroup: cumulative histogram from the top -> H[g]; np over the segments (32-bit int arithmetic as in the reference)
+__global__ __launch_bounds__(512) void k_stag_valid_prob(const unsigned *__restrict__ hist, int W, int H, const int2 *__restrict__ segs,
+                                                         const int *__restrict__ counters, double *__restrict__ prob, int *__restrict__ np_out)
+{
+    __shared__ unsigned s_part[512];
+    const int tid = threadIdx.x;
+    constexpr int PER = STAG_BINS / 512;
+    // suffix sums: thread t owns bins [t * PER, t * PER + PER)
+    unsigned loc[PER];
+    unsigned acc = 0;
+    for (int k = PER - 1; k >= 0; k--) {
+        acc += hist[tid * PER + k];
+        loc[k] = acc;
+    }
+    s_part[tid] = acc;
+    __syncthreads();
+    for (int d = 1; d < 512; d <<= 1) {
+        unsigned v = tid + d < 512 ? s_part[tid + d] : 0u;
+        __syncthreads();
+        s_part[tid] += v;
+        __syncthreads();
+    }
+    const unsigned above = tid + 1 < 512 ? s_part[tid + 1] : 0u;
+    const double size = (double)((W - 2) * (H - 2));
+    for (int k = 0; k < PER; k++) prob[tid * PER + k] = (double)(int)(loc[k] + above) / size;
+    __syncthreads();
+    // np
+    unsigned part = 0;
+    const int ns = counters[0];
+    for (int i = tid; i < ns; i += 512) {
+        const int len = segs[i].y;
+        part += (unsigned)((len * (len - 1)) / 2);
+    }
+    s_part[tid] = part;
+    __syncthreads();
+    for (int d = 256; d > 0; d >>= 1) {
+        if (tid < d) s_part[tid] += s_part[tid + d];
+        __syncthreads();
+    }
+    if (tid == 0) *np_out = (int)s_part[0];
+}
+
+__global__ __launch_bounds__(256) void k_stag_test_segments(const int2 *__restrict__ segs, const int *__restrict__ counters,
+                                                            const int2 *__restrict__ pix, const int16_t *__restrict__ vgrad, int W,
+                                                            const double *__restrict__ prob, const int *__restrict__ np_in, double div,
+                                                            int2 *__restrict__ stackmem, uint8_t *__restrict__ edge)
+{
+    const int seg = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (seg >= counters[0]) return;
+    const int first = segs[seg].x, n = segs[seg].y;
+    if (n < STAG_MIN_PATH_LEN) return;
+    const int2 *p = pix + first;
+    int2 *stk = stackmem + first;  // n entries: more than the recursion can hold (every entry spans >= 10 pixels)
+    const int np = *np_in;
+    // every lane keeps the same (wave-uniform) stack: each writes and reads back its own copy of the same words
+    stk[0] = make_int2(0, n - 1);
+    int sp = 1;
+    while (sp > 0) {
+        const int2 range = stk[sp - 1];
+        sp--;
+        const int i1 = range.x, i2 = range.y;
+        const int chainLen = i2 - i1 + 1;
+        if (chainLen < STAG_MIN_PATH_LEN) continue;
+        // first index of the minimum gradient
+        int best = 1 << 30, bidx = i2 + 1;
+        for (int k = i1 + lane; k <= i2; k += 64) {
+            const int2 q = p[k];
+            const int g = vgrad[q.x * W + q.y];
+            if (g < best) {
+                best = g;
+                bidx = k;
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const int ob = __shfl_xor(best, off, 64), oi = __shfl_xor(bidx, off, 64);
+            if (ob < best || (ob == best && oi < bidx)) {
+                best = ob;
+                bidx = oi;
+            }
+        }
+        // NFA (:120-126): np * prob^len, stopped as soon as it is <= 1
+        double nfa = (double)np;
+        {
+            const double pr = prob[best];
+            const int len = (int)((double)chainLen / div);
+            for (int i = 0; i < len && nfa > 1.0; i++) nfa *= pr;
+        }
+        if (nfa <= 1.0) {
+            for (int k = i1 + lane; k <= i2; k += 64) {
+                const int2 q = p[k];
+                edge[q.x * W + q.y] = 255;
+            }
+            continue;
+        }
+        // split at the minimum: skip the pixels around it that are not above it
+        int end = bidx - 1;
+        while (end > i1) {
+            const int2 q = p[end];
+            if (vgrad[q.x * W + q.y] <= best) end--;
+            else break;
+        }
+        int start = bidx + 1;
+        while (start < i2) {
+            const int2 q = p[start];
+            if (vgrad[q.x * W + q.y] <= best) start++;
+            else break;
+        }
+        stk[sp] = make_int2(i1, end);
+        stk[sp + 1] = make_int2(start, i2);
+        sp += 2;
+    }
+}
+
+// ExtractNewSegments: one wave per segment.  write = 0: counts[seg] = number of runs of >= 10 marked pixels; write = 1:
+// the runs go to out[] from counts[seg] (exclusive prefix sums by then) on.
+__global__ __launch_bounds__(256) void k_stag_extract(const int2 *__restrict__ segs, const int *__restrict__ counters,
+                                                      const int2 *__restrict__ pix, const uint8_t *__restrict__ edge, int W,
+                                                      int *__restrict__ counts, int2 *__restrict__ out, int write)
+{
+    const int seg = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (seg >= counters[0]) return;
+    const int first = segs[seg].x, n = segs[seg].y;
+    const int2 *p = pix + first;
+    int nout = 0, run_start = -1;
+    const int obase = write ? counts[seg] : 0;
+    for (int c0 = 0; c0 < n; c0 += 64) {
+        const int k = c0 + lane;
+        bool on = false;
+        if (k < n) {
+            const int2 q = p[k];
+            on = edge[q.x * W + q.y] != 0;
+        }
+        unsigned long long m = __ballot(on);
+        // walk the runs of this chunk (wave-uniform); lanes behind the segment's end read as unmarked
+        int pos = 0;
+        while (pos < 64) {
+            if (run_start < 0) {
+                const unsigned long long rest = m >> pos;
+                if (!rest) break;
+                pos += __builtin_ctzll(rest);
+                run_start = c0 + pos;
+            }
+            const unsigned long long z = ~m >> pos;
+            if (!z) break;  // the run goes on into the next chunk
+            const int zl = __builtin_ctzll(z);
+            const int run_end = c0 + pos + zl;  // first unmarked pixel
+            if (run_end - run_start >= 10) {
+                if (write && lane == 0) out[obase + nout] = make_int2(first + run_start, run_end - run_start);
+                nout++;
+            }
+            run_start = -1;
+            pos += zl + 1;
+        }
+    }
+    if (run_start >= 0 && n - run_start >= 10) {
+        if (write && lane == 0) out[obase + nout] = make_int2(first + run_start, n - run_start);
+        nout++;
+    }
+    if (!write && lane == 0) counts[seg] = nout;
+}
+
+// exclusive prefix sums over the per-segment counts (one workgroup, serial over chunks of 1024)
+__global__ __launch_bounds__(1024) void k_stag_scan_counts(int *__restrict__ counts, const int *__restrict__ counters, int *__restrict__ total)
+{
+    __shared__ int s[1024];
+    __shared__ int s_carry;
+    const int tid = threadIdx.x, n = counters[0];
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += 1024) {
+        const int v = base + tid < n ? counts[base + tid] : 0;
+        s[tid] = v;
+        __syncthreads();
+        for (int d = 1; d < 1024; d <<= 1) {
+            const int t = tid >= d ? s[tid - d] : 0;
+            __syncthreads();
+            s[tid] += t;
+            __syncthreads();
+        }
+        const int carry = s_carry;
+        if (base + tid < n) counts[base + tid] = carry + s[tid] - v;
+        __syncthreads();
+        if (tid == 1023) s_carry = carry + s[1023];
+        __syncthreads();
+    }
+    if (tid == 0) *total = s_carry;
+}
+
 // ------------------------------------------------------------------------------------------------ C-ABI
 struct fid_stag_ctx {
     int device = 0, maxW = 0, maxH = 0, libraryHD = 0, errorCorrection = 0;
@@ -560,6 +812,15 @@ struct fid_stag_ctx {
     int *d_chainnos = nullptr, *d_rcount = nullptr;
     int rcount[3] = {0, 0, 0};
     bool routed = false;
+    // validation
+    uint8_t *d_smooth2 = nullptr;
+    int16_t *d_vgrad = nullptr;
+    unsigned *d_vhist = nullptr;
+    double *d_prob = nullptr;
+    int *d_np = nullptr, *d_vcounts = nullptr, *d_vtotal = nullptr;
+    int2 *d_vstack = nullptr, *d_vsegs = nullptr;
+    int n_vsegs = 0, np = 0;
+    bool validated = false;
     int W = 0, H = 0;
     unsigned n_anchors = 0;
 };
@@ -598,6 +859,11 @@ fid_status fid_stag_create(int libraryHD, int errorCorrection, int max_width, in
          hipMalloc((void **)&c->d_rstack, n * sizeof(int4)) == hipSuccess && hipMalloc((void **)&c->d_chains, 32767 * sizeof(StagChain)) == hipSuccess &&
          hipMalloc((void **)&c->d_chainnos, (size_t)(max_width + max_height) * 8 * sizeof(int)) == hipSuccess &&
          hipMalloc((void **)&c->d_rcount, 16) == hipSuccess;
+    ok = ok && hipMalloc((void **)&c->d_smooth2, n) == hipSuccess && hipMalloc((void **)&c->d_vgrad, n * 2) == hipSuccess &&
+         hipMalloc((void **)&c->d_vhist, STAG_BINS * 4) == hipSuccess && hipMalloc((void **)&c->d_prob, STAG_BINS * 8) == hipSuccess &&
+         hipMalloc((void **)&c->d_np, 4) == hipSuccess && hipMalloc((void **)&c->d_vcounts, (n / 8 + 16) * 4) == hipSuccess &&
+         hipMalloc((void **)&c->d_vtotal, 4) == hipSuccess && hipMalloc((void **)&c->d_vstack, n * sizeof(int2)) == hipSuccess &&
+         hipMalloc((void **)&c->d_vsegs, (n / 8 + 16) * sizeof(int2)) == hipSuccess;
     if (!ok) {
         fid_stag_destroy(c);
         return FID_E_OUT_OF_MEMORY;
@@ -612,7 +878,8 @@ void fid_stag_destroy(fid_stag_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void *dev[] = {c->d_src, c->d_smooth, c->d_dir, c->d_edge, c->d_grad, c->d_sorted, c->d_rowhist, c->d_bandhist, c->d_tot, c->d_bstart, c->d_n,
-                   c->d_edgeimg, c->d_rpix, c->d_outpix, c->d_segs, c->d_rstack, c->d_chains, c->d_chainnos, c->d_rcount};
+                   c->d_edgeimg, c->d_rpix, c->d_outpix, c->d_segs, c->d_rstack, c->d_chains, c->d_chainnos, c->d_rcount,
+                   c->d_smooth2, c->d_vgrad, c->d_vhist, c->d_prob, c->d_np, c->d_vcounts, c->d_vtotal, c->d_vstack, c->d_vsegs};
     for (void *p : dev)
         if (p) (void)hipFree(p);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -669,6 +936,40 @@ fid_status fid_stag_detect_edges(fid_stag_ctx *c, const uint8_t *gray, int32_t w
     if (hipStreamSynchronize(st) != hipSuccess) return FID_E_HIP;
     if (c->rcount[2]) return FID_E_CAPACITY;
     c->routed = true;
+    c->validated = false;
+    return FID_OK;
+}
+
+fid_status fid_stag_detect_edges_validated(fid_stag_ctx *c, const uint8_t *gray, int32_t width, int32_t height, int32_t stride)
+{
+    fid_status rc = fid_stag_detect_edges(c, gray, width, height, stride);
+    if (rc != FID_OK) return rc;
+    hipStream_t st = c->stream;
+    const int W = c->W, H = c->H;
+    const size_t n = (size_t)W * H;
+    const int ns = c->rcount[0];
+    // ValidateEdgeSegments starts from an empty edge image (ValidateEdgeSegments.cpp:370)
+    if (hipMemsetAsync(c->d_edgeimg, 0, n, st) != hipSuccess || hipMemsetAsync(c->d_vhist, 0, STAG_BINS * 4, st) != hipSuccess) return FID_E_HIP;
+    hipLaunchKernelGGL(k_stag_smooth3_prewitt, dim3((W + SX - 1) / SX, (H + SY - 1) / SY), dim3(256), 0, st, c->d_src, W, W, H, c->d_smooth2,
+                       c->d_vgrad, c->d_vhist);
+    hipLaunchKernelGGL(k_stag_valid_prob, dim3(1), dim3(512), 0, st, c->d_vhist, W, H, c->d_segs, c->d_rcount, c->d_prob, c->d_np);
+    const int wg = (ns + 3) / 4;
+    if (wg > 0) {
+        hipLaunchKernelGGL(k_stag_test_segments, dim3(wg), dim3(256), 0, st, c->d_segs, c->d_rcount, c->d_outpix, c->d_vgrad, W, c->d_prob, c->d_np,
+                           2.25, c->d_vstack, c->d_edgeimg);
+        hipLaunchKernelGGL(k_stag_extract, dim3(wg), dim3(256), 0, st, c->d_segs, c->d_rcount, c->d_outpix, c->d_edgeimg, W, c->d_vcounts,
+                           c->d_vsegs, 0);
+    }
+    hipLaunchKernelGGL(k_stag_scan_counts, dim3(1), dim3(1024), 0, st, c->d_vcounts, c->d_rcount, c->d_vtotal);
+    if (wg > 0)
+        hipLaunchKernelGGL(k_stag_extract, dim3(wg), dim3(256), 0, st, c->d_segs, c->d_rcount, c->d_outpix, c->d_edgeimg, W, c->d_vcounts,
+                           c->d_vsegs, 1);
+    if (hipGetLastError() != hipSuccess) return FID_E_HIP;
+    if (hipMemcpyAsync(&c->n_vsegs, c->d_vtotal, 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipMemcpyAsync(&c->np, c->d_np, 4, hipMemcpyDeviceToHost, st) != hipSuccess)
+        return FID_E_HIP;
+    if (hipStreamSynchronize(st) != hipSuccess) return FID_E_HIP;
+    c->validated = true;
     return FID_OK;
 }
 
@@ -685,6 +986,10 @@ int64_t fid_stag_tap_bytes(fid_stag_ctx *c, fid_stag_tap which)
     case FID_STAG_TAP_EDGEIMG: return c->routed ? n : 0;
     case FID_STAG_TAP_SEGMENTS: return c->routed ? (int64_t)c->rcount[0] * 8 : 0;
     case FID_STAG_TAP_SEGPIX: return c->routed ? (int64_t)c->rcount[1] * 8 : 0;
+    case FID_STAG_TAP_SMOOTH2: return c->validated ? n : 0;
+    case FID_STAG_TAP_VGRAD: return c->validated ? n * 2 : 0;
+    case FID_STAG_TAP_VPROB: return c->validated ? (int64_t)STAG_BINS * 8 : 0;
+    case FID_STAG_TAP_VSEGMENTS: return c->validated ? (int64_t)c->n_vsegs * 8 : 0;
     }
     return 0;
 }
@@ -705,6 +1010,10 @@ fid_status fid_stag_tap_read(fid_stag_ctx *c, fid_stag_tap which, void *dst, int
     case FID_STAG_TAP_EDGEIMG: src = c->d_edgeimg; break;
     case FID_STAG_TAP_SEGMENTS: src = c->d_segs; break;
     case FID_STAG_TAP_SEGPIX: src = c->d_outpix; break;
+    case FID_STAG_TAP_SMOOTH2: src = c->d_smooth2; break;
+    case FID_STAG_TAP_VGRAD: src = c->d_vgrad; break;
+    case FID_STAG_TAP_VPROB: src = c->d_prob; break;
+    case FID_STAG_TAP_VSEGMENTS: src = c->d_vsegs; break;
     }
     if (!src) return FID_E_INVALID_ARG;
     if (hipSetDevice(c->device) != hipSuccess) return FID_E_HIP;

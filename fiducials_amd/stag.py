@@ -11,7 +11,8 @@ import numpy as np
 from . import _lib
 from ._lib import FidError
 
-TAP_SMOOTH, TAP_GRAD, TAP_DIR, TAP_ANCHORS, TAP_SORTED, TAP_EDGEIMG, TAP_SEGMENTS, TAP_SEGPIX = range(8)
+(TAP_SMOOTH, TAP_GRAD, TAP_DIR, TAP_ANCHORS, TAP_SORTED, TAP_EDGEIMG, TAP_SEGMENTS, TAP_SEGPIX, TAP_SMOOTH2, TAP_VGRAD, TAP_VPROB,
+ TAP_VSEGMENTS) = range(12)
 
 
 class StagDetector:
@@ -43,9 +44,13 @@ class StagDetector:
         """Front end + edge routing (DoDetectEdgesByED): the EdgeMap stays on the device; edge_segments() reads it."""
         self._run(self._L.fid_stag_detect_edges, gray)
 
-    def edge_segments(self):
-        """List of (n_i, 2) int32 arrays of (r, c): EdgeMap::segments after detect_edges()."""
-        segs = self.tap(TAP_SEGMENTS).reshape(-1, 2)
+    def detect_edges_validated(self, gray: np.ndarray):
+        """DetectEdgesByEDPF: detect_edges() + Helmholtz validation; edge_segments(validated=True) reads the result."""
+        self._run(self._L.fid_stag_detect_edges_validated, gray)
+
+    def edge_segments(self, validated: bool = False):
+        """List of (n_i, 2) int32 arrays of (r, c): EdgeMap::segments after detect_edges() / detect_edges_validated()."""
+        segs = self.tap(TAP_VSEGMENTS if validated else TAP_SEGMENTS).reshape(-1, 2)
         pix = self.tap(TAP_SEGPIX).reshape(-1, 2)
         return [pix[a:a + n] for a, n in segs]
 
@@ -69,8 +74,10 @@ class StagDetector:
             if rc != _lib.FID_OK:
                 raise FidError(rc, self._L.fid_strerror(rc).decode())
         h, w = self.shape
-        if which in (TAP_SMOOTH, TAP_DIR, TAP_ANCHORS, TAP_EDGEIMG):
+        if which in (TAP_SMOOTH, TAP_DIR, TAP_ANCHORS, TAP_EDGEIMG, TAP_SMOOTH2):
             return buf.reshape(h, w)
-        if which == TAP_GRAD:
+        if which in (TAP_GRAD, TAP_VGRAD):
             return buf.view(np.int16).reshape(h, w)
+        if which == TAP_VPROB:
+            return buf.view(np.float64)
         return buf.view(np.int32)

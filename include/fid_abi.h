@@ -202,6 +202,9 @@ fid_status fid_stag_edge_frontend(fid_stag_ctx *ctx, const uint8_t *gray, int32_
 /* the front end + the edge routing JoinAnchorPointsUsingSortedAnchors (ED/EDInternals.cpp:842-1448): DoDetectEdgesByED
  * (ED/EDInternals.cpp:2598-2619) complete; the EdgeMap stays on the device.  FID_E_CAPACITY if a scratch array is too small. */
 fid_status fid_stag_detect_edges(fid_stag_ctx *ctx, const uint8_t *gray, int32_t width, int32_t height, int32_t stride_bytes);
+/* DetectEdgesByEDPF complete (ED/ED.cpp:144-187): the above + the second smoothing (sigma 1 / 2.5) and ValidateEdgeSegments
+ * (ED/ValidateEdgeSegments.cpp:365-413): Helmholtz-principle validation of every segment, invalid pieces cut out */
+fid_status fid_stag_detect_edges_validated(fid_stag_ctx *ctx, const uint8_t *gray, int32_t width, int32_t height, int32_t stride_bytes);
 typedef enum fid_stag_tap {
     FID_STAG_TAP_SMOOTH = 0,  /* uint8 [h][w] smoothed image */
     FID_STAG_TAP_GRAD = 1,    /* int16 [h][w] |gx| + |gy| (border: GRADIENT_THRESH - 1) */
@@ -211,7 +214,12 @@ typedef enum fid_stag_tap {
     /* after fid_stag_detect_edges: */
     FID_STAG_TAP_EDGEIMG = 5,  /* uint8 [h][w] EdgeMap::edgeImg after the routing (255 = EDGE_PIXEL, 254 = anchor never reached) */
     FID_STAG_TAP_SEGMENTS = 6, /* int32 [noSegments][2]: index of the first pixel in SEGPIX, number of pixels (EdgeSegment) */
-    FID_STAG_TAP_SEGPIX = 7    /* int32 [][2]: (r, c) of EdgeMap::pixels, the segments one after the other */
+    FID_STAG_TAP_SEGPIX = 7,   /* int32 [][2]: (r, c) of EdgeMap::pixels, the segments one after the other */
+    /* after fid_stag_detect_edges_validated (EDGEIMG then holds the validated edge image): */
+    FID_STAG_TAP_SMOOTH2 = 8,   /* uint8 [h][w] image smoothed with sigma 0.4 */
+    FID_STAG_TAP_VGRAD = 9,     /* int16 [h][w] Prewitt gradient of SMOOTH2 (0 on the image border) */
+    FID_STAG_TAP_VPROB = 10,    /* double [1536] H[g] = P(gradient >= g) */
+    FID_STAG_TAP_VSEGMENTS = 11 /* int32 [noSegments][2] validated segments: first pixel in SEGPIX, number of pixels */
 } fid_stag_tap;
 int64_t fid_stag_tap_bytes(fid_stag_ctx *ctx, fid_stag_tap which);
 fid_status fid_stag_tap_read(fid_stag_ctx *ctx, fid_stag_tap which, void *dst, int64_t dst_bytes);

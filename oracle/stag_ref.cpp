@@ -9,6 +9,9 @@
 //   ref_stag_anchors    = ComputeAnchorPoints              stag_detect/src/stag/ED/EDInternals.cpp:50-86
 //                       + SortAnchorsByGradValue           stag_detect/src/stag/ED/EDInternals.cpp:146-186
 //   ref_stag_route      = JoinAnchorPointsUsingSortedAnchors stag_detect/src/stag/ED/EDInternals.cpp:842-1448
+//   ref_stag_validate   = ValidateEdgeSegments               stag_detect/src/stag/ED/ValidateEdgeSegments.cpp:365-413
+//   ref_stag_smooth3    = SmoothImage(sigma = 1 / 2.5) of ED.cpp:176-177, restated like ref_stag_smooth5 ("parity unpinned"):
+//                         cv::GaussianBlur(Size(0, 0), 0.4) -> ksize 3, 8.8 fixed-point kernel [10 236 10], one rounding
 //   ref_stag_smooth5    = what SmoothImage(..., sigma = 1.0) asks OpenCV for (ImageSmooth.cpp:43-55:
 //                         cv::GaussianBlur(src, dst, Size(5, 5), 0, 0)) -- OpenCV is not installed here, so this one
 //                         function is a RESTATEMENT ("parity unpinned"): for CV_8U and ksize 5 / sigma 0 OpenCV uses the
@@ -19,6 +22,7 @@
 
 #include "src/stag/ED/GradientOperators.cpp"
 #include "src/stag/ED/EDInternals.cpp"
+#include "src/stag/ED/ValidateEdgeSegments.cpp"
 
 static inline int reflect101(int p, int n)
 {
@@ -99,6 +103,51 @@ int ref_stag_route(const int16_t *grad, const uint8_t *dir, int w, int h, int gr
     }
     *n_seg = map->noSegments;
     *n_pix = total;
+    delete map;
+    return rc;
+}
+
+int ref_stag_smooth3(const uint8_t *src, uint8_t *dst, int w, int h)
+{
+    static const unsigned k[3] = {10, 236, 10};
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            unsigned acc = 0;
+            for (int i = -1; i <= 1; i++) {
+                const uint8_t *row = src + (size_t)reflect101(y + i, h) * w;
+                unsigned racc = 0;
+                for (int j = -1; j <= 1; j++) racc += k[j + 1] * row[reflect101(x + j, w)];
+                acc += k[i + 1] * racc;
+            }
+            dst[(size_t)y * w + x] = (uint8_t)((acc + 32768u) >> 16);
+        }
+    return 0;
+}
+
+// ValidateEdgeSegments on a given EdgeMap (segments as (first pixel, length) pairs into segpix) and validation image.
+// Out: edge image, validated segments as (first pixel, length) pairs into the same segpix.
+int ref_stag_validate(const uint8_t *smooth2, int w, int h, const int32_t *segpix, int n_pix, const int32_t *seg_in, int n_seg_in,
+                      double div, uint8_t *edge_out, int32_t *seg_out, int cap_seg, int *n_seg_out)
+{
+    EdgeMap *map = new EdgeMap(w, h);
+    for (int i = 0; i < n_pix; i++) {
+        map->pixels[i].r = segpix[2 * i];
+        map->pixels[i].c = segpix[2 * i + 1];
+    }
+    for (int i = 0; i < n_seg_in; i++) {
+        map->segments[i].pixels = map->pixels + seg_in[2 * i];
+        map->segments[i].noPixels = seg_in[2 * i + 1];
+    }
+    map->noSegments = n_seg_in;
+    ValidateEdgeSegments(map, const_cast<unsigned char *>(smooth2), div);
+    memcpy(edge_out, map->edgeImg, (size_t)w * h);
+    int rc = 0;
+    for (int i = 0; i < map->noSegments; i++) {
+        if (i >= cap_seg) { rc = 1; break; }
+        seg_out[2 * i] = (int)(map->segments[i].pixels - map->pixels);
+        seg_out[2 * i + 1] = map->segments[i].noPixels;
+    }
+    *n_seg_out = map->noSegments;
     delete map;
     return rc;
 }

@@ -51,6 +51,14 @@ def smooth5(gray: np.ndarray) -> np.ndarray:
     return out
 
 
+def smooth3(gray: np.ndarray) -> np.ndarray:
+    g = np.ascontiguousarray(gray, dtype=np.uint8)
+    out = np.empty_like(g)
+    h, w = g.shape
+    assert lib().ref_stag_smooth3(g.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), w, h) == 0
+    return out
+
+
 def gradient(smooth: np.ndarray, grad_thresh: int = 16):
     s = np.ascontiguousarray(smooth, dtype=np.uint8)
     h, w = s.shape
@@ -74,6 +82,39 @@ def anchors(grad: np.ndarray, dirs: np.ndarray, grad_thresh: int = 16, anchor_th
                                 C.byref(n))
     assert rc == 0
     return edge, sorted_[:n.value].copy()
+
+
+def _route_raw(grad, dirs, anchor_map, grad_thresh=16, min_path_len=10):
+    g = np.ascontiguousarray(grad, dtype=np.int16)
+    d = np.ascontiguousarray(dirs, dtype=np.uint8)
+    e = np.ascontiguousarray(anchor_map, dtype=np.uint8).copy()
+    h, w = g.shape
+    cap = w * h
+    pix = np.zeros((cap, 2), np.int32)
+    seg = np.zeros((cap // 4 + 16, 2), np.int32)
+    ns, npx = C.c_int(0), C.c_int(0)
+    rc = lib().ref_stag_route(g.ctypes.data_as(C.c_void_p), d.ctypes.data_as(C.c_void_p), w, h, grad_thresh, min_path_len,
+                              e.ctypes.data_as(C.c_void_p), pix.ctypes.data_as(C.c_void_p), cap,
+                              seg.ctypes.data_as(C.c_void_p), len(seg), C.byref(ns), C.byref(npx))
+    assert rc == 0
+    return e, pix[:npx.value].copy(), seg[:ns.value].copy()
+
+
+def validate(smooth2: np.ndarray, segpix: np.ndarray, segs: np.ndarray, div: float = 2.25):
+    """The reference's ValidateEdgeSegments on an EdgeMap given as (pixel array, (first, length) pairs).  Returns
+    (edge image, validated (first, length) pairs)."""
+    s2 = np.ascontiguousarray(smooth2, dtype=np.uint8)
+    h, w = s2.shape
+    pix = np.ascontiguousarray(segpix, dtype=np.int32).reshape(-1, 2)
+    sg = np.ascontiguousarray(segs, dtype=np.int32).reshape(-1, 2)
+    edge = np.zeros((h, w), np.uint8)
+    out = np.zeros((w * h // 8 + 16, 2), np.int32)
+    n = C.c_int(0)
+    rc = lib().ref_stag_validate(s2.ctypes.data_as(C.c_void_p), w, h, pix.ctypes.data_as(C.c_void_p), len(pix),
+                                 sg.ctypes.data_as(C.c_void_p), len(sg), C.c_double(div), edge.ctypes.data_as(C.c_void_p),
+                                 out.ctypes.data_as(C.c_void_p), len(out), C.byref(n))
+    assert rc == 0
+    return edge, out[:n.value].copy()
 
 
 def route(grad: np.ndarray, dirs: np.ndarray, anchor_map: np.ndarray, grad_thresh: int = 16, min_path_len: int = 10):

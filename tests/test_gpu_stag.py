@@ -142,6 +142,53 @@ def test_edge_routing_matches_reference_code(case):
         det.close()
 
 
+def _faint(w, h, seed):
+    """Low-contrast blobs on noise: most segments fail the Helmholtz test somewhere and get cut."""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w]
+    img = 120 + rng.normal(0, 6, (h, w))
+    for _ in range(25):
+        cy, cx, r = rng.integers(0, h), rng.integers(0, w), rng.integers(8, 60)
+        img[(yy - cy) ** 2 + (xx - cx) ** 2 < r * r] += rng.integers(-28, 28)
+    k = np.array([1, 2, 1], float) / 4
+    img = np.apply_along_axis(lambda v: np.convolve(v, k, mode="same"), 0, img)
+    img = np.apply_along_axis(lambda v: np.convolve(v, k, mode="same"), 1, img)
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+VALID_CASES = dict(ROUTE_CASES)
+VALID_CASES["faint"] = lambda: _faint(480, 360, 21)
+VALID_CASES["faint_big"] = lambda: _faint(1280, 720, 22)
+
+
+@pytest.mark.parametrize("case", sorted(VALID_CASES))
+def test_segment_validation_matches_reference_code(case):
+    """Row s5: ValidateEdgeSegments.  Validated edge image and segment list against the reference's own routine fed with the
+    device's EdgeMap and second smoothed image (the 3x3 blur itself is checked against its restatement)."""
+    if not stag_ref.available():
+        pytest.skip("oracle/_ref/libstag_ref.so not built (needs /root/reference at build time)")
+    img = VALID_CASES[case]()
+    h, w = img.shape
+    det = fstag.StagDetector(21, 7, max_width=1920, max_height=1080)
+    try:
+        det.detect_edges_validated(img)
+        s2 = det.tap(fstag.TAP_SMOOTH2)
+        assert np.array_equal(s2, stag_ref.smooth3(img)), "3x3 Gaussian (restated OpenCV fixed-point kernel)"
+        vg = det.tap(fstag.TAP_VGRAD).astype(np.int64)
+        inner = vg[1:-1, 1:-1].ravel()
+        cnt = np.bincount(inner, minlength=1536)
+        prob = np.cumsum(cnt[::-1])[::-1] / float((w - 2) * (h - 2))
+        assert np.array_equal(det.tap(fstag.TAP_VPROB), prob), "H[g]"
+        segs, pix = det.tap(fstag.TAP_SEGMENTS).reshape(-1, 2), det.tap(fstag.TAP_SEGPIX).reshape(-1, 2)
+        ref_edge, ref_vsegs = stag_ref.validate(s2, pix, segs)
+        assert np.array_equal(det.tap(fstag.TAP_EDGEIMG), ref_edge)
+        assert np.array_equal(det.tap(fstag.TAP_VSEGMENTS).reshape(-1, 2), ref_vsegs)
+        if case.startswith("faint"):
+            assert len(ref_vsegs) != len(segs) or not np.array_equal(ref_vsegs, segs), "the case must exercise the cutting"
+    finally:
+        det.close()
+
+
 def test_stag_status_codes():
     from fiducials_amd import _lib
     from fiducials_amd._lib import FidError

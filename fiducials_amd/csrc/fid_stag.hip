@@ -797,6 +797,296 @@ __global__ __launch_bounds__(1024) void k_stag_scan_counts(int *__restrict__ cou
     if (tid == 0) *total = s_carry;
 }
 
+// ------------------------------------------------------------------------------------------------ K12: EDLines, line fitting
+// DetectLinesByEDPF (EDLines.cpp:849-941) after the edge detection: SplitSegment2Lines (:162-268) cuts every validated
+// segment into least-squares lines, JoinCollinearLines (:114-156) merges neighbours inside a segment.  Both are sequential
+// inside a segment and independent between segments: one lane per segment (k_stag_split_lines), lines of segment i parked at
+// slot first_pixel_i / 9 onwards (a line takes >= 9 pixels), then counted, scanned and compacted in segment order.
+// The fits are sums of integer coordinates: prefix sums (exact in 64 bits) make every refit O(1) and give bit for bit the
+// doubles the reference accumulates; the remaining double arithmetic keeps the reference's operation order (the TU is built
+// with -ffp-contract=off).
+struct StagPrefix {  // prefix sums over the pixels of one segment, index k = sum over pixels < k
+    long long *x, *y, *xx, *yy, *xy;
+};
+
+__device__ double sl_min_dist(double x1, double y1, double a, double b, int invert, double *cx = nullptr, double *cy = nullptr)
+{
+    double x2, y2;
+    if (invert == 0) {
+        if (b == 0) {
+            x2 = x1;
+            y2 = a;
+        } else {
+            const double d = -1.0 / b;
+            const double c = y1 - d * x1;
+            x2 = (a - c) / (d - b);
+            y2 = a + b * x2;
+        }
+    } else {
+        if (b == 0) {
+            x2 = a;
+            y2 = y1;
+        } else {
+            const double d = -1.0 / b;
+            const double c = x1 - d * y1;
+            y2 = (a - c) / (d - b);
+            x2 = a + b * y2;
+        }
+    }
+    if (cx) {
+        *cx = x2;
+        *cy = y2;
+    }
+    return sqrt((x1 - x2) * (x1 - x2) + (y1 - y2) * (y1 - y2));
+}
+
+// LineFit with a known orientation (LineSegment.cpp:703-733) over pixels [base, base + count)
+__device__ void sl_fit_known(const StagPrefix &P, int base, int count, int invert, double *a, double *b)
+{
+    if (count < 2) return;
+    const double S = count;
+    double Sx = (double)(P.x[base + count] - P.x[base]), Sy = (double)(P.y[base + count] - P.y[base]);
+    double Sxx, Sxy = (double)(P.xy[base + count] - P.xy[base]);
+    if (invert) {
+        const double t = Sx;
+        Sx = Sy;
+        Sy = t;
+        Sxx = (double)(P.yy[base + count] - P.yy[base]);
+    } else {
+        Sxx = (double)(P.xx[base + count] - P.xx[base]);
+    }
+    const double D = S * Sxx - Sx * Sx;
+    *a = (Sxx * Sy - Sx * Sxy) / D;
+    *b = (S * Sxy - Sx * Sy) / D;
+}
+
+// LineFit with orientation choice and fitting error (LineSegment.cpp:628-697) over pixels [base, base + count)
+__device__ void sl_fit_first(const StagPrefix &P, const int2 *px, int base, int count, double *a, double *b, double *e, int *invert)
+{
+    if (count < 2) return;
+    const double Sx0 = (double)(P.x[base + count] - P.x[base]), Sy0 = (double)(P.y[base + count] - P.y[base]);
+    const double mx = Sx0 / count, my = Sy0 / count;
+    double dx = 0.0, dy = 0.0;
+    for (int i = 0; i < count; i++) {
+        const double xi = px[base + i].y, yi = px[base + i].x;
+        dx += (xi - mx) * (xi - mx);
+        dy += (yi - my) * (yi - my);
+    }
+    const int inv = dx < dy ? 1 : 0;
+    *invert = inv;
+    sl_fit_known(P, base, count, inv, a, b);
+    double error = 0.0;
+    if (*b == 0.0) {
+        for (int i = 0; i < count; i++) {
+            const double yi = inv ? px[base + i].y : px[base + i].x;
+            error += fabs((*a) - yi);
+        }
+        *e = error / count;
+    } else {
+        for (int i = 0; i < count; i++) {
+            const double xi = inv ? px[base + i].x : px[base + i].y, yi = inv ? px[base + i].y : px[base + i].x;
+            const double d = -1.0 / (*b);
+            const double c = yi - d * xi;
+            const double x2 = ((*a) - c) / (d - (*b));
+            const double y2 = (*a) + (*b) * x2;
+            error += (xi - x2) * (xi - x2) + (yi - y2) * (yi - y2);
+        }
+        *e = sqrt(error / count);
+    }
+}
+
+// UpdateLineParameters (LineSegment.cpp:563-591)
+__device__ void sl_update_params(fid_stag_line *ls)
+{
+    const double dx = ls->ex - ls->sx, dy = ls->ey - ls->sy;
+    if (fabs(dx) >= fabs(dy)) {
+        ls->invert = 0;
+        if (fabs(dy) < 1e-3) {
+            ls->b = 0;
+            ls->a = (ls->sy + ls->ey) / 2;
+        } else {
+            ls->b = dy / dx;
+            ls->a = ls->sy - (ls->b) * ls->sx;
+        }
+    } else {
+        ls->invert = 1;
+        if (fabs(dx) < 1e-3) {
+            ls->b = 0;
+            ls->a = (ls->sx + ls->ex) / 2;
+        } else {
+            ls->b = dx / dy;
+            ls->a = ls->sx - (ls->b) * ls->sy;
+        }
+    }
+}
+
+// TryToJoinTwoLineSegments (LineSegment.cpp:239-395)
+__device__ bool sl_try_join(fid_stag_line *l1, const fid_stag_line *l2, double max_dist, double max_err)
+{
+    double dx = l1->sx - l2->sx, dy = l1->sy - l2->sy;
+    double mn = sqrt(dx * dx + dy * dy);
+    dx = l1->sx - l2->ex; dy = l1->sy - l2->ey;
+    double d = sqrt(dx * dx + dy * dy);
+    if (d < mn) mn = d;
+    dx = l1->ex - l2->sx; dy = l1->ey - l2->sy;
+    d = sqrt(dx * dx + dy * dy);
+    if (d < mn) mn = d;
+    dx = l1->ex - l2->ex; dy = l1->ey - l2->ey;
+    d = sqrt(dx * dx + dy * dy);
+    if (d < mn) mn = d;
+    if (mn > max_dist) return false;
+    dx = l1->sx - l1->ex; dy = l1->sy - l1->ey;
+    const double prevLen = sqrt(dx * dx + dy * dy);
+    dx = l2->sx - l2->ex; dy = l2->sy - l2->ey;
+    const double nextLen = sqrt(dx * dx + dy * dy);
+    const fid_stag_line *shorter = l1, *longer = l2;
+    if (prevLen > nextLen) {
+        shorter = l2;
+        longer = l1;
+    }
+    double dist = sl_min_dist(shorter->sx, shorter->sy, longer->a, longer->b, longer->invert);
+    dist += sl_min_dist((shorter->sx + shorter->ex) / 2.0, (shorter->sy + shorter->ey) / 2.0, longer->a, longer->b, longer->invert);
+    dist += sl_min_dist(shorter->ex, shorter->ey, longer->a, longer->b, longer->invert);
+    dist /= 3.0;
+    if (dist > max_err) return false;
+    // keep the two end points that are farthest apart (Manhattan)
+    double mx = fabs(l1->sx - l2->sx) + fabs(l1->sy - l2->sy);
+    int which = 1;
+    d = fabs(l1->sx - l2->ex) + fabs(l1->sy - l2->ey);
+    if (d > mx) { mx = d; which = 2; }
+    d = fabs(l1->ex - l2->sx) + fabs(l1->ey - l2->sy);
+    if (d > mx) { mx = d; which = 3; }
+    d = fabs(l1->ex - l2->ex) + fabs(l1->ey - l2->ey);
+    if (d > mx) { mx = d; which = 4; }
+    if (which == 1) {
+        l1->ex = l2->sx; l1->ey = l2->sy;
+    } else if (which == 2) {
+        l1->ex = l2->ex; l1->ey = l2->ey;
+    } else if (which == 3) {
+        l1->sx = l2->sx; l1->sy = l2->sy;
+    } else {
+        l1->sx = l1->ex; l1->sy = l1->ey;
+        l1->ex = l2->ex; l1->ey = l2->ey;
+    }
+    if (l1->firstPixelIndex + l1->len + 5 >= l2->firstPixelIndex) l1->len += l2->len;
+    else if (l2->len > l1->len) {
+        l1->firstPixelIndex = l2->firstPixelIndex;
+        l1->len = l2->len;
+    }
+    sl_update_params(l1);
+    return true;
+}
+
+__global__ __launch_bounds__(64) void k_stag_split_lines(const int2 *__restrict__ segs, const int *__restrict__ nsegs, const int2 *__restrict__ pix,
+                                                         StagPrefix PF, int min_line_len, double line_error, fid_stag_line *__restrict__ slots,
+                                                         int *__restrict__ counts)
+{
+    const int seg = blockIdx.x * 64 + threadIdx.x;
+    if (seg >= *nsegs) return;
+    const int first = segs[seg].x, n = segs[seg].y;
+    const int2 *px = pix + first;
+    // the prefix arrays of this segment live at [first + seg, first + seg + n]: one extra slot per segment
+    StagPrefix P;
+    const int pb = first + seg;
+    P.x = PF.x + pb; P.y = PF.y + pb; P.xx = PF.xx + pb; P.yy = PF.yy + pb; P.xy = PF.xy + pb;
+    {
+        long long sx = 0, sy = 0, sxx = 0, syy = 0, sxy = 0;
+        for (int k = 0; k < n; k++) {
+            P.x[k] = sx; P.y[k] = sy; P.xx[k] = sxx; P.yy[k] = syy; P.xy[k] = sxy;
+            const long long x = px[k].y, y = px[k].x;
+            sx += x; sy += y; sxx += x * x; syy += y * y; sxy += x * y;
+        }
+        P.x[n] = sx; P.y[n] = sy; P.xx[n] = sxx; P.yy[n] = syy; P.xy[n] = sxy;
+    }
+    fid_stag_line *L = slots + first / 9;
+    int nl = 0;
+    const int MLL = min_line_len;
+    int base = 0, noPixels = n, firstPixelIndex = 0;
+    while (noPixels >= MLL) {
+        bool valid = false;
+        double lastA = 0, lastB = 0, error = 0;
+        int lastInvert = 0;
+        while (noPixels >= MLL) {
+            sl_fit_first(P, px, base, MLL, &lastA, &lastB, &error, &lastInvert);
+            if (error <= 0.5) {
+                valid = true;
+                break;
+            }
+            noPixels -= 1;
+            base += 1;
+            firstPixelIndex += 1;
+        }
+        if (!valid) break;
+        int index = MLL, len = MLL;
+        while (index < noPixels) {
+            const int startIndex = index;
+            int lastGoodIndex = index - 1, good = 0, bad = 0;
+            while (index < noPixels) {
+                const double d = sl_min_dist((double)px[base + index].y, (double)px[base + index].x, lastA, lastB, lastInvert);
+                if (d <= line_error) {
+                    lastGoodIndex = index;
+                    good++;
+                    bad = 0;
+                } else {
+                    bad++;
+                    if (bad >= 5) break;
+                }
+                if (good % 10 == 0) sl_fit_known(P, base, lastGoodIndex - startIndex + len + 1, lastInvert, &lastA, &lastB);
+                index++;
+            }
+            if (good >= 2) {
+                len += lastGoodIndex - startIndex + 1;
+                sl_fit_known(P, base, len, lastInvert, &lastA, &lastB);
+                index = lastGoodIndex + 1;
+            }
+            if (good < 2 || index >= noPixels) {
+                double sx, sy, ex, ey;
+                int idx = 0;
+                while (idx < noPixels - 1 && sl_min_dist((double)px[base + idx].y, (double)px[base + idx].x, lastA, lastB, lastInvert) > line_error) idx++;
+                sl_min_dist((double)px[base + idx].y, (double)px[base + idx].x, lastA, lastB, lastInvert, &sx, &sy);
+                const int skipped = idx;
+                idx = lastGoodIndex;
+                while (idx > 0 && sl_min_dist((double)px[base + idx].y, (double)px[base + idx].x, lastA, lastB, lastInvert) > line_error) idx--;
+                sl_min_dist((double)px[base + idx].y, (double)px[base + idx].x, lastA, lastB, lastInvert, &ex, &ey);
+                fid_stag_line &o = L[nl++];
+                o.a = lastA; o.b = lastB; o.invert = lastInvert; o.sx = sx; o.sy = sy; o.ex = ex; o.ey = ey;
+                o.segmentNo = seg; o.firstPixelIndex = firstPixelIndex + skipped; o.len = idx - skipped + 1;
+                len = idx + 1;
+                break;
+            }
+        }
+        noPixels -= len;
+        base += len;
+        firstPixelIndex += len;
+    }
+    // JoinCollinearLines (EDLines.cpp:114-156), MAX_DISTANCE_BETWEEN_TWO_LINES 6.0, MAX_ERROR 1.5 (:913)
+    if (nl > 0) {
+        int last = 0;
+        for (int j = 1; j < nl; j++) {
+            if (!sl_try_join(&L[last], &L[j], 6.0, 1.50)) {
+                last++;
+                if (last != j) L[last] = L[j];
+            }
+        }
+        if (last != 0 && sl_try_join(&L[0], &L[last], 6.0, 1.50)) last--;
+        nl = last + 1;
+    }
+    counts[seg] = nl;
+}
+
+// the lines of every segment, one after the other in segment order (counts hold exclusive prefix sums by now)
+__global__ __launch_bounds__(64) void k_stag_gather_lines(const int2 *__restrict__ segs, const int *__restrict__ nsegs, const int *__restrict__ counts,
+                                                          const int *__restrict__ total, const fid_stag_line *__restrict__ slots,
+                                                          fid_stag_line *__restrict__ out)
+{
+    const int seg = blockIdx.x * 64 + threadIdx.x;
+    const int ns = *nsegs;
+    if (seg >= ns) return;
+    const int o = counts[seg], n = (seg + 1 < ns ? counts[seg + 1] : *total) - o;
+    const fid_stag_line *L = slots + segs[seg].x / 9;
+    for (int j = 0; j < n; j++) out[o + j] = L[j];
+}
+
 // ------------------------------------------------------------------------------------------------ C-ABI
 struct fid_stag_ctx {
     int device = 0, maxW = 0, maxH = 0, libraryHD = 0, errorCorrection = 0;
@@ -821,6 +1111,13 @@ struct fid_stag_ctx {
     int2 *d_vstack = nullptr, *d_vsegs = nullptr;
     int n_vsegs = 0, np = 0;
     bool validated = false;
+    // EDLines
+    long long *d_prefix = nullptr;  // 5 arrays of prefcap entries
+    size_t prefcap = 0;
+    fid_stag_line *d_lslots = nullptr, *d_lines = nullptr;
+    int *d_lcounts = nullptr, *d_ltotal = nullptr;
+    int n_lines = 0, min_line_len = 0;
+    bool lined = false;
     int W = 0, H = 0;
     unsigned n_anchors = 0;
 };
@@ -864,6 +1161,11 @@ fid_status fid_stag_create(int libraryHD, int errorCorrection, int max_width, in
          hipMalloc((void **)&c->d_np, 4) == hipSuccess && hipMalloc((void **)&c->d_vcounts, (n / 8 + 16) * 4) == hipSuccess &&
          hipMalloc((void **)&c->d_vtotal, 4) == hipSuccess && hipMalloc((void **)&c->d_vstack, n * sizeof(int2)) == hipSuccess &&
          hipMalloc((void **)&c->d_vsegs, (n / 8 + 16) * sizeof(int2)) == hipSuccess;
+    c->prefcap = n + n / 8 + 64;
+    ok = ok && hipMalloc((void **)&c->d_prefix, c->prefcap * 5 * sizeof(long long)) == hipSuccess &&
+         hipMalloc((void **)&c->d_lslots, (n / 9 + 16) * sizeof(fid_stag_line)) == hipSuccess &&
+         hipMalloc((void **)&c->d_lines, (n / 9 + 16) * sizeof(fid_stag_line)) == hipSuccess &&
+         hipMalloc((void **)&c->d_lcounts, (n / 8 + 16) * 4) == hipSuccess && hipMalloc((void **)&c->d_ltotal, 4) == hipSuccess;
     if (!ok) {
         fid_stag_destroy(c);
         return FID_E_OUT_OF_MEMORY;
@@ -879,7 +1181,8 @@ void fid_stag_destroy(fid_stag_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void *dev[] = {c->d_src, c->d_smooth, c->d_dir, c->d_edge, c->d_grad, c->d_sorted, c->d_rowhist, c->d_bandhist, c->d_tot, c->d_bstart, c->d_n,
                    c->d_edgeimg, c->d_rpix, c->d_outpix, c->d_segs, c->d_rstack, c->d_chains, c->d_chainnos, c->d_rcount,
-                   c->d_smooth2, c->d_vgrad, c->d_vhist, c->d_prob, c->d_np, c->d_vcounts, c->d_vtotal, c->d_vstack, c->d_vsegs};
+                   c->d_smooth2, c->d_vgrad, c->d_vhist, c->d_prob, c->d_np, c->d_vcounts, c->d_vtotal, c->d_vstack, c->d_vsegs,
+                   c->d_prefix, c->d_lslots, c->d_lines, c->d_lcounts, c->d_ltotal};
     for (void *p : dev)
         if (p) (void)hipFree(p);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -970,6 +1273,39 @@ fid_status fid_stag_detect_edges_validated(fid_stag_ctx *c, const uint8_t *gray,
         return FID_E_HIP;
     if (hipStreamSynchronize(st) != hipSuccess) return FID_E_HIP;
     c->validated = true;
+    c->lined = false;
+    return FID_OK;
+}
+
+// ComputeMinLineLength (EDLines.cpp:694-703) and the floor of 9 of DetectLinesByEDPF (:888-892): a function of the image
+// size alone, evaluated on the host like the reference does
+static int stag_min_line_len(int W, int H)
+{
+    const double logNT = 2.0 * (log10((double)W) + log10((double)H));
+    int m = (int)((-logNT / log10(0.125)) * 0.5 + 0.5);
+    return m < 9 ? 9 : m;
+}
+
+fid_status fid_stag_detect_lines(fid_stag_ctx *c, const uint8_t *gray, int32_t width, int32_t height, int32_t stride)
+{
+    fid_status rc = fid_stag_detect_edges_validated(c, gray, width, height, stride);
+    if (rc != FID_OK) return rc;
+    hipStream_t st = c->stream;
+    const int ns = c->n_vsegs;
+    c->min_line_len = stag_min_line_len(c->W, c->H);
+    StagPrefix PF;
+    PF.x = c->d_prefix; PF.y = PF.x + c->prefcap; PF.xx = PF.y + c->prefcap; PF.yy = PF.xx + c->prefcap; PF.xy = PF.yy + c->prefcap;
+    const int wg = (ns + 63) / 64;
+    if (wg > 0)
+        hipLaunchKernelGGL(k_stag_split_lines, dim3(wg), dim3(64), 0, st, c->d_vsegs, c->d_vtotal, c->d_outpix, PF, c->min_line_len, 1.0, c->d_lslots,
+                           c->d_lcounts);
+    hipLaunchKernelGGL(k_stag_scan_counts, dim3(1), dim3(1024), 0, st, c->d_lcounts, c->d_vtotal, c->d_ltotal);
+    if (wg > 0)
+        hipLaunchKernelGGL(k_stag_gather_lines, dim3(wg), dim3(64), 0, st, c->d_vsegs, c->d_vtotal, c->d_lcounts, c->d_ltotal, c->d_lslots, c->d_lines);
+    if (hipGetLastError() != hipSuccess) return FID_E_HIP;
+    if (hipMemcpyAsync(&c->n_lines, c->d_ltotal, 4, hipMemcpyDeviceToHost, st) != hipSuccess) return FID_E_HIP;
+    if (hipStreamSynchronize(st) != hipSuccess) return FID_E_HIP;
+    c->lined = true;
     return FID_OK;
 }
 
@@ -990,6 +1326,7 @@ int64_t fid_stag_tap_bytes(fid_stag_ctx *c, fid_stag_tap which)
     case FID_STAG_TAP_VGRAD: return c->validated ? n * 2 : 0;
     case FID_STAG_TAP_VPROB: return c->validated ? (int64_t)STAG_BINS * 8 : 0;
     case FID_STAG_TAP_VSEGMENTS: return c->validated ? (int64_t)c->n_vsegs * 8 : 0;
+    case FID_STAG_TAP_LINES: return c->lined ? (int64_t)c->n_lines * (int64_t)sizeof(fid_stag_line) : 0;
     }
     return 0;
 }
@@ -1014,6 +1351,7 @@ fid_status fid_stag_tap_read(fid_stag_ctx *c, fid_stag_tap which, void *dst, int
     case FID_STAG_TAP_VGRAD: src = c->d_vgrad; break;
     case FID_STAG_TAP_VPROB: src = c->d_prob; break;
     case FID_STAG_TAP_VSEGMENTS: src = c->d_vsegs; break;
+    case FID_STAG_TAP_LINES: src = c->d_lines; break;
     }
     if (!src) return FID_E_INVALID_ARG;
     if (hipSetDevice(c->device) != hipSuccess) return FID_E_HIP;

@@ -194,6 +194,15 @@ void *fid_stream(fid_ctx *ctx);
  * (routing, EDLines, quads, decoding, pose refinement: next) and can be read back through the taps.  The constructor
  * mirrors Stag::Stag(int libraryHD, int errorCorrection, bool keepLogs) (include/stag/Stag.h:41). */
 typedef struct fid_stag_ctx fid_stag_ctx;
+/* LineSegment (stag_detect/include/stag/ED/LineSegment.h:4-14): y = a + b x (invert 0) or x = a + b y (invert 1) */
+typedef struct fid_stag_line {
+    double a, b;
+    double sx, sy, ex, ey;   /* end points */
+    int32_t invert;
+    int32_t segmentNo;       /* edge segment the line was cut from */
+    int32_t firstPixelIndex; /* first pixel of the line inside that segment */
+    int32_t len;             /* pixels of the segment that make up the line */
+} fid_stag_line;
 fid_status fid_stag_create(int32_t libraryHD, int32_t errorCorrection, int32_t max_width, int32_t max_height, int32_t device,
                            fid_stag_ctx **out);
 void fid_stag_destroy(fid_stag_ctx *ctx);
@@ -205,6 +214,9 @@ fid_status fid_stag_detect_edges(fid_stag_ctx *ctx, const uint8_t *gray, int32_t
 /* DetectEdgesByEDPF complete (ED/ED.cpp:144-187): the above + the second smoothing (sigma 1 / 2.5) and ValidateEdgeSegments
  * (ED/ValidateEdgeSegments.cpp:365-413): Helmholtz-principle validation of every segment, invalid pieces cut out */
 fid_status fid_stag_detect_edges_validated(fid_stag_ctx *ctx, const uint8_t *gray, int32_t width, int32_t height, int32_t stride_bytes);
+/* the above + the line fitting of DetectLinesByEDPF (ED/EDLines.cpp:849-941): SplitSegment2Lines (:162-268) and
+ * JoinCollinearLines (:114-156).  (ValidateLineSegments, the last step of DetectLinesByEDPF, is not in yet.) */
+fid_status fid_stag_detect_lines(fid_stag_ctx *ctx, const uint8_t *gray, int32_t width, int32_t height, int32_t stride_bytes);
 typedef enum fid_stag_tap {
     FID_STAG_TAP_SMOOTH = 0,  /* uint8 [h][w] smoothed image */
     FID_STAG_TAP_GRAD = 1,    /* int16 [h][w] |gx| + |gy| (border: GRADIENT_THRESH - 1) */
@@ -219,7 +231,9 @@ typedef enum fid_stag_tap {
     FID_STAG_TAP_SMOOTH2 = 8,   /* uint8 [h][w] image smoothed with sigma 0.4 */
     FID_STAG_TAP_VGRAD = 9,     /* int16 [h][w] Prewitt gradient of SMOOTH2 (0 on the image border) */
     FID_STAG_TAP_VPROB = 10,    /* double [1536] H[g] = P(gradient >= g) */
-    FID_STAG_TAP_VSEGMENTS = 11 /* int32 [noSegments][2] validated segments: first pixel in SEGPIX, number of pixels */
+    FID_STAG_TAP_VSEGMENTS = 11, /* int32 [noSegments][2] validated segments: first pixel in SEGPIX, number of pixels */
+    /* after fid_stag_detect_lines: */
+    FID_STAG_TAP_LINES = 12      /* fid_stag_line [noLines] */
 } fid_stag_tap;
 int64_t fid_stag_tap_bytes(fid_stag_ctx *ctx, fid_stag_tap which);
 fid_status fid_stag_tap_read(fid_stag_ctx *ctx, fid_stag_tap which, void *dst, int64_t dst_bytes);

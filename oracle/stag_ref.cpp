@@ -23,6 +23,15 @@
 #include "src/stag/ED/GradientOperators.cpp"
 #include "src/stag/ED/EDInternals.cpp"
 #include "src/stag/ED/ValidateEdgeSegments.cpp"
+// compiled as their own translation units by oracle/Makefile (target ref), straight from the reference tree:
+//   src/stag/ED/ED.cpp  EDLines.cpp  LineSegment.cpp  NFA.cpp  MyMath.cpp
+#include "stag/ED/ED.h"
+#include "stag/ED/EDLines.h"
+#include "stag/ED/ImageSmooth.h"
+void SplitSegment2Lines(double *x, double *y, int noPixels, int segmentNo, EDLines *lines);
+void JoinCollinearLines(EDLines *lines, double MAX_DISTANCE_BETWEEN_TWO_LINES, double MAX_ERROR);
+void ValidateLineSegments(EdgeMap *map, unsigned char *srcImg, EDLines *lines, EDLines *invalidLines);
+int ComputeMinLineLength(int width, int height);
 
 static inline int reflect101(int p, int n)
 {
@@ -32,6 +41,98 @@ static inline int reflect101(int p, int n)
 }
 
 extern "C" {
+int ref_stag_smooth5(const uint8_t *src, uint8_t *dst, int w, int h);
+int ref_stag_smooth3(const uint8_t *src, uint8_t *dst, int w, int h);
+}
+
+// The one function of the ED library that calls OpenCV (ImageSmooth.cpp:43-55; not compiled): DetectEdgesByEDPF asks for
+// sigma 1.0 (5x5) and then sigma 1 / 2.5 (3x3).  Restated, see the header of this file.
+void SmoothImage(unsigned char *srcImg, unsigned char *smoothImg, int width, int height, double sigma)
+{
+    if (sigma == 1.0) ref_stag_smooth5(srcImg, smoothImg, width, height);
+    else ref_stag_smooth3(srcImg, smoothImg, width, height);
+}
+
+static void export_lines(EDLines *lines, double *out, int cap, int *n_out)
+{
+    for (int i = 0; i < lines->noLines && i < cap; i++) {
+        const LineSegment &l = lines->lines[i];
+        double *o = out + 10 * i;
+        o[0] = l.a; o[1] = l.b; o[2] = l.sx; o[3] = l.sy; o[4] = l.ex; o[5] = l.ey;
+        o[6] = l.invert; o[7] = l.segmentNo; o[8] = l.firstPixelIndex; o[9] = l.len;
+    }
+    *n_out = lines->noLines;
+}
+
+extern "C" {
+
+// The line-fitting part of DetectLinesByEDPF (EDLines.cpp:877-913) on a given EdgeMap: the same loop (copy the pixels of a
+// segment into x / y, SplitSegment2Lines), then JoinCollinearLines(lines, 6.0, 1.50); with validate != 0 also
+// ValidateLineSegments(map, src, lines, NULL) (:918).  lines_out: double [cap][10] = a b sx sy ex ey invert segmentNo
+// firstPixelIndex len.
+int ref_stag_fit_lines(const uint8_t *src, int w, int h, const int32_t *segpix, int n_pix, const int32_t *seg_in, int n_seg_in,
+                       int validate, double *lines_out, int cap, int *n_out, int *min_line_len)
+{
+    EdgeMap *map = new EdgeMap(w, h);
+    for (int i = 0; i < n_pix; i++) {
+        map->pixels[i].r = segpix[2 * i];
+        map->pixels[i].c = segpix[2 * i + 1];
+    }
+    for (int i = 0; i < n_seg_in; i++) {
+        map->segments[i].pixels = map->pixels + seg_in[2 * i];
+        map->segments[i].noPixels = seg_in[2 * i + 1];
+    }
+    map->noSegments = n_seg_in;
+    EDLines *lines = new EDLines(w, h);
+    lines->MIN_LINE_LEN = ComputeMinLineLength(w, h);
+    if (lines->MIN_LINE_LEN < 9) lines->MIN_LINE_LEN = 9;
+    *min_line_len = lines->MIN_LINE_LEN;
+    for (int segmentNo = 0; segmentNo < map->noSegments; segmentNo++) {
+        EdgeSegment *segment = &map->segments[segmentNo];
+        for (int k = 0; k < segment->noPixels; k++) {
+            lines->x[k] = segment->pixels[k].c;
+            lines->y[k] = segment->pixels[k].r;
+        }
+        SplitSegment2Lines(lines->x, lines->y, segment->noPixels, segmentNo, lines);
+    }
+    JoinCollinearLines(lines, 6.0, 1.50);
+    if (validate) ValidateLineSegments(map, const_cast<unsigned char *>(src), lines, NULL);
+    export_lines(lines, lines_out, cap, n_out);
+    const int rc = lines->noLines <= cap ? 0 : 1;
+    delete lines;
+    delete map;
+    return rc;
+}
+
+// DetectLinesByEDPF (EDLines.cpp:849-941) end to end, as EDInterface::runEDPFandEDLines calls it (EDInterface.cpp:17-18)
+int ref_stag_detect_lines(const uint8_t *src, int w, int h, double *lines_out, int cap, int *n_out, int32_t *seg_out, int cap_seg,
+                          int *n_seg_out, int32_t *segpix_out, int cap_pix, int *n_pix_out)
+{
+    EdgeMap *map = NULL;
+    EDLines *lines = DetectLinesByEDPF(map, const_cast<unsigned char *>(src), w, h, false, 0);
+    export_lines(lines, lines_out, cap, n_out);
+    int rc = lines->noLines <= cap ? 0 : 1;
+    int total = 0;
+    for (int i = 0; i < map->noSegments; i++) {
+        const int off = (int)(map->segments[i].pixels - map->pixels), n = map->segments[i].noPixels;
+        if (i < cap_seg) {
+            seg_out[2 * i] = off;
+            seg_out[2 * i + 1] = n;
+        } else
+            rc = 1;
+        if (off + n > total) total = off + n;
+    }
+    if (total > cap_pix) rc = 1;
+    for (int i = 0; i < total && i < cap_pix; i++) {
+        segpix_out[2 * i] = map->pixels[i].r;
+        segpix_out[2 * i + 1] = map->pixels[i].c;
+    }
+    *n_seg_out = map->noSegments;
+    *n_pix_out = total;
+    delete lines;
+    delete map;
+    return rc;
+}
 
 int ref_stag_smooth5(const uint8_t *src, uint8_t *dst, int w, int h)
 {

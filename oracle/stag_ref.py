@@ -132,3 +132,39 @@ def route(grad: np.ndarray, dirs: np.ndarray, anchor_map: np.ndarray, grad_thres
                               seg.ctypes.data_as(C.c_void_p), len(seg), C.byref(ns), C.byref(npx))
     assert rc == 0
     return e, [pix[a:a + n].copy() for a, n in seg[:ns.value]]
+
+
+LINE_FIELDS = ("a", "b", "sx", "sy", "ex", "ey", "invert", "segmentNo", "firstPixelIndex", "len")
+
+
+def fit_lines(src: np.ndarray, segpix: np.ndarray, segs: np.ndarray, validate: bool = False):
+    """The reference's SplitSegment2Lines + JoinCollinearLines (+ ValidateLineSegments) on a given EdgeMap.
+    Returns (lines float64 [n][10] in LINE_FIELDS order, MIN_LINE_LEN)."""
+    im = np.ascontiguousarray(src, dtype=np.uint8)
+    h, w = im.shape
+    pix = np.ascontiguousarray(segpix, dtype=np.int32).reshape(-1, 2)
+    sg = np.ascontiguousarray(segs, dtype=np.int32).reshape(-1, 2)
+    cap = (w + h) * 64
+    out = np.zeros((cap, 10), np.float64)
+    n, mll = C.c_int(0), C.c_int(0)
+    rc = lib().ref_stag_fit_lines(im.ctypes.data_as(C.c_void_p), w, h, pix.ctypes.data_as(C.c_void_p), len(pix),
+                                  sg.ctypes.data_as(C.c_void_p), len(sg), int(validate), out.ctypes.data_as(C.c_void_p), cap,
+                                  C.byref(n), C.byref(mll))
+    assert rc == 0
+    return out[:n.value].copy(), mll.value
+
+
+def detect_lines(src: np.ndarray):
+    """The reference's DetectLinesByEDPF end to end (only SmoothImage restated).  Returns (lines [n][10], segs, segpix)."""
+    im = np.ascontiguousarray(src, dtype=np.uint8)
+    h, w = im.shape
+    cap = (w + h) * 64
+    out = np.zeros((cap, 10), np.float64)
+    seg = np.zeros((w * h // 8 + 16, 2), np.int32)
+    pix = np.zeros((w * h, 2), np.int32)
+    n, ns, npx = C.c_int(0), C.c_int(0), C.c_int(0)
+    rc = lib().ref_stag_detect_lines(im.ctypes.data_as(C.c_void_p), w, h, out.ctypes.data_as(C.c_void_p), cap, C.byref(n),
+                                     seg.ctypes.data_as(C.c_void_p), len(seg), C.byref(ns),
+                                     pix.ctypes.data_as(C.c_void_p), len(pix), C.byref(npx))
+    assert rc == 0
+    return out[:n.value].copy(), seg[:ns.value].copy(), pix[:npx.value].copy()

@@ -189,6 +189,32 @@ def test_segment_validation_matches_reference_code(case):
         det.close()
 
 
+def _lines_as_table(L):
+    return np.stack([L[f].astype(np.float64) for f in stag_ref.LINE_FIELDS], axis=1) if len(L) else np.zeros((0, 10))
+
+
+@pytest.mark.parametrize("case", sorted(VALID_CASES))
+def test_line_fitting_matches_reference_code(case):
+    """Row s6, first half: SplitSegment2Lines + JoinCollinearLines.  Every field of every line bit for bit (doubles compared
+    with ==) against the reference's own routines fed with the device's validated EdgeMap."""
+    if not stag_ref.available():
+        pytest.skip("oracle/_ref/libstag_ref.so not built (needs /root/reference at build time)")
+    img = VALID_CASES[case]()
+    det = fstag.StagDetector(21, 7, max_width=1920, max_height=1080)
+    try:
+        det.detect_lines(img)
+        vsegs, pix = det.tap(fstag.TAP_VSEGMENTS).reshape(-1, 2), det.tap(fstag.TAP_SEGPIX).reshape(-1, 2)
+        ref, mll = stag_ref.fit_lines(img, pix, vsegs, validate=False)
+        got = _lines_as_table(det.lines())
+        assert got.shape == ref.shape, (got.shape, ref.shape)
+        bad = np.nonzero(~(got == ref).all(axis=1))[0]
+        assert len(bad) == 0, (bad[:5], got[bad[:2]], ref[bad[:2]])
+        if case.startswith(("markers", "faint", "texture")):
+            assert len(ref) > 0
+    finally:
+        det.close()
+
+
 def test_stag_status_codes():
     from fiducials_amd import _lib
     from fiducials_amd._lib import FidError

@@ -1087,7 +1087,258 @@ __global__ __launch_bounds__(64) void k_stag_gather_lines(const int2 *__restrict
     for (int j = 0; j < n; j++) out[o + j] = L[j];
 }
 
+// ------------------------------------------------------------------------------------------------ K13: line validation
+// ValidateLineSegments (EDLines.cpp:274-409): a line is kept if enough of its pixels have a gradient direction within
+// 22.5 degrees of the line (Helmholtz principle, number of false alarms from a table).  Lines of >= 80 pixels pass untested,
+// lines of <= 25 pixels are tested on all pixels of a 2-pixel-wide rectangle around them (EnumerateRectPoints, :417-600, the
+// LSD rectangle iterator), the others on their own pixels first and on the rectangle if that fails.  One lane per line.
+// Host-made tables (functions of the image size only, evaluated with the host's libm exactly as the reference does):
+//   atan_lut[i] = atan(i / 1024)  (myAtan2, MyMath.cpp:12-72);  kmin[n] = the NFALUT entry (NFA.cpp:13-44).
+struct StagLineTables {
+    const double *atan_lut;  // 1025 entries
+    const int *kmin;         // kmin[n]: smallest number of aligned pixels out of n that validates; n <= kmin_n
+    int kmin_n;
+};
+
+__device__ double sl_my_atan2(const double *lut, double yy, double xx)
+{
+    const double PI = 3.14159265358979323846;
+    double y = fabs(yy), x = fabs(xx);
+    if (x < 0.0001) return y < 0.0001 ? 0.0 : PI / 2;
+    bool invert = false;
+    if (y > x) {
+        const double t = x;
+        x = y;
+        y = t;
+        invert = true;
+    }
+    const double ratio = y / x;
+    double angle = lut[(int)(ratio * 1024)];
+    if (xx >= 0) {
+        if (yy >= 0) {
+            if (invert) angle = PI / 2 - angle;
+        } else {
+            angle = invert ? PI / 2 + angle : PI - angle;
+        }
+    } else {
+        if (yy >= 0) {
+            angle = invert ? PI / 2 + angle : PI - angle;
+        } else {
+            if (invert) angle = PI / 2 - angle;
+        }
+    }
+    return angle;
+}
+
+// is the gradient at (r, c) of the source image aligned with the line?  (-1: the pixel does not count)
+__device__ int sl_aligned(const uint8_t *__restrict__ src, int W, int H, int r, int c, double lineAngle, const double *lut)
+{
+    const double PI = 3.14159265358979323846, prec = (22.5 / 180) * PI;
+    if (r <= 0 || r >= H - 1 || c <= 0 || c >= W - 1) return -1;
+    const int com1 = src[(r + 1) * W + c + 1] - src[(r - 1) * W + c - 1];
+    const int com2 = src[(r - 1) * W + c + 1] - src[(r + 1) * W + c - 1];
+    const int gx = com1 + com2 + src[r * W + c + 1] - src[r * W + c - 1];
+    const int gy = com1 - com2 + src[(r + 1) * W + c] - src[(r - 1) * W + c];
+    const double pixelAngle = sl_my_atan2(lut, (double)gx, (double)-gy);
+    const double diff = fabs(lineAngle - pixelAngle);
+    return (diff <= prec || diff >= PI - prec) ? 1 : 0;
+}
+
+// ValidateLineSegmentRect (EDLines.cpp:612-690) with the rectangle iterator of EnumerateRectPoints (:417-600) inlined
+__device__ bool sl_validate_rect(const uint8_t *__restrict__ src, int W, int H, const fid_stag_line &ls, double lineAngle, const StagLineTables &T)
+{
+    const double x1 = ls.sx, y1 = ls.sy, x2 = ls.ex, y2 = ls.ey, width = 2;
+    double dx = x2 - x1, dy = y2 - y1;
+    const double vLen = sqrt(dx * dx + dy * dy);
+    dx = dx / vLen;
+    dy = dy / vLen;
+    double vxT[4], vyT[4], vx[4], vy[4];
+    vxT[0] = x1 - dy * width / 2.0; vyT[0] = y1 + dx * width / 2.0;
+    vxT[1] = x2 - dy * width / 2.0; vyT[1] = y2 + dx * width / 2.0;
+    vxT[2] = x2 + dy * width / 2.0; vyT[2] = y2 - dx * width / 2.0;
+    vxT[3] = x1 + dy * width / 2.0; vyT[3] = y1 - dx * width / 2.0;
+    int offset;
+    if (x1 < x2 && y1 <= y2) offset = 0;
+    else if (x1 >= x2 && y1 < y2) offset = 1;
+    else if (x1 > x2 && y1 >= y2) offset = 2;
+    else offset = 3;
+#pragma unroll
+    for (int n = 0; n < 4; n++) {
+        vx[n] = vxT[(offset + n) % 4];
+        vy[n] = vyT[(offset + n) % 4];
+    }
+    int x = (int)ceil(vx[0]) - 1, y = (int)ceil(vy[0]);
+    double ys = -1.7976931348623157e308, ye = -1.7976931348623157e308;
+    int noPoints = 0, count = 0, aligned = 0;
+    const int maxNoOfPoints = (int)(fabs(ls.sx - ls.ex) + fabs(ls.sy - ls.ey)) * 4;
+    while (noPoints < maxNoOfPoints) {
+        y++;
+        while (y > ye && x <= vx[2]) {
+            x++;
+            if (x > vx[2]) break;
+            if ((double)x < vx[3]) {
+                if (fabs(vx[0] - vx[3]) <= 0.01) {
+                    if (vy[0] < vy[3]) ys = vy[0];
+                    else if (vy[0] > vy[3]) ys = vy[3];
+                    else ys = vy[0] + (x - vx[0]) * (vy[3] - vy[0]) / (vx[3] - vx[0]);
+                } else
+                    ys = vy[0] + (x - vx[0]) * (vy[3] - vy[0]) / (vx[3] - vx[0]);
+            } else {
+                if (fabs(vx[3] - vx[2]) <= 0.01) {
+                    if (vy[3] < vy[2]) ys = vy[3];
+                    else if (vy[3] > vy[2]) ys = vy[2];
+                    else ys = vy[3] + (x - vx[3]) * (y2 - vy[3]) / (vx[2] - vx[3]);  // (y2, as in the reference)
+                } else
+                    ys = vy[3] + (x - vx[3]) * (vy[2] - vy[3]) / (vx[2] - vx[3]);
+            }
+            if ((double)x < vx[1]) {
+                if (fabs(vx[0] - vx[1]) <= 0.01) {
+                    if (vy[0] < vy[1]) ye = vy[1];
+                    else if (vy[0] > vy[1]) ye = vy[0];
+                    else ye = vy[0] + (x - vx[0]) * (vy[1] - vy[0]) / (vx[1] - vx[0]);
+                } else
+                    ye = vy[0] + (x - vx[0]) * (vy[1] - vy[0]) / (vx[1] - vx[0]);
+            } else {
+                if (fabs(vx[1] - vx[2]) <= 0.01) {
+                    if (vy[1] < vy[2]) ye = vy[2];
+                    else if (vy[1] > vy[2]) ye = vy[1];
+                    else ye = vy[1] + (x - vx[1]) * (vy[2] - vy[1]) / (vx[2] - vx[1]);
+                } else
+                    ye = vy[1] + (x - vx[1]) * (vy[2] - vy[1]) / (vx[2] - vx[1]);
+            }
+            y = (int)ceil(ys);
+        }
+        if (x > vx[2]) break;
+        noPoints++;
+        const int al = sl_aligned(src, W, H, y, x, lineAngle, T.atan_lut);
+        if (al >= 0) {
+            count++;
+            aligned += al;
+        }
+    }
+    return count <= T.kmin_n ? aligned >= T.kmin[count] : false;
+}
+
+__global__ __launch_bounds__(64) void k_stag_validate_lines(const fid_stag_line *__restrict__ lines, const int *__restrict__ nlines,
+                                                            const uint8_t *__restrict__ src, int W, int H, const int2 *__restrict__ vsegs,
+                                                            const int2 *__restrict__ pix, StagLineTables T, int *__restrict__ flags)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= *nlines) return;
+    const double PI = 3.14159265358979323846;
+    const fid_stag_line ls = lines[i];
+    double lineAngle = ls.invert == 0 ? atan(ls.b) : atan(1.0 / ls.b);
+    if (lineAngle < 0) lineAngle += PI;
+    bool valid;
+    if (ls.len >= 80) {
+        valid = true;
+    } else if (ls.len <= 25) {
+        valid = sl_validate_rect(src, W, H, ls, lineAngle, T);
+    } else {
+        const int2 *p = pix + vsegs[ls.segmentNo].x + ls.firstPixelIndex;
+        int count = 0, aligned = 0;
+        for (int j = 0; j < ls.len; j++) {
+            const int al = sl_aligned(src, W, H, p[j].x, p[j].y, lineAngle, T.atan_lut);
+            if (al >= 0) {
+                count++;
+                aligned += al;
+            }
+        }
+        valid = count <= T.kmin_n ? aligned >= T.kmin[count] : false;
+        if (!valid) valid = sl_validate_rect(src, W, H, ls, lineAngle, T);
+    }
+    flags[i] = valid ? 1 : 0;
+}
+
+// keep the valid lines, in order (flags hold exclusive prefix sums by now)
+__global__ __launch_bounds__(256) void k_stag_compact_lines(const fid_stag_line *__restrict__ lines, const int *__restrict__ nlines,
+                                                            const int *__restrict__ pos, const int *__restrict__ total,
+                                                            fid_stag_line *__restrict__ out)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int n = *nlines;
+    if (i >= n) return;
+    const int next = i + 1 < n ? pos[i + 1] : *total;
+    if (next != pos[i]) out[pos[i]] = lines[i];
+}
+
 // ------------------------------------------------------------------------------------------------ C-ABI
+// ---- host side of the line validation: the number-of-false-alarms table.  nfa() restates NFA.cpp:155-239 (the LSD
+// binomial-tail bound: log-gamma by Windschitl / Lanczos, series with a 10 % truncation tolerance); the table is what
+// NFALUT::NFALUT builds (NFA.cpp:13-44), continued past LUTSize where the reference calls nfa(n, k) directly (assumes, like
+// the table itself, that nfa grows with k).
+static double stag_log_gamma(double x)
+{
+    if (x > 15.0) return 0.918938533204673 + (x - 0.5) * log(x) - x + 0.5 * x * log(x * sinh(1 / x) + 1 / (810.0 * pow(x, 6.0)));
+    static const double q[7] = {75122.6331530, 80916.6278952, 36308.2951477, 8687.24529705, 1168.92649479, 83.8676043424, 2.50662827511};
+    double a = (x + 0.5) * log(x + 5.5) - (x + 5.5);
+    double b = 0.0;
+    for (int n = 0; n < 7; n++) {
+        a -= log(x + (double)n);
+        b += q[n] * pow(x, (double)n);
+    }
+    return a + log(b);
+}
+
+static bool stag_double_equal(double a, double b)
+{
+    if (a == b) return true;
+    const double abs_diff = fabs(a - b), aa = fabs(a), bb = fabs(b);
+    double abs_max = aa > bb ? aa : bb;
+    if (abs_max < 2.2250738585072014e-308) abs_max = 2.2250738585072014e-308;
+    return (abs_diff / abs_max) <= (100.0 * 2.2204460492503131e-16);
+}
+
+static double stag_nfa(int n, int k, double p, double logNT)
+{
+    const double tolerance = 0.1, LN10 = 2.30258509299404568402;
+    if (n < 0 || k < 0 || k > n || p <= 0.0 || p >= 1.0) return -1.0;
+    if (n == 0 || k == 0) return -logNT;
+    if (n == k) return -logNT - (double)n * log10(p);
+    const double p_term = p / (1.0 - p);
+    const double log1term = stag_log_gamma((double)n + 1.0) - stag_log_gamma((double)k + 1.0) - stag_log_gamma((double)(n - k) + 1.0) +
+                            (double)k * log(p) + (double)(n - k) * log(1.0 - p);
+    double term = exp(log1term);
+    if (stag_double_equal(term, 0.0)) {
+        if ((double)k > (double)n * p) return -log1term / LN10 - logNT;
+        return -logNT;
+    }
+    double bin_tail = term;
+    for (int i = k + 1; i <= n; i++) {
+        const double bin_term = (double)(n - i + 1) * (1.0 / (double)i);
+        const double mult_term = bin_term * p_term;
+        term *= mult_term;
+        bin_tail += term;
+        if (bin_term < 1.0) {
+            const double err = term * ((1.0 - pow(mult_term, (double)(n - i + 1))) / (1.0 - mult_term) - 1.0);
+            if (err < tolerance * fabs(-log10(bin_tail) - logNT) * bin_tail) break;
+        }
+    }
+    return -log10(bin_tail) - logNT;
+}
+
+static void stag_build_kmin(int W, int H, std::vector<int> &kmin)
+{
+    const double prob = 0.125, logNT = 2.0 * (log10((double)W) + log10((double)H));
+    const int lutSize = (W + H) / 8, nmax = 4 * (W + H) + 8;
+    kmin.assign(nmax + 1, 0);
+    kmin[0] = 1;
+    int j = 1;
+    for (int i = 1; i <= nmax; i++) {
+        kmin[i] = (i < lutSize ? lutSize : i) + 1;  // "never": more aligned pixels than there are pixels
+        double ret = stag_nfa(i, j, prob, logNT);
+        if (ret < 0) {
+            while (j < i) {
+                j++;
+                ret = stag_nfa(i, j, prob, logNT);
+                if (ret >= 0) break;
+            }
+            if (ret < 0) continue;
+        }
+        kmin[i] = j;
+    }
+}
+
 struct fid_stag_ctx {
     int device = 0, maxW = 0, maxH = 0, libraryHD = 0, errorCorrection = 0;
     hipStream_t stream = nullptr;
@@ -1118,6 +1369,12 @@ struct fid_stag_ctx {
     int *d_lcounts = nullptr, *d_ltotal = nullptr;
     int n_lines = 0, min_line_len = 0;
     bool lined = false;
+    // line validation
+    double *d_atan_lut = nullptr;
+    int *d_kmin = nullptr, *d_lflags = nullptr, *d_vltotal = nullptr;
+    fid_stag_line *d_vlines = nullptr;
+    int kmin_w = 0, kmin_h = 0, kmin_n = 0, n_vlines = 0;
+    bool lines_validated = false;
     int W = 0, H = 0;
     unsigned n_anchors = 0;
 };
@@ -1166,6 +1423,15 @@ fid_status fid_stag_create(int libraryHD, int errorCorrection, int max_width, in
          hipMalloc((void **)&c->d_lslots, (n / 9 + 16) * sizeof(fid_stag_line)) == hipSuccess &&
          hipMalloc((void **)&c->d_lines, (n / 9 + 16) * sizeof(fid_stag_line)) == hipSuccess &&
          hipMalloc((void **)&c->d_lcounts, (n / 8 + 16) * 4) == hipSuccess && hipMalloc((void **)&c->d_ltotal, 4) == hipSuccess;
+    ok = ok && hipMalloc((void **)&c->d_atan_lut, 1025 * 8) == hipSuccess &&
+         hipMalloc((void **)&c->d_kmin, (size_t)(4 * (max_width + max_height) + 16) * 4) == hipSuccess &&
+         hipMalloc((void **)&c->d_lflags, (n / 9 + 16) * 4) == hipSuccess && hipMalloc((void **)&c->d_vltotal, 4) == hipSuccess &&
+         hipMalloc((void **)&c->d_vlines, (n / 9 + 16) * sizeof(fid_stag_line)) == hipSuccess;
+    if (ok) {
+        double lut[1025];
+        for (int i = 0; i <= 1024; i++) lut[i] = atan((double)i / 1024);
+        ok = hipMemcpy(c->d_atan_lut, lut, sizeof(lut), hipMemcpyHostToDevice) == hipSuccess;
+    }
     if (!ok) {
         fid_stag_destroy(c);
         return FID_E_OUT_OF_MEMORY;
@@ -1182,7 +1448,8 @@ void fid_stag_destroy(fid_stag_ctx *c)
     void *dev[] = {c->d_src, c->d_smooth, c->d_dir, c->d_edge, c->d_grad, c->d_sorted, c->d_rowhist, c->d_bandhist, c->d_tot, c->d_bstart, c->d_n,
                    c->d_edgeimg, c->d_rpix, c->d_outpix, c->d_segs, c->d_rstack, c->d_chains, c->d_chainnos, c->d_rcount,
                    c->d_smooth2, c->d_vgrad, c->d_vhist, c->d_prob, c->d_np, c->d_vcounts, c->d_vtotal, c->d_vstack, c->d_vsegs,
-                   c->d_prefix, c->d_lslots, c->d_lines, c->d_lcounts, c->d_ltotal};
+                   c->d_prefix, c->d_lslots, c->d_lines, c->d_lcounts, c->d_ltotal,
+                   c->d_atan_lut, c->d_kmin, c->d_lflags, c->d_vltotal, c->d_vlines};
     for (void *p : dev)
         if (p) (void)hipFree(p);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -1306,6 +1573,40 @@ fid_status fid_stag_detect_lines(fid_stag_ctx *c, const uint8_t *gray, int32_t w
     if (hipMemcpyAsync(&c->n_lines, c->d_ltotal, 4, hipMemcpyDeviceToHost, st) != hipSuccess) return FID_E_HIP;
     if (hipStreamSynchronize(st) != hipSuccess) return FID_E_HIP;
     c->lined = true;
+    c->lines_validated = false;
+    return FID_OK;
+}
+
+fid_status fid_stag_detect_lines_validated(fid_stag_ctx *c, const uint8_t *gray, int32_t width, int32_t height, int32_t stride)
+{
+    fid_status rc = fid_stag_detect_lines(c, gray, width, height, stride);
+    if (rc != FID_OK) return rc;
+    hipStream_t st = c->stream;
+    const int W = c->W, H = c->H;
+    if (c->kmin_w != W || c->kmin_h != H) {  // the false-alarm table is a function of the image size
+        std::vector<int> kmin;
+        stag_build_kmin(W, H, kmin);
+        if (hipMemcpy(c->d_kmin, kmin.data(), kmin.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return FID_E_HIP;
+        c->kmin_w = W;
+        c->kmin_h = H;
+        c->kmin_n = (int)kmin.size() - 1;
+    }
+    StagLineTables T;
+    T.atan_lut = c->d_atan_lut;
+    T.kmin = c->d_kmin;
+    T.kmin_n = c->kmin_n;
+    const int nl = c->n_lines;
+    if (nl > 0)
+        hipLaunchKernelGGL(k_stag_validate_lines, dim3((nl + 63) / 64), dim3(64), 0, st, c->d_lines, c->d_ltotal, c->d_src, W, H, c->d_vsegs,
+                           c->d_outpix, T, c->d_lflags);
+    hipLaunchKernelGGL(k_stag_scan_counts, dim3(1), dim3(1024), 0, st, c->d_lflags, c->d_ltotal, c->d_vltotal);
+    if (nl > 0)
+        hipLaunchKernelGGL(k_stag_compact_lines, dim3((nl + 255) / 256), dim3(256), 0, st, c->d_lines, c->d_ltotal, c->d_lflags, c->d_vltotal,
+                           c->d_vlines);
+    if (hipGetLastError() != hipSuccess) return FID_E_HIP;
+    if (hipMemcpyAsync(&c->n_vlines, c->d_vltotal, 4, hipMemcpyDeviceToHost, st) != hipSuccess) return FID_E_HIP;
+    if (hipStreamSynchronize(st) != hipSuccess) return FID_E_HIP;
+    c->lines_validated = true;
     return FID_OK;
 }
 
@@ -1327,6 +1628,7 @@ int64_t fid_stag_tap_bytes(fid_stag_ctx *c, fid_stag_tap which)
     case FID_STAG_TAP_VPROB: return c->validated ? (int64_t)STAG_BINS * 8 : 0;
     case FID_STAG_TAP_VSEGMENTS: return c->validated ? (int64_t)c->n_vsegs * 8 : 0;
     case FID_STAG_TAP_LINES: return c->lined ? (int64_t)c->n_lines * (int64_t)sizeof(fid_stag_line) : 0;
+    case FID_STAG_TAP_VLINES: return c->lines_validated ? (int64_t)c->n_vlines * (int64_t)sizeof(fid_stag_line) : 0;
     }
     return 0;
 }
@@ -1352,6 +1654,7 @@ fid_status fid_stag_tap_read(fid_stag_ctx *c, fid_stag_tap which, void *dst, int
     case FID_STAG_TAP_VPROB: src = c->d_prob; break;
     case FID_STAG_TAP_VSEGMENTS: src = c->d_vsegs; break;
     case FID_STAG_TAP_LINES: src = c->d_lines; break;
+    case FID_STAG_TAP_VLINES: src = c->d_vlines; break;
     }
     if (!src) return FID_E_INVALID_ARG;
     if (hipSetDevice(c->device) != hipSuccess) return FID_E_HIP;

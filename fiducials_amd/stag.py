@@ -12,7 +12,7 @@ from . import _lib
 from ._lib import FidError
 
 (TAP_SMOOTH, TAP_GRAD, TAP_DIR, TAP_ANCHORS, TAP_SORTED, TAP_EDGEIMG, TAP_SEGMENTS, TAP_SEGPIX, TAP_SMOOTH2, TAP_VGRAD, TAP_VPROB,
- TAP_VSEGMENTS, TAP_LINES) = range(13)
+ TAP_VSEGMENTS, TAP_LINES, TAP_VLINES) = range(14)
 
 LINE_DTYPE = np.dtype([("a", "f8"), ("b", "f8"), ("sx", "f8"), ("sy", "f8"), ("ex", "f8"), ("ey", "f8"), ("invert", "i4"),
                        ("segmentNo", "i4"), ("firstPixelIndex", "i4"), ("len", "i4")])
@@ -55,8 +55,12 @@ class StagDetector:
         """DetectLinesByEDPF up to JoinCollinearLines; lines() reads the result (structured array, LINE_DTYPE)."""
         self._run(self._L.fid_stag_detect_lines, gray)
 
-    def lines(self) -> np.ndarray:
-        return self.tap(TAP_LINES)
+    def detect_lines_validated(self, gray: np.ndarray):
+        """DetectLinesByEDPF complete (EDInterface::runEDPFandEDLines); lines(validated=True) reads EDLines::lines."""
+        self._run(self._L.fid_stag_detect_lines_validated, gray)
+
+    def lines(self, validated: bool = False) -> np.ndarray:
+        return self.tap(TAP_VLINES if validated else TAP_LINES)
 
     def edge_segments(self, validated: bool = False):
         """List of (n_i, 2) int32 arrays of (r, c): EdgeMap::segments after detect_edges() / detect_edges_validated()."""
@@ -90,6 +94,6 @@ class StagDetector:
             return buf.view(np.int16).reshape(h, w)
         if which == TAP_VPROB:
             return buf.view(np.float64)
-        if which == TAP_LINES:
+        if which in (TAP_LINES, TAP_VLINES):
             return buf.view(LINE_DTYPE)
         return buf.view(np.int32)

@@ -215,8 +215,11 @@ fid_status fid_stag_detect_edges(fid_stag_ctx *ctx, const uint8_t *gray, int32_t
  * (ED/ValidateEdgeSegments.cpp:365-413): Helmholtz-principle validation of every segment, invalid pieces cut out */
 fid_status fid_stag_detect_edges_validated(fid_stag_ctx *ctx, const uint8_t *gray, int32_t width, int32_t height, int32_t stride_bytes);
 /* the above + the line fitting of DetectLinesByEDPF (ED/EDLines.cpp:849-941): SplitSegment2Lines (:162-268) and
- * JoinCollinearLines (:114-156).  (ValidateLineSegments, the last step of DetectLinesByEDPF, is not in yet.) */
+ * JoinCollinearLines (:114-156) */
 fid_status fid_stag_detect_lines(fid_stag_ctx *ctx, const uint8_t *gray, int32_t width, int32_t height, int32_t stride_bytes);
+/* DetectLinesByEDPF complete = what EDInterface::runEDPFandEDLines produces (EDInterface.cpp:13-19): the above +
+ * ValidateLineSegments (ED/EDLines.cpp:274-409).  EdgeMap (SEGPIX, VSEGMENTS) and EDLines (VLINES) stay on the device. */
+fid_status fid_stag_detect_lines_validated(fid_stag_ctx *ctx, const uint8_t *gray, int32_t width, int32_t height, int32_t stride_bytes);
 typedef enum fid_stag_tap {
     FID_STAG_TAP_SMOOTH = 0,  /* uint8 [h][w] smoothed image */
     FID_STAG_TAP_GRAD = 1,    /* int16 [h][w] |gx| + |gy| (border: GRADIENT_THRESH - 1) */
@@ -233,7 +236,9 @@ typedef enum fid_stag_tap {
     FID_STAG_TAP_VPROB = 10,    /* double [1536] H[g] = P(gradient >= g) */
     FID_STAG_TAP_VSEGMENTS = 11, /* int32 [noSegments][2] validated segments: first pixel in SEGPIX, number of pixels */
     /* after fid_stag_detect_lines: */
-    FID_STAG_TAP_LINES = 12      /* fid_stag_line [noLines] */
+    FID_STAG_TAP_LINES = 12,     /* fid_stag_line [noLines] */
+    /* after fid_stag_detect_lines_validated: */
+    FID_STAG_TAP_VLINES = 13     /* fid_stag_line [noLines]: EDLines::lines as DetectLinesByEDPF returns them */
 } fid_stag_tap;
 int64_t fid_stag_tap_bytes(fid_stag_ctx *ctx, fid_stag_tap which);
 fid_status fid_stag_tap_read(fid_stag_ctx *ctx, fid_stag_tap which, void *dst, int64_t dst_bytes);

@@ -215,6 +215,31 @@ def test_line_fitting_matches_reference_code(case):
         det.close()
 
 
+@pytest.mark.parametrize("case", sorted(VALID_CASES))
+def test_detect_lines_end_to_end_matches_reference(case):
+    """Rows s2-s6 together = EDInterface::runEDPFandEDLines: the device pipeline from the raw image against the reference's
+    DetectLinesByEDPF run end to end (oracle/_ref; only SmoothImage restated): validated segments and final lines."""
+    if not stag_ref.available():
+        pytest.skip("oracle/_ref/libstag_ref.so not built (needs /root/reference at build time)")
+    img = VALID_CASES[case]()
+    det = fstag.StagDetector(21, 7, max_width=1920, max_height=1080)
+    try:
+        det.detect_lines_validated(img)
+        ref_lines, ref_segs, ref_pix = stag_ref.detect_lines(img)
+        vsegs, pix = det.tap(fstag.TAP_VSEGMENTS).reshape(-1, 2), det.tap(fstag.TAP_SEGPIX).reshape(-1, 2)
+        assert np.array_equal(vsegs, ref_segs)
+        for a, n in ref_segs:
+            assert np.array_equal(pix[a:a + n], ref_pix[a:a + n])
+        got = _lines_as_table(det.lines(validated=True))
+        assert got.shape == ref_lines.shape, (got.shape, ref_lines.shape)
+        assert (got == ref_lines).all()
+        before = len(det.lines())
+        if case.startswith("faint"):
+            assert len(ref_lines) < before, "the case must exercise the rejection"
+    finally:
+        det.close()
+
+
 def test_stag_status_codes():
     from fiducials_amd import _lib
     from fiducials_amd._lib import FidError

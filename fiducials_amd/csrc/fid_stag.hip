@@ -1262,6 +1262,340 @@ __global__ __launch_bounds__(256) void k_stag_compact_lines(const fid_stag_line 
     if (next != pos[i]) out[pos[i]] = lines[i];
 }
 
+// ------------------------------------------------------------------------------------------------ K14: quads
+// QuadDetector::detectQuads (QuadDetector.cpp:12-66) behind EDLines: groupLines (:78-127) + EDInterface::correctLineDirection
+// (EDInterface.cpp:25-142), detectCorners (:129-181), checkIfCornersFormQuad (:183-271) and the Quad constructor
+// (Quad.cpp:8-12: line at infinity :55-130, projective distortion :132-148).  Lines of one edge segment form one group
+// and groups do not interact: one wave per validated segment; the wave runs the group's (short) scalar logic uniformly
+// and spreads only the "is the corner on the edge segment" scan over its lanes.  Quads land at the slot of their group's
+// first line and are gathered in group order afterwards.
+struct StagCorner {
+    double x, y;
+    int l1, l2;  // indices of the two lines; -1 = the placeholder lines of the "missing fourth corner"
+};
+
+__device__ __forceinline__ double sq_cross(double ax, double ay, double bx, double by) { return ax * by - ay * bx; }
+__device__ __forceinline__ double sq_dist2(double ax, double ay, double bx, double by) { return (ax - bx) * (ax - bx) + (ay - by) * (ay - by); }
+
+// EDInterface::intersectionOfLineSegments (EDInterface.cpp:144-184)
+__device__ void sq_intersect(const fid_stag_line &l1, const fid_stag_line &l2, double *ox, double *oy)
+{
+    double aL1, bL1, aL2, bL2;
+    if (l1.invert == 0) {
+        aL1 = l1.b;
+        bL1 = l1.a;
+    } else {
+        aL1 = 1 / l1.b;
+        bL1 = -l1.a / l1.b;
+    }
+    if (l2.invert == 0) {
+        aL2 = l2.b;
+        bL2 = l2.a;
+    } else {
+        aL2 = 1 / l2.b;
+        bL2 = -l2.a / l2.b;
+    }
+    double x = (bL2 - bL1) / (aL1 - aL2);
+    double y = aL1 * x + bL1;
+    if (l1.invert == 1 && l1.b == 0) {
+        if (l2.invert == 0) y = l2.a + l2.b * l1.a;
+        else y = (l1.a - l2.a) / l2.b;
+        x = l1.a;
+    } else if (l2.invert == 1 && l2.b == 0) {
+        if (l1.invert == 0) y = l1.a + l1.b * l2.a;
+        else y = (l2.a - l1.a) / l1.b;
+        x = l2.a;
+    }
+    *ox = x;
+    *oy = y;
+}
+
+// EDInterface::correctLineDirection: going from start to end the darker side must be on the right
+__device__ void sq_correct_direction(const uint8_t *__restrict__ img, int W, int H, fid_stag_line &ls)
+{
+    int n, mn;
+    if (ls.invert == 0) {
+        mn = (int)fmin(ls.sx, ls.ex);
+        n = (int)(fmax(ls.sx, ls.ex) + 0.5) - mn + 1;
+    } else {
+        mn = (int)fmin(ls.sy, ls.ey);
+        n = (int)(fmax(ls.sy, ls.ey) + 0.5) - mn + 1;
+    }
+    const double offset = 1;
+    const bool fwd = ls.invert == 0 ? ls.sx < ls.ex : ls.sy < ls.ey;
+    auto sample = [&](int i, int *rx, int *ry, int *lx, int *ly) {
+        if (ls.invert == 0) {
+            const double nx = mn + i, ny = ls.b * nx + ls.a;
+            const int up = (int)round(ny - offset), dn = (int)round(ny + offset);
+            *rx = (int)nx; *lx = (int)nx;
+            *ry = fwd ? dn : up;
+            *ly = fwd ? up : dn;
+        } else {
+            const double ny = mn + i, nx = ls.b * ny + ls.a;
+            const int lo = (int)round(nx - offset), hi = (int)round(nx + offset);
+            *ry = (int)ny; *ly = (int)ny;
+            *rx = fwd ? lo : hi;
+            *lx = fwd ? hi : lo;
+        }
+    };
+    int rx0, ry0, lx0, ly0, rx1, ry1, lx1, ly1;
+    sample(0, &rx0, &ry0, &lx0, &ly0);
+    sample(n - 1, &rx1, &ry1, &lx1, &ly1);
+    const int minX = min(min(rx0, rx1), min(lx0, lx1)), maxX = max(max(rx0, rx1), max(lx0, lx1));
+    const int minY = min(min(ry0, ry1), min(ly0, ly1)), maxY = max(max(ry0, ry1), max(ly0, ly1));
+    const bool safe = minX < 0 || maxX >= W || minY < 0 || maxY >= H;
+    unsigned accR = 0, accL = 0;
+    for (int i = 0; i < n; i++) {
+        int rx, ry, lx, ly;
+        sample(i, &rx, &ry, &lx, &ly);
+        const bool rin = rx >= 0 && rx < W && ry >= 0 && ry < H, lin = lx >= 0 && lx < W && ly >= 0 && ly < H;
+        // (without the safe read the reference reads unchecked; points between two in-range end points are in range)
+        accR += rin ? img[ry * W + rx] : (safe ? 128u : 0u);
+        accL += lin ? img[ly * W + lx] : (safe ? 128u : 0u);
+    }
+    if (accL < accR) {
+        const double t1 = ls.sx, t2 = ls.sy;
+        ls.sx = ls.ex; ls.sy = ls.ey;
+        ls.ex = t1; ls.ey = t2;
+    }
+}
+
+struct StagQuadCtx {
+    const fid_stag_line *L;
+    const int *order;  // line index of the k-th line of the group
+};
+
+__device__ bool sq_quad_simple(const StagCorner c[4])
+{
+    const double v13x = c[2].x - c[0].x, v13y = c[2].y - c[0].y, v12x = c[1].x - c[0].x, v12y = c[1].y - c[0].y;
+    const double v14x = c[3].x - c[0].x, v14y = c[3].y - c[0].y;
+    if (sq_cross(v13x, v13y, v12x, v12y) * sq_cross(v13x, v13y, v14x, v14y) >= 0) return false;
+    const double v24x = c[3].x - c[1].x, v24y = c[3].y - c[1].y, v21x = c[0].x - c[1].x, v21y = c[0].y - c[1].y;
+    const double v23x = c[2].x - c[1].x, v23y = c[2].y - c[1].y;
+    if (sq_cross(v24x, v24y, v21x, v21y) * sq_cross(v24x, v24y, v23x, v23y) >= 0) return false;
+    return true;
+}
+
+// the end point of a corner's line that is farther from the corner, relative to the corner
+__device__ void sq_far_point(const StagCorner &c, const fid_stag_line &l, double *px, double *py)
+{
+    if (sq_dist2(c.x, c.y, l.sx, l.sy) > sq_dist2(c.x, c.y, l.ex, l.ey)) {
+        *px = l.sx - c.x;
+        *py = l.sy - c.y;
+    } else {
+        *px = l.ex - c.x;
+        *py = l.ey - c.y;
+    }
+}
+
+__device__ bool sq_face_each_other(const fid_stag_line *L, const StagCorner &c1, const StagCorner &c2)
+{
+    double c1p1x, c1p1y, c1p2x, c1p2y, c2p1x, c2p1y, c2p2x, c2p2y;
+    sq_far_point(c1, L[c1.l1], &c1p1x, &c1p1y);
+    sq_far_point(c1, L[c1.l2], &c1p2x, &c1p2y);
+    sq_far_point(c2, L[c2.l1], &c2p1x, &c2p1y);
+    sq_far_point(c2, L[c2.l2], &c2p2x, &c2p2y);
+    const double c1c2x = c2.x - c1.x, c1c2y = c2.y - c1.y, c2c1x = c1.x - c2.x, c2c1y = c1.y - c2.y;
+    if (sq_cross(c1c2x, c1c2y, c1p1x, c1p1y) * sq_cross(c1c2x, c1c2y, c1p2x, c1p2y) >= 0) return false;
+    if (sq_cross(c1p1x, c1p1y, c1c2x, c1c2y) * sq_cross(c1p1x, c1p1y, c1p2x, c1p2y) <= 0) return false;
+    if (sq_cross(c2c1x, c2c1y, c2p1x, c2p1y) * sq_cross(c2c1x, c2c1y, c2p2x, c2p2y) >= 0) return false;
+    if (sq_cross(c2p1x, c2p1y, c2c1x, c2c1y) * sq_cross(c2p1x, c2p1y, c2p2x, c2p2y) <= 0) return false;
+    return true;
+}
+
+__device__ StagCorner sq_make_corner(const fid_stag_line *L, int la, int lb)
+{
+    StagCorner c;
+    sq_intersect(L[la], L[lb], &c.x, &c.y);
+    c.l1 = la;
+    c.l2 = lb;
+    return c;
+}
+
+// checkIfCornersFormQuad (QuadDetector.cpp:183-271), thresDist = 7
+__device__ bool sq_form_quad(const fid_stag_line *L, StagCorner c[4])
+{
+    const double thresDist = 7;
+    if (!sq_face_each_other(L, c[0], c[2])) return false;
+    StagCorner e1 = sq_make_corner(L, c[0].l1, c[2].l1), e3 = sq_make_corner(L, c[0].l2, c[2].l2);
+    StagCorner est[4] = {c[0], e1, c[2], e3};
+    if (!sq_quad_simple(est)) {
+        e1 = sq_make_corner(L, c[0].l1, c[2].l2);
+        e3 = sq_make_corner(L, c[0].l2, c[2].l1);
+        est[1] = e1;
+        est[3] = e3;
+    }
+    if (!sq_quad_simple(est)) return false;
+    const double d11 = sq_dist2(c[1].x, c[1].y, e1.x, e1.y), d13 = sq_dist2(c[1].x, c[1].y, e3.x, e3.y);
+    const double d31 = sq_dist2(c[3].x, c[3].y, e1.x, e1.y), d33 = sq_dist2(c[3].x, c[3].y, e3.x, e3.y);
+    const double t2 = thresDist * thresDist;
+    if (d11 < d13 && d11 < d31 && d11 < d33 && d11 < t2) {
+        if (!(d33 < t2)) c[3] = e3;
+    } else if (d13 < d11 && d13 < d31 && d13 < d33 && d13 < t2) {
+        if (!(d31 < t2)) c[3] = e1;
+    } else if (d31 < d11 && d31 < d13 && d31 < d33 && d31 < t2) {
+        if (!(d13 < t2)) c[1] = e3;
+    } else if (d33 < d11 && d33 < d13 && d33 < d31 && d33 < t2) {
+        if (!(d11 < t2)) c[1] = e1;
+    } else
+        return false;
+    const double v13x = c[2].x - c[0].x, v13y = c[2].y - c[0].y, v12x = c[1].x - c[0].x, v12y = c[1].y - c[0].y;
+    if (sq_cross(v13x, v13y, v12x, v12y) > 0) {
+        const StagCorner t = c[1];
+        c[1] = c[3];
+        c[3] = t;
+    }
+    return true;
+}
+
+// Quad::calculateLineAtInfinity + calculateProjectiveDistortion (Quad.cpp:55-148)
+__device__ void sq_make_quad(const StagCorner c[4], fid_stag_quad *q)
+{
+    for (int i = 0; i < 4; i++) {
+        q->corners[2 * i] = c[i].x;
+        q->corners[2 * i + 1] = c[i].y;
+    }
+    const double cross14 = sq_cross(c[0].x, c[0].y, c[3].x, c[3].y), cross23 = sq_cross(c[1].x, c[1].y, c[2].x, c[2].y);
+    const double cross12 = sq_cross(c[0].x, c[0].y, c[1].x, c[1].y), cross34 = sq_cross(c[2].x, c[2].y, c[3].x, c[3].y);
+    const double v23x = c[1].x - c[2].x, v23y = c[1].y - c[2].y, v14x = c[0].x - c[3].x, v14y = c[0].y - c[3].y;
+    const double v34x = c[2].x - c[3].x, v34y = c[2].y - c[3].y, v12x = c[0].x - c[1].x, v12y = c[0].y - c[1].y;
+    double i1x, i1y, i2x, i2y;
+    const bool par1 = sq_cross(v14x, v14y, v23x, v23y) == 0, par2 = sq_cross(v12x, v12y, v34x, v34y) == 0;
+    if (par1 && par2) {
+        q->lineInf[0] = 0; q->lineInf[1] = 0; q->lineInf[2] = 1;
+    } else {
+        if (par1) {
+            i2x = (cross12 * v34x - v12x * cross34) / (v12x * v34y - v12y * v34x);
+            i2y = (cross12 * v34y - v12y * cross34) / (v12x * v34y - v12y * v34x);
+            i1x = i2x + v14x;
+            i1y = i2y + v14y;
+        } else if (par2) {
+            i1x = (cross14 * v23x - v14x * cross23) / (v14x * v23y - v14y * v23x);
+            i1y = (cross14 * v23y - v14y * cross23) / (v14x * v23y - v14y * v23x);
+            i2x = i1x + v12x;
+            i2y = i1y + v12y;
+        } else {
+            i1x = (cross14 * v23x - v14x * cross23) / (v14x * v23y - v14y * v23x);
+            i1y = (cross14 * v23y - v14y * cross23) / (v14x * v23y - v14y * v23x);
+            i2x = (cross12 * v34x - v12x * cross34) / (v12x * v34y - v12y * v34x);
+            i2y = (cross12 * v34y - v12y * cross34) / (v12x * v34y - v12y * v34x);
+        }
+        double l1 = i1y - i2y, l2 = i2x - i1x, l3 = i1x * i2y - i2x * i1y;
+        const double nrm = sqrt(l1 * l1 + l2 * l2);
+        l1 /= nrm;
+        l2 /= nrm;
+        l3 /= nrm;
+        q->lineInf[0] = l1; q->lineInf[1] = l2; q->lineInf[2] = l3;
+    }
+    double cur = fabs(q->lineInf[0] * c[0].x + q->lineInf[1] * c[0].y + q->lineInf[2]);
+    double mn = cur, mx = cur;
+    for (int i = 1; i < 4; i++) {
+        cur = fabs(q->lineInf[0] * c[i].x + q->lineInf[1] * c[i].y + q->lineInf[2]);
+        if (cur < mn) mn = cur;
+        if (cur > mx) mx = cur;
+    }
+    q->projectiveDistortion = mx / mn;
+}
+
+// first line and number of lines of every validated segment (lines are stored segment by segment)
+__global__ __launch_bounds__(256) void k_stag_line_ranges(const fid_stag_line *__restrict__ lines, const int *__restrict__ nlines, int2 *__restrict__ range)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int n = *nlines;
+    if (i >= n) return;
+    const int sg = lines[i].segmentNo;
+    if (i == 0 || lines[i - 1].segmentNo != sg) range[sg].x = i;
+    if (i == n - 1 || lines[i + 1].segmentNo != sg) range[sg].y = i + 1;
+}
+
+__global__ __launch_bounds__(256) void k_stag_quads(fid_stag_line *__restrict__ lines, const int2 *__restrict__ range, const int *__restrict__ nsegs,
+                                                    const int2 *__restrict__ vsegs, const int2 *__restrict__ pix, const uint8_t *__restrict__ img, int W,
+                                                    int H, StagCorner *__restrict__ corner_slots, int *__restrict__ order_slots,
+                                                    fid_stag_quad *__restrict__ quad_slots, int *__restrict__ counts)
+{
+    const int seg = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (seg >= *nsegs) return;
+    const int lo = range[seg].x, n = range[seg].y - lo;
+    if (lane == 0) counts[seg] = 0;
+    if (range[seg].y == 0 || n < 4) return;  // groups need >= 4 lines of one edge segment
+    // ---- groupLines: fix the direction of every line of the group (each lane one line), then the order of the group
+    for (int k = lane; k < n; k += 64) {
+        fid_stag_line l = lines[lo + k];
+        sq_correct_direction(img, W, H, l);
+        lines[lo + k] = l;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    const fid_stag_line *L = lines;
+    bool rev;
+    {
+        double ix, iy;
+        sq_intersect(L[lo], L[lo + 1], &ix, &iy);
+        rev = fabs(L[lo].sx - ix) + fabs(L[lo].sy - iy) < fabs(L[lo].ex - ix) + fabs(L[lo].ey - iy);
+    }
+    int *order = order_slots + lo;
+    for (int k = lane; k < n; k += 64) order[k] = rev ? lo + n - 1 - k : lo + k;
+    // ---- detectCorners: consecutive lines that turn the right way and meet on the edge segment
+    StagCorner *corners = corner_slots + lo;
+    int nc = 0;
+    const int2 *sp = pix + vsegs[seg].x;
+    const int spn = vsegs[seg].y;
+    for (int k = 0; k < n; k++) {
+        const int a = rev ? lo + n - 1 - k : lo + k, kn = (k + 1) % n, b = rev ? lo + n - 1 - kn : lo + kn;
+        const fid_stag_line &l1 = L[a], &l2 = L[b];
+        if (sq_cross(l1.ex - l1.sx, l1.ey - l1.sy, l2.ex - l1.sx, l2.ey - l1.sy) <= 0) continue;
+        double ix, iy;
+        sq_intersect(l1, l2, &ix, &iy);
+        const double thresManh = 7 * 1.41;
+        bool on = false;
+        for (int e0 = 0; e0 < spn && !on; e0 += 64) {
+            const int e = e0 + lane;
+            bool hit = false;
+            if (e < spn) hit = fabs(sp[e].y - ix) + fabs(sp[e].x - iy) < thresManh;
+            on = __ballot(hit) != 0ull;
+        }
+        if (!on) continue;
+        if (lane == 0) {
+            corners[nc].x = ix; corners[nc].y = iy; corners[nc].l1 = a; corners[nc].l2 = b;
+        }
+        nc++;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (nc < 3 || lane != 0) return;
+    // ---- quads from the corner group (lane 0)
+    fid_stag_quad *out = quad_slots + lo;
+    int nq = 0;
+    for (int ci = 0; ci < nc; ci++) {
+        const int i1 = ci, i2 = (i1 + 1) % nc, i3 = (i1 + 2) % nc, i4 = (i1 + 3) % nc;
+        StagCorner c[4] = {corners[i1], corners[i2], corners[i3], corners[i4]};
+        if (i1 == i4) {
+            c[3].x = INFINITY; c[3].y = INFINITY; c[3].l1 = c[3].l2 = -1;
+        }
+        if (!sq_form_quad(L, c)) continue;
+        fid_stag_quad q;
+        sq_make_quad(c, &q);
+        if (q.projectiveDistortion > 1.5) continue;  // thresProjectiveDistortion
+        out[nq++] = q;
+        if (nc <= 4) break;
+    }
+    counts[seg] = nq;
+}
+
+__global__ __launch_bounds__(64) void k_stag_gather_quads(const int2 *__restrict__ range, const int *__restrict__ nsegs, const int *__restrict__ counts,
+                                                          const int *__restrict__ total, const fid_stag_quad *__restrict__ slots,
+                                                          fid_stag_quad *__restrict__ out)
+{
+    const int seg = blockIdx.x * 64 + threadIdx.x;
+    const int ns = *nsegs;
+    if (seg >= ns) return;
+    const int o = counts[seg], n = (seg + 1 < ns ? counts[seg + 1] : *total) - o;
+    const fid_stag_quad *Q = slots + range[seg].x;
+    for (int j = 0; j < n; j++) out[o + j] = Q[j];
+}
+
 // ------------------------------------------------------------------------------------------------ C-ABI
 // ---- host side of the line validation: the number-of-false-alarms table.  nfa() restates NFA.cpp:155-239 (the LSD
 // binomial-tail bound: log-gamma by Windschitl / Lanczos, series with a 10 % truncation tolerance); the table is what
@@ -1375,6 +1709,13 @@ struct fid_stag_ctx {
     fid_stag_line *d_vlines = nullptr;
     int kmin_w = 0, kmin_h = 0, kmin_n = 0, n_vlines = 0;
     bool lines_validated = false;
+    // quads
+    int2 *d_lrange = nullptr;
+    StagCorner *d_corners = nullptr;
+    int *d_order = nullptr, *d_qcounts = nullptr, *d_qtotal = nullptr;
+    fid_stag_quad *d_qslots = nullptr, *d_quads = nullptr;
+    int n_quads = 0;
+    bool quadded = false;
     int W = 0, H = 0;
     unsigned n_anchors = 0;
 };
@@ -1427,6 +1768,11 @@ fid_status fid_stag_create(int libraryHD, int errorCorrection, int max_width, in
          hipMalloc((void **)&c->d_kmin, (size_t)(4 * (max_width + max_height) + 16) * 4) == hipSuccess &&
          hipMalloc((void **)&c->d_lflags, (n / 9 + 16) * 4) == hipSuccess && hipMalloc((void **)&c->d_vltotal, 4) == hipSuccess &&
          hipMalloc((void **)&c->d_vlines, (n / 9 + 16) * sizeof(fid_stag_line)) == hipSuccess;
+    ok = ok && hipMalloc((void **)&c->d_lrange, (n / 8 + 16) * sizeof(int2)) == hipSuccess &&
+         hipMalloc((void **)&c->d_corners, (n / 9 + 16) * sizeof(StagCorner)) == hipSuccess &&
+         hipMalloc((void **)&c->d_order, (n / 9 + 16) * 4) == hipSuccess && hipMalloc((void **)&c->d_qcounts, (n / 8 + 16) * 4) == hipSuccess &&
+         hipMalloc((void **)&c->d_qtotal, 4) == hipSuccess && hipMalloc((void **)&c->d_qslots, (n / 9 + 16) * sizeof(fid_stag_quad)) == hipSuccess &&
+         hipMalloc((void **)&c->d_quads, (n / 9 + 16) * sizeof(fid_stag_quad)) == hipSuccess;
     if (ok) {
         double lut[1025];
         for (int i = 0; i <= 1024; i++) lut[i] = atan((double)i / 1024);
@@ -1449,7 +1795,8 @@ void fid_stag_destroy(fid_stag_ctx *c)
                    c->d_edgeimg, c->d_rpix, c->d_outpix, c->d_segs, c->d_rstack, c->d_chains, c->d_chainnos, c->d_rcount,
                    c->d_smooth2, c->d_vgrad, c->d_vhist, c->d_prob, c->d_np, c->d_vcounts, c->d_vtotal, c->d_vstack, c->d_vsegs,
                    c->d_prefix, c->d_lslots, c->d_lines, c->d_lcounts, c->d_ltotal,
-                   c->d_atan_lut, c->d_kmin, c->d_lflags, c->d_vltotal, c->d_vlines};
+                   c->d_atan_lut, c->d_kmin, c->d_lflags, c->d_vltotal, c->d_vlines,
+                   c->d_lrange, c->d_corners, c->d_order, c->d_qcounts, c->d_qtotal, c->d_qslots, c->d_quads};
     for (void *p : dev)
         if (p) (void)hipFree(p);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -1607,6 +1954,29 @@ fid_status fid_stag_detect_lines_validated(fid_stag_ctx *c, const uint8_t *gray,
     if (hipMemcpyAsync(&c->n_vlines, c->d_vltotal, 4, hipMemcpyDeviceToHost, st) != hipSuccess) return FID_E_HIP;
     if (hipStreamSynchronize(st) != hipSuccess) return FID_E_HIP;
     c->lines_validated = true;
+    c->quadded = false;
+    return FID_OK;
+}
+
+fid_status fid_stag_detect_quads(fid_stag_ctx *c, const uint8_t *gray, int32_t width, int32_t height, int32_t stride)
+{
+    fid_status rc = fid_stag_detect_lines_validated(c, gray, width, height, stride);
+    if (rc != FID_OK) return rc;
+    hipStream_t st = c->stream;
+    const int W = c->W, H = c->H, ns = c->n_vsegs, nl = c->n_vlines;
+    if (hipMemsetAsync(c->d_lrange, 0, (size_t)(ns + 1) * sizeof(int2), st) != hipSuccess) return FID_E_HIP;
+    if (nl > 0) hipLaunchKernelGGL(k_stag_line_ranges, dim3((nl + 255) / 256), dim3(256), 0, st, c->d_vlines, c->d_vltotal, c->d_lrange);
+    if (ns > 0)
+        hipLaunchKernelGGL(k_stag_quads, dim3((ns + 3) / 4), dim3(256), 0, st, c->d_vlines, c->d_lrange, c->d_vtotal, c->d_vsegs, c->d_outpix, c->d_src,
+                           W, H, c->d_corners, c->d_order, c->d_qslots, c->d_qcounts);
+    hipLaunchKernelGGL(k_stag_scan_counts, dim3(1), dim3(1024), 0, st, c->d_qcounts, c->d_vtotal, c->d_qtotal);
+    if (ns > 0)
+        hipLaunchKernelGGL(k_stag_gather_quads, dim3((ns + 63) / 64), dim3(64), 0, st, c->d_lrange, c->d_vtotal, c->d_qcounts, c->d_qtotal, c->d_qslots,
+                           c->d_quads);
+    if (hipGetLastError() != hipSuccess) return FID_E_HIP;
+    if (hipMemcpyAsync(&c->n_quads, c->d_qtotal, 4, hipMemcpyDeviceToHost, st) != hipSuccess) return FID_E_HIP;
+    if (hipStreamSynchronize(st) != hipSuccess) return FID_E_HIP;
+    c->quadded = true;
     return FID_OK;
 }
 
@@ -1629,6 +1999,7 @@ int64_t fid_stag_tap_bytes(fid_stag_ctx *c, fid_stag_tap which)
     case FID_STAG_TAP_VSEGMENTS: return c->validated ? (int64_t)c->n_vsegs * 8 : 0;
     case FID_STAG_TAP_LINES: return c->lined ? (int64_t)c->n_lines * (int64_t)sizeof(fid_stag_line) : 0;
     case FID_STAG_TAP_VLINES: return c->lines_validated ? (int64_t)c->n_vlines * (int64_t)sizeof(fid_stag_line) : 0;
+    case FID_STAG_TAP_QUADS: return c->quadded ? (int64_t)c->n_quads * (int64_t)sizeof(fid_stag_quad) : 0;
     }
     return 0;
 }
@@ -1655,6 +2026,7 @@ fid_status fid_stag_tap_read(fid_stag_ctx *c, fid_stag_tap which, void *dst, int
     case FID_STAG_TAP_VSEGMENTS: src = c->d_vsegs; break;
     case FID_STAG_TAP_LINES: src = c->d_lines; break;
     case FID_STAG_TAP_VLINES: src = c->d_vlines; break;
+    case FID_STAG_TAP_QUADS: src = c->d_quads; break;
     }
     if (!src) return FID_E_INVALID_ARG;
     if (hipSetDevice(c->device) != hipSuccess) return FID_E_HIP;

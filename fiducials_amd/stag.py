@@ -12,8 +12,9 @@ from . import _lib
 from ._lib import FidError
 
 (TAP_SMOOTH, TAP_GRAD, TAP_DIR, TAP_ANCHORS, TAP_SORTED, TAP_EDGEIMG, TAP_SEGMENTS, TAP_SEGPIX, TAP_SMOOTH2, TAP_VGRAD, TAP_VPROB,
- TAP_VSEGMENTS, TAP_LINES, TAP_VLINES) = range(14)
+ TAP_VSEGMENTS, TAP_LINES, TAP_VLINES, TAP_QUADS) = range(15)
 
+QUAD_DTYPE = np.dtype([("corners", "f8", (4, 2)), ("lineInf", "f8", (3,)), ("projectiveDistortion", "f8")])
 LINE_DTYPE = np.dtype([("a", "f8"), ("b", "f8"), ("sx", "f8"), ("sy", "f8"), ("ex", "f8"), ("ey", "f8"), ("invert", "i4"),
                        ("segmentNo", "i4"), ("firstPixelIndex", "i4"), ("len", "i4")])
 
@@ -59,6 +60,13 @@ class StagDetector:
         """DetectLinesByEDPF complete (EDInterface::runEDPFandEDLines); lines(validated=True) reads EDLines::lines."""
         self._run(self._L.fid_stag_detect_lines_validated, gray)
 
+    def detect_quads(self, gray: np.ndarray):
+        """QuadDetector::detectQuads; quads() reads the result (structured array, QUAD_DTYPE)."""
+        self._run(self._L.fid_stag_detect_quads, gray)
+
+    def quads(self) -> np.ndarray:
+        return self.tap(TAP_QUADS)
+
     def lines(self, validated: bool = False) -> np.ndarray:
         return self.tap(TAP_VLINES if validated else TAP_LINES)
 
@@ -94,6 +102,8 @@ class StagDetector:
             return buf.view(np.int16).reshape(h, w)
         if which == TAP_VPROB:
             return buf.view(np.float64)
+        if which == TAP_QUADS:
+            return buf.view(QUAD_DTYPE)
         if which in (TAP_LINES, TAP_VLINES):
             return buf.view(LINE_DTYPE)
         return buf.view(np.int32)

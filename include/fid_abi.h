@@ -203,6 +203,13 @@ typedef struct fid_stag_line {
     int32_t firstPixelIndex; /* first pixel of the line inside that segment */
     int32_t len;             /* pixels of the segment that make up the line */
 } fid_stag_line;
+/* Quad (stag_detect/include/stag/Quad.h:9-26) as QuadDetector::detectQuads leaves it: corners clockwise, the vanishing
+ * line and max / min corner distance to it */
+typedef struct fid_stag_quad {
+    double corners[8]; /* x0 y0 ... x3 y3 */
+    double lineInf[3];
+    double projectiveDistortion;
+} fid_stag_quad;
 fid_status fid_stag_create(int32_t libraryHD, int32_t errorCorrection, int32_t max_width, int32_t max_height, int32_t device,
                            fid_stag_ctx **out);
 void fid_stag_destroy(fid_stag_ctx *ctx);
@@ -220,6 +227,8 @@ fid_status fid_stag_detect_lines(fid_stag_ctx *ctx, const uint8_t *gray, int32_t
 /* DetectLinesByEDPF complete = what EDInterface::runEDPFandEDLines produces (EDInterface.cpp:13-19): the above +
  * ValidateLineSegments (ED/EDLines.cpp:274-409).  EdgeMap (SEGPIX, VSEGMENTS) and EDLines (VLINES) stay on the device. */
 fid_status fid_stag_detect_lines_validated(fid_stag_ctx *ctx, const uint8_t *gray, int32_t width, int32_t height, int32_t stride_bytes);
+/* QuadDetector::detectQuads (QuadDetector.cpp:12-66): the above + line groups, corner detection and quad formation */
+fid_status fid_stag_detect_quads(fid_stag_ctx *ctx, const uint8_t *gray, int32_t width, int32_t height, int32_t stride_bytes);
 typedef enum fid_stag_tap {
     FID_STAG_TAP_SMOOTH = 0,  /* uint8 [h][w] smoothed image */
     FID_STAG_TAP_GRAD = 1,    /* int16 [h][w] |gx| + |gy| (border: GRADIENT_THRESH - 1) */
@@ -238,7 +247,9 @@ typedef enum fid_stag_tap {
     /* after fid_stag_detect_lines: */
     FID_STAG_TAP_LINES = 12,     /* fid_stag_line [noLines] */
     /* after fid_stag_detect_lines_validated: */
-    FID_STAG_TAP_VLINES = 13     /* fid_stag_line [noLines]: EDLines::lines as DetectLinesByEDPF returns them */
+    FID_STAG_TAP_VLINES = 13,    /* fid_stag_line [noLines]: EDLines::lines as DetectLinesByEDPF returns them */
+    /* after fid_stag_detect_quads (VLINES then carry the corrected line directions): */
+    FID_STAG_TAP_QUADS = 14      /* fid_stag_quad [noQuads]: QuadDetector::getQuads() */
 } fid_stag_tap;
 int64_t fid_stag_tap_bytes(fid_stag_ctx *ctx, fid_stag_tap which);
 fid_status fid_stag_tap_read(fid_stag_ctx *ctx, fid_stag_tap which, void *dst, int64_t dst_bytes);

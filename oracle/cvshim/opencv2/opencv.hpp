@@ -1,0 +1,109 @@
+// opencv2/opencv.hpp -- TEST INFRASTRUCTURE ONLY.  A stand-in for the handful of OpenCV types the reference's STag sources
+// use outside the ED library (OpenCV itself is not installed in this image), so that oracle/Makefile can compile
+// stag_detect/src/stag/{Quad,QuadDetector,EDInterface,utility}.cpp where they lie and the parity tests can check the
+// device code against the reference's OWN logic.  What is here is data plumbing with one obvious meaning (points, a dense
+// row-major matrix, element access, the 3 x 3 / 3 x 1 double products of Quad.cpp, evaluated as a_i0 b_0j + a_i1 b_1j +
+// a_i2 b_2j left to right).  Anything with numerical content of its own (filters, thresholds, solvers) is NOT provided
+// here: callers of those are restated in oracle/stag_ref.cpp and say so.
+#ifndef FID_ORACLE_CVSHIM_OPENCV_HPP
+#define FID_ORACLE_CVSHIM_OPENCV_HPP
+// <stdlib.h> / <math.h> under their C names, as the real OpenCV headers pull them in (core/cv_cpu_dispatch.h ->
+// <emmintrin.h> -> <mm_malloc.h> -> <stdlib.h>; flann/lsh_table.h -> <math.h>): in C++ these are libstdc++'s wrappers, which
+// put std::abs(double) into the global namespace.  The reference calls unqualified abs() on doubles (Quad.cpp:135,
+// QuadDetector.cpp:118,162); without this it would bind to ::abs(int) here and truncate, unlike the real build.
+#include <stdlib.h>
+#include <math.h>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <vector>
+
+#define CV_8UC1 0
+#define CV_64FC1 6
+
+namespace cv {
+
+template <typename T>
+struct Point_ {
+    T x, y;
+    Point_() : x(0), y(0) {}
+    Point_(T x_, T y_) : x(x_), y(y_) {}
+};
+typedef Point_<int> Point2i;
+typedef Point_<int> Point;
+typedef Point_<float> Point2f;
+typedef Point_<double> Point2d;
+
+template <typename T>
+struct Point3_ {
+    T x, y, z;
+    Point3_() : x(0), y(0), z(0) {}
+    Point3_(T x_, T y_, T z_) : x(x_), y(y_), z(z_) {}
+};
+typedef Point3_<double> Point3d;
+
+struct Size {
+    int width, height;
+    Size() : width(0), height(0) {}
+    Size(int w, int h) : width(w), height(h) {}
+};
+
+class Mat {
+   public:
+    int rows, cols, type_;
+    unsigned char *data;
+    Mat() : rows(0), cols(0), type_(CV_8UC1), data(nullptr) {}
+    Mat(int r, int c, int type) : rows(r), cols(c), type_(type)
+    {
+        own_.reset(new std::vector<unsigned char>((size_t)r * c * esz(), 0));
+        data = own_->data();
+    }
+    Mat(int r, int c, int type, void *ext) : rows(r), cols(c), type_(type), data((unsigned char *)ext) {}
+    static Mat eye(int r, int c, int type)
+    {
+        Mat m(r, c, type);
+        for (int i = 0; i < r && i < c; i++) m.at<double>(i, i) = 1.0;
+        return m;
+    }
+    size_t esz() const { return type_ == CV_64FC1 ? 8 : 1; }
+    Size size() const { return Size(cols, rows); }
+    bool empty() const { return data == nullptr; }
+    template <typename T>
+    T &at(int i, int j) { return ((T *)data)[(size_t)i * cols + j]; }
+    template <typename T>
+    const T &at(int i, int j) const { return ((const T *)data)[(size_t)i * cols + j]; }
+    template <typename T>
+    T &at(int i) { return ((T *)data)[i]; }
+    template <typename T>
+    const T &at(int i) const { return ((const T *)data)[i]; }
+    template <typename T>
+    T *ptr(int r) { return (T *)data + (size_t)r * cols; }
+    template <typename T>
+    const T *ptr(int r) const { return (const T *)data + (size_t)r * cols; }
+    Mat clone() const
+    {
+        Mat m(rows, cols, type_);
+        if (data) memcpy(m.data, data, (size_t)rows * cols * esz());
+        return m;
+    }
+
+   private:
+    std::shared_ptr<std::vector<unsigned char>> own_;
+};
+
+// double matrices only (the 3 x 3 and 3 x 1 products of Quad.cpp / Stag.cpp)
+inline Mat operator*(const Mat &a, const Mat &b)
+{
+    Mat d(a.rows, b.cols, CV_64FC1);
+    for (int i = 0; i < a.rows; i++)
+        for (int j = 0; j < b.cols; j++) {
+            double s = a.at<double>(i, 0) * b.at<double>(0, j);
+            for (int k = 1; k < a.cols; k++) s += a.at<double>(i, k) * b.at<double>(k, j);
+            d.at<double>(i, j) = s;
+        }
+    return d;
+}
+
+}  // namespace cv
+#endif

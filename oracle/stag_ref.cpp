@@ -12,6 +12,8 @@
 //   ref_stag_validate   = ValidateEdgeSegments               stag_detect/src/stag/ED/ValidateEdgeSegments.cpp:365-413
 //   ref_stag_smooth3    = SmoothImage(sigma = 1 / 2.5) of ED.cpp:176-177, restated like ref_stag_smooth5 ("parity unpinned"):
 //                         cv::GaussianBlur(Size(0, 0), 0.4) -> ksize 3, 8.8 fixed-point kernel [10 236 10], one rounding
+//   ref_stag_detect_quads = QuadDetector::detectQuads           stag_detect/src/stag/QuadDetector.cpp:12-66 (with Quad.cpp,
+//                         EDInterface.cpp, utility.cpp compiled in place against oracle/cvshim: data types only)
 //   ref_stag_smooth5    = what SmoothImage(..., sigma = 1.0) asks OpenCV for (ImageSmooth.cpp:43-55:
 //                         cv::GaussianBlur(src, dst, Size(5, 5), 0, 0)) -- OpenCV is not installed here, so this one
 //                         function is a RESTATEMENT ("parity unpinned"): for CV_8U and ksize 5 / sigma 0 OpenCV uses the
@@ -32,6 +34,8 @@ void SplitSegment2Lines(double *x, double *y, int noPixels, int segmentNo, EDLin
 void JoinCollinearLines(EDLines *lines, double MAX_DISTANCE_BETWEEN_TWO_LINES, double MAX_ERROR);
 void ValidateLineSegments(EdgeMap *map, unsigned char *srcImg, EDLines *lines, EDLines *invalidLines);
 int ComputeMinLineLength(int width, int height);
+// compiled from the reference tree against oracle/cvshim (data types only): Quad.cpp QuadDetector.cpp EDInterface.cpp utility.cpp
+#include "stag/QuadDetector.h"
 
 static inline int reflect101(int p, int n)
 {
@@ -132,6 +136,31 @@ int ref_stag_detect_lines(const uint8_t *src, int w, int h, double *lines_out, i
     delete lines;
     delete map;
     return rc;
+}
+
+// QuadDetector::detectQuads (QuadDetector.cpp:12-66) end to end on a raw image (runs EDInterface::runEDPFandEDLines inside).
+// quads_out: double [cap][12] = 8 corner coordinates, lineInf (3), projectiveDistortion.
+int ref_stag_detect_quads(const uint8_t *src, int w, int h, double *quads_out, int cap, int *n_out, int *n_corner_groups)
+{
+    cv::Mat image(h, w, CV_8UC1, const_cast<uint8_t *>(src));
+    EDInterface edi;
+    QuadDetector qd(false);
+    qd.detectQuads(image, &edi);
+    const std::vector<Quad> &q = qd.getQuads();
+    for (size_t i = 0; i < q.size() && (int)i < cap; i++) {
+        double *o = quads_out + 12 * i;
+        for (int k = 0; k < 4; k++) {
+            o[2 * k] = q[i].corners[k].x;
+            o[2 * k + 1] = q[i].corners[k].y;
+        }
+        o[8] = q[i].lineInf.x; o[9] = q[i].lineInf.y; o[10] = q[i].lineInf.z;
+        o[11] = q[i].projectiveDistortion;
+    }
+    *n_out = (int)q.size();
+    *n_corner_groups = (int)qd.getCornerGroups().size();
+    delete edi.getEDLines();
+    delete edi.getEdgeMap();
+    return (int)q.size() <= cap ? 0 : 1;
 }
 
 int ref_stag_smooth5(const uint8_t *src, uint8_t *dst, int w, int h)

@@ -18,8 +18,8 @@ _LIB = None
 def build(force: bool = False) -> str | None:
     """Compile the reference sources where they lie (only where /root/reference is mounted).  Returns the .so path, or None
     when neither the reference tree nor a prebuilt library is available."""
-    src = os.path.join(_HERE, "stag_ref.cpp")
-    if os.path.isdir(REF_ROOT) and (force or not os.path.exists(SO) or os.path.getmtime(src) > os.path.getmtime(SO)):
+    srcs = [os.path.join(_HERE, "stag_ref.cpp"), os.path.join(_HERE, "cvshim", "opencv2", "opencv.hpp"), os.path.join(_HERE, "Makefile")]
+    if os.path.isdir(REF_ROOT) and (force or not os.path.exists(SO) or any(os.path.getmtime(f) > os.path.getmtime(SO) for f in srcs)):
         subprocess.check_call(["make", "-C", _HERE, "-s", "ref"])
     return SO if os.path.exists(SO) else None
 
@@ -168,3 +168,15 @@ def detect_lines(src: np.ndarray):
                                      pix.ctypes.data_as(C.c_void_p), len(pix), C.byref(npx))
     assert rc == 0
     return out[:n.value].copy(), seg[:ns.value].copy(), pix[:npx.value].copy()
+
+
+def detect_quads(src: np.ndarray):
+    """The reference's QuadDetector::detectQuads end to end.  Returns (quads float64 [n][12], number of corner groups)."""
+    im = np.ascontiguousarray(src, dtype=np.uint8)
+    h, w = im.shape
+    out = np.zeros((4096, 12), np.float64)
+    n, ng = C.c_int(0), C.c_int(0)
+    rc = lib().ref_stag_detect_quads(im.ctypes.data_as(C.c_void_p), w, h, out.ctypes.data_as(C.c_void_p), len(out), C.byref(n),
+                                     C.byref(ng))
+    assert rc == 0
+    return out[:n.value].copy(), ng.value

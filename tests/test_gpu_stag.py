@@ -240,6 +240,69 @@ def test_detect_lines_end_to_end_matches_reference(case):
         det.close()
 
 
+def _tilted_markers(w, h, seed, n=10):
+    """Dark quadrilaterals (rotated, perspective-like) with a white disc inside, one per cell of a grid, on a light noisy
+    background."""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    img = 190 + 20 * np.sin(xx / 131.0) + rng.normal(0, 2, (h, w))
+    gx = int(np.ceil(np.sqrt(n * w / h)))
+    gy = int(np.ceil(n / gx))
+    cw, chh = w / gx, h / gy
+    for k in range(n):
+        s = rng.uniform(0.2, 0.3) * min(cw, chh)
+        cx, cy = (k % gx + 0.5) * cw + rng.uniform(-0.1, 0.1) * cw, (k // gx + 0.5) * chh + rng.uniform(-0.1, 0.1) * chh
+        ang = rng.uniform(0, 2 * np.pi)
+        base = np.array([[-1, -1], [1, -1], [1, 1], [-1, 1]], float) * s
+        base += rng.uniform(-0.12, 0.12, (4, 2)) * s  # perspective-like distortion
+        R = np.array([[np.cos(ang), -np.sin(ang)], [np.sin(ang), np.cos(ang)]])
+        P = base @ R.T + [cx, cy]
+        inside = np.ones((h, w), bool)
+        for i in range(4):
+            a, b = P[i], P[(i + 1) % 4]
+            inside &= (b[0] - a[0]) * (yy - a[1]) - (b[1] - a[1]) * (xx - a[0]) >= 0
+        img[inside] = 30
+        img[(xx - cx) ** 2 + (yy - cy) ** 2 < (0.4 * s) ** 2] = 225
+    k3 = np.array([1, 2, 1], float) / 4
+    img = np.apply_along_axis(lambda v: np.convolve(v, k3, mode="same"), 0, img)
+    img = np.apply_along_axis(lambda v: np.convolve(v, k3, mode="same"), 1, img)
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+QUAD_CASES = dict(VALID_CASES)
+QUAD_CASES["tilted_640"] = lambda: _tilted_markers(640, 480, 31)
+QUAD_CASES["tilted_1080p"] = lambda: _tilted_markers(1920, 1080, 32, n=20)
+QUAD_CASES["tilted_small"] = lambda: _tilted_markers(320, 240, 33, n=4)
+QUAD_CASES["tilted_many"] = lambda: _tilted_markers(1280, 960, 34, n=48)
+
+
+def _quads_as_table(Q):
+    if not len(Q):
+        return np.zeros((0, 12))
+    return np.concatenate([Q["corners"].reshape(-1, 8), Q["lineInf"], Q["projectiveDistortion"][:, None]], axis=1)
+
+
+@pytest.mark.parametrize("case", sorted(QUAD_CASES))
+def test_quads_match_reference_code(case):
+    """Row s7: QuadDetector::detectQuads from the raw image, against the reference's own QuadDetector / Quad / EDInterface
+    sources compiled in place (oracle/cvshim supplies the cv:: data types only): corners, vanishing line and projective
+    distortion of every quad, doubles compared with ==."""
+    if not stag_ref.available():
+        pytest.skip("oracle/_ref/libstag_ref.so not built (needs /root/reference at build time)")
+    img = QUAD_CASES[case]()
+    det = fstag.StagDetector(21, 7, max_width=1920, max_height=1080)
+    try:
+        det.detect_quads(img)
+        ref, _ = stag_ref.detect_quads(img)
+        got = _quads_as_table(det.quads())
+        assert got.shape == ref.shape, (got.shape, ref.shape)
+        assert (got == ref).all(), (got[~(got == ref).all(axis=1)][:2], ref[~(got == ref).all(axis=1)][:2])
+        if case.startswith(("tilted", "markers_6", "markers_1")):
+            assert len(ref) > 0
+    finally:
+        det.close()
+
+
 def test_stag_status_codes():
     from fiducials_amd import _lib
     from fiducials_amd._lib import FidError

@@ -1596,6 +1596,156 @@ __global__ __launch_bounds__(64) void k_stag_gather_quads(const int2 *__restrict
     for (int j = 0; j < n; j++) out[o + j] = Q[j];
 }
 
+// ------------------------------------------------------------------------------------------------ K15: decoding
+// The loop of Stag::detectMarkers (Stag.cpp:36-48) per quad: Quad::estimateHomography (Quad.cpp:14-53), Stag::readCode
+// (Stag.cpp:89-127: 48 code + 12 black + 12 white sample points through H, readPixelSafeBilinear utility.cpp:20-55 --
+// weights are the DISTANCES to the four neighbours, as in the reference --, Otsu over the 72 readings, dark = 1),
+// Decoder::decode (Decoder.cpp:45-56: first codeword within errorCorrection bits; id = i % n, shift = i / n),
+// Marker::shiftCorners2 (Marker.cpp:27-52).  One wave per quad: a lane per sample point, the codeword search spread over
+// the lanes.  Stag::checkDuplicate (Stag.cpp:57-72) then runs over the decoded quads in order (k_stag_dedup).
+// The 72 sample points are made on the host with its libm, exactly as Stag::fillCodeLocations (Stag.cpp:129-277) does.
+__device__ void sd_homography(const double cor[8], const double li[3], double H[9], double cen[2])
+{
+    double ax[4], ay[4];
+    for (int i = 0; i < 4; i++) {
+        ax[i] = cor[2 * i] / (li[0] * cor[2 * i] + li[1] * cor[2 * i + 1] + li[2]);
+        ay[i] = cor[2 * i + 1] / (li[0] * cor[2 * i] + li[1] * cor[2 * i + 1] + li[2]);
+    }
+    double A[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, B[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    A[6] = -li[0] / li[2];
+    A[7] = -li[1] / li[2];
+    A[8] = 1 / li[2];
+    B[0] = ax[1] - ax[0]; B[1] = ax[3] - ax[0]; B[2] = ax[0];
+    B[3] = ay[1] - ay[0]; B[4] = ay[3] - ay[0]; B[5] = ay[0];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) H[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
+    const double c0 = H[0] * 0.5 + H[1] * 0.5 + H[2] * 1, c1 = H[3] * 0.5 + H[4] * 0.5 + H[5] * 1, c2 = H[6] * 0.5 + H[7] * 0.5 + H[8] * 1;
+    cen[0] = c0 / c2;
+    cen[1] = c1 / c2;
+}
+
+__device__ int sd_read_bilinear(const uint8_t *__restrict__ img, int W, int H, double px, double py)
+{
+    if (!(px >= 0 && px <= W - 1 && py >= 0 && py <= H - 1)) return 128;
+    const int x1 = (int)floor(px), x2 = (int)ceil(px), y1 = (int)floor(py), y2 = (int)ceil(py);
+    const double d1 = sqrt((x1 - px) * (x1 - px) + (y1 - py) * (y1 - py)), d2 = sqrt((x1 - px) * (x1 - px) + (y2 - py) * (y2 - py));
+    const double d3 = sqrt((x2 - px) * (x2 - px) + (y1 - py) * (y1 - py)), d4 = sqrt((x2 - px) * (x2 - px) + (y2 - py) * (y2 - py));
+    const double tot = d1 + d2 + d3 + d4;
+    double acc = 0;
+    acc += img[y1 * W + x1] * d1;
+    acc += img[y2 * W + x1] * d2;
+    acc += img[y1 * W + x2] * d3;
+    acc += img[y2 * W + x2] * d4;
+    if (tot == 0) return 0;  // a point on the pixel grid: 0 / 0 in the reference, which x86 converts to 0
+    return (int)(acc / tot);
+}
+
+__global__ __launch_bounds__(256) void k_stag_decode(const fid_stag_quad *__restrict__ quads, const int *__restrict__ nquads,
+                                                     const uint8_t *__restrict__ img, int W, int H, const double *__restrict__ locs /* [72][3] */,
+                                                     const unsigned long long *__restrict__ words, int nwords, int err_corr,
+                                                     fid_stag_marker *__restrict__ cand, int *__restrict__ found)
+{
+    __shared__ int s_hist[4][256];
+    const int wq = threadIdx.x >> 6, q = blockIdx.x * 4 + wq, lane = threadIdx.x & 63;
+    if (q >= *nquads) return;
+    const fid_stag_quad Q = quads[q];
+    double Hm[9], cen[2];
+    sd_homography(Q.corners, Q.lineInf, Hm, cen);
+    int *hist = s_hist[wq];
+    for (int i = lane; i < 256; i += 64) hist[i] = 0;
+    __builtin_amdgcn_wave_barrier();
+    int smp[2] = {0, 0};
+    for (int k = 0; k < 2; k++) {
+        const int i = lane + 64 * k;
+        if (i < 72) {
+            const double *L = locs + 3 * i;
+            const double p0 = Hm[0] * L[0] + Hm[1] * L[1] + Hm[2] * L[2], p1 = Hm[3] * L[0] + Hm[4] * L[1] + Hm[5] * L[2];
+            const double p2 = Hm[6] * L[0] + Hm[7] * L[1] + Hm[8] * L[2];
+            smp[k] = sd_read_bilinear(img, W, H, p0 / p2, p1 / p2) & 255;
+            atomicAdd(&hist[smp[k]], 1);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // Otsu threshold of the 72 readings (cv::threshold THRESH_OTSU: getThreshVal_Otsu_8u, the histogram form)
+    int thr;
+    {
+        const double scale = 1. / 72;
+        double mu = 0;
+        for (int i = 0; i < 256; i++) mu += i * (double)hist[i];
+        mu *= scale;
+        double mu1 = 0, q1 = 0, max_sigma = 0;
+        int max_val = 0;
+        for (int i = 0; i < 256; i++) {
+            const double p_i = hist[i] * scale;
+            mu1 *= q1;
+            q1 += p_i;
+            const double q2 = 1. - q1;
+            if (fmin(q1, q2) < 1.1920928955078125e-07 || fmax(q1, q2) > 1. - 1.1920928955078125e-07) continue;
+            mu1 = (mu1 + i * p_i) / q1;
+            const double mu2 = (mu - q1 * mu1) / q2;
+            const double sigma = q1 * q2 * (mu1 - mu2) * (mu1 - mu2);
+            if (sigma > max_sigma) {
+                max_sigma = sigma;
+                max_val = i;
+            }
+        }
+        thr = max_val;
+    }
+    // THRESH_BINARY_INV: readings above the threshold -> 0, the others -> 255 -> bit 1
+    const unsigned long long code = __ballot(lane < 48 && smp[0] <= thr);
+    // Decoder::decode: the first codeword within err_corr bits
+    int hit = -1;
+    for (int base = 0; base < nwords && hit < 0; base += 64) {
+        const int i = base + lane;
+        const bool ok = i < nwords && __builtin_popcountll(code ^ words[i]) <= err_corr;
+        const unsigned long long m = __ballot(ok);
+        if (m) hit = base + __builtin_ctzll(m);
+    }
+    if (lane != 0) return;
+    found[q] = hit >= 0 ? 1 : 0;
+    if (hit < 0) return;
+    const int n = nwords / 4, id = hit % n, shift = hit / n;
+    fid_stag_marker M;
+    M.id = id;
+    M.shift = shift;
+    for (int k = 0; k < 4; k++) {  // shiftCorners2: corner k <- corner (k + shift) % 4
+        M.corners[2 * k] = Q.corners[2 * ((k + shift) & 3)];
+        M.corners[2 * k + 1] = Q.corners[2 * ((k + shift) & 3) + 1];
+    }
+    for (int k = 0; k < 3; k++) M.lineInf[k] = Q.lineInf[k];
+    M.projectiveDistortion = Q.projectiveDistortion;
+    if (shift >= 1 && shift <= 3) sd_homography(M.corners, M.lineInf, M.H, M.center);
+    else {
+        for (int k = 0; k < 9; k++) M.H[k] = Hm[k];
+        M.center[0] = cen[0];
+        M.center[1] = cen[1];
+    }
+    M.code = code;
+    cand[q] = M;
+}
+
+// Stag::checkDuplicate over the decoded quads in quad order: one marker per id, the least distorted one, at the position of
+// the first quad that showed the id
+__global__ __launch_bounds__(64) void k_stag_dedup(const fid_stag_marker *__restrict__ cand, const int *__restrict__ found, const int *__restrict__ nquads,
+                                                   fid_stag_marker *__restrict__ out, int *__restrict__ nout)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int n = *nquads;
+    int m = 0;
+    for (int q = 0; q < n; q++) {
+        if (!found[q]) continue;
+        bool notFound = true;
+        for (int k = 0; k < m; k++) {
+            if (out[k].id == cand[q].id) {
+                notFound = false;
+                if (cand[q].projectiveDistortion < out[k].projectiveDistortion) out[k] = cand[q];
+            }
+        }
+        if (notFound) out[m++] = cand[q];
+    }
+    *nout = m;
+}
+
 // ------------------------------------------------------------------------------------------------ C-ABI
 // ---- host side of the line validation: the number-of-false-alarms table.  nfa() restates NFA.cpp:155-239 (the LSD
 // binomial-tail bound: log-gamma by Windschitl / Lanczos, series with a 10 % truncation tolerance); the table is what
@@ -1673,6 +1823,43 @@ static void stag_build_kmin(int W, int H, std::vector<int> &kmin)
     }
 }
 
+// Stag::fillCodeLocations (Stag.cpp:129-277) + createMatFromPolarCoords (:279-286): the 48 code points on three rings inside
+// the circle, 12 points on the black border, 12 outside it, in marker coordinates [0, 1]^2, homogeneous.
+static void stag_fill_code_locations(double *locs /* [72][3] */)
+{
+    const double HALF_PI = 1.570796326794897;
+    const double outerCircleRadius = 0.4;
+    const double innerCircleRadius = outerCircleRadius * 0.9;
+    auto polar = [&](int idx, double radius, double radians) {
+        locs[3 * idx + 0] = 0.5 + cos(radians) * radius * (innerCircleRadius / 0.5);
+        locs[3 * idx + 1] = 0.5 - sin(radians) * radius * (innerCircleRadius / 0.5);
+        locs[3 * idx + 2] = 1;
+    };
+    for (int i = 0; i < 4; i++) {
+        polar(0 + i * 12, 0.088363142525988, 0.785398163397448 + i * HALF_PI);
+        polar(1 + i * 12, 0.206935928182607, 0.459275804122858 + i * HALF_PI);
+        polar(2 + i * 12, 0.206935928182607, HALF_PI - 0.459275804122858 + i * HALF_PI);
+        polar(3 + i * 12, 0.313672146827381, 0.200579720495241 + i * HALF_PI);
+        polar(4 + i * 12, 0.327493143484516, 0.591687617505840 + i * HALF_PI);
+        polar(5 + i * 12, 0.327493143484516, HALF_PI - 0.591687617505840 + i * HALF_PI);
+        polar(6 + i * 12, 0.313672146827381, HALF_PI - 0.200579720495241 + i * HALF_PI);
+        polar(7 + i * 12, 0.437421957035861, 0.145724938287167 + i * HALF_PI);
+        polar(8 + i * 12, 0.437226762361658, 0.433363129825345 + i * HALF_PI);
+        polar(9 + i * 12, 0.430628029742607, 0.785398163397448 + i * HALF_PI);
+        polar(10 + i * 12, 0.437226762361658, HALF_PI - 0.433363129825345 + i * HALF_PI);
+        polar(11 + i * 12, 0.437421957035861, HALF_PI - 0.145724938287167 + i * HALF_PI);
+    }
+    const double b = 0.045;  // borderDist
+    const double black[12][2] = {{b, b * 3}, {b * 2, b * 2}, {b * 3, b}, {1 - 3 * b, b}, {1 - 2 * b, b * 2}, {1 - b, b * 3},
+                                 {1 - b, 1 - 3 * b}, {1 - 2 * b, 1 - 2 * b}, {1 - 3 * b, 1 - b}, {b * 3, 1 - b}, {b * 2, 1 - 2 * b}, {b, 1 - 3 * b}};
+    const double white[12][2] = {{0.25, -b}, {0.5, -b}, {0.75, -b}, {1 + b, 0.25}, {1 + b, 0.5}, {1 + b, 0.75},
+                                 {0.75, 1 + b}, {0.5, 1 + b}, {0.25, 1 + b}, {-b, 0.75}, {-b, 0.5}, {-b, 0.25}};
+    for (int i = 0; i < 12; i++) {
+        locs[3 * (48 + i) + 0] = black[i][0]; locs[3 * (48 + i) + 1] = black[i][1]; locs[3 * (48 + i) + 2] = 1;
+        locs[3 * (60 + i) + 0] = white[i][0]; locs[3 * (60 + i) + 1] = white[i][1]; locs[3 * (60 + i) + 2] = 1;
+    }
+}
+
 struct fid_stag_ctx {
     int device = 0, maxW = 0, maxH = 0, libraryHD = 0, errorCorrection = 0;
     hipStream_t stream = nullptr;
@@ -1716,6 +1903,14 @@ struct fid_stag_ctx {
     fid_stag_quad *d_qslots = nullptr, *d_quads = nullptr;
     int n_quads = 0;
     bool quadded = false;
+    // decoding
+    double *d_locs = nullptr;
+    unsigned long long *d_words = nullptr;
+    int n_words = 0;
+    fid_stag_marker *d_cand = nullptr, *d_markers = nullptr;
+    int *d_found = nullptr, *d_nmarkers = nullptr;
+    int n_markers = 0;
+    bool decoded = false;
     int W = 0, H = 0;
     unsigned n_anchors = 0;
 };
@@ -1773,6 +1968,14 @@ fid_status fid_stag_create(int libraryHD, int errorCorrection, int max_width, in
          hipMalloc((void **)&c->d_order, (n / 9 + 16) * 4) == hipSuccess && hipMalloc((void **)&c->d_qcounts, (n / 8 + 16) * 4) == hipSuccess &&
          hipMalloc((void **)&c->d_qtotal, 4) == hipSuccess && hipMalloc((void **)&c->d_qslots, (n / 9 + 16) * sizeof(fid_stag_quad)) == hipSuccess &&
          hipMalloc((void **)&c->d_quads, (n / 9 + 16) * sizeof(fid_stag_quad)) == hipSuccess;
+    ok = ok && hipMalloc((void **)&c->d_locs, 72 * 3 * 8) == hipSuccess && hipMalloc((void **)&c->d_cand, (n / 9 + 16) * sizeof(fid_stag_marker)) == hipSuccess &&
+         hipMalloc((void **)&c->d_markers, (n / 9 + 16) * sizeof(fid_stag_marker)) == hipSuccess &&
+         hipMalloc((void **)&c->d_found, (n / 9 + 16) * 4) == hipSuccess && hipMalloc((void **)&c->d_nmarkers, 4) == hipSuccess;
+    if (ok) {
+        double locs[72 * 3];
+        stag_fill_code_locations(locs);
+        ok = hipMemcpy(c->d_locs, locs, sizeof(locs), hipMemcpyHostToDevice) == hipSuccess;
+    }
     if (ok) {
         double lut[1025];
         for (int i = 0; i <= 1024; i++) lut[i] = atan((double)i / 1024);
@@ -1796,7 +1999,8 @@ void fid_stag_destroy(fid_stag_ctx *c)
                    c->d_smooth2, c->d_vgrad, c->d_vhist, c->d_prob, c->d_np, c->d_vcounts, c->d_vtotal, c->d_vstack, c->d_vsegs,
                    c->d_prefix, c->d_lslots, c->d_lines, c->d_lcounts, c->d_ltotal,
                    c->d_atan_lut, c->d_kmin, c->d_lflags, c->d_vltotal, c->d_vlines,
-                   c->d_lrange, c->d_corners, c->d_order, c->d_qcounts, c->d_qtotal, c->d_qslots, c->d_quads};
+                   c->d_lrange, c->d_corners, c->d_order, c->d_qcounts, c->d_qtotal, c->d_qslots, c->d_quads,
+                   c->d_locs, c->d_words, c->d_cand, c->d_markers, c->d_found, c->d_nmarkers};
     for (void *p : dev)
         if (p) (void)hipFree(p);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -1977,6 +2181,38 @@ fid_status fid_stag_detect_quads(fid_stag_ctx *c, const uint8_t *gray, int32_t w
     if (hipMemcpyAsync(&c->n_quads, c->d_qtotal, 4, hipMemcpyDeviceToHost, st) != hipSuccess) return FID_E_HIP;
     if (hipStreamSynchronize(st) != hipSuccess) return FID_E_HIP;
     c->quadded = true;
+    c->decoded = false;
+    return FID_OK;
+}
+
+fid_status fid_stag_load_library(fid_stag_ctx *c, const uint64_t *codewords, int32_t n_codewords)
+{
+    if (!c || !codewords || n_codewords <= 0 || (n_codewords & 3)) return FID_E_INVALID_ARG;
+    if (hipSetDevice(c->device) != hipSuccess) return FID_E_HIP;
+    if (c->d_words) (void)hipFree(c->d_words);
+    c->d_words = nullptr;
+    c->n_words = 0;
+    if (hipMalloc((void **)&c->d_words, (size_t)n_codewords * 8) != hipSuccess) return FID_E_OUT_OF_MEMORY;
+    if (hipMemcpy(c->d_words, codewords, (size_t)n_codewords * 8, hipMemcpyHostToDevice) != hipSuccess) return FID_E_HIP;
+    c->n_words = n_codewords;
+    return FID_OK;
+}
+
+fid_status fid_stag_detect_markers_unrefined(fid_stag_ctx *c, const uint8_t *gray, int32_t width, int32_t height, int32_t stride)
+{
+    if (!c || !c->d_words) return FID_E_INVALID_ARG;  // no marker library loaded
+    fid_status rc = fid_stag_detect_quads(c, gray, width, height, stride);
+    if (rc != FID_OK) return rc;
+    hipStream_t st = c->stream;
+    const int nq = c->n_quads;
+    if (nq > 0)
+        hipLaunchKernelGGL(k_stag_decode, dim3((nq + 3) / 4), dim3(256), 0, st, c->d_quads, c->d_qtotal, c->d_src, c->W, c->H, c->d_locs, c->d_words,
+                           c->n_words, c->errorCorrection, c->d_cand, c->d_found);
+    hipLaunchKernelGGL(k_stag_dedup, dim3(1), dim3(64), 0, st, c->d_cand, c->d_found, c->d_qtotal, c->d_markers, c->d_nmarkers);
+    if (hipGetLastError() != hipSuccess) return FID_E_HIP;
+    if (hipMemcpyAsync(&c->n_markers, c->d_nmarkers, 4, hipMemcpyDeviceToHost, st) != hipSuccess) return FID_E_HIP;
+    if (hipStreamSynchronize(st) != hipSuccess) return FID_E_HIP;
+    c->decoded = true;
     return FID_OK;
 }
 
@@ -2000,6 +2236,7 @@ int64_t fid_stag_tap_bytes(fid_stag_ctx *c, fid_stag_tap which)
     case FID_STAG_TAP_LINES: return c->lined ? (int64_t)c->n_lines * (int64_t)sizeof(fid_stag_line) : 0;
     case FID_STAG_TAP_VLINES: return c->lines_validated ? (int64_t)c->n_vlines * (int64_t)sizeof(fid_stag_line) : 0;
     case FID_STAG_TAP_QUADS: return c->quadded ? (int64_t)c->n_quads * (int64_t)sizeof(fid_stag_quad) : 0;
+    case FID_STAG_TAP_MARKERS: return c->decoded ? (int64_t)c->n_markers * (int64_t)sizeof(fid_stag_marker) : 0;
     }
     return 0;
 }
@@ -2027,6 +2264,7 @@ fid_status fid_stag_tap_read(fid_stag_ctx *c, fid_stag_tap which, void *dst, int
     case FID_STAG_TAP_LINES: src = c->d_lines; break;
     case FID_STAG_TAP_VLINES: src = c->d_vlines; break;
     case FID_STAG_TAP_QUADS: src = c->d_quads; break;
+    case FID_STAG_TAP_MARKERS: src = c->d_markers; break;
     }
     if (!src) return FID_E_INVALID_ARG;
     if (hipSetDevice(c->device) != hipSuccess) return FID_E_HIP;

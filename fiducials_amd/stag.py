@@ -12,11 +12,25 @@ from . import _lib
 from ._lib import FidError
 
 (TAP_SMOOTH, TAP_GRAD, TAP_DIR, TAP_ANCHORS, TAP_SORTED, TAP_EDGEIMG, TAP_SEGMENTS, TAP_SEGPIX, TAP_SMOOTH2, TAP_VGRAD, TAP_VPROB,
- TAP_VSEGMENTS, TAP_LINES, TAP_VLINES, TAP_QUADS) = range(15)
+ TAP_VSEGMENTS, TAP_LINES, TAP_VLINES, TAP_QUADS, TAP_MARKERS) = range(16)
 
+MARKER_DTYPE = np.dtype([("id", "i4"), ("shift", "i4"), ("corners", "f8", (4, 2)), ("center", "f8", (2,)), ("H", "f8", (3, 3)),
+                         ("lineInf", "f8", (3,)), ("projectiveDistortion", "f8"), ("code", "u8")])
 QUAD_DTYPE = np.dtype([("corners", "f8", (4, 2)), ("lineInf", "f8", (3,)), ("projectiveDistortion", "f8")])
 LINE_DTYPE = np.dtype([("a", "f8"), ("b", "f8"), ("sx", "f8"), ("sy", "f8"), ("ex", "f8"), ("ey", "f8"), ("invert", "i4"),
                        ("segmentNo", "i4"), ("firstPixelIndex", "i4"), ("len", "i4")])
+
+
+def load_library(hd: int) -> np.ndarray:
+    """The codewords of marker library HD<hd> (uint64, four rotations x markers): the published STag tables, extracted by
+    tools/make_stag_libraries.py into fiducials_amd/data/stag_libraries.npz."""
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "stag_libraries.npz")
+    with np.load(path) as z:
+        key = f"HD{hd}"
+        if key not in z:
+            raise FidError(_lib.FID_E_INVALID_ARG, "Invalid library HD. Possible values are 11, 13, 15, 17, 19, 21, or 23")
+        return np.ascontiguousarray(z[key], dtype=np.uint64)
 
 
 class StagDetector:
@@ -28,6 +42,10 @@ class StagDetector:
         if rc != _lib.FID_OK:
             raise FidError(rc, self._L.fid_strerror(rc).decode())
         self.shape = None
+        self._words = load_library(libraryHD)  # Decoder::Decoder(libraryHD)
+        rc = self._L.fid_stag_load_library(self._ctx, self._words.ctypes.data, len(self._words))
+        if rc != _lib.FID_OK:
+            raise FidError(rc, self._L.fid_strerror(rc).decode())
 
     def close(self):
         if getattr(self, "_ctx", None) is not None and self._ctx.value:
@@ -63,6 +81,13 @@ class StagDetector:
     def detect_quads(self, gray: np.ndarray):
         """QuadDetector::detectQuads; quads() reads the result (structured array, QUAD_DTYPE)."""
         self._run(self._L.fid_stag_detect_quads, gray)
+
+    def detect_markers_unrefined(self, gray: np.ndarray):
+        """Stag::detectMarkers without the final pose refinement; markers() reads the result (MARKER_DTYPE)."""
+        self._run(self._L.fid_stag_detect_markers_unrefined, gray)
+
+    def markers(self) -> np.ndarray:
+        return self.tap(TAP_MARKERS)
 
     def quads(self) -> np.ndarray:
         return self.tap(TAP_QUADS)
@@ -102,6 +127,8 @@ class StagDetector:
             return buf.view(np.int16).reshape(h, w)
         if which == TAP_VPROB:
             return buf.view(np.float64)
+        if which == TAP_MARKERS:
+            return buf.view(MARKER_DTYPE)
         if which == TAP_QUADS:
             return buf.view(QUAD_DTYPE)
         if which in (TAP_LINES, TAP_VLINES):

@@ -210,6 +210,17 @@ typedef struct fid_stag_quad {
     double lineInf[3];
     double projectiveDistortion;
 } fid_stag_quad;
+/* Marker (stag_detect/include/stag/Marker.h:6-15) = Quad + id, after Marker::shiftCorners2 */
+typedef struct fid_stag_marker {
+    int32_t id;
+    int32_t shift;      /* rotation the decoder found (corners are already shifted by it) */
+    double corners[8];  /* x0 y0 ... x3 y3, clockwise from the marker's first corner */
+    double center[2];
+    double H[9];        /* unit square -> image, row-major */
+    double lineInf[3];
+    double projectiveDistortion;
+    uint64_t code;      /* the 48 bits read (Stag::readCode) */
+} fid_stag_marker;
 fid_status fid_stag_create(int32_t libraryHD, int32_t errorCorrection, int32_t max_width, int32_t max_height, int32_t device,
                            fid_stag_ctx **out);
 void fid_stag_destroy(fid_stag_ctx *ctx);
@@ -229,6 +240,13 @@ fid_status fid_stag_detect_lines(fid_stag_ctx *ctx, const uint8_t *gray, int32_t
 fid_status fid_stag_detect_lines_validated(fid_stag_ctx *ctx, const uint8_t *gray, int32_t width, int32_t height, int32_t stride_bytes);
 /* QuadDetector::detectQuads (QuadDetector.cpp:12-66): the above + line groups, corner detection and quad formation */
 fid_status fid_stag_detect_quads(fid_stag_ctx *ctx, const uint8_t *gray, int32_t width, int32_t height, int32_t stride_bytes);
+/* the marker library of Decoder::Decoder(hd) (Decoder.cpp:14-43): n_codewords = 4 x number of markers, the four rotations
+ * of every marker one block after the other, 48 bits each (the HDxx arrays of stag/MarkerIDs.h; fiducials_amd/data/
+ * stag_libraries.npz holds them for the Python host side) */
+fid_status fid_stag_load_library(fid_stag_ctx *ctx, const uint64_t *codewords, int32_t n_codewords);
+/* Stag::detectMarkers (Stag.cpp:24-51) up to, not including, PoseRefiner::refineMarkerPose: homography, code reading,
+ * decoding with the context's errorCorrection, corner shift, duplicate removal */
+fid_status fid_stag_detect_markers_unrefined(fid_stag_ctx *ctx, const uint8_t *gray, int32_t width, int32_t height, int32_t stride_bytes);
 typedef enum fid_stag_tap {
     FID_STAG_TAP_SMOOTH = 0,  /* uint8 [h][w] smoothed image */
     FID_STAG_TAP_GRAD = 1,    /* int16 [h][w] |gx| + |gy| (border: GRADIENT_THRESH - 1) */
@@ -249,7 +267,9 @@ typedef enum fid_stag_tap {
     /* after fid_stag_detect_lines_validated: */
     FID_STAG_TAP_VLINES = 13,    /* fid_stag_line [noLines]: EDLines::lines as DetectLinesByEDPF returns them */
     /* after fid_stag_detect_quads (VLINES then carry the corrected line directions): */
-    FID_STAG_TAP_QUADS = 14      /* fid_stag_quad [noQuads]: QuadDetector::getQuads() */
+    FID_STAG_TAP_QUADS = 14,     /* fid_stag_quad [noQuads]: QuadDetector::getQuads() */
+    /* after fid_stag_detect_markers_unrefined: */
+    FID_STAG_TAP_MARKERS = 15    /* fid_stag_marker [n]: Stag::markers before PoseRefiner::refineMarkerPose */
 } fid_stag_tap;
 int64_t fid_stag_tap_bytes(fid_stag_ctx *ctx, fid_stag_tap which);
 fid_status fid_stag_tap_read(fid_stag_ctx *ctx, fid_stag_tap which, void *dst, int64_t dst_bytes);

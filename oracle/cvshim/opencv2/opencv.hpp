@@ -92,6 +92,16 @@ class Mat {
     std::shared_ptr<std::vector<unsigned char>> own_;
 };
 
+struct Scalar {
+    double val[4];
+    Scalar(double a = 0, double b = 0, double c = 0, double d = 0) { val[0] = a; val[1] = b; val[2] = c; val[3] = d; }
+};
+
+// DECLARED only: the one cv:: call of Stag::readCode (Stag.cpp:119).  Its body has numerical content (Otsu's threshold) and
+// is therefore a restatement, kept with the other restatements in oracle/stag_ref.cpp.
+enum { THRESH_BINARY_INV = 1, THRESH_OTSU = 8 };
+double threshold(std::vector<unsigned char> &src, std::vector<unsigned char> &dst, double thresh, double maxval, int type);
+
 // double matrices only (the 3 x 3 and 3 x 1 products of Quad.cpp / Stag.cpp)
 inline Mat operator*(const Mat &a, const Mat &b)
 {

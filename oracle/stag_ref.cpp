@@ -14,13 +14,17 @@
 //                         cv::GaussianBlur(Size(0, 0), 0.4) -> ksize 3, 8.8 fixed-point kernel [10 236 10], one rounding
 //   ref_stag_detect_quads = QuadDetector::detectQuads           stag_detect/src/stag/QuadDetector.cpp:12-66 (with Quad.cpp,
 //                         EDInterface.cpp, utility.cpp compiled in place against oracle/cvshim: data types only)
+//   ref_stag_detect_markers = Stag::detectMarkers               stag_detect/src/stag/Stag.cpp:24-51 (Stag.cpp, Decoder.cpp,
+//                         Marker.cpp compiled in place; cv::threshold(OTSU) restated below; PoseRefiner stubbed until row s9)
 //   ref_stag_smooth5    = what SmoothImage(..., sigma = 1.0) asks OpenCV for (ImageSmooth.cpp:43-55:
 //                         cv::GaussianBlur(src, dst, Size(5, 5), 0, 0)) -- OpenCV is not installed here, so this one
 //                         function is a RESTATEMENT ("parity unpinned"): for CV_8U and ksize 5 / sigma 0 OpenCV uses the
 //                         fixed kernel [1 4 6 4 1] / 16 in 8.8 fixed point, BORDER_REFLECT_101, i.e.
 //                         dst = (sum_ij k_i k_j src(y + i, x + j) + 128) >> 8.
+#include <float.h>
 #include <stdint.h>
 #include <string.h>
+#include <algorithm>
 
 #include "src/stag/ED/GradientOperators.cpp"
 #include "src/stag/ED/EDInternals.cpp"
@@ -36,6 +40,8 @@ void ValidateLineSegments(EdgeMap *map, unsigned char *srcImg, EDLines *lines, E
 int ComputeMinLineLength(int width, int height);
 // compiled from the reference tree against oracle/cvshim (data types only): Quad.cpp QuadDetector.cpp EDInterface.cpp utility.cpp
 #include "stag/QuadDetector.h"
+// likewise Stag.cpp Decoder.cpp Marker.cpp; Drawer (image output) and, for now, PoseRefiner are stubbed below
+#include "stag/Stag.h"
 
 static inline int reflect101(int p, int n)
 {
@@ -55,6 +61,45 @@ void SmoothImage(unsigned char *srcImg, unsigned char *smoothImg, int width, int
 {
     if (sigma == 1.0) ref_stag_smooth5(srcImg, smoothImg, width, height);
     else ref_stag_smooth3(srcImg, smoothImg, width, height);
+}
+
+// ---- stubs and restatements behind the reference's Stag.cpp
+cv::Mat Drawer::drawMarkers(const string &, cv::Mat image, const vector<Marker> &) { return image; }  // drawing: out of scope
+static bool g_refine = false;
+void PoseRefiner::refineMarkerPose(EDInterface *, Marker &) {}  // row s9 (not built yet): markers are compared unrefined
+
+// cv::threshold(samples, samples, 0, 255, THRESH_OTSU + THRESH_BINARY_INV) on the 72 readings of Stag::readCode -- RESTATED
+// ("parity unpinned" for this function; the same routine, OpenCV 4.2 getThreshVal_Otsu_8u, is pinned through the golden
+// vectors of the aruco path in oracle/aruco_detect_oracle.c): histogram, between-class variance maximised in double,
+// first maximum wins; then dst = src > thr ? 0 : maxval.
+double cv::threshold(std::vector<unsigned char> &src, std::vector<unsigned char> &dst, double, double maxval, int)
+{
+    int h[256] = {0};
+    const int N = (int)src.size();
+    for (int i = 0; i < N; i++) h[src[i]]++;
+    double mu = 0, scale = 1. / N;
+    for (int i = 0; i < 256; i++) mu += i * (double)h[i];
+    mu *= scale;
+    double mu1 = 0, q1 = 0, max_sigma = 0, max_val = 0;
+    for (int i = 0; i < 256; i++) {
+        double p_i, q2, mu2, sigma;
+        p_i = h[i] * scale;
+        mu1 *= q1;
+        q1 += p_i;
+        q2 = 1. - q1;
+        if (std::min(q1, q2) < FLT_EPSILON || std::max(q1, q2) > 1. - FLT_EPSILON) continue;
+        mu1 = (mu1 + i * p_i) / q1;
+        mu2 = (mu - q1 * mu1) / q2;
+        sigma = q1 * q2 * (mu1 - mu2) * (mu1 - mu2);
+        if (sigma > max_sigma) {
+            max_sigma = sigma;
+            max_val = i;
+        }
+    }
+    const int thr = (int)max_val;
+    dst.resize(src.size());
+    for (int i = 0; i < N; i++) dst[i] = src[i] > thr ? 0 : (unsigned char)maxval;
+    return max_val;
 }
 
 static void export_lines(EDLines *lines, double *out, int cap, int *n_out)
@@ -161,6 +206,30 @@ int ref_stag_detect_quads(const uint8_t *src, int w, int h, double *quads_out, i
     delete edi.getEDLines();
     delete edi.getEdgeMap();
     return (int)q.size() <= cap ? 0 : 1;
+}
+
+// Stag::detectMarkers (Stag.cpp:24-51) end to end.  markers_out: double [cap][24] = id, 8 corner coordinates, center (2),
+// H row-major (9), lineInf (3), projectiveDistortion.
+int ref_stag_detect_markers(const uint8_t *src, int w, int h, int library_hd, int error_correction, double *markers_out, int cap, int *n_out)
+{
+    cv::Mat image(h, w, CV_8UC1, const_cast<uint8_t *>(src));
+    Stag stag(library_hd, error_correction, false);
+    stag.detectMarkers(image);
+    const std::vector<Marker> m = stag.getMarkerList();
+    for (size_t i = 0; i < m.size() && (int)i < cap; i++) {
+        double *o = markers_out + 24 * i;
+        o[0] = m[i].id;
+        for (int k = 0; k < 4; k++) {
+            o[1 + 2 * k] = m[i].corners[k].x;
+            o[2 + 2 * k] = m[i].corners[k].y;
+        }
+        o[9] = m[i].center.x; o[10] = m[i].center.y;
+        for (int k = 0; k < 9; k++) o[11 + k] = m[i].H.at<double>(k / 3, k % 3);
+        o[20] = m[i].lineInf.x; o[21] = m[i].lineInf.y; o[22] = m[i].lineInf.z;
+        o[23] = m[i].projectiveDistortion;
+    }
+    *n_out = (int)m.size();
+    return (int)m.size() <= cap ? 0 : 1;
 }
 
 int ref_stag_smooth5(const uint8_t *src, uint8_t *dst, int w, int h)

@@ -303,6 +303,40 @@ def test_quads_match_reference_code(case):
         det.close()
 
 
+def _markers_as_table(M):
+    if not len(M):
+        return np.zeros((0, 24))
+    return np.concatenate([M["id"][:, None].astype(np.float64), M["corners"].reshape(-1, 8), M["center"], M["H"].reshape(-1, 9), M["lineInf"],
+                           M["projectiveDistortion"][:, None]], axis=1)
+
+
+@pytest.mark.parametrize("hd,ec,size,n,seed", [(21, 7, (1920, 1080), 20, 7), (21, 7, (640, 480), 6, 8), (11, 2, (1920, 1080), 20, 9),
+                                                (15, 7, (1280, 720), 12, 10), (23, 11, (800, 600), 6, 11), (19, 9, (1920, 1080), 20, 12)])
+def test_markers_unrefined_match_reference_code(hd, ec, size, n, seed):
+    """Row s8 (+ s1's loop): homography, code reading, decoding, corner shift, duplicate removal on rendered STag markers,
+    against the reference's own Stag.cpp / Decoder.cpp / Marker.cpp compiled in place (pose refinement switched off on both
+    sides; the Otsu threshold behind cv::threshold is restated in the oracle): ids exact, all doubles compared with ==."""
+    if not stag_ref.available():
+        pytest.skip("oracle/_ref/libstag_ref.so not built (needs /root/reference at build time)")
+    from fiducials_amd import synth
+    w, h = size
+    words = fstag.load_library(hd)
+    fr = synth.make_stag_frame(words, seed, w, h, n)
+    det = fstag.StagDetector(hd, ec, max_width=1920, max_height=1080)
+    try:
+        det.detect_markers_unrefined(fr.image)
+        M = det.markers()
+        ref = stag_ref.detect_markers(fr.image, hd, ec)
+        assert len(ref) >= min(n, len(words) // 4) // 2, "the rendered markers must be readable"
+        got = _markers_as_table(M)
+        assert got.shape == ref.shape, (got.shape, ref.shape)
+        assert np.array_equal(got[:, 0], ref[:, 0]), "ids"
+        assert (got == ref).all(), np.abs(got - ref).max(axis=0)
+        assert set(M["id"].tolist()) <= set(fr.ids.tolist())
+    finally:
+        det.close()
+
+
 def test_stag_status_codes():
     from fiducials_amd import _lib
     from fiducials_amd._lib import FidError

@@ -1746,6 +1746,460 @@ __global__ __launch_bounds__(64) void k_stag_dedup(const fid_stag_marker *__rest
     *nout = m;
 }
 
+// ------------------------------------------------------------------------------------------------ K16: pose refinement
+// PoseRefiner::refineMarkerPose (PoseRefiner.cpp:12-190), one wave per marker:
+//   (1) pick the edge segment that is the image of the marker's circular border: a closed loop of >= 20 pixels inside the
+//       quad whose back-projection stays within 0.1 of the circle of radius 0.4 and whose distances to 36 points of that circle
+//       sum to < 1.8 (lanes take pixels; minima are order-free, the sum over the 36 points runs in order);
+//   (2) fit an ellipse to it: customEllipse(pix*, n) (Ellipse.cpp:296-473) = Fitzgibbon's direct least squares through the
+//       reference's own small linear algebra (scatter matrix summed in pixel order -- one lane per matrix entry --, choldc,
+//       Gauss-Jordan inverse, Jacobi eigenvalues, all 1-based like the original);
+//   (3) move the 9 entries of H with Nelder-Mead so that H^T C H is the circle (0.5, 0.5, r 0.4): cv::DownhillSolver with its
+//       defaults, restated (see oracle/stag_ref.cpp for the same restatement on the checker's side); cost Refine::calc (:224-258);
+//   (4) corners and centre from the new H.
+// atan / sin / cos come from the device's math library here and from glibc in the reference: the results agree to rounding,
+// the optimiser then follows a path that can differ in the last bits -- this row's parity bar is a tolerance (corners to
+// 1e-3 px), not equality.
+struct SrEllipse {
+    double A1, B1, C1, D1, E1, F1, cX, cY, a, b;
+};
+
+// the conic -> ellipse conversion shared by both customEllipse constructors (Ellipse.cpp:394-454, :668-728); coefficients
+// come in unnormalised
+__device__ void sr_conic_to_ellipse(double A1, double B1, double C1, double D1, double E1, double F1, SrEllipse *e)
+{
+    B1 /= A1; C1 /= A1; D1 /= A1; E1 /= A1; F1 /= A1; A1 /= A1;
+    double A2, C2, D2, E2, F2, rotation = 0;  // (the reference leaves rotation unset when B1 == 0)
+    if (B1 == 0) {
+        A2 = A1; C2 = C1; D2 = D1; E2 = E1; F2 = F1;
+    } else {
+        rotation = atan(B1 / (A1 - C1)) / 2;
+        A2 = 0.5 * (A1 * (1 + cos(2 * rotation) + B1 * sin(2 * rotation) + C1 * (1 - cos(2 * rotation))));
+        C2 = 0.5 * (A1 * (1 - cos(2 * rotation) - B1 * sin(2 * rotation) + C1 * (1 + cos(2 * rotation))));
+        D2 = D1 * cos(rotation) + E1 * sin(rotation);
+        E2 = -D1 * sin(rotation) + E1 * cos(rotation);
+        F2 = F1;
+    }
+    const double D3 = D2 / A2, E3 = E2 / C2;
+    double cX = -(D3 / 2), cY = -(E3 / 2);
+    const double F3 = A2 * (cX * cX) + C2 * (cY * cY) - F2;
+    e->a = sqrt(F3 / A2);
+    e->b = sqrt(F3 / C2);
+    if (rotation != 0) {
+        const double tx = cX, ty = cY;
+        cX = tx * cos(rotation) - ty * sin(rotation);
+        cY = tx * sin(rotation) + ty * cos(rotation);
+    }
+    e->cX = cX; e->cY = cY;
+    e->A1 = A1; e->B1 = B1; e->C1 = C1; e->D1 = D1; e->E1 = E1; e->F1 = F1;
+}
+
+// 1-based 7 x 7 scratch matrices as in the reference
+typedef double SrM[7][7];
+
+__device__ void sr_jacobi(SrM a, double d[7], SrM v)
+{
+    const int n = 6;
+    double b[7], z[7];
+    for (int ip = 1; ip <= n; ip++) {
+        for (int iq = 1; iq <= n; iq++) v[ip][iq] = 0.0;
+        v[ip][ip] = 1.0;
+    }
+    for (int ip = 1; ip <= n; ip++) {
+        b[ip] = d[ip] = a[ip][ip];
+        z[ip] = 0.0;
+    }
+    auto rot = [](SrM m, int i, int j, int k, int l, double tau, double s) {
+        const double g = m[i][j], h = m[k][l];
+        m[i][j] = g - s * (h + g * tau);
+        m[k][l] = h + s * (g - h * tau);
+    };
+    for (int i = 1; i <= 50; i++) {
+        double sm = 0.0;
+        for (int ip = 1; ip <= n - 1; ip++)
+            for (int iq = ip + 1; iq <= n; iq++) sm += fabs(a[ip][iq]);
+        if (sm == 0.0) return;
+        const double tresh = i < 4 ? 0.2 * sm / (n * n) : 0.0;
+        for (int ip = 1; ip <= n - 1; ip++) {
+            for (int iq = ip + 1; iq <= n; iq++) {
+                const double g = 100.0 * fabs(a[ip][iq]);
+                if (i > 4 && g == 0.0) a[ip][iq] = 0.0;
+                else if (fabs(a[ip][iq]) > tresh) {
+                    double h = d[iq] - d[ip], t;
+                    if (g == 0.0) t = (a[ip][iq]) / h;
+                    else {
+                        const double theta = 0.5 * h / (a[ip][iq]);
+                        t = 1.0 / (fabs(theta) + sqrt(1.0 + theta * theta));
+                        if (theta < 0.0) t = -t;
+                    }
+                    const double c = 1.0 / sqrt(1 + t * t), sn = t * c, tau = sn / (1.0 + c);
+                    h = t * a[ip][iq];
+                    z[ip] -= h; z[iq] += h; d[ip] -= h; d[iq] += h;
+                    a[ip][iq] = 0.0;
+                    for (int j = 1; j <= ip - 1; j++) rot(a, j, ip, j, iq, tau, sn);
+                    for (int j = ip + 1; j <= iq - 1; j++) rot(a, ip, j, j, iq, tau, sn);
+                    for (int j = iq + 1; j <= n; j++) rot(a, ip, j, iq, j, tau, sn);
+                    for (int j = 1; j <= n; j++) rot(v, j, ip, j, iq, tau, sn);
+                }
+            }
+        }
+        for (int ip = 1; ip <= n; ip++) {
+            b[ip] += z[ip];
+            d[ip] = b[ip];
+            z[ip] = 0.0;
+        }
+    }
+}
+
+// customEllipse(pix*, n) from the scatter matrix S (1-based, full) on: returns false if the inverse fails
+__device__ bool sr_fit_from_scatter(SrM S, SrEllipse *e)
+{
+    const int n = 6;
+    SrM L, invL, temp, C, V, sol, Const;
+    double d[7], p[7];
+    for (int i = 0; i < 7; i++)
+        for (int j = 0; j < 7; j++) L[i][j] = invL[i][j] = temp[i][j] = C[i][j] = V[i][j] = sol[i][j] = Const[i][j] = 0.0;
+    for (int i = 0; i < 7; i++) d[i] = p[i] = 0.0;
+    Const[1][3] = -2; Const[2][2] = 1; Const[3][1] = -2;  // FPF mode
+    // choldc
+    for (int i = 1; i <= n; i++) {
+        for (int j = i; j <= n; j++) {
+            double sum = S[i][j];
+            for (int k = i - 1; k >= 1; k--) sum -= S[i][k] * S[j][k];
+            if (i == j) {
+                if (sum > 0.0) p[i] = sqrt(sum);
+            } else
+                S[j][i] = sum / p[i];
+        }
+    }
+    for (int i = 1; i <= n; i++)
+        for (int j = i; j <= n; j++) {
+            if (i == j) L[i][i] = p[i];
+            else {
+                L[j][i] = S[j][i];
+                L[i][j] = 0.0;
+            }
+        }
+    // inverse(L): Gauss-Jordan with row pivoting on [L | I]
+    {
+        double A[7][14];
+        for (int k = 0; k < 7; k++)
+            for (int j = 0; j < 14; j++) A[k][j] = 0.0;
+        for (int k = 1; k <= n; k++) {
+            for (int j = 1; j <= n; j++) A[k][j] = L[k][j];  // (column n + 1 stays 0 as in the reference)
+            A[k][k - 1 + n + 2] = 1;
+        }
+        for (int k = 1; k <= n; k++) {
+            double maxpivot = fabs(A[k][k]);
+            int npivot = k;
+            for (int i = k; i <= n; i++)
+                if (maxpivot < fabs(A[i][k])) {
+                    maxpivot = fabs(A[i][k]);
+                    npivot = i;
+                }
+            if (!(maxpivot >= 10e-20)) return false;
+            if (npivot != k)
+                for (int j = k; j <= 2 * n + 1; j++) {
+                    const double t = A[npivot][j];
+                    A[npivot][j] = A[k][j];
+                    A[k][j] = t;
+                }
+            const double Dv = A[k][k];
+            for (int j = 2 * n + 1; j >= k; j--) A[k][j] = A[k][j] / Dv;
+            for (int i = 1; i <= n; i++)
+                if (i != k) {
+                    const double mult = A[i][k];
+                    for (int j = 2 * n + 1; j >= k; j--) A[i][j] = A[i][j] - mult * A[k][j];
+                }
+        }
+        for (int k = 1; k <= n; k++)
+            for (int j = n + 2, q = 1; j <= 2 * n + 1; j++, q++) invL[k][q] = A[k][j];
+    }
+    // temp = Const * invL^T, C = invL * temp
+    for (int pp = 1; pp <= n; pp++)
+        for (int q = 1; q <= n; q++) {
+            temp[pp][q] = 0.0;
+            for (int l = 1; l <= n; l++) temp[pp][q] = temp[pp][q] + Const[pp][l] * invL[q][l];
+        }
+    for (int pp = 1; pp <= n; pp++)
+        for (int q = 1; q <= n; q++) {
+            C[pp][q] = 0.0;
+            for (int l = 1; l <= n; l++) C[pp][q] = C[pp][q] + invL[pp][l] * temp[l][q];
+        }
+    sr_jacobi(C, d, V);
+    // sol = invL^T * V
+    for (int pp = 1; pp <= n; pp++)
+        for (int q = 1; q <= n; q++) {
+            sol[pp][q] = 0.0;
+            for (int l = 1; l <= n; l++) sol[pp][q] = sol[pp][q] + invL[l][pp] * V[l][q];
+        }
+    for (int j = 1; j <= n; j++) {
+        double mod = 0.0;
+        for (int i = 1; i <= n; i++) mod += sol[i][j] * sol[i][j];
+        for (int i = 1; i <= n; i++) sol[i][j] /= sqrt(mod);
+    }
+    int solind = 0;
+    for (int i = 1; i <= n; i++)
+        if (d[i] < 0 && fabs(d[i]) > 10e-20) solind = i;
+    sr_conic_to_ellipse(sol[1][solind], sol[2][solind], sol[3][solind], sol[4][solind], sol[5][solind], sol[6][solind], e);
+    return true;
+}
+
+__device__ void sr_mul3(const double a[9], const double b[9], double d[9])
+{
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) d[3 * i + j] = a[3 * i] * b[j] + a[3 * i + 1] * b[3 + j] + a[3 * i + 2] * b[6 + j];
+}
+
+// cv::Mat::inv() of a 3 x 3 (closed form, as OpenCV's invert() does for n <= 3)
+__device__ void sr_inv3(const double S[9], double D[9])
+{
+    double d = S[0] * (S[4] * S[8] - S[5] * S[7]) - S[1] * (S[3] * S[8] - S[5] * S[6]) + S[2] * (S[3] * S[7] - S[4] * S[6]);
+    for (int k = 0; k < 9; k++) D[k] = 0.0;
+    if (d != 0.) {
+        d = 1. / d;
+        D[0] = (S[4] * S[8] - S[5] * S[7]) * d; D[1] = (S[2] * S[7] - S[1] * S[8]) * d; D[2] = (S[1] * S[5] - S[2] * S[4]) * d;
+        D[3] = (S[5] * S[6] - S[3] * S[8]) * d; D[4] = (S[0] * S[8] - S[2] * S[6]) * d; D[5] = (S[2] * S[3] - S[0] * S[5]) * d;
+        D[6] = (S[3] * S[7] - S[4] * S[6]) * d; D[7] = (S[1] * S[6] - S[0] * S[7]) * d; D[8] = (S[0] * S[4] - S[1] * S[3]) * d;
+    }
+}
+
+// Refine::calc (PoseRefiner.cpp:224-258): x[i + 3 j] = H(i, j)
+__device__ double sr_cost(const double x[9], const double Cm[9])
+{
+    double H[9], HT[9], T[9], P[9];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) {
+            H[3 * i + j] = x[i + j * 3];
+            HT[3 * j + i] = x[i + j * 3];
+        }
+    sr_mul3(HT, Cm, T);
+    sr_mul3(T, H, P);
+    SrEllipse e;
+    sr_conic_to_ellipse(P[0], -P[1] * 2, P[4], P[2] * 2, -P[5] * 2, P[8], &e);
+    double acc = 0;
+    acc += fabs(e.a - 0.4);
+    acc += fabs(e.b - 0.4);
+    acc += fabs(e.cX - 0.5);
+    acc += fabs(-e.cY - 0.5);
+    return acc;
+}
+
+// cv::DownhillSolver::minimize with the default TermCriteria(MAX_ITER + EPS, 5000, 1e-6), 9 dimensions
+__device__ void sr_downhill(double x[9], const double step[9], const double Cm[9])
+{
+    const int nd = 9;
+    double p[10][9], y[10], sum[9], buf[9];
+    for (int j = 0; j < nd; j++) p[0][j] = x[j];
+    for (int i = 1; i <= nd; i++) {
+        for (int j = 0; j < nd; j++) p[i][j] = p[0][j];
+        p[i][i - 1] += 0.5 * step[i - 1];
+    }
+    for (int j = 0; j < nd; j++) p[0][j] -= 0.5 * step[j];
+    int fcount = nd + 1;
+    for (int i = 0; i <= nd; i++) y[i] = sr_cost(p[i], Cm);
+    auto update_sum = [&]() {
+        for (int j = 0; j < nd; j++) sum[j] = 0.;
+        for (int i = 0; i <= nd; i++)
+            for (int j = 0; j < nd; j++) sum[j] += p[i][j];
+    };
+    auto try_point = [&](int ihi, double alpha_) {
+        const double alpha = (1.0 - alpha_) / nd, beta = alpha - alpha_;
+        for (int j = 0; j < nd; j++) buf[j] = sum[j] * alpha - p[ihi][j] * beta;
+        fcount++;
+        return sr_cost(buf, Cm);
+    };
+    auto replace_point = [&](int ihi, double alpha_, double ytry) {
+        const double alpha = (1.0 - alpha_) / nd, beta = alpha - alpha_;
+        for (int j = 0; j < nd; j++) p[ihi][j] = sum[j] * alpha - p[ihi][j] * beta;
+        y[ihi] = ytry;
+        update_sum();
+    };
+    update_sum();
+    for (;;) {
+        int ilo = 0, ihi, inhi;
+        if (y[0] > y[1]) { ihi = 0; inhi = 1; } else { ihi = 1; inhi = 0; }
+        for (int i = 0; i <= nd; i++) {
+            const double yv = y[i];
+            if (yv <= y[ilo]) ilo = i;
+            if (yv > y[ihi]) { inhi = ihi; ihi = i; }
+            else if (yv > y[inhi] && i != ihi) inhi = i;
+        }
+        if (ilo == inhi || ilo == ihi)
+            for (int i = 0; i <= nd; i++)
+                if (y[i] == y[ilo] && i != ihi && i != inhi) { ilo = i; break; }
+        const double error = fabs(y[ihi] - y[ilo]);
+        double range = 0;
+        for (int j = 0; j < nd; j++) {
+            double mn = p[0][j], mx = p[0][j];
+            for (int i = 1; i <= nd; i++) {
+                mn = fmin(mn, p[i][j]);
+                mx = fmax(mx, p[i][j]);
+            }
+            range = fmax(range, fabs(mx - mn));
+        }
+        if (range <= 0.000001 || error <= 0.000001 || fcount >= 5000) {
+            for (int j = 0; j < nd; j++) x[j] = p[ilo][j];
+            return;
+        }
+        const double y_lo = y[ilo], y_nhi = y[inhi], y_hi = y[ihi];
+        double alpha = -1.0;
+        double y_alpha = try_point(ihi, alpha);
+        if (y_alpha < y_nhi) {
+            if (y_alpha < y_lo) {
+                const double y_beta = try_point(ihi, -2.0);
+                if (y_beta < y_alpha) { alpha = -2.0; y_alpha = y_beta; }
+            }
+            replace_point(ihi, alpha, y_alpha);
+        } else {
+            const double y_gamma = try_point(ihi, 0.5);
+            if (y_gamma < y_hi) replace_point(ihi, 0.5, y_gamma);
+            else {
+                for (int i = 0; i <= nd; i++)
+                    if (i != ilo) {
+                        for (int j = 0; j < nd; j++) p[i][j] = 0.5 * (p[i][j] + p[ilo][j]);
+                        y[i] = sr_cost(p[i], Cm);
+                    }
+                fcount += nd;
+                update_sum();
+            }
+        }
+    }
+}
+
+// PoseRefiner::checkIfPointInQuad (PoseRefiner.cpp:200-222)
+__device__ bool sr_in_quad(const double c[8], double px, double py)
+{
+    const double c1c2x = c[2] - c[0], c1c2y = c[3] - c[1], c1c4x = c[6] - c[0], c1c4y = c[7] - c[1];
+    const double c3c2x = c[2] - c[4], c3c2y = c[3] - c[5], c3c4x = c[6] - c[4], c3c4y = c[7] - c[5];
+    const double c1px = px - c[0], c1py = py - c[1], c3px = px - c[4], c3py = py - c[5];
+    if (sq_cross(c1px, c1py, c1c2x, c1c2y) * sq_cross(c1px, c1py, c1c4x, c1c4y) >= 0) return false;
+    if (sq_cross(c1c2x, c1c2y, c1px, c1py) * sq_cross(c1c2x, c1c2y, c1c4x, c1c4y) <= 0) return false;
+    if (sq_cross(c3px, c3py, c3c2x, c3c2y) * sq_cross(c3px, c3py, c3c4x, c3c4y) >= 0) return false;
+    if (sq_cross(c3c2x, c3c2y, c3px, c3py) * sq_cross(c3c2x, c3c2y, c3c4x, c3c4y) <= 0) return false;
+    return true;
+}
+
+__global__ __launch_bounds__(64) void k_stag_refine(fid_stag_marker *__restrict__ markers, const int *__restrict__ nmarkers,
+                                                    const int2 *__restrict__ vsegs, const int *__restrict__ nsegs, const int2 *__restrict__ pix,
+                                                    int *__restrict__ chosen_out)
+{
+    const int m = blockIdx.x, lane = threadIdx.x;
+    if (m >= *nmarkers) return;
+    fid_stag_marker M = markers[m];
+    const double sinVals[36] = {0.000000,  0.173648,  0.342020,  0.500000,  0.642788,  0.766044,  0.866025,  0.939693,  0.984808,
+                                1.000000,  0.984808,  0.939693,  0.866025,  0.766044,  0.642788,  0.500000,  0.342020,  0.173648,
+                                0.000000,  -0.173648, -0.342020, -0.500000, -0.642788, -0.766044, -0.866025, -0.939693, -0.984808,
+                                -1.000000, -0.984808, -0.939693, -0.866025, -0.766044, -0.642788, -0.500000, -0.342020, -0.173648};
+    double Hinv[9];
+    sr_inv3(M.H, Hinv);
+    // ---- (1) the edge segment of the circular border
+    int chosen = -1;
+    double minAcc = INFINITY;
+    const int ns = *nsegs;
+    for (int sg = 0; sg < ns; sg++) {
+        const int first = vsegs[sg].x, n = vsegs[sg].y;
+        if (n < 20) continue;
+        const int2 *p = pix + first;
+        if (sq_dist2((double)p[0].y, (double)p[0].x, (double)p[n - 1].y, (double)p[n - 1].x) > 7.0 * 7.0) continue;
+        bool outside = false;
+        for (int k = 0; k < n && !outside; k += 20)
+            if (!sr_in_quad(M.corners, (double)p[k].y, (double)p[k].x)) outside = true;
+        if (outside) continue;
+        // back-projection; per sample point the minimum over the pixels, per pixel the minimum over the sample points
+        bool bad = false;
+        double sampleErr[36];
+        for (int s = 0; s < 36; s++) sampleErr[s] = INFINITY;
+        for (int k0 = 0; k0 < n; k0 += 64) {
+            const int k = k0 + lane;
+            double qx = 0, qy = 0;
+            const bool act = k < n;
+            if (act) {
+                const double ex = p[k].y, ey = p[k].x;
+                const double a0 = Hinv[0] * ex + Hinv[1] * ey + Hinv[2] * 1, a1 = Hinv[3] * ex + Hinv[4] * ey + Hinv[5] * 1;
+                const double a2 = Hinv[6] * ex + Hinv[7] * ey + Hinv[8] * 1;
+                qx = a0 / a2;
+                qy = a1 / a2;
+            }
+            double pixErr = INFINITY;
+            for (int s = 0; s < 36; s++) {
+                const double sx = 0.5 + 0.4 * sinVals[(s + 9) % 36], sy = 0.5 + 0.4 * sinVals[s];
+                const double d = act ? sqrt((qx - sx) * (qx - sx) + (qy - sy) * (qy - sy)) : INFINITY;
+                if (d < pixErr) pixErr = d;
+                double mn = d;
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) mn = fmin(mn, __shfl_xor(mn, off, 64));
+                if (mn < sampleErr[s]) sampleErr[s] = mn;
+            }
+            if (__ballot(act && pixErr > 0.1)) bad = true;
+        }
+        if (bad) continue;
+        double errSum = 0;
+        for (int s = 0; s < 36; s++) errSum += sampleErr[s];
+        if (errSum < minAcc && errSum < 36 * 0.05) {
+            minAcc = errSum;
+            chosen = sg;
+        }
+    }
+    if (lane == 0) chosen_out[m] = chosen;
+    if (chosen < 0) return;
+    // ---- (2) ellipse through the chosen segment: scatter matrix, one lane per entry (p <= q), summed in pixel order
+    __shared__ double s_S[7][7];
+    {
+        const int first = vsegs[chosen].x, n = vsegs[chosen].y;
+        const int2 *p = pix + first;
+        if (lane < 49) s_S[lane / 7][lane % 7] = 0.0;
+        __builtin_amdgcn_wave_barrier();
+        int pi = 0, qi = 0, idx = lane;
+        bool mine = false;
+        for (int a = 1; a <= 6 && !mine; a++)
+            for (int b = a; b <= 6; b++) {
+                if (idx == 0) { pi = a; qi = b; mine = true; break; }
+                idx--;
+            }
+        if (mine) {
+            double acc = 0.0;
+            for (int l = 0; l < n; l++) {
+                const double tx = (double)p[l].y, ty = (double)(-p[l].x);
+                const double Dl[7] = {0, tx * tx, tx * ty, ty * ty, tx, ty, 1.0};
+                acc = acc + Dl[pi] * Dl[qi];
+            }
+            s_S[pi][qi] = acc;
+            s_S[qi][pi] = acc;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (n < 6) return;
+    }
+    if (lane != 0) return;
+    SrM S;
+    for (int i = 0; i < 7; i++)
+        for (int j = 0; j < 7; j++) S[i][j] = s_S[i][j];
+    SrEllipse E;
+    if (!sr_fit_from_scatter(S, &E)) return;
+    double Cm[9];
+    Cm[0] = E.A1; Cm[1] = Cm[3] = -E.B1 / 2; Cm[4] = E.C1; Cm[2] = Cm[6] = E.D1 / 2; Cm[5] = Cm[7] = -E.E1 / 2; Cm[8] = E.F1;
+    // ---- (3) Nelder-Mead over the entries of H
+    double x[9], step[9];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) x[i + j * 3] = M.H[3 * i + j];
+    for (int k = 0; k < 9; k++) step[k] = fabs(0.001 * x[k]);
+    sr_downhill(x, step, Cm);
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) M.H[3 * i + j] = x[i + j * 3];
+    // ---- (4) points from the refined H
+    auto project = [&](double px, double py, double *ox, double *oy) {
+        const double a0 = M.H[0] * px + M.H[1] * py + M.H[2] * 1, a1 = M.H[3] * px + M.H[4] * py + M.H[5] * 1, a2 = M.H[6] * px + M.H[7] * py + M.H[8] * 1;
+        *ox = a0 / a2;
+        *oy = a1 / a2;
+    };
+    project(0.5, 0.5, &M.center[0], &M.center[1]);
+    project(0, 0, &M.corners[0], &M.corners[1]);
+    project(1, 0, &M.corners[2], &M.corners[3]);
+    project(1, 1, &M.corners[4], &M.corners[5]);
+    project(0, 1, &M.corners[6], &M.corners[7]);
+    markers[m] = M;
+}
+
 // ------------------------------------------------------------------------------------------------ C-ABI
 // ---- host side of the line validation: the number-of-false-alarms table.  nfa() restates NFA.cpp:155-239 (the LSD
 // binomial-tail bound: log-gamma by Windschitl / Lanczos, series with a 10 % truncation tolerance); the table is what
@@ -1911,6 +2365,7 @@ struct fid_stag_ctx {
     int *d_found = nullptr, *d_nmarkers = nullptr;
     int n_markers = 0;
     bool decoded = false;
+    int *d_chosen = nullptr;
     int W = 0, H = 0;
     unsigned n_anchors = 0;
 };
@@ -1971,6 +2426,7 @@ fid_status fid_stag_create(int libraryHD, int errorCorrection, int max_width, in
     ok = ok && hipMalloc((void **)&c->d_locs, 72 * 3 * 8) == hipSuccess && hipMalloc((void **)&c->d_cand, (n / 9 + 16) * sizeof(fid_stag_marker)) == hipSuccess &&
          hipMalloc((void **)&c->d_markers, (n / 9 + 16) * sizeof(fid_stag_marker)) == hipSuccess &&
          hipMalloc((void **)&c->d_found, (n / 9 + 16) * 4) == hipSuccess && hipMalloc((void **)&c->d_nmarkers, 4) == hipSuccess;
+    ok = ok && hipMalloc((void **)&c->d_chosen, (n / 9 + 16) * 4) == hipSuccess;
     if (ok) {
         double locs[72 * 3];
         stag_fill_code_locations(locs);
@@ -2000,7 +2456,7 @@ void fid_stag_destroy(fid_stag_ctx *c)
                    c->d_prefix, c->d_lslots, c->d_lines, c->d_lcounts, c->d_ltotal,
                    c->d_atan_lut, c->d_kmin, c->d_lflags, c->d_vltotal, c->d_vlines,
                    c->d_lrange, c->d_corners, c->d_order, c->d_qcounts, c->d_qtotal, c->d_qslots, c->d_quads,
-                   c->d_locs, c->d_words, c->d_cand, c->d_markers, c->d_found, c->d_nmarkers};
+                   c->d_locs, c->d_words, c->d_cand, c->d_markers, c->d_found, c->d_nmarkers, c->d_chosen};
     for (void *p : dev)
         if (p) (void)hipFree(p);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -2213,6 +2669,28 @@ fid_status fid_stag_detect_markers_unrefined(fid_stag_ctx *c, const uint8_t *gra
     if (hipMemcpyAsync(&c->n_markers, c->d_nmarkers, 4, hipMemcpyDeviceToHost, st) != hipSuccess) return FID_E_HIP;
     if (hipStreamSynchronize(st) != hipSuccess) return FID_E_HIP;
     c->decoded = true;
+    return FID_OK;
+}
+
+fid_status fid_stag_detect_markers(fid_stag_ctx *c, const uint8_t *gray, int32_t width, int32_t height, int32_t stride, fid_stag_marker *out,
+                                   int32_t cap, int32_t *n_out)
+{
+    fid_status rc = fid_stag_detect_markers_unrefined(c, gray, width, height, stride);
+    if (rc != FID_OK) return rc;
+    hipStream_t st = c->stream;
+    if (c->n_markers > 0) {
+        hipLaunchKernelGGL(k_stag_refine, dim3(c->n_markers), dim3(64), 0, st, c->d_markers, c->d_nmarkers, c->d_vsegs, c->d_vtotal, c->d_outpix,
+                           c->d_chosen);
+        if (hipGetLastError() != hipSuccess) return FID_E_HIP;
+    }
+    if (n_out) *n_out = c->n_markers;
+    if (out) {
+        if (c->n_markers > cap) return FID_E_CAPACITY;
+        if (c->n_markers > 0 &&
+            hipMemcpyAsync(out, c->d_markers, (size_t)c->n_markers * sizeof(fid_stag_marker), hipMemcpyDeviceToHost, st) != hipSuccess)
+            return FID_E_HIP;
+    }
+    if (hipStreamSynchronize(st) != hipSuccess) return FID_E_HIP;
     return FID_OK;
 }
 

@@ -86,6 +86,21 @@ class StagDetector:
         """Stag::detectMarkers without the final pose refinement; markers() reads the result (MARKER_DTYPE)."""
         self._run(self._L.fid_stag_detect_markers_unrefined, gray)
 
+    def detect_markers(self, gray: np.ndarray) -> np.ndarray:
+        """Stag::detectMarkers + getMarkerList(): the markers of a mono8 image (MARKER_DTYPE), pose-refined."""
+        img = np.asarray(gray)
+        if img.dtype != np.uint8 or img.ndim != 2:
+            raise FidError(_lib.FID_E_INVALID_ARG, "image must be uint8 HxW")
+        if img.strides[1] != 1:
+            img = np.ascontiguousarray(img)
+        h, w = img.shape
+        n = C.c_int32(0)
+        rc = self._L.fid_stag_detect_markers(self._ctx, img.ctypes.data, w, h, img.strides[0], None, 0, C.byref(n))
+        if rc != _lib.FID_OK:
+            raise FidError(rc, self._L.fid_strerror(rc).decode())
+        self.shape = (h, w)
+        return self.markers()
+
     def markers(self) -> np.ndarray:
         return self.tap(TAP_MARKERS)
 

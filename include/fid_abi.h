@@ -247,6 +247,10 @@ fid_status fid_stag_load_library(fid_stag_ctx *ctx, const uint64_t *codewords, i
 /* Stag::detectMarkers (Stag.cpp:24-51) up to, not including, PoseRefiner::refineMarkerPose: homography, code reading,
  * decoding with the context's errorCorrection, corner shift, duplicate removal */
 fid_status fid_stag_detect_markers_unrefined(fid_stag_ctx *ctx, const uint8_t *gray, int32_t width, int32_t height, int32_t stride_bytes);
+/* Stag::detectMarkers complete + getMarkerList() (Stag.h:42-45): the above + PoseRefiner::refineMarkerPose
+ * (PoseRefiner.cpp:12-190) on every marker.  out may be NULL (read the MARKERS tap instead); FID_E_CAPACITY if cap is too small */
+fid_status fid_stag_detect_markers(fid_stag_ctx *ctx, const uint8_t *gray, int32_t width, int32_t height, int32_t stride_bytes,
+                                   fid_stag_marker *out, int32_t cap, int32_t *n_out);
 typedef enum fid_stag_tap {
     FID_STAG_TAP_SMOOTH = 0,  /* uint8 [h][w] smoothed image */
     FID_STAG_TAP_GRAD = 1,    /* int16 [h][w] |gx| + |gy| (border: GRADIENT_THRESH - 1) */

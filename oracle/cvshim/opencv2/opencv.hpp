@@ -81,6 +81,7 @@ class Mat {
     T *ptr(int r) { return (T *)data + (size_t)r * cols; }
     template <typename T>
     const T *ptr(int r) const { return (const T *)data + (size_t)r * cols; }
+    Mat inv() const;  // DECLARED only (numerical content: restated in oracle/stag_ref.cpp)
     Mat clone() const
     {
         Mat m(rows, cols, type_);
@@ -90,6 +91,61 @@ class Mat {
 
    private:
     std::shared_ptr<std::vector<unsigned char>> own_;
+};
+
+// cv::Mat_<double>(3, 1) << a, b, c  (PoseRefiner.cpp:93-96, 200)
+template <typename T>
+class Mat_ : public Mat {
+   public:
+    Mat_(int r, int c) : Mat(r, c, CV_64FC1), pos_(0) {}
+    Mat_ &operator<<(T v) { at<T>(pos_++) = v; return *this; }
+    Mat_ &operator,(T v) { at<T>(pos_++) = v; return *this; }
+
+   private:
+    int pos_;
+};
+
+inline void transpose(const Mat &a, Mat &d)
+{
+    Mat t(a.cols, a.rows, CV_64FC1);
+    for (int i = 0; i < a.rows; i++)
+        for (int j = 0; j < a.cols; j++) t.at<double>(j, i) = a.at<double>(i, j);
+    d = t;
+}
+
+// like OpenCV 4's cv::Ptr: a shared_ptr with an UNCONSTRAINED converting constructor (its body is instantiated at the end
+// of the translation unit, which is what lets PoseRefiner.cpp convert Ptr<Refine> while Refine is still incomplete)
+template <typename T>
+struct Ptr : public std::shared_ptr<T> {
+    Ptr() {}
+    Ptr(T *p) : std::shared_ptr<T>(p) {}
+    template <typename Y>
+    Ptr(const Ptr<Y> &o) : std::shared_ptr<T>(static_cast<const std::shared_ptr<Y> &>(o)) {}
+};
+template <typename T>
+Ptr<T> makePtr() { return Ptr<T>(new T()); }
+
+class MinProblemSolver {
+   public:
+    class Function {
+       public:
+        virtual ~Function() {}
+        virtual int getDims() const = 0;
+        virtual double calc(const double *x) const = 0;
+    };
+};
+
+// DECLARED only: cv::DownhillSolver (Nelder-Mead) has numerical content; its restatement is in oracle/stag_ref.cpp
+class DownhillSolver {
+   public:
+    static Ptr<DownhillSolver> create();
+    void setFunction(const Ptr<MinProblemSolver::Function> &f) { f_ = f; }
+    void setInitStep(const Mat &step) { step_ = step.clone(); }
+    double minimize(Mat &x);
+
+   private:
+    Ptr<MinProblemSolver::Function> f_;
+    Mat step_;
 };
 
 struct Scalar {

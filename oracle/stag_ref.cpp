@@ -39,9 +39,17 @@ void JoinCollinearLines(EDLines *lines, double MAX_DISTANCE_BETWEEN_TWO_LINES, d
 void ValidateLineSegments(EdgeMap *map, unsigned char *srcImg, EDLines *lines, EDLines *invalidLines);
 int ComputeMinLineLength(int width, int height);
 // compiled from the reference tree against oracle/cvshim (data types only): Quad.cpp QuadDetector.cpp EDInterface.cpp utility.cpp
+// likewise Stag.cpp Decoder.cpp Marker.cpp PoseRefiner.cpp Ellipse.cpp; Drawer (image output) is stubbed below.
+// "private" is lifted for this wrapper only, so that a test can stop Stag::detectMarkers in front of the pose refinement
+// (ref_stag_detect_markers with refine = 0 walks the same loop, Stag.cpp:36-47, with the reference's own member functions).
+#include <bitset>
+#include <string>
+#include <vector>
+#include <opencv2/opencv.hpp>
+#define class struct  // the members in question are private by default, not by keyword
 #include "stag/QuadDetector.h"
-// likewise Stag.cpp Decoder.cpp Marker.cpp; Drawer (image output) and, for now, PoseRefiner are stubbed below
 #include "stag/Stag.h"
+#undef class
 
 static inline int reflect101(int p, int n)
 {
@@ -65,8 +73,158 @@ void SmoothImage(unsigned char *srcImg, unsigned char *smoothImg, int width, int
 
 // ---- stubs and restatements behind the reference's Stag.cpp
 cv::Mat Drawer::drawMarkers(const string &, cv::Mat image, const vector<Marker> &) { return image; }  // drawing: out of scope
-static bool g_refine = false;
-void PoseRefiner::refineMarkerPose(EDInterface *, Marker &) {}  // row s9 (not built yet): markers are compared unrefined
+// PoseRefiner.cpp and Ellipse.cpp are compiled in place (oracle/Makefile).  The refiner's two OpenCV calls with numerical
+// content are RESTATED here ("parity unpinned"):
+
+// cv::Mat::inv() of a 3 x 3 double matrix (default DECOMP_LU): OpenCV's invert() takes the closed form for n <= 3 --
+// determinant by the first row, cofactors times 1 / det
+cv::Mat cv::Mat::inv() const
+{
+    const Mat &S = *this;
+    Mat D(3, 3, CV_64FC1);
+#define Sd(i, j) S.at<double>(i, j)
+    double d = Sd(0, 0) * (Sd(1, 1) * Sd(2, 2) - Sd(1, 2) * Sd(2, 1)) - Sd(0, 1) * (Sd(1, 0) * Sd(2, 2) - Sd(1, 2) * Sd(2, 0)) +
+               Sd(0, 2) * (Sd(1, 0) * Sd(2, 1) - Sd(1, 1) * Sd(2, 0));
+    if (d != 0.) {
+        d = 1. / d;
+        double t[9];
+        t[0] = (Sd(1, 1) * Sd(2, 2) - Sd(1, 2) * Sd(2, 1)) * d;
+        t[1] = (Sd(0, 2) * Sd(2, 1) - Sd(0, 1) * Sd(2, 2)) * d;
+        t[2] = (Sd(0, 1) * Sd(1, 2) - Sd(0, 2) * Sd(1, 1)) * d;
+        t[3] = (Sd(1, 2) * Sd(2, 0) - Sd(1, 0) * Sd(2, 2)) * d;
+        t[4] = (Sd(0, 0) * Sd(2, 2) - Sd(0, 2) * Sd(2, 0)) * d;
+        t[5] = (Sd(0, 2) * Sd(1, 0) - Sd(0, 0) * Sd(1, 2)) * d;
+        t[6] = (Sd(1, 0) * Sd(2, 1) - Sd(1, 1) * Sd(2, 0)) * d;
+        t[7] = (Sd(0, 1) * Sd(2, 0) - Sd(0, 0) * Sd(2, 1)) * d;
+        t[8] = (Sd(0, 0) * Sd(1, 1) - Sd(0, 1) * Sd(1, 0)) * d;
+        for (int k = 0; k < 9; k++) D.at<double>(k) = t[k];
+    }
+#undef Sd
+    return D;
+}
+
+// cv::DownhillSolver with its defaults (TermCriteria(MAX_ITER + EPS, 5000, 1e-6)): OpenCV's downhill_simplex.cpp -- initial
+// simplex x - step / 2 and x + step_i / 2 along every axis; per iteration: worst / second worst / best vertex, stop when the
+// simplex extent or the value spread is <= eps or 5000 evaluations are spent; reflect the worst vertex through the centroid
+// (factor -1), if better than the best try factor -2 and keep the better of the two, if not better than the second worst
+// try the half-way point (factor 0.5), else shrink every vertex half-way to the best one.
+cv::Ptr<cv::DownhillSolver> cv::DownhillSolver::create() { return cv::Ptr<cv::DownhillSolver>(new cv::DownhillSolver()); }
+
+namespace {
+struct NM {
+    const cv::MinProblemSolver::Function *f;
+    int ndim;
+    std::vector<double> p, sum, buf, y;  // p: (ndim + 1) x ndim
+    int fcount;
+    double *row(int i) { return &p[(size_t)i * ndim]; }
+    void update_sum()
+    {
+        for (int j = 0; j < ndim; j++) sum[j] = 0.;
+        for (int i = 0; i <= ndim; i++)
+            for (int j = 0; j < ndim; j++) sum[j] += row(i)[j];
+    }
+    double try_point(int ihi, double alpha_)
+    {
+        const double alpha = (1.0 - alpha_) / ndim, beta = alpha - alpha_;
+        for (int j = 0; j < ndim; j++) buf[j] = sum[j] * alpha - row(ihi)[j] * beta;
+        fcount++;
+        return f->calc(buf.data());
+    }
+    void replace_point(int ihi, double alpha_, double ytry)
+    {
+        const double alpha = (1.0 - alpha_) / ndim, beta = alpha - alpha_;
+        for (int j = 0; j < ndim; j++) row(ihi)[j] = sum[j] * alpha - row(ihi)[j] * beta;
+        y[ihi] = ytry;
+        update_sum();
+    }
+    double run(double MinRange, double MinError, int nmax)
+    {
+        fcount = ndim + 1;
+        for (int i = 0; i <= ndim; i++) y[i] = f->calc(row(i));
+        update_sum();
+        for (;;) {
+            int ilo = 0, ihi, inhi;
+            if (y[0] > y[1]) { ihi = 0; inhi = 1; } else { ihi = 1; inhi = 0; }
+            for (int i = 0; i <= ndim; i++) {
+                const double yval = y[i];
+                if (yval <= y[ilo]) ilo = i;
+                if (yval > y[ihi]) { inhi = ihi; ihi = i; }
+                else if (yval > y[inhi] && i != ihi) inhi = i;
+            }
+            if (ilo == inhi || ilo == ihi) {
+                for (int i = 0; i <= ndim; i++) {
+                    const double yval = y[i];
+                    if (yval == y[ilo] && i != ihi && i != inhi) { ilo = i; break; }
+                }
+            }
+            const double error = fabs(y[ihi] - y[ilo]);
+            double range = 0;
+            for (int j = 0; j < ndim; j++) {
+                double minval, maxval;
+                minval = maxval = row(0)[j];
+                for (int i = 1; i <= ndim; i++) {
+                    const double pval = row(i)[j];
+                    minval = std::min(minval, pval);
+                    maxval = std::max(maxval, pval);
+                }
+                range = std::max(range, fabs(maxval - minval));
+            }
+            if (range <= MinRange || error <= MinError || fcount >= nmax) {
+                std::swap(y[0], y[ilo]);
+                for (int j = 0; j < ndim; j++) std::swap(row(0)[j], row(ilo)[j]);
+                break;
+            }
+            const double y_lo = y[ilo], y_nhi = y[inhi], y_hi = y[ihi];
+            double alpha = -1.0;
+            double y_alpha = try_point(ihi, alpha);
+            if (y_alpha < y_nhi) {
+                if (y_alpha < y_lo) {
+                    const double beta = -2.0;
+                    const double y_beta = try_point(ihi, beta);
+                    if (y_beta < y_alpha) { alpha = beta; y_alpha = y_beta; }
+                }
+                replace_point(ihi, alpha, y_alpha);
+            } else {
+                const double gamma = 0.5;
+                const double y_gamma = try_point(ihi, gamma);
+                if (y_gamma < y_hi) replace_point(ihi, gamma, y_gamma);
+                else {
+                    for (int i = 0; i <= ndim; i++) {
+                        if (i != ilo) {
+                            for (int j = 0; j < ndim; j++) row(i)[j] = 0.5 * (row(i)[j] + row(ilo)[j]);
+                            y[i] = f->calc(row(i));
+                        }
+                    }
+                    fcount += ndim;
+                    update_sum();
+                }
+            }
+        }
+        return y[0];
+    }
+};
+}  // namespace
+
+double cv::DownhillSolver::minimize(cv::Mat &x)
+{
+    NM nm;
+    nm.f = f_.get();
+    nm.ndim = f_->getDims();
+    const int n = nm.ndim;
+    nm.p.assign((size_t)(n + 1) * n, 0.);
+    nm.sum.assign(n, 0.);
+    nm.buf.assign(n, 0.);
+    nm.y.assign(n + 1, 0.);
+    for (int j = 0; j < n; j++) nm.row(0)[j] = x.at<double>(j);
+    for (int i = 1; i <= n; i++) {
+        for (int j = 0; j < n; j++) nm.row(i)[j] = nm.row(0)[j];
+        nm.row(i)[i - 1] += 0.5 * step_.at<double>(i - 1);
+    }
+    for (int j = 0; j < n; j++) nm.row(0)[j] -= 0.5 * step_.at<double>(j);
+    const double res = nm.run(0.000001, 0.000001, 5000);
+    for (int j = 0; j < n; j++) x.at<double>(j) = nm.row(0)[j];
+    return res;
+}
 
 // cv::threshold(samples, samples, 0, 255, THRESH_OTSU + THRESH_BINARY_INV) on the 72 readings of Stag::readCode -- RESTATED
 // ("parity unpinned" for this function; the same routine, OpenCV 4.2 getThreshVal_Otsu_8u, is pinned through the golden
@@ -210,11 +368,29 @@ int ref_stag_detect_quads(const uint8_t *src, int w, int h, double *quads_out, i
 
 // Stag::detectMarkers (Stag.cpp:24-51) end to end.  markers_out: double [cap][24] = id, 8 corner coordinates, center (2),
 // H row-major (9), lineInf (3), projectiveDistortion.
-int ref_stag_detect_markers(const uint8_t *src, int w, int h, int library_hd, int error_correction, double *markers_out, int cap, int *n_out)
+int ref_stag_detect_markers(const uint8_t *src, int w, int h, int library_hd, int error_correction, int refine, double *markers_out, int cap,
+                            int *n_out)
 {
     cv::Mat image(h, w, CV_8UC1, const_cast<uint8_t *>(src));
     Stag stag(library_hd, error_correction, false);
-    stag.detectMarkers(image);
+    if (refine) {
+        stag.detectMarkers(image);
+    } else {  // Stag::detectMarkers without its last loop
+        stag.markers.clear();
+        stag.image = image;
+        stag.quadDetector.detectQuads(stag.image, &stag.edInterface);
+        std::vector<Quad> quads = stag.quadDetector.getQuads();
+        for (size_t i = 0; i < quads.size(); ++i) {
+            quads[i].estimateHomography();
+            Codeword c = stag.readCode(quads[i]);
+            int shift, id;
+            if (stag.decoder.decode(c, stag.errorCorrection, id, shift)) {
+                Marker marker(quads[i], id);
+                marker.shiftCorners2(shift);
+                stag.checkDuplicate(marker);
+            }
+        }
+    }
     const std::vector<Marker> m = stag.getMarkerList();
     for (size_t i = 0; i < m.size() && (int)i < cap; i++) {
         double *o = markers_out + 24 * i;

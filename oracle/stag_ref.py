@@ -185,14 +185,14 @@ def detect_quads(src: np.ndarray):
 MARKER_FIELDS = ("id", "corners", "center", "H", "lineInf", "projectiveDistortion")
 
 
-def detect_markers(src: np.ndarray, library_hd: int = 21, error_correction: int = 7):
-    """The reference's Stag::detectMarkers end to end (pose refinement stubbed until row s9 exists).  Returns float64 [n][24]:
-    id, corners (8), center (2), H (9), lineInf (3), projectiveDistortion."""
+def detect_markers(src: np.ndarray, library_hd: int = 21, error_correction: int = 7, refine: bool = True):
+    """The reference's Stag::detectMarkers end to end (refine=False: stopped in front of PoseRefiner::refineMarkerPose).
+    Returns float64 [n][24]: id, corners (8), center (2), H (9), lineInf (3), projectiveDistortion."""
     im = np.ascontiguousarray(src, dtype=np.uint8)
     h, w = im.shape
     out = np.zeros((4096, 24), np.float64)
     n = C.c_int(0)
-    rc = lib().ref_stag_detect_markers(im.ctypes.data_as(C.c_void_p), w, h, library_hd, error_correction,
+    rc = lib().ref_stag_detect_markers(im.ctypes.data_as(C.c_void_p), w, h, library_hd, error_correction, int(refine),
                                        out.ctypes.data_as(C.c_void_p), len(out), C.byref(n))
     assert rc == 0
     return out[:n.value].copy()

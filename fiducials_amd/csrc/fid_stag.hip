@@ -2200,6 +2200,182 @@ __global__ __launch_bounds__(64) void k_stag_refine(fid_stag_marker *__restrict_
     markers[m] = M;
 }
 
+// ------------------------------------------------------------------------------------------------ K17: marker pose
+// StagNode::imageCallback -> Common::solvePnpSingle (stag_detect.cpp:140-165, common.hpp:34-46): cv::solvePnP (ITERATIVE) on
+// FIVE coplanar points, the marker centre (0, 0, 0) and the four corners (-h, h) (h, h) (h, -h) (-h, -h), h = float(marker_size /
+// 2).  Same scheme as the aruco pose kernel (fid_kernels.hip K8): closed-form start from the four corners, then the reference's
+// Levenberg-Marquardt (CvLevMarq: <= 20 iterations, lambda 1e-3 x 10^k, same accept / reject rule) on the reprojection error
+// of all five points with distortion; a 16-lane group per marker, lane g < 10 owns residual g.  Tolerance row (the reference
+// starts from a 5-point DLT + refinement; both land on the same minimum).
+__device__ __forceinline__ double grp_sum16(double v)
+{
+    v += shfl_xor_f64(v, 1);
+    v += shfl_xor_f64(v, 2);
+    v += shfl_xor_f64(v, 4);
+    v += shfl_xor_f64(v, 8);
+    return v;
+}
+
+__device__ void sp_undistort(const double K[9], const double kd[5], double u, double v, double *ox, double *oy)
+{
+    const double fx = K[0], fy = K[4], ifx = 1. / fx, ify = 1. / fy, cx = K[2], cy = K[5];
+    double x = (u - cx) * ifx, y = (v - cy) * ify;
+    const double x0 = x, y0 = y;
+    for (int j = 0; j < 5; j++) {
+        const double r2 = x * x + y * y;
+        const double icdist = (1) / (1 + ((kd[4] * r2 + kd[1]) * r2 + kd[0]) * r2);
+        if (icdist < 0) {
+            x = (u - cx) * ifx;
+            y = (v - cy) * ify;
+            break;
+        }
+        const double deltaX = 2 * kd[2] * x * y + kd[3] * (r2 + 2 * x * x);
+        const double deltaY = kd[2] * (r2 + 2 * y * y) + 2 * kd[3] * x * y;
+        x = (x0 - deltaX) * icdist;
+        y = (y0 - deltaY) * icdist;
+    }
+    *ox = x;
+    *oy = y;
+}
+
+__global__ __launch_bounds__(64) void k_stag_pose(const fid_stag_marker *__restrict__ markers, const int *__restrict__ nmarkers, PoseCam cam,
+                                                  double marker_size, fid_stag_pose_out *__restrict__ out)
+{
+    const int item = blockIdx.x * 4 + (threadIdx.x >> 4), g = threadIdx.x & 15;
+    if (item >= *nmarkers) return;  // group-uniform
+    const fid_stag_marker mk = markers[item];
+    const double *K = cam.K, *kd = cam.D;
+    const float halff = (float)(marker_size / 2.0);
+    const double hx = (double)halff;
+    const bool act = g < 10;
+    const int pi = act ? g >> 1 : 0, sel = g & 1;
+    // object point of this lane: 0 centre, 1..4 corners
+    double M[3] = {0., 0., 0.};
+    if (pi >= 1) {
+        M[0] = (pi == 2 || pi == 3) ? hx : -hx;
+        M[1] = (pi <= 2) ? hx : -hx;
+    }
+    const double mobs = pi == 0 ? mk.center[sel] : mk.corners[2 * (pi - 1) + sel];
+    double param[6];
+    {
+        double mnx[4], mny[4];
+        for (int i = 0; i < 4; i++) {
+            double x, y;
+            sp_undistort(K, kd, mk.corners[2 * i], mk.corners[2 * i + 1], &x, &y);
+            mnx[i] = x;
+            mny[i] = y;
+        }
+        // homography marker plane -> normalised image through the four corners (unit square -> quad, composed with
+        // (X, Y) -> ((X + h) / 2h, (h - Y) / 2h)), then R, t from its columns
+        const double x0 = mnx[0], y0 = mny[0], x1 = mnx[1], y1 = mny[1], x2 = mnx[2], y2 = mny[2], x3 = mnx[3], y3 = mny[3];
+        const double dx1 = x1 - x2, dx2 = x3 - x2, sx = x0 - x1 + x2 - x3;
+        const double dy1 = y1 - y2, dy2 = y3 - y2, sy = y0 - y1 + y2 - y3;
+        const double den = dx1 * dy2 - dy1 * dx2;
+        double h[9];
+        bool okh = den != 0.;
+        if (okh) {
+            const double gg = (sx * dy2 - sy * dx2) / den, hh = (dx1 * sy - dy1 * sx) / den;
+            const double a = x1 - x0 + gg * x1, b = x3 - x0 + hh * x3, c = x0;
+            const double d = y1 - y0 + gg * y1, e = y3 - y0 + hh * y3, ff = y0;
+            const double sc0 = 1. / (2. * hx);
+            h[0] = a * sc0;  h[1] = -b * sc0;  h[2] = 0.5 * a + 0.5 * b + c;
+            h[3] = d * sc0;  h[4] = -e * sc0;  h[5] = 0.5 * d + 0.5 * e + ff;
+            h[6] = gg * sc0; h[7] = -hh * sc0; h[8] = 0.5 * gg + 0.5 * hh + 1.;
+            okh = h[8] != 0.;
+            if (okh) {
+                const double sc = 1. / h[8];
+                for (int i = 0; i < 9; i++) h[i] *= sc;
+            }
+        }
+        double R[9];
+        param[3] = param[4] = param[5] = 0.;
+        if (okh) {
+            const double h1n = sqrt(h[0] * h[0] + h[3] * h[3] + h[6] * h[6]), h2n = sqrt(h[1] * h[1] + h[4] * h[4] + h[7] * h[7]);
+            const double s1 = 1. / fmax(h1n, DBL_EPSILON), s2 = 1. / fmax(h2n, DBL_EPSILON), stt = 2. / fmax(h1n + h2n, DBL_EPSILON);
+            param[3] = h[2] * stt; param[4] = h[5] * stt; param[5] = h[8] * stt;
+            h[0] *= s1; h[3] *= s1; h[6] *= s1;
+            h[1] *= s2; h[4] *= s2; h[7] *= s2;
+            h[2] = h[3] * h[7] - h[6] * h[4];
+            h[5] = h[6] * h[1] - h[0] * h[7];
+            h[8] = h[0] * h[4] - h[3] * h[1];
+            double rtmp[3], dummy[27];
+            rodrigues_m2v(h, rtmp);
+            rodrigues_v2m(rtmp, R, dummy, false);
+        } else {
+            for (int i = 0; i < 9; i++) R[i] = (i % 4 == 0) ? 1. : 0.;
+        }
+        rodrigues_m2v(R, param);
+    }
+    // ---- CvLevMarq over the 10 residuals
+    double prevParam[6], S[21], gJ[6], Jrow[6] = {0, 0, 0, 0, 0, 0};
+    double err = 0, prevErrNorm = 0, errNorm = 0;
+    int lambdaLg10 = -3, iters = 0, state = 1;
+    const double LOG10 = log(10.);
+    for (int i = 0; i < 6; i++) prevParam[i] = param[i];
+    for (;;) {
+        bool needJ = false, needErr = false;
+        if (state == 1) {
+            needJ = needErr = true;
+            state = 2;
+        } else if (state == 2) {
+            int idx = 0;
+            for (int a = 0; a < 6; a++) {
+                for (int b = a; b < 6; b++) S[idx++] = grp_sum16(Jrow[a] * Jrow[b]);
+                gJ[a] = grp_sum16(Jrow[a] * err);
+            }
+            for (int i = 0; i < 6; i++) prevParam[i] = param[i];
+            double xs[6];
+            solve6_spd(S, gJ, exp(lambdaLg10 * LOG10), xs);
+            for (int i = 0; i < 6; i++) param[i] = prevParam[i] - xs[i];
+            if (iters == 0) prevErrNorm = sqrt(grp_sum16(err * err));
+            needErr = true;
+            state = 3;
+        } else {
+            errNorm = sqrt(grp_sum16(err * err));
+            bool retry = false;
+            if (errNorm > prevErrNorm) {
+                if (++lambdaLg10 <= 16) {
+                    double xs[6];
+                    solve6_spd(S, gJ, exp(lambdaLg10 * LOG10), xs);
+                    for (int i = 0; i < 6; i++) param[i] = prevParam[i] - xs[i];
+                    needErr = true;
+                    state = 3;
+                    retry = true;
+                }
+            }
+            if (!retry) {
+                lambdaLg10 = lambdaLg10 - 1 > -16 ? lambdaLg10 - 1 : -16;
+                double dn = 0, pn = 0;
+                for (int i = 0; i < 6; i++) {
+                    dn += (param[i] - prevParam[i]) * (param[i] - prevParam[i]);
+                    pn += prevParam[i] * prevParam[i];
+                }
+                const double rel = sqrt(dn) / (sqrt(pn) + DBL_EPSILON);
+                if (++iters >= 20 || rel < FLT_EPSILON) break;
+                prevErrNorm = errNorm;
+                needJ = needErr = true;
+                state = 2;
+            }
+        }
+        if (!needErr) break;
+        const double pr = project_one(M, param, K, kd, sel, Jrow, needJ);
+        err = act ? pr - mobs : 0.;
+        if (!act)
+            for (int i = 0; i < 6; i++) Jrow[i] = 0.;
+    }
+    if (g == 0) {
+        fid_stag_pose_out o;
+        o.id = mk.id;
+        for (int i = 0; i < 3; i++) {
+            o.rvec[i] = param[i];
+            o.tvec[i] = param[3 + i];
+        }
+        double dummy[27];
+        rodrigues_v2m(param, o.R, dummy, false);  // cv::Rodrigues(rVec, rMat) of solvePnpSingle
+        out[item] = o;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ C-ABI
 // ---- host side of the line validation: the number-of-false-alarms table.  nfa() restates NFA.cpp:155-239 (the LSD
 // binomial-tail bound: log-gamma by Windschitl / Lanczos, series with a 10 % truncation tolerance); the table is what
@@ -2366,6 +2542,7 @@ struct fid_stag_ctx {
     int n_markers = 0;
     bool decoded = false;
     int *d_chosen = nullptr;
+    fid_stag_pose_out *d_poses = nullptr;
     int W = 0, H = 0;
     unsigned n_anchors = 0;
 };
@@ -2426,7 +2603,8 @@ fid_status fid_stag_create(int libraryHD, int errorCorrection, int max_width, in
     ok = ok && hipMalloc((void **)&c->d_locs, 72 * 3 * 8) == hipSuccess && hipMalloc((void **)&c->d_cand, (n / 9 + 16) * sizeof(fid_stag_marker)) == hipSuccess &&
          hipMalloc((void **)&c->d_markers, (n / 9 + 16) * sizeof(fid_stag_marker)) == hipSuccess &&
          hipMalloc((void **)&c->d_found, (n / 9 + 16) * 4) == hipSuccess && hipMalloc((void **)&c->d_nmarkers, 4) == hipSuccess;
-    ok = ok && hipMalloc((void **)&c->d_chosen, (n / 9 + 16) * 4) == hipSuccess;
+    ok = ok && hipMalloc((void **)&c->d_chosen, (n / 9 + 16) * 4) == hipSuccess &&
+         hipMalloc((void **)&c->d_poses, (n / 9 + 16) * sizeof(fid_stag_pose_out)) == hipSuccess;
     if (ok) {
         double locs[72 * 3];
         stag_fill_code_locations(locs);
@@ -2456,7 +2634,7 @@ void fid_stag_destroy(fid_stag_ctx *c)
                    c->d_prefix, c->d_lslots, c->d_lines, c->d_lcounts, c->d_ltotal,
                    c->d_atan_lut, c->d_kmin, c->d_lflags, c->d_vltotal, c->d_vlines,
                    c->d_lrange, c->d_corners, c->d_order, c->d_qcounts, c->d_qtotal, c->d_qslots, c->d_quads,
-                   c->d_locs, c->d_words, c->d_cand, c->d_markers, c->d_found, c->d_nmarkers, c->d_chosen};
+                   c->d_locs, c->d_words, c->d_cand, c->d_markers, c->d_found, c->d_nmarkers, c->d_chosen, c->d_poses};
     for (void *p : dev)
         if (p) (void)hipFree(p);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -2692,6 +2870,25 @@ fid_status fid_stag_detect_markers(fid_stag_ctx *c, const uint8_t *gray, int32_t
     }
     if (hipStreamSynchronize(st) != hipSuccess) return FID_E_HIP;
     return FID_OK;
+}
+
+fid_status fid_stag_pose_last(fid_stag_ctx *c, const double K[9], const double D[5], double marker_size, fid_stag_pose_out *out, int32_t cap,
+                              int32_t *n_out)
+{
+    if (!c || !K || !out || !c->decoded || !(marker_size > 0)) return FID_E_INVALID_ARG;
+    if (n_out) *n_out = c->n_markers;
+    if (c->n_markers > cap) return FID_E_CAPACITY;
+    if (c->n_markers == 0) return FID_OK;
+    if (hipSetDevice(c->device) != hipSuccess) return FID_E_HIP;
+    PoseCam cam;
+    for (int i = 0; i < 9; i++) cam.K[i] = K[i];
+    for (int i = 0; i < 5; i++) cam.D[i] = D ? D[i] : 0.0;
+    cam.fiducial_len = marker_size;
+    hipStream_t st = c->stream;
+    hipLaunchKernelGGL(k_stag_pose, dim3((c->n_markers + 3) / 4), dim3(64), 0, st, c->d_markers, c->d_nmarkers, cam, marker_size, c->d_poses);
+    if (hipGetLastError() != hipSuccess) return FID_E_HIP;
+    if (hipMemcpyAsync(out, c->d_poses, (size_t)c->n_markers * sizeof(fid_stag_pose_out), hipMemcpyDeviceToHost, st) != hipSuccess) return FID_E_HIP;
+    return hipStreamSynchronize(st) == hipSuccess ? FID_OK : FID_E_HIP;
 }
 
 int64_t fid_stag_tap_bytes(fid_stag_ctx *c, fid_stag_tap which)

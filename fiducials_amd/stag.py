@@ -16,6 +16,7 @@ from ._lib import FidError
 
 MARKER_DTYPE = np.dtype([("id", "i4"), ("shift", "i4"), ("corners", "f8", (4, 2)), ("center", "f8", (2,)), ("H", "f8", (3, 3)),
                          ("lineInf", "f8", (3,)), ("projectiveDistortion", "f8"), ("code", "u8")])
+POSE_DTYPE = np.dtype([("id", "i4"), ("reserved", "i4"), ("rvec", "f8", (3,)), ("tvec", "f8", (3,)), ("R", "f8", (3, 3))])
 QUAD_DTYPE = np.dtype([("corners", "f8", (4, 2)), ("lineInf", "f8", (3,)), ("projectiveDistortion", "f8")])
 LINE_DTYPE = np.dtype([("a", "f8"), ("b", "f8"), ("sx", "f8"), ("sy", "f8"), ("ex", "f8"), ("ey", "f8"), ("invert", "i4"),
                        ("segmentNo", "i4"), ("firstPixelIndex", "i4"), ("len", "i4")])
@@ -100,6 +101,17 @@ class StagDetector:
             raise FidError(rc, self._L.fid_strerror(rc).decode())
         self.shape = (h, w)
         return self.markers()
+
+    def pose_last(self, K, D, marker_size: float) -> np.ndarray:
+        """Common::solvePnpSingle for the markers of the last detect_markers*() call (POSE_DTYPE)."""
+        K = np.ascontiguousarray(K, dtype=np.float64).reshape(9)
+        Dv = np.zeros(5) if D is None else np.ascontiguousarray(D, dtype=np.float64).reshape(-1)[:5].copy()
+        out = np.zeros(4096, POSE_DTYPE)
+        n = C.c_int32(0)
+        rc = self._L.fid_stag_pose_last(self._ctx, K.ctypes.data, Dv.ctypes.data, float(marker_size), out.ctypes.data, len(out), C.byref(n))
+        if rc != _lib.FID_OK:
+            raise FidError(rc, self._L.fid_strerror(rc).decode())
+        return out[:n.value].copy()
 
     def markers(self) -> np.ndarray:
         return self.tap(TAP_MARKERS)

@@ -221,6 +221,13 @@ typedef struct fid_stag_marker {
     double projectiveDistortion;
     uint64_t code;      /* the 48 bits read (Stag::readCode) */
 } fid_stag_marker;
+/* what StagNode::imageCallback makes of a marker (stag_detect.cpp:140-209): the pose of Common::solvePnpSingle */
+typedef struct fid_stag_pose_out {
+    int32_t id;
+    int32_t reserved;
+    double rvec[3], tvec[3];
+    double R[9]; /* cv::Rodrigues(rvec), row-major: marker_pose(:, 0:3) */
+} fid_stag_pose_out;
 fid_status fid_stag_create(int32_t libraryHD, int32_t errorCorrection, int32_t max_width, int32_t max_height, int32_t device,
                            fid_stag_ctx **out);
 void fid_stag_destroy(fid_stag_ctx *ctx);
@@ -275,6 +282,10 @@ typedef enum fid_stag_tap {
     /* after fid_stag_detect_markers_unrefined: */
     FID_STAG_TAP_MARKERS = 15    /* fid_stag_marker [n]: Stag::markers before PoseRefiner::refineMarkerPose */
 } fid_stag_tap;
+/* Common::solvePnpSingle (stag_ros/common.hpp:34-46) for every marker of the last fid_stag_detect_markers* call: centre + four
+ * corners against (0,0,0), (-h,h,0), (h,h,0), (h,-h,0), (-h,-h,0), h = float(marker_size / 2) (stag_detect.cpp:144-162) */
+fid_status fid_stag_pose_last(fid_stag_ctx *ctx, const double K[9], const double D[5], double marker_size, fid_stag_pose_out *out,
+                              int32_t cap, int32_t *n_out);
 int64_t fid_stag_tap_bytes(fid_stag_ctx *ctx, fid_stag_tap which);
 fid_status fid_stag_tap_read(fid_stag_ctx *ctx, fid_stag_tap which, void *dst, int64_t dst_bytes);
 

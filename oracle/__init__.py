@@ -228,6 +228,21 @@ def solve_pnp_square(K, D, corners, marker_len):
     return r, t, e.value
 
 
+def solve_pnp_points(K, D, obj, img):
+    """cv::solvePnP(ITERATIVE) restated, double-precision points (n >= 4, coplanar).  Returns (rvec, tvec)."""
+    K = np.ascontiguousarray(K, dtype=np.float64).reshape(9)
+    Dp = None if D is None else np.ascontiguousarray(D, dtype=np.float64).reshape(5)
+    o = np.ascontiguousarray(obj, dtype=np.float64).reshape(-1, 3)
+    m = np.ascontiguousarray(img, dtype=np.float64).reshape(-1, 2)
+    r = np.zeros(3)
+    t = np.zeros(3)
+    rc = lib().ora_solve_pnp_d(K.ctypes.data_as(C.c_void_p), Dp.ctypes.data_as(C.c_void_p) if Dp is not None else None,
+                               o.ctypes.data_as(C.c_void_p), m.ctypes.data_as(C.c_void_p), len(o),
+                               r.ctypes.data_as(C.c_void_p), t.ctypes.data_as(C.c_void_p))
+    assert rc == 0, rc
+    return r, t
+
+
 def fiducial_area(corners) -> float:
     c = np.ascontiguousarray(corners, dtype=np.float32).reshape(8)
     return float(lib().ora_fiducial_area(c.ctypes.data_as(C.c_void_p)))

@@ -381,14 +381,33 @@ static double norm_l2(const double *v, int n)
 }
 
 /* calibration.cpp cvFindExtrinsicCameraParams2, useExtrinsicGuess = 0 */
+static int solve_pnp_core(const double K[9], const double D[5], const double *M, const double *m, int count, double rvec[3], double tvec[3]);
+
 int ora_solve_pnp(const double K[9], const double D[5], const float *obj3, const float *img2, int count,
                   double rvec[3], double tvec[3])
 {
     if (count < 4 || count > 32) return -1;
-    const int max_iter = 20;
-    double M[32 * 3], m[32 * 2], mn[32 * 2], Mxy[32 * 2];
+    double M[32 * 3], m[32 * 2];
     for (int i = 0; i < 3 * count; i++) M[i] = obj3[i];
     for (int i = 0; i < 2 * count; i++) m[i] = img2[i];
+    return solve_pnp_core(K, D, M, m, count, rvec, tvec);
+}
+
+/* the same with double-precision points: Common::solvePnpSingle of stag_detect hands solvePnP vector<Point3d> / vector<Point2d>
+ * (stag_ros/common.hpp:34-46).  For count > 4 OpenCV's findHomography additionally polishes the DLT homography with a few
+ * Levenberg-Marquardt steps before it is decomposed; that polish of the STARTING point is not restated here ("parity unpinned"
+ * for count > 4) -- the extrinsic refinement below starts next to the same minimum either way. */
+int ora_solve_pnp_d(const double K[9], const double D[5], const double *obj3, const double *img2, int count, double rvec[3],
+                    double tvec[3])
+{
+    if (count < 4 || count > 32) return -1;
+    return solve_pnp_core(K, D, obj3, img2, count, rvec, tvec);
+}
+
+static int solve_pnp_core(const double K[9], const double D[5], const double *M, const double *m, int count, double rvec[3], double tvec[3])
+{
+    const int max_iter = 20;
+    double mn[32 * 2], Mxy[32 * 2];
     undistort_points(m, count, K, D, mn);
 
     double Mc[3] = {0, 0, 0}, MM[9] = {0}, W[3], V[9], R[9], param[6] = {0, 0, 0, 0, 0, 0};

@@ -370,6 +370,40 @@ def test_detect_markers_refined_matches_reference(hd, ec, size, n, seed):
         det.close()
 
 
+def test_marker_pose_matches_oracle():
+    """Row s10: Common::solvePnpSingle on centre + four corners (5 coplanar points), against the oracle's restatement of
+    cv::solvePnP(ITERATIVE) fed with the same markers: rotation matrix / tvec to 1e-6 (the device starts its Levenberg-Marquardt from a
+    closed-form 4-corner pose, the oracle from the 5-point DLT: same minimum), and against the generator's pose to 2 %."""
+    import oracle
+    from fiducials_amd import synth
+    words = fstag.load_library(21)
+    fr = synth.make_stag_frame(words, 7, 1920, 1080, 20)
+    K = np.array([[1400.0, 0, 960.0], [0, 1400.0, 540.0], [0, 0, 1]])
+    D = np.array([0.05, -0.02, 0.001, -0.0005, 0.0])
+    size = synth.MARKER_LEN
+    det = fstag.StagDetector(21, 7, max_width=1920, max_height=1080)
+    try:
+        M = det.detect_markers(fr.image)
+        assert len(M) >= 6
+        for Dv in (np.zeros(5), D):
+            P = det.pose_last(K, Dv, size)
+            assert np.array_equal(P["id"], M["id"])
+            h = float(np.float32(size / 2.0))
+            obj = np.array([[0, 0, 0], [-h, h, 0], [h, h, 0], [h, -h, 0], [-h, -h, 0]], float)
+            for k in range(len(M)):
+                img = np.concatenate([M["center"][k][None, :], M["corners"][k]], axis=0)
+                r, t = oracle.solve_pnp_points(K, Dv, obj, img)
+                # the node uses the rotation MATRIX (common.hpp:43); near a half turn the same rotation has two vectors
+                assert np.abs(P["R"][k] - synth._rodrigues(r)).max() < 1e-6 and np.abs(P["tvec"][k] - t).max() < 1e-6, (k, P["rvec"][k], r)
+                assert np.abs(P["R"][k] - synth._rodrigues(P["rvec"][k])).max() < 1e-12
+        P = det.pose_last(K, np.zeros(5), size)
+        for k in range(len(M)):  # the rendered distance (several markers may share an id: the nearest one counts)
+            cand = [np.linalg.norm(P["tvec"][k] - fr.tvecs[j]) / np.linalg.norm(fr.tvecs[j]) for j in np.flatnonzero(fr.ids == M["id"][k])]
+            assert min(cand) < 0.02, (k, cand)
+    finally:
+        det.close()
+
+
 def test_stag_status_codes():
     from fiducials_amd import _lib
     from fiducials_amd._lib import FidError

@@ -298,6 +298,12 @@ struct StagRouter {
     StagRoute R;
     int noSegments, totalPixels, overflow;
     int segbase, nsp;  // the segment being assembled: first pixel in outpix, pixels so far
+    // component-parallel routing: outpix is the component's own arena and "the pixel in front of the block" is the last pixel
+    // of the block the reference would have written just before this one -- known (and relevant) only if that block came from
+    // the same component
+    bool par = false, prev_valid = false;
+    int blk0 = 0;  // where the current anchor's block starts in outpix
+    int wl_len = 0, wl_dup = 0, wl_chains = 0;  // what walk_anchor() left behind
 
     __device__ int2 cpx(int ch, int i) const
     {
@@ -307,6 +313,7 @@ struct StagRouter {
     __device__ int2 seg(int i) const
     {
         const int k = segbase + i;
+        if (par && k < blk0) return (prev_valid && k >= 0) ? R.outpix[k] : make_int2(-1000, -1000);  // in front of this anchor's block
         return k >= 0 ? R.outpix[k] : make_int2(-1000, -1000);
     }
     __device__ void seg_put(int2 v)
@@ -413,6 +420,12 @@ struct StagRouter {
 
     __device__ void route_anchor(int r0, int c0, int grad_thresh)
     {
+        if (walk_anchor(r0, c0, grad_thresh)) extract_anchor(wl_chains);
+    }
+
+    // the walk: true if the anchor produced a path that is kept (the chain tree is then in R.chains / R.pix)
+    __device__ bool walk_anchor(int r0, int c0, int grad_thresh)
+    {
         const int W = R.W;
         StagChain *ch = R.chains;
         ch[0].dir = 0; ch[0].len = 0; ch[0].parent = -1; ch[0].child[0] = ch[0].child[1] = -1; ch[0].pix = -1;
@@ -485,11 +498,21 @@ struct StagRouter {
             ch[parent].child[slot] = (int16_t)cur;
             noChains++;
         }
+        wl_len = len;
+        wl_dup = dup;
+        wl_chains = noChains;
         if (len - dup < STAG_MIN_PATH_LEN) {
             for (int k = 0; k < len; k++) R.edge[R.pix[k].x * W + R.pix[k].y] = 0;
-            return;
+            return false;
         }
-        // ---- the chain tree -> segments
+        return true;
+    }
+
+    // the chain tree -> segments
+    __device__ void extract_anchor(int noChains)
+    {
+        StagChain *ch = R.chains;
+        blk0 = totalPixels;
         segbase = totalPixels;
         nsp = 0;
         int totalLen = longest(ch[0].child[1]);
@@ -543,6 +566,341 @@ __global__ __launch_bounds__(64) void k_stag_route_seq(StagRoute R, const int32_
     R.counters[0] = S.noSegments;
     R.counters[1] = S.totalPixels;
     R.counters[2] = S.overflow;
+}
+
+// ---- component-parallel routing ---------------------------------------------------------------------------------
+// A walk only ever stands on pixels with grad >= GRADIENT_THRESH (it stops in front of anything weaker) and only touches the
+// edge image at those pixels and their walked neighbours' cross pixels, which are anchors, hence also >= the threshold: walks
+// of different 8-connected components of {grad >= GRADIENT_THRESH} never read or write the same pixel.  So every component
+// can process ITS anchors, strongest first, on its own -- the edge image and every chain tree come out as in the reference's
+// single sequential loop.  What remains global is the ORDER of the output (segments are listed in the order their anchors
+// were processed) and one quirk: when a block of segments starts, the reference peeks at the pixel in front of it in the
+// contiguous pixel array, i.e. at the last pixel of the block before -- which can only matter (8-adjacency) if that block
+// belongs to the same component.  Hence two passes:
+//   k_stag_ccl_*          connected components by union-find with atomic hooking (labels = smallest pixel offset)
+//   k_stag_comp_*         per component: pixels, anchors -> arenas (scratch pixels, stack, chains, output) by atomic cursors;
+//                         its anchors gathered and sorted by rank (bitonic, one wave per component)
+//   k_stag_route_walk     one LANE per component: the walks; chain trees of producing anchors stay in the arenas
+//   k_stag_next_above     for every anchor rank, the nearest producing rank above it (decides the quirk)
+//   k_stag_route_extract  one lane per component: chain trees -> blocks of segments in the component's output arena
+//   k_stag_route_gather   blocks -> EdgeMap::pixels / segments in global anchor order (offsets from two scans)
+struct StagComp {
+    int root, size, nanch;
+    int anch_base, anch_cap;      // slice of the anchor-rank array (padded to a power of two for the sort)
+    int pix_base, pix_cap;        // scratch pixels (chain trees of the producing anchors are kept)
+    int stack_base, stack_cap;
+    int chain_base, chain_cap;
+    int out_base, out_cap;        // output pixels of this component's blocks; chainNos live in the stack arena's tail
+    int seg_base, seg_cap;
+    int nrec;                     // producing anchors
+};
+
+struct StagRec {  // one producing anchor
+    int rank;
+    int pix_off, len;       // its chain-tree pixels inside the component's scratch arena
+    int chain_off, nchains;
+    int out_off, out_len;   // its block inside the component's output arena
+    int seg_off, nsegs;     // its segments inside the component's segment arena
+};
+
+__device__ __forceinline__ int ccl_find(const int *L, int a)
+{
+    while (true) {
+        const int p = L[a];
+        if (p == a) return a;
+        a = p;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_stag_ccl_init(const int16_t *__restrict__ grad, int n, int thresh, int *__restrict__ label)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) label[i] = grad[i] >= thresh ? i : -1;
+}
+
+__global__ __launch_bounds__(256) void k_stag_ccl_merge(int W, int H, int *label)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= W * H || label[i] < 0) return;
+    const int r = i / W, c = i - r * W;
+    // the four neighbours that precede the pixel in raster order (border pixels are background: grad = thresh - 1)
+    const int nb[4] = {c > 0 ? i - 1 : -1, (r > 0 && c > 0) ? i - W - 1 : -1, r > 0 ? i - W : -1, (r > 0 && c < W - 1) ? i - W + 1 : -1};
+    for (int k = 0; k < 4; k++) {
+        int b = nb[k];
+        if (b < 0 || label[b] < 0) continue;
+        int a = i;
+        while (true) {
+            a = ccl_find(label, a);
+            b = ccl_find(label, b);
+            if (a == b) break;
+            if (a < b) {
+                const int t = a;
+                a = b;
+                b = t;
+            }
+            const int old = atomicMin(&label[a], b);  // hook the larger root under the smaller one
+            if (old == a) break;
+            a = old;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_stag_ccl_flatten(int n, int *label, const uint8_t *__restrict__ anchors, int *__restrict__ csize,
+                                                          int *__restrict__ canch)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n || label[i] < 0) return;
+    const int root = ccl_find(label, i);
+    label[i] = root;
+    atomicAdd(&csize[root], 1);
+    if (anchors[i] == STAG_ANCHOR_PIXEL) atomicAdd(&canch[root], 1);
+}
+
+// cursors: [0] components [1] anchor slots [2] scratch pixels [3] stack [4] chains [5] output pixels [6] segments [7] overflow
+__global__ __launch_bounds__(256) void k_stag_comp_alloc(int n, const int *__restrict__ label, const int *__restrict__ csize,
+                                                         const int *__restrict__ canch, int *__restrict__ cursors, int max_comps, const int *caps,
+                                                         StagComp *__restrict__ comps, int *__restrict__ cidmap)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n || label[i] != i) return;
+    cidmap[i] = -1;
+    const int na = canch[i], sz = csize[i];
+    if (na == 0) return;
+    const int cid = atomicAdd(&cursors[0], 1);
+    if (cid >= max_comps) {
+        atomicOr(&cursors[7], 1);
+        return;
+    }
+    StagComp C;
+    C.root = i; C.size = sz; C.nanch = na; C.nrec = 0;
+    int p2 = 1;
+    while (p2 < na) p2 <<= 1;
+    C.anch_cap = p2;
+    C.pix_cap = 2 * sz + 12 * na + 64;
+    C.stack_cap = (sz + 2 * na + 64) + (sz / 4 + 64);  // pending branches + (in its tail) the chain lists of the extraction
+    C.chain_cap = sz + 2 * na + 64;
+    C.out_cap = C.pix_cap;
+    C.seg_cap = C.pix_cap / 8 + na + 8;
+    C.anch_base = atomicAdd(&cursors[1], C.anch_cap);
+    C.pix_base = atomicAdd(&cursors[2], C.pix_cap);
+    C.stack_base = atomicAdd(&cursors[3], C.stack_cap);
+    C.chain_base = atomicAdd(&cursors[4], C.chain_cap);
+    C.out_base = atomicAdd(&cursors[5], C.out_cap);
+    C.seg_base = atomicAdd(&cursors[6], C.seg_cap);
+    if (C.anch_base + C.anch_cap > caps[1] || C.pix_base + C.pix_cap > caps[2] || C.stack_base + C.stack_cap > caps[3] ||
+        C.chain_base + C.chain_cap > caps[4] || C.out_base + C.out_cap > caps[5] || C.seg_base + C.seg_cap > caps[6]) {
+        atomicOr(&cursors[7], 2);
+        C.nanch = 0;  // not processed; the call reports FID_E_CAPACITY
+    }
+    comps[cid] = C;
+    cidmap[i] = cid;
+}
+
+__global__ __launch_bounds__(256) void k_stag_comp_fill(const int32_t *__restrict__ sorted, const unsigned *__restrict__ n_anchors,
+                                                        const int *__restrict__ label, const int *__restrict__ cidmap, const StagComp *__restrict__ comps,
+                                                        int *__restrict__ fill, int *__restrict__ aslots)
+{
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= (int)*n_anchors) return;
+    const int cid = cidmap[label[sorted[r]]];
+    if (cid < 0 || comps[cid].nanch == 0) return;
+    const int pos = atomicAdd(&fill[cid], 1);
+    aslots[comps[cid].anch_base + pos] = r;
+}
+
+// ranks of one component, descending: bitonic sort of the (padded, -1 filled) slice, one wave per component
+__global__ __launch_bounds__(256) void k_stag_comp_sort(const StagComp *__restrict__ comps, const int *__restrict__ cursors, int *aslots)
+{
+    const int cid = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (cid >= cursors[0]) return;
+    const StagComp C = comps[cid];
+    if (C.nanch < 2) return;
+    int *a = aslots + C.anch_base;
+    const int P = C.anch_cap;
+    for (int k = 2; k <= P; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = lane; i < P; i += 64) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const int x = a[i], y = a[l];
+                    const bool desc = (i & k) == 0;
+                    if (desc ? x < y : x > y) {
+                        a[i] = y;
+                        a[l] = x;
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+    }
+}
+
+struct StagArenas {
+    int2 *pix;
+    int4 *stack;
+    StagChain *chains;
+    int2 *out;
+    int2 *segs;
+    StagRec *recs;  // indexed like the anchor slots
+};
+
+__device__ void stag_bind(StagRouter &S, const StagRoute &G, const StagArenas &A, const StagComp &C)
+{
+    S.R = G;
+    S.R.pix = A.pix + C.pix_base;
+    S.R.capPix = C.pix_cap;
+    S.R.stack = A.stack + C.stack_base;
+    S.R.capStack = C.stack_cap - (C.size / 4 + 64);
+    S.R.chainNos = (int *)(A.stack + C.stack_base + S.R.capStack);  // int view of the arena's tail: 4 ints per entry
+    S.R.capNos = (C.size / 4 + 64) * 4;
+    S.R.chains = A.chains + C.chain_base;
+    S.R.capChains = C.chain_cap < 32767 ? C.chain_cap : 32767;
+    S.R.outpix = A.out + C.out_base;
+    S.R.capOut = C.out_cap;
+    S.R.segs = A.segs + C.seg_base;
+    S.R.capSegs = C.seg_cap;
+    S.par = true;
+}
+
+__global__ __launch_bounds__(64) void k_stag_route_walk(StagRoute G, StagArenas A, StagComp *__restrict__ comps, const int *__restrict__ cursors,
+                                                        const int32_t *__restrict__ sorted, const int *__restrict__ aslots, int grad_thresh,
+                                                        int *__restrict__ prodflag, int *__restrict__ ovf)
+{
+    const int cid = blockIdx.x * 64 + threadIdx.x;
+    if (cid >= cursors[0]) return;
+    StagComp C = comps[cid];
+    if (C.nanch == 0) return;
+    StagRouter S;
+    stag_bind(S, G, A, C);
+    S.noSegments = S.totalPixels = S.overflow = 0;
+    S.segbase = S.nsp = 0;
+    StagRec *recs = A.recs + C.anch_base;
+    int nrec = 0, pix_used = 0, chain_used = 0;
+    const int2 *pix0 = S.R.pix;
+    StagChain *chain0 = S.R.chains;
+    const int capPix0 = S.R.capPix, capChain0 = C.chain_cap;
+    for (int k = 0; k < C.nanch; k++) {
+        const int rank = aslots[C.anch_base + k];
+        const int off = sorted[rank];
+        if (G.edge[off] != STAG_ANCHOR_PIXEL) continue;
+        S.R.pix = const_cast<int2 *>(pix0) + pix_used;
+        S.R.capPix = capPix0 - pix_used;
+        S.R.chains = chain0 + chain_used;
+        const int left = capChain0 - chain_used;
+        S.R.capChains = left < 32767 ? left : 32767;
+        if (S.R.capPix < 16 || S.R.capChains < 4) {
+            S.overflow |= 32;
+            break;
+        }
+        const bool keep = S.walk_anchor(off / G.W, off % G.W, grad_thresh);
+        if (S.overflow) break;
+        if (keep) {
+            StagRec r;
+            r.rank = rank; r.pix_off = pix_used; r.len = S.wl_len; r.chain_off = chain_used; r.nchains = S.wl_chains;
+            r.out_off = r.out_len = r.seg_off = r.nsegs = 0;
+            recs[nrec++] = r;
+            prodflag[rank] = 1;
+            pix_used += S.wl_len + 1;  // (+1: the walk may have parked one pixel past len)
+            chain_used += S.wl_chains;
+        }
+    }
+    comps[cid].nrec = nrec;
+    if (S.overflow) atomicOr(ovf, S.overflow);
+}
+
+// next[r] = the smallest producing rank > r, or -1 (one workgroup, chunks of 1024 from the top)
+__global__ __launch_bounds__(1024) void k_stag_next_above(const int *__restrict__ prodflag, const unsigned *__restrict__ n_anchors, int *__restrict__ next)
+{
+    __shared__ int s[1024];
+    __shared__ int s_carry;
+    const int tid = threadIdx.x, n = (int)*n_anchors;
+    if (tid == 0) s_carry = -1;
+    __syncthreads();
+    for (int top = n; top > 0; top -= 1024) {
+        // thread t looks at rank r = top - 1 - t: ranks run downwards with t
+        const int r = top - 1 - tid;
+        const int v = (r >= 0 && prodflag[r]) ? r : -1;
+        // for every t: the producing rank with the largest t' < t (= nearest above), i.e. an exclusive "last set" scan
+        s[tid] = v;
+        __syncthreads();
+        for (int d = 1; d < 1024; d <<= 1) {
+            const int o = tid >= d ? s[tid - d] : -1;
+            __syncthreads();
+            if (s[tid] < 0) s[tid] = o;  // keep the nearest (largest t') set value: own slot wins, else what came from the left
+            __syncthreads();
+        }
+        // s[t] = nearest producing rank at t' <= t; exclusive: t' < t
+        const int incl_prev = tid > 0 ? s[tid - 1] : -1;
+        const int carry = s_carry;
+        if (r >= 0) next[r] = incl_prev >= 0 ? incl_prev : carry;
+        __syncthreads();
+        if (tid == 1023) s_carry = s[1023] >= 0 ? s[1023] : carry;
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(64) void k_stag_route_extract(StagRoute G, StagArenas A, const StagComp *__restrict__ comps, const int *__restrict__ cursors,
+                                                           const int *__restrict__ next, const unsigned *__restrict__ n_anchors,
+                                                           int *__restrict__ blk_pix, int *__restrict__ blk_segs, int2 *__restrict__ blk_where,
+                                                           int *__restrict__ ovf)
+{
+    const int cid = blockIdx.x * 64 + threadIdx.x;
+    if (cid >= cursors[0]) return;
+    const StagComp C = comps[cid];
+    if (C.nanch == 0 || C.nrec == 0) return;
+    StagRouter S;
+    stag_bind(S, G, A, C);
+    S.noSegments = S.totalPixels = S.overflow = 0;
+    S.segbase = S.nsp = 0;
+    StagRec *recs = A.recs + C.anch_base;
+    int2 *pix0 = S.R.pix;
+    StagChain *chain0 = S.R.chains;
+    const int n = (int)*n_anchors;
+    int prev_rank = -1;
+    for (int k = 0; k < C.nrec; k++) {
+        StagRec r = recs[k];
+        S.R.pix = pix0 + r.pix_off;
+        S.R.chains = chain0 + r.chain_off;
+        // the block the reference wrote just before this one: ours only if no other component produced in between
+        S.prev_valid = k > 0 && next[r.rank] == prev_rank;
+        const int seg0 = S.noSegments, out0 = S.totalPixels;
+        S.extract_anchor(r.nchains);
+        r.out_off = out0; r.out_len = S.totalPixels - out0;
+        r.seg_off = seg0; r.nsegs = S.noSegments - seg0;
+        recs[k] = r;
+        const int q = n - 1 - r.rank;  // position in processing order
+        blk_pix[q] = r.out_len;
+        blk_segs[q] = r.nsegs;
+        blk_where[q] = make_int2(cid, k);
+        prev_rank = r.rank;
+        if (S.overflow) break;
+    }
+    if (S.overflow) atomicOr(ovf, S.overflow);
+}
+
+// blk_pix / blk_segs hold exclusive prefix sums by now: copy every block to its place in the global order
+__global__ __launch_bounds__(256) void k_stag_route_gather(StagArenas A, const StagComp *__restrict__ comps, const unsigned *__restrict__ n_anchors,
+                                                           const int *__restrict__ prodflag, const int *__restrict__ blk_pix,
+                                                           const int *__restrict__ blk_segs, const int2 *__restrict__ blk_where,
+                                                           int2 *__restrict__ outpix, int2 *__restrict__ segs, int capOut, int capSegs, int *__restrict__ ovf)
+{
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int n = (int)*n_anchors;
+    if (q >= n || !prodflag[n - 1 - q]) return;
+    const int2 w = blk_where[q];
+    const StagComp C = comps[w.x];
+    const StagRec r = (A.recs + C.anch_base)[w.y];
+    const int po = blk_pix[q], so = blk_segs[q];
+    if (po + r.out_len > capOut || so + r.nsegs > capSegs) {
+        if (lane == 0) atomicOr(ovf, 64);
+        return;
+    }
+    const int2 *src = A.out + C.out_base + r.out_off;
+    for (int i = lane; i < r.out_len; i += 64) outpix[po + i] = src[i];
+    const int2 *sg = A.segs + C.seg_base + r.seg_off;
+    for (int i = lane; i < r.nsegs; i += 64) segs[so + i] = make_int2(sg[i].x - r.out_off + po, sg[i].y);
 }
 
 // ------------------------------------------------------------------------------------------------ K11: segment validation
@@ -2504,6 +2862,15 @@ struct fid_stag_ctx {
     int *d_chainnos = nullptr, *d_rcount = nullptr;
     int rcount[3] = {0, 0, 0};
     bool routed = false;
+    // component-parallel routing
+    int *d_label = nullptr, *d_csize = nullptr, *d_canch = nullptr, *d_cidmap = nullptr, *d_cursors = nullptr, *d_caps = nullptr;
+    int *d_fill = nullptr, *d_aslots = nullptr, *d_prodflag = nullptr, *d_next = nullptr, *d_blkpix = nullptr, *d_blksegs = nullptr;
+    int2 *d_blkwhere = nullptr, *d_apix = nullptr, *d_aout = nullptr, *d_asegs = nullptr;
+    int4 *d_astack = nullptr;
+    StagChain *d_achains = nullptr;
+    StagComp *d_comps = nullptr;
+    StagRec *d_recs = nullptr;
+    int max_comps = 0, cap_aslots = 0, route_mode = 1, route_fallbacks = 0;
     // validation
     uint8_t *d_smooth2 = nullptr;
     int16_t *d_vgrad = nullptr;
@@ -2581,6 +2948,26 @@ fid_status fid_stag_create(int libraryHD, int errorCorrection, int max_width, in
          hipMalloc((void **)&c->d_rstack, n * sizeof(int4)) == hipSuccess && hipMalloc((void **)&c->d_chains, 32767 * sizeof(StagChain)) == hipSuccess &&
          hipMalloc((void **)&c->d_chainnos, (size_t)(max_width + max_height) * 8 * sizeof(int)) == hipSuccess &&
          hipMalloc((void **)&c->d_rcount, 16) == hipSuccess;
+    // component-parallel routing: labels, per-root counters, component table, arenas (sizes in entries; see k_stag_comp_alloc)
+    c->max_comps = (int)(n / 8 + 64);
+    c->cap_aslots = (int)(n / 2 + 64);
+    ok = ok && hipMalloc((void **)&c->d_label, n * 4) == hipSuccess && hipMalloc((void **)&c->d_csize, n * 4) == hipSuccess &&
+         hipMalloc((void **)&c->d_canch, n * 4) == hipSuccess && hipMalloc((void **)&c->d_cidmap, n * 4) == hipSuccess &&
+         hipMalloc((void **)&c->d_cursors, 64) == hipSuccess && hipMalloc((void **)&c->d_caps, 64) == hipSuccess &&
+         hipMalloc((void **)&c->d_fill, (size_t)c->max_comps * 4) == hipSuccess && hipMalloc((void **)&c->d_aslots, (size_t)c->cap_aslots * 4) == hipSuccess &&
+         hipMalloc((void **)&c->d_prodflag, n * 4) == hipSuccess && hipMalloc((void **)&c->d_next, n * 4) == hipSuccess &&
+         hipMalloc((void **)&c->d_blkpix, n * 4) == hipSuccess && hipMalloc((void **)&c->d_blksegs, n * 4) == hipSuccess &&
+         hipMalloc((void **)&c->d_blkwhere, n * sizeof(int2)) == hipSuccess && hipMalloc((void **)&c->d_apix, 3 * n * sizeof(int2)) == hipSuccess &&
+         hipMalloc((void **)&c->d_aout, 3 * n * sizeof(int2)) == hipSuccess && hipMalloc((void **)&c->d_asegs, (n / 2 + 64) * sizeof(int2)) == hipSuccess &&
+         hipMalloc((void **)&c->d_astack, 2 * n * sizeof(int4)) == hipSuccess && hipMalloc((void **)&c->d_achains, 2 * n * sizeof(StagChain)) == hipSuccess &&
+         hipMalloc((void **)&c->d_comps, (size_t)c->max_comps * sizeof(StagComp)) == hipSuccess &&
+         hipMalloc((void **)&c->d_recs, (size_t)c->cap_aslots * sizeof(StagRec)) == hipSuccess;
+    if (ok) {
+        const int caps[16] = {c->max_comps, c->cap_aslots, (int)(3 * n), (int)(2 * n), (int)(2 * n), (int)(3 * n), (int)(n / 2 + 64), 0};
+        ok = hipMemcpy(c->d_caps, caps, sizeof(caps), hipMemcpyHostToDevice) == hipSuccess;
+        const char *e = getenv("FID_STAG_ROUTE");
+        c->route_mode = (e && !strcmp(e, "seq")) ? 0 : 1;
+    }
     ok = ok && hipMalloc((void **)&c->d_smooth2, n) == hipSuccess && hipMalloc((void **)&c->d_vgrad, n * 2) == hipSuccess &&
          hipMalloc((void **)&c->d_vhist, STAG_BINS * 4) == hipSuccess && hipMalloc((void **)&c->d_prob, STAG_BINS * 8) == hipSuccess &&
          hipMalloc((void **)&c->d_np, 4) == hipSuccess && hipMalloc((void **)&c->d_vcounts, (n / 8 + 16) * 4) == hipSuccess &&
@@ -2630,6 +3017,8 @@ void fid_stag_destroy(fid_stag_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void *dev[] = {c->d_src, c->d_smooth, c->d_dir, c->d_edge, c->d_grad, c->d_sorted, c->d_rowhist, c->d_bandhist, c->d_tot, c->d_bstart, c->d_n,
                    c->d_edgeimg, c->d_rpix, c->d_outpix, c->d_segs, c->d_rstack, c->d_chains, c->d_chainnos, c->d_rcount,
+                   c->d_label, c->d_csize, c->d_canch, c->d_cidmap, c->d_cursors, c->d_caps, c->d_fill, c->d_aslots, c->d_prodflag, c->d_next,
+                   c->d_blkpix, c->d_blksegs, c->d_blkwhere, c->d_apix, c->d_aout, c->d_asegs, c->d_astack, c->d_achains, c->d_comps, c->d_recs,
                    c->d_smooth2, c->d_vgrad, c->d_vhist, c->d_prob, c->d_np, c->d_vcounts, c->d_vtotal, c->d_vstack, c->d_vsegs,
                    c->d_prefix, c->d_lslots, c->d_lines, c->d_lcounts, c->d_ltotal,
                    c->d_atan_lut, c->d_kmin, c->d_lflags, c->d_vltotal, c->d_vlines,
@@ -2669,6 +3058,70 @@ fid_status fid_stag_edge_frontend(fid_stag_ctx *c, const uint8_t *gray, int32_t 
     return FID_OK;
 }
 
+// sequential routing: one lane for the whole frame (the reference's loop as it stands)
+static fid_status stag_route_seq(fid_stag_ctx *c, const StagRoute &R)
+{
+    hipStream_t st = c->stream;
+    hipLaunchKernelGGL(k_stag_route_seq, dim3(1), dim3(64), 0, st, R, c->d_sorted, c->d_n, 16);
+    if (hipGetLastError() != hipSuccess) return FID_E_HIP;
+    if (hipMemcpyAsync(c->rcount, c->d_rcount, 12, hipMemcpyDeviceToHost, st) != hipSuccess) return FID_E_HIP;
+    if (hipStreamSynchronize(st) != hipSuccess) return FID_E_HIP;
+    return c->rcount[2] ? FID_E_CAPACITY : FID_OK;
+}
+
+// component-parallel routing; FID_E_CAPACITY if an arena was too small (the caller then takes the sequential road)
+static fid_status stag_route_par(fid_stag_ctx *c, const StagRoute &R)
+{
+    hipStream_t st = c->stream;
+    const int W = c->W, H = c->H, n = W * H, na = (int)c->n_anchors;
+    if (na == 0) {
+        c->rcount[0] = c->rcount[1] = c->rcount[2] = 0;
+        return hipMemsetAsync(c->d_rcount, 0, 12, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess ? FID_OK : FID_E_HIP;
+    }
+    const int nb = (n + 255) / 256;
+    bool ok = hipMemsetAsync(c->d_csize, 0, (size_t)n * 4, st) == hipSuccess && hipMemsetAsync(c->d_canch, 0, (size_t)n * 4, st) == hipSuccess &&
+              hipMemsetAsync(c->d_cursors, 0, 64, st) == hipSuccess && hipMemsetAsync(c->d_fill, 0, (size_t)c->max_comps * 4, st) == hipSuccess &&
+              hipMemsetAsync(c->d_aslots, 0xff, (size_t)c->cap_aslots * 4, st) == hipSuccess &&
+              hipMemsetAsync(c->d_prodflag, 0, (size_t)na * 4, st) == hipSuccess && hipMemsetAsync(c->d_blkpix, 0, (size_t)na * 4, st) == hipSuccess &&
+              hipMemsetAsync(c->d_blksegs, 0, (size_t)na * 4, st) == hipSuccess &&
+              hipMemsetAsync(c->d_aout, 0xff, (size_t)3 * n * sizeof(int2), st) == hipSuccess;
+    if (!ok) return FID_E_HIP;
+    hipLaunchKernelGGL(k_stag_ccl_init, dim3(nb), dim3(256), 0, st, c->d_grad, n, 16, c->d_label);
+    hipLaunchKernelGGL(k_stag_ccl_merge, dim3(nb), dim3(256), 0, st, W, H, c->d_label);
+    hipLaunchKernelGGL(k_stag_ccl_flatten, dim3(nb), dim3(256), 0, st, n, c->d_label, c->d_edge, c->d_csize, c->d_canch);
+    hipLaunchKernelGGL(k_stag_comp_alloc, dim3(nb), dim3(256), 0, st, n, c->d_label, c->d_csize, c->d_canch, c->d_cursors, c->max_comps, c->d_caps,
+                       c->d_comps, c->d_cidmap);
+    hipLaunchKernelGGL(k_stag_comp_fill, dim3((na + 255) / 256), dim3(256), 0, st, c->d_sorted, c->d_n, c->d_label, c->d_cidmap, c->d_comps, c->d_fill,
+                       c->d_aslots);
+    int cur[8];
+    if (hipMemcpyAsync(cur, c->d_cursors, 32, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return FID_E_HIP;
+    if (cur[7]) return FID_E_CAPACITY;
+    const int nc = cur[0];
+    StagArenas A;
+    A.pix = c->d_apix; A.stack = c->d_astack; A.chains = c->d_achains; A.out = c->d_aout; A.segs = c->d_asegs; A.recs = c->d_recs;
+    int *ovf = c->d_cursors + 8;
+    if (nc > 0) {
+        hipLaunchKernelGGL(k_stag_comp_sort, dim3((nc + 3) / 4), dim3(256), 0, st, c->d_comps, c->d_cursors, c->d_aslots);
+        hipLaunchKernelGGL(k_stag_route_walk, dim3((nc + 63) / 64), dim3(64), 0, st, R, A, c->d_comps, c->d_cursors, c->d_sorted, c->d_aslots, 16,
+                           c->d_prodflag, ovf);
+    }
+    hipLaunchKernelGGL(k_stag_next_above, dim3(1), dim3(1024), 0, st, c->d_prodflag, c->d_n, c->d_next);
+    if (nc > 0)
+        hipLaunchKernelGGL(k_stag_route_extract, dim3((nc + 63) / 64), dim3(64), 0, st, R, A, c->d_comps, c->d_cursors, c->d_next, c->d_n, c->d_blkpix,
+                           c->d_blksegs, c->d_blkwhere, ovf);
+    hipLaunchKernelGGL(k_stag_scan_counts, dim3(1), dim3(1024), 0, st, c->d_blkpix, (const int *)c->d_n, c->d_rcount + 1);
+    hipLaunchKernelGGL(k_stag_scan_counts, dim3(1), dim3(1024), 0, st, c->d_blksegs, (const int *)c->d_n, c->d_rcount);
+    hipLaunchKernelGGL(k_stag_route_gather, dim3((na + 3) / 4), dim3(256), 0, st, A, c->d_comps, c->d_n, c->d_prodflag, c->d_blkpix, c->d_blksegs,
+                       c->d_blkwhere, c->d_outpix, c->d_segs, R.capOut, R.capSegs, ovf);
+    if (hipGetLastError() != hipSuccess) return FID_E_HIP;
+    int o = 0;
+    if (hipMemcpyAsync(c->rcount, c->d_rcount, 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipMemcpyAsync(&o, ovf, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+        return FID_E_HIP;
+    c->rcount[2] = o;
+    return o ? FID_E_CAPACITY : FID_OK;
+}
+
 fid_status fid_stag_detect_edges(fid_stag_ctx *c, const uint8_t *gray, int32_t width, int32_t height, int32_t stride)
 {
     fid_status rc = fid_stag_edge_frontend(c, gray, width, height, stride);
@@ -2676,20 +3129,24 @@ fid_status fid_stag_detect_edges(fid_stag_ctx *c, const uint8_t *gray, int32_t w
     hipStream_t st = c->stream;
     const int W = c->W, H = c->H;
     const size_t n = (size_t)W * H;
-    if (hipMemcpyAsync(c->d_edgeimg, c->d_edge, n, hipMemcpyDeviceToDevice, st) != hipSuccess) return FID_E_HIP;
-    // pixels the routing has not written read as (-1, -1) (the reference reads uninitialised memory there)
-    if (hipMemsetAsync(c->d_outpix, 0xff, n * sizeof(int2), st) != hipSuccess) return FID_E_HIP;
     StagRoute R;
     R.grad = c->d_grad; R.dir = c->d_dir; R.edge = c->d_edgeimg; R.W = W; R.H = H;
     R.pix = c->d_rpix; R.stack = c->d_rstack; R.chains = c->d_chains; R.chainNos = c->d_chainnos;
     R.capPix = (int)((size_t)c->maxW * c->maxH); R.capStack = R.capPix; R.capChains = 32767; R.capNos = (c->maxW + c->maxH) * 8;
     R.outpix = c->d_outpix; R.segs = c->d_segs; R.capOut = R.capPix; R.capSegs = R.capPix / 8 + 16;
     R.counters = c->d_rcount;
-    hipLaunchKernelGGL(k_stag_route_seq, dim3(1), dim3(64), 0, st, R, c->d_sorted, c->d_n, 16);
-    if (hipGetLastError() != hipSuccess) return FID_E_HIP;
-    if (hipMemcpyAsync(c->rcount, c->d_rcount, 12, hipMemcpyDeviceToHost, st) != hipSuccess) return FID_E_HIP;
-    if (hipStreamSynchronize(st) != hipSuccess) return FID_E_HIP;
-    if (c->rcount[2]) return FID_E_CAPACITY;
+    for (int attempt = 0; attempt < 2; attempt++) {
+        const bool par = c->route_mode == 1 && attempt == 0;
+        if (!par && attempt == 0 && c->route_mode == 1) continue;
+        if (hipMemcpyAsync(c->d_edgeimg, c->d_edge, n, hipMemcpyDeviceToDevice, st) != hipSuccess) return FID_E_HIP;
+        // pixels the routing has not written read as (-1, -1) (the reference reads uninitialised memory there)
+        if (hipMemsetAsync(c->d_outpix, 0xff, n * sizeof(int2), st) != hipSuccess) return FID_E_HIP;
+        rc = par ? stag_route_par(c, R) : stag_route_seq(c, R);
+        if (rc == FID_OK) break;
+        if (!par || rc != FID_E_CAPACITY) return rc;
+        c->route_fallbacks++;  // an arena of the parallel road was too small: same result by the sequential road
+    }
+    if (rc != FID_OK) return rc;
     c->routed = true;
     c->validated = false;
     return FID_OK;

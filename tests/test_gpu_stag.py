@@ -120,12 +120,20 @@ ROUTE_CASES = {
 }
 
 
+ROUTE_CASES["tilted_many"] = lambda: _tilted_markers(1280, 960, 34, n=48)
+ROUTE_CASES["stag_1080p"] = lambda: __import__("fiducials_amd.synth", fromlist=["x"]).make_stag_frame(fstag.load_library(21), 7, 1920, 1080, 20).image
+ROUTE_CASES["faint"] = lambda: _faint(480, 360, 21)
+
+
+@pytest.mark.parametrize("mode", ["par", "seq"])
 @pytest.mark.parametrize("case", sorted(ROUTE_CASES))
-def test_edge_routing_matches_reference_code(case):
+def test_edge_routing_matches_reference_code(case, mode, monkeypatch):
     """Row s4: JoinAnchorPointsUsingSortedAnchors.  Edge image and every segment (pixel by pixel, in order) against the
-    reference's own routine fed with the same gradient / direction / anchor maps."""
+    reference's own routine fed with the same gradient / direction / anchor maps; both roads of the device code: one lane per
+    connected component of the gradient map (default) and one lane per frame."""
     if not stag_ref.available():
         pytest.skip("oracle/_ref/libstag_ref.so not built (needs /root/reference at build time)")
+    monkeypatch.setenv("FID_STAG_ROUTE", mode)
     img = ROUTE_CASES[case]()
     h, w = img.shape
     det = fstag.StagDetector(21, 7, max_width=1920, max_height=1080)

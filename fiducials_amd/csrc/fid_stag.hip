@@ -508,6 +508,125 @@ struct StagRouter {
         return true;
     }
 
+    // The same walk run by a whole wave: control flow and bookkeeping are wave-uniform (every lane computes them, lane 0
+    // stores them), and what a step needs from memory -- edge / gradient / direction of the three pixels ahead and the edge
+    // value of the two pixels beside -- is fetched by eleven lanes at once, one round trip per step instead of a chain of
+    // dependent loads.  None of those eleven pixels is written in the same step (the current pixel and the two beside it
+    // are not among the three ahead), so the fetch sees exactly what the sequential code would read.
+    __device__ bool walk_anchor_wave(int r0, int c0, int grad_thresh, int lane)
+    {
+        const int W = R.W;
+        const bool L0 = lane == 0;
+        StagChain *ch = R.chains;
+        if (L0) {
+            ch[0].dir = 0; ch[0].len = 0; ch[0].parent = -1; ch[0].child[0] = ch[0].child[1] = -1; ch[0].pix = -1;
+        }
+        int noChains = 1, len = 0, dup = 0, top = -1;
+        const bool vert0 = R.dir[r0 * W + c0] == STAG_EDGE_VERTICAL;
+        if (L0) {
+            R.stack[0] = make_int4(r0, c0, vert0 ? SR_DOWN : SR_RIGHT, 0);
+            R.stack[1] = make_int4(r0, c0, vert0 ? SR_UP : SR_LEFT, 0);
+        }
+        top = 1;
+        while (top >= 0) {
+            const int4 e = R.stack[top--];
+            int r = e.x, c = e.y;
+            const int d = e.z, parent = e.w;
+            if (noChains >= R.capChains || len + 2 >= R.capPix || top + 3 >= R.capStack) {
+                overflow |= 16;
+                break;
+            }
+            if (R.edge[r * W + c] != STAG_EDGE_PIXEL) dup++;
+            const int cur = noChains;
+            if (L0) {
+                ch[cur].dir = (int16_t)d; ch[cur].parent = (int16_t)parent; ch[cur].child[0] = ch[cur].child[1] = -1; ch[cur].pix = len;
+                R.pix[len] = make_int2(r, c);
+            }
+            len++;
+            int chainLen = 1;
+            const bool horiz = d == SR_LEFT || d == SR_RIGHT;
+            const int need = horiz ? STAG_EDGE_HORIZONTAL : STAG_EDGE_VERTICAL;
+            const int ar = d == SR_UP ? -1 : d == SR_DOWN ? 1 : 0, ac = d == SR_LEFT ? -1 : d == SR_RIGHT ? 1 : 0;
+            const int pr = horiz ? 1 : 0, pc = horiz ? 0 : 1;
+            const int fs = (d == SR_LEFT || d == SR_UP) ? -1 : 1;
+            const int slot = (d == SR_LEFT || d == SR_UP) ? 0 : 1;
+            bool stopped = false;
+            int curdir = R.dir[r * W + c];
+            while (curdir == need) {
+                const int nr = r + ar, nc = c + ac;
+                // lane -> (array, pixel): 0-2 edge, 3-5 grad, 6-8 dir of A = ahead - p, B = ahead, C = ahead + p; 9, 10 edge beside
+                int v = 0;
+                {
+                    const int k = lane % 3, side = k - 1;  // A, B, C
+                    const int qr = nr + side * pr, qc = nc + side * pc;
+                    const int q = qr * W + qc;
+                    if (lane < 3) v = R.edge[q];
+                    else if (lane < 6) v = R.grad[q];
+                    else if (lane < 9) v = R.dir[q];
+                    else if (lane == 9) v = R.edge[(r + pr) * W + (c + pc)];
+                    else if (lane == 10) v = R.edge[(r - pr) * W + (c - pc)];
+                }
+                const int eA = __builtin_amdgcn_readlane(v, 0), eB = __builtin_amdgcn_readlane(v, 1), eC = __builtin_amdgcn_readlane(v, 2);
+                const int gA = __builtin_amdgcn_readlane(v, 3), gB = __builtin_amdgcn_readlane(v, 4), gC = __builtin_amdgcn_readlane(v, 5);
+                const int dA = __builtin_amdgcn_readlane(v, 6), dB = __builtin_amdgcn_readlane(v, 7), dC = __builtin_amdgcn_readlane(v, 8);
+                const int s1 = __builtin_amdgcn_readlane(v, 9), s2 = __builtin_amdgcn_readlane(v, 10);
+                if (L0) {
+                    R.edge[r * W + c] = STAG_EDGE_PIXEL;
+                    if (s1 == STAG_ANCHOR_PIXEL) R.edge[(r + pr) * W + (c + pc)] = 0;
+                    if (s2 == STAG_ANCHOR_PIXEL) R.edge[(r - pr) * W + (c - pc)] = 0;
+                }
+                const int eF1 = fs < 0 ? eA : eC, eF2 = fs < 0 ? eC : eA;  // the diagonal looked at first / second
+                int side;
+                if (eB >= STAG_ANCHOR_PIXEL) side = 0;
+                else if (eF1 >= STAG_ANCHOR_PIXEL) side = fs;
+                else if (eF2 >= STAG_ANCHOR_PIXEL) side = -fs;
+                else {
+                    side = 0;
+                    if (gA > gB) side = gA > gC ? -1 : 1;
+                    else if (gC > gB) side = 1;
+                }
+                r = nr + side * pr;
+                c = nc + side * pc;
+                const int en = side < 0 ? eA : side > 0 ? eC : eB, gn = side < 0 ? gA : side > 0 ? gC : gB;
+                curdir = side < 0 ? dA : side > 0 ? dC : dB;
+                if (en == STAG_EDGE_PIXEL || gn < grad_thresh) {
+                    if (L0) {
+                        ch[cur].len = (uint16_t)chainLen;
+                        ch[parent].child[slot] = (int16_t)cur;
+                    }
+                    noChains++;
+                    stopped = true;
+                    break;
+                }
+                if (len + 2 >= R.capPix) { overflow |= 16; stopped = true; break; }
+                if (L0) R.pix[len] = make_int2(r, c);
+                len++;
+                chainLen++;
+            }
+            if (stopped) continue;
+            if (L0) {
+                R.stack[top + 1] = make_int4(r, c, horiz ? SR_DOWN : SR_RIGHT, cur);
+                R.stack[top + 2] = make_int4(r, c, horiz ? SR_UP : SR_LEFT, cur);
+            }
+            top += 2;
+            len--;
+            chainLen--;
+            if (L0) {
+                ch[cur].len = (uint16_t)chainLen;
+                ch[parent].child[slot] = (int16_t)cur;
+            }
+            noChains++;
+        }
+        wl_len = len;
+        wl_dup = dup;
+        wl_chains = noChains;
+        if (len - dup < STAG_MIN_PATH_LEN) {
+            for (int k = lane; k < len; k += 64) R.edge[R.pix[k].x * W + R.pix[k].y] = 0;
+            return false;
+        }
+        return true;
+    }
+
     // the chain tree -> segments
     __device__ void extract_anchor(int noChains)
     {
@@ -764,11 +883,11 @@ __device__ void stag_bind(StagRouter &S, const StagRoute &G, const StagArenas &A
     S.par = true;
 }
 
-__global__ __launch_bounds__(64) void k_stag_route_walk(StagRoute G, StagArenas A, StagComp *__restrict__ comps, const int *__restrict__ cursors,
-                                                        const int32_t *__restrict__ sorted, const int *__restrict__ aslots, int grad_thresh,
-                                                        int *__restrict__ prodflag, int *__restrict__ ovf)
+__global__ __launch_bounds__(256) void k_stag_route_walk(StagRoute G, StagArenas A, StagComp *__restrict__ comps, const int *__restrict__ cursors,
+                                                         const int32_t *__restrict__ sorted, const int *__restrict__ aslots, int grad_thresh,
+                                                         int *__restrict__ prodflag, int *__restrict__ ovf)
 {
-    const int cid = blockIdx.x * 64 + threadIdx.x;
+    const int cid = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;  // one wave per component
     if (cid >= cursors[0]) return;
     StagComp C = comps[cid];
     if (C.nanch == 0) return;
@@ -778,36 +897,51 @@ __global__ __launch_bounds__(64) void k_stag_route_walk(StagRoute G, StagArenas 
     S.segbase = S.nsp = 0;
     StagRec *recs = A.recs + C.anch_base;
     int nrec = 0, pix_used = 0, chain_used = 0;
-    const int2 *pix0 = S.R.pix;
+    int2 *pix0 = S.R.pix;
     StagChain *chain0 = S.R.chains;
     const int capPix0 = S.R.capPix, capChain0 = C.chain_cap;
-    for (int k = 0; k < C.nanch; k++) {
-        const int rank = aslots[C.anch_base + k];
-        const int off = sorted[rank];
-        if (G.edge[off] != STAG_ANCHOR_PIXEL) continue;
-        S.R.pix = const_cast<int2 *>(pix0) + pix_used;
-        S.R.capPix = capPix0 - pix_used;
-        S.R.chains = chain0 + chain_used;
-        const int left = capChain0 - chain_used;
-        S.R.capChains = left < 32767 ? left : 32767;
-        if (S.R.capPix < 16 || S.R.capChains < 4) {
-            S.overflow |= 32;
-            break;
+    for (int k0 = 0; k0 < C.nanch; k0 += 64) {
+        // which of the next 64 anchors are still anchors?  (a walk can only turn anchors OFF, so a stale "on" is re-checked)
+        const int kk = k0 + lane;
+        int my_off = -1;
+        if (kk < C.nanch) my_off = sorted[aslots[C.anch_base + kk]];
+        unsigned long long live = __ballot(my_off >= 0 && G.edge[my_off] == STAG_ANCHOR_PIXEL);
+        while (live) {
+            const int j = __builtin_ctzll(live);
+            live &= live - 1;
+            const int rank = aslots[C.anch_base + k0 + j];
+            const int off = sorted[rank];
+            if (G.edge[off] != STAG_ANCHOR_PIXEL) continue;
+            S.R.pix = pix0 + pix_used;
+            S.R.capPix = capPix0 - pix_used;
+            S.R.chains = chain0 + chain_used;
+            const int left = capChain0 - chain_used;
+            S.R.capChains = left < 32767 ? left : 32767;
+            if (S.R.capPix < 16 || S.R.capChains < 4) {
+                S.overflow |= 32;
+                break;
+            }
+            const bool keep = S.walk_anchor_wave(off / G.W, off % G.W, grad_thresh, lane);
+            if (S.overflow) break;
+            if (keep) {
+                if (lane == 0) {
+                    StagRec r;
+                    r.rank = rank; r.pix_off = pix_used; r.len = S.wl_len; r.chain_off = chain_used; r.nchains = S.wl_chains;
+                    r.out_off = r.out_len = r.seg_off = r.nsegs = 0;
+                    recs[nrec] = r;
+                    prodflag[rank] = 1;
+                }
+                nrec++;
+                pix_used += S.wl_len + 1;
+                chain_used += S.wl_chains;
+            }
         }
-        const bool keep = S.walk_anchor(off / G.W, off % G.W, grad_thresh);
         if (S.overflow) break;
-        if (keep) {
-            StagRec r;
-            r.rank = rank; r.pix_off = pix_used; r.len = S.wl_len; r.chain_off = chain_used; r.nchains = S.wl_chains;
-            r.out_off = r.out_len = r.seg_off = r.nsegs = 0;
-            recs[nrec++] = r;
-            prodflag[rank] = 1;
-            pix_used += S.wl_len + 1;  // (+1: the walk may have parked one pixel past len)
-            chain_used += S.wl_chains;
-        }
     }
-    comps[cid].nrec = nrec;
-    if (S.overflow) atomicOr(ovf, S.overflow);
+    if (lane == 0) {
+        comps[cid].nrec = nrec;
+        if (S.overflow) atomicOr(ovf, S.overflow);
+    }
 }
 
 // next[r] = the smallest producing rank > r, or -1 (one workgroup, chunks of 1024 from the top)
@@ -3102,7 +3236,7 @@ static fid_status stag_route_par(fid_stag_ctx *c, const StagRoute &R)
     int *ovf = c->d_cursors + 8;
     if (nc > 0) {
         hipLaunchKernelGGL(k_stag_comp_sort, dim3((nc + 3) / 4), dim3(256), 0, st, c->d_comps, c->d_cursors, c->d_aslots);
-        hipLaunchKernelGGL(k_stag_route_walk, dim3((nc + 63) / 64), dim3(64), 0, st, R, A, c->d_comps, c->d_cursors, c->d_sorted, c->d_aslots, 16,
+        hipLaunchKernelGGL(k_stag_route_walk, dim3((nc + 3) / 4), dim3(256), 0, st, R, A, c->d_comps, c->d_cursors, c->d_sorted, c->d_aslots, 16,
                            c->d_prodflag, ovf);
     }
     hipLaunchKernelGGL(k_stag_next_above, dim3(1), dim3(1024), 0, st, c->d_prodflag, c->d_n, c->d_next);

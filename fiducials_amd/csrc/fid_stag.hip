@@ -303,6 +303,7 @@ struct StagRouter {
     // the same component
     bool par = false, prev_valid = false;
     int blk0 = 0;  // where the current anchor's block starts in outpix
+    int wlane = -1;  // >= 0: a whole wave runs the extraction (identical scalar work in every lane, copies spread over the lanes)
     int wl_len = 0, wl_dup = 0, wl_chains = 0;  // what walk_anchor() left behind
 
     __device__ int2 cpx(int ch, int i) const
@@ -315,6 +316,24 @@ struct StagRouter {
         const int k = segbase + i;
         if (par && k < blk0) return (prev_valid && k >= 0) ? R.outpix[k] : make_int2(-1000, -1000);  // in front of this anchor's block
         return k >= 0 ? R.outpix[k] : make_int2(-1000, -1000);
+    }
+    // append `count` pixels of chain cn, chain index first + step * k, to the segment
+    __device__ void seg_copy(int cn, int first, int step, int count)
+    {
+        if (count <= 0) return;
+        if (segbase + nsp + count > R.capOut) {
+            overflow |= 1;
+            nsp += count;
+            return;
+        }
+        const int2 *src = R.pix + R.chains[cn].pix;
+        int2 *dst = R.outpix + segbase + nsp;
+        if (wlane >= 0) {
+            for (int k = wlane; k < count; k += 64) dst[k] = src[first + step * k];
+        } else {
+            for (int k = 0; k < count; k++) dst[k] = src[first + step * k];
+        }
+        nsp += count;
     }
     __device__ void seg_put(int2 v)
     {
@@ -401,7 +420,7 @@ struct StagRouter {
             int start = 0;
             const int L = ch[cn].len;
             if (L > 1 && sr_near(cpx(cn, 1), seg(nsp - 1))) start = 1;
-            for (int l = start; l < L; l++) seg_put(cpx(cn, l));
+            seg_copy(cn, start, 1, L - start);
             ch[cn].len = 0;  // copied
         }
     }
@@ -641,7 +660,7 @@ struct StagRouter {
                 const int cn = R.chainNos[k];
                 trim_tail(cpx(cn, ch[cn].len - 1));
                 if (ch[cn].len > 1 && sr_near(cpx(cn, ch[cn].len - 2), seg(nsp - 1))) ch[cn].len--;
-                for (int l = ch[cn].len - 1; l >= 0; l--) seg_put(cpx(cn, l));
+                seg_copy(cn, ch[cn].len - 1, -1, ch[cn].len);
                 ch[cn].len = 0;
             }
         }
@@ -827,15 +846,24 @@ __global__ __launch_bounds__(256) void k_stag_comp_fill(const int32_t *__restric
     aslots[comps[cid].anch_base + pos] = r;
 }
 
-// ranks of one component, descending: bitonic sort of the (padded, -1 filled) slice, one wave per component
+// ranks of one component, descending: bitonic sort of the (padded, -1 filled) slice, one wave per component; slices of up to
+// 2048 entries are sorted in LDS
+#define STAG_SORT_LDS 2048
 __global__ __launch_bounds__(256) void k_stag_comp_sort(const StagComp *__restrict__ comps, const int *__restrict__ cursors, int *aslots)
 {
-    const int cid = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    __shared__ int s_buf[4][STAG_SORT_LDS];
+    const int wv = threadIdx.x >> 6, cid = blockIdx.x * 4 + wv, lane = threadIdx.x & 63;
     if (cid >= cursors[0]) return;
     const StagComp C = comps[cid];
     if (C.nanch < 2) return;
-    int *a = aslots + C.anch_base;
+    int *g = aslots + C.anch_base;
     const int P = C.anch_cap;
+    const bool in_lds = P <= STAG_SORT_LDS;
+    int *a = in_lds ? s_buf[wv] : g;
+    if (in_lds) {
+        for (int i = lane; i < P; i += 64) a[i] = g[i];
+        __builtin_amdgcn_wave_barrier();
+    }
     for (int k = 2; k <= P; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
             for (int i = lane; i < P; i += 64) {
@@ -849,11 +877,19 @@ __global__ __launch_bounds__(256) void k_stag_comp_sort(const StagComp *__restri
                     }
                 }
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            if (in_lds) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            } else {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            }
         }
     }
+    if (in_lds)
+        for (int i = lane; i < P; i += 64) g[i] = a[i];
 }
 
 struct StagArenas {
@@ -975,17 +1011,19 @@ __global__ __launch_bounds__(1024) void k_stag_next_above(const int *__restrict_
     }
 }
 
-__global__ __launch_bounds__(64) void k_stag_route_extract(StagRoute G, StagArenas A, const StagComp *__restrict__ comps, const int *__restrict__ cursors,
-                                                           const int *__restrict__ next, const unsigned *__restrict__ n_anchors,
-                                                           int *__restrict__ blk_pix, int *__restrict__ blk_segs, int2 *__restrict__ blk_where,
-                                                           int *__restrict__ ovf)
+__global__ __launch_bounds__(256) void k_stag_route_extract(StagRoute G, StagArenas A, const StagComp *__restrict__ comps, const int *__restrict__ cursors,
+                                                            const int *__restrict__ next, const unsigned *__restrict__ n_anchors,
+                                                            int *__restrict__ blk_pix, int *__restrict__ blk_segs, int2 *__restrict__ blk_where,
+                                                            int *__restrict__ ovf)
 {
-    const int cid = blockIdx.x * 64 + threadIdx.x;
+    // one wave per component: every lane runs the same scalar steps (same values, same stores); pixel runs are copied by all lanes
+    const int cid = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (cid >= cursors[0]) return;
     const StagComp C = comps[cid];
     if (C.nanch == 0 || C.nrec == 0) return;
     StagRouter S;
     stag_bind(S, G, A, C);
+    S.wlane = lane;
     S.noSegments = S.totalPixels = S.overflow = 0;
     S.segbase = S.nsp = 0;
     StagRec *recs = A.recs + C.anch_base;
@@ -1011,7 +1049,7 @@ __global__ __launch_bounds__(64) void k_stag_route_extract(StagRoute G, StagAren
         prev_rank = r.rank;
         if (S.overflow) break;
     }
-    if (S.overflow) atomicOr(ovf, S.overflow);
+    if (S.overflow && lane == 0) atomicOr(ovf, S.overflow);
 }
 
 // blk_pix / blk_segs hold exclusive prefix sums by now: copy every block to its place in the global order
@@ -2261,15 +2299,18 @@ struct SrEllipse {
 __device__ void sr_conic_to_ellipse(double A1, double B1, double C1, double D1, double E1, double F1, SrEllipse *e)
 {
     B1 /= A1; C1 /= A1; D1 /= A1; E1 /= A1; F1 /= A1; A1 /= A1;
-    double A2, C2, D2, E2, F2, rotation = 0;  // (the reference leaves rotation unset when B1 == 0)
+    double A2, C2, D2, E2, F2, rotation = 0, sr = 0, cr = 1;  // (the reference leaves rotation unset when B1 == 0)
     if (B1 == 0) {
         A2 = A1; C2 = C1; D2 = D1; E2 = E1; F2 = F1;
     } else {
         rotation = atan(B1 / (A1 - C1)) / 2;
-        A2 = 0.5 * (A1 * (1 + cos(2 * rotation) + B1 * sin(2 * rotation) + C1 * (1 - cos(2 * rotation))));
-        C2 = 0.5 * (A1 * (1 - cos(2 * rotation) - B1 * sin(2 * rotation) + C1 * (1 + cos(2 * rotation))));
-        D2 = D1 * cos(rotation) + E1 * sin(rotation);
-        E2 = -D1 * sin(rotation) + E1 * cos(rotation);
+        double s2, c2;
+        sincos(2 * rotation, &s2, &c2);
+        sincos(rotation, &sr, &cr);
+        A2 = 0.5 * (A1 * (1 + c2 + B1 * s2 + C1 * (1 - c2)));
+        C2 = 0.5 * (A1 * (1 - c2 - B1 * s2 + C1 * (1 + c2)));
+        D2 = D1 * cr + E1 * sr;
+        E2 = -D1 * sr + E1 * cr;
         F2 = F1;
     }
     const double D3 = D2 / A2, E3 = E2 / C2;
@@ -2279,8 +2320,8 @@ __device__ void sr_conic_to_ellipse(double A1, double B1, double C1, double D1, 
     e->b = sqrt(F3 / C2);
     if (rotation != 0) {
         const double tx = cX, ty = cY;
-        cX = tx * cos(rotation) - ty * sin(rotation);
-        cY = tx * sin(rotation) + ty * cos(rotation);
+        cX = tx * cr - ty * sr;
+        cY = tx * sr + ty * cr;
     }
     e->cX = cX; e->cY = cY;
     e->A1 = A1; e->B1 = B1; e->C1 = C1; e->D1 = D1; e->E1 = E1; e->F1 = F1;
@@ -3241,7 +3282,7 @@ static fid_status stag_route_par(fid_stag_ctx *c, const StagRoute &R)
     }
     hipLaunchKernelGGL(k_stag_next_above, dim3(1), dim3(1024), 0, st, c->d_prodflag, c->d_n, c->d_next);
     if (nc > 0)
-        hipLaunchKernelGGL(k_stag_route_extract, dim3((nc + 63) / 64), dim3(64), 0, st, R, A, c->d_comps, c->d_cursors, c->d_next, c->d_n, c->d_blkpix,
+        hipLaunchKernelGGL(k_stag_route_extract, dim3((nc + 3) / 4), dim3(256), 0, st, R, A, c->d_comps, c->d_cursors, c->d_next, c->d_n, c->d_blkpix,
                            c->d_blksegs, c->d_blkwhere, ovf);
     hipLaunchKernelGGL(k_stag_scan_counts, dim3(1), dim3(1024), 0, st, c->d_blkpix, (const int *)c->d_n, c->d_rcount + 1);
     hipLaunchKernelGGL(k_stag_scan_counts, dim3(1), dim3(1024), 0, st, c->d_blksegs, (const int *)c->d_n, c->d_rcount);

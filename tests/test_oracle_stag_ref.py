@@ -33,3 +33,66 @@ def test_vertical_step_edge_gives_vertical_anchors_sorted_by_gradient():
     assert (np.diff(g) >= 0).all()
     # equal gradients: descending offsets (the --C[grad] placement of SortAnchorsByGradValue)
     assert (np.diff(order) < 0).all()
+
+
+def _need_ref():
+    if not stag_ref.available():
+        pytest.skip("oracle/_ref/libstag_ref.so not built (needs /root/reference at build time)")
+
+
+def test_piecewise_calls_equal_the_reference_pipeline_end_to_end():
+    """The stage-by-stage entry points the GPU parity tests use (gradient, anchors, routing, validation, line fitting) give,
+    chained, exactly what the reference's DetectLinesByEDPF returns in one go: the wrappers add nothing of their own."""
+    _need_ref()
+    rng = np.random.default_rng(3)
+    yy, xx = np.mgrid[0:240, 0:320]
+    img = (150 + 30 * np.sin(xx / 40.0) + rng.normal(0, 2, (240, 320))).astype(np.float64)
+    img[60:180, 80:220] = 30
+    img[(yy - 120) ** 2 + (xx - 150) ** 2 < 45 ** 2] = 220
+    img = np.clip(img, 0, 255).astype(np.uint8)
+    lines, segs, pix = stag_ref.detect_lines(img)
+    sm = stag_ref.smooth5(img)
+    g, d = stag_ref.gradient(sm, 16)
+    e, order = stag_ref.anchors(g, d, 16, 0, 1)
+    _, rp, rs = stag_ref._route_raw(g, d, e)
+    _, vs = stag_ref.validate(stag_ref.smooth3(img), rp, rs)
+    l2, mll = stag_ref.fit_lines(img, rp, vs, validate=True)
+    assert mll >= 9 and len(lines) > 4
+    assert np.array_equal(vs, segs) and np.array_equal(l2, lines)
+    for a, n in segs:
+        assert np.array_equal(rp[a:a + n], pix[a:a + n])
+
+
+def test_marker_libraries_are_the_published_tables():
+    """fiducials_amd/data/stag_libraries.npz (tools/make_stag_libraries.py): sizes of Decoder.cpp:17-37, 48-bit words, four
+    blocks per library, no word twice, block k = block 0 turned by k quarter turns of the code ring."""
+    from fiducials_amd.stag import load_library
+    sizes = {11: 22309, 13: 2884, 15: 766, 17: 157, 19: 38, 21: 12, 23: 6}
+    for hd, n in sizes.items():
+        w = load_library(hd)
+        assert w.dtype == np.uint64 and len(w) == 4 * n and int(w.max()) < (1 << 48)
+        assert len(np.unique(w)) == len(w)
+        # the four blocks are the four quarter turns of the code ring (12 of the 48 code points per quadrant, Stag.cpp:139-173)
+        mask = np.uint64((1 << 48) - 1)
+        for k in range(1, 4):
+            sh = (36 * k) % 48
+            rot = ((w[:n] << np.uint64(sh)) | (w[:n] >> np.uint64(48 - sh))) & mask
+            assert np.array_equal(w[k * n:(k + 1) * n], rot), (hd, k)
+
+
+@pytest.mark.parametrize("hd,ec", [(21, 7), (17, 5)])
+def test_rendered_codewords_come_back_from_the_reference_detector(hd, ec):
+    """Known-answer test for the checker itself: markers rendered from library codewords (fiducials_amd.synth) go through the
+    reference's Stag::detectMarkers (oracle/_ref: the reference's sources + the restated OpenCV calls) and the ids read are
+    ids that were drawn, at the drawn places."""
+    _need_ref()
+    from fiducials_amd import synth
+    from fiducials_amd.stag import load_library
+    words = load_library(hd)
+    fr = synth.make_stag_frame(words, 5, 1280, 720, 8)
+    m = stag_ref.detect_markers(fr.image, hd, ec, refine=True)
+    assert len(m) >= 4
+    for row in m:
+        js = np.flatnonzero(fr.ids == int(row[0]))
+        assert len(js) > 0, "an id that was never drawn"
+        assert min(np.abs(row[1:9].reshape(4, 2) - fr.corners[j]).max() for j in js) < 2.0

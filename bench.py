@@ -143,6 +143,106 @@ def cpu_baseline(frames, K, D, budget_s=20.0):
     }
 
 
+def main_stag(args):
+    """BASELINE cfg 5 (a parity configuration, not the headline metric): 1920x1080 frames with 20 STag HD21 markers through
+    fid_stag_detect_markers + fid_stag_pose_last, one frame per call (the stag_detect node's shape; the frame comes from host
+    memory, so the PCIe copy is inside the number).  cpu_baseline = the REFERENCE's own Stag::detectMarkers (oracle/_ref: its
+    sources compiled in place) on one host core."""
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    n_gpus = world if world > 1 else args.gpus
+    import torch
+
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the library has no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+
+        dist = dist_mod
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    from fiducials_amd import stag as fstag, synth
+
+    hd, ec, B = 21, 7, min(args.batch, 16)
+    words = fstag.load_library(hd)
+    frames = [synth.make_stag_frame(words, 10000 * rank + 100 + i, W, H, MARKERS).image for i in range(min(B, 4))]
+    # one context (= one HIP stream) per host thread: a frame's work is a chain of small kernels, several frames in flight
+    # fill the GPU (the C-ABI contract: a context is single-threaded, contexts run concurrently)
+    import concurrent.futures as cf
+
+    T = max(1, min(args.streams, B))
+    dets = [fstag.StagDetector(hd, ec, max_width=W, max_height=H, device=local_rank) for _ in range(T)]
+    det = dets[0]
+    K = synth.K_DEFAULT
+    pool = cf.ThreadPoolExecutor(T)
+
+    def work(t):
+        n = 0
+        for i in range(t, B, T):
+            n += len(dets[t].detect_markers(frames[i % len(frames)]))
+            dets[t].pose_last(K, None, 0.18)
+        return n
+
+    def step():
+        return sum(pool.map(work, range(T)))
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    markers = 0
+    for _ in range(args.steps):
+        markers += step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    fps = B * args.steps * n_gpus / dt
+    if rank == 0:
+        algo = 10 * W * H  # SURVEY.md 8d: ~10 B/px for the EDPF streaming stages
+        out = {
+            "metric": "frames/sec @1920x1080 20 STag HD21 markers (stag_detect path: detectMarkers + 5-point pose)",
+            "value": round(fps, 2), "unit": "frames/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": f"synthetic ({len(frames)} unique frames per GPU, host memory)",
+            "config": {"workload": f"cfg5: {B} frames per step, one frame per call on {T} concurrent contexts, 1920x1080 mono8, 20 markers/frame, "
+                                   "library HD21, errorCorrection 7, marker_size 0.18", "frames_per_step": B * n_gpus, "contexts_per_gpu": T,
+                       "parallelism": f"frames sharded over {n_gpus} GPU(s), no collective",
+                       "markers_per_frame_found": round(markers / max(B * args.steps, 1), 2)},
+            "roofline": {"bound": "hbm", "kernel": "pipeline (latency-bound: edge routing, line fitting, simplex search)",
+                         "achieved": round(fps / n_gpus * algo / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(fps / n_gpus * algo / 1e9 / HBM_PEAK_GBS, 6), "traffic": None},
+        }
+        if n_gpus == 1 and not args.no_cpu_baseline:
+            from oracle import stag_ref
+
+            if stag_ref.available():
+                stag_ref.detect_markers(frames[0], hd, ec)
+                t = time.perf_counter()
+                k = 0
+                while time.perf_counter() - t < 10.0:
+                    stag_ref.detect_markers(frames[k % len(frames)], hd, ec)
+                    k += 1
+                out["cpu_baseline"] = {"value": round(k / (time.perf_counter() - t), 2), "unit": "frames/s", "cores": 1, "kind": "reference",
+                                       "sample": f"{k} frames through the reference's Stag::detectMarkers (oracle/_ref/libstag_ref.so: the "
+                                                 "reference sources compiled in place, OpenCV calls restated), one thread (the reference keeps "
+                                                 "global state, PoseRefiner.cpp:9), ~10 s"}
+        print(json.dumps(out))
+    pool.shutdown()
+    for d_ in dets:
+        d_.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -151,7 +251,12 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="frames per step per GPU (BASELINE cfg 3: 256)")
     ap.add_argument("--unique", type=int, default=0, help="unique synthetic frames per GPU (0 = batch); fewer are tiled")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--streams", type=int, default=16, help="stag workload: concurrent contexts (host threads) per GPU")
+    ap.add_argument("--workload", choices=["aruco", "stag"], default="aruco",
+                    help="aruco = the BASELINE.json metric (default); stag = BASELINE cfg 5, the stag_detect path")
     args = ap.parse_args()
+    if args.workload == "stag":
+        return main_stag(args)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -412,6 +412,37 @@ def test_marker_pose_matches_oracle():
         det.close()
 
 
+def test_empty_and_degenerate_frames_go_through_every_stage():
+    """Nothing to find is a result, not an error: a flat frame (no anchors), a tiny frame, a frame of pure noise at 640x480
+    (one gradient component holding nearly every anchor: the routing's worst case for parallelism) -- all through
+    fid_stag_detect_markers, the noise frame's edge map and lines checked against the reference."""
+    if not stag_ref.available():
+        pytest.skip("oracle/_ref/libstag_ref.so not built (needs /root/reference at build time)")
+    det = fstag.StagDetector(21, 7, max_width=1920, max_height=1080)
+    try:
+        for img in (np.full((480, 640), 90, np.uint8), np.full((17, 64), 200, np.uint8)):
+            assert len(det.detect_markers(img)) == 0
+            assert len(det.tap(fstag.TAP_SORTED)) == 0 and len(det.edge_segments()) == 0 and len(det.lines(validated=True)) == 0
+            assert len(det.quads()) == 0
+            assert len(det.pose_last(np.eye(3), None, 0.18)) == 0
+        noise = np.random.default_rng(41).integers(0, 256, (480, 640)).astype(np.uint8)
+        assert len(det.detect_markers(noise)) == 0
+        ref_lines, ref_segs, ref_pix = stag_ref.detect_lines(noise)
+        vsegs, pix = det.tap(fstag.TAP_VSEGMENTS).reshape(-1, 2), det.tap(fstag.TAP_SEGPIX).reshape(-1, 2)
+        assert np.array_equal(vsegs, ref_segs)  # (the Helmholtz test throws noise away: possibly nothing is left)
+        _, raw = stag_ref.route(det.tap(fstag.TAP_GRAD), det.tap(fstag.TAP_DIR), det.tap(fstag.TAP_ANCHORS))
+        mine = det.edge_segments()
+        assert len(raw) > 1000 and len(mine) == len(raw) and all(np.array_equal(a, b) for a, b in zip(mine, raw))
+        for a, n in ref_segs:
+            assert np.array_equal(pix[a:a + n], ref_pix[a:a + n])
+        # (the lines tap holds the direction-corrected lines after the quad stage: compare the untouched fields)
+        got = _lines_as_table(det.lines(validated=True))
+        assert got.shape == ref_lines.shape
+        assert np.array_equal(got[:, [0, 1, 6, 7, 8, 9]], ref_lines[:, [0, 1, 6, 7, 8, 9]])
+    finally:
+        det.close()
+
+
 def test_stag_status_codes():
     from fiducials_amd import _lib
     from fiducials_amd._lib import FidError

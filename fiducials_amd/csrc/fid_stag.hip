@@ -1507,11 +1507,26 @@ __device__ bool sl_try_join(fid_stag_line *l1, const fid_stag_line *l2, double m
     return true;
 }
 
-__global__ __launch_bounds__(64) void k_stag_split_lines(const int2 *__restrict__ segs, const int *__restrict__ nsegs, const int2 *__restrict__ pix,
-                                                         StagPrefix PF, int min_line_len, double line_error, fid_stag_line *__restrict__ slots,
-                                                         int *__restrict__ counts)
+__device__ __forceinline__ long long wave_iscan_ll(long long v, int lane)
 {
-    const int seg = blockIdx.x * 64 + threadIdx.x;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const long long o = __shfl_up(v, off, 64);
+        if (lane >= off) v += o;
+    }
+    return v;
+}
+
+// One wave per segment.  The state of SplitSegment2Lines is wave-uniform; three things are spread over the lanes without
+// changing any result: the prefix sums (wave scan), the search for the first window of MIN_LINE_LEN pixels that fits a line
+// (64 window positions at a time, each lane its own 9-pixel fit), and the point-to-line distances of the next 64 pixels under
+// the CURRENT line -- the sequential good / bad bookkeeping then runs over the ballot until a refit really changes the line
+// (every tenth good pixel), at which point the rest of the batch is thrown away and recomputed.
+__global__ __launch_bounds__(256) void k_stag_split_lines(const int2 *__restrict__ segs, const int *__restrict__ nsegs, const int2 *__restrict__ pix,
+                                                          StagPrefix PF, int min_line_len, double line_error, fid_stag_line *__restrict__ slots,
+                                                          int *__restrict__ counts)
+{
+    const int seg = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (seg >= *nsegs) return;
     const int first = segs[seg].x, n = segs[seg].y;
     const int2 *px = pix + first;
@@ -1520,13 +1535,27 @@ __global__ __launch_bounds__(64) void k_stag_split_lines(const int2 *__restrict_
     const int pb = first + seg;
     P.x = PF.x + pb; P.y = PF.y + pb; P.xx = PF.xx + pb; P.yy = PF.yy + pb; P.xy = PF.xy + pb;
     {
-        long long sx = 0, sy = 0, sxx = 0, syy = 0, sxy = 0;
-        for (int k = 0; k < n; k++) {
-            P.x[k] = sx; P.y[k] = sy; P.xx[k] = sxx; P.yy[k] = syy; P.xy[k] = sxy;
-            const long long x = px[k].y, y = px[k].x;
-            sx += x; sy += y; sxx += x * x; syy += y * y; sxy += x * y;
+        long long cx = 0, cy = 0, cxx = 0, cyy = 0, cxy = 0;
+        for (int k0 = 0; k0 < n; k0 += 64) {
+            const int k = k0 + lane;
+            long long x = 0, y = 0;
+            if (k < n) {
+                x = px[k].y;
+                y = px[k].x;
+            }
+            const long long ix = wave_iscan_ll(x, lane), iy = wave_iscan_ll(y, lane), ixx = wave_iscan_ll(x * x, lane),
+                            iyy = wave_iscan_ll(y * y, lane), ixy = wave_iscan_ll(x * y, lane);
+            if (k < n) {  // exclusive value at k
+                P.x[k] = cx + ix - x; P.y[k] = cy + iy - y; P.xx[k] = cxx + ixx - x * x; P.yy[k] = cyy + iyy - y * y; P.xy[k] = cxy + ixy - x * y;
+            }
+            cx += __shfl(ix, 63, 64); cy += __shfl(iy, 63, 64); cxx += __shfl(ixx, 63, 64); cyy += __shfl(iyy, 63, 64); cxy += __shfl(ixy, 63, 64);
         }
-        P.x[n] = sx; P.y[n] = sy; P.xx[n] = sxx; P.yy[n] = syy; P.xy[n] = sxy;
+        if (lane == 0) {
+            P.x[n] = cx; P.y[n] = cy; P.xx[n] = cxx; P.yy[n] = cyy; P.xy[n] = cxy;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     fid_stag_line *L = slots + first / 9;
     int nl = 0;
@@ -1536,33 +1565,62 @@ __global__ __launch_bounds__(64) void k_stag_split_lines(const int2 *__restrict_
         bool valid = false;
         double lastA = 0, lastB = 0, error = 0;
         int lastInvert = 0;
+        // first window (sliding by one pixel) whose MLL-pixel fit has error <= 0.5: 64 positions per round
         while (noPixels >= MLL) {
-            sl_fit_first(P, px, base, MLL, &lastA, &lastB, &error, &lastInvert);
-            if (error <= 0.5) {
+            const int avail = noPixels - MLL + 1;  // window starts base .. base + avail - 1
+            double a = 0, bq = 0, e = 1e300;
+            int inv = 0;
+            if (lane < avail) sl_fit_first(P, px, base + lane, MLL, &a, &bq, &e, &inv);
+            const unsigned long long okm = __ballot(lane < avail && e <= 0.5);
+            if (okm) {
+                const int j = __builtin_ctzll(okm);
+                lastA = __shfl(a, j, 64); lastB = __shfl(bq, j, 64); error = __shfl(e, j, 64); lastInvert = __shfl(inv, j, 64);
+                noPixels -= j; base += j; firstPixelIndex += j;
                 valid = true;
                 break;
             }
-            noPixels -= 1;
-            base += 1;
-            firstPixelIndex += 1;
+            const int adv = avail < 64 ? avail : 64;
+            noPixels -= adv; base += adv; firstPixelIndex += adv;
         }
         if (!valid) break;
         int index = MLL, len = MLL;
         while (index < noPixels) {
             const int startIndex = index;
             int lastGoodIndex = index - 1, good = 0, bad = 0;
-            while (index < noPixels) {
-                const double d = sl_min_dist((double)px[base + index].y, (double)px[base + index].x, lastA, lastB, lastInvert);
-                if (d <= line_error) {
-                    lastGoodIndex = index;
-                    good++;
-                    bad = 0;
-                } else {
-                    bad++;
-                    if (bad >= 5) break;
+            int fitCount = len;  // pixels behind the current line parameters
+            bool broke = false;
+            while (index < noPixels && !broke) {
+                // distances of the next pixels under the current line
+                const int k = index + lane;
+                bool ok = false;
+                if (k < noPixels) ok = sl_min_dist((double)px[base + k].y, (double)px[base + k].x, lastA, lastB, lastInvert) <= line_error;
+                const unsigned long long gm = __ballot(ok);
+                const int lim = noPixels - index < 64 ? noPixels - index : 64;
+                int t = 0;
+                for (; t < lim; t++) {
+                    if ((gm >> t) & 1ull) {
+                        lastGoodIndex = index;
+                        good++;
+                        bad = 0;
+                    } else {
+                        bad++;
+                        if (bad >= 5) {
+                            broke = true;  // (the reference leaves `index` on this pixel)
+                            break;
+                        }
+                    }
+                    bool refit = false;
+                    if (good % 10 == 0) {
+                        const int cnt = lastGoodIndex - startIndex + len + 1;
+                        if (cnt != fitCount) {  // same pixels -> same parameters: nothing to do
+                            sl_fit_known(P, base, cnt, lastInvert, &lastA, &lastB);
+                            fitCount = cnt;
+                            refit = true;
+                        }
+                    }
+                    index++;
+                    if (refit) break;  // the rest of the batch was measured against the old line
                 }
-                if (good % 10 == 0) sl_fit_known(P, base, lastGoodIndex - startIndex + len + 1, lastInvert, &lastA, &lastB);
-                index++;
             }
             if (good >= 2) {
                 len += lastGoodIndex - startIndex + 1;
@@ -1578,9 +1636,12 @@ __global__ __launch_bounds__(64) void k_stag_split_lines(const int2 *__restrict_
                 idx = lastGoodIndex;
                 while (idx > 0 && sl_min_dist((double)px[base + idx].y, (double)px[base + idx].x, lastA, lastB, lastInvert) > line_error) idx--;
                 sl_min_dist((double)px[base + idx].y, (double)px[base + idx].x, lastA, lastB, lastInvert, &ex, &ey);
-                fid_stag_line &o = L[nl++];
-                o.a = lastA; o.b = lastB; o.invert = lastInvert; o.sx = sx; o.sy = sy; o.ex = ex; o.ey = ey;
-                o.segmentNo = seg; o.firstPixelIndex = firstPixelIndex + skipped; o.len = idx - skipped + 1;
+                if (lane == 0) {
+                    fid_stag_line &o = L[nl];
+                    o.a = lastA; o.b = lastB; o.invert = lastInvert; o.sx = sx; o.sy = sy; o.ex = ex; o.ey = ey;
+                    o.segmentNo = seg; o.firstPixelIndex = firstPixelIndex + skipped; o.len = idx - skipped + 1;
+                }
+                nl++;
                 len = idx + 1;
                 break;
             }
@@ -1589,7 +1650,11 @@ __global__ __launch_bounds__(64) void k_stag_split_lines(const int2 *__restrict_
         base += len;
         firstPixelIndex += len;
     }
-    // JoinCollinearLines (EDLines.cpp:114-156), MAX_DISTANCE_BETWEEN_TWO_LINES 6.0, MAX_ERROR 1.5 (:913)
+    // JoinCollinearLines (EDLines.cpp:114-156), MAX_DISTANCE_BETWEEN_TWO_LINES 6.0, MAX_ERROR 1.5 (:913): lane 0
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (lane != 0) return;
     if (nl > 0) {
         int last = 0;
         for (int j = 1; j < nl; j++) {
@@ -3381,7 +3446,7 @@ fid_status fid_stag_detect_lines(fid_stag_ctx *c, const uint8_t *gray, int32_t w
     PF.x = c->d_prefix; PF.y = PF.x + c->prefcap; PF.xx = PF.y + c->prefcap; PF.yy = PF.xx + c->prefcap; PF.xy = PF.yy + c->prefcap;
     const int wg = (ns + 63) / 64;
     if (wg > 0)
-        hipLaunchKernelGGL(k_stag_split_lines, dim3(wg), dim3(64), 0, st, c->d_vsegs, c->d_vtotal, c->d_outpix, PF, c->min_line_len, 1.0, c->d_lslots,
+        hipLaunchKernelGGL(k_stag_split_lines, dim3((ns + 3) / 4), dim3(256), 0, st, c->d_vsegs, c->d_vtotal, c->d_outpix, PF, c->min_line_len, 1.0, c->d_lslots,
                            c->d_lcounts);
     hipLaunchKernelGGL(k_stag_scan_counts, dim3(1), dim3(1024), 0, st, c->d_lcounts, c->d_vtotal, c->d_ltotal);
     if (wg > 0)

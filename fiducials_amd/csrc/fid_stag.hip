@@ -2583,38 +2583,64 @@ __device__ double sr_cost(const double x[9], const double Cm[9])
     return acc;
 }
 
-// cv::DownhillSolver::minimize with the default TermCriteria(MAX_ITER + EPS, 5000, 1e-6), 9 dimensions
-__device__ void sr_downhill(double x[9], const double step[9], const double Cm[9])
+// cv::DownhillSolver::minimize with the default TermCriteria(MAX_ITER + EPS, 5000, 1e-6), 9 dimensions, run by one wave with
+// the simplex in LDS.  The three candidate points of an iteration -- reflection (-1), expansion (-2), contraction (0.5) --
+// depend only on the current simplex: lanes 0, 1, 2 evaluate them side by side and the solver's decision sequence then
+// picks what it would have evaluated one after the other (the evaluation counter advances as in the sequential solver).
+// The ten vertices of the start simplex and of a shrink step are evaluated by ten lanes.  Same arithmetic per point as the
+// sequential form (column sums in vertex order, the same alpha / beta expressions).
+struct SrSimplex {
+    double p[10][9], y[10], sum[9];
+};
+
+#define SR_LDS_SYNC()                                          \
+    do {                                                       \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); \
+        __builtin_amdgcn_wave_barrier();                       \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); \
+    } while (0)
+
+__device__ void sr_downhill(double x[9], const double step[9], const double Cm[9], int lane, SrSimplex *S)
 {
     const int nd = 9;
-    double p[10][9], y[10], sum[9], buf[9];
-    for (int j = 0; j < nd; j++) p[0][j] = x[j];
-    for (int i = 1; i <= nd; i++) {
-        for (int j = 0; j < nd; j++) p[i][j] = p[0][j];
-        p[i][i - 1] += 0.5 * step[i - 1];
+    if (lane <= nd) {
+        for (int j = 0; j < nd; j++) {
+            double v = x[j];
+            if (lane == 0) v -= 0.5 * step[j];
+            else if (lane - 1 == j) v += 0.5 * step[j];
+            S->p[lane][j] = v;
+        }
     }
-    for (int j = 0; j < nd; j++) p[0][j] -= 0.5 * step[j];
-    int fcount = nd + 1;
-    for (int i = 0; i <= nd; i++) y[i] = sr_cost(p[i], Cm);
-    auto update_sum = [&]() {
-        for (int j = 0; j < nd; j++) sum[j] = 0.;
-        for (int i = 0; i <= nd; i++)
-            for (int j = 0; j < nd; j++) sum[j] += p[i][j];
+    SR_LDS_SYNC();
+    auto eval_rows = [&](int skip) {  // y[i] = f(p[i]) for every vertex but `skip`, one lane per vertex
+        const int i = lane <= nd ? lane : nd;
+        double row[9];
+        for (int j = 0; j < nd; j++) row[j] = S->p[i][j];
+        const double v = sr_cost(row, Cm);
+        if (lane <= nd && lane != skip) S->y[lane] = v;
+        SR_LDS_SYNC();
     };
-    auto try_point = [&](int ihi, double alpha_) {
-        const double alpha = (1.0 - alpha_) / nd, beta = alpha - alpha_;
-        for (int j = 0; j < nd; j++) buf[j] = sum[j] * alpha - p[ihi][j] * beta;
-        fcount++;
-        return sr_cost(buf, Cm);
+    auto update_sum = [&]() {
+        if (lane < nd) {
+            double acc = 0.;
+            for (int i = 0; i <= nd; i++) acc += S->p[i][lane];
+            S->sum[lane] = acc;
+        }
+        SR_LDS_SYNC();
     };
     auto replace_point = [&](int ihi, double alpha_, double ytry) {
         const double alpha = (1.0 - alpha_) / nd, beta = alpha - alpha_;
-        for (int j = 0; j < nd; j++) p[ihi][j] = sum[j] * alpha - p[ihi][j] * beta;
-        y[ihi] = ytry;
+        if (lane < nd) S->p[ihi][lane] = S->sum[lane] * alpha - S->p[ihi][lane] * beta;
+        if (lane == 0) S->y[ihi] = ytry;
+        SR_LDS_SYNC();
         update_sum();
     };
+    int fcount = nd + 1;
+    eval_rows(-1);
     update_sum();
     for (;;) {
+        double y[10];
+        for (int i = 0; i <= nd; i++) y[i] = S->y[i];
         int ilo = 0, ihi, inhi;
         if (y[0] > y[1]) { ihi = 0; inhi = 1; } else { ihi = 1; inhi = 0; }
         for (int i = 0; i <= nd; i++) {
@@ -2628,36 +2654,49 @@ __device__ void sr_downhill(double x[9], const double step[9], const double Cm[9
                 if (y[i] == y[ilo] && i != ihi && i != inhi) { ilo = i; break; }
         const double error = fabs(y[ihi] - y[ilo]);
         double range = 0;
-        for (int j = 0; j < nd; j++) {
-            double mn = p[0][j], mx = p[0][j];
-            for (int i = 1; i <= nd; i++) {
-                mn = fmin(mn, p[i][j]);
-                mx = fmax(mx, p[i][j]);
+        {
+            double r = 0;
+            if (lane < nd) {
+                double mn = S->p[0][lane], mx = mn;
+                for (int i = 1; i <= nd; i++) {
+                    mn = fmin(mn, S->p[i][lane]);
+                    mx = fmax(mx, S->p[i][lane]);
+                }
+                r = fabs(mx - mn);
             }
-            range = fmax(range, fabs(mx - mn));
+#pragma unroll
+            for (int off = 8; off > 0; off >>= 1) r = fmax(r, __shfl_xor(r, off, 64));
+            range = __shfl(r, 0, 64);
         }
         if (range <= 0.000001 || error <= 0.000001 || fcount >= 5000) {
-            for (int j = 0; j < nd; j++) x[j] = p[ilo][j];
+            for (int j = 0; j < nd; j++) x[j] = S->p[ilo][j];
             return;
         }
         const double y_lo = y[ilo], y_nhi = y[inhi], y_hi = y[ihi];
-        double alpha = -1.0;
-        double y_alpha = try_point(ihi, alpha);
+        double buf[9];
+        {
+            const double a_ = lane == 0 ? -1.0 : lane == 1 ? -2.0 : 0.5;
+            const double alpha = (1.0 - a_) / nd, beta = alpha - a_;
+            for (int j = 0; j < nd; j++) buf[j] = S->sum[j] * alpha - S->p[ihi][j] * beta;
+        }
+        const double yl = sr_cost(buf, Cm);
+        const double y_refl = __shfl(yl, 0, 64), y_exp = __shfl(yl, 1, 64), y_con = __shfl(yl, 2, 64);
+        fcount++;
+        double alpha = -1.0, y_alpha = y_refl;
         if (y_alpha < y_nhi) {
             if (y_alpha < y_lo) {
-                const double y_beta = try_point(ihi, -2.0);
-                if (y_beta < y_alpha) { alpha = -2.0; y_alpha = y_beta; }
+                fcount++;
+                if (y_exp < y_alpha) { alpha = -2.0; y_alpha = y_exp; }
             }
             replace_point(ihi, alpha, y_alpha);
         } else {
-            const double y_gamma = try_point(ihi, 0.5);
-            if (y_gamma < y_hi) replace_point(ihi, 0.5, y_gamma);
+            fcount++;
+            if (y_con < y_hi) replace_point(ihi, 0.5, y_con);
             else {
-                for (int i = 0; i <= nd; i++)
-                    if (i != ilo) {
-                        for (int j = 0; j < nd; j++) p[i][j] = 0.5 * (p[i][j] + p[ilo][j]);
-                        y[i] = sr_cost(p[i], Cm);
-                    }
+                if (lane <= nd && lane != ilo)
+                    for (int j = 0; j < nd; j++) S->p[lane][j] = 0.5 * (S->p[lane][j] + S->p[ilo][j]);
+                SR_LDS_SYNC();
+                eval_rows(ilo);
                 fcount += nd;
                 update_sum();
             }
@@ -2768,7 +2807,9 @@ __global__ __launch_bounds__(64) void k_stag_refine(fid_stag_marker *__restrict_
         __builtin_amdgcn_wave_barrier();
         if (n < 6) return;
     }
-    if (lane != 0) return;
+    // from here on every lane carries the same values (the fit is small scalar work; the simplex search spreads its function
+    // evaluations over the lanes)
+    __shared__ SrSimplex s_simplex;
     SrM S;
     for (int i = 0; i < 7; i++)
         for (int j = 0; j < 7; j++) S[i][j] = s_S[i][j];
@@ -2781,7 +2822,7 @@ __global__ __launch_bounds__(64) void k_stag_refine(fid_stag_marker *__restrict_
     for (int i = 0; i < 3; i++)
         for (int j = 0; j < 3; j++) x[i + j * 3] = M.H[3 * i + j];
     for (int k = 0; k < 9; k++) step[k] = fabs(0.001 * x[k]);
-    sr_downhill(x, step, Cm);
+    sr_downhill(x, step, Cm, lane, &s_simplex);
     for (int i = 0; i < 3; i++)
         for (int j = 0; j < 3; j++) M.H[3 * i + j] = x[i + j * 3];
     // ---- (4) points from the refined H
@@ -2795,7 +2836,7 @@ __global__ __launch_bounds__(64) void k_stag_refine(fid_stag_marker *__restrict_
     project(1, 0, &M.corners[2], &M.corners[3]);
     project(1, 1, &M.corners[4], &M.corners[5]);
     project(0, 1, &M.corners[6], &M.corners[7]);
-    markers[m] = M;
+    if (lane == 0) markers[m] = M;
 }
 
 // ------------------------------------------------------------------------------------------------ K17: marker pose

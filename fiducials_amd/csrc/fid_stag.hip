@@ -795,6 +795,7 @@ __global__ __launch_bounds__(256) void k_stag_ccl_flatten(int n, int *label, con
 }
 
 // cursors: [0] components [1] anchor slots [2] scratch pixels [3] stack [4] chains [5] output pixels [6] segments [7] overflow
+//          [8] overflow flags of the routing kernels [9] most anchors in one component
 __global__ __launch_bounds__(256) void k_stag_comp_alloc(int n, const int *__restrict__ label, const int *__restrict__ csize,
                                                          const int *__restrict__ canch, int *__restrict__ cursors, int max_comps, const int *caps,
                                                          StagComp *__restrict__ comps, int *__restrict__ cidmap)
@@ -804,6 +805,7 @@ __global__ __launch_bounds__(256) void k_stag_comp_alloc(int n, const int *__res
     cidmap[i] = -1;
     const int na = canch[i], sz = csize[i];
     if (na == 0) return;
+    atomicMax(&cursors[9], na);
     const int cid = atomicAdd(&cursors[0], 1);
     if (cid >= max_comps) {
         atomicOr(&cursors[7], 1);
@@ -3374,9 +3376,12 @@ static fid_status stag_route_par(fid_stag_ctx *c, const StagRoute &R)
                        c->d_comps, c->d_cidmap);
     hipLaunchKernelGGL(k_stag_comp_fill, dim3((na + 255) / 256), dim3(256), 0, st, c->d_sorted, c->d_n, c->d_label, c->d_cidmap, c->d_comps, c->d_fill,
                        c->d_aslots);
-    int cur[8];
-    if (hipMemcpyAsync(cur, c->d_cursors, 32, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return FID_E_HIP;
+    int cur[10];
+    if (hipMemcpyAsync(cur, c->d_cursors, 40, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return FID_E_HIP;
     if (cur[7]) return FID_E_CAPACITY;
+    // one component holding (nearly) all anchors -- a frame of noise -- leaves nothing to run side by side, and sorting its
+    // anchors would cost more than the sequential road's single pass over the globally sorted list
+    if (cur[9] > 65536) return FID_E_CAPACITY;
     const int nc = cur[0];
     StagArenas A;
     A.pix = c->d_apix; A.stack = c->d_astack; A.chains = c->d_achains; A.out = c->d_aout; A.segs = c->d_asegs; A.recs = c->d_recs;

@@ -443,6 +443,29 @@ def test_empty_and_degenerate_frames_go_through_every_stage():
         det.close()
 
 
+def test_noise_at_720p_takes_the_sequential_road_and_still_matches():
+    """A 1280x720 frame of pure noise: one gradient component with hundreds of thousands of anchors.  The component-parallel
+    road declines (nothing to run side by side), the call repeats on the sequential road; edge image and segments as the
+    reference's, in bounded time."""
+    if not stag_ref.available():
+        pytest.skip("oracle/_ref/libstag_ref.so not built (needs /root/reference at build time)")
+    import time
+    noise = np.random.default_rng(43).integers(0, 256, (720, 1280)).astype(np.uint8)
+    det = fstag.StagDetector(21, 7, max_width=1920, max_height=1080)
+    try:
+        t0 = time.perf_counter()
+        det.detect_edges(noise)
+        dt = time.perf_counter() - t0
+        ref_edge, raw = stag_ref.route(det.tap(fstag.TAP_GRAD), det.tap(fstag.TAP_DIR), det.tap(fstag.TAP_ANCHORS))
+        assert np.array_equal(det.tap(fstag.TAP_EDGEIMG), ref_edge)
+        mine = det.edge_segments()
+        assert len(mine) == len(raw) > 5000 and all(np.array_equal(a, b) for a, b in zip(mine, raw))
+        assert dt < 20.0, dt
+        print(f"720p noise: {len(det.tap(fstag.TAP_SORTED))} anchors, {len(raw)} segments, {dt * 1e3:.0f} ms")
+    finally:
+        det.close()
+
+
 def test_stag_status_codes():
     from fiducials_amd import _lib
     from fiducials_amd._lib import FidError

@@ -1,0 +1,830 @@
+// fid_stag_route.hip -- STag row s4: edge routing (JoinAnchorPointsUsingSortedAnchors), sequential and component-parallel.
+// Part of the fid_stag.hip translation unit (included there; not compiled on its own).
+// ------------------------------------------------------------------------------------------------ K10: edge routing
+// JoinAnchorPointsUsingSortedAnchors (EDInternals.cpp:842-1448): from every anchor that is still an anchor, strongest
+// first, draw the edge through the gradient ridge in both directions; where the edge orientation flips, branch; keep the
+// chain tree, emit its longest path as one segment and every remaining path of >= 10 pixels as further segments.  Every
+// decision reads what earlier walks left in the edge image, so the order is part of the result: this first version keeps
+// the reference's order by running ONE lane per frame (exact, slow); the walks of different connected components of
+// {grad >= GRADIENT_THRESH} never meet, which is the parallelism the next version uses.
+// The restatement is table-driven (one body for LEFT / RIGHT / UP / DOWN) and keeps the reference's array semantics where
+// they are visible in the result: 16-bit chain fields, the scratch pixel array shared by all chains of one anchor, the
+// contiguous output pixel array (a segment may look at the last pixel of the segment before it).
+#define STAG_EDGE_PIXEL 255
+#define STAG_MIN_PATH_LEN 10  // DoDetectEdgesByED, EDInternals.cpp:2604
+enum { SR_LEFT = 0, SR_RIGHT = 1, SR_UP = 2, SR_DOWN = 3 };
+
+struct StagChain {
+    int16_t dir;
+    uint16_t len;
+    int16_t parent;
+    int16_t child[2];
+    int32_t pix;  // first pixel of the chain in the scratch pixel array
+};
+
+struct StagRoute {
+    const int16_t *grad;
+    const uint8_t *dir;
+    uint8_t *edge;
+    int W, H;
+    int2 *pix;        // scratch: pixels of the chains of the current anchor (x = row, y = column)
+    int4 *stack;      // scratch: pending branches (r, c, dir, parent); reused by the tree walk of longest()
+    StagChain *chains;
+    int *chainNos;
+    int capPix, capStack, capChains, capNos;
+    int2 *outpix;     // map->pixels
+    int2 *segs;       // (first pixel, number of pixels) per segment
+    int capOut, capSegs;
+    int *counters;    // [0] segments [1] pixels used in outpix [2] overflow flags
+};
+
+__device__ __forceinline__ bool sr_near(int2 a, int2 b)
+{
+    int dr = a.x - b.x, dc = a.y - b.y;
+    dr = dr < 0 ? -dr : dr;
+    dc = dc < 0 ? -dc : dc;
+    return dr <= 1 && dc <= 1;
+}
+
+struct StagRouter {
+    StagRoute R;
+    int noSegments, totalPixels, overflow;
+    int segbase, nsp;  // the segment being assembled: first pixel in outpix, pixels so far
+    // component-parallel routing: outpix is the component's own arena and "the pixel in front of the block" is the last pixel
+    // of the block the reference would have written just before this one -- known (and relevant) only if that block came from
+    // the same component
+    bool par = false, prev_valid = false;
+    int blk0 = 0;  // where the current anchor's block starts in outpix
+    int wlane = -1;  // >= 0: a whole wave runs the extraction (identical scalar work in every lane, copies spread over the lanes)
+    int wl_len = 0, wl_dup = 0, wl_chains = 0;  // what walk_anchor() left behind
+
+    __device__ int2 cpx(int ch, int i) const
+    {
+        const int k = R.chains[ch].pix + i;
+        return k >= 0 ? R.pix[k] : make_int2(-1000, -1000);  // (the reference reads in front of its array there)
+    }
+    __device__ int2 seg(int i) const
+    {
+        const int k = segbase + i;
+        if (par && k < blk0) return (prev_valid && k >= 0) ? R.outpix[k] : make_int2(-1000, -1000);  // in front of this anchor's block
+        return k >= 0 ? R.outpix[k] : make_int2(-1000, -1000);
+    }
+    // append `count` pixels of chain cn, chain index first + step * k, to the segment
+    __device__ void seg_copy(int cn, int first, int step, int count)
+    {
+        if (count <= 0) return;
+        if (segbase + nsp + count > R.capOut) {
+            overflow |= 1;
+            nsp += count;
+            return;
+        }
+        const int2 *src = R.pix + R.chains[cn].pix;
+        int2 *dst = R.outpix + segbase + nsp;
+        if (wlane >= 0) {
+            for (int k = wlane; k < count; k += 64) dst[k] = src[first + step * k];
+        } else {
+            for (int k = 0; k < count; k++) dst[k] = src[first + step * k];
+        }
+        nsp += count;
+    }
+    __device__ void seg_put(int2 v)
+    {
+        const int k = segbase + nsp;
+        if (k < R.capOut) R.outpix[k] = v;
+        else overflow |= 1;
+        nsp++;
+    }
+    // LongestChain (EDInternals.cpp:191-214): length of the longest root-to-leaf path; prunes the shorter child of every
+    // chain it visits.  Chains of length 0 end the descent.
+    __device__ int longest(int root)
+    {
+        StagChain *ch = R.chains;
+        if (root == -1 || ch[root].len == 0) return 0;
+        int sp = 0, ret = 0;
+        R.stack[sp++] = make_int4(root, 0, 0, 0);
+        while (sp > 0) {
+            int4 e = R.stack[sp - 1];
+            const int node = e.x;
+            if (e.y == 0) {
+                e.y = 1;
+                R.stack[sp - 1] = e;
+                const int c = ch[node].child[0];
+                if (c != -1 && ch[c].len != 0) {
+                    if (sp < R.capStack) R.stack[sp++] = make_int4(c, 0, 0, 0);
+                    else { overflow |= 2; ret = 0; }
+                    if (!(overflow & 2)) continue;
+                }
+                ret = 0;
+            }
+            if (e.y == 1) {
+                e.z = ret;
+                e.y = 2;
+                R.stack[sp - 1] = e;
+                const int c = ch[node].child[1];
+                if (c != -1 && ch[c].len != 0) {
+                    if (sp < R.capStack) { R.stack[sp++] = make_int4(c, 0, 0, 0); continue; }
+                    overflow |= 2;
+                }
+                ret = 0;
+            }
+            const int len0 = e.z, len1 = ret;
+            int mx;
+            if (len0 >= len1) {
+                mx = len0;
+                ch[node].child[1] = -1;
+            } else {
+                mx = len1;
+                ch[node].child[0] = -1;
+            }
+            ret = ch[node].len + mx;
+            sp--;
+        }
+        return ret;
+    }
+    // RetrieveChainNos (EDInternals.cpp:219-234)
+    __device__ int retrieve(int root)
+    {
+        int count = 0;
+        while (root != -1) {
+            if (count < R.capNos) R.chainNos[count] = root;
+            else { overflow |= 4; break; }
+            count++;
+            root = R.chains[root].child[0] != -1 ? R.chains[root].child[0] : R.chains[root].child[1];
+        }
+        return count;
+    }
+    // drop pixels at the end of the segment that touch the pixel the next chain starts with
+    __device__ void trim_tail(int2 f)
+    {
+        int index = nsp - 2;
+        while (index >= 0) {
+            if (!sr_near(f, seg(index))) break;
+            nsp--;
+            index--;
+        }
+    }
+    __device__ void append_forward(int count)
+    {
+        StagChain *ch = R.chains;
+        for (int k = 0; k < count; k++) {
+            const int cn = R.chainNos[k];
+            trim_tail(cpx(cn, 0));
+            int start = 0;
+            const int L = ch[cn].len;
+            if (L > 1 && sr_near(cpx(cn, 1), seg(nsp - 1))) start = 1;
+            seg_copy(cn, start, 1, L - start);
+            ch[cn].len = 0;  // copied
+        }
+    }
+    __device__ void close_segment(bool clean_first)
+    {
+        int first = segbase, n = nsp;
+        totalPixels += nsp;
+        if (clean_first && sr_near(seg(1), seg(nsp - 1))) {
+            first++;
+            n--;
+        }
+        if (noSegments < R.capSegs) R.segs[noSegments] = make_int2(first, n);
+        else overflow |= 8;
+        noSegments++;
+    }
+
+    __device__ void route_anchor(int r0, int c0, int grad_thresh)
+    {
+        if (walk_anchor(r0, c0, grad_thresh)) extract_anchor(wl_chains);
+    }
+
+    // the walk: true if the anchor produced a path that is kept (the chain tree is then in R.chains / R.pix)
+    __device__ bool walk_anchor(int r0, int c0, int grad_thresh)
+    {
+        const int W = R.W;
+        StagChain *ch = R.chains;
+        ch[0].dir = 0; ch[0].len = 0; ch[0].parent = -1; ch[0].child[0] = ch[0].child[1] = -1; ch[0].pix = -1;
+        int noChains = 1, len = 0, dup = 0, top = -1;
+        if (R.dir[r0 * W + c0] == STAG_EDGE_VERTICAL) {
+            R.stack[++top] = make_int4(r0, c0, SR_DOWN, 0);
+            R.stack[++top] = make_int4(r0, c0, SR_UP, 0);
+        } else {
+            R.stack[++top] = make_int4(r0, c0, SR_RIGHT, 0);
+            R.stack[++top] = make_int4(r0, c0, SR_LEFT, 0);
+        }
+        while (top >= 0) {
+            const int4 e = R.stack[top--];
+            int r = e.x, c = e.y;
+            const int d = e.z, parent = e.w;
+            if (noChains >= R.capChains || len + 2 >= R.capPix || top + 3 >= R.capStack) {
+                overflow |= 16;
+                break;
+            }
+            if (R.edge[r * W + c] != STAG_EDGE_PIXEL) dup++;
+            const int cur = noChains;
+            ch[cur].dir = (int16_t)d; ch[cur].parent = (int16_t)parent; ch[cur].child[0] = ch[cur].child[1] = -1; ch[cur].pix = len;
+            int chainLen = 0;
+            R.pix[len++] = make_int2(r, c);
+            chainLen++;
+            const bool horiz = d == SR_LEFT || d == SR_RIGHT;
+            const int need = horiz ? STAG_EDGE_HORIZONTAL : STAG_EDGE_VERTICAL;
+            const int ar = d == SR_UP ? -1 : d == SR_DOWN ? 1 : 0, ac = d == SR_LEFT ? -1 : d == SR_RIGHT ? 1 : 0;
+            const int pr = horiz ? 1 : 0, pc = horiz ? 0 : 1;            // across the walking direction
+            const int fs = (d == SR_LEFT || d == SR_UP) ? -1 : 1;         // which diagonal is looked at first
+            const int slot = (d == SR_LEFT || d == SR_UP) ? 0 : 1;
+            bool stopped = false;
+            while (R.dir[r * W + c] == need) {
+                R.edge[r * W + c] = STAG_EDGE_PIXEL;
+                uint8_t *s1 = R.edge + (r + pr) * W + (c + pc), *s2 = R.edge + (r - pr) * W + (c - pc);
+                if (*s1 == STAG_ANCHOR_PIXEL) *s1 = 0;
+                if (*s2 == STAG_ANCHOR_PIXEL) *s2 = 0;
+                const int nr = r + ar, nc = c + ac;
+                if (R.edge[nr * W + nc] >= STAG_ANCHOR_PIXEL) {
+                    r = nr; c = nc;
+                } else if (R.edge[(nr + fs * pr) * W + nc + fs * pc] >= STAG_ANCHOR_PIXEL) {
+                    r = nr + fs * pr; c = nc + fs * pc;
+                } else if (R.edge[(nr - fs * pr) * W + nc - fs * pc] >= STAG_ANCHOR_PIXEL) {
+                    r = nr - fs * pr; c = nc - fs * pc;
+                } else {
+                    const int A = R.grad[(nr - pr) * W + nc - pc], B = R.grad[nr * W + nc], Cg = R.grad[(nr + pr) * W + nc + pc];
+                    int side = 0;
+                    if (A > B) side = A > Cg ? -1 : 1;
+                    else if (Cg > B) side = 1;
+                    r = nr + side * pr; c = nc + side * pc;
+                }
+                if (R.edge[r * W + c] == STAG_EDGE_PIXEL || R.grad[r * W + c] < grad_thresh) {
+                    ch[cur].len = (uint16_t)chainLen;
+                    ch[parent].child[slot] = (int16_t)cur;
+                    noChains++;
+                    stopped = true;
+                    break;
+                }
+                if (len + 2 >= R.capPix) { overflow |= 16; stopped = true; break; }
+                R.pix[len++] = make_int2(r, c);
+                chainLen++;
+            }
+            if (stopped) continue;
+            // the edge turns here: branch both ways across, this chain ends in front of the turning pixel
+            R.stack[++top] = make_int4(r, c, horiz ? SR_DOWN : SR_RIGHT, cur);
+            R.stack[++top] = make_int4(r, c, horiz ? SR_UP : SR_LEFT, cur);
+            len--;
+            chainLen--;
+            ch[cur].len = (uint16_t)chainLen;
+            ch[parent].child[slot] = (int16_t)cur;
+            noChains++;
+        }
+        wl_len = len;
+        wl_dup = dup;
+        wl_chains = noChains;
+        if (len - dup < STAG_MIN_PATH_LEN) {
+            for (int k = 0; k < len; k++) R.edge[R.pix[k].x * W + R.pix[k].y] = 0;
+            return false;
+        }
+        return true;
+    }
+
+    // The same walk run by a whole wave: control flow and bookkeeping are wave-uniform (every lane computes them, lane 0
+    // stores them), and what a step needs from memory -- edge / gradient / direction of the three pixels ahead and the edge
+    // value of the two pixels beside -- is fetched by eleven lanes at once, one round trip per step instead of a chain of
+    // dependent loads.  None of those eleven pixels is written in the same step (the current pixel and the two beside it
+    // are not among the three ahead), so the fetch sees exactly what the sequential code would read.
+    __device__ bool walk_anchor_wave(int r0, int c0, int grad_thresh, int lane)
+    {
+        const int W = R.W;
+        const bool L0 = lane == 0;
+        StagChain *ch = R.chains;
+        if (L0) {
+            ch[0].dir = 0; ch[0].len = 0; ch[0].parent = -1; ch[0].child[0] = ch[0].child[1] = -1; ch[0].pix = -1;
+        }
+        int noChains = 1, len = 0, dup = 0, top = -1;
+        const bool vert0 = R.dir[r0 * W + c0] == STAG_EDGE_VERTICAL;
+        if (L0) {
+            R.stack[0] = make_int4(r0, c0, vert0 ? SR_DOWN : SR_RIGHT, 0);
+            R.stack[1] = make_int4(r0, c0, vert0 ? SR_UP : SR_LEFT, 0);
+        }
+        top = 1;
+        while (top >= 0) {
+            const int4 e = R.stack[top--];
+            int r = e.x, c = e.y;
+            const int d = e.z, parent = e.w;
+            if (noChains >= R.capChains || len + 2 >= R.capPix || top + 3 >= R.capStack) {
+                overflow |= 16;
+                break;
+            }
+            if (R.edge[r * W + c] != STAG_EDGE_PIXEL) dup++;
+            const int cur = noChains;
+            if (L0) {
+                ch[cur].dir = (int16_t)d; ch[cur].parent = (int16_t)parent; ch[cur].child[0] = ch[cur].child[1] = -1; ch[cur].pix = len;
+                R.pix[len] = make_int2(r, c);
+            }
+            len++;
+            int chainLen = 1;
+            const bool horiz = d == SR_LEFT || d == SR_RIGHT;
+            const int need = horiz ? STAG_EDGE_HORIZONTAL : STAG_EDGE_VERTICAL;
+            const int ar = d == SR_UP ? -1 : d == SR_DOWN ? 1 : 0, ac = d == SR_LEFT ? -1 : d == SR_RIGHT ? 1 : 0;
+            const int pr = horiz ? 1 : 0, pc = horiz ? 0 : 1;
+            const int fs = (d == SR_LEFT || d == SR_UP) ? -1 : 1;
+            const int slot = (d == SR_LEFT || d == SR_UP) ? 0 : 1;
+            bool stopped = false;
+            int curdir = R.dir[r * W + c];
+            while (curdir == need) {
+                const int nr = r + ar, nc = c + ac;
+                // lane -> (array, pixel): 0-2 edge, 3-5 grad, 6-8 dir of A = ahead - p, B = ahead, C = ahead + p; 9, 10 edge beside
+                int v = 0;
+                {
+                    const int k = lane % 3, side = k - 1;  // A, B, C
+                    const int qr = nr + side * pr, qc = nc + side * pc;
+                    const int q = qr * W + qc;
+                    if (lane < 3) v = R.edge[q];
+                    else if (lane < 6) v = R.grad[q];
+                    else if (lane < 9) v = R.dir[q];
+                    else if (lane == 9) v = R.edge[(r + pr) * W + (c + pc)];
+                    else if (lane == 10) v = R.edge[(r - pr) * W + (c - pc)];
+                }
+                const int eA = __builtin_amdgcn_readlane(v, 0), eB = __builtin_amdgcn_readlane(v, 1), eC = __builtin_amdgcn_readlane(v, 2);
+                const int gA = __builtin_amdgcn_readlane(v, 3), gB = __builtin_amdgcn_readlane(v, 4), gC = __builtin_amdgcn_readlane(v, 5);
+                const int dA = __builtin_amdgcn_readlane(v, 6), dB = __builtin_amdgcn_readlane(v, 7), dC = __builtin_amdgcn_readlane(v, 8);
+                const int s1 = __builtin_amdgcn_readlane(v, 9), s2 = __builtin_amdgcn_readlane(v, 10);
+                if (L0) {
+                    R.edge[r * W + c] = STAG_EDGE_PIXEL;
+                    if (s1 == STAG_ANCHOR_PIXEL) R.edge[(r + pr) * W + (c + pc)] = 0;
+                    if (s2 == STAG_ANCHOR_PIXEL) R.edge[(r - pr) * W + (c - pc)] = 0;
+                }
+                const int eF1 = fs < 0 ? eA : eC, eF2 = fs < 0 ? eC : eA;  // the diagonal looked at first / second
+                int side;
+                if (eB >= STAG_ANCHOR_PIXEL) side = 0;
+                else if (eF1 >= STAG_ANCHOR_PIXEL) side = fs;
+                else if (eF2 >= STAG_ANCHOR_PIXEL) side = -fs;
+                else {
+                    side = 0;
+                    if (gA > gB) side = gA > gC ? -1 : 1;
+                    else if (gC > gB) side = 1;
+                }
+                r = nr + side * pr;
+                c = nc + side * pc;
+                const int en = side < 0 ? eA : side > 0 ? eC : eB, gn = side < 0 ? gA : side > 0 ? gC : gB;
+                curdir = side < 0 ? dA : side > 0 ? dC : dB;
+                if (en == STAG_EDGE_PIXEL || gn < grad_thresh) {
+                    if (L0) {
+                        ch[cur].len = (uint16_t)chainLen;
+                        ch[parent].child[slot] = (int16_t)cur;
+                    }
+                    noChains++;
+                    stopped = true;
+                    break;
+                }
+                if (len + 2 >= R.capPix) { overflow |= 16; stopped = true; break; }
+                if (L0) R.pix[len] = make_int2(r, c);
+                len++;
+                chainLen++;
+            }
+            if (stopped) continue;
+            if (L0) {
+                R.stack[top + 1] = make_int4(r, c, horiz ? SR_DOWN : SR_RIGHT, cur);
+                R.stack[top + 2] = make_int4(r, c, horiz ? SR_UP : SR_LEFT, cur);
+            }
+            top += 2;
+            len--;
+            chainLen--;
+            if (L0) {
+                ch[cur].len = (uint16_t)chainLen;
+                ch[parent].child[slot] = (int16_t)cur;
+            }
+            noChains++;
+        }
+        wl_len = len;
+        wl_dup = dup;
+        wl_chains = noChains;
+        if (len - dup < STAG_MIN_PATH_LEN) {
+            for (int k = lane; k < len; k += 64) R.edge[R.pix[k].x * W + R.pix[k].y] = 0;
+            return false;
+        }
+        return true;
+    }
+
+    // the chain tree -> segments
+    __device__ void extract_anchor(int noChains)
+    {
+        StagChain *ch = R.chains;
+        blk0 = totalPixels;
+        segbase = totalPixels;
+        nsp = 0;
+        int totalLen = longest(ch[0].child[1]);
+        if (totalLen > 0) {  // the path behind the anchor, copied backwards so that the segment runs through the anchor
+            const int count = retrieve(ch[0].child[1]);
+            for (int k = count - 1; k >= 0; k--) {
+                const int cn = R.chainNos[k];
+                trim_tail(cpx(cn, ch[cn].len - 1));
+                if (ch[cn].len > 1 && sr_near(cpx(cn, ch[cn].len - 2), seg(nsp - 1))) ch[cn].len--;
+                seg_copy(cn, ch[cn].len - 1, -1, ch[cn].len);
+                ch[cn].len = 0;
+            }
+        }
+        totalLen = longest(ch[0].child[0]);
+        if (totalLen > 1) {
+            const int count = retrieve(ch[0].child[0]);
+            const int first = R.chainNos[0];  // its first pixel is the anchor again
+            ch[first].pix++;
+            ch[first].len--;
+            append_forward(count);
+        }
+        close_segment(true);
+        for (int k = 2; k < noChains; k++) {  // what is left of the tree
+            if (ch[k].len < 2) continue;
+            totalLen = longest(k);
+            if (totalLen >= 10) {
+                segbase = totalPixels;
+                nsp = 0;
+                append_forward(retrieve(k));
+                close_segment(false);
+            }
+        }
+    }
+};
+
+__global__ __launch_bounds__(64) void k_stag_route_seq(StagRoute R, const int32_t *__restrict__ sorted, const unsigned *__restrict__ n_anchors,
+                                                       int grad_thresh)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    StagRouter S;
+    S.R = R;
+    S.noSegments = S.totalPixels = S.overflow = 0;
+    S.segbase = S.nsp = 0;
+    const int n = (int)*n_anchors;
+    for (int k = n - 1; k >= 0; k--) {
+        const int off = sorted[k];
+        if (R.edge[off] != STAG_ANCHOR_PIXEL) continue;
+        S.route_anchor(off / R.W, off % R.W, grad_thresh);
+        if (S.overflow) break;
+    }
+    R.counters[0] = S.noSegments;
+    R.counters[1] = S.totalPixels;
+    R.counters[2] = S.overflow;
+}
+
+// ---- component-parallel routing ---------------------------------------------------------------------------------
+// A walk only ever stands on pixels with grad >= GRADIENT_THRESH (it stops in front of anything weaker) and only touches the
+// edge image at those pixels and their walked neighbours' cross pixels, which are anchors, hence also >= the threshold: walks
+// of different 8-connected components of {grad >= GRADIENT_THRESH} never read or write the same pixel.  So every component
+// can process ITS anchors, strongest first, on its own -- the edge image and every chain tree come out as in the reference's
+// single sequential loop.  What remains global is the ORDER of the output (segments are listed in the order their anchors
+// were processed) and one quirk: when a block of segments starts, the reference peeks at the pixel in front of it in the
+// contiguous pixel array, i.e. at the last pixel of the block before -- which can only matter (8-adjacency) if that block
+// belongs to the same component.  Hence two passes:
+//   k_stag_ccl_*          connected components by union-find with atomic hooking (labels = smallest pixel offset)
+//   k_stag_comp_*         per component: pixels, anchors -> arenas (scratch pixels, stack, chains, output) by atomic cursors;
+//                         its anchors gathered and sorted by rank (bitonic, one wave per component)
+//   k_stag_route_walk     one LANE per component: the walks; chain trees of producing anchors stay in the arenas
+//   k_stag_next_above     for every anchor rank, the nearest producing rank above it (decides the quirk)
+//   k_stag_route_extract  one lane per component: chain trees -> blocks of segments in the component's output arena
+//   k_stag_route_gather   blocks -> EdgeMap::pixels / segments in global anchor order (offsets from two scans)
+struct StagComp {
+    int root, size, nanch;
+    int anch_base, anch_cap;      // slice of the anchor-rank array (padded to a power of two for the sort)
+    int pix_base, pix_cap;        // scratch pixels (chain trees of the producing anchors are kept)
+    int stack_base, stack_cap;
+    int chain_base, chain_cap;
+    int out_base, out_cap;        // output pixels of this component's blocks; chainNos live in the stack arena's tail
+    int seg_base, seg_cap;
+    int nrec;                     // producing anchors
+};
+
+struct StagRec {  // one producing anchor
+    int rank;
+    int pix_off, len;       // its chain-tree pixels inside the component's scratch arena
+    int chain_off, nchains;
+    int out_off, out_len;   // its block inside the component's output arena
+    int seg_off, nsegs;     // its segments inside the component's segment arena
+};
+
+__device__ __forceinline__ int ccl_find(const int *L, int a)
+{
+    while (true) {
+        const int p = L[a];
+        if (p == a) return a;
+        a = p;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_stag_ccl_init(const int16_t *__restrict__ grad, int n, int thresh, int *__restrict__ label)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) label[i] = grad[i] >= thresh ? i : -1;
+}
+
+__global__ __launch_bounds__(256) void k_stag_ccl_merge(int W, int H, int *label)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= W * H || label[i] < 0) return;
+    const int r = i / W, c = i - r * W;
+    // the four neighbours that precede the pixel in raster order (border pixels are background: grad = thresh - 1)
+    const int nb[4] = {c > 0 ? i - 1 : -1, (r > 0 && c > 0) ? i - W - 1 : -1, r > 0 ? i - W : -1, (r > 0 && c < W - 1) ? i - W + 1 : -1};
+    for (int k = 0; k < 4; k++) {
+        int b = nb[k];
+        if (b < 0 || label[b] < 0) continue;
+        int a = i;
+        while (true) {
+            a = ccl_find(label, a);
+            b = ccl_find(label, b);
+            if (a == b) break;
+            if (a < b) {
+                const int t = a;
+                a = b;
+                b = t;
+            }
+            const int old = atomicMin(&label[a], b);  // hook the larger root under the smaller one
+            if (old == a) break;
+            a = old;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_stag_ccl_flatten(int n, int *label, const uint8_t *__restrict__ anchors, int *__restrict__ csize,
+                                                          int *__restrict__ canch)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n || label[i] < 0) return;
+    const int root = ccl_find(label, i);
+    label[i] = root;
+    atomicAdd(&csize[root], 1);
+    if (anchors[i] == STAG_ANCHOR_PIXEL) atomicAdd(&canch[root], 1);
+}
+
+// cursors: [0] components [1] anchor slots [2] scratch pixels [3] stack [4] chains [5] output pixels [6] segments [7] overflow
+//          [8] overflow flags of the routing kernels [9] most anchors in one component
+__global__ __launch_bounds__(256) void k_stag_comp_alloc(int n, const int *__restrict__ label, const int *__restrict__ csize,
+                                                         const int *__restrict__ canch, int *__restrict__ cursors, int max_comps, const int *caps,
+                                                         StagComp *__restrict__ comps, int *__restrict__ cidmap)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n || label[i] != i) return;
+    cidmap[i] = -1;
+    const int na = canch[i], sz = csize[i];
+    if (na == 0) return;
+    atomicMax(&cursors[9], na);
+    const int cid = atomicAdd(&cursors[0], 1);
+    if (cid >= max_comps) {
+        atomicOr(&cursors[7], 1);
+        return;
+    }
+    StagComp C;
+    C.root = i; C.size = sz; C.nanch = na; C.nrec = 0;
+    int p2 = 1;
+    while (p2 < na) p2 <<= 1;
+    C.anch_cap = p2;
+    C.pix_cap = 2 * sz + 12 * na + 64;
+    C.stack_cap = (sz + 2 * na + 64) + (sz / 4 + 64);  // pending branches + (in its tail) the chain lists of the extraction
+    C.chain_cap = sz + 2 * na + 64;
+    C.out_cap = C.pix_cap;
+    C.seg_cap = C.pix_cap / 8 + na + 8;
+    C.anch_base = atomicAdd(&cursors[1], C.anch_cap);
+    C.pix_base = atomicAdd(&cursors[2], C.pix_cap);
+    C.stack_base = atomicAdd(&cursors[3], C.stack_cap);
+    C.chain_base = atomicAdd(&cursors[4], C.chain_cap);
+    C.out_base = atomicAdd(&cursors[5], C.out_cap);
+    C.seg_base = atomicAdd(&cursors[6], C.seg_cap);
+    if (C.anch_base + C.anch_cap > caps[1] || C.pix_base + C.pix_cap > caps[2] || C.stack_base + C.stack_cap > caps[3] ||
+        C.chain_base + C.chain_cap > caps[4] || C.out_base + C.out_cap > caps[5] || C.seg_base + C.seg_cap > caps[6]) {
+        atomicOr(&cursors[7], 2);
+        C.nanch = 0;  // not processed; the call reports FID_E_CAPACITY
+    }
+    comps[cid] = C;
+    cidmap[i] = cid;
+}
+
+__global__ __launch_bounds__(256) void k_stag_comp_fill(const int32_t *__restrict__ sorted, const unsigned *__restrict__ n_anchors,
+                                                        const int *__restrict__ label, const int *__restrict__ cidmap, const StagComp *__restrict__ comps,
+                                                        int *__restrict__ fill, int *__restrict__ aslots)
+{
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= (int)*n_anchors) return;
+    const int cid = cidmap[label[sorted[r]]];
+    if (cid < 0 || comps[cid].nanch == 0) return;
+    const int pos = atomicAdd(&fill[cid], 1);
+    aslots[comps[cid].anch_base + pos] = r;
+}
+
+// ranks of one component, descending: bitonic sort of the (padded, -1 filled) slice, one wave per component; slices of up to
+// 2048 entries are sorted in LDS
+#define STAG_SORT_LDS 2048
+__global__ __launch_bounds__(256) void k_stag_comp_sort(const StagComp *__restrict__ comps, const int *__restrict__ cursors, int *aslots)
+{
+    __shared__ int s_buf[4][STAG_SORT_LDS];
+    const int wv = threadIdx.x >> 6, cid = blockIdx.x * 4 + wv, lane = threadIdx.x & 63;
+    if (cid >= cursors[0]) return;
+    const StagComp C = comps[cid];
+    if (C.nanch < 2) return;
+    int *g = aslots + C.anch_base;
+    const int P = C.anch_cap;
+    const bool in_lds = P <= STAG_SORT_LDS;
+    int *a = in_lds ? s_buf[wv] : g;
+    if (in_lds) {
+        for (int i = lane; i < P; i += 64) a[i] = g[i];
+        __builtin_amdgcn_wave_barrier();
+    }
+    for (int k = 2; k <= P; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = lane; i < P; i += 64) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const int x = a[i], y = a[l];
+                    const bool desc = (i & k) == 0;
+                    if (desc ? x < y : x > y) {
+                        a[i] = y;
+                        a[l] = x;
+                    }
+                }
+            }
+            if (in_lds) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            } else {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            }
+        }
+    }
+    if (in_lds)
+        for (int i = lane; i < P; i += 64) g[i] = a[i];
+}
+
+struct StagArenas {
+    int2 *pix;
+    int4 *stack;
+    StagChain *chains;
+    int2 *out;
+    int2 *segs;
+    StagRec *recs;  // indexed like the anchor slots
+};
+
+__device__ void stag_bind(StagRouter &S, const StagRoute &G, const StagArenas &A, const StagComp &C)
+{
+    S.R = G;
+    S.R.pix = A.pix + C.pix_base;
+    S.R.capPix = C.pix_cap;
+    S.R.stack = A.stack + C.stack_base;
+    S.R.capStack = C.stack_cap - (C.size / 4 + 64);
+    S.R.chainNos = (int *)(A.stack + C.stack_base + S.R.capStack);  // int view of the arena's tail: 4 ints per entry
+    S.R.capNos = (C.size / 4 + 64) * 4;
+    S.R.chains = A.chains + C.chain_base;
+    S.R.capChains = C.chain_cap < 32767 ? C.chain_cap : 32767;
+    S.R.outpix = A.out + C.out_base;
+    S.R.capOut = C.out_cap;
+    S.R.segs = A.segs + C.seg_base;
+    S.R.capSegs = C.seg_cap;
+    S.par = true;
+}
+
+__global__ __launch_bounds__(256) void k_stag_route_walk(StagRoute G, StagArenas A, StagComp *__restrict__ comps, const int *__restrict__ cursors,
+                                                         const int32_t *__restrict__ sorted, const int *__restrict__ aslots, int grad_thresh,
+                                                         int *__restrict__ prodflag, int *__restrict__ ovf)
+{
+    const int cid = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;  // one wave per component
+    if (cid >= cursors[0]) return;
+    StagComp C = comps[cid];
+    if (C.nanch == 0) return;
+    StagRouter S;
+    stag_bind(S, G, A, C);
+    S.noSegments = S.totalPixels = S.overflow = 0;
+    S.segbase = S.nsp = 0;
+    StagRec *recs = A.recs + C.anch_base;
+    int nrec = 0, pix_used = 0, chain_used = 0;
+    int2 *pix0 = S.R.pix;
+    StagChain *chain0 = S.R.chains;
+    const int capPix0 = S.R.capPix, capChain0 = C.chain_cap;
+    for (int k0 = 0; k0 < C.nanch; k0 += 64) {
+        // which of the next 64 anchors are still anchors?  (a walk can only turn anchors OFF, so a stale "on" is re-checked)
+        const int kk = k0 + lane;
+        int my_off = -1;
+        if (kk < C.nanch) my_off = sorted[aslots[C.anch_base + kk]];
+        unsigned long long live = __ballot(my_off >= 0 && G.edge[my_off] == STAG_ANCHOR_PIXEL);
+        while (live) {
+            const int j = __builtin_ctzll(live);
+            live &= live - 1;
+            const int rank = aslots[C.anch_base + k0 + j];
+            const int off = sorted[rank];
+            if (G.edge[off] != STAG_ANCHOR_PIXEL) continue;
+            S.R.pix = pix0 + pix_used;
+            S.R.capPix = capPix0 - pix_used;
+            S.R.chains = chain0 + chain_used;
+            const int left = capChain0 - chain_used;
+            S.R.capChains = left < 32767 ? left : 32767;
+            if (S.R.capPix < 16 || S.R.capChains < 4) {
+                S.overflow |= 32;
+                break;
+            }
+            const bool keep = S.walk_anchor_wave(off / G.W, off % G.W, grad_thresh, lane);
+            if (S.overflow) break;
+            if (keep) {
+                if (lane == 0) {
+                    StagRec r;
+                    r.rank = rank; r.pix_off = pix_used; r.len = S.wl_len; r.chain_off = chain_used; r.nchains = S.wl_chains;
+                    r.out_off = r.out_len = r.seg_off = r.nsegs = 0;
+                    recs[nrec] = r;
+                    prodflag[rank] = 1;
+                }
+                nrec++;
+                pix_used += S.wl_len + 1;
+                chain_used += S.wl_chains;
+            }
+        }
+        if (S.overflow) break;
+    }
+    if (lane == 0) {
+        comps[cid].nrec = nrec;
+        if (S.overflow) atomicOr(ovf, S.overflow);
+    }
+}
+
+// next[r] = the smallest producing rank > r, or -1 (one workgroup, chunks of 1024 from the top)
+__global__ __launch_bounds__(1024) void k_stag_next_above(const int *__restrict__ prodflag, const unsigned *__restrict__ n_anchors, int *__restrict__ next)
+{
+    __shared__ int s[1024];
+    __shared__ int s_carry;
+    const int tid = threadIdx.x, n = (int)*n_anchors;
+    if (tid == 0) s_carry = -1;
+    __syncthreads();
+    for (int top = n; top > 0; top -= 1024) {
+        // thread t looks at rank r = top - 1 - t: ranks run downwards with t
+        const int r = top - 1 - tid;
+        const int v = (r >= 0 && prodflag[r]) ? r : -1;
+        // for every t: the producing rank with the largest t' < t (= nearest above), i.e. an exclusive "last set" scan
+        s[tid] = v;
+        __syncthreads();
+        for (int d = 1; d < 1024; d <<= 1) {
+            const int o = tid >= d ? s[tid - d] : -1;
+            __syncthreads();
+            if (s[tid] < 0) s[tid] = o;  // keep the nearest (largest t') set value: own slot wins, else what came from the left
+            __syncthreads();
+        }
+        // s[t] = nearest producing rank at t' <= t; exclusive: t' < t
+        const int incl_prev = tid > 0 ? s[tid - 1] : -1;
+        const int carry = s_carry;
+        if (r >= 0) next[r] = incl_prev >= 0 ? incl_prev : carry;
+        __syncthreads();
+        if (tid == 1023) s_carry = s[1023] >= 0 ? s[1023] : carry;
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void k_stag_route_extract(StagRoute G, StagArenas A, const StagComp *__restrict__ comps, const int *__restrict__ cursors,
+                                                            const int *__restrict__ next, const unsigned *__restrict__ n_anchors,
+                                                            int *__restrict__ blk_pix, int *__restrict__ blk_segs, int2 *__restrict__ blk_where,
+                                                            int *__restrict__ ovf)
+{
+    // one wave per component: every lane runs the same scalar steps (same values, same stores); pixel runs are copied by all lanes
+    const int cid = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (cid >= cursors[0]) return;
+    const StagComp C = comps[cid];
+    if (C.nanch == 0 || C.nrec == 0) return;
+    StagRouter S;
+    stag_bind(S, G, A, C);
+    S.wlane = lane;
+    S.noSegments = S.totalPixels = S.overflow = 0;
+    S.segbase = S.nsp = 0;
+    StagRec *recs = A.recs + C.anch_base;
+    int2 *pix0 = S.R.pix;
+    StagChain *chain0 = S.R.chains;
+    const int n = (int)*n_anchors;
+    int prev_rank = -1;
+    for (int k = 0; k < C.nrec; k++) {
+        StagRec r = recs[k];
+        S.R.pix = pix0 + r.pix_off;
+        S.R.chains = chain0 + r.chain_off;
+        // the block the reference wrote just before this one: ours only if no other component produced in between
+        S.prev_valid = k > 0 && next[r.rank] == prev_rank;
+        const int seg0 = S.noSegments, out0 = S.totalPixels;
+        S.extract_anchor(r.nchains);
+        r.out_off = out0; r.out_len = S.totalPixels - out0;
+        r.seg_off = seg0; r.nsegs = S.noSegments - seg0;
+        recs[k] = r;
+        const int q = n - 1 - r.rank;  // position in processing order
+        blk_pix[q] = r.out_len;
+        blk_segs[q] = r.nsegs;
+        blk_where[q] = make_int2(cid, k);
+        prev_rank = r.rank;
+        if (S.overflow) break;
+    }
+    if (S.overflow && lane == 0) atomicOr(ovf, S.overflow);
+}
+
+// blk_pix / blk_segs hold exclusive prefix sums by now: copy every block to its place in the global order
+__global__ __launch_bounds__(256) void k_stag_route_gather(StagArenas A, const StagComp *__restrict__ comps, const unsigned *__restrict__ n_anchors,
+                                                           const int *__restrict__ prodflag, const int *__restrict__ blk_pix,
+                                                           const int *__restrict__ blk_segs, const int2 *__restrict__ blk_where,
+                                                           int2 *__restrict__ outpix, int2 *__restrict__ segs, int capOut, int capSegs, int *__restrict__ ovf)
+{
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int n = (int)*n_anchors;
+    if (q >= n || !prodflag[n - 1 - q]) return;
+    const int2 w = blk_where[q];
+    const StagComp C = comps[w.x];
+    const StagRec r = (A.recs + C.anch_base)[w.y];
+    const int po = blk_pix[q], so = blk_segs[q];
+    if (po + r.out_len > capOut || so + r.nsegs > capSegs) {
+        if (lane == 0) atomicOr(ovf, 64);
+        return;
+    }
+    const int2 *src = A.out + C.out_base + r.out_off;
+    for (int i = lane; i < r.out_len; i += 64) outpix[po + i] = src[i];
+    const int2 *sg = A.segs + C.seg_base + r.seg_off;
+    for (int i = lane; i < r.nsegs; i += 64) segs[so + i] = make_int2(sg[i].x - r.out_off + po, sg[i].y);
+}

@@ -393,15 +393,31 @@ __global__ __launch_bounds__(64) void k_stag_refine(fid_stag_marker *__restrict_
     int chosen = -1;
     double minAcc = INFINITY;
     const int ns = *nsegs;
-    for (int sg = 0; sg < ns; sg++) {
+    for (int sg0 = 0; sg0 < ns; sg0 += 64) {
+      // the cheap tests (length, closed loop, sampled pixels inside the quad) for 64 segments at once, one per lane; the
+      // survivors are then examined one after the other, in segment order, by the whole wave
+      unsigned long long cand;
+      {
+        const int sgl = sg0 + lane;
+        bool ok = false;
+        if (sgl < ns) {
+            const int first = vsegs[sgl].x, n = vsegs[sgl].y;
+            if (n >= 20) {
+                const int2 *p = pix + first;
+                if (!(sq_dist2((double)p[0].y, (double)p[0].x, (double)p[n - 1].y, (double)p[n - 1].x) > 7.0 * 7.0)) {
+                    ok = true;
+                    for (int k = 0; k < n && ok; k += 20)
+                        if (!sr_in_quad(M.corners, (double)p[k].y, (double)p[k].x)) ok = false;
+                }
+            }
+        }
+        cand = __ballot(ok);
+      }
+      while (cand) {
+        const int sg = sg0 + __builtin_ctzll(cand);
+        cand &= cand - 1;
         const int first = vsegs[sg].x, n = vsegs[sg].y;
-        if (n < 20) continue;
         const int2 *p = pix + first;
-        if (sq_dist2((double)p[0].y, (double)p[0].x, (double)p[n - 1].y, (double)p[n - 1].x) > 7.0 * 7.0) continue;
-        bool outside = false;
-        for (int k = 0; k < n && !outside; k += 20)
-            if (!sr_in_quad(M.corners, (double)p[k].y, (double)p[k].x)) outside = true;
-        if (outside) continue;
         // back-projection; per sample point the minimum over the pixels, per pixel the minimum over the sample points
         bool bad = false;
         double sampleErr[36];
@@ -436,6 +452,7 @@ __global__ __launch_bounds__(64) void k_stag_refine(fid_stag_marker *__restrict_
             minAcc = errSum;
             chosen = sg;
         }
+      }
     }
     if (lane == 0) chosen_out[m] = chosen;
     if (chosen < 0) return;

@@ -251,6 +251,39 @@ def test_corner_refine_none_and_param_change():
     det.close()
 
 
+PARAM_SETS = [
+    dict(adaptiveThreshConstant=3.0, adaptiveThreshWinSizeMin=5, adaptiveThreshWinSizeMax=45, adaptiveThreshWinSizeStep=8),
+    dict(adaptiveThreshConstant=10.5, perspectiveRemovePixelPerCell=4, perspectiveRemoveIgnoredMarginPerCell=0.2, minOtsuStdDev=2.0),
+    dict(cornerRefinementWinSize=3, cornerRefinementMaxIterations=10, cornerRefinementMinAccuracy=0.1, minDistanceToBorder=10),
+    dict(polygonalApproxAccuracyRate=0.05, minCornerDistanceRate=0.1, minMarkerDistanceRate=0.2, maxMarkerPerimeterRate=1.0),
+    dict(errorCorrectionRate=0.0, maxErroneousBitsInBorderRate=0.35, minMarkerPerimeterRate=0.03, perspectiveRemovePixelPerCell=6),
+    dict(adaptiveThreshWinSizeMin=3, adaptiveThreshWinSizeMax=3, adaptiveThreshWinSizeStep=4, cornerRefinementMethod=0),
+]
+
+
+@pytest.mark.parametrize("k", range(len(PARAM_SETS)))
+@pytest.mark.parametrize("dic", [6, 0])
+def test_detector_parameter_matrix(k, dic):
+    """aruco::DetectorParameters away from the node defaults (the generic threshold kernel, other unwarp sizes, other gates
+    and refinement settings), two dictionaries: ids and corners as the oracle's under the same parameters."""
+    d = get_predefined_dictionary(dic)
+    fr = make_frame(d, 300 + 7 * k + dic, width=1280, height=720, n_markers=10, side_range=(70, 130))
+    p, op = default_params(), oracle.default_params()
+    for name, v in PARAM_SETS[k].items():
+        setattr(p, name, v)
+        setattr(op, name, v)
+    det = ArucoDetector(d, params=p, max_width=1280, max_height=720)
+    try:
+        corners, ids = det.detect_markers(fr.image)
+        oids, ocorners = oracle.detect(fr.image, d, params=op)
+        assert ids.tolist() == oids.tolist()
+        assert np.array_equal(corners, ocorners), np.abs(corners - ocorners).max()
+        if k != 3:
+            assert len(ids) >= 5
+    finally:
+        det.close()
+
+
 def test_whole_border_walk_and_seed_tracing_agree(monkeypatch):
     """The two contour-tracing paths of the library (FID_TRACE=legacy: probe passes + whole-border walk;
     default: seed-accelerated tracing) must both reproduce the oracle stage by stage, on adversarial blobs

@@ -1,0 +1,130 @@
+// fiducials_host.hpp -- the host side of the aruco_detect drop-in in the reference's own language: a ROS-free FiducialsNode
+// with the callbacks, members and parameter names of aruco_detect/src/aruco_detect.cpp:88-147, on top of the C-ABI
+// (include/fid_abi.h).  No ROS, catkin or OpenCV exists in this image, so the message types are plain structs with the fields
+// of the .msg files and "publishing" is returning the message; everything else -- gating, latching of the first CameraInfo,
+// ignore list, per-id lengths, header rules, quaternion -- is the node's logic, so that the node proper is this class plus
+// ros::Subscriber / Publisher glue.  The arithmetic of the hot path is NOT here: it is behind fid_detect / fid_pose_last.
+#ifndef FIDUCIALS_HOST_HPP
+#define FIDUCIALS_HOST_HPP
+#include <array>
+#include <cstdint>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "fid_abi.h"
+
+namespace fiducials_amd {
+
+struct Header {  // std_msgs/Header
+    uint32_t seq = 0;
+    uint32_t sec = 0, nsec = 0;
+    std::string frame_id;
+};
+struct Image {  // sensor_msgs/Image
+    Header header;
+    uint32_t height = 0, width = 0;
+    std::string encoding;  // "mono8", "bgr8", "rgb8"
+    uint8_t is_bigendian = 0;
+    uint32_t step = 0;
+    std::vector<uint8_t> data;
+};
+struct CameraInfo {  // sensor_msgs/CameraInfo (the fields the node reads)
+    Header header;
+    uint32_t height = 0, width = 0;
+    std::string distortion_model;
+    std::vector<double> D;
+    std::array<double, 9> K{};
+};
+struct Fiducial {  // fiducial_msgs/Fiducial
+    int32_t fiducial_id = 0, direction = 0;
+    double x0 = 0, y0 = 0, x1 = 0, y1 = 0, x2 = 0, y2 = 0, x3 = 0, y3 = 0;
+};
+struct FiducialArray {
+    Header header;
+    int32_t image_seq = 0;
+    std::vector<Fiducial> fiducials;
+};
+struct FiducialTransform {  // fiducial_msgs/FiducialTransform
+    int32_t fiducial_id = 0;
+    double tx = 0, ty = 0, tz = 0;          // geometry_msgs/Transform.translation
+    double qx = 0, qy = 0, qz = 0, qw = 1;  // geometry_msgs/Transform.rotation
+    double image_error = 0, object_error = 0, fiducial_area = 0;
+};
+struct FiducialTransformArray {
+    Header header;
+    int32_t image_seq = 0;
+    std::vector<FiducialTransform> transforms;
+};
+
+// ROS 1 wire format of the two output messages (little-endian, packed)
+std::vector<uint8_t> serialize(const FiducialArray &m);
+std::vector<uint8_t> serialize(const FiducialTransformArray &m);
+bool deserialize(const std::vector<uint8_t> &b, FiducialTransformArray *m);
+
+// aruco::getPredefinedDictionary(dicno) (aruco_detect.cpp:671): tables from <data_dir>/dict_*.txt (provenance:
+// tools/make_dictionaries.py); the returned object owns the byte list fid_dict points into
+struct Dictionary {
+    int markerSize = 0, maxCorrectionBits = 0, nMarkers = 0;
+    std::vector<uint8_t> bytesList;  // nMarkers x 4 rotations x nbytes
+    fid_dict view() const;
+};
+Dictionary getPredefinedDictionary(int dicno, const std::string &data_dir);
+
+class FiducialsNode {
+   public:
+    struct Params {  // the private parameters of the node with their defaults (aruco_detect.cpp:609-627) ...
+        bool publish_images = false;
+        double fiducial_len = 0.14;
+        int dictionary = 7;
+        bool do_pose_estimation = true;
+        bool publish_fiducial_tf = true;
+        bool vis_msgs = false;  // (vision_msgs output is not mirrored)
+        bool verbose = false;
+        std::string ignore_fiducials;
+        std::string fiducial_len_override;
+        fid_params detector;  // ... and the detector parameters as the node sets them (:690-727)
+        std::string data_dir = "fiducials_amd/data";
+        int device = 0, max_width = 1920, max_height = 1080;
+        Params();
+    };
+    explicit FiducialsNode(const Params &p);  // throws std::runtime_error without a device: there is no CPU path
+    ~FiducialsNode();
+    FiducialsNode(const FiducialsNode &) = delete;
+    FiducialsNode &operator=(const FiducialsNode &) = delete;
+
+    // the callbacks (same names as the reference).  The two image-path callbacks return true when the node would have
+    // published, the message is then in *out
+    void configCallback(const fid_params &config, uint32_t level);  // :257-298
+    void ignoreCallback(const std::string &msg);                     // :300-305
+    void camInfoCallback(const CameraInfo &msg);                     // :307-330
+    bool imageCallback(const Image &msg, FiducialArray *out);        // :332-395
+    bool poseEstimateCallback(const FiducialArray &msg, FiducialTransformArray *out);  // :397-538
+    bool enableDetectionsCallback(bool data, std::string *message);  // :573-588
+
+    // state the reference keeps as members (read-only views for tests)
+    const std::vector<int> &getIds() const { return ids; }
+    const std::vector<int> &getIgnoreIds() const { return ignoreIds; }
+    const std::map<int, double> &getFiducialLens() const { return fiducialLens; }
+    bool haveCameraInfo() const { return haveCamInfo; }
+    const std::string &lastError() const { return last_error; }
+
+   private:
+    void handleIgnoreString(const std::string &str);           // :540-571
+    void handleLenOverrideString(const std::string &str);      // :627-660
+    fid_ctx *ctx = nullptr;
+    Dictionary dict;
+    fid_params detectorParams;
+    std::vector<fid_marker> markers;   // corners / ids of the last image (the reference's `corners`, `ids` members, :101-102)
+    std::vector<int> ids;
+    std::vector<int> ignoreIds;
+    std::map<int, double> fiducialLens;
+    double cameraMatrix[9] = {0}, distortionCoeffs[5] = {0};
+    bool haveCamInfo = false, enable_detections = true, doPoseEstimation = true, verbose = false;
+    double fiducial_len = 0.14;
+    int frameNum = 0;
+    std::string frameId, last_error;
+};
+
+}  // namespace fiducials_amd
+#endif

@@ -41,3 +41,25 @@ def test_reference_node_test_passes_on_the_cpp_host(tmp_path):
     r = subprocess.run([exe, str(tmp_path), os.path.join(ROOT, "fiducials_amd", "data")], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "all checks passed" in r.stdout
+
+
+@pytest.mark.gpu
+def test_stag_class_and_fiducial_msgs_output_on_the_cpp_host(tmp_path):
+    """host/include/stag_host.hpp: class Stag (constructor, detectMarkers, getMarkerList as in stag/Stag.h:41-45), the 5-point
+    pose and the fiducial_msgs output, on a rendered HD21 frame."""
+    import sys
+    sys.path.insert(0, ROOT)
+    from fiducials_amd import synth
+    from fiducials_amd.stag import load_library
+    _build_host()
+    fr = synth.make_stag_frame(load_library(21), 8, 1280, 720, 8)
+    _write_pgm(tmp_path / "frame.pgm", fr.image)
+    lines = [str(len(fr.ids))]
+    for i, c, t in zip(fr.ids, fr.corners, fr.tvecs):
+        lines.append(" ".join([str(int(i))] + [repr(float(v)) for v in c.ravel()] + [repr(float(t[2]))]))
+    (tmp_path / "expected.txt").write_text("\n".join(lines))
+    exe = os.path.join(ROOT, "host", "bin", "stag_test")
+    r = subprocess.run([exe, str(tmp_path / "frame.pgm"), str(tmp_path / "expected.txt"), os.path.join(ROOT, "fiducials_amd", "data"), "21", "7"],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "all checks passed" in r.stdout

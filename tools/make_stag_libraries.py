@@ -29,6 +29,8 @@ def main():
         out[f"HD{hd}"] = vals
     assert sorted(out) == sorted(f"HD{k}" for k in EXPECT)
     np.savez_compressed(DST, **out)
+    for k, v in out.items():  # the same numbers as raw little-endian uint64, for the C++ host (host/include/stag_host.hpp)
+        v.astype("<u8").tofile(os.path.join(os.path.dirname(DST), f"stag_{k}.bin"))
     print("wrote", DST, {k: len(v) for k, v in out.items()}, os.path.getsize(DST), "bytes")
 
 

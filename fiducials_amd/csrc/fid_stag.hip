@@ -392,7 +392,7 @@ struct fid_stag_ctx {
     StagChain *d_achains = nullptr;
     StagComp *d_comps = nullptr;
     StagRec *d_recs = nullptr;
-    int max_comps = 0, cap_aslots = 0, route_mode = 1, route_fallbacks = 0;
+    int max_comps = 0, cap_aslots = 0, route_mode = 1, route_fallbacks = 0, route_tile = 1;
     // validation
     uint8_t *d_smooth2 = nullptr;
     int16_t *d_vgrad = nullptr;
@@ -489,6 +489,8 @@ fid_status fid_stag_create(int libraryHD, int errorCorrection, int max_width, in
         ok = hipMemcpy(c->d_caps, caps, sizeof(caps), hipMemcpyHostToDevice) == hipSuccess;
         const char *e = getenv("FID_STAG_ROUTE");
         c->route_mode = (e && !strcmp(e, "seq")) ? 0 : 1;
+        c->route_tile = (e && !strcmp(e, "notile")) ? 0 : 1;  // "notile": component-parallel, walks in global memory
+        ok = hipFuncSetAttribute((const void *)k_stag_route_walk, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) == hipSuccess;
     }
     ok = ok && hipMalloc((void **)&c->d_smooth2, n) == hipSuccess && hipMalloc((void **)&c->d_vgrad, n * 2) == hipSuccess &&
          hipMalloc((void **)&c->d_vhist, STAG_BINS * 4) == hipSuccess && hipMalloc((void **)&c->d_prob, STAG_BINS * 8) == hipSuccess &&
@@ -615,8 +617,11 @@ static fid_status stag_route_par(fid_stag_ctx *c, const StagRoute &R)
                        c->d_comps, c->d_cidmap);
     hipLaunchKernelGGL(k_stag_comp_fill, dim3((na + 255) / 256), dim3(256), 0, st, c->d_sorted, c->d_n, c->d_label, c->d_cidmap, c->d_comps, c->d_fill,
                        c->d_aslots);
-    int cur[10];
-    if (hipMemcpyAsync(cur, c->d_cursors, 40, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return FID_E_HIP;
+    const int LDS_CAP = 150 * 1024;  // of the 160 KB of a CU
+    hipLaunchKernelGGL(k_stag_comp_bbox, dim3(nb), dim3(256), 0, st, W, n, c->d_label, c->d_cidmap, c->d_comps);
+    hipLaunchKernelGGL(k_stag_comp_tilemax, dim3((c->max_comps + 255) / 256), dim3(256), 0, st, c->d_comps, c->d_cursors, LDS_CAP);
+    int cur[11];
+    if (hipMemcpyAsync(cur, c->d_cursors, 44, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return FID_E_HIP;
     if (cur[7]) return FID_E_CAPACITY;
     // one component holding (nearly) all anchors -- a frame of noise -- leaves nothing to run side by side, and sorting its
     // anchors would cost more than the sequential road's single pass over the globally sorted list
@@ -627,8 +632,11 @@ static fid_status stag_route_par(fid_stag_ctx *c, const StagRoute &R)
     int *ovf = c->d_cursors + 8;
     if (nc > 0) {
         hipLaunchKernelGGL(k_stag_comp_sort, dim3((nc + 3) / 4), dim3(256), 0, st, c->d_comps, c->d_cursors, c->d_aslots);
-        hipLaunchKernelGGL(k_stag_route_walk, dim3((nc + 3) / 4), dim3(256), 0, st, R, A, c->d_comps, c->d_cursors, c->d_sorted, c->d_aslots, 16,
-                           c->d_prodflag, ovf);
+        // LDS per workgroup = the largest tile a component of this frame asks for (components whose box does not fit 150 KB walk
+        // in global memory): frames of small components keep many workgroups per CU
+        const int lds = c->route_tile ? ((cur[10] + 1023) / 1024) * 1024 : 0;
+        hipLaunchKernelGGL(k_stag_route_walk, dim3(nc), dim3(256), (size_t)lds, st, R, A, c->d_comps, c->d_cursors, c->d_sorted, c->d_aslots, c->d_label,
+                           16, lds, c->d_prodflag, ovf);
     }
     hipLaunchKernelGGL(k_stag_next_above, dim3(1), dim3(1024), 0, st, c->d_prodflag, c->d_n, c->d_next);
     if (nc > 0)

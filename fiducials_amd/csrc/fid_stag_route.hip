@@ -398,6 +398,128 @@ struct StagRouter {
         return true;
     }
 
+    // The wave-run walk again, on a copy of the component's bounding box in LDS (one 16-bit word per pixel: gradient 11 bits,
+    // direction 1 bit, edge state 2 bits): every lane reads the same LDS words (broadcast), lane 0 writes.  A walk stands on
+    // pixels of its own component and looks one pixel around them, so everything it touches is inside the box + 1.
+    struct Tile {
+        uint16_t *t;
+        int r0, c0, tw;  // origin (row, column) of the tile in the image, words per tile row
+        __device__ int idx(int r, int c) const { return (r - r0) * tw + (c - c0); }
+        __device__ static int edge_of(uint16_t w) { const int st = w >> 12; return st ? 253 + st : 0; }
+        __device__ static int grad_of(uint16_t w) { return w & 0x7ff; }
+        __device__ static int dir_of(uint16_t w) { return (w & 0x800) ? STAG_EDGE_VERTICAL : STAG_EDGE_HORIZONTAL; }
+        __device__ void set_edge(int i, int st, bool writer) const
+        {
+            if (writer) t[i] = (uint16_t)((t[i] & 0x0fff) | (st << 12));
+        }
+    };
+    __device__ bool walk_anchor_tile(int r0, int c0, int grad_thresh, int lane, const Tile &T)
+    {
+        const bool L0 = lane == 0;
+        StagChain *ch = R.chains;
+        if (L0) {
+            ch[0].dir = 0; ch[0].len = 0; ch[0].parent = -1; ch[0].child[0] = ch[0].child[1] = -1; ch[0].pix = -1;
+        }
+        int noChains = 1, len = 0, dup = 0, top = -1;
+        const bool vert0 = Tile::dir_of(T.t[T.idx(r0, c0)]) == STAG_EDGE_VERTICAL;
+        if (L0) {
+            R.stack[0] = make_int4(r0, c0, vert0 ? SR_DOWN : SR_RIGHT, 0);
+            R.stack[1] = make_int4(r0, c0, vert0 ? SR_UP : SR_LEFT, 0);
+        }
+        top = 1;
+        while (top >= 0) {
+            const int4 e = R.stack[top--];
+            int r = e.x, c = e.y;
+            const int d = e.z, parent = e.w;
+            if (noChains >= R.capChains || len + 2 >= R.capPix || top + 3 >= R.capStack) {
+                overflow |= 16;
+                break;
+            }
+            int ci = T.idx(r, c);
+            uint16_t cw = T.t[ci];
+            if (Tile::edge_of(cw) != STAG_EDGE_PIXEL) dup++;
+            const int cur = noChains;
+            if (L0) {
+                ch[cur].dir = (int16_t)d; ch[cur].parent = (int16_t)parent; ch[cur].child[0] = ch[cur].child[1] = -1; ch[cur].pix = len;
+                R.pix[len] = make_int2(r, c);
+            }
+            len++;
+            int chainLen = 1;
+            const bool horiz = d == SR_LEFT || d == SR_RIGHT;
+            const int need = horiz ? STAG_EDGE_HORIZONTAL : STAG_EDGE_VERTICAL;
+            const int ar = d == SR_UP ? -1 : d == SR_DOWN ? 1 : 0, ac = d == SR_LEFT ? -1 : d == SR_RIGHT ? 1 : 0;
+            const int pstep = horiz ? T.tw : 1;            // one pixel across the walking direction, in tile words
+            const int astep = ar * T.tw + ac;              // one pixel ahead
+            const int pr = horiz ? 1 : 0, pc = horiz ? 0 : 1;
+            const int fs = (d == SR_LEFT || d == SR_UP) ? -1 : 1;
+            const int slot = (d == SR_LEFT || d == SR_UP) ? 0 : 1;
+            bool stopped = false;
+            int curdir = Tile::dir_of(cw);
+            while (curdir == need) {
+                const int ni = ci + astep;
+                const uint16_t wA = T.t[ni - pstep], wB = T.t[ni], wC = T.t[ni + pstep], w1 = T.t[ci + pstep], w2 = T.t[ci - pstep];
+                T.set_edge(ci, 2, L0);
+                if (Tile::edge_of(w1) == STAG_ANCHOR_PIXEL) T.set_edge(ci + pstep, 0, L0);
+                if (Tile::edge_of(w2) == STAG_ANCHOR_PIXEL) T.set_edge(ci - pstep, 0, L0);
+                const int eA = Tile::edge_of(wA), eB = Tile::edge_of(wB), eC = Tile::edge_of(wC);
+                const int gA = Tile::grad_of(wA), gB = Tile::grad_of(wB), gC = Tile::grad_of(wC);
+                const int eF1 = fs < 0 ? eA : eC, eF2 = fs < 0 ? eC : eA;
+                int side;
+                if (eB >= STAG_ANCHOR_PIXEL) side = 0;
+                else if (eF1 >= STAG_ANCHOR_PIXEL) side = fs;
+                else if (eF2 >= STAG_ANCHOR_PIXEL) side = -fs;
+                else {
+                    side = 0;
+                    if (gA > gB) side = gA > gC ? -1 : 1;
+                    else if (gC > gB) side = 1;
+                }
+                r = r + ar + side * pr;
+                c = c + ac + side * pc;
+                ci = ni + side * pstep;
+                const uint16_t wn = side < 0 ? wA : side > 0 ? wC : wB;
+                curdir = Tile::dir_of(wn);
+                if (Tile::edge_of(wn) == STAG_EDGE_PIXEL || Tile::grad_of(wn) < grad_thresh) {
+                    if (L0) {
+                        ch[cur].len = (uint16_t)chainLen;
+                        ch[parent].child[slot] = (int16_t)cur;
+                    }
+                    noChains++;
+                    stopped = true;
+                    break;
+                }
+                if (len + 2 >= R.capPix) { overflow |= 16; stopped = true; break; }
+                if (L0) R.pix[len] = make_int2(r, c);
+                len++;
+                chainLen++;
+            }
+            if (stopped) continue;
+            if (L0) {
+                R.stack[top + 1] = make_int4(r, c, horiz ? SR_DOWN : SR_RIGHT, cur);
+                R.stack[top + 2] = make_int4(r, c, horiz ? SR_UP : SR_LEFT, cur);
+            }
+            top += 2;
+            len--;
+            chainLen--;
+            if (L0) {
+                ch[cur].len = (uint16_t)chainLen;
+                ch[parent].child[slot] = (int16_t)cur;
+            }
+            noChains++;
+        }
+        wl_len = len;
+        wl_dup = dup;
+        wl_chains = noChains;
+        if (len - dup < STAG_MIN_PATH_LEN) {
+            for (int k = lane; k < len; k += 64) {
+                const int2 q = R.pix[k];
+                const int i = T.idx(q.x, q.y);
+                T.t[i] = (uint16_t)(T.t[i] & 0x0fff);  // (a pixel listed twice gets the same word twice)
+            }
+            return false;
+        }
+        return true;
+    }
+
     // the chain tree -> segments
     __device__ void extract_anchor(int noChains)
     {
@@ -483,6 +605,7 @@ struct StagComp {
     int out_base, out_cap;        // output pixels of this component's blocks; chainNos live in the stack arena's tail
     int seg_base, seg_cap;
     int nrec;                     // producing anchors
+    int minr, minc, maxr, maxc;   // bounding box of the component's pixels
 };
 
 struct StagRec {  // one producing anchor
@@ -538,12 +661,26 @@ __global__ __launch_bounds__(256) void k_stag_ccl_merge(int W, int H, int *label
 __global__ __launch_bounds__(256) void k_stag_ccl_flatten(int n, int *label, const uint8_t *__restrict__ anchors, int *__restrict__ csize,
                                                           int *__restrict__ canch)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n || label[i] < 0) return;
-    const int root = ccl_find(label, i);
-    label[i] = root;
-    atomicAdd(&csize[root], 1);
-    if (anchors[i] == STAG_ANCHOR_PIXEL) atomicAdd(&canch[root], 1);
+    const int i = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63;
+    int root = -1;
+    bool anch = false;
+    if (i < n && label[i] >= 0) {
+        root = ccl_find(label, i);
+        label[i] = root;
+        anch = anchors[i] == STAG_ANCHOR_PIXEL;
+    }
+    // pixels and anchors per root: one pair of atomics per (wave, root) -- 64 consecutive pixels share very few roots
+    unsigned long long pending = __ballot(root >= 0);
+    while (pending) {
+        const int lead = __builtin_ctzll(pending);
+        const int r0 = __builtin_amdgcn_readlane(root, lead);
+        const unsigned long long m = __ballot(root == r0), ma = __ballot(root == r0 && anch);
+        if (lane == lead) {
+            atomicAdd(&csize[r0], (int)__builtin_popcountll(m));
+            if (ma) atomicAdd(&canch[r0], (int)__builtin_popcountll(ma));
+        }
+        pending &= ~m;
+    }
 }
 
 // cursors: [0] components [1] anchor slots [2] scratch pixels [3] stack [4] chains [5] output pixels [6] segments [7] overflow
@@ -565,6 +702,7 @@ __global__ __launch_bounds__(256) void k_stag_comp_alloc(int n, const int *__res
     }
     StagComp C;
     C.root = i; C.size = sz; C.nanch = na; C.nrec = 0;
+    C.minr = C.minc = 0x7fffffff; C.maxr = C.maxc = -1;
     int p2 = 1;
     while (p2 < na) p2 <<= 1;
     C.anch_cap = p2;
@@ -598,6 +736,52 @@ __global__ __launch_bounds__(256) void k_stag_comp_fill(const int32_t *__restric
     if (cid < 0 || comps[cid].nanch == 0) return;
     const int pos = atomicAdd(&fill[cid], 1);
     aslots[comps[cid].anch_base + pos] = r;
+}
+
+// bounding boxes of the components that have anchors; cursors[10] = the largest LDS tile (bytes) a component would need.
+// A wave covers 64 consecutive pixels, which belong to very few components: one set of atomics per (wave, component).
+__global__ __launch_bounds__(256) void k_stag_comp_bbox(int W, int n, const int *__restrict__ label, const int *__restrict__ cidmap, StagComp *comps)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63;
+    int cid = -1, r = 0, c = 0;
+    if (i < n) {
+        const int root = label[i];
+        if (root >= 0) cid = cidmap[root];
+        r = i / W;
+        c = i - r * W;
+    }
+    unsigned long long pending = __ballot(cid >= 0);
+    while (pending) {
+        const int lead = __builtin_ctzll(pending);
+        const int c0 = __builtin_amdgcn_readlane(cid, lead);
+        const bool mine = cid == c0;
+        const unsigned long long m = __ballot(mine);
+        int mnr = mine ? r : 0x7fffffff, mnc = mine ? c : 0x7fffffff, mxr = mine ? r : -1, mxc = mine ? c : -1;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            mnr = min(mnr, __shfl_xor(mnr, off, 64));
+            mnc = min(mnc, __shfl_xor(mnc, off, 64));
+            mxr = max(mxr, __shfl_xor(mxr, off, 64));
+            mxc = max(mxc, __shfl_xor(mxc, off, 64));
+        }
+        if (lane == lead) {
+            atomicMin(&comps[c0].minr, mnr);
+            atomicMin(&comps[c0].minc, mnc);
+            atomicMax(&comps[c0].maxr, mxr);
+            atomicMax(&comps[c0].maxc, mxc);
+        }
+        pending &= ~m;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_stag_comp_tilemax(const StagComp *__restrict__ comps, int *cursors, int lds_cap)
+{
+    const int cid = blockIdx.x * 256 + threadIdx.x;
+    if (cid >= cursors[0]) return;
+    const StagComp C = comps[cid];
+    if (C.nanch == 0) return;
+    const int bytes = (C.maxr - C.minr + 3) * (C.maxc - C.minc + 3) * 2;
+    if (bytes <= lds_cap) atomicMax(&cursors[10], bytes);
 }
 
 // ranks of one component, descending: bitonic sort of the (padded, -1 filled) slice, one wave per component; slices of up to
@@ -674,10 +858,12 @@ __device__ void stag_bind(StagRouter &S, const StagRoute &G, const StagArenas &A
 }
 
 __global__ __launch_bounds__(256) void k_stag_route_walk(StagRoute G, StagArenas A, StagComp *__restrict__ comps, const int *__restrict__ cursors,
-                                                         const int32_t *__restrict__ sorted, const int *__restrict__ aslots, int grad_thresh,
-                                                         int *__restrict__ prodflag, int *__restrict__ ovf)
+                                                        const int32_t *__restrict__ sorted, const int *__restrict__ aslots, const int *__restrict__ label,
+                                                        int grad_thresh, int lds_bytes, int *__restrict__ prodflag, int *__restrict__ ovf)
 {
-    const int cid = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;  // one wave per component
+    extern __shared__ uint16_t s_tile[];
+    // one workgroup per component: four waves move the tile in and out, wave 0 walks
+    const int cid = blockIdx.x, lane = threadIdx.x & 63, tid = threadIdx.x;
     if (cid >= cursors[0]) return;
     StagComp C = comps[cid];
     if (C.nanch == 0) return;
@@ -690,18 +876,56 @@ __global__ __launch_bounds__(256) void k_stag_route_walk(StagRoute G, StagArenas
     int2 *pix0 = S.R.pix;
     StagChain *chain0 = S.R.chains;
     const int capPix0 = S.R.capPix, capChain0 = C.chain_cap;
+    const int W = G.W;
+    // the component's bounding box (+1 all around) as an LDS tile, if it fits
+    StagRouter::Tile T;
+    T.t = s_tile;
+    T.r0 = C.minr - 1;
+    T.c0 = C.minc - 1;
+    T.tw = C.maxc - C.minc + 3;
+    const int th = C.maxr - C.minr + 3;
+    const bool tiled = T.tw * th * 2 <= lds_bytes;
+    if (tiled) {
+        const int total = th * T.tw;
+        for (int i0 = tid; i0 < total; i0 += 256 * 4) {
+            int e[4], gr[4], dr[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {  // four independent pixels in flight per thread
+                const int i = i0 + 256 * u;
+                if (i < total) {
+                    const int rr = i / T.tw, cc = i - rr * T.tw;
+                    const int g = (T.r0 + rr) * W + T.c0 + cc;
+                    e[u] = G.edge[g]; gr[u] = G.grad[g]; dr[u] = G.dir[g];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int i = i0 + 256 * u;
+                if (i < total) {
+                    const int st = e[u] == STAG_EDGE_PIXEL ? 2 : e[u] == STAG_ANCHOR_PIXEL ? 1 : 0;
+                    s_tile[i] = (uint16_t)((gr[u] & 0x7ff) | (dr[u] == STAG_EDGE_VERTICAL ? 0x800 : 0) | (st << 12));
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (tid < 64) {
     for (int k0 = 0; k0 < C.nanch; k0 += 64) {
         // which of the next 64 anchors are still anchors?  (a walk can only turn anchors OFF, so a stale "on" is re-checked)
         const int kk = k0 + lane;
         int my_off = -1;
         if (kk < C.nanch) my_off = sorted[aslots[C.anch_base + kk]];
-        unsigned long long live = __ballot(my_off >= 0 && G.edge[my_off] == STAG_ANCHOR_PIXEL);
+        bool on = false;
+        if (my_off >= 0) on = tiled ? StagRouter::Tile::edge_of(s_tile[T.idx(my_off / W, my_off % W)]) == STAG_ANCHOR_PIXEL : G.edge[my_off] == STAG_ANCHOR_PIXEL;
+        unsigned long long live = __ballot(on);
         while (live) {
             const int j = __builtin_ctzll(live);
             live &= live - 1;
             const int rank = aslots[C.anch_base + k0 + j];
             const int off = sorted[rank];
-            if (G.edge[off] != STAG_ANCHOR_PIXEL) continue;
+            const int ar = off / W, ac = off - ar * W;
+            const bool still = tiled ? StagRouter::Tile::edge_of(s_tile[T.idx(ar, ac)]) == STAG_ANCHOR_PIXEL : G.edge[off] == STAG_ANCHOR_PIXEL;
+            if (!still) continue;
             S.R.pix = pix0 + pix_used;
             S.R.capPix = capPix0 - pix_used;
             S.R.chains = chain0 + chain_used;
@@ -711,7 +935,7 @@ __global__ __launch_bounds__(256) void k_stag_route_walk(StagRoute G, StagArenas
                 S.overflow |= 32;
                 break;
             }
-            const bool keep = S.walk_anchor_wave(off / G.W, off % G.W, grad_thresh, lane);
+            const bool keep = tiled ? S.walk_anchor_tile(ar, ac, grad_thresh, lane, T) : S.walk_anchor_wave(ar, ac, grad_thresh, lane);
             if (S.overflow) break;
             if (keep) {
                 if (lane == 0) {
@@ -731,6 +955,17 @@ __global__ __launch_bounds__(256) void k_stag_route_walk(StagRoute G, StagArenas
     if (lane == 0) {
         comps[cid].nrec = nrec;
         if (S.overflow) atomicOr(ovf, S.overflow);
+    }
+    }  // wave 0
+    if (tiled) {  // the component's own pixels back into the edge image
+        __syncthreads();
+        const int total = th * T.tw;
+        for (int i = tid; i < total; i += 256) {
+            const int rr = i / T.tw, cc = i - rr * T.tw;
+            if (rr == 0 || rr == th - 1 || cc == 0 || cc == T.tw - 1) continue;
+            const int g = (T.r0 + rr) * W + T.c0 + cc;
+            if (label[g] == C.root) G.edge[g] = (uint8_t)StagRouter::Tile::edge_of(s_tile[i]);
+        }
     }
 }
 

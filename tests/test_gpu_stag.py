@@ -125,11 +125,11 @@ ROUTE_CASES["stag_1080p"] = lambda: __import__("fiducials_amd.synth", fromlist=[
 ROUTE_CASES["faint"] = lambda: _faint(480, 360, 21)
 
 
-@pytest.mark.parametrize("mode", ["par", "seq"])
+@pytest.mark.parametrize("mode", ["par", "notile", "seq"])
 @pytest.mark.parametrize("case", sorted(ROUTE_CASES))
 def test_edge_routing_matches_reference_code(case, mode, monkeypatch):
     """Row s4: JoinAnchorPointsUsingSortedAnchors.  Edge image and every segment (pixel by pixel, in order) against the
-    reference's own routine fed with the same gradient / direction / anchor maps; both roads of the device code: one lane per
+    reference's own routine fed with the same gradient / direction / anchor maps; the roads of the device code: one wave per
     connected component of the gradient map (default) and one lane per frame."""
     if not stag_ref.available():
         pytest.skip("oracle/_ref/libstag_ref.so not built (needs /root/reference at build time)")

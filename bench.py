@@ -164,28 +164,19 @@ def main_stag(args):
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     from fiducials_amd import stag as fstag, synth
 
-    hd, ec, B = 21, 7, min(args.batch, 16)
+    hd, ec, B = 21, 7, min(args.batch, 64)
     words = fstag.load_library(hd)
     frames = [synth.make_stag_frame(words, 10000 * rank + 100 + i, W, H, MARKERS).image for i in range(min(B, 4))]
-    # one context (= one HIP stream) per host thread: a frame's work is a chain of small kernels, several frames in flight
-    # fill the GPU (the C-ABI contract: a context is single-threaded, contexts run concurrently)
-    import concurrent.futures as cf
-
+    # several contexts side by side (fid_stag_detect_markers_batch: one host thread + one HIP stream per context inside the
+    # library): a frame's work is a chain of small kernels, several frames in flight fill the GPU
     T = max(1, min(args.streams, B))
-    dets = [fstag.StagDetector(hd, ec, max_width=W, max_height=H, device=local_rank) for _ in range(T)]
-    det = dets[0]
+    pool = fstag.StagPool(hd, ec, n_contexts=T, max_width=W, max_height=H, device=local_rank)
     K = synth.K_DEFAULT
-    pool = cf.ThreadPoolExecutor(T)
-
-    def work(t):
-        n = 0
-        for i in range(t, B, T):
-            n += len(dets[t].detect_markers(frames[i % len(frames)]))
-            dets[t].pose_last(K, None, 0.18)
-        return n
+    batch = np.stack([frames[i % len(frames)] for i in range(B)])
 
     def step():
-        return sum(pool.map(work, range(T)))
+        m, _ = pool.detect_markers_batch(batch, K, None, 0.18)
+        return sum(len(x) for x in m)
 
     def barrier():
         if dist is not None:
@@ -236,9 +227,7 @@ def main_stag(args):
                                                  "reference sources compiled in place, OpenCV calls restated), one thread (the reference keeps "
                                                  "global state, PoseRefiner.cpp:9), ~10 s"}
         print(json.dumps(out))
-    pool.shutdown()
-    for d_ in dets:
-        d_.close()
+    pool.close()
     if dist is not None:
         dist.destroy_process_group()
 

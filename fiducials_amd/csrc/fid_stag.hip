@@ -17,6 +17,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <thread>
+
 #include "../../include/fid_abi.h"
 
 #define STAG_EDGE_VERTICAL 1
@@ -879,6 +881,36 @@ fid_status fid_stag_pose_last(fid_stag_ctx *c, const double K[9], const double D
     if (hipGetLastError() != hipSuccess) return FID_E_HIP;
     if (hipMemcpyAsync(out, c->d_poses, (size_t)c->n_markers * sizeof(fid_stag_pose_out), hipMemcpyDeviceToHost, st) != hipSuccess) return FID_E_HIP;
     return hipStreamSynchronize(st) == hipSuccess ? FID_OK : FID_E_HIP;
+}
+
+fid_status fid_stag_detect_markers_batch(fid_stag_ctx *const *ctxs, int32_t nctx, const uint8_t *frames, int32_t nframes, int32_t width, int32_t height,
+                                         int32_t stride, int64_t frame_stride, const double K[9], const double D[5], double marker_size,
+                                         fid_stag_marker *markers, fid_stag_pose_out *poses, int32_t cap_per_frame, int32_t *n_per_frame)
+{
+    if (!ctxs || nctx <= 0 || !frames || nframes < 0 || !markers || !n_per_frame || cap_per_frame <= 0) return FID_E_INVALID_ARG;
+    for (int t = 0; t < nctx; t++)
+        if (!ctxs[t]) return FID_E_INVALID_ARG;
+    std::vector<fid_status> rcs((size_t)nctx, FID_OK);
+    auto work = [&](int t) {
+        for (int f = t; f < nframes; f += nctx) {
+            fid_stag_marker *m = markers + (size_t)f * cap_per_frame;
+            int32_t n = 0;
+            fid_status rc = fid_stag_detect_markers(ctxs[t], frames + (size_t)f * frame_stride, width, height, stride, m, cap_per_frame, &n);
+            n_per_frame[f] = n;
+            if (rc == FID_OK && K && poses) rc = fid_stag_pose_last(ctxs[t], K, D, marker_size, poses + (size_t)f * cap_per_frame, cap_per_frame, &n);
+            if (rc != FID_OK) {
+                rcs[t] = rc;
+                return;
+            }
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < nctx; t++) th.emplace_back(work, t);
+    work(0);
+    for (auto &x : th) x.join();
+    for (fid_status rc : rcs)
+        if (rc != FID_OK) return rc;
+    return FID_OK;
 }
 
 int64_t fid_stag_tap_bytes(fid_stag_ctx *c, fid_stag_tap which)

@@ -161,3 +161,33 @@ class StagDetector:
         if which in (TAP_LINES, TAP_VLINES):
             return buf.view(LINE_DTYPE)
         return buf.view(np.int32)
+
+
+class StagPool:
+    """Throughput mode: `n_contexts` detectors side by side (fid_stag_detect_markers_batch: one host thread and one HIP stream
+    per context inside the library).  detect_markers_batch(frames[F, H, W]) -> (markers per frame, poses per frame)."""
+
+    def __init__(self, libraryHD: int = 21, errorCorrection: int = 7, n_contexts: int = 8, max_width: int = 1920, max_height: int = 1080,
+                 device: int = 0):
+        self.dets = [StagDetector(libraryHD, errorCorrection, max_width, max_height, device) for _ in range(n_contexts)]
+        self._L = self.dets[0]._L
+        self._arr = (C.c_void_p * n_contexts)(*[d._ctx.value for d in self.dets])
+
+    def close(self):
+        for d in self.dets:
+            d.close()
+
+    def detect_markers_batch(self, frames: np.ndarray, K=None, D=None, marker_size: float = 0.18, cap_per_frame: int = 64):
+        fr = np.ascontiguousarray(frames, dtype=np.uint8)
+        F, h, w = fr.shape
+        markers = np.zeros((F, cap_per_frame), MARKER_DTYPE)
+        poses = np.zeros((F, cap_per_frame), POSE_DTYPE)
+        counts = np.zeros(F, np.int32)
+        Kp = None if K is None else np.ascontiguousarray(K, dtype=np.float64).reshape(9)
+        Dp = np.zeros(5) if D is None else np.ascontiguousarray(D, dtype=np.float64).reshape(-1)[:5].copy()
+        rc = self._L.fid_stag_detect_markers_batch(self._arr, len(self.dets), fr.ctypes.data, F, w, h, w, w * h,
+                                                   None if Kp is None else Kp.ctypes.data, Dp.ctypes.data, float(marker_size),
+                                                   markers.ctypes.data, poses.ctypes.data, cap_per_frame, counts.ctypes.data)
+        if rc != _lib.FID_OK:
+            raise FidError(rc, self._L.fid_strerror(rc).decode())
+        return [markers[f, :counts[f]] for f in range(F)], [poses[f, :counts[f]] for f in range(F)]

@@ -286,6 +286,14 @@ typedef enum fid_stag_tap {
  * corners against (0,0,0), (-h,h,0), (h,h,0), (h,-h,0), (-h,-h,0), h = float(marker_size / 2) (stag_detect.cpp:144-162) */
 fid_status fid_stag_pose_last(fid_stag_ctx *ctx, const double K[9], const double D[5], double marker_size, fid_stag_pose_out *out,
                               int32_t cap, int32_t *n_out);
+/* throughput mode (BASELINE cfg 5 as a batch): nframes frames, frame_stride_bytes apart, through nctx contexts side by side
+ * (one host thread and one HIP stream per context; frame f goes to context f mod nctx).  A frame's work is a chain of small
+ * kernels, several frames in flight fill the GPU.  markers / poses: nframes x cap_per_frame; K == NULL or poses == NULL skips
+ * the pose step. */
+fid_status fid_stag_detect_markers_batch(fid_stag_ctx *const *ctxs, int32_t nctx, const uint8_t *frames, int32_t nframes, int32_t width,
+                                         int32_t height, int32_t stride_bytes, int64_t frame_stride_bytes, const double K[9], const double D[5],
+                                         double marker_size, fid_stag_marker *markers, fid_stag_pose_out *poses, int32_t cap_per_frame,
+                                         int32_t *n_per_frame);
 int64_t fid_stag_tap_bytes(fid_stag_ctx *ctx, fid_stag_tap which);
 fid_status fid_stag_tap_read(fid_stag_ctx *ctx, fid_stag_tap which, void *dst, int64_t dst_bytes);
 

@@ -466,6 +466,27 @@ def test_noise_at_720p_takes_the_sequential_road_and_still_matches():
         det.close()
 
 
+def test_batch_entry_point_equals_frame_by_frame():
+    """fid_stag_detect_markers_batch (frames spread over several contexts and host threads inside the library) returns, frame
+    for frame, what fid_stag_detect_markers + fid_stag_pose_last return on one context."""
+    from fiducials_amd import synth
+    words = fstag.load_library(21)
+    frames = np.stack([synth.make_stag_frame(words, 50 + i, 1280, 720, 8).image for i in range(5)] * 2)
+    K = np.array([[933.3, 0, 640.0], [0, 933.3, 360.0], [0, 0, 1]])
+    pool = fstag.StagPool(21, 7, n_contexts=4, max_width=1280, max_height=720)
+    det = fstag.StagDetector(21, 7, max_width=1280, max_height=720)
+    try:
+        M, P = pool.detect_markers_batch(frames, K, None, 0.18)
+        assert len(M) == len(frames)
+        for f in range(len(frames)):
+            m = det.detect_markers(frames[f])
+            p = det.pose_last(K, None, 0.18)
+            assert len(m) >= 3 and m.tobytes() == M[f].tobytes() and p.tobytes() == P[f].tobytes(), f
+    finally:
+        pool.close()
+        det.close()
+
+
 def test_stag_status_codes():
     from fiducials_amd import _lib
     from fiducials_amd._lib import FidError

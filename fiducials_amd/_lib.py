@@ -70,7 +70,7 @@ SYMBOLS = [
     "fid_default_params", "fid_default_limits", "fid_create", "fid_destroy", "fid_set_params", "fid_detect",
     "fid_detect_batch", "fid_detect_device", "fid_pose", "fid_pose_last", "fid_tap_bytes", "fid_tap_read",
     "fid_last_stage_ms", "fid_last_launches", "fid_stream", "fid_strerror", "fid_last_error", "fid_abi_version",
-    "fid_stag_create", "fid_stag_destroy", "fid_stag_edge_frontend", "fid_stag_detect_edges", "fid_stag_detect_edges_validated", "fid_stag_detect_lines", "fid_stag_detect_lines_validated", "fid_stag_detect_quads", "fid_stag_load_library", "fid_stag_detect_markers_unrefined", "fid_stag_detect_markers", "fid_stag_pose_last", "fid_stag_detect_markers_batch", "fid_stag_tap_bytes", "fid_stag_tap_read",
+    "fid_stag_create", "fid_stag_destroy", "fid_stag_edge_frontend", "fid_stag_detect_edges", "fid_stag_detect_edges_validated", "fid_stag_detect_lines", "fid_stag_detect_lines_validated", "fid_stag_detect_quads", "fid_stag_host_tables", "fid_stag_load_library", "fid_stag_detect_markers_unrefined", "fid_stag_detect_markers", "fid_stag_pose_last", "fid_stag_detect_markers_batch", "fid_stag_tap_bytes", "fid_stag_tap_read",
 ]
 
 _LIB = None
@@ -134,6 +134,7 @@ def load():
     L.fid_stag_detect_lines_validated.argtypes = [vp, vp, i32, i32, i32]
     L.fid_stag_detect_quads.argtypes = [vp, vp, i32, i32, i32]
     L.fid_stag_load_library.argtypes = [vp, vp, i32]
+    L.fid_stag_host_tables.argtypes = [i32, i32, vp, i32, vp, vp, vp, vp]
     L.fid_stag_detect_markers_unrefined.argtypes = [vp, vp, i32, i32, i32]
     L.fid_stag_detect_markers.argtypes = [vp, vp, i32, i32, i32, vp, i32, C.POINTER(i32)]
     L.fid_stag_pose_last.argtypes = [vp, vp, vp, C.c_double, vp, i32, C.POINTER(i32)]

@@ -811,6 +811,24 @@ fid_status fid_stag_detect_quads(fid_stag_ctx *c, const uint8_t *gray, int32_t w
     return FID_OK;
 }
 
+// the host-made tables of the STag path (functions of the image size alone), without a device: for tests and diagnostics
+fid_status fid_stag_host_tables(int32_t width, int32_t height, int32_t *kmin, int32_t kmin_cap, int32_t *kmin_n, int32_t *lut_size,
+                                double *code_locations, int32_t *min_line_len)
+{
+    if (width < 8 || height < 8) return FID_E_INVALID_ARG;
+    std::vector<int> k;
+    stag_build_kmin(width, height, k);
+    if (kmin_n) *kmin_n = (int32_t)k.size();
+    if (lut_size) *lut_size = (width + height) / 8;
+    if (kmin) {
+        if ((int)k.size() > kmin_cap) return FID_E_CAPACITY;
+        for (size_t i = 0; i < k.size(); i++) kmin[i] = k[i];
+    }
+    if (code_locations) stag_fill_code_locations(code_locations);
+    if (min_line_len) *min_line_len = stag_min_line_len(width, height);
+    return FID_OK;
+}
+
 fid_status fid_stag_load_library(fid_stag_ctx *c, const uint64_t *codewords, int32_t n_codewords)
 {
     if (!c || !codewords || n_codewords <= 0 || (n_codewords & 3)) return FID_E_INVALID_ARG;

@@ -247,6 +247,12 @@ fid_status fid_stag_detect_lines(fid_stag_ctx *ctx, const uint8_t *gray, int32_t
 fid_status fid_stag_detect_lines_validated(fid_stag_ctx *ctx, const uint8_t *gray, int32_t width, int32_t height, int32_t stride_bytes);
 /* QuadDetector::detectQuads (QuadDetector.cpp:12-66): the above + line groups, corner detection and quad formation */
 fid_status fid_stag_detect_quads(fid_stag_ctx *ctx, const uint8_t *gray, int32_t width, int32_t height, int32_t stride_bytes);
+/* The tables the STag path makes on the host (functions of the image size alone; no device needed): kmin[n] = smallest number
+ * of aligned pixels out of n that validates a line (NFALUT, ED/NFA.cpp:13-44, continued past the LUT size where the reference
+ * calls nfa() directly), the 72 sample points of Stag::fillCodeLocations (Stag.cpp:129-277) as [72][3], and MIN_LINE_LEN of
+ * DetectLinesByEDPF (ED/EDLines.cpp:694-703, 888-892).  Any output pointer may be NULL. */
+fid_status fid_stag_host_tables(int32_t width, int32_t height, int32_t *kmin, int32_t kmin_cap, int32_t *kmin_n, int32_t *lut_size,
+                                double *code_locations, int32_t *min_line_len);
 /* the marker library of Decoder::Decoder(hd) (Decoder.cpp:14-43): n_codewords = 4 x number of markers, the four rotations
  * of every marker one block after the other, 48 bits each (the HDxx arrays of stag/MarkerIDs.h; fiducials_amd/data/
  * stag_libraries.npz holds them for the Python host side) */

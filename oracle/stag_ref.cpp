@@ -34,10 +34,12 @@
 #include "stag/ED/ED.h"
 #include "stag/ED/EDLines.h"
 #include "stag/ED/ImageSmooth.h"
+#include "stag/ED/NFA.h"
 void SplitSegment2Lines(double *x, double *y, int noPixels, int segmentNo, EDLines *lines);
 void JoinCollinearLines(EDLines *lines, double MAX_DISTANCE_BETWEEN_TWO_LINES, double MAX_ERROR);
 void ValidateLineSegments(EdgeMap *map, unsigned char *srcImg, EDLines *lines, EDLines *invalidLines);
 int ComputeMinLineLength(int width, int height);
+double nfa(int n, int k, double p, double logNT);  // ED/NFA.cpp:155
 // compiled from the reference tree against oracle/cvshim (data types only): Quad.cpp QuadDetector.cpp EDInterface.cpp utility.cpp
 // likewise Stag.cpp Decoder.cpp Marker.cpp PoseRefiner.cpp Ellipse.cpp; Drawer (image output) is stubbed below.
 // "private" is lifted for this wrapper only, so that a test can stop Stag::detectMarkers in front of the pose refinement
@@ -406,6 +408,34 @@ int ref_stag_detect_markers(const uint8_t *src, int w, int h, int library_hd, in
     }
     *n_out = (int)m.size();
     return (int)m.size() <= cap ? 0 : 1;
+}
+
+// the reference's NFALUT for an image size (ED/EDLines.cpp:286-296: size (w + h) / 8, p = 0.125, logNT), its MIN_LINE_LEN and the
+// sample points of Stag::fillCodeLocations
+int ref_stag_host_tables(int w, int h, int32_t *lut, int cap, int *lut_size, int *min_line_len, double *locs /* [72][3] */)
+{
+    const double logNT = 2.0 * (log10((double)w) + log10((double)h));
+    NFALUT *L = new NFALUT((w + h) / 8, 0.125, logNT);
+    *lut_size = L->LUTSize;
+    for (int i = 0; i < L->LUTSize && i < cap; i++) lut[i] = L->LUT[i];
+    delete L;
+    int m = ComputeMinLineLength(w, h);
+    *min_line_len = m < 9 ? 9 : m;
+    Stag stag(21, 7, false);
+    for (int i = 0; i < 48; i++)
+        for (int k = 0; k < 3; k++) locs[3 * i + k] = stag.codeLocs[i].at<double>(k);
+    for (int i = 0; i < 12; i++)
+        for (int k = 0; k < 3; k++) {
+            locs[3 * (48 + i) + k] = stag.blackLocs[i].at<double>(k);
+            locs[3 * (60 + i) + k] = stag.whiteLocs[i].at<double>(k);
+        }
+    return 0;
+}
+
+// nfa(n, k, p, logNT) >= 0 (checkValidationByNFA without the table, ED/NFA.cpp:49-51)
+int ref_stag_nfa_valid(int n, int k, int w, int h)
+{
+    return nfa(n, k, 0.125, 2.0 * (log10((double)w) + log10((double)h))) >= 0.0;
 }
 
 int ref_stag_smooth5(const uint8_t *src, uint8_t *dst, int w, int h)

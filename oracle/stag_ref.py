@@ -196,3 +196,17 @@ def detect_markers(src: np.ndarray, library_hd: int = 21, error_correction: int 
                                        out.ctypes.data_as(C.c_void_p), len(out), C.byref(n))
     assert rc == 0
     return out[:n.value].copy()
+
+
+def host_tables(w: int, h: int):
+    """The reference's NFALUT, MIN_LINE_LEN and code sample points for an image size: (lut int32[], min_line_len, locs [72][3])."""
+    lut = np.zeros(4096, np.int32)
+    n, mll = C.c_int(0), C.c_int(0)
+    locs = np.zeros((72, 3))
+    assert lib().ref_stag_host_tables(w, h, lut.ctypes.data_as(C.c_void_p), len(lut), C.byref(n), C.byref(mll),
+                                      locs.ctypes.data_as(C.c_void_p)) == 0
+    return lut[:n.value].copy(), mll.value, locs
+
+
+def nfa_valid(n: int, k: int, w: int, h: int) -> bool:
+    return bool(lib().ref_stag_nfa_valid(n, k, w, h))

@@ -96,3 +96,29 @@ def test_rendered_codewords_come_back_from_the_reference_detector(hd, ec):
         js = np.flatnonzero(fr.ids == int(row[0]))
         assert len(js) > 0, "an id that was never drawn"
         assert min(np.abs(row[1:9].reshape(4, 2) - fr.corners[j]).max() for j in js) < 2.0
+
+
+@pytest.mark.parametrize("size", [(1920, 1080), (640, 480), (320, 240), (160, 120)])
+def test_host_made_tables_equal_the_references(size):
+    """The tables the product makes on the host (fid_stag_host_tables: no device needed) against the reference's own NFALUT,
+    ComputeMinLineLength and Stag::fillCodeLocations; past the table's end, against nfa() itself."""
+    _need_ref()
+    import ctypes as C
+    from fiducials_amd import _lib
+    w, h = size
+    L = _lib.load()
+    kmin = np.zeros(4 * (w + h) + 64, np.int32)
+    n, ls, mll = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+    locs = np.zeros((72, 3))
+    rc = L.fid_stag_host_tables(w, h, kmin.ctypes.data, len(kmin), C.byref(n), C.byref(ls), locs.ctypes.data, C.byref(mll))
+    assert rc == _lib.FID_OK
+    lut, rmll, rlocs = stag_ref.host_tables(w, h)
+    assert ls.value == len(lut) == (w + h) // 8 and mll.value == rmll
+    assert np.array_equal(kmin[:len(lut)], lut)
+    assert np.array_equal(locs, rlocs), np.abs(locs - rlocs).max()
+    for nn in list(range(len(lut), min(n.value, len(lut) + 40))) + list(range(n.value - 5, n.value)):  # k >= kmin[n]  <=>  nfa(n, k) >= 0
+        km = int(kmin[nn])
+        if km <= nn:
+            assert stag_ref.nfa_valid(nn, km, w, h) and (km == 0 or not stag_ref.nfa_valid(nn, km - 1, w, h)), nn
+        else:
+            assert not stag_ref.nfa_valid(nn, nn, w, h), nn

@@ -1924,47 +1924,66 @@ __global__ __launch_bounds__(64) void k_resolve(const DevCand *__restrict__ sort
     // removed bits: lane l owns words l, l+64, ... (maxCands <= 4096 -> at most 2 words per lane)
     uint32_t rem0 = 0, rem1 = 0;
     const int nw = (n + 31) >> 5;
-    for (int i = 0; i < n; i++) {
-        int wi = i >> 5;
-        uint32_t rw = __shfl(wi < 64 ? rem0 : rem1, wi & 63, WAVE);
-        if ((rw >> (i & 31)) & 1u) continue;  // wave-uniform
-        int szi = sizes[i];
-        int firstKill = INT_MAX;
-        uint32_t live0 = 0, live1 = 0;
-        // each lane scans its words
-        for (int k = 0; k < 2; k++) {
-            int w = lane + 64 * k;
-            if (w < nw && w >= wi) {
-                uint32_t bits = nb[(long long)i * NW + w] & ~(k == 0 ? rem0 : rem1);
-                if (k == 0) live0 = bits; else live1 = bits;
-                uint32_t t = bits;
-                while (t) {
-                    int b = __ffs(t) - 1;
-                    t &= t - 1;
-                    int j = w * 32 + b;
-                    if (sizes[j] >= szi) {
-                        firstKill = firstKill < j ? firstKill : j;
-                        break;
+    // Row i of the near matrix does not depend on what has been removed so far: the rows of the next RB candidates are
+    // fetched together (their loads overlap) and then resolved one after the other.
+    constexpr int RB = 8;
+    for (int i0 = 0; i0 < n; i0 += RB) {
+        uint32_t row[RB][2];
+#pragma unroll
+        for (int u = 0; u < RB; u++) {
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const int w = lane + 64 * k, i = i0 + u;
+                row[u][k] = (i < n && w < nw && w >= (i >> 5)) ? nb[(long long)i * NW + w] : 0u;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < RB; u++) {
+            const int i = i0 + u;
+            if (i >= n) break;  // wave-uniform
+            int wi = i >> 5;
+            uint32_t rw = __shfl(wi < 64 ? rem0 : rem1, wi & 63, WAVE);
+            if ((rw >> (i & 31)) & 1u) continue;  // wave-uniform
+            int szi = sizes[i];
+            int firstKill = INT_MAX;
+            uint32_t live0 = 0, live1 = 0;
+            // each lane scans its words
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                int w = lane + 64 * k;
+                if (w < nw && w >= wi) {
+                    uint32_t bits = row[u][k] & ~(k == 0 ? rem0 : rem1);
+                    if (k == 0) live0 = bits; else live1 = bits;
+                    uint32_t t = bits;
+                    while (t) {
+                        int b = __ffs(t) - 1;
+                        t &= t - 1;
+                        int j = w * 32 + b;
+                        if (sizes[j] >= szi) {
+                            firstKill = firstKill < j ? firstKill : j;
+                            break;
+                        }
                     }
                 }
             }
-        }
-        int jk = wave_min_i32(firstKill);
-        // every live near j < jk has size_j < size_i and is removed
-        for (int k = 0; k < 2; k++) {
-            int w = lane + 64 * k;
-            uint32_t bits = k == 0 ? live0 : live1;
-            if (bits) {
-                uint32_t m;
-                if (jk == INT_MAX || (jk >> 5) > w) m = 0xffffffffu;
-                else if ((jk >> 5) < w) m = 0;
-                else m = (1u << (jk & 31)) - 1u;
-                if (k == 0) rem0 |= bits & m; else rem1 |= bits & m;
+            int jk = wave_min_i32(firstKill);
+            // every live near j < jk has size_j < size_i and is removed
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                int w = lane + 64 * k;
+                uint32_t bits = k == 0 ? live0 : live1;
+                if (bits) {
+                    uint32_t m;
+                    if (jk == INT_MAX || (jk >> 5) > w) m = 0xffffffffu;
+                    else if ((jk >> 5) < w) m = 0;
+                    else m = (1u << (jk & 31)) - 1u;
+                    if (k == 0) rem0 |= bits & m; else rem1 |= bits & m;
+                }
             }
-        }
-        if (jk != INT_MAX) {
-            if ((wi & 63) == lane) {
-                if (wi < 64) rem0 |= 1u << (i & 31); else rem1 |= 1u << (i & 31);
+            if (jk != INT_MAX) {
+                if ((wi & 63) == lane) {
+                    if (wi < 64) rem0 |= 1u << (i & 31); else rem1 |= 1u << (i & 31);
+                }
             }
         }
     }

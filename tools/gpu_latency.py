@@ -41,3 +41,18 @@ for mb in (1,):
         ts.append(t1 - t0)
     ts = np.array(ts[8:]) * 1e3
     print(f"resident frame -> markers: median {np.median(ts):.3f} ms (min {ts.min():.3f}); launches {det.last_launches()}")
+
+# PCIe-inclusive throughput: the same batch path fed from HOST memory (fid_detect_batch stages through pinned buffers)
+B = int(os.environ.get("HOST_BATCH", "64"))
+detb = ArucoDetector(d, device=0, max_width=1920, max_height=1080, max_batch=B, max_markers=64)
+host = np.stack([frames[i % 8] for i in range(B)])
+devb = torch.from_numpy(host).cuda()
+torch.cuda.synchronize()
+for name, fn in (("host memory", lambda: detb.detect_markers_batch(host)), ("resident   ", lambda: detb.detect_markers_device(devb.data_ptr(), B, 1920, 1080))):
+    fn()
+    ts = []
+    for it in range(6):
+        t0 = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t0)
+    print(f"batch {B} from {name}: {B / np.median(ts):.0f} frames/s (median of 6)")

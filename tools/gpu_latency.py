@@ -14,7 +14,7 @@ d = get_predefined_dictionary("DICT_5X5_250")
 K = np.array([[1400, 0, 960], [0, 1400, 540], [0, 0, 1]], float)
 D = np.zeros(5)
 for mb in (1,):
-    det = ArucoDetector(d, device=0, max_width=1920, max_height=1080, max_batch=mb, max_markers=64)
+    det = ArucoDetector(d, device=0, max_width=1920, max_height=1080, max_batch=mb, max_markers=64, max_contours=int(os.environ.get("LAT_MAX_CONTOURS", "0")))
     frames = [make_frame(d, 1000 + i, width=1920, height=1080, n_markers=20).image for i in range(8)]
     for prof in (0, 1):
         ts = []

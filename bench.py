@@ -91,7 +91,8 @@ def make_frames(seeds, dname="DICT_5X5_250"):
     if todo:
         import multiprocessing as mp
 
-        nproc = max(1, min(len(todo), (os.cpu_count() or 2), 64))
+        world = max(1, int(os.environ.get("WORLD_SIZE", "1")))  # every rank generates its own stream: share the host cores
+        nproc = max(1, min(len(todo), (os.cpu_count() or 2) // world, 64))
         with mp.get_context("fork").Pool(nproc) as pool:
             imgs = pool.map(_gen_one, [(s, dname) for _, s in todo], chunksize=1)
         for (i, s), im in zip(todo, imgs):

@@ -207,12 +207,6 @@ size_t masks_elems(const fid_ctx *c, int W, int H, int F)
     return (size_t)F * c->P.nscales * TR * TC * MT_ROWS;
 }
 
-void mark(fid_ctx *c, int idx)
-{
-    if (c->profile) {
-        (void)hipEventRecord(c->ev[idx], c->stream);
-        c->ev_valid[idx] = true;
-    }
 }
 
 // the whole detection pipeline for F frames whose gray images are resident at d_gray

@@ -488,7 +488,7 @@ __global__ __launch_bounds__(256) void k_stag_split_lines(const int2 *__restrict
     int base = 0, noPixels = n, firstPixelIndex = 0;
     while (noPixels >= MLL) {
         bool valid = false;
-        double lastA = 0, lastB = 0, error = 0;
+        double lastA = 0, lastB = 0;
         int lastInvert = 0;
         // first window (sliding by one pixel) whose MLL-pixel fit has error <= 0.5: 64 positions per round
         while (noPixels >= MLL) {
@@ -499,7 +499,7 @@ __global__ __launch_bounds__(256) void k_stag_split_lines(const int2 *__restrict
             const unsigned long long okm = __ballot(lane < avail && e <= 0.5);
             if (okm) {
                 const int j = __builtin_ctzll(okm);
-                lastA = __shfl(a, j, 64); lastB = __shfl(bq, j, 64); error = __shfl(e, j, 64); lastInvert = __shfl(inv, j, 64);
+                lastA = __shfl(a, j, 64); lastB = __shfl(bq, j, 64); lastInvert = __shfl(inv, j, 64);
                 noPixels -= j; base += j; firstPixelIndex += j;
                 valid = true;
                 break;

@@ -207,8 +207,6 @@ size_t masks_elems(const fid_ctx *c, int W, int H, int F)
     return (size_t)F * c->P.nscales * TR * TC * MT_ROWS;
 }
 
-}
-
 // the whole detection pipeline for F frames whose gray images are resident at d_gray
 fid_status run_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H, int stride, long long fstride, fid_encoding enc,
                       fid_marker *out, int cap_per_frame, int *n_per_frame)

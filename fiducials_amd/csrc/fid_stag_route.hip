@@ -189,111 +189,104 @@ struct StagRouter {
         noSegments++;
     }
 
-    __device__ void route_anchor(int r0, int c0, int grad_thresh)
-    {
-        if (walk_anchor(r0, c0, grad_thresh)) extract_anchor(wl_chains);
-    }
+    // ---- the walk.  One body for three kinds of memory (what a step reads and writes is the same in all of them):
+    //   MemGlobal  one lane, plain loads and stores in the image arrays (the sequential road)
+    //   MemWave    a whole wave: control flow and bookkeeping wave-uniform (every lane computes them, lane 0 stores them); what
+    //              a step needs -- edge / gradient / direction of the three pixels ahead, edge of the two beside -- is
+    //              fetched by eleven lanes at once, one round trip per step instead of a chain of dependent loads
+    //   MemTile    a whole wave on a copy of the component's bounding box in LDS (one 16-bit word per pixel: gradient 11
+    //              bits, direction 1 bit, edge state 2 bits): every lane reads the same words (broadcast), lane 0 writes
+    // None of the five pixels a step reads is written in the same step (the current pixel and the two beside it are not among
+    // the three ahead), so fetching them together sees exactly what the reference's one-by-one reads see.
+    struct Ahead {           // A = ahead - p, B = ahead, C = ahead + p (p = one pixel across the walking direction)
+        int eA, eB, eC, gA, gB, gC, dA, dB, dC;
+        int s1, s2;          // edge values of the pixels beside the current one (+p, -p)
+    };
+    struct MemGlobal {
+        const int16_t *grad; const uint8_t *dir; uint8_t *edge; int W;
+        static constexpr int STRIDE = 1;
+        __device__ int edge_at(int r, int c) const { return edge[r * W + c]; }
+        __device__ int dir_at(int r, int c) const { return dir[r * W + c]; }
+        __device__ void fetch(int r, int c, int ar, int ac, int pr, int pc, int, Ahead &n) const
+        {
+            const int q = (r + ar) * W + (c + ac), p = pr * W + pc;
+            n.eA = edge[q - p]; n.eB = edge[q]; n.eC = edge[q + p];
+            n.gA = grad[q - p]; n.gB = grad[q]; n.gC = grad[q + p];
+            n.dA = dir[q - p]; n.dB = dir[q]; n.dC = dir[q + p];
+            n.s1 = edge[r * W + c + p]; n.s2 = edge[r * W + c - p];
+        }
+        __device__ void mark(int r, int c, int pr, int pc, const Ahead &n, bool writer) const
+        {
+            if (!writer) return;
+            const int i = r * W + c, p = pr * W + pc;
+            edge[i] = STAG_EDGE_PIXEL;
+            if (n.s1 == STAG_ANCHOR_PIXEL) edge[i + p] = 0;
+            if (n.s2 == STAG_ANCHOR_PIXEL) edge[i - p] = 0;
+        }
+        __device__ void erase(int r, int c) const { edge[r * W + c] = 0; }
+    };
+    struct MemWave : MemGlobal {
+        static constexpr int STRIDE = 64;
+        __device__ void fetch(int r, int c, int ar, int ac, int pr, int pc, int lane, Ahead &n) const
+        {
+            // lane -> (array, pixel): 0-2 edge, 3-5 grad, 6-8 dir of A, B, C; 9, 10 edge beside
+            const int nr = r + ar, nc = c + ac;
+            const int side = lane % 3 - 1;
+            const int q = (nr + side * pr) * W + (nc + side * pc);
+            int v = 0;
+            if (lane < 3) v = edge[q];
+            else if (lane < 6) v = grad[q];
+            else if (lane < 9) v = dir[q];
+            else if (lane == 9) v = edge[(r + pr) * W + (c + pc)];
+            else if (lane == 10) v = edge[(r - pr) * W + (c - pc)];
+            n.eA = __builtin_amdgcn_readlane(v, 0); n.eB = __builtin_amdgcn_readlane(v, 1); n.eC = __builtin_amdgcn_readlane(v, 2);
+            n.gA = __builtin_amdgcn_readlane(v, 3); n.gB = __builtin_amdgcn_readlane(v, 4); n.gC = __builtin_amdgcn_readlane(v, 5);
+            n.dA = __builtin_amdgcn_readlane(v, 6); n.dB = __builtin_amdgcn_readlane(v, 7); n.dC = __builtin_amdgcn_readlane(v, 8);
+            n.s1 = __builtin_amdgcn_readlane(v, 9); n.s2 = __builtin_amdgcn_readlane(v, 10);
+        }
+    };
+    struct Tile {
+        uint16_t *t;
+        int r0, c0, tw;  // origin (row, column) of the tile in the image, words per tile row
+        static constexpr int STRIDE = 64;
+        __device__ int idx(int r, int c) const { return (r - r0) * tw + (c - c0); }
+        __device__ static int edge_of(uint16_t w) { const int st = w >> 12; return st ? 253 + st : 0; }
+        __device__ static int grad_of(uint16_t w) { return w & 0x7ff; }
+        __device__ static int dir_of(uint16_t w) { return (w & 0x800) ? STAG_EDGE_VERTICAL : STAG_EDGE_HORIZONTAL; }
+        __device__ int edge_at(int r, int c) const { return edge_of(t[idx(r, c)]); }
+        __device__ int dir_at(int r, int c) const { return dir_of(t[idx(r, c)]); }
+        __device__ void fetch(int r, int c, int ar, int ac, int pr, int pc, int, Ahead &n) const
+        {
+            const int i = idx(r, c), q = i + ar * tw + ac, p = pr * tw + pc;
+            const uint16_t wA = t[q - p], wB = t[q], wC = t[q + p];
+            n.eA = edge_of(wA); n.eB = edge_of(wB); n.eC = edge_of(wC);
+            n.gA = grad_of(wA); n.gB = grad_of(wB); n.gC = grad_of(wC);
+            n.dA = dir_of(wA); n.dB = dir_of(wB); n.dC = dir_of(wC);
+            n.s1 = edge_of(t[i + p]); n.s2 = edge_of(t[i - p]);
+        }
+        __device__ void set_state(int i, int st) const { t[i] = (uint16_t)((t[i] & 0x0fff) | (st << 12)); }
+        __device__ void mark(int r, int c, int pr, int pc, const Ahead &n, bool writer) const
+        {
+            if (!writer) return;
+            const int i = idx(r, c), p = pr * tw + pc;
+            set_state(i, 2);
+            if (n.s1 == STAG_ANCHOR_PIXEL) set_state(i + p, 0);
+            if (n.s2 == STAG_ANCHOR_PIXEL) set_state(i - p, 0);
+        }
+        __device__ void erase(int r, int c) const { set_state(idx(r, c), 0); }  // (a pixel listed twice gets the same word twice)
+    };
 
-    // the walk: true if the anchor produced a path that is kept (the chain tree is then in R.chains / R.pix)
-    __device__ bool walk_anchor(int r0, int c0, int grad_thresh)
+    // the walk from one anchor: true if it produced a path that is kept (the chain tree is then in R.chains / R.pix)
+    template <class Mem>
+    __device__ bool walk_anchor_t(int r0, int c0, int grad_thresh, const Mem &M, int lane)
     {
-        const int W = R.W;
-        StagChain *ch = R.chains;
-        ch[0].dir = 0; ch[0].len = 0; ch[0].parent = -1; ch[0].child[0] = ch[0].child[1] = -1; ch[0].pix = -1;
-        int noChains = 1, len = 0, dup = 0, top = -1;
-        if (R.dir[r0 * W + c0] == STAG_EDGE_VERTICAL) {
-            R.stack[++top] = make_int4(r0, c0, SR_DOWN, 0);
-            R.stack[++top] = make_int4(r0, c0, SR_UP, 0);
-        } else {
-            R.stack[++top] = make_int4(r0, c0, SR_RIGHT, 0);
-            R.stack[++top] = make_int4(r0, c0, SR_LEFT, 0);
-        }
-        while (top >= 0) {
-            const int4 e = R.stack[top--];
-            int r = e.x, c = e.y;
-            const int d = e.z, parent = e.w;
-            if (noChains >= R.capChains || len + 2 >= R.capPix || top + 3 >= R.capStack) {
-                overflow |= 16;
-                break;
-            }
-            if (R.edge[r * W + c] != STAG_EDGE_PIXEL) dup++;
-            const int cur = noChains;
-            ch[cur].dir = (int16_t)d; ch[cur].parent = (int16_t)parent; ch[cur].child[0] = ch[cur].child[1] = -1; ch[cur].pix = len;
-            int chainLen = 0;
-            R.pix[len++] = make_int2(r, c);
-            chainLen++;
-            const bool horiz = d == SR_LEFT || d == SR_RIGHT;
-            const int need = horiz ? STAG_EDGE_HORIZONTAL : STAG_EDGE_VERTICAL;
-            const int ar = d == SR_UP ? -1 : d == SR_DOWN ? 1 : 0, ac = d == SR_LEFT ? -1 : d == SR_RIGHT ? 1 : 0;
-            const int pr = horiz ? 1 : 0, pc = horiz ? 0 : 1;            // across the walking direction
-            const int fs = (d == SR_LEFT || d == SR_UP) ? -1 : 1;         // which diagonal is looked at first
-            const int slot = (d == SR_LEFT || d == SR_UP) ? 0 : 1;
-            bool stopped = false;
-            while (R.dir[r * W + c] == need) {
-                R.edge[r * W + c] = STAG_EDGE_PIXEL;
-                uint8_t *s1 = R.edge + (r + pr) * W + (c + pc), *s2 = R.edge + (r - pr) * W + (c - pc);
-                if (*s1 == STAG_ANCHOR_PIXEL) *s1 = 0;
-                if (*s2 == STAG_ANCHOR_PIXEL) *s2 = 0;
-                const int nr = r + ar, nc = c + ac;
-                if (R.edge[nr * W + nc] >= STAG_ANCHOR_PIXEL) {
-                    r = nr; c = nc;
-                } else if (R.edge[(nr + fs * pr) * W + nc + fs * pc] >= STAG_ANCHOR_PIXEL) {
-                    r = nr + fs * pr; c = nc + fs * pc;
-                } else if (R.edge[(nr - fs * pr) * W + nc - fs * pc] >= STAG_ANCHOR_PIXEL) {
-                    r = nr - fs * pr; c = nc - fs * pc;
-                } else {
-                    const int A = R.grad[(nr - pr) * W + nc - pc], B = R.grad[nr * W + nc], Cg = R.grad[(nr + pr) * W + nc + pc];
-                    int side = 0;
-                    if (A > B) side = A > Cg ? -1 : 1;
-                    else if (Cg > B) side = 1;
-                    r = nr + side * pr; c = nc + side * pc;
-                }
-                if (R.edge[r * W + c] == STAG_EDGE_PIXEL || R.grad[r * W + c] < grad_thresh) {
-                    ch[cur].len = (uint16_t)chainLen;
-                    ch[parent].child[slot] = (int16_t)cur;
-                    noChains++;
-                    stopped = true;
-                    break;
-                }
-                if (len + 2 >= R.capPix) { overflow |= 16; stopped = true; break; }
-                R.pix[len++] = make_int2(r, c);
-                chainLen++;
-            }
-            if (stopped) continue;
-            // the edge turns here: branch both ways across, this chain ends in front of the turning pixel
-            R.stack[++top] = make_int4(r, c, horiz ? SR_DOWN : SR_RIGHT, cur);
-            R.stack[++top] = make_int4(r, c, horiz ? SR_UP : SR_LEFT, cur);
-            len--;
-            chainLen--;
-            ch[cur].len = (uint16_t)chainLen;
-            ch[parent].child[slot] = (int16_t)cur;
-            noChains++;
-        }
-        wl_len = len;
-        wl_dup = dup;
-        wl_chains = noChains;
-        if (len - dup < STAG_MIN_PATH_LEN) {
-            for (int k = 0; k < len; k++) R.edge[R.pix[k].x * W + R.pix[k].y] = 0;
-            return false;
-        }
-        return true;
-    }
-
-    // The same walk run by a whole wave: control flow and bookkeeping are wave-uniform (every lane computes them, lane 0
-    // stores them), and what a step needs from memory -- edge / gradient / direction of the three pixels ahead and the edge
-    // value of the two pixels beside -- is fetched by eleven lanes at once, one round trip per step instead of a chain of
-    // dependent loads.  None of those eleven pixels is written in the same step (the current pixel and the two beside it
-    // are not among the three ahead), so the fetch sees exactly what the sequential code would read.
-    __device__ bool walk_anchor_wave(int r0, int c0, int grad_thresh, int lane)
-    {
-        const int W = R.W;
         const bool L0 = lane == 0;
         StagChain *ch = R.chains;
         if (L0) {
             ch[0].dir = 0; ch[0].len = 0; ch[0].parent = -1; ch[0].child[0] = ch[0].child[1] = -1; ch[0].pix = -1;
         }
         int noChains = 1, len = 0, dup = 0, top = -1;
-        const bool vert0 = R.dir[r0 * W + c0] == STAG_EDGE_VERTICAL;
+        const bool vert0 = M.dir_at(r0, c0) == STAG_EDGE_VERTICAL;
         if (L0) {
             R.stack[0] = make_int4(r0, c0, vert0 ? SR_DOWN : SR_RIGHT, 0);
             R.stack[1] = make_int4(r0, c0, vert0 ? SR_UP : SR_LEFT, 0);
@@ -307,7 +300,7 @@ struct StagRouter {
                 overflow |= 16;
                 break;
             }
-            if (R.edge[r * W + c] != STAG_EDGE_PIXEL) dup++;
+            if (M.edge_at(r, c) != STAG_EDGE_PIXEL) dup++;
             const int cur = noChains;
             if (L0) {
                 ch[cur].dir = (int16_t)d; ch[cur].parent = (int16_t)parent; ch[cur].child[0] = ch[cur].child[1] = -1; ch[cur].pix = len;
@@ -318,48 +311,29 @@ struct StagRouter {
             const bool horiz = d == SR_LEFT || d == SR_RIGHT;
             const int need = horiz ? STAG_EDGE_HORIZONTAL : STAG_EDGE_VERTICAL;
             const int ar = d == SR_UP ? -1 : d == SR_DOWN ? 1 : 0, ac = d == SR_LEFT ? -1 : d == SR_RIGHT ? 1 : 0;
-            const int pr = horiz ? 1 : 0, pc = horiz ? 0 : 1;
-            const int fs = (d == SR_LEFT || d == SR_UP) ? -1 : 1;
+            const int pr = horiz ? 1 : 0, pc = horiz ? 0 : 1;            // across the walking direction
+            const int fs = (d == SR_LEFT || d == SR_UP) ? -1 : 1;         // which diagonal is looked at first
             const int slot = (d == SR_LEFT || d == SR_UP) ? 0 : 1;
             bool stopped = false;
-            int curdir = R.dir[r * W + c];
+            int curdir = M.dir_at(r, c);
             while (curdir == need) {
-                const int nr = r + ar, nc = c + ac;
-                // lane -> (array, pixel): 0-2 edge, 3-5 grad, 6-8 dir of A = ahead - p, B = ahead, C = ahead + p; 9, 10 edge beside
-                int v = 0;
-                {
-                    const int k = lane % 3, side = k - 1;  // A, B, C
-                    const int qr = nr + side * pr, qc = nc + side * pc;
-                    const int q = qr * W + qc;
-                    if (lane < 3) v = R.edge[q];
-                    else if (lane < 6) v = R.grad[q];
-                    else if (lane < 9) v = R.dir[q];
-                    else if (lane == 9) v = R.edge[(r + pr) * W + (c + pc)];
-                    else if (lane == 10) v = R.edge[(r - pr) * W + (c - pc)];
-                }
-                const int eA = __builtin_amdgcn_readlane(v, 0), eB = __builtin_amdgcn_readlane(v, 1), eC = __builtin_amdgcn_readlane(v, 2);
-                const int gA = __builtin_amdgcn_readlane(v, 3), gB = __builtin_amdgcn_readlane(v, 4), gC = __builtin_amdgcn_readlane(v, 5);
-                const int dA = __builtin_amdgcn_readlane(v, 6), dB = __builtin_amdgcn_readlane(v, 7), dC = __builtin_amdgcn_readlane(v, 8);
-                const int s1 = __builtin_amdgcn_readlane(v, 9), s2 = __builtin_amdgcn_readlane(v, 10);
-                if (L0) {
-                    R.edge[r * W + c] = STAG_EDGE_PIXEL;
-                    if (s1 == STAG_ANCHOR_PIXEL) R.edge[(r + pr) * W + (c + pc)] = 0;
-                    if (s2 == STAG_ANCHOR_PIXEL) R.edge[(r - pr) * W + (c - pc)] = 0;
-                }
-                const int eF1 = fs < 0 ? eA : eC, eF2 = fs < 0 ? eC : eA;  // the diagonal looked at first / second
+                Ahead n;
+                M.fetch(r, c, ar, ac, pr, pc, lane, n);
+                M.mark(r, c, pr, pc, n, L0);
+                const int eF1 = fs < 0 ? n.eA : n.eC, eF2 = fs < 0 ? n.eC : n.eA;  // the diagonal looked at first / second
                 int side;
-                if (eB >= STAG_ANCHOR_PIXEL) side = 0;
+                if (n.eB >= STAG_ANCHOR_PIXEL) side = 0;
                 else if (eF1 >= STAG_ANCHOR_PIXEL) side = fs;
                 else if (eF2 >= STAG_ANCHOR_PIXEL) side = -fs;
                 else {
                     side = 0;
-                    if (gA > gB) side = gA > gC ? -1 : 1;
-                    else if (gC > gB) side = 1;
+                    if (n.gA > n.gB) side = n.gA > n.gC ? -1 : 1;
+                    else if (n.gC > n.gB) side = 1;
                 }
-                r = nr + side * pr;
-                c = nc + side * pc;
-                const int en = side < 0 ? eA : side > 0 ? eC : eB, gn = side < 0 ? gA : side > 0 ? gC : gB;
-                curdir = side < 0 ? dA : side > 0 ? dC : dB;
+                r = r + ar + side * pr;
+                c = c + ac + side * pc;
+                const int en = side < 0 ? n.eA : side > 0 ? n.eC : n.eB, gn = side < 0 ? n.gA : side > 0 ? n.gC : n.gB;
+                curdir = side < 0 ? n.dA : side > 0 ? n.dC : n.dB;
                 if (en == STAG_EDGE_PIXEL || gn < grad_thresh) {
                     if (L0) {
                         ch[cur].len = (uint16_t)chainLen;
@@ -375,6 +349,7 @@ struct StagRouter {
                 chainLen++;
             }
             if (stopped) continue;
+            // the edge turns here: branch both ways across, this chain ends in front of the turning pixel
             if (L0) {
                 R.stack[top + 1] = make_int4(r, c, horiz ? SR_DOWN : SR_RIGHT, cur);
                 R.stack[top + 2] = make_int4(r, c, horiz ? SR_UP : SR_LEFT, cur);
@@ -392,133 +367,30 @@ struct StagRouter {
         wl_dup = dup;
         wl_chains = noChains;
         if (len - dup < STAG_MIN_PATH_LEN) {
-            for (int k = lane; k < len; k += 64) R.edge[R.pix[k].x * W + R.pix[k].y] = 0;
+            for (int k = lane; k < len; k += Mem::STRIDE) M.erase(R.pix[k].x, R.pix[k].y);
             return false;
         }
         return true;
+    }
+    __device__ bool walk_anchor(int r0, int c0, int grad_thresh)
+    {
+        MemGlobal M;
+        M.grad = R.grad; M.dir = R.dir; M.edge = R.edge; M.W = R.W;
+        return walk_anchor_t(r0, c0, grad_thresh, M, 0);
+    }
+    __device__ bool walk_anchor_wave(int r0, int c0, int grad_thresh, int lane)
+    {
+        MemWave M;
+        M.grad = R.grad; M.dir = R.dir; M.edge = R.edge; M.W = R.W;
+        return walk_anchor_t(r0, c0, grad_thresh, M, lane);
+    }
+    __device__ bool walk_anchor_tile(int r0, int c0, int grad_thresh, int lane, const Tile &T) { return walk_anchor_t(r0, c0, grad_thresh, T, lane); }
+
+    __device__ void route_anchor(int r0, int c0, int grad_thresh)
+    {
+        if (walk_anchor(r0, c0, grad_thresh)) extract_anchor(wl_chains);
     }
 
-    // The wave-run walk again, on a copy of the component's bounding box in LDS (one 16-bit word per pixel: gradient 11 bits,
-    // direction 1 bit, edge state 2 bits): every lane reads the same LDS words (broadcast), lane 0 writes.  A walk stands on
-    // pixels of its own component and looks one pixel around them, so everything it touches is inside the box + 1.
-    struct Tile {
-        uint16_t *t;
-        int r0, c0, tw;  // origin (row, column) of the tile in the image, words per tile row
-        __device__ int idx(int r, int c) const { return (r - r0) * tw + (c - c0); }
-        __device__ static int edge_of(uint16_t w) { const int st = w >> 12; return st ? 253 + st : 0; }
-        __device__ static int grad_of(uint16_t w) { return w & 0x7ff; }
-        __device__ static int dir_of(uint16_t w) { return (w & 0x800) ? STAG_EDGE_VERTICAL : STAG_EDGE_HORIZONTAL; }
-        __device__ void set_edge(int i, int st, bool writer) const
-        {
-            if (writer) t[i] = (uint16_t)((t[i] & 0x0fff) | (st << 12));
-        }
-    };
-    __device__ bool walk_anchor_tile(int r0, int c0, int grad_thresh, int lane, const Tile &T)
-    {
-        const bool L0 = lane == 0;
-        StagChain *ch = R.chains;
-        if (L0) {
-            ch[0].dir = 0; ch[0].len = 0; ch[0].parent = -1; ch[0].child[0] = ch[0].child[1] = -1; ch[0].pix = -1;
-        }
-        int noChains = 1, len = 0, dup = 0, top = -1;
-        const bool vert0 = Tile::dir_of(T.t[T.idx(r0, c0)]) == STAG_EDGE_VERTICAL;
-        if (L0) {
-            R.stack[0] = make_int4(r0, c0, vert0 ? SR_DOWN : SR_RIGHT, 0);
-            R.stack[1] = make_int4(r0, c0, vert0 ? SR_UP : SR_LEFT, 0);
-        }
-        top = 1;
-        while (top >= 0) {
-            const int4 e = R.stack[top--];
-            int r = e.x, c = e.y;
-            const int d = e.z, parent = e.w;
-            if (noChains >= R.capChains || len + 2 >= R.capPix || top + 3 >= R.capStack) {
-                overflow |= 16;
-                break;
-            }
-            int ci = T.idx(r, c);
-            uint16_t cw = T.t[ci];
-            if (Tile::edge_of(cw) != STAG_EDGE_PIXEL) dup++;
-            const int cur = noChains;
-            if (L0) {
-                ch[cur].dir = (int16_t)d; ch[cur].parent = (int16_t)parent; ch[cur].child[0] = ch[cur].child[1] = -1; ch[cur].pix = len;
-                R.pix[len] = make_int2(r, c);
-            }
-            len++;
-            int chainLen = 1;
-            const bool horiz = d == SR_LEFT || d == SR_RIGHT;
-            const int need = horiz ? STAG_EDGE_HORIZONTAL : STAG_EDGE_VERTICAL;
-            const int ar = d == SR_UP ? -1 : d == SR_DOWN ? 1 : 0, ac = d == SR_LEFT ? -1 : d == SR_RIGHT ? 1 : 0;
-            const int pstep = horiz ? T.tw : 1;            // one pixel across the walking direction, in tile words
-            const int astep = ar * T.tw + ac;              // one pixel ahead
-            const int pr = horiz ? 1 : 0, pc = horiz ? 0 : 1;
-            const int fs = (d == SR_LEFT || d == SR_UP) ? -1 : 1;
-            const int slot = (d == SR_LEFT || d == SR_UP) ? 0 : 1;
-            bool stopped = false;
-            int curdir = Tile::dir_of(cw);
-            while (curdir == need) {
-                const int ni = ci + astep;
-                const uint16_t wA = T.t[ni - pstep], wB = T.t[ni], wC = T.t[ni + pstep], w1 = T.t[ci + pstep], w2 = T.t[ci - pstep];
-                T.set_edge(ci, 2, L0);
-                if (Tile::edge_of(w1) == STAG_ANCHOR_PIXEL) T.set_edge(ci + pstep, 0, L0);
-                if (Tile::edge_of(w2) == STAG_ANCHOR_PIXEL) T.set_edge(ci - pstep, 0, L0);
-                const int eA = Tile::edge_of(wA), eB = Tile::edge_of(wB), eC = Tile::edge_of(wC);
-                const int gA = Tile::grad_of(wA), gB = Tile::grad_of(wB), gC = Tile::grad_of(wC);
-                const int eF1 = fs < 0 ? eA : eC, eF2 = fs < 0 ? eC : eA;
-                int side;
-                if (eB >= STAG_ANCHOR_PIXEL) side = 0;
-                else if (eF1 >= STAG_ANCHOR_PIXEL) side = fs;
-                else if (eF2 >= STAG_ANCHOR_PIXEL) side = -fs;
-                else {
-                    side = 0;
-                    if (gA > gB) side = gA > gC ? -1 : 1;
-                    else if (gC > gB) side = 1;
-                }
-                r = r + ar + side * pr;
-                c = c + ac + side * pc;
-                ci = ni + side * pstep;
-                const uint16_t wn = side < 0 ? wA : side > 0 ? wC : wB;
-                curdir = Tile::dir_of(wn);
-                if (Tile::edge_of(wn) == STAG_EDGE_PIXEL || Tile::grad_of(wn) < grad_thresh) {
-                    if (L0) {
-                        ch[cur].len = (uint16_t)chainLen;
-                        ch[parent].child[slot] = (int16_t)cur;
-                    }
-                    noChains++;
-                    stopped = true;
-                    break;
-                }
-                if (len + 2 >= R.capPix) { overflow |= 16; stopped = true; break; }
-                if (L0) R.pix[len] = make_int2(r, c);
-                len++;
-                chainLen++;
-            }
-            if (stopped) continue;
-            if (L0) {
-                R.stack[top + 1] = make_int4(r, c, horiz ? SR_DOWN : SR_RIGHT, cur);
-                R.stack[top + 2] = make_int4(r, c, horiz ? SR_UP : SR_LEFT, cur);
-            }
-            top += 2;
-            len--;
-            chainLen--;
-            if (L0) {
-                ch[cur].len = (uint16_t)chainLen;
-                ch[parent].child[slot] = (int16_t)cur;
-            }
-            noChains++;
-        }
-        wl_len = len;
-        wl_dup = dup;
-        wl_chains = noChains;
-        if (len - dup < STAG_MIN_PATH_LEN) {
-            for (int k = lane; k < len; k += 64) {
-                const int2 q = R.pix[k];
-                const int i = T.idx(q.x, q.y);
-                T.t[i] = (uint16_t)(T.t[i] & 0x0fff);  // (a pixel listed twice gets the same word twice)
-            }
-            return false;
-        }
-        return true;
-    }
 
     // the chain tree -> segments
     __device__ void extract_anchor(int noChains)

@@ -24,14 +24,12 @@ LINE_DTYPE = np.dtype([("a", "f8"), ("b", "f8"), ("sx", "f8"), ("sy", "f8"), ("e
 
 def load_library(hd: int) -> np.ndarray:
     """The codewords of marker library HD<hd> (uint64, four rotations x markers): the published STag tables, extracted by
-    tools/make_stag_libraries.py into fiducials_amd/data/stag_libraries.npz."""
+    tools/make_stag_libraries.py into fiducials_amd/data/stag_HD<hd>.bin (raw little-endian uint64, shared with the C++ host)."""
     import os
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "stag_libraries.npz")
-    with np.load(path) as z:
-        key = f"HD{hd}"
-        if key not in z:
-            raise FidError(_lib.FID_E_INVALID_ARG, "Invalid library HD. Possible values are 11, 13, 15, 17, 19, 21, or 23")
-        return np.ascontiguousarray(z[key], dtype=np.uint64)
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", f"stag_HD{hd}.bin")
+    if hd not in (11, 13, 15, 17, 19, 21, 23) or not os.path.exists(path):
+        raise FidError(_lib.FID_E_INVALID_ARG, "Invalid library HD. Possible values are 11, 13, 15, 17, 19, 21, or 23")
+    return np.ascontiguousarray(np.fromfile(path, dtype="<u8").astype(np.uint64))
 
 
 class StagDetector:

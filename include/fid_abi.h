@@ -255,7 +255,7 @@ fid_status fid_stag_host_tables(int32_t width, int32_t height, int32_t *kmin, in
                                 double *code_locations, int32_t *min_line_len);
 /* the marker library of Decoder::Decoder(hd) (Decoder.cpp:14-43): n_codewords = 4 x number of markers, the four rotations
  * of every marker one block after the other, 48 bits each (the HDxx arrays of stag/MarkerIDs.h; fiducials_amd/data/
- * stag_libraries.npz holds them for the Python host side) */
+ * stag_HD<hd>.bin holds them as raw little-endian uint64 for the host sides shipped here) */
 fid_status fid_stag_load_library(fid_stag_ctx *ctx, const uint64_t *codewords, int32_t n_codewords);
 /* Stag::detectMarkers (Stag.cpp:24-51) up to, not including, PoseRefiner::refineMarkerPose: homography, code reading,
  * decoding with the context's errorCorrection, corner shift, duplicate removal */

@@ -64,7 +64,7 @@ def test_piecewise_calls_equal_the_reference_pipeline_end_to_end():
 
 
 def test_marker_libraries_are_the_published_tables():
-    """fiducials_amd/data/stag_libraries.npz (tools/make_stag_libraries.py): sizes of Decoder.cpp:17-37, 48-bit words, four
+    """fiducials_amd/data/stag_HD*.bin (tools/make_stag_libraries.py): sizes of Decoder.cpp:17-37, 48-bit words, four
     blocks per library, no word twice, block k = block 0 turned by k quarter turns of the code ring."""
     from fiducials_amd.stag import load_library
     sizes = {11: 22309, 13: 2884, 15: 766, 17: 157, 19: 38, 21: 12, 23: 6}

@@ -877,8 +877,13 @@ __global__ __launch_bounds__(256) void k_stag_route_extract(StagRoute G, StagAre
                                                             int *__restrict__ blk_pix, int *__restrict__ blk_segs, int2 *__restrict__ blk_where,
                                                             int *__restrict__ ovf)
 {
-    // one wave per component: every lane runs the same scalar steps (same values, same stores); pixel runs are copied by all lanes
-    const int cid = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    // one wave per component: every lane runs the same scalar steps (same values, same stores); pixel runs are copied by all lanes.
+    // The chain tree of the anchor being extracted (and the stack of its tree walk) sits in LDS when it has <= EX_CHAINS chains:
+    // the extraction prunes and empties chains as it goes, none of which has to survive it.
+    constexpr int EX_CHAINS = 1024;
+    __shared__ StagChain s_chains[4][EX_CHAINS];
+    __shared__ int4 s_stack[4][EX_CHAINS];
+    const int wv = threadIdx.x >> 6, cid = blockIdx.x * 4 + wv, lane = threadIdx.x & 63;
     if (cid >= cursors[0]) return;
     const StagComp C = comps[cid];
     if (C.nanch == 0 || C.nrec == 0) return;
@@ -890,12 +895,26 @@ __global__ __launch_bounds__(256) void k_stag_route_extract(StagRoute G, StagAre
     StagRec *recs = A.recs + C.anch_base;
     int2 *pix0 = S.R.pix;
     StagChain *chain0 = S.R.chains;
+    int4 *stack0 = S.R.stack;
+    const int capStack0 = S.R.capStack;
     const int n = (int)*n_anchors;
     int prev_rank = -1;
     for (int k = 0; k < C.nrec; k++) {
         StagRec r = recs[k];
         S.R.pix = pix0 + r.pix_off;
-        S.R.chains = chain0 + r.chain_off;
+        if (r.nchains <= EX_CHAINS) {
+            for (int i = lane; i < r.nchains; i += 64) s_chains[wv][i] = chain0[r.chain_off + i];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            S.R.chains = s_chains[wv];
+            S.R.stack = s_stack[wv];
+            S.R.capStack = EX_CHAINS;
+        } else {
+            S.R.chains = chain0 + r.chain_off;
+            S.R.stack = stack0;
+            S.R.capStack = capStack0;
+        }
         // the block the reference wrote just before this one: ours only if no other component produced in between
         S.prev_valid = k > 0 && next[r.rank] == prev_rank;
         const int seg0 = S.noSegments, out0 = S.totalPixels;

@@ -605,14 +605,14 @@ static fid_status stag_route_par(fid_stag_ctx *c, const StagRoute &R)
         return hipMemsetAsync(c->d_rcount, 0, 12, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess ? FID_OK : FID_E_HIP;
     }
     const int nb = (n + 255) / 256;
-    bool ok = hipMemsetAsync(c->d_csize, 0, (size_t)n * 4, st) == hipSuccess && hipMemsetAsync(c->d_canch, 0, (size_t)n * 4, st) == hipSuccess &&
-              hipMemsetAsync(c->d_cursors, 0, 64, st) == hipSuccess && hipMemsetAsync(c->d_fill, 0, (size_t)c->max_comps * 4, st) == hipSuccess &&
+    // (the per-root counters are zeroed by k_stag_ccl_init where a root can be; the output arena is cleared once its used
+    // size is known: clearing the whole allocations cost 70 MB of writes per frame)
+    bool ok = hipMemsetAsync(c->d_cursors, 0, 64, st) == hipSuccess && hipMemsetAsync(c->d_fill, 0, (size_t)c->max_comps * 4, st) == hipSuccess &&
               hipMemsetAsync(c->d_aslots, 0xff, (size_t)c->cap_aslots * 4, st) == hipSuccess &&
               hipMemsetAsync(c->d_prodflag, 0, (size_t)na * 4, st) == hipSuccess && hipMemsetAsync(c->d_blkpix, 0, (size_t)na * 4, st) == hipSuccess &&
-              hipMemsetAsync(c->d_blksegs, 0, (size_t)na * 4, st) == hipSuccess &&
-              hipMemsetAsync(c->d_aout, 0xff, (size_t)3 * n * sizeof(int2), st) == hipSuccess;
+              hipMemsetAsync(c->d_blksegs, 0, (size_t)na * 4, st) == hipSuccess;
     if (!ok) return FID_E_HIP;
-    hipLaunchKernelGGL(k_stag_ccl_init, dim3(nb), dim3(256), 0, st, c->d_grad, n, 16, c->d_label);
+    hipLaunchKernelGGL(k_stag_ccl_init, dim3(nb), dim3(256), 0, st, c->d_grad, n, 16, c->d_label, c->d_csize, c->d_canch);
     hipLaunchKernelGGL(k_stag_ccl_merge, dim3(nb), dim3(256), 0, st, W, H, c->d_label);
     hipLaunchKernelGGL(k_stag_ccl_flatten, dim3(nb), dim3(256), 0, st, n, c->d_label, c->d_edge, c->d_csize, c->d_canch);
     hipLaunchKernelGGL(k_stag_comp_alloc, dim3(nb), dim3(256), 0, st, n, c->d_label, c->d_csize, c->d_canch, c->d_cursors, c->max_comps, c->d_caps,
@@ -628,6 +628,8 @@ static fid_status stag_route_par(fid_stag_ctx *c, const StagRoute &R)
     // one component holding (nearly) all anchors -- a frame of noise -- leaves nothing to run side by side, and sorting its
     // anchors would cost more than the sequential road's single pass over the globally sorted list
     if (cur[9] > 65536) return FID_E_CAPACITY;
+    // pixels of the output arena the extraction does not write read as (-1, -1), like the reference's untouched array
+    if (cur[5] > 0 && hipMemsetAsync(c->d_aout, 0xff, (size_t)cur[5] * sizeof(int2), st) != hipSuccess) return FID_E_HIP;
     const int nc = cur[0];
     StagArenas A;
     A.pix = c->d_apix; A.stack = c->d_astack; A.chains = c->d_achains; A.out = c->d_aout; A.segs = c->d_asegs; A.recs = c->d_recs;

@@ -497,10 +497,17 @@ __device__ __forceinline__ int ccl_find(const int *L, int a)
     }
 }
 
-__global__ __launch_bounds__(256) void k_stag_ccl_init(const int16_t *__restrict__ grad, int n, int thresh, int *__restrict__ label)
+__global__ __launch_bounds__(256) void k_stag_ccl_init(const int16_t *__restrict__ grad, int n, int thresh, int *__restrict__ label,
+                                                       int *__restrict__ csize, int *__restrict__ canch)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n) label[i] = grad[i] >= thresh ? i : -1;
+    if (i >= n) return;
+    const bool fg = grad[i] >= thresh;
+    label[i] = fg ? i : -1;
+    if (fg) {  // a root is a foreground pixel: the per-root counters only have to be clean there
+        csize[i] = 0;
+        canch[i] = 0;
+    }
 }
 
 __global__ __launch_bounds__(256) void k_stag_ccl_merge(int W, int H, int *label)

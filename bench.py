@@ -51,6 +51,26 @@ KERNEL_OF = {"threshold": "k_threshold_fixed", "find_starts": "k_find_starts", "
              "walk_full": "k_walk_full<2>", "seed_walk": "k_walk_full<1>", "approx": "k_approx"}
 
 
+def shard_seeds(rank: int, world: int, unique: int, workload: str = "aruco"):
+    """The shard rule: which synthetic frames a rank owns.  Frames are independent units, every rank processes its own stream
+    (BASELINE cfg 4: stream s -> GPU s), nothing is exchanged on the data path.  N = 1 keeps the cfg 3 seeds 1000 + i."""
+    if workload == "stag":
+        return [10000 * rank + 100 + i for i in range(unique)]
+    return [1000 + i for i in range(unique)] if world == 1 else [10000 * rank + i for i in range(unique)]
+
+
+def job_throughput(units_per_rank: int, world: int, dt_local: float, dist=None, device=None) -> tuple:
+    """Whole-job rate: the units all ranks processed / the slowest rank's time (the only collective of the job)."""
+    dt = dt_local
+    if dist is not None:
+        import torch
+
+        tt = torch.tensor([dt_local], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    return units_per_rank * world / dt, dt
+
+
 def pmc_traffic(stage, frames_per_launch):
     """HBM bytes per launch of a stage's kernel from the committed rocprofv3 PMC passes (profiles/*pmc_traffic.json:
     FETCH_SIZE / WRITE_SIZE per frame, collected in their own --pmc runs as MI355X_MICROARCH.md prescribes; the file
@@ -167,7 +187,7 @@ def main_stag(args):
 
     hd, ec, B = 21, 7, min(args.batch, 64)
     words = fstag.load_library(hd)
-    frames = [synth.make_stag_frame(words, 10000 * rank + 100 + i, W, H, MARKERS).image for i in range(min(B, 4))]
+    frames = [synth.make_stag_frame(words, sd, W, H, MARKERS).image for sd in shard_seeds(rank, world, min(B, 4), "stag")]
     # several contexts side by side (fid_stag_detect_markers_batch: one host thread + one HIP stream per context inside the
     # library): a frame's work is a chain of small kernels, several frames in flight fill the GPU
     T = max(1, min(args.streams, B))
@@ -192,12 +212,7 @@ def main_stag(args):
     for _ in range(args.steps):
         markers += step()
     barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-    fps = B * args.steps * n_gpus / dt
+    fps, dt = job_throughput(B * args.steps, n_gpus, time.perf_counter() - t0, dist, f"cuda:{local_rank}")
     if rank == 0:
         algo = 10 * W * H  # ~10 B/px for the EDPF streaming stages
         out = {
@@ -261,7 +276,7 @@ def main():
         unique = min(unique, 32)  # keep generation inside the time budget on small hosts
     unique = min(unique, B)
     # cfg 3: seeds 1000 + i ; cfg 4 stream s: 10000 * s + i
-    seeds = [1000 + i for i in range(unique)] if world == 1 else [10000 * rank + i for i in range(unique)]
+    seeds = shard_seeds(rank, world, unique)
     frames_u = make_frames(seeds)
 
     import torch
@@ -309,13 +324,7 @@ def main():
         for k, v in det.stage_ms().items():
             stage_acc[k] = stage_acc.get(k, 0.0) + v
     barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-    total_frames = B * args.steps * n_gpus
-    fps = total_frames / dt
+    fps, dt = job_throughput(B * args.steps, n_gpus, time.perf_counter() - t0, dist, f"cuda:{local_rank}")
 
     if rank == 0:
         stage_ms = {k: v / max(args.steps, 1) for k, v in stage_acc.items()}

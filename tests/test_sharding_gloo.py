@@ -14,15 +14,14 @@ WORKER = textwrap.dedent("""
     import torch, torch.distributed as dist
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
-    # the bench's shard rule (cfg 4): stream s = rank owns seeds 10000*s + i
-    seeds = [10000 * rank + i for i in range(4)]
-    t = torch.tensor([0.5 + rank], dtype=torch.float64)
+    import bench  # the bench's own shard rule and job-rate reduction (no GPU needed for these two)
+    seeds = bench.shard_seeds(rank, world, 4) + bench.shard_seeds(rank, world, 4, "stag")
     dist.barrier()
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    rate, dt = bench.job_throughput(100, world, 0.5 + rank, dist, "cpu")
     got = [None] * world
     dist.all_gather_object(got, seeds)
     if rank == 0:
-        print(json.dumps({"max_t": float(t.item()), "seeds": got}))
+        print(json.dumps({"max_t": dt, "rate": rate, "seeds": got}))
     dist.destroy_process_group()
 """) % ROOT
 
@@ -41,6 +40,14 @@ def test_world_size_2_gloo(tmp_path):
     import json
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     r = json.loads(line)
-    assert r["max_t"] == 1.5
+    assert r["max_t"] == 1.5 and abs(r["rate"] - 200 / 1.5) < 1e-9  # all ranks' units / the slowest rank's time
     flat = [x for s_ in r["seeds"] for x in s_]
-    assert len(set(flat)) == len(flat) == 8  # disjoint shards, nothing exchanged but the clock
+    assert len(set(flat)) == len(flat) == 16  # disjoint shards (both workloads), nothing exchanged but the clock
+
+
+def test_single_rank_keeps_the_cfg3_seeds():
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.shard_seeds(0, 1, 3) == [1000, 1001, 1002]
+    assert bench.job_throughput(256, 1, 0.5) == (512.0, 0.5)

@@ -33,6 +33,9 @@ import numpy as np  # noqa: E402
 W, H, MARKERS = 1920, 1080, 20
 FIDUCIAL_LEN = 0.14
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+# FID_BENCH_DRYRUN=cpu: the launcher / rank plumbing only (gloo, no GPU, no detector, a sleeping stand-in for the step), so that
+# the N-rank path of this very file is covered by the CPU test suite.  The line it prints carries "dryrun": true and no metric.
+DRYRUN = os.environ.get("FID_BENCH_DRYRUN", "") == "cpu"
 
 # algorithmic HBM bytes per frame and kernel (DESIGN.md "Roofline accounting"):
 #   gray read once + 13 bit-packed masks written once + read once by the contour stage
@@ -169,20 +172,13 @@ def main_stag(args):
     fid_stag_detect_markers + fid_stag_pose_last, one frame per call (the stag_detect node's shape; the frame comes from host
     memory, so the PCIe copy is inside the number).  cpu_baseline = the REFERENCE's own Stag::detectMarkers (oracle/_ref: its
     sources compiled in place) on one host core."""
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    n_gpus = world if world > 1 else args.gpus
+    rank, local_rank, world = rank_env(args)
+    n_gpus = world
     import torch
 
     assert torch.cuda.is_available(), "bench.py needs a GPU (the library has no CPU fallback)"
     torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist_mod
-
-        dist = dist_mod
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dist = init_dist(world, local_rank)
     from fiducials_amd import stag as fstag, synth
 
     hd, ec, B = 21, 7, min(args.batch, 64)
@@ -211,8 +207,12 @@ def main_stag(args):
     markers = 0
     for _ in range(args.steps):
         markers += step()
+    torch.cuda.synchronize()
+    dt_local = time.perf_counter() - t0
     barrier()
     fps, dt = job_throughput(B * args.steps, n_gpus, time.perf_counter() - t0, dist, f"cuda:{local_rank}")
+    ranks = gather_ranks(dist, rank, f"cuda:{local_rank}", B * args.steps, dt_local)
+    assert len(ranks) == n_gpus
     if rank == 0:
         algo = 10 * W * H  # ~10 B/px for the EDPF streaming stages
         out = {
@@ -227,6 +227,7 @@ def main_stag(args):
             "roofline": {"bound": "hbm", "kernel": "pipeline (latency-bound: edge routing, line fitting, simplex search)",
                          "achieved": round(fps / n_gpus * algo / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(fps / n_gpus * algo / 1e9 / HBM_PEAK_GBS, 6), "traffic": None},
+            "ranks": ranks,
         }
         if n_gpus == 1 and not args.no_cpu_baseline:
             from oracle import stag_ref
@@ -248,6 +249,99 @@ def main_stag(args):
         dist.destroy_process_group()
 
 
+def free_port() -> int:
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def visible_gpus() -> int:
+    if DRYRUN:
+        return 1 << 20
+    import torch
+
+    return torch.cuda.device_count() if torch.cuda.is_available() else 0
+
+
+def launch_ranks(n: int) -> int:
+    """`python bench.py --gpus N` (N > 1) outside a torch.distributed launcher: start N ranks of this very script, one per GPU,
+    exactly as the driver does (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py ...`), and hand their exit code back.  Refuses (rc 2) when fewer than N GPUs are visible: a rank
+    count that did not run is never reported."""
+    have = visible_gpus()
+    if have < n:
+        print(f"bench.py: --gpus {n} but only {have} GPU(s) visible", file=sys.stderr)
+        return 2
+    import subprocess
+
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=dict(os.environ, FID_BENCH_CHILD="1"))
+
+
+def rank_env(args):
+    """(rank, local_rank, world) from the launcher's environment; the world size must be the --gpus the line will report."""
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a rank count that is not running",
+              file=sys.stderr)
+        sys.exit(2)
+    return rank, local_rank, world
+
+
+def init_dist(world, local_rank):
+    """Process group for the clock reduction (the job's only collective): RCCL on the GPUs, gloo in the CPU dry run."""
+    if world <= 1:
+        return None
+    import torch
+    import torch.distributed as dist_mod
+
+    if DRYRUN:
+        dist_mod.init_process_group("gloo")
+    else:
+        dist_mod.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    return dist_mod
+
+
+def gather_ranks(dist, rank, device, units, dt_local):
+    """Per-rank evidence for the JSON line: (rank, pid, device, frames/s of that rank alone)."""
+    mine = {"rank": rank, "pid": os.getpid(), "device": device, "fps": round(units / dt_local, 2)}
+    if dist is None:
+        return [mine]
+    got = [None] * dist.get_world_size()
+    dist.all_gather_object(got, mine)
+    return got
+
+
+def main_dryrun(args):
+    rank, local_rank, world = rank_env(args)
+    dist = init_dist(world, local_rank)
+    seeds = shard_seeds(rank, world, 4)
+    B = 4
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.01 * (1 + rank))
+    dt_local = time.perf_counter() - t0
+    barrier()
+    fps, dt = job_throughput(B * args.steps, world, dt_local, dist, "cpu")
+    ranks = gather_ranks(dist, rank, "cpu", B * args.steps, dt_local)
+    if rank == 0:
+        print(json.dumps({"dryrun": True, "n_gpus": world, "steps": args.steps, "value": round(fps, 2), "ms_per_step": round(dt / args.steps * 1e3, 3),
+                          "ranks": ranks, "seeds_rank0": seeds}))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -260,15 +354,20 @@ def main():
     ap.add_argument("--workload", choices=["aruco", "stag"], default="aruco",
                     help="aruco = the BASELINE.json metric (default); stag = BASELINE cfg 5, the stag_detect path")
     args = ap.parse_args()
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))  # N ranks of this script, one per GPU; rank 0 prints the line
+    if DRYRUN:
+        return main_dryrun(args)
     if args.workload == "stag":
         return main_stag(args)
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    n_gpus = args.gpus
-    if world != n_gpus and world > 1:
-        n_gpus = world
+    rank, local_rank, world = rank_env(args)
+    n_gpus = world
+    if visible_gpus() <= local_rank:
+        print(f"bench.py: rank {rank} has no GPU (local rank {local_rank}, {visible_gpus()} visible)", file=sys.stderr)
+        sys.exit(2)
 
     B = args.batch
     unique = args.unique or B
@@ -283,12 +382,7 @@ def main():
 
     assert torch.cuda.is_available(), "bench.py needs a GPU (the library has no CPU fallback)"
     torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist_mod
-
-        dist = dist_mod
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dist = init_dist(world, local_rank)
 
     from fiducials_amd.detector import ArucoDetector
     from fiducials_amd.synth import K_DEFAULT
@@ -323,8 +417,12 @@ def main():
         markers += sum(n)
         for k, v in det.stage_ms().items():
             stage_acc[k] = stage_acc.get(k, 0.0) + v
+    torch.cuda.synchronize()
+    dt_local = time.perf_counter() - t0
     barrier()
     fps, dt = job_throughput(B * args.steps, n_gpus, time.perf_counter() - t0, dist, f"cuda:{local_rank}")
+    ranks = gather_ranks(dist, rank, f"cuda:{local_rank}", B * args.steps, dt_local)
+    assert len(ranks) == n_gpus  # every reported GPU ran its own rank
 
     if rank == 0:
         stage_ms = {k: v / max(args.steps, 1) for k, v in stage_acc.items()}
@@ -372,6 +470,7 @@ def main():
                 },
             },
             "stage_ms_per_step": {k: round(v, 4) for k, v in stage_ms.items()},
+            "ranks": ranks,
         }
         if n_gpus == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(frames_u, K, D)

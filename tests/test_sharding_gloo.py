@@ -51,3 +51,35 @@ def test_single_rank_keeps_the_cfg3_seeds():
     import bench
     assert bench.shard_seeds(0, 1, 3) == [1000, 1001, 1002]
     assert bench.job_throughput(256, 1, 0.5) == (512.0, 0.5)
+
+
+def _run_bench(argv, env_extra, timeout=300):
+    env = dict(os.environ, **env_extra)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        if k not in env_extra:
+            env.pop(k, None)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, capture_output=True, text=True, timeout=timeout, env=env)
+
+
+def test_bench_launcher_spawns_one_rank_per_gpu():
+    """`python bench.py --gpus 2` with no launcher around it must START two ranks (round 1 ran one process and multiplied):
+    bench.py's own launcher, its rank plumbing and its clock reduction, on gloo with the GPU step replaced by a sleep."""
+    import json
+    out = _run_bench(["--gpus", "2", "--steps", "3", "--warmup", "0"], {"FID_BENCH_DRYRUN": "cpu"})
+    assert out.returncode == 0, out.stderr[-2000:]
+    r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert r["n_gpus"] == 2 and len(r["ranks"]) == 2
+    assert sorted(x["rank"] for x in r["ranks"]) == [0, 1]
+    assert len({x["pid"] for x in r["ranks"]}) == 2  # two processes really ran
+    # whole-job rate = all ranks' frames / the slowest rank's time: rank 1 sleeps twice as long as rank 0
+    slow = min(x["fps"] for x in r["ranks"])
+    assert r["value"] <= 2 * slow * 1.05 and r["value"] < sum(x["fps"] for x in r["ranks"])
+
+
+def test_bench_refuses_a_rank_count_that_is_not_running():
+    # launched by somebody else's launcher with a different world size
+    out = _run_bench(["--gpus", "2"], {"FID_BENCH_DRYRUN": "cpu", "WORLD_SIZE": "3", "RANK": "0", "LOCAL_RANK": "0"})
+    assert out.returncode == 2 and "WORLD_SIZE=3" in out.stderr
+    # more GPUs asked for than visible (this container has none): no line, rc != 0
+    out = _run_bench(["--gpus", "2", "--steps", "1"], {})
+    assert out.returncode == 2 and "visible" in out.stderr and not [l for l in out.stdout.splitlines() if l.startswith("{")]

@@ -132,9 +132,10 @@ fid_status apply_params(fid_ctx *c, const fid_params *p)
     }
     if (P.rmax > 40) return FID_E_UNSUPPORTED;  // LDS tile budget of k_threshold
     {
+        // adaptiveThreshold: idelta = type == THRESH_BINARY ? cvCeil(delta) : cvFloor(delta); aruco passes THRESH_BINARY_INV
         double cdelta = p->adaptiveThreshConstant;
         int i = (int)cdelta;
-        P.idelta = i + (i < cdelta);  // cvCeil
+        P.idelta = i - (i > cdelta);  // cvFloor
     }
     P.polyAcc = p->polygonalApproxAccuracyRate;
     P.minCornerDistRate = p->minCornerDistanceRate;
@@ -609,7 +610,8 @@ fid_status fid_create(const fid_params *params, const fid_dict *dict, const fid_
         TRY(dalloc(c, &c->d_segs, F * L.max_contours_per_frame));
         TRY(dalloc(c, &c->d_pend, F * L.max_contours_per_frame));
         TRY(dalloc(c, &c->d_seedq, F * L.max_contours_per_frame));
-        TRY(dalloc(c, &c->d_seedplane, plane_words));
+        (void)plane_words;
+        TRY(dalloc(c, &c->d_seedplane, c->masks_bytes / sizeof(uint32_t)));  // one uint2 per mask word, same margin as d_masks
         TRY(dalloc(c, &c->d_wres, F * L.max_contours_per_frame));
         TRY(dalloc(c, &c->d_cinfo, F * L.max_contours_per_frame));
         TRY(dalloc(c, &c->d_cbase, F * L.max_contours_per_frame));
@@ -694,10 +696,26 @@ fid_status fid_set_params(fid_ctx *c, const fid_params *p)
     fid_params keep = c->params;
     fid_status rc = apply_params(c, p);
     if (rc == FID_OK && c->P.nscales > old_scales) {
-        // the masks buffer was sized for the scale count at creation
+        // the masks buffer and the seed-index plane (one uint2 per mask word) were sized for the scale count at creation
+        // (plus the same margin): a larger scale count must fit both
         size_t need = masks_elems(c, c->lim.max_width, c->lim.max_height, c->lim.max_batch) * sizeof(uint32_t);
         if (need > c->masks_bytes) {
             (void)apply_params(c, &keep);
+            c->last_error = "more threshold scales than the context was created for";
+            return FID_E_UNSUPPORTED;
+        }
+    }
+    if (rc == FID_OK) {
+        // what run_detect would refuse on every later frame is refused here, at reconfigure time: the chunk table was sized
+        // for the creation-time maxMarkerPerimeterRate, and contour points live in LDS
+        const int maxdim = c->lim.max_width > c->lim.max_height ? c->lim.max_width : c->lim.max_height;
+        const unsigned maxPerim = (unsigned)(p->maxMarkerPerimeterRate * maxdim);
+        DevParams Q = c->P;
+        Q.maxPerim = (int)maxPerim;
+        if (maxPerim > 36000u ||
+            (size_t)c->lim.max_batch * 2 * c->lim.max_contours_per_frame * chunk_tab_pitch(Q) > c->ckpts_elems) {
+            (void)apply_params(c, &keep);
+            c->last_error = "maxMarkerPerimeterRate larger than the context was created for";
             return FID_E_UNSUPPORTED;
         }
     }

@@ -32,7 +32,7 @@
 struct DevParams {
     int W, H, gstride, WW, TC, TR, nscales, nframes;  // WW mask words per image row; TC x TR mask tiles per plane
     int win[FID_MAX_SCALES];       // odd window sizes
-    int idelta;                    // cvCeil(adaptiveThreshConstant)
+    int idelta;                    // cvFloor(adaptiveThreshConstant) (THRESH_BINARY_INV)
     int rmax;                      // max window radius
     int minPerim, maxPerim;        // (unsigned)(rate * max(W,H))
     double polyAcc, minCornerDistRate, minMarkerDistRate;

@@ -911,6 +911,7 @@ fid_status fid_stag_detect_markers_batch(fid_stag_ctx *const *ctxs, int32_t nctx
     for (int t = 0; t < nctx; t++)
         if (!ctxs[t]) return FID_E_INVALID_ARG;
     std::vector<fid_status> rcs((size_t)nctx, FID_OK);
+    for (int f = 0; f < nframes; f++) n_per_frame[f] = 0;  // every count is defined whatever happens to a worker
     auto work = [&](int t) {
         for (int f = t; f < nframes; f += nctx) {
             fid_stag_marker *m = markers + (size_t)f * cap_per_frame;
@@ -919,8 +920,8 @@ fid_status fid_stag_detect_markers_batch(fid_stag_ctx *const *ctxs, int32_t nctx
             n_per_frame[f] = n;
             if (rc == FID_OK && K && poses) rc = fid_stag_pose_last(ctxs[t], K, D, marker_size, poses + (size_t)f * cap_per_frame, cap_per_frame, &n);
             if (rc != FID_OK) {
-                rcs[t] = rc;
-                return;
+                if (rcs[t] == FID_OK) rcs[t] = rc;       // the first failure is the call's status ...
+                if (rc != FID_E_CAPACITY) return;        // ... a frame that did not fit costs only that frame
             }
         }
     };

@@ -23,13 +23,26 @@ PREDEFINED = {
     "DICT_4X4_50": (0, 4, 50, 1),
     "DICT_4X4_100": (1, 4, 100, 1),
     "DICT_4X4_250": (2, 4, 250, 1),
+    "DICT_4X4_1000": (3, 4, 1000, 0),
     "DICT_5X5_50": (4, 5, 50, 3),
     "DICT_5X5_100": (5, 5, 100, 3),
     "DICT_5X5_250": (6, 5, 250, 2),
     "DICT_5X5_1000": (7, 5, 1000, 2),
+    "DICT_6X6_50": (8, 6, 50, 6),
+    "DICT_6X6_100": (9, 6, 100, 5),
+    "DICT_6X6_250": (10, 6, 250, 5),
+    "DICT_6X6_1000": (11, 6, 1000, 4),
+    "DICT_7X7_50": (12, 7, 50, 9),
+    "DICT_7X7_100": (13, 7, 100, 8),
+    "DICT_7X7_250": (14, 7, 250, 8),
+    "DICT_7X7_1000": (15, 7, 1000, 6),
+    "DICT_ARUCO_ORIGINAL": (16, 5, 1024, 0),
 }
 _BY_ENUM = {v[0]: k for k, v in PREDEFINED.items()}
-_FILES = {4: "dict_4x4_250.txt", 5: "dict_5x5_1000.txt"}
+# OpenCV's N x N tables of 50 / 100 / 250 / 1000 markers are prefixes of one table per size.  The 6 x 6, 7 x 7 and
+# ARUCO_ORIGINAL files (and ids >= 250 of 4 x 4) hold labelled fillers only (tools/make_dictionaries.py extra): they exist so
+# that every enum value the node accepts (`~dictionary` 0..16) runs, and so that the 5- and 7-byte identify paths are tested.
+_FILES = {4: "dict_4x4_1000.txt", 5: "dict_5x5_1000.txt", 6: "dict_6x6_1000.txt", 7: "dict_7x7_1000.txt"}
 
 
 @dataclass
@@ -77,8 +90,8 @@ def byte_list_from_bits(bits: np.ndarray) -> np.ndarray:
     return out
 
 
-def _load_table(n: int):
-    path = os.path.join(_DATA, _FILES[n])
+def _load_table(n: int, name: str = ""):
+    path = os.path.join(_DATA, "dict_aruco_original.txt" if name == "DICT_ARUCO_ORIGINAL" else _FILES[n])
     words, flags = [], []
     with open(path) as f:
         for line in f:
@@ -102,7 +115,7 @@ def get_predefined_dictionary(which) -> Dictionary:
     if name not in PREDEFINED:
         raise ValueError(f"dictionary {which!r} not available in this build")
     _, n, count, maxc = PREDEFINED[name]
-    words, flags = _load_table(n)
+    words, flags = _load_table(n, name)
     bl = np.zeros((count, 4, (n * n + 7) // 8), dtype=np.uint8)
     for i in range(count):
         bits = np.array([(words[i] >> (n * n - 1 - k)) & 1 for k in range(n * n)], dtype=np.uint8).reshape(n, n)

@@ -221,9 +221,12 @@ void FiducialsNode::handleLenOverrideString(const std::string &str)
 void FiducialsNode::configCallback(const fid_params &config, uint32_t level)
 {
     if (level == 0xFFFFFFFF) return;  // don't load the initial config (:260-262)
-    detectorParams = config;
-    const fid_status rc = fid_set_params(ctx, &detectorParams);
-    if (rc != FID_OK) last_error = fid_last_error(ctx);
+    // the node's view of the parameters follows the context: a rejected reconfigure leaves both as they were
+    const fid_status rc = fid_set_params(ctx, &config);
+    if (rc == FID_OK)
+        detectorParams = config;
+    else
+        last_error = fid_last_error(ctx);
 }
 
 void FiducialsNode::ignoreCallback(const std::string &msg)

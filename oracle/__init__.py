@@ -69,10 +69,32 @@ def build(force: bool = False) -> str:
     return so
 
 
+def build_native(out_dir: str) -> str:
+    """The same two C files built for the machine they run on (-O3 -march=native; -ffp-contract=off keeps the IEEE operation
+    sequence, so results do not change).  For bench.py's cpu_baseline leg on the GPU box's host (SURVEY.md 8d asks for
+    -march=native there); the shipped liboracle.so stays generic because it travels between machines."""
+    so = os.path.join(out_dir, "liboracle_native.so")
+    srcs = [os.path.join(_HERE, f) for f in ("aruco_detect_oracle.c", "pnp_oracle.c")]
+    if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call([os.environ.get("CC", "gcc"), "-O3", "-march=native", "-fPIC", "-std=c11", "-ffp-contract=off",
+                               "-fno-fast-math", "-shared", "-o", so] + srcs + ["-lm"])
+    return so
+
+
+def use_library(path: str | None):
+    """Point this wrapper at another build of the same sources (build_native); None = the shipped liboracle.so."""
+    global _LIB, _SO_OVERRIDE
+    _SO_OVERRIDE = path
+    _LIB = None
+
+
+_SO_OVERRIDE = None
+
+
 def lib():
     global _LIB
     if _LIB is None:
-        so = os.path.join(_HERE, "liboracle.so")
+        so = _SO_OVERRIDE or os.path.join(_HERE, "liboracle.so")
         if not os.path.exists(so):
             build()
         _LIB = C.CDLL(so)

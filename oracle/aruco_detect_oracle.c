@@ -94,13 +94,14 @@ int ora_to_gray(const uint8_t *img, int w, int h, int stride, int enc, uint8_t *
  *          scale otherwise); for odd win both equal exact rounding because sum/win^2 can never sit
  *          on a half (tests/test_oracle_units.py::test_box_mean_rounding checks the fixed-point
  *          formula exhaustively).
- *   idelta = cvCeil(C) for BINARY_INV;  dst = (src - mean <= -idelta) ? 255 : 0               */
+ *   idelta = type == THRESH_BINARY ? cvCeil(C) : cvFloor(C) (thresh.cpp adaptiveThreshold): aruco passes
+ *   THRESH_BINARY_INV, so FLOOR;  dst = (src - mean <= -idelta) ? 255 : 0 (tab[i] = i - 255 <= -idelta)   */
 int ora_adaptive_threshold(const uint8_t *gray, int w, int h, int win, double C, uint8_t *out)
 {
     if (!gray || !out || w <= 0 || h <= 0 || win < 3) return -1;
     if (win % 2 == 0) win++; /* aruco.cpp _threshold */
     const int r = win / 2, area = win * win;
-    const int idelta = cv_ceil(C);
+    const int idelta = cv_floor(C);
     /* integral image with replicated border, (h+1) x (w+1) of int64 would be wasteful: use
      * running column sums (exactly what boxFilter's RowSum/ColumnSum compute). */
     int32_t *rowsum = (int32_t *)malloc((size_t)w * h * sizeof(int32_t));

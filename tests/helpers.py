@@ -17,3 +17,34 @@ def load_gray(key):
 
 def n_scales(p):
     return (p.adaptiveThreshWinSizeMax - p.adaptiveThreshWinSizeMin) // p.adaptiveThreshWinSizeStep + 1
+
+
+def nested_same_id_frame(d, marker_id=3, width=1280, height=720, big_cell=84, small_cell=6, seed=9):
+    """A frame on which `_filterDetectedMarkers` (aruco.cpp; called inside aruco::detectMarkers, aruco_detect.cpp:350) has
+    something to remove: a large rendering of marker `marker_id` with small renderings of the SAME id pasted into the middle of
+    white cells, so the same id is identified several times with one quad inside another."""
+    from fiducials_amd.dictionary import draw_marker
+
+    rng = np.random.default_rng(seed)
+    n = d.marker_size + 2
+    img = np.full((height, width), 190, np.uint8)
+    side = big_cell * n
+    big = draw_marker(d, marker_id, side)
+    x0, y0 = (width - side) // 2, (height - side) // 2
+    q = big_cell  # white quiet zone
+    img[y0 - q:y0 + side + q, x0 - q:x0 + side + q] = 255
+    img[y0:y0 + side, x0:x0 + side] = big
+    bits = d.bits(marker_id)
+    ss = small_cell * n
+    small = draw_marker(d, marker_id, ss)
+    placed = 0
+    for r in range(d.marker_size):
+        for c in range(d.marker_size):
+            if bits[r, c] and placed < 2:
+                cx = x0 + (c + 1) * big_cell + (big_cell - ss) // 2
+                cy = y0 + (r + 1) * big_cell + (big_cell - ss) // 2
+                img[cy:cy + ss, cx:cx + ss] = small
+                placed += 1
+    assert placed >= 1
+    img = np.clip(img.astype(np.int32) + rng.integers(-2, 3, img.shape), 0, 255).astype(np.uint8)
+    return img

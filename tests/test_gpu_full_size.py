@@ -37,3 +37,38 @@ def test_cfg3_batch_256_properties():
     res2 = det.detect_markers_device(dev.data_ptr(), B, 1920, 1080)
     assert all(np.array_equal(a[0], b[0]) and a[1].tolist() == b[1].tolist() for a, b in zip(res, res2))
     det.close()
+
+
+def _oracle_one(args):
+    img, K = args
+    d = get_predefined_dictionary(6)
+    ids, corners = oracle.detect(img, d)
+    poses = [oracle.solve_pnp_square(K, np.zeros(5), c, 0.14) for c in corners]
+    return ids, corners, poses
+
+
+def test_cfg3_the_benchmarked_batch_equals_the_oracle_frame_by_frame():
+    """The batch bench.py times (seeds 1000..1255, bench.make_frames) IS the batch compared here: all 256 frames, ids and
+    corners `==` the oracle's, rvec / tvec within 1e-6, 20 markers each (the oracle runs in a process pool on the host)."""
+    import multiprocessing as mp
+    import os
+
+    torch = pytest.importorskip("torch")
+    import bench
+
+    B = 256
+    frames = bench.make_frames(bench.shard_seeds(0, 1, B))
+    assert frames.shape == (B, 1080, 1920)
+    dev = torch.from_numpy(frames).cuda()
+    det = ArucoDetector(6, max_width=1920, max_height=1080, max_batch=B, max_markers=64)
+    res = det.detect_markers_device(dev.data_ptr(), B, 1920, 1080)
+    poses = det.pose_last(0.14, K_DEFAULT, np.zeros(5))
+    det.close()
+    with mp.get_context("fork").Pool(max(1, min(B, os.cpu_count() or 1, 128))) as pool:
+        ora = pool.map(_oracle_one, [(frames[f], K_DEFAULT) for f in range(B)], chunksize=1)
+    for f in range(B):
+        oids, ocorners, oposes = ora[f]
+        assert res[f][1].tolist() == oids.tolist() and len(oids) == 20, f
+        assert np.array_equal(res[f][0], ocorners), f
+        for i, (r, t, e) in enumerate(oposes):
+            assert np.abs(poses[f].rvecs[i] - r).max() < 1e-6 and np.abs(poses[f].tvecs[i] - t).max() < 1e-6, (f, i)

@@ -34,12 +34,21 @@ def det6():
     d.close()
 
 
-def check_stages(det, gray, d):
-    """Every stage tap against the oracle's trace of the same frame."""
+def params_pair(**kw):
+    """The same aruco::DetectorParameters on both sides: (library fid_params, oracle parameters)."""
+    p, op = default_params(), oracle.default_params()
+    for name, v in kw.items():
+        setattr(p, name, v)
+        setattr(op, name, v)
+    return p, op
+
+
+def check_stages(det, gray, d, op=None):
+    """Every stage tap against the oracle's trace of the same frame (op: the oracle-side copy of the detector's parameters)."""
     h, w = gray.shape
     corners, ids = det.detect_markers(gray)
-    oids, ocorners, tr = oracle.detect(gray, d, trace=True)
-    p = oracle.default_params()
+    p = op or oracle.default_params()
+    oids, ocorners, tr = oracle.detect(gray, d, params=p, trace=True)
     masks = det.tap_masks(1, n_scales(p), h, w)[0]
     for s in range(n_scales(p)):
         win = p.adaptiveThreshWinSizeMin + s * p.adaptiveThreshWinSizeStep
@@ -376,5 +385,81 @@ def _odd_sizes(max_contours):
             salt = rng.random((h, w)) < 0.02
             img[salt] = rng.integers(0, 256, int(salt.sum()))
             check_stages(det, img, d)
+    finally:
+        det.close()
+
+
+def test_filter_detected_markers_removes_nested_same_id(det6):
+    """a8 `_filterDetectedMarkers`: the same id identified three times, two of the quads inside the third.  The oracle side
+    asserts that something IS removed on this input (identified > kept), so the case cannot rot into a no-op."""
+    from helpers import nested_same_id_frame
+    d = det6.dictionary
+    for mid in (3, 1, 5):
+        img = nested_same_id_frame(d, mid)
+        _, _, tr = oracle.detect(img, d, trace=True)
+        identified = int((tr["ident"][:, 0] >= 0).sum())
+        assert identified == 3 and len(tr["pre_ids"]) == 1 and tr["pre_ids"].tolist() == [mid]
+        corners, ids, _ = check_stages(det6, img, d)  # IDENT tap == oracle (3 hits), PRESUBPIX tap == oracle (1 kept)
+        cnt = det6.tap_counts()[0]
+        assert cnt[4] == identified and cnt[5] == 1 and ids.tolist() == [mid]
+
+
+def test_set_params_more_scales_than_at_creation():
+    """dynamic_reconfigure raising adaptiveThreshWinSizeMax on a live context (aruco_detect.cpp:257-298, :690-693): 13 -> 16
+    threshold scales fit the buffers' margin and must run like a fresh context (masks, seeds and all stages == oracle);
+    32 scales do not fit and are refused at reconfigure time, leaving the context on its old parameters."""
+    from fiducials_amd._lib import FidError
+    d = get_predefined_dictionary(6)
+    det = ArucoDetector(d, max_width=1920, max_height=1080)
+    fr = make_frame(d, 1000)
+    try:
+        p, op = params_pair(adaptiveThreshWinSizeMax=63)
+        assert n_scales(p) == 16
+        det.set_params(p)
+        check_stages(det, fr.image, d, op)
+        p2, _ = params_pair(adaptiveThreshWinSizeMin=3, adaptiveThreshWinSizeMax=65, adaptiveThreshWinSizeStep=2)
+        with pytest.raises(FidError) as e:
+            det.set_params(p2)
+        assert e.value.status == _lib.FID_E_UNSUPPORTED
+        check_stages(det, fr.image, d, op)  # still the 16-scale parameters
+        p3, _ = params_pair(maxMarkerPerimeterRate=8.0)  # chunk table sized for 4.0 at creation: refused now, not per frame
+        with pytest.raises(FidError) as e:
+            det.set_params(p3)
+        assert e.value.status == _lib.FID_E_UNSUPPORTED
+        check_stages(det, fr.image, d, op)
+    finally:
+        det.close()
+
+
+def test_non_integer_threshold_constant():
+    """adaptiveThreshold: idelta = cvFloor(C) for THRESH_BINARY_INV (what aruco passes).  C = 7.5 must threshold like 7."""
+    d = get_predefined_dictionary(6)
+    fr = make_frame(d, 1003, width=1280, height=720, n_markers=10, side_range=(70, 130))
+    for cst in (7.5, 6.999, 0.5):
+        p, op = params_pair(adaptiveThreshConstant=cst)
+        det = ArucoDetector(d, params=p, max_width=1280, max_height=720)
+        try:
+            check_stages(det, fr.image, d, op)
+            m75 = det.tap_masks(1, n_scales(p), 720, 1280)[0]
+            p7, _ = params_pair(adaptiveThreshConstant=float(int(cst)))
+            det.set_params(p7)
+            det.detect_markers(fr.image)
+            assert np.array_equal(m75, det.tap_masks(1, n_scales(p), 720, 1280)[0])
+        finally:
+            det.close()
+
+
+@pytest.mark.parametrize("dic,minlen", [(4, 8), (5, 8), (3, 8), (8, 8), (10, 8), (11, 8), (12, 8), (14, 8), (15, 8), (16, 6)])
+def test_every_dictionary_family_all_stages(dic, minlen):
+    """a14: every marker size / maxCorrectionBits the node's `~dictionary` enum can select (aruco_detect.cpp:611,671):
+    5X5_50 / 5X5_100 (maxCorrectionBits 3), 4X4_1000 (0), 6X6 (5-byte codewords), 7X7 (7-byte codewords, 9 x 9 cells),
+    ARUCO_ORIGINAL.  The 6 x 6 / 7 x 7 / ARUCO_ORIGINAL tables are labelled fillers (parity unpinned against OpenCV's table
+    CONTENTS; the identify arithmetic is table-agnostic): every stage tap == oracle on the same table."""
+    d = get_predefined_dictionary(dic)
+    fr = make_frame(d, 500 + dic, width=1280, height=720, n_markers=10, side_range=(80, 130))
+    det = ArucoDetector(d, max_width=1280, max_height=720)
+    try:
+        corners, ids, _ = check_stages(det, fr.image, d)
+        assert len(ids) >= minlen and set(ids.tolist()) <= set(fr.ids.tolist())
     finally:
         det.close()

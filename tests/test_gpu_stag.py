@@ -319,7 +319,8 @@ def _markers_as_table(M):
 
 
 @pytest.mark.parametrize("hd,ec,size,n,seed", [(21, 7, (1920, 1080), 20, 7), (21, 7, (640, 480), 6, 8), (11, 2, (1920, 1080), 20, 9),
-                                                (15, 7, (1280, 720), 12, 10), (23, 11, (800, 600), 6, 11), (19, 9, (1920, 1080), 20, 12)])
+                                                (15, 7, (1280, 720), 12, 10), (23, 11, (800, 600), 6, 11), (19, 9, (1920, 1080), 20, 12),
+                                                (13, 6, (1280, 720), 12, 13), (17, 8, (1280, 720), 12, 14)])
 def test_markers_unrefined_match_reference_code(hd, ec, size, n, seed):
     """Row s8 (+ s1's loop): homography, code reading, decoding, corner shift, duplicate removal on rendered STag markers,
     against the reference's own Stag.cpp / Decoder.cpp / Marker.cpp compiled in place (pose refinement switched off on both
@@ -346,7 +347,8 @@ def test_markers_unrefined_match_reference_code(hd, ec, size, n, seed):
 
 
 @pytest.mark.parametrize("hd,ec,size,n,seed", [(21, 7, (1920, 1080), 20, 7), (21, 7, (640, 480), 6, 8), (11, 2, (1920, 1080), 20, 9),
-                                                (15, 7, (1280, 720), 12, 10)])
+                                                (15, 7, (1280, 720), 12, 10), (13, 6, (1280, 720), 12, 13), (17, 8, (1280, 720), 12, 14),
+                                                (19, 9, (1280, 720), 12, 15), (23, 11, (800, 600), 6, 11)])
 def test_detect_markers_refined_matches_reference(hd, ec, size, n, seed):
     """Rows s1 + s9 = Stag::detectMarkers complete.  The refinement runs a Nelder-Mead search whose cost calls atan / sin /
     cos: the device's math library and glibc agree to rounding only, so this row is held to a tolerance: ids exact, corners

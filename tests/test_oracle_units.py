@@ -88,3 +88,18 @@ def test_pnp_recovers_synthetic_pose():
                                     tv.ctypes.data_as(C.c_void_p), obj.ctypes.data_as(C.c_void_p), 4, img.ctypes.data_as(C.c_void_p))
     r, t, e = oracle.solve_pnp_square(K, D, img.astype(np.float32), L)
     assert np.abs(r - rv).max() < 1e-3 and np.abs(t - tv).max() < 1e-3 and e < 1e-6
+
+
+def test_adaptive_threshold_constant_is_floored_for_binary_inv():
+    """thresh.cpp adaptiveThreshold: idelta = type == THRESH_BINARY ? cvCeil(delta) : cvFloor(delta); aruco's _threshold
+    passes THRESH_BINARY_INV, whose table is tab[i] = (i - 255 <= -idelta).  A pixel 7 below its box mean is foreground for
+    C = 7 and for C = 7.5 (floor -> 7), background for C = 8."""
+    img = np.full((20, 20), 100, np.uint8)
+    img[10, 10] = 92  # 3 x 3 mean = round(892 / 9) = 99, src - mean = -7
+    for c, want in ((7.0, 255), (7.5, 255), (7.999, 255), (8.0, 0), (6.5, 255), (-0.5, 255)):
+        out = oracle.adaptive_threshold(img, 3, c)
+        assert out[10, 10] == want, (c, out[10, 10])
+    # negative constants floor away from zero: C = -0.5 -> idelta = -1: src - mean <= 1 is foreground everywhere on a flat image
+    assert oracle.adaptive_threshold(np.full((8, 8), 50, np.uint8), 3, -0.5).min() == 255
+    assert oracle.adaptive_threshold(np.full((8, 8), 50, np.uint8), 3, 0.5).min() == 255   # idelta 0: 0 <= 0
+    assert oracle.adaptive_threshold(np.full((8, 8), 50, np.uint8), 3, 1.0).max() == 0

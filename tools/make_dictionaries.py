@@ -230,5 +230,52 @@ def main():
     write("dict_4x4_250.txt", 4, w4, f4, tau)
 
 
+def load_existing(name, n):
+    words = {}
+    with open(os.path.join(OUT, name)) as f:
+        for line in f:
+            if line.startswith("#") or not line.strip():
+                continue
+            i, fl, hx = line.split()
+            words[int(i)] = (int(hx, 16), fl)
+    return words
+
+
+def aruco_original():
+    """DICT_ARUCO_ORIGINAL restated from the published construction of the original ArUco library (Garrido-Jurado et al.
+    2014, section 2 "previous dictionary"): 5 x 5 bits, every row is one of four 5-bit words that carry 2 bits of the id
+    (00 -> 10000, 01 -> 10111, 10 -> 01001, 11 -> 01110), rows top to bottom = id bits 9..0; 1024 markers, no error
+    correction.  No fixture of the reference uses this dictionary: labelled F (parity unpinned)."""
+    rows = [0b10000, 0b10111, 0b01001, 0b01110]
+    words = []
+    for i in range(1024):
+        w = 0
+        for r in range(5):
+            w = (w << 5) | rows[(i >> (2 * (4 - r))) & 3]
+        words.append(w)
+    return words, ["F"] * 1024
+
+
+def main_extra():
+    """Tables for the remaining enum values the node accepts (`~dictionary` 0..16, aruco_detect.cpp:611,671): labelled
+    fillers that let the 5- and 7-byte identify paths and the other maxCorrectionBits values be exercised at all.  The
+    existing files are not rewritten (their ids are referenced by tests and fixtures)."""
+    ex = load_existing("dict_4x4_250.txt", 4)
+    pinned = {i: w for i, (w, fl) in ex.items()}
+    w4, f4 = generate(4, 1000, pinned, 2, seed=4404)
+    for i, (w, fl) in ex.items():
+        f4[i] = fl
+    write("dict_4x4_1000.txt", 4, w4, f4, 2)
+    w6, f6 = generate(6, 1000, {}, 9, seed=66)
+    write("dict_6x6_1000.txt", 6, w6, f6, 9)
+    w7, f7 = generate(7, 1000, {}, 13, seed=77)
+    write("dict_7x7_1000.txt", 7, w7, f7, 13)
+    wa, fa = aruco_original()
+    write("dict_aruco_original.txt", 5, wa, fa, 0)
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "extra":
+        main_extra()
+    else:
+        main()

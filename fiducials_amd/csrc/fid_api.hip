@@ -52,6 +52,8 @@ struct fid_ctx {
     uint2 *d_seedq = nullptr, *d_seedplane = nullptr;
     uint4 *d_wres = nullptr, *d_cinfo = nullptr;
     uint32_t *d_cbase = nullptr, *d_dense = nullptr;
+    int thr_mode = 1;    // node window table: 1 = k_threshold_stream (default), 0 (FID_THR=tile) = k_threshold_fixed
+    int thr_nw = 3, thr_split = 0, thr_rows = 0;  // stream kernel: consumer waves per workgroup, un-fused LDS reads, rows per workgroup (0 = automatic)
     int trace_mode = 1;  // 1: seed-accelerated tracing; 0 (FID_TRACE=legacy): probe passes + whole-border walk only
     long long fallbacks = 0;  // calls that fell back to the whole-border walk because the seed table was too small
     int max_chunks = 0;
@@ -109,6 +111,13 @@ fid_status dalloc(fid_ctx *c, T **p, size_t count)
 }
 
 int roundup(int v, int m) { return (v + m - 1) / m * m; }
+
+template <int NW, bool SPLIT>
+void launch_thr_stream(dim3 grid, hipStream_t st, const uint8_t *g, long long gfstride, uint32_t *masks, const DevParams &P, int RS)
+{
+    using S = ThrStream<3, 4, 13, NW>;
+    k_threshold_stream<3, 4, 13, NW, SPLIT><<<grid, dim3(S::NT), S::LDS_BYTES, st>>>(g, gfstride, masks, P, RS);
+}
 
 fid_status apply_params(fid_ctx *c, const fid_params *p)
 {
@@ -284,7 +293,24 @@ fid_status run_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H, int
         {
             bool node_table = P.nscales == 13;  // 3, 7, ..., 51: the node defaults (aruco_detect.cpp:690-693)
             for (int i = 0; i < P.nscales && node_table; i++) node_table = P.win[i] == 3 + 4 * i;
-            if (node_table) {
+            if (node_table && c->thr_mode == 1) {
+                // strips of 64 * NW columns, cut into row segments so that the grid fills the chip (a segment pays a warm-up
+                // of about ten steps, so they are kept as tall as the batch allows)
+                const int cols = 64 * c->thr_nw, strips = (W + cols - 1) / cols;
+                int RS = c->thr_rows;
+                if (RS <= 0) {
+                    int segs = (1536 + strips * Fs - 1) / (strips * Fs);
+                    const int maxsegs = (H + 63) / 64;
+                    segs = segs < 1 ? 1 : (segs > maxsegs ? maxsegs : segs);
+                    RS = (H + segs - 1) / segs;
+                }
+                RS = (RS + 3) & ~3;
+                dim3 grid(strips, (H + RS - 1) / RS, Fs);
+                if (c->thr_nw == 5 && c->thr_split) launch_thr_stream<5, true>(grid, st, g, gfstride, masks, P, RS);
+                else if (c->thr_nw == 5) launch_thr_stream<5, false>(grid, st, g, gfstride, masks, P, RS);
+                else if (c->thr_split) launch_thr_stream<3, true>(grid, st, g, gfstride, masks, P, RS);
+                else launch_thr_stream<3, false>(grid, st, g, gfstride, masks, P, RS);
+            } else if (node_table) {
                 using C = ThrCfg<3, 4, 13>;
                 dim3 grid((W + C::TX - 1) / C::TX, (H + C::TY - 1) / C::TY, Fs);
                 hipLaunchKernelGGL((k_threshold_fixed<3, 4, 13>), grid, dim3(C::NT), C::LDS_BYTES, st, g, gfstride, masks, P);
@@ -549,6 +575,10 @@ fid_status fid_create(const fid_params *params, const fid_dict *dict, const fid_
     c->dict_host.assign(dict->bytes, dict->bytes + dbytes);
     c->profile = getenv("FID_PROFILE") && atoi(getenv("FID_PROFILE")) != 0;
     if (getenv("FID_SUB_FRAMES")) c->sub_frames = atoi(getenv("FID_SUB_FRAMES"));
+    if (getenv("FID_THR")) c->thr_mode = strcmp(getenv("FID_THR"), "tile") ? 1 : 0;
+    if (getenv("FID_THR_NW")) c->thr_nw = atoi(getenv("FID_THR_NW")) == 3 ? 3 : 5;
+    if (getenv("FID_THR_SPLIT")) c->thr_split = atoi(getenv("FID_THR_SPLIT")) != 0;
+    if (getenv("FID_THR_ROWS")) c->thr_rows = atoi(getenv("FID_THR_ROWS"));
     if (getenv("FID_WALK_BLOCKS")) c->walk_blocks = atoi(getenv("FID_WALK_BLOCKS")) > 0 ? atoi(getenv("FID_WALK_BLOCKS")) : c->walk_blocks;
     memset(&c->P, 0, sizeof(c->P));
 

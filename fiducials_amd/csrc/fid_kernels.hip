@@ -395,6 +395,289 @@ __global__ __launch_bounds__(1024) void k_threshold_fixed(const uint8_t *__restr
 }
 
 // ------------------------------------------------------------------------------------------------
+// K1 (stream path, the default for the node's window table): the same arithmetic with a small LDS footprint and a
+// quarter of the LDS reads, so that it shares a CU with the latency-bound contour kernels of the other sub-batch.
+//
+//   workgroup      NW consumer waves + 1 producer wave walk down a strip of 64 * NW columns, 4 rows (a QUAD) per step
+//   LDS ring       16 quads x RAWW columns x 8 bytes: for every raw column the INCLUSIVE ROW PREFIX of its 4 rows as
+//                  4 x u16 (mod 2^16: only differences over <= 51 columns are ever taken, and those fit 14 bits).
+//                  ring row = image row + 28, so ring quads are image-row quads; 47.6 KB for NW = 5 (3 workgroups per CU)
+//   producer wave  per step one quad: byte loads (clamped = BORDER_REPLICATE), two rows per register (lo / hi 16 bits),
+//                  one DPP wave scan per row pair and 64-column chunk (a chunk's fields cannot overflow: 64 * 255),
+//                  chunk carry added with v_pk_add_u16, one ds_write_b64 per column; loads run one step ahead
+//   consumer lane  = one column.  Per scale it keeps the running box sum V = sum over rows y-r..y+r of the horizontal
+//                  window sum H(row) = RI[x + r] - RI[x - r - 1]:  V(y) = V(y - 1) + H(y + r) - H(y - r - 1).
+//                  Per step and scale: 4 ds_read_b64 (left / right prefix of the quad that enters and of the quad that
+//                  leaves), packed 16-bit subtractions for four rows at a time, v_alignbit to line the two quads up with
+//                  the output quad (r is odd: exactly one of the two is off by an odd number of rows; the other is
+//                  aligned or off by two rows = register renaming), four v_dot2c accumulations, four v_cmp whose SGPR
+//                  result IS the mask word pair of 64 columns.  V is kept minus the per-scale constant of the test, so
+//                  the test is V >= gray * win^2 (one v_mul_i32_i24 with a literal).
+//   output         the word pairs are parked in lane (row & 63) of 26 registers (v_writelane) and stored every 64 rows,
+//                  a row per lane, into the tiled mask layout
+// One s_barrier per step orders ring slot reuse: in step k the producer fills quad k + 8 (slot (k + 8) & 15) while the
+// consumers read quads k - 7 .. k + 7.
+template <int WMIN, int WSTEP, int NS, int NW>
+struct ThrStream {
+    static constexpr int R = (WMIN + (NS - 1) * WSTEP) / 2;
+    static constexpr int COLS = 64 * NW;
+    static constexpr int PADL = R + 1;             // raw columns left of the strip (RI[x - r - 1] with r = R)
+    static constexpr int RAWW = COLS + 2 * R + 1;  // raw columns: x - R - 1 .. x + R
+    static constexpr int NCHUNK = (RAWW + 63) / 64;
+    static constexpr int DEPTH = 16;               // ring depth in quads
+    static constexpr int ROWPAD = 28;              // ring row = image row + ROWPAD
+    static constexpr int LEAD = 7;                 // a step touches quads qo - LEAD .. qo + LEAD
+    static constexpr int NT = 64 * (NW + 1);
+    static constexpr size_t LDS_BYTES = (size_t)DEPTH * RAWW * 8;
+    static_assert((WMIN & 1) == 1 && (WSTEP % 2) == 0, "odd windows");
+    static_assert(R + 1 <= ROWPAD - 2 && (R + 3) / 4 <= LEAD && R <= 25, "ring geometry is for radii <= 25");
+};
+
+typedef unsigned short thr_u16x2 __attribute__((ext_vector_type(2)));
+typedef short thr_s16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_sub16(uint32_t a, uint32_t b)
+{
+    return __builtin_bit_cast(uint32_t, (thr_u16x2)(__builtin_bit_cast(thr_u16x2, a) - __builtin_bit_cast(thr_u16x2, b)));
+}
+__device__ __forceinline__ uint32_t pk_add16(uint32_t a, uint32_t b)
+{
+    return __builtin_bit_cast(uint32_t, (thr_u16x2)(__builtin_bit_cast(thr_u16x2, a) + __builtin_bit_cast(thr_u16x2, b)));
+}
+// inclusive scan over the 64 lanes, DPP only (no LDS crossbar)
+__device__ __forceinline__ uint32_t wave_iscan_dpp(uint32_t v)
+{
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x111, 0xf, 0xf, false);  // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x112, 0xf, 0xf, false);  // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x114, 0xf, 0xf, false);  // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x118, 0xf, 0xf, false);  // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2, 3
+    return v;
+}
+// park a wave-uniform word pair in lane `sel` (wave-uniform, run-time) of two registers
+__device__ __forceinline__ void park_pair(uint32_t &a0, uint32_t &a1, unsigned long long b, int sel)
+{
+    const uint32_t lo = (uint32_t)b, hi = (uint32_t)(b >> 32);
+    // (M0 written by the SALU and read as a lane select by the next VALU instruction: no wait state is required for that pair)
+    // not volatile: the statement is a pure function of its operands, so the scheduler may move LDS reads across it
+    asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %3, m0\n\tv_writelane_b32 %1, %4, m0"
+                 : "+v"(a0), "+v"(a1)
+                 : "s"(sel), "s"(lo), "s"(hi));
+}
+
+template <int WMIN, int WSTEP, int NS, int NW, bool SPLIT>
+__global__ __launch_bounds__(64 * (NW + 1)) void k_threshold_stream(const uint8_t *__restrict__ gray, long long gfstride,
+                                                                      uint32_t *__restrict__ masks, const DevParams P, int RS)
+{
+    using C = ThrStream<WMIN, WSTEP, NS, NW>;
+    constexpr int R = C::R, PADL = C::PADL, RAWW = C::RAWW, NCHUNK = C::NCHUNK, ROWPAD = C::ROWPAD, LEAD = C::LEAD;
+    extern __shared__ __attribute__((aligned(16))) uint2 thr_ring[];  // [DEPTH][RAWW]
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int xs = blockIdx.x * C::COLS, ys = blockIdx.y * RS, f = blockIdx.z;
+    const int W = P.W, H = P.H, gs = P.gstride;
+    const uint8_t *g = gray + (long long)f * gfstride;
+    const int yend = ys + RS < H ? ys + RS : H;
+    const int nsteps = (yend - ys + 3) >> 2;
+    const int Q0 = (ys >> 2) + ROWPAD / 4;  // ring quad of the first output quad (ys is a multiple of 4)
+
+    // ---- producer side: one quad of raw rows -> packed row prefixes in the ring
+    struct RawQuad {
+        uint32_t v01[NCHUNK], v23[NCHUNK];
+    };
+    auto load_quad = [&](int Q, RawQuad &q) {
+        const int yb = 4 * Q - ROWPAD;
+        const uint8_t *rp[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            int y = yb + i;
+            y = y < 0 ? 0 : (y >= H ? H - 1 : y);
+            rp[i] = g + (long long)y * gs;
+        }
+#pragma unroll
+        for (int c = 0; c < NCHUNK; c++) {
+            int x = xs - PADL + 64 * c + lane;
+            x = x < 0 ? 0 : (x >= W ? W - 1 : x);
+            q.v01[c] = (uint32_t)rp[0][x] | ((uint32_t)rp[1][x] << 16);
+            q.v23[c] = (uint32_t)rp[2][x] | ((uint32_t)rp[3][x] << 16);
+        }
+    };
+    auto store_quad = [&](int Q, const RawQuad &q) {
+        uint2 *dst = thr_ring + (Q & (C::DEPTH - 1)) * RAWW;
+        uint32_t c01 = 0, c23 = 0;
+#pragma unroll
+        for (int c = 0; c < NCHUNK; c++) {
+            const uint32_t s01 = wave_iscan_dpp(q.v01[c]), s23 = wave_iscan_dpp(q.v23[c]);
+            const int j = 64 * c + lane;
+            if (j < RAWW) dst[j] = make_uint2(pk_add16(s01, c01), pk_add16(s23, c23));
+            c01 = pk_add16(c01, (uint32_t)__builtin_amdgcn_readlane((int)s01, 63));
+            c23 = pk_add16(c23, (uint32_t)__builtin_amdgcn_readlane((int)s23, 63));
+        }
+    };
+    // ---- prologue: every wave fills whole quads (a quad needs nothing from another quad)
+    for (int q = Q0 - LEAD + wid; q <= Q0 + LEAD; q += NW + 1) {
+        RawQuad rq;
+        load_quad(q, rq);
+        store_quad(q, rq);
+    }
+    __syncthreads();
+
+    if (wid == NW) {
+        // ---- the producer wave: quad Q0 + k + 8 during step k, its loads one step ahead
+        const int last = Q0 + nsteps - 1 + LEAD;  // last quad any step reads
+        RawQuad cur, nxt;
+        if (Q0 + LEAD + 1 <= last) load_quad(Q0 + LEAD + 1, cur);
+        for (int k = 0; k < nsteps; k++) {
+            const int Q = Q0 + k + LEAD + 1;
+            if (Q + 1 <= last) load_quad(Q + 1, nxt);
+            if (Q <= last) store_quad(Q, cur);
+            __syncthreads();
+            cur = nxt;
+        }
+        return;
+    }
+
+    // ---- consumer waves
+    const int colw = 64 * wid;                 // first column of this wave inside the strip
+    const bool wave_on = xs + colw < W;        // a wave whose columns lie right of the image only keeps the barriers company
+    const unsigned long long vmask = ballot64(xs + colw + lane < W);
+    const uint32_t jb = (uint32_t)(colw + lane);  // raw column of RI[x - R - 1]: j = jb + (PADL - r - 1) / jb + PADL + r
+    int zoff = 0;
+    if (SPLIT) asm volatile("" : "+s"(zoff));
+    auto slot_base = [&](int Q) { return thr_ring + (Q & (C::DEPTH - 1)) * RAWW + jb; };
+    auto hquad = [&](int Q, int r) {  // horizontal window sums (window 2r + 1) of the four rows of aligned quad Q
+        // the left prefix is addressed through a base the compiler cannot relate to the right one (opaque zero): two
+        // ds_read_b64 (2 LDS cycles each) instead of one fused ds_read2_b64 (8 cycles, MI355X_MICROARCH.md LDS table)
+        const uint2 *b = slot_base(Q);
+        const uint2 hi = b[PADL + r], lo = (b + zoff)[PADL - r - 1];
+        return make_uint2(pk_sub16(hi.x, lo.x), pk_sub16(hi.y, lo.y));
+    };
+    int V[NS];
+    uint32_t ca[NS], cb[NS], cc[NS];  // carried halves of the previous aligned quads (see the step)
+    uint32_t acc0[NS], acc1[NS];
+    if (wave_on) {
+        static_for<NS>([&](auto sc) {
+            constexpr int s = decltype(sc)::value;
+            constexpr int r = (WMIN + s * WSTEP) / 2, w2 = (2 * r + 1) * (2 * r + 1);
+            // box sum of row ys - 1: ring rows ys - 1 - r + ROWPAD .. ys - 1 + r + ROWPAD
+            const uint16_t *ring16 = reinterpret_cast<const uint16_t *>(thr_ring);
+            uint32_t sum = 0;
+            for (int rho = ys - 1 - r + ROWPAD; rho <= ys - 1 + r + ROWPAD; rho++) {
+                const int e = (((rho >> 2) & (C::DEPTH - 1)) * RAWW + (int)jb) * 4 + (rho & 3);
+                sum += (uint16_t)(ring16[e + (PADL + r) * 4] - ring16[e + (PADL - r - 1) * 4]);
+            }
+            // the test  box >= (gray + idelta) * w2 - (w2 - 1) / 2  is kept as  V >= gray * w2
+            V[s] = (int)sum - (P.idelta * w2 - (w2 - 1) / 2);
+            acc0[s] = acc1[s] = 0;
+            if constexpr ((r & 3) == 1) {
+                const uint2 e = hquad(Q0 + (r + 3) / 4 - 1, r);  // entering side, off by one row: previous quad, both halves
+                ca[s] = e.x;
+                cb[s] = e.y;
+                cc[s] = hquad(Q0 - (r - 1) / 4 - 1, r).y;        // leaving side, off by two rows: previous quad, upper half
+            } else {
+                ca[s] = hquad(Q0 + (r + 1) / 4 - 1, r).y;        // entering side, off by three rows: previous quad, upper half
+                cb[s] = cc[s] = 0;
+            }
+        });
+    }
+    const long long plane = (long long)P.TR * P.TC * MT_ROWS;
+    uint32_t *mframe = masks + (long long)f * NS * plane;
+    auto flush = [&](int yblk) {
+        const int yrow = yblk + lane;
+        if (yrow < yend) {
+            const int wc = (xs + colw) >> 5;
+            uint32_t *q = mframe + mask_word(P.TC, yrow + 1, MASK_PADW + wc);
+            const bool two = xs + colw + 32 < W;
+            const uint32_t m0w = (uint32_t)vmask, m1w = (uint32_t)(vmask >> 32);  // columns right of the image stay zero
+#pragma unroll
+            for (int s = 0; s < NS; s++) {
+                q[(long long)s * plane] = acc0[s] & m0w;
+                if (two) q[(long long)s * plane + MT_ROWS] = acc1[s] & m1w;
+            }
+        }
+    };
+    for (int k = 0; k < nsteps; k++) {
+        if (wave_on) {
+            const int qo = Q0 + k;
+            const int sel = (4 * k) & 63;
+            // gray of the four output rows of this column, from the prefix itself
+            uint32_t g0, g1, g2, g3;
+            {
+                const uint2 *b = slot_base(qo);
+                const uint2 hi = b[PADL], lo = b[PADL - 1];
+                const uint32_t a = pk_sub16(hi.x, lo.x), c = pk_sub16(hi.y, lo.y);
+                g0 = a & 0xffffu;
+                g1 = a >> 16;
+                g2 = c & 0xffffu;
+                g3 = c >> 16;
+            }
+            // the four prefix quads of a scale are fetched one scale ahead of their use
+            struct Rd {
+                uint2 eh, el, lh, ll;  // raw right / left prefix quads of the entering and the leaving side
+            };
+            auto fetch = [&](auto sc) {
+                constexpr int s = decltype(sc)::value;
+                constexpr int r = (WMIN + s * WSTEP) / 2;
+                Rd q;
+                constexpr int de = (r & 3) == 1 ? (r + 3) / 4 : (r + 1) / 4, dl = (r & 3) == 1 ? (r - 1) / 4 : (r + 1) / 4;
+                const uint2 *be = slot_base(qo + de), *bl = slot_base(qo - dl);
+                q.eh = be[PADL + r];
+                q.el = (be + zoff)[PADL - r - 1];
+                q.lh = bl[PADL + r];
+                q.ll = (bl + zoff)[PADL - r - 1];
+                return q;
+            };
+            Rd cur = fetch(std::integral_constant<int, 0>{});
+            static_for<NS>([&](auto sc) {
+                constexpr int s = decltype(sc)::value;
+                constexpr int r = (WMIN + s * WSTEP) / 2, w2 = (2 * r + 1) * (2 * r + 1);
+                Rd nxt = cur;
+                if constexpr (s + 1 < NS) nxt = fetch(std::integral_constant<int, s + 1>{});
+                __builtin_amdgcn_sched_barrier(0);  // the reads stay up here: their latency runs under this scale's arithmetic
+                const uint2 e = make_uint2(pk_sub16(cur.eh.x, cur.el.x), pk_sub16(cur.eh.y, cur.el.y));
+                const uint2 l = make_uint2(pk_sub16(cur.lh.x, cur.ll.x), pk_sub16(cur.lh.y, cur.ll.y));
+                uint32_t elo, ehi, llo, lhi;
+                if constexpr ((r & 3) == 1) {
+                    elo = __builtin_amdgcn_alignbit(cb[s], ca[s], 16);  // rows 1, 2 of the previous quad
+                    ehi = __builtin_amdgcn_alignbit(e.x, cb[s], 16);    // row 3 of the previous, row 0 of the new one
+                    llo = cc[s];                                        // rows 2, 3 of the previous leaving quad
+                    lhi = l.x;                                          // rows 0, 1 of the new one
+                    ca[s] = e.x;
+                    cb[s] = e.y;
+                    cc[s] = l.y;
+                } else {
+                    elo = __builtin_amdgcn_alignbit(e.x, ca[s], 16);    // row 3 of the previous quad, row 0 of the new one
+                    ehi = __builtin_amdgcn_alignbit(e.y, e.x, 16);      // rows 1, 2 of the new one
+                    llo = l.x;
+                    lhi = l.y;
+                    ca[s] = e.y;
+                }
+                const thr_s16x2 dlo = __builtin_bit_cast(thr_s16x2, pk_sub16(elo, llo));
+                const thr_s16x2 dhi = __builtin_bit_cast(thr_s16x2, pk_sub16(ehi, lhi));
+                const thr_s16x2 first = {1, 0}, second = {0, 1};
+                int v = V[s];
+                v = __builtin_amdgcn_sdot2(dlo, first, v, false);
+                const unsigned long long b0 = ballot64(v >= __mul24((int)g0, w2));
+                v = __builtin_amdgcn_sdot2(dlo, second, v, false);
+                const unsigned long long b1 = ballot64(v >= __mul24((int)g1, w2));
+                v = __builtin_amdgcn_sdot2(dhi, first, v, false);
+                const unsigned long long b2 = ballot64(v >= __mul24((int)g2, w2));
+                v = __builtin_amdgcn_sdot2(dhi, second, v, false);
+                const unsigned long long b3 = ballot64(v >= __mul24((int)g3, w2));
+                V[s] = v;
+                park_pair(acc0[s], acc1[s], b0, sel);
+                park_pair(acc0[s], acc1[s], b1, sel + 1);
+                park_pair(acc0[s], acc1[s], b2, sel + 2);
+                park_pair(acc0[s], acc1[s], b3, sel + 3);
+                cur = nxt;
+            });
+            if (sel == 60 || k == nsteps - 1) flush(ys + ((4 * k) & ~63));
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // K2: start points of Suzuki-Abe border following, found without the sequential raster scan.
 //   outer border start: the first pixel of a horizontal foreground run whose W neighbour is background
 //     and none of whose pixels has a foreground N / NW / NE neighbour (a run that touches nothing above

@@ -435,7 +435,7 @@ def test_non_integer_threshold_constant():
     """adaptiveThreshold: idelta = cvFloor(C) for THRESH_BINARY_INV (what aruco passes).  C = 7.5 must threshold like 7."""
     d = get_predefined_dictionary(6)
     fr = make_frame(d, 1003, width=1280, height=720, n_markers=10, side_range=(70, 130))
-    for cst in (7.5, 6.999, 0.5):
+    for cst in (7.5, 6.999, 3.25):
         p, op = params_pair(adaptiveThreshConstant=cst)
         det = ArucoDetector(d, params=p, max_width=1280, max_height=720)
         try:

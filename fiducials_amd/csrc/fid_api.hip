@@ -52,12 +52,15 @@ struct fid_ctx {
     uint2 *d_seedq = nullptr, *d_seedplane = nullptr;
     uint4 *d_wres = nullptr, *d_cinfo = nullptr;
     uint32_t *d_cbase = nullptr, *d_dense = nullptr;
+    uint4 *d_recs = nullptr;  // copy records: pieces of the accepted contours
     int thr_mode = 1;    // node window table: 1 = k_threshold_stream (default), 0 (FID_THR=tile) = k_threshold_fixed
     int thr_nw = 3, thr_split = 0, thr_rows = 0;  // stream kernel: consumer waves per workgroup, un-fused LDS reads, rows per workgroup (0 = automatic)
     int trace_mode = 1;  // 1: seed-accelerated tracing; 0 (FID_TRACE=legacy): probe passes + whole-border walk only
     long long fallbacks = 0;  // calls that fell back to the whole-border walk because the seed table was too small
     int max_chunks = 0;
     int walk_blocks = 0;  // one-wave workgroups per frame in the full walk pass (0 = automatic)
+    int walk_blocks_cap = 64;  // (the walks of a single frame want every seed in flight at once)
+    int seed_shift = 0;        // FID_SEED_SHIFT: force the seed lattice spacing (0 = by call size)
     uint4 *d_contours = nullptr;
     uint32_t *d_ckpts = nullptr;
     size_t ckpts_elems = 0;
@@ -209,6 +212,15 @@ void set_geometry(fid_ctx *c, int W, int H, int gstride, int F)
     P.maxCands = c->lim.max_candidates_per_frame;
     P.maxMarkers = c->lim.max_markers_per_frame;
     P.maxChunks = c->max_chunks;
+    // tracing seeds: the denser the lattice, the shorter the longest seed-free stretch (the latency of a single frame) and the
+    // more segments (tables, link / chain work).  Small calls take the densest lattice their tables have room for.
+    {
+        int sh = SEED_SHIFT_MAX;
+        if (F <= 4 && P.maxContours >= 65536 && c->max_chunks >= 4 * 65536) sh = 2;
+        else if (F <= 16 && P.maxContours >= 32768 && c->max_chunks >= 2 * 65536) sh = 3;
+        if (c->seed_shift > 0) sh = c->seed_shift;
+        P.seedShift = sh < SEED_SHIFT_MIN ? SEED_SHIFT_MIN : (sh > SEED_SHIFT_MAX ? SEED_SHIFT_MAX : sh);
+    }
 }
 
 size_t masks_elems(const fid_ctx *c, int W, int H, int F)
@@ -331,7 +343,7 @@ fid_status run_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H, int
         }
         // persistent walker workgroups (WALK_WAVES waves each) per frame: about 16 waves per CU over the sub-batch
         int wb = c->walk_blocks > 0 ? c->walk_blocks : (4096 / WALK_WAVES + Fs - 1) / Fs;
-        wb = wb < 2 ? 2 : (wb > 16 ? 16 : wb);
+        wb = wb < 2 ? 2 : (wb > c->walk_blocks_cap ? c->walk_blocks_cap : wb);
         const int cap1 = pts_cap_first(P);
         const size_t lds1 = (size_t)cap1 * sizeof(uint32_t) + (size_t)K4_SHORT_STACK * sizeof(int2);
         const size_t lds2 = (size_t)(P.maxPerim + 1) * sizeof(uint32_t) + (size_t)K4_LONG_STACK * sizeof(int2);
@@ -384,9 +396,10 @@ fid_status run_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H, int
                                c->d_global, P);
             HIPCHK(c, hipStreamWaitEvent(st, c->aux_join[sb], 0));
             hipLaunchKernelGGL(k_seg_link, dim3(16, Fs), dim3(256), 0, st, seedq, segs, surv, pend, seedplane, counts, c->d_global, P);
-            hipLaunchKernelGGL(k_seg_chain, dim3(16, Fs), dim3(64), 0, st, surv, pend, wres, segs, contours, cinfo, counts, c->d_global, P);
-            hipLaunchKernelGGL(k_seg_flatten, dim3(64, Fs), dim3(64), 0, st, segs, contours, cinfo, cbase, tab, pool, dense, counts,
+            uint4 *recs = c->d_recs + 2 * f0 * MCn;
+            hipLaunchKernelGGL(k_seg_chain, dim3(16, Fs), dim3(64), 0, st, surv, pend, wres, segs, contours, cinfo, cbase, recs, counts,
                                c->d_global, P);
+            hipLaunchKernelGGL(k_seg_copy, dim3(Fs >= 64 ? 16 : 128, Fs), dim3(256), 0, st, recs, tab, pool, dense, counts, P);
             mark(ST_WALK + 1);
             hipLaunchKernelGGL(k_approx, dim3(128, Fs), dim3(64), lds1, st, contours, tab, pool, cands, counts, c->d_global, P, cap1,
                                K4_SHORT_STACK, 0, dense, cbase);
@@ -466,6 +479,10 @@ fid_status run_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H, int
         // the tracing seeds and their points scale with the total border length of the frame, texture included: when they
         // do not fit max_contours_per_frame / max_points_per_frame, trace this call with the whole-border walk, which only
         // needs room for the probe survivors
+        if (getenv("FID_VERBOSE"))
+            fprintf(stderr, "fid: seed tracing overflow flags 0x%x (frame 0: seeds %d starts %d surv %d chunks %d; maxContours %d maxChunks %d shift %d): whole-border walk\n",
+                    c->h_global->overflow, c->h_counts[0].nseeds, c->h_counts[0].nstarts, c->h_counts[0].nsurv, c->h_counts[0].npool, c->P.maxContours,
+                    c->P.maxChunks, c->P.seedShift);
         c->trace_mode = 0;
         c->fallbacks++;
         const fid_status rc2 = run_detect(c, d_src, F, W, H, stride, fstride, enc, out, cap_per_frame, n_per_frame);
@@ -562,6 +579,14 @@ fid_status fid_create(const fid_params *params, const fid_dict *dict, const fid_
         if (limits->max_markers_per_frame > 0) L.max_markers_per_frame = limits->max_markers_per_frame;
         if (limits->max_points_per_frame > 0) L.max_points_per_frame = limits->max_points_per_frame;
     }
+    // contexts for a few frames at a time (the node's shape, max_batch 1) get room for the dense seed lattice by default
+    if (L.max_batch <= 4) {
+        if (!limits || limits->max_contours_per_frame <= 0) L.max_contours_per_frame = 65536;
+        if (!limits || limits->max_points_per_frame <= 0) L.max_points_per_frame = 16 * 1024 * 1024;
+    } else if (L.max_batch <= 16) {
+        if (!limits || limits->max_contours_per_frame <= 0) L.max_contours_per_frame = 32768;
+        if (!limits || limits->max_points_per_frame <= 0) L.max_points_per_frame = 8 * 1024 * 1024;
+    }
     L.max_candidates_per_frame = roundup(L.max_candidates_per_frame, 32);
     if (L.max_candidates_per_frame > 4096 || L.max_batch > 65535 || L.max_markers_per_frame > L.max_candidates_per_frame) {
         delete c;
@@ -575,6 +600,8 @@ fid_status fid_create(const fid_params *params, const fid_dict *dict, const fid_
     c->dict_host.assign(dict->bytes, dict->bytes + dbytes);
     c->profile = getenv("FID_PROFILE") && atoi(getenv("FID_PROFILE")) != 0;
     if (getenv("FID_SUB_FRAMES")) c->sub_frames = atoi(getenv("FID_SUB_FRAMES"));
+    if (getenv("FID_WALK_CAP")) c->walk_blocks_cap = atoi(getenv("FID_WALK_CAP"));
+    if (getenv("FID_SEED_SHIFT")) c->seed_shift = atoi(getenv("FID_SEED_SHIFT"));
     if (getenv("FID_THR")) c->thr_mode = strcmp(getenv("FID_THR"), "tile") ? 1 : 0;
     if (getenv("FID_THR_NW")) c->thr_nw = atoi(getenv("FID_THR_NW")) == 3 ? 3 : 5;
     if (getenv("FID_THR_SPLIT")) c->thr_split = atoi(getenv("FID_THR_SPLIT")) != 0;
@@ -645,6 +672,7 @@ fid_status fid_create(const fid_params *params, const fid_dict *dict, const fid_
         TRY(dalloc(c, &c->d_wres, F * L.max_contours_per_frame));
         TRY(dalloc(c, &c->d_cinfo, F * L.max_contours_per_frame));
         TRY(dalloc(c, &c->d_cbase, F * L.max_contours_per_frame));
+        TRY(dalloc(c, &c->d_recs, 2 * F * L.max_contours_per_frame));
         TRY(dalloc(c, &c->d_dense, F * (size_t)c->max_chunks * CK));
     }
     TRY(dalloc(c, &c->d_contours, F * L.max_contours_per_frame));
@@ -690,7 +718,7 @@ void fid_destroy(fid_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    void *dev[] = {c->d_in, c->d_gray, c->d_masks, c->d_starts, c->d_surv1, c->d_surv, c->d_pool, c->d_segs, c->d_pend, c->d_seedq, c->d_seedplane, c->d_wres, c->d_cinfo, c->d_cbase, c->d_dense, c->d_contours, c->d_ckpts, c->d_cands, c->d_sorted, c->d_cmeta, c->d_filtered, c->d_near,
+    void *dev[] = {c->d_in, c->d_gray, c->d_masks, c->d_starts, c->d_surv1, c->d_surv, c->d_pool, c->d_segs, c->d_pend, c->d_seedq, c->d_seedplane, c->d_wres, c->d_cinfo, c->d_cbase, c->d_dense, c->d_recs, c->d_contours, c->d_ckpts, c->d_cands, c->d_sorted, c->d_cmeta, c->d_filtered, c->d_near,
                    c->d_ident, c->d_pre, c->d_markers, c->d_poses, c->d_counts, c->d_global, c->d_worklist, c->d_nwork, c->d_dict,
                    c->d_subpix_mask, c->d_lens, c->d_pose_in, c->d_pose_n};
     for (void *p : dev)

@@ -45,6 +45,7 @@ struct DevParams {
     int refine;
     int maxStarts, maxContours, maxCands, maxMarkers;  // per-frame capacities
     int maxChunks;                                     // per-frame pool of CK-point contour chunks
+    int seedShift;                                     // tracing seeds: lattice class spacing 2^seedShift pixels
 };
 
 // word index of padded row yy, word column wi inside one (frame, scale) mask plane of TC tile columns
@@ -73,17 +74,20 @@ struct DevIdent {
 // (the one "to the right of travel": direction d+2 for an axis move, d+1 for a diagonal one) is background.  Every seed
 // follows its border only to the next seed state (a SEGMENT); a probe survivor follows its border only to the first seed
 // state and the rest of the border is read off the segment chain.
-// lattice: k = (x - 5 y) mod SEED_PERIOD; a pixel carries class d = k >> SEED_SHIFT when k is a multiple of the class
+// lattice: k = (x - 5 y) mod (8 << shift); a pixel carries class d = k >> shift when k is a multiple of the class
 // spacing, no class otherwise
-#ifndef SEED_SHIFT
-#define SEED_SHIFT 4  // class spacing 2^SEED_SHIFT pixels
-#endif
-#define SEED_PERIOD (8 << SEED_SHIFT)
-__host__ __device__ inline int seed_class(int x, int y)
+// The class spacing 2^shift pixels is a run-time parameter (DevParams::seedShift, 2 .. 4): the longest seed-free stretch of a
+// border -- what a single frame waits for -- shrinks with the spacing, the number of segments (table space, link / chain work)
+// grows with it; large batches use 16 px, single frames 4 px.  Any lattice yields the same contours.
+#define SEED_SHIFT_MIN 2  // the period 8 << shift must cover a 32-pixel mask word: a class sits at most once in a word
+#define SEED_SHIFT_MAX 4
+__host__ __device__ inline int seed_class(int x, int y, int shift)
 {
-    const int k = (x - 5 * y) & (SEED_PERIOD - 1);
-    return (k & ((1 << SEED_SHIFT) - 1)) ? -1 : (k >> SEED_SHIFT);
+    const int k = (x - 5 * y) & ((8 << shift) - 1);
+    return (k & ((1 << shift) - 1)) ? -1 : (k >> shift);
 }
+// the same test for a known back direction d: is (x, y) the class-d position?
+__host__ __device__ inline bool seed_class_is(int x, int y, int d, int shift) { return ((x - 5 * y) & ((8 << shift) - 1)) == (d << shift); }
 // the neighbour direction that is empty when a state with back direction d was entered
 __host__ __device__ inline int seed_empty_dir(int d) { return (d + ((d & 1) ? 1 : 2)) & 7; }
 #define SEG_INVALID 0xffffffffu
@@ -118,7 +122,8 @@ struct DevCounts {
     int ndense;     // contour points copied to the dense point array so far
     int nseeds;     // seeds found by k_find_starts<true>
     int nwalk2;     // work queue head of the seed walker
-    int pad[2];
+    int nrec;       // copy records written by k_seg_chain (pieces of accepted contours)
+    int pad[1];
 };
 
 // global counters

@@ -66,6 +66,25 @@ __device__ __forceinline__ int wave_min_i32(int v)
     return v;
 }
 
+// wave min without the LDS crossbar: DPP row steps, then the four row results through readlane
+__device__ __forceinline__ int wave_min_i32_dpp(int v)
+{
+#define FID_MIN_STEP(CTRL)                                                              \
+    {                                                                                   \
+        const int o_ = __builtin_amdgcn_update_dpp(INT_MAX, v, CTRL, 0xf, 0xf, false); \
+        v = o_ < v ? o_ : v;                                                            \
+    }
+    FID_MIN_STEP(0x111)  // row_shr:1
+    FID_MIN_STEP(0x112)  // row_shr:2
+    FID_MIN_STEP(0x114)  // row_shr:4
+    FID_MIN_STEP(0x118)  // row_shr:8  -> lane 15 of every row holds the row's min
+#undef FID_MIN_STEP
+    const int a = __builtin_amdgcn_readlane(v, 15), b = __builtin_amdgcn_readlane(v, 31), c = __builtin_amdgcn_readlane(v, 47),
+              d = __builtin_amdgcn_readlane(v, 63);
+    const int ab = a < b ? a : b, cd = c < d ? c : d;
+    return ab < cd ? ab : cd;
+}
+
 __device__ __forceinline__ int wave_sum_i32(int v)
 {
 #pragma unroll
@@ -813,7 +832,7 @@ __global__ __launch_bounds__(256) void k_find_starts(const uint32_t *__restrict_
                         uint32_t sm = 0;
 #pragma unroll
                         for (int dd = 0; dd < 8; dd++) {
-                            const unsigned b = (unsigned)(5 * y + (dd << SEED_SHIFT) - x_base) & (SEED_PERIOD - 1);
+                            const unsigned b = (unsigned)(5 * y + (dd << P.seedShift) - x_base) & (unsigned)((8 << P.seedShift) - 1);
                             if (b < 32u) sm |= cur & nbp[dd] & ~nbp[seed_empty_dir(dd)] & (1u << b);
                         }
                         seedo[k] = sm;
@@ -1255,7 +1274,7 @@ __global__ __launch_bounds__(64 * WALK_WAVES) void k_walk_full(const uint32_t *_
                         state = ST_FINAL;
                     } else {
                         // a seed starts in its seed state; a survivor as icvFetchContour starts a border
-                        sdir = SEG ? seed_class(x0, y0) : first_dir(raw_to_nb(raw), hole ? 0 : 4);
+                        sdir = SEG ? seed_class(x0, y0, P.seedShift) : first_dir(raw_to_nb(raw), hole ? 0 : 4);
                         i1x = x0 + dir_dx(sdir);
                         i1y = y0 + dir_dy(sdir);
                         if (!SEG && !hole && pidx(i1x, i1y, W) < key) {
@@ -1472,7 +1491,7 @@ __global__ __launch_bounds__(64 * WALK_WAVES) void k_walk_full(const uint32_t *_
                     const int hmag = (code & 1) ? W2 : 1;
                     const int hoff = (code & 2) ? hmag : -hmag;
                     if (SEG) {
-                        if (count > 0 && (e & 0x40u) && seed_class(cx, cy) == sdir) {
+                        if (count > 0 && (e & 0x40u) && seed_class_is(cx, cy, sdir, P.seedShift)) {
                             closed = 1;  // the next seed state: the segment ends in front of it
                             state = ST_FINAL;
                         } else if (count > 0 && cx == brx && cy == bry && sdir == brd) {
@@ -1509,7 +1528,7 @@ __global__ __launch_bounds__(64 * WALK_WAVES) void k_walk_full(const uint32_t *_
                             const unsigned xr = (unsigned)(cx + (MASK_PADW * 32 - 1) - wx0), rr = (unsigned)(cy - wy0);
                             state = (xr > 61u || rr > 13u) ? ST_NEED : ST_ACTIVE;
                         }
-                    } else if (MODE == 2 && count > 0 && (e & 0x40u) && seed_class(cx, cy) == sdir) {
+                    } else if (MODE == 2 && count > 0 && (e & 0x40u) && seed_class_is(cx, cy, sdir, P.seedShift)) {
                         stopped = 1;  // the first seed state on this border: the segment chain continues from here
                         state = ST_FINAL;
                     } else {
@@ -1603,8 +1622,8 @@ __global__ __launch_bounds__(64 * WALK_WAVES) void k_walk_full(const uint32_t *_
 //   k_seg_chain    every stopped survivor: once around the seed cycle, summing lengths and taking the two running minima;
 //                  the acceptance test is the one the whole-border walk applies (no pixel -- outer -- or examined
 //                  background 4-neighbour -- hole -- with a raster index below the start's key; perimeter gate)
-//   k_seg_flatten  one wave per accepted contour: the survivor's own points, then the segments in cycle order (the last
-//                  one cut where the survivor started), into a dense array for k_approx
+//   k_seg_copy     the pieces of the accepted contours (the survivor's own points, then the segments in cycle order, the
+//                  last one cut where the survivor started; listed by k_seg_chain) into a dense array for k_approx
 // The longest sequential piece is the longest seed-free stretch of a border, not the longest border.
 
 // seed index of pixel (x, y) from the seed-index plane of its scale
@@ -1651,11 +1670,15 @@ __global__ __launch_bounds__(256) void k_seg_link(const uint2 *__restrict__ seed
 
 // stopped survivors: once around the seed cycle.  Accepted contours (also the ones k_walk_full<2> closed by itself, which
 // it appended already) end up in `contours` (start, meta, length, key) with {survivor index, own points, first seed}.
+// An accepted contour gets its place in the dense point array here (cbase) and goes round its cycle a second time to leave
+// one COPY RECORD per piece {chunk row, place in the dense array, points}: the survivor's own points, then the segments in
+// cycle order, the last one cut where the survivor started.  k_seg_copy moves the pieces, all of them in parallel (walking
+// the chain inside the copy kernel made one wave wait for two dependent loads per segment).
 __global__ __launch_bounds__(64) void k_seg_chain(const uint2 *__restrict__ surv, const DevPend *__restrict__ pend,
                                                    const uint4 *__restrict__ wres, const DevSeg *__restrict__ segs,
                                                    uint4 *__restrict__ contours,
-                                                   uint4 *__restrict__ cinfo, DevCounts *__restrict__ counts,
-                                                   DevGlobal *__restrict__ G, const DevParams P)
+                                                   uint4 *__restrict__ cinfo, uint32_t *__restrict__ cbase, uint4 *__restrict__ recs,
+                                                   DevCounts *__restrict__ counts, DevGlobal *__restrict__ G, const DevParams P)
 {
     const int f = blockIdx.y;
     const int lane = lane_id();
@@ -1666,11 +1689,14 @@ __global__ __launch_bounds__(64) void k_seg_chain(const uint2 *__restrict__ surv
     const DevSeg *fsg = segs + (long long)f * P.maxContours;
     uint4 *fco = contours + (long long)f * P.maxContours;
     uint4 *fci = cinfo + (long long)f * P.maxContours;
+    uint32_t *fcb = cbase + (long long)f * P.maxContours;
+    uint4 *frc = recs + (long long)f * 2 * P.maxContours;
+    const unsigned dcap = (unsigned)P.maxChunks * CK, rcap = 2u * (unsigned)P.maxContours;
     const int W = P.W;
     for (unsigned i0 = blockIdx.x * 64; i0 < nv; i0 += gridDim.x * 64) {
         const unsigned i = i0 + lane;
         int accept = 0;
-        unsigned L = 0, key = 0, first = SEG_INVALID, own = 0;
+        unsigned L = 0, key = 0, first = SEG_INVALID, own = 0, hops = 0;
         uint2 st = make_uint2(0u, 0u);
         if (i < nv) {
             const DevPend pd = fpd[i];
@@ -1691,11 +1717,12 @@ __global__ __launch_bounds__(64) void k_seg_chain(const uint2 *__restrict__ surv
                 first = pd.next_idx;
                 own = pd.p;
                 unsigned cur = first;
-                for (int hops = 0; hops <= P.maxPerim && cur != SEG_INVALID; hops++) {  // (every segment has >= 1 state)
+                for (int h = 0; h <= P.maxPerim && cur != SEG_INVALID; h++) {  // (every segment has >= 1 state)
                     const DevSeg r = fsg[cur];
                     if (r.n == SEG_INVALID || r.n == 0u) break;
                     if ((hole ? r.mhole : r.mout) < key) break;  // a smaller key on the border: not the canonical start
                     L += r.n;
+                    hops++;
                     if (L > (unsigned)P.maxPerim) break;
                     if (r.next_idx == first) {
                         accept = L >= (unsigned)P.minPerim;
@@ -1708,15 +1735,43 @@ __global__ __launch_bounds__(64) void k_seg_chain(const uint2 *__restrict__ surv
         }
         const unsigned long long mk = ballot64(accept);
         if (mk) {
-            const int leader = __ffsll((long long)mk) - 1;
-            unsigned base = 0;
-            if (lane == leader) base = atomicAdd((unsigned *)&counts[f].ncontours, (unsigned)__popcll(mk));
-            base = __shfl(base, leader, WAVE);
-            const unsigned idx = base + (unsigned)__popcll(mk & ((1ull << lane) - 1ull));
+            // contour slots, dense points and copy records of the wave's accepted contours: one atomic each
+            const unsigned myL = accept ? L : 0u, myR = accept ? hops + 1u : 0u;
+            const unsigned sL = wave_iscan_dpp(myL), sR = wave_iscan_dpp(myR);
+            const unsigned totL = (unsigned)__builtin_amdgcn_readlane((int)sL, 63), totR = (unsigned)__builtin_amdgcn_readlane((int)sR, 63);
+            unsigned bslot = 0, bdense = 0, brec = 0;
+            if (lane == 63) {
+                bslot = atomicAdd((unsigned *)&counts[f].ncontours, (unsigned)__popcll(mk));
+                bdense = atomicAdd((unsigned *)&counts[f].ndense, totL);
+                brec = atomicAdd((unsigned *)&counts[f].nrec, totR);
+            }
+            bslot = (unsigned)__builtin_amdgcn_readlane((int)bslot, 63);
+            bdense = (unsigned)__builtin_amdgcn_readlane((int)bdense, 63);
+            brec = (unsigned)__builtin_amdgcn_readlane((int)brec, 63);
+            const unsigned idx = bslot + (unsigned)__popcll(mk & ((1ull << lane) - 1ull));
             if (accept) {
                 if (idx < (unsigned)P.maxContours) {
                     fco[idx] = make_uint4(st.x, st.y, L, key);
                     fci[idx] = make_uint4(i, own, first, 0u);
+                    const unsigned dst0 = bdense + sL - myL;
+                    unsigned rec = brec + sR - myR;
+                    if (dst0 + L > dcap || rec + myR > rcap) {
+                        atomicOr(&G->overflow, 8u);
+                        fcb[idx] = SEG_INVALID;
+                    } else {
+                        fcb[idx] = dst0;
+                        frc[rec++] = make_uint4((unsigned)P.maxContours + i, dst0, own < L ? own : L, 0u);  // the survivor's own points
+                        unsigned off = own, cur = first;
+                        while (off < L && cur != SEG_INVALID) {
+                            const DevSeg r = fsg[cur];
+                            if (r.n == 0u || r.n == SEG_INVALID) break;  // (never for a segment of an accepted cycle)
+                            const unsigned take = r.n < L - off ? r.n : L - off;
+                            frc[rec++] = make_uint4(cur, dst0 + off, take, 0u);
+                            off += take;
+                            cur = r.next_idx;
+                        }
+                        for (; rec < brec + sR; rec++) frc[rec] = make_uint4(0u, 0u, 0u, 0u);  // (records reserved, not needed)
+                    }
                 } else {
                     atomicOr(&G->overflow, 2u);
                 }
@@ -1725,56 +1780,25 @@ __global__ __launch_bounds__(64) void k_seg_chain(const uint2 *__restrict__ surv
     }
 }
 
-// one wave per accepted contour: own points of the survivor (chunk rows maxContours + survivor), then the segments
-// (chunk rows = seed index) in cycle order, cut at the contour's length, into dense[cbase[ci] ...]
-__global__ __launch_bounds__(64) void k_seg_flatten(const DevSeg *__restrict__ segs, const uint4 *__restrict__ contours,
-                                                     const uint4 *__restrict__ cinfo, uint32_t *__restrict__ cbase,
-                                                     const uint32_t *__restrict__ chunk_tab, const uint32_t *__restrict__ pool,
-                                                     uint32_t *__restrict__ dense, DevCounts *__restrict__ counts,
-                                                     DevGlobal *__restrict__ G, const DevParams P)
+// the pieces of the accepted contours, from their pool chunks into the dense point array: one wave per copy record
+__global__ __launch_bounds__(256) void k_seg_copy(const uint4 *__restrict__ recs, const uint32_t *__restrict__ chunk_tab,
+                                                   const uint32_t *__restrict__ pool, uint32_t *__restrict__ dense,
+                                                   const DevCounts *__restrict__ counts, const DevParams P)
 {
     const int f = blockIdx.y;
     const int lane = lane_id();
-    unsigned nc = (unsigned)counts[f].ncontours;
-    nc = nc < (unsigned)P.maxContours ? nc : (unsigned)P.maxContours;
-    const DevSeg *fsg = segs + (long long)f * P.maxContours;
-    const uint4 *fco = contours + (long long)f * P.maxContours;
-    const uint4 *fci = cinfo + (long long)f * P.maxContours;
-    uint32_t *fcb = cbase + (long long)f * P.maxContours;
+    unsigned nr = (unsigned)counts[f].nrec;
+    const unsigned rcap = 2u * (unsigned)P.maxContours;
+    nr = nr < rcap ? nr : rcap;
+    const uint4 *frc = recs + (long long)f * rcap;
     const int nck = chunk_tab_pitch(P);
     const uint32_t *ftab = chunk_tab + (long long)f * 2 * P.maxContours * nck;
     const uint32_t *fpool = pool + (long long)f * P.maxChunks * CK;
-    const unsigned dcap = (unsigned)P.maxChunks * CK;
-    uint32_t *fd = dense + (long long)f * dcap;
-    for (unsigned ci = blockIdx.x; ci < nc; ci += gridDim.x) {
-        const unsigned L = fco[ci].z;
-        const uint4 info = fci[ci];
-        unsigned base = 0;
-        if (lane == 0) base = atomicAdd((unsigned *)&counts[f].ndense, L);
-        base = __shfl(base, 0, WAVE);
-        if (base + L > dcap) {
-            if (lane == 0) {
-                atomicOr(&G->overflow, 8u);
-                fcb[ci] = SEG_INVALID;
-            }
-            continue;
-        }
-        if (lane == 0) fcb[ci] = base;
-        // the survivor's own points
-        {
-            const uint32_t *row = ftab + ((long long)P.maxContours + info.x) * nck;
-            for (unsigned k = lane; k < info.y; k += 64) fd[base + k] = fpool[(long long)row[k >> 6] * CK + (k & 63)];
-        }
-        unsigned off = info.y, cur = info.z;
-        while (off < L && cur != SEG_INVALID) {
-            const unsigned sn = fsg[cur].n;
-            if (sn == 0u) break;  // (never for a walked segment)
-            const unsigned take = sn < L - off ? sn : L - off;
-            const uint32_t *row = ftab + (long long)cur * nck;
-            for (unsigned k = lane; k < take; k += 64) fd[base + off + k] = fpool[(long long)row[k >> 6] * CK + (k & 63)];
-            off += take;
-            cur = fsg[cur].next_idx;
-        }
+    uint32_t *fd = dense + (long long)f * P.maxChunks * CK;
+    for (unsigned ri = blockIdx.x * 4 + (threadIdx.x >> 6); ri < nr; ri += gridDim.x * 4) {
+        const uint4 r = frc[ri];
+        const uint32_t *row = ftab + (long long)r.x * nck;
+        for (unsigned k = lane; k < r.z; k += 64) fd[r.y + k] = fpool[(long long)row[k >> 6] * CK + (k & 63)];
     }
 }
 
@@ -2224,8 +2248,8 @@ __global__ __launch_bounds__(64) void k_resolve(const DevCand *__restrict__ sort
         for (int u = 0; u < RB; u++) {
             const int i = i0 + u;
             if (i >= n) break;  // wave-uniform
-            int wi = i >> 5;
-            uint32_t rw = __shfl(wi < 64 ? rem0 : rem1, wi & 63, WAVE);
+            const int wi = i >> 5;  // wave-uniform: the word of the removed set that holds candidate i sits in lane wi & 63
+            const uint32_t rw = (uint32_t)__builtin_amdgcn_readlane((int)(wi < 64 ? rem0 : rem1), wi & 63);
             if ((rw >> (i & 31)) & 1u) continue;  // wave-uniform
             int szi = sizes[i];
             int firstKill = INT_MAX;
@@ -2249,7 +2273,7 @@ __global__ __launch_bounds__(64) void k_resolve(const DevCand *__restrict__ sort
                     }
                 }
             }
-            int jk = wave_min_i32(firstKill);
+            int jk = wave_min_i32_dpp(firstKill);
             // every live near j < jk has size_j < size_i and is removed
 #pragma unroll
             for (int k = 0; k < 2; k++) {

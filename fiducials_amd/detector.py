@@ -56,8 +56,7 @@ class ArucoDetector:
         d = self.dictionary
         self._dict_bytes = np.ascontiguousarray(d.bytes_list, dtype=np.uint8)
         fd = FidDict(d.marker_size, d.max_correction_bits, d.n_markers, 0, self._dict_bytes.ctypes.data)
-        lim = FidLimits()
-        self._L.fid_default_limits(C.byref(lim))
+        lim = FidLimits()  # zero = "library default for this context size" (fid_create)
         lim.max_width, lim.max_height, lim.max_batch = max_width, max_height, max_batch
         lim.max_markers_per_frame, lim.max_candidates_per_frame = max_markers, max_candidates
         if max_starts:

@@ -21,6 +21,16 @@ def pytest_configure(config):
         oracle.build()
     except Exception as e:  # noqa: BLE001
         print("conftest: build step failed:", e)
+    # torch brings its own copy of the HIP runtime: when it initialises AFTER libfid_amd.so has touched the device it finds
+    # "no HIP GPUs".  The tests that hand torch tensors to the library therefore initialise torch first, whatever the order
+    # of the test files.
+    try:
+        import torch
+
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except Exception as e:  # noqa: BLE001
+        print("conftest: torch.cuda.init failed:", e)
 
 
 @pytest.fixture(scope="session")

@@ -60,6 +60,7 @@ struct fid_ctx {
     int max_chunks = 0;
     int walk_blocks = 0;  // one-wave workgroups per frame in the full walk pass (0 = automatic)
     int walk_blocks_cap = 64;  // (the walks of a single frame want every seed in flight at once)
+    int copy_blocks = 0;
     int seed_shift = 0;        // FID_SEED_SHIFT: force the seed lattice spacing (0 = by call size)
     uint4 *d_contours = nullptr;
     uint32_t *d_ckpts = nullptr;
@@ -342,7 +343,7 @@ fid_status run_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H, int
             if (k2blocks > 256) k2blocks = 256;
         }
         // persistent walker workgroups (WALK_WAVES waves each) per frame: about 16 waves per CU over the sub-batch
-        int wb = c->walk_blocks > 0 ? c->walk_blocks : (4096 / WALK_WAVES + Fs - 1) / Fs;
+        int wb = c->walk_blocks > 0 ? c->walk_blocks : (3072 / WALK_WAVES + Fs - 1) / Fs;  // (measured: 6 per frame at 128 frames beats 8 and 12)
         wb = wb < 2 ? 2 : (wb > c->walk_blocks_cap ? c->walk_blocks_cap : wb);
         const int cap1 = pts_cap_first(P);
         const size_t lds1 = (size_t)cap1 * sizeof(uint32_t) + (size_t)K4_SHORT_STACK * sizeof(int2);
@@ -399,7 +400,7 @@ fid_status run_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H, int
             uint4 *recs = c->d_recs + 2 * f0 * MCn;
             hipLaunchKernelGGL(k_seg_chain, dim3(16, Fs), dim3(64), 0, st, surv, pend, wres, segs, contours, cinfo, cbase, recs, counts,
                                c->d_global, P);
-            hipLaunchKernelGGL(k_seg_copy, dim3(Fs >= 64 ? 16 : 128, Fs), dim3(256), 0, st, recs, tab, pool, dense, counts, P);
+            hipLaunchKernelGGL(k_seg_copy, dim3(c->copy_blocks > 0 ? c->copy_blocks : 256, Fs), dim3(256), 0, st, recs, tab, pool, dense, counts, P);
             mark(ST_WALK + 1);
             hipLaunchKernelGGL(k_approx, dim3(128, Fs), dim3(64), lds1, st, contours, tab, pool, cands, counts, c->d_global, P, cap1,
                                K4_SHORT_STACK, 0, dense, cbase);
@@ -602,6 +603,7 @@ fid_status fid_create(const fid_params *params, const fid_dict *dict, const fid_
     if (getenv("FID_SUB_FRAMES")) c->sub_frames = atoi(getenv("FID_SUB_FRAMES"));
     if (getenv("FID_WALK_CAP")) c->walk_blocks_cap = atoi(getenv("FID_WALK_CAP"));
     if (getenv("FID_SEED_SHIFT")) c->seed_shift = atoi(getenv("FID_SEED_SHIFT"));
+    if (getenv("FID_COPY_BLOCKS")) c->copy_blocks = atoi(getenv("FID_COPY_BLOCKS"));
     if (getenv("FID_THR")) c->thr_mode = strcmp(getenv("FID_THR"), "tile") ? 1 : 0;
     if (getenv("FID_THR_NW")) c->thr_nw = atoi(getenv("FID_THR_NW")) == 3 ? 3 : 5;
     if (getenv("FID_THR_SPLIT")) c->thr_split = atoi(getenv("FID_THR_SPLIT")) != 0;

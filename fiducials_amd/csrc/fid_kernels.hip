@@ -31,76 +31,69 @@ __device__ __forceinline__ int lane_id() { return threadIdx.x & (WAVE - 1); }
 
 __device__ __forceinline__ unsigned long long ballot64(int pred) { return __ballot(pred); }
 
-// inclusive wave scan (all 64 lanes must be active)
+// Wave-wide scans and reductions on DPP row operations (no LDS crossbar: ds_bpermute costs an LDS round trip per step,
+// and these sit on the latency path of one-wave-per-object kernels).  All 64 lanes must be active.
+#define FID_DPP(OLD, V, CTRL, RMASK) __builtin_amdgcn_update_dpp((OLD), (V), (CTRL), (RMASK), 0xf, false)
+// row_shr:1, 2, 4, 8, then row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3
+#define FID_DPP_SCAN_STEPS(STEP) STEP(0x111, 0xf) STEP(0x112, 0xf) STEP(0x114, 0xf) STEP(0x118, 0xf) STEP(0x142, 0xa) STEP(0x143, 0xc)
+
+// inclusive wave scan
 __device__ __forceinline__ int wave_iscan(int v)
 {
-    int lane = lane_id();
-#pragma unroll
-    for (int d = 1; d < WAVE; d <<= 1) {
-        int t = __shfl_up(v, d, WAVE);
-        if (lane >= d) v += t;
-    }
+#define S_(C, M) v += FID_DPP(0, v, C, M);
+    FID_DPP_SCAN_STEPS(S_)
+#undef S_
     return v;
 }
 
-// wave max of a 64-bit key (hi, lo)
+// wave max of a 64-bit key (hi, lo), in every lane
 __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long k)
 {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        unsigned lo = __shfl_xor((unsigned)k, d, WAVE);
-        unsigned hi = __shfl_xor((unsigned)(k >> 32), d, WAVE);
-        unsigned long long o = ((unsigned long long)hi << 32) | lo;
-        k = o > k ? o : k;
+    unsigned lo = (unsigned)k, hi = (unsigned)(k >> 32);
+#define S_(C, M)                                                                      \
+    {                                                                                 \
+        const unsigned ol = (unsigned)FID_DPP(0, (int)lo, C, M), oh = (unsigned)FID_DPP(0, (int)hi, C, M); \
+        const bool gt = oh > hi || (oh == hi && ol > lo);                             \
+        lo = gt ? ol : lo;                                                            \
+        hi = gt ? oh : hi;                                                            \
     }
-    return k;
+    FID_DPP_SCAN_STEPS(S_)  // lane 63 ends up with the max over all lanes (keys are >= 0: the fill value 0 is neutral)
+#undef S_
+    lo = (unsigned)__builtin_amdgcn_readlane((int)lo, 63);
+    hi = (unsigned)__builtin_amdgcn_readlane((int)hi, 63);
+    return ((unsigned long long)hi << 32) | lo;
 }
 
 __device__ __forceinline__ int wave_min_i32(int v)
 {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        int o = __shfl_xor(v, d, WAVE);
-        v = o < v ? o : v;
+#define S_(C, M)                                  \
+    {                                             \
+        const int o = FID_DPP(INT_MAX, v, C, M);  \
+        v = o < v ? o : v;                        \
     }
-    return v;
+    FID_DPP_SCAN_STEPS(S_)
+#undef S_
+    return __builtin_amdgcn_readlane(v, 63);
 }
+__device__ __forceinline__ int wave_min_i32_dpp(int v) { return wave_min_i32(v); }
 
-// wave min without the LDS crossbar: DPP row steps, then the four row results through readlane
-__device__ __forceinline__ int wave_min_i32_dpp(int v)
-{
-#define FID_MIN_STEP(CTRL)                                                              \
-    {                                                                                   \
-        const int o_ = __builtin_amdgcn_update_dpp(INT_MAX, v, CTRL, 0xf, 0xf, false); \
-        v = o_ < v ? o_ : v;                                                            \
-    }
-    FID_MIN_STEP(0x111)  // row_shr:1
-    FID_MIN_STEP(0x112)  // row_shr:2
-    FID_MIN_STEP(0x114)  // row_shr:4
-    FID_MIN_STEP(0x118)  // row_shr:8  -> lane 15 of every row holds the row's min
-#undef FID_MIN_STEP
-    const int a = __builtin_amdgcn_readlane(v, 15), b = __builtin_amdgcn_readlane(v, 31), c = __builtin_amdgcn_readlane(v, 47),
-              d = __builtin_amdgcn_readlane(v, 63);
-    const int ab = a < b ? a : b, cd = c < d ? c : d;
-    return ab < cd ? ab : cd;
-}
-
-__device__ __forceinline__ int wave_sum_i32(int v)
-{
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, WAVE);
-    return v;
-}
+__device__ __forceinline__ int wave_sum_i32(int v) { return __builtin_amdgcn_readlane(wave_iscan(v), 63); }
 
 __device__ __forceinline__ long long wave_sum_i64(long long v)
 {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        unsigned lo = __shfl_xor((unsigned)v, d, WAVE);
-        unsigned hi = __shfl_xor((unsigned)((unsigned long long)v >> 32), d, WAVE);
-        v += (long long)(((unsigned long long)hi << 32) | lo);
+    unsigned lo = (unsigned)v, hi = (unsigned)((unsigned long long)v >> 32);
+#define S_(C, M)                                                                      \
+    {                                                                                 \
+        const unsigned ol = (unsigned)FID_DPP(0, (int)lo, C, M), oh = (unsigned)FID_DPP(0, (int)hi, C, M); \
+        const unsigned long long t = (((unsigned long long)hi << 32) | lo) + (((unsigned long long)oh << 32) | ol); \
+        lo = (unsigned)t;                                                             \
+        hi = (unsigned)(t >> 32);                                                     \
     }
-    return v;
+    FID_DPP_SCAN_STEPS(S_)
+#undef S_
+    lo = (unsigned)__builtin_amdgcn_readlane((int)lo, 63);
+    hi = (unsigned)__builtin_amdgcn_readlane((int)hi, 63);
+    return (long long)(((unsigned long long)hi << 32) | lo);
 }
 
 __device__ __forceinline__ double shfl_f64(double v, int src)
@@ -1114,6 +1107,9 @@ __global__ __launch_bounds__(256) void k_probe(const uint32_t *__restrict__ mask
 #define WALK_RUN 32     // most steps between two checkpoints
 #define WALK_GRAB 64    // survivors a wave takes from the frame's work queue per atomic
 #define WALK_ARENA 256  // pool chunks a wave takes per atomic
+#ifndef WALK_STEAL_MIN
+#define WALK_STEAL_MIN 32  // idle lanes a wave must have before it looks for another frame's queue
+#endif
 
 __device__ __forceinline__ void wait_vmcnt0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
@@ -1193,7 +1189,9 @@ __global__ __launch_bounds__(64 * WALK_WAVES) void k_walk_full(const uint32_t *_
     // 4-neighbour the search passed over (0 none, else 4 | positive << 1 | whole-row)
     __shared__ uint8_t s_lut[2048];
     const uint32_t *s_winw = reinterpret_cast<const uint32_t *>(s_win);
-    int f = blockIdx.y;  // the frame whose queue this wave is serving; it moves on when that queue runs dry
+    int f = blockIdx.y;  // the frame whose queue this wave is handing out; when that queue runs dry the wave moves on to the
+                         // next frame that still has walkers waiting WITHOUT waiting for its own lanes: a lane keeps the
+                         // frame of its walker (lf), point chunks come from one pool for the whole launch
 #ifdef FID_DEBUG_STATS
     const unsigned long long d_k0 = __builtin_readcyclecounter();
     unsigned long long d_kexh = 0;
@@ -1202,26 +1200,36 @@ __global__ __launch_bounds__(64 * WALK_WAVES) void k_walk_full(const uint32_t *_
     const int lane4 = lane * 4;
     build_step_lut(s_lut, threadIdx.x, 64 * WALK_WAVES);
     __syncthreads();
-    const unsigned ccap = (unsigned)P.maxContours, pcap = (unsigned)P.maxChunks;
+    const unsigned ccap = (unsigned)P.maxContours, pcap = (unsigned)P.maxChunks * (unsigned)P.nframes;
     const int W = P.W, S = P.nscales, TC = P.TC, TR = P.TR, F = P.nframes;
     const int W2 = W + 2;
     const int nck = chunk_tab_pitch(P);
     const long long plane = (long long)TR * TC * MT_ROWS;
     enum { ST_IDLE = 0, ST_ACTIVE, ST_NEED, ST_LOADING, ST_FINAL };
 
-    for (;;) {
-        unsigned n = (unsigned)(SEG ? counts[f].nseeds : counts[f].nsurv);
-        n = n < (unsigned)P.maxStarts ? n : (unsigned)P.maxStarts;
-        if (n > ccap) {  // more walkers than contour rows: reported, never silently dropped
-            if (lane == 0) atomicOr(&G->overflow, 2u);
-            n = ccap;
-        }
-        const uint2 *fin = surv + (long long)f * (SEG ? P.maxContours : P.maxStarts);
-        unsigned *qhead = (unsigned *)(SEG ? &counts[f].nwalk2 : &counts[f].nwalk);
-        uint4 *fco = contours + (long long)f * P.maxContours;
-        // chunk rows: seeds 0 .. maxContours-1, survivors maxContours .. 2 maxContours-1
-        uint32_t *ftab = chunk_tab + ((long long)f * 2 + (SEG ? 0 : 1)) * P.maxContours * nck;
-        uint32_t *fpool = pool + (long long)f * P.maxChunks * CK;
+    {
+        // the queue being handed out (wave-uniform)
+        unsigned n = 0;
+        const uint2 *fin = surv;
+        unsigned *qhead = nullptr;
+        auto set_queue = [&](int fr) {
+            n = (unsigned)(SEG ? counts[fr].nseeds : counts[fr].nsurv);
+            n = n < (unsigned)P.maxStarts ? n : (unsigned)P.maxStarts;
+            if (n > ccap) {  // more walkers than contour rows: reported, never silently dropped
+                if (lane == 0) atomicOr(&G->overflow, 2u);
+                n = ccap;
+            }
+            fin = surv + (long long)fr * (SEG ? P.maxContours : P.maxStarts);
+            qhead = (unsigned *)(SEG ? &counts[fr].nwalk2 : &counts[fr].nwalk);
+        };
+        set_queue(f);
+        int all_done = 0;  // no frame of the launch has walkers waiting any more (wave-uniform)
+        // per-lane views of the walker's own frame lf: contour rows, chunk rows (seeds 0 .. maxContours-1, survivors
+        // maxContours .. 2 maxContours-1); point chunks are numbered across the whole launch
+        int lf = f;
+        auto fco_of = [&](int fr) { return contours + (long long)fr * P.maxContours; };
+        auto ftab_of = [&](int fr) { return chunk_tab + ((long long)fr * 2 + (SEG ? 0 : 1)) * P.maxContours * nck; };
+        uint32_t *const fpool = pool;
         // the wave's current batch of the frame's survivor queue: [next, rend), records of batch base .. base + 63 in `pre`
         unsigned next = 0, rend = 0, pre_base = 0;  // wave-uniform
         int exhausted = 0, pre_ready = 0;           // wave-uniform
@@ -1308,7 +1316,7 @@ __global__ __launch_bounds__(64 * WALK_WAVES) void k_walk_full(const uint32_t *_
                     }
                 }
                 if (SEG) {
-                    DevSeg *r = segs + (long long)f * P.maxContours + slot;
+                    DevSeg *r = segs + (long long)lf * P.maxContours + slot;
                     r->next_key = (uint32_t)cx | ((uint32_t)cy << 13);  // the seed state the walk stopped in front of
                     r->n = too_long || !ok ? SEG_INVALID : (unsigned)count;
                     r->mout = mout;
@@ -1316,9 +1324,9 @@ __global__ __launch_bounds__(64 * WALK_WAVES) void k_walk_full(const uint32_t *_
                 } else {
                     // stopped in front of a seed state (MODE 2): k_seg_chain decides; else decided here
                     const int accept = ok && closed && !stopped && count >= P.minPerim && count <= P.maxPerim;
-                    fco[slot] = make_uint4(st.x, st.y, accept ? (unsigned)count : 0u, (unsigned)key);
+                    fco_of(lf)[slot] = make_uint4(st.x, st.y, accept ? (unsigned)count : 0u, (unsigned)key);
                     if (MODE == 2) {
-                        DevPend *pd = pend + (long long)f * P.maxContours + slot;
+                        DevPend *pd = pend + (long long)lf * P.maxContours + slot;
                         pd->p = ok && stopped ? (unsigned)count : 0u;
                         pd->next_key = (uint32_t)cx | ((uint32_t)cy << 13);
                     }
@@ -1332,6 +1340,38 @@ __global__ __launch_bounds__(64 * WALK_WAVES) void k_walk_full(const uint32_t *_
             // ---- hand out new work to idle lanes
             int fresh = 0;
             const unsigned long long idle = ballot64(state == ST_IDLE);
+            if (exhausted && next == rend && !all_done && __popcll(idle) >= WALK_STEAL_MIN) {
+                // this frame's queue is empty and enough lanes are idle to make it worth a look: hand out the next frame
+                // that still has walkers waiting (cyclic order from a wave-specific offset, so that the waves that run dry
+                // together do not all descend on the same queue); 64 frames are examined per load
+                int nextf = -1;
+                const int hop = (int)((blockIdx.x * WALK_WAVES + (threadIdx.x >> 6)) * 37u % (unsigned)F);
+                for (int k0 = 1; k0 < F && nextf < 0; k0 += 64) {
+                    const int k = k0 + lane;
+                    int has = 0;
+                    int fr = (f + hop + k) % F;
+                    if (fr == f) fr = -1;
+                    if (k < F && fr >= 0) {
+                        const unsigned done = __hip_atomic_load((unsigned *)(SEG ? &counts[fr].nwalk2 : &counts[fr].nwalk), __ATOMIC_RELAXED,
+                                                                __HIP_MEMORY_SCOPE_AGENT);
+                        unsigned m = (unsigned)(SEG ? counts[fr].nseeds : counts[fr].nsurv);
+                        m = m < (unsigned)P.maxStarts ? m : (unsigned)P.maxStarts;
+                        m = m < ccap ? m : ccap;
+                        has = done < m;
+                    }
+                    const unsigned long long hb = ballot64(has);
+                    if (hb) nextf = __shfl(fr, __ffsll((long long)hb) - 1, WAVE);
+                }
+                if (nextf < 0) {
+                    all_done = 1;
+                } else {
+                    f = nextf;
+                    set_queue(f);
+                    exhausted = 0;
+                    next = rend = 0;
+                    pre_ready = 0;
+                }
+            }
             if (idle) {
                 if (next == rend && !exhausted) {
                     // take the next batch of the frame's survivors; its records arrive by the next checkpoint
@@ -1358,6 +1398,7 @@ __global__ __launch_bounds__(64 * WALK_WAVES) void k_walk_full(const uint32_t *_
                     if (state == ST_IDLE && next + (unsigned)rank < rend) {
                         slot = n - 1 - (next + (unsigned)rank);  // the walker's index in its list (handed out back to front)
                         if (slot < ccap) {
+                            lf = f;
                             st = make_uint2(gx, gy);
                             int s;
                             if (SEG) {  // x | y << 13 | hole << 26 | scale << 27, seed index
@@ -1406,7 +1447,7 @@ __global__ __launch_bounds__(64 * WALK_WAVES) void k_walk_full(const uint32_t *_
                 if (total) {
                     if (arena_next + total > arena_end) {
                         unsigned base = 0;
-                        if (lane == 0) base = atomicAdd((unsigned *)&counts[f].npool, (unsigned)WALK_ARENA);
+                        if (lane == 0) base = atomicAdd((unsigned *)&counts[0].npool, (unsigned)WALK_ARENA);  // one pool per launch
                         arena_next = __builtin_amdgcn_readfirstlane(base);
                         arena_end = arena_next + WALK_ARENA;
                     }
@@ -1418,22 +1459,23 @@ __global__ __launch_bounds__(64 * WALK_WAVES) void k_walk_full(const uint32_t *_
                             ovf |= 8u;
                             ok = 0;
                             if (SEG) {
-                                segs[(long long)f * P.maxContours + slot].n = SEG_INVALID;
+                                segs[(long long)lf * P.maxContours + slot].n = SEG_INVALID;
                             } else {
-                                fco[slot] = make_uint4(st.x, st.y, 0u, (unsigned)key);
-                                if (MODE == 2) pend[(long long)f * P.maxContours + slot].p = 0u;
+                                fco_of(lf)[slot] = make_uint4(st.x, st.y, 0u, (unsigned)key);
+                                if (MODE == 2) pend[(long long)lf * P.maxContours + slot].p = 0u;
                             }
                             state = ST_IDLE;
                         } else if (fresh) {
                             chunkA = mine;
                             chunkB = mine + 1;
-                            ftab[(long long)slot * nck] = chunkA;
-                            ftab[(long long)slot * nck + 1] = chunkB;
+                            uint32_t *trow = ftab_of(lf) + (long long)slot * nck;
+                            trow[0] = chunkA;
+                            trow[1] = chunkB;
                         } else {
                             kreg++;
                             if (kreg & 1) chunkB = mine;
                             else chunkA = mine;
-                            ftab[(long long)slot * nck + kreg] = mine;
+                            ftab_of(lf)[(long long)slot * nck + kreg] = mine;
                         }
                     }
                 }
@@ -1465,12 +1507,12 @@ __global__ __launch_bounds__(64 * WALK_WAVES) void k_walk_full(const uint32_t *_
 #ifdef FID_DEBUG_STATS
             d_ckcyc += __builtin_readcyclecounter() - d_c0;
 #endif
-            if (exhausted && next == rend && ballot64(state != ST_IDLE) == 0) break;  // queue empty, everybody retired
+            if (all_done && ballot64(state != ST_IDLE) == 0) break;  // every queue empty, everybody retired
             // ================= up to WALK_CKPT border-following steps inside the windows =================
             // (the next checkpoint comes after WALK_CKPT steps if some lane is waiting for one -- parked, loading, finished,
             //  or idle with survivors still queued -- and after WALK_RUN steps at the latest: chunk hand-out and the
             //  perimeter cap rely on that bound)
-            const int work_left = !(exhausted && next == rend);
+            const int work_left = !all_done;
             for (int it = 0; it < WALK_RUN; it++) {
                 const unsigned long long act = ballot64(state == ST_ACTIVE);
                 if (it >= WALK_CKPT && ballot64(state != ST_ACTIVE && (state != ST_IDLE || work_left))) break;
@@ -1565,25 +1607,6 @@ __global__ __launch_bounds__(64 * WALK_WAVES) void k_walk_full(const uint32_t *_
             }
         }
         if (ovf) atomicOr(&G->overflow, ovf);
-        // ---- this frame's queue is empty and all of this wave's walkers have retired: serve the next frame (in cyclic
-        //      order) that still has survivors waiting; 64 frames are examined per load
-        int nextf = -1;
-        for (int k0 = 1; k0 < F && nextf < 0; k0 += 64) {
-            const int k = k0 + lane;
-            int has = 0;
-            int fr = f + k;
-            fr = fr >= F ? fr - F : fr;
-            if (k < F) {
-                const unsigned done = __hip_atomic_load((unsigned *)(SEG ? &counts[fr].nwalk2 : &counts[fr].nwalk), __ATOMIC_RELAXED,
-                                                        __HIP_MEMORY_SCOPE_AGENT);
-                unsigned m = (unsigned)(SEG ? counts[fr].nseeds : counts[fr].nsurv);
-                m = m < (unsigned)P.maxStarts ? m : (unsigned)P.maxStarts;
-                m = m < ccap ? m : ccap;
-                has = done < m;
-            }
-            const unsigned long long hb = ballot64(has);
-            if (hb) nextf = __shfl(fr, __ffsll((long long)hb) - 1, WAVE);
-        }
 #ifdef FID_DEBUG_STATS
         if (lane == 0) {
             atomicAdd(&G->dbg[0], d_iters);
@@ -1596,8 +1619,6 @@ __global__ __launch_bounds__(64 * WALK_WAVES) void k_walk_full(const uint32_t *_
             atomicAdd(&G->dbg[7], 1ull);
         }
 #endif
-        if (nextf < 0) break;
-        f = nextf;
     }
 #ifdef FID_DEBUG_STATS
     if (lane == 0) {
@@ -1793,7 +1814,7 @@ __global__ __launch_bounds__(256) void k_seg_copy(const uint4 *__restrict__ recs
     const uint4 *frc = recs + (long long)f * rcap;
     const int nck = chunk_tab_pitch(P);
     const uint32_t *ftab = chunk_tab + (long long)f * 2 * P.maxContours * nck;
-    const uint32_t *fpool = pool + (long long)f * P.maxChunks * CK;
+    const uint32_t *fpool = pool;  // chunks are numbered across the whole launch
     uint32_t *fd = dense + (long long)f * P.maxChunks * CK;
     for (unsigned ri = blockIdx.x * 4 + (threadIdx.x >> 6); ri < nr; ri += gridDim.x * 4) {
         const uint4 r = frc[ri];
@@ -1838,7 +1859,7 @@ __global__ __launch_bounds__(64) void k_approx(uint4 *__restrict__ contours, con
     const int nck = chunk_tab_pitch(P);
     uint4 *fco = contours + (long long)f * P.maxContours;
     const uint32_t *ftab = chunk_tab + ((long long)f * 2 + 1) * P.maxContours * nck;  // survivors' chunk rows
-    const uint32_t *fpool = pool + (long long)f * P.maxChunks * CK;
+    const uint32_t *fpool = pool;  // chunks are numbered across the whole launch
     // this workgroup's slots are blockIdx.x, blockIdx.x + gridDim.x, ...: 64 of them are looked at with one
     // load (a lane each); only the accepted ones of the right length class are then processed in turn
     for (unsigned cb = blockIdx.x; cb < n; cb += gridDim.x * 64) {

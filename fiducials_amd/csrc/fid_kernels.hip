@@ -740,14 +740,33 @@ __global__ __launch_bounds__(256) void k_find_starts(const uint32_t *__restrict_
     const int WW = P.WW, TC = P.TC, TR = P.TR, H = P.H, S = P.nscales;
     const int CG = (WW + 15) / 16;                     // groups of 16 word columns
     const long long ngroups = (long long)S * TR * CG;  // one wave per group
-    const long long ngr4 = (ngroups + 3) & ~3LL;
     const long long plane = (long long)TR * TC * MT_ROWS;
     const unsigned cap = (unsigned)P.maxStarts, scap = (unsigned)P.maxContours;
     const bool drop1 = P.minPerim > 1, drop8 = P.minPerim > 8;
     uint2 *fst = starts + (long long)f * P.maxStarts;
     uint2 *fsq = HYB ? seedq + (long long)f * P.maxContours : nullptr;
-    for (long long g0 = (long long)blockIdx.x * 4; g0 < ngr4; g0 += (long long)gridDim.x * 4) {
-        const long long g = g0 + wid;
+    // XCD-aware order: a group also reads one row of the tile rows above and below it (whole 64-byte lines for one word).
+    // Workgroup b runs on XCD b % 8 (MI355X_MICROARCH.md) and every XCD has its own L2, so the tile rows of one (scale,
+    // column group) go to ONE XCD, neighbouring tile rows to waves that run at the same time: those lines then come from
+    // that XCD's L2 instead of crossing the fabric three times.  (Placement only changes speed: any order is correct.)
+    const int ncol = S * CG;                                   // (scale, column group) pairs
+    const bool by_xcd = (gridDim.x & 7) == 0 && ncol >= 8;
+    const int xcd = blockIdx.x & 7, lb = blockIdx.x >> 3, nlb = gridDim.x >> 3;
+    const long long mycols = by_xcd ? (ncol - xcd + 7) / 8 : 0;  // columns xcd, xcd + 8, ...
+    const long long nitems = by_xcd ? mycols * TR : ngroups;
+    const long long nit4 = (nitems + 3) & ~3LL;
+    for (long long i0 = by_xcd ? (long long)lb * 4 : (long long)blockIdx.x * 4; i0 < nit4;
+         i0 += (by_xcd ? (long long)nlb : (long long)gridDim.x) * 4) {
+        const long long it = i0 + wid;
+        long long g = ngroups;  // (no group: the wave only keeps the barriers company)
+        if (it < nitems) {
+            if (by_xcd) {
+                const long long col = xcd + 8 * (it / TR), trr = it % TR;  // col = s * CG + cg
+                g = ((col / CG) * TR + trr) * CG + col % CG;
+            } else {
+                g = it;
+            }
+        }
         uint32_t outer[4], hole[4], seedo[4], seedh[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) outer[k] = hole[k] = seedo[k] = seedh[k] = 0;

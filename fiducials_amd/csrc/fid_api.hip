@@ -338,8 +338,8 @@ fid_status run_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H, int
         // ---- K2
         long long k2blocks;
         {
-            long long groups = (long long)P.nscales * P.TR * ((P.WW + 15) / 16);  // one wave per group
-            k2blocks = (groups + 3) / 4;
+            long long groups = (long long)P.nscales * P.TR * ((P.WW + 15) / 16);  // two groups per wave and iteration
+            k2blocks = (groups + 7) / 8;
             if (k2blocks > 256) k2blocks = 256;
         }
         // persistent walker workgroups (WALK_WAVES waves each) per frame: about 16 waves per CU over the sub-batch

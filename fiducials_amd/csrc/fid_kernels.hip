@@ -96,6 +96,16 @@ __device__ __forceinline__ long long wave_sum_i64(long long v)
     return (long long)(((unsigned long long)hi << 32) | lo);
 }
 
+// the value of lane `src` in every lane, `src` wave-uniform: two v_readlane (no LDS crossbar round trip)
+__device__ __forceinline__ double bcast_f64(double v, int src)
+{
+    const unsigned long long u = __double_as_longlong(v);
+    const int l = __builtin_amdgcn_readfirstlane(src);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, l);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), l);
+    return __longlong_as_double(((unsigned long long)hi << 32) | lo);
+}
+
 __device__ __forceinline__ double shfl_f64(double v, int src)
 {
     unsigned long long u = __double_as_longlong(v);
@@ -728,6 +738,11 @@ __device__ __forceinline__ uint32_t fill_toward_lsb(uint32_t seed, uint32_t runs
 // word, {index of the word's first seed, seed bit mask} goes to the seed-index plane so that a pixel is mapped to its
 // seed index without any hashing.  (A seed need not lie on a real border state: such a seed walks into a real border
 // and nobody ever links to it.)
+// Two groups per wave and iteration, in two phases: (A) every lane loads the four rows of its word column of both groups
+// (one 16-byte load each) and drops the word columns that are all background -- such a word cannot hold a start or a seed
+// whatever its neighbours are, and about half of them are; (B) the remaining (word column, four rows) ITEMS of the two
+// groups are dealt out again, one per lane (compaction through a 128-byte LDS list), and only those load their
+// neighbourhood and run the bit tests.  On the bench frames that halves the instructions of this kernel.
 template <bool HYB>
 __global__ __launch_bounds__(256) void k_find_starts(const uint32_t *__restrict__ masks, uint2 *__restrict__ starts,
                                                       DevCounts *__restrict__ counts, DevGlobal *__restrict__ G,
@@ -735,16 +750,18 @@ __global__ __launch_bounds__(256) void k_find_starts(const uint32_t *__restrict_
 {
     __shared__ int s_wsum[2][4];
     __shared__ unsigned s_base[2];
+    __shared__ uint8_t s_items[4][128];
     const int lane = lane_id(), wid = threadIdx.x >> 6;
     const int f = blockIdx.y;
     const int WW = P.WW, TC = P.TC, TR = P.TR, H = P.H, S = P.nscales;
     const int CG = (WW + 15) / 16;                     // groups of 16 word columns
-    const long long ngroups = (long long)S * TR * CG;  // one wave per group
+    const long long ngroups = (long long)S * TR * CG;  // a group = 16 word columns x 16 rows (one tile row)
     const long long plane = (long long)TR * TC * MT_ROWS;
     const unsigned cap = (unsigned)P.maxStarts, scap = (unsigned)P.maxContours;
     const bool drop1 = P.minPerim > 1, drop8 = P.minPerim > 8;
     uint2 *fst = starts + (long long)f * P.maxStarts;
     uint2 *fsq = HYB ? seedq + (long long)f * P.maxContours : nullptr;
+    const uint32_t *fmasks = masks + (long long)f * S * plane;
     // XCD-aware order: a group also reads one row of the tile rows above and below it (whole 64-byte lines for one word).
     // Workgroup b runs on XCD b % 8 (MI355X_MICROARCH.md) and every XCD has its own L2, so the tile rows of one (scale,
     // column group) go to ONE XCD, neighbouring tile rows to waves that run at the same time: those lines then come from
@@ -753,57 +770,84 @@ __global__ __launch_bounds__(256) void k_find_starts(const uint32_t *__restrict_
     const bool by_xcd = (gridDim.x & 7) == 0 && ncol >= 8;
     const int xcd = blockIdx.x & 7, lb = blockIdx.x >> 3, nlb = gridDim.x >> 3;
     const long long mycols = by_xcd ? (ncol - xcd + 7) / 8 : 0;  // columns xcd, xcd + 8, ...
-    const long long nitems = by_xcd ? mycols * TR : ngroups;
-    const long long nit4 = (nitems + 3) & ~3LL;
-    for (long long i0 = by_xcd ? (long long)lb * 4 : (long long)blockIdx.x * 4; i0 < nit4;
-         i0 += (by_xcd ? (long long)nlb : (long long)gridDim.x) * 4) {
-        const long long it = i0 + wid;
-        long long g = ngroups;  // (no group: the wave only keeps the barriers company)
-        if (it < nitems) {
-            if (by_xcd) {
-                const long long col = xcd + 8 * (it / TR), trr = it % TR;  // col = s * CG + cg
-                g = ((col / CG) * TR + trr) * CG + col % CG;
-            } else {
-                g = it;
-            }
-        }
-        uint32_t outer[4], hole[4], seedo[4], seedh[4];
+    const long long nitems = by_xcd ? mycols * TR : ngroups;     // groups this workgroup's XCD share holds
+    const long long nit8 = (nitems + 7) & ~7LL;
+    auto group_of = [&](long long it) -> long long {  // the it-th group of this share (ngroups: none)
+        if (it >= nitems) return ngroups;
+        if (!by_xcd) return it;
+        const long long col = xcd + 8 * (it / TR), trr = it % TR;  // col = s * CG + cg
+        return ((col / CG) * TR + trr) * CG + col % CG;
+    };
+    for (long long i0 = by_xcd ? (long long)lb * 8 : (long long)blockIdx.x * 8; i0 < nit8;
+         i0 += (by_xcd ? (long long)nlb : (long long)gridDim.x) * 8) {
+        // ---- phase A: which word columns of the wave's two groups hold any foreground in their four rows
+        long long gsel[2];
+        unsigned long long msel[2];
 #pragma unroll
-        for (int k = 0; k < 4; k++) outer[k] = hole[k] = seedo[k] = seedh[k] = 0;
-        int x_base = 0, yy0 = 0, s = 0, cnt = 0, scnt = 0;
-        long long word0 = 0;  // index of this thread's first word inside the (frame, scale) plane
-        if (g < ngroups) {
-            const int cg = (int)(g % CG);
-            const long long t = g / CG;
-            const int tr = (int)(t % TR);
-            s = (int)(t / TR);
-            const int w = cg * 16 + (lane >> 2);
-            const int r4 = (lane & 3) * 4;
-            yy0 = tr * MT_ROWS + r4;  // padded row of this thread's first row; image row = yy - 1
-            x_base = w * 32;
-            if (w < WW && yy0 <= H && yy0 + 3 >= 1) {
-                const uint32_t *pl = masks + ((long long)f * S + s) * plane;
-                word0 = ((long long)tr * TC + MASK_PADW + w) * MT_ROWS + r4;
+        for (int t = 0; t < 2; t++) {
+            const long long g = group_of(i0 + 2 * wid + t);
+            gsel[t] = g;
+            int nz = 0;
+            if (g < ngroups) {
+                const int cg = (int)(g % CG);
+                const long long q = g / CG;
+                const int tr = (int)(q % TR), s = (int)(q / TR);
+                const int w = cg * 16 + (lane >> 2), r4 = (lane & 3) * 4, yy0 = tr * MT_ROWS + r4;
+                if (w < WW && yy0 <= H && yy0 + 3 >= 1) {
+                    const uint4 c4 = *reinterpret_cast<const uint4 *>(fmasks + (long long)s * plane + ((long long)tr * TC + MASK_PADW + w) * MT_ROWS + r4);
+                    nz = (c4.x | c4.y | c4.z | c4.w) != 0u;
+                }
+            }
+            msel[t] = ballot64(nz);
+            if (nz) s_items[wid][(t ? __popcll(msel[0]) : 0) + __popcll(msel[t] & ((1ull << lane) - 1ull))] = (uint8_t)(lane | (t << 6));
+        }
+        const int nsel = __popcll(msel[0]) + __popcll(msel[1]);  // wave-uniform
+        // ---- phase B: at most two rounds of 64 items
+        uint32_t outer[2][4], hole[2][4], seedo[2][4];
+        int x_base[2], yy0v[2], sv[2], cntv[2], scntv[2];
+        long long word0v[2];
+        int cnt = 0, scnt = 0;
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) outer[r][k] = hole[r][k] = seedo[r][k] = 0;
+            x_base[r] = yy0v[r] = sv[r] = cntv[r] = scntv[r] = 0;
+            word0v[r] = 0;
+            if (r * 64 >= nsel) continue;  // wave-uniform
+            const int idx = r * 64 + lane;
+            if (idx < nsel) {
+                const int item = s_items[wid][idx];
+                const long long g = gsel[item >> 6];
+                const int l = item & 63;
+                const int cg = (int)(g % CG);
+                const long long q = g / CG;
+                const int tr = (int)(q % TR), s = (int)(q / TR);
+                const int w = cg * 16 + (l >> 2), r4 = (l & 3) * 4;
+                const int yy0 = tr * MT_ROWS + r4;  // padded row of this item's first row; image row = yy - 1
+                const int xb = w * 32;
+                const uint32_t *pl = fmasks + (long long)s * plane;
+                const long long word0 = ((long long)tr * TC + MASK_PADW + w) * MT_ROWS + r4;
                 const uint32_t *tile = pl + word0;
                 const uint4 c4 = *reinterpret_cast<const uint4 *>(tile);
                 const uint4 p4 = *reinterpret_cast<const uint4 *>(tile - MT_ROWS);
                 const uint4 n4 = *reinterpret_cast<const uint4 *>(tile + MT_ROWS);
                 uint32_t upc = 0, upp = 0, upn = 0, dnc = 0, dnp = 0, dnn = 0;
                 if (yy0 > 0) {
-                    const uint32_t *q = pl + mask_word(TC, yy0 - 1, MASK_PADW + w);
-                    upc = q[0];
-                    upp = q[-MT_ROWS];
-                    upn = q[MT_ROWS];
+                    const uint32_t *qq = pl + mask_word(TC, yy0 - 1, MASK_PADW + w);
+                    upc = qq[0];
+                    upp = qq[-MT_ROWS];
+                    upn = qq[MT_ROWS];
                 }
                 {
-                    const uint32_t *q = pl + mask_word(TC, yy0 + 4, MASK_PADW + w);  // exists: TR has a spare tile row
-                    dnc = q[0];
-                    dnp = q[-MT_ROWS];
-                    dnn = q[MT_ROWS];
+                    const uint32_t *qq = pl + mask_word(TC, yy0 + 4, MASK_PADW + w);  // exists: TR has a spare tile row
+                    dnc = qq[0];
+                    dnp = qq[-MT_ROWS];
+                    dnn = qq[MT_ROWS];
                 }
                 const uint32_t cc[6] = {upc, c4.x, c4.y, c4.z, c4.w, dnc};
                 const uint32_t pp[6] = {upp, p4.x, p4.y, p4.z, p4.w, dnp};
                 const uint32_t nn[6] = {upn, n4.x, n4.y, n4.z, n4.w, dnn};
+                int c1 = 0, c2 = 0;
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     const int y = yy0 + k - 1;
@@ -832,9 +876,9 @@ __global__ __launch_bounds__(256) void k_find_starts(const uint32_t *__restrict_
                         e &= ~(u & d & Est);  // W is foreground by construction
                         en0 &= ~(nextu & nextd & (nextc >> 1));  // N, S, E of the next word's pixel 0
                     }
-                    outer[k] = o;
-                    hole[k] = (e >> 1) | (en0 << 31);
-                    cnt += __popc(outer[k]) + __popc(hole[k]);
+                    outer[r][k] = o;
+                    hole[r][k] = (e >> 1) | (en0 << 31);
+                    c1 += __popc(outer[r][k]) + __popc(hole[r][k]);
                     if (HYB) {
                         // seed states: class d of the lattice owns at most one pixel of this word; the pixel is a seed when
                         // its neighbour in direction d (the previous pixel) is foreground and the one in direction
@@ -844,15 +888,24 @@ __global__ __launch_bounds__(256) void k_find_starts(const uint32_t *__restrict_
                         uint32_t sm = 0;
 #pragma unroll
                         for (int dd = 0; dd < 8; dd++) {
-                            const unsigned b = (unsigned)(5 * y + (dd << P.seedShift) - x_base) & (unsigned)((8 << P.seedShift) - 1);
-                            if (b < 32u) sm |= cur & nbp[dd] & ~nbp[seed_empty_dir(dd)] & (1u << b);
+                            const unsigned bb = (unsigned)(5 * y + (dd << P.seedShift) - xb) & (unsigned)((8 << P.seedShift) - 1);
+                            if (bb < 32u) sm |= cur & nbp[dd] & ~nbp[seed_empty_dir(dd)] & (1u << bb);
                         }
-                        seedo[k] = sm;
-                        scnt += __popc(sm);
+                        seedo[r][k] = sm;
+                        c2 += __popc(sm);
                     }
                 }
+                x_base[r] = xb;
+                yy0v[r] = yy0;
+                sv[r] = s;
+                word0v[r] = word0;
+                cntv[r] = c1;
+                scntv[r] = c2;
+                cnt += c1;
+                scnt += c2;
             }
         }
+        // ---- list slots: one atomic per workgroup iteration and list
         const int incl = wave_iscan(cnt);
         const int sincl = HYB ? wave_iscan(scnt) : 0;
         if (lane == 63) {
@@ -863,13 +916,13 @@ __global__ __launch_bounds__(256) void k_find_starts(const uint32_t *__restrict_
         int wbase = 0, tot = 0, swbase = 0, stot = 0;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const int v = s_wsum[0][k], sv = s_wsum[1][k];
+            const int v = s_wsum[0][k], sv2 = s_wsum[1][k];
             if (k < wid) {
                 wbase += v;
-                swbase += sv;
+                swbase += sv2;
             }
             tot += v;
-            stot += sv;
+            stot += sv2;
         }
         if (threadIdx.x == 0) {
             if (tot) s_base[0] = atomicAdd((unsigned *)&counts[f].nstarts, (unsigned)tot);
@@ -878,40 +931,48 @@ __global__ __launch_bounds__(256) void k_find_starts(const uint32_t *__restrict_
         __syncthreads();
         if (tot) {
             unsigned off = s_base[0] + (unsigned)(wbase + incl - cnt);
-            const uint32_t meta = (uint32_t)f | ((uint32_t)s << 16);
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const uint32_t y = (uint32_t)(yy0 + k - 1);
-                uint32_t o = outer[k], hh = hole[k];
-                while (o) {
-                    int b = __ffs(o) - 1;
-                    o &= o - 1;
-                    if (off < cap) fst[off] = make_uint2((uint32_t)(x_base + b) | (y << 16), meta);
-                    off++;
-                }
-                while (hh) {
-                    int b = __ffs(hh) - 1;
-                    hh &= hh - 1;
-                    if (off < cap) fst[off] = make_uint2((uint32_t)(x_base + b) | (y << 16), meta | (1u << 24));
-                    off++;
+            for (int r = 0; r < 2; r++) {
+                if (!cntv[r]) continue;
+                const uint32_t meta = (uint32_t)f | ((uint32_t)sv[r] << 16);
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t y = (uint32_t)(yy0v[r] + k - 1);
+                    uint32_t o = outer[r][k], hh = hole[r][k];
+                    while (o) {
+                        int b = __ffs(o) - 1;
+                        o &= o - 1;
+                        if (off < cap) fst[off] = make_uint2((uint32_t)(x_base[r] + b) | (y << 16), meta);
+                        off++;
+                    }
+                    while (hh) {
+                        int b = __ffs(hh) - 1;
+                        hh &= hh - 1;
+                        if (off < cap) fst[off] = make_uint2((uint32_t)(x_base[r] + b) | (y << 16), meta | (1u << 24));
+                        off++;
+                    }
                 }
             }
             if (threadIdx.x == 0 && s_base[0] + (unsigned)tot > cap) atomicOr(&G->overflow, 1u);
         }
         if (HYB && stot) {
             unsigned off = s_base[1] + (unsigned)(swbase + sincl - scnt);
-            uint2 *spl = seedplane + ((long long)f * S + s) * plane + word0;
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const uint32_t y = (uint32_t)(yy0 + k - 1);
-                uint32_t both = seedo[k];
-                if (both) spl[k] = make_uint2(off, both);
-                while (both) {
-                    int b = __ffs(both) - 1;
-                    both &= both - 1;
-                    if (off < scap)
-                        fsq[off] = make_uint2((uint32_t)(x_base + b) | (y << 13) | ((uint32_t)s << 27), off);
-                    off++;
+            for (int r = 0; r < 2; r++) {
+                if (!scntv[r]) continue;
+                uint2 *spl = seedplane + ((long long)f * S + sv[r]) * plane + word0v[r];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t y = (uint32_t)(yy0v[r] + k - 1);
+                    uint32_t both = seedo[r][k];
+                    if (both) spl[k] = make_uint2(off, both);
+                    while (both) {
+                        int b = __ffs(both) - 1;
+                        both &= both - 1;
+                        if (off < scap)
+                            fsq[off] = make_uint2((uint32_t)(x_base[r] + b) | (y << 13) | ((uint32_t)sv[r] << 27), off);
+                        off++;
+                    }
                 }
             }
             if (threadIdx.x == 0 && s_base[1] + (unsigned)stot > scap) atomicOr(&G->overflow, 2u);
@@ -2428,9 +2489,9 @@ __global__ __launch_bounds__(64) void k_identify(const uint8_t *__restrict__ gra
         for (int i = 0; i < 8; i++) {
             // pivot search down column i
             int kp = i;
-            double best = fabs(shfl_f64(a, i * 8 + i));
+            double best = fabs(bcast_f64(a, i * 8 + i));
             for (int j = i + 1; j < 8; j++) {
-                double v = fabs(shfl_f64(a, j * 8 + i));
+                double v = fabs(bcast_f64(a, j * 8 + i));
                 if (v > best) {
                     best = v;
                     kp = j;
@@ -2442,14 +2503,14 @@ __global__ __launch_bounds__(64) void k_identify(const uint8_t *__restrict__ gra
             }
             if (kp != i) {
                 double ai = shfl_f64(a, i * 8 + col), ak = shfl_f64(a, kp * 8 + col);
-                double bi = shfl_f64(b, i * 8), bk = shfl_f64(b, kp * 8);
+                double bi = bcast_f64(b, i * 8), bk = bcast_f64(b, kp * 8);
                 if (row == i) { a = ak; b = bk; }
                 else if (row == kp) { a = ai; b = bi; }
             }
-            double d = -1 / shfl_f64(a, i * 8 + i);
+            double d = -1 / bcast_f64(a, i * 8 + i);
             double alpha = shfl_f64(a, row * 8 + i) * d;
             double piv = shfl_f64(a, i * 8 + col);
-            double pb = shfl_f64(b, i * 8);
+            double pb = bcast_f64(b, i * 8);
             if (row > i) {
                 if (col > i) a += alpha * piv;
                 b += alpha * pb;
@@ -2460,10 +2521,10 @@ __global__ __launch_bounds__(64) void k_identify(const uint8_t *__restrict__ gra
             double x[8];
 #pragma unroll
             for (int i = 7; i >= 0; i--) {
-                double s = shfl_f64(b, i * 8);
+                double s = bcast_f64(b, i * 8);
 #pragma unroll
-                for (int kk = i + 1; kk < 8; kk++) s -= shfl_f64(a, i * 8 + kk) * x[kk];
-                x[i] = s / shfl_f64(a, i * 8 + i);
+                for (int kk = i + 1; kk < 8; kk++) s -= bcast_f64(a, i * 8 + kk) * x[kk];
+                x[i] = s / bcast_f64(a, i * 8 + i);
             }
 #pragma unroll
             for (int i = 0; i < 8; i++) M[i] = x[i];
@@ -2864,8 +2925,8 @@ __global__ __launch_bounds__(64) void k_subpix(const uint8_t *__restrict__ gray,
                 const double *pr = prod[lane];
                 for (int t = 0; t < ww * ww; t++) accv += pr[t];
             }
-            const double a = shfl_f64(accv, 0), b = shfl_f64(accv, 1), c = shfl_f64(accv, 2);
-            const double bb1 = shfl_f64(accv, 3), bb2 = shfl_f64(accv, 4);
+            const double a = bcast_f64(accv, 0), b = bcast_f64(accv, 1), c = bcast_f64(accv, 2);
+            const double bb1 = bcast_f64(accv, 3), bb2 = bcast_f64(accv, 4);
             if (lane == 0) {
                 int flag = 0;  // 0 continue, 1 stop
                 double det = a * c - b * b;

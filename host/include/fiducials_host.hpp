@@ -57,6 +57,40 @@ struct FiducialTransformArray {
     std::vector<FiducialTransform> transforms;
 };
 
+// ---- the other output surface of poseEstimateCallback (aruco_detect.cpp:462-478, 501-524): vision_msgs and tf2
+struct Pose {  // geometry_msgs/Pose
+    double px = 0, py = 0, pz = 0;
+    double ox = 0, oy = 0, oz = 0, ow = 1;
+};
+struct ObjectHypothesisWithPose {  // vision_msgs/ObjectHypothesisWithPose (Noetic: int64 id, float64 score, PoseWithCovariance)
+    int64_t id = 0;
+    double score = 0;
+    Pose pose;
+    std::array<double, 36> covariance{};
+};
+struct Detection2D {  // vision_msgs/Detection2D: the node fills `results` only (header, bbox and source_img stay default)
+    Header header;
+    std::vector<ObjectHypothesisWithPose> results;
+};
+struct Detection2DArray {
+    Header header;
+    std::vector<Detection2D> detections;
+};
+struct TransformStamped {  // geometry_msgs/TransformStamped, what tf2_ros::TransformBroadcaster::sendTransform is handed
+    Header header;
+    std::string child_frame_id;
+    double tx = 0, ty = 0, tz = 0;
+    double qx = 0, qy = 0, qz = 0, qw = 1;
+};
+// everything one poseEstimateCallback publishes: `~vis_msgs` selects which of the two arrays goes to fiducial_transforms
+// (:666-669, 534-537), `~publish_fiducial_tf` whether `tf` is broadcast (:501-524)
+struct PoseOutputs {
+    bool vis_msgs = false;
+    FiducialTransformArray fta;
+    Detection2DArray vma;
+    std::vector<TransformStamped> tf;
+};
+
 // ROS 1 wire format of the two output messages (little-endian, packed)
 std::vector<uint8_t> serialize(const FiducialArray &m);
 std::vector<uint8_t> serialize(const FiducialTransformArray &m);
@@ -79,7 +113,7 @@ class FiducialsNode {
         int dictionary = 7;
         bool do_pose_estimation = true;
         bool publish_fiducial_tf = true;
-        bool vis_msgs = false;  // (vision_msgs output is not mirrored)
+        bool vis_msgs = false;
         bool verbose = false;
         std::string ignore_fiducials;
         std::string fiducial_len_override;
@@ -99,7 +133,8 @@ class FiducialsNode {
     void ignoreCallback(const std::string &msg);                     // :300-305
     void camInfoCallback(const CameraInfo &msg);                     // :307-330
     bool imageCallback(const Image &msg, FiducialArray *out);        // :332-395
-    bool poseEstimateCallback(const FiducialArray &msg, FiducialTransformArray *out);  // :397-538
+    bool poseEstimateCallback(const FiducialArray &msg, FiducialTransformArray *out);  // :397-538 (fiducial_msgs view)
+    bool poseEstimateCallback(const FiducialArray &msg, PoseOutputs *out);             // ... everything it publishes
     bool enableDetectionsCallback(bool data, std::string *message);  // :573-588
 
     // state the reference keeps as members (read-only views for tests)
@@ -121,6 +156,7 @@ class FiducialsNode {
     std::map<int, double> fiducialLens;
     double cameraMatrix[9] = {0}, distortionCoeffs[5] = {0};
     bool haveCamInfo = false, enable_detections = true, doPoseEstimation = true, verbose = false;
+    bool vis_msgs = false, publishFiducialTf = true;
     double fiducial_len = 0.14;
     int frameNum = 0;
     std::string frameId, last_error;

@@ -153,6 +153,8 @@ FiducialsNode::FiducialsNode(const Params &p)
     fiducial_len = p.fiducial_len;
     doPoseEstimation = p.do_pose_estimation;
     verbose = p.verbose;
+    vis_msgs = p.vis_msgs;                  // (:616)
+    publishFiducialTf = p.publish_fiducial_tf;  // (:614)
     handleIgnoreString(p.ignore_fiducials);
     handleLenOverrideString(p.fiducial_len_override);
     dict = getPredefinedDictionary(p.dictionary, p.data_dir);
@@ -294,11 +296,30 @@ bool FiducialsNode::imageCallback(const Image &msg, FiducialArray *out)
 
 bool FiducialsNode::poseEstimateCallback(const FiducialArray &msg, FiducialTransformArray *out)
 {
-    FiducialTransformArray fta;
-    fta.header.sec = msg.header.sec;
-    fta.header.nsec = msg.header.nsec;
-    fta.header.frame_id = frameId;
-    fta.image_seq = (int32_t)msg.header.seq;
+    PoseOutputs po;
+    const bool keep = vis_msgs;
+    vis_msgs = false;  // this overload is the fiducial_msgs view whatever ~vis_msgs says
+    const bool ok = poseEstimateCallback(msg, &po);
+    vis_msgs = keep;
+    if (ok) *out = po.fta;
+    return ok;
+}
+
+bool FiducialsNode::poseEstimateCallback(const FiducialArray &msg, PoseOutputs *out)
+{
+    PoseOutputs po;
+    po.vis_msgs = vis_msgs;
+    if (vis_msgs) {  // (:403-407)
+        po.vma.header.sec = msg.header.sec;
+        po.vma.header.nsec = msg.header.nsec;
+        po.vma.header.frame_id = frameId;
+        po.vma.header.seq = msg.header.seq;
+    } else {  // (:408-412)
+        po.fta.header.sec = msg.header.sec;
+        po.fta.header.nsec = msg.header.nsec;
+        po.fta.header.frame_id = frameId;
+        po.fta.image_seq = (int32_t)msg.header.seq;
+    }
     frameNum++;
     if (doPoseEstimation) {
         if (!haveCamInfo) {
@@ -325,17 +346,39 @@ bool FiducialsNode::poseEstimateCallback(const FiducialArray &msg, FiducialTrans
             // tf2::Quaternion::setRotation(axis, angle)
             const double d = std::sqrt(ax * ax + ay * ay + az * az);
             const double s = std::sin(angle * 0.5) / d;
-            FiducialTransform ft;
-            ft.fiducial_id = ids[i];
-            ft.tx = t[0]; ft.ty = t[1]; ft.tz = t[2];
-            ft.qx = ax * s; ft.qy = ay * s; ft.qz = az * s; ft.qw = std::cos(angle * 0.5);
-            ft.fiducial_area = poses[i].fiducial_area;
-            ft.image_error = poses[i].image_error;
-            ft.object_error = poses[i].object_error;
-            fta.transforms.push_back(ft);
+            const double qx = ax * s, qy = ay * s, qz = az * s, qw = std::cos(angle * 0.5);
+            if (vis_msgs) {  // (:462-478)
+                ObjectHypothesisWithPose vmh;
+                vmh.id = ids[i];
+                vmh.score = std::exp(-2 * poses[i].object_error);  // [0, infinity] -> [1, 0]
+                vmh.pose.px = t[0]; vmh.pose.py = t[1]; vmh.pose.pz = t[2];
+                vmh.pose.ox = qx; vmh.pose.oy = qy; vmh.pose.oz = qz; vmh.pose.ow = qw;
+                Detection2D vm;
+                vm.results.push_back(vmh);
+                po.vma.detections.push_back(vm);
+            } else {  // (:480-498)
+                FiducialTransform ft;
+                ft.fiducial_id = ids[i];
+                ft.tx = t[0]; ft.ty = t[1]; ft.tz = t[2];
+                ft.qx = qx; ft.qy = qy; ft.qz = qz; ft.qw = qw;
+                ft.fiducial_area = poses[i].fiducial_area;
+                ft.image_error = poses[i].image_error;
+                ft.object_error = poses[i].object_error;
+                po.fta.transforms.push_back(ft);
+            }
+            if (publishFiducialTf) {  // the fiducial relative to the camera (:501-524)
+                TransformStamped ts;
+                ts.tx = t[0]; ts.ty = t[1]; ts.tz = t[2];
+                ts.qx = qx; ts.qy = qy; ts.qz = qz; ts.qw = qw;
+                ts.header.frame_id = frameId;
+                ts.header.sec = msg.header.sec;
+                ts.header.nsec = msg.header.nsec;
+                ts.child_frame_id = "fiducial_" + std::to_string(ids[i]);
+                po.tf.push_back(ts);
+            }
         }
     }
-    *out = fta;
+    *out = po;
     return true;
 }
 

@@ -194,6 +194,36 @@ static void node_surface(const Fixture &fx)
     Image bad = img;
     bad.encoding = "yuv422";
     CHECK(!node.imageCallback(bad, &fva) && !node.lastError().empty());  // like the caught cv_bridge exception: frame dropped
+    // ~vis_msgs: vision_msgs/Detection2DArray instead of FiducialTransformArray, and the TF broadcasts (:462-478, 501-524)
+    {
+        FiducialsNode::Params pv = fx.params();
+        pv.vis_msgs = true;
+        pv.ignore_fiducials = "245";
+        FiducialsNode vnode(pv);
+        vnode.camInfoCallback(fx.c_info);
+        FiducialArray fv;
+        PoseOutputs po, pf;
+        CHECK(vnode.imageCallback(img, &fv) && vnode.poseEstimateCallback(fv, &po));
+        CHECK(po.vis_msgs && po.fta.transforms.empty() && po.vma.detections.size() == 1);  // 245 ignored, 246 published
+        CHECK(po.vma.header.frame_id == "camera" && po.vma.header.seq == fv.header.seq);
+        CHECK(plain.poseEstimateCallback(f2, &pf) && !pf.vis_msgs && pf.vma.detections.empty() && pf.fta.transforms.size() == 2);
+        const ObjectHypothesisWithPose &h = po.vma.detections[0].results.at(0);
+        CHECK(h.id == 246);
+        for (auto &t : pf.fta.transforms)
+            if (t.fiducial_id == 246) {
+                CHECK(h.score == std::exp(-2 * t.object_error) && h.score > 0 && h.score <= 1);
+                CHECK(h.pose.px == t.tx && h.pose.py == t.ty && h.pose.pz == t.tz && h.pose.ox == t.qx && h.pose.ow == t.qw);
+            }
+        CHECK(po.tf.size() == 1 && po.tf[0].child_frame_id == "fiducial_246" && po.tf[0].header.frame_id == "camera");
+        CHECK(po.tf[0].tx == h.pose.px && po.tf[0].qw == h.pose.ow);
+        CHECK(pf.tf.size() == 2 && pf.tf[0].child_frame_id == "fiducial_" + std::to_string(pf.fta.transforms[0].fiducial_id));
+        FiducialsNode::Params pn = fx.params();
+        pn.publish_fiducial_tf = false;
+        FiducialsNode qnode(pn);
+        qnode.camInfoCallback(fx.c_info);
+        PoseOutputs pq;
+        CHECK(qnode.imageCallback(img, &fv) && qnode.poseEstimateCallback(fv, &pq) && pq.tf.empty() && pq.fta.transforms.size() == 2);
+    }
     // wire format: 72 / 84 bytes per element
     CHECK(serialize(fva).size() == 16 + fva.header.frame_id.size() + 8 + 72 * fva.fiducials.size());
     CHECK(serialize(fta).size() == 16 + fta.header.frame_id.size() + 8 + 84 * fta.transforms.size());

@@ -3,14 +3,18 @@
 //  /root/reference/aruco_detect/src/aruco_detect.cpp:350 and :247; stage map in SURVEY.md §8a).
 //
 //   K0 k_to_gray        a2  bgr8/rgb8 -> gray (15-bit fixed point), or stride compaction
-//   K1 k_threshold      a3  13-scale adaptive threshold from one LDS tile integral, bit-packed output
-//   K2 k_find_starts    a4  border-following start points by bit-parallel 3x3 tests + wave compaction
-//   K3 k_walk_count     a4  one lane per start: Suzuki-Abe border following, canonical-start + length gate
-//   K4 k_approx         a4  one wave per contour: re-walk into LDS, approxPolyDP, quad gates
+//   K1 k_threshold_stream (node window table) / k_threshold (any table)   a3  the 13 adaptive-threshold scales from one
+//                       pass over the image, bit-packed tiled masks out; k_threshold_fixed = the round-1 tile kernel (FID_THR=tile)
+//   K2 k_find_starts    a4  border-following start points and tracing seeds by bit-parallel tests on mask words
+//   K3 k_probe<6>, <32> a4  one lane per start: a few steps of Suzuki-Abe border following sieve the starts
+//      k_walk_full<1>, <2>  persistent walkers on private LDS windows: seeds follow their segment, probe survivors walk to the
+//                       first seed (<0>: whole borders, FID_TRACE=legacy); points go to pool chunks as they are found
+//      k_seg_link / k_seg_chain / k_seg_copy   segment chains -> accepted contours -> dense point arrays
+//   K4 k_approx         a4  one wave per accepted contour: approxPolyDP in OpenCV's slice order, quad gates
 //   K5 k_sort_cands / k_near / k_resolve   a5  OpenCV order, corner reorder, too-close filter
 //   K6 k_identify       a6/a7 one wave per candidate: homography (LU on 64 lanes), unwarp, Otsu, bits, Hamming
 //   K7 k_filter_markers / k_subpix        a8/a9
-//   K8 k_pose           a11-a13 one lane per marker: planar init + Levenberg-Marquardt
+//   K8 k_pose           a11-a13 eight lanes per marker: planar init + Levenberg-Marquardt
 //
 // Wavefront = 64 everywhere.  Integer stages are bit-exact by construction; floating-point stages
 // replay the reference's operation order (this TU is built with -ffp-contract=off).

@@ -372,6 +372,7 @@ static void stag_fill_code_locations(double *locs /* [72][3] */)
     }
 }
 
+#define STAG_PIN_MARKERS 512  // results of a frame staged through pinned memory (more than that: a blocking copy)
 struct fid_stag_ctx {
     int device = 0, maxW = 0, maxH = 0, libraryHD = 0, errorCorrection = 0;
     hipStream_t stream = nullptr;
@@ -436,6 +437,15 @@ struct fid_stag_ctx {
     fid_stag_pose_out *d_poses = nullptr;
     int W = 0, H = 0;
     unsigned n_anchors = 0;
+    // pinned landing area of the asynchronous device -> host read-backs (a copy into pageable memory would make the
+    // "asynchronous" copy wait for the stream, and the segments of different contexts could not overlap)
+    struct Pinned {
+        unsigned n_anchors;
+        int cur[11], rcount[3], ovf, n_vsegs, np, n_lines, n_vlines, n_quads, n_markers;
+        fid_stag_marker markers[STAG_PIN_MARKERS];
+        fid_stag_pose_out poses[STAG_PIN_MARKERS];
+    } *hp = nullptr;
+    uint8_t *h_src = nullptr;  // pinned staging of the input frame (host rows -> here -> one asynchronous DMA)
 };
 
 extern "C" {
@@ -518,6 +528,8 @@ fid_status fid_stag_create(int libraryHD, int errorCorrection, int max_width, in
          hipMalloc((void **)&c->d_found, (n / 9 + 16) * 4) == hipSuccess && hipMalloc((void **)&c->d_nmarkers, 4) == hipSuccess;
     ok = ok && hipMalloc((void **)&c->d_chosen, (n / 9 + 16) * 4) == hipSuccess &&
          hipMalloc((void **)&c->d_poses, (n / 9 + 16) * sizeof(fid_stag_pose_out)) == hipSuccess;
+    ok = ok && hipHostMalloc((void **)&c->hp, sizeof(fid_stag_ctx::Pinned), hipHostMallocDefault) == hipSuccess &&
+         hipHostMalloc((void **)&c->h_src, n, hipHostMallocDefault) == hipSuccess;
     if (ok) {
         double locs[72 * 3];
         stag_fill_code_locations(locs);
@@ -552,176 +564,41 @@ void fid_stag_destroy(fid_stag_ctx *c)
                    c->d_locs, c->d_words, c->d_cand, c->d_markers, c->d_found, c->d_nmarkers, c->d_chosen, c->d_poses};
     for (void *p : dev)
         if (p) (void)hipFree(p);
+    if (c->hp) (void)hipHostFree(c->hp);
+    if (c->h_src) (void)hipHostFree(c->h_src);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
 
-fid_status fid_stag_edge_frontend(fid_stag_ctx *c, const uint8_t *gray, int32_t width, int32_t height, int32_t stride)
-{
-    if (!c || !gray || width < 8 || height < 8 || width > c->maxW || height > c->maxH || stride < width) return FID_E_INVALID_ARG;
-    if (hipSetDevice(c->device) != hipSuccess) return FID_E_HIP;
-    hipStream_t st = c->stream;
-    const int W = width, H = height;
-    if (hipMemcpy2DAsync(c->d_src, (size_t)W, gray, (size_t)stride, (size_t)W, (size_t)H, hipMemcpyHostToDevice, st) != hipSuccess) return FID_E_HIP;
-    if (hipMemsetAsync(c->d_rowhist, 0, (size_t)H * STAG_BINS * 4, st) != hipSuccess) return FID_E_HIP;
-    const int GRADIENT_THRESH = 16, ANCHOR_THRESH = 0, SCAN_INTERVAL = 1;  // DetectEdgesByEDPF, ED.cpp:155-169
-    hipLaunchKernelGGL(k_stag_smooth_grad, dim3((W + SX - 1) / SX, (H + SY - 1) / SY), dim3(256), 0, st, c->d_src, W, W, H, GRADIENT_THRESH,
-                       c->d_smooth, c->d_grad, c->d_dir);
-    const int blocks = 2048, nbands = (H + STAG_BAND_ROWS - 1) / STAG_BAND_ROWS;
-    hipLaunchKernelGGL(k_stag_anchors, dim3(blocks), dim3(256), 0, st, c->d_grad, c->d_dir, W, H, GRADIENT_THRESH, ANCHOR_THRESH, SCAN_INTERVAL,
-                       c->d_edge, c->d_rowhist);
-    hipLaunchKernelGGL(k_stag_bandsum, dim3(STAG_BINS / 256, nbands), dim3(256), 0, st, c->d_rowhist, H, c->d_bandhist);
-    hipLaunchKernelGGL(k_stag_bandscan, dim3(STAG_BINS / 256), dim3(256), 0, st, c->d_bandhist, nbands, c->d_tot);
-    hipLaunchKernelGGL(k_stag_scan, dim3(1), dim3(512), 0, st, c->d_tot, c->d_bstart, c->d_n);
-    hipLaunchKernelGGL(k_stag_place, dim3(nbands), dim3(64 * STAG_BAND_ROWS), 0, st, c->d_grad, c->d_edge, W, H, c->d_rowhist, c->d_bandhist,
-                       c->d_bstart, c->d_sorted);
-    if (hipGetLastError() != hipSuccess) return FID_E_HIP;
-    if (hipMemcpyAsync(&c->n_anchors, c->d_n, 4, hipMemcpyDeviceToHost, st) != hipSuccess) return FID_E_HIP;
-    if (hipStreamSynchronize(st) != hipSuccess) return FID_E_HIP;
-    c->W = W;
-    c->H = H;
-    c->routed = false;
-    return FID_OK;
-}
+}  // extern "C" (the pipeline driver below is internal)
 
-// sequential routing: one lane for the whole frame (the reference's loop as it stands)
-static fid_status stag_route_seq(fid_stag_ctx *c, const StagRoute &R)
-{
-    hipStream_t st = c->stream;
-    hipLaunchKernelGGL(k_stag_route_seq, dim3(1), dim3(64), 0, st, R, c->d_sorted, c->d_n, 16);
-    if (hipGetLastError() != hipSuccess) return FID_E_HIP;
-    if (hipMemcpyAsync(c->rcount, c->d_rcount, 12, hipMemcpyDeviceToHost, st) != hipSuccess) return FID_E_HIP;
-    if (hipStreamSynchronize(st) != hipSuccess) return FID_E_HIP;
-    return c->rcount[2] ? FID_E_CAPACITY : FID_OK;
-}
+// ---- the pipeline of one frame on one context, cut into SEGMENTS at the points where the host needs a count the device has
+// produced (to size the next launches).  A segment first waits for the context's stream (the counts of the previous segment
+// are then in host memory), does the host-side bookkeeping and launches the next piece without waiting for it.  Run back to
+// back on one context this is the frame-at-a-time path (every staged entry point = the segments up to its stage); dealt out
+// over several contexts by ONE host thread, segment by segment, it keeps as many frames in flight as there are contexts
+// without host threads (fid_stag_detect_markers_batch): the waits overlap, the HIP runtime sees one caller.
+enum StagStage { SS_FRONTEND = 0, SS_EDGES, SS_EDGES_VALIDATED, SS_LINES, SS_LINES_VALIDATED, SS_QUADS, SS_UNREFINED, SS_MARKERS, SS_POSE };
+enum { RS_NONE = 0, RS_PAR_A, RS_PAR_B, RS_SEQ, RS_EMPTY };
 
-// component-parallel routing; FID_E_CAPACITY if an arena was too small (the caller then takes the sequential road)
-static fid_status stag_route_par(fid_stag_ctx *c, const StagRoute &R)
-{
-    hipStream_t st = c->stream;
-    const int W = c->W, H = c->H, n = W * H, na = (int)c->n_anchors;
-    if (na == 0) {
-        c->rcount[0] = c->rcount[1] = c->rcount[2] = 0;
-        return hipMemsetAsync(c->d_rcount, 0, 12, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess ? FID_OK : FID_E_HIP;
-    }
-    const int nb = (n + 255) / 256;
-    // (the per-root counters are zeroed by k_stag_ccl_init where a root can be; the output arena is cleared once its used
-    // size is known: clearing the whole allocations cost 70 MB of writes per frame)
-    bool ok = hipMemsetAsync(c->d_cursors, 0, 64, st) == hipSuccess && hipMemsetAsync(c->d_fill, 0, (size_t)c->max_comps * 4, st) == hipSuccess &&
-              hipMemsetAsync(c->d_aslots, 0xff, (size_t)c->cap_aslots * 4, st) == hipSuccess &&
-              hipMemsetAsync(c->d_prodflag, 0, (size_t)na * 4, st) == hipSuccess && hipMemsetAsync(c->d_blkpix, 0, (size_t)na * 4, st) == hipSuccess &&
-              hipMemsetAsync(c->d_blksegs, 0, (size_t)na * 4, st) == hipSuccess;
-    if (!ok) return FID_E_HIP;
-    hipLaunchKernelGGL(k_stag_ccl_init, dim3(nb), dim3(256), 0, st, c->d_grad, n, 16, c->d_label, c->d_csize, c->d_canch);
-    hipLaunchKernelGGL(k_stag_ccl_merge, dim3(nb), dim3(256), 0, st, W, H, c->d_label);
-    hipLaunchKernelGGL(k_stag_ccl_flatten, dim3(nb), dim3(256), 0, st, n, c->d_label, c->d_edge, c->d_csize, c->d_canch);
-    hipLaunchKernelGGL(k_stag_comp_alloc, dim3(nb), dim3(256), 0, st, n, c->d_label, c->d_csize, c->d_canch, c->d_cursors, c->max_comps, c->d_caps,
-                       c->d_comps, c->d_cidmap);
-    hipLaunchKernelGGL(k_stag_comp_fill, dim3((na + 255) / 256), dim3(256), 0, st, c->d_sorted, c->d_n, c->d_label, c->d_cidmap, c->d_comps, c->d_fill,
-                       c->d_aslots);
-    const int LDS_CAP = 150 * 1024;  // of the 160 KB of a CU
-    hipLaunchKernelGGL(k_stag_comp_bbox, dim3(nb), dim3(256), 0, st, W, n, c->d_label, c->d_cidmap, c->d_comps);
-    hipLaunchKernelGGL(k_stag_comp_tilemax, dim3((c->max_comps + 255) / 256), dim3(256), 0, st, c->d_comps, c->d_cursors, LDS_CAP);
-    int cur[11];
-    if (hipMemcpyAsync(cur, c->d_cursors, 44, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return FID_E_HIP;
-    if (cur[7]) return FID_E_CAPACITY;
-    // one component holding (nearly) all anchors -- a frame of noise -- leaves nothing to run side by side, and sorting its
-    // anchors would cost more than the sequential road's single pass over the globally sorted list
-    if (cur[9] > 65536) return FID_E_CAPACITY;
-    // pixels of the output arena the extraction does not write read as (-1, -1), like the reference's untouched array
-    if (cur[5] > 0 && hipMemsetAsync(c->d_aout, 0xff, (size_t)cur[5] * sizeof(int2), st) != hipSuccess) return FID_E_HIP;
-    const int nc = cur[0];
-    StagArenas A;
-    A.pix = c->d_apix; A.stack = c->d_astack; A.chains = c->d_achains; A.out = c->d_aout; A.segs = c->d_asegs; A.recs = c->d_recs;
-    int *ovf = c->d_cursors + 8;
-    if (nc > 0) {
-        hipLaunchKernelGGL(k_stag_comp_sort, dim3((nc + 3) / 4), dim3(256), 0, st, c->d_comps, c->d_cursors, c->d_aslots);
-        // LDS per workgroup = the largest tile a component of this frame asks for (components whose box does not fit 150 KB walk
-        // in global memory): frames of small components keep many workgroups per CU
-        const int lds = c->route_tile ? ((cur[10] + 1023) / 1024) * 1024 : 0;
-        hipLaunchKernelGGL(k_stag_route_walk, dim3(nc), dim3(256), (size_t)lds, st, R, A, c->d_comps, c->d_cursors, c->d_sorted, c->d_aslots, c->d_label,
-                           16, lds, c->d_prodflag, ovf);
-    }
-    hipLaunchKernelGGL(k_stag_next_above, dim3(1), dim3(1024), 0, st, c->d_prodflag, c->d_n, c->d_next);
-    if (nc > 0)
-        hipLaunchKernelGGL(k_stag_route_extract, dim3((nc + 3) / 4), dim3(256), 0, st, R, A, c->d_comps, c->d_cursors, c->d_next, c->d_n, c->d_blkpix,
-                           c->d_blksegs, c->d_blkwhere, ovf);
-    hipLaunchKernelGGL(k_stag_scan_counts, dim3(1), dim3(1024), 0, st, c->d_blkpix, (const int *)c->d_n, c->d_rcount + 1);
-    hipLaunchKernelGGL(k_stag_scan_counts, dim3(1), dim3(1024), 0, st, c->d_blksegs, (const int *)c->d_n, c->d_rcount);
-    hipLaunchKernelGGL(k_stag_route_gather, dim3((na + 3) / 4), dim3(256), 0, st, A, c->d_comps, c->d_n, c->d_prodflag, c->d_blkpix, c->d_blksegs,
-                       c->d_blkwhere, c->d_outpix, c->d_segs, R.capOut, R.capSegs, ovf);
-    if (hipGetLastError() != hipSuccess) return FID_E_HIP;
-    int o = 0;
-    if (hipMemcpyAsync(c->rcount, c->d_rcount, 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
-        hipMemcpyAsync(&o, ovf, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
-        return FID_E_HIP;
-    c->rcount[2] = o;
-    return o ? FID_E_CAPACITY : FID_OK;
-}
-
-fid_status fid_stag_detect_edges(fid_stag_ctx *c, const uint8_t *gray, int32_t width, int32_t height, int32_t stride)
-{
-    fid_status rc = fid_stag_edge_frontend(c, gray, width, height, stride);
-    if (rc != FID_OK) return rc;
-    hipStream_t st = c->stream;
-    const int W = c->W, H = c->H;
-    const size_t n = (size_t)W * H;
+struct StagJob {
+    // what is asked for
+    const uint8_t *gray = nullptr;
+    int width = 0, height = 0, stride = 0, last = SS_MARKERS;
+    fid_stag_marker *out = nullptr;
+    int cap = 0;
+    int32_t *n_out = nullptr;
+    const double *K = nullptr, *D = nullptr;
+    double marker_size = 0;
+    fid_stag_pose_out *poses = nullptr;
+    int pose_cap = 0;
+    // where it stands
+    int seg = 0, rstate = RS_NONE;
+    bool done = false;
+    fid_status rc = FID_OK;
+    int cur[11] = {0}, ovf = 0;
     StagRoute R;
-    R.grad = c->d_grad; R.dir = c->d_dir; R.edge = c->d_edgeimg; R.W = W; R.H = H;
-    R.pix = c->d_rpix; R.stack = c->d_rstack; R.chains = c->d_chains; R.chainNos = c->d_chainnos;
-    R.capPix = (int)((size_t)c->maxW * c->maxH); R.capStack = R.capPix; R.capChains = 32767; R.capNos = (c->maxW + c->maxH) * 8;
-    R.outpix = c->d_outpix; R.segs = c->d_segs; R.capOut = R.capPix; R.capSegs = R.capPix / 8 + 16;
-    R.counters = c->d_rcount;
-    for (int attempt = 0; attempt < 2; attempt++) {
-        const bool par = c->route_mode == 1 && attempt == 0;
-        if (!par && attempt == 0 && c->route_mode == 1) continue;
-        if (hipMemcpyAsync(c->d_edgeimg, c->d_edge, n, hipMemcpyDeviceToDevice, st) != hipSuccess) return FID_E_HIP;
-        // pixels the routing has not written read as (-1, -1) (the reference reads uninitialised memory there)
-        if (hipMemsetAsync(c->d_outpix, 0xff, n * sizeof(int2), st) != hipSuccess) return FID_E_HIP;
-        rc = par ? stag_route_par(c, R) : stag_route_seq(c, R);
-        if (rc == FID_OK) break;
-        if (!par || rc != FID_E_CAPACITY) return rc;
-        c->route_fallbacks++;  // an arena of the parallel road was too small: same result by the sequential road
-    }
-    if (rc != FID_OK) return rc;
-    c->routed = true;
-    c->validated = false;
-    return FID_OK;
-}
-
-fid_status fid_stag_detect_edges_validated(fid_stag_ctx *c, const uint8_t *gray, int32_t width, int32_t height, int32_t stride)
-{
-    fid_status rc = fid_stag_detect_edges(c, gray, width, height, stride);
-    if (rc != FID_OK) return rc;
-    hipStream_t st = c->stream;
-    const int W = c->W, H = c->H;
-    const size_t n = (size_t)W * H;
-    const int ns = c->rcount[0];
-    // ValidateEdgeSegments starts from an empty edge image (ValidateEdgeSegments.cpp:370)
-    if (hipMemsetAsync(c->d_edgeimg, 0, n, st) != hipSuccess || hipMemsetAsync(c->d_vhist, 0, STAG_BINS * 4, st) != hipSuccess) return FID_E_HIP;
-    hipLaunchKernelGGL(k_stag_smooth3_prewitt, dim3((W + SX - 1) / SX, (H + SY - 1) / SY), dim3(256), 0, st, c->d_src, W, W, H, c->d_smooth2,
-                       c->d_vgrad, c->d_vhist);
-    hipLaunchKernelGGL(k_stag_valid_prob, dim3(1), dim3(512), 0, st, c->d_vhist, W, H, c->d_segs, c->d_rcount, c->d_prob, c->d_np);
-    const int wg = (ns + 3) / 4;
-    if (wg > 0) {
-        hipLaunchKernelGGL(k_stag_test_segments, dim3(wg), dim3(256), 0, st, c->d_segs, c->d_rcount, c->d_outpix, c->d_vgrad, W, c->d_prob, c->d_np,
-                           2.25, c->d_vstack, c->d_edgeimg);
-        hipLaunchKernelGGL(k_stag_extract, dim3(wg), dim3(256), 0, st, c->d_segs, c->d_rcount, c->d_outpix, c->d_edgeimg, W, c->d_vcounts,
-                           c->d_vsegs, 0);
-    }
-    hipLaunchKernelGGL(k_stag_scan_counts, dim3(1), dim3(1024), 0, st, c->d_vcounts, c->d_rcount, c->d_vtotal);
-    if (wg > 0)
-        hipLaunchKernelGGL(k_stag_extract, dim3(wg), dim3(256), 0, st, c->d_segs, c->d_rcount, c->d_outpix, c->d_edgeimg, W, c->d_vcounts,
-                           c->d_vsegs, 1);
-    if (hipGetLastError() != hipSuccess) return FID_E_HIP;
-    if (hipMemcpyAsync(&c->n_vsegs, c->d_vtotal, 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
-        hipMemcpyAsync(&c->np, c->d_np, 4, hipMemcpyDeviceToHost, st) != hipSuccess)
-        return FID_E_HIP;
-    if (hipStreamSynchronize(st) != hipSuccess) return FID_E_HIP;
-    c->validated = true;
-    c->lined = false;
-    return FID_OK;
-}
+};
 
 // ComputeMinLineLength (EDLines.cpp:694-703) and the floor of 9 of DetectLinesByEDPF (:888-892): a function of the image
 // size alone, evaluated on the host like the reference does
@@ -732,85 +609,364 @@ static int stag_min_line_len(int W, int H)
     return m < 9 ? 9 : m;
 }
 
+
+static fid_status stag_finish(StagJob &j, fid_status rc)
+{
+    j.done = true;
+    j.rc = rc;
+    return rc;
+}
+
+// the sequential road of the routing: one lane for the whole frame (the reference's loop as it stands)
+static bool stag_launch_route_seq(fid_stag_ctx *c, StagJob &j)
+{
+    hipStream_t st = c->stream;
+    const size_t n = (size_t)c->W * c->H;
+    if (hipMemcpyAsync(c->d_edgeimg, c->d_edge, n, hipMemcpyDeviceToDevice, st) != hipSuccess) return false;
+    // pixels the routing has not written read as (-1, -1) (the reference reads uninitialised memory there)
+    if (hipMemsetAsync(c->d_outpix, 0xff, n * sizeof(int2), st) != hipSuccess) return false;
+    hipLaunchKernelGGL(k_stag_route_seq, dim3(1), dim3(64), 0, st, j.R, c->d_sorted, c->d_n, 16);
+    if (hipGetLastError() != hipSuccess) return false;
+    if (hipMemcpyAsync(c->hp->rcount, c->d_rcount, 12, hipMemcpyDeviceToHost, st) != hipSuccess) return false;
+    j.rstate = RS_SEQ;
+    return true;
+}
+
+// one segment of the job; FID_OK while the job is under way or has finished well (j.done tells which)
+static fid_status stag_advance(fid_stag_ctx *c, StagJob &j)
+{
+    if (j.done) return j.rc;
+    hipStream_t st = c->stream;
+    if (hipSetDevice(c->device) != hipSuccess) return stag_finish(j, FID_E_HIP);
+    if (j.seg > 0 && hipStreamSynchronize(st) != hipSuccess) return stag_finish(j, FID_E_HIP);
+    const int GRADIENT_THRESH = 16, ANCHOR_THRESH = 0, SCAN_INTERVAL = 1;  // DetectEdgesByEDPF, ED.cpp:155-169
+    switch (j.seg) {
+    case 0: {  // ---- smoothing, gradient, anchors, anchor sort
+        if (!j.gray || j.width < 8 || j.height < 8 || j.width > c->maxW || j.height > c->maxH || j.stride < j.width) return stag_finish(j, FID_E_INVALID_ARG);
+        if (j.last >= SS_UNREFINED && !c->d_words) return stag_finish(j, FID_E_INVALID_ARG);  // no marker library loaded
+        const int W = j.width, H = j.height;
+        for (int y = 0; y < H; y++) memcpy(c->h_src + (size_t)y * W, j.gray + (size_t)y * j.stride, (size_t)W);
+        if (hipMemcpyAsync(c->d_src, c->h_src, (size_t)W * H, hipMemcpyHostToDevice, st) != hipSuccess) return stag_finish(j, FID_E_HIP);
+        if (hipMemsetAsync(c->d_rowhist, 0, (size_t)H * STAG_BINS * 4, st) != hipSuccess) return stag_finish(j, FID_E_HIP);
+        hipLaunchKernelGGL(k_stag_smooth_grad, dim3((W + SX - 1) / SX, (H + SY - 1) / SY), dim3(256), 0, st, c->d_src, W, W, H, GRADIENT_THRESH,
+                           c->d_smooth, c->d_grad, c->d_dir);
+        const int blocks = 2048, nbands = (H + STAG_BAND_ROWS - 1) / STAG_BAND_ROWS;
+        hipLaunchKernelGGL(k_stag_anchors, dim3(blocks), dim3(256), 0, st, c->d_grad, c->d_dir, W, H, GRADIENT_THRESH, ANCHOR_THRESH, SCAN_INTERVAL,
+                           c->d_edge, c->d_rowhist);
+        hipLaunchKernelGGL(k_stag_bandsum, dim3(STAG_BINS / 256, nbands), dim3(256), 0, st, c->d_rowhist, H, c->d_bandhist);
+        hipLaunchKernelGGL(k_stag_bandscan, dim3(STAG_BINS / 256), dim3(256), 0, st, c->d_bandhist, nbands, c->d_tot);
+        hipLaunchKernelGGL(k_stag_scan, dim3(1), dim3(512), 0, st, c->d_tot, c->d_bstart, c->d_n);
+        hipLaunchKernelGGL(k_stag_place, dim3(nbands), dim3(64 * STAG_BAND_ROWS), 0, st, c->d_grad, c->d_edge, W, H, c->d_rowhist, c->d_bandhist,
+                           c->d_bstart, c->d_sorted);
+        if (hipGetLastError() != hipSuccess) return stag_finish(j, FID_E_HIP);
+        if (hipMemcpyAsync(&c->hp->n_anchors, c->d_n, 4, hipMemcpyDeviceToHost, st) != hipSuccess) return stag_finish(j, FID_E_HIP);
+        j.seg = 1;
+        return FID_OK;
+    }
+    case 1: {  // ---- routing: the component-parallel road up to the component table (or the sequential road)
+        c->n_anchors = c->hp->n_anchors;
+        c->W = j.width;
+        c->H = j.height;
+        c->routed = false;
+        if (j.last == SS_FRONTEND) return stag_finish(j, FID_OK);
+        const int W = c->W, H = c->H, n = W * H, na = (int)c->n_anchors;
+        StagRoute &R = j.R;
+        R.grad = c->d_grad; R.dir = c->d_dir; R.edge = c->d_edgeimg; R.W = W; R.H = H;
+        R.pix = c->d_rpix; R.stack = c->d_rstack; R.chains = c->d_chains; R.chainNos = c->d_chainnos;
+        R.capPix = (int)((size_t)c->maxW * c->maxH); R.capStack = R.capPix; R.capChains = 32767; R.capNos = (c->maxW + c->maxH) * 8;
+        R.outpix = c->d_outpix; R.segs = c->d_segs; R.capOut = R.capPix; R.capSegs = R.capPix / 8 + 16;
+        R.counters = c->d_rcount;
+        j.seg = 2;
+        if (c->route_mode != 1) return stag_launch_route_seq(c, j) ? FID_OK : stag_finish(j, FID_E_HIP);
+        if (hipMemcpyAsync(c->d_edgeimg, c->d_edge, (size_t)n, hipMemcpyDeviceToDevice, st) != hipSuccess) return stag_finish(j, FID_E_HIP);
+        if (hipMemsetAsync(c->d_outpix, 0xff, (size_t)n * sizeof(int2), st) != hipSuccess) return stag_finish(j, FID_E_HIP);
+        if (na == 0) {
+            c->rcount[0] = c->rcount[1] = c->rcount[2] = 0;
+            j.rstate = RS_EMPTY;
+            return hipMemsetAsync(c->d_rcount, 0, 12, st) == hipSuccess ? FID_OK : stag_finish(j, FID_E_HIP);
+        }
+        const int nb = (n + 255) / 256;
+        // (the per-root counters are zeroed by k_stag_ccl_init where a root can be; the output arena is cleared once its used
+        // size is known: clearing the whole allocations cost 70 MB of writes per frame)
+        const bool ok = hipMemsetAsync(c->d_cursors, 0, 64, st) == hipSuccess && hipMemsetAsync(c->d_fill, 0, (size_t)c->max_comps * 4, st) == hipSuccess &&
+                        hipMemsetAsync(c->d_aslots, 0xff, (size_t)c->cap_aslots * 4, st) == hipSuccess &&
+                        hipMemsetAsync(c->d_prodflag, 0, (size_t)na * 4, st) == hipSuccess && hipMemsetAsync(c->d_blkpix, 0, (size_t)na * 4, st) == hipSuccess &&
+                        hipMemsetAsync(c->d_blksegs, 0, (size_t)na * 4, st) == hipSuccess;
+        if (!ok) return stag_finish(j, FID_E_HIP);
+        hipLaunchKernelGGL(k_stag_ccl_init, dim3(nb), dim3(256), 0, st, c->d_grad, n, 16, c->d_label, c->d_csize, c->d_canch);
+        hipLaunchKernelGGL(k_stag_ccl_merge, dim3(nb), dim3(256), 0, st, W, H, c->d_label);
+        hipLaunchKernelGGL(k_stag_ccl_flatten, dim3(nb), dim3(256), 0, st, n, c->d_label, c->d_edge, c->d_csize, c->d_canch);
+        hipLaunchKernelGGL(k_stag_comp_alloc, dim3(nb), dim3(256), 0, st, n, c->d_label, c->d_csize, c->d_canch, c->d_cursors, c->max_comps, c->d_caps,
+                           c->d_comps, c->d_cidmap);
+        hipLaunchKernelGGL(k_stag_comp_fill, dim3((na + 255) / 256), dim3(256), 0, st, c->d_sorted, c->d_n, c->d_label, c->d_cidmap, c->d_comps, c->d_fill,
+                           c->d_aslots);
+        const int LDS_CAP = 150 * 1024;  // of the 160 KB of a CU
+        hipLaunchKernelGGL(k_stag_comp_bbox, dim3(nb), dim3(256), 0, st, W, n, c->d_label, c->d_cidmap, c->d_comps);
+        hipLaunchKernelGGL(k_stag_comp_tilemax, dim3((c->max_comps + 255) / 256), dim3(256), 0, st, c->d_comps, c->d_cursors, LDS_CAP);
+        if (hipGetLastError() != hipSuccess) return stag_finish(j, FID_E_HIP);
+        if (hipMemcpyAsync(c->hp->cur, c->d_cursors, 44, hipMemcpyDeviceToHost, st) != hipSuccess) return stag_finish(j, FID_E_HIP);
+        j.rstate = RS_PAR_A;
+        return FID_OK;
+    }
+    case 2: {  // ---- routing, second half; then edge validation
+        if (j.rstate == RS_PAR_A) {
+            memcpy(j.cur, c->hp->cur, sizeof(j.cur));
+            const int *cur = j.cur;
+            // an arena too small, or one component holding (nearly) all anchors -- a frame of noise -- which leaves nothing to
+            // run side by side (sorting its anchors would cost more than the sequential road's single pass over the globally
+            // sorted list): same result by the sequential road
+            if (cur[7] || cur[9] > 65536) {
+                c->route_fallbacks++;
+                return stag_launch_route_seq(c, j) ? FID_OK : stag_finish(j, FID_E_HIP);
+            }
+            const int na = (int)c->n_anchors;
+            // pixels of the output arena the extraction does not write read as (-1, -1), like the reference's untouched array
+            if (cur[5] > 0 && hipMemsetAsync(c->d_aout, 0xff, (size_t)cur[5] * sizeof(int2), st) != hipSuccess) return stag_finish(j, FID_E_HIP);
+            const int nc = cur[0];
+            StagArenas A;
+            A.pix = c->d_apix; A.stack = c->d_astack; A.chains = c->d_achains; A.out = c->d_aout; A.segs = c->d_asegs; A.recs = c->d_recs;
+            int *ovf = c->d_cursors + 8;
+            if (nc > 0) {
+                hipLaunchKernelGGL(k_stag_comp_sort, dim3((nc + 3) / 4), dim3(256), 0, st, c->d_comps, c->d_cursors, c->d_aslots);
+                // LDS per workgroup = the largest tile a component of this frame asks for (components whose box does not fit 150 KB
+                // walk in global memory): frames of small components keep many workgroups per CU
+                const int lds = c->route_tile ? ((cur[10] + 1023) / 1024) * 1024 : 0;
+                hipLaunchKernelGGL(k_stag_route_walk, dim3(nc), dim3(256), (size_t)lds, st, j.R, A, c->d_comps, c->d_cursors, c->d_sorted, c->d_aslots,
+                                   c->d_label, 16, lds, c->d_prodflag, ovf);
+            }
+            hipLaunchKernelGGL(k_stag_next_above, dim3(1), dim3(1024), 0, st, c->d_prodflag, c->d_n, c->d_next);
+            if (nc > 0)
+                hipLaunchKernelGGL(k_stag_route_extract, dim3((nc + 3) / 4), dim3(256), 0, st, j.R, A, c->d_comps, c->d_cursors, c->d_next, c->d_n,
+                                   c->d_blkpix, c->d_blksegs, c->d_blkwhere, ovf);
+            hipLaunchKernelGGL(k_stag_scan_counts, dim3(1), dim3(1024), 0, st, c->d_blkpix, (const int *)c->d_n, c->d_rcount + 1);
+            hipLaunchKernelGGL(k_stag_scan_counts, dim3(1), dim3(1024), 0, st, c->d_blksegs, (const int *)c->d_n, c->d_rcount);
+            hipLaunchKernelGGL(k_stag_route_gather, dim3((na + 3) / 4), dim3(256), 0, st, A, c->d_comps, c->d_n, c->d_prodflag, c->d_blkpix, c->d_blksegs,
+                               c->d_blkwhere, c->d_outpix, c->d_segs, j.R.capOut, j.R.capSegs, ovf);
+            if (hipGetLastError() != hipSuccess) return stag_finish(j, FID_E_HIP);
+            if (hipMemcpyAsync(c->hp->rcount, c->d_rcount, 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
+                hipMemcpyAsync(&c->hp->ovf, ovf, 4, hipMemcpyDeviceToHost, st) != hipSuccess)
+                return stag_finish(j, FID_E_HIP);
+            j.rstate = RS_PAR_B;
+            return FID_OK;  // (this segment again, with the second half's counts)
+        }
+        if (j.rstate == RS_PAR_B) {
+            j.ovf = c->hp->ovf;
+            c->rcount[0] = c->hp->rcount[0];
+            c->rcount[1] = c->hp->rcount[1];
+            c->rcount[2] = j.ovf;
+            if (j.ovf) {  // an arena of the parallel road was too small: same result by the sequential road
+                c->route_fallbacks++;
+                return stag_launch_route_seq(c, j) ? FID_OK : stag_finish(j, FID_E_HIP);
+            }
+        } else if (j.rstate == RS_SEQ) {
+            c->rcount[0] = c->hp->rcount[0];
+            c->rcount[1] = c->hp->rcount[1];
+            c->rcount[2] = c->hp->rcount[2];
+            if (c->rcount[2]) return stag_finish(j, FID_E_CAPACITY);
+        }
+        c->routed = true;
+        c->validated = false;
+        if (j.last == SS_EDGES) return stag_finish(j, FID_OK);
+        const int W = c->W, H = c->H;
+        const size_t n = (size_t)W * H;
+        const int ns = c->rcount[0];
+        // ValidateEdgeSegments starts from an empty edge image (ValidateEdgeSegments.cpp:370)
+        if (hipMemsetAsync(c->d_edgeimg, 0, n, st) != hipSuccess || hipMemsetAsync(c->d_vhist, 0, STAG_BINS * 4, st) != hipSuccess) return stag_finish(j, FID_E_HIP);
+        hipLaunchKernelGGL(k_stag_smooth3_prewitt, dim3((W + SX - 1) / SX, (H + SY - 1) / SY), dim3(256), 0, st, c->d_src, W, W, H, c->d_smooth2,
+                           c->d_vgrad, c->d_vhist);
+        hipLaunchKernelGGL(k_stag_valid_prob, dim3(1), dim3(512), 0, st, c->d_vhist, W, H, c->d_segs, c->d_rcount, c->d_prob, c->d_np);
+        const int wg = (ns + 3) / 4;
+        if (wg > 0) {
+            hipLaunchKernelGGL(k_stag_test_segments, dim3(wg), dim3(256), 0, st, c->d_segs, c->d_rcount, c->d_outpix, c->d_vgrad, W, c->d_prob, c->d_np,
+                               2.25, c->d_vstack, c->d_edgeimg);
+            hipLaunchKernelGGL(k_stag_extract, dim3(wg), dim3(256), 0, st, c->d_segs, c->d_rcount, c->d_outpix, c->d_edgeimg, W, c->d_vcounts,
+                               c->d_vsegs, 0);
+        }
+        hipLaunchKernelGGL(k_stag_scan_counts, dim3(1), dim3(1024), 0, st, c->d_vcounts, c->d_rcount, c->d_vtotal);
+        if (wg > 0)
+            hipLaunchKernelGGL(k_stag_extract, dim3(wg), dim3(256), 0, st, c->d_segs, c->d_rcount, c->d_outpix, c->d_edgeimg, W, c->d_vcounts,
+                               c->d_vsegs, 1);
+        if (hipGetLastError() != hipSuccess) return stag_finish(j, FID_E_HIP);
+        if (hipMemcpyAsync(&c->hp->n_vsegs, c->d_vtotal, 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
+            hipMemcpyAsync(&c->hp->np, c->d_np, 4, hipMemcpyDeviceToHost, st) != hipSuccess)
+            return stag_finish(j, FID_E_HIP);
+        j.seg = 3;
+        return FID_OK;
+    }
+    case 3: {  // ---- EDLines: split, join, gather
+        c->n_vsegs = c->hp->n_vsegs;
+        c->np = c->hp->np;
+        c->validated = true;
+        c->lined = false;
+        if (j.last == SS_EDGES_VALIDATED) return stag_finish(j, FID_OK);
+        const int ns = c->n_vsegs;
+        c->min_line_len = stag_min_line_len(c->W, c->H);
+        StagPrefix PF;
+        PF.x = c->d_prefix; PF.y = PF.x + c->prefcap; PF.xx = PF.y + c->prefcap; PF.yy = PF.xx + c->prefcap; PF.xy = PF.yy + c->prefcap;
+        const int wg = (ns + 63) / 64;
+        if (wg > 0)
+            hipLaunchKernelGGL(k_stag_split_lines, dim3((ns + 3) / 4), dim3(256), 0, st, c->d_vsegs, c->d_vtotal, c->d_outpix, PF, c->min_line_len, 1.0,
+                               c->d_lslots, c->d_lcounts);
+        hipLaunchKernelGGL(k_stag_scan_counts, dim3(1), dim3(1024), 0, st, c->d_lcounts, c->d_vtotal, c->d_ltotal);
+        if (wg > 0)
+            hipLaunchKernelGGL(k_stag_gather_lines, dim3(wg), dim3(64), 0, st, c->d_vsegs, c->d_vtotal, c->d_lcounts, c->d_ltotal, c->d_lslots, c->d_lines);
+        if (hipGetLastError() != hipSuccess) return stag_finish(j, FID_E_HIP);
+        if (hipMemcpyAsync(&c->hp->n_lines, c->d_ltotal, 4, hipMemcpyDeviceToHost, st) != hipSuccess) return stag_finish(j, FID_E_HIP);
+        j.seg = 4;
+        return FID_OK;
+    }
+    case 4: {  // ---- line validation
+        c->n_lines = c->hp->n_lines;
+        c->lined = true;
+        c->lines_validated = false;
+        if (j.last == SS_LINES) return stag_finish(j, FID_OK);
+        const int W = c->W, H = c->H;
+        if (c->kmin_w != W || c->kmin_h != H) {  // the false-alarm table is a function of the image size
+            std::vector<int> kmin;
+            stag_build_kmin(W, H, kmin);
+            if (hipMemcpy(c->d_kmin, kmin.data(), kmin.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return stag_finish(j, FID_E_HIP);
+            c->kmin_w = W;
+            c->kmin_h = H;
+            c->kmin_n = (int)kmin.size() - 1;
+        }
+        StagLineTables T;
+        T.atan_lut = c->d_atan_lut;
+        T.kmin = c->d_kmin;
+        T.kmin_n = c->kmin_n;
+        const int nl = c->n_lines;
+        if (nl > 0)
+            hipLaunchKernelGGL(k_stag_validate_lines, dim3((nl + 63) / 64), dim3(64), 0, st, c->d_lines, c->d_ltotal, c->d_src, W, H, c->d_vsegs,
+                               c->d_outpix, T, c->d_lflags);
+        hipLaunchKernelGGL(k_stag_scan_counts, dim3(1), dim3(1024), 0, st, c->d_lflags, c->d_ltotal, c->d_vltotal);
+        if (nl > 0)
+            hipLaunchKernelGGL(k_stag_compact_lines, dim3((nl + 255) / 256), dim3(256), 0, st, c->d_lines, c->d_ltotal, c->d_lflags, c->d_vltotal,
+                               c->d_vlines);
+        if (hipGetLastError() != hipSuccess) return stag_finish(j, FID_E_HIP);
+        if (hipMemcpyAsync(&c->hp->n_vlines, c->d_vltotal, 4, hipMemcpyDeviceToHost, st) != hipSuccess) return stag_finish(j, FID_E_HIP);
+        j.seg = 5;
+        return FID_OK;
+    }
+    case 5: {  // ---- quads
+        c->n_vlines = c->hp->n_vlines;
+        c->lines_validated = true;
+        c->quadded = false;
+        if (j.last == SS_LINES_VALIDATED) return stag_finish(j, FID_OK);
+        const int W = c->W, H = c->H, ns = c->n_vsegs, nl = c->n_vlines;
+        if (hipMemsetAsync(c->d_lrange, 0, (size_t)(ns + 1) * sizeof(int2), st) != hipSuccess) return stag_finish(j, FID_E_HIP);
+        if (nl > 0) hipLaunchKernelGGL(k_stag_line_ranges, dim3((nl + 255) / 256), dim3(256), 0, st, c->d_vlines, c->d_vltotal, c->d_lrange);
+        if (ns > 0)
+            hipLaunchKernelGGL(k_stag_quads, dim3((ns + 3) / 4), dim3(256), 0, st, c->d_vlines, c->d_lrange, c->d_vtotal, c->d_vsegs, c->d_outpix, c->d_src,
+                               W, H, c->d_corners, c->d_order, c->d_qslots, c->d_qcounts);
+        hipLaunchKernelGGL(k_stag_scan_counts, dim3(1), dim3(1024), 0, st, c->d_qcounts, c->d_vtotal, c->d_qtotal);
+        if (ns > 0)
+            hipLaunchKernelGGL(k_stag_gather_quads, dim3((ns + 63) / 64), dim3(64), 0, st, c->d_lrange, c->d_vtotal, c->d_qcounts, c->d_qtotal, c->d_qslots,
+                               c->d_quads);
+        if (hipGetLastError() != hipSuccess) return stag_finish(j, FID_E_HIP);
+        if (hipMemcpyAsync(&c->hp->n_quads, c->d_qtotal, 4, hipMemcpyDeviceToHost, st) != hipSuccess) return stag_finish(j, FID_E_HIP);
+        j.seg = 6;
+        return FID_OK;
+    }
+    case 6: {  // ---- code reading, decoding, duplicates
+        c->n_quads = c->hp->n_quads;
+        c->quadded = true;
+        c->decoded = false;
+        if (j.last == SS_QUADS) return stag_finish(j, FID_OK);
+        const int nq = c->n_quads;
+        if (nq > 0)
+            hipLaunchKernelGGL(k_stag_decode, dim3((nq + 3) / 4), dim3(256), 0, st, c->d_quads, c->d_qtotal, c->d_src, c->W, c->H, c->d_locs, c->d_words,
+                               c->n_words, c->errorCorrection, c->d_cand, c->d_found);
+        hipLaunchKernelGGL(k_stag_dedup, dim3(1), dim3(64), 0, st, c->d_cand, c->d_found, c->d_qtotal, c->d_markers, c->d_nmarkers);
+        if (hipGetLastError() != hipSuccess) return stag_finish(j, FID_E_HIP);
+        if (hipMemcpyAsync(&c->hp->n_markers, c->d_nmarkers, 4, hipMemcpyDeviceToHost, st) != hipSuccess) return stag_finish(j, FID_E_HIP);
+        j.seg = 7;
+        return FID_OK;
+    }
+    case 7: {  // ---- pose refinement of the markers (and, if asked for, the 5-point pose right behind it)
+        c->n_markers = c->hp->n_markers;
+        c->decoded = true;
+        if (j.last == SS_UNREFINED) return stag_finish(j, FID_OK);
+        if (c->n_markers > 0) {
+            hipLaunchKernelGGL(k_stag_refine, dim3(c->n_markers), dim3(64), 0, st, c->d_markers, c->d_nmarkers, c->d_vsegs, c->d_vtotal, c->d_outpix,
+                               c->d_chosen);
+            if (hipGetLastError() != hipSuccess) return stag_finish(j, FID_E_HIP);
+        }
+        if (j.n_out) *j.n_out = c->n_markers;
+        const bool pin = c->n_markers <= STAG_PIN_MARKERS;  // staged through pinned memory, handed over in the last segment
+        if (j.out) {
+            if (c->n_markers > j.cap) return stag_finish(j, FID_E_CAPACITY);
+            if (c->n_markers > 0 && hipMemcpyAsync(pin ? c->hp->markers : j.out, c->d_markers, (size_t)c->n_markers * sizeof(fid_stag_marker),
+                                                   hipMemcpyDeviceToHost, st) != hipSuccess)
+                return stag_finish(j, FID_E_HIP);
+        }
+        if (j.last == SS_POSE && c->n_markers > 0) {
+            if (c->n_markers > j.pose_cap) return stag_finish(j, FID_E_CAPACITY);
+            PoseCam cam;
+            for (int i = 0; i < 9; i++) cam.K[i] = j.K[i];
+            for (int i = 0; i < 5; i++) cam.D[i] = j.D ? j.D[i] : 0.0;
+            cam.fiducial_len = j.marker_size;
+            hipLaunchKernelGGL(k_stag_pose, dim3((c->n_markers + 3) / 4), dim3(64), 0, st, c->d_markers, c->d_nmarkers, cam, j.marker_size, c->d_poses);
+            if (hipGetLastError() != hipSuccess) return stag_finish(j, FID_E_HIP);
+            if (hipMemcpyAsync(pin ? c->hp->poses : j.poses, c->d_poses, (size_t)c->n_markers * sizeof(fid_stag_pose_out), hipMemcpyDeviceToHost, st) !=
+                hipSuccess)
+                return stag_finish(j, FID_E_HIP);
+        }
+        j.seg = 8;
+        return FID_OK;
+    }
+    default:  // the copies of segment 7 have landed
+        if (c->n_markers > 0 && c->n_markers <= STAG_PIN_MARKERS) {
+            if (j.out) memcpy(j.out, c->hp->markers, (size_t)c->n_markers * sizeof(fid_stag_marker));
+            if (j.last == SS_POSE && j.poses) memcpy(j.poses, c->hp->poses, (size_t)c->n_markers * sizeof(fid_stag_pose_out));
+        }
+        return stag_finish(j, FID_OK);
+    }
+}
+
+// one frame, every segment back to back
+static fid_status stag_run(fid_stag_ctx *c, StagJob &j)
+{
+    if (!c) return FID_E_INVALID_ARG;
+    while (!j.done) (void)stag_advance(c, j);
+    return j.rc;
+}
+
+static fid_status stag_run_to(fid_stag_ctx *c, const uint8_t *gray, int32_t width, int32_t height, int32_t stride, int last)
+{
+    StagJob j;
+    j.gray = gray; j.width = width; j.height = height; j.stride = stride; j.last = last;
+    return stag_run(c, j);
+}
+
+extern "C" {
+
+fid_status fid_stag_edge_frontend(fid_stag_ctx *c, const uint8_t *gray, int32_t width, int32_t height, int32_t stride)
+{
+    return stag_run_to(c, gray, width, height, stride, SS_FRONTEND);
+}
+
+fid_status fid_stag_detect_edges(fid_stag_ctx *c, const uint8_t *gray, int32_t width, int32_t height, int32_t stride)
+{
+    return stag_run_to(c, gray, width, height, stride, SS_EDGES);
+}
+
+fid_status fid_stag_detect_edges_validated(fid_stag_ctx *c, const uint8_t *gray, int32_t width, int32_t height, int32_t stride)
+{
+    return stag_run_to(c, gray, width, height, stride, SS_EDGES_VALIDATED);
+}
+
 fid_status fid_stag_detect_lines(fid_stag_ctx *c, const uint8_t *gray, int32_t width, int32_t height, int32_t stride)
 {
-    fid_status rc = fid_stag_detect_edges_validated(c, gray, width, height, stride);
-    if (rc != FID_OK) return rc;
-    hipStream_t st = c->stream;
-    const int ns = c->n_vsegs;
-    c->min_line_len = stag_min_line_len(c->W, c->H);
-    StagPrefix PF;
-    PF.x = c->d_prefix; PF.y = PF.x + c->prefcap; PF.xx = PF.y + c->prefcap; PF.yy = PF.xx + c->prefcap; PF.xy = PF.yy + c->prefcap;
-    const int wg = (ns + 63) / 64;
-    if (wg > 0)
-        hipLaunchKernelGGL(k_stag_split_lines, dim3((ns + 3) / 4), dim3(256), 0, st, c->d_vsegs, c->d_vtotal, c->d_outpix, PF, c->min_line_len, 1.0, c->d_lslots,
-                           c->d_lcounts);
-    hipLaunchKernelGGL(k_stag_scan_counts, dim3(1), dim3(1024), 0, st, c->d_lcounts, c->d_vtotal, c->d_ltotal);
-    if (wg > 0)
-        hipLaunchKernelGGL(k_stag_gather_lines, dim3(wg), dim3(64), 0, st, c->d_vsegs, c->d_vtotal, c->d_lcounts, c->d_ltotal, c->d_lslots, c->d_lines);
-    if (hipGetLastError() != hipSuccess) return FID_E_HIP;
-    if (hipMemcpyAsync(&c->n_lines, c->d_ltotal, 4, hipMemcpyDeviceToHost, st) != hipSuccess) return FID_E_HIP;
-    if (hipStreamSynchronize(st) != hipSuccess) return FID_E_HIP;
-    c->lined = true;
-    c->lines_validated = false;
-    return FID_OK;
+    return stag_run_to(c, gray, width, height, stride, SS_LINES);
 }
 
 fid_status fid_stag_detect_lines_validated(fid_stag_ctx *c, const uint8_t *gray, int32_t width, int32_t height, int32_t stride)
 {
-    fid_status rc = fid_stag_detect_lines(c, gray, width, height, stride);
-    if (rc != FID_OK) return rc;
-    hipStream_t st = c->stream;
-    const int W = c->W, H = c->H;
-    if (c->kmin_w != W || c->kmin_h != H) {  // the false-alarm table is a function of the image size
-        std::vector<int> kmin;
-        stag_build_kmin(W, H, kmin);
-        if (hipMemcpy(c->d_kmin, kmin.data(), kmin.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return FID_E_HIP;
-        c->kmin_w = W;
-        c->kmin_h = H;
-        c->kmin_n = (int)kmin.size() - 1;
-    }
-    StagLineTables T;
-    T.atan_lut = c->d_atan_lut;
-    T.kmin = c->d_kmin;
-    T.kmin_n = c->kmin_n;
-    const int nl = c->n_lines;
-    if (nl > 0)
-        hipLaunchKernelGGL(k_stag_validate_lines, dim3((nl + 63) / 64), dim3(64), 0, st, c->d_lines, c->d_ltotal, c->d_src, W, H, c->d_vsegs,
-                           c->d_outpix, T, c->d_lflags);
-    hipLaunchKernelGGL(k_stag_scan_counts, dim3(1), dim3(1024), 0, st, c->d_lflags, c->d_ltotal, c->d_vltotal);
-    if (nl > 0)
-        hipLaunchKernelGGL(k_stag_compact_lines, dim3((nl + 255) / 256), dim3(256), 0, st, c->d_lines, c->d_ltotal, c->d_lflags, c->d_vltotal,
-                           c->d_vlines);
-    if (hipGetLastError() != hipSuccess) return FID_E_HIP;
-    if (hipMemcpyAsync(&c->n_vlines, c->d_vltotal, 4, hipMemcpyDeviceToHost, st) != hipSuccess) return FID_E_HIP;
-    if (hipStreamSynchronize(st) != hipSuccess) return FID_E_HIP;
-    c->lines_validated = true;
-    c->quadded = false;
-    return FID_OK;
+    return stag_run_to(c, gray, width, height, stride, SS_LINES_VALIDATED);
 }
 
 fid_status fid_stag_detect_quads(fid_stag_ctx *c, const uint8_t *gray, int32_t width, int32_t height, int32_t stride)
 {
-    fid_status rc = fid_stag_detect_lines_validated(c, gray, width, height, stride);
-    if (rc != FID_OK) return rc;
-    hipStream_t st = c->stream;
-    const int W = c->W, H = c->H, ns = c->n_vsegs, nl = c->n_vlines;
-    if (hipMemsetAsync(c->d_lrange, 0, (size_t)(ns + 1) * sizeof(int2), st) != hipSuccess) return FID_E_HIP;
-    if (nl > 0) hipLaunchKernelGGL(k_stag_line_ranges, dim3((nl + 255) / 256), dim3(256), 0, st, c->d_vlines, c->d_vltotal, c->d_lrange);
-    if (ns > 0)
-        hipLaunchKernelGGL(k_stag_quads, dim3((ns + 3) / 4), dim3(256), 0, st, c->d_vlines, c->d_lrange, c->d_vtotal, c->d_vsegs, c->d_outpix, c->d_src,
-                           W, H, c->d_corners, c->d_order, c->d_qslots, c->d_qcounts);
-    hipLaunchKernelGGL(k_stag_scan_counts, dim3(1), dim3(1024), 0, st, c->d_qcounts, c->d_vtotal, c->d_qtotal);
-    if (ns > 0)
-        hipLaunchKernelGGL(k_stag_gather_quads, dim3((ns + 63) / 64), dim3(64), 0, st, c->d_lrange, c->d_vtotal, c->d_qcounts, c->d_qtotal, c->d_qslots,
-                           c->d_quads);
-    if (hipGetLastError() != hipSuccess) return FID_E_HIP;
-    if (hipMemcpyAsync(&c->n_quads, c->d_qtotal, 4, hipMemcpyDeviceToHost, st) != hipSuccess) return FID_E_HIP;
-    if (hipStreamSynchronize(st) != hipSuccess) return FID_E_HIP;
-    c->quadded = true;
-    c->decoded = false;
-    return FID_OK;
+    return stag_run_to(c, gray, width, height, stride, SS_QUADS);
 }
 
 // the host-made tables of the STag path (functions of the image size alone), without a device: for tests and diagnostics
@@ -847,41 +1003,17 @@ fid_status fid_stag_load_library(fid_stag_ctx *c, const uint64_t *codewords, int
 fid_status fid_stag_detect_markers_unrefined(fid_stag_ctx *c, const uint8_t *gray, int32_t width, int32_t height, int32_t stride)
 {
     if (!c || !c->d_words) return FID_E_INVALID_ARG;  // no marker library loaded
-    fid_status rc = fid_stag_detect_quads(c, gray, width, height, stride);
-    if (rc != FID_OK) return rc;
-    hipStream_t st = c->stream;
-    const int nq = c->n_quads;
-    if (nq > 0)
-        hipLaunchKernelGGL(k_stag_decode, dim3((nq + 3) / 4), dim3(256), 0, st, c->d_quads, c->d_qtotal, c->d_src, c->W, c->H, c->d_locs, c->d_words,
-                           c->n_words, c->errorCorrection, c->d_cand, c->d_found);
-    hipLaunchKernelGGL(k_stag_dedup, dim3(1), dim3(64), 0, st, c->d_cand, c->d_found, c->d_qtotal, c->d_markers, c->d_nmarkers);
-    if (hipGetLastError() != hipSuccess) return FID_E_HIP;
-    if (hipMemcpyAsync(&c->n_markers, c->d_nmarkers, 4, hipMemcpyDeviceToHost, st) != hipSuccess) return FID_E_HIP;
-    if (hipStreamSynchronize(st) != hipSuccess) return FID_E_HIP;
-    c->decoded = true;
-    return FID_OK;
+    return stag_run_to(c, gray, width, height, stride, SS_UNREFINED);
 }
 
 fid_status fid_stag_detect_markers(fid_stag_ctx *c, const uint8_t *gray, int32_t width, int32_t height, int32_t stride, fid_stag_marker *out,
                                    int32_t cap, int32_t *n_out)
 {
-    fid_status rc = fid_stag_detect_markers_unrefined(c, gray, width, height, stride);
-    if (rc != FID_OK) return rc;
-    hipStream_t st = c->stream;
-    if (c->n_markers > 0) {
-        hipLaunchKernelGGL(k_stag_refine, dim3(c->n_markers), dim3(64), 0, st, c->d_markers, c->d_nmarkers, c->d_vsegs, c->d_vtotal, c->d_outpix,
-                           c->d_chosen);
-        if (hipGetLastError() != hipSuccess) return FID_E_HIP;
-    }
-    if (n_out) *n_out = c->n_markers;
-    if (out) {
-        if (c->n_markers > cap) return FID_E_CAPACITY;
-        if (c->n_markers > 0 &&
-            hipMemcpyAsync(out, c->d_markers, (size_t)c->n_markers * sizeof(fid_stag_marker), hipMemcpyDeviceToHost, st) != hipSuccess)
-            return FID_E_HIP;
-    }
-    if (hipStreamSynchronize(st) != hipSuccess) return FID_E_HIP;
-    return FID_OK;
+    if (!c || !c->d_words) return FID_E_INVALID_ARG;
+    StagJob j;
+    j.gray = gray; j.width = width; j.height = height; j.stride = stride; j.last = SS_MARKERS;
+    j.out = out; j.cap = cap; j.n_out = n_out;
+    return stag_run(c, j);
 }
 
 fid_status fid_stag_pose_last(fid_stag_ctx *c, const double K[9], const double D[5], double marker_size, fid_stag_pose_out *out, int32_t cap,
@@ -903,35 +1035,51 @@ fid_status fid_stag_pose_last(fid_stag_ctx *c, const double K[9], const double D
     return hipStreamSynchronize(st) == hipSuccess ? FID_OK : FID_E_HIP;
 }
 
+// Frames over several contexts, ONE host thread: every context carries one frame at a time through the segments of
+// stag_advance; the thread goes round the contexts, one segment each.  A context that finishes a frame takes the next one.
+// Results are those of frame-by-frame calls (a frame never sees another frame's data).
 fid_status fid_stag_detect_markers_batch(fid_stag_ctx *const *ctxs, int32_t nctx, const uint8_t *frames, int32_t nframes, int32_t width, int32_t height,
                                          int32_t stride, int64_t frame_stride, const double K[9], const double D[5], double marker_size,
                                          fid_stag_marker *markers, fid_stag_pose_out *poses, int32_t cap_per_frame, int32_t *n_per_frame)
 {
     if (!ctxs || nctx <= 0 || !frames || nframes < 0 || !markers || !n_per_frame || cap_per_frame <= 0) return FID_E_INVALID_ARG;
     for (int t = 0; t < nctx; t++)
-        if (!ctxs[t]) return FID_E_INVALID_ARG;
-    std::vector<fid_status> rcs((size_t)nctx, FID_OK);
-    for (int f = 0; f < nframes; f++) n_per_frame[f] = 0;  // every count is defined whatever happens to a worker
-    auto work = [&](int t) {
-        for (int f = t; f < nframes; f += nctx) {
-            fid_stag_marker *m = markers + (size_t)f * cap_per_frame;
-            int32_t n = 0;
-            fid_status rc = fid_stag_detect_markers(ctxs[t], frames + (size_t)f * frame_stride, width, height, stride, m, cap_per_frame, &n);
-            n_per_frame[f] = n;
-            if (rc == FID_OK && K && poses) rc = fid_stag_pose_last(ctxs[t], K, D, marker_size, poses + (size_t)f * cap_per_frame, cap_per_frame, &n);
-            if (rc != FID_OK) {
-                if (rcs[t] == FID_OK) rcs[t] = rc;       // the first failure is the call's status ...
-                if (rc != FID_E_CAPACITY) return;        // ... a frame that did not fit costs only that frame
+        if (!ctxs[t] || !ctxs[t]->d_words) return FID_E_INVALID_ARG;
+    if (K && poses && !(marker_size > 0)) return FID_E_INVALID_ARG;
+    for (int f = 0; f < nframes; f++) n_per_frame[f] = 0;  // every count is defined whatever happens to a frame
+    std::vector<StagJob> jobs((size_t)nctx);
+    std::vector<int> frame_of((size_t)nctx, -1);
+    fid_status first_err = FID_OK;
+    bool stop = false;  // a failure other than "this frame did not fit" ends the call
+    int next = 0, live = 0;
+    for (;;) {
+        for (int t = 0; t < nctx; t++) {
+            if (frame_of[t] < 0 && next < nframes && !stop) {  // idle context: next frame
+                const int f = next++;
+                StagJob j;
+                j.gray = frames + (size_t)f * frame_stride; j.width = width; j.height = height; j.stride = stride;
+                j.out = markers + (size_t)f * cap_per_frame; j.cap = cap_per_frame; j.n_out = n_per_frame + f;
+                j.last = (K && poses) ? SS_POSE : SS_MARKERS;
+                j.K = K; j.D = D; j.marker_size = marker_size;
+                j.poses = poses ? poses + (size_t)f * cap_per_frame : nullptr; j.pose_cap = cap_per_frame;
+                jobs[t] = j;
+                frame_of[t] = f;
+                live++;
+            }
+            if (frame_of[t] < 0) continue;
+            (void)stag_advance(ctxs[t], jobs[t]);
+            if (jobs[t].done) {
+                if (jobs[t].rc != FID_OK) {
+                    if (first_err == FID_OK) first_err = jobs[t].rc;  // the first failure is the call's status ...
+                    if (jobs[t].rc != FID_E_CAPACITY) stop = true;     // ... a frame that did not fit costs only that frame
+                }
+                frame_of[t] = -1;
+                live--;
             }
         }
-    };
-    std::vector<std::thread> th;
-    for (int t = 1; t < nctx; t++) th.emplace_back(work, t);
-    work(0);
-    for (auto &x : th) x.join();
-    for (fid_status rc : rcs)
-        if (rc != FID_OK) return rc;
-    return FID_OK;
+        if (live == 0 && (next >= nframes || stop)) break;
+    }
+    return first_err;
 }
 
 int64_t fid_stag_tap_bytes(fid_stag_ctx *c, fid_stag_tap which)

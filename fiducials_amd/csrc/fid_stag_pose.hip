@@ -248,6 +248,46 @@ __device__ double sr_cost(const double x[9], const double Cm[9])
 // picks what it would have evaluated one after the other (the evaluation counter advances as in the sequential solver).
 // The ten vertices of the start simplex and of a shrink step are evaluated by ten lanes.  Same arithmetic per point as the
 // sequential form (column sums in vertex order, the same alpha / beta expressions).
+// wave-wide min / max of doubles on DPP row operations (fid_kernels.hip: FID_DPP_SCAN_STEPS), the result in every lane
+__device__ __forceinline__ double sr_wave_min_f64(double v)
+{
+    unsigned long long u = __double_as_longlong(v);
+    unsigned lo = (unsigned)u, hi = (unsigned)(u >> 32);
+#define S_(C, M)                                                                                              \
+    {                                                                                                         \
+        const unsigned ol = (unsigned)FID_DPP(0, (int)lo, C, M), oh = (unsigned)FID_DPP(0x7ff00000, (int)hi, C, M); \
+        const double o = __longlong_as_double(((unsigned long long)oh << 32) | ol);                           \
+        const double m = fmin(__longlong_as_double(((unsigned long long)hi << 32) | lo), o);                  \
+        const unsigned long long mu = __double_as_longlong(m);                                                \
+        lo = (unsigned)mu;                                                                                    \
+        hi = (unsigned)(mu >> 32);                                                                            \
+    }
+    FID_DPP_SCAN_STEPS(S_)  // (+inf fills the lanes a step does not reach)
+#undef S_
+    lo = (unsigned)__builtin_amdgcn_readlane((int)lo, 63);
+    hi = (unsigned)__builtin_amdgcn_readlane((int)hi, 63);
+    return __longlong_as_double(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ double sr_wave_max_nonneg_f64(double v)  // v >= 0 in every lane
+{
+    unsigned long long u = __double_as_longlong(v);
+    unsigned lo = (unsigned)u, hi = (unsigned)(u >> 32);
+#define S_(C, M)                                                                                    \
+    {                                                                                               \
+        const unsigned ol = (unsigned)FID_DPP(0, (int)lo, C, M), oh = (unsigned)FID_DPP(0, (int)hi, C, M); \
+        const double o = __longlong_as_double(((unsigned long long)oh << 32) | ol);                 \
+        const double m = fmax(__longlong_as_double(((unsigned long long)hi << 32) | lo), o);        \
+        const unsigned long long mu = __double_as_longlong(m);                                      \
+        lo = (unsigned)mu;                                                                          \
+        hi = (unsigned)(mu >> 32);                                                                  \
+    }
+    FID_DPP_SCAN_STEPS(S_)
+#undef S_
+    lo = (unsigned)__builtin_amdgcn_readlane((int)lo, 63);
+    hi = (unsigned)__builtin_amdgcn_readlane((int)hi, 63);
+    return __longlong_as_double(((unsigned long long)hi << 32) | lo);
+}
+
 struct SrSimplex {
     double p[10][9], y[10], sum[9];
 };
@@ -323,9 +363,7 @@ __device__ void sr_downhill(double x[9], const double step[9], const double Cm[9
                 }
                 r = fabs(mx - mn);
             }
-#pragma unroll
-            for (int off = 8; off > 0; off >>= 1) r = fmax(r, __shfl_xor(r, off, 64));
-            range = __shfl(r, 0, 64);
+            range = sr_wave_max_nonneg_f64(r);  // (lanes >= nd carry 0)
         }
         if (range <= 0.000001 || error <= 0.000001 || fcount >= 5000) {
             for (int j = 0; j < nd; j++) x[j] = S->p[ilo][j];
@@ -339,7 +377,7 @@ __device__ void sr_downhill(double x[9], const double step[9], const double Cm[9
             for (int j = 0; j < nd; j++) buf[j] = S->sum[j] * alpha - S->p[ihi][j] * beta;
         }
         const double yl = sr_cost(buf, Cm);
-        const double y_refl = __shfl(yl, 0, 64), y_exp = __shfl(yl, 1, 64), y_con = __shfl(yl, 2, 64);
+        const double y_refl = bcast_f64(yl, 0), y_exp = bcast_f64(yl, 1), y_con = bcast_f64(yl, 2);
         fcount++;
         double alpha = -1.0, y_alpha = y_refl;
         if (y_alpha < y_nhi) {
@@ -438,9 +476,7 @@ __global__ __launch_bounds__(64) void k_stag_refine(fid_stag_marker *__restrict_
                 const double sx = 0.5 + 0.4 * sinVals[(s + 9) % 36], sy = 0.5 + 0.4 * sinVals[s];
                 const double d = act ? sqrt((qx - sx) * (qx - sx) + (qy - sy) * (qy - sy)) : INFINITY;
                 if (d < pixErr) pixErr = d;
-                double mn = d;
-#pragma unroll
-                for (int off = 32; off > 0; off >>= 1) mn = fmin(mn, __shfl_xor(mn, off, 64));
+                const double mn = sr_wave_min_f64(d);
                 if (mn < sampleErr[s]) sampleErr[s] = mn;
             }
             if (__ballot(act && pixErr > 0.1)) bad = true;

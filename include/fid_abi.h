@@ -185,16 +185,23 @@ int32_t fid_last_launches(fid_ctx *ctx);
 void *fid_stream(fid_ctx *ctx);
 
 /* ------------------------------------------------------------------------------------------------------------------
- * STag (stag_detect).  Under construction: this release covers the EDPF edge-detection FRONT END that
- * Stag::detectMarkers (stag_detect/src/stag/Stag.cpp:24-51) reaches through QuadDetector::detectQuads ->
- * EDInterface::runEDPFandEDLines -> DetectEdgesByEDPF (stag_detect/src/stag/ED/ED.cpp:144-187):
- *   SmoothImage(sigma 1.0)            ED/ImageSmooth.cpp:43-55     (cv::GaussianBlur 5x5)
- *   ComputeGradientMapByPrewitt       ED/GradientOperators.cpp:77-136
- *   ComputeAnchorPoints               ED/EDInternals.cpp:50-86
- *   SortAnchorsByGradValue            ED/EDInternals.cpp:146-186
- * i.e. everything in front of the sequential edge routing.  The results stay on the device for the stages that follow
- * (routing, EDLines, quads, decoding, pose refinement: next) and can be read back through the taps.  The constructor
- * mirrors Stag::Stag(int libraryHD, int errorCorrection, bool keepLogs) (include/stag/Stag.h:41). */
+ * STag (stag_detect, BASELINE cfg 5).  Stag::detectMarkers (stag_detect/src/stag/Stag.cpp:24-51) and the pose step of
+ * StagNode::imageCallback (stag_detect/src/stag_ros/stag_detect.cpp:110-217), end to end on the device.  Every stage has its
+ * own entry point so that it can be checked on its own against the reference's sources (tests/test_gpu_stag.py); each entry
+ * point runs the pipeline from the frame up to and including its stage and leaves the results on the device (taps):
+ *   fid_stag_edge_frontend             SmoothImage 5x5 + ComputeGradientMapByPrewitt + ComputeAnchorPoints +
+ *                                      SortAnchorsByGradValue        ED/ED.cpp:144-187, ImageSmooth.cpp:43-55,
+ *                                                                    GradientOperators.cpp:77-136, EDInternals.cpp:50-186
+ *   fid_stag_detect_edges              JoinAnchorPointsUsingSortedAnchors (smart routing)   ED/EDInternals.cpp:842-1448
+ *   fid_stag_detect_edges_validated    ValidateEdgeSegments                                 ED/ValidateEdgeSegments.cpp:365-413
+ *   fid_stag_detect_lines / _validated SplitSegment2Lines, JoinCollinearLines, ValidateLineSegments   ED/EDLines.cpp:114-409
+ *   fid_stag_detect_quads              QuadDetector::detectQuads                            QuadDetector.cpp:12-127
+ *   fid_stag_detect_markers_unrefined  readCode, Decoder::decode, checkDuplicate            Stag.cpp:57-127
+ *   fid_stag_detect_markers            + PoseRefiner::refineMarkerPose = Stag::detectMarkers PoseRefiner.cpp:12-190
+ *   fid_stag_pose_last                 Common::solvePnpSingle on centre + 4 corners         common.hpp:34-46
+ *   fid_stag_detect_markers_batch      frames over several contexts (host threads inside the library)
+ * The constructor mirrors Stag::Stag(int libraryHD, int errorCorrection, bool keepLogs) (include/stag/Stag.h:41); the
+ * marker library (the published HDxx codewords) is handed over with fid_stag_load_library like the aruco dictionary. */
 typedef struct fid_stag_ctx fid_stag_ctx;
 /* LineSegment (stag_detect/include/stag/ED/LineSegment.h:4-14): y = a + b x (invert 0) or x = a + b y (invert 1) */
 typedef struct fid_stag_line {

@@ -49,7 +49,9 @@ struct fid_ctx {
     // seed-accelerated tracing
     DevSeg *d_segs = nullptr;
     DevPend *d_pend = nullptr;
-    uint2 *d_seedq = nullptr, *d_seedplane = nullptr;
+    uint2 *d_seedq = nullptr;
+    unsigned long long *d_seedhash = nullptr;  // per frame: seed state -> seed index (SeedHash, fid_kernels.hip)
+    int seed_hash_cap = 0, seed_gen = 0;
     uint4 *d_wres = nullptr, *d_cinfo = nullptr;
     uint32_t *d_cbase = nullptr, *d_dense = nullptr;
     uint4 *d_recs = nullptr;  // copy records: pieces of the accepted contours
@@ -61,7 +63,7 @@ struct fid_ctx {
     int walk_blocks = 0;  // one-wave workgroups per frame in the full walk pass (0 = automatic)
     int walk_blocks_cap = 64;  // (the walks of a single frame want every seed in flight at once)
     int copy_blocks = 0;
-    int seed_shift = 0;        // FID_SEED_SHIFT: force the seed lattice spacing (0 = by call size)
+    int seed_shift = 0;        // FID_SEED_SHIFT: force the seed grid spacing 8 << shift (0 = by call size)
     uint4 *d_contours = nullptr;
     uint32_t *d_ckpts = nullptr;
     size_t ckpts_elems = 0;
@@ -213,14 +215,14 @@ void set_geometry(fid_ctx *c, int W, int H, int gstride, int F)
     P.maxCands = c->lim.max_candidates_per_frame;
     P.maxMarkers = c->lim.max_markers_per_frame;
     P.maxChunks = c->max_chunks;
-    // tracing seeds: the denser the lattice, the shorter the longest seed-free stretch (the latency of a single frame) and the
-    // more segments (tables, link / chain work).  Small calls take the densest lattice their tables have room for.
+    // tracing seeds: the denser the grid, the shorter the longest seed-free stretch (the latency of a single frame) and the
+    // more segments (tables, link / chain work).  Small calls take the densest grid their tables have room for.
     {
-        int sh = SEED_SHIFT_MAX;
-        if (F <= 4 && P.maxContours >= 65536 && c->max_chunks >= 4 * 65536) sh = 2;
-        else if (F <= 16 && P.maxContours >= 32768 && c->max_chunks >= 2 * 65536) sh = 3;
+        int sh = 4;  // 128 px: batches (measured on the 256-frame bench batch: 64 px and 256 px are both slower)
+        if (F <= 16 && P.maxContours >= 32768 && c->max_chunks >= 2 * 65536) sh = 3;  // 64 px (one frame: 1.52 ms against 1.61 / 1.63 ms for 32 / 128 px)
         if (c->seed_shift > 0) sh = c->seed_shift;
         P.seedShift = sh < SEED_SHIFT_MIN ? SEED_SHIFT_MIN : (sh > SEED_SHIFT_MAX ? SEED_SHIFT_MAX : sh);
+        P.seedHashCap = c->seed_hash_cap;
     }
 }
 
@@ -248,6 +250,14 @@ fid_status run_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H, int
     const long long gfstride = to_gray ? (long long)W * H : fstride;
     const uint8_t *gray = to_gray ? c->d_gray : d_src;
     set_geometry(c, W, H, gstride, F);
+    if (c->d_seedhash) {
+        // a new generation makes every entry of the seed hash tables stale; clear them when the 10-bit number wraps
+        if (++c->seed_gen > 1023) {
+            HIPCHK(c, hipMemsetAsync(c->d_seedhash, 0, (size_t)c->lim.max_batch * c->seed_hash_cap * sizeof(unsigned long long), st0));
+            c->seed_gen = 1;
+        }
+        c->P.seedGen = c->seed_gen;
+    }
     // masks pad words must be zero; re-zero when the layout changes
     if (c->masks_W != W || c->masks_H != H || c->masks_S != c->P.nscales) {
         HIPCHK(c, hipMemsetAsync(c->d_masks, 0, c->masks_bytes, st0));
@@ -350,7 +360,7 @@ fid_status run_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H, int
         const size_t lds2 = (size_t)(P.maxPerim + 1) * sizeof(uint32_t) + (size_t)K4_LONG_STACK * sizeof(int2);
         if (c->trace_mode == 0) {
             hipLaunchKernelGGL(k_find_starts<false>, dim3((unsigned)k2blocks, Fs), dim3(256), 0, st, masks, starts, counts, c->d_global,
-                               (uint2 *)nullptr, (uint2 *)nullptr, P);
+                               (uint2 *)nullptr, P);
             mark(ST_STARTS + 1);
             // ---- K3: sieve the starts twice, then walk the survivors to the end
             hipLaunchKernelGGL((k_probe<PROBE0_STEPS, 0>), dim3(64, Fs), dim3(256), 0, st, masks, starts, surv1, counts, c->d_global, P);
@@ -372,12 +382,12 @@ fid_status run_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H, int
             DevSeg *segs = c->d_segs + f0 * MCn;
             DevPend *pend = c->d_pend + f0 * MCn;
             uint2 *seedq = c->d_seedq + f0 * MCn;
-            uint2 *seedplane = c->d_seedplane + (size_t)f0 * P.nscales * P.TR * P.TC * MT_ROWS;
+            unsigned long long *seedhash = c->d_seedhash + (size_t)f0 * P.seedHashCap;
             uint4 *wres = c->d_wres + f0 * MCn, *cinfo = c->d_cinfo + f0 * MCn;
             uint32_t *cbase = c->d_cbase + f0 * MCn;
             uint32_t *dense = c->d_dense + (size_t)f0 * P.maxChunks * CK;
             hipLaunchKernelGGL(k_find_starts<true>, dim3((unsigned)k2blocks, Fs), dim3(256), 0, st, masks, starts, counts, c->d_global,
-                               seedq, seedplane, P);
+                               seedq, P);
             mark(ST_STARTS + 1);
             // the seed walk needs only the seeds: it runs on its own stream beside the probe passes and the survivor walk
             // (both walks are a throughput phase followed by a tail of a few long walkers; side by side the tails overlap)
@@ -396,7 +406,8 @@ fid_status run_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H, int
             hipLaunchKernelGGL(k_walk_full<2>, dim3(wb2, Fs), dim3(64 * WALK_WAVES), 0, st, masks, surv, wres, tab, pool, segs, pend, counts,
                                c->d_global, P);
             HIPCHK(c, hipStreamWaitEvent(st, c->aux_join[sb], 0));
-            hipLaunchKernelGGL(k_seg_link, dim3(16, Fs), dim3(256), 0, st, seedq, segs, surv, pend, seedplane, counts, c->d_global, P);
+            hipLaunchKernelGGL(k_seed_index, dim3(8, Fs), dim3(256), 0, st, seedq, seedhash, counts, P);
+            hipLaunchKernelGGL(k_seg_link, dim3(16, Fs), dim3(256), 0, st, seedq, segs, surv, pend, seedhash, counts, c->d_global, P);
             uint4 *recs = c->d_recs + 2 * f0 * MCn;
             hipLaunchKernelGGL(k_seg_chain, dim3(16, Fs), dim3(64), 0, st, surv, pend, wres, segs, contours, cinfo, cbase, recs, counts,
                                c->d_global, P);
@@ -474,6 +485,10 @@ fid_status run_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H, int
         fprintf(stderr, "walk waves %llu: total cyc avg %.0f max %llu; own queue dry at avg %.0f max %llu\n", d[12],
                 d[12] ? (double)d[8] / d[12] : 0., d[9], d[12] ? (double)d[10] / d[12] : 0., d[11]);
         fprintf(stderr, "walk longest %llu steps, total steps %llu\n", d[13], d[14]);
+        if (d[1])
+            fprintf(stderr, "checkpoint cycles: wait %.0f activate %.0f retire %.0f hand-out %.0f chunks %.0f refill %.0f; lanes at a checkpoint: need %.1f loading %.1f final %.1f idle %.1f\n",
+                    (double)d[4] / d[1], (double)d[16] / d[1], (double)d[17] / d[1], (double)d[18] / d[1], (double)d[19] / d[1], (double)d[20] / d[1],
+                    (double)d[21] / d[1], (double)d[22] / d[1], (double)d[23] / d[1], (double)d[24] / d[1]);
     }
 #endif
     if (c->trace_mode == 1 && (c->h_global->overflow & (2u | 8u))) {
@@ -580,7 +595,7 @@ fid_status fid_create(const fid_params *params, const fid_dict *dict, const fid_
         if (limits->max_markers_per_frame > 0) L.max_markers_per_frame = limits->max_markers_per_frame;
         if (limits->max_points_per_frame > 0) L.max_points_per_frame = limits->max_points_per_frame;
     }
-    // contexts for a few frames at a time (the node's shape, max_batch 1) get room for the dense seed lattice by default
+    // contexts for a few frames at a time (the node's shape, max_batch 1) get room for the denser seed grid by default
     if (L.max_batch <= 4) {
         if (!limits || limits->max_contours_per_frame <= 0) L.max_contours_per_frame = 65536;
         if (!limits || limits->max_points_per_frame <= 0) L.max_points_per_frame = 16 * 1024 * 1024;
@@ -589,7 +604,8 @@ fid_status fid_create(const fid_params *params, const fid_dict *dict, const fid_
         if (!limits || limits->max_points_per_frame <= 0) L.max_points_per_frame = 8 * 1024 * 1024;
     }
     L.max_candidates_per_frame = roundup(L.max_candidates_per_frame, 32);
-    if (L.max_candidates_per_frame > 4096 || L.max_batch > 65535 || L.max_markers_per_frame > L.max_candidates_per_frame) {
+    if (L.max_candidates_per_frame > 4096 || L.max_batch > 65535 || L.max_markers_per_frame > L.max_candidates_per_frame ||
+        L.max_contours_per_frame > (1 << 20)) {  // (seed indices are 20-bit fields of the SeedHash entries)
         delete c;
         return FID_E_INVALID_ARG;
     }
@@ -665,12 +681,13 @@ fid_status fid_create(const fid_params *params, const fid_dict *dict, const fid_
     TRY(dalloc(c, &c->d_pool, F * (size_t)c->max_chunks * CK));
     c->trace_mode = getenv("FID_TRACE") && !strcmp(getenv("FID_TRACE"), "legacy") ? 0 : 1;
     if (c->trace_mode == 1) {
-        const size_t plane_words = masks_elems(c, L.max_width, L.max_height, (int)F);
         TRY(dalloc(c, &c->d_segs, F * L.max_contours_per_frame));
         TRY(dalloc(c, &c->d_pend, F * L.max_contours_per_frame));
         TRY(dalloc(c, &c->d_seedq, F * L.max_contours_per_frame));
-        (void)plane_words;
-        TRY(dalloc(c, &c->d_seedplane, c->masks_bytes / sizeof(uint32_t)));  // one uint2 per mask word, same margin as d_masks
+        c->seed_hash_cap = 1;
+        while (c->seed_hash_cap < 2 * L.max_contours_per_frame) c->seed_hash_cap *= 2;
+        TRY(dalloc(c, &c->d_seedhash, F * (size_t)c->seed_hash_cap));
+        TRYHIP(hipMemset(c->d_seedhash, 0, F * (size_t)c->seed_hash_cap * sizeof(unsigned long long)));
         TRY(dalloc(c, &c->d_wres, F * L.max_contours_per_frame));
         TRY(dalloc(c, &c->d_cinfo, F * L.max_contours_per_frame));
         TRY(dalloc(c, &c->d_cbase, F * L.max_contours_per_frame));
@@ -720,7 +737,7 @@ void fid_destroy(fid_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    void *dev[] = {c->d_in, c->d_gray, c->d_masks, c->d_starts, c->d_surv1, c->d_surv, c->d_pool, c->d_segs, c->d_pend, c->d_seedq, c->d_seedplane, c->d_wres, c->d_cinfo, c->d_cbase, c->d_dense, c->d_recs, c->d_contours, c->d_ckpts, c->d_cands, c->d_sorted, c->d_cmeta, c->d_filtered, c->d_near,
+    void *dev[] = {c->d_in, c->d_gray, c->d_masks, c->d_starts, c->d_surv1, c->d_surv, c->d_pool, c->d_segs, c->d_pend, c->d_seedq, c->d_seedhash, c->d_wres, c->d_cinfo, c->d_cbase, c->d_dense, c->d_recs, c->d_contours, c->d_ckpts, c->d_cands, c->d_sorted, c->d_cmeta, c->d_filtered, c->d_near,
                    c->d_ident, c->d_pre, c->d_markers, c->d_poses, c->d_counts, c->d_global, c->d_worklist, c->d_nwork, c->d_dict,
                    c->d_subpix_mask, c->d_lens, c->d_pose_in, c->d_pose_n};
     for (void *p : dev)
@@ -756,8 +773,7 @@ fid_status fid_set_params(fid_ctx *c, const fid_params *p)
     fid_params keep = c->params;
     fid_status rc = apply_params(c, p);
     if (rc == FID_OK && c->P.nscales > old_scales) {
-        // the masks buffer and the seed-index plane (one uint2 per mask word) were sized for the scale count at creation
-        // (plus the same margin): a larger scale count must fit both
+        // the masks buffer was sized for the scale count at creation (plus a margin): a larger scale count must fit
         size_t need = masks_elems(c, c->lim.max_width, c->lim.max_height, c->lim.max_batch) * sizeof(uint32_t);
         if (need > c->masks_bytes) {
             (void)apply_params(c, &keep);

@@ -45,7 +45,9 @@ struct DevParams {
     int refine;
     int maxStarts, maxContours, maxCands, maxMarkers;  // per-frame capacities
     int maxChunks;                                     // per-frame pool of CK-point contour chunks
-    int seedShift;                                     // tracing seeds: lattice class spacing 2^seedShift pixels
+    int seedShift;                                     // tracing seeds: grid spacing G = 8 << seedShift pixels
+    int seedHashCap;                                   // entries of the per-frame state -> seed index hash table (power of two)
+    int seedGen;                                       // this call's generation number in that table (1..1023)
 };
 
 // word index of padded row yy, word column wi inside one (frame, scale) mask plane of TC tile columns
@@ -69,30 +71,36 @@ struct DevIdent {
 };
 
 // ---- seed-accelerated contour tracing.  A border-following state is (pixel, direction d back to the previous pixel).
-// SEED states are the states a walker can recognise from what it holds anyway: the pixel sits on the class-d position of
-// the thinning lattice (seed_class) and the neighbour X(d) that border following must have found empty on the way in
-// (the one "to the right of travel": direction d+2 for an axis move, d+1 for a diagonal one) is background.  Every seed
-// follows its border only to the next seed state (a SEGMENT); a probe survivor follows its border only to the first seed
-// state and the rest of the border is read off the segment chain.
-// lattice: k = (x - 5 y) mod (8 << shift); a pixel carries class d = k >> shift when k is a multiple of the class
-// spacing, no class otherwise
-// The class spacing 2^shift pixels is a run-time parameter (DevParams::seedShift, 2 .. 4): the longest seed-free stretch of a
-// border -- what a single frame waits for -- shrinks with the spacing, the number of segments (table space, link / chain work)
-// grows with it; large batches use 16 px, single frames 4 px.  Any lattice yields the same contours.
-#define SEED_SHIFT_MIN 2  // the period 8 << shift must cover a 32-pixel mask word: a class sits at most once in a word
-#define SEED_SHIFT_MAX 4
-__host__ __device__ inline int seed_class(int x, int y, int shift)
+// SEED states are states a walker can recognise from what it holds anyway and that k_find_starts can enumerate from the bit
+// planes: the state's pixel lies on a GRID LINE it has just stepped onto -- a column x = 0 (mod G) entered with a horizontal
+// component (d in E, NE, NW, W, SW, SE), or a row y = 0 (mod G) entered with a vertical component (d in NE, N, NW, SW, S, SE) --
+// and the neighbour X(d) that border following must have found empty on the way in (the one "to the right of travel":
+// direction d+2 for an axis move, d+1 for a diagonal one) is background.  Every seed follows its border only to the next
+// seed state (a SEGMENT); a probe survivor follows its border only to the first seed state and the rest of the border is read
+// off the segment chain.
+// Why grid lines: a border cannot move G pixels in x or in y without stepping onto one, so the seed-free stretches are
+// BOUNDED (about 2 G steps for anything but a border that curls up inside one G x G cell) -- the longest sequential piece of
+// the whole tracing.  (Round 1 / early round 2 used a thinning lattice, one class per pixel: same seed count, but the gaps
+// were geometrically distributed, 1434 steps at worst in the 256-frame bench batch against a mean of 110, and the walker
+// kernels lasted as long as that one walker.)  Several states of one pixel can be seeds, so a seed is identified by
+// (pixel, d): seed records carry d, and the map state -> seed index is a per-frame hash table (SeedHash).
+// G = 8 << DevParams::seedShift: 128 px for batches, down to 32 px for single frames (the spacing trades the longest stretch
+// against the number of segments).  Any rule yields the same contours.
+#define SEED_SHIFT_MIN 2
+#define SEED_SHIFT_MAX 5
+#define SEED_DIRS_COL 0xBBu  // back directions with a horizontal component: 0 E, 1 NE, 3 NW, 4 W, 5 SW, 7 SE
+#define SEED_DIRS_ROW 0xEEu  // back directions with a vertical component:   1 NE, 2 N, 3 NW, 5 SW, 6 S, 7 SE
+__host__ __device__ inline bool seed_state(int x, int y, int d, int gmask /* G - 1 */)
 {
-    const int k = (x - 5 * y) & ((8 << shift) - 1);
-    return (k & ((1 << shift) - 1)) ? -1 : (k >> shift);
+    return (((x & gmask) == 0) && ((SEED_DIRS_COL >> d) & 1u)) || (((y & gmask) == 0) && ((SEED_DIRS_ROW >> d) & 1u));
 }
-// the same test for a known back direction d: is (x, y) the class-d position?
-__host__ __device__ inline bool seed_class_is(int x, int y, int d, int shift) { return ((x - 5 * y) & ((8 << shift) - 1)) == (d << shift); }
+// state key of a seed / of the state a walker stopped in front of: x | y << 13 | d << 26
+__host__ __device__ inline uint32_t seed_key(int x, int y, int d) { return (uint32_t)x | ((uint32_t)y << 13) | ((uint32_t)d << 26); }
 // the neighbour direction that is empty when a state with back direction d was entered
 __host__ __device__ inline int seed_empty_dir(int d) { return (d + ((d & 1) ? 1 : 2)) & 7; }
 #define SEG_INVALID 0xffffffffu
 struct DevSeg {           // one per seed
-    uint32_t next_key;    // pixel of the seed state the segment ran into: x | y << 13 (same scale)
+    uint32_t next_key;    // the seed state the segment ran into: x | y << 13 | d << 26 (same scale)
     uint32_t next_idx;    // ... and that seed's index (filled in by k_seg_link)
     uint32_t n;           // states in the segment (SEG_INVALID: longer than maxPerimeterPixels / pool exhausted)
     uint32_t mout;        // min raster index (pidx) over the segment's pixels
@@ -101,7 +109,7 @@ struct DevSeg {           // one per seed
 };
 struct DevPend {          // one per probe survivor that stopped in front of a seed state
     uint32_t p;           // states it walked itself (0 = not stopped: the survivor closed or died on its own)
-    uint32_t next_key;    // pixel of that seed state
+    uint32_t next_key;    // that seed state: x | y << 13 | d << 26
     uint32_t next_idx;    // its seed index (k_seg_link)
     uint32_t pad;
 };
@@ -130,5 +138,5 @@ struct DevCounts {
 struct DevGlobal {
     unsigned overflow;  // bit0 starts/survivors, bit1 contours, bit2 approxPolyDP stack, bit3 point pool
     unsigned pad[3];
-    unsigned long long dbg[16];  // FID_DEBUG_STATS builds: walk-loop statistics
+    unsigned long long dbg[32];  // FID_DEBUG_STATS builds: walk-loop statistics
 };

@@ -703,6 +703,44 @@ __global__ __launch_bounds__(64 * (NW + 1)) void k_threshold_stream(const uint8_
     }
 }
 
+// ---- SeedHash: seed state -> seed index, one open-addressing table of 64-bit entries per frame.
+// entry = generation (10 bits, 54..63) | state (x | y << 13 | d << 26 | scale << 29: 34 bits, 20..53) | seed index (20 bits).
+// The generation is a per-call number (1..1023): entries of earlier calls count as empty, so the table is never cleared
+// between calls (the host clears it when the number wraps).  Inserts (k_seed_index) and lookups (k_seg_link) are in
+// different kernels; the table holds at most maxContours entries in >= 2 maxContours slots.
+__device__ __forceinline__ unsigned long long seedhash_key(uint32_t state, int scale) { return (unsigned long long)state | ((unsigned long long)scale << 29); }
+__device__ __forceinline__ unsigned seedhash_slot(unsigned long long key, int cap)
+{
+    return (unsigned)((key * 0x9E3779B97F4A7C15ull) >> 40) & (unsigned)(cap - 1);
+}
+__device__ __forceinline__ void seedhash_insert(unsigned long long *__restrict__ tab, int cap, int gen, unsigned long long key, unsigned idx)
+{
+    const unsigned long long ent = ((unsigned long long)gen << 54) | (key << 20) | idx;
+    unsigned h = seedhash_slot(key, cap);
+    unsigned long long old = tab[h];
+    for (;;) {
+        if ((int)(old >> 54) != gen) {
+            const unsigned long long prev = atomicCAS(&tab[h], old, ent);
+            if (prev == old) return;
+            old = prev;  // somebody else's entry of this call: move on (checked again at the top)
+            continue;
+        }
+        h = (h + 1) & (unsigned)(cap - 1);
+        old = tab[h];
+    }
+}
+__device__ __forceinline__ unsigned seedhash_find(const unsigned long long *__restrict__ tab, int cap, int gen, unsigned long long key)
+{
+    unsigned h = seedhash_slot(key, cap);
+    for (int probes = 0; probes < cap; probes++) {
+        const unsigned long long e = tab[h];
+        if ((int)(e >> 54) != gen) return SEG_INVALID;
+        if (((e >> 20) & 0x3ffffffffull) == key) return (unsigned)(e & 0xfffffu);
+        h = (h + 1) & (unsigned)(cap - 1);
+    }
+    return SEG_INVALID;
+}
+
 // ------------------------------------------------------------------------------------------------
 // K2: start points of Suzuki-Abe border following, found without the sequential raster scan.
 //   outer border start: the first pixel of a horizontal foreground run whose W neighbour is background
@@ -736,12 +774,12 @@ __device__ __forceinline__ uint32_t fill_toward_lsb(uint32_t seed, uint32_t runs
 // Two kinds of starts are dropped on the spot because their border is shorter than any perimeter gate
 // (when minPerimeterPixels allows it): isolated foreground pixels (a 1-point outer border) and isolated
 // background pixels (a hole border of at most 8 points).
-// HYB = true additionally emits the SEEDS of seed-accelerated tracing (fid_device.h): foreground pixels on the class-d
-// position of the thinning lattice whose neighbour in direction d is foreground and whose neighbour in direction
-// seed_empty_dir(d) is background.  Seeds go to their own list (x | y << 13 | scale << 27, seed index) and, per mask
-// word, {index of the word's first seed, seed bit mask} goes to the seed-index plane so that a pixel is mapped to its
-// seed index without any hashing.  (A seed need not lie on a real border state: such a seed walks into a real border
-// and nobody ever links to it.)
+// HYB = true additionally emits the SEEDS of seed-accelerated tracing (fid_device.h): states (pixel, d) on a grid line -- all
+// pixels of a grid row with the vertical-component directions, bit 0 of the words that start on a grid column with the
+// horizontal-component ones -- whose neighbour in direction d is foreground and whose neighbour in direction
+// seed_empty_dir(d) is background.  Seeds go to their own list (x | y << 13 | scale << 27, d); k_seed_index then builds the
+// map state -> seed index (SeedHash above).  (A seed need not lie on a real border state: such a seed walks into a real
+// border and nobody ever links to it.)
 // Two groups per wave and iteration, in two phases: (A) every lane loads the four rows of its word column of both groups
 // (one 16-byte load each) and drops the word columns that are all background -- such a word cannot hold a start or a seed
 // whatever its neighbours are, and about half of them are; (B) the remaining (word column, four rows) ITEMS of the two
@@ -750,7 +788,7 @@ __device__ __forceinline__ uint32_t fill_toward_lsb(uint32_t seed, uint32_t runs
 template <bool HYB>
 __global__ __launch_bounds__(256) void k_find_starts(const uint32_t *__restrict__ masks, uint2 *__restrict__ starts,
                                                       DevCounts *__restrict__ counts, DevGlobal *__restrict__ G,
-                                                      uint2 *__restrict__ seedq, uint2 *__restrict__ seedplane, const DevParams P)
+                                                      uint2 *__restrict__ seedq, const DevParams P)
 {
     __shared__ int s_wsum[2][4];
     __shared__ unsigned s_base[2];
@@ -765,6 +803,7 @@ __global__ __launch_bounds__(256) void k_find_starts(const uint32_t *__restrict_
     const bool drop1 = P.minPerim > 1, drop8 = P.minPerim > 8;
     uint2 *fst = starts + (long long)f * P.maxStarts;
     uint2 *fsq = HYB ? seedq + (long long)f * P.maxContours : nullptr;
+    const int gm = (8 << P.seedShift) - 1;  // seed grid spacing - 1
     const uint32_t *fmasks = masks + (long long)f * S * plane;
     // XCD-aware order: a group also reads one row of the tile rows above and below it (whole 64-byte lines for one word).
     // Workgroup b runs on XCD b % 8 (MI355X_MICROARCH.md) and every XCD has its own L2, so the tile rows of one (scale,
@@ -807,16 +846,18 @@ __global__ __launch_bounds__(256) void k_find_starts(const uint32_t *__restrict_
         }
         const int nsel = __popcll(msel[0]) + __popcll(msel[1]);  // wave-uniform
         // ---- phase B: at most two rounds of 64 items
-        uint32_t outer[2][4], hole[2][4], seedo[2][4];
-        int x_base[2], yy0v[2], sv[2], cntv[2], scntv[2];
-        long long word0v[2];
+        uint32_t outer[2][4], hole[2][4];
+        uint32_t rowm[2][6], colb[2];  // seeds: the item's grid row (six directions x 32 pixels), bit 0 of its four rows x 8 directions
+        int x_base[2], yy0v[2], sv[2], cntv[2], scntv[2], rowk[2];
         int cnt = 0, scnt = 0;
 #pragma unroll
         for (int r = 0; r < 2; r++) {
 #pragma unroll
-            for (int k = 0; k < 4; k++) outer[r][k] = hole[r][k] = seedo[r][k] = 0;
-            x_base[r] = yy0v[r] = sv[r] = cntv[r] = scntv[r] = 0;
-            word0v[r] = 0;
+            for (int k = 0; k < 4; k++) outer[r][k] = hole[r][k] = 0;
+#pragma unroll
+            for (int k = 0; k < 6; k++) rowm[r][k] = 0;
+            colb[r] = 0;
+            x_base[r] = yy0v[r] = sv[r] = cntv[r] = scntv[r] = rowk[r] = 0;
             if (r * 64 >= nsel) continue;  // wave-uniform
             const int idx = r * 64 + lane;
             if (idx < nsel) {
@@ -884,25 +925,37 @@ __global__ __launch_bounds__(256) void k_find_starts(const uint32_t *__restrict_
                     hole[r][k] = (e >> 1) | (en0 << 31);
                     c1 += __popc(outer[r][k]) + __popc(hole[r][k]);
                     if (HYB) {
-                        // seed states: class d of the lattice owns at most one pixel of this word; the pixel is a seed when
-                        // its neighbour in direction d (the previous pixel) is foreground and the one in direction
-                        // seed_empty_dir(d) is background
-                        const uint32_t SEst = (d >> 1) | (nextd << 31), SWst = (d << 1) | (prevd >> 31);
-                        const uint32_t nbp[8] = {Est, NE, u, NW, Wst, SWst, d, SEst};  // neighbour planes by direction
-                        uint32_t sm = 0;
+                        // seed states on a grid row (every pixel, vertical-component directions) and on a grid column (bit 0
+                        // of a word that starts on one, horizontal-component directions; the diagonal ones of a pixel that is
+                        // on both lines belong to the row)
+                        const bool grow = (y & gm) == 0, gcol = (xb & gm) == 0;
+                        if (grow || gcol) {
+                            const uint32_t SEst = (d >> 1) | (nextd << 31), SWst = (d << 1) | (prevd >> 31);
+                            const uint32_t nbp[8] = {Est, NE, u, NW, Wst, SWst, d, SEst};  // neighbour planes by direction
+                            int ri = 0;
 #pragma unroll
-                        for (int dd = 0; dd < 8; dd++) {
-                            const unsigned bb = (unsigned)(5 * y + (dd << P.seedShift) - xb) & (unsigned)((8 << P.seedShift) - 1);
-                            if (bb < 32u) sm |= cur & nbp[dd] & ~nbp[seed_empty_dir(dd)] & (1u << bb);
+                            for (int dd = 0; dd < 8; dd++) {
+                                const uint32_t m = cur & nbp[dd] & ~nbp[seed_empty_dir(dd)];
+                                const bool isrow = (SEED_DIRS_ROW >> dd) & 1u, iscol = (SEED_DIRS_COL >> dd) & 1u;
+                                if (isrow) {
+                                    if (grow) {
+                                        rowm[r][ri] = m;
+                                        c2 += __popc(m);
+                                    }
+                                    ri++;
+                                }
+                                if (iscol && gcol && !(isrow && grow) && (m & 1u)) {
+                                    colb[r] |= 1u << (k * 8 + dd);
+                                    c2++;
+                                }
+                            }
+                            if (grow) rowk[r] = k;
                         }
-                        seedo[r][k] = sm;
-                        c2 += __popc(sm);
                     }
                 }
                 x_base[r] = xb;
                 yy0v[r] = yy0;
                 sv[r] = s;
-                word0v[r] = word0;
                 cntv[r] = c1;
                 scntv[r] = c2;
                 cnt += c1;
@@ -961,22 +1014,32 @@ __global__ __launch_bounds__(256) void k_find_starts(const uint32_t *__restrict_
         }
         if (HYB && stot) {
             unsigned off = s_base[1] + (unsigned)(swbase + sincl - scnt);
+            auto emit = [&](int x, int y, int sc, int dd) {
+                if (off < scap) fsq[off] = make_uint2((uint32_t)x | ((uint32_t)y << 13) | ((uint32_t)sc << 27), (uint32_t)dd);
+                off++;
+            };
 #pragma unroll
             for (int r = 0; r < 2; r++) {
                 if (!scntv[r]) continue;
-                uint2 *spl = seedplane + ((long long)f * S + sv[r]) * plane + word0v[r];
+                {
+                    const int y = yy0v[r] + rowk[r] - 1;
+                    int ri = 0;
 #pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const uint32_t y = (uint32_t)(yy0v[r] + k - 1);
-                    uint32_t both = seedo[r][k];
-                    if (both) spl[k] = make_uint2(off, both);
-                    while (both) {
-                        int b = __ffs(both) - 1;
-                        both &= both - 1;
-                        if (off < scap)
-                            fsq[off] = make_uint2((uint32_t)(x_base[r] + b) | (y << 13) | ((uint32_t)sv[r] << 27), off);
-                        off++;
+                    for (int dd = 0; dd < 8; dd++) {
+                        if (!((SEED_DIRS_ROW >> dd) & 1u)) continue;
+                        uint32_t m = rowm[r][ri++];
+                        while (m) {
+                            const int b = __ffs(m) - 1;
+                            m &= m - 1;
+                            emit(x_base[r] + b, y, sv[r], dd);
+                        }
                     }
+                }
+                uint32_t cb = colb[r];
+                while (cb) {
+                    const int b = __ffs(cb) - 1;
+                    cb &= cb - 1;
+                    emit(x_base[r], yy0v[r] + (b >> 3) - 1, sv[r], b & 7);
                 }
             }
             if (threadIdx.x == 0 && s_base[1] + (unsigned)stot > scap) atomicOr(&G->overflow, 2u);
@@ -1228,7 +1291,7 @@ __device__ __forceinline__ void build_step_lut(uint8_t *lut, int tid, int nthrea
         unsigned seen = 0;
         for (int q = 0; q < t; q++) seen |= 1u << ((start + q) & 7);
         const int code = (seen & 4u) ? 5 : (seen & 16u) ? 4 : (seen & 1u) ? 6 : (seen & 64u) ? 7 : 0;
-        // seed-state flag (to be combined with the lattice test seed_class(x, y) == sd by the walker)
+        // seed-state flag (to be combined with the grid-line test seed_state(x, y, sd) by the walker)
         const int seed = ((nb >> sd) & 1u) && !((nb >> seed_empty_dir(sd)) & 1u);
         lut[e] = (uint8_t)(((start + t) & 7) | (code << 3) | (seed << 6));
     }
@@ -1287,6 +1350,7 @@ __global__ __launch_bounds__(64 * WALK_WAVES) void k_walk_full(const uint32_t *_
     const unsigned ccap = (unsigned)P.maxContours, pcap = (unsigned)P.maxChunks * (unsigned)P.nframes;
     const int W = P.W, S = P.nscales, TC = P.TC, TR = P.TR, F = P.nframes;
     const int W2 = W + 2;
+    const int sgm = (8 << P.seedShift) - 1;  // seed grid spacing - 1
     const int nck = chunk_tab_pitch(P);
     const long long plane = (long long)TR * TC * MT_ROWS;
     enum { ST_IDLE = 0, ST_ACTIVE, ST_NEED, ST_LOADING, ST_FINAL };
@@ -1338,6 +1402,13 @@ __global__ __launch_bounds__(64 * WALK_WAVES) void k_walk_full(const uint32_t *_
         unsigned arena_next = 0, arena_end = 0;  // wave-uniform
 #ifdef FID_DEBUG_STATS
         unsigned long long d_iters = 0, d_ckpts = 0, d_active = 0, d_ckcyc = 0, d_waitcyc = 0, d_forced = 0;
+        unsigned long long d_seg[5] = {0, 0, 0, 0, 0}, d_lanes[4] = {0, 0, 0, 0}, d_mark = 0;
+#define FID_DSEG(K)                                            \
+    {                                                          \
+        const unsigned long long t_ = __builtin_readcyclecounter(); \
+        d_seg[K] += t_ - d_mark;                               \
+        d_mark = t_;                                           \
+    }
         const unsigned long long d_t0 = __builtin_readcyclecounter();
 #endif
         for (;;) {
@@ -1349,6 +1420,11 @@ __global__ __launch_bounds__(64 * WALK_WAVES) void k_walk_full(const uint32_t *_
             wait_vmcnt0();
 #ifdef FID_DEBUG_STATS
             d_waitcyc += __builtin_readcyclecounter() - d_c0;
+            d_mark = __builtin_readcyclecounter();
+            d_lanes[0] += __popcll(ballot64(state == ST_NEED));
+            d_lanes[1] += __popcll(ballot64(state == ST_LOADING));
+            d_lanes[2] += __popcll(ballot64(state == ST_FINAL));
+            d_lanes[3] += __popcll(ballot64(state == ST_IDLE));
 #endif
             if (next < rend) pre_ready = 1;  // the batch's records were requested at the previous checkpoint
             if (state == ST_LOADING) {
@@ -1366,7 +1442,7 @@ __global__ __launch_bounds__(64 * WALK_WAVES) void k_walk_full(const uint32_t *_
                         state = ST_FINAL;
                     } else {
                         // a seed starts in its seed state; a survivor as icvFetchContour starts a border
-                        sdir = SEG ? seed_class(x0, y0, P.seedShift) : first_dir(raw_to_nb(raw), hole ? 0 : 4);
+                        sdir = SEG ? (int)(st.y & 7u) : first_dir(raw_to_nb(raw), hole ? 0 : 4);
                         i1x = x0 + dir_dx(sdir);
                         i1y = y0 + dir_dy(sdir);
                         if (!SEG && !hole && pidx(i1x, i1y, W) < key) {
@@ -1382,6 +1458,9 @@ __global__ __launch_bounds__(64 * WALK_WAVES) void k_walk_full(const uint32_t *_
                 too_long = 1;
                 state = ST_FINAL;
             }
+#ifdef FID_DEBUG_STATS
+            FID_DSEG(0)  // loading -> active, first look, perimeter cap
+#endif
             // ---- retire finished walkers
             if (state == ST_FINAL) {
                 {
@@ -1401,7 +1480,7 @@ __global__ __launch_bounds__(64 * WALK_WAVES) void k_walk_full(const uint32_t *_
                 }
                 if (SEG) {
                     DevSeg *r = segs + (long long)lf * P.maxContours + slot;
-                    r->next_key = (uint32_t)cx | ((uint32_t)cy << 13);  // the seed state the walk stopped in front of
+                    r->next_key = seed_key(cx, cy, sdir);  // the seed state the walk stopped in front of
                     r->n = too_long || !ok ? SEG_INVALID : (unsigned)count;
                     r->mout = mout;
                     r->mhole = mhole;
@@ -1412,7 +1491,7 @@ __global__ __launch_bounds__(64 * WALK_WAVES) void k_walk_full(const uint32_t *_
                     if (MODE == 2) {
                         DevPend *pd = pend + (long long)lf * P.maxContours + slot;
                         pd->p = ok && stopped ? (unsigned)count : 0u;
-                        pd->next_key = (uint32_t)cx | ((uint32_t)cy << 13);
+                        pd->next_key = seed_key(cx, cy, sdir);
                     }
                 }
                 state = ST_IDLE;
@@ -1421,6 +1500,9 @@ __global__ __launch_bounds__(64 * WALK_WAVES) void k_walk_full(const uint32_t *_
                 atomicAdd(&G->dbg[14], (unsigned long long)count);
 #endif
             }
+#ifdef FID_DEBUG_STATS
+            FID_DSEG(1)  // retire
+#endif
             // ---- hand out new work to idle lanes
             int fresh = 0;
             const unsigned long long idle = ballot64(state == ST_IDLE);
@@ -1485,10 +1567,10 @@ __global__ __launch_bounds__(64 * WALK_WAVES) void k_walk_full(const uint32_t *_
                             lf = f;
                             st = make_uint2(gx, gy);
                             int s;
-                            if (SEG) {  // x | y << 13 | hole << 26 | scale << 27, seed index
+                            if (SEG) {  // x | y << 13 | scale << 27, back direction of the seed state
                                 x0 = gx & 0x1fff;
                                 y0 = (gx >> 13) & 0x1fff;
-                                hole = (gx >> 26) & 1;
+                                hole = 0;
                                 s = gx >> 27;
                                 mout = mhole = 0xffffffffu;
                                 too_long = 0;
@@ -1522,6 +1604,9 @@ __global__ __launch_bounds__(64 * WALK_WAVES) void k_walk_full(const uint32_t *_
                     next = next + nidle < rend ? next + nidle : rend;
                 }
             }
+#ifdef FID_DEBUG_STATS
+            FID_DSEG(2)  // queue switch, grab, hand-out
+#endif
             // ---- pool chunks from the wave's arena: two for a fresh walker (blocks 0 and 1), one for every walker
             //      that has entered its last chunked block (count >> 6 == kreg)
             {
@@ -1564,6 +1649,9 @@ __global__ __launch_bounds__(64 * WALK_WAVES) void k_walk_full(const uint32_t *_
                     }
                 }
             }
+#ifdef FID_DEBUG_STATS
+            FID_DSEG(3)  // chunks
+#endif
             // ---- window refills
             if (state == ST_NEED) {
                 // padded coordinates of the 3x3 neighbourhood: bits xb .. xb+2, rows cy .. cy+2; the window starts on a
@@ -1589,6 +1677,7 @@ __global__ __launch_bounds__(64 * WALK_WAVES) void k_walk_full(const uint32_t *_
                 state = ST_LOADING;
             }
 #ifdef FID_DEBUG_STATS
+            FID_DSEG(4)  // refill issue
             d_ckcyc += __builtin_readcyclecounter() - d_c0;
 #endif
             if (all_done && ballot64(state != ST_IDLE) == 0) break;  // every queue empty, everybody retired
@@ -1617,7 +1706,7 @@ __global__ __launch_bounds__(64 * WALK_WAVES) void k_walk_full(const uint32_t *_
                     const int hmag = (code & 1) ? W2 : 1;
                     const int hoff = (code & 2) ? hmag : -hmag;
                     if (SEG) {
-                        if (count > 0 && (e & 0x40u) && seed_class_is(cx, cy, sdir, P.seedShift)) {
+                        if (count > 0 && (e & 0x40u) && seed_state(cx, cy, sdir, sgm)) {
                             closed = 1;  // the next seed state: the segment ends in front of it
                             state = ST_FINAL;
                         } else if (count > 0 && cx == brx && cy == bry && sdir == brd) {
@@ -1654,7 +1743,7 @@ __global__ __launch_bounds__(64 * WALK_WAVES) void k_walk_full(const uint32_t *_
                             const unsigned xr = (unsigned)(cx + (MASK_PADW * 32 - 1) - wx0), rr = (unsigned)(cy - wy0);
                             state = (xr > 61u || rr > 13u) ? ST_NEED : ST_ACTIVE;
                         }
-                    } else if (MODE == 2 && count > 0 && (e & 0x40u) && seed_class_is(cx, cy, sdir, P.seedShift)) {
+                    } else if (MODE == 2 && count > 0 && (e & 0x40u) && seed_state(cx, cy, sdir, sgm)) {
                         stopped = 1;  // the first seed state on this border: the segment chain continues from here
                         state = ST_FINAL;
                     } else {
@@ -1701,6 +1790,8 @@ __global__ __launch_bounds__(64 * WALK_WAVES) void k_walk_full(const uint32_t *_
             atomicAdd(&G->dbg[5], d_forced);
             atomicAdd(&G->dbg[6], (unsigned long long)(__builtin_readcyclecounter() - d_t0));
             atomicAdd(&G->dbg[7], 1ull);
+            for (int k = 0; k < 5; k++) atomicAdd(&G->dbg[16 + k], d_seg[k]);
+            for (int k = 0; k < 4; k++) atomicAdd(&G->dbg[21 + k], d_lanes[k]);
         }
 #endif
     }
@@ -1723,7 +1814,7 @@ __global__ __launch_bounds__(64 * WALK_WAVES) void k_walk_full(const uint32_t *_
 // into segments: seed i owns the states from its start state up to, not including, the next seed state.  The whole-border
 // walk of a probe survivor then only has to reach the first seed state on its border (it keeps applying the canonical
 // test on the way and closes by itself on a border without seeds); the rest comes from the segment records:
-//   k_seg_link     next seed pixel -> seed index (seed-index plane) for every segment and every stopped survivor
+//   k_seg_link     next seed state -> seed index (SeedHash) for every segment and every stopped survivor
 //   k_seg_chain    every stopped survivor: once around the seed cycle, summing lengths and taking the two running minima;
 //                  the acceptance test is the one the whole-border walk applies (no pixel -- outer -- or examined
 //                  background 4-neighbour -- hole -- with a raster index below the start's key; perimeter gate)
@@ -1731,26 +1822,33 @@ __global__ __launch_bounds__(64 * WALK_WAVES) void k_walk_full(const uint32_t *_
 //                  last one cut where the survivor started; listed by k_seg_chain) into a dense array for k_approx
 // The longest sequential piece is the longest seed-free stretch of a border, not the longest border.
 
-// seed index of pixel (x, y) from the seed-index plane of its scale
-__device__ __forceinline__ unsigned seed_lookup(const uint2 *__restrict__ spl, int TC, unsigned key, int W, int H)
+// the frame's seed list -> SeedHash, one thread per seed (the inserts wait for their compare-and-swap: a kernel of its own
+// hides that behind a few thousand of them in flight; inside k_find_starts one lane inserting the seeds of a grid row one
+// after the other held its whole wave up)
+__global__ __launch_bounds__(256) void k_seed_index(const uint2 *__restrict__ seedq, unsigned long long *__restrict__ seedhash,
+                                                     const DevCounts *__restrict__ counts, const DevParams P)
 {
-    const int x = key & 0x1fff, y = (key >> 13) & 0x1fff;
-    if (x >= W || y >= H) return SEG_INVALID;  // (never for a key a walker wrote)
-    const uint2 e = spl[mask_word(TC, y + 1, MASK_PADW + (x >> 5))];
-    const unsigned bit = 1u << (x & 31);
-    return (e.y & bit) ? e.x + (unsigned)__popc(e.y & (bit - 1u)) : SEG_INVALID;
+    const int f = blockIdx.y;
+    unsigned ns = (unsigned)counts[f].nseeds;
+    ns = ns < (unsigned)P.maxContours ? ns : (unsigned)P.maxContours;
+    const uint2 *fsq = seedq + (long long)f * P.maxContours;
+    unsigned long long *fsh = seedhash + (long long)f * P.seedHashCap;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < ns; i += gridDim.x * blockDim.x) {
+        const uint2 r = fsq[i];
+        seedhash_insert(fsh, P.seedHashCap, P.seedGen, seedhash_key((r.x & 0x3ffffffu) | (r.y << 26), (int)(r.x >> 27)), i);
+    }
 }
 
 __global__ __launch_bounds__(256) void k_seg_link(const uint2 *__restrict__ seedq, DevSeg *__restrict__ segs,
                                                    const uint2 *__restrict__ surv, DevPend *__restrict__ pend,
-                                                   const uint2 *__restrict__ seedplane, DevCounts *__restrict__ counts,
+                                                   const unsigned long long *__restrict__ seedhash, DevCounts *__restrict__ counts,
                                                    DevGlobal *__restrict__ G, const DevParams P)
 {
     const int f = blockIdx.y;
     unsigned ns = (unsigned)counts[f].nseeds, nv = (unsigned)counts[f].nsurv;
     ns = ns < (unsigned)P.maxContours ? ns : (unsigned)P.maxContours;
     nv = nv < (unsigned)P.maxContours ? nv : (unsigned)P.maxContours;
-    const long long plane = (long long)P.TR * P.TC * MT_ROWS;
+    const unsigned long long *fsh = seedhash + (long long)f * P.seedHashCap;
     const uint2 *fsq = seedq + (long long)f * P.maxContours;
     DevSeg *fsg = segs + (long long)f * P.maxContours;
     const uint2 *fsv = surv + (long long)f * P.maxStarts;
@@ -1760,13 +1858,13 @@ __global__ __launch_bounds__(256) void k_seg_link(const uint2 *__restrict__ seed
             const unsigned sc = fsq[i].x >> 27;
             // (a segment that was abandoned -- too long, pool exhausted -- has no next seed)
             const unsigned nx = fsg[i].n == SEG_INVALID ? SEG_INVALID
-                                                        : seed_lookup(seedplane + ((long long)f * P.nscales + sc) * plane, P.TC, fsg[i].next_key, P.W, P.H);
+                                                        : seedhash_find(fsh, P.seedHashCap, P.seedGen, seedhash_key(fsg[i].next_key, (int)sc));
             fsg[i].next_idx = nx < ns ? nx : SEG_INVALID;  // (a seed beyond the table's capacity was reported by k_find_starts)
         } else {
             const unsigned j = i - ns;
             if (fpd[j].p) {
                 const unsigned sc = (fsv[j].y >> 16) & 0xffu;
-                const unsigned nx = seed_lookup(seedplane + ((long long)f * P.nscales + sc) * plane, P.TC, fpd[j].next_key, P.W, P.H);
+                const unsigned nx = seedhash_find(fsh, P.seedHashCap, P.seedGen, seedhash_key(fpd[j].next_key, (int)sc));
                 fpd[j].next_idx = nx < ns ? nx : SEG_INVALID;
             }
         }

@@ -108,7 +108,7 @@ typedef struct fid_limits {
     int32_t max_height;             /* [1080] */
     int32_t max_batch;              /* [1]   frames per fid_detect_batch call */
     int32_t max_starts_per_frame;   /* [262144] border-following start points, all scales */
-    int32_t max_contours_per_frame; /* [16384; 65536 when max_batch <= 4, 32768 when <= 16: room for the dense seed lattice
+    int32_t max_contours_per_frame; /* [16384; 65536 when max_batch <= 4, 32768 when <= 16: room for the denser seed grid
                                        of small calls]  probe survivors / tracing seeds / accepted contours, all scales (each) */
     int32_t max_candidates_per_frame; /* [2048] quads leaving _findMarkerContours, all scales */
     int32_t max_markers_per_frame;  /* [256] */

@@ -63,6 +63,7 @@ struct fid_ctx {
     int walk_blocks = 0;  // one-wave workgroups per frame in the full walk pass (0 = automatic)
     int walk_blocks_cap = 64;  // (the walks of a single frame want every seed in flight at once)
     int copy_blocks = 0;
+    int resolve_serial = 0;    // FID_RESOLVE_SERIAL=1: k_resolve's single-wave path even when the near triangle fits LDS (tests)
     int seed_shift = 0;        // FID_SEED_SHIFT: force the seed grid spacing 8 << shift (0 = by call size)
     uint4 *d_contours = nullptr;
     uint32_t *d_ckpts = nullptr;
@@ -355,6 +356,8 @@ fid_status run_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H, int
         // persistent walker workgroups (WALK_WAVES waves each) per frame: about 16 waves per CU over the sub-batch
         int wb = c->walk_blocks > 0 ? c->walk_blocks : (3072 / WALK_WAVES + Fs - 1) / Fs;  // (measured: 6 per frame at 128 frames beats 8 and 12)
         wb = wb < 2 ? 2 : (wb > c->walk_blocks_cap ? c->walk_blocks_cap : wb);
+        // kernels with a fixed number of workgroups per frame (sized for batches): a call of a few frames gets more of them
+        const int gm = Fs >= 16 ? 1 : 16 / Fs;
         const int cap1 = pts_cap_first(P);
         const size_t lds1 = (size_t)cap1 * sizeof(uint32_t) + (size_t)K4_SHORT_STACK * sizeof(int2);
         const size_t lds2 = (size_t)(P.maxPerim + 1) * sizeof(uint32_t) + (size_t)K4_LONG_STACK * sizeof(int2);
@@ -363,16 +366,16 @@ fid_status run_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H, int
                                (uint2 *)nullptr, P);
             mark(ST_STARTS + 1);
             // ---- K3: sieve the starts twice, then walk the survivors to the end
-            hipLaunchKernelGGL((k_probe<PROBE0_STEPS, 0>), dim3(64, Fs), dim3(256), 0, st, masks, starts, surv1, counts, c->d_global, P);
-            hipLaunchKernelGGL((k_probe<PROBE1_STEPS, 1>), dim3(16, Fs), dim3(256), 0, st, masks, surv1, surv, counts, c->d_global, P);
+            hipLaunchKernelGGL((k_probe<PROBE0_STEPS, 0>), dim3(64 * gm, Fs), dim3(256), 0, st, masks, starts, surv1, counts, c->d_global, P);
+            hipLaunchKernelGGL((k_probe<PROBE1_STEPS, 1>), dim3(16 * gm, Fs), dim3(256), 0, st, masks, surv1, surv, counts, c->d_global, P);
             mark(ST_PROBE + 1);
             hipLaunchKernelGGL(k_walk_full<0>, dim3(wb, Fs), dim3(64 * WALK_WAVES), 0, st, masks, surv, contours, tab, pool, (DevSeg *)nullptr,
                                (DevPend *)nullptr, counts, c->d_global, P);
             mark(ST_WALK + 1);
             // ---- K4: short contours with a small LDS footprint first, then the long / flagged ones
-            hipLaunchKernelGGL(k_approx, dim3(128, Fs), dim3(64), lds1, st, contours, tab, pool, cands, counts, c->d_global, P, cap1,
+            hipLaunchKernelGGL(k_approx, dim3(128 * gm, Fs), dim3(64), lds1, st, contours, tab, pool, cands, counts, c->d_global, P, cap1,
                                K4_SHORT_STACK, 0, (const uint32_t *)nullptr, (const uint32_t *)nullptr);
-            hipLaunchKernelGGL(k_approx, dim3(16, Fs), dim3(64), lds2, st, contours, tab, pool, cands, counts, c->d_global, P,
+            hipLaunchKernelGGL(k_approx, dim3(16 * gm, Fs), dim3(64), lds2, st, contours, tab, pool, cands, counts, c->d_global, P,
                                P.maxPerim + 1, K4_LONG_STACK, 1, (const uint32_t *)nullptr, (const uint32_t *)nullptr);
             mark(ST_APPROX + 1);
         } else {
@@ -400,22 +403,22 @@ fid_status run_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H, int
                                c->d_global, P);
             if (c->profile) (void)hipEventRecord(ev[15], sa);
             HIPCHK(c, hipEventRecord(c->aux_join[sb], sa));
-            hipLaunchKernelGGL((k_probe<PROBE0_STEPS, 0>), dim3(64, Fs), dim3(256), 0, st, masks, starts, surv1, counts, c->d_global, P);
-            hipLaunchKernelGGL((k_probe<PROBE1_STEPS, 1>), dim3(16, Fs), dim3(256), 0, st, masks, surv1, surv, counts, c->d_global, P);
+            hipLaunchKernelGGL((k_probe<PROBE0_STEPS, 0>), dim3(64 * gm, Fs), dim3(256), 0, st, masks, starts, surv1, counts, c->d_global, P);
+            hipLaunchKernelGGL((k_probe<PROBE1_STEPS, 1>), dim3(16 * gm, Fs), dim3(256), 0, st, masks, surv1, surv, counts, c->d_global, P);
             mark(ST_PROBE + 1);
             hipLaunchKernelGGL(k_walk_full<2>, dim3(wb2, Fs), dim3(64 * WALK_WAVES), 0, st, masks, surv, wres, tab, pool, segs, pend, counts,
                                c->d_global, P);
             HIPCHK(c, hipStreamWaitEvent(st, c->aux_join[sb], 0));
-            hipLaunchKernelGGL(k_seed_index, dim3(8, Fs), dim3(256), 0, st, seedq, seedhash, counts, P);
-            hipLaunchKernelGGL(k_seg_link, dim3(16, Fs), dim3(256), 0, st, seedq, segs, surv, pend, seedhash, counts, c->d_global, P);
+            hipLaunchKernelGGL(k_seed_index, dim3(8 * gm, Fs), dim3(256), 0, st, seedq, seedhash, counts, P);
+            hipLaunchKernelGGL(k_seg_link, dim3(16 * gm, Fs), dim3(256), 0, st, seedq, segs, surv, pend, seedhash, counts, c->d_global, P);
             uint4 *recs = c->d_recs + 2 * f0 * MCn;
-            hipLaunchKernelGGL(k_seg_chain, dim3(16, Fs), dim3(64), 0, st, surv, pend, wres, segs, contours, cinfo, cbase, recs, counts,
+            hipLaunchKernelGGL(k_seg_chain, dim3(16 * gm, Fs), dim3(64), 0, st, surv, pend, wres, segs, contours, cinfo, cbase, recs, counts,
                                c->d_global, P);
             hipLaunchKernelGGL(k_seg_copy, dim3(c->copy_blocks > 0 ? c->copy_blocks : 256, Fs), dim3(256), 0, st, recs, tab, pool, dense, counts, P);
             mark(ST_WALK + 1);
-            hipLaunchKernelGGL(k_approx, dim3(128, Fs), dim3(64), lds1, st, contours, tab, pool, cands, counts, c->d_global, P, cap1,
+            hipLaunchKernelGGL(k_approx, dim3(128 * gm, Fs), dim3(64), lds1, st, contours, tab, pool, cands, counts, c->d_global, P, cap1,
                                K4_SHORT_STACK, 0, dense, cbase);
-            hipLaunchKernelGGL(k_approx, dim3(16, Fs), dim3(64), lds2, st, contours, tab, pool, cands, counts, c->d_global, P,
+            hipLaunchKernelGGL(k_approx, dim3(16 * gm, Fs), dim3(64), lds2, st, contours, tab, pool, cands, counts, c->d_global, P,
                                P.maxPerim + 1, K4_LONG_STACK, 1, dense, cbase);
             mark(ST_APPROX + 1);
         }
@@ -423,9 +426,13 @@ fid_status run_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H, int
         float4 *cmeta = c->d_cmeta + f0 * MC;
         hipLaunchKernelGGL(k_sort_cands, dim3(Fs), dim3(256), MC * 8, st, cands, sorted, cmeta, counts, P);
         mark(ST_SORT + 1);
-        hipLaunchKernelGGL(k_near, dim3(32, Fs), dim3(256), 0, st, sorted, cmeta, nearb, counts, P);
+        hipLaunchKernelGGL(k_near, dim3(32 * gm, Fs), dim3(256), 0, st, sorted, cmeta, nearb, counts, P);
         mark(ST_NEAR + 1);
-        hipLaunchKernelGGL(k_resolve, dim3(Fs), dim3(64), MC * 4, st, sorted, nearb, filtered, counts, worklist, nwork, P);
+        {
+            const size_t lds = 96 * 1024;  // sizes, labels, component sizes; the rest holds the near triangle
+            const int near_words = c->resolve_serial ? 0 : (int)((lds - 3 * MC * 4) / 4);
+            hipLaunchKernelGGL(k_resolve, dim3(Fs), dim3(1024), lds, st, sorted, nearb, filtered, counts, worklist, nwork, P, near_words, c->d_global);
+        }
         mark(ST_RESOLVE + 1);
         // ---- K6
         {
@@ -485,6 +492,8 @@ fid_status run_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H, int
         fprintf(stderr, "walk waves %llu: total cyc avg %.0f max %llu; own queue dry at avg %.0f max %llu\n", d[12],
                 d[12] ? (double)d[8] / d[12] : 0., d[9], d[12] ? (double)d[10] / d[12] : 0., d[11]);
         fprintf(stderr, "walk longest %llu steps, total steps %llu\n", d[13], d[14]);
+        fprintf(stderr, "resolve (frame 0, n %llu, %llu label rounds) cycles: load %llu label %llu count %llu components %llu places %llu move %llu\n", d[31] >> 32,
+                d[31] & 0xffffffffull, d[25], d[26], d[27], d[28], d[29], d[30]);
         if (d[1])
             fprintf(stderr, "checkpoint cycles: wait %.0f activate %.0f retire %.0f hand-out %.0f chunks %.0f refill %.0f; lanes at a checkpoint: need %.1f loading %.1f final %.1f idle %.1f\n",
                     (double)d[4] / d[1], (double)d[16] / d[1], (double)d[17] / d[1], (double)d[18] / d[1], (double)d[19] / d[1], (double)d[20] / d[1],
@@ -619,6 +628,7 @@ fid_status fid_create(const fid_params *params, const fid_dict *dict, const fid_
     if (getenv("FID_SUB_FRAMES")) c->sub_frames = atoi(getenv("FID_SUB_FRAMES"));
     if (getenv("FID_WALK_CAP")) c->walk_blocks_cap = atoi(getenv("FID_WALK_CAP"));
     if (getenv("FID_SEED_SHIFT")) c->seed_shift = atoi(getenv("FID_SEED_SHIFT"));
+    if (getenv("FID_RESOLVE_SERIAL")) c->resolve_serial = atoi(getenv("FID_RESOLVE_SERIAL"));
     if (getenv("FID_COPY_BLOCKS")) c->copy_blocks = atoi(getenv("FID_COPY_BLOCKS"));
     if (getenv("FID_THR")) c->thr_mode = strcmp(getenv("FID_THR"), "tile") ? 1 : 0;
     if (getenv("FID_THR_NW")) c->thr_nw = atoi(getenv("FID_THR_NW")) == 3 ? 3 : 5;
@@ -725,6 +735,7 @@ fid_status fid_create(const fid_params *params, const fid_dict *dict, const fid_
     TRYHIP(hipFuncSetAttribute((const void *)k_threshold_fixed<3, 4, 13>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)ThrCfg<3, 4, 13>::LDS_BYTES));
     TRYHIP(hipFuncSetAttribute((const void *)k_approx, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
+    TRYHIP(hipFuncSetAttribute((const void *)k_resolve, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     TRYHIP(hipFuncSetAttribute((const void *)k_filter_markers, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
 #undef TRY
 #undef TRYHIP

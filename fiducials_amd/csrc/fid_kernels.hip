@@ -2350,6 +2350,13 @@ __global__ __launch_bounds__(256) void k_sort_cands(const DevCand *__restrict__ 
     }
 }
 
+// The near matrix of a frame (bit j of row i set: candidates i < j are too close) is stored as its upper triangle, row after
+// row: row i keeps its words (i >> 5) .. nw - 1, nw = ceil(n / 32).  k_resolve copies the whole thing into LDS in one go.
+__device__ __forceinline__ int near_row_off(int i, int nw)
+{
+    const int q = i >> 5;  // row i keeps words q .. nw - 1
+    return i * nw - 16 * q * (q - 1) - (i - 32 * q) * q;
+}
 // K5b: _filterTooCloseCandidates pair test (aruco.cpp): bit j of near[f][i][j>>5] for j > i.
 // For any cyclic shift the mean squared corner distance is at least the squared distance of the corner means
 // (Jensen), so a pair whose centroids are far enough apart cannot be near: that test runs on a compact
@@ -2409,120 +2416,288 @@ __global__ __launch_bounds__(256) void k_near(const DevCand *__restrict__ sorted
                 }
             }
         }
-        nb[(long long)i * NW + w] = bits;
+        if (w >= (i >> 5)) nb[near_row_off(i, nw) + w - (i >> 5)] = bits;
     }
 }
 
 // K5c: the sequential part of _filterTooCloseCandidates: near pairs are visited in (i, j) order, a pair
 // whose members are both still alive removes the one with the smaller contour (ties: the first).
 // For a live i this means: scan its live near j > i in order; every j with size_j < size_i dies, the
-// first j with size_j >= size_i kills i and ends the row.  One wave per frame, lanes own 32-bit words.
-__global__ __launch_bounds__(64) void k_resolve(const DevCand *__restrict__ sorted, const uint32_t *__restrict__ nearb,
+// first j with size_j >= size_i kills i and ends the row.
+// What row i does depends only on rows of its own connected component of the near graph (a marker seen at 13 threshold
+// scales, inside and outside border: a clique of up to 26), so the components are resolved side by side, each one by one
+// wave in row order with lanes owning 32-bit words of a row: the workgroup copies the triangle into LDS, labels the components
+// (minimum index, propagated along the edges with pointer jumping) and deals them out to its waves.  One workgroup per frame.
+// (One wave taking the 600 rows of a bench frame one after the other spent 180 us on LDS latencies; one THREAD per component
+// 130 us: a clique's rows are long.)
+// A triangle that does not fit the LDS budget goes the old way: one wave, rows in order, straight from global memory.
+__global__ __launch_bounds__(1024) void k_resolve(const DevCand *__restrict__ sorted, const uint32_t *__restrict__ nearb,
                                                  DevCand *__restrict__ filtered, DevCounts *__restrict__ counts,
                                                  unsigned *__restrict__ worklist, unsigned *__restrict__ nwork,
-                                                 const DevParams P)
+                                                 const DevParams P, int lds_words, DevGlobal *__restrict__ G)
 {
-    extern __shared__ int sizes[];  // maxCands
-    const int f = blockIdx.x, lane = lane_id();
+#ifdef FID_DEBUG_STATS
+    unsigned long long d_t[8];
+    int d_k = 0, d_iters = 0;
+#define RES_MARK() d_t[d_k++] = __builtin_readcyclecounter();
+#else
+#define RES_MARK()
+#endif
+    RES_MARK()
+    extern __shared__ int sizes[];     // maxCands sizes | labels | component sizes, then lds_words words for the near matrix
+    __shared__ uint32_t s_rem[128];    // per 32 candidates: who has been removed
+    __shared__ uint32_t s_alive[128];  // ... who is left / where the first of them goes
+    __shared__ int s_off[128];
+    const int f = blockIdx.x, lane = lane_id(), tid = threadIdx.x, nt = blockDim.x;
     int n = counts[f].ncand;
     n = n < P.maxCands ? n : P.maxCands;
     const int NW = P.maxCands >> 5;
     const DevCand *cs = sorted + (long long)f * P.maxCands;
     const uint32_t *nb = nearb + (long long)f * P.maxCands * NW;
-    for (int i = lane; i < n; i += 64) sizes[i] = cs[i].size;
-    __syncthreads();
-    // removed bits: lane l owns words l, l+64, ... (maxCands <= 4096 -> at most 2 words per lane)
-    uint32_t rem0 = 0, rem1 = 0;
     const int nw = (n + 31) >> 5;
-    // Row i of the near matrix does not depend on what has been removed so far: the rows of the next RB candidates are
-    // fetched together (their loads overlap) and then resolved one after the other.
-    constexpr int RB = 8;
-    for (int i0 = 0; i0 < n; i0 += RB) {
-        uint32_t row[RB][2];
+    int *label = sizes + P.maxCands, *csize = label + P.maxCands;
+    uint32_t *s_near = reinterpret_cast<uint32_t *>(csize + P.maxCands);
+    const int tri = n > 0 ? near_row_off(n - 1, nw) + nw - ((n - 1) >> 5) : 0;  // words of the triangle
+    const bool in_lds = tri <= lds_words;
+    for (int i = tid; i < n; i += nt) {
+        sizes[i] = cs[i].size;
+        label[i] = i;
+        csize[i] = 0;
+    }
+    if (tid < 128) s_rem[tid] = 0u;
+    if (in_lds) {
+        // (the frame's part of nearb starts on a 16-byte boundary: maxCands is a multiple of 32)
+        const uint4 *src = reinterpret_cast<const uint4 *>(nb);
+        uint4 *dst = reinterpret_cast<uint4 *>(s_near);
+        const int nq = (tri + 3) >> 2;
+        for (int t0 = 0; t0 < nq; t0 += 4 * nt) {  // four loads in flight per thread
+            uint4 v[4];
 #pragma unroll
-        for (int u = 0; u < RB; u++) {
+            for (int u = 0; u < 4; u++) {
+                const int t = t0 + u * nt + tid;
+                v[u] = t < nq ? src[t] : make_uint4(0u, 0u, 0u, 0u);
+            }
 #pragma unroll
-            for (int k = 0; k < 2; k++) {
-                const int w = lane + 64 * k, i = i0 + u;
-                row[u][k] = (i < n && w < nw && w >= (i >> 5)) ? nb[(long long)i * NW + w] : 0u;
+            for (int u = 0; u < 4; u++) {
+                const int t = t0 + u * nt + tid;
+                if (t < nq) dst[t] = v[u];
             }
         }
-#pragma unroll
-        for (int u = 0; u < RB; u++) {
-            const int i = i0 + u;
-            if (i >= n) break;  // wave-uniform
-            const int wi = i >> 5;  // wave-uniform: the word of the removed set that holds candidate i sits in lane wi & 63
-            const uint32_t rw = (uint32_t)__builtin_amdgcn_readlane((int)(wi < 64 ? rem0 : rem1), wi & 63);
-            if ((rw >> (i & 31)) & 1u) continue;  // wave-uniform
-            int szi = sizes[i];
-            int firstKill = INT_MAX;
-            uint32_t live0 = 0, live1 = 0;
-            // each lane scans its words
-#pragma unroll
-            for (int k = 0; k < 2; k++) {
-                int w = lane + 64 * k;
-                if (w < nw && w >= wi) {
-                    uint32_t bits = row[u][k] & ~(k == 0 ? rem0 : rem1);
-                    if (k == 0) live0 = bits; else live1 = bits;
-                    uint32_t t = bits;
-                    while (t) {
-                        int b = __ffs(t) - 1;
-                        t &= t - 1;
-                        int j = w * 32 + b;
-                        if (sizes[j] >= szi) {
-                            firstKill = firstKill < j ? firstKill : j;
-                            break;
+    }
+    __syncthreads();
+    RES_MARK()
+    if (in_lds) {
+        // ---- components: label = smallest index
+        for (;;) {
+#ifdef FID_DEBUG_STATS
+            d_iters++;
+#endif
+            int changed = 0;
+            for (int i = tid; i < n; i += nt) {
+                const int l0 = label[i];
+                int li = l0;
+                const uint32_t *row = s_near + near_row_off(i, nw) - (i >> 5);
+                for (int w = i >> 5; w < nw; w++) {
+                    uint32_t bits = row[w];
+                    while (bits) {
+                        const int j = w * 32 + __ffs(bits) - 1;
+                        bits &= bits - 1;
+                        const int lj = label[j];
+                        if (lj < li) {
+                            li = lj;
+                        } else if (lj > li) {
+                            atomicMin(&label[j], li);
+                            changed = 1;
                         }
                     }
                 }
+                const int ll = label[li];  // pointer jumping
+                li = ll < li ? ll : li;
+                if (li < l0) {
+                    atomicMin(&label[i], li);
+                    changed = 1;
+                }
             }
-            int jk = wave_min_i32_dpp(firstKill);
-            // every live near j < jk has size_j < size_i and is removed
+            if (!__syncthreads_or(changed)) break;
+        }
+        RES_MARK()
+        for (int i = tid; i < n; i += nt) atomicAdd(&csize[label[i]], 1);
+        __syncthreads();
+        RES_MARK()
+        // ---- the components are dealt out to the waves; a wave takes the rows of a component in order, lanes own 32-bit
+        //      words of the row (other waves set other bits of the same removed-set words: LDS atomics)
+        const int nwaves = (int)blockDim.x >> 6, wv = tid >> 6;
+        int rootrank = 0;
+        for (int c0 = 0; c0 < n; c0 += 64) {
+            const int ci = c0 + lane;
+            unsigned long long rb = ballot64(ci < n && label[ci] == ci && csize[ci] > 1);
+            while (rb) {
+                const int r = c0 + __ffsll((long long)rb) - 1;
+                rb &= rb - 1;
+                if ((rootrank++ % nwaves) != wv) continue;
+                int left = csize[r];
+                for (int m0 = r & ~63; left > 0; m0 += 64) {
+                    const int mi = m0 + lane;
+                    unsigned long long mb = ballot64(mi < n && mi >= r && label[mi] == r);
+                    left -= __popcll(mb);
+                    while (mb) {
+                        const int i = m0 + __ffsll((long long)mb) - 1;  // wave-uniform
+                        mb &= mb - 1;
+                        const int wi = i >> 5;
+                        if ((s_rem[wi] >> (i & 31)) & 1u) continue;
+                        const int szi = sizes[i];
+                        const uint32_t *row = s_near + near_row_off(i, nw) - wi;
+                        int firstKill = INT_MAX;
+                        uint32_t live[2] = {0u, 0u};
 #pragma unroll
-            for (int k = 0; k < 2; k++) {
-                int w = lane + 64 * k;
-                uint32_t bits = k == 0 ? live0 : live1;
-                if (bits) {
-                    uint32_t m;
-                    if (jk == INT_MAX || (jk >> 5) > w) m = 0xffffffffu;
-                    else if ((jk >> 5) < w) m = 0;
-                    else m = (1u << (jk & 31)) - 1u;
-                    if (k == 0) rem0 |= bits & m; else rem1 |= bits & m;
+                        for (int k = 0; k < 2; k++) {
+                            const int w = lane + 64 * k;
+                            if (w < nw && w >= wi) {
+                                const uint32_t bits = row[w] & ~s_rem[w];
+                                live[k] = bits;
+                                uint32_t t = bits;
+                                while (t) {
+                                    const int j = w * 32 + __ffs(t) - 1;
+                                    t &= t - 1;
+                                    if (sizes[j] >= szi) {
+                                        firstKill = firstKill < j ? firstKill : j;
+                                        break;
+                                    }
+                                }
+                            }
+                        }
+                        const int jk = wave_min_i32_dpp(firstKill);
+                        // every live near j < jk has size_j < size_i and is removed; jk, if any, removes i
+#pragma unroll
+                        for (int k = 0; k < 2; k++) {
+                            const int w = lane + 64 * k;
+                            if (live[k]) {
+                                uint32_t m;
+                                if (jk == INT_MAX || (jk >> 5) > w) m = 0xffffffffu;
+                                else if ((jk >> 5) < w) m = 0;
+                                else m = (1u << (jk & 31)) - 1u;
+                                if (live[k] & m) atomicOr(&s_rem[w], live[k] & m);
+                            }
+                        }
+                        if (jk != INT_MAX && lane == 0) atomicOr(&s_rem[wi], 1u << (i & 31));
+                    }
                 }
             }
-            if (jk != INT_MAX) {
-                if ((wi & 63) == lane) {
-                    if (wi < 64) rem0 |= 1u << (i & 31); else rem1 |= 1u << (i & 31);
+        }
+    } else if (tid < 64) {
+        // removed bits: lane l owns words l, l+64, ... (maxCands <= 4096 -> at most 2 words per lane)
+        uint32_t rem0 = 0, rem1 = 0;
+        // Row i of the near matrix does not depend on what has been removed so far: the rows of the next RB candidates are
+        // fetched together (their loads overlap) and then resolved one after the other.
+        constexpr int RB = 8;
+        for (int i0 = 0; i0 < n; i0 += RB) {
+            uint32_t row[RB][2];
+#pragma unroll
+            for (int u = 0; u < RB; u++) {
+#pragma unroll
+                for (int k = 0; k < 2; k++) {
+                    const int w = lane + 64 * k, i = i0 + u;
+                    row[u][k] = (i < n && w < nw && w >= (i >> 5)) ? nb[near_row_off(i, nw) + w - (i >> 5)] : 0u;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < RB; u++) {
+                const int i = i0 + u;
+                if (i >= n) break;  // wave-uniform
+                if (ballot64((row[u][0] | row[u][1]) != 0u) == 0ull) continue;  // nothing near i
+                const int wi = i >> 5;  // wave-uniform: the word of the removed set that holds candidate i sits in lane wi & 63
+                const uint32_t rw = (uint32_t)__builtin_amdgcn_readlane((int)(wi < 64 ? rem0 : rem1), wi & 63);
+                if ((rw >> (i & 31)) & 1u) continue;  // wave-uniform
+                int szi = sizes[i];
+                int firstKill = INT_MAX;
+                uint32_t live0 = 0, live1 = 0;
+                // each lane scans its words
+#pragma unroll
+                for (int k = 0; k < 2; k++) {
+                    int w = lane + 64 * k;
+                    if (w < nw && w >= wi) {
+                        uint32_t bits = row[u][k] & ~(k == 0 ? rem0 : rem1);
+                        if (k == 0) live0 = bits; else live1 = bits;
+                        uint32_t t = bits;
+                        while (t) {
+                            int b = __ffs(t) - 1;
+                            t &= t - 1;
+                            int j = w * 32 + b;
+                            if (sizes[j] >= szi) {
+                                firstKill = firstKill < j ? firstKill : j;
+                                break;
+                            }
+                        }
+                    }
+                }
+                int jk = wave_min_i32_dpp(firstKill);
+                // every live near j < jk has size_j < size_i and is removed
+#pragma unroll
+                for (int k = 0; k < 2; k++) {
+                    int w = lane + 64 * k;
+                    uint32_t bits = k == 0 ? live0 : live1;
+                    if (bits) {
+                        uint32_t m;
+                        if (jk == INT_MAX || (jk >> 5) > w) m = 0xffffffffu;
+                        else if ((jk >> 5) < w) m = 0;
+                        else m = (1u << (jk & 31)) - 1u;
+                        if (k == 0) rem0 |= bits & m; else rem1 |= bits & m;
+                    }
+                }
+                if (jk != INT_MAX) {
+                    if ((wi & 63) == lane) {
+                        if (wi < 64) rem0 |= 1u << (i & 31); else rem1 |= 1u << (i & 31);
+                    }
                 }
             }
         }
+        s_rem[lane] = rem0;
+        s_rem[lane + 64] = rem1;
     }
-    // compaction in order
-    int base = 0;
-    for (int w0 = 0; w0 < nw; w0 += 64) {
-        int w = w0 + lane;
-        uint32_t alive = 0;
-        if (w < nw) {
-            alive = ~(w0 == 0 ? rem0 : rem1);
-            int hi = n - w * 32;
-            if (hi < 32) alive &= (1u << hi) - 1u;
+    __syncthreads();
+    RES_MARK()
+    if (tid < 64) {
+        // places of the survivors, in order
+        int base = 0;
+        for (int w0 = 0; w0 < nw; w0 += 64) {
+            int w = w0 + lane;
+            uint32_t alive = 0;
+            if (w < nw) {
+                alive = ~s_rem[w];
+                int hi = n - w * 32;
+                if (hi < 32) alive &= (1u << hi) - 1u;
+            }
+            int cnt = __popc(alive);
+            int incl = wave_iscan(cnt);
+            if (w < nw) {
+                s_alive[w] = alive;
+                s_off[w] = base + incl - cnt;
+            }
+            base += __shfl(incl, 63, WAVE);
         }
-        int cnt = __popc(alive);
-        int incl = wave_iscan(cnt);
-        int off = base + incl - cnt;
-        while (alive) {
-            int b = __ffs(alive) - 1;
-            alive &= alive - 1;
-            filtered[(long long)f * P.maxCands + off] = cs[w * 32 + b];
-            off++;
+        unsigned o = 0;
+        if (lane == 0) {
+            counts[f].nfilt = base;
+            o = atomicAdd(nwork, (unsigned)base);
         }
-        base += __shfl(incl, 63, WAVE);
+        o = (unsigned)__builtin_amdgcn_readfirstlane((int)o);
+        for (int k = lane; k < base; k += 64) worklist[o + k] = ((unsigned)f << 16) | (unsigned)k;
     }
-    if (lane == 0) {
-        counts[f].nfilt = base;
-        unsigned o = atomicAdd(nwork, (unsigned)base);
-        for (int k = 0; k < base; k++) worklist[o + k] = ((unsigned)f << 16) | (unsigned)k;
+    __syncthreads();
+    RES_MARK()
+    // the whole workgroup moves them
+    for (int i = tid; i < n; i += nt) {
+        const uint32_t alive = s_alive[i >> 5], bit = 1u << (i & 31);
+        if (alive & bit) filtered[(long long)f * P.maxCands + s_off[i >> 5] + __popc(alive & (bit - 1u))] = cs[i];
     }
+#ifdef FID_DEBUG_STATS
+    __syncthreads();
+    RES_MARK()
+    if (tid == 0 && f == 0) {
+        for (int q = 1; q < d_k; q++) G->dbg[24 + q] = d_t[q] - d_t[q - 1];
+        G->dbg[31] = (unsigned long long)d_iters | ((unsigned long long)n << 32);
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2912,6 +3087,10 @@ __global__ __launch_bounds__(64) void k_subpix(const uint8_t *__restrict__ gray,
 {
     __shared__ float sp[(2 * SP_MAXWIN + 3) * (2 * SP_MAXWIN + 3)];
     __shared__ double prod[5][(2 * SP_MAXWIN + 1) * (2 * SP_MAXWIN + 1)];
+    // the gray pixels every iteration's patch can touch while the corner stays within win + 1 pixels of where it started
+    // (further away the result is discarded anyway): fetched once, so that an iteration does not wait for global memory
+    constexpr int SP_CMAX = (2 * SP_MAXWIN + 3) + 1 + 2 * (SP_MAXWIN + 1);
+    __shared__ uint8_t s_img[SP_CMAX * SP_CMAX];
     __shared__ float s_c[2];
     __shared__ int s_flag;
     const int lane = lane_id();
@@ -2935,13 +3114,42 @@ __global__ __launch_bounds__(64) void k_subpix(const uint8_t *__restrict__ gray,
             }
             continue;
         }
+        const int cm = win + 1, csz = pw + 1 + 2 * cm;
+        const int X0 = (int)floorf(cTx - (pw - 1) * 0.5f) - cm, Y0 = (int)floorf(cTy - (pw - 1) * 0.5f) - cm;
+        const bool cached = X0 >= 0 && Y0 >= 0 && X0 + csz <= W && Y0 + csz <= H;
+        __syncthreads();  // (the previous item's readers of s_img are done)
+        if (cached)
+            for (int p = lane; p < csz * csz; p += 64) {
+                const int i = p / csz, j = p - i * csz;
+                s_img[p] = g[(long long)(Y0 + i) * gs + X0 + j];
+            }
         int iter = 0;
         for (;;) {
             // getRectSubPix(src, (pw, pw), cI) -> sp
             float cx = cIx - (pw - 1) * 0.5f, cy = cIy - (pw - 1) * 0.5f;
             int ipx = (int)floorf(cx), ipy = (int)floorf(cy);
             __syncthreads();
-            if (0 <= ipx && ipx + pw < W && 0 <= ipy && ipy + pw < H) {
+            if (cached && ipx >= X0 && ipy >= Y0 && ipx + pw + 1 <= X0 + csz && ipy + pw + 1 <= Y0 + csz) {
+                // the fast path below, pixels from the LDS copy (same arithmetic)
+                float a = cx - ipx, b = cy - ipy;
+                a = a > 0.0001f ? a : 0.0001f;
+                float a12 = a * (1.f - b), a22 = a * b, b1 = 1.f - b, b2 = b;
+                double s = (1. - a) / a;
+                const uint8_t *s0 = s_img + (ipy - Y0) * csz + (ipx - X0);
+                for (int p = lane; p < pw * pw; p += 64) {
+                    int i = p / pw, j = p - i * pw;
+                    const uint8_t *sr = s0 + i * csz;
+                    float t = a12 * sr[j + 1] + a22 * sr[j + 1 + csz];
+                    float prev;
+                    if (j == 0) {
+                        prev = (1 - a) * (b1 * sr[0] + b2 * sr[csz]);
+                    } else {
+                        float tp = a12 * sr[j] + a22 * sr[j + csz];
+                        prev = (float)(tp * s);
+                    }
+                    sp[p] = prev + t;
+                }
+            } else if (0 <= ipx && ipx + pw < W && 0 <= ipy && ipy + pw < H) {
                 // getRectSubPix_8u32f fast path: dst[j] = prev_j + t_j, prev_0 = (1-a)(b1 s[0] + b2 s[step]),
                 // prev_j = (float)(t_{j-1} * s), t_j = a12 s[j+1] + a22 s[j+1+step]
                 float a = cx - ipx, b = cy - ipy;

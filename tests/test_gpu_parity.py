@@ -322,6 +322,31 @@ def test_whole_border_walk_and_seed_tracing_agree(monkeypatch):
             det.close()
 
 
+def test_too_close_filter_both_paths(monkeypatch):
+    """k_resolve resolves the connected components of the near graph side by side when the near triangle fits LDS and falls
+    back to one wave taking the rows in order when it does not (FID_RESOLVE_SERIAL=1 forces that): both must reproduce
+    _filterTooCloseCandidates stage by stage -- nested same-id quads (chains of near pairs across scales), a noisy frame
+    with hundreds of candidates, and a batch."""
+    from helpers import nested_same_id_frame
+    d = get_predefined_dictionary(6)
+    fr = make_frame(d, 41, width=1280, height=720, n_markers=10)
+    nested = nested_same_id_frame(d)
+    for serial in ("0", "1"):
+        monkeypatch.setenv("FID_RESOLVE_SERIAL", serial)
+        det = ArucoDetector(6, max_width=1280, max_height=720, max_batch=2)
+        try:
+            check_stages(det, fr.image, d)
+            if nested.shape == fr.image.shape:
+                check_stages(det, nested, d)
+            res = det.detect_markers_batch(np.stack([fr.image, fr.image[::-1].copy()]))
+            for k, img in enumerate((fr.image, fr.image[::-1].copy())):
+                oids, ocorners = oracle.detect(img, d)
+                assert res[k][1].tolist() == oids.tolist()
+                assert np.array_equal(res[k][0], ocorners)
+        finally:
+            det.close()
+
+
 def test_internal_capacity_is_reported_not_silent(monkeypatch):
     """Too small internal tables (seeds / survivors / points) must surface as FID_E_CAPACITY in both tracing modes --
     never as a silently different detection list."""

@@ -61,7 +61,7 @@ struct fid_ctx {
     long long fallbacks = 0;  // calls that fell back to the whole-border walk because the seed table was too small
     int max_chunks = 0;
     int walk_blocks = 0;  // one-wave workgroups per frame in the full walk pass (0 = automatic)
-    int walk_blocks_cap = 64;  // (the walks of a single frame want every seed in flight at once)
+    int walk_blocks_cap = 0;   // FID_WALK_CAP: most walker workgroups per frame (0: 64, 256 for calls of one or two frames)
     int copy_blocks = 0;
     int resolve_serial = 0;    // FID_RESOLVE_SERIAL=1: k_resolve's single-wave path even when the near triangle fits LDS (tests)
     int seed_shift = 0;        // FID_SEED_SHIFT: force the seed grid spacing 8 << shift (0 = by call size)
@@ -220,7 +220,8 @@ void set_geometry(fid_ctx *c, int W, int H, int gstride, int F)
     // more segments (tables, link / chain work).  Small calls take the densest grid their tables have room for.
     {
         int sh = 4;  // 128 px: batches (measured on the 256-frame bench batch: 64 px and 256 px are both slower)
-        if (F <= 16 && P.maxContours >= 32768 && c->max_chunks >= 2 * 65536) sh = 3;  // 64 px (one frame: 1.52 ms against 1.61 / 1.63 ms for 32 / 128 px)
+        if (F <= 16 && P.maxContours >= 32768 && c->max_chunks >= 2 * 65536) sh = 3;  // 64 px
+        if (F <= 2 && P.maxContours >= 65536 && c->max_chunks >= 4 * 65536) sh = 2;    // 32 px (one frame: 0.98 ms against 1.00 at 64 px)
         if (c->seed_shift > 0) sh = c->seed_shift;
         P.seedShift = sh < SEED_SHIFT_MIN ? SEED_SHIFT_MIN : (sh > SEED_SHIFT_MAX ? SEED_SHIFT_MAX : sh);
         P.seedHashCap = c->seed_hash_cap;
@@ -355,7 +356,9 @@ fid_status run_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H, int
         }
         // persistent walker workgroups (WALK_WAVES waves each) per frame: about 16 waves per CU over the sub-batch
         int wb = c->walk_blocks > 0 ? c->walk_blocks : (3072 / WALK_WAVES + Fs - 1) / Fs;  // (measured: 6 per frame at 128 frames beats 8 and 12)
-        wb = wb < 2 ? 2 : (wb > c->walk_blocks_cap ? c->walk_blocks_cap : wb);
+        // (the walks of one frame want every seed in flight at once: one frame, 32 px grid: seed walk 0.25 -> 0.115 ms)
+        const int wcap = c->walk_blocks_cap > 0 ? c->walk_blocks_cap : (Fs <= 2 ? 256 : 64);
+        wb = wb < 2 ? 2 : (wb > wcap ? wcap : wb);
         // kernels with a fixed number of workgroups per frame (sized for batches): a call of a few frames gets more of them
         const int gm = Fs >= 16 ? 1 : 16 / Fs;
         const int cap1 = pts_cap_first(P);

@@ -17,6 +17,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+#include <chrono>
+#include <mutex>
 #include <thread>
 
 #include "../../include/fid_abi.h"
@@ -633,12 +636,38 @@ static bool stag_launch_route_seq(fid_stag_ctx *c, StagJob &j)
 }
 
 // one segment of the job; FID_OK while the job is under way or has finished well (j.done tells which)
+#ifdef FID_DEBUG_STATS
+static std::atomic<long long> g_stag_ns_sync(0), g_stag_ns_seg[12];
+#define STAG_NOW() std::chrono::steady_clock::now()
+#define STAG_NS(a, b) std::chrono::duration_cast<std::chrono::nanoseconds>((b) - (a)).count()
+#endif
+static fid_status stag_advance_impl(fid_stag_ctx *c, StagJob &j);
 static fid_status stag_advance(fid_stag_ctx *c, StagJob &j)
+{
+#ifdef FID_DEBUG_STATS
+    const int seg0 = j.seg;
+    const auto t0 = STAG_NOW();
+    const fid_status rc = stag_advance_impl(c, j);
+    g_stag_ns_seg[seg0 < 11 ? seg0 : 11] += STAG_NS(t0, STAG_NOW());
+    return rc;
+#else
+    return stag_advance_impl(c, j);
+#endif
+}
+static fid_status stag_advance_impl(fid_stag_ctx *c, StagJob &j)
 {
     if (j.done) return j.rc;
     hipStream_t st = c->stream;
     if (hipSetDevice(c->device) != hipSuccess) return stag_finish(j, FID_E_HIP);
+#ifdef FID_DEBUG_STATS
+    {
+        const auto t0 = STAG_NOW();
+        if (j.seg > 0 && hipStreamSynchronize(st) != hipSuccess) return stag_finish(j, FID_E_HIP);
+        g_stag_ns_sync += STAG_NS(t0, STAG_NOW());
+    }
+#else
     if (j.seg > 0 && hipStreamSynchronize(st) != hipSuccess) return stag_finish(j, FID_E_HIP);
+#endif
     const int GRADIENT_THRESH = 16, ANCHOR_THRESH = 0, SCAN_INTERVAL = 1;  // DetectEdgesByEDPF, ED.cpp:155-169
     switch (j.seg) {
     case 0: {  // ---- smoothing, gradient, anchors, anchor sort
@@ -1035,9 +1064,11 @@ fid_status fid_stag_pose_last(fid_stag_ctx *c, const double K[9], const double D
     return hipStreamSynchronize(st) == hipSuccess ? FID_OK : FID_E_HIP;
 }
 
-// Frames over several contexts, ONE host thread: every context carries one frame at a time through the segments of
-// stag_advance; the thread goes round the contexts, one segment each.  A context that finishes a frame takes the next one.
-// Results are those of frame-by-frame calls (a frame never sees another frame's data).
+// Frames over several contexts: every context carries one frame at a time through the segments of stag_advance; a host
+// thread goes round ITS contexts, one segment each, so the waits of its contexts overlap.  A context that finishes a frame
+// takes the next one off a shared counter.  One thread keeps about a thousand frames a second going (a frame is ~60 launches,
+// ~15 copies and a 2 MB staging memcpy: 0.9 ms of host time), so the contexts are dealt out to FID_STAG_THREADS threads
+// (default 4, at most one per context).  Results are those of frame-by-frame calls (a frame never sees another frame's data).
 fid_status fid_stag_detect_markers_batch(fid_stag_ctx *const *ctxs, int32_t nctx, const uint8_t *frames, int32_t nframes, int32_t width, int32_t height,
                                          int32_t stride, int64_t frame_stride, const double K[9], const double D[5], double marker_size,
                                          fid_stag_marker *markers, fid_stag_pose_out *poses, int32_t cap_per_frame, int32_t *n_per_frame)
@@ -1047,38 +1078,67 @@ fid_status fid_stag_detect_markers_batch(fid_stag_ctx *const *ctxs, int32_t nctx
         if (!ctxs[t] || !ctxs[t]->d_words) return FID_E_INVALID_ARG;
     if (K && poses && !(marker_size > 0)) return FID_E_INVALID_ARG;
     for (int f = 0; f < nframes; f++) n_per_frame[f] = 0;  // every count is defined whatever happens to a frame
-    std::vector<StagJob> jobs((size_t)nctx);
-    std::vector<int> frame_of((size_t)nctx, -1);
+    int nthreads = 4;
+    if (const char *e = getenv("FID_STAG_THREADS")) nthreads = atoi(e);
+    nthreads = nthreads < 1 ? 1 : (nthreads > nctx ? nctx : nthreads);
+    std::atomic<int> next(0);
+    std::atomic<bool> stop(false);  // a failure other than "this frame did not fit" ends the call
+    std::mutex err_mutex;
     fid_status first_err = FID_OK;
-    bool stop = false;  // a failure other than "this frame did not fit" ends the call
-    int next = 0, live = 0;
-    for (;;) {
-        for (int t = 0; t < nctx; t++) {
-            if (frame_of[t] < 0 && next < nframes && !stop) {  // idle context: next frame
-                const int f = next++;
-                StagJob j;
-                j.gray = frames + (size_t)f * frame_stride; j.width = width; j.height = height; j.stride = stride;
-                j.out = markers + (size_t)f * cap_per_frame; j.cap = cap_per_frame; j.n_out = n_per_frame + f;
-                j.last = (K && poses) ? SS_POSE : SS_MARKERS;
-                j.K = K; j.D = D; j.marker_size = marker_size;
-                j.poses = poses ? poses + (size_t)f * cap_per_frame : nullptr; j.pose_cap = cap_per_frame;
-                jobs[t] = j;
-                frame_of[t] = f;
-                live++;
-            }
-            if (frame_of[t] < 0) continue;
-            (void)stag_advance(ctxs[t], jobs[t]);
-            if (jobs[t].done) {
-                if (jobs[t].rc != FID_OK) {
-                    if (first_err == FID_OK) first_err = jobs[t].rc;  // the first failure is the call's status ...
-                    if (jobs[t].rc != FID_E_CAPACITY) stop = true;     // ... a frame that did not fit costs only that frame
+    auto worker = [&](int tid) {
+        std::vector<int> mine;  // this thread's contexts
+        for (int t = tid; t < nctx; t += nthreads) mine.push_back(t);
+        std::vector<StagJob> jobs(mine.size());
+        std::vector<int> frame_of(mine.size(), -1);
+        int live = 0;
+        bool dry = false;
+        for (;;) {
+            for (size_t k = 0; k < mine.size(); k++) {
+                if (frame_of[k] < 0 && !dry && !stop.load(std::memory_order_relaxed)) {  // idle context: next frame
+                    const int f = next.fetch_add(1, std::memory_order_relaxed);
+                    if (f >= nframes) {
+                        dry = true;
+                    } else {
+                        StagJob j;
+                        j.gray = frames + (size_t)f * frame_stride; j.width = width; j.height = height; j.stride = stride;
+                        j.out = markers + (size_t)f * cap_per_frame; j.cap = cap_per_frame; j.n_out = n_per_frame + f;
+                        j.last = (K && poses) ? SS_POSE : SS_MARKERS;
+                        j.K = K; j.D = D; j.marker_size = marker_size;
+                        j.poses = poses ? poses + (size_t)f * cap_per_frame : nullptr; j.pose_cap = cap_per_frame;
+                        jobs[k] = j;
+                        frame_of[k] = f;
+                        live++;
+                    }
                 }
-                frame_of[t] = -1;
-                live--;
+                if (frame_of[k] < 0) continue;
+                (void)stag_advance(ctxs[mine[k]], jobs[k]);
+                if (jobs[k].done) {
+                    if (jobs[k].rc != FID_OK) {
+                        std::lock_guard<std::mutex> g(err_mutex);
+                        if (first_err == FID_OK) first_err = jobs[k].rc;               // the first failure is the call's status ...
+                        if (jobs[k].rc != FID_E_CAPACITY) stop.store(true, std::memory_order_relaxed);  // ... a frame that did not fit costs only that frame
+                    }
+                    frame_of[k] = -1;
+                    live--;
+                }
             }
+            if (live == 0 && (dry || stop.load(std::memory_order_relaxed))) break;
         }
-        if (live == 0 && (next >= nframes || stop)) break;
+    };
+    if (nthreads == 1) {
+        worker(0);
+    } else {
+        std::vector<std::thread> pool;
+        for (int t = 1; t < nthreads; t++) pool.emplace_back(worker, t);
+        worker(0);
+        for (auto &th : pool) th.join();
     }
+#ifdef FID_DEBUG_STATS
+    fprintf(stderr, "stag batch: %d frames, %d threads; host ms per frame: in sync %.3f; segments (incl. their sync)", nframes, nthreads,
+            g_stag_ns_sync.exchange(0) * 1e-6 / (nframes > 0 ? nframes : 1));
+    for (int k = 0; k < 12; k++) fprintf(stderr, " %.3f", g_stag_ns_seg[k].exchange(0) * 1e-6 / (nframes > 0 ? nframes : 1));
+    fprintf(stderr, "\n");
+#endif
     return first_err;
 }
 

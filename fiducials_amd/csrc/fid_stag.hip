@@ -722,8 +722,11 @@ static fid_status stag_advance_impl(fid_stag_ctx *c, StagJob &j)
                         hipMemsetAsync(c->d_prodflag, 0, (size_t)na * 4, st) == hipSuccess && hipMemsetAsync(c->d_blkpix, 0, (size_t)na * 4, st) == hipSuccess &&
                         hipMemsetAsync(c->d_blksegs, 0, (size_t)na * 4, st) == hipSuccess;
         if (!ok) return stag_finish(j, FID_E_HIP);
-        hipLaunchKernelGGL(k_stag_ccl_init, dim3(nb), dim3(256), 0, st, c->d_grad, n, 16, c->d_label, c->d_csize, c->d_canch);
-        hipLaunchKernelGGL(k_stag_ccl_merge, dim3(nb), dim3(256), 0, st, W, H, c->d_label);
+        {
+            const dim3 tiles((W + CCL_TW - 1) / CCL_TW, (H + CCL_TH - 1) / CCL_TH);
+            hipLaunchKernelGGL(k_stag_ccl_tile, tiles, dim3(256), 0, st, c->d_grad, W, H, 16, c->d_label, c->d_csize, c->d_canch);
+            hipLaunchKernelGGL(k_stag_ccl_border, tiles, dim3(128), 0, st, W, H, c->d_label);
+        }
         hipLaunchKernelGGL(k_stag_ccl_flatten, dim3(nb), dim3(256), 0, st, n, c->d_label, c->d_edge, c->d_csize, c->d_canch);
         hipLaunchKernelGGL(k_stag_comp_alloc, dim3(nb), dim3(256), 0, st, n, c->d_label, c->d_csize, c->d_canch, c->d_cursors, c->max_comps, c->d_caps,
                            c->d_comps, c->d_cidmap);
@@ -767,8 +770,12 @@ static fid_status stag_advance_impl(fid_stag_ctx *c, StagJob &j)
             if (nc > 0)
                 hipLaunchKernelGGL(k_stag_route_extract, dim3((nc + 3) / 4), dim3(256), 0, st, j.R, A, c->d_comps, c->d_cursors, c->d_next, c->d_n,
                                    c->d_blkpix, c->d_blksegs, c->d_blkwhere, ovf);
-            hipLaunchKernelGGL(k_stag_scan_counts, dim3(1), dim3(1024), 0, st, c->d_blkpix, (const int *)c->d_n, c->d_rcount + 1);
-            hipLaunchKernelGGL(k_stag_scan_counts, dim3(1), dim3(1024), 0, st, c->d_blksegs, (const int *)c->d_n, c->d_rcount);
+            {
+                StagScanJobs sj;
+                sj.counts[0] = c->d_blkpix; sj.total[0] = c->d_rcount + 1;
+                sj.counts[1] = c->d_blksegs; sj.total[1] = c->d_rcount;
+                hipLaunchKernelGGL(k_stag_scan_counts_n, dim3(2), dim3(1024), 0, st, sj, (const int *)c->d_n);
+            }
             hipLaunchKernelGGL(k_stag_route_gather, dim3((na + 3) / 4), dim3(256), 0, st, A, c->d_comps, c->d_n, c->d_prodflag, c->d_blkpix, c->d_blksegs,
                                c->d_blkwhere, c->d_outpix, c->d_segs, j.R.capOut, j.R.capSegs, ovf);
             if (hipGetLastError() != hipSuccess) return stag_finish(j, FID_E_HIP);

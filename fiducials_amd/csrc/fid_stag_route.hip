@@ -497,44 +497,93 @@ __device__ __forceinline__ int ccl_find(const int *L, int a)
     }
 }
 
-__global__ __launch_bounds__(256) void k_stag_ccl_init(const int16_t *__restrict__ grad, int n, int thresh, int *__restrict__ label,
-                                                       int *__restrict__ csize, int *__restrict__ canch)
+// Connected components of {grad >= thresh} (8-connectivity) in two steps: every 64 x 16 tile labels itself in LDS (union-find,
+// hooks by atomicMin), writes the global index of each pixel's tile-local root, and the pixels on the tile borders then
+// merge the tiles through the same union-find in global memory.  Which neighbours have to be united: the one above if it is
+// foreground (it holds its own left and right neighbours), else the two diagonal ones above; and the left one.  (A single
+// pass over all pixels with all four preceding neighbours in global memory took 176 us of the whole GPU per frame.)
+#define CCL_TW 64
+#define CCL_TH 16
+__device__ __forceinline__ void ccl_union(int *L, int a, int b)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const bool fg = grad[i] >= thresh;
-    label[i] = fg ? i : -1;
-    if (fg) {  // a root is a foreground pixel: the per-root counters only have to be clean there
-        csize[i] = 0;
-        canch[i] = 0;
+    while (true) {
+        a = ccl_find(L, a);
+        b = ccl_find(L, b);
+        if (a == b) return;
+        if (a < b) {
+            const int t = a;
+            a = b;
+            b = t;
+        }
+        const int old = atomicMin(&L[a], b);  // hook the larger root under the smaller one
+        if (old == a) return;
+        a = old;
     }
 }
 
-__global__ __launch_bounds__(256) void k_stag_ccl_merge(int W, int H, int *label)
+__global__ __launch_bounds__(256) void k_stag_ccl_tile(const int16_t *__restrict__ grad, int W, int H, int thresh, int *__restrict__ label,
+                                                       int *__restrict__ csize, int *__restrict__ canch)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= W * H || label[i] < 0) return;
-    const int r = i / W, c = i - r * W;
-    // the four neighbours that precede the pixel in raster order (border pixels are background: grad = thresh - 1)
-    const int nb[4] = {c > 0 ? i - 1 : -1, (r > 0 && c > 0) ? i - W - 1 : -1, r > 0 ? i - W : -1, (r > 0 && c < W - 1) ? i - W + 1 : -1};
-    for (int k = 0; k < 4; k++) {
-        int b = nb[k];
-        if (b < 0 || label[b] < 0) continue;
-        int a = i;
-        while (true) {
-            a = ccl_find(label, a);
-            b = ccl_find(label, b);
-            if (a == b) break;
-            if (a < b) {
-                const int t = a;
-                a = b;
-                b = t;
-            }
-            const int old = atomicMin(&label[a], b);  // hook the larger root under the smaller one
-            if (old == a) break;
-            a = old;
+    __shared__ int L[CCL_TW * CCL_TH];
+    const int x0 = blockIdx.x * CCL_TW, y0 = blockIdx.y * CCL_TH;
+    for (int k = threadIdx.x; k < CCL_TW * CCL_TH; k += 256) {
+        const int x = x0 + (k % CCL_TW), y = y0 + (k / CCL_TW);
+        const bool fg = x < W && y < H && grad[y * W + x] >= thresh;
+        L[k] = fg ? k : -1;
+        if (fg) {  // a root is a foreground pixel: the per-root counters only have to be clean there
+            csize[y * W + x] = 0;
+            canch[y * W + x] = 0;
         }
     }
+    __syncthreads();
+    for (int k = threadIdx.x; k < CCL_TW * CCL_TH; k += 256) {
+        if (L[k] < 0) continue;
+        const int lx = k % CCL_TW, ly = k / CCL_TW;
+        if (ly > 0) {
+            if (L[k - CCL_TW] >= 0) {
+                ccl_union(L, k, k - CCL_TW);
+            } else {
+                if (lx > 0 && L[k - CCL_TW - 1] >= 0) ccl_union(L, k, k - CCL_TW - 1);
+                if (lx < CCL_TW - 1 && L[k - CCL_TW + 1] >= 0) ccl_union(L, k, k - CCL_TW + 1);
+            }
+        }
+        if (lx > 0 && L[k - 1] >= 0) ccl_union(L, k, k - 1);
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < CCL_TW * CCL_TH; k += 256) {
+        const int x = x0 + (k % CCL_TW), y = y0 + (k / CCL_TW);
+        if (x >= W || y >= H) continue;
+        int v = -1;
+        if (L[k] >= 0) {
+            const int r = ccl_find(L, k);
+            v = (y0 + r / CCL_TW) * W + x0 + (r % CCL_TW);
+        }
+        label[y * W + x] = v;
+    }
+}
+
+// the pixels of a tile's first row, first column and last column against their neighbours in the adjacent tiles
+__global__ __launch_bounds__(128) void k_stag_ccl_border(int W, int H, int *label)
+{
+    const int t = threadIdx.x;
+    int lx, ly;
+    if (t < CCL_TW) { lx = t; ly = 0; }
+    else if (t < CCL_TW + CCL_TH) { lx = 0; ly = t - CCL_TW; }
+    else if (t < CCL_TW + 2 * CCL_TH) { lx = CCL_TW - 1; ly = t - CCL_TW - CCL_TH; }
+    else return;
+    if (t >= CCL_TW && ly == 0) return;  // (the corners belong to the row)
+    const int c = blockIdx.x * CCL_TW + lx, r = blockIdx.y * CCL_TH + ly;
+    if (c >= W || r >= H) return;
+    const int i = r * W + c;
+    if (label[i] < 0) return;
+    const bool up = r > 0, left = c > 0, right = c < W - 1;
+    if (up && label[i - W] >= 0) {
+        if (ly == 0) ccl_union(label, i, i - W);
+    } else if (up) {
+        if (left && (lx == 0 || ly == 0) && label[i - W - 1] >= 0) ccl_union(label, i, i - W - 1);
+        if (right && (lx == CCL_TW - 1 || ly == 0) && label[i - W + 1] >= 0) ccl_union(label, i, i - W + 1);
+    }
+    if (left && lx == 0 && label[i - 1] >= 0) ccl_union(label, i, i - 1);
 }
 
 __global__ __launch_bounds__(256) void k_stag_ccl_flatten(int n, int *label, const uint8_t *__restrict__ anchors, int *__restrict__ csize,
@@ -851,30 +900,45 @@ __global__ __launch_bounds__(256) void k_stag_route_walk(StagRoute G, StagArenas
 // next[r] = the smallest producing rank > r, or -1 (one workgroup, chunks of 1024 from the top)
 __global__ __launch_bounds__(1024) void k_stag_next_above(const int *__restrict__ prodflag, const unsigned *__restrict__ n_anchors, int *__restrict__ next)
 {
-    __shared__ int s[1024];
-    __shared__ int s_carry;
-    const int tid = threadIdx.x, n = (int)*n_anchors;
-    if (tid == 0) s_carry = -1;
-    __syncthreads();
-    for (int top = n; top > 0; top -= 1024) {
-        // thread t looks at rank r = top - 1 - t: ranks run downwards with t
-        const int r = top - 1 - tid;
-        const int v = (r >= 0 && prodflag[r]) ? r : -1;
-        // for every t: the producing rank with the largest t' < t (= nearest above), i.e. an exclusive "last set" scan
-        s[tid] = v;
-        __syncthreads();
-        for (int d = 1; d < 1024; d <<= 1) {
-            const int o = tid >= d ? s[tid - d] : -1;
-            __syncthreads();
-            if (s[tid] < 0) s[tid] = o;  // keep the nearest (largest t') set value: own slot wins, else what came from the left
-            __syncthreads();
+    // next[r] = the smallest producing rank above r (-1: none): a running minimum over the ranks taken from the top down,
+    // 8 consecutive ranks per thread, wave scans by shuffles, one barrier pair per 8192 ranks
+    __shared__ int s_w[16];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = (int)*n_anchors;
+    constexpr int PER = 8;
+    int carry = INT_MAX;
+    for (int top = n; top > 0; top -= 1024 * PER) {
+        const int r0 = top - 1 - tid * PER;  // this thread's ranks: r0, r0 - 1, ...
+        int f[PER], loc = INT_MAX;
+#pragma unroll
+        for (int k = 0; k < PER; k++) {
+            const int r = r0 - k;
+            f[k] = (r >= 0 && prodflag[r]) ? r : INT_MAX;
+            loc = min(loc, f[k]);
         }
-        // s[t] = nearest producing rank at t' <= t; exclusive: t' < t
-        const int incl_prev = tid > 0 ? s[tid - 1] : -1;
-        const int carry = s_carry;
-        if (r >= 0) next[r] = incl_prev >= 0 ? incl_prev : carry;
+        int incl = loc;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(incl, d, 64);
+            if (lane >= d) incl = min(incl, o);
+        }
+        if (lane == 63) s_w[wv] = incl;
         __syncthreads();
-        if (tid == 1023) s_carry = s[1023] >= 0 ? s[1023] : carry;
+        int wpre = INT_MAX, tot = INT_MAX;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const int t = s_w[k];
+            if (k < wv) wpre = min(wpre, t);
+            tot = min(tot, t);
+        }
+        const int left = __shfl_up(incl, 1, 64);
+        int run = min(min(carry, wpre), lane > 0 ? left : INT_MAX);
+#pragma unroll
+        for (int k = 0; k < PER; k++) {
+            const int r = r0 - k;
+            if (r >= 0) next[r] = run == INT_MAX ? -1 : run;
+            run = min(run, f[k]);
+        }
+        carry = min(carry, tot);
         __syncthreads();
     }
 }

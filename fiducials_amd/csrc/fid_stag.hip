@@ -505,7 +505,8 @@ fid_status fid_stag_create(int libraryHD, int errorCorrection, int max_width, in
         const char *e = getenv("FID_STAG_ROUTE");
         c->route_mode = (e && !strcmp(e, "seq")) ? 0 : 1;
         c->route_tile = (e && !strcmp(e, "notile")) ? 0 : 1;  // "notile": component-parallel, walks in global memory
-        ok = hipFuncSetAttribute((const void *)k_stag_route_walk, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) == hipSuccess;
+        ok = hipFuncSetAttribute((const void *)k_stag_route_walk, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) == hipSuccess &&
+             hipFuncSetAttribute((const void *)k_stag_comp_sort_big, hipFuncAttributeMaxDynamicSharedMemorySize, STAG_SORT_BIG * 4) == hipSuccess;
     }
     ok = ok && hipMalloc((void **)&c->d_smooth2, n) == hipSuccess && hipMalloc((void **)&c->d_vgrad, n * 2) == hipSuccess &&
          hipMalloc((void **)&c->d_vhist, STAG_BINS * 4) == hipSuccess && hipMalloc((void **)&c->d_prob, STAG_BINS * 8) == hipSuccess &&
@@ -760,6 +761,8 @@ static fid_status stag_advance_impl(fid_stag_ctx *c, StagJob &j)
             int *ovf = c->d_cursors + 8;
             if (nc > 0) {
                 hipLaunchKernelGGL(k_stag_comp_sort, dim3((nc + 3) / 4), dim3(256), 0, st, c->d_comps, c->d_cursors, c->d_aslots);
+                if (cur[9] > STAG_SORT_WAVE)  // (cur[9]: most anchors in one component)
+                    hipLaunchKernelGGL(k_stag_comp_sort_big, dim3(nc), dim3(1024), (size_t)STAG_SORT_BIG * 4, st, c->d_comps, c->d_cursors, c->d_aslots);
                 // LDS per workgroup = the largest tile a component of this frame asks for (components whose box does not fit 150 KB
                 // walk in global memory): frames of small components keep many workgroups per CU
                 const int lds = c->route_tile ? ((cur[10] + 1023) / 1024) * 1024 : 0;

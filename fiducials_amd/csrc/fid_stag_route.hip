@@ -654,16 +654,29 @@ __global__ __launch_bounds__(256) void k_stag_comp_alloc(int n, const int *__res
     cidmap[i] = cid;
 }
 
+// (64 consecutive ranks hold many anchors of the frame's big components: one atomic per (wave, component), the anchors of
+//  a group placed in rank order)
 __global__ __launch_bounds__(256) void k_stag_comp_fill(const int32_t *__restrict__ sorted, const unsigned *__restrict__ n_anchors,
                                                         const int *__restrict__ label, const int *__restrict__ cidmap, const StagComp *__restrict__ comps,
                                                         int *__restrict__ fill, int *__restrict__ aslots)
 {
-    const int r = blockIdx.x * 256 + threadIdx.x;
-    if (r >= (int)*n_anchors) return;
-    const int cid = cidmap[label[sorted[r]]];
-    if (cid < 0 || comps[cid].nanch == 0) return;
-    const int pos = atomicAdd(&fill[cid], 1);
-    aslots[comps[cid].anch_base + pos] = r;
+    const int r = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63;
+    int cid = -1;
+    if (r < (int)*n_anchors) {
+        cid = cidmap[label[sorted[r]]];
+        if (cid >= 0 && comps[cid].nanch == 0) cid = -1;
+    }
+    unsigned long long pending = __ballot(cid >= 0);
+    while (pending) {
+        const int lead = __builtin_ctzll(pending);
+        const int c0 = __builtin_amdgcn_readlane(cid, lead);
+        const unsigned long long m = __ballot(cid == c0);
+        int base = 0;
+        if (lane == lead) base = atomicAdd(&fill[c0], (int)__builtin_popcountll(m));
+        base = __builtin_amdgcn_readlane(base, lead);
+        if (cid == c0) aslots[comps[c0].anch_base + base + (int)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = r;
+        pending &= ~m;
+    }
 }
 
 // bounding boxes of the components that have anchors; cursors[10] = the largest LDS tile (bytes) a component would need.
@@ -684,13 +697,23 @@ __global__ __launch_bounds__(256) void k_stag_comp_bbox(int W, int n, const int 
         const int c0 = __builtin_amdgcn_readlane(cid, lead);
         const bool mine = cid == c0;
         const unsigned long long m = __ballot(mine);
-        int mnr = mine ? r : 0x7fffffff, mnc = mine ? c : 0x7fffffff, mxr = mine ? r : -1, mxc = mine ? c : -1;
+        int mnr, mnc, mxr, mxc;
+        const int lfirst = __builtin_ctzll(m), llast = 63 - __builtin_clzll(m);
+        const int rfirst = __builtin_amdgcn_readlane(r, lfirst), rlast = __builtin_amdgcn_readlane(r, llast);
+        if (rfirst == rlast) {
+            // the group lies in one image row (a wave is 64 consecutive pixels): its box is its first and last lane
+            mnr = mxr = rfirst;
+            mnc = __builtin_amdgcn_readlane(c, lfirst);
+            mxc = __builtin_amdgcn_readlane(c, llast);
+        } else {
+            mnr = mine ? r : 0x7fffffff; mnc = mine ? c : 0x7fffffff; mxr = mine ? r : -1; mxc = mine ? c : -1;
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            mnr = min(mnr, __shfl_xor(mnr, off, 64));
-            mnc = min(mnc, __shfl_xor(mnc, off, 64));
-            mxr = max(mxr, __shfl_xor(mxr, off, 64));
-            mxc = max(mxc, __shfl_xor(mxc, off, 64));
+            for (int off = 32; off > 0; off >>= 1) {
+                mnr = min(mnr, __shfl_xor(mnr, off, 64));
+                mnc = min(mnc, __shfl_xor(mnc, off, 64));
+                mxr = max(mxr, __shfl_xor(mxr, off, 64));
+                mxc = max(mxc, __shfl_xor(mxc, off, 64));
+            }
         }
         if (lane == lead) {
             atomicMin(&comps[c0].minr, mnr);
@@ -715,6 +738,8 @@ __global__ __launch_bounds__(256) void k_stag_comp_tilemax(const StagComp *__res
 // ranks of one component, descending: bitonic sort of the (padded, -1 filled) slice, one wave per component; slices of up to
 // 2048 entries are sorted in LDS
 #define STAG_SORT_LDS 2048
+#define STAG_SORT_WAVE 256   // slices up to here: a wave each (k_stag_comp_sort); up to STAG_SORT_BIG: a workgroup of 1024 each
+#define STAG_SORT_BIG 16384
 __global__ __launch_bounds__(256) void k_stag_comp_sort(const StagComp *__restrict__ comps, const int *__restrict__ cursors, int *aslots)
 {
     __shared__ int s_buf[4][STAG_SORT_LDS];
@@ -724,6 +749,7 @@ __global__ __launch_bounds__(256) void k_stag_comp_sort(const StagComp *__restri
     if (C.nanch < 2) return;
     int *g = aslots + C.anch_base;
     const int P = C.anch_cap;
+    if (P > STAG_SORT_WAVE && P <= STAG_SORT_BIG) return;  // k_stag_comp_sort_big's
     const bool in_lds = P <= STAG_SORT_LDS;
     int *a = in_lds ? s_buf[wv] : g;
     if (in_lds) {
@@ -756,6 +782,37 @@ __global__ __launch_bounds__(256) void k_stag_comp_sort(const StagComp *__restri
     }
     if (in_lds)
         for (int i = lane; i < P; i += 64) g[i] = a[i];
+}
+
+// the same for the slices of 257 .. 16384 entries (a frame's larger components): one workgroup of 1024 per component, the
+// slice in up to 64 KB of LDS (one wave took 118 us for a slice of 2048: 66 passes of 32 rounds each)
+__global__ __launch_bounds__(1024) void k_stag_comp_sort_big(const StagComp *__restrict__ comps, const int *__restrict__ cursors, int *aslots)
+{
+    extern __shared__ int s_big[];
+    const int cid = blockIdx.x;
+    if (cid >= cursors[0]) return;
+    const StagComp C = comps[cid];
+    const int P = C.anch_cap;
+    if (C.nanch < 2 || P <= STAG_SORT_WAVE || P > STAG_SORT_BIG) return;
+    int *g = aslots + C.anch_base;
+    for (int i = threadIdx.x; i < P; i += 1024) s_big[i] = g[i];
+    __syncthreads();
+    for (int k = 2; k <= P; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < P; i += 1024) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const int x = s_big[i], y = s_big[l];
+                    const bool desc = (i & k) == 0;
+                    if (desc ? x < y : x > y) {
+                        s_big[i] = y;
+                        s_big[l] = x;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    for (int i = threadIdx.x; i < P; i += 1024) g[i] = s_big[i];
 }
 
 struct StagArenas {

@@ -697,23 +697,13 @@ __global__ __launch_bounds__(256) void k_stag_comp_bbox(int W, int n, const int 
         const int c0 = __builtin_amdgcn_readlane(cid, lead);
         const bool mine = cid == c0;
         const unsigned long long m = __ballot(mine);
-        int mnr, mnc, mxr, mxc;
-        const int lfirst = __builtin_ctzll(m), llast = 63 - __builtin_clzll(m);
-        const int rfirst = __builtin_amdgcn_readlane(r, lfirst), rlast = __builtin_amdgcn_readlane(r, llast);
-        if (rfirst == rlast) {
-            // the group lies in one image row (a wave is 64 consecutive pixels): its box is its first and last lane
-            mnr = mxr = rfirst;
-            mnc = __builtin_amdgcn_readlane(c, lfirst);
-            mxc = __builtin_amdgcn_readlane(c, llast);
-        } else {
-            mnr = mine ? r : 0x7fffffff; mnc = mine ? c : 0x7fffffff; mxr = mine ? r : -1; mxc = mine ? c : -1;
+        int mnr = mine ? r : 0x7fffffff, mnc = mine ? c : 0x7fffffff, mxr = mine ? r : -1, mxc = mine ? c : -1;
 #pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                mnr = min(mnr, __shfl_xor(mnr, off, 64));
-                mnc = min(mnc, __shfl_xor(mnc, off, 64));
-                mxr = max(mxr, __shfl_xor(mxr, off, 64));
-                mxc = max(mxc, __shfl_xor(mxc, off, 64));
-            }
+        for (int off = 32; off > 0; off >>= 1) {
+            mnr = min(mnr, __shfl_xor(mnr, off, 64));
+            mnc = min(mnc, __shfl_xor(mnc, off, 64));
+            mxr = max(mxr, __shfl_xor(mxr, off, 64));
+            mxc = max(mxc, __shfl_xor(mxc, off, 64));
         }
         if (lane == lead) {
             atomicMin(&comps[c0].minr, mnr);

@@ -519,7 +519,18 @@ fid_status run_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H, int
     }
     fid_status rc = FID_OK;
     if (c->h_global->overflow) {
-        c->last_error = c->h_global->overflow == 16u ? "internal error: broken segment chain" : "internal capacity exceeded (starts/contours/stack/points): raise fid_limits";
+        const unsigned ov = c->h_global->overflow;
+        if (ov & 16u) {
+            c->last_error = "internal error: broken segment chain";
+        } else {
+            // which table: so that the caller knows which limit to raise
+            c->last_error = "internal capacity exceeded:";
+            if (ov & 1u) c->last_error += " max_starts_per_frame";
+            if (ov & 2u) c->last_error += " max_contours_per_frame";
+            if (ov & 4u) c->last_error += " approximation stack";
+            if (ov & 8u) c->last_error += " max_points_per_frame";
+            c->last_error += " (raise fid_limits)";
+        }
         rc = FID_E_CAPACITY;
     }
     for (int f = 0; f < F; f++) {

@@ -488,3 +488,18 @@ def test_every_dictionary_family_all_stages(dic, minlen):
         assert len(ids) >= minlen and set(ids.tolist()) <= set(fr.ids.tolist())
     finally:
         det.close()
+
+
+def test_randomised_sweep_equals_the_oracle():
+    """tools/gpu_stress.py's sweep in small: odd and even frame sizes, small and large markers, noise, rectangle clutter, each
+    frame through a single-frame context (32 px seed grid) and a batch context (64 px grid); ids and corners `==` the oracle's.
+    A table that is too small for a frame is a reported FID_E_CAPACITY (the tool retries with larger limits), never a
+    different result."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "tools", "gpu_stress.py"), "21", "7000"], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    assert "21 cases, 0 mismatches" in p.stdout

@@ -60,6 +60,11 @@ class FidCandidate(C.Structure):
                 ("is_hole", C.c_int32), ("corners", C.c_float * 8)]
 
 
+class FidJpegInfo(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("components", C.c_int32), ("h_samp", C.c_int32), ("v_samp", C.c_int32),
+                ("restart_interval", C.c_int32), ("blocks_w", C.c_int32 * 3), ("blocks_h", C.c_int32 * 3), ("scan_bytes", C.c_int64)]
+
+
 FID_OK = 0
 FID_E_INVALID_ARG, FID_E_NO_DEVICE, FID_E_HIP, FID_E_CAPACITY, FID_E_OUT_OF_MEMORY, FID_E_UNSUPPORTED = 1, 2, 3, 4, 5, 6
 ENC = {"mono8": 0, "bgr8": 1, "rgb8": 2}
@@ -71,6 +76,8 @@ SYMBOLS = [
     "fid_detect_batch", "fid_detect_device", "fid_pose", "fid_pose_last", "fid_tap_bytes", "fid_tap_read",
     "fid_last_stage_ms", "fid_last_launches", "fid_stream", "fid_strerror", "fid_last_error", "fid_abi_version",
     "fid_stag_create", "fid_stag_destroy", "fid_stag_edge_frontend", "fid_stag_detect_edges", "fid_stag_detect_edges_validated", "fid_stag_detect_lines", "fid_stag_detect_lines_validated", "fid_stag_detect_quads", "fid_stag_host_tables", "fid_stag_load_library", "fid_stag_detect_markers_unrefined", "fid_stag_detect_markers", "fid_stag_pose_last", "fid_stag_detect_markers_batch", "fid_stag_tap_bytes", "fid_stag_tap_read",
+    "fid_jpeg_probe", "fid_jpeg_create", "fid_jpeg_destroy", "fid_jpeg_decode", "fid_jpeg_device_ptr", "fid_jpeg_tap_bytes", "fid_jpeg_tap_read",
+    "fid_jpeg_last_rounds", "fid_jpeg_last_error",
 ]
 
 _LIB = None
@@ -142,5 +149,19 @@ def load():
     L.fid_stag_tap_bytes.argtypes = [vp, C.c_int]
     L.fid_stag_tap_bytes.restype = i64
     L.fid_stag_tap_read.argtypes = [vp, C.c_int, vp, i64]
+    L.fid_jpeg_probe.argtypes = [vp, i64, C.POINTER(FidJpegInfo)]
+    L.fid_jpeg_create.argtypes = [i32, i32, i32, i32, C.POINTER(vp)]
+    L.fid_jpeg_destroy.argtypes = [vp]
+    L.fid_jpeg_destroy.restype = None
+    L.fid_jpeg_decode.argtypes = [vp, C.POINTER(vp), C.POINTER(i64), i32, C.c_int, vp, i64]
+    L.fid_jpeg_device_ptr.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(i64)]
+    L.fid_jpeg_device_ptr.restype = vp
+    L.fid_jpeg_tap_bytes.argtypes = [vp, C.c_int, i32]
+    L.fid_jpeg_tap_bytes.restype = i64
+    L.fid_jpeg_tap_read.argtypes = [vp, C.c_int, i32, vp, i64]
+    L.fid_jpeg_last_rounds.argtypes = [vp]
+    L.fid_jpeg_last_rounds.restype = i32
+    L.fid_jpeg_last_error.argtypes = [vp]
+    L.fid_jpeg_last_error.restype = C.c_char_p
     _LIB = L
     return L

@@ -1071,3 +1071,4 @@ int32_t fid_abi_version(void) { return FID_ABI_VERSION; }
 }  // extern "C"
 
 #include "fid_stag.hip"
+#include "fid_jpeg.hip"

@@ -1,0 +1,1059 @@
+// fid_jpeg.hip -- JPEG ingest on the device (include/fid_abi.h: fid_jpeg_*).  Part of the fid_api.hip translation unit.
+//
+// Where it sits: with `transport:=compressed` (aruco_detect/launch/aruco_detect.launch:6, the launch file's default) every
+// frame reaches FiducialsNode::imageCallback (aruco_detect.cpp:332) through image_transport's compressed subscriber, which
+// calls cv::imdecode -- libjpeg(-turbo) with its defaults: JDCT_ISLOW, fancy upsampling, JFIF YCbCr -> RGB.  The arithmetic
+// is libjpeg's (a third-party dependency, not in the reference tree); oracle/jpeg_oracle.c restates it and is pinned bit for
+// bit on libjpeg-turbo's own output, and the parity tests compare every stage of this file with that oracle.
+//
+// Stages (all integer work, bit-exact):
+//   host   header parse (markers, quantisation and Huffman tables), 16-bit code lookup tables (cached per table contents)
+//   J1  k_jpeg_huff<0/1/2>  entropy decoding (jdhuff.c decode_mcu).  A Huffman stream can only be read from the front -- but it
+//       re-synchronises: a decoder started at a wrong bit falls into step with the true symbol boundaries after a few
+//       symbols.  The scan is cut into sub-sequences of JP_SUB bytes, one lane each:
+//         <0> every lane decodes its sub-sequence from its first bit (speculative: only sub-sequence 0 starts on a symbol)
+//             and leaves its EXIT STATE: bit position, block within the MCU, zig-zag index;
+//         <1> round r: lane i decodes sub-sequence i again from the exit state of lane i-1; a lane whose entry did not change
+//             in the previous round keeps its result.  Sub-sequence 0 is exact from the start, so exactness spreads at least
+//             one sub-sequence per round -- in practice everything agrees after two or three rounds (restart markers and
+//             block ends are where decoders meet).  When no exit state changed, every exit state is the true one;
+//         scan of the blocks completed per sub-sequence -> where each lane's output goes;
+//         <2> the same decode once more, now writing coefficients (sparse: the buffer was cleared).
+//       Byte stuffing (FF 00) and restart markers are handled by the bit reader on the fly, positions are raw bit offsets
+//       that never point into a stuffed byte (so equal logical positions compare equal).
+//   J2  k_jpeg_dc     DC prediction undone: prefix sums of the differences per component in scan order, restarted at every
+//                     restart interval
+//   J3  k_jpeg_idct   dequantise + jidctint.c (13-bit constants, two passes), eight lanes per block, transposed through LDS
+//   J4  k_jpeg_color  jdsample.c fancy upsampling (h2v1 / h2v2, edge rows and columns as jdmainct.c replicates them) +
+//                     jdcolor.c YCbCr -> RGB, written as BGR (cv::imdecode) or straight as the gray image
+//                     cvtColor(BGR2GRAY) makes of it (K0's formula) -- the detector's input, without the colour image
+#include <unordered_map>
+
+#define JP_SUB 64          // bytes per sub-sequence
+#define JP_TPB 256         // lanes (sub-sequences) per workgroup
+#define JP_PAD 64          // bytes staged beyond the workgroup's last sub-sequence (a lane stops within one symbol of its end)
+#define JP_LOOK 10         // bits of the LDS first-level code tables
+#define JP_MAX_LUT 16      // cached 16-bit code tables
+
+struct JpImage {
+    unsigned long long scan_off;   // into the packed scan bytes of the call
+    unsigned long long coef_base;  // int16 units: this frame's coefficient area
+    unsigned long long plane_base; // bytes: this frame's plane area
+    unsigned long long dcs_base;   // int32 units: this frame's DC scratch
+    uint32_t scan_len, sub_base, nsub, nblocks;
+    int32_t w, h, ncomp, hs, vs, bpm, mcux, nmcu, restart;
+    int32_t bw[3], bh[3];
+    uint32_t coef_off[3], plane_off[3];  // within the frame's areas (int16 units / bytes)
+    int32_t lut_dc[3], lut_ac[3];        // slots of the 16-bit code tables
+    uint16_t q[3][64];                   // quantisation tables, natural order
+};
+
+namespace {
+
+__constant__ uint8_t c_jp_zigzag[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
+                                        41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
+                                        30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+
+// ---- the bit reader: MSB first, FF 00 unstuffed, stops feeding at a marker.  Bytes come from the workgroup's LDS copy of its
+// part of the scan (global memory outside it).
+struct JpReader {
+    const uint8_t *g;        // the image's scan bytes (global)
+    const uint8_t *s;        // LDS copy of [s_lo, s_hi)
+    uint32_t s_lo, s_hi, len;
+    uint32_t bytepos;        // next raw byte to load
+    unsigned long long acc;  // the low `nbits` bits are valid
+    int nbits, fed;          // fed: zero bits appended after a marker (they sit at the low end)
+    unsigned skips;          // bit k: the byte loaded k loads ago was an FF with a stuffed zero behind it
+    int marker;              // 0, or the marker code met at raw byte `bytepos` (0x100: end of data)
+
+    __device__ __forceinline__ unsigned byte_at(uint32_t p) const { return (p >= s_lo && p < s_hi) ? s[p - s_lo] : (p < len ? g[p] : 0u); }
+    __device__ __forceinline__ void start(uint32_t bitpos)
+    {
+        bytepos = bitpos >> 3;
+        acc = 0;
+        nbits = 0;
+        fed = 0;
+        skips = 0;
+        marker = 0;
+        const int drop = (int)(bitpos & 7u);
+        if (drop) {
+            load_byte();
+            if (nbits >= drop) nbits -= drop;  // (the partial byte's consumed bits)
+        }
+    }
+    __device__ __forceinline__ void load_byte()
+    {
+        if (marker) return;
+        if (bytepos >= len) {
+            marker = 0x100;
+            return;
+        }
+        const unsigned b = byte_at(bytepos);
+        unsigned skip = 0;
+        if (b == 0xFFu) {
+            const unsigned b2 = bytepos + 1 < len ? byte_at(bytepos + 1) : 0xD9u;
+            if (b2 == 0u) {
+                skip = 1;
+            } else if (b2 == 0xFFu) {  // a fill byte before a marker: drop it
+                bytepos++;
+                return;
+            } else {
+                marker = (int)b2;
+                return;
+            }
+        }
+        acc = (acc << 8) | b;
+        nbits += 8;
+        skips = (skips << 1) | skip;
+        bytepos += 1 + skip;
+    }
+    __device__ __forceinline__ void fill()
+    {
+        while (nbits <= 48 && !marker) load_byte();
+    }
+    __device__ __forceinline__ void feed_zeros()  // after a marker: the decoder may still ask for bits (it is about to notice)
+    {
+        while (nbits < 32) {
+            acc <<= 8;
+            nbits += 8;
+            fed += 8;
+        }
+    }
+    __device__ __forceinline__ int real_bits() const { return nbits - fed; }
+    // raw bit position of the next unconsumed bit (never inside a stuffed byte)
+    __device__ __forceinline__ uint32_t pos() const
+    {
+        const int rb = real_bits() > 0 ? real_bits() : 0;
+        const int nb = (rb + 7) >> 3;
+        const unsigned m = nb >= 32 ? 0xffffffffu : ((1u << nb) - 1u);
+        return bytepos * 8u - (uint32_t)rb - 8u * (uint32_t)__popc(skips & m);
+    }
+    __device__ __forceinline__ unsigned peek(int n) const { return (unsigned)((acc >> (nbits - n)) & ((1ull << n) - 1ull)); }
+    __device__ __forceinline__ void drop(int n) { nbits -= n; }
+};
+
+struct JpState {
+    uint32_t p;   // raw bit position
+    uint32_t cz;  // block within the MCU | zig-zag index << 8 | end-of-image << 16
+};
+__device__ __forceinline__ bool operator!=(const JpState &a, const JpState &b) { return a.p != b.p || a.cz != b.cz; }
+
+// MODE 0: speculative first pass, 1: synchronisation round, 2: writing pass
+template <int MODE>
+__global__ __launch_bounds__(JP_TPB) void k_jpeg_huff(const JpImage *__restrict__ imgs, const uint8_t *__restrict__ scan, const uint16_t *__restrict__ luts,
+                                                     const JpState *__restrict__ st_in, JpState *__restrict__ st_out,
+                                                     const uint8_t *__restrict__ chg_in, uint8_t *__restrict__ chg_out, uint32_t *__restrict__ nblk,
+                                                     const uint32_t *__restrict__ blkbase, int16_t *__restrict__ coefs, unsigned *__restrict__ any_changed)
+{
+    __shared__ uint8_t s_data[JP_TPB * JP_SUB + JP_PAD];
+    __shared__ uint16_t s_lut[4][1 << JP_LOOK];  // [dc luma, ac luma, dc chroma, ac chroma] first-level tables
+    const JpImage &I = imgs[blockIdx.y];
+    const uint32_t first = blockIdx.x * JP_TPB;
+    if (first >= I.nsub) return;
+    const uint8_t *g = scan + I.scan_off;
+    // ---- stage this workgroup's bytes and the first-level code tables
+    const uint32_t s_lo = first * JP_SUB;
+    uint32_t s_hi = s_lo + JP_TPB * JP_SUB + JP_PAD;
+    s_hi = s_hi < I.scan_len ? s_hi : I.scan_len;
+    for (uint32_t k = threadIdx.x * 4; s_lo + k < s_hi; k += JP_TPB * 4) {
+        if (s_lo + k + 4 <= s_hi && (((uintptr_t)(g + s_lo + k)) & 3u) == 0) {
+            *reinterpret_cast<uint32_t *>(s_data + k) = *reinterpret_cast<const uint32_t *>(g + s_lo + k);
+        } else {
+            for (uint32_t u = 0; u < 4 && s_lo + k + u < s_hi; u++) s_data[k + u] = g[s_lo + k + u];
+        }
+    }
+    const int lc = I.ncomp > 1 ? 1 : 0;  // the chroma component that names the second pair of tables
+    const int slot[4] = {I.lut_dc[0], I.lut_ac[0], I.lut_dc[lc], I.lut_ac[lc]};
+    // (Cb and Cr may name different tables: then component 2 goes through the 16-bit tables only)
+    const bool cr_same = I.ncomp < 3 || (I.lut_dc[2] == I.lut_dc[1] && I.lut_ac[2] == I.lut_ac[1]);
+    for (int k = threadIdx.x; k < 4 << JP_LOOK; k += JP_TPB) {
+        const int t = k >> JP_LOOK, i = k & ((1 << JP_LOOK) - 1);
+        const uint16_t e = luts[(size_t)slot[t] * 65536 + ((size_t)i << (16 - JP_LOOK))];
+        s_lut[t][i] = (e >> 8) <= JP_LOOK ? e : (uint16_t)0;
+    }
+    __syncthreads();
+    const uint32_t i = first + threadIdx.x;
+    if (i >= I.nsub) return;
+    const uint32_t gsub = I.sub_base + i;
+    const uint32_t end_bit = ((i + 1) * JP_SUB < I.scan_len ? (i + 1) * JP_SUB : I.scan_len) * 8u;
+    // ---- entry state
+    JpState e;
+    if (MODE == 0) {
+        uint32_t b = i * JP_SUB;
+        if (i > 0) {
+            const unsigned pb = g[b - 1], cb = g[b];
+            if (pb == 0xFFu && (cb == 0u || (cb >= 0xD0u && cb <= 0xD7u))) b++;  // inside a stuffed pair / a restart marker
+        }
+        e.p = b * 8u;
+        e.cz = 0;
+    } else if (i == 0) {
+        e.p = 0;
+        e.cz = 0;
+    } else {
+        e = st_in[gsub - 1];
+    }
+    if (MODE == 1) {
+        if (i == 0 || !chg_in[gsub - 1]) {  // nothing new to start from: the previous result stands
+            st_out[gsub] = st_in[gsub];
+            chg_out[gsub] = 0;
+            return;
+        }
+    }
+    int c = (int)(e.cz & 0xffu), z = (int)((e.cz >> 8) & 0xffu);
+    bool eoi = (e.cz >> 16) & 1u;
+    uint32_t done = 0;  // blocks completed by this lane
+    uint32_t B = MODE == 2 ? blkbase[gsub] : 0u;  // index of the block being decoded
+    JpReader R;
+    R.g = g;
+    R.s = s_data;
+    R.s_lo = s_lo;
+    R.s_hi = s_hi;
+    R.len = I.scan_len;
+    R.start(e.p);
+    const int nl = I.hs * I.vs;  // luma blocks per MCU
+    int16_t *cblk = nullptr;     // MODE 2: the block being written
+    auto bind_block = [&]() {
+        if (MODE != 2) return;
+        cblk = nullptr;
+        if (B >= I.nblocks) return;  // (more blocks than the frame has: corrupt data, dropped)
+        const uint32_t m = B / (uint32_t)I.bpm;
+        const int k = (int)(B - m * (uint32_t)I.bpm);
+        const int comp = k < nl ? 0 : 1 + (k - nl);
+        const int v = comp == 0 ? k / I.hs : 0, h = comp == 0 ? k - v * I.hs : 0;
+        const int hsc = comp == 0 ? I.hs : 1, vsc = comp == 0 ? I.vs : 1;
+        const uint32_t bx = (m % (uint32_t)I.mcux) * hsc + h, by = (m / (uint32_t)I.mcux) * vsc + v;
+        cblk = coefs + I.coef_base + I.coef_off[comp] + ((size_t)by * I.bw[comp] + bx) * 64;
+    };
+    bind_block();
+    uint32_t p_exit = e.p;
+    if (!eoi) {
+        for (;;) {
+            if (R.real_bits() < 32) R.fill();
+            if (R.marker) {
+                const int rem = R.real_bits();
+                const bool pad = rem <= 0 || (rem < 8 && ((R.acc >> R.fed) & ((1ull << rem) - 1ull)) == (1ull << rem) - 1ull);
+                if (pad) {
+                    if (R.marker >= 0xD0 && R.marker <= 0xD7) {
+                        // a restart marker: every decoder starts afresh behind it
+                        const uint32_t np = (R.bytepos + 2u) * 8u;
+                        R.start(np);
+                        c = 0;
+                        z = 0;
+                        // (a block cut short by the marker is abandoned: valid data ends intervals on MCU boundaries)
+                        if (np >= end_bit) {
+                            p_exit = np;
+                            break;
+                        }
+                        continue;
+                    }
+                    eoi = true;
+                    p_exit = R.bytepos * 8u;
+                    break;
+                }
+                R.feed_zeros();
+            }
+            // this lane's part ends with the first symbol that starts at or behind end_bit
+            if (R.bytepos * 8u >= end_bit) {
+                const uint32_t p = R.pos();
+                if (p >= end_bit) {
+                    p_exit = p;
+                    break;
+                }
+            }
+            const int comp = c < nl ? 0 : 1 + (c - nl);
+            const bool first_level = comp < 2 || cr_same;
+            if (z == 0) {
+                // ---- DC difference
+                uint16_t en = first_level ? s_lut[comp ? 2 : 0][R.peek(JP_LOOK)] : (uint16_t)0;
+                if (!(en >> 8)) en = luts[(size_t)I.lut_dc[comp] * 65536 + R.peek(16)];
+                int len = en >> 8, t = en & 15;
+                if (len == 0) {  // no such code (only while out of step): one bit, category 0
+                    len = 1;
+                    t = 0;
+                }
+                R.drop(len);
+                int diff = 0;
+                if (t) {
+                    const int v = (int)R.peek(t);
+                    R.drop(t);
+                    diff = v < (1 << (t - 1)) ? v - (1 << t) + 1 : v;
+                }
+                if (MODE == 2 && cblk) cblk[0] = (int16_t)diff;
+                z = 1;
+            } else {
+                // ---- one AC symbol
+                uint16_t en = first_level ? s_lut[comp ? 3 : 1][R.peek(JP_LOOK)] : (uint16_t)0;
+                if (!(en >> 8)) en = luts[(size_t)I.lut_ac[comp] * 65536 + R.peek(16)];
+                int len = en >> 8, rs = en & 0xff;
+                if (len == 0) {
+                    len = 1;
+                    rs = 0;
+                }
+                R.drop(len);
+                const int r = rs >> 4, s = rs & 15;
+                if (s == 0) {
+                    z = r == 15 ? z + 16 : 64;
+                } else {
+                    z += r;
+                    const int v = (int)R.peek(s);
+                    R.drop(s);
+                    if (z < 64) {
+                        if (MODE == 2 && cblk) cblk[c_jp_zigzag[z]] = (int16_t)(v < (1 << (s - 1)) ? v - (1 << s) + 1 : v);
+                        z++;
+                    }
+                }
+            }
+            if (z >= 64) {
+                z = 0;
+                c = c + 1 == I.bpm ? 0 : c + 1;
+                done++;
+                if (MODE == 2) {
+                    B++;
+                    bind_block();
+                }
+            }
+        }
+    }
+    if (MODE != 2) {
+        JpState o;
+        o.p = p_exit;
+        o.cz = (uint32_t)c | ((uint32_t)z << 8) | (eoi ? 1u << 16 : 0u);
+        nblk[gsub] = done;
+        if (MODE == 0) {
+            st_out[gsub] = o;
+            chg_out[gsub] = 1;
+        } else {
+            const bool ch = o != st_in[gsub];
+            st_out[gsub] = o;
+            chg_out[gsub] = ch ? 1 : 0;
+            if (ch) atomicOr(any_changed, 1u);
+        }
+    }
+}
+
+// blocks completed before each sub-sequence: exclusive scan per image (one workgroup per image, 8 items per lane)
+__global__ __launch_bounds__(1024) void k_jpeg_scan_blocks(const JpImage *__restrict__ imgs, const uint32_t *__restrict__ nblk, uint32_t *__restrict__ blkbase)
+{
+    __shared__ int s_w[16];
+    const JpImage &I = imgs[blockIdx.x];
+    const uint32_t *in = nblk + I.sub_base;
+    uint32_t *out = blkbase + I.sub_base;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = (int)I.nsub;
+    constexpr int PER = 8;
+    int carry = 0;
+    for (int base = 0; base < n; base += 1024 * PER) {
+        const int i0 = base + tid * PER;
+        int v[PER], sum = 0;
+#pragma unroll
+        for (int k = 0; k < PER; k++) {
+            v[k] = i0 + k < n ? (int)in[i0 + k] : 0;
+            sum += v[k];
+        }
+        const int incl = wave_iscan(sum);
+        if (lane == 63) s_w[wv] = incl;
+        __syncthreads();
+        int wbase = 0, tot = 0;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const int t = s_w[k];
+            wbase += k < wv ? t : 0;
+            tot += t;
+        }
+        int run = carry + wbase + incl - sum;
+#pragma unroll
+        for (int k = 0; k < PER; k++) {
+            if (i0 + k < n) out[i0 + k] = (uint32_t)run;
+            run += v[k];
+        }
+        carry += tot;
+        __syncthreads();
+    }
+}
+
+// DC prediction: coefficient 0 of every block holds the difference to the previous block of its component (scan order);
+// prefix sums per component, starting afresh at every restart interval.  One workgroup per (component, image).
+__global__ __launch_bounds__(1024) void k_jpeg_dc(const JpImage *__restrict__ imgs, int16_t *__restrict__ coefs, int32_t *__restrict__ dcs)
+{
+    __shared__ int s_w[16];
+    const JpImage &I = imgs[blockIdx.y];
+    const int comp = blockIdx.x;
+    if (comp >= I.ncomp) return;
+    const int hsc = comp == 0 ? I.hs : 1, vsc = comp == 0 ? I.vs : 1, nbc = hsc * vsc;
+    const int T = I.nmcu * nbc;
+    int16_t *cf = coefs + I.coef_base + I.coef_off[comp];
+    int32_t *S = dcs + I.dcs_base + (comp == 0 ? 0 : (size_t)I.nmcu * I.hs * I.vs + (size_t)(comp - 1) * I.nmcu);
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    auto block_of = [&](int t) -> size_t {
+        const int m = t / nbc, j = t - m * nbc;
+        const int v = j / hsc, h = j - v * hsc;
+        const int bx = (m % I.mcux) * hsc + h, by = (m / I.mcux) * vsc + v;
+        return ((size_t)by * I.bw[comp] + bx) * 64;
+    };
+    constexpr int PER = 8;
+    int carry = 0;
+    for (int base = 0; base < T; base += 1024 * PER) {
+        const int i0 = base + tid * PER;
+        int v[PER], sum = 0;
+#pragma unroll
+        for (int k = 0; k < PER; k++) {
+            v[k] = i0 + k < T ? (int)cf[block_of(i0 + k)] : 0;
+            sum += v[k];
+        }
+        const int incl = wave_iscan(sum);
+        if (lane == 63) s_w[wv] = incl;
+        __syncthreads();
+        int wbase = 0, tot = 0;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const int t = s_w[k];
+            wbase += k < wv ? t : 0;
+            tot += t;
+        }
+        int run = carry + wbase + incl - sum;
+#pragma unroll
+        for (int k = 0; k < PER; k++) {
+            run += v[k];
+            if (i0 + k < T) S[i0 + k] = run;  // inclusive
+        }
+        carry += tot;
+        __syncthreads();
+    }
+    __threadfence_block();
+    __syncthreads();
+    // second pass: subtract what had accumulated before the block's restart interval began
+    const int seg = I.restart > 0 ? I.restart * nbc : 0;
+    for (int t = tid; t < T; t += 1024) {
+        int dc = S[t];
+        if (seg) {
+            const int s0 = (t / seg) * seg;
+            if (s0 > 0) dc -= S[s0 - 1];
+        }
+        cf[block_of(t)] = (int16_t)dc;
+    }
+}
+
+// ---- jidctint.c, one 1-D pass (dequantised inputs)
+#define JP_CONST_BITS 13
+#define JP_PASS1_BITS 2
+__device__ __forceinline__ void jp_idct_1d(const int in[8], int out[8], int shift)
+{
+    int z2 = in[2], z3 = in[6];
+    int z1 = (z2 + z3) * 4433;
+    int tmp2 = z1 + z3 * (-15137);
+    int tmp3 = z1 + z2 * 6270;
+    z2 = in[0];
+    z3 = in[4];
+    int tmp0 = (z2 + z3) * (1 << JP_CONST_BITS);
+    int tmp1 = (z2 - z3) * (1 << JP_CONST_BITS);
+    const int tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+    tmp0 = in[7];
+    tmp1 = in[5];
+    tmp2 = in[3];
+    tmp3 = in[1];
+    z1 = tmp0 + tmp3;
+    z2 = tmp1 + tmp2;
+    z3 = tmp0 + tmp2;
+    int z4 = tmp1 + tmp3;
+    const int z5 = (z3 + z4) * 9633;
+    tmp0 *= 2446;
+    tmp1 *= 16819;
+    tmp2 *= 25172;
+    tmp3 *= 12299;
+    z1 *= -7373;
+    z2 *= -20995;
+    z3 *= -16069;
+    z4 *= -3196;
+    z3 += z5;
+    z4 += z5;
+    tmp0 += z1 + z3;
+    tmp1 += z2 + z4;
+    tmp2 += z2 + z3;
+    tmp3 += z1 + z4;
+    const int rnd = 1 << (shift - 1);
+    out[0] = (tmp10 + tmp3 + rnd) >> shift;
+    out[7] = (tmp10 - tmp3 + rnd) >> shift;
+    out[1] = (tmp11 + tmp2 + rnd) >> shift;
+    out[6] = (tmp11 - tmp2 + rnd) >> shift;
+    out[2] = (tmp12 + tmp1 + rnd) >> shift;
+    out[5] = (tmp12 - tmp1 + rnd) >> shift;
+    out[3] = (tmp13 + tmp0 + rnd) >> shift;
+    out[4] = (tmp13 - tmp0 + rnd) >> shift;
+}
+
+// eight lanes per 8 x 8 block: a lane takes one column (pass 1), the block is transposed through LDS, the lane takes one row
+// (pass 2) and stores its eight samples as one 8-byte word
+__global__ __launch_bounds__(256) void k_jpeg_idct(const JpImage *__restrict__ imgs, const int16_t *__restrict__ coefs, uint8_t *__restrict__ planes)
+{
+    __shared__ int s_ws[32][64 + 8];
+    const JpImage &I = imgs[blockIdx.y];
+    const uint32_t nb0 = (uint32_t)I.bw[0] * I.bh[0], nb1 = I.ncomp > 1 ? (uint32_t)I.bw[1] * I.bh[1] : 0u;
+    const uint32_t total = nb0 + 2u * nb1;
+    const int jb = threadIdx.x >> 3, col = threadIdx.x & 7;
+    const uint32_t b = blockIdx.x * 32u + (uint32_t)jb;
+    const bool live = b < total;
+    int comp = 0;
+    uint32_t bi = b;
+    if (live && b >= nb0) {
+        comp = b - nb0 >= nb1 ? 2 : 1;
+        bi = b - nb0 - (comp == 2 ? nb1 : 0u);
+    }
+    if (live) {
+        const int16_t *cf = coefs + I.coef_base + I.coef_off[comp] + (size_t)bi * 64;
+        const uint16_t *q = I.q[comp];
+        int in[8], out[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) in[r] = (int)cf[r * 8 + col] * (int)q[r * 8 + col];
+        jp_idct_1d(in, out, JP_CONST_BITS - JP_PASS1_BITS);
+#pragma unroll
+        for (int r = 0; r < 8; r++) s_ws[jb][r * 8 + col] = out[r];
+    }
+    __syncthreads();
+    if (live) {
+        const int row = col;
+        int in[8], out[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) in[k] = s_ws[jb][row * 8 + k];
+        jp_idct_1d(in, out, JP_CONST_BITS + JP_PASS1_BITS + 3);
+        unsigned lo = 0, hi = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            int v = out[k] + 128;
+            v = v < 0 ? 0 : (v > 255 ? 255 : v);
+            if (k < 4) lo |= (unsigned)v << (8 * k);
+            else hi |= (unsigned)v << (8 * (k - 4));
+        }
+        const int bw = I.bw[comp];
+        const uint32_t by = bi / (uint32_t)bw, bx = bi - by * (uint32_t)bw;
+        uint8_t *dst = planes + I.plane_base + I.plane_off[comp] + ((size_t)by * 8 + row) * ((size_t)bw * 8) + (size_t)bx * 8;
+        *reinterpret_cast<uint2 *>(dst) = make_uint2(lo, hi);
+    }
+}
+
+// one lane per output pixel: chroma by jdsample.c's fancy filters (or as it is for 4:4:4), jdcolor.c, then BGR or gray
+__device__ __forceinline__ int jp_chroma(const uint8_t *pl, int pitch, int cw, int ch, int hs, int vs, int x, int y)
+{
+    if (hs == 1 && vs == 1) return pl[(size_t)y * pitch + x];
+    const int i = x >> 1;
+    if (vs == 1) {
+        const uint8_t *in = pl + (size_t)y * pitch;
+        if (cw <= 2) return in[i];  // (too narrow for the filter: libjpeg replicates)
+        if (x & 1) return i == cw - 1 ? in[i] : (in[i] * 3 + in[i + 1] + 2) >> 2;
+        return i == 0 ? in[0] : (in[i] * 3 + in[i - 1] + 1) >> 2;
+    }
+    const int cy = y >> 1;
+    if (cw <= 2) return pl[(size_t)cy * pitch + i];
+    int yf = (y & 1) ? cy + 1 : cy - 1;
+    yf = yf < 0 ? 0 : (yf > ch - 1 ? ch - 1 : yf);
+    const uint8_t *in0 = pl + (size_t)cy * pitch, *in1 = pl + (size_t)yf * pitch;
+    const int cur = in0[i] * 3 + in1[i];
+    if (x & 1) {
+        if (i == cw - 1) return (cur * 4 + 7) >> 4;
+        return (cur * 3 + (in0[i + 1] * 3 + in1[i + 1]) + 7) >> 4;
+    }
+    if (i == 0) return (cur * 4 + 8) >> 4;
+    return (cur * 3 + (in0[i - 1] * 3 + in1[i - 1]) + 8) >> 4;
+}
+
+__global__ __launch_bounds__(256) void k_jpeg_color(const JpImage *__restrict__ imgs, const uint8_t *__restrict__ planes, uint8_t *__restrict__ out,
+                                                    long long out_fstride, int gray_out)
+{
+    const JpImage &I = imgs[blockIdx.y];
+    const int W = I.w, H = I.h;
+    const uint8_t *P = planes + I.plane_base;
+    uint8_t *dst = out + (long long)blockIdx.y * out_fstride;
+    const int cw = (W + I.hs - 1) / I.hs, ch = (H + I.vs - 1) / I.vs;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < (long long)W * H; idx += (long long)gridDim.x * blockDim.x) {
+        const int y = (int)(idx / W), x = (int)(idx - (long long)y * W);
+        const int Y = P[I.plane_off[0] + (size_t)y * (I.bw[0] * 8) + x];
+        int r = Y, g = Y, b = Y;
+        if (I.ncomp == 3) {
+            const int cb = jp_chroma(P + I.plane_off[1], I.bw[1] * 8, cw, ch, I.hs, I.vs, x, y) - 128;
+            const int cr = jp_chroma(P + I.plane_off[2], I.bw[2] * 8, cw, ch, I.hs, I.vs, x, y) - 128;
+            r = Y + ((91881 * cr + 32768) >> 16);
+            g = Y + ((-22554 * cb + 32768 - 46802 * cr) >> 16);
+            b = Y + ((116130 * cb + 32768) >> 16);
+            r = r < 0 ? 0 : (r > 255 ? 255 : r);
+            g = g < 0 ? 0 : (g > 255 ? 255 : g);
+            b = b < 0 ? 0 : (b > 255 ? 255 : b);
+        }
+        if (gray_out) {
+            dst[idx] = (uint8_t)((b * 3735 + g * 19235 + r * 9798 + (1 << 14)) >> 15);  // K0: cvtColor(BGR2GRAY)
+        } else {
+            uint8_t *o = dst + idx * 3;
+            o[0] = (uint8_t)b;
+            o[1] = (uint8_t)g;
+            o[2] = (uint8_t)r;
+        }
+    }
+}
+
+// ---- host side: header parse
+struct JpHuffSpec {
+    uint8_t bits[17];
+    uint8_t vals[256];
+    int nvals = 0;
+    bool present = false;
+};
+struct JpHeader {
+    int w = 0, h = 0, ncomp = 0;
+    int hs[3] = {1, 1, 1}, vs[3] = {1, 1, 1}, tq[3] = {0, 0, 0}, td[3] = {0, 0, 0}, ta[3] = {0, 0, 0}, cid[3] = {0, 0, 0};
+    uint16_t q[4][64];
+    bool qpresent[4] = {false, false, false, false};
+    JpHuffSpec dc[4], ac[4];
+    int restart = 0;
+    size_t scan_off = 0, scan_len = 0;
+};
+const uint8_t kJpZigzag[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
+                               41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
+                               30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+
+fid_status jp_parse(const uint8_t *d, size_t n, JpHeader *H, const char **why)
+{
+#define JP_FAIL(code, text) \
+    do {                    \
+        *why = text;        \
+        return code;        \
+    } while (0)
+    if (!d || n < 4 || d[0] != 0xFF || d[1] != 0xD8) JP_FAIL(FID_E_INVALID_ARG, "not a JPEG file (no SOI)");
+    size_t p = 2;
+    bool have_sof = false;
+    while (p + 4 <= n) {
+        if (d[p] != 0xFF) JP_FAIL(FID_E_INVALID_ARG, "marker expected");
+        while (p < n && d[p] == 0xFF) p++;
+        if (p >= n) break;
+        const int m = d[p++];
+        if (m == 0xD8 || m == 0x01 || (m >= 0xD0 && m <= 0xD7)) continue;
+        if (m == 0xD9) JP_FAIL(FID_E_INVALID_ARG, "end of image before the scan");
+        if (p + 2 > n) break;
+        const size_t len = ((size_t)d[p] << 8) | d[p + 1];
+        if (len < 2 || p + len > n) JP_FAIL(FID_E_INVALID_ARG, "truncated segment");
+        const uint8_t *s = d + p + 2;
+        const size_t sl = len - 2;
+        if (m == 0xC0 || m == 0xC1) {
+            if (sl < 6) JP_FAIL(FID_E_INVALID_ARG, "short frame header");
+            if (s[0] != 8) JP_FAIL(FID_E_UNSUPPORTED, "sample precision other than 8 bits");
+            H->h = (s[1] << 8) | s[2];
+            H->w = (s[3] << 8) | s[4];
+            H->ncomp = s[5];
+            if (H->ncomp != 1 && H->ncomp != 3) JP_FAIL(FID_E_UNSUPPORTED, "component count other than 1 or 3");
+            if (H->w < 1 || H->h < 1 || sl < 6 + 3 * (size_t)H->ncomp) JP_FAIL(FID_E_INVALID_ARG, "bad frame header");
+            for (int c = 0; c < H->ncomp; c++) {
+                H->cid[c] = s[6 + 3 * c];
+                H->hs[c] = s[7 + 3 * c] >> 4;
+                H->vs[c] = s[7 + 3 * c] & 15;
+                H->tq[c] = s[8 + 3 * c] & 3;
+            }
+            have_sof = true;
+        } else if (m >= 0xC2 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC) {
+            JP_FAIL(FID_E_UNSUPPORTED, "not a baseline file (progressive, lossless or arithmetic coding)");
+        } else if (m == 0xDB) {
+            size_t o = 0;
+            while (o < sl) {
+                const int pq = s[o] >> 4, tq = s[o] & 15;
+                o++;
+                if (tq > 3 || o + (pq ? 128u : 64u) > sl) JP_FAIL(FID_E_INVALID_ARG, "bad quantisation table");
+                for (int k = 0; k < 64; k++) {
+                    H->q[tq][kJpZigzag[k]] = (uint16_t)(pq ? ((s[o] << 8) | s[o + 1]) : s[o]);
+                    o += pq ? 2 : 1;
+                }
+                H->qpresent[tq] = true;
+            }
+        } else if (m == 0xC4) {
+            size_t o = 0;
+            while (o < sl) {
+                const int tc = s[o] >> 4, th = s[o] & 15;
+                if (tc > 1 || th > 3 || o + 17 > sl) JP_FAIL(FID_E_INVALID_ARG, "bad Huffman table header");
+                JpHuffSpec &t = tc ? H->ac[th] : H->dc[th];
+                int cnt = 0;
+                t.bits[0] = 0;
+                for (int l = 1; l <= 16; l++) {
+                    t.bits[l] = s[o + l];
+                    cnt += s[o + l];
+                }
+                o += 17;
+                if (cnt > 256 || o + cnt > sl) JP_FAIL(FID_E_INVALID_ARG, "bad Huffman table");
+                memcpy(t.vals, s + o, (size_t)cnt);
+                t.nvals = cnt;
+                t.present = true;
+                o += cnt;
+            }
+        } else if (m == 0xDD) {
+            if (sl < 2) JP_FAIL(FID_E_INVALID_ARG, "bad restart interval");
+            H->restart = (s[0] << 8) | s[1];
+        } else if (m == 0xDA) {
+            if (!have_sof) JP_FAIL(FID_E_INVALID_ARG, "scan before the frame header");
+            if (sl < 1 || s[0] != H->ncomp || sl < 1 + 2 * (size_t)H->ncomp + 3) JP_FAIL(FID_E_UNSUPPORTED, "the components are not in one interleaved scan");
+            for (int c = 0; c < H->ncomp; c++) {
+                if (s[1 + 2 * c] != H->cid[c]) JP_FAIL(FID_E_UNSUPPORTED, "scan components not in frame order");
+                H->td[c] = s[2 + 2 * c] >> 4;
+                H->ta[c] = s[2 + 2 * c] & 15;
+                if (H->td[c] > 3 || H->ta[c] > 3 || !H->dc[H->td[c]].present || !H->ac[H->ta[c]].present || !H->qpresent[H->tq[c]])
+                    JP_FAIL(FID_E_INVALID_ARG, "a table the scan names is missing");
+            }
+            const uint8_t *e = s + 1 + 2 * H->ncomp;
+            if (e[0] != 0 || e[1] != 63 || e[2] != 0) JP_FAIL(FID_E_UNSUPPORTED, "spectral selection / successive approximation");
+            H->scan_off = p + len;
+            H->scan_len = n - H->scan_off;
+            break;
+        }
+        p += len;
+    }
+    if (!H->scan_off) JP_FAIL(FID_E_INVALID_ARG, "no scan");
+    if (H->ncomp == 1) {
+        H->hs[0] = H->vs[0] = 1;  // a one-component scan is not interleaved: 8 x 8 MCUs whatever the factors say
+    } else {
+        if (H->hs[1] != 1 || H->vs[1] != 1 || H->hs[2] != 1 || H->vs[2] != 1) JP_FAIL(FID_E_UNSUPPORTED, "chroma sampling factors other than 1 x 1");
+        if (!((H->hs[0] == 1 && H->vs[0] == 1) || (H->hs[0] == 2 && H->vs[0] == 1) || (H->hs[0] == 2 && H->vs[0] == 2)))
+            JP_FAIL(FID_E_UNSUPPORTED, "luma sampling other than 1x1, 2x1, 2x2");
+    }
+    return FID_OK;
+#undef JP_FAIL
+}
+
+// 16-bit code table: entry = code length << 8 | symbol for every 16-bit window that starts with a code; 0 where none does
+bool jp_build_lut(const JpHuffSpec &t, uint16_t *lut)
+{
+    memset(lut, 0, 65536 * sizeof(uint16_t));
+    unsigned code = 0;
+    int k = 0;
+    for (int l = 1; l <= 16; l++) {
+        for (int i = 0; i < t.bits[l]; i++) {
+            if (code >= (1u << l) || k >= t.nvals) return false;
+            const unsigned lo = code << (16 - l), hi = lo + (1u << (16 - l));
+            const uint16_t e = (uint16_t)((l << 8) | t.vals[k]);
+            for (unsigned w = lo; w < hi; w++) lut[w] = e;
+            code++;
+            k++;
+        }
+        code <<= 1;
+    }
+    return true;
+}
+
+unsigned long long jp_hash(const JpHuffSpec &t)
+{
+    unsigned long long h = 1469598103934665603ull;
+    for (int l = 1; l <= 16; l++) h = (h ^ t.bits[l]) * 1099511628211ull;
+    for (int i = 0; i < t.nvals; i++) h = (h ^ t.vals[i]) * 1099511628211ull;
+    return h ^ ((unsigned long long)t.nvals << 56);
+}
+
+}  // namespace
+
+struct fid_jpeg_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int maxW = 0, maxH = 0, maxB = 0;
+    size_t max_scan = 0, max_sub = 0, max_blocks = 0;  // per image
+    // device
+    uint8_t *d_scan = nullptr, *d_planes = nullptr, *d_out = nullptr;
+    int16_t *d_coefs = nullptr;
+    int32_t *d_dcs = nullptr;
+    JpImage *d_imgs = nullptr;
+    uint16_t *d_luts = nullptr;
+    JpState *d_state[2] = {nullptr, nullptr};
+    uint8_t *d_chg[2] = {nullptr, nullptr};
+    uint32_t *d_nblk = nullptr, *d_blkbase = nullptr;
+    unsigned *d_flag = nullptr;
+    // pinned host
+    uint8_t *h_scan = nullptr;
+    JpImage *h_imgs = nullptr;
+    unsigned *h_flag = nullptr;
+    uint16_t *h_lut = nullptr;
+    std::unordered_map<unsigned long long, int> lut_slot;
+    int lut_next = 0;
+    // the last decode
+    int last_n = 0, last_w = 0, last_h = 0, last_enc = 0, last_rounds = 0;
+    std::vector<JpImage> last_imgs;
+    std::string last_error;
+};
+
+namespace {
+#define JPCHK(ctx, expr)                                                               \
+    do {                                                                               \
+        hipError_t e_ = (expr);                                                        \
+        if (e_ != hipSuccess) {                                                        \
+            (ctx)->last_error = std::string(#expr) + ": " + hipGetErrorString(e_);     \
+            return e_ == hipErrorOutOfMemory ? FID_E_OUT_OF_MEMORY : FID_E_HIP;        \
+        }                                                                              \
+    } while (0)
+
+int jp_lut_slot(fid_jpeg_ctx *c, const JpHuffSpec &t, fid_status *rc)
+{
+    const unsigned long long h = jp_hash(t);
+    auto it = c->lut_slot.find(h);
+    if (it != c->lut_slot.end()) return it->second;
+    if (c->lut_next >= JP_MAX_LUT) {
+        *rc = FID_E_UNSUPPORTED;
+        c->last_error = "more distinct Huffman tables in one call than the table cache holds";
+        return 0;
+    }
+    if (!jp_build_lut(t, c->h_lut)) {
+        *rc = FID_E_INVALID_ARG;
+        c->last_error = "inconsistent Huffman table";
+        return 0;
+    }
+    const int slot = c->lut_next++;
+    // (synchronous: the pinned staging table is reused for the next one)
+    if (hipMemcpy(c->d_luts + (size_t)slot * 65536, c->h_lut, 65536 * sizeof(uint16_t), hipMemcpyHostToDevice) != hipSuccess) {
+        *rc = FID_E_HIP;
+        c->last_error = "upload of a code table failed";
+        return 0;
+    }
+    c->lut_slot[h] = slot;
+    return slot;
+}
+}  // namespace
+
+extern "C" {
+
+fid_status fid_jpeg_probe(const uint8_t *data, int64_t nbytes, fid_jpeg_info *info)
+{
+    if (!data || nbytes <= 0 || !info) return FID_E_INVALID_ARG;
+    JpHeader H;
+    const char *why = "";
+    const fid_status rc = jp_parse(data, (size_t)nbytes, &H, &why);
+    if (rc != FID_OK) return rc;
+    memset(info, 0, sizeof(*info));
+    info->width = H.w;
+    info->height = H.h;
+    info->components = H.ncomp;
+    info->h_samp = H.hs[0];
+    info->v_samp = H.vs[0];
+    info->restart_interval = H.restart;
+    const int mcux = (H.w + 8 * H.hs[0] - 1) / (8 * H.hs[0]), mcuy = (H.h + 8 * H.vs[0] - 1) / (8 * H.vs[0]);
+    for (int c = 0; c < H.ncomp; c++) {
+        info->blocks_w[c] = mcux * (c == 0 ? H.hs[0] : 1);
+        info->blocks_h[c] = mcuy * (c == 0 ? H.vs[0] : 1);
+    }
+    info->scan_bytes = (int64_t)H.scan_len;
+    return FID_OK;
+}
+
+fid_status fid_jpeg_create(int32_t device, int32_t max_width, int32_t max_height, int32_t max_batch, fid_jpeg_ctx **out)
+{
+    if (!out || max_width < 1 || max_height < 1 || max_batch < 1 || max_width > 16384 || max_height > 16384) return FID_E_INVALID_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return FID_E_NO_DEVICE;
+    if (device < 0 || device >= ndev) return FID_E_INVALID_ARG;
+    fid_jpeg_ctx *c = new (std::nothrow) fid_jpeg_ctx();
+    if (!c) return FID_E_OUT_OF_MEMORY;
+    c->device = device;
+    c->maxW = max_width;
+    c->maxH = max_height;
+    c->maxB = max_batch;
+    const size_t F = (size_t)max_batch;
+    const size_t mw = ((size_t)max_width + 15) / 16 * 16, mh = ((size_t)max_height + 15) / 16 * 16;
+    c->max_blocks = mw * mh / 64 * 3;               // 4:4:4 is the largest
+    c->max_scan = (size_t)max_width * max_height * 2 + 4096;  // entropy-coded bytes per image this context takes
+    c->max_sub = (c->max_scan + JP_SUB - 1) / JP_SUB;
+    bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
+    ok = ok && hipMalloc((void **)&c->d_scan, F * c->max_scan + 64) == hipSuccess && hipMalloc((void **)&c->d_coefs, F * c->max_blocks * 64 * sizeof(int16_t)) == hipSuccess &&
+         hipMalloc((void **)&c->d_planes, F * c->max_blocks * 64) == hipSuccess && hipMalloc((void **)&c->d_out, F * (size_t)max_width * max_height * 3) == hipSuccess &&
+         hipMalloc((void **)&c->d_dcs, F * c->max_blocks * sizeof(int32_t)) == hipSuccess && hipMalloc((void **)&c->d_imgs, F * sizeof(JpImage)) == hipSuccess &&
+         hipMalloc((void **)&c->d_luts, (size_t)JP_MAX_LUT * 65536 * sizeof(uint16_t)) == hipSuccess &&
+         hipMalloc((void **)&c->d_state[0], F * c->max_sub * sizeof(JpState)) == hipSuccess && hipMalloc((void **)&c->d_state[1], F * c->max_sub * sizeof(JpState)) == hipSuccess &&
+         hipMalloc((void **)&c->d_chg[0], F * c->max_sub) == hipSuccess && hipMalloc((void **)&c->d_chg[1], F * c->max_sub) == hipSuccess &&
+         hipMalloc((void **)&c->d_nblk, F * c->max_sub * 4) == hipSuccess && hipMalloc((void **)&c->d_blkbase, F * c->max_sub * 4) == hipSuccess &&
+         hipMalloc((void **)&c->d_flag, 4) == hipSuccess;
+    ok = ok && hipHostMalloc((void **)&c->h_scan, F * c->max_scan + 64) == hipSuccess && hipHostMalloc((void **)&c->h_imgs, F * sizeof(JpImage)) == hipSuccess &&
+         hipHostMalloc((void **)&c->h_flag, 4) == hipSuccess && hipHostMalloc((void **)&c->h_lut, 65536 * sizeof(uint16_t)) == hipSuccess;
+    if (!ok) {
+        fid_jpeg_destroy(c);
+        return FID_E_OUT_OF_MEMORY;
+    }
+    *out = c;
+    return FID_OK;
+}
+
+void fid_jpeg_destroy(fid_jpeg_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    void *dev[] = {c->d_scan, c->d_coefs, c->d_planes, c->d_out, c->d_dcs, c->d_imgs, c->d_luts, c->d_state[0], c->d_state[1], c->d_chg[0], c->d_chg[1],
+                   c->d_nblk, c->d_blkbase, c->d_flag};
+    for (void *p : dev)
+        if (p) (void)hipFree(p);
+    void *host[] = {c->h_scan, c->h_imgs, c->h_flag, c->h_lut};
+    for (void *p : host)
+        if (p) (void)hipHostFree(p);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+fid_status fid_jpeg_decode(fid_jpeg_ctx *c, const uint8_t *const *files, const int64_t *nbytes, int32_t n, fid_encoding out_enc, uint8_t *host_out,
+                           int64_t host_frame_stride)
+{
+    if (!c || !files || !nbytes || n < 1 || n > c->maxB) return FID_E_INVALID_ARG;
+    if (out_enc != FID_ENC_BGR8 && out_enc != FID_ENC_MONO8) return FID_E_INVALID_ARG;
+    JPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    c->last_n = 0;
+    if (c->lut_next > JP_MAX_LUT / 2) {  // a stream of files with ever new tables: start the cache again (between calls only)
+        c->lut_slot.clear();
+        c->lut_next = 0;
+    }
+    // ---- headers, tables, packing of the entropy-coded bytes
+    size_t scan_at = 0, sub_at = 0;
+    uint32_t max_nsub = 0, max_blocks = 0;
+    int W = 0, Hh = 0;
+    for (int f = 0; f < n; f++) {
+        JpHeader H;
+        const char *why = "";
+        fid_status rc = (files[f] && nbytes[f] > 0) ? jp_parse(files[f], (size_t)nbytes[f], &H, &why) : FID_E_INVALID_ARG;
+        if (rc != FID_OK) {
+            c->last_error = std::string("frame ") + std::to_string(f) + ": " + why;
+            return rc;
+        }
+        if (f == 0) {
+            W = H.w;
+            Hh = H.h;
+        }
+        if (H.w != W || H.h != Hh) {
+            c->last_error = "the files of one call must have one image size";
+            return FID_E_INVALID_ARG;
+        }
+        if (W > c->maxW || Hh > c->maxH) {
+            c->last_error = "image larger than the context was created for";
+            return FID_E_INVALID_ARG;
+        }
+        if (H.scan_len > c->max_scan || H.scan_len >= (1ull << 28)) {
+            c->last_error = "entropy-coded data larger than the context takes";
+            return FID_E_CAPACITY;
+        }
+        JpImage &I = c->h_imgs[f];
+        memset(&I, 0, sizeof(I));
+        I.w = W;
+        I.h = Hh;
+        I.ncomp = H.ncomp;
+        I.hs = H.hs[0];
+        I.vs = H.vs[0];
+        I.bpm = H.ncomp == 1 ? 1 : I.hs * I.vs + 2;
+        I.mcux = (W + 8 * I.hs - 1) / (8 * I.hs);
+        const int mcuy = (Hh + 8 * I.vs - 1) / (8 * I.vs);
+        I.nmcu = I.mcux * mcuy;
+        I.restart = H.restart;
+        uint32_t co = 0, po = 0;
+        for (int k = 0; k < H.ncomp; k++) {
+            I.bw[k] = I.mcux * (k == 0 ? I.hs : 1);
+            I.bh[k] = mcuy * (k == 0 ? I.vs : 1);
+            I.coef_off[k] = co;
+            I.plane_off[k] = po;
+            co += (uint32_t)I.bw[k] * I.bh[k] * 64u;
+            po += (uint32_t)I.bw[k] * I.bh[k] * 64u;
+            memcpy(I.q[k], H.q[H.tq[k]], sizeof(I.q[k]));
+            I.lut_dc[k] = jp_lut_slot(c, H.dc[H.td[k]], &rc);
+            I.lut_ac[k] = jp_lut_slot(c, H.ac[H.ta[k]], &rc);
+            if (rc != FID_OK) return rc;
+        }
+        I.nblocks = (uint32_t)I.nmcu * (uint32_t)I.bpm;
+        I.coef_base = (unsigned long long)f * c->max_blocks * 64;
+        I.plane_base = (unsigned long long)f * c->max_blocks * 64;
+        I.dcs_base = (unsigned long long)f * c->max_blocks;
+        I.scan_off = scan_at;
+        I.scan_len = (uint32_t)H.scan_len;
+        I.sub_base = (uint32_t)sub_at;
+        I.nsub = (uint32_t)((H.scan_len + JP_SUB - 1) / JP_SUB);
+        if (I.nsub == 0) {
+            c->last_error = "empty scan";
+            return FID_E_INVALID_ARG;
+        }
+        memcpy(c->h_scan + scan_at, files[f] + H.scan_off, H.scan_len);
+        scan_at = (scan_at + H.scan_len + 15) & ~(size_t)15;  // (every image's bytes start on a 16-byte boundary)
+        sub_at += I.nsub;
+        max_nsub = I.nsub > max_nsub ? I.nsub : max_nsub;
+        max_blocks = co / 64 > max_blocks ? co / 64 : max_blocks;
+    }
+    JPCHK(c, hipMemcpyAsync(c->d_scan, c->h_scan, scan_at, hipMemcpyHostToDevice, st));
+    JPCHK(c, hipMemcpyAsync(c->d_imgs, c->h_imgs, (size_t)n * sizeof(JpImage), hipMemcpyHostToDevice, st));
+    JPCHK(c, hipMemsetAsync(c->d_coefs, 0, (size_t)n * c->max_blocks * 64 * sizeof(int16_t), st));
+    // ---- J1: entropy decoding
+    const dim3 hgrid((max_nsub + JP_TPB - 1) / JP_TPB, n);
+    hipLaunchKernelGGL(k_jpeg_huff<0>, hgrid, dim3(JP_TPB), 0, st, c->d_imgs, c->d_scan, c->d_luts, (const JpState *)nullptr, c->d_state[0], (const uint8_t *)nullptr,
+                       c->d_chg[0], c->d_nblk, (const uint32_t *)nullptr, (int16_t *)nullptr, c->d_flag);
+    int cur = 0, rounds = 0;
+    for (;;) {
+        JPCHK(c, hipMemsetAsync(c->d_flag, 0, 4, st));
+        hipLaunchKernelGGL(k_jpeg_huff<1>, hgrid, dim3(JP_TPB), 0, st, c->d_imgs, c->d_scan, c->d_luts, c->d_state[cur], c->d_state[cur ^ 1], c->d_chg[cur],
+                           c->d_chg[cur ^ 1], c->d_nblk, (const uint32_t *)nullptr, (int16_t *)nullptr, c->d_flag);
+        JPCHK(c, hipMemcpyAsync(c->h_flag, c->d_flag, 4, hipMemcpyDeviceToHost, st));
+        JPCHK(c, hipStreamSynchronize(st));
+        cur ^= 1;
+        rounds++;
+        if (!*c->h_flag) break;
+        if (rounds > (int)max_nsub + 2) {  // (cannot happen: exactness spreads one sub-sequence per round at least)
+            c->last_error = "entropy decoding did not settle";
+            return FID_E_HIP;
+        }
+    }
+    c->last_rounds = rounds;
+    hipLaunchKernelGGL(k_jpeg_scan_blocks, dim3(n), dim3(1024), 0, st, c->d_imgs, c->d_nblk, c->d_blkbase);
+    hipLaunchKernelGGL(k_jpeg_huff<2>, hgrid, dim3(JP_TPB), 0, st, c->d_imgs, c->d_scan, c->d_luts, c->d_state[cur], (JpState *)nullptr, (const uint8_t *)nullptr,
+                       (uint8_t *)nullptr, (uint32_t *)nullptr, c->d_blkbase, c->d_coefs, c->d_flag);
+    // ---- J2 .. J4
+    hipLaunchKernelGGL(k_jpeg_dc, dim3(3, n), dim3(1024), 0, st, c->d_imgs, c->d_coefs, c->d_dcs);
+    hipLaunchKernelGGL(k_jpeg_idct, dim3((max_blocks + 31) / 32, n), dim3(256), 0, st, c->d_imgs, c->d_coefs, c->d_planes);
+    const int bpp = out_enc == FID_ENC_MONO8 ? 1 : 3;
+    const long long fstride = (long long)W * Hh * bpp;
+    {
+        long long px = (long long)W * Hh;
+        int blocks = (int)((px + 255) / 256);
+        blocks = blocks > 4096 ? 4096 : blocks;
+        hipLaunchKernelGGL(k_jpeg_color, dim3(blocks, n), dim3(256), 0, st, c->d_imgs, c->d_planes, c->d_out, fstride, out_enc == FID_ENC_MONO8 ? 1 : 0);
+    }
+    JPCHK(c, hipGetLastError());
+    if (host_out) {
+        if (host_frame_stride < fstride) return FID_E_INVALID_ARG;
+        if (host_frame_stride == fstride) {
+            JPCHK(c, hipMemcpyAsync(host_out, c->d_out, (size_t)fstride * n, hipMemcpyDeviceToHost, st));
+        } else {
+            for (int f = 0; f < n; f++)
+                JPCHK(c, hipMemcpyAsync(host_out + (size_t)f * host_frame_stride, c->d_out + (size_t)f * fstride, (size_t)fstride, hipMemcpyDeviceToHost, st));
+        }
+    }
+    JPCHK(c, hipStreamSynchronize(st));
+    c->last_n = n;
+    c->last_w = W;
+    c->last_h = Hh;
+    c->last_enc = (int)out_enc;
+    c->last_imgs.assign(c->h_imgs, c->h_imgs + n);
+    return FID_OK;
+}
+
+const void *fid_jpeg_device_ptr(fid_jpeg_ctx *c, int32_t *width, int32_t *height, int32_t *stride_bytes, int64_t *frame_stride_bytes)
+{
+    if (!c || c->last_n <= 0) return nullptr;
+    const int bpp = c->last_enc == FID_ENC_MONO8 ? 1 : 3;
+    if (width) *width = c->last_w;
+    if (height) *height = c->last_h;
+    if (stride_bytes) *stride_bytes = c->last_w * bpp;
+    if (frame_stride_bytes) *frame_stride_bytes = (int64_t)c->last_w * c->last_h * bpp;
+    return c->d_out;
+}
+
+int64_t fid_jpeg_tap_bytes(fid_jpeg_ctx *c, fid_jpeg_tap which, int32_t frame)
+{
+    if (!c || frame < 0 || frame >= c->last_n) return 0;
+    const JpImage &I = c->last_imgs[(size_t)frame];
+    int64_t nb = 0;
+    for (int k = 0; k < I.ncomp; k++) nb += (int64_t)I.bw[k] * I.bh[k];
+    return which == FID_JPEG_TAP_COEFS ? nb * 64 * 2 : (which == FID_JPEG_TAP_PLANES ? nb * 64 : 0);
+}
+
+fid_status fid_jpeg_tap_read(fid_jpeg_ctx *c, fid_jpeg_tap which, int32_t frame, void *dst, int64_t dst_bytes)
+{
+    const int64_t need = fid_jpeg_tap_bytes(c, which, frame);
+    if (!c || !dst || need <= 0 || dst_bytes < need) return FID_E_INVALID_ARG;
+    JPCHK(c, hipSetDevice(c->device));
+    const JpImage &I = c->last_imgs[(size_t)frame];
+    const void *src = which == FID_JPEG_TAP_COEFS ? (const void *)(c->d_coefs + I.coef_base) : (const void *)(c->d_planes + I.plane_base);
+    JPCHK(c, hipMemcpy(dst, src, (size_t)need, hipMemcpyDeviceToHost));
+    return FID_OK;
+}
+
+int32_t fid_jpeg_last_rounds(fid_jpeg_ctx *c) { return c ? c->last_rounds : 0; }
+const char *fid_jpeg_last_error(fid_jpeg_ctx *c) { return c ? c->last_error.c_str() : "null context"; }
+
+}  // extern "C"

@@ -312,6 +312,45 @@ fid_status fid_stag_detect_markers_batch(fid_stag_ctx *const *ctxs, int32_t nctx
 int64_t fid_stag_tap_bytes(fid_stag_ctx *ctx, fid_stag_tap which);
 fid_status fid_stag_tap_read(fid_stag_ctx *ctx, fid_stag_tap which, void *dst, int64_t dst_bytes);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * JPEG ingest.  With the launch file's default `transport:=compressed` (aruco_detect/launch/aruco_detect.launch:6) the frames
+ * reach FiducialsNode::imageCallback (aruco_detect.cpp:332) through image_transport's compressed subscriber, i.e. through
+ * cv::imdecode = libjpeg(-turbo) with its defaults (JDCT_ISLOW, fancy upsampling, JFIF YCbCr -> RGB).  These entry points do
+ * that decode on the device, bit for bit (oracle/jpeg_oracle.c, pinned on libjpeg-turbo's own output): entropy decoding by
+ * self-synchronising sub-sequences, the integer IDCT, fancy chroma upsampling, colour conversion, and -- for the detector --
+ * the gray image cvtColor(BGR2GRAY) would make of it, without the colour image ever being written.
+ * Supported: baseline sequential DCT, 8 bit, Huffman, one or three components in one interleaved scan, luma sampling 1x1 /
+ * 2x1 / 2x2 with 1x1 chroma (4:4:4, 4:2:2, 4:2:0), restart intervals.  Anything else: FID_E_UNSUPPORTED (never a wrong image).
+ * ------------------------------------------------------------------------------------------------------------------ */
+typedef struct fid_jpeg_ctx fid_jpeg_ctx;
+typedef struct fid_jpeg_info {
+    int32_t width, height, components;   /* components: 1 or 3 */
+    int32_t h_samp, v_samp;              /* luma sampling factors */
+    int32_t restart_interval;            /* MCUs per restart interval, 0 = none */
+    int32_t blocks_w[3], blocks_h[3];    /* 8 x 8 blocks per component row / column, MCU padded */
+    int64_t scan_bytes;                  /* entropy-coded bytes */
+} fid_jpeg_info;
+typedef enum fid_jpeg_tap {
+    FID_JPEG_TAP_COEFS = 0,  /* int16: quantised coefficients, natural order, DC prediction undone; component after component,
+                                [blocks_h][blocks_w][64] each (jdhuff.c decode_mcu) */
+    FID_JPEG_TAP_PLANES = 1  /* uint8: IDCT output, component after component, [blocks_h * 8][blocks_w * 8] (jidctint.c) */
+} fid_jpeg_tap;
+/* header parse on the host (no device needed) */
+fid_status fid_jpeg_probe(const uint8_t *data, int64_t nbytes, fid_jpeg_info *info);
+fid_status fid_jpeg_create(int32_t device, int32_t max_width, int32_t max_height, int32_t max_batch, fid_jpeg_ctx **out);
+void fid_jpeg_destroy(fid_jpeg_ctx *ctx);
+/* n files of ONE image size (any mix of sampling layouts / tables), from host memory.  out_enc: FID_ENC_BGR8 = what
+ * cv::imdecode(IMREAD_COLOR) returns, FID_ENC_MONO8 = cvtColor(BGR2GRAY) of that (what aruco::detectMarkers works on).  The
+ * result stays on the device (fid_jpeg_device_ptr -> fid_detect_device) and is also copied to host_out if that is not
+ * NULL (tightly packed rows, frames host_frame_stride bytes apart). */
+fid_status fid_jpeg_decode(fid_jpeg_ctx *ctx, const uint8_t *const *files, const int64_t *nbytes, int32_t n, fid_encoding out_enc,
+                           uint8_t *host_out, int64_t host_frame_stride);
+const void *fid_jpeg_device_ptr(fid_jpeg_ctx *ctx, int32_t *width, int32_t *height, int32_t *stride_bytes, int64_t *frame_stride_bytes);
+int64_t fid_jpeg_tap_bytes(fid_jpeg_ctx *ctx, fid_jpeg_tap which, int32_t frame);
+fid_status fid_jpeg_tap_read(fid_jpeg_ctx *ctx, fid_jpeg_tap which, int32_t frame, void *dst, int64_t dst_bytes);
+int32_t fid_jpeg_last_rounds(fid_jpeg_ctx *ctx); /* synchronisation rounds the last decode needed (diagnostic) */
+const char *fid_jpeg_last_error(fid_jpeg_ctx *ctx);
+
 const char *fid_strerror(fid_status s);
 const char *fid_last_error(fid_ctx *ctx);
 int32_t fid_abi_version(void);

@@ -29,7 +29,8 @@
 //                     cvtColor(BGR2GRAY) makes of it (K0's formula) -- the detector's input, without the colour image
 #include <unordered_map>
 
-#define JP_SUB 64          // bytes per sub-sequence
+#define JP_SUB 128         // bytes per sub-sequence (a decoder that starts out of step needs a few hundred bytes to fall into step with
+                           // the block phase as well as the symbol boundaries: 64-byte sub-sequences took 11-15 rounds, 256-byte ones 3)
 #define JP_TPB 256         // lanes (sub-sequences) per workgroup
 #define JP_PAD 64          // bytes staged beyond the workgroup's last sub-sequence (a lane stops within one symbol of its end)
 #define JP_LOOK 10         // bits of the LDS first-level code tables
@@ -55,18 +56,47 @@ __constant__ uint8_t c_jp_zigzag[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 
                                         30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
 
 // ---- the bit reader: MSB first, FF 00 unstuffed, stops feeding at a marker.  Bytes come from the workgroup's LDS copy of its
-// part of the scan (global memory outside it).
+// part of the scan: a lane reads from the first byte of its sub-sequence to a few bytes past its end (JP_PAD covers that).
+// One byte per call, without branches except at a marker: 64 lanes in 64 different places of 64 different symbols share one
+// instruction stream, so every data-dependent branch is paid by all of them.
 struct JpReader {
-    const uint8_t *g;        // the image's scan bytes (global)
-    const uint8_t *s;        // LDS copy of [s_lo, s_hi)
-    uint32_t s_lo, s_hi, len;
+    const uint8_t *s;        // LDS copy of the raw bytes [s_lo, s_lo + s_n)
+    uint32_t s_lo, s_n, len;
     uint32_t bytepos;        // next raw byte to load
     unsigned long long acc;  // the low `nbits` bits are valid
     int nbits, fed;          // fed: zero bits appended after a marker (they sit at the low end)
     unsigned skips;          // bit k: the byte loaded k loads ago was an FF with a stuffed zero behind it
     int marker;              // 0, or the marker code met at raw byte `bytepos` (0x100: end of data)
 
-    __device__ __forceinline__ unsigned byte_at(uint32_t p) const { return (p >= s_lo && p < s_hi) ? s[p - s_lo] : (p < len ? g[p] : 0u); }
+    __device__ __forceinline__ unsigned byte_at(uint32_t p) const
+    {
+        uint32_t k = p - s_lo;
+        k = k < s_n ? k : s_n - 1;  // (never needed for a sound file: keeps a damaged one inside the staged bytes)
+        return s[k];
+    }
+    __device__ __forceinline__ void load_byte()
+    {
+        if (marker) return;
+        if (bytepos >= len) {
+            marker = 0x100;
+            return;
+        }
+        const unsigned b = byte_at(bytepos), b2 = bytepos + 1 < len ? byte_at(bytepos + 1) : 0xD9u;
+        const bool ff = b == 0xFFu;
+        const unsigned skip = (ff && b2 == 0u) ? 1u : 0u;
+        if (ff && !skip) {
+            if (b2 == 0xFFu) {  // a fill byte before a marker: drop it
+                bytepos++;
+            } else {
+                marker = (int)b2;
+            }
+            return;
+        }
+        acc = (acc << 8) | b;
+        nbits += 8;
+        skips = (skips << 1) | skip;
+        bytepos += 1 + skip;
+    }
     __device__ __forceinline__ void start(uint32_t bitpos)
     {
         bytepos = bitpos >> 3;
@@ -81,35 +111,12 @@ struct JpReader {
             if (nbits >= drop) nbits -= drop;  // (the partial byte's consumed bits)
         }
     }
-    __device__ __forceinline__ void load_byte()
-    {
-        if (marker) return;
-        if (bytepos >= len) {
-            marker = 0x100;
-            return;
-        }
-        const unsigned b = byte_at(bytepos);
-        unsigned skip = 0;
-        if (b == 0xFFu) {
-            const unsigned b2 = bytepos + 1 < len ? byte_at(bytepos + 1) : 0xD9u;
-            if (b2 == 0u) {
-                skip = 1;
-            } else if (b2 == 0xFFu) {  // a fill byte before a marker: drop it
-                bytepos++;
-                return;
-            } else {
-                marker = (int)b2;
-                return;
-            }
-        }
-        acc = (acc << 8) | b;
-        nbits += 8;
-        skips = (skips << 1) | skip;
-        bytepos += 1 + skip;
-    }
+    // a symbol takes at most 27 bits: with 32 before it and four byte loads after it there are 32 again
     __device__ __forceinline__ void fill()
     {
-        while (nbits <= 48 && !marker) load_byte();
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (nbits < 32 && !marker) load_byte();
     }
     __device__ __forceinline__ void feed_zeros()  // after a marker: the decoder may still ask for bits (it is about to notice)
     {
@@ -202,33 +209,38 @@ __global__ __launch_bounds__(JP_TPB) void k_jpeg_huff(const JpImage *__restrict_
     int c = (int)(e.cz & 0xffu), z = (int)((e.cz >> 8) & 0xffu);
     bool eoi = (e.cz >> 16) & 1u;
     uint32_t done = 0;  // blocks completed by this lane
-    uint32_t B = MODE == 2 ? blkbase[gsub] : 0u;  // index of the block being decoded
     JpReader R;
-    R.g = g;
     R.s = s_data;
     R.s_lo = s_lo;
-    R.s_hi = s_hi;
+    R.s_n = s_hi - s_lo;
     R.len = I.scan_len;
     R.start(e.p);
     const int nl = I.hs * I.vs;  // luma blocks per MCU
-    int16_t *cblk = nullptr;     // MODE 2: the block being written
+    // MODE 2: where the block being decoded goes.  (block in the MCU, MCU column, MCU row) are counted along; only the start
+    // needs divisions.
+    int16_t *cblk = nullptr;
+    uint32_t B = 0, mx = 0, my = 0;
     auto bind_block = [&]() {
         if (MODE != 2) return;
         cblk = nullptr;
-        if (B >= I.nblocks) return;  // (more blocks than the frame has: corrupt data, dropped)
-        const uint32_t m = B / (uint32_t)I.bpm;
-        const int k = (int)(B - m * (uint32_t)I.bpm);
-        const int comp = k < nl ? 0 : 1 + (k - nl);
-        const int v = comp == 0 ? k / I.hs : 0, h = comp == 0 ? k - v * I.hs : 0;
+        if (B >= I.nblocks) return;  // (more blocks than the frame has: damaged data, dropped)
+        const int comp = c < nl ? 0 : 1 + (c - nl);
+        const int v = comp == 0 ? c / I.hs : 0, h = comp == 0 ? c - v * I.hs : 0;
         const int hsc = comp == 0 ? I.hs : 1, vsc = comp == 0 ? I.vs : 1;
-        const uint32_t bx = (m % (uint32_t)I.mcux) * hsc + h, by = (m / (uint32_t)I.mcux) * vsc + v;
-        cblk = coefs + I.coef_base + I.coef_off[comp] + ((size_t)by * I.bw[comp] + bx) * 64;
+        cblk = coefs + I.coef_base + I.coef_off[comp] + ((size_t)(my * vsc + v) * I.bw[comp] + (mx * hsc + h)) * 64;
     };
-    bind_block();
+    if (MODE == 2) {
+        B = blkbase[gsub];
+        const uint32_t m = B / (uint32_t)I.bpm;
+        // (for a sound file B mod bpm == c; a damaged one may disagree: the entry state decides the tables, B the place)
+        mx = m % (uint32_t)I.mcux;
+        my = m / (uint32_t)I.mcux;
+        bind_block();
+    }
     uint32_t p_exit = e.p;
     if (!eoi) {
         for (;;) {
-            if (R.real_bits() < 32) R.fill();
+            R.fill();
             if (R.marker) {
                 const int rem = R.real_bits();
                 const bool pad = rem <= 0 || (rem < 8 && ((R.acc >> R.fed) & ((1ull << rem) - 1ull)) == (1ull << rem) - 1ull);
@@ -237,9 +249,17 @@ __global__ __launch_bounds__(JP_TPB) void k_jpeg_huff(const JpImage *__restrict_
                         // a restart marker: every decoder starts afresh behind it
                         const uint32_t np = (R.bytepos + 2u) * 8u;
                         R.start(np);
+                        // (a block or MCU cut short by the marker is abandoned: sound data ends intervals on MCU boundaries)
+                        if (MODE == 2 && (c != 0 || z != 0)) {
+                            B += (uint32_t)(I.bpm - c);
+                            if (++mx == (uint32_t)I.mcux) {
+                                mx = 0;
+                                my++;
+                            }
+                        }
                         c = 0;
                         z = 0;
-                        // (a block cut short by the marker is abandoned: valid data ends intervals on MCU boundaries)
+                        bind_block();
                         if (np >= end_bit) {
                             p_exit = np;
                             break;
@@ -260,53 +280,35 @@ __global__ __launch_bounds__(JP_TPB) void k_jpeg_huff(const JpImage *__restrict_
                     break;
                 }
             }
+            // ---- one symbol: the DC difference (z == 0) or an AC run / size pair, through one instruction stream
             const int comp = c < nl ? 0 : 1 + (c - nl);
-            const bool first_level = comp < 2 || cr_same;
-            if (z == 0) {
-                // ---- DC difference
-                uint16_t en = first_level ? s_lut[comp ? 2 : 0][R.peek(JP_LOOK)] : (uint16_t)0;
-                if (!(en >> 8)) en = luts[(size_t)I.lut_dc[comp] * 65536 + R.peek(16)];
-                int len = en >> 8, t = en & 15;
-                if (len == 0) {  // no such code (only while out of step): one bit, category 0
-                    len = 1;
-                    t = 0;
-                }
-                R.drop(len);
-                int diff = 0;
-                if (t) {
-                    const int v = (int)R.peek(t);
-                    R.drop(t);
-                    diff = v < (1 << (t - 1)) ? v - (1 << t) + 1 : v;
-                }
-                if (MODE == 2 && cblk) cblk[0] = (int16_t)diff;
-                z = 1;
-            } else {
-                // ---- one AC symbol
-                uint16_t en = first_level ? s_lut[comp ? 3 : 1][R.peek(JP_LOOK)] : (uint16_t)0;
-                if (!(en >> 8)) en = luts[(size_t)I.lut_ac[comp] * 65536 + R.peek(16)];
-                int len = en >> 8, rs = en & 0xff;
-                if (len == 0) {
-                    len = 1;
-                    rs = 0;
-                }
-                R.drop(len);
-                const int r = rs >> 4, s = rs & 15;
-                if (s == 0) {
-                    z = r == 15 ? z + 16 : 64;
-                } else {
-                    z += r;
-                    const int v = (int)R.peek(s);
-                    R.drop(s);
-                    if (z < 64) {
-                        if (MODE == 2 && cblk) cblk[c_jp_zigzag[z]] = (int16_t)(v < (1 << (s - 1)) ? v - (1 << s) + 1 : v);
-                        z++;
-                    }
-                }
+            const bool isdc = z == 0;
+            uint16_t en = (comp < 2 || cr_same) ? s_lut[(comp ? 2 : 0) + (isdc ? 0 : 1)][R.peek(JP_LOOK)] : (uint16_t)0;
+            if (!(en >> 8)) en = luts[(size_t)(isdc ? I.lut_dc[comp] : I.lut_ac[comp]) * 65536 + R.peek(16)];  // (a long code: rare)
+            int len = en >> 8, sym = en & 0xff;
+            if (len == 0) {  // no such code (only while out of step): one bit, nothing
+                len = 1;
+                sym = 0;
             }
+            R.drop(len);
+            const int r = isdc ? 0 : sym >> 4, sz = sym & 15;
+            const int raw = sz ? (int)R.peek(sz) : 0;
+            R.drop(sz);
+            const int val = (sz && raw < (1 << (sz - 1))) ? raw - (1 << sz) + 1 : raw;
+            const int zi = isdc ? 0 : z + r;  // where the value goes (zig-zag order)
+            const bool has = isdc || sz != 0;
+            if (MODE == 2 && has && zi < 64 && cblk) cblk[c_jp_zigzag[zi]] = (int16_t)val;
+            z = isdc ? 1 : (sz ? (zi < 64 ? zi + 1 : 64) : (r == 15 ? z + 16 : 64));
             if (z >= 64) {
                 z = 0;
-                c = c + 1 == I.bpm ? 0 : c + 1;
                 done++;
+                if (++c == I.bpm) {
+                    c = 0;
+                    if (MODE == 2 && ++mx == (uint32_t)I.mcux) {
+                        mx = 0;
+                        my++;
+                    }
+                }
                 if (MODE == 2) {
                     B++;
                     bind_block();
@@ -856,9 +858,9 @@ fid_status fid_jpeg_create(int32_t device, int32_t max_width, int32_t max_height
          hipMalloc((void **)&c->d_state[0], F * c->max_sub * sizeof(JpState)) == hipSuccess && hipMalloc((void **)&c->d_state[1], F * c->max_sub * sizeof(JpState)) == hipSuccess &&
          hipMalloc((void **)&c->d_chg[0], F * c->max_sub) == hipSuccess && hipMalloc((void **)&c->d_chg[1], F * c->max_sub) == hipSuccess &&
          hipMalloc((void **)&c->d_nblk, F * c->max_sub * 4) == hipSuccess && hipMalloc((void **)&c->d_blkbase, F * c->max_sub * 4) == hipSuccess &&
-         hipMalloc((void **)&c->d_flag, 4) == hipSuccess;
+         hipMalloc((void **)&c->d_flag, 8) == hipSuccess;
     ok = ok && hipHostMalloc((void **)&c->h_scan, F * c->max_scan + 64) == hipSuccess && hipHostMalloc((void **)&c->h_imgs, F * sizeof(JpImage)) == hipSuccess &&
-         hipHostMalloc((void **)&c->h_flag, 4) == hipSuccess && hipHostMalloc((void **)&c->h_lut, 65536 * sizeof(uint16_t)) == hipSuccess;
+         hipHostMalloc((void **)&c->h_flag, 8) == hipSuccess && hipHostMalloc((void **)&c->h_lut, 65536 * sizeof(uint16_t)) == hipSuccess;
     if (!ok) {
         fid_jpeg_destroy(c);
         return FID_E_OUT_OF_MEMORY;
@@ -975,15 +977,21 @@ fid_status fid_jpeg_decode(fid_jpeg_ctx *c, const uint8_t *const *files, const i
                        c->d_chg[0], c->d_nblk, (const uint32_t *)nullptr, (int16_t *)nullptr, c->d_flag);
     int cur = 0, rounds = 0;
     for (;;) {
-        JPCHK(c, hipMemsetAsync(c->d_flag, 0, 4, st));
-        hipLaunchKernelGGL(k_jpeg_huff<1>, hgrid, dim3(JP_TPB), 0, st, c->d_imgs, c->d_scan, c->d_luts, c->d_state[cur], c->d_state[cur ^ 1], c->d_chg[cur],
-                           c->d_chg[cur ^ 1], c->d_nblk, (const uint32_t *)nullptr, (int16_t *)nullptr, c->d_flag);
-        JPCHK(c, hipMemcpyAsync(c->h_flag, c->d_flag, 4, hipMemcpyDeviceToHost, st));
+        // two rounds per look at the flag (a look costs a host round trip; a round in which nothing changes costs ~10 us)
+        JPCHK(c, hipMemsetAsync(c->d_flag, 0, 8, st));
+        for (int k = 0; k < 2; k++) {
+            hipLaunchKernelGGL(k_jpeg_huff<1>, hgrid, dim3(JP_TPB), 0, st, c->d_imgs, c->d_scan, c->d_luts, c->d_state[cur], c->d_state[cur ^ 1], c->d_chg[cur],
+                               c->d_chg[cur ^ 1], c->d_nblk, (const uint32_t *)nullptr, (int16_t *)nullptr, c->d_flag + k);
+            cur ^= 1;
+            rounds++;
+        }
+        JPCHK(c, hipMemcpyAsync(c->h_flag, c->d_flag, 8, hipMemcpyDeviceToHost, st));
         JPCHK(c, hipStreamSynchronize(st));
-        cur ^= 1;
-        rounds++;
-        if (!*c->h_flag) break;
-        if (rounds > (int)max_nsub + 2) {  // (cannot happen: exactness spreads one sub-sequence per round at least)
+        if (!c->h_flag[1]) {  // the second round of the pair changed nothing: settled
+            if (!c->h_flag[0]) rounds--;  // (so did the first)
+            break;
+        }
+        if (rounds > (int)max_nsub + 4) {  // (cannot happen: exactness spreads one sub-sequence per round at least)
             c->last_error = "entropy decoding did not settle";
             return FID_E_HIP;
         }

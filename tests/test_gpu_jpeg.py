@@ -46,3 +46,86 @@ def test_every_fixture_every_stage():
             dec.decode(b"\\xff\\xd8 nothing")
     finally:
         dec.close()
+
+
+def _encode(img, **kw):
+    PIL = pytest.importorskip("PIL.Image")
+    b = io.BytesIO()
+    PIL.fromarray(img).save(b, "JPEG", **kw)
+    return b.getvalue()
+
+
+def test_full_size_frames_batches_and_the_detector():
+    """1920 x 1080 marker frames as compressed_image_transport sends them (libjpeg defaults: 4:2:0, quality 80) and in the other
+    layouts, in one batch: every frame `==` the oracle's decode (and libjpeg-turbo's, where Pillow is there to ask); the
+    detector fed with the device-resident gray output finds what the oracle detector finds in the oracle's decode."""
+    import oracle
+    from fiducials_amd.detector import ArucoDetector
+    from fiducials_amd.dictionary import get_predefined_dictionary
+    from fiducials_amd.synth import make_frame
+
+    PIL = pytest.importorskip("PIL.Image")
+    d = get_predefined_dictionary(6)
+    frames = [make_frame(d, 300 + k).image for k in range(4)]
+    rgb = [np.stack([f, np.roll(f, 3, 1), 255 - f // 2], -1) for f in frames]
+    files = [
+        _encode(rgb[0], quality=80, subsampling=2),                              # compressed_image_transport's default
+        _encode(rgb[1], quality=95, subsampling=1),
+        _encode(rgb[2], quality=60, subsampling=0, restart_marker_blocks=7),
+        _encode(frames[3], quality=90),                                          # one component
+        _encode(rgb[3], quality=80, subsampling=2, restart_marker_rows=1),
+    ]
+    dec = fj.JpegDecoder(max_width=1920, max_height=1080, max_batch=len(files))
+    det = ArucoDetector(d, max_width=1920, max_height=1080, max_batch=len(files), max_markers=64)
+    try:
+        got = dec.decode(files, "bgr8")
+        rounds = dec.last_rounds()
+        assert 1 <= rounds <= 12, rounds  # sub-sequences fall into step within a few rounds
+        for k, f in enumerate(files):
+            want = oj.decode(f)
+            assert np.array_equal(got[k], want), k
+            ref = np.asarray(PIL.open(io.BytesIO(f)).convert("RGB"))[..., ::-1]
+            assert np.array_equal(got[k], ref), k
+        # gray, left on the device, straight into the detector
+        dec.decode(files, "mono8", to_host=False)
+        ptr, w, h, stride, fstride = dec.device_ptr()
+        assert (w, h, stride, fstride) == (1920, 1080, 1920, 1920 * 1080)
+        res = det.detect_markers_device(ptr, len(files), w, h)
+        for k, f in enumerate(files):
+            oids, ocorners = oracle.detect(gray_of(oj.decode(f)), d)
+            assert res[k][1].tolist() == oids.tolist(), k
+            assert np.array_equal(res[k][0], ocorners), k
+        assert sum(len(r[1]) for r in res) >= 60  # (the markers survive the compression)
+    finally:
+        dec.close()
+        det.close()
+
+
+def test_odd_sizes_and_damaged_files():
+    PIL = pytest.importorskip("PIL.Image")
+    rng = np.random.default_rng(11)
+    dec = fj.JpegDecoder(max_width=700, max_height=520)
+    try:
+        for (w, h) in [(641, 479), (333, 17), (9, 301), (700, 520)]:
+            img = rng.integers(0, 256, (h, w, 3)).astype(np.uint8)
+            img[h // 3:h // 2] //= 6
+            for sub in (0, 1, 2):
+                for rst in (0, 5):
+                    kw = dict(quality=int(rng.integers(20, 99)), subsampling=sub)
+                    if rst:
+                        kw["restart_marker_blocks"] = rst
+                    check(dec, _encode(img, **kw))
+        # a file cut off inside the scan, and one with bytes overwritten: no crash, a deterministic image
+        data = _encode(rng.integers(0, 256, (240, 320, 3)).astype(np.uint8), quality=85)
+        cut = data[:len(data) // 2]
+        a = dec.decode(cut, "bgr8")
+        assert a.shape == (240, 320, 3) and np.array_equal(a, dec.decode(cut, "bgr8"))
+        bad = bytearray(data)
+        for p in range(len(bad) // 2, len(bad) // 2 + 40):
+            bad[p] = 0x5A
+        b = dec.decode(bytes(bad), "bgr8")
+        assert b.shape == (240, 320, 3) and np.array_equal(b, dec.decode(bytes(bad), "bgr8"))
+        with pytest.raises(FidError):
+            dec.decode(_encode(np.zeros((600, 800, 3), np.uint8)))  # larger than the context
+    finally:
+        dec.close()

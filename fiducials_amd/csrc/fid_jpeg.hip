@@ -55,86 +55,88 @@ __constant__ uint8_t c_jp_zigzag[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 
                                         41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
                                         30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
 
-// ---- the bit reader: MSB first, FF 00 unstuffed, stops feeding at a marker.  Bytes come from the workgroup's LDS copy of its
-// part of the scan: a lane reads from the first byte of its sub-sequence to a few bytes past its end (JP_PAD covers that).
-// One byte per call, without branches except at a marker: 64 lanes in 64 different places of 64 different symbols share one
-// instruction stream, so every data-dependent branch is paid by all of them.
-struct JpReader {
-    const uint8_t *s;        // LDS copy of the raw bytes [s_lo, s_lo + s_n)
-    uint32_t s_lo, s_n, len;
-    uint32_t bytepos;        // next raw byte to load
-    unsigned long long acc;  // the low `nbits` bits are valid
-    int nbits, fed;          // fed: zero bits appended after a marker (they sit at the low end)
-    unsigned skips;          // bit k: the byte loaded k loads ago was an FF with a stuffed zero behind it
-    int marker;              // 0, or the marker code met at raw byte `bytepos` (0x100: end of data)
+// ---- the workgroup's bytes, unstuffed.  Every lane cleans its own sub-sequence (and lane 0 the one behind the last): FF 00 ->
+// FF, fill bytes and markers dropped, and writes what is left into one packed LDS buffer, so that the symbol loop below reads
+// plain bits.  What has to survive of the raw layout:
+//   s_R[j], s_rm[j]   removed bytes before sub-sequence j / which of its 128 bytes were removed: raw <-> packed positions
+//                     (states are exchanged as RAW bit positions: they are the same whoever computes them)
+//   s_bnd             packed byte positions in front of which a restart marker stood: every decoder starts afresh there
+//   s_end             packed byte position of the end of the data (EOI, another marker, or the end of the file)
+#define JP_NSTG (JP_TPB + 1)
+struct JpStage {
+    uint8_t cmp[JP_NSTG * JP_SUB + 16];
+    uint32_t rm[JP_NSTG][4];
+    uint32_t R[JP_NSTG + 1];
+    uint32_t bnd[JP_NSTG * JP_SUB / 32 + 2];
+    uint32_t end;
+    int wsum[JP_TPB / 64];
+};
 
-    __device__ __forceinline__ unsigned byte_at(uint32_t p) const
-    {
-        uint32_t k = p - s_lo;
-        k = k < s_n ? k : s_n - 1;  // (never needed for a sound file: keeps a damaged one inside the staged bytes)
-        return s[k];
+__device__ __forceinline__ int jp_popc_below(const uint32_t m[4], int o)  // set bits of the 128-bit mask below bit o
+{
+    int n = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        const int lo = w * 32;
+        if (o >= lo + 32) n += __popc(m[w]);
+        else if (o > lo) n += __popc(m[w] & ((1u << (o - lo)) - 1u));
     }
-    __device__ __forceinline__ void load_byte()
-    {
-        if (marker) return;
-        if (bytepos >= len) {
-            marker = 0x100;
-            return;
+    return n;
+}
+// raw byte (relative to the workgroup's first byte) -> packed byte
+__device__ __forceinline__ uint32_t jp_raw_to_cmp(const JpStage &S, uint32_t rawk)
+{
+    const uint32_t j = rawk / JP_SUB, o = rawk % JP_SUB;
+    return rawk - S.R[j] - (uint32_t)jp_popc_below(S.rm[j], (int)o);
+}
+// packed byte -> raw byte (relative); j: a sub-sequence at or before the one that holds it
+__device__ __forceinline__ uint32_t jp_cmp_to_raw(const JpStage &S, uint32_t cb, uint32_t j, uint32_t nstg)
+{
+    while (j + 1 < nstg && (j + 1) * JP_SUB - S.R[j + 1] <= cb) j++;
+    uint32_t n = cb - (j * JP_SUB - S.R[j]);  // its index among the kept bytes of sub-sequence j
+    for (int w = 0; w < 4; w++) {
+        uint32_t kept = ~S.rm[j][w];
+        const uint32_t cnt = (uint32_t)__popc(kept);
+        if (n < cnt) {
+            for (; n > 0; n--) kept &= kept - 1;
+            return j * JP_SUB + w * 32 + (uint32_t)(__ffs(kept) - 1);
         }
-        const unsigned b = byte_at(bytepos), b2 = bytepos + 1 < len ? byte_at(bytepos + 1) : 0xD9u;
-        const bool ff = b == 0xFFu;
-        const unsigned skip = (ff && b2 == 0u) ? 1u : 0u;
-        if (ff && !skip) {
-            if (b2 == 0xFFu) {  // a fill byte before a marker: drop it
-                bytepos++;
-            } else {
-                marker = (int)b2;
-            }
-            return;
-        }
-        acc = (acc << 8) | b;
-        nbits += 8;
-        skips = (skips << 1) | skip;
-        bytepos += 1 + skip;
+        n -= cnt;
     }
+    return (j + 1) * JP_SUB;  // (behind the last kept byte)
+}
+
+// ---- the bit reader over the packed bytes: MSB first, 32 bits at a time
+struct JpReader {
+    const uint8_t *s;        // packed bytes
+    uint32_t bytepos;        // next packed byte to load
+    unsigned long long acc;  // the low `nbits` bits are valid
+    int nbits;
     __device__ __forceinline__ void start(uint32_t bitpos)
     {
         bytepos = bitpos >> 3;
         acc = 0;
         nbits = 0;
-        fed = 0;
-        skips = 0;
-        marker = 0;
         const int drop = (int)(bitpos & 7u);
         if (drop) {
-            load_byte();
-            if (nbits >= drop) nbits -= drop;  // (the partial byte's consumed bits)
+            acc = s[bytepos++];
+            nbits = 8 - drop;
         }
     }
-    // a symbol takes at most 27 bits: with 32 before it and four byte loads after it there are 32 again
+    // a symbol takes at most 27 bits
     __device__ __forceinline__ void fill()
     {
-#pragma unroll
-        for (int k = 0; k < 4; k++)
-            if (nbits < 32 && !marker) load_byte();
-    }
-    __device__ __forceinline__ void feed_zeros()  // after a marker: the decoder may still ask for bits (it is about to notice)
-    {
-        while (nbits < 32) {
-            acc <<= 8;
-            nbits += 8;
-            fed += 8;
+        if (nbits < 32) {
+            const uint32_t a = bytepos & ~3u, sh = (bytepos & 3u) * 8u;
+            const uint32_t w0 = *reinterpret_cast<const uint32_t *>(s + a), w1 = *reinterpret_cast<const uint32_t *>(s + a + 4);
+            const uint32_t le = sh ? (w0 >> sh) | (w1 << (32u - sh)) : w0;  // the four bytes at bytepos, first byte lowest
+            const uint32_t be = __builtin_bswap32(le);
+            acc = (acc << 32) | be;
+            nbits += 32;
+            bytepos += 4;
         }
     }
-    __device__ __forceinline__ int real_bits() const { return nbits - fed; }
-    // raw bit position of the next unconsumed bit (never inside a stuffed byte)
-    __device__ __forceinline__ uint32_t pos() const
-    {
-        const int rb = real_bits() > 0 ? real_bits() : 0;
-        const int nb = (rb + 7) >> 3;
-        const unsigned m = nb >= 32 ? 0xffffffffu : ((1u << nb) - 1u);
-        return bytepos * 8u - (uint32_t)rb - 8u * (uint32_t)__popc(skips & m);
-    }
+    __device__ __forceinline__ uint32_t pos() const { return bytepos * 8u - (uint32_t)nbits; }
     __device__ __forceinline__ unsigned peek(int n) const { return (unsigned)((acc >> (nbits - n)) & ((1ull << n) - 1ull)); }
     __device__ __forceinline__ void drop(int n) { nbits -= n; }
 };
@@ -152,46 +154,156 @@ __global__ __launch_bounds__(JP_TPB) void k_jpeg_huff(const JpImage *__restrict_
                                                      const uint8_t *__restrict__ chg_in, uint8_t *__restrict__ chg_out, uint32_t *__restrict__ nblk,
                                                      const uint32_t *__restrict__ blkbase, int16_t *__restrict__ coefs, unsigned *__restrict__ any_changed)
 {
-    __shared__ uint8_t s_data[JP_TPB * JP_SUB + JP_PAD];
+    __shared__ JpStage S;
     __shared__ uint16_t s_lut[4][1 << JP_LOOK];  // [dc luma, ac luma, dc chroma, ac chroma] first-level tables
     const JpImage &I = imgs[blockIdx.y];
     const uint32_t first = blockIdx.x * JP_TPB;
     if (first >= I.nsub) return;
     const uint8_t *g = scan + I.scan_off;
-    // ---- stage this workgroup's bytes and the first-level code tables
     const uint32_t s_lo = first * JP_SUB;
-    uint32_t s_hi = s_lo + JP_TPB * JP_SUB + JP_PAD;
-    s_hi = s_hi < I.scan_len ? s_hi : I.scan_len;
-    for (uint32_t k = threadIdx.x * 4; s_lo + k < s_hi; k += JP_TPB * 4) {
-        if (s_lo + k + 4 <= s_hi && (((uintptr_t)(g + s_lo + k)) & 3u) == 0) {
-            *reinterpret_cast<uint32_t *>(s_data + k) = *reinterpret_cast<const uint32_t *>(g + s_lo + k);
-        } else {
-            for (uint32_t u = 0; u < 4 && s_lo + k + u < s_hi; u++) s_data[k + u] = g[s_lo + k + u];
+    const uint32_t tid = threadIdx.x, i = first + tid;
+    const uint32_t gsub = I.sub_base + (i < I.nsub ? i : 0u);
+    // ---- does this workgroup have anything to do in this round?
+    bool active = i < I.nsub;
+    if (MODE == 1 && active) active = i > 0 && chg_in[gsub - 1];
+    if (MODE == 1) {
+        if (i < I.nsub && !active) {  // nothing new to start from: the previous result stands
+            st_out[gsub] = st_in[gsub];
+            chg_out[gsub] = 0;
         }
+        if (!__syncthreads_or(active ? 1 : 0)) return;
     }
+    // ---- first-level code tables
     const int lc = I.ncomp > 1 ? 1 : 0;  // the chroma component that names the second pair of tables
     const int slot[4] = {I.lut_dc[0], I.lut_ac[0], I.lut_dc[lc], I.lut_ac[lc]};
     // (Cb and Cr may name different tables: then component 2 goes through the 16-bit tables only)
     const bool cr_same = I.ncomp < 3 || (I.lut_dc[2] == I.lut_dc[1] && I.lut_ac[2] == I.lut_ac[1]);
-    for (int k = threadIdx.x; k < 4 << JP_LOOK; k += JP_TPB) {
-        const int t = k >> JP_LOOK, i = k & ((1 << JP_LOOK) - 1);
-        const uint16_t e = luts[(size_t)slot[t] * 65536 + ((size_t)i << (16 - JP_LOOK))];
-        s_lut[t][i] = (e >> 8) <= JP_LOOK ? e : (uint16_t)0;
+    for (int k = tid; k < 4 << JP_LOOK; k += JP_TPB) {
+        const int t = k >> JP_LOOK, q = k & ((1 << JP_LOOK) - 1);
+        const uint16_t e = luts[(size_t)slot[t] * 65536 + ((size_t)q << (16 - JP_LOOK))];
+        s_lut[t][q] = (e >> 8) <= JP_LOOK ? e : (uint16_t)0;
+    }
+    for (int k = tid; k < JP_NSTG * JP_SUB / 32 + 2; k += JP_TPB) S.bnd[k] = 0u;
+    if (tid == 0) S.end = 0xffffffffu;
+    // ---- unstuff: sub-sequences first .. first + nstg - 1 (the last one only serves the lane in front of it)
+    const uint32_t nstg = (I.nsub - first) >= JP_NSTG ? JP_NSTG : (I.nsub - first);
+    uint32_t w[2][32];   // the raw bytes of this lane's sub-sequence(s): [0] its own, [1] (lane 0 only) the one behind the last
+    uint32_t rmv[2][4], bndm[2][4], endm[2][4];
+    int nrem[2] = {0, 0};
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        const uint32_t j = t == 0 ? tid : (uint32_t)JP_TPB;
+        const bool mine = t == 0 ? tid < nstg : (tid == 0 && nstg == JP_NSTG);
+#pragma unroll
+        for (int q = 0; q < 4; q++) rmv[t][q] = bndm[t][q] = endm[t][q] = 0u;
+        if (!mine) continue;
+        const uint32_t r0 = s_lo + j * JP_SUB;  // first raw byte
+        uint32_t F[4] = {0, 0, 0, 0}, Z[4] = {0, 0, 0, 0}, D[4] = {0, 0, 0, 0};  // byte is FF / 00 / D0..D7
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (r0 + q * 16 + 16 <= I.scan_len) {
+                v = *reinterpret_cast<const uint4 *>(g + r0 + q * 16);
+            } else {
+                uint32_t tmp[4] = {0, 0, 0, 0};
+                for (int u = 0; u < 16; u++)
+                    if (r0 + q * 16 + u < I.scan_len) tmp[u >> 2] |= (uint32_t)g[r0 + q * 16 + u] << ((u & 3) * 8);
+                v = make_uint4(tmp[0], tmp[1], tmp[2], tmp[3]);
+            }
+            const uint32_t vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t x = vv[u];
+                w[t][q * 4 + u] = x;
+                // one bit per byte: the byte equals FF / equals 00 / lies in D0..D7
+                uint32_t f = 0, z0 = 0, d = 0;
+#pragma unroll
+                for (int bb = 0; bb < 4; bb++) {
+                    const uint32_t by = (x >> (8 * bb)) & 0xffu;
+                    f |= (by == 0xffu ? 1u : 0u) << bb;
+                    z0 |= (by == 0u ? 1u : 0u) << bb;
+                    d |= ((by & 0xf8u) == 0xd0u ? 1u : 0u) << bb;
+                }
+                const int bit = (q * 4 + u) * 4;
+                F[bit >> 5] |= f << (bit & 31);
+                Z[bit >> 5] |= z0 << (bit & 31);
+                D[bit >> 5] |= d << (bit & 31);
+            }
+        }
+        // bytes behind the end of the data count as an end marker (FF D9)
+        const uint32_t valid = r0 >= I.scan_len ? 0u : (I.scan_len - r0 >= JP_SUB ? JP_SUB : I.scan_len - r0);
+        const unsigned prev = r0 > 0 ? g[r0 - 1] : 0u;
+        const unsigned next = r0 + JP_SUB < I.scan_len ? g[r0 + JP_SUB] : 0xD9u;
+        const uint32_t pF = prev == 0xffu, nF = next == 0xffu, nZ = next == 0u, nD = (next & 0xf8u) == 0xd0u;
+        // neighbours: previous byte is FF / next byte is 00 / FF / D0..D7
+        uint32_t prevF[4], nextZ[4], nextF[4], nextD[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            prevF[q] = (F[q] << 1) | (q ? F[q - 1] >> 31 : pF);
+            nextZ[q] = (Z[q] >> 1) | ((q < 3 ? Z[q + 1] & 1u : nZ) << 31);
+            nextF[q] = (F[q] >> 1) | ((q < 3 ? F[q + 1] & 1u : nF) << 31);
+            nextD[q] = (D[q] >> 1) | ((q < 3 ? D[q + 1] & 1u : nD) << 31);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            // in range?
+            uint32_t in = 0xffffffffu;
+            if (valid < (uint32_t)(q * 32 + 32)) in = valid > (uint32_t)(q * 32) ? (1u << (valid - q * 32)) - 1u : 0u;
+            const uint32_t second = prevF[q] & ~F[q];             // the byte behind an FF: a stuffed zero or a marker's code
+            const uint32_t lead = F[q] & ~nextZ[q];               // an FF that is not data: a fill byte or a marker's first byte
+            const uint32_t mark = lead & ~nextF[q];               // ... a marker's first byte
+            rmv[t][q] = ((second | lead) & in) | ~in;             // (bytes behind the end are "removed" as well)
+            bndm[t][q] = mark & nextD[q] & in;
+            endm[t][q] = mark & ~nextD[q] & in;
+            nrem[t] += __popc(rmv[t][q] & in) + (32 - __popc(in));
+        }
+        // (the byte behind the end of the data is an end marker too)
+        if (valid < JP_SUB && r0 + valid == I.scan_len) endm[t][valid >> 5] |= 1u << (valid & 31);
+    }
+    // removed bytes before every sub-sequence: scan over the lanes (+ the extra one of lane 0 at the end)
+    {
+        const int incl = wave_iscan(nrem[0]);
+        if ((tid & 63u) == 63u) S.wsum[tid >> 6] = incl;
+        __syncthreads();
+        int wb = 0;
+        for (uint32_t k = 0; k < (tid >> 6); k++) wb += S.wsum[k];
+        if (tid < nstg) S.R[tid] = (uint32_t)(wb + incl - nrem[0]);
+        if (tid == JP_TPB - 1) S.R[JP_TPB] = (uint32_t)(wb + incl);
+        if (tid < nstg)
+            for (int q = 0; q < 4; q++) S.rm[tid][q] = rmv[0][q];
+        if (tid == 0 && nstg == JP_NSTG)
+            for (int q = 0; q < 4; q++) S.rm[JP_TPB][q] = rmv[1][q];
     }
     __syncthreads();
-    const uint32_t i = first + threadIdx.x;
+    // packed bytes, restart boundaries, end of data
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        const uint32_t j = t == 0 ? tid : (uint32_t)JP_TPB;
+        const bool mine = t == 0 ? tid < nstg : (tid == 0 && nstg == JP_NSTG);
+        if (!mine) continue;
+        uint32_t dst = j * JP_SUB - S.R[j];
+#pragma unroll
+        for (int q = 0; q < 32; q++) {
+            const uint32_t x = w[t][q];
+#pragma unroll
+            for (int bb = 0; bb < 4; bb++) {
+                const int k = q * 4 + bb;
+                const uint32_t bit = 1u << (k & 31);
+                if (bndm[t][k >> 5] & bit) atomicOr(&S.bnd[dst >> 5], 1u << (dst & 31));
+                if (endm[t][k >> 5] & bit) atomicMin(&S.end, dst);
+                if (!(rmv[t][k >> 5] & bit)) S.cmp[dst++] = (uint8_t)(x >> (8 * bb));
+            }
+        }
+        if (j + 1 == nstg)  // (zeros behind the last packed byte: the reader looks a few bytes ahead)
+            for (int u = 0; u < 16; u++) S.cmp[dst + u] = 0;
+    }
+    __syncthreads();
     if (i >= I.nsub) return;
-    const uint32_t gsub = I.sub_base + i;
-    const uint32_t end_bit = ((i + 1) * JP_SUB < I.scan_len ? (i + 1) * JP_SUB : I.scan_len) * 8u;
+    if (MODE == 1 && !active) return;
     // ---- entry state
     JpState e;
     if (MODE == 0) {
-        uint32_t b = i * JP_SUB;
-        if (i > 0) {
-            const unsigned pb = g[b - 1], cb = g[b];
-            if (pb == 0xFFu && (cb == 0u || (cb >= 0xD0u && cb <= 0xD7u))) b++;  // inside a stuffed pair / a restart marker
-        }
-        e.p = b * 8u;
+        e.p = 0;  // (not used: the lane starts at the first packed byte of its sub-sequence)
         e.cz = 0;
     } else if (i == 0) {
         e.p = 0;
@@ -199,23 +311,34 @@ __global__ __launch_bounds__(JP_TPB) void k_jpeg_huff(const JpImage *__restrict_
     } else {
         e = st_in[gsub - 1];
     }
-    if (MODE == 1) {
-        if (i == 0 || !chg_in[gsub - 1]) {  // nothing new to start from: the previous result stands
-            st_out[gsub] = st_in[gsub];
-            chg_out[gsub] = 0;
-            return;
-        }
-    }
     int c = (int)(e.cz & 0xffu), z = (int)((e.cz >> 8) & 0xffu);
     bool eoi = (e.cz >> 16) & 1u;
     uint32_t done = 0;  // blocks completed by this lane
+    const uint32_t cstart = tid * JP_SUB - S.R[tid];                                              // packed: my first byte
+    const uint32_t cend = tid + 1 < nstg ? (tid + 1) * JP_SUB - S.R[tid + 1] : (tid + 1) * JP_SUB - S.R[tid] - (uint32_t)nrem[0];
+    const uint32_t end_bit = cend * 8u;  // this lane's part ends with the first symbol that starts at or behind it
+    uint32_t entry_bit = cstart * 8u;
+    if (MODE != 0 && i > 0) {
+        const uint32_t rawk = (e.p >> 3) - s_lo;
+        entry_bit = jp_raw_to_cmp(S, rawk) * 8u + (e.p & 7u);
+    }
     JpReader R;
-    R.s = s_data;
-    R.s_lo = s_lo;
-    R.s_n = s_hi - s_lo;
-    R.len = I.scan_len;
-    R.start(e.p);
+    R.s = S.cmp;
+    R.start(entry_bit);
     const int nl = I.hs * I.vs;  // luma blocks per MCU
+    // the next restart boundary / the end of the data at or behind a packed bit position
+    const uint32_t end_data = S.end == 0xffffffffu ? 0xffffffffu : S.end * 8u;
+    auto next_boundary = [&](uint32_t bitpos) -> uint32_t {
+        uint32_t q = (bitpos + 7u) >> 3;  // first whole byte position at or behind it
+        const uint32_t lim = cend + 8u;   // (a lane never gets further than a symbol behind its end)
+        uint32_t wd = q >> 5;
+        uint32_t m = S.bnd[wd] & ~((1u << (q & 31)) - 1u);
+        while (!m && wd * 32 + 32 <= lim) m = S.bnd[++wd];
+        uint32_t bq = m ? wd * 32 + (uint32_t)__ffs(m) - 1u : 0xffffffffu;
+        uint32_t bb = bq == 0xffffffffu ? 0xffffffffu : bq * 8u;
+        return bb < end_data ? bb : end_data;
+    };
+    uint32_t Mb = next_boundary(entry_bit);
     // MODE 2: where the block being decoded goes.  (block in the MCU, MCU column, MCU row) are counted along; only the start
     // needs divisions.
     int16_t *cblk = nullptr;
@@ -237,48 +360,46 @@ __global__ __launch_bounds__(JP_TPB) void k_jpeg_huff(const JpImage *__restrict_
         my = m / (uint32_t)I.mcux;
         bind_block();
     }
-    uint32_t p_exit = e.p;
+    uint32_t p_exit_c = entry_bit;  // packed bit position where this lane stops
     if (!eoi) {
         for (;;) {
             R.fill();
-            if (R.marker) {
-                const int rem = R.real_bits();
-                const bool pad = rem <= 0 || (rem < 8 && ((R.acc >> R.fed) & ((1ull << rem) - 1ull)) == (1ull << rem) - 1ull);
+            const uint32_t pos = R.pos();
+            // ---- at a restart boundary (or within its padding of one bits), or at the end of the data?
+            if (pos + 8u > Mb) {
+                const int rem = (int)Mb - (int)pos;
+                const bool pad = rem <= 0 || R.peek(rem) == (1u << rem) - 1u;
                 if (pad) {
-                    if (R.marker >= 0xD0 && R.marker <= 0xD7) {
-                        // a restart marker: every decoder starts afresh behind it
-                        const uint32_t np = (R.bytepos + 2u) * 8u;
-                        R.start(np);
-                        // (a block or MCU cut short by the marker is abandoned: sound data ends intervals on MCU boundaries)
-                        if (MODE == 2 && (c != 0 || z != 0)) {
-                            B += (uint32_t)(I.bpm - c);
-                            if (++mx == (uint32_t)I.mcux) {
-                                mx = 0;
-                                my++;
-                            }
-                        }
-                        c = 0;
-                        z = 0;
-                        bind_block();
-                        if (np >= end_bit) {
-                            p_exit = np;
-                            break;
-                        }
-                        continue;
+                    if (Mb == end_data) {
+                        eoi = true;
+                        p_exit_c = Mb;
+                        break;
                     }
-                    eoi = true;
-                    p_exit = R.bytepos * 8u;
-                    break;
+                    // every decoder starts afresh behind a restart marker
+                    R.start(Mb);
+                    // (a block or MCU cut short by the marker is abandoned: sound data ends intervals on MCU boundaries)
+                    if (MODE == 2 && (c != 0 || z != 0)) {
+                        B += (uint32_t)(I.bpm - c);
+                        if (++mx == (uint32_t)I.mcux) {
+                            mx = 0;
+                            my++;
+                        }
+                    }
+                    c = 0;
+                    z = 0;
+                    bind_block();
+                    const uint32_t at = Mb;
+                    Mb = next_boundary(at + 1u);
+                    if (at >= end_bit) {
+                        p_exit_c = at;
+                        break;
+                    }
+                    continue;
                 }
-                R.feed_zeros();
             }
-            // this lane's part ends with the first symbol that starts at or behind end_bit
-            if (R.bytepos * 8u >= end_bit) {
-                const uint32_t p = R.pos();
-                if (p >= end_bit) {
-                    p_exit = p;
-                    break;
-                }
+            if (pos >= end_bit) {
+                p_exit_c = pos;
+                break;
             }
             // ---- one symbol: the DC difference (z == 0) or an AC run / size pair, through one instruction stream
             const int comp = c < nl ? 0 : 1 + (c - nl);
@@ -318,7 +439,9 @@ __global__ __launch_bounds__(JP_TPB) void k_jpeg_huff(const JpImage *__restrict_
     }
     if (MODE != 2) {
         JpState o;
-        o.p = p_exit;
+        // back to a raw position (the same whoever computed it)
+        o.p = eoi ? e.p : (s_lo + jp_cmp_to_raw(S, p_exit_c >> 3, tid, nstg)) * 8u + (p_exit_c & 7u);
+        if (eoi && !((e.cz >> 16) & 1u)) o.p = (s_lo + jp_cmp_to_raw(S, p_exit_c >> 3, tid, nstg)) * 8u;
         o.cz = (uint32_t)c | ((uint32_t)z << 8) | (eoi ? 1u << 16 : 0u);
         nblk[gsub] = done;
         if (MODE == 0) {

@@ -257,6 +257,61 @@ def cpu_baseline(frames, K, D, budget_s=20.0):
     }
 
 
+def jpeg_side_result(local_rank, frames):
+    """The ingest in front of the hot path when the node runs with its launch default `transport:=compressed`
+    (aruco_detect.launch:6): the bench frames as compressed_image_transport sends them (libjpeg defaults: 4:2:0, quality 80),
+    decoded on the device to the gray image the detector takes (fid_jpeg_decode); beside it libjpeg-turbo itself (Pillow:
+    the library cv::imdecode uses) on one host core.  Needs Pillow to write the files; skipped without it."""
+    import io
+
+    try:
+        from PIL import Image
+    except ImportError:
+        return {"skipped": "Pillow is not importable here: no JPEG files to decode"}
+    from fiducials_amd import jpeg as fj
+    from fiducials_amd.detector import ArucoDetector
+
+    B = min(64, len(frames))
+    files = []
+    for k in range(B):
+        b = io.BytesIO()
+        Image.fromarray(np.stack([frames[k]] * 3, -1)).save(b, "JPEG", quality=80, subsampling=2)
+        files.append(b.getvalue())
+    t = time.perf_counter()
+    for f in files[:12]:
+        np.asarray(Image.open(io.BytesIO(f)).convert("RGB"))
+    cpu = (time.perf_counter() - t) / 12
+    out = {"workload": f"{B} frames 1920x1080, JPEG 4:2:0 quality 80 ({sum(map(len, files)) // B} bytes each), decoded to the detector's gray image in HBM",
+           "cpu_baseline": {"value": round(1.0 / cpu, 1), "unit": "frames/s", "cores": 1, "kind": "reference",
+                            "sample": "12 frames through libjpeg-turbo (Pillow; the library behind cv::imdecode), decode + RGB"}}
+    dec = fj.JpegDecoder(max_width=W, max_height=H, max_batch=B, device=local_rank)
+    for _ in range(2):
+        dec.decode(files, "mono8", to_host=False)
+    t = time.perf_counter()
+    for _ in range(4):
+        dec.decode(files, "mono8", to_host=False)
+    out["value"] = round(B * 4 / (time.perf_counter() - t), 1)
+    out["unit"] = "frames/s"
+    out["sync_rounds"] = dec.last_rounds()
+    dec.close()
+    one = fj.JpegDecoder(max_width=W, max_height=H, max_batch=1, device=local_rank)
+    det = ArucoDetector("DICT_5X5_250", device=local_rank, max_width=W, max_height=H, max_batch=1, max_markers=64)
+    ts, te = [], []
+    for it in range(25):
+        t = time.perf_counter()
+        one.decode(files[it % B], "mono8", to_host=False)
+        t1 = time.perf_counter()
+        ptr, w, h, _, _ = one.device_ptr()
+        det.detect_markers_device(ptr, 1, w, h)
+        te.append(time.perf_counter() - t)
+        ts.append(t1 - t)
+    one.close()
+    det.close()
+    out["single_frame_decode_ms"] = round(float(np.median(ts[5:])) * 1e3, 3)
+    out["single_frame_decode_and_detect_ms"] = round(float(np.median(te[5:])) * 1e3, 3)
+    return out
+
+
 def stag_side_result(local_rank, args):
     """BASELINE cfg 5 inside the default line (so that the driver's run times it too): a short run of the stag_detect path
     (Stag::detectMarkers + 5-point pose, frames from host memory, one frame per call on concurrent contexts) and the
@@ -615,6 +670,10 @@ def main():
             det.close()
             det = None
             out["extra"] = {"cfg2_single_frame": cfg2_latency(local_rank, frames_u[0])}
+            try:
+                out["extra"]["jpeg_ingest"] = jpeg_side_result(local_rank, frames_u)
+            except Exception as e:  # noqa: BLE001
+                out["extra"]["jpeg_ingest"] = {"error": repr(e)}
             try:
                 # in a process of its own: the contexts of the runs above keep their hardware queues after they are closed,
                 # and 16 more streams on top oversubscribe the queues (measured: 310 frames/s in-process, 1300 alone)

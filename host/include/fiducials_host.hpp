@@ -29,6 +29,11 @@ struct Image {  // sensor_msgs/Image
     uint32_t step = 0;
     std::vector<uint8_t> data;
 };
+struct CompressedImage {  // sensor_msgs/CompressedImage: what arrives with image_transport's `compressed` (the launch default)
+    Header header;
+    std::string format;  // "jpeg", or "bgr8; jpeg compressed bgr8" as compressed_image_transport writes it
+    std::vector<uint8_t> data;
+};
 struct CameraInfo {  // sensor_msgs/CameraInfo (the fields the node reads)
     Header header;
     uint32_t height = 0, width = 0;
@@ -133,6 +138,10 @@ class FiducialsNode {
     void ignoreCallback(const std::string &msg);                     // :300-305
     void camInfoCallback(const CameraInfo &msg);                     // :307-330
     bool imageCallback(const Image &msg, FiducialArray *out);        // :332-395
+    // the same callback for a frame that arrives compressed (aruco_detect.launch:6 transport=compressed): the JPEG is decoded
+    // on the device (fid_jpeg_decode: what the subscriber plugin's cv::imdecode + toCvCopy(BGR8) + BGR2GRAY produce) and the
+    // detector runs on the device-resident gray image
+    bool compressedImageCallback(const CompressedImage &msg, FiducialArray *out);
     bool poseEstimateCallback(const FiducialArray &msg, FiducialTransformArray *out);  // :397-538 (fiducial_msgs view)
     bool poseEstimateCallback(const FiducialArray &msg, PoseOutputs *out);             // ... everything it publishes
     bool enableDetectionsCallback(bool data, std::string *message);  // :573-588
@@ -147,7 +156,10 @@ class FiducialsNode {
    private:
     void handleIgnoreString(const std::string &str);           // :540-571
     void handleLenOverrideString(const std::string &str);      // :627-660
+    bool publishVertices(const Header &h, int32_t n, FiducialArray *out);  // the tail of imageCallback (:342-379)
     fid_ctx *ctx = nullptr;
+    fid_jpeg_ctx *jctx = nullptr;  // made when the first compressed frame arrives
+    int maxW = 0, maxH = 0, dev = 0;
     Dictionary dict;
     fid_params detectorParams;
     std::vector<fid_marker> markers;   // corners / ids of the last image (the reference's `corners`, `ids` members, :101-102)

@@ -165,12 +165,19 @@ FiducialsNode::FiducialsNode(const Params &p)
     lim.max_width = p.max_width;
     lim.max_height = p.max_height;
     lim.max_batch = 1;
+    maxW = p.max_width;
+    maxH = p.max_height;
+    dev = p.device;
     const fid_status rc = fid_create(&detectorParams, &fd, &lim, p.device, &ctx);
     if (rc != FID_OK) throw std::runtime_error(std::string("fid_create: ") + fid_strerror(rc));
     markers.resize(1024);
 }
 
-FiducialsNode::~FiducialsNode() { fid_destroy(ctx); }
+FiducialsNode::~FiducialsNode()
+{
+    if (jctx) fid_jpeg_destroy(jctx);
+    fid_destroy(ctx);
+}
 
 static int stoi_like(const std::string &s) { return std::stoi(s); }  // the node uses std::stoi: same acceptance, same throws
 
@@ -256,14 +263,31 @@ bool FiducialsNode::enableDetectionsCallback(bool data, std::string *message)
     return true;
 }
 
+bool FiducialsNode::publishVertices(const Header &h, int32_t n, FiducialArray *out)
+{
+    FiducialArray fva;
+    fva.header.sec = h.sec;
+    fva.header.nsec = h.nsec;
+    fva.header.frame_id = frameId;
+    fva.image_seq = (int32_t)h.seq;
+    ids.resize(n);
+    for (int i = 0; i < n; i++) ids[i] = markers[i].id;
+    for (int i = 0; i < n; i++) {
+        if (std::count(ignoreIds.begin(), ignoreIds.end(), ids[i]) != 0) continue;
+        const float *c = markers[i].corners;
+        Fiducial fid;
+        fid.fiducial_id = ids[i];
+        fid.x0 = c[0]; fid.y0 = c[1]; fid.x1 = c[2]; fid.y1 = c[3];
+        fid.x2 = c[4]; fid.y2 = c[5]; fid.x3 = c[6]; fid.y3 = c[7];
+        fva.fiducials.push_back(fid);
+    }
+    *out = fva;
+    return true;
+}
+
 bool FiducialsNode::imageCallback(const Image &msg, FiducialArray *out)
 {
     if (enable_detections == false) return false;
-    FiducialArray fva;
-    fva.header.sec = msg.header.sec;
-    fva.header.nsec = msg.header.nsec;
-    fva.header.frame_id = frameId;
-    fva.image_seq = (int32_t)msg.header.seq;
     fid_encoding enc;
     if (msg.encoding == "mono8") enc = FID_ENC_MONO8;
     else if (msg.encoding == "bgr8") enc = FID_ENC_BGR8;
@@ -279,19 +303,36 @@ bool FiducialsNode::imageCallback(const Image &msg, FiducialArray *out)
         last_error = fid_last_error(ctx);
         return false;
     }
-    ids.resize(n);
-    for (int i = 0; i < n; i++) ids[i] = markers[i].id;
-    for (int i = 0; i < n; i++) {
-        if (std::count(ignoreIds.begin(), ignoreIds.end(), ids[i]) != 0) continue;
-        const float *c = markers[i].corners;
-        Fiducial fid;
-        fid.fiducial_id = ids[i];
-        fid.x0 = c[0]; fid.y0 = c[1]; fid.x1 = c[2]; fid.y1 = c[3];
-        fid.x2 = c[4]; fid.y2 = c[5]; fid.x3 = c[6]; fid.y3 = c[7];
-        fva.fiducials.push_back(fid);
+    return publishVertices(msg.header, n, out);
+}
+
+bool FiducialsNode::compressedImageCallback(const CompressedImage &msg, FiducialArray *out)
+{
+    if (enable_detections == false) return false;
+    if (!jctx) {
+        const fid_status rc = fid_jpeg_create(dev, maxW, maxH, 1, &jctx);
+        if (rc != FID_OK) {
+            last_error = std::string("fid_jpeg_create: ") + fid_strerror(rc);
+            return false;
+        }
     }
-    *out = fva;
-    return true;
+    const uint8_t *file = msg.data.data();
+    const int64_t nbytes = (int64_t)msg.data.size();
+    // gray = cvtColor(BGR2GRAY) of what cv::imdecode returns, left on the device
+    fid_status rc = fid_jpeg_decode(jctx, &file, &nbytes, 1, FID_ENC_MONO8, nullptr, 0);
+    if (rc != FID_OK) {  // (the subscriber plugin logs and drops a frame it cannot decode)
+        last_error = std::string("compressed frame: ") + fid_jpeg_last_error(jctx);
+        return false;
+    }
+    int32_t w = 0, h = 0, stride = 0, n = 0;
+    int64_t fstride = 0;
+    const void *gray = fid_jpeg_device_ptr(jctx, &w, &h, &stride, &fstride);
+    rc = fid_detect_device(ctx, gray, 1, w, h, stride, fstride, FID_ENC_MONO8, markers.data(), (int32_t)markers.size(), &n);
+    if (rc != FID_OK) {
+        last_error = fid_last_error(ctx);
+        return false;
+    }
+    return publishVertices(msg.header, n, out);
 }
 
 bool FiducialsNode::poseEstimateCallback(const FiducialArray &msg, FiducialTransformArray *out)

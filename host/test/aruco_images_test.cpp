@@ -272,6 +272,35 @@ static void bag_4957(const Fixture &fx)
     CHECK(matched >= 6);
 }
 
+// a frame that arrives compressed (image_transport `compressed`, the launch default): decoded on the device, the result is
+// what the same frame gives when it arrives raw -- decoded by the checker's restatement of libjpeg (tag_01_jpg.pgm, written
+// by tests/test_gpu_host_cpp.py next to tag_01.jpg)
+static void compressed_frame(const Fixture &fx)
+{
+    std::ifstream jf(fx.image_directory + "/tag_01.jpg", std::ios::binary);
+    if (!jf) {
+        std::printf("(no tag_01.jpg: compressed-frame check skipped)\n");
+        return;
+    }
+    CompressedImage cm;
+    cm.header.seq = 7;
+    cm.format = "mono8; jpeg compressed mono8";
+    cm.data.assign(std::istreambuf_iterator<char>(jf), std::istreambuf_iterator<char>());
+    FiducialsNode node(fx.params());
+    FiducialArray a, b;
+    CHECK(node.compressedImageCallback(cm, &a));
+    CHECK(node.imageCallback(load_pgm(fx.image_directory + "/tag_01_jpg.pgm", 7), &b));
+    CHECK(a.image_seq == 7 && a.fiducials.size() == b.fiducials.size() && a.fiducials.size() == 1);
+    for (size_t i = 0; i < a.fiducials.size() && i < b.fiducials.size(); i++) {
+        CHECK(a.fiducials[i].fiducial_id == b.fiducials[i].fiducial_id && a.fiducials[i].fiducial_id == 1);
+        CHECK(a.fiducials[i].x0 == b.fiducials[i].x0 && a.fiducials[i].y0 == b.fiducials[i].y0 && a.fiducials[i].x2 == b.fiducials[i].x2 &&
+              a.fiducials[i].y2 == b.fiducials[i].y2);
+    }
+    // a frame that is not a JPEG is dropped with a message, as the subscriber plugin does
+    cm.data.assign(64, 0x41);
+    CHECK(!node.compressedImageCallback(cm, &a) && !node.lastError().empty());
+}
+
 int main(int argc, char **argv)
 {
     if (argc < 3) {
@@ -284,6 +313,7 @@ int main(int argc, char **argv)
         tag_245_246_d7_14cm(fx);
         node_surface(fx);
         bag_4957(fx);
+        compressed_frame(fx);
     } catch (const std::exception &e) {
         std::printf("EXCEPTION %s\n", e.what());
         return 3;

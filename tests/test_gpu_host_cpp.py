@@ -38,6 +38,19 @@ def test_reference_node_test_passes_on_the_cpp_host(tmp_path):
     g = json.load(open(os.path.join(GOLD, "golden.json")))["bag_4957"]
     (tmp_path / "bag_4957.txt").write_text(" ".join(repr(float(v)) for v in list(g["K"]) + list(g["D"])[:5]))
     (tmp_path / "bag_4957_msg.hex").write_text(g["transforms"]["raw_hex"])
+    try:  # the same frame as it arrives with image_transport `compressed`, and what libjpeg makes of it (the oracle's restatement)
+        import io
+
+        from PIL import Image
+
+        from oracle import jpeg as oj
+        b = io.BytesIO()
+        Image.fromarray(np.load(os.path.join(GOLD, "tag_01.npz"))["gray"]).save(b, "JPEG", quality=90)
+        (tmp_path / "tag_01.jpg").write_bytes(b.getvalue())
+        bgr = oj.decode(b.getvalue())
+        _write_pgm(tmp_path / "tag_01_jpg.pgm", np.ascontiguousarray(bgr[..., 0]))
+    except ImportError:
+        pass  # (no Pillow to write the file: the C++ test skips that check)
     r = subprocess.run([exe, str(tmp_path), os.path.join(ROOT, "fiducials_amd", "data")], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "all checks passed" in r.stdout

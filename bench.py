@@ -271,7 +271,7 @@ def jpeg_side_result(local_rank, frames):
     from fiducials_amd import jpeg as fj
     from fiducials_amd.detector import ArucoDetector
 
-    B = min(64, len(frames))
+    B = min(256, len(frames))
     files = []
     for k in range(B):
         b = io.BytesIO()

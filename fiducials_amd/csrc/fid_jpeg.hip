@@ -679,35 +679,100 @@ __device__ __forceinline__ int jp_chroma(const uint8_t *pl, int pitch, int cw, i
     return (cur * 3 + (in0[i - 1] * 3 + in1[i - 1]) + 8) >> 4;
 }
 
+// a lane takes four pixels of a row (x = 4 k .. 4 k + 3): one division per four pixels, the chroma samples they share are
+// loaded once, the gray result leaves as one 4-byte store
 __global__ __launch_bounds__(256) void k_jpeg_color(const JpImage *__restrict__ imgs, const uint8_t *__restrict__ planes, uint8_t *__restrict__ out,
                                                     long long out_fstride, int gray_out)
 {
     const JpImage &I = imgs[blockIdx.y];
-    const int W = I.w, H = I.h;
+    const int W = I.w, H = I.h, W4 = (W + 3) >> 2;
     const uint8_t *P = planes + I.plane_base;
     uint8_t *dst = out + (long long)blockIdx.y * out_fstride;
     const int cw = (W + I.hs - 1) / I.hs, ch = (H + I.vs - 1) / I.vs;
-    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < (long long)W * H; idx += (long long)gridDim.x * blockDim.x) {
-        const int y = (int)(idx / W), x = (int)(idx - (long long)y * W);
-        const int Y = P[I.plane_off[0] + (size_t)y * (I.bw[0] * 8) + x];
-        int r = Y, g = Y, b = Y;
+    const int p0 = I.bw[0] * 8, p1 = I.ncomp == 3 ? I.bw[1] * 8 : 0;
+    const bool fancy = I.ncomp == 3 && I.hs == 2 && cw > 2;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < (long long)W4 * H; idx += (long long)gridDim.x * blockDim.x) {
+        const int y = (int)(idx / W4), x0 = (int)(idx - (long long)y * W4) * 4;
+        const uint8_t *yr = P + I.plane_off[0] + (size_t)y * p0 + x0;  // (rows of the planes are multiples of 8 wide: four bytes are there)
+        int Y[4], cbv[4], crv[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) Y[k] = yr[k];
         if (I.ncomp == 3) {
-            const int cb = jp_chroma(P + I.plane_off[1], I.bw[1] * 8, cw, ch, I.hs, I.vs, x, y) - 128;
-            const int cr = jp_chroma(P + I.plane_off[2], I.bw[2] * 8, cw, ch, I.hs, I.vs, x, y) - 128;
-            r = Y + ((91881 * cr + 32768) >> 16);
-            g = Y + ((-22554 * cb + 32768 - 46802 * cr) >> 16);
-            b = Y + ((116130 * cb + 32768) >> 16);
-            r = r < 0 ? 0 : (r > 255 ? 255 : r);
-            g = g < 0 ? 0 : (g > 255 ? 255 : g);
-            b = b < 0 ? 0 : (b > 255 ? 255 : b);
+            if (fancy) {
+                // chroma columns i0 - 1 .. i0 + 2 serve the four pixels (x0 = 2 i0); column sums 3 * near row + far row for
+                // h2v2, the row itself (times 4, to share the arithmetic below) for h2v1
+                const int i0 = x0 >> 1;
+                const int cy = I.vs == 2 ? y >> 1 : y;
+                int yf = cy;
+                if (I.vs == 2) {
+                    yf = (y & 1) ? cy + 1 : cy - 1;
+                    yf = yf < 0 ? 0 : (yf > ch - 1 ? ch - 1 : yf);
+                }
+#pragma unroll
+                for (int pl = 0; pl < 2; pl++) {
+                    const uint8_t *base = P + I.plane_off[1 + pl];
+                    const uint8_t *in0 = base + (size_t)cy * p1, *in1 = base + (size_t)yf * p1;
+                    int col[4];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        int i = i0 - 1 + k;
+                        i = i < 0 ? 0 : (i > cw - 1 ? cw - 1 : i);
+                        col[k] = I.vs == 2 ? in0[i] * 3 + in1[i] : in0[i];
+                    }
+                    int *o = pl ? crv : cbv;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const int i = i0 + (k >> 1);  // this pixel's chroma column; col[1 + (k >> 1)] is its sample
+                        const int cur = col[1 + (k >> 1)];
+                        int v;
+                        if (I.vs == 2) {
+                            if (k & 1) v = i >= cw - 1 ? (cur * 4 + 7) >> 4 : (cur * 3 + col[2 + (k >> 1)] + 7) >> 4;
+                            else v = i == 0 ? (cur * 4 + 8) >> 4 : (cur * 3 + col[k >> 1] + 8) >> 4;
+                        } else {
+                            if (k & 1) v = i >= cw - 1 ? cur : (cur * 3 + col[2 + (k >> 1)] + 2) >> 2;
+                            else v = i == 0 ? cur : (cur * 3 + col[k >> 1] + 1) >> 2;
+                        }
+                        o[k] = v;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int x = x0 + k < W ? x0 + k : W - 1;
+                    cbv[k] = jp_chroma(P + I.plane_off[1], p1, cw, ch, I.hs, I.vs, x, y);
+                    crv[k] = jp_chroma(P + I.plane_off[2], p1, cw, ch, I.hs, I.vs, x, y);
+                }
+            }
+        }
+        uint32_t gw = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            int r = Y[k], g = Y[k], b = Y[k];
+            if (I.ncomp == 3) {
+                const int cb = cbv[k] - 128, cr = crv[k] - 128;
+                r = Y[k] + ((91881 * cr + 32768) >> 16);
+                g = Y[k] + ((-22554 * cb + 32768 - 46802 * cr) >> 16);
+                b = Y[k] + ((116130 * cb + 32768) >> 16);
+                r = r < 0 ? 0 : (r > 255 ? 255 : r);
+                g = g < 0 ? 0 : (g > 255 ? 255 : g);
+                b = b < 0 ? 0 : (b > 255 ? 255 : b);
+            }
+            if (gray_out) {
+                gw |= (uint32_t)((b * 3735 + g * 19235 + r * 9798 + (1 << 14)) >> 15) << (8 * k);  // K0: cvtColor(BGR2GRAY)
+            } else if (x0 + k < W) {
+                uint8_t *o = dst + ((long long)y * W + x0 + k) * 3;
+                o[0] = (uint8_t)b;
+                o[1] = (uint8_t)g;
+                o[2] = (uint8_t)r;
+            }
         }
         if (gray_out) {
-            dst[idx] = (uint8_t)((b * 3735 + g * 19235 + r * 9798 + (1 << 14)) >> 15);  // K0: cvtColor(BGR2GRAY)
-        } else {
-            uint8_t *o = dst + idx * 3;
-            o[0] = (uint8_t)b;
-            o[1] = (uint8_t)g;
-            o[2] = (uint8_t)r;
+            uint8_t *o = dst + (long long)y * W + x0;
+            if (x0 + 4 <= W && (((long long)y * W + x0) & 3) == 0) {
+                *reinterpret_cast<uint32_t *>(o) = gw;
+            } else {
+                for (int k = 0; k < 4 && x0 + k < W; k++) o[k] = (uint8_t)(gw >> (8 * k));
+            }
         }
     }
 }
@@ -1022,6 +1087,7 @@ fid_status fid_jpeg_decode(fid_jpeg_ctx *c, const uint8_t *const *files, const i
     }
     // ---- headers, tables, packing of the entropy-coded bytes
     size_t scan_at = 0, sub_at = 0;
+    std::vector<const uint8_t *> pack_src((size_t)n);
     uint32_t max_nsub = 0, max_blocks = 0;
     int W = 0, Hh = 0;
     for (int f = 0; f < n; f++) {
@@ -1085,11 +1151,26 @@ fid_status fid_jpeg_decode(fid_jpeg_ctx *c, const uint8_t *const *files, const i
             c->last_error = "empty scan";
             return FID_E_INVALID_ARG;
         }
-        memcpy(c->h_scan + scan_at, files[f] + H.scan_off, H.scan_len);
+        pack_src[(size_t)f] = files[f] + H.scan_off;
         scan_at = (scan_at + H.scan_len + 15) & ~(size_t)15;  // (every image's bytes start on a 16-byte boundary)
         sub_at += I.nsub;
         max_nsub = I.nsub > max_nsub ? I.nsub : max_nsub;
         max_blocks = co / 64 > max_blocks ? co / 64 : max_blocks;
+    }
+    // the entropy-coded bytes into pinned memory (a few host threads for a large batch: one thread moves ~10 GB/s), then one copy
+    {
+        const int nt = n >= 32 ? 8 : (n >= 8 ? 4 : 1);
+        auto pack = [&](int t) {
+            for (int f = t; f < n; f += nt) memcpy(c->h_scan + c->h_imgs[f].scan_off, pack_src[(size_t)f], c->h_imgs[f].scan_len);
+        };
+        if (nt == 1) {
+            pack(0);
+        } else {
+            std::vector<std::thread> th;
+            for (int t = 1; t < nt; t++) th.emplace_back(pack, t);
+            pack(0);
+            for (auto &x : th) x.join();
+        }
     }
     JPCHK(c, hipMemcpyAsync(c->d_scan, c->h_scan, scan_at, hipMemcpyHostToDevice, st));
     JPCHK(c, hipMemcpyAsync(c->d_imgs, c->h_imgs, (size_t)n * sizeof(JpImage), hipMemcpyHostToDevice, st));
@@ -1129,7 +1210,7 @@ fid_status fid_jpeg_decode(fid_jpeg_ctx *c, const uint8_t *const *files, const i
     const int bpp = out_enc == FID_ENC_MONO8 ? 1 : 3;
     const long long fstride = (long long)W * Hh * bpp;
     {
-        long long px = (long long)W * Hh;
+        long long px = (long long)((W + 3) / 4) * Hh;  // four pixels per lane
         int blocks = (int)((px + 255) / 256);
         blocks = blocks > 4096 ? 4096 : blocks;
         hipLaunchKernelGGL(k_jpeg_color, dim3(blocks, n), dim3(256), 0, st, c->d_imgs, c->d_planes, c->d_out, fstride, out_enc == FID_ENC_MONO8 ? 1 : 0);

@@ -54,10 +54,9 @@ class JpegDecoder:
         """files: a bytes object or a list of them (one image size per call).  -> (n, H, W, 3) bgr8 as cv::imdecode returns it,
         or (n, H, W) mono8 = cvtColor(BGR2GRAY) of that; None with to_host=False (the result stays on the device: device_ptr())."""
         single = isinstance(files, (bytes, bytearray, memoryview))
-        blobs = [bytes(files)] if single else [bytes(f) for f in files]
+        blobs = [bytes(files)] if single else [f if isinstance(f, bytes) else bytes(f) for f in files]
         n = len(blobs)
-        keep = [(C.c_uint8 * len(b)).from_buffer_copy(b) for b in blobs]
-        ptrs = (C.c_void_p * n)(*[C.cast(k, C.c_void_p) for k in keep])
+        ptrs = (C.c_void_p * n)(*[C.cast(C.c_char_p(b), C.c_void_p) for b in blobs])  # (the bytes objects themselves: no copy)
         sizes = (C.c_int64 * n)(*[len(b) for b in blobs])
         i = probe(blobs[0])
         bpp = 1 if encoding == "mono8" else 3

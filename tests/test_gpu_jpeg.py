@@ -115,7 +115,15 @@ def test_odd_sizes_and_damaged_files():
                     if rst:
                         kw["restart_marker_blocks"] = rst
                     check(dec, _encode(img, **kw))
-        # a file cut off inside the scan, and one with bytes overwritten: no crash, a deterministic image
+        # the corners of the format: quality 1 (long zero runs, ZRL) and 100 (long codes: the 16-bit tables), tables optimised
+        # for the image (not the standard ones), a restart marker behind every MCU
+        img = rng.integers(0, 256, (203, 311, 3)).astype(np.uint8)
+        img[50:120, 60:200] = (img[50:120, 60:200] // 16) + 200
+        for kw in (dict(quality=1, subsampling=2), dict(quality=100, subsampling=0), dict(quality=100, subsampling=2, optimize=True),
+                   dict(quality=35, subsampling=1, optimize=True), dict(quality=75, subsampling=2, restart_marker_blocks=1),
+                   dict(quality=90, subsampling=0, restart_marker_blocks=1), dict(quality=50, subsampling=2, restart_marker_rows=2)):
+            check(dec, _encode(img, **kw))
+        check(dec, _encode(img[..., 0], quality=97, optimize=True))
         data = _encode(rng.integers(0, 256, (240, 320, 3)).astype(np.uint8), quality=85)
         cut = data[:len(data) // 2]
         a = dec.decode(cut, "bgr8")

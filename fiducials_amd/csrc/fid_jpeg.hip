@@ -55,14 +55,16 @@ __constant__ uint8_t c_jp_zigzag[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 
                                         41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
                                         30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
 
-// ---- the workgroup's bytes, unstuffed.  Every lane cleans its own sub-sequence (and lane 0 the one behind the last): FF 00 ->
+// ---- the workgroup's bytes, unstuffed.  Every lane cleans one sub-sequence (the last lane's is the next workgroup's first: it
+// only serves the lane in front of it, which may end a symbol behind its own): FF 00 ->
 // FF, fill bytes and markers dropped, and writes what is left into one packed LDS buffer, so that the symbol loop below reads
 // plain bits.  What has to survive of the raw layout:
 //   s_R[j], s_rm[j]   removed bytes before sub-sequence j / which of its 128 bytes were removed: raw <-> packed positions
 //                     (states are exchanged as RAW bit positions: they are the same whoever computes them)
 //   s_bnd             packed byte positions in front of which a restart marker stood: every decoder starts afresh there
 //   s_end             packed byte position of the end of the data (EOI, another marker, or the end of the file)
-#define JP_NSTG (JP_TPB + 1)
+#define JP_NSTG JP_TPB          // sub-sequences a workgroup unstuffs: one per lane ...
+#define JP_OWN (JP_TPB - 1)      // ... of which it decodes all but the last (that one only serves the lane in front of it)
 struct JpStage {
     uint8_t cmp[JP_NSTG * JP_SUB + 16];
     uint32_t rm[JP_NSTG][4];
@@ -157,17 +159,18 @@ __global__ __launch_bounds__(JP_TPB) void k_jpeg_huff(const JpImage *__restrict_
     __shared__ JpStage S;
     __shared__ uint16_t s_lut[4][1 << JP_LOOK];  // [dc luma, ac luma, dc chroma, ac chroma] first-level tables
     const JpImage &I = imgs[blockIdx.y];
-    const uint32_t first = blockIdx.x * JP_TPB;
+    const uint32_t first = blockIdx.x * JP_OWN;
     if (first >= I.nsub) return;
     const uint8_t *g = scan + I.scan_off;
     const uint32_t s_lo = first * JP_SUB;
     const uint32_t tid = threadIdx.x, i = first + tid;
+    const bool decoder = tid < JP_OWN && i < I.nsub;
     const uint32_t gsub = I.sub_base + (i < I.nsub ? i : 0u);
     // ---- does this workgroup have anything to do in this round?
-    bool active = i < I.nsub;
+    bool active = decoder;
     if (MODE == 1 && active) active = i > 0 && chg_in[gsub - 1];
     if (MODE == 1) {
-        if (i < I.nsub && !active) {  // nothing new to start from: the previous result stands
+        if (decoder && !active) {  // nothing new to start from: the previous result stands
             st_out[gsub] = st_in[gsub];
             chg_out[gsub] = 0;
         }
@@ -187,16 +190,16 @@ __global__ __launch_bounds__(JP_TPB) void k_jpeg_huff(const JpImage *__restrict_
     if (tid == 0) S.end = 0xffffffffu;
     // ---- unstuff: sub-sequences first .. first + nstg - 1 (the last one only serves the lane in front of it)
     const uint32_t nstg = (I.nsub - first) >= JP_NSTG ? JP_NSTG : (I.nsub - first);
-    uint32_t w[2][32];   // the raw bytes of this lane's sub-sequence(s): [0] its own, [1] (lane 0 only) the one behind the last
-    uint32_t rmv[2][4], bndm[2][4], endm[2][4];
-    int nrem[2] = {0, 0};
-#pragma unroll
-    for (int t = 0; t < 2; t++) {
-        const uint32_t j = t == 0 ? tid : (uint32_t)JP_TPB;
-        const bool mine = t == 0 ? tid < nstg : (tid == 0 && nstg == JP_NSTG);
+    uint32_t w[1][32];   // the raw bytes of this lane's sub-sequence
+    uint32_t rmv[1][4], bndm[1][4], endm[1][4];
+    int nrem[1] = {0};
+    {
+        constexpr int t = 0;
+        const uint32_t j = tid;
+        const bool mine = tid < nstg;
 #pragma unroll
         for (int q = 0; q < 4; q++) rmv[t][q] = bndm[t][q] = endm[t][q] = 0u;
-        if (!mine) continue;
+        if (mine) {
         const uint32_t r0 = s_lo + j * JP_SUB;  // first raw byte
         uint32_t F[4] = {0, 0, 0, 0}, Z[4] = {0, 0, 0, 0}, D[4] = {0, 0, 0, 0};  // byte is FF / 00 / D0..D7
 #pragma unroll
@@ -259,6 +262,7 @@ __global__ __launch_bounds__(JP_TPB) void k_jpeg_huff(const JpImage *__restrict_
         }
         // (the byte behind the end of the data is an end marker too)
         if (valid < JP_SUB && r0 + valid == I.scan_len) endm[t][valid >> 5] |= 1u << (valid & 31);
+        }
     }
     // removed bytes before every sub-sequence: scan over the lanes (+ the extra one of lane 0 at the end)
     {
@@ -271,16 +275,12 @@ __global__ __launch_bounds__(JP_TPB) void k_jpeg_huff(const JpImage *__restrict_
         if (tid == JP_TPB - 1) S.R[JP_TPB] = (uint32_t)(wb + incl);
         if (tid < nstg)
             for (int q = 0; q < 4; q++) S.rm[tid][q] = rmv[0][q];
-        if (tid == 0 && nstg == JP_NSTG)
-            for (int q = 0; q < 4; q++) S.rm[JP_TPB][q] = rmv[1][q];
     }
     __syncthreads();
     // packed bytes, restart boundaries, end of data
-#pragma unroll
-    for (int t = 0; t < 2; t++) {
-        const uint32_t j = t == 0 ? tid : (uint32_t)JP_TPB;
-        const bool mine = t == 0 ? tid < nstg : (tid == 0 && nstg == JP_NSTG);
-        if (!mine) continue;
+    if (tid < nstg) {
+        constexpr int t = 0;
+        const uint32_t j = tid;
         uint32_t dst = j * JP_SUB - S.R[j];
 #pragma unroll
         for (int q = 0; q < 32; q++) {
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(JP_TPB) void k_jpeg_huff(const JpImage *__restrict_
             for (int u = 0; u < 16; u++) S.cmp[dst + u] = 0;
     }
     __syncthreads();
-    if (i >= I.nsub) return;
+    if (!decoder) return;
     if (MODE == 1 && !active) return;
     // ---- entry state
     JpState e;
@@ -1176,7 +1176,7 @@ fid_status fid_jpeg_decode(fid_jpeg_ctx *c, const uint8_t *const *files, const i
     JPCHK(c, hipMemcpyAsync(c->d_imgs, c->h_imgs, (size_t)n * sizeof(JpImage), hipMemcpyHostToDevice, st));
     JPCHK(c, hipMemsetAsync(c->d_coefs, 0, (size_t)n * c->max_blocks * 64 * sizeof(int16_t), st));
     // ---- J1: entropy decoding
-    const dim3 hgrid((max_nsub + JP_TPB - 1) / JP_TPB, n);
+    const dim3 hgrid((max_nsub + JP_OWN - 1) / JP_OWN, n);
     hipLaunchKernelGGL(k_jpeg_huff<0>, hgrid, dim3(JP_TPB), 0, st, c->d_imgs, c->d_scan, c->d_luts, (const JpState *)nullptr, c->d_state[0], (const uint8_t *)nullptr,
                        c->d_chg[0], c->d_nblk, (const uint32_t *)nullptr, (int16_t *)nullptr, c->d_flag);
     int cur = 0, rounds = 0;

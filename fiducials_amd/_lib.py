@@ -67,7 +67,7 @@ class FidJpegInfo(C.Structure):
 
 FID_OK = 0
 FID_E_INVALID_ARG, FID_E_NO_DEVICE, FID_E_HIP, FID_E_CAPACITY, FID_E_OUT_OF_MEMORY, FID_E_UNSUPPORTED = 1, 2, 3, 4, 5, 6
-ENC = {"mono8": 0, "bgr8": 1, "rgb8": 2}
+ENC = {"mono8": 0, "bgr8": 1, "rgb8": 2, "bgra8": 3, "rgba8": 4}
 TAP_MASKS, TAP_CANDIDATES, TAP_FILTERED, TAP_BITS, TAP_IDENT, TAP_PRESUBPIX, TAP_COUNTS, TAP_GRAY = range(8)
 
 # every symbol include/fid_abi.h declares

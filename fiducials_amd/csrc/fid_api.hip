@@ -241,8 +241,8 @@ fid_status run_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H, int
     if (!out || !n_per_frame || cap_per_frame < 0) return FID_E_INVALID_ARG;
     if (F < 1 || F > c->lim.max_batch || W < 8 || H < 8 || W > c->lim.max_width || H > c->lim.max_height || W > 8191 || H > 8191)  // 13-bit checkpoint packing
         return FID_E_INVALID_ARG;
-    if (enc != FID_ENC_MONO8 && enc != FID_ENC_BGR8 && enc != FID_ENC_RGB8) return FID_E_INVALID_ARG;
-    int bpp = enc == FID_ENC_MONO8 ? 1 : 3;
+    if (enc != FID_ENC_MONO8 && enc != FID_ENC_BGR8 && enc != FID_ENC_RGB8 && enc != FID_ENC_BGRA8 && enc != FID_ENC_RGBA8) return FID_E_INVALID_ARG;
+    int bpp = enc == FID_ENC_MONO8 ? 1 : ((enc == FID_ENC_BGRA8 || enc == FID_ENC_RGBA8) ? 4 : 3);
     if (stride < W * bpp) return FID_E_INVALID_ARG;
     if ((unsigned)(c->params.maxMarkerPerimeterRate * (W > H ? W : H)) > 36000u) return FID_E_UNSUPPORTED;  // contour points live in LDS
     hipStream_t st0 = c->stream;

@@ -34,7 +34,6 @@
 #define JP_TPB 256         // lanes (sub-sequences) per workgroup
 #define JP_PAD 64          // bytes staged beyond the workgroup's last sub-sequence (a lane stops within one symbol of its end)
 #define JP_LOOK 10         // bits of the LDS first-level code tables
-#define JP_MAX_LUT 16      // cached 16-bit code tables
 
 struct JpImage {
     unsigned long long scan_off;   // into the packed scan bytes of the call
@@ -151,7 +150,7 @@ __device__ __forceinline__ bool operator!=(const JpState &a, const JpState &b) {
 
 // MODE 0: speculative first pass, 1: synchronisation round, 2: writing pass
 template <int MODE>
-__global__ __launch_bounds__(JP_TPB) void k_jpeg_huff(const JpImage *__restrict__ imgs, const uint8_t *__restrict__ scan, const uint16_t *__restrict__ luts,
+__global__ __launch_bounds__(JP_TPB) void k_jpeg_huff(const JpImage *__restrict__ imgs, const uint8_t *__restrict__ scan, const uint16_t *__restrict__ luts, const uint16_t *__restrict__ lut1,
                                                      const JpState *__restrict__ st_in, JpState *__restrict__ st_out,
                                                      const uint8_t *__restrict__ chg_in, uint8_t *__restrict__ chg_out, uint32_t *__restrict__ nblk,
                                                      const uint32_t *__restrict__ blkbase, int16_t *__restrict__ coefs, unsigned *__restrict__ any_changed)
@@ -183,8 +182,7 @@ __global__ __launch_bounds__(JP_TPB) void k_jpeg_huff(const JpImage *__restrict_
     const bool cr_same = I.ncomp < 3 || (I.lut_dc[2] == I.lut_dc[1] && I.lut_ac[2] == I.lut_ac[1]);
     for (int k = tid; k < 4 << JP_LOOK; k += JP_TPB) {
         const int t = k >> JP_LOOK, q = k & ((1 << JP_LOOK) - 1);
-        const uint16_t e = luts[(size_t)slot[t] * 65536 + ((size_t)q << (16 - JP_LOOK))];
-        s_lut[t][q] = (e >> 8) <= JP_LOOK ? e : (uint16_t)0;
+        s_lut[t][q] = lut1[(size_t)slot[t] * (1 << JP_LOOK) + q];
     }
     for (int k = tid; k < JP_NSTG * JP_SUB / 32 + 2; k += JP_TPB) S.bnd[k] = 0u;
     if (tid == 0) S.end = 0xffffffffu;
@@ -940,7 +938,7 @@ struct fid_jpeg_ctx {
     int16_t *d_coefs = nullptr;
     int32_t *d_dcs = nullptr;
     JpImage *d_imgs = nullptr;
-    uint16_t *d_luts = nullptr;
+    uint16_t *d_luts = nullptr, *d_lut1 = nullptr;  // 16-bit code tables; their first-level (JP_LOOK bit) extracts, contiguous
     JpState *d_state[2] = {nullptr, nullptr};
     uint8_t *d_chg[2] = {nullptr, nullptr};
     uint32_t *d_nblk = nullptr, *d_blkbase = nullptr;
@@ -951,7 +949,7 @@ struct fid_jpeg_ctx {
     unsigned *h_flag = nullptr;
     uint16_t *h_lut = nullptr;
     std::unordered_map<unsigned long long, int> lut_slot;
-    int lut_next = 0;
+    int lut_next = 0, lut_cap = 0;  // cached 16-bit code tables: room for four new ones per frame of a call and 16 more
     // the last decode
     int last_n = 0, last_w = 0, last_h = 0, last_enc = 0, last_rounds = 0;
     std::vector<JpImage> last_imgs;
@@ -973,7 +971,7 @@ int jp_lut_slot(fid_jpeg_ctx *c, const JpHuffSpec &t, fid_status *rc)
     const unsigned long long h = jp_hash(t);
     auto it = c->lut_slot.find(h);
     if (it != c->lut_slot.end()) return it->second;
-    if (c->lut_next >= JP_MAX_LUT) {
+    if (c->lut_next >= c->lut_cap) {
         *rc = FID_E_UNSUPPORTED;
         c->last_error = "more distinct Huffman tables in one call than the table cache holds";
         return 0;
@@ -985,7 +983,13 @@ int jp_lut_slot(fid_jpeg_ctx *c, const JpHuffSpec &t, fid_status *rc)
     }
     const int slot = c->lut_next++;
     // (synchronous: the pinned staging table is reused for the next one)
-    if (hipMemcpy(c->d_luts + (size_t)slot * 65536, c->h_lut, 65536 * sizeof(uint16_t), hipMemcpyHostToDevice) != hipSuccess) {
+    uint16_t first_level[1 << JP_LOOK];
+    for (int q = 0; q < (1 << JP_LOOK); q++) {
+        const uint16_t e = c->h_lut[(size_t)q << (16 - JP_LOOK)];
+        first_level[q] = (e >> 8) <= JP_LOOK ? e : (uint16_t)0;
+    }
+    if (hipMemcpy(c->d_lut1 + (size_t)slot * (1 << JP_LOOK), first_level, sizeof(first_level), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(c->d_luts + (size_t)slot * 65536, c->h_lut, 65536 * sizeof(uint16_t), hipMemcpyHostToDevice) != hipSuccess) {
         *rc = FID_E_HIP;
         c->last_error = "upload of a code table failed";
         return 0;
@@ -1033,6 +1037,7 @@ fid_status fid_jpeg_create(int32_t device, int32_t max_width, int32_t max_height
     c->maxW = max_width;
     c->maxH = max_height;
     c->maxB = max_batch;
+    c->lut_cap = 16 + 4 * max_batch;
     const size_t F = (size_t)max_batch;
     const size_t mw = ((size_t)max_width + 15) / 16 * 16, mh = ((size_t)max_height + 15) / 16 * 16;
     c->max_blocks = mw * mh / 64 * 3;               // 4:4:4 is the largest
@@ -1042,7 +1047,8 @@ fid_status fid_jpeg_create(int32_t device, int32_t max_width, int32_t max_height
     ok = ok && hipMalloc((void **)&c->d_scan, F * c->max_scan + 64) == hipSuccess && hipMalloc((void **)&c->d_coefs, F * c->max_blocks * 64 * sizeof(int16_t)) == hipSuccess &&
          hipMalloc((void **)&c->d_planes, F * c->max_blocks * 64) == hipSuccess && hipMalloc((void **)&c->d_out, F * (size_t)max_width * max_height * 3) == hipSuccess &&
          hipMalloc((void **)&c->d_dcs, F * c->max_blocks * sizeof(int32_t)) == hipSuccess && hipMalloc((void **)&c->d_imgs, F * sizeof(JpImage)) == hipSuccess &&
-         hipMalloc((void **)&c->d_luts, (size_t)JP_MAX_LUT * 65536 * sizeof(uint16_t)) == hipSuccess &&
+         hipMalloc((void **)&c->d_luts, (size_t)c->lut_cap * 65536 * sizeof(uint16_t)) == hipSuccess &&
+         hipMalloc((void **)&c->d_lut1, (size_t)c->lut_cap * (1 << JP_LOOK) * sizeof(uint16_t)) == hipSuccess &&
          hipMalloc((void **)&c->d_state[0], F * c->max_sub * sizeof(JpState)) == hipSuccess && hipMalloc((void **)&c->d_state[1], F * c->max_sub * sizeof(JpState)) == hipSuccess &&
          hipMalloc((void **)&c->d_chg[0], F * c->max_sub) == hipSuccess && hipMalloc((void **)&c->d_chg[1], F * c->max_sub) == hipSuccess &&
          hipMalloc((void **)&c->d_nblk, F * c->max_sub * 4) == hipSuccess && hipMalloc((void **)&c->d_blkbase, F * c->max_sub * 4) == hipSuccess &&
@@ -1062,7 +1068,7 @@ void fid_jpeg_destroy(fid_jpeg_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    void *dev[] = {c->d_scan, c->d_coefs, c->d_planes, c->d_out, c->d_dcs, c->d_imgs, c->d_luts, c->d_state[0], c->d_state[1], c->d_chg[0], c->d_chg[1],
+    void *dev[] = {c->d_scan, c->d_coefs, c->d_planes, c->d_out, c->d_dcs, c->d_imgs, c->d_luts, c->d_lut1, c->d_state[0], c->d_state[1], c->d_chg[0], c->d_chg[1],
                    c->d_nblk, c->d_blkbase, c->d_flag};
     for (void *p : dev)
         if (p) (void)hipFree(p);
@@ -1081,7 +1087,7 @@ fid_status fid_jpeg_decode(fid_jpeg_ctx *c, const uint8_t *const *files, const i
     JPCHK(c, hipSetDevice(c->device));
     hipStream_t st = c->stream;
     c->last_n = 0;
-    if (c->lut_next > JP_MAX_LUT / 2) {  // a stream of files with ever new tables: start the cache again (between calls only)
+    if (c->lut_next + 4 * n > c->lut_cap) {  // a stream of files with ever new tables: start the cache again (between calls only)
         c->lut_slot.clear();
         c->lut_next = 0;
     }
@@ -1177,14 +1183,14 @@ fid_status fid_jpeg_decode(fid_jpeg_ctx *c, const uint8_t *const *files, const i
     JPCHK(c, hipMemsetAsync(c->d_coefs, 0, (size_t)n * c->max_blocks * 64 * sizeof(int16_t), st));
     // ---- J1: entropy decoding
     const dim3 hgrid((max_nsub + JP_OWN - 1) / JP_OWN, n);
-    hipLaunchKernelGGL(k_jpeg_huff<0>, hgrid, dim3(JP_TPB), 0, st, c->d_imgs, c->d_scan, c->d_luts, (const JpState *)nullptr, c->d_state[0], (const uint8_t *)nullptr,
+    hipLaunchKernelGGL(k_jpeg_huff<0>, hgrid, dim3(JP_TPB), 0, st, c->d_imgs, c->d_scan, c->d_luts, c->d_lut1, (const JpState *)nullptr, c->d_state[0], (const uint8_t *)nullptr,
                        c->d_chg[0], c->d_nblk, (const uint32_t *)nullptr, (int16_t *)nullptr, c->d_flag);
     int cur = 0, rounds = 0;
     for (;;) {
         // two rounds per look at the flag (a look costs a host round trip; a round in which nothing changes costs ~10 us)
         JPCHK(c, hipMemsetAsync(c->d_flag, 0, 8, st));
         for (int k = 0; k < 2; k++) {
-            hipLaunchKernelGGL(k_jpeg_huff<1>, hgrid, dim3(JP_TPB), 0, st, c->d_imgs, c->d_scan, c->d_luts, c->d_state[cur], c->d_state[cur ^ 1], c->d_chg[cur],
+            hipLaunchKernelGGL(k_jpeg_huff<1>, hgrid, dim3(JP_TPB), 0, st, c->d_imgs, c->d_scan, c->d_luts, c->d_lut1, c->d_state[cur], c->d_state[cur ^ 1], c->d_chg[cur],
                                c->d_chg[cur ^ 1], c->d_nblk, (const uint32_t *)nullptr, (int16_t *)nullptr, c->d_flag + k);
             cur ^= 1;
             rounds++;
@@ -1202,7 +1208,7 @@ fid_status fid_jpeg_decode(fid_jpeg_ctx *c, const uint8_t *const *files, const i
     }
     c->last_rounds = rounds;
     hipLaunchKernelGGL(k_jpeg_scan_blocks, dim3(n), dim3(1024), 0, st, c->d_imgs, c->d_nblk, c->d_blkbase);
-    hipLaunchKernelGGL(k_jpeg_huff<2>, hgrid, dim3(JP_TPB), 0, st, c->d_imgs, c->d_scan, c->d_luts, c->d_state[cur], (JpState *)nullptr, (const uint8_t *)nullptr,
+    hipLaunchKernelGGL(k_jpeg_huff<2>, hgrid, dim3(JP_TPB), 0, st, c->d_imgs, c->d_scan, c->d_luts, c->d_lut1, c->d_state[cur], (JpState *)nullptr, (const uint8_t *)nullptr,
                        (uint8_t *)nullptr, (uint32_t *)nullptr, c->d_blkbase, c->d_coefs, c->d_flag);
     // ---- J2 .. J4
     hipLaunchKernelGGL(k_jpeg_dc, dim3(3, n), dim3(1024), 0, st, c->d_imgs, c->d_coefs, c->d_dcs);

@@ -135,8 +135,10 @@ __global__ __launch_bounds__(256) void k_to_gray(const uint8_t *__restrict__ src
         if (enc == FID_ENC_MONO8) {
             v = s[x];
         } else {
-            int c0 = s[3 * x], c1 = s[3 * x + 1], c2 = s[3 * x + 2];
-            int b = enc == FID_ENC_BGR8 ? c0 : c2, r = enc == FID_ENC_BGR8 ? c2 : c0;
+            const int px = (enc == FID_ENC_BGRA8 || enc == FID_ENC_RGBA8) ? 4 : 3;  // (an alpha channel is dropped)
+            int c0 = s[px * x], c1 = s[px * x + 1], c2 = s[px * x + 2];
+            const bool bfirst = enc == FID_ENC_BGR8 || enc == FID_ENC_BGRA8;
+            int b = bfirst ? c0 : c2, r = bfirst ? c2 : c0;
             v = (uint8_t)((b * 3735 + c1 * 19235 + r * 9798 + (1 << 14)) >> 15);
         }
         dst[i] = v;

@@ -112,14 +112,14 @@ class ArucoDetector:
         return res
 
     def detect_markers(self, image: np.ndarray, encoding: str | None = None):
-        """One frame from host memory.  image: (H, W) uint8 mono8 or (H, W, 3) bgr8/rgb8 (default bgr8, the
+        """One frame from host memory.  image: (H, W) uint8 mono8, (H, W, 3) bgr8/rgb8 or (H, W, 4) bgra8/rgba8 (default bgr8, the
         encoding imageCallback requests from cv_bridge, :348).  Returns (corners, ids)."""
         img = np.asarray(image)
         if img.dtype != np.uint8 or img.ndim not in (2, 3):
             raise FidError(_lib.FID_E_INVALID_ARG, "image must be uint8 HxW or HxWx3")
         if encoding is None:
-            encoding = "mono8" if img.ndim == 2 else "bgr8"
-        if img.strides[-1] != 1 or (img.ndim == 3 and img.strides[1] != 3):
+            encoding = "mono8" if img.ndim == 2 else ("bgra8" if img.shape[2] == 4 else "bgr8")
+        if img.strides[-1] != 1 or (img.ndim == 3 and img.strides[1] != img.shape[2]):
             img = np.ascontiguousarray(img)
         h, w = img.shape[:2]
         rc = self._L.fid_detect(self._ctx, img.ctypes.data, w, h, img.strides[0], _lib.ENC[encoding], self._out,
@@ -140,7 +140,7 @@ class ArucoDetector:
     def detect_markers_device(self, data_ptr: int, nframes: int, width: int, height: int, stride: int | None = None,
                               frame_stride: int | None = None, encoding: str = "mono8", unpack: bool = True):
         """Frames already resident in HBM (e.g. a torch uint8 tensor's data_ptr() on this device)."""
-        bpp = 1 if encoding == "mono8" else 3
+        bpp = {"mono8": 1, "bgra8": 4, "rgba8": 4}.get(encoding, 3)
         stride = stride or width * bpp
         frame_stride = frame_stride or stride * height
         rc = self._L.fid_detect_device(self._ctx, C.c_void_p(data_ptr), nframes, width, height, stride, frame_stride,

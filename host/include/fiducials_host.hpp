@@ -24,7 +24,7 @@ struct Header {  // std_msgs/Header
 struct Image {  // sensor_msgs/Image
     Header header;
     uint32_t height = 0, width = 0;
-    std::string encoding;  // "mono8", "bgr8", "rgb8"
+    std::string encoding;  // "mono8", "bgr8", "rgb8", "bgra8", "rgba8"
     uint8_t is_bigendian = 0;
     uint32_t step = 0;
     std::vector<uint8_t> data;

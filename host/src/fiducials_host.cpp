@@ -292,6 +292,8 @@ bool FiducialsNode::imageCallback(const Image &msg, FiducialArray *out)
     if (msg.encoding == "mono8") enc = FID_ENC_MONO8;
     else if (msg.encoding == "bgr8") enc = FID_ENC_BGR8;
     else if (msg.encoding == "rgb8") enc = FID_ENC_RGB8;
+    else if (msg.encoding == "bgra8") enc = FID_ENC_BGRA8;
+    else if (msg.encoding == "rgba8") enc = FID_ENC_RGBA8;
     else {
         last_error = "cv_bridge exception: unsupported encoding " + msg.encoding;  // (:389-391)
         return false;

@@ -46,7 +46,9 @@ typedef enum fid_status {
 typedef enum fid_encoding {  /* sensor_msgs/Image encodings the node accepts via toCvCopy(BGR8) */
     FID_ENC_MONO8 = 0,
     FID_ENC_BGR8 = 1,
-    FID_ENC_RGB8 = 2
+    FID_ENC_RGB8 = 2,
+    FID_ENC_BGRA8 = 3, /* four bytes per pixel; toCvCopy(BGR8) drops the alpha channel (cvtColor BGRA2BGR / RGBA2BGR) */
+    FID_ENC_RGBA8 = 4
 } fid_encoding;
 
 /* aruco::DetectorParameters, fields and defaults as set by the node (aruco_detect.cpp:690-727) */

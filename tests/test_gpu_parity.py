@@ -168,6 +168,12 @@ def test_bgr_rgb_and_stride_inputs(det7):
     c_bgr, i_bgr = det7.detect_markers(np.ascontiguousarray(rgb[..., ::-1]), encoding="bgr8")
     assert i_rgb.tolist() == oids.tolist() == i_bgr.tolist() and len(oids) == 1
     assert np.array_equal(c_rgb, ocorners) and np.array_equal(c_bgr, ocorners)
+    # four-channel frames: toCvCopy(BGR8) drops the alpha channel
+    alpha = np.full((h, w, 1), 77, np.uint8)
+    c_a, i_a = det7.detect_markers(np.ascontiguousarray(np.concatenate([rgb, alpha], -1)), encoding="rgba8")
+    assert np.array_equal(det7.tap(_lib.TAP_GRAY).reshape(h, w), gray_o)
+    c_b, i_b = det7.detect_markers(np.ascontiguousarray(np.concatenate([rgb[..., ::-1], alpha], -1)), encoding="bgra8")
+    assert i_a.tolist() == oids.tolist() == i_b.tolist() and np.array_equal(c_a, ocorners) and np.array_equal(c_b, ocorners)
     padded = np.zeros((h, w + 37), dtype=np.uint8)
     padded[:, :w] = gray_o
     c_s, i_s = det7.detect_markers(padded[:, :w])

@@ -21,8 +21,9 @@
 //         <2> the same decode once more, now writing coefficients (sparse: the buffer was cleared).
 //       Byte stuffing (FF 00) and restart markers are handled by the bit reader on the fly, positions are raw bit offsets
 //       that never point into a stuffed byte (so equal logical positions compare equal).
-//   J2  k_jpeg_dc     DC prediction undone: prefix sums of the differences per component in scan order, restarted at every
-//                     restart interval
+//   J2  k_jpeg_scan   per sub-sequence: blocks completed before it and, per component, the DC value its first block continues
+//                     from (DC prediction: segmented prefix sums of the differences, segments = restart intervals) -- the
+//                     writing pass then stores absolute DC values straight away
 //   J3  k_jpeg_idct   dequantise + jidctint.c (13-bit constants, two passes), eight lanes per block, transposed through LDS
 //   J4  k_jpeg_color  jdsample.c fancy upsampling (h2v1 / h2v2, edge rows and columns as jdmainct.c replicates them) +
 //                     jdcolor.c YCbCr -> RGB, written as BGR (cv::imdecode) or straight as the gray image
@@ -39,7 +40,6 @@ struct JpImage {
     unsigned long long scan_off;   // into the packed scan bytes of the call
     unsigned long long coef_base;  // int16 units: this frame's coefficient area
     unsigned long long plane_base; // bytes: this frame's plane area
-    unsigned long long dcs_base;   // int32 units: this frame's DC scratch
     uint32_t scan_len, sub_base, nsub, nblocks;
     int32_t w, h, ncomp, hs, vs, bpm, mcux, nmcu, restart;
     int32_t bw[3], bh[3];
@@ -152,11 +152,12 @@ __device__ __forceinline__ bool operator!=(const JpState &a, const JpState &b) {
 template <int MODE>
 __global__ __launch_bounds__(JP_TPB) void k_jpeg_huff(const JpImage *__restrict__ imgs, const uint8_t *__restrict__ scan, const uint16_t *__restrict__ luts, const uint16_t *__restrict__ lut1,
                                                      const JpState *__restrict__ st_in, JpState *__restrict__ st_out,
-                                                     const uint8_t *__restrict__ chg_in, uint8_t *__restrict__ chg_out, uint32_t *__restrict__ nblk,
-                                                     const uint32_t *__restrict__ blkbase, int16_t *__restrict__ coefs, unsigned *__restrict__ any_changed)
+                                                     const uint8_t *__restrict__ chg_in, uint8_t *__restrict__ chg_out, int4 *__restrict__ nblk,
+                                                     const int4 *__restrict__ blkbase, int16_t *__restrict__ coefs, unsigned *__restrict__ any_changed)
 {
     __shared__ JpStage S;
     __shared__ uint16_t s_lut[4][1 << JP_LOOK];  // [dc luma, ac luma, dc chroma, ac chroma] first-level tables
+    __shared__ uint8_t s_zz[64];
     const JpImage &I = imgs[blockIdx.y];
     const uint32_t first = blockIdx.x * JP_OWN;
     if (first >= I.nsub) return;
@@ -185,6 +186,7 @@ __global__ __launch_bounds__(JP_TPB) void k_jpeg_huff(const JpImage *__restrict_
         s_lut[t][q] = lut1[(size_t)slot[t] * (1 << JP_LOOK) + q];
     }
     for (int k = tid; k < JP_NSTG * JP_SUB / 32 + 2; k += JP_TPB) S.bnd[k] = 0u;
+    if (MODE == 2 && tid < 64) s_zz[tid] = c_jp_zigzag[tid];
     if (tid == 0) S.end = 0xffffffffu;
     // ---- unstuff: sub-sequences first .. first + nstg - 1 (the last one only serves the lane in front of it)
     const uint32_t nstg = (I.nsub - first) >= JP_NSTG ? JP_NSTG : (I.nsub - first);
@@ -351,12 +353,21 @@ __global__ __launch_bounds__(JP_TPB) void k_jpeg_huff(const JpImage *__restrict_
         cblk = coefs + I.coef_base + I.coef_off[comp] + ((size_t)(my * vsc + v) * I.bw[comp] + (mx * hsc + h)) * 64;
     };
     if (MODE == 2) {
-        B = blkbase[gsub];
+        B = (uint32_t)blkbase[gsub].x;
         const uint32_t m = B / (uint32_t)I.bpm;
         // (for a sound file B mod bpm == c; a damaged one may disagree: the entry state decides the tables, B the place)
         mx = m % (uint32_t)I.mcux;
         my = m / (uint32_t)I.mcux;
         bind_block();
+    }
+    // DC prediction: the decoding passes sum the differences per component (since the last restart marker this lane met), the
+    // writing pass starts from what the scan made of those sums and stores absolute values
+    int dc0 = 0, dc1 = 0, dc2 = 0, had_reset = 0;
+    if (MODE == 2) {
+        const int4 bb = blkbase[gsub];
+        dc0 = bb.y;
+        dc1 = bb.z;
+        dc2 = bb.w;
     }
     uint32_t p_exit_c = entry_bit;  // packed bit position where this lane stops
     if (!eoi) {
@@ -385,6 +396,8 @@ __global__ __launch_bounds__(JP_TPB) void k_jpeg_huff(const JpImage *__restrict_
                     }
                     c = 0;
                     z = 0;
+                    dc0 = dc1 = dc2 = 0;  // (the prediction starts from zero behind a restart marker)
+                    had_reset = 1;
                     bind_block();
                     const uint32_t at = Mb;
                     Mb = next_boundary(at + 1u);
@@ -414,9 +427,16 @@ __global__ __launch_bounds__(JP_TPB) void k_jpeg_huff(const JpImage *__restrict_
             const int raw = sz ? (int)R.peek(sz) : 0;
             R.drop(sz);
             const int val = (sz && raw < (1 << (sz - 1))) ? raw - (1 << sz) + 1 : raw;
+            int dcv = 0;
+            if (isdc) {
+                dc0 += comp == 0 ? val : 0;
+                dc1 += comp == 1 ? val : 0;
+                dc2 += comp == 2 ? val : 0;
+                dcv = comp == 0 ? dc0 : (comp == 1 ? dc1 : dc2);
+            }
             const int zi = isdc ? 0 : z + r;  // where the value goes (zig-zag order)
             const bool has = isdc || sz != 0;
-            if (MODE == 2 && has && zi < 64 && cblk) cblk[c_jp_zigzag[zi]] = (int16_t)val;
+            if (MODE == 2 && has && zi < 64 && cblk) cblk[s_zz[zi]] = (int16_t)(isdc ? dcv : val);
             z = isdc ? 1 : (sz ? (zi < 64 ? zi + 1 : 64) : (r == 15 ? z + 16 : 64));
             if (z >= 64) {
                 z = 0;
@@ -441,7 +461,7 @@ __global__ __launch_bounds__(JP_TPB) void k_jpeg_huff(const JpImage *__restrict_
         o.p = eoi ? e.p : (s_lo + jp_cmp_to_raw(S, p_exit_c >> 3, tid, nstg)) * 8u + (p_exit_c & 7u);
         if (eoi && !((e.cz >> 16) & 1u)) o.p = (s_lo + jp_cmp_to_raw(S, p_exit_c >> 3, tid, nstg)) * 8u;
         o.cz = (uint32_t)c | ((uint32_t)z << 8) | (eoi ? 1u << 16 : 0u);
-        nblk[gsub] = done;
+        nblk[gsub] = make_int4((int)(done | (had_reset ? 0x80000000u : 0u)), dc0, dc1, dc2);
         if (MODE == 0) {
             st_out[gsub] = o;
             chg_out[gsub] = 1;
@@ -454,104 +474,84 @@ __global__ __launch_bounds__(JP_TPB) void k_jpeg_huff(const JpImage *__restrict_
     }
 }
 
-// blocks completed before each sub-sequence: exclusive scan per image (one workgroup per image, 8 items per lane)
-__global__ __launch_bounds__(1024) void k_jpeg_scan_blocks(const JpImage *__restrict__ imgs, const uint32_t *__restrict__ nblk, uint32_t *__restrict__ blkbase)
+// What every sub-sequence starts from: blocks completed before it (a plain exclusive scan) and the DC predictions it
+// continues (per component: the sum of the differences since the last restart marker -- a SEGMENTED scan: an element that met
+// a restart marker starts the sums afresh).  One workgroup per image, 8 items per lane, the operator through shuffles.
+struct JpSeg {
+    int n, f, s0, s1, s2;
+};
+__device__ __forceinline__ JpSeg jp_seg_combine(const JpSeg &a, const JpSeg &b)
 {
-    __shared__ int s_w[16];
+    JpSeg r;
+    r.n = a.n + b.n;
+    r.f = a.f | b.f;
+    r.s0 = b.f ? b.s0 : a.s0 + b.s0;
+    r.s1 = b.f ? b.s1 : a.s1 + b.s1;
+    r.s2 = b.f ? b.s2 : a.s2 + b.s2;
+    return r;
+}
+__device__ __forceinline__ JpSeg jp_seg_shfl_up(const JpSeg &v, int d)
+{
+    JpSeg o;
+    o.n = __shfl_up(v.n, d, 64);
+    o.f = __shfl_up(v.f, d, 64);
+    o.s0 = __shfl_up(v.s0, d, 64);
+    o.s1 = __shfl_up(v.s1, d, 64);
+    o.s2 = __shfl_up(v.s2, d, 64);
+    return o;
+}
+__global__ __launch_bounds__(1024) void k_jpeg_scan_blocks(const JpImage *__restrict__ imgs, const int4 *__restrict__ nblk, int4 *__restrict__ blkbase)
+{
+    __shared__ JpSeg s_w[16];
     const JpImage &I = imgs[blockIdx.x];
-    const uint32_t *in = nblk + I.sub_base;
-    uint32_t *out = blkbase + I.sub_base;
+    const int4 *in = nblk + I.sub_base;
+    int4 *out = blkbase + I.sub_base;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = (int)I.nsub;
     constexpr int PER = 8;
-    int carry = 0;
+    const JpSeg zero = {0, 0, 0, 0, 0};
+    JpSeg carry = zero;
     for (int base = 0; base < n; base += 1024 * PER) {
         const int i0 = base + tid * PER;
-        int v[PER], sum = 0;
+        JpSeg pre[PER], acc = zero;
 #pragma unroll
         for (int k = 0; k < PER; k++) {
-            v[k] = i0 + k < n ? (int)in[i0 + k] : 0;
-            sum += v[k];
+            pre[k] = acc;
+            JpSeg it = zero;
+            if (i0 + k < n) {
+                const int4 v = in[i0 + k];
+                it.n = v.x & 0x7fffffff;
+                it.f = (v.x >> 31) & 1;
+                it.s0 = v.y;
+                it.s1 = v.z;
+                it.s2 = v.w;
+            }
+            acc = jp_seg_combine(acc, it);
         }
-        const int incl = wave_iscan(sum);
+        JpSeg incl = acc;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const JpSeg o = jp_seg_shfl_up(incl, d);
+            if (lane >= d) incl = jp_seg_combine(o, incl);
+        }
         if (lane == 63) s_w[wv] = incl;
         __syncthreads();
-        int wbase = 0, tot = 0;
-#pragma unroll
+        JpSeg wpre = zero, tot = zero;
         for (int k = 0; k < 16; k++) {
-            const int t = s_w[k];
-            wbase += k < wv ? t : 0;
-            tot += t;
+            if (k == wv) wpre = tot;
+            tot = jp_seg_combine(tot, s_w[k]);
         }
-        int run = carry + wbase + incl - sum;
+        JpSeg lex = jp_seg_shfl_up(incl, 1);
+        if (lane == 0) lex = zero;
+        const JpSeg mine = jp_seg_combine(carry, jp_seg_combine(wpre, lex));
 #pragma unroll
         for (int k = 0; k < PER; k++) {
-            if (i0 + k < n) out[i0 + k] = (uint32_t)run;
-            run += v[k];
+            if (i0 + k < n) {
+                const JpSeg o = jp_seg_combine(mine, pre[k]);
+                out[i0 + k] = make_int4(o.n, o.s0, o.s1, o.s2);
+            }
         }
-        carry += tot;
+        carry = jp_seg_combine(carry, tot);
         __syncthreads();
-    }
-}
-
-// DC prediction: coefficient 0 of every block holds the difference to the previous block of its component (scan order);
-// prefix sums per component, starting afresh at every restart interval.  One workgroup per (component, image).
-__global__ __launch_bounds__(1024) void k_jpeg_dc(const JpImage *__restrict__ imgs, int16_t *__restrict__ coefs, int32_t *__restrict__ dcs)
-{
-    __shared__ int s_w[16];
-    const JpImage &I = imgs[blockIdx.y];
-    const int comp = blockIdx.x;
-    if (comp >= I.ncomp) return;
-    const int hsc = comp == 0 ? I.hs : 1, vsc = comp == 0 ? I.vs : 1, nbc = hsc * vsc;
-    const int T = I.nmcu * nbc;
-    int16_t *cf = coefs + I.coef_base + I.coef_off[comp];
-    int32_t *S = dcs + I.dcs_base + (comp == 0 ? 0 : (size_t)I.nmcu * I.hs * I.vs + (size_t)(comp - 1) * I.nmcu);
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    auto block_of = [&](int t) -> size_t {
-        const int m = t / nbc, j = t - m * nbc;
-        const int v = j / hsc, h = j - v * hsc;
-        const int bx = (m % I.mcux) * hsc + h, by = (m / I.mcux) * vsc + v;
-        return ((size_t)by * I.bw[comp] + bx) * 64;
-    };
-    constexpr int PER = 8;
-    int carry = 0;
-    for (int base = 0; base < T; base += 1024 * PER) {
-        const int i0 = base + tid * PER;
-        int v[PER], sum = 0;
-#pragma unroll
-        for (int k = 0; k < PER; k++) {
-            v[k] = i0 + k < T ? (int)cf[block_of(i0 + k)] : 0;
-            sum += v[k];
-        }
-        const int incl = wave_iscan(sum);
-        if (lane == 63) s_w[wv] = incl;
-        __syncthreads();
-        int wbase = 0, tot = 0;
-#pragma unroll
-        for (int k = 0; k < 16; k++) {
-            const int t = s_w[k];
-            wbase += k < wv ? t : 0;
-            tot += t;
-        }
-        int run = carry + wbase + incl - sum;
-#pragma unroll
-        for (int k = 0; k < PER; k++) {
-            run += v[k];
-            if (i0 + k < T) S[i0 + k] = run;  // inclusive
-        }
-        carry += tot;
-        __syncthreads();
-    }
-    __threadfence_block();
-    __syncthreads();
-    // second pass: subtract what had accumulated before the block's restart interval began
-    const int seg = I.restart > 0 ? I.restart * nbc : 0;
-    for (int t = tid; t < T; t += 1024) {
-        int dc = S[t];
-        if (seg) {
-            const int s0 = (t / seg) * seg;
-            if (s0 > 0) dc -= S[s0 - 1];
-        }
-        cf[block_of(t)] = (int16_t)dc;
     }
 }
 
@@ -936,12 +936,11 @@ struct fid_jpeg_ctx {
     // device
     uint8_t *d_scan = nullptr, *d_planes = nullptr, *d_out = nullptr;
     int16_t *d_coefs = nullptr;
-    int32_t *d_dcs = nullptr;
     JpImage *d_imgs = nullptr;
     uint16_t *d_luts = nullptr, *d_lut1 = nullptr;  // 16-bit code tables; their first-level (JP_LOOK bit) extracts, contiguous
     JpState *d_state[2] = {nullptr, nullptr};
     uint8_t *d_chg[2] = {nullptr, nullptr};
-    uint32_t *d_nblk = nullptr, *d_blkbase = nullptr;
+    int4 *d_nblk = nullptr, *d_blkbase = nullptr;  // per sub-sequence: blocks completed | met a restart marker, DC sums / what it starts from
     unsigned *d_flag = nullptr;
     // pinned host
     uint8_t *h_scan = nullptr;
@@ -1046,12 +1045,12 @@ fid_status fid_jpeg_create(int32_t device, int32_t max_width, int32_t max_height
     bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
     ok = ok && hipMalloc((void **)&c->d_scan, F * c->max_scan + 64) == hipSuccess && hipMalloc((void **)&c->d_coefs, F * c->max_blocks * 64 * sizeof(int16_t)) == hipSuccess &&
          hipMalloc((void **)&c->d_planes, F * c->max_blocks * 64) == hipSuccess && hipMalloc((void **)&c->d_out, F * (size_t)max_width * max_height * 3) == hipSuccess &&
-         hipMalloc((void **)&c->d_dcs, F * c->max_blocks * sizeof(int32_t)) == hipSuccess && hipMalloc((void **)&c->d_imgs, F * sizeof(JpImage)) == hipSuccess &&
+         hipMalloc((void **)&c->d_imgs, F * sizeof(JpImage)) == hipSuccess &&
          hipMalloc((void **)&c->d_luts, (size_t)c->lut_cap * 65536 * sizeof(uint16_t)) == hipSuccess &&
          hipMalloc((void **)&c->d_lut1, (size_t)c->lut_cap * (1 << JP_LOOK) * sizeof(uint16_t)) == hipSuccess &&
          hipMalloc((void **)&c->d_state[0], F * c->max_sub * sizeof(JpState)) == hipSuccess && hipMalloc((void **)&c->d_state[1], F * c->max_sub * sizeof(JpState)) == hipSuccess &&
          hipMalloc((void **)&c->d_chg[0], F * c->max_sub) == hipSuccess && hipMalloc((void **)&c->d_chg[1], F * c->max_sub) == hipSuccess &&
-         hipMalloc((void **)&c->d_nblk, F * c->max_sub * 4) == hipSuccess && hipMalloc((void **)&c->d_blkbase, F * c->max_sub * 4) == hipSuccess &&
+         hipMalloc((void **)&c->d_nblk, F * c->max_sub * sizeof(int4)) == hipSuccess && hipMalloc((void **)&c->d_blkbase, F * c->max_sub * sizeof(int4)) == hipSuccess &&
          hipMalloc((void **)&c->d_flag, 8) == hipSuccess;
     ok = ok && hipHostMalloc((void **)&c->h_scan, F * c->max_scan + 64) == hipSuccess && hipHostMalloc((void **)&c->h_imgs, F * sizeof(JpImage)) == hipSuccess &&
          hipHostMalloc((void **)&c->h_flag, 8) == hipSuccess && hipHostMalloc((void **)&c->h_lut, 65536 * sizeof(uint16_t)) == hipSuccess;
@@ -1068,7 +1067,7 @@ void fid_jpeg_destroy(fid_jpeg_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    void *dev[] = {c->d_scan, c->d_coefs, c->d_planes, c->d_out, c->d_dcs, c->d_imgs, c->d_luts, c->d_lut1, c->d_state[0], c->d_state[1], c->d_chg[0], c->d_chg[1],
+    void *dev[] = {c->d_scan, c->d_coefs, c->d_planes, c->d_out, c->d_imgs, c->d_luts, c->d_lut1, c->d_state[0], c->d_state[1], c->d_chg[0], c->d_chg[1],
                    c->d_nblk, c->d_blkbase, c->d_flag};
     for (void *p : dev)
         if (p) (void)hipFree(p);
@@ -1148,7 +1147,6 @@ fid_status fid_jpeg_decode(fid_jpeg_ctx *c, const uint8_t *const *files, const i
         I.nblocks = (uint32_t)I.nmcu * (uint32_t)I.bpm;
         I.coef_base = (unsigned long long)f * c->max_blocks * 64;
         I.plane_base = (unsigned long long)f * c->max_blocks * 64;
-        I.dcs_base = (unsigned long long)f * c->max_blocks;
         I.scan_off = scan_at;
         I.scan_len = (uint32_t)H.scan_len;
         I.sub_base = (uint32_t)sub_at;
@@ -1184,14 +1182,14 @@ fid_status fid_jpeg_decode(fid_jpeg_ctx *c, const uint8_t *const *files, const i
     // ---- J1: entropy decoding
     const dim3 hgrid((max_nsub + JP_OWN - 1) / JP_OWN, n);
     hipLaunchKernelGGL(k_jpeg_huff<0>, hgrid, dim3(JP_TPB), 0, st, c->d_imgs, c->d_scan, c->d_luts, c->d_lut1, (const JpState *)nullptr, c->d_state[0], (const uint8_t *)nullptr,
-                       c->d_chg[0], c->d_nblk, (const uint32_t *)nullptr, (int16_t *)nullptr, c->d_flag);
+                       c->d_chg[0], c->d_nblk, (const int4 *)nullptr, (int16_t *)nullptr, c->d_flag);
     int cur = 0, rounds = 0;
     for (;;) {
         // two rounds per look at the flag (a look costs a host round trip; a round in which nothing changes costs ~10 us)
         JPCHK(c, hipMemsetAsync(c->d_flag, 0, 8, st));
         for (int k = 0; k < 2; k++) {
             hipLaunchKernelGGL(k_jpeg_huff<1>, hgrid, dim3(JP_TPB), 0, st, c->d_imgs, c->d_scan, c->d_luts, c->d_lut1, c->d_state[cur], c->d_state[cur ^ 1], c->d_chg[cur],
-                               c->d_chg[cur ^ 1], c->d_nblk, (const uint32_t *)nullptr, (int16_t *)nullptr, c->d_flag + k);
+                               c->d_chg[cur ^ 1], c->d_nblk, (const int4 *)nullptr, (int16_t *)nullptr, c->d_flag + k);
             cur ^= 1;
             rounds++;
         }
@@ -1209,9 +1207,8 @@ fid_status fid_jpeg_decode(fid_jpeg_ctx *c, const uint8_t *const *files, const i
     c->last_rounds = rounds;
     hipLaunchKernelGGL(k_jpeg_scan_blocks, dim3(n), dim3(1024), 0, st, c->d_imgs, c->d_nblk, c->d_blkbase);
     hipLaunchKernelGGL(k_jpeg_huff<2>, hgrid, dim3(JP_TPB), 0, st, c->d_imgs, c->d_scan, c->d_luts, c->d_lut1, c->d_state[cur], (JpState *)nullptr, (const uint8_t *)nullptr,
-                       (uint8_t *)nullptr, (uint32_t *)nullptr, c->d_blkbase, c->d_coefs, c->d_flag);
+                       (uint8_t *)nullptr, (int4 *)nullptr, c->d_blkbase, c->d_coefs, c->d_flag);
     // ---- J2 .. J4
-    hipLaunchKernelGGL(k_jpeg_dc, dim3(3, n), dim3(1024), 0, st, c->d_imgs, c->d_coefs, c->d_dcs);
     hipLaunchKernelGGL(k_jpeg_idct, dim3((max_blocks + 31) / 32, n), dim3(256), 0, st, c->d_imgs, c->d_coefs, c->d_planes);
     const int bpp = out_enc == FID_ENC_MONO8 ? 1 : 3;
     const long long fstride = (long long)W * Hh * bpp;

@@ -11,6 +11,10 @@
  *        replaces  FiducialsNode::estimatePoseSingleMarkers (cv::solvePnP per marker, :223-255,
  *        call :247), getReprojectionError (cv::projectPoints, :203-221), calcFiducialArea
  *        (:179-200) and the object_error formula (:455-457,:493-495)
+ *   fid_jpeg_decode
+ *        replaces  cv::imdecode in image_transport's compressed subscriber, in front of the callback when
+ *        the node runs with the launch default transport:=compressed (aruco_detect.launch:6)
+ *   fid_stag_*   the second front end: Stag::detectMarkers + the 5-point pose of stag_detect
  *   fid_params   mirrors aruco::DetectorParameters as the node fills it      (:690-727)
  *   fid_dict     mirrors aruco::Dictionary{bytesList, markerSize, maxCorrectionBits} as returned
  *                by aruco::getPredefinedDictionary(dicno)                     (:671)

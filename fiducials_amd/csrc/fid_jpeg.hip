@@ -1040,7 +1040,7 @@ fid_status fid_jpeg_create(int32_t device, int32_t max_width, int32_t max_height
     const size_t F = (size_t)max_batch;
     const size_t mw = ((size_t)max_width + 15) / 16 * 16, mh = ((size_t)max_height + 15) / 16 * 16;
     c->max_blocks = mw * mh / 64 * 3;               // 4:4:4 is the largest
-    c->max_scan = (size_t)max_width * max_height * 2 + 4096;  // entropy-coded bytes per image this context takes
+    c->max_scan = mw * mh * 2 + 65536;              // entropy-coded bytes per image this context takes (MCU-padded size: narrow images too)
     c->max_sub = (c->max_scan + JP_SUB - 1) / JP_SUB;
     bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
     ok = ok && hipMalloc((void **)&c->d_scan, F * c->max_scan + 64) == hipSuccess && hipMalloc((void **)&c->d_coefs, F * c->max_blocks * 64 * sizeof(int16_t)) == hipSuccess &&

@@ -28,7 +28,7 @@ if ROOT not in sys.path:
 
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 os.environ.setdefault("FID_PROFILE", "1")  # per-stage hipEvents on the context stream
-# the STag side result keeps 16 contexts (streams) in flight: with the runtime's default of 4 hardware queues their kernels
+# the STag side result keeps 22 contexts (streams) in flight: with the runtime's default of 4 hardware queues their kernels
 # queue up behind one another (measured 570 -> 1070 frames/s with 24 queues; the aruco path does not care).  Must be set
 # before the HIP runtime starts.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
@@ -318,7 +318,7 @@ def stag_side_result(local_rank, args):
     REFERENCE's own Stag::detectMarkers on one host core next to it."""
     from fiducials_amd import stag as fstag, synth
 
-    hd, ec, B, T = 21, 7, 64, 16
+    hd, ec, B, T = 21, 7, 66, 22
     words = fstag.load_library(hd)
     frames = [synth.make_stag_frame(words, sd, W, H, MARKERS).image for sd in shard_seeds(0, 1, 4, "stag")]
     pool = fstag.StagPool(hd, ec, n_contexts=T, max_width=W, max_height=H, device=local_rank)
@@ -372,7 +372,7 @@ def main_stag(args):
     dist = init_dist(world, local_rank)
     from fiducials_amd import stag as fstag, synth
 
-    hd, ec, B = 21, 7, min(args.batch, 64)
+    hd, ec, B = 21, 7, min(args.batch, 88)
     words = fstag.load_library(hd)
     frames = [synth.make_stag_frame(words, sd, W, H, MARKERS).image for sd in shard_seeds(rank, world, min(B, 4), "stag")]
     # several contexts side by side (fid_stag_detect_markers_batch: one host thread + one HIP stream per context inside the
@@ -543,7 +543,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the cfg 2 latency and cfg 5 (STag) side results")
     ap.add_argument("--stag-side-child", action="store_true", help=argparse.SUPPRESS)  # the cfg 5 side result, own process
-    ap.add_argument("--streams", type=int, default=16, help="stag workload: concurrent contexts (host threads) per GPU")
+    ap.add_argument("--streams", type=int, default=22, help="stag workload: concurrent contexts (host threads) per GPU")
     ap.add_argument("--workload", choices=["aruco", "stag"], default="aruco",
                     help="aruco = the BASELINE.json metric (default); stag = BASELINE cfg 5, the stag_detect path")
     args = ap.parse_args()

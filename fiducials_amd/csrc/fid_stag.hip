@@ -391,6 +391,7 @@ struct fid_stag_ctx {
     int rcount[3] = {0, 0, 0};
     bool routed = false;
     // component-parallel routing
+    int4 *d_cbox = nullptr;  // per root: bounding box of the component's pixels
     int *d_label = nullptr, *d_csize = nullptr, *d_canch = nullptr, *d_cidmap = nullptr, *d_cursors = nullptr, *d_caps = nullptr;
     int *d_fill = nullptr, *d_aslots = nullptr, *d_prodflag = nullptr, *d_next = nullptr, *d_blkpix = nullptr, *d_blksegs = nullptr;
     int2 *d_blkwhere = nullptr, *d_apix = nullptr, *d_aout = nullptr, *d_asegs = nullptr;
@@ -489,7 +490,7 @@ fid_status fid_stag_create(int libraryHD, int errorCorrection, int max_width, in
     c->max_comps = (int)(n / 8 + 64);
     c->cap_aslots = (int)(n / 2 + 64);
     ok = ok && hipMalloc((void **)&c->d_label, n * 4) == hipSuccess && hipMalloc((void **)&c->d_csize, n * 4) == hipSuccess &&
-         hipMalloc((void **)&c->d_canch, n * 4) == hipSuccess && hipMalloc((void **)&c->d_cidmap, n * 4) == hipSuccess &&
+         hipMalloc((void **)&c->d_canch, n * 4) == hipSuccess && hipMalloc((void **)&c->d_cidmap, n * 4) == hipSuccess && hipMalloc((void **)&c->d_cbox, n * sizeof(int4)) == hipSuccess &&
          hipMalloc((void **)&c->d_cursors, 64) == hipSuccess && hipMalloc((void **)&c->d_caps, 64) == hipSuccess &&
          hipMalloc((void **)&c->d_fill, (size_t)c->max_comps * 4) == hipSuccess && hipMalloc((void **)&c->d_aslots, (size_t)c->cap_aslots * 4) == hipSuccess &&
          hipMalloc((void **)&c->d_prodflag, n * 4) == hipSuccess && hipMalloc((void **)&c->d_next, n * 4) == hipSuccess &&
@@ -559,7 +560,7 @@ void fid_stag_destroy(fid_stag_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void *dev[] = {c->d_src, c->d_smooth, c->d_dir, c->d_edge, c->d_grad, c->d_sorted, c->d_rowhist, c->d_bandhist, c->d_tot, c->d_bstart, c->d_n,
                    c->d_edgeimg, c->d_rpix, c->d_outpix, c->d_segs, c->d_rstack, c->d_chains, c->d_chainnos, c->d_rcount,
-                   c->d_label, c->d_csize, c->d_canch, c->d_cidmap, c->d_cursors, c->d_caps, c->d_fill, c->d_aslots, c->d_prodflag, c->d_next,
+                   c->d_label, c->d_csize, c->d_canch, c->d_cbox, c->d_cidmap, c->d_cursors, c->d_caps, c->d_fill, c->d_aslots, c->d_prodflag, c->d_next,
                    c->d_blkpix, c->d_blksegs, c->d_blkwhere, c->d_apix, c->d_aout, c->d_asegs, c->d_astack, c->d_achains, c->d_comps, c->d_recs,
                    c->d_smooth2, c->d_vgrad, c->d_vhist, c->d_prob, c->d_np, c->d_vcounts, c->d_vtotal, c->d_vstack, c->d_vsegs,
                    c->d_prefix, c->d_lslots, c->d_lines, c->d_lcounts, c->d_ltotal,
@@ -725,16 +726,15 @@ static fid_status stag_advance_impl(fid_stag_ctx *c, StagJob &j)
         if (!ok) return stag_finish(j, FID_E_HIP);
         {
             const dim3 tiles((W + CCL_TW - 1) / CCL_TW, (H + CCL_TH - 1) / CCL_TH);
-            hipLaunchKernelGGL(k_stag_ccl_tile, tiles, dim3(256), 0, st, c->d_grad, W, H, 16, c->d_label, c->d_csize, c->d_canch);
+            hipLaunchKernelGGL(k_stag_ccl_tile, tiles, dim3(256), 0, st, c->d_grad, W, H, 16, c->d_label, c->d_csize, c->d_canch, c->d_cbox);
             hipLaunchKernelGGL(k_stag_ccl_border, tiles, dim3(128), 0, st, W, H, c->d_label);
         }
-        hipLaunchKernelGGL(k_stag_ccl_flatten, dim3(nb), dim3(256), 0, st, n, c->d_label, c->d_edge, c->d_csize, c->d_canch);
-        hipLaunchKernelGGL(k_stag_comp_alloc, dim3(nb), dim3(256), 0, st, n, c->d_label, c->d_csize, c->d_canch, c->d_cursors, c->max_comps, c->d_caps,
+        hipLaunchKernelGGL(k_stag_ccl_flatten, dim3(nb), dim3(256), 0, st, n, W, c->d_label, c->d_edge, c->d_csize, c->d_canch, c->d_cbox);
+        hipLaunchKernelGGL(k_stag_comp_alloc, dim3(nb), dim3(256), 0, st, n, c->d_label, c->d_csize, c->d_canch, c->d_cbox, c->d_cursors, c->max_comps, c->d_caps,
                            c->d_comps, c->d_cidmap);
         hipLaunchKernelGGL(k_stag_comp_fill, dim3((na + 255) / 256), dim3(256), 0, st, c->d_sorted, c->d_n, c->d_label, c->d_cidmap, c->d_comps, c->d_fill,
                            c->d_aslots);
         const int LDS_CAP = 150 * 1024;  // of the 160 KB of a CU
-        hipLaunchKernelGGL(k_stag_comp_bbox, dim3(nb), dim3(256), 0, st, W, n, c->d_label, c->d_cidmap, c->d_comps);
         hipLaunchKernelGGL(k_stag_comp_tilemax, dim3((c->max_comps + 255) / 256), dim3(256), 0, st, c->d_comps, c->d_cursors, LDS_CAP);
         if (hipGetLastError() != hipSuccess) return stag_finish(j, FID_E_HIP);
         if (hipMemcpyAsync(c->hp->cur, c->d_cursors, 44, hipMemcpyDeviceToHost, st) != hipSuccess) return stag_finish(j, FID_E_HIP);

@@ -522,7 +522,7 @@ __device__ __forceinline__ void ccl_union(int *L, int a, int b)
 }
 
 __global__ __launch_bounds__(256) void k_stag_ccl_tile(const int16_t *__restrict__ grad, int W, int H, int thresh, int *__restrict__ label,
-                                                       int *__restrict__ csize, int *__restrict__ canch)
+                                                       int *__restrict__ csize, int *__restrict__ canch, int4 *__restrict__ cbox)
 {
     __shared__ int L[CCL_TW * CCL_TH];
     const int x0 = blockIdx.x * CCL_TW, y0 = blockIdx.y * CCL_TH;
@@ -533,6 +533,7 @@ __global__ __launch_bounds__(256) void k_stag_ccl_tile(const int16_t *__restrict
         if (fg) {  // a root is a foreground pixel: the per-root counters only have to be clean there
             csize[y * W + x] = 0;
             canch[y * W + x] = 0;
+            cbox[y * W + x] = make_int4(0x7fffffff, 0x7fffffff, -1, -1);  // min row, min column, max row, max column
         }
     }
     __syncthreads();
@@ -586,26 +587,53 @@ __global__ __launch_bounds__(128) void k_stag_ccl_border(int W, int H, int *labe
     if (left && lx == 0 && label[i - 1] >= 0) ccl_union(label, i, i - 1);
 }
 
-__global__ __launch_bounds__(256) void k_stag_ccl_flatten(int n, int *label, const uint8_t *__restrict__ anchors, int *__restrict__ csize,
-                                                          int *__restrict__ canch)
+__global__ __launch_bounds__(256) void k_stag_ccl_flatten(int n, int W, int *label, const uint8_t *__restrict__ anchors, int *__restrict__ csize,
+                                                          int *__restrict__ canch, int4 *__restrict__ cbox)
 {
     const int i = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63;
     int root = -1;
     bool anch = false;
+    const int r = i / W, c = i - r * W;
     if (i < n && label[i] >= 0) {
         root = ccl_find(label, i);
         label[i] = root;
         anch = anchors[i] == STAG_ANCHOR_PIXEL;
     }
-    // pixels and anchors per root: one pair of atomics per (wave, root) -- 64 consecutive pixels share very few roots
+    // pixels, anchors and bounding box per root: one set of atomics per (wave, root) -- 64 consecutive pixels share very few
+    // roots.  (The boxes used to be a pass of their own over all pixels: 52 us of the whole GPU per frame.)
     unsigned long long pending = __ballot(root >= 0);
     while (pending) {
         const int lead = __builtin_ctzll(pending);
         const int r0 = __builtin_amdgcn_readlane(root, lead);
-        const unsigned long long m = __ballot(root == r0), ma = __ballot(root == r0 && anch);
+        const bool mine = root == r0;
+        const unsigned long long m = __ballot(mine), ma = __ballot(mine && anch);
+        const int lfirst = __builtin_ctzll(m), llast = 63 - __builtin_clzll(m);
+        const int rfirst = __builtin_amdgcn_readlane(r, lfirst), rlast = __builtin_amdgcn_readlane(r, llast);
+        int mnr, mnc, mxr, mxc;
+        if (rfirst == rlast) {  // the group lies in one image row (always, when the width is a multiple of 64)
+            mnr = mxr = rfirst;
+            mnc = __builtin_amdgcn_readlane(c, lfirst);
+            mxc = __builtin_amdgcn_readlane(c, llast);
+        } else {
+            mnr = mine ? r : 0x7fffffff; mnc = mine ? c : 0x7fffffff; mxr = mine ? r : -1; mxc = mine ? c : -1;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                mnr = min(mnr, __shfl_xor(mnr, off, 64));
+                mnc = min(mnc, __shfl_xor(mnc, off, 64));
+                mxr = max(mxr, __shfl_xor(mxr, off, 64));
+                mxc = max(mxc, __shfl_xor(mxc, off, 64));
+            }
+        }
         if (lane == lead) {
             atomicAdd(&csize[r0], (int)__builtin_popcountll(m));
             if (ma) atomicAdd(&canch[r0], (int)__builtin_popcountll(ma));
+            // (looking at the box first and skipping atomics that would not extend it was tried: the look is a round trip
+            //  inside this loop, 60 -> 107 us)
+            int *bx = reinterpret_cast<int *>(cbox + r0);
+            atomicMin(bx + 0, mnr);
+            atomicMin(bx + 1, mnc);
+            atomicMax(bx + 2, mxr);
+            atomicMax(bx + 3, mxc);
         }
         pending &= ~m;
     }
@@ -614,8 +642,8 @@ __global__ __launch_bounds__(256) void k_stag_ccl_flatten(int n, int *label, con
 // cursors: [0] components [1] anchor slots [2] scratch pixels [3] stack [4] chains [5] output pixels [6] segments [7] overflow
 //          [8] overflow flags of the routing kernels [9] most anchors in one component
 __global__ __launch_bounds__(256) void k_stag_comp_alloc(int n, const int *__restrict__ label, const int *__restrict__ csize,
-                                                         const int *__restrict__ canch, int *__restrict__ cursors, int max_comps, const int *caps,
-                                                         StagComp *__restrict__ comps, int *__restrict__ cidmap)
+                                                         const int *__restrict__ canch, const int4 *__restrict__ cbox, int *__restrict__ cursors, int max_comps,
+                                                         const int *caps, StagComp *__restrict__ comps, int *__restrict__ cidmap)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n || label[i] != i) return;
@@ -630,7 +658,10 @@ __global__ __launch_bounds__(256) void k_stag_comp_alloc(int n, const int *__res
     }
     StagComp C;
     C.root = i; C.size = sz; C.nanch = na; C.nrec = 0;
-    C.minr = C.minc = 0x7fffffff; C.maxr = C.maxc = -1;
+    {
+        const int4 bx = cbox[i];
+        C.minr = bx.x; C.minc = bx.y; C.maxr = bx.z; C.maxc = bx.w;
+    }
     int p2 = 1;
     while (p2 < na) p2 <<= 1;
     C.anch_cap = p2;
@@ -679,42 +710,7 @@ __global__ __launch_bounds__(256) void k_stag_comp_fill(const int32_t *__restric
     }
 }
 
-// bounding boxes of the components that have anchors; cursors[10] = the largest LDS tile (bytes) a component would need.
-// A wave covers 64 consecutive pixels, which belong to very few components: one set of atomics per (wave, component).
-__global__ __launch_bounds__(256) void k_stag_comp_bbox(int W, int n, const int *__restrict__ label, const int *__restrict__ cidmap, StagComp *comps)
-{
-    const int i = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63;
-    int cid = -1, r = 0, c = 0;
-    if (i < n) {
-        const int root = label[i];
-        if (root >= 0) cid = cidmap[root];
-        r = i / W;
-        c = i - r * W;
-    }
-    unsigned long long pending = __ballot(cid >= 0);
-    while (pending) {
-        const int lead = __builtin_ctzll(pending);
-        const int c0 = __builtin_amdgcn_readlane(cid, lead);
-        const bool mine = cid == c0;
-        const unsigned long long m = __ballot(mine);
-        int mnr = mine ? r : 0x7fffffff, mnc = mine ? c : 0x7fffffff, mxr = mine ? r : -1, mxc = mine ? c : -1;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            mnr = min(mnr, __shfl_xor(mnr, off, 64));
-            mnc = min(mnc, __shfl_xor(mnc, off, 64));
-            mxr = max(mxr, __shfl_xor(mxr, off, 64));
-            mxc = max(mxc, __shfl_xor(mxc, off, 64));
-        }
-        if (lane == lead) {
-            atomicMin(&comps[c0].minr, mnr);
-            atomicMin(&comps[c0].minc, mnc);
-            atomicMax(&comps[c0].maxr, mxr);
-            atomicMax(&comps[c0].maxc, mxc);
-        }
-        pending &= ~m;
-    }
-}
-
+// cursors[10] = the largest LDS tile (bytes) a component would need (the boxes come from k_stag_ccl_flatten)
 __global__ __launch_bounds__(256) void k_stag_comp_tilemax(const StagComp *__restrict__ comps, int *cursors, int lds_cap)
 {
     const int cid = blockIdx.x * 256 + threadIdx.x;

@@ -710,7 +710,8 @@ static fid_status stag_advance_impl(fid_stag_ctx *c, StagJob &j)
         j.seg = 2;
         if (c->route_mode != 1) return stag_launch_route_seq(c, j) ? FID_OK : stag_finish(j, FID_E_HIP);
         if (hipMemcpyAsync(c->d_edgeimg, c->d_edge, (size_t)n, hipMemcpyDeviceToDevice, st) != hipSuccess) return stag_finish(j, FID_E_HIP);
-        if (hipMemsetAsync(c->d_outpix, 0xff, (size_t)n * sizeof(int2), st) != hipSuccess) return stag_finish(j, FID_E_HIP);
+        // (EdgeMap::pixels needs no clearing on this road: k_stag_route_gather writes every entry below the final count from
+        //  the cleared arenas; the sequential road clears it itself -- 16.6 MB of writes per 1080p frame less)
         if (na == 0) {
             c->rcount[0] = c->rcount[1] = c->rcount[2] = 0;
             j.rstate = RS_EMPTY;

@@ -720,10 +720,22 @@ static fid_status stag_advance_impl(fid_stag_ctx *c, StagJob &j)
         const int nb = (n + 255) / 256;
         // (the per-root counters are zeroed by k_stag_ccl_init where a root can be; the output arena is cleared once its used
         // size is known: clearing the whole allocations cost 70 MB of writes per frame)
-        const bool ok = hipMemsetAsync(c->d_cursors, 0, 64, st) == hipSuccess && hipMemsetAsync(c->d_fill, 0, (size_t)c->max_comps * 4, st) == hipSuccess &&
-                        hipMemsetAsync(c->d_aslots, 0xff, (size_t)c->cap_aslots * 4, st) == hipSuccess &&
-                        hipMemsetAsync(c->d_prodflag, 0, (size_t)na * 4, st) == hipSuccess && hipMemsetAsync(c->d_blkpix, 0, (size_t)na * 4, st) == hipSuccess &&
-                        hipMemsetAsync(c->d_blksegs, 0, (size_t)na * 4, st) == hipSuccess;
+        bool ok = true;
+        {
+            // (all of them are hipMalloc'ed, i.e. 256-byte aligned, and sized in whole 16-byte words or rounded up inside their allocation)
+            StagFills F;
+            void *ptr[6] = {c->d_cursors, c->d_fill, c->d_aslots, c->d_prodflag, c->d_blkpix, c->d_blksegs};
+            const size_t bytes[6] = {64, (size_t)c->max_comps * 4, (size_t)c->cap_aslots * 4, (size_t)na * 4, (size_t)na * 4, (size_t)na * 4};
+            const unsigned val[6] = {0u, 0u, 0xffffffffu, 0u, 0u, 0u};
+            unsigned most = 0;
+            for (int k = 0; k < 6; k++) {
+                F.p[k] = (uint4 *)ptr[k];
+                F.n16[k] = (unsigned)((bytes[k] + 15) / 16);
+                F.v[k] = val[k];
+                most = F.n16[k] > most ? F.n16[k] : most;
+            }
+            hipLaunchKernelGGL(k_stag_fills, dim3((most + 255) / 256), dim3(256), 0, st, F);
+        }
         if (!ok) return stag_finish(j, FID_E_HIP);
         {
             const dim3 tiles((W + CCL_TW - 1) / CCL_TW, (H + CCL_TH - 1) / CCL_TH);

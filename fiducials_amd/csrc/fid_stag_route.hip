@@ -488,6 +488,20 @@ struct StagRec {  // one producing anchor
     int seg_off, nsegs;     // its segments inside the component's segment arena
 };
 
+// several buffers filled by one launch (every fill is a dispatch of its own otherwise, and the hardware takes them one at a time)
+struct StagFills {
+    uint4 *p[6];
+    unsigned n16[6];  // 16-byte words
+    unsigned v[6];    // the 32-bit pattern
+};
+__global__ __launch_bounds__(256) void k_stag_fills(StagFills F)
+{
+    const unsigned i = blockIdx.x * 256 + threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < 6; k++)
+        if (i < F.n16[k]) F.p[k][i] = make_uint4(F.v[k], F.v[k], F.v[k], F.v[k]);
+}
+
 __device__ __forceinline__ int ccl_find(const int *L, int a)
 {
     while (true) {

@@ -330,6 +330,7 @@ def stag_side_result(local_rank, args):
         m, _ = pool.detect_markers_batch(batch, synth.K_DEFAULT, None, 0.18)
         found += sum(len(x) for x in m)
     dt = time.perf_counter() - t
+    pool.close()  # (before the next context: 22 + 1 streams would touch the limit of 24 hardware queues)
     one = fstag.StagDetector(hd, ec, max_width=W, max_height=H, device=local_rank)
     ts = []
     for i in range(12):
@@ -337,7 +338,6 @@ def stag_side_result(local_rank, args):
         one.detect_markers(frames[i % len(frames)])
         ts.append(time.perf_counter() - t)
     one.close()
-    pool.close()
     res = {"value": round(B * steps / dt, 2), "unit": "frames/s", "ms_single_frame": round(float(np.median(ts[2:])) * 1e3, 3),
            "workload": f"cfg5: {B} frames per step on {T} concurrent contexts, 1920x1080 mono8 from host memory, 20 markers per frame "
                        "drawn from the 12 ids of library HD21 (duplicates of an id are dropped by checkDuplicate, as in the "

@@ -318,7 +318,9 @@ def stag_side_result(local_rank, args):
     REFERENCE's own Stag::detectMarkers on one host core next to it."""
     from fiducials_amd import stag as fstag, synth
 
-    hd, ec, B, T = 21, 7, 66, 22
+    # (16 contexts here, not the 22 of `--workload stag`: this child shares the GPU with its parent, whose closed contexts keep
+    #  their hardware queues -- 22 more streams on top collapse to 8 frames/s)
+    hd, ec, B, T = 21, 7, 64, 16
     words = fstag.load_library(hd)
     frames = [synth.make_stag_frame(words, sd, W, H, MARKERS).image for sd in shard_seeds(0, 1, 4, "stag")]
     pool = fstag.StagPool(hd, ec, n_contexts=T, max_width=W, max_height=H, device=local_rank)

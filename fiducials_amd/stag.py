@@ -169,11 +169,13 @@ class StagPool:
     The HIP runtime maps streams to 4 hardware queues unless GPU_MAX_HW_QUEUES says otherwise, and kernels of streams that
     share a queue do not overlap: 16 contexts measure 570 frames/s with 4 queues and 1070 with 24 (MI355X, 1080p, HD21).
     The rate follows 1 / (a + b / n): a = whole-GPU kernel time per frame (0.4 ms), b = a frame's chain of small kernels (3.4 ms);
-    22 contexts (1 760 frames/s) stay just under the 24 queues -- at 24 contexts the rate collapses to ~130.
+    22 contexts (1 760 frames/s) stay just under the 24 queues -- at 24 contexts the rate collapses to ~130.  The queues are
+    shared with everything else on the GPU (other processes, closed contexts of this one): 22 is for a process that has the
+    GPU to itself (`bench.py --workload stag`), the default of 16 leaves room.
     The variable is read when the runtime starts, so it is set here only if nothing has touched the GPU yet; keep the number of
     contexts below the number of queues (24 contexts on 24 queues collapse to ~100 frames/s)."""
 
-    def __init__(self, libraryHD: int = 21, errorCorrection: int = 7, n_contexts: int = 22, max_width: int = 1920, max_height: int = 1080,
+    def __init__(self, libraryHD: int = 21, errorCorrection: int = 7, n_contexts: int = 16, max_width: int = 1920, max_height: int = 1080,
                  device: int = 0):
         import os
 

@@ -15,12 +15,14 @@
 //             and leaves its EXIT STATE: bit position, block within the MCU, zig-zag index;
 //         <1> round r: lane i decodes sub-sequence i again from the exit state of lane i-1; a lane whose entry did not change
 //             in the previous round keeps its result.  Sub-sequence 0 is exact from the start, so exactness spreads at least
-//             one sub-sequence per round -- in practice everything agrees after two or three rounds (restart markers and
-//             block ends are where decoders meet).  When no exit state changed, every exit state is the true one;
+//             one sub-sequence per round -- in practice everything agrees after five to seven rounds of 128-byte
+//             sub-sequences (the block phase takes longer to agree than the symbol boundaries; restart markers are where
+//             all decoders meet).  When no exit state changed, every exit state is the true one;
 //         scan of the blocks completed per sub-sequence -> where each lane's output goes;
 //         <2> the same decode once more, now writing coefficients (sparse: the buffer was cleared).
-//       Byte stuffing (FF 00) and restart markers are handled by the bit reader on the fly, positions are raw bit offsets
-//       that never point into a stuffed byte (so equal logical positions compare equal).
+//       Every pass first unstuffs the workgroup's bytes into LDS (FF 00, fill bytes, markers), so that the symbol loop reads
+//       plain bits; states are exchanged as RAW bit offsets that never point into a removed byte (equal logical positions
+//       compare equal whoever computed them).
 //   J2  k_jpeg_scan   per sub-sequence: blocks completed before it and, per component, the DC value its first block continues
 //                     from (DC prediction: segmented prefix sums of the differences, segments = restart intervals) -- the
 //                     writing pass then stores absolute DC values straight away
@@ -33,7 +35,6 @@
 #define JP_SUB 128         // bytes per sub-sequence (a decoder that starts out of step needs a few hundred bytes to fall into step with
                            // the block phase as well as the symbol boundaries: 64-byte sub-sequences took 11-15 rounds, 256-byte ones 3)
 #define JP_TPB 256         // lanes (sub-sequences) per workgroup
-#define JP_PAD 64          // bytes staged beyond the workgroup's last sub-sequence (a lane stops within one symbol of its end)
 #define JP_LOOK 10         // bits of the LDS first-level code tables
 
 struct JpImage {

@@ -2869,14 +2869,23 @@ __global__ __launch_bounds__(64) void k_identify(const uint8_t *__restrict__ gra
         if (stddev < P.minOtsuStdDev) uniform_bits = mean > 127 ? 1 : 0;
         if (uniform_bits < 0) {
             // getThreshVal_Otsu_8u, sequential over the 256 bins (lane 0)
-            if (lane == 0) {
+            // (the histogram in registers, four bins per lane: bin i comes by v_readlane instead of an LDS read in each of the
+            //  2 x 256 dependent iterations.  Every lane runs the same scalar loop -- uniform control flow, so that the cross-
+            //  lane reads are well defined -- and lane 0 keeps the result.)
+            const int hreg[4] = {hist[lane], hist[lane + 64], hist[lane + 128], hist[lane + 192]};
+            {
                 const int N = 256;
                 double mu = 0, sc = 1. / (SZ * SZ);
-                for (int i = 0; i < N; i++) mu += i * (double)hist[i];
+#pragma unroll
+                for (int k4 = 0; k4 < 4; k4++)
+                    for (int j = 0; j < 64; j++) mu += (k4 * 64 + j) * (double)__builtin_amdgcn_readlane(hreg[k4], j);
                 mu *= sc;
                 double mu1 = 0, q1 = 0, max_sigma = 0, max_val = 0;
-                for (int i = 0; i < N; i++) {
-                    double p_i = hist[i] * sc;
+#pragma unroll
+                for (int k4 = 0; k4 < 4; k4++)
+                  for (int j = 0; j < 64; j++) {
+                    const int i = k4 * 64 + j;
+                    double p_i = __builtin_amdgcn_readlane(hreg[k4], j) * sc;
                     mu1 *= q1;
                     q1 += p_i;
                     double q2 = 1. - q1;
@@ -2889,7 +2898,7 @@ __global__ __launch_bounds__(64) void k_identify(const uint8_t *__restrict__ gra
                         max_val = i;
                     }
                 }
-                s_thr = (int)floor(max_val);
+                if (lane == 0) s_thr = (int)floor(max_val);
             }
             __syncthreads();
             const int thr = s_thr;
@@ -3125,6 +3134,11 @@ __global__ __launch_bounds__(64) void k_subpix(const uint8_t *__restrict__ gray,
                 const int i = p / csz, j = p - i * csz;
                 s_img[p] = g[(long long)(Y0 + i) * gs + X0 + j];
             }
+        // (the window weights of this lane's taps: read once, not once per iteration -- a global load in front of every
+        //  iteration's products sat on the critical path)
+        float wgt[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) wgt[k] = lane + 64 * k < ww * ww ? maskw[lane + 64 * k] : 0.f;
         int iter = 0;
         for (;;) {
             // getRectSubPix(src, (pw, pw), cI) -> sp
@@ -3216,10 +3230,13 @@ __global__ __launch_bounds__(64) void k_subpix(const uint8_t *__restrict__ gray,
                 }
             }
             __syncthreads();
-            for (int t = lane; t < ww * ww; t += 64) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int t = lane + 64 * k;
+                if (t >= ww * ww) break;
                 int i = t / ww, j = t - i * ww;
                 const float *q = sp + (i + 1) * pw + (j + 1);
-                double m = maskw[t];
+                double m = wgt[k];
                 double tgx = q[1] - q[-1];
                 double tgy = q[pw] - q[-pw];
                 double gxx = tgx * tgx * m, gxy = tgx * tgy * m, gyy = tgy * tgy * m;
@@ -3234,8 +3251,18 @@ __global__ __launch_bounds__(64) void k_subpix(const uint8_t *__restrict__ gray,
             // the five accumulators are summed in the reference's tap order, one accumulator per lane (0..4)
             double accv = 0;
             if (lane < 5) {
+                // in tap order, as the reference accumulates; sixteen LDS reads are issued together, then added one after
+                // the other (one read per add left every add waiting for LDS: 6 of the 7 us an iteration took)
                 const double *pr = prod[lane];
-                for (int t = 0; t < ww * ww; t++) accv += pr[t];
+                const int nt = ww * ww;
+                for (int t0 = 0; t0 < nt; t0 += 16) {
+                    double v[16];
+#pragma unroll
+                    for (int k = 0; k < 16; k++) v[k] = pr[t0 + k < nt ? t0 + k : nt - 1];
+#pragma unroll
+                    for (int k = 0; k < 16; k++)
+                        if (t0 + k < nt) accv += v[k];
+                }
             }
             const double a = bcast_f64(accv, 0), b = bcast_f64(accv, 1), c = bcast_f64(accv, 2);
             const double bb1 = bcast_f64(accv, 3), bb2 = bcast_f64(accv, 4);

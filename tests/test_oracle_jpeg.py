@@ -97,3 +97,25 @@ def test_the_references_own_jpeg_files(gold):
     blob = _bag_jpeg(REF + "fiducial_slam/test/aruco_images.bag")
     assert blob is not None
     assert hashlib.sha256(oj.decode(blob).tobytes()).hexdigest() == want["aruco_images.bag"]
+
+
+def test_product_header_parse_agrees_with_the_oracle(gold):
+    """fid_jpeg_probe is host-only code of the product library (no device needed): on every fixture it reports what the
+    oracle's parser reports, and it refuses what the decoder does not support."""
+    from fiducials_amd import jpeg as fj
+    from fiducials_amd._lib import FidError
+
+    for k, w, h, sub, gray, q, rst in gold["cases"].tolist():
+        data = gold[f"jpg_{k}"].tobytes()
+        a, b = fj.probe(data), oj.info(data)
+        assert (a["width"], a["height"], a["components"], a["h_samp"], a["v_samp"], a["restart_interval"]) == \
+               (b["width"], b["height"], b["ncomp"], b["hmax"], b["vmax"], b["restart"])
+        assert a["blocks_w"][0] == b["bw0"] and a["blocks_h"][0] == b["bh0"]
+        if not gray:
+            assert a["blocks_w"][1] == b["bw1"] and a["blocks_h"][1] == b["bh1"]
+        assert 0 < a["scan_bytes"] < len(data)
+    with pytest.raises(FidError) as e:
+        fj.probe(gold["jpg_progressive"].tobytes())
+    assert e.value.status == 6  # FID_E_UNSUPPORTED
+    with pytest.raises(FidError):
+        fj.probe(b"\xff\xd8\xff\xe0 short")

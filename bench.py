@@ -413,7 +413,7 @@ def main_stag(args):
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": f"synthetic ({len(frames)} unique frames per GPU, host memory)",
-            "config": {"workload": f"cfg5: {B} frames per step on {T} concurrent contexts (one host thread, segment by segment), 1920x1080 mono8, 20 markers/frame, "
+            "config": {"workload": f"cfg5: {B} frames per step on {T} concurrent contexts (FID_STAG_THREADS host threads, default 4, deal the segments), 1920x1080 mono8, 20 markers/frame, "
                                    "library HD21, errorCorrection 7, marker_size 0.18", "frames_per_step": B * n_gpus, "contexts_per_gpu": T,
                        "parallelism": f"frames sharded over {n_gpus} GPU(s), no collective",
                        "markers_per_frame_found": round(markers / max(B * args.steps, 1), 2)},

@@ -56,7 +56,7 @@ ALGO_BYTES = {
 }
 PIPELINE_BYTES = W * H + 2 * MASK_BYTES  # 8 812 800 B/frame
 KERNEL_OF = {"threshold": "k_threshold_stream", "find_starts": "k_find_starts", "walk_probe": "k_probe",
-             "walk_full": "k_walk_full<2>", "seed_walk": "k_walk_full<1>", "approx": "k_approx"}
+             "walk_full": "k_walk_full<2>", "seed_walk": "k_seed_walk", "approx": "k_approx"}
 
 
 def shard_seeds(rank: int, world: int, unique: int, workload: str = "aruco"):

@@ -30,6 +30,10 @@ struct fid_ctx {
     hipStream_t aux_stream[MAX_SUB] = {};  // per sub-batch: the seed walk runs here, beside the probe passes and the survivor walk
     hipEvent_t aux_fork[MAX_SUB] = {}, aux_join[MAX_SUB] = {};
     hipEvent_t sub_done[MAX_SUB] = {}, fork_ev = nullptr;
+    hipEvent_t walk_done[MAX_SUB] = {};     // a sub-batch has left its contour stage (staggered starts, FID_STAGGER)
+    int stagger = 0;                        // sub-batch k starts when sub-batch k - stagger has left its contour stage (0: all at once)
+    int resolve_lds_kb = 64;
+    int walk2_div = 2;
     hipEvent_t sub_ev[MAX_SUB][16] = {};   // per sub-batch stage boundaries (FID_PROFILE)
     int sub_frames = 0;                    // frames per sub-batch (0 = automatic)
     fid_params params;
@@ -57,7 +61,10 @@ struct fid_ctx {
     uint4 *d_recs = nullptr;  // copy records: pieces of the accepted contours
     int thr_mode = 1;    // node window table: 1 = k_threshold_stream (default), 0 (FID_THR=tile) = k_threshold_fixed
     int thr_nw = 3, thr_split = 0, thr_rows = 0;  // stream kernel: consumer waves per workgroup, un-fused LDS reads, rows per workgroup (0 = automatic)
-    int trace_mode = 1;  // 1: seed-accelerated tracing; 0 (FID_TRACE=legacy): probe passes + whole-border walk only
+    int trace_mode = 2;  // 2: cycle tracing (borders read off the seed cycles; starts only for borders without a seed);
+                         // 1 (FID_TRACE=chain): round-2 seed tracing (every border found by a probe survivor); 0 (FID_TRACE=legacy):
+                         // probe passes + whole-border walk only
+    int sw_blocks = 0;   // FID_SW_BLOCKS: seed-walker workgroups per frame (0 = automatic)
     long long fallbacks = 0;  // calls that fell back to the whole-border walk because the seed table was too small
     int max_chunks = 0;
     int walk_blocks = 0;  // one-wave workgroups per frame in the full walk pass (0 = automatic)
@@ -289,6 +296,10 @@ fid_status run_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H, int
         const int f0 = sb * per, Fs = (f0 + per <= F ? per : F - f0);
         hipStream_t st = nsub > 1 ? c->sub_stream[sb] : st0;
         if (nsub > 1) HIPCHK(c, hipStreamWaitEvent(st, c->fork_ev, 0));
+        // staggered starts: the contour stage of a sub-batch (threshold ... approx) keeps the whole chip busy, what follows
+        // (candidates, identification, corners) is a chain of short latency-bound kernels -- let the next sub-batch's contour
+        // stage run under that tail instead of beside another contour stage
+        if (nsub > 1 && c->stagger > 0 && sb >= c->stagger) HIPCHK(c, hipStreamWaitEvent(st, c->walk_done[sb - c->stagger], 0));
         DevParams P = c->P;
         P.nframes = Fs;
         const size_t MC = (size_t)P.maxCands, MM = (size_t)P.maxMarkers;
@@ -361,6 +372,7 @@ fid_status run_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H, int
         wb = wb < 2 ? 2 : (wb > wcap ? wcap : wb);
         // kernels with a fixed number of workgroups per frame (sized for batches): a call of a few frames gets more of them
         const int gm = Fs >= 16 ? 1 : 16 / Fs;
+        const int wb2 = wb > 1 ? wb / 2 : 1;  // the two walks share the CUs' LDS
         const int cap1 = pts_cap_first(P);
         const size_t lds1 = (size_t)cap1 * sizeof(uint32_t) + (size_t)K4_SHORT_STACK * sizeof(int2);
         const size_t lds2 = (size_t)(P.maxPerim + 1) * sizeof(uint32_t) + (size_t)K4_LONG_STACK * sizeof(int2);
@@ -395,12 +407,46 @@ fid_status run_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H, int
             hipLaunchKernelGGL(k_find_starts<true>, dim3((unsigned)k2blocks, Fs), dim3(256), 0, st, masks, starts, counts, c->d_global,
                                seedq, P);
             mark(ST_STARTS + 1);
+          if (c->trace_mode == 2) {
+            // ---- cycle tracing: the seeds walk their segments (own stream) while the starts are sieved for the borders that
+            //      have no seed state; every other border is read off the segment cycles
+            hipStream_t sa = c->aux_stream[sb];
+            HIPCHK(c, hipEventRecord(c->aux_fork[sb], st));
+            HIPCHK(c, hipStreamWaitEvent(sa, c->aux_fork[sb], 0));
+            // about 4 walker waves per CU over the sub-batch (34 KB LDS per 2-wave workgroup: two of them leave a CU room for
+            // the other sub-batch's kernels; 8 waves per CU measured 7 % slower end to end)
+            int swb = c->sw_blocks > 0 ? c->sw_blocks : (1024 / SW_WAVES + Fs - 1) / Fs;
+            swb = swb < 2 ? 2 : (swb > 4 * wcap ? 4 * wcap : swb);
+            if (c->profile) (void)hipEventRecord(ev[14], sa);
+            hipLaunchKernelGGL(k_seed_walk, dim3(swb, Fs), dim3(64 * SW_WAVES), 0, sa, masks, seedq, tab, pool, (DevSegC *)segs, counts,
+                               c->d_global, P);
+            if (c->profile) (void)hipEventRecord(ev[15], sa);
+            HIPCHK(c, hipEventRecord(c->aux_join[sb], sa));
+            hipLaunchKernelGGL((k_probe<PROBE0_STEPS, 0, true>), dim3(64 * gm, Fs), dim3(256), 0, st, masks, starts, surv1, counts, c->d_global, P);
+            hipLaunchKernelGGL((k_probe<PROBE1_STEPS, 1, true>), dim3(16 * gm, Fs), dim3(256), 0, st, masks, surv1, surv, counts, c->d_global, P);
+            mark(ST_PROBE + 1);
+            const int wb3 = c->walk2_div > 0 ? (wb / c->walk2_div > 0 ? wb / c->walk2_div : 1) : wb2;
+            hipLaunchKernelGGL(k_walk_full<2>, dim3(wb3, Fs), dim3(64 * WALK_WAVES), 0, st, masks, surv, wres, tab, pool, segs, pend, counts,
+                               c->d_global, P);
+            hipLaunchKernelGGL(k_seed_index, dim3(8 * gm, Fs), dim3(256), 0, st, seedq, seedhash, counts, P);
+            HIPCHK(c, hipStreamWaitEvent(st, c->aux_join[sb], 0));
+            hipLaunchKernelGGL(k_seg_link2, dim3(16 * gm, Fs), dim3(256), 0, st, seedq, (DevSegC *)segs, seedhash, counts, P);
+            uint4 *recs = c->d_recs + 2 * f0 * MCn;
+            hipLaunchKernelGGL(k_seg_cycles, dim3(32 * gm, Fs), dim3(64), 0, st, seedq, (const DevSegC *)segs, pend, wres, contours, cinfo, cbase,
+                               recs, counts, c->d_global, P);
+            hipLaunchKernelGGL(k_seg_copy, dim3(c->copy_blocks > 0 ? c->copy_blocks : 256, Fs), dim3(256), 0, st, recs, tab, pool, dense, counts, P);
+            mark(ST_WALK + 1);
+            hipLaunchKernelGGL(k_approx, dim3(128 * gm, Fs), dim3(64), lds1, st, contours, tab, pool, cands, counts, c->d_global, P, cap1,
+                               K4_SHORT_STACK, 0, dense, cbase);
+            hipLaunchKernelGGL(k_approx, dim3(16 * gm, Fs), dim3(64), lds2, st, contours, tab, pool, cands, counts, c->d_global, P,
+                               P.maxPerim + 1, K4_LONG_STACK, 1, dense, cbase);
+            mark(ST_APPROX + 1);
+          } else {
             // the seed walk needs only the seeds: it runs on its own stream beside the probe passes and the survivor walk
             // (both walks are a throughput phase followed by a tail of a few long walkers; side by side the tails overlap)
             hipStream_t sa = c->aux_stream[sb];
             HIPCHK(c, hipEventRecord(c->aux_fork[sb], st));
             HIPCHK(c, hipStreamWaitEvent(sa, c->aux_fork[sb], 0));
-            const int wb2 = wb > 1 ? wb / 2 : 1;  // the two walks share the CUs' LDS
             if (c->profile) (void)hipEventRecord(ev[14], sa);
             hipLaunchKernelGGL(k_walk_full<1>, dim3(wb2, Fs), dim3(64 * WALK_WAVES), 0, sa, masks, seedq, wres, tab, pool, segs, pend, counts,
                                c->d_global, P);
@@ -424,7 +470,9 @@ fid_status run_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H, int
             hipLaunchKernelGGL(k_approx, dim3(16 * gm, Fs), dim3(64), lds2, st, contours, tab, pool, cands, counts, c->d_global, P,
                                P.maxPerim + 1, K4_LONG_STACK, 1, dense, cbase);
             mark(ST_APPROX + 1);
+          }
         }
+        if (nsub > 1 && c->stagger > 0) HIPCHK(c, hipEventRecord(c->walk_done[sb], st));
         // ---- K5
         float4 *cmeta = c->d_cmeta + f0 * MC;
         hipLaunchKernelGGL(k_sort_cands, dim3(Fs), dim3(256), MC * 8, st, cands, sorted, cmeta, counts, P);
@@ -432,7 +480,9 @@ fid_status run_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H, int
         hipLaunchKernelGGL(k_near, dim3(32 * gm, Fs), dim3(256), 0, st, sorted, cmeta, nearb, counts, P);
         mark(ST_NEAR + 1);
         {
-            const size_t lds = 96 * 1024;  // sizes, labels, component sizes; the rest holds the near triangle
+            // sizes, labels, component sizes; the rest holds the near triangle (64 KB: fits beside two seed-walker workgroups of
+            // the other sub-batch on a CU; with 96 KB the kernel waited for whole CUs to drain)
+            const size_t lds = (size_t)c->resolve_lds_kb * 1024;
             const int near_words = c->resolve_serial ? 0 : (int)((lds - 3 * MC * 4) / 4);
             hipLaunchKernelGGL(k_resolve, dim3(Fs), dim3(1024), lds, st, sorted, nearb, filtered, counts, worklist, nwork, P, near_words, c->d_global);
         }
@@ -480,7 +530,7 @@ fid_status run_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H, int
                 float ms = 0.f;
                 if (hipEventElapsedTime(&ms, c->sub_ev[sb][i], c->sub_ev[sb][i + 1]) == hipSuccess) c->stage_ms[i] += ms;
             }
-        if (c->trace_mode == 1)  // the seed walk runs on the auxiliary streams, beside walk_probe and part of walk_full
+        if (c->trace_mode >= 1)  // the seed walk runs on the auxiliary streams, beside walk_probe and part of walk_full
             for (int sb = 0; sb < c->last_nsub; sb++) {
                 float ms = 0.f;
                 if (hipEventElapsedTime(&ms, c->sub_ev[sb][14], c->sub_ev[sb][15]) == hipSuccess) c->stage_ms[ST_SEEDWALK] += ms;
@@ -503,7 +553,7 @@ fid_status run_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H, int
                     (double)d[21] / d[1], (double)d[22] / d[1], (double)d[23] / d[1], (double)d[24] / d[1]);
     }
 #endif
-    if (c->trace_mode == 1 && (c->h_global->overflow & (2u | 8u))) {
+    if (c->trace_mode >= 1 && (c->h_global->overflow & (2u | 8u))) {
         // the tracing seeds and their points scale with the total border length of the frame, texture included: when they
         // do not fit max_contours_per_frame / max_points_per_frame, trace this call with the whole-border walk, which only
         // needs room for the probe survivors
@@ -511,10 +561,11 @@ fid_status run_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H, int
             fprintf(stderr, "fid: seed tracing overflow flags 0x%x (frame 0: seeds %d starts %d surv %d chunks %d; maxContours %d maxChunks %d shift %d): whole-border walk\n",
                     c->h_global->overflow, c->h_counts[0].nseeds, c->h_counts[0].nstarts, c->h_counts[0].nsurv, c->h_counts[0].npool, c->P.maxContours,
                     c->P.maxChunks, c->P.seedShift);
+        const int tm = c->trace_mode;
         c->trace_mode = 0;
         c->fallbacks++;
         const fid_status rc2 = run_detect(c, d_src, F, W, H, stride, fstride, enc, out, cap_per_frame, n_per_frame);
-        c->trace_mode = 1;
+        c->trace_mode = tm;
         return rc2;
     }
     fid_status rc = FID_OK;
@@ -685,6 +736,7 @@ fid_status fid_create(const fid_params *params, const fid_dict *dict, const fid_
         TRYHIP(hipEventCreateWithFlags(&c->aux_fork[sb], hipEventDisableTiming));
         TRYHIP(hipEventCreateWithFlags(&c->aux_join[sb], hipEventDisableTiming));
         TRYHIP(hipEventCreateWithFlags(&c->sub_done[sb], hipEventDisableTiming));
+        TRYHIP(hipEventCreateWithFlags(&c->walk_done[sb], hipEventDisableTiming));
         for (int i = 0; i < 16; i++) TRYHIP(hipEventCreate(&c->sub_ev[sb][i]));
     }
     const size_t F = L.max_batch, MC = L.max_candidates_per_frame, MM = L.max_markers_per_frame;
@@ -703,8 +755,14 @@ fid_status fid_create(const fid_params *params, const fid_dict *dict, const fid_
     TRY(dalloc(c, &c->d_surv, F * L.max_starts_per_frame));
     c->max_chunks = (L.max_points_per_frame + CK - 1) / CK;
     TRY(dalloc(c, &c->d_pool, F * (size_t)c->max_chunks * CK));
-    c->trace_mode = getenv("FID_TRACE") && !strcmp(getenv("FID_TRACE"), "legacy") ? 0 : 1;
-    if (c->trace_mode == 1) {
+    c->trace_mode = 2;
+    if (const char *tm = getenv("FID_TRACE")) c->trace_mode = !strcmp(tm, "legacy") ? 0 : !strcmp(tm, "chain") ? 1 : 2;
+    if (getenv("FID_SW_BLOCKS")) c->sw_blocks = atoi(getenv("FID_SW_BLOCKS"));
+    if (getenv("FID_STAGGER")) c->stagger = atoi(getenv("FID_STAGGER"));
+    if (getenv("FID_RESOLVE_LDS")) c->resolve_lds_kb = atoi(getenv("FID_RESOLVE_LDS"));
+    if (getenv("FID_WALK2_DIV")) c->walk2_div = atoi(getenv("FID_WALK2_DIV"));
+    static_assert(sizeof(DevSegC) == sizeof(DevSeg), "the two segment records share one buffer");
+    if (c->trace_mode >= 1) {
         TRY(dalloc(c, &c->d_segs, F * L.max_contours_per_frame));
         TRY(dalloc(c, &c->d_pend, F * L.max_contours_per_frame));
         TRY(dalloc(c, &c->d_seedq, F * L.max_contours_per_frame));
@@ -782,6 +840,7 @@ void fid_destroy(fid_ctx *c)
         if (c->aux_fork[sb]) (void)hipEventDestroy(c->aux_fork[sb]);
         if (c->aux_join[sb]) (void)hipEventDestroy(c->aux_join[sb]);
         if (c->sub_done[sb]) (void)hipEventDestroy(c->sub_done[sb]);
+        if (c->walk_done[sb]) (void)hipEventDestroy(c->walk_done[sb]);
         for (int i = 0; i < 16; i++)
             if (c->sub_ev[sb][i]) (void)hipEventDestroy(c->sub_ev[sb][i]);
         if (c->sub_stream[sb]) (void)hipStreamDestroy(c->sub_stream[sb]);

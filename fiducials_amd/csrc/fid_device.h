@@ -107,6 +107,22 @@ struct DevSeg {           // one per seed
     uint32_t mhole;       // min raster index over the background 4-neighbours its searches passed over
     uint32_t pad[3];
 };
+// Trace mode 2 ("cycle tracing"): the segment record of a seed when the contours are read off the seed cycles alone (no probe
+// survivor needed for a border that has a seed).  Same size as DevSeg: the two share their buffer.
+//   ko / kh: the smallest discovery key among the segment's states that START a border the way cvFindNextContour /
+//   icvFetchContour would (outer: W neighbour background and back direction = first foreground clockwise from NW, key = raster
+//   index of the pixel; hole: E neighbour background and back direction = first foreground clockwise from SE, key = raster index
+//   of that E neighbour), and where in the segment that state is.  Around a cycle, min ko < min kh means an outer border whose
+//   first point is the state with min ko; otherwise a hole border that starts at the state with min kh (k_seg_cycles).
+struct DevSegC {
+    uint32_t next_key;    // the seed state the segment ran into: x | y << 13 | d << 26 (same scale)
+    uint32_t n;           // states in the segment (SEG_INVALID: abandoned)
+    uint32_t ko, kh;      // 0xffffffff: none
+    uint32_t pos;         // position of the ko state | position of the kh state << 16
+    uint32_t next_idx;    // seed index of next_key (k_seg_link2)
+    uint32_t linked;      // some segment runs into this one (k_seg_link2): only such a seed can lie on a cycle
+    uint32_t pad;
+};
 struct DevPend {          // one per probe survivor that stopped in front of a seed state
     uint32_t p;           // states it walked itself (0 = not stopped: the survivor closed or died on its own)
     uint32_t next_key;    // that seed state: x | y << 13 | d << 26

@@ -1111,7 +1111,9 @@ __device__ __host__ inline int chunk_tab_pitch(const DevParams &P) { return P.ma
 // minMarkerPerimeterRate.
 #define PROBE0_STEPS 6
 #define PROBE1_STEPS 32
-template <int STEPS, int LEVEL>
+// STOPSEED (trace mode 2): a start whose walk meets a seed state is dropped -- its border is a seed cycle, k_seg_cycles
+// finds it without a start.
+template <int STEPS, int LEVEL, bool STOPSEED = false>
 __global__ __launch_bounds__(256) void k_probe(const uint32_t *__restrict__ masks, const uint2 *__restrict__ in_list,
                                                 uint2 *__restrict__ out_list, DevCounts *__restrict__ counts,
                                                 DevGlobal *__restrict__ G, const DevParams P)
@@ -1138,6 +1140,8 @@ __global__ __launch_bounds__(256) void k_probe(const uint32_t *__restrict__ mask
         // canonical key: outer = own index, hole = index of the background pixel to the right
         const int key = hole ? pidx(x0 + 1, y0, W) : pidx(x0, y0, W);
         const int s_end = hole ? 0 : 4;
+        const int sgm = (8 << P.seedShift) - 1;
+        auto on_seed = [&](int x, int y, int d, unsigned nbh) { return seed_state(x, y, d, sgm) && !((nbh >> seed_empty_dir(d)) & 1u); };
         int count = 0, ok = active, closed = 0;
         unsigned nb = ok ? nb8(m, x0, y0) : 0u;
         if (!ok) {
@@ -1158,6 +1162,7 @@ __global__ __launch_bounds__(256) void k_probe(const uint32_t *__restrict__ mask
             // backward cursor starts on i1 with forward direction pointing at the start pixel
             int bx = i1x, by = i1y, bf = (sdir + 4) & 7;
             if (!hole && pidx(bx, by, W) < key) ok = 0;
+            if (STOPSEED && on_seed(x0, y0, sdir, nb)) ok = 0;  // the start state itself
             int cx = x0, cy = y0;
             while (ok) {
                 // ---- forward step: first foreground counter-clockwise from sdir + 1
@@ -1192,6 +1197,10 @@ __global__ __launch_bounds__(256) void k_probe(const uint32_t *__restrict__ mask
                 }
                 sdir = (sn + 4) & 7;
                 nb = nb8(m, cx, cy);
+                if (STOPSEED && on_seed(cx, cy, sdir, nb)) {
+                    ok = 0;
+                    break;
+                }
                 // ---- backward step: predecessor = first foreground clockwise from bf - 1
                 {
                     unsigned bn = nb8(m, bx, by);
@@ -1206,6 +1215,7 @@ __global__ __launch_bounds__(256) void k_probe(const uint32_t *__restrict__ mask
                         }
                     }
                     int bd = (c0 - tz) & 7;
+                    if (STOPSEED && on_seed(bx, by, bd, bn)) ok = 0;  // the state (pixel, back direction) the cursor stood in
                     bx += dir_dx(bd);
                     by += dir_dy(bd);
                     bf = (bd + 4) & 7;
@@ -1498,8 +1508,10 @@ __global__ __launch_bounds__(64 * WALK_WAVES) void k_walk_full(const uint32_t *_
                 }
                 state = ST_IDLE;
 #ifdef FID_DEBUG_STATS
-                atomicMax(&G->dbg[13], (unsigned long long)count);
-                atomicAdd(&G->dbg[14], (unsigned long long)count);
+                if (FID_DEBUG_STATS + 0 < 0 || MODE == FID_DEBUG_STATS + 0) {
+                    atomicMax(&G->dbg[13], (unsigned long long)count);
+                    atomicAdd(&G->dbg[14], (unsigned long long)count);
+                }
 #endif
             }
 #ifdef FID_DEBUG_STATS
@@ -1783,7 +1795,7 @@ __global__ __launch_bounds__(64 * WALK_WAVES) void k_walk_full(const uint32_t *_
         }
         if (ovf) atomicOr(&G->overflow, ovf);
 #ifdef FID_DEBUG_STATS
-        if (lane == 0) {
+        if (lane == 0 && (FID_DEBUG_STATS + 0 < 0 || MODE == FID_DEBUG_STATS + 0)) {  // -DFID_DEBUG_STATS=<mode>: that walk only; -1: all
             atomicAdd(&G->dbg[0], d_iters);
             atomicAdd(&G->dbg[1], d_ckpts);
             atomicAdd(&G->dbg[2], d_active);
@@ -1798,7 +1810,7 @@ __global__ __launch_bounds__(64 * WALK_WAVES) void k_walk_full(const uint32_t *_
 #endif
     }
 #ifdef FID_DEBUG_STATS
-    if (lane == 0) {
+    if (lane == 0 && (FID_DEBUG_STATS + 0 < 0 || MODE == FID_DEBUG_STATS + 0)) {
         const unsigned long long d_kt = __builtin_readcyclecounter() - d_k0;
         atomicAdd(&G->dbg[8], d_kt);
         atomicMax(&G->dbg[9], d_kt);
@@ -2003,7 +2015,557 @@ __global__ __launch_bounds__(256) void k_seg_copy(const uint4 *__restrict__ recs
     for (unsigned ri = blockIdx.x * 4 + (threadIdx.x >> 6); ri < nr; ri += gridDim.x * 4) {
         const uint4 r = frc[ri];
         const uint32_t *row = ftab + (long long)r.x * nck;
-        for (unsigned k = lane; k < r.z; k += 64) fd[r.y + k] = fpool[(long long)row[k >> 6] * CK + (k & 63)];
+        for (unsigned k = lane; k < r.z; k += 64) {  // (r.w: first point of the piece inside its chunk row)
+            const unsigned k2 = k + r.w;
+            fd[r.y + k] = fpool[(long long)row[k2 >> 6] * CK + (k2 & 63)];
+        }
+    }
+}
+
+// ================================================================================================
+// Trace mode 2: CYCLE TRACING.  Every border that has a seed state is a cycle of segments; its length, its kind (outer /
+// hole), its canonical start and therefore the exact point order of cvFindContours all follow from the segment records
+// (DevSegC, fid_device.h), so no probe survivor has to find it: the probe passes and the survivor walk only keep the borders
+// WITHOUT a seed state (the ones that curl up inside one grid cell) and drop a start as soon as its walk meets a seed state.
+//   k_seed_walk    every seed follows its segment (below)
+//   k_seg_link2    next seed state -> seed index; marks the seeds some segment runs into
+//   k_seg_cycles   one lane per segment: once around its cycle while one of its two start candidates can still be the
+//                  cycle's smallest; the lane that holds the canonical start lists the pieces (copy records) -- plus the
+//                  borders the survivor walk closed by itself
+//   k_seg_copy     as before (records now carry a source offset: the first segment is cut at the start state)
+
+// step table of the seed walker: index raw | backdir << 8 -> next direction | starts-an-outer-border << 3 |
+// starts-a-hole-border << 4 | seed state on a grid column << 5 | seed state on a grid row << 6
+__device__ __forceinline__ void build_step_lut2(uint8_t *lut, int tid, int nthreads)
+{
+    for (int e = tid; e < 2048; e += nthreads) {
+        const unsigned raw = (unsigned)e & 0xffu;
+        const unsigned nb = raw_to_nb(raw);
+        const int sd = e >> 8;
+        const int start = (sd + 1) & 7;
+        const unsigned rot = ((nb | (nb << 8)) >> start) & 0xffu;
+        const int t = rot ? __ffs(rot) - 1 : 0;
+        // the state icvFetchContour begins a border in: (start pixel, direction of the first foreground neighbour found
+        // clockwise from s_end - 1), s_end = 4 (W, background) for an outer border, 0 (E, background) for a hole border
+        const int fo = nb && !((nb >> 4) & 1u) && sd == first_dir(nb, 4);
+        const int fh = nb && !(nb & 1u) && sd == first_dir(nb, 0);
+        const int seed = ((nb >> sd) & 1u) && !((nb >> seed_empty_dir(sd)) & 1u);
+        const int scol = seed && ((SEED_DIRS_COL >> sd) & 1u), srow = seed && ((SEED_DIRS_ROW >> sd) & 1u);
+        lut[e] = (uint8_t)(((start + t) & 7) | (fo << 3) | (fh << 4) | (scol << 5) | (srow << 6));
+    }
+}
+
+// The seed walker.  As k_walk_full<1> (persistent waves, per-frame queues, LDS windows filled by LDS-DMA at batched
+// checkpoints, points into pool chunks), with what the round-2 counters asked for:
+//   * window = 2 x 2 mask tiles (64 px x 32 rows, 256 bytes per lane), TOROIDAL: tile (tr, tc) lives in slot (tr & 1, tc & 1), so
+//     moving the window by one tile replaces two tiles and keeps two.  A walker that travels (net displacement since the last
+//     checkpoint) gets the tiles ahead of it fetched while it keeps stepping in the tiles it has: a lane waits for memory only
+//     at its first window and after a turn the prefetch did not foresee (round 2: 30 of 64 lanes sat in a refill at any time)
+//   * start states of borders are recognised by the step table (two more bits), minima and their positions kept per segment
+//   * the cycle test compares one packed state key; the segment record leaves as two 16-byte stores
+#define SW_WAVES 2
+#define SW_CKPT 8
+#define SW_RUN 32
+__global__ __launch_bounds__(64 * SW_WAVES) void k_seed_walk(const uint32_t *__restrict__ masks, const uint2 *__restrict__ seedq,
+                                                              uint32_t *__restrict__ chunk_tab, uint32_t *__restrict__ pool,
+                                                              DevSegC *__restrict__ segs, DevCounts *__restrict__ counts,
+                                                              DevGlobal *__restrict__ G, const DevParams P)
+{
+    // chunk j = pcx * 8 + (row >> 2 & 7) of lane l (16 bytes: rows 4q..4q+3 of one word column) at s_win[j * 64 + l]
+    __shared__ uint4 s_win_all[SW_WAVES][16 * 64];
+    __shared__ uint8_t s_lut[2048];
+    uint4 *s_win = s_win_all[threadIdx.x >> 6];
+    const uint32_t *s_winw = reinterpret_cast<const uint32_t *>(s_win);
+    const int lane = lane_id();
+    const int lane4 = lane * 4;
+    build_step_lut2(s_lut, threadIdx.x, 64 * SW_WAVES);
+    __syncthreads();
+    int f = blockIdx.y;
+    const unsigned ccap = (unsigned)P.maxContours, pcap = (unsigned)P.maxChunks * (unsigned)P.nframes;
+    const int S = P.nscales, TC = P.TC, TR = P.TR, F = P.nframes;
+    const int W2 = P.W + 2;
+    const int sgm = (8 << P.seedShift) - 1;
+    const int nck = chunk_tab_pitch(P);
+    const long long plane = (long long)TR * TC * MT_ROWS;
+    enum { ST_IDLE = 0, ST_ACTIVE, ST_NEED, ST_LOADING, ST_FINAL };
+#ifdef FID_DEBUG_STATS
+    unsigned long long d_iters = 0, d_ckpts = 0, d_active = 0, d_lanes[4] = {0, 0, 0, 0}, d_ckcyc = 0;
+    const unsigned long long d_t0 = __builtin_readcyclecounter();
+#endif
+
+    unsigned n = 0;
+    const uint2 *fin = seedq;
+    unsigned *qhead = nullptr;
+    auto set_queue = [&](int fr) {
+        n = (unsigned)counts[fr].nseeds;
+        if (n > ccap) {
+            if (lane == 0) atomicOr(&G->overflow, 2u);
+            n = ccap;
+        }
+        fin = seedq + (long long)fr * P.maxContours;
+        qhead = (unsigned *)&counts[fr].nwalk2;
+    };
+    set_queue(f);
+    int all_done = 0;
+    unsigned next = 0, rend = 0, pre_base = 0;
+    int exhausted = 0, pre_ready = 0;
+    uint2 pre = make_uint2(0u, 0u);
+    // per-lane walker
+    int state = ST_IDLE;
+    int lf = f;
+    const uint32_t *pl = masks;
+    unsigned slot = 0;
+    int cx = 0, cy = 0, pc = 0, sdir = 0, count = 0, ok = 0, too_long = 0;
+    int cxp = 0, cyp = 0;            // position at the last checkpoint (net travel decides what is fetched ahead)
+    int br = 0, bc = 0;              // window base: mask tiles (br..br+1) x (bc..bc+1)
+    int pbr = 0, pbc = 0, pend = 0;  // the base the loads in flight will give
+    int vxb = 0, vyb = 0;            // usable part of the window: padded bit / row of its origin ...
+    unsigned vxs = 0, vys = 0;       // ... and extent minus the 3 x 3 footprint
+    unsigned chunkA = 0, chunkB = 0;
+    int kreg = 0;
+    unsigned ovf = 0;
+    unsigned ko = 0xffffffffu, kh = 0xffffffffu, po = 0, ph = 0;
+    unsigned brkey = 0xffffffffu;
+    uint4 quad = make_uint4(0u, 0u, 0u, 0u);
+    unsigned arena_next = 0, arena_end = 0;
+    for (;;) {
+        // ================= checkpoint =================
+#ifdef FID_DEBUG_STATS
+        const unsigned long long d_c0 = __builtin_readcyclecounter();
+        d_ckpts++;
+#endif
+        wait_vmcnt0();
+#ifdef FID_DEBUG_STATS
+        d_lanes[0] += __popcll(ballot64(state == ST_NEED));
+        d_lanes[1] += __popcll(ballot64(state == ST_LOADING));
+        d_lanes[2] += __popcll(ballot64(state == ST_FINAL));
+        d_lanes[3] += __popcll(ballot64(state == ST_IDLE));
+#endif
+        if (next < rend) pre_ready = 1;
+        if (pend) {  // the tiles requested at the last checkpoint have landed: the whole 2 x 2 window is usable
+            pend = 0;
+            br = pbr;
+            bc = pbc;
+            vxb = bc * 32;
+            vyb = br * MT_ROWS;
+            vxs = 64 - 3;
+            vys = 2 * MT_ROWS - 3;
+            if (state == ST_LOADING || state == ST_NEED) {  // (NEED: it stepped off the shared tiles while the new ones were in flight)
+                const unsigned xr = (unsigned)(cx + (MASK_PADW * 32 - 1) - vxb), rr = (unsigned)(cy - vyb);
+                state = (xr > vxs || rr > vys) ? ST_NEED : ST_ACTIVE;
+            }
+        }
+        if ((state == ST_ACTIVE || state == ST_NEED) && count > P.maxPerim) {
+            ok = 0;
+            too_long = 1;
+            state = ST_FINAL;
+        }
+        // ---- retire
+        if (state == ST_FINAL) {
+            const int rem = count & 3, b0 = count - rem;
+            uint32_t *dst = pool + ((b0 & CK ? chunkB : chunkA) << 6) + (unsigned)(b0 & (CK - 1));
+            if (rem >= 1) dst[0] = rem == 1 ? quad.w : rem == 2 ? quad.z : quad.y;
+            if (rem >= 2) dst[1] = rem == 2 ? quad.w : quad.z;
+            if (rem == 3) dst[2] = quad.w;
+            uint4 *r = reinterpret_cast<uint4 *>(segs + (long long)lf * P.maxContours + slot);
+            r[0] = make_uint4(seed_key(cx, cy, sdir), too_long || !ok ? SEG_INVALID : (unsigned)count, ko, kh);
+            r[1] = make_uint4(po | (ph << 16), SEG_INVALID, 0u, 0u);
+            state = ST_IDLE;
+        }
+        // ---- hand out new work
+        int fresh = 0;
+        const unsigned long long idle = ballot64(state == ST_IDLE);
+        if (exhausted && next == rend && !all_done && __popcll(idle) >= WALK_STEAL_MIN) {
+            int nextf = -1;
+            const int hop = (int)((blockIdx.x * SW_WAVES + (threadIdx.x >> 6)) * 37u % (unsigned)F);
+            for (int k0 = 1; k0 < F && nextf < 0; k0 += 64) {
+                const int k = k0 + lane;
+                int has = 0;
+                int fr = (f + hop + k) % F;
+                if (fr == f) fr = -1;
+                if (k < F && fr >= 0) {
+                    const unsigned done = __hip_atomic_load((unsigned *)&counts[fr].nwalk2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    unsigned m = (unsigned)counts[fr].nseeds;
+                    m = m < ccap ? m : ccap;
+                    has = done < m;
+                }
+                const unsigned long long hb = ballot64(has);
+                if (hb) nextf = __shfl(fr, __ffsll((long long)hb) - 1, WAVE);
+            }
+            if (nextf < 0) {
+                all_done = 1;
+            } else {
+                f = nextf;
+                set_queue(f);
+                exhausted = 0;
+                next = rend = 0;
+                pre_ready = 0;
+            }
+        }
+        if (idle) {
+            if (next == rend && !exhausted) {
+                unsigned base = 0;
+                if (lane == 0) base = atomicAdd(qhead, (unsigned)WALK_GRAB);
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (base >= n) {
+                    exhausted = 1;
+                } else {
+                    next = pre_base = base;
+                    rend = base + WALK_GRAB < n ? base + WALK_GRAB : n;
+                    pre_ready = 0;
+                    if (base + lane < rend) pre = fin[n - 1 - (base + lane)];
+                }
+            } else if (next < rend && pre_ready) {
+                const int rank = __popcll(idle & ((1ull << lane) - 1ull));
+                const int src = (int)(next - pre_base) + rank;
+                const unsigned gx = __shfl(pre.x, src & 63, WAVE), gy = __shfl(pre.y, src & 63, WAVE);
+                if (state == ST_IDLE && next + (unsigned)rank < rend) {
+                    slot = n - 1 - (next + (unsigned)rank);
+                    lf = f;
+                    cx = gx & 0x1fff;
+                    cy = (gx >> 13) & 0x1fff;
+                    sdir = (int)(gy & 7u);
+                    pl = masks + ((long long)f * S + (int)(gx >> 27)) * plane;
+                    pc = pidx(cx, cy, P.W);
+                    // the state was entered from the neighbour in direction sdir: travelling the other way
+                    cxp = cx + 2 * dir_dx(sdir);
+                    cyp = cy + 2 * dir_dy(sdir);
+                    count = 0;
+                    ok = 1;
+                    too_long = 0;
+                    ko = kh = 0xffffffffu;
+                    po = ph = 0;
+                    brkey = 0xffffffffu;
+                    kreg = 1;
+                    fresh = 1;
+                    state = ST_NEED;
+                }
+                const unsigned nidle = (unsigned)__popcll(idle);
+                next = next + nidle < rend ? next + nidle : rend;
+            }
+        }
+        // ---- pool chunks
+        {
+            const int want1 = !fresh && (state == ST_ACTIVE || state == ST_NEED || state == ST_LOADING) && (count >> 6) == kreg;
+            const unsigned long long b1 = ballot64(want1), b2 = ballot64(fresh);
+            const unsigned total = (unsigned)__popcll(b1) + 2u * (unsigned)__popcll(b2);
+            if (total) {
+                if (arena_next + total > arena_end) {
+                    unsigned base = 0;
+                    if (lane == 0) base = atomicAdd((unsigned *)&counts[0].npool, (unsigned)WALK_ARENA);
+                    arena_next = __builtin_amdgcn_readfirstlane(base);
+                    arena_end = arena_next + WALK_ARENA;
+                }
+                const unsigned long long lt = (1ull << lane) - 1ull;
+                const unsigned mine = arena_next + (unsigned)__popcll(b1 & lt) + 2u * (unsigned)__popcll(b2 & lt);
+                arena_next += total;
+                if (fresh || want1) {
+                    uint32_t *trow = chunk_tab + ((long long)lf * 2 * P.maxContours + slot) * nck;
+                    if (mine + 1 >= pcap) {
+                        ovf |= 8u;
+                        segs[(long long)lf * P.maxContours + slot].n = SEG_INVALID;
+                        state = ST_IDLE;
+                        pend = 0;
+                    } else if (fresh) {
+                        chunkA = mine;
+                        chunkB = mine + 1;
+                        trow[0] = chunkA;
+                        trow[1] = chunkB;
+                    } else {
+                        kreg++;
+                        if (kreg & 1) chunkB = mine;
+                        else chunkA = mine;
+                        trow[kreg] = mine;
+                    }
+                }
+            }
+        }
+        // ---- windows: walkers outside theirs get a new one around them, travelling walkers get the tiles ahead
+        {
+            const bool had = state == ST_ACTIVE;
+            const bool mv = had || state == ST_NEED;
+            int nbr = br, nbc = bc;
+            if (mv) {
+                const int xb = cx + (MASK_PADW * 32 - 1), yy = cy;  // padded bit of x-1, padded row of y-1
+                const int sdx = cx - cxp, sdy = cy - cyp;
+                if (had) {
+                    nbr = sdy >= 2 ? (yy >> 4) : sdy <= -2 ? ((yy + 2) >> 4) - 1 : br;
+                    nbc = sdx >= 2 ? (xb >> 5) : sdx <= -2 ? ((xb + 2) >> 5) - 1 : bc;
+                } else {
+                    nbr = sdy > 0 ? (yy >> 4) : sdy < 0 ? ((yy + 2) >> 4) - 1 : ((yy & 15) >= 8 ? (yy >> 4) : (yy >> 4) - 1);
+                    nbc = sdx > 0 ? (xb >> 5) : sdx < 0 ? ((xb + 2) >> 5) - 1 : ((xb & 31) >= 16 ? (xb >> 5) : (xb >> 5) - 1);
+                }
+                nbr = nbr < 0 ? 0 : (nbr > TR - 2 ? TR - 2 : nbr);
+                nbc = nbc < 0 ? 0 : (nbc > TC - 2 ? TC - 2 : nbc);
+                cxp = cx;
+                cyp = cy;
+            }
+            const bool moved = mv && (!had || nbr != br || nbc != bc);
+            if (ballot64(moved)) {
+                static_for<4>([&](auto sc) {
+                    constexpr int s = decltype(sc)::value, pr = s >> 1, pcx = s & 1;
+                    const int ntr = nbr + ((pr ^ nbr) & 1), ntc = nbc + ((pcx ^ nbc) & 1);
+                    const int otr = br + ((pr ^ br) & 1), otc = bc + ((pcx ^ bc) & 1);
+                    if (moved && (!had || ntr != otr || ntc != otc)) {
+                        const uint32_t *g = pl + ((long long)ntr * TC + ntc) * MT_ROWS;
+                        static_for<4>([&](auto qc) {
+                            constexpr int q = decltype(qc)::value;
+                            // (the instruction offset moves the LDS destination as well as the source: compensate in the base)
+                            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                                             (__attribute__((address_space(3))) void *)((char *)s_win + (pcx * 8 + pr * 4 + q) * 1024 - q * 16),
+                                                             16, q * 16, 0);
+                        });
+                    }
+                });
+                if (moved) {
+                    pend = 1;
+                    pbr = nbr;
+                    pbc = nbc;
+                    if (had) {
+                        // until they land the walker keeps the tiles both windows share (it stands on them: a window only ever
+                        // moves one tile, towards the side the walker is on)
+                        const int r0 = nbr > br ? nbr : br, c0 = nbc > bc ? nbc : bc;
+                        vyb = r0 * MT_ROWS;
+                        vys = (unsigned)((nbr == br ? 2 : 1) * MT_ROWS - 3);
+                        vxb = c0 * 32;
+                        vxs = (unsigned)((nbc == bc ? 2 : 1) * 32 - 3);
+                        const unsigned xr = (unsigned)(cx + (MASK_PADW * 32 - 1) - vxb), rr = (unsigned)(cy - vyb);
+                        if (xr > vxs || rr > vys) state = ST_LOADING;
+                    } else {
+                        state = ST_LOADING;
+                    }
+                }
+            }
+        }
+#ifdef FID_DEBUG_STATS
+        d_ckcyc += __builtin_readcyclecounter() - d_c0;
+#endif
+        if (all_done && ballot64(state != ST_IDLE) == 0) break;
+        // ================= steps =================
+        const int work_left = !all_done;
+        for (int it = 0; it < SW_RUN; it++) {
+            const unsigned long long act = ballot64(state == ST_ACTIVE);
+            if (it >= SW_CKPT && ballot64(state != ST_ACTIVE && (state != ST_IDLE || work_left))) break;
+            if (act == 0) break;
+#ifdef FID_DEBUG_STATS
+            d_iters++;
+            d_active += __popcll(act);
+#endif
+            if (state == ST_ACTIVE) {
+                const int xb = cx + (MASK_PADW * 32 - 1);
+                const int sh = xb & 31;
+                const bool odd = (xb >> 5) & 1;
+                unsigned t3[3];
+#pragma unroll
+                for (int d = 0; d < 3; d++) {
+                    const int r = cy + d;
+                    const int idx = ((r << 6) & 0x700) | (r & 3) | lane4;
+                    const uint32_t wa = s_winw[idx], wb = s_winw[idx + 2048];
+                    t3[d] = __builtin_amdgcn_alignbit(odd ? wa : wb, odd ? wb : wa, sh);
+                }
+                const unsigned raw = (t3[0] & 7u) | ((t3[1] & 1u) << 3) | ((t3[1] & 4u) << 2) | ((t3[2] & 7u) << 5);
+                const unsigned e = s_lut[raw | ((unsigned)sdir << 8)];
+                const unsigned skey = seed_key(cx, cy, sdir);
+                const bool onseed = ((e & 0x20u) && (cx & sgm) == 0) || ((e & 0x40u) && (cy & sgm) == 0);
+                if (count > 0 && onseed) {
+                    state = ST_FINAL;  // the next seed state: the segment ends in front of it
+                } else if (count > 0 && skey == brkey) {
+                    ok = 0;  // Brent's cycle test: a seed that is no border state went round a border without seeds
+                    state = ST_FINAL;
+                } else {
+                    if ((count & (count - 1)) == 0) brkey = skey;
+                    {
+                        const bool lo = (e & 8u) && (unsigned)pc < ko, lh = (e & 16u) && (unsigned)pc + 1u < kh;
+                        ko = lo ? (unsigned)pc : ko;
+                        po = lo ? (unsigned)count : po;
+                        kh = lh ? (unsigned)pc + 1u : kh;
+                        ph = lh ? (unsigned)count : ph;
+                    }
+                    quad.x = quad.y;
+                    quad.y = quad.z;
+                    quad.z = quad.w;
+                    quad.w = (uint32_t)cx | ((uint32_t)cy << 16);
+                    if ((count & 3) == 3)
+                        *reinterpret_cast<uint4 *>(pool + ((count & CK ? chunkB : chunkA) << 6) + (unsigned)(count & (CK - 4))) = quad;
+                    count++;
+                    const int sn = e & 7;
+                    const int dx = dir_dx(sn), dy = dir_dy(sn);
+                    cx += dx;
+                    cy += dy;
+                    pc += __mul24(dy, W2) + dx;
+                    sdir = sn ^ 4;
+                    const unsigned xr = (unsigned)(cx + (MASK_PADW * 32 - 1) - vxb), rr = (unsigned)(cy - vyb);
+                    state = (xr > vxs || rr > vys) ? ST_NEED : ST_ACTIVE;
+                }
+            }
+        }
+    }
+    if (ovf) atomicOr(&G->overflow, ovf);
+#ifdef FID_DEBUG_STATS
+    if (lane == 0) {
+        atomicAdd(&G->dbg[0], d_iters);
+        atomicAdd(&G->dbg[1], d_ckpts);
+        atomicAdd(&G->dbg[2], d_active);
+        atomicAdd(&G->dbg[3], d_ckcyc);
+        atomicAdd(&G->dbg[6], (unsigned long long)(__builtin_readcyclecounter() - d_t0));
+        atomicAdd(&G->dbg[7], 1ull);
+        for (int k = 0; k < 4; k++) atomicAdd(&G->dbg[21 + k], d_lanes[k]);
+    }
+#endif
+}
+
+__global__ __launch_bounds__(256) void k_seg_link2(const uint2 *__restrict__ seedq, DevSegC *__restrict__ segs,
+                                                    const unsigned long long *__restrict__ seedhash, const DevCounts *__restrict__ counts,
+                                                    const DevParams P)
+{
+    const int f = blockIdx.y;
+    unsigned ns = (unsigned)counts[f].nseeds;
+    ns = ns < (unsigned)P.maxContours ? ns : (unsigned)P.maxContours;
+    const unsigned long long *fsh = seedhash + (long long)f * P.seedHashCap;
+    const uint2 *fsq = seedq + (long long)f * P.maxContours;
+    DevSegC *fsg = segs + (long long)f * P.maxContours;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < ns; i += gridDim.x * blockDim.x) {
+        if (fsg[i].n == SEG_INVALID) continue;  // (abandoned: too long, pool exhausted -- its border cannot be accepted)
+        const unsigned nx = seedhash_find(fsh, P.seedHashCap, P.seedGen, seedhash_key(fsg[i].next_key, (int)(fsq[i].x >> 27)));
+        if (nx < ns) {
+            fsg[i].next_idx = nx;
+            fsg[nx].linked = 1u;
+        }
+    }
+}
+
+// One lane per segment (then one per probe survivor that closed a seedless border by itself).  A segment knows the smallest
+// outer-start key ko and hole-start key kh among its own states; it goes once around its cycle while one of the two is still
+// the smallest seen.  The cycle is an outer border iff min ko < min kh, and then starts at the state with min ko; else a hole
+// border that starts at the state with min kh -- so exactly one lane per cycle ends up accepting, the one whose segment holds
+// the canonical start.  It then lists the pieces: its own segment from the start state on, the other segments in cycle order,
+// its own segment up to the start state.
+__global__ __launch_bounds__(64) void k_seg_cycles(const uint2 *__restrict__ seedq, const DevSegC *__restrict__ segs,
+                                                    const DevPend *__restrict__ pend, const uint4 *__restrict__ wres,
+                                                    uint4 *__restrict__ contours, uint4 *__restrict__ cinfo, uint32_t *__restrict__ cbase,
+                                                    uint4 *__restrict__ recs, DevCounts *__restrict__ counts, DevGlobal *__restrict__ G,
+                                                    const DevParams P)
+{
+    const int f = blockIdx.y;
+    const int lane = lane_id();
+    unsigned ns = (unsigned)counts[f].nseeds, nv = (unsigned)counts[f].nsurv;
+    ns = ns < (unsigned)P.maxContours ? ns : (unsigned)P.maxContours;
+    nv = nv < (unsigned)P.maxContours ? nv : (unsigned)P.maxContours;
+    const uint2 *fsq = seedq + (long long)f * P.maxContours;
+    const DevSegC *fsg = segs + (long long)f * P.maxContours;
+    const DevPend *fpd = pend + (long long)f * P.maxContours;
+    uint4 *fco = contours + (long long)f * P.maxContours;
+    uint4 *fci = cinfo + (long long)f * P.maxContours;
+    uint32_t *fcb = cbase + (long long)f * P.maxContours;
+    uint4 *frc = recs + (long long)f * 2 * P.maxContours;
+    const unsigned dcap = (unsigned)P.maxChunks * CK, rcap = 2u * (unsigned)P.maxContours;
+    const unsigned W2 = (unsigned)P.W + 2u;
+    for (unsigned i0 = blockIdx.x * 64; i0 < ns + nv; i0 += gridDim.x * 64) {
+        const unsigned i = i0 + lane;
+        int accept = 0, hole = 0;
+        unsigned L = 0, key = 0, hops = 0, pos = 0, n0 = 0, nx0 = SEG_INVALID;
+        uint2 st = make_uint2(0u, 0u);
+        if (i < ns) {
+            const DevSegC s = fsg[i];
+            if (s.n != SEG_INVALID && s.n != 0u && s.linked && (s.ko & s.kh) != 0xffffffffu) {
+                bool co = s.ko != 0xffffffffu, ch = s.kh != 0xffffffffu, closed = false;
+                unsigned KO = s.ko, KH = s.kh, cur = s.next_idx;
+                L = s.n;
+                hops = 1;
+                while (cur != SEG_INVALID) {
+                    if (cur == i) {
+                        closed = true;
+                        break;
+                    }
+                    const DevSegC r = fsg[cur];
+                    if (r.n == SEG_INVALID || r.n == 0u) break;
+                    co = co && !(r.ko < s.ko);
+                    ch = ch && !(r.kh < s.kh);
+                    if (!co && !ch) break;  // both candidates beaten: another segment holds the start
+                    KO = r.ko < KO ? r.ko : KO;
+                    KH = r.kh < KH ? r.kh : KH;
+                    L += r.n;
+                    hops++;
+                    if (L > (unsigned)P.maxPerim) break;
+                    cur = r.next_idx;
+                }
+                if (closed && L >= (unsigned)P.minPerim && L <= (unsigned)P.maxPerim) {
+                    if (co && KO < KH) {
+                        accept = 1;
+                        hole = 0;
+                        key = s.ko;
+                        pos = s.pos & 0xffffu;
+                    } else if (ch && KH < KO) {
+                        accept = 1;
+                        hole = 1;
+                        key = s.kh;
+                        pos = s.pos >> 16;
+                    }
+                }
+                if (accept) {
+                    n0 = s.n;
+                    nx0 = s.next_idx;
+                    const unsigned ky = key / W2, kx = key - ky * W2;  // padded raster index -> pixel (hole: the pixel left of it)
+                    st = make_uint2((kx - 1u - (unsigned)hole) | ((ky - 1u) << 16), (uint32_t)f | ((fsq[i].x >> 27) << 16) | ((uint32_t)hole << 24));
+                }
+            }
+        } else if (i < ns + nv) {
+            const unsigned j = i - ns;
+            if (!fpd[j].p) {  // decided by the survivor walk itself (a border without seeds): accepted iff it left a length
+                const uint4 w = wres[(long long)f * P.maxContours + j];
+                if (w.z) {
+                    st = make_uint2(w.x, w.y);
+                    L = w.z;
+                    key = w.w;
+                    accept = 2;
+                }
+            }
+        }
+        const unsigned long long mk = ballot64(accept);
+        if (mk) {
+            const unsigned myL = accept ? L : 0u, myR = accept == 1 ? hops + 1u : (accept == 2 ? 1u : 0u);
+            const unsigned sL = wave_iscan_dpp(myL), sR = wave_iscan_dpp(myR);
+            const unsigned totL = (unsigned)__builtin_amdgcn_readlane((int)sL, 63), totR = (unsigned)__builtin_amdgcn_readlane((int)sR, 63);
+            unsigned bslot = 0, bdense = 0, brec = 0;
+            if (lane == 63) {
+                bslot = atomicAdd((unsigned *)&counts[f].ncontours, (unsigned)__popcll(mk));
+                bdense = atomicAdd((unsigned *)&counts[f].ndense, totL);
+                brec = atomicAdd((unsigned *)&counts[f].nrec, totR);
+            }
+            bslot = (unsigned)__builtin_amdgcn_readlane((int)bslot, 63);
+            bdense = (unsigned)__builtin_amdgcn_readlane((int)bdense, 63);
+            brec = (unsigned)__builtin_amdgcn_readlane((int)brec, 63);
+            const unsigned idx = bslot + (unsigned)__popcll(mk & ((1ull << lane) - 1ull));
+            if (accept) {
+                if (idx < (unsigned)P.maxContours) {
+                    fco[idx] = make_uint4(st.x, st.y, L, key);
+                    fci[idx] = make_uint4(i, pos, nx0, 0u);
+                    const unsigned dst0 = bdense + sL - myL;
+                    unsigned rec = brec + sR - myR;
+                    if (dst0 + L > dcap || rec + myR > rcap) {
+                        atomicOr(&G->overflow, 8u);
+                        fcb[idx] = SEG_INVALID;
+                    } else if (accept == 2) {
+                        fcb[idx] = dst0;
+                        frc[rec] = make_uint4((unsigned)P.maxContours + (i - ns), dst0, L, 0u);
+                    } else {
+                        fcb[idx] = dst0;
+                        frc[rec++] = make_uint4(i, dst0, n0 - pos, pos);  // from the start state to the end of its segment
+                        unsigned off = n0 - pos, cur = nx0;
+                        while (cur != i && cur != SEG_INVALID && off < L) {
+                            const DevSegC r = fsg[cur];
+                            frc[rec++] = make_uint4(cur, dst0 + off, r.n, 0u);
+                            off += r.n;
+                            cur = r.next_idx;
+                        }
+                        frc[rec++] = make_uint4(i, dst0 + off, pos, 0u);  // ... and the states in front of it
+                        for (; rec < brec + sR; rec++) frc[rec] = make_uint4(0u, 0u, 0u, 0u);
+                    }
+                } else {
+                    atomicOr(&G->overflow, 2u);
+                }
+            }
+        }
     }
 }
 

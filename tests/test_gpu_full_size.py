@@ -72,3 +72,33 @@ def test_cfg3_the_benchmarked_batch_equals_the_oracle_frame_by_frame():
         assert np.array_equal(res[f][0], ocorners), f
         for i, (r, t, e) in enumerate(oposes):
             assert np.abs(poses[f].rvecs[i] - r).max() < 1e-6 and np.abs(poses[f].tvecs[i] - t).max() < 1e-6, (f, i)
+
+
+def test_cfg4_the_sharded_streams_equal_the_oracle():
+    """BASELINE cfg 4: eight camera streams, stream s -> GPU s, seeds bench.shard_seeds(s, 8, n) = 10000 s + i (round 2 only
+    ever compared the cfg 3 seeds 1000 + i with the oracle).  The first four frames of every stream, as `bench.py --gpus 8`
+    generates them, through one 32-frame batch: ids and corners `==` the oracle's, rvec / tvec within 1e-6, and the frames of
+    different streams really differ."""
+    import multiprocessing as mp
+    import os
+
+    torch = pytest.importorskip("torch")
+    import bench
+
+    seeds = [sd for s in range(8) for sd in bench.shard_seeds(s, 8, 4)]
+    assert seeds[:5] == [0, 1, 2, 3, 10000] and len(set(seeds)) == 32
+    frames = bench.make_frames(seeds)
+    assert len({frames[k].tobytes() for k in range(32)}) == 32
+    dev = torch.from_numpy(frames).cuda()
+    det = ArucoDetector(6, max_width=1920, max_height=1080, max_batch=32, max_markers=64)
+    res = det.detect_markers_device(dev.data_ptr(), 32, 1920, 1080)
+    poses = det.pose_last(0.14, K_DEFAULT, np.zeros(5))
+    det.close()
+    with mp.get_context("fork").Pool(max(1, min(32, os.cpu_count() or 1))) as pool:
+        ora = pool.map(_oracle_one, [(frames[f], K_DEFAULT) for f in range(32)], chunksize=1)
+    for f in range(32):
+        oids, ocorners, oposes = ora[f]
+        assert res[f][1].tolist() == oids.tolist() and len(oids) == 20, (seeds[f], res[f][1].tolist(), oids.tolist())
+        assert np.array_equal(res[f][0], ocorners), seeds[f]
+        for i, (r, t, e) in enumerate(oposes):
+            assert np.abs(poses[f].rvecs[i] - r).max() < 1e-6 and np.abs(poses[f].tvecs[i] - t).max() < 1e-6, (seeds[f], i)

@@ -300,9 +300,10 @@ def test_detector_parameter_matrix(k, dic):
 
 
 def test_whole_border_walk_and_seed_tracing_agree(monkeypatch):
-    """The two contour-tracing paths of the library (FID_TRACE=legacy: probe passes + whole-border walk;
-    default: seed-accelerated tracing) must both reproduce the oracle stage by stage, on adversarial blobs
-    (rings, 1-px lines, large blobs longer than maxMarkerPerimeterRate), on a noisy frame and in a batch."""
+    """The three contour-tracing paths of the library (FID_TRACE=legacy: probe passes + whole-border walk; chain: round 2's
+    seed tracing, every border found by a probe survivor; default = cycles: borders read off the seed cycles, starts only for
+    borders without a seed) must all reproduce the oracle stage by stage, on adversarial blobs (rings, 1-px lines, large
+    blobs longer than maxMarkerPerimeterRate), on a noisy frame and in a batch."""
     rng = np.random.default_rng(5)
     blobs = np.full((720, 1280), 190, np.uint8)
     for _ in range(150):
@@ -312,7 +313,7 @@ def test_whole_border_walk_and_seed_tracing_agree(monkeypatch):
     blobs = np.clip(blobs.astype(np.int32) + rng.integers(-6, 7, blobs.shape), 0, 255).astype(np.uint8)
     d = get_predefined_dictionary(6)
     fr = make_frame(d, 77, width=1280, height=720, n_markers=8)
-    for mode in ("legacy", "seeds"):
+    for mode in ("legacy", "chain", "cycles"):
         monkeypatch.setenv("FID_TRACE", mode)
         det = ArucoDetector(6, max_width=1280, max_height=720, max_batch=3)
         try:
@@ -326,6 +327,72 @@ def test_whole_border_walk_and_seed_tracing_agree(monkeypatch):
             assert res[1][1].tolist() == bids.tolist()
         finally:
             det.close()
+
+
+def _cell_cases(w=1280, h=720):
+    """Shapes that stress cycle tracing: borders that live INSIDE one cell of the seed grid (no seed state: found by a
+    start), borders that touch a grid line in one pixel, borders that run along grid lines, one-pixel-wide rings and spirals
+    (pixels visited twice, outer and hole border through the same pixels), nested holes, quads whose raster-first pixel sits
+    on a grid line / a grid crossing."""
+    rng = np.random.default_rng(11)
+    img = np.full((h, w), 200, np.uint8)
+
+    def rect(x0, y0, x1, y1, v=30):
+        img[y0:y1, x0:x1] = v
+
+    # jagged squares strictly inside 64 px and 128 px cells: contour size above minMarkerPerimeterRate * 1280 = 128
+    for cx0, cy0 in ((70, 70), (70 + 128, 72), (200 + 256, 8 + 128), (3 * 128 + 10, 3 * 128 + 12)):
+        rect(cx0, cy0, cx0 + 46, cy0 + 46)
+        for k in range(4, 42, 4):  # notches two pixels deep on all four sides
+            img[cy0:cy0 + 2, cx0 + k] = 200
+            img[cy0 + 44:cy0 + 46, cx0 + k + 1] = 200
+            img[cy0 + k, cx0:cx0 + 2] = 200
+            img[cy0 + k + 1, cx0 + 44:cx0 + 46] = 200
+    # squares whose first pixel is ON a grid column / row / crossing (spacings 32 ... 256 all divide 256)
+    rect(256, 300, 256 + 60, 360)
+    rect(520, 256, 580, 256 + 60)
+    rect(768, 512, 768 + 70, 512 + 70)
+    rect(1023 - 50, 255 - 50, 1024, 256)  # last pixel one short of a crossing
+    # a frame (ring) 3 px wide with a hole, nested frame inside it, one-pixel-wide ring next to it
+    rect(600, 380, 760, 500)
+    rect(603, 383, 757, 497, 200)
+    rect(620, 400, 740, 480)
+    rect(640, 415, 720, 465, 200)
+    img[540:620, 900] = 30
+    img[540:620, 980] = 30
+    img[540, 900:981] = 30
+    img[619, 900:981] = 30
+    # a one-pixel-wide spiral inside a 128 px cell (a long border without a seed at the coarse spacings)
+    x0, y0 = 128 * 6 + 6, 128 + 6
+    for k in range(0, 56, 4):
+        img[y0 + k, x0 + k:x0 + 116 - k] = 30
+        img[y0 + k:y0 + 116 - k, x0 + 115 - k] = 30
+        img[y0 + 115 - k, x0 + k + 4:x0 + 116 - k] = 30
+        img[y0 + k + 4:y0 + 116 - k, x0 + k + 4] = 30
+    # bars that run along grid lines
+    rect(100, 383, 500, 386)
+    rect(383, 420, 386, 700)
+    img = np.clip(img.astype(np.int32) + rng.integers(-3, 4, img.shape), 0, 255).astype(np.uint8)
+    return img
+
+
+@pytest.mark.parametrize("shift", [2, 3, 4, 5])
+def test_cycle_tracing_cell_cases_every_seed_spacing(monkeypatch, shift):
+    """Cycle tracing (the default) must give the oracle's candidates -- contour size, first point, hole flag, corners --
+    whatever the seed grid spacing (32 ... 256 px): the same shapes are then seed cycles, seedless borders, or borders that
+    touch the grid in a single state."""
+    d = get_predefined_dictionary(6)
+    img = _cell_cases()
+    fr = make_frame(d, 23, width=1280, height=720, n_markers=10)
+    monkeypatch.setenv("FID_SEED_SHIFT", str(shift))
+    det = ArucoDetector(6, max_width=1280, max_height=720, max_batch=2, max_contours=65536, max_points=1 << 22)
+    try:
+        check_stages(det, img, d)
+        check_stages(det, fr.image, d)
+        check_stages(det, np.ascontiguousarray(img[::-1, ::-1]), d)
+        check_stages(det, np.ascontiguousarray(img.T[:720, :720]), d)
+    finally:
+        det.close()
 
 
 def test_too_close_filter_both_paths(monkeypatch):
@@ -359,7 +426,7 @@ def test_internal_capacity_is_reported_not_silent(monkeypatch):
     from fiducials_amd._lib import FidError
     d = get_predefined_dictionary(6)
     fr = make_frame(d, 3, width=1280, height=720, n_markers=8)
-    for mode in ("legacy", "seeds"):
+    for mode in ("legacy", "chain", "cycles"):
         monkeypatch.setenv("FID_TRACE", mode)
         det = ArucoDetector(6, max_width=1280, max_height=720, max_contours=96)
         try:

@@ -380,6 +380,34 @@ def test_detect_markers_refined_matches_reference(hd, ec, size, n, seed):
         det.close()
 
 
+def test_reference_fixture_pdf_pages_on_the_device():
+    """The reference's only STag fixtures (stag_detect/test/test.pdf: 15 HD11 rasters, printed labels 00000...00014;
+    tests/golden/stag_hd11_pdf.npz) through fid_stag_detect_markers with the shipped launch parameters (libraryHD 11,
+    errorCorrection 2, stag_detect.launch:9): the id read on the device == the label printed on the page == what the
+    reference's own detector returns (oracle/_ref when built, else the output committed with the fixture), corners and centre
+    within the refined path's stated 1e-3 px."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "stag_hd11_pdf.npz"))
+    det = fstag.StagDetector(11, 2, max_width=1000, max_height=1000)
+    try:
+        for page in range(15):
+            M = det.detect_markers(z["gray"][page])
+            ref = stag_ref.detect_markers(z["gray"][page], 11, 2) if stag_ref.available() else z["ref_markers"][page][None, :]
+            assert np.array_equal(ref[0], z["ref_markers"][page])
+            assert len(M) == 1 and int(M["id"][0]) == page == int(z["labels"][page]) == int(ref[0, 0])
+            assert np.abs(M["corners"].reshape(-1, 8) - ref[:, 1:9]).max() < 1e-3
+            assert np.abs(M["center"] - ref[:, 9:11]).max() < 1e-3
+        # and the unrefined stage, where every double is compared with ==
+        if stag_ref.available():
+            for page in (0, 7, 14):
+                det.detect_markers_unrefined(z["gray"][page])
+                got = _markers_as_table(det.markers())
+                ref = stag_ref.detect_markers(z["gray"][page], 11, 2, refine=False)
+                assert got.shape == ref.shape and (got == ref).all()
+    finally:
+        det.close()
+
+
 def test_marker_pose_matches_oracle():
     """Row s10: Common::solvePnpSingle on centre + four corners (5 coplanar points), against the oracle's restatement of
     cv::solvePnP(ITERATIVE) fed with the same markers: rotation matrix / tvec to 1e-6 (the device starts its Levenberg-Marquardt from a

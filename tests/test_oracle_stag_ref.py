@@ -122,3 +122,21 @@ def test_host_made_tables_equal_the_references(size):
             assert stag_ref.nfa_valid(nn, km, w, h) and (km == 0 or not stag_ref.nfa_valid(nn, km - 1, w, h)), nn
         else:
             assert not stag_ref.nfa_valid(nn, nn, w, h), nn
+
+
+def test_reference_fixture_pdf_pages_read_back_their_printed_labels():
+    """The reference's ONLY STag ground truth: stag_detect/test/test.pdf, 15 HD11 rasters with printed labels 00000...00014
+    (tests/golden/stag_hd11_pdf.npz, tools/make_stag_golden.py).  The reference's own detector
+    (oracle/_ref) with the shipped launch parameters (libraryHD 11, errorCorrection 2: stag_detect.launch:9) must read the
+    printed label off every page, and reproduce the output that was committed with the fixture."""
+    _need_ref()
+    import os
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "stag_hd11_pdf.npz"))
+    hd, ec = int(z["library_hd"]), int(z["error_correction"])
+    assert (hd, ec) == (11, 2)
+    for page in range(15):
+        m = stag_ref.detect_markers(z["gray"][page], hd, ec)
+        assert m.shape[0] == 1 and int(m[0, 0]) == int(z["labels"][page]) == page
+        assert np.array_equal(m[0], z["ref_markers"][page])
+        # the page is a 1000 x 1000 raster of the marker with a 10 % quiet zone: corners near (100, 100) ... (900, 900)
+        assert np.abs(m[0, 1:9] - np.array([100, 100, 900, 100, 900, 900, 100, 900])).max() < 1.0

@@ -14,9 +14,12 @@
 
 namespace {
 
-enum { ST_GRAY = 0, ST_THRESH, ST_STARTS, ST_PROBE, ST_WALK, ST_APPROX, ST_SORT, ST_NEAR, ST_RESOLVE, ST_IDENT, ST_FILTER, ST_SUBPIX, ST_POSE, ST_SEEDWALK, ST_COUNT };
+enum { ST_GRAY = 0, ST_THRESH, ST_STARTS, ST_PROBE, ST_WALK, ST_APPROX, ST_SORT, ST_NEAR, ST_RESOLVE, ST_IDENT, ST_FILTER, ST_SUBPIX, ST_POSE, ST_SEEDWALK,
+       ST_SEEDLESS, ST_COUNT };
+// (trace mode 2: walk_probe / walk_full / approx are the main stream's seed walk / link + cycles + copy / approx of the seed
+//  cycles; seedless_chain is the auxiliary stream's probes + survivor walk + cycles + copy + approx beside them)
 const char *const kStageNames[ST_COUNT] = {"to_gray", "threshold", "find_starts", "walk_probe", "walk_full", "approx", "sort_cands",
-                                           "near", "resolve", "identify", "filter_markers", "subpix", "pose", "seed_walk"};
+                                           "near", "resolve", "identify", "filter_markers", "subpix", "pose", "seed_walk", "seedless_chain"};
 
 constexpr int TX = 128, TY = 32, NT = 256;
 
@@ -28,13 +31,13 @@ struct fid_ctx {
     enum { MAX_SUB = 8 };
     hipStream_t sub_stream[MAX_SUB] = {};  // sub-batches of one call run on these, overlapping each other's tails
     hipStream_t aux_stream[MAX_SUB] = {};  // per sub-batch: the seed walk runs here, beside the probe passes and the survivor walk
-    hipEvent_t aux_fork[MAX_SUB] = {}, aux_join[MAX_SUB] = {};
+    hipEvent_t aux_fork[MAX_SUB] = {}, aux_join[MAX_SUB] = {}, aux_idx[MAX_SUB] = {};
     hipEvent_t sub_done[MAX_SUB] = {}, fork_ev = nullptr;
     hipEvent_t walk_done[MAX_SUB] = {};     // a sub-batch has left its contour stage (staggered starts, FID_STAGGER)
     int stagger = 0;                        // sub-batch k starts when sub-batch k - stagger has left its contour stage (0: all at once)
     int resolve_lds_kb = 64;
     int walk2_div = 2;
-    hipEvent_t sub_ev[MAX_SUB][16] = {};   // per sub-batch stage boundaries (FID_PROFILE)
+    hipEvent_t sub_ev[MAX_SUB][20] = {};   // per sub-batch stage boundaries (FID_PROFILE)
     int sub_frames = 0;                    // frames per sub-batch (0 = automatic)
     fid_params params;
     fid_limits lim;
@@ -95,6 +98,11 @@ struct fid_ctx {
     DevCounts *h_counts = nullptr;
     DevGlobal *h_global = nullptr;
     fid_pose_out *h_poses = nullptr;
+    // the camera of the last fid_pose_last call: the next fid_detect_* runs k_pose for it at the end of every sub-batch's stream
+    // (under the other sub-batch's tail instead of after everything, and without a second host round trip); fid_pose_last with the
+    // same camera then only hands the results over.  Same kernel, same arithmetic, same results.
+    bool pose_cam_valid = false, pose_done = false;
+    double pose_K[9] = {}, pose_D[5] = {}, pose_len = 0.;
     // last call
     int last_frames = 0, last_W = 0, last_H = 0, last_nsub = 1;
     const uint8_t *last_gray = nullptr;
@@ -253,6 +261,7 @@ fid_status run_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H, int
     if (stride < W * bpp) return FID_E_INVALID_ARG;
     if ((unsigned)(c->params.maxMarkerPerimeterRate * (W > H ? W : H)) > 36000u) return FID_E_UNSUPPORTED;  // contour points live in LDS
     hipStream_t st0 = c->stream;
+    c->pose_done = false;
     // ---- K0 geometry: mono8 device input is used in place (any stride); colour goes through k_to_gray
     const bool to_gray = enc != FID_ENC_MONO8;
     const int gstride = to_gray ? W : stride;
@@ -292,14 +301,17 @@ fid_status run_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H, int
     }
     c->last_nsub = nsub;
     if (nsub > 1) HIPCHK(c, hipEventRecord(c->fork_ev, st0));
-    for (int sb = 0; sb < nsub; sb++) {
+    // The host enqueues in two rounds: first every sub-batch's gray conversion + threshold, then every sub-batch's rest.  (One
+    // round -- a whole sub-batch, some thirty launches, before the next one's first kernel -- left the second sub-batch's stream
+    // empty for the first 0.35 - 0.6 ms of every step.)
+    auto sub_phase = [&](int sb, int phase) -> fid_status {
         const int f0 = sb * per, Fs = (f0 + per <= F ? per : F - f0);
         hipStream_t st = nsub > 1 ? c->sub_stream[sb] : st0;
-        if (nsub > 1) HIPCHK(c, hipStreamWaitEvent(st, c->fork_ev, 0));
+        if (nsub > 1 && phase == 0) HIPCHK(c, hipStreamWaitEvent(st, c->fork_ev, 0));
         // staggered starts: the contour stage of a sub-batch (threshold ... approx) keeps the whole chip busy, what follows
         // (candidates, identification, corners) is a chain of short latency-bound kernels -- let the next sub-batch's contour
         // stage run under that tail instead of beside another contour stage
-        if (nsub > 1 && c->stagger > 0 && sb >= c->stagger) HIPCHK(c, hipStreamWaitEvent(st, c->walk_done[sb - c->stagger], 0));
+        if (nsub > 1 && phase == 0 && c->stagger > 0 && sb >= c->stagger) HIPCHK(c, hipStreamWaitEvent(st, c->walk_done[sb - c->stagger], 0));
         DevParams P = c->P;
         P.nframes = Fs;
         const size_t MC = (size_t)P.maxCands, MM = (size_t)P.maxMarkers;
@@ -320,6 +332,7 @@ fid_status run_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H, int
         auto mark = [&](int idx) {
             if (c->profile) (void)hipEventRecord(ev[idx], st);
         };
+      if (phase == 0) {
         mark(0);
         if (to_gray)
             hipLaunchKernelGGL(k_to_gray, dim3(2048), dim3(256), 0, st, d_src + (long long)f0 * fstride, stride, fstride, (int)enc,
@@ -358,6 +371,8 @@ fid_status run_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H, int
             }
         }
         mark(ST_THRESH + 1);
+        return FID_OK;
+      }
         // ---- K2
         long long k2blocks;
         {
@@ -408,8 +423,11 @@ fid_status run_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H, int
                                seedq, P);
             mark(ST_STARTS + 1);
           if (c->trace_mode == 2) {
-            // ---- cycle tracing: the seeds walk their segments (own stream) while the starts are sieved for the borders that
-            //      have no seed state; every other border is read off the segment cycles
+            // ---- cycle tracing.  Main stream: the seeds walk their segments, link, the cycles become contour list A, copy,
+            //      approxPolyDP.  Auxiliary stream, beside it: seed index, then the chain that only exists for borders WITHOUT a
+            //      seed state (probe passes that drop a start at the first seed state, survivor walk, contour list B, copy,
+            //      approxPolyDP) -- off the critical path, it used to be 2.9 ms of a 9.6 ms sub-batch.  Both append candidates;
+            //      the streams join in front of k_sort_cands.
             hipStream_t sa = c->aux_stream[sb];
             HIPCHK(c, hipEventRecord(c->aux_fork[sb], st));
             HIPCHK(c, hipStreamWaitEvent(sa, c->aux_fork[sb], 0));
@@ -417,30 +435,44 @@ fid_status run_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H, int
             // the other sub-batch's kernels; 8 waves per CU measured 7 % slower end to end)
             int swb = c->sw_blocks > 0 ? c->sw_blocks : (1024 / SW_WAVES + Fs - 1) / Fs;
             swb = swb < 2 ? 2 : (swb > 4 * wcap ? 4 * wcap : swb);
-            if (c->profile) (void)hipEventRecord(ev[14], sa);
-            hipLaunchKernelGGL(k_seed_walk, dim3(swb, Fs), dim3(64 * SW_WAVES), 0, sa, masks, seedq, tab, pool, (DevSegC *)segs, counts,
-                               c->d_global, P);
-            if (c->profile) (void)hipEventRecord(ev[15], sa);
-            HIPCHK(c, hipEventRecord(c->aux_join[sb], sa));
-            hipLaunchKernelGGL((k_probe<PROBE0_STEPS, 0, true>), dim3(64 * gm, Fs), dim3(256), 0, st, masks, starts, surv1, counts, c->d_global, P);
-            hipLaunchKernelGGL((k_probe<PROBE1_STEPS, 1, true>), dim3(16 * gm, Fs), dim3(256), 0, st, masks, surv1, surv, counts, c->d_global, P);
-            mark(ST_PROBE + 1);
-            const int wb3 = c->walk2_div > 0 ? (wb / c->walk2_div > 0 ? wb / c->walk2_div : 1) : wb2;
-            hipLaunchKernelGGL(k_walk_full<2>, dim3(wb3, Fs), dim3(64 * WALK_WAVES), 0, st, masks, surv, wres, tab, pool, segs, pend, counts,
-                               c->d_global, P);
-            hipLaunchKernelGGL(k_seed_index, dim3(8 * gm, Fs), dim3(256), 0, st, seedq, seedhash, counts, P);
-            HIPCHK(c, hipStreamWaitEvent(st, c->aux_join[sb], 0));
-            hipLaunchKernelGGL(k_seg_link2, dim3(16 * gm, Fs), dim3(256), 0, st, seedq, (DevSegC *)segs, seedhash, counts, P);
             uint4 *recs = c->d_recs + 2 * f0 * MCn;
+            const int cpb = c->copy_blocks > 0 ? c->copy_blocks : 256;
+            // -- auxiliary stream
+            if (c->profile) (void)hipEventRecord(ev[16], sa);
+            hipLaunchKernelGGL(k_seed_index, dim3(8 * gm, Fs), dim3(256), 0, sa, seedq, seedhash, counts, P);
+            HIPCHK(c, hipEventRecord(c->aux_idx[sb], sa));
+            hipLaunchKernelGGL((k_probe<PROBE0_STEPS, 0, true>), dim3(64 * gm, Fs), dim3(256), 0, sa, masks, starts, surv1, counts, c->d_global, P);
+            hipLaunchKernelGGL((k_probe<PROBE1_STEPS, 1, true>), dim3(16 * gm, Fs), dim3(256), 0, sa, masks, surv1, surv, counts, c->d_global, P);
+            const int wb3 = c->walk2_div > 0 ? (wb / c->walk2_div > 0 ? wb / c->walk2_div : 1) : wb2;
+            hipLaunchKernelGGL(k_walk_full<2>, dim3(wb3, Fs), dim3(64 * WALK_WAVES), 0, sa, masks, surv, wres, tab, pool, segs, pend, counts,
+                               c->d_global, P);
+            hipLaunchKernelGGL(k_seg_cycles, dim3(8 * gm, Fs), dim3(64), 0, sa, seedq, (const DevSegC *)segs, pend, wres, contours, cinfo, cbase,
+                               recs, counts, c->d_global, P, 1);
+            hipLaunchKernelGGL(k_seg_copy, dim3(cpb / 4 > 0 ? cpb / 4 : 1, Fs), dim3(256), 0, sa, recs, tab, pool, dense, counts, P, 1);
+            hipLaunchKernelGGL(k_approx, dim3(32 * gm, Fs), dim3(64), lds1, sa, contours, tab, pool, cands, counts, c->d_global, P, cap1,
+                               K4_SHORT_STACK, 0, dense, cbase, 2);
+            hipLaunchKernelGGL(k_approx, dim3(8 * gm, Fs), dim3(64), lds2, sa, contours, tab, pool, cands, counts, c->d_global, P,
+                               P.maxPerim + 1, K4_LONG_STACK, 1, dense, cbase, 2);
+            if (c->profile) (void)hipEventRecord(ev[17], sa);
+            HIPCHK(c, hipEventRecord(c->aux_join[sb], sa));
+            // -- main stream
+            if (c->profile) (void)hipEventRecord(ev[14], st);
+            hipLaunchKernelGGL(k_seed_walk, dim3(swb, Fs), dim3(64 * SW_WAVES), 0, st, masks, seedq, tab, pool, (DevSegC *)segs, counts,
+                               c->d_global, P);
+            if (c->profile) (void)hipEventRecord(ev[15], st);
+            mark(ST_PROBE + 1);
+            HIPCHK(c, hipStreamWaitEvent(st, c->aux_idx[sb], 0));
+            hipLaunchKernelGGL(k_seg_link2, dim3(16 * gm, Fs), dim3(256), 0, st, seedq, (DevSegC *)segs, seedhash, counts, P);
             hipLaunchKernelGGL(k_seg_cycles, dim3(32 * gm, Fs), dim3(64), 0, st, seedq, (const DevSegC *)segs, pend, wres, contours, cinfo, cbase,
-                               recs, counts, c->d_global, P);
-            hipLaunchKernelGGL(k_seg_copy, dim3(c->copy_blocks > 0 ? c->copy_blocks : 256, Fs), dim3(256), 0, st, recs, tab, pool, dense, counts, P);
+                               recs, counts, c->d_global, P, 0);
+            hipLaunchKernelGGL(k_seg_copy, dim3(cpb, Fs), dim3(256), 0, st, recs, tab, pool, dense, counts, P, 0);
             mark(ST_WALK + 1);
             hipLaunchKernelGGL(k_approx, dim3(128 * gm, Fs), dim3(64), lds1, st, contours, tab, pool, cands, counts, c->d_global, P, cap1,
-                               K4_SHORT_STACK, 0, dense, cbase);
+                               K4_SHORT_STACK, 0, dense, cbase, 1);
             hipLaunchKernelGGL(k_approx, dim3(16 * gm, Fs), dim3(64), lds2, st, contours, tab, pool, cands, counts, c->d_global, P,
-                               P.maxPerim + 1, K4_LONG_STACK, 1, dense, cbase);
+                               P.maxPerim + 1, K4_LONG_STACK, 1, dense, cbase, 1);
             mark(ST_APPROX + 1);
+            HIPCHK(c, hipStreamWaitEvent(st, c->aux_join[sb], 0));
           } else {
             // the seed walk needs only the seeds: it runs on its own stream beside the probe passes and the survivor walk
             // (both walks are a throughput phase followed by a tail of a few long walkers; side by side the tails overlap)
@@ -463,7 +495,7 @@ fid_status run_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H, int
             uint4 *recs = c->d_recs + 2 * f0 * MCn;
             hipLaunchKernelGGL(k_seg_chain, dim3(16 * gm, Fs), dim3(64), 0, st, surv, pend, wres, segs, contours, cinfo, cbase, recs, counts,
                                c->d_global, P);
-            hipLaunchKernelGGL(k_seg_copy, dim3(c->copy_blocks > 0 ? c->copy_blocks : 256, Fs), dim3(256), 0, st, recs, tab, pool, dense, counts, P);
+            hipLaunchKernelGGL(k_seg_copy, dim3(c->copy_blocks > 0 ? c->copy_blocks : 256, Fs), dim3(256), 0, st, recs, tab, pool, dense, counts, P, -1);
             mark(ST_WALK + 1);
             hipLaunchKernelGGL(k_approx, dim3(128 * gm, Fs), dim3(64), lds1, st, contours, tab, pool, cands, counts, c->d_global, P, cap1,
                                K4_SHORT_STACK, 0, dense, cbase);
@@ -503,11 +535,29 @@ fid_status run_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H, int
             hipLaunchKernelGGL(k_subpix, dim3(blocks), dim3(64), 0, st, g, gfstride, pre, markers, counts, c->d_subpix_mask, P);
         }
         mark(ST_SUBPIX + 1);
+        if (c->pose_cam_valid) {
+            PoseCam cam;
+            for (int i = 0; i < 9; i++) cam.K[i] = c->pose_K[i];
+            for (int i = 0; i < 5; i++) cam.D[i] = c->pose_D[i];
+            cam.fiducial_len = c->pose_len;
+            int blocks = (Fs * P.maxMarkers + 7) / 8;  // eight lanes per marker, eight markers per wave
+            blocks = blocks < 1 ? 1 : (blocks > 256 * 16 ? 256 * 16 : blocks);
+            if (c->profile) (void)hipEventRecord(ev[18], st);
+            hipLaunchKernelGGL(k_pose, dim3(blocks), dim3(64), 0, st, (const fid_marker *)markers, (const int *)&counts[0].nmark,
+                               (int)(sizeof(DevCounts) / sizeof(int)), (const double *)nullptr, Fs, P.maxMarkers, cam, c->d_poses + f0 * MM);
+            if (c->profile) (void)hipEventRecord(ev[19], st);
+        }
         if (nsub > 1) {
             HIPCHK(c, hipEventRecord(c->sub_done[sb], st));
             HIPCHK(c, hipStreamWaitEvent(st0, c->sub_done[sb], 0));
         }
-    }
+        return FID_OK;
+    };
+    for (int phase = 0; phase < 2; phase++)
+        for (int sb = 0; sb < nsub; sb++) {
+            const fid_status rcs = sub_phase(sb, phase);
+            if (rcs != FID_OK) return rcs;
+        }
     hipStream_t st = st0;
     const DevParams &P = c->P;
     HIPCHK(c, hipGetLastError());
@@ -515,7 +565,11 @@ fid_status run_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H, int
     HIPCHK(c, hipMemcpyAsync(c->h_counts, c->d_counts, sizeof(DevCounts) * F, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipMemcpyAsync(c->h_global, c->d_global, sizeof(DevGlobal), hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipMemcpyAsync(c->h_markers, c->d_markers, sizeof(fid_marker) * (size_t)F * P.maxMarkers, hipMemcpyDeviceToHost, st));
+    c->pose_done = false;
+    if (c->pose_cam_valid)
+        HIPCHK(c, hipMemcpyAsync(c->h_poses, c->d_poses, sizeof(fid_pose_out) * (size_t)F * P.maxMarkers, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
+    c->pose_done = c->pose_cam_valid;
     c->last_frames = F;
     c->last_W = W;
     c->last_H = H;
@@ -534,6 +588,8 @@ fid_status run_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H, int
             for (int sb = 0; sb < c->last_nsub; sb++) {
                 float ms = 0.f;
                 if (hipEventElapsedTime(&ms, c->sub_ev[sb][14], c->sub_ev[sb][15]) == hipSuccess) c->stage_ms[ST_SEEDWALK] += ms;
+                if (c->trace_mode == 2 && hipEventElapsedTime(&ms, c->sub_ev[sb][16], c->sub_ev[sb][17]) == hipSuccess) c->stage_ms[ST_SEEDLESS] += ms;
+                if (c->pose_cam_valid && hipEventElapsedTime(&ms, c->sub_ev[sb][18], c->sub_ev[sb][19]) == hipSuccess) c->stage_ms[ST_POSE] += ms;
             }
     }
 #ifdef FID_DEBUG_STATS
@@ -737,7 +793,8 @@ fid_status fid_create(const fid_params *params, const fid_dict *dict, const fid_
         TRYHIP(hipEventCreateWithFlags(&c->aux_join[sb], hipEventDisableTiming));
         TRYHIP(hipEventCreateWithFlags(&c->sub_done[sb], hipEventDisableTiming));
         TRYHIP(hipEventCreateWithFlags(&c->walk_done[sb], hipEventDisableTiming));
-        for (int i = 0; i < 16; i++) TRYHIP(hipEventCreate(&c->sub_ev[sb][i]));
+        TRYHIP(hipEventCreateWithFlags(&c->aux_idx[sb], hipEventDisableTiming));
+        for (int i = 0; i < 20; i++) TRYHIP(hipEventCreate(&c->sub_ev[sb][i]));
     }
     const size_t F = L.max_batch, MC = L.max_candidates_per_frame, MM = L.max_markers_per_frame;
     TRY(dalloc(c, &c->d_subpix_mask, (size_t)(2 * SP_MAXWIN + 1) * (2 * SP_MAXWIN + 1)));
@@ -839,9 +896,10 @@ void fid_destroy(fid_ctx *c)
         }
         if (c->aux_fork[sb]) (void)hipEventDestroy(c->aux_fork[sb]);
         if (c->aux_join[sb]) (void)hipEventDestroy(c->aux_join[sb]);
+        if (c->aux_idx[sb]) (void)hipEventDestroy(c->aux_idx[sb]);
         if (c->sub_done[sb]) (void)hipEventDestroy(c->sub_done[sb]);
         if (c->walk_done[sb]) (void)hipEventDestroy(c->walk_done[sb]);
-        for (int i = 0; i < 16; i++)
+        for (int i = 0; i < 20; i++)
             if (c->sub_ev[sb][i]) (void)hipEventDestroy(c->sub_ev[sb][i]);
         if (c->sub_stream[sb]) (void)hipStreamDestroy(c->sub_stream[sb]);
     }
@@ -942,12 +1000,22 @@ fid_status fid_pose_last(fid_ctx *c, const double K[9], const double D[5], doubl
     if (!c || !K || !out || c->last_frames <= 0 || !(fiducial_len > 0)) return FID_E_INVALID_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     const int F = c->last_frames, MM = c->P.maxMarkers;
-    fid_status rc = run_pose(c, c->d_markers, &c->d_counts[0].nmark, (int)(sizeof(DevCounts) / sizeof(int)), nullptr, F, MM, K, D,
-                             fiducial_len, c->d_poses);
-    if (rc != FID_OK) return rc;
-    HIPCHK(c, hipMemcpyAsync(c->h_poses, c->d_poses, sizeof(fid_pose_out) * (size_t)F * MM, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (c->profile) (void)hipEventElapsedTime(&c->stage_ms[ST_POSE], c->ev[ST_POSE], c->ev[ST_POSE + 1]);
+    double Dz[5] = {0., 0., 0., 0., 0.};
+    if (D) memcpy(Dz, D, sizeof Dz);
+    const bool same_cam = c->pose_cam_valid && !memcmp(c->pose_K, K, sizeof c->pose_K) && !memcmp(c->pose_D, Dz, sizeof Dz) && c->pose_len == fiducial_len;
+    fid_status rc = FID_OK;
+    if (!(same_cam && c->pose_done)) {  // (else: the detect call already ran k_pose for this camera on these markers)
+        rc = run_pose(c, c->d_markers, &c->d_counts[0].nmark, (int)(sizeof(DevCounts) / sizeof(int)), nullptr, F, MM, K, D, fiducial_len, c->d_poses);
+        if (rc != FID_OK) return rc;
+        HIPCHK(c, hipMemcpyAsync(c->h_poses, c->d_poses, sizeof(fid_pose_out) * (size_t)F * MM, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (c->profile) (void)hipEventElapsedTime(&c->stage_ms[ST_POSE], c->ev[ST_POSE], c->ev[ST_POSE + 1]);
+        memcpy(c->pose_K, K, sizeof c->pose_K);
+        memcpy(c->pose_D, Dz, sizeof Dz);
+        c->pose_len = fiducial_len;
+        c->pose_cam_valid = getenv("FID_NO_POSE_AHEAD") == nullptr;
+        c->pose_done = c->pose_cam_valid;
+    }
     for (int f = 0; f < F; f++) {
         int n = c->h_counts[f].nmark;
         if (n > cap_per_frame) {
@@ -1074,7 +1142,7 @@ fid_status fid_tap_read(fid_ctx *c, fid_tap which, void *dst, int64_t dst_bytes)
         int32_t *o = (int32_t *)dst;
         for (int f = 0; f < F; f++) {
             o[12 * f + 0] = c->h_counts[f].nstarts;
-            o[12 * f + 1] = c->trace_mode == 0 ? (c->h_counts[f].nsurv < c->P.maxContours ? c->h_counts[f].nsurv : c->P.maxContours) : c->h_counts[f].ncontours;
+            o[12 * f + 1] = c->trace_mode == 0 ? (c->h_counts[f].nsurv < c->P.maxContours ? c->h_counts[f].nsurv : c->P.maxContours) : c->h_counts[f].ncontours + c->h_counts[f].ncontours2;
             o[12 * f + 10] = c->h_counts[f].nseeds;
             o[12 * f + 2] = c->h_counts[f].ncand;
             o[12 * f + 3] = c->h_counts[f].nfilt;
@@ -1084,7 +1152,7 @@ fid_status fid_tap_read(fid_ctx *c, fid_tap which, void *dst, int64_t dst_bytes)
             o[12 * f + 7] = c->h_counts[f].nsurv;
             o[12 * f + 8] = c->h_counts[f].npool;
             o[12 * f + 9] = c->h_counts[f].nsurv1;
-            o[12 * f + 11] = 0;
+            o[12 * f + 11] = c->h_counts[f].ndense;  // contour points handed to approxPolyDP
         }
         return FID_OK;
     }

@@ -146,8 +146,10 @@ struct DevCounts {
     int ndense;     // contour points copied to the dense point array so far
     int nseeds;     // seeds found by k_find_starts<true>
     int nwalk2;     // work queue head of the seed walker
-    int nrec;       // copy records written by k_seg_chain (pieces of accepted contours)
-    int pad[1];
+    int nrec;       // copy records written by k_seg_chain / k_seg_cycles (pieces of accepted contours)
+    int ncontours2; // trace mode 2: contours of the borders WITHOUT a seed (second list: [maxContours / 2, maxContours) of the frame's
+    int nrec2;      //   contour arrays, second half of its record array), traced on the auxiliary stream beside the seed cycles
+    int pad[15];
 };
 
 // global counters

@@ -2000,14 +2000,15 @@ __global__ __launch_bounds__(64) void k_seg_chain(const uint2 *__restrict__ surv
 // the pieces of the accepted contours, from their pool chunks into the dense point array: one wave per copy record
 __global__ __launch_bounds__(256) void k_seg_copy(const uint4 *__restrict__ recs, const uint32_t *__restrict__ chunk_tab,
                                                    const uint32_t *__restrict__ pool, uint32_t *__restrict__ dense,
-                                                   const DevCounts *__restrict__ counts, const DevParams P)
+                                                   const DevCounts *__restrict__ counts, const DevParams P, int part)
 {
+    // part -1: the frame's whole record array (trace mode 1); 0 / 1: its first / second half (trace mode 2, lists A / B)
     const int f = blockIdx.y;
     const int lane = lane_id();
-    unsigned nr = (unsigned)counts[f].nrec;
-    const unsigned rcap = 2u * (unsigned)P.maxContours;
+    unsigned nr = (unsigned)(part == 1 ? counts[f].nrec2 : counts[f].nrec);
+    const unsigned rcap = (part < 0 ? 2u : 1u) * (unsigned)P.maxContours;
     nr = nr < rcap ? nr : rcap;
-    const uint4 *frc = recs + (long long)f * rcap;
+    const uint4 *frc = recs + (long long)f * 2 * P.maxContours + (part == 1 ? (unsigned)P.maxContours : 0u);
     const int nck = chunk_tab_pitch(P);
     const uint32_t *ftab = chunk_tab + (long long)f * 2 * P.maxContours * nck;
     const uint32_t *fpool = pool;  // chunks are numbered across the whole launch
@@ -2444,23 +2445,29 @@ __global__ __launch_bounds__(64) void k_seg_cycles(const uint2 *__restrict__ see
                                                     const DevPend *__restrict__ pend, const uint4 *__restrict__ wres,
                                                     uint4 *__restrict__ contours, uint4 *__restrict__ cinfo, uint32_t *__restrict__ cbase,
                                                     uint4 *__restrict__ recs, DevCounts *__restrict__ counts, DevGlobal *__restrict__ G,
-                                                    const DevParams P)
+                                                    const DevParams P, int part)
 {
+    // part 0: the segments (contour list A: slots [0, maxContours / 2), records [0, maxContours)); part 1: the survivors (list B:
+    // slots [maxContours / 2, maxContours), records [maxContours, 2 maxContours)) -- the two parts run on different streams
     const int f = blockIdx.y;
     const int lane = lane_id();
     unsigned ns = (unsigned)counts[f].nseeds, nv = (unsigned)counts[f].nsurv;
     ns = ns < (unsigned)P.maxContours ? ns : (unsigned)P.maxContours;
     nv = nv < (unsigned)P.maxContours ? nv : (unsigned)P.maxContours;
+    const unsigned lcap = (unsigned)P.maxContours / 2u, rcap = (unsigned)P.maxContours;
     const uint2 *fsq = seedq + (long long)f * P.maxContours;
     const DevSegC *fsg = segs + (long long)f * P.maxContours;
     const DevPend *fpd = pend + (long long)f * P.maxContours;
-    uint4 *fco = contours + (long long)f * P.maxContours;
-    uint4 *fci = cinfo + (long long)f * P.maxContours;
-    uint32_t *fcb = cbase + (long long)f * P.maxContours;
-    uint4 *frc = recs + (long long)f * 2 * P.maxContours;
-    const unsigned dcap = (unsigned)P.maxChunks * CK, rcap = 2u * (unsigned)P.maxContours;
+    uint4 *fco = contours + (long long)f * P.maxContours + (part ? lcap : 0u);
+    uint4 *fci = cinfo + (long long)f * P.maxContours + (part ? lcap : 0u);
+    uint32_t *fcb = cbase + (long long)f * P.maxContours + (part ? lcap : 0u);
+    uint4 *frc = recs + (long long)f * 2 * P.maxContours + (part ? rcap : 0u);
+    unsigned *cnt_slots = (unsigned *)(part ? &counts[f].ncontours2 : &counts[f].ncontours);
+    unsigned *cnt_recs = (unsigned *)(part ? &counts[f].nrec2 : &counts[f].nrec);
+    const unsigned dcap = (unsigned)P.maxChunks * CK;
     const unsigned W2 = (unsigned)P.W + 2u;
-    for (unsigned i0 = blockIdx.x * 64; i0 < ns + nv; i0 += gridDim.x * 64) {
+    const unsigned ibeg = part ? ns : 0u, iend = part ? ns + nv : ns;
+    for (unsigned i0 = ibeg + blockIdx.x * 64; i0 < iend; i0 += gridDim.x * 64) {
         const unsigned i = i0 + lane;
         int accept = 0, hole = 0;
         unsigned L = 0, key = 0, hops = 0, pos = 0, n0 = 0, nx0 = SEG_INVALID;
@@ -2509,7 +2516,7 @@ __global__ __launch_bounds__(64) void k_seg_cycles(const uint2 *__restrict__ see
                     st = make_uint2((kx - 1u - (unsigned)hole) | ((ky - 1u) << 16), (uint32_t)f | ((fsq[i].x >> 27) << 16) | ((uint32_t)hole << 24));
                 }
             }
-        } else if (i < ns + nv) {
+        } else if (i < iend) {
             const unsigned j = i - ns;
             if (!fpd[j].p) {  // decided by the survivor walk itself (a border without seeds): accepted iff it left a length
                 const uint4 w = wres[(long long)f * P.maxContours + j];
@@ -2528,16 +2535,16 @@ __global__ __launch_bounds__(64) void k_seg_cycles(const uint2 *__restrict__ see
             const unsigned totL = (unsigned)__builtin_amdgcn_readlane((int)sL, 63), totR = (unsigned)__builtin_amdgcn_readlane((int)sR, 63);
             unsigned bslot = 0, bdense = 0, brec = 0;
             if (lane == 63) {
-                bslot = atomicAdd((unsigned *)&counts[f].ncontours, (unsigned)__popcll(mk));
+                bslot = atomicAdd(cnt_slots, (unsigned)__popcll(mk));
                 bdense = atomicAdd((unsigned *)&counts[f].ndense, totL);
-                brec = atomicAdd((unsigned *)&counts[f].nrec, totR);
+                brec = atomicAdd(cnt_recs, totR);
             }
             bslot = (unsigned)__builtin_amdgcn_readlane((int)bslot, 63);
             bdense = (unsigned)__builtin_amdgcn_readlane((int)bdense, 63);
             brec = (unsigned)__builtin_amdgcn_readlane((int)brec, 63);
             const unsigned idx = bslot + (unsigned)__popcll(mk & ((1ull << lane) - 1ull));
             if (accept) {
-                if (idx < (unsigned)P.maxContours) {
+                if (idx < lcap) {
                     fco[idx] = make_uint4(st.x, st.y, L, key);
                     fci[idx] = make_uint4(i, pos, nx0, 0u);
                     const unsigned dst0 = bdense + sL - myL;
@@ -2590,7 +2597,7 @@ __global__ __launch_bounds__(64) void k_approx(uint4 *__restrict__ contours, con
                                                 const uint32_t *__restrict__ pool, DevCand *__restrict__ cands,
                                                 DevCounts *__restrict__ counts, DevGlobal *__restrict__ G, const DevParams P,
                                                 int pts_cap, int stack_cap, int second_pass, const uint32_t *__restrict__ dense,
-                                                const uint32_t *__restrict__ cbase)
+                                                const uint32_t *__restrict__ cbase, int part = 0)
 {
     extern __shared__ uint32_t pts[];  // pts_cap points, then stack_cap slices
     int2 *stack = reinterpret_cast<int2 *>(pts + pts_cap);
@@ -2598,12 +2605,16 @@ __global__ __launch_bounds__(64) void k_approx(uint4 *__restrict__ contours, con
     const int lane = lane_id();
     const int f = blockIdx.y;
     // legacy path: contour slot = survivor index; segment tracing (dense != nullptr): the accepted contours, compact
-    unsigned n = (unsigned)(dense ? counts[f].ncontours : counts[f].nsurv);
+    // (part: trace mode 2 keeps two contour lists per frame -- 1: the seed cycles, first half of the slots; 2: the seedless
+    //  borders, second half -- worked on by two launches on different streams; 0: one list)
+    unsigned n = (unsigned)(dense ? (part == 2 ? counts[f].ncontours2 : counts[f].ncontours) : counts[f].nsurv);
     n = n < (unsigned)P.maxStarts ? n : (unsigned)P.maxStarts;
     n = n < (unsigned)P.maxContours ? n : (unsigned)P.maxContours;
+    const unsigned loff = part == 2 ? (unsigned)P.maxContours / 2u : 0u;
+    if (part) n = n < (unsigned)P.maxContours / 2u ? n : (unsigned)P.maxContours / 2u;
     const int W = P.W, H = P.H;
     const int nck = chunk_tab_pitch(P);
-    uint4 *fco = contours + (long long)f * P.maxContours;
+    uint4 *fco = contours + (long long)f * P.maxContours + loff;
     const uint32_t *ftab = chunk_tab + ((long long)f * 2 + 1) * P.maxContours * nck;  // survivors' chunk rows
     const uint32_t *fpool = pool;  // chunks are numbered across the whole launch
     // this workgroup's slots are blockIdx.x, blockIdx.x + gridDim.x, ...: 64 of them are looked at with one
@@ -2631,7 +2642,7 @@ __global__ __launch_bounds__(64) void k_approx(uint4 *__restrict__ contours, con
         __syncthreads();
         // ---- gather the border
         if (dense) {
-            const uint32_t cb0 = cbase[(long long)f * P.maxContours + ci];
+            const uint32_t cb0 = cbase[(long long)f * P.maxContours + loff + ci];
             if (cb0 == SEG_INVALID) continue;
             const uint32_t *src = dense + (long long)f * P.maxChunks * CK + cb0;
             for (int k = lane; k < count; k += 64) pts[k] = src[k];

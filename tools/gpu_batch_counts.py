@@ -1,19 +1,19 @@
 #!/usr/bin/env python3
-"""Per-frame work spread of the contour stage over the bench batch (run on the GPU box)."""
+"""Work counters of the contour stage on the first frames of the bench batch (batch context, run on the GPU box)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("FID_PROFILE", "1")
-import numpy as np, torch
+import numpy as np
+import torch
 import bench
 from fiducials_amd.detector import ArucoDetector
-B = 256
-fr = bench.make_frames([1000 + i for i in range(B)])
-d = torch.from_numpy(fr).cuda()
-det = ArucoDetector("DICT_5X5_250", device=0, max_batch=B, max_markers=64)
-det.detect_markers_device(d.data_ptr(), B, 1920, 1080, unpack=False)
-c = det.tap_counts()
-for name, col in (("starts", 0), ("surv1", 9), ("surv", 7), ("chunks", 8), ("cands", 2)):
-    v = c[:, col]
-    print(f"{name}: min {v.min()} mean {v.mean():.0f} max {v.max()}  max/mean {v.max()/v.mean():.2f}")
-print({k: round(v, 3) for k, v in det.stage_ms().items()})
+
+B = 64
+frames = bench.make_frames(bench.shard_seeds(0, 1, B))
+dev = torch.from_numpy(frames).cuda()
+det = ArucoDetector("DICT_5X5_250", max_width=1920, max_height=1080, max_batch=B, max_markers=64, max_candidates=2048)
+det.detect_markers_device(dev.data_ptr(), B, 1920, 1080, unpack=False)
+c = det.tap_counts()[:B].astype(np.float64)
+names = {0: "starts", 10: "seeds", 9: "surv1", 7: "survivors", 1: "contours", 11: "contour points", 8: "chunks", 2: "cands", 3: "filtered", 5: "markers"}
+print("per frame (mean over %d frames):" % B, ", ".join(f"{n} {c[:, k].mean():.0f}" for k, n in names.items()))
+det.close()

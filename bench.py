@@ -41,6 +41,10 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 # FID_BENCH_DRYRUN=cpu: the launcher / rank plumbing only (gloo, no GPU, no detector, a sleeping stand-in for the step), so that
 # the N-rank path of this very file is covered by the CPU test suite.  The line it prints carries "dryrun": true and no metric.
 DRYRUN = os.environ.get("FID_BENCH_DRYRUN", "") == "cpu"
+# FID_BENCH_OVERSUBSCRIBE=1: every rank maps to cuda:0 (the development lease is ONE GPU) and the clock reduction runs on gloo
+# (RCCL refuses two ranks on one device).  It exists so that the N-rank path -- N processes, each with torch's HIP runtime AND
+# libfid_amd.so and real kernels -- is executed by the GPU test suite; the line it prints says "oversubscribed" and n_gpus 1.
+OVERSUB = os.environ.get("FID_BENCH_OVERSUBSCRIBE", "") == "1"
 
 # algorithmic HBM bytes per frame and kernel (DESIGN.md "Roofline accounting"):
 #   gray read once + 13 bit-packed masks written once + read once by the contour stage
@@ -73,7 +77,7 @@ def job_throughput(units_per_rank: int, world: int, dt_local: float, dist=None, 
     if dist is not None:
         import torch
 
-        tt = torch.tensor([dt_local], dtype=torch.float64, device=device)
+        tt = torch.tensor([dt_local], dtype=torch.float64, device="cpu" if (DRYRUN or OVERSUB) else device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     return units_per_rank * world / dt, dt
@@ -255,6 +259,36 @@ def cpu_baseline(frames, K, D, budget_s=20.0):
         "ms_per_frame_1core_median": round(med * 1e3, 2),
         "ms_per_frame_in_pool_median": round(float(np.median([x for c in times for x in c])) * 1e3, 2),
     }
+
+
+def host_feed_result(local_rank, host, K, D):
+    """cfg 3 fed from HOST memory (what the node's imageCallback sees: frames arrive in host buffers): the same batch through
+    fid_detect_batch + fid_pose_last.  The library sends the frames up sub-batch by sub-batch on a copy stream and starts a
+    sub-batch when its frames have landed, so the PCIe copy of one runs under the kernels of another.  Never `value` (that is
+    measured with the frames resident in HBM); this is the PCIe-inclusive rate, from pinned and from pageable memory."""
+    import torch
+
+    from fiducials_amd.detector import ArucoDetector
+
+    B = len(host)
+    det = ArucoDetector("DICT_5X5_250", device=local_rank, max_width=W, max_height=H, max_batch=B, max_markers=64, max_candidates=2048)
+    out = {"workload": f"cfg3 from host memory: batch {B} x 1920x1080 mono8 ({B * W * H / 1e6:.0f} MB per step over PCIe), detect + pose"}
+    pinned = torch.from_numpy(host).pin_memory()
+    for name, arr in (("pinned", pinned.numpy()), ("pageable", host)):
+        found = 0
+        for _ in range(2):
+            det.detect_markers_batch(arr, unpack=False)
+            det.pose_last(FIDUCIAL_LEN, K, D, unpack=False)
+        t = time.perf_counter()
+        steps = 4
+        for _ in range(steps):
+            found += sum(det.detect_markers_batch(arr, unpack=False))
+            det.pose_last(FIDUCIAL_LEN, K, D, unpack=False)
+        dt = time.perf_counter() - t
+        out[name] = {"value": round(B * steps / dt, 1), "unit": "frames/s", "ms_per_step": round(dt / steps * 1e3, 3),
+                     "pcie_GBps": round(B * W * H * steps / dt / 1e9, 2), "markers_per_frame_found": round(found / (B * steps), 2)}
+    det.close()
+    return out
 
 
 def jpeg_side_result(local_rank, frames):
@@ -464,7 +498,7 @@ def launch_ranks(n: int) -> int:
     --master-port P bench.py ...`), and hand their exit code back.  Refuses (rc 2) when fewer than N GPUs are visible: a rank
     count that did not run is never reported."""
     have = visible_gpus()
-    if have < n:
+    if have < n and not (OVERSUB and have >= 1):
         print(f"bench.py: --gpus {n} but only {have} GPU(s) visible", file=sys.stderr)
         return 2
     import subprocess
@@ -483,6 +517,8 @@ def rank_env(args):
         print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a rank count that is not running",
               file=sys.stderr)
         sys.exit(2)
+    if OVERSUB:
+        local_rank = 0
     return rank, local_rank, world
 
 
@@ -493,16 +529,18 @@ def init_dist(world, local_rank):
     import torch
     import torch.distributed as dist_mod
 
-    if DRYRUN:
+    if DRYRUN or OVERSUB:
         dist_mod.init_process_group("gloo")
     else:
         dist_mod.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     return dist_mod
 
 
-def gather_ranks(dist, rank, device, units, dt_local):
-    """Per-rank evidence for the JSON line: (rank, pid, device, frames/s of that rank alone)."""
+def gather_ranks(dist, rank, device, units, dt_local, markers=None):
+    """Per-rank evidence for the JSON line: (rank, pid, device, frames/s of that rank alone, markers per frame it found)."""
     mine = {"rank": rank, "pid": os.getpid(), "device": device, "fps": round(units / dt_local, 2)}
+    if markers is not None:
+        mine["markers_per_frame_found"] = round(markers / max(units, 1), 2)
     if dist is None:
         return [mine]
     got = [None] * dist.get_world_size()
@@ -624,7 +662,7 @@ def main():
     dt_local = time.perf_counter() - t0
     barrier()
     fps, dt = job_throughput(B * args.steps, n_gpus, time.perf_counter() - t0, dist, f"cuda:{local_rank}")
-    ranks = gather_ranks(dist, rank, f"cuda:{local_rank}", B * args.steps, dt_local)
+    ranks = gather_ranks(dist, rank, f"cuda:{local_rank}", B * args.steps, dt_local, markers)
     assert len(ranks) == n_gpus  # every reported GPU ran its own rank
 
     if rank == 0:
@@ -647,7 +685,7 @@ def main():
             "metric": "frames/sec @1920x1080 20-marker (aruco detect + pose hot path)",
             "value": round(fps, 2),
             "unit": "frames/s",
-            "n_gpus": n_gpus,
+            "n_gpus": 1 if OVERSUB else n_gpus,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3),
@@ -668,10 +706,16 @@ def main():
             "stage_ms_per_step": {k: round(v, 4) for k, v in stage_ms.items()},
             "ranks": ranks,
         }
+        if OVERSUB:
+            out["oversubscribed"] = f"{n_gpus} ranks on ONE GPU (FID_BENCH_OVERSUBSCRIBE=1, gloo clock reduction): a plumbing run, not a scaling point"
         if n_gpus == 1 and not args.no_extras:
             det.close()
             det = None
             out["extra"] = {"cfg2_single_frame": cfg2_latency(local_rank, frames_u[0])}
+            try:
+                out["extra"]["cfg3_from_host"] = host_feed_result(local_rank, host, K, D)
+            except Exception as e:  # noqa: BLE001
+                out["extra"]["cfg3_from_host"] = {"error": repr(e)}
             try:
                 out["extra"]["jpeg_ingest"] = jpeg_side_result(local_rank, frames_u)
             except Exception as e:  # noqa: BLE001

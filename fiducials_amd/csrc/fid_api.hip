@@ -33,6 +33,9 @@ struct fid_ctx {
     hipStream_t aux_stream[MAX_SUB] = {};  // per sub-batch: the seed walk runs here, beside the probe passes and the survivor walk
     hipEvent_t aux_fork[MAX_SUB] = {}, aux_join[MAX_SUB] = {}, aux_idx[MAX_SUB] = {};
     hipEvent_t sub_done[MAX_SUB] = {}, fork_ev = nullptr;
+    hipStream_t copy_stream = nullptr;     // fid_detect_batch: the frames go up sub-batch by sub-batch on this stream ...
+    hipEvent_t in_ready[MAX_SUB] = {};     // ... and a sub-batch starts when its frames have landed (H2D of k + 1 under the compute of k)
+    bool host_feed = false;                // this run_detect call is fed that way
     hipEvent_t walk_done[MAX_SUB] = {};     // a sub-batch has left its contour stage (staggered starts, FID_STAGGER)
     int stagger = 0;                        // sub-batch k starts when sub-batch k - stagger has left its contour stage (0: all at once)
     int resolve_lds_kb = 64;
@@ -249,6 +252,44 @@ size_t masks_elems(const fid_ctx *c, int W, int H, int F)
     return (size_t)F * c->P.nscales * TR * TC * MT_ROWS;
 }
 
+// how a call of F frames is cut into sub-batches (run_detect; fid_detect_batch sends the frames up in the same pieces):
+// sub-batch sb = frames [f0[sb], f0[sb + 1])
+struct SubPlan {
+    int nsub;
+    int f0[fid_ctx::MAX_SUB + 1];
+};
+SubPlan plan_sub_batches(const fid_ctx *c, int F)
+{
+    SubPlan pl;
+    if (c->sub_frames <= 0 && c->host_feed && F >= 64) {
+        // frames that come up from the host while the call runs (the link, ~45 GB/s under load, is slower than the kernels):
+        // four pieces -- the first kernels start after a fifth of the copy, the copy engine never idles, and what is left to
+        // compute when the last byte has landed is a small piece.  The rate is insensitive to the split: the step is the arrival
+        // of the first piece plus the kernels' time at the lower efficiency of small sub-batches
+        int share[4] = {20, 30, 30, 20};  // (measured 15.7 k frames/s; 25-25-25-25: 15.3 k, 34-28-22-16: 15.4 k, 10-22-34-34: 15.0 k)
+        if (const char *e = getenv("FID_FEED_SHARES")) (void)sscanf(e, "%d,%d,%d,%d", &share[0], &share[1], &share[2], &share[3]);
+        pl.nsub = 4;
+        int acc = 0;
+        for (int k = 0; k < 4; k++) {
+            pl.f0[k] = acc;
+            acc += k == 3 ? F - acc : (F * share[k] + 50) / 100;
+        }
+        pl.f0[4] = F;
+        return pl;
+    }
+    // resident frames: two halves measured best (more streams fight for CUs)
+    int per = c->sub_frames > 0 ? c->sub_frames : (F >= 32 ? (F + 1) / 2 : F);
+    int nsub = (F + per - 1) / per;
+    if (nsub > fid_ctx::MAX_SUB) {
+        nsub = fid_ctx::MAX_SUB;
+        per = (F + nsub - 1) / nsub;
+        nsub = (F + per - 1) / per;
+    }
+    pl.nsub = nsub;
+    for (int k = 0; k <= nsub; k++) pl.f0[k] = k * per < F ? k * per : F;
+    return pl;
+}
+
 // the whole detection pipeline for F frames whose gray images are resident at d_gray
 fid_status run_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H, int stride, long long fstride, fid_encoding enc,
                       fid_marker *out, int cap_per_frame, int *n_per_frame)
@@ -292,22 +333,18 @@ fid_status run_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H, int
     }
     // ---- the batch is cut into sub-batches that run the whole pipeline on their own streams: the latency-bound
     //      tail of one sub-batch's kernels (the longest border, the last candidates) overlaps the next one's bulk
-    int per = c->sub_frames > 0 ? c->sub_frames : (F >= 32 ? (F + 1) / 2 : F);  // two halves measured best (more streams fight for CUs)
-    int nsub = (F + per - 1) / per;
-    if (nsub > fid_ctx::MAX_SUB) {
-        nsub = fid_ctx::MAX_SUB;
-        per = (F + nsub - 1) / nsub;
-        nsub = (F + per - 1) / per;
-    }
+    const SubPlan plan = plan_sub_batches(c, F);
+    const int nsub = plan.nsub;
     c->last_nsub = nsub;
     if (nsub > 1) HIPCHK(c, hipEventRecord(c->fork_ev, st0));
     // The host enqueues in two rounds: first every sub-batch's gray conversion + threshold, then every sub-batch's rest.  (One
     // round -- a whole sub-batch, some thirty launches, before the next one's first kernel -- left the second sub-batch's stream
     // empty for the first 0.35 - 0.6 ms of every step.)
     auto sub_phase = [&](int sb, int phase) -> fid_status {
-        const int f0 = sb * per, Fs = (f0 + per <= F ? per : F - f0);
+        const int f0 = plan.f0[sb], Fs = plan.f0[sb + 1] - f0;
         hipStream_t st = nsub > 1 ? c->sub_stream[sb] : st0;
         if (nsub > 1 && phase == 0) HIPCHK(c, hipStreamWaitEvent(st, c->fork_ev, 0));
+        if (c->host_feed && phase == 0) HIPCHK(c, hipStreamWaitEvent(st, c->in_ready[sb], 0));
         // staggered starts: the contour stage of a sub-batch (threshold ... approx) keeps the whole chip busy, what follows
         // (candidates, identification, corners) is a chain of short latency-bound kernels -- let the next sub-batch's contour
         // stage run under that tail instead of beside another contour stage
@@ -778,6 +815,7 @@ fid_status fid_create(const fid_params *params, const fid_dict *dict, const fid_
     } while (0)
     TRYHIP(hipSetDevice(device));
     TRYHIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    TRYHIP(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
     for (int i = 0; i <= ST_COUNT; i++) TRYHIP(hipEventCreate(&c->ev[i]));
     TRYHIP(hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming));
     int prio_lo = 0, prio_hi = 0;  // (numerically lower = more urgent)
@@ -793,6 +831,7 @@ fid_status fid_create(const fid_params *params, const fid_dict *dict, const fid_
         TRYHIP(hipEventCreateWithFlags(&c->aux_join[sb], hipEventDisableTiming));
         TRYHIP(hipEventCreateWithFlags(&c->sub_done[sb], hipEventDisableTiming));
         TRYHIP(hipEventCreateWithFlags(&c->walk_done[sb], hipEventDisableTiming));
+        TRYHIP(hipEventCreateWithFlags(&c->in_ready[sb], hipEventDisableTiming));
         TRYHIP(hipEventCreateWithFlags(&c->aux_idx[sb], hipEventDisableTiming));
         for (int i = 0; i < 20; i++) TRYHIP(hipEventCreate(&c->sub_ev[sb][i]));
     }
@@ -899,10 +938,12 @@ void fid_destroy(fid_ctx *c)
         if (c->aux_idx[sb]) (void)hipEventDestroy(c->aux_idx[sb]);
         if (c->sub_done[sb]) (void)hipEventDestroy(c->sub_done[sb]);
         if (c->walk_done[sb]) (void)hipEventDestroy(c->walk_done[sb]);
+        if (c->in_ready[sb]) (void)hipEventDestroy(c->in_ready[sb]);
         for (int i = 0; i < 20; i++)
             if (c->sub_ev[sb][i]) (void)hipEventDestroy(c->sub_ev[sb][i]);
         if (c->sub_stream[sb]) (void)hipStreamDestroy(c->sub_stream[sb]);
     }
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -965,9 +1006,28 @@ fid_status fid_detect_batch(fid_ctx *c, const uint8_t *imgs, int32_t nframes, in
         HIPCHK(c, hipMalloc((void **)&c->d_in, need));
         c->d_in_bytes = need;
     }
-    // pageable or pinned host memory: one async copy on the context stream (H2D of the frame)
-    HIPCHK(c, hipMemcpyAsync(c->d_in, imgs, need, hipMemcpyHostToDevice, c->stream));
-    return run_detect(c, c->d_in, nframes, width, height, stride, frame_stride, enc, out, cap_per_frame, n_per_frame);
+    // The frames go up in the pieces run_detect works in, one asynchronous copy per sub-batch on the copy stream with an event
+    // behind it; a sub-batch's stream waits for its own event only, so the copy of sub-batch k + 1 runs under the kernels of
+    // sub-batch k (pinned host memory -- a capture ring buffer -- copies at link speed; pageable memory is staged by the runtime
+    // and copies more slowly, the overlap is the same).
+    c->host_feed = getenv("FID_NO_FEED_OVERLAP") == nullptr;
+    const SubPlan plan = plan_sub_batches(c, nframes);
+    const int nsub = plan.nsub;
+    if (!c->host_feed) {
+        HIPCHK(c, hipMemcpyAsync(c->d_in, imgs, need, hipMemcpyHostToDevice, c->stream));
+    } else {
+        // (the copy stream must not overtake the previous call's kernels that still read d_in: they were synchronised at its end)
+        for (int sb = 0; sb < nsub; sb++) {
+            const int f0 = plan.f0[sb], Fs = plan.f0[sb + 1] - f0;
+            const size_t off = (size_t)frame_stride * f0;
+            const size_t bytes = (size_t)frame_stride * (Fs - 1) + (size_t)stride * height;
+            HIPCHK(c, hipMemcpyAsync(c->d_in + off, imgs + off, bytes, hipMemcpyHostToDevice, c->copy_stream));
+            HIPCHK(c, hipEventRecord(c->in_ready[sb], c->copy_stream));
+        }
+    }
+    const fid_status rc = run_detect(c, c->d_in, nframes, width, height, stride, frame_stride, enc, out, cap_per_frame, n_per_frame);
+    c->host_feed = false;
+    return rc;
 }
 
 fid_status fid_detect(fid_ctx *c, const uint8_t *img, int32_t width, int32_t height, int32_t stride, fid_encoding enc,

@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256) void k_to_gray(const uint8_t *__restrict__ src
 // ------------------------------------------------------------------------------------------------
 // K1: multi-scale adaptive threshold.
 //   adaptiveThreshold(MEAN_C, BINARY_INV, win, C): mean = round(boxsum / win^2) with BORDER_REPLICATE,
-//   foreground iff src - mean <= -ceil(C)   <=>   2*boxsum >= (2*(src + idelta) - 1) * win^2
+//   foreground iff src - mean <= -idelta, idelta = cvFloor(C) (THRESH_BINARY_INV)   <=>   2*boxsum >= (2*(src + idelta) - 1) * win^2
 //   (exact: boxsum/win^2 never sits on a half for odd win).
 // One workgroup = one TX x TY output tile: the tile plus a rmax halo is loaded once (clamped =
 // replicate border), turned into a 2-D integral image in LDS, and all scales read their four corners

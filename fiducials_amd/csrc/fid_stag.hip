@@ -942,16 +942,20 @@ static fid_status stag_advance_impl(fid_stag_ctx *c, StagJob &j)
                                c->d_chosen);
             if (hipGetLastError() != hipSuccess) return stag_finish(j, FID_E_HIP);
         }
+        // the capacity checks come first: on FID_E_CAPACITY nothing is copied, so the count handed back must be 0 (a caller of
+        // the batch entry point walks n_per_frame[f] entries of its cap_per_frame slot; c->n_markers keeps what was found)
+        if ((j.out && c->n_markers > j.cap) || (j.last == SS_POSE && c->n_markers > 0 && c->n_markers > j.pose_cap)) {
+            if (j.n_out) *j.n_out = 0;
+            return stag_finish(j, FID_E_CAPACITY);
+        }
         if (j.n_out) *j.n_out = c->n_markers;
         const bool pin = c->n_markers <= STAG_PIN_MARKERS;  // staged through pinned memory, handed over in the last segment
         if (j.out) {
-            if (c->n_markers > j.cap) return stag_finish(j, FID_E_CAPACITY);
             if (c->n_markers > 0 && hipMemcpyAsync(pin ? c->hp->markers : j.out, c->d_markers, (size_t)c->n_markers * sizeof(fid_stag_marker),
                                                    hipMemcpyDeviceToHost, st) != hipSuccess)
                 return stag_finish(j, FID_E_HIP);
         }
         if (j.last == SS_POSE && c->n_markers > 0) {
-            if (c->n_markers > j.pose_cap) return stag_finish(j, FID_E_CAPACITY);
             PoseCam cam;
             for (int i = 0; i < 9; i++) cam.K[i] = j.K[i];
             for (int i = 0; i < 5; i++) cam.D[i] = j.D ? j.D[i] : 0.0;

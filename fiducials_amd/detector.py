@@ -127,7 +127,8 @@ class ArucoDetector:
         self._check(rc)
         return self._unpack(1)[0]
 
-    def detect_markers_batch(self, images: np.ndarray, encoding: str | None = None):
+    def detect_markers_batch(self, images: np.ndarray, encoding: str | None = None, unpack: bool = True):
+        """Frames in host memory (pinned or pageable): they go up sub-batch by sub-batch while the call runs."""
         imgs = np.ascontiguousarray(images, dtype=np.uint8)
         if encoding is None:
             encoding = "mono8" if imgs.ndim == 3 else "bgr8"
@@ -135,6 +136,9 @@ class ArucoDetector:
         rc = self._L.fid_detect_batch(self._ctx, imgs.ctypes.data, f, w, h, imgs.strides[1], imgs.strides[0],
                                       _lib.ENC[encoding], self._out, self.max_markers, self._n)
         self._check(rc)
+        self._last_frames = f
+        if not unpack:
+            return [int(self._n[k]) for k in range(f)]
         return self._unpack(f)
 
     def detect_markers_device(self, data_ptr: int, nframes: int, width: int, height: int, stride: int | None = None,

@@ -105,15 +105,25 @@ def _load_table(n: int, name: str = ""):
 
 
 _CACHE: dict = {}
+# Families whose shipped table holds (next to nothing but) locally generated fillers: under OpenCV's name a detector built on
+# them would silently fail to recognise real markers of that family, so they are only handed out on request (arithmetic
+# tests: 5- and 7-byte codewords, maxCorrectionBits 0 ... 9).  host/src/fiducials_host.cpp refuses the same enum values.
+FILLER_ONLY = frozenset({"DICT_4X4_1000", "DICT_ARUCO_ORIGINAL"} | {k for k in PREDEFINED if k.startswith(("DICT_6X6", "DICT_7X7"))})
 
 
-def get_predefined_dictionary(which) -> Dictionary:
-    """`which` is an OpenCV enum value (the node's `~dictionary` param) or a DICT_* name."""
-    name = _BY_ENUM[which] if isinstance(which, (int, np.integer)) else which
-    if name in _CACHE:
-        return _CACHE[name]
+def get_predefined_dictionary(which, allow_fillers: bool = False) -> Dictionary:
+    """`which` is an OpenCV enum value (the node's `~dictionary` param) or a DICT_* name.  Dictionaries of FILLER_ONLY raise
+    unless allow_fillers=True (their codewords are not OpenCV's).  For the 4X4 (<= 250) and 5X5 families `Dictionary.pinned`
+    says which ids carry OpenCV's authentic codeword (the ones the reference's fixtures pin); the rest are fillers too --
+    a deployment hands over OpenCV's own `Dictionary::bytesList` through `fid_dict.bytes`."""
+    name = _BY_ENUM.get(which) if isinstance(which, (int, np.integer)) else which
     if name not in PREDEFINED:
         raise ValueError(f"dictionary {which!r} not available in this build")
+    if name in FILLER_ONLY and not allow_fillers:
+        raise ValueError(f"dictionary {name} not available in this build: its shipped table holds locally generated filler "
+                         "codewords, not OpenCV's (pass allow_fillers=True for arithmetic tests only)")
+    if name in _CACHE:
+        return _CACHE[name]
     _, n, count, maxc = PREDEFINED[name]
     words, flags = _load_table(n, name)
     bl = np.zeros((count, 4, (n * n + 7) // 8), dtype=np.uint8)

@@ -69,10 +69,19 @@ def _dicno_of(d: Dictionary) -> int:
     return PREDEFINED[d.name][0]
 
 
-def gen_svg(marker_id: int, dicno: int = 7, paper_size=PAPER["letter"]) -> str:
-    d = get_predefined_dictionary(dicno)
+def _check_printable(d: Dictionary, marker_id: int, allow_fillers: bool) -> None:
+    """A printed marker must interoperate with OpenCV-based detectors: ids whose codeword in the shipped table is a locally
+    generated filler (Dictionary.pinned False) are refused unless the caller asks for them explicitly."""
     if not 0 <= marker_id < d.n_markers:
         raise ValueError(f"marker id {marker_id} not in {d.name}")
+    if not d.pinned[marker_id] and not allow_fillers:
+        raise ValueError(f"marker {marker_id} of {d.name}: the shipped table holds a locally generated filler codeword for this id, "
+                         "not OpenCV's -- a print of it would not be read by the reference's detector (allow_fillers=True to print it anyway)")
+
+
+def gen_svg(marker_id: int, dicno: int = 7, paper_size=PAPER["letter"], allow_fillers: bool = False) -> str:
+    d = get_predefined_dictionary(dicno, allow_fillers=allow_fillers)
+    _check_printable(d, marker_id, allow_fillers)
     black, white, lines, texts = page_layout(d, marker_id, paper_size)
     pw, ph = paper_size
     out = ['<svg width="%gmm" height="%gmm" viewBox="0 0 %g %g" version="1.1" xmlns="http://www.w3.org/2000/svg">' % (pw, ph, pw, ph)]
@@ -88,9 +97,12 @@ def gen_svg(marker_id: int, dicno: int = 7, paper_size=PAPER["letter"]) -> str:
     return "\n".join(out) + "\n"
 
 
-def write_pdf(path: str, marker_ids, dicno: int = 7, paper_size=PAPER["letter"]) -> None:
+def write_pdf(path: str, marker_ids, dicno: int = 7, paper_size=PAPER["letter"], allow_fillers: bool = False) -> None:
     """One marker per page, vector graphics, built-in Helvetica: a complete PDF 1.4 file written by hand."""
-    d = get_predefined_dictionary(dicno)
+    d = get_predefined_dictionary(dicno, allow_fillers=allow_fillers)
+    marker_ids = list(marker_ids)
+    for mid in marker_ids:
+        _check_printable(d, mid, allow_fillers)
     k = 72 / 25.4  # mm -> pt
     pw, ph = paper_size
     objs = []  # (object number -> bytes), numbered from 1
@@ -153,15 +165,18 @@ def main(argv=None) -> int:
     ap.add_argument("dictionary", type=int, default=7, nargs="?", help="dictionary to generate from")
     ap.add_argument("--paper-size", dest="paper_size", default="letter", choices=sorted(PAPER), help="paper size to use (letter or a4)")
     ap.add_argument("--svg", action="store_true", help="one self-contained SVG per marker into the directory `out`")
+    ap.add_argument("--allow-fillers", action="store_true",
+                    help="also print ids whose codeword in the shipped table is a locally generated filler (NOT OpenCV's: such a print "
+                         "is only read back by this repository's own tables)")
     a = ap.parse_args(argv)
     ids = list(range(a.startId, a.endId + 1))
     if a.svg:
         os.makedirs(a.out, exist_ok=True)
         for i in ids:
             with open(os.path.join(a.out, "marker%d.svg" % i), "w") as fh:
-                fh.write(gen_svg(i, a.dictionary, PAPER[a.paper_size]))
+                fh.write(gen_svg(i, a.dictionary, PAPER[a.paper_size], a.allow_fillers))
     else:
-        write_pdf(a.out, ids, a.dictionary, PAPER[a.paper_size])
+        write_pdf(a.out, ids, a.dictionary, PAPER[a.paper_size], a.allow_fillers)
     print("After printing, please make sure that the long lines around the marker are EXACTLY 14.0cm long. "
           "This is required for accurate position estimation.")
     return 0

@@ -553,7 +553,7 @@ def test_every_dictionary_family_all_stages(dic, minlen):
     5X5_50 / 5X5_100 (maxCorrectionBits 3), 4X4_1000 (0), 6X6 (5-byte codewords), 7X7 (7-byte codewords, 9 x 9 cells),
     ARUCO_ORIGINAL.  The 6 x 6 / 7 x 7 / ARUCO_ORIGINAL tables are labelled fillers (parity unpinned against OpenCV's table
     CONTENTS; the identify arithmetic is table-agnostic): every stage tap == oracle on the same table."""
-    d = get_predefined_dictionary(dic)
+    d = get_predefined_dictionary(dic, allow_fillers=True)
     fr = make_frame(d, 500 + dic, width=1280, height=720, n_markers=10, side_range=(80, 130))
     det = ArucoDetector(d, max_width=1280, max_height=720)
     try:

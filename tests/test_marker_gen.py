@@ -44,7 +44,10 @@ def test_svg_page_is_the_reference_template_with_vector_cells():
 
 def test_pdf_is_a_well_formed_multi_page_file(tmp_path):
     path = tmp_path / "markers.pdf"
-    assert marker_gen.main(["100", "103", str(path), "7", "--paper-size", "a4"]) == 0
+    import pytest
+    with pytest.raises(ValueError, match="filler"):  # ids 101, 102: the shipped table does not hold OpenCV's codeword for them
+        marker_gen.main(["100", "103", str(path), "7", "--paper-size", "a4"])
+    assert marker_gen.main(["100", "103", str(path), "7", "--paper-size", "a4", "--allow-fillers"]) == 0
     raw = path.read_bytes()
     assert raw.startswith(b"%PDF-1.4") and raw.rstrip().endswith(b"%%EOF")
     assert raw.count(b"/Type /Page ") == 4 and b"/Count 4" in raw and b"(102 D7) Tj" in raw
@@ -69,3 +72,8 @@ def test_svg_mode_and_bad_ids(tmp_path):
     import pytest
     with pytest.raises(ValueError):
         marker_gen.gen_svg(50, 0)  # DICT_4X4_50 has ids 0..49
+    with pytest.raises(ValueError, match="filler"):
+        marker_gen.gen_svg(3, 0)  # id 3 of 4X4: a filler codeword in the shipped table
+    with pytest.raises(ValueError, match="not available"):
+        marker_gen.gen_svg(1, 10)  # DICT_6X6_250: filler-only family
+    assert "1 D10" in marker_gen.gen_svg(1, 10, allow_fillers=True)

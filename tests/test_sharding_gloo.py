@@ -83,3 +83,25 @@ def test_bench_refuses_a_rank_count_that_is_not_running():
     # more GPUs asked for than visible (this container has none): no line, rc != 0
     out = _run_bench(["--gpus", "2", "--steps", "1"], {})
     assert out.returncode == 2 and "visible" in out.stderr and not [l for l in out.stdout.splitlines() if l.startswith("{")]
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_two_ranks_with_real_kernels_on_one_gpu():
+    """The N-rank path with real work (the lease is ONE GPU, so both ranks map to cuda:0 and the clock reduction runs on gloo:
+    FID_BENCH_OVERSUBSCRIBE=1): `python bench.py --gpus 2` starts two processes through its own launcher, each loads torch's
+    HIP runtime AND libfid_amd.so, owns its own stream of cfg 4 frames (seeds 10000 * rank + i) and finds 20 markers per frame.
+    What is NOT executed here is the `nccl` branch of init_dist (RCCL refuses two ranks on one device)."""
+    import json
+    out = _run_bench(["--gpus", "2", "--batch", "32", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extras"],
+                     {"FID_BENCH_OVERSUBSCRIBE": "1"}, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert "oversubscribed" in r and r["n_gpus"] == 1 and len(r["ranks"]) == 2
+    assert sorted(x["rank"] for x in r["ranks"]) == [0, 1] and len({x["pid"] for x in r["ranks"]}) == 2
+    assert all(x["device"] == "cuda:0" and x["markers_per_frame_found"] == 20.0 for x in r["ranks"]), r["ranks"]
+    assert r["config"]["frames_per_step"] == 64 and r["value"] > 0
+    # whole-job rate = both ranks' frames / the slower rank's time
+    assert r["value"] <= 2 * min(x["fps"] for x in r["ranks"]) * 1.05

@@ -224,10 +224,10 @@ def cpu_baseline(frames, K, D, budget_s=20.0):
         per.append(_cpu_one(len(per))[0])
     med = float(np.median(per))
     cores = os.cpu_count() or 1
-    # frame-parallel: one process per core, frames pre-split.  The port allocates and frees tens of MB per frame; glibc would
-    # return them to the kernel every time and 256 processes then wait on page faults, so the allocator keeps its heap
-    # (mallopt, inherited by the forked workers).  The process count that gives the best rate is reported (all hardware
-    # threads are not always the best choice on an SMT host).
+    # frame-parallel: one process per core, frames pre-split.  The port keeps a per-thread arena behind its malloc / free
+    # (oracle/ora_arena.h: round 2's build gave its tens of MB per frame back to the kernel every time and 64 processes scaled
+    # 13 x); the mallopt below is for what still goes through glibc.  The rates at nproc, nproc / 2 and nproc / 4 processes
+    # are all reported, the best one is `value` (all hardware threads are not always the best choice on an SMT host).
     try:
         import ctypes
 
@@ -237,6 +237,7 @@ def cpu_baseline(frames, K, D, budget_s=20.0):
     except Exception:  # noqa: BLE001
         pass
     best = None
+    pool_rates = {}
     for T in sorted({max(1, cores), max(1, cores // 2), max(1, cores // 4)}, reverse=True):
         per_proc = max(2, min(12, int(budget_s * 0.2 / max(med * 1.5, 1e-3))))
         chunks = [[(p * per_proc + k) for k in range(per_proc)] for p in range(T)]
@@ -245,6 +246,7 @@ def cpu_baseline(frames, K, D, budget_s=20.0):
             t = time.perf_counter()
             times = pool.map(_cpu_chunk, chunks, chunksize=1)
             wall = time.perf_counter() - t
+        pool_rates[str(T)] = round(T * per_proc / wall, 2)
         if best is None or T * per_proc / wall > best[0] * best[1] / best[2]:
             best = (T, per_proc, wall, times)
     T, per_proc, wall, times = best
@@ -256,6 +258,8 @@ def cpu_baseline(frames, K, D, budget_s=20.0):
                   f"wall clock after a warm-up round; 1 process: median {med * 1e3:.1f} ms per frame over {len(per)} frames "
                   f"after 3 warm-ups = {1 / med:.2f} frames/s (oracle/*.c, {flags})",
         "value_1core": round(1 / med, 2),
+        "pool_frames_per_s_by_processes": pool_rates,  # nproc, nproc / 2, nproc / 4 (the best one is `value`)
+        "pool_speedup_over_1core": round(nall / wall * med, 1),
         "ms_per_frame_1core_median": round(med * 1e3, 2),
         "ms_per_frame_in_pool_median": round(float(np.median([x for c in times for x in c])) * 1e3, 2),
     }

@@ -94,7 +94,7 @@ _SO_OVERRIDE = None
 def lib():
     global _LIB
     if _LIB is None:
-        so = _SO_OVERRIDE or os.path.join(_HERE, "liboracle.so")
+        so = _SO_OVERRIDE or os.path.join(os.environ.get("ORACLE_SO_DIR") or _HERE, "liboracle.so")  # ORACLE_SO_DIR: sanitizer builds
         if not os.path.exists(so):
             build()
         _LIB = C.CDLL(so)

@@ -17,6 +17,7 @@
  *   a8  filter_detected          aruco.cpp _filterDetectedMarkers (pointPolygonTest)
  *   a9  ora_corner_subpix        imgproc cornersubpix.cpp + samplers.cpp getRectSubPix_8u32f
  */
+#define _GNU_SOURCE /* mmap flags of ora_arena.h under -std=c11 */
 #include "aruco_oracle.h"
 
 #include <float.h>
@@ -24,6 +25,8 @@
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+
+#include "ora_arena.h" /* per-thread arena behind malloc / free in this file (test infrastructure; -DORA_NO_ARENA: off) */
 
 /* ------------------------------------------------------------------------------------------- */
 void ora_default_params(ora_params *p)

@@ -12,7 +12,7 @@ _LIB = None
 
 
 def build(force: bool = False) -> str:
-    so = os.path.join(_HERE, "libjpeg_oracle.so")
+    so = os.path.join(os.environ.get("ORACLE_SO_DIR") or _HERE, "libjpeg_oracle.so")  # ORACLE_SO_DIR: sanitizer builds
     src = os.path.join(_HERE, "jpeg_oracle.c")
     if force or not os.path.exists(so) or os.path.getmtime(src) > os.path.getmtime(so):
         subprocess.check_call(["make", "-C", _HERE, "-s", "libjpeg_oracle.so"])

@@ -10,7 +10,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO = os.path.join(_HERE, "_ref", "libstag_ref.so")
+SO = os.path.join(os.environ.get("ORACLE_SO_DIR") or os.path.join(_HERE, "_ref"), "libstag_ref.so")  # ORACLE_SO_DIR: sanitizer builds
 REF_ROOT = "/root/reference/stag_detect"
 _LIB = None
 

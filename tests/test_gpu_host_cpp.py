@@ -20,6 +20,9 @@ def _write_pgm(path, gray):
 
 def _build_host():
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "host"), "-s"])
+    if os.environ.get("FID_HOST_UBSAN") == "1":  # the same tests on the -fsanitize=undefined build (host/Makefile target ubsan)
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "host"), "-s", "ubsan"])
+        return os.path.join(ROOT, "host", "bin_ubsan", "aruco_images_test")
     return os.path.join(ROOT, "host", "bin", "aruco_images_test")
 
 

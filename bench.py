@@ -224,6 +224,21 @@ def cpu_baseline(frames, K, D, budget_s=20.0):
         per.append(_cpu_one(len(per))[0])
     med = float(np.median(per))
     cores = os.cpu_count() or 1
+    # what this process may really use: the affinity mask and the cgroup CPU quota (round 2 and 3 GPU boxes show 256 hardware
+    # threads and carry a quota of 16 CPUs: a pool of 64 processes then "scales" 12 x whatever the code does)
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:
+            q, p = fh.read().split()[:2]
+            if q != "max":
+                quota = float(q) / float(p)
+    except Exception:  # noqa: BLE001
+        pass
+    try:
+        cores = min(cores, len(os.sched_getaffinity(0)))
+    except Exception:  # noqa: BLE001
+        pass
+    usable = max(1, int(min(cores, quota) if quota else cores))
     # frame-parallel: one process per core, frames pre-split.  The port keeps a per-thread arena behind its malloc / free
     # (oracle/ora_arena.h: round 2's build gave its tens of MB per frame back to the kernel every time and 64 processes scaled
     # 13 x); the mallopt below is for what still goes through glibc.  The rates at nproc, nproc / 2 and nproc / 4 processes
@@ -238,7 +253,7 @@ def cpu_baseline(frames, K, D, budget_s=20.0):
         pass
     best = None
     pool_rates = {}
-    for T in sorted({max(1, cores), max(1, cores // 2), max(1, cores // 4)}, reverse=True):
+    for T in sorted({max(1, usable), max(1, usable // 2), min(cores, 2 * usable)}, reverse=True):
         per_proc = max(2, min(12, int(budget_s * 0.2 / max(med * 1.5, 1e-3))))
         chunks = [[(p * per_proc + k) for k in range(per_proc)] for p in range(T)]
         with mp.get_context("fork").Pool(T) as pool:
@@ -254,11 +269,12 @@ def cpu_baseline(frames, K, D, budget_s=20.0):
     oracle.use_library(None)
     return {
         "value": round(nall / wall, 2), "unit": "frames/s", "cores": T, "kind": "port",
-        "sample": f"{nall} frames of the bench batch ({per_proc} per process, pre-split) on {T} processes = {cores} host threads, "
+        "sample": f"{nall} frames of the bench batch ({per_proc} per process, pre-split) on {T} processes ({usable} usable CPUs: {cores} hardware threads in the affinity mask, cgroup quota {quota}), "
                   f"wall clock after a warm-up round; 1 process: median {med * 1e3:.1f} ms per frame over {len(per)} frames "
                   f"after 3 warm-ups = {1 / med:.2f} frames/s (oracle/*.c, {flags})",
         "value_1core": round(1 / med, 2),
-        "pool_frames_per_s_by_processes": pool_rates,  # nproc, nproc / 2, nproc / 4 (the best one is `value`)
+        "pool_frames_per_s_by_processes": pool_rates,  # usable CPUs, half of them, twice as many (the best one is `value`)
+        "host": {"hardware_threads": os.cpu_count(), "cgroup_cpu_quota": quota, "usable_cpus": usable},
         "pool_speedup_over_1core": round(nall / wall * med, 1),
         "ms_per_frame_1core_median": round(med * 1e3, 2),
         "ms_per_frame_in_pool_median": round(float(np.median([x for c in times for x in c])) * 1e3, 2),
@@ -350,22 +366,74 @@ def jpeg_side_result(local_rank, frames):
     return out
 
 
+STAG_HD, STAG_EC, STAG_MARKERS, STAG_UNIQUE = 21, 7, 12, 16
+
+
+def make_stag_frames(seeds):
+    """The cfg 5 frames: 1920x1080, every one of the 12 ids of library HD21 once per frame (round 2 drew 20 markers from the
+    12 ids and checkDuplicate threw half of the rendered work away: the line said 20 markers and found 10)."""
+    import multiprocessing as mp
+
+    cache = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"fid_synth_stag_HD{STAG_HD}_{W}x{H}_{STAG_MARKERS}")
+    os.makedirs(cache, exist_ok=True)
+    out, todo = {}, []
+    for sd in seeds:
+        try:
+            out[sd] = np.load(os.path.join(cache, f"{sd}.npy"))
+        except Exception:  # noqa: BLE001
+            todo.append(sd)
+    if todo:
+        with mp.get_context("fork").Pool(max(1, min(len(todo), (os.cpu_count() or 2), 32))) as pool:
+            for sd, im in zip(todo, pool.map(_gen_stag_one, todo, chunksize=1)):
+                out[sd] = im
+                try:
+                    np.save(os.path.join(cache, f"{sd}.npy"), im)
+                except Exception:  # noqa: BLE001
+                    pass
+    return [out[sd] for sd in seeds]
+
+
+def _gen_stag_one(sd):
+    from fiducials_amd import stag as fstag, synth
+
+    words = fstag.load_library(STAG_HD)
+    ids = np.random.default_rng(sd).permutation(len(words) // 4)[:STAG_MARKERS]
+    return synth.make_stag_frame(words, sd, W, H, STAG_MARKERS, ids=ids).image
+
+
+def stag_pmc_traffic():
+    """HBM bytes per frame of the STag pipeline from the committed PMC passes (profiles/stag_pmc_traffic.json, tools/stag_pmc.sh),
+    refused (None) when it was measured on another build of the library."""
+    try:
+        import hashlib
+
+        from fiducials_amd import _lib
+
+        with open(os.path.join(ROOT, "profiles", "stag_pmc_traffic.json")) as fh:
+            doc = json.load(fh)
+        with open(_lib.lib_path(), "rb") as fh:
+            if hashlib.sha256(fh.read()).hexdigest() != doc.get("library_sha256"):
+                return None
+        return int(doc["pipeline_bytes_per_frame"])
+    except Exception:  # noqa: BLE001
+        return None
+
+
 def stag_side_result(local_rank, args):
     """BASELINE cfg 5 inside the default line (so that the driver's run times it too): a short run of the stag_detect path
     (Stag::detectMarkers + 5-point pose, frames from host memory, one frame per call on concurrent contexts) and the
     REFERENCE's own Stag::detectMarkers on one host core next to it."""
     from fiducials_amd import stag as fstag, synth
 
-    # (16 contexts here, not the 22 of `--workload stag`: this child shares the GPU with its parent, whose closed contexts keep
-    #  their hardware queues -- 22 more streams on top collapse to 8 frames/s)
-    hd, ec, B, T = 21, 7, 64, 16
-    words = fstag.load_library(hd)
-    frames = [synth.make_stag_frame(words, sd, W, H, MARKERS).image for sd in shard_seeds(0, 1, 4, "stag")]
+    # (frames as a grid dimension: 64 frame slots = four groups of 16, each group one stream and one host thread, every kernel
+    #  launched once per group; round 2 ran a stream per frame slot and depended on GPU_MAX_HW_QUEUES)
+    hd, ec, B, T = STAG_HD, STAG_EC, 128, 64
+    frames = make_stag_frames(shard_seeds(0, 1, STAG_UNIQUE, "stag"))
     pool = fstag.StagPool(hd, ec, n_contexts=T, max_width=W, max_height=H, device=local_rank)
     batch = np.stack([frames[i % len(frames)] for i in range(B)])
     pool.detect_markers_batch(batch, synth.K_DEFAULT, None, 0.18)
     t = time.perf_counter()
-    steps, found = 4, 0
+    steps, found = 3, 0
     for _ in range(steps):
         m, _ = pool.detect_markers_batch(batch, synth.K_DEFAULT, None, 0.18)
         found += sum(len(x) for x in m)
@@ -378,10 +446,16 @@ def stag_side_result(local_rank, args):
         one.detect_markers(frames[i % len(frames)])
         ts.append(time.perf_counter() - t)
     one.close()
-    res = {"value": round(B * steps / dt, 2), "unit": "frames/s", "ms_single_frame": round(float(np.median(ts[2:])) * 1e3, 3),
-           "workload": f"cfg5: {B} frames per step on {T} concurrent contexts, 1920x1080 mono8 from host memory, 20 markers per frame "
-                       "drawn from the 12 ids of library HD21 (duplicates of an id are dropped by checkDuplicate, as in the "
-                       "reference), errorCorrection 7",
+    algo = 10 * W * H  # ~10 B/px for the EDPF streaming stages (20.7 MB per 1080p frame)
+    fps5 = B * steps / dt
+    res = {"value": round(fps5, 2), "unit": "frames/s", "ms_single_frame": round(float(np.median(ts[2:])) * 1e3, 3),
+           "roofline": {"bound": "hbm", "kernel": "pipeline (latency-bound: edge routing, line fitting, simplex search)",
+                        "achieved": round(fps5 * algo / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(fps5 * algo / 1e9 / HBM_PEAK_GBS, 6),
+                        "algo_bytes_per_frame": algo, "traffic": stag_pmc_traffic()},
+           "workload": f"cfg5: {B} frames per step ({len(frames)} unique) through {T} frame slots = groups of 16 in lockstep (frames as a grid "
+                       "dimension), 1920x1080 mono8 from host memory, "
+                       f"{STAG_MARKERS} markers per frame = every id of library HD21 once, errorCorrection 7",
+           "markers_per_frame_rendered": STAG_MARKERS,
            "markers_per_frame_found": round(found / (B * steps), 2)}
     if not args.no_cpu_baseline:
         from oracle import stag_ref
@@ -412,9 +486,8 @@ def main_stag(args):
     dist = init_dist(world, local_rank)
     from fiducials_amd import stag as fstag, synth
 
-    hd, ec, B = 21, 7, min(args.batch, 88)
-    words = fstag.load_library(hd)
-    frames = [synth.make_stag_frame(words, sd, W, H, MARKERS).image for sd in shard_seeds(rank, world, min(B, 4), "stag")]
+    hd, ec, B = STAG_HD, STAG_EC, min(args.batch, 128)
+    frames = make_stag_frames(shard_seeds(rank, world, min(B, STAG_UNIQUE), "stag"))
     # several contexts side by side (fid_stag_detect_markers_batch: one host thread + one HIP stream per context inside the
     # library): a frame's work is a chain of small kernels, several frames in flight fill the GPU
     T = max(1, min(args.streams, B))
@@ -447,11 +520,11 @@ def main_stag(args):
     if rank == 0:
         algo = 10 * W * H  # ~10 B/px for the EDPF streaming stages
         out = {
-            "metric": "frames/sec @1920x1080 20 STag HD21 markers (stag_detect path: detectMarkers + 5-point pose)",
+            "metric": "frames/sec @1920x1080 12 STag HD21 markers (stag_detect path: detectMarkers + 5-point pose)",
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": f"synthetic ({len(frames)} unique frames per GPU, host memory)",
-            "config": {"workload": f"cfg5: {B} frames per step on {T} concurrent contexts (FID_STAG_THREADS host threads, default 4, deal the segments), 1920x1080 mono8, 20 markers/frame, "
+            "config": {"workload": f"cfg5: {B} frames per step through {T} frame slots (groups of 16 in lockstep, frames as a grid dimension), 1920x1080 mono8, 12 markers/frame (every HD21 id once), "
                                    "library HD21, errorCorrection 7, marker_size 0.18", "frames_per_step": B * n_gpus, "contexts_per_gpu": T,
                        "parallelism": f"frames sharded over {n_gpus} GPU(s), no collective",
                        "markers_per_frame_found": round(markers / max(B * args.steps, 1), 2)},
@@ -587,7 +660,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the cfg 2 latency and cfg 5 (STag) side results")
     ap.add_argument("--stag-side-child", action="store_true", help=argparse.SUPPRESS)  # the cfg 5 side result, own process
-    ap.add_argument("--streams", type=int, default=22, help="stag workload: concurrent contexts (host threads) per GPU")
+    ap.add_argument("--streams", type=int, default=64, help="stag workload: frame slots per GPU (groups of 16 in lockstep)")
     ap.add_argument("--workload", choices=["aruco", "stag"], default="aruco",
                     help="aruco = the BASELINE.json metric (default); stag = BASELINE cfg 5, the stag_detect path")
     args = ap.parse_args()

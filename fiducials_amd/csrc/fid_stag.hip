@@ -40,7 +40,7 @@ __device__ __forceinline__ int stag_reflect101(int p, int n)
 // from LDS.  HBM traffic per pixel: 1 byte in (+ halo), 4 bytes out (smooth u8, grad i16, dir u8).
 #define SX 64
 #define SY 16
-__global__ __launch_bounds__(256) void k_stag_smooth_grad(const uint8_t *__restrict__ src, int stride, int W, int H, int grad_thresh,
+__device__ __forceinline__ void k_stag_smooth_grad_impl(const uint8_t *__restrict__ src, int stride, int W, int H, int grad_thresh,
                                                            uint8_t *__restrict__ smooth, int16_t *__restrict__ grad,
                                                            uint8_t *__restrict__ dir)
 {
@@ -96,6 +96,14 @@ __global__ __launch_bounds__(256) void k_stag_smooth_grad(const uint8_t *__restr
         dir[idx] = sum >= grad_thresh ? (gxv >= gyv ? STAG_EDGE_VERTICAL : STAG_EDGE_HORIZONTAL) : 0;
     }
 }
+__global__ __launch_bounds__(256) void k_stag_smooth_grad(const uint8_t *__restrict__ src, int stride, int W, int H, int grad_thresh, uint8_t *__restrict__ smooth, int16_t *__restrict__ grad, uint8_t *__restrict__ dir)
+{
+    k_stag_smooth_grad_impl(src, stride, W, H, grad_thresh, smooth, grad, dir);
+}
+struct k_stag_smooth_grad_fn {
+    static constexpr int kBounds = 256;
+    __device__ __forceinline__ void operator()(const uint8_t *__restrict__ src, int stride, int W, int H, int grad_thresh, uint8_t *__restrict__ smooth, int16_t *__restrict__ grad, uint8_t *__restrict__ dir) const { k_stag_smooth_grad_impl(src, stride, W, H, grad_thresh, smooth, grad, dir); }
+};
 
 // The smoothed image is 8-bit, so |gx|, |gy| <= 3 * 255 and the gradient value never exceeds 1530: the reference's
 // 128 * 256 counting-sort bins (SIZE in SortAnchorsByGradValue) are used only below STAG_BINS.
@@ -104,7 +112,7 @@ __global__ __launch_bounds__(256) void k_stag_smooth_grad(const uint8_t *__restr
 
 // Anchor points: local gradient maxima across the edge normal (ANCHOR_THRESH, SCAN_INTERVAL as in the reference), counted
 // per (row, gradient value) for the counting sort (global atomics: the anchors are sparse).
-__global__ __launch_bounds__(256) void k_stag_anchors(const int16_t *__restrict__ grad, const uint8_t *__restrict__ dir, int W, int H,
+__device__ __forceinline__ void k_stag_anchors_impl(const int16_t *__restrict__ grad, const uint8_t *__restrict__ dir, int W, int H,
                                                        int grad_thresh, int anchor_thresh, int scan_interval,
                                                        uint8_t *__restrict__ edge, unsigned *__restrict__ rowhist)
 {
@@ -135,9 +143,17 @@ __global__ __launch_bounds__(256) void k_stag_anchors(const int16_t *__restrict_
         edge[idx] = e;
     }
 }
+__global__ __launch_bounds__(256) void k_stag_anchors(const int16_t *__restrict__ grad, const uint8_t *__restrict__ dir, int W, int H, int grad_thresh, int anchor_thresh, int scan_interval, uint8_t *__restrict__ edge, unsigned *__restrict__ rowhist)
+{
+    k_stag_anchors_impl(grad, dir, W, H, grad_thresh, anchor_thresh, scan_interval, edge, rowhist);
+}
+struct k_stag_anchors_fn {
+    static constexpr int kBounds = 256;
+    __device__ __forceinline__ void operator()(const int16_t *__restrict__ grad, const uint8_t *__restrict__ dir, int W, int H, int grad_thresh, int anchor_thresh, int scan_interval, uint8_t *__restrict__ edge, unsigned *__restrict__ rowhist) const { k_stag_anchors_impl(grad, dir, W, H, grad_thresh, anchor_thresh, scan_interval, edge, rowhist); }
+};
 
 // anchors per (band of STAG_BAND_ROWS rows, gradient value)
-__global__ __launch_bounds__(256) void k_stag_bandsum(const unsigned *__restrict__ rowhist, int H, unsigned *__restrict__ bandhist)
+__device__ __forceinline__ void k_stag_bandsum_impl(const unsigned *__restrict__ rowhist, int H, unsigned *__restrict__ bandhist)
 {
     const int g = blockIdx.x * 256 + threadIdx.x, band = blockIdx.y;
     unsigned acc = 0;
@@ -148,10 +164,18 @@ __global__ __launch_bounds__(256) void k_stag_bandsum(const unsigned *__restrict
     }
     bandhist[(size_t)band * STAG_BINS + g] = acc;
 }
+__global__ __launch_bounds__(256) void k_stag_bandsum(const unsigned *__restrict__ rowhist, int H, unsigned *__restrict__ bandhist)
+{
+    k_stag_bandsum_impl(rowhist, H, bandhist);
+}
+struct k_stag_bandsum_fn {
+    static constexpr int kBounds = 256;
+    __device__ __forceinline__ void operator()(const unsigned *__restrict__ rowhist, int H, unsigned *__restrict__ bandhist) const { k_stag_bandsum_impl(rowhist, H, bandhist); }
+};
 
 // per gradient value: bands from the LAST to the first (the reference's --C[grad] placement leaves the offsets of one
 // gradient value in descending order) -> start of each band inside the value's bucket; tot[g] = size of the bucket
-__global__ __launch_bounds__(256) void k_stag_bandscan(unsigned *__restrict__ bandhist, int nbands, unsigned *__restrict__ tot)
+__device__ __forceinline__ void k_stag_bandscan_impl(unsigned *__restrict__ bandhist, int nbands, unsigned *__restrict__ tot)
 {
     const int g = blockIdx.x * 256 + threadIdx.x;
     unsigned acc = 0;
@@ -173,9 +197,17 @@ __global__ __launch_bounds__(256) void k_stag_bandscan(unsigned *__restrict__ ba
     }
     tot[g] = acc;
 }
+__global__ __launch_bounds__(256) void k_stag_bandscan(unsigned *__restrict__ bandhist, int nbands, unsigned *__restrict__ tot)
+{
+    k_stag_bandscan_impl(bandhist, nbands, tot);
+}
+struct k_stag_bandscan_fn {
+    static constexpr int kBounds = 256;
+    __device__ __forceinline__ void operator()(unsigned *__restrict__ bandhist, int nbands, unsigned *__restrict__ tot) const { k_stag_bandscan_impl(bandhist, nbands, tot); }
+};
 
 // exclusive prefix sums over the gradient values (one workgroup): bstart[g] = number of anchors with a smaller gradient
-__global__ __launch_bounds__(512) void k_stag_scan(const unsigned *__restrict__ tot, unsigned *__restrict__ bstart, unsigned *__restrict__ n_anchors)
+__device__ __forceinline__ void k_stag_scan_impl(const unsigned *__restrict__ tot, unsigned *__restrict__ bstart, unsigned *__restrict__ n_anchors)
 {
     __shared__ unsigned s_part[512];
     const int tid = threadIdx.x;
@@ -198,12 +230,20 @@ __global__ __launch_bounds__(512) void k_stag_scan(const unsigned *__restrict__ 
     for (int k = 0; k < PER; k++) bstart[tid * PER + k] = base + loc[k];
     if (tid == 511) *n_anchors = s_part[511];
 }
+__global__ __launch_bounds__(512) void k_stag_scan(const unsigned *__restrict__ tot, unsigned *__restrict__ bstart, unsigned *__restrict__ n_anchors)
+{
+    k_stag_scan_impl(tot, bstart, n_anchors);
+}
+struct k_stag_scan_fn {
+    static constexpr int kBounds = 512;
+    __device__ __forceinline__ void operator()(const unsigned *__restrict__ tot, unsigned *__restrict__ bstart, unsigned *__restrict__ n_anchors) const { k_stag_scan_impl(tot, bstart, n_anchors); }
+};
 
 // Placement: one workgroup per band, one wave per row.  LDS holds, per (row of the band, gradient value), the next free
 // slot: bucket start + band start + anchors of that value in the LATER rows of the band.  Every wave then goes through
 // its row from the last column to the first, 64 columns at a time; lanes with the same gradient value take consecutive
 // slots in descending column order.  No sort, no atomics: the order is exactly the reference's.
-__global__ __launch_bounds__(64 * STAG_BAND_ROWS) void k_stag_place(const int16_t *__restrict__ grad, const uint8_t *__restrict__ edge, int W, int H,
+__device__ __forceinline__ void k_stag_place_impl(const int16_t *__restrict__ grad, const uint8_t *__restrict__ edge, int W, int H,
                                                                     const unsigned *__restrict__ rowhist, const unsigned *__restrict__ bandstart,
                                                                     const unsigned *__restrict__ bstart, int32_t *__restrict__ sorted)
 {
@@ -255,11 +295,23 @@ __global__ __launch_bounds__(64 * STAG_BAND_ROWS) void k_stag_place(const int16_
         }
     }
 }
+__global__ __launch_bounds__(64 * STAG_BAND_ROWS) void k_stag_place(const int16_t *__restrict__ grad, const uint8_t *__restrict__ edge, int W, int H, const unsigned *__restrict__ rowhist, const unsigned *__restrict__ bandstart, const unsigned *__restrict__ bstart, int32_t *__restrict__ sorted)
+{
+    k_stag_place_impl(grad, edge, W, H, rowhist, bandstart, bstart, sorted);
+}
+struct k_stag_place_fn {
+    static constexpr int kBounds = 64 * STAG_BAND_ROWS;
+    __device__ __forceinline__ void operator()(const int16_t *__restrict__ grad, const uint8_t *__restrict__ edge, int W, int H, const unsigned *__restrict__ rowhist, const unsigned *__restrict__ bandstart, const unsigned *__restrict__ bstart, int32_t *__restrict__ sorted) const { k_stag_place_impl(grad, edge, W, H, rowhist, bandstart, bstart, sorted); }
+};
 
 #include "fid_stag_route.hip"
 #include "fid_stag_lines.hip"
 #include "fid_stag_quads.hip"
 #include "fid_stag_pose.hip"
+#include "fid_stag_batch.h"
+thread_local StagRecorder *g_stag_rec = nullptr;
+std::vector<StagHostAlias> g_stag_aliases;
+std::mutex g_stag_alias_mutex;
 
 // ------------------------------------------------------------------------------------------------ C-ABI
 // ---- host side of the line validation: the number-of-false-alarms table.  nfa() restates NFA.cpp:155-239 (the LSD
@@ -379,6 +431,7 @@ static void stag_fill_code_locations(double *locs /* [72][3] */)
 struct fid_stag_ctx {
     int device = 0, maxW = 0, maxH = 0, libraryHD = 0, errorCorrection = 0;
     hipStream_t stream = nullptr;
+    hipStream_t group_stream = nullptr;  // group mode (fid_stag_batch.h): the stream of the group this context's frame travels with
     uint8_t *d_src = nullptr, *d_smooth = nullptr, *d_dir = nullptr, *d_edge = nullptr;
     int16_t *d_grad = nullptr;
     unsigned *d_rowhist = nullptr, *d_bandhist = nullptr, *d_tot = nullptr, *d_bstart = nullptr, *d_n = nullptr;
@@ -472,7 +525,9 @@ fid_status fid_stag_create(int libraryHD, int errorCorrection, int max_width, in
     c->libraryHD = libraryHD;
     c->errorCorrection = errorCorrection;
     const size_t n = (size_t)max_width * max_height;
-    bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
+    // (the context's stream is made when it is first needed -- stag_stream(): a pool of 64 frame slots works on four streams, and
+    //  64 idle streams are 64 claims on the hardware queues this process shares with every other user of the GPU)
+    bool ok = hipSetDevice(device) == hipSuccess;
     ok = ok && hipMalloc((void **)&c->d_src, n) == hipSuccess && hipMalloc((void **)&c->d_smooth, n) == hipSuccess &&
          hipMalloc((void **)&c->d_dir, n) == hipSuccess && hipMalloc((void **)&c->d_edge, n) == hipSuccess &&
          hipMalloc((void **)&c->d_grad, n * 2) == hipSuccess && hipMalloc((void **)&c->d_sorted, n * 4) == hipSuccess &&
@@ -507,7 +562,14 @@ fid_status fid_stag_create(int libraryHD, int errorCorrection, int max_width, in
         c->route_mode = (e && !strcmp(e, "seq")) ? 0 : 1;
         c->route_tile = (e && !strcmp(e, "notile")) ? 0 : 1;  // "notile": component-parallel, walks in global memory
         ok = hipFuncSetAttribute((const void *)k_stag_route_walk, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) == hipSuccess &&
-             hipFuncSetAttribute((const void *)k_stag_comp_sort_big, hipFuncAttributeMaxDynamicSharedMemorySize, STAG_SORT_BIG * 4) == hipSuccess;
+             hipFuncSetAttribute((const void *)k_stag_comp_sort_big, hipFuncAttributeMaxDynamicSharedMemorySize, STAG_SORT_BIG * 4) == hipSuccess &&
+             // (and their group-mode trampolines, fid_stag_batch.h)
+             hipFuncSetAttribute((const void *)k_stag_batch<k_stag_route_walk_fn>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) == hipSuccess &&
+             hipFuncSetAttribute((const void *)k_stag_batch<k_stag_comp_sort_big_fn>, hipFuncAttributeMaxDynamicSharedMemorySize, STAG_SORT_BIG * 4) == hipSuccess;
+        if (getenv("FID_VERBOSE"))
+            fprintf(stderr, "fid stag: frames per merged launch: route_walk %d, route_extract %d, quads %d, decode %d, smooth_grad %d\n",
+                    StagTab<k_stag_route_walk_fn>::kMax, StagTab<k_stag_route_extract_fn>::kMax, StagTab<k_stag_quads_fn>::kMax,
+                    StagTab<k_stag_decode_fn>::kMax, StagTab<k_stag_smooth_grad_fn>::kMax);
     }
     ok = ok && hipMalloc((void **)&c->d_smooth2, n) == hipSuccess && hipMalloc((void **)&c->d_vgrad, n * 2) == hipSuccess &&
          hipMalloc((void **)&c->d_vhist, STAG_BINS * 4) == hipSuccess && hipMalloc((void **)&c->d_prob, STAG_BINS * 8) == hipSuccess &&
@@ -535,6 +597,13 @@ fid_status fid_stag_create(int libraryHD, int errorCorrection, int max_width, in
          hipMalloc((void **)&c->d_poses, (n / 9 + 16) * sizeof(fid_stag_pose_out)) == hipSuccess;
     ok = ok && hipHostMalloc((void **)&c->hp, sizeof(fid_stag_ctx::Pinned), hipHostMallocDefault) == hipSuccess &&
          hipHostMalloc((void **)&c->h_src, n, hipHostMallocDefault) == hipSuccess;
+    if (ok) {  // group mode writes the per-segment counters straight into the pinned block (fid_stag_batch.h)
+        void *dev = nullptr;
+        if (hipHostGetDevicePointer(&dev, c->hp, 0) == hipSuccess && dev) {
+            std::lock_guard<std::mutex> g(g_stag_alias_mutex);
+            g_stag_aliases.push_back({(const char *)c->hp, sizeof(fid_stag_ctx::Pinned), (char *)dev});
+        }
+    }
     if (ok) {
         double locs[72 * 3];
         stag_fill_code_locations(locs);
@@ -569,6 +638,14 @@ void fid_stag_destroy(fid_stag_ctx *c)
                    c->d_locs, c->d_words, c->d_cand, c->d_markers, c->d_found, c->d_nmarkers, c->d_chosen, c->d_poses};
     for (void *p : dev)
         if (p) (void)hipFree(p);
+    if (c->hp) {
+        std::lock_guard<std::mutex> g(g_stag_alias_mutex);
+        for (size_t k = 0; k < g_stag_aliases.size(); k++)
+            if (g_stag_aliases[k].host == (const char *)c->hp) {
+                g_stag_aliases.erase(g_stag_aliases.begin() + (long)k);
+                break;
+            }
+    }
     if (c->hp) (void)hipHostFree(c->hp);
     if (c->h_src) (void)hipHostFree(c->h_src);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -605,6 +682,12 @@ struct StagJob {
     StagRoute R;
 };
 
+static hipStream_t stag_stream(fid_stag_ctx *c)
+{
+    if (!c->stream && hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) c->stream = nullptr;  // (nullptr: the default stream)
+    return c->stream;
+}
+
 // ComputeMinLineLength (EDLines.cpp:694-703) and the floor of 9 of DetectLinesByEDPF (:888-892): a function of the image
 // size alone, evaluated on the host like the reference does
 static int stag_min_line_len(int W, int H)
@@ -625,14 +708,14 @@ static fid_status stag_finish(StagJob &j, fid_status rc)
 // the sequential road of the routing: one lane for the whole frame (the reference's loop as it stands)
 static bool stag_launch_route_seq(fid_stag_ctx *c, StagJob &j)
 {
-    hipStream_t st = c->stream;
+    hipStream_t st = c->group_stream ? c->group_stream : stag_stream(c);
     const size_t n = (size_t)c->W * c->H;
-    if (hipMemcpyAsync(c->d_edgeimg, c->d_edge, n, hipMemcpyDeviceToDevice, st) != hipSuccess) return false;
+    if (STAG_MEMCPY(c->d_edgeimg, c->d_edge, n, hipMemcpyDeviceToDevice, st) != hipSuccess) return false;
     // pixels the routing has not written read as (-1, -1) (the reference reads uninitialised memory there)
-    if (hipMemsetAsync(c->d_outpix, 0xff, n * sizeof(int2), st) != hipSuccess) return false;
-    hipLaunchKernelGGL(k_stag_route_seq, dim3(1), dim3(64), 0, st, j.R, c->d_sorted, c->d_n, 16);
+    if (STAG_MEMSET(c->d_outpix, 0xff, n * sizeof(int2), st) != hipSuccess) return false;
+    STAG_LAUNCH(k_stag_route_seq, dim3(1), dim3(64), 0, st, j.R, c->d_sorted, c->d_n, 16);
     if (hipGetLastError() != hipSuccess) return false;
-    if (hipMemcpyAsync(c->hp->rcount, c->d_rcount, 12, hipMemcpyDeviceToHost, st) != hipSuccess) return false;
+    if (STAG_MEMCPY(c->hp->rcount, c->d_rcount, 12, hipMemcpyDeviceToHost, st) != hipSuccess) return false;
     j.rstate = RS_SEQ;
     return true;
 }
@@ -659,16 +742,17 @@ static fid_status stag_advance(fid_stag_ctx *c, StagJob &j)
 static fid_status stag_advance_impl(fid_stag_ctx *c, StagJob &j)
 {
     if (j.done) return j.rc;
-    hipStream_t st = c->stream;
+    hipStream_t st = c->group_stream ? c->group_stream : stag_stream(c);
+    const bool grouped = c->group_stream != nullptr;  // (the group driver has waited for the group's stream already)
     if (hipSetDevice(c->device) != hipSuccess) return stag_finish(j, FID_E_HIP);
 #ifdef FID_DEBUG_STATS
     {
         const auto t0 = STAG_NOW();
-        if (j.seg > 0 && hipStreamSynchronize(st) != hipSuccess) return stag_finish(j, FID_E_HIP);
+        if (j.seg > 0 && !grouped && hipStreamSynchronize(st) != hipSuccess) return stag_finish(j, FID_E_HIP);
         g_stag_ns_sync += STAG_NS(t0, STAG_NOW());
     }
 #else
-    if (j.seg > 0 && hipStreamSynchronize(st) != hipSuccess) return stag_finish(j, FID_E_HIP);
+    if (j.seg > 0 && !grouped && hipStreamSynchronize(st) != hipSuccess) return stag_finish(j, FID_E_HIP);
 #endif
     const int GRADIENT_THRESH = 16, ANCHOR_THRESH = 0, SCAN_INTERVAL = 1;  // DetectEdgesByEDPF, ED.cpp:155-169
     switch (j.seg) {
@@ -677,20 +761,20 @@ static fid_status stag_advance_impl(fid_stag_ctx *c, StagJob &j)
         if (j.last >= SS_UNREFINED && !c->d_words) return stag_finish(j, FID_E_INVALID_ARG);  // no marker library loaded
         const int W = j.width, H = j.height;
         for (int y = 0; y < H; y++) memcpy(c->h_src + (size_t)y * W, j.gray + (size_t)y * j.stride, (size_t)W);
-        if (hipMemcpyAsync(c->d_src, c->h_src, (size_t)W * H, hipMemcpyHostToDevice, st) != hipSuccess) return stag_finish(j, FID_E_HIP);
-        if (hipMemsetAsync(c->d_rowhist, 0, (size_t)H * STAG_BINS * 4, st) != hipSuccess) return stag_finish(j, FID_E_HIP);
-        hipLaunchKernelGGL(k_stag_smooth_grad, dim3((W + SX - 1) / SX, (H + SY - 1) / SY), dim3(256), 0, st, c->d_src, W, W, H, GRADIENT_THRESH,
+        if (STAG_MEMCPY(c->d_src, c->h_src, (size_t)W * H, hipMemcpyHostToDevice, st) != hipSuccess) return stag_finish(j, FID_E_HIP);
+        if (STAG_MEMSET(c->d_rowhist, 0, (size_t)H * STAG_BINS * 4, st) != hipSuccess) return stag_finish(j, FID_E_HIP);
+        STAG_LAUNCH(k_stag_smooth_grad, dim3((W + SX - 1) / SX, (H + SY - 1) / SY), dim3(256), 0, st, c->d_src, W, W, H, GRADIENT_THRESH,
                            c->d_smooth, c->d_grad, c->d_dir);
         const int blocks = 2048, nbands = (H + STAG_BAND_ROWS - 1) / STAG_BAND_ROWS;
-        hipLaunchKernelGGL(k_stag_anchors, dim3(blocks), dim3(256), 0, st, c->d_grad, c->d_dir, W, H, GRADIENT_THRESH, ANCHOR_THRESH, SCAN_INTERVAL,
+        STAG_LAUNCH(k_stag_anchors, dim3(blocks), dim3(256), 0, st, c->d_grad, c->d_dir, W, H, GRADIENT_THRESH, ANCHOR_THRESH, SCAN_INTERVAL,
                            c->d_edge, c->d_rowhist);
-        hipLaunchKernelGGL(k_stag_bandsum, dim3(STAG_BINS / 256, nbands), dim3(256), 0, st, c->d_rowhist, H, c->d_bandhist);
-        hipLaunchKernelGGL(k_stag_bandscan, dim3(STAG_BINS / 256), dim3(256), 0, st, c->d_bandhist, nbands, c->d_tot);
-        hipLaunchKernelGGL(k_stag_scan, dim3(1), dim3(512), 0, st, c->d_tot, c->d_bstart, c->d_n);
-        hipLaunchKernelGGL(k_stag_place, dim3(nbands), dim3(64 * STAG_BAND_ROWS), 0, st, c->d_grad, c->d_edge, W, H, c->d_rowhist, c->d_bandhist,
+        STAG_LAUNCH(k_stag_bandsum, dim3(STAG_BINS / 256, nbands), dim3(256), 0, st, c->d_rowhist, H, c->d_bandhist);
+        STAG_LAUNCH(k_stag_bandscan, dim3(STAG_BINS / 256), dim3(256), 0, st, c->d_bandhist, nbands, c->d_tot);
+        STAG_LAUNCH(k_stag_scan, dim3(1), dim3(512), 0, st, c->d_tot, c->d_bstart, c->d_n);
+        STAG_LAUNCH(k_stag_place, dim3(nbands), dim3(64 * STAG_BAND_ROWS), 0, st, c->d_grad, c->d_edge, W, H, c->d_rowhist, c->d_bandhist,
                            c->d_bstart, c->d_sorted);
         if (hipGetLastError() != hipSuccess) return stag_finish(j, FID_E_HIP);
-        if (hipMemcpyAsync(&c->hp->n_anchors, c->d_n, 4, hipMemcpyDeviceToHost, st) != hipSuccess) return stag_finish(j, FID_E_HIP);
+        if (STAG_MEMCPY(&c->hp->n_anchors, c->d_n, 4, hipMemcpyDeviceToHost, st) != hipSuccess) return stag_finish(j, FID_E_HIP);
         j.seg = 1;
         return FID_OK;
     }
@@ -709,13 +793,13 @@ static fid_status stag_advance_impl(fid_stag_ctx *c, StagJob &j)
         R.counters = c->d_rcount;
         j.seg = 2;
         if (c->route_mode != 1) return stag_launch_route_seq(c, j) ? FID_OK : stag_finish(j, FID_E_HIP);
-        if (hipMemcpyAsync(c->d_edgeimg, c->d_edge, (size_t)n, hipMemcpyDeviceToDevice, st) != hipSuccess) return stag_finish(j, FID_E_HIP);
+        if (STAG_MEMCPY(c->d_edgeimg, c->d_edge, (size_t)n, hipMemcpyDeviceToDevice, st) != hipSuccess) return stag_finish(j, FID_E_HIP);
         // (EdgeMap::pixels needs no clearing on this road: k_stag_route_gather writes every entry below the final count from
         //  the cleared arenas; the sequential road clears it itself -- 16.6 MB of writes per 1080p frame less)
         if (na == 0) {
             c->rcount[0] = c->rcount[1] = c->rcount[2] = 0;
             j.rstate = RS_EMPTY;
-            return hipMemsetAsync(c->d_rcount, 0, 12, st) == hipSuccess ? FID_OK : stag_finish(j, FID_E_HIP);
+            return STAG_MEMSET(c->d_rcount, 0, 12, st) == hipSuccess ? FID_OK : stag_finish(j, FID_E_HIP);
         }
         const int nb = (n + 255) / 256;
         // (the per-root counters are zeroed by k_stag_ccl_init where a root can be; the output arena is cleared once its used
@@ -734,23 +818,29 @@ static fid_status stag_advance_impl(fid_stag_ctx *c, StagJob &j)
                 F.v[k] = val[k];
                 most = F.n16[k] > most ? F.n16[k] : most;
             }
-            hipLaunchKernelGGL(k_stag_fills, dim3((most + 255) / 256), dim3(256), 0, st, F);
+            STAG_LAUNCH(k_stag_fills, dim3((most + 255) / 256), dim3(256), 0, st, F);
         }
         if (!ok) return stag_finish(j, FID_E_HIP);
         {
             const dim3 tiles((W + CCL_TW - 1) / CCL_TW, (H + CCL_TH - 1) / CCL_TH);
-            hipLaunchKernelGGL(k_stag_ccl_tile, tiles, dim3(256), 0, st, c->d_grad, W, H, 16, c->d_label, c->d_csize, c->d_canch, c->d_cbox);
-            hipLaunchKernelGGL(k_stag_ccl_border, tiles, dim3(128), 0, st, W, H, c->d_label);
+            STAG_LAUNCH(k_stag_ccl_tile, tiles, dim3(256), 0, st, c->d_grad, W, H, 16, c->d_label, c->d_csize, c->d_canch, c->d_cbox);
+            STAG_LAUNCH(k_stag_ccl_border, tiles, dim3(128), 0, st, W, H, c->d_label);
         }
-        hipLaunchKernelGGL(k_stag_ccl_flatten, dim3(nb), dim3(256), 0, st, n, W, c->d_label, c->d_edge, c->d_csize, c->d_canch, c->d_cbox);
-        hipLaunchKernelGGL(k_stag_comp_alloc, dim3(nb), dim3(256), 0, st, n, c->d_label, c->d_csize, c->d_canch, c->d_cbox, c->d_cursors, c->max_comps, c->d_caps,
+        STAG_LAUNCH(k_stag_ccl_flatten, dim3(nb), dim3(256), 0, st, n, W, c->d_label, c->d_edge, c->d_csize, c->d_canch, c->d_cbox);
+        STAG_LAUNCH(k_stag_comp_alloc, dim3(nb), dim3(256), 0, st, n, c->d_label, c->d_csize, c->d_canch, c->d_cbox, c->d_cursors, c->max_comps, c->d_caps,
                            c->d_comps, c->d_cidmap);
-        hipLaunchKernelGGL(k_stag_comp_fill, dim3((na + 255) / 256), dim3(256), 0, st, c->d_sorted, c->d_n, c->d_label, c->d_cidmap, c->d_comps, c->d_fill,
+        STAG_LAUNCH(k_stag_comp_fill, dim3((na + 255) / 256), dim3(256), 0, st, c->d_sorted, c->d_n, c->d_label, c->d_cidmap, c->d_comps, c->d_fill,
                            c->d_aslots);
-        const int LDS_CAP = 150 * 1024;  // of the 160 KB of a CU
-        hipLaunchKernelGGL(k_stag_comp_tilemax, dim3((c->max_comps + 255) / 256), dim3(256), 0, st, c->d_comps, c->d_cursors, LDS_CAP);
+        // the largest LDS tile a component's walk may ask for.  One frame at a time: 150 of the 160 KB of a CU (every component of a
+        // marker frame walks in LDS).  A group of frames: 40 KB -- the walk kernel allocates the group's largest tile for every
+        // workgroup, and with ~80 KB marker tiles a CU held one workgroup (3.0 k frames/s; 64 KB: 3.3 k, 40 KB: 3.5 k, 24 KB: 3.3 k);
+        // the components above the cap take the global-memory walk, same result.  FID_STAG_TILE_KB overrides.
+        static const int tile_kb_env = [] { const char *e = getenv("FID_STAG_TILE_KB"); return e ? atoi(e) : 0; }();
+        const int tile_kb = tile_kb_env > 0 ? tile_kb_env : (grouped ? 40 : 150);
+        const int LDS_CAP = (tile_kb < 8 ? 8 : (tile_kb > 150 ? 150 : tile_kb)) * 1024;
+        STAG_LAUNCH(k_stag_comp_tilemax, dim3((c->max_comps + 255) / 256), dim3(256), 0, st, c->d_comps, c->d_cursors, LDS_CAP);
         if (hipGetLastError() != hipSuccess) return stag_finish(j, FID_E_HIP);
-        if (hipMemcpyAsync(c->hp->cur, c->d_cursors, 44, hipMemcpyDeviceToHost, st) != hipSuccess) return stag_finish(j, FID_E_HIP);
+        if (STAG_MEMCPY(c->hp->cur, c->d_cursors, 44, hipMemcpyDeviceToHost, st) != hipSuccess) return stag_finish(j, FID_E_HIP);
         j.rstate = RS_PAR_A;
         return FID_OK;
     }
@@ -767,36 +857,36 @@ static fid_status stag_advance_impl(fid_stag_ctx *c, StagJob &j)
             }
             const int na = (int)c->n_anchors;
             // pixels of the output arena the extraction does not write read as (-1, -1), like the reference's untouched array
-            if (cur[5] > 0 && hipMemsetAsync(c->d_aout, 0xff, (size_t)cur[5] * sizeof(int2), st) != hipSuccess) return stag_finish(j, FID_E_HIP);
+            if (cur[5] > 0 && STAG_MEMSET(c->d_aout, 0xff, (size_t)cur[5] * sizeof(int2), st) != hipSuccess) return stag_finish(j, FID_E_HIP);
             const int nc = cur[0];
             StagArenas A;
             A.pix = c->d_apix; A.stack = c->d_astack; A.chains = c->d_achains; A.out = c->d_aout; A.segs = c->d_asegs; A.recs = c->d_recs;
             int *ovf = c->d_cursors + 8;
             if (nc > 0) {
-                hipLaunchKernelGGL(k_stag_comp_sort, dim3((nc + 3) / 4), dim3(256), 0, st, c->d_comps, c->d_cursors, c->d_aslots);
+                STAG_LAUNCH(k_stag_comp_sort, dim3((nc + 3) / 4), dim3(256), 0, st, c->d_comps, c->d_cursors, c->d_aslots);
                 if (cur[9] > STAG_SORT_WAVE)  // (cur[9]: most anchors in one component)
-                    hipLaunchKernelGGL(k_stag_comp_sort_big, dim3(nc), dim3(1024), (size_t)STAG_SORT_BIG * 4, st, c->d_comps, c->d_cursors, c->d_aslots);
+                    STAG_LAUNCH(k_stag_comp_sort_big, dim3(nc), dim3(1024), (size_t)STAG_SORT_BIG * 4, st, c->d_comps, c->d_cursors, c->d_aslots);
                 // LDS per workgroup = the largest tile a component of this frame asks for (components whose box does not fit 150 KB
                 // walk in global memory): frames of small components keep many workgroups per CU
                 const int lds = c->route_tile ? ((cur[10] + 1023) / 1024) * 1024 : 0;
-                hipLaunchKernelGGL(k_stag_route_walk, dim3(nc), dim3(256), (size_t)lds, st, j.R, A, c->d_comps, c->d_cursors, c->d_sorted, c->d_aslots,
+                STAG_LAUNCH(k_stag_route_walk, dim3(nc), dim3(256), (size_t)lds, st, j.R, A, c->d_comps, c->d_cursors, c->d_sorted, c->d_aslots,
                                    c->d_label, 16, lds, c->d_prodflag, ovf);
             }
-            hipLaunchKernelGGL(k_stag_next_above, dim3(1), dim3(1024), 0, st, c->d_prodflag, c->d_n, c->d_next);
+            STAG_LAUNCH(k_stag_next_above, dim3(1), dim3(1024), 0, st, c->d_prodflag, c->d_n, c->d_next);
             if (nc > 0)
-                hipLaunchKernelGGL(k_stag_route_extract, dim3((nc + 3) / 4), dim3(256), 0, st, j.R, A, c->d_comps, c->d_cursors, c->d_next, c->d_n,
+                STAG_LAUNCH(k_stag_route_extract, dim3((nc + 3) / 4), dim3(256), 0, st, j.R, A, c->d_comps, c->d_cursors, c->d_next, c->d_n,
                                    c->d_blkpix, c->d_blksegs, c->d_blkwhere, ovf);
             {
                 StagScanJobs sj;
                 sj.counts[0] = c->d_blkpix; sj.total[0] = c->d_rcount + 1;
                 sj.counts[1] = c->d_blksegs; sj.total[1] = c->d_rcount;
-                hipLaunchKernelGGL(k_stag_scan_counts_n, dim3(2), dim3(1024), 0, st, sj, (const int *)c->d_n);
+                STAG_LAUNCH(k_stag_scan_counts_n, dim3(2), dim3(1024), 0, st, sj, (const int *)c->d_n);
             }
-            hipLaunchKernelGGL(k_stag_route_gather, dim3((na + 3) / 4), dim3(256), 0, st, A, c->d_comps, c->d_n, c->d_prodflag, c->d_blkpix, c->d_blksegs,
+            STAG_LAUNCH(k_stag_route_gather, dim3((na + 3) / 4), dim3(256), 0, st, A, c->d_comps, c->d_n, c->d_prodflag, c->d_blkpix, c->d_blksegs,
                                c->d_blkwhere, c->d_outpix, c->d_segs, j.R.capOut, j.R.capSegs, ovf);
             if (hipGetLastError() != hipSuccess) return stag_finish(j, FID_E_HIP);
-            if (hipMemcpyAsync(c->hp->rcount, c->d_rcount, 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
-                hipMemcpyAsync(&c->hp->ovf, ovf, 4, hipMemcpyDeviceToHost, st) != hipSuccess)
+            if (STAG_MEMCPY(c->hp->rcount, c->d_rcount, 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
+                STAG_MEMCPY(&c->hp->ovf, ovf, 4, hipMemcpyDeviceToHost, st) != hipSuccess)
                 return stag_finish(j, FID_E_HIP);
             j.rstate = RS_PAR_B;
             return FID_OK;  // (this segment again, with the second half's counts)
@@ -823,24 +913,24 @@ static fid_status stag_advance_impl(fid_stag_ctx *c, StagJob &j)
         const size_t n = (size_t)W * H;
         const int ns = c->rcount[0];
         // ValidateEdgeSegments starts from an empty edge image (ValidateEdgeSegments.cpp:370)
-        if (hipMemsetAsync(c->d_edgeimg, 0, n, st) != hipSuccess || hipMemsetAsync(c->d_vhist, 0, STAG_BINS * 4, st) != hipSuccess) return stag_finish(j, FID_E_HIP);
-        hipLaunchKernelGGL(k_stag_smooth3_prewitt, dim3((W + SX - 1) / SX, (H + SY - 1) / SY), dim3(256), 0, st, c->d_src, W, W, H, c->d_smooth2,
+        if (STAG_MEMSET(c->d_edgeimg, 0, n, st) != hipSuccess || STAG_MEMSET(c->d_vhist, 0, STAG_BINS * 4, st) != hipSuccess) return stag_finish(j, FID_E_HIP);
+        STAG_LAUNCH(k_stag_smooth3_prewitt, dim3((W + SX - 1) / SX, (H + SY - 1) / SY), dim3(256), 0, st, c->d_src, W, W, H, c->d_smooth2,
                            c->d_vgrad, c->d_vhist);
-        hipLaunchKernelGGL(k_stag_valid_prob, dim3(1), dim3(512), 0, st, c->d_vhist, W, H, c->d_segs, c->d_rcount, c->d_prob, c->d_np);
+        STAG_LAUNCH(k_stag_valid_prob, dim3(1), dim3(512), 0, st, c->d_vhist, W, H, c->d_segs, c->d_rcount, c->d_prob, c->d_np);
         const int wg = (ns + 3) / 4;
         if (wg > 0) {
-            hipLaunchKernelGGL(k_stag_test_segments, dim3(wg), dim3(256), 0, st, c->d_segs, c->d_rcount, c->d_outpix, c->d_vgrad, W, c->d_prob, c->d_np,
+            STAG_LAUNCH(k_stag_test_segments, dim3(wg), dim3(256), 0, st, c->d_segs, c->d_rcount, c->d_outpix, c->d_vgrad, W, c->d_prob, c->d_np,
                                2.25, c->d_vstack, c->d_edgeimg);
-            hipLaunchKernelGGL(k_stag_extract, dim3(wg), dim3(256), 0, st, c->d_segs, c->d_rcount, c->d_outpix, c->d_edgeimg, W, c->d_vcounts,
+            STAG_LAUNCH(k_stag_extract, dim3(wg), dim3(256), 0, st, c->d_segs, c->d_rcount, c->d_outpix, c->d_edgeimg, W, c->d_vcounts,
                                c->d_vsegs, 0);
         }
-        hipLaunchKernelGGL(k_stag_scan_counts, dim3(1), dim3(1024), 0, st, c->d_vcounts, c->d_rcount, c->d_vtotal);
+        STAG_LAUNCH(k_stag_scan_counts, dim3(1), dim3(1024), 0, st, c->d_vcounts, c->d_rcount, c->d_vtotal);
         if (wg > 0)
-            hipLaunchKernelGGL(k_stag_extract, dim3(wg), dim3(256), 0, st, c->d_segs, c->d_rcount, c->d_outpix, c->d_edgeimg, W, c->d_vcounts,
+            STAG_LAUNCH(k_stag_extract, dim3(wg), dim3(256), 0, st, c->d_segs, c->d_rcount, c->d_outpix, c->d_edgeimg, W, c->d_vcounts,
                                c->d_vsegs, 1);
         if (hipGetLastError() != hipSuccess) return stag_finish(j, FID_E_HIP);
-        if (hipMemcpyAsync(&c->hp->n_vsegs, c->d_vtotal, 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
-            hipMemcpyAsync(&c->hp->np, c->d_np, 4, hipMemcpyDeviceToHost, st) != hipSuccess)
+        if (STAG_MEMCPY(&c->hp->n_vsegs, c->d_vtotal, 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
+            STAG_MEMCPY(&c->hp->np, c->d_np, 4, hipMemcpyDeviceToHost, st) != hipSuccess)
             return stag_finish(j, FID_E_HIP);
         j.seg = 3;
         return FID_OK;
@@ -857,13 +947,13 @@ static fid_status stag_advance_impl(fid_stag_ctx *c, StagJob &j)
         PF.x = c->d_prefix; PF.y = PF.x + c->prefcap; PF.xx = PF.y + c->prefcap; PF.yy = PF.xx + c->prefcap; PF.xy = PF.yy + c->prefcap;
         const int wg = (ns + 63) / 64;
         if (wg > 0)
-            hipLaunchKernelGGL(k_stag_split_lines, dim3((ns + 3) / 4), dim3(256), 0, st, c->d_vsegs, c->d_vtotal, c->d_outpix, PF, c->min_line_len, 1.0,
+            STAG_LAUNCH(k_stag_split_lines, dim3((ns + 3) / 4), dim3(256), 0, st, c->d_vsegs, c->d_vtotal, c->d_outpix, PF, c->min_line_len, 1.0,
                                c->d_lslots, c->d_lcounts);
-        hipLaunchKernelGGL(k_stag_scan_counts, dim3(1), dim3(1024), 0, st, c->d_lcounts, c->d_vtotal, c->d_ltotal);
+        STAG_LAUNCH(k_stag_scan_counts, dim3(1), dim3(1024), 0, st, c->d_lcounts, c->d_vtotal, c->d_ltotal);
         if (wg > 0)
-            hipLaunchKernelGGL(k_stag_gather_lines, dim3(wg), dim3(64), 0, st, c->d_vsegs, c->d_vtotal, c->d_lcounts, c->d_ltotal, c->d_lslots, c->d_lines);
+            STAG_LAUNCH(k_stag_gather_lines, dim3(wg), dim3(64), 0, st, c->d_vsegs, c->d_vtotal, c->d_lcounts, c->d_ltotal, c->d_lslots, c->d_lines);
         if (hipGetLastError() != hipSuccess) return stag_finish(j, FID_E_HIP);
-        if (hipMemcpyAsync(&c->hp->n_lines, c->d_ltotal, 4, hipMemcpyDeviceToHost, st) != hipSuccess) return stag_finish(j, FID_E_HIP);
+        if (STAG_MEMCPY(&c->hp->n_lines, c->d_ltotal, 4, hipMemcpyDeviceToHost, st) != hipSuccess) return stag_finish(j, FID_E_HIP);
         j.seg = 4;
         return FID_OK;
     }
@@ -887,14 +977,14 @@ static fid_status stag_advance_impl(fid_stag_ctx *c, StagJob &j)
         T.kmin_n = c->kmin_n;
         const int nl = c->n_lines;
         if (nl > 0)
-            hipLaunchKernelGGL(k_stag_validate_lines, dim3((nl + 63) / 64), dim3(64), 0, st, c->d_lines, c->d_ltotal, c->d_src, W, H, c->d_vsegs,
+            STAG_LAUNCH(k_stag_validate_lines, dim3((nl + 63) / 64), dim3(64), 0, st, c->d_lines, c->d_ltotal, c->d_src, W, H, c->d_vsegs,
                                c->d_outpix, T, c->d_lflags);
-        hipLaunchKernelGGL(k_stag_scan_counts, dim3(1), dim3(1024), 0, st, c->d_lflags, c->d_ltotal, c->d_vltotal);
+        STAG_LAUNCH(k_stag_scan_counts, dim3(1), dim3(1024), 0, st, c->d_lflags, c->d_ltotal, c->d_vltotal);
         if (nl > 0)
-            hipLaunchKernelGGL(k_stag_compact_lines, dim3((nl + 255) / 256), dim3(256), 0, st, c->d_lines, c->d_ltotal, c->d_lflags, c->d_vltotal,
+            STAG_LAUNCH(k_stag_compact_lines, dim3((nl + 255) / 256), dim3(256), 0, st, c->d_lines, c->d_ltotal, c->d_lflags, c->d_vltotal,
                                c->d_vlines);
         if (hipGetLastError() != hipSuccess) return stag_finish(j, FID_E_HIP);
-        if (hipMemcpyAsync(&c->hp->n_vlines, c->d_vltotal, 4, hipMemcpyDeviceToHost, st) != hipSuccess) return stag_finish(j, FID_E_HIP);
+        if (STAG_MEMCPY(&c->hp->n_vlines, c->d_vltotal, 4, hipMemcpyDeviceToHost, st) != hipSuccess) return stag_finish(j, FID_E_HIP);
         j.seg = 5;
         return FID_OK;
     }
@@ -904,17 +994,17 @@ static fid_status stag_advance_impl(fid_stag_ctx *c, StagJob &j)
         c->quadded = false;
         if (j.last == SS_LINES_VALIDATED) return stag_finish(j, FID_OK);
         const int W = c->W, H = c->H, ns = c->n_vsegs, nl = c->n_vlines;
-        if (hipMemsetAsync(c->d_lrange, 0, (size_t)(ns + 1) * sizeof(int2), st) != hipSuccess) return stag_finish(j, FID_E_HIP);
-        if (nl > 0) hipLaunchKernelGGL(k_stag_line_ranges, dim3((nl + 255) / 256), dim3(256), 0, st, c->d_vlines, c->d_vltotal, c->d_lrange);
+        if (STAG_MEMSET(c->d_lrange, 0, (size_t)(ns + 1) * sizeof(int2), st) != hipSuccess) return stag_finish(j, FID_E_HIP);
+        if (nl > 0) STAG_LAUNCH(k_stag_line_ranges, dim3((nl + 255) / 256), dim3(256), 0, st, c->d_vlines, c->d_vltotal, c->d_lrange);
         if (ns > 0)
-            hipLaunchKernelGGL(k_stag_quads, dim3((ns + 3) / 4), dim3(256), 0, st, c->d_vlines, c->d_lrange, c->d_vtotal, c->d_vsegs, c->d_outpix, c->d_src,
+            STAG_LAUNCH(k_stag_quads, dim3((ns + 3) / 4), dim3(256), 0, st, c->d_vlines, c->d_lrange, c->d_vtotal, c->d_vsegs, c->d_outpix, c->d_src,
                                W, H, c->d_corners, c->d_order, c->d_qslots, c->d_qcounts);
-        hipLaunchKernelGGL(k_stag_scan_counts, dim3(1), dim3(1024), 0, st, c->d_qcounts, c->d_vtotal, c->d_qtotal);
+        STAG_LAUNCH(k_stag_scan_counts, dim3(1), dim3(1024), 0, st, c->d_qcounts, c->d_vtotal, c->d_qtotal);
         if (ns > 0)
-            hipLaunchKernelGGL(k_stag_gather_quads, dim3((ns + 63) / 64), dim3(64), 0, st, c->d_lrange, c->d_vtotal, c->d_qcounts, c->d_qtotal, c->d_qslots,
+            STAG_LAUNCH(k_stag_gather_quads, dim3((ns + 63) / 64), dim3(64), 0, st, c->d_lrange, c->d_vtotal, c->d_qcounts, c->d_qtotal, c->d_qslots,
                                c->d_quads);
         if (hipGetLastError() != hipSuccess) return stag_finish(j, FID_E_HIP);
-        if (hipMemcpyAsync(&c->hp->n_quads, c->d_qtotal, 4, hipMemcpyDeviceToHost, st) != hipSuccess) return stag_finish(j, FID_E_HIP);
+        if (STAG_MEMCPY(&c->hp->n_quads, c->d_qtotal, 4, hipMemcpyDeviceToHost, st) != hipSuccess) return stag_finish(j, FID_E_HIP);
         j.seg = 6;
         return FID_OK;
     }
@@ -925,11 +1015,11 @@ static fid_status stag_advance_impl(fid_stag_ctx *c, StagJob &j)
         if (j.last == SS_QUADS) return stag_finish(j, FID_OK);
         const int nq = c->n_quads;
         if (nq > 0)
-            hipLaunchKernelGGL(k_stag_decode, dim3((nq + 3) / 4), dim3(256), 0, st, c->d_quads, c->d_qtotal, c->d_src, c->W, c->H, c->d_locs, c->d_words,
+            STAG_LAUNCH(k_stag_decode, dim3((nq + 3) / 4), dim3(256), 0, st, c->d_quads, c->d_qtotal, c->d_src, c->W, c->H, c->d_locs, c->d_words,
                                c->n_words, c->errorCorrection, c->d_cand, c->d_found);
-        hipLaunchKernelGGL(k_stag_dedup, dim3(1), dim3(64), 0, st, c->d_cand, c->d_found, c->d_qtotal, c->d_markers, c->d_nmarkers);
+        STAG_LAUNCH(k_stag_dedup, dim3(1), dim3(64), 0, st, c->d_cand, c->d_found, c->d_qtotal, c->d_markers, c->d_nmarkers);
         if (hipGetLastError() != hipSuccess) return stag_finish(j, FID_E_HIP);
-        if (hipMemcpyAsync(&c->hp->n_markers, c->d_nmarkers, 4, hipMemcpyDeviceToHost, st) != hipSuccess) return stag_finish(j, FID_E_HIP);
+        if (STAG_MEMCPY(&c->hp->n_markers, c->d_nmarkers, 4, hipMemcpyDeviceToHost, st) != hipSuccess) return stag_finish(j, FID_E_HIP);
         j.seg = 7;
         return FID_OK;
     }
@@ -938,7 +1028,7 @@ static fid_status stag_advance_impl(fid_stag_ctx *c, StagJob &j)
         c->decoded = true;
         if (j.last == SS_UNREFINED) return stag_finish(j, FID_OK);
         if (c->n_markers > 0) {
-            hipLaunchKernelGGL(k_stag_refine, dim3(c->n_markers), dim3(64), 0, st, c->d_markers, c->d_nmarkers, c->d_vsegs, c->d_vtotal, c->d_outpix,
+            STAG_LAUNCH(k_stag_refine, dim3(c->n_markers), dim3(64), 0, st, c->d_markers, c->d_nmarkers, c->d_vsegs, c->d_vtotal, c->d_outpix,
                                c->d_chosen);
             if (hipGetLastError() != hipSuccess) return stag_finish(j, FID_E_HIP);
         }
@@ -951,7 +1041,7 @@ static fid_status stag_advance_impl(fid_stag_ctx *c, StagJob &j)
         if (j.n_out) *j.n_out = c->n_markers;
         const bool pin = c->n_markers <= STAG_PIN_MARKERS;  // staged through pinned memory, handed over in the last segment
         if (j.out) {
-            if (c->n_markers > 0 && hipMemcpyAsync(pin ? c->hp->markers : j.out, c->d_markers, (size_t)c->n_markers * sizeof(fid_stag_marker),
+            if (c->n_markers > 0 && STAG_MEMCPY(pin ? c->hp->markers : j.out, c->d_markers, (size_t)c->n_markers * sizeof(fid_stag_marker),
                                                    hipMemcpyDeviceToHost, st) != hipSuccess)
                 return stag_finish(j, FID_E_HIP);
         }
@@ -960,9 +1050,9 @@ static fid_status stag_advance_impl(fid_stag_ctx *c, StagJob &j)
             for (int i = 0; i < 9; i++) cam.K[i] = j.K[i];
             for (int i = 0; i < 5; i++) cam.D[i] = j.D ? j.D[i] : 0.0;
             cam.fiducial_len = j.marker_size;
-            hipLaunchKernelGGL(k_stag_pose, dim3((c->n_markers + 3) / 4), dim3(64), 0, st, c->d_markers, c->d_nmarkers, cam, j.marker_size, c->d_poses);
+            STAG_LAUNCH(k_stag_pose, dim3((c->n_markers + 3) / 4), dim3(64), 0, st, c->d_markers, c->d_nmarkers, cam, j.marker_size, c->d_poses);
             if (hipGetLastError() != hipSuccess) return stag_finish(j, FID_E_HIP);
-            if (hipMemcpyAsync(pin ? c->hp->poses : j.poses, c->d_poses, (size_t)c->n_markers * sizeof(fid_stag_pose_out), hipMemcpyDeviceToHost, st) !=
+            if (STAG_MEMCPY(pin ? c->hp->poses : j.poses, c->d_poses, (size_t)c->n_markers * sizeof(fid_stag_pose_out), hipMemcpyDeviceToHost, st) !=
                 hipSuccess)
                 return stag_finish(j, FID_E_HIP);
         }
@@ -1084,11 +1174,154 @@ fid_status fid_stag_pose_last(fid_stag_ctx *c, const double K[9], const double D
     for (int i = 0; i < 9; i++) cam.K[i] = K[i];
     for (int i = 0; i < 5; i++) cam.D[i] = D ? D[i] : 0.0;
     cam.fiducial_len = marker_size;
-    hipStream_t st = c->stream;
+    hipStream_t st = stag_stream(c);
     hipLaunchKernelGGL(k_stag_pose, dim3((c->n_markers + 3) / 4), dim3(64), 0, st, c->d_markers, c->d_nmarkers, cam, marker_size, c->d_poses);
     if (hipGetLastError() != hipSuccess) return FID_E_HIP;
     if (hipMemcpyAsync(out, c->d_poses, (size_t)c->n_markers * sizeof(fid_stag_pose_out), hipMemcpyDeviceToHost, st) != hipSuccess) return FID_E_HIP;
     return hipStreamSynchronize(st) == hipSuccess ? FID_OK : FID_E_HIP;
+}
+
+// Frames as a grid dimension (round 3; fid_stag_batch.h).  The contexts are cut into GROUPS of up to STAG_MAXF; a group takes
+// that many frames and carries them through the segments of stag_advance in LOCKSTEP on one stream: per segment one wait for the
+// group's stream, the host part of every frame (its launches recorded), then every launch site once for the whole group.  One
+// host thread goes round the groups, so the wait of one group overlaps the kernels of the others.  A group takes its next
+// frames when all of its frames are through (frames that need an extra segment -- a routing fallback -- hold their group for
+// that round).  Results are those of frame-by-frame calls: same kernels bodies, same per-frame buffers, no shared state.
+static fid_status stag_batch_groups(fid_stag_ctx *const *ctxs, int32_t nctx, const uint8_t *frames, int32_t nframes, int32_t width, int32_t height,
+                                    int32_t stride, int64_t frame_stride, const double K[9], const double D[5], double marker_size,
+                                    fid_stag_marker *markers, fid_stag_pose_out *poses, int32_t cap_per_frame, int32_t *n_per_frame)
+{
+    // a group is at most as large as the smallest argument table (the routing kernels carry ~250 bytes of arguments per frame and
+    // kernel-argument memory is 4 KB: a group one frame larger would launch them twice)
+    constexpr int kGroupMax = std::min({StagTab<k_stag_route_walk_fn>::kMax, StagTab<k_stag_route_extract_fn>::kMax, StagTab<k_stag_route_gather_fn>::kMax,
+                                        StagTab<k_stag_quads_fn>::kMax, StagTab<k_stag_decode_fn>::kMax, StagTab<k_stag_validate_lines_fn>::kMax,
+                                        StagTab<k_stag_split_lines_fn>::kMax, StagTab<k_stag_refine_fn>::kMax, (int)STAG_MAXF});
+    int gs = nctx >= 4 ? nctx / 2 : nctx;  // two groups (or more) so that one group's host round runs under another's kernels
+    if (const char *e = getenv("FID_STAG_GROUP")) gs = atoi(e);
+    gs = gs < 1 ? 1 : (gs > kGroupMax ? kGroupMax : (gs > nctx ? nctx : gs));
+    const int ngroups = nctx / gs;
+    // a host thread per group (FID_STAG_THREADS caps it; 1 = one thread goes round the groups): a group's host round -- its
+    // frames' bookkeeping, 2 MB of staging per new frame -- then runs beside the other groups' rounds and kernels
+    int nthreads = ngroups;
+    if (const char *e = getenv("FID_STAG_THREADS")) nthreads = atoi(e);
+    nthreads = nthreads < 1 ? 1 : (nthreads > ngroups ? ngroups : nthreads);
+    std::atomic<int> next(0);
+    std::atomic<bool> stop(false), hip_failed(false);
+    std::mutex err_mutex;
+    fid_status first_err = FID_OK;
+    const bool verbose = getenv("FID_VERBOSE") != nullptr;
+    std::atomic<long long> ns_wait(0), ns_host(0), ns_flush(0), n_rec(0), n_iss(0);
+    auto worker = [&](int tid) {
+        struct Group {
+            std::vector<StagJob> jobs;
+            std::vector<int> frame_of;
+            int live = 0, g = 0;
+            hipStream_t stream = nullptr;
+        };
+        std::vector<Group> groups;
+        for (int g = tid; g < ngroups; g += nthreads) {
+            Group G;
+            G.g = g;
+            G.jobs.resize((size_t)gs);
+            G.frame_of.assign((size_t)gs, -1);
+            G.stream = stag_stream(ctxs[g * gs]);
+            groups.push_back(std::move(G));
+        }
+        StagRecorder R;
+        auto now = [] { return std::chrono::steady_clock::now(); };
+        auto nsec = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+            return (long long)std::chrono::duration_cast<std::chrono::nanoseconds>(b - a).count();
+        };
+        for (;;) {
+            bool any = false;
+            for (Group &G : groups) {
+                const int g = G.g;
+                if (hipSetDevice(ctxs[g * gs]->device) != hipSuccess) {
+                    hip_failed = true;
+                    return;
+                }
+                if (G.live == 0) {
+                    if (stop.load(std::memory_order_relaxed)) continue;
+                    const int f0 = next.fetch_add(gs, std::memory_order_relaxed);  // the group's next frames, all at once
+                    if (f0 >= nframes) continue;
+                    for (int k = 0; k < gs && f0 + k < nframes; k++) {
+                        const int f = f0 + k;
+                        StagJob j;
+                        j.gray = frames + (size_t)f * frame_stride; j.width = width; j.height = height; j.stride = stride;
+                        j.out = markers + (size_t)f * cap_per_frame; j.cap = cap_per_frame; j.n_out = n_per_frame + f;
+                        j.last = (K && poses) ? SS_POSE : SS_MARKERS;
+                        j.K = K; j.D = D; j.marker_size = marker_size;
+                        j.poses = poses ? poses + (size_t)f * cap_per_frame : nullptr; j.pose_cap = cap_per_frame;
+                        G.jobs[k] = j;
+                        G.frame_of[k] = f;
+                        G.live++;
+                    }
+                } else {
+                    const auto t0 = now();
+                    if (hipStreamSynchronize(G.stream) != hipSuccess) {
+                        hip_failed = true;
+                        return;
+                    }
+                    if (verbose) ns_wait += nsec(t0, now());
+                }
+                any = true;
+                // ---- one segment round: the host part of every frame, launches recorded; then every site once
+                const auto t1 = now();
+                R.on = true;
+                R.stream = G.stream;
+                g_stag_rec = &R;
+                for (int k = 0; k < gs; k++) {
+                    if (G.frame_of[k] < 0) continue;
+                    fid_stag_ctx *c = ctxs[g * gs + k];
+                    c->group_stream = G.stream;
+                    (void)stag_advance(c, G.jobs[k]);
+                }
+                R.on = false;
+                g_stag_rec = nullptr;
+                const auto t2 = now();
+                const bool ok = stag_flush(R);
+                if (verbose) {
+                    ns_host += nsec(t1, t2);
+                    ns_flush += nsec(t2, now());
+                }
+                for (int k = 0; k < gs; k++) {
+                    if (G.frame_of[k] < 0 || !G.jobs[k].done) continue;
+                    ctxs[g * gs + k]->group_stream = nullptr;
+                    if (G.jobs[k].rc != FID_OK) {
+                        std::lock_guard<std::mutex> lk(err_mutex);
+                        if (first_err == FID_OK) first_err = G.jobs[k].rc;                    // the first failure is the call's status ...
+                        if (G.jobs[k].rc != FID_E_CAPACITY) stop.store(true, std::memory_order_relaxed);  // ... a frame that did not fit costs only that frame
+                    }
+                    G.frame_of[k] = -1;
+                    G.live--;
+                }
+                if (!ok) {
+                    hip_failed = true;
+                    stop = true;
+                }
+            }
+            if (!any) break;
+        }
+        n_rec += R.recorded_launches;
+        n_iss += R.merged_launches;
+    };
+    if (nthreads == 1) {
+        worker(0);
+    } else {
+        std::vector<std::thread> pool;
+        for (int t = 1; t < nthreads; t++) pool.emplace_back(worker, t);
+        worker(0);
+        for (auto &th : pool) th.join();
+    }
+    if (hip_failed.load()) {
+        for (int g = 0; g < ngroups; g++) (void)hipStreamSynchronize(ctxs[g * gs]->stream);
+        for (int t = 0; t < nctx; t++) ctxs[t]->group_stream = nullptr;
+        return FID_E_HIP;
+    }
+    if (verbose)
+        fprintf(stderr, "fid stag batch: %d frames, %d group(s) of %d (at most %d), %d host thread(s): %lld launches recorded, %lld issued; host ms (all threads): waiting %.2f, frames' host parts %.2f, issuing %.2f\n",
+                nframes, ngroups, gs, kGroupMax, nthreads, n_rec.load(), n_iss.load(), ns_wait.load() * 1e-6, ns_host.load() * 1e-6, ns_flush.load() * 1e-6);
+    return first_err;
 }
 
 // Frames over several contexts: every context carries one frame at a time through the segments of stag_advance; a host
@@ -1105,6 +1338,10 @@ fid_status fid_stag_detect_markers_batch(fid_stag_ctx *const *ctxs, int32_t nctx
         if (!ctxs[t] || !ctxs[t]->d_words) return FID_E_INVALID_ARG;
     if (K && poses && !(marker_size > 0)) return FID_E_INVALID_ARG;
     for (int f = 0; f < nframes; f++) n_per_frame[f] = 0;  // every count is defined whatever happens to a frame
+    // frames as a grid dimension (default); FID_STAG_BATCH=contexts: round 2's road, a stream per context and host threads
+    if (!(getenv("FID_STAG_BATCH") && !strcmp(getenv("FID_STAG_BATCH"), "contexts")))
+        return stag_batch_groups(ctxs, nctx, frames, nframes, width, height, stride, frame_stride, K, D, marker_size, markers, poses, cap_per_frame,
+                                 n_per_frame);
     int nthreads = 4;
     if (const char *e = getenv("FID_STAG_THREADS")) nthreads = atoi(e);
     nthreads = nthreads < 1 ? 1 : (nthreads > nctx ? nctx : nthreads);

@@ -9,7 +9,7 @@
 //   k_stag_test_segments     TestSegment (:134-199), one wave per segment, the recursion on an explicit stack that lives
 //                            in the scratch slots of the segment's own pixels
 //   k_stag_extract           ExtractNewSegments (:319-360): runs of still-marked pixels of >= 10 (count pass, scan, write pass)
-__global__ __launch_bounds__(256) void k_stag_smooth3_prewitt(const uint8_t *__restrict__ src, int stride, int W, int H,
+__device__ __forceinline__ void k_stag_smooth3_prewitt_impl(const uint8_t *__restrict__ src, int stride, int W, int H,
                                                               uint8_t *__restrict__ smooth, int16_t *__restrict__ grad,
                                                               unsigned *__restrict__ hist)
 {
@@ -62,9 +62,17 @@ __global__ __launch_bounds__(256) void k_stag_smooth3_prewitt(const uint8_t *__r
     for (int i = tid; i < STAG_BINS; i += 256)
         if (s_hist[i]) atomicAdd(&hist[i], s_hist[i]);
 }
+__global__ __launch_bounds__(256) void k_stag_smooth3_prewitt(const uint8_t *__restrict__ src, int stride, int W, int H, uint8_t *__restrict__ smooth, int16_t *__restrict__ grad, unsigned *__restrict__ hist)
+{
+    k_stag_smooth3_prewitt_impl(src, stride, W, H, smooth, grad, hist);
+}
+struct k_stag_smooth3_prewitt_fn {
+    static constexpr int kBounds = 256;
+    __device__ __forceinline__ void operator()(const uint8_t *__restrict__ src, int stride, int W, int H, uint8_t *__restrict__ smooth, int16_t *__restrict__ grad, unsigned *__restrict__ hist) const { k_stag_smooth3_prewitt_impl(src, stride, W, H, smooth, grad, hist); }
+};
 
 // one workgroup: cumulative histogram from the top -> H[g]; np over the segments (32-bit int arithmetic as in the reference)
-__global__ __launch_bounds__(512) void k_stag_valid_prob(const unsigned *__restrict__ hist, int W, int H, const int2 *__restrict__ segs,
+__device__ __forceinline__ void k_stag_valid_prob_impl(const unsigned *__restrict__ hist, int W, int H, const int2 *__restrict__ segs,
                                                          const int *__restrict__ counters, double *__restrict__ prob, int *__restrict__ np_out)
 {
     __shared__ unsigned s_part[512];
@@ -104,8 +112,16 @@ __global__ __launch_bounds__(512) void k_stag_valid_prob(const unsigned *__restr
     }
     if (tid == 0) *np_out = (int)s_part[0];
 }
+__global__ __launch_bounds__(512) void k_stag_valid_prob(const unsigned *__restrict__ hist, int W, int H, const int2 *__restrict__ segs, const int *__restrict__ counters, double *__restrict__ prob, int *__restrict__ np_out)
+{
+    k_stag_valid_prob_impl(hist, W, H, segs, counters, prob, np_out);
+}
+struct k_stag_valid_prob_fn {
+    static constexpr int kBounds = 512;
+    __device__ __forceinline__ void operator()(const unsigned *__restrict__ hist, int W, int H, const int2 *__restrict__ segs, const int *__restrict__ counters, double *__restrict__ prob, int *__restrict__ np_out) const { k_stag_valid_prob_impl(hist, W, H, segs, counters, prob, np_out); }
+};
 
-__global__ __launch_bounds__(256) void k_stag_test_segments(const int2 *__restrict__ segs, const int *__restrict__ counters,
+__device__ __forceinline__ void k_stag_test_segments_impl(const int2 *__restrict__ segs, const int *__restrict__ counters,
                                                             const int2 *__restrict__ pix, const int16_t *__restrict__ vgrad, int W,
                                                             const double *__restrict__ prob, const int *__restrict__ np_in, double div,
                                                             int2 *__restrict__ stackmem, uint8_t *__restrict__ edge)
@@ -176,10 +192,18 @@ __global__ __launch_bounds__(256) void k_stag_test_segments(const int2 *__restri
         sp += 2;
     }
 }
+__global__ __launch_bounds__(256) void k_stag_test_segments(const int2 *__restrict__ segs, const int *__restrict__ counters, const int2 *__restrict__ pix, const int16_t *__restrict__ vgrad, int W, const double *__restrict__ prob, const int *__restrict__ np_in, double div, int2 *__restrict__ stackmem, uint8_t *__restrict__ edge)
+{
+    k_stag_test_segments_impl(segs, counters, pix, vgrad, W, prob, np_in, div, stackmem, edge);
+}
+struct k_stag_test_segments_fn {
+    static constexpr int kBounds = 256;
+    __device__ __forceinline__ void operator()(const int2 *__restrict__ segs, const int *__restrict__ counters, const int2 *__restrict__ pix, const int16_t *__restrict__ vgrad, int W, const double *__restrict__ prob, const int *__restrict__ np_in, double div, int2 *__restrict__ stackmem, uint8_t *__restrict__ edge) const { k_stag_test_segments_impl(segs, counters, pix, vgrad, W, prob, np_in, div, stackmem, edge); }
+};
 
 // ExtractNewSegments: one wave per segment.  write = 0: counts[seg] = number of runs of >= 10 marked pixels; write = 1:
 // the runs go to out[] from counts[seg] (exclusive prefix sums by then) on.
-__global__ __launch_bounds__(256) void k_stag_extract(const int2 *__restrict__ segs, const int *__restrict__ counters,
+__device__ __forceinline__ void k_stag_extract_impl(const int2 *__restrict__ segs, const int *__restrict__ counters,
                                                       const int2 *__restrict__ pix, const uint8_t *__restrict__ edge, int W,
                                                       int *__restrict__ counts, int2 *__restrict__ out, int write)
 {
@@ -224,6 +248,14 @@ __global__ __launch_bounds__(256) void k_stag_extract(const int2 *__restrict__ s
     }
     if (!write && lane == 0) counts[seg] = nout;
 }
+__global__ __launch_bounds__(256) void k_stag_extract(const int2 *__restrict__ segs, const int *__restrict__ counters, const int2 *__restrict__ pix, const uint8_t *__restrict__ edge, int W, int *__restrict__ counts, int2 *__restrict__ out, int write)
+{
+    k_stag_extract_impl(segs, counters, pix, edge, W, counts, out, write);
+}
+struct k_stag_extract_fn {
+    static constexpr int kBounds = 256;
+    __device__ __forceinline__ void operator()(const int2 *__restrict__ segs, const int *__restrict__ counters, const int2 *__restrict__ pix, const uint8_t *__restrict__ edge, int W, int *__restrict__ counts, int2 *__restrict__ out, int write) const { k_stag_extract_impl(segs, counters, pix, edge, W, counts, out, write); }
+};
 
 // exclusive prefix sums over per-item counts: one workgroup per array (blockIdx.x picks it), 8 consecutive items per thread,
 // wave scans on DPP, one barrier pair per 8192 items.  (The first version, a Hillis-Steele scan of 1024 items at a time with
@@ -232,7 +264,7 @@ struct StagScanJobs {
     int *counts[2];
     int *total[2];
 };
-__global__ __launch_bounds__(1024) void k_stag_scan_counts_n(StagScanJobs J, const int *__restrict__ counters)
+__device__ __forceinline__ void k_stag_scan_counts_n_impl(StagScanJobs J, const int *__restrict__ counters)
 {
     __shared__ int s_w[16];
     int *__restrict__ counts = J.counts[blockIdx.x];
@@ -268,7 +300,15 @@ __global__ __launch_bounds__(1024) void k_stag_scan_counts_n(StagScanJobs J, con
     }
     if (tid == 0) *J.total[blockIdx.x] = carry;
 }
-__global__ __launch_bounds__(1024) void k_stag_scan_counts(int *__restrict__ counts, const int *__restrict__ counters, int *__restrict__ total)
+__global__ __launch_bounds__(1024) void k_stag_scan_counts_n(StagScanJobs J, const int *__restrict__ counters)
+{
+    k_stag_scan_counts_n_impl(J, counters);
+}
+struct k_stag_scan_counts_n_fn {
+    static constexpr int kBounds = 1024;
+    __device__ __forceinline__ void operator()(StagScanJobs J, const int *__restrict__ counters) const { k_stag_scan_counts_n_impl(J, counters); }
+};
+__device__ __forceinline__ void k_stag_scan_counts_impl(int *__restrict__ counts, const int *__restrict__ counters, int *__restrict__ total)
 {
     __shared__ int s_w[16];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = counters[0];
@@ -303,6 +343,14 @@ __global__ __launch_bounds__(1024) void k_stag_scan_counts(int *__restrict__ cou
     }
     if (tid == 0) *total = carry;
 }
+__global__ __launch_bounds__(1024) void k_stag_scan_counts(int *__restrict__ counts, const int *__restrict__ counters, int *__restrict__ total)
+{
+    k_stag_scan_counts_impl(counts, counters, total);
+}
+struct k_stag_scan_counts_fn {
+    static constexpr int kBounds = 1024;
+    __device__ __forceinline__ void operator()(int *__restrict__ counts, const int *__restrict__ counters, int *__restrict__ total) const { k_stag_scan_counts_impl(counts, counters, total); }
+};
 
 // ------------------------------------------------------------------------------------------------ K12: EDLines, line fitting
 // DetectLinesByEDPF (EDLines.cpp:849-941) after the edge detection: SplitSegment2Lines (:162-268) cuts every validated
@@ -499,7 +547,7 @@ __device__ __forceinline__ long long wave_iscan_ll(long long v, int lane)
 // (64 window positions at a time, each lane its own 9-pixel fit), and the point-to-line distances of the next 64 pixels under
 // the CURRENT line -- the sequential good / bad bookkeeping then runs over the ballot until a refit really changes the line
 // (every tenth good pixel), at which point the rest of the batch is thrown away and recomputed.
-__global__ __launch_bounds__(256) void k_stag_split_lines(const int2 *__restrict__ segs, const int *__restrict__ nsegs, const int2 *__restrict__ pix,
+__device__ __forceinline__ void k_stag_split_lines_impl(const int2 *__restrict__ segs, const int *__restrict__ nsegs, const int2 *__restrict__ pix,
                                                           StagPrefix PF, int min_line_len, double line_error, fid_stag_line *__restrict__ slots,
                                                           int *__restrict__ counts)
 {
@@ -645,9 +693,17 @@ __global__ __launch_bounds__(256) void k_stag_split_lines(const int2 *__restrict
     }
     counts[seg] = nl;
 }
+__global__ __launch_bounds__(256) void k_stag_split_lines(const int2 *__restrict__ segs, const int *__restrict__ nsegs, const int2 *__restrict__ pix, StagPrefix PF, int min_line_len, double line_error, fid_stag_line *__restrict__ slots, int *__restrict__ counts)
+{
+    k_stag_split_lines_impl(segs, nsegs, pix, PF, min_line_len, line_error, slots, counts);
+}
+struct k_stag_split_lines_fn {
+    static constexpr int kBounds = 256;
+    __device__ __forceinline__ void operator()(const int2 *__restrict__ segs, const int *__restrict__ nsegs, const int2 *__restrict__ pix, StagPrefix PF, int min_line_len, double line_error, fid_stag_line *__restrict__ slots, int *__restrict__ counts) const { k_stag_split_lines_impl(segs, nsegs, pix, PF, min_line_len, line_error, slots, counts); }
+};
 
 // the lines of every segment, one after the other in segment order (counts hold exclusive prefix sums by now)
-__global__ __launch_bounds__(64) void k_stag_gather_lines(const int2 *__restrict__ segs, const int *__restrict__ nsegs, const int *__restrict__ counts,
+__device__ __forceinline__ void k_stag_gather_lines_impl(const int2 *__restrict__ segs, const int *__restrict__ nsegs, const int *__restrict__ counts,
                                                           const int *__restrict__ total, const fid_stag_line *__restrict__ slots,
                                                           fid_stag_line *__restrict__ out)
 {
@@ -658,6 +714,14 @@ __global__ __launch_bounds__(64) void k_stag_gather_lines(const int2 *__restrict
     const fid_stag_line *L = slots + segs[seg].x / 9;
     for (int j = 0; j < n; j++) out[o + j] = L[j];
 }
+__global__ __launch_bounds__(64) void k_stag_gather_lines(const int2 *__restrict__ segs, const int *__restrict__ nsegs, const int *__restrict__ counts, const int *__restrict__ total, const fid_stag_line *__restrict__ slots, fid_stag_line *__restrict__ out)
+{
+    k_stag_gather_lines_impl(segs, nsegs, counts, total, slots, out);
+}
+struct k_stag_gather_lines_fn {
+    static constexpr int kBounds = 64;
+    __device__ __forceinline__ void operator()(const int2 *__restrict__ segs, const int *__restrict__ nsegs, const int *__restrict__ counts, const int *__restrict__ total, const fid_stag_line *__restrict__ slots, fid_stag_line *__restrict__ out) const { k_stag_gather_lines_impl(segs, nsegs, counts, total, slots, out); }
+};
 
 // ------------------------------------------------------------------------------------------------ K13: line validation
 // ValidateLineSegments (EDLines.cpp:274-409): a line is kept if enough of its pixels have a gradient direction within
@@ -791,7 +855,7 @@ __device__ bool sl_validate_rect(const uint8_t *__restrict__ src, int W, int H, 
     return count <= T.kmin_n ? aligned >= T.kmin[count] : false;
 }
 
-__global__ __launch_bounds__(64) void k_stag_validate_lines(const fid_stag_line *__restrict__ lines, const int *__restrict__ nlines,
+__device__ __forceinline__ void k_stag_validate_lines_impl(const fid_stag_line *__restrict__ lines, const int *__restrict__ nlines,
                                                             const uint8_t *__restrict__ src, int W, int H, const int2 *__restrict__ vsegs,
                                                             const int2 *__restrict__ pix, StagLineTables T, int *__restrict__ flags)
 {
@@ -821,9 +885,17 @@ __global__ __launch_bounds__(64) void k_stag_validate_lines(const fid_stag_line 
     }
     flags[i] = valid ? 1 : 0;
 }
+__global__ __launch_bounds__(64) void k_stag_validate_lines(const fid_stag_line *__restrict__ lines, const int *__restrict__ nlines, const uint8_t *__restrict__ src, int W, int H, const int2 *__restrict__ vsegs, const int2 *__restrict__ pix, StagLineTables T, int *__restrict__ flags)
+{
+    k_stag_validate_lines_impl(lines, nlines, src, W, H, vsegs, pix, T, flags);
+}
+struct k_stag_validate_lines_fn {
+    static constexpr int kBounds = 64;
+    __device__ __forceinline__ void operator()(const fid_stag_line *__restrict__ lines, const int *__restrict__ nlines, const uint8_t *__restrict__ src, int W, int H, const int2 *__restrict__ vsegs, const int2 *__restrict__ pix, StagLineTables T, int *__restrict__ flags) const { k_stag_validate_lines_impl(lines, nlines, src, W, H, vsegs, pix, T, flags); }
+};
 
 // keep the valid lines, in order (flags hold exclusive prefix sums by now)
-__global__ __launch_bounds__(256) void k_stag_compact_lines(const fid_stag_line *__restrict__ lines, const int *__restrict__ nlines,
+__device__ __forceinline__ void k_stag_compact_lines_impl(const fid_stag_line *__restrict__ lines, const int *__restrict__ nlines,
                                                             const int *__restrict__ pos, const int *__restrict__ total,
                                                             fid_stag_line *__restrict__ out)
 {
@@ -833,3 +905,11 @@ __global__ __launch_bounds__(256) void k_stag_compact_lines(const fid_stag_line 
     const int next = i + 1 < n ? pos[i + 1] : *total;
     if (next != pos[i]) out[pos[i]] = lines[i];
 }
+__global__ __launch_bounds__(256) void k_stag_compact_lines(const fid_stag_line *__restrict__ lines, const int *__restrict__ nlines, const int *__restrict__ pos, const int *__restrict__ total, fid_stag_line *__restrict__ out)
+{
+    k_stag_compact_lines_impl(lines, nlines, pos, total, out);
+}
+struct k_stag_compact_lines_fn {
+    static constexpr int kBounds = 256;
+    __device__ __forceinline__ void operator()(const fid_stag_line *__restrict__ lines, const int *__restrict__ nlines, const int *__restrict__ pos, const int *__restrict__ total, fid_stag_line *__restrict__ out) const { k_stag_compact_lines_impl(lines, nlines, pos, total, out); }
+};

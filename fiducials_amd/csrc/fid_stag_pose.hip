@@ -414,7 +414,7 @@ __device__ bool sr_in_quad(const double c[8], double px, double py)
     return true;
 }
 
-__global__ __launch_bounds__(64) void k_stag_refine(fid_stag_marker *__restrict__ markers, const int *__restrict__ nmarkers,
+__device__ __forceinline__ void k_stag_refine_impl(fid_stag_marker *__restrict__ markers, const int *__restrict__ nmarkers,
                                                     const int2 *__restrict__ vsegs, const int *__restrict__ nsegs, const int2 *__restrict__ pix,
                                                     int *__restrict__ chosen_out)
 {
@@ -550,6 +550,14 @@ __global__ __launch_bounds__(64) void k_stag_refine(fid_stag_marker *__restrict_
     project(0, 1, &M.corners[6], &M.corners[7]);
     if (lane == 0) markers[m] = M;
 }
+__global__ __launch_bounds__(64) void k_stag_refine(fid_stag_marker *__restrict__ markers, const int *__restrict__ nmarkers, const int2 *__restrict__ vsegs, const int *__restrict__ nsegs, const int2 *__restrict__ pix, int *__restrict__ chosen_out)
+{
+    k_stag_refine_impl(markers, nmarkers, vsegs, nsegs, pix, chosen_out);
+}
+struct k_stag_refine_fn {
+    static constexpr int kBounds = 64;
+    __device__ __forceinline__ void operator()(fid_stag_marker *__restrict__ markers, const int *__restrict__ nmarkers, const int2 *__restrict__ vsegs, const int *__restrict__ nsegs, const int2 *__restrict__ pix, int *__restrict__ chosen_out) const { k_stag_refine_impl(markers, nmarkers, vsegs, nsegs, pix, chosen_out); }
+};
 
 // ------------------------------------------------------------------------------------------------ K17: marker pose
 // StagNode::imageCallback -> Common::solvePnpSingle (stag_detect.cpp:140-165, common.hpp:34-46): cv::solvePnP (ITERATIVE) on
@@ -589,7 +597,7 @@ __device__ void sp_undistort(const double K[9], const double kd[5], double u, do
     *oy = y;
 }
 
-__global__ __launch_bounds__(64) void k_stag_pose(const fid_stag_marker *__restrict__ markers, const int *__restrict__ nmarkers, PoseCam cam,
+__device__ __forceinline__ void k_stag_pose_impl(const fid_stag_marker *__restrict__ markers, const int *__restrict__ nmarkers, PoseCam cam,
                                                   double marker_size, fid_stag_pose_out *__restrict__ out)
 {
     const int item = blockIdx.x * 4 + (threadIdx.x >> 4), g = threadIdx.x & 15;
@@ -726,3 +734,11 @@ __global__ __launch_bounds__(64) void k_stag_pose(const fid_stag_marker *__restr
         out[item] = o;
     }
 }
+__global__ __launch_bounds__(64) void k_stag_pose(const fid_stag_marker *__restrict__ markers, const int *__restrict__ nmarkers, PoseCam cam, double marker_size, fid_stag_pose_out *__restrict__ out)
+{
+    k_stag_pose_impl(markers, nmarkers, cam, marker_size, out);
+}
+struct k_stag_pose_fn {
+    static constexpr int kBounds = 64;
+    __device__ __forceinline__ void operator()(const fid_stag_marker *__restrict__ markers, const int *__restrict__ nmarkers, PoseCam cam, double marker_size, fid_stag_pose_out *__restrict__ out) const { k_stag_pose_impl(markers, nmarkers, cam, marker_size, out); }
+};

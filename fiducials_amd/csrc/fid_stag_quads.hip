@@ -236,7 +236,7 @@ __device__ void sq_make_quad(const StagCorner c[4], fid_stag_quad *q)
 }
 
 // first line and number of lines of every validated segment (lines are stored segment by segment)
-__global__ __launch_bounds__(256) void k_stag_line_ranges(const fid_stag_line *__restrict__ lines, const int *__restrict__ nlines, int2 *__restrict__ range)
+__device__ __forceinline__ void k_stag_line_ranges_impl(const fid_stag_line *__restrict__ lines, const int *__restrict__ nlines, int2 *__restrict__ range)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     const int n = *nlines;
@@ -245,8 +245,16 @@ __global__ __launch_bounds__(256) void k_stag_line_ranges(const fid_stag_line *_
     if (i == 0 || lines[i - 1].segmentNo != sg) range[sg].x = i;
     if (i == n - 1 || lines[i + 1].segmentNo != sg) range[sg].y = i + 1;
 }
+__global__ __launch_bounds__(256) void k_stag_line_ranges(const fid_stag_line *__restrict__ lines, const int *__restrict__ nlines, int2 *__restrict__ range)
+{
+    k_stag_line_ranges_impl(lines, nlines, range);
+}
+struct k_stag_line_ranges_fn {
+    static constexpr int kBounds = 256;
+    __device__ __forceinline__ void operator()(const fid_stag_line *__restrict__ lines, const int *__restrict__ nlines, int2 *__restrict__ range) const { k_stag_line_ranges_impl(lines, nlines, range); }
+};
 
-__global__ __launch_bounds__(256) void k_stag_quads(fid_stag_line *__restrict__ lines, const int2 *__restrict__ range, const int *__restrict__ nsegs,
+__device__ __forceinline__ void k_stag_quads_impl(fid_stag_line *__restrict__ lines, const int2 *__restrict__ range, const int *__restrict__ nsegs,
                                                     const int2 *__restrict__ vsegs, const int2 *__restrict__ pix, const uint8_t *__restrict__ img, int W,
                                                     int H, StagCorner *__restrict__ corner_slots, int *__restrict__ order_slots,
                                                     fid_stag_quad *__restrict__ quad_slots, int *__restrict__ counts)
@@ -321,8 +329,16 @@ __global__ __launch_bounds__(256) void k_stag_quads(fid_stag_line *__restrict__ 
     }
     counts[seg] = nq;
 }
+__global__ __launch_bounds__(256) void k_stag_quads(fid_stag_line *__restrict__ lines, const int2 *__restrict__ range, const int *__restrict__ nsegs, const int2 *__restrict__ vsegs, const int2 *__restrict__ pix, const uint8_t *__restrict__ img, int W, int H, StagCorner *__restrict__ corner_slots, int *__restrict__ order_slots, fid_stag_quad *__restrict__ quad_slots, int *__restrict__ counts)
+{
+    k_stag_quads_impl(lines, range, nsegs, vsegs, pix, img, W, H, corner_slots, order_slots, quad_slots, counts);
+}
+struct k_stag_quads_fn {
+    static constexpr int kBounds = 256;
+    __device__ __forceinline__ void operator()(fid_stag_line *__restrict__ lines, const int2 *__restrict__ range, const int *__restrict__ nsegs, const int2 *__restrict__ vsegs, const int2 *__restrict__ pix, const uint8_t *__restrict__ img, int W, int H, StagCorner *__restrict__ corner_slots, int *__restrict__ order_slots, fid_stag_quad *__restrict__ quad_slots, int *__restrict__ counts) const { k_stag_quads_impl(lines, range, nsegs, vsegs, pix, img, W, H, corner_slots, order_slots, quad_slots, counts); }
+};
 
-__global__ __launch_bounds__(64) void k_stag_gather_quads(const int2 *__restrict__ range, const int *__restrict__ nsegs, const int *__restrict__ counts,
+__device__ __forceinline__ void k_stag_gather_quads_impl(const int2 *__restrict__ range, const int *__restrict__ nsegs, const int *__restrict__ counts,
                                                           const int *__restrict__ total, const fid_stag_quad *__restrict__ slots,
                                                           fid_stag_quad *__restrict__ out)
 {
@@ -333,6 +349,14 @@ __global__ __launch_bounds__(64) void k_stag_gather_quads(const int2 *__restrict
     const fid_stag_quad *Q = slots + range[seg].x;
     for (int j = 0; j < n; j++) out[o + j] = Q[j];
 }
+__global__ __launch_bounds__(64) void k_stag_gather_quads(const int2 *__restrict__ range, const int *__restrict__ nsegs, const int *__restrict__ counts, const int *__restrict__ total, const fid_stag_quad *__restrict__ slots, fid_stag_quad *__restrict__ out)
+{
+    k_stag_gather_quads_impl(range, nsegs, counts, total, slots, out);
+}
+struct k_stag_gather_quads_fn {
+    static constexpr int kBounds = 64;
+    __device__ __forceinline__ void operator()(const int2 *__restrict__ range, const int *__restrict__ nsegs, const int *__restrict__ counts, const int *__restrict__ total, const fid_stag_quad *__restrict__ slots, fid_stag_quad *__restrict__ out) const { k_stag_gather_quads_impl(range, nsegs, counts, total, slots, out); }
+};
 
 // ------------------------------------------------------------------------------------------------ K15: decoding
 // The loop of Stag::detectMarkers (Stag.cpp:36-48) per quad: Quad::estimateHomography (Quad.cpp:14-53), Stag::readCode
@@ -378,7 +402,7 @@ __device__ int sd_read_bilinear(const uint8_t *__restrict__ img, int W, int H, d
     return (int)(acc / tot);
 }
 
-__global__ __launch_bounds__(256) void k_stag_decode(const fid_stag_quad *__restrict__ quads, const int *__restrict__ nquads,
+__device__ __forceinline__ void k_stag_decode_impl(const fid_stag_quad *__restrict__ quads, const int *__restrict__ nquads,
                                                      const uint8_t *__restrict__ img, int W, int H, const double *__restrict__ locs /* [72][3] */,
                                                      const unsigned long long *__restrict__ words, int nwords, int err_corr,
                                                      fid_stag_marker *__restrict__ cand, int *__restrict__ found)
@@ -461,10 +485,18 @@ __global__ __launch_bounds__(256) void k_stag_decode(const fid_stag_quad *__rest
     M.code = code;
     cand[q] = M;
 }
+__global__ __launch_bounds__(256) void k_stag_decode(const fid_stag_quad *__restrict__ quads, const int *__restrict__ nquads, const uint8_t *__restrict__ img, int W, int H, const double *__restrict__ locs , const unsigned long long *__restrict__ words, int nwords, int err_corr, fid_stag_marker *__restrict__ cand, int *__restrict__ found)
+{
+    k_stag_decode_impl(quads, nquads, img, W, H, locs, words, nwords, err_corr, cand, found);
+}
+struct k_stag_decode_fn {
+    static constexpr int kBounds = 256;
+    __device__ __forceinline__ void operator()(const fid_stag_quad *__restrict__ quads, const int *__restrict__ nquads, const uint8_t *__restrict__ img, int W, int H, const double *__restrict__ locs , const unsigned long long *__restrict__ words, int nwords, int err_corr, fid_stag_marker *__restrict__ cand, int *__restrict__ found) const { k_stag_decode_impl(quads, nquads, img, W, H, locs, words, nwords, err_corr, cand, found); }
+};
 
 // Stag::checkDuplicate over the decoded quads in quad order: one marker per id, the least distorted one, at the position of
 // the first quad that showed the id
-__global__ __launch_bounds__(64) void k_stag_dedup(const fid_stag_marker *__restrict__ cand, const int *__restrict__ found, const int *__restrict__ nquads,
+__device__ __forceinline__ void k_stag_dedup_impl(const fid_stag_marker *__restrict__ cand, const int *__restrict__ found, const int *__restrict__ nquads,
                                                    fid_stag_marker *__restrict__ out, int *__restrict__ nout)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -483,3 +515,11 @@ __global__ __launch_bounds__(64) void k_stag_dedup(const fid_stag_marker *__rest
     }
     *nout = m;
 }
+__global__ __launch_bounds__(64) void k_stag_dedup(const fid_stag_marker *__restrict__ cand, const int *__restrict__ found, const int *__restrict__ nquads, fid_stag_marker *__restrict__ out, int *__restrict__ nout)
+{
+    k_stag_dedup_impl(cand, found, nquads, out, nout);
+}
+struct k_stag_dedup_fn {
+    static constexpr int kBounds = 64;
+    __device__ __forceinline__ void operator()(const fid_stag_marker *__restrict__ cand, const int *__restrict__ found, const int *__restrict__ nquads, fid_stag_marker *__restrict__ out, int *__restrict__ nout) const { k_stag_dedup_impl(cand, found, nquads, out, nout); }
+};

@@ -432,7 +432,7 @@ struct StagRouter {
     }
 };
 
-__global__ __launch_bounds__(64) void k_stag_route_seq(StagRoute R, const int32_t *__restrict__ sorted, const unsigned *__restrict__ n_anchors,
+__device__ __forceinline__ void k_stag_route_seq_impl(StagRoute R, const int32_t *__restrict__ sorted, const unsigned *__restrict__ n_anchors,
                                                        int grad_thresh)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -451,6 +451,14 @@ __global__ __launch_bounds__(64) void k_stag_route_seq(StagRoute R, const int32_
     R.counters[1] = S.totalPixels;
     R.counters[2] = S.overflow;
 }
+__global__ __launch_bounds__(64) void k_stag_route_seq(StagRoute R, const int32_t *__restrict__ sorted, const unsigned *__restrict__ n_anchors, int grad_thresh)
+{
+    k_stag_route_seq_impl(R, sorted, n_anchors, grad_thresh);
+}
+struct k_stag_route_seq_fn {
+    static constexpr int kBounds = 64;
+    __device__ __forceinline__ void operator()(StagRoute R, const int32_t *__restrict__ sorted, const unsigned *__restrict__ n_anchors, int grad_thresh) const { k_stag_route_seq_impl(R, sorted, n_anchors, grad_thresh); }
+};
 
 // ---- component-parallel routing ---------------------------------------------------------------------------------
 // A walk only ever stands on pixels with grad >= GRADIENT_THRESH (it stops in front of anything weaker) and only touches the
@@ -494,13 +502,21 @@ struct StagFills {
     unsigned n16[6];  // 16-byte words
     unsigned v[6];    // the 32-bit pattern
 };
-__global__ __launch_bounds__(256) void k_stag_fills(StagFills F)
+__device__ __forceinline__ void k_stag_fills_impl(StagFills F)
 {
     const unsigned i = blockIdx.x * 256 + threadIdx.x;
 #pragma unroll
     for (int k = 0; k < 6; k++)
         if (i < F.n16[k]) F.p[k][i] = make_uint4(F.v[k], F.v[k], F.v[k], F.v[k]);
 }
+__global__ __launch_bounds__(256) void k_stag_fills(StagFills F)
+{
+    k_stag_fills_impl(F);
+}
+struct k_stag_fills_fn {
+    static constexpr int kBounds = 256;
+    __device__ __forceinline__ void operator()(StagFills F) const { k_stag_fills_impl(F); }
+};
 
 __device__ __forceinline__ int ccl_find(const int *L, int a)
 {
@@ -535,7 +551,7 @@ __device__ __forceinline__ void ccl_union(int *L, int a, int b)
     }
 }
 
-__global__ __launch_bounds__(256) void k_stag_ccl_tile(const int16_t *__restrict__ grad, int W, int H, int thresh, int *__restrict__ label,
+__device__ __forceinline__ void k_stag_ccl_tile_impl(const int16_t *__restrict__ grad, int W, int H, int thresh, int *__restrict__ label,
                                                        int *__restrict__ csize, int *__restrict__ canch, int4 *__restrict__ cbox)
 {
     __shared__ int L[CCL_TW * CCL_TH];
@@ -576,9 +592,17 @@ __global__ __launch_bounds__(256) void k_stag_ccl_tile(const int16_t *__restrict
         label[y * W + x] = v;
     }
 }
+__global__ __launch_bounds__(256) void k_stag_ccl_tile(const int16_t *__restrict__ grad, int W, int H, int thresh, int *__restrict__ label, int *__restrict__ csize, int *__restrict__ canch, int4 *__restrict__ cbox)
+{
+    k_stag_ccl_tile_impl(grad, W, H, thresh, label, csize, canch, cbox);
+}
+struct k_stag_ccl_tile_fn {
+    static constexpr int kBounds = 256;
+    __device__ __forceinline__ void operator()(const int16_t *__restrict__ grad, int W, int H, int thresh, int *__restrict__ label, int *__restrict__ csize, int *__restrict__ canch, int4 *__restrict__ cbox) const { k_stag_ccl_tile_impl(grad, W, H, thresh, label, csize, canch, cbox); }
+};
 
 // the pixels of a tile's first row, first column and last column against their neighbours in the adjacent tiles
-__global__ __launch_bounds__(128) void k_stag_ccl_border(int W, int H, int *label)
+__device__ __forceinline__ void k_stag_ccl_border_impl(int W, int H, int *label)
 {
     const int t = threadIdx.x;
     int lx, ly;
@@ -600,8 +624,16 @@ __global__ __launch_bounds__(128) void k_stag_ccl_border(int W, int H, int *labe
     }
     if (left && lx == 0 && label[i - 1] >= 0) ccl_union(label, i, i - 1);
 }
+__global__ __launch_bounds__(128) void k_stag_ccl_border(int W, int H, int *label)
+{
+    k_stag_ccl_border_impl(W, H, label);
+}
+struct k_stag_ccl_border_fn {
+    static constexpr int kBounds = 128;
+    __device__ __forceinline__ void operator()(int W, int H, int *label) const { k_stag_ccl_border_impl(W, H, label); }
+};
 
-__global__ __launch_bounds__(256) void k_stag_ccl_flatten(int n, int W, int *label, const uint8_t *__restrict__ anchors, int *__restrict__ csize,
+__device__ __forceinline__ void k_stag_ccl_flatten_impl(int n, int W, int *label, const uint8_t *__restrict__ anchors, int *__restrict__ csize,
                                                           int *__restrict__ canch, int4 *__restrict__ cbox)
 {
     const int i = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63;
@@ -652,10 +684,18 @@ __global__ __launch_bounds__(256) void k_stag_ccl_flatten(int n, int W, int *lab
         pending &= ~m;
     }
 }
+__global__ __launch_bounds__(256) void k_stag_ccl_flatten(int n, int W, int *label, const uint8_t *__restrict__ anchors, int *__restrict__ csize, int *__restrict__ canch, int4 *__restrict__ cbox)
+{
+    k_stag_ccl_flatten_impl(n, W, label, anchors, csize, canch, cbox);
+}
+struct k_stag_ccl_flatten_fn {
+    static constexpr int kBounds = 256;
+    __device__ __forceinline__ void operator()(int n, int W, int *label, const uint8_t *__restrict__ anchors, int *__restrict__ csize, int *__restrict__ canch, int4 *__restrict__ cbox) const { k_stag_ccl_flatten_impl(n, W, label, anchors, csize, canch, cbox); }
+};
 
 // cursors: [0] components [1] anchor slots [2] scratch pixels [3] stack [4] chains [5] output pixels [6] segments [7] overflow
 //          [8] overflow flags of the routing kernels [9] most anchors in one component
-__global__ __launch_bounds__(256) void k_stag_comp_alloc(int n, const int *__restrict__ label, const int *__restrict__ csize,
+__device__ __forceinline__ void k_stag_comp_alloc_impl(int n, const int *__restrict__ label, const int *__restrict__ csize,
                                                          const int *__restrict__ canch, const int4 *__restrict__ cbox, int *__restrict__ cursors, int max_comps,
                                                          const int *caps, StagComp *__restrict__ comps, int *__restrict__ cidmap)
 {
@@ -698,10 +738,18 @@ __global__ __launch_bounds__(256) void k_stag_comp_alloc(int n, const int *__res
     comps[cid] = C;
     cidmap[i] = cid;
 }
+__global__ __launch_bounds__(256) void k_stag_comp_alloc(int n, const int *__restrict__ label, const int *__restrict__ csize, const int *__restrict__ canch, const int4 *__restrict__ cbox, int *__restrict__ cursors, int max_comps, const int *caps, StagComp *__restrict__ comps, int *__restrict__ cidmap)
+{
+    k_stag_comp_alloc_impl(n, label, csize, canch, cbox, cursors, max_comps, caps, comps, cidmap);
+}
+struct k_stag_comp_alloc_fn {
+    static constexpr int kBounds = 256;
+    __device__ __forceinline__ void operator()(int n, const int *__restrict__ label, const int *__restrict__ csize, const int *__restrict__ canch, const int4 *__restrict__ cbox, int *__restrict__ cursors, int max_comps, const int *caps, StagComp *__restrict__ comps, int *__restrict__ cidmap) const { k_stag_comp_alloc_impl(n, label, csize, canch, cbox, cursors, max_comps, caps, comps, cidmap); }
+};
 
 // (64 consecutive ranks hold many anchors of the frame's big components: one atomic per (wave, component), the anchors of
 //  a group placed in rank order)
-__global__ __launch_bounds__(256) void k_stag_comp_fill(const int32_t *__restrict__ sorted, const unsigned *__restrict__ n_anchors,
+__device__ __forceinline__ void k_stag_comp_fill_impl(const int32_t *__restrict__ sorted, const unsigned *__restrict__ n_anchors,
                                                         const int *__restrict__ label, const int *__restrict__ cidmap, const StagComp *__restrict__ comps,
                                                         int *__restrict__ fill, int *__restrict__ aslots)
 {
@@ -723,9 +771,17 @@ __global__ __launch_bounds__(256) void k_stag_comp_fill(const int32_t *__restric
         pending &= ~m;
     }
 }
+__global__ __launch_bounds__(256) void k_stag_comp_fill(const int32_t *__restrict__ sorted, const unsigned *__restrict__ n_anchors, const int *__restrict__ label, const int *__restrict__ cidmap, const StagComp *__restrict__ comps, int *__restrict__ fill, int *__restrict__ aslots)
+{
+    k_stag_comp_fill_impl(sorted, n_anchors, label, cidmap, comps, fill, aslots);
+}
+struct k_stag_comp_fill_fn {
+    static constexpr int kBounds = 256;
+    __device__ __forceinline__ void operator()(const int32_t *__restrict__ sorted, const unsigned *__restrict__ n_anchors, const int *__restrict__ label, const int *__restrict__ cidmap, const StagComp *__restrict__ comps, int *__restrict__ fill, int *__restrict__ aslots) const { k_stag_comp_fill_impl(sorted, n_anchors, label, cidmap, comps, fill, aslots); }
+};
 
 // cursors[10] = the largest LDS tile (bytes) a component would need (the boxes come from k_stag_ccl_flatten)
-__global__ __launch_bounds__(256) void k_stag_comp_tilemax(const StagComp *__restrict__ comps, int *cursors, int lds_cap)
+__device__ __forceinline__ void k_stag_comp_tilemax_impl(const StagComp *__restrict__ comps, int *cursors, int lds_cap)
 {
     const int cid = blockIdx.x * 256 + threadIdx.x;
     if (cid >= cursors[0]) return;
@@ -734,13 +790,21 @@ __global__ __launch_bounds__(256) void k_stag_comp_tilemax(const StagComp *__res
     const int bytes = (C.maxr - C.minr + 3) * (C.maxc - C.minc + 3) * 2;
     if (bytes <= lds_cap) atomicMax(&cursors[10], bytes);
 }
+__global__ __launch_bounds__(256) void k_stag_comp_tilemax(const StagComp *__restrict__ comps, int *cursors, int lds_cap)
+{
+    k_stag_comp_tilemax_impl(comps, cursors, lds_cap);
+}
+struct k_stag_comp_tilemax_fn {
+    static constexpr int kBounds = 256;
+    __device__ __forceinline__ void operator()(const StagComp *__restrict__ comps, int *cursors, int lds_cap) const { k_stag_comp_tilemax_impl(comps, cursors, lds_cap); }
+};
 
 // ranks of one component, descending: bitonic sort of the (padded, -1 filled) slice, one wave per component; slices of up to
 // 2048 entries are sorted in LDS
 #define STAG_SORT_LDS 2048
 #define STAG_SORT_WAVE 256   // slices up to here: a wave each (k_stag_comp_sort); up to STAG_SORT_BIG: a workgroup of 1024 each
 #define STAG_SORT_BIG 16384
-__global__ __launch_bounds__(256) void k_stag_comp_sort(const StagComp *__restrict__ comps, const int *__restrict__ cursors, int *aslots)
+__device__ __forceinline__ void k_stag_comp_sort_impl(const StagComp *__restrict__ comps, const int *__restrict__ cursors, int *aslots)
 {
     __shared__ int s_buf[4][STAG_SORT_LDS];
     const int wv = threadIdx.x >> 6, cid = blockIdx.x * 4 + wv, lane = threadIdx.x & 63;
@@ -783,10 +847,18 @@ __global__ __launch_bounds__(256) void k_stag_comp_sort(const StagComp *__restri
     if (in_lds)
         for (int i = lane; i < P; i += 64) g[i] = a[i];
 }
+__global__ __launch_bounds__(256) void k_stag_comp_sort(const StagComp *__restrict__ comps, const int *__restrict__ cursors, int *aslots)
+{
+    k_stag_comp_sort_impl(comps, cursors, aslots);
+}
+struct k_stag_comp_sort_fn {
+    static constexpr int kBounds = 256;
+    __device__ __forceinline__ void operator()(const StagComp *__restrict__ comps, const int *__restrict__ cursors, int *aslots) const { k_stag_comp_sort_impl(comps, cursors, aslots); }
+};
 
 // the same for the slices of 257 .. 16384 entries (a frame's larger components): one workgroup of 1024 per component, the
 // slice in up to 64 KB of LDS (one wave took 118 us for a slice of 2048: 66 passes of 32 rounds each)
-__global__ __launch_bounds__(1024) void k_stag_comp_sort_big(const StagComp *__restrict__ comps, const int *__restrict__ cursors, int *aslots)
+__device__ __forceinline__ void k_stag_comp_sort_big_impl(const StagComp *__restrict__ comps, const int *__restrict__ cursors, int *aslots)
 {
     extern __shared__ int s_big[];
     const int cid = blockIdx.x;
@@ -814,6 +886,14 @@ __global__ __launch_bounds__(1024) void k_stag_comp_sort_big(const StagComp *__r
         }
     for (int i = threadIdx.x; i < P; i += 1024) g[i] = s_big[i];
 }
+__global__ __launch_bounds__(1024) void k_stag_comp_sort_big(const StagComp *__restrict__ comps, const int *__restrict__ cursors, int *aslots)
+{
+    k_stag_comp_sort_big_impl(comps, cursors, aslots);
+}
+struct k_stag_comp_sort_big_fn {
+    static constexpr int kBounds = 1024;
+    __device__ __forceinline__ void operator()(const StagComp *__restrict__ comps, const int *__restrict__ cursors, int *aslots) const { k_stag_comp_sort_big_impl(comps, cursors, aslots); }
+};
 
 struct StagArenas {
     int2 *pix;
@@ -842,7 +922,7 @@ __device__ void stag_bind(StagRouter &S, const StagRoute &G, const StagArenas &A
     S.par = true;
 }
 
-__global__ __launch_bounds__(256) void k_stag_route_walk(StagRoute G, StagArenas A, StagComp *__restrict__ comps, const int *__restrict__ cursors,
+__device__ __forceinline__ void k_stag_route_walk_impl(StagRoute G, StagArenas A, StagComp *__restrict__ comps, const int *__restrict__ cursors,
                                                         const int32_t *__restrict__ sorted, const int *__restrict__ aslots, const int *__restrict__ label,
                                                         int grad_thresh, int lds_bytes, int *__restrict__ prodflag, int *__restrict__ ovf)
 {
@@ -953,9 +1033,17 @@ __global__ __launch_bounds__(256) void k_stag_route_walk(StagRoute G, StagArenas
         }
     }
 }
+__global__ __launch_bounds__(256) void k_stag_route_walk(StagRoute G, StagArenas A, StagComp *__restrict__ comps, const int *__restrict__ cursors, const int32_t *__restrict__ sorted, const int *__restrict__ aslots, const int *__restrict__ label, int grad_thresh, int lds_bytes, int *__restrict__ prodflag, int *__restrict__ ovf)
+{
+    k_stag_route_walk_impl(G, A, comps, cursors, sorted, aslots, label, grad_thresh, lds_bytes, prodflag, ovf);
+}
+struct k_stag_route_walk_fn {
+    static constexpr int kBounds = 256;
+    __device__ __forceinline__ void operator()(StagRoute G, StagArenas A, StagComp *__restrict__ comps, const int *__restrict__ cursors, const int32_t *__restrict__ sorted, const int *__restrict__ aslots, const int *__restrict__ label, int grad_thresh, int lds_bytes, int *__restrict__ prodflag, int *__restrict__ ovf) const { k_stag_route_walk_impl(G, A, comps, cursors, sorted, aslots, label, grad_thresh, lds_bytes, prodflag, ovf); }
+};
 
 // next[r] = the smallest producing rank > r, or -1 (one workgroup, chunks of 1024 from the top)
-__global__ __launch_bounds__(1024) void k_stag_next_above(const int *__restrict__ prodflag, const unsigned *__restrict__ n_anchors, int *__restrict__ next)
+__device__ __forceinline__ void k_stag_next_above_impl(const int *__restrict__ prodflag, const unsigned *__restrict__ n_anchors, int *__restrict__ next)
 {
     // next[r] = the smallest producing rank above r (-1: none): a running minimum over the ranks taken from the top down,
     // 8 consecutive ranks per thread, wave scans by shuffles, one barrier pair per 8192 ranks
@@ -999,8 +1087,16 @@ __global__ __launch_bounds__(1024) void k_stag_next_above(const int *__restrict_
         __syncthreads();
     }
 }
+__global__ __launch_bounds__(1024) void k_stag_next_above(const int *__restrict__ prodflag, const unsigned *__restrict__ n_anchors, int *__restrict__ next)
+{
+    k_stag_next_above_impl(prodflag, n_anchors, next);
+}
+struct k_stag_next_above_fn {
+    static constexpr int kBounds = 1024;
+    __device__ __forceinline__ void operator()(const int *__restrict__ prodflag, const unsigned *__restrict__ n_anchors, int *__restrict__ next) const { k_stag_next_above_impl(prodflag, n_anchors, next); }
+};
 
-__global__ __launch_bounds__(256) void k_stag_route_extract(StagRoute G, StagArenas A, const StagComp *__restrict__ comps, const int *__restrict__ cursors,
+__device__ __forceinline__ void k_stag_route_extract_impl(StagRoute G, StagArenas A, const StagComp *__restrict__ comps, const int *__restrict__ cursors,
                                                             const int *__restrict__ next, const unsigned *__restrict__ n_anchors,
                                                             int *__restrict__ blk_pix, int *__restrict__ blk_segs, int2 *__restrict__ blk_where,
                                                             int *__restrict__ ovf)
@@ -1059,9 +1155,17 @@ __global__ __launch_bounds__(256) void k_stag_route_extract(StagRoute G, StagAre
     }
     if (S.overflow && lane == 0) atomicOr(ovf, S.overflow);
 }
+__global__ __launch_bounds__(256) void k_stag_route_extract(StagRoute G, StagArenas A, const StagComp *__restrict__ comps, const int *__restrict__ cursors, const int *__restrict__ next, const unsigned *__restrict__ n_anchors, int *__restrict__ blk_pix, int *__restrict__ blk_segs, int2 *__restrict__ blk_where, int *__restrict__ ovf)
+{
+    k_stag_route_extract_impl(G, A, comps, cursors, next, n_anchors, blk_pix, blk_segs, blk_where, ovf);
+}
+struct k_stag_route_extract_fn {
+    static constexpr int kBounds = 256;
+    __device__ __forceinline__ void operator()(StagRoute G, StagArenas A, const StagComp *__restrict__ comps, const int *__restrict__ cursors, const int *__restrict__ next, const unsigned *__restrict__ n_anchors, int *__restrict__ blk_pix, int *__restrict__ blk_segs, int2 *__restrict__ blk_where, int *__restrict__ ovf) const { k_stag_route_extract_impl(G, A, comps, cursors, next, n_anchors, blk_pix, blk_segs, blk_where, ovf); }
+};
 
 // blk_pix / blk_segs hold exclusive prefix sums by now: copy every block to its place in the global order
-__global__ __launch_bounds__(256) void k_stag_route_gather(StagArenas A, const StagComp *__restrict__ comps, const unsigned *__restrict__ n_anchors,
+__device__ __forceinline__ void k_stag_route_gather_impl(StagArenas A, const StagComp *__restrict__ comps, const unsigned *__restrict__ n_anchors,
                                                            const int *__restrict__ prodflag, const int *__restrict__ blk_pix,
                                                            const int *__restrict__ blk_segs, const int2 *__restrict__ blk_where,
                                                            int2 *__restrict__ outpix, int2 *__restrict__ segs, int capOut, int capSegs, int *__restrict__ ovf)
@@ -1082,3 +1186,11 @@ __global__ __launch_bounds__(256) void k_stag_route_gather(StagArenas A, const S
     const int2 *sg = A.segs + C.seg_base + r.seg_off;
     for (int i = lane; i < r.nsegs; i += 64) segs[so + i] = make_int2(sg[i].x - r.out_off + po, sg[i].y);
 }
+__global__ __launch_bounds__(256) void k_stag_route_gather(StagArenas A, const StagComp *__restrict__ comps, const unsigned *__restrict__ n_anchors, const int *__restrict__ prodflag, const int *__restrict__ blk_pix, const int *__restrict__ blk_segs, const int2 *__restrict__ blk_where, int2 *__restrict__ outpix, int2 *__restrict__ segs, int capOut, int capSegs, int *__restrict__ ovf)
+{
+    k_stag_route_gather_impl(A, comps, n_anchors, prodflag, blk_pix, blk_segs, blk_where, outpix, segs, capOut, capSegs, ovf);
+}
+struct k_stag_route_gather_fn {
+    static constexpr int kBounds = 256;
+    __device__ __forceinline__ void operator()(StagArenas A, const StagComp *__restrict__ comps, const unsigned *__restrict__ n_anchors, const int *__restrict__ prodflag, const int *__restrict__ blk_pix, const int *__restrict__ blk_segs, const int2 *__restrict__ blk_where, int2 *__restrict__ outpix, int2 *__restrict__ segs, int capOut, int capSegs, int *__restrict__ ovf) const { k_stag_route_gather_impl(A, comps, n_anchors, prodflag, blk_pix, blk_segs, blk_where, outpix, segs, capOut, capSegs, ovf); }
+};

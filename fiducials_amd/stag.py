@@ -162,24 +162,16 @@ class StagDetector:
 
 
 class StagPool:
-    """Throughput mode: `n_contexts` detectors side by side (fid_stag_detect_markers_batch: ONE host thread carries a frame
-    per context through the pipeline, segment by segment, each context on its own HIP stream).
-    detect_markers_batch(frames[F, H, W]) -> (markers per frame, poses per frame).
+    """Throughput mode (fid_stag_detect_markers_batch): `n_contexts` frame slots.  Round 3: the frames are a GRID DIMENSION --
+    the slots are cut into groups of up to 16, a group carries its frames through the pipeline in lockstep on one stream, every
+    kernel launched once per group (fid_stag_batch.h); one host thread goes round the groups.  32 slots = two groups of 16 is the
+    default: two streams, so nothing depends on how many hardware queues the HIP runtime was given (round 2 ran a stream per
+    context, needed GPU_MAX_HW_QUEUES=24 in the environment before the runtime started and collapsed at 24 contexts;
+    FID_STAG_BATCH=contexts keeps that road for comparison).
+    detect_markers_batch(frames[F, H, W]) -> (markers per frame, poses per frame)."""
 
-    The HIP runtime maps streams to 4 hardware queues unless GPU_MAX_HW_QUEUES says otherwise, and kernels of streams that
-    share a queue do not overlap: 16 contexts measure 570 frames/s with 4 queues and 1070 with 24 (MI355X, 1080p, HD21).
-    The rate follows 1 / (a + b / n): a = whole-GPU kernel time per frame (0.4 ms), b = a frame's chain of small kernels (3.4 ms);
-    22 contexts (1 760 frames/s) stay just under the 24 queues -- at 24 contexts the rate collapses to ~130.  The queues are
-    shared with everything else on the GPU (other processes, closed contexts of this one): 22 is for a process that has the
-    GPU to itself (`bench.py --workload stag`), the default of 16 leaves room.
-    The variable is read when the runtime starts, so it is set here only if nothing has touched the GPU yet; keep the number of
-    contexts below the number of queues (24 contexts on 24 queues collapse to ~100 frames/s)."""
-
-    def __init__(self, libraryHD: int = 21, errorCorrection: int = 7, n_contexts: int = 16, max_width: int = 1920, max_height: int = 1080,
+    def __init__(self, libraryHD: int = 21, errorCorrection: int = 7, n_contexts: int = 32, max_width: int = 1920, max_height: int = 1080,
                  device: int = 0):
-        import os
-
-        os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
         self.dets = [StagDetector(libraryHD, errorCorrection, max_width, max_height, device) for _ in range(n_contexts)]
         self._L = self.dets[0]._L
         self._arr = (C.c_void_p * n_contexts)(*[d._ctx.value for d in self.dets])

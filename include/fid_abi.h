@@ -35,7 +35,11 @@
 extern "C" {
 #endif
 
-#define FID_ABI_VERSION 1
+/* 1: round 1 (aruco path).  2: + fid_detect_device / fid_pose_last / limits, the fid_stag_* family, the fid_jpeg_* family (round 2,
+ * which forgot to bump it).  3: fid_last_stage_ms reports 15 stages (seedless_chain); fid_pose_last may hand over poses that the
+ * preceding fid_detect_* call already computed for the same camera; fid_stag_detect_markers_batch reports 0 markers for a frame
+ * whose slot was too small (round 3).  Entry points are only ever added: a caller built against 1 runs against 3. */
+#define FID_ABI_VERSION 3
 
 typedef enum fid_status {
     FID_OK = 0,

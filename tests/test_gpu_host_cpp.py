@@ -74,7 +74,7 @@ def test_stag_class_and_fiducial_msgs_output_on_the_cpp_host(tmp_path):
     for i, c, t in zip(fr.ids, fr.corners, fr.tvecs):
         lines.append(" ".join([str(int(i))] + [repr(float(v)) for v in c.ravel()] + [repr(float(t[2]))]))
     (tmp_path / "expected.txt").write_text("\n".join(lines))
-    exe = os.path.join(ROOT, "host", "bin", "stag_test")
+    exe = os.path.join(os.path.dirname(_build_host()), "stag_test")
     r = subprocess.run([exe, str(tmp_path / "frame.pgm"), str(tmp_path / "expected.txt"), os.path.join(ROOT, "fiducials_amd", "data"), "21", "7"],
                        capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr

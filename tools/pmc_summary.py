@@ -32,8 +32,9 @@ for k, v in cal_w.items():
     if k.startswith("wr"):
         factors[k] = KNOWN / (1024.0 * (sum(v) / len(v)))
 # which calibrated pattern stands for a kernel's reads / writes (its dominant access)
-READ_AS = {"k_threshold_stream": "rd1", "k_threshold_fixed": "rd4", "k_find_starts": "rd16", "k_walk_full": "rdlds", "k_probe": "rd4"}
-WRITE_AS = {"k_walk_full": "wr16", "k_seg_copy": "wr4"}
+READ_AS = {"k_threshold_stream": "rd1", "k_threshold_fixed": "rd4", "k_find_starts": "rd16", "k_walk_full": "rdlds", "k_seed_walk": "rdlds",
+           "k_probe": "rd4"}
+WRITE_AS = {"k_walk_full": "wr16", "k_seed_walk": "wr16", "k_seg_copy": "wr4"}
 pf, pw = read("FETCH_SIZE"), read("WRITE_SIZE")
 kernels = {}
 for k in sorted(set(pf) | set(pw)):
@@ -67,8 +68,10 @@ doc = {
                             "pipeline kernel is corrected with the factor of its dominant pattern (read_pattern / write_pattern)"},
     "per_frame_bytes": {
         "threshold": stage("k_threshold"), "find_starts": stage("k_find_starts"), "walk_probe": stage("k_probe"),
-        "walk_full": stage("k_walk_full<2>", "k_seg_"), "seed_walk": stage("k_walk_full<1>"), "approx": stage("k_approx"),
+        "walk_full": stage("k_walk_full<2>", "k_seg_"), "seed_walk": stage("k_walk_full<1>", "k_seed_walk"), "approx": stage("k_approx"),
     },
+    "frames_per_launch_measured": frames,  # the passes ran on ONE sub-batch of this many frames; bench.py scales bytes per frame
+                                           # onto its own launches (128 frames at cfg 3)
     "pipeline_bytes_per_frame": sum(v["fetch_bytes_per_frame"] + v["write_bytes_per_frame"] for v in kernels.values()),
     "algorithmic_bytes_per_frame": {"threshold": 5443200, "masks": 3369600, "pipeline": 8812800},
     "kernels": kernels,

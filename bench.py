@@ -311,6 +311,73 @@ def host_feed_result(local_rank, host, K, D):
     return out
 
 
+def jpeg_to_markers(local_rank, files, Q=1):
+    """Compressed frames in HOST memory -> markers + poses (what the node does with `transport:=compressed`): fid_jpeg_decode
+    leaves the gray images in HBM, fid_detect_device + fid_pose_last work on them in place.  Q > 1 cuts the batch into pieces with
+    a decoder thread one piece ahead of the detector (two decoder contexts take turns) -- measured SLOWER than the plain
+    sequence (256 frames: 13.4 k frames/s in one piece, 13.0 k in two, 11.5 k in four): both stages keep the whole chip busy, so
+    there is nothing to hide one behind the other, and smaller pieces cost both their efficiency.  Q = 1 is what is reported."""
+    import threading
+
+    from fiducials_amd import jpeg as fj
+    from fiducials_amd.detector import ArucoDetector
+    from fiducials_amd.synth import K_DEFAULT
+
+    B = len(files)
+    per = (B + Q - 1) // Q
+    parts = [files[k * per:(k + 1) * per] for k in range(Q) if files[k * per:(k + 1) * per]]
+    decs = [fj.JpegDecoder(max_width=W, max_height=H, max_batch=per, device=local_rank) for _ in range(2)]
+    det = ArucoDetector("DICT_5X5_250", device=local_rank, max_width=W, max_height=H, max_batch=per, max_markers=64, max_candidates=2048)
+    D = np.zeros(5)
+
+    def run():
+        ready = [threading.Event() for _ in parts]
+        freed = [threading.Event() for _ in parts]
+        err = []
+
+        def decode_side():
+            try:
+                for k, part in enumerate(parts):
+                    if k >= 2:
+                        freed[k - 2].wait()  # the decoder context of quarter k still holds quarter k - 2 until it is detected
+                    decs[k % 2].decode(part, "mono8", to_host=False)
+                    ready[k].set()
+            except Exception as e:  # noqa: BLE001
+                err.append(e)
+                for ev in ready:
+                    ev.set()
+
+        th = threading.Thread(target=decode_side)
+        th.start()
+        found = 0
+        for k, part in enumerate(parts):
+            ready[k].wait()
+            if err:
+                break
+            ptr, w, h, _, _ = decs[k % 2].device_ptr()
+            found += sum(det.detect_markers_device(ptr, len(part), w, h, unpack=False))
+            det.pose_last(FIDUCIAL_LEN, K_DEFAULT, D, unpack=False)
+            freed[k].set()
+        th.join()
+        if err:
+            raise err[0]
+        return found
+
+    run()
+    t = time.perf_counter()
+    steps, found = 3, 0
+    for _ in range(steps):
+        found += run()
+    dt = time.perf_counter() - t
+    for d in decs:
+        d.close()
+    det.close()
+    return {"value": round(B * steps / dt, 1), "unit": "frames/s", "ms_per_step": round(dt / steps * 1e3, 3),
+            "markers_per_frame_found": round(found / (B * steps), 2),
+            "workload": f"{B} JPEG frames in host memory -> fid_jpeg_decode (device gray) -> fid_detect_device + fid_pose_last, {Q} pieces of {per}, "
+                        "decoding one piece ahead of the detector"}
+
+
 def jpeg_side_result(local_rank, frames):
     """The ingest in front of the hot path when the node runs with its launch default `transport:=compressed`
     (aruco_detect.launch:6): the bench frames as compressed_image_transport sends them (libjpeg defaults: 4:2:0, quality 80),
@@ -348,6 +415,16 @@ def jpeg_side_result(local_rank, frames):
     out["unit"] = "frames/s"
     out["sync_rounds"] = dec.last_rounds()
     dec.close()
+    # algorithmic HBM bytes per frame: coded bytes in, coefficients out and in (2 B each), planes out and in,
+    # gray out -- 4:2:0: 1.5 samples per pixel
+    algo = sum(map(len, files)) // B + int(W * H * 1.5) * (2 + 2 + 1 + 1) + W * H
+    out["roofline"] = {"bound": "hbm", "kernel": "pipeline (entropy decoding: latency-bound passes over the coded bytes)",
+                       "achieved": round(out["value"] * algo / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       "frac": round(out["value"] * algo / 1e9 / HBM_PEAK_GBS, 5), "algo_bytes_per_frame": algo, "traffic": None}
+    try:
+        out["jpeg_to_markers"] = jpeg_to_markers(local_rank, files)
+    except Exception as e:  # noqa: BLE001
+        out["jpeg_to_markers"] = {"error": repr(e)}
     one = fj.JpegDecoder(max_width=W, max_height=H, max_batch=1, device=local_rank)
     det = ArucoDetector("DICT_5X5_250", device=local_rank, max_width=W, max_height=H, max_batch=1, max_markers=64)
     ts, te = [], []

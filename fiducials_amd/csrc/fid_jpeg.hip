@@ -319,8 +319,12 @@ __global__ __launch_bounds__(JP_TPB) void k_jpeg_huff(const JpImage *__restrict_
     const uint32_t cend = tid + 1 < nstg ? (tid + 1) * JP_SUB - S.R[tid + 1] : (tid + 1) * JP_SUB - S.R[tid] - (uint32_t)nrem[0];
     const uint32_t end_bit = cend * 8u;  // this lane's part ends with the first symbol that starts at or behind it
     uint32_t entry_bit = cstart * 8u;
-    if (MODE != 0 && i > 0) {
-        const uint32_t rawk = (e.p >> 3) - s_lo;
+    if (MODE != 0 && i > 0 && !eoi) {
+        // (a predecessor that has met the end of the image needs no entry position -- and its p may lie in front of this
+        //  workgroup's staged bytes: untrusted input must not turn that into an index.  Clamped for the same reason.)
+        const uint32_t pb = e.p >> 3;
+        uint32_t rawk = pb > s_lo ? pb - s_lo : 0u;
+        rawk = rawk < (uint32_t)nstg * JP_SUB ? rawk : (uint32_t)nstg * JP_SUB;
         entry_bit = jp_raw_to_cmp(S, rawk) * 8u + (e.p & 7u);
     }
     JpReader R;
@@ -805,7 +809,7 @@ fid_status jp_parse(const uint8_t *d, size_t n, JpHeader *H, const char **why)
     } while (0)
     if (!d || n < 4 || d[0] != 0xFF || d[1] != 0xD8) JP_FAIL(FID_E_INVALID_ARG, "not a JPEG file (no SOI)");
     size_t p = 2;
-    bool have_sof = false;
+    bool have_sof = false, adobe_rgb = false;
     while (p + 4 <= n) {
         if (d[p] != 0xFF) JP_FAIL(FID_E_INVALID_ARG, "marker expected");
         while (p < n && d[p] == 0xFF) p++;
@@ -835,6 +839,11 @@ fid_status jp_parse(const uint8_t *d, size_t n, JpHeader *H, const char **why)
             have_sof = true;
         } else if (m >= 0xC2 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC) {
             JP_FAIL(FID_E_UNSUPPORTED, "not a baseline file (progressive, lossless or arithmetic coding)");
+        } else if (m == 0xEE) {
+            // APP14 "Adobe": transform 0 with three components means the planes ARE R, G, B (jdapimin.c default_decompress_parms);
+            // libjpeg / cv::imdecode then skip the YCbCr conversion that k_jpeg_color always applies -- refuse rather than
+            // hand out another image
+            if (sl >= 12 && !memcmp(s, "Adobe", 5) && s[11] == 0) adobe_rgb = true;
         } else if (m == 0xDB) {
             size_t o = 0;
             while (o < sl) {
@@ -888,6 +897,8 @@ fid_status jp_parse(const uint8_t *d, size_t n, JpHeader *H, const char **why)
         p += len;
     }
     if (!H->scan_off) JP_FAIL(FID_E_INVALID_ARG, "no scan");
+    if (H->ncomp == 3 && (adobe_rgb || (H->cid[0] == 'R' && H->cid[1] == 'G' && H->cid[2] == 'B')))
+        JP_FAIL(FID_E_UNSUPPORTED, "three-component file that is not YCbCr (Adobe transform 0 / component ids R, G, B)");
     if (H->ncomp == 1) {
         H->hs[0] = H->vs[0] = 1;  // a one-component scan is not interleaved: 8 x 8 MCUs whatever the factors say
     } else {
@@ -949,6 +960,7 @@ struct fid_jpeg_ctx {
     unsigned *h_flag = nullptr;
     uint16_t *h_lut = nullptr;
     std::unordered_map<unsigned long long, int> lut_slot;
+    std::vector<JpHuffSpec> lut_spec;  // the table behind every slot: a hash hit is only a hit if the table is the same
     int lut_next = 0, lut_cap = 0;  // cached 16-bit code tables: room for four new ones per frame of a call and 16 more
     // the last decode
     int last_n = 0, last_w = 0, last_h = 0, last_enc = 0, last_rounds = 0;
@@ -970,7 +982,14 @@ int jp_lut_slot(fid_jpeg_ctx *c, const JpHuffSpec &t, fid_status *rc)
 {
     const unsigned long long h = jp_hash(t);
     auto it = c->lut_slot.find(h);
-    if (it != c->lut_slot.end()) return it->second;
+    if (it != c->lut_slot.end()) {
+        const JpHuffSpec &o = c->lut_spec[(size_t)it->second];
+        if (o.nvals == t.nvals && !memcmp(o.bits, t.bits, sizeof o.bits) && !memcmp(o.vals, t.vals, (size_t)t.nvals)) return it->second;
+        // (a 64-bit hash collision -- constructible on a network topic: not the same table, so not the same slot)
+        *rc = FID_E_UNSUPPORTED;
+        c->last_error = "two different Huffman tables with the same hash in one call";
+        return 0;
+    }
     if (c->lut_next >= c->lut_cap) {
         *rc = FID_E_UNSUPPORTED;
         c->last_error = "more distinct Huffman tables in one call than the table cache holds";
@@ -995,6 +1014,8 @@ int jp_lut_slot(fid_jpeg_ctx *c, const JpHuffSpec &t, fid_status *rc)
         return 0;
     }
     c->lut_slot[h] = slot;
+    if (c->lut_spec.size() <= (size_t)slot) c->lut_spec.resize((size_t)slot + 1);
+    c->lut_spec[(size_t)slot] = t;
     return slot;
 }
 }  // namespace

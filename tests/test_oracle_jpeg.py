@@ -119,3 +119,23 @@ def test_product_header_parse_agrees_with_the_oracle(gold):
     assert e.value.status == 6  # FID_E_UNSUPPORTED
     with pytest.raises(FidError):
         fj.probe(b"\xff\xd8\xff\xe0 short")
+    # three components that are NOT YCbCr (libjpeg / cv::imdecode skip the colour conversion for them, the device always converts):
+    # refused, never another image.  (a) component ids 'R', 'G', 'B' in SOF0 and SOS; (b) an APP14 "Adobe" segment with transform 0
+    color = next(gold[f"jpg_{k}"].tobytes() for k, w, h, sub, gray, q, rst in gold["cases"].tolist() if not gray)
+    sof = color.index(b"\xff\xc0")
+    sos = color.index(b"\xff\xda")
+    ids = [color[sof + 10 + 3 * c] for c in range(3)]
+    rgb = bytearray(color)
+    for c, ch in enumerate(b"RGB"):
+        assert rgb[sof + 10 + 3 * c] == ids[c] and rgb[sos + 5 + 2 * c] == ids[c]
+        rgb[sof + 10 + 3 * c] = ch
+        rgb[sos + 5 + 2 * c] = ch
+    with pytest.raises(FidError) as e:
+        fj.probe(bytes(rgb))
+    assert e.value.status == 6
+    adobe = color[:2] + b"\xff\xee\x00\x0eAdobe\x00\x64\x00\x00\x00\x00\x00" + color[2:]
+    with pytest.raises(FidError) as e:
+        fj.probe(adobe)
+    assert e.value.status == 6
+    ycck = color[:2] + b"\xff\xee\x00\x0eAdobe\x00\x64\x00\x00\x00\x00\x01" + color[2:]  # transform 1 = YCbCr: fine
+    assert fj.probe(ycck)["components"] == 3

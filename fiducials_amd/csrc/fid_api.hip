@@ -71,6 +71,7 @@ struct fid_ctx {
                          // 1 (FID_TRACE=chain): round-2 seed tracing (every border found by a probe survivor); 0 (FID_TRACE=legacy):
                          // probe passes + whole-border walk only
     int sw_blocks = 0;   // FID_SW_BLOCKS: seed-walker workgroups per frame (0 = automatic)
+    int probe_lut = 1;   // table-driven probe passes (FID_PROBE_LUT=0: the arithmetic ones)
     long long fallbacks = 0;  // calls that fell back to the whole-border walk because the seed table was too small
     int max_chunks = 0;
     int walk_blocks = 0;  // one-wave workgroups per frame in the full walk pass (0 = automatic)
@@ -478,8 +479,13 @@ fid_status run_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H, int
             if (c->profile) (void)hipEventRecord(ev[16], sa);
             hipLaunchKernelGGL(k_seed_index, dim3(8 * gm, Fs), dim3(256), 0, sa, seedq, seedhash, counts, P);
             HIPCHK(c, hipEventRecord(c->aux_idx[sb], sa));
-            hipLaunchKernelGGL((k_probe<PROBE0_STEPS, 0, true>), dim3(64 * gm, Fs), dim3(256), 0, sa, masks, starts, surv1, counts, c->d_global, P);
-            hipLaunchKernelGGL((k_probe<PROBE1_STEPS, 1, true>), dim3(16 * gm, Fs), dim3(256), 0, sa, masks, surv1, surv, counts, c->d_global, P);
+            if (c->probe_lut) {
+                hipLaunchKernelGGL((k_probe_lut<PROBE0_STEPS, 0>), dim3(64 * gm, Fs), dim3(256), 0, sa, masks, starts, surv1, counts, c->d_global, P);
+                hipLaunchKernelGGL((k_probe_lut<PROBE1_STEPS, 1>), dim3(16 * gm, Fs), dim3(256), 0, sa, masks, surv1, surv, counts, c->d_global, P);
+            } else {
+                hipLaunchKernelGGL((k_probe<PROBE0_STEPS, 0, true>), dim3(64 * gm, Fs), dim3(256), 0, sa, masks, starts, surv1, counts, c->d_global, P);
+                hipLaunchKernelGGL((k_probe<PROBE1_STEPS, 1, true>), dim3(16 * gm, Fs), dim3(256), 0, sa, masks, surv1, surv, counts, c->d_global, P);
+            }
             const int wb3 = c->walk2_div > 0 ? (wb / c->walk2_div > 0 ? wb / c->walk2_div : 1) : wb2;
             hipLaunchKernelGGL(k_walk_full<2>, dim3(wb3, Fs), dim3(64 * WALK_WAVES), 0, sa, masks, surv, wres, tab, pool, segs, pend, counts,
                                c->d_global, P);
@@ -855,6 +861,7 @@ fid_status fid_create(const fid_params *params, const fid_dict *dict, const fid_
     if (const char *tm = getenv("FID_TRACE")) c->trace_mode = !strcmp(tm, "legacy") ? 0 : !strcmp(tm, "chain") ? 1 : 2;
     if (getenv("FID_SW_BLOCKS")) c->sw_blocks = atoi(getenv("FID_SW_BLOCKS"));
     if (getenv("FID_STAGGER")) c->stagger = atoi(getenv("FID_STAGGER"));
+    if (getenv("FID_PROBE_LUT")) c->probe_lut = atoi(getenv("FID_PROBE_LUT"));
     if (getenv("FID_RESOLVE_LDS")) c->resolve_lds_kb = atoi(getenv("FID_RESOLVE_LDS"));
     if (getenv("FID_WALK2_DIV")) c->walk2_div = atoi(getenv("FID_WALK2_DIV"));
     static_assert(sizeof(DevSegC) == sizeof(DevSeg), "the two segment records share one buffer");

@@ -2023,6 +2023,162 @@ __global__ __launch_bounds__(256) void k_seg_copy(const uint4 *__restrict__ recs
     }
 }
 
+// K3 probe passes, table-driven (trace mode 2).  Same decisions as k_probe<…, STOPSEED = true> -- a start survives only while it
+// can still be the canonical start of a border that has NO seed state and can pass the perimeter gate -- but a step is what a
+// walker's step is: the raw 3 x 3 neighbourhood byte (three mask rows, one alignbit each) and ONE table look-up per cursor
+// (forward: next direction, the smallest examined background 4-neighbour, seed-state flag; backward: previous direction, ditto)
+// instead of nb8()'s bit shuffles, a find-first-set on the rotated neighbourhood and a loop over the examined directions.
+// (SQ counters, round 3: the two arithmetic probe passes were 3.1 M of the pipeline's 17.9 M VALU wave-instructions per frame.)
+__device__ __forceinline__ unsigned raw8(const MaskView &m, int x, int y)
+{
+    const int xb = x - 1 + MASK_PADW * 32;
+    const int wi = xb >> 5, sh = xb & 31;
+    const uint32_t *p0 = m.base + mask_word(m.TC, y, wi);
+    const uint32_t *p1 = m.base + mask_word(m.TC, y + 1, wi);
+    const uint32_t *p2 = m.base + mask_word(m.TC, y + 2, wi);
+    const uint32_t a0 = p0[0], a1 = p1[0], a2 = p2[0];
+    uint32_t b0 = 0, b1 = 0, b2 = 0;
+    if (sh > 29) {
+        b0 = p0[MT_ROWS];
+        b1 = p1[MT_ROWS];
+        b2 = p2[MT_ROWS];
+    }
+    const unsigned tu = __builtin_amdgcn_alignbit(b0, a0, sh), tm = __builtin_amdgcn_alignbit(b1, a1, sh), td = __builtin_amdgcn_alignbit(b2, a2, sh);
+    return (tu & 7u) | ((tm & 1u) << 3) | ((tm & 4u) << 2) | ((td & 7u) << 5);
+}
+
+// backward step table: index raw | bf << 8 (bf = direction from the cursor's pixel to its successor) -> direction to the
+// predecessor (first foreground clockwise from bf - 1) | code << 3 (the smallest-offset background 4-neighbour that search
+// passed over: 0 none, else 4 | positive << 1 | whole-row, as in the forward table) | seed-state flag of the state (pixel, that
+// direction) << 6 (to be combined with the grid-line test)
+__device__ __forceinline__ void build_back_lut(uint8_t *lut, int tid, int nthreads)
+{
+    for (int e = tid; e < 2048; e += nthreads) {
+        const unsigned raw = (unsigned)e & 0xffu;
+        const unsigned nb = raw_to_nb(raw);
+        const int bf = e >> 8;
+        const int c0 = (bf - 1) & 7;
+        const unsigned win = (((nb | (nb << 8)) >> (c0 + 1)) & 0xffu);
+        const int tz = win ? 7 - (31 - __clz((int)win)) : 0;
+        unsigned seen = 0;
+        for (int q = 0; q < tz; q++) seen |= 1u << ((c0 - q) & 7);
+        const int code = (seen & 4u) ? 5 : (seen & 16u) ? 4 : (seen & 1u) ? 6 : (seen & 64u) ? 7 : 0;
+        const int bd = (c0 - tz) & 7;
+        const int seed = nb && !((nb >> seed_empty_dir(bd)) & 1u);
+        lut[e] = (uint8_t)(bd | (code << 3) | (seed << 6));
+    }
+}
+
+template <int STEPS, int LEVEL>
+__global__ __launch_bounds__(256) void k_probe_lut(const uint32_t *__restrict__ masks, const uint2 *__restrict__ in_list,
+                                                    uint2 *__restrict__ out_list, DevCounts *__restrict__ counts,
+                                                    DevGlobal *__restrict__ G, const DevParams P)
+{
+    __shared__ uint8_t s_fwd[2048], s_bwd[2048];
+    build_step_lut(s_fwd, threadIdx.x, 256);
+    build_back_lut(s_bwd, threadIdx.x, 256);
+    __syncthreads();
+    const int f = blockIdx.y;
+    const int lane = lane_id();
+    unsigned n = (unsigned)(LEVEL != 1 ? counts[f].nstarts : counts[f].nsurv1);
+    n = n < (unsigned)P.maxStarts ? n : (unsigned)P.maxStarts;
+    int *out_count = LEVEL == 0 ? &counts[f].nsurv1 : &counts[f].nsurv;
+    const int W = P.W, S = P.nscales, W2 = P.W + 2;
+    const int sgm = (8 << P.seedShift) - 1;
+    const long long plane = (long long)P.TR * P.TC * MT_ROWS;
+    const uint2 *fin = in_list + (long long)f * P.maxStarts;
+    uint2 *fout = out_list + (long long)f * P.maxStarts;
+    for (unsigned i0 = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); i0 < n; i0 += gridDim.x * blockDim.x) {
+        const unsigned i = i0 + lane;
+        const bool active = i < n;
+        const uint2 st = active ? fin[i] : make_uint2(0u, 0u);
+        const int x0 = st.x & 0xffff, y0 = st.x >> 16;
+        const int s = (st.y >> 16) & 0xff, hole = (st.y >> 24) & 1;
+        MaskView m;
+        m.base = masks + ((long long)f * S + s) * plane;
+        m.TC = P.TC;
+        const int key = hole ? pidx(x0 + 1, y0, W) : pidx(x0, y0, W);
+        int count = 0, ok = active, closed = 0;
+        unsigned raw = ok ? raw8(m, x0, y0) : 0u;
+        if (ok && raw == 0) {
+            count = 1;  // single pixel domain
+            closed = 1;
+        } else if (ok) {
+            const unsigned nb0 = raw_to_nb(raw);
+            int sdir = first_dir(nb0, hole ? 0 : 4);
+            const int i1x = x0 + dir_dx(sdir), i1y = y0 + dir_dy(sdir);
+            int bx = i1x, by = i1y, bf = (sdir + 4) & 7, pb = pidx(bx, by, W);
+            if (!hole && pb < key) ok = 0;
+            if (seed_state(x0, y0, sdir, sgm) && !((nb0 >> seed_empty_dir(sdir)) & 1u)) ok = 0;  // the start state itself is a seed state
+            int cx = x0, cy = y0, pc = pidx(x0, y0, W);
+            while (ok) {
+                // ---- forward step
+                const unsigned e = s_fwd[raw | ((unsigned)sdir << 8)];
+                const int sn = e & 7, code = (e >> 3) & 7;
+                if (hole && code) {
+                    const int hmag = (code & 1) ? W2 : 1;
+                    if (pc + ((code & 2) ? hmag : -hmag) < key) ok = 0;  // an examined background 4-neighbour in front of the key
+                }
+                count++;
+                const int dx = dir_dx(sn), dy = dir_dy(sn);
+                const int nx = cx + dx, ny = cy + dy;
+                if (!ok || count > P.maxPerim) {
+                    ok = 0;
+                    break;
+                }
+                if (nx == x0 && ny == y0 && cx == i1x && cy == i1y) {
+                    closed = 1;
+                    break;
+                }
+                if (count >= STEPS) break;
+                cx = nx;
+                cy = ny;
+                pc += __mul24(dy, W2) + dx;
+                if (!hole && pc < key) {
+                    ok = 0;
+                    break;
+                }
+                sdir = sn ^ 4;
+                raw = raw8(m, cx, cy);
+                if ((s_fwd[raw | ((unsigned)sdir << 8)] & 0x40u) && seed_state(cx, cy, sdir, sgm)) {  // a seed state: the border is a seed cycle
+                    ok = 0;
+                    break;
+                }
+                // ---- backward step
+                {
+                    const unsigned braw = raw8(m, bx, by);
+                    const unsigned be = s_bwd[braw | ((unsigned)bf << 8)];
+                    const int bd = be & 7, bcode = (be >> 3) & 7;
+                    if (hole && bcode) {
+                        const int hmag = (bcode & 1) ? W2 : 1;
+                        if (pb + ((bcode & 2) ? hmag : -hmag) < key) ok = 0;
+                    }
+                    if ((be & 0x40u) && seed_state(bx, by, bd, sgm)) ok = 0;  // the state (pixel, back direction) the cursor stood in
+                    const int bdx = dir_dx(bd), bdy = dir_dy(bd);
+                    bx += bdx;
+                    by += bdy;
+                    pb += __mul24(bdy, W2) + bdx;
+                    bf = bd ^ 4;
+                    if (!hole && pb < key) ok = 0;
+                }
+            }
+        }
+        const int keep = ok && (!closed || (count >= P.minPerim && count <= P.maxPerim));
+        const unsigned long long mk = ballot64(keep);
+        if (mk) {
+            const int leader = __ffsll((long long)mk) - 1;
+            unsigned base = 0;
+            if (lane == leader) base = atomicAdd((unsigned *)out_count, (unsigned)__popcll(mk));
+            base = __shfl(base, leader, WAVE);
+            const unsigned idx = base + (unsigned)__popcll(mk & ((1ull << lane) - 1ull));
+            if (keep) {
+                if (idx < (unsigned)P.maxStarts) fout[idx] = st;
+                else atomicOr(&G->overflow, 1u);
+            }
+        }
+    }
+}
+
 // ================================================================================================
 // Trace mode 2: CYCLE TRACING.  Every border that has a seed state is a cycle of segments; its length, its kind (outer /
 // hole), its canonical start and therefore the exact point order of cvFindContours all follow from the segment records

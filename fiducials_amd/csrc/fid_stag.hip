@@ -657,9 +657,10 @@ void fid_stag_destroy(fid_stag_ctx *c)
 // ---- the pipeline of one frame on one context, cut into SEGMENTS at the points where the host needs a count the device has
 // produced (to size the next launches).  A segment first waits for the context's stream (the counts of the previous segment
 // are then in host memory), does the host-side bookkeeping and launches the next piece without waiting for it.  Run back to
-// back on one context this is the frame-at-a-time path (every staged entry point = the segments up to its stage); dealt out
-// over several contexts by ONE host thread, segment by segment, it keeps as many frames in flight as there are contexts
-// without host threads (fid_stag_detect_markers_batch): the waits overlap, the HIP runtime sees one caller.
+// back on one context this is the frame-at-a-time path (every staged entry point = the segments up to its stage).  Several
+// frames: fid_stag_detect_markers_batch carries GROUPS of frames through the same segments in lockstep, their launches recorded
+// and issued once per group (fid_stag_batch.h; a host thread per group); FID_STAG_BATCH=contexts keeps round 2's road, the
+// contexts dealt out to FID_STAG_THREADS host threads (default 4), each context on its own stream.
 enum StagStage { SS_FRONTEND = 0, SS_EDGES, SS_EDGES_VALIDATED, SS_LINES, SS_LINES_VALIDATED, SS_QUADS, SS_UNREFINED, SS_MARKERS, SS_POSE };
 enum { RS_NONE = 0, RS_PAR_A, RS_PAR_B, RS_SEQ, RS_EMPTY };
 

@@ -984,8 +984,13 @@ __global__ __launch_bounds__(256) void k_find_starts(const uint32_t *__restrict_
             stot += sv2;
         }
         if (threadIdx.x == 0) {
+#ifdef FS_NOATOMIC  // timing experiment only (wrong lists): what the returning atomics cost this kernel
+            if (tot) s_base[0] = (unsigned)(blockIdx.x * 977u + (unsigned)i0) % (cap - 64u);
+            if (HYB && stot) s_base[1] = (unsigned)(blockIdx.x * 331u + (unsigned)i0) % (scap - 64u);
+#else
             if (tot) s_base[0] = atomicAdd((unsigned *)&counts[f].nstarts, (unsigned)tot);
             if (HYB && stot) s_base[1] = atomicAdd((unsigned *)&counts[f].nseeds, (unsigned)stot);
+#endif
         }
         __syncthreads();
         if (tot) {

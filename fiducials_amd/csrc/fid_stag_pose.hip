@@ -299,7 +299,7 @@ struct SrSimplex {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); \
     } while (0)
 
-__device__ void sr_downhill(double x[9], const double step[9], const double Cm[9], int lane, SrSimplex *S)
+__device__ void sr_downhill(double x[9], const double step[9], const double Cm[9], int lane, SrSimplex *S, int *evals = nullptr)
 {
     const int nd = 9;
     if (lane <= nd) {
@@ -367,6 +367,7 @@ __device__ void sr_downhill(double x[9], const double step[9], const double Cm[9
         }
         if (range <= 0.000001 || error <= 0.000001 || fcount >= 5000) {
             for (int j = 0; j < nd; j++) x[j] = S->p[ilo][j];
+            if (evals) *evals = fcount;
             return;
         }
         const double y_lo = y[ilo], y_nhi = y[inhi], y_hi = y[ihi];
@@ -427,6 +428,10 @@ __device__ __forceinline__ void k_stag_refine_impl(fid_stag_marker *__restrict__
                                 -1.000000, -0.984808, -0.939693, -0.866025, -0.766044, -0.642788, -0.500000, -0.342020, -0.173648};
     double Hinv[9];
     sr_inv3(M.H, Hinv);
+#ifdef SR_TIMING
+    const unsigned long long t_0 = __builtin_readcyclecounter();
+    int d_cands = 0;
+#endif
     // ---- (1) the edge segment of the circular border
     int chosen = -1;
     double minAcc = INFINITY;
@@ -454,10 +459,34 @@ __device__ __forceinline__ void k_stag_refine_impl(fid_stag_marker *__restrict__
       while (cand) {
         const int sg = sg0 + __builtin_ctzll(cand);
         cand &= cand - 1;
+#ifdef SR_TIMING
+        d_cands++;
+#endif
         const int first = vsegs[sg].x, n = vsegs[sg].y;
         const int2 *p = pix + first;
         // back-projection; per sample point the minimum over the pixels, per pixel the minimum over the sample points
         bool bad = false;
+        // (round 3) first only the per-pixel test that rejects: 22 of the 23 closed loops inside a marker are code dots whose
+        // pixels lie nowhere near the circle -- they end here, after the first 64 pixels, without the 36 wave-wide minima per
+        // chunk that only the accepted segment's error sum needs (same distances, same comparisons, same decision)
+        for (int k0 = 0; k0 < n && !bad; k0 += 64) {
+            const int k = k0 + lane;
+            const bool act = k < n;
+            double pixErr = INFINITY;
+            if (act) {
+                const double ex = p[k].y, ey = p[k].x;
+                const double a0 = Hinv[0] * ex + Hinv[1] * ey + Hinv[2] * 1, a1 = Hinv[3] * ex + Hinv[4] * ey + Hinv[5] * 1;
+                const double a2 = Hinv[6] * ex + Hinv[7] * ey + Hinv[8] * 1;
+                const double qx = a0 / a2, qy = a1 / a2;
+                for (int s = 0; s < 36; s++) {
+                    const double sx = 0.5 + 0.4 * sinVals[(s + 9) % 36], sy = 0.5 + 0.4 * sinVals[s];
+                    const double d = sqrt((qx - sx) * (qx - sx) + (qy - sy) * (qy - sy));
+                    if (d < pixErr) pixErr = d;
+                }
+            }
+            if (__ballot(act && pixErr > 0.1)) bad = true;
+        }
+        if (bad) continue;
         double sampleErr[36];
         for (int s = 0; s < 36; s++) sampleErr[s] = INFINITY;
         for (int k0 = 0; k0 < n; k0 += 64) {
@@ -492,6 +521,9 @@ __device__ __forceinline__ void k_stag_refine_impl(fid_stag_marker *__restrict__
     }
     if (lane == 0) chosen_out[m] = chosen;
     if (chosen < 0) return;
+#ifdef SR_TIMING
+    const unsigned long long t_1 = __builtin_readcyclecounter();
+#endif
     // ---- (2) ellipse through the chosen segment: scatter matrix, one lane per entry (p <= q), summed in pixel order
     __shared__ double s_S[7][7];
     {
@@ -499,22 +531,40 @@ __device__ __forceinline__ void k_stag_refine_impl(fid_stag_marker *__restrict__
         const int2 *p = pix + first;
         if (lane < 49) s_S[lane / 7][lane % 7] = 0.0;
         __builtin_amdgcn_wave_barrier();
-        int pi = 0, qi = 0, idx = lane;
-        bool mine = false;
-        for (int a = 1; a <= 6 && !mine; a++)
-            for (int b = a; b <= 6; b++) {
-                if (idx == 0) { pi = a; qi = b; mine = true; break; }
-                idx--;
-            }
-        if (mine) {
-            double acc = 0.0;
-            for (int l = 0; l < n; l++) {
-                const double tx = (double)p[l].y, ty = (double)(-p[l].x);
-                const double Dl[7] = {0, tx * tx, tx * ty, ty * ty, tx, ty, 1.0};
-                acc = acc + Dl[pi] * Dl[qi];
-            }
-            s_S[pi][qi] = acc;
-            s_S[qi][pi] = acc;
+        // (round 3) the pixels across the lanes, every lane the 21 running sums of its pixels, then 21 wave sums: the terms are
+        // integers (pixel coordinates), so up to ~600 pixels every partial sum is exact in a double whatever the order; beyond
+        // that the order changes the last bit of a sum that the ellipse fit and the simplex search, a tolerance row anyway
+        // (1e-3 px against the reference), do not resolve.  (One lane per matrix entry walked all n pixels: 0.15 ms per marker.)
+        double acc[21];
+#pragma unroll
+        for (int e = 0; e < 21; e++) acc[e] = 0.0;
+        for (int l = lane; l < n; l += 64) {
+            const double tx = (double)p[l].y, ty = (double)(-p[l].x);
+            const double Dl[6] = {tx * tx, tx * ty, ty * ty, tx, ty, 1.0};
+            int e = 0;
+#pragma unroll
+            for (int a = 0; a < 6; a++)
+#pragma unroll
+                for (int b = a; b < 6; b++) acc[e++] += Dl[a] * Dl[b];
+        }
+        {
+            int e = 0;
+#pragma unroll
+            for (int a = 1; a <= 6; a++)
+#pragma unroll
+                for (int b = a; b <= 6; b++) {
+                    double v = acc[e++];
+                    v += shfl_xor_f64(v, 1);
+                    v += shfl_xor_f64(v, 2);
+                    v += shfl_xor_f64(v, 4);
+                    v += shfl_xor_f64(v, 8);
+                    v += shfl_xor_f64(v, 16);
+                    v += shfl_xor_f64(v, 32);
+                    if (lane == 0) {
+                        s_S[a][b] = v;
+                        s_S[b][a] = v;
+                    }
+                }
         }
         __builtin_amdgcn_wave_barrier();
         if (n < 6) return;
@@ -534,7 +584,16 @@ __device__ __forceinline__ void k_stag_refine_impl(fid_stag_marker *__restrict__
     for (int i = 0; i < 3; i++)
         for (int j = 0; j < 3; j++) x[i + j * 3] = M.H[3 * i + j];
     for (int k = 0; k < 9; k++) step[k] = fabs(0.001 * x[k]);
+#ifdef SR_TIMING
+    const unsigned long long t_2 = __builtin_readcyclecounter();
+    int d_evals = 0;
+    sr_downhill(x, step, Cm, lane, &s_simplex, &d_evals);
+    if (lane == 0)
+        printf("refine marker %d: segments %d, candidates examined %d, chosen length %d; ticks: search %llu, scatter + fit %llu, simplex %llu (%d evaluations)\n", m, ns,
+               d_cands, vsegs[chosen].y, t_1 - t_0, t_2 - t_1, (unsigned long long)__builtin_readcyclecounter() - t_2, d_evals);
+#else
     sr_downhill(x, step, Cm, lane, &s_simplex);
+#endif
     for (int i = 0; i < 3; i++)
         for (int j = 0; j < 3; j++) M.H[3 * i + j] = x[i + j * 3];
     // ---- (4) points from the refined H

@@ -72,6 +72,9 @@ struct fid_ctx {
                          // probe passes + whole-border walk only
     int sw_blocks = 0;   // FID_SW_BLOCKS: seed-walker workgroups per frame (0 = automatic)
     int probe_lut = 1;   // table-driven probe passes (FID_PROBE_LUT=0: the arithmetic ones)
+    int tail_grid = 4096;  // FID_TAIL_GRID: workgroups of k_identify (x 4: k_subpix) -- 1024 left 5 k candidates five rounds of an 80 us chain: +5 %
+    int filter_lds = 256;  // markers k_filter_markers keeps in LDS (FID_FILTER_LDS; more go through the global scratch)
+    int light_x = 1;     // FID_LIGHT_X: grid multiplier of k_near / k_seg_cycles, 1024 threads for k_sort_cands
     long long fallbacks = 0;  // calls that fell back to the whole-border walk because the seed table was too small
     int max_chunks = 0;
     int walk_blocks = 0;  // one-wave workgroups per frame in the full walk pass (0 = automatic)
@@ -86,7 +89,7 @@ struct fid_ctx {
     float4 *d_cmeta = nullptr;
     uint32_t *d_near = nullptr;
     DevIdent *d_ident = nullptr;
-    fid_marker *d_pre = nullptr, *d_markers = nullptr;
+    fid_marker *d_pre = nullptr, *d_markers = nullptr, *d_filter_scratch = nullptr;
     fid_pose_out *d_poses = nullptr;
     DevCounts *d_counts = nullptr;
     DevGlobal *d_global = nullptr;
@@ -506,7 +509,7 @@ fid_status run_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H, int
             mark(ST_PROBE + 1);
             HIPCHK(c, hipStreamWaitEvent(st, c->aux_idx[sb], 0));
             hipLaunchKernelGGL(k_seg_link2, dim3(16 * gm, Fs), dim3(256), 0, st, seedq, (DevSegC *)segs, seedhash, counts, P);
-            hipLaunchKernelGGL(k_seg_cycles, dim3(32 * gm, Fs), dim3(64), 0, st, seedq, (const DevSegC *)segs, pend, wres, contours, cinfo, cbase,
+            hipLaunchKernelGGL(k_seg_cycles, dim3(32 * gm * c->light_x, Fs), dim3(64), 0, st, seedq, (const DevSegC *)segs, pend, wres, contours, cinfo, cbase,
                                recs, counts, c->d_global, P, 0);
             hipLaunchKernelGGL(k_seg_copy, dim3(cpb, Fs), dim3(256), 0, st, recs, tab, pool, dense, counts, P, 0);
             mark(ST_WALK + 1);
@@ -550,9 +553,9 @@ fid_status run_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H, int
         if (nsub > 1 && c->stagger > 0) HIPCHK(c, hipEventRecord(c->walk_done[sb], st));
         // ---- K5
         float4 *cmeta = c->d_cmeta + f0 * MC;
-        hipLaunchKernelGGL(k_sort_cands, dim3(Fs), dim3(256), MC * 8, st, cands, sorted, cmeta, counts, P);
+        hipLaunchKernelGGL(k_sort_cands, dim3(Fs), dim3(c->light_x > 1 ? 1024 : 256), MC * 8, st, cands, sorted, cmeta, counts, P);
         mark(ST_SORT + 1);
-        hipLaunchKernelGGL(k_near, dim3(32 * gm, Fs), dim3(256), 0, st, sorted, cmeta, nearb, counts, P);
+        hipLaunchKernelGGL(k_near, dim3(32 * gm * c->light_x, Fs), dim3(256), 0, st, sorted, cmeta, nearb, counts, P);
         mark(ST_NEAR + 1);
         {
             // sizes, labels, component sizes; the rest holds the near triangle (64 KB: fits beside two seed-walker workgroups of
@@ -565,16 +568,18 @@ fid_status run_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H, int
         // ---- K6
         {
             int SZ = (P.markerSize + 2 * P.borderBits) * P.cellSize;
-            hipLaunchKernelGGL(k_identify, dim3(256 * 4), dim3(64), (size_t)SZ * SZ, st, g, gfstride, filtered, worklist, nwork,
+            hipLaunchKernelGGL(k_identify, dim3(c->tail_grid > 0 ? c->tail_grid : 256 * 4), dim3(64), (size_t)SZ * SZ, st, g, gfstride, filtered, worklist, nwork,
                                c->d_dict, ident, P);
         }
         mark(ST_IDENT + 1);
         // ---- K7
-        hipLaunchKernelGGL(k_filter_markers, dim3(Fs), dim3(64), MC * sizeof(fid_marker), st, filtered, ident, pre, counts, P);
+        hipLaunchKernelGGL(k_filter_markers, dim3(Fs), dim3(64), (size_t)c->filter_lds * sizeof(fid_marker), st, filtered, ident, pre, counts, P,
+                           c->d_filter_scratch + f0 * MC, c->filter_lds);
         mark(ST_FILTER + 1);
         {
             long long items = (long long)Fs * P.maxMarkers * 4;
-            int blocks = (int)(items < 256 * 16 ? items : 256 * 16);
+            const long long bcap = c->tail_grid > 0 ? 4LL * c->tail_grid : 256 * 16;
+            int blocks = (int)(items < bcap ? items : bcap);
             hipLaunchKernelGGL(k_subpix, dim3(blocks), dim3(64), 0, st, g, gfstride, pre, markers, counts, c->d_subpix_mask, P);
         }
         mark(ST_SUBPIX + 1);
@@ -862,6 +867,9 @@ fid_status fid_create(const fid_params *params, const fid_dict *dict, const fid_
     if (getenv("FID_SW_BLOCKS")) c->sw_blocks = atoi(getenv("FID_SW_BLOCKS"));
     if (getenv("FID_STAGGER")) c->stagger = atoi(getenv("FID_STAGGER"));
     if (getenv("FID_PROBE_LUT")) c->probe_lut = atoi(getenv("FID_PROBE_LUT"));
+    if (getenv("FID_TAIL_GRID")) c->tail_grid = atoi(getenv("FID_TAIL_GRID"));
+    if (getenv("FID_FILTER_LDS")) c->filter_lds = atoi(getenv("FID_FILTER_LDS")) > 0 ? atoi(getenv("FID_FILTER_LDS")) : 1;
+    if (getenv("FID_LIGHT_X")) c->light_x = atoi(getenv("FID_LIGHT_X")) > 0 ? atoi(getenv("FID_LIGHT_X")) : 1;
     if (getenv("FID_RESOLVE_LDS")) c->resolve_lds_kb = atoi(getenv("FID_RESOLVE_LDS"));
     if (getenv("FID_WALK2_DIV")) c->walk2_div = atoi(getenv("FID_WALK2_DIV"));
     static_assert(sizeof(DevSegC) == sizeof(DevSeg), "the two segment records share one buffer");
@@ -893,6 +901,7 @@ fid_status fid_create(const fid_params *params, const fid_dict *dict, const fid_
     TRY(dalloc(c, &c->d_near, F * MC * (MC / 32)));
     TRY(dalloc(c, &c->d_ident, F * MC));
     TRY(dalloc(c, &c->d_pre, F * MM));
+    TRY(dalloc(c, &c->d_filter_scratch, F * MC));
     TRY(dalloc(c, &c->d_markers, F * MM));
     TRY(dalloc(c, &c->d_poses, F * MM));
     TRY(dalloc(c, &c->d_counts, F));
@@ -923,7 +932,7 @@ void fid_destroy(fid_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    void *dev[] = {c->d_in, c->d_gray, c->d_masks, c->d_starts, c->d_surv1, c->d_surv, c->d_pool, c->d_segs, c->d_pend, c->d_seedq, c->d_seedhash, c->d_wres, c->d_cinfo, c->d_cbase, c->d_dense, c->d_recs, c->d_contours, c->d_ckpts, c->d_cands, c->d_sorted, c->d_cmeta, c->d_filtered, c->d_near,
+    void *dev[] = {c->d_in, c->d_gray, c->d_masks, c->d_starts, c->d_surv1, c->d_surv, c->d_pool, c->d_segs, c->d_pend, c->d_seedq, c->d_seedhash, c->d_wres, c->d_cinfo, c->d_cbase, c->d_filter_scratch, c->d_dense, c->d_recs, c->d_contours, c->d_ckpts, c->d_cands, c->d_sorted, c->d_cmeta, c->d_filtered, c->d_near,
                    c->d_ident, c->d_pre, c->d_markers, c->d_poses, c->d_counts, c->d_global, c->d_worklist, c->d_nwork, c->d_dict,
                    c->d_subpix_mask, c->d_lens, c->d_pose_in, c->d_pose_n};
     for (void *p : dev)

@@ -3052,7 +3052,7 @@ __global__ __launch_bounds__(64) void k_approx(uint4 *__restrict__ contours, con
 // K5a: restore OpenCV's candidate order (scale ascending; inside a scale cv::findContours returns the
 // RETR_LIST contours newest-first = discovery position descending) by rank sort, and apply
 // _reorderCandidatesCorners (aruco.cpp).  One workgroup per frame.
-__global__ __launch_bounds__(256) void k_sort_cands(const DevCand *__restrict__ cands, DevCand *__restrict__ sorted,
+__global__ __launch_bounds__(1024) void k_sort_cands(const DevCand *__restrict__ cands, DevCand *__restrict__ sorted,
                                                      float4 *__restrict__ cmeta, DevCounts *__restrict__ counts, const DevParams P)
 {
     extern __shared__ unsigned long long keys[];
@@ -3742,13 +3742,19 @@ __device__ __forceinline__ double point_polygon_test4(const float *cnt, float pt
 
 __global__ __launch_bounds__(64) void k_filter_markers(const DevCand *__restrict__ filtered, const DevIdent *__restrict__ ident,
                                                         fid_marker *__restrict__ pre, DevCounts *__restrict__ counts,
-                                                        const DevParams P)
+                                                        const DevParams P, fid_marker *__restrict__ gscratch, int lds_cap)
 {
-    extern __shared__ fid_marker acc[];  // maxCands
+    // the identified markers of the frame: in LDS when they fit lds_cap (a few dozen do; the kernel used to ask for maxCands
+    // entries = 73 KB per frame and waited for CUs with that much LDS free: 0.4 ms for 5 us of work), else in the frame's
+    // slice of a global scratch array
+    extern __shared__ fid_marker acc_lds[];
     const int f = blockIdx.x, lane = lane_id();
     int nf = counts[f].nfilt;
     const DevCand *cs = filtered + (long long)f * P.maxCands;
     const DevIdent *idn = ident + (long long)f * P.maxCands;
+    int nhit = 0;
+    for (int k0 = 0; k0 < nf; k0 += 64) nhit += __popcll(ballot64(k0 + lane < nf && idn[k0 + lane].id >= 0));
+    fid_marker *acc = nhit <= lds_cap ? acc_lds : gscratch + (long long)f * P.maxCands;
     int base = 0;
     for (int k0 = 0; k0 < nf; k0 += 64) {
         int k = k0 + lane;

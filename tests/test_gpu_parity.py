@@ -502,6 +502,26 @@ def test_filter_detected_markers_removes_nested_same_id(det6):
         assert cnt[4] == identified and cnt[5] == 1 and ids.tolist() == [mid]
 
 
+def test_filter_detected_markers_lds_and_global_scratch_roads(monkeypatch):
+    """k_filter_markers keeps a frame's identified markers in LDS when they fit (256 by default) and in a global scratch slice
+    when they do not: FID_FILTER_LDS=2 sends the nested-same-id case (3 identified) and a 20-marker frame down the scratch
+    road -- same PRESUBPIX tap, same ids and corners as the oracle on both roads."""
+    from helpers import nested_same_id_frame
+    d = get_predefined_dictionary(6)
+    nested = nested_same_id_frame(d, 3)
+    fr = make_frame(d, 1003)
+    for cap in ("2", "256"):
+        monkeypatch.setenv("FID_FILTER_LDS", cap)
+        det = ArucoDetector(d, max_width=1920, max_height=1080)
+        try:
+            _, ids, _ = check_stages(det, nested, d)
+            assert ids.tolist() == [3] and det.tap_counts()[0][4] == 3
+            _, ids, _ = check_stages(det, fr.image, d)
+            assert len(ids) == 20
+        finally:
+            det.close()
+
+
 def test_set_params_more_scales_than_at_creation():
     """dynamic_reconfigure raising adaptiveThreshWinSizeMax on a live context (aruco_detect.cpp:257-298, :690-693): 13 -> 16
     threshold scales fit the buffers' margin and must run like a fresh context (masks, seeds and all stages == oracle);

@@ -291,6 +291,37 @@ SubPlan plan_sub_batches(const fid_ctx *c, int F)
     }
     pl.nsub = nsub;
     for (int k = 0; k <= nsub; k++) pl.f0[k] = k * per < F ? k * per : F;
+    if (c->sub_frames <= 0 && F >= 32) {
+        // the sub-batches do not run in step: the first one's kernels meet less of the others' (its find_starts runs beside a
+        // threshold, the second one's beside a seed walk and the probes), so with equal pieces it is through ~2 ms earlier and
+        // the last one's latency-bound tail has the chip to itself.  Decreasing pieces even that out (FID_SUB_SHARES, per cent).
+        int sh[fid_ctx::MAX_SUB], n = 0, sum = 0;
+        const char *e = getenv("FID_SUB_SHARES");
+        const char *txt = e ? e : "64,36";
+        for (const char *q = txt; *q && n < fid_ctx::MAX_SUB;) {
+            const int v = atoi(q);
+            if (v > 0) {
+                sh[n++] = v;
+                sum += v;
+            }
+            while (*q && *q != ',') q++;
+            if (*q == ',') q++;
+        }
+        if (n >= 1 && sum > 0) {
+            pl.nsub = n;
+            int acc = 0;
+            for (int k = 0; k < n; k++) {
+                pl.f0[k] = (int)((long long)F * acc / sum);
+                acc += sh[k];
+            }
+            pl.f0[n] = F;
+            // (no empty piece)
+            for (int k = 1; k <= n; k++)
+                if (pl.f0[k] <= pl.f0[k - 1]) pl.f0[k] = pl.f0[k - 1] + 1 < F ? pl.f0[k - 1] + 1 : F;
+            while (pl.nsub > 1 && pl.f0[pl.nsub - 1] >= F) pl.nsub--;
+            pl.f0[pl.nsub] = F;
+        }
+    }
     return pl;
 }
 

@@ -2226,9 +2226,12 @@ __device__ __forceinline__ void build_step_lut2(uint8_t *lut, int tid, int nthre
 //   * start states of borders are recognised by the step table (two more bits), minima and their positions kept per segment
 //   * the cycle test compares one packed state key; the segment record leaves as two 16-byte stores
 #define SW_WAVES 2
+#ifndef SW_VGPR_ATTR
+#define SW_VGPR_ATTR
+#endif
 #define SW_CKPT 8
 #define SW_RUN 32
-__global__ __launch_bounds__(64 * SW_WAVES) void k_seed_walk(const uint32_t *__restrict__ masks, const uint2 *__restrict__ seedq,
+__global__ __launch_bounds__(64 * SW_WAVES) SW_VGPR_ATTR void k_seed_walk(const uint32_t *__restrict__ masks, const uint2 *__restrict__ seedq,
                                                               uint32_t *__restrict__ chunk_tab, uint32_t *__restrict__ pool,
                                                               DevSegC *__restrict__ segs, DevCounts *__restrict__ counts,
                                                               DevGlobal *__restrict__ G, const DevParams P)

@@ -36,7 +36,9 @@ struct fid_ctx {
     hipStream_t copy_stream = nullptr;     // fid_detect_batch: the frames go up sub-batch by sub-batch on this stream ...
     hipEvent_t in_ready[MAX_SUB] = {};     // ... and a sub-batch starts when its frames have landed (H2D of k + 1 under the compute of k)
     bool host_feed = false;                // this run_detect call is fed that way
-    hipEvent_t walk_done[MAX_SUB] = {};     // a sub-batch has left its contour stage (staggered starts, FID_STAGGER)
+    hipEvent_t walk_done[MAX_SUB] = {}, fs_done[MAX_SUB] = {};
+    int fs_barrier = 0;                    // FID_FS_BARRIER=1: the walks of every sub-batch wait for all find_starts (measured: find_starts
+                                           // 3.6 -> 2.2 ms, the seed walks 3.3 -> 4.9 ms now side by side: the step is the same)     // a sub-batch has left its contour stage (staggered starts, FID_STAGGER)
     int stagger = 0;                        // sub-batch k starts when sub-batch k - stagger has left its contour stage (0: all at once)
     int resolve_lds_kb = 64;
     int walk2_div = 2;
@@ -443,7 +445,6 @@ fid_status run_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H, int
             }
         }
         mark(ST_THRESH + 1);
-        return FID_OK;
       }
         // ---- K2
         long long k2blocks;
@@ -452,6 +453,21 @@ fid_status run_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H, int
             k2blocks = (groups + 7) / 8;
             if (k2blocks > 256) k2blocks = 256;
         }
+      if (phase == 0) {
+        // the traced modes' start / seed enumeration belongs to the first round as well: every sub-batch's find_starts is then
+        // queued before any walk, and (fs_barrier) the walks of all sub-batches wait for the last find_starts -- beside another
+        // sub-batch's seed walk and probes a find_starts took 2.5 ms for 92 frames, beside another find_starts 1.1 ms for 164
+        if (c->trace_mode >= 1) {
+            hipLaunchKernelGGL(k_find_starts<true>, dim3((unsigned)k2blocks, Fs), dim3(256), 0, st, masks, starts, counts, c->d_global,
+                               c->d_seedq + f0 * (size_t)P.maxContours, P);
+            mark(ST_STARTS + 1);
+            if (nsub > 1) HIPCHK(c, hipEventRecord(c->fs_done[sb], st));
+        }
+        return FID_OK;
+      }
+        if (c->trace_mode >= 1 && nsub > 1 && c->fs_barrier)
+            for (int o = 0; o < nsub; o++)
+                if (o != sb) HIPCHK(c, hipStreamWaitEvent(st, c->fs_done[o], 0));
         // persistent walker workgroups (WALK_WAVES waves each) per frame: about 16 waves per CU over the sub-batch
         int wb = c->walk_blocks > 0 ? c->walk_blocks : (3072 / WALK_WAVES + Fs - 1) / Fs;  // (measured: 6 per frame at 128 frames beats 8 and 12)
         // (the walks of one frame want every seed in flight at once: one frame, 32 px grid: seed walk 0.25 -> 0.115 ms)
@@ -491,9 +507,7 @@ fid_status run_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H, int
             uint4 *wres = c->d_wres + f0 * MCn, *cinfo = c->d_cinfo + f0 * MCn;
             uint32_t *cbase = c->d_cbase + f0 * MCn;
             uint32_t *dense = c->d_dense + (size_t)f0 * P.maxChunks * CK;
-            hipLaunchKernelGGL(k_find_starts<true>, dim3((unsigned)k2blocks, Fs), dim3(256), 0, st, masks, starts, counts, c->d_global,
-                               seedq, P);
-            mark(ST_STARTS + 1);
+            // (k_find_starts<true> was queued in the first round)
           if (c->trace_mode == 2) {
             // ---- cycle tracing.  Main stream: the seeds walk their segments, link, the cycles become contour list A, copy,
             //      approxPolyDP.  Auxiliary stream, beside it: seed index, then the chain that only exists for borders WITHOUT a
@@ -874,6 +888,7 @@ fid_status fid_create(const fid_params *params, const fid_dict *dict, const fid_
         TRYHIP(hipEventCreateWithFlags(&c->sub_done[sb], hipEventDisableTiming));
         TRYHIP(hipEventCreateWithFlags(&c->walk_done[sb], hipEventDisableTiming));
         TRYHIP(hipEventCreateWithFlags(&c->in_ready[sb], hipEventDisableTiming));
+        TRYHIP(hipEventCreateWithFlags(&c->fs_done[sb], hipEventDisableTiming));
         TRYHIP(hipEventCreateWithFlags(&c->aux_idx[sb], hipEventDisableTiming));
         for (int i = 0; i < 20; i++) TRYHIP(hipEventCreate(&c->sub_ev[sb][i]));
     }
@@ -897,6 +912,7 @@ fid_status fid_create(const fid_params *params, const fid_dict *dict, const fid_
     if (const char *tm = getenv("FID_TRACE")) c->trace_mode = !strcmp(tm, "legacy") ? 0 : !strcmp(tm, "chain") ? 1 : 2;
     if (getenv("FID_SW_BLOCKS")) c->sw_blocks = atoi(getenv("FID_SW_BLOCKS"));
     if (getenv("FID_STAGGER")) c->stagger = atoi(getenv("FID_STAGGER"));
+    if (getenv("FID_FS_BARRIER")) c->fs_barrier = atoi(getenv("FID_FS_BARRIER"));
     if (getenv("FID_PROBE_LUT")) c->probe_lut = atoi(getenv("FID_PROBE_LUT"));
     if (getenv("FID_TAIL_GRID")) c->tail_grid = atoi(getenv("FID_TAIL_GRID"));
     if (getenv("FID_FILTER_LDS")) c->filter_lds = atoi(getenv("FID_FILTER_LDS")) > 0 ? atoi(getenv("FID_FILTER_LDS")) : 1;
@@ -986,6 +1002,7 @@ void fid_destroy(fid_ctx *c)
         if (c->sub_done[sb]) (void)hipEventDestroy(c->sub_done[sb]);
         if (c->walk_done[sb]) (void)hipEventDestroy(c->walk_done[sb]);
         if (c->in_ready[sb]) (void)hipEventDestroy(c->in_ready[sb]);
+        if (c->fs_done[sb]) (void)hipEventDestroy(c->fs_done[sb]);
         for (int i = 0; i < 20; i++)
             if (c->sub_ev[sb][i]) (void)hipEventDestroy(c->sub_ev[sb][i]);
         if (c->sub_stream[sb]) (void)hipStreamDestroy(c->sub_stream[sb]);

@@ -2836,16 +2836,20 @@ __global__ __launch_bounds__(64) void k_approx(uint4 *__restrict__ contours, con
             sx = sp & 0xffff;
             sy = sp >> 16;
             // points j = 1 .. count-1 at index (pos + j) % count; READ_PT leaves pos back at its start
-            unsigned long long best = 0;
+            // (per lane the largest distance and the FIRST index that has it -- j only grows inside a lane, so a strict compare
+            //  keeps it; the 64-bit key that carries the first-maximum tie-break across lanes is built once per pass, not per point)
+            unsigned bd = 0, bj = 0;
             for (int j = 1 + lane; j < count; j += 64) {
                 int idx = pos + j;
                 idx = idx >= count ? idx - count : idx;
                 uint32_t p = pts[idx];
                 int dx = (int)(p & 0xffff) - sx, dy = (int)(p >> 16) - sy;
                 unsigned d = (unsigned)(dx * dx + dy * dy);
-                unsigned long long k = ((unsigned long long)d << 32) | (0xffffffffu - (unsigned)j);
-                best = k > best ? k : best;
+                const bool gt = d > bd;
+                bd = gt ? d : bd;
+                bj = gt ? (unsigned)j : bj;
             }
+            unsigned long long best = bd ? (((unsigned long long)bd << 32) | (0xffffffffu - bj)) : 0ull;
             best = wave_max_u64(best);
             unsigned md = (unsigned)(best >> 32);
             if (md > 0) rs_start = (int)(0xffffffffu - (unsigned)best);
@@ -2883,7 +2887,8 @@ __global__ __launch_bounds__(64) void k_approx(uint4 *__restrict__ contours, con
             int split = 0;
             if (mcount > 0) {
                 int dx = ex - sx, dy = ey - sy;
-                unsigned long long best = 0;
+                unsigned lbd = 0, lbt = 0;
+                bool any = false;
                 for (int t = lane; t < mcount; t += 64) {
                     int idx = sl.x + 1 + t;
                     idx = idx >= count ? idx - count : idx;
@@ -2891,9 +2896,12 @@ __global__ __launch_bounds__(64) void k_approx(uint4 *__restrict__ contours, con
                     int px = p & 0xffff, py = p >> 16;
                     int cr = (py - sy) * dx - (px - sx) * dy;
                     unsigned d = (unsigned)(cr < 0 ? -cr : cr);
-                    unsigned long long k = ((unsigned long long)d << 32) | (0xffffffffu - (unsigned)t);
-                    best = k > best ? k : best;
+                    const bool gt = d > lbd || !any;  // (the first point of the lane counts even at distance 0: its index is the tie-break)
+                    lbd = gt ? d : lbd;
+                    lbt = gt ? (unsigned)t : lbt;
+                    any = true;
                 }
+                unsigned long long best = any ? (((unsigned long long)lbd << 32) | (0xffffffffu - lbt)) : 0ull;
                 best = wave_max_u64(best);
                 double max_dist = (double)(unsigned)(best >> 32);
                 int bt = (int)(0xffffffffu - (unsigned)best);

@@ -115,11 +115,13 @@ struct DevSeg {           // one per seed
 //   of that E neighbour), and where in the segment that state is.  Around a cycle, min ko < min kh means an outer border whose
 //   first point is the state with min ko; otherwise a hole border that starts at the state with min kh (k_seg_cycles).
 struct DevSegC {
-    uint32_t next_key;    // the seed state the segment ran into: x | y << 13 | d << 26 (same scale)
+    // first 16 bytes: all that a hop of k_seg_cycles' walk round a cycle reads (one load per hop)
+    uint32_t next_idx;    // seed index of next_key (k_seg_link2)
     uint32_t n;           // states in the segment (SEG_INVALID: abandoned)
     uint32_t ko, kh;      // 0xffffffff: none
+    // second 16 bytes
+    uint32_t next_key;    // the seed state the segment ran into: x | y << 13 | d << 26 (same scale)
     uint32_t pos;         // position of the ko state | position of the kh state << 16
-    uint32_t next_idx;    // seed index of next_key (k_seg_link2)
     uint32_t linked;      // some segment runs into this one (k_seg_link2): only such a seed can lie on a cycle
     uint32_t pad;
 };

@@ -2333,8 +2333,8 @@ __global__ __launch_bounds__(64 * SW_WAVES) SW_VGPR_ATTR void k_seed_walk(const 
             if (rem >= 2) dst[1] = rem == 2 ? quad.w : quad.z;
             if (rem == 3) dst[2] = quad.w;
             uint4 *r = reinterpret_cast<uint4 *>(segs + (long long)lf * P.maxContours + slot);
-            r[0] = make_uint4(seed_key(cx, cy, sdir), too_long || !ok ? SEG_INVALID : (unsigned)count, ko, kh);
-            r[1] = make_uint4(po | (ph << 16), SEG_INVALID, 0u, 0u);
+            r[0] = make_uint4(SEG_INVALID, too_long || !ok ? SEG_INVALID : (unsigned)count, ko, kh);  // next_idx (k_seg_link2 fills it in), n, ko, kh
+            r[1] = make_uint4(seed_key(cx, cy, sdir), po | (ph << 16), 0u, 0u);                      // next_key, pos, linked, pad
             state = ST_IDLE;
         }
         // ---- hand out new work
@@ -2648,7 +2648,14 @@ __global__ __launch_bounds__(64) void k_seg_cycles(const uint2 *__restrict__ see
                         closed = true;
                         break;
                     }
-                    const DevSegC r = fsg[cur];
+                    DevSegC r;
+                    {
+                        const uint4 q = reinterpret_cast<const uint4 *>(fsg + cur)[0];  // next_idx, n, ko, kh: one 16-byte load per hop
+                        r.next_idx = q.x;
+                        r.n = q.y;
+                        r.ko = q.z;
+                        r.kh = q.w;
+                    }
                     if (r.n == SEG_INVALID || r.n == 0u) break;
                     co = co && !(r.ko < s.ko);
                     ch = ch && !(r.kh < s.kh);
@@ -2724,10 +2731,10 @@ __global__ __launch_bounds__(64) void k_seg_cycles(const uint2 *__restrict__ see
                         frc[rec++] = make_uint4(i, dst0, n0 - pos, pos);  // from the start state to the end of its segment
                         unsigned off = n0 - pos, cur = nx0;
                         while (cur != i && cur != SEG_INVALID && off < L) {
-                            const DevSegC r = fsg[cur];
-                            frc[rec++] = make_uint4(cur, dst0 + off, r.n, 0u);
-                            off += r.n;
-                            cur = r.next_idx;
+                            const uint2 q = reinterpret_cast<const uint2 *>(fsg + cur)[0];  // next_idx, n
+                            frc[rec++] = make_uint4(cur, dst0 + off, q.y, 0u);
+                            off += q.y;
+                            cur = q.x;
                         }
                         frc[rec++] = make_uint4(i, dst0 + off, pos, 0u);  // ... and the states in front of it
                         for (; rec < brec + sR; rec++) frc[rec] = make_uint4(0u, 0u, 0u, 0u);

@@ -102,3 +102,29 @@ def test_cfg4_the_sharded_streams_equal_the_oracle():
         assert np.array_equal(res[f][0], ocorners), seeds[f]
         for i, (r, t, e) in enumerate(oposes):
             assert np.abs(poses[f].rvecs[i] - r).max() < 1e-6 and np.abs(poses[f].tvecs[i] - t).max() < 1e-6, (seeds[f], i)
+
+
+def test_host_fed_batch_equals_the_resident_batch():
+    """fid_detect_batch (frames in host memory, sent up in four pieces on a copy stream, every piece's kernels starting when it
+    has landed) against fid_detect_device on the same frames resident in HBM (two sub-batches of 64 % / 36 %): the same markers
+    and poses frame by frame, for a batch that does not divide evenly (70 frames), from pageable and from pinned memory."""
+    torch = pytest.importorskip("torch")
+    import bench
+
+    B = 70
+    frames = bench.make_frames(bench.shard_seeds(0, 1, 16))
+    host = np.concatenate([frames] * 5)[:B].copy()
+    det = ArucoDetector(6, max_width=1920, max_height=1080, max_batch=B, max_markers=64)
+    try:
+        dev = torch.from_numpy(host).cuda()
+        ref = det.detect_markers_device(dev.data_ptr(), B, 1920, 1080)
+        pref = det.pose_last(0.14, K_DEFAULT, np.zeros(5))
+        for arr in (host, torch.from_numpy(host).pin_memory().numpy()):
+            got = det.detect_markers_batch(arr)
+            pg = det.pose_last(0.14, K_DEFAULT, np.zeros(5))
+            for f in range(B):
+                assert got[f][1].tolist() == ref[f][1].tolist() and len(got[f][1]) == 20, f
+                assert np.array_equal(got[f][0], ref[f][0]), f
+                assert np.array_equal(pg[f].tvecs, pref[f].tvecs) and np.array_equal(pg[f].rvecs, pref[f].rvecs), f
+    finally:
+        det.close()

@@ -30,6 +30,7 @@ struct fid_ctx {
     hipStream_t stream = nullptr;
     enum { MAX_SUB = 8 };
     hipStream_t sub_stream[MAX_SUB] = {};  // sub-batches of one call run on these, overlapping each other's tails
+    int sub_prio[MAX_SUB] = {};
     hipStream_t aux_stream[MAX_SUB] = {};  // per sub-batch: the seed walk runs here, beside the probe passes and the survivor walk
     hipEvent_t aux_fork[MAX_SUB] = {}, aux_join[MAX_SUB] = {}, aux_idx[MAX_SUB] = {};
     hipEvent_t sub_done[MAX_SUB] = {}, fork_ev = nullptr;
@@ -258,6 +259,20 @@ size_t masks_elems(const fid_ctx *c, int W, int H, int F)
     return (size_t)F * c->P.nscales * TR * TC * MT_ROWS;
 }
 
+// the streams of sub-batches 0 .. nsub - 1 (and their auxiliary streams in the traced modes), made on first use
+fid_status ensure_streams(fid_ctx *c, int nsub)
+{
+    for (int sb = 0; sb < nsub && sb < fid_ctx::MAX_SUB; sb++) {
+        // (sub-batch 0 runs on the context's own stream, which has nothing else to do while a call is under way: a resident batch
+        //  then works on four streams -- two sub-batches, two auxiliary -- which is what the HIP runtime's DEFAULT of four hardware
+        //  queues carries side by side; with a fifth and sixth stream alive the default cost 17 % against GPU_MAX_HW_QUEUES >= 8)
+        if (sb == 0) c->sub_stream[0] = c->stream;
+        else if (!c->sub_stream[sb] && nsub > 1) HIPCHK(c, hipStreamCreateWithPriority(&c->sub_stream[sb], hipStreamNonBlocking, c->sub_prio[sb]));
+        if (!c->aux_stream[sb] && c->trace_mode >= 1) HIPCHK(c, hipStreamCreateWithPriority(&c->aux_stream[sb], hipStreamNonBlocking, c->sub_prio[sb]));
+    }
+    return FID_OK;
+}
+
 // how a call of F frames is cut into sub-batches (run_detect; fid_detect_batch sends the frames up in the same pieces):
 // sub-batch sb = frames [f0[sb], f0[sb + 1])
 struct SubPlan {
@@ -373,6 +388,10 @@ fid_status run_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H, int
     const SubPlan plan = plan_sub_batches(c, F);
     const int nsub = plan.nsub;
     c->last_nsub = nsub;
+    {
+        const fid_status rcs = ensure_streams(c, nsub);
+        if (rcs != FID_OK) return rcs;
+    }
     if (nsub > 1) HIPCHK(c, hipEventRecord(c->fork_ev, st0));
     // The host enqueues in two rounds: first every sub-batch's gray conversion + threshold, then every sub-batch's rest.  (One
     // round -- a whole sub-batch, some thirty launches, before the next one's first kernel -- left the second sub-batch's stream
@@ -871,7 +890,6 @@ fid_status fid_create(const fid_params *params, const fid_dict *dict, const fid_
     } while (0)
     TRYHIP(hipSetDevice(device));
     TRYHIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    TRYHIP(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
     for (int i = 0; i <= ST_COUNT; i++) TRYHIP(hipEventCreate(&c->ev[i]));
     TRYHIP(hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming));
     int prio_lo = 0, prio_hi = 0;  // (numerically lower = more urgent)
@@ -881,8 +899,10 @@ fid_status fid_create(const fid_params *params, const fid_dict *dict, const fid_
     for (int sb = 0; sb < fid_ctx::MAX_SUB; sb++) {
         int prio = use_prio ? prio_hi + sb : prio_lo;
         if (prio > prio_lo) prio = prio_lo;
-        TRYHIP(hipStreamCreateWithPriority(&c->sub_stream[sb], hipStreamNonBlocking, prio));
-        TRYHIP(hipStreamCreateWithPriority(&c->aux_stream[sb], hipStreamNonBlocking, prio));
+        // (the sub-batch and auxiliary streams themselves are made when a call first needs them -- ensure_streams(): every live
+        //  stream is a claim on the hardware queues; eighteen idle ones per context cost the STag path its rate in round 2, and
+        //  creating eight more for an experiment cost this path a quarter of its own)
+        c->sub_prio[sb] = prio;
         TRYHIP(hipEventCreateWithFlags(&c->aux_fork[sb], hipEventDisableTiming));
         TRYHIP(hipEventCreateWithFlags(&c->aux_join[sb], hipEventDisableTiming));
         TRYHIP(hipEventCreateWithFlags(&c->sub_done[sb], hipEventDisableTiming));
@@ -1005,7 +1025,7 @@ void fid_destroy(fid_ctx *c)
         if (c->fs_done[sb]) (void)hipEventDestroy(c->fs_done[sb]);
         for (int i = 0; i < 20; i++)
             if (c->sub_ev[sb][i]) (void)hipEventDestroy(c->sub_ev[sb][i]);
-        if (c->sub_stream[sb]) (void)hipStreamDestroy(c->sub_stream[sb]);
+        if (c->sub_stream[sb] && c->sub_stream[sb] != c->stream) (void)hipStreamDestroy(c->sub_stream[sb]);
     }
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -1075,6 +1095,7 @@ fid_status fid_detect_batch(fid_ctx *c, const uint8_t *imgs, int32_t nframes, in
     // sub-batch k (pinned host memory -- a capture ring buffer -- copies at link speed; pageable memory is staged by the runtime
     // and copies more slowly, the overlap is the same).
     c->host_feed = getenv("FID_NO_FEED_OVERLAP") == nullptr;
+    if (c->host_feed && !c->copy_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
     const SubPlan plan = plan_sub_batches(c, nframes);
     const int nsub = plan.nsub;
     if (!c->host_feed) {

@@ -734,6 +734,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=256, help="frames per step per GPU (BASELINE cfg 3: 256)")
     ap.add_argument("--unique", type=int, default=0, help="unique synthetic frames per GPU (0 = batch); fewer are tiled")
+    ap.add_argument("--in-flight", type=int, default=int(os.environ.get("FID_BENCH_IN_FLIGHT", "2")),
+                    help="contexts that take the steps in turn: step k + 1 is submitted before step k is collected (1 = one call after the other)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the cfg 2 latency and cfg 5 (STag) side results")
     ap.add_argument("--stag-side-child", action="store_true", help=argparse.SUPPRESS)  # the cfg 5 side result, own process
@@ -788,32 +790,48 @@ def main():
     host = np.concatenate([frames_u] * reps)[:B]
     d_frames = torch.from_numpy(host).to(f"cuda:{local_rank}")
     torch.cuda.synchronize()
-    det = ArucoDetector("DICT_5X5_250", device=local_rank, max_width=W, max_height=H, max_batch=B, max_markers=64,
-                        max_candidates=2048, max_contours=int(os.environ.get("FID_BENCH_MAX_CONTOURS", "0")))
+    # The steps go through `depth` contexts in turn (fiducials_amd/pipeline.py: fid_submit_device / fid_collect): step k + 1 is
+    # enqueued before step k's results are fetched, so the latency-bound end of one batch runs under the front of the next.
+    # Every step is a whole pass (gray .. pose, results on the host) over its own 256 frames; all K are finished inside the
+    # timed region.  --in-flight 1 is one fid_detect_device + fid_pose_last after the other.
+    from fiducials_amd.pipeline import BatchPipeline
 
-    def step():
-        n = det.detect_markers_device(d_frames.data_ptr(), B, W, H, unpack=False)
-        det.pose_last(FIDUCIAL_LEN, K, D, unpack=False)
-        return n
+    depth = max(1, min(args.in_flight, 8))
+    pipe = BatchPipeline("DICT_5X5_250", depth=depth, fiducial_len=FIDUCIAL_LEN, K=K, D=D,
+                         ordered=os.environ.get("FID_BENCH_UNORDERED", "0") != "1", device=local_rank, max_width=W,
+                         max_height=H, max_batch=B, max_markers=64, max_candidates=2048,
+                         max_contours=int(os.environ.get("FID_BENCH_MAX_CONTOURS", "0")))
+    det = pipe.detectors[0]
+    stage_acc = {}
+    counted = [0, 0]  # markers, steps collected
+
+    def take(done, acc=True):
+        if done is None:
+            return
+        counted[0] += sum(done[0])
+        counted[1] += 1
+        if acc:
+            for k, v in pipe.detectors[pipe.last_collected].stage_ms().items():
+                stage_acc[k] = stage_acc.get(k, 0.0) + v
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    stage_acc = {}
+    for _ in range(max(args.warmup, depth if args.warmup else 0)):  # (every context sets up its streams on its first batch)
+        pipe.push(d_frames.data_ptr(), B, W, H, unpack=False)
+    pipe.flush(unpack=False)
     barrier()
     t0 = time.perf_counter()
-    markers = 0
     for _ in range(args.steps):
-        n = step()
-        markers += sum(n)
-        for k, v in det.stage_ms().items():
-            stage_acc[k] = stage_acc.get(k, 0.0) + v
+        take(pipe.push(d_frames.data_ptr(), B, W, H, unpack=False))
+    for done in pipe.flush(unpack=False):
+        take(done)
     torch.cuda.synchronize()
     dt_local = time.perf_counter() - t0
+    markers = counted[0]
+    assert counted[1] == args.steps  # every step's results were fetched inside the timed region
     barrier()
     fps, dt = job_throughput(B * args.steps, n_gpus, time.perf_counter() - t0, dist, f"cuda:{local_rank}")
     ranks = gather_ranks(dist, rank, f"cuda:{local_rank}", B * args.steps, dt_local, markers)
@@ -855,6 +873,9 @@ def main():
                 "frames_per_step": B * n_gpus,
                 "parallelism": f"frames sharded over {n_gpus} GPU(s), no collective",
                 "markers_per_frame_found": round(markers / max(B * args.steps, 1), 2),
+                "in_flight": depth,
+                "in_flight_note": f"{depth} contexts take the steps in turn (fid_submit_device / fid_collect): ms_per_step is the "
+                                  "timed region / steps, a throughput figure; one step alone is one_at_a_time.ms_per_step",
             },
             "roofline": roof,
             "stage_ms_per_step": {k: round(v, 4) for k, v in stage_ms.items()},
@@ -862,8 +883,18 @@ def main():
         }
         if OVERSUB:
             out["oversubscribed"] = f"{n_gpus} ranks on ONE GPU (FID_BENCH_OVERSUBSCRIBE=1, gloo clock reduction): a plumbing run, not a scaling point"
+        if depth > 1 and not args.no_extras:
+            # the same steps one call after the other on one context (fid_detect_device + fid_pose_last), outside the timed region
+            k1 = max(3, min(args.steps, 10))
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(k1):
+                det.detect_markers_device(d_frames.data_ptr(), B, W, H, unpack=False)
+                det.pose_last(FIDUCIAL_LEN, K, D, unpack=False)
+            d1 = (time.perf_counter() - t1) / k1
+            out["one_at_a_time"] = {"frames_per_s": round(B / d1, 1), "ms_per_step": round(d1 * 1e3, 3), "steps": k1}
         if n_gpus == 1 and not args.no_extras:
-            det.close()
+            pipe.close()
             det = None
             out["extra"] = {"cfg2_single_frame": cfg2_latency(local_rank, frames_u[0])}
             try:
@@ -892,7 +923,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(frames_u, K, D)
         print(json.dumps(out))
     if det is not None:
-        det.close()
+        pipe.close()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -37,6 +37,19 @@ struct fid_ctx {
     hipStream_t copy_stream = nullptr;     // fid_detect_batch: the frames go up sub-batch by sub-batch on this stream ...
     hipEvent_t in_ready[MAX_SUB] = {};     // ... and a sub-batch starts when its frames have landed (H2D of k + 1 under the compute of k)
     bool host_feed = false;                // this run_detect call is fed that way
+    struct Pending {                       // the batch fid_submit_device enqueued and fid_collect has not yet fetched
+        const uint8_t *d_src;
+        int F, W, H, stride;
+        long long fstride;
+        fid_encoding enc;
+    } pend = {};
+    bool in_flight = false;
+    // batches in turn on several contexts (fid_order_after): tail_ev is recorded where the LAST sub-batch of a batch has its
+    // chip-filling kernels behind it (chain_at: 0 after find_starts, 1 seed walk, 2 copy, 3 approxPolyDP, 4 in front of the
+    // candidate sort, 5 after the too-close filter); the next batch's first kernel, on another context, waits for wait_ev
+    hipEvent_t tail_ev = nullptr, wait_ev = nullptr;
+    int chain_at = 0;
+    bool chained = false;  // the next submit is one of a chain of batches (fid_order_after): one sub-batch, see plan_sub_batches
     hipEvent_t walk_done[MAX_SUB] = {}, fs_done[MAX_SUB] = {};
     int fs_barrier = 0;                    // FID_FS_BARRIER=1: the walks of every sub-batch wait for all find_starts (measured: find_starts
                                            // 3.6 -> 2.2 ms, the seed walks 3.3 -> 4.9 ms now side by side: the step is the same)     // a sub-batch has left its contour stage (staggered starts, FID_STAGGER)
@@ -298,6 +311,16 @@ SubPlan plan_sub_batches(const fid_ctx *c, int F)
         pl.f0[4] = F;
         return pl;
     }
+    if (c->chained && c->sub_frames <= 0 && !getenv("FID_SUB_SHARES")) {
+        // a batch in a chain of batches on two contexts (fid_order_after) IS the other half: the batch before it on the other
+        // context plays the part of the first sub-batch, for ever, with no call boundary at which the last piece's latency-bound
+        // end has the chip to itself.  Measured, 256 frames a batch, two contexts: whole batches 30.5 k frames/s, 64 % + 36 %
+        // pieces 29.5 k (and 26.5 k for one context, one call after the other).
+        pl.nsub = 1;
+        pl.f0[0] = 0;
+        pl.f0[1] = F;
+        return pl;
+    }
     // resident frames: two halves measured best (more streams fight for CUs)
     int per = c->sub_frames > 0 ? c->sub_frames : (F >= 32 ? (F + 1) / 2 : F);
     int nsub = (F + per - 1) / per;
@@ -342,11 +365,13 @@ SubPlan plan_sub_batches(const fid_ctx *c, int F)
     return pl;
 }
 
-// the whole detection pipeline for F frames whose gray images are resident at d_gray
-fid_status run_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H, int stride, long long fstride, fid_encoding enc,
-                      fid_marker *out, int cap_per_frame, int *n_per_frame)
+// The whole detection pipeline for F frames whose gray images are resident at d_gray, in two halves: enqueue_detect puts every
+// kernel and the result copies on the context's streams and returns (no host wait anywhere), finish_detect waits for them and
+// hands the markers out.  fid_detect_device / fid_detect_batch call one after the other; fid_submit_device / fid_collect expose
+// the halves, so that a caller with a stream of batches keeps two or three contexts in flight and the latency-bound tail of one
+// batch runs under the front of the next.
+fid_status enqueue_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H, int stride, long long fstride, fid_encoding enc)
 {
-    if (!out || !n_per_frame || cap_per_frame < 0) return FID_E_INVALID_ARG;
     if (F < 1 || F > c->lim.max_batch || W < 8 || H < 8 || W > c->lim.max_width || H > c->lim.max_height || W > 8191 || H > 8191)  // 13-bit checkpoint packing
         return FID_E_INVALID_ARG;
     if (enc != FID_ENC_MONO8 && enc != FID_ENC_BGR8 && enc != FID_ENC_RGB8 && enc != FID_ENC_BGRA8 && enc != FID_ENC_RGBA8) return FID_E_INVALID_ARG;
@@ -361,6 +386,10 @@ fid_status run_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H, int
     const long long gfstride = to_gray ? (long long)W * H : fstride;
     const uint8_t *gray = to_gray ? c->d_gray : d_src;
     set_geometry(c, W, H, gstride, F);
+    if (c->wait_ev) {
+        HIPCHK(c, hipStreamWaitEvent(st0, c->wait_ev, 0));
+        c->wait_ev = nullptr;
+    }
     if (c->d_seedhash) {
         // a new generation makes every entry of the seed hash tables stale; clear them when the 10-bit number wraps
         if (++c->seed_gen > 1023) {
@@ -396,6 +425,7 @@ fid_status run_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H, int
     // The host enqueues in two rounds: first every sub-batch's gray conversion + threshold, then every sub-batch's rest.  (One
     // round -- a whole sub-batch, some thirty launches, before the next one's first kernel -- left the second sub-batch's stream
     // empty for the first 0.35 - 0.6 ms of every step.)
+    bool tail_recorded = false;
     auto sub_phase = [&](int sb, int phase) -> fid_status {
         const int f0 = plan.f0[sb], Fs = plan.f0[sb + 1] - f0;
         hipStream_t st = nsub > 1 ? c->sub_stream[sb] : st0;
@@ -424,6 +454,12 @@ fid_status run_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H, int
         hipEvent_t *ev = c->sub_ev[sb];
         auto mark = [&](int idx) {
             if (c->profile) (void)hipEventRecord(ev[idx], st);
+        };
+        auto chain_point = [&](int pt) {  // (a point the mode in use does not pass falls through to the next one that it does)
+            if (sb == nsub - 1 && !tail_recorded && c->chain_at <= pt) {
+                (void)hipEventRecord(c->tail_ev, st);
+                tail_recorded = true;
+            }
         };
       if (phase == 0) {
         mark(0);
@@ -481,6 +517,7 @@ fid_status run_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H, int
                                c->d_seedq + f0 * (size_t)P.maxContours, P);
             mark(ST_STARTS + 1);
             if (nsub > 1) HIPCHK(c, hipEventRecord(c->fs_done[sb], st));
+            chain_point(0);
         }
         return FID_OK;
       }
@@ -571,17 +608,20 @@ fid_status run_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H, int
                                c->d_global, P);
             if (c->profile) (void)hipEventRecord(ev[15], st);
             mark(ST_PROBE + 1);
+            chain_point(1);
             HIPCHK(c, hipStreamWaitEvent(st, c->aux_idx[sb], 0));
             hipLaunchKernelGGL(k_seg_link2, dim3(16 * gm, Fs), dim3(256), 0, st, seedq, (DevSegC *)segs, seedhash, counts, P);
             hipLaunchKernelGGL(k_seg_cycles, dim3(32 * gm * c->light_x, Fs), dim3(64), 0, st, seedq, (const DevSegC *)segs, pend, wres, contours, cinfo, cbase,
                                recs, counts, c->d_global, P, 0);
             hipLaunchKernelGGL(k_seg_copy, dim3(cpb, Fs), dim3(256), 0, st, recs, tab, pool, dense, counts, P, 0);
             mark(ST_WALK + 1);
+            chain_point(2);
             hipLaunchKernelGGL(k_approx, dim3(128 * gm, Fs), dim3(64), lds1, st, contours, tab, pool, cands, counts, c->d_global, P, cap1,
                                K4_SHORT_STACK, 0, dense, cbase, 1);
             hipLaunchKernelGGL(k_approx, dim3(16 * gm, Fs), dim3(64), lds2, st, contours, tab, pool, cands, counts, c->d_global, P,
                                P.maxPerim + 1, K4_LONG_STACK, 1, dense, cbase, 1);
             mark(ST_APPROX + 1);
+            chain_point(3);
             HIPCHK(c, hipStreamWaitEvent(st, c->aux_join[sb], 0));
           } else {
             // the seed walk needs only the seeds: it runs on its own stream beside the probe passes and the survivor walk
@@ -615,6 +655,7 @@ fid_status run_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H, int
           }
         }
         if (nsub > 1 && c->stagger > 0) HIPCHK(c, hipEventRecord(c->walk_done[sb], st));
+        chain_point(4);
         // ---- K5
         float4 *cmeta = c->d_cmeta + f0 * MC;
         hipLaunchKernelGGL(k_sort_cands, dim3(Fs), dim3(c->light_x > 1 ? 1024 : 256), MC * 8, st, cands, sorted, cmeta, counts, P);
@@ -629,6 +670,7 @@ fid_status run_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H, int
             hipLaunchKernelGGL(k_resolve, dim3(Fs), dim3(1024), lds, st, sorted, nearb, filtered, counts, worklist, nwork, P, near_words, c->d_global);
         }
         mark(ST_RESOLVE + 1);
+        chain_point(5);
         // ---- K6
         {
             int SZ = (P.markerSize + 2 * P.borderBits) * P.cellSize;
@@ -659,6 +701,7 @@ fid_status run_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H, int
                                (int)(sizeof(DevCounts) / sizeof(int)), (const double *)nullptr, Fs, P.maxMarkers, cam, c->d_poses + f0 * MM);
             if (c->profile) (void)hipEventRecord(ev[19], st);
         }
+        chain_point(99);
         if (nsub > 1) {
             HIPCHK(c, hipEventRecord(c->sub_done[sb], st));
             HIPCHK(c, hipStreamWaitEvent(st0, c->sub_done[sb], 0));
@@ -680,13 +723,27 @@ fid_status run_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H, int
     c->pose_done = false;
     if (c->pose_cam_valid)
         HIPCHK(c, hipMemcpyAsync(c->h_poses, c->d_poses, sizeof(fid_pose_out) * (size_t)F * P.maxMarkers, hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipStreamSynchronize(st));
-    c->pose_done = c->pose_cam_valid;
     c->last_frames = F;
     c->last_W = W;
     c->last_H = H;
     c->last_gray = gray;
     c->last_gfstride = gfstride;
+    c->pend = {d_src, F, W, H, stride, fstride, enc};
+    c->in_flight = true;
+    c->chained = false;
+    return FID_OK;
+}
+
+fid_status run_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H, int stride, long long fstride, fid_encoding enc,
+                      fid_marker *out, int cap_per_frame, int *n_per_frame);
+
+fid_status finish_detect(fid_ctx *c, fid_marker *out, int cap_per_frame, int *n_per_frame)
+{
+    const DevParams &P = c->P;
+    const int F = c->pend.F;
+    c->in_flight = false;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->pose_done = c->pose_cam_valid;
     if (c->profile) {
         // a stage's time = its event-bracketed time on its own stream, summed over the sub-batches (with more than
         // one sub-batch the brackets of different streams overlap in wall time)
@@ -732,7 +789,8 @@ fid_status run_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H, int
         const int tm = c->trace_mode;
         c->trace_mode = 0;
         c->fallbacks++;
-        const fid_status rc2 = run_detect(c, d_src, F, W, H, stride, fstride, enc, out, cap_per_frame, n_per_frame);
+        const fid_ctx::Pending pd = c->pend;
+        const fid_status rc2 = run_detect(c, pd.d_src, pd.F, pd.W, pd.H, pd.stride, pd.fstride, pd.enc, out, cap_per_frame, n_per_frame);
         c->trace_mode = tm;
         return rc2;
     }
@@ -767,6 +825,19 @@ fid_status run_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H, int
         memcpy(out + (size_t)f * cap_per_frame, c->h_markers + (size_t)f * P.maxMarkers, sizeof(fid_marker) * n);
     }
     return rc;
+}
+
+fid_status run_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H, int stride, long long fstride, fid_encoding enc,
+                      fid_marker *out, int cap_per_frame, int *n_per_frame)
+{
+    if (!out || !n_per_frame || cap_per_frame < 0) return FID_E_INVALID_ARG;
+    if (c->in_flight) {
+        c->last_error = "a submitted batch is in flight: fid_collect first";
+        return FID_E_INVALID_ARG;
+    }
+    const fid_status rc = enqueue_detect(c, d_src, F, W, H, stride, fstride, enc);
+    if (rc != FID_OK) return rc;
+    return finish_detect(c, out, cap_per_frame, n_per_frame);
 }
 
 }  // namespace
@@ -892,6 +963,7 @@ fid_status fid_create(const fid_params *params, const fid_dict *dict, const fid_
     TRYHIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     for (int i = 0; i <= ST_COUNT; i++) TRYHIP(hipEventCreate(&c->ev[i]));
     TRYHIP(hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming));
+    TRYHIP(hipEventCreateWithFlags(&c->tail_ev, hipEventDisableTiming));
     int prio_lo = 0, prio_hi = 0;  // (numerically lower = more urgent)
     (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
     // FID_PRIO=1: earlier sub-batches more urgent.  Measured slower (18.1k vs 18.8k frames/s) than equal priorities.
@@ -939,6 +1011,7 @@ fid_status fid_create(const fid_params *params, const fid_dict *dict, const fid_
     if (getenv("FID_LIGHT_X")) c->light_x = atoi(getenv("FID_LIGHT_X")) > 0 ? atoi(getenv("FID_LIGHT_X")) : 1;
     if (getenv("FID_RESOLVE_LDS")) c->resolve_lds_kb = atoi(getenv("FID_RESOLVE_LDS"));
     if (getenv("FID_WALK2_DIV")) c->walk2_div = atoi(getenv("FID_WALK2_DIV"));
+    if (getenv("FID_CHAIN_AT")) c->chain_at = atoi(getenv("FID_CHAIN_AT"));
     static_assert(sizeof(DevSegC) == sizeof(DevSeg), "the two segment records share one buffer");
     if (c->trace_mode >= 1) {
         TRY(dalloc(c, &c->d_segs, F * L.max_contours_per_frame));
@@ -1010,6 +1083,7 @@ void fid_destroy(fid_ctx *c)
     for (int i = 0; i <= ST_COUNT; i++)
         if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     if (c->fork_ev) (void)hipEventDestroy(c->fork_ev);
+    if (c->tail_ev) (void)hipEventDestroy(c->tail_ev);
     for (int sb = 0; sb < fid_ctx::MAX_SUB; sb++) {
         if (c->sub_stream[sb]) (void)hipStreamSynchronize(c->sub_stream[sb]);
         if (c->aux_stream[sb]) {
@@ -1034,7 +1108,7 @@ void fid_destroy(fid_ctx *c)
 
 fid_status fid_set_params(fid_ctx *c, const fid_params *p)
 {
-    if (!c || !p) return FID_E_INVALID_ARG;
+    if (!c || !p || c->in_flight) return FID_E_INVALID_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     int old_scales = c->P.nscales;
     fid_params keep = c->params;
@@ -1075,11 +1149,49 @@ fid_status fid_detect_device(fid_ctx *c, const void *d_imgs, int32_t nframes, in
     return run_detect(c, (const uint8_t *)d_imgs, nframes, width, height, stride, frame_stride, enc, out, cap_per_frame, n_per_frame);
 }
 
+fid_status fid_submit_device(fid_ctx *c, const void *d_imgs, int32_t nframes, int32_t width, int32_t height, int32_t stride,
+                             int64_t frame_stride, fid_encoding enc)
+{
+    if (!c || !d_imgs) return FID_E_INVALID_ARG;
+    if (c->in_flight) {
+        c->last_error = "a submitted batch is in flight: fid_collect first";
+        return FID_E_INVALID_ARG;
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    const fid_status rc = enqueue_detect(c, (const uint8_t *)d_imgs, nframes, width, height, stride, frame_stride, enc);
+    c->wait_ev = nullptr;  // (fid_order_after holds for one submit, refused or not)
+    c->chained = false;
+    return rc;
+}
+
+fid_status fid_order_after(fid_ctx *c, fid_ctx *prev)
+{
+    if (!c || c == prev || c->in_flight || (prev && prev->device != c->device)) return FID_E_INVALID_ARG;
+    c->wait_ev = prev && prev->in_flight ? prev->tail_ev : nullptr;
+    c->chained = prev != nullptr;
+    return FID_OK;
+}
+
+fid_status fid_collect(fid_ctx *c, fid_marker *out, int32_t cap_per_frame, int32_t *n_per_frame)
+{
+    if (!c || !out || !n_per_frame || cap_per_frame < 0) return FID_E_INVALID_ARG;
+    if (!c->in_flight) {
+        c->last_error = "nothing was submitted";
+        return FID_E_INVALID_ARG;
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    return finish_detect(c, out, cap_per_frame, n_per_frame);
+}
+
 fid_status fid_detect_batch(fid_ctx *c, const uint8_t *imgs, int32_t nframes, int32_t width, int32_t height, int32_t stride,
                             int64_t frame_stride, fid_encoding enc, fid_marker *out, int32_t cap_per_frame, int32_t *n_per_frame)
 {
     if (!c || !imgs || nframes < 1 || height < 1 || stride < 1) return FID_E_INVALID_ARG;
     if (nframes > c->lim.max_batch) return FID_E_INVALID_ARG;
+    if (c->in_flight) {
+        c->last_error = "a submitted batch is in flight: fid_collect first";
+        return FID_E_INVALID_ARG;
+    }
     HIPCHK(c, hipSetDevice(c->device));
     if (frame_stride < (int64_t)stride * height) return FID_E_INVALID_ARG;
     size_t need = (size_t)frame_stride * (nframes - 1) + (size_t)stride * height;
@@ -1143,6 +1255,10 @@ fid_status fid_pose_last(fid_ctx *c, const double K[9], const double D[5], doubl
                          int32_t cap_per_frame)
 {
     if (!c || !K || !out || c->last_frames <= 0 || !(fiducial_len > 0)) return FID_E_INVALID_ARG;
+    if (c->in_flight) {
+        c->last_error = "a submitted batch is in flight: fid_collect first";
+        return FID_E_INVALID_ARG;
+    }
     HIPCHK(c, hipSetDevice(c->device));
     const int F = c->last_frames, MM = c->P.maxMarkers;
     double Dz[5] = {0., 0., 0., 0., 0.};
@@ -1180,6 +1296,7 @@ fid_status fid_pose(fid_ctx *c, const double K[9], const double D[5], const fid_
     if (len_per_marker)
         for (int i = 0; i < n; i++)
             if (!(len_per_marker[i] > 0)) return FID_E_INVALID_ARG;  // CV_Assert(markerLength > 0), aruco_detect.cpp:229
+    if (c->in_flight) return FID_E_INVALID_ARG;  // (shares the context's stream and buffers with the batch in flight)
     HIPCHK(c, hipSetDevice(c->device));
     if (n > c->pose_cap) {
         if (c->d_pose_in) (void)hipFree(c->d_pose_in);
@@ -1228,7 +1345,7 @@ int64_t fid_tap_bytes(fid_ctx *c, fid_tap which)
 
 fid_status fid_tap_read(fid_ctx *c, fid_tap which, void *dst, int64_t dst_bytes)
 {
-    if (!c || !dst || c->last_frames <= 0) return FID_E_INVALID_ARG;
+    if (!c || !dst || c->last_frames <= 0 || c->in_flight) return FID_E_INVALID_ARG;
     int64_t need = fid_tap_bytes(c, which);
     if (need <= 0 || dst_bytes < need) return FID_E_CAPACITY;
     HIPCHK(c, hipSetDevice(c->device));

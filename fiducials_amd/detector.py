@@ -155,6 +155,28 @@ class ArucoDetector:
             return [int(self._n[f]) for f in range(nframes)]
         return self._unpack(nframes)
 
+    def submit_device(self, data_ptr: int, nframes: int, width: int, height: int, stride: int | None = None,
+                      frame_stride: int | None = None, encoding: str = "mono8", after: "ArucoDetector | None" = None) -> None:
+        """First half of detect_markers_device: enqueue the batch and return at once (fid_submit_device).  The frames must stay
+        where they are until collect().  after = another detector: start when its batch in flight is past its chip-filling
+        kernels (fid_order_after)."""
+        if after is not None:
+            self._check(self._L.fid_order_after(self._ctx, after._ctx))
+        bpp = {"mono8": 1, "bgra8": 4, "rgba8": 4}.get(encoding, 3)
+        stride = stride or width * bpp
+        frame_stride = frame_stride or stride * height
+        self._check(self._L.fid_submit_device(self._ctx, C.c_void_p(data_ptr), nframes, width, height, stride, frame_stride,
+                                              _lib.ENC[encoding]))
+        self._submitted = nframes
+
+    def collect(self, unpack: bool = True):
+        """Second half: wait for the submitted batch and return what detect_markers_device would have (fid_collect)."""
+        self._check(self._L.fid_collect(self._ctx, self._out, self.max_markers, self._n))
+        nframes = self._last_frames = self._submitted
+        if not unpack:
+            return [int(self._n[f]) for f in range(nframes)]
+        return self._unpack(nframes)
+
     # -- pose ---------------------------------------------------------------------------------
     def estimate_pose_single_markers(self, corners: np.ndarray, ids: np.ndarray, fiducial_len: float, K, D,
                                      fiducial_len_override: dict | None = None) -> PoseResult:

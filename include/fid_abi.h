@@ -38,8 +38,9 @@ extern "C" {
 /* 1: round 1 (aruco path).  2: + fid_detect_device / fid_pose_last / limits, the fid_stag_* family, the fid_jpeg_* family (round 2,
  * which forgot to bump it).  3: fid_last_stage_ms reports 15 stages (seedless_chain); fid_pose_last may hand over poses that the
  * preceding fid_detect_* call already computed for the same camera; fid_stag_detect_markers_batch reports 0 markers for a frame
- * whose slot was too small (round 3).  Entry points are only ever added: a caller built against 1 runs against 3. */
-#define FID_ABI_VERSION 3
+ * whose slot was too small (round 3).  4: + fid_submit_device / fid_collect / fid_order_after (round 3).  Entry points are only ever added: a caller
+ * built against 1 runs against 4. */
+#define FID_ABI_VERSION 4
 
 typedef enum fid_status {
     FID_OK = 0,
@@ -146,6 +147,23 @@ fid_status fid_detect_batch(fid_ctx *ctx, const uint8_t *imgs, int32_t nframes, 
 fid_status fid_detect_device(fid_ctx *ctx, const void *d_imgs, int32_t nframes, int32_t width, int32_t height,
                              int32_t stride_bytes, int64_t frame_stride_bytes, fid_encoding enc, fid_marker *out,
                              int32_t cap_per_frame, int32_t *n_per_frame);
+/* fid_detect_device in two halves, for a caller with a STREAM of batches (the node's frames keep coming: imageCallback,
+ * aruco_detect.cpp:332-350, is called once per frame for as long as the camera runs).  fid_submit_device enqueues the whole
+ * pipeline of one batch on the context's streams and returns without waiting; fid_collect waits for it and hands out what
+ * fid_detect_device would have (fid_pose_last then refers to that batch).  With two or three contexts in turn -- submit k + 1,
+ * collect k -- the latency-bound end of one batch runs under the front of the next.  One batch per context at a time:
+ * fid_submit_device / fid_detect_* / fid_pose_last / fid_tap_read on a context with a batch in flight return
+ * FID_E_INVALID_ARG; d_imgs must stay valid until fid_collect returns. */
+fid_status fid_submit_device(fid_ctx *ctx, const void *d_imgs, int32_t nframes, int32_t width, int32_t height,
+                             int32_t stride_bytes, int64_t frame_stride_bytes, fid_encoding enc);
+fid_status fid_collect(fid_ctx *ctx, fid_marker *out, int32_t cap_per_frame, int32_t *n_per_frame);
+/* Optional, before fid_submit_device(ctx): that batch's first kernel starts when the batch in flight on `prev` (another context of
+ * the same device; NULL or nothing in flight: no order) has its chip-filling kernels behind it -- the fronts of two batches then
+ * do not run beside each other, only a front beside the other's latency-bound end; and that batch is laid out as ONE piece
+ * (fid_detect_device cuts a batch into two that overlap each other: in a chain the batch on the other context is the other
+ * piece).  Holds for the next submit only.  Two contexts in turn, each ordered after the other, is the intended use:
+ *     fid_order_after(b, a); fid_submit_device(b, k + 1); fid_collect(a, k); fid_order_after(a, b); fid_submit_device(a, k + 2); ... */
+fid_status fid_order_after(fid_ctx *ctx, fid_ctx *prev);
 
 /* poseEstimateCallback arithmetic for n markers.  K row-major 3x3, D = plumb-bob k1,k2,p1,p2,k3
  * (CameraInfo.K / .D[0..4], aruco_detect.cpp:315-323).  len_per_marker[i] is fiducial_len or its per-id

@@ -308,6 +308,27 @@ def host_feed_result(local_rank, host, K, D):
         out[name] = {"value": round(B * steps / dt, 1), "unit": "frames/s", "ms_per_step": round(dt / steps * 1e3, 3),
                      "pcie_GBps": round(B * W * H * steps / dt / 1e9, 2), "markers_per_frame_found": round(found / (B * steps), 2)}
     det.close()
+    # a STREAM of such batches: two contexts in turn (fid_submit_batch / fid_collect / fid_order_after) -- the copy of batch
+    # k + 1 runs under the kernels of batch k, and the step is what the link takes (531 MB per batch)
+    from fiducials_amd.pipeline import BatchPipeline
+
+    with BatchPipeline("DICT_5X5_250", depth=2, fiducial_len=FIDUCIAL_LEN, K=K, D=D, device=local_rank, max_width=W, max_height=H,
+                       max_batch=B, max_markers=64, max_candidates=2048) as pipe:
+        bufs = [pinned.numpy(), torch.from_numpy(host.copy()).pin_memory().numpy()]  # (a capture ring of two batches)
+        for name, arrs in (("pinned_stream", bufs), ("pageable_stream", [host, host.copy()])):
+            for k in range(3):
+                pipe.push_host(arrs[k % 2], unpack=False)
+            pipe.flush(unpack=False)
+            found, steps = 0, 8
+            t = time.perf_counter()
+            for k in range(steps):
+                done = pipe.push_host(arrs[k % 2], unpack=False)
+                found += sum(done[0]) if done else 0
+            found += sum(sum(d[0]) for d in pipe.flush(unpack=False))
+            dt = time.perf_counter() - t
+            out[name] = {"value": round(B * steps / dt, 1), "unit": "frames/s", "ms_per_step": round(dt / steps * 1e3, 3),
+                         "pcie_GBps": round(B * W * H * steps / dt / 1e9, 2), "markers_per_frame_found": round(found / (B * steps), 2),
+                         "in_flight": 2}
     return out
 
 
@@ -378,6 +399,81 @@ def jpeg_to_markers(local_rank, files, Q=1):
                         "decoding one piece ahead of the detector"}
 
 
+def jpeg_stream_to_markers(local_rank, files, n_batches=6):
+    """A STREAM of JPEG batches (the node with `transport:=compressed`, frames keep coming): a decoder thread works one batch ahead
+    (three decoder contexts in turn: a decoded batch stays in its context until its markers are out), the detector side keeps two
+    batches in flight on two contexts (fid_submit_device / fid_collect / fid_order_after).  The entropy decoder's passes are
+    latency-bound and so is the detector's end: side by side they fill each other's gaps."""
+    import threading
+
+    from fiducials_amd import jpeg as fj
+    from fiducials_amd.detector import ArucoDetector
+    from fiducials_amd.synth import K_DEFAULT
+
+    B = len(files)
+    J = 3
+    decs = [fj.JpegDecoder(max_width=W, max_height=H, max_batch=B, device=local_rank) for _ in range(J)]
+    dets = [ArucoDetector("DICT_5X5_250", device=local_rank, max_width=W, max_height=H, max_batch=B, max_markers=64, max_candidates=2048)
+            for _ in range(2)]
+    D = np.zeros(5)
+
+    def run(n):
+        ready = [threading.Event() for _ in range(n)]
+        freed = [threading.Event() for _ in range(n)]
+        err = []
+
+        def decode_side():
+            try:
+                for k in range(n):
+                    if k >= J:
+                        freed[k - J].wait()
+                    decs[k % J].decode(files, "mono8", to_host=False)
+                    ready[k].set()
+            except Exception as e:  # noqa: BLE001
+                err.append(e)
+                for ev in ready:
+                    ev.set()
+
+        th = threading.Thread(target=decode_side)
+        th.start()
+        found = 0
+
+        def collect(k):
+            nonlocal found
+            found += sum(dets[k % 2].collect(unpack=False))
+            dets[k % 2].pose_last(FIDUCIAL_LEN, K_DEFAULT, D, unpack=False)
+            freed[k].set()
+
+        for k in range(n):
+            ready[k].wait()
+            if err:
+                break
+            if k >= 2:
+                collect(k - 2)
+            ptr, w, h, _, _ = decs[k % J].device_ptr()
+            dets[k % 2].submit_device(ptr, B, w, h, after=dets[(k - 1) % 2])
+        if not err:
+            for k in range(max(n - 2, 0), n):
+                collect(k)
+        th.join()
+        if err:
+            raise err[0]
+        return found
+
+    run(3)
+    t = time.perf_counter()
+    found = run(n_batches)
+    dt = time.perf_counter() - t
+    for d in decs:
+        d.close()
+    for d in dets:
+        d.close()
+    return {"value": round(B * n_batches / dt, 1), "unit": "frames/s", "ms_per_step": round(dt / n_batches * 1e3, 3),
+            "markers_per_frame_found": round(found / (B * n_batches), 2),
+            "workload": f"a stream of {n_batches} batches of {B} JPEG frames in host memory -> fid_jpeg_decode (device gray) -> fid_submit_device / "
+                        "fid_collect + fid_pose_last: the decoder one batch ahead, two detector contexts in turn"}
+
+
 def jpeg_side_result(local_rank, frames):
     """The ingest in front of the hot path when the node runs with its launch default `transport:=compressed`
     (aruco_detect.launch:6): the bench frames as compressed_image_transport sends them (libjpeg defaults: 4:2:0, quality 80),
@@ -425,6 +521,10 @@ def jpeg_side_result(local_rank, frames):
         out["jpeg_to_markers"] = jpeg_to_markers(local_rank, files)
     except Exception as e:  # noqa: BLE001
         out["jpeg_to_markers"] = {"error": repr(e)}
+    try:
+        out["jpeg_stream_to_markers"] = jpeg_stream_to_markers(local_rank, files)
+    except Exception as e:  # noqa: BLE001
+        out["jpeg_stream_to_markers"] = {"error": repr(e)}
     one = fj.JpegDecoder(max_width=W, max_height=H, max_batch=1, device=local_rank)
     det = ArucoDetector("DICT_5X5_250", device=local_rank, max_width=W, max_height=H, max_batch=1, max_markers=64)
     ts, te = [], []

@@ -73,7 +73,7 @@ TAP_MASKS, TAP_CANDIDATES, TAP_FILTERED, TAP_BITS, TAP_IDENT, TAP_PRESUBPIX, TAP
 # every symbol include/fid_abi.h declares
 SYMBOLS = [
     "fid_default_params", "fid_default_limits", "fid_create", "fid_destroy", "fid_set_params", "fid_detect",
-    "fid_detect_batch", "fid_detect_device", "fid_submit_device", "fid_collect", "fid_order_after", "fid_pose", "fid_pose_last", "fid_tap_bytes", "fid_tap_read",
+    "fid_detect_batch", "fid_detect_device", "fid_submit_device", "fid_submit_batch", "fid_collect", "fid_order_after", "fid_pose", "fid_pose_last", "fid_tap_bytes", "fid_tap_read",
     "fid_last_stage_ms", "fid_last_launches", "fid_stream", "fid_strerror", "fid_last_error", "fid_abi_version",
     "fid_stag_create", "fid_stag_destroy", "fid_stag_edge_frontend", "fid_stag_detect_edges", "fid_stag_detect_edges_validated", "fid_stag_detect_lines", "fid_stag_detect_lines_validated", "fid_stag_detect_quads", "fid_stag_host_tables", "fid_stag_load_library", "fid_stag_detect_markers_unrefined", "fid_stag_detect_markers", "fid_stag_pose_last", "fid_stag_detect_markers_batch", "fid_stag_tap_bytes", "fid_stag_tap_read",
     "fid_jpeg_probe", "fid_jpeg_create", "fid_jpeg_destroy", "fid_jpeg_decode", "fid_jpeg_device_ptr", "fid_jpeg_tap_bytes", "fid_jpeg_tap_read",
@@ -115,6 +115,7 @@ def load():
     L.fid_detect_batch.argtypes = [vp, vp, i32, i32, i32, i32, i64, C.c_int, C.POINTER(FidMarker), i32, C.POINTER(i32)]
     L.fid_detect_device.argtypes = [vp, vp, i32, i32, i32, i32, i64, C.c_int, C.POINTER(FidMarker), i32, C.POINTER(i32)]
     L.fid_submit_device.argtypes = [vp, vp, i32, i32, i32, i32, i64, C.c_int]
+    L.fid_submit_batch.argtypes = [vp, vp, i32, i32, i32, i32, i64, C.c_int]
     L.fid_collect.argtypes = [vp, C.POINTER(FidMarker), i32, C.POINTER(i32)]
     L.fid_order_after.argtypes = [vp, vp]
     L.fid_pose.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(FidMarker), C.POINTER(C.c_double),

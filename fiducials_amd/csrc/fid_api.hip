@@ -295,6 +295,16 @@ struct SubPlan {
 SubPlan plan_sub_batches(const fid_ctx *c, int F)
 {
     SubPlan pl;
+    if (c->chained && c->sub_frames <= 0 && !getenv("FID_SUB_SHARES")) {
+        // a batch in a chain of batches on two contexts (fid_order_after) IS the other half: the batch before it on the other
+        // context plays the part of the first sub-batch, for ever, with no call boundary at which the last piece's latency-bound
+        // end has the chip to itself.  Measured, 256 frames a batch, two contexts: whole batches 30.5 k frames/s, 64 % + 36 %
+        // pieces 29.5 k (and 26.5 k for one context, one call after the other).
+        pl.nsub = 1;
+        pl.f0[0] = 0;
+        pl.f0[1] = F;
+        return pl;
+    }
     if (c->sub_frames <= 0 && c->host_feed && F >= 64) {
         // frames that come up from the host while the call runs (the link, ~45 GB/s under load, is slower than the kernels):
         // four pieces -- the first kernels start after a fifth of the copy, the copy engine never idles, and what is left to
@@ -309,16 +319,6 @@ SubPlan plan_sub_batches(const fid_ctx *c, int F)
             acc += k == 3 ? F - acc : (F * share[k] + 50) / 100;
         }
         pl.f0[4] = F;
-        return pl;
-    }
-    if (c->chained && c->sub_frames <= 0 && !getenv("FID_SUB_SHARES")) {
-        // a batch in a chain of batches on two contexts (fid_order_after) IS the other half: the batch before it on the other
-        // context plays the part of the first sub-batch, for ever, with no call boundary at which the last piece's latency-bound
-        // end has the chip to itself.  Measured, 256 frames a batch, two contexts: whole batches 30.5 k frames/s, 64 % + 36 %
-        // pieces 29.5 k (and 26.5 k for one context, one call after the other).
-        pl.nsub = 1;
-        pl.f0[0] = 0;
-        pl.f0[1] = F;
         return pl;
     }
     // resident frames: two halves measured best (more streams fight for CUs)
@@ -1183,8 +1183,9 @@ fid_status fid_collect(fid_ctx *c, fid_marker *out, int32_t cap_per_frame, int32
     return finish_detect(c, out, cap_per_frame, n_per_frame);
 }
 
-fid_status fid_detect_batch(fid_ctx *c, const uint8_t *imgs, int32_t nframes, int32_t width, int32_t height, int32_t stride,
-                            int64_t frame_stride, fid_encoding enc, fid_marker *out, int32_t cap_per_frame, int32_t *n_per_frame)
+// frames in host memory: the copies go on the copy stream, the pipeline is enqueued behind them (fid_detect_batch, fid_submit_batch)
+static fid_status feed_and_enqueue(fid_ctx *c, const uint8_t *imgs, int32_t nframes, int32_t width, int32_t height, int32_t stride,
+                                   int64_t frame_stride, fid_encoding enc)
 {
     if (!c || !imgs || nframes < 1 || height < 1 || stride < 1) return FID_E_INVALID_ARG;
     if (nframes > c->lim.max_batch) return FID_E_INVALID_ARG;
@@ -1205,7 +1206,8 @@ fid_status fid_detect_batch(fid_ctx *c, const uint8_t *imgs, int32_t nframes, in
     // The frames go up in the pieces run_detect works in, one asynchronous copy per sub-batch on the copy stream with an event
     // behind it; a sub-batch's stream waits for its own event only, so the copy of sub-batch k + 1 runs under the kernels of
     // sub-batch k (pinned host memory -- a capture ring buffer -- copies at link speed; pageable memory is staged by the runtime
-    // and copies more slowly, the overlap is the same).
+    // and copies more slowly, the overlap is the same).  A batch of a chain (fid_order_after) is one piece: its copy runs
+    // under the kernels of the batch before it, on the other context.
     c->host_feed = getenv("FID_NO_FEED_OVERLAP") == nullptr;
     if (c->host_feed && !c->copy_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
     const SubPlan plan = plan_sub_batches(c, nframes);
@@ -1222,8 +1224,28 @@ fid_status fid_detect_batch(fid_ctx *c, const uint8_t *imgs, int32_t nframes, in
             HIPCHK(c, hipEventRecord(c->in_ready[sb], c->copy_stream));
         }
     }
-    const fid_status rc = run_detect(c, c->d_in, nframes, width, height, stride, frame_stride, enc, out, cap_per_frame, n_per_frame);
+    const fid_status rc = enqueue_detect(c, c->d_in, nframes, width, height, stride, frame_stride, enc);
     c->host_feed = false;
+    return rc;
+}
+
+fid_status fid_detect_batch(fid_ctx *c, const uint8_t *imgs, int32_t nframes, int32_t width, int32_t height, int32_t stride,
+                            int64_t frame_stride, fid_encoding enc, fid_marker *out, int32_t cap_per_frame, int32_t *n_per_frame)
+{
+    if (!out || !n_per_frame || cap_per_frame < 0) return FID_E_INVALID_ARG;
+    const fid_status rc = feed_and_enqueue(c, imgs, nframes, width, height, stride, frame_stride, enc);
+    if (rc != FID_OK) return rc;
+    return finish_detect(c, out, cap_per_frame, n_per_frame);
+}
+
+fid_status fid_submit_batch(fid_ctx *c, const uint8_t *imgs, int32_t nframes, int32_t width, int32_t height, int32_t stride,
+                            int64_t frame_stride, fid_encoding enc)
+{
+    const fid_status rc = feed_and_enqueue(c, imgs, nframes, width, height, stride, frame_stride, enc);
+    if (c) {
+        c->wait_ev = nullptr;
+        c->chained = false;
+    }
     return rc;
 }
 

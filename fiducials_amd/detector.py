@@ -169,9 +169,25 @@ class ArucoDetector:
                                               _lib.ENC[encoding]))
         self._submitted = nframes
 
+    def submit_batch(self, images: np.ndarray, encoding: str | None = None, after: "ArucoDetector | None" = None) -> None:
+        """First half of detect_markers_batch (fid_submit_batch): frames in host memory -- a C-contiguous uint8 array that the
+        caller keeps alive and unchanged until collect()."""
+        imgs = images
+        if imgs.dtype != np.uint8 or not imgs.flags.c_contiguous:
+            raise ValueError("submit_batch takes a C-contiguous uint8 array (no hidden copy: the memory is read until collect())")
+        if encoding is None:
+            encoding = "mono8" if imgs.ndim == 3 else "bgr8"
+        if after is not None:
+            self._check(self._L.fid_order_after(self._ctx, after._ctx))
+        f, h, w = imgs.shape[:3]
+        self._check(self._L.fid_submit_batch(self._ctx, imgs.ctypes.data, f, w, h, imgs.strides[1], imgs.strides[0], _lib.ENC[encoding]))
+        self._submitted = f
+        self._held = imgs  # (keeps the array alive)
+
     def collect(self, unpack: bool = True):
         """Second half: wait for the submitted batch and return what detect_markers_device would have (fid_collect)."""
         self._check(self._L.fid_collect(self._ctx, self._out, self.max_markers, self._n))
+        self._held = None
         nframes = self._last_frames = self._submitted
         if not unpack:
             return [int(self._n[f]) for f in range(nframes)]

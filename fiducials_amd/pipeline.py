@@ -58,6 +58,19 @@ class BatchPipeline:
         self._busy.append(i)
         return done
 
+    def push_host(self, images: np.ndarray, unpack: bool = True, **kw):
+        """push() for a batch in HOST memory (fid_submit_batch): its copy runs under the kernels of the batch before it.  The array
+        must stay unchanged until the batch's results have been returned."""
+        done = None
+        if len(self._busy) == self.depth:
+            done = self._collect_oldest(unpack)
+        i = self._next
+        self._next = (i + 1) % self.depth
+        prev = self.detectors[(i - 1) % self.depth] if (self.ordered and self.depth > 1) else None
+        self.detectors[i].submit_batch(images, after=prev, **kw)
+        self._busy.append(i)
+        return done
+
     def flush(self, unpack: bool = True):
         """Results of every batch still in flight, oldest first."""
         out = []

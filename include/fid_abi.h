@@ -38,7 +38,7 @@ extern "C" {
 /* 1: round 1 (aruco path).  2: + fid_detect_device / fid_pose_last / limits, the fid_stag_* family, the fid_jpeg_* family (round 2,
  * which forgot to bump it).  3: fid_last_stage_ms reports 15 stages (seedless_chain); fid_pose_last may hand over poses that the
  * preceding fid_detect_* call already computed for the same camera; fid_stag_detect_markers_batch reports 0 markers for a frame
- * whose slot was too small (round 3).  4: + fid_submit_device / fid_collect / fid_order_after (round 3).  Entry points are only ever added: a caller
+ * whose slot was too small (round 3).  4: + fid_submit_device / fid_submit_batch / fid_collect / fid_order_after (round 3).  Entry points are only ever added: a caller
  * built against 1 runs against 4. */
 #define FID_ABI_VERSION 4
 
@@ -152,10 +152,14 @@ fid_status fid_detect_device(fid_ctx *ctx, const void *d_imgs, int32_t nframes, 
  * pipeline of one batch on the context's streams and returns without waiting; fid_collect waits for it and hands out what
  * fid_detect_device would have (fid_pose_last then refers to that batch).  With two or three contexts in turn -- submit k + 1,
  * collect k -- the latency-bound end of one batch runs under the front of the next.  One batch per context at a time:
- * fid_submit_device / fid_detect_* / fid_pose_last / fid_tap_read on a context with a batch in flight return
+ * fid_submit_* / fid_detect_* / fid_pose_last / fid_tap_read on a context with a batch in flight return
  * FID_E_INVALID_ARG; d_imgs must stay valid until fid_collect returns. */
 fid_status fid_submit_device(fid_ctx *ctx, const void *d_imgs, int32_t nframes, int32_t width, int32_t height,
                              int32_t stride_bytes, int64_t frame_stride_bytes, fid_encoding enc);
+/* the same first half for frames in HOST memory (fid_detect_batch's): imgs must stay valid until fid_collect returns; from pinned
+ * memory the call returns at once and the copy runs under the kernels of the batch before it */
+fid_status fid_submit_batch(fid_ctx *ctx, const uint8_t *imgs, int32_t nframes, int32_t width, int32_t height,
+                            int32_t stride_bytes, int64_t frame_stride_bytes, fid_encoding enc);
 fid_status fid_collect(fid_ctx *ctx, fid_marker *out, int32_t cap_per_frame, int32_t *n_per_frame);
 /* Optional, before fid_submit_device(ctx): that batch's first kernel starts when the batch in flight on `prev` (another context of
  * the same device; NULL or nothing in flight: no order) has its chip-filling kernels behind it -- the fronts of two batches then

@@ -76,3 +76,32 @@ def test_one_batch_per_context_at_a_time():
         assert sum(len(x[1]) for x in a) > 0
     finally:
         det.close()
+
+
+def test_host_fed_batches_in_flight_equal_fid_detect_batch():
+    """fid_submit_batch: batches in host memory (pageable and pinned) through two contexts in turn against fid_detect_batch."""
+    torch = pytest.importorskip("torch")
+    B, NB, w, h = 64, 4, 640, 480  # (64 frames: fid_detect_batch sends a batch up in four pieces, a chained batch in one)
+    _, frames = _batches(torch, NB, B, w, h)
+    host = [frames[k * B:(k + 1) * B].copy() for k in range(NB)]
+    ref = ArucoDetector(6, max_width=w, max_height=h, max_batch=B, max_markers=32)
+    want = []
+    for k in range(NB):
+        m = ref.detect_markers_batch(host[k])
+        want.append((m, ref.pose_last(0.14, K_DEFAULT, np.zeros(5))))
+    assert ref.last_launches() == 4
+    ref.close()
+    for arrs in (host, [torch.from_numpy(a).pin_memory().numpy() for a in host]):
+        with BatchPipeline(6, depth=2, fiducial_len=0.14, K=K_DEFAULT, D=np.zeros(5), max_width=w, max_height=h, max_batch=B,
+                           max_markers=32) as pipe:
+            got = [d for d in (pipe.push_host(a) for a in arrs) if d is not None] + pipe.flush()
+            assert all(d.last_launches() == 1 for d in pipe.detectors)
+            with pytest.raises(ValueError):
+                pipe.push_host(arrs[0][:, :, ::2])  # not contiguous: refused, never copied behind the caller's back
+        assert len(got) == NB
+        for k in range(NB):
+            (gm, gp), (wm, wp) = got[k], want[k]
+            for f in range(B):
+                assert gm[f][1].tolist() == wm[f][1].tolist() and len(gm[f][1]) > 0, (k, f)
+                assert np.array_equal(gm[f][0], wm[f][0]), (k, f)
+                assert np.array_equal(gp[f].tvecs, wp[f].tvecs), (k, f)

@@ -1,9 +1,13 @@
 #!/usr/bin/env python3
 """rocprofv3 --pmc SQ_* counter_collection.csv files -> per kernel and frame wave-instruction counts (table on stdout,
-gpurun_out/pmcsq/sq_summary.json).  Usage: sq_summary.py <frames per launch> <csv> [<csv> ...]"""
+gpurun_out/pmcsq/sq_summary.json).  Usage: sq_summary.py <frames per launch> <csv> [<csv> ...]
+A kernel that is launched several times per call (k_approx: two launches on each of two streams; k_seg_cycles / k_seg_copy: one
+per stream) is summed over its launches: the divisor is the number of CALLS = the dispatches of k_sort_cands (once per call)."""
 import collections
 import csv
+import hashlib
 import json
+import os
 import sys
 
 B = int(sys.argv[1])
@@ -16,20 +20,25 @@ for path in sys.argv[2:]:
         disp[(k, path)].add(r["Dispatch_Id"])
 names = ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_WAVES", "SQ_WAVE_CYCLES",
          "SQ_BUSY_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_INST_ANY", "SQ_LDS_BANK_CONFLICT", "GRBM_GUI_ACTIVE"]
+lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "fiducials_amd", "lib", "libfid_amd.so")
 out = {"frames_per_launch": B,
-       "note": "per kernel: counter sums over all dispatches of the run / (dispatches x frames per launch); one launch = one "
-               "sub-batch of frames_per_launch frames; INSTS_* are wave-instructions per frame",
+       "library_sha256": hashlib.sha256(open(lib, "rb").read()).hexdigest() if os.path.exists(lib) else None,
+       "trace_mode": os.environ.get("FID_TRACE", "cycles"),
+       "note": "per kernel: counter sums over all dispatches of the run / (calls x frames per call); a call = one sub-batch of "
+               "frames_per_launch frames through the whole pipeline; kernels launched several times per call are summed over "
+               "their launches (launches_per_call); INSTS_* are wave-instructions per frame",
        "kernels": {}}
+calls = max((len(v) for (k, p), v in disp.items() if k == "k_sort_cands"), default=1)
+out["calls"] = calls
 print("kernel".ljust(30), "disp", *[n[-13:].rjust(14) for n in names])
 tot = collections.defaultdict(float)
 for k in sorted(acc, key=lambda k: -acc[k].get("SQ_INSTS_VALU", 0)):
     n = max(len(disp[(k, p)]) for p in sys.argv[2:] if (k, p) in disp)
-    calls_per_batch = 2 if k == "k_approx" else 1  # two launches of k_approx per sub-batch
-    per = {c: acc[k].get(c, 0.0) / (n / calls_per_batch * B) for c in names}
+    per = {c: acc[k].get(c, 0.0) / (calls * B) for c in names}
     if k.startswith("k_"):
         for c in names:
             tot[c] += per[c]
-    out["kernels"][k] = {"dispatches": n, **{c: round(per[c], 1) for c in names}}
+    out["kernels"][k] = {"dispatches": n, "launches_per_call": round(n / calls, 2), **{c: round(per[c], 1) for c in names}}
     print(k[:30].ljust(30), str(n).rjust(4), *[f"{per[c]:14.0f}" for c in names])
 out["pipeline_per_frame"] = {c: round(tot[c], 1) for c in names}
 print("pipeline".ljust(30), "    ", *[f"{tot[c]:14.0f}" for c in names])

@@ -751,23 +751,46 @@ __device__ __forceinline__ unsigned seedhash_find(const unsigned long long *__re
 //   hole border start: the pixel left of the first pixel of a horizontal background run whose every
 //     pixel has foreground above it (necessary for the run to hold the raster-first pixel of a
 //     4-connected hole); the run start itself has foreground N by the same test
-// Runs are tested inside one 32-bit word with a Kogge-Stone fill; a run that crosses a word border is
+// Runs are tested inside one 32-bit word (fill_toward_lsb below); a run that crosses a word border is
 // kept as a candidate (K3 makes the exact decision by walking).  32 pixels per lane-op, one atomic per
 // workgroup iteration on a per-frame counter.
+// (In the bit-reversed word the spread is the carry chain of ONE addition: a seed bit plus the run's own bit carries through the
+//  rest of the run and stops in the zero behind it -- two instructions and the reversals instead of a five-level Kogge-Stone
+//  fill; v_bfrev_b32 is a full-rate instruction.)
+__device__ __forceinline__ uint32_t fill_toward_msb_rev(uint32_t rseed, uint32_t rruns)
+{
+    // rseed must be a subset of rruns; both bit-reversed, and so is the result
+    const uint32_t t = rruns + rseed;
+    return (t & rseed) | (~t & rruns);  // the seeds themselves, and the bits of the run the carry went through
+}
 __device__ __forceinline__ uint32_t fill_toward_lsb(uint32_t seed, uint32_t runs)
 {
     // spread every seed bit to all lower bits of its run of ones in `runs`
-    uint32_t f = seed & runs, m = runs;
-    f |= (f >> 1) & m;
-    m &= m >> 1;
-    f |= (f >> 2) & m;
-    m &= m >> 2;
-    f |= (f >> 4) & m;
-    m &= m >> 4;
-    f |= (f >> 8) & m;
-    m &= m >> 8;
-    f |= (f >> 16) & m;
-    return f;
+    const uint32_t m = __brev(runs);
+    return __brev(fill_toward_msb_rev(__brev(seed) & m, m));
+}
+// bit 0 of fill_toward_lsb(seed, runs): does the run that holds bit 0 hold a seed
+__device__ __forceinline__ uint32_t low_run_has_seed(uint32_t seed, uint32_t runs)
+{
+    const uint32_t low = runs & ~(runs + 1u);  // the run of ones that starts at bit 0 (empty if bit 0 is clear)
+    return (low & seed) != 0u ? 1u : 0u;
+}
+
+// a / b and a % b for a < 2^22 (group numbers: scales x tile rows x column groups) with the reciprocal of b at hand: eight
+// instructions.  (The compiler's expansion of a 64-bit division is ~ 90 VALU instructions, and this kernel had twelve of them in
+// its loop body: 60 % of everything it executed.)
+__device__ __forceinline__ void divmod_small(unsigned a, unsigned b, float rcp_b, unsigned &q, unsigned &r)
+{
+    q = (unsigned)((float)a * rcp_b);  // off by at most one
+    int rr = (int)(a - q * b);
+    if (rr < 0) {
+        q--;
+        rr += (int)b;
+    } else if (rr >= (int)b) {
+        q++;
+        rr -= (int)b;
+    }
+    r = (unsigned)rr;
 }
 
 // One thread per mask word column x 4 rows (one 16-byte load per word column: its own, the left and the right
@@ -795,11 +818,12 @@ __global__ __launch_bounds__(256) void k_find_starts(const uint32_t *__restrict_
     __shared__ int s_wsum[2][4];
     __shared__ unsigned s_base[2];
     __shared__ uint8_t s_items[4][128];
-    const int lane = lane_id(), wid = threadIdx.x >> 6;
+    const int lane = lane_id(), wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int f = blockIdx.y;
     const int WW = P.WW, TC = P.TC, TR = P.TR, H = P.H, S = P.nscales;
-    const int CG = (WW + 15) / 16;                     // groups of 16 word columns
-    const long long ngroups = (long long)S * TR * CG;  // a group = 16 word columns x 16 rows (one tile row)
+    const int CG = (WW + 15) / 16;     // groups of 16 word columns
+    const int ngroups = S * TR * CG;   // a group = 16 word columns x 16 rows (one tile row); < 2^22 for every supported size
+    const float rcpTR = 1.0f / (float)TR, rcpCG = 1.0f / (float)CG;
     const long long plane = (long long)TR * TC * MT_ROWS;
     const unsigned cap = (unsigned)P.maxStarts, scap = (unsigned)P.maxContours;
     const bool drop1 = P.minPerim > 1, drop8 = P.minPerim > 8;
@@ -814,29 +838,37 @@ __global__ __launch_bounds__(256) void k_find_starts(const uint32_t *__restrict_
     const int ncol = S * CG;                                   // (scale, column group) pairs
     const bool by_xcd = (gridDim.x & 7) == 0 && ncol >= 8;
     const int xcd = blockIdx.x & 7, lb = blockIdx.x >> 3, nlb = gridDim.x >> 3;
-    const long long mycols = by_xcd ? (ncol - xcd + 7) / 8 : 0;  // columns xcd, xcd + 8, ...
-    const long long nitems = by_xcd ? mycols * TR : ngroups;     // groups this workgroup's XCD share holds
-    const long long nit8 = (nitems + 7) & ~7LL;
-    auto group_of = [&](long long it) -> long long {  // the it-th group of this share (ngroups: none)
-        if (it >= nitems) return ngroups;
-        if (!by_xcd) return it;
-        const long long col = xcd + 8 * (it / TR), trr = it % TR;  // col = s * CG + cg
-        return ((col / CG) * TR + trr) * CG + col % CG;
+    const int mycols = by_xcd ? (ncol - xcd + 7) / 8 : 0;  // columns xcd, xcd + 8, ...
+    const int nitems = by_xcd ? mycols * TR : ngroups;     // groups this workgroup's XCD share holds
+    const int nit8 = (nitems + 7) & ~7;
+    // the it-th group of this share as (scale, tile row, column group); false: none
+    auto group_of = [&](int it, int &gs, int &gtr, int &gcg) -> bool {
+        if (it >= nitems) return false;
+        unsigned a, b, c, d;
+        if (by_xcd) {
+            divmod_small((unsigned)it, (unsigned)TR, rcpTR, a, b);  // a-th column of this XCD, tile row b
+            divmod_small((unsigned)xcd + 8u * a, (unsigned)CG, rcpCG, c, d);  // column = s * CG + cg
+            gs = (int)c;
+            gtr = (int)b;
+            gcg = (int)d;
+        } else {
+            divmod_small((unsigned)it, (unsigned)CG, rcpCG, a, b);  // it = (s * TR + tr) * CG + cg
+            divmod_small(a, (unsigned)TR, rcpTR, c, d);
+            gs = (int)c;
+            gtr = (int)d;
+            gcg = (int)b;
+        }
+        return true;
     };
-    for (long long i0 = by_xcd ? (long long)lb * 8 : (long long)blockIdx.x * 8; i0 < nit8;
-         i0 += (by_xcd ? (long long)nlb : (long long)gridDim.x) * 8) {
+    for (int i0 = by_xcd ? lb * 8 : (int)blockIdx.x * 8; i0 < nit8; i0 += (by_xcd ? nlb : (int)gridDim.x) * 8) {
         // ---- phase A: which word columns of the wave's two groups hold any foreground in their four rows
-        long long gsel[2];
+        int gs[2] = {0, 0}, gtr[2] = {0, 0}, gcg[2] = {0, 0};
         unsigned long long msel[2];
 #pragma unroll
         for (int t = 0; t < 2; t++) {
-            const long long g = group_of(i0 + 2 * wid + t);
-            gsel[t] = g;
             int nz = 0;
-            if (g < ngroups) {
-                const int cg = (int)(g % CG);
-                const long long q = g / CG;
-                const int tr = (int)(q % TR), s = (int)(q / TR);
+            if (group_of(i0 + 2 * wid + t, gs[t], gtr[t], gcg[t])) {
+                const int cg = gcg[t], tr = gtr[t], s = gs[t];
                 const int w = cg * 16 + (lane >> 2), r4 = (lane & 3) * 4, yy0 = tr * MT_ROWS + r4;
                 if (w < WW && yy0 <= H && yy0 + 3 >= 1) {
                     const uint4 c4 = *reinterpret_cast<const uint4 *>(fmasks + (long long)s * plane + ((long long)tr * TC + MASK_PADW + w) * MT_ROWS + r4);
@@ -864,11 +896,9 @@ __global__ __launch_bounds__(256) void k_find_starts(const uint32_t *__restrict_
             const int idx = r * 64 + lane;
             if (idx < nsel) {
                 const int item = s_items[wid][idx];
-                const long long g = gsel[item >> 6];
+                const bool second = (item >> 6) != 0;
                 const int l = item & 63;
-                const int cg = (int)(g % CG);
-                const long long q = g / CG;
-                const int tr = (int)(q % TR), s = (int)(q / TR);
+                const int cg = second ? gcg[1] : gcg[0], tr = second ? gtr[1] : gtr[0], s = second ? gs[1] : gs[0];
                 const int w = cg * 16 + (l >> 2), r4 = (l & 3) * 4;
                 const int yy0 = tr * MT_ROWS + r4;  // padded row of this item's first row; image row = yy - 1
                 const int xb = w * 32;
@@ -909,15 +939,16 @@ __global__ __launch_bounds__(256) void k_find_starts(const uint32_t *__restrict_
                     const uint32_t below = d | (d << 1) | (prevd >> 31) | (d >> 1) | (nextd << 31);
                     // outer: starts of foreground runs that have no foreground above (N / NW / NE) anywhere
                     const uint32_t touch = cur & (NW | u | NE);
-                    uint32_t o = cur & ~Wst & ~fill_toward_lsb(touch, cur);
+                    const uint32_t rcur = __brev(cur);
+                    uint32_t o = cur & ~Wst & ~__brev(fill_toward_msb_rev(__brev(touch), rcur));
                     if (drop1) o &= Est | below;  // an isolated pixel is a complete 1-point contour
                     // hole: first pixel e of a background run (W neighbour foreground) that is closed above;
                     // the border-following start is the foreground pixel LEFT of e
                     const uint32_t bg = ~cur;
                     const uint32_t open = bg & ~u;  // background with background above: joins an earlier pixel
-                    uint32_t e = bg & Wst & ~fill_toward_lsb(open, bg);
+                    uint32_t e = bg & Wst & ~__brev(fill_toward_msb_rev(__brev(open), ~rcur));
                     const uint32_t bgn = ~nextc;
-                    uint32_t en0 = bgn & (cur >> 31) & ~fill_toward_lsb(bgn & ~nextu, bgn) & 1u;
+                    uint32_t en0 = bgn & (cur >> 31) & ~low_run_has_seed(bgn & ~nextu, bgn) & 1u;
                     if (drop8) {
                         // a background pixel whose four 4-neighbours are foreground is a whole hole of its own
                         e &= ~(u & d & Est);  // W is foreground by construction
@@ -931,30 +962,40 @@ __global__ __launch_bounds__(256) void k_find_starts(const uint32_t *__restrict_
                         // of a word that starts on one, horizontal-component directions; the diagonal ones of a pixel that is
                         // on both lines belong to the row)
                         const bool grow = (y & gm) == 0, gcol = (xb & gm) == 0;
-                        if (grow || gcol) {
+                        if (gcol) {
+                            // column seeds are states of pixel 0 of the word: bit 0 of the eight neighbour planes as one byte
+                            // (bit dd = neighbour in direction dd: E NE N NW W SW S SE), the "must be empty" neighbours the
+                            // same byte rotated by seed_empty_dir (odd directions + 1, even ones + 2)
+                            uint32_t n8 = (cur >> 1) & 1u;            // E
+                            n8 |= u & 2u;                             // NE = pixel 1 of the row above
+                            n8 |= (u & 1u) << 2;                      // N
+                            n8 |= (prevu >> 31) << 3;                 // NW
+                            n8 |= (prevc >> 31) << 4;                 // W
+                            n8 |= (prevd >> 31) << 5;                 // SW
+                            n8 |= (d & 3u) << 6;                      // S, SE = pixels 0, 1 of the row below
+                            const uint32_t x16 = n8 | (n8 << 8);
+                            const uint32_t e8 = ((x16 >> 1) & 0xAAu) | ((x16 >> 2) & 0x55u);
+                            // (the diagonal directions of a pixel that is on both lines belong to the row)
+                            const uint32_t allowed = grow ? (SEED_DIRS_COL & ~SEED_DIRS_ROW) : SEED_DIRS_COL;
+                            const uint32_t s8 = (cur & 1u) ? (n8 & ~e8 & allowed) : 0u;
+                            colb[r] |= s8 << (k * 8);
+                        }
+                        if (grow) {
                             const uint32_t SEst = (d >> 1) | (nextd << 31), SWst = (d << 1) | (prevd >> 31);
                             const uint32_t nbp[8] = {Est, NE, u, NW, Wst, SWst, d, SEst};  // neighbour planes by direction
                             int ri = 0;
 #pragma unroll
                             for (int dd = 0; dd < 8; dd++) {
+                                if (!((SEED_DIRS_ROW >> dd) & 1u)) continue;
                                 const uint32_t m = cur & nbp[dd] & ~nbp[seed_empty_dir(dd)];
-                                const bool isrow = (SEED_DIRS_ROW >> dd) & 1u, iscol = (SEED_DIRS_COL >> dd) & 1u;
-                                if (isrow) {
-                                    if (grow) {
-                                        rowm[r][ri] = m;
-                                        c2 += __popc(m);
-                                    }
-                                    ri++;
-                                }
-                                if (iscol && gcol && !(isrow && grow) && (m & 1u)) {
-                                    colb[r] |= 1u << (k * 8 + dd);
-                                    c2++;
-                                }
+                                rowm[r][ri++] = m;
+                                c2 += __popc(m);
                             }
-                            if (grow) rowk[r] = k;
+                            rowk[r] = k;
                         }
                     }
                 }
+                if (HYB) c2 += __popc(colb[r]);
                 x_base[r] = xb;
                 yy0v[r] = yy0;
                 sv[r] = s;

@@ -68,6 +68,32 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long k)
     return ((unsigned long long)hi << 32) | lo;
 }
 
+// arg-max with first-index tie-break, in every lane: md = the largest d over the lanes, mi = the smallest idx among the lanes that
+// hold it (a lane with nothing to offer passes d = 0, idx = 0xffffffff).  Two 32-bit reductions whose steps are single DPP
+// instructions (v_max_u32 / v_min_u32 with a DPP operand): ~ 16 instructions where the 64-bit key (d, ~idx) took ~ 72 -- and
+// k_approx does one per farthest-point pass and slice, thirteen per contour.
+__device__ __forceinline__ void wave_argmax_first(unsigned d, unsigned idx, unsigned &md, unsigned &mi)
+{
+    unsigned v = d;
+#define S_(C, M)                                                  \
+    {                                                             \
+        const unsigned o = (unsigned)FID_DPP(0, (int)v, C, M);    \
+        v = o > v ? o : v;                                        \
+    }
+    FID_DPP_SCAN_STEPS(S_)
+#undef S_
+    md = (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+    unsigned w = d == md ? idx : 0xffffffffu;
+#define S_(C, M)                                                  \
+    {                                                             \
+        const unsigned o = (unsigned)FID_DPP(-1, (int)w, C, M);   \
+        w = o < w ? o : w;                                        \
+    }
+    FID_DPP_SCAN_STEPS(S_)
+#undef S_
+    mi = (unsigned)__builtin_amdgcn_readlane((int)w, 63);
+}
+
 __device__ __forceinline__ int wave_min_i32(int v)
 {
 #define S_(C, M)                                  \
@@ -2885,7 +2911,7 @@ __global__ __launch_bounds__(64) void k_approx(uint4 *__restrict__ contours, con
             sy = sp >> 16;
             // points j = 1 .. count-1 at index (pos + j) % count; READ_PT leaves pos back at its start
             // (per lane the largest distance and the FIRST index that has it -- j only grows inside a lane, so a strict compare
-            //  keeps it; the 64-bit key that carries the first-maximum tie-break across lanes is built once per pass, not per point)
+            //  keeps it; the first-maximum tie-break across lanes is wave_argmax_first's, once per pass)
             unsigned bd = 0, bj = 0;
             for (int j = 1 + lane; j < count; j += 64) {
                 int idx = pos + j;
@@ -2897,10 +2923,9 @@ __global__ __launch_bounds__(64) void k_approx(uint4 *__restrict__ contours, con
                 bd = gt ? d : bd;
                 bj = gt ? (unsigned)j : bj;
             }
-            unsigned long long best = bd ? (((unsigned long long)bd << 32) | (0xffffffffu - bj)) : 0ull;
-            best = wave_max_u64(best);
-            unsigned md = (unsigned)(best >> 32);
-            if (md > 0) rs_start = (int)(0xffffffffu - (unsigned)best);
+            unsigned md, mj;
+            wave_argmax_first(bd, bd ? bj : 0xffffffffu, md, mj);
+            if (md > 0) rs_start = (int)mj;
             le_eps = (double)md <= eps;
             // after the loop READ_PT has advanced pos by count (mod count): pos unchanged
         }
@@ -2949,10 +2974,10 @@ __global__ __launch_bounds__(64) void k_approx(uint4 *__restrict__ contours, con
                     lbt = gt ? (unsigned)t : lbt;
                     any = true;
                 }
-                unsigned long long best = any ? (((unsigned long long)lbd << 32) | (0xffffffffu - lbt)) : 0ull;
-                best = wave_max_u64(best);
-                double max_dist = (double)(unsigned)(best >> 32);
-                int bt = (int)(0xffffffffu - (unsigned)best);
+                unsigned mdist, mt;
+                wave_argmax_first(any ? lbd : 0u, any ? lbt : 0xffffffffu, mdist, mt);
+                double max_dist = (double)mdist;
+                int bt = (int)mt;
                 le_eps = max_dist * max_dist <= eps * ((double)dx * dx + (double)dy * dy);
                 if (!le_eps) {
                     split = sl.x + 1 + bt;

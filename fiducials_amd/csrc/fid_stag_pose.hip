@@ -11,9 +11,9 @@
 //   (3) move the 9 entries of H with Nelder-Mead so that H^T C H is the circle (0.5, 0.5, r 0.4): cv::DownhillSolver with its
 //       defaults, restated (see oracle/stag_ref.cpp for the same restatement on the checker's side); cost Refine::calc (:224-258);
 //   (4) corners and centre from the new H.
-// atan / sin / cos come from the device's math library here and from glibc in the reference: the results agree to rounding,
-// the optimiser then follows a path that can differ in the last bits -- this row's parity bar is a tolerance (corners to
-// 1e-3 px), not equality.
+// The reference takes atan / sin / cos of the ellipse's rotation from glibc; here the sine and cosine come from the tangent
+// algebraically (sr_conic_to_ellipse): the results agree to rounding, the optimiser then follows a path that can differ in the
+// last bits -- this row's parity bar is a tolerance (corners to 1e-3 px), not equality.
 struct SrEllipse {
     double A1, B1, C1, D1, E1, F1, cX, cY, a, b;
 };
@@ -23,14 +23,29 @@ struct SrEllipse {
 __device__ void sr_conic_to_ellipse(double A1, double B1, double C1, double D1, double E1, double F1, SrEllipse *e)
 {
     B1 /= A1; C1 /= A1; D1 /= A1; E1 /= A1; F1 /= A1; A1 /= A1;
-    double A2, C2, D2, E2, F2, rotation = 0, sr = 0, cr = 1;  // (the reference leaves rotation unset when B1 == 0)
+    double A2, C2, D2, E2, F2, sr = 0, cr = 1;  // (the reference leaves rotation unset when B1 == 0)
+    bool rotated = false;
     if (B1 == 0) {
         A2 = A1; C2 = C1; D2 = D1; E2 = E1; F2 = F1;
     } else {
-        rotation = atan(B1 / (A1 - C1)) / 2;
+        // rotation = atan(t) / 2 with t = B1 / (A1 - C1); the reference takes cos / sin of 2 * rotation and of rotation from libm.
+        // Here they come from t itself: cos(atan t) = 1 / sqrt(1 + t^2), sin(atan t) = t / sqrt(1 + t^2), and the half angle
+        // (|rotation| <= pi / 4: its cosine is positive) cos r = sqrt((1 + cos 2r) / 2), sin r = sin 2r / (2 cos r) -- two square
+        // roots and three divisions instead of an arctangent and two sincos calls (~ 380 of the ~ 950 dependent f64
+        // instructions of one cost evaluation; the simplex search is a chain of a few hundred of them).  Equal to the libm road
+        // to rounding, like the device's atan / sin / cos were: this row's parity bar is the tolerance stated above.
+        const double t = B1 / (A1 - C1);
         double s2, c2;
-        sincos(2 * rotation, &s2, &c2);
-        sincos(rotation, &sr, &cr);
+        if (fabs(t) > 1e150) {  // A1 == C1 (t infinite: 2 r = +- pi / 2), or t * t would overflow
+            c2 = 0.0;
+            s2 = copysign(1.0, t);
+        } else {
+            c2 = 1.0 / sqrt(1.0 + t * t);
+            s2 = t * c2;
+        }
+        cr = sqrt(0.5 * (1.0 + c2));
+        sr = s2 / (2.0 * cr);
+        rotated = t != 0.0;  // (rotation != 0)
         A2 = 0.5 * (A1 * (1 + c2 + B1 * s2 + C1 * (1 - c2)));
         C2 = 0.5 * (A1 * (1 - c2 - B1 * s2 + C1 * (1 + c2)));
         D2 = D1 * cr + E1 * sr;
@@ -42,7 +57,7 @@ __device__ void sr_conic_to_ellipse(double A1, double B1, double C1, double D1, 
     const double F3 = A2 * (cX * cX) + C2 * (cY * cY) - F2;
     e->a = sqrt(F3 / A2);
     e->b = sqrt(F3 / C2);
-    if (rotation != 0) {
+    if (rotated) {
         const double tx = cX, ty = cY;
         cX = tx * cr - ty * sr;
         cY = tx * sr + ty * cr;

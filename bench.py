@@ -319,16 +319,19 @@ def host_feed_result(local_rank, host, K, D):
             for k in range(3):
                 pipe.push_host(arrs[k % 2], unpack=False)
             pipe.flush(unpack=False)
-            found, steps = 0, 8
-            t = time.perf_counter()
-            for k in range(steps):
-                done = pipe.push_host(arrs[k % 2], unpack=False)
-                found += sum(done[0]) if done else 0
-            found += sum(sum(d[0]) for d in pipe.flush(unpack=False))
-            dt = time.perf_counter() - t
+            steps, runs = 12, []
+            for _ in range(3):  # (the link and the host's cores are shared with other tenants: the median of three runs)
+                found = 0
+                t = time.perf_counter()
+                for k in range(steps):
+                    done = pipe.push_host(arrs[k % 2], unpack=False)
+                    found += sum(done[0]) if done else 0
+                found += sum(sum(d[0]) for d in pipe.flush(unpack=False))
+                runs.append((time.perf_counter() - t, found))
+            dt, found = sorted(runs)[1]
             out[name] = {"value": round(B * steps / dt, 1), "unit": "frames/s", "ms_per_step": round(dt / steps * 1e3, 3),
                          "pcie_GBps": round(B * W * H * steps / dt / 1e9, 2), "markers_per_frame_found": round(found / (B * steps), 2),
-                         "in_flight": 2}
+                         "in_flight": 2, "runs_frames_per_s": [round(B * steps / r[0], 1) for r in runs]}
     return out
 
 
@@ -986,6 +989,9 @@ def main():
         if depth > 1 and not args.no_extras:
             # the same steps one call after the other on one context (fid_detect_device + fid_pose_last), outside the timed region
             k1 = max(3, min(args.steps, 10))
+            for other in pipe.detectors[1:]:  # (their streams would still claim hardware queues beside this one's)
+                other.close()
+            pipe.detectors = pipe.detectors[:1]
             for _ in range(2):  # (the context makes its second sub-batch's streams on the first such call)
                 det.detect_markers_device(d_frames.data_ptr(), B, W, H, unpack=False)
                 det.pose_last(FIDUCIAL_LEN, K, D, unpack=False)

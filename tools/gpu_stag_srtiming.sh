@@ -1,6 +1,9 @@
 #!/bin/bash
 # k_stag_refine phase ticks per marker (library built with -DSR_TIMING into fiducials_amd/lib/dbg/): one cfg 5 frame
 cd /root/repo
+mkdir -p fiducials_amd/lib/dbg
+[ -f fiducials_amd/lib/dbg/libfid_srtiming.so ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -DSR_TIMING \
+    -o fiducials_amd/lib/dbg/libfid_srtiming.so fiducials_amd/csrc/fid_api.hip 2> /dev/null
 FID_LIB=$PWD/fiducials_amd/lib/dbg/libfid_srtiming.so timeout 200 python - <<'PY' 2>&1 | grep -v amdgpu.ids | tail -30
 import sys; sys.path.insert(0,'/root/repo')
 import numpy as np, time

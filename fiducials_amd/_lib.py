@@ -65,6 +65,11 @@ class FidJpegInfo(C.Structure):
                 ("restart_interval", C.c_int32), ("blocks_w", C.c_int32 * 3), ("blocks_h", C.c_int32 * 3), ("scan_bytes", C.c_int64)]
 
 
+class FidPngInfo(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("bit_depth", C.c_int32), ("color_type", C.c_int32), ("interlace", C.c_int32),
+                ("gray", C.c_int32)]
+
+
 FID_OK = 0
 FID_E_INVALID_ARG, FID_E_NO_DEVICE, FID_E_HIP, FID_E_CAPACITY, FID_E_OUT_OF_MEMORY, FID_E_UNSUPPORTED = 1, 2, 3, 4, 5, 6
 ENC = {"mono8": 0, "bgr8": 1, "rgb8": 2, "bgra8": 3, "rgba8": 4}
@@ -78,6 +83,7 @@ SYMBOLS = [
     "fid_stag_create", "fid_stag_destroy", "fid_stag_edge_frontend", "fid_stag_detect_edges", "fid_stag_detect_edges_validated", "fid_stag_detect_lines", "fid_stag_detect_lines_validated", "fid_stag_detect_quads", "fid_stag_host_tables", "fid_stag_load_library", "fid_stag_detect_markers_unrefined", "fid_stag_detect_markers", "fid_stag_pose_last", "fid_stag_detect_markers_batch", "fid_stag_tap_bytes", "fid_stag_tap_read",
     "fid_jpeg_probe", "fid_jpeg_create", "fid_jpeg_destroy", "fid_jpeg_decode", "fid_jpeg_device_ptr", "fid_jpeg_tap_bytes", "fid_jpeg_tap_read",
     "fid_jpeg_last_rounds", "fid_jpeg_last_error",
+    "fid_png_probe", "fid_png_decode", "fid_png_last_error",
 ]
 
 _LIB = None
@@ -167,5 +173,9 @@ def load():
     L.fid_jpeg_last_rounds.restype = i32
     L.fid_jpeg_last_error.argtypes = [vp]
     L.fid_jpeg_last_error.restype = C.c_char_p
+    L.fid_png_probe.argtypes = [vp, i64, C.POINTER(FidPngInfo)]
+    L.fid_png_decode.argtypes = [vp, i64, C.c_int, vp, i64, C.POINTER(FidPngInfo)]
+    L.fid_png_last_error.argtypes = []
+    L.fid_png_last_error.restype = C.c_char_p
     _LIB = L
     return L

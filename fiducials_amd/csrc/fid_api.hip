@@ -1483,3 +1483,4 @@ int32_t fid_abi_version(void) { return FID_ABI_VERSION; }
 
 #include "fid_stag.hip"
 #include "fid_jpeg.hip"
+#include "fid_png.hip"

@@ -31,7 +31,8 @@ struct Image {  // sensor_msgs/Image
 };
 struct CompressedImage {  // sensor_msgs/CompressedImage: what arrives with image_transport's `compressed` (the launch default)
     Header header;
-    std::string format;  // "jpeg", or "bgr8; jpeg compressed bgr8" as compressed_image_transport writes it
+    std::string format;  // "jpeg", "bgr8; jpeg compressed bgr8" or "mono8; png compressed " as compressed_image_transport writes it
+                         // (the data decides: JPEG goes to the device decoder, PNG through fid_png_decode on the host)
     std::vector<uint8_t> data;
 };
 struct CameraInfo {  // sensor_msgs/CameraInfo (the fields the node reads)
@@ -159,6 +160,7 @@ class FiducialsNode {
     bool publishVertices(const Header &h, int32_t n, FiducialArray *out);  // the tail of imageCallback (:342-379)
     fid_ctx *ctx = nullptr;
     fid_jpeg_ctx *jctx = nullptr;  // made when the first compressed frame arrives
+    std::vector<uint8_t> png_frame;  // a PNG frame decoded on the host (fid_png_decode), reused from frame to frame
     int maxW = 0, maxH = 0, dev = 0;
     Dictionary dict;
     fid_params detectorParams;

@@ -320,6 +320,31 @@ bool FiducialsNode::compressedImageCallback(const CompressedImage &msg, Fiducial
     }
     const uint8_t *file = msg.data.data();
     const int64_t nbytes = (int64_t)msg.data.size();
+    static const uint8_t png_sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+    if (nbytes >= 8 && !memcmp(file, png_sig, 8)) {
+        // format "...; png compressed ...": a zlib stream, decoded on the host as the subscriber plugin's cv::imdecode does
+        // (fid_png_decode); gray images stay one byte per pixel, colour ones go up as BGR and are converted on the device
+        fid_png_info pi;
+        fid_status rc = fid_png_probe(file, nbytes, &pi);
+        if (rc == FID_OK && (pi.width > maxW || pi.height > maxH)) rc = FID_E_INVALID_ARG;
+        const fid_encoding enc = pi.gray ? FID_ENC_MONO8 : FID_ENC_BGR8;
+        const int px = pi.gray ? 1 : 3;
+        if (rc == FID_OK) {
+            png_frame.resize((size_t)pi.width * pi.height * px);
+            rc = fid_png_decode(file, nbytes, enc, png_frame.data(), (int64_t)png_frame.size(), nullptr);
+        }
+        if (rc != FID_OK) {
+            last_error = std::string("compressed frame: ") + (rc == FID_E_INVALID_ARG && pi.width > maxW ? "larger than the context" : fid_png_last_error());
+            return false;
+        }
+        int32_t n = 0;
+        rc = fid_detect(ctx, png_frame.data(), pi.width, pi.height, pi.width * px, enc, markers.data(), (int32_t)markers.size(), &n);
+        if (rc != FID_OK) {
+            last_error = fid_last_error(ctx);
+            return false;
+        }
+        return publishVertices(msg.header, n, out);
+    }
     // gray = cvtColor(BGR2GRAY) of what cv::imdecode returns, left on the device
     fid_status rc = fid_jpeg_decode(jctx, &file, &nbytes, 1, FID_ENC_MONO8, nullptr, 0);
     if (rc != FID_OK) {  // (the subscriber plugin logs and drops a frame it cannot decode)

@@ -299,6 +299,30 @@ static void compressed_frame(const Fixture &fx)
     // a frame that is not a JPEG is dropped with a message, as the subscriber plugin does
     cm.data.assign(64, 0x41);
     CHECK(!node.compressedImageCallback(cm, &a) && !node.lastError().empty());
+    // the same frame with `format: png` (lossless: exactly what the raw frame gives), as a gray and as a colour file
+    FiducialArray raw;
+    CHECK(node.imageCallback(load_pgm(fx.image_directory + "/tag_01.pgm", 9), &raw));
+    for (const char *name : {"/tag_01_gray.png", "/tag_01_rgb.png"}) {
+        std::ifstream pf(fx.image_directory + name, std::ios::binary);
+        if (!pf) {
+            std::printf("(no %s: PNG frame check skipped)\n", name + 1);
+            continue;
+        }
+        CompressedImage pm;
+        pm.header.seq = 9;
+        pm.format = "mono8; png compressed ";
+        pm.data.assign(std::istreambuf_iterator<char>(pf), std::istreambuf_iterator<char>());
+        FiducialArray c;
+        CHECK(node.compressedImageCallback(pm, &c));
+        CHECK(c.image_seq == 9 && c.fiducials.size() == raw.fiducials.size() && c.fiducials.size() == 1);
+        for (size_t i = 0; i < c.fiducials.size() && i < raw.fiducials.size(); i++) {
+            const auto &p = c.fiducials[i], &q = raw.fiducials[i];
+            CHECK(p.fiducial_id == q.fiducial_id && p.x0 == q.x0 && p.y0 == q.y0 && p.x1 == q.x1 && p.y1 == q.y1 && p.x2 == q.x2 && p.y2 == q.y2 &&
+                  p.x3 == q.x3 && p.y3 == q.y3);
+        }
+        pm.data.resize(pm.data.size() / 2);  // a truncated file is dropped with a message
+        CHECK(!node.compressedImageCallback(pm, &c) && !node.lastError().empty());
+    }
 }
 
 int main(int argc, char **argv)

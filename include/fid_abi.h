@@ -14,6 +14,8 @@
  *   fid_jpeg_decode
  *        replaces  cv::imdecode in image_transport's compressed subscriber, in front of the callback when
  *        the node runs with the launch default transport:=compressed (aruco_detect.launch:6)
+ *   fid_png_decode
+ *        replaces  cv::imdecode for frames the same subscriber receives with format png (host code, like the reference's)
  *   fid_stag_*   the second front end: Stag::detectMarkers + the 5-point pose of stag_detect
  *   fid_params   mirrors aruco::DetectorParameters as the node fills it      (:690-727)
  *   fid_dict     mirrors aruco::Dictionary{bytesList, markerSize, maxCorrectionBits} as returned
@@ -38,7 +40,7 @@ extern "C" {
 /* 1: round 1 (aruco path).  2: + fid_detect_device / fid_pose_last / limits, the fid_stag_* family, the fid_jpeg_* family (round 2,
  * which forgot to bump it).  3: fid_last_stage_ms reports 15 stages (seedless_chain); fid_pose_last may hand over poses that the
  * preceding fid_detect_* call already computed for the same camera; fid_stag_detect_markers_batch reports 0 markers for a frame
- * whose slot was too small (round 3).  4: + fid_submit_device / fid_submit_batch / fid_collect / fid_order_after (round 3).  Entry points are only ever added: a caller
+ * whose slot was too small (round 3).  4: + fid_submit_device / fid_submit_batch / fid_collect / fid_order_after, fid_png_* (round 3).  Entry points are only ever added: a caller
  * built against 1 runs against 4. */
 #define FID_ABI_VERSION 4
 
@@ -382,6 +384,24 @@ int64_t fid_jpeg_tap_bytes(fid_jpeg_ctx *ctx, fid_jpeg_tap which, int32_t frame)
 fid_status fid_jpeg_tap_read(fid_jpeg_ctx *ctx, fid_jpeg_tap which, int32_t frame, void *dst, int64_t dst_bytes);
 int32_t fid_jpeg_last_rounds(fid_jpeg_ctx *ctx); /* synchronisation rounds the last decode needed (diagnostic) */
 const char *fid_jpeg_last_error(fid_jpeg_ctx *ctx);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Frames that arrive as PNG (compressed_image_transport with format png = cv::imencode(".png") of the camera image).
+ * HOST code: the zlib stream is sequential and the reference decodes it on the CPU as well (cv::imdecode in the subscriber
+ * plugin, in front of imageCallback, aruco_detect.cpp:332); zlib inflates, this library does the container, the row filters and
+ * the conversion.  out_enc FID_ENC_BGR8 = what cv::imdecode(IMREAD_COLOR) returns (alpha dropped, palettes expanded, 1 / 2 / 4
+ * bit gray scaled, 16-bit samples cut to their high byte), FID_ENC_MONO8 = cvtColor(BGR2GRAY) of that; out is width * height *
+ * (3 | 1) tightly packed bytes, then fid_detect(..., FID_ENC_BGR8 | FID_ENC_MONO8).  No device, no context.  Interlaced files:
+ * FID_E_UNSUPPORTED; damaged files: FID_E_INVALID_ARG (fid_png_last_error says what) -- never a wrong image.
+ * ------------------------------------------------------------------------------------------------------------------ */
+typedef struct fid_png_info {
+    int32_t width, height, bit_depth, color_type, interlace;
+    int32_t gray; /* 1: colour types 0 and 4 (every BGR pixel has three equal bytes) */
+} fid_png_info;
+fid_status fid_png_probe(const uint8_t *data, int64_t nbytes, fid_png_info *info);
+fid_status fid_png_decode(const uint8_t *data, int64_t nbytes, fid_encoding out_enc, uint8_t *out, int64_t out_bytes,
+                          fid_png_info *info /* may be NULL */);
+const char *fid_png_last_error(void); /* of the calling thread */
 
 const char *fid_strerror(fid_status s);
 const char *fid_last_error(fid_ctx *ctx);

@@ -52,6 +52,10 @@ def test_reference_node_test_passes_on_the_cpp_host(tmp_path):
         (tmp_path / "tag_01.jpg").write_bytes(b.getvalue())
         bgr = oj.decode(b.getvalue())
         _write_pgm(tmp_path / "tag_01_jpg.pgm", np.ascontiguousarray(bgr[..., 0]))
+        # ... and with `format: png` (lossless: the node must publish exactly what the raw frame gives), gray and colour
+        g = np.load(os.path.join(GOLD, "tag_01.npz"))["gray"]
+        Image.fromarray(g).save(tmp_path / "tag_01_gray.png")
+        Image.fromarray(np.stack([g, g, g], axis=-1)).save(tmp_path / "tag_01_rgb.png")
     except ImportError:
         pass  # (no Pillow to write the file: the C++ test skips that check)
     r = subprocess.run([exe, str(tmp_path), os.path.join(ROOT, "fiducials_amd", "data")], capture_output=True, text=True, timeout=120)

@@ -48,6 +48,11 @@ struct fid_ctx {
     // chip-filling kernels behind it (chain_at: 0 after find_starts, 1 seed walk, 2 copy, 3 approxPolyDP, 4 in front of the
     // candidate sort, 5 after the too-close filter); the next batch's first kernel, on another context, waits for wait_ev
     hipEvent_t tail_ev = nullptr, wait_ev = nullptr;
+    // host-fed batches in turn: the copy of this context's next batch starts when the copy of the batch in flight on the other
+    // context has landed (wait_copy_ev = that context's in_ready event).  Two copies side by side share the link, both take
+    // twice as long, and the two contexts then run in lockstep: 13.8 k frames/s from pinned memory instead of 21 k.
+    hipEvent_t wait_copy_ev = nullptr;
+    bool fed_from_host = false;  // the batch in flight came through feed_and_enqueue
     int chain_at = 0;
     bool chained = false;  // the next submit is one of a chain of batches (fid_order_after): one sub-batch, see plan_sub_batches
     hipEvent_t walk_done[MAX_SUB] = {}, fs_done[MAX_SUB] = {};
@@ -731,6 +736,7 @@ fid_status enqueue_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H,
     c->pend = {d_src, F, W, H, stride, fstride, enc};
     c->in_flight = true;
     c->chained = false;
+    c->fed_from_host = false;  // (feed_and_enqueue sets it after this call)
     return FID_OK;
 }
 
@@ -1160,6 +1166,7 @@ fid_status fid_submit_device(fid_ctx *c, const void *d_imgs, int32_t nframes, in
     HIPCHK(c, hipSetDevice(c->device));
     const fid_status rc = enqueue_detect(c, (const uint8_t *)d_imgs, nframes, width, height, stride, frame_stride, enc);
     c->wait_ev = nullptr;  // (fid_order_after holds for one submit, refused or not)
+    c->wait_copy_ev = nullptr;
     c->chained = false;
     return rc;
 }
@@ -1168,6 +1175,7 @@ fid_status fid_order_after(fid_ctx *c, fid_ctx *prev)
 {
     if (!c || c == prev || c->in_flight || (prev && prev->device != c->device)) return FID_E_INVALID_ARG;
     c->wait_ev = prev && prev->in_flight ? prev->tail_ev : nullptr;
+    c->wait_copy_ev = prev && prev->in_flight && prev->fed_from_host && prev->last_nsub >= 1 ? prev->in_ready[prev->last_nsub - 1] : nullptr;
     c->chained = prev != nullptr;
     return FID_OK;
 }
@@ -1212,6 +1220,8 @@ static fid_status feed_and_enqueue(fid_ctx *c, const uint8_t *imgs, int32_t nfra
     if (c->host_feed && !c->copy_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
     const SubPlan plan = plan_sub_batches(c, nframes);
     const int nsub = plan.nsub;
+    if (c->host_feed && c->wait_copy_ev) HIPCHK(c, hipStreamWaitEvent(c->copy_stream, c->wait_copy_ev, 0));
+    c->wait_copy_ev = nullptr;
     if (!c->host_feed) {
         HIPCHK(c, hipMemcpyAsync(c->d_in, imgs, need, hipMemcpyHostToDevice, c->stream));
     } else {
@@ -1224,8 +1234,10 @@ static fid_status feed_and_enqueue(fid_ctx *c, const uint8_t *imgs, int32_t nfra
             HIPCHK(c, hipEventRecord(c->in_ready[sb], c->copy_stream));
         }
     }
+    const bool fed = c->host_feed;
     const fid_status rc = enqueue_detect(c, c->d_in, nframes, width, height, stride, frame_stride, enc);
     c->host_feed = false;
+    if (rc == FID_OK) c->fed_from_host = fed;
     return rc;
 }
 
@@ -1244,6 +1256,7 @@ fid_status fid_submit_batch(fid_ctx *c, const uint8_t *imgs, int32_t nframes, in
     const fid_status rc = feed_and_enqueue(c, imgs, nframes, width, height, stride, frame_stride, enc);
     if (c) {
         c->wait_ev = nullptr;
+        c->wait_copy_ev = nullptr;
         c->chained = false;
     }
     return rc;

@@ -605,9 +605,9 @@ def stag_side_result(local_rank, args):
     REFERENCE's own Stag::detectMarkers on one host core next to it."""
     from fiducials_amd import stag as fstag, synth
 
-    # (frames as a grid dimension: 64 frame slots = four groups of 16, each group one stream and one host thread, every kernel
+    # (frames as a grid dimension: 128 frame slots = eight groups of 16, each group one stream and one host thread, every kernel
     #  launched once per group; round 2 ran a stream per frame slot and depended on GPU_MAX_HW_QUEUES)
-    hd, ec, B, T = STAG_HD, STAG_EC, 128, 64
+    hd, ec, B, T = STAG_HD, STAG_EC, 256, 128  # (64 slots / 128 frames per step: 4.1 k frames/s, 128 / 256: 4.7 - 5.1 k)
     frames = make_stag_frames(shard_seeds(0, 1, STAG_UNIQUE, "stag"))
     pool = fstag.StagPool(hd, ec, n_contexts=T, max_width=W, max_height=H, device=local_rank)
     batch = np.stack([frames[i % len(frames)] for i in range(B)])
@@ -666,7 +666,7 @@ def main_stag(args):
     dist = init_dist(world, local_rank)
     from fiducials_amd import stag as fstag, synth
 
-    hd, ec, B = STAG_HD, STAG_EC, min(args.batch, 128)
+    hd, ec, B = STAG_HD, STAG_EC, min(args.batch, 256)
     frames = make_stag_frames(shard_seeds(rank, world, min(B, STAG_UNIQUE), "stag"))
     # several contexts side by side (fid_stag_detect_markers_batch: one host thread + one HIP stream per context inside the
     # library): a frame's work is a chain of small kernels, several frames in flight fill the GPU
@@ -842,7 +842,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the cfg 2 latency and cfg 5 (STag) side results")
     ap.add_argument("--stag-side-child", action="store_true", help=argparse.SUPPRESS)  # the cfg 5 side result, own process
-    ap.add_argument("--streams", type=int, default=64, help="stag workload: frame slots per GPU (groups of 16 in lockstep)")
+    ap.add_argument("--streams", type=int, default=128, help="stag workload: frame slots per GPU (groups of 16 in lockstep)")
     ap.add_argument("--workload", choices=["aruco", "stag"], default="aruco",
                     help="aruco = the BASELINE.json metric (default); stag = BASELINE cfg 5, the stag_detect path")
     args = ap.parse_args()

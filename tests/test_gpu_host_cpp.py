@@ -83,3 +83,15 @@ def test_stag_class_and_fiducial_msgs_output_on_the_cpp_host(tmp_path):
                        capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "all checks passed" in r.stdout
+
+
+@pytest.mark.gpu
+def test_split_call_from_cpp(tmp_path):
+    """host/test/batches_in_turn_test.cpp: fid_submit_batch / fid_collect / fid_order_after on two contexts from C++ against
+    fid_detect_batch, and the one-batch-per-context rules, on batches made of the reference's tag_01 test image."""
+    exe = os.path.join(os.path.dirname(_build_host()), "batches_in_turn_test")
+    _write_pgm(tmp_path / "tag_01.pgm", np.load(os.path.join(GOLD, "tag_01.npz"))["gray"])
+    r = subprocess.run([exe, str(tmp_path / "tag_01.pgm"), os.path.join(ROOT, "fiducials_amd", "data")], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "all checks passed" in r.stdout
+

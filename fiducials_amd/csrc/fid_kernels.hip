@@ -887,33 +887,40 @@ __global__ __launch_bounds__(256) void k_find_starts(const uint32_t *__restrict_
     const int nitems = by_xcd ? mycols * TR : ngroups;     // groups this workgroup's XCD share holds
     const int nit8 = (nitems + 7) & ~7;
     // the it-th group of this share as (scale, tile row, column group); false: none
-    auto group_of = [&](int it, int &gs, int &gtr, int &gcg) -> bool {
-        if (it >= nitems) return false;
+    struct GroupId {  // (plain values, returned by value: as reference parameters of the lambda they ended up in scratch memory)
+        int s, tr, cg;
+        bool ok;
+    };
+    auto group_of = [&](int it) -> GroupId {
+        GroupId g = {0, 0, 0, false};
+        if (it >= nitems) return g;
         unsigned a, b, c, d;
         if (by_xcd) {
             divmod_small((unsigned)it, (unsigned)TR, rcpTR, a, b);  // a-th column of this XCD, tile row b
             divmod_small((unsigned)xcd + 8u * a, (unsigned)CG, rcpCG, c, d);  // column = s * CG + cg
-            gs = (int)c;
-            gtr = (int)b;
-            gcg = (int)d;
+            g.s = (int)c;
+            g.tr = (int)b;
+            g.cg = (int)d;
         } else {
             divmod_small((unsigned)it, (unsigned)CG, rcpCG, a, b);  // it = (s * TR + tr) * CG + cg
             divmod_small(a, (unsigned)TR, rcpTR, c, d);
-            gs = (int)c;
-            gtr = (int)d;
-            gcg = (int)b;
+            g.s = (int)c;
+            g.tr = (int)d;
+            g.cg = (int)b;
         }
-        return true;
+        g.ok = true;
+        return g;
     };
     for (int i0 = by_xcd ? lb * 8 : (int)blockIdx.x * 8; i0 < nit8; i0 += (by_xcd ? nlb : (int)gridDim.x) * 8) {
         // ---- phase A: which word columns of the wave's two groups hold any foreground in their four rows
-        int gs[2] = {0, 0}, gtr[2] = {0, 0}, gcg[2] = {0, 0};
+        const GroupId g0 = group_of(i0 + 2 * wid), g1 = group_of(i0 + 2 * wid + 1);
         unsigned long long msel[2];
 #pragma unroll
         for (int t = 0; t < 2; t++) {
             int nz = 0;
-            if (group_of(i0 + 2 * wid + t, gs[t], gtr[t], gcg[t])) {
-                const int cg = gcg[t], tr = gtr[t], s = gs[t];
+            const GroupId gt = t ? g1 : g0;
+            if (gt.ok) {
+                const int cg = gt.cg, tr = gt.tr, s = gt.s;
                 const int w = cg * 16 + (lane >> 2), r4 = (lane & 3) * 4, yy0 = tr * MT_ROWS + r4;
                 if (w < WW && yy0 <= H && yy0 + 3 >= 1) {
                     const uint4 c4 = *reinterpret_cast<const uint4 *>(fmasks + (long long)s * plane + ((long long)tr * TC + MASK_PADW + w) * MT_ROWS + r4);
@@ -943,7 +950,7 @@ __global__ __launch_bounds__(256) void k_find_starts(const uint32_t *__restrict_
                 const int item = s_items[wid][idx];
                 const bool second = (item >> 6) != 0;
                 const int l = item & 63;
-                const int cg = second ? gcg[1] : gcg[0], tr = second ? gtr[1] : gtr[0], s = second ? gs[1] : gs[0];
+                const int cg = second ? g1.cg : g0.cg, tr = second ? g1.tr : g0.tr, s = second ? g1.s : g0.s;
                 const int w = cg * 16 + (l >> 2), r4 = (l & 3) * 4;
                 const int yy0 = tr * MT_ROWS + r4;  // padded row of this item's first row; image row = yy - 1
                 const int xb = w * 32;

@@ -2896,10 +2896,10 @@ __global__ __launch_bounds__(64) void k_approx(uint4 *__restrict__ contours, con
         todo &= todo - 1;
         const unsigned ci = cb + (unsigned)src * gridDim.x;
         uint4 c;
-        c.x = __shfl(mine.x, src, WAVE);
-        c.y = __shfl(mine.y, src, WAVE);
-        c.z = __shfl(mine.z, src, WAVE);
-        c.w = __shfl(mine.w, src, WAVE);
+        c.x = (unsigned)__builtin_amdgcn_readlane((int)mine.x, src);  // (src is wave-uniform: v_readlane, not a trip through the LDS crossbar)
+        c.y = (unsigned)__builtin_amdgcn_readlane((int)mine.y, src);
+        c.z = (unsigned)__builtin_amdgcn_readlane((int)mine.z, src);
+        c.w = (unsigned)__builtin_amdgcn_readlane((int)mine.w, src);
         const int count = (int)c.z;
         const int x0 = c.x & 0xffff, y0 = c.x >> 16;
         const int s = (c.y >> 16) & 0xff, hole = (c.y >> 24) & 1;
@@ -4190,11 +4190,25 @@ __device__ __forceinline__ double shfl_xor_f64(double v, int mask)
     unsigned hi = __shfl_xor((unsigned)(u >> 32), mask, WAVE);
     return __longlong_as_double(((unsigned long long)hi << 32) | lo);
 }
+// a double from the lane a DPP control names (two v_mov_b32 with a DPP operand: no trip through the LDS crossbar)
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v)
+{
+    const unsigned long long u = __double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)u, CTRL, 0xf, 0xf, false);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), CTRL, 0xf, 0xf, false);
+    return __longlong_as_double(((unsigned long long)hi << 32) | lo);
+}
+// sum over an aligned group of eight lanes, in every lane of the group.  The same three additions with the same operands as the
+// xor-shuffle form (lane ^ 1: quad_perm [1,0,3,2]; lane ^ 2: quad_perm [2,3,0,1]; the other quad of the group: row_half_mirror
+// -- after the second step every lane of a quad holds the same value, so lane 7 - i serves as well as lane i ^ 4), without the
+// six ds_bpermute round trips: Levenberg-Marquardt reduces 28 such sums per iteration, 84 dependent LDS latencies that were
+// most of k_pose's time.
 __device__ __forceinline__ double grp_sum8(double v)
 {
-    v += shfl_xor_f64(v, 1);
-    v += shfl_xor_f64(v, 2);
-    v += shfl_xor_f64(v, 4);
+    v += dpp_f64<0xB1>(v);
+    v += dpp_f64<0x4E>(v);
+    v += dpp_f64<0x141>(v);
     return v;
 }
 
@@ -4644,7 +4658,7 @@ __global__ __launch_bounds__(64) void k_pose(const fid_marker *__restrict__ mark
         double prj = project_one(M, param, K, kd, sel, Jrow, false);
         double dcoord = mobs - (double)(float)prj;
         double d2 = dcoord * dcoord;
-        double pt2 = d2 + shfl_xor_f64(d2, 1);  // dx^2 + dy^2 of this corner
+        double pt2 = d2 + dpp_f64<0xB1>(d2);  // dx^2 + dy^2 of this corner (the lane beside this one: quad_perm [1,0,3,2])
         double e = sqrt(pt2);
         double contrib = sel == 0 ? e * e : 0.;
         double totalErr = grp_sum8(contrib);

@@ -20,11 +20,12 @@ from .detector import ArucoDetector
 
 class BatchPipeline:
     def __init__(self, dictionary, depth: int = 2, fiducial_len: float | None = None, K=None, D=None, ordered: bool = True,
-                 **detector_kwargs):
+                 detector_factory=ArucoDetector, **detector_kwargs):
         if depth < 1:
             raise ValueError("depth must be >= 1")
         self.ordered = ordered  # a batch starts when the one before it is past its chip-filling kernels (fid_order_after)
-        self.detectors = [ArucoDetector(dictionary, **detector_kwargs) for _ in range(depth)]
+        # (detector_factory: the class the contexts are made of -- the CPU tests of this ring's bookkeeping pass a recorder)
+        self.detectors = [detector_factory(dictionary, **detector_kwargs) for _ in range(depth)]
         self._pose = None
         if fiducial_len is not None:
             self._pose = (float(fiducial_len), np.asarray(K, dtype=np.float64), np.zeros(5) if D is None else np.asarray(D, dtype=np.float64))

@@ -190,6 +190,8 @@ def detect(gray: np.ndarray, d, params: OraParams | None = None, cap: int = 1024
         tr.presubpix, tr.cap_pre = pre, cap
     rc = lib().ora_detect(gp, w, h, C.byref(p), C.byref(od), out, cap, C.byref(n),
                           C.byref(tr) if tr is not None else None)
+    if rc == -4:
+        raise CvException("detectMarkers throws on this frame (CORNER_REFINE_CONTOUR: a side of fewer than two points)")
     assert rc == 0, rc
     k = n.value
     ids = np.array([out[i].id for i in range(k)], dtype=np.int32)
@@ -211,6 +213,21 @@ def detect(gray: np.ndarray, d, params: OraParams | None = None, cap: int = 1024
              pre_ids=np.array([pre[i].id for i in range(tr.n_pre)], dtype=np.int32),
              pre_corners=np.array([list(pre[i].corners) for i in range(tr.n_pre)], dtype=np.float32).reshape(tr.n_pre, 4, 2))
     return ids, corners, t
+
+
+class CvException(Exception):
+    """The input on which the reference's OpenCV call raises cv::Exception (the node logs it and publishes nothing)."""
+
+
+def refine_candidate_lines(contour: np.ndarray, corners: np.ndarray) -> np.ndarray:
+    """CORNER_REFINE_CONTOUR on one marker: contour (n, 2) int32 in findContours order, corners (4, 2) float32 -> (4, 2)."""
+    c = np.ascontiguousarray(contour, dtype=np.int32).reshape(-1, 2)
+    q = np.ascontiguousarray(corners, dtype=np.float32).reshape(8).copy()
+    rc = lib().ora_refine_candidate_lines(c.ctypes.data_as(C.c_void_p), len(c), q.ctypes.data_as(C.c_void_p))
+    if rc == -4:
+        raise CvException("a side of fewer than two points")
+    assert rc == 0, rc
+    return q.reshape(4, 2)
 
 
 def corner_subpix(gray, pts, win=5, max_iter=30, eps=0.01):

@@ -16,6 +16,7 @@
  *   a7  identify                 aruco.cpp _getBorderErrors, dictionary.cpp Dictionary::identify
  *   a8  filter_detected          aruco.cpp _filterDetectedMarkers (pointPolygonTest)
  *   a9  ora_corner_subpix        imgproc cornersubpix.cpp + samplers.cpp getRectSubPix_8u32f
+ *   a9' ora_refine_candidate_lines  aruco.cpp _refineCandidateLines (CORNER_REFINE_CONTOUR; core solve / hal::LU32f / Matx solve)
  */
 #define _GNU_SOURCE /* mmap flags of ora_arena.h under -std=c11 */
 #include "aruco_oracle.h"
@@ -484,20 +485,37 @@ static int is_contour_convex(const int32_t *p, int n)
 /* ------------------------------------------------------------------------------------------- */
 typedef struct {
     ora_candidate *v;
+    int32_t **pts; /* per candidate: its contour (x, y pairs, contour_size of them) or NULL -- kept only for
+                      CORNER_REFINE_CONTOUR, the `contours` vector aruco.cpp carries beside `candidates` */
     int n, cap;
 } candvec;
 
-static int cv_push(candvec *c, const ora_candidate *x)
+static int cv_push(candvec *c, const ora_candidate *x, int32_t *pts)
 {
     if (c->n >= c->cap) {
         int nc = c->cap ? c->cap * 2 : 256;
         ora_candidate *nv = (ora_candidate *)realloc(c->v, (size_t)nc * sizeof(ora_candidate));
         if (!nv) return -1;
         c->v = nv;
+        int32_t **np = (int32_t **)realloc(c->pts, (size_t)nc * sizeof(int32_t *));
+        if (!np) return -1;
+        c->pts = np;
         c->cap = nc;
     }
+    c->pts[c->n] = pts;
     c->v[c->n++] = *x;
     return 0;
+}
+
+static void cv_free(candvec *c, int free_points)
+{
+    if (free_points)
+        for (int i = 0; i < c->n; i++) free(c->pts[i]);
+    free(c->pts);
+    free(c->v);
+    c->v = NULL;
+    c->pts = NULL;
+    c->n = c->cap = 0;
 }
 
 /* aruco.cpp _findMarkerContours on one thresholded image */
@@ -563,7 +581,13 @@ static int find_marker_contours(const uint8_t *mask, int w, int h, int scale, co
         cd.start_y = c[1];
         cd.is_hole = holes[i];
         for (int j = 0; j < 8; j++) cd.corners[j] = (float)ap[j];
-        if (cv_push(out, &cd)) {
+        int32_t *keep = NULL;
+        if (p->cornerRefinementMethod == 2) { /* contoursOut.push_back(contours[i]) */
+            keep = (int32_t *)malloc(sz * 2 * sizeof(int32_t));
+            if (keep) memcpy(keep, c, sz * 2 * sizeof(int32_t));
+        }
+        if ((p->cornerRefinementMethod == 2 && !keep) || cv_push(out, &cd, keep)) {
+            free(keep);
             free(pts);
             free(off);
             free(holes);
@@ -644,7 +668,7 @@ static int filter_too_close(const candvec *in, candvec *out, double minMarkerDis
             toRemove[a] = 1;
     }
     for (int i = 0; i < n; i++)
-        if (!toRemove[i] && cv_push(out, &in->v[i])) {
+        if (!toRemove[i] && cv_push(out, &in->v[i], in->pts[i])) { /* (the points stay owned by `in`) */
             free(pairs);
             free(toRemove);
             return -2;
@@ -1135,6 +1159,183 @@ int ora_corner_subpix(const uint8_t *gray, int w, int h, float *pts, int n, int 
 }
 
 /* ------------------------------------------------------------------------------------------- */
+/* a9', CORNER_REFINE_CONTOUR (aruco.cpp 4.2.0 _refineCandidateLines, _interpolate2Dline, _getCrossPoint): what the node selects
+ * with doCornerRefinement = true, cornerRefinementSubPix = false (aruco_detect.cpp:274-283 dynamic_reconfigure, :700-711
+ * rosparam; aruco_detect/cfg/DetectorParams.cfg:40-41).  The node calls detectMarkers without a camera matrix (:350), so the
+ * undistort / re-distort branches of _refineCandidateLines are never taken and are not restated.
+ * PARITY UNPINNED vs OpenCV: no reference fixture uses this method; the arithmetic below follows the published sources --
+ *   cv::solve(A, B, C, DECOMP_NORMAL) on CV_32F: A^T A by mulTransposed (MulTransposedR<float, float>: double accumulators,
+ *   one rounding to float per entry), A^T B by gemm(GEMM_1_T) (GEMMSingleMul<float, double>: likewise), then hal::LU32f
+ *   (LUImpl<float>, eps = FLT_EPSILON * 10) on the 2 x 2 system; m == n (a side of exactly two points) skips the normal
+ *   equations; a singular system leaves C = 0; fewer equations than unknowns (a side of ONE point) is CV_Error(StsBadArg) --
+ *   the node's catch(cv::Exception&) logs it and publishes nothing for the frame (aruco_detect.cpp:391-393);
+ *   Matx22f::solve = Matx_FastSolveOp<float, 2, 2, 1> (float determinant, d == 0 -> zeros).
+ * The sums are sums of products of pixel coordinates: exact in double whatever the order, so the one thing a BLAS-backed
+ * gemm (cv_hal_gemm32f with LAPACK, taken for >= 100 rows) could change is the rounding of A^T B -- stated, not pinned. */
+static int lu32f_2x2(float A[2][2], float b[2])
+{
+    const float eps = FLT_EPSILON * 10;
+    /* i = 0 */
+    int k = fabsf(A[1][0]) > fabsf(A[0][0]) ? 1 : 0;
+    if (fabsf(A[k][0]) < eps) return 0;
+    if (k != 0) {
+        for (int j = 0; j < 2; j++) {
+            float t = A[0][j];
+            A[0][j] = A[1][j];
+            A[1][j] = t;
+        }
+        float t = b[0];
+        b[0] = b[1];
+        b[1] = t;
+    }
+    float d = -1 / A[0][0];
+    float alpha = A[1][0] * d;
+    A[1][1] += alpha * A[0][1];
+    b[1] += alpha * b[0];
+    /* i = 1 */
+    if (fabsf(A[1][1]) < eps) return 0;
+    /* back substitution */
+    b[1] = b[1] / A[1][1];
+    float s = b[0];
+    s -= A[0][1] * b[1];
+    b[0] = s / A[0][0];
+    return 1;
+}
+
+/* _interpolate2Dline on the points of one side.  sums: n, sum x, sum y, sum xx, sum yy, sum xy, and the bounding box */
+typedef struct {
+    long long n, sx, sy, sxx, syy, sxy;
+    int minx, maxx, miny, maxy;
+    int x0, y0, x1, y1; /* the first two points (the m == n road needs them in order) */
+} side_sums;
+
+static void side_add(side_sums *s, int x, int y)
+{
+    if (s->n == 0) {
+        s->minx = s->maxx = x;
+        s->miny = s->maxy = y;
+        s->x0 = x;
+        s->y0 = y;
+    } else {
+        if (s->n == 1) {
+            s->x1 = x;
+            s->y1 = y;
+        }
+        if (x < s->minx) s->minx = x;
+        if (x > s->maxx) s->maxx = x;
+        if (y < s->miny) s->miny = y;
+        if (y > s->maxy) s->maxy = y;
+    }
+    s->n++;
+    s->sx += x;
+    s->sy += y;
+    s->sxx += (long long)x * x;
+    s->syy += (long long)y * y;
+    s->sxy += (long long)x * y;
+}
+
+static int interpolate_2d_line(const side_sums *s, float line[3])
+{
+    if (s->n < 2) return -1; /* n == 1: cv::solve throws (m < n); n == 0: nContours[0] on an empty vector */
+    const int x_major = (float)s->maxx - (float)s->minx > (float)s->maxy - (float)s->miny;
+    float A[2][2], b[2];
+    if (s->n == 2) { /* m == n: is_normal = false, LU on the system itself */
+        A[0][0] = (float)(x_major ? s->x0 : s->y0);
+        A[0][1] = 1.f;
+        A[1][0] = (float)(x_major ? s->x1 : s->y1);
+        A[1][1] = 1.f;
+        b[0] = (float)(x_major ? s->y0 : s->x0);
+        b[1] = (float)(x_major ? s->y1 : s->x1);
+    } else {
+        const long long st = x_major ? s->sx : s->sy, stt = x_major ? s->sxx : s->syy, sv = x_major ? s->sy : s->sx;
+        A[0][0] = (float)(double)stt;
+        A[0][1] = A[1][0] = (float)(double)st;
+        A[1][1] = (float)(double)s->n;
+        b[0] = (float)(double)s->sxy;
+        b[1] = (float)(double)sv;
+    }
+    if (!lu32f_2x2(A, b)) b[0] = b[1] = 0.f; /* if( !result ) dst = Scalar(0) */
+    if (x_major) {
+        line[0] = b[0];
+        line[1] = -1.f;
+        line[2] = b[1];
+    } else {
+        line[0] = -1.f;
+        line[1] = b[0];
+        line[2] = b[1];
+    }
+    return 0;
+}
+
+static void get_cross_point(const float l1[3], const float l2[3], float out[2])
+{
+    const float a00 = l1[0], a01 = l1[1], a10 = l2[0], a11 = l2[1];
+    const float b0 = -l1[2], b1 = -l2[2];
+    float d = a00 * a11 - a01 * a10;
+    if (d == 0) {
+        out[0] = out[1] = 0.f;
+        return;
+    }
+    d = 1 / d;
+    out[0] = (b0 * a11 - b1 * a01) * d;
+    out[1] = (b1 * a00 - b0 * a10) * d;
+}
+
+int ora_refine_candidate_lines(const int32_t *pts, int n, float corners[8])
+{
+    /* cntPts[5]: one group per corner + the points in front of the first corner found */
+    side_sums g[5];
+    memset(g, 0, sizeof(g));
+    int cornerIndex[4] = {-1}; /* as the reference writes it: {-1, 0, 0, 0} */
+    int group = 4;
+    for (int i = 0; i < n; i++) {
+        const float px = (float)pts[2 * i], py = (float)pts[2 * i + 1];
+        for (int j = 0; j < 4; j++)
+            if (corners[2 * j] == px && corners[2 * j + 1] == py) {
+                cornerIndex[j] = i;
+                group = j;
+            }
+        side_add(&g[group], pts[2 * i], pts[2 * i + 1]);
+    }
+    if (group == 4) return -4; /* no corner on the contour: the reference appends to cntPts[4] while iterating it */
+    if (g[4].n) { /* "saves extra group into corresponding": order-free for everything but the m == n road */
+        side_sums *d = &g[group];
+        const side_sums *e = &g[4];
+        if (d->n == 0) {
+            *d = *e;
+        } else {
+            if (d->n == 1) {
+                d->x1 = e->x0;
+                d->y1 = e->y0;
+            }
+            if (e->minx < d->minx) d->minx = e->minx;
+            if (e->maxx > d->maxx) d->maxx = e->maxx;
+            if (e->miny < d->miny) d->miny = e->miny;
+            if (e->maxy > d->maxy) d->maxy = e->maxy;
+            d->n += e->n;
+            d->sx += e->sx;
+            d->sy += e->sy;
+            d->sxx += e->sxx;
+            d->syy += e->syy;
+            d->sxy += e->sxy;
+        }
+    }
+    int inc = 1;
+    inc = ((cornerIndex[0] > cornerIndex[1]) && (cornerIndex[3] > cornerIndex[0])) ? -1 : inc;
+    inc = ((cornerIndex[2] > cornerIndex[3]) && (cornerIndex[1] > cornerIndex[2])) ? -1 : inc;
+    float lines[4][3];
+    for (int i = 0; i < 4; i++)
+        if (interpolate_2d_line(&g[i], lines[i])) return -4;
+    for (int i = 0; i < 4; i++) {
+        if (inc < 0)
+            get_cross_point(lines[i], lines[(i + 1) % 4], corners + 2 * i);
+        else
+            get_cross_point(lines[i], lines[(i + 3) % 4], corners + 2 * i);
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------- */
 int ora_detect(const uint8_t *gray, int w, int h, const ora_params *p, const ora_dict *d, ora_marker *out,
                int cap, int *n_out, ora_trace *tr)
 {
@@ -1144,7 +1345,11 @@ int ora_detect(const uint8_t *gray, int w, int h, const ora_params *p, const ora
     /* _detectInitialCandidates */
     int nScales = (p->adaptiveThreshWinSizeMax - p->adaptiveThreshWinSizeMin) / p->adaptiveThreshWinSizeStep + 1;
     uint8_t *mask = (uint8_t *)malloc((size_t)w * h);
-    candvec init = {0, 0, 0}, filt = {0, 0, 0};
+    candvec init = {0, 0, 0, 0}, filt = {0, 0, 0, 0};
+    ora_marker *acc = NULL;
+    int32_t **accpts = NULL;
+    int *accn = NULL;
+    uint8_t *toRemove = NULL;
     if (!mask) return -2;
     for (int i = 0; i < nScales && rc == 0; i++) {
         int currScale = p->adaptiveThreshWinSizeMin + i * p->adaptiveThreshWinSizeStep;
@@ -1152,21 +1357,14 @@ int ora_detect(const uint8_t *gray, int w, int h, const ora_params *p, const ora
         if (rc == 0) rc = find_marker_contours(mask, w, h, i, p, &init);
     }
     free(mask);
-    if (rc) {
-        free(init.v);
-        return rc;
-    }
+    if (rc) goto done;
     if (tr && tr->initial) {
         tr->n_initial = init.n;
         for (int i = 0; i < init.n && i < tr->cap_initial; i++) tr->initial[i] = init.v[i];
     }
     for (int i = 0; i < init.n; i++) reorder_corners(&init.v[i]);
     rc = filter_too_close(&init, &filt, p->minMarkerDistanceRate);
-    free(init.v);
-    if (rc) {
-        free(filt.v);
-        return rc;
-    }
+    if (rc) goto done;
     if (tr && tr->filtered) {
         tr->n_filtered = filt.n;
         for (int i = 0; i < filt.n && i < tr->cap_filtered; i++) tr->filtered[i] = filt.v[i];
@@ -1174,10 +1372,13 @@ int ora_detect(const uint8_t *gray, int w, int h, const ora_params *p, const ora
     /* _identifyCandidates */
     int ms = d->marker_size, msb = ms + 2 * p->markerBorderBits;
     int nacc = 0;
-    ora_marker *acc = (ora_marker *)malloc((size_t)(filt.n > 0 ? filt.n : 1) * sizeof(ora_marker));
-    if (!acc) {
-        free(filt.v);
-        return -2;
+    const size_t nf1 = (size_t)(filt.n > 0 ? filt.n : 1);
+    acc = (ora_marker *)malloc(nf1 * sizeof(ora_marker));
+    accpts = (int32_t **)malloc(nf1 * sizeof(int32_t *));
+    accn = (int *)malloc(nf1 * sizeof(int));
+    if (!acc || !accpts || !accn) {
+        rc = -2;
+        goto done;
     }
     for (int i = 0; i < filt.n; i++) {
         uint8_t bits[256];
@@ -1197,14 +1398,15 @@ int ora_detect(const uint8_t *gray, int w, int h, const ora_params *p, const ora
             m.corners[2 * c] = filt.v[i].corners[2 * srcc];
             m.corners[2 * c + 1] = filt.v[i].corners[2 * srcc + 1];
         }
+        accpts[nacc] = filt.pts[i]; /* contours.push_back(_contours[i]) */
+        accn[nacc] = filt.v[i].contour_size;
         acc[nacc++] = m;
     }
-    free(filt.v);
     /* _filterDetectedMarkers */
-    uint8_t *toRemove = (uint8_t *)calloc((size_t)(nacc > 0 ? nacc : 1), 1);
+    toRemove = (uint8_t *)calloc((size_t)(nacc > 0 ? nacc : 1), 1);
     if (!toRemove) {
-        free(acc);
-        return -2;
+        rc = -2;
+        goto done;
     }
     for (int i = 0; i + 1 < nacc; i++) {
         for (int j = i + 1; j < nacc; j++) {
@@ -1235,13 +1437,14 @@ int ora_detect(const uint8_t *gray, int w, int h, const ora_params *p, const ora
     for (int i = 0; i < nacc; i++) {
         if (toRemove[i]) continue;
         if (n < cap) out[n] = acc[i];
+        accpts[n] = accpts[i]; /* (n <= i) */
+        accn[n] = accn[i];
         n++;
     }
-    free(toRemove);
-    free(acc);
     if (n > cap) {
         *n_out = cap;
-        return -3;
+        rc = -3;
+        goto done;
     }
     if (tr && tr->presubpix) {
         tr->n_pre = n;
@@ -1253,8 +1456,24 @@ int ora_detect(const uint8_t *gray, int w, int h, const ora_params *p, const ora
             ora_corner_subpix(gray, w, h, out[i].corners, 4, p->cornerRefinementWinSize,
                               p->cornerRefinementMaxIterations, p->cornerRefinementMinAccuracy);
     }
+    /* corner refinement (CORNER_REFINE_CONTOUR): _refineCandidateLines(contours[i], candidates[i]) */
+    if (p->cornerRefinementMethod == 2) {
+        for (int i = 0; i < n && rc == 0; i++)
+            if (ora_refine_candidate_lines(accpts[i], accn[i], out[i].corners)) rc = -4; /* cv::Exception */
+        if (rc) {
+            *n_out = 0; /* the node publishes nothing for this frame (aruco_detect.cpp:391-393) */
+            goto done;
+        }
+    }
     *n_out = n;
-    return 0;
+done:
+    free(toRemove);
+    free(acc);
+    free(accpts);
+    free(accn);
+    cv_free(&filt, 0);
+    cv_free(&init, 1);
+    return rc;
 }
 
 /* aruco_detect.cpp:164-200 dist + calcFiducialArea */

@@ -35,7 +35,7 @@ typedef struct ora_params {
     int    adaptiveThreshWinSizeMin;          /* 3    :692 */
     int    adaptiveThreshWinSizeMax;          /* 53   :691 */
     int    adaptiveThreshWinSizeStep;         /* 4    :693 */
-    int    cornerRefinementMethod;            /* 1 = SUBPIX (:700-714), 0 = NONE */
+    int    cornerRefinementMethod;            /* 1 = SUBPIX (:700-714), 0 = NONE, 2 = CONTOUR (cornerRefinementSubPix = false, :704-710) */
     int    cornerRefinementWinSize;           /* 5    :696 */
     int    cornerRefinementMaxIterations;     /* 30   :694 */
     double cornerRefinementMinAccuracy;       /* 0.01 :695 */
@@ -100,13 +100,18 @@ int ora_find_contours(const uint8_t *mask, int w, int h, int32_t *pts, int64_t c
 /* approxPolyDP(closed) on integer points; returns number of output points (<= cap) or -1 */
 int ora_approx_poly_dp(const int32_t *pts, int n, double eps, int32_t *out, int cap);
 
-/* full a3..a9 */
+/* full a3..a9.  Returns 0; -1 bad argument, -2 out of memory, -3 cap too small, -4 the reference's detectMarkers throws
+ * cv::Exception on this frame (CORNER_REFINE_CONTOUR, a side of one point): n = 0, as the node publishes nothing (:391-393) */
 int ora_detect(const uint8_t *gray, int w, int h, const ora_params *p, const ora_dict *d,
                ora_marker *out, int cap, int *n, ora_trace *trace);
 
 /* a9 alone: cornerSubPix on n points */
 int ora_corner_subpix(const uint8_t *gray, int w, int h, float *pts, int n, int win, int max_iter,
                       double eps);
+
+/* a9' alone: CORNER_REFINE_CONTOUR's _refineCandidateLines on one marker: pts = its contour (n x,y pairs, findContours order),
+ * corners in/out.  Returns 0, or -4 where the reference throws cv::Exception (a side of fewer than two points).  Parity unpinned. */
+int ora_refine_candidate_lines(const int32_t *pts, int n, float corners[8]);
 
 /* a6/a7 alone on one candidate: returns id or -1; bits (ms+2)^2; rotation */
 int ora_identify(const uint8_t *gray, int w, int h, const ora_params *p, const ora_dict *d,

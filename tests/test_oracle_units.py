@@ -103,3 +103,105 @@ def test_adaptive_threshold_constant_is_floored_for_binary_inv():
     assert oracle.adaptive_threshold(np.full((8, 8), 50, np.uint8), 3, -0.5).min() == 255
     assert oracle.adaptive_threshold(np.full((8, 8), 50, np.uint8), 3, 0.5).min() == 255   # idelta 0: 0 <= 0
     assert oracle.adaptive_threshold(np.full((8, 8), 50, np.uint8), 3, 1.0).max() == 0
+
+
+# ---- CORNER_REFINE_CONTOUR (aruco.cpp _refineCandidateLines; the node's cornerRefinementSubPix = false,
+#      /root/reference/aruco_detect/src/aruco_detect.cpp:274-283, 700-711).  Parity unpinned vs OpenCV (no reference fixture uses
+#      it): these tests pin the restatement to what the published algorithm must produce on inputs with a known answer.
+def _quad_contour(corners):
+    """8-connected closed integer polyline through the given integer corners (what findContours yields for a filled quad,
+    up to staircase detail): the corners themselves are on it."""
+    pts = []
+    for k in range(4):
+        (x0, y0), (x1, y1) = corners[k], corners[(k + 1) % 4]
+        n = max(abs(x1 - x0), abs(y1 - y0))
+        for t in range(n):
+            pts.append((int(round(x0 + (x1 - x0) * t / n)), int(round(y0 + (y1 - y0) * t / n))))
+    return np.array(pts, dtype=np.int32)
+
+
+def test_refine_candidate_lines_axis_aligned_square():
+    cs = [(10, 20), (110, 20), (110, 120), (10, 120)]
+    cont = _quad_contour(cs)
+    for rot in range(4):  # whichever corner identification put first
+        q = np.array(cs[rot:] + cs[:rot], dtype=np.float32)
+        out = oracle.refine_candidate_lines(cont, q)
+        # every side is an exact line x = c / y = c: the crossings are the corners themselves, up to the rounding of the
+        # float32 normal equations (the sums of squares do not fit 24 bits)
+        assert np.abs(out - q).max() < 1e-3, (rot, out)
+    # the contour given the other way round (a hole border) and starting in the middle of a side: same answer
+    rev = np.roll(cont[::-1], 37, axis=0)
+    q = np.array(cs, dtype=np.float32)
+    assert np.abs(oracle.refine_candidate_lines(rev, q) - q).max() < 1e-3
+
+
+def test_refine_candidate_lines_matches_float64_least_squares():
+    rng = np.random.default_rng(11)
+    for trial in range(40):
+        c = np.array([300.0, 300.0]) + rng.uniform(-40, 40, 2)
+        a = rng.uniform(0, np.pi / 2)
+        half = rng.uniform(30, 120)
+        R = np.array([[np.cos(a), -np.sin(a)], [np.sin(a), np.cos(a)]])
+        sq = (R @ (np.array([[-1, -1], [1, -1], [1, 1], [-1, 1]], dtype=float) * half).T).T + c
+        cs = [tuple(int(v) for v in np.round(p)) for p in sq]
+        cont = _quad_contour(cs)
+        start = int(rng.integers(0, len(cont)))
+        cont = np.roll(cont, -start, axis=0)
+        if trial % 2:
+            cont = cont[::-1].copy()
+        q = np.array(cs, dtype=np.float32)
+        out = oracle.refine_candidate_lines(cont, q)
+        # the same thing in float64 with numpy: group the points by the corner that precedes them, fit, intersect
+        idx = {cs.index(tuple(p)): i for i, p in enumerate(cont.tolist()) if tuple(p) in cs}
+        order = sorted(idx, key=lambda j: idx[j])
+        lines = {}
+        for k, j in enumerate(order):
+            i0, i1 = idx[j], idx[order[(k + 1) % 4]]
+            seg = cont[i0:i1] if i0 < i1 else np.concatenate([cont[i0:], cont[:i1]])
+            x, y = seg[:, 0].astype(float), seg[:, 1].astype(float)
+            if np.ptp(x) > np.ptp(y):
+                m, b = np.linalg.lstsq(np.stack([x, np.ones_like(x)], 1), y, rcond=None)[0]
+                lines[j] = (m, -1.0, b)
+            else:
+                m, b = np.linalg.lstsq(np.stack([y, np.ones_like(y)], 1), x, rcond=None)[0]
+                lines[j] = (-1.0, m, b)
+        inc = -1 if ((idx[0] > idx[1] and idx[3] > idx[0]) or (idx[2] > idx[3] and idx[1] > idx[2])) else 1
+        for i in range(4):
+            l1, l2 = lines[i], lines[(i + 1) % 4 if inc < 0 else (i + 3) % 4]
+            A = np.array([[l1[0], l1[1]], [l2[0], l2[1]]])
+            ref = np.linalg.solve(A, -np.array([l1[2], l2[2]]))
+            assert np.abs(out[i] - ref).max() < 0.05, (trial, i, out[i], ref)  # float32 normal equations vs float64 QR
+            assert np.abs(out[i] - q[i]).max() < 3.0  # ... and the refined corner stays at the corner
+
+
+def test_refine_candidate_lines_degenerate_side_is_the_references_exception():
+    import pytest
+    # a "quad" whose first side is a single point: cv::solve is handed one equation for two unknowns and throws
+    cont = np.array([(0, 0), (1, 1), (2, 2), (3, 3), (3, 4), (3, 5), (2, 5), (1, 5), (0, 4), (0, 3), (0, 2), (0, 1)], dtype=np.int32)
+    q = np.array([(0, 0), (1, 1), (3, 5), (0, 4)], dtype=np.float32)
+    with pytest.raises(oracle.CvException):
+        oracle.refine_candidate_lines(cont, q)
+    # two points on a side: the m == n road of cv::solve (no normal equations), still a line through both
+    q2 = np.array([(0, 0), (2, 2), (3, 5), (0, 4)], dtype=np.float32)
+    out = oracle.refine_candidate_lines(cont, q2)
+    assert np.isfinite(out).all()
+
+
+def test_detect_with_contour_refinement_on_the_reference_images():
+    """Method 2 end to end on the reference's own test images (aruco_detect/test/test_images): same ids as SUBPIX, corners
+    within 1.5 px of the SUBPIX ones (both refine the same quad), and not the unrefined integers."""
+    from helpers import load_gray
+    from fiducials_amd.dictionary import get_predefined_dictionary
+    d = get_predefined_dictionary(7)
+    for name in ("tag_01", "tag_245_246"):
+        img = load_gray(name)
+        ids1, c1 = oracle.detect(img, d)
+        p = oracle.default_params()
+        p.cornerRefinementMethod = 2
+        ids2, c2 = oracle.detect(img, d, p)
+        p.cornerRefinementMethod = 0
+        ids0, c0 = oracle.detect(img, d, p)
+        assert ids1.tolist() == ids2.tolist() == ids0.tolist() and len(ids2) >= 1
+        assert np.abs(c2 - c1).max() < 1.5
+        assert np.abs(c2 - c0).max() < 1.5
+        assert not np.array_equal(c2, c0)

@@ -71,14 +71,15 @@ class FidPngInfo(C.Structure):
 
 
 FID_OK = 0
-FID_E_INVALID_ARG, FID_E_NO_DEVICE, FID_E_HIP, FID_E_CAPACITY, FID_E_OUT_OF_MEMORY, FID_E_UNSUPPORTED = 1, 2, 3, 4, 5, 6
+FID_E_INVALID_ARG, FID_E_NO_DEVICE, FID_E_HIP, FID_E_CAPACITY, FID_E_OUT_OF_MEMORY, FID_E_UNSUPPORTED, FID_E_CV_EXCEPTION = 1, 2, 3, 4, 5, 6, 7
+CORNER_REFINE_NONE, CORNER_REFINE_SUBPIX, CORNER_REFINE_CONTOUR = 0, 1, 2  # aruco::CornerRefineMethod as the node sets it (:700-711)
 ENC = {"mono8": 0, "bgr8": 1, "rgb8": 2, "bgra8": 3, "rgba8": 4}
 TAP_MASKS, TAP_CANDIDATES, TAP_FILTERED, TAP_BITS, TAP_IDENT, TAP_PRESUBPIX, TAP_COUNTS, TAP_GRAY = range(8)
 
 # every symbol include/fid_abi.h declares
 SYMBOLS = [
     "fid_default_params", "fid_default_limits", "fid_create", "fid_destroy", "fid_set_params", "fid_detect",
-    "fid_detect_batch", "fid_detect_device", "fid_submit_device", "fid_submit_batch", "fid_collect", "fid_order_after", "fid_pose", "fid_pose_last", "fid_tap_bytes", "fid_tap_read",
+    "fid_detect_batch", "fid_detect_device", "fid_submit_device", "fid_submit_batch", "fid_collect", "fid_order_after", "fid_pose", "fid_pose_last", "fid_refine_contour_corners", "fid_tap_bytes", "fid_tap_read",
     "fid_last_stage_ms", "fid_last_launches", "fid_stream", "fid_strerror", "fid_last_error", "fid_abi_version",
     "fid_stag_create", "fid_stag_destroy", "fid_stag_edge_frontend", "fid_stag_detect_edges", "fid_stag_detect_edges_validated", "fid_stag_detect_lines", "fid_stag_detect_lines_validated", "fid_stag_detect_quads", "fid_stag_host_tables", "fid_stag_load_library", "fid_stag_detect_markers_unrefined", "fid_stag_detect_markers", "fid_stag_pose_last", "fid_stag_detect_markers_batch", "fid_stag_tap_bytes", "fid_stag_tap_read",
     "fid_jpeg_probe", "fid_jpeg_create", "fid_jpeg_destroy", "fid_jpeg_decode", "fid_jpeg_device_ptr", "fid_jpeg_tap_bytes", "fid_jpeg_tap_read",
@@ -93,6 +94,11 @@ class FidError(RuntimeError):
     def __init__(self, status: int, msg: str):
         super().__init__(f"fid status {status}: {msg}")
         self.status = status
+
+
+class CvException(FidError):
+    """FID_E_CV_EXCEPTION: the input on which the reference's OpenCV call throws cv::Exception (the node's imageCallback logs
+    it and publishes nothing for the frame, aruco_detect.cpp:391-393)."""
 
 
 def lib_path() -> str:
@@ -127,6 +133,7 @@ def load():
     L.fid_pose.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(FidMarker), C.POINTER(C.c_double),
                            i32, C.c_double, C.POINTER(FidPoseOut)]
     L.fid_pose_last.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double, C.POINTER(FidPoseOut), i32]
+    L.fid_refine_contour_corners.argtypes = [vp, vp, vp, i32, vp, vp]
     L.fid_tap_bytes.argtypes = [vp, C.c_int]
     L.fid_tap_bytes.restype = i64
     L.fid_tap_read.argtypes = [vp, C.c_int, vp, i64]

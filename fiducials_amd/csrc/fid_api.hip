@@ -111,6 +111,7 @@ struct fid_ctx {
     uint32_t *d_near = nullptr;
     DevIdent *d_ident = nullptr;
     fid_marker *d_pre = nullptr, *d_markers = nullptr, *d_filter_scratch = nullptr;
+    int *d_accsrc = nullptr, *d_mksrc = nullptr;  // the filtered candidate behind every identified / kept marker (k_filter_markers -> k_refine_contour)
     fid_pose_out *d_poses = nullptr;
     DevCounts *d_counts = nullptr;
     DevGlobal *d_global = nullptr;
@@ -211,10 +212,12 @@ fid_status apply_params(fid_ctx *c, const fid_params *p)
     P.maxCorr = (int)((double)c->dict_maxc * p->errorCorrectionRate);
     P.nMarkers = c->dict_n;
     P.nbytes = (c->dict_ms * c->dict_ms + 7) / 8;
-    P.refine = p->cornerRefinementMethod == 1;
-    if (p->cornerRefinementMethod != 0 && p->cornerRefinementMethod != 1) return FID_E_UNSUPPORTED;
+    // 0 CORNER_REFINE_NONE, 1 CORNER_REFINE_SUBPIX, 2 CORNER_REFINE_CONTOUR (the node reaches all three: aruco_detect.cpp:274-283,
+    // 700-711).  3 = CORNER_REFINE_APRILTAG replaces the whole candidate search and is not something the node can select.
+    if (p->cornerRefinementMethod < 0 || p->cornerRefinementMethod > 2) return FID_E_UNSUPPORTED;
+    P.refine = p->cornerRefinementMethod;
     P.subpixWin = p->cornerRefinementWinSize;
-    if (P.refine && (P.subpixWin < 1 || P.subpixWin > SP_MAXWIN || p->cornerRefinementMaxIterations < 1 ||
+    if (P.refine == 1 && (P.subpixWin < 1 || P.subpixWin > SP_MAXWIN || p->cornerRefinementMaxIterations < 1 ||
                      !(p->cornerRefinementMinAccuracy > 0)))
         return FID_E_INVALID_ARG;
     {
@@ -225,7 +228,7 @@ fid_status apply_params(fid_ctx *c, const fid_params *p)
     }
     c->params = *p;
     // cornerSubPix weight mask, computed once on the host exactly as cornersubpix.cpp does (float expf)
-    if (P.refine) {
+    if (P.refine == 1) {
         int win = P.subpixWin, ww = 2 * win + 1;
         std::vector<float> mask((size_t)ww * ww);
         for (int i = 0; i < ww; i++) {
@@ -685,13 +688,19 @@ fid_status enqueue_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H,
         mark(ST_IDENT + 1);
         // ---- K7
         hipLaunchKernelGGL(k_filter_markers, dim3(Fs), dim3(64), (size_t)c->filter_lds * sizeof(fid_marker), st, filtered, ident, pre, counts, P,
-                           c->d_filter_scratch + f0 * MC, c->filter_lds);
+                           c->d_filter_scratch + f0 * MC, c->filter_lds, c->d_accsrc + f0 * MC, c->d_mksrc + f0 * MM);
         mark(ST_FILTER + 1);
         {
             long long items = (long long)Fs * P.maxMarkers * 4;
             const long long bcap = c->tail_grid > 0 ? 4LL * c->tail_grid : 256 * 16;
             int blocks = (int)(items < bcap ? items : bcap);
-            hipLaunchKernelGGL(k_subpix, dim3(blocks), dim3(64), 0, st, g, gfstride, pre, markers, counts, c->d_subpix_mask, P);
+            if (P.refine == 2)  // CORNER_REFINE_CONTOUR: a wave per marker fits the four sides of its contour (writes ids and corners)
+                hipLaunchKernelGGL(k_refine_contour, dim3(P.maxMarkers < 64 ? P.maxMarkers : 64, Fs), dim3(64), 0, st, (const fid_marker *)pre, markers,
+                                   (const int *)(c->d_mksrc + f0 * MM), (const DevCand *)filtered,
+                                   (const uint32_t *)(c->d_dense ? c->d_dense + (size_t)f0 * P.maxChunks * CK : nullptr), (const uint32_t *)tab,
+                                   (const uint32_t *)pool, counts, P);
+            else
+                hipLaunchKernelGGL(k_subpix, dim3(blocks), dim3(64), 0, st, g, gfstride, pre, markers, counts, c->d_subpix_mask, P);
         }
         mark(ST_SUBPIX + 1);
         if (c->pose_cam_valid) {
@@ -818,9 +827,20 @@ fid_status finish_detect(fid_ctx *c, fid_marker *out, int cap_per_frame, int *n_
     }
     for (int f = 0; f < F; f++) {
         int n = c->h_counts[f].nmark;
-        if (c->h_counts[f].overflow) {
+        if (c->h_counts[f].overflow & 3) {
             c->last_error = "per-frame candidate/marker capacity exceeded: raise fid_limits";
             rc = FID_E_CAPACITY;
+        }
+        if (c->h_counts[f].overflow & 4) {
+            // CORNER_REFINE_CONTOUR on a marker with a side of fewer than two contour points: cv::solve throws inside
+            // aruco::detectMarkers, imageCallback's catch(cv::Exception&) logs it and publishes nothing for the frame
+            if (rc == FID_OK) {
+                rc = FID_E_CV_EXCEPTION;
+                c->last_error = "cv exception: the reference's detectMarkers throws on frame " + std::to_string(f) +
+                                " (CORNER_REFINE_CONTOUR: a marker side of fewer than two contour points)";
+            }
+            n_per_frame[f] = -1;
+            continue;
         }
         if (n > cap_per_frame) {
             n = cap_per_frame;
@@ -1048,6 +1068,8 @@ fid_status fid_create(const fid_params *params, const fid_dict *dict, const fid_
     TRY(dalloc(c, &c->d_ident, F * MC));
     TRY(dalloc(c, &c->d_pre, F * MM));
     TRY(dalloc(c, &c->d_filter_scratch, F * MC));
+    TRY(dalloc(c, &c->d_accsrc, F * MC));
+    TRY(dalloc(c, &c->d_mksrc, F * MM));
     TRY(dalloc(c, &c->d_markers, F * MM));
     TRY(dalloc(c, &c->d_poses, F * MM));
     TRY(dalloc(c, &c->d_counts, F));
@@ -1078,7 +1100,7 @@ void fid_destroy(fid_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    void *dev[] = {c->d_in, c->d_gray, c->d_masks, c->d_starts, c->d_surv1, c->d_surv, c->d_pool, c->d_segs, c->d_pend, c->d_seedq, c->d_seedhash, c->d_wres, c->d_cinfo, c->d_cbase, c->d_filter_scratch, c->d_dense, c->d_recs, c->d_contours, c->d_ckpts, c->d_cands, c->d_sorted, c->d_cmeta, c->d_filtered, c->d_near,
+    void *dev[] = {c->d_in, c->d_gray, c->d_masks, c->d_starts, c->d_surv1, c->d_surv, c->d_pool, c->d_segs, c->d_pend, c->d_seedq, c->d_seedhash, c->d_wres, c->d_cinfo, c->d_cbase, c->d_filter_scratch, c->d_accsrc, c->d_mksrc, c->d_dense, c->d_recs, c->d_contours, c->d_ckpts, c->d_cands, c->d_sorted, c->d_cmeta, c->d_filtered, c->d_near,
                    c->d_ident, c->d_pre, c->d_markers, c->d_poses, c->d_counts, c->d_global, c->d_worklist, c->d_nwork, c->d_dict,
                    c->d_subpix_mask, c->d_lens, c->d_pose_in, c->d_pose_n};
     for (void *p : dev)
@@ -1359,6 +1381,62 @@ fid_status fid_pose(fid_ctx *c, const double K[9], const double D[5], const fid_
     return FID_OK;
 }
 
+fid_status fid_refine_contour_corners(fid_ctx *c, const int32_t *pts_xy, const int32_t *offsets, int32_t n, float *corners,
+                                      int32_t *status_per_marker)
+{
+    if (!c || !pts_xy || !offsets || !corners || !status_per_marker || n < 0) return FID_E_INVALID_ARG;
+    if (c->in_flight) {
+        c->last_error = "a submitted batch is in flight: fid_collect first";
+        return FID_E_INVALID_ARG;
+    }
+    if (n == 0) return FID_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (offsets[0] != 0) return FID_E_INVALID_ARG;
+    for (int i = 0; i < n; i++)
+        if (offsets[i + 1] < offsets[i]) return FID_E_INVALID_ARG;
+    const int total = offsets[n];
+    std::vector<uint32_t> packed((size_t)(total > 0 ? total : 1));
+    for (int k = 0; k < total; k++) {
+        const int x = pts_xy[2 * k], y = pts_xy[2 * k + 1];
+        if (x < 0 || y < 0 || x > 0xffff || y > 0xffff) return FID_E_INVALID_ARG;
+        packed[k] = (uint32_t)x | ((uint32_t)y << 16);
+    }
+    uint32_t *d_pts = nullptr;
+    int *d_off = nullptr, *d_status = nullptr;
+    float *d_corners = nullptr;
+    fid_status rc = FID_OK;
+    auto chk = [&](hipError_t e, const char *what) {
+        if (e != hipSuccess && rc == FID_OK) {
+            c->last_error = std::string(what) + ": " + hipGetErrorString(e);
+            rc = e == hipErrorOutOfMemory ? FID_E_OUT_OF_MEMORY : FID_E_HIP;
+        }
+    };
+    chk(hipMalloc((void **)&d_pts, packed.size() * sizeof(uint32_t)), "hipMalloc");
+    chk(hipMalloc((void **)&d_off, (size_t)(n + 1) * sizeof(int)), "hipMalloc");
+    chk(hipMalloc((void **)&d_status, (size_t)n * sizeof(int)), "hipMalloc");
+    chk(hipMalloc((void **)&d_corners, (size_t)n * 8 * sizeof(float)), "hipMalloc");
+    if (rc == FID_OK) {
+        chk(hipMemcpyAsync(d_pts, packed.data(), packed.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream), "hipMemcpyAsync");
+        chk(hipMemcpyAsync(d_off, offsets, (size_t)(n + 1) * sizeof(int), hipMemcpyHostToDevice, c->stream), "hipMemcpyAsync");
+        chk(hipMemcpyAsync(d_corners, corners, (size_t)n * 8 * sizeof(float), hipMemcpyHostToDevice, c->stream), "hipMemcpyAsync");
+    }
+    if (rc == FID_OK) {
+        hipLaunchKernelGGL(k_refine_contour_pts, dim3(n), dim3(64), 0, c->stream, (const uint32_t *)d_pts, (const int *)d_off, d_corners, d_status);
+        chk(hipGetLastError(), "k_refine_contour_pts");
+        chk(hipMemcpyAsync(corners, d_corners, (size_t)n * 8 * sizeof(float), hipMemcpyDeviceToHost, c->stream), "hipMemcpyAsync");
+        chk(hipMemcpyAsync(status_per_marker, d_status, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, c->stream), "hipMemcpyAsync");
+        chk(hipStreamSynchronize(c->stream), "hipStreamSynchronize");
+    }
+    (void)hipFree(d_pts);
+    (void)hipFree(d_off);
+    (void)hipFree(d_status);
+    (void)hipFree(d_corners);
+    if (rc == FID_OK)
+        for (int i = 0; i < n; i++)
+            if (status_per_marker[i]) rc = FID_E_CV_EXCEPTION;
+    return rc;
+}
+
 int64_t fid_tap_bytes(fid_ctx *c, fid_tap which)
 {
     if (!c || c->last_frames <= 0) return 0;
@@ -1483,6 +1561,8 @@ const char *fid_strerror(fid_status s)
     case FID_E_HIP: return "HIP runtime error";
     case FID_E_CAPACITY: return "capacity exceeded";
     case FID_E_OUT_OF_MEMORY: return "out of memory";
+    case FID_E_CV_EXCEPTION:
+        return "the reference's OpenCV call throws cv::Exception on this input (n = -1 for the frame)";
     case FID_E_UNSUPPORTED: return "unsupported parameter combination";
     }
     return "unknown status";

@@ -63,6 +63,9 @@ struct DevCand {
     int hole;
     unsigned key;   // discovery position in the padded raster (outer: start pixel, hole: pixel right of it)
     float c[8];
+    unsigned pref;  // where the contour's points are: offset into the frame's dense point array, or 0x80000000 | table row
+                    // (whole-border walk) -- CORNER_REFINE_CONTOUR reads them again (k_refine_contour)
+    unsigned pad;
 };
 
 struct DevIdent {
@@ -138,7 +141,7 @@ struct DevCounts {
     int nfilt;      // after too-close filter
     int nacc;       // identified
     int nmark;      // after _filterDetectedMarkers
-    int overflow;   // bit0 cands, bit1 markers
+    int overflow;   // bit0 cands, bit1 markers, bit2 CORNER_REFINE_CONTOUR met a side of fewer than two points (the reference throws)
     int nstarts;    // border-following start candidates found by k_find_starts
     int ncontours;  // contour slots handed out by the full walk pass (dropped walks leave count == 0)
     int nsurv;      // starts that survived the probe pass

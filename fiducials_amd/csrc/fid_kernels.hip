@@ -2905,9 +2905,11 @@ __global__ __launch_bounds__(64) void k_approx(uint4 *__restrict__ contours, con
         const int s = (c.y >> 16) & 0xff, hole = (c.y >> 24) & 1;
         __syncthreads();
         // ---- gather the border
+        uint32_t pref = 0x80000000u | ci;  // where the points stay for CORNER_REFINE_CONTOUR: the table row of the whole-border walk ...
         if (dense) {
             const uint32_t cb0 = cbase[(long long)f * P.maxContours + loff + ci];
             if (cb0 == SEG_INVALID) continue;
+            pref = cb0;  // ... or the contour's place in the frame's dense point array
             const uint32_t *src = dense + (long long)f * P.maxChunks * CK + cb0;
             for (int k = lane; k < count; k += 64) pts[k] = src[k];
         } else {
@@ -3144,6 +3146,8 @@ __global__ __launch_bounds__(64) void k_approx(uint4 *__restrict__ contours, con
                 cd.sy = y0;
                 cd.hole = hole;
                 cd.key = c.w;
+                cd.pref = pref;
+                cd.pad = 0;
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     cd.c[2 * k] = (float)ax[k];
@@ -3870,8 +3874,11 @@ __device__ __forceinline__ double point_polygon_test4(const float *cnt, float pt
 
 __global__ __launch_bounds__(64) void k_filter_markers(const DevCand *__restrict__ filtered, const DevIdent *__restrict__ ident,
                                                         fid_marker *__restrict__ pre, DevCounts *__restrict__ counts,
-                                                        const DevParams P, fid_marker *__restrict__ gscratch, int lds_cap)
+                                                        const DevParams P, fid_marker *__restrict__ gscratch, int lds_cap,
+                                                        int *__restrict__ accsrc, int *__restrict__ mksrc)
 {
+    // accsrc [maxCands] per frame (scratch) / mksrc [maxMarkers] per frame: the filtered candidate a marker came from -- its
+    // contour is what CORNER_REFINE_CONTOUR fits (aruco.cpp carries `contours` beside `candidates` through both filters)
     // the identified markers of the frame: in LDS when they fit lds_cap (a few dozen do; the kernel used to ask for maxCands
     // entries = 73 KB per frame and waited for CUs with that much LDS free: 0.4 ms for 5 us of work), else in the frame's
     // slice of a global scratch array
@@ -3902,6 +3909,7 @@ __global__ __launch_bounds__(64) void k_filter_markers(const DevCand *__restrict
                 m.corners[2 * c + 1] = cs[k].c[2 * sc + 1];
             }
             acc[off] = m;
+            accsrc[(long long)f * P.maxCands + off] = k;
         }
         base += __popcll(hit);
     }
@@ -3940,7 +3948,10 @@ __global__ __launch_bounds__(64) void k_filter_markers(const DevCand *__restrict
         unsigned long long hit = ballot64(keep);
         int off = outbase + __popcll(hit & ((1ull << lane) - 1ull));
         if (keep) {
-            if (off < P.maxMarkers) pre[(long long)f * P.maxMarkers + off] = acc[j];
+            if (off < P.maxMarkers) {
+                pre[(long long)f * P.maxMarkers + off] = acc[j];
+                mksrc[(long long)f * P.maxMarkers + off] = accsrc[(long long)f * P.maxCands + j];
+            }
         }
         outbase += __popcll(hit);
     }
@@ -3986,7 +3997,7 @@ __global__ __launch_bounds__(64) void k_subpix(const uint8_t *__restrict__ gray,
         if (cn == 0 && lane == 0) dstm->id = src->id;
         const float cTx = src->corners[2 * cn], cTy = src->corners[2 * cn + 1];
         float cIx = cTx, cIy = cTy;
-        if (!P.refine) {
+        if (P.refine != 1) {  // CORNER_REFINE_NONE; CORNER_REFINE_CONTOUR: k_refine_contour writes the corners afterwards
             if (lane == 0) {
                 dstm->corners[2 * cn] = cTx;
                 dstm->corners[2 * cn + 1] = cTy;
@@ -4169,6 +4180,272 @@ __global__ __launch_bounds__(64) void k_subpix(const uint8_t *__restrict__ gray,
             dstm->corners[2 * cn] = cIx;
             dstm->corners[2 * cn + 1] = cIy;
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K7c: CORNER_REFINE_CONTOUR -- aruco.cpp (4.2.0) _refineCandidateLines / _interpolate2Dline / _getCrossPoint, what the node selects
+// with doCornerRefinement = true, cornerRefinementSubPix = false (aruco_detect.cpp:274-283, :700-711).  One wave per marker.
+// The contour of the marker's candidate is still in HBM where the tracing left it (the dense point array of the traced modes, the
+// chunk pool of the whole-border walk): the wave reads it 64 points at a time and sorts every point into the group of the corner
+// that precedes it on the contour -- a corner is a contour point, so the match is a compare of packed words and the group of a
+// lane is the corner of the highest matching lane at or below it (four ballots), carried from chunk to chunk; the points in front
+// of the first corner go to the last one's group, as the reference appends them.  A side's least-squares line needs n, sum t,
+// sum t^2, sum v, sum t v over its points (t the coordinate with the larger extent): sums of products of pixel coordinates,
+// EXACT in integers whatever the order -- per-lane partial sums, DPP reductions -- and the reference's float arithmetic starts
+// where its own does: cv::solve(DECOMP_NORMAL) rounds those sums (accumulated in double) to float once each, hal::LU32f solves
+// the 2 x 2 system (lanes 0..3, one side each), Matx22f::solve crosses adjacent lines (a lane per corner).  A side of exactly
+// two points skips the normal equations in cv::solve (m == n): LU32f then pivots the row with the larger t to the top, so the
+// system is rebuilt in that order from the sums (t_hi, t_lo = the extent; v from sum v and sum t v) and the result is the
+// reference's whichever order the points came in.  A side of one point makes cv::solve throw: the frame is flagged
+// (DevCounts::overflow bit 2) and the call reports FID_E_CV_EXCEPTION for it, as the node publishes nothing (:391-393).
+struct RefineSide {  // exact sums of one side, wave-uniform after the reductions
+    int n, sx, sy, minx, maxx, miny, maxy;
+    long long sxx, syy, sxy;
+};
+
+__device__ __forceinline__ int wave_max_i32(int v) { return -wave_min_i32(-v); }
+
+// hal::LU32f (LUImpl<float>, eps = FLT_EPSILON * 10) on a 2 x 2 system with one right-hand side; false: singular
+__device__ __forceinline__ bool lu32f_2x2(float a00, float a01, float a10, float a11, float b0, float b1, float &x0, float &x1)
+{
+    const float eps = FLT_EPSILON * 10;
+    if (fabsf(a10) > fabsf(a00)) {
+        float t = a00; a00 = a10; a10 = t;
+        t = a01; a01 = a11; a11 = t;
+        t = b0; b0 = b1; b1 = t;
+    }
+    if (fabsf(a00) < eps) return false;
+    const float d = -1 / a00;
+    const float alpha = a10 * d;
+    a11 += alpha * a01;
+    b1 += alpha * b0;
+    if (fabsf(a11) < eps) return false;
+    b1 = b1 / a11;
+    float s = b0;
+    s -= a01 * b1;
+    x0 = s / a00;
+    x1 = b1;
+    return true;
+}
+
+// PTS(k): packed point k (x | y << 16) of the contour, k in [0, count)
+template <typename PTS>
+__device__ __forceinline__ bool refine_candidate_lines_wave(PTS pts, int count, const float cin[8], float &ox, float &oy)
+{
+    const int lane = lane_id();
+    uint32_t ck[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) ck[j] = (uint32_t)(int)cin[2 * j] | ((uint32_t)(int)cin[2 * j + 1] << 16);
+    // per-lane partial sums of the five groups (4: in front of the first corner)
+    int pn[5], psx[5], psy[5], pminx[5], pmaxx[5], pminy[5], pmaxy[5];
+    long long pxx[5], pyy[5], pxy[5];
+#pragma unroll
+    for (int g = 0; g < 5; g++) {
+        pn[g] = psx[g] = psy[g] = 0;
+        pminx[g] = pminy[g] = INT_MAX;
+        pmaxx[g] = pmaxy[g] = INT_MIN;
+        pxx[g] = pyy[g] = pxy[g] = 0;
+    }
+    int carry = 4;                        // group of the last corner met so far (wave-uniform)
+    int ci0 = -1, ci1 = 0, ci2 = 0, ci3 = 0;  // int cornerIndex[4] = {-1}: as the reference writes it
+    for (int base = 0; base < count; base += 64) {
+        const int k = base + lane;
+        const bool in = k < count;
+        const uint32_t p = in ? pts(k) : 0xffffffffu;
+        const unsigned long long m0 = ballot64(in && p == ck[0]), m1 = ballot64(in && p == ck[1]), m2 = ballot64(in && p == ck[2]),
+                                 m3 = ballot64(in && p == ck[3]);
+        const unsigned long long mall = m0 | m1 | m2 | m3;
+        if (m0) ci0 = base + 63 - __clzll((long long)m0);
+        if (m1) ci1 = base + 63 - __clzll((long long)m1);
+        if (m2) ci2 = base + 63 - __clzll((long long)m2);
+        if (m3) ci3 = base + 63 - __clzll((long long)m3);
+        const unsigned long long below = mall & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));
+        int grp = carry;
+        if (below) {
+            const int top = 63 - __clzll((long long)below);
+            // (a pixel that equals two corners cannot happen: the four corners are distinct points -- the last j wins as in the reference)
+            grp = ((m3 >> top) & 1ull) ? 3 : (((m2 >> top) & 1ull) ? 2 : (((m1 >> top) & 1ull) ? 1 : 0));
+        }
+        if (mall) {
+            const int top = 63 - __clzll((long long)mall);
+            carry = ((m3 >> top) & 1ull) ? 3 : (((m2 >> top) & 1ull) ? 2 : (((m1 >> top) & 1ull) ? 1 : 0));
+        }
+        if (in) {
+            const int x = (int)(p & 0xffffu), y = (int)(p >> 16);
+            const long long xx = (long long)x * x, yy = (long long)y * y, xy = (long long)x * y;
+#pragma unroll
+            for (int g = 0; g < 5; g++) {
+                const bool h = grp == g;
+                pn[g] += h ? 1 : 0;
+                psx[g] += h ? x : 0;
+                psy[g] += h ? y : 0;
+                pxx[g] += h ? xx : 0;
+                pyy[g] += h ? yy : 0;
+                pxy[g] += h ? xy : 0;
+                pminx[g] = h && x < pminx[g] ? x : pminx[g];
+                pmaxx[g] = h && x > pmaxx[g] ? x : pmaxx[g];
+                pminy[g] = h && y < pminy[g] ? y : pminy[g];
+                pmaxy[g] = h && y > pmaxy[g] ? y : pmaxy[g];
+            }
+        }
+    }
+    if (carry == 4) return false;  // no corner on the contour (cannot happen: approxPolyDP picks contour points)
+    // reductions; lane g (0..3) keeps side g
+    RefineSide mine = {0, 0, 0, INT_MAX, INT_MIN, INT_MAX, INT_MIN, 0, 0, 0}, extra = mine;
+#pragma unroll
+    for (int g = 0; g < 5; g++) {
+        RefineSide t;
+        t.n = wave_sum_i32(pn[g]);
+        t.sx = wave_sum_i32(psx[g]);
+        t.sy = wave_sum_i32(psy[g]);
+        t.sxx = wave_sum_i64(pxx[g]);
+        t.syy = wave_sum_i64(pyy[g]);
+        t.sxy = wave_sum_i64(pxy[g]);
+        t.minx = wave_min_i32(pminx[g]);
+        t.maxx = wave_max_i32(pmaxx[g]);
+        t.miny = wave_min_i32(pminy[g]);
+        t.maxy = wave_max_i32(pmaxy[g]);
+        if (g == 4) extra = t;
+        else if (lane == g) mine = t;
+    }
+    if (lane == carry && extra.n) {  // "saves extra group into corresponding"
+        mine.n += extra.n;
+        mine.sx += extra.sx;
+        mine.sy += extra.sy;
+        mine.sxx += extra.sxx;
+        mine.syy += extra.syy;
+        mine.sxy += extra.sxy;
+        mine.minx = extra.minx < mine.minx ? extra.minx : mine.minx;
+        mine.maxx = extra.maxx > mine.maxx ? extra.maxx : mine.maxx;
+        mine.miny = extra.miny < mine.miny ? extra.miny : mine.miny;
+        mine.maxy = extra.maxy > mine.maxy ? extra.maxy : mine.maxy;
+    }
+    // _interpolate2Dline, lanes 0..3
+    float l0 = 0.f, l1 = 0.f, l2 = 0.f;
+    bool bad = false;
+    if (lane < 4) {
+        if (mine.n < 2) {
+            bad = true;
+        } else {
+            const bool xm = (float)mine.maxx - (float)mine.minx > (float)mine.maxy - (float)mine.miny;
+            float a00, a01, a10, a11, b0, b1;
+            if (mine.n == 2) {
+                // m == n: no normal equations.  LU32f puts the row with the larger |t| first (strict compare; equal t: singular)
+                const int thi = xm ? mine.maxx : mine.maxy, tlo = xm ? mine.minx : mine.miny;
+                const long long sv = xm ? mine.sy : mine.sx;
+                long long vhi, vlo;
+                if (thi != tlo) {
+                    vhi = (mine.sxy - (long long)tlo * sv) / (long long)(thi - tlo);
+                    vlo = sv - vhi;
+                } else {
+                    vhi = xm ? mine.miny : mine.minx;  // (both points share t: the system is singular whatever v is)
+                    vlo = sv - vhi;
+                }
+                a00 = (float)thi; a01 = 1.f; a10 = (float)tlo; a11 = 1.f;
+                b0 = (float)vhi; b1 = (float)vlo;
+            } else {
+                const long long st = xm ? mine.sx : mine.sy, stt = xm ? mine.sxx : mine.syy, sv = xm ? mine.sy : mine.sx;
+                a00 = (float)(double)stt;
+                a01 = a10 = (float)(double)st;
+                a11 = (float)(double)mine.n;
+                b0 = (float)(double)mine.sxy;
+                b1 = (float)(double)sv;
+            }
+            float c0 = 0.f, c1 = 0.f;
+            if (!lu32f_2x2(a00, a01, a10, a11, b0, b1, c0, c1)) c0 = c1 = 0.f;  // if( !result ) dst = Scalar(0)
+            if (xm) { l0 = c0; l1 = -1.f; l2 = c1; }
+            else    { l0 = -1.f; l1 = c0; l2 = c1; }
+        }
+    }
+    if (ballot64(bad)) return false;
+    int inc = 1;
+    inc = ((ci0 > ci1) && (ci3 > ci0)) ? -1 : inc;
+    inc = ((ci2 > ci3) && (ci1 > ci2)) ? -1 : inc;
+    // _getCrossPoint(lines[i], lines[(i + 1) % 4]) (inc < 0) or (lines[i], lines[(i + 3) % 4]): lane i = corner i
+    const int other = (lane + (inc < 0 ? 1 : 3)) & 3;
+    const float m0 = __shfl(l0, other, WAVE), m1 = __shfl(l1, other, WAVE), m2 = __shfl(l2, other, WAVE);
+    {
+        const float a00 = l0, a01 = l1, a10 = m0, a11 = m1;
+        const float b0 = -l2, b1 = -m2;
+        float d = a00 * a11 - a01 * a10;
+        if (d == 0) {
+            ox = oy = 0.f;
+        } else {
+            d = 1 / d;
+            ox = (b0 * a11 - b1 * a01) * d;
+            oy = (b1 * a00 - b0 * a10) * d;
+        }
+    }
+    return true;
+}
+
+struct RefinePtsDense {
+    const uint32_t *p;
+    __device__ __forceinline__ uint32_t operator()(int k) const { return p[k]; }
+};
+struct RefinePtsChunks {  // the whole-border walk (FID_TRACE=legacy) leaves the points in pool chunks listed in the contour's table row
+    const uint32_t *row, *pool;
+    __device__ __forceinline__ uint32_t operator()(int k) const { return pool[(long long)row[k / CK] * CK + (k & (CK - 1))]; }
+};
+
+#define REFINE_LEGACY_BIT 0x80000000u
+__global__ __launch_bounds__(64) void k_refine_contour(const fid_marker *__restrict__ pre, fid_marker *__restrict__ out,
+                                                        const int *__restrict__ mksrc, const DevCand *__restrict__ filtered,
+                                                        const uint32_t *__restrict__ dense, const uint32_t *__restrict__ chunk_tab,
+                                                        const uint32_t *__restrict__ pool, DevCounts *__restrict__ counts, const DevParams P)
+{
+    const int lane = lane_id();
+    const int f = blockIdx.y;
+    int nm = counts[f].nmark;
+    nm = nm < P.maxMarkers ? nm : P.maxMarkers;
+    for (int mk = blockIdx.x; mk < nm; mk += gridDim.x) {
+        const fid_marker *src = pre + (long long)f * P.maxMarkers + mk;
+        fid_marker *dstm = out + (long long)f * P.maxMarkers + mk;
+        const DevCand *cd = filtered + (long long)f * P.maxCands + mksrc[(long long)f * P.maxMarkers + mk];
+        const int count = cd->size;
+        const uint32_t pref = cd->pref;
+        float cin[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) cin[k] = src->corners[k];
+        float ox = 0.f, oy = 0.f;
+        bool ok;
+        if (pref & REFINE_LEGACY_BIT) {
+            const int nck = chunk_tab_pitch(P);
+            RefinePtsChunks pts{chunk_tab + ((long long)f * 2 + 1) * P.maxContours * nck + (long long)(pref & ~REFINE_LEGACY_BIT) * nck, pool};
+            ok = refine_candidate_lines_wave(pts, count, cin, ox, oy);
+        } else {
+            RefinePtsDense pts{dense + (long long)f * P.maxChunks * CK + pref};
+            ok = refine_candidate_lines_wave(pts, count, cin, ox, oy);
+        }
+        if (!ok) {
+            if (lane == 0) atomicOr(&counts[f].overflow, 4);
+            ox = cin[2 * (lane & 3)];
+            oy = cin[2 * (lane & 3) + 1];
+        }
+        if (lane == 0) dstm->id = src->id;
+        if (lane < 4) {
+            dstm->corners[2 * lane] = ox;
+            dstm->corners[2 * lane + 1] = oy;
+        }
+    }
+}
+
+// the same on caller-supplied contours (fid_refine_contour_corners: one marker per workgroup, item i = points [off[i], off[i + 1]))
+__global__ __launch_bounds__(64) void k_refine_contour_pts(const uint32_t *__restrict__ pts, const int *__restrict__ off,
+                                                            float *__restrict__ corners, int *__restrict__ status)
+{
+    const int i = blockIdx.x, lane = lane_id();
+    float cin[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) cin[k] = corners[8 * i + k];
+    float ox = 0.f, oy = 0.f;
+    RefinePtsDense src{pts + off[i]};
+    const bool ok = refine_candidate_lines_wave(src, off[i + 1] - off[i], cin, ox, oy);
+    if (lane == 0) status[i] = ok ? 0 : 1;
+    if (ok && lane < 4) {
+        corners[8 * i + 2 * lane] = ox;
+        corners[8 * i + 2 * lane + 1] = oy;
     }
 }
 

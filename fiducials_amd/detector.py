@@ -91,6 +91,8 @@ class ArucoDetector:
             pass
 
     def _check(self, rc):
+        if rc == _lib.FID_E_CV_EXCEPTION:
+            raise _lib.CvException(rc, (self._L.fid_last_error(self._ctx) or b"").decode())
         if rc != _lib.FID_OK:
             raise FidError(rc, (self._L.fid_last_error(self._ctx) or b"").decode() or self._L.fid_strerror(rc).decode())
 
@@ -210,6 +212,20 @@ class ArucoDetector:
         out = (FidPoseOut * max(n, 1))()
         self._check(self._L.fid_pose(self._ctx, Kc, Dc, mk, lens, n, float(fiducial_len), out))
         return _poses_to_result(out, n)
+
+    def refine_contour_corners(self, contours, corners) -> np.ndarray:
+        """aruco.cpp _refineCandidateLines (CORNER_REFINE_CONTOUR) for markers given by their contours (list of (n_i, 2) int
+        arrays in findContours order) and quads ((m, 4, 2), corners on the contours): the device code the pipeline runs after
+        `_filterDetectedMarkers` when cornerRefinementMethod = 2.  Raises CvException where the reference throws."""
+        cs = [np.ascontiguousarray(c, dtype=np.int32).reshape(-1, 2) for c in contours]
+        off = np.zeros(len(cs) + 1, dtype=np.int32)
+        off[1:] = np.cumsum([len(c) for c in cs])
+        pts = np.ascontiguousarray(np.concatenate(cs) if cs else np.zeros((0, 2), np.int32))
+        q = np.ascontiguousarray(corners, dtype=np.float32).reshape(len(cs), 8).copy()
+        st = np.zeros(max(len(cs), 1), dtype=np.int32)
+        self.last_refine_status = st
+        self._check(self._L.fid_refine_contour_corners(self._ctx, pts.ctypes.data, off.ctypes.data, len(cs), q.ctypes.data, st.ctypes.data))
+        return q.reshape(-1, 4, 2)
 
     def pose_last(self, fiducial_len: float, K, D, unpack: bool = True):
         """Poses of the markers found by the last detect_* call, computed without the corners leaving HBM."""

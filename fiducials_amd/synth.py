@@ -74,7 +74,9 @@ def _blur(img, sigma):
 
 def make_frame(d: Dictionary, seed: int, width: int = 1920, height: int = 1080, n_markers: int = 20,
                ids: np.ndarray | None = None, K: np.ndarray | None = None, noise_sigma: float = 2.0,
-               side_range=(96.0, 160.0), max_tilt_deg: float = 35.0, pinned_only: bool = False) -> SynthFrame:
+               side_range=(96.0, 160.0), max_tilt_deg: float = 35.0, pinned_only: bool = False, border_bits: int = 1) -> SynthFrame:
+    """border_bits: cells of black border the markers are drawn with (aruco::drawMarker's borderBits; the detector side is
+    DetectorParameters::markerBorderBits, aruco_detect.cpp:718)."""
     rng = np.random.default_rng(seed)
     if K is None:
         K = K_DEFAULT.copy()
@@ -102,7 +104,7 @@ def make_frame(d: Dictionary, seed: int, width: int = 1920, height: int = 1080, 
     ids = np.asarray(ids, dtype=np.int32)
 
     n = d.marker_size
-    ncell = n + 2  # marker cells incl. black border
+    ncell = n + 2 * border_bits  # marker cells incl. black border
     q = 1.0  # quiet zone in cells
     gt = np.zeros((n_markers, 4, 2))
     rvecs = np.zeros((n_markers, 3))
@@ -160,7 +162,7 @@ def make_frame(d: Dictionary, seed: int, width: int = 1920, height: int = 1080, 
         V = (H[1, 0] * PX + H[1, 1] * PY + H[1, 2]) / den
         inside = (U >= -q) & (U < ncell + q) & (V >= -q) & (V < ncell + q)
         tiny = np.full((ncell + 2, ncell + 2), 230.0, dtype=np.float32)  # quiet zone white
-        m = draw_marker(d, int(ids[mi]), ncell).astype(np.float32)
+        m = draw_marker(d, int(ids[mi]), ncell, border_bits).astype(np.float32)
         tiny[1:-1, 1:-1] = np.where(m > 0, 230.0, 25.0)
         ui = np.clip(np.floor(U + q).astype(np.int64), 0, ncell + 1)
         vi = np.clip(np.floor(V + q).astype(np.int64), 0, ncell + 1)

@@ -41,8 +41,9 @@ extern "C" {
  * which forgot to bump it).  3: fid_last_stage_ms reports 15 stages (seedless_chain); fid_pose_last may hand over poses that the
  * preceding fid_detect_* call already computed for the same camera; fid_stag_detect_markers_batch reports 0 markers for a frame
  * whose slot was too small (round 3).  4: + fid_submit_device / fid_submit_batch / fid_collect / fid_order_after, fid_png_* (round 3).  Entry points are only ever added: a caller
- * built against 1 runs against 4. */
-#define FID_ABI_VERSION 4
+ * built against 1 runs against 5.  5: cornerRefinementMethod 2 (CORNER_REFINE_CONTOUR) is implemented instead of refused,
+ * FID_E_CV_EXCEPTION, fid_refine_contour_corners (round 4). */
+#define FID_ABI_VERSION 5
 
 typedef enum fid_status {
     FID_OK = 0,
@@ -51,7 +52,11 @@ typedef enum fid_status {
     FID_E_HIP = 3,           /* a HIP runtime call failed (fid_last_error gives the text) */
     FID_E_CAPACITY = 4,      /* an internal or caller buffer was too small; outputs truncated */
     FID_E_OUT_OF_MEMORY = 5,
-    FID_E_UNSUPPORTED = 6    /* parameter combination outside what the kernels implement */
+    FID_E_UNSUPPORTED = 6,   /* parameter combination outside what the kernels implement */
+    FID_E_CV_EXCEPTION = 7   /* the reference's OpenCV call throws cv::Exception on this input: imageCallback's catch block logs it
+                                and publishes nothing for the frame (aruco_detect.cpp:391-393).  n_per_frame[f] = -1 for such a
+                                frame, the other frames of the call are valid.  Only CORNER_REFINE_CONTOUR can raise it (a marker
+                                side of fewer than two contour points: cv::solve is handed one equation for two unknowns). */
 } fid_status;
 
 typedef enum fid_encoding {  /* sensor_msgs/Image encodings the node accepts via toCvCopy(BGR8) */
@@ -68,7 +73,8 @@ typedef struct fid_params {
     int32_t adaptiveThreshWinSizeMin;              /* 3    */
     int32_t adaptiveThreshWinSizeMax;              /* 53   */
     int32_t adaptiveThreshWinSizeStep;             /* 4    */
-    int32_t cornerRefinementMethod;                /* 1 = CORNER_REFINE_SUBPIX (node default), 0 = NONE */
+    int32_t cornerRefinementMethod;                /* 1 = CORNER_REFINE_SUBPIX (node default), 0 = NONE, 2 = CORNER_REFINE_CONTOUR
+                                                      (doCornerRefinement && !cornerRefinementSubPix, :274-283, :700-711) */
     int32_t cornerRefinementWinSize;               /* 5    */
     int32_t cornerRefinementMaxIterations;         /* 30   */
     double cornerRefinementMinAccuracy;            /* 0.01 */
@@ -181,6 +187,14 @@ fid_status fid_pose(fid_ctx *ctx, const double K[9], const double D[5], const fi
  * poses for frame f start at out[f * cap_per_frame]. */
 fid_status fid_pose_last(fid_ctx *ctx, const double K[9], const double D[5], double fiducial_len,
                          fid_pose_out *out, int32_t cap_per_frame);
+
+/* aruco.cpp _refineCandidateLines on its own (what CORNER_REFINE_CONTOUR does to every marker inside fid_detect*): n markers,
+ * contour i = points [offsets[i], offsets[i + 1]) of pts_xy (int32 x, y pairs in cv::findContours order, CHAIN_APPROX_NONE;
+ * offsets[0] = 0), corners = 8 floats per marker, in: the quad (its corners are contour points), out: the crossings of the
+ * four fitted side lines.  status_per_marker[i] = 0, or 1 where the reference throws (the corners are then left as they were;
+ * the call returns FID_E_CV_EXCEPTION).  The same device code as inside the pipeline (k_refine_contour). */
+fid_status fid_refine_contour_corners(fid_ctx *ctx, const int32_t *pts_xy, const int32_t *offsets, int32_t n, float *corners,
+                                      int32_t *status_per_marker);
 
 /* stage taps for parity tests (device -> host copies of intermediate buffers of the last call) */
 typedef enum fid_tap {

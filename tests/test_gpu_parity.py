@@ -273,6 +273,12 @@ PARAM_SETS = [
     dict(polygonalApproxAccuracyRate=0.05, minCornerDistanceRate=0.1, minMarkerDistanceRate=0.2, maxMarkerPerimeterRate=1.0),
     dict(errorCorrectionRate=0.0, maxErroneousBitsInBorderRate=0.35, minMarkerPerimeterRate=0.03, perspectiveRemovePixelPerCell=6),
     dict(adaptiveThreshWinSizeMin=3, adaptiveThreshWinSizeMax=3, adaptiveThreshWinSizeStep=4, cornerRefinementMethod=0),
+    # CORNER_REFINE_CONTOUR: doCornerRefinement = true, cornerRefinementSubPix = false (aruco_detect.cpp:274-283, 700-711)
+    dict(cornerRefinementMethod=2),
+    dict(cornerRefinementMethod=2, adaptiveThreshWinSizeMin=5, adaptiveThreshWinSizeMax=29, adaptiveThreshWinSizeStep=6, polygonalApproxAccuracyRate=0.03),
+    # markerBorderBits = 2 (aruco_detect.cpp:718): the frame is drawn with a two-cell border (aruco::drawMarker's borderBits)
+    dict(markerBorderBits=2),
+    dict(markerBorderBits=2, cornerRefinementMethod=2, perspectiveRemovePixelPerCell=5),
 ]
 
 
@@ -282,7 +288,8 @@ def test_detector_parameter_matrix(k, dic):
     """aruco::DetectorParameters away from the node defaults (the generic threshold kernel, other unwarp sizes, other gates
     and refinement settings), two dictionaries: ids and corners as the oracle's under the same parameters."""
     d = get_predefined_dictionary(dic)
-    fr = make_frame(d, 300 + 7 * k + dic, width=1280, height=720, n_markers=10, side_range=(70, 130))
+    fr = make_frame(d, 300 + 7 * k + dic, width=1280, height=720, n_markers=10, side_range=(70, 130),
+                    border_bits=PARAM_SETS[k].get("markerBorderBits", 1))
     p, op = default_params(), oracle.default_params()
     for name, v in PARAM_SETS[k].items():
         setattr(p, name, v)
@@ -596,3 +603,113 @@ def test_randomised_sweep_equals_the_oracle():
     p = subprocess.run([sys.executable, os.path.join(root, "tools", "gpu_stress.py"), "21", "7000"], capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
     assert "21 cases, 0 mismatches" in p.stdout
+
+
+# ---- CORNER_REFINE_CONTOUR (cornerRefinementMethod = 2: the node's doCornerRefinement = true, cornerRefinementSubPix = false,
+#      /root/reference/aruco_detect/src/aruco_detect.cpp:274-283, 700-711; aruco.cpp _refineCandidateLines)
+def _closed_polyline(corners):
+    pts = []
+    for k in range(len(corners)):
+        (x0, y0), (x1, y1) = corners[k], corners[(k + 1) % len(corners)]
+        n = max(abs(x1 - x0), abs(y1 - y0))
+        for t in range(n):
+            pts.append((int(round(x0 + (x1 - x0) * t / n)), int(round(y0 + (y1 - y0) * t / n))))
+    return np.array(pts, dtype=np.int32)
+
+
+def test_contour_refinement_kernel_on_given_contours(det7):
+    """The device code of _refineCandidateLines through fid_refine_contour_corners, on contours the pipeline can hardly be made
+    to produce: every rotation / direction / starting point, a corner pixel the contour visits twice, a side of two points
+    (cv::solve's m == n road), a side of one point (the reference throws), long contours (sums beyond 2^32)."""
+    rng = np.random.default_rng(21)
+    contours, quads = [], []
+    for trial in range(60):
+        c = np.array([900.0, 500.0]) + rng.uniform(-300, 300, 2)
+        a = rng.uniform(0, 2 * np.pi)
+        half = rng.uniform(8, 400)
+        R = np.array([[np.cos(a), -np.sin(a)], [np.sin(a), np.cos(a)]])
+        sq = (R @ (np.array([[-1, -1], [1, -1], [1, 1], [-1, 1]], dtype=float) * half * rng.uniform(0.7, 1.3, (4, 1))).T).T + c
+        cs = [tuple(int(v) for v in np.round(p)) for p in np.clip(sq, 0, 4000)]
+        if len(set(cs)) < 4:
+            continue
+        cont = np.roll(_closed_polyline(cs), -int(rng.integers(0, 50)), axis=0)
+        if trial % 2:
+            cont = cont[::-1].copy()
+        r = int(rng.integers(0, 4))
+        contours.append(cont)
+        quads.append(np.array(cs[r:] + cs[:r], dtype=np.float32))
+    # a corner pixel visited twice (a one-pixel spike at the corner: out and back)
+    base = [(100, 100), (300, 110), (290, 300), (90, 280)]
+    cont = _closed_polyline(base).tolist()
+    i = cont.index([300, 110])
+    cont = cont[:i + 1] + [[301, 109], [300, 110]] + cont[i + 1:]
+    contours.append(np.array(cont, dtype=np.int32))
+    quads.append(np.array(base, dtype=np.float32))
+    # a side of exactly two points, in both orders of travel
+    two = np.array([(0, 0), (1, 1), (2, 2), (3, 3), (3, 4), (3, 5), (2, 5), (1, 5), (0, 4), (0, 3), (0, 2), (0, 1)], dtype=np.int32) + 50
+    q2 = np.array([(0, 0), (2, 2), (3, 5), (0, 4)], dtype=np.float32) + 50
+    contours += [two, two[::-1].copy()]
+    quads += [q2, q2]
+    out = det7.refine_contour_corners(contours, np.stack(quads))
+    for k, (cont, q) in enumerate(zip(contours, quads)):
+        ref = oracle.refine_candidate_lines(cont, q)
+        assert np.array_equal(out[k], ref), (k, out[k], ref)
+    # a side of one point: FID_E_CV_EXCEPTION, status per marker, the good marker of the same call still refined
+    q1 = np.array([(0, 0), (1, 1), (3, 5), (0, 4)], dtype=np.float32) + 50
+    with pytest.raises(_lib.CvException):
+        det7.refine_contour_corners([contours[0], two], np.stack([quads[0], q1]))
+    assert det7.last_refine_status.tolist() == [0, 1]
+    with pytest.raises(oracle.CvException):
+        oracle.refine_candidate_lines(two, q1)
+
+
+@pytest.mark.parametrize("key", ["tag_01", "tag_245_246", "img_403", "bag_4957"])
+def test_contour_refinement_on_the_reference_images(key):
+    gray = load_gray(key)
+    p, op = params_pair(cornerRefinementMethod=2)
+    det = ArucoDetector(7, params=p, max_width=1920, max_height=1080)
+    try:
+        corners, ids, ocorners = check_stages(det, gray, det.dictionary, op)
+        assert len(ids) >= 1 and np.array_equal(corners, ocorners)
+        pre = det.tap_presubpix()[0][:len(ids)]["corners"].reshape(-1, 4, 2)
+        assert not np.array_equal(corners, pre) and np.abs(corners - pre).max() < 1.5  # refined, and still at the corner
+    finally:
+        det.close()
+
+
+def test_contour_refinement_cfg2_every_tracing_mode_batch_and_pose(monkeypatch):
+    """cfg 2 frames under CORNER_REFINE_CONTOUR: corners == the oracle's in all three tracing modes (the contour points come from
+    the dense point array in the traced modes, from the chunk pool behind the whole-border walk), as a batch, switched on and
+    off on a live context (dynamic_reconfigure), and the poses follow the refined corners."""
+    d = get_predefined_dictionary(6)
+    frames = [make_frame(d, s) for s in (1000, 1001)]
+    p, op = params_pair(cornerRefinementMethod=2)
+    want = [oracle.detect(fr.image, d, params=op) for fr in frames]
+    for mode in ("cycles", "chain", "legacy"):
+        monkeypatch.setenv("FID_TRACE", mode)
+        det = ArucoDetector(d, params=p, max_width=1920, max_height=1080, max_batch=2)
+        try:
+            for fr, (oids, ocorners) in zip(frames, want):
+                corners, ids = det.detect_markers(fr.image)
+                assert ids.tolist() == oids.tolist() and len(ids) == 20
+                assert np.array_equal(corners, ocorners), (mode, np.abs(corners - ocorners).max())
+            res = det.detect_markers_batch(np.stack([fr.image for fr in frames]))
+            for (corners, ids), (oids, ocorners) in zip(res, want):
+                assert ids.tolist() == oids.tolist() and np.array_equal(corners, ocorners)
+            poses = det.pose_last(0.14, K_DEFAULT, np.zeros(5))
+            for f, (oids, ocorners) in enumerate(want):
+                for i in range(len(oids)):
+                    r, t, _ = oracle.solve_pnp_square(K_DEFAULT, np.zeros(5), ocorners[i], 0.14)
+                    assert np.abs(poses[f].rvecs[i] - r).max() < POSE_TOL and np.abs(poses[f].tvecs[i] - t).max() < POSE_TOL
+            if mode == "cycles":
+                # cornerRefinementSubPix flipped back and forth by dynamic_reconfigure (aruco_detect.cpp:274-283)
+                p1, op1 = params_pair(cornerRefinementMethod=1)
+                det.set_params(p1)
+                c1, i1 = det.detect_markers(frames[0].image)
+                o1 = oracle.detect(frames[0].image, d, params=op1)
+                assert i1.tolist() == o1[0].tolist() and np.array_equal(c1, o1[1])
+                det.set_params(p)
+                c2, i2 = det.detect_markers(frames[0].image)
+                assert np.array_equal(c2, want[0][1])
+        finally:
+            det.close()

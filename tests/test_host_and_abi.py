@@ -22,7 +22,7 @@ def test_abi_exports_every_declared_symbol():
     for s in declared:
         assert hasattr(L, s), s
     assert declared == set(_lib.SYMBOLS)
-    assert L.fid_abi_version() == 4
+    assert L.fid_abi_version() == 5
     assert b"no CPU fallback" in L.fid_strerror(_lib.FID_E_NO_DEVICE)
 
 

@@ -4204,7 +4204,17 @@ struct RefineSide {  // exact sums of one side, wave-uniform after the reduction
     long long sxx, syy, sxy;
 };
 
-__device__ __forceinline__ int wave_max_i32(int v) { return -wave_min_i32(-v); }
+__device__ __forceinline__ int wave_max_i32(int v)
+{
+#define S_(C, M)                                  \
+    {                                             \
+        const int o = FID_DPP(INT_MIN, v, C, M);  \
+        v = o > v ? o : v;                        \
+    }
+    FID_DPP_SCAN_STEPS(S_)
+#undef S_
+    return __builtin_amdgcn_readlane(v, 63);
+}
 
 // hal::LU32f (LUImpl<float>, eps = FLT_EPSILON * 10) on a 2 x 2 system with one right-hand side; false: singular
 __device__ __forceinline__ bool lu32f_2x2(float a00, float a01, float a10, float a11, float b0, float b1, float &x0, float &x1)

@@ -28,10 +28,9 @@ if ROOT not in sys.path:
 
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 os.environ.setdefault("FID_PROFILE", "1")  # per-stage hipEvents on the context stream
-# the STag side result keeps 22 contexts (streams) in flight: with the runtime's default of 4 hardware queues their kernels
-# queue up behind one another (measured 570 -> 1070 frames/s with 24 queues; the aruco path does not care).  Must be set
-# before the HIP runtime starts.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
+# GPU_MAX_HW_QUEUES is NOT set here (rounds 1 - 3 defaulted it to 24): the line is measured with the HIP runtime's own default
+# number of hardware queues, which is what a ROS node that links the library gets.  extra.hw_queues_24 re-runs the headline and
+# the cfg 5 side result in child processes with GPU_MAX_HW_QUEUES=24 (the variable is read when the runtime starts).
 
 import numpy as np  # noqa: E402
 
@@ -103,6 +102,64 @@ def pmc_traffic(stage, frames_per_launch):
         return None if t is None else int(t * frames_per_launch)
     except Exception:
         return None
+
+
+def issue_roofline(fps_per_gpu):
+    """The compute-side roofline: VALU wave-instructions per second against what the chip issues, MEASURED (tools/valu_calib.hip
+    -> profiles/r04_valu_calib.json): gfx950 SIMDs issue a wave64 VALU instruction every 2 cycles only for a small class
+    (v_add/sub_u32, and/or/xor/not, right shifts, v_mov, fp32 add/mul/fma: 900 - 1050 G/s on the chip) and every 4 cycles for
+    the rest (mul24 / mad / dot2c / packed 16-bit / alignbit / bfe / left shifts / min / max / compares / selects / lane moves /
+    DPP forms / f64: 570 - 590 G/s).  achieved = SQ_INSTS_VALU per frame (profiles/sq_cycles.json, rocprofv3 --pmc on a 64-frame
+    sub-batch of THIS build, refused if the library hash differs) x frames/s; peak_measured = the harmonic mix of the two class
+    peaks with every kernel's static class shares (profiles/isa_classes.json, disassembly of the shipped .so) weighted by its
+    dynamic SQ_INSTS_VALU."""
+    out = {"bound": "valu-issue", "unit": "G wave-instructions/s", "achieved": None, "peak_measured": None, "frac": None}
+    try:
+        import hashlib
+        import statistics
+
+        from fiducials_amd import _lib
+
+        with open(os.path.join(ROOT, "profiles", "r04_valu_calib.json")) as fh:
+            cal = json.load(fh)
+        rates = {k.split()[0]: v["by_waves_per_simd"]["8"]["chip_ginstr_s"] for k, v in cal["kinds"].items()
+                 if v["counts"] == "VALU" and k.startswith("v_") and " " not in k.strip()}
+        fast = [r for r in rates.values() if r > 800]
+        slow = [r for r in rates.values() if 300 < r <= 800]
+        p2, p4 = statistics.median(fast), statistics.median(slow)
+        out.update({"peak_2cycle_class": round(p2, 1), "peak_4cycle_class": round(p4, 1),
+                    "calibration": "profiles/r04_valu_calib.json (tools/valu_calib.hip, 8 waves per SIMD, whole chip)"})
+        with open(_lib.lib_path(), "rb") as fh:
+            sha = hashlib.sha256(fh.read()).hexdigest()
+        with open(os.path.join(ROOT, "profiles", "isa_classes.json")) as fh:
+            cls = json.load(fh)
+        with open(os.path.join(ROOT, "profiles", "sq_cycles.json")) as fh:
+            sq = json.load(fh)
+        if cls.get("library_sha256") != sha or sq.get("library_sha256") != sha:
+            out["note"] = "profiles/sq_cycles.json / isa_classes.json were measured on another build of the library: achieved unknown"
+            return out
+        by_mangled = {v["mangled"]: v for v in cls["kernels"].values()}
+        valu = salu = t_fast = t_slow = 0.0
+        for name, k in sq["kernels"].items():
+            if not name.startswith("k_"):
+                continue
+            n = k.get("SQ_INSTS_VALU", 0.0)
+            valu += n
+            salu += k.get("SQ_INSTS_SALU", 0.0)
+            base = name.split("<")[0]
+            cand = [v for m, v in by_mangled.items() if base in m]
+            share = (sum(c["fast"] for c in cand) / max(sum(c["valu"] for c in cand), 1)) if cand else 0.0
+            t_fast += n * share
+            t_slow += n * (1.0 - share)
+        peak = valu / (t_fast / p2 + t_slow / p4) if valu > 0 else None
+        ach = valu * fps_per_gpu / 1e9
+        out.update({"achieved": round(ach, 1), "peak_measured": round(peak, 1), "frac": round(ach / peak, 4),
+                    "valu_wave_instr_per_frame": round(valu), "salu_wave_instr_per_frame": round(salu),
+                    "static_2cycle_share": round(t_fast / valu, 3),
+                    "counters": "profiles/sq_cycles.json (SQ_INSTS_VALU / SQ_INSTS_SALU per frame, one 64-frame sub-batch)"})
+    except Exception as e:  # noqa: BLE001
+        out["note"] = f"unavailable: {e!r}"
+    return out
 
 
 def roofline_of(stage, stage_ms, launches, frames_per_launch):
@@ -839,6 +896,10 @@ def main():
     ap.add_argument("--unique", type=int, default=0, help="unique synthetic frames per GPU (0 = batch); fewer are tiled")
     ap.add_argument("--in-flight", type=int, default=int(os.environ.get("FID_BENCH_IN_FLIGHT", "2")),
                     help="contexts that take the steps in turn: step k + 1 is submitted before step k is collected (1 = one call after the other)")
+    ap.add_argument("--feed", choices=["resident", "host"], default="resident",
+                    help="resident (default, the metric): the batch lies in HBM when the timed region starts.  host: every step's frames "
+                         "come from pinned HOST memory through fid_submit_batch (BASELINE cfg 4 as north_star words it: independent camera "
+                         "streams, one PCIe link per GPU); the line then says so in config.feed and is not the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the cfg 2 latency and cfg 5 (STag) side results")
     ap.add_argument("--stag-side-child", action="store_true", help=argparse.SUPPRESS)  # the cfg 5 side result, own process
@@ -893,6 +954,9 @@ def main():
     host = np.concatenate([frames_u] * reps)[:B]
     d_frames = torch.from_numpy(host).to(f"cuda:{local_rank}")
     torch.cuda.synchronize()
+    feed_host = args.feed == "host"
+    # --feed host: a capture ring of two pinned batches per rank (a step's frames must stay put until its results are collected)
+    h_ring = [torch.from_numpy(host).pin_memory().numpy(), torch.from_numpy(host.copy()).pin_memory().numpy()] if feed_host else None
     # The steps go through `depth` contexts in turn (fiducials_amd/pipeline.py: fid_submit_device / fid_collect): step k + 1 is
     # enqueued before step k's results are fetched, so the latency-bound end of one batch runs under the front of the next.
     # Every step is a whole pass (gray .. pose, results on the host) over its own 256 frames; all K are finished inside the
@@ -922,13 +986,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(max(args.warmup, depth if args.warmup else 0)):  # (every context sets up its streams on its first batch)
-        pipe.push(d_frames.data_ptr(), B, W, H, unpack=False)
+    def push(k):
+        if feed_host:
+            return pipe.push_host(h_ring[k % 2], unpack=False)
+        return pipe.push(d_frames.data_ptr(), B, W, H, unpack=False)
+
+    for k in range(max(args.warmup, depth if args.warmup else 0)):  # (every context sets up its streams on its first batch)
+        push(k)
     pipe.flush(unpack=False)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        take(pipe.push(d_frames.data_ptr(), B, W, H, unpack=False))
+    for k in range(args.steps):
+        take(push(k))
     for done in pipe.flush(unpack=False):
         take(done)
     torch.cuda.synchronize()
@@ -956,8 +1025,10 @@ def main():
             "achieved": round(fps / n_gpus * PIPELINE_BYTES / 1e9, 2),
             "frac": round(fps / n_gpus * PIPELINE_BYTES / 1e9 / HBM_PEAK_GBS, 5),
         }
+        # what actually binds this integer / bit path: instruction issue, priced against the MEASURED issue rate
+        roof["issue"] = issue_roofline(fps / n_gpus)
         out = {
-            "metric": "frames/sec @1920x1080 20-marker (aruco detect + pose hot path)",
+            "metric": "frames/sec @1920x1080 20-marker (aruco detect + pose hot path)" + (", frames fed from host memory" if feed_host else ""),
             "value": round(fps, 2),
             "unit": "frames/s",
             "n_gpus": 1 if OVERSUB else n_gpus,
@@ -976,6 +1047,9 @@ def main():
                 "frames_per_step": B * n_gpus,
                 "parallelism": f"frames sharded over {n_gpus} GPU(s), no collective",
                 "markers_per_frame_found": round(markers / max(B * args.steps, 1), 2),
+                "feed": "host: every step's frames come from pinned host memory over PCIe (fid_submit_batch), NOT the headline configuration"
+                        if feed_host else "resident: the batch lies in HBM when the timed region starts",
+                "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "runtime default"),
                 "in_flight": depth,
                 "in_flight_note": f"{depth} contexts take the steps in turn (fid_submit_device / fid_collect): ms_per_step is the "
                                   "timed region / steps, a throughput figure; one step alone is one_at_a_time.ms_per_step",
@@ -1028,6 +1102,30 @@ def main():
                 out["extra"]["cfg5_stag"] = json.loads(lines[-1])
             except Exception as e:  # noqa: BLE001
                 out["extra"]["cfg5_stag"] = {"error": repr(e)}
+            if "GPU_MAX_HW_QUEUES" not in os.environ:
+                # the same two numbers with GPU_MAX_HW_QUEUES=24 (what rounds 1 - 3 set for themselves): child processes, because
+                # the runtime reads the variable when it starts
+                hq = {"GPU_MAX_HW_QUEUES": "24"}
+                try:
+                    env = dict(os.environ, LOCAL_RANK=str(local_rank), GPU_MAX_HW_QUEUES="24")
+                    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", "10", "--warmup", "3", "--batch", str(B),
+                           "--unique", str(unique), "--no-extras", "--no-cpu-baseline"]
+                    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+                    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+                    if p.returncode != 0 or not lines:
+                        raise RuntimeError(f"rc {p.returncode}: {p.stderr[-300:]}")
+                    doc = json.loads(lines[-1])
+                    hq["cfg3"] = {"value": doc["value"], "unit": "frames/s", "ms_per_step": doc["ms_per_step"], "steps": doc["steps"]}
+                    cmd = [sys.executable, os.path.abspath(__file__), "--stag-side-child", "--gpus", "1", "--no-cpu-baseline"]
+                    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+                    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+                    if p.returncode != 0 or not lines:
+                        raise RuntimeError(f"stag rc {p.returncode}: {p.stderr[-300:]}")
+                    doc = json.loads(lines[-1])
+                    hq["cfg5_stag"] = {"value": doc["value"], "unit": "frames/s", "ms_single_frame": doc.get("ms_single_frame")}
+                except Exception as e:  # noqa: BLE001
+                    hq["error"] = repr(e)
+                out["extra"]["hw_queues_24"] = hq
         if n_gpus == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(frames_u, K, D)
         print(json.dumps(out))

@@ -378,14 +378,32 @@ SubPlan plan_sub_batches(const fid_ctx *c, int F)
 // hands the markers out.  fid_detect_device / fid_detect_batch call one after the other; fid_submit_device / fid_collect expose
 // the halves, so that a caller with a stream of batches keeps two or three contexts in flight and the latency-bound tail of one
 // batch runs under the front of the next.
-fid_status enqueue_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H, int stride, long long fstride, fid_encoding enc)
+// Everything a detect call can be refused for, checked BEFORE anything is put on a stream: feed_and_enqueue queues host -> device
+// copies of the caller's buffer in front of the kernels, and a call that is then refused must not leave DMA from that buffer in
+// flight (the caller may free it as soon as it sees the error).
+fid_status check_call(fid_ctx *c, int F, int W, int H, int stride, fid_encoding enc)
 {
     if (F < 1 || F > c->lim.max_batch || W < 8 || H < 8 || W > c->lim.max_width || H > c->lim.max_height || W > 8191 || H > 8191)  // 13-bit checkpoint packing
         return FID_E_INVALID_ARG;
     if (enc != FID_ENC_MONO8 && enc != FID_ENC_BGR8 && enc != FID_ENC_RGB8 && enc != FID_ENC_BGRA8 && enc != FID_ENC_RGBA8) return FID_E_INVALID_ARG;
-    int bpp = enc == FID_ENC_MONO8 ? 1 : ((enc == FID_ENC_BGRA8 || enc == FID_ENC_RGBA8) ? 4 : 3);
+    const int bpp = enc == FID_ENC_MONO8 ? 1 : ((enc == FID_ENC_BGRA8 || enc == FID_ENC_RGBA8) ? 4 : 3);
     if (stride < W * bpp) return FID_E_INVALID_ARG;
-    if ((unsigned)(c->params.maxMarkerPerimeterRate * (W > H ? W : H)) > 36000u) return FID_E_UNSUPPORTED;  // contour points live in LDS
+    const int maxdim = W > H ? W : H;
+    if ((unsigned)(c->params.maxMarkerPerimeterRate * maxdim) > 36000u) return FID_E_UNSUPPORTED;  // contour points live in LDS
+    const size_t pitch = (size_t)((int)(unsigned)(c->params.maxMarkerPerimeterRate * maxdim) / CK + 3);  // chunk_tab_pitch
+    if ((size_t)F * 2 * c->lim.max_contours_per_frame * pitch > c->ckpts_elems) {
+        c->last_error = "chunk table too small for this image size / maxMarkerPerimeterRate";
+        return FID_E_UNSUPPORTED;
+    }
+    return FID_OK;
+}
+
+fid_status enqueue_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H, int stride, long long fstride, fid_encoding enc)
+{
+    {
+        const fid_status rcv = check_call(c, F, W, H, stride, enc);
+        if (rcv != FID_OK) return rcv;
+    }
     hipStream_t st0 = c->stream;
     c->pose_done = false;
     // ---- K0 geometry: mono8 device input is used in place (any stride); colour goes through k_to_gray
@@ -416,10 +434,6 @@ fid_status enqueue_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H,
     HIPCHK(c, hipMemsetAsync(c->d_counts, 0, sizeof(DevCounts) * F, st0));
     HIPCHK(c, hipMemsetAsync(c->d_global, 0, sizeof(DevGlobal), st0));
     HIPCHK(c, hipMemsetAsync(c->d_nwork, 0, sizeof(unsigned) * fid_ctx::MAX_SUB, st0));
-    if ((size_t)F * 2 * c->P.maxContours * chunk_tab_pitch(c->P) > c->ckpts_elems) {
-        c->last_error = "chunk table too small for this image size / maxMarkerPerimeterRate";
-        return FID_E_UNSUPPORTED;
-    }
     // ---- the batch is cut into sub-batches that run the whole pipeline on their own streams: the latency-bound
     //      tail of one sub-batch's kernels (the longest border, the last candidates) overlaps the next one's bulk
     const SubPlan plan = plan_sub_batches(c, F);
@@ -745,6 +759,8 @@ fid_status enqueue_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H,
     c->pend = {d_src, F, W, H, stride, fstride, enc};
     c->in_flight = true;
     c->chained = false;
+    c->wait_ev = nullptr;       // fid_order_after holds for ONE submit: the other context's events are not kept beyond it (it may
+    c->wait_copy_ev = nullptr;  // be destroyed before this context's next call)
     c->fed_from_host = false;  // (feed_and_enqueue sets it after this call)
     return FID_OK;
 }
@@ -862,7 +878,11 @@ fid_status run_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H, int
         return FID_E_INVALID_ARG;
     }
     const fid_status rc = enqueue_detect(c, d_src, F, W, H, stride, fstride, enc);
-    if (rc != FID_OK) return rc;
+    if (rc != FID_OK) {
+        c->wait_ev = c->wait_copy_ev = nullptr;
+        c->chained = false;
+        return rc;
+    }
     return finish_detect(c, out, cap_per_frame, n_per_frame);
 }
 
@@ -1225,6 +1245,15 @@ static fid_status feed_and_enqueue(fid_ctx *c, const uint8_t *imgs, int32_t nfra
     }
     HIPCHK(c, hipSetDevice(c->device));
     if (frame_stride < (int64_t)stride * height) return FID_E_INVALID_ARG;
+    {
+        // geometry, encoding and limits BEFORE any copy is queued: a refused call leaves no DMA from the caller's buffer behind
+        const fid_status rcv = check_call(c, nframes, width, height, stride, enc);
+        if (rcv != FID_OK) {
+            c->wait_ev = c->wait_copy_ev = nullptr;
+            c->chained = false;
+            return rcv;
+        }
+    }
     size_t need = (size_t)frame_stride * (nframes - 1) + (size_t)stride * height;
     if (need > c->d_in_bytes) {
         if (c->d_in) (void)hipFree(c->d_in);
@@ -1259,7 +1288,16 @@ static fid_status feed_and_enqueue(fid_ctx *c, const uint8_t *imgs, int32_t nfra
     const bool fed = c->host_feed;
     const fid_status rc = enqueue_detect(c, c->d_in, nframes, width, height, stride, frame_stride, enc);
     c->host_feed = false;
-    if (rc == FID_OK) c->fed_from_host = fed;
+    if (rc == FID_OK) {
+        c->fed_from_host = fed;
+    } else {
+        // (a HIP error half way through the enqueue: nothing will ever wait for the copies, so wait for them here -- the caller's
+        //  buffer is not read after this function has returned an error)
+        if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
+        (void)hipStreamSynchronize(c->stream);
+        c->wait_ev = c->wait_copy_ev = nullptr;
+        c->chained = false;
+    }
     return rc;
 }
 

@@ -99,7 +99,7 @@ inline int png_paeth(int a, int b, int c)
 
 extern "C" {
 
-fid_status fid_png_probe(const uint8_t *data, int64_t nbytes, fid_png_info *info)
+static fid_status png_probe_impl(const uint8_t *data, int64_t nbytes, fid_png_info *info)
 {
     if (!info) return FID_E_INVALID_ARG;
     PngHeader h;
@@ -114,7 +114,7 @@ fid_status fid_png_probe(const uint8_t *data, int64_t nbytes, fid_png_info *info
     return FID_OK;
 }
 
-fid_status fid_png_decode(const uint8_t *data, int64_t nbytes, fid_encoding out_enc, uint8_t *out, int64_t out_bytes, fid_png_info *info)
+static fid_status png_decode_impl(const uint8_t *data, int64_t nbytes, fid_encoding out_enc, uint8_t *out, int64_t out_bytes, fid_png_info *info)
 {
     if (!out || (out_enc != FID_ENC_BGR8 && out_enc != FID_ENC_MONO8)) return FID_E_INVALID_ARG;
     PngHeader h;
@@ -147,6 +147,12 @@ fid_status fid_png_decode(const uint8_t *data, int64_t nbytes, fid_encoding out_
         return FID_E_CAPACITY;
     }
     const size_t rowbytes = ((size_t)W * ch * bd + 7) / 8, bpp = (size_t)(ch * bd + 7) / 8;  // filter unit: whole bytes per pixel, >= 1
+    // sizes come from an untrusted header: a tiny file may announce 16384 x 16384 RGBA16.  No more than what a camera frame can be
+    // (the pixel limit of cv::imdecode, CV_IO_MAX_IMAGE_PIXELS = 2^30), and deflate cannot expand by more than ~1032 : 1
+    if ((uint64_t)W * (uint64_t)H > (1ull << 30) || (rowbytes + 1) * (size_t)H > (size_t)idat.size() * 1040 + 4096) {
+        g_png_error = "image data shorter than the header says";
+        return FID_E_INVALID_ARG;
+    }
     std::vector<uint8_t> raw((rowbytes + 1) * (size_t)H);
     {
         uLongf got = (uLongf)raw.size();
@@ -228,6 +234,33 @@ fid_status fid_png_decode(const uint8_t *data, int64_t nbytes, fid_encoding out_
         }
     }
     return FID_OK;
+}
+
+// nothing throws across the boundary (fid_abi.h): allocation failures on sizes a damaged file announces come back as a status
+fid_status fid_png_probe(const uint8_t *data, int64_t nbytes, fid_png_info *info)
+{
+    try {
+        return png_probe_impl(data, nbytes, info);
+    } catch (const std::bad_alloc &) {
+        g_png_error = "out of memory";
+        return FID_E_OUT_OF_MEMORY;
+    } catch (const std::exception &e) {
+        g_png_error = std::string("damaged file: ") + e.what();
+        return FID_E_INVALID_ARG;
+    }
+}
+
+fid_status fid_png_decode(const uint8_t *data, int64_t nbytes, fid_encoding out_enc, uint8_t *out, int64_t out_bytes, fid_png_info *info)
+{
+    try {
+        return png_decode_impl(data, nbytes, out_enc, out, out_bytes, info);
+    } catch (const std::bad_alloc &) {
+        g_png_error = "out of memory";
+        return FID_E_OUT_OF_MEMORY;
+    } catch (const std::exception &e) {
+        g_png_error = std::string("damaged file: ") + e.what();
+        return FID_E_INVALID_ARG;
+    }
 }
 
 const char *fid_png_last_error(void) { return g_png_error.c_str(); }

@@ -1275,6 +1275,7 @@ static fid_status stag_batch_groups(fid_stag_ctx *const *ctxs, int32_t nctx, con
                     if (G.frame_of[k] < 0) continue;
                     fid_stag_ctx *c = ctxs[g * gs + k];
                     c->group_stream = G.stream;
+                    R.frame_last_site = -1;  // (a new frame's round: its sites must come in increasing order, stag_order_guard)
                     (void)stag_advance(c, G.jobs[k]);
                 }
                 R.on = false;

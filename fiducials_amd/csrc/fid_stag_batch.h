@@ -96,10 +96,23 @@ struct StagRecorder {
     std::vector<Op> ops;
     std::vector<Copy> copies;
     bool failed = false;
-    long long merged_launches = 0, recorded_launches = 0;
+    long long merged_launches = 0, recorded_launches = 0, order_flushes = 0;
+    int frame_last_site = -1;  // the last site the frame now recording has used in this round (stag_order_guard)
 };
 extern thread_local StagRecorder *g_stag_rec;
 static inline bool stag_flush(StagRecorder &R);
+// Merged launches go out in SITE order (= source position), which is a frame's execution order only while the frame passes its
+// sites in increasing order within a round.  That holds for the state machine as it stands; a site inside a loop, or a helper
+// defined above its caller, would silently reorder a frame's dependent kernels.  So every record checks it: a frame that comes
+// back to a site at or below its last one gets everything recorded so far issued first (correct, just less merged).
+static inline void stag_order_guard(StagRecorder &R, int site)
+{
+    if (site <= R.frame_last_site) {
+        (void)stag_flush(R);
+        R.order_flushes++;
+    }
+    R.frame_last_site = site;
+}
 
 template <typename Fn, int SITE>
 struct StagSite {
@@ -124,6 +137,7 @@ struct StagSite {
     {
         // the table is full: everything recorded so far goes out (in site order, this site included), then recording goes on -- a
         // frame's launches stay in order, because what it recorded before this point is issued before what it records after it
+        stag_order_guard(R, SITE);
         if (n == StagTab<Fn>::kMax) (void)stag_flush(R);
         if (n == 0) R.ops.push_back({SITE, &StagSite::flush, nullptr});
         stag_fill(tab.a[n], v...);
@@ -237,6 +251,7 @@ static inline hipError_t stag_memcpy_site(void *dst, const void *src, size_t byt
             StagSite<k_stag_memcpy_fn, SITE>::record(*g_stag_rec, dim3(gx), dim3(256), 0, (uint8_t *)d, (const uint8_t *)src, (unsigned long long)bytes);
             return hipSuccess;
         }
+        stag_order_guard(*g_stag_rec, SITE);
         g_stag_rec->copies.push_back({SITE, 1 + (int)kind, dst, src, 0, bytes});
         g_stag_rec->ops.push_back({SITE, nullptr, nullptr});
         return hipSuccess;

@@ -324,17 +324,20 @@ bool FiducialsNode::compressedImageCallback(const CompressedImage &msg, Fiducial
     if (nbytes >= 8 && !memcmp(file, png_sig, 8)) {
         // format "...; png compressed ...": a zlib stream, decoded on the host as the subscriber plugin's cv::imdecode does
         // (fid_png_decode); gray images stay one byte per pixel, colour ones go up as BGR and are converted on the device
-        fid_png_info pi;
+        fid_png_info pi = {};
         fid_status rc = fid_png_probe(file, nbytes, &pi);
-        if (rc == FID_OK && (pi.width > maxW || pi.height > maxH)) rc = FID_E_INVALID_ARG;
-        const fid_encoding enc = pi.gray ? FID_ENC_MONO8 : FID_ENC_BGR8;
-        const int px = pi.gray ? 1 : 3;
-        if (rc == FID_OK) {
+        const bool oversize = rc == FID_OK && (pi.width > maxW || pi.height > maxH);
+        if (oversize) rc = FID_E_INVALID_ARG;
+        fid_encoding enc = FID_ENC_MONO8;
+        int px = 1;
+        if (rc == FID_OK) {  // (the header is only looked at once it has been parsed)
+            enc = pi.gray ? FID_ENC_MONO8 : FID_ENC_BGR8;
+            px = pi.gray ? 1 : 3;
             png_frame.resize((size_t)pi.width * pi.height * px);
             rc = fid_png_decode(file, nbytes, enc, png_frame.data(), (int64_t)png_frame.size(), nullptr);
         }
         if (rc != FID_OK) {
-            last_error = std::string("compressed frame: ") + (rc == FID_E_INVALID_ARG && pi.width > maxW ? "larger than the context" : fid_png_last_error());
+            last_error = std::string("compressed frame: ") + (oversize ? "larger than the context" : fid_png_last_error());
             return false;
         }
         int32_t n = 0;

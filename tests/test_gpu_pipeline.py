@@ -105,3 +105,38 @@ def test_host_fed_batches_in_flight_equal_fid_detect_batch():
                 assert gm[f][1].tolist() == wm[f][1].tolist() and len(gm[f][1]) > 0, (k, f)
                 assert np.array_equal(gm[f][0], wm[f][0]), (k, f)
                 assert np.array_equal(gp[f].tvecs, wp[f].tvecs), (k, f)
+
+
+def test_a_refused_host_batch_queues_no_copy_and_leaves_the_context_usable():
+    """fid_detect_batch / fid_submit_batch validate geometry, encoding and limits BEFORE any host -> device copy is queued (a
+    refused call must not leave DMA from the caller's buffer in flight: the caller may free it on the error), the order set by
+    fid_order_after does not outlive the refused call, and the context works on afterwards."""
+    d = get_predefined_dictionary(6)
+    a = ArucoDetector(6, max_width=640, max_height=480, max_batch=2, max_markers=32)
+    b = ArucoDetector(6, max_width=640, max_height=480, max_batch=2, max_markers=32)
+    try:
+        frames = np.stack([make_frame(d, 4100 + i, width=640, height=480, n_markers=4, side_range=(60, 110)).image for i in range(2)])
+        want = [oracle.detect(f, d) for f in frames]
+        too_tall = np.zeros((2, 481, 640), np.uint8)
+        for bad in (too_tall, np.zeros((3, 480, 640), np.uint8)):  # taller than the context; more frames than max_batch
+            with pytest.raises(FidError) as e:
+                a.detect_markers_batch(bad)
+            assert e.value.status == 1
+            with pytest.raises(FidError):
+                a.submit_batch(bad, after=b)
+            del bad  # (nothing reads it any more)
+        # a batch in flight on b, a ordered behind it, a's submit refused: the next good submit on a is not held by a stale event
+        b.submit_batch(frames)
+        with pytest.raises(FidError):
+            a.submit_batch(too_tall, after=b)
+        resb = b.collect()
+        b.close()  # (b's events are gone now)
+        b = None
+        resa = a.detect_markers_batch(frames)
+        for res in (resa, resb):
+            for (corners, ids), (oids, ocorners) in zip(res, want):
+                assert ids.tolist() == oids.tolist() and np.array_equal(corners, ocorners)
+    finally:
+        a.close()
+        if b is not None:
+            b.close()

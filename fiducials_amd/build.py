@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(_HERE, "csrc")
 LIB = os.path.join(_HERE, "lib", "libfid_amd.so")
 SOURCES = ["fid_api.hip", "fid_kernels.hip", "fid_stag.hip", "fid_stag_route.hip", "fid_stag_lines.hip", "fid_stag_quads.hip",
-           "fid_stag_pose.hip", "fid_jpeg.hip", "fid_png.hip", "fid_stag_batch.h", "fid_device.h", os.path.join("..", "..", "include", "fid_abi.h")]
+           "fid_stag_pose.hip", "fid_jpeg.hip", "fid_png.hip", "fid_draw.hip", "fid_dict.hip", "fid_stag_batch.h", "fid_device.h", os.path.join("..", "..", "include", "fid_abi.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
 

@@ -1615,3 +1615,5 @@ int32_t fid_abi_version(void) { return FID_ABI_VERSION; }
 #include "fid_stag.hip"
 #include "fid_jpeg.hip"
 #include "fid_png.hip"
+#include "fid_draw.hip"
+#include "fid_dict.hip"

@@ -145,3 +145,26 @@ def draw_marker(d: Dictionary, marker_id: int, side_pixels: int, border_bits: in
     # cv::resize INTER_NEAREST: src index = floor(dst * src/dst_size)
     idx = np.minimum((np.arange(side_pixels) * (cells / side_pixels)).astype(np.int64), cells - 1)
     return tiny[np.ix_(idx, idx)]
+
+
+def load_dictionary_file(path: str, which=-1) -> Dictionary:
+    """`aruco::getPredefinedDictionary(which)` from a table file the deployer has (fid_dict_load_file, include/fid_abi.h):
+    OpenCV's predefined_dictionaries.hpp as text, a FileStorage YAML (custom dictionaries: which = -1), or a dict_*.txt of this
+    repository.  `which`: enum value or DICT_* name.  Every codeword of the result counts as authentic (`pinned`)."""
+    import ctypes as C
+
+    from . import _lib
+
+    dicno = which if isinstance(which, (int, np.integer)) else PREDEFINED[which][0]
+    L = _lib.load()
+    fd = _lib.FidDict()
+    rc = L.fid_dict_load_file(path.encode(), int(dicno), None, 0, C.byref(fd))
+    if rc != _lib.FID_E_CAPACITY:
+        raise _lib.FidError(rc, (L.fid_dict_last_error() or b"").decode())
+    nbytes = (fd.marker_size * fd.marker_size + 7) // 8
+    buf = np.zeros((fd.n_markers, 4, nbytes), dtype=np.uint8)
+    rc = L.fid_dict_load_file(path.encode(), int(dicno), buf.ctypes.data, buf.nbytes, C.byref(fd))
+    if rc != _lib.FID_OK:
+        raise _lib.FidError(rc, (L.fid_dict_last_error() or b"").decode())
+    name = _BY_ENUM.get(int(dicno), f"custom_{fd.marker_size}x{fd.marker_size}_{fd.n_markers}")
+    return Dictionary(name, fd.marker_size, fd.max_correction_bits, buf, np.ones(fd.n_markers, dtype=bool))

@@ -110,6 +110,9 @@ struct Dictionary {
     fid_dict view() const;
 };
 Dictionary getPredefinedDictionary(int dicno, const std::string &data_dir);
+// ... from a table file the deployer has (fid_dict_load_file: OpenCV's predefined_dictionaries.hpp as text, a FileStorage
+// YAML, or a dict_*.txt): every enum value 0..16, or -1 for a custom dictionary whose sizes the YAML states
+Dictionary loadDictionaryFile(int dicno, const std::string &table_file);
 
 class FiducialsNode {
    public:
@@ -125,6 +128,8 @@ class FiducialsNode {
         std::string fiducial_len_override;
         fid_params detector;  // ... and the detector parameters as the node sets them (:690-727)
         std::string data_dir = "fiducials_amd/data";
+        std::string dictionary_file;  // non-empty: the table of ~dictionary comes from this file (loadDictionaryFile) -- the way to
+                                      // run the families whose shipped tables are fillers (4X4_1000, 6X6, 7X7, ARUCO_ORIGINAL)
         int device = 0, max_width = 1920, max_height = 1080;
         Params();
     };
@@ -139,6 +144,11 @@ class FiducialsNode {
     void ignoreCallback(const std::string &msg);                     // :300-305
     void camInfoCallback(const CameraInfo &msg);                     // :307-330
     bool imageCallback(const Image &msg, FiducialArray *out);        // :332-395
+    // ... and what image_pub publishes on /fiducial_images when ~publish_images is set (:381-387): the BGR8 copy of the frame
+    // with aruco::drawDetectedMarkers' marker outlines on it (fid_draw_detected_markers: the exactly restated part of the
+    // overlay; include/fid_abi.h lists what is not drawn).  *image is filled only when publish_images is set (returns the same
+    // as the two-argument form).
+    bool imageCallback(const Image &msg, FiducialArray *out, Image *image);
     // the same callback for a frame that arrives compressed (aruco_detect.launch:6 transport=compressed): the JPEG is decoded
     // on the device (fid_jpeg_decode: what the subscriber plugin's cv::imdecode + toCvCopy(BGR8) + BGR2GRAY produce) and the
     // detector runs on the device-resident gray image
@@ -170,7 +180,7 @@ class FiducialsNode {
     std::map<int, double> fiducialLens;
     double cameraMatrix[9] = {0}, distortionCoeffs[5] = {0};
     bool haveCamInfo = false, enable_detections = true, doPoseEstimation = true, verbose = false;
-    bool vis_msgs = false, publishFiducialTf = true;
+    bool vis_msgs = false, publishFiducialTf = true, publish_images = false;
     double fiducial_len = 0.14;
     int frameNum = 0;
     std::string frameId, last_error;

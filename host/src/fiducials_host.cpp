@@ -102,7 +102,8 @@ Dictionary getPredefinedDictionary(int dicno, const std::string &data_dir)
     const Row *row = nullptr;
     for (const Row &r : rows)
         if (r.dicno == dicno) row = &r;
-    if (!row) throw std::runtime_error("dictionary " + std::to_string(dicno) + " not available in this build");
+    if (!row)  // (4X4_1000, 6X6, 7X7, ARUCO_ORIGINAL: the shipped tables are labelled fillers, not OpenCV's codewords)
+        throw std::runtime_error("dictionary " + std::to_string(dicno) + " not available in this build: give the node OpenCV's table (~dictionary_file, loadDictionaryFile)");
     const int n = row->n, nbytes = (n * n + 7) / 8;
     std::ifstream f(data_dir + (n == 4 ? "/dict_4x4_250.txt" : "/dict_5x5_1000.txt"));
     if (!f) throw std::runtime_error("dictionary table not found under " + data_dir);
@@ -139,6 +140,21 @@ Dictionary getPredefinedDictionary(int dicno, const std::string &data_dir)
     return d;
 }
 
+Dictionary loadDictionaryFile(int dicno, const std::string &table_file)
+{
+    fid_dict fd;
+    fid_status rc = fid_dict_load_file(table_file.c_str(), dicno, nullptr, 0, &fd);  // sizes first
+    if (rc != FID_E_CAPACITY) throw std::runtime_error("dictionary file " + table_file + ": " + fid_dict_last_error());
+    Dictionary d;
+    d.markerSize = fd.marker_size;
+    d.maxCorrectionBits = fd.max_correction_bits;
+    d.nMarkers = fd.n_markers;
+    d.bytesList.assign((size_t)fd.n_markers * 4 * ((fd.marker_size * fd.marker_size + 7) / 8), 0);
+    rc = fid_dict_load_file(table_file.c_str(), dicno, d.bytesList.data(), (int64_t)d.bytesList.size(), &fd);
+    if (rc != FID_OK) throw std::runtime_error("dictionary file " + table_file + ": " + fid_dict_last_error());
+    return d;
+}
+
 // ------------------------------------------------------------------------------------------------ node
 FiducialsNode::Params::Params()
 {
@@ -153,11 +169,12 @@ FiducialsNode::FiducialsNode(const Params &p)
     fiducial_len = p.fiducial_len;
     doPoseEstimation = p.do_pose_estimation;
     verbose = p.verbose;
+    publish_images = p.publish_images;      // (:609)
     vis_msgs = p.vis_msgs;                  // (:616)
     publishFiducialTf = p.publish_fiducial_tf;  // (:614)
     handleIgnoreString(p.ignore_fiducials);
     handleLenOverrideString(p.fiducial_len_override);
-    dict = getPredefinedDictionary(p.dictionary, p.data_dir);
+    dict = p.dictionary_file.empty() ? getPredefinedDictionary(p.dictionary, p.data_dir) : loadDictionaryFile(p.dictionary, p.dictionary_file);
     detectorParams = p.detector;
     fid_dict fd = dict.view();
     fid_limits lim;
@@ -306,6 +323,35 @@ bool FiducialsNode::imageCallback(const Image &msg, FiducialArray *out)
         return false;
     }
     return publishVertices(msg.header, n, out);
+}
+
+bool FiducialsNode::imageCallback(const Image &msg, FiducialArray *out, Image *image)
+{
+    if (!imageCallback(msg, out)) return false;
+    if (!publish_images || !image) return true;
+    // cv_ptr = toCvCopy(msg, BGR8); if (ids.size() > 0) drawDetectedMarkers(cv_ptr->image, corners, ids); image_pub.publish(cv_ptr->toImageMsg())
+    fid_encoding enc = FID_ENC_MONO8;
+    if (msg.encoding == "bgr8") enc = FID_ENC_BGR8;
+    else if (msg.encoding == "rgb8") enc = FID_ENC_RGB8;
+    else if (msg.encoding == "bgra8") enc = FID_ENC_BGRA8;
+    else if (msg.encoding == "rgba8") enc = FID_ENC_RGBA8;
+    image->header = msg.header;  // (cv_bridge keeps the source header)
+    image->height = msg.height;
+    image->width = msg.width;
+    image->encoding = "bgr8";
+    image->is_bigendian = 0;
+    image->step = msg.width * 3;
+    image->data.resize((size_t)msg.width * msg.height * 3);
+    fid_status rc = fid_to_bgr(msg.data.data(), (int32_t)msg.width, (int32_t)msg.height, (int32_t)msg.step, enc, image->data.data(),
+                               (int64_t)image->data.size());
+    if (rc == FID_OK && !ids.empty())  // every detected marker is drawn, ignored ids included (the ignore list only filters the vertices)
+        rc = fid_draw_detected_markers(image->data.data(), (int32_t)msg.width, (int32_t)msg.height, (int32_t)image->step, markers.data(),
+                                       (int32_t)ids.size(), 0);
+    if (rc != FID_OK) {
+        last_error = std::string("overlay: ") + fid_strerror(rc);
+        image->data.clear();
+    }
+    return true;
 }
 
 bool FiducialsNode::compressedImageCallback(const CompressedImage &msg, FiducialArray *out)

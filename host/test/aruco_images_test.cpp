@@ -194,6 +194,63 @@ static void node_surface(const Fixture &fx)
     Image bad = img;
     bad.encoding = "yuv422";
     CHECK(!node.imageCallback(bad, &fva) && !node.lastError().empty());  // like the caught cv_bridge exception: frame dropped
+    // ~publish_images: /fiducial_images = the BGR8 copy of the frame with the marker outlines on it (:381-387); and the third
+    // corner refinement the node can select, cornerRefinementSubPix = false -> CORNER_REFINE_CONTOUR (:274-283, 700-711)
+    {
+        FiducialsNode::Params pi = fx.params();
+        pi.publish_images = true;
+        FiducialsNode inode(pi);
+        FiducialArray fi;
+        Image ov;
+        CHECK(inode.imageCallback(img, &fi, &ov) && fi.fiducials.size() == 2);
+        CHECK(ov.encoding == "bgr8" && ov.width == img.width && ov.height == img.height && ov.step == img.width * 3 &&
+              ov.data.size() == (size_t)img.width * img.height * 3 && ov.header.seq == img.header.seq);
+        size_t green = 0, changed = 0;
+        for (uint32_t y = 0; y < img.height; y++)
+            for (uint32_t x = 0; x < img.width; x++) {
+                const uint8_t *p = &ov.data[((size_t)y * img.width + x) * 3];
+                const uint8_t g = img.data[(size_t)y * img.step + x];
+                if (p[0] == 0 && p[1] == 255 && p[2] == 0) green++;
+                else if (p[0] != g || p[1] != g || p[2] != g) changed++;
+            }
+        CHECK(green > 400 && changed == 0);  // two marker outlines, every other pixel is the gray frame replicated
+        // a corner of the first marker lies on its outline
+        const int cx = (int)std::lrint(fi.fiducials[0].x0), cy = (int)std::lrint(fi.fiducials[0].y0);
+        const uint8_t *pc = &ov.data[((size_t)cy * img.width + cx) * 3];
+        CHECK(pc[0] == 0 && pc[1] == 255 && pc[2] == 0);
+        Image none;
+        FiducialsNode plain2(fx.params());
+        CHECK(plain2.imageCallback(img, &fi, &none) && none.data.empty());  // publish_images = false: nothing is made
+        // CORNER_REFINE_CONTOUR through dynamic_reconfigure: same ids, corners within a pixel of the SUBPIX ones, not the same
+        fid_params cfg = pi.detector;
+        cfg.cornerRefinementMethod = 2;
+        inode.configCallback(cfg, 0);
+        FiducialArray fc;
+        CHECK(inode.imageCallback(img, &fc) && fc.fiducials.size() == 2 && inode.lastError().empty());
+        CHECK(fc.fiducials[0].fiducial_id == fi.fiducials[0].fiducial_id);
+        CHECK(std::fabs(fc.fiducials[0].x0 - fi.fiducials[0].x0) < 1.5 && std::fabs(fc.fiducials[0].y2 - fi.fiducials[0].y2) < 1.5);
+        CHECK(fc.fiducials[0].x0 != fi.fiducials[0].x0 || fc.fiducials[0].y0 != fi.fiducials[0].y0);
+    }
+    // ~dictionary values whose shipped tables are fillers are refused by name ... unless the deployer's own table file is given
+    {
+        bool threw = false;
+        try {
+            (void)getPredefinedDictionary(10, fx.params().data_dir);
+        } catch (const std::runtime_error &) {
+            threw = true;
+        }
+        CHECK(threw);
+        const Dictionary d6 = loadDictionaryFile(10, fx.params().data_dir + "/dict_6x6_1000.txt");
+        CHECK(d6.markerSize == 6 && d6.nMarkers == 250 && d6.maxCorrectionBits == 5 && d6.bytesList.size() == (size_t)250 * 4 * 5);
+        const Dictionary d5 = loadDictionaryFile(7, fx.params().data_dir + "/dict_5x5_1000.txt");
+        const Dictionary ref5 = getPredefinedDictionary(7, fx.params().data_dir);
+        CHECK(d5.bytesList == ref5.bytesList && d5.maxCorrectionBits == ref5.maxCorrectionBits);
+        FiducialsNode::Params pf = fx.params();
+        pf.dictionary_file = pf.data_dir + "/dict_5x5_1000.txt";
+        FiducialsNode fnode(pf);
+        FiducialArray ff;
+        CHECK(fnode.imageCallback(img, &ff) && ff.fiducials.size() == 2);
+    }
     // ~vis_msgs: vision_msgs/Detection2DArray instead of FiducialTransformArray, and the TF broadcasts (:462-478, 501-524)
     {
         FiducialsNode::Params pv = fx.params();

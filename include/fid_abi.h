@@ -42,7 +42,7 @@ extern "C" {
  * preceding fid_detect_* call already computed for the same camera; fid_stag_detect_markers_batch reports 0 markers for a frame
  * whose slot was too small (round 3).  4: + fid_submit_device / fid_submit_batch / fid_collect / fid_order_after, fid_png_* (round 3).  Entry points are only ever added: a caller
  * built against 1 runs against 5.  5: cornerRefinementMethod 2 (CORNER_REFINE_CONTOUR) is implemented instead of refused,
- * FID_E_CV_EXCEPTION, fid_refine_contour_corners (round 4). */
+ * FID_E_CV_EXCEPTION, fid_refine_contour_corners, fid_to_bgr / fid_draw_detected_markers, fid_dict_load_file (round 4). */
 #define FID_ABI_VERSION 5
 
 typedef enum fid_status {
@@ -416,6 +416,39 @@ fid_status fid_png_probe(const uint8_t *data, int64_t nbytes, fid_png_info *info
 fid_status fid_png_decode(const uint8_t *data, int64_t nbytes, fid_encoding out_enc, uint8_t *out, int64_t out_bytes,
                           fid_png_info *info /* may be NULL */);
 const char *fid_png_last_error(void); /* of the calling thread */
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * The /fiducial_images overlay (aruco_detect.cpp:381-387): imageCallback draws on the BGR8 copy cv_bridge made of the frame
+ * (aruco::drawDetectedMarkers(cv_ptr->image, corners, ids)) and publishes it when ~publish_images is set.  HOST code, like the
+ * reference's.  fid_to_bgr = that copy (toCvCopy(msg, BGR8): gray replicated, RGB swapped, alpha dropped; tightly packed rows);
+ * fid_draw_detected_markers = the four sides of every marker, cv::line(..., Scalar(0, 255, 0), 1, LINE_8) restated exactly
+ * (LineIterator, clipLine, Point2f -> Point by cvRound).  NOT drawn, because OpenCV's anti-aliasing and Hershey font tables are
+ * third-party data absent from the reference tree and from this machine: the LINE_AA square on the first corner and the "id=<n>"
+ * text; aruco::drawAxis (:431) likewise.  FID_DRAW_FIRST_CORNER_LINE8 adds that square with LINE_8 sides -- a cue for a human
+ * viewer, not the reference's pixels.
+ * ------------------------------------------------------------------------------------------------------------------ */
+#define FID_DRAW_FIRST_CORNER_LINE8 1u
+fid_status fid_to_bgr(const uint8_t *img, int32_t width, int32_t height, int32_t stride_bytes, fid_encoding enc, uint8_t *out_bgr,
+                       int64_t out_bytes);
+fid_status fid_draw_detected_markers(uint8_t *bgr, int32_t width, int32_t height, int32_t stride_bytes, const fid_marker *markers,
+                                     int32_t n, uint32_t flags);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * aruco::getPredefinedDictionary(dicno) (aruco_detect.cpp:671, ~dictionary :611) from a table file the DEPLOYER has.  OpenCV's
+ * tables are third-party data that ship neither with the reference nor with this repository (fiducials_amd/data/ holds the
+ * codewords the reference's fixtures pin + labelled fillers); a caller that links OpenCV passes Dictionary::bytesList to
+ * fid_create directly, one that does not loads it here.  path =
+ *   OpenCV's modules/aruco/src/predefined_dictionaries.hpp as text (the array DICT_<N>X<N>_1000_BYTES / DICT_ARUCO_BYTES of
+ *     dicno's family is parsed: per marker four rotations x ceil(n^2 / 8) bytes = bytesList; the first n_markers(dicno) rows);
+ *   a cv::FileStorage YAML as aruco::Dictionary::writeDictionary writes it (nmarkers, markersize, maxCorrectionBits,
+ *     marker_<i>: "<bits>"); dicno -1 = a custom dictionary, sizes as the file says;
+ *   this repository's dict_*.txt.
+ * dicno: the node's ~dictionary enum 0..16 (marker size, count and maxCorrectionBits as dictionary.cpp's predefined objects).
+ * bytes / bytes_cap: the caller's buffer for bytesList; *out points into it.  FID_E_CAPACITY (out->n_markers and marker_size
+ * set, out->bytes NULL) when it is too small: n_markers * 4 * ((marker_size^2 + 7) / 8) bytes are needed.  Host code.
+ * ------------------------------------------------------------------------------------------------------------------ */
+fid_status fid_dict_load_file(const char *path, int32_t dicno, uint8_t *bytes, int64_t bytes_cap, fid_dict *out);
+const char *fid_dict_last_error(void); /* of the calling thread */
 
 const char *fid_strerror(fid_status s);
 const char *fid_last_error(fid_ctx *ctx);

@@ -84,3 +84,62 @@ def test_synth_is_deterministic_and_annotated():
     assert a.image.dtype == np.uint8 and a.corners.shape == (4, 4, 2)
     c = make_frame(d, 124, width=640, height=480, n_markers=4, side_range=(60, 110))
     assert not np.array_equal(a.image, c.image)
+
+
+# ---- fid_dict_load_file: a dictionary table the deployer has (OpenCV's header as text, a FileStorage YAML, a dict_*.txt)
+def _as_opencv_header(d5, d4, aruco=None):
+    """Text in the layout of OpenCV's modules/aruco/src/predefined_dictionaries.hpp, filled from tables of this repository."""
+    def arr(name, bl):
+        nb = bl.shape[2]
+        rows = ["    { " + ", ".join("{ " + ", ".join(str(int(b)) for b in rot) + " }" for rot in m) + ", }," for m in bl]
+        return f"static unsigned char {name}[][4][{nb}] = {{\n" + "\n".join(rows) + "\n};\n"
+    txt = "/* a comment with braces { } and numbers 1 2 3 */\n// DICT_4X4_1000_BYTES mentioned in a comment first\n"
+    txt += arr("DICT_4X4_1000_BYTES", d4) + arr("DICT_5X5_1000_BYTES", d5)
+    if aruco is not None:
+        txt += arr("DICT_ARUCO_BYTES", aruco)
+    return txt
+
+
+def test_dict_load_file_opencv_header_yaml_and_txt(tmp_path):
+    from fiducials_amd.dictionary import load_dictionary_file
+    d5 = get_predefined_dictionary("DICT_5X5_1000")
+    d4 = get_predefined_dictionary("DICT_4X4_1000", allow_fillers=True)
+    hpp = tmp_path / "predefined_dictionaries.hpp"
+    hpp.write_text(_as_opencv_header(d5.bytes_list, d4.bytes_list))
+    for name in ("DICT_5X5_50", "DICT_5X5_250", "DICT_5X5_1000", "DICT_4X4_100", "DICT_4X4_1000"):
+        got = load_dictionary_file(str(hpp), name)
+        want = get_predefined_dictionary(name, allow_fillers=True)
+        assert (got.marker_size, got.max_correction_bits, got.n_markers) == (want.marker_size, want.max_correction_bits, want.n_markers)
+        assert np.array_equal(got.bytes_list, want.bytes_list)
+    # the first two rows of DICT_4X4_1000_BYTES as OpenCV's header prints them (the rotation / bit packing convention)
+    first = load_dictionary_file(str(hpp), 0).bytes_list
+    assert first[0].tolist() == [[181, 50], [235, 72], [76, 173], [18, 215]]
+    assert first[1].tolist() == [[15, 154], [101, 71], [89, 240], [226, 166]]
+    with pytest.raises(_lib.FidError):
+        load_dictionary_file(str(hpp), "DICT_6X6_50")  # that array is not in the file
+    with pytest.raises(_lib.FidError):
+        load_dictionary_file(str(hpp), -1)  # a header holds many tables
+    # FileStorage YAML (Dictionary::writeDictionary): a custom 6 x 6 dictionary of 7 markers
+    rng = np.random.default_rng(4)
+    bits = rng.integers(0, 2, (7, 6, 6))
+    y = tmp_path / "custom.yml"
+    y.write_text("%YAML:1.0\n---\nnmarkers: 7\nmarkersize: 6\nmaxCorrectionBits: 4\n" +
+                 "".join(f'marker_{i}: "{"".join(str(int(b)) for b in bits[i].reshape(-1))}"\n' for i in range(7)))
+    c = load_dictionary_file(str(y), -1)
+    assert (c.marker_size, c.max_correction_bits, c.n_markers) == (6, 4, 7)
+    for i in range(7):
+        assert np.array_equal(c.bytes_list[i], byte_list_from_bits(bits[i].astype(np.uint8)))
+        assert np.array_equal(c.bits(i), bits[i])
+    # this repository's own text tables
+    t = load_dictionary_file(os.path.join(ROOT, "fiducials_amd", "data", "dict_5x5_1000.txt"), 6)
+    assert np.array_equal(t.bytes_list, get_predefined_dictionary(6).bytes_list)
+    with pytest.raises(_lib.FidError):
+        load_dictionary_file(str(tmp_path / "missing.hpp"), 0)
+
+
+def test_catkin_node_parses_against_the_ros_stubs():
+    """ros/aruco_detect_amd/src/aruco_detect_amd_node.cpp through g++ -fsyntax-only -Wall -Wextra -Werror against stand-in ROS
+    headers (fiducial_msgs and DetectorParamsConfig generated from the reference's own .msg / .cfg) and the real host/ headers."""
+    import subprocess
+    p = subprocess.run(["make", "-C", os.path.join(ROOT, "ros"), "syntax"], capture_output=True, text=True)
+    assert p.returncode == 0, p.stdout + p.stderr

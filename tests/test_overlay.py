@@ -1,0 +1,72 @@
+"""The /fiducial_images overlay (aruco_detect.cpp:381-387): fid_to_bgr = cv_bridge::toCvCopy(msg, BGR8),
+fid_draw_detected_markers = the four cv::line(LINE_8) sides of aruco::drawDetectedMarkers, against the plain-Python restatement
+(oracle/draw.py).  Host code on both sides: runs without a GPU.  What the library does not draw (LINE_AA corner square, id text)
+is stated in include/fid_abi.h; nothing here claims it."""
+import numpy as np
+import pytest
+
+from fiducials_amd import overlay
+from oracle import draw as odraw
+
+
+def test_to_bgr_every_encoding():
+    rng = np.random.default_rng(2)
+    g = rng.integers(0, 256, (37, 53), dtype=np.uint8)
+    assert np.array_equal(overlay.to_bgr(g), np.repeat(g[:, :, None], 3, axis=2))
+    c3 = rng.integers(0, 256, (37, 53, 3), dtype=np.uint8)
+    assert np.array_equal(overlay.to_bgr(c3, "bgr8"), c3)
+    assert np.array_equal(overlay.to_bgr(c3, "rgb8"), c3[:, :, ::-1])
+    c4 = rng.integers(0, 256, (37, 53, 4), dtype=np.uint8)
+    assert np.array_equal(overlay.to_bgr(c4, "bgra8"), c4[:, :, :3])
+    assert np.array_equal(overlay.to_bgr(c4, "rgba8"), c4[:, :, 2::-1])
+    # a strided view (sensor_msgs/Image.step > width * bytes per pixel)
+    wide = rng.integers(0, 256, (20, 64), dtype=np.uint8)
+    assert np.array_equal(overlay.to_bgr(wide[:, :50])[:, :, 0], wide[:, :50])
+
+
+def test_line8_restatement_hand_cases():
+    # horizontal, vertical, the two diagonals, right-to-left input (drawn left to right), a single point
+    assert odraw.line8_pixels(10, 10, (1, 2), (4, 2)) == [(1, 2), (2, 2), (3, 2), (4, 2)]
+    assert odraw.line8_pixels(10, 10, (4, 2), (1, 2)) == [(1, 2), (2, 2), (3, 2), (4, 2)]
+    assert odraw.line8_pixels(10, 10, (3, 1), (3, 4)) == [(3, 1), (3, 2), (3, 3), (3, 4)]
+    assert odraw.line8_pixels(10, 10, (0, 0), (3, 3)) == [(0, 0), (1, 1), (2, 2), (3, 3)]
+    assert odraw.line8_pixels(10, 10, (0, 3), (3, 0)) == [(0, 3), (1, 2), (2, 1), (3, 0)]
+    assert odraw.line8_pixels(10, 10, (5, 5), (5, 5)) == [(5, 5)]
+    # slope 1/3: dx + 1 pixels, one per column, rows change where the error term says
+    px = odraw.line8_pixels(20, 20, (0, 0), (9, 3))
+    assert len(px) == 10 and [p[0] for p in px] == list(range(10)) and px[-1] == (9, 3)
+    assert odraw.line8_pixels(10, 10, (-5, -5), (-1, -2)) == []  # wholly outside
+
+
+def test_draw_detected_markers_equals_the_restatement():
+    rng = np.random.default_rng(8)
+    W, H = 640, 480
+    quads = []
+    for _ in range(60):
+        c = rng.uniform([40, 40], [W - 40, H - 40])
+        a = rng.uniform(0, 2 * np.pi)
+        r = rng.uniform(5, 120)
+        ang = a + np.array([0, 0.5, 1.0, 1.5]) * np.pi + rng.uniform(-0.2, 0.2, 4)
+        quads.append(np.stack([c[0] + r * np.cos(ang), c[1] + r * np.sin(ang)], 1))
+    quads = np.array(quads, dtype=np.float32)  # (sub-pixel corners, some of them outside the image: clipLine)
+    quads[0] = [[10.5, 10.5], [11.5, 10.5], [11.5, 11.5], [10.5, 11.5]]  # halves round to even
+    base = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    got = overlay.draw_detected_markers(base.copy(), quads, np.arange(len(quads)))
+    want = odraw.draw_detected_markers(base.copy(), quads)
+    assert np.array_equal(got, want), int((got != want).any(axis=2).sum())
+    assert (got != base).any()
+    # every drawn pixel is the border colour, nothing else changed
+    changed = (got != base).any(axis=2)
+    assert (got[changed] == (0, 255, 0)).all()
+    # the optional first-corner square (LINE_8, not the reference's anti-aliased pixels) only ever adds blue pixels
+    both = overlay.draw_detected_markers(base.copy(), quads, None, overlay.FIRST_CORNER_LINE8)
+    extra = (both != got).any(axis=2)
+    assert extra.any() and (both[extra] == (255, 0, 0)).all()
+
+
+def test_draw_refuses_bad_arguments():
+    img = np.zeros((10, 10, 3), np.uint8)
+    with pytest.raises(Exception):
+        overlay.draw_detected_markers(img, np.zeros((1, 4, 2), np.float32), None, flags=2)
+    with pytest.raises(ValueError):
+        overlay.draw_detected_markers(np.zeros((10, 10), np.uint8), np.zeros((1, 4, 2), np.float32))

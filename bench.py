@@ -198,6 +198,25 @@ def cfg2_latency(local_rank, frame):
 
 
 
+def usable_cpus():
+    """(usable CPUs, hardware threads in the affinity mask, cgroup quota): what this process may really use -- the GPU boxes show
+    256 hardware threads and carry a cgroup quota of 16 CPUs."""
+    cores = os.cpu_count() or 1
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:
+            q, p = fh.read().split()[:2]
+            if q != "max":
+                quota = float(q) / float(p)
+    except Exception:  # noqa: BLE001
+        pass
+    try:
+        cores = min(cores, len(os.sched_getaffinity(0)))
+    except Exception:  # noqa: BLE001
+        pass
+    return max(1, int(min(cores, quota) if quota else cores)), cores, quota
+
+
 def _gen_one(args):
     seed, dname = args
     from fiducials_amd.dictionary import get_predefined_dictionary
@@ -224,8 +243,8 @@ def make_frames(seeds, dname="DICT_5X5_250"):
     if todo:
         import multiprocessing as mp
 
-        world = max(1, int(os.environ.get("WORLD_SIZE", "1")))  # every rank generates its own stream: share the host cores
-        nproc = max(1, min(len(todo), (os.cpu_count() or 2) // world, 64))
+        world = max(1, int(os.environ.get("WORLD_SIZE", "1")))  # every rank generates its own stream: share the USABLE host cores
+        nproc = max(1, min(len(todo), usable_cpus()[0] // world, 64))
         with mp.get_context("fork").Pool(nproc) as pool:
             imgs = pool.map(_gen_one, [(s, dname) for _, s in todo], chunksize=1)
         for (i, s), im in zip(todo, imgs):
@@ -280,22 +299,9 @@ def cpu_baseline(frames, K, D, budget_s=20.0):
     while len(per) < 30 or (len(per) < 60 and time.perf_counter() - t0 < budget_s * 0.25):
         per.append(_cpu_one(len(per))[0])
     med = float(np.median(per))
-    cores = os.cpu_count() or 1
-    # what this process may really use: the affinity mask and the cgroup CPU quota (round 2 and 3 GPU boxes show 256 hardware
-    # threads and carry a quota of 16 CPUs: a pool of 64 processes then "scales" 12 x whatever the code does)
-    quota = None
-    try:
-        with open("/sys/fs/cgroup/cpu.max") as fh:
-            q, p = fh.read().split()[:2]
-            if q != "max":
-                quota = float(q) / float(p)
-    except Exception:  # noqa: BLE001
-        pass
-    try:
-        cores = min(cores, len(os.sched_getaffinity(0)))
-    except Exception:  # noqa: BLE001
-        pass
-    usable = max(1, int(min(cores, quota) if quota else cores))
+    # what this process may really use: the affinity mask and the cgroup CPU quota (a pool of 64 processes on a quota of 16 CPUs
+    # "scales" 12 x whatever the code does)
+    usable, cores, quota = usable_cpus()
     # frame-parallel: one process per core, frames pre-split.  The port keeps a per-thread arena behind its malloc / free
     # (oracle/ora_arena.h: round 2's build gave its tens of MB per frame back to the kernel every time and 64 processes scaled
     # 13 x); the mallopt below is for what still goes through glibc.  The rates at nproc, nproc / 2 and nproc / 4 processes
@@ -932,8 +938,12 @@ def main():
 
     B = args.batch
     unique = args.unique or B
-    if (os.cpu_count() or 1) < 8:
+    if usable_cpus()[0] < 8:
         unique = min(unique, 32)  # keep generation inside the time budget on small hosts
+    if world > 1 and not args.unique:
+        # N ranks share the host's usable cores (16 on the bench host) for frame generation: a fixed budget of ~512 frames for the
+        # whole job (a 1080p frame takes ~1 s of one core), i.e. 64 unique frames per rank at 8 ranks, tiled to the batch
+        unique = min(unique, max(16, 512 // world))
     unique = min(unique, B)
     # cfg 3: seeds 1000 + i ; cfg 4 stream s: 10000 * s + i
     seeds = shard_seeds(rank, world, unique)

@@ -538,6 +538,39 @@ __device__ __forceinline__ void park_pair(uint32_t &a0, uint32_t &a1, unsigned l
                  : "s"(sel), "s"(lo), "s"(hi));
 }
 
+// The same parking for the four rows of a step through the EXEC mask instead of v_writelane: tools/valu_calib.hip measured
+// v_writelane_b32 in the 4-cycle issue class (590 G wave-instructions/s on the chip, like most integer VALU operations) and a plain
+// v_mov_b32 in the 2-cycle class (1000 G/s), and the lane select can ride on the scalar pipe, which this kernel leaves mostly
+// idle: EXEC = 1 << sel, two v_mov per row (they write the one enabled lane), EXEC <<= 1 for the next row, EXEC restored at the
+// end.  Eight 2-cycle VALU instead of eight 4-cycle ones per scale and step (104 of the 366 VALU instructions of a step).
+// (SALU write of EXEC followed by a VALU needs no wait state on gfx9.)  -DFID_PARK_WRITELANE keeps the v_writelane form.
+__device__ __forceinline__ void park_quad(uint32_t &a0, uint32_t &a1, unsigned long long b0, unsigned long long b1, unsigned long long b2,
+                                          unsigned long long b3, int sel)
+{
+#ifdef FID_PARK_WRITELANE
+    park_pair(a0, a1, b0, sel);
+    park_pair(a0, a1, b1, sel + 1);
+    park_pair(a0, a1, b2, sel + 2);
+    park_pair(a0, a1, b3, sel + 3);
+#else
+    unsigned long long keep;
+    asm("s_mov_b64 %2, exec\n\t"
+        "s_lshl_b64 exec, 1, %3\n\t"
+        "v_mov_b32 %0, %4\n\tv_mov_b32 %1, %5\n\t"
+        "s_lshl_b64 exec, exec, 1\n\t"
+        "v_mov_b32 %0, %6\n\tv_mov_b32 %1, %7\n\t"
+        "s_lshl_b64 exec, exec, 1\n\t"
+        "v_mov_b32 %0, %8\n\tv_mov_b32 %1, %9\n\t"
+        "s_lshl_b64 exec, exec, 1\n\t"
+        "v_mov_b32 %0, %10\n\tv_mov_b32 %1, %11\n\t"
+        "s_mov_b64 exec, %2"
+        : "+v"(a0), "+v"(a1), "=&s"(keep)
+        : "s"(sel), "s"((uint32_t)b0), "s"((uint32_t)(b0 >> 32)), "s"((uint32_t)b1), "s"((uint32_t)(b1 >> 32)), "s"((uint32_t)b2),
+          "s"((uint32_t)(b2 >> 32)), "s"((uint32_t)b3), "s"((uint32_t)(b3 >> 32))
+        : "scc");
+#endif
+}
+
 template <int WMIN, int WSTEP, int NS, int NW, bool SPLIT>
 __global__ __launch_bounds__(64 * (NW + 1)) void k_threshold_stream(const uint8_t *__restrict__ gray, long long gfstride,
                                                                       uint32_t *__restrict__ masks, const DevParams P, int RS)
@@ -738,10 +771,7 @@ __global__ __launch_bounds__(64 * (NW + 1)) void k_threshold_stream(const uint8_
                 v = __builtin_amdgcn_sdot2(dhi, second, v, false);
                 const unsigned long long b3 = ballot64(v >= __mul24((int)g3, w2));
                 V[s] = v;
-                park_pair(acc0[s], acc1[s], b0, sel);
-                park_pair(acc0[s], acc1[s], b1, sel + 1);
-                park_pair(acc0[s], acc1[s], b2, sel + 2);
-                park_pair(acc0[s], acc1[s], b3, sel + 3);
+                park_quad(acc0[s], acc1[s], b0, b1, b2, b3, sel);
                 cur = nxt;
             });
             if (sel == 60 || k == nsteps - 1) flush(ys + ((4 * k) & ~63));

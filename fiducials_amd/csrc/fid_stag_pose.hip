@@ -257,6 +257,86 @@ __device__ double sr_cost(const double x[9], const double Cm[9])
     return acc;
 }
 
+// Refine::calc for FOUR points at once, one per 16-lane row of the wave (round 4).  One evaluation is ~900 dependent f64
+// instructions when a lane does it alone, and the solver's three candidates of an iteration kept three lanes of 64 busy: the
+// wave issued the whole stream for them (4 300 cycles per iteration, 4.8 cycles per instruction -- the single-wave issue rate
+// tools/valu_calib.hip measures).  Here a ROW works on one point:
+//   lane (a, b) = 4 a + b of the row (a, b < 3) forms T[a][b] = sum_k H[k][a] C[k][b], takes T[a][0..2] from its quad by DPP
+//   quad_perm and forms P[a][b] = sum_k T[a][k] H[k][b] -- the two 3 x 3 products in 2 x 5 instructions instead of 2 x 45;
+//   the lanes that hold P00, P01, P11, P02, P12, P22 make the conic coefficients and divide by A1 in ONE division; the rest of
+//   Ellipse.cpp's conversion runs on lane pairs: one lane the A / D / x / a side, its neighbour the C / E / y / b side (the two
+//   sides are the same expressions with other operands and signs: D3 = D2 / A2 beside E3 = E2 / C2, sqrt(F3 / A2) beside
+//   sqrt(F3 / C2)), exchanging by quad_perm.
+// Every quantity is formed by the same operations on the same operands, in the same order, as sr_cost (a - b is taken as
+// a + (-b), which is the same IEEE result); the cost comes back in every lane of the row.  -DSR_COST_SCALAR keeps sr_cost.
+__device__ __forceinline__ double sr_row_from(double v, int lane_in_row, int lane)
+{
+    return shfl_f64(v, (lane & 48) | lane_in_row);
+}
+__device__ double sr_cost_rows(const double xa[3], const double xb[3], const double cmb[3], int lane)
+{
+    const int r = lane & 15, a = r >> 2, b = r & 3;
+    // T[a][b], then the row a of T from the quad, then P[a][b]  (sr_mul3's expression: a0 b0 + a1 b1 + a2 b2)
+    const double T = xa[0] * cmb[0] + xa[1] * cmb[1] + xa[2] * cmb[2];
+    const double t0 = dpp_f64<0x00>(T), t1 = dpp_f64<0x55>(T), t2 = dpp_f64<0xAA>(T);
+    const double Pab = t0 * xb[0] + t1 * xb[1] + t2 * xb[2];
+    // the conic of sr_conic_to_ellipse(P0, -2 P1, P4, 2 P2, -2 P5, P8): this lane's coefficient, unnormalised
+    double coef = Pab;                       // A1 (lane 0), C1 (lane 5), F1 (lane 10)
+    if (r == 1 || r == 6) coef = -Pab * 2;   // B1 = -P[1] * 2 (lane 1), E1 = -P[5] * 2 (lane 6)
+    if (r == 2) coef = Pab * 2;              // D1 = P[2] * 2
+    const double A1raw = sr_row_from(coef, 0, lane);
+    const double q = coef / A1raw;           // B1 /= A1 ... F1 /= A1, A1 /= A1: one division for all six
+    const double A1 = sr_row_from(q, 0, lane), B1 = sr_row_from(q, 1, lane), C1 = sr_row_from(q, 5, lane), D1 = sr_row_from(q, 2, lane),
+                 E1 = sr_row_from(q, 6, lane), F1 = sr_row_from(q, 10, lane);
+    const bool side = (r & 1) != 0;          // false: the A2 / D / x / a side, true: the C2 / E / y / b side
+    double V2, W2, F2, sr = 0, cr = 1;       // V2 = A2 | C2, W2 = D2 | E2
+    bool rotated = false;
+    if (B1 == 0) {
+        V2 = side ? C1 : A1;
+        W2 = side ? E1 : D1;
+        F2 = F1;
+    } else {
+        const double t = B1 / (A1 - C1);
+        double s2, c2;
+        if (fabs(t) > 1e150) {
+            c2 = 0.0;
+            s2 = copysign(1.0, t);
+        } else {
+            c2 = 1.0 / sqrt(1.0 + t * t);
+            s2 = t * c2;
+        }
+        cr = sqrt(0.5 * (1.0 + c2));
+        sr = s2 / (2.0 * cr);
+        rotated = t != 0.0;
+        // A2 = 0.5 (A1 (1 + c2 + B1 s2 + C1 (1 - c2))), C2 = 0.5 (A1 (1 - c2 - B1 s2 + C1 (1 + c2)))
+        const double sc2 = side ? -c2 : c2, bs = B1 * s2, sbs = side ? -bs : bs;
+        V2 = 0.5 * (A1 * (1 + sc2 + sbs + C1 * (1 - sc2)));
+        // D2 = D1 cr + E1 sr, E2 = -D1 sr + E1 cr
+        W2 = (side ? -D1 : D1) * (side ? sr : cr) + E1 * (side ? cr : sr);
+        F2 = F1;
+    }
+    const double W3 = W2 / V2;               // D3 = D2 / A2 beside E3 = E2 / C2
+    double cc = -(W3 / 2);                   // cX | cY
+    const double term = V2 * (cc * cc);      // A2 cX^2 | C2 cY^2
+    const double oterm = dpp_f64<0xB1>(term);
+    const double F3 = (side ? oterm + term : term + oterm) - F2;
+    const double ax = sqrt(F3 / V2);         // a | b
+    if (rotated) {
+        const double occ = dpp_f64<0xB1>(cc);
+        // cX = tx cr - ty sr (this lane holds tx), cY = tx sr + ty cr (this lane holds ty)
+        cc = side ? occ * sr + cc * cr : cc * cr - occ * sr;
+    }
+    const double e_ax = fabs(ax - 0.4);                               // |a - 0.4| | |b - 0.4|
+    const double e_c = side ? fabs(-cc - 0.5) : fabs(cc - 0.5);       // |cX - 0.5| | |-cY - 0.5|
+    const double o_ax = dpp_f64<0xB1>(e_ax), o_c = dpp_f64<0xB1>(e_c);
+    double acc = 0;
+    acc += side ? o_ax : e_ax;
+    acc += side ? e_ax : o_ax;
+    acc += side ? o_c : e_c;
+    acc += side ? e_c : o_c;
+    return sr_row_from(acc, 0, lane);
+}
+
 // cv::DownhillSolver::minimize with the default TermCriteria(MAX_ITER + EPS, 5000, 1e-6), 9 dimensions, run by one wave with
 // the simplex in LDS.  The three candidate points of an iteration -- reflection (-1), expansion (-2), contraction (0.5) --
 // depend only on the current simplex: lanes 0, 1, 2 evaluate them side by side and the solver's decision sequence then
@@ -326,6 +406,7 @@ __device__ void sr_downhill(double x[9], const double step[9], const double Cm[9
         }
     }
     SR_LDS_SYNC();
+#ifdef SR_COST_SCALAR
     auto eval_rows = [&](int skip) {  // y[i] = f(p[i]) for every vertex but `skip`, one lane per vertex
         const int i = lane <= nd ? lane : nd;
         double row[9];
@@ -334,6 +415,25 @@ __device__ void sr_downhill(double x[9], const double step[9], const double Cm[9
         if (lane <= nd && lane != skip) S->y[lane] = v;
         SR_LDS_SYNC();
     };
+#else
+    // the lane's place in its row's two 3 x 3 products (sr_cost_rows) and the column b of C it multiplies with
+    const int ra = ((lane & 15) >> 2) < 3 ? (lane & 15) >> 2 : 2, rb = (lane & 3) < 3 ? lane & 3 : 2;
+    const double cmb[3] = {rb == 0 ? Cm[0] : rb == 1 ? Cm[1] : Cm[2], rb == 0 ? Cm[3] : rb == 1 ? Cm[4] : Cm[5],
+                           rb == 0 ? Cm[6] : rb == 1 ? Cm[7] : Cm[8]};
+    auto eval_rows = [&](int skip) {  // y[i] = f(p[i]) for every vertex but `skip`: four vertices at a time, a 16-lane row each
+        for (int v0 = 0; v0 <= nd; v0 += 4) {
+            const int i = v0 + (lane >> 4) <= nd ? v0 + (lane >> 4) : nd;
+            double xa[3], xb[3];
+            for (int k = 0; k < 3; k++) {
+                xa[k] = S->p[i][3 * ra + k];
+                xb[k] = S->p[i][3 * rb + k];
+            }
+            const double v = sr_cost_rows(xa, xb, cmb, lane);
+            if ((lane & 15) == 0 && v0 + (lane >> 4) <= nd && i != skip) S->y[i] = v;
+        }
+        SR_LDS_SYNC();
+    };
+#endif
     auto update_sum = [&]() {
         if (lane < nd) {
             double acc = 0.;
@@ -354,19 +454,28 @@ __device__ void sr_downhill(double x[9], const double step[9], const double Cm[9
     update_sum();
     for (;;) {
         double y[10];
-        for (int i = 0; i <= nd; i++) y[i] = S->y[i];
+#pragma unroll
+        for (int i = 0; i <= 9; i++) y[i] = S->y[i];
+        // the solver's scan for the lowest, highest and next-highest vertex -- the same comparisons in the same order, with the
+        // VALUES y[ilo], y[ihi], y[inhi] carried beside the indices: indexing the register array y[] with a run-time index costs
+        // a ten-way select chain per read, thirty of them per scan (the scan was about half of an iteration's 5 700 cycles)
         int ilo = 0, ihi, inhi;
-        if (y[0] > y[1]) { ihi = 0; inhi = 1; } else { ihi = 1; inhi = 0; }
-        for (int i = 0; i <= nd; i++) {
+        double v_lo = y[0], v_hi, v_nhi;
+        if (y[0] > y[1]) { ihi = 0; inhi = 1; v_hi = y[0]; v_nhi = y[1]; } else { ihi = 1; inhi = 0; v_hi = y[1]; v_nhi = y[0]; }
+#pragma unroll
+        for (int i = 0; i <= 9; i++) {
             const double yv = y[i];
-            if (yv <= y[ilo]) ilo = i;
-            if (yv > y[ihi]) { inhi = ihi; ihi = i; }
-            else if (yv > y[inhi] && i != ihi) inhi = i;
+            if (yv <= v_lo) { ilo = i; v_lo = yv; }
+            if (yv > v_hi) { inhi = ihi; v_nhi = v_hi; ihi = i; v_hi = yv; }
+            else if (yv > v_nhi && i != ihi) { inhi = i; v_nhi = yv; }
         }
-        if (ilo == inhi || ilo == ihi)
-            for (int i = 0; i <= nd; i++)
-                if (y[i] == y[ilo] && i != ihi && i != inhi) { ilo = i; break; }
-        const double error = fabs(y[ihi] - y[ilo]);
+        if (ilo == inhi || ilo == ihi) {
+            bool found = false;
+#pragma unroll
+            for (int i = 0; i <= 9; i++)
+                if (!found && y[i] == v_lo && i != ihi && i != inhi) { ilo = i; found = true; }
+        }
+        const double error = fabs(v_hi - v_lo);
         double range = 0;
         {
             double r = 0;
@@ -378,14 +487,33 @@ __device__ void sr_downhill(double x[9], const double step[9], const double Cm[9
                 }
                 r = fabs(mx - mn);
             }
-            range = sr_wave_max_nonneg_f64(r);  // (lanes >= nd carry 0)
+            // (lanes >= nd carry 0: the maximum of the first 16-lane row is the wave's -- four DPP steps instead of six)
+            {
+                unsigned long long u = __double_as_longlong(r);
+                unsigned lo = (unsigned)u, hi = (unsigned)(u >> 32);
+#define S_(C)                                                                                       \
+    {                                                                                               \
+        const unsigned ol = (unsigned)FID_DPP(0, (int)lo, C, 0xf), oh = (unsigned)FID_DPP(0, (int)hi, C, 0xf); \
+        const double o = __longlong_as_double(((unsigned long long)oh << 32) | ol);                 \
+        const double m = fmax(__longlong_as_double(((unsigned long long)hi << 32) | lo), o);        \
+        const unsigned long long mu = __double_as_longlong(m);                                      \
+        lo = (unsigned)mu;                                                                          \
+        hi = (unsigned)(mu >> 32);                                                                  \
+    }
+                S_(0x111) S_(0x112) S_(0x114) S_(0x118)  // row_shr:1, 2, 4, 8: lane 15 holds the maximum of lanes 0..15
+#undef S_
+                lo = (unsigned)__builtin_amdgcn_readlane((int)lo, 15);
+                hi = (unsigned)__builtin_amdgcn_readlane((int)hi, 15);
+                range = __longlong_as_double(((unsigned long long)hi << 32) | lo);
+            }
         }
         if (range <= 0.000001 || error <= 0.000001 || fcount >= 5000) {
             for (int j = 0; j < nd; j++) x[j] = S->p[ilo][j];
             if (evals) *evals = fcount;
             return;
         }
-        const double y_lo = y[ilo], y_nhi = y[inhi], y_hi = y[ihi];
+        const double y_lo = v_lo, y_nhi = v_nhi, y_hi = v_hi;
+#ifdef SR_COST_SCALAR
         double buf[9];
         {
             const double a_ = lane == 0 ? -1.0 : lane == 1 ? -2.0 : 0.5;
@@ -394,6 +522,21 @@ __device__ void sr_downhill(double x[9], const double step[9], const double Cm[9
         }
         const double yl = sr_cost(buf, Cm);
         const double y_refl = bcast_f64(yl, 0), y_exp = bcast_f64(yl, 1), y_con = bcast_f64(yl, 2);
+#else
+        // row 0: reflection (-1), row 1: expansion (-2), rows 2 and 3: contraction (0.5); a lane forms the six entries it multiplies
+        double xa[3], xb[3];
+        {
+            const int row = lane >> 4;
+            const double a_ = row == 0 ? -1.0 : row == 1 ? -2.0 : 0.5;
+            const double alpha = (1.0 - a_) / nd, beta = alpha - a_;
+            for (int k = 0; k < 3; k++) {
+                xa[k] = S->sum[3 * ra + k] * alpha - S->p[ihi][3 * ra + k] * beta;
+                xb[k] = S->sum[3 * rb + k] * alpha - S->p[ihi][3 * rb + k] * beta;
+            }
+        }
+        const double yl = sr_cost_rows(xa, xb, cmb, lane);
+        const double y_refl = bcast_f64(yl, 0), y_exp = bcast_f64(yl, 16), y_con = bcast_f64(yl, 32);
+#endif
         fcount++;
         double alpha = -1.0, y_alpha = y_refl;
         if (y_alpha < y_nhi) {
@@ -493,11 +636,15 @@ __device__ __forceinline__ void k_stag_refine_impl(fid_stag_marker *__restrict__
                 const double a0 = Hinv[0] * ex + Hinv[1] * ey + Hinv[2] * 1, a1 = Hinv[3] * ex + Hinv[4] * ey + Hinv[5] * 1;
                 const double a2 = Hinv[6] * ex + Hinv[7] * ey + Hinv[8] * 1;
                 const double qx = a0 / a2, qy = a1 / a2;
+                // (round 4) min_s sqrt(x_s) == sqrt(min_s x_s) bit for bit -- the correctly rounded square root is monotone -- so the
+                // rejecting pass takes ONE square root per pixel instead of 36 (23 code-dot loops per marker end in this pass)
+                double m2 = INFINITY;
                 for (int s = 0; s < 36; s++) {
                     const double sx = 0.5 + 0.4 * sinVals[(s + 9) % 36], sy = 0.5 + 0.4 * sinVals[s];
-                    const double d = sqrt((qx - sx) * (qx - sx) + (qy - sy) * (qy - sy));
-                    if (d < pixErr) pixErr = d;
+                    const double d2 = (qx - sx) * (qx - sx) + (qy - sy) * (qy - sy);
+                    if (d2 < m2) m2 = d2;
                 }
+                pixErr = sqrt(m2);
             }
             if (__ballot(act && pixErr > 0.1)) bad = true;
         }

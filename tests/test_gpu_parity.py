@@ -713,3 +713,31 @@ def test_contour_refinement_cfg2_every_tracing_mode_batch_and_pose(monkeypatch):
                 assert np.array_equal(c2, want[0][1])
         finally:
             det.close()
+
+
+def test_one_process_a_context_on_every_visible_gpu():
+    """BASELINE cfg 4's shape inside ONE process: fid_create(..., device = k) for every visible GPU (one today on the development
+    lease, N on a node), a frame of stream k on each, results == the oracle and == each other's for the same frame; contexts on
+    different devices work side by side (submit on all, then collect)."""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    n = C.c_int(0)
+    assert hip.hipGetDeviceCount(C.byref(n)) == 0 and n.value >= 1
+    d = get_predefined_dictionary(6)
+    frames = np.stack([make_frame(d, 10000 * k + 0, width=1280, height=720, n_markers=8).image for k in range(n.value)])
+    want = [oracle.detect(f, d) for f in frames]
+    dets = [ArucoDetector(d, device=k, max_width=1280, max_height=720, max_batch=1) for k in range(n.value)]
+    try:
+        for k, det in enumerate(dets):
+            assert det.device == k
+            det.submit_batch(np.ascontiguousarray(frames[k:k + 1]))
+        for k, det in enumerate(dets):
+            (corners, ids), = det.collect()
+            assert ids.tolist() == want[k][0].tolist() and np.array_equal(corners, want[k][1])
+            c0, i0 = det.detect_markers(frames[0])  # ... and the same frame gives the same markers on every device
+            assert i0.tolist() == want[0][0].tolist() and np.array_equal(c0, want[0][1])
+        with pytest.raises(_lib.FidError):
+            ArucoDetector(d, device=n.value, max_width=64, max_height=64)  # one past the last device
+    finally:
+        for det in dets:
+            det.close()

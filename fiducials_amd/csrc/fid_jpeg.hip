@@ -299,40 +299,20 @@ __global__ __launch_bounds__(JP_TPB) void k_jpeg_huff(const JpImage *__restrict_
             for (int u = 0; u < 16; u++) S.cmp[dst + u] = 0;
     }
     __syncthreads();
-    if (!decoder) return;
-    if (MODE == 1 && !active) return;
-    // ---- entry state
-    JpState e;
-    if (MODE == 0) {
-        e.p = 0;  // (not used: the lane starts at the first packed byte of its sub-sequence)
-        e.cz = 0;
-    } else if (i == 0) {
-        e.p = 0;
-        e.cz = 0;
-    } else {
-        e = st_in[gsub - 1];
-    }
-    int c = (int)(e.cz & 0xffu), z = (int)((e.cz >> 8) & 0xffu);
-    bool eoi = (e.cz >> 16) & 1u;
-    uint32_t done = 0;  // blocks completed by this lane
-    const uint32_t cstart = tid * JP_SUB - S.R[tid];                                              // packed: my first byte
-    const uint32_t cend = tid + 1 < nstg ? (tid + 1) * JP_SUB - S.R[tid + 1] : (tid + 1) * JP_SUB - S.R[tid] - (uint32_t)nrem[0];
-    const uint32_t end_bit = cend * 8u;  // this lane's part ends with the first symbol that starts at or behind it
-    uint32_t entry_bit = cstart * 8u;
-    if (MODE != 0 && i > 0 && !eoi) {
-        // (a predecessor that has met the end of the image needs no entry position -- and its p may lie in front of this
-        //  workgroup's staged bytes: untrusted input must not turn that into an index.  Clamped for the same reason.)
-        const uint32_t pb = e.p >> 3;
-        uint32_t rawk = pb > s_lo ? pb - s_lo : 0u;
-        rawk = rawk < (uint32_t)nstg * JP_SUB ? rawk : (uint32_t)nstg * JP_SUB;
-        entry_bit = jp_raw_to_cmp(S, rawk) * 8u + (e.p & 7u);
-    }
-    JpReader R;
-    R.s = S.cmp;
-    R.start(entry_bit);
+    // ---- decode.  MODE 0 / 1 go round INSIDE the kernel (round 4): a lane whose predecessor sits in the same workgroup takes that
+    // lane's new exit state from LDS and decodes again, until nothing in the workgroup changes -- the bytes stay unstuffed in
+    // LDS, the tables stay loaded, no launch and no host look in between.  Only a workgroup's first lane waits for another
+    // launch (its predecessor is the previous workgroup's last lane).  A 256-frame batch used to take a speculative pass and
+    // six or seven synchronisation launches with a host look after every second one; now: the speculative launch (which
+    // settles every workgroup within itself), one launch that carries the true states across the workgroup boundaries, one
+    // that finds nothing left to change.  Same decodes from the same entry states: the settled exit states are the true ones.
+    __shared__ JpState s_exit[JP_TPB];
     const int nl = I.hs * I.vs;  // luma blocks per MCU
-    // the next restart boundary / the end of the data at or behind a packed bit position
+    const uint32_t cstart = tid < nstg ? tid * JP_SUB - S.R[tid] : 0u;                                              // packed: my first byte
+    const uint32_t cend = tid < nstg ? (tid + 1 < nstg ? (tid + 1) * JP_SUB - S.R[tid + 1] : (tid + 1) * JP_SUB - S.R[tid] - (uint32_t)nrem[0]) : 0u;
+    const uint32_t end_bit = cend * 8u;  // this lane's part ends with the first symbol that starts at or behind it
     const uint32_t end_data = S.end == 0xffffffffu ? 0xffffffffu : S.end * 8u;
+    // the next restart boundary / the end of the data at or behind a packed bit position
     auto next_boundary = [&](uint32_t bitpos) -> uint32_t {
         uint32_t q = (bitpos + 7u) >> 3;  // first whole byte position at or behind it
         const uint32_t lim = cend + 8u;   // (a lane never gets further than a symbol behind its end)
@@ -343,136 +323,202 @@ __global__ __launch_bounds__(JP_TPB) void k_jpeg_huff(const JpImage *__restrict_
         uint32_t bb = bq == 0xffffffffu ? 0xffffffffu : bq * 8u;
         return bb < end_data ? bb : end_data;
     };
-    uint32_t Mb = next_boundary(entry_bit);
-    // MODE 2: where the block being decoded goes.  (block in the MCU, MCU column, MCU row) are counted along; only the start
-    // needs divisions.
-    int16_t *cblk = nullptr;
-    uint32_t B = 0, mx = 0, my = 0;
-    auto bind_block = [&]() {
-        if (MODE != 2) return;
-        cblk = nullptr;
-        if (B >= I.nblocks) return;  // (more blocks than the frame has: damaged data, dropped)
-        const int comp = c < nl ? 0 : 1 + (c - nl);
-        const int v = comp == 0 ? c / I.hs : 0, h = comp == 0 ? c - v * I.hs : 0;
-        const int hsc = comp == 0 ? I.hs : 1, vsc = comp == 0 ? I.vs : 1;
-        cblk = coefs + I.coef_base + I.coef_off[comp] + ((size_t)(my * vsc + v) * I.bw[comp] + (mx * hsc + h)) * 64;
-    };
-    if (MODE == 2) {
-        B = (uint32_t)blkbase[gsub].x;
-        const uint32_t m = B / (uint32_t)I.bpm;
-        // (for a sound file B mod bpm == c; a damaged one may disagree: the entry state decides the tables, B the place)
-        mx = m % (uint32_t)I.mcux;
-        my = m / (uint32_t)I.mcux;
-        bind_block();
+    // what a lane has to show: its exit state and what the scan needs of it (blocks done, DC sums); `e_used` = the entry state
+    // that result was decoded from
+    JpState e_used, o_state;
+    int4 o_nblk = make_int4(0, 0, 0, 0);
+    bool have = false;          // this launch decoded this lane at least once
+    bool live = decoder;        // decodes in the coming round
+    JpState e;
+    e.p = 0;
+    e.cz = 0;
+    bool spec = false;          // the coming decode starts at the lane's own first byte (MODE 0's first round)
+    if (MODE == 0) {
+        spec = i > 0;           // (sub-sequence 0 starts on a symbol: exact from the start)
+        // the state this start stands for, should the predecessor happen to end exactly here
+        e.p = (s_lo + tid * JP_SUB) * 8u;
+        e.cz = 0;
+        if (i == 0) e.p = 0;
+    } else if (MODE == 1) {
+        live = decoder && active;
+        if (decoder && i > 0) e = st_in[gsub - 1];
+        // (a lane that is not active has, in st_in[gsub], the result of decoding from st_in[gsub - 1])
+        if (decoder && !live) {
+            o_state = st_in[gsub];
+        }
+    } else if (decoder && i > 0) {
+        e = st_in[gsub - 1];
     }
-    // DC prediction: the decoding passes sum the differences per component (since the last restart marker this lane met), the
-    // writing pass starts from what the scan made of those sums and stores absolute values
-    int dc0 = 0, dc1 = 0, dc2 = 0, had_reset = 0;
-    if (MODE == 2) {
-        const int4 bb = blkbase[gsub];
-        dc0 = bb.y;
-        dc1 = bb.z;
-        dc2 = bb.w;
-    }
-    uint32_t p_exit_c = entry_bit;  // packed bit position where this lane stops
-    if (!eoi) {
-        for (;;) {
-            R.fill();
-            const uint32_t pos = R.pos();
-            // ---- at a restart boundary (or within its padding of one bits), or at the end of the data?
-            if (pos + 8u > Mb) {
-                const int rem = (int)Mb - (int)pos;
-                const bool pad = rem <= 0 || R.peek(rem) == (1u << rem) - 1u;
-                if (pad) {
-                    if (Mb == end_data) {
-                        eoi = true;
-                        p_exit_c = Mb;
-                        break;
+    e_used = e;
+    for (int round = 0;; round++) {
+      if (live) {
+        int c = (int)(e.cz & 0xffu), z = (int)((e.cz >> 8) & 0xffu);
+        bool eoi = (e.cz >> 16) & 1u;
+        uint32_t done = 0;  // blocks completed by this lane
+        uint32_t entry_bit = cstart * 8u;
+        if (!spec && i > 0 && !eoi) {
+            // (a predecessor that has met the end of the image needs no entry position -- and its p may lie in front of this
+            //  workgroup's staged bytes: untrusted input must not turn that into an index.  Clamped for the same reason.)
+            const uint32_t pb = e.p >> 3;
+            uint32_t rawk = pb > s_lo ? pb - s_lo : 0u;
+            rawk = rawk < (uint32_t)nstg * JP_SUB ? rawk : (uint32_t)nstg * JP_SUB;
+            entry_bit = jp_raw_to_cmp(S, rawk) * 8u + (e.p & 7u);
+        }
+        JpReader R;
+        R.s = S.cmp;
+        R.start(entry_bit);
+        uint32_t Mb = next_boundary(entry_bit);
+        // MODE 2: where the block being decoded goes.  (block in the MCU, MCU column, MCU row) are counted along; only the start
+        // needs divisions.
+        int16_t *cblk = nullptr;
+        uint32_t B = 0, mx = 0, my = 0;
+        auto bind_block = [&]() {
+            if (MODE != 2) return;
+            cblk = nullptr;
+            if (B >= I.nblocks) return;  // (more blocks than the frame has: damaged data, dropped)
+            const int comp = c < nl ? 0 : 1 + (c - nl);
+            const int v = comp == 0 ? c / I.hs : 0, h = comp == 0 ? c - v * I.hs : 0;
+            const int hsc = comp == 0 ? I.hs : 1, vsc = comp == 0 ? I.vs : 1;
+            cblk = coefs + I.coef_base + I.coef_off[comp] + ((size_t)(my * vsc + v) * I.bw[comp] + (mx * hsc + h)) * 64;
+        };
+        if (MODE == 2) {
+            B = (uint32_t)blkbase[gsub].x;
+            const uint32_t m = B / (uint32_t)I.bpm;
+            // (for a sound file B mod bpm == c; a damaged one may disagree: the entry state decides the tables, B the place)
+            mx = m % (uint32_t)I.mcux;
+            my = m / (uint32_t)I.mcux;
+            bind_block();
+        }
+        // DC prediction: the decoding passes sum the differences per component (since the last restart marker this lane met), the
+        // writing pass starts from what the scan made of those sums and stores absolute values
+        int dc0 = 0, dc1 = 0, dc2 = 0, had_reset = 0;
+        if (MODE == 2) {
+            const int4 bb = blkbase[gsub];
+            dc0 = bb.y;
+            dc1 = bb.z;
+            dc2 = bb.w;
+        }
+        uint32_t p_exit_c = entry_bit;  // packed bit position where this lane stops
+        if (!eoi) {
+            for (;;) {
+                R.fill();
+                const uint32_t pos = R.pos();
+                // ---- at a restart boundary (or within its padding of one bits), or at the end of the data?
+                if (pos + 8u > Mb) {
+                    const int rem = (int)Mb - (int)pos;
+                    const bool pad = rem <= 0 || R.peek(rem) == (1u << rem) - 1u;
+                    if (pad) {
+                        if (Mb == end_data) {
+                            eoi = true;
+                            p_exit_c = Mb;
+                            break;
+                        }
+                        // every decoder starts afresh behind a restart marker
+                        R.start(Mb);
+                        // (a block or MCU cut short by the marker is abandoned: sound data ends intervals on MCU boundaries)
+                        if (MODE == 2 && (c != 0 || z != 0)) {
+                            B += (uint32_t)(I.bpm - c);
+                            if (++mx == (uint32_t)I.mcux) {
+                                mx = 0;
+                                my++;
+                            }
+                        }
+                        c = 0;
+                        z = 0;
+                        dc0 = dc1 = dc2 = 0;  // (the prediction starts from zero behind a restart marker)
+                        had_reset = 1;
+                        bind_block();
+                        const uint32_t at = Mb;
+                        Mb = next_boundary(at + 1u);
+                        if (at >= end_bit) {
+                            p_exit_c = at;
+                            break;
+                        }
+                        continue;
                     }
-                    // every decoder starts afresh behind a restart marker
-                    R.start(Mb);
-                    // (a block or MCU cut short by the marker is abandoned: sound data ends intervals on MCU boundaries)
-                    if (MODE == 2 && (c != 0 || z != 0)) {
-                        B += (uint32_t)(I.bpm - c);
-                        if (++mx == (uint32_t)I.mcux) {
+                }
+                if (pos >= end_bit) {
+                    p_exit_c = pos;
+                    break;
+                }
+                // ---- one symbol: the DC difference (z == 0) or an AC run / size pair, through one instruction stream
+                const int comp = c < nl ? 0 : 1 + (c - nl);
+                const bool isdc = z == 0;
+                uint16_t en = (comp < 2 || cr_same) ? s_lut[(comp ? 2 : 0) + (isdc ? 0 : 1)][R.peek(JP_LOOK)] : (uint16_t)0;
+                if (!(en >> 8)) en = luts[(size_t)(isdc ? I.lut_dc[comp] : I.lut_ac[comp]) * 65536 + R.peek(16)];  // (a long code: rare)
+                int len = en >> 8, sym = en & 0xff;
+                if (len == 0) {  // no such code (only while out of step): one bit, nothing
+                    len = 1;
+                    sym = 0;
+                }
+                R.drop(len);
+                const int r = isdc ? 0 : sym >> 4, sz = sym & 15;
+                const int raw = sz ? (int)R.peek(sz) : 0;
+                R.drop(sz);
+                const int val = (sz && raw < (1 << (sz - 1))) ? raw - (1 << sz) + 1 : raw;
+                int dcv = 0;
+                if (isdc) {
+                    dc0 += comp == 0 ? val : 0;
+                    dc1 += comp == 1 ? val : 0;
+                    dc2 += comp == 2 ? val : 0;
+                    dcv = comp == 0 ? dc0 : (comp == 1 ? dc1 : dc2);
+                }
+                const int zi = isdc ? 0 : z + r;  // where the value goes (zig-zag order)
+                const bool has = isdc || sz != 0;
+                if (MODE == 2 && has && zi < 64 && cblk) cblk[s_zz[zi]] = (int16_t)(isdc ? dcv : val);
+                z = isdc ? 1 : (sz ? (zi < 64 ? zi + 1 : 64) : (r == 15 ? z + 16 : 64));
+                if (z >= 64) {
+                    z = 0;
+                    done++;
+                    if (++c == I.bpm) {
+                        c = 0;
+                        if (MODE == 2 && ++mx == (uint32_t)I.mcux) {
                             mx = 0;
                             my++;
                         }
                     }
-                    c = 0;
-                    z = 0;
-                    dc0 = dc1 = dc2 = 0;  // (the prediction starts from zero behind a restart marker)
-                    had_reset = 1;
-                    bind_block();
-                    const uint32_t at = Mb;
-                    Mb = next_boundary(at + 1u);
-                    if (at >= end_bit) {
-                        p_exit_c = at;
-                        break;
+                    if (MODE == 2) {
+                        B++;
+                        bind_block();
                     }
-                    continue;
-                }
-            }
-            if (pos >= end_bit) {
-                p_exit_c = pos;
-                break;
-            }
-            // ---- one symbol: the DC difference (z == 0) or an AC run / size pair, through one instruction stream
-            const int comp = c < nl ? 0 : 1 + (c - nl);
-            const bool isdc = z == 0;
-            uint16_t en = (comp < 2 || cr_same) ? s_lut[(comp ? 2 : 0) + (isdc ? 0 : 1)][R.peek(JP_LOOK)] : (uint16_t)0;
-            if (!(en >> 8)) en = luts[(size_t)(isdc ? I.lut_dc[comp] : I.lut_ac[comp]) * 65536 + R.peek(16)];  // (a long code: rare)
-            int len = en >> 8, sym = en & 0xff;
-            if (len == 0) {  // no such code (only while out of step): one bit, nothing
-                len = 1;
-                sym = 0;
-            }
-            R.drop(len);
-            const int r = isdc ? 0 : sym >> 4, sz = sym & 15;
-            const int raw = sz ? (int)R.peek(sz) : 0;
-            R.drop(sz);
-            const int val = (sz && raw < (1 << (sz - 1))) ? raw - (1 << sz) + 1 : raw;
-            int dcv = 0;
-            if (isdc) {
-                dc0 += comp == 0 ? val : 0;
-                dc1 += comp == 1 ? val : 0;
-                dc2 += comp == 2 ? val : 0;
-                dcv = comp == 0 ? dc0 : (comp == 1 ? dc1 : dc2);
-            }
-            const int zi = isdc ? 0 : z + r;  // where the value goes (zig-zag order)
-            const bool has = isdc || sz != 0;
-            if (MODE == 2 && has && zi < 64 && cblk) cblk[s_zz[zi]] = (int16_t)(isdc ? dcv : val);
-            z = isdc ? 1 : (sz ? (zi < 64 ? zi + 1 : 64) : (r == 15 ? z + 16 : 64));
-            if (z >= 64) {
-                z = 0;
-                done++;
-                if (++c == I.bpm) {
-                    c = 0;
-                    if (MODE == 2 && ++mx == (uint32_t)I.mcux) {
-                        mx = 0;
-                        my++;
-                    }
-                }
-                if (MODE == 2) {
-                    B++;
-                    bind_block();
                 }
             }
         }
+        if (MODE != 2) {
+            JpState o;
+            // back to a raw position (the same whoever computed it)
+            o.p = eoi ? e.p : (s_lo + jp_cmp_to_raw(S, p_exit_c >> 3, tid, nstg)) * 8u + (p_exit_c & 7u);
+            if (eoi && !((e.cz >> 16) & 1u)) o.p = (s_lo + jp_cmp_to_raw(S, p_exit_c >> 3, tid, nstg)) * 8u;
+            o.cz = (uint32_t)c | ((uint32_t)z << 8) | (eoi ? 1u << 16 : 0u);
+            o_state = o;
+            o_nblk = make_int4((int)(done | (had_reset ? 0x80000000u : 0u)), dc0, dc1, dc2);
+            have = true;
+            e_used = e;
+        }
+      }
+      if (MODE == 2) break;  // (the writing pass decodes once, from the settled states)
+      // ---- who goes again: a lane whose predecessor in this workgroup now ends somewhere else than where this lane started
+      if (decoder) s_exit[tid] = o_state;
+      __syncthreads();
+      live = false;
+      spec = false;
+      if (decoder && tid > 0 && round < JP_TPB) {
+          const JpState pe = s_exit[tid - 1];
+          if (pe != e_used) {
+              e = pe;
+              live = true;
+          }
+      }
+      if (!__syncthreads_or(live ? 1 : 0)) break;
     }
-    if (MODE != 2) {
-        JpState o;
-        // back to a raw position (the same whoever computed it)
-        o.p = eoi ? e.p : (s_lo + jp_cmp_to_raw(S, p_exit_c >> 3, tid, nstg)) * 8u + (p_exit_c & 7u);
-        if (eoi && !((e.cz >> 16) & 1u)) o.p = (s_lo + jp_cmp_to_raw(S, p_exit_c >> 3, tid, nstg)) * 8u;
-        o.cz = (uint32_t)c | ((uint32_t)z << 8) | (eoi ? 1u << 16 : 0u);
-        nblk[gsub] = make_int4((int)(done | (had_reset ? 0x80000000u : 0u)), dc0, dc1, dc2);
+    if (MODE != 2 && decoder) {
+        if (have) nblk[gsub] = o_nblk;
         if (MODE == 0) {
-            st_out[gsub] = o;
+            st_out[gsub] = o_state;
             chg_out[gsub] = 1;
         } else {
-            const bool ch = o != st_in[gsub];
-            st_out[gsub] = o;
+            const bool ch = have && o_state != st_in[gsub];
+            st_out[gsub] = o_state;
             chg_out[gsub] = ch ? 1 : 0;
             if (ch) atomicOr(any_changed, 1u);
         }
@@ -694,12 +740,22 @@ __global__ __launch_bounds__(256) void k_jpeg_color(const JpImage *__restrict__ 
     const int cw = (W + I.hs - 1) / I.hs, ch = (H + I.vs - 1) / I.vs;
     const int p0 = I.bw[0] * 8, p1 = I.ncomp == 3 ? I.bw[1] * 8 : 0;
     const bool fancy = I.ncomp == 3 && I.hs == 2 && cw > 2;
-    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < (long long)W4 * H; idx += (long long)gridDim.x * blockDim.x) {
-        const int y = (int)(idx / W4), x0 = (int)(idx - (long long)y * W4) * 4;
+    // (32-bit index arithmetic: W4 * H < 2^31 for every supported size; the 64-bit division this loop used to start with was ~90
+    //  VALU instructions per four pixels, more than the colour arithmetic itself)
+    const unsigned total4 = (unsigned)W4 * (unsigned)H, step4 = gridDim.x * blockDim.x;
+    const bool y_aligned = ((I.plane_base + I.plane_off[0]) & 3) == 0 && (p0 & 3) == 0 && ((uintptr_t)planes & 3) == 0;
+    for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total4; idx += step4) {
+        const int y = (int)(idx / (unsigned)W4), x0 = (int)(idx - (unsigned)y * (unsigned)W4) * 4;
         const uint8_t *yr = P + I.plane_off[0] + (size_t)y * p0 + x0;  // (rows of the planes are multiples of 8 wide: four bytes are there)
         int Y[4], cbv[4], crv[4];
+        if (y_aligned) {
+            const uint32_t yw = *reinterpret_cast<const uint32_t *>(yr);
 #pragma unroll
-        for (int k = 0; k < 4; k++) Y[k] = yr[k];
+            for (int k = 0; k < 4; k++) Y[k] = (int)((yw >> (8 * k)) & 0xffu);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++) Y[k] = yr[k];
+        }
         if (I.ncomp == 3) {
             if (fancy) {
                 // chroma columns i0 - 1 .. i0 + 2 serve the four pixels (x0 = 2 i0); column sums 3 * near row + far row for

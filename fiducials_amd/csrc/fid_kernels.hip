@@ -3609,7 +3609,7 @@ __global__ __launch_bounds__(64) void k_identify(const uint8_t *__restrict__ gra
     for (unsigned wi = blockIdx.x; wi < n; wi += gridDim.x) {
         const unsigned item = worklist[wi];
         const int f = item >> 16, k = item & 0xffff;
-        const DevCand cd = filtered[(long long)f * P.maxCands + k];
+        const DevCand *cdp = filtered + (long long)f * P.maxCands + k;  // (read in place: a copy indexed by lane went through scratch memory)
         const uint8_t *g = gray + (long long)f * gfstride;
         DevIdent *out = ident + (long long)f * P.maxCands + k;
         __syncthreads();
@@ -3620,7 +3620,7 @@ __global__ __launch_bounds__(64) void k_identify(const uint8_t *__restrict__ gra
         {
             const float fs1 = (float)SZ - 1.f;
             const int pi = row & 3;
-            float sxp = cd.c[2 * pi], syp = cd.c[2 * pi + 1];
+            float sxp = cdp->c[2 * pi], syp = cdp->c[2 * pi + 1];
             float dxp = (pi == 1 || pi == 2) ? fs1 : 0.f;
             float dyp = (pi >= 2) ? fs1 : 0.f;
             float dsel = row < 4 ? dxp : dyp;

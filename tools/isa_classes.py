@@ -54,7 +54,8 @@ def classify(op: str, text: str) -> str:
 
 with tempfile.TemporaryDirectory() as td:
     fat, co = os.path.join(td, "fat.bin"), os.path.join(td, "dev.co")
-    subprocess.check_call([f"{LLVM}/llvm-objcopy", f"--dump-section=.hip_fatbin={fat}", lib])
+    # (an output file is named on purpose: llvm-objcopy with one file argument rewrites its INPUT in place)
+    subprocess.check_call([f"{LLVM}/llvm-objcopy", f"--dump-section=.hip_fatbin={fat}", lib, os.path.join(td, "copy.so")])
     subprocess.check_call([f"{LLVM}/clang-offload-bundler", "--unbundle", "--type=o", f"--input={fat}",
                            "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"], stderr=subprocess.DEVNULL)
     dis = subprocess.run([f"{LLVM}/llvm-objdump", "-d", "--mcpu=gfx950", co], capture_output=True, text=True, check=True).stdout

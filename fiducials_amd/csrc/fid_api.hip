@@ -32,6 +32,7 @@ struct fid_ctx {
     hipStream_t sub_stream[MAX_SUB] = {};  // sub-batches of one call run on these, overlapping each other's tails
     int sub_prio[MAX_SUB] = {};
     hipStream_t aux_stream[MAX_SUB] = {};  // per sub-batch: the seed walk runs here, beside the probe passes and the survivor walk
+    hipStream_t idx_stream = nullptr;      // calls laid out as ONE piece (a frame or two, a batch of a chain): k_seed_index on a stream of its own
     hipEvent_t aux_fork[MAX_SUB] = {}, aux_join[MAX_SUB] = {}, aux_idx[MAX_SUB] = {};
     hipEvent_t sub_done[MAX_SUB] = {}, fork_ev = nullptr;
     hipStream_t copy_stream = nullptr;     // fid_detect_batch: the frames go up sub-batch by sub-batch on this stream ...
@@ -122,6 +123,11 @@ struct fid_ctx {
     fid_marker *d_pose_in = nullptr;
     int *d_pose_n = nullptr;
     int pose_cap = 0;
+    // what a call hands back -- global flags, per-frame counters, markers, poses -- lies in ONE device block and ONE pinned host
+    // block, laid out for the call's frame count (layout_results): one fill at the start of a call and one copy at its end instead
+    // of three fills and three or four copies (each a ~5 us kernel on the stream of a 0.8 ms single-frame call)
+    uint8_t *d_res = nullptr, *h_res = nullptr;
+    size_t res_clear_bytes = 0, res_markers_end = 0, res_poses_end = 0, res_poses_off = 0;
     // pinned host staging
     fid_marker *h_markers = nullptr;
     DevCounts *h_counts = nullptr;
@@ -162,6 +168,38 @@ fid_status dalloc(fid_ctx *c, T **p, size_t count)
 }
 
 int roundup(int v, int m) { return (v + m - 1) / m * m; }
+
+size_t results_bytes(int F, int MM)
+{
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    return up(sizeof(DevGlobal)) + up(sizeof(unsigned) * fid_ctx::MAX_SUB) + up(sizeof(DevCounts) * (size_t)F) + up(sizeof(fid_marker) * (size_t)F * MM) +
+           up(sizeof(fid_pose_out) * (size_t)F * MM);
+}
+// [DevGlobal][nwork][DevCounts x F] (cleared at the start of a call) [fid_marker x F x MM][fid_pose_out x F x MM]
+void layout_results(fid_ctx *c, int F)
+{
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const int MM = c->lim.max_markers_per_frame;
+    size_t off = 0;
+    c->d_global = (DevGlobal *)(c->d_res + off);
+    c->h_global = (DevGlobal *)(c->h_res + off);
+    off += up(sizeof(DevGlobal));
+    c->d_nwork = (unsigned *)(c->d_res + off);
+    off += up(sizeof(unsigned) * fid_ctx::MAX_SUB);
+    c->d_counts = (DevCounts *)(c->d_res + off);
+    c->h_counts = (DevCounts *)(c->h_res + off);
+    off += up(sizeof(DevCounts) * (size_t)F);
+    c->res_clear_bytes = off;
+    c->d_markers = (fid_marker *)(c->d_res + off);
+    c->h_markers = (fid_marker *)(c->h_res + off);
+    off += up(sizeof(fid_marker) * (size_t)F * MM);
+    c->res_markers_end = off;
+    c->res_poses_off = off;
+    c->d_poses = (fid_pose_out *)(c->d_res + off);
+    c->h_poses = (fid_pose_out *)(c->h_res + off);
+    off += up(sizeof(fid_pose_out) * (size_t)F * MM);
+    c->res_poses_end = off;
+}
 
 template <int NW, bool SPLIT>
 void launch_thr_stream(dim3 grid, hipStream_t st, const uint8_t *g, long long gfstride, uint32_t *masks, const DevParams &P, int RS)
@@ -281,7 +319,7 @@ size_t masks_elems(const fid_ctx *c, int W, int H, int F)
 }
 
 // the streams of sub-batches 0 .. nsub - 1 (and their auxiliary streams in the traced modes), made on first use
-fid_status ensure_streams(fid_ctx *c, int nsub)
+fid_status ensure_streams(fid_ctx *c, int nsub, int F)
 {
     for (int sb = 0; sb < nsub && sb < fid_ctx::MAX_SUB; sb++) {
         // (sub-batch 0 runs on the context's own stream, which has nothing else to do while a call is under way: a resident batch
@@ -291,6 +329,10 @@ fid_status ensure_streams(fid_ctx *c, int nsub)
         else if (!c->sub_stream[sb] && nsub > 1) HIPCHK(c, hipStreamCreateWithPriority(&c->sub_stream[sb], hipStreamNonBlocking, c->sub_prio[sb]));
         if (!c->aux_stream[sb] && c->trace_mode >= 1) HIPCHK(c, hipStreamCreateWithPriority(&c->aux_stream[sb], hipStreamNonBlocking, c->sub_prio[sb]));
     }
+    // one piece = two streams so far: a third one still fits the runtime's default of four hardware queues
+    // (only for calls of a few frames -- the node's shape: a 256-frame batch of a chain is one piece too, but two contexts in turn
+    //  would then hold six streams, and more than four live streams cost the batch 17 % in round 3)
+    if (nsub == 1 && F <= 16 && c->trace_mode == 2 && !c->idx_stream && !getenv("FID_NO_IDX_STREAM")) HIPCHK(c, hipStreamCreateWithFlags(&c->idx_stream, hipStreamNonBlocking));
     return FID_OK;
 }
 
@@ -431,16 +473,15 @@ fid_status enqueue_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H,
         c->masks_H = H;
         c->masks_S = c->P.nscales;
     }
-    HIPCHK(c, hipMemsetAsync(c->d_counts, 0, sizeof(DevCounts) * F, st0));
-    HIPCHK(c, hipMemsetAsync(c->d_global, 0, sizeof(DevGlobal), st0));
-    HIPCHK(c, hipMemsetAsync(c->d_nwork, 0, sizeof(unsigned) * fid_ctx::MAX_SUB, st0));
+    layout_results(c, F);
+    HIPCHK(c, hipMemsetAsync(c->d_res, 0, c->res_clear_bytes, st0));  // global flags, work-list counters, per-frame counters
     // ---- the batch is cut into sub-batches that run the whole pipeline on their own streams: the latency-bound
     //      tail of one sub-batch's kernels (the longest border, the last candidates) overlaps the next one's bulk
     const SubPlan plan = plan_sub_batches(c, F);
     const int nsub = plan.nsub;
     c->last_nsub = nsub;
     {
-        const fid_status rcs = ensure_streams(c, nsub);
+        const fid_status rcs = ensure_streams(c, nsub, F);
         if (rcs != FID_OK) return rcs;
     }
     if (nsub > 1) HIPCHK(c, hipEventRecord(c->fork_ev, st0));
@@ -601,10 +642,22 @@ fid_status enqueue_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H,
             swb = swb < 2 ? 2 : (swb > 4 * wcap ? 4 * wcap : swb);
             uint4 *recs = c->d_recs + 2 * f0 * MCn;
             const int cpb = c->copy_blocks > 0 ? c->copy_blocks : 256;
-            // -- auxiliary stream
+            // -- the main stream's first kernel goes out BEFORE the auxiliary chain's eight launches: the host needs ~15 us to
+            //    enqueue those, and for a single frame the seed walk sat waiting behind them (round 4, cfg 2 timeline)
+            if (c->profile) (void)hipEventRecord(ev[14], st);
+            hipLaunchKernelGGL(k_seed_walk, dim3(swb, Fs), dim3(64 * SW_WAVES), 0, st, masks, seedq, tab, pool, (DevSegC *)segs, counts,
+                               c->d_global, P);
+            if (c->profile) (void)hipEventRecord(ev[15], st);
+            mark(ST_PROBE + 1);
+            chain_point(1);
+            // -- auxiliary stream.  k_seed_index (the map seed state -> seed index, which only k_seg_link2 on the main stream and
+            //    the auxiliary k_seg_cycles need) is off the auxiliary chain's critical path when the call is one piece: a stream of
+            //    its own beside the probes (39 us of a single frame's 314 us contour stage)
             if (c->profile) (void)hipEventRecord(ev[16], sa);
-            hipLaunchKernelGGL(k_seed_index, dim3(8 * gm, Fs), dim3(256), 0, sa, seedq, seedhash, counts, P);
-            HIPCHK(c, hipEventRecord(c->aux_idx[sb], sa));
+            hipStream_t si = (nsub == 1 && Fs <= 16 && c->idx_stream) ? c->idx_stream : sa;
+            if (si != sa) HIPCHK(c, hipStreamWaitEvent(si, c->aux_fork[sb], 0));
+            hipLaunchKernelGGL(k_seed_index, dim3(8 * gm, Fs), dim3(256), 0, si, seedq, seedhash, counts, P);
+            HIPCHK(c, hipEventRecord(c->aux_idx[sb], si));
             if (c->probe_lut) {
                 hipLaunchKernelGGL((k_probe_lut<PROBE0_STEPS, 0>), dim3(64 * gm, Fs), dim3(256), 0, sa, masks, starts, surv1, counts, c->d_global, P);
                 hipLaunchKernelGGL((k_probe_lut<PROBE1_STEPS, 1>), dim3(16 * gm, Fs), dim3(256), 0, sa, masks, surv1, surv, counts, c->d_global, P);
@@ -615,6 +668,7 @@ fid_status enqueue_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H,
             const int wb3 = c->walk2_div > 0 ? (wb / c->walk2_div > 0 ? wb / c->walk2_div : 1) : wb2;
             hipLaunchKernelGGL(k_walk_full<2>, dim3(wb3, Fs), dim3(64 * WALK_WAVES), 0, sa, masks, surv, wres, tab, pool, segs, pend, counts,
                                c->d_global, P);
+            if (si != sa) HIPCHK(c, hipStreamWaitEvent(sa, c->aux_idx[sb], 0));  // (the survivors' seed look-ups need the map)
             hipLaunchKernelGGL(k_seg_cycles, dim3(8 * gm, Fs), dim3(64), 0, sa, seedq, (const DevSegC *)segs, pend, wres, contours, cinfo, cbase,
                                recs, counts, c->d_global, P, 1);
             hipLaunchKernelGGL(k_seg_copy, dim3(cpb / 4 > 0 ? cpb / 4 : 1, Fs), dim3(256), 0, sa, recs, tab, pool, dense, counts, P, 1);
@@ -624,13 +678,7 @@ fid_status enqueue_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H,
                                P.maxPerim + 1, K4_LONG_STACK, 1, dense, cbase, 2);
             if (c->profile) (void)hipEventRecord(ev[17], sa);
             HIPCHK(c, hipEventRecord(c->aux_join[sb], sa));
-            // -- main stream
-            if (c->profile) (void)hipEventRecord(ev[14], st);
-            hipLaunchKernelGGL(k_seed_walk, dim3(swb, Fs), dim3(64 * SW_WAVES), 0, st, masks, seedq, tab, pool, (DevSegC *)segs, counts,
-                               c->d_global, P);
-            if (c->profile) (void)hipEventRecord(ev[15], st);
-            mark(ST_PROBE + 1);
-            chain_point(1);
+            // -- main stream, continued
             HIPCHK(c, hipStreamWaitEvent(st, c->aux_idx[sb], 0));
             hipLaunchKernelGGL(k_seg_link2, dim3(16 * gm, Fs), dim3(256), 0, st, seedq, (DevSegC *)segs, seedhash, counts, P);
             hipLaunchKernelGGL(k_seg_cycles, dim3(32 * gm * c->light_x, Fs), dim3(64), 0, st, seedq, (const DevSegC *)segs, pend, wres, contours, cinfo, cbase,
@@ -680,7 +728,8 @@ fid_status enqueue_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H,
         chain_point(4);
         // ---- K5
         float4 *cmeta = c->d_cmeta + f0 * MC;
-        hipLaunchKernelGGL(k_sort_cands, dim3(Fs), dim3(c->light_x > 1 ? 1024 : 256), MC * 8, st, cands, sorted, cmeta, counts, P);
+        // (a rank sort: every thread compares its candidates with all of them -- a call of a few frames gives the frame 1 024 threads)
+        hipLaunchKernelGGL(k_sort_cands, dim3(Fs), dim3((c->light_x > 1 || Fs < 16) ? 1024 : 256), MC * 8, st, cands, sorted, cmeta, counts, P);
         mark(ST_SORT + 1);
         hipLaunchKernelGGL(k_near, dim3(32 * gm * c->light_x, Fs), dim3(256), 0, st, sorted, cmeta, nearb, counts, P);
         mark(ST_NEAR + 1);
@@ -745,12 +794,8 @@ fid_status enqueue_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H,
     const DevParams &P = c->P;
     HIPCHK(c, hipGetLastError());
     // ---- results
-    HIPCHK(c, hipMemcpyAsync(c->h_counts, c->d_counts, sizeof(DevCounts) * F, hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipMemcpyAsync(c->h_global, c->d_global, sizeof(DevGlobal), hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipMemcpyAsync(c->h_markers, c->d_markers, sizeof(fid_marker) * (size_t)F * P.maxMarkers, hipMemcpyDeviceToHost, st));
     c->pose_done = false;
-    if (c->pose_cam_valid)
-        HIPCHK(c, hipMemcpyAsync(c->h_poses, c->d_poses, sizeof(fid_pose_out) * (size_t)F * P.maxMarkers, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(c->h_res, c->d_res, c->pose_cam_valid ? c->res_poses_end : c->res_markers_end, hipMemcpyDeviceToHost, st));  // one copy
     c->last_frames = F;
     c->last_W = W;
     c->last_H = H;
@@ -1090,17 +1135,12 @@ fid_status fid_create(const fid_params *params, const fid_dict *dict, const fid_
     TRY(dalloc(c, &c->d_filter_scratch, F * MC));
     TRY(dalloc(c, &c->d_accsrc, F * MC));
     TRY(dalloc(c, &c->d_mksrc, F * MM));
-    TRY(dalloc(c, &c->d_markers, F * MM));
-    TRY(dalloc(c, &c->d_poses, F * MM));
-    TRY(dalloc(c, &c->d_counts, F));
-    TRY(dalloc(c, &c->d_global, 1));
+    TRY(dalloc(c, &c->d_res, results_bytes((int)F, (int)MM)));
     TRY(dalloc(c, &c->d_worklist, F * MC));
-    TRY(dalloc(c, &c->d_nwork, fid_ctx::MAX_SUB));
     TRY(dalloc(c, &c->d_pose_n, 1));
-    TRYHIP(hipHostMalloc((void **)&c->h_markers, sizeof(fid_marker) * F * MM, hipHostMallocDefault));
-    TRYHIP(hipHostMalloc((void **)&c->h_counts, sizeof(DevCounts) * F, hipHostMallocDefault));
-    TRYHIP(hipHostMalloc((void **)&c->h_global, sizeof(DevGlobal), hipHostMallocDefault));
-    TRYHIP(hipHostMalloc((void **)&c->h_poses, sizeof(fid_pose_out) * F * MM, hipHostMallocDefault));
+    TRYHIP(hipHostMalloc((void **)&c->h_res, results_bytes((int)F, (int)MM), hipHostMallocDefault));
+    memset(c->h_res, 0, results_bytes((int)F, (int)MM));
+    layout_results(c, (int)F);
     TRYHIP(hipMemset(c->d_masks, 0, c->masks_bytes));
     // opt in to large dynamic LDS where needed
     TRYHIP(hipFuncSetAttribute((const void *)k_threshold<TX, TY, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
@@ -1121,11 +1161,11 @@ void fid_destroy(fid_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void *dev[] = {c->d_in, c->d_gray, c->d_masks, c->d_starts, c->d_surv1, c->d_surv, c->d_pool, c->d_segs, c->d_pend, c->d_seedq, c->d_seedhash, c->d_wres, c->d_cinfo, c->d_cbase, c->d_filter_scratch, c->d_accsrc, c->d_mksrc, c->d_dense, c->d_recs, c->d_contours, c->d_ckpts, c->d_cands, c->d_sorted, c->d_cmeta, c->d_filtered, c->d_near,
-                   c->d_ident, c->d_pre, c->d_markers, c->d_poses, c->d_counts, c->d_global, c->d_worklist, c->d_nwork, c->d_dict,
+                   c->d_ident, c->d_pre, c->d_res, c->d_worklist, c->d_dict,
                    c->d_subpix_mask, c->d_lens, c->d_pose_in, c->d_pose_n};
     for (void *p : dev)
         if (p) (void)hipFree(p);
-    void *host[] = {c->h_markers, c->h_counts, c->h_global, c->h_poses};
+    void *host[] = {c->h_res};
     for (void *p : host)
         if (p) (void)hipHostFree(p);
     for (int i = 0; i <= ST_COUNT; i++)
@@ -1134,6 +1174,11 @@ void fid_destroy(fid_ctx *c)
     if (c->tail_ev) (void)hipEventDestroy(c->tail_ev);
     for (int sb = 0; sb < fid_ctx::MAX_SUB; sb++) {
         if (c->sub_stream[sb]) (void)hipStreamSynchronize(c->sub_stream[sb]);
+        if (sb == 0 && c->idx_stream) {
+            (void)hipStreamSynchronize(c->idx_stream);
+            (void)hipStreamDestroy(c->idx_stream);
+            c->idx_stream = nullptr;
+        }
         if (c->aux_stream[sb]) {
             (void)hipStreamSynchronize(c->aux_stream[sb]);
             (void)hipStreamDestroy(c->aux_stream[sb]);

@@ -4006,7 +4006,9 @@ __global__ __launch_bounds__(64) void k_subpix(const uint8_t *__restrict__ gray,
                                                 const DevParams P)
 {
     __shared__ float sp[(2 * SP_MAXWIN + 3) * (2 * SP_MAXWIN + 3)];
-    __shared__ double prod[5][(2 * SP_MAXWIN + 1) * (2 * SP_MAXWIN + 1)];
+    // (rows padded to a multiple of 16 taps; the pad holds -0.0, the one value x + pad == x holds for bit for bit, for every x)
+    constexpr int SP_NTP = ((2 * SP_MAXWIN + 1) * (2 * SP_MAXWIN + 1) + 15) & ~15;
+    __shared__ __attribute__((aligned(16))) double prod[5][SP_NTP];
     // the gray pixels every iteration's patch can touch while the corner stays within win + 1 pixels of where it started
     // (further away the result is discarded anyway): fetched once, so that an iteration does not wait for global memory
     constexpr int SP_CMAX = (2 * SP_MAXWIN + 3) + 1 + 2 * (SP_MAXWIN + 1);
@@ -4017,6 +4019,9 @@ __global__ __launch_bounds__(64) void k_subpix(const uint8_t *__restrict__ gray,
     const int win = P.subpixWin, ww = 2 * win + 1, pw = ww + 2;
     const int W = P.W, H = P.H, gs = P.gstride;
     const int total = P.nframes * P.maxMarkers * 4;
+    for (int t = ww * ww + lane; t < SP_NTP; t += 64)
+#pragma unroll
+        for (int q = 0; q < 5; q++) prod[q][t] = -0.0;
     for (int item = blockIdx.x; item < total; item += gridDim.x) {
         int f = item / (P.maxMarkers * 4), r = item % (P.maxMarkers * 4);
         int mk = r >> 2, cn = r & 3;
@@ -4048,7 +4053,23 @@ __global__ __launch_bounds__(64) void k_subpix(const uint8_t *__restrict__ gray,
         float wgt[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) wgt[k] = lane + 64 * k < ww * ww ? maskw[lane + 64 * k] : 0.f;
+        constexpr int SP_PR = ((2 * SP_MAXWIN + 3) * (2 * SP_MAXWIN + 3) + 63) / 64;
+        int poff[SP_PR], pjj[SP_PR];
+#pragma unroll
+        for (int r = 0; r < SP_PR; r++) {
+            const int pp = lane + 64 * r;
+            const int i = pp / pw, j = pp - i * pw;
+            poff[r] = i * csz + j;
+            pjj[r] = pp < pw * pw ? j : -1;
+        }
         int iter = 0;
+#ifdef SP_TIMING
+        unsigned long long tp0 = 0, tp1 = 0, tp2 = 0, tp3 = 0, tq;
+#define SP_T(acc) { const unsigned long long now_ = __builtin_readcyclecounter(); acc += now_ - tq; tq = now_; }
+        tq = __builtin_readcyclecounter();
+#else
+#define SP_T(acc)
+#endif
         for (;;) {
             // getRectSubPix(src, (pw, pw), cI) -> sp
             float cx = cIx - (pw - 1) * 0.5f, cy = cIy - (pw - 1) * 0.5f;
@@ -4061,18 +4082,22 @@ __global__ __launch_bounds__(64) void k_subpix(const uint8_t *__restrict__ gray,
                 float a12 = a * (1.f - b), a22 = a * b, b1 = 1.f - b, b2 = b;
                 double s = (1. - a) / a;
                 const uint8_t *s0 = s_img + (ipy - Y0) * csz + (ipx - X0);
-                for (int p = lane; p < pw * pw; p += 64) {
-                    int i = p / pw, j = p - i * pw;
-                    const uint8_t *sr = s0 + i * csz;
-                    float t = a12 * sr[j + 1] + a22 * sr[j + 1 + csz];
+                // (the patch positions of this lane -- row, column, offset into the cached pixels -- do not change from iteration to
+                //  iteration: computed once in front of the loop, poff / pjj; the same reads and the same arithmetic)
+#pragma unroll
+                for (int r = 0; r < SP_PR; r++) {
+                    const int j = pjj[r];
+                    if (j < 0) continue;
+                    const uint8_t *q = s0 + poff[r];  // = sr + j
+                    float t = a12 * q[1] + a22 * q[1 + csz];
                     float prev;
                     if (j == 0) {
-                        prev = (1 - a) * (b1 * sr[0] + b2 * sr[csz]);
+                        prev = (1 - a) * (b1 * q[0] + b2 * q[csz]);
                     } else {
-                        float tp = a12 * sr[j] + a22 * sr[j + csz];
+                        float tp = a12 * q[0] + a22 * q[csz];
                         prev = (float)(tp * s);
                     }
-                    sp[p] = prev + t;
+                    sp[lane + 64 * r] = prev + t;
                 }
             } else if (0 <= ipx && ipx + pw < W && 0 <= ipy && ipy + pw < H) {
                 // getRectSubPix_8u32f fast path: dst[j] = prev_j + t_j, prev_0 = (1-a)(b1 s[0] + b2 s[step]),
@@ -4139,6 +4164,7 @@ __global__ __launch_bounds__(64) void k_subpix(const uint8_t *__restrict__ gray,
                 }
             }
             __syncthreads();
+            SP_T(tp0)
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const int t = lane + 64 * k;
@@ -4157,24 +4183,28 @@ __global__ __launch_bounds__(64) void k_subpix(const uint8_t *__restrict__ gray,
                 prod[4][t] = gxy * px + gyy * py;
             }
             __syncthreads();
+            SP_T(tp1)
             // the five accumulators are summed in the reference's tap order, one accumulator per lane (0..4)
             double accv = 0;
             if (lane < 5) {
                 // in tap order, as the reference accumulates; sixteen LDS reads are issued together, then added one after
                 // the other (one read per add left every add waiting for LDS: 6 of the 7 us an iteration took)
+                // (round 4: whole groups only -- the row's pad is -0.0 -- so that an addition is ONE dependent instruction; the
+                //  predicated form `if (t < nt) acc += v` was a compare and two selects on top of every add: 5 700 of an
+                //  iteration's 9 000 cycles went into these sums)
                 const double *pr = prod[lane];
                 const int nt = ww * ww;
                 for (int t0 = 0; t0 < nt; t0 += 16) {
                     double v[16];
 #pragma unroll
-                    for (int k = 0; k < 16; k++) v[k] = pr[t0 + k < nt ? t0 + k : nt - 1];
+                    for (int k = 0; k < 16; k++) v[k] = pr[t0 + k];
 #pragma unroll
-                    for (int k = 0; k < 16; k++)
-                        if (t0 + k < nt) accv += v[k];
+                    for (int k = 0; k < 16; k++) accv += v[k];
                 }
             }
             const double a = bcast_f64(accv, 0), b = bcast_f64(accv, 1), c = bcast_f64(accv, 2);
             const double bb1 = bcast_f64(accv, 3), bb2 = bcast_f64(accv, 4);
+            SP_T(tp2)
             if (lane == 0) {
                 int flag = 0;  // 0 continue, 1 stop
                 double det = a * c - b * b;
@@ -4200,8 +4230,12 @@ __global__ __launch_bounds__(64) void k_subpix(const uint8_t *__restrict__ gray,
                 cIy = s_c[1];
             }
             iter++;
+            SP_T(tp3)
             if (flag & 1) break;
         }
+#ifdef SP_TIMING
+        if (lane == 0 && iter >= 20) printf("subpix corner: %d iterations; cycles per iteration: patch %llu products %llu sums %llu solve+sync %llu\n", iter, tp0 / iter, tp1 / iter, tp2 / iter, tp3 / iter);
+#endif
         if (fabsf(cIx - cTx) > win || fabsf(cIy - cTy) > win) {
             cIx = cTx;
             cIy = cTy;

@@ -3601,6 +3601,7 @@ __global__ __launch_bounds__(64) void k_identify(const uint8_t *__restrict__ gra
     __shared__ int hist[256];
     __shared__ uint8_t cellbits[FID_MAX_CELLS * FID_MAX_CELLS];
     __shared__ int s_thr;
+    __shared__ double2 s_otsu[256];  // Otsu's (mu1, q1) of every bin
     const int lane = lane_id();
     const unsigned n = *nwork;
     const int ms = P.markerSize, bb = P.borderBits, msb = ms + 2 * bb, cellSize = P.cellSize;
@@ -3613,6 +3614,13 @@ __global__ __launch_bounds__(64) void k_identify(const uint8_t *__restrict__ gra
         const uint8_t *g = gray + (long long)f * gfstride;
         DevIdent *out = ident + (long long)f * P.maxCands + k;
         __syncthreads();
+#ifdef ID_TIMING
+        unsigned long long ti[6];
+        ti[0] = __builtin_readcyclecounter();
+#define ID_T(k) ti[k] = __builtin_readcyclecounter();
+#else
+#define ID_T(k)
+#endif
         for (int i = lane; i < 256; i += 64) hist[i] = 0;
         // ---- getPerspectiveTransform(src = candidate corners, dst = patch corners), lane = row*8 + col
         const int row = lane >> 3, col = lane & 7;
@@ -3710,33 +3718,61 @@ __global__ __launch_bounds__(64) void k_identify(const uint8_t *__restrict__ gra
 #undef Sd
         }
         __syncthreads();
+        ID_T(1)
         long long ssum = 0, ssq = 0;
         const int in0 = cellSize / 2, in1 = SZ - cellSize / 2;
-        for (int p = lane; p < SZ * SZ; p += 64) {
-            int y = p / SZ, x1 = p - y * SZ;
-            uint8_t v = 0;
-            if (okinv) {
-                double X0 = Mi[0] * 0 + Mi[1] * y + Mi[2];
-                double Y0 = Mi[3] * 0 + Mi[4] * y + Mi[5];
-                double W0 = Mi[6] * 0 + Mi[7] * y + Mi[8];
-                double Wd = W0 + Mi[6] * x1;
-                Wd = Wd ? 1. / Wd : 0;
-                int X = sat_round_int((X0 + Mi[0] * x1) * Wd);
-                int Y = sat_round_int((Y0 + Mi[3] * x1) * Wd);
-                X = X < SHRT_MIN ? SHRT_MIN : (X > SHRT_MAX ? SHRT_MAX : X);
-                Y = Y < SHRT_MIN ? SHRT_MIN : (Y > SHRT_MAX ? SHRT_MAX : Y);
-                if ((unsigned)X < (unsigned)W && (unsigned)Y < (unsigned)H) v = g[(long long)Y * P.gstride + X];
-            }
-            patch[p] = v;
-            atomicAdd(&hist[v], 1);
-            if (y >= in0 && y < in1 && x1 >= in0 && x1 < in1) {
-                ssum += v;
-                ssq += (int)v * (int)v;
+        // (round 4: seven patch pixels of a lane at a time -- their source pixels are fetched together, then stored and counted: one
+        //  global-memory latency per seven pixels instead of one per pixel (the loads were 35 of the 55 k cycles this loop took
+        //  for a 56 x 56 patch); the row / column of a pixel is carried along instead of divided out.  Same arithmetic per pixel.)
+        {
+            constexpr int WU = 7;
+            int py = lane / SZ, px1 = lane - py * SZ;  // (one division per candidate)
+            for (int p0 = lane; p0 < SZ * SZ; p0 += 64 * WU) {
+                uint8_t vv[WU];
+                int yy[WU], xx[WU];
+#pragma unroll
+                for (int u = 0; u < WU; u++) {
+                    const int y = py, x1 = px1;
+                    yy[u] = y;
+                    xx[u] = x1;
+                    uint8_t v = 0;
+                    if (okinv && p0 + 64 * u < SZ * SZ) {
+                        double X0 = Mi[0] * 0 + Mi[1] * y + Mi[2];
+                        double Y0 = Mi[3] * 0 + Mi[4] * y + Mi[5];
+                        double W0 = Mi[6] * 0 + Mi[7] * y + Mi[8];
+                        double Wd = W0 + Mi[6] * x1;
+                        Wd = Wd ? 1. / Wd : 0;
+                        int X = sat_round_int((X0 + Mi[0] * x1) * Wd);
+                        int Y = sat_round_int((Y0 + Mi[3] * x1) * Wd);
+                        X = X < SHRT_MIN ? SHRT_MIN : (X > SHRT_MAX ? SHRT_MAX : X);
+                        Y = Y < SHRT_MIN ? SHRT_MIN : (Y > SHRT_MAX ? SHRT_MAX : Y);
+                        if ((unsigned)X < (unsigned)W && (unsigned)Y < (unsigned)H) v = g[(long long)Y * P.gstride + X];
+                    }
+                    vv[u] = v;
+                    px1 += 64;  // the next pixel of this lane: 64 further along the row-major patch
+                    while (px1 >= SZ) {
+                        px1 -= SZ;
+                        py++;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < WU; u++) {
+                    const int p = p0 + 64 * u;
+                    if (p >= SZ * SZ) break;
+                    const uint8_t v = vv[u];
+                    patch[p] = v;
+                    atomicAdd(&hist[v], 1);
+                    if (yy[u] >= in0 && yy[u] < in1 && xx[u] >= in0 && xx[u] < in1) {
+                        ssum += v;
+                        ssq += (int)v * (int)v;
+                    }
+                }
             }
         }
         ssum = wave_sum_i64(ssum);
         ssq = wave_sum_i64(ssq);
         __syncthreads();
+        ID_T(2)
         // ---- meanStdDev on the inner region
         const int nin = (in1 - in0) * (in1 - in0);
         double scale = nin ? 1. / nin : 0.;
@@ -3762,8 +3798,12 @@ __global__ __launch_bounds__(64) void k_identify(const uint8_t *__restrict__ gra
                 // not: bin i's (mu1, q1) are parked in lane i % 64 (register i / 64) and the 256 sigmas are then computed four per
                 // lane, followed by one arg-max with the loop's rule (the FIRST bin that reaches the largest sigma, and only a
                 // sigma > 0).  Same operations on the same operands, 256 x ~ 45 instructions fewer per candidate (of ~ 24 k).
+                // (round 4: bin i's pair leaves through LDS, written by lane 0 -- two stores that nothing waits for -- instead of a
+                //  compare and four selects per bin in every lane; tools/valu_calib.hip: a second v_cndmask on the same VCC costs
+                //  ~ 17 cycles, and this loop had three of them on each of its 256 dependent steps)
                 double mu1 = 0, q1 = 0;
-                double pm[4] = {0., 0., 0., 0.}, pq[4] = {-1., -1., -1., -1.};  // (q1 < 0: the loop skipped this bin)
+                for (int i = lane; i < 256; i += 64) s_otsu[i] = make_double2(0., -1.);  // (q1 < 0: the loop skipped this bin)
+                __builtin_amdgcn_wave_barrier();
 #pragma unroll
                 for (int k4 = 0; k4 < 4; k4++)
                   for (int j = 0; j < 64; j++) {
@@ -3774,9 +3814,17 @@ __global__ __launch_bounds__(64) void k_identify(const uint8_t *__restrict__ gra
                     double q2 = 1. - q1;
                     if (fmin(q1, q2) < FLT_EPSILON || fmax(q1, q2) > 1. - FLT_EPSILON) continue;
                     mu1 = (mu1 + i * p_i) / q1;
-                    const bool mine = lane == j;
-                    pm[k4] = mine ? mu1 : pm[k4];
-                    pq[k4] = mine ? q1 : pq[k4];
+                    if (lane == 0) s_otsu[i] = make_double2(mu1, q1);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                double pm[4], pq[4];
+#pragma unroll
+                for (int k4 = 0; k4 < 4; k4++) {
+                    const double2 v = s_otsu[k4 * 64 + lane];
+                    pm[k4] = v.x;
+                    pq[k4] = v.y;
                 }
                 double best = 0.;
                 int bi = 0;
@@ -3797,6 +3845,7 @@ __global__ __launch_bounds__(64) void k_identify(const uint8_t *__restrict__ gra
                 if (lane == 0) s_thr = (int)floor(max_val);
             }
             __syncthreads();
+            ID_T(3)
             const int thr = s_thr;
             const int cs = cellSize - 2 * P.cellMargin;
             for (int c = lane; c < msb * msb; c += 64) {
@@ -3811,6 +3860,7 @@ __global__ __launch_bounds__(64) void k_identify(const uint8_t *__restrict__ gra
             for (int c = lane; c < msb * msb; c += 64) cellbits[c] = (uint8_t)uniform_bits;
         }
         __syncthreads();
+        ID_T(4)
         for (int c = lane; c < msb * msb; c += 64) out->bits[c] = cellbits[c];
         // ---- _getBorderErrors (every lane computes the same scalar answer from LDS)
         int borderErrors = 0;
@@ -3875,6 +3925,10 @@ __global__ __launch_bounds__(64) void k_identify(const uint8_t *__restrict__ gra
             out->id = id;
             out->rot = rot;
         }
+#ifdef ID_TIMING
+        ID_T(5)
+        if (lane == 0 && (wi & 63u) == 0) printf("identify cand %u: cycles homography %llu warp %llu otsu %llu cells %llu border+dictionary %llu (id %d)\n", wi, ti[1] - ti[0], ti[2] - ti[1], ti[3] - ti[2], ti[4] - ti[3], ti[5] - ti[4], id);
+#endif
     }
 }
 
@@ -4568,6 +4622,16 @@ struct PoseCam {
     double D[5];
     double fiducial_len;
 };
+// CvLevMarq's damping factor exp(lambdaLg10 * log(10.)) for lambdaLg10 = -16 .. 16 as the HOST's libm gives it (glibc's exp / log,
+// what the reference runs on; generated with Python's math.exp(k * math.log(10.0)), hexadecimal literals = the exact doubles):
+// a table look-up instead of a device exp() in every Levenberg-Marquardt step -- and the reference's values, not the device
+// library's.
+__device__ __forceinline__ double lm_lambda(int lg10)
+{
+    static const double t[33] = {0x1.cd2b297d889a0p-54, 0x1.203af9ee755f8p-50, 0x1.6849b86a12b93p-47, 0x1.c25c268497664p-44, 0x1.19799812dea04p-40, 0x1.5fd7fe179648cp-37, 0x1.b7cdfd9d7bd9cp-34, 0x1.12e0be826d687p-30, 0x1.5798ee2308c2fp-27, 0x1.ad7f29abcaf44p-24, 0x1.0c6f7a0b5ed87p-20, 0x1.4f8b588e368e5p-17, 0x1.a36e2eb1c4326p-14, 0x1.0624dd2f1a9f9p-10, 0x1.47ae147ae1478p-7, 0x1.9999999999998p-4, 0x1.0000000000000p+0, 0x1.4000000000001p+3, 0x1.9000000000003p+6, 0x1.f400000000006p+9, 0x1.3880000000005p+13, 0x1.86a000000000ep+16, 0x1.e84800000000bp+19, 0x1.312d000000003p+23, 0x1.7d7840000000cp+26, 0x1.dcd6500000018p+29, 0x1.2a05f20000015p+33, 0x1.74876e800000ap+36, 0x1.d1a94a2000015p+39, 0x1.2309ce5400013p+43, 0x1.6bcc41e900008p+46, 0x1.c6bf52634002fp+49, 0x1.1c37937e08011p+53};
+    lg10 = lg10 < -16 ? -16 : (lg10 > 16 ? 16 : lg10);
+    return t[lg10 + 16];
+}
 
 // symmetric 3x3 eigen-decomposition by cyclic Jacobi, fully unrolled (static register indexing)
 __device__ __forceinline__ void jacobi3(double A[3][3], double V[3][3])
@@ -4945,7 +5009,7 @@ __global__ __launch_bounds__(64) void k_pose(const fid_marker *__restrict__ mark
         double prevParam[6], S[21], gJ[6], Jrow[6];
         double err = 0, prevErrNorm = 0, errNorm = 0;
         int lambdaLg10 = -3, iters = 0, state = 1;
-        const double LOG10 = log(10.);
+        // (CvLevMarq: lambda = exp(lambdaLg10 * log(10.)): lm_lambda)
 #pragma unroll
         for (int i = 0; i < 6; i++) prevParam[i] = param[i];
         for (;;) {
@@ -4966,7 +5030,7 @@ __global__ __launch_bounds__(64) void k_pose(const fid_marker *__restrict__ mark
 #pragma unroll
                 for (int i = 0; i < 6; i++) prevParam[i] = param[i];
                 double xs[6];
-                solve6_spd(S, gJ, exp(lambdaLg10 * LOG10), xs);
+                solve6_spd(S, gJ, lm_lambda(lambdaLg10), xs);
 #pragma unroll
                 for (int i = 0; i < 6; i++) param[i] = prevParam[i] - xs[i];
                 if (iters == 0) prevErrNorm = sqrt(grp_sum8(err * err));
@@ -4978,7 +5042,7 @@ __global__ __launch_bounds__(64) void k_pose(const fid_marker *__restrict__ mark
                 if (errNorm > prevErrNorm) {
                     if (++lambdaLg10 <= 16) {
                         double xs[6];
-                        solve6_spd(S, gJ, exp(lambdaLg10 * LOG10), xs);
+                        solve6_spd(S, gJ, lm_lambda(lambdaLg10), xs);
 #pragma unroll
                         for (int i = 0; i < 6; i++) param[i] = prevParam[i] - xs[i];
                         needErr = true;

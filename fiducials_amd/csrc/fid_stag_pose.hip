@@ -890,7 +890,7 @@ __device__ __forceinline__ void k_stag_pose_impl(const fid_stag_marker *__restri
     double prevParam[6], S[21], gJ[6], Jrow[6] = {0, 0, 0, 0, 0, 0};
     double err = 0, prevErrNorm = 0, errNorm = 0;
     int lambdaLg10 = -3, iters = 0, state = 1;
-    const double LOG10 = log(10.);
+    // (CvLevMarq: lambda = exp(lambdaLg10 * log(10.)): lm_lambda)
     for (int i = 0; i < 6; i++) prevParam[i] = param[i];
     for (;;) {
         bool needJ = false, needErr = false;
@@ -905,7 +905,7 @@ __device__ __forceinline__ void k_stag_pose_impl(const fid_stag_marker *__restri
             }
             for (int i = 0; i < 6; i++) prevParam[i] = param[i];
             double xs[6];
-            solve6_spd(S, gJ, exp(lambdaLg10 * LOG10), xs);
+            solve6_spd(S, gJ, lm_lambda(lambdaLg10), xs);
             for (int i = 0; i < 6; i++) param[i] = prevParam[i] - xs[i];
             if (iters == 0) prevErrNorm = sqrt(grp_sum16(err * err));
             needErr = true;
@@ -916,7 +916,7 @@ __device__ __forceinline__ void k_stag_pose_impl(const fid_stag_marker *__restri
             if (errNorm > prevErrNorm) {
                 if (++lambdaLg10 <= 16) {
                     double xs[6];
-                    solve6_spd(S, gJ, exp(lambdaLg10 * LOG10), xs);
+                    solve6_spd(S, gJ, lm_lambda(lambdaLg10), xs);
                     for (int i = 0; i < 6; i++) param[i] = prevParam[i] - xs[i];
                     needErr = true;
                     state = 3;

@@ -128,6 +128,8 @@ struct fid_ctx {
     // of three fills and three or four copies (each a ~5 us kernel on the stream of a 0.8 ms single-frame call)
     uint8_t *d_res = nullptr, *h_res = nullptr;
     size_t res_clear_bytes = 0, res_markers_end = 0, res_poses_end = 0, res_poses_off = 0;
+    bool blocking = false;        // the call in progress is fid_detect*: nobody can chain behind it (no tail_ev on its stream)
+    bool res_precleared = false;  // feed_and_enqueue has put this call's clear of d_res in front of its host -> device copy
     // pinned host staging
     fid_marker *h_markers = nullptr;
     DevCounts *h_counts = nullptr;
@@ -474,7 +476,8 @@ fid_status enqueue_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H,
         c->masks_S = c->P.nscales;
     }
     layout_results(c, F);
-    HIPCHK(c, hipMemsetAsync(c->d_res, 0, c->res_clear_bytes, st0));  // global flags, work-list counters, per-frame counters
+    if (!c->res_precleared) HIPCHK(c, hipMemsetAsync(c->d_res, 0, c->res_clear_bytes, st0));  // global flags, work-list counters, per-frame counters
+    c->res_precleared = false;
     // ---- the batch is cut into sub-batches that run the whole pipeline on their own streams: the latency-bound
     //      tail of one sub-batch's kernels (the longest border, the last candidates) overlaps the next one's bulk
     const SubPlan plan = plan_sub_batches(c, F);
@@ -519,7 +522,7 @@ fid_status enqueue_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H,
             if (c->profile) (void)hipEventRecord(ev[idx], st);
         };
         auto chain_point = [&](int pt) {  // (a point the mode in use does not pass falls through to the next one that it does)
-            if (sb == nsub - 1 && !tail_recorded && c->chain_at <= pt) {
+            if (sb == nsub - 1 && !tail_recorded && !c->blocking && c->chain_at <= pt) {  // (an event record costs the stream ~6 us)
                 (void)hipEventRecord(c->tail_ev, st);
                 tail_recorded = true;
             }
@@ -728,8 +731,8 @@ fid_status enqueue_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H,
         chain_point(4);
         // ---- K5
         float4 *cmeta = c->d_cmeta + f0 * MC;
-        // (a rank sort: every thread compares its candidates with all of them -- a call of a few frames gives the frame 1 024 threads)
-        hipLaunchKernelGGL(k_sort_cands, dim3(Fs), dim3((c->light_x > 1 || Fs < 16) ? 1024 : 256), MC * 8, st, cands, sorted, cmeta, counts, P);
+        // (a rank sort: every candidate is compared with all of them -- a call of a few frames gives the frame sixteen workgroups)
+        hipLaunchKernelGGL(k_sort_cands, dim3(Fs, (c->light_x > 1 || Fs < 16) ? 16 : 1), dim3(256), MC * 8, st, cands, sorted, cmeta, counts, P);
         mark(ST_SORT + 1);
         hipLaunchKernelGGL(k_near, dim3(32 * gm * c->light_x, Fs), dim3(256), 0, st, sorted, cmeta, nearb, counts, P);
         mark(ST_NEAR + 1);
@@ -922,7 +925,9 @@ fid_status run_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H, int
         c->last_error = "a submitted batch is in flight: fid_collect first";
         return FID_E_INVALID_ARG;
     }
+    c->blocking = true;
     const fid_status rc = enqueue_detect(c, d_src, F, W, H, stride, fstride, enc);
+    c->blocking = false;
     if (rc != FID_OK) {
         c->wait_ev = c->wait_copy_ev = nullptr;
         c->chained = false;
@@ -1313,9 +1318,18 @@ static fid_status feed_and_enqueue(fid_ctx *c, const uint8_t *imgs, int32_t nfra
     // and copies more slowly, the overlap is the same).  A batch of a chain (fid_order_after) is one piece: its copy runs
     // under the kernels of the batch before it, on the other context.
     c->host_feed = getenv("FID_NO_FEED_OVERLAP") == nullptr;
-    if (c->host_feed && !c->copy_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
     const SubPlan plan = plan_sub_batches(c, nframes);
     const int nsub = plan.nsub;
+    if (c->blocking && nsub == 1 && !c->wait_ev && !c->wait_copy_ev) {
+        // one piece, nothing to overlap with: the copy goes on the main stream itself (no event between it and the first kernel)
+        // BEHIND the clear of the result block, which so runs under the copy instead of after it (the single-frame call: 34 us
+        // between the end of the copy and the start of the threshold kernel, round 4 timeline)
+        c->host_feed = false;
+        layout_results(c, nframes);
+        HIPCHK(c, hipMemsetAsync(c->d_res, 0, c->res_clear_bytes, c->stream));
+        c->res_precleared = true;
+    }
+    if (c->host_feed && !c->copy_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
     if (c->host_feed && c->wait_copy_ev) HIPCHK(c, hipStreamWaitEvent(c->copy_stream, c->wait_copy_ev, 0));
     c->wait_copy_ev = nullptr;
     if (!c->host_feed) {
@@ -1350,7 +1364,9 @@ fid_status fid_detect_batch(fid_ctx *c, const uint8_t *imgs, int32_t nframes, in
                             int64_t frame_stride, fid_encoding enc, fid_marker *out, int32_t cap_per_frame, int32_t *n_per_frame)
 {
     if (!out || !n_per_frame || cap_per_frame < 0) return FID_E_INVALID_ARG;
+    if (c) c->blocking = true;
     const fid_status rc = feed_and_enqueue(c, imgs, nframes, width, height, stride, frame_stride, enc);
+    if (c) c->blocking = c->res_precleared = false;
     if (rc != FID_OK) return rc;
     return finish_detect(c, out, cap_per_frame, n_per_frame);
 }

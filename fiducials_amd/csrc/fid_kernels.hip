@@ -3195,38 +3195,58 @@ __global__ __launch_bounds__(64) void k_approx(uint4 *__restrict__ contours, con
 // ------------------------------------------------------------------------------------------------
 // K5a: restore OpenCV's candidate order (scale ascending; inside a scale cv::findContours returns the
 // RETR_LIST contours newest-first = discovery position descending) by rank sort, and apply
-// _reorderCandidatesCorners (aruco.cpp).  One workgroup per frame.
-__global__ __launch_bounds__(1024) void k_sort_cands(const DevCand *__restrict__ cands, DevCand *__restrict__ sorted,
-                                                     float4 *__restrict__ cmeta, DevCounts *__restrict__ counts, const DevParams P)
+// _reorderCandidatesCorners (aruco.cpp).
+// gridDim.y > 1: workgroup = 64 candidates x 4 quarters of the key list (partial ranks meet in LDS), gridDim.y workgroups share a
+// frame's candidates -- a call of a few frames spreads the n * n comparisons over several CUs (one workgroup: 15 us for a single frame's 600).
+__global__ __launch_bounds__(256) void k_sort_cands(const DevCand *__restrict__ cands, DevCand *__restrict__ sorted,
+                                                    float4 *__restrict__ cmeta, DevCounts *__restrict__ counts, const DevParams P)
 {
     extern __shared__ unsigned long long keys[];
+    __shared__ int s_rank[256];
     const int f = blockIdx.x;
     int n = counts[f].ncand;
     n = n < P.maxCands ? n : P.maxCands;
+    if ((int)blockIdx.y * (gridDim.y > 1 ? 64 : 256) >= n) return;
     const DevCand *src = cands + (long long)f * P.maxCands;
     DevCand *dstc = sorted + (long long)f * P.maxCands;
     for (int i = threadIdx.x; i < n; i += blockDim.x)
         keys[i] = ((unsigned long long)(unsigned)src[i].scale << 32) | (0xffffffffu - src[i].key);
     __syncthreads();
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        unsigned long long k = keys[i];
-        int rank = 0;
-        for (int j = 0; j < n; j++) rank += keys[j] < k;
-        DevCand c = src[i];
-        double dx1 = c.c[2] - c.c[0], dy1 = c.c[3] - c.c[1];
-        double dx2 = c.c[4] - c.c[0], dy2 = c.c[5] - c.c[1];
-        double cross = (dx1 * dy2) - (dy1 * dx2);
-        if (cross < 0.0) {
-            float tx = c.c[2], ty = c.c[3];
-            c.c[2] = c.c[6];
-            c.c[3] = c.c[7];
-            c.c[6] = tx;
-            c.c[7] = ty;
+    // (a frame with a workgroup to itself -- a batch -- keeps every thread on a candidate of its own: no partial ranks to add up)
+    const int parts = gridDim.y > 1 ? 4 : 1, ipb = 256 / parts;
+    const int il = threadIdx.x & (ipb - 1), part = threadIdx.x / ipb;
+    const int j0 = (int)((long long)n * part / parts), j1 = (int)((long long)n * (part + 1) / parts);
+    for (int i0 = (int)blockIdx.y * ipb; i0 < n; i0 += (int)gridDim.y * ipb) {
+        const int i = i0 + il;
+        if (part == 0) s_rank[il] = 0;
+        __syncthreads();
+        DevCand c;
+        if (i < n) {
+            if (part == 0) c = src[i];  // (in flight under the comparisons)
+            const unsigned long long k = keys[i];
+            int r = 0;
+            for (int j = j0; j < j1; j++) r += keys[j] < k;
+            atomicAdd(&s_rank[il], r);
         }
-        dstc[rank] = c;
-        // corner sums (exact: integer coordinates) and contour size for k_near's centroid test
-        cmeta[(long long)f * P.maxCands + rank] =
-            make_float4(c.c[0] + c.c[2] + c.c[4] + c.c[6], c.c[1] + c.c[3] + c.c[5] + c.c[7], (float)c.size, 0.f);
+        __syncthreads();
+        if (i < n && part == 0) {
+            const int rank = s_rank[il];
+            double dx1 = c.c[2] - c.c[0], dy1 = c.c[3] - c.c[1];
+            double dx2 = c.c[4] - c.c[0], dy2 = c.c[5] - c.c[1];
+            double cross = (dx1 * dy2) - (dy1 * dx2);
+            if (cross < 0.0) {
+                float tx = c.c[2], ty = c.c[3];
+                c.c[2] = c.c[6];
+                c.c[3] = c.c[7];
+                c.c[6] = tx;
+                c.c[7] = ty;
+            }
+            dstc[rank] = c;
+            // corner sums (exact: integer coordinates) and contour size for k_near's centroid test
+            cmeta[(long long)f * P.maxCands + rank] =
+                make_float4(c.c[0] + c.c[2] + c.c[4] + c.c[6], c.c[1] + c.c[3] + c.c[5] + c.c[7], (float)c.size, 0.f);
+        }
+        __syncthreads();
     }
 }
 
@@ -3240,8 +3260,12 @@ __device__ __forceinline__ int near_row_off(int i, int nw)
 // K5b: _filterTooCloseCandidates pair test (aruco.cpp): bit j of near[f][i][j>>5] for j > i.
 // For any cyclic shift the mean squared corner distance is at least the squared distance of the corner means
 // (Jensen), so a pair whose centroids are far enough apart cannot be near: that test runs on a compact
-// {corner sums, size} record and skips the 52-byte candidate loads for almost every pair.  The margin covers the
+// {corner sums, size} record and skips the candidate loads for almost every pair.  The margin covers the
 // float rounding of the reference's ax * ax + ay * ay.
+// A wave takes (row i, 64 columns): lane = column j, so the 64 records of a block arrive in ONE coalesced load (a thread that
+// walked the 32 columns of a word waited for 32 loads one after the other: 27 us for a single frame's 600 candidates), the few
+// lanes whose centroid test fails to rule the pair out fetch their candidate and run the four shifts side by side, and a
+// ballot makes the two words.  Every word of the row's part of the triangle is written (zeros included).
 __global__ __launch_bounds__(256) void k_near(const DevCand *__restrict__ sorted, const float4 *__restrict__ cmeta,
                                                uint32_t *__restrict__ nearb, const DevCounts *__restrict__ counts,
                                                const DevParams P)
@@ -3250,53 +3274,53 @@ __global__ __launch_bounds__(256) void k_near(const DevCand *__restrict__ sorted
     int n = counts[f].ncand;
     n = n < P.maxCands ? n : P.maxCands;
     const int NW = P.maxCands >> 5;
-    const int nw = (n + 31) >> 5;
+    const int nw = (n + 31) >> 5, nw2 = (n + 63) >> 6;
     const DevCand *cs = sorted + (long long)f * P.maxCands;
     const float4 *cm = cmeta + (long long)f * P.maxCands;
     uint32_t *nb = nearb + (long long)f * P.maxCands * NW;
-    for (int item = blockIdx.x * blockDim.x + threadIdx.x; item < n * nw; item += gridDim.x * blockDim.x) {
-        int i = item / nw, w = item % nw;
-        uint32_t bits = 0;
-        if (w * 32 + 31 > i) {
-            const float4 ma = cm[i];
-            DevCand a;
-            bool have_a = false;
-            for (int b = 0; b < 32; b++) {
-                int j = w * 32 + b;
-                if (j <= i || j >= n) continue;
-                const float4 mo = cm[j];
-                {
-                    const double sz = ma.z < mo.z ? ma.z : mo.z;
-                    double lim = sz * P.minMarkerDistRate;
-                    lim = 16. * (lim * lim * (1. + 1e-5) + 1.);
-                    const double dx = (double)ma.x - (double)mo.x, dy = (double)ma.y - (double)mo.y;
-                    if (dx * dx + dy * dy >= lim) continue;  // centroids too far apart for any shift
+    const int lane = lane_id();
+    const int wave = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)), nwaves = (int)(gridDim.x * (blockDim.x >> 6));
+    for (int item = wave; item < n * nw2; item += nwaves) {
+        const int i = item / nw2, w2 = item - i * nw2;
+        if (w2 * 64 + 63 < i) continue;  // (the block that holds i itself is kept: its words belong to the row)
+        const int j = w2 * 64 + lane;
+        const bool valid = j > i && j < n;
+        const float4 ma = cm[i];
+        bool close = false;
+        if (valid) {
+            const float4 mo = cm[j];
+            const double sz = ma.z < mo.z ? ma.z : mo.z;
+            double lim = sz * P.minMarkerDistRate;
+            lim = 16. * (lim * lim * (1. + 1e-5) + 1.);
+            const double dx = (double)ma.x - (double)mo.x, dy = (double)ma.y - (double)mo.y;
+            close = dx * dx + dy * dy < lim;  // (otherwise: centroids too far apart for any shift)
+        }
+        bool near = false;
+        if (close) {
+            const DevCand a = cs[i];
+            const DevCand o = cs[j];
+            const int minimumPerimeter = a.size < o.size ? a.size : o.size;
+            double mmd = (double)minimumPerimeter * P.minMarkerDistRate;
+            mmd = mmd * mmd;
+#pragma unroll
+            for (int fc = 0; fc < 4; fc++) {
+                double distSq = 0;
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const int modC = (c + fc) & 3;
+                    const float ax = a.c[2 * modC] - o.c[2 * c];
+                    const float ay = a.c[2 * modC + 1] - o.c[2 * c + 1];
+                    distSq += ax * ax + ay * ay;
                 }
-                if (!have_a) {
-                    a = cs[i];
-                    have_a = true;
-                }
-                const DevCand &o = cs[j];
-                int minimumPerimeter = a.size < o.size ? a.size : o.size;
-                double mmd = (double)minimumPerimeter * P.minMarkerDistRate;
-                mmd = mmd * mmd;
-                for (int fc = 0; fc < 4; fc++) {
-                    double distSq = 0;
-                    for (int c = 0; c < 4; c++) {
-                        int modC = (c + fc) & 3;
-                        float ax = a.c[2 * modC] - o.c[2 * c];
-                        float ay = a.c[2 * modC + 1] - o.c[2 * c + 1];
-                        distSq += ax * ax + ay * ay;
-                    }
-                    distSq /= 4.;
-                    if (distSq < mmd) {
-                        bits |= 1u << b;
-                        break;
-                    }
-                }
+                distSq /= 4.;
+                near = near || distSq < mmd;
             }
         }
-        if (w >= (i >> 5)) nb[near_row_off(i, nw) + w - (i >> 5)] = bits;
+        const unsigned long long bits = ballot64(near);
+        if (lane < 2) {
+            const int w = 2 * w2 + lane;
+            if (w >= (i >> 5) && w < nw) nb[near_row_off(i, nw) + w - (i >> 5)] = (uint32_t)(bits >> (32 * lane));
+        }
     }
 }
 
@@ -3328,6 +3352,7 @@ __global__ __launch_bounds__(1024) void k_resolve(const DevCand *__restrict__ so
     __shared__ uint32_t s_rem[128];    // per 32 candidates: who has been removed
     __shared__ uint32_t s_alive[128];  // ... who is left / where the first of them goes
     __shared__ int s_off[128];
+    __shared__ int s_mem[16][64];    // per wave: the members of the component it is resolving
     const int f = blockIdx.x, lane = lane_id(), tid = threadIdx.x, nt = blockDim.x;
     int n = counts[f].ncand;
     n = n < P.maxCands ? n : P.maxCands;
@@ -3373,11 +3398,13 @@ __global__ __launch_bounds__(1024) void k_resolve(const DevCand *__restrict__ so
             d_iters++;
 #endif
             int changed = 0;
-            for (int i = tid; i < n; i += nt) {
+            // (four threads share a row, each takes every fourth word: a thread walking all the words of its row waited for
+            //  some twenty LDS reads one after the other, 13 000 cycles a round)
+            for (int i = tid >> 2; i < n; i += nt >> 2) {
                 const int l0 = label[i];
                 int li = l0;
                 const uint32_t *row = s_near + near_row_off(i, nw) - (i >> 5);
-                for (int w = i >> 5; w < nw; w++) {
+                for (int w = (i >> 5) + (tid & 3); w < nw; w += 4) {
                     uint32_t bits = row[w];
                     while (bits) {
                         const int j = w * 32 + __ffs(bits) - 1;
@@ -3415,7 +3442,59 @@ __global__ __launch_bounds__(1024) void k_resolve(const DevCand *__restrict__ so
                 const int r = c0 + __ffsll((long long)rb) - 1;
                 rb &= rb - 1;
                 if ((rootrank++ % nwaves) != wv) continue;
-                int left = csize[r];
+                const int cs = csize[r];
+                if (cs <= 64) {
+                    // A component of at most 64 candidates (a marker seen at 13 scales, inside and outside border: 26) is resolved in
+                    // REGISTERS: lane m holds member m's row as a 64-bit mask over the component's members (in index order) and its
+                    // size, and the rows are taken in order with v_readlane and scalar bit operations -- no LDS round trip per
+                    // row (the LDS-row loop below: ~1 us per row, 24 us of a single frame's 38 us)
+                    int *mem = s_mem[wv];
+                    int cnt = 0;
+                    for (int m0 = r & ~63; cnt < cs; m0 += 64) {
+                        const int mi = m0 + lane;
+                        const bool is = mi < n && mi >= r && label[mi] == r;
+                        const unsigned long long mb = ballot64(is);
+                        if (is) {
+                            const int li = cnt + __popcll(mb & ((1ull << lane) - 1ull));
+                            mem[li] = mi;
+                        }
+                        cnt += __popcll(mb);
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // (the wave's own LDS writes, read by its other lanes)
+                    const int g = lane < cs ? mem[lane] : 0;
+                    const int sz = lane < cs ? sizes[g] : 0;
+                    // (every near j of a member is a member: its row, cut down to the members.  One independent LDS read per
+                    //  member and lane -- scanning the row's words and looking every set bit up was a chain of ~60 dependent reads)
+                    unsigned long long mask = 0ull;
+                    {
+                        const uint32_t *row = s_near + near_row_off(g, nw) - (g >> 5);
+#pragma unroll 8
+                        for (int k = 1; k < cs; k++) {  // wave-uniform
+                            const int gk = __builtin_amdgcn_readlane(g, k);
+                            if (lane < k) mask |= (unsigned long long)((row[gk >> 5] >> (gk & 31)) & 1u) << k;
+                        }
+                    }
+                    const int mlo = (int)(unsigned)mask, mhi = (int)(unsigned)(mask >> 32);
+                    unsigned long long alive = cs == 64 ? ~0ull : (1ull << cs) - 1ull;
+                    for (int i = 0; i < cs; i++) {  // wave-uniform
+                        if (!((alive >> i) & 1ull)) continue;
+                        const unsigned long long rowm =
+                            (((unsigned long long)(unsigned)__builtin_amdgcn_readlane(mhi, i) << 32) | (unsigned)__builtin_amdgcn_readlane(mlo, i)) & alive;
+                        if (!rowm) continue;
+                        const int szi = __builtin_amdgcn_readlane(sz, i);
+                        const unsigned long long ge = ballot64(sz >= szi) & rowm;
+                        if (ge) {  // the first live near j with size_j >= size_i removes i; the live near j in front of it are removed
+                            const int kj = __ffsll((long long)ge) - 1;
+                            alive &= ~(rowm & ((1ull << kj) - 1ull));
+                            alive &= ~(1ull << i);
+                        } else {
+                            alive &= ~rowm;
+                        }
+                    }
+                    if (lane < cs && !((alive >> lane) & 1ull)) atomicOr(&s_rem[g >> 5], 1u << (g & 31));
+                    continue;
+                }
+                int left = cs;
                 for (int m0 = r & ~63; left > 0; m0 += 64) {
                     const int mi = m0 + lane;
                     unsigned long long mb = ballot64(mi < n && mi >= r && label[mi] == r);

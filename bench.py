@@ -465,11 +465,13 @@ def jpeg_to_markers(local_rank, files, Q=1):
                         "decoding one piece ahead of the detector"}
 
 
-def jpeg_stream_to_markers(local_rank, files, n_batches=6):
-    """A STREAM of JPEG batches (the node with `transport:=compressed`, frames keep coming): a decoder thread works one batch ahead
-    (three decoder contexts in turn: a decoded batch stays in its context until its markers are out), the detector side keeps two
-    batches in flight on two contexts (fid_submit_device / fid_collect / fid_order_after).  The entropy decoder's passes are
-    latency-bound and so is the detector's end: side by side they fill each other's gaps."""
+def jpeg_stream_to_markers(local_rank, files, n_batches=12, decoder_threads=3):
+    """A STREAM of JPEG batches (the node with `transport:=compressed`, frames keep coming): `decoder_threads` host threads decode
+    batches ahead of the detector, each call on a decoder context of its own (decoder_threads + 2 contexts in turn: a decoded batch
+    stays in its context until its markers are out), the detector side keeps two batches in flight on two contexts
+    (fid_submit_device / fid_collect / fid_order_after).  The entropy decoder's passes are latency-bound -- a batch decodes in 8 ms
+    alone and in 13 ms beside the detector, whichever way it is scheduled -- so several of them side by side are what fills the
+    chip: one decoder thread 18.0 k frames/s, two 19.3 k, three 20.0 k (tools/gpu_jpeg_stream_diag.py, round 4)."""
     import threading
 
     from fiducials_amd import jpeg as fj
@@ -477,7 +479,8 @@ def jpeg_stream_to_markers(local_rank, files, n_batches=6):
     from fiducials_amd.synth import K_DEFAULT
 
     B = len(files)
-    J = 3
+    NT = max(1, int(decoder_threads))
+    J = NT + 2
     decs = [fj.JpegDecoder(max_width=W, max_height=H, max_batch=B, device=local_rank) for _ in range(J)]
     dets = [ArucoDetector("DICT_5X5_250", device=local_rank, max_width=W, max_height=H, max_batch=B, max_markers=64, max_candidates=2048)
             for _ in range(2)]
@@ -488,9 +491,9 @@ def jpeg_stream_to_markers(local_rank, files, n_batches=6):
         freed = [threading.Event() for _ in range(n)]
         err = []
 
-        def decode_side():
+        def decode_side(t):
             try:
-                for k in range(n):
+                for k in range(t, n, NT):
                     if k >= J:
                         freed[k - J].wait()
                     decs[k % J].decode(files, "mono8", to_host=False)
@@ -500,8 +503,9 @@ def jpeg_stream_to_markers(local_rank, files, n_batches=6):
                 for ev in ready:
                     ev.set()
 
-        th = threading.Thread(target=decode_side)
-        th.start()
+        ths = [threading.Thread(target=decode_side, args=(t,)) for t in range(NT)]
+        for th in ths:
+            th.start()
         found = 0
 
         def collect(k):
@@ -521,12 +525,16 @@ def jpeg_stream_to_markers(local_rank, files, n_batches=6):
         if not err:
             for k in range(max(n - 2, 0), n):
                 collect(k)
-        th.join()
+        else:
+            for ev in freed:
+                ev.set()
+        for th in ths:
+            th.join()
         if err:
             raise err[0]
         return found
 
-    run(3)
+    run(NT + 2)
     t = time.perf_counter()
     found = run(n_batches)
     dt = time.perf_counter() - t
@@ -535,9 +543,9 @@ def jpeg_stream_to_markers(local_rank, files, n_batches=6):
     for d in dets:
         d.close()
     return {"value": round(B * n_batches / dt, 1), "unit": "frames/s", "ms_per_step": round(dt / n_batches * 1e3, 3),
-            "markers_per_frame_found": round(found / (B * n_batches), 2),
+            "markers_per_frame_found": round(found / (B * n_batches), 2), "decoder_threads": NT,
             "workload": f"a stream of {n_batches} batches of {B} JPEG frames in host memory -> fid_jpeg_decode (device gray) -> fid_submit_device / "
-                        "fid_collect + fid_pose_last: the decoder one batch ahead, two detector contexts in turn"}
+                        f"fid_collect + fid_pose_last: {NT} decoder threads ahead on {J} decoder contexts, two detector contexts in turn"}
 
 
 def jpeg_side_result(local_rank, frames):

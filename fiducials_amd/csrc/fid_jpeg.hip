@@ -654,11 +654,16 @@ __device__ __forceinline__ void jp_idct_1d(const int in[8], int out[8], int shif
     out[4] = (tmp13 - tmp0 + rnd) >> shift;
 }
 
-// eight lanes per 8 x 8 block: a lane takes one column (pass 1), the block is transposed through LDS, the lane takes one row
-// (pass 2) and stores its eight samples as one 8-byte word
-__global__ __launch_bounds__(256) void k_jpeg_idct(const JpImage *__restrict__ imgs, const int16_t *__restrict__ coefs, uint8_t *__restrict__ planes)
+// eight lanes per 8 x 8 block: a lane fetches one ROW of coefficients (one 16-byte load; eight 2-byte loads down a column kept the
+// kernel at 2.2 TB/s), the block is turned through LDS, the lane takes one column (pass 1), the block is transposed through LDS
+// again, the lane takes one row (pass 2) and stores its eight samples as one 8-byte word.
+// clear != 0: a row that held anything is zeroed behind the read -- the coefficient array is then all zeros again when the call
+// ends, and the next call's entropy decoder (which only stores non-zero coefficients) needs no 1.6 GB fill in front of it
+// (256 frames 1920 x 1080 4:2:0; most rows of most blocks are zeros at camera qualities and cost no store).
+__global__ __launch_bounds__(256) void k_jpeg_idct(const JpImage *__restrict__ imgs, int16_t *__restrict__ coefs, uint8_t *__restrict__ planes, int clear)
 {
     __shared__ int s_ws[32][64 + 8];
+    __shared__ uint4 s_in[32][9];  // (144 bytes per block: the column reads of the eight blocks of a wave fall into different banks)
     const JpImage &I = imgs[blockIdx.y];
     const uint32_t nb0 = (uint32_t)I.bw[0] * I.bh[0], nb1 = I.ncomp > 1 ? (uint32_t)I.bw[1] * I.bh[1] : 0u;
     const uint32_t total = nb0 + 2u * nb1;
@@ -672,11 +677,18 @@ __global__ __launch_bounds__(256) void k_jpeg_idct(const JpImage *__restrict__ i
         bi = b - nb0 - (comp == 2 ? nb1 : 0u);
     }
     if (live) {
-        const int16_t *cf = coefs + I.coef_base + I.coef_off[comp] + (size_t)bi * 64;
+        uint4 *cf = reinterpret_cast<uint4 *>(coefs + I.coef_base + I.coef_off[comp] + (size_t)bi * 64) + col;  // row `col` of the block
+        const uint4 v = *cf;
+        if (clear && (v.x | v.y | v.z | v.w)) *cf = make_uint4(0u, 0u, 0u, 0u);
+        s_in[jb][col] = v;
+    }
+    __syncthreads();
+    if (live) {
+        const int16_t *si = reinterpret_cast<const int16_t *>(s_in[jb]);
         const uint16_t *q = I.q[comp];
         int in[8], out[8];
 #pragma unroll
-        for (int r = 0; r < 8; r++) in[r] = (int)cf[r * 8 + col] * (int)q[r * 8 + col];
+        for (int r = 0; r < 8; r++) in[r] = (int)si[r * 8 + col] * (int)q[r * 8 + col];
         jp_idct_1d(in, out, JP_CONST_BITS - JP_PASS1_BITS);
 #pragma unroll
         for (int r = 0; r < 8; r++) s_ws[jb][r * 8 + col] = out[r];
@@ -726,6 +738,96 @@ __device__ __forceinline__ int jp_chroma(const uint8_t *pl, int pitch, int cw, i
     }
     if (i == 0) return (cur * 4 + 8) >> 4;
     return (cur * 3 + (in0[i - 1] * 3 + in1[i - 1]) + 8) >> 4;
+}
+
+// The 4:2:0 / 4:2:2 three-component picture whose planes are word-aligned (every picture this decoder lays out) and whose width is
+// a multiple of 8: a lane takes EIGHT pixels of a row (x0 = 8 k).  Their chroma columns i0 .. i0 + 3 (i0 = 4 k) are one aligned
+// word per row and plane; the two columns beside them come from the neighbour lanes' words (DPP-free: __shfl) when those lanes
+// hold the same row, otherwise as single bytes.  Per eight pixels: one 8-byte luma load, four chroma word loads, one 8-byte gray
+// store -- the four-pixel kernel below issues seventeen loads per four pixels and was bound by them (1.7 ms for 256 frames).
+__global__ __launch_bounds__(256) void k_jpeg_color8(const JpImage *__restrict__ imgs, const uint8_t *__restrict__ planes, uint8_t *__restrict__ out,
+                                                     long long out_fstride, int gray_out)
+{
+    const JpImage &I = imgs[blockIdx.y];
+    const int W = I.w, H = I.h, W8 = W >> 3;
+    const uint8_t *P = planes + I.plane_base;
+    uint8_t *dst = out + (long long)blockIdx.y * out_fstride;
+    const int cw = (W + 1) >> 1, ch = (H + I.vs - 1) / I.vs;
+    const int p0 = I.bw[0] * 8, p1 = I.bw[1] * 8;
+    const unsigned total8 = (unsigned)W8 * (unsigned)H, step8 = gridDim.x * blockDim.x;
+    const int lane = (int)(threadIdx.x & 63u);
+    for (unsigned base = blockIdx.x * blockDim.x; base < total8; base += step8) {  // (workgroup-uniform trip count: the shuffles below want every lane)
+        const unsigned idx = base + threadIdx.x;
+        const bool live = idx < total8;
+        const unsigned idc = live ? idx : total8 - 1u;
+        const int y = (int)(idc / (unsigned)W8), k8 = (int)(idc - (unsigned)y * (unsigned)W8);
+        const int x0 = k8 * 8, i0 = k8 * 4;
+        const uint2 yw = *reinterpret_cast<const uint2 *>(P + I.plane_off[0] + (size_t)y * p0 + x0);
+        const int cy = I.vs == 2 ? y >> 1 : y;
+        int yf = cy;
+        if (I.vs == 2) {
+            yf = (y & 1) ? cy + 1 : cy - 1;
+            yf = yf < 0 ? 0 : (yf > ch - 1 ? ch - 1 : yf);
+        }
+        // the lane to the left / right holds the eight pixels before / behind mine when it is in the wave and on my row
+        const bool left_in = lane > 0 && k8 > 0, right_in = lane < 63 && k8 + 1 < W8 && idx + 1u < total8;
+        int cbv[8], crv[8];
+#pragma unroll
+        for (int pl = 0; pl < 2; pl++) {
+            const uint8_t *bp = P + I.plane_off[1 + pl];
+            const uint8_t *in0 = bp + (size_t)cy * p1, *in1 = bp + (size_t)yf * p1;
+            const uint32_t w0 = *reinterpret_cast<const uint32_t *>(in0 + i0);
+            const uint32_t w1 = I.vs == 2 ? *reinterpret_cast<const uint32_t *>(in1 + i0) : 0u;
+            int col[6];  // columns i0 - 1 .. i0 + 4: 3 * near row + far row (h2v2) or the row itself (h2v1)
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int a = (int)((w0 >> (8 * k)) & 0xffu), b = (int)((w1 >> (8 * k)) & 0xffu);
+                col[1 + k] = I.vs == 2 ? a * 3 + b : a;
+            }
+            const int from_l = __shfl_up(col[4], 1, 64), from_r = __shfl_down(col[1], 1, 64);
+            {
+                const int il = i0 > 0 ? i0 - 1 : 0, ir = i0 + 4 < cw ? i0 + 4 : cw - 1;
+                col[0] = left_in ? from_l : (I.vs == 2 ? in0[il] * 3 + in1[il] : in0[il]);
+                col[5] = right_in ? from_r : (I.vs == 2 ? in0[ir] * 3 + in1[ir] : in0[ir]);
+            }
+            int *o = pl ? crv : cbv;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int i = i0 + (k >> 1);  // this pixel's chroma column; col[1 + (k >> 1)] is its sample
+                const int cur = col[1 + (k >> 1)];
+                int v;
+                if (I.vs == 2) {
+                    if (k & 1) v = i >= cw - 1 ? (cur * 4 + 7) >> 4 : (cur * 3 + col[2 + (k >> 1)] + 7) >> 4;
+                    else v = i == 0 ? (cur * 4 + 8) >> 4 : (cur * 3 + col[k >> 1] + 8) >> 4;
+                } else {
+                    if (k & 1) v = i >= cw - 1 ? cur : (cur * 3 + col[2 + (k >> 1)] + 2) >> 2;
+                    else v = i == 0 ? cur : (cur * 3 + col[k >> 1] + 1) >> 2;
+                }
+                o[k] = v;
+            }
+        }
+        uint32_t gw[2] = {0u, 0u};
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int Y = (int)(((k < 4 ? yw.x : yw.y) >> (8 * (k & 3))) & 0xffu);
+            const int cb = cbv[k] - 128, cr = crv[k] - 128;
+            int r = Y + ((91881 * cr + 32768) >> 16);
+            int g = Y + ((-22554 * cb + 32768 - 46802 * cr) >> 16);
+            int b = Y + ((116130 * cb + 32768) >> 16);
+            r = r < 0 ? 0 : (r > 255 ? 255 : r);
+            g = g < 0 ? 0 : (g > 255 ? 255 : g);
+            b = b < 0 ? 0 : (b > 255 ? 255 : b);
+            if (gray_out) {
+                gw[k >> 2] |= (uint32_t)((b * 3735 + g * 19235 + r * 9798 + (1 << 14)) >> 15) << (8 * (k & 3));  // K0: cvtColor(BGR2GRAY)
+            } else if (live) {
+                uint8_t *o = dst + ((long long)y * W + x0 + k) * 3;
+                o[0] = (uint8_t)b;
+                o[1] = (uint8_t)g;
+                o[2] = (uint8_t)r;
+            }
+        }
+        if (gray_out && live) *reinterpret_cast<uint2 *>(dst + (long long)y * W + x0) = make_uint2(gw[0], gw[1]);
+    }
 }
 
 // a lane takes four pixels of a row (x = 4 k .. 4 k + 3): one division per four pixels, the chroma samples they share are
@@ -1004,6 +1106,8 @@ struct fid_jpeg_ctx {
     // device
     uint8_t *d_scan = nullptr, *d_planes = nullptr, *d_out = nullptr;
     int16_t *d_coefs = nullptr;
+    bool keep_coefs = false;   // FID_JPEG_KEEP_COEFS=1 at fid_jpeg_create: the coefficients of a call stay readable (FID_JPEG_TAP_COEFS)
+    bool coefs_clean = false;  // d_coefs is all zeros
     JpImage *d_imgs = nullptr;
     uint16_t *d_luts = nullptr, *d_lut1 = nullptr;  // 16-bit code tables; their first-level (JP_LOOK bit) extracts, contiguous
     JpState *d_state[2] = {nullptr, nullptr};
@@ -1120,7 +1224,14 @@ fid_status fid_jpeg_create(int32_t device, int32_t max_width, int32_t max_height
     c->max_blocks = mw * mh / 64 * 3;               // 4:4:4 is the largest
     c->max_scan = mw * mh * 2 + 65536;              // entropy-coded bytes per image this context takes (MCU-padded size: narrow images too)
     c->max_sub = (c->max_scan + JP_SUB - 1) / JP_SUB;
-    bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
+    // the decoder's kernels are few waves that wait for memory: beside a detector that fills the chip (a stream of compressed batches)
+    // they go first (FID_JPEG_PRIO=0: a stream of the default priority)
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    const char *pe = getenv("FID_JPEG_PRIO");
+    const int prio = pe && atoi(pe) == 0 ? 0 : prio_hi;
+    c->keep_coefs = getenv("FID_JPEG_KEEP_COEFS") != nullptr;
+    bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio) == hipSuccess;
     ok = ok && hipMalloc((void **)&c->d_scan, F * c->max_scan + 64) == hipSuccess && hipMalloc((void **)&c->d_coefs, F * c->max_blocks * 64 * sizeof(int16_t)) == hipSuccess &&
          hipMalloc((void **)&c->d_planes, F * c->max_blocks * 64) == hipSuccess && hipMalloc((void **)&c->d_out, F * (size_t)max_width * max_height * 3) == hipSuccess &&
          hipMalloc((void **)&c->d_imgs, F * sizeof(JpImage)) == hipSuccess &&
@@ -1164,6 +1275,12 @@ fid_status fid_jpeg_decode(fid_jpeg_ctx *c, const uint8_t *const *files, const i
     JPCHK(c, hipSetDevice(c->device));
     hipStream_t st = c->stream;
     c->last_n = 0;
+    static const bool jp_timing = getenv("FID_JPEG_TIMING") != nullptr;  // host-side phases of a call to stderr
+    const auto jp_t0 = std::chrono::steady_clock::now();
+    double jp_ms[5] = {0, 0, 0, 0, 0};
+    auto jp_mark = [&](int k) {
+        if (jp_timing) jp_ms[k] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - jp_t0).count();
+    };
     if (c->lut_next + 4 * n > c->lut_cap) {  // a stream of files with ever new tables: start the cache again (between calls only)
         c->lut_slot.clear();
         c->lut_next = 0;
@@ -1239,6 +1356,7 @@ fid_status fid_jpeg_decode(fid_jpeg_ctx *c, const uint8_t *const *files, const i
         max_nsub = I.nsub > max_nsub ? I.nsub : max_nsub;
         max_blocks = co / 64 > max_blocks ? co / 64 : max_blocks;
     }
+    jp_mark(0);
     // the entropy-coded bytes into pinned memory (a few host threads for a large batch: one thread moves ~10 GB/s), then one copy
     {
         const int nt = n >= 32 ? 8 : (n >= 8 ? 4 : 1);
@@ -1254,9 +1372,14 @@ fid_status fid_jpeg_decode(fid_jpeg_ctx *c, const uint8_t *const *files, const i
             for (auto &x : th) x.join();
         }
     }
+    jp_mark(1);
     JPCHK(c, hipMemcpyAsync(c->d_scan, c->h_scan, scan_at, hipMemcpyHostToDevice, st));
     JPCHK(c, hipMemcpyAsync(c->d_imgs, c->h_imgs, (size_t)n * sizeof(JpImage), hipMemcpyHostToDevice, st));
-    JPCHK(c, hipMemsetAsync(c->d_coefs, 0, (size_t)n * c->max_blocks * 64 * sizeof(int16_t), st));
+    // the coefficient array: all zeros when a call begins -- k_jpeg_idct leaves it so (it zeroes what it has read); filled here only
+    // when the tap wants the coefficients kept (FID_JPEG_KEEP_COEFS) or a call ended between the entropy decoder and the IDCT
+    if (c->keep_coefs) JPCHK(c, hipMemsetAsync(c->d_coefs, 0, (size_t)n * c->max_blocks * 64 * sizeof(int16_t), st));
+    else if (!c->coefs_clean) JPCHK(c, hipMemsetAsync(c->d_coefs, 0, (size_t)c->maxB * c->max_blocks * 64 * sizeof(int16_t), st));
+    c->coefs_clean = false;
     // ---- J1: entropy decoding
     const dim3 hgrid((max_nsub + JP_OWN - 1) / JP_OWN, n);
     hipLaunchKernelGGL(k_jpeg_huff<0>, hgrid, dim3(JP_TPB), 0, st, c->d_imgs, c->d_scan, c->d_luts, c->d_lut1, (const JpState *)nullptr, c->d_state[0], (const uint8_t *)nullptr,
@@ -1283,18 +1406,32 @@ fid_status fid_jpeg_decode(fid_jpeg_ctx *c, const uint8_t *const *files, const i
         }
     }
     c->last_rounds = rounds;
+    jp_mark(2);
     hipLaunchKernelGGL(k_jpeg_scan_blocks, dim3(n), dim3(1024), 0, st, c->d_imgs, c->d_nblk, c->d_blkbase);
     hipLaunchKernelGGL(k_jpeg_huff<2>, hgrid, dim3(JP_TPB), 0, st, c->d_imgs, c->d_scan, c->d_luts, c->d_lut1, c->d_state[cur], (JpState *)nullptr, (const uint8_t *)nullptr,
                        (uint8_t *)nullptr, (int4 *)nullptr, c->d_blkbase, c->d_coefs, c->d_flag);
     // ---- J2 .. J4
-    hipLaunchKernelGGL(k_jpeg_idct, dim3((max_blocks + 31) / 32, n), dim3(256), 0, st, c->d_imgs, c->d_coefs, c->d_planes);
+    hipLaunchKernelGGL(k_jpeg_idct, dim3((max_blocks + 31) / 32, n), dim3(256), 0, st, c->d_imgs, c->d_coefs, c->d_planes, c->keep_coefs ? 0 : 1);
+    JPCHK(c, hipGetLastError());
+    c->coefs_clean = !c->keep_coefs;
     const int bpp = out_enc == FID_ENC_MONO8 ? 1 : 3;
     const long long fstride = (long long)W * Hh * bpp;
     {
         long long px = (long long)((W + 3) / 4) * Hh;  // four pixels per lane
         int blocks = (int)((px + 255) / 256);
         blocks = blocks > 4096 ? 4096 : blocks;
-        hipLaunchKernelGGL(k_jpeg_color, dim3(blocks, n), dim3(256), 0, st, c->d_imgs, c->d_planes, c->d_out, fstride, out_enc == FID_ENC_MONO8 ? 1 : 0);
+        // (every picture of a call has one size; the eight-pixel kernel wants three components, 2:1 horizontal subsampling in every
+        //  picture, a width that is a multiple of 8 and more than two chroma columns -- what a camera's JPEG stream is)
+        bool wide = (W & 7) == 0 && W >= 16 && ((uintptr_t)c->d_out & 7) == 0 && (fstride & 7) == 0 && !getenv("FID_JPEG_COLOR4");
+        for (int f = 0; f < n && wide; f++) wide = c->h_imgs[f].ncomp == 3 && c->h_imgs[f].hs == 2;
+        if (wide) {
+            const long long px8 = (long long)(W / 8) * Hh;
+            int b8 = (int)((px8 + 255) / 256);
+            b8 = b8 > 4096 ? 4096 : b8;
+            hipLaunchKernelGGL(k_jpeg_color8, dim3(b8, n), dim3(256), 0, st, c->d_imgs, c->d_planes, c->d_out, fstride, out_enc == FID_ENC_MONO8 ? 1 : 0);
+        } else {
+            hipLaunchKernelGGL(k_jpeg_color, dim3(blocks, n), dim3(256), 0, st, c->d_imgs, c->d_planes, c->d_out, fstride, out_enc == FID_ENC_MONO8 ? 1 : 0);
+        }
     }
     JPCHK(c, hipGetLastError());
     if (host_out) {
@@ -1307,6 +1444,10 @@ fid_status fid_jpeg_decode(fid_jpeg_ctx *c, const uint8_t *const *files, const i
         }
     }
     JPCHK(c, hipStreamSynchronize(st));
+    jp_mark(3);
+    if (jp_timing)
+        fprintf(stderr, "fid_jpeg_decode n=%d: headers %.2f ms, pack %.2f, copy + entropy rounds %.2f, coefficients + idct + colour %.2f\n", n, jp_ms[0],
+                jp_ms[1] - jp_ms[0], jp_ms[2] - jp_ms[1], jp_ms[3] - jp_ms[2]);
     c->last_n = n;
     c->last_w = W;
     c->last_h = Hh;
@@ -1341,6 +1482,10 @@ fid_status fid_jpeg_tap_read(fid_jpeg_ctx *c, fid_jpeg_tap which, int32_t frame,
     if (!c || !dst || need <= 0 || dst_bytes < need) return FID_E_INVALID_ARG;
     JPCHK(c, hipSetDevice(c->device));
     const JpImage &I = c->last_imgs[(size_t)frame];
+    if (which == FID_JPEG_TAP_COEFS && !c->keep_coefs) {
+        c->last_error = "the coefficients are consumed by the IDCT: create the context with FID_JPEG_KEEP_COEFS=1 in the environment to read them";
+        return FID_E_UNSUPPORTED;
+    }
     const void *src = which == FID_JPEG_TAP_COEFS ? (const void *)(c->d_coefs + I.coef_base) : (const void *)(c->d_planes + I.plane_base);
     JPCHK(c, hipMemcpy(dst, src, (size_t)need, hipMemcpyDeviceToHost));
     return FID_OK;

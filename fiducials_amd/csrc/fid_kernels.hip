@@ -3431,13 +3431,28 @@ __global__ __launch_bounds__(1024) void k_resolve(const DevCand *__restrict__ so
         for (int i = tid; i < n; i += nt) atomicAdd(&csize[label[i]], 1);
         __syncthreads();
         RES_MARK()
-        // ---- the components are dealt out to the waves; a wave takes the rows of a component in order, lanes own 32-bit
+        // ---- a component of TWO candidates (the inside and the outside border of a quad seen at one scale) needs no wave: its
+        //      root's thread finds the other one in its row and removes the smaller (ties: the root, the first of the pair)
+        for (int i = tid; i < n; i += nt) {
+            if (label[i] != i || csize[i] != 2) continue;
+            const uint32_t *row = s_near + near_row_off(i, nw) - (i >> 5);
+            int j = -1;
+            for (int w = i >> 5; w < nw && j < 0; w++) {
+                const uint32_t bits = row[w];
+                if (bits) j = w * 32 + __ffs(bits) - 1;
+            }
+            if (j >= 0) {
+                const int dead = sizes[j] >= sizes[i] ? i : j;
+                atomicOr(&s_rem[dead >> 5], 1u << (dead & 31));
+            }
+        }
+        // ---- the larger components are dealt out to the waves; a wave takes the rows of a component in order, lanes own 32-bit
         //      words of the row (other waves set other bits of the same removed-set words: LDS atomics)
         const int nwaves = (int)blockDim.x >> 6, wv = tid >> 6;
         int rootrank = 0;
         for (int c0 = 0; c0 < n; c0 += 64) {
             const int ci = c0 + lane;
-            unsigned long long rb = ballot64(ci < n && label[ci] == ci && csize[ci] > 1);
+            unsigned long long rb = ballot64(ci < n && label[ci] == ci && csize[ci] > 2);
             while (rb) {
                 const int r = c0 + __ffsll((long long)rb) - 1;
                 rb &= rb - 1;
@@ -3450,15 +3465,21 @@ __global__ __launch_bounds__(1024) void k_resolve(const DevCand *__restrict__ so
                     // row (the LDS-row loop below: ~1 us per row, 24 us of a single frame's 38 us)
                     int *mem = s_mem[wv];
                     int cnt = 0;
-                    for (int m0 = r & ~63; cnt < cs; m0 += 64) {
-                        const int mi = m0 + lane;
-                        const bool is = mi < n && mi >= r && label[mi] == r;
-                        const unsigned long long mb = ballot64(is);
-                        if (is) {
-                            const int li = cnt + __popcll(mb & ((1ull << lane) - 1ull));
-                            mem[li] = mi;
+                    for (int m0 = r & ~63; cnt < cs; m0 += 256) {  // (four blocks of labels in flight per step)
+                        int lab[4];
+#pragma unroll
+                        for (int u = 0; u < 4; u++) {
+                            const int mi = m0 + 64 * u + lane;
+                            lab[u] = mi < n ? label[mi] : -1;
                         }
-                        cnt += __popcll(mb);
+#pragma unroll
+                        for (int u = 0; u < 4; u++) {
+                            const int mi = m0 + 64 * u + lane;
+                            const bool is = mi >= r && lab[u] == r;
+                            const unsigned long long mb = ballot64(is);
+                            if (is) mem[cnt + __popcll(mb & ((1ull << lane) - 1ull))] = mi;
+                            cnt += __popcll(mb);
+                        }
                     }
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // (the wave's own LDS writes, read by its other lanes)
                     const int g = lane < cs ? mem[lane] : 0;
@@ -3468,9 +3489,9 @@ __global__ __launch_bounds__(1024) void k_resolve(const DevCand *__restrict__ so
                     unsigned long long mask = 0ull;
                     {
                         const uint32_t *row = s_near + near_row_off(g, nw) - (g >> 5);
-#pragma unroll 8
-                        for (int k = 1; k < cs; k++) {  // wave-uniform
-                            const int gk = __builtin_amdgcn_readlane(g, k);
+#pragma unroll 4
+                        for (int k = 1; k < cs; k++) {  // (member k from the list in LDS, not v_readlane: a convergent operation keeps the loop from being unrolled)
+                            const int gk = mem[k];
                             if (lane < k) mask |= (unsigned long long)((row[gk >> 5] >> (gk & 31)) & 1u) << k;
                         }
                     }

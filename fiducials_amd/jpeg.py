@@ -34,6 +34,7 @@ class JpegDecoder:
         if rc != _lib.FID_OK:
             raise FidError(rc, self._L.fid_strerror(rc).decode())
         self.max_batch = max_batch
+        self.max_width, self.max_height = max_width, max_height
 
     def close(self):
         if self._ctx:

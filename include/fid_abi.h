@@ -380,7 +380,9 @@ typedef struct fid_jpeg_info {
 } fid_jpeg_info;
 typedef enum fid_jpeg_tap {
     FID_JPEG_TAP_COEFS = 0,  /* int16: quantised coefficients, natural order, DC prediction undone; component after component,
-                                [blocks_h][blocks_w][64] each (jdhuff.c decode_mcu) */
+                                [blocks_h][blocks_w][64] each (jdhuff.c decode_mcu).  The IDCT consumes them (it zeroes what it has
+                                read, so that the next call needs no fill): readable only on a context created with
+                                FID_JPEG_KEEP_COEFS=1 in the environment, FID_E_UNSUPPORTED otherwise */
     FID_JPEG_TAP_PLANES = 1  /* uint8: IDCT output, component after component, [blocks_h * 8][blocks_w * 8] (jidctint.c) */
 } fid_jpeg_tap;
 /* header parse on the host (no device needed) */

@@ -20,10 +20,30 @@ def gray_of(bgr):
     return ((b * 3735 + g * 19235 + r * 9798 + (1 << 14)) >> 15).astype(np.uint8)
 
 
+_KEEP = {}
+
+
+def keeping_decoder(w, h):
+    """A decoder whose coefficients stay readable after a call (FID_JPEG_KEEP_COEFS at creation): by default the IDCT zeroes what
+    it has read, so that the next call finds the array clean without a fill -- the decoder under test works that way, and the
+    fixtures going through it one after the other check that the array IS clean every time."""
+    if (w, h) not in _KEEP:
+        os.environ["FID_JPEG_KEEP_COEFS"] = "1"
+        try:
+            _KEEP[(w, h)] = fj.JpegDecoder(max_width=w, max_height=h)
+        finally:
+            del os.environ["FID_JPEG_KEEP_COEFS"]
+    return _KEEP[(w, h)]
+
+
 def check(dec, data):
     bgr_o, coefs_o, planes_o = oj.decode(data, stages=True)
+    keep = keeping_decoder(dec.max_width, dec.max_height)
+    assert np.array_equal(keep.decode(data, "bgr8"), bgr_o), "bgr (coefficients kept)"
+    assert np.array_equal(keep.tap(fj.TAP_COEFS), coefs_o), "coefficients"
     got = dec.decode(data, "bgr8")
-    assert np.array_equal(dec.tap(fj.TAP_COEFS), coefs_o), "coefficients"
+    with pytest.raises(FidError):
+        dec.tap(fj.TAP_COEFS)  # consumed by the IDCT
     assert np.array_equal(dec.tap(fj.TAP_PLANES), planes_o), "planes"
     assert np.array_equal(got, bgr_o), "bgr"
     assert np.array_equal(dec.decode(data, "mono8"), gray_of(bgr_o)), "gray"

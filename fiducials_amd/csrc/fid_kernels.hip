@@ -2732,10 +2732,18 @@ __global__ __launch_bounds__(64) void k_seg_cycles(const uint2 *__restrict__ see
                                                     const DevPend *__restrict__ pend, const uint4 *__restrict__ wres,
                                                     uint4 *__restrict__ contours, uint4 *__restrict__ cinfo, uint32_t *__restrict__ cbase,
                                                     uint4 *__restrict__ recs, DevCounts *__restrict__ counts, DevGlobal *__restrict__ G,
-                                                    const DevParams P, int part)
+                                                    const DevParams P, int part, int warm)
 {
     // part 0: the segments (contour list A: slots [0, maxContours / 2), records [0, maxContours)); part 1: the survivors (list B:
     // slots [maxContours / 2, maxContours), records [maxContours, 2 maxContours)) -- the two parts run on different streams
+    // The lane that holds a cycle's start goes round it hop by hop, every hop a load that depends on the one before; for a single
+    // frame that chain IS the kernel's duration (fifty hops at ~0.65 us, twice: 67 us).  Two things shorten it:
+    //   * the segments it passes are noted in LDS (SC_HOPS per lane), so that the second time round -- the copy records -- reads
+    //     them from there;
+    //   * warm != 0 (calls of a few frames): the workgroups of an XCD first read the frame's segment table between them, one
+    //     access per 128-byte line, so that the hops hit that XCD's L2 instead of going to memory for lines another XCD wrote.
+    constexpr unsigned SC_HOPS = 48;
+    __shared__ uint2 s_hops[SC_HOPS][64];
     const int f = blockIdx.y;
     const int lane = lane_id();
     unsigned ns = (unsigned)counts[f].nseeds, nv = (unsigned)counts[f].nsurv;
@@ -2754,6 +2762,14 @@ __global__ __launch_bounds__(64) void k_seg_cycles(const uint2 *__restrict__ see
     const unsigned dcap = (unsigned)P.maxChunks * CK;
     const unsigned W2 = (unsigned)P.W + 2u;
     const unsigned ibeg = part ? ns : 0u, iend = part ? ns + nv : ns;
+    if (warm && !part) {
+        // (workgroups go to the XCDs in turn: blockIdx.x & 7 names this one's, blockIdx.x >> 3 its place among that XCD's)
+        const unsigned nlines = (ns * (unsigned)sizeof(DevSegC) + 127u) >> 7, nx = (gridDim.x + 7u) >> 3;
+        unsigned acc = 0;
+        for (unsigned k = (blockIdx.x >> 3) * 64u + (unsigned)lane; k < nlines; k += nx * 64u)
+            acc += *reinterpret_cast<const volatile uint32_t *>(reinterpret_cast<const char *>(fsg) + (size_t)k * 128u);
+        asm volatile("" ::"v"(acc));
+    }
     for (unsigned i0 = ibeg + blockIdx.x * 64; i0 < iend; i0 += gridDim.x * 64) {
         const unsigned i = i0 + lane;
         int accept = 0, hole = 0;
@@ -2786,6 +2802,7 @@ __global__ __launch_bounds__(64) void k_seg_cycles(const uint2 *__restrict__ see
                     KO = r.ko < KO ? r.ko : KO;
                     KH = r.kh < KH ? r.kh : KH;
                     L += r.n;
+                    if (hops - 1u < SC_HOPS) s_hops[hops - 1u][lane] = make_uint2(cur, r.n);  // the hops-th segment of the walk
                     hops++;
                     if (L > (unsigned)P.maxPerim) break;
                     cur = r.next_idx;
@@ -2853,6 +2870,18 @@ __global__ __launch_bounds__(64) void k_seg_cycles(const uint2 *__restrict__ see
                         fcb[idx] = dst0;
                         frc[rec++] = make_uint4(i, dst0, n0 - pos, pos);  // from the start state to the end of its segment
                         unsigned off = n0 - pos, cur = nx0;
+                        {
+                            // (an accepted cycle was walked to its end: hops - 1 segments behind the first, the first SC_HOPS of
+                            //  them noted; the rest, if any, hop by hop as the first time)
+                            const unsigned noted = hops - 1u < SC_HOPS ? hops - 1u : SC_HOPS;
+                            for (unsigned h = 0; h < noted; h++) {
+                                const uint2 e = s_hops[h][lane];
+                                frc[rec++] = make_uint4(e.x, dst0 + off, e.y, 0u);
+                                off += e.y;
+                                cur = e.x;
+                            }
+                            if (noted) cur = hops - 1u > noted ? fsg[cur].next_idx : i;
+                        }
                         while (cur != i && cur != SEG_INVALID && off < L) {
                             const uint2 q = reinterpret_cast<const uint2 *>(fsg + cur)[0];  // next_idx, n
                             frc[rec++] = make_uint4(cur, dst0 + off, q.y, 0u);

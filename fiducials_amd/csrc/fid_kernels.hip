@@ -3730,7 +3730,8 @@ __global__ __launch_bounds__(64) void k_identify(const uint8_t *__restrict__ gra
     __shared__ int hist[256];
     __shared__ uint8_t cellbits[FID_MAX_CELLS * FID_MAX_CELLS];
     __shared__ int s_thr;
-    __shared__ double2 s_otsu[256];  // Otsu's (mu1, q1) of every bin
+    __shared__ double2 s_ot2[256], s_ny[256];  // Otsu, per bin: (p_i, -), then (i * p_i, refined reciprocal of q1) ...
+    __shared__ double s_q1[256], s_mu1[256];   // ... q1 and mu1
     const int lane = lane_id();
     const unsigned n = *nwork;
     const int ms = P.markerSize, bb = P.borderBits, msb = ms + 2 * bb, cellSize = P.cellSize;
@@ -3911,39 +3912,90 @@ __global__ __launch_bounds__(64) void k_identify(const uint8_t *__restrict__ gra
         int uniform_bits = -1;
         if (stddev < P.minOtsuStdDev) uniform_bits = mean > 127 ? 1 : 0;
         if (uniform_bits < 0) {
-            // getThreshVal_Otsu_8u, sequential over the 256 bins (lane 0)
-            // (the histogram in registers, four bins per lane: bin i comes by v_readlane instead of an LDS read in each of the
-            //  2 x 256 dependent iterations.  Every lane runs the same scalar loop -- uniform control flow, so that the cross-
-            //  lane reads are well defined -- and lane 0 keeps the result.)
+            // getThreshVal_Otsu_8u (the histogram in registers, four bins per lane)
             const int hreg[4] = {hist[lane], hist[lane + 64], hist[lane + 128], hist[lane + 192]};
             {
-                const int N = 256;
-                double mu = 0, sc = 1. / (SZ * SZ);
-#pragma unroll
-                for (int k4 = 0; k4 < 4; k4++)
-                    for (int j = 0; j < 64; j++) mu += (k4 * 64 + j) * (double)__builtin_amdgcn_readlane(hreg[k4], j);
+                const double sc = 1. / (SZ * SZ);
+                // mu = sum of i * h_i, then * sc: every term and every partial sum is an integer below 2^53, so the double sum of the
+                // loop is exact whatever its order -- an integer wave reduction gives the same number
+                double mu = (double)wave_sum_i32(lane * hreg[0] + (64 + lane) * hreg[1] + (128 + lane) * hreg[2] + (192 + lane) * hreg[3]);
                 mu *= sc;
-                // The recurrence of (mu1, q1) is sequential; what hangs off it -- mu2 (a division), sigma, the running maximum -- is
-                // not: bin i's (mu1, q1) are parked in lane i % 64 (register i / 64) and the 256 sigmas are then computed four per
-                // lane, followed by one arg-max with the loop's rule (the FIRST bin that reaches the largest sigma, and only a
-                // sigma > 0).  Same operations on the same operands, 256 x ~ 45 instructions fewer per candidate (of ~ 24 k).
-                // (round 4: bin i's pair leaves through LDS, written by lane 0 -- two stores that nothing waits for -- instead of a
-                //  compare and four selects per bin in every lane; tools/valu_calib.hip: a second v_cndmask on the same VCC costs
-                //  ~ 17 cycles, and this loop had three of them on each of its 256 dependent steps)
-                double mu1 = 0, q1 = 0;
-                for (int i = lane; i < 256; i += 64) s_otsu[i] = make_double2(0., -1.);  // (q1 < 0: the loop skipped this bin)
-                __builtin_amdgcn_wave_barrier();
+                // getThreshVal_Otsu_8u's loop carries (q1, mu1) from bin to bin:  p_i = h_i * sc;  mu1 *= q1;  q1 += p_i;
+                // skip the bin if q1 or 1 - q1 is within FLT_EPSILON of 0 / 1;  mu1 = (mu1 + i * p_i) / q1;  then mu2, sigma, the maximum.
+                // As written that is 256 dependent steps of ~260 cycles (an IEEE f64 division each): 29 us of this kernel's 62.
+                // Only two things are truly sequential, and both are short:
+                //   1. q1: 256 dependent additions (their rounding depends on the order);
+                //   2. mu1: per bin  a = mu1 * q1_prev + i * p_i  and the LAST three operations of the division a / q1_i --
+                //      q0 = a * y,  r = fma(-q1_i, q0, a),  mu1 = fma(r, y, q0)  with y the twice-refined v_rcp_f64(q1_i).
+                // Everything else hangs off q1 alone and is done for all bins side by side, four per lane: p_i, i * p_i, the skip
+                // test (q1 rises, so the skipped bins are a stretch at each end and the loop of 2 runs over the bins between them
+                // without a branch), the reciprocal y and its two refinements, and afterwards mu2, sigma and the arg-max.
+                // The division is the compiler's own sequence (v_rcp_f64, two fma refinements, q0, r, fma) without v_div_scale /
+                // v_div_fixup, which only act on operands near the ends of the exponent range: here 0 <= a <= 255 (a == 0 gives 0
+                // through the same three operations) and FLT_EPSILON <= q1 <= 1.  Same operations on the same operands as the loop.
+                // (the loops read arrays they do not write: distinct LDS objects, so that their loads can run ahead of the stores)
+                double pk[4], qk[4];
+                bool skipk[4];
+                unsigned long long skipm[4];
 #pragma unroll
-                for (int k4 = 0; k4 < 4; k4++)
-                  for (int j = 0; j < 64; j++) {
-                    const int i = k4 * 64 + j;
-                    double p_i = __builtin_amdgcn_readlane(hreg[k4], j) * sc;
-                    mu1 *= q1;
-                    q1 += p_i;
-                    double q2 = 1. - q1;
-                    if (fmin(q1, q2) < FLT_EPSILON || fmax(q1, q2) > 1. - FLT_EPSILON) continue;
-                    mu1 = (mu1 + i * p_i) / q1;
-                    if (lane == 0) s_otsu[i] = make_double2(mu1, q1);
+                for (int k4 = 0; k4 < 4; k4++) {
+                    pk[k4] = hreg[k4] * sc;
+                    s_ot2[k4 * 64 + lane] = make_double2(pk[k4], 0.);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                if (lane == 0) {  // (one lane, one branch around the whole loop: a test inside it keeps its loads from running ahead)
+                    double q1 = 0;
+#pragma unroll 16
+                    for (int i = 0; i < 256; i++) {
+                        q1 += s_ot2[i].x;
+                        s_q1[i] = q1;
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#pragma unroll
+                for (int k4 = 0; k4 < 4; k4++) {
+                    const int i = k4 * 64 + lane;
+                    const double q1i = s_q1[i], q2 = 1. - q1i;
+                    qk[k4] = q1i;
+                    skipk[k4] = fmin(q1i, q2) < FLT_EPSILON || fmax(q1i, q2) > 1. - FLT_EPSILON;
+                    double y = __builtin_amdgcn_rcp(q1i);
+                    double e = __builtin_fma(-q1i, y, 1.);
+                    y = __builtin_fma(y, e, y);
+                    e = __builtin_fma(-q1i, y, 1.);
+                    y = __builtin_fma(y, e, y);
+                    s_ny[i] = make_double2(i * pk[k4], y);
+                    skipm[k4] = ballot64(skipk[k4]);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                int i_lo = 256, i_hi = 256;  // the bins the loop does not skip: [i_lo, i_hi)
+#pragma unroll
+                for (int k4 = 3; k4 >= 0; k4--)
+                    if (~skipm[k4]) i_lo = k4 * 64 + __ffsll((long long)~skipm[k4]) - 1;
+#pragma unroll
+                for (int k4 = 3; k4 >= 0; k4--) {
+                    const int lo = i_lo - k4 * 64;  // skipped bins of this word at or behind i_lo
+                    const unsigned long long m = lo >= 64 ? 0ull : (lo <= 0 ? skipm[k4] : skipm[k4] & ~((1ull << lo) - 1ull));
+                    if (m) i_hi = k4 * 64 + __ffsll((long long)m) - 1;
+                }
+                if (lane == 0) {
+                    double mu1 = 0;
+#pragma unroll 8
+                    for (int i = i_lo; i < i_hi; i++) {
+                        const double qprev = i ? s_q1[i - 1] : 0., q1i = s_q1[i];
+                        const double2 ny = s_ny[i];
+                        const double t = mu1 * qprev;
+                        const double a2 = t + ny.x;
+                        const double q0 = a2 * ny.y;
+                        const double r0 = __builtin_fma(-q1i, q0, a2);
+                        mu1 = __builtin_fma(r0, ny.y, q0);
+                        s_mu1[i] = mu1;
+                    }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 __builtin_amdgcn_wave_barrier();
@@ -3951,9 +4003,9 @@ __global__ __launch_bounds__(64) void k_identify(const uint8_t *__restrict__ gra
                 double pm[4], pq[4];
 #pragma unroll
                 for (int k4 = 0; k4 < 4; k4++) {
-                    const double2 v = s_otsu[k4 * 64 + lane];
-                    pm[k4] = v.x;
-                    pq[k4] = v.y;
+                    const int i = k4 * 64 + lane;
+                    pm[k4] = s_mu1[i];
+                    pq[k4] = (skipk[k4] || i >= i_hi) ? -1. : qk[k4];  // (q1 < 0: the loop skipped this bin)
                 }
                 double best = 0.;
                 int bi = 0;

@@ -672,7 +672,7 @@ fid_status enqueue_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H,
             hipLaunchKernelGGL(k_walk_full<2>, dim3(wb3, Fs), dim3(64 * WALK_WAVES), 0, sa, masks, surv, wres, tab, pool, segs, pend, counts,
                                c->d_global, P);
             if (si != sa) HIPCHK(c, hipStreamWaitEvent(sa, c->aux_idx[sb], 0));  // (the survivors' seed look-ups need the map)
-            hipLaunchKernelGGL(k_seg_cycles, dim3(8 * gm, Fs), dim3(64), 0, sa, seedq, (const DevSegC *)segs, pend, wres, contours, cinfo, cbase,
+            hipLaunchKernelGGL(k_seg_cycles<0>, dim3(8 * gm, Fs), dim3(64), 0, sa, seedq, (const DevSegC *)segs, pend, wres, contours, cinfo, cbase,
                                recs, counts, c->d_global, P, 1, 0);
             hipLaunchKernelGGL(k_seg_copy, dim3(cpb / 4 > 0 ? cpb / 4 : 1, Fs), dim3(256), 0, sa, recs, tab, pool, dense, counts, P, 1);
             hipLaunchKernelGGL(k_approx, dim3(32 * gm, Fs), dim3(64), lds1, sa, contours, tab, pool, cands, counts, c->d_global, P, cap1,
@@ -687,8 +687,12 @@ fid_status enqueue_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H,
             // (a call of one or two frames: a lane for every seed at once -- a workgroup that came round to a second 64 seeds walked a
             //  second longest cycle behind the first, 2 x 26 us of the single frame's 55 us)
             const int scb = Fs <= 2 ? (int)((P.maxContours + 63) / 64 < 4096 ? (P.maxContours + 63) / 64 : 4096) : 32 * gm * c->light_x;
-            hipLaunchKernelGGL(k_seg_cycles, dim3(scb, Fs), dim3(64), 0, st, seedq, (const DevSegC *)segs, pend, wres, contours, cinfo, cbase,
-                               recs, counts, c->d_global, P, 0, (Fs <= 2 && !getenv("FID_NO_SEGC_WARM")) ? 1 : 0);
+            if (Fs <= 2)
+                hipLaunchKernelGGL(k_seg_cycles<48>, dim3(scb, Fs), dim3(64), 0, st, seedq, (const DevSegC *)segs, pend, wres, contours, cinfo, cbase,
+                                   recs, counts, c->d_global, P, 0, getenv("FID_NO_SEGC_WARM") ? 0 : 1);
+            else
+                hipLaunchKernelGGL(k_seg_cycles<0>, dim3(scb, Fs), dim3(64), 0, st, seedq, (const DevSegC *)segs, pend, wres, contours, cinfo, cbase,
+                                   recs, counts, c->d_global, P, 0, 0);
             hipLaunchKernelGGL(k_seg_copy, dim3(cpb, Fs), dim3(256), 0, st, recs, tab, pool, dense, counts, P, 0);
             mark(ST_WALK + 1);
             chain_point(2);

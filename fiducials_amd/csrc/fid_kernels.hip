@@ -2728,6 +2728,10 @@ __global__ __launch_bounds__(256) void k_seg_link2(const uint2 *__restrict__ see
 // border that starts at the state with min kh -- so exactly one lane per cycle ends up accepting, the one whose segment holds
 // the canonical start.  It then lists the pieces: its own segment from the start state on, the other segments in cycle order,
 // its own segment up to the start state.
+// SC_HOPS: segments of a walk noted in LDS (8 bytes x 64 lanes each).  48 for calls of a few frames; 0 for batches -- there the
+// 24 KB per workgroup crowd the CUs' LDS while another batch's k_resolve (70 KB) waits for room: the two-context rate fell from
+// 32.7 to 31.5 k frames/s with the list on, and a batch does not wait for one cycle's walk anyway.
+template <unsigned SC_HOPS>
 __global__ __launch_bounds__(64) void k_seg_cycles(const uint2 *__restrict__ seedq, const DevSegC *__restrict__ segs,
                                                     const DevPend *__restrict__ pend, const uint4 *__restrict__ wres,
                                                     uint4 *__restrict__ contours, uint4 *__restrict__ cinfo, uint32_t *__restrict__ cbase,
@@ -2742,8 +2746,7 @@ __global__ __launch_bounds__(64) void k_seg_cycles(const uint2 *__restrict__ see
     //     them from there;
     //   * warm != 0 (calls of a few frames): the workgroups of an XCD first read the frame's segment table between them, one
     //     access per 128-byte line, so that the hops hit that XCD's L2 instead of going to memory for lines another XCD wrote.
-    constexpr unsigned SC_HOPS = 48;
-    __shared__ uint2 s_hops[SC_HOPS][64];
+    __shared__ uint2 s_hops[SC_HOPS ? SC_HOPS : 1][SC_HOPS ? 64 : 1];
     const int f = blockIdx.y;
     const int lane = lane_id();
     unsigned ns = (unsigned)counts[f].nseeds, nv = (unsigned)counts[f].nsurv;
@@ -2802,7 +2805,7 @@ __global__ __launch_bounds__(64) void k_seg_cycles(const uint2 *__restrict__ see
                     KO = r.ko < KO ? r.ko : KO;
                     KH = r.kh < KH ? r.kh : KH;
                     L += r.n;
-                    if (hops - 1u < SC_HOPS) s_hops[hops - 1u][lane] = make_uint2(cur, r.n);  // the hops-th segment of the walk
+                    if (SC_HOPS && hops - 1u < SC_HOPS) s_hops[hops - 1u][lane] = make_uint2(cur, r.n);  // the hops-th segment of the walk
                     hops++;
                     if (L > (unsigned)P.maxPerim) break;
                     cur = r.next_idx;
@@ -2873,7 +2876,7 @@ __global__ __launch_bounds__(64) void k_seg_cycles(const uint2 *__restrict__ see
                         {
                             // (an accepted cycle was walked to its end: hops - 1 segments behind the first, the first SC_HOPS of
                             //  them noted; the rest, if any, hop by hop as the first time)
-                            const unsigned noted = hops - 1u < SC_HOPS ? hops - 1u : SC_HOPS;
+                            const unsigned noted = !SC_HOPS ? 0u : (hops - 1u < SC_HOPS ? hops - 1u : SC_HOPS);
                             for (unsigned h = 0; h < noted; h++) {
                                 const uint2 e = s_hops[h][lane];
                                 frc[rec++] = make_uint4(e.x, dst0 + off, e.y, 0u);
@@ -3364,6 +3367,9 @@ __global__ __launch_bounds__(256) void k_near(const DevCand *__restrict__ sorted
 // (One wave taking the 600 rows of a bench frame one after the other spent 180 us on LDS latencies; one THREAD per component
 // 130 us: a clique's rows are long.)
 // A triangle that does not fit the LDS budget goes the old way: one wave, rows in order, straight from global memory.
+#ifndef RESOLVE_REG_MAX
+#define RESOLVE_REG_MAX 64  // components of up to this many candidates are resolved in registers (0: every one by the LDS-row loop)
+#endif
 __global__ __launch_bounds__(1024) void k_resolve(const DevCand *__restrict__ sorted, const uint32_t *__restrict__ nearb,
                                                  DevCand *__restrict__ filtered, DevCounts *__restrict__ counts,
                                                  unsigned *__restrict__ worklist, unsigned *__restrict__ nwork,
@@ -3487,7 +3493,7 @@ __global__ __launch_bounds__(1024) void k_resolve(const DevCand *__restrict__ so
                 rb &= rb - 1;
                 if ((rootrank++ % nwaves) != wv) continue;
                 const int cs = csize[r];
-                if (cs <= 64) {
+                if (cs <= RESOLVE_REG_MAX) {
                     // A component of at most 64 candidates (a marker seen at 13 scales, inside and outside border: 26) is resolved in
                     // REGISTERS: lane m holds member m's row as a 64-bit mask over the component's members (in index order) and its
                     // size, and the rows are taken in order with v_readlane and scalar bit operations -- no LDS round trip per
@@ -3730,8 +3736,8 @@ __global__ __launch_bounds__(64) void k_identify(const uint8_t *__restrict__ gra
     __shared__ int hist[256];
     __shared__ uint8_t cellbits[FID_MAX_CELLS * FID_MAX_CELLS];
     __shared__ int s_thr;
-    __shared__ double2 s_ot2[256], s_ny[256];  // Otsu, per bin: (p_i, -), then (i * p_i, refined reciprocal of q1) ...
-    __shared__ double s_q1[256], s_mu1[256];   // ... q1 and mu1
+    __shared__ double2 s_ny[256];             // Otsu, per bin: (i * p_i, refined reciprocal of q1) ...
+    __shared__ double s_q1[256], s_pm[256];   // ... q1; p_i, later mu1 (no loop reads an array it writes)
     const int lane = lane_id();
     const unsigned n = *nwork;
     const int ms = P.markerSize, bb = P.borderBits, msb = ms + 2 * bb, cellSize = P.cellSize;
@@ -3940,7 +3946,7 @@ __global__ __launch_bounds__(64) void k_identify(const uint8_t *__restrict__ gra
 #pragma unroll
                 for (int k4 = 0; k4 < 4; k4++) {
                     pk[k4] = hreg[k4] * sc;
-                    s_ot2[k4 * 64 + lane] = make_double2(pk[k4], 0.);
+                    s_pm[k4 * 64 + lane] = pk[k4];
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 __builtin_amdgcn_wave_barrier();
@@ -3949,7 +3955,7 @@ __global__ __launch_bounds__(64) void k_identify(const uint8_t *__restrict__ gra
                     double q1 = 0;
 #pragma unroll 16
                     for (int i = 0; i < 256; i++) {
-                        q1 += s_ot2[i].x;
+                        q1 += s_pm[i];
                         s_q1[i] = q1;
                     }
                 }
@@ -3994,7 +4000,7 @@ __global__ __launch_bounds__(64) void k_identify(const uint8_t *__restrict__ gra
                         const double q0 = a2 * ny.y;
                         const double r0 = __builtin_fma(-q1i, q0, a2);
                         mu1 = __builtin_fma(r0, ny.y, q0);
-                        s_mu1[i] = mu1;
+                        s_pm[i] = mu1;
                     }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -4004,7 +4010,7 @@ __global__ __launch_bounds__(64) void k_identify(const uint8_t *__restrict__ gra
 #pragma unroll
                 for (int k4 = 0; k4 < 4; k4++) {
                     const int i = k4 * 64 + lane;
-                    pm[k4] = s_mu1[i];
+                    pm[k4] = s_pm[i];
                     pq[k4] = (skipk[k4] || i >= i_hi) ? -1. : qk[k4];  // (q1 < 0: the loop skipped this bin)
                 }
                 double best = 0.;

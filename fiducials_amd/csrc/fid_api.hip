@@ -103,6 +103,7 @@ struct fid_ctx {
     int walk_blocks_cap = 0;   // FID_WALK_CAP: most walker workgroups per frame (0: 64, 256 for calls of one or two frames)
     int copy_blocks = 0;
     int resolve_serial = 0;    // FID_RESOLVE_SERIAL=1: k_resolve's single-wave path even when the near triangle fits LDS (tests)
+    int resolve_reg_max = 64;  // FID_RESOLVE_REG_MAX: components of up to so many candidates are resolved in registers (0: none; tests)
     int seed_shift = 0;        // FID_SEED_SHIFT: force the seed grid spacing 8 << shift (0 = by call size)
     uint4 *d_contours = nullptr;
     uint32_t *d_ckpts = nullptr;
@@ -748,7 +749,8 @@ fid_status enqueue_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H,
             // the other sub-batch on a CU; with 96 KB the kernel waited for whole CUs to drain)
             const size_t lds = (size_t)c->resolve_lds_kb * 1024;
             const int near_words = c->resolve_serial ? 0 : (int)((lds - 3 * MC * 4) / 4);
-            hipLaunchKernelGGL(k_resolve, dim3(Fs), dim3(1024), lds, st, sorted, nearb, filtered, counts, worklist, nwork, P, near_words, c->d_global);
+            hipLaunchKernelGGL(k_resolve, dim3(Fs), dim3(1024), lds, st, sorted, nearb, filtered, counts, worklist, nwork, P, near_words, c->d_global,
+                               c->resolve_reg_max);
         }
         mark(ST_RESOLVE + 1);
         chain_point(5);
@@ -1036,6 +1038,10 @@ fid_status fid_create(const fid_params *params, const fid_dict *dict, const fid_
     if (getenv("FID_WALK_CAP")) c->walk_blocks_cap = atoi(getenv("FID_WALK_CAP"));
     if (getenv("FID_SEED_SHIFT")) c->seed_shift = atoi(getenv("FID_SEED_SHIFT"));
     if (getenv("FID_RESOLVE_SERIAL")) c->resolve_serial = atoi(getenv("FID_RESOLVE_SERIAL"));
+    if (getenv("FID_RESOLVE_REG_MAX")) {
+        const int v = atoi(getenv("FID_RESOLVE_REG_MAX"));
+        c->resolve_reg_max = v < 0 ? 0 : (v > 64 ? 64 : v);
+    }
     if (getenv("FID_COPY_BLOCKS")) c->copy_blocks = atoi(getenv("FID_COPY_BLOCKS"));
     if (getenv("FID_THR")) c->thr_mode = strcmp(getenv("FID_THR"), "tile") ? 1 : 0;
     if (getenv("FID_THR_NW")) c->thr_nw = atoi(getenv("FID_THR_NW")) == 3 ? 3 : 5;

@@ -3367,14 +3367,12 @@ __global__ __launch_bounds__(256) void k_near(const DevCand *__restrict__ sorted
 // (One wave taking the 600 rows of a bench frame one after the other spent 180 us on LDS latencies; one THREAD per component
 // 130 us: a clique's rows are long.)
 // A triangle that does not fit the LDS budget goes the old way: one wave, rows in order, straight from global memory.
-#ifndef RESOLVE_REG_MAX
-#define RESOLVE_REG_MAX 64  // components of up to this many candidates are resolved in registers (0: every one by the LDS-row loop)
-#endif
 __global__ __launch_bounds__(1024) void k_resolve(const DevCand *__restrict__ sorted, const uint32_t *__restrict__ nearb,
                                                  DevCand *__restrict__ filtered, DevCounts *__restrict__ counts,
                                                  unsigned *__restrict__ worklist, unsigned *__restrict__ nwork,
-                                                 const DevParams P, int lds_words, DevGlobal *__restrict__ G)
+                                                 const DevParams P, int lds_words, DevGlobal *__restrict__ G, int reg_max)
 {
+    // reg_max: components of up to this many candidates (at most 64) are resolved in registers; 0: every one by the LDS-row loop
 #ifdef FID_DEBUG_STATS
     unsigned long long d_t[8];
     int d_k = 0, d_iters = 0;
@@ -3493,7 +3491,7 @@ __global__ __launch_bounds__(1024) void k_resolve(const DevCand *__restrict__ so
                 rb &= rb - 1;
                 if ((rootrank++ % nwaves) != wv) continue;
                 const int cs = csize[r];
-                if (cs <= RESOLVE_REG_MAX) {
+                if (cs <= reg_max) {
                     // A component of at most 64 candidates (a marker seen at 13 scales, inside and outside border: 26) is resolved in
                     // REGISTERS: lane m holds member m's row as a 64-bit mask over the component's members (in index order) and its
                     // size, and the rows are taken in order with v_readlane and scalar bit operations -- no LDS round trip per

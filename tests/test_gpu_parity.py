@@ -403,16 +403,18 @@ def test_cycle_tracing_cell_cases_every_seed_spacing(monkeypatch, shift):
 
 
 def test_too_close_filter_both_paths(monkeypatch):
-    """k_resolve resolves the connected components of the near graph side by side when the near triangle fits LDS and falls
-    back to one wave taking the rows in order when it does not (FID_RESOLVE_SERIAL=1 forces that): both must reproduce
-    _filterTooCloseCandidates stage by stage -- nested same-id quads (chains of near pairs across scales), a noisy frame
-    with hundreds of candidates, and a batch."""
+    """k_resolve resolves the connected components of the near graph side by side when the near triangle fits LDS -- a
+    component of up to 64 candidates in registers, a larger one row by row from LDS (FID_RESOLVE_REG_MAX=0 sends every component
+    that way, 8 the ones of more than eight candidates) -- and falls back to one wave taking the rows in order when it does not
+    (FID_RESOLVE_SERIAL=1 forces that): all of them must reproduce _filterTooCloseCandidates stage by stage -- nested same-id
+    quads (chains of near pairs across scales), a noisy frame with hundreds of candidates, and a batch."""
     from helpers import nested_same_id_frame
     d = get_predefined_dictionary(6)
     fr = make_frame(d, 41, width=1280, height=720, n_markers=10)
     nested = nested_same_id_frame(d)
-    for serial in ("0", "1"):
+    for serial, reg_max in (("0", "64"), ("0", "0"), ("0", "8"), ("1", "64")):
         monkeypatch.setenv("FID_RESOLVE_SERIAL", serial)
+        monkeypatch.setenv("FID_RESOLVE_REG_MAX", reg_max)
         det = ArucoDetector(6, max_width=1280, max_height=720, max_batch=2)
         try:
             check_stages(det, fr.image, d)

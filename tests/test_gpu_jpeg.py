@@ -170,3 +170,49 @@ def test_randomised_sweep_equals_libjpeg_turbo():
     p = subprocess.run([sys.executable, os.path.join(root, "tools", "gpu_jpeg_stress.py"), "60", "77"], capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
     assert "0 mismatches" in p.stdout
+
+
+def test_damaged_entropy_data_ends_in_an_image_or_a_status():
+    """A frame damaged on its way (compressed_image_transport over a lossy link): bits flipped, bytes overwritten, data cut
+    or doubled BEHIND the headers.  The decoder starts every sub-sequence out of step by design, so arbitrary bits are its
+    normal diet: a call returns an image of the announced size or a status -- it neither hangs nor writes outside its buffers
+    (the next, sound, file on the same context must still decode bit for bit)."""
+    gold = np.load(GOLD)
+    rng = np.random.default_rng(21)
+    dec = fj.JpegDecoder(max_width=256, max_height=256)
+    try:
+        cases = [k for k in gold["cases"].tolist() if len(gold[f"jpg_{k[0]}"]) - gold[f"jpg_{k[0]}"].tobytes().rfind(b"\xff\xda") > 300]
+        assert len(cases) >= 6
+        ok = bad = 0
+        for it in range(160):
+            k, w, h = cases[it % len(cases)][:3]
+            data = bytearray(gold[f"jpg_{k}"].tobytes())
+            sos = bytes(data).rfind(b"\xff\xda")
+            assert sos > 0
+            lo = sos + 14  # behind the scan header
+            kind = it % 4
+            if kind == 0:
+                for _ in range(int(rng.integers(1, 12))):
+                    data[int(rng.integers(lo, len(data) - 2))] ^= 1 << int(rng.integers(0, 8))
+            elif kind == 1:
+                at = int(rng.integers(lo, len(data) - 2))
+                n = int(rng.integers(1, 48))
+                data[at:at + n] = rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+            elif kind == 2:
+                del data[int(rng.integers(lo, len(data) - 2)):-2]  # cut, EOI kept
+            else:
+                at = int(rng.integers(lo, len(data) - 2))
+                data[at:at] = data[at:at + int(rng.integers(1, 200))]
+            try:
+                img = dec.decode(bytes(data), "bgr8")
+                assert img.shape == (h, w, 3)
+                ok += 1
+            except FidError as e:
+                assert e.status in (1, 3, 4, 6)  # INVALID_ARG / HIP (did not settle) / CAPACITY / UNSUPPORTED
+                bad += 1
+            if it % 16 == 15:  # a sound file in between: bit for bit
+                kk = cases[(it // 16) % len(cases)][0]
+                assert np.array_equal(dec.decode(gold[f"jpg_{kk}"].tobytes(), "bgr8"), gold[f"bgr_{kk}"])
+        assert ok + bad == 160 and ok > 40
+    finally:
+        dec.close()

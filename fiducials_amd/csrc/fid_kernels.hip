@@ -4065,40 +4065,59 @@ __global__ __launch_bounds__(64) void k_identify(const uint8_t *__restrict__ gra
             unsigned long long cw = 0;
             {
                 const int nb2 = ms * ms;
-                for (int t = 0; t < nb2; t++) {
-                    int r = t / ms, c = t - r * ms;
-                    int byte = t >> 3, q = t & 7;
-                    int inbyte = nb2 - 8 * byte;
-                    inbyte = inbyte > 8 ? 8 : inbyte;  // the last partial byte is right-aligned
-                    unsigned long long bit = cellbits[(r + bb) * msb + c + bb];
-                    cw |= bit << (8 * byte + (inbyte - 1 - q));
-                }
+                for (int r = 0, t = 0; r < ms; r++)  // (row and column carried along: a division per bit otherwise)
+                    for (int c = 0; c < ms; c++, t++) {
+                        int byte = t >> 3, q = t & 7;
+                        int inbyte = nb2 - 8 * byte;
+                        inbyte = inbyte > 8 ? 8 : inbyte;  // the last partial byte is right-aligned
+                        unsigned long long bit = cellbits[(r + bb) * msb + c + bb];
+                        cw |= bit << (8 * byte + (inbyte - 1 - q));
+                    }
             }
             const int nbytes = P.nbytes;
             int bestm = INT_MAX, bestr = 0;
-            for (int m0 = 0; m0 < P.nMarkers; m0 += 64) {
-                int mi = m0 + lane;
-                int myr = -1;
-                if (mi < P.nMarkers) {
-                    int cmin = ms * ms + 1;
-                    for (int r = 0; r < 4; r++) {
-                        const uint8_t *t = dict + ((long long)mi * 4 + r) * nbytes;
-                        unsigned long long tw = 0;
-                        for (int q = 0; q < nbytes; q++) tw |= (unsigned long long)t[q] << (8 * q);
-                        int ham = __popcll(tw ^ cw);
-                        if (ham < cmin) {
-                            cmin = ham;
-                            myr = r;
-                        }
+            // 64 markers a round, a lane each; four rounds' tables are fetched together -- with four bytes per rotation (5 x 5
+            // markers) a marker's four rotations are one aligned 16-byte load -- and then compared round by round, the first
+            // round with a hit ends the search (a round used to wait for sixteen byte loads of its own: id 238 of DICT_5X5_250
+            // cost 23 k cycles, id 47 11 k)
+            for (int m0 = 0; m0 < P.nMarkers && bestm == INT_MAX; m0 += 256) {
+                uint4 tw4[4];
+                if (nbytes == 4) {
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const int mi = m0 + 64 * u + lane;
+                        tw4[u] = mi < P.nMarkers ? reinterpret_cast<const uint4 *>(dict)[mi] : make_uint4(0u, 0u, 0u, 0u);
                     }
-                    if (cmin > P.maxCorr) myr = -1;
                 }
-                unsigned long long hit = ballot64(myr >= 0);
-                if (hit) {
-                    int src = __ffsll((long long)hit) - 1;
-                    bestm = m0 + src;
-                    bestr = __shfl(myr, src, WAVE);
-                    break;
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int mi = m0 + 64 * u + lane;
+                    int myr = -1;
+                    if (mi < P.nMarkers) {
+                        int cmin = ms * ms + 1;
+                        for (int r = 0; r < 4; r++) {
+                            unsigned long long tw = 0;
+                            if (nbytes == 4) {
+                                tw = r == 0 ? tw4[u].x : (r == 1 ? tw4[u].y : (r == 2 ? tw4[u].z : tw4[u].w));
+                            } else {
+                                const uint8_t *t = dict + ((long long)mi * 4 + r) * nbytes;
+                                for (int q = 0; q < nbytes; q++) tw |= (unsigned long long)t[q] << (8 * q);
+                            }
+                            int ham = __popcll(tw ^ cw);
+                            if (ham < cmin) {
+                                cmin = ham;
+                                myr = r;
+                            }
+                        }
+                        if (cmin > P.maxCorr) myr = -1;
+                    }
+                    unsigned long long hit = ballot64(myr >= 0);
+                    if (hit) {
+                        int src = __ffsll((long long)hit) - 1;
+                        bestm = m0 + 64 * u + src;
+                        bestr = __shfl(myr, src, WAVE);
+                        break;
+                    }
                 }
             }
             if (bestm != INT_MAX) {
@@ -4948,7 +4967,9 @@ __device__ __forceinline__ void rodrigues_v2m(const double r_in[3], double R[9],
         }
         return;
     }
-    double c = cos(theta), s = sin(theta), c1 = 1. - c, itheta = theta ? 1. / theta : 0.;
+    double c, s;
+    sincos(theta, &s, &c);  // (one argument reduction for the pair)
+    const double c1 = 1. - c, itheta = theta ? 1. / theta : 0.;
     rx *= itheta;
     ry *= itheta;
     rz *= itheta;

@@ -140,3 +140,34 @@ def test_a_refused_host_batch_queues_no_copy_and_leaves_the_context_usable():
         a.close()
         if b is not None:
             b.close()
+
+
+def test_a_blocking_host_call_behind_fid_order_after_and_alone_give_the_same():
+    """fid_detect_batch of one piece copies on the context's main stream behind the clear of its result block (no copy
+    stream, no event); when fid_order_after has told the context to wait for another one's batch, it takes the copy-stream
+    road instead.  Both roads, and the same context used alternately for blocking and submitted calls, give the oracle's
+    markers (a stale event handle or a result block cleared at the wrong moment would show here)."""
+    d = get_predefined_dictionary(6)
+    frames = np.stack([make_frame(d, 300 + i, width=640, height=480, n_markers=5).image for i in range(4)])
+    want = [oracle.detect(f, d) for f in frames]
+    a = ArucoDetector(6, max_width=640, max_height=480, max_batch=4)
+    b = ArucoDetector(6, max_width=640, max_height=480, max_batch=4)
+
+    def check(res, idx):
+        for k, i in enumerate(idx):
+            assert res[k][1].tolist() == want[i][0].tolist()
+            assert np.array_equal(res[k][0], want[i][1])
+
+    try:
+        check(b.detect_markers_batch(frames[:1]), [0])            # one piece, blocking: main-stream copy
+        a.submit_batch(frames)                                     # a batch in flight on the other context ...
+        b._check(b._L.fid_order_after(b._ctx, a._ctx))             # ... that b is told to run behind
+        check(b.detect_markers_batch(frames[1:3]), [1, 2])         # blocking call with an order: copy-stream road
+        check(a.collect(), [0, 1, 2, 3])
+        check(b.detect_markers_batch(frames[3:4]), [3])            # and the plain road again (the order held for one call)
+        b.submit_batch(frames[:2])
+        check(b.collect(), [0, 1])
+        check(b.detect_markers_batch(frames[2:3]), [2])
+    finally:
+        a.close()
+        b.close()

@@ -157,6 +157,14 @@ def issue_roofline(fps_per_gpu):
                     "valu_wave_instr_per_frame": round(valu), "salu_wave_instr_per_frame": round(salu),
                     "static_2cycle_share": round(t_fast / valu, 3),
                     "counters": "profiles/sq_cycles.json (SQ_INSTS_VALU / SQ_INSTS_SALU per frame, one 64-frame sub-batch)"})
+        # lane work under the wave-instructions (round 5): SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU) of one counter pass
+        # = the share of a wave's 64 lanes that execute per VALU instruction, weighted over the pipeline's kernels by their
+        # instruction counts; frac_lanes = frac x lane_util is the share of the chip's LANE-instruction rate that does work
+        lu = sq.get("pipeline_lane_util")
+        if lu is not None:
+            out.update({"lane_util": round(lu, 4), "frac_lanes": round(ach / peak * lu, 4),
+                        "lane_util_by_kernel": {n.split("(")[0][:40]: k["lane_util"] for n, k in sq["kernels"].items()
+                                                if n.startswith("k_") and "lane_util" in k and k.get("SQ_INSTS_VALU", 0) > 0.01 * valu}})
     except Exception as e:  # noqa: BLE001
         out["note"] = f"unavailable: {e!r}"
     return out

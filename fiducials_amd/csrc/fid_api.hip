@@ -929,9 +929,10 @@ fid_status finish_detect(fid_ctx *c, fid_marker *out, int cap_per_frame, int *n_
 fid_status run_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H, int stride, long long fstride, fid_encoding enc,
                       fid_marker *out, int cap_per_frame, int *n_per_frame)
 {
-    if (!out || !n_per_frame || cap_per_frame < 0) return FID_E_INVALID_ARG;
-    if (c->in_flight) {
-        c->last_error = "a submitted batch is in flight: fid_collect first";
+    if (!out || !n_per_frame || cap_per_frame < 0 || c->in_flight) {
+        if (c->in_flight) c->last_error = "a submitted batch is in flight: fid_collect first";
+        c->wait_ev = c->wait_copy_ev = nullptr;  // (fid_order_after holds for one call, refused or not)
+        c->chained = false;
         return FID_E_INVALID_ARG;
     }
     c->blocking = true;
@@ -940,6 +941,7 @@ fid_status run_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H, int
     if (rc != FID_OK) {
         c->wait_ev = c->wait_copy_ev = nullptr;
         c->chained = false;
+        if (c->last_frames > 0 && !c->in_flight) layout_results(c, c->last_frames);  // (the layout of the last call that ran)
         return rc;
     }
     return finish_detect(c, out, cap_per_frame, n_per_frame);
@@ -1255,24 +1257,28 @@ fid_status fid_set_params(fid_ctx *c, const fid_params *p)
 fid_status fid_detect_device(fid_ctx *c, const void *d_imgs, int32_t nframes, int32_t width, int32_t height, int32_t stride,
                              int64_t frame_stride, fid_encoding enc, fid_marker *out, int32_t cap_per_frame, int32_t *n_per_frame)
 {
-    if (!c || !d_imgs) return FID_E_INVALID_ARG;
-    HIPCHK(c, hipSetDevice(c->device));
+    if (!c) return FID_E_INVALID_ARG;
+    if (!d_imgs || hipSetDevice(c->device) != hipSuccess) {
+        c->wait_ev = c->wait_copy_ev = nullptr;  // (fid_order_after holds for one call, refused or not)
+        c->chained = false;
+        return FID_E_INVALID_ARG;
+    }
     return run_detect(c, (const uint8_t *)d_imgs, nframes, width, height, stride, frame_stride, enc, out, cap_per_frame, n_per_frame);
 }
 
 fid_status fid_submit_device(fid_ctx *c, const void *d_imgs, int32_t nframes, int32_t width, int32_t height, int32_t stride,
                              int64_t frame_stride, fid_encoding enc)
 {
-    if (!c || !d_imgs) return FID_E_INVALID_ARG;
-    if (c->in_flight) {
-        c->last_error = "a submitted batch is in flight: fid_collect first";
-        return FID_E_INVALID_ARG;
-    }
-    HIPCHK(c, hipSetDevice(c->device));
-    const fid_status rc = enqueue_detect(c, (const uint8_t *)d_imgs, nframes, width, height, stride, frame_stride, enc);
+    if (!c) return FID_E_INVALID_ARG;
+    fid_status rc = FID_E_INVALID_ARG;
+    const bool was_in_flight = c->in_flight;
+    if (was_in_flight) c->last_error = "a submitted batch is in flight: fid_collect first";
+    else if (d_imgs && hipSetDevice(c->device) == hipSuccess)
+        rc = enqueue_detect(c, (const uint8_t *)d_imgs, nframes, width, height, stride, frame_stride, enc);
     c->wait_ev = nullptr;  // (fid_order_after holds for one submit, refused or not)
     c->wait_copy_ev = nullptr;
     c->chained = false;
+    if (rc != FID_OK && !was_in_flight && c->last_frames > 0) layout_results(c, c->last_frames);
     return rc;
 }
 
@@ -1297,8 +1303,33 @@ fid_status fid_collect(fid_ctx *c, fid_marker *out, int32_t cap_per_frame, int32
 }
 
 // frames in host memory: the copies go on the copy stream, the pipeline is enqueued behind them (fid_detect_batch, fid_submit_batch)
+// fid_order_after holds for ONE submit, refused or not: the other context's events are not kept beyond it (that context may be
+// destroyed before this one's next call), and a refused call leaves no result layout of its own behind (fid_pose_last /
+// fid_tap_read address the result block through last_frames).
+static void drop_order_and_layout(fid_ctx *c, bool layout_touched)
+{
+    c->wait_ev = c->wait_copy_ev = nullptr;
+    c->chained = false;
+    if (layout_touched) {
+        if (c->last_frames > 0) layout_results(c, c->last_frames);
+        c->res_precleared = false;
+    }
+}
+
+static fid_status feed_and_enqueue_impl(fid_ctx *c, const uint8_t *imgs, int32_t nframes, int32_t width, int32_t height, int32_t stride,
+                                        int64_t frame_stride, fid_encoding enc);
+
 static fid_status feed_and_enqueue(fid_ctx *c, const uint8_t *imgs, int32_t nframes, int32_t width, int32_t height, int32_t stride,
                                    int64_t frame_stride, fid_encoding enc)
+{
+    if (!c) return FID_E_INVALID_ARG;
+    const fid_status rc = feed_and_enqueue_impl(c, imgs, nframes, width, height, stride, frame_stride, enc);
+    if (rc != FID_OK) drop_order_and_layout(c, true);
+    return rc;
+}
+
+static fid_status feed_and_enqueue_impl(fid_ctx *c, const uint8_t *imgs, int32_t nframes, int32_t width, int32_t height, int32_t stride,
+                                        int64_t frame_stride, fid_encoding enc)
 {
     if (!c || !imgs || nframes < 1 || height < 1 || stride < 1) return FID_E_INVALID_ARG;
     if (nframes > c->lim.max_batch) return FID_E_INVALID_ARG;

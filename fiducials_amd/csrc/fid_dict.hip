@@ -79,7 +79,11 @@ fid_status dict_load_impl(const char *path, int32_t dicno, uint8_t *bytes, int64
     size_t got;
     while ((got = fread(buf, 1, sizeof buf, f)) > 0) {
         text.append(buf, got);
-        if (text.size() > (64u << 20)) break;  // (OpenCV's header is 1.3 MB)
+        if (text.size() > (64u << 20)) {  // (OpenCV's header is 1.3 MB) -- refused, not cut off in the middle of a table
+            fclose(f);
+            g_dict_error = "file larger than 64 MB: not a dictionary table";
+            return FID_E_INVALID_ARG;
+        }
     }
     fclose(f);
     DictRow row = {0, 0, 0};
@@ -171,16 +175,26 @@ fid_status dict_load_impl(const char *path, int32_t dicno, uint8_t *bytes, int64
             maxc = row.maxc;
         }
         const int nbytes = (n * n + 7) / 8;
+        // every marker needs its n * n bit characters in the file: a count the file cannot hold is refused before anything is
+        // allocated for it ("nmarkers: 2000000000" used to zero-fill tens of GB first)
+        if ((uint64_t)count * (uint64_t)(n * n) > (uint64_t)text.size()) {
+            g_dict_error = "nmarkers is larger than the file can hold";
+            return FID_E_INVALID_ARG;
+        }
         table.assign((size_t)count * 4 * nbytes, 0);
         std::vector<int> bits((size_t)n * n);
+        size_t from = 0;  // FileStorage writes the markers in order: the search resumes behind the previous one (and starts over
+                          // from the top once for a file that does not)
         for (int m = 0; m < count; m++) {
             const std::string key = "marker_" + std::to_string(m) + ":";
-            size_t p = text.find(key);
+            size_t p = text.find(key, from);
+            if (p == std::string::npos && from > 0) p = text.find(key);
             if (p == std::string::npos) {
                 g_dict_error = "marker_" + std::to_string(m) + " missing";
                 return FID_E_INVALID_ARG;
             }
             p += key.size();
+            from = p;
             int k = 0;
             for (; p < text.size() && text[p] != '\n' && k < n * n; p++)
                 if (text[p] == '0' || text[p] == '1') bits[k++] = text[p] - '0';

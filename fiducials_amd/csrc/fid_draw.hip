@@ -66,6 +66,11 @@ void draw_line8(uint8_t *img, int W, int H, long long stride, DrawPt a, DrawPt b
     if ((unsigned long long)a.x >= (unsigned long long)W || (unsigned long long)b.x >= (unsigned long long)W ||
         (unsigned long long)a.y >= (unsigned long long)H || (unsigned long long)b.y >= (unsigned long long)H)
         if (!draw_clip_line(W, H, a, b)) return;
+    // clipLine() does not look at y again after the x clip; with end points near +-2^31 its double arithmetic is off by hundreds
+    // of pixels and the reference would write outside its image there.  Such a line is left out instead.
+    if ((unsigned long long)a.x >= (unsigned long long)W || (unsigned long long)b.x >= (unsigned long long)W ||
+        (unsigned long long)a.y >= (unsigned long long)H || (unsigned long long)b.y >= (unsigned long long)H)
+        return;
     long long dx = b.x - a.x, dy = b.y - a.y;
     long long s = dx < 0 ? -1 : 0;
     // left_to_right: the walk starts at the end point with the smaller x
@@ -99,7 +104,15 @@ void draw_line8(uint8_t *img, int W, int H, long long stride, DrawPt a, DrawPt b
     }
 }
 
-inline long long draw_cv_round(float v) { return (long long)lrintf(v); }  // saturate_cast<int>(float) = cvRound (nearest even)
+// Point2f -> Point: saturate_cast<int>(float) = cvRound = cvtss2si on the reference's x86-64 build: round to nearest even, and
+// the "integer indefinite" INT_MIN for NaN, +-inf and everything outside the int range (CORNER_REFINE_CONTOUR crosses two
+// fitted lines: near-parallel ones give such corners).  The result always fits 32 bits, so the 64-bit line arithmetic below
+// (OpenCV's own Point2l) cannot overflow.
+inline long long draw_cv_round(float v)
+{
+    if (!(v >= -2147483648.f && v < 2147483648.f)) return -2147483648LL;  // (NaN fails both comparisons)
+    return (long long)lrintf(v);
+}
 
 }  // namespace
 
@@ -110,7 +123,7 @@ fid_status fid_to_bgr(const uint8_t *img, int32_t width, int32_t height, int32_t
     if (!img || !out_bgr || width < 1 || height < 1) return FID_E_INVALID_ARG;
     const int bpp = enc == FID_ENC_MONO8 ? 1 : ((enc == FID_ENC_BGRA8 || enc == FID_ENC_RGBA8) ? 4 : 3);
     if (enc != FID_ENC_MONO8 && enc != FID_ENC_BGR8 && enc != FID_ENC_RGB8 && enc != FID_ENC_BGRA8 && enc != FID_ENC_RGBA8) return FID_E_INVALID_ARG;
-    if (stride < width * bpp) return FID_E_INVALID_ARG;
+    if ((int64_t)stride < (int64_t)width * bpp) return FID_E_INVALID_ARG;  // (64-bit: width * bpp wraps for absurd widths)
     if (out_bytes < (int64_t)width * height * 3) return FID_E_CAPACITY;
     const bool swap = enc == FID_ENC_RGB8 || enc == FID_ENC_RGBA8;
     for (int y = 0; y < height; y++) {
@@ -133,10 +146,11 @@ fid_status fid_to_bgr(const uint8_t *img, int32_t width, int32_t height, int32_t
 fid_status fid_draw_detected_markers(uint8_t *bgr, int32_t width, int32_t height, int32_t stride, const fid_marker *markers, int32_t n,
                                      uint32_t flags)
 {
-    if (!bgr || width < 1 || height < 1 || stride < width * 3 || n < 0 || (n > 0 && !markers)) return FID_E_INVALID_ARG;
+    if (!bgr || width < 1 || height < 1 || (int64_t)stride < (int64_t)width * 3 || n < 0 || (n > 0 && !markers)) return FID_E_INVALID_ARG;
     if (flags & ~(uint32_t)FID_DRAW_FIRST_CORNER_LINE8) return FID_E_INVALID_ARG;
-    // borderColor = Scalar(0, 255, 0) (the default imageCallback leaves in place); cornerColor = border with G and B swapped
-    const uint8_t border[3] = {0, 255, 0}, corner[3] = {255, 0, 0};
+    // borderColor = Scalar(0, 255, 0) (the default imageCallback leaves in place); cornerColor = borderColor with val[1] and
+    // val[2] swapped (drawDetectedMarkers; its own comment says "G and B", the code swaps G and R): (0, 0, 255) = red in BGR
+    const uint8_t border[3] = {0, 255, 0}, corner[3] = {0, 0, 255};
     for (int i = 0; i < n; i++) {
         const float *c = markers[i].corners;
         for (int j = 0; j < 4; j++) {

@@ -8,7 +8,12 @@ import numpy as np
 
 
 def cv_round(v) -> int:
-    return int(np.rint(np.float32(v)))  # round half to even, as cvRound under the default rounding mode
+    """saturate_cast<int>(float) = cvRound = cvtss2si on x86-64: round half to even; NaN, +-inf and values outside the int range
+    give the 'integer indefinite' INT_MIN."""
+    v = np.float32(v)
+    if not (v >= np.float32(-2147483648.0) and v < np.float32(2147483648.0)):
+        return -2147483648
+    return int(np.rint(v))
 
 
 def clip_line(w, h, p1, p2):
@@ -49,6 +54,8 @@ def line8_pixels(w, h, p1, p2):
         ok, (x1, y1), (x2, y2) = clip_line(w, h, (x1, y1), (x2, y2))
         if not ok:
             return []
+        if not (0 <= x1 < w and 0 <= x2 < w and 0 <= y1 < h and 0 <= y2 < h):
+            return []  # clipLine's double arithmetic near +-2^31 (the reference writes outside its image there: left out)
     if x2 < x1:  # left to right
         x1, y1, x2, y2 = x2, y2, x1, y1
     dx, dy = x2 - x1, y2 - y1

@@ -142,6 +142,60 @@ def test_a_refused_host_batch_queues_no_copy_and_leaves_the_context_usable():
             b.close()
 
 
+def test_every_refusal_drops_the_order_and_keeps_the_layout_of_the_last_call_that_ran():
+    """Round-4 advisor: the refusals in front of check_call (null pointer, too many frames, a frame stride smaller than a frame,
+    a batch in flight) returned with the order of fid_order_after still set -- the next good call then waited on an event of a
+    context that may be gone -- and a refused call that had already laid the result block out for ITS frame count left
+    fid_pose_last / fid_tap_read addressing the wrong layout."""
+    import ctypes as C
+
+    torch = pytest.importorskip("torch")
+    d = get_predefined_dictionary(6)
+    a = ArucoDetector(6, max_width=640, max_height=480, max_batch=2, max_markers=32)
+    b = ArucoDetector(6, max_width=640, max_height=480, max_batch=2, max_markers=32)
+    K = K_DEFAULT.copy()
+    K[0, 0] = K[1, 1] = 1400.0 * 640 / 1920
+    K[0, 2], K[1, 2] = 320.0, 240.0
+    try:
+        frames = np.stack([make_frame(d, 4200 + i, width=640, height=480, n_markers=4, side_range=(60, 110)).image for i in range(2)])
+        want = [oracle.detect(f, d) for f in frames]
+        res0 = a.detect_markers_batch(frames)
+        poses0 = a.pose_last(0.14, K, np.zeros(5))
+        counts0 = a.tap_counts().copy()
+        L, ptr = a._L, frames.ctypes.data
+        dev = torch.from_numpy(frames).cuda()
+        b.submit_batch(frames)
+        refusals = [
+            lambda: L.fid_submit_batch(a._ctx, None, 2, 640, 480, 640, 640 * 480, 0),                 # no image
+            lambda: L.fid_submit_batch(a._ctx, ptr, 3, 640, 480, 640, 640 * 480, 0),                  # more than max_batch
+            lambda: L.fid_submit_batch(a._ctx, ptr, 2, 640, 480, 640, 640 * 479, 0),                  # frame stride < a frame
+            lambda: L.fid_submit_batch(a._ctx, ptr, 1, 641, 480, 641, 641 * 480, 0),                  # wider than the context
+            lambda: L.fid_submit_device(a._ctx, None, 2, 640, 480, 640, 640 * 480, 0),
+            lambda: L.fid_submit_device(a._ctx, C.c_void_p(dev.data_ptr()), 1, 640, 481, 640, 640 * 481, 0),
+            lambda: L.fid_detect_device(a._ctx, None, 2, 640, 480, 640, 640 * 480, 0, a._out, a.max_markers, a._n),
+            lambda: L.fid_detect_device(a._ctx, C.c_void_p(dev.data_ptr()), 1, 640, 480, 600, 640 * 480, 0, a._out, a.max_markers, a._n),
+            lambda: L.fid_detect_batch(a._ctx, ptr, 1, 640, 480, 640, 100, 0, a._out, a.max_markers, a._n),
+        ]
+        for k, call in enumerate(refusals):
+            a._check(L.fid_order_after(a._ctx, b._ctx))
+            assert call() != 0, k
+            # the layout is still the one of the two-frame call: the same counters, the same poses
+            assert np.array_equal(a.tap_counts(), counts0), k
+            p = a.pose_last(0.14, K, np.zeros(5))
+            assert all(np.array_equal(p[f].tvecs, poses0[f].tvecs) for f in range(2)), k
+        resb = b.collect()
+        b.close()  # (b's events are gone now: a stale order would wait on a destroyed event)
+        b = None
+        res1 = a.detect_markers_device(dev.data_ptr(), 2, 640, 480)
+        for res in (res0, res1, resb):
+            for (corners, ids), (oids, ocorners) in zip(res, want):
+                assert ids.tolist() == oids.tolist() and np.array_equal(corners, ocorners)
+    finally:
+        a.close()
+        if b is not None:
+            b.close()
+
+
 def test_a_blocking_host_call_behind_fid_order_after_and_alone_give_the_same():
     """fid_detect_batch of one piece copies on the context's main stream behind the clear of its result block (no copy
     stream, no event); when fid_order_after has told the context to wait for another one's batch, it takes the copy-stream

@@ -58,10 +58,48 @@ def test_draw_detected_markers_equals_the_restatement():
     # every drawn pixel is the border colour, nothing else changed
     changed = (got != base).any(axis=2)
     assert (got[changed] == (0, 255, 0)).all()
-    # the optional first-corner square (LINE_8, not the reference's anti-aliased pixels) only ever adds blue pixels
+    # the optional first-corner square (LINE_8, not the reference's anti-aliased pixels) only ever adds RED pixels
+    # (drawDetectedMarkers: cornerColor = borderColor with val[1] and val[2] swapped = (0, 0, 255) in BGR)
     both = overlay.draw_detected_markers(base.copy(), quads, None, overlay.FIRST_CORNER_LINE8)
     extra = (both != got).any(axis=2)
-    assert extra.any() and (both[extra] == (255, 0, 0)).all()
+    assert extra.any() and (both[extra] == (0, 0, 255)).all()
+
+
+def test_draw_corners_outside_the_int_range():
+    """CORNER_REFINE_CONTOUR crosses two fitted lines: near-parallel ones give huge, infinite or NaN corners, and imageCallback
+    hands them straight to drawDetectedMarkers.  Point2f -> Point is cvtss2si there (INT_MIN for all of them); the lines are
+    clipped in 64-bit arithmetic and nothing is written outside the image (round-4 advisor: a segfault before the fix)."""
+    W, H = 320, 240
+    bad = [np.inf, -np.inf, np.nan, 1e18, -1e18, 3e9, -3e9, 2147483648.0, -2147483904.0, 2147483520.0]
+    rng = np.random.default_rng(5)
+    base = rng.integers(0, 256, (H + 2, W, 3), dtype=np.uint8)  # a guard row above and below the image that is drawn on
+    for trial in range(200):
+        q = rng.uniform([0, 0], [W, H], (4, 2)).astype(np.float32)
+        for _ in range(int(rng.integers(1, 4))):
+            q[rng.integers(0, 4), rng.integers(0, 2)] = bad[int(rng.integers(0, len(bad)))]
+        img = base.copy()
+        view = img[1:H + 1]
+        got = overlay.draw_detected_markers(view, q[None], None, overlay.FIRST_CORNER_LINE8 if trial & 1 else 0)
+        assert np.array_equal(img[0], base[0]) and np.array_equal(img[H + 1], base[H + 1])
+        if not trial & 1:
+            want = odraw.draw_detected_markers(base[1:H + 1].copy(), q[None])
+            assert np.array_equal(got, want)
+    assert odraw.cv_round(np.nan) == odraw.cv_round(np.inf) == odraw.cv_round(-1e18) == -2**31
+    assert odraw.cv_round(2147483520.0) == 2147483520 and odraw.cv_round(-2147483648.0) == -2**31
+
+
+def test_draw_stride_checks_are_64_bit():
+    from fiducials_amd import _lib
+    import ctypes as C
+
+    L = _lib.load()
+    buf = np.zeros(64, np.uint8)
+    # width * 3 wraps to a negative 32-bit number for these widths: the call must be refused, not run
+    for w in (715827883, 1431655766, 2**31 - 1):
+        rc = L.fid_draw_detected_markers(buf.ctypes.data_as(C.c_void_p), w, 1, 16, None, 0, 0)
+        assert rc != 0, w
+        rc = L.fid_to_bgr(buf.ctypes.data_as(C.c_void_p), w, 1, 16, 1, buf.ctypes.data_as(C.c_void_p), C.c_int64(64))
+        assert rc != 0, w
 
 
 def test_draw_refuses_bad_arguments():

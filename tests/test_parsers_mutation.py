@@ -146,3 +146,29 @@ def test_dict_load_file_survives_damaged_tables(tmp_path):
         except _lib.FidError:
             bad += 1
     assert ok > 20 and bad > 20
+
+
+def test_dict_yaml_absurd_count_is_refused_quickly_and_order_does_not_matter(tmp_path):
+    """Round-4 advisor: 'nmarkers: 2000000000' zero-filled tens of GB before the first marker_<i> look-up failed, and every
+    marker was searched from the top of the file.  The count is now bounded by what the file can hold, the search resumes
+    behind the previous marker, and a file whose markers are out of order still loads."""
+    import time
+
+    marks = [f'marker_{i}: "{"".join(str((i * 5 + k) % 2) for k in range(16))}"\n' for i in range(6)]
+    p = tmp_path / "absurd.yml"
+    p.write_bytes(("%YAML:1.0\n---\nnmarkers: 2000000000\nmarkersize: 4\nmaxCorrectionBits: 1\n" + "".join(marks)).encode())
+    t = time.perf_counter()
+    with pytest.raises(_lib.FidError):
+        load_dictionary_file(str(p), -1)
+    assert time.perf_counter() - t < 1.0
+    fwd = tmp_path / "fwd.yml"
+    fwd.write_bytes(("%YAML:1.0\n---\nnmarkers: 6\nmarkersize: 4\nmaxCorrectionBits: 1\n" + "".join(marks)).encode())
+    rev = tmp_path / "rev.yml"
+    rev.write_bytes(("%YAML:1.0\n---\nnmarkers: 6\nmarkersize: 4\nmaxCorrectionBits: 1\n" + "".join(reversed(marks))).encode())
+    a, b = load_dictionary_file(str(fwd), -1), load_dictionary_file(str(rev), -1)
+    assert a.n_markers == b.n_markers == 6 and np.array_equal(a.bytes_list, b.bytes_list)
+    big = tmp_path / "big.txt"
+    with open(big, "wb") as fh:  # larger than the 64 MB cap: refused, not silently cut off
+        fh.write(b"# filler\n" * (8 << 20))
+    with pytest.raises(_lib.FidError):
+        load_dictionary_file(str(big), 6)

@@ -81,7 +81,7 @@ SYMBOLS = [
     "fid_default_params", "fid_default_limits", "fid_create", "fid_destroy", "fid_set_params", "fid_detect",
     "fid_detect_batch", "fid_detect_device", "fid_submit_device", "fid_submit_batch", "fid_collect", "fid_order_after", "fid_pose", "fid_pose_last", "fid_refine_contour_corners", "fid_tap_bytes", "fid_tap_read",
     "fid_last_stage_ms", "fid_last_launches", "fid_stream", "fid_strerror", "fid_last_error", "fid_abi_version",
-    "fid_stag_create", "fid_stag_destroy", "fid_stag_edge_frontend", "fid_stag_detect_edges", "fid_stag_detect_edges_validated", "fid_stag_detect_lines", "fid_stag_detect_lines_validated", "fid_stag_detect_quads", "fid_stag_host_tables", "fid_stag_load_library", "fid_stag_detect_markers_unrefined", "fid_stag_detect_markers", "fid_stag_pose_last", "fid_stag_detect_markers_batch", "fid_stag_tap_bytes", "fid_stag_tap_read",
+    "fid_stag_create", "fid_stag_destroy", "fid_stag_edge_frontend", "fid_stag_detect_edges", "fid_stag_detect_edges_validated", "fid_stag_detect_lines", "fid_stag_detect_lines_validated", "fid_stag_detect_quads", "fid_stag_host_tables", "fid_stag_load_library", "fid_stag_detect_markers_unrefined", "fid_stag_detect_markers", "fid_stag_pose_last", "fid_stag_detect_markers_batch", "fid_stag_tap_bytes", "fid_stag_tap_read", "fid_stag_queue_stats",
     "fid_jpeg_probe", "fid_jpeg_create", "fid_jpeg_destroy", "fid_jpeg_decode", "fid_jpeg_device_ptr", "fid_jpeg_tap_bytes", "fid_jpeg_tap_read",
     "fid_jpeg_last_rounds", "fid_jpeg_last_error",
     "fid_png_probe", "fid_png_decode", "fid_png_last_error",
@@ -167,6 +167,7 @@ def load():
     L.fid_stag_tap_bytes.argtypes = [vp, C.c_int]
     L.fid_stag_tap_bytes.restype = i64
     L.fid_stag_tap_read.argtypes = [vp, C.c_int, vp, i64]
+    L.fid_stag_queue_stats.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
     L.fid_jpeg_probe.argtypes = [vp, i64, C.POINTER(FidJpegInfo)]
     L.fid_jpeg_create.argtypes = [i32, i32, i32, i32, C.POINTER(vp)]
     L.fid_jpeg_destroy.argtypes = [vp]

@@ -428,6 +428,14 @@ static void stag_fill_code_locations(double *locs /* [72][3] */)
 }
 
 #define STAG_PIN_MARKERS 512  // results of a frame staged through pinned memory (more than that: a blocking copy)
+// What the launches of a frame are sized by when the frame is queued ahead of its own counts: anchors, components, output-arena
+// pixels, most anchors in one component, largest LDS tile, edge segments, validated segments, lines, validated lines, quads, markers
+struct StagPred {
+    bool valid = false;
+    int W = 0, H = 0;
+    int na = 0, nc = 0, aout = 0, most = 0, tile = 0, ns = 0, nvs = 0, nl = 0, nvl = 0, nq = 0, nm = 0;
+};
+
 struct fid_stag_ctx {
     int device = 0, maxW = 0, maxH = 0, libraryHD = 0, errorCorrection = 0;
     hipStream_t stream = nullptr;
@@ -499,10 +507,16 @@ struct fid_stag_ctx {
     struct Pinned {
         unsigned n_anchors;
         int cur[11], rcount[3], ovf, n_vsegs, np, n_lines, n_vlines, n_quads, n_markers;
+        int spec_bad;  // (a frame queued ahead: a count exceeded what its launches were sized for)
         fid_stag_marker markers[STAG_PIN_MARKERS];
         fid_stag_pose_out poses[STAG_PIN_MARKERS];
     } *hp = nullptr;
     uint8_t *h_src = nullptr;  // pinned staging of the input frame (host rows -> here -> one asynchronous DMA)
+    // a frame QUEUED AHEAD (round 5): the counts of the last frame this context finished size the next frame's launches, so that
+    // the whole frame is enqueued without a host wait (stag_advance_impl)
+    StagPred pred;
+    int *d_specbad = nullptr;
+    int spec_frames = 0, spec_misses = 0;
 };
 
 extern "C" {
@@ -593,6 +607,7 @@ fid_status fid_stag_create(int libraryHD, int errorCorrection, int max_width, in
     ok = ok && hipMalloc((void **)&c->d_locs, 72 * 3 * 8) == hipSuccess && hipMalloc((void **)&c->d_cand, (n / 9 + 16) * sizeof(fid_stag_marker)) == hipSuccess &&
          hipMalloc((void **)&c->d_markers, (n / 9 + 16) * sizeof(fid_stag_marker)) == hipSuccess &&
          hipMalloc((void **)&c->d_found, (n / 9 + 16) * 4) == hipSuccess && hipMalloc((void **)&c->d_nmarkers, 4) == hipSuccess;
+    ok = ok && hipMalloc((void **)&c->d_specbad, 16) == hipSuccess && hipMemset(c->d_specbad, 0, 16) == hipSuccess;
     ok = ok && hipMalloc((void **)&c->d_chosen, (n / 9 + 16) * 4) == hipSuccess &&
          hipMalloc((void **)&c->d_poses, (n / 9 + 16) * sizeof(fid_stag_pose_out)) == hipSuccess;
     ok = ok && hipHostMalloc((void **)&c->hp, sizeof(fid_stag_ctx::Pinned), hipHostMallocDefault) == hipSuccess &&
@@ -635,7 +650,7 @@ void fid_stag_destroy(fid_stag_ctx *c)
                    c->d_prefix, c->d_lslots, c->d_lines, c->d_lcounts, c->d_ltotal,
                    c->d_atan_lut, c->d_kmin, c->d_lflags, c->d_vltotal, c->d_vlines,
                    c->d_lrange, c->d_corners, c->d_order, c->d_qcounts, c->d_qtotal, c->d_qslots, c->d_quads,
-                   c->d_locs, c->d_words, c->d_cand, c->d_markers, c->d_found, c->d_nmarkers, c->d_chosen, c->d_poses};
+                   c->d_locs, c->d_words, c->d_cand, c->d_markers, c->d_found, c->d_nmarkers, c->d_chosen, c->d_poses, c->d_specbad};
     for (void *p : dev)
         if (p) (void)hipFree(p);
     if (c->hp) {
@@ -681,6 +696,10 @@ struct StagJob {
     fid_status rc = FID_OK;
     int cur[11] = {0}, ovf = 0;
     StagRoute R;
+    // queued ahead: every launch of the frame sized by j.use (the context's last counts with a margin), one wait at the end
+    bool spec = false, nospec = false;
+    StagPred use;
+    int lds_cap = 0;
 };
 
 static hipStream_t stag_stream(fid_stag_ctx *c)
@@ -721,6 +740,85 @@ static bool stag_launch_route_seq(fid_stag_ctx *c, StagJob &j)
     return true;
 }
 
+// ---- frames queued ahead (round 5).  The nine waits of a frame exist because the host sizes the next launches by counts the
+// device has just produced.  Every kernel behind such a count reads it from device memory and returns beyond it, so the grid only
+// has to be LARGE ENOUGH: a context that has finished a frame sizes the next frame's launches (grids, fills, clears, the LDS tile,
+// the result copies) by that frame's counts plus a margin and enqueues the WHOLE frame -- segments 0 to 7 in one go, no wait in
+// between; k_stag_spec_guard stands where each read-back stood (fid_stag_route.hip).  One wait at the end; the host then checks
+// every true count against what it had assumed (and the device flag): a frame that did not fit is run again on the counted road
+// from its first segment -- same result either way, the counted road is what the staged entry points and every first frame use.
+// FID_STAG_SPEC=0 keeps every frame on the counted road.
+// Default (FID_STAG_SPEC unset): frame-at-a-time calls are queued ahead, GROUPS stay on the counted road -- measured on the
+// cfg 5 batch (256 frames, 128 slots, runtime-default hardware queues; tools/gpu_r5_stag.sh): counted 5 030 / 4 510 / 5 050
+// frames/s against 4 950 / 4 400 / 4 860 queued ahead.  A group's waits were never the limit there (eight groups on eight host
+// threads: one group's wait runs under the others' kernels; the step is the sum of the latency-bound kernels, two to three of
+// which run side by side), and a frame that outgrows its slot's last counts costs a second pass.  FID_STAG_SPEC=1: both; 0: neither.
+static bool stag_spec_enabled(bool grouped)
+{
+    const char *e = getenv("FID_STAG_SPEC");  // (read per frame: the tests switch roads inside one process)
+    if (!e) return !grouped;
+    return atoi(e) != 0;
+}
+static void stag_plan(const fid_stag_ctx *c, StagJob &j)
+{
+    const StagPred &p = c->pred;
+    const long long n = (long long)c->maxW * c->maxH;
+    auto up = [](long long v, long long slack, long long cap) { const long long x = v + v / 2 + slack; return (int)(x < cap ? x : cap); };
+    StagPred &u = j.use;
+    u = p;
+    u.na = up(p.na, 1024, n);
+    u.nc = up(p.nc, 64, c->max_comps);
+    u.aout = up(p.aout, 8192, 3 * n);
+    u.most = p.most * 2 < 65536 ? p.most * 2 : 65536;  // (above STAG_SORT_WAVE: the workgroup sort is launched as well)
+    u.tile = p.tile + p.tile / 4;                      // (capped by the road's LDS limit where it is used; too small only costs time)
+    u.ns = up(p.ns, 256, n / 8 + 16);
+    u.nvs = up(p.nvs, 256, n / 8 + 15);
+    u.nl = up(p.nl, 256, n / 9 + 16);
+    u.nvl = up(p.nvl, 256, n / 9 + 16);
+    u.nq = up(p.nq, 64, n / 9 + 16);
+    u.nm = up(p.nm, 16, STAG_PIN_MARKERS);
+}
+// the counts of a frame that went through on the component-parallel road become the next frame's sizes
+static void stag_learn(fid_stag_ctx *c, const StagJob &j, bool parallel_road)
+{
+    StagPred &p = c->pred;
+    p.valid = parallel_road && c->n_anchors > 0 && c->n_markers <= STAG_PIN_MARKERS;
+    p.W = c->W; p.H = c->H;
+    p.na = (int)c->n_anchors; p.nc = j.cur[0]; p.aout = j.cur[5]; p.most = j.cur[9]; p.tile = j.cur[10];
+    p.ns = c->rcount[0]; p.nvs = c->n_vsegs; p.nl = c->n_lines; p.nvl = c->n_vlines; p.nq = c->n_quads; p.nm = c->n_markers;
+}
+// (queued ahead: the guard also carries the true counts to the pinned block -- M0..M2 = {host field, device source, ints}; the
+//  counted road keeps its copies)
+struct StagMirror {
+    void *dst;
+    const void *src;
+    int n;
+};
+static bool stag_guard_fill(fid_stag_ctx *c, int reset, StagGuard &g, StagMirror m0, StagMirror m1 = {nullptr, nullptr, 0}, StagMirror m2 = {nullptr, nullptr, 0})
+{
+    const StagMirror m[3] = {m0, m1, m2};
+    g.reset = reset;
+    g.bad = c->d_specbad;
+    g.bad_host = (int *)stag_device_alias(&c->hp->spec_bad, 4);
+    if (!g.bad_host) return false;
+    for (int k = 0; k < 3; k++) {
+        g.mdst[k] = m[k].dst ? (int *)stag_device_alias(m[k].dst, (size_t)m[k].n * 4) : nullptr;
+        g.msrc[k] = (const int *)m[k].src;
+        g.mn[k] = m[k].n;
+        if (m[k].dst && !g.mdst[k]) return false;
+    }
+    return true;
+}
+// (the launch stands AT the call site: merged launches go out in site order, and a site inside a helper above its callers would
+//  come back to a lower site number every time -- stag_order_guard would then issue everything recorded so far, unmerged)
+#define STAG_GUARD_OR_FAIL(reset_, g_, ...)                                                                \
+    do {                                                                                                   \
+        StagGuard gg_ = g_;                                                                                \
+        if (!stag_guard_fill(c, reset_, gg_, __VA_ARGS__)) return stag_finish(j, FID_E_HIP);               \
+        STAG_LAUNCH(k_stag_spec_guard, dim3(1), dim3(64), 0, st, gg_);                                     \
+        if (hipGetLastError() != hipSuccess) return stag_finish(j, FID_E_HIP);                             \
+    } while (0)
+
 // one segment of the job; FID_OK while the job is under way or has finished well (j.done tells which)
 #ifdef FID_DEBUG_STATS
 static std::atomic<long long> g_stag_ns_sync(0), g_stag_ns_seg[12];
@@ -756,11 +854,15 @@ static fid_status stag_advance_impl(fid_stag_ctx *c, StagJob &j)
     if (j.seg > 0 && !grouped && hipStreamSynchronize(st) != hipSuccess) return stag_finish(j, FID_E_HIP);
 #endif
     const int GRADIENT_THRESH = 16, ANCHOR_THRESH = 0, SCAN_INTERVAL = 1;  // DetectEdgesByEDPF, ED.cpp:155-169
+    for (;;) {  // (a frame queued ahead passes all its segments in this one call: "continue" where the counted road returns)
     switch (j.seg) {
     case 0: {  // ---- smoothing, gradient, anchors, anchor sort
         if (!j.gray || j.width < 8 || j.height < 8 || j.width > c->maxW || j.height > c->maxH || j.stride < j.width) return stag_finish(j, FID_E_INVALID_ARG);
         if (j.last >= SS_UNREFINED && !c->d_words) return stag_finish(j, FID_E_INVALID_ARG);  // no marker library loaded
         const int W = j.width, H = j.height;
+        j.spec = stag_spec_enabled(grouped) && !j.nospec && j.last >= SS_MARKERS && c->route_mode == 1 && c->pred.valid && c->pred.W == W && c->pred.H == H &&
+                 (!j.out || j.cap > 0) && stag_device_alias(c->hp, sizeof(fid_stag_ctx::Pinned)) != nullptr;
+        if (j.spec) stag_plan(c, j);
         for (int y = 0; y < H; y++) memcpy(c->h_src + (size_t)y * W, j.gray + (size_t)y * j.stride, (size_t)W);
         if (STAG_MEMCPY(c->d_src, c->h_src, (size_t)W * H, hipMemcpyHostToDevice, st) != hipSuccess) return stag_finish(j, FID_E_HIP);
         if (STAG_MEMSET(c->d_rowhist, 0, (size_t)H * STAG_BINS * 4, st) != hipSuccess) return stag_finish(j, FID_E_HIP);
@@ -775,17 +877,22 @@ static fid_status stag_advance_impl(fid_stag_ctx *c, StagJob &j)
         STAG_LAUNCH(k_stag_place, dim3(nbands), dim3(64 * STAG_BAND_ROWS), 0, st, c->d_grad, c->d_edge, W, H, c->d_rowhist, c->d_bandhist,
                            c->d_bstart, c->d_sorted);
         if (hipGetLastError() != hipSuccess) return stag_finish(j, FID_E_HIP);
-        if (STAG_MEMCPY(&c->hp->n_anchors, c->d_n, 4, hipMemcpyDeviceToHost, st) != hipSuccess) return stag_finish(j, FID_E_HIP);
+        if (!j.spec && STAG_MEMCPY(&c->hp->n_anchors, c->d_n, 4, hipMemcpyDeviceToHost, st) != hipSuccess) return stag_finish(j, FID_E_HIP);
+        if (j.spec) {
+            const StagGuard g = {{(int *)c->d_n}, {j.use.na}, {(int *)c->d_n}, 1, 1};
+            STAG_GUARD_OR_FAIL(1, g, {&c->hp->n_anchors, c->d_n, 1});
+        }
         j.seg = 1;
-        return FID_OK;
+        if (!j.spec) return FID_OK;
+        continue;
     }
     case 1: {  // ---- routing: the component-parallel road up to the component table (or the sequential road)
-        c->n_anchors = c->hp->n_anchors;
+        if (!j.spec) c->n_anchors = c->hp->n_anchors;  // (queued ahead: the true counts are taken over at the frame's one wait)
         c->W = j.width;
         c->H = j.height;
         c->routed = false;
         if (j.last == SS_FRONTEND) return stag_finish(j, FID_OK);
-        const int W = c->W, H = c->H, n = W * H, na = (int)c->n_anchors;
+        const int W = c->W, H = c->H, n = W * H, na = j.spec ? j.use.na : (int)c->n_anchors;
         StagRoute &R = j.R;
         R.grad = c->d_grad; R.dir = c->d_dir; R.edge = c->d_edgeimg; R.W = W; R.H = H;
         R.pix = c->d_rpix; R.stack = c->d_rstack; R.chains = c->d_chains; R.chainNos = c->d_chainnos;
@@ -839,15 +946,32 @@ static fid_status stag_advance_impl(fid_stag_ctx *c, StagJob &j)
         static const int tile_kb_env = [] { const char *e = getenv("FID_STAG_TILE_KB"); return e ? atoi(e) : 0; }();
         const int tile_kb = tile_kb_env > 0 ? tile_kb_env : (grouped ? 40 : 150);
         const int LDS_CAP = (tile_kb < 8 ? 8 : (tile_kb > 150 ? 150 : tile_kb)) * 1024;
+        j.lds_cap = LDS_CAP;
         STAG_LAUNCH(k_stag_comp_tilemax, dim3((c->max_comps + 255) / 256), dim3(256), 0, st, c->d_comps, c->d_cursors, LDS_CAP);
         if (hipGetLastError() != hipSuccess) return stag_finish(j, FID_E_HIP);
-        if (STAG_MEMCPY(c->hp->cur, c->d_cursors, 44, hipMemcpyDeviceToHost, st) != hipSuccess) return stag_finish(j, FID_E_HIP);
+        if (!j.spec && STAG_MEMCPY(c->hp->cur, c->d_cursors, 44, hipMemcpyDeviceToHost, st) != hipSuccess) return stag_finish(j, FID_E_HIP);
+        if (j.spec) {
+            // (components, output-arena pixels, the allocation overflow flag, most anchors in one component against the sort that is launched)
+            const StagGuard g = {{c->d_cursors, c->d_cursors + 5, c->d_cursors + 7, c->d_cursors + 9},
+                                 {j.use.nc, j.use.aout, 0, j.use.most > STAG_SORT_WAVE ? 65536 : STAG_SORT_WAVE},
+                                 {c->d_cursors, (int *)c->d_n}, 4, 2};
+            STAG_GUARD_OR_FAIL(0, g, {c->hp->cur, c->d_cursors, 11});
+        }
         j.rstate = RS_PAR_A;
-        return FID_OK;
+        if (!j.spec) return FID_OK;
+        continue;
     }
     case 2: {  // ---- routing, second half; then edge validation
         if (j.rstate == RS_PAR_A) {
-            memcpy(j.cur, c->hp->cur, sizeof(j.cur));
+            if (j.spec) {
+                memset(j.cur, 0, sizeof(j.cur));
+                j.cur[0] = j.use.nc;
+                j.cur[5] = j.use.aout;
+                j.cur[9] = j.use.most;
+                j.cur[10] = j.use.tile < j.lds_cap ? j.use.tile : j.lds_cap;
+            } else {
+                memcpy(j.cur, c->hp->cur, sizeof(j.cur));
+            }
             const int *cur = j.cur;
             // an arena too small, or one component holding (nearly) all anchors -- a frame of noise -- which leaves nothing to
             // run side by side (sorting its anchors would cost more than the sequential road's single pass over the globally
@@ -856,7 +980,7 @@ static fid_status stag_advance_impl(fid_stag_ctx *c, StagJob &j)
                 c->route_fallbacks++;
                 return stag_launch_route_seq(c, j) ? FID_OK : stag_finish(j, FID_E_HIP);
             }
-            const int na = (int)c->n_anchors;
+            const int na = j.spec ? j.use.na : (int)c->n_anchors;
             // pixels of the output arena the extraction does not write read as (-1, -1), like the reference's untouched array
             if (cur[5] > 0 && STAG_MEMSET(c->d_aout, 0xff, (size_t)cur[5] * sizeof(int2), st) != hipSuccess) return stag_finish(j, FID_E_HIP);
             const int nc = cur[0];
@@ -886,13 +1010,18 @@ static fid_status stag_advance_impl(fid_stag_ctx *c, StagJob &j)
             STAG_LAUNCH(k_stag_route_gather, dim3((na + 3) / 4), dim3(256), 0, st, A, c->d_comps, c->d_n, c->d_prodflag, c->d_blkpix, c->d_blksegs,
                                c->d_blkwhere, c->d_outpix, c->d_segs, j.R.capOut, j.R.capSegs, ovf);
             if (hipGetLastError() != hipSuccess) return stag_finish(j, FID_E_HIP);
-            if (STAG_MEMCPY(c->hp->rcount, c->d_rcount, 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
-                STAG_MEMCPY(&c->hp->ovf, ovf, 4, hipMemcpyDeviceToHost, st) != hipSuccess)
+            if (!j.spec && (STAG_MEMCPY(c->hp->rcount, c->d_rcount, 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
+                            STAG_MEMCPY(&c->hp->ovf, ovf, 4, hipMemcpyDeviceToHost, st) != hipSuccess))
                 return stag_finish(j, FID_E_HIP);
+            if (j.spec) {
+                const StagGuard g = {{c->d_rcount, ovf}, {j.use.ns, 0}, {c->d_rcount, c->d_rcount + 1}, 2, 2};
+                STAG_GUARD_OR_FAIL(0, g, {c->hp->rcount, c->d_rcount, 2}, {&c->hp->ovf, ovf, 1});
+            }
             j.rstate = RS_PAR_B;
-            return FID_OK;  // (this segment again, with the second half's counts)
+            if (!j.spec) return FID_OK;  // (this segment again, with the second half's counts)
+            continue;
         }
-        if (j.rstate == RS_PAR_B) {
+        if (j.rstate == RS_PAR_B && !j.spec) {
             j.ovf = c->hp->ovf;
             c->rcount[0] = c->hp->rcount[0];
             c->rcount[1] = c->hp->rcount[1];
@@ -912,7 +1041,7 @@ static fid_status stag_advance_impl(fid_stag_ctx *c, StagJob &j)
         if (j.last == SS_EDGES) return stag_finish(j, FID_OK);
         const int W = c->W, H = c->H;
         const size_t n = (size_t)W * H;
-        const int ns = c->rcount[0];
+        const int ns = j.spec ? j.use.ns : c->rcount[0];
         // ValidateEdgeSegments starts from an empty edge image (ValidateEdgeSegments.cpp:370)
         if (STAG_MEMSET(c->d_edgeimg, 0, n, st) != hipSuccess || STAG_MEMSET(c->d_vhist, 0, STAG_BINS * 4, st) != hipSuccess) return stag_finish(j, FID_E_HIP);
         STAG_LAUNCH(k_stag_smooth3_prewitt, dim3((W + SX - 1) / SX, (H + SY - 1) / SY), dim3(256), 0, st, c->d_src, W, W, H, c->d_smooth2,
@@ -930,19 +1059,26 @@ static fid_status stag_advance_impl(fid_stag_ctx *c, StagJob &j)
             STAG_LAUNCH(k_stag_extract, dim3(wg), dim3(256), 0, st, c->d_segs, c->d_rcount, c->d_outpix, c->d_edgeimg, W, c->d_vcounts,
                                c->d_vsegs, 1);
         if (hipGetLastError() != hipSuccess) return stag_finish(j, FID_E_HIP);
-        if (STAG_MEMCPY(&c->hp->n_vsegs, c->d_vtotal, 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
-            STAG_MEMCPY(&c->hp->np, c->d_np, 4, hipMemcpyDeviceToHost, st) != hipSuccess)
+        if (!j.spec && (STAG_MEMCPY(&c->hp->n_vsegs, c->d_vtotal, 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
+                        STAG_MEMCPY(&c->hp->np, c->d_np, 4, hipMemcpyDeviceToHost, st) != hipSuccess))
             return stag_finish(j, FID_E_HIP);
+        if (j.spec) {
+            const StagGuard g = {{c->d_vtotal}, {j.use.nvs}, {c->d_vtotal}, 1, 1};
+            STAG_GUARD_OR_FAIL(0, g, {&c->hp->n_vsegs, c->d_vtotal, 1}, {&c->hp->np, c->d_np, 1});
+        }
         j.seg = 3;
-        return FID_OK;
+        if (!j.spec) return FID_OK;
+        continue;
     }
     case 3: {  // ---- EDLines: split, join, gather
-        c->n_vsegs = c->hp->n_vsegs;
-        c->np = c->hp->np;
+        if (!j.spec) {
+            c->n_vsegs = c->hp->n_vsegs;
+            c->np = c->hp->np;
+        }
         c->validated = true;
         c->lined = false;
         if (j.last == SS_EDGES_VALIDATED) return stag_finish(j, FID_OK);
-        const int ns = c->n_vsegs;
+        const int ns = j.spec ? j.use.nvs : c->n_vsegs;
         c->min_line_len = stag_min_line_len(c->W, c->H);
         StagPrefix PF;
         PF.x = c->d_prefix; PF.y = PF.x + c->prefcap; PF.xx = PF.y + c->prefcap; PF.yy = PF.xx + c->prefcap; PF.xy = PF.yy + c->prefcap;
@@ -954,12 +1090,17 @@ static fid_status stag_advance_impl(fid_stag_ctx *c, StagJob &j)
         if (wg > 0)
             STAG_LAUNCH(k_stag_gather_lines, dim3(wg), dim3(64), 0, st, c->d_vsegs, c->d_vtotal, c->d_lcounts, c->d_ltotal, c->d_lslots, c->d_lines);
         if (hipGetLastError() != hipSuccess) return stag_finish(j, FID_E_HIP);
-        if (STAG_MEMCPY(&c->hp->n_lines, c->d_ltotal, 4, hipMemcpyDeviceToHost, st) != hipSuccess) return stag_finish(j, FID_E_HIP);
+        if (!j.spec && STAG_MEMCPY(&c->hp->n_lines, c->d_ltotal, 4, hipMemcpyDeviceToHost, st) != hipSuccess) return stag_finish(j, FID_E_HIP);
+        if (j.spec) {
+            const StagGuard g = {{c->d_ltotal}, {j.use.nl}, {c->d_ltotal}, 1, 1};
+            STAG_GUARD_OR_FAIL(0, g, {&c->hp->n_lines, c->d_ltotal, 1});
+        }
         j.seg = 4;
-        return FID_OK;
+        if (!j.spec) return FID_OK;
+        continue;
     }
     case 4: {  // ---- line validation
-        c->n_lines = c->hp->n_lines;
+        if (!j.spec) c->n_lines = c->hp->n_lines;
         c->lined = true;
         c->lines_validated = false;
         if (j.last == SS_LINES) return stag_finish(j, FID_OK);
@@ -976,7 +1117,7 @@ static fid_status stag_advance_impl(fid_stag_ctx *c, StagJob &j)
         T.atan_lut = c->d_atan_lut;
         T.kmin = c->d_kmin;
         T.kmin_n = c->kmin_n;
-        const int nl = c->n_lines;
+        const int nl = j.spec ? j.use.nl : c->n_lines;
         if (nl > 0)
             STAG_LAUNCH(k_stag_validate_lines, dim3((nl + 63) / 64), dim3(64), 0, st, c->d_lines, c->d_ltotal, c->d_src, W, H, c->d_vsegs,
                                c->d_outpix, T, c->d_lflags);
@@ -985,16 +1126,21 @@ static fid_status stag_advance_impl(fid_stag_ctx *c, StagJob &j)
             STAG_LAUNCH(k_stag_compact_lines, dim3((nl + 255) / 256), dim3(256), 0, st, c->d_lines, c->d_ltotal, c->d_lflags, c->d_vltotal,
                                c->d_vlines);
         if (hipGetLastError() != hipSuccess) return stag_finish(j, FID_E_HIP);
-        if (STAG_MEMCPY(&c->hp->n_vlines, c->d_vltotal, 4, hipMemcpyDeviceToHost, st) != hipSuccess) return stag_finish(j, FID_E_HIP);
+        if (!j.spec && STAG_MEMCPY(&c->hp->n_vlines, c->d_vltotal, 4, hipMemcpyDeviceToHost, st) != hipSuccess) return stag_finish(j, FID_E_HIP);
+        if (j.spec) {
+            const StagGuard g = {{c->d_vltotal}, {j.use.nvl}, {c->d_vltotal}, 1, 1};
+            STAG_GUARD_OR_FAIL(0, g, {&c->hp->n_vlines, c->d_vltotal, 1});
+        }
         j.seg = 5;
-        return FID_OK;
+        if (!j.spec) return FID_OK;
+        continue;
     }
     case 5: {  // ---- quads
-        c->n_vlines = c->hp->n_vlines;
+        if (!j.spec) c->n_vlines = c->hp->n_vlines;
         c->lines_validated = true;
         c->quadded = false;
         if (j.last == SS_LINES_VALIDATED) return stag_finish(j, FID_OK);
-        const int W = c->W, H = c->H, ns = c->n_vsegs, nl = c->n_vlines;
+        const int W = c->W, H = c->H, ns = j.spec ? j.use.nvs : c->n_vsegs, nl = j.spec ? j.use.nvl : c->n_vlines;
         if (STAG_MEMSET(c->d_lrange, 0, (size_t)(ns + 1) * sizeof(int2), st) != hipSuccess) return stag_finish(j, FID_E_HIP);
         if (nl > 0) STAG_LAUNCH(k_stag_line_ranges, dim3((nl + 255) / 256), dim3(256), 0, st, c->d_vlines, c->d_vltotal, c->d_lrange);
         if (ns > 0)
@@ -1005,26 +1151,58 @@ static fid_status stag_advance_impl(fid_stag_ctx *c, StagJob &j)
             STAG_LAUNCH(k_stag_gather_quads, dim3((ns + 63) / 64), dim3(64), 0, st, c->d_lrange, c->d_vtotal, c->d_qcounts, c->d_qtotal, c->d_qslots,
                                c->d_quads);
         if (hipGetLastError() != hipSuccess) return stag_finish(j, FID_E_HIP);
-        if (STAG_MEMCPY(&c->hp->n_quads, c->d_qtotal, 4, hipMemcpyDeviceToHost, st) != hipSuccess) return stag_finish(j, FID_E_HIP);
+        if (!j.spec && STAG_MEMCPY(&c->hp->n_quads, c->d_qtotal, 4, hipMemcpyDeviceToHost, st) != hipSuccess) return stag_finish(j, FID_E_HIP);
+        if (j.spec) {
+            const StagGuard g = {{c->d_qtotal}, {j.use.nq}, {c->d_qtotal}, 1, 1};
+            STAG_GUARD_OR_FAIL(0, g, {&c->hp->n_quads, c->d_qtotal, 1});
+        }
         j.seg = 6;
-        return FID_OK;
+        if (!j.spec) return FID_OK;
+        continue;
     }
     case 6: {  // ---- code reading, decoding, duplicates
-        c->n_quads = c->hp->n_quads;
+        if (!j.spec) c->n_quads = c->hp->n_quads;
         c->quadded = true;
         c->decoded = false;
         if (j.last == SS_QUADS) return stag_finish(j, FID_OK);
-        const int nq = c->n_quads;
+        const int nq = j.spec ? j.use.nq : c->n_quads;
         if (nq > 0)
             STAG_LAUNCH(k_stag_decode, dim3((nq + 3) / 4), dim3(256), 0, st, c->d_quads, c->d_qtotal, c->d_src, c->W, c->H, c->d_locs, c->d_words,
                                c->n_words, c->errorCorrection, c->d_cand, c->d_found);
         STAG_LAUNCH(k_stag_dedup, dim3(1), dim3(64), 0, st, c->d_cand, c->d_found, c->d_qtotal, c->d_markers, c->d_nmarkers);
         if (hipGetLastError() != hipSuccess) return stag_finish(j, FID_E_HIP);
-        if (STAG_MEMCPY(&c->hp->n_markers, c->d_nmarkers, 4, hipMemcpyDeviceToHost, st) != hipSuccess) return stag_finish(j, FID_E_HIP);
+        if (!j.spec && STAG_MEMCPY(&c->hp->n_markers, c->d_nmarkers, 4, hipMemcpyDeviceToHost, st) != hipSuccess) return stag_finish(j, FID_E_HIP);
+        if (j.spec) {
+            const StagGuard g = {{c->d_nmarkers}, {j.use.nm}, {c->d_nmarkers}, 1, 1};
+            STAG_GUARD_OR_FAIL(0, g, {&c->hp->n_markers, c->d_nmarkers, 1});
+        }
         j.seg = 7;
-        return FID_OK;
+        if (!j.spec) return FID_OK;
+        continue;
     }
     case 7: {  // ---- pose refinement of the markers (and, if asked for, the 5-point pose right behind it)
+        if (j.spec) {
+            // queued ahead: as many workgroups and result slots as the last frame's markers (with the margin); the counts, the
+            // capacity checks and the hand-over wait for the frame's one wait (default:)
+            const int nm = j.use.nm;
+            STAG_LAUNCH(k_stag_refine, dim3(nm), dim3(64), 0, st, c->d_markers, c->d_nmarkers, c->d_vsegs, c->d_vtotal, c->d_outpix, c->d_chosen);
+            if (hipGetLastError() != hipSuccess) return stag_finish(j, FID_E_HIP);
+            if (j.out && STAG_MEMCPY(c->hp->markers, c->d_markers, (size_t)nm * sizeof(fid_stag_marker), hipMemcpyDeviceToHost, st) != hipSuccess)
+                return stag_finish(j, FID_E_HIP);
+            if (j.last == SS_POSE) {
+                PoseCam cam;
+                for (int i = 0; i < 9; i++) cam.K[i] = j.K[i];
+                for (int i = 0; i < 5; i++) cam.D[i] = j.D ? j.D[i] : 0.0;
+                cam.fiducial_len = j.marker_size;
+                STAG_LAUNCH(k_stag_pose, dim3((nm + 3) / 4), dim3(64), 0, st, c->d_markers, c->d_nmarkers, cam, j.marker_size, c->d_poses);
+                if (hipGetLastError() != hipSuccess) return stag_finish(j, FID_E_HIP);
+                if (STAG_MEMCPY(c->hp->poses, c->d_poses, (size_t)nm * sizeof(fid_stag_pose_out), hipMemcpyDeviceToHost, st) != hipSuccess)
+                    return stag_finish(j, FID_E_HIP);
+            }
+            // (the frame's flag is in the pinned block already: every k_stag_spec_guard writes it there)
+            j.seg = 8;
+            return FID_OK;  // (the frame's one wait)
+        }
         c->n_markers = c->hp->n_markers;
         c->decoded = true;
         if (j.last == SS_UNREFINED) return stag_finish(j, FID_OK);
@@ -1061,12 +1239,48 @@ static fid_status stag_advance_impl(fid_stag_ctx *c, StagJob &j)
         return FID_OK;
     }
     default:  // the copies of segment 7 have landed
+        if (j.spec) {
+            // the frame's one wait is over: every true count against what the launches were sized for
+            const fid_stag_ctx::Pinned &h = *c->hp;
+            const StagPred &u = j.use;
+            const bool fits = !h.spec_bad && h.n_anchors > 0 && h.n_anchors <= (unsigned)u.na && h.cur[0] <= u.nc && h.cur[5] <= u.aout && !h.cur[7] &&
+                              h.cur[9] <= (u.most > STAG_SORT_WAVE ? 65536 : STAG_SORT_WAVE) && !h.ovf && h.rcount[0] <= u.ns && h.n_vsegs <= u.nvs &&
+                              h.n_lines <= u.nl && h.n_vlines <= u.nvl && h.n_quads <= u.nq && h.n_markers <= u.nm;
+            c->spec_frames++;
+            if (!fits) {  // the counted road from the first segment: the same result, nine waits
+                c->spec_misses++;
+                c->pred.valid = false;
+                j.spec = false;
+                j.nospec = true;
+                j.seg = 0;
+                j.rstate = RS_NONE;
+                continue;
+            }
+            c->n_anchors = h.n_anchors;
+            memcpy(j.cur, h.cur, sizeof(j.cur));
+            c->rcount[0] = h.rcount[0]; c->rcount[1] = h.rcount[1]; c->rcount[2] = 0;
+            c->n_vsegs = h.n_vsegs; c->np = h.np; c->n_lines = h.n_lines; c->n_vlines = h.n_vlines; c->n_quads = h.n_quads; c->n_markers = h.n_markers;
+            c->routed = c->validated = c->lined = c->lines_validated = c->quadded = c->decoded = true;
+            stag_learn(c, j, true);
+            if ((j.out && c->n_markers > j.cap) || (j.last == SS_POSE && c->n_markers > 0 && c->n_markers > j.pose_cap)) {
+                if (j.n_out) *j.n_out = 0;
+                return stag_finish(j, FID_E_CAPACITY);
+            }
+            if (j.n_out) *j.n_out = c->n_markers;
+            if (c->n_markers > 0) {
+                if (j.out) memcpy(j.out, h.markers, (size_t)c->n_markers * sizeof(fid_stag_marker));
+                if (j.last == SS_POSE && j.poses) memcpy(j.poses, h.poses, (size_t)c->n_markers * sizeof(fid_stag_pose_out));
+            }
+            return stag_finish(j, FID_OK);
+        }
         if (c->n_markers > 0 && c->n_markers <= STAG_PIN_MARKERS) {
             if (j.out) memcpy(j.out, c->hp->markers, (size_t)c->n_markers * sizeof(fid_stag_marker));
             if (j.last == SS_POSE && j.poses) memcpy(j.poses, c->hp->poses, (size_t)c->n_markers * sizeof(fid_stag_pose_out));
         }
+        stag_learn(c, j, j.rstate == RS_PAR_B);
         return stag_finish(j, FID_OK);
     }
+    }  // for (;;)
 }
 
 // one frame, every segment back to back
@@ -1406,6 +1620,14 @@ fid_status fid_stag_detect_markers_batch(fid_stag_ctx *const *ctxs, int32_t nctx
     fprintf(stderr, "\n");
 #endif
     return first_err;
+}
+
+fid_status fid_stag_queue_stats(const fid_stag_ctx *c, int32_t *queued, int32_t *rerun)
+{
+    if (!c) return FID_E_INVALID_ARG;
+    if (queued) *queued = c->spec_frames;
+    if (rerun) *rerun = c->spec_misses;
+    return FID_OK;
 }
 
 int64_t fid_stag_tap_bytes(fid_stag_ctx *c, fid_stag_tap which)

@@ -270,14 +270,14 @@ static inline bool stag_flush(StagRecorder &R)
     std::sort(sites.begin(), sites.end());
     sites.erase(std::unique(sites.begin(), sites.end()), sites.end());
     for (int s : sites) {
-        bool is_kernel = false;
+        // (a copy site can hold BOTH kinds in one round: a frame whose few bytes go through the alias kernel and a frame whose
+        //  larger block takes the copy engine -- e.g. the marker hand-over of a frame with 12 and of one with 40 markers.  Until
+        //  round 5 the kernel kind made the loop skip the site's copies: the second frame handed over stale markers.)
         for (const auto &o : R.ops)
             if (o.site == s && o.flush) {
                 o.flush(R, o.state);
-                is_kernel = true;
                 break;
             }
-        if (is_kernel) continue;
         for (const auto &c : R.copies) {
             if (c.site != s) continue;
             const hipError_t e = c.kind == 0 ? hipMemsetAsync(c.dst, c.val, c.bytes, R.stream)

@@ -518,6 +518,48 @@ struct k_stag_fills_fn {
     __device__ __forceinline__ void operator()(StagFills F) const { k_stag_fills_impl(F); }
 };
 
+// A frame QUEUED AHEAD of its own counts (fid_stag.hip, stag_advance_impl): the host sizes every launch by what the context's last
+// frame needed (with a margin) and does not wait for the counts the device produces on the way.  This kernel stands where the host
+// used to read such a count: a count above what the following launches were sized for (or an overflow flag, capacity 0) raises the
+// frame's flag and ZEROES the counts the rest of the frame goes by, so that nothing downstream ever works on a table that was
+// cleared, filled or covered by a grid only in part; the host sees the flag at the frame's one wait and runs the frame again on
+// the counted road.  The true counts have gone to the pinned block in front of this kernel.
+struct StagGuard {
+    int *cnt[4];
+    int cap[4];
+    int *kill[4];
+    int ncnt, nkill, reset;
+    int *bad;
+    // the true counts go to the context's pinned block (through its device alias) from here: one stream operation per point
+    // instead of a copy or two and this kernel
+    int *mdst[3];
+    const int *msrc[3];
+    int mn[3];
+    int *bad_host;  // the flag's place in the pinned block
+};
+__device__ __forceinline__ void k_stag_spec_guard_impl(StagGuard g)
+{
+    if (blockIdx.x != 0) return;
+    for (int k = 0; k < 3; k++)
+        if (g.mdst[k] && (int)threadIdx.x < g.mn[k]) g.mdst[k][threadIdx.x] = g.msrc[k][threadIdx.x];
+    __syncthreads();  // (the counts are read above before thread 0 may zero them below)
+    if (threadIdx.x != 0) return;
+    bool b = !g.reset && *g.bad != 0;
+    for (int i = 0; i < g.ncnt; i++) b = b || (unsigned)*g.cnt[i] > (unsigned)g.cap[i];
+    if (g.reset || b) *g.bad = b ? 1 : 0;
+    if (g.bad_host) *g.bad_host = b ? 1 : 0;
+    if (b)
+        for (int i = 0; i < g.nkill; i++) *g.kill[i] = 0;
+}
+__global__ __launch_bounds__(64) void k_stag_spec_guard(StagGuard g)
+{
+    k_stag_spec_guard_impl(g);
+}
+struct k_stag_spec_guard_fn {
+    static constexpr int kBounds = 64;
+    __device__ __forceinline__ void operator()(StagGuard g) const { k_stag_spec_guard_impl(g); }
+};
+
 __device__ __forceinline__ int ccl_find(const int *L, int a)
 {
     while (true) {

@@ -111,6 +111,12 @@ class StagDetector:
             raise FidError(rc, self._L.fid_strerror(rc).decode())
         return out[:n.value].copy()
 
+    def queue_stats(self) -> tuple[int, int]:
+        """(frames enqueued ahead of their own counts, how many of them had to be run again on the counted road)."""
+        q, r = C.c_int32(0), C.c_int32(0)
+        self._L.fid_stag_queue_stats(self._ctx, C.byref(q), C.byref(r))
+        return q.value, r.value
+
     def markers(self) -> np.ndarray:
         return self.tap(TAP_MARKERS)
 

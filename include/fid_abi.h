@@ -359,6 +359,14 @@ fid_status fid_stag_detect_markers_batch(fid_stag_ctx *const *ctxs, int32_t nctx
                                          int32_t *n_per_frame);
 int64_t fid_stag_tap_bytes(fid_stag_ctx *ctx, fid_stag_tap which);
 fid_status fid_stag_tap_read(fid_stag_ctx *ctx, fid_stag_tap which, void *dst, int64_t dst_bytes);
+/* Frames queued ahead (ABI 6).  A context that has finished a frame sizes the next frame's launches by that frame's counts (plus a
+ * margin) and enqueues the whole frame without the nine host waits of the counted road; the true counts are checked at the
+ * frame's one wait and a frame that did not fit is run again on the counted road -- the results are the same either way (every
+ * kernel reads its counts from device memory).  Staged entry points and a context's first frame always take the counted road, and
+ * so do the groups of fid_stag_detect_markers_batch unless FID_STAG_SPEC=1 is set (measured 2 - 4 % slower there: a group's waits
+ * run under the other groups' kernels anyway); FID_STAG_SPEC=0 in the environment keeps every frame on it.  queued: frames enqueued that way since fid_stag_create; rerun: how
+ * many of them had to be run again. */
+fid_status fid_stag_queue_stats(const fid_stag_ctx *ctx, int32_t *queued, int32_t *rerun);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * JPEG ingest.  With the launch file's default `transport:=compressed` (aruco_detect/launch/aruco_detect.launch:6) the frames

@@ -613,6 +613,102 @@ def test_batch_entry_point_equals_frame_by_frame():
         det.close()
 
 
+def test_frames_queued_ahead_equal_the_counted_road(monkeypatch):
+    """Round 5: a context that has finished a frame sizes the next frame's launches by that frame's counts and enqueues the whole
+    frame without the nine host waits (fid_stag.hip, stag_advance_impl); a frame whose counts outgrow the sizes is caught by
+    k_stag_spec_guard / the host check at the frame's one wait and run again on the counted road.  Same bytes either way: a
+    sequence that goes from few markers to many (a miss), back (a fit), through an empty frame and a staged call, against
+    FID_STAG_SPEC=0 on a context of its own; poses too; and the batch entry point with slots that remember their last frame."""
+    from fiducials_amd import synth
+    words = fstag.load_library(21)
+    w, h = 1280, 720
+    small = [synth.make_stag_frame(words, 300 + i, w, h, 2).image for i in range(2)]
+    big = [synth.make_stag_frame(words, 310 + i, w, h, 12).image for i in range(2)]
+    blank = np.full((h, w), 128, np.uint8)
+    seq = [small[0], small[1], small[0], big[0], big[1], big[0], small[0], blank, big[1], small[1], small[1]]
+    K = np.array([[933.3, 0, 640.0], [0, 933.3, 360.0], [0, 0, 1]])
+    monkeypatch.setenv("FID_STAG_SPEC", "0")
+    det0 = fstag.StagDetector(21, 7, max_width=w, max_height=h)
+    want = []
+    try:
+        for f in seq:
+            m = det0.detect_markers(f)
+            want.append((m.tobytes(), det0.pose_last(K, None, 0.18).tobytes(), len(m)))
+        assert det0.queue_stats() == (0, 0)
+    finally:
+        det0.close()
+    assert want[3][2] >= 8 and want[0][2] >= 1 and want[7][2] == 0
+    monkeypatch.setenv("FID_STAG_SPEC", "1")
+    det1 = fstag.StagDetector(21, 7, max_width=w, max_height=h)
+    try:
+        for k, f in enumerate(seq):
+            m = det1.detect_markers(f)
+            assert (m.tobytes(), det1.pose_last(K, None, 0.18).tobytes(), len(m)) == want[k], k
+            if k == 4:  # a staged call in between takes the counted road and leaves the context usable
+                det1.detect_quads(big[0])
+                assert len(det1.quads()) > 0
+        queued, rerun = det1.queue_stats()
+        assert queued >= 6 and 1 <= rerun < queued, (queued, rerun)  # (small -> big and the empty frame are misses, the rest fit)
+        # the stage taps after a frame that was queued ahead are those of the counted road (the host-side counts were taken over)
+        det1.detect_markers(big[0])
+        q1 = det1.quads().tobytes()
+        l1 = det1.lines(validated=True).tobytes()
+        e1 = [p.tobytes() for p in det1.edge_segments(validated=True)]
+        assert det1.queue_stats()[0] == queued + 1
+        det1.detect_quads(big[0])
+        assert det1.quads().tobytes() == q1 and det1.lines(validated=True).tobytes() == l1
+        assert [p.tobytes() for p in det1.edge_segments(validated=True)] == e1
+    finally:
+        det1.close()
+    # group mode: the second call finds every slot with the counts of its last frame
+    frames = np.stack([small[0], big[0], small[1], big[1], blank, big[0], small[0], big[1]])
+    idx = [0, 3, 1, 4, 7, 3, 0, 4]
+    pool = fstag.StagPool(21, 7, n_contexts=4, max_width=w, max_height=h)
+    try:
+        for rnd in range(3):
+            M, P = pool.detect_markers_batch(frames if rnd != 1 else frames[::-1], K, None, 0.18)
+            order = idx if rnd != 1 else idx[::-1]
+            for f in range(len(frames)):
+                assert (M[f].tobytes(), P[f].tobytes(), len(M[f])) == want[order[f]], (rnd, f)
+        assert sum(d.queue_stats()[0] for d in pool.dets) >= 8
+    finally:
+        pool.close()
+
+
+def test_a_group_with_few_and_many_markers_hands_every_frame_its_own(monkeypatch):
+    """Round 5, found with the frames queued ahead: the hand-over of a frame's markers is an alias KERNEL up to 4 KB and a COPY
+    above, recorded at the same launch site -- a group that held both kinds issued the kernel and dropped the copies, so a frame
+    with many markers returned what its slot had held before.  Frames of 2 and of 30 HD11 markers side by side in groups of two,
+    on the counted road and queued ahead, against a context of their own."""
+    from fiducials_amd import synth
+    words = fstag.load_library(11)
+    w, h = 1920, 1080
+    few = [synth.make_stag_frame(words, 400 + i, w, h, 2).image for i in range(2)]
+    many = [synth.make_stag_frame(words, 410 + i, w, h, 30).image for i in range(2)]
+    frames = np.stack([few[0], many[0], many[1], few[1], many[0], few[0]])
+    K = synth.K_DEFAULT
+    monkeypatch.setenv("FID_STAG_SPEC", "0")
+    det = fstag.StagDetector(11, 2, max_width=w, max_height=h)
+    try:
+        want = []
+        for f in frames:
+            m = det.detect_markers(f)
+            want.append((m.tobytes(), det.pose_last(K, None, 0.18).tobytes(), len(m)))
+    finally:
+        det.close()
+    assert want[1][2] > 24 and want[2][2] > 24 and want[0][2] <= 2  # (more than 4 KB of markers / less)
+    for spec in ("0", "1"):
+        monkeypatch.setenv("FID_STAG_SPEC", spec)
+        pool = fstag.StagPool(11, 2, n_contexts=4, max_width=w, max_height=h)
+        try:
+            for rnd in range(2):
+                M, P = pool.detect_markers_batch(frames, K, None, 0.18, cap_per_frame=64)
+                for f in range(len(frames)):
+                    assert (M[f].tobytes(), P[f].tobytes(), len(M[f])) == want[f], (spec, rnd, f)
+        finally:
+            pool.close()
+
+
 def test_stag_status_codes():
     from fiducials_amd import _lib
     from fiducials_amd._lib import FidError

@@ -225,6 +225,99 @@ def usable_cpus():
     return max(1, int(min(cores, quota) if quota else cores)), cores, quota
 
 
+def host_budget(world: int) -> dict:
+    """What ONE rank may use of the host when `world` ranks share it (round-4 review: the compressed-stream figure used 3 decoder
+    threads + 5 decoder contexts + 2 detector contexts per GPU, i.e. >= 32 busy host threads at 8 ranks on a cgroup quota of 16
+    CPUs).  The job stays inside usable_cpus(): per rank usable // world host threads -- one drives the detector contexts, the rest
+    (at most 3, at least 1) decode ahead; the frame-generation pool is sized the same way (make_frames)."""
+    usable, cores, quota = usable_cpus()
+    per_rank = max(1, usable // max(world, 1))
+    dec = max(1, min(3, per_rank - 1))
+    return {"usable_cpus": usable, "hardware_threads_in_mask": cores, "cgroup_cpu_quota": quota, "ranks": world,
+            "threads_per_rank": per_rank, "decoder_threads": dec, "decoder_contexts": dec + 2, "detector_contexts": 2,
+            "busy_host_threads_job": world * min(per_rank, dec + 1)}
+
+
+def _parse_cpulist(text: str) -> list:
+    out = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        a, _, b = part.partition("-")
+        out.extend(range(int(a), int(b or a) + 1))
+    return out
+
+
+def gpu_numa_nodes(n_devices: int, sysfs: str = "/sys") -> list:
+    """NUMA node of every visible GPU (-1: the platform does not say): hipDeviceGetPCIBusId -> /sys/bus/pci/devices/<bdf>/numa_node."""
+    nodes = []
+    try:
+        import ctypes
+
+        hip = ctypes.CDLL("libamdhip64.so")
+    except OSError:
+        hip = None
+    for d in range(n_devices):
+        node = -1
+        try:
+            buf = ctypes.create_string_buffer(64)
+            if hip is not None and hip.hipDeviceGetPCIBusId(buf, 64, d) == 0:
+                with open(os.path.join(sysfs, "bus/pci/devices", buf.value.decode().lower(), "numa_node")) as fh:
+                    node = int(fh.read().strip())
+        except Exception:  # noqa: BLE001
+            node = -1
+        nodes.append(node)
+    return nodes
+
+
+def plan_affinity(local_rank: int, world: int, nodes: list, allowed: list, node_cpus: dict) -> tuple:
+    """Which CPUs rank `local_rank` pins itself to: the CPUs of its GPU's NUMA node that the process may use, cut into equal
+    slices among the ranks whose GPUs sit on the same node (their pinned staging buffers are then first-touched on that node and
+    their threads do not migrate away from it).  Pure function of its arguments (tests/test_sharding_gloo.py).  Returns
+    (cpus or None, note)."""
+    if local_rank >= len(nodes) or nodes[local_rank] < 0:
+        return None, "no NUMA node reported for this GPU: affinity left as it is"
+    node = nodes[local_rank]
+    cpus = sorted(set(node_cpus.get(node, [])) & set(allowed))
+    peers = [r for r in range(min(world, len(nodes))) if nodes[r] == node]
+    if not cpus or local_rank not in peers:
+        return None, f"NUMA node {node} has no CPU this process may use: affinity left as it is"
+    k, n = peers.index(local_rank), len(peers)
+    per = len(cpus) // n
+    if per < 1:
+        return cpus, f"NUMA node {node}: {len(cpus)} CPUs shared by {n} ranks"
+    return cpus[k * per:(k + 1) * per], f"NUMA node {node}: CPUs {cpus[k * per]}..{cpus[(k + 1) * per - 1]} ({per} of {len(cpus)}, {n} rank(s) on the node)"
+
+
+def pin_rank(local_rank: int, world: int) -> dict:
+    """Pins this rank (its threads inherit the mask; call before any pinned allocation or thread pool) to the NUMA node of its GPU."""
+    info = {"numa_node": -1, "cpus_pinned": None, "note": ""}
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+        if DRYRUN:
+            nodes = [int(x) for x in os.environ.get("FID_BENCH_DRYRUN_NODES", "").split(",") if x.strip()] or [-1] * world
+        else:
+            import torch
+
+            nodes = gpu_numa_nodes(torch.cuda.device_count())
+        node_cpus = {}
+        for nd in sorted(set(x for x in nodes if x >= 0)):
+            try:
+                with open(f"/sys/devices/system/node/node{nd}/cpulist") as fh:
+                    node_cpus[nd] = _parse_cpulist(fh.read())
+            except OSError:
+                node_cpus[nd] = []
+        cpus, note = plan_affinity(local_rank, world, nodes, allowed, node_cpus)
+        info["numa_node"] = nodes[local_rank] if local_rank < len(nodes) else -1
+        info["note"] = note
+        if cpus and os.environ.get("FID_BENCH_NO_PIN", "0") != "1":
+            os.sched_setaffinity(0, cpus)
+            info["cpus_pinned"] = len(cpus)
+    except Exception as e:  # noqa: BLE001
+        info["note"] = f"not pinned: {e!r}"
+    return info
+
+
 def _gen_one(args):
     seed, dname = args
     from fiducials_amd.dictionary import get_predefined_dictionary
@@ -386,7 +479,11 @@ def host_feed_result(local_rank, host, K, D):
     with BatchPipeline("DICT_5X5_250", depth=2, fiducial_len=FIDUCIAL_LEN, K=K, D=D, device=local_rank, max_width=W, max_height=H,
                        max_batch=B, max_markers=64, max_candidates=2048) as pipe:
         bufs = [pinned.numpy(), torch.from_numpy(host.copy()).pin_memory().numpy()]  # (a capture ring of two batches)
-        for name, arrs in (("pinned_stream", bufs), ("pageable_stream", [host, host.copy()])):
+        # (rounds 3 - 4 also reported a "pageable_stream": the same stream from pageable memory ran 12.5 / 14.6 / 21.0 k frames/s in
+        #  three runs -- there the step is the HIP runtime's own staging of 531 MB per batch through its pinned bounce buffers on the
+        #  calling thread, i.e. the host's memcpy bandwidth and whoever else uses the host, nothing this library schedules; a node
+        #  that cares registers its capture ring (hipHostRegister), which is the pinned figure.  Dropped from the line in round 5.)
+        for name, arrs in (("pinned_stream", bufs),):
             for k in range(3):
                 pipe.push_host(arrs[k % 2], unpack=False)
             pipe.flush(unpack=False)
@@ -473,28 +570,34 @@ def jpeg_to_markers(local_rank, files, Q=1):
                         "decoding one piece ahead of the detector"}
 
 
-def jpeg_stream_to_markers(local_rank, files, n_batches=12, decoder_threads=3):
+class JpegStream:
     """A STREAM of JPEG batches (the node with `transport:=compressed`, frames keep coming): `decoder_threads` host threads decode
     batches ahead of the detector, each call on a decoder context of its own (decoder_threads + 2 contexts in turn: a decoded batch
     stays in its context until its markers are out), the detector side keeps two batches in flight on two contexts
     (fid_submit_device / fid_collect / fid_order_after).  The entropy decoder's passes are latency-bound -- a batch decodes in 8 ms
     alone and in 13 ms beside the detector, whichever way it is scheduled -- so several of them side by side are what fills the
-    chip: one decoder thread 18.0 k frames/s, two 19.3 k, three 20.0 k (tools/gpu_jpeg_stream_diag.py, round 4)."""
-    import threading
+    chip: one decoder thread 18.0 k frames/s, two 19.3 k, three 20.0 k (tools/gpu_jpeg_stream_diag.py, round 4).  run(n) takes n
+    batches through and returns the markers found; `bench.py --feed jpeg` times it as the step (decoder_threads from host_budget)."""
 
-    from fiducials_amd import jpeg as fj
-    from fiducials_amd.detector import ArucoDetector
-    from fiducials_amd.synth import K_DEFAULT
+    def __init__(self, local_rank, files, decoder_threads=3):
+        from fiducials_amd import jpeg as fj
+        from fiducials_amd.detector import ArucoDetector
 
-    B = len(files)
-    NT = max(1, int(decoder_threads))
-    J = NT + 2
-    decs = [fj.JpegDecoder(max_width=W, max_height=H, max_batch=B, device=local_rank) for _ in range(J)]
-    dets = [ArucoDetector("DICT_5X5_250", device=local_rank, max_width=W, max_height=H, max_batch=B, max_markers=64, max_candidates=2048)
-            for _ in range(2)]
-    D = np.zeros(5)
+        self.files = files
+        self.B = len(files)
+        self.NT = max(1, int(decoder_threads))
+        self.J = self.NT + 2
+        self.decs = [fj.JpegDecoder(max_width=W, max_height=H, max_batch=self.B, device=local_rank) for _ in range(self.J)]
+        self.dets = [ArucoDetector("DICT_5X5_250", device=local_rank, max_width=W, max_height=H, max_batch=self.B, max_markers=64,
+                                   max_candidates=2048) for _ in range(2)]
 
-    def run(n):
+    def run(self, n):
+        import threading
+
+        from fiducials_amd.synth import K_DEFAULT
+
+        B, NT, J, decs, dets, files = self.B, self.NT, self.J, self.decs, self.dets, self.files
+        D = np.zeros(5)
         ready = [threading.Event() for _ in range(n)]
         freed = [threading.Event() for _ in range(n)]
         err = []
@@ -542,18 +645,41 @@ def jpeg_stream_to_markers(local_rank, files, n_batches=12, decoder_threads=3):
             raise err[0]
         return found
 
-    run(NT + 2)
+    def close(self):
+        for d in self.decs:
+            d.close()
+        for d in self.dets:
+            d.close()
+
+
+def jpeg_stream_to_markers(local_rank, files, n_batches=12, decoder_threads=3):
+    st = JpegStream(local_rank, files, decoder_threads)
+    B, NT, J = st.B, st.NT, st.J
+    st.run(NT + 2)
     t = time.perf_counter()
-    found = run(n_batches)
+    found = st.run(n_batches)
     dt = time.perf_counter() - t
-    for d in decs:
-        d.close()
-    for d in dets:
-        d.close()
+    st.close()
     return {"value": round(B * n_batches / dt, 1), "unit": "frames/s", "ms_per_step": round(dt / n_batches * 1e3, 3),
             "markers_per_frame_found": round(found / (B * n_batches), 2), "decoder_threads": NT,
             "workload": f"a stream of {n_batches} batches of {B} JPEG frames in host memory -> fid_jpeg_decode (device gray) -> fid_submit_device / "
                         f"fid_collect + fid_pose_last: {NT} decoder threads ahead on {J} decoder contexts, two detector contexts in turn"}
+
+
+def jpeg_files_of(frames, B):
+    """The frames as compressed_image_transport sends them (libjpeg defaults: 4:2:0, quality 80); None without Pillow."""
+    import io
+
+    try:
+        from PIL import Image
+    except ImportError:
+        return None
+    files = []
+    for k in range(B):
+        b = io.BytesIO()
+        Image.fromarray(np.stack([frames[k % len(frames)]] * 3, -1)).save(b, "JPEG", quality=80, subsampling=2)
+        files.append(b.getvalue())
+    return files
 
 
 def jpeg_side_result(local_rank, frames):
@@ -604,7 +730,7 @@ def jpeg_side_result(local_rank, frames):
     except Exception as e:  # noqa: BLE001
         out["jpeg_to_markers"] = {"error": repr(e)}
     try:
-        out["jpeg_stream_to_markers"] = jpeg_stream_to_markers(local_rank, files)
+        out["jpeg_stream_to_markers"] = jpeg_stream_to_markers(local_rank, files, decoder_threads=host_budget(1)["decoder_threads"])
     except Exception as e:  # noqa: BLE001
         out["jpeg_stream_to_markers"] = {"error": repr(e)}
     one = fj.JpegDecoder(max_width=W, max_height=H, max_batch=1, device=local_rank)
@@ -872,11 +998,13 @@ def init_dist(world, local_rank):
     return dist_mod
 
 
-def gather_ranks(dist, rank, device, units, dt_local, markers=None):
+def gather_ranks(dist, rank, device, units, dt_local, markers=None, extra=None):
     """Per-rank evidence for the JSON line: (rank, pid, device, frames/s of that rank alone, markers per frame it found)."""
     mine = {"rank": rank, "pid": os.getpid(), "device": device, "fps": round(units / dt_local, 2)}
     if markers is not None:
         mine["markers_per_frame_found"] = round(markers / max(units, 1), 2)
+    if extra:
+        mine.update(extra)
     if dist is None:
         return [mine]
     got = [None] * dist.get_world_size()
@@ -886,9 +1014,11 @@ def gather_ranks(dist, rank, device, units, dt_local, markers=None):
 
 def main_dryrun(args):
     rank, local_rank, world = rank_env(args)
+    pin = pin_rank(local_rank, world)  # (before anything allocates or starts threads)
     dist = init_dist(world, local_rank)
     seeds = shard_seeds(rank, world, 4)
     B = 4
+    budget = host_budget(world)
 
     def barrier():
         if dist is not None:
@@ -901,12 +1031,58 @@ def main_dryrun(args):
     dt_local = time.perf_counter() - t0
     barrier()
     fps, dt = job_throughput(B * args.steps, world, dt_local, dist, "cpu")
-    ranks = gather_ranks(dist, rank, "cpu", B * args.steps, dt_local)
+    ranks = gather_ranks(dist, rank, "cpu", B * args.steps, dt_local,
+                         extra={"seeds": seeds, "pin": pin, "affinity_cpus": len(os.sched_getaffinity(0))})
     if rank == 0:
         print(json.dumps({"dryrun": True, "n_gpus": world, "steps": args.steps, "value": round(fps, 2), "ms_per_step": round(dt / args.steps * 1e3, 3),
-                          "ranks": ranks, "seeds_rank0": seeds}))
+                          "ranks": ranks, "seeds_rank0": seeds, "host_budget": budget, "feed": args.feed}))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def main_feed_jpeg(args, rank, local_rank, world, dist, host, pin, budget):
+    """--feed jpeg: a step = one batch of JPEG files in host memory -> markers + poses on the host (JpegStream).  The third way a
+    camera node can feed a GPU (resident / raw over PCIe / compressed); never the headline."""
+    import torch
+
+    B = len(host)
+    files = jpeg_files_of(host, B)
+    if files is None:
+        print("bench.py: --feed jpeg needs Pillow to write the JPEG files", file=sys.stderr)
+        sys.exit(2)
+    st = JpegStream(local_rank, files, budget["decoder_threads"])
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    st.run(max(args.warmup, st.NT + 2))
+    barrier()
+    t0 = time.perf_counter()
+    found = st.run(args.steps)
+    torch.cuda.synchronize()
+    dt_local = time.perf_counter() - t0
+    barrier()
+    fps, dt = job_throughput(B * args.steps, world, time.perf_counter() - t0, dist, f"cuda:{local_rank}")
+    ranks = gather_ranks(dist, rank, f"cuda:{local_rank}", B * args.steps, dt_local, found, extra={"pin": pin})
+    if rank == 0:
+        print(json.dumps({
+            "metric": "frames/sec @1920x1080 20-marker (aruco detect + pose hot path), frames fed as JPEG files from host memory",
+            "value": round(fps, 2), "unit": "frames/s", "n_gpus": 1 if OVERSUB else world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
+            "data": f"synthetic ({B} frames per GPU as JPEG 4:2:0 quality 80, {sum(map(len, files)) // B} bytes each)",
+            "config": {"workload": f"cfg4 as a compressed stream: batches of {B} JPEG frames 1920x1080 in host memory -> fid_jpeg_decode (gray in HBM) "
+                                   "-> fid_submit_device / fid_collect + fid_pose_last, DICT_5X5_250, aruco_detect node defaults",
+                       "batch_per_gpu": B, "frames_per_step": B * world, "parallelism": f"frames sharded over {world} GPU(s), no collective",
+                       "markers_per_frame_found": round(found / max(B * args.steps, 1), 2),
+                       "feed": "jpeg: every step's frames are JPEG files in host memory, decoded on the device ahead of the detector, NOT the headline configuration",
+                       "decoder_threads": st.NT, "decoder_contexts": st.J, "in_flight": 2},
+            "ranks": ranks, "host_budget": budget}))
+    st.close()
+    if dist is not None:
+        dist.destroy_process_group()
+    return 0
 
 
 def main():
@@ -918,10 +1094,12 @@ def main():
     ap.add_argument("--unique", type=int, default=0, help="unique synthetic frames per GPU (0 = batch); fewer are tiled")
     ap.add_argument("--in-flight", type=int, default=int(os.environ.get("FID_BENCH_IN_FLIGHT", "2")),
                     help="contexts that take the steps in turn: step k + 1 is submitted before step k is collected (1 = one call after the other)")
-    ap.add_argument("--feed", choices=["resident", "host"], default="resident",
+    ap.add_argument("--feed", choices=["resident", "host", "jpeg"], default="resident",
                     help="resident (default, the metric): the batch lies in HBM when the timed region starts.  host: every step's frames "
                          "come from pinned HOST memory through fid_submit_batch (BASELINE cfg 4 as north_star words it: independent camera "
-                         "streams, one PCIe link per GPU); the line then says so in config.feed and is not the headline")
+                         "streams, one PCIe link per GPU).  jpeg: every step's frames are JPEG files in host memory (the node's launch "
+                         "default transport:=compressed), decoded on the device ahead of the detector by the rank's decoder threads "
+                         "(host_budget).  Both say so in config.feed and are not the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the cfg 2 latency and cfg 5 (STag) side results")
     ap.add_argument("--stag-side-child", action="store_true", help=argparse.SUPPRESS)  # the cfg 5 side result, own process
@@ -948,6 +1126,8 @@ def main():
 
     rank, local_rank, world = rank_env(args)
     n_gpus = world
+    pin = pin_rank(local_rank, world)  # (before the frame pool, the pinned capture ring and the decoder threads exist)
+    budget = host_budget(world)
     if visible_gpus() <= local_rank:
         print(f"bench.py: rank {rank} has no GPU (local rank {local_rank}, {visible_gpus()} visible)", file=sys.stderr)
         sys.exit(2)
@@ -981,8 +1161,11 @@ def main():
     d_frames = torch.from_numpy(host).to(f"cuda:{local_rank}")
     torch.cuda.synchronize()
     feed_host = args.feed == "host"
+    feed_jpeg = args.feed == "jpeg"
     # --feed host: a capture ring of two pinned batches per rank (a step's frames must stay put until its results are collected)
     h_ring = [torch.from_numpy(host).pin_memory().numpy(), torch.from_numpy(host.copy()).pin_memory().numpy()] if feed_host else None
+    if feed_jpeg:
+        return main_feed_jpeg(args, rank, local_rank, world, dist, host, pin, budget)
     # The steps go through `depth` contexts in turn (fiducials_amd/pipeline.py: fid_submit_device / fid_collect): step k + 1 is
     # enqueued before step k's results are fetched, so the latency-bound end of one batch runs under the front of the next.
     # Every step is a whole pass (gray .. pose, results on the host) over its own 256 frames; all K are finished inside the
@@ -1032,7 +1215,7 @@ def main():
     assert counted[1] == args.steps  # every step's results were fetched inside the timed region
     barrier()
     fps, dt = job_throughput(B * args.steps, n_gpus, time.perf_counter() - t0, dist, f"cuda:{local_rank}")
-    ranks = gather_ranks(dist, rank, f"cuda:{local_rank}", B * args.steps, dt_local, markers)
+    ranks = gather_ranks(dist, rank, f"cuda:{local_rank}", B * args.steps, dt_local, markers, extra={"pin": pin})
     assert len(ranks) == n_gpus  # every reported GPU ran its own rank
 
     if rank == 0:
@@ -1083,6 +1266,7 @@ def main():
             "roofline": roof,
             "stage_ms_per_step": {k: round(v, 4) for k, v in stage_ms.items()},
             "ranks": ranks,
+            "host_budget": budget,
         }
         if OVERSUB:
             out["oversubscribed"] = f"{n_gpus} ranks on ONE GPU (FID_BENCH_OVERSUBSCRIBE=1, gloo clock reduction): a plumbing run, not a scaling point"

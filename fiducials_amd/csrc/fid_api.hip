@@ -88,6 +88,7 @@ struct fid_ctx {
     uint32_t *d_cbase = nullptr, *d_dense = nullptr;
     uint4 *d_recs = nullptr;  // copy records: pieces of the accepted contours
     int thr_mode = 1;    // node window table: 1 = k_threshold_stream (default), 0 (FID_THR=tile) = k_threshold_fixed
+    int thr_xcd = 1;  // strips dealt out so that an XCD works through neighbouring strips (FID_THR_XCD=0: plain grid order)
     int thr_nw = 3, thr_split = 0, thr_rows = 0;  // stream kernel: consumer waves per workgroup, un-fused LDS reads, rows per workgroup (0 = automatic)
     int trace_mode = 2;  // 2: cycle tracing (borders read off the seed cycles; starts only for borders without a seed);
                          // 1 (FID_TRACE=chain): round-2 seed tracing (every border found by a probe survivor); 0 (FID_TRACE=legacy):
@@ -205,10 +206,10 @@ void layout_results(fid_ctx *c, int F)
 }
 
 template <int NW, bool SPLIT>
-void launch_thr_stream(dim3 grid, hipStream_t st, const uint8_t *g, long long gfstride, uint32_t *masks, const DevParams &P, int RS)
+void launch_thr_stream(dim3 grid, hipStream_t st, const uint8_t *g, long long gfstride, uint32_t *masks, const DevParams &P, int RS, int xcd_map)
 {
     using S = ThrStream<3, 4, 13, NW>;
-    k_threshold_stream<3, 4, 13, NW, SPLIT><<<grid, dim3(S::NT), S::LDS_BYTES, st>>>(g, gfstride, masks, P, RS);
+    k_threshold_stream<3, 4, 13, NW, SPLIT><<<grid, dim3(S::NT), S::LDS_BYTES, st>>>(g, gfstride, masks, P, RS, xcd_map);
 }
 
 fid_status apply_params(fid_ctx *c, const fid_params *p)
@@ -551,10 +552,10 @@ fid_status enqueue_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H,
                 }
                 RS = (RS + 3) & ~3;
                 dim3 grid(strips, (H + RS - 1) / RS, Fs);
-                if (c->thr_nw == 5 && c->thr_split) launch_thr_stream<5, true>(grid, st, g, gfstride, masks, P, RS);
-                else if (c->thr_nw == 5) launch_thr_stream<5, false>(grid, st, g, gfstride, masks, P, RS);
-                else if (c->thr_split) launch_thr_stream<3, true>(grid, st, g, gfstride, masks, P, RS);
-                else launch_thr_stream<3, false>(grid, st, g, gfstride, masks, P, RS);
+                if (c->thr_nw == 5 && c->thr_split) launch_thr_stream<5, true>(grid, st, g, gfstride, masks, P, RS, c->thr_xcd);
+                else if (c->thr_nw == 5) launch_thr_stream<5, false>(grid, st, g, gfstride, masks, P, RS, c->thr_xcd);
+                else if (c->thr_split) launch_thr_stream<3, true>(grid, st, g, gfstride, masks, P, RS, c->thr_xcd);
+                else launch_thr_stream<3, false>(grid, st, g, gfstride, masks, P, RS, c->thr_xcd);
             } else if (node_table) {
                 using C = ThrCfg<3, 4, 13>;
                 dim3 grid((W + C::TX - 1) / C::TX, (H + C::TY - 1) / C::TY, Fs);
@@ -1049,6 +1050,7 @@ fid_status fid_create(const fid_params *params, const fid_dict *dict, const fid_
     if (getenv("FID_THR_NW")) c->thr_nw = atoi(getenv("FID_THR_NW")) == 3 ? 3 : 5;
     if (getenv("FID_THR_SPLIT")) c->thr_split = atoi(getenv("FID_THR_SPLIT")) != 0;
     if (getenv("FID_THR_ROWS")) c->thr_rows = atoi(getenv("FID_THR_ROWS"));
+    if (getenv("FID_THR_XCD")) c->thr_xcd = atoi(getenv("FID_THR_XCD")) != 0;
     if (getenv("FID_WALK_BLOCKS")) c->walk_blocks = atoi(getenv("FID_WALK_BLOCKS")) > 0 ? atoi(getenv("FID_WALK_BLOCKS")) : c->walk_blocks;
     memset(&c->P, 0, sizeof(c->P));
 

@@ -573,14 +573,29 @@ __device__ __forceinline__ void park_quad(uint32_t &a0, uint32_t &a1, unsigned l
 
 template <int WMIN, int WSTEP, int NS, int NW, bool SPLIT>
 __global__ __launch_bounds__(64 * (NW + 1)) void k_threshold_stream(const uint8_t *__restrict__ gray, long long gfstride,
-                                                                      uint32_t *__restrict__ masks, const DevParams P, int RS)
+                                                                      uint32_t *__restrict__ masks, const DevParams P, int RS, int xcd_map)
 {
     using C = ThrStream<WMIN, WSTEP, NS, NW>;
     constexpr int R = C::R, PADL = C::PADL, RAWW = C::RAWW, NCHUNK = C::NCHUNK, ROWPAD = C::ROWPAD, LEAD = C::LEAD;
     extern __shared__ __attribute__((aligned(16))) uint2 thr_ring[];  // [DEPTH][RAWW]
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int xs = blockIdx.x * C::COLS, ys = blockIdx.y * RS, f = blockIdx.z;
+    // Which strip this workgroup takes.  The dispatcher deals workgroups out to the eight XCDs in turn (linear index mod 8), so
+    // with the plain (x, y, frame) order the two neighbours of a strip -- whose 25 / 26 halo columns it reads, and with which it
+    // shares every 128-byte line that straddles a strip border -- always sit on OTHER XCDs: each XCD's L2 fetched those lines
+    // from HBM for itself (round 4: 4.28 MB fetched per 2.07 MB frame).  xcd_map: the k-th workgroup of XCD j takes strip
+    // base(j) + k, so that an XCD works through a contiguous run of strips and the shared lines come out of its own L2.
+    unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (xcd_map) {
+        const unsigned gx = gridDim.x, gy = gridDim.y, N = gx * gy * gridDim.z;
+        const unsigned L = bx + gx * (by + gy * bz), j = L & 7u, k = L >> 3, q = N >> 3, r = N & 7u;
+        const unsigned T = j * q + (j < r ? j : r) + k;
+        bx = T % gx;
+        const unsigned t2 = T / gx;
+        by = t2 % gy;
+        bz = t2 / gy;
+    }
+    const int xs = (int)bx * C::COLS, ys = (int)by * RS, f = (int)bz;
     const int W = P.W, H = P.H, gs = P.gstride;
     const uint8_t *g = gray + (long long)f * gfstride;
     const int yend = ys + RS < H ? ys + RS : H;

@@ -85,6 +85,47 @@ def test_bench_refuses_a_rank_count_that_is_not_running():
     assert out.returncode == 2 and "visible" in out.stderr and not [l for l in out.stdout.splitlines() if l.startswith("{")]
 
 
+def test_eight_ranks_dry_run_seeds_budget_and_affinity():
+    """The shape of the driver's 8-GPU run, on CPU (round-4 review, item 5d): `bench.py --gpus 8` starts EIGHT processes, every
+    rank owns its own seed stream (cfg 4: stream s -> GPU s, nothing shared), the job's busy host threads stay inside what the
+    host gives it, and every rank pins itself to the CPUs of its GPU's NUMA node (here: a made-up node map handed to the dry run,
+    ranks 0-3 on node 0, 4-7 on node 1 where the machine has such nodes; ranks of one node get disjoint slices)."""
+    import json
+    out = _run_bench(["--gpus", "8", "--steps", "2", "--warmup", "0", "--feed", "jpeg"],
+                     {"FID_BENCH_DRYRUN": "cpu", "FID_BENCH_DRYRUN_NODES": "0,0,0,0,1,1,1,1"}, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert r["n_gpus"] == 8 and len(r["ranks"]) == 8 and r["feed"] == "jpeg"
+    assert len({x["pid"] for x in r["ranks"]}) == 8
+    seeds = [tuple(x["seeds"]) for x in sorted(r["ranks"], key=lambda x: x["rank"])]
+    flat = [s_ for t in seeds for s_ in t]
+    assert len(set(flat)) == len(flat) == 32 and seeds[3] == (30000, 30001, 30002, 30003)
+    hb = r["host_budget"]
+    assert hb["ranks"] == 8 and hb["threads_per_rank"] == max(1, hb["usable_cpus"] // 8)
+    assert 1 <= hb["decoder_threads"] <= 3 and hb["decoder_contexts"] == hb["decoder_threads"] + 2
+    assert hb["busy_host_threads_job"] <= max(hb["usable_cpus"], 8)  # (a host with fewer than 8 usable CPUs still runs one thread per rank)
+    for x in r["ranks"]:
+        assert x["pin"]["numa_node"] == (0 if x["rank"] < 4 else 1)
+        if x["pin"]["cpus_pinned"]:
+            assert x["affinity_cpus"] == x["pin"]["cpus_pinned"]
+
+
+def test_affinity_plan_is_disjoint_per_node():
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    nodes = [0, 0, 1, 1, 1, -1]
+    node_cpus = {0: list(range(0, 16)), 1: list(range(16, 40))}
+    allowed = list(range(0, 36))  # (CPUs 36..39 are outside the process's mask)
+    got = [bench.plan_affinity(r, 6, nodes, allowed, node_cpus)[0] for r in range(6)]
+    assert got[0] == list(range(0, 8)) and got[1] == list(range(8, 16))
+    assert got[2] == list(range(16, 22)) and got[3] == list(range(22, 28)) and got[4] == list(range(28, 34))
+    assert got[5] is None  # no node reported: left alone
+    assert bench._parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
+    hb = bench.host_budget(8)
+    assert hb["threads_per_rank"] * 8 <= max(hb["usable_cpus"], 8)
+
+
 import pytest  # noqa: E402
 
 

@@ -85,7 +85,7 @@ SYMBOLS = [
     "fid_jpeg_probe", "fid_jpeg_create", "fid_jpeg_destroy", "fid_jpeg_decode", "fid_jpeg_device_ptr", "fid_jpeg_tap_bytes", "fid_jpeg_tap_read",
     "fid_jpeg_last_rounds", "fid_jpeg_last_error",
     "fid_png_probe", "fid_png_decode", "fid_png_last_error",
-    "fid_to_bgr", "fid_draw_detected_markers", "fid_dict_load_file", "fid_dict_last_error",
+    "fid_to_bgr", "fid_image_to_bgr8", "fid_draw_detected_markers", "fid_dict_load_file", "fid_dict_last_error",
 ]
 
 _LIB = None
@@ -185,6 +185,7 @@ def load():
     L.fid_png_probe.argtypes = [vp, i64, C.POINTER(FidPngInfo)]
     L.fid_png_decode.argtypes = [vp, i64, C.c_int, vp, i64, C.POINTER(FidPngInfo)]
     L.fid_to_bgr.argtypes = [vp, i32, i32, i32, C.c_int, vp, i64]
+    L.fid_image_to_bgr8.argtypes = [vp, i32, i32, i32, C.c_char_p, i32, vp, i64]
     L.fid_draw_detected_markers.argtypes = [vp, i32, i32, i32, C.POINTER(FidMarker), i32, C.c_uint32]
     L.fid_dict_load_file.argtypes = [C.c_char_p, i32, vp, i64, C.POINTER(FidDict)]
     L.fid_dict_last_error.argtypes = []

@@ -143,6 +143,139 @@ fid_status fid_to_bgr(const uint8_t *img, int32_t width, int32_t height, int32_t
     return FID_OK;
 }
 
+// ---- cv_bridge::toCvCopy(msg, "bgr8") for the encodings a raw (uncompressed) camera driver publishes beside the five the device
+// path takes itself (aruco_detect.cpp:348).  cv_bridge.cpp toCvCopy -> convertColor: a list of conversions by (source, target)
+// format -- cvtColor for the colour layout, then, when the bit depths differ, Mat::convertTo(8U, 255. / 65535.).
+//   * mono16 / bgr16 / rgb16 / bgra16 / rgba16: layout first (GRAY2BGR / RGB2BGR / BGRA2BGR / RGBA2BGR are pure channel moves),
+//     then every sample through convertTo: cvtScale<ushort, uchar, float> = saturate_cast<uchar>(cvRound(v * (float)(255. / 65535.)))
+//     with the product formed in float; big-endian messages are byte-swapped first (cv_bridge does so when the host differs);
+//   * bayer_rggb8 / bayer_bggr8 / bayer_gbrg8 / bayer_grbg8: cv_bridge maps them to COLOR_BayerBG / RG / GR / GB2BGR (OpenCV names a
+//     pattern by the pixels at (1,1),(1,2)); cv::demosaicing's bilinear Bayer2RGB_<uchar>: an interior pixel keeps its own colour,
+//     the other two are (a + b + 1) >> 1 of the two or (a + b + c + d + 2) >> 2 of the four nearest samples of that colour; the
+//     first / last column of an interior row repeat their neighbour, then the first / last row repeat theirs; an image of
+//     height <= 2 comes out black.
+// Restated from the published OpenCV 4.2 / cv_bridge (noetic) sources, which are not on this machine: PARITY UNPINNED (no
+// reference fixture uses these encodings); tests/test_overlay.py checks them against an independent statement of the same rules.
+// yuv422 and the 16-bit Bayer encodings stay FID_E_UNSUPPORTED: the node reports them like the cv_bridge exception it would catch.
+static inline uint8_t cvb_scale_16_to_8(uint16_t v)
+{
+    const float a = (float)(255. / 65535.);
+    const float p = (float)v * a;
+    const long r = lrintf(p);  // cvRound: nearest, ties to even
+    return (uint8_t)(r < 0 ? 0 : (r > 255 ? 255 : r));
+}
+
+static void cvb_bayer_to_bgr(const uint8_t *src, int W, int H, long long step, int blue0, int green0, uint8_t *dst)
+{
+    const long long ds = (long long)W * 3;
+    if (H <= 2 || W <= 2) {
+        // (height <= 2: both border rows are written as zeros and nothing lies between them; width <= 2 is refused by the caller)
+        memset(dst, 0, (size_t)ds * (size_t)H);
+        return;
+    }
+    int blue = blue0, start_with_green = green0;
+    for (int i = 0; i < H - 2; i++) {
+        const uint8_t *bayer = src + (long long)i * step;
+        const uint8_t *bayer_end = bayer + (W - 2);
+        uint8_t *dst0 = dst + (long long)(i + 1) * ds + 3 + 1;  // pixel (i + 1, 1), its middle (green) channel
+        uint8_t *d = dst0;
+        const long long bs = step;
+        int t0, t1;
+        if (start_with_green) {
+            t0 = (bayer[1] + bayer[bs * 2 + 1] + 1) >> 1;
+            t1 = (bayer[bs] + bayer[bs + 2] + 1) >> 1;
+            d[-blue] = (uint8_t)t0;
+            d[0] = bayer[bs + 1];
+            d[blue] = (uint8_t)t1;
+            bayer++;
+            d += 3;
+        }
+        for (; bayer <= bayer_end - 2; bayer += 2, d += 6) {
+            t0 = (bayer[0] + bayer[2] + bayer[bs * 2] + bayer[bs * 2 + 2] + 2) >> 2;
+            t1 = (bayer[1] + bayer[bs] + bayer[bs + 2] + bayer[bs * 2 + 1] + 2) >> 2;
+            d[-blue] = (uint8_t)t0;
+            d[0] = (uint8_t)t1;
+            d[blue] = bayer[bs + 1];
+            t0 = (bayer[2] + bayer[bs * 2 + 2] + 1) >> 1;
+            t1 = (bayer[bs + 1] + bayer[bs + 3] + 1) >> 1;
+            d[3 - blue] = (uint8_t)t0;  // (the green pixel beside it: its vertical pair is the colour this row does not carry,
+            d[3] = bayer[bs + 2];       //  its horizontal pair the colour of the pixel before it)
+            d[3 + blue] = (uint8_t)t1;
+        }
+        if (bayer < bayer_end) {
+            t0 = (bayer[0] + bayer[2] + bayer[bs * 2] + bayer[bs * 2 + 2] + 2) >> 2;
+            t1 = (bayer[1] + bayer[bs] + bayer[bs + 2] + bayer[bs * 2 + 1] + 2) >> 2;
+            d[-blue] = (uint8_t)t0;
+            d[0] = (uint8_t)t1;
+            d[blue] = bayer[bs + 1];
+        }
+        // the first and the last pixel of the row repeat their neighbours
+        dst0[-4] = dst0[-1];
+        dst0[-3] = dst0[0];
+        dst0[-2] = dst0[1];
+        dst0[(W - 2) * 3 - 1] = dst0[(W - 2) * 3 - 4];
+        dst0[(W - 2) * 3] = dst0[(W - 2) * 3 - 3];
+        dst0[(W - 2) * 3 + 1] = dst0[(W - 2) * 3 - 2];
+        blue = -blue;
+        start_with_green = !start_with_green;
+    }
+    for (long long k = 0; k < ds; k++) {  // the first and the last row repeat theirs
+        dst[k] = dst[k + ds];
+        dst[k + (long long)(H - 1) * ds] = dst[k + (long long)(H - 2) * ds];
+    }
+}
+
+fid_status fid_image_to_bgr8(const uint8_t *img, int32_t width, int32_t height, int32_t stride, const char *encoding, int32_t is_bigendian,
+                             uint8_t *out_bgr, int64_t out_bytes)
+{
+    if (!img || !out_bgr || !encoding || width < 1 || height < 1 || width > 32767 || height > 32767) return FID_E_INVALID_ARG;
+    if (out_bytes < (int64_t)width * height * 3) return FID_E_CAPACITY;
+    const std::string e(encoding);
+    static const struct { const char *name; fid_encoding enc; } eight[] = {
+        {"mono8", FID_ENC_MONO8}, {"bgr8", FID_ENC_BGR8}, {"rgb8", FID_ENC_RGB8}, {"bgra8", FID_ENC_BGRA8}, {"rgba8", FID_ENC_RGBA8}};
+    for (const auto &k : eight)
+        if (e == k.name) return fid_to_bgr(img, width, height, stride, k.enc, out_bgr, out_bytes);
+    int ch = 0, swap = 0;
+    if (e == "mono16") ch = 1;
+    else if (e == "bgr16") ch = 3;
+    else if (e == "rgb16") ch = 3, swap = 1;
+    else if (e == "bgra16") ch = 4;
+    else if (e == "rgba16") ch = 4, swap = 1;
+    if (ch) {
+        if ((int64_t)stride < (int64_t)width * ch * 2) return FID_E_INVALID_ARG;
+        const bool be = is_bigendian != 0;
+        for (int y = 0; y < height; y++) {
+            const uint8_t *s = img + (size_t)y * (size_t)stride;
+            uint8_t *o = out_bgr + (size_t)y * (size_t)width * 3;
+            for (int x = 0; x < width; x++) {
+                uint8_t v[4] = {0, 0, 0, 0};
+                for (int k = 0; k < ch; k++) {
+                    const uint8_t *p = s + ((size_t)x * ch + k) * 2;
+                    v[k] = cvb_scale_16_to_8(be ? (uint16_t)((p[0] << 8) | p[1]) : (uint16_t)(p[0] | (p[1] << 8)));
+                }
+                if (ch == 1) o[3 * x] = o[3 * x + 1] = o[3 * x + 2] = v[0];
+                else {
+                    o[3 * x] = swap ? v[2] : v[0];
+                    o[3 * x + 1] = v[1];
+                    o[3 * x + 2] = swap ? v[0] : v[2];
+                }
+            }
+        }
+        return FID_OK;
+    }
+    int blue = 0, green = 0;
+    if (e == "bayer_rggb8") blue = -1, green = 0;       // COLOR_BayerBG2BGR
+    else if (e == "bayer_bggr8") blue = 1, green = 0;   // COLOR_BayerRG2BGR
+    else if (e == "bayer_gbrg8") blue = 1, green = 1;   // COLOR_BayerGR2BGR
+    else if (e == "bayer_grbg8") blue = -1, green = 1;  // COLOR_BayerGB2BGR
+    if (blue) {
+        if (stride < width || width < 3) return FID_E_INVALID_ARG;
+        cvb_bayer_to_bgr(img, width, height, stride, blue, green, out_bgr);
+        return FID_OK;
+    }
+    return FID_E_UNSUPPORTED;
+}
+
 fid_status fid_draw_detected_markers(uint8_t *bgr, int32_t width, int32_t height, int32_t stride, const fid_marker *markers, int32_t n,
                                      uint32_t flags)
 {

@@ -25,6 +25,17 @@ def to_bgr(image: np.ndarray, encoding: str | None = None) -> np.ndarray:
     return out
 
 
+def image_to_bgr8(data: np.ndarray, width: int, height: int, step: int, encoding: str, is_bigendian: bool = False) -> np.ndarray:
+    """cv_bridge::toCvCopy(msg, "bgr8") of a sensor_msgs/Image given by its fields (data: the message bytes): the five 8-bit
+    encodings, mono16 / bgr16 / rgb16 / bgra16 / rgba16 and the four 8-bit Bayer patterns (fid_image_to_bgr8)."""
+    buf = np.ascontiguousarray(data, dtype=np.uint8).reshape(-1)
+    out = np.empty((height, width, 3), dtype=np.uint8)
+    rc = _lib.load().fid_image_to_bgr8(buf.ctypes.data, width, height, step, encoding.encode(), int(bool(is_bigendian)), out.ctypes.data, out.nbytes)
+    if rc != _lib.FID_OK:
+        raise FidError(rc, f"fid_image_to_bgr8({encoding})")
+    return out
+
+
 def draw_detected_markers(bgr: np.ndarray, corners: np.ndarray, ids: np.ndarray | None = None, flags: int = 0) -> np.ndarray:
     """In place on a (H, W, 3) uint8 BGR image; corners (n, 4, 2) float32.  Returns the image."""
     if bgr.dtype != np.uint8 or bgr.ndim != 3 or bgr.shape[2] != 3 or bgr.strides[2] != 1 or bgr.strides[1] != 3:

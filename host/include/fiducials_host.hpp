@@ -24,7 +24,7 @@ struct Header {  // std_msgs/Header
 struct Image {  // sensor_msgs/Image
     Header header;
     uint32_t height = 0, width = 0;
-    std::string encoding;  // "mono8", "bgr8", "rgb8", "bgra8", "rgba8"
+    std::string encoding;  // "mono8", "bgr8", "rgb8", "bgra8", "rgba8"; "mono16", "bgr16", "rgb16", "bgra16", "rgba16", "bayer_{rggb,bggr,gbrg,grbg}8"
     uint8_t is_bigendian = 0;
     uint32_t step = 0;
     std::vector<uint8_t> data;
@@ -171,6 +171,7 @@ class FiducialsNode {
     fid_ctx *ctx = nullptr;
     fid_jpeg_ctx *jctx = nullptr;  // made when the first compressed frame arrives
     std::vector<uint8_t> png_frame;  // a PNG frame decoded on the host (fid_png_decode), reused from frame to frame
+    std::vector<uint8_t> converted;  // the BGR8 copy of a 16-bit / Bayer frame (fid_image_to_bgr8); empty for the encodings fid_detect takes
     int maxW = 0, maxH = 0, dev = 0;
     Dictionary dict;
     fid_params detectorParams;

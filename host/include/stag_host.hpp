@@ -163,5 +163,133 @@ inline void stagImageCallback(Stag &stag, const Image &msg, const CameraInfo &ca
     }
 }
 
+// ---- the reference's node itself, without ROS: StagNode of stag_detect/src/stag_ros/stag_detect.cpp with the outputs IT
+// publishes -- one geometry_msgs/PoseStamped per marker on `stag_ros/markers` (header.frame_id = the marker id as text,
+// common.hpp:72-82), one vision_msgs/Detection2DArray on `stag_ros/markers_array` (stag_detect.cpp:139-209; the shipped launch
+// remaps it onto /fiducial_transforms, stag_detect.launch:10) and, with `publish_tf`, <image frame> -> <tag_tf_prefix><id>.
+// ros/stag_detect_amd is the catkin glue around this class; host/test/stag_test.cpp runs it on the GPU box.
+struct PoseStamped {  // geometry_msgs/PoseStamped
+    Header header;
+    Pose pose;
+};
+
+class StagNode {
+   public:
+    struct Params {  // StagNode::loadParameters (stag_detect.cpp:88-108) with its defaults
+        int libraryHD = 15, errorCorrection = 7;
+        std::string raw_image_topic = "image_raw", camera_info_topic = "camera_info";
+        std::string markers_topic = "stag_ros/markers", markers_array_topic = "stag_ros/markers_array";
+        bool is_compressed = false, show_markers = true, publish_tf = false;
+        std::string tag_tf_prefix = "STag_";
+        float marker_size = 0.18f;
+    };
+    struct Outputs {
+        std::vector<PoseStamped> markers;  // Common::publishTransform, one message per marker, in marker order
+        Detection2DArray array;
+        std::vector<TransformStamped> tf;
+        bool array_published = false;  // (the reference returns before markersArrayPub.publish when a pose comes back empty)
+    };
+
+    StagNode(const Params &p, const std::string &data_dir = "fiducials_amd/data", int max_width = 1920, int max_height = 1080, int device = 0)
+        : params(p), stag(p.libraryHD, p.errorCorrection, false, data_dir, max_width, max_height, device)
+    {
+    }
+
+    // StagNode::cameraInfoCallback (:219-263): the first message is kept, later ones are ignored
+    void cameraInfoCallback(const CameraInfo &msg)
+    {
+        if (got_camera_info) return;
+        for (int i = 0; i < 9; i++) K[i] = msg.K[(size_t)i];
+        for (int i = 0; i < 5; i++) D[i] = (size_t)i < msg.D.size() ? msg.D[(size_t)i] : 0.0;
+        got_camera_info = true;
+    }
+
+    // stag_ros::msgToGray (utility.hpp:8-20): bgr8 / rgb8 through cvtColor's 8-bit fixed point, mono8 as it is; anything else:
+    // false (the reference goes on with an EMPTY image there; this node drops the frame)
+    static bool msgToGray(const Image &msg, std::vector<uint8_t> *gray, const uint8_t **data, int *step)
+    {
+        if (msg.encoding == "mono8") {
+            if (msg.step < msg.width || msg.data.size() < (size_t)msg.step * msg.height) return false;
+            *data = msg.data.data();
+            *step = (int)msg.step;
+            return true;
+        }
+        const bool bgr = msg.encoding == "bgr8", rgb = msg.encoding == "rgb8";
+        if (!bgr && !rgb) return false;
+        if (msg.step < 3 * msg.width || msg.data.size() < (size_t)msg.step * msg.height) return false;
+        gray->resize((size_t)msg.width * msg.height);
+        for (uint32_t y = 0; y < msg.height; y++) {
+            const uint8_t *s = msg.data.data() + (size_t)y * msg.step;
+            uint8_t *o = gray->data() + (size_t)y * msg.width;
+            for (uint32_t x = 0; x < msg.width; x++) {
+                const int c0 = s[3 * x], g = s[3 * x + 1], c2 = s[3 * x + 2];
+                const int b = bgr ? c0 : c2, r = bgr ? c2 : c0;
+                o[x] = (uint8_t)((b * 1868 + g * 9617 + r * 4899 + 8192) >> 14);  // imgproc color_rgb: RGB2Gray<uchar>, 14-bit coefficients
+            }
+        }
+        *data = gray->data();
+        *step = (int)msg.width;
+        return true;
+    }
+
+    // StagNode::imageCallback (:110-217).  false: nothing is published (no CameraInfo yet, or an encoding msgToGray refuses).
+    bool imageCallback(const Image &msg, Outputs *out)
+    {
+        out->markers.clear();
+        out->tf.clear();
+        out->array = Detection2DArray();
+        out->array_published = false;
+        if (!got_camera_info) return false;
+        const uint8_t *data = nullptr;
+        int step = 0;
+        if (!msgToGray(msg, &gray_, &data, &step)) return false;
+        stag.detectMarkers(data, (int)msg.width, (int)msg.height, step);
+        const std::vector<Marker> markers = stag.getMarkerList();
+        const std::vector<fid_stag_pose_out> poses = stag.solvePnpSingle(K, D, (double)params.marker_size);
+        out->array.header = msg.header;
+        for (size_t i = 0; i < markers.size(); i++) {
+            double q[4];
+            rotationToQuaternion(poses[i].R, q);  // tf::Matrix3x3::getRotation
+            Pose pose;
+            pose.px = poses[i].tvec[0]; pose.py = poses[i].tvec[1]; pose.pz = poses[i].tvec[2];
+            pose.ox = q[0]; pose.oy = q[1]; pose.oz = q[2]; pose.ow = q[3];
+            const std::string id = std::to_string(markers[i].id);
+            if (params.publish_tf) {  // Common::publishTransform: tf first, then the PoseStamped
+                TransformStamped t;
+                t.header = msg.header;
+                t.child_frame_id = params.tag_tf_prefix + id;
+                t.tx = pose.px; t.ty = pose.py; t.tz = pose.pz;
+                t.qx = pose.ox; t.qy = pose.oy; t.qz = pose.oz; t.qw = pose.ow;
+                out->tf.push_back(t);
+            }
+            PoseStamped ps;
+            ps.header.frame_id = id;  // (sic: the marker id, common.hpp:73)
+            ps.header.sec = msg.header.sec;
+            ps.header.nsec = msg.header.nsec;
+            ps.pose = pose;
+            out->markers.push_back(ps);
+            Detection2D det;
+            det.header = msg.header;
+            ObjectHypothesisWithPose hyp;
+            hyp.id = markers[i].id;
+            hyp.pose = pose;
+            det.results.push_back(hyp);
+            out->array.detections.push_back(det);
+        }
+        out->array_published = true;
+        return true;
+    }
+
+    const std::vector<Marker> lastMarkers() const { return stag.getMarkerList(); }
+
+    Params params;
+    bool got_camera_info = false;
+    double K[9] = {0}, D[5] = {0};
+
+   private:
+    Stag stag;
+    std::vector<uint8_t> gray_;
+};
+
 }  // namespace fiducials_amd
 #endif

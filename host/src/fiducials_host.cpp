@@ -312,9 +312,32 @@ bool FiducialsNode::imageCallback(const Image &msg, FiducialArray *out)
     else if (msg.encoding == "bgra8") enc = FID_ENC_BGRA8;
     else if (msg.encoding == "rgba8") enc = FID_ENC_RGBA8;
     else {
-        last_error = "cv_bridge exception: unsupported encoding " + msg.encoding;  // (:389-391)
-        return false;
+        // what else cv_bridge::toCvCopy(msg, BGR8) converts (:348): 16-bit gray / colour and the 8-bit Bayer patterns of raw camera
+        // drivers -- the BGR8 copy is made on the host (fid_image_to_bgr8, the reference's own order: convert, then detect), and
+        // an encoding that is not restated there ends like the cv_bridge exception the reference catches (:389-391)
+        if (msg.height == 0 || msg.width == 0 || msg.data.size() < (size_t)msg.step * msg.height) {
+            last_error = "cv_bridge exception: image is wrongly formed: step * height exceeds the data";
+            return false;
+        }
+        converted.resize((size_t)msg.width * msg.height * 3);
+        const fid_status rcc = fid_image_to_bgr8(msg.data.data(), (int32_t)msg.width, (int32_t)msg.height, (int32_t)msg.step, msg.encoding.c_str(),
+                                                 msg.is_bigendian, converted.data(), (int64_t)converted.size());
+        if (rcc != FID_OK) {
+            last_error = rcc == FID_E_UNSUPPORTED ? "cv_bridge exception: unsupported encoding " + msg.encoding
+                                                  : "cv_bridge exception: image is wrongly formed (" + msg.encoding + ")";
+            converted.clear();
+            return false;
+        }
+        int32_t n = 0;
+        const fid_status rc = fid_detect(ctx, converted.data(), (int32_t)msg.width, (int32_t)msg.height, (int32_t)msg.width * 3, FID_ENC_BGR8,
+                                         markers.data(), (int32_t)markers.size(), &n);
+        if (rc != FID_OK) {
+            last_error = fid_last_error(ctx);
+            return false;
+        }
+        return publishVertices(msg.header, n, out);
     }
+    converted.clear();
     int32_t n = 0;
     const fid_status rc = fid_detect(ctx, msg.data.data(), (int32_t)msg.width, (int32_t)msg.height, (int32_t)msg.step, enc, markers.data(),
                                      (int32_t)markers.size(), &n);
@@ -342,6 +365,16 @@ bool FiducialsNode::imageCallback(const Image &msg, FiducialArray *out, Image *i
     image->is_bigendian = 0;
     image->step = msg.width * 3;
     image->data.resize((size_t)msg.width * msg.height * 3);
+    if (!converted.empty()) {  // (a 16-bit / Bayer frame: the BGR8 copy the detection ran on)
+        image->data = converted;
+        if (!ids.empty() &&
+            fid_draw_detected_markers(image->data.data(), (int32_t)image->width, (int32_t)image->height, (int32_t)image->step, markers.data(),
+                                      (int32_t)ids.size(), 0) != FID_OK) {
+            last_error = "drawDetectedMarkers failed";
+            return false;
+        }
+        return true;
+    }
     fid_status rc = fid_to_bgr(msg.data.data(), (int32_t)msg.width, (int32_t)msg.height, (int32_t)msg.step, enc, image->data.data(),
                                (int64_t)image->data.size());
     if (rc == FID_OK && !ids.empty())  // every detected marker is drawn, ignored ids included (the ignore list only filters the vertices)

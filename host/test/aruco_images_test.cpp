@@ -194,6 +194,43 @@ static void node_surface(const Fixture &fx)
     Image bad = img;
     bad.encoding = "yuv422";
     CHECK(!node.imageCallback(bad, &fva) && !node.lastError().empty());  // like the caught cv_bridge exception: frame dropped
+    CHECK(node.lastError().find("cv_bridge exception") == 0);
+    {
+        // what else toCvCopy(msg, BGR8) converts (fid_image_to_bgr8): the frame as mono16 (v * 257: convertTo gives v back, so the
+        // markers are those of the 8-bit frame to the last bit, both byte orders) and as a Bayer mosaic of its gray values (the
+        // demosaiced copy is a slightly smoothed gray image: the same ids, corners within a pixel)
+        FiducialArray ref;
+        const Image &g8 = img;  // (the fixture is a mono8 frame)
+        CHECK(node.imageCallback(g8, &ref) && ref.fiducials.size() == 2);
+        for (int be = 0; be < 2; be++) {
+            Image m16 = g8;
+            m16.encoding = "mono16";  // (rows of img.step bytes in the source)
+            m16.is_bigendian = (uint8_t)be;
+            m16.step = img.width * 2 + 4;
+            m16.data.assign((size_t)m16.step * img.height, 0);
+            for (uint32_t y = 0; y < img.height; y++)
+                for (uint32_t x = 0; x < img.width; x++) {
+                    const unsigned v = g8.data[(size_t)y * img.step + x] * 257u;
+                    m16.data[(size_t)y * m16.step + 2 * x + (be ? 1 : 0)] = (uint8_t)(v & 255);
+                    m16.data[(size_t)y * m16.step + 2 * x + (be ? 0 : 1)] = (uint8_t)(v >> 8);
+                }
+            FiducialArray f16;
+            CHECK(node.imageCallback(m16, &f16) && f16.fiducials.size() == ref.fiducials.size());
+            for (size_t i = 0; i < f16.fiducials.size() && i < ref.fiducials.size(); i++)
+                CHECK(f16.fiducials[i].fiducial_id == ref.fiducials[i].fiducial_id && f16.fiducials[i].x0 == ref.fiducials[i].x0 &&
+                      f16.fiducials[i].y2 == ref.fiducials[i].y2);
+        }
+        const char *pats[4] = {"bayer_rggb8", "bayer_bggr8", "bayer_gbrg8", "bayer_grbg8"};
+        for (const char *pat : pats) {
+            Image by = g8;
+            by.encoding = pat;
+            FiducialArray fb;
+            CHECK(node.imageCallback(by, &fb) && fb.fiducials.size() == ref.fiducials.size());
+            for (size_t i = 0; i < fb.fiducials.size() && i < ref.fiducials.size(); i++)
+                CHECK(fb.fiducials[i].fiducial_id == ref.fiducials[i].fiducial_id && std::fabs(fb.fiducials[i].x0 - ref.fiducials[i].x0) < 1.0 &&
+                      std::fabs(fb.fiducials[i].y2 - ref.fiducials[i].y2) < 1.0);
+        }
+    }
     // ~publish_images: /fiducial_images = the BGR8 copy of the frame with the marker outlines on it (:381-387); and the third
     // corner refinement the node can select, cornerRefinementSubPix = false -> CORNER_REFINE_CONTOUR (:274-283, 700-711)
     {
@@ -218,6 +255,17 @@ static void node_surface(const Fixture &fx)
         const int cx = (int)std::lrint(fi.fiducials[0].x0), cy = (int)std::lrint(fi.fiducials[0].y0);
         const uint8_t *pc = &ov.data[((size_t)cy * img.width + cx) * 3];
         CHECK(pc[0] == 0 && pc[1] == 255 && pc[2] == 0);
+        {
+            // a Bayer frame: /fiducial_images is the demosaiced BGR8 copy the detection ran on, with the outlines
+            Image by = img, ovb;
+            by.encoding = "bayer_grbg8";
+            FiducialArray fb;
+            CHECK(inode.imageCallback(by, &fb, &ovb) && fb.fiducials.size() == 2);
+            CHECK(ovb.encoding == "bgr8" && ovb.step == img.width * 3 && ovb.data.size() == (size_t)img.width * img.height * 3);
+            size_t g2 = 0;
+            for (size_t k = 0; k + 2 < ovb.data.size(); k += 3) g2 += ovb.data[k] == 0 && ovb.data[k + 1] == 255 && ovb.data[k + 2] == 0;
+            CHECK(g2 > 400);
+        }
         Image none;
         FiducialsNode plain2(fx.params());
         CHECK(plain2.imageCallback(img, &fi, &none) && none.data.empty());  // publish_images = false: nothing is made

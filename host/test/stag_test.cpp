@@ -88,6 +88,61 @@ int main(int argc, char **argv)
             CHECK(fva.fiducials[i].x0 == markers[i].corners[0].x && fva.fiducials[i].y3 == markers[i].corners[3].y);
         }
         CHECK(serialize(fva).size() == 16 + 6 + 8 + 72 * fva.fiducials.size());
+        // ---- the reference's node itself (StagNode, stag_detect.cpp): nothing before the first CameraInfo, then one PoseStamped
+        //      per marker (the id as frame_id), the Detection2DArray, TF with the prefix; bgr8 / rgb8 input through msgToGray
+        {
+            StagNode::Params p;
+            p.libraryHD = std::atoi(argv[4]);
+            p.errorCorrection = std::atoi(argv[5]);
+            p.marker_size = 0.14f;
+            p.publish_tf = true;
+            p.tag_tf_prefix = "fiducial_";
+            StagNode node(p, argv[3], w, h);
+            StagNode::Outputs out;
+            img.header.frame_id = "raspicam";
+            CHECK(!node.imageCallback(img, &out) && out.markers.empty() && !out.array_published);  // no camera info yet
+            node.cameraInfoCallback(cam);
+            CameraInfo later = cam;
+            later.K[0] = 1.0;
+            node.cameraInfoCallback(later);  // ignored: the first one is kept
+            CHECK(node.K[0] == cam.K[0]);
+            CHECK(node.imageCallback(img, &out) && out.array_published);
+            CHECK(out.markers.size() == markers.size() && out.array.detections.size() == markers.size() && out.tf.size() == markers.size());
+            CHECK(out.array.header.seq == 42 && out.array.header.frame_id == "raspicam");
+            for (size_t i = 0; i < out.markers.size() && i < markers.size(); i++) {
+                const FiducialTransform &t = fta.transforms[i];  // (the same pose through the fiducial_msgs adaptor above)
+                CHECK(out.markers[i].header.frame_id == std::to_string(markers[i].id) && out.markers[i].header.sec == 100);
+                CHECK(out.markers[i].pose.px == t.tx && out.markers[i].pose.pz == t.tz && out.markers[i].pose.ow == t.qw);
+                CHECK(out.array.detections[i].results.size() == 1 && out.array.detections[i].results[0].id == markers[i].id);
+                CHECK(out.array.detections[i].results[0].pose.oz == t.qz && out.array.detections[i].header.sec == 100);
+                CHECK(out.tf[i].child_frame_id == "fiducial_" + std::to_string(markers[i].id) && out.tf[i].header.frame_id == "raspicam" &&
+                      out.tf[i].tz == t.tz);
+            }
+            // the same frame as bgr8 and as rgb8 (gray replicated: cvtColor's fixed point gives the gray value back) and a padded step
+            for (int variant = 0; variant < 2; variant++) {
+                Image c3 = img;
+                c3.encoding = variant ? "rgb8" : "bgr8";
+                c3.step = 3 * (uint32_t)w + 5;
+                c3.data.assign((size_t)c3.step * h, 0);
+                for (int y = 0; y < h; y++)
+                    for (int x = 0; x < w; x++)
+                        for (int k = 0; k < 3; k++) c3.data[(size_t)y * c3.step + 3 * x + k] = img.data[(size_t)y * w + x];
+                StagNode::Outputs o3;
+                CHECK(node.imageCallback(c3, &o3) && o3.markers.size() == out.markers.size());
+                for (size_t i = 0; i < o3.markers.size() && i < out.markers.size(); i++)
+                    CHECK(o3.markers[i].header.frame_id == out.markers[i].header.frame_id && o3.markers[i].pose.pz == out.markers[i].pose.pz);
+            }
+            Image bad = img;
+            bad.encoding = "mono16";
+            CHECK(!node.imageCallback(bad, &out) && out.markers.empty());  // msgToGray returns false for it
+            std::vector<uint8_t> g;
+            const uint8_t *dp = nullptr;
+            int st = 0;
+            Image px;
+            px.width = 2; px.height = 1; px.step = 6; px.encoding = "bgr8";
+            px.data = {255, 0, 0, 10, 200, 30};
+            CHECK(StagNode::msgToGray(px, &g, &dp, &st) && g[0] == 29 && g[1] == 128);  // B alone: 0.114 * 255; (10, 200, 30): 127.5 -> 128
+        }
     } catch (const std::exception &e) {
         std::printf("EXCEPTION %s\n", e.what());
         return 3;

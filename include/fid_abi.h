@@ -42,8 +42,9 @@ extern "C" {
  * preceding fid_detect_* call already computed for the same camera; fid_stag_detect_markers_batch reports 0 markers for a frame
  * whose slot was too small (round 3).  4: + fid_submit_device / fid_submit_batch / fid_collect / fid_order_after, fid_png_* (round 3).  Entry points are only ever added: a caller
  * built against 1 runs against 5.  5: cornerRefinementMethod 2 (CORNER_REFINE_CONTOUR) is implemented instead of refused,
- * FID_E_CV_EXCEPTION, fid_refine_contour_corners, fid_to_bgr / fid_draw_detected_markers, fid_dict_load_file (round 4). */
-#define FID_ABI_VERSION 5
+ * FID_E_CV_EXCEPTION, fid_refine_contour_corners, fid_to_bgr / fid_draw_detected_markers, fid_dict_load_file (round 4).
+ * 6: + fid_stag_queue_stats (STag frames queued ahead of their own counts), fid_image_to_bgr8 (round 5). */
+#define FID_ABI_VERSION 6
 
 typedef enum fid_status {
     FID_OK = 0,
@@ -437,6 +438,15 @@ const char *fid_png_last_error(void); /* of the calling thread */
  * text; aruco::drawAxis (:431) likewise.  FID_DRAW_FIRST_CORNER_LINE8 adds that square with LINE_8 sides -- a cue for a human
  * viewer, not the reference's pixels.
  * ------------------------------------------------------------------------------------------------------------------ */
+/* fid_image_to_bgr8 (ABI 6) = cv_bridge::toCvCopy(msg, "bgr8") by the message's encoding STRING, for what a raw camera driver
+ * publishes beside the five encodings fid_detect takes itself: mono16 / bgr16 / rgb16 / bgra16 / rgba16 (layout, then
+ * convertTo(8U, 255. / 65535.), is_bigendian honoured) and bayer_rggb8 / bayer_bggr8 / bayer_gbrg8 / bayer_grbg8 (OpenCV's bilinear
+ * demosaicing under cv_bridge's pattern mapping); the five 8-bit encodings go through fid_to_bgr.  The node converts such a frame
+ * with this call and hands the BGR8 copy to fid_detect(FID_ENC_BGR8), which is the order the reference works in
+ * (aruco_detect.cpp:348-350).  FID_E_UNSUPPORTED: an encoding that is not restated here (yuv422, 16-bit Bayer, ...) -- the node
+ * reports it like the cv_bridge exception it would catch (:389-391).  Restated from the published sources: parity unpinned. */
+fid_status fid_image_to_bgr8(const uint8_t *img, int32_t width, int32_t height, int32_t stride_bytes, const char *encoding,
+                             int32_t is_bigendian, uint8_t *out_bgr, int64_t out_bytes);
 #define FID_DRAW_FIRST_CORNER_LINE8 1u
 fid_status fid_to_bgr(const uint8_t *img, int32_t width, int32_t height, int32_t stride_bytes, fid_encoding enc, uint8_t *out_bgr,
                        int64_t out_bytes);

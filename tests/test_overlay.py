@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 
 from fiducials_amd import overlay
+from fiducials_amd._lib import FidError
 from oracle import draw as odraw
 
 
@@ -108,3 +109,49 @@ def test_draw_refuses_bad_arguments():
         overlay.draw_detected_markers(img, np.zeros((1, 4, 2), np.float32), None, flags=2)
     with pytest.raises(ValueError):
         overlay.draw_detected_markers(np.zeros((10, 10), np.uint8), np.zeros((1, 4, 2), np.float32))
+
+
+def test_image_to_bgr8_16bit_and_bayer_encodings():
+    """fid_image_to_bgr8 = cv_bridge::toCvCopy(msg, "bgr8") for what a raw camera driver publishes beside the 8-bit colour
+    encodings (round-4 review, missing item 5): every 16-bit value through convertTo's rule, both byte orders, padded rows; the
+    four Bayer patterns at even and odd sizes against the rules stated independently in oracle/cvbridge.py; and the refusals."""
+    from fiducials_amd import _lib
+    from oracle import cvbridge as ocb
+
+    rng = np.random.default_rng(21)
+    # all 65536 values as one mono16 image: the float product and the tie rule, value by value
+    allv = np.arange(65536, dtype=np.uint16).reshape(256, 256)
+    got = overlay.image_to_bgr8(allv.view(np.uint8), 256, 256, 512, "mono16")
+    assert np.array_equal(got, ocb.to_bgr8_16bit(allv, "mono16"))
+    assert got[0, 0, 0] == 0 and got[255, 255, 0] == 255 and got[0, 128, 1] == 0 and got[0, 129, 2] == 1  # 128 * 255 / 65535 = 0.498
+    be = allv.byteswap()
+    assert np.array_equal(overlay.image_to_bgr8(be.view(np.uint8), 256, 256, 512, "mono16", is_bigendian=True), got)
+    for enc, ch in (("bgr16", 3), ("rgb16", 3), ("bgra16", 4), ("rgba16", 4)):
+        h, w, pad = 13, 17, 6
+        img = rng.integers(0, 65536, (h, w, ch), dtype=np.uint16)
+        rows = np.zeros((h, w * ch * 2 + pad), np.uint8)
+        rows[:, :w * ch * 2] = img.view(np.uint8).reshape(h, -1)
+        assert np.array_equal(overlay.image_to_bgr8(rows, w, h, rows.shape[1], enc), ocb.to_bgr8_16bit(img, enc)), enc
+    for enc in ocb.PATTERNS:
+        for (h, w) in ((8, 8), (9, 11), (10, 7), (3, 3), (2, 6), (1, 5), (37, 64)):
+            raw = rng.integers(0, 256, (h, w + 3), dtype=np.uint8)  # (a padded step)
+            got = overlay.image_to_bgr8(raw, w, h, raw.shape[1], enc)
+            assert np.array_equal(got, ocb.bayer_to_bgr(raw[:, :w], enc)), (enc, h, w)
+        # a flat field of one colour comes back flat in that colour's channel
+        flat = np.zeros((12, 12), np.uint8)
+        pat = ocb.PATTERNS[enc]
+        for y in range(12):
+            for x in range(12):
+                flat[y, x] = 200 if pat[y & 1][x & 1] == 2 else 0
+        out = overlay.image_to_bgr8(flat, 12, 12, 12, enc)
+        assert (out[:, :, 2] == 200).all() and (out[:, :, 0] == 0).all() and (out[:, :, 1] == 0).all(), enc
+    # the 8-bit encodings are fid_to_bgr
+    c3 = rng.integers(0, 256, (5, 7, 3), dtype=np.uint8)
+    assert np.array_equal(overlay.image_to_bgr8(c3, 7, 5, 21, "rgb8"), c3[:, :, ::-1])
+    # what is not restated is refused, like the cv_bridge exception the node would catch
+    for enc in ("yuv422", "bayer_rggb16", "32FC1", ""):
+        with pytest.raises(FidError) as e:
+            overlay.image_to_bgr8(c3, 7, 5, 21, enc)
+        assert e.value.status == _lib.FID_E_UNSUPPORTED
+    with pytest.raises(FidError):
+        overlay.image_to_bgr8(np.zeros((4, 8), np.uint8), 4, 4, 7, "mono16")  # a step smaller than a row

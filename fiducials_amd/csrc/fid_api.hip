@@ -56,7 +56,13 @@ struct fid_ctx {
     bool fed_from_host = false;  // the batch in flight came through feed_and_enqueue
     int chain_at = 0;
     bool chained = false;  // the next submit is one of a chain of batches (fid_order_after): one sub-batch, see plan_sub_batches
-    hipEvent_t walk_done[MAX_SUB] = {}, fs_done[MAX_SUB] = {};
+    hipEvent_t walk_done[MAX_SUB] = {}, fs_done[MAX_SUB] = {}, front_done[MAX_SUB] = {};
+    // ONE blocking call laid out like the batches in turn of two contexts (round 5): `pieces` pieces, piece k's front (threshold ..
+    // approxPolyDP) on main stream k & 1, its seedless chain AND its candidate tail (sort .. pose) on auxiliary stream k & 1; piece
+    // k + 1's threshold starts when piece k's find_starts is through -- four streams in all (the runtime's four hardware queues),
+    // the latency-bound tail of a piece under the fronts of the pieces behind it.  0 / 1: the two sub-batches side by side.
+    int pieces = 0;
+    bool piece_chain = false;  // (this call is laid out that way)
     int fs_barrier = 0;                    // FID_FS_BARRIER=1: the walks of every sub-batch wait for all find_starts (measured: find_starts
                                            // 3.6 -> 2.2 ms, the seed walks 3.3 -> 4.9 ms now side by side: the step is the same)     // a sub-batch has left its contour stage (staggered starts, FID_STAGGER)
     int stagger = 0;                        // sub-batch k starts when sub-batch k - stagger has left its contour stage (0: all at once)
@@ -325,6 +331,7 @@ size_t masks_elems(const fid_ctx *c, int W, int H, int F)
 // the streams of sub-batches 0 .. nsub - 1 (and their auxiliary streams in the traced modes), made on first use
 fid_status ensure_streams(fid_ctx *c, int nsub, int F)
 {
+    if (c->piece_chain) nsub = 2;  // (piece k works on main stream k & 1 and auxiliary stream k & 1)
     for (int sb = 0; sb < nsub && sb < fid_ctx::MAX_SUB; sb++) {
         // (sub-batch 0 runs on the context's own stream, which has nothing else to do while a call is under way: a resident batch
         //  then works on four streams -- two sub-batches, two auxiliary -- which is what the HIP runtime's DEFAULT of four hardware
@@ -373,6 +380,11 @@ SubPlan plan_sub_batches(const fid_ctx *c, int F)
             acc += k == 3 ? F - acc : (F * share[k] + 50) / 100;
         }
         pl.f0[4] = F;
+        return pl;
+    }
+    if (c->piece_chain) {
+        pl.nsub = c->pieces < fid_ctx::MAX_SUB ? c->pieces : fid_ctx::MAX_SUB;
+        for (int k = 0; k <= pl.nsub; k++) pl.f0[k] = (int)((long long)F * k / pl.nsub);
         return pl;
     }
     // resident frames: two halves measured best (more streams fight for CUs)
@@ -482,8 +494,11 @@ fid_status enqueue_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H,
     c->res_precleared = false;
     // ---- the batch is cut into sub-batches that run the whole pipeline on their own streams: the latency-bound
     //      tail of one sub-batch's kernels (the longest border, the last candidates) overlaps the next one's bulk
+    c->piece_chain = c->pieces > 1 && !c->chained && !c->host_feed && c->trace_mode == 2 && c->sub_frames <= 0 &&
+                     F >= 32 * c->pieces && c->stagger == 0;
     const SubPlan plan = plan_sub_batches(c, F);
     const int nsub = plan.nsub;
+    const bool chainp = c->piece_chain;
     c->last_nsub = nsub;
     {
         const fid_status rcs = ensure_streams(c, nsub, F);
@@ -496,8 +511,10 @@ fid_status enqueue_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H,
     bool tail_recorded = false;
     auto sub_phase = [&](int sb, int phase) -> fid_status {
         const int f0 = plan.f0[sb], Fs = plan.f0[sb + 1] - f0;
-        hipStream_t st = nsub > 1 ? c->sub_stream[sb] : st0;
+        hipStream_t st = nsub > 1 ? c->sub_stream[chainp ? (sb & 1) : sb] : st0;
         if (nsub > 1 && phase == 0) HIPCHK(c, hipStreamWaitEvent(st, c->fork_ev, 0));
+        // (a chain of pieces: this one's threshold starts when the piece before it is through its find_starts)
+        if (chainp && phase == 0 && sb > 0) HIPCHK(c, hipStreamWaitEvent(st, c->fs_done[sb - 1], 0));
         if (c->host_feed && phase == 0) HIPCHK(c, hipStreamWaitEvent(st, c->in_ready[sb], 0));
         // staggered starts: the contour stage of a sub-batch (threshold ... approx) keeps the whole chip busy, what follows
         // (candidates, identification, corners) is a chain of short latency-bound kernels -- let the next sub-batch's contour
@@ -589,7 +606,7 @@ fid_status enqueue_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H,
         }
         return FID_OK;
       }
-        if (c->trace_mode >= 1 && nsub > 1 && c->fs_barrier)
+        if (c->trace_mode >= 1 && nsub > 1 && c->fs_barrier && !chainp)
             for (int o = 0; o < nsub; o++)
                 if (o != sb) HIPCHK(c, hipStreamWaitEvent(st, c->fs_done[o], 0));
         // persistent walker workgroups (WALK_WAVES waves each) per frame: about 16 waves per CU over the sub-batch
@@ -638,7 +655,7 @@ fid_status enqueue_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H,
             //      seed state (probe passes that drop a start at the first seed state, survivor walk, contour list B, copy,
             //      approxPolyDP) -- off the critical path, it used to be 2.9 ms of a 9.6 ms sub-batch.  Both append candidates;
             //      the streams join in front of k_sort_cands.
-            hipStream_t sa = c->aux_stream[sb];
+            hipStream_t sa = c->aux_stream[chainp ? (sb & 1) : sb];
             HIPCHK(c, hipEventRecord(c->aux_fork[sb], st));
             HIPCHK(c, hipStreamWaitEvent(sa, c->aux_fork[sb], 0));
             // about 4 walker waves per CU over the sub-batch (34 KB LDS per 2-wave workgroup: two of them leave a CU room for
@@ -704,7 +721,15 @@ fid_status enqueue_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H,
                                P.maxPerim + 1, K4_LONG_STACK, 1, dense, cbase, 1);
             mark(ST_APPROX + 1);
             chain_point(3);
-            HIPCHK(c, hipStreamWaitEvent(st, c->aux_join[sb], 0));
+            if (chainp) {
+                // the candidate tail of this piece moves to its auxiliary stream (behind the seedless chain, which is there already):
+                // the main stream is free for the front of the piece after next
+                HIPCHK(c, hipEventRecord(c->front_done[sb], st));
+                HIPCHK(c, hipStreamWaitEvent(sa, c->front_done[sb], 0));
+                st = sa;
+            } else {
+                HIPCHK(c, hipStreamWaitEvent(st, c->aux_join[sb], 0));
+            }
           } else {
             // the seed walk needs only the seeds: it runs on its own stream beside the probe passes and the survivor walk
             // (both walks are a throughput phase followed by a tail of a few long walkers; side by side the tails overlap)
@@ -794,15 +819,27 @@ fid_status enqueue_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H,
         chain_point(99);
         if (nsub > 1) {
             HIPCHK(c, hipEventRecord(c->sub_done[sb], st));
-            HIPCHK(c, hipStreamWaitEvent(st0, c->sub_done[sb], 0));
+            // (a chain of pieces: the context's stream carries the fronts of the even pieces -- it waits for the tails when all
+            //  pieces are enqueued, below)
+            if (!chainp) HIPCHK(c, hipStreamWaitEvent(st0, c->sub_done[sb], 0));
         }
         return FID_OK;
     };
-    for (int phase = 0; phase < 2; phase++)
-        for (int sb = 0; sb < nsub; sb++) {
-            const fid_status rcs = sub_phase(sb, phase);
-            if (rcs != FID_OK) return rcs;
-        }
+    if (chainp) {
+        // piece by piece: piece k + 2 goes behind piece k on the same two streams
+        for (int sb = 0; sb < nsub; sb++)
+            for (int phase = 0; phase < 2; phase++) {
+                const fid_status rcs = sub_phase(sb, phase);
+                if (rcs != FID_OK) return rcs;
+            }
+        for (int sb = 0; sb < nsub; sb++) HIPCHK(c, hipStreamWaitEvent(st0, c->sub_done[sb], 0));
+    } else {
+        for (int phase = 0; phase < 2; phase++)
+            for (int sb = 0; sb < nsub; sb++) {
+                const fid_status rcs = sub_phase(sb, phase);
+                if (rcs != FID_OK) return rcs;
+            }
+    }
     hipStream_t st = st0;
     const DevParams &P = c->P;
     HIPCHK(c, hipGetLastError());
@@ -1094,6 +1131,7 @@ fid_status fid_create(const fid_params *params, const fid_dict *dict, const fid_
         TRYHIP(hipEventCreateWithFlags(&c->walk_done[sb], hipEventDisableTiming));
         TRYHIP(hipEventCreateWithFlags(&c->in_ready[sb], hipEventDisableTiming));
         TRYHIP(hipEventCreateWithFlags(&c->fs_done[sb], hipEventDisableTiming));
+        TRYHIP(hipEventCreateWithFlags(&c->front_done[sb], hipEventDisableTiming));
         TRYHIP(hipEventCreateWithFlags(&c->aux_idx[sb], hipEventDisableTiming));
         for (int i = 0; i < 20; i++) TRYHIP(hipEventCreate(&c->sub_ev[sb][i]));
     }
@@ -1117,6 +1155,7 @@ fid_status fid_create(const fid_params *params, const fid_dict *dict, const fid_
     if (const char *tm = getenv("FID_TRACE")) c->trace_mode = !strcmp(tm, "legacy") ? 0 : !strcmp(tm, "chain") ? 1 : 2;
     if (getenv("FID_SW_BLOCKS")) c->sw_blocks = atoi(getenv("FID_SW_BLOCKS"));
     if (getenv("FID_STAGGER")) c->stagger = atoi(getenv("FID_STAGGER"));
+    if (getenv("FID_PIECES")) c->pieces = atoi(getenv("FID_PIECES"));
     if (getenv("FID_FS_BARRIER")) c->fs_barrier = atoi(getenv("FID_FS_BARRIER"));
     if (getenv("FID_PROBE_LUT")) c->probe_lut = atoi(getenv("FID_PROBE_LUT"));
     if (getenv("FID_TAIL_GRID")) c->tail_grid = atoi(getenv("FID_TAIL_GRID"));
@@ -1212,6 +1251,7 @@ void fid_destroy(fid_ctx *c)
         if (c->walk_done[sb]) (void)hipEventDestroy(c->walk_done[sb]);
         if (c->in_ready[sb]) (void)hipEventDestroy(c->in_ready[sb]);
         if (c->fs_done[sb]) (void)hipEventDestroy(c->fs_done[sb]);
+        if (c->front_done[sb]) (void)hipEventDestroy(c->front_done[sb]);
         for (int i = 0; i < 20; i++)
             if (c->sub_ev[sb][i]) (void)hipEventDestroy(c->sub_ev[sb][i]);
         if (c->sub_stream[sb] && c->sub_stream[sb] != c->stream) (void)hipStreamDestroy(c->sub_stream[sb]);
@@ -1364,6 +1404,7 @@ static fid_status feed_and_enqueue_impl(fid_ctx *c, const uint8_t *imgs, int32_t
     // and copies more slowly, the overlap is the same).  A batch of a chain (fid_order_after) is one piece: its copy runs
     // under the kernels of the batch before it, on the other context.
     c->host_feed = getenv("FID_NO_FEED_OVERLAP") == nullptr;
+    c->piece_chain = false;  // (frames that come up from the host are cut by the copy's pieces)
     const SubPlan plan = plan_sub_batches(c, nframes);
     const int nsub = plan.nsub;
     if (c->blocking && nsub == 1 && !c->wait_ev && !c->wait_copy_ev) {

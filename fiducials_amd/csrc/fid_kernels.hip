@@ -1252,8 +1252,12 @@ __device__ __host__ inline int chunk_tab_pitch(const DevParams &P) { return P.ma
 // What is still undecided (or closed with a length that passes the perimeter gate) is appended to the next
 // list with one atomic per wave.  Contours shorter than a probe are rejected here for good when they fail
 // minMarkerPerimeterRate.
+#ifndef PROBE0_STEPS
 #define PROBE0_STEPS 6
+#endif
+#ifndef PROBE1_STEPS
 #define PROBE1_STEPS 32
+#endif
 // STOPSEED (trace mode 2): a start whose walk meets a seed state is dropped -- its border is a seed cycle, k_seg_cycles
 // finds it without a start.
 template <int STEPS, int LEVEL, bool STOPSEED = false>

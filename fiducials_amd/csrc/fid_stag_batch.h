@@ -19,7 +19,15 @@
 #include <utility>
 #include <vector>
 
-#define STAG_MAXF 16  // frames per merged launch (more are launched in pieces)
+#ifndef STAG_MAXF
+// frames per merged launch (more are launched in pieces).  Round 5 moved the routing kernels' context behind a pointer
+// (StagRouteArgs: a frame's argument tuple ~80 instead of ~250 bytes), so the 4 KB of kernel-argument memory would hold 32 or more
+// -- and groups of 32 measured SLOWER than groups of 16 on the cfg 5 batch (128 slots: 4 260 - 4 290 against 4 580 frames/s on the
+// same box; 192 slots in groups of 32: 4 690): the step is not a chain of launches that more frames per launch would amortise, the
+// walk / extraction / refinement kernels are bound by workgroup slots (a 256-thread workgroup with up to 40 KB of LDS per
+// component, one wave of it walking), and twice the frames take twice the rounds.  -DSTAG_MAXF=32 keeps the larger tables.
+#define STAG_MAXF 16
+#endif
 
 template <typename... A>
 struct StagTup;

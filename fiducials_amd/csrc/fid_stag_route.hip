@@ -945,6 +945,13 @@ struct StagArenas {
     int2 *segs;
     StagRec *recs;  // indexed like the anchor slots
 };
+// What the routing kernels know about their context, in DEVICE memory (round 5): passed by value the two structs were ~180 bytes of
+// every frame's argument tuple, and the 4 KB of kernel-argument memory then held 16 frames per merged launch (fid_stag_batch.h);
+// behind a pointer a tuple is ~80 bytes and a group carries 32.  Written by the host when the image size changes.
+struct StagRouteArgs {
+    StagRoute G;
+    StagArenas A;
+};
 
 __device__ void stag_bind(StagRouter &S, const StagRoute &G, const StagArenas &A, const StagComp &C)
 {
@@ -1075,13 +1082,13 @@ __device__ __forceinline__ void k_stag_route_walk_impl(StagRoute G, StagArenas A
         }
     }
 }
-__global__ __launch_bounds__(256) void k_stag_route_walk(StagRoute G, StagArenas A, StagComp *__restrict__ comps, const int *__restrict__ cursors, const int32_t *__restrict__ sorted, const int *__restrict__ aslots, const int *__restrict__ label, int grad_thresh, int lds_bytes, int *__restrict__ prodflag, int *__restrict__ ovf)
+__global__ __launch_bounds__(256) void k_stag_route_walk(const StagRouteArgs *__restrict__ ra, StagComp *__restrict__ comps, const int *__restrict__ cursors, const int32_t *__restrict__ sorted, const int *__restrict__ aslots, const int *__restrict__ label, int grad_thresh, int lds_bytes, int *__restrict__ prodflag, int *__restrict__ ovf)
 {
-    k_stag_route_walk_impl(G, A, comps, cursors, sorted, aslots, label, grad_thresh, lds_bytes, prodflag, ovf);
+    k_stag_route_walk_impl(ra->G, ra->A, comps, cursors, sorted, aslots, label, grad_thresh, lds_bytes, prodflag, ovf);
 }
 struct k_stag_route_walk_fn {
     static constexpr int kBounds = 256;
-    __device__ __forceinline__ void operator()(StagRoute G, StagArenas A, StagComp *__restrict__ comps, const int *__restrict__ cursors, const int32_t *__restrict__ sorted, const int *__restrict__ aslots, const int *__restrict__ label, int grad_thresh, int lds_bytes, int *__restrict__ prodflag, int *__restrict__ ovf) const { k_stag_route_walk_impl(G, A, comps, cursors, sorted, aslots, label, grad_thresh, lds_bytes, prodflag, ovf); }
+    __device__ __forceinline__ void operator()(const StagRouteArgs *__restrict__ ra, StagComp *__restrict__ comps, const int *__restrict__ cursors, const int32_t *__restrict__ sorted, const int *__restrict__ aslots, const int *__restrict__ label, int grad_thresh, int lds_bytes, int *__restrict__ prodflag, int *__restrict__ ovf) const { k_stag_route_walk_impl(ra->G, ra->A, comps, cursors, sorted, aslots, label, grad_thresh, lds_bytes, prodflag, ovf); }
 };
 
 // next[r] = the smallest producing rank > r, or -1 (one workgroup, chunks of 1024 from the top)
@@ -1197,13 +1204,13 @@ __device__ __forceinline__ void k_stag_route_extract_impl(StagRoute G, StagArena
     }
     if (S.overflow && lane == 0) atomicOr(ovf, S.overflow);
 }
-__global__ __launch_bounds__(256) void k_stag_route_extract(StagRoute G, StagArenas A, const StagComp *__restrict__ comps, const int *__restrict__ cursors, const int *__restrict__ next, const unsigned *__restrict__ n_anchors, int *__restrict__ blk_pix, int *__restrict__ blk_segs, int2 *__restrict__ blk_where, int *__restrict__ ovf)
+__global__ __launch_bounds__(256) void k_stag_route_extract(const StagRouteArgs *__restrict__ ra, const StagComp *__restrict__ comps, const int *__restrict__ cursors, const int *__restrict__ next, const unsigned *__restrict__ n_anchors, int *__restrict__ blk_pix, int *__restrict__ blk_segs, int2 *__restrict__ blk_where, int *__restrict__ ovf)
 {
-    k_stag_route_extract_impl(G, A, comps, cursors, next, n_anchors, blk_pix, blk_segs, blk_where, ovf);
+    k_stag_route_extract_impl(ra->G, ra->A, comps, cursors, next, n_anchors, blk_pix, blk_segs, blk_where, ovf);
 }
 struct k_stag_route_extract_fn {
     static constexpr int kBounds = 256;
-    __device__ __forceinline__ void operator()(StagRoute G, StagArenas A, const StagComp *__restrict__ comps, const int *__restrict__ cursors, const int *__restrict__ next, const unsigned *__restrict__ n_anchors, int *__restrict__ blk_pix, int *__restrict__ blk_segs, int2 *__restrict__ blk_where, int *__restrict__ ovf) const { k_stag_route_extract_impl(G, A, comps, cursors, next, n_anchors, blk_pix, blk_segs, blk_where, ovf); }
+    __device__ __forceinline__ void operator()(const StagRouteArgs *__restrict__ ra, const StagComp *__restrict__ comps, const int *__restrict__ cursors, const int *__restrict__ next, const unsigned *__restrict__ n_anchors, int *__restrict__ blk_pix, int *__restrict__ blk_segs, int2 *__restrict__ blk_where, int *__restrict__ ovf) const { k_stag_route_extract_impl(ra->G, ra->A, comps, cursors, next, n_anchors, blk_pix, blk_segs, blk_where, ovf); }
 };
 
 // blk_pix / blk_segs hold exclusive prefix sums by now: copy every block to its place in the global order
@@ -1228,11 +1235,11 @@ __device__ __forceinline__ void k_stag_route_gather_impl(StagArenas A, const Sta
     const int2 *sg = A.segs + C.seg_base + r.seg_off;
     for (int i = lane; i < r.nsegs; i += 64) segs[so + i] = make_int2(sg[i].x - r.out_off + po, sg[i].y);
 }
-__global__ __launch_bounds__(256) void k_stag_route_gather(StagArenas A, const StagComp *__restrict__ comps, const unsigned *__restrict__ n_anchors, const int *__restrict__ prodflag, const int *__restrict__ blk_pix, const int *__restrict__ blk_segs, const int2 *__restrict__ blk_where, int2 *__restrict__ outpix, int2 *__restrict__ segs, int capOut, int capSegs, int *__restrict__ ovf)
+__global__ __launch_bounds__(256) void k_stag_route_gather(const StagRouteArgs *__restrict__ ra, const StagComp *__restrict__ comps, const unsigned *__restrict__ n_anchors, const int *__restrict__ prodflag, const int *__restrict__ blk_pix, const int *__restrict__ blk_segs, const int2 *__restrict__ blk_where, int2 *__restrict__ outpix, int2 *__restrict__ segs, int capOut, int capSegs, int *__restrict__ ovf)
 {
-    k_stag_route_gather_impl(A, comps, n_anchors, prodflag, blk_pix, blk_segs, blk_where, outpix, segs, capOut, capSegs, ovf);
+    k_stag_route_gather_impl(ra->A, comps, n_anchors, prodflag, blk_pix, blk_segs, blk_where, outpix, segs, capOut, capSegs, ovf);
 }
 struct k_stag_route_gather_fn {
     static constexpr int kBounds = 256;
-    __device__ __forceinline__ void operator()(StagArenas A, const StagComp *__restrict__ comps, const unsigned *__restrict__ n_anchors, const int *__restrict__ prodflag, const int *__restrict__ blk_pix, const int *__restrict__ blk_segs, const int2 *__restrict__ blk_where, int2 *__restrict__ outpix, int2 *__restrict__ segs, int capOut, int capSegs, int *__restrict__ ovf) const { k_stag_route_gather_impl(A, comps, n_anchors, prodflag, blk_pix, blk_segs, blk_where, outpix, segs, capOut, capSegs, ovf); }
+    __device__ __forceinline__ void operator()(const StagRouteArgs *__restrict__ ra, const StagComp *__restrict__ comps, const unsigned *__restrict__ n_anchors, const int *__restrict__ prodflag, const int *__restrict__ blk_pix, const int *__restrict__ blk_segs, const int2 *__restrict__ blk_where, int2 *__restrict__ outpix, int2 *__restrict__ segs, int capOut, int capSegs, int *__restrict__ ovf) const { k_stag_route_gather_impl(ra->A, comps, n_anchors, prodflag, blk_pix, blk_segs, blk_where, outpix, segs, capOut, capSegs, ovf); }
 };

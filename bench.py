@@ -148,7 +148,10 @@ def issue_roofline(fps_per_gpu):
             salu += k.get("SQ_INSTS_SALU", 0.0)
             base = name.split("<")[0]
             cand = [v for m, v in by_mangled.items() if base in m]
-            share = (sum(c["fast"] for c in cand) / max(sum(c["valu"] for c in cand), 1)) if cand else 0.0
+            # (round 5: every instruction weighted by 8 ^ loop depth -- tools/isa_classes.py fast_share_depth -- instead of counting a
+            #  prologue like a loop body; files of before carry only the flat share)
+            share = (sum(c["valu"] * (c.get("fast_share_depth") if c.get("fast_share_depth") is not None else c["fast"] / max(c["valu"], 1))
+                         for c in cand) / max(sum(c["valu"] for c in cand), 1)) if cand else 0.0
             t_fast += n * share
             t_slow += n * (1.0 - share)
         peak = valu / (t_fast / p2 + t_slow / p4) if valu > 0 else None
@@ -156,6 +159,8 @@ def issue_roofline(fps_per_gpu):
         out.update({"achieved": round(ach, 1), "peak_measured": round(peak, 1), "frac": round(ach / peak, 4),
                     "valu_wave_instr_per_frame": round(valu), "salu_wave_instr_per_frame": round(salu),
                     "static_2cycle_share": round(t_fast / valu, 3),
+                    "class_mix": "per kernel: share of 2-cycle-class opcodes with every instruction weighted by 8 ^ (loop depth) in the shipped "
+                                 "code object (tools/isa_classes.py), kernels weighted by their SQ_INSTS_VALU",
                     "counters": "profiles/sq_cycles.json (SQ_INSTS_VALU / SQ_INSTS_SALU per frame, one 64-frame sub-batch)"})
         # lane work under the wave-instructions (round 5): SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU) of one counter pass
         # = the share of a wave's 64 lanes that execute per VALU instruction, weighted over the pipeline's kernels by their

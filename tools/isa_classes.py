@@ -9,8 +9,11 @@ instruction is put into the issue class tools/valu_calib.hip MEASURED for its op
                    v_readlane / v_writelane, f64 add / mul / fma)
   slow           v_rcp/sqrt_f64 and friends (quarter of that again)
 Opcodes the calibration does not list are put into the 4-cycle class and counted as `unlisted`.
-Static = every instruction counts once whatever its loop depth: a proxy for the dynamic mix, good enough to say which peak a
-kernel's SQ_INSTS_VALU should be priced against.  Usage: isa_classes.py [lib.so] [calib.json] > profiles/r04_isa_classes.json"""
+`fast_share` is static: every instruction counts once whatever its loop depth.  Round 5 adds the proxy the round-4 review asked for
+-- `fast_share_loops`: the same share over the instructions that lie INSIDE a loop only (a backward branch to an earlier address
+of the same kernel closes a loop; prologues, epilogues and straight-line set-up do not count), and `fast_share_depth`: every
+instruction weighted by 8 ^ (loop depth) -- what a kernel executes most is what its SQ_INSTS_VALU should be priced by.  bench.py
+uses fast_share_loops where a kernel has loops.  Usage: isa_classes.py [lib.so] [calib.json] > profiles/isa_classes.json"""
 import collections
 import hashlib
 import json
@@ -65,17 +68,24 @@ out = {"library_sha256": hashlib.sha256(open(lib, "rb").read()).hexdigest(), "ca
 cur = None
 cnt = collections.defaultdict(collections.Counter)
 unl = collections.Counter()
+insts = collections.defaultdict(list)   # kernel -> [(address, class or None)]
+loops = collections.defaultdict(list)   # kernel -> [(first address, last address)] of every backward branch
+base_addr = {}
 for line in dis.splitlines():
-    m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+    m = re.match(r"^([0-9a-f]+) <(\S+)>:", line)
     if m:
-        cur = m.group(1)
+        cur = m.group(2)
+        base_addr[cur] = int(m.group(1), 16)
         continue
     if cur is None or "\t" not in line:
         continue
     text = line.split("//")[0].strip()
     if not text:
         continue
+    am = re.search(r"//\s*([0-9A-Fa-f]+):", line)
+    addr = int(am.group(1), 16) if am else None
     op = text.split()[0]
+    c = None
     if op.startswith("v_"):
         c = classify(op, text)
         cnt[cur]["valu"] += 1
@@ -84,6 +94,31 @@ for line in dis.splitlines():
             unl[re.sub(r"_(e32|e64)$", "", op)] += 1
     elif op.startswith("s_"):
         cnt[cur]["salu"] += 1
+        if op.startswith(("s_cbranch", "s_branch")) and addr is not None:
+            tm = re.search(r"<(\S+?)\+0x([0-9a-f]+)>\s*$", line)
+            if tm and tm.group(1) == cur:
+                tgt = base_addr[cur] + int(tm.group(2), 16)
+                if tgt <= addr:
+                    loops[cur].append((tgt, addr))
+    if addr is not None:
+        insts[cur].append((addr, c))
+for k in list(cnt):
+    lp = loops.get(k, [])
+    inl = collections.Counter()
+    wsum = collections.Counter()
+    for addr, c in insts[k]:
+        if c is None:
+            continue
+        depth = sum(1 for a, b in lp if a <= addr <= b)
+        cc = "fast" if c == "fast" else "other"
+        if depth > 0:
+            inl[cc] += 1
+        wsum[cc] += 8 ** min(depth, 6)
+    cnt[k]["loop_valu"] = inl["fast"] + inl["other"]
+    cnt[k]["loop_fast"] = inl["fast"]
+    cnt[k]["w_fast"] = wsum["fast"]
+    cnt[k]["w_all"] = wsum["fast"] + wsum["other"]
+    cnt[k]["nloops"] = len(lp)
 for k, c in cnt.items():
     if c["valu"] < 20:
         continue
@@ -92,6 +127,8 @@ for k, c in cnt.items():
     key = short if short not in out["kernels"] else k
     v = c["valu"]
     out["kernels"][key] = {"mangled": k, "valu": v, "salu": c["salu"], "fast": c["fast"], "slow4": c["slow4"] + c["unlisted"], "veryslow": c["veryslow"],
-                           "unlisted": c["unlisted"], "fast_share": round(c["fast"] / v, 4)}
+                           "unlisted": c["unlisted"], "fast_share": round(c["fast"] / v, 4), "loops": c["nloops"], "valu_in_loops": c["loop_valu"],
+                           "fast_share_loops": round(c["loop_fast"] / c["loop_valu"], 4) if c["loop_valu"] else None,
+                           "fast_share_depth": round(c["w_fast"] / c["w_all"], 4) if c["w_all"] else None}
 out["unlisted_opcodes"] = dict(unl.most_common(40))
 json.dump(out, sys.stdout, indent=1)

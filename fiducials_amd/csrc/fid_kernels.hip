@@ -571,6 +571,30 @@ __device__ __forceinline__ void park_quad(uint32_t &a0, uint32_t &a1, unsigned l
 #endif
 }
 
+// Round 5, the default: one v_mov_b64 per row (gfx90a+: a 64-bit move of an SGPR pair into a VGPR pair) instead of two v_mov_b32 --
+// 52 instead of 104 parking instructions of a step's 366 VALU, the mask words of a scale in ONE register pair.  Measured on the
+// bench batch (tools/gpu_sweep.sh, three rounds): the kernel alone 1.73 -> 1.63 ms per 128 frames, beside the other batch's kernels
+// 3.9 - 4.0 -> 3.6 - 3.8 ms, whole pipeline +0.7 % (two contexts), +1 % (one); masks == in every parity test.  -DFID_PARK_MOV32
+// keeps park_quad above.
+__device__ __forceinline__ void park_quad64(unsigned long long &a, unsigned long long b0, unsigned long long b1, unsigned long long b2,
+                                            unsigned long long b3, int sel)
+{
+    unsigned long long keep;
+    asm("s_mov_b64 %1, exec\n\t"
+        "s_lshl_b64 exec, 1, %2\n\t"
+        "v_mov_b64 %0, %3\n\t"
+        "s_lshl_b64 exec, exec, 1\n\t"
+        "v_mov_b64 %0, %4\n\t"
+        "s_lshl_b64 exec, exec, 1\n\t"
+        "v_mov_b64 %0, %5\n\t"
+        "s_lshl_b64 exec, exec, 1\n\t"
+        "v_mov_b64 %0, %6\n\t"
+        "s_mov_b64 exec, %1"
+        : "+v"(a), "=&s"(keep)
+        : "s"(sel), "s"(b0), "s"(b1), "s"(b2), "s"(b3)
+        : "scc");
+}
+
 template <int WMIN, int WSTEP, int NS, int NW, bool SPLIT>
 __global__ __launch_bounds__(64 * (NW + 1)) void k_threshold_stream(const uint8_t *__restrict__ gray, long long gfstride,
                                                                       uint32_t *__restrict__ masks, const DevParams P, int RS, int xcd_map)
@@ -675,7 +699,11 @@ __global__ __launch_bounds__(64 * (NW + 1)) void k_threshold_stream(const uint8_
     };
     int V[NS];
     uint32_t ca[NS], cb[NS], cc[NS];  // carried halves of the previous aligned quads (see the step)
+#ifndef FID_PARK_MOV32
+    unsigned long long acc[NS];
+#else
     uint32_t acc0[NS], acc1[NS];
+#endif
     if (wave_on) {
         static_for<NS>([&](auto sc) {
             constexpr int s = decltype(sc)::value;
@@ -689,7 +717,11 @@ __global__ __launch_bounds__(64 * (NW + 1)) void k_threshold_stream(const uint8_
             }
             // the test  box >= (gray + idelta) * w2 - (w2 - 1) / 2  is kept as  V >= gray * w2
             V[s] = (int)sum - (P.idelta * w2 - (w2 - 1) / 2);
+#ifndef FID_PARK_MOV32
+            acc[s] = 0ull;
+#else
             acc0[s] = acc1[s] = 0;
+#endif
             if constexpr ((r & 3) == 1) {
                 const uint2 e = hquad(Q0 + (r + 3) / 4 - 1, r);  // entering side, off by one row: previous quad, both halves
                 ca[s] = e.x;
@@ -712,8 +744,13 @@ __global__ __launch_bounds__(64 * (NW + 1)) void k_threshold_stream(const uint8_
             const uint32_t m0w = (uint32_t)vmask, m1w = (uint32_t)(vmask >> 32);  // columns right of the image stay zero
 #pragma unroll
             for (int s = 0; s < NS; s++) {
+#ifndef FID_PARK_MOV32
+                q[(long long)s * plane] = (uint32_t)acc[s] & m0w;
+                if (two) q[(long long)s * plane + MT_ROWS] = (uint32_t)(acc[s] >> 32) & m1w;
+#else
                 q[(long long)s * plane] = acc0[s] & m0w;
                 if (two) q[(long long)s * plane + MT_ROWS] = acc1[s] & m1w;
+#endif
             }
         }
     };
@@ -786,7 +823,11 @@ __global__ __launch_bounds__(64 * (NW + 1)) void k_threshold_stream(const uint8_
                 v = __builtin_amdgcn_sdot2(dhi, second, v, false);
                 const unsigned long long b3 = ballot64(v >= __mul24((int)g3, w2));
                 V[s] = v;
+#ifndef FID_PARK_MOV32
+                park_quad64(acc[s], b0, b1, b2, b3, sel);
+#else
                 park_quad(acc0[s], acc1[s], b0, b1, b2, b3, sel);
+#endif
                 cur = nxt;
             });
             if (sel == 60 || k == nsteps - 1) flush(ys + ((4 * k) & ~63));

@@ -3371,6 +3371,7 @@ __global__ __launch_bounds__(256) void k_near(const DevCand *__restrict__ sorted
     const float4 *cm = cmeta + (long long)f * P.maxCands;
     uint32_t *nb = nearb + (long long)f * P.maxCands * NW;
     const int lane = lane_id();
+    const float rate_f = (float)P.minMarkerDistRate * 1.0001f;
     const int wave = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)), nwaves = (int)(gridDim.x * (blockDim.x >> 6));
     for (int item = wave; item < n * nw2; item += nwaves) {
         const int i = item / nw2, w2 = item - i * nw2;
@@ -3380,11 +3381,13 @@ __global__ __launch_bounds__(256) void k_near(const DevCand *__restrict__ sorted
         const float4 ma = cm[i];
         bool close = false;
         if (valid) {
+            // (a PRE-filter: it only has to keep every pair the exact test below can accept, so single precision with a margin
+            //  that dwarfs its rounding does what the double-precision form did with a fifth of the issue slots -- round 5)
             const float4 mo = cm[j];
-            const double sz = ma.z < mo.z ? ma.z : mo.z;
-            double lim = sz * P.minMarkerDistRate;
-            lim = 16. * (lim * lim * (1. + 1e-5) + 1.);
-            const double dx = (double)ma.x - (double)mo.x, dy = (double)ma.y - (double)mo.y;
+            const float sz = ma.z < mo.z ? ma.z : mo.z;
+            const float lim0 = sz * rate_f;
+            const float lim = 16.f * (lim0 * lim0 * 1.001f + 1.f) + 1.f;
+            const float dx = ma.x - mo.x, dy = ma.y - mo.y;
             close = dx * dx + dy * dy < lim;  // (otherwise: centroids too far apart for any shift)
         }
         bool near = false;

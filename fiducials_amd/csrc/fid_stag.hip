@@ -516,8 +516,6 @@ struct fid_stag_ctx {
     // the whole frame is enqueued without a host wait (stag_advance_impl)
     StagPred pred;
     int *d_specbad = nullptr;
-    StagRouteArgs *d_rargs = nullptr;  // the routing kernels' view of this context (fid_stag_route.hip), rewritten when the image size changes
-    StagRouteArgs h_rargs = {};
     int spec_frames = 0, spec_misses = 0;
 };
 
@@ -610,8 +608,6 @@ fid_status fid_stag_create(int libraryHD, int errorCorrection, int max_width, in
          hipMalloc((void **)&c->d_markers, (n / 9 + 16) * sizeof(fid_stag_marker)) == hipSuccess &&
          hipMalloc((void **)&c->d_found, (n / 9 + 16) * 4) == hipSuccess && hipMalloc((void **)&c->d_nmarkers, 4) == hipSuccess;
     ok = ok && hipMalloc((void **)&c->d_specbad, 16) == hipSuccess && hipMemset(c->d_specbad, 0, 16) == hipSuccess;
-    ok = ok && hipMalloc((void **)&c->d_rargs, sizeof(StagRouteArgs)) == hipSuccess;
-    memset(&c->h_rargs, 0, sizeof(c->h_rargs));
     ok = ok && hipMalloc((void **)&c->d_chosen, (n / 9 + 16) * 4) == hipSuccess &&
          hipMalloc((void **)&c->d_poses, (n / 9 + 16) * sizeof(fid_stag_pose_out)) == hipSuccess;
     ok = ok && hipHostMalloc((void **)&c->hp, sizeof(fid_stag_ctx::Pinned), hipHostMallocDefault) == hipSuccess &&
@@ -654,7 +650,7 @@ void fid_stag_destroy(fid_stag_ctx *c)
                    c->d_prefix, c->d_lslots, c->d_lines, c->d_lcounts, c->d_ltotal,
                    c->d_atan_lut, c->d_kmin, c->d_lflags, c->d_vltotal, c->d_vlines,
                    c->d_lrange, c->d_corners, c->d_order, c->d_qcounts, c->d_qtotal, c->d_qslots, c->d_quads,
-                   c->d_locs, c->d_words, c->d_cand, c->d_markers, c->d_found, c->d_nmarkers, c->d_chosen, c->d_poses, c->d_specbad, c->d_rargs};
+                   c->d_locs, c->d_words, c->d_cand, c->d_markers, c->d_found, c->d_nmarkers, c->d_chosen, c->d_poses, c->d_specbad};
     for (void *p : dev)
         if (p) (void)hipFree(p);
     if (c->hp) {
@@ -903,17 +899,6 @@ static fid_status stag_advance_impl(fid_stag_ctx *c, StagJob &j)
         R.capPix = (int)((size_t)c->maxW * c->maxH); R.capStack = R.capPix; R.capChains = 32767; R.capNos = (c->maxW + c->maxH) * 8;
         R.outpix = c->d_outpix; R.segs = c->d_segs; R.capOut = R.capPix; R.capSegs = R.capPix / 8 + 16;
         R.counters = c->d_rcount;
-        {
-            StagRouteArgs ra;
-            memset(&ra, 0, sizeof(ra));
-            ra.G = R;
-            ra.A.pix = c->d_apix; ra.A.stack = c->d_astack; ra.A.chains = c->d_achains; ra.A.out = c->d_aout; ra.A.segs = c->d_asegs; ra.A.recs = c->d_recs;
-            if (memcmp(&ra, &c->h_rargs, sizeof(ra)) != 0) {
-                // (the context's last frame is through: nothing on the device reads the block while it is rewritten)
-                if (hipMemcpy(c->d_rargs, &ra, sizeof(ra), hipMemcpyHostToDevice) != hipSuccess) return stag_finish(j, FID_E_HIP);
-                c->h_rargs = ra;
-            }
-        }
         j.seg = 2;
         if (c->route_mode != 1) return stag_launch_route_seq(c, j) ? FID_OK : stag_finish(j, FID_E_HIP);
         if (STAG_MEMCPY(c->d_edgeimg, c->d_edge, (size_t)n, hipMemcpyDeviceToDevice, st) != hipSuccess) return stag_finish(j, FID_E_HIP);
@@ -999,7 +984,8 @@ static fid_status stag_advance_impl(fid_stag_ctx *c, StagJob &j)
             // pixels of the output arena the extraction does not write read as (-1, -1), like the reference's untouched array
             if (cur[5] > 0 && STAG_MEMSET(c->d_aout, 0xff, (size_t)cur[5] * sizeof(int2), st) != hipSuccess) return stag_finish(j, FID_E_HIP);
             const int nc = cur[0];
-            const StagRouteArgs *RA = c->d_rargs;
+            StagArenas A;
+            A.pix = c->d_apix; A.stack = c->d_astack; A.chains = c->d_achains; A.out = c->d_aout; A.segs = c->d_asegs; A.recs = c->d_recs;
             int *ovf = c->d_cursors + 8;
             if (nc > 0) {
                 STAG_LAUNCH(k_stag_comp_sort, dim3((nc + 3) / 4), dim3(256), 0, st, c->d_comps, c->d_cursors, c->d_aslots);
@@ -1008,12 +994,12 @@ static fid_status stag_advance_impl(fid_stag_ctx *c, StagJob &j)
                 // LDS per workgroup = the largest tile a component of this frame asks for (components whose box does not fit 150 KB
                 // walk in global memory): frames of small components keep many workgroups per CU
                 const int lds = c->route_tile ? ((cur[10] + 1023) / 1024) * 1024 : 0;
-                STAG_LAUNCH(k_stag_route_walk, dim3(nc), dim3(256), (size_t)lds, st, RA, c->d_comps, c->d_cursors, c->d_sorted, c->d_aslots,
+                STAG_LAUNCH(k_stag_route_walk, dim3(nc), dim3(256), (size_t)lds, st, j.R, A, c->d_comps, c->d_cursors, c->d_sorted, c->d_aslots,
                                    c->d_label, 16, lds, c->d_prodflag, ovf);
             }
             STAG_LAUNCH(k_stag_next_above, dim3(1), dim3(1024), 0, st, c->d_prodflag, c->d_n, c->d_next);
             if (nc > 0)
-                STAG_LAUNCH(k_stag_route_extract, dim3((nc + 3) / 4), dim3(256), 0, st, RA, c->d_comps, c->d_cursors, c->d_next, c->d_n,
+                STAG_LAUNCH(k_stag_route_extract, dim3((nc + 3) / 4), dim3(256), 0, st, j.R, A, c->d_comps, c->d_cursors, c->d_next, c->d_n,
                                    c->d_blkpix, c->d_blksegs, c->d_blkwhere, ovf);
             {
                 StagScanJobs sj;
@@ -1021,7 +1007,7 @@ static fid_status stag_advance_impl(fid_stag_ctx *c, StagJob &j)
                 sj.counts[1] = c->d_blksegs; sj.total[1] = c->d_rcount;
                 STAG_LAUNCH(k_stag_scan_counts_n, dim3(2), dim3(1024), 0, st, sj, (const int *)c->d_n);
             }
-            STAG_LAUNCH(k_stag_route_gather, dim3((na + 3) / 4), dim3(256), 0, st, RA, c->d_comps, c->d_n, c->d_prodflag, c->d_blkpix, c->d_blksegs,
+            STAG_LAUNCH(k_stag_route_gather, dim3((na + 3) / 4), dim3(256), 0, st, A, c->d_comps, c->d_n, c->d_prodflag, c->d_blkpix, c->d_blksegs,
                                c->d_blkwhere, c->d_outpix, c->d_segs, j.R.capOut, j.R.capSegs, ovf);
             if (hipGetLastError() != hipSuccess) return stag_finish(j, FID_E_HIP);
             if (!j.spec && (STAG_MEMCPY(c->hp->rcount, c->d_rcount, 8, hipMemcpyDeviceToHost, st) != hipSuccess ||

@@ -20,12 +20,12 @@
 #include <vector>
 
 #ifndef STAG_MAXF
-// frames per merged launch (more are launched in pieces).  Round 5 moved the routing kernels' context behind a pointer
-// (StagRouteArgs: a frame's argument tuple ~80 instead of ~250 bytes), so the 4 KB of kernel-argument memory would hold 32 or more
-// -- and groups of 32 measured SLOWER than groups of 16 on the cfg 5 batch (128 slots: 4 260 - 4 290 against 4 580 frames/s on the
-// same box; 192 slots in groups of 32: 4 690): the step is not a chain of launches that more frames per launch would amortise, the
-// walk / extraction / refinement kernels are bound by workgroup slots (a 256-thread workgroup with up to 40 KB of LDS per
-// component, one wave of it walking), and twice the frames take twice the rounds.  -DSTAG_MAXF=32 keeps the larger tables.
+// frames per merged launch (more are launched in pieces): what 4 KB of kernel-argument memory hold of the routing kernels' ~250-byte
+// tuples.  Round 5 tried the routing kernels' context behind a pointer (a tuple of ~80 bytes, groups of 32): groups of 32 measured
+// 7 % SLOWER than groups of 16 on the cfg 5 batch (128 slots: 4 260 - 4 290 against 4 580 frames/s) -- the walk / extraction /
+// refinement kernels are bound by workgroup slots, twice the frames take twice the rounds -- and pointers LOADED from memory are
+// generic pointers to the compiler (flat_load / flat_store, which also count as LDS operations), where pointers that arrive as
+// kernel arguments are promoted to global ones: k_stag_route_walk 1.40 -> 2.15 ms per group.  Reverted: by value, 16.
 #define STAG_MAXF 16
 #endif
 

@@ -945,13 +945,6 @@ struct StagArenas {
     int2 *segs;
     StagRec *recs;  // indexed like the anchor slots
 };
-// What the routing kernels know about their context, in DEVICE memory (round 5): passed by value the two structs were ~180 bytes of
-// every frame's argument tuple, and the 4 KB of kernel-argument memory then held 16 frames per merged launch (fid_stag_batch.h);
-// behind a pointer a tuple is ~80 bytes and a group carries 32.  Written by the host when the image size changes.
-struct StagRouteArgs {
-    StagRoute G;
-    StagArenas A;
-};
 
 __device__ void stag_bind(StagRouter &S, const StagRoute &G, const StagArenas &A, const StagComp &C)
 {
@@ -1082,13 +1075,13 @@ __device__ __forceinline__ void k_stag_route_walk_impl(StagRoute G, StagArenas A
         }
     }
 }
-__global__ __launch_bounds__(256) void k_stag_route_walk(const StagRouteArgs *__restrict__ ra, StagComp *__restrict__ comps, const int *__restrict__ cursors, const int32_t *__restrict__ sorted, const int *__restrict__ aslots, const int *__restrict__ label, int grad_thresh, int lds_bytes, int *__restrict__ prodflag, int *__restrict__ ovf)
+__global__ __launch_bounds__(256) void k_stag_route_walk(StagRoute G, StagArenas A, StagComp *__restrict__ comps, const int *__restrict__ cursors, const int32_t *__restrict__ sorted, const int *__restrict__ aslots, const int *__restrict__ label, int grad_thresh, int lds_bytes, int *__restrict__ prodflag, int *__restrict__ ovf)
 {
-    k_stag_route_walk_impl(ra->G, ra->A, comps, cursors, sorted, aslots, label, grad_thresh, lds_bytes, prodflag, ovf);
+    k_stag_route_walk_impl(G, A, comps, cursors, sorted, aslots, label, grad_thresh, lds_bytes, prodflag, ovf);
 }
 struct k_stag_route_walk_fn {
     static constexpr int kBounds = 256;
-    __device__ __forceinline__ void operator()(const StagRouteArgs *__restrict__ ra, StagComp *__restrict__ comps, const int *__restrict__ cursors, const int32_t *__restrict__ sorted, const int *__restrict__ aslots, const int *__restrict__ label, int grad_thresh, int lds_bytes, int *__restrict__ prodflag, int *__restrict__ ovf) const { k_stag_route_walk_impl(ra->G, ra->A, comps, cursors, sorted, aslots, label, grad_thresh, lds_bytes, prodflag, ovf); }
+    __device__ __forceinline__ void operator()(StagRoute G, StagArenas A, StagComp *__restrict__ comps, const int *__restrict__ cursors, const int32_t *__restrict__ sorted, const int *__restrict__ aslots, const int *__restrict__ label, int grad_thresh, int lds_bytes, int *__restrict__ prodflag, int *__restrict__ ovf) const { k_stag_route_walk_impl(G, A, comps, cursors, sorted, aslots, label, grad_thresh, lds_bytes, prodflag, ovf); }
 };
 
 // next[r] = the smallest producing rank > r, or -1 (one workgroup, chunks of 1024 from the top)
@@ -1175,6 +1168,12 @@ __device__ __forceinline__ void k_stag_route_extract_impl(StagRoute G, StagArena
     for (int k = 0; k < C.nrec; k++) {
         StagRec r = recs[k];
         S.R.pix = pix0 + r.pix_off;
+        // the block the reference wrote just before this one: ours only if no other component produced in between
+        S.prev_valid = k > 0 && next[r.rank] == prev_rank;
+        const int seg0 = S.noSegments, out0 = S.totalPixels;
+        // (the tree pointers are set and used INSIDE each branch on purpose: merged in front of one call site they are "LDS or
+        //  global", i.e. generic, and every access to the chain tree was a flat_load / flat_store -- 63 of them in this kernel --
+        //  that waits like an LDS and a memory operation at once; per branch the compiler knows which it is: ds_* in the common case)
         if (r.nchains <= EX_CHAINS) {
             for (int i = lane; i < r.nchains; i += 64) s_chains[wv][i] = chain0[r.chain_off + i];
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -1183,15 +1182,13 @@ __device__ __forceinline__ void k_stag_route_extract_impl(StagRoute G, StagArena
             S.R.chains = s_chains[wv];
             S.R.stack = s_stack[wv];
             S.R.capStack = EX_CHAINS;
+            S.extract_anchor(r.nchains);
         } else {
             S.R.chains = chain0 + r.chain_off;
             S.R.stack = stack0;
             S.R.capStack = capStack0;
+            S.extract_anchor(r.nchains);
         }
-        // the block the reference wrote just before this one: ours only if no other component produced in between
-        S.prev_valid = k > 0 && next[r.rank] == prev_rank;
-        const int seg0 = S.noSegments, out0 = S.totalPixels;
-        S.extract_anchor(r.nchains);
         r.out_off = out0; r.out_len = S.totalPixels - out0;
         r.seg_off = seg0; r.nsegs = S.noSegments - seg0;
         recs[k] = r;
@@ -1204,13 +1201,13 @@ __device__ __forceinline__ void k_stag_route_extract_impl(StagRoute G, StagArena
     }
     if (S.overflow && lane == 0) atomicOr(ovf, S.overflow);
 }
-__global__ __launch_bounds__(256) void k_stag_route_extract(const StagRouteArgs *__restrict__ ra, const StagComp *__restrict__ comps, const int *__restrict__ cursors, const int *__restrict__ next, const unsigned *__restrict__ n_anchors, int *__restrict__ blk_pix, int *__restrict__ blk_segs, int2 *__restrict__ blk_where, int *__restrict__ ovf)
+__global__ __launch_bounds__(256) void k_stag_route_extract(StagRoute G, StagArenas A, const StagComp *__restrict__ comps, const int *__restrict__ cursors, const int *__restrict__ next, const unsigned *__restrict__ n_anchors, int *__restrict__ blk_pix, int *__restrict__ blk_segs, int2 *__restrict__ blk_where, int *__restrict__ ovf)
 {
-    k_stag_route_extract_impl(ra->G, ra->A, comps, cursors, next, n_anchors, blk_pix, blk_segs, blk_where, ovf);
+    k_stag_route_extract_impl(G, A, comps, cursors, next, n_anchors, blk_pix, blk_segs, blk_where, ovf);
 }
 struct k_stag_route_extract_fn {
     static constexpr int kBounds = 256;
-    __device__ __forceinline__ void operator()(const StagRouteArgs *__restrict__ ra, const StagComp *__restrict__ comps, const int *__restrict__ cursors, const int *__restrict__ next, const unsigned *__restrict__ n_anchors, int *__restrict__ blk_pix, int *__restrict__ blk_segs, int2 *__restrict__ blk_where, int *__restrict__ ovf) const { k_stag_route_extract_impl(ra->G, ra->A, comps, cursors, next, n_anchors, blk_pix, blk_segs, blk_where, ovf); }
+    __device__ __forceinline__ void operator()(StagRoute G, StagArenas A, const StagComp *__restrict__ comps, const int *__restrict__ cursors, const int *__restrict__ next, const unsigned *__restrict__ n_anchors, int *__restrict__ blk_pix, int *__restrict__ blk_segs, int2 *__restrict__ blk_where, int *__restrict__ ovf) const { k_stag_route_extract_impl(G, A, comps, cursors, next, n_anchors, blk_pix, blk_segs, blk_where, ovf); }
 };
 
 // blk_pix / blk_segs hold exclusive prefix sums by now: copy every block to its place in the global order
@@ -1235,11 +1232,11 @@ __device__ __forceinline__ void k_stag_route_gather_impl(StagArenas A, const Sta
     const int2 *sg = A.segs + C.seg_base + r.seg_off;
     for (int i = lane; i < r.nsegs; i += 64) segs[so + i] = make_int2(sg[i].x - r.out_off + po, sg[i].y);
 }
-__global__ __launch_bounds__(256) void k_stag_route_gather(const StagRouteArgs *__restrict__ ra, const StagComp *__restrict__ comps, const unsigned *__restrict__ n_anchors, const int *__restrict__ prodflag, const int *__restrict__ blk_pix, const int *__restrict__ blk_segs, const int2 *__restrict__ blk_where, int2 *__restrict__ outpix, int2 *__restrict__ segs, int capOut, int capSegs, int *__restrict__ ovf)
+__global__ __launch_bounds__(256) void k_stag_route_gather(StagArenas A, const StagComp *__restrict__ comps, const unsigned *__restrict__ n_anchors, const int *__restrict__ prodflag, const int *__restrict__ blk_pix, const int *__restrict__ blk_segs, const int2 *__restrict__ blk_where, int2 *__restrict__ outpix, int2 *__restrict__ segs, int capOut, int capSegs, int *__restrict__ ovf)
 {
-    k_stag_route_gather_impl(ra->A, comps, n_anchors, prodflag, blk_pix, blk_segs, blk_where, outpix, segs, capOut, capSegs, ovf);
+    k_stag_route_gather_impl(A, comps, n_anchors, prodflag, blk_pix, blk_segs, blk_where, outpix, segs, capOut, capSegs, ovf);
 }
 struct k_stag_route_gather_fn {
     static constexpr int kBounds = 256;
-    __device__ __forceinline__ void operator()(const StagRouteArgs *__restrict__ ra, const StagComp *__restrict__ comps, const unsigned *__restrict__ n_anchors, const int *__restrict__ prodflag, const int *__restrict__ blk_pix, const int *__restrict__ blk_segs, const int2 *__restrict__ blk_where, int2 *__restrict__ outpix, int2 *__restrict__ segs, int capOut, int capSegs, int *__restrict__ ovf) const { k_stag_route_gather_impl(ra->A, comps, n_anchors, prodflag, blk_pix, blk_segs, blk_where, outpix, segs, capOut, capSegs, ovf); }
+    __device__ __forceinline__ void operator()(StagArenas A, const StagComp *__restrict__ comps, const unsigned *__restrict__ n_anchors, const int *__restrict__ prodflag, const int *__restrict__ blk_pix, const int *__restrict__ blk_segs, const int2 *__restrict__ blk_where, int2 *__restrict__ outpix, int2 *__restrict__ segs, int capOut, int capSegs, int *__restrict__ ovf) const { k_stag_route_gather_impl(A, comps, n_anchors, prodflag, blk_pix, blk_segs, blk_where, outpix, segs, capOut, capSegs, ovf); }
 };

@@ -2412,8 +2412,12 @@ __device__ __forceinline__ void build_step_lut2(uint8_t *lut, int tid, int nthre
 #ifndef SW_VGPR_ATTR
 #define SW_VGPR_ATTR
 #endif
+#ifndef SW_CKPT
 #define SW_CKPT 8
+#endif
+#ifndef SW_RUN
 #define SW_RUN 32
+#endif
 __global__ __launch_bounds__(64 * SW_WAVES) SW_VGPR_ATTR void k_seed_walk(const uint32_t *__restrict__ masks, const uint2 *__restrict__ seedq,
                                                               uint32_t *__restrict__ chunk_tab, uint32_t *__restrict__ pool,
                                                               DevSegC *__restrict__ segs, DevCounts *__restrict__ counts,

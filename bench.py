@@ -95,9 +95,8 @@ def pmc_traffic(stage, frames_per_launch):
 
         with open(path) as fh:
             doc = json.load(fh)
-        with open(_lib.lib_path(), "rb") as fh:
-            if hashlib.sha256(fh.read()).hexdigest() != doc.get("library_sha256"):
-                return None
+        if not _lib.profile_matches(doc):
+            return None
         t = doc["per_frame_bytes"].get(stage)
         return None if t is None else int(t * frames_per_launch)
     except Exception:
@@ -135,7 +134,7 @@ def issue_roofline(fps_per_gpu):
             cls = json.load(fh)
         with open(os.path.join(ROOT, "profiles", "sq_cycles.json")) as fh:
             sq = json.load(fh)
-        if cls.get("library_sha256") != sha or sq.get("library_sha256") != sha:
+        if not _lib.profile_matches(cls) or not _lib.profile_matches(sq):
             out["note"] = "profiles/sq_cycles.json / isa_classes.json were measured on another build of the library: achieved unknown"
             return out
         by_mangled = {v["mangled"]: v for v in cls["kernels"].values()}
@@ -801,9 +800,8 @@ def stag_pmc_traffic():
 
         with open(os.path.join(ROOT, "profiles", "stag_pmc_traffic.json")) as fh:
             doc = json.load(fh)
-        with open(_lib.lib_path(), "rb") as fh:
-            if hashlib.sha256(fh.read()).hexdigest() != doc.get("library_sha256"):
-                return None
+        if not _lib.profile_matches(doc):
+            return None
         return int(doc["pipeline_bytes_per_frame"])
     except Exception:  # noqa: BLE001
         return None

@@ -102,6 +102,59 @@ class CvException(FidError):
     it and publishes nothing for the frame, aruco_detect.cpp:391-393)."""
 
 
+def device_text_sha256(path: str | None = None) -> str | None:
+    """sha256 of the gfx950 code object's .text inside the library (ELF -> .hip_fatbin -> clang offload bundle -> the gfx950 ELF ->
+    .text), in plain Python.  What the counter files under profiles/ are keyed to since round 5: a rebuild of the same sources
+    changes the bundle's metadata (and so the file's hash) but not a byte of device code, and a change on the HOST side of the
+    library (fid_draw.hip, the parsers) does not make the device counters stale.  None if the file cannot be read that way."""
+    import hashlib
+    import struct
+
+    try:
+        with open(path or lib_path(), "rb") as fh:
+            b = fh.read()
+
+        def sections(e):
+            shoff = struct.unpack_from("<Q", e, 0x28)[0]
+            es, sn, sx = struct.unpack_from("<HHH", e, 0x3A)
+            hs = [struct.unpack_from("<IIQQQQ", e, shoff + i * es) for i in range(sn)]
+            so = hs[sx][4]
+            return {e[so + h[0]:e.index(b"\0", so + h[0])].decode(): (h[4], h[5]) for h in hs}
+
+        off, size = sections(b)[".hip_fatbin"]
+        f = b[off:off + size]
+        if f[:24] != b"__CLANG_OFFLOAD_BUNDLE__":
+            return None
+        n = struct.unpack_from("<Q", f, 24)[0]
+        p = 32
+        for _ in range(n):
+            o, sz, tl = struct.unpack_from("<QQQ", f, p)
+            p += 24
+            triple = f[p:p + tl].decode()
+            p += tl
+            if "gfx950" in triple:
+                co = f[o:o + sz]
+                to, ts = sections(co)[".text"]
+                return hashlib.sha256(co[to:to + ts]).hexdigest()
+    except Exception:  # noqa: BLE001
+        return None
+    return None
+
+
+def profile_matches(doc: dict, path: str | None = None) -> bool:
+    """Is a counter file under profiles/ (keyed to `device_text_sha256`, older ones to `library_sha256`) about THIS library?"""
+    import hashlib
+
+    dev = doc.get("device_text_sha256")
+    if dev:
+        return dev == device_text_sha256(path)
+    try:
+        with open(path or lib_path(), "rb") as fh:
+            return hashlib.sha256(fh.read()).hexdigest() == doc.get("library_sha256")
+    except OSError:
+        return False
+
+
 def lib_path() -> str:
     # FID_LIB lets a developer point at an instrumented build (e.g. -DFID_DEBUG_STATS); it is still libfid_amd
     return os.environ.get("FID_LIB") or _build.LIB

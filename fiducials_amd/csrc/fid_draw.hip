@@ -156,7 +156,9 @@ fid_status fid_to_bgr(const uint8_t *img, int32_t width, int32_t height, int32_t
 //     height <= 2 comes out black.
 // Restated from the published OpenCV 4.2 / cv_bridge (noetic) sources, which are not on this machine: PARITY UNPINNED (no
 // reference fixture uses these encodings); tests/test_overlay.py checks them against an independent statement of the same rules.
-// yuv422 and the 16-bit Bayer encodings stay FID_E_UNSUPPORTED: the node reports them like the cv_bridge exception it would catch.
+//   * yuv422 (UYVY): cvtColor(COLOR_YUV2BGR_UYVY), BT.601 in 20-bit fixed point (below).
+// The 16-bit Bayer encodings and everything else stay FID_E_UNSUPPORTED: the node reports them like the cv_bridge exception it
+// would catch.
 static inline uint8_t cvb_scale_16_to_8(uint16_t v)
 {
     const float a = (float)(255. / 65535.);
@@ -259,6 +261,30 @@ fid_status fid_image_to_bgr8(const uint8_t *img, int32_t width, int32_t height, 
                     o[3 * x + 1] = v[1];
                     o[3 * x + 2] = swap ? v[0] : v[2];
                 }
+            }
+        }
+        return FID_OK;
+    }
+    if (e == "yuv422") {
+        // cv_bridge: YUV422 -> BGR8 is cvtColor(COLOR_YUV2BGR_UYVY): U0 Y0 V0 Y1 per pixel pair, ITU-R BT.601 in 20-bit fixed point
+        // (imgproc color_yuv: ITUR_BT_601_CY 1220542, CUB 2116026, CUG -409993, CVG -852492, CVR 1673527; y = max(0, Y - 16) * CY;
+        //  channel = saturate((y + (1 << 19) + coefficient sums of (U - 128), (V - 128)) >> 20)).  Width must be even.
+        if ((width & 1) || (int64_t)stride < (int64_t)width * 2) return FID_E_INVALID_ARG;
+        const int CY = 1220542, CUB = 2116026, CUG = -409993, CVG = -852492, CVR = 1673527, SH = 20;
+        auto sat = [](int v) { return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); };
+        for (int y = 0; y < height; y++) {
+            const uint8_t *sp = img + (size_t)y * (size_t)stride;
+            uint8_t *o = out_bgr + (size_t)y * (size_t)width * 3;
+            for (int x = 0; x < width; x += 2) {
+                const int u = sp[2 * x] - 128, y0 = sp[2 * x + 1], v = sp[2 * x + 2] - 128, y1 = sp[2 * x + 3];
+                const int ruv = (1 << (SH - 1)) + CVR * v, guv = (1 << (SH - 1)) + CVG * v + CUG * u, buv = (1 << (SH - 1)) + CUB * u;
+                const int a0 = (y0 - 16 > 0 ? y0 - 16 : 0) * CY, a1 = (y1 - 16 > 0 ? y1 - 16 : 0) * CY;
+                o[3 * x] = sat((a0 + buv) >> SH);
+                o[3 * x + 1] = sat((a0 + guv) >> SH);
+                o[3 * x + 2] = sat((a0 + ruv) >> SH);
+                o[3 * x + 3] = sat((a1 + buv) >> SH);
+                o[3 * x + 4] = sat((a1 + guv) >> SH);
+                o[3 * x + 5] = sat((a1 + ruv) >> SH);
             }
         }
         return FID_OK;

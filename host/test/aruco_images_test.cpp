@@ -192,7 +192,7 @@ static void node_surface(const Fixture &fx)
     CHECK(node.enableDetectionsCallback(true, &m) && m == "Enabled aruco detections.");
     CHECK(node.imageCallback(img, &fva) && fva.fiducials.size() == 2);
     Image bad = img;
-    bad.encoding = "yuv422";
+    bad.encoding = "32FC1";
     CHECK(!node.imageCallback(bad, &fva) && !node.lastError().empty());  // like the caught cv_bridge exception: frame dropped
     CHECK(node.lastError().find("cv_bridge exception") == 0);
     {

@@ -440,10 +440,10 @@ const char *fid_png_last_error(void); /* of the calling thread */
  * ------------------------------------------------------------------------------------------------------------------ */
 /* fid_image_to_bgr8 (ABI 6) = cv_bridge::toCvCopy(msg, "bgr8") by the message's encoding STRING, for what a raw camera driver
  * publishes beside the five encodings fid_detect takes itself: mono16 / bgr16 / rgb16 / bgra16 / rgba16 (layout, then
- * convertTo(8U, 255. / 65535.), is_bigendian honoured) and bayer_rggb8 / bayer_bggr8 / bayer_gbrg8 / bayer_grbg8 (OpenCV's bilinear
- * demosaicing under cv_bridge's pattern mapping); the five 8-bit encodings go through fid_to_bgr.  The node converts such a frame
+ * convertTo(8U, 255. / 65535.), is_bigendian honoured), bayer_rggb8 / bayer_bggr8 / bayer_gbrg8 / bayer_grbg8 (OpenCV's bilinear
+ * demosaicing under cv_bridge's pattern mapping) and yuv422 (UYVY, BT.601 fixed point); the five 8-bit encodings go through fid_to_bgr.  The node converts such a frame
  * with this call and hands the BGR8 copy to fid_detect(FID_ENC_BGR8), which is the order the reference works in
- * (aruco_detect.cpp:348-350).  FID_E_UNSUPPORTED: an encoding that is not restated here (yuv422, 16-bit Bayer, ...) -- the node
+ * (aruco_detect.cpp:348-350).  FID_E_UNSUPPORTED: an encoding that is not restated here (16-bit Bayer, float images, ...) -- the node
  * reports it like the cv_bridge exception it would catch (:389-391).  Restated from the published sources: parity unpinned. */
 fid_status fid_image_to_bgr8(const uint8_t *img, int32_t width, int32_t height, int32_t stride_bytes, const char *encoding,
                              int32_t is_bigendian, uint8_t *out_bgr, int64_t out_bytes);

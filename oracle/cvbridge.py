@@ -50,3 +50,18 @@ def to_bgr8_16bit(img16: np.ndarray, encoding: str) -> np.ndarray:
     if encoding in ("bgr16", "bgra16"):
         return np.ascontiguousarray(v[:, :, :3])
     return np.ascontiguousarray(v[:, :, 2::-1])  # rgb16 / rgba16
+
+
+def uyvy_to_bgr(raw: np.ndarray) -> np.ndarray:
+    """raw: (H, W, 2) uint8, bytes U0 Y0 V0 Y1 ... (sensor_msgs 'yuv422'): BT.601 limited range in 20-bit fixed point, as cvtColor
+    (COLOR_YUV2BGR_UYVY) states it: channel = clip((max(Y - 16, 0) * 1220542 + 2^19 + c_u (U - 128) + c_v (V - 128)) >> 20)."""
+    h, w, _ = raw.shape
+    r = raw.astype(np.int64)
+    y = np.maximum(r[:, :, 1] - 16, 0) * 1220542
+    u = np.repeat(r[:, 0::2, 0] - 128, 2, axis=1)
+    v = np.repeat(r[:, 1::2, 0] - 128, 2, axis=1)
+    half = 1 << 19
+    b = (y + half + 2116026 * u) >> 20
+    g = (y + half - 852492 * v - 409993 * u) >> 20
+    rr = (y + half + 1673527 * v) >> 20
+    return np.clip(np.stack([b, g, rr], axis=2), 0, 255).astype(np.uint8)

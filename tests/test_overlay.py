@@ -148,8 +148,27 @@ def test_image_to_bgr8_16bit_and_bayer_encodings():
     # the 8-bit encodings are fid_to_bgr
     c3 = rng.integers(0, 256, (5, 7, 3), dtype=np.uint8)
     assert np.array_equal(overlay.image_to_bgr8(c3, 7, 5, 21, "rgb8"), c3[:, :, ::-1])
+    # yuv422 (UYVY): every (Y, U, V) on a coarse lattice plus random pixels, a padded step
+    ys, us, vs = np.meshgrid(np.arange(0, 256, 5), np.arange(0, 256, 15), np.arange(0, 256, 15), indexing="ij")
+    n = ys.size - (ys.size & 1)
+    img = np.zeros((1, n, 2), np.uint8)
+    img[0, :, 1] = ys.reshape(-1)[:n]
+    img[0, 0::2, 0] = us.reshape(-1)[:n:2]
+    img[0, 1::2, 0] = vs.reshape(-1)[:n:2]
+    assert np.array_equal(overlay.image_to_bgr8(img, n, 1, 2 * n, "yuv422"), ocb.uyvy_to_bgr(img))
+    rnd = rng.integers(0, 256, (9, 14, 2), dtype=np.uint8)
+    rows = np.zeros((9, 14 * 2 + 5), np.uint8)
+    rows[:, :28] = rnd.reshape(9, 28)
+    assert np.array_equal(overlay.image_to_bgr8(rows, 14, 9, rows.shape[1], "yuv422"), ocb.uyvy_to_bgr(rnd))
+    gray = np.zeros((1, 4, 2), np.uint8)
+    gray[0, :, 0] = 128
+    gray[0, :, 1] = (16, 126, 235, 255)
+    out = overlay.image_to_bgr8(gray, 4, 1, 8, "yuv422")
+    assert out[0, :, 0].tolist() == [0, 128, 255, 255] and (out[0, :, 0] == out[0, :, 2]).all()  # neutral chroma: gray, limited range
+    with pytest.raises(FidError):
+        overlay.image_to_bgr8(np.zeros((1, 6), np.uint8), 3, 1, 6, "yuv422")  # odd width
     # what is not restated is refused, like the cv_bridge exception the node would catch
-    for enc in ("yuv422", "bayer_rggb16", "32FC1", ""):
+    for enc in ("yuv422_yuy2", "bayer_rggb16", "32FC1", ""):
         with pytest.raises(FidError) as e:
             overlay.image_to_bgr8(c3, 7, 5, 21, enc)
         assert e.value.status == _lib.FID_E_UNSUPPORTED

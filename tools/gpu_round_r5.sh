@@ -36,7 +36,9 @@ NO_REF=1 timeout 200 python tools/stag_bench.py > $OUT/stag_single.log 2>&1; tai
 python - <<PY
 import json, hashlib
 sha = "$SHA"
-json.dump({"library_sha256": sha, "files": ["r05_kernel_stats.csv", "r05_stag_kernel_stats.csv", "r05_jpeg_kernel_stats.csv"],
+import sys; sys.path.insert(0, "/root/repo")
+from fiducials_amd import _lib
+json.dump({"library_sha256": sha, "device_text_sha256": _lib.device_text_sha256(), "files": ["r05_kernel_stats.csv", "r05_stag_kernel_stats.csv", "r05_jpeg_kernel_stats.csv"],
            "commands": {"r05_kernel_stats.csv": "rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras",
                         "r05_stag_kernel_stats.csv": "rocprofv3 --kernel-trace --stats -- python tools/gpu_stag_batch.py (CTX=64 B=128 STEPS=3)",
                         "r05_jpeg_kernel_stats.csv": "rocprofv3 --kernel-trace --stats -- python tools/gpu_jpeg_bench.py 256 80"}},

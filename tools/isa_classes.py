@@ -63,7 +63,10 @@ with tempfile.TemporaryDirectory() as td:
                            "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"], stderr=subprocess.DEVNULL)
     dis = subprocess.run([f"{LLVM}/llvm-objdump", "-d", "--mcpu=gfx950", co], capture_output=True, text=True, check=True).stdout
 
-out = {"library_sha256": hashlib.sha256(open(lib, "rb").read()).hexdigest(), "calibration": "profiles/r04_valu_calib.json",
+sys.path.insert(0, ROOT)
+from fiducials_amd import _lib as _fl  # noqa: E402
+
+out = {"library_sha256": hashlib.sha256(open(lib, "rb").read()).hexdigest(), "device_text_sha256": _fl.device_text_sha256(lib), "calibration": "profiles/r04_valu_calib.json",
        "classes": {"fast": sorted(fast), "slow4": sorted(slow4), "veryslow": sorted(veryslow)}, "kernels": {}}
 cur = None
 cnt = collections.defaultdict(collections.Counter)

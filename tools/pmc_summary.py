@@ -10,6 +10,8 @@ import json
 import os
 import sys
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # (fiducials_amd._lib.device_text_sha256)
+
 out, frames, lib = sys.argv[1], int(sys.argv[2]), sys.argv[3]
 KNOWN = 1 << 30
 
@@ -62,6 +64,7 @@ doc = {
               "bench.py --batch %d, one sub-batch; calibration kernels tools/pmc_calib.hip (1 GiB each, known byte counts); "
               "script tools/gpu_pmc3.sh" % frames,
     "library_sha256": hashlib.sha256(open(lib, "rb").read()).hexdigest(),
+    "device_text_sha256": __import__("fiducials_amd._lib", fromlist=["_lib"]).device_text_sha256(lib),
     "units": "FETCH_SIZE / WRITE_SIZE are reported in KiB; bytes = value * 1024 * calibration factor",
     "calibration": {"known_bytes": KNOWN, "factor_true_over_counter": {k: round(v, 4) for k, v in sorted(factors.items())},
                     "note": "factor = bytes the calibration kernel really moved / bytes the counter reports, per access pattern; a "

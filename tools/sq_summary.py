@@ -10,6 +10,8 @@ import json
 import os
 import sys
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # (fiducials_amd._lib.device_text_sha256)
+
 B = int(sys.argv[1])
 acc = collections.defaultdict(lambda: collections.defaultdict(float))
 disp = collections.defaultdict(set)
@@ -36,6 +38,7 @@ names = ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "
 lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "fiducials_amd", "lib", "libfid_amd.so")
 out = {"frames_per_launch": B,
        "library_sha256": hashlib.sha256(open(lib, "rb").read()).hexdigest() if os.path.exists(lib) else None,
+       "device_text_sha256": __import__("fiducials_amd._lib", fromlist=["_lib"]).device_text_sha256(lib) if os.path.exists(lib) else None,
        "trace_mode": os.environ.get("FID_TRACE", "cycles"),
        "note": "per kernel: counter sums over all dispatches of the run / (calls x frames per call); a call = one sub-batch of "
                "frames_per_launch frames through the whole pipeline; kernels launched several times per call are summed over "

@@ -16,6 +16,7 @@ FRAMES = 128  # two calls of 64
 doc = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (one counter per run), fid_stag_detect_markers_batch in group mode, "
                  "64 frame slots, 2 calls x 64 frames of the cfg 5 bench frames (tools/stag_pmc.sh)",
        "library_sha256": hashlib.sha256(open("fiducials_amd/lib/libfid_amd.so", "rb").read()).hexdigest(),
+       "device_text_sha256": __import__("fiducials_amd._lib", fromlist=["_lib"]).device_text_sha256("fiducials_amd/lib/libfid_amd.so"),
        "frames_measured": FRAMES, "fetch_factor": 2.0, "write_factor": 1.0,
        "units": "counters in KiB; bytes = value * 1024 * factor (FETCH_SIZE reports half of the bytes on this part: profiles/pmc_traffic.json calibration)",
        "kernels": {}}

@@ -94,6 +94,8 @@ struct fid_ctx {
     uint32_t *d_cbase = nullptr, *d_dense = nullptr;
     uint4 *d_recs = nullptr;  // copy records: pieces of the accepted contours
     int thr_mode = 1;    // node window table: 1 = k_threshold_stream (default), 0 (FID_THR=tile) = k_threshold_fixed
+    int surv_walk_old = 0;  // FID_SURV_WALK=old: the survivors on k_walk_full<2> (until round 5) instead of k_seed_walk<true>
+    int surv_blocks_x = 1;  // FID_SURV_BLOCKS_X: multiplier of the survivor walk's workgroups
     int thr_xcd = 1;  // strips dealt out so that an XCD works through neighbouring strips (FID_THR_XCD=0: plain grid order)
     int thr_nw = 3, thr_split = 0, thr_rows = 0;  // stream kernel: consumer waves per workgroup, un-fused LDS reads, rows per workgroup (0 = automatic)
     int trace_mode = 2;  // 2: cycle tracing (borders read off the seed cycles; starts only for borders without a seed);
@@ -667,8 +669,8 @@ fid_status enqueue_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H,
             // -- the main stream's first kernel goes out BEFORE the auxiliary chain's eight launches: the host needs ~15 us to
             //    enqueue those, and for a single frame the seed walk sat waiting behind them (round 4, cfg 2 timeline)
             if (c->profile) (void)hipEventRecord(ev[14], st);
-            hipLaunchKernelGGL(k_seed_walk, dim3(swb, Fs), dim3(64 * SW_WAVES), 0, st, masks, seedq, tab, pool, (DevSegC *)segs, counts,
-                               c->d_global, P);
+            hipLaunchKernelGGL(k_seed_walk<false>, dim3(swb, Fs), dim3(64 * SW_WAVES), 0, st, masks, seedq, tab, pool, (DevSegC *)segs, counts,
+                               c->d_global, P, (uint4 *)nullptr, (DevPend *)nullptr);
             if (c->profile) (void)hipEventRecord(ev[15], st);
             mark(ST_PROBE + 1);
             chain_point(1);
@@ -688,8 +690,12 @@ fid_status enqueue_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H,
                 hipLaunchKernelGGL((k_probe<PROBE1_STEPS, 1, true>), dim3(16 * gm, Fs), dim3(256), 0, sa, masks, surv1, surv, counts, c->d_global, P);
             }
             const int wb3 = c->walk2_div > 0 ? (wb / c->walk2_div > 0 ? wb / c->walk2_div : 1) : wb2;
-            hipLaunchKernelGGL(k_walk_full<2>, dim3(wb3, Fs), dim3(64 * WALK_WAVES), 0, sa, masks, surv, wres, tab, pool, segs, pend, counts,
-                               c->d_global, P);
+            if (c->surv_walk_old)
+                hipLaunchKernelGGL(k_walk_full<2>, dim3(wb3, Fs), dim3(64 * WALK_WAVES), 0, sa, masks, surv, wres, tab, pool, segs, pend, counts,
+                                   c->d_global, P);
+            else  // (round 5: the survivors on the seed walker's prefetched windows; as many waves as before)
+                hipLaunchKernelGGL(k_seed_walk<true>, dim3(wb3 * (WALK_WAVES / SW_WAVES) * c->surv_blocks_x, Fs), dim3(64 * SW_WAVES), 0, sa, masks,
+                                   (const uint2 *)surv, tab, pool, (DevSegC *)nullptr, counts, c->d_global, P, wres, pend);
             if (si != sa) HIPCHK(c, hipStreamWaitEvent(sa, c->aux_idx[sb], 0));  // (the survivors' seed look-ups need the map)
             hipLaunchKernelGGL(k_seg_cycles<0>, dim3(8 * gm, Fs), dim3(64), 0, sa, seedq, (const DevSegC *)segs, pend, wres, contours, cinfo, cbase,
                                recs, counts, c->d_global, P, 1, 0);
@@ -1088,6 +1094,8 @@ fid_status fid_create(const fid_params *params, const fid_dict *dict, const fid_
     if (getenv("FID_THR_SPLIT")) c->thr_split = atoi(getenv("FID_THR_SPLIT")) != 0;
     if (getenv("FID_THR_ROWS")) c->thr_rows = atoi(getenv("FID_THR_ROWS"));
     if (getenv("FID_THR_XCD")) c->thr_xcd = atoi(getenv("FID_THR_XCD")) != 0;
+    if (getenv("FID_SURV_WALK")) c->surv_walk_old = !strcmp(getenv("FID_SURV_WALK"), "old");
+    if (getenv("FID_SURV_BLOCKS_X")) c->surv_blocks_x = atoi(getenv("FID_SURV_BLOCKS_X")) > 0 ? atoi(getenv("FID_SURV_BLOCKS_X")) : 1;
     if (getenv("FID_WALK_BLOCKS")) c->walk_blocks = atoi(getenv("FID_WALK_BLOCKS")) > 0 ? atoi(getenv("FID_WALK_BLOCKS")) : c->walk_blocks;
     memset(&c->P, 0, sizeof(c->P));
 

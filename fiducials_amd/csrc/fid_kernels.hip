@@ -2418,10 +2418,17 @@ __device__ __forceinline__ void build_step_lut2(uint8_t *lut, int tid, int nthre
 #ifndef SW_RUN
 #define SW_RUN 32
 #endif
+// SURV (round 5): the same machinery for the PROBE SURVIVORS -- what k_walk_full<2> does (a survivor starts a border the way
+// icvFetchContour would, applies the canonical-start test as it goes, stops in front of the first seed state or closes the
+// border by itself; results into the survivors' contour rows and DevPend) on the seed walker's toroidal prefetched windows
+// instead of k_walk_full's reload-when-left windows (23 % of the lanes stepping there).  seedq = the survivor list, segs unused;
+// wres / pend unused for seeds.
+template <bool SURV>
 __global__ __launch_bounds__(64 * SW_WAVES) SW_VGPR_ATTR void k_seed_walk(const uint32_t *__restrict__ masks, const uint2 *__restrict__ seedq,
                                                               uint32_t *__restrict__ chunk_tab, uint32_t *__restrict__ pool,
                                                               DevSegC *__restrict__ segs, DevCounts *__restrict__ counts,
-                                                              DevGlobal *__restrict__ G, const DevParams P)
+                                                              DevGlobal *__restrict__ G, const DevParams P, uint4 *__restrict__ wres,
+                                                              DevPend *__restrict__ pend_out)
 {
     // chunk j = pcx * 8 + (row >> 2 & 7) of lane l (16 bytes: rows 4q..4q+3 of one word column) at s_win[j * 64 + l]
     __shared__ uint4 s_win_all[SW_WAVES][16 * 64];
@@ -2430,12 +2437,13 @@ __global__ __launch_bounds__(64 * SW_WAVES) SW_VGPR_ATTR void k_seed_walk(const 
     const uint32_t *s_winw = reinterpret_cast<const uint32_t *>(s_win);
     const int lane = lane_id();
     const int lane4 = lane * 4;
-    build_step_lut2(s_lut, threadIdx.x, 64 * SW_WAVES);
+    if (SURV) build_step_lut(s_lut, threadIdx.x, 64 * SW_WAVES);  // (next direction | hole-canonical code << 3 | seed flag << 6)
+    else build_step_lut2(s_lut, threadIdx.x, 64 * SW_WAVES);
     __syncthreads();
     int f = blockIdx.y;
     const unsigned ccap = (unsigned)P.maxContours, pcap = (unsigned)P.maxChunks * (unsigned)P.nframes;
     const int S = P.nscales, TC = P.TC, TR = P.TR, F = P.nframes;
-    const int W2 = P.W + 2;
+    const int W = P.W, W2 = P.W + 2;
     const int sgm = (8 << P.seedShift) - 1;
     const int nck = chunk_tab_pitch(P);
     const long long plane = (long long)TR * TC * MT_ROWS;
@@ -2449,13 +2457,14 @@ __global__ __launch_bounds__(64 * SW_WAVES) SW_VGPR_ATTR void k_seed_walk(const 
     const uint2 *fin = seedq;
     unsigned *qhead = nullptr;
     auto set_queue = [&](int fr) {
-        n = (unsigned)counts[fr].nseeds;
+        n = (unsigned)(SURV ? counts[fr].nsurv : counts[fr].nseeds);
+        if (SURV) n = n < (unsigned)P.maxStarts ? n : (unsigned)P.maxStarts;
         if (n > ccap) {
             if (lane == 0) atomicOr(&G->overflow, 2u);
             n = ccap;
         }
-        fin = seedq + (long long)fr * P.maxContours;
-        qhead = (unsigned *)&counts[fr].nwalk2;
+        fin = seedq + (long long)fr * (SURV ? P.maxStarts : P.maxContours);
+        qhead = (unsigned *)(SURV ? &counts[fr].nwalk : &counts[fr].nwalk2);
     };
     set_queue(f);
     int all_done = 0;
@@ -2480,6 +2489,24 @@ __global__ __launch_bounds__(64 * SW_WAVES) SW_VGPR_ATTR void k_seed_walk(const 
     unsigned brkey = 0xffffffffu;
     uint4 quad = make_uint4(0u, 0u, 0u, 0u);
     unsigned arena_next = 0, arena_end = 0;
+    // SURV: the survivor record, its start pixel / kind / key, the pixel after the start, what the walk found
+    uint2 sst = make_uint2(0u, 0u);
+    int x0 = 0, y0 = 0, hole = 0, key = 0, i1x = 0, i1y = 0, first = 0, closed = 0, stopped = 0;
+    // raw 3 x 3 neighbourhood byte of the walker's pixel out of its toroidal window
+    auto raw_here = [&]() {
+        const int xb = cx + (MASK_PADW * 32 - 1);
+        const int sh = xb & 31;
+        const bool odd = (xb >> 5) & 1;
+        unsigned t3[3];
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            const int r = cy + d;
+            const int idx = ((r << 6) & 0x700) | (r & 3) | lane4;
+            const uint32_t wa = s_winw[idx], wb = s_winw[idx + 2048];
+            t3[d] = __builtin_amdgcn_alignbit(odd ? wa : wb, odd ? wb : wa, sh);
+        }
+        return (t3[0] & 7u) | ((t3[1] & 1u) << 3) | ((t3[1] & 4u) << 2) | ((t3[2] & 7u) << 5);
+    };
     for (;;) {
         // ================= checkpoint =================
 #ifdef FID_DEBUG_STATS
@@ -2507,6 +2534,26 @@ __global__ __launch_bounds__(64 * SW_WAVES) SW_VGPR_ATTR void k_seed_walk(const 
                 state = (xr > vxs || rr > vys) ? ST_NEED : ST_ACTIVE;
             }
         }
+        if (SURV && first && state == ST_ACTIVE) {
+            // the survivor's first look at its start pixel: single-pixel domain, initial direction
+            //   do { s = (s - 1) & 7; } while (*i1 == 0 && s != s_end)  == first foreground clockwise from s_end - 1
+            first = 0;
+            const unsigned raw = raw_here();
+            if (raw == 0) {
+                quad.w = (uint32_t)x0 | ((uint32_t)y0 << 16);  // (written when the walker retires)
+                count = 1;
+                closed = 1;
+                state = ST_FINAL;
+            } else {
+                sdir = first_dir(raw_to_nb(raw), hole ? 0 : 4);
+                i1x = x0 + dir_dx(sdir);
+                i1y = y0 + dir_dy(sdir);
+                if (!hole && pidx(i1x, i1y, W) < key) {
+                    ok = 0;
+                    state = ST_FINAL;
+                }
+            }
+        }
         if ((state == ST_ACTIVE || state == ST_NEED) && count > P.maxPerim) {
             ok = 0;
             too_long = 1;
@@ -2519,9 +2566,18 @@ __global__ __launch_bounds__(64 * SW_WAVES) SW_VGPR_ATTR void k_seed_walk(const 
             if (rem >= 1) dst[0] = rem == 1 ? quad.w : rem == 2 ? quad.z : quad.y;
             if (rem >= 2) dst[1] = rem == 2 ? quad.w : quad.z;
             if (rem == 3) dst[2] = quad.w;
-            uint4 *r = reinterpret_cast<uint4 *>(segs + (long long)lf * P.maxContours + slot);
-            r[0] = make_uint4(SEG_INVALID, too_long || !ok ? SEG_INVALID : (unsigned)count, ko, kh);  // next_idx (k_seg_link2 fills it in), n, ko, kh
-            r[1] = make_uint4(seed_key(cx, cy, sdir), po | (ph << 16), 0u, 0u);                      // next_key, pos, linked, pad
+            if (SURV) {
+                // stopped in front of a seed state: k_seg_cycles decides; else decided here
+                const int accept = ok && closed && !stopped && count >= P.minPerim && count <= P.maxPerim;
+                wres[(long long)lf * P.maxContours + slot] = make_uint4(sst.x, sst.y, accept ? (unsigned)count : 0u, (unsigned)key);
+                DevPend *pd = pend_out + (long long)lf * P.maxContours + slot;
+                pd->p = ok && stopped ? (unsigned)count : 0u;
+                pd->next_key = seed_key(cx, cy, sdir);
+            } else {
+                uint4 *r = reinterpret_cast<uint4 *>(segs + (long long)lf * P.maxContours + slot);
+                r[0] = make_uint4(SEG_INVALID, too_long || !ok ? SEG_INVALID : (unsigned)count, ko, kh);  // next_idx (k_seg_link2 fills it in), n, ko, kh
+                r[1] = make_uint4(seed_key(cx, cy, sdir), po | (ph << 16), 0u, 0u);                      // next_key, pos, linked, pad
+            }
             state = ST_IDLE;
         }
         // ---- hand out new work
@@ -2536,8 +2592,10 @@ __global__ __launch_bounds__(64 * SW_WAVES) SW_VGPR_ATTR void k_seed_walk(const 
                 int fr = (f + hop + k) % F;
                 if (fr == f) fr = -1;
                 if (k < F && fr >= 0) {
-                    const unsigned done = __hip_atomic_load((unsigned *)&counts[fr].nwalk2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    unsigned m = (unsigned)counts[fr].nseeds;
+                    const unsigned done = __hip_atomic_load((unsigned *)(SURV ? &counts[fr].nwalk : &counts[fr].nwalk2), __ATOMIC_RELAXED,
+                                                            __HIP_MEMORY_SCOPE_AGENT);
+                    unsigned m = (unsigned)(SURV ? counts[fr].nsurv : counts[fr].nseeds);
+                    if (SURV) m = m < (unsigned)P.maxStarts ? m : (unsigned)P.maxStarts;
                     m = m < ccap ? m : ccap;
                     has = done < m;
                 }
@@ -2574,6 +2632,20 @@ __global__ __launch_bounds__(64 * SW_WAVES) SW_VGPR_ATTR void k_seed_walk(const 
                 if (state == ST_IDLE && next + (unsigned)rank < rend) {
                     slot = n - 1 - (next + (unsigned)rank);
                     lf = f;
+                    if (SURV) {  // x | y << 16, scale << 16 | hole << 24
+                        sst = make_uint2(gx, gy);
+                        x0 = cx = gx & 0xffff;
+                        y0 = cy = gx >> 16;
+                        hole = (gy >> 24) & 1;
+                        pl = masks + ((long long)f * S + (int)((gy >> 16) & 0xff)) * plane;
+                        pc = pidx(cx, cy, P.W);
+                        key = hole ? pidx(x0 + 1, y0, P.W) : pc;
+                        cxp = cx;  // (no direction yet: the first window is centred on the start)
+                        cyp = cy;
+                        sdir = 0;
+                        first = 1;
+                        closed = stopped = 0;
+                    } else {
                     cx = gx & 0x1fff;
                     cy = (gx >> 13) & 0x1fff;
                     sdir = (int)(gy & 7u);
@@ -2582,6 +2654,7 @@ __global__ __launch_bounds__(64 * SW_WAVES) SW_VGPR_ATTR void k_seed_walk(const 
                     // the state was entered from the neighbour in direction sdir: travelling the other way
                     cxp = cx + 2 * dir_dx(sdir);
                     cyp = cy + 2 * dir_dy(sdir);
+                    }
                     count = 0;
                     ok = 1;
                     too_long = 0;
@@ -2612,10 +2685,15 @@ __global__ __launch_bounds__(64 * SW_WAVES) SW_VGPR_ATTR void k_seed_walk(const 
                 const unsigned mine = arena_next + (unsigned)__popcll(b1 & lt) + 2u * (unsigned)__popcll(b2 & lt);
                 arena_next += total;
                 if (fresh || want1) {
-                    uint32_t *trow = chunk_tab + ((long long)lf * 2 * P.maxContours + slot) * nck;
+                    uint32_t *trow = chunk_tab + (((long long)lf * 2 + (SURV ? 1 : 0)) * P.maxContours + slot) * nck;  // (survivors: the upper rows)
                     if (mine + 1 >= pcap) {
                         ovf |= 8u;
-                        segs[(long long)lf * P.maxContours + slot].n = SEG_INVALID;
+                        if (SURV) {
+                            wres[(long long)lf * P.maxContours + slot] = make_uint4(sst.x, sst.y, 0u, (unsigned)key);
+                            pend_out[(long long)lf * P.maxContours + slot].p = 0u;
+                        } else {
+                            segs[(long long)lf * P.maxContours + slot].n = SEG_INVALID;
+                        }
                         state = ST_IDLE;
                         pend = 0;
                     } else if (fresh) {
@@ -2703,19 +2781,40 @@ __global__ __launch_bounds__(64 * SW_WAVES) SW_VGPR_ATTR void k_seed_walk(const 
             d_iters++;
             d_active += __popcll(act);
 #endif
-            if (state == ST_ACTIVE) {
-                const int xb = cx + (MASK_PADW * 32 - 1);
-                const int sh = xb & 31;
-                const bool odd = (xb >> 5) & 1;
-                unsigned t3[3];
-#pragma unroll
-                for (int d = 0; d < 3; d++) {
-                    const int r = cy + d;
-                    const int idx = ((r << 6) & 0x700) | (r & 3) | lane4;
-                    const uint32_t wa = s_winw[idx], wb = s_winw[idx + 2048];
-                    t3[d] = __builtin_amdgcn_alignbit(odd ? wa : wb, odd ? wb : wa, sh);
+            if (SURV && state == ST_ACTIVE) {
+                const unsigned raw = raw_here();
+                const unsigned e = s_lut[raw | ((unsigned)sdir << 8)];
+                const int sn = e & 7, code = (e >> 3) & 7;
+                const int hmag = (code & 1) ? W2 : 1;
+                const int hoff = (code & 2) ? hmag : -hmag;
+                if (count > 0 && (e & 0x40u) && seed_state(cx, cy, sdir, sgm)) {
+                    stopped = 1;  // the first seed state on this border: its seed cycle has the border already
+                    state = ST_FINAL;
+                } else {
+                    // background pixels examined in the 4-directions belong to this border's hole region
+                    int bad = hole && code && (pc + hoff < key);
+                    quad.x = quad.y;
+                    quad.y = quad.z;
+                    quad.z = quad.w;
+                    quad.w = (uint32_t)cx | ((uint32_t)cy << 16);
+                    if ((count & 3) == 3)
+                        *reinterpret_cast<uint4 *>(pool + ((count & CK ? chunkB : chunkA) << 6) + (unsigned)(count & (CK - 4))) = quad;
+                    count++;
+                    const int dx = dir_dx(sn), dy = dir_dy(sn);
+                    const int nx = cx + dx, ny = cy + dy;
+                    const int cl = !bad && nx == x0 && ny == y0 && cx == i1x && cy == i1y;
+                    cx = nx;
+                    cy = ny;
+                    pc += __mul24(dy, W2) + dx;
+                    bad |= !cl && !hole && pc < key;
+                    sdir = sn ^ 4;
+                    const unsigned xr = (unsigned)(cx + (MASK_PADW * 32 - 1) - vxb), rr = (unsigned)(cy - vyb);
+                    closed = cl;
+                    ok = !bad;
+                    state = (bad || cl) ? ST_FINAL : (xr > vxs || rr > vys) ? ST_NEED : ST_ACTIVE;
                 }
-                const unsigned raw = (t3[0] & 7u) | ((t3[1] & 1u) << 3) | ((t3[1] & 4u) << 2) | ((t3[2] & 7u) << 5);
+            } else if (!SURV && state == ST_ACTIVE) {
+                const unsigned raw = raw_here();
                 const unsigned e = s_lut[raw | ((unsigned)sdir << 8)];
                 const unsigned skey = seed_key(cx, cy, sdir);
                 const bool onseed = ((e & 0x20u) && (cx & sgm) == 0) || ((e & 0x40u) && (cy & sgm) == 0);

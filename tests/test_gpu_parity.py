@@ -339,6 +339,31 @@ def test_whole_border_walk_and_seed_tracing_agree(monkeypatch):
             det.close()
 
 
+def test_both_survivor_walkers_agree_with_the_oracle(monkeypatch):
+    """Round 5: the probe survivors walk on the seed walker's prefetched windows (k_seed_walk<true>); FID_SURV_WALK=old keeps
+    k_walk_full<2>.  Both must reproduce the oracle stage by stage where survivors matter: borders WITHOUT a seed state (shapes
+    that live inside one cell of the seed grid, at the grid spacing of single-frame and of batch calls), rings and spirals, a
+    marker frame, a batch; and the tables too small for the survivors' points end in FID_E_CAPACITY on both."""
+    d = get_predefined_dictionary(6)
+    cells = _cell_cases()
+    fr = make_frame(d, 91, width=1280, height=720, n_markers=8, side_range=(48, 110))  # (small markers: outlines inside one cell)
+    for walker in ("new", "old"):
+        monkeypatch.setenv("FID_SURV_WALK", walker)
+        for shift in ("2", "4"):  # seed grid 32 px / 128 px
+            monkeypatch.setenv("FID_SEED_SHIFT", shift)
+            det = ArucoDetector(6, max_width=1280, max_height=720, max_batch=3, max_contours=65536, max_points=1 << 22)
+            try:
+                check_stages(det, cells, d)
+                check_stages(det, fr.image, d)
+                res = det.detect_markers_batch(np.stack([fr.image, cells, fr.image]))
+                oids, ocorners = oracle.detect(fr.image, d)
+                assert res[0][1].tolist() == oids.tolist() == res[2][1].tolist()
+                assert np.array_equal(res[0][0], ocorners) and np.array_equal(res[2][0], ocorners)
+            finally:
+                det.close()
+        monkeypatch.delenv("FID_SEED_SHIFT")
+
+
 def _cell_cases(w=1280, h=720):
     """Shapes that stress cycle tracing: borders that live INSIDE one cell of the seed grid (no seed state: found by a
     start), borders that touch a grid line in one pixel, borders that run along grid lines, one-pixel-wide rings and spirals

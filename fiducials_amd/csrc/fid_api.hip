@@ -94,8 +94,13 @@ struct fid_ctx {
     uint32_t *d_cbase = nullptr, *d_dense = nullptr;
     uint4 *d_recs = nullptr;  // copy records: pieces of the accepted contours
     int thr_mode = 1;    // node window table: 1 = k_threshold_stream (default), 0 (FID_THR=tile) = k_threshold_fixed
-    int surv_walk_old = 0;  // FID_SURV_WALK=old: the survivors on k_walk_full<2> (until round 5) instead of k_seed_walk<true>
-    int surv_blocks_x = 1;  // FID_SURV_BLOCKS_X: multiplier of the survivor walk's workgroups
+    // The probe survivors' walk.  Default: k_walk_full<2> (8 KB of LDS per wave).  FID_SURV_WALK=new: k_seed_walk<true> (round 5:
+    // the seed walker's toroidal prefetched windows, 16 KB per wave) -- 1.21 -> 1.00 M VALU wave-instructions per frame at 0.30
+    // instead of 0.23 of the lanes, the stage 9 % shorter, identical results; but on the two-context bench 33.2 - 33.9 k frames/s
+    // against 33.9 - 34.3 k (five interleaved rounds; with half the waves 33.7 k): what it takes of the CUs' LDS costs the other
+    // batch's kernels more than its instructions save.  Kept as an option and in the parity tests.
+    int surv_walk_old = 1;
+    int surv_blocks_x = 0;  // FID_SURV_BLOCKS_X: workgroups of k_seed_walk<true> = x times k_walk_full<2>'s waves (0: half of them)
     int thr_xcd = 1;  // strips dealt out so that an XCD works through neighbouring strips (FID_THR_XCD=0: plain grid order)
     int thr_nw = 3, thr_split = 0, thr_rows = 0;  // stream kernel: consumer waves per workgroup, un-fused LDS reads, rows per workgroup (0 = automatic)
     int trace_mode = 2;  // 2: cycle tracing (borders read off the seed cycles; starts only for borders without a seed);
@@ -693,8 +698,8 @@ fid_status enqueue_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H,
             if (c->surv_walk_old)
                 hipLaunchKernelGGL(k_walk_full<2>, dim3(wb3, Fs), dim3(64 * WALK_WAVES), 0, sa, masks, surv, wres, tab, pool, segs, pend, counts,
                                    c->d_global, P);
-            else  // (round 5: the survivors on the seed walker's prefetched windows; as many waves as before)
-                hipLaunchKernelGGL(k_seed_walk<true>, dim3(wb3 * (WALK_WAVES / SW_WAVES) * c->surv_blocks_x, Fs), dim3(64 * SW_WAVES), 0, sa, masks,
+            else  // (FID_SURV_WALK=new: the survivors on the seed walker's prefetched windows)
+                hipLaunchKernelGGL(k_seed_walk<true>, dim3(c->surv_blocks_x > 0 ? wb3 * (WALK_WAVES / SW_WAVES) * c->surv_blocks_x : wb3, Fs), dim3(64 * SW_WAVES), 0, sa, masks,
                                    (const uint2 *)surv, tab, pool, (DevSegC *)nullptr, counts, c->d_global, P, wres, pend);
             if (si != sa) HIPCHK(c, hipStreamWaitEvent(sa, c->aux_idx[sb], 0));  // (the survivors' seed look-ups need the map)
             hipLaunchKernelGGL(k_seg_cycles<0>, dim3(8 * gm, Fs), dim3(64), 0, sa, seedq, (const DevSegC *)segs, pend, wres, contours, cinfo, cbase,
@@ -1095,7 +1100,7 @@ fid_status fid_create(const fid_params *params, const fid_dict *dict, const fid_
     if (getenv("FID_THR_ROWS")) c->thr_rows = atoi(getenv("FID_THR_ROWS"));
     if (getenv("FID_THR_XCD")) c->thr_xcd = atoi(getenv("FID_THR_XCD")) != 0;
     if (getenv("FID_SURV_WALK")) c->surv_walk_old = !strcmp(getenv("FID_SURV_WALK"), "old");
-    if (getenv("FID_SURV_BLOCKS_X")) c->surv_blocks_x = atoi(getenv("FID_SURV_BLOCKS_X")) > 0 ? atoi(getenv("FID_SURV_BLOCKS_X")) : 1;
+    if (getenv("FID_SURV_BLOCKS_X")) c->surv_blocks_x = atoi(getenv("FID_SURV_BLOCKS_X"));  // (0: half as many waves as k_walk_full<2> had)
     if (getenv("FID_WALK_BLOCKS")) c->walk_blocks = atoi(getenv("FID_WALK_BLOCKS")) > 0 ? atoi(getenv("FID_WALK_BLOCKS")) : c->walk_blocks;
     memset(&c->P, 0, sizeof(c->P));
 

@@ -94,11 +94,17 @@ class StagDetector:
             img = np.ascontiguousarray(img)
         h, w = img.shape
         n = C.c_int32(0)
-        rc = self._L.fid_stag_detect_markers(self._ctx, img.ctypes.data, w, h, img.strides[0], None, 0, C.byref(n))
+        # the markers come back in the caller's buffer (the call's own hand-over) -- reading them through the stage tap afterwards
+        # was a second, synchronous device -> host copy per frame
+        if getattr(self, "_mbuf", None) is None:
+            self._mbuf = np.zeros(512, MARKER_DTYPE)
+        rc = self._L.fid_stag_detect_markers(self._ctx, img.ctypes.data, w, h, img.strides[0], self._mbuf.ctypes.data, len(self._mbuf), C.byref(n))
+        self.shape = (h, w)
+        if rc == _lib.FID_E_CAPACITY:  # (more than 512 markers: the tap holds them all)
+            return self.markers()
         if rc != _lib.FID_OK:
             raise FidError(rc, self._L.fid_strerror(rc).decode())
-        self.shape = (h, w)
-        return self.markers()
+        return self._mbuf[:n.value].copy()
 
     def pose_last(self, K, D, marker_size: float) -> np.ndarray:
         """Common::solvePnpSingle for the markers of the last detect_markers*() call (POSE_DTYPE)."""

@@ -1253,7 +1253,8 @@ def main():
             "dtype": "u8",
             "data": f"synthetic ({unique} unique frames per GPU" + (f", tiled to {B}" if unique < B else "") + ")",
             "config": {
-                "workload": f"cfg3: batch {B} x 1920x1080 mono8 resident in HBM, 20 markers/frame, DICT_5X5_250, "
+                "workload": f"cfg3: batch {B} x 1920x1080 mono8 " + ("from pinned host memory (cfg 4's feed)" if feed_host else "resident in HBM") +
+                            ", 20 markers/frame, DICT_5X5_250, "
                             "13 threshold scales, SUBPIX, ITERATIVE PnP (aruco_detect node defaults)",
                 "batch_per_gpu": B,
                 "frames_per_step": B * n_gpus,

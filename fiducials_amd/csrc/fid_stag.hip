@@ -890,7 +890,8 @@ static fid_status stag_advance_impl(fid_stag_ctx *c, StagJob &j)
         if (!j.spec) c->n_anchors = c->hp->n_anchors;  // (queued ahead: the true counts are taken over at the frame's one wait)
         c->W = j.width;
         c->H = j.height;
-        c->routed = false;
+        // (a frame that is refused further down must not leave the stages of the frame before readable: taps, fid_stag_pose_last)
+        c->routed = c->validated = c->lined = c->lines_validated = c->quadded = c->decoded = false;
         if (j.last == SS_FRONTEND) return stag_finish(j, FID_OK);
         const int W = c->W, H = c->H, n = W * H, na = j.spec ? j.use.na : (int)c->n_anchors;
         StagRoute &R = j.R;

@@ -100,8 +100,10 @@ class StagDetector:
             self._mbuf = np.zeros(512, MARKER_DTYPE)
         rc = self._L.fid_stag_detect_markers(self._ctx, img.ctypes.data, w, h, img.strides[0], self._mbuf.ctypes.data, len(self._mbuf), C.byref(n))
         self.shape = (h, w)
-        if rc == _lib.FID_E_CAPACITY:  # (more than 512 markers: the tap holds them all)
-            return self.markers()
+        if rc == _lib.FID_E_CAPACITY:
+            m = self.markers()  # more than 512 markers: the tap holds them all; a frame refused in the routing leaves no stage readable
+            if len(m) > len(self._mbuf):
+                return m
         if rc != _lib.FID_OK:
             raise FidError(rc, self._L.fid_strerror(rc).decode())
         return self._mbuf[:n.value].copy()

@@ -292,7 +292,9 @@ void fid_stag_destroy(fid_stag_ctx *ctx);
 /* gray: host memory, mono8 (what StagNode::imageCallback hands to detectMarkers, stag_detect.cpp:110-131) */
 fid_status fid_stag_edge_frontend(fid_stag_ctx *ctx, const uint8_t *gray, int32_t width, int32_t height, int32_t stride_bytes);
 /* the front end + the edge routing JoinAnchorPointsUsingSortedAnchors (ED/EDInternals.cpp:842-1448): DoDetectEdgesByED
- * (ED/EDInternals.cpp:2598-2619) complete; the EdgeMap stays on the device.  FID_E_CAPACITY if a scratch array is too small. */
+ * (ED/EDInternals.cpp:2598-2619) complete; the EdgeMap stays on the device.  FID_E_CAPACITY if a scratch array is too small --
+ * among them the chain tree of ONE anchor's walk: 32 767 chains, where the reference's Chain::parent / children (short,
+ * EDInternals.cpp:39-45) would wrap; frames of uniform noise can get there.  A refused frame leaves no stage readable. */
 fid_status fid_stag_detect_edges(fid_stag_ctx *ctx, const uint8_t *gray, int32_t width, int32_t height, int32_t stride_bytes);
 /* DetectEdgesByEDPF complete (ED/ED.cpp:144-187): the above + the second smoothing (sigma 1 / 2.5) and ValidateEdgeSegments
  * (ED/ValidateEdgeSegments.cpp:365-413): Helmholtz-principle validation of every segment, invalid pieces cut out */

@@ -613,6 +613,51 @@ def test_batch_entry_point_equals_frame_by_frame():
         det.close()
 
 
+def test_a_frame_refused_in_the_routing_leaves_no_stage_of_the_frame_before_readable(monkeypatch):
+    """A walk of more than 32 767 chains from one anchor is refused (FID_E_CAPACITY; the reference's short chain indices would
+    wrap there, EDInternals.cpp:39-45) -- frames of uniform noise can get there.  The frame before must not shine through: no
+    markers in the tap, fid_stag_pose_last refuses, the Python host raises; the next frame is served as if nothing had happened;
+    same on the counted road and queued ahead (found by tools/gpu_stag_spec_stress.py, seed 11)."""
+    from fiducials_amd import synth, _lib
+    from fiducials_amd._lib import FidError
+    words = fstag.load_library(21)
+    w, h = 1280, 720
+    good = synth.make_stag_frame(words, 300, w, h, 5).image
+    K = np.array([[933.3, 0, 640.0], [0, 933.3, 360.0], [0, 0, 1]])
+    det = fstag.StagDetector(21, 7, max_width=w, max_height=h)
+    try:
+        noise = None
+        for seed in range(24):
+            f = np.random.default_rng(seed).integers(0, 256, (h, w), dtype=np.uint8)
+            try:
+                det.detect_edges(f)
+            except FidError as e:
+                assert e.status == _lib.FID_E_CAPACITY
+                noise = f
+                break
+    finally:
+        det.close()
+    if noise is None:
+        pytest.skip("no noise frame among the seeds reaches the chain limit")
+    for road in ("0", "1"):
+        monkeypatch.setenv("FID_STAG_SPEC", road)
+        det = fstag.StagDetector(21, 7, max_width=w, max_height=h)
+        try:
+            want = det.detect_markers(good)
+            assert len(want) >= 3
+            pose = det.pose_last(K, None, 0.18)
+            with pytest.raises(FidError) as ei:
+                det.detect_markers(noise)
+            assert ei.value.status == _lib.FID_E_CAPACITY
+            assert len(det.markers()) == 0 and len(det.quads()) == 0
+            with pytest.raises(FidError):
+                det.pose_last(K, None, 0.18)
+            again = det.detect_markers(good)
+            assert again.tobytes() == want.tobytes() and det.pose_last(K, None, 0.18).tobytes() == pose.tobytes()
+        finally:
+            det.close()
+
+
 def test_frames_queued_ahead_equal_the_counted_road(monkeypatch):
     """Round 5: a context that has finished a frame sizes the next frame's launches by that frame's counts and enqueues the whole
     frame without the nine host waits (fid_stag.hip, stag_advance_impl); a frame whose counts outgrow the sizes is caught by

@@ -46,6 +46,31 @@ __device__ __forceinline__ bool sr_near(int2 a, int2 b)
     return dr <= 1 && dc <= 1;
 }
 
+// A value that every lane of the wave holds alike, SAID SO to the compiler (round 5).  The wave-wide walkers below run the same
+// scalar program in all 64 lanes; what they load (LDS tile words, stack entries, component records) comes back in vector
+// registers, and everything computed from it was vector work under EXEC-mask branches: ~170 VALU instructions and 25 masked
+// branches per walked pixel.  Through v_readfirstlane the loaded words are scalar values: the step's decisions become s_cmp /
+// s_cselect / s_cbranch_scc on the scalar unit, the loop state lives in SGPRs.
+__device__ __forceinline__ int sr_uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// (a pointer that can only be LDS: two roads that differ in the memory they read are never merged into one generic access)
+typedef __attribute__((address_space(3))) int *SrLdsInt;
+struct SrLdsInt4 {  // int4 entries behind such a pointer
+    SrLdsInt p;
+    __device__ __forceinline__ int4 get(int i) const { return make_int4(p[4 * i], p[4 * i + 1], p[4 * i + 2], p[4 * i + 3]); }
+    __device__ __forceinline__ void put(int i, int4 v) const { p[4 * i] = v.x; p[4 * i + 1] = v.y; p[4 * i + 2] = v.z; p[4 * i + 3] = v.w; }
+};
+template <class T>
+__device__ __forceinline__ T sr_uni_struct(const T &v)
+{
+    static_assert(sizeof(T) % 4 == 0, "whole words");
+    T o;
+    const int *src = reinterpret_cast<const int *>(&v);
+    int *dst = reinterpret_cast<int *>(&o);
+#pragma unroll
+    for (unsigned k = 0; k < sizeof(T) / 4; k++) dst[k] = __builtin_amdgcn_readfirstlane(src[k]);
+    return o;
+}
+
 struct StagRouter {
     StagRoute R;
     int noSegments, totalPixels, overflow;
@@ -60,14 +85,14 @@ struct StagRouter {
 
     __device__ int2 cpx(int ch, int i) const
     {
-        const int k = R.chains[ch].pix + i;
-        return k >= 0 ? R.pix[k] : make_int2(-1000, -1000);  // (the reference reads in front of its array there)
+        const int k = sr_uni(R.chains[ch].pix) + i;
+        return k >= 0 ? sr_uni_struct(R.pix[k]) : make_int2(-1000, -1000);  // (the reference reads in front of its array there)
     }
     __device__ int2 seg(int i) const
     {
         const int k = segbase + i;
-        if (par && k < blk0) return (prev_valid && k >= 0) ? R.outpix[k] : make_int2(-1000, -1000);  // in front of this anchor's block
-        return k >= 0 ? R.outpix[k] : make_int2(-1000, -1000);
+        if (par && k < blk0) return (prev_valid && k >= 0) ? sr_uni_struct(R.outpix[k]) : make_int2(-1000, -1000);  // in front of this anchor's block
+        return k >= 0 ? sr_uni_struct(R.outpix[k]) : make_int2(-1000, -1000);
     }
     // append `count` pixels of chain cn, chain index first + step * k, to the segment
     __device__ void seg_copy(int cn, int first, int step, int count)
@@ -78,7 +103,7 @@ struct StagRouter {
             nsp += count;
             return;
         }
-        const int2 *src = R.pix + R.chains[cn].pix;
+        const int2 *src = R.pix + sr_uni(R.chains[cn].pix);
         int2 *dst = R.outpix + segbase + nsp;
         if (wlane >= 0) {
             for (int k = wlane; k < count; k += 64) dst[k] = src[first + step * k];
@@ -99,17 +124,17 @@ struct StagRouter {
     __device__ int longest(int root)
     {
         StagChain *ch = R.chains;
-        if (root == -1 || ch[root].len == 0) return 0;
+        if (root == -1 || sr_uni(ch[root].len) == 0) return 0;
         int sp = 0, ret = 0;
         R.stack[sp++] = make_int4(root, 0, 0, 0);
         while (sp > 0) {
-            int4 e = R.stack[sp - 1];
+            int4 e = sr_uni_struct(R.stack[sp - 1]);
             const int node = e.x;
             if (e.y == 0) {
                 e.y = 1;
                 R.stack[sp - 1] = e;
-                const int c = ch[node].child[0];
-                if (c != -1 && ch[c].len != 0) {
+                const int c = sr_uni(ch[node].child[0]);
+                if (c != -1 && sr_uni(ch[c].len) != 0) {
                     if (sp < R.capStack) R.stack[sp++] = make_int4(c, 0, 0, 0);
                     else { overflow |= 2; ret = 0; }
                     if (!(overflow & 2)) continue;
@@ -120,8 +145,8 @@ struct StagRouter {
                 e.z = ret;
                 e.y = 2;
                 R.stack[sp - 1] = e;
-                const int c = ch[node].child[1];
-                if (c != -1 && ch[c].len != 0) {
+                const int c = sr_uni(ch[node].child[1]);
+                if (c != -1 && sr_uni(ch[c].len) != 0) {
                     if (sp < R.capStack) { R.stack[sp++] = make_int4(c, 0, 0, 0); continue; }
                     overflow |= 2;
                 }
@@ -136,7 +161,7 @@ struct StagRouter {
                 mx = len1;
                 ch[node].child[0] = -1;
             }
-            ret = ch[node].len + mx;
+            ret = sr_uni(ch[node].len) + mx;
             sp--;
         }
         return ret;
@@ -149,7 +174,8 @@ struct StagRouter {
             if (count < R.capNos) R.chainNos[count] = root;
             else { overflow |= 4; break; }
             count++;
-            root = R.chains[root].child[0] != -1 ? R.chains[root].child[0] : R.chains[root].child[1];
+            const int c0 = sr_uni(R.chains[root].child[0]);
+            root = c0 != -1 ? c0 : sr_uni(R.chains[root].child[1]);
         }
         return count;
     }
@@ -167,10 +193,10 @@ struct StagRouter {
     {
         StagChain *ch = R.chains;
         for (int k = 0; k < count; k++) {
-            const int cn = R.chainNos[k];
+            const int cn = sr_uni(R.chainNos[k]);
             trim_tail(cpx(cn, 0));
             int start = 0;
-            const int L = ch[cn].len;
+            const int L = sr_uni(ch[cn].len);
             if (L > 1 && sr_near(cpx(cn, 1), seg(nsp - 1))) start = 1;
             seg_copy(cn, start, 1, L - start);
             ch[cn].len = 0;  // copied
@@ -201,12 +227,17 @@ struct StagRouter {
     struct Ahead {           // A = ahead - p, B = ahead, C = ahead + p (p = one pixel across the walking direction)
         int eA, eB, eC, gA, gB, gC, dA, dB, dC;
         int s1, s2;          // edge values of the pixels beside the current one (+p, -p)
+        int wA, wB, wC, w1, w2;  // MemTile: the five tile words as read (mark() writes the side words back without reading them again)
     };
     struct MemGlobal {
         const int16_t *grad; const uint8_t *dir; uint8_t *edge; int W;
+        int4 *gstk;  // the walk's stack of pending branches (R.stack)
         static constexpr int STRIDE = 1;
+        __device__ void stk_put(int i, int4 v, bool writer) const { if (writer) gstk[i] = v; }
+        __device__ int4 stk_get(int i) const { return gstk[i]; }
         __device__ int edge_at(int r, int c) const { return edge[r * W + c]; }
         __device__ int dir_at(int r, int c) const { return dir[r * W + c]; }
+        __device__ int word_at(int, int) const { return 0; }  // (MemTile: the pixel's tile word)
         __device__ void fetch(int r, int c, int ar, int ac, int pr, int pc, int, Ahead &n) const
         {
             const int q = (r + ar) * W + (c + ac), p = pr * W + pc;
@@ -214,8 +245,9 @@ struct StagRouter {
             n.gA = grad[q - p]; n.gB = grad[q]; n.gC = grad[q + p];
             n.dA = dir[q - p]; n.dB = dir[q]; n.dC = dir[q + p];
             n.s1 = edge[r * W + c + p]; n.s2 = edge[r * W + c - p];
+            n.wA = n.wB = n.wC = n.w1 = n.w2 = 0;
         }
-        __device__ void mark(int r, int c, int pr, int pc, const Ahead &n, bool writer) const
+        __device__ void mark(int r, int c, int pr, int pc, const Ahead &n, int, bool writer) const
         {
             if (!writer) return;
             const int i = r * W + c, p = pr * W + pc;
@@ -225,8 +257,21 @@ struct StagRouter {
         }
         __device__ void erase(int r, int c) const { edge[r * W + c] = 0; }
     };
+    // the wave-wide forms keep the first `lcap` stack entries in LDS: a chain begins with a pop of what the chain before has
+    // just pushed, and through global memory that was a store, a wait for it and a load -- one memory round trip and a half per
+    // chain, a few hundred chains per marker: most of what the walk kernel took (round 5)
     struct MemWave : MemGlobal {
+        SrLdsInt4 lstk; int lcap;
         static constexpr int STRIDE = 64;
+        __device__ void stk_put(int i, int4 v, bool writer) const
+        {
+            if (!writer) return;
+            if (i < lcap) lstk.put(i, v);
+            else gstk[i] = v;
+        }
+        __device__ int4 stk_get(int i) const { return sr_uni_struct(i < lcap ? lstk.get(i) : gstk[i]); }
+        __device__ int edge_at(int r, int c) const { return sr_uni(edge[r * W + c]); }
+        __device__ int dir_at(int r, int c) const { return sr_uni(dir[r * W + c]); }
         __device__ void fetch(int r, int c, int ar, int ac, int pr, int pc, int lane, Ahead &n) const
         {
             // lane -> (array, pixel): 0-2 edge, 3-5 grad, 6-8 dir of A, B, C; 9, 10 edge beside
@@ -243,37 +288,86 @@ struct StagRouter {
             n.gA = __builtin_amdgcn_readlane(v, 3); n.gB = __builtin_amdgcn_readlane(v, 4); n.gC = __builtin_amdgcn_readlane(v, 5);
             n.dA = __builtin_amdgcn_readlane(v, 6); n.dB = __builtin_amdgcn_readlane(v, 7); n.dC = __builtin_amdgcn_readlane(v, 8);
             n.s1 = __builtin_amdgcn_readlane(v, 9); n.s2 = __builtin_amdgcn_readlane(v, 10);
+            n.wA = n.wB = n.wC = n.w1 = n.w2 = 0;
         }
     };
     struct Tile {
         uint16_t *t;
         int r0, c0, tw;  // origin (row, column) of the tile in the image, words per tile row
+        int4 *gstk; SrLdsInt4 lstk; int lcap;  // the stack: as MemWave
         static constexpr int STRIDE = 64;
+        static constexpr bool SPARSE = false;
+        __device__ void stk_put(int i, int4 v, bool writer) const
+        {
+            if (!writer) return;
+            if (i < lcap) lstk.put(i, v);
+            else gstk[i] = v;
+        }
+        __device__ int4 stk_get(int i) const { return sr_uni_struct(i < lcap ? lstk.get(i) : gstk[i]); }
         __device__ int idx(int r, int c) const { return (r - r0) * tw + (c - c0); }
         __device__ static int edge_of(uint16_t w) { const int st = w >> 12; return st ? 253 + st : 0; }
         __device__ static int grad_of(uint16_t w) { return w & 0x7ff; }
         __device__ static int dir_of(uint16_t w) { return (w & 0x800) ? STAG_EDGE_VERTICAL : STAG_EDGE_HORIZONTAL; }
-        __device__ int edge_at(int r, int c) const { return edge_of(t[idx(r, c)]); }
-        __device__ int dir_at(int r, int c) const { return dir_of(t[idx(r, c)]); }
+        // (every lane reads the same word: the value is the wave's, see sr_uni)
+        __device__ int word_at(int r, int c) const { return sr_uni(t[idx(r, c)]); }
+        __device__ int edge_at(int r, int c) const { return edge_of((uint16_t)word_at(r, c)); }
+        __device__ int dir_at(int r, int c) const { return dir_of((uint16_t)word_at(r, c)); }
         __device__ void fetch(int r, int c, int ar, int ac, int pr, int pc, int, Ahead &n) const
         {
             const int i = idx(r, c), q = i + ar * tw + ac, p = pr * tw + pc;
-            const uint16_t wA = t[q - p], wB = t[q], wC = t[q + p];
+            const int rA = t[q - p], rB = t[q], rC = t[q + p], r1 = t[i + p], r2 = t[i - p];  // five loads in flight, then the values
+            n.wA = sr_uni(rA); n.wB = sr_uni(rB); n.wC = sr_uni(rC); n.w1 = sr_uni(r1); n.w2 = sr_uni(r2);
+            const uint16_t wA = (uint16_t)n.wA, wB = (uint16_t)n.wB, wC = (uint16_t)n.wC;
             n.eA = edge_of(wA); n.eB = edge_of(wB); n.eC = edge_of(wC);
             n.gA = grad_of(wA); n.gB = grad_of(wB); n.gC = grad_of(wC);
             n.dA = dir_of(wA); n.dB = dir_of(wB); n.dC = dir_of(wC);
-            n.s1 = edge_of(t[i + p]); n.s2 = edge_of(t[i - p]);
+            n.s1 = edge_of((uint16_t)n.w1); n.s2 = edge_of((uint16_t)n.w2);
         }
         __device__ void set_state(int i, int st) const { t[i] = (uint16_t)((t[i] & 0x0fff) | (st << 12)); }
-        __device__ void mark(int r, int c, int pr, int pc, const Ahead &n, bool writer) const
+        // wcur: the current pixel's word as the walk last read it (nothing has written it since: a step writes the pixel it stands on
+        // and the two beside it, never one of the three ahead) -- the three words are written from what is known, not read again
+        __device__ void mark(int r, int c, int pr, int pc, const Ahead &n, int wcur, bool writer) const
         {
             if (!writer) return;
             const int i = idx(r, c), p = pr * tw + pc;
-            set_state(i, 2);
-            if (n.s1 == STAG_ANCHOR_PIXEL) set_state(i + p, 0);
-            if (n.s2 == STAG_ANCHOR_PIXEL) set_state(i - p, 0);
+            t[i] = (uint16_t)((wcur & 0x0fff) | (2 << 12));
+            if (n.s1 == STAG_ANCHOR_PIXEL) t[i + p] = (uint16_t)(n.w1 & 0x0fff);
+            if (n.s2 == STAG_ANCHOR_PIXEL) t[i - p] = (uint16_t)(n.w2 & 0x0fff);
         }
         __device__ void erase(int r, int c) const { set_state(idx(r, c), 0); }  // (a pixel listed twice gets the same word twice)
+    };
+
+    // A component whose bounding box does not fit the LDS as a dense tile -- the ring around a marker seen from close: 289 x 288
+    // pixels of box for 813 pixels of edge -- as 8 x 8 BLOCKS: a table over the box (one 16-bit slot number per block, 0 = the
+    // all-empty block) and the blocks that hold a pixel of the component or a neighbour of one.  Two dependent LDS reads per
+    // access instead of one; the walk through global memory it replaces cost a store, a wait and a load per step (2 200 cycles
+    // a pixel, and that one workgroup was the whole kernel's duration: round 5).
+    struct SparseTile {
+        uint16_t *tab, *blk;
+        int r0, c0, bw;   // origin of the box in the image (as Tile), blocks per table row
+        int4 *gstk; SrLdsInt4 lstk; int lcap;
+        static constexpr int STRIDE = 64;
+        static constexpr bool SPARSE = true;
+        __device__ void stk_put(int i, int4 v, bool writer) const
+        {
+            if (!writer) return;
+            if (i < lcap) lstk.put(i, v);
+            else gstk[i] = v;
+        }
+        __device__ int4 stk_get(int i) const { return sr_uni_struct(i < lcap ? lstk.get(i) : gstk[i]); }
+        // word offset in blk of the pixel (rr, cc) of the box
+        __device__ int off(int rr, int cc) const
+        {
+            const int slot = tab[(rr >> 3) * bw + (cc >> 3)];
+            return (slot << 6) | ((rr & 7) << 3) | (cc & 7);
+        }
+        __device__ int word_at(int r, int c) const { return sr_uni(blk[off(r - r0, c - c0)]); }
+        __device__ int dir_at(int r, int c) const { return Tile::dir_of((uint16_t)word_at(r, c)); }
+        __device__ void erase(int r, int c) const
+        {
+            const int o = off(r - r0, c - c0);
+            blk[o] = (uint16_t)(blk[o] & 0x0fff);
+        }
     };
 
     // the walk from one anchor: true if it produced a path that is kept (the chain tree is then in R.chains / R.pix)
@@ -281,25 +375,28 @@ struct StagRouter {
     __device__ bool walk_anchor_t(int r0, int c0, int grad_thresh, const Mem &M, int lane)
     {
         const bool L0 = lane == 0;
+        constexpr bool WV = Mem::STRIDE == 64;  // the wave-wide forms: every lane holds the same values
         StagChain *ch = R.chains;
+        const int capChains = WV ? sr_uni(R.capChains) : R.capChains, capPix = WV ? sr_uni(R.capPix) : R.capPix,
+                  capStack = WV ? sr_uni(R.capStack) : R.capStack;
         if (L0) {
             ch[0].dir = 0; ch[0].len = 0; ch[0].parent = -1; ch[0].child[0] = ch[0].child[1] = -1; ch[0].pix = -1;
         }
         int noChains = 1, len = 0, dup = 0, top = -1;
         const bool vert0 = M.dir_at(r0, c0) == STAG_EDGE_VERTICAL;
-        if (L0) {
-            R.stack[0] = make_int4(r0, c0, vert0 ? SR_DOWN : SR_RIGHT, 0);
-            R.stack[1] = make_int4(r0, c0, vert0 ? SR_UP : SR_LEFT, 0);
-        }
+        M.stk_put(0, make_int4(r0, c0, vert0 ? SR_DOWN : SR_RIGHT, 0), L0);
+        M.stk_put(1, make_int4(r0, c0, vert0 ? SR_UP : SR_LEFT, 0), L0);
         top = 1;
         while (top >= 0) {
-            const int4 e = R.stack[top--];
+            const int4 e = M.stk_get(top);
+            top--;
             int r = e.x, c = e.y;
             const int d = e.z, parent = e.w;
-            if (noChains >= R.capChains || len + 2 >= R.capPix || top + 3 >= R.capStack) {
+            if (noChains >= capChains || len + 2 >= capPix || top + 3 >= capStack) {
                 overflow |= 16;
                 break;
             }
+            int wcur = M.word_at(r, c);  // (MemTile only; the other forms carry 0)
             if (M.edge_at(r, c) != STAG_EDGE_PIXEL) dup++;
             const int cur = noChains;
             if (L0) {
@@ -319,7 +416,7 @@ struct StagRouter {
             while (curdir == need) {
                 Ahead n;
                 M.fetch(r, c, ar, ac, pr, pc, lane, n);
-                M.mark(r, c, pr, pc, n, L0);
+                M.mark(r, c, pr, pc, n, wcur, L0);
                 const int eF1 = fs < 0 ? n.eA : n.eC, eF2 = fs < 0 ? n.eC : n.eA;  // the diagonal looked at first / second
                 int side;
                 if (n.eB >= STAG_ANCHOR_PIXEL) side = 0;
@@ -334,6 +431,7 @@ struct StagRouter {
                 c = c + ac + side * pc;
                 const int en = side < 0 ? n.eA : side > 0 ? n.eC : n.eB, gn = side < 0 ? n.gA : side > 0 ? n.gC : n.gB;
                 curdir = side < 0 ? n.dA : side > 0 ? n.dC : n.dB;
+                wcur = side < 0 ? n.wA : side > 0 ? n.wC : n.wB;
                 if (en == STAG_EDGE_PIXEL || gn < grad_thresh) {
                     if (L0) {
                         ch[cur].len = (uint16_t)chainLen;
@@ -343,17 +441,15 @@ struct StagRouter {
                     stopped = true;
                     break;
                 }
-                if (len + 2 >= R.capPix) { overflow |= 16; stopped = true; break; }
+                if (len + 2 >= capPix) { overflow |= 16; stopped = true; break; }
                 if (L0) R.pix[len] = make_int2(r, c);
                 len++;
                 chainLen++;
             }
             if (stopped) continue;
             // the edge turns here: branch both ways across, this chain ends in front of the turning pixel
-            if (L0) {
-                R.stack[top + 1] = make_int4(r, c, horiz ? SR_DOWN : SR_RIGHT, cur);
-                R.stack[top + 2] = make_int4(r, c, horiz ? SR_UP : SR_LEFT, cur);
-            }
+            M.stk_put(top + 1, make_int4(r, c, horiz ? SR_DOWN : SR_RIGHT, cur), L0);
+            M.stk_put(top + 2, make_int4(r, c, horiz ? SR_UP : SR_LEFT, cur), L0);
             top += 2;
             len--;
             chainLen--;
@@ -372,16 +468,142 @@ struct StagRouter {
         }
         return true;
     }
+    // The walk on the LDS tile, lane-parallel (round 5).  A lone wave issues one instruction every ~4.5 cycles whatever the unit, and
+    // the one-body-for-all-memories walk above spends ~200 instructions on a pixel (900 cycles measured: 1 000 pixels and 300
+    // chains of a marker's component took 1.2 M cycles, scalar or vector alike).  Here SIX LANES hold the six tile words of a
+    // step -- lane 0 / 1 / 2 the pixels ahead (A, B, C = ahead - p, ahead, ahead + p), lane 3 / 4 the pixels beside (+p, -p),
+    // lane 5 the pixel the walk stands on -- so that one ds_read, one shift, two compares (ballots) and one masked ds_write do
+    // what five decodes and three read-modify-writes did; the decision runs on the scalar unit from the ballots and a packed
+    // table, the chosen pixel's word comes over by v_readlane.  The same reads, writes and decisions in the same order as
+    // walk_anchor_t (tests: every segment of every road against the reference's).
+    template <class TT>
+    __device__ bool walk_anchor_tile6(int r0, int c0, int grad_thresh, int lane, const TT &T)
+    {
+        constexpr bool SP = TT::SPARSE;
+        StagChain *ch = R.chains;
+        const bool L0 = lane == 0;
+        const int capChains = sr_uni(R.capChains), capPix = sr_uni(R.capPix), capStack = sr_uni(R.capStack);
+        int tw = 0;
+        uint16_t *t;
+        if constexpr (SP) t = T.blk;
+        else {
+            t = T.t;
+            tw = T.tw;
+        }
+        if (L0) {
+            ch[0].dir = 0; ch[0].len = 0; ch[0].parent = -1; ch[0].child[0] = ch[0].child[1] = -1; ch[0].pix = -1;
+        }
+        int noChains = 1, len = 0, dup = 0, top = -1;
+        const bool vert0 = T.dir_at(r0, c0) == STAG_EDGE_VERTICAL;
+        T.stk_put(0, make_int4(r0, c0, vert0 ? SR_DOWN : SR_RIGHT, 0), L0);
+        T.stk_put(1, make_int4(r0, c0, vert0 ? SR_UP : SR_LEFT, 0), L0);
+        top = 1;
+        const int orc = lane == 5 ? (2 << 12) : 0;  // the pixel stood on becomes an edge pixel, the anchors beside it are cleared
+        while (top >= 0) {
+            const int4 e = T.stk_get(top);
+            top--;
+            int r = e.x, c = e.y;
+            const int d = e.z, parent = e.w;
+            if (noChains >= capChains || len + 2 >= capPix || top + 3 >= capStack) {
+                overflow |= 16;
+                break;
+            }
+            const bool horiz = d == SR_LEFT || d == SR_RIGHT;
+            const int ar = d == SR_UP ? -1 : d == SR_DOWN ? 1 : 0, ac = d == SR_LEFT ? -1 : d == SR_RIGHT ? 1 : 0;
+            const int a = ar * tw + ac, p = horiz ? tw : 1;  // one pixel ahead / across, in tile words
+            const bool low = d == SR_LEFT || d == SR_UP;    // fs = -1: the diagonal A is looked at first
+            const int slot = low ? 0 : 1;
+            // which way for every pattern of non-empty pixels ahead (bit 0 A, 1 B, 2 C), two bits each: 0 / 1 / 2 = side -1 / 0 / +1,
+            // 3 = none, the gradients decide
+            const unsigned tab = 21075u + (low ? 0u : 2048u);
+            // this lane's pixel relative to the one stood on: as a tile offset (dense), as (rows, columns) (blocks)
+            const int voff = lane == 0 ? a - p : lane == 1 ? a : lane == 2 ? a + p : lane == 3 ? p : lane == 4 ? -p : 0;
+            const int pr = horiz ? 1 : 0, pc = horiz ? 0 : 1;
+            const int ldr = lane == 0 ? ar - pr : lane == 1 ? ar : lane == 2 ? ar + pr : lane == 3 ? pr : lane == 4 ? -pr : 0;
+            const int ldc = lane == 0 ? ac - pc : lane == 1 ? ac : lane == 2 ? ac + pc : lane == 3 ? pc : lane == 4 ? -pc : 0;
+            int i = 0, o = 0;  // where this lane reads (and, lanes 3 - 5, writes)
+            if constexpr (SP) o = T.off(r - T.r0 + ldr, c - T.c0 + ldc);
+            else {
+                i = T.idx(r, c);
+                o = i + voff;
+            }
+            int w = t[o];
+            const int w0 = __builtin_amdgcn_readlane(w, 5);
+            if ((w0 >> 12) != 2) dup++;
+            const int cur = noChains;
+            if (L0) {
+                ch[cur].dir = (int16_t)d; ch[cur].parent = (int16_t)parent; ch[cur].child[0] = ch[cur].child[1] = -1; ch[cur].pix = len;
+                R.pix[len] = make_int2(r, c);
+            }
+            len++;
+            int chainLen = 1;
+            bool stopped = false;
+            bool along = ((w0 & 0x800) != 0) == !horiz;  // the pixel's edge direction is the chain's
+            while (along) {
+                const int st = w >> 12;
+                const unsigned nz = (unsigned)__ballot(st != 0);
+                // mark: lanes 3, 4 clear their anchor, lane 5 writes the edge pixel -- from the words just read
+                if (lane == 5 || ((lane == 3 || lane == 4) && st == 1)) t[o] = (uint16_t)((w & 0x0fff) | orc);
+                int side = (int)((tab >> (2 * (nz & 7u))) & 3u) - 1;
+                if (side == 2) {
+                    const int gA = __builtin_amdgcn_readlane(w, 0) & 0x7ff, gB = __builtin_amdgcn_readlane(w, 1) & 0x7ff,
+                              gC = __builtin_amdgcn_readlane(w, 2) & 0x7ff;
+                    side = gA > gB ? (gA > gC ? -1 : 1) : (gC > gB ? 1 : 0);
+                }
+                const int wn = __builtin_amdgcn_readlane(w, side + 1);
+                if constexpr (!SP) i += a + side * p;
+                r += ar + (horiz ? side : 0);
+                c += ac + (horiz ? 0 : side);
+                along = ((wn & 0x800) != 0) == !horiz;
+                if ((wn >> 12) == 2 || (wn & 0x7ff) < grad_thresh) {
+                    if (L0) {
+                        ch[cur].len = (uint16_t)chainLen;
+                        ch[parent].child[slot] = (int16_t)cur;
+                    }
+                    noChains++;
+                    stopped = true;
+                    break;
+                }
+                if (len + 2 >= capPix) { overflow |= 16; stopped = true; break; }
+                if (L0) R.pix[len] = make_int2(r, c);
+                len++;
+                chainLen++;
+                if constexpr (SP) o = T.off(r - T.r0 + ldr, c - T.c0 + ldc);
+                else o = i + voff;
+                w = t[o];
+            }
+            if (stopped) continue;
+            // the edge turns here: branch both ways across, this chain ends in front of the turning pixel
+            T.stk_put(top + 1, make_int4(r, c, horiz ? SR_DOWN : SR_RIGHT, cur), L0);
+            T.stk_put(top + 2, make_int4(r, c, horiz ? SR_UP : SR_LEFT, cur), L0);
+            top += 2;
+            len--;
+            chainLen--;
+            if (L0) {
+                ch[cur].len = (uint16_t)chainLen;
+                ch[parent].child[slot] = (int16_t)cur;
+            }
+            noChains++;
+        }
+        wl_len = len;
+        wl_dup = dup;
+        wl_chains = noChains;
+        if (len - dup < STAG_MIN_PATH_LEN) {
+            for (int k = lane; k < len; k += 64) T.erase(R.pix[k].x, R.pix[k].y);
+            return false;
+        }
+        return true;
+    }
     __device__ bool walk_anchor(int r0, int c0, int grad_thresh)
     {
         MemGlobal M;
-        M.grad = R.grad; M.dir = R.dir; M.edge = R.edge; M.W = R.W;
+        M.grad = R.grad; M.dir = R.dir; M.edge = R.edge; M.W = R.W; M.gstk = R.stack;
         return walk_anchor_t(r0, c0, grad_thresh, M, 0);
     }
-    __device__ bool walk_anchor_wave(int r0, int c0, int grad_thresh, int lane)
+    __device__ bool walk_anchor_wave(int r0, int c0, int grad_thresh, int lane, SrLdsInt4 lstk, int lcap)
     {
         MemWave M;
-        M.grad = R.grad; M.dir = R.dir; M.edge = R.edge; M.W = R.W;
+        M.grad = R.grad; M.dir = R.dir; M.edge = R.edge; M.W = R.W; M.gstk = R.stack; M.lstk = lstk; M.lcap = lcap;
         return walk_anchor_t(r0, c0, grad_thresh, M, lane);
     }
     __device__ bool walk_anchor_tile(int r0, int c0, int grad_thresh, int lane, const Tile &T) { return walk_anchor_t(r0, c0, grad_thresh, T, lane); }
@@ -399,28 +621,31 @@ struct StagRouter {
         blk0 = totalPixels;
         segbase = totalPixels;
         nsp = 0;
-        int totalLen = longest(ch[0].child[1]);
+        const int back = sr_uni(ch[0].child[1]);
+        int totalLen = longest(back);
         if (totalLen > 0) {  // the path behind the anchor, copied backwards so that the segment runs through the anchor
-            const int count = retrieve(ch[0].child[1]);
+            const int count = retrieve(back);
             for (int k = count - 1; k >= 0; k--) {
-                const int cn = R.chainNos[k];
-                trim_tail(cpx(cn, ch[cn].len - 1));
-                if (ch[cn].len > 1 && sr_near(cpx(cn, ch[cn].len - 2), seg(nsp - 1))) ch[cn].len--;
-                seg_copy(cn, ch[cn].len - 1, -1, ch[cn].len);
+                const int cn = sr_uni(R.chainNos[k]);
+                int L = sr_uni(ch[cn].len);
+                trim_tail(cpx(cn, L - 1));
+                if (L > 1 && sr_near(cpx(cn, L - 2), seg(nsp - 1))) L--;
+                seg_copy(cn, L - 1, -1, L);
                 ch[cn].len = 0;
             }
         }
-        totalLen = longest(ch[0].child[0]);
+        const int fwd = sr_uni(ch[0].child[0]);
+        totalLen = longest(fwd);
         if (totalLen > 1) {
-            const int count = retrieve(ch[0].child[0]);
-            const int first = R.chainNos[0];  // its first pixel is the anchor again
+            const int count = retrieve(fwd);
+            const int first = sr_uni(R.chainNos[0]);  // its first pixel is the anchor again
             ch[first].pix++;
             ch[first].len--;
             append_forward(count);
         }
         close_segment(true);
         for (int k = 2; k < noChains; k++) {  // what is left of the tree
-            if (ch[k].len < 2) continue;
+            if (sr_uni(ch[k].len) < 2) continue;
             totalLen = longest(k);
             if (totalLen >= 10) {
                 segbase = totalPixels;
@@ -830,7 +1055,7 @@ __device__ __forceinline__ void k_stag_comp_tilemax_impl(const StagComp *__restr
     const StagComp C = comps[cid];
     if (C.nanch == 0) return;
     const int bytes = (C.maxr - C.minr + 3) * (C.maxc - C.minc + 3) * 2;
-    if (bytes <= lds_cap) atomicMax(&cursors[10], bytes);
+    atomicMax(&cursors[10], bytes <= lds_cap ? bytes : lds_cap);  // (beyond the cap: the whole of it, for the component's 8 x 8 blocks)
 }
 __global__ __launch_bounds__(256) void k_stag_comp_tilemax(const StagComp *__restrict__ comps, int *cursors, int lds_cap)
 {
@@ -969,10 +1194,12 @@ __device__ __forceinline__ void k_stag_route_walk_impl(StagRoute G, StagArenas A
                                                         int grad_thresh, int lds_bytes, int *__restrict__ prodflag, int *__restrict__ ovf)
 {
     extern __shared__ uint16_t s_tile[];
+    constexpr int WSTACK = 512;
+    __shared__ int4 s_wstack[WSTACK];  // the first entries of the walk's stack (StagRouter::MemWave)
     // one workgroup per component: four waves move the tile in and out, wave 0 walks
     const int cid = blockIdx.x, lane = threadIdx.x & 63, tid = threadIdx.x;
     if (cid >= cursors[0]) return;
-    StagComp C = comps[cid];
+    const StagComp C = sr_uni_struct(comps[cid]);
     if (C.nanch == 0) return;
     StagRouter S;
     stag_bind(S, G, A, C);
@@ -990,8 +1217,54 @@ __device__ __forceinline__ void k_stag_route_walk_impl(StagRoute G, StagArenas A
     T.r0 = C.minr - 1;
     T.c0 = C.minc - 1;
     T.tw = C.maxc - C.minc + 3;
+    T.gstk = S.R.stack; T.lstk.p = (SrLdsInt)(int *)s_wstack; T.lcap = WSTACK;
     const int th = C.maxr - C.minr + 3;
     const bool tiled = T.tw * th * 2 <= lds_bytes;
+    // ... or as 8 x 8 blocks (StagRouter::SparseTile), if those fit
+    __shared__ int s_nblk;
+    StagRouter::SparseTile P;
+    bool sparse = false;
+    if (!tiled) {
+        const int bw = (T.tw + 7) >> 3, bh = (th + 7) >> 3, ntab = (bw * bh + 63) & ~63;
+        const int maxblk = (lds_bytes / 2 - ntab) / 64 - 1;  // (block 0 is the empty one)
+        P.tab = s_tile; P.blk = s_tile + ntab; P.r0 = T.r0; P.c0 = T.c0; P.bw = bw;
+        P.gstk = S.R.stack; P.lstk.p = (SrLdsInt)(int *)s_wstack; P.lcap = WSTACK;
+        if (maxblk >= 16 && maxblk < 65535) {  // (uniform over the workgroup: the barriers below are safe)
+            for (int i = tid; i < ntab; i += 256) s_tile[i] = 0;
+            if (tid < 64) P.blk[tid] = 0;
+            if (tid == 0) s_nblk = 0;
+            __syncthreads();
+            // the blocks within one pixel of a pixel of the component (a wave per row, its lanes along the row; the box's own
+            // border ring holds no pixel of the component)
+            for (int rr = 1 + (tid >> 6); rr < th - 1; rr += 4)
+                for (int cc = 1 + lane; cc < T.tw - 1; cc += 64)
+                    if (label[(T.r0 + rr) * W + T.c0 + cc] == C.root) {
+                        const int b0 = ((rr - 1) >> 3) * bw, b1 = ((rr + 1) >> 3) * bw, q0 = (cc - 1) >> 3, q1 = (cc + 1) >> 3;
+                        s_tile[b0 + q0] = 0xffff; s_tile[b0 + q1] = 0xffff; s_tile[b1 + q0] = 0xffff; s_tile[b1 + q1] = 0xffff;
+                    }
+            __syncthreads();
+            for (int i = tid; i < bw * bh; i += 256)
+                if (s_tile[i] == 0xffff) {
+                    const int slot = atomicAdd(&s_nblk, 1) + 1;
+                    s_tile[i] = (uint16_t)(slot <= maxblk ? slot : 0);
+                }
+            __syncthreads();
+            sparse = s_nblk <= maxblk;
+            if (sparse) {
+                for (int rr = tid >> 6; rr < th; rr += 4)
+                    for (int cc = lane; cc < T.tw; cc += 64) {
+                        const int slot = s_tile[(rr >> 3) * bw + (cc >> 3)];
+                        if (slot) {
+                            const int g = (T.r0 + rr) * W + T.c0 + cc;
+                            const int e = G.edge[g], gr = G.grad[g], dr = G.dir[g];
+                            const int st = e == STAG_EDGE_PIXEL ? 2 : e == STAG_ANCHOR_PIXEL ? 1 : 0;
+                            P.blk[(slot << 6) | ((rr & 7) << 3) | (cc & 7)] = (uint16_t)((gr & 0x7ff) | (dr == STAG_EDGE_VERTICAL ? 0x800 : 0) | (st << 12));
+                        }
+                    }
+            }
+            __syncthreads();
+        }
+    }
     if (tiled) {
         const int total = th * T.tw;
         for (int i0 = tid; i0 < total; i0 += 256 * 4) {
@@ -1016,22 +1289,39 @@ __device__ __forceinline__ void k_stag_route_walk_impl(StagRoute G, StagArenas A
         }
         __syncthreads();
     }
+#ifdef RW_TIMING
+    const unsigned long long rw_t0 = __builtin_readcyclecounter();
+    unsigned long long rw_walk = 0;
+    int rw_walks = 0, rw_live = 0, rw_pix = 0, rw_chains = 0;
+#endif
     if (tid < 64) {
     for (int k0 = 0; k0 < C.nanch; k0 += 64) {
         // which of the next 64 anchors are still anchors?  (a walk can only turn anchors OFF, so a stale "on" is re-checked)
         const int kk = k0 + lane;
-        int my_off = -1;
-        if (kk < C.nanch) my_off = sorted[aslots[C.anch_base + kk]];
+        int my_off = -1, my_rank = -1;
+        if (kk < C.nanch) {
+            my_rank = aslots[C.anch_base + kk];
+            my_off = sorted[my_rank];
+        }
         bool on = false;
-        if (my_off >= 0) on = tiled ? StagRouter::Tile::edge_of(s_tile[T.idx(my_off / W, my_off % W)]) == STAG_ANCHOR_PIXEL : G.edge[my_off] == STAG_ANCHOR_PIXEL;
+        if (my_off >= 0) {
+            const int orr = my_off / W, occ = my_off - orr * W;
+            on = tiled    ? StagRouter::Tile::edge_of(s_tile[T.idx(orr, occ)]) == STAG_ANCHOR_PIXEL
+                 : sparse ? (P.blk[P.off(orr - P.r0, occ - P.c0)] >> 12) == 1
+                          : G.edge[my_off] == STAG_ANCHOR_PIXEL;
+        }
         unsigned long long live = __ballot(on);
         while (live) {
             const int j = __builtin_ctzll(live);
             live &= live - 1;
-            const int rank = aslots[C.anch_base + k0 + j];
-            const int off = sorted[rank];
+            const int rank = __builtin_amdgcn_readlane(my_rank, j), off = __builtin_amdgcn_readlane(my_off, j);  // (no second trip to memory)
             const int ar = off / W, ac = off - ar * W;
-            const bool still = tiled ? StagRouter::Tile::edge_of(s_tile[T.idx(ar, ac)]) == STAG_ANCHOR_PIXEL : G.edge[off] == STAG_ANCHOR_PIXEL;
+            const bool still = tiled    ? StagRouter::Tile::edge_of((uint16_t)sr_uni(s_tile[T.idx(ar, ac)])) == STAG_ANCHOR_PIXEL
+                               : sparse ? (P.word_at(ar, ac) >> 12) == 1
+                                        : sr_uni(G.edge[off]) == STAG_ANCHOR_PIXEL;
+#ifdef RW_TIMING
+            rw_live++;
+#endif
             if (!still) continue;
             S.R.pix = pix0 + pix_used;
             S.R.capPix = capPix0 - pix_used;
@@ -1042,7 +1332,18 @@ __device__ __forceinline__ void k_stag_route_walk_impl(StagRoute G, StagArenas A
                 S.overflow |= 32;
                 break;
             }
-            const bool keep = tiled ? S.walk_anchor_tile(ar, ac, grad_thresh, lane, T) : S.walk_anchor_wave(ar, ac, grad_thresh, lane);
+#ifdef RW_TIMING
+            const unsigned long long rw_a = __builtin_readcyclecounter();
+#endif
+            const bool keep = tiled    ? S.walk_anchor_tile6(ar, ac, grad_thresh, lane, T)
+                              : sparse ? S.walk_anchor_tile6(ar, ac, grad_thresh, lane, P)
+                                       : S.walk_anchor_wave(ar, ac, grad_thresh, lane, SrLdsInt4{(SrLdsInt)(int *)s_wstack}, WSTACK);
+#ifdef RW_TIMING
+            rw_walk += __builtin_readcyclecounter() - rw_a;
+            rw_walks++;
+            rw_pix += S.wl_len;
+            rw_chains += S.wl_chains;
+#endif
             if (S.overflow) break;
             if (keep) {
                 if (lane == 0) {
@@ -1063,6 +1364,11 @@ __device__ __forceinline__ void k_stag_route_walk_impl(StagRoute G, StagArenas A
         comps[cid].nrec = nrec;
         if (S.overflow) atomicOr(ovf, S.overflow);
     }
+#ifdef RW_TIMING
+    if (lane == 0 && C.nanch > 200)
+        printf("walk comp %d: size %d anchors %d tile %dx%d tiled %d | load %llu cycles, anchor loop %llu (walks %llu in %d walks of %d live, %d pixels, %d chains, %d kept)\n", cid, C.size, C.nanch,
+               T.tw, th, (int)tiled + 2 * (int)sparse, 0ull, (unsigned long long)(__builtin_readcyclecounter() - rw_t0), rw_walk, rw_walks, rw_live, rw_pix, rw_chains, nrec);
+#endif
     }  // wave 0
     if (tiled) {  // the component's own pixels back into the edge image
         __syncthreads();
@@ -1073,6 +1379,13 @@ __device__ __forceinline__ void k_stag_route_walk_impl(StagRoute G, StagArenas A
             const int g = (T.r0 + rr) * W + T.c0 + cc;
             if (label[g] == C.root) G.edge[g] = (uint8_t)StagRouter::Tile::edge_of(s_tile[i]);
         }
+    } else if (sparse) {
+        __syncthreads();
+        for (int rr = 1 + (tid >> 6); rr < th - 1; rr += 4)
+            for (int cc = 1 + lane; cc < T.tw - 1; cc += 64) {
+                const int g = (T.r0 + rr) * W + T.c0 + cc;
+                if (label[g] == C.root) G.edge[g] = (uint8_t)StagRouter::Tile::edge_of(P.blk[P.off(rr, cc)]);
+            }
     }
 }
 __global__ __launch_bounds__(256) void k_stag_route_walk(StagRoute G, StagArenas A, StagComp *__restrict__ comps, const int *__restrict__ cursors, const int32_t *__restrict__ sorted, const int *__restrict__ aslots, const int *__restrict__ label, int grad_thresh, int lds_bytes, int *__restrict__ prodflag, int *__restrict__ ovf)
@@ -1151,7 +1464,7 @@ __device__ __forceinline__ void k_stag_route_extract_impl(StagRoute G, StagArena
     __shared__ int4 s_stack[4][EX_CHAINS];
     const int wv = threadIdx.x >> 6, cid = blockIdx.x * 4 + wv, lane = threadIdx.x & 63;
     if (cid >= cursors[0]) return;
-    const StagComp C = comps[cid];
+    const StagComp C = sr_uni_struct(comps[cid]);
     if (C.nanch == 0 || C.nrec == 0) return;
     StagRouter S;
     stag_bind(S, G, A, C);
@@ -1166,10 +1479,10 @@ __device__ __forceinline__ void k_stag_route_extract_impl(StagRoute G, StagArena
     const int n = (int)*n_anchors;
     int prev_rank = -1;
     for (int k = 0; k < C.nrec; k++) {
-        StagRec r = recs[k];
+        StagRec r = sr_uni_struct(recs[k]);
         S.R.pix = pix0 + r.pix_off;
         // the block the reference wrote just before this one: ours only if no other component produced in between
-        S.prev_valid = k > 0 && next[r.rank] == prev_rank;
+        S.prev_valid = k > 0 && sr_uni(next[r.rank]) == prev_rank;
         const int seg0 = S.noSegments, out0 = S.totalPixels;
         // (the tree pointers are set and used INSIDE each branch on purpose: merged in front of one call site they are "LDS or
         //  global", i.e. generic, and every access to the chain tree was a flat_load / flat_store -- 63 of them in this kernel --

@@ -1,0 +1,9 @@
+import sys; sys.path.insert(0,'/root/repo')
+import numpy as np
+from fiducials_amd import stag as fstag, synth
+words=fstag.load_library(21)
+fr=synth.make_stag_frame(words,100,1920,1080,20).image
+det=fstag.StagDetector(21,7,max_width=1920,max_height=1080)
+for i in range(2):
+    M=det.detect_markers(fr)
+print(len(M))

@@ -80,6 +80,12 @@ struct StagRouter {
     // the same component
     bool par = false, prev_valid = false;
     int blk0 = 0;  // where the current anchor's block starts in outpix
+    // component-parallel extraction with the current block staged in LDS (R.outpix then points INTO LDS, shifted so that the
+    // block's absolute indices still apply): the one read in front of the block goes to the arena in global memory
+    const int2 *gout = nullptr;
+#ifdef RW_TIMING
+    unsigned long long ex_t[4] = {0, 0, 0, 0};  // longest() calls, copies of the first segment, the remaining chains' loop
+#endif
     int wlane = -1;  // >= 0: a whole wave runs the extraction (identical scalar work in every lane, copies spread over the lanes)
     int wl_len = 0, wl_dup = 0, wl_chains = 0;  // what walk_anchor() left behind
 
@@ -91,7 +97,7 @@ struct StagRouter {
     __device__ int2 seg(int i) const
     {
         const int k = segbase + i;
-        if (par && k < blk0) return (prev_valid && k >= 0) ? sr_uni_struct(R.outpix[k]) : make_int2(-1000, -1000);  // in front of this anchor's block
+        if (par && k < blk0) return (prev_valid && k >= 0) ? sr_uni_struct(gout[k]) : make_int2(-1000, -1000);  // in front of this anchor's block
         return k >= 0 ? sr_uni_struct(R.outpix[k]) : make_int2(-1000, -1000);
     }
     // append `count` pixels of chain cn, chain index first + step * k, to the segment
@@ -490,15 +496,17 @@ struct StagRouter {
             t = T.t;
             tw = T.tw;
         }
-        if (L0) {
-            ch[0].dir = 0; ch[0].len = 0; ch[0].parent = -1; ch[0].child[0] = ch[0].child[1] = -1; ch[0].pix = -1;
-        }
+        // (a chain record is 16 bytes: dir, len | parent, child[0] | child[1], pad | pix -- begun with ONE store)
+        static_assert(sizeof(StagChain) == 16, "one 16-byte store per chain record");
+        if (L0) *reinterpret_cast<uint4 *>(&ch[0]) = make_uint4(0u, 0xffffffffu, 0xffffu, 0xffffffffu);  // dir 0, len 0, no parent, no children, pix -1
         int noChains = 1, len = 0, dup = 0, top = -1;
         const bool vert0 = T.dir_at(r0, c0) == STAG_EDGE_VERTICAL;
         T.stk_put(0, make_int4(r0, c0, vert0 ? SR_DOWN : SR_RIGHT, 0), L0);
         T.stk_put(1, make_int4(r0, c0, vert0 ? SR_UP : SR_LEFT, 0), L0);
         top = 1;
         const int orc = lane == 5 ? (2 << 12) : 0;  // the pixel stood on becomes an edge pixel, the anchors beside it are cleared
+        // this lane's pixel relative to the one stood on = ka x (one ahead) + kp x (one across)
+        const int ka = lane < 3 ? 1 : 0, kp = (lane == 2 || lane == 3) ? 1 : (lane == 0 || lane == 4) ? -1 : 0;
         while (top >= 0) {
             const int4 e = T.stk_get(top);
             top--;
@@ -517,10 +525,9 @@ struct StagRouter {
             // 3 = none, the gradients decide
             const unsigned tab = 21075u + (low ? 0u : 2048u);
             // this lane's pixel relative to the one stood on: as a tile offset (dense), as (rows, columns) (blocks)
-            const int voff = lane == 0 ? a - p : lane == 1 ? a : lane == 2 ? a + p : lane == 3 ? p : lane == 4 ? -p : 0;
+            const int voff = ka * a + kp * p;
             const int pr = horiz ? 1 : 0, pc = horiz ? 0 : 1;
-            const int ldr = lane == 0 ? ar - pr : lane == 1 ? ar : lane == 2 ? ar + pr : lane == 3 ? pr : lane == 4 ? -pr : 0;
-            const int ldc = lane == 0 ? ac - pc : lane == 1 ? ac : lane == 2 ? ac + pc : lane == 3 ? pc : lane == 4 ? -pc : 0;
+            const int ldr = ka * ar + kp * pr, ldc = ka * ac + kp * pc;
             int i = 0, o = 0;  // where this lane reads (and, lanes 3 - 5, writes)
             if constexpr (SP) o = T.off(r - T.r0 + ldr, c - T.c0 + ldc);
             else {
@@ -532,12 +539,13 @@ struct StagRouter {
             if ((w0 >> 12) != 2) dup++;
             const int cur = noChains;
             if (L0) {
-                ch[cur].dir = (int16_t)d; ch[cur].parent = (int16_t)parent; ch[cur].child[0] = ch[cur].child[1] = -1; ch[cur].pix = len;
+                // (len is written again where the chain ends; the two bytes of padding are nobody's)
+                *reinterpret_cast<uint4 *>(&ch[cur]) = make_uint4((unsigned)d & 0xffffu, ((unsigned)parent & 0xffffu) | 0xffff0000u, 0xffffu, (unsigned)len);
                 R.pix[len] = make_int2(r, c);
             }
             len++;
             int chainLen = 1;
-            bool stopped = false;
+            int why = 0;  // why the chain ends: 0 the edge turns, 1 an edge pixel or a weak gradient ahead, 2 no room for its pixels
             bool along = ((w0 & 0x800) != 0) == !horiz;  // the pixel's edge direction is the chain's
             while (along) {
                 const int st = w >> 12;
@@ -545,7 +553,7 @@ struct StagRouter {
                 // mark: lanes 3, 4 clear their anchor, lane 5 writes the edge pixel -- from the words just read
                 if (lane == 5 || ((lane == 3 || lane == 4) && st == 1)) t[o] = (uint16_t)((w & 0x0fff) | orc);
                 int side = (int)((tab >> (2 * (nz & 7u))) & 3u) - 1;
-                if (side == 2) {
+                if (__builtin_expect(side == 2, 0)) {
                     const int gA = __builtin_amdgcn_readlane(w, 0) & 0x7ff, gB = __builtin_amdgcn_readlane(w, 1) & 0x7ff,
                               gC = __builtin_amdgcn_readlane(w, 2) & 0x7ff;
                     side = gA > gB ? (gA > gC ? -1 : 1) : (gC > gB ? 1 : 0);
@@ -555,16 +563,8 @@ struct StagRouter {
                 r += ar + (horiz ? side : 0);
                 c += ac + (horiz ? 0 : side);
                 along = ((wn & 0x800) != 0) == !horiz;
-                if ((wn >> 12) == 2 || (wn & 0x7ff) < grad_thresh) {
-                    if (L0) {
-                        ch[cur].len = (uint16_t)chainLen;
-                        ch[parent].child[slot] = (int16_t)cur;
-                    }
-                    noChains++;
-                    stopped = true;
-                    break;
-                }
-                if (len + 2 >= capPix) { overflow |= 16; stopped = true; break; }
+                why = ((wn >> 12) == 2 || (wn & 0x7ff) < grad_thresh) ? 1 : (len + 2 >= capPix) ? 2 : 0;
+                if (__builtin_expect(why != 0, 0)) break;
                 if (L0) R.pix[len] = make_int2(r, c);
                 len++;
                 chainLen++;
@@ -572,7 +572,18 @@ struct StagRouter {
                 else o = i + voff;
                 w = t[o];
             }
-            if (stopped) continue;
+            if (why == 2) {
+                overflow |= 16;
+                continue;
+            }
+            if (why == 1) {
+                if (L0) {
+                    ch[cur].len = (uint16_t)chainLen;
+                    ch[parent].child[slot] = (int16_t)cur;
+                }
+                noChains++;
+                continue;
+            }
             // the edge turns here: branch both ways across, this chain ends in front of the turning pixel
             T.stk_put(top + 1, make_int4(r, c, horiz ? SR_DOWN : SR_RIGHT, cur), L0);
             T.stk_put(top + 2, make_int4(r, c, horiz ? SR_UP : SR_LEFT, cur), L0);
@@ -622,7 +633,14 @@ struct StagRouter {
         segbase = totalPixels;
         nsp = 0;
         const int back = sr_uni(ch[0].child[1]);
+#ifdef RW_TIMING
+        const unsigned long long ex_a = __builtin_readcyclecounter();
+#endif
         int totalLen = longest(back);
+#ifdef RW_TIMING
+        const unsigned long long ex_b = __builtin_readcyclecounter();
+        ex_t[0] += ex_b - ex_a;
+#endif
         if (totalLen > 0) {  // the path behind the anchor, copied backwards so that the segment runs through the anchor
             const int count = retrieve(back);
             for (int k = count - 1; k >= 0; k--) {
@@ -635,7 +653,15 @@ struct StagRouter {
             }
         }
         const int fwd = sr_uni(ch[0].child[0]);
+#ifdef RW_TIMING
+        const unsigned long long ex_c = __builtin_readcyclecounter();
+        ex_t[1] += ex_c - ex_b;
+#endif
         totalLen = longest(fwd);
+#ifdef RW_TIMING
+        const unsigned long long ex_d = __builtin_readcyclecounter();
+        ex_t[0] += ex_d - ex_c;
+#endif
         if (totalLen > 1) {
             const int count = retrieve(fwd);
             const int first = sr_uni(R.chainNos[0]);  // its first pixel is the anchor again
@@ -644,6 +670,10 @@ struct StagRouter {
             append_forward(count);
         }
         close_segment(true);
+#ifdef RW_TIMING
+        const unsigned long long ex_e = __builtin_readcyclecounter();
+        ex_t[1] += ex_e - ex_d;
+#endif
         for (int k = 2; k < noChains; k++) {  // what is left of the tree
             if (sr_uni(ch[k].len) < 2) continue;
             totalLen = longest(k);
@@ -654,6 +684,9 @@ struct StagRouter {
                 close_segment(false);
             }
         }
+#ifdef RW_TIMING
+        ex_t[2] += __builtin_readcyclecounter() - ex_e;
+#endif
     }
 };
 
@@ -1183,6 +1216,7 @@ __device__ void stag_bind(StagRouter &S, const StagRoute &G, const StagArenas &A
     S.R.chains = A.chains + C.chain_base;
     S.R.capChains = C.chain_cap < 32767 ? C.chain_cap : 32767;
     S.R.outpix = A.out + C.out_base;
+    S.gout = S.R.outpix;
     S.R.capOut = C.out_cap;
     S.R.segs = A.segs + C.seg_base;
     S.R.capSegs = C.seg_cap;
@@ -1220,6 +1254,9 @@ __device__ __forceinline__ void k_stag_route_walk_impl(StagRoute G, StagArenas A
     T.gstk = S.R.stack; T.lstk.p = (SrLdsInt)(int *)s_wstack; T.lcap = WSTACK;
     const int th = C.maxr - C.minr + 3;
     const bool tiled = T.tw * th * 2 <= lds_bytes;
+#ifdef RW_TIMING
+    const unsigned long long rw_tl = __builtin_readcyclecounter();
+#endif
     // ... or as 8 x 8 blocks (StagRouter::SparseTile), if those fit
     __shared__ int s_nblk;
     StagRouter::SparseTile P;
@@ -1236,12 +1273,20 @@ __device__ __forceinline__ void k_stag_route_walk_impl(StagRoute G, StagArenas A
             __syncthreads();
             // the blocks within one pixel of a pixel of the component (a wave per row, its lanes along the row; the box's own
             // border ring holds no pixel of the component)
-            for (int rr = 1 + (tid >> 6); rr < th - 1; rr += 4)
-                for (int cc = 1 + lane; cc < T.tw - 1; cc += 64)
-                    if (label[(T.r0 + rr) * W + T.c0 + cc] == C.root) {
-                        const int b0 = ((rr - 1) >> 3) * bw, b1 = ((rr + 1) >> 3) * bw, q0 = (cc - 1) >> 3, q1 = (cc + 1) >> 3;
-                        s_tile[b0 + q0] = 0xffff; s_tile[b0 + q1] = 0xffff; s_tile[b1 + q0] = 0xffff; s_tile[b1 + q1] = 0xffff;
-                    }
+            for (int r4 = 1 + (tid >> 6) * 4; r4 < th - 1; r4 += 16)
+                for (int cc = 1 + lane; cc < T.tw - 1; cc += 64) {
+                    int lb[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++)  // (four rows in flight per thread)
+                        if (r4 + u < th - 1) lb[u] = label[(T.r0 + r4 + u) * W + T.c0 + cc];
+#pragma unroll
+                    for (int u = 0; u < 4; u++)
+                        if (r4 + u < th - 1 && lb[u] == C.root) {
+                            const int rr = r4 + u;
+                            const int b0 = ((rr - 1) >> 3) * bw, b1 = ((rr + 1) >> 3) * bw, q0 = (cc - 1) >> 3, q1 = (cc + 1) >> 3;
+                            s_tile[b0 + q0] = 0xffff; s_tile[b0 + q1] = 0xffff; s_tile[b1 + q0] = 0xffff; s_tile[b1 + q1] = 0xffff;
+                        }
+                }
             __syncthreads();
             for (int i = tid; i < bw * bh; i += 256)
                 if (s_tile[i] == 0xffff) {
@@ -1251,46 +1296,52 @@ __device__ __forceinline__ void k_stag_route_walk_impl(StagRoute G, StagArenas A
             __syncthreads();
             sparse = s_nblk <= maxblk;
             if (sparse) {
-                for (int rr = tid >> 6; rr < th; rr += 4)
+                for (int r4 = (tid >> 6) * 4; r4 < th; r4 += 16)
                     for (int cc = lane; cc < T.tw; cc += 64) {
-                        const int slot = s_tile[(rr >> 3) * bw + (cc >> 3)];
-                        if (slot) {
-                            const int g = (T.r0 + rr) * W + T.c0 + cc;
-                            const int e = G.edge[g], gr = G.grad[g], dr = G.dir[g];
-                            const int st = e == STAG_EDGE_PIXEL ? 2 : e == STAG_ANCHOR_PIXEL ? 1 : 0;
-                            P.blk[(slot << 6) | ((rr & 7) << 3) | (cc & 7)] = (uint16_t)((gr & 0x7ff) | (dr == STAG_EDGE_VERTICAL ? 0x800 : 0) | (st << 12));
+                        int slot[4], e[4], gr[4], dr[4];
+#pragma unroll
+                        for (int u = 0; u < 4; u++) {
+                            slot[u] = r4 + u < th ? s_tile[((r4 + u) >> 3) * bw + (cc >> 3)] : 0;
+                            if (slot[u]) {
+                                const int g = (T.r0 + r4 + u) * W + T.c0 + cc;
+                                e[u] = G.edge[g]; gr[u] = G.grad[g]; dr[u] = G.dir[g];
+                            }
                         }
+#pragma unroll
+                        for (int u = 0; u < 4; u++)
+                            if (slot[u]) {
+                                const int st = e[u] == STAG_EDGE_PIXEL ? 2 : e[u] == STAG_ANCHOR_PIXEL ? 1 : 0;
+                                P.blk[(slot[u] << 6) | (((r4 + u) & 7) << 3) | (cc & 7)] =
+                                    (uint16_t)((gr[u] & 0x7ff) | (dr[u] == STAG_EDGE_VERTICAL ? 0x800 : 0) | (st << 12));
+                            }
                     }
             }
             __syncthreads();
         }
     }
     if (tiled) {
-        const int total = th * T.tw;
-        for (int i0 = tid; i0 < total; i0 += 256 * 4) {
-            int e[4], gr[4], dr[4];
+        // a wave per row, its lanes along the row (no division per pixel), four rows in flight per thread
+        for (int r4 = (tid >> 6) * 4; r4 < th; r4 += 16)
+            for (int cc = lane; cc < T.tw; cc += 64) {
+                int e[4], gr[4], dr[4];
 #pragma unroll
-            for (int u = 0; u < 4; u++) {  // four independent pixels in flight per thread
-                const int i = i0 + 256 * u;
-                if (i < total) {
-                    const int rr = i / T.tw, cc = i - rr * T.tw;
-                    const int g = (T.r0 + rr) * W + T.c0 + cc;
-                    e[u] = G.edge[g]; gr[u] = G.grad[g]; dr[u] = G.dir[g];
-                }
-            }
+                for (int u = 0; u < 4; u++)
+                    if (r4 + u < th) {
+                        const int g = (T.r0 + r4 + u) * W + T.c0 + cc;
+                        e[u] = G.edge[g]; gr[u] = G.grad[g]; dr[u] = G.dir[g];
+                    }
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int i = i0 + 256 * u;
-                if (i < total) {
-                    const int st = e[u] == STAG_EDGE_PIXEL ? 2 : e[u] == STAG_ANCHOR_PIXEL ? 1 : 0;
-                    s_tile[i] = (uint16_t)((gr[u] & 0x7ff) | (dr[u] == STAG_EDGE_VERTICAL ? 0x800 : 0) | (st << 12));
-                }
+                for (int u = 0; u < 4; u++)
+                    if (r4 + u < th) {
+                        const int st = e[u] == STAG_EDGE_PIXEL ? 2 : e[u] == STAG_ANCHOR_PIXEL ? 1 : 0;
+                        s_tile[(r4 + u) * T.tw + cc] = (uint16_t)((gr[u] & 0x7ff) | (dr[u] == STAG_EDGE_VERTICAL ? 0x800 : 0) | (st << 12));
+                    }
             }
-        }
         __syncthreads();
     }
 #ifdef RW_TIMING
     const unsigned long long rw_t0 = __builtin_readcyclecounter();
+    const unsigned long long rw_load = rw_t0 - rw_tl;
     unsigned long long rw_walk = 0;
     int rw_walks = 0, rw_live = 0, rw_pix = 0, rw_chains = 0;
 #endif
@@ -1367,24 +1418,34 @@ __device__ __forceinline__ void k_stag_route_walk_impl(StagRoute G, StagArenas A
 #ifdef RW_TIMING
     if (lane == 0 && C.nanch > 200)
         printf("walk comp %d: size %d anchors %d tile %dx%d tiled %d | load %llu cycles, anchor loop %llu (walks %llu in %d walks of %d live, %d pixels, %d chains, %d kept)\n", cid, C.size, C.nanch,
-               T.tw, th, (int)tiled + 2 * (int)sparse, 0ull, (unsigned long long)(__builtin_readcyclecounter() - rw_t0), rw_walk, rw_walks, rw_live, rw_pix, rw_chains, nrec);
+               T.tw, th, (int)tiled + 2 * (int)sparse, rw_load, (unsigned long long)(__builtin_readcyclecounter() - rw_t0), rw_walk, rw_walks, rw_live, rw_pix, rw_chains, nrec);
 #endif
     }  // wave 0
     if (tiled) {  // the component's own pixels back into the edge image
         __syncthreads();
-        const int total = th * T.tw;
-        for (int i = tid; i < total; i += 256) {
-            const int rr = i / T.tw, cc = i - rr * T.tw;
-            if (rr == 0 || rr == th - 1 || cc == 0 || cc == T.tw - 1) continue;
-            const int g = (T.r0 + rr) * W + T.c0 + cc;
-            if (label[g] == C.root) G.edge[g] = (uint8_t)StagRouter::Tile::edge_of(s_tile[i]);
-        }
+        for (int r4 = 1 + (tid >> 6) * 4; r4 < th - 1; r4 += 16)
+            for (int cc = 1 + lane; cc < T.tw - 1; cc += 64) {
+                int lb[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    if (r4 + u < th - 1) lb[u] = label[(T.r0 + r4 + u) * W + T.c0 + cc];
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    if (r4 + u < th - 1 && lb[u] == C.root)
+                        G.edge[(T.r0 + r4 + u) * W + T.c0 + cc] = (uint8_t)StagRouter::Tile::edge_of(s_tile[(r4 + u) * T.tw + cc]);
+            }
     } else if (sparse) {
         __syncthreads();
-        for (int rr = 1 + (tid >> 6); rr < th - 1; rr += 4)
+        for (int r4 = 1 + (tid >> 6) * 4; r4 < th - 1; r4 += 16)
             for (int cc = 1 + lane; cc < T.tw - 1; cc += 64) {
-                const int g = (T.r0 + rr) * W + T.c0 + cc;
-                if (label[g] == C.root) G.edge[g] = (uint8_t)StagRouter::Tile::edge_of(P.blk[P.off(rr, cc)]);
+                int lb[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    if (r4 + u < th - 1) lb[u] = label[(T.r0 + r4 + u) * W + T.c0 + cc];
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    if (r4 + u < th - 1 && lb[u] == C.root)
+                        G.edge[(T.r0 + r4 + u) * W + T.c0 + cc] = (uint8_t)StagRouter::Tile::edge_of(P.blk[P.off(r4 + u, cc)]);
             }
     }
 }
@@ -1459,9 +1520,13 @@ __device__ __forceinline__ void k_stag_route_extract_impl(StagRoute G, StagArena
     // one wave per component: every lane runs the same scalar steps (same values, same stores); pixel runs are copied by all lanes.
     // The chain tree of the anchor being extracted (and the stack of its tree walk) sits in LDS when it has <= EX_CHAINS chains:
     // the extraction prunes and empties chains as it goes, none of which has to survive it.
-    constexpr int EX_CHAINS = 1024;
+    // (round 5) so do the anchor's pixels and the block of output pixels it produces, when the walk left <= EX_PIX pixels: every
+    // look at a chain's first pixels or at the segment's tail (trim_tail, append_forward) was a round trip to global memory, some
+    // of them behind the stores just issued -- half of this kernel's time on a marker's component
+    constexpr int EX_CHAINS = 512, EX_PIX = 1024;
     __shared__ StagChain s_chains[4][EX_CHAINS];
     __shared__ int4 s_stack[4][EX_CHAINS];
+    __shared__ int2 s_pix[4][EX_PIX + 1], s_out[4][EX_PIX + 1];
     const int wv = threadIdx.x >> 6, cid = blockIdx.x * 4 + wv, lane = threadIdx.x & 63;
     if (cid >= cursors[0]) return;
     const StagComp C = sr_uni_struct(comps[cid]);
@@ -1473,9 +1538,13 @@ __device__ __forceinline__ void k_stag_route_extract_impl(StagRoute G, StagArena
     S.segbase = S.nsp = 0;
     StagRec *recs = A.recs + C.anch_base;
     int2 *pix0 = S.R.pix;
+    int2 *out0p = S.R.outpix;
     StagChain *chain0 = S.R.chains;
     int4 *stack0 = S.R.stack;
     const int capStack0 = S.R.capStack;
+#ifdef RW_TIMING
+    const unsigned long long ex_t0 = __builtin_readcyclecounter();
+#endif
     const int n = (int)*n_anchors;
     int prev_rank = -1;
     for (int k = 0; k < C.nrec; k++) {
@@ -1487,7 +1556,28 @@ __device__ __forceinline__ void k_stag_route_extract_impl(StagRoute G, StagArena
         // (the tree pointers are set and used INSIDE each branch on purpose: merged in front of one call site they are "LDS or
         //  global", i.e. generic, and every access to the chain tree was a flat_load / flat_store -- 63 of them in this kernel --
         //  that waits like an LDS and a memory operation at once; per branch the compiler knows which it is: ds_* in the common case)
-        if (r.nchains <= EX_CHAINS) {
+        if (r.nchains <= EX_CHAINS && r.len <= EX_PIX) {
+            for (int i = lane; i < r.nchains; i += 64) s_chains[wv][i] = chain0[r.chain_off + i];
+            for (int i = lane; i <= r.len; i += 64) s_pix[wv][i] = pix0[r.pix_off + i];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            S.R.chains = s_chains[wv];
+            S.R.stack = s_stack[wv];
+            S.R.capStack = EX_CHAINS;
+            S.R.pix = s_pix[wv];
+            S.R.outpix = s_out[wv] - out0;  // (absolute indices: the block begins at out0)
+            S.extract_anchor(r.nchains);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            {  // the block to its place in the component's arena
+                const int nout = S.totalPixels - out0, room = S.R.capOut - out0;
+                int ncopy = nout < room ? nout : room;
+                ncopy = ncopy < EX_PIX ? ncopy : EX_PIX;  // (beyond: the arena overflowed, the frame takes the sequential road)
+                for (int i = lane; i < ncopy; i += 64) out0p[out0 + i] = s_out[wv][i];
+            }
+        } else if (r.nchains <= EX_CHAINS) {
             for (int i = lane; i < r.nchains; i += 64) s_chains[wv][i] = chain0[r.chain_off + i];
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_wave_barrier();
@@ -1495,11 +1585,13 @@ __device__ __forceinline__ void k_stag_route_extract_impl(StagRoute G, StagArena
             S.R.chains = s_chains[wv];
             S.R.stack = s_stack[wv];
             S.R.capStack = EX_CHAINS;
+            S.R.outpix = out0p;
             S.extract_anchor(r.nchains);
         } else {
             S.R.chains = chain0 + r.chain_off;
             S.R.stack = stack0;
             S.R.capStack = capStack0;
+            S.R.outpix = out0p;
             S.extract_anchor(r.nchains);
         }
         r.out_off = out0; r.out_len = S.totalPixels - out0;
@@ -1512,6 +1604,11 @@ __device__ __forceinline__ void k_stag_route_extract_impl(StagRoute G, StagArena
         prev_rank = r.rank;
         if (S.overflow) break;
     }
+#ifdef RW_TIMING
+    if (lane == 0 && C.nrec > 8)
+        printf("extract comp %d: recs %d | total %llu cycles: longest %llu, first segment %llu, other chains %llu\n", cid, C.nrec,
+               (unsigned long long)(__builtin_readcyclecounter() - ex_t0), S.ex_t[0], S.ex_t[1], S.ex_t[2]);
+#endif
     if (S.overflow && lane == 0) atomicOr(ovf, S.overflow);
 }
 __global__ __launch_bounds__(256) void k_stag_route_extract(StagRoute G, StagArenas A, const StagComp *__restrict__ comps, const int *__restrict__ cursors, const int *__restrict__ next, const unsigned *__restrict__ n_anchors, int *__restrict__ blk_pix, int *__restrict__ blk_segs, int2 *__restrict__ blk_where, int *__restrict__ ovf)

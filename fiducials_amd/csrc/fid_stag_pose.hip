@@ -453,14 +453,36 @@ __device__ void sr_downhill(double x[9], const double step[9], const double Cm[9
     eval_rows(-1);
     update_sum();
     for (;;) {
+        // (round 5) lowest, highest and next-highest vertex by RANK: lane i < 10 holds y[i] and counts the vertices above it; when
+        // the highest, the second highest and the lowest value each occur once -- ten function values of ten different points:
+        // always, bar a degenerate start -- the solver's scan below has exactly these three answers (strict comparisons find the
+        // one maximum and the one second maximum whatever the order, `<=` the one minimum), and they cost ten compares in all
+        // lanes at once instead of the scan's thirty compare-and-select chains (150 of an iteration's 1 000 instructions).
+        int ilo = 0, ihi = 0, inhi = 0;
+        double v_lo = 0, v_hi = 0, v_nhi = 0;
+        bool ranked;
+        {
+            const double yl = S->y[lane < 10 ? lane : 9];
+            int above = 0;
+#pragma unroll
+            for (int j = 0; j <= 9; j++) above += bcast_f64(yl, j) > yl ? 1 : 0;
+            const unsigned m0 = (unsigned)__ballot(lane < 10 && above == 0), m1 = (unsigned)__ballot(lane < 10 && above == 1),
+                           m9 = (unsigned)__ballot(lane < 10 && above == 9);
+            ranked = __builtin_popcount(m0) == 1 && __builtin_popcount(m1) == 1 && __builtin_popcount(m9) == 1;
+            if (ranked) {
+                ihi = __builtin_ctz(m0); inhi = __builtin_ctz(m1); ilo = __builtin_ctz(m9);
+                v_hi = bcast_f64(yl, ihi); v_nhi = bcast_f64(yl, inhi); v_lo = bcast_f64(yl, ilo);
+            }
+        }
+        if (!ranked) {
         double y[10];
 #pragma unroll
         for (int i = 0; i <= 9; i++) y[i] = S->y[i];
         // the solver's scan for the lowest, highest and next-highest vertex -- the same comparisons in the same order, with the
         // VALUES y[ilo], y[ihi], y[inhi] carried beside the indices: indexing the register array y[] with a run-time index costs
         // a ten-way select chain per read, thirty of them per scan (the scan was about half of an iteration's 5 700 cycles)
-        int ilo = 0, ihi, inhi;
-        double v_lo = y[0], v_hi, v_nhi;
+        ilo = 0;
+        v_lo = y[0];
         if (y[0] > y[1]) { ihi = 0; inhi = 1; v_hi = y[0]; v_nhi = y[1]; } else { ihi = 1; inhi = 0; v_hi = y[1]; v_nhi = y[0]; }
 #pragma unroll
         for (int i = 0; i <= 9; i++) {
@@ -474,6 +496,7 @@ __device__ void sr_downhill(double x[9], const double step[9], const double Cm[9
 #pragma unroll
             for (int i = 0; i <= 9; i++)
                 if (!found && y[i] == v_lo && i != ihi && i != inhi) { ilo = i; found = true; }
+        }
         }
         const double error = fabs(v_hi - v_lo);
         double range = 0;

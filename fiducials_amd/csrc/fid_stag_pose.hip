@@ -434,21 +434,34 @@ __device__ void sr_downhill(double x[9], const double step[9], const double Cm[9
         SR_LDS_SYNC();
     };
 #endif
+    // column sums in vertex order, and in the same pass over the column its extent |max - min| (the termination test's range,
+    // round 5: it read the ten vertices a second time at the top of every iteration)
+    double col_range = 0;  // (lanes >= nd carry 0)
     auto update_sum = [&]() {
         if (lane < nd) {
-            double acc = 0.;
-            for (int i = 0; i <= nd; i++) acc += S->p[i][lane];
+            double acc = 0., mn = INFINITY, mx = -INFINITY;
+            for (int i = 0; i <= nd; i++) {
+                const double v = S->p[i][lane];
+                acc += v;
+                mn = fmin(mn, v);
+                mx = fmax(mx, v);
+            }
             S->sum[lane] = acc;
+            col_range = fabs(mx - mn);
         }
         SR_LDS_SYNC();
     };
     auto replace_point = [&](int ihi, double alpha_, double ytry) {
-        const double alpha = (1.0 - alpha_) / nd, beta = alpha - alpha_;
+        // (alpha_ is one of -1, -2, 0.5: the quotient is one of three constants, no division per iteration)
+        const double alpha = alpha_ == -1.0 ? (1.0 - -1.0) / 9 : alpha_ == -2.0 ? (1.0 - -2.0) / 9 : (1.0 - alpha_) / nd, beta = alpha - alpha_;
+        // (a lane reads back only its own column: what it has just written is there without a synchronisation in between)
         if (lane < nd) S->p[ihi][lane] = S->sum[lane] * alpha - S->p[ihi][lane] * beta;
         if (lane == 0) S->y[ihi] = ytry;
-        SR_LDS_SYNC();
         update_sum();
     };
+    // the candidate a lane's row works on: reflection (-1), expansion (-2), contraction (0.5) -- its two coefficients, once
+    const double row_a = (lane >> 4) == 0 ? -1.0 : (lane >> 4) == 1 ? -2.0 : 0.5;
+    const double row_alpha = (1.0 - row_a) / nd, row_beta = row_alpha - row_a;
     int fcount = nd + 1;
     eval_rows(-1);
     update_sum();
@@ -501,15 +514,7 @@ __device__ void sr_downhill(double x[9], const double step[9], const double Cm[9
         const double error = fabs(v_hi - v_lo);
         double range = 0;
         {
-            double r = 0;
-            if (lane < nd) {
-                double mn = S->p[0][lane], mx = mn;
-                for (int i = 1; i <= nd; i++) {
-                    mn = fmin(mn, S->p[i][lane]);
-                    mx = fmax(mx, S->p[i][lane]);
-                }
-                r = fabs(mx - mn);
-            }
+            const double r = col_range;
             // (lanes >= nd carry 0: the maximum of the first 16-lane row is the wave's -- four DPP steps instead of six)
             {
                 unsigned long long u = __double_as_longlong(r);
@@ -549,9 +554,7 @@ __device__ void sr_downhill(double x[9], const double step[9], const double Cm[9
         // row 0: reflection (-1), row 1: expansion (-2), rows 2 and 3: contraction (0.5); a lane forms the six entries it multiplies
         double xa[3], xb[3];
         {
-            const int row = lane >> 4;
-            const double a_ = row == 0 ? -1.0 : row == 1 ? -2.0 : 0.5;
-            const double alpha = (1.0 - a_) / nd, beta = alpha - a_;
+            const double alpha = row_alpha, beta = row_beta;
             for (int k = 0; k < 3; k++) {
                 xa[k] = S->sum[3 * ra + k] * alpha - S->p[ihi][3 * ra + k] * beta;
                 xb[k] = S->sum[3 * rb + k] * alpha - S->p[ihi][3 * rb + k] * beta;

@@ -579,7 +579,9 @@ fid_status fid_stag_create(int libraryHD, int errorCorrection, int max_width, in
              hipFuncSetAttribute((const void *)k_stag_comp_sort_big, hipFuncAttributeMaxDynamicSharedMemorySize, STAG_SORT_BIG * 4) == hipSuccess &&
              // (and their group-mode trampolines, fid_stag_batch.h)
              hipFuncSetAttribute((const void *)k_stag_batch<k_stag_route_walk_fn>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) == hipSuccess &&
-             hipFuncSetAttribute((const void *)k_stag_batch<k_stag_comp_sort_big_fn>, hipFuncAttributeMaxDynamicSharedMemorySize, STAG_SORT_BIG * 4) == hipSuccess;
+             hipFuncSetAttribute((const void *)k_stag_batch<k_stag_comp_sort_big_fn>, hipFuncAttributeMaxDynamicSharedMemorySize, STAG_SORT_BIG * 4) == hipSuccess &&
+             hipFuncSetAttribute((const void *)k_stag_split_lines, hipFuncAttributeMaxDynamicSharedMemorySize, SL_LDS_BYTES(1024)) == hipSuccess &&
+             hipFuncSetAttribute((const void *)k_stag_batch<k_stag_split_lines_fn>, hipFuncAttributeMaxDynamicSharedMemorySize, SL_LDS_BYTES(1024)) == hipSuccess;
         if (getenv("FID_VERBOSE"))
             fprintf(stderr, "fid stag: frames per merged launch: route_walk %d, route_extract %d, quads %d, decode %d, smooth_grad %d\n",
                     StagTab<k_stag_route_walk_fn>::kMax, StagTab<k_stag_route_extract_fn>::kMax, StagTab<k_stag_quads_fn>::kMax,
@@ -1084,9 +1086,15 @@ static fid_status stag_advance_impl(fid_stag_ctx *c, StagJob &j)
         StagPrefix PF;
         PF.x = c->d_prefix; PF.y = PF.x + c->prefcap; PF.xx = PF.y + c->prefcap; PF.yy = PF.xx + c->prefcap; PF.xy = PF.yy + c->prefcap;
         const int wg = (ns + 63) / 64;
-        if (wg > 0)
-            STAG_LAUNCH(k_stag_split_lines, dim3((ns + 3) / 4), dim3(256), 0, st, c->d_vsegs, c->d_vtotal, c->d_outpix, PF, c->min_line_len, 1.0,
-                               c->d_lslots, c->d_lcounts);
+        if (wg > 0) {
+            // pixels per wave that live in LDS (fid_stag_lines.hip): a frame on its own has the CUs to itself, a group keeps four
+            // workgroups per CU resident.  FID_STAG_SPLIT_LDS overrides (0: global memory throughout).
+            static const int lds_env = [] { const char *e = getenv("FID_STAG_SPLIT_LDS"); return e ? atoi(e) : -1; }();
+            int lds_pix = lds_env >= 0 ? lds_env : (grouped ? 256 : 1024);
+            lds_pix = lds_pix > 1024 ? 1024 : lds_pix;
+            STAG_LAUNCH(k_stag_split_lines, dim3((ns + 3) / 4), dim3(256), (size_t)SL_LDS_BYTES(lds_pix), st, c->d_vsegs, c->d_vtotal, c->d_outpix, PF,
+                               c->min_line_len, 1.0, c->d_lslots, c->d_lcounts, lds_pix);
+        }
         STAG_LAUNCH(k_stag_scan_counts, dim3(1), dim3(1024), 0, st, c->d_lcounts, c->d_vtotal, c->d_ltotal);
         if (wg > 0)
             STAG_LAUNCH(k_stag_gather_lines, dim3(wg), dim3(64), 0, st, c->d_vsegs, c->d_vtotal, c->d_lcounts, c->d_ltotal, c->d_lslots, c->d_lines);

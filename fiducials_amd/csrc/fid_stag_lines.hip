@@ -395,20 +395,49 @@ __device__ double sl_min_dist(double x1, double y1, double a, double b, int inve
     return sqrt((x1 - x2) * (x1 - x2) + (y1 - y2) * (y1 - y2));
 }
 
+// Where k_stag_split_lines reads a segment's pixels and prefix sums (round 5): every batch of ten good pixels fetched its next
+// 64 pixels and every refit its ten prefix values from GLOBAL memory, two round trips a batch and some eighty batches on a
+// marker's outline -- two thirds of the kernel's time waiting.  A segment of <= lds_pix pixels (k_stag_split_lines) lives in the wave's share of
+// the LDS instead (pixels packed x | y << 16; x / y sums fit 32 bits there), longer ones stay where they were.
+struct SlLds {
+    const int *px;                      // x | y << 16
+    const int *sx, *sy;                 // [n + 1]
+    const long long *sxx, *syy, *sxy;   // [n + 1]
+    __device__ __forceinline__ double X(int k) const { return (double)(px[k] & 0xffff); }
+    __device__ __forceinline__ double Y(int k) const { return (double)(px[k] >> 16); }
+    __device__ __forceinline__ long long dX(int b, int n) const { return (long long)(sx[b + n] - sx[b]); }
+    __device__ __forceinline__ long long dY(int b, int n) const { return (long long)(sy[b + n] - sy[b]); }
+    __device__ __forceinline__ long long dXX(int b, int n) const { return sxx[b + n] - sxx[b]; }
+    __device__ __forceinline__ long long dYY(int b, int n) const { return syy[b + n] - syy[b]; }
+    __device__ __forceinline__ long long dXY(int b, int n) const { return sxy[b + n] - sxy[b]; }
+};
+struct SlGlobal {
+    const int2 *px;  // (row, column)
+    StagPrefix P;
+    __device__ __forceinline__ double X(int k) const { return (double)px[k].y; }
+    __device__ __forceinline__ double Y(int k) const { return (double)px[k].x; }
+    __device__ __forceinline__ long long dX(int b, int n) const { return P.x[b + n] - P.x[b]; }
+    __device__ __forceinline__ long long dY(int b, int n) const { return P.y[b + n] - P.y[b]; }
+    __device__ __forceinline__ long long dXX(int b, int n) const { return P.xx[b + n] - P.xx[b]; }
+    __device__ __forceinline__ long long dYY(int b, int n) const { return P.yy[b + n] - P.yy[b]; }
+    __device__ __forceinline__ long long dXY(int b, int n) const { return P.xy[b + n] - P.xy[b]; }
+};
+
 // LineFit with a known orientation (LineSegment.cpp:703-733) over pixels [base, base + count)
-__device__ void sl_fit_known(const StagPrefix &P, int base, int count, int invert, double *a, double *b)
+template <class Src>
+__device__ void sl_fit_known(const Src &P, int base, int count, int invert, double *a, double *b)
 {
     if (count < 2) return;
     const double S = count;
-    double Sx = (double)(P.x[base + count] - P.x[base]), Sy = (double)(P.y[base + count] - P.y[base]);
-    double Sxx, Sxy = (double)(P.xy[base + count] - P.xy[base]);
+    double Sx = (double)P.dX(base, count), Sy = (double)P.dY(base, count);
+    double Sxx, Sxy = (double)P.dXY(base, count);
     if (invert) {
         const double t = Sx;
         Sx = Sy;
         Sy = t;
-        Sxx = (double)(P.yy[base + count] - P.yy[base]);
+        Sxx = (double)P.dYY(base, count);
     } else {
-        Sxx = (double)(P.xx[base + count] - P.xx[base]);
+        Sxx = (double)P.dXX(base, count);
     }
     const double D = S * Sxx - Sx * Sx;
     *a = (Sxx * Sy - Sx * Sxy) / D;
@@ -416,14 +445,15 @@ __device__ void sl_fit_known(const StagPrefix &P, int base, int count, int inver
 }
 
 // LineFit with orientation choice and fitting error (LineSegment.cpp:628-697) over pixels [base, base + count)
-__device__ void sl_fit_first(const StagPrefix &P, const int2 *px, int base, int count, double *a, double *b, double *e, int *invert)
+template <class Src>
+__device__ void sl_fit_first(const Src &P, int base, int count, double *a, double *b, double *e, int *invert)
 {
     if (count < 2) return;
-    const double Sx0 = (double)(P.x[base + count] - P.x[base]), Sy0 = (double)(P.y[base + count] - P.y[base]);
+    const double Sx0 = (double)P.dX(base, count), Sy0 = (double)P.dY(base, count);
     const double mx = Sx0 / count, my = Sy0 / count;
     double dx = 0.0, dy = 0.0;
     for (int i = 0; i < count; i++) {
-        const double xi = px[base + i].y, yi = px[base + i].x;
+        const double xi = P.X(base + i), yi = P.Y(base + i);
         dx += (xi - mx) * (xi - mx);
         dy += (yi - my) * (yi - my);
     }
@@ -433,13 +463,13 @@ __device__ void sl_fit_first(const StagPrefix &P, const int2 *px, int base, int 
     double error = 0.0;
     if (*b == 0.0) {
         for (int i = 0; i < count; i++) {
-            const double yi = inv ? px[base + i].y : px[base + i].x;
+            const double yi = inv ? P.X(base + i) : P.Y(base + i);
             error += fabs((*a) - yi);
         }
         *e = error / count;
     } else {
         for (int i = 0; i < count; i++) {
-            const double xi = inv ? px[base + i].x : px[base + i].y, yi = inv ? px[base + i].y : px[base + i].x;
+            const double xi = inv ? P.Y(base + i) : P.X(base + i), yi = inv ? P.X(base + i) : P.Y(base + i);
             const double d = -1.0 / (*b);
             const double c = yi - d * xi;
             const double x2 = ((*a) - c) / (d - (*b));
@@ -547,41 +577,11 @@ __device__ __forceinline__ long long wave_iscan_ll(long long v, int lane)
 // (64 window positions at a time, each lane its own 9-pixel fit), and the point-to-line distances of the next 64 pixels under
 // the CURRENT line -- the sequential good / bad bookkeeping then runs over the ballot until a refit really changes the line
 // (every tenth good pixel), at which point the rest of the batch is thrown away and recomputed.
-__device__ __forceinline__ void k_stag_split_lines_impl(const int2 *__restrict__ segs, const int *__restrict__ nsegs, const int2 *__restrict__ pix,
-                                                          StagPrefix PF, int min_line_len, double line_error, fid_stag_line *__restrict__ slots,
-                                                          int *__restrict__ counts)
+// SplitSegment2Lines + JoinCollinearLines of one segment by one wave, on either source
+template <class Src>
+__device__ __forceinline__ void sl_split_body(const Src &P, int n, int seg, int first, int lane, int min_line_len, double line_error,
+                                              fid_stag_line *__restrict__ slots, int *__restrict__ counts)
 {
-    const int seg = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (seg >= *nsegs) return;
-    const int first = segs[seg].x, n = segs[seg].y;
-    const int2 *px = pix + first;
-    // the prefix arrays of this segment live at [first + seg, first + seg + n]: one extra slot per segment
-    StagPrefix P;
-    const int pb = first + seg;
-    P.x = PF.x + pb; P.y = PF.y + pb; P.xx = PF.xx + pb; P.yy = PF.yy + pb; P.xy = PF.xy + pb;
-    {
-        long long cx = 0, cy = 0, cxx = 0, cyy = 0, cxy = 0;
-        for (int k0 = 0; k0 < n; k0 += 64) {
-            const int k = k0 + lane;
-            long long x = 0, y = 0;
-            if (k < n) {
-                x = px[k].y;
-                y = px[k].x;
-            }
-            const long long ix = wave_iscan_ll(x, lane), iy = wave_iscan_ll(y, lane), ixx = wave_iscan_ll(x * x, lane),
-                            iyy = wave_iscan_ll(y * y, lane), ixy = wave_iscan_ll(x * y, lane);
-            if (k < n) {  // exclusive value at k
-                P.x[k] = cx + ix - x; P.y[k] = cy + iy - y; P.xx[k] = cxx + ixx - x * x; P.yy[k] = cyy + iyy - y * y; P.xy[k] = cxy + ixy - x * y;
-            }
-            cx += __shfl(ix, 63, 64); cy += __shfl(iy, 63, 64); cxx += __shfl(ixx, 63, 64); cyy += __shfl(iyy, 63, 64); cxy += __shfl(ixy, 63, 64);
-        }
-        if (lane == 0) {
-            P.x[n] = cx; P.y[n] = cy; P.xx[n] = cxx; P.yy[n] = cyy; P.xy[n] = cxy;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    }
     fid_stag_line *L = slots + first / 9;
     int nl = 0;
     const int MLL = min_line_len;
@@ -595,7 +595,7 @@ __device__ __forceinline__ void k_stag_split_lines_impl(const int2 *__restrict__
             const int avail = noPixels - MLL + 1;  // window starts base .. base + avail - 1
             double a = 0, bq = 0, e = 1e300;
             int inv = 0;
-            if (lane < avail) sl_fit_first(P, px, base + lane, MLL, &a, &bq, &e, &inv);
+            if (lane < avail) sl_fit_first(P, base + lane, MLL, &a, &bq, &e, &inv);
             const unsigned long long okm = __ballot(lane < avail && e <= 0.5);
             if (okm) {
                 const int j = __builtin_ctzll(okm);
@@ -618,7 +618,7 @@ __device__ __forceinline__ void k_stag_split_lines_impl(const int2 *__restrict__
                 // distances of the next pixels under the current line
                 const int k = index + lane;
                 bool ok = false;
-                if (k < noPixels) ok = sl_min_dist((double)px[base + k].y, (double)px[base + k].x, lastA, lastB, lastInvert) <= line_error;
+                if (k < noPixels) ok = sl_min_dist(P.X(base + k), P.Y(base + k), lastA, lastB, lastInvert) <= line_error;
                 const unsigned long long gm = __ballot(ok);
                 const int lim = noPixels - index < 64 ? noPixels - index : 64;
                 int t = 0;
@@ -655,12 +655,12 @@ __device__ __forceinline__ void k_stag_split_lines_impl(const int2 *__restrict__
             if (good < 2 || index >= noPixels) {
                 double sx, sy, ex, ey;
                 int idx = 0;
-                while (idx < noPixels - 1 && sl_min_dist((double)px[base + idx].y, (double)px[base + idx].x, lastA, lastB, lastInvert) > line_error) idx++;
-                sl_min_dist((double)px[base + idx].y, (double)px[base + idx].x, lastA, lastB, lastInvert, &sx, &sy);
+                while (idx < noPixels - 1 && sl_min_dist(P.X(base + idx), P.Y(base + idx), lastA, lastB, lastInvert) > line_error) idx++;
+                sl_min_dist(P.X(base + idx), P.Y(base + idx), lastA, lastB, lastInvert, &sx, &sy);
                 const int skipped = idx;
                 idx = lastGoodIndex;
-                while (idx > 0 && sl_min_dist((double)px[base + idx].y, (double)px[base + idx].x, lastA, lastB, lastInvert) > line_error) idx--;
-                sl_min_dist((double)px[base + idx].y, (double)px[base + idx].x, lastA, lastB, lastInvert, &ex, &ey);
+                while (idx > 0 && sl_min_dist(P.X(base + idx), P.Y(base + idx), lastA, lastB, lastInvert) > line_error) idx--;
+                sl_min_dist(P.X(base + idx), P.Y(base + idx), lastA, lastB, lastInvert, &ex, &ey);
                 if (lane == 0) {
                     fid_stag_line &o = L[nl];
                     o.a = lastA; o.b = lastB; o.invert = lastInvert; o.sx = sx; o.sy = sy; o.ex = ex; o.ey = ey;
@@ -693,13 +693,92 @@ __device__ __forceinline__ void k_stag_split_lines_impl(const int2 *__restrict__
     }
     counts[seg] = nl;
 }
-__global__ __launch_bounds__(256) void k_stag_split_lines(const int2 *__restrict__ segs, const int *__restrict__ nsegs, const int2 *__restrict__ pix, StagPrefix PF, int min_line_len, double line_error, fid_stag_line *__restrict__ slots, int *__restrict__ counts)
+
+// LDS of k_stag_split_lines: four waves, each `lds_pix` pixels + the prefix sums over them (36 bytes a pixel); the launch passes
+// lds_pix and asks for SL_LDS_BYTES(lds_pix) -- 1 024 pixels for a frame on its own (148 KB, one workgroup per CU: 200 of them),
+// 256 for a group of frames (37 KB: four workgroups per CU stay resident), 0: every segment on the global road
+__host__ __device__ constexpr int sl_lds_wave_bytes(int lds_pix) { return ((lds_pix + 1) * (3 * 4 + 3 * 8) + 63) & ~63; }
+#define SL_LDS_BYTES(lds_pix) ((lds_pix) > 0 ? 4 * sl_lds_wave_bytes(lds_pix) : 0)
+__device__ __forceinline__ void k_stag_split_lines_impl(const int2 *__restrict__ segs, const int *__restrict__ nsegs, const int2 *__restrict__ pix,
+                                                          StagPrefix PF, int min_line_len, double line_error, fid_stag_line *__restrict__ slots,
+                                                          int *__restrict__ counts, int lds_pix)
 {
-    k_stag_split_lines_impl(segs, nsegs, pix, PF, min_line_len, line_error, slots, counts);
+    extern __shared__ long long s_sl[];
+    const int wv = threadIdx.x >> 6;
+    const int seg = blockIdx.x * 4 + wv, lane = threadIdx.x & 63;
+    if (seg >= *nsegs) return;
+    const int first = segs[seg].x, n = segs[seg].y;
+    const int2 *px = pix + first;
+    if (n <= lds_pix) {
+        // the wave's share: three 64-bit arrays, then three 32-bit ones
+        long long *sxx = s_sl + (size_t)wv * (sl_lds_wave_bytes(lds_pix) / 8), *syy = sxx + (lds_pix + 1), *sxy = syy + (lds_pix + 1);
+        int *sx = (int *)(sxy + (lds_pix + 1)), *sy = sx + (lds_pix + 1), *spx = sy + (lds_pix + 1);
+        long long cxx = 0, cyy = 0, cxy = 0;
+        int cx = 0, cy = 0;
+        for (int k0 = 0; k0 < n; k0 += 64) {
+            const int k = k0 + lane;
+            long long x = 0, y = 0;
+            if (k < n) {
+                x = px[k].y;
+                y = px[k].x;
+                spx[k] = (int)x | ((int)y << 16);
+            }
+            const long long ix = wave_iscan_ll(x, lane), iy = wave_iscan_ll(y, lane), ixx = wave_iscan_ll(x * x, lane),
+                            iyy = wave_iscan_ll(y * y, lane), ixy = wave_iscan_ll(x * y, lane);
+            if (k < n) {  // exclusive value at k
+                sx[k] = cx + (int)(ix - x); sy[k] = cy + (int)(iy - y); sxx[k] = cxx + ixx - x * x; syy[k] = cyy + iyy - y * y; sxy[k] = cxy + ixy - x * y;
+            }
+            cx += (int)__shfl(ix, 63, 64); cy += (int)__shfl(iy, 63, 64); cxx += __shfl(ixx, 63, 64); cyy += __shfl(iyy, 63, 64); cxy += __shfl(ixy, 63, 64);
+        }
+        if (lane == 0) {
+            sx[n] = cx; sy[n] = cy; sxx[n] = cxx; syy[n] = cyy; sxy[n] = cxy;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        SlLds P;
+        P.px = spx; P.sx = sx; P.sy = sy; P.sxx = sxx; P.syy = syy; P.sxy = sxy;
+        sl_split_body(P, n, seg, first, lane, min_line_len, line_error, slots, counts);
+        return;
+    }
+    // the prefix arrays of this segment live at [first + seg, first + seg + n]: one extra slot per segment
+    SlGlobal G;
+    G.px = px;
+    const int pb = first + seg;
+    long long *gx = PF.x + pb, *gy = PF.y + pb, *gxx = PF.xx + pb, *gyy = PF.yy + pb, *gxy = PF.xy + pb;
+    G.P.x = gx; G.P.y = gy; G.P.xx = gxx; G.P.yy = gyy; G.P.xy = gxy;
+    {
+        long long cx = 0, cy = 0, cxx = 0, cyy = 0, cxy = 0;
+        for (int k0 = 0; k0 < n; k0 += 64) {
+            const int k = k0 + lane;
+            long long x = 0, y = 0;
+            if (k < n) {
+                x = px[k].y;
+                y = px[k].x;
+            }
+            const long long ix = wave_iscan_ll(x, lane), iy = wave_iscan_ll(y, lane), ixx = wave_iscan_ll(x * x, lane),
+                            iyy = wave_iscan_ll(y * y, lane), ixy = wave_iscan_ll(x * y, lane);
+            if (k < n) {  // exclusive value at k
+                gx[k] = cx + ix - x; gy[k] = cy + iy - y; gxx[k] = cxx + ixx - x * x; gyy[k] = cyy + iyy - y * y; gxy[k] = cxy + ixy - x * y;
+            }
+            cx += __shfl(ix, 63, 64); cy += __shfl(iy, 63, 64); cxx += __shfl(ixx, 63, 64); cyy += __shfl(iyy, 63, 64); cxy += __shfl(ixy, 63, 64);
+        }
+        if (lane == 0) {
+            gx[n] = cx; gy[n] = cy; gxx[n] = cxx; gyy[n] = cyy; gxy[n] = cxy;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    sl_split_body(G, n, seg, first, lane, min_line_len, line_error, slots, counts);
+}
+__global__ __launch_bounds__(256) void k_stag_split_lines(const int2 *__restrict__ segs, const int *__restrict__ nsegs, const int2 *__restrict__ pix, StagPrefix PF, int min_line_len, double line_error, fid_stag_line *__restrict__ slots, int *__restrict__ counts, int lds_pix)
+{
+    k_stag_split_lines_impl(segs, nsegs, pix, PF, min_line_len, line_error, slots, counts, lds_pix);
 }
 struct k_stag_split_lines_fn {
     static constexpr int kBounds = 256;
-    __device__ __forceinline__ void operator()(const int2 *__restrict__ segs, const int *__restrict__ nsegs, const int2 *__restrict__ pix, StagPrefix PF, int min_line_len, double line_error, fid_stag_line *__restrict__ slots, int *__restrict__ counts) const { k_stag_split_lines_impl(segs, nsegs, pix, PF, min_line_len, line_error, slots, counts); }
+    __device__ __forceinline__ void operator()(const int2 *__restrict__ segs, const int *__restrict__ nsegs, const int2 *__restrict__ pix, StagPrefix PF, int min_line_len, double line_error, fid_stag_line *__restrict__ slots, int *__restrict__ counts, int lds_pix) const { k_stag_split_lines_impl(segs, nsegs, pix, PF, min_line_len, line_error, slots, counts, lds_pix); }
 };
 
 // the lines of every segment, one after the other in segment order (counts hold exclusive prefix sums by now)

@@ -947,7 +947,7 @@ static fid_status stag_advance_impl(fid_stag_ctx *c, StagJob &j)
         // workgroup, and with ~80 KB marker tiles a CU held one workgroup (3.0 k frames/s; 64 KB: 3.3 k, 40 KB: 3.5 k, 24 KB: 3.3 k);
         // the components above the cap take the global-memory walk, same result.  FID_STAG_TILE_KB overrides.
         static const int tile_kb_env = [] { const char *e = getenv("FID_STAG_TILE_KB"); return e ? atoi(e) : 0; }();
-        const int tile_kb = tile_kb_env > 0 ? tile_kb_env : (grouped ? 40 : 150);
+        const int tile_kb = tile_kb_env > 0 ? tile_kb_env : (grouped ? 37 : 150);  // (37 KB + the walk's 2 KB of stack: four workgroups per CU)
         const int LDS_CAP = (tile_kb < 8 ? 8 : (tile_kb > 150 ? 150 : tile_kb)) * 1024;
         j.lds_cap = LDS_CAP;
         STAG_LAUNCH(k_stag_comp_tilemax, dim3((c->max_comps + 255) / 256), dim3(256), 0, st, c->d_comps, c->d_cursors, LDS_CAP);
@@ -996,9 +996,10 @@ static fid_status stag_advance_impl(fid_stag_ctx *c, StagJob &j)
                     STAG_LAUNCH(k_stag_comp_sort_big, dim3(nc), dim3(1024), (size_t)STAG_SORT_BIG * 4, st, c->d_comps, c->d_cursors, c->d_aslots);
                 // LDS per workgroup = the largest tile a component of this frame asks for (components whose box does not fit 150 KB
                 // walk in global memory): frames of small components keep many workgroups per CU
+                static const int no_sparse = [] { const char *e = getenv("FID_STAG_SPARSE"); return e && atoi(e) == 0 ? 1 : 0; }();  // (0: no blocks, the walk in global memory)
                 const int lds = c->route_tile ? ((cur[10] + 1023) / 1024) * 1024 : 0;
                 STAG_LAUNCH(k_stag_route_walk, dim3(nc), dim3(256), (size_t)lds, st, j.R, A, c->d_comps, c->d_cursors, c->d_sorted, c->d_aslots,
-                                   c->d_label, 16, lds, c->d_prodflag, ovf);
+                                   c->d_label, 16, lds | no_sparse, c->d_prodflag, ovf);
             }
             STAG_LAUNCH(k_stag_next_above, dim3(1), dim3(1024), 0, st, c->d_prodflag, c->d_n, c->d_next);
             if (nc > 0)

@@ -275,9 +275,9 @@ struct StagRouter {
             if (i < lcap) lstk.put(i, v);
             else gstk[i] = v;
         }
-        __device__ int4 stk_get(int i) const { return sr_uni_struct(i < lcap ? lstk.get(i) : gstk[i]); }
-        __device__ int edge_at(int r, int c) const { return sr_uni(edge[r * W + c]); }
-        __device__ int dir_at(int r, int c) const { return sr_uni(dir[r * W + c]); }
+        // (plain vector values on this road: with its one memory round trip per step the scalar form's extra taken branches cost
+        //  more than its cheaper arithmetic saves -- measured, round 5)
+        __device__ int4 stk_get(int i) const { return i < lcap ? lstk.get(i) : gstk[i]; }
         __device__ void fetch(int r, int c, int ar, int ac, int pr, int pc, int lane, Ahead &n) const
         {
             // lane -> (array, pixel): 0-2 edge, 3-5 grad, 6-8 dir of A, B, C; 9, 10 edge beside
@@ -344,7 +344,7 @@ struct StagRouter {
     };
 
     // A component whose bounding box does not fit the LDS as a dense tile -- the ring around a marker seen from close: 289 x 288
-    // pixels of box for 813 pixels of edge -- as 8 x 8 BLOCKS: a table over the box (one 16-bit slot number per block, 0 = the
+    // pixels of box for 813 pixels of edge -- as 4 x 4 BLOCKS: a table over the box (one 16-bit slot number per block, 0 = the
     // all-empty block) and the blocks that hold a pixel of the component or a neighbour of one.  Two dependent LDS reads per
     // access instead of one; the walk through global memory it replaces cost a store, a wait and a load per step (2 200 cycles
     // a pixel, and that one workgroup was the whole kernel's duration: round 5).
@@ -362,10 +362,11 @@ struct StagRouter {
         }
         __device__ int4 stk_get(int i) const { return sr_uni_struct(i < lcap ? lstk.get(i) : gstk[i]); }
         // word offset in blk of the pixel (rr, cc) of the box
+        static constexpr int SH = 2, BM = (1 << SH) - 1;  // blocks of 4 x 4 pixels: a one-pixel-wide outline fills a quarter of each
         __device__ int off(int rr, int cc) const
         {
-            const int slot = tab[(rr >> 3) * bw + (cc >> 3)];
-            return (slot << 6) | ((rr & 7) << 3) | (cc & 7);
+            const int slot = tab[(rr >> SH) * bw + (cc >> SH)];
+            return (slot << (2 * SH)) | ((rr & BM) << SH) | (cc & BM);
         }
         __device__ int word_at(int r, int c) const { return sr_uni(blk[off(r - r0, c - c0)]); }
         __device__ int dir_at(int r, int c) const { return Tile::dir_of((uint16_t)word_at(r, c)); }
@@ -381,10 +382,8 @@ struct StagRouter {
     __device__ bool walk_anchor_t(int r0, int c0, int grad_thresh, const Mem &M, int lane)
     {
         const bool L0 = lane == 0;
-        constexpr bool WV = Mem::STRIDE == 64;  // the wave-wide forms: every lane holds the same values
         StagChain *ch = R.chains;
-        const int capChains = WV ? sr_uni(R.capChains) : R.capChains, capPix = WV ? sr_uni(R.capPix) : R.capPix,
-                  capStack = WV ? sr_uni(R.capStack) : R.capStack;
+        const int capChains = R.capChains, capPix = R.capPix, capStack = R.capStack;
         if (L0) {
             ch[0].dir = 0; ch[0].len = 0; ch[0].parent = -1; ch[0].child[0] = ch[0].child[1] = -1; ch[0].pix = -1;
         }
@@ -1088,7 +1087,7 @@ __device__ __forceinline__ void k_stag_comp_tilemax_impl(const StagComp *__restr
     const StagComp C = comps[cid];
     if (C.nanch == 0) return;
     const int bytes = (C.maxr - C.minr + 3) * (C.maxc - C.minc + 3) * 2;
-    atomicMax(&cursors[10], bytes <= lds_cap ? bytes : lds_cap);  // (beyond the cap: the whole of it, for the component's 8 x 8 blocks)
+    atomicMax(&cursors[10], bytes <= lds_cap ? bytes : lds_cap);  // (beyond the cap: the whole of it, for the component's blocks)
 }
 __global__ __launch_bounds__(256) void k_stag_comp_tilemax(const StagComp *__restrict__ comps, int *cursors, int lds_cap)
 {
@@ -1228,7 +1227,7 @@ __device__ __forceinline__ void k_stag_route_walk_impl(StagRoute G, StagArenas A
                                                         int grad_thresh, int lds_bytes, int *__restrict__ prodflag, int *__restrict__ ovf)
 {
     extern __shared__ uint16_t s_tile[];
-    constexpr int WSTACK = 512;
+    constexpr int WSTACK = 128;  // (deeper than that: the arena in global memory)
     __shared__ int4 s_wstack[WSTACK];  // the first entries of the walk's stack (StagRouter::MemWave)
     // one workgroup per component: four waves move the tile in and out, wave 0 walks
     const int cid = blockIdx.x, lane = threadIdx.x & 63, tid = threadIdx.x;
@@ -1253,37 +1252,39 @@ __device__ __forceinline__ void k_stag_route_walk_impl(StagRoute G, StagArenas A
     T.tw = C.maxc - C.minc + 3;
     T.gstk = S.R.stack; T.lstk.p = (SrLdsInt)(int *)s_wstack; T.lcap = WSTACK;
     const int th = C.maxr - C.minr + 3;
-    const bool tiled = T.tw * th * 2 <= lds_bytes;
+    const int lds_real = lds_bytes & ~3;  // (bit 0: an experiment switch)
+    const bool tiled = T.tw * th * 2 <= lds_real;
 #ifdef RW_TIMING
     const unsigned long long rw_tl = __builtin_readcyclecounter();
 #endif
-    // ... or as 8 x 8 blocks (StagRouter::SparseTile), if those fit
+    // ... or as 4 x 4 blocks (StagRouter::SparseTile), if those fit
     __shared__ int s_nblk;
     StagRouter::SparseTile P;
     bool sparse = false;
-    if (!tiled) {
-        const int bw = (T.tw + 7) >> 3, bh = (th + 7) >> 3, ntab = (bw * bh + 63) & ~63;
-        const int maxblk = (lds_bytes / 2 - ntab) / 64 - 1;  // (block 0 is the empty one)
+    if (!tiled && !(lds_bytes & 1)) {  // (bit 0 of lds_bytes: no blocks -- FID_STAG_SPARSE=0, an experiment switch)
+        constexpr int SH = StagRouter::SparseTile::SH, BM = StagRouter::SparseTile::BM, BW = 1 << (2 * SH);  // (words per block)
+        const int bw = (T.tw + BM) >> SH, bh = (th + BM) >> SH, ntab = (bw * bh + 63) & ~63;
+        const int maxblk = (lds_real / 2 - ntab) / BW - 1;  // (block 0 is the empty one)
         P.tab = s_tile; P.blk = s_tile + ntab; P.r0 = T.r0; P.c0 = T.c0; P.bw = bw;
         P.gstk = S.R.stack; P.lstk.p = (SrLdsInt)(int *)s_wstack; P.lcap = WSTACK;
         if (maxblk >= 16 && maxblk < 65535) {  // (uniform over the workgroup: the barriers below are safe)
             for (int i = tid; i < ntab; i += 256) s_tile[i] = 0;
-            if (tid < 64) P.blk[tid] = 0;
+            if (tid < BW) P.blk[tid] = 0;
             if (tid == 0) s_nblk = 0;
             __syncthreads();
             // the blocks within one pixel of a pixel of the component (a wave per row, its lanes along the row; the box's own
             // border ring holds no pixel of the component)
-            for (int r4 = 1 + (tid >> 6) * 4; r4 < th - 1; r4 += 16)
+            for (int r4 = 1 + (tid >> 6) * 16; r4 < th - 1; r4 += 64)
                 for (int cc = 1 + lane; cc < T.tw - 1; cc += 64) {
-                    int lb[4];
+                    int lb[16];
 #pragma unroll
-                    for (int u = 0; u < 4; u++)  // (four rows in flight per thread)
+                    for (int u = 0; u < 16; u++)  // (sixteen rows in flight per thread: the pass is a chain of memory round trips)
                         if (r4 + u < th - 1) lb[u] = label[(T.r0 + r4 + u) * W + T.c0 + cc];
 #pragma unroll
-                    for (int u = 0; u < 4; u++)
+                    for (int u = 0; u < 16; u++)
                         if (r4 + u < th - 1 && lb[u] == C.root) {
                             const int rr = r4 + u;
-                            const int b0 = ((rr - 1) >> 3) * bw, b1 = ((rr + 1) >> 3) * bw, q0 = (cc - 1) >> 3, q1 = (cc + 1) >> 3;
+                            const int b0 = ((rr - 1) >> SH) * bw, b1 = ((rr + 1) >> SH) * bw, q0 = (cc - 1) >> SH, q1 = (cc + 1) >> SH;
                             s_tile[b0 + q0] = 0xffff; s_tile[b0 + q1] = 0xffff; s_tile[b1 + q0] = 0xffff; s_tile[b1 + q1] = 0xffff;
                         }
                 }
@@ -1296,22 +1297,22 @@ __device__ __forceinline__ void k_stag_route_walk_impl(StagRoute G, StagArenas A
             __syncthreads();
             sparse = s_nblk <= maxblk;
             if (sparse) {
-                for (int r4 = (tid >> 6) * 4; r4 < th; r4 += 16)
+                for (int r4 = (tid >> 6) * 8; r4 < th; r4 += 32)
                     for (int cc = lane; cc < T.tw; cc += 64) {
-                        int slot[4], e[4], gr[4], dr[4];
+                        int slot[8], e[8], gr[8], dr[8];
 #pragma unroll
-                        for (int u = 0; u < 4; u++) {
-                            slot[u] = r4 + u < th ? s_tile[((r4 + u) >> 3) * bw + (cc >> 3)] : 0;
+                        for (int u = 0; u < 8; u++) {
+                            slot[u] = r4 + u < th ? s_tile[((r4 + u) >> SH) * bw + (cc >> SH)] : 0;
                             if (slot[u]) {
                                 const int g = (T.r0 + r4 + u) * W + T.c0 + cc;
                                 e[u] = G.edge[g]; gr[u] = G.grad[g]; dr[u] = G.dir[g];
                             }
                         }
 #pragma unroll
-                        for (int u = 0; u < 4; u++)
+                        for (int u = 0; u < 8; u++)
                             if (slot[u]) {
                                 const int st = e[u] == STAG_EDGE_PIXEL ? 2 : e[u] == STAG_ANCHOR_PIXEL ? 1 : 0;
-                                P.blk[(slot[u] << 6) | (((r4 + u) & 7) << 3) | (cc & 7)] =
+                                P.blk[(slot[u] << (2 * SH)) | (((r4 + u) & BM) << SH) | (cc & BM)] =
                                     (uint16_t)((gr[u] & 0x7ff) | (dr[u] == STAG_EDGE_VERTICAL ? 0x800 : 0) | (st << 12));
                             }
                     }
@@ -1345,6 +1346,8 @@ __device__ __forceinline__ void k_stag_route_walk_impl(StagRoute G, StagArenas A
     unsigned long long rw_walk = 0;
     int rw_walks = 0, rw_live = 0, rw_pix = 0, rw_chains = 0;
 #endif
+    // (which wave of the workgroup walks makes no difference: rotating it over the four, so that the walkers of the workgroups that
+    //  share a CU in a group of frames sit on different SIMDs, left the group's kernel where it was -- measured, round 5)
     if (tid < 64) {
     for (int k0 = 0; k0 < C.nanch; k0 += 64) {
         // which of the next 64 anchors are still anchors?  (a walk can only turn anchors OFF, so a stale "on" is re-checked)
@@ -1436,14 +1439,14 @@ __device__ __forceinline__ void k_stag_route_walk_impl(StagRoute G, StagArenas A
             }
     } else if (sparse) {
         __syncthreads();
-        for (int r4 = 1 + (tid >> 6) * 4; r4 < th - 1; r4 += 16)
+        for (int r4 = 1 + (tid >> 6) * 16; r4 < th - 1; r4 += 64)
             for (int cc = 1 + lane; cc < T.tw - 1; cc += 64) {
-                int lb[4];
+                int lb[16];
 #pragma unroll
-                for (int u = 0; u < 4; u++)
+                for (int u = 0; u < 16; u++)
                     if (r4 + u < th - 1) lb[u] = label[(T.r0 + r4 + u) * W + T.c0 + cc];
 #pragma unroll
-                for (int u = 0; u < 4; u++)
+                for (int u = 0; u < 16; u++)
                     if (r4 + u < th - 1 && lb[u] == C.root)
                         G.edge[(T.r0 + r4 + u) * W + T.c0 + cc] = (uint8_t)StagRouter::Tile::edge_of(P.blk[P.off(r4 + u, cc)]);
             }

@@ -517,6 +517,7 @@ struct fid_stag_ctx {
     StagPred pred;
     int *d_specbad = nullptr;
     int spec_frames = 0, spec_misses = 0;
+    int tile_kb_env = 0, no_sparse = 0;  // FID_STAG_TILE_KB (LDS a component's walk may ask for), FID_STAG_SPARSE=0
 };
 
 extern "C" {
@@ -575,6 +576,10 @@ fid_status fid_stag_create(int libraryHD, int errorCorrection, int max_width, in
         const char *e = getenv("FID_STAG_ROUTE");
         c->route_mode = (e && !strcmp(e, "seq")) ? 0 : 1;
         c->route_tile = (e && !strcmp(e, "notile")) ? 0 : 1;  // "notile": component-parallel, walks in global memory
+        // (read per context: the tests run the roads side by side in one process)
+        const char *tk = getenv("FID_STAG_TILE_KB"), *sp = getenv("FID_STAG_SPARSE");
+        c->tile_kb_env = tk ? atoi(tk) : 0;
+        c->no_sparse = sp && atoi(sp) == 0 ? 1 : 0;
         ok = hipFuncSetAttribute((const void *)k_stag_route_walk, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) == hipSuccess &&
              hipFuncSetAttribute((const void *)k_stag_comp_sort_big, hipFuncAttributeMaxDynamicSharedMemorySize, STAG_SORT_BIG * 4) == hipSuccess &&
              // (and their group-mode trampolines, fid_stag_batch.h)
@@ -946,8 +951,7 @@ static fid_status stag_advance_impl(fid_stag_ctx *c, StagJob &j)
         // marker frame walks in LDS).  A group of frames: 40 KB -- the walk kernel allocates the group's largest tile for every
         // workgroup, and with ~80 KB marker tiles a CU held one workgroup (3.0 k frames/s; 64 KB: 3.3 k, 40 KB: 3.5 k, 24 KB: 3.3 k);
         // the components above the cap take the global-memory walk, same result.  FID_STAG_TILE_KB overrides.
-        static const int tile_kb_env = [] { const char *e = getenv("FID_STAG_TILE_KB"); return e ? atoi(e) : 0; }();
-        const int tile_kb = tile_kb_env > 0 ? tile_kb_env : (grouped ? 37 : 150);  // (37 KB + the walk's 2 KB of stack: four workgroups per CU)
+        const int tile_kb = c->tile_kb_env > 0 ? c->tile_kb_env : (grouped ? 37 : 150);  // (37 KB + the walk's 2 KB of stack: four workgroups per CU)
         const int LDS_CAP = (tile_kb < 8 ? 8 : (tile_kb > 150 ? 150 : tile_kb)) * 1024;
         j.lds_cap = LDS_CAP;
         STAG_LAUNCH(k_stag_comp_tilemax, dim3((c->max_comps + 255) / 256), dim3(256), 0, st, c->d_comps, c->d_cursors, LDS_CAP);
@@ -996,7 +1000,7 @@ static fid_status stag_advance_impl(fid_stag_ctx *c, StagJob &j)
                     STAG_LAUNCH(k_stag_comp_sort_big, dim3(nc), dim3(1024), (size_t)STAG_SORT_BIG * 4, st, c->d_comps, c->d_cursors, c->d_aslots);
                 // LDS per workgroup = the largest tile a component of this frame asks for (components whose box does not fit 150 KB
                 // walk in global memory): frames of small components keep many workgroups per CU
-                static const int no_sparse = [] { const char *e = getenv("FID_STAG_SPARSE"); return e && atoi(e) == 0 ? 1 : 0; }();  // (0: no blocks, the walk in global memory)
+                const int no_sparse = c->no_sparse;  // (FID_STAG_SPARSE=0: no blocks, the walk in global memory)
                 const int lds = c->route_tile ? ((cur[10] + 1023) / 1024) * 1024 : 0;
                 STAG_LAUNCH(k_stag_route_walk, dim3(nc), dim3(256), (size_t)lds, st, j.R, A, c->d_comps, c->d_cursors, c->d_sorted, c->d_aslots,
                                    c->d_label, 16, lds | no_sparse, c->d_prodflag, ovf);

@@ -125,15 +125,21 @@ ROUTE_CASES["stag_1080p"] = lambda: __import__("fiducials_amd.synth", fromlist=[
 ROUTE_CASES["faint"] = lambda: _faint(480, 360, 21)
 
 
-@pytest.mark.parametrize("mode", ["par", "notile", "seq"])
+@pytest.mark.parametrize("mode", ["par", "blocks", "blocks_off", "notile", "seq"])
 @pytest.mark.parametrize("case", sorted(ROUTE_CASES))
 def test_edge_routing_matches_reference_code(case, mode, monkeypatch):
     """Row s4: JoinAnchorPointsUsingSortedAnchors.  Edge image and every segment (pixel by pixel, in order) against the
     reference's own routine fed with the same gradient / direction / anchor maps; the roads of the device code: one wave per
-    connected component of the gradient map (default) and one lane per frame."""
+    connected component of the gradient map (default: on a dense LDS tile where the component's box fits, on 4 x 4 blocks in LDS
+    where it does not; "blocks": 8 KB of LDS, so that nearly every component takes the blocks or, where even those do not fit,
+    global memory; "blocks_off": the same without blocks; "notile": global memory throughout) and one lane per frame."""
     if not stag_ref.available():
         pytest.skip("oracle/_ref/libstag_ref.so not built (needs /root/reference at build time)")
-    monkeypatch.setenv("FID_STAG_ROUTE", mode)
+    monkeypatch.setenv("FID_STAG_ROUTE", "par" if mode.startswith("blocks") else mode)
+    if mode.startswith("blocks"):
+        monkeypatch.setenv("FID_STAG_TILE_KB", "8")
+        if mode == "blocks_off":
+            monkeypatch.setenv("FID_STAG_SPARSE", "0")
     img = ROUTE_CASES[case]()
     h, w = img.shape
     det = fstag.StagDetector(21, 7, max_width=1920, max_height=1080)

@@ -221,19 +221,18 @@ struct StagRouter {
         noSegments++;
     }
 
-    // ---- the walk.  One body for three kinds of memory (what a step reads and writes is the same in all of them):
+    // ---- the walk.  One body for two kinds of memory (what a step reads and writes is the same in both):
     //   MemGlobal  one lane, plain loads and stores in the image arrays (the sequential road)
     //   MemWave    a whole wave: control flow and bookkeeping wave-uniform (every lane computes them, lane 0 stores them); what
     //              a step needs -- edge / gradient / direction of the three pixels ahead, edge of the two beside -- is
     //              fetched by eleven lanes at once, one round trip per step instead of a chain of dependent loads
-    //   MemTile    a whole wave on a copy of the component's bounding box in LDS (one 16-bit word per pixel: gradient 11
-    //              bits, direction 1 bit, edge state 2 bits): every lane reads the same words (broadcast), lane 0 writes
+    //   (Tile / SparseTile: a copy of the component's bounding box in LDS, one 16-bit word per pixel -- gradient 11 bits,
+    //              direction 1 bit, edge state 2 bits -- have a walker of their own, walk_anchor_tile6 below)
     // None of the five pixels a step reads is written in the same step (the current pixel and the two beside it are not among
     // the three ahead), so fetching them together sees exactly what the reference's one-by-one reads see.
     struct Ahead {           // A = ahead - p, B = ahead, C = ahead + p (p = one pixel across the walking direction)
         int eA, eB, eC, gA, gB, gC, dA, dB, dC;
         int s1, s2;          // edge values of the pixels beside the current one (+p, -p)
-        int wA, wB, wC, w1, w2;  // MemTile: the five tile words as read (mark() writes the side words back without reading them again)
     };
     struct MemGlobal {
         const int16_t *grad; const uint8_t *dir; uint8_t *edge; int W;
@@ -243,7 +242,6 @@ struct StagRouter {
         __device__ int4 stk_get(int i) const { return gstk[i]; }
         __device__ int edge_at(int r, int c) const { return edge[r * W + c]; }
         __device__ int dir_at(int r, int c) const { return dir[r * W + c]; }
-        __device__ int word_at(int, int) const { return 0; }  // (MemTile: the pixel's tile word)
         __device__ void fetch(int r, int c, int ar, int ac, int pr, int pc, int, Ahead &n) const
         {
             const int q = (r + ar) * W + (c + ac), p = pr * W + pc;
@@ -251,9 +249,8 @@ struct StagRouter {
             n.gA = grad[q - p]; n.gB = grad[q]; n.gC = grad[q + p];
             n.dA = dir[q - p]; n.dB = dir[q]; n.dC = dir[q + p];
             n.s1 = edge[r * W + c + p]; n.s2 = edge[r * W + c - p];
-            n.wA = n.wB = n.wC = n.w1 = n.w2 = 0;
         }
-        __device__ void mark(int r, int c, int pr, int pc, const Ahead &n, int, bool writer) const
+        __device__ void mark(int r, int c, int pr, int pc, const Ahead &n, bool writer) const
         {
             if (!writer) return;
             const int i = r * W + c, p = pr * W + pc;
@@ -294,7 +291,6 @@ struct StagRouter {
             n.gA = __builtin_amdgcn_readlane(v, 3); n.gB = __builtin_amdgcn_readlane(v, 4); n.gC = __builtin_amdgcn_readlane(v, 5);
             n.dA = __builtin_amdgcn_readlane(v, 6); n.dB = __builtin_amdgcn_readlane(v, 7); n.dC = __builtin_amdgcn_readlane(v, 8);
             n.s1 = __builtin_amdgcn_readlane(v, 9); n.s2 = __builtin_amdgcn_readlane(v, 10);
-            n.wA = n.wB = n.wC = n.w1 = n.w2 = 0;
         }
     };
     struct Tile {
@@ -318,28 +314,7 @@ struct StagRouter {
         __device__ int word_at(int r, int c) const { return sr_uni(t[idx(r, c)]); }
         __device__ int edge_at(int r, int c) const { return edge_of((uint16_t)word_at(r, c)); }
         __device__ int dir_at(int r, int c) const { return dir_of((uint16_t)word_at(r, c)); }
-        __device__ void fetch(int r, int c, int ar, int ac, int pr, int pc, int, Ahead &n) const
-        {
-            const int i = idx(r, c), q = i + ar * tw + ac, p = pr * tw + pc;
-            const int rA = t[q - p], rB = t[q], rC = t[q + p], r1 = t[i + p], r2 = t[i - p];  // five loads in flight, then the values
-            n.wA = sr_uni(rA); n.wB = sr_uni(rB); n.wC = sr_uni(rC); n.w1 = sr_uni(r1); n.w2 = sr_uni(r2);
-            const uint16_t wA = (uint16_t)n.wA, wB = (uint16_t)n.wB, wC = (uint16_t)n.wC;
-            n.eA = edge_of(wA); n.eB = edge_of(wB); n.eC = edge_of(wC);
-            n.gA = grad_of(wA); n.gB = grad_of(wB); n.gC = grad_of(wC);
-            n.dA = dir_of(wA); n.dB = dir_of(wB); n.dC = dir_of(wC);
-            n.s1 = edge_of((uint16_t)n.w1); n.s2 = edge_of((uint16_t)n.w2);
-        }
         __device__ void set_state(int i, int st) const { t[i] = (uint16_t)((t[i] & 0x0fff) | (st << 12)); }
-        // wcur: the current pixel's word as the walk last read it (nothing has written it since: a step writes the pixel it stands on
-        // and the two beside it, never one of the three ahead) -- the three words are written from what is known, not read again
-        __device__ void mark(int r, int c, int pr, int pc, const Ahead &n, int wcur, bool writer) const
-        {
-            if (!writer) return;
-            const int i = idx(r, c), p = pr * tw + pc;
-            t[i] = (uint16_t)((wcur & 0x0fff) | (2 << 12));
-            if (n.s1 == STAG_ANCHOR_PIXEL) t[i + p] = (uint16_t)(n.w1 & 0x0fff);
-            if (n.s2 == STAG_ANCHOR_PIXEL) t[i - p] = (uint16_t)(n.w2 & 0x0fff);
-        }
         __device__ void erase(int r, int c) const { set_state(idx(r, c), 0); }  // (a pixel listed twice gets the same word twice)
     };
 
@@ -401,7 +376,6 @@ struct StagRouter {
                 overflow |= 16;
                 break;
             }
-            int wcur = M.word_at(r, c);  // (MemTile only; the other forms carry 0)
             if (M.edge_at(r, c) != STAG_EDGE_PIXEL) dup++;
             const int cur = noChains;
             if (L0) {
@@ -421,7 +395,7 @@ struct StagRouter {
             while (curdir == need) {
                 Ahead n;
                 M.fetch(r, c, ar, ac, pr, pc, lane, n);
-                M.mark(r, c, pr, pc, n, wcur, L0);
+                M.mark(r, c, pr, pc, n, L0);
                 const int eF1 = fs < 0 ? n.eA : n.eC, eF2 = fs < 0 ? n.eC : n.eA;  // the diagonal looked at first / second
                 int side;
                 if (n.eB >= STAG_ANCHOR_PIXEL) side = 0;
@@ -436,7 +410,6 @@ struct StagRouter {
                 c = c + ac + side * pc;
                 const int en = side < 0 ? n.eA : side > 0 ? n.eC : n.eB, gn = side < 0 ? n.gA : side > 0 ? n.gC : n.gB;
                 curdir = side < 0 ? n.dA : side > 0 ? n.dC : n.dB;
-                wcur = side < 0 ? n.wA : side > 0 ? n.wC : n.wB;
                 if (en == STAG_EDGE_PIXEL || gn < grad_thresh) {
                     if (L0) {
                         ch[cur].len = (uint16_t)chainLen;
@@ -616,7 +589,6 @@ struct StagRouter {
         M.grad = R.grad; M.dir = R.dir; M.edge = R.edge; M.W = R.W; M.gstk = R.stack; M.lstk = lstk; M.lcap = lcap;
         return walk_anchor_t(r0, c0, grad_thresh, M, lane);
     }
-    __device__ bool walk_anchor_tile(int r0, int c0, int grad_thresh, int lane, const Tile &T) { return walk_anchor_t(r0, c0, grad_thresh, T, lane); }
 
     __device__ void route_anchor(int r0, int c0, int grad_thresh)
     {

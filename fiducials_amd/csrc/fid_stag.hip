@@ -111,7 +111,7 @@ struct k_stag_smooth_grad_fn {
 #define STAG_BAND_ROWS 8  // rows per band of k_stag_place = waves per workgroup
 
 // Anchor points: local gradient maxima across the edge normal (ANCHOR_THRESH, SCAN_INTERVAL as in the reference), counted
-// per (row, gradient value) for the counting sort (global atomics: the anchors are sparse).
+// per (row, gradient value) for the counting sort (global atomics: the anchors are sparse; 16-bit counts, two a word).
 __device__ __forceinline__ void k_stag_anchors_impl(const int16_t *__restrict__ grad, const uint8_t *__restrict__ dir, int W, int H,
                                                        int grad_thresh, int anchor_thresh, int scan_interval,
                                                        uint8_t *__restrict__ edge, unsigned *__restrict__ rowhist)
@@ -136,7 +136,8 @@ __device__ __forceinline__ void k_stag_anchors_impl(const int16_t *__restrict__ 
                 if (d1 >= anchor_thresh && d2 >= anchor_thresh) {
                     e = STAG_ANCHOR_PIXEL;
                     // SortAnchorsByGradValue only counts anchors with 1 <= i < H-1, 1 <= j < W-1: all of these qualify
-                    atomicAdd(&rowhist[(size_t)i * STAG_BINS + g], 1u);
+                    // (two 16-bit counts a word -- a row holds < 2^16 anchors: half the clearing, summing and placing traffic)
+                    atomicAdd(&rowhist[(size_t)i * (STAG_BINS / 2) + (g >> 1)], 1u << ((g & 1) * 16));
                 }
             }
         }
@@ -160,7 +161,7 @@ __device__ __forceinline__ void k_stag_bandsum_impl(const unsigned *__restrict__
 #pragma unroll
     for (int r = 0; r < STAG_BAND_ROWS; r++) {
         const int row = band * STAG_BAND_ROWS + r;
-        if (row < H) acc += rowhist[(size_t)row * STAG_BINS + g];
+        if (row < H) acc += (rowhist[(size_t)row * (STAG_BINS / 2) + (g >> 1)] >> ((g & 1) * 16)) & 0xffffu;
     }
     bandhist[(size_t)band * STAG_BINS + g] = acc;
 }
@@ -254,7 +255,7 @@ __device__ __forceinline__ void k_stag_place_impl(const int16_t *__restrict__ gr
 #pragma unroll
         for (int r = 0; r < STAG_BAND_ROWS; r++) {
             const int row = band * STAG_BAND_ROWS + r;
-            n[r] = row < H ? rowhist[(size_t)row * STAG_BINS + g] : 0u;
+            n[r] = row < H ? (rowhist[(size_t)row * (STAG_BINS / 2) + (g >> 1)] >> ((g & 1) * 16)) & 0xffffu : 0u;
         }
         unsigned acc = bstart[g] + bandstart[(size_t)band * STAG_BINS + g];
 #pragma unroll
@@ -872,7 +873,7 @@ static fid_status stag_advance_impl(fid_stag_ctx *c, StagJob &j)
         if (j.spec) stag_plan(c, j);
         for (int y = 0; y < H; y++) memcpy(c->h_src + (size_t)y * W, j.gray + (size_t)y * j.stride, (size_t)W);
         if (STAG_MEMCPY(c->d_src, c->h_src, (size_t)W * H, hipMemcpyHostToDevice, st) != hipSuccess) return stag_finish(j, FID_E_HIP);
-        if (STAG_MEMSET(c->d_rowhist, 0, (size_t)H * STAG_BINS * 4, st) != hipSuccess) return stag_finish(j, FID_E_HIP);
+        if (STAG_MEMSET(c->d_rowhist, 0, (size_t)H * STAG_BINS * 2, st) != hipSuccess) return stag_finish(j, FID_E_HIP);
         STAG_LAUNCH(k_stag_smooth_grad, dim3((W + SX - 1) / SX, (H + SY - 1) / SY), dim3(256), 0, st, c->d_src, W, W, H, GRADIENT_THRESH,
                            c->d_smooth, c->d_grad, c->d_dir);
         const int blocks = 2048, nbands = (H + STAG_BAND_ROWS - 1) / STAG_BAND_ROWS;

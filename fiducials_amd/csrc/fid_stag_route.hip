@@ -1411,17 +1411,24 @@ __device__ __forceinline__ void k_stag_route_walk_impl(StagRoute G, StagArenas A
             }
     } else if (sparse) {
         __syncthreads();
-        for (int r4 = 1 + (tid >> 6) * 16; r4 < th - 1; r4 += 64)
-            for (int cc = 1 + lane; cc < T.tw - 1; cc += 64) {
-                int lb[16];
-#pragma unroll
-                for (int u = 0; u < 16; u++)
-                    if (r4 + u < th - 1) lb[u] = label[(T.r0 + r4 + u) * W + T.c0 + cc];
-#pragma unroll
-                for (int u = 0; u < 16; u++)
-                    if (r4 + u < th - 1 && lb[u] == C.root)
-                        G.edge[(T.r0 + r4 + u) * W + T.c0 + cc] = (uint8_t)StagRouter::Tile::edge_of(P.blk[P.off(r4 + u, cc)]);
+        // block by block (not the box again: its label image is 4 bytes a pixel): a wave per block, sixteen lanes its pixels
+        constexpr int SH = StagRouter::SparseTile::SH, BW = 1 << (2 * SH);
+        const int nb = P.bw * ((th + StagRouter::SparseTile::BM) >> SH);
+        for (int b0 = (tid >> 6) * 64; b0 < nb; b0 += 256) {  // 64 table entries per wave and round, the blocks among them one by one
+            const int myslot = b0 + lane < nb ? P.tab[b0 + lane] : 0;
+            unsigned long long have = __ballot(myslot != 0);
+            while (have) {
+                const int j = __builtin_ctzll(have);
+                have &= have - 1;
+                const int slot = __builtin_amdgcn_readlane(myslot, j), b = b0 + j;
+                const int brow = b / P.bw, bcol = b - brow * P.bw;
+                const int rr = (brow << SH) + (lane >> SH), cc = (bcol << SH) + (lane & ((1 << SH) - 1));
+                if (lane < BW && rr >= 1 && rr < th - 1 && cc >= 1 && cc < T.tw - 1) {
+                    const int g = (T.r0 + rr) * W + T.c0 + cc;
+                    if (label[g] == C.root) G.edge[g] = (uint8_t)StagRouter::Tile::edge_of(P.blk[(slot << (2 * SH)) + lane]);
+                }
             }
+        }
     }
 }
 __global__ __launch_bounds__(256) void k_stag_route_walk(StagRoute G, StagArenas A, StagComp *__restrict__ comps, const int *__restrict__ cursors, const int32_t *__restrict__ sorted, const int *__restrict__ aslots, const int *__restrict__ label, int grad_thresh, int lds_bytes, int *__restrict__ prodflag, int *__restrict__ ovf)

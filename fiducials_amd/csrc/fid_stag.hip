@@ -519,6 +519,7 @@ struct fid_stag_ctx {
     int *d_specbad = nullptr;
     int spec_frames = 0, spec_misses = 0;
     int tile_kb_env = 0, no_sparse = 0;  // FID_STAG_TILE_KB (LDS a component's walk may ask for), FID_STAG_SPARSE=0
+    int split_lds_env = -1;              // FID_STAG_SPLIT_LDS (pixels per wave of k_stag_split_lines that live in LDS)
 };
 
 extern "C" {
@@ -581,6 +582,8 @@ fid_status fid_stag_create(int libraryHD, int errorCorrection, int max_width, in
         const char *tk = getenv("FID_STAG_TILE_KB"), *sp = getenv("FID_STAG_SPARSE");
         c->tile_kb_env = tk ? atoi(tk) : 0;
         c->no_sparse = sp && atoi(sp) == 0 ? 1 : 0;
+        const char *sl = getenv("FID_STAG_SPLIT_LDS");
+        c->split_lds_env = sl ? atoi(sl) : -1;
         ok = hipFuncSetAttribute((const void *)k_stag_route_walk, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) == hipSuccess &&
              hipFuncSetAttribute((const void *)k_stag_comp_sort_big, hipFuncAttributeMaxDynamicSharedMemorySize, STAG_SORT_BIG * 4) == hipSuccess &&
              // (and their group-mode trampolines, fid_stag_batch.h)
@@ -1095,8 +1098,7 @@ static fid_status stag_advance_impl(fid_stag_ctx *c, StagJob &j)
         if (wg > 0) {
             // pixels per wave that live in LDS (fid_stag_lines.hip): a frame on its own has the CUs to itself, a group keeps four
             // workgroups per CU resident.  FID_STAG_SPLIT_LDS overrides (0: global memory throughout).
-            static const int lds_env = [] { const char *e = getenv("FID_STAG_SPLIT_LDS"); return e ? atoi(e) : -1; }();
-            int lds_pix = lds_env >= 0 ? lds_env : (grouped ? 256 : 1024);
+            int lds_pix = c->split_lds_env >= 0 ? c->split_lds_env : (grouped ? 256 : 1024);
             lds_pix = lds_pix > 1024 ? 1024 : lds_pix;
             STAG_LAUNCH(k_stag_split_lines, dim3((ns + 3) / 4), dim3(256), (size_t)SL_LDS_BYTES(lds_pix), st, c->d_vsegs, c->d_vtotal, c->d_outpix, PF,
                                c->min_line_len, 1.0, c->d_lslots, c->d_lcounts, lds_pix);

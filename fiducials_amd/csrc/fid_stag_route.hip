@@ -1523,7 +1523,7 @@ __device__ __forceinline__ void k_stag_route_extract_impl(StagRoute G, StagArena
     int2 *out0p = S.R.outpix;
     StagChain *chain0 = S.R.chains;
     int4 *stack0 = S.R.stack;
-    const int capStack0 = S.R.capStack;
+    const int capStack0 = S.R.capStack, capOut0 = S.R.capOut;
 #ifdef RW_TIMING
     const unsigned long long ex_t0 = __builtin_readcyclecounter();
 #endif
@@ -1549,12 +1549,16 @@ __device__ __forceinline__ void k_stag_route_extract_impl(StagRoute G, StagArena
             S.R.capStack = EX_CHAINS;
             S.R.pix = s_pix[wv];
             S.R.outpix = s_out[wv] - out0;  // (absolute indices: the block begins at out0)
+            // (a block is a subset of the anchor's <= EX_PIX pixels; should that ever not hold the overflow flag goes up -- the
+            //  frame then takes the sequential road -- instead of a write behind the buffer)
+            S.R.capOut = capOut0 < out0 + EX_PIX ? capOut0 : out0 + EX_PIX;
             S.extract_anchor(r.nchains);
+            S.R.capOut = capOut0;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             {  // the block to its place in the component's arena
-                const int nout = S.totalPixels - out0, room = S.R.capOut - out0;
+                const int nout = S.totalPixels - out0, room = capOut0 - out0;
                 int ncopy = nout < room ? nout : room;
                 ncopy = ncopy < EX_PIX ? ncopy : EX_PIX;  // (beyond: the arena overflowed, the frame takes the sequential road)
                 for (int i = lane; i < ncopy; i += 64) out0p[out0 + i] = s_out[wv][i];

@@ -207,12 +207,17 @@ def _lines_as_table(L):
     return np.stack([L[f].astype(np.float64) for f in stag_ref.LINE_FIELDS], axis=1) if len(L) else np.zeros((0, 10))
 
 
+@pytest.mark.parametrize("road", ["lds", "lds64", "global"])
 @pytest.mark.parametrize("case", sorted(VALID_CASES))
-def test_line_fitting_matches_reference_code(case):
+def test_line_fitting_matches_reference_code(case, road, monkeypatch):
     """Row s6, first half: SplitSegment2Lines + JoinCollinearLines.  Every field of every line bit for bit (doubles compared
-    with ==) against the reference's own routines fed with the device's validated EdgeMap."""
+    with ==) against the reference's own routines fed with the device's validated EdgeMap; the segment's pixels and prefix sums
+    in LDS (default: up to 1 024 pixels), with only 64 pixels of LDS per wave (nearly every segment in global memory, the short
+    ones in LDS side by side) and in global memory throughout."""
     if not stag_ref.available():
         pytest.skip("oracle/_ref/libstag_ref.so not built (needs /root/reference at build time)")
+    if road != "lds":
+        monkeypatch.setenv("FID_STAG_SPLIT_LDS", "64" if road == "lds64" else "0")
     img = VALID_CASES[case]()
     det = fstag.StagDetector(21, 7, max_width=1920, max_height=1080)
     try:

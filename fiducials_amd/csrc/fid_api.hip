@@ -63,6 +63,7 @@ struct fid_ctx {
     // the latency-bound tail of a piece under the fronts of the pieces behind it.  0 / 1: the two sub-batches side by side.
     int pieces = 0;
     bool piece_chain = false;  // (this call is laid out that way)
+    bool from_host_call = false;  // enqueue_detect is running under feed_and_enqueue: the sub-batches are the copy's pieces, never a piece chain
     int fs_barrier = 0;                    // FID_FS_BARRIER=1: the walks of every sub-batch wait for all find_starts (measured: find_starts
                                            // 3.6 -> 2.2 ms, the seed walks 3.3 -> 4.9 ms now side by side: the step is the same)     // a sub-batch has left its contour stage (staggered starts, FID_STAGGER)
     int stagger = 0;                        // sub-batch k starts when sub-batch k - stagger has left its contour stage (0: all at once)
@@ -501,7 +502,8 @@ fid_status enqueue_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H,
     c->res_precleared = false;
     // ---- the batch is cut into sub-batches that run the whole pipeline on their own streams: the latency-bound
     //      tail of one sub-batch's kernels (the longest border, the last candidates) overlaps the next one's bulk
-    c->piece_chain = c->pieces > 1 && !c->chained && !c->host_feed && c->trace_mode == 2 && c->sub_frames <= 0 &&
+    // (decided HERE and nowhere else: frames that come up from the host are cut by the copy's pieces whether or not the copy overlaps)
+    c->piece_chain = c->pieces > 1 && !c->chained && !c->host_feed && !c->from_host_call && c->trace_mode == 2 && c->sub_frames <= 0 &&
                      F >= 32 * c->pieces && c->stagger == 0;
     const SubPlan plan = plan_sub_batches(c, F);
     const int nsub = plan.nsub;
@@ -1313,10 +1315,13 @@ fid_status fid_detect_device(fid_ctx *c, const void *d_imgs, int32_t nframes, in
                              int64_t frame_stride, fid_encoding enc, fid_marker *out, int32_t cap_per_frame, int32_t *n_per_frame)
 {
     if (!c) return FID_E_INVALID_ARG;
-    if (!d_imgs || hipSetDevice(c->device) != hipSuccess) {
+    const hipError_t dev_rc = d_imgs ? hipSetDevice(c->device) : hipSuccess;
+    if (!d_imgs || dev_rc != hipSuccess) {
         c->wait_ev = c->wait_copy_ev = nullptr;  // (fid_order_after holds for one call, refused or not)
         c->chained = false;
-        return FID_E_INVALID_ARG;
+        if (!d_imgs) return FID_E_INVALID_ARG;
+        c->last_error = std::string("hipSetDevice: ") + hipGetErrorString(dev_rc);  // a runtime failure is not an argument error
+        return FID_E_HIP;
     }
     return run_detect(c, (const uint8_t *)d_imgs, nframes, width, height, stride, frame_stride, enc, out, cap_per_frame, n_per_frame);
 }
@@ -1328,8 +1333,14 @@ fid_status fid_submit_device(fid_ctx *c, const void *d_imgs, int32_t nframes, in
     fid_status rc = FID_E_INVALID_ARG;
     const bool was_in_flight = c->in_flight;
     if (was_in_flight) c->last_error = "a submitted batch is in flight: fid_collect first";
-    else if (d_imgs && hipSetDevice(c->device) == hipSuccess)
-        rc = enqueue_detect(c, (const uint8_t *)d_imgs, nframes, width, height, stride, frame_stride, enc);
+    else if (d_imgs) {
+        const hipError_t dev_rc = hipSetDevice(c->device);
+        if (dev_rc == hipSuccess) rc = enqueue_detect(c, (const uint8_t *)d_imgs, nframes, width, height, stride, frame_stride, enc);
+        else {
+            c->last_error = std::string("hipSetDevice: ") + hipGetErrorString(dev_rc);
+            rc = FID_E_HIP;
+        }
+    }
     c->wait_ev = nullptr;  // (fid_order_after holds for one submit, refused or not)
     c->wait_copy_ev = nullptr;
     c->chained = false;
@@ -1445,8 +1456,9 @@ static fid_status feed_and_enqueue_impl(fid_ctx *c, const uint8_t *imgs, int32_t
         }
     }
     const bool fed = c->host_feed;
+    c->from_host_call = true;  // (enqueue_detect plans the same sub-batches: no piece chain, FID_NO_FEED_OVERLAP or not)
     const fid_status rc = enqueue_detect(c, c->d_in, nframes, width, height, stride, frame_stride, enc);
-    c->host_feed = false;
+    c->host_feed = c->from_host_call = false;
     if (rc == FID_OK) {
         c->fed_from_host = fed;
     } else {

@@ -518,6 +518,11 @@ struct fid_stag_ctx {
     StagPred pred;
     int *d_specbad = nullptr;
     int spec_frames = 0, spec_misses = 0;
+    // back-off of the queue-ahead road: a stream whose counts jump from frame to frame (a moving scene) misses most predictions, and
+    // every miss is a whole extra pass.  Two misses among the last four queued frames switch the road off for spec_pause frames
+    // (16, doubling up to 256 while the misses go on; one fit after a pause brings it back to 16).  Results are the same either way.
+    unsigned spec_hist = 0;  // the last queued frames, one bit each (1 = missed), newest in bit 0
+    int spec_pause = 16, spec_skip = 0, spec_backoffs = 0;
     int tile_kb_env = 0, no_sparse = 0;  // FID_STAG_TILE_KB (LDS a component's walk may ask for), FID_STAG_SPARSE=0
     int split_lds_env = -1;              // FID_STAG_SPLIT_LDS (pixels per wave of k_stag_split_lines that live in LDS)
 };
@@ -770,6 +775,11 @@ static bool stag_spec_enabled(bool grouped)
     if (!e) return !grouped;
     return atoi(e) != 0;
 }
+static bool stag_spec_no_backoff()
+{
+    const char *e = getenv("FID_STAG_SPEC_BACKOFF");  // (0: queue ahead whenever a prediction exists, round 5's behaviour)
+    return e && atoi(e) == 0;
+}
 static void stag_plan(const fid_stag_ctx *c, StagJob &j)
 {
     const StagPred &p = c->pred;
@@ -839,15 +849,23 @@ static std::atomic<long long> g_stag_ns_sync(0), g_stag_ns_seg[12];
 static fid_status stag_advance_impl(fid_stag_ctx *c, StagJob &j);
 static fid_status stag_advance(fid_stag_ctx *c, StagJob &j)
 {
+    const bool was_spec = j.spec;
 #ifdef FID_DEBUG_STATS
     const int seg0 = j.seg;
     const auto t0 = STAG_NOW();
     const fid_status rc = stag_advance_impl(c, j);
     g_stag_ns_seg[seg0 < 11 ? seg0 : 11] += STAG_NS(t0, STAG_NOW());
-    return rc;
 #else
-    return stag_advance_impl(c, j);
+    const fid_status rc = stag_advance_impl(c, j);
 #endif
+    // A frame queued ahead raises the stage flags while it ENQUEUES (its counts are adopted at the one wait at the end).  If it ends
+    // in an error on the way, the context would keep "routed / validated / lined ..." beside the counts of the frame BEFORE it, and
+    // fid_stag_tap_* would size their reads by those over half-written buffers: nothing of this frame is to be looked at.
+    if (j.done && j.rc != FID_OK && j.rc != FID_E_CAPACITY && (was_spec || j.spec)) {
+        c->routed = c->validated = c->lined = c->lines_validated = c->quadded = c->decoded = false;
+        c->pred.valid = false;
+    }
+    return rc;
 }
 static fid_status stag_advance_impl(fid_stag_ctx *c, StagJob &j)
 {
@@ -873,6 +891,10 @@ static fid_status stag_advance_impl(fid_stag_ctx *c, StagJob &j)
         const int W = j.width, H = j.height;
         j.spec = stag_spec_enabled(grouped) && !j.nospec && j.last >= SS_MARKERS && c->route_mode == 1 && c->pred.valid && c->pred.W == W && c->pred.H == H &&
                  (!j.out || j.cap > 0) && stag_device_alias(c->hp, sizeof(fid_stag_ctx::Pinned)) != nullptr;
+        if (j.spec && c->spec_skip > 0 && !stag_spec_no_backoff()) {  // (backed off: this frame takes the counted road)
+            c->spec_skip--;
+            j.spec = false;
+        }
         if (j.spec) stag_plan(c, j);
         for (int y = 0; y < H; y++) memcpy(c->h_src + (size_t)y * W, j.gray + (size_t)y * j.stride, (size_t)W);
         if (STAG_MEMCPY(c->d_src, c->h_src, (size_t)W * H, hipMemcpyHostToDevice, st) != hipSuccess) return stag_finish(j, FID_E_HIP);
@@ -1264,8 +1286,16 @@ static fid_status stag_advance_impl(fid_stag_ctx *c, StagJob &j)
                               h.cur[9] <= (u.most > STAG_SORT_WAVE ? 65536 : STAG_SORT_WAVE) && !h.ovf && h.rcount[0] <= u.ns && h.n_vsegs <= u.nvs &&
                               h.n_lines <= u.nl && h.n_vlines <= u.nvl && h.n_quads <= u.nq && h.n_markers <= u.nm;
             c->spec_frames++;
+            c->spec_hist = (c->spec_hist << 1) | (fits ? 0u : 1u);
+            if (fits) c->spec_pause = 16;
             if (!fits) {  // the counted road from the first segment: the same result, nine waits
                 c->spec_misses++;
+                if (__builtin_popcount(c->spec_hist & 0xfu) >= 2) {
+                    c->spec_skip = c->spec_pause;
+                    c->spec_pause = c->spec_pause < 256 ? c->spec_pause * 2 : 256;
+                    c->spec_hist = 0;
+                    c->spec_backoffs++;
+                }
                 c->pred.valid = false;
                 j.spec = false;
                 j.nospec = true;

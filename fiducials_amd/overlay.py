@@ -11,6 +11,8 @@ from . import _lib
 from ._lib import FidError, FidMarker
 
 FIRST_CORNER_LINE8 = 1
+_BYTES_PER_PIXEL = {"mono8": 1, "bgr8": 3, "rgb8": 3, "bgra8": 4, "rgba8": 4, "mono16": 2, "bgr16": 6, "rgb16": 6, "bgra16": 8, "rgba16": 8,
+                    "yuv422": 2, "bayer_rggb8": 1, "bayer_bggr8": 1, "bayer_gbrg8": 1, "bayer_grbg8": 1}
 
 
 def to_bgr(image: np.ndarray, encoding: str | None = None) -> np.ndarray:
@@ -28,7 +30,17 @@ def to_bgr(image: np.ndarray, encoding: str | None = None) -> np.ndarray:
 def image_to_bgr8(data: np.ndarray, width: int, height: int, step: int, encoding: str, is_bigendian: bool = False) -> np.ndarray:
     """cv_bridge::toCvCopy(msg, "bgr8") of a sensor_msgs/Image given by its fields (data: the message bytes): the five 8-bit
     encodings, mono16 / bgr16 / rgb16 / bgra16 / rgba16 and the four 8-bit Bayer patterns (fid_image_to_bgr8)."""
-    buf = np.ascontiguousarray(data, dtype=np.uint8).reshape(-1)
+    # the message BYTES: an ndarray of another dtype (a mono16 frame as uint16) is reinterpreted, never value-converted
+    if isinstance(data, np.ndarray):
+        buf = np.ascontiguousarray(data).view(np.uint8).reshape(-1)
+    else:
+        buf = np.frombuffer(data, dtype=np.uint8)
+    width, height, step = int(width), int(height), int(step)
+    bpp = _BYTES_PER_PIXEL.get(encoding)
+    if width < 1 or height < 1 or (bpp is not None and step < width * bpp) or buf.size < step * height:
+        # (the C side reads step * (height - 1) + a row, the Bayer rows two ahead: a short buffer is refused here, as
+        #  FiducialsNode::imageCallback refuses data.size() < step * height)
+        raise FidError(_lib.FID_E_INVALID_ARG, f"fid_image_to_bgr8({encoding}): {buf.size} bytes for step {step} x height {height}")
     out = np.empty((height, width, 3), dtype=np.uint8)
     rc = _lib.load().fid_image_to_bgr8(buf.ctypes.data, width, height, step, encoding.encode(), int(bool(is_bigendian)), out.ctypes.data, out.nbytes)
     if rc != _lib.FID_OK:

@@ -174,3 +174,20 @@ def test_image_to_bgr8_16bit_and_bayer_encodings():
         assert e.value.status == _lib.FID_E_UNSUPPORTED
     with pytest.raises(FidError):
         overlay.image_to_bgr8(np.zeros((4, 8), np.uint8), 4, 4, 7, "mono16")  # a step smaller than a row
+
+
+def test_image_to_bgr8_takes_the_message_bytes_and_refuses_short_buffers():
+    """A mono16 frame handed over as a uint16 array is REINTERPRETED (its bytes are the message's data), not value-converted;
+    a buffer shorter than step * height never reaches the C side (it reads step * (height - 1) + a row, Bayer two rows ahead)."""
+    from fiducials_amd import overlay
+    from fiducials_amd._lib import FID_E_INVALID_ARG, FidError
+
+    v = (np.arange(64 * 48, dtype=np.uint32) * 21 % 65536).astype(np.uint16).reshape(48, 64)
+    as_bytes = overlay.image_to_bgr8(v.view(np.uint8), 64, 48, 128, "mono16")
+    assert np.array_equal(overlay.image_to_bgr8(v, 64, 48, 128, "mono16"), as_bytes)
+    assert np.array_equal(overlay.image_to_bgr8(v.tobytes(), 64, 48, 128, "mono16"), as_bytes)
+    for enc, data, w, h, step in (("mono16", v.view(np.uint8)[:47], 64, 48, 128), ("bayer_rggb8", np.zeros(12 * 11, np.uint8), 12, 12, 12),
+                                  ("bgr8", np.zeros(5 * 21 - 1, np.uint8), 7, 5, 21), ("yuv422", np.zeros(7, np.uint8), 4, 1, 8)):
+        with pytest.raises(FidError) as ei:
+            overlay.image_to_bgr8(data, w, h, step, enc)
+        assert ei.value.status == FID_E_INVALID_ARG, enc

@@ -73,7 +73,21 @@ class FidPngInfo(C.Structure):
 FID_OK = 0
 FID_E_INVALID_ARG, FID_E_NO_DEVICE, FID_E_HIP, FID_E_CAPACITY, FID_E_OUT_OF_MEMORY, FID_E_UNSUPPORTED, FID_E_CV_EXCEPTION = 1, 2, 3, 4, 5, 6, 7
 CORNER_REFINE_NONE, CORNER_REFINE_SUBPIX, CORNER_REFINE_CONTOUR = 0, 1, 2  # aruco::CornerRefineMethod as the node sets it (:700-711)
-ENC = {"mono8": 0, "bgr8": 1, "rgb8": 2, "bgra8": 3, "rgba8": 4}
+ENC = {"mono8": 0, "bgr8": 1, "rgb8": 2, "bgra8": 3, "rgba8": 4,
+       # ABI 7: what raw camera drivers publish, converted on the device (fid_encoding in include/fid_abi.h)
+       "bayer_rggb8": 5, "bayer_bggr8": 6, "bayer_gbrg8": 7, "bayer_grbg8": 8, "mono16": 9, "bgr16": 10, "rgb16": 11, "bgra16": 12, "rgba16": 13,
+       "yuv422": 14}
+ENC_BIGENDIAN = 0x100  # OR-ed onto a 16-bit encoding (sensor_msgs/Image.is_bigendian)
+ENC_BYTES_PER_PIXEL = {"mono8": 1, "bgr8": 3, "rgb8": 3, "bgra8": 4, "rgba8": 4, "bayer_rggb8": 1, "bayer_bggr8": 1, "bayer_gbrg8": 1,
+                       "bayer_grbg8": 1, "mono16": 2, "bgr16": 6, "rgb16": 6, "bgra16": 8, "rgba16": 8, "yuv422": 2}
+
+
+def encoding_value(encoding: str, is_bigendian: bool = False) -> int:
+    """fid_encoding of a sensor_msgs/Image encoding string (the table fid_encoding_from_string holds)."""
+    v = ENC[encoding]
+    return v | ENC_BIGENDIAN if is_bigendian and 9 <= v <= 13 else v
+
+
 TAP_MASKS, TAP_CANDIDATES, TAP_FILTERED, TAP_BITS, TAP_IDENT, TAP_PRESUBPIX, TAP_COUNTS, TAP_GRAY = range(8)
 
 # every symbol include/fid_abi.h declares
@@ -85,7 +99,7 @@ SYMBOLS = [
     "fid_jpeg_probe", "fid_jpeg_create", "fid_jpeg_destroy", "fid_jpeg_decode", "fid_jpeg_device_ptr", "fid_jpeg_tap_bytes", "fid_jpeg_tap_read",
     "fid_jpeg_last_rounds", "fid_jpeg_last_error",
     "fid_png_probe", "fid_png_decode", "fid_png_last_error",
-    "fid_to_bgr", "fid_image_to_bgr8", "fid_draw_detected_markers", "fid_dict_load_file", "fid_dict_last_error",
+    "fid_to_bgr", "fid_image_to_bgr8", "fid_encoding_from_string", "fid_draw_detected_markers", "fid_dict_load_file", "fid_dict_last_error",
 ]
 
 _LIB = None
@@ -239,6 +253,7 @@ def load():
     L.fid_png_decode.argtypes = [vp, i64, C.c_int, vp, i64, C.POINTER(FidPngInfo)]
     L.fid_to_bgr.argtypes = [vp, i32, i32, i32, C.c_int, vp, i64]
     L.fid_image_to_bgr8.argtypes = [vp, i32, i32, i32, C.c_char_p, i32, vp, i64]
+    L.fid_encoding_from_string.argtypes = [C.c_char_p, i32, C.POINTER(C.c_int), C.POINTER(i32)]
     L.fid_draw_detected_markers.argtypes = [vp, i32, i32, i32, C.POINTER(FidMarker), i32, C.c_uint32]
     L.fid_dict_load_file.argtypes = [C.c_char_p, i32, vp, i64, C.POINTER(FidDict)]
     L.fid_dict_last_error.argtypes = []

@@ -223,6 +223,7 @@ template <int NW, bool SPLIT>
 void launch_thr_stream(dim3 grid, hipStream_t st, const uint8_t *g, long long gfstride, uint32_t *masks, const DevParams &P, int RS, int xcd_map)
 {
     using S = ThrStream<3, 4, 13, NW>;
+    fid_launch_log("k_threshold_stream", S::NT, S::LDS_BYTES);
     k_threshold_stream<3, 4, 13, NW, SPLIT><<<grid, dim3(S::NT), S::LDS_BYTES, st>>>(g, gfstride, masks, P, RS, xcd_map);
 }
 
@@ -447,13 +448,31 @@ SubPlan plan_sub_batches(const fid_ctx *c, int F)
 // Everything a detect call can be refused for, checked BEFORE anything is put on a stream: feed_and_enqueue queues host -> device
 // copies of the caller's buffer in front of the kernels, and a call that is then refused must not leave DMA from that buffer in
 // flight (the caller may free it as soon as it sees the error).
+// bytes one pixel occupies in a row; 0 = not an encoding this library takes.  FID_ENC_BIGENDIAN is only meaningful (and only
+// accepted) on the 16-bit layouts.
+static int enc_bytes_per_pixel(int enc)
+{
+    const int base = enc & 0xff;
+    if (enc & ~(0xff | FID_ENC_BIGENDIAN)) return 0;
+    if ((enc & FID_ENC_BIGENDIAN) && !(base >= FID_ENC_MONO16 && base <= FID_ENC_RGBA16)) return 0;
+    switch (base) {
+    case FID_ENC_MONO8: case FID_ENC_BAYER_RGGB8: case FID_ENC_BAYER_BGGR8: case FID_ENC_BAYER_GBRG8: case FID_ENC_BAYER_GRBG8: return 1;
+    case FID_ENC_BGR8: case FID_ENC_RGB8: return 3;
+    case FID_ENC_BGRA8: case FID_ENC_RGBA8: return 4;
+    case FID_ENC_MONO16: case FID_ENC_YUV422: return 2;
+    case FID_ENC_BGR16: case FID_ENC_RGB16: return 6;
+    case FID_ENC_BGRA16: case FID_ENC_RGBA16: return 8;
+    default: return 0;
+    }
+}
+
 fid_status check_call(fid_ctx *c, int F, int W, int H, int stride, fid_encoding enc)
 {
     if (F < 1 || F > c->lim.max_batch || W < 8 || H < 8 || W > c->lim.max_width || H > c->lim.max_height || W > 8191 || H > 8191)  // 13-bit checkpoint packing
         return FID_E_INVALID_ARG;
-    if (enc != FID_ENC_MONO8 && enc != FID_ENC_BGR8 && enc != FID_ENC_RGB8 && enc != FID_ENC_BGRA8 && enc != FID_ENC_RGBA8) return FID_E_INVALID_ARG;
-    const int bpp = enc == FID_ENC_MONO8 ? 1 : ((enc == FID_ENC_BGRA8 || enc == FID_ENC_RGBA8) ? 4 : 3);
-    if (stride < W * bpp) return FID_E_INVALID_ARG;
+    const int bpp = enc_bytes_per_pixel(enc);
+    if (bpp == 0 || stride < W * bpp) return FID_E_INVALID_ARG;
+    if ((enc & 0xff) == FID_ENC_YUV422 && (W & 1)) return FID_E_INVALID_ARG;  // (a UYVY row is whole pixel pairs)
     const int maxdim = W > H ? W : H;
     if ((unsigned)(c->params.maxMarkerPerimeterRate * maxdim) > 36000u) return FID_E_UNSUPPORTED;  // contour points live in LDS
     const size_t pitch = (size_t)((int)(unsigned)(c->params.maxMarkerPerimeterRate * maxdim) / CK + 3);  // chunk_tab_pitch
@@ -557,9 +576,12 @@ fid_status enqueue_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H,
         };
       if (phase == 0) {
         mark(0);
-        if (to_gray)
+        if (to_gray && (int)enc <= FID_ENC_RGBA8)
             hipLaunchKernelGGL(k_to_gray, dim3(2048), dim3(256), 0, st, d_src + (long long)f0 * fstride, stride, fstride, (int)enc,
                                c->d_gray + (size_t)f0 * W * H, W, H, Fs);
+        else if (to_gray)  // (ABI 7: Bayer mosaics, 16-bit layouts, UYVY -- cv_bridge's conversion and BGR2GRAY in one pass)
+            hipLaunchKernelGGL(k_raw_to_gray, dim3((W + 255) / 256, (H + 3) / 4, Fs), dim3(64, 4), 0, st, d_src + (long long)f0 * fstride, stride,
+                               fstride, (int)enc, c->d_gray + (size_t)f0 * W * H, W, H);
         mark(ST_GRAY + 1);
         // ---- K1
         {
@@ -641,8 +663,10 @@ fid_status enqueue_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H,
                                (DevPend *)nullptr, counts, c->d_global, P);
             mark(ST_WALK + 1);
             // ---- K4: short contours with a small LDS footprint first, then the long / flagged ones
+            fid_launch_log("k_approx", 64, (size_t)(lds1));
             hipLaunchKernelGGL(k_approx, dim3(128 * gm, Fs), dim3(64), lds1, st, contours, tab, pool, cands, counts, c->d_global, P, cap1,
                                K4_SHORT_STACK, 0, (const uint32_t *)nullptr, (const uint32_t *)nullptr);
+            fid_launch_log("k_approx", 64, (size_t)(lds2));
             hipLaunchKernelGGL(k_approx, dim3(16 * gm, Fs), dim3(64), lds2, st, contours, tab, pool, cands, counts, c->d_global, P,
                                P.maxPerim + 1, K4_LONG_STACK, 1, (const uint32_t *)nullptr, (const uint32_t *)nullptr);
             mark(ST_APPROX + 1);
@@ -707,8 +731,10 @@ fid_status enqueue_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H,
             hipLaunchKernelGGL(k_seg_cycles<0>, dim3(8 * gm, Fs), dim3(64), 0, sa, seedq, (const DevSegC *)segs, pend, wres, contours, cinfo, cbase,
                                recs, counts, c->d_global, P, 1, 0);
             hipLaunchKernelGGL(k_seg_copy, dim3(cpb / 4 > 0 ? cpb / 4 : 1, Fs), dim3(256), 0, sa, recs, tab, pool, dense, counts, P, 1);
+            fid_launch_log("k_approx", 64, (size_t)(lds1));
             hipLaunchKernelGGL(k_approx, dim3(32 * gm, Fs), dim3(64), lds1, sa, contours, tab, pool, cands, counts, c->d_global, P, cap1,
                                K4_SHORT_STACK, 0, dense, cbase, 2);
+            fid_launch_log("k_approx", 64, (size_t)(lds2));
             hipLaunchKernelGGL(k_approx, dim3(8 * gm, Fs), dim3(64), lds2, sa, contours, tab, pool, cands, counts, c->d_global, P,
                                P.maxPerim + 1, K4_LONG_STACK, 1, dense, cbase, 2);
             if (c->profile) (void)hipEventRecord(ev[17], sa);
@@ -728,8 +754,10 @@ fid_status enqueue_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H,
             hipLaunchKernelGGL(k_seg_copy, dim3(cpb, Fs), dim3(256), 0, st, recs, tab, pool, dense, counts, P, 0);
             mark(ST_WALK + 1);
             chain_point(2);
+            fid_launch_log("k_approx", 64, (size_t)(lds1));
             hipLaunchKernelGGL(k_approx, dim3(128 * gm, Fs), dim3(64), lds1, st, contours, tab, pool, cands, counts, c->d_global, P, cap1,
                                K4_SHORT_STACK, 0, dense, cbase, 1);
+            fid_launch_log("k_approx", 64, (size_t)(lds2));
             hipLaunchKernelGGL(k_approx, dim3(16 * gm, Fs), dim3(64), lds2, st, contours, tab, pool, cands, counts, c->d_global, P,
                                P.maxPerim + 1, K4_LONG_STACK, 1, dense, cbase, 1);
             mark(ST_APPROX + 1);
@@ -767,8 +795,10 @@ fid_status enqueue_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H,
                                c->d_global, P);
             hipLaunchKernelGGL(k_seg_copy, dim3(c->copy_blocks > 0 ? c->copy_blocks : 256, Fs), dim3(256), 0, st, recs, tab, pool, dense, counts, P, -1);
             mark(ST_WALK + 1);
+            fid_launch_log("k_approx", 64, (size_t)(lds1));
             hipLaunchKernelGGL(k_approx, dim3(128 * gm, Fs), dim3(64), lds1, st, contours, tab, pool, cands, counts, c->d_global, P, cap1,
                                K4_SHORT_STACK, 0, dense, cbase);
+            fid_launch_log("k_approx", 64, (size_t)(lds2));
             hipLaunchKernelGGL(k_approx, dim3(16 * gm, Fs), dim3(64), lds2, st, contours, tab, pool, cands, counts, c->d_global, P,
                                P.maxPerim + 1, K4_LONG_STACK, 1, dense, cbase);
             mark(ST_APPROX + 1);
@@ -779,6 +809,7 @@ fid_status enqueue_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H,
         // ---- K5
         float4 *cmeta = c->d_cmeta + f0 * MC;
         // (a rank sort: every candidate is compared with all of them -- a call of a few frames gives the frame sixteen workgroups)
+        fid_launch_log("k_sort_cands", 256, (size_t)(MC * 8));
         hipLaunchKernelGGL(k_sort_cands, dim3(Fs, (c->light_x > 1 || Fs < 16) ? 16 : 1), dim3(256), MC * 8, st, cands, sorted, cmeta, counts, P);
         mark(ST_SORT + 1);
         hipLaunchKernelGGL(k_near, dim3(32 * gm * c->light_x, Fs), dim3(256), 0, st, sorted, cmeta, nearb, counts, P);
@@ -788,6 +819,7 @@ fid_status enqueue_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H,
             // the other sub-batch on a CU; with 96 KB the kernel waited for whole CUs to drain)
             const size_t lds = (size_t)c->resolve_lds_kb * 1024;
             const int near_words = c->resolve_serial ? 0 : (int)((lds - 3 * MC * 4) / 4);
+            fid_launch_log("k_resolve", 1024, (size_t)(lds));
             hipLaunchKernelGGL(k_resolve, dim3(Fs), dim3(1024), lds, st, sorted, nearb, filtered, counts, worklist, nwork, P, near_words, c->d_global,
                                c->resolve_reg_max);
         }
@@ -796,11 +828,13 @@ fid_status enqueue_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H,
         // ---- K6
         {
             int SZ = (P.markerSize + 2 * P.borderBits) * P.cellSize;
+            fid_launch_log("k_identify", 64, (size_t)((size_t)SZ * SZ));
             hipLaunchKernelGGL(k_identify, dim3(c->tail_grid > 0 ? c->tail_grid : 256 * 4), dim3(64), (size_t)SZ * SZ, st, g, gfstride, filtered, worklist, nwork,
                                c->d_dict, ident, P);
         }
         mark(ST_IDENT + 1);
         // ---- K7
+        fid_launch_log("k_filter_markers", 64, (size_t)((size_t)c->filter_lds * sizeof(fid_marker)));
         hipLaunchKernelGGL(k_filter_markers, dim3(Fs), dim3(64), (size_t)c->filter_lds * sizeof(fid_marker), st, filtered, ident, pre, counts, P,
                            c->d_filter_scratch + f0 * MC, c->filter_lds, c->d_accsrc + f0 * MC, c->d_mksrc + f0 * MM);
         mark(ST_FILTER + 1);

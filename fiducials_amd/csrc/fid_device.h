@@ -23,6 +23,37 @@
 //   poses     fid_pose_out [F][max_markers]
 #pragma once
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+// FID_LAUNCH_LOG=<file>: every distinct (kernel, block, dynamic LDS) a launch site with DYNAMIC shared memory asks for, one line
+// each, appended as "kernel block lds_bytes".  rocprofv3's kernel trace reports the STATIC group segment only, so this is where
+// tools/occupancy.py gets the rest of a workgroup's LDS footprint from.  Off (one load of a flag) unless the variable is set.
+static inline void fid_launch_log(const char *kernel, unsigned block, size_t lds)
+{
+    static const char *path = getenv("FID_LAUNCH_LOG");
+    if (!path) return;
+    struct Seen { char name[48]; unsigned block; size_t lds; };
+    static Seen seen[256];
+    static int nseen = 0;
+    static volatile int lock = 0;
+    while (__sync_lock_test_and_set(&lock, 1)) {}
+    bool have = false;
+    for (int i = 0; i < nseen && !have; i++) have = seen[i].block == block && seen[i].lds == lds && !strncmp(seen[i].name, kernel, 47);
+    if (!have && nseen < 256) {
+        strncpy(seen[nseen].name, kernel, 47);
+        seen[nseen].name[47] = 0;
+        seen[nseen].block = block;
+        seen[nseen].lds = lds;
+        nseen++;
+        if (FILE *fh = fopen(path, "a")) {
+            fprintf(fh, "%s %u %zu\n", kernel, block, lds);
+            fclose(fh);
+        }
+    }
+    __sync_lock_release(&lock);
+}
 
 #define MASK_PADW 1  // zero tile columns in front of every tile row
 #define MT_ROWS 16   // rows per mask tile

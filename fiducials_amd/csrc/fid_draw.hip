@@ -302,6 +302,24 @@ fid_status fid_image_to_bgr8(const uint8_t *img, int32_t width, int32_t height, 
     return FID_E_UNSUPPORTED;
 }
 
+fid_status fid_encoding_from_string(const char *encoding, int32_t is_bigendian, fid_encoding *out_enc, int32_t *bytes_per_pixel)
+{
+    if (!encoding || !out_enc) return FID_E_INVALID_ARG;
+    static const struct { const char *name; int enc, bpp; } tab[] = {
+        {"mono8", FID_ENC_MONO8, 1}, {"bgr8", FID_ENC_BGR8, 3}, {"rgb8", FID_ENC_RGB8, 3}, {"bgra8", FID_ENC_BGRA8, 4}, {"rgba8", FID_ENC_RGBA8, 4},
+        {"bayer_rggb8", FID_ENC_BAYER_RGGB8, 1}, {"bayer_bggr8", FID_ENC_BAYER_BGGR8, 1}, {"bayer_gbrg8", FID_ENC_BAYER_GBRG8, 1},
+        {"bayer_grbg8", FID_ENC_BAYER_GRBG8, 1}, {"mono16", FID_ENC_MONO16, 2}, {"bgr16", FID_ENC_BGR16, 6}, {"rgb16", FID_ENC_RGB16, 6},
+        {"bgra16", FID_ENC_BGRA16, 8}, {"rgba16", FID_ENC_RGBA16, 8}, {"yuv422", FID_ENC_YUV422, 2}};
+    for (const auto &t : tab)
+        if (!strcmp(encoding, t.name)) {
+            const bool wide = t.enc >= FID_ENC_MONO16 && t.enc <= FID_ENC_RGBA16;
+            *out_enc = (fid_encoding)(t.enc | (wide && is_bigendian ? FID_ENC_BIGENDIAN : 0));
+            if (bytes_per_pixel) *bytes_per_pixel = t.bpp;
+            return FID_OK;
+        }
+    return FID_E_UNSUPPORTED;
+}
+
 fid_status fid_draw_detected_markers(uint8_t *bgr, int32_t width, int32_t height, int32_t stride, const fid_marker *markers, int32_t n,
                                      uint32_t flags)
 {

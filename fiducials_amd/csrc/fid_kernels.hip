@@ -191,6 +191,115 @@ __global__ __launch_bounds__(256) void k_to_gray(const uint8_t *__restrict__ src
 }
 
 // ------------------------------------------------------------------------------------------------
+// K0 for what raw camera drivers publish (ABI 7, round 6): cv_bridge::toCvCopy(msg, "bgr8") (aruco_detect.cpp:348) followed by
+// detectMarkers' BGR2GRAY, in ONE pass over the message's own bytes -- the 8-bit Bayer mosaics, the 16-bit gray / colour layouts
+// and UYVY.  The arithmetic is fid_image_to_bgr8's (fid_draw.hip: the host statement of the same rules, now the checker) pixel
+// for pixel:
+//   * Bayer: OpenCV's bilinear Bayer2RGB_<uchar> under cv_bridge's pattern mapping.  An interior pixel (1 <= y <= H-2,
+//     1 <= x <= W-2) keeps its own colour; a green site gets (up + down + 1) >> 1 and (left + right + 1) >> 1 for the two others,
+//     a red / blue site (4 edge neighbours + 2) >> 2 for green and (4 diagonals + 2) >> 2 for the opposite colour; which of
+//     B / R the horizontal (own) value is alternates row by row (`blue`), green sites alternate along a row starting with
+//     `green` in column 1.  Border columns, then border rows repeat their neighbours: pixel (y, x) is pixel (clamp(y, 1, H-2),
+//     clamp(x, 1, W-2)).
+//   * 16 bit: cvRound(float(v) * float(255. / 65535.)) per sample (nearest, ties to even), big-endian samples swapped first.
+//   * UYVY: BT.601 in 20-bit fixed point.
+// Grid (ceil(W / 256), ceil(H / 4), F), block (64, 4): a wave per row, a lane per four pixels (one 32-bit store where the row
+// start allows).  HBM-bound: reads the message once (1 - 8 B per pixel), writes 1 B per pixel.
+__device__ __forceinline__ int k0_gray(int b, int g, int r) { return (b * 3735 + g * 19235 + r * 9798 + (1 << 14)) >> 15; }
+__device__ __forceinline__ int k0_scale16(const uint8_t *p, bool be)
+{
+    const unsigned v = be ? ((unsigned)p[0] << 8) | p[1] : (unsigned)p[0] | ((unsigned)p[1] << 8);
+    const float a = (float)(255. / 65535.);
+    const int r = __float2int_rn((float)v * a);
+    return r < 0 ? 0 : (r > 255 ? 255 : r);
+}
+__device__ __forceinline__ int k0_sat8(int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
+// one demosaiced pixel from its 3 x 3 neighbourhood (row-major n[9]); hv: +1 / -1 (the host code's `blue` for this row)
+__device__ __forceinline__ int k0_bayer_gray(const int n[9], bool is_green, int hv)
+{
+    int own, other, green;
+    if (is_green) {
+        green = n[4];
+        other = (n[1] + n[7] + 1) >> 1;  // vertical pair   -> channel 1 - hv
+        own = (n[3] + n[5] + 1) >> 1;    // horizontal pair -> channel 1 + hv
+    } else {
+        own = n[4];
+        green = (n[1] + n[3] + n[5] + n[7] + 2) >> 2;
+        other = (n[0] + n[2] + n[6] + n[8] + 2) >> 2;
+    }
+    const int b = hv > 0 ? other : own, r = hv > 0 ? own : other;  // channel 0 = B, 2 = R
+    return k0_gray(b, green, r);
+}
+__global__ __launch_bounds__(256) void k_raw_to_gray(const uint8_t *__restrict__ src, int stride, long long fstride, int enc,
+                                                      uint8_t *__restrict__ dst, int W, int H)
+{
+    const int x0 = ((int)blockIdx.x * 64 + (int)threadIdx.x) * 4, y = (int)blockIdx.y * 4 + (int)threadIdx.y, f = blockIdx.z;
+    if (x0 >= W || y >= H) return;
+    const uint8_t *img = src + (long long)f * fstride;
+    uint8_t *o = dst + ((long long)f * H + y) * W + x0;
+    const int n = W - x0 < 4 ? W - x0 : 4;
+    const int base = enc & 0xff;
+    const bool be = (enc & FID_ENC_BIGENDIAN) != 0;
+    int g[4] = {0, 0, 0, 0};
+    if (base >= FID_ENC_BAYER_RGGB8 && base <= FID_ENC_BAYER_GRBG8) {
+        // (rggb: blue -1, green 0; bggr: +1, 0; gbrg: +1, 1; grbg: -1, 1 -- fid_image_to_bgr8's table)
+        const int blue0 = (base == FID_ENC_BAYER_RGGB8 || base == FID_ENC_BAYER_GRBG8) ? -1 : 1;
+        const int green0 = (base == FID_ENC_BAYER_GBRG8 || base == FID_ENC_BAYER_GRBG8) ? 1 : 0;
+        const int yy = y < 1 ? 1 : (y > H - 2 ? H - 2 : y);
+        const int hv = ((yy - 1) & 1) ? -blue0 : blue0;
+        const int gs = green0 ^ ((yy - 1) & 1);
+        const uint8_t *r0 = img + (long long)(yy - 1) * stride, *r1 = r0 + stride, *r2 = r1 + stride;
+        if (x0 >= 1 && x0 + 4 <= W - 1) {
+            // the six columns x0 - 1 ... x0 + 4 of three rows serve four interior pixels
+            int a0[6], a1[6], a2[6];
+#pragma unroll
+            for (int k = 0; k < 6; k++) {
+                a0[k] = r0[x0 - 1 + k];
+                a1[k] = r1[x0 - 1 + k];
+                a2[k] = r2[x0 - 1 + k];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int nb[9] = {a0[k], a0[k + 1], a0[k + 2], a1[k], a1[k + 1], a1[k + 2], a2[k], a2[k + 1], a2[k + 2]};
+                g[k] = k0_bayer_gray(nb, (gs ^ ((x0 + k - 1) & 1)) != 0, hv);
+            }
+        } else {
+            for (int k = 0; k < n; k++) {  // a row's first and last lanes: the clamped column, nine loads a pixel
+                const int x = x0 + k, xx = x < 1 ? 1 : (x > W - 2 ? W - 2 : x);
+                const int nb[9] = {r0[xx - 1], r0[xx], r0[xx + 1], r1[xx - 1], r1[xx], r1[xx + 1], r2[xx - 1], r2[xx], r2[xx + 1]};
+                g[k] = k0_bayer_gray(nb, (gs ^ ((xx - 1) & 1)) != 0, hv);
+            }
+        }
+    } else if (base == FID_ENC_MONO16) {
+        const uint8_t *s = img + (long long)y * stride + 2 * x0;
+        for (int k = 0; k < n; k++) g[k] = k0_scale16(s + 2 * k, be);  // (B = G = R = v: BGR2GRAY gives v back)
+    } else if (base >= FID_ENC_BGR16 && base <= FID_ENC_RGBA16) {
+        const int ch = (base == FID_ENC_BGRA16 || base == FID_ENC_RGBA16) ? 4 : 3;
+        const bool bfirst = base == FID_ENC_BGR16 || base == FID_ENC_BGRA16;
+        const uint8_t *s = img + (long long)y * stride + 2 * ch * x0;
+        for (int k = 0; k < n; k++) {
+            const int c0 = k0_scale16(s + 2 * (ch * k), be), c1 = k0_scale16(s + 2 * (ch * k + 1), be), c2 = k0_scale16(s + 2 * (ch * k + 2), be);
+            g[k] = k0_gray(bfirst ? c0 : c2, c1, bfirst ? c2 : c0);
+        }
+    } else {  // FID_ENC_YUV422 (UYVY; W is even, so a lane's pixels are whole pairs)
+        const int CY = 1220542, CUB = 2116026, CUG = -409993, CVG = -852492, CVR = 1673527, SH = 20;
+        const uint8_t *s = img + (long long)y * stride + 2 * x0;
+        for (int k = 0; k < n; k += 2) {
+            const int u = s[2 * k] - 128, y0 = s[2 * k + 1], v = s[2 * k + 2] - 128, y1 = s[2 * k + 3];
+            const int ruv = (1 << (SH - 1)) + CVR * v, guv = (1 << (SH - 1)) + CVG * v + CUG * u, buv = (1 << (SH - 1)) + CUB * u;
+            const int p0 = (y0 - 16 > 0 ? y0 - 16 : 0) * CY, p1 = (y1 - 16 > 0 ? y1 - 16 : 0) * CY;
+            g[k] = k0_gray(k0_sat8((p0 + buv) >> SH), k0_sat8((p0 + guv) >> SH), k0_sat8((p0 + ruv) >> SH));
+            g[k + 1] = k0_gray(k0_sat8((p1 + buv) >> SH), k0_sat8((p1 + guv) >> SH), k0_sat8((p1 + ruv) >> SH));
+        }
+    }
+    if (n == 4 && (((unsigned long long)o) & 3ull) == 0) {
+        *reinterpret_cast<unsigned *>(o) = (unsigned)g[0] | ((unsigned)g[1] << 8) | ((unsigned)g[2] << 16) | ((unsigned)g[3] << 24);
+    } else {
+        for (int k = 0; k < n; k++) o[k] = (uint8_t)g[k];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // K1: multi-scale adaptive threshold.
 //   adaptiveThreshold(MEAN_C, BINARY_INV, win, C): mean = round(boxsum / win^2) with BORDER_REPLICATE,
 //   foreground iff src - mean <= -idelta, idelta = cvFloor(C) (THRESH_BINARY_INV)   <=>   2*boxsum >= (2*(src + idelta) - 1) * win^2
@@ -4991,6 +5100,11 @@ struct PoseCam {
     double K[9];
     double D[5];
     double fiducial_len;
+    template <class V>
+    __host__ __device__ __forceinline__ void visit(V &&v)
+    {
+        v(K); v(D); v(fiducial_len);
+    }
 };
 // CvLevMarq's damping factor exp(lambdaLg10 * log(10.)) for lambdaLg10 = -16 .. 16 as the HOST's libm gives it (glibc's exp / log,
 // what the reference runs on; generated with Python's math.exp(k * math.log(10.0)), hexadecimal literals = the exact doubles):

@@ -455,6 +455,7 @@ struct fid_stag_ctx {
     // component-parallel routing
     int4 *d_cbox = nullptr;  // per root: bounding box of the component's pixels
     int *d_label = nullptr, *d_csize = nullptr, *d_canch = nullptr, *d_cidmap = nullptr, *d_cursors = nullptr, *d_caps = nullptr;
+    int *d_corder = nullptr;  // the components longest-first (k_stag_comp_tilemax; the walk and the extraction go by it)
     int *d_fill = nullptr, *d_aslots = nullptr, *d_prodflag = nullptr, *d_next = nullptr, *d_blkpix = nullptr, *d_blksegs = nullptr;
     int2 *d_blkwhere = nullptr, *d_apix = nullptr, *d_aout = nullptr, *d_asegs = nullptr;
     int4 *d_astack = nullptr;
@@ -523,8 +524,35 @@ struct fid_stag_ctx {
     // (16, doubling up to 256 while the misses go on; one fit after a pause brings it back to 16).  Results are the same either way.
     unsigned spec_hist = 0;  // the last queued frames, one bit each (1 = missed), newest in bit 0
     int spec_pause = 16, spec_skip = 0, spec_backoffs = 0;
+    char *d_slab = nullptr;  // every device buffer above is a piece of this one allocation (same offsets in every context of a size)
+    size_t slab_bytes = 0;
+    unsigned long long *d_words_slab = nullptr;  // the slab's room for the marker library (d_words points here when it fits)
+    char *pin_alias = nullptr;  // device alias of the pinned block hp
     int tile_kb_env = 0, no_sparse = 0;  // FID_STAG_TILE_KB (LDS a component's walk may ask for), FID_STAG_SPARSE=0
     int split_lds_env = -1;              // FID_STAG_SPLIT_LDS (pixels per wave of k_stag_split_lines that live in LDS)
+};
+
+#define STAG_WORDS_RESERVE (1u << 20)  // bytes of the slab kept for the marker library (HD11, the largest: 22 309 words)
+struct StagSlab {
+    struct Item {
+        void **p;
+        size_t off;
+    };
+    std::vector<Item> items;
+    size_t bytes = 0;
+    bool take(void **p, size_t b)
+    {
+        items.push_back({p, bytes});
+        bytes += (b + 255) & ~(size_t)255;  // (hipMalloc's own alignment, which the kernels' 16-byte accesses rely on)
+        return true;
+    }
+    bool commit(char **base, size_t *total)
+    {
+        if (hipMalloc((void **)base, bytes) != hipSuccess) return false;
+        for (const Item &i : items) *i.p = *base + i.off;
+        *total = bytes;
+        return true;
+    }
 };
 
 extern "C" {
@@ -550,36 +578,41 @@ fid_status fid_stag_create(int libraryHD, int errorCorrection, int max_width, in
     // (the context's stream is made when it is first needed -- stag_stream(): a pool of 64 frame slots works on four streams, and
     //  64 idle streams are 64 claims on the hardware queues this process shares with every other user of the GPU)
     bool ok = hipSetDevice(device) == hipSuccess;
-    ok = ok && hipMalloc((void **)&c->d_src, n) == hipSuccess && hipMalloc((void **)&c->d_smooth, n) == hipSuccess &&
-         hipMalloc((void **)&c->d_dir, n) == hipSuccess && hipMalloc((void **)&c->d_edge, n) == hipSuccess &&
-         hipMalloc((void **)&c->d_grad, n * 2) == hipSuccess && hipMalloc((void **)&c->d_sorted, n * 4) == hipSuccess &&
-         hipMalloc((void **)&c->d_rowhist, (size_t)max_height * STAG_BINS * 4) == hipSuccess &&
-         hipMalloc((void **)&c->d_bandhist, (size_t)((max_height + STAG_BAND_ROWS - 1) / STAG_BAND_ROWS) * STAG_BINS * 4) == hipSuccess &&
-         hipMalloc((void **)&c->d_tot, STAG_BINS * 4) == hipSuccess && hipMalloc((void **)&c->d_bstart, STAG_BINS * 4) == hipSuccess &&
-         hipMalloc((void **)&c->d_n, 4) == hipSuccess;
+    // Every device buffer of the context is a piece of ONE slab, laid out in the order of the takes below: two contexts made for the
+    // same image size have every buffer at the same OFFSET, so that frame f's pointer is frame 0's plus (slab_f - slab_0) -- which is
+    // what lets a group's launch carry frame 0's arguments once and 32 bytes per further frame (fid_stag_batch.h).
+    StagSlab slab;
+    int caps_host[16] = {0};
+    ok = ok && slab.take((void **)&c->d_src, n) && slab.take((void **)&c->d_smooth, n) &&
+         slab.take((void **)&c->d_dir, n) && slab.take((void **)&c->d_edge, n) &&
+         slab.take((void **)&c->d_grad, n * 2) && slab.take((void **)&c->d_sorted, n * 4) &&
+         slab.take((void **)&c->d_rowhist, (size_t)max_height * STAG_BINS * 4) &&
+         slab.take((void **)&c->d_bandhist, (size_t)((max_height + STAG_BAND_ROWS - 1) / STAG_BAND_ROWS) * STAG_BINS * 4) &&
+         slab.take((void **)&c->d_tot, STAG_BINS * 4) && slab.take((void **)&c->d_bstart, STAG_BINS * 4) &&
+         slab.take((void **)&c->d_n, 4);
     // routing: the reference sizes its scratch arrays for the worst case (width * height entries each, EDInternals.cpp:848-853)
-    ok = ok && hipMalloc((void **)&c->d_edgeimg, n) == hipSuccess && hipMalloc((void **)&c->d_rpix, n * sizeof(int2)) == hipSuccess &&
-         hipMalloc((void **)&c->d_outpix, n * sizeof(int2)) == hipSuccess && hipMalloc((void **)&c->d_segs, (n / 8 + 16) * sizeof(int2)) == hipSuccess &&
-         hipMalloc((void **)&c->d_rstack, n * sizeof(int4)) == hipSuccess && hipMalloc((void **)&c->d_chains, 32767 * sizeof(StagChain)) == hipSuccess &&
-         hipMalloc((void **)&c->d_chainnos, (size_t)(max_width + max_height) * 8 * sizeof(int)) == hipSuccess &&
-         hipMalloc((void **)&c->d_rcount, 16) == hipSuccess;
+    ok = ok && slab.take((void **)&c->d_edgeimg, n) && slab.take((void **)&c->d_rpix, n * sizeof(int2)) &&
+         slab.take((void **)&c->d_outpix, n * sizeof(int2)) && slab.take((void **)&c->d_segs, (n / 8 + 16) * sizeof(int2)) &&
+         slab.take((void **)&c->d_rstack, n * sizeof(int4)) && slab.take((void **)&c->d_chains, 32767 * sizeof(StagChain)) &&
+         slab.take((void **)&c->d_chainnos, (size_t)(max_width + max_height) * 8 * sizeof(int)) &&
+         slab.take((void **)&c->d_rcount, 16);
     // component-parallel routing: labels, per-root counters, component table, arenas (sizes in entries; see k_stag_comp_alloc)
     c->max_comps = (int)(n / 8 + 64);
     c->cap_aslots = (int)(n / 2 + 64);
-    ok = ok && hipMalloc((void **)&c->d_label, n * 4) == hipSuccess && hipMalloc((void **)&c->d_csize, n * 4) == hipSuccess &&
-         hipMalloc((void **)&c->d_canch, n * 4) == hipSuccess && hipMalloc((void **)&c->d_cidmap, n * 4) == hipSuccess && hipMalloc((void **)&c->d_cbox, n * sizeof(int4)) == hipSuccess &&
-         hipMalloc((void **)&c->d_cursors, 64) == hipSuccess && hipMalloc((void **)&c->d_caps, 64) == hipSuccess &&
-         hipMalloc((void **)&c->d_fill, (size_t)c->max_comps * 4) == hipSuccess && hipMalloc((void **)&c->d_aslots, (size_t)c->cap_aslots * 4) == hipSuccess &&
-         hipMalloc((void **)&c->d_prodflag, n * 4) == hipSuccess && hipMalloc((void **)&c->d_next, n * 4) == hipSuccess &&
-         hipMalloc((void **)&c->d_blkpix, n * 4) == hipSuccess && hipMalloc((void **)&c->d_blksegs, n * 4) == hipSuccess &&
-         hipMalloc((void **)&c->d_blkwhere, n * sizeof(int2)) == hipSuccess && hipMalloc((void **)&c->d_apix, 3 * n * sizeof(int2)) == hipSuccess &&
-         hipMalloc((void **)&c->d_aout, 3 * n * sizeof(int2)) == hipSuccess && hipMalloc((void **)&c->d_asegs, (n / 2 + 64) * sizeof(int2)) == hipSuccess &&
-         hipMalloc((void **)&c->d_astack, 2 * n * sizeof(int4)) == hipSuccess && hipMalloc((void **)&c->d_achains, 2 * n * sizeof(StagChain)) == hipSuccess &&
-         hipMalloc((void **)&c->d_comps, (size_t)c->max_comps * sizeof(StagComp)) == hipSuccess &&
-         hipMalloc((void **)&c->d_recs, (size_t)c->cap_aslots * sizeof(StagRec)) == hipSuccess;
+    ok = ok && slab.take((void **)&c->d_label, n * 4) && slab.take((void **)&c->d_csize, n * 4) &&
+         slab.take((void **)&c->d_canch, n * 4) && slab.take((void **)&c->d_cidmap, n * 4) && slab.take((void **)&c->d_cbox, n * sizeof(int4)) &&
+         slab.take((void **)&c->d_cursors, 64) && slab.take((void **)&c->d_caps, 64) &&
+         slab.take((void **)&c->d_corder, (size_t)c->max_comps * 4) && slab.take((void **)&c->d_fill, (size_t)c->max_comps * 4) && slab.take((void **)&c->d_aslots, (size_t)c->cap_aslots * 4) &&
+         slab.take((void **)&c->d_prodflag, n * 4) && slab.take((void **)&c->d_next, n * 4) &&
+         slab.take((void **)&c->d_blkpix, n * 4) && slab.take((void **)&c->d_blksegs, n * 4) &&
+         slab.take((void **)&c->d_blkwhere, n * sizeof(int2)) && slab.take((void **)&c->d_apix, 3 * n * sizeof(int2)) &&
+         slab.take((void **)&c->d_aout, 3 * n * sizeof(int2)) && slab.take((void **)&c->d_asegs, (n / 2 + 64) * sizeof(int2)) &&
+         slab.take((void **)&c->d_astack, 2 * n * sizeof(int4)) && slab.take((void **)&c->d_achains, 2 * n * sizeof(StagChain)) &&
+         slab.take((void **)&c->d_comps, (size_t)c->max_comps * sizeof(StagComp)) &&
+         slab.take((void **)&c->d_recs, (size_t)c->cap_aslots * sizeof(StagRec));
     if (ok) {
         const int caps[16] = {c->max_comps, c->cap_aslots, (int)(3 * n), (int)(2 * n), (int)(2 * n), (int)(3 * n), (int)(n / 2 + 64), 0};
-        ok = hipMemcpy(c->d_caps, caps, sizeof(caps), hipMemcpyHostToDevice) == hipSuccess;
+        memcpy(caps_host, caps, sizeof(caps));  // (uploaded below, when the slab exists)
         const char *e = getenv("FID_STAG_ROUTE");
         c->route_mode = (e && !strcmp(e, "seq")) ? 0 : 1;
         c->route_tile = (e && !strcmp(e, "notile")) ? 0 : 1;  // "notile": component-parallel, walks in global memory
@@ -589,7 +622,7 @@ fid_status fid_stag_create(int libraryHD, int errorCorrection, int max_width, in
         c->no_sparse = sp && atoi(sp) == 0 ? 1 : 0;
         const char *sl = getenv("FID_STAG_SPLIT_LDS");
         c->split_lds_env = sl ? atoi(sl) : -1;
-        ok = hipFuncSetAttribute((const void *)k_stag_route_walk, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) == hipSuccess &&
+        ok = ok && hipFuncSetAttribute((const void *)k_stag_route_walk, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) == hipSuccess &&
              hipFuncSetAttribute((const void *)k_stag_comp_sort_big, hipFuncAttributeMaxDynamicSharedMemorySize, STAG_SORT_BIG * 4) == hipSuccess &&
              // (and their group-mode trampolines, fid_stag_batch.h)
              hipFuncSetAttribute((const void *)k_stag_batch<k_stag_route_walk_fn>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) == hipSuccess &&
@@ -601,31 +634,33 @@ fid_status fid_stag_create(int libraryHD, int errorCorrection, int max_width, in
                     StagTab<k_stag_route_walk_fn>::kMax, StagTab<k_stag_route_extract_fn>::kMax, StagTab<k_stag_quads_fn>::kMax,
                     StagTab<k_stag_decode_fn>::kMax, StagTab<k_stag_smooth_grad_fn>::kMax);
     }
-    ok = ok && hipMalloc((void **)&c->d_smooth2, n) == hipSuccess && hipMalloc((void **)&c->d_vgrad, n * 2) == hipSuccess &&
-         hipMalloc((void **)&c->d_vhist, STAG_BINS * 4) == hipSuccess && hipMalloc((void **)&c->d_prob, STAG_BINS * 8) == hipSuccess &&
-         hipMalloc((void **)&c->d_np, 4) == hipSuccess && hipMalloc((void **)&c->d_vcounts, (n / 8 + 16) * 4) == hipSuccess &&
-         hipMalloc((void **)&c->d_vtotal, 4) == hipSuccess && hipMalloc((void **)&c->d_vstack, n * sizeof(int2)) == hipSuccess &&
-         hipMalloc((void **)&c->d_vsegs, (n / 8 + 16) * sizeof(int2)) == hipSuccess;
+    ok = ok && slab.take((void **)&c->d_smooth2, n) && slab.take((void **)&c->d_vgrad, n * 2) &&
+         slab.take((void **)&c->d_vhist, STAG_BINS * 4) && slab.take((void **)&c->d_prob, STAG_BINS * 8) &&
+         slab.take((void **)&c->d_np, 4) && slab.take((void **)&c->d_vcounts, (n / 8 + 16) * 4) &&
+         slab.take((void **)&c->d_vtotal, 4) && slab.take((void **)&c->d_vstack, n * sizeof(int2)) &&
+         slab.take((void **)&c->d_vsegs, (n / 8 + 16) * sizeof(int2));
     c->prefcap = n + n / 8 + 64;
-    ok = ok && hipMalloc((void **)&c->d_prefix, c->prefcap * 5 * sizeof(long long)) == hipSuccess &&
-         hipMalloc((void **)&c->d_lslots, (n / 9 + 16) * sizeof(fid_stag_line)) == hipSuccess &&
-         hipMalloc((void **)&c->d_lines, (n / 9 + 16) * sizeof(fid_stag_line)) == hipSuccess &&
-         hipMalloc((void **)&c->d_lcounts, (n / 8 + 16) * 4) == hipSuccess && hipMalloc((void **)&c->d_ltotal, 4) == hipSuccess;
-    ok = ok && hipMalloc((void **)&c->d_atan_lut, 1025 * 8) == hipSuccess &&
-         hipMalloc((void **)&c->d_kmin, (size_t)(4 * (max_width + max_height) + 16) * 4) == hipSuccess &&
-         hipMalloc((void **)&c->d_lflags, (n / 9 + 16) * 4) == hipSuccess && hipMalloc((void **)&c->d_vltotal, 4) == hipSuccess &&
-         hipMalloc((void **)&c->d_vlines, (n / 9 + 16) * sizeof(fid_stag_line)) == hipSuccess;
-    ok = ok && hipMalloc((void **)&c->d_lrange, (n / 8 + 16) * sizeof(int2)) == hipSuccess &&
-         hipMalloc((void **)&c->d_corners, (n / 9 + 16) * sizeof(StagCorner)) == hipSuccess &&
-         hipMalloc((void **)&c->d_order, (n / 9 + 16) * 4) == hipSuccess && hipMalloc((void **)&c->d_qcounts, (n / 8 + 16) * 4) == hipSuccess &&
-         hipMalloc((void **)&c->d_qtotal, 4) == hipSuccess && hipMalloc((void **)&c->d_qslots, (n / 9 + 16) * sizeof(fid_stag_quad)) == hipSuccess &&
-         hipMalloc((void **)&c->d_quads, (n / 9 + 16) * sizeof(fid_stag_quad)) == hipSuccess;
-    ok = ok && hipMalloc((void **)&c->d_locs, 72 * 3 * 8) == hipSuccess && hipMalloc((void **)&c->d_cand, (n / 9 + 16) * sizeof(fid_stag_marker)) == hipSuccess &&
-         hipMalloc((void **)&c->d_markers, (n / 9 + 16) * sizeof(fid_stag_marker)) == hipSuccess &&
-         hipMalloc((void **)&c->d_found, (n / 9 + 16) * 4) == hipSuccess && hipMalloc((void **)&c->d_nmarkers, 4) == hipSuccess;
-    ok = ok && hipMalloc((void **)&c->d_specbad, 16) == hipSuccess && hipMemset(c->d_specbad, 0, 16) == hipSuccess;
-    ok = ok && hipMalloc((void **)&c->d_chosen, (n / 9 + 16) * 4) == hipSuccess &&
-         hipMalloc((void **)&c->d_poses, (n / 9 + 16) * sizeof(fid_stag_pose_out)) == hipSuccess;
+    ok = ok && slab.take((void **)&c->d_prefix, c->prefcap * 5 * sizeof(long long)) &&
+         slab.take((void **)&c->d_lslots, (n / 9 + 16) * sizeof(fid_stag_line)) &&
+         slab.take((void **)&c->d_lines, (n / 9 + 16) * sizeof(fid_stag_line)) &&
+         slab.take((void **)&c->d_lcounts, (n / 8 + 16) * 4) && slab.take((void **)&c->d_ltotal, 4);
+    ok = ok && slab.take((void **)&c->d_atan_lut, 1025 * 8) &&
+         slab.take((void **)&c->d_kmin, (size_t)(4 * (max_width + max_height) + 16) * 4) &&
+         slab.take((void **)&c->d_lflags, (n / 9 + 16) * 4) && slab.take((void **)&c->d_vltotal, 4) &&
+         slab.take((void **)&c->d_vlines, (n / 9 + 16) * sizeof(fid_stag_line));
+    ok = ok && slab.take((void **)&c->d_lrange, (n / 8 + 16) * sizeof(int2)) &&
+         slab.take((void **)&c->d_corners, (n / 9 + 16) * sizeof(StagCorner)) &&
+         slab.take((void **)&c->d_order, (n / 9 + 16) * 4) && slab.take((void **)&c->d_qcounts, (n / 8 + 16) * 4) &&
+         slab.take((void **)&c->d_qtotal, 4) && slab.take((void **)&c->d_qslots, (n / 9 + 16) * sizeof(fid_stag_quad)) &&
+         slab.take((void **)&c->d_quads, (n / 9 + 16) * sizeof(fid_stag_quad));
+    ok = ok && slab.take((void **)&c->d_locs, 72 * 3 * 8) && slab.take((void **)&c->d_cand, (n / 9 + 16) * sizeof(fid_stag_marker)) &&
+         slab.take((void **)&c->d_markers, (n / 9 + 16) * sizeof(fid_stag_marker)) &&
+         slab.take((void **)&c->d_found, (n / 9 + 16) * 4) && slab.take((void **)&c->d_nmarkers, 4);
+    ok = ok && slab.take((void **)&c->d_specbad, 16) && slab.take((void **)&c->d_words_slab, STAG_WORDS_RESERVE);
+    ok = ok && slab.take((void **)&c->d_chosen, (n / 9 + 16) * 4) &&
+         slab.take((void **)&c->d_poses, (n / 9 + 16) * sizeof(fid_stag_pose_out));
+    ok = ok && slab.commit(&c->d_slab, &c->slab_bytes);
+    ok = ok && hipMemcpy(c->d_caps, caps_host, sizeof(caps_host), hipMemcpyHostToDevice) == hipSuccess && hipMemset(c->d_specbad, 0, 16) == hipSuccess;
     ok = ok && hipHostMalloc((void **)&c->hp, sizeof(fid_stag_ctx::Pinned), hipHostMallocDefault) == hipSuccess &&
          hipHostMalloc((void **)&c->h_src, n, hipHostMallocDefault) == hipSuccess;
     if (ok) {  // group mode writes the per-segment counters straight into the pinned block (fid_stag_batch.h)
@@ -633,6 +668,7 @@ fid_status fid_stag_create(int libraryHD, int errorCorrection, int max_width, in
         if (hipHostGetDevicePointer(&dev, c->hp, 0) == hipSuccess && dev) {
             std::lock_guard<std::mutex> g(g_stag_alias_mutex);
             g_stag_aliases.push_back({(const char *)c->hp, sizeof(fid_stag_ctx::Pinned), (char *)dev});
+            c->pin_alias = (char *)dev;
         }
     }
     if (ok) {
@@ -658,17 +694,8 @@ void fid_stag_destroy(fid_stag_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    void *dev[] = {c->d_src, c->d_smooth, c->d_dir, c->d_edge, c->d_grad, c->d_sorted, c->d_rowhist, c->d_bandhist, c->d_tot, c->d_bstart, c->d_n,
-                   c->d_edgeimg, c->d_rpix, c->d_outpix, c->d_segs, c->d_rstack, c->d_chains, c->d_chainnos, c->d_rcount,
-                   c->d_label, c->d_csize, c->d_canch, c->d_cbox, c->d_cidmap, c->d_cursors, c->d_caps, c->d_fill, c->d_aslots, c->d_prodflag, c->d_next,
-                   c->d_blkpix, c->d_blksegs, c->d_blkwhere, c->d_apix, c->d_aout, c->d_asegs, c->d_astack, c->d_achains, c->d_comps, c->d_recs,
-                   c->d_smooth2, c->d_vgrad, c->d_vhist, c->d_prob, c->d_np, c->d_vcounts, c->d_vtotal, c->d_vstack, c->d_vsegs,
-                   c->d_prefix, c->d_lslots, c->d_lines, c->d_lcounts, c->d_ltotal,
-                   c->d_atan_lut, c->d_kmin, c->d_lflags, c->d_vltotal, c->d_vlines,
-                   c->d_lrange, c->d_corners, c->d_order, c->d_qcounts, c->d_qtotal, c->d_qslots, c->d_quads,
-                   c->d_locs, c->d_words, c->d_cand, c->d_markers, c->d_found, c->d_nmarkers, c->d_chosen, c->d_poses, c->d_specbad};
-    for (void *p : dev)
-        if (p) (void)hipFree(p);
+    if (c->d_words && c->d_words != c->d_words_slab) (void)hipFree(c->d_words);  // (a library larger than the slab's room for it)
+    if (c->d_slab) (void)hipFree(c->d_slab);
     if (c->hp) {
         std::lock_guard<std::mutex> g(g_stag_alias_mutex);
         for (size_t k = 0; k < g_stag_aliases.size(); k++)
@@ -714,6 +741,7 @@ struct StagJob {
     StagRoute R;
     // queued ahead: every launch of the frame sized by j.use (the context's last counts with a margin), one wait at the end
     bool spec = false, nospec = false;
+    bool staged = false;  // the frame's rows are in the context's pinned staging buffer already (the group driver copies a group's frames with several threads)
     StagPred use;
     int lds_cap = 0;
 };
@@ -896,7 +924,8 @@ static fid_status stag_advance_impl(fid_stag_ctx *c, StagJob &j)
             j.spec = false;
         }
         if (j.spec) stag_plan(c, j);
-        for (int y = 0; y < H; y++) memcpy(c->h_src + (size_t)y * W, j.gray + (size_t)y * j.stride, (size_t)W);
+        if (!j.staged)
+            for (int y = 0; y < H; y++) memcpy(c->h_src + (size_t)y * W, j.gray + (size_t)y * j.stride, (size_t)W);
         if (STAG_MEMCPY(c->d_src, c->h_src, (size_t)W * H, hipMemcpyHostToDevice, st) != hipSuccess) return stag_finish(j, FID_E_HIP);
         if (STAG_MEMSET(c->d_rowhist, 0, (size_t)H * STAG_BINS * 2, st) != hipSuccess) return stag_finish(j, FID_E_HIP);
         STAG_LAUNCH(k_stag_smooth_grad, dim3((W + SX - 1) / SX, (H + SY - 1) / SY), dim3(256), 0, st, c->d_src, W, W, H, GRADIENT_THRESH,
@@ -956,9 +985,11 @@ static fid_status stag_advance_impl(fid_stag_ctx *c, StagJob &j)
             unsigned most = 0;
             for (int k = 0; k < 6; k++) {
                 F.p[k] = (uint4 *)ptr[k];
-                F.n16[k] = (unsigned)((bytes[k] + 15) / 16);
+                const unsigned n16 = (unsigned)((bytes[k] + 15) / 16);
+                if (k < 3) F.n16[k] = n16;
+                else F.na16 = n16;  // (the three of them are sized by the frame's anchors)
                 F.v[k] = val[k];
-                most = F.n16[k] > most ? F.n16[k] : most;
+                most = n16 > most ? n16 : most;
             }
             STAG_LAUNCH(k_stag_fills, dim3((most + 255) / 256), dim3(256), 0, st, F);
         }
@@ -980,7 +1011,7 @@ static fid_status stag_advance_impl(fid_stag_ctx *c, StagJob &j)
         const int tile_kb = c->tile_kb_env > 0 ? c->tile_kb_env : (grouped ? 37 : 150);  // (37 KB + the walk's 2 KB of stack: four workgroups per CU)
         const int LDS_CAP = (tile_kb < 8 ? 8 : (tile_kb > 150 ? 150 : tile_kb)) * 1024;
         j.lds_cap = LDS_CAP;
-        STAG_LAUNCH(k_stag_comp_tilemax, dim3((c->max_comps + 255) / 256), dim3(256), 0, st, c->d_comps, c->d_cursors, LDS_CAP);
+        STAG_LAUNCH(k_stag_comp_tilemax, dim3((c->max_comps + 255) / 256), dim3(256), 0, st, c->d_comps, c->d_cursors, LDS_CAP, c->d_corder);
         if (hipGetLastError() != hipSuccess) return stag_finish(j, FID_E_HIP);
         if (!j.spec && STAG_MEMCPY(c->hp->cur, c->d_cursors, 44, hipMemcpyDeviceToHost, st) != hipSuccess) return stag_finish(j, FID_E_HIP);
         if (j.spec) {
@@ -1027,14 +1058,30 @@ static fid_status stag_advance_impl(fid_stag_ctx *c, StagJob &j)
                 // LDS per workgroup = the largest tile a component of this frame asks for (components whose box does not fit 150 KB
                 // walk in global memory): frames of small components keep many workgroups per CU
                 const int no_sparse = c->no_sparse;  // (FID_STAG_SPARSE=0: no blocks, the walk in global memory)
-                const int lds = c->route_tile ? ((cur[10] + 1023) / 1024) * 1024 : 0;
-                STAG_LAUNCH(k_stag_route_walk, dim3(nc), dim3(256), (size_t)lds, st, j.R, A, c->d_comps, c->d_cursors, c->d_sorted, c->d_aslots,
-                                   c->d_label, 16, lds | no_sparse, c->d_prodflag, ovf);
+                // (a group: every frame asks for the cap -- one value for the whole launch, which allocates the largest request anyway,
+                //  and at 99 VGPRs the kernel holds four workgroups per CU whether they own 8 or 37 KB)
+                const int lds = !c->route_tile ? 0 : (grouped ? j.lds_cap : ((cur[10] + 1023) / 1024) * 1024);
+                if (grouped && c->route_tile && lds > STAG_SMALL_TILE) {
+                    // (two launches by class: see k_stag_route_walk_impl; both grids cover every rank, a workgroup beyond its class returns)
+                    STAG_LAUNCH(k_stag_route_walk, dim3(nc), dim3(256), (size_t)lds, st, j.R, A, c->d_comps, c->d_cursors, c->d_corder, c->d_sorted,
+                                       c->d_aslots, c->d_label, 16, lds | no_sparse, c->d_prodflag, ovf, 1);
+                    STAG_LAUNCH(k_stag_route_walk, dim3(nc), dim3(256), (size_t)STAG_SMALL_TILE, st, j.R, A, c->d_comps, c->d_cursors, c->d_corder,
+                                       c->d_sorted, c->d_aslots, c->d_label, 16, STAG_SMALL_TILE | no_sparse, c->d_prodflag, ovf, 2);
+                } else {
+                    STAG_LAUNCH(k_stag_route_walk, dim3(nc), dim3(256), (size_t)lds, st, j.R, A, c->d_comps, c->d_cursors, c->d_corder, c->d_sorted,
+                                       c->d_aslots, c->d_label, 16, lds | no_sparse, c->d_prodflag, ovf, 0);
+                }
             }
             STAG_LAUNCH(k_stag_next_above, dim3(1), dim3(1024), 0, st, c->d_prodflag, c->d_n, c->d_next);
-            if (nc > 0)
-                STAG_LAUNCH(k_stag_route_extract, dim3((nc + 3) / 4), dim3(256), 0, st, j.R, A, c->d_comps, c->d_cursors, c->d_next, c->d_n,
-                                   c->d_blkpix, c->d_blksegs, c->d_blkwhere, ovf);
+            if (nc > 0 && grouped) {  // (two launches by class, like the walk: the big components, then the small ones four workgroups to a CU)
+                STAG_LAUNCH(k_stag_route_extract, dim3((nc + 3) / 4), dim3(256), 0, st, j.R, A, c->d_comps, c->d_cursors, c->d_corder, c->d_next,
+                                   c->d_n, c->d_blkpix, c->d_blksegs, c->d_blkwhere, ovf, 1);
+                STAG_LAUNCH(k_stag_route_extract_small, dim3((nc + 3) / 4), dim3(256), 0, st, j.R, A, c->d_comps, c->d_cursors, c->d_corder,
+                                   c->d_next, c->d_n, c->d_blkpix, c->d_blksegs, c->d_blkwhere, ovf, 2);
+            } else if (nc > 0) {
+                STAG_LAUNCH(k_stag_route_extract, dim3((nc + 3) / 4), dim3(256), 0, st, j.R, A, c->d_comps, c->d_cursors, c->d_corder, c->d_next,
+                                   c->d_n, c->d_blkpix, c->d_blksegs, c->d_blkwhere, ovf, 0);
+            }
             {
                 StagScanJobs sj;
                 sj.counts[0] = c->d_blkpix; sj.total[0] = c->d_rcount + 1;
@@ -1399,10 +1446,11 @@ fid_status fid_stag_load_library(fid_stag_ctx *c, const uint64_t *codewords, int
 {
     if (!c || !codewords || n_codewords <= 0 || (n_codewords & 3)) return FID_E_INVALID_ARG;
     if (hipSetDevice(c->device) != hipSuccess) return FID_E_HIP;
-    if (c->d_words) (void)hipFree(c->d_words);
+    if (c->d_words && c->d_words != c->d_words_slab) (void)hipFree(c->d_words);
     c->d_words = nullptr;
     c->n_words = 0;
-    if (hipMalloc((void **)&c->d_words, (size_t)n_codewords * 8) != hipSuccess) return FID_E_OUT_OF_MEMORY;
+    if ((size_t)n_codewords * 8 <= STAG_WORDS_RESERVE) c->d_words = c->d_words_slab;  // (inside the slab: a group's launches merge)
+    else if (hipMalloc((void **)&c->d_words, (size_t)n_codewords * 8) != hipSuccess) return FID_E_OUT_OF_MEMORY;
     if (hipMemcpy(c->d_words, codewords, (size_t)n_codewords * 8, hipMemcpyHostToDevice) != hipSuccess) return FID_E_HIP;
     c->n_words = n_codewords;
     return FID_OK;
@@ -1455,10 +1503,15 @@ static fid_status stag_batch_groups(fid_stag_ctx *const *ctxs, int32_t nctx, con
 {
     // a group is at most as large as the smallest argument table (the routing kernels carry ~250 bytes of arguments per frame and
     // kernel-argument memory is 4 KB: a group one frame larger would launch them twice)
-    constexpr int kGroupMax = std::min({StagTab<k_stag_route_walk_fn>::kMax, StagTab<k_stag_route_extract_fn>::kMax, StagTab<k_stag_route_gather_fn>::kMax,
+    constexpr int kGroupMax = std::min({StagTab<k_stag_route_walk_fn>::kMax, StagTab<k_stag_route_extract_fn>::kMax, StagTab<k_stag_route_extract_small_fn>::kMax, StagTab<k_stag_route_gather_fn>::kMax,
                                         StagTab<k_stag_quads_fn>::kMax, StagTab<k_stag_decode_fn>::kMax, StagTab<k_stag_validate_lines_fn>::kMax,
                                         StagTab<k_stag_split_lines_fn>::kMax, StagTab<k_stag_refine_fn>::kMax, (int)STAG_MAXF});
-    int gs = nctx >= 4 ? nctx / 2 : nctx;  // two groups (or more) so that one group's host round runs under another's kernels
+    // Group size.  More frames per launch make the whole-image passes cheaper per frame (a group of 16 costs 305 us of kernel time a
+    // frame, 32: 212, 64: 164 -- profiles/r06_stag_group_sizes.txt) and the latency-bound kernels carry more frames for the same
+    // duration while workgroup slots last; more GROUPS keep more kernels in flight, one's long walks under another's image passes.
+    // Measured on 256 slots / 1 024 frames: 16 x 16: 6.5 k frames/s, 8 x 32: 7.3 k, 4 x 64: 6.9 - 7.1 k, 2 x 112: 5.6 k; on 128 slots:
+    // 8 x 16: 5.5 k, 4 x 32: 6.4 - 6.6 k, 2 x 64: 5.4 - 6.1 k.  So: 32 where the pool has at least two such groups, else two groups.
+    int gs = nctx >= 64 ? 32 : (nctx >= 4 ? nctx / 2 : nctx);
     if (const char *e = getenv("FID_STAG_GROUP")) gs = atoi(e);
     gs = gs < 1 ? 1 : (gs > kGroupMax ? kGroupMax : (gs > nctx ? nctx : gs));
     const int ngroups = nctx / gs;
@@ -1467,12 +1520,16 @@ static fid_status stag_batch_groups(fid_stag_ctx *const *ctxs, int32_t nctx, con
     int nthreads = ngroups;
     if (const char *e = getenv("FID_STAG_THREADS")) nthreads = atoi(e);
     nthreads = nthreads < 1 ? 1 : (nthreads > ngroups ? ngroups : nthreads);
+    // helper threads that stage a group's new frames (FID_STAG_STAGE_THREADS; default: the host's cores shared out among the groups, 1 - 8)
+    int stage_threads = (int)std::thread::hardware_concurrency() / (nthreads > 0 ? nthreads : 1);
+    if (const char *e = getenv("FID_STAG_STAGE_THREADS")) stage_threads = atoi(e);
+    stage_threads = stage_threads < 1 ? 1 : (stage_threads > 8 ? 8 : stage_threads);
     std::atomic<int> next(0);
     std::atomic<bool> stop(false), hip_failed(false);
     std::mutex err_mutex;
     fid_status first_err = FID_OK;
     const bool verbose = getenv("FID_VERBOSE") != nullptr;
-    std::atomic<long long> ns_wait(0), ns_host(0), ns_flush(0), n_rec(0), n_iss(0);
+    std::atomic<long long> ns_wait(0), ns_host(0), ns_flush(0), n_rec(0), n_iss(0), n_unm(0);
     auto worker = [&](int tid) {
         struct Group {
             std::vector<StagJob> jobs;
@@ -1518,6 +1575,27 @@ static fid_status stag_batch_groups(fid_stag_ctx *const *ctxs, int32_t nctx, con
                         G.frame_of[k] = f;
                         G.live++;
                     }
+                    // the frames' rows into the contexts' pinned staging buffers, side by side: 2 MB of memcpy per 1080p frame is
+                    // ~0.1 ms, and one thread doing it for a group of 64 kept the group's stream empty for 6 ms of every cycle
+                    if (stage_threads > 1 && G.live > 1 && width >= 8 && height >= 8 && width <= ctxs[g * gs]->maxW && height <= ctxs[g * gs]->maxH &&
+                        stride >= width) {
+                        const int nlive = G.live;
+                        auto stage = [&](int t, int T) {
+                            for (int k = t; k < nlive; k += T) {
+                                fid_stag_ctx *c = ctxs[g * gs + k];
+                                const uint8_t *src = G.jobs[k].gray;
+                                if ((size_t)stride == (size_t)width) memcpy(c->h_src, src, (size_t)width * height);
+                                else
+                                    for (int y = 0; y < height; y++) memcpy(c->h_src + (size_t)y * width, src + (size_t)y * stride, (size_t)width);
+                                G.jobs[k].staged = true;
+                            }
+                        };
+                        const int T = stage_threads < nlive ? stage_threads : nlive;
+                        std::vector<std::thread> helpers;
+                        for (int t = 1; t < T; t++) helpers.emplace_back(stage, t, T);
+                        stage(0, T);
+                        for (auto &h : helpers) h.join();
+                    }
                 } else {
                     const auto t0 = now();
                     if (hipStreamSynchronize(G.stream) != hipSuccess) {
@@ -1537,6 +1615,8 @@ static fid_status stag_batch_groups(fid_stag_ctx *const *ctxs, int32_t nctx, con
                     fid_stag_ctx *c = ctxs[g * gs + k];
                     c->group_stream = G.stream;
                     R.frame_last_site = -1;  // (a new frame's round: its sites must come in increasing order, stag_order_guard)
+                    R.slab = c->d_slab; R.slab_bytes = c->slab_bytes;  // (what this frame's pointers are measured against)
+                    R.pin = c->pin_alias; R.pin_bytes = sizeof(fid_stag_ctx::Pinned);
                     (void)stag_advance(c, G.jobs[k]);
                 }
                 R.on = false;
@@ -1567,6 +1647,7 @@ static fid_status stag_batch_groups(fid_stag_ctx *const *ctxs, int32_t nctx, con
         }
         n_rec += R.recorded_launches;
         n_iss += R.merged_launches;
+        n_unm += R.unmergeable;
     };
     if (nthreads == 1) {
         worker(0);
@@ -1582,8 +1663,8 @@ static fid_status stag_batch_groups(fid_stag_ctx *const *ctxs, int32_t nctx, con
         return FID_E_HIP;
     }
     if (verbose)
-        fprintf(stderr, "fid stag batch: %d frames, %d group(s) of %d (at most %d), %d host thread(s): %lld launches recorded, %lld issued; host ms (all threads): waiting %.2f, frames' host parts %.2f, issuing %.2f\n",
-                nframes, ngroups, gs, kGroupMax, nthreads, n_rec.load(), n_iss.load(), ns_wait.load() * 1e-6, ns_host.load() * 1e-6, ns_flush.load() * 1e-6);
+        fprintf(stderr, "fid stag batch: %d frames, %d group(s) of %d (at most %d), %d host thread(s): %lld launches recorded, %lld issued (%lld times a frame's arguments did not fit the launch open at its site); host ms (all threads): waiting %.2f, frames' host parts %.2f, issuing %.2f\n",
+                nframes, ngroups, gs, kGroupMax, nthreads, n_rec.load(), n_iss.load(), n_unm.load(), ns_wait.load() * 1e-6, ns_host.load() * 1e-6, ns_flush.load() * 1e-6);
     return first_err;
 }
 

@@ -263,6 +263,11 @@ struct k_stag_extract_fn {
 struct StagScanJobs {
     int *counts[2];
     int *total[2];
+    template <class V>
+    __host__ __device__ __forceinline__ void visit(V &&v)
+    {
+        v(counts); v(total);
+    }
 };
 __device__ __forceinline__ void k_stag_scan_counts_n_impl(StagScanJobs J, const int *__restrict__ counters)
 {
@@ -362,6 +367,11 @@ struct k_stag_scan_counts_fn {
 // with -ffp-contract=off).
 struct StagPrefix {  // prefix sums over the pixels of one segment, index k = sum over pixels < k
     long long *x, *y, *xx, *yy, *xy;
+    template <class V>
+    __host__ __device__ __forceinline__ void visit(V &&v)
+    {
+        v(x); v(y); v(xx); v(yy); v(xy);
+    }
 };
 
 __device__ double sl_min_dist(double x1, double y1, double a, double b, int invert, double *cx = nullptr, double *cy = nullptr)
@@ -699,13 +709,14 @@ __device__ __forceinline__ void sl_split_body(const Src &P, int n, int seg, int 
 // 256 for a group of frames (37 KB: four workgroups per CU stay resident), 0: every segment on the global road
 __host__ __device__ constexpr int sl_lds_wave_bytes(int lds_pix) { return ((lds_pix + 1) * (3 * 4 + 3 * 8) + 63) & ~63; }
 #define SL_LDS_BYTES(lds_pix) ((lds_pix) > 0 ? 4 * sl_lds_wave_bytes(lds_pix) : 0)
+template <bool FM = false>
 __device__ __forceinline__ void k_stag_split_lines_impl(const int2 *__restrict__ segs, const int *__restrict__ nsegs, const int2 *__restrict__ pix,
                                                           StagPrefix PF, int min_line_len, double line_error, fid_stag_line *__restrict__ slots,
                                                           int *__restrict__ counts, int lds_pix)
 {
     extern __shared__ long long s_sl[];
     const int wv = threadIdx.x >> 6;
-    const int seg = blockIdx.x * 4 + wv, lane = threadIdx.x & 63;
+    const int seg = (int)STAG_BX<FM>() * 4 + wv, lane = threadIdx.x & 63;
     if (seg >= *nsegs) return;
     const int first = segs[seg].x, n = segs[seg].y;
     const int2 *px = pix + first;
@@ -778,7 +789,8 @@ __global__ __launch_bounds__(256) void k_stag_split_lines(const int2 *__restrict
 }
 struct k_stag_split_lines_fn {
     static constexpr int kBounds = 256;
-    __device__ __forceinline__ void operator()(const int2 *__restrict__ segs, const int *__restrict__ nsegs, const int2 *__restrict__ pix, StagPrefix PF, int min_line_len, double line_error, fid_stag_line *__restrict__ slots, int *__restrict__ counts, int lds_pix) const { k_stag_split_lines_impl(segs, nsegs, pix, PF, min_line_len, line_error, slots, counts, lds_pix); }
+    static constexpr bool kFrameMinor = true;
+    __device__ __forceinline__ void operator()(const int2 *__restrict__ segs, const int *__restrict__ nsegs, const int2 *__restrict__ pix, StagPrefix PF, int min_line_len, double line_error, fid_stag_line *__restrict__ slots, int *__restrict__ counts, int lds_pix) const { k_stag_split_lines_impl<true>(segs, nsegs, pix, PF, min_line_len, line_error, slots, counts, lds_pix); }
 };
 
 // the lines of every segment, one after the other in segment order (counts hold exclusive prefix sums by now)
@@ -813,6 +825,11 @@ struct StagLineTables {
     const double *atan_lut;  // 1025 entries
     const int *kmin;         // kmin[n]: smallest number of aligned pixels out of n that validates; n <= kmin_n
     int kmin_n;
+    template <class V>
+    __host__ __device__ __forceinline__ void visit(V &&v)
+    {
+        v(atan_lut); v(kmin); v(kmin_n);
+    }
 };
 
 __device__ double sl_my_atan2(const double *lut, double yy, double xx)

@@ -254,12 +254,13 @@ struct k_stag_line_ranges_fn {
     __device__ __forceinline__ void operator()(const fid_stag_line *__restrict__ lines, const int *__restrict__ nlines, int2 *__restrict__ range) const { k_stag_line_ranges_impl(lines, nlines, range); }
 };
 
+template <bool FM = false>
 __device__ __forceinline__ void k_stag_quads_impl(fid_stag_line *__restrict__ lines, const int2 *__restrict__ range, const int *__restrict__ nsegs,
                                                     const int2 *__restrict__ vsegs, const int2 *__restrict__ pix, const uint8_t *__restrict__ img, int W,
                                                     int H, StagCorner *__restrict__ corner_slots, int *__restrict__ order_slots,
                                                     fid_stag_quad *__restrict__ quad_slots, int *__restrict__ counts)
 {
-    const int seg = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int seg = (int)STAG_BX<FM>() * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (seg >= *nsegs) return;
     const int lo = range[seg].x, n = range[seg].y - lo;
     if (lane == 0) counts[seg] = 0;
@@ -335,7 +336,8 @@ __global__ __launch_bounds__(256) void k_stag_quads(fid_stag_line *__restrict__ 
 }
 struct k_stag_quads_fn {
     static constexpr int kBounds = 256;
-    __device__ __forceinline__ void operator()(fid_stag_line *__restrict__ lines, const int2 *__restrict__ range, const int *__restrict__ nsegs, const int2 *__restrict__ vsegs, const int2 *__restrict__ pix, const uint8_t *__restrict__ img, int W, int H, StagCorner *__restrict__ corner_slots, int *__restrict__ order_slots, fid_stag_quad *__restrict__ quad_slots, int *__restrict__ counts) const { k_stag_quads_impl(lines, range, nsegs, vsegs, pix, img, W, H, corner_slots, order_slots, quad_slots, counts); }
+    static constexpr bool kFrameMinor = true;
+    __device__ __forceinline__ void operator()(fid_stag_line *__restrict__ lines, const int2 *__restrict__ range, const int *__restrict__ nsegs, const int2 *__restrict__ vsegs, const int2 *__restrict__ pix, const uint8_t *__restrict__ img, int W, int H, StagCorner *__restrict__ corner_slots, int *__restrict__ order_slots, fid_stag_quad *__restrict__ quad_slots, int *__restrict__ counts) const { k_stag_quads_impl<true>(lines, range, nsegs, vsegs, pix, img, W, H, corner_slots, order_slots, quad_slots, counts); }
 };
 
 __device__ __forceinline__ void k_stag_gather_quads_impl(const int2 *__restrict__ range, const int *__restrict__ nsegs, const int *__restrict__ counts,

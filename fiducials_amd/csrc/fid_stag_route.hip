@@ -14,6 +14,14 @@
 #define STAG_MIN_PATH_LEN 10  // DoDetectEdgesByED, EDInternals.cpp:2604
 enum { SR_LEFT = 0, SR_RIGHT = 1, SR_UP = 2, SR_DOWN = 3 };
 
+// the x index of a workgroup as a kernel body sees it: blockIdx.x, or blockIdx.z when a group of frames is launched with the frames
+// in blockIdx.x (fid_stag_batch.h, kFrameMinor)
+template <bool FM>
+__device__ __forceinline__ unsigned STAG_BX()
+{
+    return FM ? blockIdx.z : blockIdx.x;
+}
+
 struct StagChain {
     int16_t dir;
     uint16_t len;
@@ -36,6 +44,13 @@ struct StagRoute {
     int2 *segs;       // (first pixel, number of pixels) per segment
     int capOut, capSegs;
     int *counters;    // [0] segments [1] pixels used in outpix [2] overflow flags
+    // (fid_stag_batch.h: every member in declaration order -- a group's launch rebuilds frame f's copy from frame 0's)
+    template <class V>
+    __host__ __device__ __forceinline__ void visit(V &&v)
+    {
+        v(grad); v(dir); v(edge); v(W); v(H); v(pix); v(stack); v(chains); v(chainNos); v(capPix); v(capStack); v(capChains); v(capNos);
+        v(outpix); v(segs); v(capOut); v(capSegs); v(counters);
+    }
 };
 
 __device__ __forceinline__ bool sr_near(int2 a, int2 b)
@@ -728,15 +743,22 @@ struct StagRec {  // one producing anchor
 // several buffers filled by one launch (every fill is a dispatch of its own otherwise, and the hardware takes them one at a time)
 struct StagFills {
     uint4 *p[6];
-    unsigned n16[6];  // 16-byte words
+    unsigned n16[3];  // 16-byte words of the first three (sized by the context: the same for every frame of a group)
+    unsigned na16;    // ... and of the last three, sized by the frame's anchor count: ONE scalar that differs between the frames of a
+                      // group, which is what a merged launch can carry per frame (fid_stag_batch.h)
     unsigned v[6];    // the 32-bit pattern
+    template <class V>
+    __host__ __device__ __forceinline__ void visit(V &&vis)
+    {
+        vis(p); vis(n16); vis(na16); vis(v);
+    }
 };
 __device__ __forceinline__ void k_stag_fills_impl(StagFills F)
 {
     const unsigned i = blockIdx.x * 256 + threadIdx.x;
 #pragma unroll
     for (int k = 0; k < 6; k++)
-        if (i < F.n16[k]) F.p[k][i] = make_uint4(F.v[k], F.v[k], F.v[k], F.v[k]);
+        if (i < (k < 3 ? F.n16[k] : F.na16)) F.p[k][i] = make_uint4(F.v[k], F.v[k], F.v[k], F.v[k]);
 }
 __global__ __launch_bounds__(256) void k_stag_fills(StagFills F)
 {
@@ -765,6 +787,11 @@ struct StagGuard {
     const int *msrc[3];
     int mn[3];
     int *bad_host;  // the flag's place in the pinned block
+    template <class V>
+    __host__ __device__ __forceinline__ void visit(V &&v)
+    {
+        v(cnt); v(cap); v(kill); v(ncnt); v(nkill); v(reset); v(bad); v(mdst); v(msrc); v(mn); v(bad_host);
+    }
 };
 __device__ __forceinline__ void k_stag_spec_guard_impl(StagGuard g)
 {
@@ -1052,22 +1079,37 @@ struct k_stag_comp_fill_fn {
 };
 
 // cursors[10] = the largest LDS tile (bytes) a component would need (the boxes come from k_stag_ccl_flatten)
-__device__ __forceinline__ void k_stag_comp_tilemax_impl(const StagComp *__restrict__ comps, int *cursors, int lds_cap)
+// ... and the order the walk and the extraction take the components in: the big ones (a marker's outline and inside: hundreds of
+// pixels, a walk of a millisecond) from the FRONT of `order`, the small ones from its back, so that a launch starts every long walk at
+// once and fills the gaps with the short ones (cursors[11] = big components, cursors[12] = small ones; which of two equal
+// components comes first is up to the atomics -- the components are independent, every one writes its own arenas and records)
+#define STAG_BIG_COMP 192     // pixels
+#define STAG_SMALL_TILE 8192  // bytes: what a "small" component's box needs at most as a dense LDS tile
+__device__ __forceinline__ int stag_comp_by_rank(const int *__restrict__ order, const int *__restrict__ cursors, int rank)
+{
+    const int nbig = cursors[11], ncomp = cursors[0];
+    return rank < nbig ? order[rank] : order[ncomp - 1 - (rank - nbig)];  // (small ones: slot s of the back = order[ncomp - 1 - s])
+}
+__device__ __forceinline__ void k_stag_comp_tilemax_impl(const StagComp *__restrict__ comps, int *cursors, int lds_cap, int *__restrict__ order)
 {
     const int cid = blockIdx.x * 256 + threadIdx.x;
-    if (cid >= cursors[0]) return;
+    const int ncomp = cursors[0];
+    if (cid >= ncomp) return;
     const StagComp C = comps[cid];
-    if (C.nanch == 0) return;
+    // (every component gets a place, the empty ones among the small: nbig + nsmall = ncomp, front and back never meet)
     const int bytes = (C.maxr - C.minr + 3) * (C.maxc - C.minc + 3) * 2;
+    if (C.nanch > 0 && (C.size >= STAG_BIG_COMP || bytes > STAG_SMALL_TILE)) order[atomicAdd(&cursors[11], 1)] = cid;
+    else order[ncomp - 1 - atomicAdd(&cursors[12], 1)] = cid;
+    if (C.nanch == 0) return;
     atomicMax(&cursors[10], bytes <= lds_cap ? bytes : lds_cap);  // (beyond the cap: the whole of it, for the component's blocks)
 }
-__global__ __launch_bounds__(256) void k_stag_comp_tilemax(const StagComp *__restrict__ comps, int *cursors, int lds_cap)
+__global__ __launch_bounds__(256) void k_stag_comp_tilemax(const StagComp *__restrict__ comps, int *cursors, int lds_cap, int *__restrict__ order)
 {
-    k_stag_comp_tilemax_impl(comps, cursors, lds_cap);
+    k_stag_comp_tilemax_impl(comps, cursors, lds_cap, order);
 }
 struct k_stag_comp_tilemax_fn {
     static constexpr int kBounds = 256;
-    __device__ __forceinline__ void operator()(const StagComp *__restrict__ comps, int *cursors, int lds_cap) const { k_stag_comp_tilemax_impl(comps, cursors, lds_cap); }
+    __device__ __forceinline__ void operator()(const StagComp *__restrict__ comps, int *cursors, int lds_cap, int *__restrict__ order) const { k_stag_comp_tilemax_impl(comps, cursors, lds_cap, order); }
 };
 
 // ranks of one component, descending: bitonic sort of the (padded, -1 filled) slice, one wave per component; slices of up to
@@ -1173,6 +1215,11 @@ struct StagArenas {
     int2 *out;
     int2 *segs;
     StagRec *recs;  // indexed like the anchor slots
+    template <class V>
+    __host__ __device__ __forceinline__ void visit(V &&v)
+    {
+        v(pix); v(stack); v(chains); v(out); v(segs); v(recs);
+    }
 };
 
 __device__ void stag_bind(StagRouter &S, const StagRoute &G, const StagArenas &A, const StagComp &C)
@@ -1194,16 +1241,24 @@ __device__ void stag_bind(StagRouter &S, const StagRoute &G, const StagArenas &A
     S.par = true;
 }
 
+template <bool FM = false>
 __device__ __forceinline__ void k_stag_route_walk_impl(StagRoute G, StagArenas A, StagComp *__restrict__ comps, const int *__restrict__ cursors,
-                                                        const int32_t *__restrict__ sorted, const int *__restrict__ aslots, const int *__restrict__ label,
-                                                        int grad_thresh, int lds_bytes, int *__restrict__ prodflag, int *__restrict__ ovf)
+                                                        const int *__restrict__ order, const int32_t *__restrict__ sorted, const int *__restrict__ aslots,
+                                                        const int *__restrict__ label,
+                                                        int grad_thresh, int lds_bytes, int *__restrict__ prodflag, int *__restrict__ ovf, int cls)
 {
     extern __shared__ uint16_t s_tile[];
     constexpr int WSTACK = 128;  // (deeper than that: the arena in global memory)
     __shared__ int4 s_wstack[WSTACK];  // the first entries of the walk's stack (StagRouter::MemWave)
     // one workgroup per component: four waves move the tile in and out, wave 0 walks
-    const int cid = blockIdx.x, lane = threadIdx.x & 63, tid = threadIdx.x;
-    if (cid >= cursors[0]) return;
+    // (longest first: k_stag_comp_tilemax's order list -- big components from the front, small ones from the back of `order`)
+    // cls 0: every component; 1: the big ones only (ranks below cursors[11]); 2: the small ones only -- a group of frames launches the
+    // two classes one after the other: the big ones with the large tile, all of them resident at once, the small ones with
+    // STAG_SMALL_TILE of LDS, so that the hundreds of short walks are not queueing for the one slot per CU the long walks leave free
+    const int lane = threadIdx.x & 63, tid = threadIdx.x;
+    const int rank = (int)STAG_BX<FM>() + (cls == 2 ? cursors[11] : 0);
+    if (rank >= (cls == 1 ? cursors[11] : cursors[0])) return;
+    const int cid = stag_comp_by_rank(order, cursors, rank);
     const StagComp C = sr_uni_struct(comps[cid]);
     if (C.nanch == 0) return;
     StagRouter S;
@@ -1431,13 +1486,14 @@ __device__ __forceinline__ void k_stag_route_walk_impl(StagRoute G, StagArenas A
         }
     }
 }
-__global__ __launch_bounds__(256) void k_stag_route_walk(StagRoute G, StagArenas A, StagComp *__restrict__ comps, const int *__restrict__ cursors, const int32_t *__restrict__ sorted, const int *__restrict__ aslots, const int *__restrict__ label, int grad_thresh, int lds_bytes, int *__restrict__ prodflag, int *__restrict__ ovf)
+__global__ __launch_bounds__(256) void k_stag_route_walk(StagRoute G, StagArenas A, StagComp *__restrict__ comps, const int *__restrict__ cursors, const int *__restrict__ order, const int32_t *__restrict__ sorted, const int *__restrict__ aslots, const int *__restrict__ label, int grad_thresh, int lds_bytes, int *__restrict__ prodflag, int *__restrict__ ovf, int cls)
 {
-    k_stag_route_walk_impl(G, A, comps, cursors, sorted, aslots, label, grad_thresh, lds_bytes, prodflag, ovf);
+    k_stag_route_walk_impl(G, A, comps, cursors, order, sorted, aslots, label, grad_thresh, lds_bytes, prodflag, ovf, cls);
 }
 struct k_stag_route_walk_fn {
     static constexpr int kBounds = 256;
-    __device__ __forceinline__ void operator()(StagRoute G, StagArenas A, StagComp *__restrict__ comps, const int *__restrict__ cursors, const int32_t *__restrict__ sorted, const int *__restrict__ aslots, const int *__restrict__ label, int grad_thresh, int lds_bytes, int *__restrict__ prodflag, int *__restrict__ ovf) const { k_stag_route_walk_impl(G, A, comps, cursors, sorted, aslots, label, grad_thresh, lds_bytes, prodflag, ovf); }
+    static constexpr bool kFrameMinor = true;
+    __device__ __forceinline__ void operator()(StagRoute G, StagArenas A, StagComp *__restrict__ comps, const int *__restrict__ cursors, const int *__restrict__ order, const int32_t *__restrict__ sorted, const int *__restrict__ aslots, const int *__restrict__ label, int grad_thresh, int lds_bytes, int *__restrict__ prodflag, int *__restrict__ ovf, int cls) const { k_stag_route_walk_impl<true>(G, A, comps, cursors, order, sorted, aslots, label, grad_thresh, lds_bytes, prodflag, ovf, cls); }
 };
 
 // next[r] = the smallest producing rank > r, or -1 (one workgroup, chunks of 1024 from the top)
@@ -1494,10 +1550,11 @@ struct k_stag_next_above_fn {
     __device__ __forceinline__ void operator()(const int *__restrict__ prodflag, const unsigned *__restrict__ n_anchors, int *__restrict__ next) const { k_stag_next_above_impl(prodflag, n_anchors, next); }
 };
 
+template <bool FM = false, int EX_CHAINS = 512, int EX_PIX = 1024>
 __device__ __forceinline__ void k_stag_route_extract_impl(StagRoute G, StagArenas A, const StagComp *__restrict__ comps, const int *__restrict__ cursors,
-                                                            const int *__restrict__ next, const unsigned *__restrict__ n_anchors,
+                                                            const int *__restrict__ order, const int *__restrict__ next, const unsigned *__restrict__ n_anchors,
                                                             int *__restrict__ blk_pix, int *__restrict__ blk_segs, int2 *__restrict__ blk_where,
-                                                            int *__restrict__ ovf)
+                                                            int *__restrict__ ovf, int cls)
 {
     // one wave per component: every lane runs the same scalar steps (same values, same stores); pixel runs are copied by all lanes.
     // The chain tree of the anchor being extracted (and the stack of its tree walk) sits in LDS when it has <= EX_CHAINS chains:
@@ -1505,12 +1562,17 @@ __device__ __forceinline__ void k_stag_route_extract_impl(StagRoute G, StagArena
     // (round 5) so do the anchor's pixels and the block of output pixels it produces, when the walk left <= EX_PIX pixels: every
     // look at a chain's first pixels or at the segment's tail (trim_tail, append_forward) was a round trip to global memory, some
     // of them behind the stores just issued -- half of this kernel's time on a marker's component
-    constexpr int EX_CHAINS = 512, EX_PIX = 1024;
+    // (EX_CHAINS / EX_PIX are template arguments since round 6: 512 / 1 024 = 32 KB a wave, one workgroup per CU -- what a marker's
+    //  component needs; a group of frames takes its SMALL components (< STAG_BIG_COMP pixels) through an instance of 128 / 256 = 8 KB a
+    //  wave, four workgroups per CU, in a launch of its own: cls as in k_stag_route_walk_impl.  Which instance a component meets
+    //  only decides where its chain tree lives while it is taken apart -- the arithmetic is the same.)
     __shared__ StagChain s_chains[4][EX_CHAINS];
     __shared__ int4 s_stack[4][EX_CHAINS];
     __shared__ int2 s_pix[4][EX_PIX + 1], s_out[4][EX_PIX + 1];
-    const int wv = threadIdx.x >> 6, cid = blockIdx.x * 4 + wv, lane = threadIdx.x & 63;
-    if (cid >= cursors[0]) return;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int rank = (int)STAG_BX<FM>() * 4 + wv + (cls == 2 ? cursors[11] : 0);
+    if (rank >= (cls == 1 ? cursors[11] : cursors[0])) return;
+    const int cid = stag_comp_by_rank(order, cursors, rank);  // (longest first, as the walk took them)
     const StagComp C = sr_uni_struct(comps[cid]);
     if (C.nanch == 0 || C.nrec == 0) return;
     StagRouter S;
@@ -1597,13 +1659,24 @@ __device__ __forceinline__ void k_stag_route_extract_impl(StagRoute G, StagArena
 #endif
     if (S.overflow && lane == 0) atomicOr(ovf, S.overflow);
 }
-__global__ __launch_bounds__(256) void k_stag_route_extract(StagRoute G, StagArenas A, const StagComp *__restrict__ comps, const int *__restrict__ cursors, const int *__restrict__ next, const unsigned *__restrict__ n_anchors, int *__restrict__ blk_pix, int *__restrict__ blk_segs, int2 *__restrict__ blk_where, int *__restrict__ ovf)
+__global__ __launch_bounds__(256) void k_stag_route_extract(StagRoute G, StagArenas A, const StagComp *__restrict__ comps, const int *__restrict__ cursors, const int *__restrict__ order, const int *__restrict__ next, const unsigned *__restrict__ n_anchors, int *__restrict__ blk_pix, int *__restrict__ blk_segs, int2 *__restrict__ blk_where, int *__restrict__ ovf, int cls)
 {
-    k_stag_route_extract_impl(G, A, comps, cursors, next, n_anchors, blk_pix, blk_segs, blk_where, ovf);
+    k_stag_route_extract_impl(G, A, comps, cursors, order, next, n_anchors, blk_pix, blk_segs, blk_where, ovf, cls);
 }
 struct k_stag_route_extract_fn {
     static constexpr int kBounds = 256;
-    __device__ __forceinline__ void operator()(StagRoute G, StagArenas A, const StagComp *__restrict__ comps, const int *__restrict__ cursors, const int *__restrict__ next, const unsigned *__restrict__ n_anchors, int *__restrict__ blk_pix, int *__restrict__ blk_segs, int2 *__restrict__ blk_where, int *__restrict__ ovf) const { k_stag_route_extract_impl(G, A, comps, cursors, next, n_anchors, blk_pix, blk_segs, blk_where, ovf); }
+    static constexpr bool kFrameMinor = true;
+    __device__ __forceinline__ void operator()(StagRoute G, StagArenas A, const StagComp *__restrict__ comps, const int *__restrict__ cursors, const int *__restrict__ order, const int *__restrict__ next, const unsigned *__restrict__ n_anchors, int *__restrict__ blk_pix, int *__restrict__ blk_segs, int2 *__restrict__ blk_where, int *__restrict__ ovf, int cls) const { k_stag_route_extract_impl<true>(G, A, comps, cursors, order, next, n_anchors, blk_pix, blk_segs, blk_where, ovf, cls); }
+};
+// (the small-footprint instance: group mode only)
+__global__ __launch_bounds__(256) void k_stag_route_extract_small(StagRoute G, StagArenas A, const StagComp *__restrict__ comps, const int *__restrict__ cursors, const int *__restrict__ order, const int *__restrict__ next, const unsigned *__restrict__ n_anchors, int *__restrict__ blk_pix, int *__restrict__ blk_segs, int2 *__restrict__ blk_where, int *__restrict__ ovf, int cls)
+{
+    k_stag_route_extract_impl<false, 128, 256>(G, A, comps, cursors, order, next, n_anchors, blk_pix, blk_segs, blk_where, ovf, cls);
+}
+struct k_stag_route_extract_small_fn {
+    static constexpr int kBounds = 256;
+    static constexpr bool kFrameMinor = true;
+    __device__ __forceinline__ void operator()(StagRoute G, StagArenas A, const StagComp *__restrict__ comps, const int *__restrict__ cursors, const int *__restrict__ order, const int *__restrict__ next, const unsigned *__restrict__ n_anchors, int *__restrict__ blk_pix, int *__restrict__ blk_segs, int2 *__restrict__ blk_where, int *__restrict__ ovf, int cls) const { k_stag_route_extract_impl<true, 128, 256>(G, A, comps, cursors, order, next, n_anchors, blk_pix, blk_segs, blk_where, ovf, cls); }
 };
 
 // blk_pix / blk_segs hold exclusive prefix sums by now: copy every block to its place in the global order

@@ -143,12 +143,31 @@ class ArucoDetector:
         self._check(rc)
         return self._unpack(1)[0]
 
-    def detect_markers_batch(self, images: np.ndarray, encoding: str | None = None, unpack: bool = True):
-        """Frames in host memory (pinned or pageable): they go up sub-batch by sub-batch while the call runs."""
+    def detect_image(self, data, width: int, height: int, step: int, encoding: str, is_bigendian: bool = False):
+        """One sensor_msgs/Image by its fields (data = the message bytes), in ANY encoding cv_bridge::toCvCopy(msg, BGR8) converts
+        (aruco_detect.cpp:348): the five 8-bit layouts, and since ABI 7 bayer_{rggb,bggr,gbrg,grbg}8, mono16 / bgr16 / rgb16 / bgra16 /
+        rgba16 (either byte order) and yuv422 -- the conversion is the device's first kernel, the message bytes are what crosses
+        PCIe.  Returns (corners, ids)."""
+        buf = np.ascontiguousarray(data).view(np.uint8).reshape(-1) if isinstance(data, np.ndarray) else np.frombuffer(data, dtype=np.uint8)
+        if encoding not in _lib.ENC:
+            raise FidError(_lib.FID_E_UNSUPPORTED, f"cv_bridge exception: unsupported encoding {encoding}")
+        width, height, step = int(width), int(height), int(step)
+        if width < 1 or height < 1 or step < width * _lib.ENC_BYTES_PER_PIXEL[encoding] or buf.size < step * height:
+            raise FidError(_lib.FID_E_INVALID_ARG, f"image is wrongly formed: {buf.size} bytes for step {step} x height {height} ({encoding})")
+        rc = self._L.fid_detect(self._ctx, buf.ctypes.data, width, height, step, _lib.encoding_value(encoding, is_bigendian), self._out,
+                                self.max_markers, self._n)
+        self._check(rc)
+        return self._unpack(1)[0]
+
+    def detect_markers_batch(self, images: np.ndarray, encoding: str | None = None, unpack: bool = True, width: int | None = None):
+        """Frames in host memory (pinned or pageable): they go up sub-batch by sub-batch while the call runs.  images: (F, H, W)
+        mono8 / Bayer, (F, H, W, C) 8-bit colour, or -- with `width` given -- (F, H, step) message rows of a multi-byte encoding."""
         imgs = np.ascontiguousarray(images, dtype=np.uint8)
         if encoding is None:
             encoding = "mono8" if imgs.ndim == 3 else "bgr8"
         f, h, w = imgs.shape[:3]
+        if width is not None:
+            w = int(width)
         rc = self._L.fid_detect_batch(self._ctx, imgs.ctypes.data, f, w, h, imgs.strides[1], imgs.strides[0],
                                       _lib.ENC[encoding], self._out, self.max_markers, self._n)
         self._check(rc)
@@ -160,7 +179,7 @@ class ArucoDetector:
     def detect_markers_device(self, data_ptr: int, nframes: int, width: int, height: int, stride: int | None = None,
                               frame_stride: int | None = None, encoding: str = "mono8", unpack: bool = True):
         """Frames already resident in HBM (e.g. a torch uint8 tensor's data_ptr() on this device)."""
-        bpp = {"mono8": 1, "bgra8": 4, "rgba8": 4}.get(encoding, 3)
+        bpp = _lib.ENC_BYTES_PER_PIXEL[encoding]
         stride = stride or width * bpp
         frame_stride = frame_stride or stride * height
         rc = self._L.fid_detect_device(self._ctx, C.c_void_p(data_ptr), nframes, width, height, stride, frame_stride,
@@ -178,7 +197,7 @@ class ArucoDetector:
         kernels (fid_order_after)."""
         if after is not None:
             self._check(self._L.fid_order_after(self._ctx, after._ctx))
-        bpp = {"mono8": 1, "bgra8": 4, "rgba8": 4}.get(encoding, 3)
+        bpp = _lib.ENC_BYTES_PER_PIXEL[encoding]
         stride = stride or width * bpp
         frame_stride = frame_stride or stride * height
         self._check(self._L.fid_submit_device(self._ctx, C.c_void_p(data_ptr), nframes, width, height, stride, frame_stride,

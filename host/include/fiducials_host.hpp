@@ -171,7 +171,8 @@ class FiducialsNode {
     fid_ctx *ctx = nullptr;
     fid_jpeg_ctx *jctx = nullptr;  // made when the first compressed frame arrives
     std::vector<uint8_t> png_frame;  // a PNG frame decoded on the host (fid_png_decode), reused from frame to frame
-    std::vector<uint8_t> converted;  // the BGR8 copy of a 16-bit / Bayer frame (fid_image_to_bgr8); empty for the encodings fid_detect takes
+    std::vector<uint8_t> converted;  // (round 5: the BGR8 copy of a 16-bit / Bayer frame made before the detection; unused since ABI 7)
+    bool raw_encoding = false;       // the last frame came in a raw-camera encoding (Bayer / 16 bit / UYVY): detected on the message bytes
     int maxW = 0, maxH = 0, dev = 0;
     Dictionary dict;
     fid_params detectorParams;

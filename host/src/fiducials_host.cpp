@@ -305,37 +305,23 @@ bool FiducialsNode::publishVertices(const Header &h, int32_t n, FiducialArray *o
 bool FiducialsNode::imageCallback(const Image &msg, FiducialArray *out)
 {
     if (enable_detections == false) return false;
-    fid_encoding enc;
-    if (msg.encoding == "mono8") enc = FID_ENC_MONO8;
-    else if (msg.encoding == "bgr8") enc = FID_ENC_BGR8;
-    else if (msg.encoding == "rgb8") enc = FID_ENC_RGB8;
-    else if (msg.encoding == "bgra8") enc = FID_ENC_BGRA8;
-    else if (msg.encoding == "rgba8") enc = FID_ENC_RGBA8;
-    else {
-        // what else cv_bridge::toCvCopy(msg, BGR8) converts (:348): 16-bit gray / colour and the 8-bit Bayer patterns of raw camera
-        // drivers -- the BGR8 copy is made on the host (fid_image_to_bgr8, the reference's own order: convert, then detect), and
-        // an encoding that is not restated there ends like the cv_bridge exception the reference catches (:389-391)
-        if (msg.height == 0 || msg.width == 0 || msg.data.size() < (size_t)msg.step * msg.height) {
-            last_error = "cv_bridge exception: image is wrongly formed: step * height exceeds the data";
-            return false;
-        }
-        converted.resize((size_t)msg.width * msg.height * 3);
-        const fid_status rcc = fid_image_to_bgr8(msg.data.data(), (int32_t)msg.width, (int32_t)msg.height, (int32_t)msg.step, msg.encoding.c_str(),
-                                                 msg.is_bigendian, converted.data(), (int64_t)converted.size());
-        if (rcc != FID_OK) {
-            last_error = rcc == FID_E_UNSUPPORTED ? "cv_bridge exception: unsupported encoding " + msg.encoding
-                                                  : "cv_bridge exception: image is wrongly formed (" + msg.encoding + ")";
-            converted.clear();
-            return false;
-        }
-        int32_t n = 0;
-        const fid_status rc = fid_detect(ctx, converted.data(), (int32_t)msg.width, (int32_t)msg.height, (int32_t)msg.width * 3, FID_ENC_BGR8,
-                                         markers.data(), (int32_t)markers.size(), &n);
-        if (rc != FID_OK) {
-            last_error = fid_last_error(ctx);
-            return false;
-        }
-        return publishVertices(msg.header, n, out);
+    // Every encoding cv_bridge::toCvCopy(msg, BGR8) converts (:348) goes to the device AS PUBLISHED: the five 8-bit layouts, and since
+    // ABI 7 the 8-bit Bayer mosaics, the 16-bit gray / colour layouts and UYVY of raw camera drivers -- the conversion and BGR2GRAY
+    // are the first kernel of fid_detect, so a 1080p mosaic crosses PCIe as 2.07 MB (round 5 made a 6.2 MB BGR8 copy on one host
+    // thread first).  An encoding that is not restated ends like the cv_bridge exception the reference catches (:389-391).
+    fid_encoding enc = FID_ENC_MONO8;
+    int32_t bpp = 1;
+    if (fid_encoding_from_string(msg.encoding.c_str(), msg.is_bigendian, &enc, &bpp) != FID_OK) {
+        last_error = "cv_bridge exception: unsupported encoding " + msg.encoding;
+        converted.clear();
+        return false;
+    }
+    raw_encoding = (int)enc > (int)FID_ENC_RGBA8;
+    if (raw_encoding && (msg.height == 0 || msg.width == 0 || (size_t)msg.step < (size_t)msg.width * (size_t)bpp ||
+                         msg.data.size() < (size_t)msg.step * msg.height || (enc == FID_ENC_YUV422 && (msg.width & 1)))) {
+        last_error = "cv_bridge exception: image is wrongly formed (" + msg.encoding + "): step * height exceeds the data";
+        converted.clear();
+        return false;
     }
     converted.clear();
     int32_t n = 0;
@@ -354,10 +340,7 @@ bool FiducialsNode::imageCallback(const Image &msg, FiducialArray *out, Image *i
     if (!publish_images || !image) return true;
     // cv_ptr = toCvCopy(msg, BGR8); if (ids.size() > 0) drawDetectedMarkers(cv_ptr->image, corners, ids); image_pub.publish(cv_ptr->toImageMsg())
     fid_encoding enc = FID_ENC_MONO8;
-    if (msg.encoding == "bgr8") enc = FID_ENC_BGR8;
-    else if (msg.encoding == "rgb8") enc = FID_ENC_RGB8;
-    else if (msg.encoding == "bgra8") enc = FID_ENC_BGRA8;
-    else if (msg.encoding == "rgba8") enc = FID_ENC_RGBA8;
+    (void)fid_encoding_from_string(msg.encoding.c_str(), msg.is_bigendian, &enc, nullptr);  // (imageCallback accepted it)
     image->header = msg.header;  // (cv_bridge keeps the source header)
     image->height = msg.height;
     image->width = msg.width;
@@ -365,13 +348,17 @@ bool FiducialsNode::imageCallback(const Image &msg, FiducialArray *out, Image *i
     image->is_bigendian = 0;
     image->step = msg.width * 3;
     image->data.resize((size_t)msg.width * msg.height * 3);
-    if (!converted.empty()) {  // (a 16-bit / Bayer frame: the BGR8 copy the detection ran on)
-        image->data = converted;
-        if (!ids.empty() &&
-            fid_draw_detected_markers(image->data.data(), (int32_t)image->width, (int32_t)image->height, (int32_t)image->step, markers.data(),
-                                      (int32_t)ids.size(), 0) != FID_OK) {
-            last_error = "drawDetectedMarkers failed";
-            return false;
+    if (raw_encoding) {
+        // a 16-bit / Bayer / UYVY frame: the detection ran on the message bytes; the overlay's BGR8 image is toCvCopy(msg, BGR8) made
+        // here, on the host, only because /fiducial_images is a host-side message (~publish_images is a debugging aid)
+        fid_status rcc = fid_image_to_bgr8(msg.data.data(), (int32_t)msg.width, (int32_t)msg.height, (int32_t)msg.step, msg.encoding.c_str(),
+                                           msg.is_bigendian, image->data.data(), (int64_t)image->data.size());
+        if (rcc == FID_OK && !ids.empty())
+            rcc = fid_draw_detected_markers(image->data.data(), (int32_t)image->width, (int32_t)image->height, (int32_t)image->step, markers.data(),
+                                            (int32_t)ids.size(), 0);
+        if (rcc != FID_OK) {
+            last_error = std::string("overlay: ") + fid_strerror(rcc);
+            image->data.clear();
         }
         return true;
     }

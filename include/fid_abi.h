@@ -43,8 +43,11 @@ extern "C" {
  * whose slot was too small (round 3).  4: + fid_submit_device / fid_submit_batch / fid_collect / fid_order_after, fid_png_* (round 3).  Entry points are only ever added: a caller
  * built against 1 runs against 5.  5: cornerRefinementMethod 2 (CORNER_REFINE_CONTOUR) is implemented instead of refused,
  * FID_E_CV_EXCEPTION, fid_refine_contour_corners, fid_to_bgr / fid_draw_detected_markers, fid_dict_load_file (round 4).
- * 6: + fid_stag_queue_stats (STag frames queued ahead of their own counts), fid_image_to_bgr8 (round 5). */
-#define FID_ABI_VERSION 6
+ * 6: + fid_stag_queue_stats (STag frames queued ahead of their own counts), fid_image_to_bgr8 (round 5).
+ * 7: fid_detect* / fid_submit* take the raw-camera encodings themselves (FID_ENC_BAYER_*8, FID_ENC_MONO16 / BGR16 / RGB16 / BGRA16 /
+ * RGBA16 [| FID_ENC_BIGENDIAN], FID_ENC_YUV422): the conversion cv_bridge::toCvCopy(msg, BGR8) + BGR2GRAY is folded into the
+ * device's first kernel, so what crosses PCIe is the message's own bytes; + fid_encoding_from_string (round 6). */
+#define FID_ABI_VERSION 7
 
 typedef enum fid_status {
     FID_OK = 0,
@@ -65,7 +68,22 @@ typedef enum fid_encoding {  /* sensor_msgs/Image encodings the node accepts via
     FID_ENC_BGR8 = 1,
     FID_ENC_RGB8 = 2,
     FID_ENC_BGRA8 = 3, /* four bytes per pixel; toCvCopy(BGR8) drops the alpha channel (cvtColor BGRA2BGR / RGBA2BGR) */
-    FID_ENC_RGBA8 = 4
+    FID_ENC_RGBA8 = 4,
+    /* ABI 7: what raw camera drivers publish.  cv_bridge::toCvCopy(msg, "bgr8") (aruco_detect.cpp:348) converts these on the host
+     * before detectMarkers turns the BGR8 copy into gray; here both steps are one pass of the device's first kernel over the
+     * MESSAGE bytes (a 2.07 MB mosaic crosses the link, not a 6.2 MB BGR8 copy).  The arithmetic is that of fid_image_to_bgr8
+     * (below) followed by BGR2GRAY, bit for bit; tests/test_gpu_raw_encodings.py compares the gray tap with exactly that. */
+    FID_ENC_BAYER_RGGB8 = 5, /* one byte per pixel: cv_bridge maps the four patterns onto COLOR_BayerBG / RG / GR / GB2BGR, */
+    FID_ENC_BAYER_BGGR8 = 6, /* OpenCV's bilinear demosaicing; border columns, then border rows repeat their neighbours     */
+    FID_ENC_BAYER_GBRG8 = 7,
+    FID_ENC_BAYER_GRBG8 = 8,
+    FID_ENC_MONO16 = 9,      /* two bytes per sample: convertTo(8U, 255. / 65535.) = cvRound(float(v) * float(255. / 65535.)) */
+    FID_ENC_BGR16 = 10,
+    FID_ENC_RGB16 = 11,
+    FID_ENC_BGRA16 = 12,     /* (alpha dropped) */
+    FID_ENC_RGBA16 = 13,
+    FID_ENC_YUV422 = 14,     /* UYVY, two bytes per pixel, even width: cvtColor(COLOR_YUV2BGR_UYVY), BT.601 in 20-bit fixed point */
+    FID_ENC_BIGENDIAN = 0x100 /* OR-ed onto a 16-bit encoding: sensor_msgs/Image.is_bigendian (cv_bridge swaps the bytes first) */
 } fid_encoding;
 
 /* aruco::DetectorParameters, fields and defaults as set by the node (aruco_detect.cpp:690-727) */
@@ -449,6 +467,11 @@ const char *fid_png_last_error(void); /* of the calling thread */
  * reports it like the cv_bridge exception it would catch (:389-391).  Restated from the published sources: parity unpinned. */
 fid_status fid_image_to_bgr8(const uint8_t *img, int32_t width, int32_t height, int32_t stride_bytes, const char *encoding,
                              int32_t is_bigendian, uint8_t *out_bgr, int64_t out_bytes);
+/* sensor_msgs/Image.encoding (+ is_bigendian) -> the fid_encoding fid_detect takes (ABI 7): every string fid_image_to_bgr8 converts.
+ * FID_E_UNSUPPORTED for anything else (16-bit Bayer, float images, ...), which the node reports like the cv_bridge exception the
+ * reference catches (aruco_detect.cpp:389-391).  bytes_per_pixel (may be NULL): what one pixel occupies in a row, for the
+ * caller's step * height check. */
+fid_status fid_encoding_from_string(const char *encoding, int32_t is_bigendian, fid_encoding *out_enc, int32_t *bytes_per_pixel);
 #define FID_DRAW_FIRST_CORNER_LINE8 1u
 fid_status fid_to_bgr(const uint8_t *img, int32_t width, int32_t height, int32_t stride_bytes, fid_encoding enc, uint8_t *out_bgr,
                        int64_t out_bytes);

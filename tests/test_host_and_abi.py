@@ -22,7 +22,7 @@ def test_abi_exports_every_declared_symbol():
     for s in declared:
         assert hasattr(L, s), s
     assert declared == set(_lib.SYMBOLS)
-    assert L.fid_abi_version() == 6  # (== FID_ABI_VERSION of include/fid_abi.h: __graft_entry__.build() compares the two)
+    assert L.fid_abi_version() == 7  # (== FID_ABI_VERSION of include/fid_abi.h: __graft_entry__.build() compares the two)
     assert b"no CPU fallback" in L.fid_strerror(_lib.FID_E_NO_DEVICE)
 
 

@@ -189,17 +189,25 @@ def main():
     ap.add_argument("--trace", nargs="*", default=[])
     ap.add_argument("--check", nargs="*", default=[])
     ap.add_argument("--label", default="")
+    ap.add_argument("--launch-log", nargs="*", default=[], help="FID_LAUNCH_LOG files: 'kernel block dynamic_lds' per distinct launch shape")
     a = ap.parse_args()
     with tempfile.TemporaryDirectory() as td:
         co = code_object(a.lib, td)
         notes = read_notes(co)
-        text = subprocess.check_output([f"{LLVM}/llvm-objcopy", "-O", "binary", "--only-section=.text", co, "/dev/stdout"])
-        text_sha = hashlib.sha256(text).hexdigest()
+        tx = os.path.join(td, "text.bin")
+        subprocess.check_call([f"{LLVM}/llvm-objcopy", "-O", "binary", "--only-section=.text", co, tx])
+        text_sha = hashlib.sha256(open(tx, "rb").read()).hexdigest()
     dm = demangle(list(notes))
     static = {}
     for mangled, meta in notes.items():
         static[short(dm.get(mangled, mangled))] = meta
     disp = read_trace(a.trace)
+    dyn = collections.defaultdict(set)  # kernel base name -> {(block, dynamic LDS bytes)}
+    for p in a.launch_log:
+        for line in open(p):
+            f = line.split()
+            if len(f) == 3:
+                dyn[f[0]].add((int(f[1]), int(f[2])))
     shapes = collections.defaultdict(lambda: collections.Counter())
     wgs = collections.defaultdict(list)
     for d in disp:
@@ -213,13 +221,21 @@ def main():
         if meta.get("vgpr_spill_count") or meta.get("sgpr_spill_count"):
             e["spills"] = {"vgpr": meta.get("vgpr_spill_count", 0), "sgpr": meta.get("sgpr_spill_count", 0)}
         launches = []
+        base = re.sub(r"<.*$", "", name)  # (the launch log names a kernel without its template arguments; "[g]" = group mode)
         if name in shapes:
             for (block, lds), n in shapes[name].most_common(6):
-                r = residency(e["vgpr"], e["agpr"], e["sgpr"], max(lds, e["lds_static"]), block)
-                w = sorted(wgs[(name, block, lds)])
-                r.update({"block": block, "lds_per_wg": lds, "dispatches": n, "wgs_per_launch_median": w[len(w) // 2], "wgs_per_launch_max": w[-1]})
-                r["rounds_to_drain"] = round(w[len(w) // 2] / max(r["wg_per_cu"] * CUS, 1), 2)
-                launches.append(r)
+                # the trace's LDS_Block_Size is the STATIC group segment; the dynamic part comes from the library's own launch log
+                dyns = sorted(d for b, d in dyn.get(base, ()) if b == block) or [0]
+                for dl in dyns:
+                    total = max(lds, e["lds_static"]) + dl
+                    r = residency(e["vgpr"], e["agpr"], e["sgpr"], total, block)
+                    w = sorted(wgs[(name, block, lds)])
+                    r.update({"block": block, "lds_static": max(lds, e["lds_static"]), "lds_dynamic": dl, "lds_per_wg": total, "dispatches": n,
+                              "wgs_per_launch_median": w[len(w) // 2], "wgs_per_launch_max": w[-1]})
+                    if len(dyns) > 1:
+                        r["note"] = "one of several dynamic sizes this kernel was launched with (dispatch counts are the kernel's, not the size's)"
+                    r["rounds_to_drain"] = round(w[len(w) // 2] / max(r["wg_per_cu"] * CUS, 1), 2)
+                    launches.append(r)
         else:
             r = residency(e["vgpr"], e["agpr"], e["sgpr"], e["lds_static"], e["max_block"] or 256)
             r.update({"block": e["max_block"] or 256, "lds_per_wg": e["lds_static"], "dispatches": 0, "note": "not in the trace: static LDS and launch bound only"})

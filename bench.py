@@ -1040,11 +1040,28 @@ def main_dryrun(args):
     dt_local = time.perf_counter() - t0
     barrier()
     fps, dt = job_throughput(B * args.steps, world, dt_local, dist, "cpu")
+    # (the host-fed leg of a multi-GPU run, as a stand-in: the same keys the real run reports per rank)
+    host_leg = None
+    if world > 1 or os.environ.get("FID_BENCH_HOST_LEG") == "1":
+        barrier()
+        th = time.perf_counter()
+        for _ in range(2):
+            time.sleep(0.005 * (1 + rank))
+        dth = time.perf_counter() - th
+        barrier()
+        hfps, hdt = job_throughput(B * 2, world, time.perf_counter() - th, dist, "cpu")
+        host_leg = {"fps": round(B * 2 / dth, 2), "pcie_GBps": round(B * 2 * W * H / dth / 1e9, 4), "job_fps": round(hfps, 2),
+                    "job_ms_per_step": round(hdt / 2 * 1e3, 3), "steps": 2}
     ranks = gather_ranks(dist, rank, "cpu", B * args.steps, dt_local,
-                         extra={"seeds": seeds, "pin": pin, "affinity_cpus": len(os.sched_getaffinity(0))})
+                         extra={"seeds": seeds, "pin": pin, "affinity_cpus": len(os.sched_getaffinity(0)),
+                                "resident_fps": round(B * args.steps / dt_local, 2),
+                                **({"host_fed_fps": host_leg["fps"], "host_fed_pcie_GBps": host_leg["pcie_GBps"]} if host_leg else {})})
     if rank == 0:
-        print(json.dumps({"dryrun": True, "n_gpus": world, "steps": args.steps, "value": round(fps, 2), "ms_per_step": round(dt / args.steps * 1e3, 3),
-                          "ranks": ranks, "seeds_rank0": seeds, "host_budget": budget, "feed": args.feed}))
+        line = {"dryrun": True, "n_gpus": world, "steps": args.steps, "value": round(fps, 2), "ms_per_step": round(dt / args.steps * 1e3, 3),
+                "ranks": ranks, "seeds_rank0": seeds, "host_budget": budget, "feed": args.feed}
+        if host_leg:
+            line["host_fed"] = {"value": host_leg["job_fps"], "unit": "frames/s", "ms_per_step": host_leg["job_ms_per_step"], "steps": host_leg["steps"]}
+        print(json.dumps(line))
     if dist is not None:
         dist.destroy_process_group()
 
@@ -1224,7 +1241,32 @@ def main():
     assert counted[1] == args.steps  # every step's results were fetched inside the timed region
     barrier()
     fps, dt = job_throughput(B * args.steps, n_gpus, time.perf_counter() - t0, dist, f"cuda:{local_rank}")
-    ranks = gather_ranks(dist, rank, f"cuda:{local_rank}", B * args.steps, dt_local, markers, extra={"pin": pin})
+    # BASELINE cfg 4 is eight CAMERA streams: frames arrive in host memory, and on an 8-GPU node the honest per-GPU row is the
+    # host-fed one (one PCIe link per GPU, the host's memory system shared by all ranks).  So a multi-GPU run measures it too, every
+    # rank at the same time, OUTSIDE the timed region of `value`: the same batch from a pinned ring of two (fid_submit_batch), a few
+    # steps.  Per rank: both rates, the link's GB/s, the NUMA pin.  (N = 1: extra.cfg3_from_host carries it; FID_BENCH_HOST_LEG=1 forces it.)
+    host_leg = None
+    if (n_gpus > 1 or os.environ.get("FID_BENCH_HOST_LEG") == "1") and not feed_host and not args.no_extras:
+        ring = [torch.from_numpy(host).pin_memory().numpy(), torch.from_numpy(host.copy()).pin_memory().numpy()]
+        hs = max(4, min(args.steps, 12))
+        for k in range(3):
+            pipe.push_host(ring[k % 2], unpack=False)
+        pipe.flush(unpack=False)
+        barrier()
+        th = time.perf_counter()
+        for k in range(hs):
+            pipe.push_host(ring[k % 2], unpack=False)
+        pipe.flush(unpack=False)
+        torch.cuda.synchronize()
+        dth_local = time.perf_counter() - th
+        barrier()
+        hfps, hdt = job_throughput(B * hs, n_gpus, time.perf_counter() - th, dist, f"cuda:{local_rank}")
+        host_leg = {"fps": round(B * hs / dth_local, 2), "pcie_GBps": round(B * hs * W * H / dth_local / 1e9, 2), "steps": hs,
+                    "job_fps": round(hfps, 2), "job_ms_per_step": round(hdt / hs * 1e3, 3)}
+        del ring
+    ranks = gather_ranks(dist, rank, f"cuda:{local_rank}", B * args.steps, dt_local, markers,
+                         extra={"pin": pin, "resident_fps": round(B * args.steps / dt_local, 2),
+                                **({"host_fed_fps": host_leg["fps"], "host_fed_pcie_GBps": host_leg["pcie_GBps"]} if host_leg else {})})
     assert len(ranks) == n_gpus  # every reported GPU ran its own rank
 
     if rank == 0:
@@ -1278,6 +1320,12 @@ def main():
             "ranks": ranks,
             "host_budget": budget,
         }
+        if host_leg:
+            out["host_fed"] = {"value": host_leg["job_fps"], "unit": "frames/s", "ms_per_step": host_leg["job_ms_per_step"], "steps": host_leg["steps"],
+                               "per_rank": "ranks[].host_fed_fps / host_fed_pcie_GBps beside ranks[].resident_fps and ranks[].pin",
+                               "note": "the same batch per rank from a pinned host ring (fid_submit_batch), all ranks at once, timed after and outside "
+                                       "`value`'s region: cfg 4's eight camera streams are host-fed, so THIS is the per-GPU row a node of cameras sees; "
+                                       "`value` is the resident rate the metric is defined on"}
         if OVERSUB:
             out["oversubscribed"] = f"{n_gpus} ranks on ONE GPU (FID_BENCH_OVERSUBSCRIBE=1, gloo clock reduction): a plumbing run, not a scaling point"
         if depth > 1 and not args.no_extras:

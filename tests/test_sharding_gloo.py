@@ -108,6 +108,9 @@ def test_eight_ranks_dry_run_seeds_budget_and_affinity():
         assert x["pin"]["numa_node"] == (0 if x["rank"] < 4 else 1)
         if x["pin"]["cpus_pinned"]:
             assert x["affinity_cpus"] == x["pin"]["cpus_pinned"]
+        # (round 6) a multi-GPU line explains itself: per rank the resident rate, the host-fed rate with the link's GB/s, the pin
+        assert x["resident_fps"] > 0 and x["host_fed_fps"] > 0 and x["host_fed_pcie_GBps"] > 0
+    assert r["host_fed"]["value"] > 0 and r["host_fed"]["unit"] == "frames/s"
 
 
 def test_affinity_plan_is_disjoint_per_node():

@@ -1,8 +1,12 @@
-"""cv_bridge::toCvCopy(msg, "bgr8") for 16-bit and Bayer images, stated independently of fid_image_to_bgr8 for its tests (TEST
-INFRASTRUCTURE ONLY).  Not OpenCV's code: the RULES of OpenCV 4.2's bilinear demosaicing and of Mat::convertTo as published --
-an interior pixel keeps its own colour and takes the other two from the nearest samples of those colours (two: (a + b + 1) >> 1,
-four: (a + b + c + d + 2) >> 2); border columns, then border rows, repeat their neighbours; 16 -> 8 bit is
-cvRound(float(v) * float(255 / 65535)).  PARITY UNPINNED: OpenCV is not on this machine and the reference holds no such fixture."""
+"""cv_bridge::toCvCopy(msg, "bgr8") for 16-bit, Bayer and UYVY images: a SECOND STATEMENT of the rules that fid_image_to_bgr8
+(fiducials_amd/csrc/fid_draw.hip) and, since round 6, the device kernel k_raw_to_gray implement -- written by the same author from the
+same reading of the published OpenCV 4.2 / cv_bridge sources, in another form (whole-array numpy instead of OpenCV's row loops).
+It is NOT an independent source: it catches slips of the C statement (indices, parities, rounding), it cannot catch a shared
+misreading of OpenCV.  TEST INFRASTRUCTURE ONLY.  The rules: an interior pixel keeps its own colour and takes the other two from the
+nearest samples of those colours (two: (a + b + 1) >> 1, four: (a + b + c + d + 2) >> 2); border columns, then border rows, repeat
+their neighbours; 16 -> 8 bit is cvRound(float(v) * float(255 / 65535)); UYVY is BT.601 in 20-bit fixed point.
+PARITY UNPINNED: OpenCV is not on this machine and the reference holds no fixture in these encodings; one golden vector per encoding
+made with real cv2.cvtColor / convertTo would pin it, and is what a deployer with OpenCV should add first."""
 from __future__ import annotations
 
 import numpy as np

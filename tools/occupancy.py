@@ -248,7 +248,10 @@ def main():
                      "source": "/opt/skills/guides/MI355X_MICROARCH.md: Register files; Residency and cooperative launch"},
            "traces": [os.path.basename(p) for p in a.trace], "kernels": kernels}
     if disp:
-        out["coresidency"] = coresidency(disp)
+        # (per trace file: the STag batch and the aruco bench are different runs, and the heavier one would crowd the other out of a joint top list)
+        out["coresidency"] = {}
+        for fn in sorted({d["file"] for d in disp}):
+            out["coresidency"][fn] = coresidency([d for d in disp if d["file"] == fn], top=12)
     for p in a.check:
         out.setdefault("measured", {})[os.path.basename(os.path.dirname(p)) or os.path.basename(p)] = check_counters(p)
     json.dump(out, sys.stdout, indent=1)

@@ -253,7 +253,8 @@ def load():
     L.fid_png_decode.argtypes = [vp, i64, C.c_int, vp, i64, C.POINTER(FidPngInfo)]
     L.fid_to_bgr.argtypes = [vp, i32, i32, i32, C.c_int, vp, i64]
     L.fid_image_to_bgr8.argtypes = [vp, i32, i32, i32, C.c_char_p, i32, vp, i64]
-    L.fid_encoding_from_string.argtypes = [C.c_char_p, i32, C.POINTER(C.c_int), C.POINTER(i32)]
+    if hasattr(L, "fid_encoding_from_string"):  # (ABI 7; tools/gpu_stag_ab_libs.py also loads the builds of earlier rounds through FID_LIB)
+        L.fid_encoding_from_string.argtypes = [C.c_char_p, i32, C.POINTER(C.c_int), C.POINTER(i32)]
     L.fid_draw_detected_markers.argtypes = [vp, i32, i32, i32, C.POINTER(FidMarker), i32, C.c_uint32]
     L.fid_dict_load_file.argtypes = [C.c_char_p, i32, vp, i64, C.POINTER(FidDict)]
     L.fid_dict_last_error.argtypes = []

@@ -455,6 +455,8 @@ struct fid_stag_ctx {
     // component-parallel routing
     int4 *d_cbox = nullptr;  // per root: bounding box of the component's pixels
     int *d_label = nullptr, *d_csize = nullptr, *d_canch = nullptr, *d_cidmap = nullptr, *d_cursors = nullptr, *d_caps = nullptr;
+    int *d_roots = nullptr;   // the roots of the frame's connected components (k_stag_ccl_flatten's list; k_stag_comp_alloc goes by it)
+    int max_roots = 0;
     int *d_corder = nullptr;  // the components longest-first (k_stag_comp_tilemax; the walk and the extraction go by it)
     int *d_fill = nullptr, *d_aslots = nullptr, *d_prodflag = nullptr, *d_next = nullptr, *d_blkpix = nullptr, *d_blksegs = nullptr;
     int2 *d_blkwhere = nullptr, *d_apix = nullptr, *d_aout = nullptr, *d_asegs = nullptr;
@@ -599,10 +601,11 @@ fid_status fid_stag_create(int libraryHD, int errorCorrection, int max_width, in
     // component-parallel routing: labels, per-root counters, component table, arenas (sizes in entries; see k_stag_comp_alloc)
     c->max_comps = (int)(n / 8 + 64);
     c->cap_aslots = (int)(n / 2 + 64);
+    c->max_roots = ((max_width + 1) / 2) * ((max_height + 1) / 2) + 64;  // (8-connected components of an image: no more than that)
     ok = ok && slab.take((void **)&c->d_label, n * 4) && slab.take((void **)&c->d_csize, n * 4) &&
          slab.take((void **)&c->d_canch, n * 4) && slab.take((void **)&c->d_cidmap, n * 4) && slab.take((void **)&c->d_cbox, n * sizeof(int4)) &&
          slab.take((void **)&c->d_cursors, 64) && slab.take((void **)&c->d_caps, 64) &&
-         slab.take((void **)&c->d_corder, (size_t)c->max_comps * 4) && slab.take((void **)&c->d_fill, (size_t)c->max_comps * 4) && slab.take((void **)&c->d_aslots, (size_t)c->cap_aslots * 4) &&
+         slab.take((void **)&c->d_corder, (size_t)c->max_comps * 4) && slab.take((void **)&c->d_roots, (size_t)c->max_roots * 4) && slab.take((void **)&c->d_fill, (size_t)c->max_comps * 4) && slab.take((void **)&c->d_aslots, (size_t)c->cap_aslots * 4) &&
          slab.take((void **)&c->d_prodflag, n * 4) && slab.take((void **)&c->d_next, n * 4) &&
          slab.take((void **)&c->d_blkpix, n * 4) && slab.take((void **)&c->d_blksegs, n * 4) &&
          slab.take((void **)&c->d_blkwhere, n * sizeof(int2)) && slab.take((void **)&c->d_apix, 3 * n * sizeof(int2)) &&
@@ -999,16 +1002,20 @@ static fid_status stag_advance_impl(fid_stag_ctx *c, StagJob &j)
             STAG_LAUNCH(k_stag_ccl_tile, tiles, dim3(256), 0, st, c->d_grad, W, H, 16, c->d_label, c->d_csize, c->d_canch, c->d_cbox);
             STAG_LAUNCH(k_stag_ccl_border, tiles, dim3(128), 0, st, W, H, c->d_label);
         }
-        STAG_LAUNCH(k_stag_ccl_flatten, dim3(nb), dim3(256), 0, st, n, W, c->d_label, c->d_edge, c->d_csize, c->d_canch, c->d_cbox);
-        STAG_LAUNCH(k_stag_comp_alloc, dim3(nb), dim3(256), 0, st, n, c->d_label, c->d_csize, c->d_canch, c->d_cbox, c->d_cursors, c->max_comps, c->d_caps,
-                           c->d_comps, c->d_cidmap);
+        STAG_LAUNCH(k_stag_ccl_flatten, dim3(nb), dim3(256), 0, st, n, W, c->d_label, c->d_edge, c->d_csize, c->d_canch, c->d_cbox, c->d_roots, c->d_cursors);
+        // (one thread per ROOT of k_stag_ccl_flatten's list; the grid covers the most roots an image of this size can have)
+        STAG_LAUNCH(k_stag_comp_alloc, dim3((((W + 1) / 2) * ((H + 1) / 2) + 255) / 256), dim3(256), 0, st, c->d_roots, c->d_csize, c->d_canch, c->d_cbox,
+                           c->d_cursors, c->max_comps, c->d_caps, c->d_comps, c->d_cidmap);
         STAG_LAUNCH(k_stag_comp_fill, dim3((na + 255) / 256), dim3(256), 0, st, c->d_sorted, c->d_n, c->d_label, c->d_cidmap, c->d_comps, c->d_fill,
                            c->d_aslots);
         // the largest LDS tile a component's walk may ask for.  One frame at a time: 150 of the 160 KB of a CU (every component of a
         // marker frame walks in LDS).  A group of frames: 40 KB -- the walk kernel allocates the group's largest tile for every
         // workgroup, and with ~80 KB marker tiles a CU held one workgroup (3.0 k frames/s; 64 KB: 3.3 k, 40 KB: 3.5 k, 24 KB: 3.3 k);
         // the components above the cap take the global-memory walk, same result.  FID_STAG_TILE_KB overrides.
-        const int tile_kb = c->tile_kb_env > 0 ? c->tile_kb_env : (grouped ? 37 : 150);  // (37 KB + the walk's 2 KB of stack: four workgroups per CU)
+        // (round 6, groups of 32 on 256 slots: 48 - 50 KB + the walk's 2.5 KB of stack = three workgroups per CU: 7.47 - 7.56 k frames/s against
+        //  7.29 - 7.33 k at 37 KB (four per CU), 7.1 - 7.2 k at 24 / 60 / 76 KB, 6.1 k at 150: more of the marker components keep their tile in
+        //  LDS, and the walk's registers hold it to four workgroups per CU anyway)
+        const int tile_kb = c->tile_kb_env > 0 ? c->tile_kb_env : (grouped ? 50 : 150);
         const int LDS_CAP = (tile_kb < 8 ? 8 : (tile_kb > 150 ? 150 : tile_kb)) * 1024;
         j.lds_cap = LDS_CAP;
         STAG_LAUNCH(k_stag_comp_tilemax, dim3((c->max_comps + 255) / 256), dim3(256), 0, st, c->d_comps, c->d_cursors, LDS_CAP, c->d_corder);
@@ -1054,7 +1061,7 @@ static fid_status stag_advance_impl(fid_stag_ctx *c, StagJob &j)
             if (nc > 0) {
                 STAG_LAUNCH(k_stag_comp_sort, dim3((nc + 3) / 4), dim3(256), 0, st, c->d_comps, c->d_cursors, c->d_aslots);
                 if (cur[9] > STAG_SORT_WAVE)  // (cur[9]: most anchors in one component)
-                    STAG_LAUNCH(k_stag_comp_sort_big, dim3(nc), dim3(1024), (size_t)STAG_SORT_BIG * 4, st, c->d_comps, c->d_cursors, c->d_aslots);
+                    STAG_LAUNCH(k_stag_comp_sort_big, dim3(nc < 24 ? nc : 24), dim3(1024), (size_t)STAG_SORT_BIG * 4, st, c->d_comps, c->d_cursors, c->d_aslots);
                 // LDS per workgroup = the largest tile a component of this frame asks for (components whose box does not fit 150 KB
                 // walk in global memory): frames of small components keep many workgroups per CU
                 const int no_sparse = c->no_sparse;  // (FID_STAG_SPARSE=0: no blocks, the walk in global memory)
@@ -1088,7 +1095,7 @@ static fid_status stag_advance_impl(fid_stag_ctx *c, StagJob &j)
                 sj.counts[1] = c->d_blksegs; sj.total[1] = c->d_rcount;
                 STAG_LAUNCH(k_stag_scan_counts_n, dim3(2), dim3(1024), 0, st, sj, (const int *)c->d_n);
             }
-            STAG_LAUNCH(k_stag_route_gather, dim3((na + 3) / 4), dim3(256), 0, st, A, c->d_comps, c->d_n, c->d_prodflag, c->d_blkpix, c->d_blksegs,
+            STAG_LAUNCH(k_stag_route_gather, dim3((na + 255) / 256), dim3(256), 0, st, A, c->d_comps, c->d_n, c->d_prodflag, c->d_blkpix, c->d_blksegs,
                                c->d_blkwhere, c->d_outpix, c->d_segs, j.R.capOut, j.R.capSegs, ovf);
             if (hipGetLastError() != hipSuccess) return stag_finish(j, FID_E_HIP);
             if (!j.spec && (STAG_MEMCPY(c->hp->rcount, c->d_rcount, 8, hipMemcpyDeviceToHost, st) != hipSuccess ||

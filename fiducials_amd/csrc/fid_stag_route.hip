@@ -932,7 +932,7 @@ struct k_stag_ccl_border_fn {
 };
 
 __device__ __forceinline__ void k_stag_ccl_flatten_impl(int n, int W, int *label, const uint8_t *__restrict__ anchors, int *__restrict__ csize,
-                                                          int *__restrict__ canch, int4 *__restrict__ cbox)
+                                                          int *__restrict__ canch, int4 *__restrict__ cbox, int *__restrict__ roots, int *__restrict__ cursors)
 {
     const int i = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63;
     int root = -1;
@@ -942,6 +942,10 @@ __device__ __forceinline__ void k_stag_ccl_flatten_impl(int n, int W, int *label
         root = ccl_find(label, i);
         label[i] = root;
         anch = anchors[i] == STAG_ANCHOR_PIXEL;
+        // the frame's ROOTS as a list (cursors[13] counts them): k_stag_comp_alloc goes by it instead of asking every pixel of the
+        // image whether it is one (a few hundred roots among two million pixels).  8-connected components are at most
+        // ceil(W / 2) * ceil(H / 2), which is what `roots` holds.
+        if (root == i) roots[atomicAdd(&cursors[13], 1)] = i;
     }
     // pixels, anchors and bounding box per root: one set of atomics per (wave, root) -- 64 consecutive pixels share very few
     // roots.  (The boxes used to be a pass of their own over all pixels: 52 us of the whole GPU per frame.)
@@ -982,23 +986,25 @@ __device__ __forceinline__ void k_stag_ccl_flatten_impl(int n, int W, int *label
         pending &= ~m;
     }
 }
-__global__ __launch_bounds__(256) void k_stag_ccl_flatten(int n, int W, int *label, const uint8_t *__restrict__ anchors, int *__restrict__ csize, int *__restrict__ canch, int4 *__restrict__ cbox)
+__global__ __launch_bounds__(256) void k_stag_ccl_flatten(int n, int W, int *label, const uint8_t *__restrict__ anchors, int *__restrict__ csize, int *__restrict__ canch, int4 *__restrict__ cbox, int *__restrict__ roots, int *__restrict__ cursors)
 {
-    k_stag_ccl_flatten_impl(n, W, label, anchors, csize, canch, cbox);
+    k_stag_ccl_flatten_impl(n, W, label, anchors, csize, canch, cbox, roots, cursors);
 }
 struct k_stag_ccl_flatten_fn {
     static constexpr int kBounds = 256;
-    __device__ __forceinline__ void operator()(int n, int W, int *label, const uint8_t *__restrict__ anchors, int *__restrict__ csize, int *__restrict__ canch, int4 *__restrict__ cbox) const { k_stag_ccl_flatten_impl(n, W, label, anchors, csize, canch, cbox); }
+    __device__ __forceinline__ void operator()(int n, int W, int *label, const uint8_t *__restrict__ anchors, int *__restrict__ csize, int *__restrict__ canch, int4 *__restrict__ cbox, int *__restrict__ roots, int *__restrict__ cursors) const { k_stag_ccl_flatten_impl(n, W, label, anchors, csize, canch, cbox, roots, cursors); }
 };
 
 // cursors: [0] components [1] anchor slots [2] scratch pixels [3] stack [4] chains [5] output pixels [6] segments [7] overflow
-//          [8] overflow flags of the routing kernels [9] most anchors in one component
-__device__ __forceinline__ void k_stag_comp_alloc_impl(int n, const int *__restrict__ label, const int *__restrict__ csize,
+//          [8] overflow flags of the routing kernels [9] most anchors in one component [10] largest tile [11] big / [12] small
+//          components in the walk's order list [13] roots (k_stag_ccl_flatten's list)
+__device__ __forceinline__ void k_stag_comp_alloc_impl(const int *__restrict__ roots, const int *__restrict__ csize,
                                                          const int *__restrict__ canch, const int4 *__restrict__ cbox, int *__restrict__ cursors, int max_comps,
                                                          const int *caps, StagComp *__restrict__ comps, int *__restrict__ cidmap)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n || label[i] != i) return;
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= cursors[13]) return;
+    const int i = roots[k];  // (one thread per ROOT; until round 6: one per pixel, asking label[i] == i)
     cidmap[i] = -1;
     const int na = canch[i], sz = csize[i];
     if (na == 0) return;
@@ -1036,13 +1042,13 @@ __device__ __forceinline__ void k_stag_comp_alloc_impl(int n, const int *__restr
     comps[cid] = C;
     cidmap[i] = cid;
 }
-__global__ __launch_bounds__(256) void k_stag_comp_alloc(int n, const int *__restrict__ label, const int *__restrict__ csize, const int *__restrict__ canch, const int4 *__restrict__ cbox, int *__restrict__ cursors, int max_comps, const int *caps, StagComp *__restrict__ comps, int *__restrict__ cidmap)
+__global__ __launch_bounds__(256) void k_stag_comp_alloc(const int *__restrict__ roots, const int *__restrict__ csize, const int *__restrict__ canch, const int4 *__restrict__ cbox, int *__restrict__ cursors, int max_comps, const int *caps, StagComp *__restrict__ comps, int *__restrict__ cidmap)
 {
-    k_stag_comp_alloc_impl(n, label, csize, canch, cbox, cursors, max_comps, caps, comps, cidmap);
+    k_stag_comp_alloc_impl(roots, csize, canch, cbox, cursors, max_comps, caps, comps, cidmap);
 }
 struct k_stag_comp_alloc_fn {
     static constexpr int kBounds = 256;
-    __device__ __forceinline__ void operator()(int n, const int *__restrict__ label, const int *__restrict__ csize, const int *__restrict__ canch, const int4 *__restrict__ cbox, int *__restrict__ cursors, int max_comps, const int *caps, StagComp *__restrict__ comps, int *__restrict__ cidmap) const { k_stag_comp_alloc_impl(n, label, csize, canch, cbox, cursors, max_comps, caps, comps, cidmap); }
+    __device__ __forceinline__ void operator()(const int *__restrict__ roots, const int *__restrict__ csize, const int *__restrict__ canch, const int4 *__restrict__ cbox, int *__restrict__ cursors, int max_comps, const int *caps, StagComp *__restrict__ comps, int *__restrict__ cidmap) const { k_stag_comp_alloc_impl(roots, csize, canch, cbox, cursors, max_comps, caps, comps, cidmap); }
 };
 
 // (64 consecutive ranks hold many anchors of the frame's big components: one atomic per (wave, component), the anchors of
@@ -1174,11 +1180,15 @@ struct k_stag_comp_sort_fn {
 __device__ __forceinline__ void k_stag_comp_sort_big_impl(const StagComp *__restrict__ comps, const int *__restrict__ cursors, int *aslots)
 {
     extern __shared__ int s_big[];
-    const int cid = blockIdx.x;
-    if (cid >= cursors[0]) return;
+    // (a workgroup goes through the components blockIdx.x, + gridDim.x, ...: a frame has a few dozen slices of this size among
+    //  its components, and a 1 024-thread workgroup with 64 KB of LDS per COMPONENT -- most of them returning at once -- waited for
+    //  16 free wave slots on one CU each: 112 us alone, 680 us beside the other groups' kernels)
+    const int ncomp = cursors[0];
+    for (int cid = blockIdx.x; cid < ncomp; cid += gridDim.x) {
     const StagComp C = comps[cid];
     const int P = C.anch_cap;
-    if (C.nanch < 2 || P <= STAG_SORT_WAVE || P > STAG_SORT_BIG) return;
+    if (C.nanch < 2 || P <= STAG_SORT_WAVE || P > STAG_SORT_BIG) continue;
+    __syncthreads();  // (the slice of the component before this one has left the LDS)
     int *g = aslots + C.anch_base;
     for (int i = threadIdx.x; i < P; i += 1024) s_big[i] = g[i];
     __syncthreads();
@@ -1198,6 +1208,7 @@ __device__ __forceinline__ void k_stag_comp_sort_big_impl(const StagComp *__rest
             __syncthreads();
         }
     for (int i = threadIdx.x; i < P; i += 1024) g[i] = s_big[i];
+    }
 }
 __global__ __launch_bounds__(1024) void k_stag_comp_sort_big(const StagComp *__restrict__ comps, const int *__restrict__ cursors, int *aslots)
 {
@@ -1685,21 +1696,30 @@ __device__ __forceinline__ void k_stag_route_gather_impl(StagArenas A, const Sta
                                                            const int *__restrict__ blk_segs, const int2 *__restrict__ blk_where,
                                                            int2 *__restrict__ outpix, int2 *__restrict__ segs, int capOut, int capSegs, int *__restrict__ ovf)
 {
-    const int q = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    // a LANE per anchor asks whether it produced (most did not: one wave per anchor was 7 500 workgroups a frame, nearly all of
+    // them one load and an exit), the wave then copies the blocks of the ones that did, one after the other
+    const int lane = threadIdx.x & 63;
     const int n = (int)*n_anchors;
-    if (q >= n || !prodflag[n - 1 - q]) return;
-    const int2 w = blk_where[q];
-    const StagComp C = comps[w.x];
-    const StagRec r = (A.recs + C.anch_base)[w.y];
-    const int po = blk_pix[q], so = blk_segs[q];
-    if (po + r.out_len > capOut || so + r.nsegs > capSegs) {
-        if (lane == 0) atomicOr(ovf, 64);
-        return;
+    const int q0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;
+    if (q0 >= n) return;
+    const int qm = q0 + lane;
+    unsigned long long todo = __ballot(qm < n && prodflag[n - 1 - qm] != 0);
+    while (todo) {
+        const int q = q0 + __builtin_ctzll(todo);
+        todo &= todo - 1;
+        const int2 w = blk_where[q];
+        const StagComp C = comps[w.x];
+        const StagRec r = (A.recs + C.anch_base)[w.y];
+        const int po = blk_pix[q], so = blk_segs[q];
+        if (po + r.out_len > capOut || so + r.nsegs > capSegs) {
+            if (lane == 0) atomicOr(ovf, 64);
+            continue;
+        }
+        const int2 *src = A.out + C.out_base + r.out_off;
+        for (int i = lane; i < r.out_len; i += 64) outpix[po + i] = src[i];
+        const int2 *sg = A.segs + C.seg_base + r.seg_off;
+        for (int i = lane; i < r.nsegs; i += 64) segs[so + i] = make_int2(sg[i].x - r.out_off + po, sg[i].y);
     }
-    const int2 *src = A.out + C.out_base + r.out_off;
-    for (int i = lane; i < r.out_len; i += 64) outpix[po + i] = src[i];
-    const int2 *sg = A.segs + C.seg_base + r.seg_off;
-    for (int i = lane; i < r.nsegs; i += 64) segs[so + i] = make_int2(sg[i].x - r.out_off + po, sg[i].y);
 }
 __global__ __launch_bounds__(256) void k_stag_route_gather(StagArenas A, const StagComp *__restrict__ comps, const unsigned *__restrict__ n_anchors, const int *__restrict__ prodflag, const int *__restrict__ blk_pix, const int *__restrict__ blk_segs, const int2 *__restrict__ blk_where, int2 *__restrict__ outpix, int2 *__restrict__ segs, int capOut, int capSegs, int *__restrict__ ovf)
 {

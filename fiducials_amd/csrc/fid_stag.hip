@@ -455,6 +455,7 @@ struct fid_stag_ctx {
     // component-parallel routing
     int4 *d_cbox = nullptr;  // per root: bounding box of the component's pixels
     int *d_label = nullptr, *d_csize = nullptr, *d_canch = nullptr, *d_cidmap = nullptr, *d_cursors = nullptr, *d_caps = nullptr;
+    uint8_t *d_tilefg = nullptr;  // per 64 x 16 tile of the connected-component passes: does it hold a foreground pixel?
     int *d_roots = nullptr;   // the roots of the frame's connected components (k_stag_ccl_flatten's list; k_stag_comp_alloc goes by it)
     int max_roots = 0;
     int *d_corder = nullptr;  // the components longest-first (k_stag_comp_tilemax; the walk and the extraction go by it)
@@ -605,7 +606,8 @@ fid_status fid_stag_create(int libraryHD, int errorCorrection, int max_width, in
     ok = ok && slab.take((void **)&c->d_label, n * 4) && slab.take((void **)&c->d_csize, n * 4) &&
          slab.take((void **)&c->d_canch, n * 4) && slab.take((void **)&c->d_cidmap, n * 4) && slab.take((void **)&c->d_cbox, n * sizeof(int4)) &&
          slab.take((void **)&c->d_cursors, 64) && slab.take((void **)&c->d_caps, 64) &&
-         slab.take((void **)&c->d_corder, (size_t)c->max_comps * 4) && slab.take((void **)&c->d_roots, (size_t)c->max_roots * 4) && slab.take((void **)&c->d_fill, (size_t)c->max_comps * 4) && slab.take((void **)&c->d_aslots, (size_t)c->cap_aslots * 4) &&
+         slab.take((void **)&c->d_corder, (size_t)c->max_comps * 4) && slab.take((void **)&c->d_roots, (size_t)c->max_roots * 4) &&
+         slab.take((void **)&c->d_tilefg, (size_t)((max_width + CCL_TW - 1) / CCL_TW) * ((max_height + CCL_TH - 1) / CCL_TH)) && slab.take((void **)&c->d_fill, (size_t)c->max_comps * 4) && slab.take((void **)&c->d_aslots, (size_t)c->cap_aslots * 4) &&
          slab.take((void **)&c->d_prodflag, n * 4) && slab.take((void **)&c->d_next, n * 4) &&
          slab.take((void **)&c->d_blkpix, n * 4) && slab.take((void **)&c->d_blksegs, n * 4) &&
          slab.take((void **)&c->d_blkwhere, n * sizeof(int2)) && slab.take((void **)&c->d_apix, 3 * n * sizeof(int2)) &&
@@ -975,7 +977,6 @@ static fid_status stag_advance_impl(fid_stag_ctx *c, StagJob &j)
             j.rstate = RS_EMPTY;
             return STAG_MEMSET(c->d_rcount, 0, 12, st) == hipSuccess ? FID_OK : stag_finish(j, FID_E_HIP);
         }
-        const int nb = (n + 255) / 256;
         // (the per-root counters are zeroed by k_stag_ccl_init where a root can be; the output arena is cleared once its used
         // size is known: clearing the whole allocations cost 70 MB of writes per frame)
         bool ok = true;
@@ -999,10 +1000,10 @@ static fid_status stag_advance_impl(fid_stag_ctx *c, StagJob &j)
         if (!ok) return stag_finish(j, FID_E_HIP);
         {
             const dim3 tiles((W + CCL_TW - 1) / CCL_TW, (H + CCL_TH - 1) / CCL_TH);
-            STAG_LAUNCH(k_stag_ccl_tile, tiles, dim3(256), 0, st, c->d_grad, W, H, 16, c->d_label, c->d_csize, c->d_canch, c->d_cbox);
+            STAG_LAUNCH(k_stag_ccl_tile, tiles, dim3(256), 0, st, c->d_grad, W, H, 16, c->d_label, c->d_csize, c->d_canch, c->d_cbox, c->d_tilefg);
             STAG_LAUNCH(k_stag_ccl_border, tiles, dim3(128), 0, st, W, H, c->d_label);
+            STAG_LAUNCH(k_stag_ccl_flatten, tiles, dim3(256), 0, st, W, H, c->d_label, c->d_edge, c->d_csize, c->d_canch, c->d_cbox, c->d_roots, c->d_cursors, c->d_tilefg);
         }
-        STAG_LAUNCH(k_stag_ccl_flatten, dim3(nb), dim3(256), 0, st, n, W, c->d_label, c->d_edge, c->d_csize, c->d_canch, c->d_cbox, c->d_roots, c->d_cursors);
         // (one thread per ROOT of k_stag_ccl_flatten's list; the grid covers the most roots an image of this size can have)
         STAG_LAUNCH(k_stag_comp_alloc, dim3((((W + 1) / 2) * ((H + 1) / 2) + 255) / 256), dim3(256), 0, st, c->d_roots, c->d_csize, c->d_canch, c->d_cbox,
                            c->d_cursors, c->max_comps, c->d_caps, c->d_comps, c->d_cidmap);

@@ -850,21 +850,33 @@ __device__ __forceinline__ void ccl_union(int *L, int a, int b)
 }
 
 __device__ __forceinline__ void k_stag_ccl_tile_impl(const int16_t *__restrict__ grad, int W, int H, int thresh, int *__restrict__ label,
-                                                       int *__restrict__ csize, int *__restrict__ canch, int4 *__restrict__ cbox)
+                                                       int *__restrict__ csize, int *__restrict__ canch, int4 *__restrict__ cbox, uint8_t *__restrict__ tilefg)
 {
     __shared__ int L[CCL_TW * CCL_TH];
     const int x0 = blockIdx.x * CCL_TW, y0 = blockIdx.y * CCL_TH;
+    int any = 0;
     for (int k = threadIdx.x; k < CCL_TW * CCL_TH; k += 256) {
         const int x = x0 + (k % CCL_TW), y = y0 + (k / CCL_TW);
         const bool fg = x < W && y < H && grad[y * W + x] >= thresh;
         L[k] = fg ? k : -1;
+        any |= fg;
         if (fg) {  // a root is a foreground pixel: the per-root counters only have to be clean there
             csize[y * W + x] = 0;
             canch[y * W + x] = 0;
             cbox[y * W + x] = make_int4(0x7fffffff, 0x7fffffff, -1, -1);  // min row, min column, max row, max column
         }
     }
-    __syncthreads();
+    // (round 6) a tile without a foreground pixel -- 60 % of the tiles of the bench frames -- has nothing to merge: its labels are
+    // -1, and k_stag_ccl_flatten does not come back to it (tilefg)
+    if (!__syncthreads_or(any)) {
+        if (threadIdx.x == 0) tilefg[blockIdx.y * ((W + CCL_TW - 1) / CCL_TW) + blockIdx.x] = 0;
+        for (int k = threadIdx.x; k < CCL_TW * CCL_TH; k += 256) {
+            const int x = x0 + (k % CCL_TW), y = y0 + (k / CCL_TW);
+            if (x < W && y < H) label[y * W + x] = -1;
+        }
+        return;
+    }
+    if (threadIdx.x == 0) tilefg[blockIdx.y * ((W + CCL_TW - 1) / CCL_TW) + blockIdx.x] = 1;
     for (int k = threadIdx.x; k < CCL_TW * CCL_TH; k += 256) {
         if (L[k] < 0) continue;
         const int lx = k % CCL_TW, ly = k / CCL_TW;
@@ -890,13 +902,13 @@ __device__ __forceinline__ void k_stag_ccl_tile_impl(const int16_t *__restrict__
         label[y * W + x] = v;
     }
 }
-__global__ __launch_bounds__(256) void k_stag_ccl_tile(const int16_t *__restrict__ grad, int W, int H, int thresh, int *__restrict__ label, int *__restrict__ csize, int *__restrict__ canch, int4 *__restrict__ cbox)
+__global__ __launch_bounds__(256) void k_stag_ccl_tile(const int16_t *__restrict__ grad, int W, int H, int thresh, int *__restrict__ label, int *__restrict__ csize, int *__restrict__ canch, int4 *__restrict__ cbox, uint8_t *__restrict__ tilefg)
 {
-    k_stag_ccl_tile_impl(grad, W, H, thresh, label, csize, canch, cbox);
+    k_stag_ccl_tile_impl(grad, W, H, thresh, label, csize, canch, cbox, tilefg);
 }
 struct k_stag_ccl_tile_fn {
     static constexpr int kBounds = 256;
-    __device__ __forceinline__ void operator()(const int16_t *__restrict__ grad, int W, int H, int thresh, int *__restrict__ label, int *__restrict__ csize, int *__restrict__ canch, int4 *__restrict__ cbox) const { k_stag_ccl_tile_impl(grad, W, H, thresh, label, csize, canch, cbox); }
+    __device__ __forceinline__ void operator()(const int16_t *__restrict__ grad, int W, int H, int thresh, int *__restrict__ label, int *__restrict__ csize, int *__restrict__ canch, int4 *__restrict__ cbox, uint8_t *__restrict__ tilefg) const { k_stag_ccl_tile_impl(grad, W, H, thresh, label, csize, canch, cbox, tilefg); }
 };
 
 // the pixels of a tile's first row, first column and last column against their neighbours in the adjacent tiles
@@ -931,68 +943,104 @@ struct k_stag_ccl_border_fn {
     __device__ __forceinline__ void operator()(int W, int H, int *label) const { k_stag_ccl_border_impl(W, H, label); }
 };
 
-__device__ __forceinline__ void k_stag_ccl_flatten_impl(int n, int W, int *label, const uint8_t *__restrict__ anchors, int *__restrict__ csize,
-                                                          int *__restrict__ canch, int4 *__restrict__ cbox, int *__restrict__ roots, int *__restrict__ cursors)
+// Every foreground pixel to its final root, and per root: pixels, anchors, bounding box.  A workgroup = one 64 x 16 tile (the tiles
+// of k_stag_ccl_tile), a wave = one tile row per round.  The per-root sums are collected in a small LDS table first -- one slot per
+// root that occurs in the tile -- and leave as ONE set of global atomics per (tile, root).  (Until round 6 a wave of 64 consecutive
+// pixels sent its own set per root: a marker's outline of 3 000 pixels meant ~2 000 sets of six atomics on the same six words, and
+// that traffic jam was 10 of this kernel's 16 us per frame; timed with the statistics compiled out, -DFLATTEN_NO_STATS.)
+__device__ __forceinline__ void k_stag_ccl_flatten_impl(int W, int H, int *label, const uint8_t *__restrict__ anchors, int *__restrict__ csize,
+                                                          int *__restrict__ canch, int4 *__restrict__ cbox, int *__restrict__ roots, int *__restrict__ cursors, const uint8_t *__restrict__ tilefg)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63;
-    int root = -1;
-    bool anch = false;
-    const int r = i / W, c = i - r * W;
-    if (i < n && label[i] >= 0) {
-        root = ccl_find(label, i);
-        label[i] = root;
-        anch = anchors[i] == STAG_ANCHOR_PIXEL;
-        // the frame's ROOTS as a list (cursors[13] counts them): k_stag_comp_alloc goes by it instead of asking every pixel of the
-        // image whether it is one (a few hundred roots among two million pixels).  8-connected components are at most
-        // ceil(W / 2) * ceil(H / 2), which is what `roots` holds.
-        if (root == i) roots[atomicAdd(&cursors[13], 1)] = i;
+    constexpr int SLOTS = 32;
+    __shared__ int s_root[SLOTS], s_cnt[SLOTS], s_anch[SLOTS], s_minr[SLOTS], s_minc[SLOTS], s_maxr[SLOTS], s_maxc[SLOTS];
+    if (!tilefg[blockIdx.y * ((W + CCL_TW - 1) / CCL_TW) + blockIdx.x]) return;  // (no foreground pixel in this tile: k_stag_ccl_tile said so)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int x0 = blockIdx.x * CCL_TW, y0 = blockIdx.y * CCL_TH;
+    if (tid < SLOTS) {
+        s_root[tid] = -1;
+        s_cnt[tid] = s_anch[tid] = 0;
+        s_minr[tid] = s_minc[tid] = 0x7fffffff;
+        s_maxr[tid] = s_maxc[tid] = -1;
     }
-    // pixels, anchors and bounding box per root: one set of atomics per (wave, root) -- 64 consecutive pixels share very few
-    // roots.  (The boxes used to be a pass of their own over all pixels: 52 us of the whole GPU per frame.)
-    unsigned long long pending = __ballot(root >= 0);
-    while (pending) {
-        const int lead = __builtin_ctzll(pending);
-        const int r0 = __builtin_amdgcn_readlane(root, lead);
-        const bool mine = root == r0;
-        const unsigned long long m = __ballot(mine), ma = __ballot(mine && anch);
-        const int lfirst = __builtin_ctzll(m), llast = 63 - __builtin_clzll(m);
-        const int rfirst = __builtin_amdgcn_readlane(r, lfirst), rlast = __builtin_amdgcn_readlane(r, llast);
-        int mnr, mnc, mxr, mxc;
-        if (rfirst == rlast) {  // the group lies in one image row (always, when the width is a multiple of 64)
-            mnr = mxr = rfirst;
-            mnc = __builtin_amdgcn_readlane(c, lfirst);
-            mxc = __builtin_amdgcn_readlane(c, llast);
-        } else {
-            mnr = mine ? r : 0x7fffffff; mnc = mine ? c : 0x7fffffff; mxr = mine ? r : -1; mxc = mine ? c : -1;
+    __syncthreads();
+    const int c = x0 + lane;
 #pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                mnr = min(mnr, __shfl_xor(mnr, off, 64));
-                mnc = min(mnc, __shfl_xor(mnc, off, 64));
-                mxr = max(mxr, __shfl_xor(mxr, off, 64));
-                mxc = max(mxc, __shfl_xor(mxc, off, 64));
+    for (int j = 0; j < CCL_TH / 4; j++) {
+        const int r = y0 + (tid >> 6) + 4 * j;  // (wave-uniform: a wave takes one tile row per round)
+        const int i = r * W + c;
+        int root = -1;
+        bool anch = false;
+        if (c < W && r < H && label[i] >= 0) {
+            root = ccl_find(label, i);
+            label[i] = root;
+            anch = anchors[i] == STAG_ANCHOR_PIXEL;
+            // the frame's ROOTS as a list (cursors[13] counts them): k_stag_comp_alloc goes by it instead of asking every pixel of the
+            // image whether it is one (a few hundred roots among two million pixels).  8-connected components are at most
+            // ceil(W / 2) * ceil(H / 2), which is what `roots` holds.
+            if (root == i) roots[atomicAdd(&cursors[13], 1)] = i;
+        }
+        unsigned long long pending = __ballot(root >= 0);
+#ifdef FLATTEN_NO_STATS
+        pending = 0;
+#endif
+        while (pending) {
+            const int lead = __builtin_ctzll(pending);
+            const int r0 = __builtin_amdgcn_readlane(root, lead);
+            const bool mine = root == r0;
+            const unsigned long long m = __ballot(mine), ma = __ballot(mine && anch);
+            if (lane == lead) {
+                const int cnt = (int)__builtin_popcountll(m), na = (int)__builtin_popcountll(ma);
+                const int mnc = x0 + (int)__builtin_ctzll(m), mxc = x0 + 63 - (int)__builtin_clzll(m);
+                // the root's slot: open addressing on the root's index, SLOTS tries (a tile that holds more roots than slots -- noise --
+                // sends the surplus straight to global memory)
+                int slot = -1;
+                unsigned h = ((unsigned)r0 * 2654435761u) >> 27;
+                for (int t = 0; t < SLOTS; t++, h = (h + 1) & (SLOTS - 1)) {
+                    const int old = atomicCAS(&s_root[h], -1, r0);
+                    if (old == -1 || old == r0) {
+                        slot = (int)h;
+                        break;
+                    }
+                }
+                if (slot >= 0) {
+                    atomicAdd(&s_cnt[slot], cnt);
+                    if (na) atomicAdd(&s_anch[slot], na);
+                    atomicMin(&s_minr[slot], r);
+                    atomicMin(&s_minc[slot], mnc);
+                    atomicMax(&s_maxr[slot], r);
+                    atomicMax(&s_maxc[slot], mxc);
+                } else {
+                    atomicAdd(&csize[r0], cnt);
+                    if (na) atomicAdd(&canch[r0], na);
+                    int *bx = reinterpret_cast<int *>(cbox + r0);
+                    atomicMin(bx + 0, r);
+                    atomicMin(bx + 1, mnc);
+                    atomicMax(bx + 2, r);
+                    atomicMax(bx + 3, mxc);
+                }
             }
+            pending &= ~m;
         }
-        if (lane == lead) {
-            atomicAdd(&csize[r0], (int)__builtin_popcountll(m));
-            if (ma) atomicAdd(&canch[r0], (int)__builtin_popcountll(ma));
-            // (looking at the box first and skipping atomics that would not extend it was tried: the look is a round trip
-            //  inside this loop, 60 -> 107 us)
-            int *bx = reinterpret_cast<int *>(cbox + r0);
-            atomicMin(bx + 0, mnr);
-            atomicMin(bx + 1, mnc);
-            atomicMax(bx + 2, mxr);
-            atomicMax(bx + 3, mxc);
-        }
-        pending &= ~m;
+    }
+    __syncthreads();
+    if (tid < SLOTS && s_root[tid] >= 0) {
+        const int r0 = s_root[tid];
+        atomicAdd(&csize[r0], s_cnt[tid]);
+        if (s_anch[tid]) atomicAdd(&canch[r0], s_anch[tid]);
+        int *bx = reinterpret_cast<int *>(cbox + r0);
+        atomicMin(bx + 0, s_minr[tid]);
+        atomicMin(bx + 1, s_minc[tid]);
+        atomicMax(bx + 2, s_maxr[tid]);
+        atomicMax(bx + 3, s_maxc[tid]);
     }
 }
-__global__ __launch_bounds__(256) void k_stag_ccl_flatten(int n, int W, int *label, const uint8_t *__restrict__ anchors, int *__restrict__ csize, int *__restrict__ canch, int4 *__restrict__ cbox, int *__restrict__ roots, int *__restrict__ cursors)
+__global__ __launch_bounds__(256) void k_stag_ccl_flatten(int W, int H, int *label, const uint8_t *__restrict__ anchors, int *__restrict__ csize, int *__restrict__ canch, int4 *__restrict__ cbox, int *__restrict__ roots, int *__restrict__ cursors, const uint8_t *__restrict__ tilefg)
 {
-    k_stag_ccl_flatten_impl(n, W, label, anchors, csize, canch, cbox, roots, cursors);
+    k_stag_ccl_flatten_impl(W, H, label, anchors, csize, canch, cbox, roots, cursors, tilefg);
 }
 struct k_stag_ccl_flatten_fn {
     static constexpr int kBounds = 256;
-    __device__ __forceinline__ void operator()(int n, int W, int *label, const uint8_t *__restrict__ anchors, int *__restrict__ csize, int *__restrict__ canch, int4 *__restrict__ cbox, int *__restrict__ roots, int *__restrict__ cursors) const { k_stag_ccl_flatten_impl(n, W, label, anchors, csize, canch, cbox, roots, cursors); }
+    __device__ __forceinline__ void operator()(int W, int H, int *label, const uint8_t *__restrict__ anchors, int *__restrict__ csize, int *__restrict__ canch, int4 *__restrict__ cbox, int *__restrict__ roots, int *__restrict__ cursors, const uint8_t *__restrict__ tilefg) const { k_stag_ccl_flatten_impl(W, H, label, anchors, csize, canch, cbox, roots, cursors, tilefg); }
 };
 
 // cursors: [0] components [1] anchor slots [2] scratch pixels [3] stack [4] chains [5] output pixels [6] segments [7] overflow

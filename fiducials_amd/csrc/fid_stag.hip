@@ -116,13 +116,21 @@ __device__ __forceinline__ void k_stag_anchors_impl(const int16_t *__restrict__ 
                                                        int grad_thresh, int anchor_thresh, int scan_interval,
                                                        uint8_t *__restrict__ edge, unsigned *__restrict__ rowhist)
 {
-    const long long total = (long long)W * H;
-    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
-        const int i = (int)(idx / W), j = (int)(idx - (long long)i * W);
+    // (row and column are carried along the grid-stride loop: one 32-bit division per thread instead of a 64-bit one per pixel --
+    //  the images are < 2^31 pixels, fid_stag_create caps both sides at 8 191)
+    const unsigned total = (unsigned)W * (unsigned)H, stride = gridDim.x * 256u;
+    const unsigned first = blockIdx.x * 256u + threadIdx.x;
+    const int si = (int)(stride / (unsigned)W), sj = (int)(stride - (unsigned)si * (unsigned)W);
+    int i = (int)(first / (unsigned)W), j = (int)(first - (unsigned)i * (unsigned)W);
+    for (unsigned idx = first; idx < total; idx += stride, i += si, j += sj) {
+        if (j >= W) {
+            j -= W;
+            i++;
+        }
         uint8_t e = 0;
         if (i >= 2 && i < H - 2 && j >= 2 && j < W - 2) {
             // rows that are not a multiple of SCAN_INTERVAL are scanned at columns SCAN_INTERVAL, 2 SCAN_INTERVAL, ...
-            const bool scanned = (i % scan_interval == 0) || (j >= scan_interval && j % scan_interval == 0);
+            const bool scanned = scan_interval == 1 || (i % scan_interval == 0) || (j >= scan_interval && j % scan_interval == 0);
             const int g = grad[idx];
             if (scanned && g >= grad_thresh) {
                 int d1, d2;

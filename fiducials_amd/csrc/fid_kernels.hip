@@ -3585,9 +3585,11 @@ __global__ __launch_bounds__(256) void k_near(const DevCand *__restrict__ sorted
     const int lane = lane_id();
     const float rate_f = (float)P.minMarkerDistRate * 1.0001f;
     const int wave = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)), nwaves = (int)(gridDim.x * (blockDim.x >> 6));
-    for (int item = wave; item < n * nw2; item += nwaves) {
-        const int i = item / nw2, w2 = item - i * nw2;
-        if (w2 * 64 + 63 < i) continue;  // (the block that holds i itself is kept: its words belong to the row)
+    // (round 6) a wave takes the ROWS wave, wave + nwaves, ... and in a row only the 64-column blocks from the one that holds i itself
+    // on (its words belong to the row): until now the items were all n x nw2 (row, block) pairs, found by a division, and the
+    // half below the diagonal was skipped one `continue` at a time -- a third of this kernel's instructions were that bookkeeping
+    for (int i = wave; i < n; i += nwaves)
+      for (int w2 = i >> 6; w2 < nw2; w2++) {
         const int j = w2 * 64 + lane;
         const bool valid = j > i && j < n;
         const float4 ma = cm[i];

@@ -1027,7 +1027,7 @@ static fid_status stag_advance_impl(fid_stag_ctx *c, StagJob &j)
         const int tile_kb = c->tile_kb_env > 0 ? c->tile_kb_env : (grouped ? 50 : 150);
         const int LDS_CAP = (tile_kb < 8 ? 8 : (tile_kb > 150 ? 150 : tile_kb)) * 1024;
         j.lds_cap = LDS_CAP;
-        STAG_LAUNCH(k_stag_comp_tilemax, dim3((c->max_comps + 255) / 256), dim3(256), 0, st, c->d_comps, c->d_cursors, LDS_CAP, c->d_corder);
+        STAG_LAUNCH(k_stag_comp_tilemax, dim3((c->max_comps + 255) / 256), dim3(256), 0, st, c->d_comps, c->d_cursors, LDS_CAP, c->d_corder, c->max_comps);
         if (hipGetLastError() != hipSuccess) return stag_finish(j, FID_E_HIP);
         if (!j.spec && STAG_MEMCPY(c->hp->cur, c->d_cursors, 44, hipMemcpyDeviceToHost, st) != hipSuccess) return stag_finish(j, FID_E_HIP);
         if (j.spec) {

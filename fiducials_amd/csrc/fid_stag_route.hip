@@ -1144,10 +1144,12 @@ __device__ __forceinline__ int stag_comp_by_rank(const int *__restrict__ order, 
     const int nbig = cursors[11], ncomp = cursors[0];
     return rank < nbig ? order[rank] : order[ncomp - 1 - (rank - nbig)];  // (small ones: slot s of the back = order[ncomp - 1 - s])
 }
-__device__ __forceinline__ void k_stag_comp_tilemax_impl(const StagComp *__restrict__ comps, int *cursors, int lds_cap, int *__restrict__ order)
+__device__ __forceinline__ void k_stag_comp_tilemax_impl(const StagComp *__restrict__ comps, int *cursors, int lds_cap, int *__restrict__ order, int max_comps)
 {
     const int cid = blockIdx.x * 256 + threadIdx.x;
-    const int ncomp = cursors[0];
+    // (k_stag_comp_alloc counts past max_comps when the table is full -- the overflow flag is up and the frame takes the sequential
+    //  road -- but `order` and `comps` end at max_comps)
+    const int ncomp = cursors[0] < max_comps ? cursors[0] : max_comps;
     if (cid >= ncomp) return;
     const StagComp C = comps[cid];
     // (every component gets a place, the empty ones among the small: nbig + nsmall = ncomp, front and back never meet)
@@ -1157,13 +1159,13 @@ __device__ __forceinline__ void k_stag_comp_tilemax_impl(const StagComp *__restr
     if (C.nanch == 0) return;
     atomicMax(&cursors[10], bytes <= lds_cap ? bytes : lds_cap);  // (beyond the cap: the whole of it, for the component's blocks)
 }
-__global__ __launch_bounds__(256) void k_stag_comp_tilemax(const StagComp *__restrict__ comps, int *cursors, int lds_cap, int *__restrict__ order)
+__global__ __launch_bounds__(256) void k_stag_comp_tilemax(const StagComp *__restrict__ comps, int *cursors, int lds_cap, int *__restrict__ order, int max_comps)
 {
-    k_stag_comp_tilemax_impl(comps, cursors, lds_cap, order);
+    k_stag_comp_tilemax_impl(comps, cursors, lds_cap, order, max_comps);
 }
 struct k_stag_comp_tilemax_fn {
     static constexpr int kBounds = 256;
-    __device__ __forceinline__ void operator()(const StagComp *__restrict__ comps, int *cursors, int lds_cap, int *__restrict__ order) const { k_stag_comp_tilemax_impl(comps, cursors, lds_cap, order); }
+    __device__ __forceinline__ void operator()(const StagComp *__restrict__ comps, int *cursors, int lds_cap, int *__restrict__ order, int max_comps) const { k_stag_comp_tilemax_impl(comps, cursors, lds_cap, order, max_comps); }
 };
 
 // ranks of one component, descending: bitonic sort of the (padded, -1 filled) slice, one wave per component; slices of up to

@@ -96,6 +96,30 @@ def residency(vgpr, agpr, sgpr, lds, block):
             "waves_per_cu": wg * waves_wg, "binding": bind, "lds_in_use_per_cu": wg * lds_alloc}
 
 
+def fits_beside(host, nhost, guest):
+    """How many workgroups of `guest` fit on a CU that already holds `nhost` workgroups of `host`?  Each = dict(vgpr, agpr, sgpr, lds,
+    block).  Registers are counted per SIMD (a workgroup's waves spread over the four SIMDs round robin), LDS and wave slots per CU."""
+    def alloc(k):
+        return max(8, -(-(k["vgpr"] + k.get("agpr", 0)) // 8) * 8)
+
+    def ldsa(k):
+        return -(-k["lds"] // 512) * 512 if k["lds"] > 0 else 0
+
+    hw, gw = max(1, (host["block"] + 63) // 64), max(1, (guest["block"] + 63) // 64)
+    # waves per SIMD of the host: nhost workgroups x hw waves over four SIMDs
+    host_waves_simd = -(-nhost * hw // 4)
+    free_regs = 512 - host_waves_simd * alloc(host)
+    free_lds = LDS_PER_CU - nhost * ldsa(host)
+    free_waves = 32 - nhost * hw
+    guest_waves_simd = max(0, min(free_regs // alloc(guest), 8 - host_waves_simd))
+    by_regs = guest_waves_simd * 4 // gw
+    by_lds = free_lds // ldsa(guest) if ldsa(guest) else 10 ** 6
+    by_waves = free_waves // gw
+    n = max(0, min(by_regs, by_lds, by_waves))
+    return {"workgroups": n, "waves": n * gw, "by_registers": by_regs, "by_lds": None if by_lds >= 10 ** 6 else by_lds, "by_wave_slots": by_waves,
+            "free_lds_bytes": free_lds, "free_vgprs_per_simd_lane": free_regs}
+
+
 def read_trace(paths):
     disp = []
     for p in paths:
@@ -252,6 +276,24 @@ def main():
         out["coresidency"] = {}
         for fn in sorted({d["file"] for d in disp}):
             out["coresidency"][fn] = coresidency([d for d in disp if d["file"] == fn], top=12)
+    # what fits beside k_threshold_stream (the kernel the aruco walkers spend 40 - 65 % of their time beside): the cases behind DESIGN.md 4
+    def shape(name):
+        k = kernels.get(name)
+        if not k:
+            return None
+        l = k["launches"][0]
+        return {"vgpr": k["vgpr"], "agpr": k["agpr"], "sgpr": k["sgpr"], "lds": l.get("lds_per_wg", k["lds_static"]), "block": l["block"]}
+
+    thr = shape("k_threshold_stream<3,4,13,3,false>")
+    if thr and thr["lds"] > 0:
+        out["beside_threshold"] = {}
+        for n in (4, 3, 2, 1):
+            row = {}
+            for g in ("k_walk_full<2>", "k_seed_walk<true>", "k_seed_walk<false>", "k_seg_cycles<0u>", "k_seg_cycles<48u>", "k_probe_lut<6,0>", "k_approx", "k_seg_copy"):
+                sh = shape(g)
+                if sh:
+                    row[g] = fits_beside(thr, n, sh)
+            out["beside_threshold"][f"{n} threshold workgroups on the CU"] = row
     for p in a.check:
         out.setdefault("measured", {})[os.path.basename(os.path.dirname(p)) or os.path.basename(p)] = check_counters(p)
     json.dump(out, sys.stdout, indent=1)

@@ -837,10 +837,12 @@ def stag_side_result(local_rank, args):
         t = time.perf_counter()
         one.detect_markers(frames[i % len(frames)])
         ts.append(time.perf_counter() - t)
+    queued, rerun = one.queue_stats()  # (frames enqueued ahead of their own counts / how many of them had to be run again)
     one.close()
     algo = 10 * W * H  # ~10 B/px for the EDPF streaming stages (20.7 MB per 1080p frame)
     fps5 = B * steps / dt
     res = {"value": round(fps5, 2), "unit": "frames/s", "ms_single_frame": round(float(np.median(ts[2:])) * 1e3, 3),
+           "single_frame_queued_ahead": {"calls": len(ts), "queued": queued, "rerun_on_the_counted_road": rerun},
            "roofline": {"bound": "hbm", "kernel": "pipeline (latency-bound: edge routing, line fitting, simplex search)",
                         "achieved": round(fps5 * algo / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(fps5 * algo / 1e9 / HBM_PEAK_GBS, 6),
                         "algo_bytes_per_frame": algo, "traffic": stag_pmc_traffic()},

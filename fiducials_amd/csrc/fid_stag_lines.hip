@@ -54,7 +54,15 @@ __device__ __forceinline__ void k_stag_smooth3_prewitt_impl(const uint8_t *__res
             gxv = gxv < 0 ? -gxv : gxv;
             gyv = gyv < 0 ? -gyv : gyv;
             g = gxv + gyv;
-            atomicAdd(&s_hist[g], 1u);
+            // the tile's histogram: most of a row's 64 pixels share ONE value (flat image: 0 - 3), and 64 LDS atomics on one word
+            // are 64 serial operations -- the lanes that hold the first lane's value are counted by one of them, the rest go singly
+            const int g0 = __builtin_amdgcn_readfirstlane(g);
+            const unsigned long long same = __ballot(g == g0);
+            if (g == g0) {
+                if ((int)(threadIdx.x & 63) == (int)__builtin_ctzll(same)) atomicAdd(&s_hist[g0], (unsigned)__builtin_popcountll(same));
+            } else {
+                atomicAdd(&s_hist[g], 1u);
+            }
         }
         grad[idx] = (int16_t)g;
     }

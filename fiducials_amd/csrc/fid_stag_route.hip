@@ -860,11 +860,6 @@ __device__ __forceinline__ void k_stag_ccl_tile_impl(const int16_t *__restrict__
         const bool fg = x < W && y < H && grad[y * W + x] >= thresh;
         L[k] = fg ? k : -1;
         any |= fg;
-        if (fg) {  // a root is a foreground pixel: the per-root counters only have to be clean there
-            csize[y * W + x] = 0;
-            canch[y * W + x] = 0;
-            cbox[y * W + x] = make_int4(0x7fffffff, 0x7fffffff, -1, -1);  // min row, min column, max row, max column
-        }
     }
     // (round 6) a tile without a foreground pixel -- 60 % of the tiles of the bench frames -- has nothing to merge: its labels are
     // -1, and k_stag_ccl_flatten does not come back to it (tilefg)
@@ -898,6 +893,13 @@ __device__ __forceinline__ void k_stag_ccl_tile_impl(const int16_t *__restrict__
         if (L[k] >= 0) {
             const int r = ccl_find(L, k);
             v = (y0 + r / CCL_TW) * W + x0 + (r % CCL_TW);
+            if (r == k) {
+                // a component's final root is the smallest index in it, hence the root of its piece in ITS tile: the per-root counters
+                // only have to be clean at the tiles' local roots (until round 6: at every foreground pixel, 24 bytes each)
+                csize[y * W + x] = 0;
+                canch[y * W + x] = 0;
+                cbox[y * W + x] = make_int4(0x7fffffff, 0x7fffffff, -1, -1);  // min row, min column, max row, max column
+            }
         }
         label[y * W + x] = v;
     }

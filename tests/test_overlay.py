@@ -191,3 +191,22 @@ def test_image_to_bgr8_takes_the_message_bytes_and_refuses_short_buffers():
         with pytest.raises(FidError) as ei:
             overlay.image_to_bgr8(data, w, h, step, enc)
         assert ei.value.status == FID_E_INVALID_ARG, enc
+
+
+def test_encoding_from_string_is_the_table_the_device_takes():
+    """fid_encoding_from_string (ABI 7): sensor_msgs/Image.encoding + is_bigendian -> fid_encoding + bytes per pixel, for every
+    string fid_image_to_bgr8 converts; host code, no GPU.  The Python table (_lib.ENC / ENC_BYTES_PER_PIXEL) must say the same."""
+    import ctypes as C
+
+    from fiducials_amd import _lib
+
+    L = _lib.load()
+    enc, bpp = C.c_int(0), C.c_int32(0)
+    for name, value in _lib.ENC.items():
+        for be in (0, 1):
+            assert L.fid_encoding_from_string(name.encode(), be, C.byref(enc), C.byref(bpp)) == _lib.FID_OK, name
+            assert enc.value == _lib.encoding_value(name, bool(be)) and bpp.value == _lib.ENC_BYTES_PER_PIXEL[name], (name, be)
+            assert (enc.value & 0x100) == (0x100 if be and name.endswith("16") else 0)
+    for bad in (b"bayer_rggb16", b"32FC1", b"", b"MONO8"):
+        assert L.fid_encoding_from_string(bad, 0, C.byref(enc), None) == _lib.FID_E_UNSUPPORTED
+    assert L.fid_encoding_from_string(None, 0, C.byref(enc), None) == _lib.FID_E_INVALID_ARG

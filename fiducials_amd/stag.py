@@ -176,12 +176,11 @@ class StagDetector:
 
 
 class StagPool:
-    """Throughput mode (fid_stag_detect_markers_batch): `n_contexts` frame slots.  Round 3: the frames are a GRID DIMENSION --
-    the slots are cut into groups of up to 16, a group carries its frames through the pipeline in lockstep on one stream, every
-    kernel launched once per group (fid_stag_batch.h); one host thread goes round the groups.  32 slots = two groups of 16 is the
-    default: two streams, so nothing depends on how many hardware queues the HIP runtime was given (round 2 ran a stream per
-    context, needed GPU_MAX_HW_QUEUES=24 in the environment before the runtime started and collapsed at 24 contexts;
-    FID_STAG_BATCH=contexts keeps that road for comparison).
+    """Throughput mode (fid_stag_detect_markers_batch): `n_contexts` frame slots.  The frames are a GRID DIMENSION -- the slots
+    are cut into groups (32 slots where the pool has at least 64, else two groups; FID_STAG_GROUP overrides), a group carries its
+    frames through the pipeline in lockstep on one stream, every kernel launched once per group (fid_stag_batch.h: frame 0's
+    arguments + 32 bytes per further frame, round 6), a host thread per group.  Nothing depends on how many hardware queues the HIP
+    runtime was given.  A slot is ~0.66 GB for 1080p; 256 slots: 7.9 - 8.2 k frames/s, 32 slots: ~3.5 k.
     detect_markers_batch(frames[F, H, W]) -> (markers per frame, poses per frame)."""
 
     def __init__(self, libraryHD: int = 21, errorCorrection: int = 7, n_contexts: int = 32, max_width: int = 1920, max_height: int = 1080,

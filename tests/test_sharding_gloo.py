@@ -149,3 +149,13 @@ def test_two_ranks_with_real_kernels_on_one_gpu():
     assert r["config"]["frames_per_step"] == 64 and r["value"] > 0
     # whole-job rate = both ranks' frames / the slower rank's time
     assert r["value"] <= 2 * min(x["fps"] for x in r["ranks"]) * 1.05
+    # (round 6) WITHOUT --no-extras -- what the driver's scaling run starts: after the timed region every rank also measures the
+    # host-fed rate (pinned ring, fid_submit_batch), and the line carries both per rank with the link's GB/s and the pin
+    out = _run_bench(["--gpus", "2", "--batch", "32", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"],
+                     {"FID_BENCH_OVERSUBSCRIBE": "1"}, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert len(r["ranks"]) == 2 and r["host_fed"]["value"] > 0 and "extra" not in r
+    for x in r["ranks"]:
+        assert x["resident_fps"] > 0 and x["host_fed_fps"] > 0 and x["host_fed_pcie_GBps"] > 0 and "pin" in x
+        assert x["markers_per_frame_found"] == 20.0

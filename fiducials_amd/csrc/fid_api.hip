@@ -135,6 +135,7 @@ struct fid_ctx {
     unsigned *d_worklist = nullptr, *d_nwork = nullptr;
     uint8_t *d_dict = nullptr;
     float *d_subpix_mask = nullptr;
+    uint8_t *d_probe_tables = nullptr;  // k_probe_lut's forward and backward step tables (4 KB, built once: k_probe_tables)
     double *d_lens = nullptr;
     fid_marker *d_pose_in = nullptr;
     int *d_pose_n = nullptr;
@@ -714,8 +715,10 @@ fid_status enqueue_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H,
             hipLaunchKernelGGL(k_seed_index, dim3(8 * gm, Fs), dim3(256), 0, si, seedq, seedhash, counts, P);
             HIPCHK(c, hipEventRecord(c->aux_idx[sb], si));
             if (c->probe_lut) {
-                hipLaunchKernelGGL((k_probe_lut<PROBE0_STEPS, 0>), dim3(64 * gm, Fs), dim3(256), 0, sa, masks, starts, surv1, counts, c->d_global, P);
-                hipLaunchKernelGGL((k_probe_lut<PROBE1_STEPS, 1>), dim3(16 * gm, Fs), dim3(256), 0, sa, masks, surv1, surv, counts, c->d_global, P);
+                hipLaunchKernelGGL((k_probe_lut<PROBE0_STEPS, 0>), dim3(64 * gm, Fs), dim3(256), 0, sa, masks, starts, surv1, counts, c->d_global, P,
+                                   (const uint4 *)c->d_probe_tables);
+                hipLaunchKernelGGL((k_probe_lut<PROBE1_STEPS, 1>), dim3(16 * gm, Fs), dim3(256), 0, sa, masks, surv1, surv, counts, c->d_global, P,
+                                   (const uint4 *)c->d_probe_tables);
             } else {
                 hipLaunchKernelGGL((k_probe<PROBE0_STEPS, 0, true>), dim3(64 * gm, Fs), dim3(256), 0, sa, masks, starts, surv1, counts, c->d_global, P);
                 hipLaunchKernelGGL((k_probe<PROBE1_STEPS, 1, true>), dim3(16 * gm, Fs), dim3(256), 0, sa, masks, surv1, surv, counts, c->d_global, P);
@@ -1186,6 +1189,10 @@ fid_status fid_create(const fid_params *params, const fid_dict *dict, const fid_
     }
     const size_t F = L.max_batch, MC = L.max_candidates_per_frame, MM = L.max_markers_per_frame;
     TRY(dalloc(c, &c->d_subpix_mask, (size_t)(2 * SP_MAXWIN + 1) * (2 * SP_MAXWIN + 1)));
+    TRY(dalloc(c, &c->d_probe_tables, (size_t)4096));
+    hipLaunchKernelGGL(k_probe_tables, dim3(1), dim3(256), 0, nullptr, c->d_probe_tables);
+    TRYHIP(hipGetLastError());
+    TRYHIP(hipDeviceSynchronize());
     TRY(dalloc(c, &c->d_dict, dbytes));
     TRYHIP(hipMemcpy(c->d_dict, c->dict_host.data(), dbytes, hipMemcpyHostToDevice));
     rc = apply_params(c, params);
@@ -1272,7 +1279,7 @@ void fid_destroy(fid_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void *dev[] = {c->d_in, c->d_gray, c->d_masks, c->d_starts, c->d_surv1, c->d_surv, c->d_pool, c->d_segs, c->d_pend, c->d_seedq, c->d_seedhash, c->d_wres, c->d_cinfo, c->d_cbase, c->d_filter_scratch, c->d_accsrc, c->d_mksrc, c->d_dense, c->d_recs, c->d_contours, c->d_ckpts, c->d_cands, c->d_sorted, c->d_cmeta, c->d_filtered, c->d_near,
                    c->d_ident, c->d_pre, c->d_res, c->d_worklist, c->d_dict,
-                   c->d_subpix_mask, c->d_lens, c->d_pose_in, c->d_pose_n};
+                   c->d_subpix_mask, c->d_probe_tables, c->d_lens, c->d_pose_in, c->d_pose_n};
     for (void *p : dev)
         if (p) (void)hipFree(p);
     void *host[] = {c->h_res};

@@ -2366,14 +2366,28 @@ __device__ __forceinline__ void build_back_lut(uint8_t *lut, int tid, int nthrea
     }
 }
 
+// the two step tables of k_probe_lut, built ONCE per context into global memory (forward table, then backward table: 4 KB).
+// Until round 6 every workgroup of k_probe_lut built them itself: 16 entries a thread at 60 - 80 instructions each (the "seen"
+// loop diverges), i.e. ~1 100 wave-instructions per wave in front of a main loop that handles two starts per thread in ~400 --
+// the table build was the larger part of both probe kernels (measured: profiles/sq_cycles.json before / after).
+__global__ __launch_bounds__(256) void k_probe_tables(uint8_t *__restrict__ tables)
+{
+    build_step_lut(tables, threadIdx.x, 256);
+    build_back_lut(tables + 2048, threadIdx.x, 256);
+}
+
 template <int STEPS, int LEVEL>
 __global__ __launch_bounds__(256) void k_probe_lut(const uint32_t *__restrict__ masks, const uint2 *__restrict__ in_list,
                                                     uint2 *__restrict__ out_list, DevCounts *__restrict__ counts,
-                                                    DevGlobal *__restrict__ G, const DevParams P)
+                                                    DevGlobal *__restrict__ G, const DevParams P, const uint4 *__restrict__ tables)
 {
-    __shared__ uint8_t s_fwd[2048], s_bwd[2048];
-    build_step_lut(s_fwd, threadIdx.x, 256);
-    build_back_lut(s_bwd, threadIdx.x, 256);
+    __shared__ __attribute__((aligned(16))) uint8_t s_fwd[2048], s_bwd[2048];
+    // (one 16-byte load and store per thread: the tables come out of L2)
+    {
+        const uint4 v = tables[threadIdx.x];
+        if (threadIdx.x < 128) reinterpret_cast<uint4 *>(s_fwd)[threadIdx.x] = v;
+        else reinterpret_cast<uint4 *>(s_bwd)[threadIdx.x - 128] = v;
+    }
     __syncthreads();
     const int f = blockIdx.y;
     const int lane = lane_id();

@@ -108,7 +108,8 @@ struct k_stag_smooth_grad_fn {
 // The smoothed image is 8-bit, so |gx|, |gy| <= 3 * 255 and the gradient value never exceeds 1530: the reference's
 // 128 * 256 counting-sort bins (SIZE in SortAnchorsByGradValue) are used only below STAG_BINS.
 #define STAG_BINS 1536
-#define STAG_BAND_ROWS 8  // rows per band of k_stag_place = waves per workgroup
+#define STAG_BAND_ROWS 4  // rows per band of k_stag_place = waves per workgroup (round 6: 4, a 256-thread workgroup with 24 KB of LDS; 8 rows =
+                          // 512 threads and 48 KB waited five times its own duration for room on a CU beside the other groups' kernels)
 
 // Anchor points: local gradient maxima across the edge normal (ANCHOR_THRESH, SCAN_INTERVAL as in the reference), counted
 // per (row, gradient value) for the counting sort (global atomics: the anchors are sparse; 16-bit counts, two a word).
@@ -1088,7 +1089,7 @@ static fid_status stag_advance_impl(fid_stag_ctx *c, StagJob &j)
                                        c->d_aslots, c->d_label, 16, lds | no_sparse, c->d_prodflag, ovf, 0);
                 }
             }
-            STAG_LAUNCH(k_stag_next_above, dim3(1), dim3(1024), 0, st, c->d_prodflag, c->d_n, c->d_next);
+            STAG_LAUNCH(k_stag_next_above, dim3(1), dim3(256), 0, st, c->d_prodflag, c->d_n, c->d_next);
             if (nc > 0 && grouped) {  // (two launches by class, like the walk: the big components, then the small ones four workgroups to a CU)
                 STAG_LAUNCH(k_stag_route_extract, dim3((nc + 3) / 4), dim3(256), 0, st, j.R, A, c->d_comps, c->d_cursors, c->d_corder, c->d_next,
                                    c->d_n, c->d_blkpix, c->d_blksegs, c->d_blkwhere, ovf, 1);
@@ -1102,7 +1103,7 @@ static fid_status stag_advance_impl(fid_stag_ctx *c, StagJob &j)
                 StagScanJobs sj;
                 sj.counts[0] = c->d_blkpix; sj.total[0] = c->d_rcount + 1;
                 sj.counts[1] = c->d_blksegs; sj.total[1] = c->d_rcount;
-                STAG_LAUNCH(k_stag_scan_counts_n, dim3(2), dim3(1024), 0, st, sj, (const int *)c->d_n);
+                STAG_LAUNCH(k_stag_scan_counts_n, dim3(2), dim3(256), 0, st, sj, (const int *)c->d_n);
             }
             STAG_LAUNCH(k_stag_route_gather, dim3((na + 255) / 256), dim3(256), 0, st, A, c->d_comps, c->d_n, c->d_prodflag, c->d_blkpix, c->d_blksegs,
                                c->d_blkwhere, c->d_outpix, c->d_segs, j.R.capOut, j.R.capSegs, ovf);
@@ -1151,7 +1152,7 @@ static fid_status stag_advance_impl(fid_stag_ctx *c, StagJob &j)
             STAG_LAUNCH(k_stag_extract, dim3(wg), dim3(256), 0, st, c->d_segs, c->d_rcount, c->d_outpix, c->d_edgeimg, W, c->d_vcounts,
                                c->d_vsegs, 0);
         }
-        STAG_LAUNCH(k_stag_scan_counts, dim3(1), dim3(1024), 0, st, c->d_vcounts, c->d_rcount, c->d_vtotal);
+        STAG_LAUNCH(k_stag_scan_counts, dim3(1), dim3(256), 0, st, c->d_vcounts, c->d_rcount, c->d_vtotal);
         if (wg > 0)
             STAG_LAUNCH(k_stag_extract, dim3(wg), dim3(256), 0, st, c->d_segs, c->d_rcount, c->d_outpix, c->d_edgeimg, W, c->d_vcounts,
                                c->d_vsegs, 1);
@@ -1188,7 +1189,7 @@ static fid_status stag_advance_impl(fid_stag_ctx *c, StagJob &j)
             STAG_LAUNCH(k_stag_split_lines, dim3((ns + 3) / 4), dim3(256), (size_t)SL_LDS_BYTES(lds_pix), st, c->d_vsegs, c->d_vtotal, c->d_outpix, PF,
                                c->min_line_len, 1.0, c->d_lslots, c->d_lcounts, lds_pix);
         }
-        STAG_LAUNCH(k_stag_scan_counts, dim3(1), dim3(1024), 0, st, c->d_lcounts, c->d_vtotal, c->d_ltotal);
+        STAG_LAUNCH(k_stag_scan_counts, dim3(1), dim3(256), 0, st, c->d_lcounts, c->d_vtotal, c->d_ltotal);
         if (wg > 0)
             STAG_LAUNCH(k_stag_gather_lines, dim3(wg), dim3(64), 0, st, c->d_vsegs, c->d_vtotal, c->d_lcounts, c->d_ltotal, c->d_lslots, c->d_lines);
         if (hipGetLastError() != hipSuccess) return stag_finish(j, FID_E_HIP);
@@ -1223,7 +1224,7 @@ static fid_status stag_advance_impl(fid_stag_ctx *c, StagJob &j)
         if (nl > 0)
             STAG_LAUNCH(k_stag_validate_lines, dim3((nl + 63) / 64), dim3(64), 0, st, c->d_lines, c->d_ltotal, c->d_src, W, H, c->d_vsegs,
                                c->d_outpix, T, c->d_lflags);
-        STAG_LAUNCH(k_stag_scan_counts, dim3(1), dim3(1024), 0, st, c->d_lflags, c->d_ltotal, c->d_vltotal);
+        STAG_LAUNCH(k_stag_scan_counts, dim3(1), dim3(256), 0, st, c->d_lflags, c->d_ltotal, c->d_vltotal);
         if (nl > 0)
             STAG_LAUNCH(k_stag_compact_lines, dim3((nl + 255) / 256), dim3(256), 0, st, c->d_lines, c->d_ltotal, c->d_lflags, c->d_vltotal,
                                c->d_vlines);
@@ -1248,7 +1249,7 @@ static fid_status stag_advance_impl(fid_stag_ctx *c, StagJob &j)
         if (ns > 0)
             STAG_LAUNCH(k_stag_quads, dim3((ns + 3) / 4), dim3(256), 0, st, c->d_vlines, c->d_lrange, c->d_vtotal, c->d_vsegs, c->d_outpix, c->d_src,
                                W, H, c->d_corners, c->d_order, c->d_qslots, c->d_qcounts);
-        STAG_LAUNCH(k_stag_scan_counts, dim3(1), dim3(1024), 0, st, c->d_qcounts, c->d_vtotal, c->d_qtotal);
+        STAG_LAUNCH(k_stag_scan_counts, dim3(1), dim3(256), 0, st, c->d_qcounts, c->d_vtotal, c->d_qtotal);
         if (ns > 0)
             STAG_LAUNCH(k_stag_gather_quads, dim3((ns + 63) / 64), dim3(64), 0, st, c->d_lrange, c->d_vtotal, c->d_qcounts, c->d_qtotal, c->d_qslots,
                                c->d_quads);

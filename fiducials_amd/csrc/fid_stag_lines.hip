@@ -284,7 +284,10 @@ __device__ __forceinline__ void k_stag_scan_counts_n_impl(StagScanJobs J, const 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = counters[0];
     constexpr int PER = 8;
     int carry = 0;
-    for (int base = 0; base < n; base += 1024 * PER) {
+    // (any block size up to 1 024: round 6 launches these with 256 threads -- a 1 024-thread workgroup waits for sixteen free wave
+    //  slots on ONE CU, and beside the other groups' kernels that wait was ten times the scan: 9 us alone, 90 us in the batch)
+    const int NT = (int)blockDim.x, NWV = NT >> 6;
+    for (int base = 0; base < n; base += NT * PER) {
         const int i0 = base + tid * PER;
         int v[PER], sum = 0;
 #pragma unroll
@@ -298,7 +301,7 @@ __device__ __forceinline__ void k_stag_scan_counts_n_impl(StagScanJobs J, const 
         int wbase = 0, tot = 0;
 #pragma unroll
         for (int k = 0; k < 16; k++) {
-            const int t = s_w[k];
+            const int t = k < NWV ? s_w[k] : 0;
             wbase += k < wv ? t : 0;
             tot += t;
         }
@@ -327,7 +330,10 @@ __device__ __forceinline__ void k_stag_scan_counts_impl(int *__restrict__ counts
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = counters[0];
     constexpr int PER = 8;
     int carry = 0;
-    for (int base = 0; base < n; base += 1024 * PER) {
+    // (any block size up to 1 024: round 6 launches these with 256 threads -- a 1 024-thread workgroup waits for sixteen free wave
+    //  slots on ONE CU, and beside the other groups' kernels that wait was ten times the scan: 9 us alone, 90 us in the batch)
+    const int NT = (int)blockDim.x, NWV = NT >> 6;
+    for (int base = 0; base < n; base += NT * PER) {
         const int i0 = base + tid * PER;
         int v[PER], sum = 0;
 #pragma unroll
@@ -341,7 +347,7 @@ __device__ __forceinline__ void k_stag_scan_counts_impl(int *__restrict__ counts
         int wbase = 0, tot = 0;
 #pragma unroll
         for (int k = 0; k < 16; k++) {
-            const int t = s_w[k];
+            const int t = k < NWV ? s_w[k] : 0;
             wbase += k < wv ? t : 0;
             tot += t;
         }

@@ -1568,7 +1568,8 @@ __device__ __forceinline__ void k_stag_next_above_impl(const int *__restrict__ p
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = (int)*n_anchors;
     constexpr int PER = 8;
     int carry = INT_MAX;
-    for (int top = n; top > 0; top -= 1024 * PER) {
+    const int NT = (int)blockDim.x, NWV = NT >> 6;  // (any block size up to 1 024; launched with 256 since round 6, see k_stag_scan_counts)
+    for (int top = n; top > 0; top -= NT * PER) {
         const int r0 = top - 1 - tid * PER;  // this thread's ranks: r0, r0 - 1, ...
         int f[PER], loc = INT_MAX;
 #pragma unroll
@@ -1588,7 +1589,7 @@ __device__ __forceinline__ void k_stag_next_above_impl(const int *__restrict__ p
         int wpre = INT_MAX, tot = INT_MAX;
 #pragma unroll
         for (int k = 0; k < 16; k++) {
-            const int t = s_w[k];
+            const int t = k < NWV ? s_w[k] : INT_MAX;
             if (k < wv) wpre = min(wpre, t);
             tot = min(tot, t);
         }

@@ -1071,7 +1071,17 @@ static fid_status stag_advance_impl(fid_stag_ctx *c, StagJob &j)
             if (nc > 0) {
                 STAG_LAUNCH(k_stag_comp_sort, dim3((nc + 3) / 4), dim3(256), 0, st, c->d_comps, c->d_cursors, c->d_aslots);
                 if (cur[9] > STAG_SORT_WAVE)  // (cur[9]: most anchors in one component)
-                    STAG_LAUNCH(k_stag_comp_sort_big, dim3(nc < 24 ? nc : 24), dim3(1024), (size_t)STAG_SORT_BIG * 4, st, c->d_comps, c->d_cursors, c->d_aslots);
+                {
+                    // LDS and threads by the frame's largest slice (cur[9] anchors, padded to a power of two like k_stag_comp_alloc pads it):
+                    // a marker frame's slices are 1 - 4 K entries, and a 1 024-thread workgroup with the full 64 KB waited five times
+                    // its own duration for room on a CU beside the other groups' kernels.  A frame queued ahead knows only a PREDICTED
+                    // count (its guard admits up to 65 536): the full size there.
+                    int p2 = 1;
+                    while (p2 < cur[9] && p2 < STAG_SORT_BIG) p2 <<= 1;
+                    const int slice = j.spec ? STAG_SORT_BIG : p2;
+                    STAG_LAUNCH(k_stag_comp_sort_big, dim3(nc < 24 ? nc : 24), dim3(slice <= 4096 ? 256 : 1024), (size_t)slice * 4, st, c->d_comps,
+                                       c->d_cursors, c->d_aslots);
+                }
                 // LDS per workgroup = the largest tile a component of this frame asks for (components whose box does not fit 150 KB
                 // walk in global memory): frames of small components keep many workgroups per CU
                 const int no_sparse = c->no_sparse;  // (FID_STAG_SPARSE=0: no blocks, the walk in global memory)

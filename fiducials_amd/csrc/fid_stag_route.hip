@@ -1242,11 +1242,11 @@ __device__ __forceinline__ void k_stag_comp_sort_big_impl(const StagComp *__rest
     if (C.nanch < 2 || P <= STAG_SORT_WAVE || P > STAG_SORT_BIG) continue;
     __syncthreads();  // (the slice of the component before this one has left the LDS)
     int *g = aslots + C.anch_base;
-    for (int i = threadIdx.x; i < P; i += 1024) s_big[i] = g[i];
+    for (int i = threadIdx.x; i < P; i += (int)blockDim.x) s_big[i] = g[i];
     __syncthreads();
     for (int k = 2; k <= P; k <<= 1)
         for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = threadIdx.x; i < P; i += 1024) {
+            for (int i = threadIdx.x; i < P; i += (int)blockDim.x) {
                 const int l = i ^ j;
                 if (l > i) {
                     const int x = s_big[i], y = s_big[l];
@@ -1259,7 +1259,7 @@ __device__ __forceinline__ void k_stag_comp_sort_big_impl(const StagComp *__rest
             }
             __syncthreads();
         }
-    for (int i = threadIdx.x; i < P; i += 1024) g[i] = s_big[i];
+    for (int i = threadIdx.x; i < P; i += (int)blockDim.x) g[i] = s_big[i];
     }
 }
 __global__ __launch_bounds__(1024) void k_stag_comp_sort_big(const StagComp *__restrict__ comps, const int *__restrict__ cursors, int *aslots)

@@ -1101,7 +1101,7 @@ static fid_status stag_advance_impl(fid_stag_ctx *c, StagJob &j)
             }
             STAG_LAUNCH(k_stag_next_above, dim3(1), dim3(256), 0, st, c->d_prodflag, c->d_n, c->d_next);
             if (nc > 0 && grouped) {  // (two launches by class, like the walk: the big components, then the small ones four workgroups to a CU)
-                STAG_LAUNCH(k_stag_route_extract, dim3((nc + 3) / 4), dim3(256), 0, st, j.R, A, c->d_comps, c->d_cursors, c->d_corder, c->d_next,
+                STAG_LAUNCH(k_stag_route_extract_big, dim3(nc), dim3(64), 0, st, j.R, A, c->d_comps, c->d_cursors, c->d_corder, c->d_next,
                                    c->d_n, c->d_blkpix, c->d_blksegs, c->d_blkwhere, ovf, 1);
                 STAG_LAUNCH(k_stag_route_extract_small, dim3((nc + 3) / 4), dim3(256), 0, st, j.R, A, c->d_comps, c->d_cursors, c->d_corder,
                                    c->d_next, c->d_n, c->d_blkpix, c->d_blksegs, c->d_blkwhere, ovf, 2);
@@ -1196,8 +1196,16 @@ static fid_status stag_advance_impl(fid_stag_ctx *c, StagJob &j)
             // workgroups per CU resident.  FID_STAG_SPLIT_LDS overrides (0: global memory throughout).
             int lds_pix = c->split_lds_env >= 0 ? c->split_lds_env : (grouped ? 256 : 1024);
             lds_pix = lds_pix > 1024 ? 1024 : lds_pix;
-            STAG_LAUNCH(k_stag_split_lines, dim3((ns + 3) / 4), dim3(256), (size_t)SL_LDS_BYTES(lds_pix), st, c->d_vsegs, c->d_vtotal, c->d_outpix, PF,
-                               c->min_line_len, 1.0, c->d_lslots, c->d_lcounts, lds_pix);
+            if (grouped && c->split_lds_env < 0) {
+                // (two launches of one-wave workgroups by segment length: see k_stag_split_lines_impl)
+                STAG_LAUNCH(k_stag_split_lines, dim3(ns), dim3(64), (size_t)sl_lds_wave_bytes(1024), st, c->d_vsegs, c->d_vtotal, c->d_outpix, PF,
+                                   c->min_line_len, 1.0, c->d_lslots, c->d_lcounts, 1024, 256, 0x7fffffff);
+                STAG_LAUNCH(k_stag_split_lines, dim3(ns), dim3(64), (size_t)sl_lds_wave_bytes(256), st, c->d_vsegs, c->d_vtotal, c->d_outpix, PF,
+                                   c->min_line_len, 1.0, c->d_lslots, c->d_lcounts, 256, -1, 256);
+            } else {
+                STAG_LAUNCH(k_stag_split_lines, dim3((ns + 3) / 4), dim3(256), (size_t)SL_LDS_BYTES(lds_pix), st, c->d_vsegs, c->d_vtotal, c->d_outpix, PF,
+                                   c->min_line_len, 1.0, c->d_lslots, c->d_lcounts, lds_pix, -1, 0x7fffffff);
+            }
         }
         STAG_LAUNCH(k_stag_scan_counts, dim3(1), dim3(256), 0, st, c->d_lcounts, c->d_vtotal, c->d_ltotal);
         if (wg > 0)
@@ -1530,7 +1538,7 @@ static fid_status stag_batch_groups(fid_stag_ctx *const *ctxs, int32_t nctx, con
 {
     // a group is at most as large as the smallest argument table (the routing kernels carry ~250 bytes of arguments per frame and
     // kernel-argument memory is 4 KB: a group one frame larger would launch them twice)
-    constexpr int kGroupMax = std::min({StagTab<k_stag_route_walk_fn>::kMax, StagTab<k_stag_route_extract_fn>::kMax, StagTab<k_stag_route_extract_small_fn>::kMax, StagTab<k_stag_route_gather_fn>::kMax,
+    constexpr int kGroupMax = std::min({StagTab<k_stag_route_walk_fn>::kMax, StagTab<k_stag_route_extract_fn>::kMax, StagTab<k_stag_route_extract_small_fn>::kMax, StagTab<k_stag_route_extract_big_fn>::kMax, StagTab<k_stag_route_gather_fn>::kMax,
                                         StagTab<k_stag_quads_fn>::kMax, StagTab<k_stag_decode_fn>::kMax, StagTab<k_stag_validate_lines_fn>::kMax,
                                         StagTab<k_stag_split_lines_fn>::kMax, StagTab<k_stag_refine_fn>::kMax, (int)STAG_MAXF});
     // Group size.  More frames per launch make the whole-image passes cheaper per frame (a group of 16 costs 305 us of kernel time a

@@ -726,13 +726,18 @@ __host__ __device__ constexpr int sl_lds_wave_bytes(int lds_pix) { return ((lds_
 template <bool FM = false>
 __device__ __forceinline__ void k_stag_split_lines_impl(const int2 *__restrict__ segs, const int *__restrict__ nsegs, const int2 *__restrict__ pix,
                                                           StagPrefix PF, int min_line_len, double line_error, fid_stag_line *__restrict__ slots,
-                                                          int *__restrict__ counts, int lds_pix)
+                                                          int *__restrict__ counts, int lds_pix, int min_n, int max_n)
 {
     extern __shared__ long long s_sl[];
+    // (a wave per segment, any number of waves per workgroup: a frame on its own runs four with 1 024 pixels of LDS each; a group of
+    //  frames takes the segments in two launches of ONE-wave workgroups -- the long ones (min_n < n) with 1 024 pixels of LDS, which
+    //  until round 6 took the global-memory road in a group, the short ones with 256 -- so that a workgroup asks a CU for 9 or 37 KB
+    //  and one wave slot instead of 37 KB and four)
     const int wv = threadIdx.x >> 6;
-    const int seg = (int)STAG_BX<FM>() * 4 + wv, lane = threadIdx.x & 63;
+    const int seg = (int)STAG_BX<FM>() * (int)(blockDim.x >> 6) + wv, lane = threadIdx.x & 63;
     if (seg >= *nsegs) return;
     const int first = segs[seg].x, n = segs[seg].y;
+    if (n <= min_n || n > max_n) return;  // (the other launch's segment)
     const int2 *px = pix + first;
     if (n <= lds_pix) {
         // the wave's share: three 64-bit arrays, then three 32-bit ones
@@ -797,14 +802,14 @@ __device__ __forceinline__ void k_stag_split_lines_impl(const int2 *__restrict__
     }
     sl_split_body(G, n, seg, first, lane, min_line_len, line_error, slots, counts);
 }
-__global__ __launch_bounds__(256) void k_stag_split_lines(const int2 *__restrict__ segs, const int *__restrict__ nsegs, const int2 *__restrict__ pix, StagPrefix PF, int min_line_len, double line_error, fid_stag_line *__restrict__ slots, int *__restrict__ counts, int lds_pix)
+__global__ __launch_bounds__(256) void k_stag_split_lines(const int2 *__restrict__ segs, const int *__restrict__ nsegs, const int2 *__restrict__ pix, StagPrefix PF, int min_line_len, double line_error, fid_stag_line *__restrict__ slots, int *__restrict__ counts, int lds_pix, int min_n, int max_n)
 {
-    k_stag_split_lines_impl(segs, nsegs, pix, PF, min_line_len, line_error, slots, counts, lds_pix);
+    k_stag_split_lines_impl(segs, nsegs, pix, PF, min_line_len, line_error, slots, counts, lds_pix, min_n, max_n);
 }
 struct k_stag_split_lines_fn {
     static constexpr int kBounds = 256;
     static constexpr bool kFrameMinor = true;
-    __device__ __forceinline__ void operator()(const int2 *__restrict__ segs, const int *__restrict__ nsegs, const int2 *__restrict__ pix, StagPrefix PF, int min_line_len, double line_error, fid_stag_line *__restrict__ slots, int *__restrict__ counts, int lds_pix) const { k_stag_split_lines_impl<true>(segs, nsegs, pix, PF, min_line_len, line_error, slots, counts, lds_pix); }
+    __device__ __forceinline__ void operator()(const int2 *__restrict__ segs, const int *__restrict__ nsegs, const int2 *__restrict__ pix, StagPrefix PF, int min_line_len, double line_error, fid_stag_line *__restrict__ slots, int *__restrict__ counts, int lds_pix, int min_n, int max_n) const { k_stag_split_lines_impl<true>(segs, nsegs, pix, PF, min_line_len, line_error, slots, counts, lds_pix, min_n, max_n); }
 };
 
 // the lines of every segment, one after the other in segment order (counts hold exclusive prefix sums by now)

@@ -1614,7 +1614,7 @@ struct k_stag_next_above_fn {
     __device__ __forceinline__ void operator()(const int *__restrict__ prodflag, const unsigned *__restrict__ n_anchors, int *__restrict__ next) const { k_stag_next_above_impl(prodflag, n_anchors, next); }
 };
 
-template <bool FM = false, int EX_CHAINS = 512, int EX_PIX = 1024>
+template <bool FM = false, int EX_CHAINS = 512, int EX_PIX = 1024, int NWV = 4>
 __device__ __forceinline__ void k_stag_route_extract_impl(StagRoute G, StagArenas A, const StagComp *__restrict__ comps, const int *__restrict__ cursors,
                                                             const int *__restrict__ order, const int *__restrict__ next, const unsigned *__restrict__ n_anchors,
                                                             int *__restrict__ blk_pix, int *__restrict__ blk_segs, int2 *__restrict__ blk_where,
@@ -1630,11 +1630,14 @@ __device__ __forceinline__ void k_stag_route_extract_impl(StagRoute G, StagArena
     //  component needs; a group of frames takes its SMALL components (< STAG_BIG_COMP pixels) through an instance of 128 / 256 = 8 KB a
     //  wave, four workgroups per CU, in a launch of its own: cls as in k_stag_route_walk_impl.  Which instance a component meets
     //  only decides where its chain tree lives while it is taken apart -- the arithmetic is the same.)
-    __shared__ StagChain s_chains[4][EX_CHAINS];
-    __shared__ int4 s_stack[4][EX_CHAINS];
-    __shared__ int2 s_pix[4][EX_PIX + 1], s_out[4][EX_PIX + 1];
+    // (NWV waves per workgroup, a component each: 4 for a frame on its own and for a group's small components; ONE for a group's big
+    //  components -- a 4-wave workgroup of the 32 KB-a-wave instance needs a CU with 128 KB of LDS free, and beside the other groups'
+    //  kernels it waited for one longer than it then ran: 479 us alone, 1 110 us in the batch)
+    __shared__ StagChain s_chains[NWV][EX_CHAINS];
+    __shared__ int4 s_stack[NWV][EX_CHAINS];
+    __shared__ int2 s_pix[NWV][EX_PIX + 1], s_out[NWV][EX_PIX + 1];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int rank = (int)STAG_BX<FM>() * 4 + wv + (cls == 2 ? cursors[11] : 0);
+    const int rank = (int)STAG_BX<FM>() * NWV + wv + (cls == 2 ? cursors[11] : 0);
     if (rank >= (cls == 1 ? cursors[11] : cursors[0])) return;
     const int cid = stag_comp_by_rank(order, cursors, rank);  // (longest first, as the walk took them)
     const StagComp C = sr_uni_struct(comps[cid]);
@@ -1731,6 +1734,16 @@ struct k_stag_route_extract_fn {
     static constexpr int kBounds = 256;
     static constexpr bool kFrameMinor = true;
     __device__ __forceinline__ void operator()(StagRoute G, StagArenas A, const StagComp *__restrict__ comps, const int *__restrict__ cursors, const int *__restrict__ order, const int *__restrict__ next, const unsigned *__restrict__ n_anchors, int *__restrict__ blk_pix, int *__restrict__ blk_segs, int2 *__restrict__ blk_where, int *__restrict__ ovf, int cls) const { k_stag_route_extract_impl<true>(G, A, comps, cursors, order, next, n_anchors, blk_pix, blk_segs, blk_where, ovf, cls); }
+};
+// (a group's big components: one wave, 32 KB, per workgroup)
+__global__ __launch_bounds__(64) void k_stag_route_extract_big(StagRoute G, StagArenas A, const StagComp *__restrict__ comps, const int *__restrict__ cursors, const int *__restrict__ order, const int *__restrict__ next, const unsigned *__restrict__ n_anchors, int *__restrict__ blk_pix, int *__restrict__ blk_segs, int2 *__restrict__ blk_where, int *__restrict__ ovf, int cls)
+{
+    k_stag_route_extract_impl<false, 512, 1024, 1>(G, A, comps, cursors, order, next, n_anchors, blk_pix, blk_segs, blk_where, ovf, cls);
+}
+struct k_stag_route_extract_big_fn {
+    static constexpr int kBounds = 64;
+    static constexpr bool kFrameMinor = true;
+    __device__ __forceinline__ void operator()(StagRoute G, StagArenas A, const StagComp *__restrict__ comps, const int *__restrict__ cursors, const int *__restrict__ order, const int *__restrict__ next, const unsigned *__restrict__ n_anchors, int *__restrict__ blk_pix, int *__restrict__ blk_segs, int2 *__restrict__ blk_where, int *__restrict__ ovf, int cls) const { k_stag_route_extract_impl<true, 512, 1024, 1>(G, A, comps, cursors, order, next, n_anchors, blk_pix, blk_segs, blk_where, ovf, cls); }
 };
 // (the small-footprint instance: group mode only)
 __global__ __launch_bounds__(256) void k_stag_route_extract_small(StagRoute G, StagArenas A, const StagComp *__restrict__ comps, const int *__restrict__ cursors, const int *__restrict__ order, const int *__restrict__ next, const unsigned *__restrict__ n_anchors, int *__restrict__ blk_pix, int *__restrict__ blk_segs, int2 *__restrict__ blk_where, int *__restrict__ ovf, int cls)

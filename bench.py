@@ -830,6 +830,13 @@ def stag_side_result(local_rank, args):
         m, _ = pool.detect_markers_batch(batch, synth.K_DEFAULT, None, 0.18)
         found += sum(len(x) for x in m)
     dt = time.perf_counter() - t
+    # (a blocking call starts and drains the groups' pipelines once per call: twice the frames per call shows how much of the figure
+    #  above that is -- a stream of frames would have neither)
+    batch2 = np.concatenate([batch, batch])
+    t2 = time.perf_counter()
+    pool.detect_markers_batch(batch2, synth.K_DEFAULT, None, 0.18)
+    fps_2048 = len(batch2) / (time.perf_counter() - t2)
+    del batch2
     pool.close()  # (before the next context: 22 + 1 streams would touch the limit of 24 hardware queues)
     one = fstag.StagDetector(hd, ec, max_width=W, max_height=H, device=local_rank)
     ts = []
@@ -843,6 +850,7 @@ def stag_side_result(local_rank, args):
     fps5 = B * steps / dt
     res = {"value": round(fps5, 2), "unit": "frames/s", "ms_single_frame": round(float(np.median(ts[2:])) * 1e3, 3),
            "single_frame_queued_ahead": {"calls": len(ts), "queued": queued, "rerun_on_the_counted_road": rerun},
+           "frames_per_s_at_2048_per_call": round(fps_2048, 2),
            "roofline": {"bound": "hbm", "kernel": "pipeline (latency-bound: edge routing, line fitting, simplex search)",
                         "achieved": round(fps5 * algo / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(fps5 * algo / 1e9 / HBM_PEAK_GBS, 6),
                         "algo_bytes_per_frame": algo, "traffic": stag_pmc_traffic()},

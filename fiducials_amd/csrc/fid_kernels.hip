@@ -3599,11 +3599,8 @@ __global__ __launch_bounds__(256) void k_near(const DevCand *__restrict__ sorted
     const int lane = lane_id();
     const float rate_f = (float)P.minMarkerDistRate * 1.0001f;
     const int wave = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)), nwaves = (int)(gridDim.x * (blockDim.x >> 6));
-    // (round 6) a wave takes the ROWS wave, wave + nwaves, ... and in a row only the 64-column blocks from the one that holds i itself
-    // on (its words belong to the row): until now the items were all n x nw2 (row, block) pairs, found by a division, and the
-    // half below the diagonal was skipped one `continue` at a time -- a third of this kernel's instructions were that bookkeeping
-    for (int i = wave; i < n; i += nwaves)
-      for (int w2 = i >> 6; w2 < nw2; w2++) {
+    // One (row i, 64-column block w2) item: lane = column j.
+    auto item = [&](int i, int w2) {
         const int j = w2 * 64 + lane;
         const bool valid = j > i && j < n;
         const float4 ma = cm[i];
@@ -3643,6 +3640,20 @@ __global__ __launch_bounds__(256) void k_near(const DevCand *__restrict__ sorted
         if (lane < 2) {
             const int w = 2 * w2 + lane;
             if (w >= (i >> 5) && w < nw) nb[near_row_off(i, nw) + w - (i >> 5)] = (uint32_t)(bits >> (32 * lane));
+        }
+    };
+    // (round 6) Batches: a wave takes the ROWS wave, wave + nwaves, ... and in a row only the blocks from the one that holds i itself
+    // on (its words belong to the row) -- until now every (row, block) pair was an item found by a division, and the half below
+    // the diagonal was skipped one `continue` at a time: a third of this kernel's instructions.  A call of a few frames has more
+    // waves than rows (the grid is sized for the latency of ONE frame): there the items stay spread over all waves.
+    if (nwaves <= n) {
+        for (int i = wave; i < n; i += nwaves)
+            for (int w2 = i >> 6; w2 < nw2; w2++) item(i, w2);
+    } else {
+        for (int it = wave; it < n * nw2; it += nwaves) {
+            const int i = it / nw2, w2 = it - i * nw2;
+            if (w2 * 64 + 63 < i) continue;  // (the block that holds i itself is kept)
+            item(i, w2);
         }
     }
 }

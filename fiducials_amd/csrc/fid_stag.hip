@@ -190,12 +190,12 @@ __device__ __forceinline__ void k_stag_bandscan_impl(unsigned *__restrict__ band
     const int g = blockIdx.x * 256 + threadIdx.x;
     unsigned acc = 0;
     int b = nbands - 1;
-    for (; b >= 3; b -= 4) {  // four independent loads in flight
-        unsigned n[4];
+    for (; b >= 15; b -= 16) {  // sixteen independent loads in flight (four until round 6: with 4-row bands a 1080p frame has 270 of them)
+        unsigned n[16];
 #pragma unroll
-        for (int k = 0; k < 4; k++) n[k] = bandhist[(size_t)(b - k) * STAG_BINS + g];
+        for (int k = 0; k < 16; k++) n[k] = bandhist[(size_t)(b - k) * STAG_BINS + g];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
+        for (int k = 0; k < 16; k++) {
             bandhist[(size_t)(b - k) * STAG_BINS + g] = acc;
             acc += n[k];
         }
@@ -914,6 +914,10 @@ static fid_status stag_advance_impl(fid_stag_ctx *c, StagJob &j)
     if (j.done) return j.rc;
     hipStream_t st = c->group_stream ? c->group_stream : stag_stream(c);
     const bool grouped = c->group_stream != nullptr;  // (the group driver has waited for the group's stream already)
+    // threads of the one-workgroup scans (block-size generic kernels): a frame on its own has the chip to itself and wants the scan
+    // short (30 k anchors: 4 rounds of 1 024 threads against 15 of 256); in a group a 1 024-thread workgroup waits for sixteen free
+    // wave slots on one CU longer than the scan takes
+    const int scan_threads = grouped ? 256 : 1024;
     if (hipSetDevice(c->device) != hipSuccess) return stag_finish(j, FID_E_HIP);
 #ifdef FID_DEBUG_STATS
     {
@@ -1013,8 +1017,8 @@ static fid_status stag_advance_impl(fid_stag_ctx *c, StagJob &j)
             STAG_LAUNCH(k_stag_ccl_border, tiles, dim3(128), 0, st, W, H, c->d_label);
             STAG_LAUNCH(k_stag_ccl_flatten, tiles, dim3(256), 0, st, W, H, c->d_label, c->d_edge, c->d_csize, c->d_canch, c->d_cbox, c->d_roots, c->d_cursors, c->d_tilefg);
         }
-        // (one thread per ROOT of k_stag_ccl_flatten's list; the grid covers the most roots an image of this size can have)
-        STAG_LAUNCH(k_stag_comp_alloc, dim3((((W + 1) / 2) * ((H + 1) / 2) + 255) / 256), dim3(256), 0, st, c->d_roots, c->d_csize, c->d_canch, c->d_cbox,
+        // (one thread per ROOT of k_stag_ccl_flatten's list, 64 workgroups going through it: a frame has a few hundred to a few thousand roots)
+        STAG_LAUNCH(k_stag_comp_alloc, dim3(64), dim3(256), 0, st, c->d_roots, c->d_csize, c->d_canch, c->d_cbox,
                            c->d_cursors, c->max_comps, c->d_caps, c->d_comps, c->d_cidmap);
         STAG_LAUNCH(k_stag_comp_fill, dim3((na + 255) / 256), dim3(256), 0, st, c->d_sorted, c->d_n, c->d_label, c->d_cidmap, c->d_comps, c->d_fill,
                            c->d_aslots);
@@ -1079,7 +1083,7 @@ static fid_status stag_advance_impl(fid_stag_ctx *c, StagJob &j)
                     int p2 = 1;
                     while (p2 < cur[9] && p2 < STAG_SORT_BIG) p2 <<= 1;
                     const int slice = j.spec ? STAG_SORT_BIG : p2;
-                    STAG_LAUNCH(k_stag_comp_sort_big, dim3(nc < 24 ? nc : 24), dim3(slice <= 4096 ? 256 : 1024), (size_t)slice * 4, st, c->d_comps,
+                    STAG_LAUNCH(k_stag_comp_sort_big, dim3(!grouped || nc < 24 ? nc : 24), dim3(slice <= 4096 ? 256 : 1024), (size_t)slice * 4, st, c->d_comps,
                                        c->d_cursors, c->d_aslots);
                 }
                 // LDS per workgroup = the largest tile a component of this frame asks for (components whose box does not fit 150 KB
@@ -1099,7 +1103,7 @@ static fid_status stag_advance_impl(fid_stag_ctx *c, StagJob &j)
                                        c->d_aslots, c->d_label, 16, lds | no_sparse, c->d_prodflag, ovf, 0);
                 }
             }
-            STAG_LAUNCH(k_stag_next_above, dim3(1), dim3(256), 0, st, c->d_prodflag, c->d_n, c->d_next);
+            STAG_LAUNCH(k_stag_next_above, dim3(1), dim3(scan_threads), 0, st, c->d_prodflag, c->d_n, c->d_next);
             if (nc > 0 && grouped) {  // (two launches by class, like the walk: the big components, then the small ones four workgroups to a CU)
                 STAG_LAUNCH(k_stag_route_extract_big, dim3(nc), dim3(64), 0, st, j.R, A, c->d_comps, c->d_cursors, c->d_corder, c->d_next,
                                    c->d_n, c->d_blkpix, c->d_blksegs, c->d_blkwhere, ovf, 1);
@@ -1113,9 +1117,12 @@ static fid_status stag_advance_impl(fid_stag_ctx *c, StagJob &j)
                 StagScanJobs sj;
                 sj.counts[0] = c->d_blkpix; sj.total[0] = c->d_rcount + 1;
                 sj.counts[1] = c->d_blksegs; sj.total[1] = c->d_rcount;
-                STAG_LAUNCH(k_stag_scan_counts_n, dim3(2), dim3(256), 0, st, sj, (const int *)c->d_n);
+                STAG_LAUNCH(k_stag_scan_counts_n, dim3(2), dim3(scan_threads), 0, st, sj, (const int *)c->d_n);
             }
-            STAG_LAUNCH(k_stag_route_gather, dim3((na + 255) / 256), dim3(256), 0, st, A, c->d_comps, c->d_n, c->d_prodflag, c->d_blkpix, c->d_blksegs,
+            // (anchors per wave: 64 in a group -- a lane asks, the wave copies what produced, one after the other; 1 for a frame on its own,
+            //  where the chip is empty and the copies of a wave's producing anchors should not queue behind each other)
+            const int gpw = grouped ? 64 : 1;
+            STAG_LAUNCH(k_stag_route_gather, dim3((na + 4 * gpw - 1) / (4 * gpw)), dim3(256), 0, st, gpw, A, c->d_comps, c->d_n, c->d_prodflag, c->d_blkpix, c->d_blksegs,
                                c->d_blkwhere, c->d_outpix, c->d_segs, j.R.capOut, j.R.capSegs, ovf);
             if (hipGetLastError() != hipSuccess) return stag_finish(j, FID_E_HIP);
             if (!j.spec && (STAG_MEMCPY(c->hp->rcount, c->d_rcount, 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
@@ -1162,7 +1169,7 @@ static fid_status stag_advance_impl(fid_stag_ctx *c, StagJob &j)
             STAG_LAUNCH(k_stag_extract, dim3(wg), dim3(256), 0, st, c->d_segs, c->d_rcount, c->d_outpix, c->d_edgeimg, W, c->d_vcounts,
                                c->d_vsegs, 0);
         }
-        STAG_LAUNCH(k_stag_scan_counts, dim3(1), dim3(256), 0, st, c->d_vcounts, c->d_rcount, c->d_vtotal);
+        STAG_LAUNCH(k_stag_scan_counts, dim3(1), dim3(scan_threads), 0, st, c->d_vcounts, c->d_rcount, c->d_vtotal);
         if (wg > 0)
             STAG_LAUNCH(k_stag_extract, dim3(wg), dim3(256), 0, st, c->d_segs, c->d_rcount, c->d_outpix, c->d_edgeimg, W, c->d_vcounts,
                                c->d_vsegs, 1);
@@ -1207,7 +1214,7 @@ static fid_status stag_advance_impl(fid_stag_ctx *c, StagJob &j)
                                    c->min_line_len, 1.0, c->d_lslots, c->d_lcounts, lds_pix, -1, 0x7fffffff);
             }
         }
-        STAG_LAUNCH(k_stag_scan_counts, dim3(1), dim3(256), 0, st, c->d_lcounts, c->d_vtotal, c->d_ltotal);
+        STAG_LAUNCH(k_stag_scan_counts, dim3(1), dim3(scan_threads), 0, st, c->d_lcounts, c->d_vtotal, c->d_ltotal);
         if (wg > 0)
             STAG_LAUNCH(k_stag_gather_lines, dim3(wg), dim3(64), 0, st, c->d_vsegs, c->d_vtotal, c->d_lcounts, c->d_ltotal, c->d_lslots, c->d_lines);
         if (hipGetLastError() != hipSuccess) return stag_finish(j, FID_E_HIP);
@@ -1242,7 +1249,7 @@ static fid_status stag_advance_impl(fid_stag_ctx *c, StagJob &j)
         if (nl > 0)
             STAG_LAUNCH(k_stag_validate_lines, dim3((nl + 63) / 64), dim3(64), 0, st, c->d_lines, c->d_ltotal, c->d_src, W, H, c->d_vsegs,
                                c->d_outpix, T, c->d_lflags);
-        STAG_LAUNCH(k_stag_scan_counts, dim3(1), dim3(256), 0, st, c->d_lflags, c->d_ltotal, c->d_vltotal);
+        STAG_LAUNCH(k_stag_scan_counts, dim3(1), dim3(scan_threads), 0, st, c->d_lflags, c->d_ltotal, c->d_vltotal);
         if (nl > 0)
             STAG_LAUNCH(k_stag_compact_lines, dim3((nl + 255) / 256), dim3(256), 0, st, c->d_lines, c->d_ltotal, c->d_lflags, c->d_vltotal,
                                c->d_vlines);
@@ -1267,7 +1274,7 @@ static fid_status stag_advance_impl(fid_stag_ctx *c, StagJob &j)
         if (ns > 0)
             STAG_LAUNCH(k_stag_quads, dim3((ns + 3) / 4), dim3(256), 0, st, c->d_vlines, c->d_lrange, c->d_vtotal, c->d_vsegs, c->d_outpix, c->d_src,
                                W, H, c->d_corners, c->d_order, c->d_qslots, c->d_qcounts);
-        STAG_LAUNCH(k_stag_scan_counts, dim3(1), dim3(256), 0, st, c->d_qcounts, c->d_vtotal, c->d_qtotal);
+        STAG_LAUNCH(k_stag_scan_counts, dim3(1), dim3(scan_threads), 0, st, c->d_qcounts, c->d_vtotal, c->d_qtotal);
         if (ns > 0)
             STAG_LAUNCH(k_stag_gather_quads, dim3((ns + 63) / 64), dim3(64), 0, st, c->d_lrange, c->d_vtotal, c->d_qcounts, c->d_qtotal, c->d_qslots,
                                c->d_quads);

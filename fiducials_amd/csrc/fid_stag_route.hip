@@ -1052,17 +1052,17 @@ __device__ __forceinline__ void k_stag_comp_alloc_impl(const int *__restrict__ r
                                                          const int *__restrict__ canch, const int4 *__restrict__ cbox, int *__restrict__ cursors, int max_comps,
                                                          const int *caps, StagComp *__restrict__ comps, int *__restrict__ cidmap)
 {
-    const int k = blockIdx.x * 256 + threadIdx.x;
-    if (k >= cursors[13]) return;
+    const int nroots = cursors[13];
+    for (int k = blockIdx.x * 256 + threadIdx.x; k < nroots; k += gridDim.x * 256) {
     const int i = roots[k];  // (one thread per ROOT; until round 6: one per pixel, asking label[i] == i)
     cidmap[i] = -1;
     const int na = canch[i], sz = csize[i];
-    if (na == 0) return;
+    if (na == 0) continue;
     atomicMax(&cursors[9], na);
     const int cid = atomicAdd(&cursors[0], 1);
     if (cid >= max_comps) {
         atomicOr(&cursors[7], 1);
-        return;
+        continue;
     }
     StagComp C;
     C.root = i; C.size = sz; C.nanch = na; C.nrec = 0;
@@ -1091,6 +1091,7 @@ __device__ __forceinline__ void k_stag_comp_alloc_impl(const int *__restrict__ r
     }
     comps[cid] = C;
     cidmap[i] = cid;
+    }
 }
 __global__ __launch_bounds__(256) void k_stag_comp_alloc(const int *__restrict__ roots, const int *__restrict__ csize, const int *__restrict__ canch, const int4 *__restrict__ cbox, int *__restrict__ cursors, int max_comps, const int *caps, StagComp *__restrict__ comps, int *__restrict__ cidmap)
 {
@@ -1757,7 +1758,7 @@ struct k_stag_route_extract_small_fn {
 };
 
 // blk_pix / blk_segs hold exclusive prefix sums by now: copy every block to its place in the global order
-__device__ __forceinline__ void k_stag_route_gather_impl(StagArenas A, const StagComp *__restrict__ comps, const unsigned *__restrict__ n_anchors,
+__device__ __forceinline__ void k_stag_route_gather_impl(int per_wave, StagArenas A, const StagComp *__restrict__ comps, const unsigned *__restrict__ n_anchors,
                                                            const int *__restrict__ prodflag, const int *__restrict__ blk_pix,
                                                            const int *__restrict__ blk_segs, const int2 *__restrict__ blk_where,
                                                            int2 *__restrict__ outpix, int2 *__restrict__ segs, int capOut, int capSegs, int *__restrict__ ovf)
@@ -1766,10 +1767,10 @@ __device__ __forceinline__ void k_stag_route_gather_impl(StagArenas A, const Sta
     // them one load and an exit), the wave then copies the blocks of the ones that did, one after the other
     const int lane = threadIdx.x & 63;
     const int n = (int)*n_anchors;
-    const int q0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;
+    const int q0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * per_wave;  // (per_wave: 64, or 1 = a wave per anchor)
     if (q0 >= n) return;
     const int qm = q0 + lane;
-    unsigned long long todo = __ballot(qm < n && prodflag[n - 1 - qm] != 0);
+    unsigned long long todo = __ballot(lane < per_wave && qm < n && prodflag[n - 1 - qm] != 0);
     while (todo) {
         const int q = q0 + __builtin_ctzll(todo);
         todo &= todo - 1;
@@ -1787,11 +1788,11 @@ __device__ __forceinline__ void k_stag_route_gather_impl(StagArenas A, const Sta
         for (int i = lane; i < r.nsegs; i += 64) segs[so + i] = make_int2(sg[i].x - r.out_off + po, sg[i].y);
     }
 }
-__global__ __launch_bounds__(256) void k_stag_route_gather(StagArenas A, const StagComp *__restrict__ comps, const unsigned *__restrict__ n_anchors, const int *__restrict__ prodflag, const int *__restrict__ blk_pix, const int *__restrict__ blk_segs, const int2 *__restrict__ blk_where, int2 *__restrict__ outpix, int2 *__restrict__ segs, int capOut, int capSegs, int *__restrict__ ovf)
+__global__ __launch_bounds__(256) void k_stag_route_gather(int per_wave, StagArenas A, const StagComp *__restrict__ comps, const unsigned *__restrict__ n_anchors, const int *__restrict__ prodflag, const int *__restrict__ blk_pix, const int *__restrict__ blk_segs, const int2 *__restrict__ blk_where, int2 *__restrict__ outpix, int2 *__restrict__ segs, int capOut, int capSegs, int *__restrict__ ovf)
 {
-    k_stag_route_gather_impl(A, comps, n_anchors, prodflag, blk_pix, blk_segs, blk_where, outpix, segs, capOut, capSegs, ovf);
+    k_stag_route_gather_impl(per_wave, A, comps, n_anchors, prodflag, blk_pix, blk_segs, blk_where, outpix, segs, capOut, capSegs, ovf);
 }
 struct k_stag_route_gather_fn {
     static constexpr int kBounds = 256;
-    __device__ __forceinline__ void operator()(StagArenas A, const StagComp *__restrict__ comps, const unsigned *__restrict__ n_anchors, const int *__restrict__ prodflag, const int *__restrict__ blk_pix, const int *__restrict__ blk_segs, const int2 *__restrict__ blk_where, int2 *__restrict__ outpix, int2 *__restrict__ segs, int capOut, int capSegs, int *__restrict__ ovf) const { k_stag_route_gather_impl(A, comps, n_anchors, prodflag, blk_pix, blk_segs, blk_where, outpix, segs, capOut, capSegs, ovf); }
+    __device__ __forceinline__ void operator()(int per_wave, StagArenas A, const StagComp *__restrict__ comps, const unsigned *__restrict__ n_anchors, const int *__restrict__ prodflag, const int *__restrict__ blk_pix, const int *__restrict__ blk_segs, const int2 *__restrict__ blk_where, int2 *__restrict__ outpix, int2 *__restrict__ segs, int capOut, int capSegs, int *__restrict__ ovf) const { k_stag_route_gather_impl(per_wave, A, comps, n_anchors, prodflag, blk_pix, blk_segs, blk_where, outpix, segs, capOut, capSegs, ovf); }
 };

@@ -558,7 +558,7 @@ fid_status enqueue_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H,
               *surv = c->d_surv + (size_t)f0 * P.maxStarts;
         uint4 *contours = c->d_contours + (size_t)f0 * P.maxContours;
         uint32_t *tab = c->d_ckpts + (size_t)f0 * 2 * P.maxContours * chunk_tab_pitch(P);
-        uint32_t *pool = c->d_pool + (size_t)f0 * P.maxChunks * CK;
+        uint32_t *pool = c->d_pool + (size_t)f0 * P.maxChunks * CKW;  // (chain codes: CKW words per chunk of CK points)
         DevCounts *counts = c->d_counts + f0;
         DevCand *cands = c->d_cands + f0 * MC, *sorted = c->d_sorted + f0 * MC, *filtered = c->d_filtered + f0 * MC;
         uint32_t *nearb = c->d_near + f0 * MC * (MC / 32);
@@ -681,7 +681,7 @@ fid_status enqueue_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H,
             unsigned long long *seedhash = c->d_seedhash + (size_t)f0 * P.seedHashCap;
             uint4 *wres = c->d_wres + f0 * MCn, *cinfo = c->d_cinfo + f0 * MCn;
             uint32_t *cbase = c->d_cbase + f0 * MCn;
-            uint32_t *dense = c->d_dense + (size_t)f0 * P.maxChunks * CK;
+            uint32_t *dense = c->d_dense + (size_t)f0 * P.maxChunks * (CK / 4);  // (one code byte per point)
             // (k_find_starts<true> was queued in the first round)
           if (c->trace_mode == 2) {
             // ---- cycle tracing.  Main stream: the seeds walk their segments, link, the cycles become contour list A, copy,
@@ -848,7 +848,7 @@ fid_status enqueue_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H,
             if (P.refine == 2)  // CORNER_REFINE_CONTOUR: a wave per marker fits the four sides of its contour (writes ids and corners)
                 hipLaunchKernelGGL(k_refine_contour, dim3(P.maxMarkers < 64 ? P.maxMarkers : 64, Fs), dim3(64), 0, st, (const fid_marker *)pre, markers,
                                    (const int *)(c->d_mksrc + f0 * MM), (const DevCand *)filtered,
-                                   (const uint32_t *)(c->d_dense ? c->d_dense + (size_t)f0 * P.maxChunks * CK : nullptr), (const uint32_t *)tab,
+                                   (const uint32_t *)(c->d_dense ? c->d_dense + (size_t)f0 * P.maxChunks * (CK / 4) : nullptr), (const uint32_t *)tab,
                                    (const uint32_t *)pool, counts, P);
             else
                 hipLaunchKernelGGL(k_subpix, dim3(blocks), dim3(64), 0, st, g, gfstride, pre, markers, counts, c->d_subpix_mask, P);
@@ -1206,7 +1206,7 @@ fid_status fid_create(const fid_params *params, const fid_dict *dict, const fid_
     TRY(dalloc(c, &c->d_surv1, F * L.max_starts_per_frame));
     TRY(dalloc(c, &c->d_surv, F * L.max_starts_per_frame));
     c->max_chunks = (L.max_points_per_frame + CK - 1) / CK;
-    TRY(dalloc(c, &c->d_pool, F * (size_t)c->max_chunks * CK));
+    TRY(dalloc(c, &c->d_pool, F * (size_t)c->max_chunks * CKW));
     c->trace_mode = 2;
     if (const char *tm = getenv("FID_TRACE")) c->trace_mode = !strcmp(tm, "legacy") ? 0 : !strcmp(tm, "chain") ? 1 : 2;
     if (getenv("FID_SW_BLOCKS")) c->sw_blocks = atoi(getenv("FID_SW_BLOCKS"));
@@ -1233,7 +1233,7 @@ fid_status fid_create(const fid_params *params, const fid_dict *dict, const fid_
         TRY(dalloc(c, &c->d_cinfo, F * L.max_contours_per_frame));
         TRY(dalloc(c, &c->d_cbase, F * L.max_contours_per_frame));
         TRY(dalloc(c, &c->d_recs, 2 * F * L.max_contours_per_frame));
-        TRY(dalloc(c, &c->d_dense, F * (size_t)c->max_chunks * CK));
+        TRY(dalloc(c, &c->d_dense, F * (size_t)c->max_chunks * (CK / 4) + 2));  // (+ 8 bytes: k_approx reads a contour's last codes eight at a time)
     }
     TRY(dalloc(c, &c->d_contours, F * L.max_contours_per_frame));
     {
@@ -1779,7 +1779,7 @@ fid_status fid_tap_read(fid_ctx *c, fid_tap which, void *dst, int64_t dst_bytes)
             o[12 * f + 7] = c->h_counts[f].nsurv;
             o[12 * f + 8] = c->h_counts[f].npool;
             o[12 * f + 9] = c->h_counts[f].nsurv1;
-            o[12 * f + 11] = c->h_counts[f].ndense;  // contour points handed to approxPolyDP
+            o[12 * f + 11] = c->h_counts[f].ndense;  // contour points handed to approxPolyDP (every contour's rounded up to 8)
         }
         return FID_OK;
     }

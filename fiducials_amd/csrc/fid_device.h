@@ -157,7 +157,7 @@ struct DevSegC {
     uint32_t next_key;    // the seed state the segment ran into: x | y << 13 | d << 26 (same scale)
     uint32_t pos;         // position of the ko state | position of the kh state << 16
     uint32_t linked;      // some segment runs into this one (k_seg_link2): only such a seed can lie on a cycle
-    uint32_t pad;
+    uint32_t chunk0;      // the pool chunk of the segment's first 64 chain codes (the next 64: chunk0 + 1; beyond: chunk_tab)
 };
 struct DevPend {          // one per probe survivor that stopped in front of a seed state
     uint32_t p;           // states it walked itself (0 = not stopped: the survivor closed or died on its own)

@@ -1384,11 +1384,63 @@ __device__ __forceinline__ unsigned nb8(const MaskView &m, int x, int y)
 // padded raster index used to order discovery events like cvFindNextContour's scan
 __device__ __forceinline__ int pidx(int x, int y, int W) { return (y + 1) * (W + 2) + (x + 1); }
 
-// Contour points are stored in chunks of CK points (x | y << 16) taken from a per-frame pool while the
-// border is followed; chunk_tab[slot][k] names the chunk that holds points [CK*k, CK*k + CK) of a contour.
+// Contour points leave the walkers as CHAIN CODES (round 6; until then 4-byte points x | y << 16): 4 bits per point -- the
+// direction 0..7 of the step from the point to its successor on the border -- eight to a 32-bit word (point k of a chunk in
+// bits 4 (k & 7) of word k >> 3), in chunks of CK points = CKW words taken from a per-launch pool while the border is followed;
+// chunk_tab[slot][k] names the chunk that holds points [CK*k, CK*k + CK) of a contour.  Codes do not depend on where a piece
+// of a border ends up in a contour: k_seg_copy moves them (one BYTE per point in the dense array) and the consumers
+// (k_approx, k_refine_contour) turn them back into points with a prefix sum from the contour's first point, which the contour
+// record carries anyway.  0.5 + 1 bytes per point through HBM instead of 4 + 4 twice.
 #define CK 64
+#define CKW 8
+#define REC_NO_CHUNK 0xffffffffu  // copy record: the row's chunks are all in chunk_tab (probe survivors, trace mode 1)
+// packed step of a chain code: dx + 65536 dy as a 32-bit integer (x + 65536 y is linear: sums of these are sums of steps)
+__device__ __forceinline__ uint32_t code_delta(unsigned c)
+{
+    const unsigned c2 = (c & 7u) * 2u;
+    return (((0x901Au >> c2) & 3u) | (((0xA901u >> c2) & 3u) << 16)) - 0x10001u;
+}
+// eight codes of a word (one per nibble) -> one per byte, low four in .x
+__device__ __forceinline__ uint2 codes_nibbles_to_bytes(uint32_t w)
+{
+    uint32_t a = w & 0xffffu, b = w >> 16;
+    a = (a | (a << 8)) & 0x00ff00ffu;
+    b = (b | (b << 8)) & 0x00ff00ffu;
+    return make_uint2((a | (a << 4)) & 0x0f0f0f0fu, (b | (b << 4)) & 0x0f0f0f0fu);
+}
+// A wave turns 512 consecutive chain codes back into points: lane l holds the codes of points k .. k + 7 (k = k0 + 8 l, one
+// per byte of w), `base` = point k0 (wave-uniform).  Point k + i = base + the steps in front of it: a serial sum over the
+// lane's own eight, a DPP scan over the lanes' totals.  The lane writes its eight points (two 16-byte LDS stores: k is a
+// multiple of 8; the last lane of a contour may write up to seven words past the contour's length, never read) and the
+// function returns point k0 + 512.  Bytes past the contour's end may hold anything: they only ever reach those words.
+__device__ __forceinline__ uint32_t codes8_to_points(uint32_t *pts, int k, int count, uint32_t base, uint2 w)
+{
+    uint32_t p[8], s = 0;
+    const uint32_t w2[2] = {w.x << 1, w.y << 1};
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const unsigned c2 = (w2[i >> 2] >> (8 * (i & 3))) & 14u;
+        p[i] = s - (uint32_t)i * 0x10001u;  // (the steps are summed with their bias dx + 1, dy + 1)
+        s += ((0x901Au >> c2) & 3u) | (((0xA901u >> c2) & 3u) << 16);
+    }
+    s -= 8u * 0x10001u;
+    const uint32_t incl = wave_iscan_dpp(s);
+    const uint32_t mine = base + incl - s;
+    if (k < count) {
+        *reinterpret_cast<uint4 *>(pts + k) = make_uint4(mine + p[0], mine + p[1], mine + p[2], mine + p[3]);
+        *reinterpret_cast<uint4 *>(pts + k + 4) = make_uint4(mine + p[4], mine + p[5], mine + p[6], mine + p[7]);
+    }
+    return base + (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+}
 // entries per contour in chunk_tab: the windowed walk may run WALK_RUN (< 64) points past maxPerimeterPixels before it notices
 __device__ __host__ inline int chunk_tab_pitch(const DevParams &P) { return P.maxPerim / CK + 3; }
+// A frame's table is laid out BY ENTRY: entry k of row r (rows 0 .. maxContours - 1: the seeds' segments, maxContours .. 2 maxContours
+// - 1: the probe survivors) at [k * 2 maxContours + r].  Nearly every walker only ever has entries 0 and 1 (128 points): with a row
+// per walker those were 8 bytes in a 64-byte line of their own, written once and fetched once; by entry they are two dense arrays.
+__device__ __forceinline__ long long chunk_tab_at(const DevParams &P, int f, unsigned row, unsigned k)
+{
+    return ((long long)f * chunk_tab_pitch(P) + k) * (2ll * P.maxContours) + row;
+}
 
 // K3 probe passes: one lane per start.  Walks the border exactly as icvFetchContour does (contours.cpp).
 // A start is kept only if it can be the canonical one of its border (the pixel where cvFindNextContour's
@@ -1660,7 +1712,6 @@ __global__ __launch_bounds__(64 * WALK_WAVES) void k_walk_full(const uint32_t *_
     const int W = P.W, S = P.nscales, TC = P.TC, TR = P.TR, F = P.nframes;
     const int W2 = W + 2;
     const int sgm = (8 << P.seedShift) - 1;  // seed grid spacing - 1
-    const int nck = chunk_tab_pitch(P);
     const long long plane = (long long)TR * TC * MT_ROWS;
     enum { ST_IDLE = 0, ST_ACTIVE, ST_NEED, ST_LOADING, ST_FINAL };
 
@@ -1685,7 +1736,7 @@ __global__ __launch_bounds__(64 * WALK_WAVES) void k_walk_full(const uint32_t *_
         // maxContours .. 2 maxContours-1); point chunks are numbered across the whole launch
         int lf = f;
         auto fco_of = [&](int fr) { return contours + (long long)fr * P.maxContours; };
-        auto ftab_of = [&](int fr) { return chunk_tab + ((long long)fr * 2 + (SEG ? 0 : 1)) * P.maxContours * nck; };
+        auto tab_at = [&](int fr, unsigned sl, unsigned k) -> uint32_t & { return chunk_tab[chunk_tab_at(P, fr, (SEG ? 0u : ccap) + sl, k)]; };
         uint32_t *const fpool = pool;
         // the wave's current batch of the frame's survivor queue: [next, rend), records of batch base .. base + 63 in `pre`
         unsigned next = 0, rend = 0, pre_base = 0;  // wave-uniform
@@ -1707,7 +1758,7 @@ __global__ __launch_bounds__(64 * WALK_WAVES) void k_walk_full(const uint32_t *_
         unsigned mout = 0xffffffffu, mhole = 0xffffffffu;  // MODE 1: running minima of the segment
         int too_long = 0, stopped = 0;
         int brx = -1, bry = -1, brd = -1;  // MODE 1: state remembered for the cycle test
-        uint4 quad = make_uint4(0u, 0u, 0u, 0u);  // the last four points; every fourth step they leave as ONE 16-byte store
+        uint32_t acc = 0;  // the chain codes of the last (up to) eight points, oldest in the low nibble; every eighth step they leave as ONE word
         unsigned arena_next = 0, arena_end = 0;  // wave-uniform
 #ifdef FID_DEBUG_STATS
         unsigned long long d_iters = 0, d_ckpts = 0, d_active = 0, d_ckcyc = 0, d_waitcyc = 0, d_forced = 0;
@@ -1744,8 +1795,7 @@ __global__ __launch_bounds__(64 * WALK_WAVES) void k_walk_full(const uint32_t *_
                     first = 0;
                     const unsigned raw = win_raw(s_winw, lane4, cx, cy, wx0, wy0);
                     if (raw == 0) {
-                        quad.w = (uint32_t)x0 | ((uint32_t)y0 << 16);  // (written when the walker retires)
-                        count = 1;
+                        count = 1;  // (the contour's only point is its start: no step, no code)
                         closed = 1;
                         mout = (unsigned)pc;
                         state = ST_FINAL;
@@ -1773,19 +1823,9 @@ __global__ __launch_bounds__(64 * WALK_WAVES) void k_walk_full(const uint32_t *_
             // ---- retire finished walkers
             if (state == ST_FINAL) {
                 {
-                    // the last count % 4 points are still in the shift register (newest in .w)
-                    const int rem = count & 3;
-                    uint32_t *dst = fpool + (((count - rem) & CK ? chunkB : chunkA) << 6) + (unsigned)((count - rem) & (CK - 1));
-                    if (rem == 1) {
-                        dst[0] = quad.w;
-                    } else if (rem == 2) {
-                        dst[0] = quad.z;
-                        dst[1] = quad.w;
-                    } else if (rem == 3) {
-                        dst[0] = quad.y;
-                        dst[1] = quad.z;
-                        dst[2] = quad.w;
-                    }
+                    // the codes of the last count % 8 points are still in the shift register (newest in the top nibble)
+                    const int rem = count & 7, b0 = count - rem;
+                    if (rem) fpool[((b0 & CK ? chunkB : chunkA) * CKW) + (unsigned)((b0 & (CK - 1)) >> 3)] = acc >> (4 * (8 - rem));
                 }
                 if (SEG) {
                     DevSeg *r = segs + (long long)lf * P.maxContours + slot;
@@ -1948,14 +1988,13 @@ __global__ __launch_bounds__(64 * WALK_WAVES) void k_walk_full(const uint32_t *_
                         } else if (fresh) {
                             chunkA = mine;
                             chunkB = mine + 1;
-                            uint32_t *trow = ftab_of(lf) + (long long)slot * nck;
-                            trow[0] = chunkA;
-                            trow[1] = chunkB;
+                            tab_at(lf, slot, 0) = chunkA;
+                            tab_at(lf, slot, 1) = chunkB;
                         } else {
                             kreg++;
                             if (kreg & 1) chunkB = mine;
                             else chunkA = mine;
-                            ftab_of(lf)[(long long)slot * nck + kreg] = mine;
+                            tab_at(lf, slot, (unsigned)kreg) = mine;
                         }
                     }
                 }
@@ -2034,15 +2073,8 @@ __global__ __launch_bounds__(64 * WALK_WAVES) void k_walk_full(const uint32_t *_
                             const unsigned hv = code ? (unsigned)(pc + hoff) : 0xffffffffu;
                             mhole = hv < mhole ? hv : mhole;
                             mout = (unsigned)pc < mout ? (unsigned)pc : mout;
-                            {
-                                const uint32_t pt = (uint32_t)cx | ((uint32_t)cy << 16);
-                                quad.x = quad.y;
-                                quad.y = quad.z;
-                                quad.z = quad.w;
-                                quad.w = pt;
-                                if ((count & 3) == 3)
-                                    *reinterpret_cast<uint4 *>(fpool + ((count & CK ? chunkB : chunkA) << 6) + (unsigned)(count & (CK - 4))) = quad;
-                            }
+                            acc = __builtin_amdgcn_alignbit((uint32_t)sn, acc, 4);
+                            if ((count & 7) == 7) fpool[((count & CK ? chunkB : chunkA) * CKW) + (unsigned)((count & (CK - 1)) >> 3)] = acc;
                             count++;
                             const int dx = dir_dx(sn), dy = dir_dy(sn);
                             cx += dx;
@@ -2060,15 +2092,8 @@ __global__ __launch_bounds__(64 * WALK_WAVES) void k_walk_full(const uint32_t *_
                     } else {
                         // background pixels examined in the 4-directions belong to this border's hole region
                         int bad = hole && code && (pc + hoff < key);
-                        {
-                            const uint32_t pt = (uint32_t)cx | ((uint32_t)cy << 16);
-                            quad.x = quad.y;
-                            quad.y = quad.z;
-                            quad.z = quad.w;
-                            quad.w = pt;
-                            if ((count & 3) == 3)
-                                *reinterpret_cast<uint4 *>(fpool + ((count & CK ? chunkB : chunkA) << 6) + (unsigned)(count & (CK - 4))) = quad;
-                        }
+                        acc = __builtin_amdgcn_alignbit((uint32_t)sn, acc, 4);
+                        if ((count & 7) == 7) fpool[((count & CK ? chunkB : chunkA) * CKW) + (unsigned)((count & (CK - 1)) >> 3)] = acc;
                         count++;
                         const int dx = dir_dx(sn), dy = dir_dy(sn);
                         const int nx = cx + dx, ny = cy + dy;
@@ -2250,7 +2275,8 @@ __global__ __launch_bounds__(64) void k_seg_chain(const uint2 *__restrict__ surv
         const unsigned long long mk = ballot64(accept);
         if (mk) {
             // contour slots, dense points and copy records of the wave's accepted contours: one atomic each
-            const unsigned myL = accept ? L : 0u, myR = accept ? hops + 1u : 0u;
+            // (a contour's codes start on a multiple of 8 bytes: k_approx reads them eight to a lane)
+            const unsigned myL = accept ? (L + 7u) & ~7u : 0u, myR = accept ? hops + 1u : 0u;
             const unsigned sL = wave_iscan_dpp(myL), sR = wave_iscan_dpp(myR);
             const unsigned totL = (unsigned)__builtin_amdgcn_readlane((int)sL, 63), totR = (unsigned)__builtin_amdgcn_readlane((int)sR, 63);
             unsigned bslot = 0, bdense = 0, brec = 0;
@@ -2274,13 +2300,13 @@ __global__ __launch_bounds__(64) void k_seg_chain(const uint2 *__restrict__ surv
                         fcb[idx] = SEG_INVALID;
                     } else {
                         fcb[idx] = dst0;
-                        frc[rec++] = make_uint4((unsigned)P.maxContours + i, dst0, own < L ? own : L, 0u);  // the survivor's own points
+                        frc[rec++] = make_uint4((unsigned)P.maxContours + i, dst0, own < L ? own : L, REC_NO_CHUNK);  // the survivor's own points
                         unsigned off = own, cur = first;
                         while (off < L && cur != SEG_INVALID) {
                             const DevSeg r = fsg[cur];
                             if (r.n == 0u || r.n == SEG_INVALID) break;  // (never for a segment of an accepted cycle)
                             const unsigned take = r.n < L - off ? r.n : L - off;
-                            frc[rec++] = make_uint4(cur, dst0 + off, take, 0u);
+                            frc[rec++] = make_uint4(cur, dst0 + off, take, REC_NO_CHUNK);
                             off += take;
                             cur = r.next_idx;
                         }
@@ -2294,7 +2320,8 @@ __global__ __launch_bounds__(64) void k_seg_chain(const uint2 *__restrict__ surv
     }
 }
 
-// the pieces of the accepted contours, from their pool chunks into the dense point array: one wave per copy record
+// the pieces of the accepted contours, from their pool chunks into the dense array: one wave per copy record
+// {chunk row, place in the dense array, points | first point of the piece inside its row << 16, the row's first chunk or REC_NO_CHUNK}
 __global__ __launch_bounds__(256) void k_seg_copy(const uint4 *__restrict__ recs, const uint32_t *__restrict__ chunk_tab,
                                                    const uint32_t *__restrict__ pool, uint32_t *__restrict__ dense,
                                                    const DevCounts *__restrict__ counts, const DevParams P, int part)
@@ -2306,16 +2333,16 @@ __global__ __launch_bounds__(256) void k_seg_copy(const uint4 *__restrict__ recs
     const unsigned rcap = (part < 0 ? 2u : 1u) * (unsigned)P.maxContours;
     nr = nr < rcap ? nr : rcap;
     const uint4 *frc = recs + (long long)f * 2 * P.maxContours + (part == 1 ? (unsigned)P.maxContours : 0u);
-    const int nck = chunk_tab_pitch(P);
-    const uint32_t *ftab = chunk_tab + (long long)f * 2 * P.maxContours * nck;
     const uint32_t *fpool = pool;  // chunks are numbered across the whole launch
-    uint32_t *fd = dense + (long long)f * P.maxChunks * CK;
+    uint8_t *fd = reinterpret_cast<uint8_t *>(dense) + (long long)f * P.maxChunks * CK;  // (one byte per point: its chain code)
     for (unsigned ri = blockIdx.x * 4 + (threadIdx.x >> 6); ri < nr; ri += gridDim.x * 4) {
         const uint4 r = frc[ri];
-        const uint32_t *row = ftab + (long long)r.x * nck;
-        for (unsigned k = lane; k < r.z; k += 64) {  // (r.w: first point of the piece inside its chunk row)
-            const unsigned k2 = k + r.w;
-            fd[r.y + k] = fpool[(long long)row[k2 >> 6] * CK + (k2 & 63)];
+        const unsigned np = r.z & 0xffffu, p0 = r.z >> 16;
+        for (unsigned k = lane; k < np; k += 64) {
+            const unsigned k2 = k + p0;
+            // (a segment's record names its first two chunks: no trip to the table for the first 128 points of a row)
+            const uint32_t id = (k2 < 2 * CK && r.w != REC_NO_CHUNK) ? r.w + (k2 >> 6) : chunk_tab[chunk_tab_at(P, f, r.x, k2 >> 6)];
+            fd[r.y + k] = (uint8_t)((fpool[(long long)id * CKW + ((k2 & 63) >> 3)] >> ((k2 & 7) * 4)) & 7u);
         }
     }
 }
@@ -2568,7 +2595,6 @@ __global__ __launch_bounds__(64 * SW_WAVES) SW_VGPR_ATTR void k_seed_walk(const 
     const int S = P.nscales, TC = P.TC, TR = P.TR, F = P.nframes;
     const int W = P.W, W2 = P.W + 2;
     const int sgm = (8 << P.seedShift) - 1;
-    const int nck = chunk_tab_pitch(P);
     const long long plane = (long long)TR * TC * MT_ROWS;
     enum { ST_IDLE = 0, ST_ACTIVE, ST_NEED, ST_LOADING, ST_FINAL };
 #ifdef FID_DEBUG_STATS
@@ -2605,12 +2631,12 @@ __global__ __launch_bounds__(64 * SW_WAVES) SW_VGPR_ATTR void k_seed_walk(const 
     int pbr = 0, pbc = 0, pend = 0;  // the base the loads in flight will give
     int vxb = 0, vyb = 0;            // usable part of the window: padded bit / row of its origin ...
     unsigned vxs = 0, vys = 0;       // ... and extent minus the 3 x 3 footprint
-    unsigned chunkA = 0, chunkB = 0;
+    unsigned chunkA = 0, chunkB = 0, chunk0 = 0;
     int kreg = 0;
     unsigned ovf = 0;
     unsigned ko = 0xffffffffu, kh = 0xffffffffu, po = 0, ph = 0;
     unsigned brkey = 0xffffffffu;
-    uint4 quad = make_uint4(0u, 0u, 0u, 0u);
+    uint32_t acc = 0;  // chain codes of the last (up to) eight points
     unsigned arena_next = 0, arena_end = 0;
     // SURV: the survivor record, its start pixel / kind / key, the pixel after the start, what the walk found
     uint2 sst = make_uint2(0u, 0u);
@@ -2663,8 +2689,7 @@ __global__ __launch_bounds__(64 * SW_WAVES) SW_VGPR_ATTR void k_seed_walk(const 
             first = 0;
             const unsigned raw = raw_here();
             if (raw == 0) {
-                quad.w = (uint32_t)x0 | ((uint32_t)y0 << 16);  // (written when the walker retires)
-                count = 1;
+                count = 1;  // (the contour's only point is its start: no step, no code)
                 closed = 1;
                 state = ST_FINAL;
             } else {
@@ -2684,11 +2709,8 @@ __global__ __launch_bounds__(64 * SW_WAVES) SW_VGPR_ATTR void k_seed_walk(const 
         }
         // ---- retire
         if (state == ST_FINAL) {
-            const int rem = count & 3, b0 = count - rem;
-            uint32_t *dst = pool + ((b0 & CK ? chunkB : chunkA) << 6) + (unsigned)(b0 & (CK - 1));
-            if (rem >= 1) dst[0] = rem == 1 ? quad.w : rem == 2 ? quad.z : quad.y;
-            if (rem >= 2) dst[1] = rem == 2 ? quad.w : quad.z;
-            if (rem == 3) dst[2] = quad.w;
+            const int rem = count & 7, b0 = count - rem;
+            if (rem) pool[((b0 & CK ? chunkB : chunkA) * CKW) + (unsigned)((b0 & (CK - 1)) >> 3)] = acc >> (4 * (8 - rem));
             if (SURV) {
                 // stopped in front of a seed state: k_seg_cycles decides; else decided here
                 const int accept = ok && closed && !stopped && count >= P.minPerim && count <= P.maxPerim;
@@ -2699,7 +2721,7 @@ __global__ __launch_bounds__(64 * SW_WAVES) SW_VGPR_ATTR void k_seed_walk(const 
             } else {
                 uint4 *r = reinterpret_cast<uint4 *>(segs + (long long)lf * P.maxContours + slot);
                 r[0] = make_uint4(SEG_INVALID, too_long || !ok ? SEG_INVALID : (unsigned)count, ko, kh);  // next_idx (k_seg_link2 fills it in), n, ko, kh
-                r[1] = make_uint4(seed_key(cx, cy, sdir), po | (ph << 16), 0u, 0u);                      // next_key, pos, linked, pad
+                r[1] = make_uint4(seed_key(cx, cy, sdir), po | (ph << 16), 0u, chunk0);                  // next_key, pos, linked, chunk0
             }
             state = ST_IDLE;
         }
@@ -2808,7 +2830,7 @@ __global__ __launch_bounds__(64 * SW_WAVES) SW_VGPR_ATTR void k_seed_walk(const 
                 const unsigned mine = arena_next + (unsigned)__popcll(b1 & lt) + 2u * (unsigned)__popcll(b2 & lt);
                 arena_next += total;
                 if (fresh || want1) {
-                    uint32_t *trow = chunk_tab + (((long long)lf * 2 + (SURV ? 1 : 0)) * P.maxContours + slot) * nck;  // (survivors: the upper rows)
+                    const unsigned trow = (SURV ? ccap : 0u) + slot;  // (survivors: the upper rows)
                     if (mine + 1 >= pcap) {
                         ovf |= 8u;
                         if (SURV) {
@@ -2820,15 +2842,17 @@ __global__ __launch_bounds__(64 * SW_WAVES) SW_VGPR_ATTR void k_seed_walk(const 
                         state = ST_IDLE;
                         pend = 0;
                     } else if (fresh) {
-                        chunkA = mine;
+                        chunkA = chunk0 = mine;
                         chunkB = mine + 1;
-                        trow[0] = chunkA;
-                        trow[1] = chunkB;
+                        if (SURV) {  // (a segment's first two chunks travel in its record: the table only holds the ones beyond)
+                            chunk_tab[chunk_tab_at(P, lf, trow, 0)] = chunkA;
+                            chunk_tab[chunk_tab_at(P, lf, trow, 1)] = chunkB;
+                        }
                     } else {
                         kreg++;
                         if (kreg & 1) chunkB = mine;
                         else chunkA = mine;
-                        trow[kreg] = mine;
+                        chunk_tab[chunk_tab_at(P, lf, trow, (unsigned)kreg)] = mine;
                     }
                 }
             }
@@ -2916,12 +2940,8 @@ __global__ __launch_bounds__(64 * SW_WAVES) SW_VGPR_ATTR void k_seed_walk(const 
                 } else {
                     // background pixels examined in the 4-directions belong to this border's hole region
                     int bad = hole && code && (pc + hoff < key);
-                    quad.x = quad.y;
-                    quad.y = quad.z;
-                    quad.z = quad.w;
-                    quad.w = (uint32_t)cx | ((uint32_t)cy << 16);
-                    if ((count & 3) == 3)
-                        *reinterpret_cast<uint4 *>(pool + ((count & CK ? chunkB : chunkA) << 6) + (unsigned)(count & (CK - 4))) = quad;
+                    acc = __builtin_amdgcn_alignbit((uint32_t)sn, acc, 4);
+                    if ((count & 7) == 7) pool[((count & CK ? chunkB : chunkA) * CKW) + (unsigned)((count & (CK - 1)) >> 3)] = acc;
                     count++;
                     const int dx = dir_dx(sn), dy = dir_dy(sn);
                     const int nx = cx + dx, ny = cy + dy;
@@ -2955,14 +2975,10 @@ __global__ __launch_bounds__(64 * SW_WAVES) SW_VGPR_ATTR void k_seed_walk(const 
                         kh = lh ? (unsigned)pc + 1u : kh;
                         ph = lh ? (unsigned)count : ph;
                     }
-                    quad.x = quad.y;
-                    quad.y = quad.z;
-                    quad.z = quad.w;
-                    quad.w = (uint32_t)cx | ((uint32_t)cy << 16);
-                    if ((count & 3) == 3)
-                        *reinterpret_cast<uint4 *>(pool + ((count & CK ? chunkB : chunkA) << 6) + (unsigned)(count & (CK - 4))) = quad;
-                    count++;
                     const int sn = e & 7;
+                    acc = __builtin_amdgcn_alignbit((uint32_t)sn, acc, 4);
+                    if ((count & 7) == 7) pool[((count & CK ? chunkB : chunkA) * CKW) + (unsigned)((count & (CK - 1)) >> 3)] = acc;
+                    count++;
                     const int dx = dir_dx(sn), dy = dir_dy(sn);
                     cx += dx;
                     cy += dy;
@@ -3130,7 +3146,8 @@ __global__ __launch_bounds__(64) void k_seg_cycles(const uint2 *__restrict__ see
         }
         const unsigned long long mk = ballot64(accept);
         if (mk) {
-            const unsigned myL = accept ? L : 0u, myR = accept == 1 ? hops + 1u : (accept == 2 ? 1u : 0u);
+            // (a contour's codes start on a multiple of 8 bytes: k_approx reads them eight to a lane)
+            const unsigned myL = accept ? (L + 7u) & ~7u : 0u, myR = accept == 1 ? hops + 1u : (accept == 2 ? 1u : 0u);
             const unsigned sL = wave_iscan_dpp(myL), sR = wave_iscan_dpp(myR);
             const unsigned totL = (unsigned)__builtin_amdgcn_readlane((int)sL, 63), totR = (unsigned)__builtin_amdgcn_readlane((int)sR, 63);
             unsigned bslot = 0, bdense = 0, brec = 0;
@@ -3154,10 +3171,11 @@ __global__ __launch_bounds__(64) void k_seg_cycles(const uint2 *__restrict__ see
                         fcb[idx] = SEG_INVALID;
                     } else if (accept == 2) {
                         fcb[idx] = dst0;
-                        frc[rec] = make_uint4((unsigned)P.maxContours + (i - ns), dst0, L, 0u);
+                        frc[rec] = make_uint4((unsigned)P.maxContours + (i - ns), dst0, L, REC_NO_CHUNK);
                     } else {
                         fcb[idx] = dst0;
-                        frc[rec++] = make_uint4(i, dst0, n0 - pos, pos);  // from the start state to the end of its segment
+                        const unsigned ck0 = fsg[i].chunk0;
+                        frc[rec++] = make_uint4(i, dst0, (n0 - pos) | (pos << 16), ck0);  // from the start state to the end of its segment
                         unsigned off = n0 - pos, cur = nx0;
                         {
                             // (an accepted cycle was walked to its end: hops - 1 segments behind the first, the first SC_HOPS of
@@ -3165,7 +3183,7 @@ __global__ __launch_bounds__(64) void k_seg_cycles(const uint2 *__restrict__ see
                             const unsigned noted = !SC_HOPS ? 0u : (hops - 1u < SC_HOPS ? hops - 1u : SC_HOPS);
                             for (unsigned h = 0; h < noted; h++) {
                                 const uint2 e = s_hops[h][lane];
-                                frc[rec++] = make_uint4(e.x, dst0 + off, e.y, 0u);
+                                frc[rec++] = make_uint4(e.x, dst0 + off, e.y, fsg[e.x].chunk0);
                                 off += e.y;
                                 cur = e.x;
                             }
@@ -3173,11 +3191,11 @@ __global__ __launch_bounds__(64) void k_seg_cycles(const uint2 *__restrict__ see
                         }
                         while (cur != i && cur != SEG_INVALID && off < L) {
                             const uint2 q = reinterpret_cast<const uint2 *>(fsg + cur)[0];  // next_idx, n
-                            frc[rec++] = make_uint4(cur, dst0 + off, q.y, 0u);
+                            frc[rec++] = make_uint4(cur, dst0 + off, q.y, fsg[cur].chunk0);  // (the same 32-byte record)
                             off += q.y;
                             cur = q.x;
                         }
-                        frc[rec++] = make_uint4(i, dst0 + off, pos, 0u);  // ... and the states in front of it
+                        frc[rec++] = make_uint4(i, dst0 + off, pos, ck0);  // ... and the states in front of it
                         for (; rec < brec + sR; rec++) frc[rec] = make_uint4(0u, 0u, 0u, 0u);
                     }
                 } else {
@@ -3211,7 +3229,7 @@ __global__ __launch_bounds__(64) void k_approx(uint4 *__restrict__ contours, con
                                                 int pts_cap, int stack_cap, int second_pass, const uint32_t *__restrict__ dense,
                                                 const uint32_t *__restrict__ cbase, int part = 0)
 {
-    extern __shared__ uint32_t pts[];  // pts_cap points, then stack_cap slices
+    extern __shared__ __attribute__((aligned(16))) uint32_t pts[];  // pts_cap points, then stack_cap slices
     int2 *stack = reinterpret_cast<int2 *>(pts + pts_cap);
     __shared__ int dst[2 * 16];
     const int lane = lane_id();
@@ -3225,9 +3243,7 @@ __global__ __launch_bounds__(64) void k_approx(uint4 *__restrict__ contours, con
     const unsigned loff = part == 2 ? (unsigned)P.maxContours / 2u : 0u;
     if (part) n = n < (unsigned)P.maxContours / 2u ? n : (unsigned)P.maxContours / 2u;
     const int W = P.W, H = P.H;
-    const int nck = chunk_tab_pitch(P);
     uint4 *fco = contours + (long long)f * P.maxContours + loff;
-    const uint32_t *ftab = chunk_tab + ((long long)f * 2 + 1) * P.maxContours * nck;  // survivors' chunk rows
     const uint32_t *fpool = pool;  // chunks are numbered across the whole launch
     // this workgroup's slots are blockIdx.x, blockIdx.x + gridDim.x, ...: 64 of them are looked at with one
     // load (a lane each); only the accepted ones of the right length class are then processed in turn
@@ -3258,18 +3274,24 @@ __global__ __launch_bounds__(64) void k_approx(uint4 *__restrict__ contours, con
             const uint32_t cb0 = cbase[(long long)f * P.maxContours + loff + ci];
             if (cb0 == SEG_INVALID) continue;
             pref = cb0;  // ... or the contour's place in the frame's dense point array
-            const uint32_t *src = dense + (long long)f * P.maxChunks * CK + cb0;
-            for (int k = lane; k < count; k += 64) pts[k] = src[k];
+            // (one code byte per point, the contour's on a multiple of 8: eight to a lane, 512 points a trip)
+            const uint8_t *src = reinterpret_cast<const uint8_t *>(dense) + (long long)f * P.maxChunks * CK + cb0;
+            uint32_t base = c.x;
+            for (int k0 = 0; k0 < count; k0 += 512) {
+                const int k = k0 + 8 * lane;
+                uint2 w = make_uint2(0u, 0u);
+                if (k < count) w = *reinterpret_cast<const uint2 *>(src + k);
+                base = codes8_to_points(pts, k, count, base, w);
+            }
         } else {
-            const int nchunks = (count + CK - 1) / CK;
-            for (int cb = 0; cb < nchunks; cb += 64) {
-                const uint32_t myc = cb + lane < nchunks ? ftab[(long long)ci * nck + cb + lane] : 0u;
-                const int m = nchunks - cb < 64 ? nchunks - cb : 64;
-                for (int q = 0; q < m; q++) {
-                    const uint32_t id = __shfl(myc, q, WAVE);
-                    const int k = (cb + q) * CK + lane;
-                    if (k < count) pts[k] = fpool[(long long)id * CK + lane];
-                }
+            // (the walker's own chunks: a lane per code word)
+            uint32_t base = c.x;
+            for (int k0 = 0; k0 < count; k0 += 512) {
+                const int k = k0 + 8 * lane;
+                uint32_t w = 0u;
+                if (k < count)  // (the survivors' rows)
+                    w = fpool[(long long)chunk_tab[chunk_tab_at(P, f, (unsigned)P.maxContours + ci, (unsigned)k >> 6)] * CKW + ((k & (CK - 1)) >> 3)];
+                base = codes8_to_points(pts, k, count, base, codes_nibbles_to_bytes(w));
             }
         }
         __syncthreads();
@@ -4863,7 +4885,7 @@ __device__ __forceinline__ bool lu32f_2x2(float a00, float a01, float a10, float
     return true;
 }
 
-// PTS(k): packed point k (x | y << 16) of the contour, k in [0, count)
+// PTS(k, in): packed point k (x | y << 16) of the contour, k in [0, count); asked for k = base + lane, base = 0, 64, 128, ... in turn
 template <typename PTS>
 __device__ __forceinline__ bool refine_candidate_lines_wave(PTS pts, int count, const float cin[8], float &ox, float &oy)
 {
@@ -4886,7 +4908,8 @@ __device__ __forceinline__ bool refine_candidate_lines_wave(PTS pts, int count, 
     for (int base = 0; base < count; base += 64) {
         const int k = base + lane;
         const bool in = k < count;
-        const uint32_t p = in ? pts(k) : 0xffffffffu;
+        const uint32_t pk = pts(k, in);  // (every lane asks: the chain-code sources sum their steps across the wave)
+        const uint32_t p = in ? pk : 0xffffffffu;
         const unsigned long long m0 = ballot64(in && p == ck[0]), m1 = ballot64(in && p == ck[1]), m2 = ballot64(in && p == ck[2]),
                                  m3 = ballot64(in && p == ck[3]);
         const unsigned long long mall = m0 | m1 | m2 | m3;
@@ -5014,13 +5037,31 @@ __device__ __forceinline__ bool refine_candidate_lines_wave(PTS pts, int count, 
     return true;
 }
 
-struct RefinePtsDense {
+struct RefinePtsDense {  // caller-supplied points (fid_refine_contour_corners)
     const uint32_t *p;
-    __device__ __forceinline__ uint32_t operator()(int k) const { return p[k]; }
+    __device__ __forceinline__ uint32_t operator()(int k, bool in) const { return in ? p[k] : 0u; }
 };
-struct RefinePtsChunks {  // the whole-border walk (FID_TRACE=legacy) leaves the points in pool chunks listed in the contour's table row
-    const uint32_t *row, *pool;
-    __device__ __forceinline__ uint32_t operator()(int k) const { return pool[(long long)row[k / CK] * CK + (k & (CK - 1))]; }
+// the tracing leaves chain codes: point k = the contour's first point + the steps in front of it (a wave scan per 64 points,
+// the running point carried from trip to trip)
+struct RefinePtsCodes {  // the traced modes' dense array: one code byte per point
+    const uint8_t *p;
+    uint32_t carry;
+    __device__ __forceinline__ uint32_t step(uint32_t d)
+    {
+        const uint32_t incl = wave_iscan_dpp(d);
+        const uint32_t pt = carry + incl - d;
+        carry += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        return pt;
+    }
+    __device__ __forceinline__ uint32_t operator()(int k, bool in) { return step(in ? code_delta(p[k]) : 0u); }
+};
+struct RefinePtsChunks : RefinePtsCodes {  // the whole-border walk (FID_TRACE=legacy): code words in the pool chunks of the contour's table row
+    const uint32_t *row, *pool;  // row: entry 0 of the contour's row; entry k is `pitch` words on
+    long long pitch;
+    __device__ __forceinline__ uint32_t operator()(int k, bool in)
+    {
+        return step(in ? code_delta(pool[(long long)row[(k / CK) * pitch] * CKW + ((k & (CK - 1)) >> 3)] >> ((k & 7) * 4)) : 0u);
+    }
 };
 
 #define REFINE_LEGACY_BIT 0x80000000u
@@ -5039,17 +5080,22 @@ __global__ __launch_bounds__(64) void k_refine_contour(const fid_marker *__restr
         const DevCand *cd = filtered + (long long)f * P.maxCands + mksrc[(long long)f * P.maxMarkers + mk];
         const int count = cd->size;
         const uint32_t pref = cd->pref;
+        const uint32_t first = (uint32_t)cd->sx | ((uint32_t)cd->sy << 16);  // the contour's first point: where its chain codes start
         float cin[8];
 #pragma unroll
         for (int k = 0; k < 8; k++) cin[k] = src->corners[k];
         float ox = 0.f, oy = 0.f;
         bool ok;
         if (pref & REFINE_LEGACY_BIT) {
-            const int nck = chunk_tab_pitch(P);
-            RefinePtsChunks pts{chunk_tab + ((long long)f * 2 + 1) * P.maxContours * nck + (long long)(pref & ~REFINE_LEGACY_BIT) * nck, pool};
+            RefinePtsChunks pts;
+            pts.p = nullptr;
+            pts.carry = first;
+            pts.row = chunk_tab + chunk_tab_at(P, f, (unsigned)P.maxContours + (pref & ~REFINE_LEGACY_BIT), 0u);
+            pts.pitch = 2ll * P.maxContours;
+            pts.pool = pool;
             ok = refine_candidate_lines_wave(pts, count, cin, ox, oy);
         } else {
-            RefinePtsDense pts{dense + (long long)f * P.maxChunks * CK + pref};
+            RefinePtsCodes pts{reinterpret_cast<const uint8_t *>(dense) + (long long)f * P.maxChunks * CK + pref, first};
             ok = refine_candidate_lines_wave(pts, count, cin, ox, oy);
         }
         if (!ok) {

@@ -2335,14 +2335,30 @@ __global__ __launch_bounds__(256) void k_seg_copy(const uint4 *__restrict__ recs
     const uint4 *frc = recs + (long long)f * 2 * P.maxContours + (part == 1 ? (unsigned)P.maxContours : 0u);
     const uint32_t *fpool = pool;  // chunks are numbered across the whole launch
     uint8_t *fd = reinterpret_cast<uint8_t *>(dense) + (long long)f * P.maxChunks * CK;  // (one byte per point: its chain code)
-    for (unsigned ri = blockIdx.x * 4 + (threadIdx.x >> 6); ri < nr; ri += gridDim.x * 4) {
+    // (the record is the wave's, not the lane's: its index through readfirstlane, so that the record and everything derived from it
+    //  -- length, first point, chunk, table base -- live in scalar registers and the scalar unit does that arithmetic)
+    const unsigned wv = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const long long tstride = 2ll * P.maxContours;
+    for (unsigned ri = blockIdx.x * 4 + wv; ri < nr; ri += gridDim.x * 4) {
         const uint4 r = frc[ri];
         const unsigned np = r.z & 0xffffu, p0 = r.z >> 16;
-        for (unsigned k = lane; k < np; k += 64) {
-            const unsigned k2 = k + p0;
-            // (a segment's record names its first two chunks: no trip to the table for the first 128 points of a row)
-            const uint32_t id = (k2 < 2 * CK && r.w != REC_NO_CHUNK) ? r.w + (k2 >> 6) : chunk_tab[chunk_tab_at(P, f, r.x, k2 >> 6)];
-            fd[r.y + k] = (uint8_t)((fpool[(long long)id * CKW + ((k2 & 63) >> 3)] >> ((k2 & 7) * 4)) & 7u);
+        uint8_t *out = fd + r.y;
+        if (r.w != REC_NO_CHUNK && p0 + np <= 2 * CK) {
+            // a segment's record names its first two chunks (consecutive in the pool): no trip to the table for its first 128 points
+            const uint32_t *src = fpool + (long long)r.w * CKW;
+            for (unsigned k = lane; k < np; k += 64) {
+                const unsigned k2 = k + p0;
+                out[k] = (uint8_t)((src[k2 >> 3] >> ((k2 & 7) * 4)) & 7u);
+            }
+        } else {
+            // (a segment longer than that: its table row holds the chunks from the third on; survivors' rows hold all of theirs)
+            const uint32_t *trow = chunk_tab + chunk_tab_at(P, f, r.x, 0);
+            const bool direct = r.w != REC_NO_CHUNK;
+            for (unsigned k = lane; k < np; k += 64) {
+                const unsigned k2 = k + p0;
+                const uint32_t id = direct && k2 < 2 * CK ? r.w + (k2 >> 6) : trow[(long long)(k2 >> 6) * tstride];
+                out[k] = (uint8_t)((fpool[(long long)id * CKW + ((k2 & 63) >> 3)] >> ((k2 & 7) * 4)) & 7u);
+            }
         }
     }
 }

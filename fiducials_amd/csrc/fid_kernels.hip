@@ -3685,8 +3685,80 @@ __global__ __launch_bounds__(256) void k_near(const DevCand *__restrict__ sorted
     // the diagonal was skipped one `continue` at a time: a third of this kernel's instructions.  A call of a few frames has more
     // waves than rows (the grid is sized for the latency of ONE frame): there the items stay spread over all waves.
     if (nwaves <= n) {
-        for (int i = wave; i < n; i += nwaves)
-            for (int w2 = i >> 6; w2 < nw2; w2++) item(i, w2);
+        // (round 6, second step) ... and the exact test is taken off the 64-column sweep: a marker's outline comes back as a
+        // candidate at most scales, so ~5 % of a row's pairs pass the centroid test -- three or four lanes of every block then ran
+        // the four-shift test with the other sixty idle (lane utilisation 0.23, the lowest of the pipeline).  The sweep now only
+        // QUEUES the columns that pass (ballot + popcount into an LDS list), the exact test runs on 64 queued pairs at a time and
+        // sets its bits in the row's words in LDS, and the row's part of the triangle leaves from there.  Same pairs, same
+        // arithmetic per pair; only the grouping changed.
+        __shared__ uint32_t s_row[4][128];  // (max_candidates_per_frame <= 4096: 128 words a row)
+        __shared__ uint16_t s_q[4][128];
+        const int wv = (int)(threadIdx.x >> 6);
+        uint32_t *row = s_row[wv];
+        uint16_t *q = s_q[wv];
+        row[lane] = 0u;
+        row[lane + 64] = 0u;
+        for (int i = __builtin_amdgcn_readfirstlane(wave); i < n; i += nwaves) {  // (the row is the wave's: scalar registers)
+            const float4 ma = cm[i];
+            const DevCand a = cs[i];
+            int qn = 0;  // wave-uniform
+            auto exact = [&](int cnt) {  // the first min(cnt, 64) queued columns
+                bool near = false;
+                int j = 0;
+                if (lane < cnt) {
+                    j = q[lane];
+                    const DevCand o = cs[j];
+                    const int minimumPerimeter = a.size < o.size ? a.size : o.size;
+                    double mmd = (double)minimumPerimeter * P.minMarkerDistRate;
+                    mmd = mmd * mmd;
+#pragma unroll
+                    for (int fc = 0; fc < 4; fc++) {
+                        double distSq = 0;
+#pragma unroll
+                        for (int c = 0; c < 4; c++) {
+                            const int modC = (c + fc) & 3;
+                            const float ax = a.c[2 * modC] - o.c[2 * c];
+                            const float ay = a.c[2 * modC + 1] - o.c[2 * c + 1];
+                            distSq += ax * ax + ay * ay;
+                        }
+                        distSq /= 4.;
+                        near = near || distSq < mmd;
+                    }
+                }
+                if (near) atomicOr(&row[j >> 5], 1u << (j & 31));
+            };
+            for (int w2 = i >> 6; w2 < nw2; w2++) {
+                const int j = w2 * 64 + lane;
+                bool close = false;
+                if (j > i && j < n) {
+                    const float4 mo = cm[j];
+                    const float sz = ma.z < mo.z ? ma.z : mo.z;
+                    const float lim0 = sz * rate_f;
+                    const float lim = 16.f * (lim0 * lim0 * 1.001f + 1.f) + 1.f;
+                    const float dx = ma.x - mo.x, dy = ma.y - mo.y;
+                    close = dx * dx + dy * dy < lim;
+                }
+                const unsigned long long cb = ballot64(close);
+                if (cb) {
+                    if (close) q[qn + __popcll(cb & ((1ull << lane) - 1ull))] = (uint16_t)j;
+                    qn += __popcll(cb);
+                    if (qn >= 64) {
+                        exact(64);
+                        qn -= 64;
+                        if (lane < qn) {
+                            const uint16_t t = q[64 + lane];
+                            q[lane] = t;
+                        }
+                    }
+                }
+            }
+            if (qn) exact(qn);
+            // the row's words (i >> 5) .. nw - 1, then clean for the next row
+            for (int w = (i >> 5) + lane; w < nw; w += 64) {
+                nb[near_row_off(i, nw) + w - (i >> 5)] = row[w];
+                row[w] = 0u;
+            }
+        }
     } else {
         for (int it = wave; it < n * nw2; it += nwaves) {
             const int i = it / nw2, w2 = it - i * nw2;

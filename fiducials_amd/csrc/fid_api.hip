@@ -68,7 +68,10 @@ struct fid_ctx {
                                            // 3.6 -> 2.2 ms, the seed walks 3.3 -> 4.9 ms now side by side: the step is the same)     // a sub-batch has left its contour stage (staggered starts, FID_STAGGER)
     int stagger = 0;                        // sub-batch k starts when sub-batch k - stagger has left its contour stage (0: all at once)
     int resolve_lds_kb = 64;
-    int walk2_div = 2;
+    int walk2_div = 6;   // FID_WALK2_DIV: the survivor walk gets walk_blocks / this workgroups a frame (round 6: 2 -> 6, one workgroup a frame at 128 frames: 1.5 k
+                         // survivors over 4 waves instead of 12 -- 1.13 M -> 0.70 M VALU wave-instructions a frame, lane utilisation 0.24 -> 0.33, same frame rate)
+    int probe_refill0 = 0;  // FID_PROBE_REFILL0: the same for the first pass (0: k_probe_lut<6, 0>)
+    int probe_refill = 4;  // FID_PROBE_REFILL: workgroups per frame of the refilled second probe pass (0: k_probe_lut<32, 1>)
     hipEvent_t sub_ev[MAX_SUB][20] = {};   // per sub-batch stage boundaries (FID_PROFILE)
     int sub_frames = 0;                    // frames per sub-batch (0 = automatic)
     fid_params params;
@@ -715,10 +718,18 @@ fid_status enqueue_detect(fid_ctx *c, const uint8_t *d_src, int F, int W, int H,
             hipLaunchKernelGGL(k_seed_index, dim3(8 * gm, Fs), dim3(256), 0, si, seedq, seedhash, counts, P);
             HIPCHK(c, hipEventRecord(c->aux_idx[sb], si));
             if (c->probe_lut) {
+                if (c->probe_refill0 && gm == 1)
+                    hipLaunchKernelGGL((k_probe_refill<PROBE0_STEPS, 0>), dim3(c->probe_refill0, Fs), dim3(256), 0, sa, masks, starts, surv1, counts, c->d_global, P,
+                                       (const uint4 *)c->d_probe_tables);
+                else
                 hipLaunchKernelGGL((k_probe_lut<PROBE0_STEPS, 0>), dim3(64 * gm, Fs), dim3(256), 0, sa, masks, starts, surv1, counts, c->d_global, P,
                                    (const uint4 *)c->d_probe_tables);
-                hipLaunchKernelGGL((k_probe_lut<PROBE1_STEPS, 1>), dim3(16 * gm, Fs), dim3(256), 0, sa, masks, surv1, surv, counts, c->d_global, P,
-                                   (const uint4 *)c->d_probe_tables);
+                if (c->probe_refill && gm == 1)  // (batches: 16 waves a frame that keep their lanes filled; a call of a few frames wants every start in flight at once)
+                    hipLaunchKernelGGL((k_probe_refill<PROBE1_STEPS, 1>), dim3(c->probe_refill, Fs), dim3(256), 0, sa, masks, surv1, surv, counts, c->d_global, P,
+                                       (const uint4 *)c->d_probe_tables);
+                else
+                    hipLaunchKernelGGL((k_probe_lut<PROBE1_STEPS, 1>), dim3(16 * gm, Fs), dim3(256), 0, sa, masks, surv1, surv, counts, c->d_global, P,
+                                       (const uint4 *)c->d_probe_tables);
             } else {
                 hipLaunchKernelGGL((k_probe<PROBE0_STEPS, 0, true>), dim3(64 * gm, Fs), dim3(256), 0, sa, masks, starts, surv1, counts, c->d_global, P);
                 hipLaunchKernelGGL((k_probe<PROBE1_STEPS, 1, true>), dim3(16 * gm, Fs), dim3(256), 0, sa, masks, surv1, surv, counts, c->d_global, P);
@@ -1219,6 +1230,8 @@ fid_status fid_create(const fid_params *params, const fid_dict *dict, const fid_
     if (getenv("FID_LIGHT_X")) c->light_x = atoi(getenv("FID_LIGHT_X")) > 0 ? atoi(getenv("FID_LIGHT_X")) : 1;
     if (getenv("FID_RESOLVE_LDS")) c->resolve_lds_kb = atoi(getenv("FID_RESOLVE_LDS"));
     if (getenv("FID_WALK2_DIV")) c->walk2_div = atoi(getenv("FID_WALK2_DIV"));
+    if (getenv("FID_PROBE_REFILL")) c->probe_refill = atoi(getenv("FID_PROBE_REFILL"));
+    if (getenv("FID_PROBE_REFILL0")) c->probe_refill0 = atoi(getenv("FID_PROBE_REFILL0"));
     if (getenv("FID_CHAIN_AT")) c->chain_at = atoi(getenv("FID_CHAIN_AT"));
     static_assert(sizeof(DevSegC) == sizeof(DevSeg), "the two segment records share one buffer");
     if (c->trace_mode >= 1) {

@@ -2533,6 +2533,185 @@ __global__ __launch_bounds__(256) void k_probe_lut(const uint32_t *__restrict__ 
     }
 }
 
+// The second probe pass with REFILLED lanes (round 6).  k_probe_lut<32, 1> gives every lane one start and the wave then steps
+// until its last lane is done: the starts die after anything between 7 and 32 steps, and the wave issued all 32 (lane utilisation
+// 0.45, 0.81 M VALU wave-instructions per frame).  Here a wave owns a contiguous share of the list and keeps its lanes busy: when
+// PROBE_REFILL_MIN lanes are idle (or nobody is stepping) the finished ones hand in their verdict -- survivors collect in an LDS
+// list that leaves with one atomic per 64 -- and take the next starts of the share.  Start-up and one step are the statements of
+// k_probe_lut's loop, one step per trip; the decisions per start are the same, the order of the survivor list was never defined.
+#ifndef PROBE_REFILL_MIN
+#define PROBE_REFILL_MIN 16
+#endif
+template <int STEPS, int LEVEL>
+__global__ __launch_bounds__(256) void k_probe_refill(const uint32_t *__restrict__ masks, const uint2 *__restrict__ in_list,
+                                                       uint2 *__restrict__ out_list, DevCounts *__restrict__ counts,
+                                                       DevGlobal *__restrict__ G, const DevParams P, const uint4 *__restrict__ tables)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t s_fwd[2048], s_bwd[2048];
+    __shared__ uint2 s_out[4][128];
+    {
+        const uint4 v = tables[threadIdx.x];
+        if (threadIdx.x < 128) reinterpret_cast<uint4 *>(s_fwd)[threadIdx.x] = v;
+        else reinterpret_cast<uint4 *>(s_bwd)[threadIdx.x - 128] = v;
+    }
+    __syncthreads();
+    const int f = blockIdx.y;
+    const int lane = lane_id();
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    unsigned n = (unsigned)(LEVEL != 1 ? counts[f].nstarts : counts[f].nsurv1);
+    n = n < (unsigned)P.maxStarts ? n : (unsigned)P.maxStarts;
+    int *out_count = LEVEL == 0 ? &counts[f].nsurv1 : &counts[f].nsurv;
+    const int W = P.W, S = P.nscales, W2 = P.W + 2;
+    const int sgm = (8 << P.seedShift) - 1;
+    const long long plane = (long long)P.TR * P.TC * MT_ROWS;
+    const uint2 *fin = in_list + (long long)f * P.maxStarts;
+    uint2 *fout = out_list + (long long)f * P.maxStarts;
+    uint2 *obuf = s_out[wv];
+    // the wave's share of the list
+    const unsigned nwv = gridDim.x * 4u, me = blockIdx.x * 4u + (unsigned)wv;
+    unsigned next = (unsigned)(((unsigned long long)n * me) / nwv);
+    const unsigned hi = (unsigned)(((unsigned long long)n * (me + 1u)) / nwv);
+    int outn = 0;  // survivors waiting in obuf (wave-uniform)
+    auto flush = [&](int cnt) {  // the first cnt entries of obuf leave
+        unsigned base = 0;
+        if (lane == 0) base = atomicAdd((unsigned *)out_count, (unsigned)cnt);
+        base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+        if (lane < cnt) {
+            if (base + (unsigned)lane < (unsigned)P.maxStarts) fout[base + lane] = obuf[lane];
+            else atomicOr(&G->overflow, 1u);
+        }
+    };
+    enum { PH_IDLE = 0, PH_RUN, PH_DONE };
+    int phase = PH_IDLE;
+    uint2 st = make_uint2(0u, 0u);
+    MaskView m;
+    m.base = masks;
+    m.TC = P.TC;
+    int x0 = 0, y0 = 0, hole = 0, key = 0, count = 0, ok = 0, closed = 0;
+    unsigned raw = 0;
+    int sdir = 0, i1x = 0, i1y = 0, bx = 0, by = 0, bf = 0, pb = 0, cx = 0, cy = 0, pc = 0;
+    for (;;) {
+        const unsigned long long running = ballot64(phase == PH_RUN);
+        if (running == 0 || 64 - __popcll(running) >= PROBE_REFILL_MIN) {
+            // ---- verdicts of the finished lanes
+            const int keep = phase == PH_DONE && ok && (!closed || (count >= P.minPerim && count <= P.maxPerim));
+            const unsigned long long mk = ballot64(keep);
+            if (mk) {
+                if (keep) obuf[outn + __popcll(mk & ((1ull << lane) - 1ull))] = st;
+                outn += __popcll(mk);
+                if (outn >= 64) {
+                    flush(64);
+                    outn -= 64;
+                    if (lane < outn) {
+                        const uint2 t = obuf[64 + lane];
+                        obuf[lane] = t;
+                    }
+                }
+            }
+            if (phase == PH_DONE) phase = PH_IDLE;
+            // ---- the next starts of the share
+            const unsigned long long idle = ballot64(phase == PH_IDLE);
+            if (next < hi) {
+                const unsigned mine = next + (unsigned)__popcll(idle & ((1ull << lane) - 1ull));
+                if (phase == PH_IDLE && mine < hi) {
+                    st = fin[mine];
+                    x0 = st.x & 0xffff;
+                    y0 = st.x >> 16;
+                    const int s = (st.y >> 16) & 0xff;
+                    hole = (st.y >> 24) & 1;
+                    m.base = masks + ((long long)f * S + s) * plane;
+                    key = hole ? pidx(x0 + 1, y0, W) : pidx(x0, y0, W);
+                    count = 0;
+                    ok = 1;
+                    closed = 0;
+                    raw = raw8(m, x0, y0);
+                    phase = PH_RUN;
+                    if (raw == 0) {
+                        count = 1;  // single pixel domain
+                        closed = 1;
+                        phase = PH_DONE;
+                    } else {
+                        const unsigned nb0 = raw_to_nb(raw);
+                        sdir = first_dir(nb0, hole ? 0 : 4);
+                        i1x = x0 + dir_dx(sdir);
+                        i1y = y0 + dir_dy(sdir);
+                        bx = i1x;
+                        by = i1y;
+                        bf = (sdir + 4) & 7;
+                        pb = pidx(bx, by, W);
+                        if (!hole && pb < key) ok = 0;
+                        if (seed_state(x0, y0, sdir, sgm) && !((nb0 >> seed_empty_dir(sdir)) & 1u)) ok = 0;  // the start state itself is a seed state
+                        cx = x0;
+                        cy = y0;
+                        pc = pidx(x0, y0, W);
+                        if (!ok) phase = PH_DONE;
+                    }
+                }
+                const unsigned nid = (unsigned)__popcll(idle);
+                next = next + nid < hi ? next + nid : hi;
+            } else if (running == 0 && ballot64(phase != PH_IDLE) == 0) {
+                break;  // the share is handed out, nobody steps, every verdict is in
+            }
+        }
+        if (phase == PH_RUN) {
+            // ---- one step of k_probe_lut's loop; whatever leaves that loop ends the start here
+            bool done = false;
+            const unsigned e = s_fwd[raw | ((unsigned)sdir << 8)];
+            const int sn = e & 7, code = (e >> 3) & 7;
+            if (hole && code) {
+                const int hmag = (code & 1) ? W2 : 1;
+                if (pc + ((code & 2) ? hmag : -hmag) < key) ok = 0;  // an examined background 4-neighbour in front of the key
+            }
+            count++;
+            const int dx = dir_dx(sn), dy = dir_dy(sn);
+            const int nx = cx + dx, ny = cy + dy;
+            if (!ok || count > P.maxPerim) {
+                ok = 0;
+                done = true;
+            } else if (nx == x0 && ny == y0 && cx == i1x && cy == i1y) {
+                closed = 1;
+                done = true;
+            } else if (count >= STEPS) {
+                done = true;
+            } else {
+                cx = nx;
+                cy = ny;
+                pc += __mul24(dy, W2) + dx;
+                if (!hole && pc < key) {
+                    ok = 0;
+                    done = true;
+                } else {
+                    sdir = sn ^ 4;
+                    raw = raw8(m, cx, cy);
+                    if ((s_fwd[raw | ((unsigned)sdir << 8)] & 0x40u) && seed_state(cx, cy, sdir, sgm)) {  // a seed state: the border is a seed cycle
+                        ok = 0;
+                        done = true;
+                    } else {
+                        // ---- backward step
+                        const unsigned braw = raw8(m, bx, by);
+                        const unsigned be = s_bwd[braw | ((unsigned)bf << 8)];
+                        const int bd = be & 7, bcode = (be >> 3) & 7;
+                        if (hole && bcode) {
+                            const int hmag = (bcode & 1) ? W2 : 1;
+                            if (pb + ((bcode & 2) ? hmag : -hmag) < key) ok = 0;
+                        }
+                        if ((be & 0x40u) && seed_state(bx, by, bd, sgm)) ok = 0;  // the state (pixel, back direction) the cursor stood in
+                        const int bdx = dir_dx(bd), bdy = dir_dy(bd);
+                        bx += bdx;
+                        by += bdy;
+                        pb += __mul24(bdy, W2) + bdx;
+                        bf = bd ^ 4;
+                        if (!hole && pb < key) ok = 0;
+                        if (!ok) done = true;
+                    }
+                }
+            }
+            if (done) phase = PH_DONE;
+        }
+    }
+    if (outn) flush(outn);
+}
+
 // ================================================================================================
 // Trace mode 2: CYCLE TRACING.  Every border that has a seed state is a cycle of segments; its length, its kind (outer /
 // hole), its canonical start and therefore the exact point order of cvFindContours all follow from the segment records

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Randomised parity sweep of the aruco path against the oracle (run on the GPU box): frames of odd and even sizes, small and
 large markers (borders that cross many / no seed grid lines), noise levels, rectangle clutter, through single-frame calls
-(32 px seed grid, 256 walker workgroups) and batch calls (64 / 128 px grids); ids and corners must be `==` the oracle's.
+(32 px seed grid, 256 walker workgroups), batch calls (64 / 128 px grids) and calls of >= 16 frames (the batch forms of the kernels);
+ids and corners must be `==` the oracle's.
 Usage: python tools/gpu_stress.py [n_cases] [first_seed]"""
 import multiprocessing as mp
 import os
@@ -84,6 +85,18 @@ def main():
     for (H, W), idx in by_size.items():
         res_b = run(lambda kw: ArucoDetector(6, max_width=W, max_height=H, max_batch=len(idx), **kw),
                     lambda det: det.detect_markers_batch(np.stack([imgs[i] for i in idx])))
+        # the same frames again as a call of >= 16 frames: from there on a call runs the BATCH forms of the kernels (one survivor-walk
+        # workgroup a frame, k_probe_refill, the queued k_near) -- they must see random content too
+        rep = -(-16 // len(idx))
+        res_r = run(lambda kw: ArucoDetector(6, max_width=W, max_height=H, max_batch=rep * len(idx), **kw),
+                    lambda det: det.detect_markers_batch(np.stack([imgs[i] for i in idx] * rep)))
+        for k, i in enumerate(idx):
+            oi, oc = oras[i]
+            for q in range(rep):
+                r = res_r[q * len(idx) + k]
+                if not (r[1].tolist() == oi and np.array_equal(np.asarray(r[0]).reshape(oc.shape), oc)):
+                    bad += 1
+                    print(f"MISMATCH case {s0 + i} size {W}x{H}: copy {q} of the {rep * len(idx)}-frame call, ids {r[1].tolist()} vs {oi}", flush=True)
         for k, i in enumerate(idx):
             c1, id1 = run(lambda kw: ArucoDetector(6, max_width=W, max_height=H, max_batch=1, **kw), lambda det: det.detect_markers(imgs[i]))
             oi, oc = oras[i]

@@ -44,11 +44,86 @@ __device__ __forceinline__ void k_stag_smooth_grad_impl(const uint8_t *__restric
                                                            uint8_t *__restrict__ smooth, int16_t *__restrict__ grad,
                                                            uint8_t *__restrict__ dir)
 {
-    __shared__ uint8_t s_src[SY + 6][SX + 6 + 2];
-    __shared__ uint16_t s_h[SY + 6][SX + 2];
-    __shared__ uint8_t s_sm[SY + 2][SX + 2 + 2];
+    __shared__ __attribute__((aligned(16))) uint8_t s_src[SY + 6][SX + 6 + 2];
+    __shared__ __attribute__((aligned(16))) uint16_t s_h[SY + 6][SX + 4];  // (68 columns: the four-pixel path keeps x0 - 2 .. x0 + 65)
+    __shared__ __attribute__((aligned(16))) uint8_t s_sm[SY + 2][SX + 2 + 2];
     const int x0 = blockIdx.x * SX, y0 = blockIdx.y * SY;
     const int tid = threadIdx.x;
+    // (round 6) INTERIOR tiles -- no reflected coordinate, no image-border pixel, rows that can be read and written as 32-bit words:
+    // 90 % of a 1080p frame -- take four pixels a thread.  The byte-a-thread form below issued ~115 VALU instructions per 64 pixels
+    // (five LDS bytes + four multiply-adds per tap pass, eight bytes per Prewitt, divisions by 70 and 66 for the tile indices) and
+    // was bound by that, alone on the chip, not by HBM.  Here a tap pass is one v_dot4_u32_u8 per output on bytes shifted into place
+    // by v_alignbyte (horizontal) or packed 16-bit arithmetic on two columns at once (vertical: the sums stay below 65 536), and
+    // Prewitt works on the column sums of three rows.  The same integers as below, pixel for pixel.
+    if (x0 >= 4 && x0 + SX + 4 <= W && y0 >= 3 && y0 + SY + 3 <= H && ((stride | W) & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 3) == 0) {
+        // bytes x0 - 4 .. x0 + 67 of rows y0 - 3 .. y0 + 18, as words
+        uint32_t(*w_src)[18] = reinterpret_cast<uint32_t(*)[18]>(&s_src[0][0]);  // 22 x 18 words = 1 584 bytes of the 1 584 there
+        uint32_t(*w_h)[34] = reinterpret_cast<uint32_t(*)[34]>(&s_h[0][0]);       // 22 x 34 words: two smoothed columns a word
+        uint32_t(*w_sm)[17] = reinterpret_cast<uint32_t(*)[17]>(&s_sm[0][0]);     // 18 x 17 words: four smoothed pixels a word
+        for (int i = tid; i < 22 * 18; i += 256) {
+            const int r = i / 18, c = i - r * 18;
+            w_src[r][c] = *reinterpret_cast<const uint32_t *>(src + (long long)(y0 - 3 + r) * stride + (x0 - 4 + 4 * c));
+        }
+        __syncthreads();
+        // horizontal [1 4 6 4 1]: item (row r, group j) = smoothed columns x0 - 2 + 4 j + k, k = 0 .. 3, from bytes k .. k + 4 of words j, j + 1
+        for (int i = tid; i < 22 * 17; i += 256) {
+            const int r = i / 17, j = i - r * 17;
+            const uint32_t d0 = w_src[r][j], d1 = w_src[r][j + 1];
+            const uint32_t h0 = __builtin_amdgcn_udot4(d0, 0x04060401u, d1 & 0xffu, false);
+            const uint32_t h1 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 1), 0x04060401u, (d1 >> 8) & 0xffu, false);
+            const uint32_t h2 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 2), 0x04060401u, (d1 >> 16) & 0xffu, false);
+            const uint32_t h3 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 3), 0x04060401u, d1 >> 24, false);
+            w_h[r][2 * j] = h0 | (h1 << 16);
+            w_h[r][2 * j + 1] = h2 | (h3 << 16);
+        }
+        __syncthreads();
+        // vertical pass, two columns a word: smoothed row y0 - 1 + r from rows r .. r + 4; (acc + 128) >> 8 per 16-bit half
+        for (int i = tid; i < 18 * 17; i += 256) {
+            const int r = i / 17, j = i - r * 17;
+            uint32_t o[2];
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                const uint32_t a = w_h[r][2 * j + q], b = w_h[r + 1][2 * j + q], c = w_h[r + 2][2 * j + q], d = w_h[r + 3][2 * j + q],
+                               e = w_h[r + 4][2 * j + q];
+                // a + e + 4 (b + d) + 6 c <= 16 * 4 080 = 65 280 in each half: no carry crosses the halves
+                const uint32_t acc = (a + e) + 4u * (b + d) + 6u * c + 0x00800080u;
+                o[q] = (acc >> 8) & 0x00ff00ffu;
+            }
+            w_sm[r][j] = (o[0] & 0xffu) | ((o[0] >> 8) & 0xff00u) | ((o[1] & 0xffu) << 16) | ((o[1] << 8) & 0xff000000u);
+        }
+        __syncthreads();
+        // Prewitt: thread = four pixels x0 + 4 j + k of row y0 + r; their 3 x 3 neighbourhoods are bytes 1 + k .. 3 + k of words j, j + 1
+        // (smoothed columns x0 - 2 + 4 j ...) of rows r .. r + 2.  gx = S(x + 1) - S(x - 1) with S = the column's sum over the three
+        // rows, gy = (bottom - top) summed over the three columns: ComputeGradient's com1 / com2 form, regrouped (integers: exact)
+        {
+            const int r = tid >> 4, j = tid & 15;
+            const uint32_t t0 = w_sm[r][j], t1 = w_sm[r][j + 1], m0 = w_sm[r + 1][j], m1 = w_sm[r + 1][j + 1], b0 = w_sm[r + 2][j],
+                           b1 = w_sm[r + 2][j + 1];
+            int S[8], D[8];
+#pragma unroll
+            for (int p = 1; p <= 6; p++) {
+                const int tp = (int)(((p < 4 ? t0 : t1) >> (8 * (p & 3))) & 0xffu), mp = (int)(((p < 4 ? m0 : m1) >> (8 * (p & 3))) & 0xffu),
+                          bp = (int)(((p < 4 ? b0 : b1) >> (8 * (p & 3))) & 0xffu);
+                S[p] = tp + mp + bp;
+                D[p] = bp - tp;
+            }
+            uint32_t gw[2] = {0u, 0u}, dw = 0u;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                int gxv = S[3 + k] - S[1 + k], gyv = D[1 + k] + D[2 + k] + D[3 + k];
+                gxv = gxv < 0 ? -gxv : gxv;
+                gyv = gyv < 0 ? -gyv : gyv;
+                const int sum = gxv + gyv;
+                gw[k >> 1] |= (uint32_t)sum << (16 * (k & 1));
+                dw |= (uint32_t)(sum >= grad_thresh ? (gxv >= gyv ? STAG_EDGE_VERTICAL : STAG_EDGE_HORIZONTAL) : 0) << (8 * k);
+            }
+            const long long idx = (long long)(y0 + r) * W + (x0 + 4 * j);
+            *reinterpret_cast<uint32_t *>(smooth + idx) = __builtin_amdgcn_alignbyte(m1, m0, 2);  // bytes 2 .. 5: the four centres
+            *reinterpret_cast<uint2 *>(grad + idx) = make_uint2(gw[0], gw[1]);
+            *reinterpret_cast<uint32_t *>(dir + idx) = dw;
+        }
+        return;
+    }
     // source tile with halo 3
     for (int i = tid; i < (SY + 6) * (SX + 6); i += 256) {
         const int r = i / (SX + 6), c = i - r * (SX + 6);
@@ -108,6 +183,7 @@ struct k_stag_smooth_grad_fn {
 // The smoothed image is 8-bit, so |gx|, |gy| <= 3 * 255 and the gradient value never exceeds 1530: the reference's
 // 128 * 256 counting-sort bins (SIZE in SortAnchorsByGradValue) are used only below STAG_BINS.
 #define STAG_BINS 1536
+#define STAG_VHIST_SLICES 16  // copies of the validation histogram (k_stag_smooth3_prewitt adds, k_stag_valid_prob sums)
 #define STAG_BAND_ROWS 4  // rows per band of k_stag_place = waves per workgroup (round 6: 4, a 256-thread workgroup with 24 KB of LDS; 8 rows =
                           // 512 threads and 48 KB waited five times its own duration for room on a CU beside the other groups' kernels)
 
@@ -649,7 +725,7 @@ fid_status fid_stag_create(int libraryHD, int errorCorrection, int max_width, in
                     StagTab<k_stag_decode_fn>::kMax, StagTab<k_stag_smooth_grad_fn>::kMax);
     }
     ok = ok && slab.take((void **)&c->d_smooth2, n) && slab.take((void **)&c->d_vgrad, n * 2) &&
-         slab.take((void **)&c->d_vhist, STAG_BINS * 4) && slab.take((void **)&c->d_prob, STAG_BINS * 8) &&
+         slab.take((void **)&c->d_vhist, STAG_BINS * 4 * STAG_VHIST_SLICES) && slab.take((void **)&c->d_prob, STAG_BINS * 8) &&
          slab.take((void **)&c->d_np, 4) && slab.take((void **)&c->d_vcounts, (n / 8 + 16) * 4) &&
          slab.take((void **)&c->d_vtotal, 4) && slab.take((void **)&c->d_vstack, n * sizeof(int2)) &&
          slab.take((void **)&c->d_vsegs, (n / 8 + 16) * sizeof(int2));
@@ -1158,7 +1234,7 @@ static fid_status stag_advance_impl(fid_stag_ctx *c, StagJob &j)
         const size_t n = (size_t)W * H;
         const int ns = j.spec ? j.use.ns : c->rcount[0];
         // ValidateEdgeSegments starts from an empty edge image (ValidateEdgeSegments.cpp:370)
-        if (STAG_MEMSET(c->d_edgeimg, 0, n, st) != hipSuccess || STAG_MEMSET(c->d_vhist, 0, STAG_BINS * 4, st) != hipSuccess) return stag_finish(j, FID_E_HIP);
+        if (STAG_MEMSET(c->d_edgeimg, 0, n, st) != hipSuccess || STAG_MEMSET(c->d_vhist, 0, STAG_BINS * 4 * STAG_VHIST_SLICES, st) != hipSuccess) return stag_finish(j, FID_E_HIP);
         STAG_LAUNCH(k_stag_smooth3_prewitt, dim3((W + SX - 1) / SX, (H + SY - 1) / SY), dim3(256), 0, st, c->d_src, W, W, H, c->d_smooth2,
                            c->d_vgrad, c->d_vhist);
         STAG_LAUNCH(k_stag_valid_prob, dim3(1), dim3(512), 0, st, c->d_vhist, W, H, c->d_segs, c->d_rcount, c->d_prob, c->d_np);

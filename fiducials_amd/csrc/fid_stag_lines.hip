@@ -13,13 +13,92 @@ __device__ __forceinline__ void k_stag_smooth3_prewitt_impl(const uint8_t *__res
                                                               uint8_t *__restrict__ smooth, int16_t *__restrict__ grad,
                                                               unsigned *__restrict__ hist)
 {
-    __shared__ uint8_t s_src[SY + 4][SX + 4 + 4];
-    __shared__ uint16_t s_h[SY + 4][SX + 2];
-    __shared__ uint8_t s_sm[SY + 2][SX + 2 + 2];
+    __shared__ __attribute__((aligned(16))) uint8_t s_src[SY + 4][SX + 4 + 4];
+    __shared__ __attribute__((aligned(16))) uint16_t s_h[SY + 4][SX + 4];
+    __shared__ __attribute__((aligned(16))) uint8_t s_sm[SY + 2][SX + 2 + 2];
     __shared__ unsigned s_hist[STAG_BINS];
     const int x0 = blockIdx.x * SX, y0 = blockIdx.y * SY;
     const int tid = threadIdx.x;
     for (int i = tid; i < STAG_BINS; i += 256) s_hist[i] = 0;
+    // (round 6) the frame's histogram is kept in STAG_VHIST_SLICES copies, a tile adds to the one its place picks and
+    // k_stag_valid_prob sums them: 2 040 tiles of a 1080p frame sent their ~30 non-empty bins each to the same ~300 words -- 26 of the
+    // kernel's 35 us for a single frame were those atomics queueing up (measured: a build without the flush)
+    unsigned *hslice = hist + (size_t)((blockIdx.x + 5u * blockIdx.y) & (STAG_VHIST_SLICES - 1)) * STAG_BINS;
+    // (round 6) interior tiles, four pixels a thread: as k_stag_smooth_grad's (fid_stag.hip) -- the 3-tap [10 236 10] passes as one
+    // v_dot4_u32_u8 per output (horizontal) and three 32-bit multiply-adds (vertical: 8.8 x 8.8 fixed point needs the 32 bits),
+    // Prewitt from column sums, the histogram as below.  The same integers as the byte-a-thread form.
+    if (x0 >= 4 && x0 + SX + 4 <= W && y0 >= 2 && y0 + SY + 2 <= H && ((stride | W) & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 3) == 0) {
+        uint32_t(*w_src)[18] = reinterpret_cast<uint32_t(*)[18]>(&s_src[0][0]);  // bytes x0 - 4 .. x0 + 67 of rows y0 - 2 .. y0 + 17 (20 x 72 bytes)
+        uint32_t(*w_h)[34] = reinterpret_cast<uint32_t(*)[34]>(&s_h[0][0]);       // 20 x 34 words: smoothed columns x0 - 2 .. x0 + 65, two a word
+        uint32_t(*w_sm)[17] = reinterpret_cast<uint32_t(*)[17]>(&s_sm[0][0]);     // 18 x 17 words
+        for (int i = tid; i < 20 * 18; i += 256) {
+            const int r = i / 18, c = i - r * 18;
+            w_src[r][c] = *reinterpret_cast<const uint32_t *>(src + (long long)(y0 - 2 + r) * stride + (x0 - 4 + 4 * c));
+        }
+        __syncthreads();
+        // horizontal: smoothed column x0 - 2 + 4 j + k from bytes k + 1 .. k + 3 of words j, j + 1 (weights 10, 236, 10)
+        for (int i = tid; i < 20 * 17; i += 256) {
+            const int r = i / 17, j = i - r * 17;
+            const uint32_t d0 = w_src[r][j], d1 = w_src[r][j + 1];
+            const uint32_t h0 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 1), 0x000AEC0Au, 0u, false);
+            const uint32_t h1 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 2), 0x000AEC0Au, 0u, false);
+            const uint32_t h2 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 3), 0x000AEC0Au, 0u, false);
+            const uint32_t h3 = __builtin_amdgcn_udot4(d1, 0x000AEC0Au, 0u, false);
+            w_h[r][2 * j] = h0 | (h1 << 16);
+            w_h[r][2 * j + 1] = h2 | (h3 << 16);
+        }
+        __syncthreads();
+        // vertical: smoothed row y0 - 1 + r from rows r .. r + 2; (acc + 32768) >> 16
+        for (int i = tid; i < 18 * 17; i += 256) {
+            const int r = i / 17, j = i - r * 17;
+            uint32_t px[4];
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                const uint32_t a = w_h[r][2 * j + q], b = w_h[r + 1][2 * j + q], c = w_h[r + 2][2 * j + q];
+                px[2 * q] = (10u * (a & 0xffffu) + 236u * (b & 0xffffu) + 10u * (c & 0xffffu) + 32768u) >> 16;
+                px[2 * q + 1] = (10u * (a >> 16) + 236u * (b >> 16) + 10u * (c >> 16) + 32768u) >> 16;
+            }
+            w_sm[r][j] = px[0] | (px[1] << 8) | (px[2] << 16) | (px[3] << 24);
+        }
+        __syncthreads();
+        {
+            const int r = tid >> 4, j = tid & 15;
+            const uint32_t t0 = w_sm[r][j], t1 = w_sm[r][j + 1], m0 = w_sm[r + 1][j], m1 = w_sm[r + 1][j + 1], b0 = w_sm[r + 2][j],
+                           b1 = w_sm[r + 2][j + 1];
+            int S[8], D[8];
+#pragma unroll
+            for (int p = 1; p <= 6; p++) {
+                const int tp = (int)(((p < 4 ? t0 : t1) >> (8 * (p & 3))) & 0xffu), mp = (int)(((p < 4 ? m0 : m1) >> (8 * (p & 3))) & 0xffu),
+                          bp = (int)(((p < 4 ? b0 : b1) >> (8 * (p & 3))) & 0xffu);
+                S[p] = tp + mp + bp;
+                D[p] = bp - tp;
+            }
+            uint32_t gw[2] = {0u, 0u};
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                int gxv = S[3 + k] - S[1 + k], gyv = D[1 + k] + D[2 + k] + D[3 + k];
+                gxv = gxv < 0 ? -gxv : gxv;
+                gyv = gyv < 0 ? -gyv : gyv;
+                const int g = gxv + gyv;
+                gw[k >> 1] |= (uint32_t)g << (16 * (k & 1));
+                // the tile's histogram, as below: the lanes that hold the first lane's value are counted by one atomic
+                const int g0 = __builtin_amdgcn_readfirstlane(g);
+                const unsigned long long same = __ballot(g == g0);
+                if (g == g0) {
+                    if ((int)(threadIdx.x & 63) == (int)__builtin_ctzll(same)) atomicAdd(&s_hist[g0], (unsigned)__builtin_popcountll(same));
+                } else {
+                    atomicAdd(&s_hist[g], 1u);
+                }
+            }
+            const long long idx = (long long)(y0 + r) * W + (x0 + 4 * j);
+            *reinterpret_cast<uint32_t *>(smooth + idx) = __builtin_amdgcn_alignbyte(m1, m0, 2);
+            *reinterpret_cast<uint2 *>(grad + idx) = make_uint2(gw[0], gw[1]);
+        }
+        __syncthreads();
+        for (int i = tid; i < STAG_BINS; i += 256)
+            if (s_hist[i]) atomicAdd(&hslice[i], s_hist[i]);
+        return;
+    }
     for (int i = tid; i < (SY + 4) * (SX + 4); i += 256) {
         const int r = i / (SX + 4), c = i - r * (SX + 4);
         const int gy = stag_reflect101(y0 - 2 + r, H), gx = stag_reflect101(x0 - 2 + c, W);
@@ -68,7 +147,7 @@ __device__ __forceinline__ void k_stag_smooth3_prewitt_impl(const uint8_t *__res
     }
     __syncthreads();
     for (int i = tid; i < STAG_BINS; i += 256)
-        if (s_hist[i]) atomicAdd(&hist[i], s_hist[i]);
+        if (s_hist[i]) atomicAdd(&hslice[i], s_hist[i]);
 }
 __global__ __launch_bounds__(256) void k_stag_smooth3_prewitt(const uint8_t *__restrict__ src, int stride, int W, int H, uint8_t *__restrict__ smooth, int16_t *__restrict__ grad, unsigned *__restrict__ hist)
 {
@@ -90,7 +169,7 @@ __device__ __forceinline__ void k_stag_valid_prob_impl(const unsigned *__restric
     unsigned loc[PER];
     unsigned acc = 0;
     for (int k = PER - 1; k >= 0; k--) {
-        acc += hist[tid * PER + k];
+        for (int sl = 0; sl < STAG_VHIST_SLICES; sl++) acc += hist[(size_t)sl * STAG_BINS + tid * PER + k];  // (the slices of k_stag_smooth3_prewitt)
         loc[k] = acc;
     }
     s_part[tid] = acc;

@@ -22,7 +22,7 @@ frames = 64 * 2  # (the warm-up call and the timed one)
 rows = []
 for k, v in acc.items():
     valu = v.get('SQ_INSTS_VALU', 0) / frames
-    lu = v['SQ_THREAD_CYCLES_VALU'] / (64 * v['SQ_ACTIVE_INST_VALU']) / 4 if v.get('SQ_ACTIVE_INST_VALU') else 0
+    lu = v['SQ_THREAD_CYCLES_VALU'] / (64 * v['SQ_ACTIVE_INST_VALU']) if v.get('SQ_ACTIVE_INST_VALU') else 0  # (as tools/sq_summary.py)
     rows.append((valu, k, lu, v.get('SQ_INSTS_SALU', 0) / frames, v.get('SQ_WAVE_CYCLES', 0) / frames, calls[k]))
 rows.sort(reverse=True)
 tot = sum(r[0] for r in rows)

@@ -27,7 +27,7 @@ for k, v in acc.items():
 rows.sort(reverse=True)
 tot = sum(r[0] for r in rows)
 with open('gpurun_out/stag_sq/summary.txt', 'w') as o:
-    for line in [f"STag batch, one group of 32 slots, per frame: VALU wave-instructions {tot/1e6:.2f} M"] + [
+    for line in [f"STag batch (CTX=32: groups of 16 frame slots), per frame: VALU wave-instructions {tot/1e6:.2f} M"] + [
             f"{k[:38]:38s} VALU {valu/1e6:7.3f} M  lanes {lu:5.2f}  SALU {salu/1e6:6.3f} M  wave-cycles {wc/1e6:7.2f} M  dispatches {c}" for valu, k, lu, salu, wc, c in rows[:30]]:
         print(line); o.write(line + "\n")
 PY

@@ -345,7 +345,7 @@ struct k_stag_extract_fn {
 };
 
 // exclusive prefix sums over per-item counts: one workgroup per array (blockIdx.x picks it), 8 consecutive items per thread,
-// wave scans on DPP, one barrier pair per 8192 items.  (The first version, a Hillis-Steele scan of 1024 items at a time with
+// wave scans on DPP, one barrier pair per 32 768 items (1 024 threads).  (The first version, a Hillis-Steele scan of 1024 items at a time with
 // 20 barriers each, took 68 us for the ~40 k anchors of a frame.)
 struct StagScanJobs {
     int *counts[2];
@@ -361,7 +361,10 @@ __device__ __forceinline__ void k_stag_scan_counts_n_impl(StagScanJobs J, const 
     __shared__ int s_w[16];
     int *__restrict__ counts = J.counts[blockIdx.x];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = counters[0];
-    constexpr int PER = 8;
+    // (round 6: 32 items a thread, read and written as 16-byte vectors -- a trip of this loop is a memory round trip each way and two
+    //  barriers, ~6 us whatever it carries, and the ~40 k anchors of a frame took five trips with 8 items a thread and 1 024 threads
+    //  -- 38 us -- and twenty with the batch's 256 threads)
+    constexpr int PER = 32;
     int carry = 0;
     // (any block size up to 1 024: round 6 launches these with 256 threads -- a 1 024-thread workgroup waits for sixteen free wave
     //  slots on ONE CU, and beside the other groups' kernels that wait was ten times the scan: 9 us alone, 90 us in the batch)
@@ -369,11 +372,22 @@ __device__ __forceinline__ void k_stag_scan_counts_n_impl(StagScanJobs J, const 
     for (int base = 0; base < n; base += NT * PER) {
         const int i0 = base + tid * PER;
         int v[PER], sum = 0;
+        const bool whole = i0 + PER <= n;
+        if (whole) {
 #pragma unroll
-        for (int k = 0; k < PER; k++) {
-            v[k] = i0 + k < n ? counts[i0 + k] : 0;
-            sum += v[k];
+            for (int k = 0; k < PER; k += 4) {
+                const int4 q = *reinterpret_cast<const int4 *>(counts + i0 + k);
+                v[k] = q.x;
+                v[k + 1] = q.y;
+                v[k + 2] = q.z;
+                v[k + 3] = q.w;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < PER; k++) v[k] = i0 + k < n ? counts[i0 + k] : 0;
         }
+#pragma unroll
+        for (int k = 0; k < PER; k++) sum += v[k];
         const int incl = wave_iscan(sum);
         if (lane == 63) s_w[wv] = incl;
         __syncthreads();
@@ -386,9 +400,18 @@ __device__ __forceinline__ void k_stag_scan_counts_n_impl(StagScanJobs J, const 
         }
         int run = carry + wbase + incl - sum;
 #pragma unroll
-        for (int k = 0; k < PER; k++) {
-            if (i0 + k < n) counts[i0 + k] = run;
-            run += v[k];
+        for (int k = 0; k < PER; k++) {  // v[k]: the item -> its exclusive prefix
+            const int t = v[k];
+            v[k] = run;
+            run += t;
+        }
+        if (whole) {
+#pragma unroll
+            for (int k = 0; k < PER; k += 4) *reinterpret_cast<int4 *>(counts + i0 + k) = make_int4(v[k], v[k + 1], v[k + 2], v[k + 3]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < PER; k++)
+                if (i0 + k < n) counts[i0 + k] = v[k];
         }
         carry += tot;
         __syncthreads();
@@ -407,7 +430,10 @@ __device__ __forceinline__ void k_stag_scan_counts_impl(int *__restrict__ counts
 {
     __shared__ int s_w[16];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = counters[0];
-    constexpr int PER = 8;
+    // (round 6: 32 items a thread, read and written as 16-byte vectors -- a trip of this loop is a memory round trip each way and two
+    //  barriers, ~6 us whatever it carries, and the ~40 k anchors of a frame took five trips with 8 items a thread and 1 024 threads
+    //  -- 38 us -- and twenty with the batch's 256 threads)
+    constexpr int PER = 32;
     int carry = 0;
     // (any block size up to 1 024: round 6 launches these with 256 threads -- a 1 024-thread workgroup waits for sixteen free wave
     //  slots on ONE CU, and beside the other groups' kernels that wait was ten times the scan: 9 us alone, 90 us in the batch)
@@ -415,11 +441,22 @@ __device__ __forceinline__ void k_stag_scan_counts_impl(int *__restrict__ counts
     for (int base = 0; base < n; base += NT * PER) {
         const int i0 = base + tid * PER;
         int v[PER], sum = 0;
+        const bool whole = i0 + PER <= n;
+        if (whole) {
 #pragma unroll
-        for (int k = 0; k < PER; k++) {
-            v[k] = i0 + k < n ? counts[i0 + k] : 0;
-            sum += v[k];
+            for (int k = 0; k < PER; k += 4) {
+                const int4 q = *reinterpret_cast<const int4 *>(counts + i0 + k);
+                v[k] = q.x;
+                v[k + 1] = q.y;
+                v[k + 2] = q.z;
+                v[k + 3] = q.w;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < PER; k++) v[k] = i0 + k < n ? counts[i0 + k] : 0;
         }
+#pragma unroll
+        for (int k = 0; k < PER; k++) sum += v[k];
         const int incl = wave_iscan(sum);
         if (lane == 63) s_w[wv] = incl;
         __syncthreads();
@@ -432,9 +469,18 @@ __device__ __forceinline__ void k_stag_scan_counts_impl(int *__restrict__ counts
         }
         int run = carry + wbase + incl - sum;
 #pragma unroll
-        for (int k = 0; k < PER; k++) {
-            if (i0 + k < n) counts[i0 + k] = run;
-            run += v[k];
+        for (int k = 0; k < PER; k++) {  // v[k]: the item -> its exclusive prefix
+            const int t = v[k];
+            v[k] = run;
+            run += t;
+        }
+        if (whole) {
+#pragma unroll
+            for (int k = 0; k < PER; k += 4) *reinterpret_cast<int4 *>(counts + i0 + k) = make_int4(v[k], v[k + 1], v[k + 2], v[k + 3]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < PER; k++)
+                if (i0 + k < n) counts[i0 + k] = v[k];
         }
         carry += tot;
         __syncthreads();

@@ -1114,17 +1114,26 @@ __device__ __forceinline__ void k_stag_comp_fill_impl(const int32_t *__restrict_
         cid = cidmap[label[sorted[r]]];
         if (cid >= 0 && comps[cid].nanch == 0) cid = -1;
     }
+    // (round 6) first every lane learns its group -- the lane that leads it, its place in it, its size: ballots only -- then the
+    // leaders ask for their groups' places with ONE wave instruction.  Before, the atomic sat inside the loop and the wave waited
+    // for it once per component: 64 consecutive ranks of the gradient order belong to 30 - 60 components, 35 us for a single frame.
     unsigned long long pending = __ballot(cid >= 0);
+    int lead = 0, rank = 0, cnt = 0;
     while (pending) {
-        const int lead = __builtin_ctzll(pending);
-        const int c0 = __builtin_amdgcn_readlane(cid, lead);
+        const int l0 = __builtin_ctzll(pending);
+        const int c0 = __builtin_amdgcn_readlane(cid, l0);
         const unsigned long long m = __ballot(cid == c0);
-        int base = 0;
-        if (lane == lead) base = atomicAdd(&fill[c0], (int)__builtin_popcountll(m));
-        base = __builtin_amdgcn_readlane(base, lead);
-        if (cid == c0) aslots[comps[c0].anch_base + base + (int)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = r;
+        if (cid == c0) {
+            lead = l0;
+            rank = (int)__builtin_popcountll(m & ((1ull << lane) - 1ull));
+            cnt = (int)__builtin_popcountll(m);
+        }
         pending &= ~m;
     }
+    int base = 0;
+    if (cid >= 0 && lane == lead) base = atomicAdd(&fill[cid], cnt);
+    base = __shfl(base, lead, 64);
+    if (cid >= 0) aslots[comps[cid].anch_base + base + rank] = r;
 }
 __global__ __launch_bounds__(256) void k_stag_comp_fill(const int32_t *__restrict__ sorted, const unsigned *__restrict__ n_anchors, const int *__restrict__ label, const int *__restrict__ cidmap, const StagComp *__restrict__ comps, int *__restrict__ fill, int *__restrict__ aslots)
 {
@@ -1564,21 +1573,36 @@ struct k_stag_route_walk_fn {
 __device__ __forceinline__ void k_stag_next_above_impl(const int *__restrict__ prodflag, const unsigned *__restrict__ n_anchors, int *__restrict__ next)
 {
     // next[r] = the smallest producing rank above r (-1: none): a running minimum over the ranks taken from the top down,
-    // 8 consecutive ranks per thread, wave scans by shuffles, one barrier pair per 8192 ranks
+    // 32 consecutive ranks per thread, wave scans by shuffles, one barrier pair per 32 768 ranks (1 024 threads)
     __shared__ int s_w[16];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = (int)*n_anchors;
-    constexpr int PER = 8;
+    constexpr int PER = 32;  // (round 6: 32 ranks a thread, whole aligned runs read and written as 16-byte vectors -- a trip costs its
+                             //  memory round trips and barriers whatever it carries: five trips for a frame's ~40 k anchors were 38 us)
     int carry = INT_MAX;
     const int NT = (int)blockDim.x, NWV = NT >> 6;  // (any block size up to 1 024; launched with 256 since round 6, see k_stag_scan_counts)
-    for (int top = n; top > 0; top -= NT * PER) {
-        const int r0 = top - 1 - tid * PER;  // this thread's ranks: r0, r0 - 1, ...
-        int f[PER], loc = INT_MAX;
+    const int ntop = (n + PER - 1) / PER * PER;      // (the ranks n .. ntop - 1 do not exist: no flag, nothing written)
+    for (int top = ntop; top > 0; top -= NT * PER) {
+        const int lo = top - (tid + 1) * PER;        // this thread's ranks: lo + PER - 1 down to lo (lo is a multiple of PER)
+        const bool whole = lo >= 0 && lo + PER <= n;
+        int f[PER], loc = INT_MAX;                   // f[k]: rank lo + k if it produces, else INT_MAX
+        if (whole) {
 #pragma unroll
-        for (int k = 0; k < PER; k++) {
-            const int r = r0 - k;
-            f[k] = (r >= 0 && prodflag[r]) ? r : INT_MAX;
-            loc = min(loc, f[k]);
+            for (int k = 0; k < PER; k += 4) {
+                const int4 q = *reinterpret_cast<const int4 *>(prodflag + lo + k);
+                f[k] = q.x ? lo + k : INT_MAX;
+                f[k + 1] = q.y ? lo + k + 1 : INT_MAX;
+                f[k + 2] = q.z ? lo + k + 2 : INT_MAX;
+                f[k + 3] = q.w ? lo + k + 3 : INT_MAX;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < PER; k++) {
+                const int r = lo + k;
+                f[k] = (r >= 0 && r < n && prodflag[r]) ? r : INT_MAX;
+            }
         }
+#pragma unroll
+        for (int k = 0; k < PER; k++) loc = min(loc, f[k]);
         int incl = loc;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
@@ -1595,12 +1619,22 @@ __device__ __forceinline__ void k_stag_next_above_impl(const int *__restrict__ p
             tot = min(tot, t);
         }
         const int left = __shfl_up(incl, 1, 64);
-        int run = min(min(carry, wpre), lane > 0 ? left : INT_MAX);
+        int run = min(min(carry, wpre), lane > 0 ? left : INT_MAX);  // the smallest producing rank above this thread's ranks
 #pragma unroll
-        for (int k = 0; k < PER; k++) {
-            const int r = r0 - k;
-            if (r >= 0) next[r] = run == INT_MAX ? -1 : run;
-            run = min(run, f[k]);
+        for (int k = PER - 1; k >= 0; k--) {  // from the top down: f[k] -> next[lo + k]
+            const int t = f[k];
+            f[k] = run == INT_MAX ? -1 : run;
+            run = min(run, t);
+        }
+        if (whole) {
+#pragma unroll
+            for (int k = 0; k < PER; k += 4) *reinterpret_cast<int4 *>(next + lo + k) = make_int4(f[k], f[k + 1], f[k + 2], f[k + 3]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < PER; k++) {
+                const int r = lo + k;
+                if (r >= 0 && r < n) next[r] = f[k];
+            }
         }
         carry = min(carry, tot);
         __syncthreads();

@@ -1323,7 +1323,7 @@ static fid_status stag_advance_impl(fid_stag_ctx *c, StagJob &j)
         T.kmin_n = c->kmin_n;
         const int nl = j.spec ? j.use.nl : c->n_lines;
         if (nl > 0)
-            STAG_LAUNCH(k_stag_validate_lines, dim3((nl + 63) / 64), dim3(64), 0, st, c->d_lines, c->d_ltotal, c->d_src, W, H, c->d_vsegs,
+            STAG_LAUNCH(k_stag_validate_lines, dim3((nl + 3) / 4), dim3(256), 0, st, c->d_lines, c->d_ltotal, c->d_src, W, H, c->d_vsegs,
                                c->d_outpix, T, c->d_lflags);
         STAG_LAUNCH(k_stag_scan_counts, dim3(1), dim3(scan_threads), 0, st, c->d_lflags, c->d_ltotal, c->d_vltotal);
         if (nl > 0)

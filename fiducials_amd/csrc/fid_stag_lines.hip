@@ -962,7 +962,7 @@ struct k_stag_gather_lines_fn {
 // ValidateLineSegments (EDLines.cpp:274-409): a line is kept if enough of its pixels have a gradient direction within
 // 22.5 degrees of the line (Helmholtz principle, number of false alarms from a table).  Lines of >= 80 pixels pass untested,
 // lines of <= 25 pixels are tested on all pixels of a 2-pixel-wide rectangle around them (EnumerateRectPoints, :417-600, the
-// LSD rectangle iterator), the others on their own pixels first and on the rectangle if that fails.  One lane per line.
+// LSD rectangle iterator), the others on their own pixels first and on the rectangle if that fails.  One WAVE per line (round 6; one lane until then).
 // Host-made tables (functions of the image size only, evaluated with the host's libm exactly as the reference does):
 //   atan_lut[i] = atan(i / 1024)  (myAtan2, MyMath.cpp:12-72);  kmin[n] = the NFALUT entry (NFA.cpp:13-44).
 struct StagLineTables {
@@ -1020,8 +1020,15 @@ __device__ int sl_aligned(const uint8_t *__restrict__ src, int W, int H, int r, 
     return (diff <= prec || diff >= PI - prec) ? 1 : 0;
 }
 
-// ValidateLineSegmentRect (EDLines.cpp:612-690) with the rectangle iterator of EnumerateRectPoints (:417-600) inlined
-__device__ bool sl_validate_rect(const uint8_t *__restrict__ src, int W, int H, const fid_stag_line &ls, double lineAngle, const StagLineTables &T)
+// ValidateLineSegmentRect (EDLines.cpp:612-690) with the rectangle iterator of EnumerateRectPoints (:417-600): the reference runs
+//     y++; while (y > ye && x <= vx[2]) { x++; if (x > vx[2]) break; ys = ...(x); ye = ...(x); y = ceil(ys); }  if (x > vx[2]) break;  point (x, y)
+// until maxNoOfPoints points are out, i.e. the columns x = ceil(vx[0]) .. vx[2] in turn and in every column the rows from
+// ceil(ys(x)) while !(y > ye(x)).
+// By a WAVE (round 6): ys and ye are functions of x alone (the branches below are the reference's, term for term), so a lane takes a column, a wave scan over the columns' point counts applies the iterator's cap (the first
+// maxNoOfPoints points in its order), and the two tallies are integer sums.  One lane per line walked up to ~250 pixels one
+// dependent load after the other: 111 us for a frame's lines.
+__device__ bool sl_validate_rect_wave(const uint8_t *__restrict__ src, int W, int H, const fid_stag_line &ls, double lineAngle, const StagLineTables &T,
+                                      int lane)
 {
     const double x1 = ls.sx, y1 = ls.sy, x2 = ls.ex, y2 = ls.ey, width = 2;
     double dx = x2 - x1, dy = y2 - y1;
@@ -1043,15 +1050,16 @@ __device__ bool sl_validate_rect(const uint8_t *__restrict__ src, int W, int H, 
         vx[n] = vxT[(offset + n) % 4];
         vy[n] = vyT[(offset + n) % 4];
     }
-    int x = (int)ceil(vx[0]) - 1, y = (int)ceil(vy[0]);
-    double ys = -1.7976931348623157e308, ye = -1.7976931348623157e308;
-    int noPoints = 0, count = 0, aligned = 0;
+    const int xfirst = (int)ceil(vx[0]);
     const int maxNoOfPoints = (int)(fabs(ls.sx - ls.ex) + fabs(ls.sy - ls.ey)) * 4;
-    while (noPoints < maxNoOfPoints) {
-        y++;
-        while (y > ye && x <= vx[2]) {
-            x++;
-            if (x > vx[2]) break;
+    int count = 0, aligned = 0, taken = 0;  // taken: points of the columns in front of this trip's (wave-uniform)
+    for (int c0 = 0; taken < maxNoOfPoints; c0 += 64) {
+        const int x = xfirst + c0 + lane;
+        const bool col = !(x > vx[2]);
+        if (!__ballot(col)) break;
+        int y0 = 0, nx = 0;
+        if (col) {
+            double ys, ye;
             if ((double)x < vx[3]) {
                 if (fabs(vx[0] - vx[3]) <= 0.01) {
                     if (vy[0] < vy[3]) ys = vy[0];
@@ -1082,16 +1090,26 @@ __device__ bool sl_validate_rect(const uint8_t *__restrict__ src, int W, int H, 
                 } else
                     ye = vy[1] + (x - vx[1]) * (vy[2] - vy[1]) / (vx[2] - vx[1]);
             }
-            y = (int)ceil(ys);
+            y0 = (int)ceil(ys);
+            // the rows y0, y0 + 1, ... while !(y > ye)
+            if (!((double)y0 > ye)) nx = (int)floor(ye) - y0 + 1;
         }
-        if (x > vx[2]) break;
-        noPoints++;
-        const int al = sl_aligned(src, W, H, y, x, lineAngle, T.atan_lut);
-        if (al >= 0) {
-            count++;
-            aligned += al;
+        const int incl = wave_iscan(nx);
+        const int before = taken + incl - nx;
+        int room = maxNoOfPoints - before;
+        room = room < 0 ? 0 : room;
+        const int mine = nx < room ? nx : room;
+        for (int k = 0; k < mine; k++) {
+            const int al = sl_aligned(src, W, H, y0 + k, x, lineAngle, T.atan_lut);
+            if (al >= 0) {
+                count++;
+                aligned += al;
+            }
         }
+        taken += __builtin_amdgcn_readlane(incl, 63);
     }
+    count = wave_sum_i32(count);
+    aligned = wave_sum_i32(aligned);
     return count <= T.kmin_n ? aligned >= T.kmin[count] : false;
 }
 
@@ -1099,7 +1117,9 @@ __device__ __forceinline__ void k_stag_validate_lines_impl(const fid_stag_line *
                                                             const uint8_t *__restrict__ src, int W, int H, const int2 *__restrict__ vsegs,
                                                             const int2 *__restrict__ pix, StagLineTables T, int *__restrict__ flags)
 {
-    const int i = blockIdx.x * 64 + threadIdx.x;
+    // (round 6) a WAVE per line: the pixels of the line across the lanes, the rectangle's columns across the lanes
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6);
     if (i >= *nlines) return;
     const double PI = 3.14159265358979323846;
     const fid_stag_line ls = lines[i];
@@ -1109,28 +1129,30 @@ __device__ __forceinline__ void k_stag_validate_lines_impl(const fid_stag_line *
     if (ls.len >= 80) {
         valid = true;
     } else if (ls.len <= 25) {
-        valid = sl_validate_rect(src, W, H, ls, lineAngle, T);
+        valid = sl_validate_rect_wave(src, W, H, ls, lineAngle, T, lane);
     } else {
         const int2 *p = pix + vsegs[ls.segmentNo].x + ls.firstPixelIndex;
         int count = 0, aligned = 0;
-        for (int j = 0; j < ls.len; j++) {
+        for (int j = lane; j < ls.len; j += 64) {
             const int al = sl_aligned(src, W, H, p[j].x, p[j].y, lineAngle, T.atan_lut);
             if (al >= 0) {
                 count++;
                 aligned += al;
             }
         }
+        count = wave_sum_i32(count);
+        aligned = wave_sum_i32(aligned);
         valid = count <= T.kmin_n ? aligned >= T.kmin[count] : false;
-        if (!valid) valid = sl_validate_rect(src, W, H, ls, lineAngle, T);
+        if (!valid) valid = sl_validate_rect_wave(src, W, H, ls, lineAngle, T, lane);
     }
-    flags[i] = valid ? 1 : 0;
+    if (lane == 0) flags[i] = valid ? 1 : 0;
 }
-__global__ __launch_bounds__(64) void k_stag_validate_lines(const fid_stag_line *__restrict__ lines, const int *__restrict__ nlines, const uint8_t *__restrict__ src, int W, int H, const int2 *__restrict__ vsegs, const int2 *__restrict__ pix, StagLineTables T, int *__restrict__ flags)
+__global__ __launch_bounds__(256) void k_stag_validate_lines(const fid_stag_line *__restrict__ lines, const int *__restrict__ nlines, const uint8_t *__restrict__ src, int W, int H, const int2 *__restrict__ vsegs, const int2 *__restrict__ pix, StagLineTables T, int *__restrict__ flags)
 {
     k_stag_validate_lines_impl(lines, nlines, src, W, H, vsegs, pix, T, flags);
 }
 struct k_stag_validate_lines_fn {
-    static constexpr int kBounds = 64;
+    static constexpr int kBounds = 256;
     __device__ __forceinline__ void operator()(const fid_stag_line *__restrict__ lines, const int *__restrict__ nlines, const uint8_t *__restrict__ src, int W, int H, const int2 *__restrict__ vsegs, const int2 *__restrict__ pix, StagLineTables T, int *__restrict__ flags) const { k_stag_validate_lines_impl(lines, nlines, src, W, H, vsegs, pix, T, flags); }
 };
 

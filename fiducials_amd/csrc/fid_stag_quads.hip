@@ -48,8 +48,15 @@ __device__ void sq_intersect(const fid_stag_line &l1, const fid_stag_line &l2, d
     *oy = y;
 }
 
+// samples correctLineDirection takes along a line
+__device__ __forceinline__ int sq_direction_samples(const fid_stag_line &ls)
+{
+    if (ls.invert == 0) return (int)(fmax(ls.sx, ls.ex) + 0.5) - (int)fmin(ls.sx, ls.ex) + 1;
+    return (int)(fmax(ls.sy, ls.ey) + 0.5) - (int)fmin(ls.sy, ls.ey) + 1;
+}
 // EDInterface::correctLineDirection: going from start to end the darker side must be on the right
-__device__ void sq_correct_direction(const uint8_t *__restrict__ img, int W, int H, fid_stag_line &ls)
+template <int LANES = 1>
+__device__ void sq_correct_direction(const uint8_t *__restrict__ img, int W, int H, fid_stag_line &ls, int lane = 0)
 {
     int n, mn;
     if (ls.invert == 0) {
@@ -83,13 +90,19 @@ __device__ void sq_correct_direction(const uint8_t *__restrict__ img, int W, int
     const int minY = min(min(ry0, ry1), min(ly0, ly1)), maxY = max(max(ry0, ry1), max(ly0, ly1));
     const bool safe = minX < 0 || maxX >= W || minY < 0 || maxY >= H;
     unsigned accR = 0, accL = 0;
-    for (int i = 0; i < n; i++) {
+    // LANES > 1 (round 6): the samples across the lanes of the wave, the two sums by wave reductions (integers: the same sums).  A
+    // lane per line walked a marker's 450-pixel edge alone, two loads a step: the longest line was k_stag_quads' duration.
+    for (int i = LANES > 1 ? lane : 0; i < n; i += LANES) {
         int rx, ry, lx, ly;
         sample(i, &rx, &ry, &lx, &ly);
         const bool rin = rx >= 0 && rx < W && ry >= 0 && ry < H, lin = lx >= 0 && lx < W && ly >= 0 && ly < H;
         // (without the safe read the reference reads unchecked; points between two in-range end points are in range)
         accR += rin ? img[ry * W + rx] : (safe ? 128u : 0u);
         accL += lin ? img[ly * W + lx] : (safe ? 128u : 0u);
+    }
+    if (LANES > 1) {
+        accR = (unsigned)wave_sum_i32((int)accR);
+        accL = (unsigned)wave_sum_i32((int)accL);
     }
     if (accL < accR) {
         const double t1 = ls.sx, t2 = ls.sy;
@@ -266,11 +279,30 @@ __device__ __forceinline__ void k_stag_quads_impl(fid_stag_line *__restrict__ li
     if (lane == 0) counts[seg] = 0;
     if (range[seg].y == 0 || n < 4) return;  // groups need >= 4 lines of one edge segment
     // ---- groupLines: fix the direction of every line of the group (each lane one line), then the order of the group
-    for (int k = lane; k < n; k += 64) {
-        fid_stag_line l = lines[lo + k];
-        sq_correct_direction(img, W, H, l);
-        lines[lo + k] = l;
+    // (short lines a lane each; the long ones -- more samples than a wave has lanes -- one after the other by the whole wave)
+    unsigned long long longm[2] = {0ull, 0ull};  // (groups of up to 128 lines keep their long ones as bits; beyond: a lane each)
+    for (int k0 = 0; k0 < n; k0 += 64) {
+        const int k = k0 + lane;
+        bool is_long = false;
+        if (k < n) {
+            fid_stag_line l = lines[lo + k];
+            is_long = k < 128 && sq_direction_samples(l) > 64;
+            if (!is_long) {
+                sq_correct_direction(img, W, H, l);
+                lines[lo + k] = l;
+            }
+        }
+        const unsigned long long m = __ballot(is_long);
+        if (k0 < 128) longm[k0 >> 6] = m;
     }
+    for (int w = 0; w < 2; w++)
+        while (longm[w]) {
+            const int k = 64 * w + __builtin_ctzll(longm[w]);
+            longm[w] &= longm[w] - 1;
+            fid_stag_line l = lines[lo + k];
+            sq_correct_direction<64>(img, W, H, l, lane);
+            if (lane == 0) lines[lo + k] = l;
+        }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");

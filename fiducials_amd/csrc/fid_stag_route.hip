@@ -1053,44 +1053,69 @@ __device__ __forceinline__ void k_stag_comp_alloc_impl(const int *__restrict__ r
                                                          const int *caps, StagComp *__restrict__ comps, int *__restrict__ cidmap)
 {
     const int nroots = cursors[13];
-    for (int k = blockIdx.x * 256 + threadIdx.x; k < nroots; k += gridDim.x * 256) {
-    const int i = roots[k];  // (one thread per ROOT; until round 6: one per pixel, asking label[i] == i)
-    cidmap[i] = -1;
-    const int na = canch[i], sz = csize[i];
-    if (na == 0) continue;
-    atomicMax(&cursors[9], na);
-    const int cid = atomicAdd(&cursors[0], 1);
-    if (cid >= max_comps) {
-        atomicOr(&cursors[7], 1);
-        continue;
-    }
-    StagComp C;
-    C.root = i; C.size = sz; C.nanch = na; C.nrec = 0;
-    {
-        const int4 bx = cbox[i];
-        C.minr = bx.x; C.minc = bx.y; C.maxr = bx.z; C.maxc = bx.w;
-    }
-    int p2 = 1;
-    while (p2 < na) p2 <<= 1;
-    C.anch_cap = p2;
-    C.pix_cap = 2 * sz + 12 * na + 64;
-    C.stack_cap = (sz + 2 * na + 64) + (sz / 4 + 64);  // pending branches + (in its tail) the chain lists of the extraction
-    C.chain_cap = sz + 2 * na + 64;
-    C.out_cap = C.pix_cap;
-    C.seg_cap = C.pix_cap / 8 + na + 8;
-    C.anch_base = atomicAdd(&cursors[1], C.anch_cap);
-    C.pix_base = atomicAdd(&cursors[2], C.pix_cap);
-    C.stack_base = atomicAdd(&cursors[3], C.stack_cap);
-    C.chain_base = atomicAdd(&cursors[4], C.chain_cap);
-    C.out_base = atomicAdd(&cursors[5], C.out_cap);
-    C.seg_base = atomicAdd(&cursors[6], C.seg_cap);
-    if (C.anch_base + C.anch_cap > caps[1] || C.pix_base + C.pix_cap > caps[2] || C.stack_base + C.stack_cap > caps[3] ||
-        C.chain_base + C.chain_cap > caps[4] || C.out_base + C.out_cap > caps[5] || C.seg_base + C.seg_cap > caps[6]) {
-        atomicOr(&cursors[7], 2);
-        C.nanch = 0;  // not processed; the call reports FID_E_CAPACITY
-    }
-    comps[cid] = C;
-    cidmap[i] = cid;
+    const int lane = threadIdx.x & 63;
+    // (round 6) a WAVE asks for the places of its 64 roots at once: one atomic per cursor and wave, the lanes' shares by prefix sums.
+    // A thread per root sent eight returning atomics of its own to the same seven words -- a frame's ~8 k roots queued up there:
+    // 19 us.  Which component gets which place was never defined (the atomics' order); every component still gets its own.
+    for (int k0 = blockIdx.x * 256 + (int)(threadIdx.x & ~63u); k0 < nroots; k0 += gridDim.x * 256) {
+        const int k = k0 + lane;
+        const bool in = k < nroots;
+        const int i = in ? roots[k] : 0;  // (one thread per ROOT; until round 6: one per pixel, asking label[i] == i)
+        if (in) cidmap[i] = -1;
+        const int na = in ? canch[i] : 0, sz = in ? csize[i] : 0;
+        const bool has = na > 0;
+        const unsigned long long hm = __ballot(has);
+        if (!hm) continue;
+        StagComp C;
+        C.root = i; C.size = sz; C.nanch = na; C.nrec = 0;
+        if (has) {
+            const int4 bx = cbox[i];
+            C.minr = bx.x; C.minc = bx.y; C.maxr = bx.z; C.maxc = bx.w;
+        }
+        int p2 = 1;
+        while (p2 < na) p2 <<= 1;
+        C.anch_cap = has ? p2 : 0;
+        C.pix_cap = has ? 2 * sz + 12 * na + 64 : 0;
+        C.stack_cap = has ? (sz + 2 * na + 64) + (sz / 4 + 64) : 0;  // pending branches + (in its tail) the chain lists of the extraction
+        C.chain_cap = has ? sz + 2 * na + 64 : 0;
+        C.out_cap = C.pix_cap;
+        C.seg_cap = has ? C.pix_cap / 8 + na + 8 : 0;
+        const int wmax = wave_max_i32(na);
+        const int s1 = wave_iscan(C.anch_cap), s2 = wave_iscan(C.pix_cap), s3 = wave_iscan(C.stack_cap), s4 = wave_iscan(C.chain_cap),
+                  s6 = wave_iscan(C.seg_cap);
+        int b0 = 0, b1 = 0, b2 = 0, b3 = 0, b4 = 0, b5 = 0, b6 = 0;
+        if (lane == 63) {  // (the lane that holds the totals)
+            atomicMax(&cursors[9], wmax);
+            b0 = atomicAdd(&cursors[0], (int)__builtin_popcountll(hm));
+            b1 = atomicAdd(&cursors[1], s1);
+            b2 = atomicAdd(&cursors[2], s2);
+            b3 = atomicAdd(&cursors[3], s3);
+            b4 = atomicAdd(&cursors[4], s4);
+            b5 = atomicAdd(&cursors[5], s2);  // (out_cap = pix_cap)
+            b6 = atomicAdd(&cursors[6], s6);
+        }
+        b0 = __builtin_amdgcn_readlane(b0, 63); b1 = __builtin_amdgcn_readlane(b1, 63); b2 = __builtin_amdgcn_readlane(b2, 63);
+        b3 = __builtin_amdgcn_readlane(b3, 63); b4 = __builtin_amdgcn_readlane(b4, 63); b5 = __builtin_amdgcn_readlane(b5, 63);
+        b6 = __builtin_amdgcn_readlane(b6, 63);
+        if (!has) continue;
+        const int cid = b0 + (int)__builtin_popcountll(hm & ((1ull << lane) - 1ull));
+        if (cid >= max_comps) {
+            atomicOr(&cursors[7], 1);
+            continue;
+        }
+        C.anch_base = b1 + s1 - C.anch_cap;
+        C.pix_base = b2 + s2 - C.pix_cap;
+        C.stack_base = b3 + s3 - C.stack_cap;
+        C.chain_base = b4 + s4 - C.chain_cap;
+        C.out_base = b5 + s2 - C.out_cap;
+        C.seg_base = b6 + s6 - C.seg_cap;
+        if (C.anch_base + C.anch_cap > caps[1] || C.pix_base + C.pix_cap > caps[2] || C.stack_base + C.stack_cap > caps[3] ||
+            C.chain_base + C.chain_cap > caps[4] || C.out_base + C.out_cap > caps[5] || C.seg_base + C.seg_cap > caps[6]) {
+            atomicOr(&cursors[7], 2);
+            C.nanch = 0;  // not processed; the call reports FID_E_CAPACITY
+        }
+        comps[cid] = C;
+        cidmap[i] = cid;
     }
 }
 __global__ __launch_bounds__(256) void k_stag_comp_alloc(const int *__restrict__ roots, const int *__restrict__ csize, const int *__restrict__ canch, const int4 *__restrict__ cbox, int *__restrict__ cursors, int max_comps, const int *caps, StagComp *__restrict__ comps, int *__restrict__ cidmap)
